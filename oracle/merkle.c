@@ -1,0 +1,93 @@
+/*
+ * oracle/merkle.c -- Poseidon2 Merkle commitment over matrix rows, CPU restatement.
+ * TEST INFRASTRUCTURE ONLY; PARITY UNPINNED (see oracle/oracle.h).
+ *
+ * Restates p3-merkle-tree 0.2.1-succinct FieldMerkleTreeMmcs (reference
+ * Cargo.lock:4013; reached from crates/guest-prover-sp1/src/sp1.rs:116):
+ *   leaf i      = sponge(row i of every matrix of the tallest height, concatenated)
+ *   parent      = compress(left, right)
+ *   injection   = when a level has as many nodes as a shorter matrix has rows,
+ *                 node i = compress(node i, sponge(row i of those matrices))
+ *   open/verify = the sibling path, leaf rows re-hashed by the verifier.
+ */
+#include "oracle.h"
+#include <stdlib.h>
+#include <string.h>
+
+static void hash_concat_row(const uint32_t* const* mats, const size_t* widths,
+                            const int* sel, int nsel, size_t row, uint32_t out[8]) {
+    size_t total = 0;
+    for (int k = 0; k < nsel; k++) total += widths[sel[k]];
+    uint32_t* buf = (uint32_t*)malloc((total ? total : 1) * sizeof(uint32_t));
+    size_t pos = 0;
+    for (int k = 0; k < nsel; k++) {
+        int m = sel[k];
+        memcpy(buf + pos, mats[m] + row * widths[m], widths[m] * sizeof(uint32_t));
+        pos += widths[m];
+    }
+    orc_sponge_hash(buf, total, out);
+    free(buf);
+}
+
+void orc_hash_rows(const uint32_t* const* mats, const size_t* widths, int nmats,
+                   size_t height, uint32_t* digests) {
+    int sel[64];
+    for (int i = 0; i < nmats; i++) sel[i] = i;
+#pragma omp parallel for schedule(static)
+    for (size_t r = 0; r < height; r++) hash_concat_row(mats, widths, sel, nmats, r, digests + 8 * r);
+}
+
+void orc_merkle_tree_mixed(const uint32_t* const* mats, const size_t* widths,
+                           const int* log_heights, int nmats, uint32_t* tree) {
+    int log_h = 0;
+    for (int i = 0; i < nmats; i++) if (log_heights[i] > log_h) log_h = log_heights[i];
+    int sel[64], nsel = 0;
+    for (int i = 0; i < nmats; i++) if (log_heights[i] == log_h) sel[nsel++] = i;
+    size_t n = (size_t)1 << log_h;
+#pragma omp parallel for schedule(static)
+    for (size_t r = 0; r < n; r++) hash_concat_row(mats, widths, sel, nsel, r, tree + 8 * r);
+    uint32_t* prev = tree;
+    for (int lvl = log_h - 1; lvl >= 0; lvl--) {
+        size_t cnt = (size_t)1 << lvl;
+        uint32_t* cur = prev + 16 * cnt;   /* prev has 2*cnt digests */
+        nsel = 0;
+        for (int i = 0; i < nmats; i++) if (log_heights[i] == lvl) sel[nsel++] = i;
+#pragma omp parallel for schedule(static)
+        for (size_t i = 0; i < cnt; i++) {
+            orc_compress(prev + 16 * i, prev + 16 * i + 8, cur + 8 * i);
+            if (nsel) {
+                uint32_t rh[8];
+                hash_concat_row(mats, widths, sel, nsel, i, rh);
+                orc_compress(cur + 8 * i, rh, cur + 8 * i);
+            }
+        }
+        prev = cur;
+    }
+}
+
+void orc_merkle_tree(const uint32_t* const* mats, const size_t* widths, int nmats,
+                     int log_h, uint32_t* tree) {
+    int lh[64];
+    for (int i = 0; i < nmats; i++) lh[i] = log_h;
+    orc_merkle_tree_mixed(mats, widths, lh, nmats, tree);
+}
+
+int orc_merkle_verify(const uint32_t root[8], int log_h, size_t index,
+                      const uint32_t* const* rows, const size_t* widths, int nmats,
+                      const uint32_t* siblings) {
+    /* equal-height matrices: `rows[m]` is the opened row of matrix m */
+    size_t total = 0;
+    for (int m = 0; m < nmats; m++) total += widths[m];
+    uint32_t* buf = (uint32_t*)malloc((total ? total : 1) * sizeof(uint32_t));
+    size_t pos = 0;
+    for (int m = 0; m < nmats; m++) { memcpy(buf + pos, rows[m], widths[m] * 4); pos += widths[m]; }
+    uint32_t cur[8];
+    orc_sponge_hash(buf, total, cur);
+    free(buf);
+    for (int lvl = 0; lvl < log_h; lvl++) {
+        const uint32_t* sib = siblings + 8 * lvl;
+        if ((index >> lvl) & 1) orc_compress(sib, cur, cur);
+        else orc_compress(cur, sib, cur);
+    }
+    return memcmp(cur, root, 32) == 0 ? 0 : 1;
+}

@@ -1,0 +1,142 @@
+/*
+ * oracle/oracle.h -- API of the CPU restatement (the parity oracle).
+ *
+ * TEST INFRASTRUCTURE ONLY (see oracle/bb.h).  PARITY UNPINNED: every function
+ * below restates a PUBLISHED algorithm whose reference implementation lives in a
+ * crate that is absent from /root/reference; the reference's own call sites are
+ * crates/guest-prover-sp1/src/sp1.rs:113 (setup), :116 (prove), :120 (verify) and
+ * crates/guest-prover-r0/src/prover.rs:90 (prove_with_opts).  Pinned crates
+ * (reference Cargo.lock line): p3-dft :3903, p3-poseidon2 :4030, p3-symmetric :4044,
+ * p3-merkle-tree :4013, p3-challenger :3875, p3-fri :3930, p3-uni-stark :4055,
+ * sp1-stark :6172 -- all 0.2.1-succinct / 4.1.4.
+ *
+ * All field values crossing this API are CANONICAL residues (not Montgomery).
+ * Matrices are row-major: element (row r, column c) at m[r * width + c].
+ */
+#ifndef ORACLE_ORACLE_H
+#define ORACLE_ORACLE_H
+
+#include "bb.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ---- threads (OpenMP) used by the heavy loops; returns the count in effect ---- */
+int orc_set_threads(int n);
+
+/* ---- field helpers exported for the Python tests ---- */
+uint32_t orc_bb_mul(uint32_t a, uint32_t b);
+uint32_t orc_bb_inv(uint32_t a);
+uint32_t orc_bb_pow(uint32_t a, uint64_t e);
+uint32_t orc_two_adic_generator(int bits);
+void orc_bb4_mul(const uint32_t a[4], const uint32_t b[4], uint32_t out[4]);
+void orc_bb4_inv(const uint32_t a[4], uint32_t out[4]);
+void orc_to_monty(const uint32_t* in, uint32_t* out, size_t n);
+void orc_from_monty(const uint32_t* in, uint32_t* out, size_t n);
+
+/* ---- NTT / LDE  (p3-dft: Radix2Dit / Radix2DitParallel) ---- */
+/* O(n^2) definition: out[k] = sum_j in[j] w^(jk)  (inverse: w^-1 and 1/n). */
+void orc_dft_naive(const uint32_t* in, uint32_t* out, int log_n, size_t width, int inverse);
+/* radix-2 NTT over every column, in place, natural order in and out. */
+void orc_ntt(uint32_t* a, int log_n, size_t width, int inverse);
+/* coset_lde_batch(evals, log_blowup, shift).bit_reverse_rows():
+ * out row bitrev(i) = f(shift * w_{N*B}^i), f interpolating `in` on the subgroup. */
+void orc_coset_lde(const uint32_t* in, uint32_t* out, int log_n, size_t width,
+                   int log_blowup, uint32_t shift);
+
+/* ---- Poseidon2 width 16 (p3-poseidon2) + sponge/compress (p3-symmetric) ---- */
+void orc_poseidon2_permute(uint32_t state[16]);
+/* PaddingFreeSponge<16,8,8>: overwrite-mode absorb of `n` elements. */
+void orc_sponge_hash(const uint32_t* in, size_t n, uint32_t out[8]);
+/* TruncatedPermutation<2,8,16>: permute(left || right)[0..8]. */
+void orc_compress(const uint32_t left[8], const uint32_t right[8], uint32_t out[8]);
+
+/* ---- Merkle commitment (p3-merkle-tree FieldMerkleTreeMmcs, equal heights) ----
+ * leaf r = sponge(row r of mats[0] || row r of mats[1] || ...).
+ * tree: all levels, level 0 = 2^log_h leaf digests, then 2^(log_h-1) ..., root last;
+ *       (2^(log_h+1) - 1) * 8 words. */
+void orc_hash_rows(const uint32_t* const* mats, const size_t* widths, int nmats,
+                   size_t height, uint32_t* digests);
+void orc_merkle_tree(const uint32_t* const* mats, const size_t* widths, int nmats,
+                     int log_h, uint32_t* tree);
+/* Mixed-height commit (matrices sorted by height, tallest first, heights powers of two):
+ * shorter matrices are injected at their level as compress(node, sponge(row)). */
+void orc_merkle_tree_mixed(const uint32_t* const* mats, const size_t* widths,
+                           const int* log_heights, int nmats, uint32_t* tree);
+/* verify an opening of leaf `index`: siblings[log_h][8], rows of all matrices. */
+int orc_merkle_verify(const uint32_t root[8], int log_h, size_t index,
+                      const uint32_t* const* rows, const size_t* widths, int nmats,
+                      const uint32_t* siblings);
+
+/* ---- Fiat-Shamir duplex challenger (p3-challenger DuplexChallenger<16,8>) ---- */
+typedef struct {
+    uint32_t state[16];
+    uint32_t input[8];
+    int n_input;
+    uint32_t output[8];
+    int n_output;
+} orc_challenger_t;
+void orc_chal_init(orc_challenger_t* c);
+void orc_chal_observe(orc_challenger_t* c, uint32_t v);
+void orc_chal_observe_slice(orc_challenger_t* c, const uint32_t* v, size_t n);
+uint32_t orc_chal_sample(orc_challenger_t* c);
+void orc_chal_sample_ext(orc_challenger_t* c, uint32_t out[4]);
+uint32_t orc_chal_sample_bits(orc_challenger_t* c, int bits);
+/* smallest witness w (canonical order) with check_witness(bits, w); observes it. */
+uint32_t orc_chal_grind(orc_challenger_t* c, int bits);
+int orc_chal_check_witness(orc_challenger_t* c, int bits, uint32_t witness);
+
+/* ---- synthetic shard: trace generator + AIR ---- */
+/* counter-based uniform field element for (seed, linear index) */
+uint32_t orc_synth_value(uint64_t seed, uint64_t index);
+/* fill a matrix with orc_synth_value(seed, r*width + c)  (NTT / Merkle workloads) */
+void orc_fill_uniform(uint64_t seed, int log_n, size_t width, uint32_t* out);
+/* AIR-satisfying trace for shard `shard` (width % 4 == 0) */
+void orc_gen_trace(uint64_t seed, uint64_t shard, int log_n, size_t width, uint32_t* out);
+/* number of constraint violations of the synthetic AIR on a trace (0 = valid) */
+size_t orc_check_trace(const uint32_t* trace, int log_n, size_t width);
+
+/* ---- STARK stages (sp1-stark / p3-uni-stark / p3-fri), exposed for parity ---- */
+typedef struct {
+    int log_blowup;       /* 1  (SP1 core)                    */
+    int num_queries;      /* 100                              */
+    int pow_bits;         /* 16                               */
+} orc_params_t;
+
+/* quotient values on the LDE coset, in bit-reversed row order like the LDE:
+ * out[p] (4 words) for p in [0, 2^(log_n+1)).  lde: bit-reversed rows, blowup 2. */
+void orc_quotient_values(const uint32_t* lde, int log_n, size_t width,
+                         const uint32_t alpha[4], uint32_t* out);
+/* open every column of a committed LDE (bit-reversed rows, 2^(log_n+log_blowup) rows)
+ * at ext point z by barycentric interpolation on its low coset: out[width][4]. */
+void orc_open_at(const uint32_t* lde, int log_n, size_t width, const uint32_t z[4],
+                 uint32_t* out);
+/* one FRI fold (arity 2) of `in` (2^log_h ext elements, bit-reversed) -> 2^(log_h-1). */
+void orc_fri_fold(const uint32_t* in, int log_h, const uint32_t beta[4], uint32_t* out);
+
+/* full shard proof; returns bytes written (0 on error); proof layout: DESIGN.md. */
+size_t orc_proof_size(int log_n, size_t width, const orc_params_t* prm, size_t n_public);
+size_t orc_prove_shard(const uint32_t* trace, int log_n, size_t width,
+                       const uint32_t* public_values, size_t n_public,
+                       const orc_params_t* prm, uint8_t* proof, size_t cap);
+/* 0 = accept; nonzero = reject code (which check failed). */
+int orc_verify_shard(const uint8_t* proof, size_t len, int log_n, size_t width,
+                     const uint32_t* public_values, size_t n_public,
+                     const orc_params_t* prm);
+
+/* intermediates of the last orc_prove_shard call in this thread (for parity tests) */
+typedef struct {
+    uint32_t trace_root[8];
+    uint32_t quotient_root[8];
+    uint32_t alpha[4];
+    uint32_t zeta[4];
+    uint32_t fri_alpha[4];
+    uint32_t pow_witness;
+} orc_prove_debug_t;
+void orc_last_prove_debug(orc_prove_debug_t* out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

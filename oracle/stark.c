@@ -1,0 +1,541 @@
+/*
+ * oracle/stark.c -- synthetic shard AIR, quotient, PCS opening, FRI prover and the
+ * verifier, CPU restatement.  TEST INFRASTRUCTURE ONLY; PARITY UNPINNED
+ * (see oracle/oracle.h).
+ *
+ * What it restates (published algorithms; the implementing crates are absent from
+ * /root/reference, reference call site crates/guest-prover-sp1/src/sp1.rs:116):
+ *   p3-uni-stark 0.2.1-succinct `prove`/`verify` (Cargo.lock:4055): commit trace,
+ *     sample alpha, quotient on the disjoint coset, split in 2^log_qd chunks, commit,
+ *     sample zeta, open trace at zeta and zeta*g, chunks at zeta;
+ *   p3-fri 0.2.1-succinct TwoAdicFriPcs::{commit,open} + prover::{commit_phase,
+ *     answer_query} + verifier (Cargo.lock:3930): alpha-batched reduced openings
+ *     (sum alpha^k (p(x) - p(z)) / (x - z)), fold-by-2 with beta per layer, one
+ *     Merkle commitment per layer, PoW grinding, num_queries index openings;
+ *   sp1-stark 4.1.4 BabyBearPoseidon2 parameters for core shards (Cargo.lock:6172):
+ *     log_blowup 1, 100 queries, 16 PoW bits.
+ * What is NOT restated: SP1's real chip AIRs (sp1-core-machine, unobtainable here).
+ * They are replaced by the documented synthetic AIR below.
+ *
+ * Deviation from upstream, on purpose: the opened values are observed by the
+ * challenger before the FRI batching challenge is drawn (upstream 0.2.1 draws it
+ * first); PoW takes the smallest witness.
+ */
+#include "oracle.h"
+#include <stdlib.h>
+#include <string.h>
+
+/* ------------------------------------------------------------------ */
+/* synthetic data                                                      */
+/* ------------------------------------------------------------------ */
+static uint64_t mix64(uint64_t z) {         /* splitmix64 output function */
+    z += 0x9E3779B97F4A7C15ull;
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    return z ^ (z >> 31);
+}
+/* = the (index+1)-th output of splitmix64 seeded with `seed`, reduced mod p */
+uint32_t orc_synth_value(uint64_t seed, uint64_t index) {
+    return (uint32_t)(mix64(seed + index * 0x9E3779B97F4A7C15ull) % BB_P);
+}
+void orc_fill_uniform(uint64_t seed, int log_n, size_t width, uint32_t* out) {
+    size_t total = ((size_t)1 << log_n) * width;
+#pragma omp parallel for schedule(static)
+    for (size_t i = 0; i < total; i++) out[i] = orc_synth_value(seed, i);
+}
+
+/* Synthetic AIR, width = 4 G, group g owns columns (a, b, c, d) = 4g .. 4g+3:
+ *   C1_g  all rows    :  c - a*a*b - K1_g                = 0     (degree 3)
+ *   C2_g  transition  :  d' - a*b - c - K2_g             = 0     (degree 2)
+ *   C3_g  first row   :  d - D0_g                        = 0     (degree 1)
+ * K1_g = g+1, K2_g = 2g+3, D0_g = 5g+7.  a, b are free (uniform); c, d are derived. */
+static inline bb_t air_k1(size_t g) { return (bb_t)((g + 1) % BB_P); }
+static inline bb_t air_k2(size_t g) { return (bb_t)((2 * g + 3) % BB_P); }
+static inline bb_t air_d0(size_t g) { return (bb_t)((5 * g + 7) % BB_P); }
+
+void orc_gen_trace(uint64_t seed, uint64_t shard, int log_n, size_t width, uint32_t* out) {
+    size_t n = (size_t)1 << log_n, G = width / 4;
+    uint64_t s = seed + shard;
+#pragma omp parallel for schedule(static)
+    for (size_t i = 0; i < n; i++) {
+        for (size_t g = 0; g < G; g++) {
+            uint32_t* row = out + i * width + 4 * g;
+            bb_t a = orc_synth_value(s, i * width + 4 * g);
+            bb_t b = orc_synth_value(s, i * width + 4 * g + 1);
+            bb_t c = bb_add(bb_mul(bb_mul(a, a), b), air_k1(g));
+            bb_t d;
+            if (i == 0) d = air_d0(g);
+            else {
+                bb_t pa = orc_synth_value(s, (i - 1) * width + 4 * g);
+                bb_t pb = orc_synth_value(s, (i - 1) * width + 4 * g + 1);
+                bb_t pc = bb_add(bb_mul(bb_mul(pa, pa), pb), air_k1(g));
+                d = bb_add(bb_add(bb_mul(pa, pb), pc), air_k2(g));
+            }
+            row[0] = a; row[1] = b; row[2] = c; row[3] = d;
+        }
+    }
+}
+
+size_t orc_check_trace(const uint32_t* t, int log_n, size_t width) {
+    size_t n = (size_t)1 << log_n, G = width / 4, bad = 0;
+    for (size_t i = 0; i < n; i++)
+        for (size_t g = 0; g < G; g++) {
+            const uint32_t* r = t + i * width + 4 * g;
+            if (r[2] != bb_add(bb_mul(bb_mul(r[0], r[0]), r[1]), air_k1(g))) bad++;
+            if (i + 1 < n) {
+                const uint32_t* nx = t + (i + 1) * width + 4 * g;
+                if (nx[3] != bb_add(bb_add(bb_mul(r[0], r[1]), r[2]), air_k2(g))) bad++;
+            }
+            if (i == 0 && r[3] != air_d0(g)) bad++;
+        }
+    return bad;
+}
+
+/* ------------------------------------------------------------------ */
+/* constraint folding:  acc = acc * alpha + C_k, k in AIR order         */
+/* ------------------------------------------------------------------ */
+static bb4_t fold_constraints_base(const uint32_t* local, const uint32_t* next, size_t width,
+                                   bb_t sel_first, bb_t sel_trans, bb4_t alpha) {
+    bb4_t acc = bb4_zero();
+    size_t G = width / 4;
+    for (size_t g = 0; g < G; g++) {
+        bb_t a = local[4 * g], b = local[4 * g + 1], c = local[4 * g + 2], d = local[4 * g + 3];
+        bb_t dn = next[4 * g + 3];
+        bb_t c1 = bb_sub(bb_sub(c, bb_mul(bb_mul(a, a), b)), air_k1(g));
+        bb_t c2 = bb_mul(sel_trans, bb_sub(bb_sub(bb_sub(dn, bb_mul(a, b)), c), air_k2(g)));
+        bb_t c3 = bb_mul(sel_first, bb_sub(d, air_d0(g)));
+        acc = bb4_add_base(bb4_mul(acc, alpha), c1);
+        acc = bb4_add_base(bb4_mul(acc, alpha), c2);
+        acc = bb4_add_base(bb4_mul(acc, alpha), c3);
+    }
+    return acc;
+}
+static bb4_t fold_constraints_ext(const bb4_t* local, const bb4_t* next, size_t width,
+                                  bb4_t sel_first, bb4_t sel_trans, bb4_t alpha) {
+    bb4_t acc = bb4_zero();
+    size_t G = width / 4;
+    for (size_t g = 0; g < G; g++) {
+        bb4_t a = local[4 * g], b = local[4 * g + 1], c = local[4 * g + 2], d = local[4 * g + 3];
+        bb4_t dn = next[4 * g + 3];
+        bb4_t c1 = bb4_sub_base(bb4_sub(c, bb4_mul(bb4_mul(a, a), b)), air_k1(g));
+        bb4_t c2 = bb4_mul(sel_trans, bb4_sub_base(bb4_sub(bb4_sub(dn, bb4_mul(a, b)), c), air_k2(g)));
+        bb4_t c3 = bb4_mul(sel_first, bb4_sub_base(d, air_d0(g)));
+        acc = bb4_add(bb4_mul(acc, alpha), c1);
+        acc = bb4_add(bb4_mul(acc, alpha), c2);
+        acc = bb4_add(bb4_mul(acc, alpha), c3);
+    }
+    return acc;
+}
+
+static bb4_t ld4(const uint32_t* p) { bb4_t r; memcpy(r.c, p, 16); return r; }
+static void st4(uint32_t* p, bb4_t v) { memcpy(p, v.c, 16); }
+
+/* ------------------------------------------------------------------ */
+/* quotient values on the coset g * <w_2N>  (log_blowup = log_qd = 1)   */
+/* ------------------------------------------------------------------ */
+void orc_quotient_values(const uint32_t* lde, int log_n, size_t width,
+                         const uint32_t alpha_[4], uint32_t* out) {
+    int log_m = log_n + 1;
+    size_t m = (size_t)1 << log_m, n = (size_t)1 << log_n;
+    bb4_t alpha = ld4(alpha_);
+    bb_t w = bb_two_adic_generator(log_m);
+    bb_t wn_inv = bb_inv(bb_two_adic_generator(log_n));   /* g_N^-1: last row of H */
+#pragma omp parallel for schedule(static)
+    for (size_t i = 0; i < m; i++) {
+        bb_t x = bb_mul(BB_GEN, bb_pow(w, i));
+        bb_t zh = bb_sub(bb_pow(x, n), 1);                 /* Z_H(x) = x^N - 1 */
+        bb_t sel_first = bb_mul(zh, bb_inv(bb_sub(x, 1)));
+        bb_t sel_trans = bb_sub(x, wn_inv);
+        bb_t inv_zh = bb_inv(zh);
+        size_t p = bb_reverse_bits((uint32_t)i, log_m);
+        size_t pn = bb_reverse_bits((uint32_t)((i + 2) & (m - 1)), log_m);
+        bb4_t acc = fold_constraints_base(lde + p * width, lde + pn * width, width,
+                                          sel_first, sel_trans, alpha);
+        st4(out + 4 * p, bb4_mul_base(acc, inv_zh));
+    }
+}
+
+/* ------------------------------------------------------------------ */
+/* barycentric opening on the low coset g * <w_N> of a bit-reversed LDE  */
+/*   f(z) = ((z/g)^N - 1)/N * sum_i f(x_i) x_i / (z - x_i)              */
+/* ------------------------------------------------------------------ */
+void orc_open_at(const uint32_t* lde, int log_n, size_t width, const uint32_t z_[4],
+                 uint32_t* out) {
+    size_t n = (size_t)1 << log_n;
+    bb4_t z = ld4(z_);
+    bb_t w = bb_two_adic_generator(log_n);
+    bb4_t* wts = (bb4_t*)malloc(n * sizeof(bb4_t));   /* indexed by row q */
+#pragma omp parallel for schedule(static)
+    for (size_t q = 0; q < n; q++) {
+        size_t i = bb_reverse_bits((uint32_t)q, log_n);
+        bb_t x = bb_mul(BB_GEN, bb_pow(w, i));
+        bb4_t den = bb4_sub_base(z, x);                /* z - x */
+        wts[q] = bb4_mul_base(bb4_inv(den), x);
+    }
+    bb4_t zg = bb4_mul_base(z, bb_inv(BB_GEN));
+    bb4_t scale = bb4_mul_base(bb4_sub_base(bb4_pow(zg, n), 1), bb_inv((bb_t)(n % BB_P)));
+#pragma omp parallel for schedule(static)
+    for (size_t c = 0; c < width; c++) {
+        bb4_t acc = bb4_zero();
+        for (size_t q = 0; q < n; q++) acc = bb4_add(acc, bb4_mul_base(wts[q], lde[q * width + c]));
+        st4(out + 4 * c, bb4_mul(acc, scale));
+    }
+    free(wts);
+}
+
+/* ------------------------------------------------------------------ */
+/* FRI fold:  out[i] = (e0+e1)/2 + beta (e0-e1)/(2 x_i),  x_i = w_{2h}^{bitrev_h(i)} */
+/* written as upstream's fold_row:  e0 + (beta - x)(e1 - e0)/(-2x)                   */
+/* ------------------------------------------------------------------ */
+static bb4_t fri_fold_row(size_t index, int log_folded_h, bb4_t beta, bb4_t e0, bb4_t e1) {
+    bb_t x = bb_pow(bb_two_adic_generator(log_folded_h + 1),
+                    bb_reverse_bits((uint32_t)index, log_folded_h));
+    bb_t inv = bb_inv(bb_sub(0, bb_add(x, x)));            /* 1 / (x1 - x0) = 1/(-2x) */
+    bb4_t t = bb4_mul(bb4_sub_base(beta, x), bb4_sub(e1, e0));
+    return bb4_add(e0, bb4_mul_base(t, inv));
+}
+void orc_fri_fold(const uint32_t* in, int log_h, const uint32_t beta_[4], uint32_t* out) {
+    size_t half = (size_t)1 << (log_h - 1);
+    bb4_t beta = ld4(beta_);
+#pragma omp parallel for schedule(static)
+    for (size_t i = 0; i < half; i++)
+        st4(out + 4 * i, fri_fold_row(i, log_h - 1, beta, ld4(in + 8 * i), ld4(in + 8 * i + 4)));
+}
+
+/* ------------------------------------------------------------------ */
+/* proof layout (all words little-endian u32, canonical residues)       */
+/* ------------------------------------------------------------------ */
+#define PROOF_MAGIC 0x41544B5Au   /* "ZKTA" */
+#define PROOF_VERSION 1u
+
+size_t orc_proof_size(int log_n, size_t width, const orc_params_t* prm, size_t n_public) {
+    (void)n_public;
+    size_t H = (size_t)(log_n + prm->log_blowup), L = (size_t)log_n;
+    size_t words = 8 + 16 + 8 * width + 32 + 8 * L + 5;
+    size_t perq = width + 8 + 16 * H;
+    for (size_t l = 0; l < L; l++) perq += 4 + 8 * (H - 1 - l);
+    words += (size_t)prm->num_queries * perq;
+    return words * 4;
+}
+
+static __thread orc_prove_debug_t g_dbg;
+void orc_last_prove_debug(orc_prove_debug_t* out) { *out = g_dbg; }
+
+static void observe_ext(orc_challenger_t* ch, bb4_t v) { orc_chal_observe_slice(ch, v.c, 4); }
+static bb4_t sample_ext(orc_challenger_t* ch) { bb4_t r; orc_chal_sample_ext(ch, r.c); return r; }
+
+static void transcript_init(orc_challenger_t* ch, int log_n, size_t width,
+                            const orc_params_t* prm, size_t n_public) {
+    orc_chal_init(ch);
+    orc_chal_observe(ch, (uint32_t)log_n);
+    orc_chal_observe(ch, (uint32_t)width);
+    orc_chal_observe(ch, (uint32_t)prm->log_blowup);
+    orc_chal_observe(ch, (uint32_t)prm->num_queries);
+    orc_chal_observe(ch, (uint32_t)prm->pow_bits);
+    orc_chal_observe(ch, (uint32_t)n_public);
+}
+
+size_t orc_prove_shard(const uint32_t* trace, int log_n, size_t width,
+                       const uint32_t* public_values, size_t n_public,
+                       const orc_params_t* prm, uint8_t* proof_bytes, size_t cap) {
+    if (prm->log_blowup != 1 || width % 4 != 0 || width == 0) return 0;
+    size_t need = orc_proof_size(log_n, width, prm, n_public);
+    if (cap < need) return 0;
+    uint32_t* pf = (uint32_t*)proof_bytes;
+    size_t pos = 0;
+    const int H = log_n + 1;
+    const size_t n = (size_t)1 << log_n, m = (size_t)1 << H;
+
+    pf[pos++] = PROOF_MAGIC; pf[pos++] = PROOF_VERSION; pf[pos++] = (uint32_t)log_n;
+    pf[pos++] = (uint32_t)width; pf[pos++] = (uint32_t)prm->log_blowup;
+    pf[pos++] = (uint32_t)prm->num_queries; pf[pos++] = (uint32_t)prm->pow_bits;
+    pf[pos++] = (uint32_t)n_public;
+
+    orc_challenger_t ch;
+    transcript_init(&ch, log_n, width, prm, n_public);
+
+    /* 1. commit the trace: LDE on g*<w_2N>, bit-reversed rows, Merkle tree */
+    uint32_t* tlde = (uint32_t*)malloc(m * width * 4);
+    orc_coset_lde(trace, tlde, log_n, width, 1, BB_GEN);
+    uint32_t* ttree = (uint32_t*)malloc((2 * m - 1) * 32);
+    { const uint32_t* mats[1] = {tlde}; size_t ws[1] = {width}; orc_merkle_tree(mats, ws, 1, H, ttree); }
+    const uint32_t* troot = ttree + (2 * m - 2) * 8;
+    memcpy(pf + pos, troot, 32); pos += 8;
+    memcpy(g_dbg.trace_root, troot, 32);
+    orc_chal_observe_slice(&ch, troot, 8);
+    orc_chal_observe_slice(&ch, public_values, n_public);
+
+    /* 2. constraint challenge, quotient, chunks, commit */
+    bb4_t alpha = sample_ext(&ch);
+    memcpy(g_dbg.alpha, alpha.c, 16);
+    uint32_t* qv = (uint32_t*)malloc(m * 16);          /* bit-reversed like the LDE */
+    orc_quotient_values(tlde, log_n, width, alpha.c, qv);
+    /* chunk k = natural rows i = 2j + k  <->  bit-reversed rows [k*N, (k+1)*N);
+     * as a matrix on the coset (g w^k) * <w_N> in natural order j: */
+    uint32_t* qlde = (uint32_t*)malloc(m * 8 * 4);     /* [chunk0 | chunk1], width 8 */
+    {
+        uint32_t* chunk = (uint32_t*)malloc(n * 4 * 4);
+        uint32_t* clde = (uint32_t*)malloc(m * 4 * 4);
+        bb_t w2n = bb_two_adic_generator(H);
+        for (int k = 0; k < 2; k++) {
+            for (size_t j = 0; j < n; j++) {
+                size_t p = bb_reverse_bits((uint32_t)(2 * j + k), H);
+                memcpy(chunk + 4 * j, qv + 4 * p, 16);
+            }
+            /* values on (g w^k)*<w_N> -> LDE on g*<w_2N>: shift = g / (g w^k) */
+            bb_t shift = bb_inv(bb_pow(w2n, (uint64_t)k));
+            orc_coset_lde(chunk, clde, log_n, 4, 1, shift);
+            for (size_t r = 0; r < m; r++) memcpy(qlde + r * 8 + 4 * k, clde + r * 4, 16);
+        }
+        free(chunk); free(clde);
+    }
+    free(qv);
+    uint32_t* qtree = (uint32_t*)malloc((2 * m - 1) * 32);
+    { const uint32_t* mats[1] = {qlde}; size_t ws[1] = {8}; orc_merkle_tree(mats, ws, 1, H, qtree); }
+    const uint32_t* qroot = qtree + (2 * m - 2) * 8;
+    memcpy(pf + pos, qroot, 32); pos += 8;
+    memcpy(g_dbg.quotient_root, qroot, 32);
+    orc_chal_observe_slice(&ch, qroot, 8);
+
+    /* 3. out-of-domain point, openings */
+    bb4_t zeta = sample_ext(&ch);
+    memcpy(g_dbg.zeta, zeta.c, 16);
+    bb4_t zeta_next = bb4_mul_base(zeta, bb_two_adic_generator(log_n));
+    uint32_t* op_local = pf + pos; pos += 4 * width;
+    uint32_t* op_next = pf + pos; pos += 4 * width;
+    uint32_t* op_q = pf + pos; pos += 32;
+    orc_open_at(tlde, log_n, width, zeta.c, op_local);
+    orc_open_at(tlde, log_n, width, zeta_next.c, op_next);
+    orc_open_at(qlde, log_n, 8, zeta.c, op_q);
+    orc_chal_observe_slice(&ch, op_local, 4 * width);
+    orc_chal_observe_slice(&ch, op_next, 4 * width);
+    orc_chal_observe_slice(&ch, op_q, 32);
+
+    /* 4. FRI input: alpha-batched reduced openings at every LDE point */
+    bb4_t fa = sample_ext(&ch);
+    memcpy(g_dbg.fri_alpha, fa.c, 16);
+    bb4_t* fapow = (bb4_t*)malloc((width > 8 ? width : 8) * sizeof(bb4_t));
+    fapow[0] = bb4_one();
+    for (size_t j = 1; j < (width > 8 ? width : 8); j++) fapow[j] = bb4_mul(fapow[j - 1], fa);
+    bb4_t y_loc = bb4_zero(), y_nxt = bb4_zero(), y_q = bb4_zero();
+    for (size_t j = 0; j < width; j++) {
+        y_loc = bb4_add(y_loc, bb4_mul(fapow[j], ld4(op_local + 4 * j)));
+        y_nxt = bb4_add(y_nxt, bb4_mul(fapow[j], ld4(op_next + 4 * j)));
+    }
+    for (size_t j = 0; j < 8; j++) y_q = bb4_add(y_q, bb4_mul(fapow[j], ld4(op_q + 4 * j)));
+    bb4_t off_next = bb4_pow(fa, width), off_q = bb4_pow(fa, 2 * width);
+    bb4_t* cur = (bb4_t*)malloc(m * sizeof(bb4_t));
+    {
+        bb_t w2n = bb_two_adic_generator(H);
+#pragma omp parallel for schedule(static)
+        for (size_t p = 0; p < m; p++) {
+            bb_t x = bb_mul(BB_GEN, bb_pow(w2n, bb_reverse_bits((uint32_t)p, H)));
+            bb4_t d1 = bb4_inv(bb4_neg(bb4_sub_base(zeta, x)));        /* 1/(x - zeta) */
+            bb4_t d2 = bb4_inv(bb4_neg(bb4_sub_base(zeta_next, x)));
+            bb4_t at = bb4_zero(), aq = bb4_zero();
+            for (size_t j = 0; j < width; j++) at = bb4_add(at, bb4_mul_base(fapow[j], tlde[p * width + j]));
+            for (size_t j = 0; j < 8; j++) aq = bb4_add(aq, bb4_mul_base(fapow[j], qlde[p * 8 + j]));
+            bb4_t r = bb4_mul(bb4_sub(at, y_loc), d1);
+            r = bb4_add(r, bb4_mul(off_next, bb4_mul(bb4_sub(at, y_nxt), d2)));
+            r = bb4_add(r, bb4_mul(off_q, bb4_mul(bb4_sub(aq, y_q), d1)));
+            cur[p] = r;
+        }
+    }
+    free(fapow);
+
+    /* 5. FRI commit phase */
+    const int L = log_n;
+    bb4_t** layers = (bb4_t**)malloc(L * sizeof(bb4_t*));
+    uint32_t** ltrees = (uint32_t**)malloc(L * sizeof(uint32_t*));
+    uint32_t* commits = pf + pos; pos += 8 * (size_t)L;
+    for (int l = 0; l < L; l++) {
+        int lh = H - 1 - l;                      /* log rows of this layer's matrix */
+        size_t rows = (size_t)1 << lh;
+        layers[l] = cur;
+        ltrees[l] = (uint32_t*)malloc((2 * rows - 1) * 32);
+        { const uint32_t* mats[1] = {(const uint32_t*)cur}; size_t ws[1] = {8};
+          orc_merkle_tree(mats, ws, 1, lh, ltrees[l]); }
+        const uint32_t* root = ltrees[l] + (2 * rows - 2) * 8;
+        memcpy(commits + 8 * l, root, 32);
+        orc_chal_observe_slice(&ch, root, 8);
+        bb4_t beta = sample_ext(&ch);
+        bb4_t* nxt = (bb4_t*)malloc(rows * sizeof(bb4_t));
+        orc_fri_fold((const uint32_t*)cur, lh + 1, beta.c, (uint32_t*)nxt);
+        cur = nxt;
+    }
+    /* two evaluations of a constant polynomial remain */
+    int const_ok = bb4_eq(cur[0], cur[1]);
+    bb4_t final_poly = cur[0];
+    free(cur);
+    st4(pf + pos, final_poly); pos += 4;
+    observe_ext(&ch, final_poly);
+
+    /* 6. proof of work, queries */
+    uint32_t witness = orc_chal_grind(&ch, prm->pow_bits);
+    g_dbg.pow_witness = witness;
+    pf[pos++] = witness;
+    for (int q = 0; q < prm->num_queries; q++) {
+        size_t index = orc_chal_sample_bits(&ch, H);
+        memcpy(pf + pos, tlde + index * width, width * 4); pos += width;
+        { size_t idx = index; const uint32_t* lvl = ttree; size_t cnt = m;
+          for (int k = 0; k < H; k++) { memcpy(pf + pos, lvl + 8 * (idx ^ 1), 32); pos += 8; lvl += 8 * cnt; cnt >>= 1; idx >>= 1; } }
+        memcpy(pf + pos, qlde + index * 8, 32); pos += 8;
+        { size_t idx = index; const uint32_t* lvl = qtree; size_t cnt = m;
+          for (int k = 0; k < H; k++) { memcpy(pf + pos, lvl + 8 * (idx ^ 1), 32); pos += 8; lvl += 8 * cnt; cnt >>= 1; idx >>= 1; } }
+        size_t idx = index;
+        for (int l = 0; l < L; l++) {
+            int lh = H - 1 - l;
+            size_t sib = idx ^ 1, pair = idx >> 1;
+            st4(pf + pos, layers[l][sib]); pos += 4;
+            size_t id2 = pair; const uint32_t* lvl = ltrees[l]; size_t cnt = (size_t)1 << lh;
+            for (int k = 0; k < lh; k++) { memcpy(pf + pos, lvl + 8 * (id2 ^ 1), 32); pos += 8; lvl += 8 * cnt; cnt >>= 1; id2 >>= 1; }
+            idx = pair;
+        }
+    }
+    for (int l = 0; l < L; l++) { free(layers[l]); free(ltrees[l]); }
+    free(layers); free(ltrees); free(tlde); free(ttree); free(qlde); free(qtree);
+    if (!const_ok) return 0;
+    return pos * 4 == need ? need : 0;
+}
+
+/* ------------------------------------------------------------------ */
+/* verifier                                                             */
+/* ------------------------------------------------------------------ */
+static int verify_path(const uint32_t root[8], int log_h, size_t index,
+                       const uint32_t* row, size_t width, const uint32_t* sibs) {
+    const uint32_t* rows[1] = {row}; size_t ws[1] = {width};
+    return orc_merkle_verify(root, log_h, index, rows, ws, 1, sibs);
+}
+
+int orc_verify_shard(const uint8_t* proof_bytes, size_t len, int log_n, size_t width,
+                     const uint32_t* public_values, size_t n_public,
+                     const orc_params_t* prm) {
+    if (prm->log_blowup != 1 || width % 4 != 0 || width == 0) return 1;
+    if (len != orc_proof_size(log_n, width, prm, n_public)) return 2;
+    const uint32_t* pf = (const uint32_t*)proof_bytes;
+    size_t pos = 0;
+    const int H = log_n + 1, L = log_n;
+    const size_t n = (size_t)1 << log_n;
+    if (pf[0] != PROOF_MAGIC || pf[1] != PROOF_VERSION || pf[2] != (uint32_t)log_n ||
+        pf[3] != (uint32_t)width || pf[4] != (uint32_t)prm->log_blowup ||
+        pf[5] != (uint32_t)prm->num_queries || pf[6] != (uint32_t)prm->pow_bits ||
+        pf[7] != (uint32_t)n_public) return 3;
+    pos = 8;
+    for (size_t i = 8; i < len / 4; i++) if (pf[i] >= BB_P) return 4;   /* canonical words only */
+
+    orc_challenger_t ch;
+    transcript_init(&ch, log_n, width, prm, n_public);
+    const uint32_t* troot = pf + pos; pos += 8;
+    const uint32_t* qroot = pf + pos; pos += 8;
+    orc_chal_observe_slice(&ch, troot, 8);
+    orc_chal_observe_slice(&ch, public_values, n_public);
+    bb4_t alpha = sample_ext(&ch);
+    orc_chal_observe_slice(&ch, qroot, 8);
+    bb4_t zeta = sample_ext(&ch);
+    bb_t gn = bb_two_adic_generator(log_n);
+    bb4_t zeta_next = bb4_mul_base(zeta, gn);
+    const uint32_t* op_local = pf + pos; pos += 4 * width;
+    const uint32_t* op_next = pf + pos; pos += 4 * width;
+    const uint32_t* op_q = pf + pos; pos += 32;
+    orc_chal_observe_slice(&ch, op_local, 4 * width);
+    orc_chal_observe_slice(&ch, op_next, 4 * width);
+    orc_chal_observe_slice(&ch, op_q, 32);
+
+    /* (a) constraint check at zeta */
+    {
+        bb4_t* loc = (bb4_t*)malloc(width * sizeof(bb4_t));
+        bb4_t* nxt = (bb4_t*)malloc(width * sizeof(bb4_t));
+        for (size_t j = 0; j < width; j++) { loc[j] = ld4(op_local + 4 * j); nxt[j] = ld4(op_next + 4 * j); }
+        bb4_t zn = bb4_pow(zeta, n);
+        bb4_t zh = bb4_sub_base(zn, 1);
+        bb4_t sel_first = bb4_mul(zh, bb4_inv(bb4_sub_base(zeta, 1)));
+        bb4_t sel_trans = bb4_sub_base(zeta, bb_inv(gn));
+        bb4_t folded = fold_constraints_ext(loc, nxt, width, sel_first, sel_trans, alpha);
+        free(loc); free(nxt);
+        /* quotient(zeta) = sum_k zps_k(zeta) * q_k(zeta); chunk domain k: shift s_k = g w_2N^k */
+        bb_t w2n = bb_two_adic_generator(H);
+        bb_t s[2] = {BB_GEN, bb_mul(BB_GEN, w2n)};
+        bb4_t quot = bb4_zero();
+        for (int k = 0; k < 2; k++) {
+            int j = 1 - k;
+            bb_t sjn_inv = bb_inv(bb_pow(s[j], n));
+            bb4_t num = bb4_sub_base(bb4_mul_base(zn, sjn_inv), 1);                 /* Z_Dj(zeta) */
+            bb_t den = bb_sub(bb_mul(bb_pow(s[k], n), sjn_inv), 1);                 /* Z_Dj(s_k)  */
+            bb4_t zps = bb4_mul_base(num, bb_inv(den));
+            bb4_t qk = bb4_zero();
+            for (int e = 0; e < 4; e++) {
+                bb4_t basis = bb4_zero(); basis.c[e] = 1;
+                qk = bb4_add(qk, bb4_mul(basis, ld4(op_q + 4 * (4 * k + e))));
+            }
+            quot = bb4_add(quot, bb4_mul(zps, qk));
+        }
+        if (!bb4_eq(bb4_mul(folded, bb4_inv(zh)), quot)) return 10;
+    }
+
+    /* (b) FRI */
+    bb4_t fa = sample_ext(&ch);
+    size_t np = width > 8 ? width : 8;
+    bb4_t* fapow = (bb4_t*)malloc(np * sizeof(bb4_t));
+    fapow[0] = bb4_one();
+    for (size_t j = 1; j < np; j++) fapow[j] = bb4_mul(fapow[j - 1], fa);
+    bb4_t y_loc = bb4_zero(), y_nxt = bb4_zero(), y_q = bb4_zero();
+    for (size_t j = 0; j < width; j++) {
+        y_loc = bb4_add(y_loc, bb4_mul(fapow[j], ld4(op_local + 4 * j)));
+        y_nxt = bb4_add(y_nxt, bb4_mul(fapow[j], ld4(op_next + 4 * j)));
+    }
+    for (size_t j = 0; j < 8; j++) y_q = bb4_add(y_q, bb4_mul(fapow[j], ld4(op_q + 4 * j)));
+    bb4_t off_next = bb4_pow(fa, width), off_q = bb4_pow(fa, 2 * width);
+
+    const uint32_t* commits = pf + pos; pos += 8 * (size_t)L;
+    bb4_t* betas = (bb4_t*)malloc(L * sizeof(bb4_t));
+    for (int l = 0; l < L; l++) {
+        orc_chal_observe_slice(&ch, commits + 8 * l, 8);
+        betas[l] = sample_ext(&ch);
+    }
+    bb4_t final_poly = ld4(pf + pos); pos += 4;
+    observe_ext(&ch, final_poly);
+    uint32_t witness = pf[pos++];
+    int rc = 0;
+    if (!orc_chal_check_witness(&ch, prm->pow_bits, witness)) rc = 20;
+
+    bb_t w2n = bb_two_adic_generator(H);
+    for (int q = 0; q < prm->num_queries && rc == 0; q++) {
+        size_t index = orc_chal_sample_bits(&ch, H);
+        const uint32_t* trow = pf + pos; pos += width;
+        const uint32_t* tpath = pf + pos; pos += 8 * (size_t)H;
+        const uint32_t* qrow = pf + pos; pos += 8;
+        const uint32_t* qpath = pf + pos; pos += 8 * (size_t)H;
+        if (verify_path(troot, H, index, trow, width, tpath)) { rc = 30; break; }
+        if (verify_path(qroot, H, index, qrow, 8, qpath)) { rc = 31; break; }
+        bb_t x = bb_mul(BB_GEN, bb_pow(w2n, bb_reverse_bits((uint32_t)index, H)));
+        bb4_t d1 = bb4_inv(bb4_neg(bb4_sub_base(zeta, x)));
+        bb4_t d2 = bb4_inv(bb4_neg(bb4_sub_base(zeta_next, x)));
+        bb4_t at = bb4_zero(), aq = bb4_zero();
+        for (size_t j = 0; j < width; j++) at = bb4_add(at, bb4_mul_base(fapow[j], trow[j]));
+        for (size_t j = 0; j < 8; j++) aq = bb4_add(aq, bb4_mul_base(fapow[j], qrow[j]));
+        bb4_t ro = bb4_mul(bb4_sub(at, y_loc), d1);
+        ro = bb4_add(ro, bb4_mul(off_next, bb4_mul(bb4_sub(at, y_nxt), d2)));
+        ro = bb4_add(ro, bb4_mul(off_q, bb4_mul(bb4_sub(aq, y_q), d1)));
+
+        bb4_t folded = ro;          /* single height: the reduced opening enters at layer 0 */
+        size_t idx = index;
+        for (int l = 0; l < L; l++) {
+            int lh = H - 1 - l;
+            bb4_t sib = ld4(pf + pos); pos += 4;
+            const uint32_t* path = pf + pos; pos += 8 * (size_t)lh;
+            bb4_t ev[2];
+            ev[idx & 1] = folded; ev[(idx & 1) ^ 1] = sib;
+            size_t pair = idx >> 1;
+            uint32_t rowbuf[8];
+            memcpy(rowbuf, ev[0].c, 16); memcpy(rowbuf + 4, ev[1].c, 16);
+            if (verify_path(commits + 8 * l, lh, pair, rowbuf, 8, path)) { rc = 40 + (l < 50 ? l : 50); break; }
+            folded = fri_fold_row(pair, lh, betas[l], ev[0], ev[1]);
+            idx = pair;
+        }
+        if (rc) break;
+        if (!bb4_eq(folded, final_poly)) { rc = 100; break; }
+    }
+    free(fapow); free(betas);
+    if (rc == 0 && pos * 4 != len) rc = 5;
+    return rc;
+}

@@ -1,0 +1,289 @@
+"""ctypes loader for the CPU oracle (oracle/liboracle.so).
+
+TEST INFRASTRUCTURE: imported only by tests/, __graft_entry__.smoke() and
+bench.py's cpu_baseline leg -- never by the product package zktls_amd/.
+All values crossing this API are canonical residues in [0, p).
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+P = 2013265921
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ORACLE_DIR = os.path.join(ROOT, "oracle")
+_LIB = None
+
+u32p = C.POINTER(C.c_uint32)
+
+
+class Params(C.Structure):
+    _fields_ = [("log_blowup", C.c_int), ("num_queries", C.c_int), ("pow_bits", C.c_int)]
+
+
+class ProveDebug(C.Structure):
+    _fields_ = [
+        ("trace_root", C.c_uint32 * 8),
+        ("quotient_root", C.c_uint32 * 8),
+        ("alpha", C.c_uint32 * 4),
+        ("zeta", C.c_uint32 * 4),
+        ("fri_alpha", C.c_uint32 * 4),
+        ("pow_witness", C.c_uint32),
+    ]
+
+
+class Challenger(C.Structure):
+    _fields_ = [
+        ("state", C.c_uint32 * 16),
+        ("input", C.c_uint32 * 8),
+        ("n_input", C.c_int),
+        ("output", C.c_uint32 * 8),
+        ("n_output", C.c_int),
+    ]
+
+
+def build(force=False):
+    so = os.path.join(ORACLE_DIR, "liboracle.so")
+    srcs = [os.path.join(ORACLE_DIR, f) for f in os.listdir(ORACLE_DIR) if f.endswith((".c", ".h"))]
+    if force or not os.path.exists(so) or any(os.path.getmtime(s) > os.path.getmtime(so) for s in srcs):
+        subprocess.check_call(["make", "-C", ORACLE_DIR, "-B", "liboracle.so"], stdout=subprocess.DEVNULL)
+    return so
+
+
+def lib():
+    global _LIB
+    if _LIB is not None:
+        return _LIB
+    so = os.path.join(ORACLE_DIR, "liboracle.so")
+    if not os.path.exists(so):
+        so = build()
+    L = C.CDLL(so)
+    L.orc_set_threads.restype = C.c_int
+    L.orc_set_threads.argtypes = [C.c_int]
+    L.orc_bb_mul.restype = C.c_uint32
+    L.orc_bb_mul.argtypes = [C.c_uint32, C.c_uint32]
+    L.orc_bb_inv.restype = C.c_uint32
+    L.orc_bb_inv.argtypes = [C.c_uint32]
+    L.orc_bb_pow.restype = C.c_uint32
+    L.orc_bb_pow.argtypes = [C.c_uint32, C.c_uint64]
+    L.orc_two_adic_generator.restype = C.c_uint32
+    L.orc_two_adic_generator.argtypes = [C.c_int]
+    L.orc_synth_value.restype = C.c_uint32
+    L.orc_synth_value.argtypes = [C.c_uint64, C.c_uint64]
+    L.orc_check_trace.restype = C.c_size_t
+    L.orc_proof_size.restype = C.c_size_t
+    L.orc_prove_shard.restype = C.c_size_t
+    L.orc_verify_shard.restype = C.c_int
+    L.orc_chal_sample.restype = C.c_uint32
+    L.orc_chal_sample_bits.restype = C.c_uint32
+    L.orc_chal_grind.restype = C.c_uint32
+    L.orc_chal_check_witness.restype = C.c_int
+    L.orc_merkle_verify.restype = C.c_int
+    _LIB = L
+    return L
+
+
+def _p(a):
+    return a.ctypes.data_as(u32p)
+
+
+def _u32(a):
+    return np.ascontiguousarray(a, dtype=np.uint32)
+
+
+def to_monty(a):
+    a = np.asarray(a, dtype=np.uint64)
+    return ((a << np.uint64(32)) % np.uint64(P)).astype(np.uint32)
+
+
+def from_monty(a):
+    a = np.asarray(a, dtype=np.uint64)
+    return ((a * np.uint64(943718400)) % np.uint64(P)).astype(np.uint32)
+
+
+def set_threads(n):
+    return lib().orc_set_threads(int(n))
+
+
+def dft_naive(mat, inverse=False):
+    mat = _u32(mat)
+    n, w = mat.shape
+    out = np.empty_like(mat)
+    lib().orc_dft_naive(_p(mat), _p(out), C.c_int(n.bit_length() - 1), C.c_size_t(w), C.c_int(int(inverse)))
+    return out
+
+
+def ntt(mat, inverse=False):
+    a = _u32(mat).copy()
+    n, w = a.shape
+    lib().orc_ntt(_p(a), C.c_int(n.bit_length() - 1), C.c_size_t(w), C.c_int(int(inverse)))
+    return a
+
+
+def coset_lde(mat, log_blowup=1, shift=31):
+    mat = _u32(mat)
+    n, w = mat.shape
+    out = np.empty((n << log_blowup, w), dtype=np.uint32)
+    lib().orc_coset_lde(_p(mat), _p(out), C.c_int(n.bit_length() - 1), C.c_size_t(w),
+                        C.c_int(log_blowup), C.c_uint32(shift))
+    return out
+
+
+def poseidon2(state):
+    s = _u32(state).copy()
+    assert s.shape == (16,)
+    lib().orc_poseidon2_permute(_p(s))
+    return s
+
+
+def sponge_hash(vals):
+    v = _u32(vals).ravel()
+    out = np.empty(8, dtype=np.uint32)
+    lib().orc_sponge_hash(_p(v), C.c_size_t(v.size), _p(out))
+    return out
+
+
+def compress(l, r):
+    l, r = _u32(l), _u32(r)
+    out = np.empty(8, dtype=np.uint32)
+    lib().orc_compress(_p(l), _p(r), _p(out))
+    return out
+
+
+def _mats_args(mats):
+    mats = [_u32(m) for m in mats]
+    ptrs = (u32p * len(mats))(*[_p(m) for m in mats])
+    widths = (C.c_size_t * len(mats))(*[m.shape[1] for m in mats])
+    return mats, ptrs, widths
+
+
+def hash_rows(mats):
+    mats, ptrs, widths = _mats_args(mats)
+    h = mats[0].shape[0]
+    out = np.empty((h, 8), dtype=np.uint32)
+    lib().orc_hash_rows(ptrs, widths, C.c_int(len(mats)), C.c_size_t(h), _p(out))
+    return out
+
+
+def merkle_tree(mats):
+    """equal-height matrices -> all levels [(2^(h+1)-1), 8]; root = last row"""
+    mats, ptrs, widths = _mats_args(mats)
+    h = mats[0].shape[0]
+    log_h = h.bit_length() - 1
+    out = np.empty((2 * h - 1, 8), dtype=np.uint32)
+    lib().orc_merkle_tree(ptrs, widths, C.c_int(len(mats)), C.c_int(log_h), _p(out))
+    return out
+
+
+def merkle_tree_mixed(mats):
+    mats, ptrs, widths = _mats_args(mats)
+    lhs = [m.shape[0].bit_length() - 1 for m in mats]
+    h = 1 << max(lhs)
+    out = np.empty((2 * h - 1, 8), dtype=np.uint32)
+    lib().orc_merkle_tree_mixed(ptrs, widths, (C.c_int * len(mats))(*lhs), C.c_int(len(mats)), _p(out))
+    return out
+
+
+def fill_uniform(seed, log_n, width):
+    out = np.empty((1 << log_n, width), dtype=np.uint32)
+    lib().orc_fill_uniform(C.c_uint64(seed), C.c_int(log_n), C.c_size_t(width), _p(out))
+    return out
+
+
+def gen_trace(seed, shard, log_n, width):
+    out = np.empty((1 << log_n, width), dtype=np.uint32)
+    lib().orc_gen_trace(C.c_uint64(seed), C.c_uint64(shard), C.c_int(log_n), C.c_size_t(width), _p(out))
+    return out
+
+
+def check_trace(trace):
+    t = _u32(trace)
+    n, w = t.shape
+    return lib().orc_check_trace(_p(t), C.c_int(n.bit_length() - 1), C.c_size_t(w))
+
+
+def quotient_values(lde, log_n, alpha):
+    lde = _u32(lde)
+    w = lde.shape[1]
+    a = _u32(alpha)
+    out = np.empty((lde.shape[0], 4), dtype=np.uint32)
+    lib().orc_quotient_values(_p(lde), C.c_int(log_n), C.c_size_t(w), _p(a), _p(out))
+    return out
+
+
+def open_at(lde, log_n, z):
+    lde = _u32(lde)
+    w = lde.shape[1]
+    zz = _u32(z)
+    out = np.empty((w, 4), dtype=np.uint32)
+    lib().orc_open_at(_p(lde), C.c_int(log_n), C.c_size_t(w), _p(zz), _p(out))
+    return out
+
+
+def fri_fold(vals, beta):
+    v = _u32(vals)
+    h = v.shape[0]
+    b = _u32(beta)
+    out = np.empty((h // 2, 4), dtype=np.uint32)
+    lib().orc_fri_fold(_p(v), C.c_int(h.bit_length() - 1), _p(b), _p(out))
+    return out
+
+
+def default_params(log_blowup=1, num_queries=100, pow_bits=16):
+    return Params(log_blowup, num_queries, pow_bits)
+
+
+def prove_shard(trace, public_values=(), params=None):
+    params = params or default_params()
+    t = _u32(trace)
+    n, w = t.shape
+    log_n = n.bit_length() - 1
+    pv = _u32(np.array(public_values, dtype=np.uint32))
+    size = lib().orc_proof_size(C.c_int(log_n), C.c_size_t(w), C.byref(params), C.c_size_t(pv.size))
+    buf = np.empty(size, dtype=np.uint8)
+    got = lib().orc_prove_shard(_p(t), C.c_int(log_n), C.c_size_t(w), _p(pv), C.c_size_t(pv.size),
+                                C.byref(params), buf.ctypes.data_as(C.POINTER(C.c_uint8)), C.c_size_t(size))
+    if got != size:
+        raise RuntimeError("oracle prove failed")
+    return buf
+
+
+def prove_debug():
+    d = ProveDebug()
+    lib().orc_last_prove_debug(C.byref(d))
+    return {k: np.array(getattr(d, k), dtype=np.uint32) if k != "pow_witness" else int(d.pow_witness)
+            for k, _ in ProveDebug._fields_}
+
+
+def verify_shard(proof, log_n, width, public_values=(), params=None):
+    params = params or default_params()
+    pr = np.ascontiguousarray(proof, dtype=np.uint8)
+    pv = _u32(np.array(public_values, dtype=np.uint32))
+    return lib().orc_verify_shard(pr.ctypes.data_as(C.POINTER(C.c_uint8)), C.c_size_t(pr.size),
+                                  C.c_int(log_n), C.c_size_t(width), _p(pv), C.c_size_t(pv.size),
+                                  C.byref(params))
+
+
+class OracleChallenger:
+    def __init__(self):
+        self.c = Challenger()
+        lib().orc_chal_init(C.byref(self.c))
+
+    def observe(self, vals):
+        v = _u32(np.atleast_1d(np.asarray(vals, dtype=np.uint32))).ravel()
+        lib().orc_chal_observe_slice(C.byref(self.c), _p(v), C.c_size_t(v.size))
+
+    def sample(self):
+        return lib().orc_chal_sample(C.byref(self.c))
+
+    def sample_ext(self):
+        out = np.empty(4, dtype=np.uint32)
+        lib().orc_chal_sample_ext(C.byref(self.c), _p(out))
+        return out
+
+    def sample_bits(self, bits):
+        return lib().orc_chal_sample_bits(C.byref(self.c), C.c_int(bits))
+
+    def grind(self, bits):
+        return lib().orc_chal_grind(C.byref(self.c), C.c_int(bits))
