@@ -1,0 +1,167 @@
+/*
+ * zkhip.h -- C ABI of libzkhip.so: the MI355X (gfx950) shard-prove hot path for zkTLS.
+ *
+ * This is the drop-in boundary a Rust `ZkProver` backend binds with `extern "C"`
+ * (binding sketch: INTEGRATION.md).  The reference has no FFI of its own; each entry
+ * point below names the reference interface or third-party call it stands in for:
+ *
+ *   zkhip_prove_shard / zkhip_verify_shard
+ *       the span the reference times at crates/guest-prover-sp1/src/sp1.rs:115-118
+ *       (`client.prove`, :116) and checks at :120 (`client.verify`), reached through
+ *       trait ZkProver::prove (core/src/prelude.rs:12-18); RISC Zero twin:
+ *       crates/guest-prover-r0/src/prover.rs:88-93.
+ *   zkhip_coset_lde, zkhip_dft, zkhip_ntt_pass
+ *       p3-dft Radix2DitParallel::{coset_lde_batch, dft_batch} (reference
+ *       Cargo.lock:3903) == risc0-zkp Hal::{batch_interpolate_ntt,
+ *       batch_expand_into_evaluate_ntt} (Cargo.lock:5057).
+ *   zkhip_hash_rows, zkhip_merkle_commit
+ *       p3-merkle-tree FieldMerkleTreeMmcs::commit (Cargo.lock:4013) == Hal::hash_rows
+ *       + Hal::hash_fold.
+ *   zkhip_quotient_values, zkhip_open_at, zkhip_fri_fold
+ *       sp1-stark quotient_values (Cargo.lock:6172), p3-fri TwoAdicFriPcs::open and
+ *       fold (Cargo.lock:3930) == Hal::{eval_check, batch_evaluate_any, fri_fold}.
+ *
+ * Conventions:
+ *   - every function returns 0 on success or a negative zkhip_status; it never throws,
+ *     aborts or unwinds across the ABI (the Rust glue wraps calls in catch_unwind,
+ *     sp1.rs:85); zkhip_last_error() gives the thread-local message;
+ *   - a context is bound to one device ordinal and one HIP stream; calls on one context
+ *     are serialised by the caller, separate contexts are independent; no global state;
+ *   - matrices are row-major uint32 words in MONTGOMERY form (R = 2^32), canonical range
+ *     [0, p), p = 2^31 - 2^27 + 1 -- the in-memory form of p3 MontyField31; `ld` is the
+ *     row pitch in words; extension elements are 4 consecutive words (x^4 = 11);
+ *   - pointers named d_* are DEVICE pointers (hipMalloc / torch data_ptr); proof bytes
+ *     and public values are HOST pointers; digests on the device are 8 Montgomery words;
+ *   - proof bytes hold CANONICAL little-endian words (layout: DESIGN.md section 6);
+ *     a proof of <= 4 bytes means "no proof" (sp1.rs:128-130), which this library
+ *     never returns on success.
+ *   - there is NO CPU fallback: without a usable gfx950 device every compute entry
+ *     point fails with ZKHIP_ERR_NO_DEVICE.
+ */
+#ifndef ZKHIP_H
+#define ZKHIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define ZKHIP_VERSION 100 /* 0.1.0 */
+
+typedef enum {
+    ZKHIP_OK = 0,
+    ZKHIP_ERR_INVALID = -1,     /* bad argument                        */
+    ZKHIP_ERR_NO_DEVICE = -2,   /* no HIP device / wrong architecture  */
+    ZKHIP_ERR_HIP = -3,         /* HIP runtime error (see last_error)  */
+    ZKHIP_ERR_NOMEM = -4,
+    ZKHIP_ERR_BUFFER = -5,      /* caller buffer too small             */
+    ZKHIP_ERR_VERIFY = -6,      /* proof rejected                      */
+    ZKHIP_ERR_INTERNAL = -7
+} zkhip_status;
+
+typedef struct zkhip_ctx zkhip_ctx;
+
+/* SP1-core-like parameters (sp1-stark 4.1.4 BabyBearPoseidon2: log_blowup 1,
+ * 100 queries, 16 proof-of-work bits). */
+typedef struct {
+    int32_t log_blowup;
+    int32_t num_queries;
+    int32_t pow_bits;
+} zkhip_params;
+
+/* ---- library / context ---- */
+int zkhip_version(void);
+const char* zkhip_last_error(void);
+/* number of usable devices (0 when there is no GPU; never fails) */
+int zkhip_device_count(void);
+/* stream: a hipStream_t owned by the caller, or NULL to let the context create one */
+int zkhip_ctx_create(int device, void* stream, zkhip_ctx** out);
+void zkhip_ctx_destroy(zkhip_ctx* ctx);
+int zkhip_ctx_sync(zkhip_ctx* ctx);
+void* zkhip_ctx_stream(zkhip_ctx* ctx);
+
+/* ---- device memory helpers (for callers without their own allocator) ---- */
+int zkhip_malloc(zkhip_ctx* ctx, size_t bytes, void** d_ptr);
+int zkhip_free(zkhip_ctx* ctx, void* d_ptr);
+int zkhip_memcpy_h2d(zkhip_ctx* ctx, void* d_dst, const void* h_src, size_t bytes);
+int zkhip_memcpy_d2h(zkhip_ctx* ctx, void* h_dst, const void* d_src, size_t bytes);
+/* element-wise canonical <-> Montgomery on the device (n words, in place allowed) */
+int zkhip_to_monty(zkhip_ctx* ctx, const uint32_t* d_in, uint32_t* d_out, size_t n);
+int zkhip_from_monty(zkhip_ctx* ctx, const uint32_t* d_in, uint32_t* d_out, size_t n);
+
+/* ---- synthetic shards: element (r, c) = splitmix64(seed)[r*width+c] mod p ---- */
+int zkhip_fill_uniform(zkhip_ctx* ctx, uint64_t seed, int log_n, uint32_t width,
+                       uint32_t* d_out, size_t ld);
+/* AIR-satisfying trace of shard `shard` (width % 4 == 0); stream seed = seed + shard */
+int zkhip_gen_trace(zkhip_ctx* ctx, uint64_t seed, uint64_t shard, int log_n, uint32_t width,
+                    uint32_t* d_out, size_t ld);
+
+/* ---- NTT / LDE over the columns of a row-major matrix, 2^log_n rows, 5 <= log_n <= 20 ---- */
+/* forward DFT: natural rows in; rows out natural (bitrev_out = 0) or bit-reversed (1);
+ * inverse DFT (inverse = 1): natural in, natural out, scaled by 1/N. */
+int zkhip_dft(zkhip_ctx* ctx, const uint32_t* d_in, size_t in_ld, uint32_t* d_out, size_t out_ld,
+              int log_n, uint32_t width, int inverse, int bitrev_out);
+/* coset_lde_batch(in, log_blowup, shift).bit_reverse_rows(): out has 2^(log_n+log_blowup)
+ * rows; row bitrev(i) = f(shift * w^i).  `shift` is a CANONICAL field element. */
+int zkhip_coset_lde(zkhip_ctx* ctx, const uint32_t* d_in, size_t in_ld, uint32_t* d_out,
+                    size_t out_ld, int log_n, uint32_t width, int log_blowup, uint32_t shift);
+/* benchmark hook: ONE launch of the NTT pass kernel (the roofline kernel) on a
+ * 2^log_n x width matrix: which = 0 strided (first) pass, 1 contiguous (second) pass of
+ * the forward transform.  d_out may equal d_in. */
+int zkhip_ntt_pass(zkhip_ctx* ctx, const uint32_t* d_in, uint32_t* d_out, size_t ld, int log_n,
+                   uint32_t width, int which);
+
+/* ---- Poseidon2 Merkle commitment ---- */
+/* states: count x 16 words, permuted in place (known-answer tests) */
+int zkhip_poseidon2_permute(zkhip_ctx* ctx, uint32_t* d_states, size_t count);
+/* leaf digests of the row-wise concatenation of nmats (<= 4) equal-height matrices */
+int zkhip_hash_rows(zkhip_ctx* ctx, const uint32_t* const* d_mats, const size_t* lds,
+                    const uint32_t* widths, int nmats, size_t height, uint32_t* d_digests);
+/* full tree over 2^log_h leaves: d_tree holds (2^(log_h+1) - 1) * 8 words, level 0
+ * (leaves) first, root last. */
+int zkhip_merkle_commit(zkhip_ctx* ctx, const uint32_t* const* d_mats, const size_t* lds,
+                        const uint32_t* widths, int nmats, int log_h, uint32_t* d_tree);
+
+/* ---- STARK stages (synthetic AIR, log_blowup = 1) ---- */
+/* quotient values on the LDE coset, bit-reversed rows: d_out[2^(log_n+1)][4] */
+int zkhip_quotient_values(zkhip_ctx* ctx, const uint32_t* d_lde, size_t ld, int log_n,
+                          uint32_t width, const uint32_t alpha[4] /* host, Montgomery */,
+                          uint32_t* d_out);
+/* barycentric opening of every column of a bit-reversed LDE at `npoints` extension
+ * points (host, Montgomery): h_out[npoints][width][4] (host, Montgomery) */
+int zkhip_open_at(zkhip_ctx* ctx, const uint32_t* d_lde, size_t ld, int log_n, int log_blowup,
+                  uint32_t width, const uint32_t* z, int npoints, uint32_t* h_out);
+/* one fold-by-2 FRI step on 2^log_h extension elements (bit-reversed order) */
+int zkhip_fri_fold(zkhip_ctx* ctx, const uint32_t* d_in, int log_h,
+                   const uint32_t beta[4] /* host, Montgomery */, uint32_t* d_out);
+
+/* ---- whole shard ---- */
+size_t zkhip_proof_size(int log_n, uint32_t width, const zkhip_params* prm, size_t n_public);
+/* d_trace: 2^log_n x width AIR trace (Montgomery).  public_values: host, canonical.
+ * proof: host buffer of `cap` bytes; *len receives the bytes written. */
+int zkhip_prove_shard(zkhip_ctx* ctx, const uint32_t* d_trace, size_t ld, int log_n,
+                      uint32_t width, const uint32_t* public_values, size_t n_public,
+                      const zkhip_params* prm, uint8_t* proof, size_t cap, size_t* len);
+/* host-side verifier (CPU; the reference verifies on the CPU too, sp1.rs:120).
+ * Returns ZKHIP_OK or ZKHIP_ERR_VERIFY; *reason (optional) gets the failing check. */
+int zkhip_verify_shard(const uint8_t* proof, size_t len, int log_n, uint32_t width,
+                       const uint32_t* public_values, size_t n_public,
+                       const zkhip_params* prm, int* reason);
+
+/* intermediates of the last zkhip_prove_shard on this context (canonical words) */
+typedef struct {
+    uint32_t trace_root[8];
+    uint32_t quotient_root[8];
+    uint32_t alpha[4];
+    uint32_t zeta[4];
+    uint32_t fri_alpha[4];
+    uint32_t pow_witness;
+} zkhip_prove_debug;
+int zkhip_last_prove_debug(zkhip_ctx* ctx, zkhip_prove_debug* out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* ZKHIP_H */

@@ -1,0 +1,71 @@
+#!/usr/bin/env python3
+"""Regenerate tests/golden/oracle_kat.json from the CPU oracle.
+
+The reference (the3cloud/zktls) holds NO golden vector for the prover path (SURVEY.md
+section 4), so these fixtures are produced by this repo's own oracle ("parity
+unpinned"): they freeze the oracle against regressions and give the GPU tests fixed
+expected values that travel to the GPU box.  Independent pinning of the primitives comes
+from tests/pyref.py (pure-Python first-principles definitions), checked in
+tests/test_oracle.py.  Run:  python tests/golden/make_golden.py
+"""
+import hashlib
+import json
+import os
+import sys
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.dirname(HERE))
+import oracle_lib as O  # noqa: E402
+
+SEED = 0x5A4B544C53
+
+
+def main():
+    O.build()
+    out = {}
+    out["poseidon2_iota"] = O.poseidon2(np.arange(16, dtype=np.uint32)).tolist()
+    out["poseidon2_zero"] = O.poseidon2(np.zeros(16, dtype=np.uint32)).tolist()
+    out["sponge_1_to_20"] = O.sponge_hash(np.arange(1, 21, dtype=np.uint32)).tolist()
+    out["compress"] = O.compress(np.arange(8, dtype=np.uint32), np.arange(8, 16, dtype=np.uint32)).tolist()
+    out["ntt_1_to_8"] = O.ntt(np.arange(1, 9, dtype=np.uint32).reshape(8, 1)).ravel().tolist()
+    m = O.fill_uniform(SEED, 6, 4)
+    out["fill_uniform_6x4_first8"] = m.ravel()[:8].tolist()
+    lde = O.coset_lde(m, 1, 31)
+    out["lde_6x4_sha256"] = hashlib.sha256(lde.tobytes()).hexdigest()
+    out["lde_6x4_root"] = O.merkle_tree([lde])[-1].tolist()
+    # bigger commit used by the GPU tests (two-pass NTT path: log_n = 12)
+    m12 = O.fill_uniform(SEED + 1, 12, 24)
+    lde12 = O.coset_lde(m12, 1, 31)
+    out["lde_12x24_sha256"] = hashlib.sha256(lde12.tobytes()).hexdigest()
+    out["lde_12x24_root"] = O.merkle_tree([lde12])[-1].tolist()
+    ch = O.OracleChallenger()
+    ch.observe(np.arange(1, 12, dtype=np.uint32))
+    out["challenger_samples"] = [int(ch.sample()) for _ in range(10)]
+    out["challenger_bits"] = int(ch.sample_bits(12))
+    ch2 = O.OracleChallenger()
+    ch2.observe(np.arange(5, dtype=np.uint32))
+    out["challenger_grind8"] = int(ch2.grind(8))
+    proofs = {}
+    for name, (log_n, w, q, pw) in {"p6x8": (6, 8, 10, 8), "p10x16": (10, 16, 100, 16), "p12x32": (12, 32, 100, 16)}.items():
+        t = O.gen_trace(SEED, 3, log_n, w)
+        prm = O.default_params(1, q, pw)
+        pf = O.prove_shard(t, [7, 8, 9], prm)
+        assert O.verify_shard(pf, log_n, w, [7, 8, 9], prm) == 0
+        d = O.prove_debug()
+        proofs[name] = {
+            "log_n": log_n, "width": w, "num_queries": q, "pow_bits": pw, "shard": 3, "public": [7, 8, 9],
+            "bytes": int(pf.size), "sha256": hashlib.sha256(pf.tobytes()).hexdigest(),
+            "trace_root": d["trace_root"].tolist(), "quotient_root": d["quotient_root"].tolist(),
+            "alpha": d["alpha"].tolist(), "zeta": d["zeta"].tolist(), "fri_alpha": d["fri_alpha"].tolist(),
+            "pow_witness": d["pow_witness"],
+        }
+    out["proofs"] = proofs
+    with open(os.path.join(HERE, "oracle_kat.json"), "w") as f:
+        json.dump(out, f, indent=1)
+    print("wrote oracle_kat.json")
+
+
+if __name__ == "__main__":
+    main()

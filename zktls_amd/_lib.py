@@ -1,0 +1,111 @@
+"""ctypes binding of libzkhip.so (C ABI: include/zkhip.h).
+
+The product path: everything here calls the HIP library.  There is no CPU fallback --
+if the shared library is missing, or no gfx950 device is visible, the calls raise.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+P = 2013265921
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libzkhip.so")
+
+u32p = C.POINTER(C.c_uint32)
+u8p = C.POINTER(C.c_uint8)
+
+EXPORTS = [
+    "zkhip_version", "zkhip_last_error", "zkhip_device_count", "zkhip_ctx_create", "zkhip_ctx_destroy",
+    "zkhip_ctx_sync", "zkhip_ctx_stream", "zkhip_malloc", "zkhip_free", "zkhip_memcpy_h2d",
+    "zkhip_memcpy_d2h", "zkhip_to_monty", "zkhip_from_monty", "zkhip_fill_uniform", "zkhip_gen_trace",
+    "zkhip_dft", "zkhip_coset_lde", "zkhip_ntt_pass", "zkhip_poseidon2_permute", "zkhip_hash_rows",
+    "zkhip_merkle_commit", "zkhip_quotient_values", "zkhip_open_at", "zkhip_fri_fold",
+    "zkhip_proof_size", "zkhip_prove_shard", "zkhip_verify_shard", "zkhip_last_prove_debug",
+]
+
+
+class ZkHipError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__("zkhip error %d: %s" % (code, msg))
+        self.code = code
+
+
+class Params(C.Structure):
+    _fields_ = [("log_blowup", C.c_int32), ("num_queries", C.c_int32), ("pow_bits", C.c_int32)]
+
+
+class ProveDebug(C.Structure):
+    _fields_ = [
+        ("trace_root", C.c_uint32 * 8),
+        ("quotient_root", C.c_uint32 * 8),
+        ("alpha", C.c_uint32 * 4),
+        ("zeta", C.c_uint32 * 4),
+        ("fri_alpha", C.c_uint32 * 4),
+        ("pow_witness", C.c_uint32),
+    ]
+
+
+_LIB = None
+
+
+def load():
+    """Load libzkhip.so; raises if it has not been built (no fallback)."""
+    global _LIB
+    if _LIB is not None:
+        return _LIB
+    if not os.path.exists(LIB_PATH):
+        raise ImportError("libzkhip.so not built: run `python -c 'import __graft_entry__ as g; g.build()'` "
+                          "(zktls_amd has no CPU fallback)")
+    L = C.CDLL(LIB_PATH)
+    L.zkhip_last_error.restype = C.c_char_p
+    L.zkhip_ctx_stream.restype = C.c_void_p
+    L.zkhip_ctx_stream.argtypes = [C.c_void_p]
+    L.zkhip_ctx_create.argtypes = [C.c_int, C.c_void_p, C.POINTER(C.c_void_p)]
+    L.zkhip_ctx_destroy.argtypes = [C.c_void_p]
+    L.zkhip_ctx_destroy.restype = None
+    L.zkhip_ctx_sync.argtypes = [C.c_void_p]
+    L.zkhip_malloc.argtypes = [C.c_void_p, C.c_size_t, C.POINTER(C.c_void_p)]
+    L.zkhip_free.argtypes = [C.c_void_p, C.c_void_p]
+    L.zkhip_memcpy_h2d.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t]
+    L.zkhip_memcpy_d2h.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t]
+    L.zkhip_to_monty.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t]
+    L.zkhip_from_monty.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t]
+    L.zkhip_fill_uniform.argtypes = [C.c_void_p, C.c_uint64, C.c_int, C.c_uint32, C.c_void_p, C.c_size_t]
+    L.zkhip_gen_trace.argtypes = [C.c_void_p, C.c_uint64, C.c_uint64, C.c_int, C.c_uint32, C.c_void_p, C.c_size_t]
+    L.zkhip_dft.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_int, C.c_uint32, C.c_int, C.c_int]
+    L.zkhip_coset_lde.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_int, C.c_uint32, C.c_int, C.c_uint32]
+    L.zkhip_ntt_pass.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_uint32, C.c_int]
+    L.zkhip_poseidon2_permute.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t]
+    L.zkhip_hash_rows.argtypes = [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t), C.POINTER(C.c_uint32), C.c_int, C.c_size_t, C.c_void_p]
+    L.zkhip_merkle_commit.argtypes = [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t), C.POINTER(C.c_uint32), C.c_int, C.c_int, C.c_void_p]
+    L.zkhip_quotient_values.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_uint32, u32p, C.c_void_p]
+    L.zkhip_open_at.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_int, C.c_uint32, u32p, C.c_int, u32p]
+    L.zkhip_fri_fold.argtypes = [C.c_void_p, C.c_void_p, C.c_int, u32p, C.c_void_p]
+    L.zkhip_proof_size.restype = C.c_size_t
+    L.zkhip_proof_size.argtypes = [C.c_int, C.c_uint32, C.POINTER(Params), C.c_size_t]
+    L.zkhip_prove_shard.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_uint32, u32p, C.c_size_t,
+                                    C.POINTER(Params), u8p, C.c_size_t, C.POINTER(C.c_size_t)]
+    L.zkhip_verify_shard.argtypes = [u8p, C.c_size_t, C.c_int, C.c_uint32, u32p, C.c_size_t, C.POINTER(Params), C.POINTER(C.c_int)]
+    L.zkhip_last_prove_debug.argtypes = [C.c_void_p, C.POINTER(ProveDebug)]
+    _LIB = L
+    return L
+
+
+def check(rc):
+    if rc != 0:
+        raise ZkHipError(rc, load().zkhip_last_error().decode("utf-8", "replace"))
+
+
+def device_count():
+    return load().zkhip_device_count()
+
+
+def to_monty(a):
+    a = np.asarray(a, dtype=np.uint64)
+    return ((a << np.uint64(32)) % np.uint64(P)).astype(np.uint32)
+
+
+def from_monty(a):
+    a = np.asarray(a, dtype=np.uint64)
+    return ((a * np.uint64(943718400)) % np.uint64(P)).astype(np.uint32)

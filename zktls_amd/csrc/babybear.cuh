@@ -1,0 +1,145 @@
+// babybear.cuh -- BabyBear (p = 2^31 - 2^27 + 1) in Montgomery form, R = 2^32, and the
+// quartic extension F_p[x]/(x^4 - 11).  Shared by the gfx950 kernels and the host-side
+// transcript code of libzkhip (host + device + constexpr in one definition).
+//
+// Replaces, for the shard-prove hot path, the arithmetic that the reference reaches
+// through p3-baby-bear 0.2.1-succinct (reference Cargo.lock:3845) below
+// crates/guest-prover-sp1/src/sp1.rs:116.  Values are canonical Montgomery residues
+// in [0, p): the same in-memory form Plonky3's MontyField31 uses, which is what the
+// row-major trace matrices crossing the C ABI (include/zkhip.h) hold.
+#pragma once
+#include <stdint.h>
+
+#if defined(__HIPCC__)
+#include <hip/hip_runtime.h>
+#define ZK_HD __host__ __device__ __forceinline__
+#define ZK_D __device__ __forceinline__
+#else
+#define ZK_HD inline
+#define ZK_D inline
+#endif
+
+namespace zk {
+
+constexpr uint32_t P = 0x78000001u;        // 2013265921
+constexpr uint32_t MONTY_MU = 0x88000001u; // P^-1 mod 2^32  (= 2^31 + 2^27 + 1)
+constexpr uint32_t MONTY_R1 = 0x0ffffffeu; // R mod P   = Montgomery form of 1
+constexpr uint32_t MONTY_R2 = 1172168163u; // R^2 mod P
+constexpr uint32_t GEN = 31u;              // multiplicative generator (canonical)
+constexpr int TWO_ADICITY = 27;
+constexpr uint32_t TWO_ADIC_GEN = 440564289u;  // 31^15, order 2^27 (canonical)
+constexpr uint32_t EXT_W = 11u;            // x^4 = 11 (canonical)
+
+// ---- raw Montgomery arithmetic on uint32_t (all operands/results in [0, P)) ----
+// montgomery reduction of x < P * 2^32:  x * 2^-32 mod P
+ZK_HD constexpr uint32_t monty_reduce(uint64_t x) {
+    uint32_t lo = (uint32_t)x;
+    uint32_t hi = (uint32_t)(x >> 32);
+    uint32_t m = lo * MONTY_MU;
+    uint32_t t = (uint32_t)(((uint64_t)m * P) >> 32);
+    uint32_t r = hi - t;
+    return hi < t ? r + P : r;
+}
+ZK_HD constexpr uint32_t fmul(uint32_t a, uint32_t b) { return monty_reduce((uint64_t)a * b); }
+ZK_HD constexpr uint32_t fadd(uint32_t a, uint32_t b) {
+    uint32_t s = a + b;          // < 2P < 2^32
+    uint32_t t = s - P;          // wraps high when s < P
+    return s < t ? s : t;        // unsigned min
+}
+ZK_HD constexpr uint32_t fsub(uint32_t a, uint32_t b) {
+    uint32_t d = a - b;          // wraps high when a < b
+    uint32_t t = d + P;
+    return d < t ? d : t;
+}
+ZK_HD constexpr uint32_t fneg(uint32_t a) { return a ? P - a : 0u; }
+ZK_HD constexpr uint32_t fdbl(uint32_t a) { return fadd(a, a); }
+ZK_HD constexpr uint32_t to_monty(uint32_t canonical) { return (uint32_t)((((uint64_t)canonical) << 32) % P); }
+ZK_HD constexpr uint32_t from_monty(uint32_t m) { return monty_reduce((uint64_t)m); }
+ZK_HD constexpr uint32_t fpow(uint32_t a, uint64_t e) {
+    uint32_t r = MONTY_R1;
+    while (e) { if (e & 1) r = fmul(r, a); a = fmul(a, a); e >>= 1; }
+    return r;
+}
+ZK_HD constexpr uint32_t finv(uint32_t a) { return fpow(a, (uint64_t)P - 2); }
+// element of order 2^bits, Montgomery form
+ZK_HD constexpr uint32_t two_adic_generator(int bits) {
+    uint32_t g = to_monty(TWO_ADIC_GEN);
+    for (int i = bits; i < TWO_ADICITY; i++) g = fmul(g, g);
+    return g;
+}
+constexpr uint32_t MONTY_GEN = to_monty(GEN);
+constexpr uint32_t MONTY_EXT_W = to_monty(EXT_W);
+constexpr uint32_t MONTY_INV2 = to_monty((P + 1) / 2);
+
+// ---- quartic extension, coefficients in Montgomery form ----
+struct Ext { uint32_t c[4]; };
+
+ZK_HD constexpr Ext ext_zero() { return Ext{{0, 0, 0, 0}}; }
+ZK_HD constexpr Ext ext_one() { return Ext{{MONTY_R1, 0, 0, 0}}; }
+ZK_HD constexpr Ext ext_from_base(uint32_t a) { return Ext{{a, 0, 0, 0}}; }
+ZK_HD constexpr bool ext_eq(const Ext& a, const Ext& b) {
+    return a.c[0] == b.c[0] && a.c[1] == b.c[1] && a.c[2] == b.c[2] && a.c[3] == b.c[3];
+}
+ZK_HD constexpr Ext ext_add(const Ext& a, const Ext& b) {
+    return Ext{{fadd(a.c[0], b.c[0]), fadd(a.c[1], b.c[1]), fadd(a.c[2], b.c[2]), fadd(a.c[3], b.c[3])}};
+}
+ZK_HD constexpr Ext ext_sub(const Ext& a, const Ext& b) {
+    return Ext{{fsub(a.c[0], b.c[0]), fsub(a.c[1], b.c[1]), fsub(a.c[2], b.c[2]), fsub(a.c[3], b.c[3])}};
+}
+ZK_HD constexpr Ext ext_neg(const Ext& a) { return Ext{{fneg(a.c[0]), fneg(a.c[1]), fneg(a.c[2]), fneg(a.c[3])}}; }
+ZK_HD constexpr Ext ext_mul_base(const Ext& a, uint32_t b) {
+    return Ext{{fmul(a.c[0], b), fmul(a.c[1], b), fmul(a.c[2], b), fmul(a.c[3], b)}};
+}
+ZK_HD constexpr Ext ext_add_base(Ext a, uint32_t b) { a.c[0] = fadd(a.c[0], b); return a; }
+ZK_HD constexpr Ext ext_sub_base(Ext a, uint32_t b) { a.c[0] = fsub(a.c[0], b); return a; }
+// (a*b) with x^4 = W: pairs of products are summed in 64 bits and reduced together
+// (2 P^2 < P 2^32), which halves the number of Montgomery reductions.
+ZK_HD constexpr uint32_t mr2(uint32_t a0, uint32_t b0, uint32_t a1, uint32_t b1) {
+    return monty_reduce((uint64_t)a0 * b0 + (uint64_t)a1 * b1);
+}
+ZK_HD constexpr Ext ext_mul(const Ext& a, const Ext& b) {
+    const uint32_t* x = a.c; const uint32_t* y = b.c;
+    // high half  h_k = sum_{i+j = k+4}
+    uint32_t h0 = fadd(mr2(x[1], y[3], x[2], y[2]), fmul(x[3], y[1]));
+    uint32_t h1 = mr2(x[2], y[3], x[3], y[2]);
+    uint32_t h2 = fmul(x[3], y[3]);
+    uint32_t l0 = fmul(x[0], y[0]);
+    uint32_t l1 = mr2(x[0], y[1], x[1], y[0]);
+    uint32_t l2 = fadd(mr2(x[0], y[2], x[1], y[1]), fmul(x[2], y[0]));
+    uint32_t l3 = fadd(mr2(x[0], y[3], x[1], y[2]), mr2(x[2], y[1], x[3], y[0]));
+    return Ext{{fadd(l0, fmul(h0, MONTY_EXT_W)), fadd(l1, fmul(h1, MONTY_EXT_W)),
+                fadd(l2, fmul(h2, MONTY_EXT_W)), l3}};
+}
+ZK_HD constexpr Ext ext_sqr(const Ext& a) { return ext_mul(a, a); }
+ZK_HD constexpr Ext ext_pow(Ext a, uint64_t e) {
+    Ext r = ext_one();
+    while (e) { if (e & 1) r = ext_mul(r, a); a = ext_mul(a, a); e >>= 1; }
+    return r;
+}
+// Frobenius x -> x^p acts on the basis as x^i -> z^i x^i with z = W^((p-1)/4).
+constexpr uint32_t FROB_Z1 = to_monty(1728404513u);           // 11^((p-1)/4)
+constexpr uint32_t FROB_Z2 = fmul(FROB_Z1, FROB_Z1);          // = -1
+constexpr uint32_t FROB_Z3 = fmul(FROB_Z2, FROB_Z1);
+ZK_HD constexpr Ext ext_frobenius(const Ext& a) {
+    return Ext{{a.c[0], fmul(a.c[1], FROB_Z1), fmul(a.c[2], FROB_Z2), fmul(a.c[3], FROB_Z3)}};
+}
+// inverse through the norm to F_p:  a^-1 = a^(r-1) / a^r,  r = 1 + p + p^2 + p^3
+ZK_HD constexpr Ext ext_inv(const Ext& a) {
+    Ext f1 = ext_frobenius(a);
+    Ext f2 = ext_frobenius(f1);
+    Ext f3 = ext_frobenius(f2);
+    Ext conj = ext_mul(ext_mul(f1, f2), f3);
+    // norm = (a * conj) lies in F_p: only coefficient 0 is needed
+    const uint32_t* x = a.c; const uint32_t* y = conj.c;
+    uint32_t h0 = fadd(mr2(x[1], y[3], x[2], y[2]), fmul(x[3], y[1]));
+    uint32_t norm = fadd(fmul(x[0], y[0]), fmul(h0, MONTY_EXT_W));
+    return ext_mul_base(conj, finv(norm));
+}
+
+ZK_HD constexpr uint32_t reverse_bits(uint32_t x, int bits) {
+    uint32_t r = 0;
+    for (int i = 0; i < bits; i++) { r = (r << 1) | (x & 1); x >>= 1; }
+    return r;
+}
+
+}  // namespace zk

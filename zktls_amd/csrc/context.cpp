@@ -1,0 +1,428 @@
+// context.cpp -- zkhip_ctx lifecycle, NTT plan cache and the op-level C ABI entry points
+// (memory helpers, synthetic data, DFT / coset LDE, Poseidon2 Merkle commit).
+// Boundary contract: include/zkhip.h.  No CPU fallback: everything here launches gfx950
+// kernels on the context's stream and fails with ZKHIP_ERR_NO_DEVICE without a device.
+#include "context.h"
+
+#include <cstdio>
+#include <cstring>
+
+namespace zk {
+
+static thread_local std::string g_last_error;
+
+void set_error(const std::string& msg) { g_last_error = msg; }
+int fail(int code, const std::string& msg) { g_last_error = msg; return code; }
+int hip_fail(hipError_t e, const char* what) {
+    g_last_error = std::string("HIP error ") + hipGetErrorName(e) + " (" + hipGetErrorString(e) + ") in " + what;
+    (void)hipGetLastError();
+    return e == hipErrorOutOfMemory ? ZKHIP_ERR_NOMEM : ZKHIP_ERR_HIP;
+}
+
+int ctx_reserve(zkhip_ctx* ctx, int slot, size_t bytes, void** out) {
+    DeviceBuffer& b = ctx->scratch[slot];
+    if (b.bytes < bytes) {
+        if (b.ptr) { ZK_HIP(hipStreamSynchronize(ctx->stream)); ZK_HIP(hipFree(b.ptr)); b.ptr = nullptr; b.bytes = 0; }
+        ZK_HIP(hipMalloc(&b.ptr, bytes));
+        b.bytes = bytes;
+    }
+    *out = b.ptr;
+    return ZKHIP_OK;
+}
+
+// factorisation N = M1 * M2 used by every two-pass transform of this size
+static void split(int log_n, int* m1, int* m2) {
+    if (log_n <= 10) { *m1 = 0; *m2 = log_n; return; }
+    *m2 = (log_n + 1) / 2;
+    *m1 = log_n - *m2;
+}
+
+int get_plan(zkhip_ctx* ctx, int log_n, int kind, uint32_t shift, const NttPlan** out) {
+    for (const NttPlan& p : ctx->plans)
+        if (p.log_n == log_n && p.kind == kind && (kind == 0 || p.shift == shift)) { *out = &p; return ZKHIP_OK; }
+    NttPlan p;
+    p.log_n = log_n; p.kind = kind; p.shift = shift;
+    split(log_n, &p.m1, &p.m2);
+    const size_t n = (size_t)1 << log_n;
+    const uint32_t w = two_adic_generator(log_n);
+    hipStream_t s = ctx->stream;
+    if (kind == 0) {
+        // inverse: post[i1*M2 + k2] = w^-(i1 k2) / N   (single pass: post[k] = 1/N)
+        const uint32_t ninv = finv(to_monty((uint32_t)(n % P)));
+        ZK_HIP(hipMalloc((void**)&p.post, n * 4));
+        if (p.m1 == 0) ZK_HIP(launch_pow_table(p.post, n, MONTY_R1, ninv, s));
+        else ZK_HIP(launch_post_table(p.post, 1u << p.m1, 1u << p.m2, finv(w), MONTY_R1, ninv, s));
+    } else if (kind == 1) {
+        // forward from natural order, coset shift s: x_j * s^j
+        //   two passes: j = i1 + M1 i2; pre[i2] = (s^M1)^i2; post[i1*M2 + k2] = w^(i1 k2) s^i1
+        //   one pass:   pre[j] = s^j
+        if (p.m1 == 0) {
+            if (shift != MONTY_R1) {
+                ZK_HIP(hipMalloc((void**)&p.pre, n * 4));
+                ZK_HIP(launch_pow_table(p.pre, n, shift, MONTY_R1, s));
+            }
+        } else {
+            const uint32_t M1 = 1u << p.m1, M2 = 1u << p.m2;
+            if (shift != MONTY_R1) {
+                ZK_HIP(hipMalloc((void**)&p.pre, (size_t)M2 * 4));
+                ZK_HIP(launch_pow_table(p.pre, M2, fpow(shift, M1), MONTY_R1, s));
+            }
+            ZK_HIP(hipMalloc((void**)&p.post, n * 4));
+            ZK_HIP(launch_post_table(p.post, M1, M2, w, shift, MONTY_R1, s));
+        }
+    } else {
+        // forward from TRANSPOSED coefficients (c[M2 k1 + k2] at row k2*M1 + k1):
+        //   j = i1' + M1' i2' with M1' = M2 (block index), M2' = M1
+        //   pre[i2'] = (s^M1')^i2';  post[i1'*M2' + k2'] = w^(i1' k2') s^i1'
+        if (p.m1 == 0) return fail(ZKHIP_ERR_INTERNAL, "transposed plan needs two passes");
+        const uint32_t M1p = 1u << p.m2, M2p = 1u << p.m1;
+        ZK_HIP(hipMalloc((void**)&p.pre, (size_t)M2p * 4));
+        ZK_HIP(launch_pow_table(p.pre, M2p, fpow(shift, M1p), MONTY_R1, s));
+        ZK_HIP(hipMalloc((void**)&p.post, n * 4));
+        ZK_HIP(launch_post_table(p.post, M1p, M2p, w, shift, MONTY_R1, s));
+    }
+    ctx->plans.push_back(p);
+    *out = &ctx->plans.back();
+    return ZKHIP_OK;
+}
+
+static NttPassArgs base_args(zkhip_ctx* ctx, const uint32_t* in, size_t in_ld, uint32_t* out, size_t out_ld,
+                             uint32_t width, bool inverse) {
+    NttPassArgs a{};
+    a.in = in; a.out = out; a.in_ld = in_ld; a.out_ld = out_ld; a.ncols = width;
+    a.w1024 = inverse ? ctx->w1024_inv : ctx->w1024_fwd;
+    a.map_mode = 1;
+    return a;
+}
+
+// inverse DFT, natural in; coefficients out natural (transposed = false) or in the
+// transposed order c[M2 k1 + k2] -> row k2*M1 + k1 (transposed = true, two-pass sizes)
+static int run_inverse(zkhip_ctx* ctx, const uint32_t* in, size_t in_ld, uint32_t* out, size_t out_ld,
+                       int log_n, uint32_t width, bool transposed) {
+    const NttPlan* p;
+    ZK_TRY(get_plan(ctx, log_n, 0, 0, &p));
+    if (p->m1 == 0) {
+        NttPassArgs a = base_args(ctx, in, in_ld, out, out_ld, width, true);
+        a.num_tiles = 1; a.log_m = log_n; a.in_tile_mul = 0; a.in_stride = 1; a.out_tile_mul = 0; a.out_stride = 1;
+        a.post = p->post;
+        ZK_HIP(launch_ntt_pass(a, true, ctx->stream));
+        return ZKHIP_OK;
+    }
+    const uint64_t M1 = 1ull << p->m1, M2 = 1ull << p->m2;
+    NttPassArgs a = base_args(ctx, in, in_ld, out, out_ld, width, true);
+    a.num_tiles = (uint32_t)M1; a.log_m = p->m2;
+    a.in_tile_mul = 1; a.in_stride = M1; a.out_tile_mul = 1; a.out_stride = M1; a.post = p->post;
+    ZK_HIP(launch_ntt_pass(a, true, ctx->stream));
+    NttPassArgs b = base_args(ctx, out, out_ld, out, out_ld, width, true);
+    b.num_tiles = (uint32_t)M2; b.log_m = p->m1;
+    b.in_tile_mul = M1; b.in_stride = 1;
+    if (transposed) { b.out_tile_mul = M1; b.out_stride = 1; }
+    else { b.out_tile_mul = 1; b.out_stride = M2; }
+    if (!transposed) {
+        // natural output rows interleave across tiles: not in-place safe -> bounce
+        void* tmp;
+        ZK_TRY(ctx_reserve(ctx, 1, ((size_t)1 << log_n) * width * 4, &tmp));
+        b.out = (uint32_t*)tmp; b.out_ld = width;
+        ZK_HIP(launch_ntt_pass(b, true, ctx->stream));
+        ZK_HIP(hipMemcpy2DAsync(out, out_ld * 4, tmp, (size_t)width * 4, (size_t)width * 4, (size_t)1 << log_n,
+                                hipMemcpyDeviceToDevice, ctx->stream));
+        return ZKHIP_OK;
+    }
+    ZK_HIP(launch_ntt_pass(b, true, ctx->stream));
+    return ZKHIP_OK;
+}
+
+// forward coset DFT of natural-order input; output natural or bit-reversed rows
+static int run_forward_natural(zkhip_ctx* ctx, const uint32_t* in, size_t in_ld, uint32_t* out, size_t out_ld,
+                               int log_n, uint32_t width, uint32_t shift, bool bitrev_out) {
+    const NttPlan* p;
+    ZK_TRY(get_plan(ctx, log_n, 1, shift, &p));
+    if (p->m1 == 0) {
+        NttPassArgs a = base_args(ctx, in, in_ld, out, out_ld, width, false);
+        a.num_tiles = 1; a.log_m = log_n; a.in_tile_mul = 0; a.in_stride = 1; a.out_tile_mul = 0; a.out_stride = 1;
+        a.pre = p->pre; a.bitrev_out = bitrev_out ? 1 : 0;
+        ZK_HIP(launch_ntt_pass(a, false, ctx->stream));
+        return ZKHIP_OK;
+    }
+    const uint64_t M1 = 1ull << p->m1, M2 = 1ull << p->m2;
+    // pass 1 goes through a scratch matrix so that `in` is preserved and `out` may be strided
+    void* tmp;
+    ZK_TRY(ctx_reserve(ctx, 1, ((size_t)1 << log_n) * width * 4, &tmp));
+    NttPassArgs a = base_args(ctx, in, in_ld, (uint32_t*)tmp, width, width, false);
+    a.num_tiles = (uint32_t)M1; a.log_m = p->m2;
+    a.in_tile_mul = 1; a.in_stride = M1; a.out_tile_mul = 1; a.out_stride = M1;
+    a.pre = p->pre; a.post = p->post; a.bitrev_out = bitrev_out ? 1 : 0;
+    ZK_HIP(launch_ntt_pass(a, false, ctx->stream));
+    NttPassArgs b = base_args(ctx, (uint32_t*)tmp, width, out, out_ld, width, false);
+    b.num_tiles = (uint32_t)M2; b.log_m = p->m1;
+    b.in_tile_mul = M1; b.in_stride = 1;
+    if (bitrev_out) { b.out_tile_mul = M1; b.out_stride = 1; b.bitrev_out = 1; }
+    else { b.out_tile_mul = 1; b.out_stride = M2; b.bitrev_out = 0; }
+    ZK_HIP(launch_ntt_pass(b, false, ctx->stream));
+    return ZKHIP_OK;
+}
+
+int op_coset_lde(zkhip_ctx* ctx, const uint32_t* in, size_t in_ld, uint32_t* out, size_t out_ld,
+                 int log_n, uint32_t width, int log_blowup, uint32_t shift) {
+    if (log_n < 5 || log_n > 20) return fail(ZKHIP_ERR_INVALID, "coset_lde: log_n must be in [5, 20]");
+    if (log_blowup < 0 || log_blowup > 4 || log_n + log_blowup > TWO_ADICITY) return fail(ZKHIP_ERR_INVALID, "coset_lde: bad log_blowup");
+    if (width == 0 || in_ld < width || out_ld < width) return fail(ZKHIP_ERR_INVALID, "coset_lde: bad width / ld");
+    const size_t n = (size_t)1 << log_n;
+    const int B = 1 << log_blowup;
+    int m1, m2;
+    split(log_n, &m1, &m2);
+    // coefficients into scratch slot 0
+    void* coef_v;
+    ZK_TRY(ctx_reserve(ctx, 0, n * width * 4, &coef_v));
+    uint32_t* coef = (uint32_t*)coef_v;
+    ZK_TRY(run_inverse(ctx, in, in_ld, coef, width, log_n, width, /*transposed=*/m1 != 0));
+    const uint32_t wnb = two_adic_generator(log_n + log_blowup);
+    for (int t = 0; t < B; t++) {
+        const uint32_t st = fmul(shift, fpow(wnb, (uint64_t)t));
+        uint32_t* dst = out + (size_t)reverse_bits((uint32_t)t, log_blowup) * n * out_ld;
+        if (m1 == 0) {
+            const NttPlan* p;
+            ZK_TRY(get_plan(ctx, log_n, 1, st, &p));
+            NttPassArgs a = base_args(ctx, coef, width, dst, out_ld, width, false);
+            a.num_tiles = 1; a.log_m = log_n; a.in_tile_mul = 0; a.in_stride = 1; a.out_tile_mul = 0; a.out_stride = 1;
+            a.pre = p->pre; a.bitrev_out = 1;
+            ZK_HIP(launch_ntt_pass(a, false, ctx->stream));
+            continue;
+        }
+        const NttPlan* p;
+        ZK_TRY(get_plan(ctx, log_n, 2, st, &p));
+        const uint64_t M1p = 1ull << p->m2, M2p = 1ull << p->m1;   // forward factors (swapped)
+        NttPassArgs a = base_args(ctx, coef, width, dst, out_ld, width, false);
+        a.num_tiles = (uint32_t)M1p; a.log_m = p->m1;
+        a.in_tile_mul = M2p; a.in_stride = 1;
+        a.out_tile_mul = 1; a.out_stride = M1p; a.bitrev_out = 1;
+        a.pre = p->pre; a.post = p->post;
+        ZK_HIP(launch_ntt_pass(a, false, ctx->stream));
+        NttPassArgs b = base_args(ctx, dst, out_ld, dst, out_ld, width, false);
+        b.num_tiles = (uint32_t)M2p; b.log_m = p->m2;
+        b.in_tile_mul = M1p; b.in_stride = 1; b.out_tile_mul = M1p; b.out_stride = 1; b.bitrev_out = 1;
+        ZK_HIP(launch_ntt_pass(b, false, ctx->stream));
+    }
+    return ZKHIP_OK;
+}
+
+int op_merkle_commit(zkhip_ctx* ctx, const MatDesc* mats, int nmats, int log_h, uint32_t* tree) {
+    if (nmats < 1 || nmats > MAX_LEAF_MATS) return fail(ZKHIP_ERR_INVALID, "merkle_commit: 1..4 matrices");
+    if (log_h < 0 || log_h > 30) return fail(ZKHIP_ERR_INVALID, "merkle_commit: bad log_h");
+    LeafArgs la{};
+    for (int m = 0; m < nmats; m++) la.mats[m] = mats[m];
+    la.nmats = nmats; la.height = (uint64_t)1 << log_h; la.digests = tree;
+    ZK_HIP(launch_hash_rows(la, ctx->stream));
+    uint32_t* level = tree;
+    uint64_t count = la.height;
+    while (count > 2048) {
+        uint32_t* next = level + 8 * count;
+        ZK_HIP(launch_compress_level(level, next, count / 2, ctx->stream));
+        level = next; count >>= 1;
+    }
+    ZK_HIP(launch_compress_top(level, (uint32_t)count, ctx->stream));
+    return ZKHIP_OK;
+}
+
+}  // namespace zk
+
+using namespace zk;
+
+extern "C" {
+
+int zkhip_version(void) { return ZKHIP_VERSION; }
+const char* zkhip_last_error(void) { return g_last_error.c_str(); }
+
+int zkhip_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) { (void)hipGetLastError(); return 0; }
+    return n;
+}
+
+int zkhip_ctx_create(int device, void* stream, zkhip_ctx** out) {
+    if (!out) return fail(ZKHIP_ERR_INVALID, "ctx_create: out is null");
+    *out = nullptr;
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) {
+        (void)hipGetLastError();
+        return fail(ZKHIP_ERR_NO_DEVICE, "no HIP device visible: libzkhip has no CPU fallback");
+    }
+    if (device < 0 || device >= n) return fail(ZKHIP_ERR_INVALID, "ctx_create: device ordinal out of range");
+    ZK_HIP(hipSetDevice(device));
+    hipDeviceProp_t prop;
+    ZK_HIP(hipGetDeviceProperties(&prop, device));
+    if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+        return fail(ZKHIP_ERR_NO_DEVICE, std::string("device is ") + prop.gcnArchName + ", libzkhip is built for gfx950 only");
+    zkhip_ctx* ctx = new (std::nothrow) zkhip_ctx();
+    if (!ctx) return fail(ZKHIP_ERR_NOMEM, "ctx_create: out of host memory");
+    ctx->device = device;
+    if (stream) { ctx->stream = (hipStream_t)stream; ctx->own_stream = false; }
+    else {
+        hipError_t e = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking);
+        if (e != hipSuccess) { delete ctx; return hip_fail(e, "hipStreamCreate"); }
+        ctx->own_stream = true;
+    }
+    int rc = ZKHIP_OK;
+    do {
+        hipError_t e;
+        if ((e = hipMalloc((void**)&ctx->w1024_fwd, 1024 * 4)) != hipSuccess) { rc = hip_fail(e, "hipMalloc"); break; }
+        if ((e = hipMalloc((void**)&ctx->w1024_inv, 1024 * 4)) != hipSuccess) { rc = hip_fail(e, "hipMalloc"); break; }
+        const uint32_t w = two_adic_generator(10);
+        if ((e = launch_pow_table(ctx->w1024_fwd, 1024, w, MONTY_R1, ctx->stream)) != hipSuccess) { rc = hip_fail(e, "pow_table"); break; }
+        if ((e = launch_pow_table(ctx->w1024_inv, 1024, finv(w), MONTY_R1, ctx->stream)) != hipSuccess) { rc = hip_fail(e, "pow_table"); break; }
+        if ((e = hipStreamSynchronize(ctx->stream)) != hipSuccess) { rc = hip_fail(e, "sync"); break; }
+    } while (0);
+    if (rc != ZKHIP_OK) { zkhip_ctx_destroy(ctx); return rc; }
+    *out = ctx;
+    return ZKHIP_OK;
+}
+
+void zkhip_ctx_destroy(zkhip_ctx* ctx) {
+    if (!ctx) return;
+    (void)hipSetDevice(ctx->device);
+    if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
+    for (NttPlan& p : ctx->plans) { if (p.pre) (void)hipFree(p.pre); if (p.post) (void)hipFree(p.post); }
+    for (DeviceBuffer& b : ctx->scratch) if (b.ptr) (void)hipFree(b.ptr);
+    if (ctx->w1024_fwd) (void)hipFree(ctx->w1024_fwd);
+    if (ctx->w1024_inv) (void)hipFree(ctx->w1024_inv);
+    if (ctx->dom_xs) (void)hipFree(ctx->dom_xs);
+    if (ctx->dom_sel_first) (void)hipFree(ctx->dom_sel_first);
+    if (ctx->dom_itw) (void)hipFree(ctx->dom_itw);
+    if (ctx->own_stream && ctx->stream) (void)hipStreamDestroy(ctx->stream);
+    delete ctx;
+}
+
+#define CHECK_CTX(ctx)                                                  \
+    do {                                                                \
+        if (!(ctx)) return fail(ZKHIP_ERR_INVALID, "null context");     \
+        ZK_HIP(hipSetDevice((ctx)->device));                            \
+    } while (0)
+
+int zkhip_ctx_sync(zkhip_ctx* ctx) { CHECK_CTX(ctx); ZK_HIP(hipStreamSynchronize(ctx->stream)); return ZKHIP_OK; }
+void* zkhip_ctx_stream(zkhip_ctx* ctx) { return ctx ? (void*)ctx->stream : nullptr; }
+
+int zkhip_malloc(zkhip_ctx* ctx, size_t bytes, void** d_ptr) {
+    CHECK_CTX(ctx);
+    if (!d_ptr) return fail(ZKHIP_ERR_INVALID, "malloc: null out pointer");
+    ZK_HIP(hipMalloc(d_ptr, bytes ? bytes : 4));
+    return ZKHIP_OK;
+}
+int zkhip_free(zkhip_ctx* ctx, void* d_ptr) {
+    CHECK_CTX(ctx);
+    ZK_HIP(hipStreamSynchronize(ctx->stream));
+    if (d_ptr) ZK_HIP(hipFree(d_ptr));
+    return ZKHIP_OK;
+}
+int zkhip_memcpy_h2d(zkhip_ctx* ctx, void* d_dst, const void* h_src, size_t bytes) {
+    CHECK_CTX(ctx);
+    ZK_HIP(hipMemcpyAsync(d_dst, h_src, bytes, hipMemcpyHostToDevice, ctx->stream));
+    ZK_HIP(hipStreamSynchronize(ctx->stream));
+    return ZKHIP_OK;
+}
+int zkhip_memcpy_d2h(zkhip_ctx* ctx, void* h_dst, const void* d_src, size_t bytes) {
+    CHECK_CTX(ctx);
+    ZK_HIP(hipMemcpyAsync(h_dst, d_src, bytes, hipMemcpyDeviceToHost, ctx->stream));
+    ZK_HIP(hipStreamSynchronize(ctx->stream));
+    return ZKHIP_OK;
+}
+int zkhip_to_monty(zkhip_ctx* ctx, const uint32_t* d_in, uint32_t* d_out, size_t n) {
+    CHECK_CTX(ctx);
+    ZK_HIP(launch_convert(d_in, d_out, n, true, ctx->stream));
+    return ZKHIP_OK;
+}
+int zkhip_from_monty(zkhip_ctx* ctx, const uint32_t* d_in, uint32_t* d_out, size_t n) {
+    CHECK_CTX(ctx);
+    ZK_HIP(launch_convert(d_in, d_out, n, false, ctx->stream));
+    return ZKHIP_OK;
+}
+
+int zkhip_fill_uniform(zkhip_ctx* ctx, uint64_t seed, int log_n, uint32_t width, uint32_t* d_out, size_t ld) {
+    CHECK_CTX(ctx);
+    if (log_n < 0 || log_n > 30 || width == 0 || ld < width || !d_out) return fail(ZKHIP_ERR_INVALID, "fill_uniform: bad arguments");
+    ZK_HIP(launch_fill_uniform(d_out, ld, seed, (uint64_t)1 << log_n, width, ctx->stream));
+    return ZKHIP_OK;
+}
+int zkhip_gen_trace(zkhip_ctx* ctx, uint64_t seed, uint64_t shard, int log_n, uint32_t width, uint32_t* d_out, size_t ld) {
+    CHECK_CTX(ctx);
+    if (log_n < 0 || log_n > 30 || width == 0 || width % 4 != 0 || ld < width || !d_out)
+        return fail(ZKHIP_ERR_INVALID, "gen_trace: width must be a positive multiple of 4");
+    ZK_HIP(launch_gen_trace(d_out, ld, seed + shard, (uint64_t)1 << log_n, width, ctx->stream));
+    return ZKHIP_OK;
+}
+
+int zkhip_dft(zkhip_ctx* ctx, const uint32_t* d_in, size_t in_ld, uint32_t* d_out, size_t out_ld,
+              int log_n, uint32_t width, int inverse, int bitrev_out) {
+    CHECK_CTX(ctx);
+    if (log_n < 5 || log_n > 20) return fail(ZKHIP_ERR_INVALID, "dft: log_n must be in [5, 20]");
+    if (!d_in || !d_out || width == 0 || in_ld < width || out_ld < width) return fail(ZKHIP_ERR_INVALID, "dft: bad arguments");
+    if (inverse) {
+        if (bitrev_out) return fail(ZKHIP_ERR_INVALID, "dft: inverse transform writes natural order only");
+        return run_inverse(ctx, d_in, in_ld, d_out, out_ld, log_n, width, false);
+    }
+    return run_forward_natural(ctx, d_in, in_ld, d_out, out_ld, log_n, width, MONTY_R1, bitrev_out != 0);
+}
+
+int zkhip_coset_lde(zkhip_ctx* ctx, const uint32_t* d_in, size_t in_ld, uint32_t* d_out, size_t out_ld,
+                    int log_n, uint32_t width, int log_blowup, uint32_t shift) {
+    CHECK_CTX(ctx);
+    if (!d_in || !d_out) return fail(ZKHIP_ERR_INVALID, "coset_lde: null pointer");
+    if (shift == 0 || shift >= P) return fail(ZKHIP_ERR_INVALID, "coset_lde: shift must be a canonical non-zero element");
+    return op_coset_lde(ctx, d_in, in_ld, d_out, out_ld, log_n, width, log_blowup, to_monty(shift));
+}
+
+int zkhip_ntt_pass(zkhip_ctx* ctx, const uint32_t* d_in, uint32_t* d_out, size_t ld, int log_n, uint32_t width, int which) {
+    CHECK_CTX(ctx);
+    if (log_n < 11 || log_n > 20) return fail(ZKHIP_ERR_INVALID, "ntt_pass: log_n must be in [11, 20]");
+    if (!d_in || !d_out || width == 0 || ld < width) return fail(ZKHIP_ERR_INVALID, "ntt_pass: bad arguments");
+    const NttPlan* p;
+    ZK_TRY(get_plan(ctx, log_n, 1, MONTY_R1, &p));
+    const uint64_t M1 = 1ull << p->m1, M2 = 1ull << p->m2;
+    NttPassArgs a = base_args(ctx, d_in, ld, d_out, ld, width, false);
+    if (which == 0) {
+        a.num_tiles = (uint32_t)M1; a.log_m = p->m2;
+        a.in_tile_mul = 1; a.in_stride = M1; a.out_tile_mul = 1; a.out_stride = M1; a.post = p->post; a.bitrev_out = 1;
+    } else {
+        a.num_tiles = (uint32_t)M2; a.log_m = p->m1;
+        a.in_tile_mul = M1; a.in_stride = 1; a.out_tile_mul = M1; a.out_stride = 1; a.bitrev_out = 1;
+    }
+    ZK_HIP(launch_ntt_pass(a, false, ctx->stream));
+    return ZKHIP_OK;
+}
+
+int zkhip_poseidon2_permute(zkhip_ctx* ctx, uint32_t* d_states, size_t count) {
+    CHECK_CTX(ctx);
+    if (!d_states && count) return fail(ZKHIP_ERR_INVALID, "poseidon2_permute: null pointer");
+    ZK_HIP(launch_permute_states(d_states, count, ctx->stream));
+    return ZKHIP_OK;
+}
+
+static int make_descs(const uint32_t* const* d_mats, const size_t* lds, const uint32_t* widths, int nmats, MatDesc* out) {
+    if (nmats < 1 || nmats > MAX_LEAF_MATS || !d_mats || !lds || !widths) return fail(ZKHIP_ERR_INVALID, "1..4 matrices required");
+    for (int m = 0; m < nmats; m++) {
+        if (!d_mats[m] || lds[m] < widths[m]) return fail(ZKHIP_ERR_INVALID, "bad matrix descriptor");
+        out[m].ptr = d_mats[m]; out[m].ld = lds[m]; out[m].width = widths[m];
+    }
+    return ZKHIP_OK;
+}
+
+int zkhip_hash_rows(zkhip_ctx* ctx, const uint32_t* const* d_mats, const size_t* lds, const uint32_t* widths,
+                    int nmats, size_t height, uint32_t* d_digests) {
+    CHECK_CTX(ctx);
+    LeafArgs la{};
+    ZK_TRY(make_descs(d_mats, lds, widths, nmats, la.mats));
+    if (!d_digests) return fail(ZKHIP_ERR_INVALID, "hash_rows: null output");
+    la.nmats = nmats; la.height = height; la.digests = d_digests;
+    ZK_HIP(launch_hash_rows(la, ctx->stream));
+    return ZKHIP_OK;
+}
+
+int zkhip_merkle_commit(zkhip_ctx* ctx, const uint32_t* const* d_mats, const size_t* lds, const uint32_t* widths,
+                        int nmats, int log_h, uint32_t* d_tree) {
+    CHECK_CTX(ctx);
+    MatDesc descs[MAX_LEAF_MATS];
+    ZK_TRY(make_descs(d_mats, lds, widths, nmats, descs));
+    if (!d_tree) return fail(ZKHIP_ERR_INVALID, "merkle_commit: null output");
+    return op_merkle_commit(ctx, descs, nmats, log_h, d_tree);
+}
+
+}  // extern "C"

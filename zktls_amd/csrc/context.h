@@ -1,0 +1,71 @@
+// context.h -- internal definition of zkhip_ctx (host side of libzkhip).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <deque>
+#include <new>
+#include <string>
+#include <vector>
+
+#include "../../include/zkhip.h"
+#include "babybear.cuh"
+#include "kernels.h"
+
+namespace zk {
+
+void set_error(const std::string& msg);
+int fail(int code, const std::string& msg);
+int hip_fail(hipError_t e, const char* what);
+
+#define ZK_HIP(call)                                            \
+    do {                                                        \
+        hipError_t _e = (call);                                 \
+        if (_e != hipSuccess) return zk::hip_fail(_e, #call);   \
+    } while (0)
+#define ZK_TRY(call)                 \
+    do {                             \
+        int _r = (call);             \
+        if (_r != ZKHIP_OK) return _r; \
+    } while (0)
+
+// twiddle tables of one transform size / shift, built on first use and cached
+struct NttPlan {
+    int log_n = 0;
+    int kind = 0;            // 0 inverse, 1 forward from natural order, 2 forward from transposed coefficients
+    uint32_t shift = 0;      // Montgomery; coset shift (kinds 1, 2)
+    int m1 = 0, m2 = 0;      // log sizes of the two factors (m1 = 0: single pass)
+    uint32_t* pre = nullptr;   // device
+    uint32_t* post = nullptr;  // device
+};
+
+struct DeviceBuffer {
+    void* ptr = nullptr;
+    size_t bytes = 0;
+};
+
+}  // namespace zk
+
+struct zkhip_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    bool own_stream = false;
+    uint32_t* w1024_fwd = nullptr;
+    uint32_t* w1024_inv = nullptr;
+    std::deque<zk::NttPlan> plans;   // deque: references stay valid on push_back
+    zk::DeviceBuffer scratch[8];       // grow-only workspaces, indexed by role
+    zkhip_prove_debug debug{};
+    // domain tables of the last proved size (prover.cpp)
+    int dom_log_n = -1;
+    uint32_t* dom_xs = nullptr;        // x_p = g * w_2N^bitrev(p), p < 2N
+    uint32_t* dom_sel_first = nullptr; // Z_H(x_p) / (x_p - 1)
+    uint32_t* dom_itw = nullptr;       // w_2N^-bitrev_n(i) / 2, i < N (FRI fold)
+};
+
+namespace zk {
+int ctx_reserve(zkhip_ctx* ctx, int slot, size_t bytes, void** out);
+int get_plan(zkhip_ctx* ctx, int log_n, int kind, uint32_t shift_monty, const NttPlan** out);
+// internal op entry points shared by capi.cpp and prover.cpp (device pointers, ctx stream)
+int op_coset_lde(zkhip_ctx* ctx, const uint32_t* d_in, size_t in_ld, uint32_t* d_out, size_t out_ld,
+                 int log_n, uint32_t width, int log_blowup, uint32_t shift_monty);
+int op_merkle_commit(zkhip_ctx* ctx, const MatDesc* mats, int nmats, int log_h, uint32_t* d_tree);
+}  // namespace zk

@@ -1,0 +1,233 @@
+// ntt.hip -- batched radix-2 NTT passes over the columns of a row-major BabyBear matrix,
+// hand-written for gfx950 (wave64, 160 KiB LDS/CU).
+//
+// Replaces p3-dft 0.2.1-succinct Radix2DitParallel::{dft_batch, coset_lde_batch}
+// (reference Cargo.lock:3903) on the path below crates/guest-prover-sp1/src/sp1.rs:116.
+//
+// Design.  A column transform of N = M1*M2 points runs as two
+// launches of this one kernel (four-step factorisation); a launch moves every element
+// HBM -> registers -> HBM exactly once (8 B/element algorithmic traffic).  A workgroup
+// owns a tile of M = 32*P rows x C columns (P = 2^b threads per column, b <= 5):
+//   load      thread (u, c) pulls x[u + P*n1], n1 = 0..31 straight into 32 VGPRs; the
+//             64 lanes of a wave cover 4 consecutive tile rows x 16 columns (4 x 64 B);
+//   phase A   32-point DIF in registers, twiddles are instruction literals;
+//   twiddle   * w_M^(u*k1), table staged in LDS (broadcast reads);
+//   exchange  one pass through LDS, row pitch (P+1)*C words -> conflict-free both ways;
+//   phase B   the last b stages of the same 32-point network = P-point DIFs;
+//   store     * post[tile][k] (inter-pass twiddle / coset shift / 1/N, staged in LDS),
+//             written natural or bit-reversed inside the tile.
+// No MFMA: a 31-bit modular butterfly is not a dense contraction.
+#include "babybear.cuh"
+#include "kernels.h"
+
+namespace zk {
+
+struct Tw32 { uint32_t w[16]; };
+constexpr Tw32 make_tw32(bool inv) {
+    Tw32 t{};
+    uint32_t g = two_adic_generator(5);
+    if (inv) g = finv(g);
+    uint32_t x = MONTY_R1;
+    for (int j = 0; j < 16; j++) { t.w[j] = x; x = fmul(x, g); }
+    return t;
+}
+constexpr Tw32 TW32_FWD = make_tw32(false);
+constexpr Tw32 TW32_INV = make_tw32(true);
+
+constexpr int rev5(int r) {
+    return ((r & 1) << 4) | ((r & 2) << 2) | (r & 4) | ((r & 8) >> 2) | ((r & 16) >> 4);
+}
+
+// stage S of the 32-point decimation-in-frequency network (S = 0 pairs i, i+16)
+template <bool INV, int S>
+ZK_D void dif_stage(uint32_t (&x)[32]) {
+    constexpr int half = 16 >> S;
+    constexpr int stride = 16 / half;
+#pragma unroll
+    for (int base = 0; base < 32; base += 2 * half) {
+#pragma unroll
+        for (int j = 0; j < half; j++) {
+            uint32_t a = x[base + j], b = x[base + j + half];
+            x[base + j] = fadd(a, b);
+            uint32_t d = fsub(a, b);
+            x[base + j + half] = (j == 0) ? d : fmul(d, (INV ? TW32_INV : TW32_FWD).w[j * stride]);
+        }
+    }
+}
+
+template <int LOG_C, bool INV>
+__global__ void __launch_bounds__(32 << LOG_C) ntt_pass_kernel(NttPassArgs a) {
+    extern __shared__ uint32_t lds[];
+    constexpr int C = 1 << LOG_C;
+    const int b = (int)a.log_m - 5;
+    const int Pn = 1 << b;
+    const int M = 32 << b;
+    const int pitch = (Pn + 1) * C;
+    uint32_t* sdata = lds;
+    uint32_t* stw = lds + 32 * pitch;
+    uint32_t* spost = stw + M;
+    uint32_t* spre = spost + M;
+
+    const int tid = threadIdx.x;
+    const int c = tid & (C - 1);
+    const int u = tid >> LOG_C;
+
+    const uint32_t ncg = (a.ncols + C - 1) >> LOG_C;
+    uint32_t tile, cg;
+    if (a.map_mode == 1) {
+        // blocks b and b+8 share an XCD (round-robin dispatch): keep the column groups
+        // of one tile on one XCD so that they share L2 lines and DRAM pages
+        const uint32_t xcd = blockIdx.x & 7u, l = blockIdx.x >> 3;
+        cg = l % ncg;
+        tile = (l / ncg) * 8u + xcd;
+    } else {
+        cg = blockIdx.x % ncg;
+        tile = blockIdx.x / ncg;
+    }
+    const uint32_t col = cg * C + c;
+    const bool active = col < a.ncols;
+
+    // ---- global -> registers (32 independent loads in flight per lane)
+    uint32_t x[32];
+    {
+        const uint32_t* ip = a.in + ((uint64_t)tile * a.in_tile_mul + (uint64_t)u * a.in_stride) * a.in_ld + col;
+        const uint64_t istep = (uint64_t)Pn * a.in_stride * a.in_ld;
+#pragma unroll
+        for (int n1 = 0; n1 < 32; n1++) x[n1] = active ? ip[(uint64_t)n1 * istep] : 0u;
+    }
+    // ---- twiddle tables -> LDS while the loads fly
+    {
+        const int sh = 5 - b;
+        const bool has_post = a.post != nullptr, has_pre = a.pre != nullptr;
+        for (int i = tid; i < M; i += blockDim.x) {
+            stw[i] = a.w1024[i << sh];
+            if (has_post) spost[i] = a.post[(uint64_t)tile * M + i];
+            if (has_pre) spre[i] = a.pre[i];
+        }
+    }
+    __syncthreads();
+    if (a.pre != nullptr) {
+#pragma unroll
+        for (int n1 = 0; n1 < 32; n1++) x[n1] = fmul(x[n1], spre[u + Pn * n1]);
+    }
+
+    // ---- phase A: 32-point DIF over n1; x[r] <- A[rev5(r)]
+    dif_stage<INV, 0>(x);
+    dif_stage<INV, 1>(x);
+    dif_stage<INV, 2>(x);
+    dif_stage<INV, 3>(x);
+    dif_stage<INV, 4>(x);
+
+    // ---- tile twiddle w_M^(u*k1), exchange through LDS
+    {
+        uint32_t* wp = sdata + u * C + c;
+#pragma unroll
+        for (int r = 0; r < 32; r++) {
+            constexpr int dummy = 0; (void)dummy;
+            const int k1 = rev5(r);
+            uint32_t v = (k1 == 0) ? x[r] : fmul(x[r], stw[u * k1]);
+            wp[k1 * pitch] = v;
+        }
+    }
+    __syncthreads();
+    {
+        const uint32_t* rp = sdata + c;
+#pragma unroll
+        for (int rho = 0; rho < 32; rho++) {
+            const int t = rho & (Pn - 1);
+            const int k1 = (rho & ~(Pn - 1)) + u;
+            x[rho] = rp[k1 * pitch + t * C];
+        }
+    }
+
+    // ---- phase B: P-point DIFs = the last b stages of the 32-point network
+    if (b >= 5) dif_stage<INV, 0>(x);
+    if (b >= 4) dif_stage<INV, 1>(x);
+    if (b >= 3) dif_stage<INV, 2>(x);
+    if (b >= 2) dif_stage<INV, 3>(x);
+    if (b >= 1) dif_stage<INV, 4>(x);
+
+    // ---- post multiply and store
+    {
+        const bool has_post = a.post != nullptr;
+        const int m = (int)a.log_m;
+        uint32_t* op = a.out + (uint64_t)tile * a.out_tile_mul * a.out_ld + col;
+        const uint64_t ostep = a.out_stride * a.out_ld;
+#pragma unroll
+        for (int rho = 0; rho < 32; rho++) {
+            const uint32_t t = rho & (Pn - 1);
+            const uint32_t k1 = (rho & ~(Pn - 1)) + u;
+            const uint32_t k0 = b ? (__brev(t) >> (32 - b)) : 0u;
+            const uint32_t k = 32u * k0 + k1;
+            uint32_t v = x[rho];
+            if (has_post) v = fmul(v, spost[k]);
+            const uint32_t o = a.bitrev_out ? (__brev(k) >> (32 - m)) : k;
+            if (active) op[(uint64_t)o * ostep] = v;
+        }
+    }
+}
+
+static size_t ntt_lds_bytes(int log_m, int log_c) {
+    int b = log_m - 5, Pn = 1 << b, M = 32 << b, C = 1 << log_c;
+    return (size_t)(32 * (Pn + 1) * C + 3 * M) * sizeof(uint32_t);
+}
+
+template <int LOG_C>
+static hipError_t launch_ntt_c(const NttPassArgs& a, bool inverse, hipStream_t s) {
+    const int C = 1 << LOG_C;
+    const uint32_t ncg = (a.ncols + C - 1) / C;
+    const int b = (int)a.log_m - 5;
+    dim3 grid(a.num_tiles * ncg), block((1 << b) * C);
+    size_t lds = ntt_lds_bytes((int)a.log_m, LOG_C);
+    if (inverse) {
+        hipError_t e = hipFuncSetAttribute((const void*)ntt_pass_kernel<LOG_C, true>,
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+        hipLaunchKernelGGL((ntt_pass_kernel<LOG_C, true>), grid, block, lds, s, a);
+    } else {
+        hipError_t e = hipFuncSetAttribute((const void*)ntt_pass_kernel<LOG_C, false>,
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+        hipLaunchKernelGGL((ntt_pass_kernel<LOG_C, false>), grid, block, lds, s, a);
+    }
+    return hipGetLastError();
+}
+
+hipError_t launch_ntt_pass(const NttPassArgs& a_, bool inverse, hipStream_t s) {
+    NttPassArgs a = a_;
+    if (a.log_m < 5 || a.log_m > 10) return hipErrorInvalidValue;
+    if (a.map_mode == 1 && (a.num_tiles % 8u) != 0) a.map_mode = 0;
+    // narrow matrices use narrower tiles so that lanes are not wasted on masked columns
+    if (a.ncols <= 4) return launch_ntt_c<2>(a, inverse, s);
+    if (a.ncols <= 8) return launch_ntt_c<3>(a, inverse, s);
+    return launch_ntt_c<4>(a, inverse, s);
+}
+
+// ------------------------------------------------------------------ table generators
+__global__ void pow_table_kernel(uint32_t* out, size_t n, uint32_t base, uint32_t scale) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = fmul(scale, fpow(base, i));
+}
+hipError_t launch_pow_table(uint32_t* out, size_t n, uint32_t base, uint32_t scale, hipStream_t s) {
+    if (n == 0) return hipSuccess;
+    hipLaunchKernelGGL(pow_table_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, out, n, base, scale);
+    return hipGetLastError();
+}
+
+__global__ void post_table_kernel(uint32_t* out, uint32_t rows, uint32_t cols, uint32_t omega,
+                                  uint32_t shift, uint32_t scale) {
+    size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (size_t)rows * cols) return;
+    uint32_t i = (uint32_t)(idx / cols), k = (uint32_t)(idx % cols);
+    uint32_t v = fmul(fpow(omega, (uint64_t)i * k), fpow(shift, i));
+    out[idx] = fmul(v, scale);
+}
+hipError_t launch_post_table(uint32_t* out, uint32_t rows, uint32_t cols, uint32_t omega,
+                             uint32_t shift, uint32_t scale, hipStream_t s) {
+    size_t n = (size_t)rows * cols;
+    if (n == 0) return hipSuccess;
+    hipLaunchKernelGGL(post_table_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, out, rows, cols, omega, shift, scale);
+    return hipGetLastError();
+}
+
+}  // namespace zk

@@ -1,0 +1,86 @@
+// util.hip -- synthetic shard generation on the device and form conversion.
+//
+// The synthetic workload is the one SURVEY.md section 8(d) / BASELINE.md fix for the
+// benchmark ("synthetic 2^20-row shards"): the reference's real trace comes from
+// executing the zkTLS guest ELF inside sp1-core-executor, which is out of scope and
+// unobtainable offline (crates/guest-prover-sp1/src/sp1.rs:113,116 are the call sites).
+// Values are a counter-based splitmix64 stream reduced mod p, written in Montgomery form.
+#include "babybear.cuh"
+#include "kernels.h"
+
+namespace zk {
+
+__device__ __forceinline__ uint64_t mix64(uint64_t z) {
+    z += 0x9E3779B97F4A7C15ull;
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    return z ^ (z >> 31);
+}
+// canonical value: the (index+1)-th splitmix64 output for `seed`, mod p
+__device__ __forceinline__ uint32_t synth_value(uint64_t seed, uint64_t index) {
+    return (uint32_t)(mix64(seed + index * 0x9E3779B97F4A7C15ull) % P);
+}
+
+__global__ void fill_uniform_kernel(uint32_t* out, uint64_t ld, uint64_t seed, uint64_t rows, uint32_t width) {
+    const uint64_t total = rows * width;
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+         i += (uint64_t)gridDim.x * blockDim.x) {
+        uint64_t r = i / width, c = i % width;
+        out[r * ld + c] = to_monty(synth_value(seed, i));
+    }
+}
+hipError_t launch_fill_uniform(uint32_t* out, uint64_t ld, uint64_t seed, uint64_t rows, uint32_t width, hipStream_t s) {
+    if (rows == 0 || width == 0) return hipSuccess;
+    uint64_t total = rows * width;
+    unsigned blocks = (unsigned)((total + 255) / 256 < 16384 ? (total + 255) / 256 : 16384);
+    hipLaunchKernelGGL(fill_uniform_kernel, dim3(blocks), dim3(256), 0, s, out, ld, seed, rows, width);
+    return hipGetLastError();
+}
+
+// synthetic AIR trace: group g = columns 4g..4g+3 = (a, b, c, d)
+//   a, b uniform;  c = a*a*b + (g+1);  d[0] = 5g+7;  d[i] = a[i-1]*b[i-1] + c[i-1] + (2g+3)
+__global__ void gen_trace_kernel(uint32_t* out, uint64_t ld, uint64_t seed, uint64_t rows, uint32_t width) {
+    const uint32_t G = width / 4;
+    const uint64_t total = rows * G;
+    for (uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; t < total;
+         t += (uint64_t)gridDim.x * blockDim.x) {
+        const uint64_t i = t / G;
+        const uint32_t g = (uint32_t)(t % G);
+        const uint32_t k1 = to_monty((g + 1) % P), k2 = to_monty((2 * g + 3) % P);
+        uint32_t a = to_monty(synth_value(seed, i * width + 4 * g));
+        uint32_t b = to_monty(synth_value(seed, i * width + 4 * g + 1));
+        uint32_t c = fadd(fmul(fmul(a, a), b), k1);
+        uint32_t d;
+        if (i == 0) d = to_monty((5 * g + 7) % P);
+        else {
+            uint32_t pa = to_monty(synth_value(seed, (i - 1) * width + 4 * g));
+            uint32_t pb = to_monty(synth_value(seed, (i - 1) * width + 4 * g + 1));
+            uint32_t pc = fadd(fmul(fmul(pa, pa), pb), k1);
+            d = fadd(fadd(fmul(pa, pb), pc), k2);
+        }
+        uint4 v = make_uint4(a, b, c, d);
+        uint32_t* p = out + i * ld + 4 * g;
+        if ((ld & 3) == 0 && (reinterpret_cast<uintptr_t>(out) & 15) == 0) *reinterpret_cast<uint4*>(p) = v;
+        else { p[0] = a; p[1] = b; p[2] = c; p[3] = d; }
+    }
+}
+hipError_t launch_gen_trace(uint32_t* out, uint64_t ld, uint64_t seed, uint64_t rows, uint32_t width, hipStream_t s) {
+    if (rows == 0 || width < 4) return hipSuccess;
+    uint64_t total = rows * (width / 4);
+    unsigned blocks = (unsigned)((total + 255) / 256 < 16384 ? (total + 255) / 256 : 16384);
+    hipLaunchKernelGGL(gen_trace_kernel, dim3(blocks), dim3(256), 0, s, out, ld, seed, rows, width);
+    return hipGetLastError();
+}
+
+__global__ void convert_kernel(const uint32_t* in, uint32_t* out, uint64_t n, bool to_m) {
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x)
+        out[i] = to_m ? fmul(in[i], MONTY_R2) : from_monty(in[i]);
+}
+hipError_t launch_convert(const uint32_t* in, uint32_t* out, uint64_t n, bool to_monty_form, hipStream_t s) {
+    if (n == 0) return hipSuccess;
+    unsigned blocks = (unsigned)((n + 255) / 256 < 16384 ? (n + 255) / 256 : 16384);
+    hipLaunchKernelGGL(convert_kernel, dim3(blocks), dim3(256), 0, s, in, out, n, to_monty_form);
+    return hipGetLastError();
+}
+
+}  // namespace zk

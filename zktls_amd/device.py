@@ -1,0 +1,199 @@
+"""Thin object layer over the C ABI: a context bound to one GPU + stream, and device
+buffers.  Used by the tests, bench.py and the host-side prover mirror (prover.py).
+All numpy arrays crossing this layer are CANONICAL residues unless a name says monty.
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+from ._lib import Params, ProveDebug, check, from_monty, to_monty, u32p, u8p
+
+
+class DeviceBuffer:
+    """A device allocation of uint32 words owned by a Context (or wrapping a torch tensor)."""
+
+    def __init__(self, ctx, nwords, ptr=None, owner=None):
+        self.ctx = ctx
+        self.nwords = int(nwords)
+        self._owned = ptr is None
+        self._owner = owner
+        if ptr is None:
+            p = C.c_void_p()
+            check(ctx.lib.zkhip_malloc(ctx.handle, C.c_size_t(self.nwords * 4), C.byref(p)))
+            ptr = p.value
+        self.ptr = ptr
+
+    def offset(self, words):
+        return C.c_void_p(self.ptr + 4 * int(words))
+
+    def upload_monty(self, arr):
+        arr = np.ascontiguousarray(arr, dtype=np.uint32)
+        assert arr.size <= self.nwords
+        check(self.ctx.lib.zkhip_memcpy_h2d(self.ctx.handle, C.c_void_p(self.ptr), arr.ctypes.data_as(C.c_void_p), C.c_size_t(arr.size * 4)))
+
+    def upload(self, canonical):
+        self.upload_monty(to_monty(canonical))
+
+    def download_monty(self, nwords=None, offset=0):
+        n = self.nwords - offset if nwords is None else int(nwords)
+        out = np.empty(n, dtype=np.uint32)
+        check(self.ctx.lib.zkhip_memcpy_d2h(self.ctx.handle, out.ctypes.data_as(C.c_void_p), self.offset(offset), C.c_size_t(n * 4)))
+        return out
+
+    def download(self, nwords=None, offset=0):
+        return from_monty(self.download_monty(nwords, offset))
+
+    def free(self):
+        if self._owned and self.ptr:
+            self.ctx.lib.zkhip_free(self.ctx.handle, C.c_void_p(self.ptr))
+            self.ptr = None
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
+
+class Context:
+    def __init__(self, device=0, stream=None):
+        self.lib = _lib.load()
+        h = C.c_void_p()
+        check(self.lib.zkhip_ctx_create(int(device), C.c_void_p(stream) if stream else None, C.byref(h)))
+        self.handle = h
+        self.device = device
+
+    def close(self):
+        if self.handle:
+            self.lib.zkhip_ctx_destroy(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def sync(self):
+        check(self.lib.zkhip_ctx_sync(self.handle))
+
+    @property
+    def stream(self):
+        return self.lib.zkhip_ctx_stream(self.handle)
+
+    def alloc(self, nwords):
+        return DeviceBuffer(self, nwords)
+
+    def wrap(self, tensor):
+        """wrap a torch CUDA tensor (int32/uint32 storage) without copying"""
+        return DeviceBuffer(self, tensor.numel(), ptr=tensor.data_ptr(), owner=tensor)
+
+    def from_numpy(self, canonical):
+        a = np.ascontiguousarray(canonical, dtype=np.uint32)
+        buf = self.alloc(a.size)
+        buf.upload(a)
+        return buf
+
+    # ---- synthetic data
+    def fill_uniform(self, seed, log_n, width, out=None):
+        out = out or self.alloc(width << log_n)
+        check(self.lib.zkhip_fill_uniform(self.handle, seed, log_n, width, C.c_void_p(out.ptr), width))
+        return out
+
+    def gen_trace(self, seed, shard, log_n, width, out=None):
+        out = out or self.alloc(width << log_n)
+        check(self.lib.zkhip_gen_trace(self.handle, seed, shard, log_n, width, C.c_void_p(out.ptr), width))
+        return out
+
+    # ---- NTT / LDE
+    def dft(self, src, log_n, width, inverse=False, bitrev_out=False, out=None):
+        out = out or self.alloc(width << log_n)
+        check(self.lib.zkhip_dft(self.handle, C.c_void_p(src.ptr), width, C.c_void_p(out.ptr), width, log_n, width,
+                                 int(inverse), int(bitrev_out)))
+        return out
+
+    def coset_lde(self, src, log_n, width, log_blowup=1, shift=31, out=None, in_ld=None, out_ld=None, out_col=0):
+        out_ld = out_ld or width
+        in_ld = in_ld or width
+        out = out or self.alloc(out_ld << (log_n + log_blowup))
+        check(self.lib.zkhip_coset_lde(self.handle, C.c_void_p(src.ptr), in_ld, out.offset(out_col), out_ld,
+                                       log_n, width, log_blowup, shift))
+        return out
+
+    def ntt_pass(self, src, dst, log_n, width, which):
+        check(self.lib.zkhip_ntt_pass(self.handle, C.c_void_p(src.ptr), C.c_void_p(dst.ptr), width, log_n, width, which))
+
+    # ---- Poseidon2 / Merkle
+    def poseidon2_permute(self, states):
+        check(self.lib.zkhip_poseidon2_permute(self.handle, C.c_void_p(states.ptr), states.nwords // 16))
+
+    def _mat_args(self, mats):
+        n = len(mats)
+        ptrs = (C.c_void_p * n)(*[m[0].ptr for m in mats])
+        lds = (C.c_size_t * n)(*[m[1] for m in mats])
+        ws = (C.c_uint32 * n)(*[m[1] for m in mats])
+        return ptrs, lds, ws
+
+    def hash_rows(self, mats, height, out=None):
+        """mats: list of (DeviceBuffer, width) with contiguous rows"""
+        out = out or self.alloc(8 * height)
+        ptrs, lds, ws = self._mat_args(mats)
+        check(self.lib.zkhip_hash_rows(self.handle, ptrs, lds, ws, len(mats), height, C.c_void_p(out.ptr)))
+        return out
+
+    def merkle_commit(self, mats, log_h, out=None):
+        out = out or self.alloc(8 * ((2 << log_h) - 1))
+        ptrs, lds, ws = self._mat_args(mats)
+        check(self.lib.zkhip_merkle_commit(self.handle, ptrs, lds, ws, len(mats), log_h, C.c_void_p(out.ptr)))
+        return out
+
+    # ---- STARK stages
+    def quotient_values(self, lde, log_n, width, alpha, out=None):
+        out = out or self.alloc(4 << (log_n + 1))
+        a = to_monty(np.asarray(alpha, dtype=np.uint32))
+        check(self.lib.zkhip_quotient_values(self.handle, C.c_void_p(lde.ptr), width, log_n, width,
+                                             a.ctypes.data_as(u32p), C.c_void_p(out.ptr)))
+        return out
+
+    def open_at(self, lde, log_n, log_blowup, width, points):
+        pts = to_monty(np.ascontiguousarray(points, dtype=np.uint32).reshape(-1, 4))
+        out = np.empty((pts.shape[0], width, 4), dtype=np.uint32)
+        check(self.lib.zkhip_open_at(self.handle, C.c_void_p(lde.ptr), width, log_n, log_blowup, width,
+                                     pts.ctypes.data_as(u32p), pts.shape[0], out.ctypes.data_as(u32p)))
+        return from_monty(out)
+
+    def fri_fold(self, src, log_h, beta, out=None):
+        out = out or self.alloc(4 << (log_h - 1))
+        b = to_monty(np.asarray(beta, dtype=np.uint32))
+        check(self.lib.zkhip_fri_fold(self.handle, C.c_void_p(src.ptr), log_h, b.ctypes.data_as(u32p), C.c_void_p(out.ptr)))
+        return out
+
+    # ---- whole shard
+    def prove_shard(self, trace, log_n, width, public_values=(), params=None):
+        params = params or Params(1, 100, 16)
+        pv = np.ascontiguousarray(np.array(public_values, dtype=np.uint32))
+        size = self.lib.zkhip_proof_size(log_n, width, C.byref(params), pv.size)
+        buf = np.empty(size, dtype=np.uint8)
+        got = C.c_size_t(0)
+        check(self.lib.zkhip_prove_shard(self.handle, C.c_void_p(trace.ptr), width, log_n, width,
+                                         pv.ctypes.data_as(u32p), pv.size, C.byref(params),
+                                         buf.ctypes.data_as(u8p), size, C.byref(got)))
+        return buf[: got.value]
+
+    def prove_debug(self):
+        d = ProveDebug()
+        check(self.lib.zkhip_last_prove_debug(self.handle, C.byref(d)))
+        return {k: (np.array(getattr(d, k), dtype=np.uint32) if k != "pow_witness" else int(d.pow_witness))
+                for k, _ in ProveDebug._fields_}
+
+
+def verify_shard(proof, log_n, width, public_values=(), params=None):
+    params = params or Params(1, 100, 16)
+    lib = _lib.load()
+    pr = np.ascontiguousarray(proof, dtype=np.uint8)
+    pv = np.ascontiguousarray(np.array(public_values, dtype=np.uint32))
+    reason = C.c_int(0)
+    rc = lib.zkhip_verify_shard(pr.ctypes.data_as(u8p), pr.size, log_n, width, pv.ctypes.data_as(u32p), pv.size,
+                                C.byref(params), C.byref(reason))
+    return rc, reason.value
