@@ -1,0 +1,109 @@
+"""GPU parity tests for the STARK stages and the whole-shard prover: the HIP path through
+the C ABI against the CPU oracle, bit-exact (proof BYTES included), plus the committed
+golden proof fixtures and verifier acceptance."""
+import hashlib
+import json
+import os
+
+import numpy as np
+import pytest
+
+from zktls_amd._lib import Params
+from zktls_amd.device import verify_shard
+
+pytestmark = pytest.mark.gpu
+
+P = 2013265921
+SEED = 0x5A4B544C53
+HERE = os.path.dirname(os.path.abspath(__file__))
+KAT = json.load(open(os.path.join(HERE, "golden", "oracle_kat.json")))
+
+
+@pytest.mark.parametrize("log_n,width", [(5, 4), (6, 8), (8, 12), (10, 16), (11, 36), (12, 256), (13, 260)])
+def test_quotient_values_match_oracle(ctx, oracle, log_n, width):
+    t = oracle.gen_trace(SEED, 2, log_n, width)
+    lde = oracle.coset_lde(t, 1, 31)
+    alpha = np.random.default_rng(log_n).integers(0, P, 4, dtype=np.uint32)
+    exp = oracle.quotient_values(lde, log_n, alpha)
+    got = ctx.quotient_values(ctx.from_numpy(lde), log_n, width, alpha).download().reshape(-1, 4)
+    assert (got == exp).all()
+
+
+@pytest.mark.parametrize("log_n,width", [(5, 4), (7, 8), (10, 20), (12, 64), (13, 3)])
+def test_open_at_matches_oracle(ctx, oracle, log_n, width):
+    m = oracle.fill_uniform(SEED + log_n, log_n, width)
+    lde = oracle.coset_lde(m, 1, 31)
+    rng = np.random.default_rng(log_n)
+    z = rng.integers(0, P, (2, 4), dtype=np.uint32)
+    d = ctx.from_numpy(lde)
+    got = ctx.open_at(d, log_n, 1, width, z)
+    assert (got[0] == oracle.open_at(lde, log_n, z[0])).all()
+    assert (got[1] == oracle.open_at(lde, log_n, z[1])).all()
+    one = ctx.open_at(d, log_n, 1, width, z[1:2])
+    assert (one[0] == got[1]).all()
+
+
+@pytest.mark.parametrize("log_h", [1, 2, 5, 10, 14, 17])
+def test_fri_fold_matches_oracle(ctx, oracle, log_h):
+    rng = np.random.default_rng(log_h)
+    v = rng.integers(0, P, (1 << log_h, 4), dtype=np.uint32)
+    beta = rng.integers(0, P, 4, dtype=np.uint32)
+    got = ctx.fri_fold(ctx.from_numpy(v), log_h, beta).download().reshape(-1, 4)
+    assert (got == oracle.fri_fold(v, beta)).all()
+
+
+@pytest.mark.parametrize("log_n,width,q,pw,npub", [(5, 4, 4, 4, 0), (6, 8, 10, 8, 3), (9, 12, 20, 10, 1),
+                                                    (10, 16, 100, 16, 3), (11, 24, 30, 12, 2), (12, 32, 100, 16, 3),
+                                                    (14, 64, 100, 16, 0)])
+def test_prove_shard_bytes_equal_oracle(ctx, oracle, log_n, width, q, pw, npub):
+    pub = [7, 8, 9][:npub]
+    trace = ctx.gen_trace(SEED, 3, log_n, width)
+    prm = Params(1, q, pw)
+    proof = ctx.prove_shard(trace, log_n, width, pub, prm)
+    oprm = oracle.default_params(1, q, pw)
+    oproof = oracle.prove_shard(oracle.gen_trace(SEED, 3, log_n, width), pub, oprm)
+    dbg, odbg = ctx.prove_debug(), oracle.prove_debug()
+    for k in ("trace_root", "alpha", "quotient_root", "zeta", "fri_alpha"):
+        assert (dbg[k] == odbg[k]).all(), k
+    assert dbg["pow_witness"] == odbg["pow_witness"]
+    assert proof.size == oproof.size
+    assert proof.tobytes() == oproof.tobytes()
+    assert oracle.verify_shard(proof, log_n, width, pub, oprm) == 0
+    assert verify_shard(proof, log_n, width, pub, prm) == (0, 0)
+
+
+@pytest.mark.parametrize("name", sorted(KAT["proofs"]))
+def test_golden_proofs_on_gpu(ctx, name):
+    g = KAT["proofs"][name]
+    trace = ctx.gen_trace(SEED, g["shard"], g["log_n"], g["width"])
+    proof = ctx.prove_shard(trace, g["log_n"], g["width"], g["public"], Params(1, g["num_queries"], g["pow_bits"]))
+    assert proof.size == g["bytes"]
+    assert hashlib.sha256(proof.tobytes()).hexdigest() == g["sha256"]
+    d = ctx.prove_debug()
+    assert d["trace_root"].tolist() == g["trace_root"] and d["quotient_root"].tolist() == g["quotient_root"]
+    assert d["pow_witness"] == g["pow_witness"]
+
+
+def test_invalid_trace_is_refused_or_rejected(ctx, oracle):
+    log_n, width = 8, 8
+    t = oracle.gen_trace(SEED, 0, log_n, width)
+    t[17, 2] = (int(t[17, 2]) + 1) % P
+    from zktls_amd._lib import ZkHipError
+    prm = Params(1, 10, 4)
+    try:
+        proof = ctx.prove_shard(ctx.from_numpy(t), log_n, width, [], prm)
+    except ZkHipError as e:
+        assert e.code == -1
+        return
+    assert verify_shard(proof, log_n, width, [], prm)[0] == -6
+
+
+def test_bad_arguments_fail_loudly(ctx):
+    from zktls_amd._lib import ZkHipError
+    trace = ctx.gen_trace(SEED, 0, 6, 8)
+    with pytest.raises(ZkHipError):
+        ctx.prove_shard(trace, 6, 6, [], Params(1, 10, 4))        # width not a multiple of 4
+    with pytest.raises(ZkHipError):
+        ctx.prove_shard(trace, 6, 8, [P], Params(1, 10, 4))       # non-canonical public value
+    with pytest.raises(ZkHipError):
+        ctx.coset_lde(trace, 4, 8)                                # log_n below the tile minimum

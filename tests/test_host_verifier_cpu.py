@@ -1,0 +1,47 @@
+"""CPU tests of the product's HOST-side logic (libzkhip's C++ transcript + verifier, which
+run on the CPU by design, like the reference's `client.verify`, sp1.rs:120): it must
+accept the oracle's proofs and reject corrupted ones.  No GPU compute is called."""
+import numpy as np
+import pytest
+
+from zktls_amd._lib import Params
+from zktls_amd.device import verify_shard
+
+P = 2013265921
+SEED = 0x5A4B544C53
+
+
+@pytest.mark.parametrize("log_n,width,q,pw", [(5, 4, 5, 4), (6, 8, 10, 8), (10, 16, 100, 16)])
+def test_host_verifier_accepts_oracle_proofs(oracle, log_n, width, q, pw):
+    t = oracle.gen_trace(SEED, 1, log_n, width)
+    pf = oracle.prove_shard(t, [4, 5], oracle.default_params(1, q, pw))
+    rc, reason = verify_shard(pf, log_n, width, [4, 5], Params(1, q, pw))
+    assert (rc, reason) == (0, 0)
+
+
+def test_host_verifier_rejects_like_the_oracle(oracle):
+    log_n, w = 6, 8
+    oprm, prm = oracle.default_params(1, 10, 8), Params(1, 10, 8)
+    pf = oracle.prove_shard(oracle.gen_trace(SEED, 3, log_n, w), [7, 8, 9], oprm)
+    assert verify_shard(pf, log_n, w, [7, 8, 9], prm)[0] == 0
+    assert verify_shard(pf, log_n, w, [7, 8, 10], prm)[0] == -6
+    assert verify_shard(pf[:-4], log_n, w, [7, 8, 9], prm) == (-6, 2)
+    words = pf.view(np.uint32)
+    rng = np.random.default_rng(3)
+    for i in sorted(set([8, 16, 24, len(words) - 1] + [int(x) for x in rng.integers(8, len(words), 40)])):
+        bad = words.copy()
+        bad[i] = (int(bad[i]) + 1) % P
+        rc, reason = verify_shard(bad.view(np.uint8), log_n, w, [7, 8, 9], prm)
+        orc = oracle.verify_shard(bad.view(np.uint8), log_n, w, [7, 8, 9], oprm)
+        assert rc == -6 and reason == orc, (i, reason, orc)
+
+
+def test_proof_size_matches_oracle(oracle):
+    from zktls_amd import _lib
+    import ctypes as C
+    L = _lib.load()
+    for log_n, w, q in ((6, 8, 10), (10, 16, 100), (20, 256, 100)):
+        prm = Params(1, q, 16)
+        oprm = oracle.default_params(1, q, 16)
+        assert L.zkhip_proof_size(log_n, w, C.byref(prm), 3) == oracle.lib().orc_proof_size(
+            C.c_int(log_n), C.c_size_t(w), C.byref(oprm), C.c_size_t(3))

@@ -42,6 +42,28 @@ OP_KERNEL(k_mad_u32_u24, asm volatile("v_mad_u32_u24 %0, %0, %1, %2" : "+v"(a[i]
 OP_KERNEL(k_lshl_add_u32, asm volatile("v_lshl_add_u32 %0, %0, 3, %1" : "+v"(a[i]) : "v"(b)))
 OP_KERNEL(k_min_u32, asm volatile("v_min_u32 %0, %0, %1" : "+v"(a[i]) : "v"(b)))
 OP_KERNEL(k_add3_u32, asm volatile("v_add3_u32 %0, %0, %1, %2" : "+v"(a[i]) : "v"(b), "v"(c)))
+OP_KERNEL(k_sub_u32, asm volatile("v_sub_u32 %0, %0, %1" : "+v"(a[i]) : "v"(b)))
+OP_KERNEL(k_and_b32, asm volatile("v_and_b32 %0, %0, %1" : "+v"(a[i]) : "v"(b)))
+OP_KERNEL(k_xor_b32, asm volatile("v_xor_b32 %0, %0, %1" : "+v"(a[i]) : "v"(b)))
+OP_KERNEL(k_lshrrev_b32, asm volatile("v_lshrrev_b32 %0, 3, %0" : "+v"(a[i])))
+OP_KERNEL(k_ashrrev_i32, asm volatile("v_ashrrev_i32 %0, 3, %0" : "+v"(a[i])))
+OP_KERNEL(k_max_u32, asm volatile("v_max_u32 %0, %0, %1" : "+v"(a[i]) : "v"(b)))
+OP_KERNEL(k_mov_b32, asm volatile("v_mov_b32 %0, %1" : "+v"(a[i]) : "v"(b)))
+OP_KERNEL(k_add_lit, asm volatile("v_add_u32 %0, 0x87ffffff, %0" : "+v"(a[i])))
+OP_KERNEL(k_add_sgpr, asm volatile("v_add_u32 %0, %1, %0" : "+v"(a[i]) : "s"(seed)))
+OP_KERNEL(k_add_co, asm volatile("v_add_co_u32 %0, vcc, %0, %1" : "+v"(a[i]) : "v"(b) : "vcc"))
+OP_KERNEL(k_sub_co, asm volatile("v_sub_co_u32 %0, vcc, %0, %1" : "+v"(a[i]) : "v"(b) : "vcc"))
+OP_KERNEL(k_cndmask, asm volatile("v_cndmask_b32 %0, %0, %1, vcc" : "+v"(a[i]) : "v"(b) : "vcc"))
+OP_KERNEL(k_cmp_cnd, asm volatile("v_cmp_lt_u32 vcc, %0, %1\n\tv_cndmask_b32 %0, %0, %2, vcc" : "+v"(a[i]) : "v"(b), "v"(c) : "vcc"))
+OP_KERNEL(k_subco_cnd, asm volatile("v_sub_co_u32 %0, vcc, %0, %1\n\tv_cndmask_b32 %0, %0, %2, vcc" : "+v"(a[i]) : "v"(b), "v"(c) : "vcc"))
+OP_KERNEL(k_mul_hi_i32, asm volatile("v_mul_hi_i32 %0, %0, %1" : "+v"(a[i]) : "v"(b)))
+OP_KERNEL(k_mul_lo_sgpr, asm volatile("v_mul_lo_u32 %0, %0, %1" : "+v"(a[i]) : "s"(seed)))
+OP_KERNEL(k_alignbit, asm volatile("v_alignbit_b32 %0, %0, %1, 5" : "+v"(a[i]) : "v"(b)))
+OP_KERNEL(k_bfe_u32, asm volatile("v_bfe_u32 %0, %0, 3, 9" : "+v"(a[i])))
+OP_KERNEL(k_sub_dpp, asm volatile("v_add_u32_dpp %0, %0, %1 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf" : "+v"(a[i]) : "v"(b)))
+OP_KERNEL(k_pk_add_u16, asm volatile("v_pk_add_u16 %0, %0, %1" : "+v"(a[i]) : "v"(b)))
+OP_KERNEL(k_pk_mul_lo_u16, asm volatile("v_pk_mul_lo_u16 %0, %0, %1" : "+v"(a[i]) : "v"(b)))
+OP_KERNEL(k_dot4_u32_u8, asm volatile("v_dot4_u32_u8 %0, %0, %1, %2" : "+v"(a[i]) : "v"(b), "v"(c)))
 
 // 64-bit result ops
 __global__ void __launch_bounds__(256) k_mad_u64_u32(uint32_t* out, uint32_t seed) {
@@ -191,7 +213,7 @@ static void run_op(const char* name, opk_t k, double ops_per_thread_inst, int bl
 // copy a [rows][cols] u32 matrix in tiles of TR rows x CW words, where tile rows are
 // `stride` rows apart (strided = first NTT pass) or adjacent (second pass); each lane
 // moves one dword per access like the NTT kernel (CW words per row chunk).
-__global__ void __launch_bounds__(512) k_tile_copy(const uint32_t* __restrict__ in, uint32_t* __restrict__ out,
+__global__ void __launch_bounds__(1024) k_tile_copy(const uint32_t* __restrict__ in, uint32_t* __restrict__ out,
                                                    uint64_t ld, uint32_t tiles_r, uint32_t ncg, uint32_t log_cw,
                                                    uint64_t tile_mul, uint64_t row_stride, int xcd_map) {
     const uint32_t CW = 1u << log_cw;
@@ -220,6 +242,37 @@ __global__ void __launch_bounds__(256) k_stream_copy(const uint4* __restrict__ i
 
 static float time_ms(hipEvent_t e0, hipEvent_t e1) { float ms; CK(hipEventElapsedTime(&ms, e0, e1)); return ms; }
 
+// streaming variants: U x 16 B per lane in flight, optional nontemporal hints
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+template <int U, bool NT>
+__global__ void __launch_bounds__(256) k_stream_copy_u(const u32x4* __restrict__ in, u32x4* __restrict__ out, size_t n) {
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i + (U - 1) * stride < n; i += U * stride) {
+        u32x4 v[U];
+#pragma unroll
+        for (int k = 0; k < U; k++) v[k] = NT ? __builtin_nontemporal_load(&in[i + k * stride]) : in[i + k * stride];
+#pragma unroll
+        for (int k = 0; k < U; k++) {
+            v[k].x += 1;
+            if (NT) __builtin_nontemporal_store(v[k], &out[i + k * stride]); else out[i + k * stride] = v[k];
+        }
+    }
+}
+__global__ void __launch_bounds__(256) k_stream_read(const uint4* __restrict__ in, uint32_t* out, size_t n) {
+    uint32_t acc = 0;
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i + 3 * stride < n; i += 4 * stride) {
+        uint4 a = in[i], b = in[i + stride], c = in[i + 2 * stride], d = in[i + 3 * stride];
+        acc += a.x ^ b.y ^ c.z ^ d.w;
+    }
+    if (acc == 0x12345678u) out[0] = acc;
+}
+__global__ void __launch_bounds__(256) k_stream_write(uint4* __restrict__ out, size_t n) {
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride)
+        out[i] = make_uint4((uint32_t)i, 1, 2, 3);
+}
+
 static void run_mem(void) {
     const uint64_t rows = 1 << 20, cols = 256;
     size_t bytes = rows * cols * 4;
@@ -227,38 +280,42 @@ static void run_mem(void) {
     CK(hipMalloc(&a, bytes)); CK(hipMalloc(&b, bytes));
     CK(hipMemset(a, 1, bytes)); CK(hipMemset(b, 0, bytes));
     hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
-    // stream copy
-    for (int rep = 0; rep < 3; rep++) {
-        CK(hipEventRecord(e0));
-        hipLaunchKernelGGL(k_stream_copy, dim3(256 * 8), dim3(256), 0, 0, (const uint4*)a, (uint4*)b, bytes / 16);
-        CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
-        if (rep == 2) printf("MEM stream_copy 1GiB+1GiB: %.3f ms  %.2f TB/s\n", time_ms(e0, e1), 2.0 * bytes / time_ms(e0, e1) / 1e9);
+#define TIME_IT(LABEL, BYTES, LAUNCH)                                                   \
+    {                                                                                    \
+        float best = 1e30f;                                                              \
+        for (int rep = 0; rep < 4; rep++) {                                              \
+            CK(hipEventRecord(e0)); LAUNCH; CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1)); \
+            float ms = time_ms(e0, e1); if (rep > 0 && ms < best) best = ms;             \
+        }                                                                                \
+        CK(hipGetLastError());                                                           \
+        printf("MEM %-44s %.3f ms  %.2f TB/s\n", LABEL, best, (double)(BYTES) / best / 1e9); \
     }
-    // tile patterns: 1024-row tiles (32 per thread x P=32 threads) with chunk width CW words
+    for (int bpc = 2; bpc <= 16; bpc *= 2) {
+        char lab[96];
+        snprintf(lab, sizeof lab, "stream_copy U=1 blocks/CU=%d", bpc);
+        TIME_IT(lab, 2.0 * bytes, hipLaunchKernelGGL(k_stream_copy, dim3(256 * bpc), dim3(256), 0, 0, (const uint4*)a, (uint4*)b, bytes / 16));
+        snprintf(lab, sizeof lab, "stream_copy U=4 blocks/CU=%d", bpc);
+        TIME_IT(lab, 2.0 * bytes, hipLaunchKernelGGL((k_stream_copy_u<4, false>), dim3(256 * bpc), dim3(256), 0, 0, (const u32x4*)a, (u32x4*)b, bytes / 16));
+        snprintf(lab, sizeof lab, "stream_copy U=4 nontemporal blocks/CU=%d", bpc);
+        TIME_IT(lab, 2.0 * bytes, hipLaunchKernelGGL((k_stream_copy_u<4, true>), dim3(256 * bpc), dim3(256), 0, 0, (const u32x4*)a, (u32x4*)b, bytes / 16));
+    }
+    TIME_IT("stream_read U=4 blocks/CU=8", 1.0 * bytes, hipLaunchKernelGGL(k_stream_read, dim3(256 * 8), dim3(256), 0, 0, (const uint4*)a, b, bytes / 16));
+    TIME_IT("stream_write blocks/CU=8", 1.0 * bytes, hipLaunchKernelGGL(k_stream_write, dim3(256 * 8), dim3(256), 0, 0, (uint4*)b, bytes / 16));
+    // tile patterns: 32 rows per thread, P = threads / CW threads per column, chunk width CW words
     for (int strided = 1; strided >= 0; strided--) {
         for (int log_cw = 4; log_cw <= 6; log_cw++) {
             for (int xcd = 0; xcd <= 1; xcd++) {
                 uint32_t CW = 1u << log_cw;
-                uint32_t threads = 32 * CW;   // P = 32
-                if (threads > 1024) {
-                    continue;
-                }
-                uint32_t ncg = cols / CW, tiles = rows / 1024;
-                uint64_t tile_mul = strided ? 1 : 1024, row_stride = strided ? 1024 : 1;
-                float best = 1e30f;
-                for (int rep = 0; rep < 4; rep++) {
-                    CK(hipEventRecord(e0));
-                    hipLaunchKernelGGL(k_tile_copy, dim3(tiles * ncg), dim3(threads), 0, 0, a, b, cols, tiles, ncg, log_cw, tile_mul, row_stride, xcd);
-                    CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
-                    float ms = time_ms(e0, e1);
-                    if (rep > 0 && ms < best) best = ms;
-                }
-                printf("MEM tile_copy %s chunk=%3uB threads=%4u xcd_map=%d: %.3f ms  %.2f TB/s\n",
-                       strided ? "strided   " : "contiguous", CW * 4, threads, xcd, best, 2.0 * bytes / best / 1e9);
+                uint32_t threads = 32 * CW > 1024 ? 1024 : 32 * CW;
+                uint32_t Pn = threads / CW, trows = 32 * Pn;
+                uint32_t ncg = cols / CW, tiles = rows / trows;
+                uint64_t tile_mul = strided ? 1 : trows, row_stride = strided ? tiles : 1;
+                char lab[96];
+                snprintf(lab, sizeof lab, "tile_copy %s chunk=%3uB thr=%4u rows=%4u xcd=%d", strided ? "strided" : "contig ", CW * 4, threads, trows, xcd);
+                TIME_IT(lab, 2.0 * bytes, hipLaunchKernelGGL(k_tile_copy, dim3(tiles * ncg), dim3(threads), 0, 0, a, b, cols, tiles, ncg, log_cw, tile_mul, row_stride, xcd));
             }
         }
     }
-    CK(hipGetLastError());
     CK(hipFree(a)); CK(hipFree(b));
 }
 
@@ -267,11 +324,33 @@ int main(int argc, char** argv) {
     CK(hipSetDevice(dev));
     hipDeviceProp_t p; CK(hipGetDeviceProperties(&p, dev));
     printf("device %s CUs=%d clock=%d kHz\n", p.gcnArchName, p.multiProcessorCount, p.clockRate);
-    for (int bpc = 4; bpc <= 8; bpc += 4) {
+    for (int bpc = 8; bpc <= 8; bpc += 4) {
         run_op("v_add_u32", k_add_u32, 1, bpc);
         run_op("v_min_u32", k_min_u32, 1, bpc);
         run_op("v_add3_u32", k_add3_u32, 1, bpc);
         run_op("v_lshl_add_u32", k_lshl_add_u32, 1, bpc);
+        run_op("v_sub_u32", k_sub_u32, 1, bpc);
+        run_op("v_and_b32", k_and_b32, 1, bpc);
+        run_op("v_xor_b32", k_xor_b32, 1, bpc);
+        run_op("v_lshrrev_b32", k_lshrrev_b32, 1, bpc);
+        run_op("v_ashrrev_i32", k_ashrrev_i32, 1, bpc);
+        run_op("v_max_u32", k_max_u32, 1, bpc);
+        run_op("v_mov_b32", k_mov_b32, 1, bpc);
+        run_op("v_add_u32 literal", k_add_lit, 1, bpc);
+        run_op("v_add_u32 sgpr", k_add_sgpr, 1, bpc);
+        run_op("v_add_co_u32", k_add_co, 1, bpc);
+        run_op("v_sub_co_u32", k_sub_co, 1, bpc);
+        run_op("v_cndmask_b32", k_cndmask, 1, bpc);
+        run_op("cmp+cndmask(x2)", k_cmp_cnd, 2, bpc);
+        run_op("sub_co+cndmask(x2)", k_subco_cnd, 2, bpc);
+        run_op("v_mul_hi_i32", k_mul_hi_i32, 1, bpc);
+        run_op("v_mul_lo_u32 sgpr", k_mul_lo_sgpr, 1, bpc);
+        run_op("v_alignbit_b32", k_alignbit, 1, bpc);
+        run_op("v_bfe_u32", k_bfe_u32, 1, bpc);
+        run_op("v_add_u32_dpp", k_sub_dpp, 1, bpc);
+        run_op("v_pk_add_u16", k_pk_add_u16, 1, bpc);
+        run_op("v_pk_mul_lo_u16", k_pk_mul_lo_u16, 1, bpc);
+        run_op("v_dot4_u32_u8", k_dot4_u32_u8, 1, bpc);
         run_op("v_mul_lo_u32", k_mul_lo_u32, 1, bpc);
         run_op("v_mul_hi_u32", k_mul_hi_u32, 1, bpc);
         run_op("v_mul_u32_u24", k_mul_u32_u24, 1, bpc);

@@ -52,7 +52,7 @@ struct zkhip_ctx {
     uint32_t* w1024_fwd = nullptr;
     uint32_t* w1024_inv = nullptr;
     std::deque<zk::NttPlan> plans;   // deque: references stay valid on push_back
-    zk::DeviceBuffer scratch[8];       // grow-only workspaces, indexed by role
+    zk::DeviceBuffer scratch[16];       // grow-only workspaces, indexed by role
     zkhip_prove_debug debug{};
     // domain tables of the last proved size (prover.cpp)
     int dom_log_n = -1;

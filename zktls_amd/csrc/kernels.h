@@ -6,6 +6,8 @@
 #include <stddef.h>
 #include <stdint.h>
 
+#include "babybear.cuh"
+
 namespace zk {
 
 // ---------------------------------------------------------------- NTT pass (ntt.hip)
@@ -69,5 +71,72 @@ hipError_t launch_gen_trace(uint32_t* out, uint64_t ld, uint64_t seed, uint64_t 
 // element-wise Montgomery <-> canonical conversion
 hipError_t launch_convert(const uint32_t* in, uint32_t* out, uint64_t n, bool to_monty_form,
                           hipStream_t s);
+
+// ---------------------------------------------------------------- STARK stages (stark.hip)
+// x_p = g w_2N^bitrev(p) (p < 2N), Z_H(x_p)/(x_p - 1), and 1/(2 w_2N^bitrev_n(i)) (i < N)
+hipError_t launch_domain_tables(uint32_t* xs, uint32_t* sel_first, uint32_t* itw, int log_n, hipStream_t s);
+
+struct QuotientArgs {
+    const uint32_t* lde;        // [2N][ld] trace LDE, bit-reversed rows
+    uint64_t ld;
+    uint32_t width;
+    int log_n;
+    int lanes_per_row;          // power of two <= 64
+    const uint32_t* xs;
+    const uint32_t* sel_first;
+    uint32_t wn_inv;            // w_N^-1
+    uint32_t inv_zh_even, inv_zh_odd;
+    Ext alpha, alpha2;
+    const uint32_t* alpha_pow;  // [width/4] ext: alpha^(3 (G-1-g))
+    uint32_t* out;              // [2][N][4]: chunk k, natural row j
+};
+hipError_t launch_quotient(const QuotientArgs& a, hipStream_t s);
+
+// out[k][p] = 1 / (x_p - z_k), k < npoints (<= 2), p < count
+hipError_t launch_inv_denominators(const uint32_t* xs, uint64_t count, const Ext& z0, const Ext& z1, int npoints,
+                                   uint32_t* out, hipStream_t s);
+
+struct OpenArgs {
+    const uint32_t* mat;        // first `rows` rows of a bit-reversed LDE
+    uint64_t ld;
+    uint32_t width;
+    uint64_t rows;              // N
+    const uint32_t* xs;
+    const uint32_t* dinv;       // [npts][dinv_stride] ext
+    uint64_t dinv_stride;
+    uint32_t* partial;          // [ceil(rows/2048)][npts][width] ext
+    int tx;                     // columns per workgroup (power of two <= 64)
+};
+// out[k][col] = -scale_k * sum_q mat[q][col] x_q dinv_k[q]
+hipError_t launch_open(const OpenArgs& a, int npts, const Ext& scale0, const Ext& scale1, uint32_t* out, hipStream_t s);
+
+struct ReducedArgs {
+    const uint32_t* tlde; uint64_t t_ld; uint32_t width;
+    const uint32_t* qlde; uint64_t q_ld;
+    uint64_t rows;              // 2N
+    int lanes_per_row;
+    const uint32_t* alpha_pow;  // [max(width, 8)] ext: alpha^j
+    const uint32_t* dinv;       // [2][rows] ext
+    Ext y_loc, y_next, y_q, off_next, off_q;
+    uint32_t* out;              // [rows] ext
+};
+hipError_t launch_reduced_opening(const ReducedArgs& a, hipStream_t s);
+
+hipError_t launch_fri_fold(const uint32_t* in, uint32_t* out, const uint32_t* itw, uint64_t half, const Ext& beta, hipStream_t s);
+
+struct GrindArgs {
+    uint32_t state[16];         // Montgomery
+    int slot;                   // where the candidate witness goes
+    uint32_t mask;              // (1 << bits) - 1
+};
+// *result = min(*result, smallest hit in [base, base + count))
+hipError_t launch_grind(const GrindArgs& a, uint32_t base, uint32_t count, uint32_t* result, hipStream_t s);
+
+struct GatherDesc {
+    const uint32_t* src;
+    uint32_t dst_off;           // words
+    uint32_t nwords;
+};
+hipError_t launch_gather(const GatherDesc* descs, uint32_t ndesc, uint32_t* dst, hipStream_t s);
 
 }  // namespace zk

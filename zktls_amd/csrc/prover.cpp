@@ -1,27 +1,599 @@
-// prover.cpp -- STARK stages and the whole-shard prover (host orchestration).
+// prover.cpp -- whole-shard STARK prover (host orchestration of the gfx950 kernels), the
+// host-side Fiat-Shamir transcript, the CPU verifier, and the stage-level C ABI entries.
+//
+// Stands in for the span the reference times around `client.prove`
+// (crates/guest-prover-sp1/src/sp1.rs:115-118) and for `client.verify` (:120); the
+// protocol restates p3-uni-stark `prove` + p3-fri TwoAdicFriPcs over the synthetic AIR
+// (DESIGN.md sections 3 and 6).  Every heavy step is a HIP kernel on the context's
+// stream; the host only runs the duplex challenger (a few dozen permutations) between
+// launches, exactly where the protocol forces a round trip (commit -> challenge).
+#include <cstring>
+#include <vector>
+
 #include "context.h"
+#include "poseidon2.cuh"
+
+namespace zk {
+
+// ---------------------------------------------------------------- transcript (host)
+// p3-challenger DuplexChallenger<16, 8> over Poseidon2; values in Montgomery form.
+struct Challenger {
+    uint32_t state[16] = {0};
+    uint32_t in[8] = {0};
+    int n_in = 0;
+    uint32_t out[8] = {0};
+    int n_out = 0;
+    void duplex() {
+        for (int i = 0; i < n_in; i++) state[i] = in[i];
+        n_in = 0;
+        p2_permute(state);
+        for (int i = 0; i < 8; i++) out[i] = state[i];
+        n_out = 8;
+    }
+    void observe(uint32_t m) {
+        n_out = 0;
+        in[n_in++] = m;
+        if (n_in == 8) duplex();
+    }
+    void observe_canonical(uint32_t c) { observe(to_monty(c)); }
+    void observe_ext(const Ext& e) { for (int i = 0; i < 4; i++) observe(e.c[i]); }
+    uint32_t sample() {
+        if (n_in != 0 || n_out == 0) duplex();
+        return out[--n_out];
+    }
+    Ext sample_ext() { Ext e; for (int i = 0; i < 4; i++) e.c[i] = sample(); return e; }
+    uint32_t sample_bits(int bits) { return from_monty(sample()) & ((1u << bits) - 1u); }
+};
+
+static void transcript_init(Challenger& ch, int log_n, uint32_t width, const zkhip_params* prm, size_t n_public) {
+    ch.observe_canonical((uint32_t)log_n);
+    ch.observe_canonical(width);
+    ch.observe_canonical((uint32_t)prm->log_blowup);
+    ch.observe_canonical((uint32_t)prm->num_queries);
+    ch.observe_canonical((uint32_t)prm->pow_bits);
+    ch.observe_canonical((uint32_t)n_public);
+}
+
+constexpr uint32_t PROOF_MAGIC = 0x41544B5Au;   // "ZKTA"
+constexpr uint32_t PROOF_VERSION = 1u;
+
+enum Slot { S_COEF = 0, S_TMP = 1, S_TLDE, S_TTREE, S_QCHUNK, S_QLDE, S_QTREE, S_DINV, S_PARTIAL, S_OPEN_OUT,
+            S_APOW_Q, S_APOW_F, S_FRI_LAYERS, S_FRI_TREES, S_GATHER_DESC, S_GATHER_OUT };
+
+static int pow2ceil(int v) { int r = 1; while (r < v) r <<= 1; return r; }
+
+static int ensure_domain(zkhip_ctx* ctx, int log_n) {
+    if (ctx->dom_log_n == log_n) return ZKHIP_OK;
+    if (ctx->dom_xs) { ZK_HIP(hipStreamSynchronize(ctx->stream)); (void)hipFree(ctx->dom_xs); (void)hipFree(ctx->dom_sel_first); (void)hipFree(ctx->dom_itw); }
+    ctx->dom_xs = ctx->dom_sel_first = ctx->dom_itw = nullptr;
+    ctx->dom_log_n = -1;
+    const size_t m = (size_t)2 << log_n;
+    ZK_HIP(hipMalloc((void**)&ctx->dom_xs, m * 4));
+    ZK_HIP(hipMalloc((void**)&ctx->dom_sel_first, m * 4));
+    ZK_HIP(hipMalloc((void**)&ctx->dom_itw, (m / 2) * 4));
+    ZK_HIP(launch_domain_tables(ctx->dom_xs, ctx->dom_sel_first, ctx->dom_itw, log_n, ctx->stream));
+    ctx->dom_log_n = log_n;
+    return ZKHIP_OK;
+}
+
+static int d2h(zkhip_ctx* ctx, void* dst, const void* src, size_t bytes) {
+    ZK_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, ctx->stream));
+    ZK_HIP(hipStreamSynchronize(ctx->stream));
+    return ZKHIP_OK;
+}
+static int h2d(zkhip_ctx* ctx, void* dst, const void* src, size_t bytes) {
+    ZK_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, ctx->stream));
+    ZK_HIP(hipStreamSynchronize(ctx->stream));   // source is pageable host memory that may go out of scope
+    return ZKHIP_OK;
+}
+
+static int run_quotient(zkhip_ctx* ctx, const uint32_t* lde, size_t ld, int log_n, uint32_t width, const Ext& alpha,
+                        uint32_t* out_chunks) {
+    ZK_TRY(ensure_domain(ctx, log_n));
+    const uint32_t G = width / 4;
+    std::vector<Ext> ap(G);
+    const Ext a3 = ext_mul(ext_mul(alpha, alpha), alpha);
+    ap[G - 1] = ext_one();
+    for (int g = (int)G - 2; g >= 0; g--) ap[g] = ext_mul(ap[g + 1], a3);
+    void* d_ap;
+    ZK_TRY(ctx_reserve(ctx, S_APOW_Q, (size_t)G * 16, &d_ap));
+    ZK_TRY(h2d(ctx, d_ap, ap.data(), (size_t)G * 16));
+    QuotientArgs q{};
+    q.lde = lde; q.ld = ld; q.width = width; q.log_n = log_n;
+    q.lanes_per_row = pow2ceil((int)G) > 64 ? 64 : pow2ceil((int)G);
+    q.xs = ctx->dom_xs; q.sel_first = ctx->dom_sel_first;
+    q.wn_inv = finv(two_adic_generator(log_n));
+    const uint32_t gn = fpow(MONTY_GEN, (uint64_t)1 << log_n);
+    q.inv_zh_even = finv(fsub(gn, MONTY_R1));
+    q.inv_zh_odd = finv(fsub(fneg(gn), MONTY_R1));
+    q.alpha = alpha; q.alpha2 = ext_mul(alpha, alpha);
+    q.alpha_pow = (const uint32_t*)d_ap;
+    q.out = out_chunks;
+    ZK_HIP(launch_quotient(q, ctx->stream));
+    return ZKHIP_OK;
+}
+
+// opens `width` columns at npts points; dinv must hold 1/(x_p - z_k) with stride `dinv_stride`
+static int run_open(zkhip_ctx* ctx, const uint32_t* lde, size_t ld, int log_n, uint32_t width, const Ext* z, int npts,
+                    const uint32_t* dinv, uint64_t dinv_stride, uint32_t* d_out) {
+    const uint64_t n = (uint64_t)1 << log_n;
+    OpenArgs o{};
+    o.mat = lde; o.ld = ld; o.width = width; o.rows = n; o.xs = ctx->dom_xs; o.dinv = dinv; o.dinv_stride = dinv_stride;
+    o.tx = pow2ceil((int)width) > 64 ? 64 : pow2ceil((int)width);
+    const size_t nchunks = (size_t)((n + 2047) / 2048);
+    void* part;
+    ZK_TRY(ctx_reserve(ctx, S_PARTIAL, nchunks * npts * width * 16, &part));
+    o.partial = (uint32_t*)part;
+    Ext scale[2] = {ext_zero(), ext_zero()};
+    const uint32_t ginv = finv(MONTY_GEN), ninv = finv(to_monty((uint32_t)(n % P)));
+    for (int k = 0; k < npts; k++)
+        scale[k] = ext_mul_base(ext_sub_base(ext_pow(ext_mul_base(z[k], ginv), n), MONTY_R1), ninv);
+    ZK_HIP(launch_open(o, npts, scale[0], scale[1], d_out, ctx->stream));
+    return ZKHIP_OK;
+}
+
+static size_t proof_words(int log_n, uint32_t width, const zkhip_params* prm) {
+    const size_t H = (size_t)(log_n + prm->log_blowup), L = (size_t)log_n;
+    size_t words = 8 + 16 + 8 * (size_t)width + 32 + 8 * L + 5;
+    size_t perq = width + 8 + 16 * H;
+    for (size_t l = 0; l < L; l++) perq += 4 + 8 * (H - 1 - l);
+    return words + (size_t)prm->num_queries * perq;
+}
+
+static int check_shape(int log_n, uint32_t width, const zkhip_params* prm) {
+    if (!prm) return fail(ZKHIP_ERR_INVALID, "null params");
+    if (log_n < 5 || log_n > 20) return fail(ZKHIP_ERR_INVALID, "log_n must be in [5, 20]");
+    if (width == 0 || width % 4 != 0) return fail(ZKHIP_ERR_INVALID, "width must be a positive multiple of 4");
+    if (prm->log_blowup != 1) return fail(ZKHIP_ERR_INVALID, "only log_blowup = 1 is supported by the synthetic AIR path");
+    if (prm->num_queries < 1 || prm->num_queries > 4096) return fail(ZKHIP_ERR_INVALID, "num_queries out of range");
+    if (prm->pow_bits < 0 || prm->pow_bits > 28) return fail(ZKHIP_ERR_INVALID, "pow_bits out of range");
+    return ZKHIP_OK;
+}
+
+}  // namespace zk
 
 using namespace zk;
 
+#define CHECK_CTX(ctx)                                                  \
+    do {                                                                \
+        if (!(ctx)) return fail(ZKHIP_ERR_INVALID, "null context");     \
+        ZK_HIP(hipSetDevice((ctx)->device));                            \
+    } while (0)
+
 extern "C" {
 
-int zkhip_quotient_values(zkhip_ctx*, const uint32_t*, size_t, int, uint32_t, const uint32_t*, uint32_t*) {
-    return fail(ZKHIP_ERR_INTERNAL, "quotient_values: not implemented yet");
+int zkhip_quotient_values(zkhip_ctx* ctx, const uint32_t* d_lde, size_t ld, int log_n, uint32_t width,
+                          const uint32_t alpha[4], uint32_t* d_out) {
+    CHECK_CTX(ctx);
+    zkhip_params prm{1, 1, 0};
+    ZK_TRY(check_shape(log_n, width, &prm));
+    if (!d_lde || !d_out || !alpha || ld < width) return fail(ZKHIP_ERR_INVALID, "quotient_values: bad arguments");
+    // kernel writes natural-order chunks; this entry point returns the bit-reversed
+    // layout of the LDE (row p), so gather it back: p = bitrev(2 j + k)
+    const size_t n = (size_t)1 << log_n;
+    void* chunks;
+    ZK_TRY(ctx_reserve(ctx, S_QCHUNK, 2 * n * 16, &chunks));
+    Ext a{{alpha[0], alpha[1], alpha[2], alpha[3]}};
+    ZK_TRY(run_quotient(ctx, d_lde, ld, log_n, width, a, (uint32_t*)chunks));
+    // the chunk layout is [k][j]; position p holds e = bitrev(p) = 2 j + k, and bit-reversing a
+    // (log_n+1)-bit index moves k to the top bit: p = k * N + bitrev_n(j).  Use the gather kernel.
+    std::vector<GatherDesc> descs(2 * n);
+    for (size_t k = 0; k < 2; k++)
+        for (size_t j = 0; j < n; j++) {
+            size_t p = k * n + reverse_bits((uint32_t)j, log_n);
+            descs[p] = GatherDesc{(const uint32_t*)chunks + (k * n + j) * 4, (uint32_t)(p * 4), 4};
+        }
+    void* dd;
+    ZK_TRY(ctx_reserve(ctx, S_GATHER_DESC, descs.size() * sizeof(GatherDesc), &dd));
+    ZK_TRY(h2d(ctx, dd, descs.data(), descs.size() * sizeof(GatherDesc)));
+    ZK_HIP(launch_gather((const GatherDesc*)dd, (uint32_t)descs.size(), d_out, ctx->stream));   // -> canonical
+    ZK_HIP(launch_convert(d_out, d_out, 2 * n * 4, true, ctx->stream));                        // back to Montgomery
+    return ZKHIP_OK;
 }
-int zkhip_open_at(zkhip_ctx*, const uint32_t*, size_t, int, int, uint32_t, const uint32_t*, int, uint32_t*) {
-    return fail(ZKHIP_ERR_INTERNAL, "open_at: not implemented yet");
+
+int zkhip_open_at(zkhip_ctx* ctx, const uint32_t* d_lde, size_t ld, int log_n, int log_blowup, uint32_t width,
+                  const uint32_t* z, int npoints, uint32_t* h_out) {
+    CHECK_CTX(ctx);
+    if (log_n < 5 || log_n > 20 || log_blowup != 1) return fail(ZKHIP_ERR_INVALID, "open_at: log_n in [5,20], log_blowup = 1");
+    if (!d_lde || !z || !h_out || width == 0 || ld < width || npoints < 1 || npoints > 2)
+        return fail(ZKHIP_ERR_INVALID, "open_at: bad arguments (1 or 2 points)");
+    ZK_TRY(ensure_domain(ctx, log_n));
+    const uint64_t m = (uint64_t)2 << log_n;
+    Ext zz[2];
+    for (int k = 0; k < npoints; k++) zz[k] = Ext{{z[4 * k], z[4 * k + 1], z[4 * k + 2], z[4 * k + 3]}};
+    if (npoints == 1) zz[1] = zz[0];
+    void *dinv, *dout;
+    ZK_TRY(ctx_reserve(ctx, S_DINV, 2 * m * 16, &dinv));
+    ZK_TRY(ctx_reserve(ctx, S_OPEN_OUT, (size_t)npoints * width * 16, &dout));
+    ZK_HIP(launch_inv_denominators(ctx->dom_xs, m, zz[0], zz[1], npoints, (uint32_t*)dinv, ctx->stream));
+    ZK_TRY(run_open(ctx, d_lde, ld, log_n, width, zz, npoints, (const uint32_t*)dinv, m, (uint32_t*)dout));
+    return d2h(ctx, h_out, dout, (size_t)npoints * width * 16);
 }
-int zkhip_fri_fold(zkhip_ctx*, const uint32_t*, int, const uint32_t*, uint32_t*) {
-    return fail(ZKHIP_ERR_INTERNAL, "fri_fold: not implemented yet");
+
+int zkhip_fri_fold(zkhip_ctx* ctx, const uint32_t* d_in, int log_h, const uint32_t beta[4], uint32_t* d_out) {
+    CHECK_CTX(ctx);
+    if (!d_in || !d_out || !beta || log_h < 1 || log_h > 21) return fail(ZKHIP_ERR_INVALID, "fri_fold: bad arguments");
+    // the inverse-twiddle table of size 2^(log_h - 1) is a prefix of the table of any larger domain
+    const int need_log_n = log_h - 1 < 5 ? 5 : log_h - 1;
+    if (ctx->dom_log_n < need_log_n) ZK_TRY(ensure_domain(ctx, need_log_n));
+    Ext b{{beta[0], beta[1], beta[2], beta[3]}};
+    ZK_HIP(launch_fri_fold(d_in, d_out, ctx->dom_itw, (uint64_t)1 << (log_h - 1), b, ctx->stream));
+    return ZKHIP_OK;
 }
-size_t zkhip_proof_size(int, uint32_t, const zkhip_params*, size_t) { return 0; }
-int zkhip_prove_shard(zkhip_ctx*, const uint32_t*, size_t, int, uint32_t, const uint32_t*, size_t,
-                      const zkhip_params*, uint8_t*, size_t, size_t*) {
-    return fail(ZKHIP_ERR_INTERNAL, "prove_shard: not implemented yet");
+
+size_t zkhip_proof_size(int log_n, uint32_t width, const zkhip_params* prm, size_t n_public) {
+    (void)n_public;
+    if (check_shape(log_n, width, prm) != ZKHIP_OK) return 0;
+    return proof_words(log_n, width, prm) * 4;
 }
-int zkhip_verify_shard(const uint8_t*, size_t, int, uint32_t, const uint32_t*, size_t, const zkhip_params*, int*) {
-    return fail(ZKHIP_ERR_INTERNAL, "verify_shard: not implemented yet");
+
+int zkhip_prove_shard(zkhip_ctx* ctx, const uint32_t* d_trace, size_t ld, int log_n, uint32_t width,
+                      const uint32_t* public_values, size_t n_public, const zkhip_params* prm,
+                      uint8_t* proof, size_t cap, size_t* len) {
+    CHECK_CTX(ctx);
+    ZK_TRY(check_shape(log_n, width, prm));
+    if (!d_trace || !proof || !len || ld < width || (n_public && !public_values)) return fail(ZKHIP_ERR_INVALID, "prove_shard: bad arguments");
+    for (size_t i = 0; i < n_public; i++) if (public_values[i] >= P) return fail(ZKHIP_ERR_INVALID, "prove_shard: public values must be canonical");
+    const size_t need = proof_words(log_n, width, prm) * 4;
+    if (cap < need) return fail(ZKHIP_ERR_BUFFER, "prove_shard: proof buffer too small (see zkhip_proof_size)");
+    *len = 0;
+    const int H = log_n + 1, L = log_n, Q = prm->num_queries;
+    const size_t n = (size_t)1 << log_n, m = (size_t)1 << H;
+    hipStream_t st = ctx->stream;
+    ZK_TRY(ensure_domain(ctx, log_n));
+
+    uint32_t* pf = (uint32_t*)proof;
+    size_t pos = 0;
+    pf[pos++] = PROOF_MAGIC; pf[pos++] = PROOF_VERSION; pf[pos++] = (uint32_t)log_n; pf[pos++] = width;
+    pf[pos++] = (uint32_t)prm->log_blowup; pf[pos++] = (uint32_t)Q; pf[pos++] = (uint32_t)prm->pow_bits; pf[pos++] = (uint32_t)n_public;
+
+    Challenger ch;
+    transcript_init(ch, log_n, width, prm, n_public);
+    uint32_t root[8];
+
+    // ---- 1. commit the trace: LDE on g <w_2N> (bit-reversed rows) + Merkle tree
+    void *v_tlde, *v_ttree;
+    ZK_TRY(ctx_reserve(ctx, S_TLDE, m * width * 4, &v_tlde));
+    ZK_TRY(ctx_reserve(ctx, S_TTREE, (2 * m - 1) * 32, &v_ttree));
+    uint32_t* tlde = (uint32_t*)v_tlde; uint32_t* ttree = (uint32_t*)v_ttree;
+    ZK_TRY(op_coset_lde(ctx, d_trace, ld, tlde, width, log_n, width, 1, MONTY_GEN));
+    { MatDesc md{tlde, width, width}; ZK_TRY(op_merkle_commit(ctx, &md, 1, H, ttree)); }
+    ZK_TRY(d2h(ctx, root, ttree + (2 * m - 2) * 8, 32));
+    for (int i = 0; i < 8; i++) { ch.observe(root[i]); pf[pos++] = ctx->debug.trace_root[i] = from_monty(root[i]); }
+    for (size_t i = 0; i < n_public; i++) ch.observe_canonical(public_values[i]);
+
+    // ---- 2. constraint challenge, quotient chunks, their LDE + commitment
+    const Ext alpha = ch.sample_ext();
+    void *v_qchunk, *v_qlde, *v_qtree;
+    ZK_TRY(ctx_reserve(ctx, S_QCHUNK, 2 * n * 16, &v_qchunk));
+    ZK_TRY(ctx_reserve(ctx, S_QLDE, m * 8 * 4, &v_qlde));
+    ZK_TRY(ctx_reserve(ctx, S_QTREE, (2 * m - 1) * 32, &v_qtree));
+    uint32_t* qchunk = (uint32_t*)v_qchunk; uint32_t* qlde = (uint32_t*)v_qlde; uint32_t* qtree = (uint32_t*)v_qtree;
+    ZK_TRY(run_quotient(ctx, tlde, width, log_n, width, alpha, qchunk));
+    {
+        const uint32_t w2n = two_adic_generator(H);
+        for (int k = 0; k < 2; k++) {
+            // chunk k lives on (g w_2N^k) <w_N>; extend it to g <w_2N>: shift = g / (g w^k)
+            const uint32_t shift = finv(fpow(w2n, (uint64_t)k));
+            ZK_TRY(op_coset_lde(ctx, qchunk + (size_t)k * n * 4, 4, qlde + 4 * k, 8, log_n, 4, 1, shift));
+        }
+        MatDesc md{qlde, 8, 8};
+        ZK_TRY(op_merkle_commit(ctx, &md, 1, H, qtree));
+    }
+    ZK_TRY(d2h(ctx, root, qtree + (2 * m - 2) * 8, 32));
+    for (int i = 0; i < 8; i++) { ch.observe(root[i]); pf[pos++] = ctx->debug.quotient_root[i] = from_monty(root[i]); }
+
+    // ---- 3. out-of-domain point, openings
+    const Ext zeta = ch.sample_ext();
+    const Ext zpts[2] = {zeta, ext_mul_base(zeta, two_adic_generator(log_n))};
+    void *v_dinv, *v_open;
+    ZK_TRY(ctx_reserve(ctx, S_DINV, 2 * m * 16, &v_dinv));
+    ZK_TRY(ctx_reserve(ctx, S_OPEN_OUT, (2 * (size_t)width + 8) * 16, &v_open));
+    uint32_t* dinv = (uint32_t*)v_dinv; uint32_t* d_open = (uint32_t*)v_open;
+    ZK_HIP(launch_inv_denominators(ctx->dom_xs, m, zpts[0], zpts[1], 2, dinv, st));
+    ZK_TRY(run_open(ctx, tlde, width, log_n, width, zpts, 2, dinv, m, d_open));
+    ZK_HIP(hipStreamSynchronize(st));   // S_PARTIAL is reused by the next call
+    ZK_TRY(run_open(ctx, qlde, 8, log_n, 8, zpts, 1, dinv, m, d_open + 8 * (size_t)width));
+    std::vector<uint32_t> opened((2 * (size_t)width + 8) * 4);
+    ZK_TRY(d2h(ctx, opened.data(), d_open, opened.size() * 4));
+    for (size_t i = 0; i < opened.size(); i++) { ch.observe(opened[i]); pf[pos++] = from_monty(opened[i]); }
+    const Ext* op_loc = (const Ext*)opened.data();
+    const Ext* op_nxt = op_loc + width;
+    const Ext* op_q = op_nxt + width;
+
+    // ---- 4. FRI input: alpha-batched reduced openings at every LDE point
+    const Ext fa = ch.sample_ext();
+    const size_t np = width > 8 ? width : 8;
+    std::vector<Ext> fapow(np);
+    fapow[0] = ext_one();
+    for (size_t j = 1; j < np; j++) fapow[j] = ext_mul(fapow[j - 1], fa);
+    ReducedArgs ra{};
+    ra.y_loc = ra.y_next = ra.y_q = ext_zero();
+    for (size_t j = 0; j < width; j++) {
+        ra.y_loc = ext_add(ra.y_loc, ext_mul(fapow[j], op_loc[j]));
+        ra.y_next = ext_add(ra.y_next, ext_mul(fapow[j], op_nxt[j]));
+    }
+    for (size_t j = 0; j < 8; j++) ra.y_q = ext_add(ra.y_q, ext_mul(fapow[j], op_q[j]));
+    ra.off_next = ext_pow(fa, width);
+    ra.off_q = ext_pow(fa, 2 * (uint64_t)width);
+    void *v_apf, *v_layers, *v_ltrees;
+    ZK_TRY(ctx_reserve(ctx, S_APOW_F, np * 16, &v_apf));
+    ZK_TRY(h2d(ctx, v_apf, fapow.data(), np * 16));
+    ZK_TRY(ctx_reserve(ctx, S_FRI_LAYERS, 2 * m * 16, &v_layers));
+    ZK_TRY(ctx_reserve(ctx, S_FRI_TREES, 2 * m * 32, &v_ltrees));
+    uint32_t* layers = (uint32_t*)v_layers; uint32_t* ltrees = (uint32_t*)v_ltrees;
+    ra.tlde = tlde; ra.t_ld = width; ra.width = width; ra.qlde = qlde; ra.q_ld = 8; ra.rows = m;
+    ra.lanes_per_row = pow2ceil((int)(width / 4)) > 64 ? 64 : pow2ceil((int)(width / 4));
+    ra.alpha_pow = (const uint32_t*)v_apf; ra.dinv = dinv; ra.out = layers;
+    ZK_HIP(launch_reduced_opening(ra, st));
+
+    // ---- 5. FRI commit phase: commit, challenge, fold
+    std::vector<size_t> layer_off(L + 1), tree_off(L + 1);
+    {
+        size_t lo = 0, to = 0;
+        for (int l = 0; l <= L; l++) {
+            layer_off[l] = lo; tree_off[l] = to;
+            lo += ((size_t)1 << (H - l)) * 4;
+            if (l < L) to += (2 * ((size_t)1 << (H - 1 - l)) - 1) * 8;
+        }
+    }
+    for (int l = 0; l < L; l++) {
+        const int lh = H - 1 - l;
+        const size_t rows = (size_t)1 << lh;
+        uint32_t* cur = layers + layer_off[l];
+        uint32_t* tree = ltrees + tree_off[l];
+        MatDesc md{cur, 8, 8};
+        ZK_TRY(op_merkle_commit(ctx, &md, 1, lh, tree));
+        ZK_TRY(d2h(ctx, root, tree + (2 * rows - 2) * 8, 32));
+        for (int i = 0; i < 8; i++) { ch.observe(root[i]); pf[pos++] = from_monty(root[i]); }
+        const Ext beta = ch.sample_ext();
+        ZK_HIP(launch_fri_fold(cur, layers + layer_off[l + 1], ctx->dom_itw, rows, beta, st));
+    }
+    Ext fin[2];
+    ZK_TRY(d2h(ctx, fin, layers + layer_off[L], 32));
+    if (!ext_eq(fin[0], fin[1]))
+        return fail(ZKHIP_ERR_INVALID, "prove_shard: final FRI layer is not constant (the trace violates the AIR)");
+    for (int i = 0; i < 4; i++) pf[pos++] = from_monty(fin[0].c[i]);
+    ch.observe_ext(fin[0]);
+
+    // ---- 6. proof of work: smallest witness, searched 2^20 candidates per launch
+    uint32_t witness = 0xFFFFFFFFu;
+    {
+        GrindArgs ga{};
+        for (int i = 0; i < 16; i++) ga.state[i] = ch.state[i];
+        for (int i = 0; i < ch.n_in; i++) ga.state[i] = ch.in[i];
+        ga.slot = ch.n_in;
+        ga.mask = (1u << prm->pow_bits) - 1u;
+        void* v_res;
+        ZK_TRY(ctx_reserve(ctx, S_GATHER_OUT, 4, &v_res));
+        ZK_HIP(hipMemsetAsync(v_res, 0xFF, 4, st));
+        const uint32_t batch = 1u << 20;
+        for (uint64_t base = 0; base < P && witness == 0xFFFFFFFFu; base += batch) {
+            ZK_HIP(launch_grind(ga, (uint32_t)base, batch, (uint32_t*)v_res, st));
+            ZK_TRY(d2h(ctx, &witness, v_res, 4));
+        }
+        if (witness == 0xFFFFFFFFu) return fail(ZKHIP_ERR_INTERNAL, "prove_shard: no proof-of-work witness found");
+    }
+    ch.observe_canonical(witness);
+    if (ch.sample_bits(prm->pow_bits) != 0) return fail(ZKHIP_ERR_INTERNAL, "prove_shard: device and host disagree on the PoW witness");
+    pf[pos++] = ctx->debug.pow_witness = witness;
+
+    // ---- 7. queries: one gather launch over (row, path, sibling) descriptors
+    {
+        std::vector<GatherDesc> descs;
+        descs.reserve((size_t)Q * (4 + 2 * H + (size_t)L * (H + 1)));
+        size_t qpos = 0;   // word offset inside the query section
+        auto push = [&](const uint32_t* src, size_t nwords) { descs.push_back(GatherDesc{src, (uint32_t)qpos, (uint32_t)nwords}); qpos += nwords; };
+        auto push_path = [&](const uint32_t* tree, size_t leaves, size_t index, int levels) {
+            const uint32_t* lvl = tree; size_t cnt = leaves, idx = index;
+            for (int k = 0; k < levels; k++) { push(lvl + 8 * (idx ^ 1), 8); lvl += 8 * cnt; cnt >>= 1; idx >>= 1; }
+        };
+        for (int q = 0; q < Q; q++) {
+            const size_t index = ch.sample_bits(H);
+            push(tlde + index * width, width);
+            push_path(ttree, m, index, H);
+            push(qlde + index * 8, 8);
+            push_path(qtree, m, index, H);
+            size_t idx = index;
+            for (int l = 0; l < L; l++) {
+                const int lh = H - 1 - l;
+                const size_t sib = idx ^ 1, pair = idx >> 1;
+                push(layers + layer_off[l] + sib * 4, 4);
+                push_path(ltrees + tree_off[l], (size_t)1 << lh, pair, lh);
+                idx = pair;
+            }
+        }
+        if (pos + qpos != need / 4) return fail(ZKHIP_ERR_INTERNAL, "prove_shard: proof layout mismatch");
+        void *v_desc, *v_out;
+        ZK_TRY(ctx_reserve(ctx, S_GATHER_DESC, descs.size() * sizeof(GatherDesc), &v_desc));
+        ZK_TRY(ctx_reserve(ctx, S_GATHER_OUT, qpos * 4, &v_out));
+        ZK_TRY(h2d(ctx, v_desc, descs.data(), descs.size() * sizeof(GatherDesc)));
+        ZK_HIP(launch_gather((const GatherDesc*)v_desc, (uint32_t)descs.size(), (uint32_t*)v_out, st));
+        ZK_TRY(d2h(ctx, pf + pos, v_out, qpos * 4));
+        pos += qpos;
+    }
+    for (int i = 0; i < 4; i++) {
+        ctx->debug.alpha[i] = from_monty(alpha.c[i]);
+        ctx->debug.zeta[i] = from_monty(zeta.c[i]);
+        ctx->debug.fri_alpha[i] = from_monty(fa.c[i]);
+    }
+    *len = pos * 4;
+    return ZKHIP_OK;
 }
+
+// ---------------------------------------------------------------- verifier (host CPU)
+static bool verify_path(const uint32_t* root_m, int log_h, size_t index, const uint32_t* row_canon, size_t width,
+                        const uint32_t* sibs_canon) {
+    uint32_t s[16] = {0};
+    size_t posn = 0;
+    for (size_t i = 0; i < width; i++) {
+        s[posn++] = to_monty(row_canon[i]);
+        if (posn == 8) { p2_permute(s); posn = 0; }
+    }
+    if (posn) p2_permute(s);
+    uint32_t cur[8];
+    for (int i = 0; i < 8; i++) cur[i] = s[i];
+    for (int lvl = 0; lvl < log_h; lvl++) {
+        uint32_t sib[8];
+        for (int i = 0; i < 8; i++) sib[i] = to_monty(sibs_canon[8 * lvl + i]);
+        if ((index >> lvl) & 1) p2_compress(sib, cur, cur);
+        else p2_compress(cur, sib, cur);
+    }
+    for (int i = 0; i < 8; i++) if (cur[i] != root_m[i]) return false;
+    return true;
+}
+static Ext ext_from_canon(const uint32_t* p) { return Ext{{to_monty(p[0]), to_monty(p[1]), to_monty(p[2]), to_monty(p[3])}}; }
+static Ext fri_fold_row(size_t index, int log_folded_h, const Ext& beta, const Ext& e0, const Ext& e1) {
+    const uint32_t x = fpow(two_adic_generator(log_folded_h + 1), reverse_bits((uint32_t)index, log_folded_h));
+    const uint32_t inv = finv(fneg(fadd(x, x)));
+    return ext_add(e0, ext_mul_base(ext_mul(ext_sub_base(beta, x), ext_sub(e1, e0)), inv));
+}
+
+int zkhip_verify_shard(const uint8_t* proof, size_t len, int log_n, uint32_t width, const uint32_t* public_values,
+                       size_t n_public, const zkhip_params* prm, int* reason) {
+    int dummy;
+    if (!reason) reason = &dummy;
+    *reason = 0;
+    auto reject = [&](int why) { *reason = why; return fail(ZKHIP_ERR_VERIFY, "proof rejected (check " + std::to_string(why) + ")"); };
+    if (check_shape(log_n, width, prm) != ZKHIP_OK) return reject(1);
+    if (!proof || (n_public && !public_values)) return reject(1);
+    if (len != proof_words(log_n, width, prm) * 4) return reject(2);
+    const uint32_t* pf = (const uint32_t*)proof;
+    const int H = log_n + 1, L = log_n;
+    const size_t n = (size_t)1 << log_n;
+    if (pf[0] != PROOF_MAGIC || pf[1] != PROOF_VERSION || pf[2] != (uint32_t)log_n || pf[3] != width ||
+        pf[4] != (uint32_t)prm->log_blowup || pf[5] != (uint32_t)prm->num_queries || pf[6] != (uint32_t)prm->pow_bits ||
+        pf[7] != (uint32_t)n_public) return reject(3);
+    for (size_t i = 8; i < len / 4; i++) if (pf[i] >= P) return reject(4);
+    for (size_t i = 0; i < n_public; i++) if (public_values[i] >= P) return reject(4);
+    size_t pos = 8;
+    Challenger ch;
+    transcript_init(ch, log_n, width, prm, n_public);
+    uint32_t troot[8], qroot[8];
+    for (int i = 0; i < 8; i++) { troot[i] = to_monty(pf[pos++]); }
+    for (int i = 0; i < 8; i++) { qroot[i] = to_monty(pf[pos++]); }
+    for (int i = 0; i < 8; i++) ch.observe(troot[i]);
+    for (size_t i = 0; i < n_public; i++) ch.observe_canonical(public_values[i]);
+    const Ext alpha = ch.sample_ext();
+    for (int i = 0; i < 8; i++) ch.observe(qroot[i]);
+    const Ext zeta = ch.sample_ext();
+    const uint32_t gn = two_adic_generator(log_n);
+    const Ext zeta_next = ext_mul_base(zeta, gn);
+    std::vector<Ext> loc(width), nxt(width);
+    Ext opq[8];
+    for (size_t j = 0; j < width; j++) loc[j] = ext_from_canon(pf + pos + 4 * j);
+    pos += 4 * (size_t)width;
+    for (size_t j = 0; j < width; j++) nxt[j] = ext_from_canon(pf + pos + 4 * j);
+    pos += 4 * (size_t)width;
+    for (int j = 0; j < 8; j++) opq[j] = ext_from_canon(pf + pos + 4 * j);
+    pos += 32;
+    for (size_t j = 0; j < width; j++) ch.observe_ext(loc[j]);
+    for (size_t j = 0; j < width; j++) ch.observe_ext(nxt[j]);
+    for (int j = 0; j < 8; j++) ch.observe_ext(opq[j]);
+
+    // (a) the AIR identity at zeta: folded constraints / Z_H == sum_k zps_k * q_k
+    {
+        const Ext zn = ext_pow(zeta, n);
+        const Ext zh = ext_sub_base(zn, MONTY_R1);
+        const Ext sel_first = ext_mul(zh, ext_inv(ext_sub_base(zeta, MONTY_R1)));
+        const Ext sel_trans = ext_sub_base(zeta, finv(gn));
+        Ext acc = ext_zero();
+        for (uint32_t g = 0; g < width / 4; g++) {
+            const Ext &a = loc[4 * g], &b = loc[4 * g + 1], &c = loc[4 * g + 2], &d = loc[4 * g + 3], &dn = nxt[4 * g + 3];
+            const uint32_t k1 = to_monty(g + 1), k2 = to_monty(2 * g + 3), d0 = to_monty(5 * g + 7);
+            const Ext c1 = ext_sub_base(ext_sub(c, ext_mul(ext_mul(a, a), b)), k1);
+            const Ext c2 = ext_mul(sel_trans, ext_sub_base(ext_sub(ext_sub(dn, ext_mul(a, b)), c), k2));
+            const Ext c3 = ext_mul(sel_first, ext_sub_base(d, d0));
+            acc = ext_add(ext_mul(acc, alpha), c1);
+            acc = ext_add(ext_mul(acc, alpha), c2);
+            acc = ext_add(ext_mul(acc, alpha), c3);
+        }
+        const uint32_t w2n = two_adic_generator(H);
+        const uint32_t s[2] = {MONTY_GEN, fmul(MONTY_GEN, w2n)};
+        Ext quot = ext_zero();
+        for (int k = 0; k < 2; k++) {
+            const int j = 1 - k;
+            const uint32_t sjn_inv = finv(fpow(s[j], n));
+            const Ext num = ext_sub_base(ext_mul_base(zn, sjn_inv), MONTY_R1);
+            const uint32_t den = fsub(fmul(fpow(s[k], n), sjn_inv), MONTY_R1);
+            const Ext zps = ext_mul_base(num, finv(den));
+            Ext qk = ext_zero();
+            for (int e = 0; e < 4; e++) {
+                Ext basis = ext_zero();
+                basis.c[e] = MONTY_R1;
+                qk = ext_add(qk, ext_mul(basis, opq[4 * k + e]));
+            }
+            quot = ext_add(quot, ext_mul(zps, qk));
+        }
+        if (!ext_eq(ext_mul(acc, ext_inv(zh)), quot)) return reject(10);
+    }
+
+    // (b) FRI
+    const Ext fa = ch.sample_ext();
+    const size_t np = width > 8 ? width : 8;
+    std::vector<Ext> fapow(np);
+    fapow[0] = ext_one();
+    for (size_t j = 1; j < np; j++) fapow[j] = ext_mul(fapow[j - 1], fa);
+    Ext y_loc = ext_zero(), y_nxt = ext_zero(), y_q = ext_zero();
+    for (size_t j = 0; j < width; j++) {
+        y_loc = ext_add(y_loc, ext_mul(fapow[j], loc[j]));
+        y_nxt = ext_add(y_nxt, ext_mul(fapow[j], nxt[j]));
+    }
+    for (int j = 0; j < 8; j++) y_q = ext_add(y_q, ext_mul(fapow[j], opq[j]));
+    const Ext off_next = ext_pow(fa, width), off_q = ext_pow(fa, 2 * (uint64_t)width);
+    std::vector<uint32_t> commits((size_t)L * 8);
+    std::vector<Ext> betas(L);
+    for (int l = 0; l < L; l++) {
+        for (int i = 0; i < 8; i++) { commits[8 * l + i] = to_monty(pf[pos++]); ch.observe(commits[8 * l + i]); }
+        betas[l] = ch.sample_ext();
+    }
+    const Ext final_poly = ext_from_canon(pf + pos);
+    pos += 4;
+    ch.observe_ext(final_poly);
+    const uint32_t witness = pf[pos++];
+    ch.observe_canonical(witness);
+    if (ch.sample_bits(prm->pow_bits) != 0) return reject(20);
+    const uint32_t w2n = two_adic_generator(H);
+    for (int q = 0; q < prm->num_queries; q++) {
+        const size_t index = ch.sample_bits(H);
+        const uint32_t* trow = pf + pos; pos += width;
+        const uint32_t* tpath = pf + pos; pos += 8 * (size_t)H;
+        const uint32_t* qrow = pf + pos; pos += 8;
+        const uint32_t* qpath = pf + pos; pos += 8 * (size_t)H;
+        if (!verify_path(troot, H, index, trow, width, tpath)) return reject(30);
+        if (!verify_path(qroot, H, index, qrow, 8, qpath)) return reject(31);
+        const uint32_t x = fmul(MONTY_GEN, fpow(w2n, reverse_bits((uint32_t)index, H)));
+        const Ext d1 = ext_inv(ext_neg(ext_sub_base(zeta, x)));
+        const Ext d2 = ext_inv(ext_neg(ext_sub_base(zeta_next, x)));
+        Ext at = ext_zero(), aq = ext_zero();
+        for (size_t j = 0; j < width; j++) at = ext_add(at, ext_mul_base(fapow[j], to_monty(trow[j])));
+        for (int j = 0; j < 8; j++) aq = ext_add(aq, ext_mul_base(fapow[j], to_monty(qrow[j])));
+        Ext folded = ext_mul(ext_sub(at, y_loc), d1);
+        folded = ext_add(folded, ext_mul(off_next, ext_mul(ext_sub(at, y_nxt), d2)));
+        folded = ext_add(folded, ext_mul(off_q, ext_mul(ext_sub(aq, y_q), d1)));
+        size_t idx = index;
+        for (int l = 0; l < L; l++) {
+            const int lh = H - 1 - l;
+            const Ext sib = ext_from_canon(pf + pos);
+            const uint32_t* sib_canon = pf + pos;
+            pos += 4;
+            const uint32_t* path = pf + pos; pos += 8 * (size_t)lh;
+            Ext ev[2];
+            ev[idx & 1] = folded; ev[(idx & 1) ^ 1] = sib;
+            uint32_t rowbuf[8];
+            for (int i = 0; i < 4; i++) rowbuf[4 * (idx & 1) + i] = from_monty(folded.c[i]);
+            for (int i = 0; i < 4; i++) rowbuf[4 * ((idx & 1) ^ 1) + i] = sib_canon[i];
+            const size_t pair = idx >> 1;
+            if (!verify_path(&commits[8 * l], lh, pair, rowbuf, 8, path)) return reject(40 + (l < 50 ? l : 50));
+            folded = fri_fold_row(pair, lh, betas[l], ev[0], ev[1]);
+            idx = pair;
+        }
+        if (!ext_eq(folded, final_poly)) return reject(100);
+    }
+    if (pos * 4 != len) return reject(5);
+    return ZKHIP_OK;
+}
+
 int zkhip_last_prove_debug(zkhip_ctx* ctx, zkhip_prove_debug* out) {
     if (!ctx || !out) return fail(ZKHIP_ERR_INVALID, "null argument");
     *out = ctx->debug;

@@ -1,1 +1,271 @@
+// stark.hip -- gfx950 kernels for the STARK stages of a shard proof over the synthetic AIR:
+// domain tables, quotient values, out-of-domain opening (barycentric), alpha-batched
+// reduced openings, FRI fold, proof-of-work search and the query gather.
+//
+// Replaces, on the path below crates/guest-prover-sp1/src/sp1.rs:116: sp1-stark 4.1.4
+// `quotient_values` (reference Cargo.lock:6172), p3-uni-stark folders (:4055), p3-fri
+// TwoAdicFriPcs::open + prover::{commit_phase, answer_query} (:3930), p3-challenger
+// `grind` (:3875).  RISC Zero twins behind risc0-zkp Hal (:5057): eval_check,
+// batch_evaluate_any, mix_poly_coeffs, fri_fold, gather_sample.
+//
+// Layout: every matrix is row-major, rows in bit-reversed evaluation order (row p holds
+// the point x_p = g * w_2N^bitrev(p)); extension elements are 4 consecutive words.
+// Row-wise kernels give a row to a group of L <= 64 adjacent lanes so that a wave reads
+// whole rows with 16-byte loads and reduces with cross-lane shuffles (no LDS traffic).
+#include "poseidon2.cuh"
 #include "kernels.h"
+
+namespace zk {
+
+ZK_D Ext ld_ext(const uint32_t* p) {
+    uint4 v = *reinterpret_cast<const uint4*>(p);
+    return Ext{{v.x, v.y, v.z, v.w}};
+}
+ZK_D void st_ext(uint32_t* p, const Ext& e) { *reinterpret_cast<uint4*>(p) = make_uint4(e.c[0], e.c[1], e.c[2], e.c[3]); }
+
+// sum an extension element over the `width` lanes of a lane group (width power of two <= 64)
+ZK_D Ext group_sum(Ext v, int width) {
+    for (int off = width >> 1; off > 0; off >>= 1) {
+        Ext o;
+        o.c[0] = __shfl_down(v.c[0], off, width);
+        o.c[1] = __shfl_down(v.c[1], off, width);
+        o.c[2] = __shfl_down(v.c[2], off, width);
+        o.c[3] = __shfl_down(v.c[3], off, width);
+        v = ext_add(v, o);
+    }
+    return v;
+}
+
+// ------------------------------------------------------------------ domain tables
+__global__ void domain_tables_kernel(uint32_t* xs, uint32_t* sel_first, uint32_t* itw, int log_n, uint32_t g_pow_n) {
+    const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
+    const int H = log_n + 1;
+    if (p >= (1u << H)) return;
+    const uint32_t e = __brev(p) >> (32 - H);
+    const uint32_t w2n = two_adic_generator(H);
+    const uint32_t x = fmul(MONTY_GEN, fpow(w2n, e));
+    xs[p] = x;
+    const uint32_t xn = (e & 1) ? fneg(g_pow_n) : g_pow_n;        // x^N = g^N (-1)^e
+    const uint32_t zh = fsub(xn, MONTY_R1);
+    sel_first[p] = fmul(zh, finv(fsub(x, MONTY_R1)));
+    if (p < (1u << log_n)) {
+        const uint32_t ei = log_n ? (__brev(p) >> (32 - log_n)) : 0u;
+        itw[p] = fmul(finv(fpow(w2n, ei)), MONTY_INV2);            // 1 / (2 w_2N^bitrev_n(p))
+    }
+}
+hipError_t launch_domain_tables(uint32_t* xs, uint32_t* sel_first, uint32_t* itw, int log_n, hipStream_t s) {
+    const uint32_t m = 2u << log_n;
+    const uint32_t gpn = fpow(MONTY_GEN, (uint64_t)1 << log_n);
+    hipLaunchKernelGGL(domain_tables_kernel, dim3((m + 255) / 256), dim3(256), 0, s, xs, sel_first, itw, log_n, gpn);
+    return hipGetLastError();
+}
+
+// ------------------------------------------------------------------ quotient
+// acc = sum_k alpha^(K-1-k) C_k(x_p), k = 3 g + type, then * 1/Z_H(x_p).
+// Output in NATURAL chunk order: chunk (e & 1), row (e >> 1), e = bitrev(p).
+__global__ void __launch_bounds__(256) quotient_kernel(QuotientArgs a) {
+    const int L = a.lanes_per_row;
+    const uint32_t gid = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t p = gid / L;
+    const int lane = gid % L;
+    const int H = a.log_n + 1;
+    const uint32_t m = 1u << H;
+    if (p >= m) return;     // m*L is a multiple of the block size: whole groups exit together
+    const uint32_t e = __brev(p) >> (32 - H);
+    const uint32_t pn = __brev((e + 2) & (m - 1)) >> (32 - H);
+    const uint32_t* row = a.lde + (uint64_t)p * a.ld;
+    const uint32_t* nrow = a.lde + (uint64_t)pn * a.ld;
+    const uint32_t x = a.xs[p];
+    const uint32_t sel_first = a.sel_first[p];
+    const uint32_t sel_trans = fsub(x, a.wn_inv);
+    const Ext alpha = a.alpha, alpha2 = a.alpha2;
+    const uint32_t G = a.width / 4;
+    Ext acc = ext_zero();
+    for (uint32_t g = lane; g < G; g += L) {
+        const uint4 v = *reinterpret_cast<const uint4*>(row + 4 * g);
+        const uint32_t dn = nrow[4 * g + 3];
+        const uint32_t k1 = fmul(g + 1, MONTY_R2), k2 = fmul(2 * g + 3, MONTY_R2), d0 = fmul(5 * g + 7, MONTY_R2);
+        const uint32_t c1 = fsub(fsub(v.z, fmul(fmul(v.x, v.x), v.y)), k1);
+        const uint32_t c2 = fmul(sel_trans, fsub(fsub(fsub(dn, fmul(v.x, v.y)), v.z), k2));
+        const uint32_t c3 = fmul(sel_first, fsub(v.w, d0));
+        Ext loc = ext_add_base(ext_add(ext_mul_base(alpha2, c1), ext_mul_base(alpha, c2)), c3);
+        acc = ext_add(acc, ext_mul(loc, ld_ext(a.alpha_pow + 4 * g)));
+    }
+    acc = group_sum(acc, L);
+    if (lane == 0) {
+        acc = ext_mul_base(acc, (e & 1) ? a.inv_zh_odd : a.inv_zh_even);
+        const uint32_t chunk = e & 1, j = e >> 1;
+        st_ext(a.out + ((uint64_t)chunk * (m >> 1) + j) * 4, acc);
+    }
+}
+hipError_t launch_quotient(const QuotientArgs& a, hipStream_t s) {
+    const uint64_t m = 2ull << a.log_n;
+    const uint64_t threads = m * a.lanes_per_row;
+    hipLaunchKernelGGL(quotient_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, s, a);
+    return hipGetLastError();
+}
+
+// ------------------------------------------------------------------ 1 / (x_p - z)
+__global__ void __launch_bounds__(256) inv_denominators_kernel(const uint32_t* xs, uint64_t count, Ext z0, Ext z1, int npoints,
+                                                               uint32_t* out) {
+    const uint64_t p = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= count) return;
+    const uint32_t x = xs[p];
+    st_ext(out + 4 * p, ext_inv(ext_neg(ext_sub_base(z0, x))));
+    if (npoints > 1) st_ext(out + 4 * (count + p), ext_inv(ext_neg(ext_sub_base(z1, x))));
+}
+hipError_t launch_inv_denominators(const uint32_t* xs, uint64_t count, const Ext& z0, const Ext& z1, int npoints,
+                                   uint32_t* out, hipStream_t s) {
+    hipLaunchKernelGGL(inv_denominators_kernel, dim3((unsigned)((count + 255) / 256)), dim3(256), 0, s, xs, count, z0, z1, npoints, out);
+    return hipGetLastError();
+}
+
+// ------------------------------------------------------------------ barycentric opening
+// partial[chunk][pt][col] = sum_{q in chunk} (m[q][col] * x_q) * dinv_pt[q]
+constexpr int OPEN_ROWS = 2048;   // rows per workgroup
+template <int NPTS>
+__global__ void __launch_bounds__(256) open_partial_kernel(OpenArgs a) {
+    __shared__ uint32_t red[256 * 4];
+    const int TX = a.tx, TY = 256 / TX;
+    const int tx = threadIdx.x % TX, ty = threadIdx.x / TX;
+    const uint32_t col = blockIdx.y * TX + tx;
+    const uint64_t r0 = (uint64_t)blockIdx.x * OPEN_ROWS;
+    const bool active = col < a.width;
+    Ext acc[NPTS];
+#pragma unroll
+    for (int k = 0; k < NPTS; k++) acc[k] = ext_zero();
+    for (int r = ty; r < OPEN_ROWS; r += TY) {
+        const uint64_t q = r0 + r;
+        if (q >= a.rows) break;
+        const uint32_t v = active ? fmul(a.mat[q * a.ld + col], a.xs[q]) : 0u;
+#pragma unroll
+        for (int k = 0; k < NPTS; k++) acc[k] = ext_add(acc[k], ext_mul_base(ld_ext(a.dinv + 4 * ((uint64_t)k * a.dinv_stride + q)), v));
+    }
+#pragma unroll
+    for (int k = 0; k < NPTS; k++) {
+        __syncthreads();
+        for (int i = 0; i < 4; i++) red[threadIdx.x * 4 + i] = acc[k].c[i];
+        __syncthreads();
+        if (ty == 0 && active) {
+            Ext sum = acc[k];
+            for (int y = 1; y < TY; y++) {
+                Ext o = Ext{{red[(y * TX + tx) * 4], red[(y * TX + tx) * 4 + 1], red[(y * TX + tx) * 4 + 2], red[(y * TX + tx) * 4 + 3]}};
+                sum = ext_add(sum, o);
+            }
+            st_ext(a.partial + 4 * (((uint64_t)blockIdx.x * NPTS + k) * a.width + col), sum);
+        }
+    }
+}
+// out[pt][col] = -scale_pt * sum_chunk partial[chunk][pt][col]
+__global__ void __launch_bounds__(256) open_final_kernel(const uint32_t* partial, uint32_t nchunks, int npts, uint32_t width,
+                                                         Ext scale0, Ext scale1, uint32_t* out) {
+    const uint32_t idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (uint32_t)npts * width) return;
+    const uint32_t k = idx / width, col = idx % width;
+    Ext sum = ext_zero();
+    for (uint32_t c = 0; c < nchunks; c++) sum = ext_add(sum, ld_ext(partial + 4 * (((uint64_t)c * npts + k) * width + col)));
+    st_ext(out + 4 * (uint64_t)idx, ext_neg(ext_mul(sum, k ? scale1 : scale0)));
+}
+hipError_t launch_open(const OpenArgs& a, int npts, const Ext& scale0, const Ext& scale1, uint32_t* out, hipStream_t s) {
+    const uint32_t nchunks = (uint32_t)((a.rows + OPEN_ROWS - 1) / OPEN_ROWS);
+    dim3 grid(nchunks, (a.width + a.tx - 1) / a.tx);
+    if (npts == 1) hipLaunchKernelGGL(open_partial_kernel<1>, grid, dim3(256), 0, s, a);
+    else hipLaunchKernelGGL(open_partial_kernel<2>, grid, dim3(256), 0, s, a);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return e;
+    const uint32_t n = (uint32_t)npts * a.width;
+    hipLaunchKernelGGL(open_final_kernel, dim3((n + 255) / 256), dim3(256), 0, s, a.partial, nchunks, npts, a.width, scale0, scale1, out);
+    return hipGetLastError();
+}
+
+// ------------------------------------------------------------------ reduced openings (FRI input)
+// ro[p] = d1 (A_T - y_loc) + off_next d2 (A_T - y_next) + off_q d1 (A_Q - y_q),
+// A_T = sum_j alpha^j T[p][j], A_Q = sum_{j<8} alpha^j Q[p][j]
+__global__ void __launch_bounds__(256) reduced_opening_kernel(ReducedArgs a) {
+    const int L = a.lanes_per_row;
+    const uint64_t gid = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const uint64_t p = gid / L;
+    const int lane = (int)(gid % L);
+    if (p >= a.rows) return;
+    const uint32_t* row = a.tlde + p * a.t_ld;
+    Ext acc = ext_zero();
+    const uint32_t nq = a.width / 4;
+    for (uint32_t q = lane; q < nq; q += L) {
+        const uint4 v = *reinterpret_cast<const uint4*>(row + 4 * q);
+        const uint32_t* ap = a.alpha_pow + 16 * q;
+        acc = ext_add(acc, ext_mul_base(ld_ext(ap), v.x));
+        acc = ext_add(acc, ext_mul_base(ld_ext(ap + 4), v.y));
+        acc = ext_add(acc, ext_mul_base(ld_ext(ap + 8), v.z));
+        acc = ext_add(acc, ext_mul_base(ld_ext(ap + 12), v.w));
+    }
+    acc = group_sum(acc, L);
+    if (lane == 0) {
+        const uint32_t* qrow = a.qlde + p * a.q_ld;
+        Ext aq = ext_zero();
+#pragma unroll
+        for (int j = 0; j < 8; j++) aq = ext_add(aq, ext_mul_base(ld_ext(a.alpha_pow + 4 * j), qrow[j]));
+        const Ext d1 = ld_ext(a.dinv + 4 * p), d2 = ld_ext(a.dinv + 4 * (a.rows + p));
+        Ext r = ext_mul(ext_sub(acc, a.y_loc), d1);
+        r = ext_add(r, ext_mul(a.off_next, ext_mul(ext_sub(acc, a.y_next), d2)));
+        r = ext_add(r, ext_mul(a.off_q, ext_mul(ext_sub(aq, a.y_q), d1)));
+        st_ext(a.out + 4 * p, r);
+    }
+}
+hipError_t launch_reduced_opening(const ReducedArgs& a, hipStream_t s) {
+    const uint64_t threads = a.rows * a.lanes_per_row;
+    hipLaunchKernelGGL(reduced_opening_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, s, a);
+    return hipGetLastError();
+}
+
+// ------------------------------------------------------------------ FRI fold (arity 2)
+// out[i] = (e0 + e1)/2 + beta (e0 - e1) / (2 x_i),  itw[i] = 1 / (2 x_i)
+__global__ void __launch_bounds__(256) fri_fold_kernel(const uint32_t* in, uint32_t* out, const uint32_t* itw, uint64_t half, Ext beta) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= half) return;
+    const Ext e0 = ld_ext(in + 8 * i), e1 = ld_ext(in + 8 * i + 4);
+    const Ext s = ext_mul_base(ext_add(e0, e1), MONTY_INV2);
+    const Ext d = ext_mul_base(ext_sub(e0, e1), itw[i]);
+    st_ext(out + 4 * i, ext_add(s, ext_mul(beta, d)));
+}
+hipError_t launch_fri_fold(const uint32_t* in, uint32_t* out, const uint32_t* itw, uint64_t half, const Ext& beta, hipStream_t s) {
+    hipLaunchKernelGGL(fri_fold_kernel, dim3((unsigned)((half + 255) / 256)), dim3(256), 0, s, in, out, itw, half, beta);
+    return hipGetLastError();
+}
+
+// ------------------------------------------------------------------ proof-of-work search
+// state: sponge state with the pending inputs already written to words [0, slot);
+// candidate w goes to word `slot`; hit when canonical(permute(state)[7]) & mask == 0.
+__global__ void __launch_bounds__(256) grind_kernel(GrindArgs a, uint32_t base, uint32_t* result) {
+    const uint32_t w = base + blockIdx.x * blockDim.x + threadIdx.x;
+    if (w >= P) return;
+    uint32_t s[16];
+#pragma unroll
+    for (int i = 0; i < 16; i++) s[i] = a.state[i];
+    const uint32_t wm = fmul(w, MONTY_R2);
+#pragma unroll
+    for (int i = 0; i < 8; i++) if (i == a.slot) s[i] = wm;
+    p2_permute(s);
+    if ((from_monty(s[7]) & a.mask) == 0) atomicMin(result, w);
+}
+hipError_t launch_grind(const GrindArgs& a, uint32_t base, uint32_t count, uint32_t* result, hipStream_t s) {
+    hipLaunchKernelGGL(grind_kernel, dim3((count + 255) / 256), dim3(256), 0, s, a, base, result);
+    return hipGetLastError();
+}
+
+// ------------------------------------------------------------------ query gather
+// one wave per descriptor: copy nwords from src, Montgomery -> canonical, to dst + off
+__global__ void __launch_bounds__(256) gather_kernel(const GatherDesc* descs, uint32_t ndesc, uint32_t* dst) {
+    const uint32_t d = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const uint32_t lane = threadIdx.x & 63;
+    if (d >= ndesc) return;
+    const GatherDesc g = descs[d];
+    for (uint32_t i = lane; i < g.nwords; i += 64) dst[g.dst_off + i] = from_monty(g.src[i]);
+}
+hipError_t launch_gather(const GatherDesc* descs, uint32_t ndesc, uint32_t* dst, hipStream_t s) {
+    if (ndesc == 0) return hipSuccess;
+    const uint64_t threads = (uint64_t)ndesc * 64;
+    hipLaunchKernelGGL(gather_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, s, descs, ndesc, dst);
+    return hipGetLastError();
+}
+
+}  // namespace zk
