@@ -1,0 +1,197 @@
+#!/usr/bin/env python3
+"""Contract benchmark: whole-shard STARK proofs on MI355X through libzkhip's C ABI.
+
+  python bench.py --gpus N --steps K --warmup W
+  (N > 1: launched by torch.distributed.run, one rank per GPU, RCCL backend)
+
+One "step" = one complete shard proof (commit trace -> quotient -> openings -> FRI ->
+PoW -> queries) of a synthetic SP1-core-like shard: 2^20 rows x 256 columns, log_blowup 1,
+100 queries, 16 PoW bits (BASELINE.json configs[1] / SURVEY.md 8d).  The trace is resident
+in HBM before the timed region.  Shards are independent: rank r proves shards r*K..r*K+K-1
+(weak scaling, no data-path collective); RCCL broadcasts the 8-word batch transcript seed.
+
+Prints ONE JSON line (rank 0): metric trace-cells/s (+ proofs/s), `roofline` for the NTT
+pass kernel (HIP events on the launch stream) and `cpu_baseline` (the CPU oracle timed on
+the host cores, bounded sample, N = 1 only).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+SEED = 0x5A4B544C53
+HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: 8 TB/s spec
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--log-n", type=int, default=20)
+    ap.add_argument("--width", type=int, default=256)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-log-n", type=int, default=15, help="rows of the bounded CPU-baseline sample")
+    args = ap.parse_args()
+
+    import numpy as np
+    import torch
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("--gpus %d needs torch.distributed.run with --nproc-per-node %d" % (args.gpus, args.gpus))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: libzkhip has no CPU path")
+    torch.cuda.set_device(local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist_mod
+        dist = dist_mod
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="nccl", rank=rank, world_size=world,
+                                device_id=torch.device("cuda", local_rank))
+
+    from zktls_amd._lib import Params
+    from zktls_amd.device import Context, verify_shard
+
+    log_n, width = args.log_n, args.width
+    n = 1 << log_n
+    cells = n * width
+    prm = Params(1, 100, 16)
+    stream = torch.cuda.Stream(device=local_rank)
+    ctx = Context(local_rank, stream=stream.cuda_stream)
+
+    # batch transcript seed: rank 0 draws it, RCCL broadcasts it (the only collective)
+    seed_words = torch.tensor([(SEED >> (8 * i)) & 0xFF for i in range(8)], dtype=torch.int32, device="cuda")
+    if dist is not None:
+        dist.broadcast(seed_words, src=0)
+    public = [int(x) for x in seed_words.tolist()]
+
+    K, W = args.steps, args.warmup
+    nbuf = min(max(K, 1), 4)
+    with torch.cuda.stream(stream):
+        traces = [torch.empty(cells, dtype=torch.int32, device="cuda") for _ in range(nbuf)]
+    bufs = [ctx.wrap(t) for t in traces]
+    for i, b in enumerate(bufs):
+        ctx.gen_trace(SEED, rank * max(K, 1) + i, log_n, width, out=b)
+    ctx.sync()
+
+    def step(i):
+        return ctx.prove_shard(bufs[i % nbuf], log_n, width, public + [rank * max(K, 1) + (i % nbuf)], prm)
+
+    for i in range(W):
+        step(i)
+    ctx.sync()
+
+    def barrier():
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    barrier()
+    t0 = time.perf_counter()
+    last = None
+    for i in range(K):
+        last = step(i)
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    # the last proof of the timed region must verify (host verifier of the product)
+    rc, reason = verify_shard(last, log_n, width, public + [rank * max(K, 1) + ((K - 1) % nbuf)], prm)
+    verified = rc == 0
+
+    # ---- roofline of the dominant kernel: one NTT pass = 8 B/element (read 4 + write 4)
+    roof = None
+    if rank == 0:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        with torch.cuda.stream(stream):
+            scratch = torch.empty(cells, dtype=torch.int32, device="cuda")
+        sbuf = ctx.wrap(scratch)
+        reps = 20
+        per_which = []
+        for which in (0, 1):
+            for _ in range(3):
+                ctx.ntt_pass(bufs[0], sbuf, log_n, width, which)
+            e0.record(stream)
+            for _ in range(reps):
+                ctx.ntt_pass(bufs[0], sbuf, log_n, width, which)
+            e1.record(stream)
+            e1.synchronize()
+            per_which.append(e0.elapsed_time(e1) / reps)
+        avg_ms = sum(per_which) / len(per_which)
+        alg_bytes = 8.0 * cells
+        achieved = alg_bytes / (avg_ms * 1e-3) / 1e9
+        traffic = None
+        pmc = os.path.join(ROOT, "profiles", "pmc_ntt_pass.json")
+        if os.path.exists(pmc):
+            try:
+                traffic = json.load(open(pmc)).get("hbm_bytes_per_launch")
+            except Exception:
+                traffic = None
+        roof = {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
+                "kernel": "zk::ntt_pass_kernel<4,false>", "algorithmic_bytes_per_launch": alg_bytes,
+                "avg_launch_ms": round(avg_ms, 4),
+                "per_pass_ms": {"strided": round(per_which[0], 4), "contiguous": round(per_which[1], 4)}}
+
+    # ---- CPU baseline: the oracle on the host cores, bounded sample of the same workload
+    cpu = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        sys.path.insert(0, os.path.join(ROOT, "tests"))
+        import oracle_lib as O
+        cores = os.cpu_count() or 1
+        used = O.set_threads(cores)
+        cl = args.cpu_log_n
+        tr = O.gen_trace(SEED, 0, cl, width)
+        oprm = O.default_params(1, 100, 16)
+        tc0 = time.perf_counter()
+        O.prove_shard(tr, public + [0], oprm)
+        dt = time.perf_counter() - tc0
+        cpu = {"value": round((width << cl) / dt, 1), "unit": "trace-cells/s", "cores": used, "kind": "port",
+               "sample": "one 2^%d x %d shard proof (same AIR, log_blowup 1, 100 queries, 16 PoW bits), %.1f s, scalar C oracle + OpenMP" % (cl, width, dt)}
+
+    if rank == 0:
+        total_cells = cells * K * world
+        out = {
+            "metric": "trace-cells/s",
+            "value": round(total_cells / elapsed, 1),
+            "unit": "trace-cells/s",
+            "n_gpus": world,
+            "steps": K,
+            "warmup": W,
+            "ms_per_step": round(elapsed / K * 1e3, 3),
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "u32",
+            "data": "synthetic",
+            "config": {"workload": "SP1-core-like synthetic shard: 2^%d rows x %d cols BabyBear, log_blowup 1, 100 queries, 16 PoW bits, full prove_shard" % (log_n, width),
+                       "parallelism": "shard-parallel x%d" % world, "shards_per_step": world},
+            "proofs_per_s": round(K * world / elapsed, 3),
+            "proof_bytes": int(last.size),
+            "verified": bool(verified),
+            "roofline": roof,
+            "cpu_baseline": cpu,
+        }
+        print(json.dumps(out), flush=True)
+    ctx.close()
+    if dist is not None:
+        dist.destroy_process_group()
+    if not verified:
+        raise SystemExit("last proof failed verification (reason %d)" % reason)
+
+
+if __name__ == "__main__":
+    main()
