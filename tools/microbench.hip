@@ -181,6 +181,63 @@ __global__ void __launch_bounds__(256) k_fadd(uint32_t* out, uint32_t seed) {
     out[blockIdx.x * blockDim.x + threadIdx.x] = r;
 }
 
+// tuned device primitives (babybear.cuh): dmul = 2 mad_u64 + mul_lo + subrev_co + cndmask
+__global__ void __launch_bounds__(256) k_dmul(uint32_t* out, uint32_t seed) {
+    uint32_t a[NACC];
+    uint32_t b = (seed | 1u) % zk::P;
+#pragma unroll
+    for (int i = 0; i < NACC; i++) a[i] = (threadIdx.x * 7u + i + seed) % zk::P;
+    for (int it = 0; it < ITER; it++) {
+#pragma unroll
+        for (int u = 0; u < UNROLL; u++) {
+#pragma unroll
+            for (int i = 0; i < NACC; i++) a[i] = zk::dmul(a[i], b);
+        }
+    }
+    uint32_t r = 0;
+#pragma unroll
+    for (int i = 0; i < NACC; i++) r ^= a[i];
+    out[blockIdx.x * blockDim.x + threadIdx.x] = r;
+}
+__global__ void __launch_bounds__(256) k_dadd(uint32_t* out, uint32_t seed) {
+    uint32_t a[NACC];
+    uint32_t b = (threadIdx.x * 13u + seed) % zk::P;
+#pragma unroll
+    for (int i = 0; i < NACC; i++) a[i] = (threadIdx.x * 7u + i + seed) % zk::P;
+    for (int it = 0; it < ITER; it++) {
+#pragma unroll
+        for (int u = 0; u < UNROLL; u++) {
+#pragma unroll
+            for (int i = 0; i < NACC; i++) a[i] = zk::dadd(a[i], b);
+        }
+    }
+    uint32_t r = 0;
+#pragma unroll
+    for (int i = 0; i < NACC; i++) r ^= a[i];
+    out[blockIdx.x * blockDim.x + threadIdx.x] = r;
+}
+__global__ void __launch_bounds__(256) k_dbutterfly(uint32_t* out, uint32_t seed) {
+    uint32_t a[NACC];
+    uint32_t b = (threadIdx.x * 13u + seed) % zk::P;
+#pragma unroll
+    for (int i = 0; i < NACC; i++) a[i] = (threadIdx.x * 7u + i + seed) % zk::P;
+    for (int it = 0; it < ITER; it++) {
+#pragma unroll
+        for (int u = 0; u < UNROLL; u++) {
+#pragma unroll
+            for (int i = 0; i < NACC; i += 2) {
+                uint32_t s = zk::dadd(a[i], a[i + 1]);
+                uint32_t d = zk::dmul(zk::dsub_lazy(a[i], a[i + 1]), b);
+                a[i] = s; a[i + 1] = d;
+            }
+        }
+    }
+    uint32_t r = 0;
+#pragma unroll
+    for (int i = 0; i < NACC; i++) r ^= a[i];
+    out[blockIdx.x * blockDim.x + threadIdx.x] = r;
+}
+
 typedef void (*opk_t)(uint32_t*, uint32_t);
 
 static void run_op(const char* name, opk_t k, double ops_per_thread_inst, int blocks_per_cu) {
@@ -361,6 +418,9 @@ int main(int argc, char** argv) {
         run_op("monty fmul", k_fmul, 1, bpc);
         run_op("monty fadd", k_fadd, 1, bpc);
         run_op("butterfly(x0.5)", k_butterfly, 0.5, bpc);
+        run_op("tuned dmul", k_dmul, 1, bpc);
+        run_op("tuned dadd", k_dadd, 1, bpc);
+        run_op("tuned butterfly(x0.5)", k_dbutterfly, 0.5, bpc);
     }
     run_mem();
     return 0;

@@ -37,8 +37,9 @@ ZK_HD constexpr uint32_t monty_reduce(uint64_t x) {
     uint32_t hi = (uint32_t)(x >> 32);
     uint32_t m = lo * MONTY_MU;
     uint32_t t = (uint32_t)(((uint64_t)m * P) >> 32);
-    uint32_t r = hi - t;
-    return hi < t ? r + P : r;
+    uint32_t r = hi - t;          // in (-P, P): wraps high when hi < t
+    uint32_t r2 = r + P;
+    return r < r2 ? r : r2;       // unsigned min picks the in-range one
 }
 ZK_HD constexpr uint32_t fmul(uint32_t a, uint32_t b) { return monty_reduce((uint64_t)a * b); }
 ZK_HD constexpr uint32_t fadd(uint32_t a, uint32_t b) {
@@ -70,6 +71,39 @@ ZK_HD constexpr uint32_t two_adic_generator(int bits) {
 constexpr uint32_t MONTY_GEN = to_monty(GEN);
 constexpr uint32_t MONTY_EXT_W = to_monty(EXT_W);
 constexpr uint32_t MONTY_INV2 = to_monty((P + 1) / 2);
+
+// ---- gfx950-tuned device primitives ------------------------------------------------------
+// Measured on MI355X (tools/microbench): add/sub/logic/shift 2.4 clk per wave64 instruction,
+// min/max/add3/lshl_add/*_co and every integer multiply 4.2 clk, and a v_cndmask right
+// behind the v_sub_co that feeds it is nearly free (pair = 4.8 clk).  So:
+//   dmont_lazy : 2 x v_mad_u64_u32 + v_mul_lo_u32 (12.8 clk), result in [0, 2P), no fix-up;
+//                the multiplicand may be ANY 32-bit value as long as the other factor is < P
+//   dred       : [0, 2P) -> [0, P) as v_subrev_co + v_cndmask (4.8 clk)
+//   dsub_lazy  : a - b + P in (0, 2P), two plain adds (4.8 clk), feeds dmont_lazy directly
+#if defined(__HIPCC__)
+constexpr uint32_t MONTY_MU_NEG = 0x77ffffffu;   // -P^-1 mod 2^32
+ZK_D uint32_t dmont_lazy(uint32_t a, uint32_t b) {
+    uint64_t x = (uint64_t)a * b;
+    uint32_t m = (uint32_t)x * MONTY_MU_NEG;
+    uint64_t y = x + (uint64_t)m * P;            // low word cancels; < 2^33 P
+    return (uint32_t)(y >> 32);
+}
+ZK_D uint32_t dred(uint32_t x) {
+    uint32_t t;
+    asm("v_subrev_co_u32_e32 %0, vcc, 0x78000001, %1\n\tv_cndmask_b32_e32 %0, %0, %1, vcc" : "=&v"(t) : "v"(x) : "vcc");
+    return t;
+}
+ZK_D uint32_t dmul(uint32_t a, uint32_t b) { return dred(dmont_lazy(a, b)); }
+ZK_D uint32_t dadd(uint32_t a, uint32_t b) { return dred(a + b); }
+ZK_D uint32_t dsub(uint32_t a, uint32_t b) {
+    uint32_t t, u;
+    asm("v_sub_co_u32_e32 %0, vcc, %2, %3\n\tv_add_u32_e32 %1, 0x78000001, %0\n\tv_cndmask_b32_e32 %0, %0, %1, vcc"
+        : "=&v"(t), "=&v"(u) : "v"(a), "v"(b) : "vcc");
+    return t;
+}
+ZK_D uint32_t dsub_lazy(uint32_t a, uint32_t b) { return a + (P - b); }
+ZK_D uint32_t ddbl(uint32_t a) { return dred(a + a); }
+#endif
 
 // ---- quartic extension, coefficients in Montgomery form ----
 struct Ext { uint32_t c[4]; };

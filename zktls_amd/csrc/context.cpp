@@ -5,6 +5,7 @@
 #include "context.h"
 
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 
 namespace zk {
@@ -92,6 +93,11 @@ static NttPassArgs base_args(zkhip_ctx* ctx, const uint32_t* in, size_t in_ld, u
     a.in = in; a.out = out; a.in_ld = in_ld; a.out_ld = out_ld; a.ncols = width;
     a.w1024 = inverse ? ctx->w1024_inv : ctx->w1024_fwd;
     a.map_mode = 1;
+    // tuning knobs for A/B runs (never needed for correctness)
+    static const int force_cpt = [] { const char* e = getenv("ZKHIP_NTT_CPT"); return e ? atoi(e) : 0; }();
+    static const int map_mode = [] { const char* e = getenv("ZKHIP_NTT_MAP"); return e ? atoi(e) : 1; }();
+    a.cols_per_thread = (uint32_t)force_cpt;
+    a.map_mode = (uint32_t)map_mode;
     return a;
 }
 

@@ -38,7 +38,7 @@ __global__ void __launch_bounds__(256) hash_rows_generic_kernel(LeafArgs a, uint
 #pragma unroll
         for (int i = 0; i < 8; i++)
             if (q + i < total_w) s[i] = load_virtual(a, row, q + i);
-        p2_permute(s);
+        p2_permute_dev(s);
     }
     uint4* d = reinterpret_cast<uint4*>(a.digests + row * 8);
     d[0] = make_uint4(s[0], s[1], s[2], s[3]);
@@ -59,7 +59,7 @@ __global__ void __launch_bounds__(256) hash_rows_vec_kernel(const uint32_t* __re
         uint4 v0 = rp[2 * q], v1 = rp[2 * q + 1];
         s[0] = v0.x; s[1] = v0.y; s[2] = v0.z; s[3] = v0.w;
         s[4] = v1.x; s[5] = v1.y; s[6] = v1.z; s[7] = v1.w;
-        p2_permute(s);
+        p2_permute_dev(s);
     }
     uint4* d = reinterpret_cast<uint4*>(digests + row * 8);
     d[0] = make_uint4(s[0], s[1], s[2], s[3]);
@@ -87,7 +87,7 @@ __device__ __forceinline__ void compress_node(const uint32_t* children, uint32_t
     uint4 v0 = cp[0], v1 = cp[1], v2 = cp[2], v3 = cp[3];
     uint32_t s[16] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w,
                       v2.x, v2.y, v2.z, v2.w, v3.x, v3.y, v3.z, v3.w};
-    p2_permute(s);
+    p2_permute_dev(s);
     uint4* d = reinterpret_cast<uint4*>(parent);
     d[0] = make_uint4(s[0], s[1], s[2], s[3]);
     d[1] = make_uint4(s[4], s[5], s[6], s[7]);
@@ -130,7 +130,7 @@ __global__ void __launch_bounds__(256) permute_states_kernel(uint32_t* states, u
     uint32_t s[16];
 #pragma unroll
     for (int k = 0; k < 16; k++) s[k] = states[16 * i + k];
-    p2_permute(s);
+    p2_permute_dev(s);
 #pragma unroll
     for (int k = 0; k < 16; k++) states[16 * i + k] = s[k];
 }

@@ -28,6 +28,7 @@ struct NttPassArgs {
     uint64_t out_tile_mul, out_stride;
     uint32_t bitrev_out;
     uint32_t map_mode;               // 0: column group fastest; 1: XCD-aware
+    uint32_t cols_per_thread;        // 2: two columns per lane when the shape allows (A/B knob); else 1
     const uint32_t* w1024;           // w_1024^e (forward) or w_1024^-e (inverse), e < 1024
     const uint32_t* pre;             // [M] or nullptr
     const uint32_t* post;            // [num_tiles * M] or nullptr

@@ -38,27 +38,42 @@ constexpr int rev5(int r) {
     return ((r & 1) << 4) | ((r & 2) << 2) | (r & 4) | ((r & 8) >> 2) | ((r & 16) >> 4);
 }
 
-// stage S of the 32-point decimation-in-frequency network (S = 0 pairs i, i+16)
-template <bool INV, int S>
+// stage S of the 32-point decimation-in-frequency network (S = 0 pairs i, i+16).
+// Inputs are canonical.  The difference is taken lazily (a - b + P, any 32-bit value is a valid
+// Montgomery multiplicand), so a butterfly is add + dred, two plain adds, dmont_lazy + dred.
+// LAZY_OUT (only legal for the twiddle-free stage 4): sums and differences are left in
+// [0, 2P) because the next thing that touches them is a Montgomery multiplication.
+template <bool INV, int S, bool LAZY_OUT = false>
 ZK_D void dif_stage(uint32_t (&x)[32]) {
     constexpr int half = 16 >> S;
     constexpr int stride = 16 / half;
+    static_assert(!LAZY_OUT || S == 4, "lazy outputs only after the twiddle-free stage");
 #pragma unroll
     for (int base = 0; base < 32; base += 2 * half) {
 #pragma unroll
         for (int j = 0; j < half; j++) {
-            uint32_t a = x[base + j], b = x[base + j + half];
-            x[base + j] = fadd(a, b);
-            uint32_t d = fsub(a, b);
-            x[base + j + half] = (j == 0) ? d : fmul(d, (INV ? TW32_INV : TW32_FWD).w[j * stride]);
+            const uint32_t a = x[base + j], b = x[base + j + half];
+            if (LAZY_OUT) {
+                x[base + j] = a + b;
+                x[base + j + half] = dsub_lazy(a, b);
+            } else {
+                x[base + j] = dadd(a, b);
+                x[base + j + half] = (j == 0) ? dsub(a, b) : dmul(dsub_lazy(a, b), (INV ? TW32_INV : TW32_FWD).w[j * stride]);
+            }
         }
     }
 }
 
-template <int LOG_C, bool INV>
-__global__ void __launch_bounds__(32 << LOG_C) ntt_pass_kernel(NttPassArgs a) {
+// CPT = columns per thread.  CPT = 2 doubles the row chunk a wave touches to 128 B (16 lanes
+// x 8 B), which the HBM likes much better than 64 B (tools/microbench: 5.1-5.5 vs 3.8-4.8
+// TB/s for the same tile shapes), and halves the twiddle-table LDS reads per element.  The
+// LDS exchange then runs once per column, reusing one 64 KiB buffer, so two workgroups
+// still fit a CU.
+template <int LOG_C, bool INV, int CPT>
+__global__ void __launch_bounds__(32 << LOG_C, 4) ntt_pass_kernel(NttPassArgs a) {
     extern __shared__ uint32_t lds[];
-    constexpr int C = 1 << LOG_C;
+    constexpr int C = 1 << LOG_C;          // lanes along the row chunk
+    constexpr int TC = C * CPT;            // tile columns
     const int b = (int)a.log_m - 5;
     const int Pn = 1 << b;
     const int M = 32 << b;
@@ -72,7 +87,7 @@ __global__ void __launch_bounds__(32 << LOG_C) ntt_pass_kernel(NttPassArgs a) {
     const int c = tid & (C - 1);
     const int u = tid >> LOG_C;
 
-    const uint32_t ncg = (a.ncols + C - 1) >> LOG_C;
+    const uint32_t ncg = (a.ncols + TC - 1) / TC;
     uint32_t tile, cg;
     if (a.map_mode == 1) {
         // blocks b and b+8 share an XCD (round-robin dispatch): keep the column groups
@@ -84,21 +99,29 @@ __global__ void __launch_bounds__(32 << LOG_C) ntt_pass_kernel(NttPassArgs a) {
         cg = blockIdx.x % ncg;
         tile = blockIdx.x / ncg;
     }
-    const uint32_t col = cg * C + c;
-    const bool active = col < a.ncols;
+    const uint32_t col = cg * TC + c * CPT;
+    const bool active = col < a.ncols;      // CPT = 2 requires an even width: both or none
+    const uint32_t lcol = active ? col : 0u;   // inactive lanes load a valid address, never store
 
     // ---- global -> registers (32 independent loads in flight per lane)
-    uint32_t x[32];
+    uint32_t x[CPT][32];
     {
-        const uint32_t* ip = a.in + ((uint64_t)tile * a.in_tile_mul + (uint64_t)u * a.in_stride) * a.in_ld + col;
+        const uint32_t* ip = a.in + ((uint64_t)tile * a.in_tile_mul + (uint64_t)u * a.in_stride) * a.in_ld + lcol;
         const uint64_t istep = (uint64_t)Pn * a.in_stride * a.in_ld;
 #pragma unroll
-        for (int n1 = 0; n1 < 32; n1++) x[n1] = active ? ip[(uint64_t)n1 * istep] : 0u;
+        for (int n1 = 0; n1 < 32; n1++) {
+            if (CPT == 2) {
+                const uint2 v = *reinterpret_cast<const uint2*>(ip + (uint64_t)n1 * istep);
+                x[0][n1] = v.x; x[CPT - 1][n1] = v.y;
+            } else {
+                x[0][n1] = ip[(uint64_t)n1 * istep];
+            }
+        }
     }
     // ---- twiddle tables -> LDS while the loads fly
+    const bool has_post = a.post != nullptr, has_pre = a.pre != nullptr;
     {
         const int sh = 5 - b;
-        const bool has_post = a.post != nullptr, has_pre = a.pre != nullptr;
         for (int i = tid; i < M; i += blockDim.x) {
             stw[i] = a.w1024[i << sh];
             if (has_post) spost[i] = a.post[(uint64_t)tile * M + i];
@@ -106,50 +129,77 @@ __global__ void __launch_bounds__(32 << LOG_C) ntt_pass_kernel(NttPassArgs a) {
         }
     }
     __syncthreads();
-    if (a.pre != nullptr) {
+    if (has_pre) {
 #pragma unroll
-        for (int n1 = 0; n1 < 32; n1++) x[n1] = fmul(x[n1], spre[u + Pn * n1]);
+        for (int n1 = 0; n1 < 32; n1++) {
+            const uint32_t w = spre[u + Pn * n1];
+#pragma unroll
+            for (int cc = 0; cc < CPT; cc++) x[cc][n1] = dmul(x[cc][n1], w);
+        }
     }
 
     // ---- phase A: 32-point DIF over n1; x[r] <- A[rev5(r)]
-    dif_stage<INV, 0>(x);
-    dif_stage<INV, 1>(x);
-    dif_stage<INV, 2>(x);
-    dif_stage<INV, 3>(x);
-    dif_stage<INV, 4>(x);
+#pragma unroll
+    for (int cc = 0; cc < CPT; cc++) {
+        dif_stage<INV, 0>(x[cc]);
+        dif_stage<INV, 1>(x[cc]);
+        dif_stage<INV, 2>(x[cc]);
+        dif_stage<INV, 3>(x[cc]);
+        dif_stage<INV, 4, true>(x[cc]);    // lazy: every output is multiplied (or reduced) next
+    }
+    // ---- tile twiddle w_M^(u*k1)
+#pragma unroll
+    for (int r = 1; r < 32; r++) {
+        const uint32_t w = stw[u * rev5(r)];
+#pragma unroll
+        for (int cc = 0; cc < CPT; cc++) x[cc][r] = dmul(x[cc][r], w);
+    }
+#pragma unroll
+    for (int cc = 0; cc < CPT; cc++) x[cc][0] = dred(x[cc][0]);
 
-    // ---- tile twiddle w_M^(u*k1), exchange through LDS
-    {
+    // ---- exchange through LDS, one column per round
+#pragma unroll
+    for (int cc = 0; cc < CPT; cc++) {
+        if (cc) __syncthreads();           // previous round's reads are done
         uint32_t* wp = sdata + u * C + c;
 #pragma unroll
-        for (int r = 0; r < 32; r++) {
-            constexpr int dummy = 0; (void)dummy;
-            const int k1 = rev5(r);
-            uint32_t v = (k1 == 0) ? x[r] : fmul(x[r], stw[u * k1]);
-            wp[k1 * pitch] = v;
-        }
-    }
-    __syncthreads();
-    {
+        for (int r = 0; r < 32; r++) wp[rev5(r) * pitch] = x[cc][r];
+        __syncthreads();
         const uint32_t* rp = sdata + c;
 #pragma unroll
         for (int rho = 0; rho < 32; rho++) {
             const int t = rho & (Pn - 1);
             const int k1 = (rho & ~(Pn - 1)) + u;
-            x[rho] = rp[k1 * pitch + t * C];
+            x[cc][rho] = rp[k1 * pitch + t * C];
         }
     }
 
     // ---- phase B: P-point DIFs = the last b stages of the 32-point network
-    if (b >= 5) dif_stage<INV, 0>(x);
-    if (b >= 4) dif_stage<INV, 1>(x);
-    if (b >= 3) dif_stage<INV, 2>(x);
-    if (b >= 2) dif_stage<INV, 3>(x);
-    if (b >= 1) dif_stage<INV, 4>(x);
+#pragma unroll
+    for (int cc = 0; cc < CPT; cc++) {
+        if (b >= 5) dif_stage<INV, 0>(x[cc]);
+        if (b >= 4) dif_stage<INV, 1>(x[cc]);
+        if (b >= 3) dif_stage<INV, 2>(x[cc]);
+        if (b >= 2) dif_stage<INV, 3>(x[cc]);
+        if (b >= 1) {
+            if (has_post) dif_stage<INV, 4, true>(x[cc]);   // outputs go straight into the post multiplication
+            else dif_stage<INV, 4>(x[cc]);
+        }
+    }
 
     // ---- post multiply and store
-    {
-        const bool has_post = a.post != nullptr;
+    if (has_post) {
+#pragma unroll
+        for (int rho = 0; rho < 32; rho++) {
+            const uint32_t t = rho & (Pn - 1);
+            const uint32_t k1 = (rho & ~(Pn - 1)) + u;
+            const uint32_t k0 = b ? (__brev(t) >> (32 - b)) : 0u;
+            const uint32_t w = spost[32u * k0 + k1];
+#pragma unroll
+            for (int cc = 0; cc < CPT; cc++) x[cc][rho] = dmul(x[cc][rho], w);
+        }
+    }
+    if (active) {
         const int m = (int)a.log_m;
         uint32_t* op = a.out + (uint64_t)tile * a.out_tile_mul * a.out_ld + col;
         const uint64_t ostep = a.out_stride * a.out_ld;
@@ -159,10 +209,9 @@ __global__ void __launch_bounds__(32 << LOG_C) ntt_pass_kernel(NttPassArgs a) {
             const uint32_t k1 = (rho & ~(Pn - 1)) + u;
             const uint32_t k0 = b ? (__brev(t) >> (32 - b)) : 0u;
             const uint32_t k = 32u * k0 + k1;
-            uint32_t v = x[rho];
-            if (has_post) v = fmul(v, spost[k]);
             const uint32_t o = a.bitrev_out ? (__brev(k) >> (32 - m)) : k;
-            if (active) op[(uint64_t)o * ostep] = v;
+            if (CPT == 2) *reinterpret_cast<uint2*>(op + (uint64_t)o * ostep) = make_uint2(x[0][rho], x[CPT - 1][rho]);
+            else op[(uint64_t)o * ostep] = x[0][rho];
         }
     }
 }
@@ -172,24 +221,21 @@ static size_t ntt_lds_bytes(int log_m, int log_c) {
     return (size_t)(32 * (Pn + 1) * C + 3 * M) * sizeof(uint32_t);
 }
 
-template <int LOG_C>
-static hipError_t launch_ntt_c(const NttPassArgs& a, bool inverse, hipStream_t s) {
-    const int C = 1 << LOG_C;
-    const uint32_t ncg = (a.ncols + C - 1) / C;
+template <int LOG_C, bool INV, int CPT>
+static hipError_t launch_ntt_k(const NttPassArgs& a, hipStream_t s) {
+    const int TC = (1 << LOG_C) * CPT;
+    const uint32_t ncg = (a.ncols + TC - 1) / TC;
     const int b = (int)a.log_m - 5;
-    dim3 grid(a.num_tiles * ncg), block((1 << b) * C);
-    size_t lds = ntt_lds_bytes((int)a.log_m, LOG_C);
-    if (inverse) {
-        hipError_t e = hipFuncSetAttribute((const void*)ntt_pass_kernel<LOG_C, true>,
+    dim3 grid(a.num_tiles * ncg), block((1 << b) << LOG_C);
+    const size_t lds = ntt_lds_bytes((int)a.log_m, LOG_C);
+    static size_t configured = 0;      // raise the dynamic-LDS cap once per instantiation
+    if (lds > configured) {
+        hipError_t e = hipFuncSetAttribute((const void*)ntt_pass_kernel<LOG_C, INV, CPT>,
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
-        hipLaunchKernelGGL((ntt_pass_kernel<LOG_C, true>), grid, block, lds, s, a);
-    } else {
-        hipError_t e = hipFuncSetAttribute((const void*)ntt_pass_kernel<LOG_C, false>,
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) return e;
-        hipLaunchKernelGGL((ntt_pass_kernel<LOG_C, false>), grid, block, lds, s, a);
+        configured = lds;
     }
+    hipLaunchKernelGGL((ntt_pass_kernel<LOG_C, INV, CPT>), grid, block, lds, s, a);
     return hipGetLastError();
 }
 
@@ -197,10 +243,15 @@ hipError_t launch_ntt_pass(const NttPassArgs& a_, bool inverse, hipStream_t s) {
     NttPassArgs a = a_;
     if (a.log_m < 5 || a.log_m > 10) return hipErrorInvalidValue;
     if (a.map_mode == 1 && (a.num_tiles % 8u) != 0) a.map_mode = 0;
+    // two columns per lane need 8-byte aligned row chunks
+    const bool pair_ok = a.ncols >= 32 && a.ncols % 2 == 0 && a.in_ld % 2 == 0 && a.out_ld % 2 == 0 &&
+                         (reinterpret_cast<uintptr_t>(a.in) & 7) == 0 && (reinterpret_cast<uintptr_t>(a.out) & 7) == 0 &&
+                         a.cols_per_thread == 2;   // opt-in: measured slower than 1 (register spills), kept for A/B
+    if (pair_ok) return inverse ? launch_ntt_k<4, true, 2>(a, s) : launch_ntt_k<4, false, 2>(a, s);
     // narrow matrices use narrower tiles so that lanes are not wasted on masked columns
-    if (a.ncols <= 4) return launch_ntt_c<2>(a, inverse, s);
-    if (a.ncols <= 8) return launch_ntt_c<3>(a, inverse, s);
-    return launch_ntt_c<4>(a, inverse, s);
+    if (a.ncols <= 4) return inverse ? launch_ntt_k<2, true, 1>(a, s) : launch_ntt_k<2, false, 1>(a, s);
+    if (a.ncols <= 8) return inverse ? launch_ntt_k<3, true, 1>(a, s) : launch_ntt_k<3, false, 1>(a, s);
+    return inverse ? launch_ntt_k<4, true, 1>(a, s) : launch_ntt_k<4, false, 1>(a, s);
 }
 
 // ------------------------------------------------------------------ table generators

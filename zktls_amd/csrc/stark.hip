@@ -244,7 +244,7 @@ __global__ void __launch_bounds__(256) grind_kernel(GrindArgs a, uint32_t base, 
     const uint32_t wm = fmul(w, MONTY_R2);
 #pragma unroll
     for (int i = 0; i < 8; i++) if (i == a.slot) s[i] = wm;
-    p2_permute(s);
+    p2_permute_dev(s);
     if ((from_monty(s[7]) & a.mask) == 0) atomicMin(result, w);
 }
 hipError_t launch_grind(const GrindArgs& a, uint32_t base, uint32_t count, uint32_t* result, hipStream_t s) {
