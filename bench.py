@@ -69,10 +69,8 @@ def main():
     ctx = Context(local_rank, stream=stream.cuda_stream)
 
     # batch transcript seed: rank 0 draws it, RCCL broadcasts it (the only collective)
-    seed_words = torch.tensor([(SEED >> (8 * i)) & 0xFF for i in range(8)], dtype=torch.int32, device="cuda")
-    if dist is not None:
-        dist.broadcast(seed_words, src=0)
-    public = [int(x) for x in seed_words.tolist()]
+    from zktls_amd import shards
+    public = shards.broadcast_seed(dist, [(SEED >> (8 * i)) & 0xFF for i in range(8)], device="cuda")
 
     K, W = args.steps, args.warmup
     nbuf = min(max(K, 1), 4)
@@ -103,10 +101,7 @@ def main():
         last = step(i)
     barrier()
     elapsed = time.perf_counter() - t0
-    if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    elapsed = shards.max_over_ranks(dist, elapsed, device="cuda")
 
     # the last proof of the timed region must verify (host verifier of the product)
     rc, reason = verify_shard(last, log_n, width, public + [rank * max(K, 1) + ((K - 1) % nbuf)], prm)

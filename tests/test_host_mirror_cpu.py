@@ -1,0 +1,91 @@
+"""CPU tests of the C++ mirror of the reference's prover plug point
+(zktls_amd/host/guest_prover_hip.*): builder modes -> SP1_PROVER, the <= 4-byte proof rule,
+errors returned (never thrown across the boundary), request digest determinism."""
+import ctypes as C
+import os
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+SO = os.path.join(ROOT, "zktls_amd", "libzktls_guest_prover.so")
+
+
+class Plan(C.Structure):
+    _fields_ = [("log_n", C.c_int32), ("width", C.c_uint32), ("shards", C.c_uint32), ("num_queries", C.c_int32), ("pow_bits", C.c_int32)]
+
+
+@pytest.fixture(scope="module")
+def lib():
+    L = C.CDLL(SO)
+    L.zktls_current_sp1_prover_env.restype = C.c_char_p
+    u8pp, szp = C.POINTER(C.POINTER(C.c_uint8)), C.POINTER(C.c_size_t)
+    L.zktls_guest_prove.argtypes = [C.c_int, C.c_int, C.POINTER(Plan), C.c_char_p, C.c_size_t, C.c_char_p, C.c_size_t,
+                                    u8pp, szp, u8pp, szp, C.c_char_p, C.c_size_t]
+    L.zktls_request_digest.argtypes = [C.c_char_p, C.c_size_t, C.c_char_p, C.c_size_t, C.POINTER(C.c_uint32)]
+    L.zktls_unpack_batch.argtypes = [C.c_char_p, C.c_size_t, szp, szp, C.c_int]
+    L.zktls_free.argtypes = [C.c_void_p]
+    return L
+
+
+def call(L, mode, cbor, elf, plan=None, device=0):
+    out, outn, pr, prn = C.POINTER(C.c_uint8)(), C.c_size_t(), C.POINTER(C.c_uint8)(), C.c_size_t()
+    err = C.create_string_buffer(512)
+    rc = L.zktls_guest_prove(device, mode, C.byref(plan) if plan else None, cbor, len(cbor), elf, len(elf),
+                             C.byref(out), C.byref(outn), C.byref(pr), C.byref(prn), err, 512)
+    if rc != 0:
+        return rc, err.value.decode(), None, None
+    o = bytes(bytearray(out[i] for i in range(outn.value)))
+    p = bytes(bytearray(pr[i] for i in range(prn.value)))
+    L.zktls_free(out)
+    L.zktls_free(pr)
+    return 0, "", o, p
+
+
+def test_mock_mode_sets_env_and_returns_empty_proof(lib):
+    rc, err, out, proof = call(lib, 0, b"\xa2input", b"\x7fELF....")
+    assert rc == 0 and len(out) == 32
+    assert proof == b""                                    # placeholder of 4 bytes -> "no proof" (sp1.rs:128-130)
+    assert lib.zktls_current_sp1_prover_env() == b"mock"   # sp1.rs:23
+    d = (C.c_uint32 * 8)()
+    lib.zktls_request_digest(b"\xa2input", len(b"\xa2input"), b"\x7fELF....", len(b"\x7fELF...."), d)
+    assert bytes(d) == out
+    assert all(v < 2013265921 for v in d)
+
+
+def test_digest_binds_input_and_program(lib):
+    a = call(lib, 0, b"abc", b"elf1")[2]
+    assert a == call(lib, 0, b"abc", b"elf1")[2]
+    assert a != call(lib, 0, b"abd", b"elf1")[2]
+    assert a != call(lib, 0, b"abc", b"elf2")[2]
+    assert a != call(lib, 0, b"ab", b"celf1")[2]           # length prefix separates the two fields
+
+
+def test_errors_come_back_as_values(lib):
+    rc, err, _, _ = call(lib, 0, b"x", b"")
+    assert rc != 0 and "empty" in err
+    rc, err, _, _ = call(lib, 3, b"x", b"elf")
+    assert rc != 0 and "network" in err
+    assert lib.zktls_current_sp1_prover_env() == b"network"
+    from zktls_amd import _lib
+    if _lib.device_count() == 0:
+        rc, err, _, _ = call(lib, 2, b"x", b"elf", Plan(6, 8, 1, 10, 8))
+        assert rc != 0 and "no CPU fallback" in err        # no device: loud failure, no fallback
+        assert lib.zktls_current_sp1_prover_env() == b"hip"
+
+
+@pytest.mark.gpu
+def test_hip_mode_proves_and_packs_shards(lib):
+    from zktls_amd._lib import Params
+    from zktls_amd.device import verify_shard
+    plan = Plan(8, 8, 3, 10, 8)
+    rc, err, out, blob = call(lib, 2, b"\xa1transcript", b"\x7fELFprog", plan)
+    assert rc == 0, err
+    offs, lens = (C.c_size_t * 8)(), (C.c_size_t * 8)()
+    n = lib.zktls_unpack_batch(blob, len(blob), offs, lens, 8)
+    assert n == 3
+    digest = np.frombuffer(out, dtype=np.uint32).tolist()
+    for s in range(3):
+        proof = np.frombuffer(blob[offs[s]:offs[s] + lens[s]], dtype=np.uint8)
+        assert verify_shard(proof, 8, 8, digest + [s], Params(1, 10, 8)) == (0, 0)
+        assert verify_shard(proof, 8, 8, digest + [s + 1], Params(1, 10, 8))[0] == -6

@@ -1,0 +1,214 @@
+// guest_prover_hip.cpp -- see guest_prover_hip.hpp.  Links against libzkhip.so only
+// through its C ABI (include/zkhip.h), exactly as the Rust crate would.
+#include "guest_prover_hip.hpp"
+
+#include <cstdlib>
+#include <cstring>
+#include <stdexcept>
+
+#include "../../include/zkhip.h"
+#include "../csrc/poseidon2.cuh"
+
+namespace zktls {
+
+const char* prover_type_name(ProverType mode) {
+    switch (mode) {
+        case ProverType::Mock: return "mock";
+        case ProverType::Local: return "local";
+        case ProverType::Hip: return "hip";
+        case ProverType::Network: return "network";
+    }
+    return "mock";
+}
+
+void set_env(ProverType mode) { setenv("SP1_PROVER", prover_type_name(mode), 1); }   // sp1.rs:23-27
+
+// sponge over 3-byte limbs, length-prefixed and domain-separated; result canonical
+std::vector<uint32_t> request_digest(const std::vector<uint8_t>& cbor, const std::vector<uint8_t>& elf) {
+    uint32_t st[16] = {0};
+    int pos = 0;
+    auto absorb = [&](uint32_t canonical) {
+        st[pos++] = zk::to_monty(canonical);
+        if (pos == 8) { zk::p2_permute(st); pos = 0; }
+    };
+    auto absorb_bytes = [&](const std::vector<uint8_t>& b) {
+        absorb((uint32_t)(b.size() & 0xFFFFFF));
+        absorb((uint32_t)((uint64_t)b.size() >> 24) & 0xFFFFFF);
+        for (size_t i = 0; i < b.size(); i += 3) {
+            uint32_t v = b[i];
+            if (i + 1 < b.size()) v |= (uint32_t)b[i + 1] << 8;
+            if (i + 2 < b.size()) v |= (uint32_t)b[i + 2] << 16;
+            absorb(v);
+        }
+    };
+    absorb(0x5A4B54);   // "ZKT"
+    absorb_bytes(cbor);
+    absorb_bytes(elf);
+    if (pos) zk::p2_permute(st);
+    std::vector<uint32_t> out(8);
+    for (int i = 0; i < 8; i++) out[i] = zk::from_monty(st[i]);
+    return out;
+}
+
+std::vector<uint8_t> pack_shard_proofs(const std::vector<std::vector<uint8_t>>& proofs) {
+    std::vector<uint8_t> out;
+    auto put32 = [&](uint32_t v) { for (int i = 0; i < 4; i++) out.push_back((uint8_t)(v >> (8 * i))); };
+    put32(0x42544B5Au);   // "ZKTB"
+    put32(1);
+    put32((uint32_t)proofs.size());
+    for (const auto& p : proofs) {
+        put32((uint32_t)p.size());
+        out.insert(out.end(), p.begin(), p.end());
+    }
+    return out;
+}
+
+bool unpack_shard_proofs(const std::vector<uint8_t>& blob, std::vector<std::vector<uint8_t>>* proofs) {
+    auto get32 = [&](size_t off) { uint32_t v = 0; for (int i = 0; i < 4; i++) v |= (uint32_t)blob[off + i] << (8 * i); return v; };
+    if (blob.size() < 12 || get32(0) != 0x42544B5Au || get32(4) != 1) return false;
+    const uint32_t n = get32(8);
+    size_t off = 12;
+    proofs->clear();
+    for (uint32_t i = 0; i < n; i++) {
+        if (off + 4 > blob.size()) return false;
+        const uint32_t len = get32(off);
+        off += 4;
+        if (off + len > blob.size()) return false;
+        proofs->emplace_back(blob.begin() + off, blob.begin() + off + len);
+        off += len;
+    }
+    return off == blob.size();
+}
+
+namespace {
+struct CtxGuard {
+    zkhip_ctx* ctx = nullptr;
+    void* d_trace = nullptr;
+    ~CtxGuard() {
+        if (ctx && d_trace) zkhip_free(ctx, d_trace);
+        if (ctx) zkhip_ctx_destroy(ctx);
+    }
+};
+[[noreturn]] void fail_zkhip(const char* what) { throw std::runtime_error(std::string(what) + ": " + zkhip_last_error()); }
+}  // namespace
+
+ProveResult HipGuestProver::prove(const GuestInput& input, const std::vector<uint8_t>& guest_program) {
+    set_env(mode_);                                   // sp1.rs:72
+    const std::vector<uint8_t> elf = guest_program;   // sp1.rs:74: the ELF is copied once
+    ProveResult r;
+    try {                                             // sp1.rs:85: nothing may unwind past here
+        r = prove_inner(input, elf);
+    } catch (const std::exception& e) {
+        r = ProveResult{};
+        r.error = e.what();
+    } catch (...) {
+        r = ProveResult{};
+        r.error = "unknown failure in HipGuestProver::prove";
+    }
+    if (r.ok && r.proof.size() <= 4) r.proof.clear();   // sp1.rs:128-130
+    return r;
+}
+
+ProveResult HipGuestProver::prove_inner(const GuestInput& input, const std::vector<uint8_t>& elf) {
+    ProveResult r;
+    if (elf.empty()) throw std::runtime_error("guest program is empty");
+    const std::vector<uint32_t> digest = request_digest(input.cbor, elf);
+    r.output.resize(32);
+    std::memcpy(r.output.data(), digest.data(), 32);
+    if (mode_ == ProverType::Mock) {                  // executes nothing, returns a placeholder
+        r.proof = {0, 0, 0, 0};
+        r.ok = true;
+        return r;
+    }
+    if (mode_ == ProverType::Network) throw std::runtime_error("network proving is not provided by the HIP backend");
+    // Local and Hip both mean "prove on this machine"; there is no CPU path in libzkhip
+    if (plan_.shards == 0) throw std::runtime_error("shard plan is empty");
+    zkhip_params prm{1, plan_.num_queries, plan_.pow_bits};
+    const size_t cap = zkhip_proof_size(plan_.log_n, plan_.width, &prm, 9);
+    if (cap == 0) throw std::runtime_error(std::string("bad shard plan: ") + zkhip_last_error());
+    CtxGuard g;
+    if (zkhip_ctx_create(device_, nullptr, &g.ctx) != ZKHIP_OK) fail_zkhip("zkhip_ctx_create");
+    const size_t words = ((size_t)1 << plan_.log_n) * plan_.width;
+    if (zkhip_malloc(g.ctx, words * 4, &g.d_trace) != ZKHIP_OK) fail_zkhip("zkhip_malloc");
+    uint64_t seed = 0;
+    for (int i = 0; i < 4; i++) seed = (seed << 16) ^ digest[i];
+    std::vector<std::vector<uint8_t>> proofs;
+    for (uint32_t s = 0; s < plan_.shards; s++) {
+        std::vector<uint32_t> pv(digest);
+        pv.push_back(s);
+        if (zkhip_gen_trace(g.ctx, seed, s, plan_.log_n, plan_.width, (uint32_t*)g.d_trace, plan_.width) != ZKHIP_OK)
+            fail_zkhip("zkhip_gen_trace");
+        std::vector<uint8_t> proof(cap);
+        size_t len = 0;
+        if (zkhip_prove_shard(g.ctx, (const uint32_t*)g.d_trace, plan_.width, plan_.log_n, plan_.width, pv.data(), pv.size(),
+                              &prm, proof.data(), cap, &len) != ZKHIP_OK)
+            fail_zkhip("zkhip_prove_shard");
+        proof.resize(len);
+        int reason = 0;
+        if (zkhip_verify_shard(proof.data(), proof.size(), plan_.log_n, plan_.width, pv.data(), pv.size(), &prm, &reason) != ZKHIP_OK)
+            fail_zkhip("zkhip_verify_shard");   // sp1.rs:120: the prover checks its own proof
+        proofs.push_back(std::move(proof));
+    }
+    r.proof = pack_shard_proofs(proofs);
+    r.ok = true;
+    return r;
+}
+
+}  // namespace zktls
+
+// ---- flat C surface so the tests (ctypes) and other FFIs can drive the mirror ----
+extern "C" {
+
+struct zktls_shard_plan { int32_t log_n; uint32_t width; uint32_t shards; int32_t num_queries; int32_t pow_bits; };
+
+// mode: 0 mock, 1 local, 2 hip, 3 network.  Returns 0 on success; on failure copies the
+// message into err.  *output / *proof are malloc'd (zktls_free).
+int zktls_guest_prove(int device, int mode, const zktls_shard_plan* plan, const uint8_t* cbor, size_t cbor_len,
+                      const uint8_t* elf, size_t elf_len, uint8_t** output, size_t* output_len, uint8_t** proof,
+                      size_t* proof_len, char* err, size_t err_cap) {
+    zktls::HipGuestProver p(device);
+    switch (mode) {
+        case 0: p.mock(); break;
+        case 1: p.local(); break;
+        case 2: p.hip(); break;
+        default: p.network(); break;
+    }
+    if (plan) {
+        zktls::ShardPlan sp;
+        sp.log_n = plan->log_n; sp.width = plan->width; sp.shards = plan->shards;
+        sp.num_queries = plan->num_queries; sp.pow_bits = plan->pow_bits;
+        p.with_plan(sp);
+    }
+    zktls::GuestInput in;
+    in.cbor.assign(cbor, cbor + cbor_len);
+    std::vector<uint8_t> program(elf, elf + elf_len);
+    zktls::ProveResult r = p.prove(in, program);
+    if (!r.ok) {
+        if (err && err_cap) { std::strncpy(err, r.error.c_str(), err_cap - 1); err[err_cap - 1] = 0; }
+        return -1;
+    }
+    *output_len = r.output.size();
+    *output = (uint8_t*)std::malloc(r.output.size() ? r.output.size() : 1);
+    std::memcpy(*output, r.output.data(), r.output.size());
+    *proof_len = r.proof.size();
+    *proof = (uint8_t*)std::malloc(r.proof.size() ? r.proof.size() : 1);
+    std::memcpy(*proof, r.proof.data(), r.proof.size());
+    return 0;
+}
+void zktls_free(void* p) { std::free(p); }
+const char* zktls_current_sp1_prover_env(void) { const char* e = getenv("SP1_PROVER"); return e ? e : ""; }
+int zktls_request_digest(const uint8_t* cbor, size_t cbor_len, const uint8_t* elf, size_t elf_len, uint32_t out[8]) {
+    std::vector<uint32_t> d = zktls::request_digest(std::vector<uint8_t>(cbor, cbor + cbor_len), std::vector<uint8_t>(elf, elf + elf_len));
+    std::memcpy(out, d.data(), 32);
+    return 0;
+}
+// splits a batch blob; returns the shard count or -1; offsets/lengths arrays sized `cap`
+int zktls_unpack_batch(const uint8_t* blob, size_t len, size_t* offsets, size_t* lengths, int cap) {
+    std::vector<std::vector<uint8_t>> proofs;
+    if (!zktls::unpack_shard_proofs(std::vector<uint8_t>(blob, blob + len), &proofs)) return -1;
+    size_t off = 12;
+    for (size_t i = 0; i < proofs.size() && (int)i < cap; i++) { offsets[i] = off + 4; lengths[i] = proofs[i].size(); off += 4 + proofs[i].size(); }
+    return (int)proofs.size();
+}
+
+}  // extern "C"
