@@ -221,7 +221,7 @@ int op_merkle_commit(zkhip_ctx* ctx, const MatDesc* mats, int nmats, int log_h, 
     ZK_HIP(launch_hash_rows(la, ctx->stream));
     uint32_t* level = tree;
     uint64_t count = la.height;
-    while (count > 2048) {
+    while (count > COOP_TOP_NODES) {
         uint32_t* next = level + 8 * count;
         ZK_HIP(launch_compress_level(level, next, count / 2, ctx->stream));
         level = next; count >>= 1;

@@ -28,6 +28,11 @@ __device__ __forceinline__ uint32_t load_virtual(const LeafArgs& a, uint64_t row
     return 0u;
 }
 
+// 16-lanes-per-permutation kernels, defined further down
+__global__ void hash_rows16_kernel(LeafArgs a, uint32_t total_w);
+__global__ void compress_level16_kernel(const uint32_t* __restrict__ children, uint32_t* __restrict__ parents, uint32_t count);
+__global__ void compress_top16_kernel(uint32_t* tree, uint32_t count);
+
 __global__ void __launch_bounds__(256) hash_rows_generic_kernel(LeafArgs a, uint32_t total_w) {
     const uint64_t row = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (row >= a.height) return;
@@ -71,6 +76,11 @@ hipError_t launch_hash_rows(const LeafArgs& a, hipStream_t s) {
     if (a.nmats < 1 || a.nmats > MAX_LEAF_MATS) return hipErrorInvalidValue;
     uint32_t total = 0;
     for (int m = 0; m < a.nmats; m++) total += a.mats[m].width;
+    if (a.height <= COOP_MAX_NODES) {
+        const uint64_t threads = a.height * 16;
+        hipLaunchKernelGGL(hash_rows16_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, s, a, total);
+        return hipGetLastError();
+    }
     dim3 block(256), grid((unsigned)((a.height + 255) / 256));
     const MatDesc& m0 = a.mats[0];
     bool vec = a.nmats == 1 && m0.width % 8 == 0 && m0.ld % 4 == 0 &&
@@ -101,6 +111,11 @@ __global__ void __launch_bounds__(256) compress_level_kernel(const uint32_t* __r
 }
 hipError_t launch_compress_level(const uint32_t* children, uint32_t* parents, uint64_t count, hipStream_t s) {
     if (count == 0) return hipSuccess;
+    if (count <= COOP_MAX_NODES) {
+        const uint64_t threads = count * 16;
+        hipLaunchKernelGGL(compress_level16_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, s, children, parents, (uint32_t)count);
+        return hipGetLastError();
+    }
     hipLaunchKernelGGL(compress_level_kernel, dim3((unsigned)((count + 255) / 256)), dim3(256), 0, s, children, parents, count);
     return hipGetLastError();
 }
@@ -118,10 +133,104 @@ __global__ void __launch_bounds__(1024) compress_top_kernel(uint32_t* tree, uint
 }
 hipError_t launch_compress_top(uint32_t* tree, uint32_t count, hipStream_t s) {
     if (count <= 1) return hipSuccess;
-    if (count > 2048) return hipErrorInvalidValue;
-    unsigned threads = count / 2 < 64 ? 64 : count / 2;
-    hipLaunchKernelGGL(compress_top_kernel, dim3(1), dim3(threads), 0, s, tree, count);
+    if (count > COOP_TOP_NODES) return hipErrorInvalidValue;
+    unsigned threads = count * 8 < 64 ? 64 : (count * 8 > 1024 ? 1024 : count * 8);
+    hipLaunchKernelGGL(compress_top16_kernel, dim3(1), dim3(threads), 0, s, tree, count);
     return hipGetLastError();
+}
+
+// ------------------------------------------------------------------ latency-optimised form
+// One permutation spread over the 16 lanes of a DPP row (state word i in lane i): an
+// external round is 4 dependent products + ~13 dependent additions, an internal round one
+// S-box + a 4-step rotate-and-add + one product, instead of ~10 k serial instructions.  A
+// permutation finishes in ~3 us instead of ~19 us, which is what bounds the SMALL levels of
+// every Merkle tree (a proof walks ~250 such levels one after the other).  Throughput per
+// wave is worse (4 permutations instead of 64), so the wide levels keep the lane-per-state form.
+template <int CTRL>
+ZK_D uint32_t dpp(uint32_t v) { return (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, CTRL, 0xF, 0xF, false); }
+
+struct CoopConsts { uint32_t rc_ext[8]; uint32_t diag; };
+ZK_D CoopConsts coop_load_consts(int lane16) {
+    CoopConsts k;
+#pragma unroll
+    for (int r = 0; r < 8; r++) k.rc_ext[r] = P2K.ext_rc[r][lane16];
+    k.diag = P2K.diag[lane16];
+    return k;
+}
+ZK_D uint32_t coop_external_linear(uint32_t x, bool even_lane) {
+    // quad_perm [0,0,2,2] [1,1,3,3] [2,2,0,0] [3,3,1,1]: lanes 2,3 of a quad see it swapped,
+    // which turns rows 2,3 of M4 into rows 0,1
+    const uint32_t p0 = dpp<0xA0>(x), p1 = dpp<0xF5>(x), p2 = dpp<0x0A>(x), p3 = dpp<0x5F>(x);
+    const uint32_t s01 = dadd(p0, p1);
+    const uint32_t q = ddbl(ddbl(s01));                                   // 4 p0 + 4 p1
+    const uint32_t base = dadd(dadd(q, ddbl(p1)), dadd(p2, p3));          // 4 p0 + 6 p1 + p2 + p3
+    const uint32_t full = dadd(base, dadd(s01, ddbl(p3)));                // 5 p0 + 7 p1 + p2 + 3 p3
+    const uint32_t y = even_lane ? full : base;
+    uint32_t t = dadd(y, dpp<0x124>(y));                                  // row_ror:4
+    t = dadd(t, dpp<0x128>(t));                                           // row_ror:8
+    return dadd(y, t);
+}
+ZK_D uint32_t coop_permute(uint32_t x, int lane16, const CoopConsts& k) {
+    const bool even_lane = (lane16 & 1) == 0;
+    x = coop_external_linear(x, even_lane);
+#pragma unroll 1
+    for (int r = 0; r < 4; r++) x = coop_external_linear(p2_sbox_dev(dadd(x, k.rc_ext[r])), even_lane);
+#pragma unroll 1
+    for (int r = 0; r < 13; r++) {
+        const uint32_t sb = p2_sbox_dev(dadd(x, P2K.int_rc[r]));
+        x = lane16 == 0 ? sb : x;
+        uint32_t t = dadd(x, dpp<0x128>(x));
+        t = dadd(t, dpp<0x124>(t));
+        t = dadd(t, dpp<0x122>(t));
+        t = dadd(t, dpp<0x121>(t));                                       // every lane holds the sum
+        x = dadd(dmul(x, k.diag), t);
+    }
+#pragma unroll 1
+    for (int r = 4; r < 8; r++) x = coop_external_linear(p2_sbox_dev(dadd(x, k.rc_ext[r])), even_lane);
+    return x;
+}
+
+// parents[i] = compress(children[2i], children[2i+1]); one node per 16 lanes
+__global__ void __launch_bounds__(256) compress_level16_kernel(const uint32_t* __restrict__ children,
+                                                               uint32_t* __restrict__ parents, uint32_t count) {
+    const uint32_t gid = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t node = gid >> 4;
+    const int lane16 = threadIdx.x & 15;
+    if (node >= count) return;                       // whole rows leave together
+    const CoopConsts k = coop_load_consts(lane16);
+    const uint32_t x = coop_permute(children[16 * (size_t)node + lane16], lane16, k);
+    if (lane16 < 8) parents[8 * (size_t)node + lane16] = x;
+}
+// all levels count -> 1 in one workgroup of 1024 threads (count <= 512), 64 nodes per step
+__global__ void __launch_bounds__(1024) compress_top16_kernel(uint32_t* tree, uint32_t count) {
+    const int lane16 = threadIdx.x & 15;
+    const uint32_t grp = threadIdx.x >> 4, ngrp = blockDim.x >> 4;
+    const CoopConsts k = coop_load_consts(lane16);
+    uint32_t* level = tree;
+    for (uint32_t n = count; n > 1; n >>= 1) {
+        uint32_t* next = level + 8 * (size_t)n;
+        for (uint32_t i = grp; i < n / 2; i += ngrp) {
+            const uint32_t x = coop_permute(level[16 * (size_t)i + lane16], lane16, k);
+            if (lane16 < 8) next[8 * (size_t)i + lane16] = x;
+        }
+        __threadfence_block();
+        __syncthreads();
+        level = next;
+    }
+}
+// leaf digests, one row per 16 lanes (small heights: FRI layers, tests)
+__global__ void __launch_bounds__(256) hash_rows16_kernel(LeafArgs a, uint32_t total_w) {
+    const uint32_t gid = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint64_t row = gid >> 4;
+    const int lane16 = threadIdx.x & 15;
+    if (row >= a.height) return;
+    const CoopConsts k = coop_load_consts(lane16);
+    uint32_t x = 0;
+    for (uint32_t q = 0; q < total_w; q += 8) {
+        if (lane16 < 8 && q + lane16 < total_w) x = load_virtual(a, row, q + lane16);
+        x = coop_permute(x, lane16, k);
+    }
+    if (lane16 < 8) a.digests[row * 8 + lane16] = x;
 }
 
 __global__ void __launch_bounds__(256) permute_states_kernel(uint32_t* states, uint64_t count) {

@@ -48,6 +48,10 @@ struct MatDesc {
     uint32_t width;
 };
 constexpr int MAX_LEAF_MATS = 4;
+// levels / heights up to this many nodes use the 16-lanes-per-permutation kernels (latency-bound regime)
+constexpr uint32_t COOP_MAX_NODES = 16384;
+// the single-workgroup kernel finishes a tree from this many nodes down to the root
+constexpr uint32_t COOP_TOP_NODES = 512;
 struct LeafArgs {
     MatDesc mats[MAX_LEAF_MATS];
     int nmats;
@@ -59,7 +63,7 @@ hipError_t launch_hash_rows(const LeafArgs& a, hipStream_t s);
 hipError_t launch_compress_level(const uint32_t* children, uint32_t* parents, uint64_t count,
                                  hipStream_t s);
 // all remaining levels of a small subtree in one launch: `tree` points at a level with
-// `count` (<= 2048, power of two) digests followed by room for the levels above it
+// `count` (<= COOP_TOP_NODES, power of two) digests followed by room for the levels above it
 hipError_t launch_compress_top(uint32_t* tree, uint32_t count, hipStream_t s);
 // raw permutation on `count` states of 16 words (KAT / microbenchmark)
 hipError_t launch_permute_states(uint32_t* states, uint64_t count, hipStream_t s);
