@@ -102,6 +102,13 @@ ZK_D uint32_t dsub(uint32_t a, uint32_t b) {
     return t;
 }
 ZK_D uint32_t dsub_lazy(uint32_t a, uint32_t b) { return a + (P - b); }
+// a0*b0 + a1*b1 reduced together (operands canonical): 3 x v_mad_u64_u32 + v_mul_lo_u32 + dred
+ZK_D uint32_t dmr2(uint32_t a0, uint32_t b0, uint32_t a1, uint32_t b1) {
+    uint64_t x = (uint64_t)a0 * b0 + (uint64_t)a1 * b1;       // < 2 P^2
+    uint32_t m = (uint32_t)x * MONTY_MU_NEG;
+    uint64_t y = x + (uint64_t)m * P;                         // < 2 P^2 + 2^32 P < 2^64
+    return dred((uint32_t)(y >> 32));                         // y / 2^32 < 2 P
+}
 ZK_D uint32_t ddbl(uint32_t a) { return dred(a + a); }
 #endif
 

@@ -91,8 +91,7 @@ struct QuotientArgs {
     const uint32_t* sel_first;
     uint32_t wn_inv;            // w_N^-1
     uint32_t inv_zh_even, inv_zh_odd;
-    Ext alpha, alpha2;
-    const uint32_t* alpha_pow;  // [width/4] ext: alpha^(3 (G-1-g))
+    const uint32_t* alpha_pow;  // [width/4][3] ext: alpha^(K-1-3g-t), K = 3 width/4
     uint32_t* out;              // [2][N][4]: chunk k, natural row j
 };
 hipError_t launch_quotient(const QuotientArgs& a, hipStream_t s);
@@ -125,7 +124,8 @@ struct ReducedArgs {
     Ext y_loc, y_next, y_q, off_next, off_q;
     uint32_t* out;              // [rows] ext
 };
-hipError_t launch_reduced_opening(const ReducedArgs& a, hipStream_t s);
+// scratch_at: [rows] ext workspace for the per-row alpha-dot of the trace matrix
+hipError_t launch_reduced_opening(const ReducedArgs& a, uint32_t* scratch_at, hipStream_t s);
 
 hipError_t launch_fri_fold(const uint32_t* in, uint32_t* out, const uint32_t* itw, uint64_t half, const Ext& beta, hipStream_t s);
 

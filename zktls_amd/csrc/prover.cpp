@@ -91,13 +91,13 @@ static int run_quotient(zkhip_ctx* ctx, const uint32_t* lde, size_t ld, int log_
                         uint32_t* out_chunks) {
     ZK_TRY(ensure_domain(ctx, log_n));
     const uint32_t G = width / 4;
-    std::vector<Ext> ap(G);
-    const Ext a3 = ext_mul(ext_mul(alpha, alpha), alpha);
-    ap[G - 1] = ext_one();
-    for (int g = (int)G - 2; g >= 0; g--) ap[g] = ext_mul(ap[g + 1], a3);
+    // weight of constraint k = 3 g + t is alpha^(K-1-k): filled from the last constraint backwards
+    std::vector<Ext> ap((size_t)3 * G);
+    Ext w = ext_one();
+    for (size_t k = (size_t)3 * G; k-- > 0;) { ap[k] = w; w = ext_mul(w, alpha); }
     void* d_ap;
-    ZK_TRY(ctx_reserve(ctx, S_APOW_Q, (size_t)G * 16, &d_ap));
-    ZK_TRY(h2d(ctx, d_ap, ap.data(), (size_t)G * 16));
+    ZK_TRY(ctx_reserve(ctx, S_APOW_Q, ap.size() * 16, &d_ap));
+    ZK_TRY(h2d(ctx, d_ap, ap.data(), ap.size() * 16));
     QuotientArgs q{};
     q.lde = lde; q.ld = ld; q.width = width; q.log_n = log_n;
     q.lanes_per_row = pow2ceil((int)G) > 64 ? 64 : pow2ceil((int)G);
@@ -106,7 +106,6 @@ static int run_quotient(zkhip_ctx* ctx, const uint32_t* lde, size_t ld, int log_
     const uint32_t gn = fpow(MONTY_GEN, (uint64_t)1 << log_n);
     q.inv_zh_even = finv(fsub(gn, MONTY_R1));
     q.inv_zh_odd = finv(fsub(fneg(gn), MONTY_R1));
-    q.alpha = alpha; q.alpha2 = ext_mul(alpha, alpha);
     q.alpha_pow = (const uint32_t*)d_ap;
     q.out = out_chunks;
     ZK_HIP(launch_quotient(q, ctx->stream));
@@ -325,7 +324,9 @@ int zkhip_prove_shard(zkhip_ctx* ctx, const uint32_t* d_trace, size_t ld, int lo
     ra.tlde = tlde; ra.t_ld = width; ra.width = width; ra.qlde = qlde; ra.q_ld = 8; ra.rows = m;
     ra.lanes_per_row = pow2ceil((int)(width / 4)) > 64 ? 64 : pow2ceil((int)(width / 4));
     ra.alpha_pow = (const uint32_t*)v_apf; ra.dinv = dinv; ra.out = layers;
-    ZK_HIP(launch_reduced_opening(ra, st));
+    void* v_at;
+    ZK_TRY(ctx_reserve(ctx, S_PARTIAL, m * 16, &v_at));   // openings are done with S_PARTIAL by now
+    ZK_HIP(launch_reduced_opening(ra, (uint32_t*)v_at, st));
 
     // ---- 5. FRI commit phase: commit, challenge, fold
     std::vector<size_t> layer_off(L + 1), tree_off(L + 1);

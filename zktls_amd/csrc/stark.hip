@@ -31,7 +31,7 @@ ZK_D Ext group_sum(Ext v, int width) {
         o.c[1] = __shfl_down(v.c[1], off, width);
         o.c[2] = __shfl_down(v.c[2], off, width);
         o.c[3] = __shfl_down(v.c[3], off, width);
-        v = ext_add(v, o);
+        v = Ext{{dadd(v.c[0], o.c[0]), dadd(v.c[1], o.c[1]), dadd(v.c[2], o.c[2]), dadd(v.c[3], o.c[3])}};
     }
     return v;
 }
@@ -61,7 +61,9 @@ hipError_t launch_domain_tables(uint32_t* xs, uint32_t* sel_first, uint32_t* itw
 }
 
 // ------------------------------------------------------------------ quotient
-// acc = sum_k alpha^(K-1-k) C_k(x_p), k = 3 g + type, then * 1/Z_H(x_p).
+// acc = sum_k alpha^(K-1-k) C_k(x_p), k = 3 g + type, then * 1/Z_H(x_p).  The host passes
+// the three weights of each column group (alpha_pow[g][t] = alpha^(K-1-3g-t)) so that a group
+// costs 3 base*extension products, two of them reduced together.
 // Output in NATURAL chunk order: chunk (e & 1), row (e >> 1), e = bitrev(p).
 __global__ void __launch_bounds__(256) quotient_kernel(QuotientArgs a) {
     const int L = a.lanes_per_row;
@@ -77,19 +79,25 @@ __global__ void __launch_bounds__(256) quotient_kernel(QuotientArgs a) {
     const uint32_t* nrow = a.lde + (uint64_t)pn * a.ld;
     const uint32_t x = a.xs[p];
     const uint32_t sel_first = a.sel_first[p];
-    const uint32_t sel_trans = fsub(x, a.wn_inv);
-    const Ext alpha = a.alpha, alpha2 = a.alpha2;
+    const uint32_t sel_trans = dsub(x, a.wn_inv);
     const uint32_t G = a.width / 4;
     Ext acc = ext_zero();
     for (uint32_t g = lane; g < G; g += L) {
         const uint4 v = *reinterpret_cast<const uint4*>(row + 4 * g);
         const uint32_t dn = nrow[4 * g + 3];
-        const uint32_t k1 = fmul(g + 1, MONTY_R2), k2 = fmul(2 * g + 3, MONTY_R2), d0 = fmul(5 * g + 7, MONTY_R2);
-        const uint32_t c1 = fsub(fsub(v.z, fmul(fmul(v.x, v.x), v.y)), k1);
-        const uint32_t c2 = fmul(sel_trans, fsub(fsub(fsub(dn, fmul(v.x, v.y)), v.z), k2));
-        const uint32_t c3 = fmul(sel_first, fsub(v.w, d0));
-        Ext loc = ext_add_base(ext_add(ext_mul_base(alpha2, c1), ext_mul_base(alpha, c2)), c3);
-        acc = ext_add(acc, ext_mul(loc, ld_ext(a.alpha_pow + 4 * g)));
+        const uint32_t k1 = dmul(g + 1, MONTY_R2), k2 = dmul(2 * g + 3, MONTY_R2), d0 = dmul(5 * g + 7, MONTY_R2);
+        // c1 = c - a a b - k1 ; c2 = sel_trans (d' - a b - c - k2) ; c3 = sel_first (d - d0)
+        const uint32_t aab = dmul(dmont_lazy(v.x, v.x), v.y);
+        const uint32_t c1 = dsub(dsub(v.z, aab), k1);
+        const uint32_t ab = dmul(v.x, v.y);
+        const uint32_t c2 = dmul(dsub_lazy(dsub(dsub(dn, ab), v.z), k2), sel_trans);
+        const uint32_t c3 = dmul(dsub_lazy(v.w, d0), sel_first);
+        const uint4* wp = reinterpret_cast<const uint4*>(a.alpha_pow + 12 * g);
+        const uint4 w0 = wp[0], w1 = wp[1], w2 = wp[2];
+        acc.c[0] = dadd(acc.c[0], dadd(dmr2(w0.x, c1, w1.x, c2), dmul(w2.x, c3)));
+        acc.c[1] = dadd(acc.c[1], dadd(dmr2(w0.y, c1, w1.y, c2), dmul(w2.y, c3)));
+        acc.c[2] = dadd(acc.c[2], dadd(dmr2(w0.z, c1, w1.z, c2), dmul(w2.z, c3)));
+        acc.c[3] = dadd(acc.c[3], dadd(dmr2(w0.w, c1, w1.w, c2), dmul(w2.w, c3)));
     }
     acc = group_sum(acc, L);
     if (lane == 0) {
@@ -180,8 +188,11 @@ hipError_t launch_open(const OpenArgs& a, int npts, const Ext& scale0, const Ext
 
 // ------------------------------------------------------------------ reduced openings (FRI input)
 // ro[p] = d1 (A_T - y_loc) + off_next d2 (A_T - y_next) + off_q d1 (A_Q - y_q),
-// A_T = sum_j alpha^j T[p][j], A_Q = sum_{j<8} alpha^j Q[p][j]
-__global__ void __launch_bounds__(256) reduced_opening_kernel(ReducedArgs a) {
+// A_T = sum_j alpha^j T[p][j], A_Q = sum_{j<8} alpha^j Q[p][j].
+// Two launches: (1) A_T per row, a row spread over L lanes, products summed in pairs in 64
+// bits before one Montgomery reduction; (2) one lane per row for the extension-field tail,
+// so that the ~100 multiplications of the tail keep all 64 lanes busy.
+__global__ void __launch_bounds__(256) rowdot_kernel(ReducedArgs a, uint32_t* __restrict__ out_at) {
     const int L = a.lanes_per_row;
     const uint64_t gid = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const uint64_t p = gid / L;
@@ -192,28 +203,38 @@ __global__ void __launch_bounds__(256) reduced_opening_kernel(ReducedArgs a) {
     const uint32_t nq = a.width / 4;
     for (uint32_t q = lane; q < nq; q += L) {
         const uint4 v = *reinterpret_cast<const uint4*>(row + 4 * q);
-        const uint32_t* ap = a.alpha_pow + 16 * q;
-        acc = ext_add(acc, ext_mul_base(ld_ext(ap), v.x));
-        acc = ext_add(acc, ext_mul_base(ld_ext(ap + 4), v.y));
-        acc = ext_add(acc, ext_mul_base(ld_ext(ap + 8), v.z));
-        acc = ext_add(acc, ext_mul_base(ld_ext(ap + 12), v.w));
+        const uint4* ap = reinterpret_cast<const uint4*>(a.alpha_pow + 16 * q);
+        const uint4 a0 = ap[0], a1 = ap[1], a2 = ap[2], a3 = ap[3];
+        acc.c[0] = dadd(acc.c[0], dadd(dmr2(a0.x, v.x, a1.x, v.y), dmr2(a2.x, v.z, a3.x, v.w)));
+        acc.c[1] = dadd(acc.c[1], dadd(dmr2(a0.y, v.x, a1.y, v.y), dmr2(a2.y, v.z, a3.y, v.w)));
+        acc.c[2] = dadd(acc.c[2], dadd(dmr2(a0.z, v.x, a1.z, v.y), dmr2(a2.z, v.z, a3.z, v.w)));
+        acc.c[3] = dadd(acc.c[3], dadd(dmr2(a0.w, v.x, a1.w, v.y), dmr2(a2.w, v.z, a3.w, v.w)));
     }
     acc = group_sum(acc, L);
-    if (lane == 0) {
-        const uint32_t* qrow = a.qlde + p * a.q_ld;
-        Ext aq = ext_zero();
-#pragma unroll
-        for (int j = 0; j < 8; j++) aq = ext_add(aq, ext_mul_base(ld_ext(a.alpha_pow + 4 * j), qrow[j]));
-        const Ext d1 = ld_ext(a.dinv + 4 * p), d2 = ld_ext(a.dinv + 4 * (a.rows + p));
-        Ext r = ext_mul(ext_sub(acc, a.y_loc), d1);
-        r = ext_add(r, ext_mul(a.off_next, ext_mul(ext_sub(acc, a.y_next), d2)));
-        r = ext_add(r, ext_mul(a.off_q, ext_mul(ext_sub(aq, a.y_q), d1)));
-        st_ext(a.out + 4 * p, r);
-    }
+    if (lane == 0) st_ext(out_at + 4 * p, acc);
 }
-hipError_t launch_reduced_opening(const ReducedArgs& a, hipStream_t s) {
+__global__ void __launch_bounds__(256) reduced_combine_kernel(ReducedArgs a, const uint32_t* __restrict__ at_in) {
+    const uint64_t p = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= a.rows) return;
+    const Ext at = ld_ext(at_in + 4 * p);
+    const uint4* qrow = reinterpret_cast<const uint4*>(a.qlde + p * a.q_ld);
+    const uint4 q0 = qrow[0], q1 = qrow[1];
+    const uint32_t qv[8] = {q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, q1.z, q1.w};
+    Ext aq = ext_zero();
+#pragma unroll
+    for (int j = 0; j < 8; j++) aq = ext_add(aq, ext_mul_base(ld_ext(a.alpha_pow + 4 * j), qv[j]));
+    const Ext d1 = ld_ext(a.dinv + 4 * p), d2 = ld_ext(a.dinv + 4 * (a.rows + p));
+    Ext r = ext_mul(ext_sub(at, a.y_loc), d1);
+    r = ext_add(r, ext_mul(a.off_next, ext_mul(ext_sub(at, a.y_next), d2)));
+    r = ext_add(r, ext_mul(a.off_q, ext_mul(ext_sub(aq, a.y_q), d1)));
+    st_ext(a.out + 4 * p, r);
+}
+hipError_t launch_reduced_opening(const ReducedArgs& a, uint32_t* scratch_at, hipStream_t s) {
     const uint64_t threads = a.rows * a.lanes_per_row;
-    hipLaunchKernelGGL(reduced_opening_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, s, a);
+    hipLaunchKernelGGL(rowdot_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, s, a, scratch_at);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(reduced_combine_kernel, dim3((unsigned)((a.rows + 255) / 256)), dim3(256), 0, s, a, scratch_at);
     return hipGetLastError();
 }
 
