@@ -96,15 +96,21 @@ static inline bb4_t bb4_pow(bb4_t a, uint64_t e) {
     while (e) { if (e & 1) r = bb4_mul(r, a); a = bb4_mul(a, a); e >>= 1; }
     return r;
 }
-/* inverse by Fermat in F_{p^4}: a^(p^4 - 2).  Slow but obviously correct:
- * p^4 - 2 does not fit in 64 bits, so use a^(p^4-2) = a^(p-2) * (a^p)^(p^3...) --
- * instead we use the norm route written out with plain powers:
- *   r = 1 + p + p^2 + p^3,  a^r lies in F_p,  a^-1 = a^(r-1) * (a^r)^-1.
- * a^(r-1) = a^p * a^(p^2) * a^(p^3), each obtained by repeated bb4_pow(.., p). */
+/* Frobenius x -> x^p: (sum a_i x^i)^p = sum a_i z^i x^i with z = 11^((p-1)/4), because
+ * x^p = x * (x^4)^((p-1)/4) and a_i^p = a_i. */
+#define BB_FROB_Z 1728404513u
+static inline bb4_t bb4_frobenius(bb4_t a) {
+    bb_t z2 = bb_mul(BB_FROB_Z, BB_FROB_Z), z3 = bb_mul(z2, BB_FROB_Z);
+    bb4_t r = {{a.c[0], bb_mul(a.c[1], BB_FROB_Z), bb_mul(a.c[2], z2), bb_mul(a.c[3], z3)}};
+    return r;
+}
+/* inverse through the norm to F_p: r = 1 + p + p^2 + p^3, a^r lies in F_p,
+ * a^-1 = a^(r-1) / a^r with a^(r-1) = a^p a^(p^2) a^(p^3).  (tests/test_oracle.py checks it
+ * against the plain Fermat power a^(p^4-2) computed in Python.) */
 static inline bb4_t bb4_inv(bb4_t a) {
-    bb4_t ap = bb4_pow(a, BB_P);      /* a^p     */
-    bb4_t ap2 = bb4_pow(ap, BB_P);    /* a^(p^2) */
-    bb4_t ap3 = bb4_pow(ap2, BB_P);   /* a^(p^3) */
+    bb4_t ap = bb4_frobenius(a);
+    bb4_t ap2 = bb4_frobenius(ap);
+    bb4_t ap3 = bb4_frobenius(ap2);
     bb4_t conj = bb4_mul(bb4_mul(ap, ap2), ap3);   /* a^(r-1) */
     bb4_t norm = bb4_mul(a, conj);                 /* in F_p: c[1..3] == 0 */
     bb_t ninv = bb_inv(norm.c[0]);
