@@ -35,7 +35,7 @@ def main():
     ap.add_argument("--log-n", type=int, default=20)
     ap.add_argument("--width", type=int, default=256)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-log-n", type=int, default=17, help="rows of the bounded CPU-baseline sample")
+    ap.add_argument("--cpu-log-n", type=int, default=19, help="rows of the bounded CPU-baseline sample")
     ap.add_argument("--cpu-threads", type=int, default=0, help="OpenMP threads of the CPU baseline (0: min(cores, 64))")
     args = ap.parse_args()
 
@@ -138,7 +138,7 @@ def main():
                 traffic = None
         roof = {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
-                "kernel": "zk::ntt_pass_kernel<4,false>", "algorithmic_bytes_per_launch": alg_bytes,
+                "kernel": "zk::ntt_pass1024x2_kernel<false>", "algorithmic_bytes_per_launch": alg_bytes,
                 "avg_launch_ms": round(avg_ms, 4),
                 "per_pass_ms": {"strided": round(per_which[0], 4), "contiguous": round(per_which[1], 4)}}
 

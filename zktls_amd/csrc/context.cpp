@@ -96,6 +96,10 @@ static NttPassArgs base_args(zkhip_ctx* ctx, const uint32_t* in, size_t in_ld, u
     // tuning knobs for A/B runs (never needed for correctness)
     static const int force_cpt = [] { const char* e = getenv("ZKHIP_NTT_CPT"); return e ? atoi(e) : 0; }();
     static const int map_mode = [] { const char* e = getenv("ZKHIP_NTT_MAP"); return e ? atoi(e) : 1; }();
+    static const int fast = [] { const char* e = getenv("ZKHIP_NTT_FAST"); return e ? atoi(e) : 1; }();
+    a.fast_path = fast == 1 ? 0u : (fast == 0 ? 2u : (uint32_t)fast);
+    static const int dbg = [] { const char* e = getenv("ZKHIP_NTT_DEBUG"); return e ? atoi(e) : 0; }();
+    a.debug_flags = (uint32_t)dbg;
     a.cols_per_thread = (uint32_t)force_cpt;
     a.map_mode = (uint32_t)map_mode;
     return a;

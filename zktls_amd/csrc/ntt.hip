@@ -216,6 +216,293 @@ __global__ void __launch_bounds__(32 << LOG_C, 4) ntt_pass_kernel(NttPassArgs a)
     }
 }
 
+// ------------------------------------------------------------------ persistent fast path
+// M = 1024 rows x 32 columns per tile, one 1024-thread workgroup per CU that walks its tiles:
+//   * 128-byte row chunks (a wave = 2 rows x 32 columns) -- the HBM likes them far better than
+//     the 64-byte chunks of the generic kernel (tools/microbench: 5.1-5.5 vs 3.8-4.8 TB/s);
+//   * the 32 loads of the NEXT tile are issued before the current tile is transformed and stay
+//     in flight behind counted waits (raw s_barrier + lgkmcnt(0) only, never vmcnt(0)), so HBM
+//     latency hides under ~9 us of butterflies instead of being exposed at every tile start;
+//   * stores are fire-and-forget.
+// LDS: exchange buffer 32 x 33 x 32 words + three 1024-word tables = 147 456 B (one per CU).
+ZK_D void wg_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
+struct ItemPos { uint32_t tile, cg; };
+ZK_D ItemPos item_pos(uint32_t item, uint32_t ncg, uint32_t map_mode) {
+    ItemPos p;
+    if (map_mode == 1) {
+        const uint32_t xcd = item & 7u, l = item >> 3;
+        p.cg = l % ncg;
+        p.tile = (l / ncg) * 8u + xcd;
+    } else {
+        p.cg = item % ncg;
+        p.tile = item / ncg;
+    }
+    return p;
+}
+
+template <bool INV>
+__global__ void __launch_bounds__(1024) ntt_pass1024_kernel(NttPassArgs a, uint32_t total_items) {
+    extern __shared__ uint32_t lds[];
+    constexpr int C = 32, Pn = 32, M = 1024, pitch = (Pn + 1) * C;
+    uint32_t* sdata = lds;
+    uint32_t* stw = lds + 32 * pitch;
+    uint32_t* spost = stw + M;
+    uint32_t* spre = spost + M;
+    const int tid = threadIdx.x;
+    const int c = tid & (C - 1);
+    const int u = tid >> 5;
+    const uint32_t ncg = a.ncols / C;
+    const bool has_post = a.post != nullptr, has_pre = a.pre != nullptr;
+    const uint64_t istep = (uint64_t)Pn * a.in_stride * a.in_ld;
+    const uint64_t ostep = a.out_stride * a.out_ld;
+
+    // tile-independent tables, once per workgroup
+    stw[tid] = a.w1024[tid];
+    if (has_pre) spre[tid] = a.pre[tid];
+
+    // buffer addressing: wave-uniform descriptor (tile base) + one 32-bit per-lane byte offset +
+    // a scalar offset per row group -> no 64-bit address VGPRs, which is what lets 64 data
+    // registers (this tile + the prefetched one) fit the 128-VGPR budget of 16 waves per CU
+    const uint32_t in_off = 4u * ((uint32_t)((uint64_t)u * a.in_stride * a.in_ld) + (uint32_t)c);
+    const uint32_t istep_b = (uint32_t)(4u * istep);
+    const uint32_t ostep_b = (uint32_t)(4u * ostep);
+    uint32_t nx[32];
+    uint32_t item = blockIdx.x;
+    {
+        const ItemPos p = item_pos(item, ncg, a.map_mode);
+        const uint32_t* ib = a.in + (uint64_t)p.tile * a.in_tile_mul * a.in_ld + p.cg * C;
+        const auto rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint32_t*>(ib), 0, 0xFFFFFFFFu, 0x00020000);
+#pragma unroll
+        for (int n1 = 0; n1 < 32; n1++) nx[n1] = __builtin_amdgcn_raw_buffer_load_b32(rs, in_off, n1 * istep_b, 0);
+    }
+    wg_barrier();
+    for (; item < total_items; item += gridDim.x) {
+        const ItemPos cur = item_pos(item, ncg, a.map_mode);
+        // this tile's inter-pass twiddles (one per thread), requested before the prefetch so that
+        // the counted wait for it leaves the prefetch in flight
+        uint32_t pv = 0;
+        if (has_post) pv = a.post[(uint64_t)cur.tile * M + tid];
+        uint32_t x[32];
+#pragma unroll
+        for (int n1 = 0; n1 < 32; n1++) x[n1] = nx[n1];
+        const uint32_t nitem = item + gridDim.x;
+        if (nitem < total_items) {
+            const ItemPos p = item_pos(nitem, ncg, a.map_mode);
+            const uint32_t* ib = a.in + (uint64_t)p.tile * a.in_tile_mul * a.in_ld + p.cg * C;
+            const auto rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint32_t*>(ib), 0, 0xFFFFFFFFu, 0x00020000);
+#pragma unroll
+            for (int n1 = 0; n1 < 32; n1++) nx[n1] = __builtin_amdgcn_raw_buffer_load_b32(rs, in_off, n1 * istep_b, 0);
+        }
+        if (has_post) spost[tid] = pv;
+
+        if (has_pre) {
+#pragma unroll
+            for (int n1 = 0; n1 < 32; n1++) x[n1] = dmul(x[n1], spre[u + Pn * n1]);
+        }
+        dif_stage<INV, 0>(x);
+        dif_stage<INV, 1>(x);
+        dif_stage<INV, 2>(x);
+        dif_stage<INV, 3>(x);
+        dif_stage<INV, 4, true>(x);
+        {
+            uint32_t* wp = sdata + u * C + c;
+#pragma unroll
+            for (int r = 0; r < 32; r++) {
+                const int k1 = rev5(r);
+                wp[k1 * pitch] = (k1 == 0) ? dred(x[r]) : dmul(x[r], stw[u * k1]);
+            }
+        }
+        wg_barrier();
+        {
+            const uint32_t* rp = sdata + u * pitch + c;      // P = 32: k1 = u, t = rho
+#pragma unroll
+            for (int rho = 0; rho < 32; rho++) x[rho] = rp[rho * C];
+        }
+        dif_stage<INV, 0>(x);
+        dif_stage<INV, 1>(x);
+        dif_stage<INV, 2>(x);
+        dif_stage<INV, 3>(x);
+        // element k = 32 rev5(rho) + u goes to tile row o(k) = k, or bitrev10(k) = 32 rev5(u) + rho:
+        // either way o * ostep splits into a wave-uniform part (rho) and a per-lane 32-bit offset
+        uint32_t* ob = a.out + (uint64_t)cur.tile * a.out_tile_mul * a.out_ld + cur.cg * C;
+        const auto ors = __builtin_amdgcn_make_buffer_rsrc(ob, 0, 0xFFFFFFFFu, 0x00020000);
+        const uint32_t out_off = (a.bitrev_out ? 32u * (__brev((uint32_t)u) >> 27) : (uint32_t)u) * ostep_b + 4u * (uint32_t)c;
+        if (has_post) {
+            dif_stage<INV, 4, true>(x);
+#pragma unroll
+            for (int rho = 0; rho < 32; rho++) {
+                const uint32_t v = dmul(x[rho], spost[32 * rev5(rho) + u]);
+                const uint32_t ro = a.bitrev_out ? (uint32_t)rho : (uint32_t)(32 * rev5(rho));
+                __builtin_amdgcn_raw_buffer_store_b32(v, ors, out_off, ro * ostep_b, 0);
+            }
+        } else {
+            dif_stage<INV, 4>(x);
+#pragma unroll
+            for (int rho = 0; rho < 32; rho++) {
+                const uint32_t ro = a.bitrev_out ? (uint32_t)rho : (uint32_t)(32 * rev5(rho));
+                __builtin_amdgcn_raw_buffer_store_b32(x[rho], ors, out_off, ro * ostep_b, 0);
+            }
+        }
+        wg_barrier();          // sdata / spost are rewritten by the next tile
+    }
+}
+
+// Two columns per lane, 512 threads (2 waves per SIMD, up to 256 VGPRs): the register file
+// then holds this tile (64 values) AND the prefetched next tile (64 values) without spills,
+// loads/stores are 8 bytes per lane (a wave = 4 rows x 128 B) and the LDS exchange moves
+// both columns with one ds_write_b64 / ds_read_b64.
+typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+template <bool INV>
+__global__ void __launch_bounds__(512) ntt_pass1024x2_kernel(NttPassArgs a, uint32_t total_items) {
+    extern __shared__ uint32_t lds[];
+    constexpr int C = 32, C2 = 16, Pn = 32, M = 1024, pitch2 = (Pn + 1) * C2;   // pitch in column pairs
+    uint2* sdata = reinterpret_cast<uint2*>(lds);
+    uint32_t* stw = lds + 2 * 32 * pitch2;
+    uint32_t* spost = stw + M;
+    uint32_t* spre = spost + M;
+    const int tid = threadIdx.x;
+    const int c2 = tid & (C2 - 1);
+    const int u = tid >> 4;
+    const uint32_t ncg = a.ncols / C;
+    const bool has_post = a.post != nullptr, has_pre = a.pre != nullptr;
+    const uint32_t istep_b = (uint32_t)(4u * (uint64_t)Pn * a.in_stride * a.in_ld);
+    const uint32_t ostep_b = (uint32_t)(4u * a.out_stride * a.out_ld);
+    const uint32_t in_off = 4u * (uint32_t)((uint64_t)u * a.in_stride * a.in_ld) + 8u * (uint32_t)c2;
+    // timing-only knobs (tools/ab_ntt.sh): a zero-record descriptor drops the loads / stores
+    const uint32_t in_rec = (a.debug_flags & 1u) ? 0u : 0xFFFFFFFFu, out_rec = (a.debug_flags & 2u) ? 0u : 0xFFFFFFFFu;
+
+    stw[tid] = a.w1024[tid];
+    stw[tid + 512] = a.w1024[tid + 512];
+    if (has_pre) { spre[tid] = a.pre[tid]; spre[tid + 512] = a.pre[tid + 512]; }
+
+    uint32_t n0[32], n1[32];
+    uint32_t item = blockIdx.x;
+    {
+        const ItemPos p = item_pos(item, ncg, a.map_mode);
+        const uint32_t* ib = a.in + (uint64_t)p.tile * a.in_tile_mul * a.in_ld + p.cg * C;
+        const auto rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint32_t*>(ib), 0, in_rec, 0x00020000);
+#pragma unroll
+        for (int k = 0; k < 32; k++) {
+            const u32x2 v = __builtin_amdgcn_raw_buffer_load_b64(rs, in_off, k * istep_b, 0);
+            n0[k] = v.x; n1[k] = v.y;
+        }
+    }
+    wg_barrier();
+    for (; item < total_items; item += gridDim.x) {
+        const ItemPos cur = item_pos(item, ncg, a.map_mode);
+        uint32_t pv0 = 0, pv1 = 0;
+        if (has_post) { pv0 = a.post[(uint64_t)cur.tile * M + tid]; pv1 = a.post[(uint64_t)cur.tile * M + tid + 512]; }
+        uint32_t x0[32], x1[32];
+#pragma unroll
+        for (int k = 0; k < 32; k++) { x0[k] = n0[k]; x1[k] = n1[k]; }
+        const uint32_t nitem = item + gridDim.x;
+        if (nitem < total_items) {
+            const ItemPos p = item_pos(nitem, ncg, a.map_mode);
+            const uint32_t* ib = a.in + (uint64_t)p.tile * a.in_tile_mul * a.in_ld + p.cg * C;
+            const auto rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint32_t*>(ib), 0, in_rec, 0x00020000);
+#pragma unroll
+            for (int k = 0; k < 32; k++) {
+                const u32x2 v = __builtin_amdgcn_raw_buffer_load_b64(rs, in_off, k * istep_b, 0);
+                n0[k] = v.x; n1[k] = v.y;
+            }
+        }
+        if (has_post) { spost[tid] = pv0; spost[tid + 512] = pv1; }
+
+        if (has_pre) {
+#pragma unroll
+            for (int k = 0; k < 32; k++) {
+                const uint32_t w = spre[u + Pn * k];
+                x0[k] = dmul(x0[k], w); x1[k] = dmul(x1[k], w);
+            }
+        }
+        dif_stage<INV, 0>(x0); dif_stage<INV, 0>(x1);
+        dif_stage<INV, 1>(x0); dif_stage<INV, 1>(x1);
+        dif_stage<INV, 2>(x0); dif_stage<INV, 2>(x1);
+        dif_stage<INV, 3>(x0); dif_stage<INV, 3>(x1);
+        dif_stage<INV, 4, true>(x0); dif_stage<INV, 4, true>(x1);
+        {
+            uint2* wp = sdata + u * C2 + c2;
+#pragma unroll
+            for (int r = 0; r < 32; r++) {
+                const int k1 = rev5(r);
+                if (k1 == 0) wp[0] = make_uint2(dred(x0[r]), dred(x1[r]));
+                else { const uint32_t w = stw[u * k1]; wp[k1 * pitch2] = make_uint2(dmul(x0[r], w), dmul(x1[r], w)); }
+            }
+        }
+        wg_barrier();
+        {
+            const uint2* rp = sdata + u * pitch2 + c2;       // P = 32: k1 = u, t = rho
+#pragma unroll
+            for (int rho = 0; rho < 32; rho++) { const uint2 v = rp[rho * C2]; x0[rho] = v.x; x1[rho] = v.y; }
+        }
+        dif_stage<INV, 0>(x0); dif_stage<INV, 0>(x1);
+        dif_stage<INV, 1>(x0); dif_stage<INV, 1>(x1);
+        dif_stage<INV, 2>(x0); dif_stage<INV, 2>(x1);
+        dif_stage<INV, 3>(x0); dif_stage<INV, 3>(x1);
+        uint32_t* ob = a.out + (uint64_t)cur.tile * a.out_tile_mul * a.out_ld + cur.cg * C;
+        const auto ors = __builtin_amdgcn_make_buffer_rsrc(ob, 0, out_rec, 0x00020000);
+        const uint32_t out_off = (a.bitrev_out ? 32u * (__brev((uint32_t)u) >> 27) : (uint32_t)u) * ostep_b + 8u * (uint32_t)c2;
+        if (has_post) {
+            dif_stage<INV, 4, true>(x0); dif_stage<INV, 4, true>(x1);
+#pragma unroll
+            for (int rho = 0; rho < 32; rho++) {
+                const uint32_t w = spost[32 * rev5(rho) + u];
+                const uint32_t ro = a.bitrev_out ? (uint32_t)rho : (uint32_t)(32 * rev5(rho));
+                u32x2 v; v.x = dmul(x0[rho], w); v.y = dmul(x1[rho], w);
+                __builtin_amdgcn_raw_buffer_store_b64(v, ors, out_off, ro * ostep_b, 0);
+            }
+        } else {
+            dif_stage<INV, 4>(x0); dif_stage<INV, 4>(x1);
+#pragma unroll
+            for (int rho = 0; rho < 32; rho++) {
+                const uint32_t ro = a.bitrev_out ? (uint32_t)rho : (uint32_t)(32 * rev5(rho));
+                u32x2 v; v.x = x0[rho]; v.y = x1[rho];
+                __builtin_amdgcn_raw_buffer_store_b64(v, ors, out_off, ro * ostep_b, 0);
+            }
+        }
+        wg_barrier();
+    }
+}
+
+static int cu_count() {
+    static int n = 0;
+    if (n == 0) {
+        int dev = 0;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
+    }
+    return n;
+}
+
+template <bool INV>
+static hipError_t launch_ntt1024(const NttPassArgs& a, hipStream_t s) {
+    const uint32_t total = a.num_tiles * (a.ncols / 32);
+    const uint32_t grid = total < (uint32_t)cu_count() ? total : (uint32_t)cu_count();
+    const size_t lds = (size_t)(32 * 33 * 32 + 3 * 1024) * sizeof(uint32_t);
+    static bool configured = false;
+    if (!configured) {
+        hipError_t e = hipFuncSetAttribute((const void*)ntt_pass1024_kernel<INV>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+        configured = true;
+    }
+    hipLaunchKernelGGL((ntt_pass1024_kernel<INV>), dim3(grid), dim3(1024), lds, s, a, total);
+    return hipGetLastError();
+}
+template <bool INV>
+static hipError_t launch_ntt1024x2(const NttPassArgs& a, hipStream_t s) {
+    const uint32_t total = a.num_tiles * (a.ncols / 32);
+    const uint32_t grid = total < (uint32_t)cu_count() ? total : (uint32_t)cu_count();
+    const size_t lds = (size_t)(2 * 32 * 33 * 16 + 3 * 1024) * sizeof(uint32_t);
+    static bool configured = false;
+    if (!configured) {
+        hipError_t e = hipFuncSetAttribute((const void*)ntt_pass1024x2_kernel<INV>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+        configured = true;
+    }
+    hipLaunchKernelGGL((ntt_pass1024x2_kernel<INV>), dim3(grid), dim3(512), lds, s, a, total);
+    return hipGetLastError();
+}
+
 static size_t ntt_lds_bytes(int log_m, int log_c) {
     int b = log_m - 5, Pn = 1 << b, M = 32 << b, C = 1 << log_c;
     return (size_t)(32 * (Pn + 1) * C + 3 * M) * sizeof(uint32_t);
@@ -243,6 +530,14 @@ hipError_t launch_ntt_pass(const NttPassArgs& a_, bool inverse, hipStream_t s) {
     NttPassArgs a = a_;
     if (a.log_m < 5 || a.log_m > 10) return hipErrorInvalidValue;
     if (a.map_mode == 1 && (a.num_tiles % 8u) != 0) a.map_mode = 0;
+    // headline shape: 1024-row tiles of a matrix whose width is a multiple of 32
+    if (a.log_m == 10 && a.ncols >= 32 && a.ncols % 32 == 0 && a.fast_path != 2) {
+        if (a.map_mode == 1 && ((a.num_tiles % 8u) != 0 || (cu_count() % 8) != 0)) a.map_mode = 0;
+        const bool al8 = a.in_ld % 2 == 0 && a.out_ld % 2 == 0 && (reinterpret_cast<uintptr_t>(a.in) & 7) == 0 &&
+                         (reinterpret_cast<uintptr_t>(a.out) & 7) == 0;
+        if (a.fast_path == 3 || !al8) return inverse ? launch_ntt1024<true>(a, s) : launch_ntt1024<false>(a, s);
+        return inverse ? launch_ntt1024x2<true>(a, s) : launch_ntt1024x2<false>(a, s);
+    }
     // two columns per lane need 8-byte aligned row chunks
     const bool pair_ok = a.ncols >= 32 && a.ncols % 2 == 0 && a.in_ld % 2 == 0 && a.out_ld % 2 == 0 &&
                          (reinterpret_cast<uintptr_t>(a.in) & 7) == 0 && (reinterpret_cast<uintptr_t>(a.out) & 7) == 0 &&
