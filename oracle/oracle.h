@@ -94,6 +94,14 @@ uint32_t orc_synth_value(uint64_t seed, uint64_t index);
 void orc_fill_uniform(uint64_t seed, int log_n, size_t width, uint32_t* out);
 /* AIR-satisfying trace for shard `shard` (width % 4 == 0) */
 void orc_gen_trace(uint64_t seed, uint64_t shard, int log_n, size_t width, uint32_t* out);
+/* trace whose odd groups (first `pairs` pairs) receive the even groups' (a, b) under the row
+ * permutation 5i+3 mod N: satisfies the LogUp-extended AIR (orc_params_t.logup_pairs = pairs) */
+void orc_gen_trace_logup(uint64_t seed, uint64_t shard, int log_n, size_t width, int pairs, uint32_t* out);
+/* permutation trace [phi_0 .. phi_{Q-1} | S]: N x 4(Q+1) words */
+void orc_perm_trace(const uint32_t* trace, int log_n, size_t width, int pairs,
+                    const uint32_t gamma[4], const uint32_t beta[4], uint32_t* out);
+void orc_quotient_values_logup(const uint32_t* lde, int log_n, size_t width, const uint32_t* perm_lde, int pairs,
+                               const uint32_t gamma[4], const uint32_t beta[4], const uint32_t alpha[4], uint32_t* out);
 /* number of constraint violations of the synthetic AIR on a trace (0 = valid) */
 size_t orc_check_trace(const uint32_t* trace, int log_n, size_t width);
 
@@ -102,6 +110,7 @@ typedef struct {
     int log_blowup;       /* 1  (SP1 core)                    */
     int num_queries;      /* 100                              */
     int pow_bits;         /* 16                               */
+    int logup_pairs;      /* 0: no lookup argument; Q > 0: Q LogUp sender/receiver group pairs */
 } orc_params_t;
 
 /* quotient values on the LDE coset, in bit-reversed row order like the LDE:

@@ -92,6 +92,79 @@ size_t orc_check_trace(const uint32_t* t, int log_n, size_t width) {
 }
 
 /* ------------------------------------------------------------------ */
+/* LogUp lookups (sp1-stark permutation trace)      */
+/* ------------------------------------------------------------------ */
+/* With `pairs` = Q > 0, group 2q+1 RECEIVES what group 2q SENDS: its (a, b) columns are the
+ * sender's (a, b) under the row permutation pi(i) = 5 i + 3 mod N, which no local constraint
+ * can express.  The lookup argument (LogUp, as sp1-stark's generate_permutation_trace builds
+ * it per chip): after the main commitment the verifier draws gamma, beta; the permutation
+ * trace has Q + 1 extension columns
+ *     phi_q[i] = 1/(gamma + a_s[i] + beta b_s[i]) - 1/(gamma + a_r[i] + beta b_r[i])
+ *     S[i]     = sum_{r <= i} sum_q phi_q[r]                     (cumulative sum)
+ * with constraints (appended after the 3 G main ones, same alpha folding):
+ *     L_q  all rows    : phi_q den_s den_r - (den_r - den_s)      = 0   (degree 3)
+ *     T1   first row   : S - sum_q phi_q                           = 0
+ *     T2   transition  : S' - S - sum_q phi'_q                     = 0
+ *     T3   last row    : S                                         = 0   (multisets are equal) */
+static inline size_t logup_perm_row(size_t i, int log_n) { return (5 * i + 3) & (((size_t)1 << log_n) - 1); }
+
+void orc_gen_trace_logup(uint64_t seed, uint64_t shard, int log_n, size_t width, int pairs, uint32_t* out) {
+    size_t n = (size_t)1 << log_n, G = width / 4;
+    uint64_t s = seed + shard;
+#pragma omp parallel for schedule(static)
+    for (size_t i = 0; i < n; i++) {
+        for (size_t g = 0; g < G; g++) {
+            uint32_t* row = out + i * width + 4 * g;
+            /* receivers read the sender group's stream at the permuted row */
+            int recv = (g & 1) && (int)(g / 2) < pairs;
+            size_t sg = recv ? g - 1 : g;
+            size_t ri = recv ? logup_perm_row(i, log_n) : i;
+            bb_t a = orc_synth_value(s, ri * width + 4 * sg);
+            bb_t b = orc_synth_value(s, ri * width + 4 * sg + 1);
+            bb_t c = bb_add(bb_mul(bb_mul(a, a), b), air_k1(g));
+            bb_t d;
+            if (i == 0) d = air_d0(g);
+            else {
+                size_t pi = recv ? logup_perm_row(i - 1, log_n) : i - 1;
+                bb_t pa = orc_synth_value(s, pi * width + 4 * sg);
+                bb_t pb = orc_synth_value(s, pi * width + 4 * sg + 1);
+                bb_t pc = bb_add(bb_mul(bb_mul(pa, pa), pb), air_k1(g));
+                d = bb_add(bb_add(bb_mul(pa, pb), pc), air_k2(g));
+            }
+            row[0] = a; row[1] = b; row[2] = c; row[3] = d;
+        }
+    }
+}
+
+static bb4_t ld4(const uint32_t* p);
+static void st4(uint32_t* p, bb4_t v);
+
+/* N x 4 (Q + 1) words: [phi_0 | ... | phi_{Q-1} | S], extension elements flattened */
+void orc_perm_trace(const uint32_t* trace, int log_n, size_t width, int pairs,
+                    const uint32_t gamma_[4], const uint32_t beta_[4], uint32_t* out) {
+    size_t n = (size_t)1 << log_n, wp = 4 * ((size_t)pairs + 1);
+    bb4_t gamma = ld4(gamma_), beta = ld4(beta_);
+#pragma omp parallel for schedule(static)
+    for (size_t i = 0; i < n; i++) {
+        const uint32_t* row = trace + i * width;
+        bb4_t sum = bb4_zero();
+        for (int q = 0; q < pairs; q++) {
+            bb4_t ds = bb4_add(bb4_add_base(gamma, row[8 * q]), bb4_mul_base(beta, row[8 * q + 1]));
+            bb4_t dr = bb4_add(bb4_add_base(gamma, row[8 * q + 4]), bb4_mul_base(beta, row[8 * q + 5]));
+            bb4_t phi = bb4_sub(bb4_inv(ds), bb4_inv(dr));
+            st4(out + i * wp + 4 * q, phi);
+            sum = bb4_add(sum, phi);
+        }
+        st4(out + i * wp + 4 * pairs, sum);          /* row sum, turned into the running sum below */
+    }
+    bb4_t run = bb4_zero();
+    for (size_t i = 0; i < n; i++) {
+        run = bb4_add(run, ld4(out + i * wp + 4 * pairs));
+        st4(out + i * wp + 4 * pairs, run);
+    }
+}
+
+/* ------------------------------------------------------------------ */
 /* constraint folding:  acc = acc * alpha + C_k, k in AIR order         */
 /* ------------------------------------------------------------------ */
 static bb4_t fold_constraints_base(const uint32_t* local, const uint32_t* next, size_t width,
@@ -130,14 +203,37 @@ static bb4_t fold_constraints_ext(const bb4_t* local, const bb4_t* next, size_t 
 static bb4_t ld4(const uint32_t* p) { bb4_t r; memcpy(r.c, p, 16); return r; }
 static void st4(uint32_t* p, bb4_t v) { memcpy(p, v.c, 16); }
 
+/* LogUp constraints in extension arithmetic, continuing the Horner fold of `acc`.
+ * as/bs/ar/br: sender / receiver tuple of pair q; perm_* hold phi_0..phi_{Q-1}, S. */
+static bb4_t fold_logup(bb4_t acc, int pairs, const bb4_t* as, const bb4_t* bs, const bb4_t* ar, const bb4_t* br,
+                        const bb4_t* perm_local, const bb4_t* perm_next, bb4_t gamma, bb4_t beta,
+                        bb4_t sel_first, bb4_t sel_trans, bb4_t sel_last, bb4_t alpha) {
+    bb4_t sum_l = bb4_zero(), sum_n = bb4_zero();
+    for (int q = 0; q < pairs; q++) {
+        bb4_t ds = bb4_add(bb4_add(gamma, as[q]), bb4_mul(beta, bs[q]));
+        bb4_t dr = bb4_add(bb4_add(gamma, ar[q]), bb4_mul(beta, br[q]));
+        bb4_t c = bb4_sub(bb4_mul(bb4_mul(perm_local[q], ds), dr), bb4_sub(dr, ds));
+        acc = bb4_add(bb4_mul(acc, alpha), c);
+        sum_l = bb4_add(sum_l, perm_local[q]);
+        sum_n = bb4_add(sum_n, perm_next[q]);
+    }
+    bb4_t S = perm_local[pairs], Sn = perm_next[pairs];
+    acc = bb4_add(bb4_mul(acc, alpha), bb4_mul(sel_first, bb4_sub(S, sum_l)));
+    acc = bb4_add(bb4_mul(acc, alpha), bb4_mul(sel_trans, bb4_sub(bb4_sub(Sn, S), sum_n)));
+    acc = bb4_add(bb4_mul(acc, alpha), bb4_mul(sel_last, S));
+    return acc;
+}
+
 /* ------------------------------------------------------------------ */
 /* quotient values on the coset g * <w_2N>  (log_blowup = log_qd = 1)   */
 /* ------------------------------------------------------------------ */
-void orc_quotient_values(const uint32_t* lde, int log_n, size_t width,
-                         const uint32_t alpha_[4], uint32_t* out) {
+void orc_quotient_values_logup(const uint32_t* lde, int log_n, size_t width,
+                                const uint32_t* perm_lde, int pairs, const uint32_t gamma_[4], const uint32_t beta_[4],
+                                const uint32_t alpha_[4], uint32_t* out) {
     int log_m = log_n + 1;
-    size_t m = (size_t)1 << log_m, n = (size_t)1 << log_n;
+    size_t m = (size_t)1 << log_m, n = (size_t)1 << log_n, wp = 4 * ((size_t)pairs + 1);
     bb4_t alpha = ld4(alpha_);
+    bb4_t gamma = pairs ? ld4(gamma_) : bb4_zero(), beta = pairs ? ld4(beta_) : bb4_zero();
     bb_t w = bb_two_adic_generator(log_m);
     bb_t wn_inv = bb_inv(bb_two_adic_generator(log_n));   /* g_N^-1: last row of H */
 #pragma omp parallel for schedule(static)
@@ -151,8 +247,24 @@ void orc_quotient_values(const uint32_t* lde, int log_n, size_t width,
         size_t pn = bb_reverse_bits((uint32_t)((i + 2) & (m - 1)), log_m);
         bb4_t acc = fold_constraints_base(lde + p * width, lde + pn * width, width,
                                           sel_first, sel_trans, alpha);
+        if (pairs) {
+            bb_t sel_last = bb_mul(zh, bb_inv(bb_sub(x, wn_inv)));
+            bb4_t as[64], bs[64], ar[64], br[64], pl[65], pn_[65];
+            const uint32_t* row = lde + p * width;
+            for (int q = 0; q < pairs; q++) {
+                as[q] = bb4_from_base(row[8 * q]); bs[q] = bb4_from_base(row[8 * q + 1]);
+                ar[q] = bb4_from_base(row[8 * q + 4]); br[q] = bb4_from_base(row[8 * q + 5]);
+            }
+            for (int q = 0; q <= pairs; q++) { pl[q] = ld4(perm_lde + p * wp + 4 * q); pn_[q] = ld4(perm_lde + pn * wp + 4 * q); }
+            acc = fold_logup(acc, pairs, as, bs, ar, br, pl, pn_, gamma, beta, bb4_from_base(sel_first),
+                             bb4_from_base(sel_trans), bb4_from_base(sel_last), alpha);
+        }
         st4(out + 4 * p, bb4_mul_base(acc, inv_zh));
     }
+}
+void orc_quotient_values(const uint32_t* lde, int log_n, size_t width,
+                         const uint32_t alpha_[4], uint32_t* out) {
+    orc_quotient_values_logup(lde, log_n, width, NULL, 0, NULL, NULL, alpha_, out);
 }
 
 /* ------------------------------------------------------------------ */
@@ -211,8 +323,10 @@ void orc_fri_fold(const uint32_t* in, int log_h, const uint32_t beta_[4], uint32
 size_t orc_proof_size(int log_n, size_t width, const orc_params_t* prm, size_t n_public) {
     (void)n_public;
     size_t H = (size_t)(log_n + prm->log_blowup), L = (size_t)log_n;
+    size_t Q = (size_t)prm->logup_pairs, wp = Q ? 4 * (Q + 1) : 0;
     size_t words = 8 + 16 + 8 * width + 32 + 8 * L + 5;
     size_t perq = width + 8 + 16 * H;
+    if (Q) { words += 1 + 8 + 8 * wp; perq += wp + 8 * H; }
     for (size_t l = 0; l < L; l++) perq += 4 + 8 * (H - 1 - l);
     words += (size_t)prm->num_queries * perq;
     return words * 4;
@@ -233,23 +347,43 @@ static void transcript_init(orc_challenger_t* ch, int log_n, size_t width,
     orc_chal_observe(ch, (uint32_t)prm->num_queries);
     orc_chal_observe(ch, (uint32_t)prm->pow_bits);
     orc_chal_observe(ch, (uint32_t)n_public);
+    if (prm->logup_pairs) orc_chal_observe(ch, (uint32_t)prm->logup_pairs);
+}
+
+static int params_ok(int log_n, size_t width, const orc_params_t* prm) {
+    if (prm->log_blowup != 1 || width % 4 != 0 || width == 0) return 0;
+    if (prm->logup_pairs < 0 || prm->logup_pairs > 64 || (size_t)prm->logup_pairs * 8 > width) return 0;
+    (void)log_n;
+    return 1;
+}
+
+/* sum_j alpha^j * row[j] over `w` base-field words */
+static bb4_t row_dot(const bb4_t* pw, const uint32_t* row, size_t w) {
+    bb4_t a = bb4_zero();
+    for (size_t j = 0; j < w; j++) a = bb4_add(a, bb4_mul_base(pw[j], row[j]));
+    return a;
+}
+static void copy_path(uint32_t* pf, size_t* pos, const uint32_t* tree, size_t leaves, size_t index, int levels) {
+    const uint32_t* lvl = tree; size_t cnt = leaves, idx = index;
+    for (int k = 0; k < levels; k++) { memcpy(pf + *pos, lvl + 8 * (idx ^ 1), 32); *pos += 8; lvl += 8 * cnt; cnt >>= 1; idx >>= 1; }
 }
 
 size_t orc_prove_shard(const uint32_t* trace, int log_n, size_t width,
                        const uint32_t* public_values, size_t n_public,
                        const orc_params_t* prm, uint8_t* proof_bytes, size_t cap) {
-    if (prm->log_blowup != 1 || width % 4 != 0 || width == 0) return 0;
+    if (!params_ok(log_n, width, prm)) return 0;
     size_t need = orc_proof_size(log_n, width, prm, n_public);
     if (cap < need) return 0;
     uint32_t* pf = (uint32_t*)proof_bytes;
     size_t pos = 0;
-    const int H = log_n + 1;
-    const size_t n = (size_t)1 << log_n, m = (size_t)1 << H;
+    const int H = log_n + 1, Q = prm->logup_pairs;
+    const size_t n = (size_t)1 << log_n, m = (size_t)1 << H, wp = Q ? 4 * ((size_t)Q + 1) : 0;
 
-    pf[pos++] = PROOF_MAGIC; pf[pos++] = PROOF_VERSION; pf[pos++] = (uint32_t)log_n;
+    pf[pos++] = PROOF_MAGIC; pf[pos++] = Q ? 2u : PROOF_VERSION; pf[pos++] = (uint32_t)log_n;
     pf[pos++] = (uint32_t)width; pf[pos++] = (uint32_t)prm->log_blowup;
     pf[pos++] = (uint32_t)prm->num_queries; pf[pos++] = (uint32_t)prm->pow_bits;
     pf[pos++] = (uint32_t)n_public;
+    if (Q) pf[pos++] = (uint32_t)Q;
 
     orc_challenger_t ch;
     transcript_init(&ch, log_n, width, prm, n_public);
@@ -265,11 +399,29 @@ size_t orc_prove_shard(const uint32_t* trace, int log_n, size_t width,
     orc_chal_observe_slice(&ch, troot, 8);
     orc_chal_observe_slice(&ch, public_values, n_public);
 
+    /* 1b. LogUp: lookup challenges, permutation trace, its commitment */
+    bb4_t gamma = bb4_zero(), beta_l = bb4_zero();
+    uint32_t *plde = NULL, *ptree = NULL;
+    if (Q) {
+        gamma = sample_ext(&ch);
+        beta_l = sample_ext(&ch);
+        uint32_t* perm = (uint32_t*)malloc(n * wp * 4);
+        orc_perm_trace(trace, log_n, width, Q, gamma.c, beta_l.c, perm);
+        plde = (uint32_t*)malloc(m * wp * 4);
+        orc_coset_lde(perm, plde, log_n, wp, 1, BB_GEN);
+        free(perm);
+        ptree = (uint32_t*)malloc((2 * m - 1) * 32);
+        { const uint32_t* mats[1] = {plde}; size_t ws[1] = {wp}; orc_merkle_tree(mats, ws, 1, H, ptree); }
+        const uint32_t* proot = ptree + (2 * m - 2) * 8;
+        memcpy(pf + pos, proot, 32); pos += 8;
+        orc_chal_observe_slice(&ch, proot, 8);
+    }
+
     /* 2. constraint challenge, quotient, chunks, commit */
     bb4_t alpha = sample_ext(&ch);
     memcpy(g_dbg.alpha, alpha.c, 16);
     uint32_t* qv = (uint32_t*)malloc(m * 16);          /* bit-reversed like the LDE */
-    orc_quotient_values(tlde, log_n, width, alpha.c, qv);
+    orc_quotient_values_logup(tlde, log_n, width, plde, Q, gamma.c, beta_l.c, alpha.c, qv);
     /* chunk k = natural rows i = 2j + k  <->  bit-reversed rows [k*N, (k+1)*N);
      * as a matrix on the coset (g w^k) * <w_N> in natural order j: */
     uint32_t* qlde = (uint32_t*)malloc(m * 8 * 4);     /* [chunk0 | chunk1], width 8 */
@@ -303,27 +455,40 @@ size_t orc_prove_shard(const uint32_t* trace, int log_n, size_t width,
     bb4_t zeta_next = bb4_mul_base(zeta, bb_two_adic_generator(log_n));
     uint32_t* op_local = pf + pos; pos += 4 * width;
     uint32_t* op_next = pf + pos; pos += 4 * width;
+    uint32_t *op_pl = NULL, *op_pn = NULL;
+    if (Q) { op_pl = pf + pos; pos += 4 * wp; op_pn = pf + pos; pos += 4 * wp; }
     uint32_t* op_q = pf + pos; pos += 32;
     orc_open_at(tlde, log_n, width, zeta.c, op_local);
     orc_open_at(tlde, log_n, width, zeta_next.c, op_next);
+    if (Q) { orc_open_at(plde, log_n, wp, zeta.c, op_pl); orc_open_at(plde, log_n, wp, zeta_next.c, op_pn); }
     orc_open_at(qlde, log_n, 8, zeta.c, op_q);
     orc_chal_observe_slice(&ch, op_local, 4 * width);
     orc_chal_observe_slice(&ch, op_next, 4 * width);
+    if (Q) { orc_chal_observe_slice(&ch, op_pl, 4 * wp); orc_chal_observe_slice(&ch, op_pn, 4 * wp); }
     orc_chal_observe_slice(&ch, op_q, 32);
 
-    /* 4. FRI input: alpha-batched reduced openings at every LDE point */
+    /* 4. FRI input: alpha-batched reduced openings at every LDE point.
+     * batching order (offsets in powers of the FRI alpha): trace@zeta 0, trace@zeta_next W,
+     * [perm@zeta 2W, perm@zeta_next 2W+Wp], quotient@zeta 2W+2Wp */
     bb4_t fa = sample_ext(&ch);
     memcpy(g_dbg.fri_alpha, fa.c, 16);
-    bb4_t* fapow = (bb4_t*)malloc((width > 8 ? width : 8) * sizeof(bb4_t));
+    size_t np = width > 8 ? width : 8;
+    if (wp > np) np = wp;
+    bb4_t* fapow = (bb4_t*)malloc(np * sizeof(bb4_t));
     fapow[0] = bb4_one();
-    for (size_t j = 1; j < (width > 8 ? width : 8); j++) fapow[j] = bb4_mul(fapow[j - 1], fa);
-    bb4_t y_loc = bb4_zero(), y_nxt = bb4_zero(), y_q = bb4_zero();
+    for (size_t j = 1; j < np; j++) fapow[j] = bb4_mul(fapow[j - 1], fa);
+    bb4_t y_loc = bb4_zero(), y_nxt = bb4_zero(), y_pl = bb4_zero(), y_pn = bb4_zero(), y_q = bb4_zero();
     for (size_t j = 0; j < width; j++) {
         y_loc = bb4_add(y_loc, bb4_mul(fapow[j], ld4(op_local + 4 * j)));
         y_nxt = bb4_add(y_nxt, bb4_mul(fapow[j], ld4(op_next + 4 * j)));
     }
+    for (size_t j = 0; j < wp; j++) {
+        y_pl = bb4_add(y_pl, bb4_mul(fapow[j], ld4(op_pl + 4 * j)));
+        y_pn = bb4_add(y_pn, bb4_mul(fapow[j], ld4(op_pn + 4 * j)));
+    }
     for (size_t j = 0; j < 8; j++) y_q = bb4_add(y_q, bb4_mul(fapow[j], ld4(op_q + 4 * j)));
-    bb4_t off_next = bb4_pow(fa, width), off_q = bb4_pow(fa, 2 * width);
+    bb4_t off_next = bb4_pow(fa, width), off_pl = bb4_pow(fa, 2 * width), off_pn = bb4_pow(fa, 2 * width + wp),
+          off_q = bb4_pow(fa, 2 * width + 2 * wp);
     bb4_t* cur = (bb4_t*)malloc(m * sizeof(bb4_t));
     {
         bb_t w2n = bb_two_adic_generator(H);
@@ -332,11 +497,15 @@ size_t orc_prove_shard(const uint32_t* trace, int log_n, size_t width,
             bb_t x = bb_mul(BB_GEN, bb_pow(w2n, bb_reverse_bits((uint32_t)p, H)));
             bb4_t d1 = bb4_inv(bb4_neg(bb4_sub_base(zeta, x)));        /* 1/(x - zeta) */
             bb4_t d2 = bb4_inv(bb4_neg(bb4_sub_base(zeta_next, x)));
-            bb4_t at = bb4_zero(), aq = bb4_zero();
-            for (size_t j = 0; j < width; j++) at = bb4_add(at, bb4_mul_base(fapow[j], tlde[p * width + j]));
-            for (size_t j = 0; j < 8; j++) aq = bb4_add(aq, bb4_mul_base(fapow[j], qlde[p * 8 + j]));
+            bb4_t at = row_dot(fapow, tlde + p * width, width);
+            bb4_t aq = row_dot(fapow, qlde + p * 8, 8);
             bb4_t r = bb4_mul(bb4_sub(at, y_loc), d1);
             r = bb4_add(r, bb4_mul(off_next, bb4_mul(bb4_sub(at, y_nxt), d2)));
+            if (Q) {
+                bb4_t ap = row_dot(fapow, plde + p * wp, wp);
+                r = bb4_add(r, bb4_mul(off_pl, bb4_mul(bb4_sub(ap, y_pl), d1)));
+                r = bb4_add(r, bb4_mul(off_pn, bb4_mul(bb4_sub(ap, y_pn), d2)));
+            }
             r = bb4_add(r, bb4_mul(off_q, bb4_mul(bb4_sub(aq, y_q), d1)));
             cur[p] = r;
         }
@@ -377,23 +546,21 @@ size_t orc_prove_shard(const uint32_t* trace, int log_n, size_t width,
     for (int q = 0; q < prm->num_queries; q++) {
         size_t index = orc_chal_sample_bits(&ch, H);
         memcpy(pf + pos, tlde + index * width, width * 4); pos += width;
-        { size_t idx = index; const uint32_t* lvl = ttree; size_t cnt = m;
-          for (int k = 0; k < H; k++) { memcpy(pf + pos, lvl + 8 * (idx ^ 1), 32); pos += 8; lvl += 8 * cnt; cnt >>= 1; idx >>= 1; } }
+        copy_path(pf, &pos, ttree, m, index, H);
+        if (Q) { memcpy(pf + pos, plde + index * wp, wp * 4); pos += wp; copy_path(pf, &pos, ptree, m, index, H); }
         memcpy(pf + pos, qlde + index * 8, 32); pos += 8;
-        { size_t idx = index; const uint32_t* lvl = qtree; size_t cnt = m;
-          for (int k = 0; k < H; k++) { memcpy(pf + pos, lvl + 8 * (idx ^ 1), 32); pos += 8; lvl += 8 * cnt; cnt >>= 1; idx >>= 1; } }
+        copy_path(pf, &pos, qtree, m, index, H);
         size_t idx = index;
         for (int l = 0; l < L; l++) {
             int lh = H - 1 - l;
             size_t sib = idx ^ 1, pair = idx >> 1;
             st4(pf + pos, layers[l][sib]); pos += 4;
-            size_t id2 = pair; const uint32_t* lvl = ltrees[l]; size_t cnt = (size_t)1 << lh;
-            for (int k = 0; k < lh; k++) { memcpy(pf + pos, lvl + 8 * (id2 ^ 1), 32); pos += 8; lvl += 8 * cnt; cnt >>= 1; id2 >>= 1; }
+            copy_path(pf, &pos, ltrees[l], (size_t)1 << lh, pair, lh);
             idx = pair;
         }
     }
     for (int l = 0; l < L; l++) { free(layers[l]); free(ltrees[l]); }
-    free(layers); free(ltrees); free(tlde); free(ttree); free(qlde); free(qtree);
+    free(layers); free(ltrees); free(tlde); free(ttree); free(qlde); free(qtree); free(plde); free(ptree);
     if (!const_ok) return 0;
     return pos * 4 == need ? need : 0;
 }
@@ -406,29 +573,47 @@ static int verify_path(const uint32_t root[8], int log_h, size_t index,
     const uint32_t* rows[1] = {row}; size_t ws[1] = {width};
     return orc_merkle_verify(root, log_h, index, rows, ws, 1, sibs);
 }
+/* value at zeta of an extension column committed as 4 base columns: sum_e x^e * v_e(zeta) */
+static bb4_t recombine(const uint32_t* opened4) {
+    bb4_t r = bb4_zero();
+    for (int e = 0; e < 4; e++) {
+        bb4_t basis = bb4_zero(); basis.c[e] = 1;
+        r = bb4_add(r, bb4_mul(basis, ld4(opened4 + 4 * e)));
+    }
+    return r;
+}
 
 int orc_verify_shard(const uint8_t* proof_bytes, size_t len, int log_n, size_t width,
                      const uint32_t* public_values, size_t n_public,
                      const orc_params_t* prm) {
-    if (prm->log_blowup != 1 || width % 4 != 0 || width == 0) return 1;
+    if (!params_ok(log_n, width, prm)) return 1;
     if (len != orc_proof_size(log_n, width, prm, n_public)) return 2;
     const uint32_t* pf = (const uint32_t*)proof_bytes;
     size_t pos = 0;
-    const int H = log_n + 1, L = log_n;
-    const size_t n = (size_t)1 << log_n;
-    if (pf[0] != PROOF_MAGIC || pf[1] != PROOF_VERSION || pf[2] != (uint32_t)log_n ||
+    const int H = log_n + 1, L = log_n, Q = prm->logup_pairs;
+    const size_t n = (size_t)1 << log_n, wp = Q ? 4 * ((size_t)Q + 1) : 0;
+    if (pf[0] != PROOF_MAGIC || pf[1] != (Q ? 2u : PROOF_VERSION) || pf[2] != (uint32_t)log_n ||
         pf[3] != (uint32_t)width || pf[4] != (uint32_t)prm->log_blowup ||
         pf[5] != (uint32_t)prm->num_queries || pf[6] != (uint32_t)prm->pow_bits ||
         pf[7] != (uint32_t)n_public) return 3;
     pos = 8;
-    for (size_t i = 8; i < len / 4; i++) if (pf[i] >= BB_P) return 4;   /* canonical words only */
+    if (Q) { if (pf[8] != (uint32_t)Q) return 3; pos = 9; }
+    for (size_t i = pos; i < len / 4; i++) if (pf[i] >= BB_P) return 4;   /* canonical words only */
 
     orc_challenger_t ch;
     transcript_init(&ch, log_n, width, prm, n_public);
     const uint32_t* troot = pf + pos; pos += 8;
-    const uint32_t* qroot = pf + pos; pos += 8;
     orc_chal_observe_slice(&ch, troot, 8);
     orc_chal_observe_slice(&ch, public_values, n_public);
+    bb4_t gamma = bb4_zero(), beta_l = bb4_zero();
+    const uint32_t* proot = NULL;
+    if (Q) {
+        gamma = sample_ext(&ch);
+        beta_l = sample_ext(&ch);
+        proot = pf + pos; pos += 8;
+        orc_chal_observe_slice(&ch, proot, 8);
+    }
+    const uint32_t* qroot = pf + pos; pos += 8;
     bb4_t alpha = sample_ext(&ch);
     orc_chal_observe_slice(&ch, qroot, 8);
     bb4_t zeta = sample_ext(&ch);
@@ -436,9 +621,12 @@ int orc_verify_shard(const uint8_t* proof_bytes, size_t len, int log_n, size_t w
     bb4_t zeta_next = bb4_mul_base(zeta, gn);
     const uint32_t* op_local = pf + pos; pos += 4 * width;
     const uint32_t* op_next = pf + pos; pos += 4 * width;
+    const uint32_t *op_pl = NULL, *op_pn = NULL;
+    if (Q) { op_pl = pf + pos; pos += 4 * wp; op_pn = pf + pos; pos += 4 * wp; }
     const uint32_t* op_q = pf + pos; pos += 32;
     orc_chal_observe_slice(&ch, op_local, 4 * width);
     orc_chal_observe_slice(&ch, op_next, 4 * width);
+    if (Q) { orc_chal_observe_slice(&ch, op_pl, 4 * wp); orc_chal_observe_slice(&ch, op_pn, 4 * wp); }
     orc_chal_observe_slice(&ch, op_q, 32);
 
     /* (a) constraint check at zeta */
@@ -451,6 +639,13 @@ int orc_verify_shard(const uint8_t* proof_bytes, size_t len, int log_n, size_t w
         bb4_t sel_first = bb4_mul(zh, bb4_inv(bb4_sub_base(zeta, 1)));
         bb4_t sel_trans = bb4_sub_base(zeta, bb_inv(gn));
         bb4_t folded = fold_constraints_ext(loc, nxt, width, sel_first, sel_trans, alpha);
+        if (Q) {
+            bb4_t sel_last = bb4_mul(zh, bb4_inv(bb4_sub_base(zeta, bb_inv(gn))));
+            bb4_t as[64], bs[64], ar[64], br[64], pl[65], pn[65];
+            for (int q = 0; q < Q; q++) { as[q] = loc[8 * q]; bs[q] = loc[8 * q + 1]; ar[q] = loc[8 * q + 4]; br[q] = loc[8 * q + 5]; }
+            for (int q = 0; q <= Q; q++) { pl[q] = recombine(op_pl + 16 * q); pn[q] = recombine(op_pn + 16 * q); }
+            folded = fold_logup(folded, Q, as, bs, ar, br, pl, pn, gamma, beta_l, sel_first, sel_trans, sel_last, alpha);
+        }
         free(loc); free(nxt);
         /* quotient(zeta) = sum_k zps_k(zeta) * q_k(zeta); chunk domain k: shift s_k = g w_2N^k */
         bb_t w2n = bb_two_adic_generator(H);
@@ -462,12 +657,7 @@ int orc_verify_shard(const uint8_t* proof_bytes, size_t len, int log_n, size_t w
             bb4_t num = bb4_sub_base(bb4_mul_base(zn, sjn_inv), 1);                 /* Z_Dj(zeta) */
             bb_t den = bb_sub(bb_mul(bb_pow(s[k], n), sjn_inv), 1);                 /* Z_Dj(s_k)  */
             bb4_t zps = bb4_mul_base(num, bb_inv(den));
-            bb4_t qk = bb4_zero();
-            for (int e = 0; e < 4; e++) {
-                bb4_t basis = bb4_zero(); basis.c[e] = 1;
-                qk = bb4_add(qk, bb4_mul(basis, ld4(op_q + 4 * (4 * k + e))));
-            }
-            quot = bb4_add(quot, bb4_mul(zps, qk));
+            quot = bb4_add(quot, bb4_mul(zps, recombine(op_q + 16 * k)));
         }
         if (!bb4_eq(bb4_mul(folded, bb4_inv(zh)), quot)) return 10;
     }
@@ -475,16 +665,22 @@ int orc_verify_shard(const uint8_t* proof_bytes, size_t len, int log_n, size_t w
     /* (b) FRI */
     bb4_t fa = sample_ext(&ch);
     size_t np = width > 8 ? width : 8;
+    if (wp > np) np = wp;
     bb4_t* fapow = (bb4_t*)malloc(np * sizeof(bb4_t));
     fapow[0] = bb4_one();
     for (size_t j = 1; j < np; j++) fapow[j] = bb4_mul(fapow[j - 1], fa);
-    bb4_t y_loc = bb4_zero(), y_nxt = bb4_zero(), y_q = bb4_zero();
+    bb4_t y_loc = bb4_zero(), y_nxt = bb4_zero(), y_pl = bb4_zero(), y_pn = bb4_zero(), y_q = bb4_zero();
     for (size_t j = 0; j < width; j++) {
         y_loc = bb4_add(y_loc, bb4_mul(fapow[j], ld4(op_local + 4 * j)));
         y_nxt = bb4_add(y_nxt, bb4_mul(fapow[j], ld4(op_next + 4 * j)));
     }
+    for (size_t j = 0; j < wp; j++) {
+        y_pl = bb4_add(y_pl, bb4_mul(fapow[j], ld4(op_pl + 4 * j)));
+        y_pn = bb4_add(y_pn, bb4_mul(fapow[j], ld4(op_pn + 4 * j)));
+    }
     for (size_t j = 0; j < 8; j++) y_q = bb4_add(y_q, bb4_mul(fapow[j], ld4(op_q + 4 * j)));
-    bb4_t off_next = bb4_pow(fa, width), off_q = bb4_pow(fa, 2 * width);
+    bb4_t off_next = bb4_pow(fa, width), off_pl = bb4_pow(fa, 2 * width), off_pn = bb4_pow(fa, 2 * width + wp),
+          off_q = bb4_pow(fa, 2 * width + 2 * wp);
 
     const uint32_t* commits = pf + pos; pos += 8 * (size_t)L;
     bb4_t* betas = (bb4_t*)malloc(L * sizeof(bb4_t));
@@ -503,18 +699,24 @@ int orc_verify_shard(const uint8_t* proof_bytes, size_t len, int log_n, size_t w
         size_t index = orc_chal_sample_bits(&ch, H);
         const uint32_t* trow = pf + pos; pos += width;
         const uint32_t* tpath = pf + pos; pos += 8 * (size_t)H;
+        const uint32_t *prow = NULL, *ppath = NULL;
+        if (Q) { prow = pf + pos; pos += wp; ppath = pf + pos; pos += 8 * (size_t)H; }
         const uint32_t* qrow = pf + pos; pos += 8;
         const uint32_t* qpath = pf + pos; pos += 8 * (size_t)H;
         if (verify_path(troot, H, index, trow, width, tpath)) { rc = 30; break; }
+        if (Q && verify_path(proot, H, index, prow, wp, ppath)) { rc = 32; break; }
         if (verify_path(qroot, H, index, qrow, 8, qpath)) { rc = 31; break; }
         bb_t x = bb_mul(BB_GEN, bb_pow(w2n, bb_reverse_bits((uint32_t)index, H)));
         bb4_t d1 = bb4_inv(bb4_neg(bb4_sub_base(zeta, x)));
         bb4_t d2 = bb4_inv(bb4_neg(bb4_sub_base(zeta_next, x)));
-        bb4_t at = bb4_zero(), aq = bb4_zero();
-        for (size_t j = 0; j < width; j++) at = bb4_add(at, bb4_mul_base(fapow[j], trow[j]));
-        for (size_t j = 0; j < 8; j++) aq = bb4_add(aq, bb4_mul_base(fapow[j], qrow[j]));
+        bb4_t at = row_dot(fapow, trow, width), aq = row_dot(fapow, qrow, 8);
         bb4_t ro = bb4_mul(bb4_sub(at, y_loc), d1);
         ro = bb4_add(ro, bb4_mul(off_next, bb4_mul(bb4_sub(at, y_nxt), d2)));
+        if (Q) {
+            bb4_t ap = row_dot(fapow, prow, wp);
+            ro = bb4_add(ro, bb4_mul(off_pl, bb4_mul(bb4_sub(ap, y_pl), d1)));
+            ro = bb4_add(ro, bb4_mul(off_pn, bb4_mul(bb4_sub(ap, y_pn), d2)));
+        }
         ro = bb4_add(ro, bb4_mul(off_q, bb4_mul(bb4_sub(aq, y_q), d1)));
 
         bb4_t folded = ro;          /* single height: the reduced opening enters at layer 0 */

@@ -19,7 +19,7 @@ u32p = C.POINTER(C.c_uint32)
 
 
 class Params(C.Structure):
-    _fields_ = [("log_blowup", C.c_int), ("num_queries", C.c_int), ("pow_bits", C.c_int)]
+    _fields_ = [("log_blowup", C.c_int), ("num_queries", C.c_int), ("pow_bits", C.c_int), ("logup_pairs", C.c_int)]
 
 
 class ProveDebug(C.Structure):
@@ -230,8 +230,32 @@ def fri_fold(vals, beta):
     return out
 
 
-def default_params(log_blowup=1, num_queries=100, pow_bits=16):
-    return Params(log_blowup, num_queries, pow_bits)
+def default_params(log_blowup=1, num_queries=100, pow_bits=16, logup_pairs=0):
+    return Params(log_blowup, num_queries, pow_bits, logup_pairs)
+
+
+def gen_trace_logup(seed, shard, log_n, width, pairs):
+    out = np.empty((1 << log_n, width), dtype=np.uint32)
+    lib().orc_gen_trace_logup(C.c_uint64(seed), C.c_uint64(shard), C.c_int(log_n), C.c_size_t(width), C.c_int(pairs), _p(out))
+    return out
+
+
+def perm_trace(trace, pairs, gamma, beta):
+    t = _u32(trace)
+    n, w = t.shape
+    g, b = _u32(gamma), _u32(beta)
+    out = np.empty((n, 4 * (pairs + 1)), dtype=np.uint32)
+    lib().orc_perm_trace(_p(t), C.c_int(n.bit_length() - 1), C.c_size_t(w), C.c_int(pairs), _p(g), _p(b), _p(out))
+    return out
+
+
+def quotient_values_logup(lde, log_n, perm_lde, pairs, gamma, beta, alpha):
+    lde, perm_lde = _u32(lde), _u32(perm_lde)
+    g, b, a = _u32(gamma), _u32(beta), _u32(alpha)
+    out = np.empty((lde.shape[0], 4), dtype=np.uint32)
+    lib().orc_quotient_values_logup(_p(lde), C.c_int(log_n), C.c_size_t(lde.shape[1]), _p(perm_lde), C.c_int(pairs),
+                                    _p(g), _p(b), _p(a), _p(out))
+    return out
 
 
 def prove_shard(trace, public_values=(), params=None):
