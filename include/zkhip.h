@@ -69,6 +69,10 @@ typedef struct {
     int32_t log_blowup;
     int32_t num_queries;
     int32_t pow_bits;
+    /* 0: no lookup argument.  Q > 0: the first Q pairs of column groups are tied by a LogUp
+     * lookup argument (sp1-stark permutation trace): group 2q+1 must hold a
+     * row permutation of group 2q's (a, b) columns, see zkhip_gen_trace_logup. */
+    int32_t logup_pairs;
 } zkhip_params;
 
 /* ---- library / context ---- */
@@ -97,6 +101,11 @@ int zkhip_fill_uniform(zkhip_ctx* ctx, uint64_t seed, int log_n, uint32_t width,
 /* AIR-satisfying trace of shard `shard` (width % 4 == 0); stream seed = seed + shard */
 int zkhip_gen_trace(zkhip_ctx* ctx, uint64_t seed, uint64_t shard, int log_n, uint32_t width,
                     uint32_t* d_out, size_t ld);
+
+/* same AIR with lookups: the odd group of each of the first `pairs` group pairs receives the even
+ * group's (a, b) columns under the row permutation 5i+3 mod N (prove with logup_pairs = pairs) */
+int zkhip_gen_trace_logup(zkhip_ctx* ctx, uint64_t seed, uint64_t shard, int log_n, uint32_t width,
+                          int pairs, uint32_t* d_out, size_t ld);
 
 /* ---- NTT / LDE over the columns of a row-major matrix, 2^log_n rows, 5 <= log_n <= 20 ---- */
 /* forward DFT: natural rows in; rows out natural (bitrev_out = 0) or bit-reversed (1);
@@ -129,6 +138,10 @@ int zkhip_merkle_commit(zkhip_ctx* ctx, const uint32_t* const* d_mats, const siz
 int zkhip_quotient_values(zkhip_ctx* ctx, const uint32_t* d_lde, size_t ld, int log_n,
                           uint32_t width, const uint32_t alpha[4] /* host, Montgomery */,
                           uint32_t* d_out);
+/* LogUp permutation trace of a main trace (natural rows): d_out[2^log_n][4 (pairs + 1)] =
+ * [phi_0 .. phi_{Q-1} | running sum]; gamma, beta: host, Montgomery extension elements */
+int zkhip_perm_trace(zkhip_ctx* ctx, const uint32_t* d_trace, size_t ld, int log_n, uint32_t width, int pairs,
+                     const uint32_t gamma[4], const uint32_t beta[4], uint32_t* d_out);
 /* barycentric opening of every column of a bit-reversed LDE at `npoints` extension
  * points (host, Montgomery): h_out[npoints][width][4] (host, Montgomery) */
 int zkhip_open_at(zkhip_ctx* ctx, const uint32_t* d_lde, size_t ld, int log_n, int log_blowup,

@@ -107,3 +107,44 @@ def test_bad_arguments_fail_loudly(ctx):
         ctx.prove_shard(trace, 6, 8, [P], Params(1, 10, 4))       # non-canonical public value
     with pytest.raises(ZkHipError):
         ctx.coset_lde(trace, 4, 8)                                # log_n below the tile minimum
+
+
+# ------------------------------------------------------------------ LogUp
+@pytest.mark.parametrize("log_n,width,pairs,shard", [(5, 8, 1, 0), (8, 16, 2, 1), (10, 24, 3, 2), (12, 256, 32, 3)])
+def test_gen_trace_logup_and_perm_trace_match_oracle(ctx, oracle, log_n, width, pairs, shard):
+    d = ctx.gen_trace_logup(SEED, shard, log_n, width, pairs)
+    t = d.download().reshape(-1, width)
+    assert (t == oracle.gen_trace_logup(SEED, shard, log_n, width, pairs)).all()
+    rng = np.random.default_rng(log_n)
+    gamma = rng.integers(0, P, 4, dtype=np.uint32)
+    beta = rng.integers(0, P, 4, dtype=np.uint32)
+    got = ctx.perm_trace(d, log_n, width, pairs, gamma, beta).download().reshape(-1, 4 * (pairs + 1))
+    assert (got == oracle.perm_trace(t, pairs, gamma, beta)).all()
+    assert got[-1, -4:].tolist() == [0, 0, 0, 0]
+
+
+@pytest.mark.parametrize("log_n,width,pairs,q,pw", [(5, 8, 1, 4, 4), (6, 16, 2, 10, 8), (10, 24, 3, 30, 10), (12, 64, 8, 100, 16),
+                                                    (13, 256, 32, 100, 16)])
+def test_prove_shard_logup_bytes_equal_oracle(ctx, oracle, log_n, width, pairs, q, pw):
+    trace = ctx.gen_trace_logup(SEED, 3, log_n, width, pairs)
+    prm = Params(1, q, pw, pairs)
+    proof = ctx.prove_shard(trace, log_n, width, [7, 8], prm)
+    oprm = oracle.default_params(1, q, pw, pairs)
+    oproof = oracle.prove_shard(oracle.gen_trace_logup(SEED, 3, log_n, width, pairs), [7, 8], oprm)
+    assert proof.size == oproof.size
+    assert proof.tobytes() == oproof.tobytes()
+    assert oracle.verify_shard(proof, log_n, width, [7, 8], oprm) == 0
+    assert verify_shard(proof, log_n, width, [7, 8], prm) == (0, 0)
+
+
+def test_logup_rejects_trace_without_the_permutation(ctx):
+    from zktls_amd._lib import ZkHipError
+    log_n, width = 8, 16
+    plain = ctx.gen_trace(SEED, 0, log_n, width)
+    prm = Params(1, 10, 4, 2)
+    try:
+        proof = ctx.prove_shard(plain, log_n, width, [], prm)
+    except ZkHipError as e:
+        assert e.code == -1
+        return
+    assert verify_shard(proof, log_n, width, [], prm)[0] == -6

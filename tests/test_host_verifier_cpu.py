@@ -45,3 +45,19 @@ def test_proof_size_matches_oracle(oracle):
         oprm = oracle.default_params(1, q, 16)
         assert L.zkhip_proof_size(log_n, w, C.byref(prm), 3) == oracle.lib().orc_proof_size(
             C.c_int(log_n), C.c_size_t(w), C.byref(oprm), C.c_size_t(3))
+
+
+@pytest.mark.parametrize("log_n,width,pairs", [(5, 8, 1), (6, 16, 2), (8, 24, 3)])
+def test_host_verifier_logup_proofs(oracle, log_n, width, pairs):
+    """proofs with the LogUp lookup argument"""
+    oprm, prm = oracle.default_params(1, 10, 8, pairs), Params(1, 10, 8, pairs)
+    pf = oracle.prove_shard(oracle.gen_trace_logup(SEED, 1, log_n, width, pairs), [4, 5], oprm)
+    assert verify_shard(pf, log_n, width, [4, 5], prm) == (0, 0)
+    assert verify_shard(pf, log_n, width, [4, 5], Params(1, 10, 8, 0))[0] == -6      # wrong protocol variant
+    words = pf.view(np.uint32)
+    rng = np.random.default_rng(pairs)
+    for i in sorted(set([9, 17, 25, len(words) - 1] + [int(x) for x in rng.integers(9, len(words), 25)])):
+        bad = words.copy()
+        bad[i] = (int(bad[i]) + 1) % P
+        rc, reason = verify_shard(bad.view(np.uint8), log_n, width, [4, 5], prm)
+        assert rc == -6 and reason == oracle.verify_shard(bad.view(np.uint8), log_n, width, [4, 5], oprm), i

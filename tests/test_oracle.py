@@ -322,3 +322,58 @@ def test_golden_commit_fixtures(oracle):
     lde = oracle.coset_lde(m, 1, 31)
     assert hashlib.sha256(lde.tobytes()).hexdigest() == KAT["lde_6x4_sha256"]
     assert oracle.merkle_tree([lde])[-1].tolist() == KAT["lde_6x4_root"]
+
+
+# ------------------------------------------------------------------ LogUp
+@pytest.mark.parametrize("log_n,width,pairs", [(5, 8, 1), (6, 16, 2), (7, 24, 2)])
+def test_logup_trace_and_permutation_columns(oracle, log_n, width, pairs):
+    t = oracle.gen_trace_logup(SEED, 1, log_n, width, pairs)
+    assert oracle.check_trace(t) == 0                       # still satisfies the main AIR
+    n = 1 << log_n
+    for q in range(pairs):
+        # receiver columns = sender columns under pi(i) = 5 i + 3 mod N, not the identity
+        for i in (0, 1, n - 1):
+            assert t[i, 8 * q + 4] == t[(5 * i + 3) % n, 8 * q] and t[i, 8 * q + 5] == t[(5 * i + 3) % n, 8 * q + 1]
+        assert (t[:, 8 * q + 4] != t[:, 8 * q]).any()
+    rng = np.random.default_rng(log_n)
+    gamma = [int(x) for x in rng.integers(0, P, 4)]
+    beta = [int(x) for x in rng.integers(0, P, 4)]
+    pt = oracle.perm_trace(t, pairs, gamma, beta)
+    assert pt.shape == (n, 4 * (pairs + 1))
+    assert pt[-1, -4:].tolist() == [0, 0, 0, 0]             # equal multisets: the running sum closes at 0
+    # first-principles value of phi_0 at row 3 and of the running sum at row 1
+    def den(i, ca, cb):
+        d = pyref.ext_mul(beta, [int(t[i, cb]), 0, 0, 0])
+        d[0] = (d[0] + int(t[i, ca])) % P
+        return [(x + y) % P for x, y in zip(d, gamma)]
+    def phi(i, q):
+        a, b = pyref.ext_inv(den(i, 8 * q, 8 * q + 1)), pyref.ext_inv(den(i, 8 * q + 4, 8 * q + 5))
+        return [(x - y) % P for x, y in zip(a, b)]
+    assert pt[3, :4].tolist() == phi(3, 0)
+    s1 = [0, 0, 0, 0]
+    for i in (0, 1):
+        for q in range(pairs):
+            s1 = [(x + y) % P for x, y in zip(s1, phi(i, q))]
+    assert pt[1, -4:].tolist() == s1
+
+
+def test_logup_proofs_verify_and_bind(oracle):
+    log_n, w, pairs = 6, 16, 2
+    prm = oracle.default_params(1, 10, 8, pairs)
+    t = oracle.gen_trace_logup(SEED, 3, log_n, w, pairs)
+    pf = oracle.prove_shard(t, [7], prm)
+    assert oracle.verify_shard(pf, log_n, w, [7], prm) == 0
+    assert oracle.verify_shard(pf, log_n, w, [7], oracle.default_params(1, 10, 8, 1)) != 0
+    words = pf.view(np.uint32)
+    rng = np.random.default_rng(5)
+    for i in sorted(set([9, 17, 25, len(words) - 1] + [int(x) for x in rng.integers(9, len(words), 60)])):
+        bad = words.copy()
+        bad[i] = (int(bad[i]) + 1) % P
+        assert oracle.verify_shard(bad.view(np.uint8), log_n, w, [7], prm) != 0, i
+    # a trace WITHOUT the permutation structure cannot be proven under the lookup argument
+    plain = oracle.gen_trace(SEED, 3, log_n, w)
+    try:
+        bad_pf = oracle.prove_shard(plain, [7], prm)
+    except RuntimeError:
+        return
+    assert oracle.verify_shard(bad_pf, log_n, w, [7], prm) != 0

@@ -19,6 +19,7 @@ EXPORTS = [
     "zkhip_version", "zkhip_last_error", "zkhip_device_count", "zkhip_ctx_create", "zkhip_ctx_destroy",
     "zkhip_ctx_sync", "zkhip_ctx_stream", "zkhip_malloc", "zkhip_free", "zkhip_memcpy_h2d",
     "zkhip_memcpy_d2h", "zkhip_to_monty", "zkhip_from_monty", "zkhip_fill_uniform", "zkhip_gen_trace",
+    "zkhip_gen_trace_logup", "zkhip_perm_trace",
     "zkhip_dft", "zkhip_coset_lde", "zkhip_ntt_pass", "zkhip_poseidon2_permute", "zkhip_hash_rows",
     "zkhip_merkle_commit", "zkhip_quotient_values", "zkhip_open_at", "zkhip_fri_fold",
     "zkhip_proof_size", "zkhip_prove_shard", "zkhip_verify_shard", "zkhip_last_prove_debug",
@@ -32,7 +33,7 @@ class ZkHipError(RuntimeError):
 
 
 class Params(C.Structure):
-    _fields_ = [("log_blowup", C.c_int32), ("num_queries", C.c_int32), ("pow_bits", C.c_int32)]
+    _fields_ = [("log_blowup", C.c_int32), ("num_queries", C.c_int32), ("pow_bits", C.c_int32), ("logup_pairs", C.c_int32)]
 
 
 class ProveDebug(C.Structure):
@@ -73,6 +74,8 @@ def load():
     L.zkhip_from_monty.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t]
     L.zkhip_fill_uniform.argtypes = [C.c_void_p, C.c_uint64, C.c_int, C.c_uint32, C.c_void_p, C.c_size_t]
     L.zkhip_gen_trace.argtypes = [C.c_void_p, C.c_uint64, C.c_uint64, C.c_int, C.c_uint32, C.c_void_p, C.c_size_t]
+    L.zkhip_gen_trace_logup.argtypes = [C.c_void_p, C.c_uint64, C.c_uint64, C.c_int, C.c_uint32, C.c_int, C.c_void_p, C.c_size_t]
+    L.zkhip_perm_trace.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_uint32, C.c_int, u32p, u32p, C.c_void_p]
     L.zkhip_dft.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_int, C.c_uint32, C.c_int, C.c_int]
     L.zkhip_coset_lde.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_int, C.c_uint32, C.c_int, C.c_uint32]
     L.zkhip_ntt_pass.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_uint32, C.c_int]

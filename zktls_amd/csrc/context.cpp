@@ -297,6 +297,7 @@ void zkhip_ctx_destroy(zkhip_ctx* ctx) {
     if (ctx->w1024_inv) (void)hipFree(ctx->w1024_inv);
     if (ctx->dom_xs) (void)hipFree(ctx->dom_xs);
     if (ctx->dom_sel_first) (void)hipFree(ctx->dom_sel_first);
+    if (ctx->dom_sel_last) (void)hipFree(ctx->dom_sel_last);
     if (ctx->dom_itw) (void)hipFree(ctx->dom_itw);
     if (ctx->own_stream && ctx->stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;
@@ -357,6 +358,14 @@ int zkhip_gen_trace(zkhip_ctx* ctx, uint64_t seed, uint64_t shard, int log_n, ui
     if (log_n < 0 || log_n > 30 || width == 0 || width % 4 != 0 || ld < width || !d_out)
         return fail(ZKHIP_ERR_INVALID, "gen_trace: width must be a positive multiple of 4");
     ZK_HIP(launch_gen_trace(d_out, ld, seed + shard, (uint64_t)1 << log_n, width, ctx->stream));
+    return ZKHIP_OK;
+}
+
+int zkhip_gen_trace_logup(zkhip_ctx* ctx, uint64_t seed, uint64_t shard, int log_n, uint32_t width, int pairs, uint32_t* d_out, size_t ld) {
+    CHECK_CTX(ctx);
+    if (log_n < 0 || log_n > 30 || width == 0 || width % 4 != 0 || ld < width || !d_out || pairs < 0 || (uint32_t)pairs * 8 > width)
+        return fail(ZKHIP_ERR_INVALID, "gen_trace_logup: width must be a multiple of 4 and hold 2 groups per pair");
+    ZK_HIP(launch_gen_trace_logup(d_out, ld, seed + shard, (uint64_t)1 << log_n, width, (uint32_t)pairs, ctx->stream));
     return ZKHIP_OK;
 }
 

@@ -52,12 +52,13 @@ struct zkhip_ctx {
     uint32_t* w1024_fwd = nullptr;
     uint32_t* w1024_inv = nullptr;
     std::deque<zk::NttPlan> plans;   // deque: references stay valid on push_back
-    zk::DeviceBuffer scratch[16];       // grow-only workspaces, indexed by role
+    zk::DeviceBuffer scratch[24];       // grow-only workspaces, indexed by role
     zkhip_prove_debug debug{};
     // domain tables of the last proved size (prover.cpp)
     int dom_log_n = -1;
     uint32_t* dom_xs = nullptr;        // x_p = g * w_2N^bitrev(p), p < 2N
     uint32_t* dom_sel_first = nullptr; // Z_H(x_p) / (x_p - 1)
+    uint32_t* dom_sel_last = nullptr;  // Z_H(x_p) / (x_p - w_N^-1)
     uint32_t* dom_itw = nullptr;       // w_2N^-bitrev_n(i) / 2, i < N (FRI fold)
 };
 

@@ -75,13 +75,15 @@ hipError_t launch_fill_uniform(uint32_t* out, uint64_t ld, uint64_t seed, uint64
                                uint32_t width, hipStream_t s);
 hipError_t launch_gen_trace(uint32_t* out, uint64_t ld, uint64_t seed, uint64_t rows,
                             uint32_t width, hipStream_t s);
+hipError_t launch_gen_trace_logup(uint32_t* out, uint64_t ld, uint64_t seed, uint64_t rows, uint32_t width,
+                                  uint32_t pairs, hipStream_t s);
 // element-wise Montgomery <-> canonical conversion
 hipError_t launch_convert(const uint32_t* in, uint32_t* out, uint64_t n, bool to_monty_form,
                           hipStream_t s);
 
 // ---------------------------------------------------------------- STARK stages (stark.hip)
 // x_p = g w_2N^bitrev(p) (p < 2N), Z_H(x_p)/(x_p - 1), and 1/(2 w_2N^bitrev_n(i)) (i < N)
-hipError_t launch_domain_tables(uint32_t* xs, uint32_t* sel_first, uint32_t* itw, int log_n, hipStream_t s);
+hipError_t launch_domain_tables(uint32_t* xs, uint32_t* sel_first, uint32_t* sel_last, uint32_t* itw, int log_n, hipStream_t s);
 
 struct QuotientArgs {
     const uint32_t* lde;        // [2N][ld] trace LDE, bit-reversed rows
@@ -93,7 +95,13 @@ struct QuotientArgs {
     const uint32_t* sel_first;
     uint32_t wn_inv;            // w_N^-1
     uint32_t inv_zh_even, inv_zh_odd;
-    const uint32_t* alpha_pow;  // [width/4][3] ext: alpha^(K-1-3g-t), K = 3 width/4
+    const uint32_t* alpha_pow;  // [3 G + Q + 3] ext: weight of constraint k is alpha^(K-1-k), K = 3 G + (Q ? Q + 3 : 0)
+    // LogUp part (pairs = Q > 0): permutation-trace LDE [2N][perm_ld], lookup challenges, last-row selector
+    uint32_t pairs;
+    const uint32_t* perm;
+    uint64_t perm_ld;
+    Ext gamma, beta;
+    const uint32_t* sel_last;
     uint32_t* out;              // [2][N][4]: chunk k, natural row j
 };
 hipError_t launch_quotient(const QuotientArgs& a, hipStream_t s);
@@ -119,15 +127,24 @@ hipError_t launch_open(const OpenArgs& a, int npts, const Ext& scale0, const Ext
 struct ReducedArgs {
     const uint32_t* tlde; uint64_t t_ld; uint32_t width;
     const uint32_t* qlde; uint64_t q_ld;
+    const uint32_t* plde; uint64_t p_ld; uint32_t p_width;   // permutation trace LDE (p_width = 0: none)
     uint64_t rows;              // 2N
-    int lanes_per_row;
-    const uint32_t* alpha_pow;  // [max(width, 8)] ext: alpha^j
+    const uint32_t* alpha_pow;  // [max(width, p_width, 8)] ext: alpha^j
     const uint32_t* dinv;       // [2][rows] ext
-    Ext y_loc, y_next, y_q, off_next, off_q;
+    Ext y_loc, y_next, y_pl, y_pn, y_q, off_next, off_pl, off_pn, off_q;
     uint32_t* out;              // [rows] ext
 };
-// scratch_at: [rows] ext workspace for the per-row alpha-dot of the trace matrix
+// scratch_at: [2][rows] ext workspace for the per-row alpha-dots of the trace / permutation matrices
 hipError_t launch_reduced_opening(const ReducedArgs& a, uint32_t* scratch_at, hipStream_t s);
+
+struct PermArgs {
+    const uint32_t* trace; uint64_t ld;     // main trace (natural rows), Montgomery
+    uint64_t rows; uint32_t pairs;
+    Ext gamma, beta;
+    uint32_t* out; uint64_t out_ld;         // [rows][4 (pairs + 1)]
+};
+// block_scratch: ceil(rows / 256) ext values
+hipError_t launch_perm_trace(const PermArgs& a, uint32_t* block_scratch, hipStream_t s);
 
 hipError_t launch_fri_fold(const uint32_t* in, uint32_t* out, const uint32_t* itw, uint64_t half, const Ext& beta, hipStream_t s);
 

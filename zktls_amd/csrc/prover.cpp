@@ -52,26 +52,28 @@ static void transcript_init(Challenger& ch, int log_n, uint32_t width, const zkh
     ch.observe_canonical((uint32_t)prm->num_queries);
     ch.observe_canonical((uint32_t)prm->pow_bits);
     ch.observe_canonical((uint32_t)n_public);
+    if (prm->logup_pairs) ch.observe_canonical((uint32_t)prm->logup_pairs);
 }
 
 constexpr uint32_t PROOF_MAGIC = 0x41544B5Au;   // "ZKTA"
 constexpr uint32_t PROOF_VERSION = 1u;
 
 enum Slot { S_COEF = 0, S_TMP = 1, S_TLDE, S_TTREE, S_QCHUNK, S_QLDE, S_QTREE, S_DINV, S_PARTIAL, S_OPEN_OUT,
-            S_APOW_Q, S_APOW_F, S_FRI_LAYERS, S_FRI_TREES, S_GATHER_DESC, S_GATHER_OUT };
+            S_APOW_Q, S_APOW_F, S_FRI_LAYERS, S_FRI_TREES, S_GATHER_DESC, S_GATHER_OUT, S_PERM, S_PLDE, S_PTREE };
 
 static int pow2ceil(int v) { int r = 1; while (r < v) r <<= 1; return r; }
 
 static int ensure_domain(zkhip_ctx* ctx, int log_n) {
     if (ctx->dom_log_n == log_n) return ZKHIP_OK;
-    if (ctx->dom_xs) { ZK_HIP(hipStreamSynchronize(ctx->stream)); (void)hipFree(ctx->dom_xs); (void)hipFree(ctx->dom_sel_first); (void)hipFree(ctx->dom_itw); }
-    ctx->dom_xs = ctx->dom_sel_first = ctx->dom_itw = nullptr;
+    if (ctx->dom_xs) { ZK_HIP(hipStreamSynchronize(ctx->stream)); (void)hipFree(ctx->dom_xs); (void)hipFree(ctx->dom_sel_first); (void)hipFree(ctx->dom_sel_last); (void)hipFree(ctx->dom_itw); }
+    ctx->dom_xs = ctx->dom_sel_first = ctx->dom_sel_last = ctx->dom_itw = nullptr;
     ctx->dom_log_n = -1;
     const size_t m = (size_t)2 << log_n;
     ZK_HIP(hipMalloc((void**)&ctx->dom_xs, m * 4));
     ZK_HIP(hipMalloc((void**)&ctx->dom_sel_first, m * 4));
+    ZK_HIP(hipMalloc((void**)&ctx->dom_sel_last, m * 4));
     ZK_HIP(hipMalloc((void**)&ctx->dom_itw, (m / 2) * 4));
-    ZK_HIP(launch_domain_tables(ctx->dom_xs, ctx->dom_sel_first, ctx->dom_itw, log_n, ctx->stream));
+    ZK_HIP(launch_domain_tables(ctx->dom_xs, ctx->dom_sel_first, ctx->dom_sel_last, ctx->dom_itw, log_n, ctx->stream));
     ctx->dom_log_n = log_n;
     return ZKHIP_OK;
 }
@@ -87,14 +89,21 @@ static int h2d(zkhip_ctx* ctx, void* dst, const void* src, size_t bytes) {
     return ZKHIP_OK;
 }
 
+struct LogupIn {
+    uint32_t pairs = 0;
+    const uint32_t* perm_lde = nullptr;   // [2N][4 (pairs + 1)]
+    Ext gamma = ext_zero(), beta = ext_zero();
+};
 static int run_quotient(zkhip_ctx* ctx, const uint32_t* lde, size_t ld, int log_n, uint32_t width, const Ext& alpha,
-                        uint32_t* out_chunks) {
+                        const LogupIn& lu, uint32_t* out_chunks) {
     ZK_TRY(ensure_domain(ctx, log_n));
     const uint32_t G = width / 4;
-    // weight of constraint k = 3 g + t is alpha^(K-1-k): filled from the last constraint backwards
-    std::vector<Ext> ap((size_t)3 * G);
+    // weight of constraint k is alpha^(K-1-k): filled from the last constraint backwards;
+    // order: 3 per column group, then (LogUp) L_0 .. L_{Q-1}, T1, T2, T3
+    const size_t K = (size_t)3 * G + (lu.pairs ? lu.pairs + 3 : 0);
+    std::vector<Ext> ap(K);
     Ext w = ext_one();
-    for (size_t k = (size_t)3 * G; k-- > 0;) { ap[k] = w; w = ext_mul(w, alpha); }
+    for (size_t k = K; k-- > 0;) { ap[k] = w; w = ext_mul(w, alpha); }
     void* d_ap;
     ZK_TRY(ctx_reserve(ctx, S_APOW_Q, ap.size() * 16, &d_ap));
     ZK_TRY(h2d(ctx, d_ap, ap.data(), ap.size() * 16));
@@ -107,6 +116,8 @@ static int run_quotient(zkhip_ctx* ctx, const uint32_t* lde, size_t ld, int log_
     q.inv_zh_even = finv(fsub(gn, MONTY_R1));
     q.inv_zh_odd = finv(fsub(fneg(gn), MONTY_R1));
     q.alpha_pow = (const uint32_t*)d_ap;
+    q.pairs = lu.pairs; q.perm = lu.perm_lde; q.perm_ld = 4 * ((uint64_t)lu.pairs + 1);
+    q.gamma = lu.gamma; q.beta = lu.beta; q.sel_last = ctx->dom_sel_last;
     q.out = out_chunks;
     ZK_HIP(launch_quotient(q, ctx->stream));
     return ZKHIP_OK;
@@ -133,8 +144,10 @@ static int run_open(zkhip_ctx* ctx, const uint32_t* lde, size_t ld, int log_n, u
 
 static size_t proof_words(int log_n, uint32_t width, const zkhip_params* prm) {
     const size_t H = (size_t)(log_n + prm->log_blowup), L = (size_t)log_n;
+    const size_t Q = (size_t)prm->logup_pairs, wp = Q ? 4 * (Q + 1) : 0;
     size_t words = 8 + 16 + 8 * (size_t)width + 32 + 8 * L + 5;
     size_t perq = width + 8 + 16 * H;
+    if (Q) { words += 1 + 8 + 8 * wp; perq += wp + 8 * H; }
     for (size_t l = 0; l < L; l++) perq += 4 + 8 * (H - 1 - l);
     return words + (size_t)prm->num_queries * perq;
 }
@@ -146,6 +159,8 @@ static int check_shape(int log_n, uint32_t width, const zkhip_params* prm) {
     if (prm->log_blowup != 1) return fail(ZKHIP_ERR_INVALID, "only log_blowup = 1 is supported by the synthetic AIR path");
     if (prm->num_queries < 1 || prm->num_queries > 4096) return fail(ZKHIP_ERR_INVALID, "num_queries out of range");
     if (prm->pow_bits < 0 || prm->pow_bits > 28) return fail(ZKHIP_ERR_INVALID, "pow_bits out of range");
+    if (prm->logup_pairs < 0 || prm->logup_pairs > 64 || (uint32_t)prm->logup_pairs * 8 > width)
+        return fail(ZKHIP_ERR_INVALID, "logup_pairs out of range (each pair needs two column groups, at most 64 pairs)");
     return ZKHIP_OK;
 }
 
@@ -164,7 +179,7 @@ extern "C" {
 int zkhip_quotient_values(zkhip_ctx* ctx, const uint32_t* d_lde, size_t ld, int log_n, uint32_t width,
                           const uint32_t alpha[4], uint32_t* d_out) {
     CHECK_CTX(ctx);
-    zkhip_params prm{1, 1, 0};
+    zkhip_params prm{1, 1, 0, 0};
     ZK_TRY(check_shape(log_n, width, &prm));
     if (!d_lde || !d_out || !alpha || ld < width) return fail(ZKHIP_ERR_INVALID, "quotient_values: bad arguments");
     // kernel writes natural-order chunks; this entry point returns the bit-reversed
@@ -173,7 +188,7 @@ int zkhip_quotient_values(zkhip_ctx* ctx, const uint32_t* d_lde, size_t ld, int 
     void* chunks;
     ZK_TRY(ctx_reserve(ctx, S_QCHUNK, 2 * n * 16, &chunks));
     Ext a{{alpha[0], alpha[1], alpha[2], alpha[3]}};
-    ZK_TRY(run_quotient(ctx, d_lde, ld, log_n, width, a, (uint32_t*)chunks));
+    ZK_TRY(run_quotient(ctx, d_lde, ld, log_n, width, a, LogupIn{}, (uint32_t*)chunks));
     // the chunk layout is [k][j]; position p holds e = bitrev(p) = 2 j + k, and bit-reversing a
     // (log_n+1)-bit index moves k to the top bit: p = k * N + bitrev_n(j).  Use the gather kernel.
     std::vector<GatherDesc> descs(2 * n);
@@ -188,6 +203,27 @@ int zkhip_quotient_values(zkhip_ctx* ctx, const uint32_t* d_lde, size_t ld, int 
     ZK_HIP(launch_gather((const GatherDesc*)dd, (uint32_t)descs.size(), d_out, ctx->stream));   // -> canonical
     ZK_HIP(launch_convert(d_out, d_out, 2 * n * 4, true, ctx->stream));                        // back to Montgomery
     return ZKHIP_OK;
+}
+
+static int run_perm_trace(zkhip_ctx* ctx, const uint32_t* d_trace, size_t ld, int log_n, uint32_t pairs,
+                          const Ext& gamma, const Ext& beta, uint32_t* d_out) {
+    PermArgs pa{};
+    pa.trace = d_trace; pa.ld = ld; pa.rows = (uint64_t)1 << log_n; pa.pairs = pairs;
+    pa.gamma = gamma; pa.beta = beta; pa.out = d_out; pa.out_ld = 4 * ((uint64_t)pairs + 1);
+    void* scratch;
+    ZK_TRY(ctx_reserve(ctx, S_GATHER_OUT, ((pa.rows + 255) / 256) * 16, &scratch));
+    ZK_HIP(launch_perm_trace(pa, (uint32_t*)scratch, ctx->stream));
+    return ZKHIP_OK;
+}
+
+int zkhip_perm_trace(zkhip_ctx* ctx, const uint32_t* d_trace, size_t ld, int log_n, uint32_t width, int pairs,
+                     const uint32_t gamma[4], const uint32_t beta[4], uint32_t* d_out) {
+    CHECK_CTX(ctx);
+    if (!d_trace || !d_out || !gamma || !beta || log_n < 0 || log_n > 24 || pairs < 1 || pairs > 64 ||
+        (uint32_t)pairs * 8 > width || ld < width || (ld % 4) != 0)
+        return fail(ZKHIP_ERR_INVALID, "perm_trace: bad arguments");
+    Ext g{{gamma[0], gamma[1], gamma[2], gamma[3]}}, b{{beta[0], beta[1], beta[2], beta[3]}};
+    return run_perm_trace(ctx, d_trace, ld, log_n, (uint32_t)pairs, g, b, d_out);
 }
 
 int zkhip_open_at(zkhip_ctx* ctx, const uint32_t* d_lde, size_t ld, int log_n, int log_blowup, uint32_t width,
@@ -243,8 +279,11 @@ int zkhip_prove_shard(zkhip_ctx* ctx, const uint32_t* d_trace, size_t ld, int lo
 
     uint32_t* pf = (uint32_t*)proof;
     size_t pos = 0;
-    pf[pos++] = PROOF_MAGIC; pf[pos++] = PROOF_VERSION; pf[pos++] = (uint32_t)log_n; pf[pos++] = width;
+    const uint32_t LQ = (uint32_t)prm->logup_pairs;          // LogUp pairs (0 = none)
+    const size_t wp = LQ ? 4 * ((size_t)LQ + 1) : 0;         // permutation-trace width in words
+    pf[pos++] = PROOF_MAGIC; pf[pos++] = LQ ? 2u : PROOF_VERSION; pf[pos++] = (uint32_t)log_n; pf[pos++] = width;
     pf[pos++] = (uint32_t)prm->log_blowup; pf[pos++] = (uint32_t)Q; pf[pos++] = (uint32_t)prm->pow_bits; pf[pos++] = (uint32_t)n_public;
+    if (LQ) pf[pos++] = LQ;
 
     Challenger ch;
     transcript_init(ch, log_n, width, prm, n_public);
@@ -261,6 +300,26 @@ int zkhip_prove_shard(zkhip_ctx* ctx, const uint32_t* d_trace, size_t ld, int lo
     for (int i = 0; i < 8; i++) { ch.observe(root[i]); pf[pos++] = ctx->debug.trace_root[i] = from_monty(root[i]); }
     for (size_t i = 0; i < n_public; i++) ch.observe_canonical(public_values[i]);
 
+    // ---- 1b. LogUp: lookup challenges, permutation trace (per-row inverses + prefix sum), its commitment
+    LogupIn lu;
+    uint32_t *plde = nullptr, *ptree = nullptr;
+    if (LQ) {
+        lu.pairs = LQ;
+        lu.gamma = ch.sample_ext();
+        lu.beta = ch.sample_ext();
+        void *v_perm, *v_plde, *v_ptree;
+        ZK_TRY(ctx_reserve(ctx, S_PERM, n * wp * 4, &v_perm));
+        ZK_TRY(ctx_reserve(ctx, S_PLDE, m * wp * 4, &v_plde));
+        ZK_TRY(ctx_reserve(ctx, S_PTREE, (2 * m - 1) * 32, &v_ptree));
+        plde = (uint32_t*)v_plde; ptree = (uint32_t*)v_ptree;
+        ZK_TRY(run_perm_trace(ctx, d_trace, ld, log_n, LQ, lu.gamma, lu.beta, (uint32_t*)v_perm));
+        ZK_TRY(op_coset_lde(ctx, (const uint32_t*)v_perm, wp, plde, wp, log_n, (uint32_t)wp, 1, MONTY_GEN));
+        { MatDesc md{plde, wp, (uint32_t)wp}; ZK_TRY(op_merkle_commit(ctx, &md, 1, H, ptree)); }
+        ZK_TRY(d2h(ctx, root, ptree + (2 * m - 2) * 8, 32));
+        for (int i = 0; i < 8; i++) { ch.observe(root[i]); pf[pos++] = from_monty(root[i]); }
+        lu.perm_lde = plde;
+    }
+
     // ---- 2. constraint challenge, quotient chunks, their LDE + commitment
     const Ext alpha = ch.sample_ext();
     void *v_qchunk, *v_qlde, *v_qtree;
@@ -268,7 +327,7 @@ int zkhip_prove_shard(zkhip_ctx* ctx, const uint32_t* d_trace, size_t ld, int lo
     ZK_TRY(ctx_reserve(ctx, S_QLDE, m * 8 * 4, &v_qlde));
     ZK_TRY(ctx_reserve(ctx, S_QTREE, (2 * m - 1) * 32, &v_qtree));
     uint32_t* qchunk = (uint32_t*)v_qchunk; uint32_t* qlde = (uint32_t*)v_qlde; uint32_t* qtree = (uint32_t*)v_qtree;
-    ZK_TRY(run_quotient(ctx, tlde, width, log_n, width, alpha, qchunk));
+    ZK_TRY(run_quotient(ctx, tlde, width, log_n, width, alpha, lu, qchunk));
     {
         const uint32_t w2n = two_adic_generator(H);
         for (int k = 0; k < 2; k++) {
@@ -287,34 +346,48 @@ int zkhip_prove_shard(zkhip_ctx* ctx, const uint32_t* d_trace, size_t ld, int lo
     const Ext zpts[2] = {zeta, ext_mul_base(zeta, two_adic_generator(log_n))};
     void *v_dinv, *v_open;
     ZK_TRY(ctx_reserve(ctx, S_DINV, 2 * m * 16, &v_dinv));
-    ZK_TRY(ctx_reserve(ctx, S_OPEN_OUT, (2 * (size_t)width + 8) * 16, &v_open));
+    ZK_TRY(ctx_reserve(ctx, S_OPEN_OUT, (2 * (size_t)width + 2 * wp + 8) * 16, &v_open));
     uint32_t* dinv = (uint32_t*)v_dinv; uint32_t* d_open = (uint32_t*)v_open;
     ZK_HIP(launch_inv_denominators(ctx->dom_xs, m, zpts[0], zpts[1], 2, dinv, st));
     ZK_TRY(run_open(ctx, tlde, width, log_n, width, zpts, 2, dinv, m, d_open));
     ZK_HIP(hipStreamSynchronize(st));   // S_PARTIAL is reused by the next call
-    ZK_TRY(run_open(ctx, qlde, 8, log_n, 8, zpts, 1, dinv, m, d_open + 8 * (size_t)width));
-    std::vector<uint32_t> opened((2 * (size_t)width + 8) * 4);
+    if (LQ) {
+        ZK_TRY(run_open(ctx, plde, wp, log_n, (uint32_t)wp, zpts, 2, dinv, m, d_open + 8 * (size_t)width));
+        ZK_HIP(hipStreamSynchronize(st));
+    }
+    ZK_TRY(run_open(ctx, qlde, 8, log_n, 8, zpts, 1, dinv, m, d_open + 8 * (size_t)width + 8 * wp));
+    std::vector<uint32_t> opened((2 * (size_t)width + 2 * wp + 8) * 4);
     ZK_TRY(d2h(ctx, opened.data(), d_open, opened.size() * 4));
     for (size_t i = 0; i < opened.size(); i++) { ch.observe(opened[i]); pf[pos++] = from_monty(opened[i]); }
     const Ext* op_loc = (const Ext*)opened.data();
     const Ext* op_nxt = op_loc + width;
-    const Ext* op_q = op_nxt + width;
+    const Ext* op_pl = op_nxt + width;
+    const Ext* op_pn = op_pl + wp;
+    const Ext* op_q = op_pn + wp;
 
     // ---- 4. FRI input: alpha-batched reduced openings at every LDE point
     const Ext fa = ch.sample_ext();
-    const size_t np = width > 8 ? width : 8;
+    size_t np = width > 8 ? width : 8;
+    if (wp > np) np = wp;
     std::vector<Ext> fapow(np);
     fapow[0] = ext_one();
     for (size_t j = 1; j < np; j++) fapow[j] = ext_mul(fapow[j - 1], fa);
     ReducedArgs ra{};
-    ra.y_loc = ra.y_next = ra.y_q = ext_zero();
+    ra.y_loc = ra.y_next = ra.y_pl = ra.y_pn = ra.y_q = ext_zero();
     for (size_t j = 0; j < width; j++) {
         ra.y_loc = ext_add(ra.y_loc, ext_mul(fapow[j], op_loc[j]));
         ra.y_next = ext_add(ra.y_next, ext_mul(fapow[j], op_nxt[j]));
     }
+    for (size_t j = 0; j < wp; j++) {
+        ra.y_pl = ext_add(ra.y_pl, ext_mul(fapow[j], op_pl[j]));
+        ra.y_pn = ext_add(ra.y_pn, ext_mul(fapow[j], op_pn[j]));
+    }
     for (size_t j = 0; j < 8; j++) ra.y_q = ext_add(ra.y_q, ext_mul(fapow[j], op_q[j]));
+    // batching offsets: trace@zeta 0, trace@zeta_next W, [perm@zeta 2W, perm@zeta_next 2W+Wp], quotient 2W+2Wp
     ra.off_next = ext_pow(fa, width);
-    ra.off_q = ext_pow(fa, 2 * (uint64_t)width);
+    ra.off_pl = ext_pow(fa, 2 * (uint64_t)width);
+    ra.off_pn = ext_pow(fa, 2 * (uint64_t)width + wp);
+    ra.off_q = ext_pow(fa, 2 * (uint64_t)width + 2 * wp);
     void *v_apf, *v_layers, *v_ltrees;
     ZK_TRY(ctx_reserve(ctx, S_APOW_F, np * 16, &v_apf));
     ZK_TRY(h2d(ctx, v_apf, fapow.data(), np * 16));
@@ -322,10 +395,10 @@ int zkhip_prove_shard(zkhip_ctx* ctx, const uint32_t* d_trace, size_t ld, int lo
     ZK_TRY(ctx_reserve(ctx, S_FRI_TREES, 2 * m * 32, &v_ltrees));
     uint32_t* layers = (uint32_t*)v_layers; uint32_t* ltrees = (uint32_t*)v_ltrees;
     ra.tlde = tlde; ra.t_ld = width; ra.width = width; ra.qlde = qlde; ra.q_ld = 8; ra.rows = m;
-    ra.lanes_per_row = pow2ceil((int)(width / 4)) > 64 ? 64 : pow2ceil((int)(width / 4));
+    ra.plde = plde; ra.p_ld = wp; ra.p_width = (uint32_t)wp;
     ra.alpha_pow = (const uint32_t*)v_apf; ra.dinv = dinv; ra.out = layers;
     void* v_at;
-    ZK_TRY(ctx_reserve(ctx, S_PARTIAL, m * 16, &v_at));   // openings are done with S_PARTIAL by now
+    ZK_TRY(ctx_reserve(ctx, S_PARTIAL, 2 * m * 16, &v_at));   // openings are done with S_PARTIAL by now
     ZK_HIP(launch_reduced_opening(ra, (uint32_t*)v_at, st));
 
     // ---- 5. FRI commit phase: commit, challenge, fold
@@ -393,6 +466,7 @@ int zkhip_prove_shard(zkhip_ctx* ctx, const uint32_t* d_trace, size_t ld, int lo
             const size_t index = ch.sample_bits(H);
             push(tlde + index * width, width);
             push_path(ttree, m, index, H);
+            if (LQ) { push(plde + index * wp, wp); push_path(ptree, m, index, H); }
             push(qlde + index * 8, 8);
             push_path(qtree, m, index, H);
             size_t idx = index;
@@ -450,6 +524,17 @@ static Ext fri_fold_row(size_t index, int log_folded_h, const Ext& beta, const E
     return ext_add(e0, ext_mul_base(ext_mul(ext_sub_base(beta, x), ext_sub(e1, e0)), inv));
 }
 
+// value at zeta of an extension column committed as 4 base columns: sum_e x^e * v_e(zeta)
+static Ext recombine(const Ext* opened4) {
+    Ext r = ext_zero();
+    for (int e = 0; e < 4; e++) {
+        Ext basis = ext_zero();
+        basis.c[e] = MONTY_R1;
+        r = ext_add(r, ext_mul(basis, opened4[e]));
+    }
+    return r;
+}
+
 int zkhip_verify_shard(const uint8_t* proof, size_t len, int log_n, uint32_t width, const uint32_t* public_values,
                        size_t n_public, const zkhip_params* prm, int* reason) {
     int dummy;
@@ -462,34 +547,49 @@ int zkhip_verify_shard(const uint8_t* proof, size_t len, int log_n, uint32_t wid
     const uint32_t* pf = (const uint32_t*)proof;
     const int H = log_n + 1, L = log_n;
     const size_t n = (size_t)1 << log_n;
-    if (pf[0] != PROOF_MAGIC || pf[1] != PROOF_VERSION || pf[2] != (uint32_t)log_n || pf[3] != width ||
+    const uint32_t LQ = (uint32_t)prm->logup_pairs;
+    const size_t wp = LQ ? 4 * ((size_t)LQ + 1) : 0;
+    if (pf[0] != PROOF_MAGIC || pf[1] != (LQ ? 2u : PROOF_VERSION) || pf[2] != (uint32_t)log_n || pf[3] != width ||
         pf[4] != (uint32_t)prm->log_blowup || pf[5] != (uint32_t)prm->num_queries || pf[6] != (uint32_t)prm->pow_bits ||
         pf[7] != (uint32_t)n_public) return reject(3);
-    for (size_t i = 8; i < len / 4; i++) if (pf[i] >= P) return reject(4);
-    for (size_t i = 0; i < n_public; i++) if (public_values[i] >= P) return reject(4);
     size_t pos = 8;
+    if (LQ) { if (pf[8] != LQ) return reject(3); pos = 9; }
+    for (size_t i = pos; i < len / 4; i++) if (pf[i] >= P) return reject(4);
+    for (size_t i = 0; i < n_public; i++) if (public_values[i] >= P) return reject(4);
     Challenger ch;
     transcript_init(ch, log_n, width, prm, n_public);
-    uint32_t troot[8], qroot[8];
+    uint32_t troot[8], proot[8], qroot[8];
     for (int i = 0; i < 8; i++) { troot[i] = to_monty(pf[pos++]); }
-    for (int i = 0; i < 8; i++) { qroot[i] = to_monty(pf[pos++]); }
     for (int i = 0; i < 8; i++) ch.observe(troot[i]);
     for (size_t i = 0; i < n_public; i++) ch.observe_canonical(public_values[i]);
+    Ext gamma = ext_zero(), beta_l = ext_zero();
+    if (LQ) {
+        gamma = ch.sample_ext();
+        beta_l = ch.sample_ext();
+        for (int i = 0; i < 8; i++) { proot[i] = to_monty(pf[pos++]); ch.observe(proot[i]); }
+    }
+    for (int i = 0; i < 8; i++) { qroot[i] = to_monty(pf[pos++]); }
     const Ext alpha = ch.sample_ext();
     for (int i = 0; i < 8; i++) ch.observe(qroot[i]);
     const Ext zeta = ch.sample_ext();
     const uint32_t gn = two_adic_generator(log_n);
     const Ext zeta_next = ext_mul_base(zeta, gn);
-    std::vector<Ext> loc(width), nxt(width);
+    std::vector<Ext> loc(width), nxt(width), opl(wp), opn(wp);
     Ext opq[8];
     for (size_t j = 0; j < width; j++) loc[j] = ext_from_canon(pf + pos + 4 * j);
     pos += 4 * (size_t)width;
     for (size_t j = 0; j < width; j++) nxt[j] = ext_from_canon(pf + pos + 4 * j);
     pos += 4 * (size_t)width;
+    for (size_t j = 0; j < wp; j++) opl[j] = ext_from_canon(pf + pos + 4 * j);
+    pos += 4 * wp;
+    for (size_t j = 0; j < wp; j++) opn[j] = ext_from_canon(pf + pos + 4 * j);
+    pos += 4 * wp;
     for (int j = 0; j < 8; j++) opq[j] = ext_from_canon(pf + pos + 4 * j);
     pos += 32;
     for (size_t j = 0; j < width; j++) ch.observe_ext(loc[j]);
     for (size_t j = 0; j < width; j++) ch.observe_ext(nxt[j]);
+    for (size_t j = 0; j < wp; j++) ch.observe_ext(opl[j]);
+    for (size_t j = 0; j < wp; j++) ch.observe_ext(opn[j]);
     for (int j = 0; j < 8; j++) ch.observe_ext(opq[j]);
 
     // (a) the AIR identity at zeta: folded constraints / Z_H == sum_k zps_k * q_k
@@ -509,6 +609,24 @@ int zkhip_verify_shard(const uint8_t* proof, size_t len, int log_n, uint32_t wid
             acc = ext_add(ext_mul(acc, alpha), c2);
             acc = ext_add(ext_mul(acc, alpha), c3);
         }
+        if (LQ) {
+            // LogUp: L_q, then T1 (first row), T2 (transition), T3 (last row)
+            const Ext sel_last = ext_mul(zh, ext_inv(ext_sub_base(zeta, finv(gn))));
+            Ext sum_l = ext_zero(), sum_n = ext_zero();
+            for (uint32_t q = 0; q < LQ; q++) {
+                const Ext ds = ext_add(ext_add(gamma, loc[8 * q]), ext_mul(beta_l, loc[8 * q + 1]));
+                const Ext dr = ext_add(ext_add(gamma, loc[8 * q + 4]), ext_mul(beta_l, loc[8 * q + 5]));
+                const Ext phi = recombine(&opl[4 * q]), phin = recombine(&opn[4 * q]);
+                const Ext c = ext_sub(ext_mul(ext_mul(phi, ds), dr), ext_sub(dr, ds));
+                acc = ext_add(ext_mul(acc, alpha), c);
+                sum_l = ext_add(sum_l, phi);
+                sum_n = ext_add(sum_n, phin);
+            }
+            const Ext S = recombine(&opl[4 * LQ]), Sn = recombine(&opn[4 * LQ]);
+            acc = ext_add(ext_mul(acc, alpha), ext_mul(sel_first, ext_sub(S, sum_l)));
+            acc = ext_add(ext_mul(acc, alpha), ext_mul(sel_trans, ext_sub(ext_sub(Sn, S), sum_n)));
+            acc = ext_add(ext_mul(acc, alpha), ext_mul(sel_last, S));
+        }
         const uint32_t w2n = two_adic_generator(H);
         const uint32_t s[2] = {MONTY_GEN, fmul(MONTY_GEN, w2n)};
         Ext quot = ext_zero();
@@ -518,30 +636,30 @@ int zkhip_verify_shard(const uint8_t* proof, size_t len, int log_n, uint32_t wid
             const Ext num = ext_sub_base(ext_mul_base(zn, sjn_inv), MONTY_R1);
             const uint32_t den = fsub(fmul(fpow(s[k], n), sjn_inv), MONTY_R1);
             const Ext zps = ext_mul_base(num, finv(den));
-            Ext qk = ext_zero();
-            for (int e = 0; e < 4; e++) {
-                Ext basis = ext_zero();
-                basis.c[e] = MONTY_R1;
-                qk = ext_add(qk, ext_mul(basis, opq[4 * k + e]));
-            }
-            quot = ext_add(quot, ext_mul(zps, qk));
+            quot = ext_add(quot, ext_mul(zps, recombine(&opq[4 * k])));
         }
         if (!ext_eq(ext_mul(acc, ext_inv(zh)), quot)) return reject(10);
     }
 
     // (b) FRI
     const Ext fa = ch.sample_ext();
-    const size_t np = width > 8 ? width : 8;
+    size_t np = width > 8 ? width : 8;
+    if (wp > np) np = wp;
     std::vector<Ext> fapow(np);
     fapow[0] = ext_one();
     for (size_t j = 1; j < np; j++) fapow[j] = ext_mul(fapow[j - 1], fa);
-    Ext y_loc = ext_zero(), y_nxt = ext_zero(), y_q = ext_zero();
+    Ext y_loc = ext_zero(), y_nxt = ext_zero(), y_pl = ext_zero(), y_pn = ext_zero(), y_q = ext_zero();
     for (size_t j = 0; j < width; j++) {
         y_loc = ext_add(y_loc, ext_mul(fapow[j], loc[j]));
         y_nxt = ext_add(y_nxt, ext_mul(fapow[j], nxt[j]));
     }
+    for (size_t j = 0; j < wp; j++) {
+        y_pl = ext_add(y_pl, ext_mul(fapow[j], opl[j]));
+        y_pn = ext_add(y_pn, ext_mul(fapow[j], opn[j]));
+    }
     for (int j = 0; j < 8; j++) y_q = ext_add(y_q, ext_mul(fapow[j], opq[j]));
-    const Ext off_next = ext_pow(fa, width), off_q = ext_pow(fa, 2 * (uint64_t)width);
+    const Ext off_next = ext_pow(fa, width), off_pl = ext_pow(fa, 2 * (uint64_t)width),
+              off_pn = ext_pow(fa, 2 * (uint64_t)width + wp), off_q = ext_pow(fa, 2 * (uint64_t)width + 2 * wp);
     std::vector<uint32_t> commits((size_t)L * 8);
     std::vector<Ext> betas(L);
     for (int l = 0; l < L; l++) {
@@ -559,18 +677,26 @@ int zkhip_verify_shard(const uint8_t* proof, size_t len, int log_n, uint32_t wid
         const size_t index = ch.sample_bits(H);
         const uint32_t* trow = pf + pos; pos += width;
         const uint32_t* tpath = pf + pos; pos += 8 * (size_t)H;
+        const uint32_t *prow = nullptr, *ppath = nullptr;
+        if (LQ) { prow = pf + pos; pos += wp; ppath = pf + pos; pos += 8 * (size_t)H; }
         const uint32_t* qrow = pf + pos; pos += 8;
         const uint32_t* qpath = pf + pos; pos += 8 * (size_t)H;
         if (!verify_path(troot, H, index, trow, width, tpath)) return reject(30);
+        if (LQ && !verify_path(proot, H, index, prow, wp, ppath)) return reject(32);
         if (!verify_path(qroot, H, index, qrow, 8, qpath)) return reject(31);
         const uint32_t x = fmul(MONTY_GEN, fpow(w2n, reverse_bits((uint32_t)index, H)));
         const Ext d1 = ext_inv(ext_neg(ext_sub_base(zeta, x)));
         const Ext d2 = ext_inv(ext_neg(ext_sub_base(zeta_next, x)));
-        Ext at = ext_zero(), aq = ext_zero();
+        Ext at = ext_zero(), ap = ext_zero(), aq = ext_zero();
         for (size_t j = 0; j < width; j++) at = ext_add(at, ext_mul_base(fapow[j], to_monty(trow[j])));
+        for (size_t j = 0; j < wp; j++) ap = ext_add(ap, ext_mul_base(fapow[j], to_monty(prow[j])));
         for (int j = 0; j < 8; j++) aq = ext_add(aq, ext_mul_base(fapow[j], to_monty(qrow[j])));
         Ext folded = ext_mul(ext_sub(at, y_loc), d1);
         folded = ext_add(folded, ext_mul(off_next, ext_mul(ext_sub(at, y_nxt), d2)));
+        if (LQ) {
+            folded = ext_add(folded, ext_mul(off_pl, ext_mul(ext_sub(ap, y_pl), d1)));
+            folded = ext_add(folded, ext_mul(off_pn, ext_mul(ext_sub(ap, y_pn), d2)));
+        }
         folded = ext_add(folded, ext_mul(off_q, ext_mul(ext_sub(aq, y_q), d1)));
         size_t idx = index;
         for (int l = 0; l < L; l++) {

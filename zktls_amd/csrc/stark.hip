@@ -37,7 +37,7 @@ ZK_D Ext group_sum(Ext v, int width) {
 }
 
 // ------------------------------------------------------------------ domain tables
-__global__ void domain_tables_kernel(uint32_t* xs, uint32_t* sel_first, uint32_t* itw, int log_n, uint32_t g_pow_n) {
+__global__ void domain_tables_kernel(uint32_t* xs, uint32_t* sel_first, uint32_t* sel_last, uint32_t* itw, int log_n, uint32_t g_pow_n) {
     const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
     const int H = log_n + 1;
     if (p >= (1u << H)) return;
@@ -48,15 +48,16 @@ __global__ void domain_tables_kernel(uint32_t* xs, uint32_t* sel_first, uint32_t
     const uint32_t xn = (e & 1) ? fneg(g_pow_n) : g_pow_n;        // x^N = g^N (-1)^e
     const uint32_t zh = fsub(xn, MONTY_R1);
     sel_first[p] = fmul(zh, finv(fsub(x, MONTY_R1)));
+    sel_last[p] = fmul(zh, finv(fsub(x, finv(two_adic_generator(log_n)))));   // Z_H(x) / (x - w_N^-1)
     if (p < (1u << log_n)) {
         const uint32_t ei = log_n ? (__brev(p) >> (32 - log_n)) : 0u;
         itw[p] = fmul(finv(fpow(w2n, ei)), MONTY_INV2);            // 1 / (2 w_2N^bitrev_n(p))
     }
 }
-hipError_t launch_domain_tables(uint32_t* xs, uint32_t* sel_first, uint32_t* itw, int log_n, hipStream_t s) {
+hipError_t launch_domain_tables(uint32_t* xs, uint32_t* sel_first, uint32_t* sel_last, uint32_t* itw, int log_n, hipStream_t s) {
     const uint32_t m = 2u << log_n;
     const uint32_t gpn = fpow(MONTY_GEN, (uint64_t)1 << log_n);
-    hipLaunchKernelGGL(domain_tables_kernel, dim3((m + 255) / 256), dim3(256), 0, s, xs, sel_first, itw, log_n, gpn);
+    hipLaunchKernelGGL(domain_tables_kernel, dim3((m + 255) / 256), dim3(256), 0, s, xs, sel_first, sel_last, itw, log_n, gpn);
     return hipGetLastError();
 }
 
@@ -98,6 +99,30 @@ __global__ void __launch_bounds__(256) quotient_kernel(QuotientArgs a) {
         acc.c[1] = dadd(acc.c[1], dadd(dmr2(w0.y, c1, w1.y, c2), dmul(w2.y, c3)));
         acc.c[2] = dadd(acc.c[2], dadd(dmr2(w0.z, c1, w1.z, c2), dmul(w2.z, c3)));
         acc.c[3] = dadd(acc.c[3], dadd(dmr2(w0.w, c1, w1.w, c2), dmul(w2.w, c3)));
+    }
+    if (a.pairs) {
+        // LogUp constraints (weights continue after the 3 G main ones): L_q, then T1, T2, T3.
+        // The sums over q inside T1 / T2 are distributed: pair q adds -F1 phi_q - F2 phi'_q.
+        const uint32_t* prow = a.perm + (uint64_t)p * a.perm_ld;
+        const uint32_t* pnrow = a.perm + (uint64_t)pn * a.perm_ld;
+        const uint32_t* wl = a.alpha_pow + 12 * G;                 // [Q + 3] ext weights
+        const Ext F1 = ext_mul_base(ld_ext(wl + 4 * a.pairs), sel_first);
+        const Ext F2 = ext_mul_base(ld_ext(wl + 4 * (a.pairs + 1)), sel_trans);
+        for (uint32_t q = lane; q < a.pairs; q += L) {
+            const uint4 vs = *reinterpret_cast<const uint4*>(row + 8 * q);
+            const uint4 vr = *reinterpret_cast<const uint4*>(row + 8 * q + 4);
+            const Ext ds = ext_add(ext_add_base(a.gamma, vs.x), ext_mul_base(a.beta, vs.y));
+            const Ext dr = ext_add(ext_add_base(a.gamma, vr.x), ext_mul_base(a.beta, vr.y));
+            const Ext phi = ld_ext(prow + 4 * q), phin = ld_ext(pnrow + 4 * q);
+            const Ext c = ext_sub(ext_mul(ext_mul(phi, ds), dr), ext_sub(dr, ds));
+            acc = ext_add(acc, ext_mul(c, ld_ext(wl + 4 * q)));
+            acc = ext_sub(acc, ext_add(ext_mul(F1, phi), ext_mul(F2, phin)));
+        }
+        if (lane == 0) {
+            const Ext S = ld_ext(prow + 4 * a.pairs), Sn = ld_ext(pnrow + 4 * a.pairs);
+            const Ext F3 = ext_mul_base(ld_ext(wl + 4 * (a.pairs + 2)), a.sel_last[p]);
+            acc = ext_add(acc, ext_add(ext_mul(F1, S), ext_add(ext_mul(F2, ext_sub(Sn, S)), ext_mul(F3, S))));
+        }
     }
     acc = group_sum(acc, L);
     if (lane == 0) {
@@ -192,18 +217,18 @@ hipError_t launch_open(const OpenArgs& a, int npts, const Ext& scale0, const Ext
 // Two launches: (1) A_T per row, a row spread over L lanes, products summed in pairs in 64
 // bits before one Montgomery reduction; (2) one lane per row for the extension-field tail,
 // so that the ~100 multiplications of the tail keep all 64 lanes busy.
-__global__ void __launch_bounds__(256) rowdot_kernel(ReducedArgs a, uint32_t* __restrict__ out_at) {
-    const int L = a.lanes_per_row;
+__global__ void __launch_bounds__(256) rowdot_kernel(const uint32_t* __restrict__ mat, uint64_t ld, uint32_t width, uint64_t rows,
+                                                     int L, const uint32_t* __restrict__ alpha_pow, uint32_t* __restrict__ out_at) {
     const uint64_t gid = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const uint64_t p = gid / L;
     const int lane = (int)(gid % L);
-    if (p >= a.rows) return;
-    const uint32_t* row = a.tlde + p * a.t_ld;
+    if (p >= rows) return;
+    const uint32_t* row = mat + p * ld;
     Ext acc = ext_zero();
-    const uint32_t nq = a.width / 4;
+    const uint32_t nq = width / 4;
     for (uint32_t q = lane; q < nq; q += L) {
         const uint4 v = *reinterpret_cast<const uint4*>(row + 4 * q);
-        const uint4* ap = reinterpret_cast<const uint4*>(a.alpha_pow + 16 * q);
+        const uint4* ap = reinterpret_cast<const uint4*>(alpha_pow + 16 * q);
         const uint4 a0 = ap[0], a1 = ap[1], a2 = ap[2], a3 = ap[3];
         acc.c[0] = dadd(acc.c[0], dadd(dmr2(a0.x, v.x, a1.x, v.y), dmr2(a2.x, v.z, a3.x, v.w)));
         acc.c[1] = dadd(acc.c[1], dadd(dmr2(a0.y, v.x, a1.y, v.y), dmr2(a2.y, v.z, a3.y, v.w)));
@@ -213,7 +238,7 @@ __global__ void __launch_bounds__(256) rowdot_kernel(ReducedArgs a, uint32_t* __
     acc = group_sum(acc, L);
     if (lane == 0) st_ext(out_at + 4 * p, acc);
 }
-__global__ void __launch_bounds__(256) reduced_combine_kernel(ReducedArgs a, const uint32_t* __restrict__ at_in) {
+__global__ void __launch_bounds__(256) reduced_combine_kernel(ReducedArgs a, const uint32_t* __restrict__ at_in, const uint32_t* __restrict__ ap_in) {
     const uint64_t p = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (p >= a.rows) return;
     const Ext at = ld_ext(at_in + 4 * p);
@@ -226,15 +251,109 @@ __global__ void __launch_bounds__(256) reduced_combine_kernel(ReducedArgs a, con
     const Ext d1 = ld_ext(a.dinv + 4 * p), d2 = ld_ext(a.dinv + 4 * (a.rows + p));
     Ext r = ext_mul(ext_sub(at, a.y_loc), d1);
     r = ext_add(r, ext_mul(a.off_next, ext_mul(ext_sub(at, a.y_next), d2)));
+    if (a.p_width) {
+        const Ext ap = ld_ext(ap_in + 4 * p);
+        r = ext_add(r, ext_mul(a.off_pl, ext_mul(ext_sub(ap, a.y_pl), d1)));
+        r = ext_add(r, ext_mul(a.off_pn, ext_mul(ext_sub(ap, a.y_pn), d2)));
+    }
     r = ext_add(r, ext_mul(a.off_q, ext_mul(ext_sub(aq, a.y_q), d1)));
     st_ext(a.out + 4 * p, r);
 }
+static int lanes_for(uint32_t width) { int g = (int)(width / 4), l = 1; while (l < g && l < 64) l <<= 1; return l; }
 hipError_t launch_reduced_opening(const ReducedArgs& a, uint32_t* scratch_at, hipStream_t s) {
-    const uint64_t threads = a.rows * a.lanes_per_row;
-    hipLaunchKernelGGL(rowdot_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, s, a, scratch_at);
+    int L = lanes_for(a.width);
+    uint64_t threads = a.rows * L;
+    hipLaunchKernelGGL(rowdot_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, s, a.tlde, a.t_ld, a.width, a.rows, L, a.alpha_pow, scratch_at);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(reduced_combine_kernel, dim3((unsigned)((a.rows + 255) / 256)), dim3(256), 0, s, a, scratch_at);
+    uint32_t* scratch_ap = scratch_at + 4 * a.rows;
+    if (a.p_width) {
+        L = lanes_for(a.p_width);
+        threads = a.rows * L;
+        hipLaunchKernelGGL(rowdot_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, s, a.plde, a.p_ld, a.p_width, a.rows, L, a.alpha_pow, scratch_ap);
+        e = hipGetLastError();
+        if (e != hipSuccess) return e;
+    }
+    hipLaunchKernelGGL(reduced_combine_kernel, dim3((unsigned)((a.rows + 255) / 256)), dim3(256), 0, s, a, scratch_at, scratch_ap);
+    return hipGetLastError();
+}
+
+// ------------------------------------------------------------------ LogUp permutation trace
+// phi_q[i] = 1/(gamma + a_s + beta b_s) - 1/(gamma + a_r + beta b_r), S = running sum of the row sums.
+// (sp1-stark generate_permutation_trace, reference Cargo.lock:6172: per-row extension inverses,
+// then a prefix sum.)  Three launches: rows + block-local scan, scan of the block totals, fix-up.
+constexpr int PERM_BLOCK = 256;
+__global__ void __launch_bounds__(PERM_BLOCK) perm_rows_kernel(PermArgs a, uint32_t* __restrict__ block_tot) {
+    __shared__ uint32_t sh[PERM_BLOCK * 4];
+    const uint64_t i = (uint64_t)blockIdx.x * PERM_BLOCK + threadIdx.x;
+    Ext sum = ext_zero();
+    if (i < a.rows) {
+        const uint32_t* row = a.trace + i * a.ld;
+        uint32_t* prow = a.out + i * a.out_ld;
+        for (uint32_t q = 0; q < a.pairs; q++) {
+            const uint4 vs = *reinterpret_cast<const uint4*>(row + 8 * q);
+            const uint4 vr = *reinterpret_cast<const uint4*>(row + 8 * q + 4);
+            const Ext ds = ext_add(ext_add_base(a.gamma, vs.x), ext_mul_base(a.beta, vs.y));
+            const Ext dr = ext_add(ext_add_base(a.gamma, vr.x), ext_mul_base(a.beta, vr.y));
+            const Ext phi = ext_sub(ext_inv(ds), ext_inv(dr));
+            st_ext(prow + 4 * q, phi);
+            sum = ext_add(sum, phi);
+        }
+    }
+    // inclusive scan of the row sums inside the block (Hillis-Steele, exact modular adds)
+    for (int k = 0; k < 4; k++) sh[threadIdx.x * 4 + k] = sum.c[k];
+    __syncthreads();
+    for (int off = 1; off < PERM_BLOCK; off <<= 1) {
+        Ext o = ext_zero();
+        if ((int)threadIdx.x >= off) o = Ext{{sh[(threadIdx.x - off) * 4], sh[(threadIdx.x - off) * 4 + 1], sh[(threadIdx.x - off) * 4 + 2], sh[(threadIdx.x - off) * 4 + 3]}};
+        __syncthreads();
+        sum = ext_add(sum, o);
+        for (int k = 0; k < 4; k++) sh[threadIdx.x * 4 + k] = sum.c[k];
+        __syncthreads();
+    }
+    if (i < a.rows) st_ext(a.out + i * a.out_ld + 4 * a.pairs, sum);
+    if (threadIdx.x == PERM_BLOCK - 1) st_ext(block_tot + 4 * (uint64_t)blockIdx.x, sum);
+}
+// exclusive scan of the block totals, one workgroup (nblocks <= 65536)
+__global__ void __launch_bounds__(1024) perm_scan_blocks_kernel(uint32_t* block_tot, uint32_t nblocks) {
+    __shared__ uint32_t sh[1024 * 4];
+    const uint32_t per = (nblocks + 1023) / 1024;
+    const uint32_t b0 = threadIdx.x * per;
+    Ext sum = ext_zero();
+    for (uint32_t k = 0; k < per && b0 + k < nblocks; k++) sum = ext_add(sum, ld_ext(block_tot + 4 * (uint64_t)(b0 + k)));
+    for (int k = 0; k < 4; k++) sh[threadIdx.x * 4 + k] = sum.c[k];
+    __syncthreads();
+    Ext incl = sum;
+    for (int off = 1; off < 1024; off <<= 1) {
+        Ext o = ext_zero();
+        if ((int)threadIdx.x >= off) o = Ext{{sh[(threadIdx.x - off) * 4], sh[(threadIdx.x - off) * 4 + 1], sh[(threadIdx.x - off) * 4 + 2], sh[(threadIdx.x - off) * 4 + 3]}};
+        __syncthreads();
+        incl = ext_add(incl, o);
+        for (int k = 0; k < 4; k++) sh[threadIdx.x * 4 + k] = incl.c[k];
+        __syncthreads();
+    }
+    Ext run = ext_sub(incl, sum);                  // exclusive prefix of this thread's chunk
+    for (uint32_t k = 0; k < per && b0 + k < nblocks; k++) {
+        const Ext t = ld_ext(block_tot + 4 * (uint64_t)(b0 + k));
+        st_ext(block_tot + 4 * (uint64_t)(b0 + k), run);
+        run = ext_add(run, t);
+    }
+}
+__global__ void __launch_bounds__(PERM_BLOCK) perm_fixup_kernel(PermArgs a, const uint32_t* __restrict__ block_off) {
+    const uint64_t i = (uint64_t)blockIdx.x * PERM_BLOCK + threadIdx.x;
+    if (i >= a.rows) return;
+    uint32_t* sp = a.out + i * a.out_ld + 4 * a.pairs;
+    st_ext(sp, ext_add(ld_ext(sp), ld_ext(block_off + 4 * (uint64_t)blockIdx.x)));
+}
+hipError_t launch_perm_trace(const PermArgs& a, uint32_t* block_scratch, hipStream_t s) {
+    const uint32_t nblocks = (uint32_t)((a.rows + PERM_BLOCK - 1) / PERM_BLOCK);
+    hipLaunchKernelGGL(perm_rows_kernel, dim3(nblocks), dim3(PERM_BLOCK), 0, s, a, block_scratch);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(perm_scan_blocks_kernel, dim3(1), dim3(1024), 0, s, block_scratch, nblocks);
+    e = hipGetLastError();
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(perm_fixup_kernel, dim3(nblocks), dim3(PERM_BLOCK), 0, s, a, block_scratch);
     return hipGetLastError();
 }
 

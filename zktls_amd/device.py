@@ -106,6 +106,19 @@ class Context:
         check(self.lib.zkhip_gen_trace(self.handle, seed, shard, log_n, width, C.c_void_p(out.ptr), width))
         return out
 
+    def gen_trace_logup(self, seed, shard, log_n, width, pairs, out=None):
+        out = out or self.alloc(width << log_n)
+        check(self.lib.zkhip_gen_trace_logup(self.handle, seed, shard, log_n, width, pairs, C.c_void_p(out.ptr), width))
+        return out
+
+    def perm_trace(self, trace, log_n, width, pairs, gamma, beta, out=None):
+        out = out or self.alloc((4 * (pairs + 1)) << log_n)
+        g = to_monty(np.asarray(gamma, dtype=np.uint32))
+        b = to_monty(np.asarray(beta, dtype=np.uint32))
+        check(self.lib.zkhip_perm_trace(self.handle, C.c_void_p(trace.ptr), width, log_n, width, pairs,
+                                        g.ctypes.data_as(u32p), b.ctypes.data_as(u32p), C.c_void_p(out.ptr)))
+        return out
+
     # ---- NTT / LDE
     def dft(self, src, log_n, width, inverse=False, bitrev_out=False, out=None):
         out = out or self.alloc(width << log_n)
@@ -171,7 +184,7 @@ class Context:
 
     # ---- whole shard
     def prove_shard(self, trace, log_n, width, public_values=(), params=None):
-        params = params or Params(1, 100, 16)
+        params = params or Params(1, 100, 16, 0)
         pv = np.ascontiguousarray(np.array(public_values, dtype=np.uint32))
         size = self.lib.zkhip_proof_size(log_n, width, C.byref(params), pv.size)
         buf = np.empty(size, dtype=np.uint8)

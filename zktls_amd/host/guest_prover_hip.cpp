@@ -123,7 +123,7 @@ ProveResult HipGuestProver::prove_inner(const GuestInput& input, const std::vect
     if (mode_ == ProverType::Network) throw std::runtime_error("network proving is not provided by the HIP backend");
     // Local and Hip both mean "prove on this machine"; there is no CPU path in libzkhip
     if (plan_.shards == 0) throw std::runtime_error("shard plan is empty");
-    zkhip_params prm{1, plan_.num_queries, plan_.pow_bits};
+    zkhip_params prm{1, plan_.num_queries, plan_.pow_bits, 0};
     const size_t cap = zkhip_proof_size(plan_.log_n, plan_.width, &prm, 9);
     if (cap == 0) throw std::runtime_error(std::string("bad shard plan: ") + zkhip_last_error());
     CtxGuard g;
