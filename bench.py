@@ -34,6 +34,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--log-n", type=int, default=20)
     ap.add_argument("--width", type=int, default=256)
+    ap.add_argument("--logup-pairs", type=int, default=0, help="LogUp lookup pairs (SURVEY 8a row a8); 0 = main AIR only")
+    ap.add_argument("--streams", type=int, default=3, help="shards in flight per GPU: each on its own context + HIP stream")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-log-n", type=int, default=19, help="rows of the bounded CPU-baseline sample")
     ap.add_argument("--cpu-threads", type=int, default=0, help="OpenMP threads of the CPU baseline (0: min(cores, 64))")
@@ -65,9 +67,14 @@ def main():
     log_n, width = args.log_n, args.width
     n = 1 << log_n
     cells = n * width
-    prm = Params(1, 100, 16)
-    stream = torch.cuda.Stream(device=local_rank)
-    ctx = Context(local_rank, stream=stream.cuda_stream)
+    LQ = args.logup_pairs
+    prm = Params(1, 100, 16, LQ)
+    # one context (= one HIP stream + its workspaces) per shard in flight: while one shard sits in a
+    # latency-bound stretch (small FRI layers, host round trips) the other keeps the CUs busy
+    S = max(1, args.streams)
+    streams = [torch.cuda.Stream(device=local_rank) for _ in range(S)]
+    ctxs = [Context(local_rank, stream=st.cuda_stream) for st in streams]
+    stream, ctx = streams[0], ctxs[0]
 
     # batch transcript seed: rank 0 draws it, RCCL broadcasts it (the only collective)
     from zktls_amd import shards
@@ -79,15 +86,44 @@ def main():
         traces = [torch.empty(cells, dtype=torch.int32, device="cuda") for _ in range(nbuf)]
     bufs = [ctx.wrap(t) for t in traces]
     for i, b in enumerate(bufs):
-        ctx.gen_trace(SEED, rank * max(K, 1) + i, log_n, width, out=b)
+        if LQ:
+            ctx.gen_trace_logup(SEED, rank * max(K, 1) + i, log_n, width, LQ, out=b)
+        else:
+            ctx.gen_trace(SEED, rank * max(K, 1) + i, log_n, width, out=b)
     ctx.sync()
 
-    def step(i):
-        return ctx.prove_shard(bufs[i % nbuf], log_n, width, public + [rank * max(K, 1) + (i % nbuf)], prm)
+    def step(i, c=None):
+        return (c or ctx).prove_shard(bufs[i % nbuf], log_n, width, public + [rank * max(K, 1) + (i % nbuf)], prm)
 
-    for i in range(W):
-        step(i)
-    ctx.sync()
+    def run_steps(count):
+        """`count` shard proofs, S at a time (one host thread per context; ctypes drops the GIL)"""
+        if S == 1:
+            out = None
+            for i in range(count):
+                out = step(i)
+            return out
+        import threading
+        results = [None] * count
+        errors = []
+
+        def worker(w):
+            try:
+                for i in range(w, count, S):
+                    results[i] = step(i, ctxs[w])
+            except Exception as e:          # surfaced after the join
+                errors.append(e)
+        ts = [threading.Thread(target=worker, args=(w,)) for w in range(min(S, count))]
+        for t in ts:
+            t.start()
+        for t in ts:
+            t.join()
+        if errors:
+            raise errors[0]
+        return results[count - 1] if count else None
+
+    run_steps(max(W, S if W else 0))       # warm every context (plans, workspaces)
+    for c in ctxs:
+        c.sync()
 
     def barrier():
         torch.cuda.synchronize()
@@ -97,9 +133,7 @@ def main():
 
     barrier()
     t0 = time.perf_counter()
-    last = None
-    for i in range(K):
-        last = step(i)
+    last = run_steps(K)
     barrier()
     elapsed = time.perf_counter() - t0
     elapsed = shards.max_over_ranks(dist, elapsed, device="cuda")
@@ -151,8 +185,8 @@ def main():
         # the scalar oracle's loops stop scaling long before 256 threads: cap, and say so
         used = O.set_threads(args.cpu_threads if args.cpu_threads > 0 else min(cores, 64))
         cl = args.cpu_log_n
-        tr = O.gen_trace(SEED, 0, cl, width)
-        oprm = O.default_params(1, 100, 16)
+        tr = O.gen_trace_logup(SEED, 0, cl, width, LQ) if LQ else O.gen_trace(SEED, 0, cl, width)
+        oprm = O.default_params(1, 100, 16, LQ)
         tc0 = time.perf_counter()
         O.prove_shard(tr, public + [0], oprm)
         dt = time.perf_counter() - tc0
@@ -174,7 +208,8 @@ def main():
             "vs_baseline": None,
             "dtype": "u32",
             "data": "synthetic",
-            "config": {"workload": "SP1-core-like synthetic shard: 2^%d rows x %d cols BabyBear, log_blowup 1, 100 queries, 16 PoW bits, full prove_shard" % (log_n, width),
+            "streams_per_gpu": S,
+            "config": {"workload": "SP1-core-like synthetic shard: 2^%d rows x %d cols BabyBear, log_blowup 1, 100 queries, 16 PoW bits, %s, full prove_shard" % (log_n, width, ("LogUp x%d" % LQ) if LQ else "no lookups"),
                        "parallelism": "shard-parallel x%d" % world, "shards_per_step": world},
             "proofs_per_s": round(K * world / elapsed, 3),
             "proof_bytes": int(last.size),
@@ -183,7 +218,8 @@ def main():
             "cpu_baseline": cpu,
         }
         print(json.dumps(out), flush=True)
-    ctx.close()
+    for c in ctxs:
+        c.close()
     if dist is not None:
         dist.destroy_process_group()
     if not verified:
