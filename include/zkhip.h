@@ -133,6 +133,13 @@ int zkhip_hash_rows(zkhip_ctx* ctx, const uint32_t* const* d_mats, const size_t*
 int zkhip_merkle_commit(zkhip_ctx* ctx, const uint32_t* const* d_mats, const size_t* lds,
                         const uint32_t* widths, int nmats, int log_h, uint32_t* d_tree);
 
+/* matrices of different power-of-two heights (an SP1 shard commits one matrix per chip):
+ * the tallest form the leaves, a shorter one is injected at the level that has as many nodes as
+ * it has rows, node = compress(node, sponge(row)).  Tree layout as above for the tallest height;
+ * at most 4 matrices per distinct height, 16 in all. */
+int zkhip_merkle_commit_mixed(zkhip_ctx* ctx, const uint32_t* const* d_mats, const size_t* lds,
+                              const uint32_t* widths, const int* log_heights, int nmats, uint32_t* d_tree);
+
 /* ---- STARK stages (synthetic AIR, log_blowup = 1) ---- */
 /* quotient values on the LDE coset, bit-reversed rows: d_out[2^(log_n+1)][4] */
 int zkhip_quotient_values(zkhip_ctx* ctx, const uint32_t* d_lde, size_t ld, int log_n,

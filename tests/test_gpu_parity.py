@@ -168,3 +168,14 @@ def test_ntt_pass_hook_composes_to_bitrev_dft(ctx, oracle):
     ctx.ntt_pass(buf, buf, log_n, width, 1)
     got = buf.download().reshape(-1, width)
     assert (got[bitrev_perm(log_n)] == oracle.ntt(m)).all()
+
+
+@pytest.mark.parametrize("shapes", [[(3, 3), (2, 2)], [(10, 16), (10, 5), (7, 8), (3, 4)], [(13, 24), (12, 8), (12, 3), (0, 6)],
+                                    [(15, 8), (9, 40)]])
+def test_merkle_commit_mixed_heights_matches_oracle(ctx, oracle, shapes):
+    # an SP1 shard commits one matrix per chip, of different heights (p3-merkle-tree injection rule)
+    rng = np.random.default_rng(len(shapes))
+    mats = [rng.integers(0, P, size=(1 << lh, w), dtype=np.uint32) for lh, w in shapes]
+    dm = [(ctx.from_numpy(m), m.shape[1], lh) for m, (lh, _) in zip(mats, shapes)]
+    got = ctx.merkle_commit_mixed(dm).download().reshape(-1, 8)
+    assert (got == oracle.merkle_tree_mixed(mats)).all()

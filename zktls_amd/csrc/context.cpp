@@ -234,6 +234,49 @@ int op_merkle_commit(zkhip_ctx* ctx, const MatDesc* mats, int nmats, int log_h, 
     return ZKHIP_OK;
 }
 
+// p3-merkle-tree FieldMerkleTreeMmcs::commit with matrices of different (power-of-two) heights:
+// the tallest ones form the leaves; a shorter matrix is injected at the level with as many
+// nodes as it has rows: node = compress(node, sponge(row)).
+int op_merkle_commit_mixed(zkhip_ctx* ctx, const MatDesc* mats, const int* log_heights, int nmats, uint32_t* tree) {
+    if (nmats < 1 || nmats > 16) return fail(ZKHIP_ERR_INVALID, "merkle_commit_mixed: 1..16 matrices");
+    int log_h = 0;
+    for (int m = 0; m < nmats; m++) {
+        if (log_heights[m] < 0 || log_heights[m] > 30) return fail(ZKHIP_ERR_INVALID, "merkle_commit_mixed: bad height");
+        if (log_heights[m] > log_h) log_h = log_heights[m];
+    }
+    auto gather = [&](int lh, LeafArgs& la) {
+        la = LeafArgs{};
+        for (int m = 0; m < nmats; m++)
+            if (log_heights[m] == lh) {
+                if (la.nmats == MAX_LEAF_MATS) return false;
+                la.mats[la.nmats++] = mats[m];
+            }
+        la.height = (uint64_t)1 << lh;
+        return true;
+    };
+    LeafArgs la;
+    if (!gather(log_h, la)) return fail(ZKHIP_ERR_INVALID, "merkle_commit_mixed: at most 4 matrices per height");
+    la.digests = tree;
+    ZK_HIP(launch_hash_rows(la, ctx->stream));
+    uint32_t* level = tree;
+    for (int lvl = log_h - 1; lvl >= 0; lvl--) {
+        const uint64_t cnt = (uint64_t)1 << lvl;
+        uint32_t* next = level + 16 * cnt;
+        ZK_HIP(launch_compress_level(level, next, cnt, ctx->stream));
+        LeafArgs inj;
+        if (!gather(lvl, inj)) return fail(ZKHIP_ERR_INVALID, "merkle_commit_mixed: at most 4 matrices per height");
+        if (inj.nmats) {
+            void* tmp;
+            ZK_TRY(ctx_reserve(ctx, 1, cnt * 32, &tmp));
+            inj.digests = (uint32_t*)tmp;
+            ZK_HIP(launch_hash_rows(inj, ctx->stream));
+            ZK_HIP(launch_inject(next, (const uint32_t*)tmp, cnt, ctx->stream));
+        }
+        level = next;
+    }
+    return ZKHIP_OK;
+}
+
 }  // namespace zk
 
 using namespace zk;
@@ -442,6 +485,19 @@ int zkhip_merkle_commit(zkhip_ctx* ctx, const uint32_t* const* d_mats, const siz
     ZK_TRY(make_descs(d_mats, lds, widths, nmats, descs));
     if (!d_tree) return fail(ZKHIP_ERR_INVALID, "merkle_commit: null output");
     return op_merkle_commit(ctx, descs, nmats, log_h, d_tree);
+}
+
+int zkhip_merkle_commit_mixed(zkhip_ctx* ctx, const uint32_t* const* d_mats, const size_t* lds, const uint32_t* widths,
+                              const int* log_heights, int nmats, uint32_t* d_tree) {
+    CHECK_CTX(ctx);
+    if (nmats < 1 || nmats > 16 || !d_mats || !lds || !widths || !log_heights || !d_tree)
+        return fail(ZKHIP_ERR_INVALID, "merkle_commit_mixed: bad arguments");
+    MatDesc descs[16];
+    for (int m = 0; m < nmats; m++) {
+        if (!d_mats[m] || lds[m] < widths[m]) return fail(ZKHIP_ERR_INVALID, "bad matrix descriptor");
+        descs[m].ptr = d_mats[m]; descs[m].ld = lds[m]; descs[m].width = widths[m];
+    }
+    return op_merkle_commit_mixed(ctx, descs, log_heights, nmats, d_tree);
 }
 
 }  // extern "C"

@@ -69,4 +69,5 @@ int get_plan(zkhip_ctx* ctx, int log_n, int kind, uint32_t shift_monty, const Nt
 int op_coset_lde(zkhip_ctx* ctx, const uint32_t* d_in, size_t in_ld, uint32_t* d_out, size_t out_ld,
                  int log_n, uint32_t width, int log_blowup, uint32_t shift_monty);
 int op_merkle_commit(zkhip_ctx* ctx, const MatDesc* mats, int nmats, int log_h, uint32_t* d_tree);
+int op_merkle_commit_mixed(zkhip_ctx* ctx, const MatDesc* mats, const int* log_heights, int nmats, uint32_t* d_tree);
 }  // namespace zk

@@ -120,6 +120,25 @@ hipError_t launch_compress_level(const uint32_t* children, uint32_t* parents, ui
     return hipGetLastError();
 }
 
+// node[i] = compress(node[i], extra[i]): injection of a shorter matrix's row digests at its level
+__global__ void __launch_bounds__(256) inject_kernel(uint32_t* __restrict__ nodes, const uint32_t* __restrict__ extra, uint64_t count) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= count) return;
+    const uint4* a = reinterpret_cast<const uint4*>(nodes + 8 * i);
+    const uint4* b = reinterpret_cast<const uint4*>(extra + 8 * i);
+    const uint4 v0 = a[0], v1 = a[1], v2 = b[0], v3 = b[1];
+    uint32_t s[16] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w, v2.x, v2.y, v2.z, v2.w, v3.x, v3.y, v3.z, v3.w};
+    p2_permute_dev(s);
+    uint4* d = reinterpret_cast<uint4*>(nodes + 8 * i);
+    d[0] = make_uint4(s[0], s[1], s[2], s[3]);
+    d[1] = make_uint4(s[4], s[5], s[6], s[7]);
+}
+hipError_t launch_inject(uint32_t* nodes, const uint32_t* extra, uint64_t count, hipStream_t s) {
+    if (count == 0) return hipSuccess;
+    hipLaunchKernelGGL(inject_kernel, dim3((unsigned)((count + 255) / 256)), dim3(256), 0, s, nodes, extra, count);
+    return hipGetLastError();
+}
+
 // levels count -> count/2 -> ... -> 1 inside one workgroup (count <= 2048)
 __global__ void __launch_bounds__(1024) compress_top_kernel(uint32_t* tree, uint32_t count) {
     uint32_t* level = tree;

@@ -64,6 +64,8 @@ hipError_t launch_hash_rows(const LeafArgs& a, hipStream_t s);
 // parents[i] = compress(children[2i], children[2i+1]), i < count
 hipError_t launch_compress_level(const uint32_t* children, uint32_t* parents, uint64_t count,
                                  hipStream_t s);
+// nodes[i] = compress(nodes[i], extra[i])  (mixed-height commitments)
+hipError_t launch_inject(uint32_t* nodes, const uint32_t* extra, uint64_t count, hipStream_t s);
 // all remaining levels of a small subtree in one launch: `tree` points at a level with
 // `count` (<= COOP_TOP_NODES, power of two) digests followed by room for the levels above it
 hipError_t launch_compress_top(uint32_t* tree, uint32_t count, hipStream_t s);

@@ -161,6 +161,15 @@ class Context:
         check(self.lib.zkhip_merkle_commit(self.handle, ptrs, lds, ws, len(mats), log_h, C.c_void_p(out.ptr)))
         return out
 
+    def merkle_commit_mixed(self, mats, out=None):
+        """mats: list of (DeviceBuffer, width, log_height); tree sized for the tallest"""
+        log_h = max(m[2] for m in mats)
+        out = out or self.alloc(8 * ((2 << log_h) - 1))
+        ptrs, lds, ws = self._mat_args(mats)
+        lhs = (C.c_int * len(mats))(*[m[2] for m in mats])
+        check(self.lib.zkhip_merkle_commit_mixed(self.handle, ptrs, lds, ws, lhs, len(mats), C.c_void_p(out.ptr)))
+        return out
+
     # ---- STARK stages
     def quotient_values(self, lde, log_n, width, alpha, out=None):
         out = out or self.alloc(4 << (log_n + 1))
