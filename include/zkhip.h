@@ -140,6 +140,22 @@ int zkhip_merkle_commit(zkhip_ctx* ctx, const uint32_t* const* d_mats, const siz
 int zkhip_merkle_commit_mixed(zkhip_ctx* ctx, const uint32_t* const* d_mats, const size_t* lds,
                               const uint32_t* widths, const int* log_heights, int nmats, uint32_t* d_tree);
 
+/* RISC Zero layout (risc0-zkp Hal::hash_rows + hash_fold, reference
+ * Cargo.lock:5057, call site crates/guest-prover-r0/src/prover.rs:90): d_mat is COLUMN-major
+ * [cols][2^log_rows]; leaf r = Poseidon2-width-24 sponge (rate 16) over row r; parents =
+ * permute(l || r || 0^8)[0..8].  Own constants "zktls-amd/p2-bb24-v1". */
+int zkhip_merkle_commit_p24_colmajor(zkhip_ctx* ctx, const uint32_t* d_mat, uint32_t cols, int log_rows,
+                                     uint32_t* d_tree);
+/* Hal::batch_interpolate_ntt: `count` polynomials, column-major [count][2^log_size]; evaluations
+ * in BIT-REVERSED order in, coefficients in natural order out (scaled by 1/size). */
+int zkhip_batch_interpolate_colmajor(zkhip_ctx* ctx, const uint32_t* d_evals, uint32_t* d_coeffs,
+                                     uint32_t count, int log_size);
+/* Hal::zk_shift + batch_expand_into_evaluate_ntt: coefficients (natural) -> evaluations of the same
+ * polynomials on shift * <w_(size * 2^log_blowup)>, bit-reversed, [count][size << log_blowup].
+ * RISC Zero expands by 4 (log_blowup = 2).  `shift` canonical. */
+int zkhip_batch_expand_colmajor(zkhip_ctx* ctx, const uint32_t* d_coeffs, uint32_t* d_evals,
+                                uint32_t count, int log_size, int log_blowup, uint32_t shift);
+
 /* ---- STARK stages (synthetic AIR, log_blowup = 1) ---- */
 /* quotient values on the LDE coset, bit-reversed rows: d_out[2^(log_n+1)][4] */
 int zkhip_quotient_values(zkhip_ctx* ctx, const uint32_t* d_lde, size_t ld, int log_n,
@@ -156,6 +172,11 @@ int zkhip_open_at(zkhip_ctx* ctx, const uint32_t* d_lde, size_t ld, int log_n, i
 /* one fold-by-2 FRI step on 2^log_h extension elements (bit-reversed order) */
 int zkhip_fri_fold(zkhip_ctx* ctx, const uint32_t* d_in, int log_h,
                    const uint32_t beta[4] /* host, Montgomery */, uint32_t* d_out);
+
+/* fold of arity 2^log_arity (RISC Zero folds by 16, log_arity = 4): log_arity chained fold-by-2
+ * launches with beta, beta^2, beta^4, ...; d_out gets 2^(log_h - log_arity) elements */
+int zkhip_fri_fold_k(zkhip_ctx* ctx, const uint32_t* d_in, int log_h, int log_arity,
+                     const uint32_t beta[4] /* host, Montgomery */, uint32_t* d_out);
 
 /* ---- whole shard ---- */
 size_t zkhip_proof_size(int log_n, uint32_t width, const zkhip_params* prm, size_t n_public);

@@ -52,6 +52,12 @@ void orc_sponge_hash(const uint32_t* in, size_t n, uint32_t out[8]);
 /* TruncatedPermutation<2,8,16>: permute(left || right)[0..8]. */
 void orc_compress(const uint32_t left[8], const uint32_t right[8], uint32_t out[8]);
 
+/* ---- width 24 (RISC Zero's Poseidon2 shape) ---- */
+void orc_poseidon2_24_permute(uint32_t state[24]);
+void orc_sponge24_hash(const uint32_t* in, size_t n, size_t stride, uint32_t out[8]);
+void orc_compress24(const uint32_t left[8], const uint32_t right[8], uint32_t out[8]);
+void orc_merkle_tree_p24_colmajor(const uint32_t* mat, size_t cols, int log_rows, uint32_t* tree);
+
 /* ---- Merkle commitment (p3-merkle-tree FieldMerkleTreeMmcs, equal heights) ----
  * leaf r = sponge(row r of mats[0] || row r of mats[1] || ...).
  * tree: all levels, level 0 = 2^log_h leaf digests, then 2^(log_h-1) ..., root last;
@@ -123,6 +129,9 @@ void orc_open_at(const uint32_t* lde, int log_n, size_t width, const uint32_t z[
                  uint32_t* out);
 /* one FRI fold (arity 2) of `in` (2^log_h ext elements, bit-reversed) -> 2^(log_h-1). */
 void orc_fri_fold(const uint32_t* in, int log_h, const uint32_t beta[4], uint32_t* out);
+
+/* fold of arity 2^log_arity (<= 64), definition by interpolation; out has 2^(log_h-log_arity) entries */
+void orc_fri_fold_k(const uint32_t* in, int log_h, int log_arity, const uint32_t beta[4], uint32_t* out);
 
 /* full shard proof; returns bytes written (0 on error); proof layout: DESIGN.md. */
 size_t orc_proof_size(int log_n, size_t width, const orc_params_t* prm, size_t n_public);

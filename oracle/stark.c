@@ -314,6 +314,35 @@ void orc_fri_fold(const uint32_t* in, int log_h, const uint32_t beta_[4], uint32
         st4(out + 4 * i, fri_fold_row(i, log_h - 1, beta, ld4(in + 8 * i), ld4(in + 8 * i + 4)));
 }
 
+/* FRI fold of arity 2^k (RISC Zero folds by 16: risc0-zkp `fri_fold`, reference Cargo.lock:5057,
+ * call site crates/guest-prover-r0/src/prover.rs:90).  Restated from the definition: the 2^k
+ * consecutive (bit-reversed) entries of `in` are the evaluations of f on one coset
+ * { x w_{2^k}^j }; out[i] = value at beta of the degree < 2^k interpolant through them
+ * (= sum_j beta^j f_j(x^(2^k)) for f = sum_j X^j f_j(X^(2^k))).  Naive Lagrange form. */
+void orc_fri_fold_k(const uint32_t* in, int log_h, int log_arity, const uint32_t beta_[4], uint32_t* out) {
+    size_t arity = (size_t)1 << log_arity, nout = (size_t)1 << (log_h - log_arity);
+    bb4_t beta = ld4(beta_);
+    bb_t w = bb_two_adic_generator(log_h);
+#pragma omp parallel for schedule(static)
+    for (size_t i = 0; i < nout; i++) {
+        bb_t xs[64];
+        for (size_t j = 0; j < arity; j++)
+            xs[j] = bb_pow(w, bb_reverse_bits((uint32_t)(i * arity + j), log_h));
+        bb4_t acc = bb4_zero();
+        for (size_t j = 0; j < arity; j++) {
+            bb4_t num = bb4_one();
+            bb_t den = 1;
+            for (size_t l = 0; l < arity; l++) {
+                if (l == j) continue;
+                num = bb4_mul(num, bb4_sub_base(beta, xs[l]));
+                den = bb_mul(den, bb_sub(xs[j], xs[l]));
+            }
+            acc = bb4_add(acc, bb4_mul(ld4(in + 4 * (i * arity + j)), bb4_mul_base(num, bb_inv(den))));
+        }
+        st4(out + 4 * i, acc);
+    }
+}
+
 /* ------------------------------------------------------------------ */
 /* proof layout (all words little-endian u32, canonical residues)       */
 /* ------------------------------------------------------------------ */

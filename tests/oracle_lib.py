@@ -151,6 +151,22 @@ def compress(l, r):
     return out
 
 
+def poseidon2_24(state):
+    s = _u32(state).copy()
+    assert s.shape == (24,)
+    lib().orc_poseidon2_24_permute(_p(s))
+    return s
+
+
+def merkle_tree_p24_colmajor(mat):
+    """mat: [cols][rows] column-major"""
+    m = _u32(mat)
+    cols, rows = m.shape
+    out = np.empty((2 * rows - 1, 8), dtype=np.uint32)
+    lib().orc_merkle_tree_p24_colmajor(_p(m), C.c_size_t(cols), C.c_int(rows.bit_length() - 1), _p(out))
+    return out
+
+
 def _mats_args(mats):
     mats = [_u32(m) for m in mats]
     ptrs = (u32p * len(mats))(*[_p(m) for m in mats])
@@ -227,6 +243,15 @@ def fri_fold(vals, beta):
     b = _u32(beta)
     out = np.empty((h // 2, 4), dtype=np.uint32)
     lib().orc_fri_fold(_p(v), C.c_int(h.bit_length() - 1), _p(b), _p(out))
+    return out
+
+
+def fri_fold_k(vals, log_arity, beta):
+    v = _u32(vals)
+    h = v.shape[0]
+    b = _u32(beta)
+    out = np.empty((h >> log_arity, 4), dtype=np.uint32)
+    lib().orc_fri_fold_k(_p(v), C.c_int(h.bit_length() - 1), C.c_int(log_arity), _p(b), _p(out))
     return out
 
 

@@ -141,3 +141,44 @@ def mix64(z):
 def synth_value(seed, index):
     M = (1 << 64) - 1
     return mix64((seed + index * 0x9E3779B97F4A7C15) & M) % P
+
+
+# ---- width 24 (RISC Zero's shape), same construction from its own parameter file
+PARAMS24 = json.load(open(os.path.join(_HERE, "golden", "poseidon2_24_params.json")))
+
+
+def poseidon2_24(state):
+    m4 = PARAMS24["m4"]
+    t = 24
+    ME24 = [[(2 if i // 4 == j // 4 else 1) * m4[i % 4][j % 4] for j in range(t)] for i in range(t)]
+    d = PARAMS24["internal_diag"]
+    MI24 = [[(1 + (d[i] if i == j else 0)) % P for j in range(t)] for i in range(t)]
+    mv = lambda M, v: [sum(M[i][j] * v[j] for j in range(t)) % P for i in range(t)]
+    rc_e, rc_i = PARAMS24["external_rc"], PARAMS24["internal_rc"]
+    s = mv(ME24, [x % P for x in state])
+    for r in range(4):
+        s = mv(ME24, [pow((s[i] + rc_e[r][i]) % P, 7, P) for i in range(t)])
+    for r in range(21):
+        s[0] = pow((s[0] + rc_i[r]) % P, 7, P)
+        s = mv(MI24, s)
+    for r in range(4, 8):
+        s = mv(ME24, [pow((s[i] + rc_e[r][i]) % P, 7, P) for i in range(t)])
+    return s
+
+
+def sponge24(vals):
+    st = [0] * 24
+    pos = 0
+    for v in vals:
+        st[pos] = v % P
+        pos += 1
+        if pos == 16:
+            st = poseidon2_24(st)
+            pos = 0
+    if pos:
+        st = poseidon2_24(st)
+    return st[:8]
+
+
+def compress24(l, r):
+    return poseidon2_24(list(l) + list(r) + [0] * 8)[:8]

@@ -179,3 +179,28 @@ def test_merkle_commit_mixed_heights_matches_oracle(ctx, oracle, shapes):
     dm = [(ctx.from_numpy(m), m.shape[1], lh) for m, (lh, _) in zip(mats, shapes)]
     got = ctx.merkle_commit_mixed(dm).download().reshape(-1, 8)
     assert (got == oracle.merkle_tree_mixed(mats)).all()
+
+
+@pytest.mark.parametrize("cols,log_rows", [(1, 0), (16, 3), (19, 6), (40, 10), (7, 13)])
+def test_merkle_commit_p24_colmajor_matches_oracle(ctx, oracle, cols, log_rows):
+    # RISC Zero layout: column-major polynomials, Poseidon2 width 24
+    rng = np.random.default_rng(cols)
+    mat = rng.integers(0, P, size=(cols, 1 << log_rows), dtype=np.uint32)
+    got = ctx.merkle_commit_p24_colmajor(ctx.from_numpy(mat), cols, log_rows).download().reshape(-1, 8)
+    assert (got == oracle.merkle_tree_p24_colmajor(mat)).all()
+
+
+@pytest.mark.parametrize("count,log_size,log_blowup", [(1, 5, 2), (3, 8, 2), (40, 10, 2), (17, 12, 1), (64, 14, 2)])
+def test_colmajor_interpolate_and_expand_match_oracle(ctx, oracle, count, log_size, log_blowup):
+    # RISC Zero Hal layout: `count` contiguous polynomials
+    rng = np.random.default_rng(count)
+    n = 1 << log_size
+    evals_nat = rng.integers(0, P, size=(n, count), dtype=np.uint32)          # row-major view for the oracle
+    coeffs = oracle.ntt(evals_nat, inverse=True)
+    evals_br_colmajor = np.ascontiguousarray(evals_nat[bitrev_perm(log_size)].T)   # [count][n], bit-reversed order
+    got_c = ctx.batch_interpolate_colmajor(ctx.from_numpy(evals_br_colmajor), count, log_size).download().reshape(count, n)
+    assert (got_c == coeffs.T).all()
+    # expansion: evaluations on 31 * <w_{n 2^b}>, bit-reversed = the oracle's coset LDE of the evaluations
+    exp = oracle.coset_lde(evals_nat, log_blowup, 31)                         # [n << b][count]
+    got_e = ctx.batch_expand_colmajor(ctx.from_numpy(np.ascontiguousarray(coeffs.T)), count, log_size, log_blowup, 31)
+    assert (got_e.download().reshape(count, n << log_blowup) == exp.T).all()

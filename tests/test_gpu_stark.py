@@ -148,3 +148,13 @@ def test_logup_rejects_trace_without_the_permutation(ctx):
         assert e.code == -1
         return
     assert verify_shard(proof, log_n, width, [], prm)[0] == -6
+
+
+# ------------------------------------------------------------------ RISC0-style arity-16 fold (row a11)
+@pytest.mark.parametrize("log_h,log_arity", [(4, 4), (6, 2), (10, 4), (12, 3), (16, 4)])
+def test_fri_fold_k_matches_interpolation_definition(ctx, oracle, log_h, log_arity):
+    rng = np.random.default_rng(log_h * 8 + log_arity)
+    v = rng.integers(0, P, (1 << log_h, 4), dtype=np.uint32)
+    beta = rng.integers(0, P, 4, dtype=np.uint32)
+    got = ctx.fri_fold_k(ctx.from_numpy(v), log_h, log_arity, beta).download().reshape(-1, 4)
+    assert (got == oracle.fri_fold_k(v, log_arity, beta)).all()

@@ -377,3 +377,29 @@ def test_logup_proofs_verify_and_bind(oracle):
     except RuntimeError:
         return
     assert oracle.verify_shard(bad_pf, log_n, w, [7], prm) != 0
+
+
+def test_fri_fold_k_equals_chained_binary_folds(oracle):
+    # arity 2^k (RISC Zero: 16) = k binary folds with beta, beta^2, beta^4, ...
+    rng = np.random.default_rng(21)
+    v = rng.integers(0, P, (256, 4), dtype=np.uint32)
+    beta = [int(x) for x in rng.integers(0, P, 4)]
+    cur, b = v, beta
+    for _ in range(4):
+        cur = oracle.fri_fold(cur, b)
+        b = pyref.ext_mul(b, b)
+    assert (oracle.fri_fold_k(v, 4, beta) == cur).all()
+    assert (oracle.fri_fold_k(v, 1, beta) == oracle.fri_fold(v, beta)).all()
+
+
+def test_poseidon2_width24_against_python_definition(oracle):
+    rng = np.random.default_rng(24)
+    assert oracle.poseidon2_24(np.arange(24)).tolist() == pyref.poseidon2_24(list(range(24)))
+    s = rng.integers(0, P, 24, dtype=np.uint32)
+    assert oracle.poseidon2_24(s).tolist() == pyref.poseidon2_24(s.tolist())
+    # column-major commit: leaf = sponge over the row across columns, rate 16
+    mat = rng.integers(0, P, size=(19, 8), dtype=np.uint32)          # 19 columns, 8 rows
+    tree = oracle.merkle_tree_p24_colmajor(mat)
+    assert tree[3].tolist() == pyref.sponge24(mat[:, 3].tolist())
+    assert tree[8].tolist() == pyref.compress24(tree[0].tolist(), tree[1].tolist())
+    assert tree[-1].tolist() == pyref.compress24(tree[-3].tolist(), tree[-2].tolist())

@@ -21,7 +21,7 @@ EXPORTS = [
     "zkhip_memcpy_d2h", "zkhip_to_monty", "zkhip_from_monty", "zkhip_fill_uniform", "zkhip_gen_trace",
     "zkhip_gen_trace_logup", "zkhip_perm_trace",
     "zkhip_dft", "zkhip_coset_lde", "zkhip_ntt_pass", "zkhip_poseidon2_permute", "zkhip_hash_rows",
-    "zkhip_merkle_commit", "zkhip_merkle_commit_mixed", "zkhip_quotient_values", "zkhip_open_at", "zkhip_fri_fold",
+    "zkhip_merkle_commit", "zkhip_merkle_commit_mixed", "zkhip_merkle_commit_p24_colmajor", "zkhip_batch_interpolate_colmajor", "zkhip_batch_expand_colmajor", "zkhip_quotient_values", "zkhip_open_at", "zkhip_fri_fold", "zkhip_fri_fold_k",
     "zkhip_proof_size", "zkhip_prove_shard", "zkhip_verify_shard", "zkhip_last_prove_debug",
 ]
 
@@ -83,9 +83,13 @@ def load():
     L.zkhip_hash_rows.argtypes = [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t), C.POINTER(C.c_uint32), C.c_int, C.c_size_t, C.c_void_p]
     L.zkhip_merkle_commit.argtypes = [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t), C.POINTER(C.c_uint32), C.c_int, C.c_int, C.c_void_p]
     L.zkhip_merkle_commit_mixed.argtypes = [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t), C.POINTER(C.c_uint32), C.POINTER(C.c_int), C.c_int, C.c_void_p]
+    L.zkhip_merkle_commit_p24_colmajor.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_int, C.c_void_p]
+    L.zkhip_batch_interpolate_colmajor.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_int]
+    L.zkhip_batch_expand_colmajor.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_int, C.c_int, C.c_uint32]
     L.zkhip_quotient_values.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_uint32, u32p, C.c_void_p]
     L.zkhip_open_at.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_int, C.c_uint32, u32p, C.c_int, u32p]
     L.zkhip_fri_fold.argtypes = [C.c_void_p, C.c_void_p, C.c_int, u32p, C.c_void_p]
+    L.zkhip_fri_fold_k.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, u32p, C.c_void_p]
     L.zkhip_proof_size.restype = C.c_size_t
     L.zkhip_proof_size.argtypes = [C.c_int, C.c_uint32, C.POINTER(Params), C.c_size_t]
     L.zkhip_prove_shard.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_uint32, u32p, C.c_size_t,

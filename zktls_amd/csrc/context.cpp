@@ -487,6 +487,52 @@ int zkhip_merkle_commit(zkhip_ctx* ctx, const uint32_t* const* d_mats, const siz
     return op_merkle_commit(ctx, descs, nmats, log_h, d_tree);
 }
 
+// ---- RISC Zero Hal layout (column-major [count][size]) served through a transposing adapter:
+// the polynomials become the columns of a row-major matrix, which is what the NTT kernels
+// stream at full width; natively contiguous-vector passes are a later step.
+int zkhip_batch_interpolate_colmajor(zkhip_ctx* ctx, const uint32_t* d_evals, uint32_t* d_coeffs, uint32_t count, int log_size) {
+    CHECK_CTX(ctx);
+    if (!d_evals || !d_coeffs || count == 0 || log_size < 5 || log_size > 20) return fail(ZKHIP_ERR_INVALID, "batch_interpolate_colmajor: bad arguments");
+    const uint64_t n = (uint64_t)1 << log_size;
+    void *a, *b;
+    ZK_TRY(ctx_reserve(ctx, 19, n * count * 4, &a));
+    ZK_TRY(ctx_reserve(ctx, 20, n * count * 4, &b));
+    // evaluations arrive bit-reversed (Hal convention): undo it while transposing
+    ZK_HIP(launch_transpose(d_evals, (uint32_t*)a, count, n, log_size, 0, ctx->stream));
+    ZK_TRY(run_inverse(ctx, (const uint32_t*)a, count, (uint32_t*)b, count, log_size, count, false));
+    ZK_HIP(launch_transpose((const uint32_t*)b, d_coeffs, n, count, 0, 0, ctx->stream));
+    return ZKHIP_OK;
+}
+
+int zkhip_batch_expand_colmajor(zkhip_ctx* ctx, const uint32_t* d_coeffs, uint32_t* d_evals, uint32_t count, int log_size,
+                                int log_blowup, uint32_t shift) {
+    CHECK_CTX(ctx);
+    if (!d_coeffs || !d_evals || count == 0 || log_size < 5 || log_size > 20 || log_blowup < 0 || log_blowup > 4 ||
+        log_size + log_blowup > 24 || shift == 0 || shift >= P)
+        return fail(ZKHIP_ERR_INVALID, "batch_expand_colmajor: bad arguments");
+    const uint64_t n = (uint64_t)1 << log_size, m = n << log_blowup;
+    void *a, *b;
+    ZK_TRY(ctx_reserve(ctx, 19, n * count * 4, &a));
+    ZK_TRY(ctx_reserve(ctx, 20, m * count * 4, &b));
+    ZK_HIP(launch_transpose(d_coeffs, (uint32_t*)a, count, n, 0, 0, ctx->stream));
+    // zero-padded size-m transform = 2^b coset transforms of size n (as in op_coset_lde)
+    const uint32_t sm = to_monty(shift), wnb = two_adic_generator(log_size + log_blowup);
+    for (int t = 0; t < (1 << log_blowup); t++) {
+        const uint32_t st = fmul(sm, fpow(wnb, (uint64_t)t));
+        uint32_t* dst = (uint32_t*)b + (size_t)reverse_bits((uint32_t)t, log_blowup) * n * count;
+        ZK_TRY(run_forward_natural(ctx, (const uint32_t*)a, count, dst, count, log_size, count, st, true));
+    }
+    ZK_HIP(launch_transpose((const uint32_t*)b, d_evals, m, count, 0, 0, ctx->stream));
+    return ZKHIP_OK;
+}
+
+int zkhip_merkle_commit_p24_colmajor(zkhip_ctx* ctx, const uint32_t* d_mat, uint32_t cols, int log_rows, uint32_t* d_tree) {
+    CHECK_CTX(ctx);
+    if (!d_mat || !d_tree || cols == 0 || log_rows < 0 || log_rows > 28) return fail(ZKHIP_ERR_INVALID, "merkle_commit_p24_colmajor: bad arguments");
+    ZK_HIP(launch_merkle_p24_colmajor(d_mat, cols, log_rows, d_tree, ctx->stream));
+    return ZKHIP_OK;
+}
+
 int zkhip_merkle_commit_mixed(zkhip_ctx* ctx, const uint32_t* const* d_mats, const size_t* lds, const uint32_t* widths,
                               const int* log_heights, int nmats, uint32_t* d_tree) {
     CHECK_CTX(ctx);

@@ -252,6 +252,52 @@ __global__ void __launch_bounds__(256) hash_rows16_kernel(LeafArgs a, uint32_t t
     if (lane16 < 8) a.digests[row * 8 + lane16] = x;
 }
 
+// ------------------------------------------------------------------ RISC Zero layout (row a11)
+// column-major [cols][rows] polynomials, Poseidon2 width 24, rate 16: one row per lane, so a
+// wave reads 64 consecutive words of every column -- the layout is coalesced as it stands.
+__global__ void __launch_bounds__(256) hash_cols24_kernel(const uint32_t* __restrict__ mat, uint32_t cols, uint64_t rows,
+                                                          uint32_t* __restrict__ digests) {
+    const uint64_t r = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= rows) return;
+    uint32_t s[24];
+#pragma unroll
+    for (int i = 0; i < 24; i++) s[i] = 0u;
+    for (uint32_t q = 0; q < cols; q += 16) {
+#pragma unroll
+        for (int i = 0; i < 16; i++)
+            if (q + i < cols) s[i] = mat[(uint64_t)(q + i) * rows + r];
+        p24_permute_dev(s);
+    }
+    uint4* d = reinterpret_cast<uint4*>(digests + r * 8);
+    d[0] = make_uint4(s[0], s[1], s[2], s[3]);
+    d[1] = make_uint4(s[4], s[5], s[6], s[7]);
+}
+__global__ void __launch_bounds__(256) compress24_level_kernel(const uint32_t* __restrict__ children, uint32_t* __restrict__ parents, uint64_t count) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= count) return;
+    const uint4* cp = reinterpret_cast<const uint4*>(children + 16 * i);
+    const uint4 v0 = cp[0], v1 = cp[1], v2 = cp[2], v3 = cp[3];
+    uint32_t s[24] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w, v2.x, v2.y, v2.z, v2.w, v3.x, v3.y, v3.z, v3.w,
+                      0, 0, 0, 0, 0, 0, 0, 0};
+    p24_permute_dev(s);
+    uint4* d = reinterpret_cast<uint4*>(parents + 8 * i);
+    d[0] = make_uint4(s[0], s[1], s[2], s[3]);
+    d[1] = make_uint4(s[4], s[5], s[6], s[7]);
+}
+hipError_t launch_merkle_p24_colmajor(const uint32_t* mat, uint32_t cols, int log_rows, uint32_t* tree, hipStream_t s) {
+    const uint64_t rows = (uint64_t)1 << log_rows;
+    hipLaunchKernelGGL(hash_cols24_kernel, dim3((unsigned)((rows + 255) / 256)), dim3(256), 0, s, mat, cols, rows, tree);
+    hipError_t e = hipGetLastError();
+    uint32_t* level = tree;
+    for (uint64_t cnt = rows / 2; cnt >= 1 && e == hipSuccess; cnt >>= 1) {
+        uint32_t* next = level + 16 * cnt;
+        hipLaunchKernelGGL(compress24_level_kernel, dim3((unsigned)((cnt + 255) / 256)), dim3(256), 0, s, level, next, cnt);
+        e = hipGetLastError();
+        level = next;
+    }
+    return e;
+}
+
 __global__ void __launch_bounds__(256) permute_states_kernel(uint32_t* states, uint64_t count) {
     const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= count) return;

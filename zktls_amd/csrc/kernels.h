@@ -69,6 +69,8 @@ hipError_t launch_inject(uint32_t* nodes, const uint32_t* extra, uint64_t count,
 // all remaining levels of a small subtree in one launch: `tree` points at a level with
 // `count` (<= COOP_TOP_NODES, power of two) digests followed by room for the levels above it
 hipError_t launch_compress_top(uint32_t* tree, uint32_t count, hipStream_t s);
+// RISC Zero layout: column-major [cols][rows], Poseidon2 width 24 (rate 16); full tree, leaves first
+hipError_t launch_merkle_p24_colmajor(const uint32_t* mat, uint32_t cols, int log_rows, uint32_t* tree, hipStream_t s);
 // raw permutation on `count` states of 16 words (KAT / microbenchmark)
 hipError_t launch_permute_states(uint32_t* states, uint64_t count, hipStream_t s);
 
@@ -79,6 +81,8 @@ hipError_t launch_gen_trace(uint32_t* out, uint64_t ld, uint64_t seed, uint64_t 
                             uint32_t width, hipStream_t s);
 hipError_t launch_gen_trace_logup(uint32_t* out, uint64_t ld, uint64_t seed, uint64_t rows, uint32_t width,
                                   uint32_t pairs, hipStream_t s);
+// [rows][cols] -> [cols][rows], optional bit reversal of the column index on either side
+hipError_t launch_transpose(const uint32_t* in, uint32_t* out, uint64_t rows, uint64_t cols, int rev_bits_in, int rev_bits_out, hipStream_t s);
 // element-wise Montgomery <-> canonical conversion
 hipError_t launch_convert(const uint32_t* in, uint32_t* out, uint64_t n, bool to_monty_form,
                           hipStream_t s);

@@ -256,6 +256,29 @@ int zkhip_fri_fold(zkhip_ctx* ctx, const uint32_t* d_in, int log_h, const uint32
     return ZKHIP_OK;
 }
 
+int zkhip_fri_fold_k(zkhip_ctx* ctx, const uint32_t* d_in, int log_h, int log_arity, const uint32_t beta[4], uint32_t* d_out) {
+    CHECK_CTX(ctx);
+    if (!d_in || !d_out || !beta || log_arity < 1 || log_arity > 6 || log_h < log_arity || log_h > 21)
+        return fail(ZKHIP_ERR_INVALID, "fri_fold_k: bad arguments");
+    const int need_log_n = log_h - 1 < 5 ? 5 : log_h - 1;
+    if (ctx->dom_log_n < need_log_n) ZK_TRY(ensure_domain(ctx, need_log_n));
+    // f = sum_j X^j f_j(X^(2^k)); folding by 2 with b, then b^2, b^4, ... leaves sum_j b^j f_j
+    void* tmp;
+    ZK_TRY(ctx_reserve(ctx, S_PARTIAL, ((size_t)1 << log_h) * 16, &tmp));
+    uint32_t* ping = (uint32_t*)tmp;
+    uint32_t* pong = ping + ((size_t)2 << log_h);          // second half of the scratch
+    Ext b{{beta[0], beta[1], beta[2], beta[3]}};
+    const uint32_t* src = d_in;
+    for (int j = 0; j < log_arity; j++) {
+        const int lh = log_h - j;
+        uint32_t* dst = (j == log_arity - 1) ? d_out : ((j & 1) ? pong : ping);
+        ZK_HIP(launch_fri_fold(src, dst, ctx->dom_itw, (uint64_t)1 << (lh - 1), b, ctx->stream));
+        src = dst;
+        b = ext_mul(b, b);
+    }
+    return ZKHIP_OK;
+}
+
 size_t zkhip_proof_size(int log_n, uint32_t width, const zkhip_params* prm, size_t n_public) {
     (void)n_public;
     if (check_shape(log_n, width, prm) != ZKHIP_OK) return 0;

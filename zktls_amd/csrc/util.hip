@@ -109,6 +109,40 @@ hipError_t launch_gen_trace_logup(uint32_t* out, uint64_t ld, uint64_t seed, uin
     return hipGetLastError();
 }
 
+// ------------------------------------------------------------------ layout adapter (row a11)
+// out[c][r'] = in[r][c] with r' = r or bitrev(r): moves between RISC Zero's column-major
+// [count][size] polynomials and the row-major [size][count] matrices the NTT kernels stream.
+// 32 x 32 tiles through LDS (pitch 33): 128-byte segments on both sides.
+__global__ void __launch_bounds__(256) transpose_kernel(const uint32_t* __restrict__ in, uint32_t* __restrict__ out,
+                                                        uint64_t rows, uint64_t cols, int rev_bits_in, int rev_bits_out) {
+    __shared__ uint32_t tile[32][33];
+    const uint64_t r0 = (uint64_t)blockIdx.y * 32, c0 = (uint64_t)blockIdx.x * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;     // 32 x 8
+    for (int k = ty; k < 32; k += 8) {
+        const uint64_t r = r0 + k, c = c0 + tx;
+        if (r < rows && c < cols) {
+            const uint64_t cs = rev_bits_in ? (uint64_t)(__brev((uint32_t)c) >> (32 - rev_bits_in)) : c;
+            tile[k][tx] = in[r * cols + cs];
+        }
+    }
+    __syncthreads();
+    for (int k = ty; k < 32; k += 8) {
+        const uint64_t c = c0 + k, r = r0 + tx;                  // out[c][r]
+        if (r < rows && c < cols) {
+            const uint64_t cd = rev_bits_out ? (uint64_t)(__brev((uint32_t)c) >> (32 - rev_bits_out)) : c;
+            out[cd * rows + r] = tile[tx][k];
+        }
+    }
+}
+// in: [rows][cols] row-major; out: [cols][rows].  rev_bits_in / rev_bits_out (0 = off) bit-reverse the
+// COLUMN index of `in` on the read side / on the write side (it becomes the row index of `out`).
+hipError_t launch_transpose(const uint32_t* in, uint32_t* out, uint64_t rows, uint64_t cols, int rev_bits_in, int rev_bits_out, hipStream_t s) {
+    if (rows == 0 || cols == 0) return hipSuccess;
+    dim3 grid((unsigned)((cols + 31) / 32), (unsigned)((rows + 31) / 32));
+    hipLaunchKernelGGL(transpose_kernel, grid, dim3(256), 0, s, in, out, rows, cols, rev_bits_in, rev_bits_out);
+    return hipGetLastError();
+}
+
 __global__ void convert_kernel(const uint32_t* in, uint32_t* out, uint64_t n, bool to_m) {
     for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x)
         out[i] = to_m ? fmul(in[i], MONTY_R2) : from_monty(in[i]);

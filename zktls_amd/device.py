@@ -170,6 +170,21 @@ class Context:
         check(self.lib.zkhip_merkle_commit_mixed(self.handle, ptrs, lds, ws, lhs, len(mats), C.c_void_p(out.ptr)))
         return out
 
+    def merkle_commit_p24_colmajor(self, mat, cols, log_rows, out=None):
+        out = out or self.alloc(8 * ((2 << log_rows) - 1))
+        check(self.lib.zkhip_merkle_commit_p24_colmajor(self.handle, C.c_void_p(mat.ptr), cols, log_rows, C.c_void_p(out.ptr)))
+        return out
+
+    def batch_interpolate_colmajor(self, evals, count, log_size, out=None):
+        out = out or self.alloc(count << log_size)
+        check(self.lib.zkhip_batch_interpolate_colmajor(self.handle, C.c_void_p(evals.ptr), C.c_void_p(out.ptr), count, log_size))
+        return out
+
+    def batch_expand_colmajor(self, coeffs, count, log_size, log_blowup=2, shift=31, out=None):
+        out = out or self.alloc(count << (log_size + log_blowup))
+        check(self.lib.zkhip_batch_expand_colmajor(self.handle, C.c_void_p(coeffs.ptr), C.c_void_p(out.ptr), count, log_size, log_blowup, shift))
+        return out
+
     # ---- STARK stages
     def quotient_values(self, lde, log_n, width, alpha, out=None):
         out = out or self.alloc(4 << (log_n + 1))
@@ -189,6 +204,12 @@ class Context:
         out = out or self.alloc(4 << (log_h - 1))
         b = to_monty(np.asarray(beta, dtype=np.uint32))
         check(self.lib.zkhip_fri_fold(self.handle, C.c_void_p(src.ptr), log_h, b.ctypes.data_as(u32p), C.c_void_p(out.ptr)))
+        return out
+
+    def fri_fold_k(self, src, log_h, log_arity, beta, out=None):
+        out = out or self.alloc(4 << (log_h - log_arity))
+        b = to_monty(np.asarray(beta, dtype=np.uint32))
+        check(self.lib.zkhip_fri_fold_k(self.handle, C.c_void_p(src.ptr), log_h, log_arity, b.ctypes.data_as(u32p), C.c_void_p(out.ptr)))
         return out
 
     # ---- whole shard
