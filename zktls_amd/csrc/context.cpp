@@ -96,8 +96,9 @@ static NttPassArgs base_args(zkhip_ctx* ctx, const uint32_t* in, size_t in_ld, u
     // tuning knobs for A/B runs (never needed for correctness)
     static const int force_cpt = [] { const char* e = getenv("ZKHIP_NTT_CPT"); return e ? atoi(e) : 0; }();
     static const int map_mode = [] { const char* e = getenv("ZKHIP_NTT_MAP"); return e ? atoi(e) : 1; }();
-    static const int fast = [] { const char* e = getenv("ZKHIP_NTT_FAST"); return e ? atoi(e) : 1; }();
-    a.fast_path = fast == 1 ? 0u : (fast == 0 ? 2u : (uint32_t)fast);
+    static const int fast = [] { const char* e = getenv("ZKHIP_NTT_FAST"); return e ? atoi(e) : 4; }();
+    // ZKHIP_NTT_FAST: unset/4 = automatic, 0 = generic kernel only, 1 = persistent 2-column kernel always, 3 = persistent 1-column
+    a.fast_path = fast == 4 ? 0u : (fast == 0 ? 2u : (uint32_t)fast);
     static const int dbg = [] { const char* e = getenv("ZKHIP_NTT_DEBUG"); return e ? atoi(e) : 0; }();
     a.debug_flags = (uint32_t)dbg;
     a.cols_per_thread = (uint32_t)force_cpt;

@@ -64,6 +64,8 @@ ZK_D void dif_stage(uint32_t (&x)[32]) {
     }
 }
 
+typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+
 // CPT = columns per thread.  CPT = 2 doubles the row chunk a wave touches to 128 B (16 lanes
 // x 8 B), which the HBM likes much better than 64 B (tools/microbench: 5.1-5.5 vs 3.8-4.8
 // TB/s for the same tile shapes), and halves the twiddle-table LDS reads per element.  The
@@ -103,18 +105,22 @@ __global__ void __launch_bounds__(32 << LOG_C, 4) ntt_pass_kernel(NttPassArgs a)
     const bool active = col < a.ncols;      // CPT = 2 requires an even width: both or none
     const uint32_t lcol = active ? col : 0u;   // inactive lanes load a valid address, never store
 
-    // ---- global -> registers (32 independent loads in flight per lane)
+    // ---- global -> registers (32 independent loads in flight per lane).  Buffer addressing:
+    // wave-uniform descriptor + one 32-bit lane offset + a scalar offset per row group, so the
+    // 64 address VGPRs of flat addressing are free for data (launch_ntt_pass checks the 4 GiB span).
     uint32_t x[CPT][32];
     {
-        const uint32_t* ip = a.in + ((uint64_t)tile * a.in_tile_mul + (uint64_t)u * a.in_stride) * a.in_ld + lcol;
-        const uint64_t istep = (uint64_t)Pn * a.in_stride * a.in_ld;
+        const uint32_t* ib = a.in + (uint64_t)tile * a.in_tile_mul * a.in_ld;
+        const auto rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint32_t*>(ib), 0, 0xFFFFFFFFu, 0x00020000);
+        const uint32_t voff = 4u * ((uint32_t)((uint64_t)u * a.in_stride * a.in_ld) + lcol);
+        const uint32_t istep_b = (uint32_t)(4u * (uint64_t)Pn * a.in_stride * a.in_ld);
 #pragma unroll
         for (int n1 = 0; n1 < 32; n1++) {
             if (CPT == 2) {
-                const uint2 v = *reinterpret_cast<const uint2*>(ip + (uint64_t)n1 * istep);
+                const u32x2 v = __builtin_amdgcn_raw_buffer_load_b64(rs, voff, n1 * istep_b, 0);
                 x[0][n1] = v.x; x[CPT - 1][n1] = v.y;
             } else {
-                x[0][n1] = ip[(uint64_t)n1 * istep];
+                x[0][n1] = __builtin_amdgcn_raw_buffer_load_b32(rs, voff, n1 * istep_b, 0);
             }
         }
     }
@@ -201,8 +207,9 @@ __global__ void __launch_bounds__(32 << LOG_C, 4) ntt_pass_kernel(NttPassArgs a)
     }
     if (active) {
         const int m = (int)a.log_m;
-        uint32_t* op = a.out + (uint64_t)tile * a.out_tile_mul * a.out_ld + col;
-        const uint64_t ostep = a.out_stride * a.out_ld;
+        uint32_t* ob = a.out + (uint64_t)tile * a.out_tile_mul * a.out_ld;
+        const auto ors = __builtin_amdgcn_make_buffer_rsrc(ob, 0, 0xFFFFFFFFu, 0x00020000);
+        const uint32_t ostep_b = (uint32_t)(4u * a.out_stride * a.out_ld);
 #pragma unroll
         for (int rho = 0; rho < 32; rho++) {
             const uint32_t t = rho & (Pn - 1);
@@ -210,8 +217,9 @@ __global__ void __launch_bounds__(32 << LOG_C, 4) ntt_pass_kernel(NttPassArgs a)
             const uint32_t k0 = b ? (__brev(t) >> (32 - b)) : 0u;
             const uint32_t k = 32u * k0 + k1;
             const uint32_t o = a.bitrev_out ? (__brev(k) >> (32 - m)) : k;
-            if (CPT == 2) *reinterpret_cast<uint2*>(op + (uint64_t)o * ostep) = make_uint2(x[0][rho], x[CPT - 1][rho]);
-            else op[(uint64_t)o * ostep] = x[0][rho];
+            const uint32_t off = o * ostep_b + 4u * col;
+            if (CPT == 2) { u32x2 v; v.x = x[0][rho]; v.y = x[CPT - 1][rho]; __builtin_amdgcn_raw_buffer_store_b64(v, ors, off, 0, 0); }
+            else __builtin_amdgcn_raw_buffer_store_b32(x[0][rho], ors, off, 0, 0);
         }
     }
 }
@@ -352,7 +360,6 @@ __global__ void __launch_bounds__(1024) ntt_pass1024_kernel(NttPassArgs a, uint3
 // then holds this tile (64 values) AND the prefetched next tile (64 values) without spills,
 // loads/stores are 8 bytes per lane (a wave = 4 rows x 128 B) and the LDS exchange moves
 // both columns with one ds_write_b64 / ds_read_b64.
-typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
 template <bool INV>
 __global__ void __launch_bounds__(512) ntt_pass1024x2_kernel(NttPassArgs a, uint32_t total_items) {
     extern __shared__ uint32_t lds[];
@@ -529,9 +536,19 @@ static hipError_t launch_ntt_k(const NttPassArgs& a, hipStream_t s) {
 hipError_t launch_ntt_pass(const NttPassArgs& a_, bool inverse, hipStream_t s) {
     NttPassArgs a = a_;
     if (a.log_m < 5 || a.log_m > 10) return hipErrorInvalidValue;
+    {   // buffer addressing: every byte offset inside one tile must fit 32 bits
+        const uint64_t M = 1ull << a.log_m;
+        const uint64_t in_span = 4ull * ((M - 1) * a.in_stride * a.in_ld + a.ncols);
+        const uint64_t out_span = 4ull * ((M - 1) * a.out_stride * a.out_ld + a.ncols);
+        if (in_span >= (1ull << 32) || out_span >= (1ull << 32)) return hipErrorInvalidValue;
+    }
     if (a.map_mode == 1 && (a.num_tiles % 8u) != 0) a.map_mode = 0;
     // headline shape: 1024-row tiles of a matrix whose width is a multiple of 32
-    if (a.log_m == 10 && a.ncols >= 32 && a.ncols % 32 == 0 && a.fast_path != 2) {
+    // measured (2^20 x 256): the persistent 128-byte-chunk kernel wins when a side of the pass is strided
+    // (0.69 vs 0.72 ms), the two-workgroups-per-CU generic kernel when both sides are contiguous blocks
+    // (0.54 vs 0.56 ms); fast_path = 1 forces the persistent kernel for A/B runs
+    const bool strided = a.in_stride != 1 || a.out_stride != 1;
+    if (a.log_m == 10 && a.ncols >= 32 && a.ncols % 32 == 0 && a.fast_path != 2 && (strided || a.fast_path == 1 || a.fast_path == 3)) {
         if (a.map_mode == 1 && ((a.num_tiles % 8u) != 0 || (cu_count() % 8) != 0)) a.map_mode = 0;
         const bool al8 = a.in_ld % 2 == 0 && a.out_ld % 2 == 0 && (reinterpret_cast<uintptr_t>(a.in) & 7) == 0 &&
                          (reinterpret_cast<uintptr_t>(a.out) & 7) == 0;
