@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Minimal driver for profiler runs: launches the NTT pass kernel (both passes of the
+"""Minimal driver for profiler runs: launches the NTT pass kernels (both passes of the
 forward transform) a few times on a 2^20 x 256 matrix.  Used under rocprofv3 --pmc."""
 import os
 import sys

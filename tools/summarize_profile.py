@@ -37,7 +37,7 @@ def pmc(name, counter):
     vals = []
     if files:
         for r in csv.DictReader(open(files[0])):
-            if "ntt_pass_kernel<4" in r["Kernel_Name"] and r["Counter_Name"] == counter:
+            if "ntt_pass" in r["Kernel_Name"] and r["Counter_Name"] == counter:
                 vals.append(float(r["Counter_Value"]))
         shutil.copy(files[0], os.path.join(dst, "%s_%s_counter_collection.csv" % (tag, name)))
     return vals
@@ -46,7 +46,7 @@ fetch, write = pmc("pmc_fetch", "FETCH_SIZE"), pmc("pmc_write", "WRITE_SIZE")
 if fetch and write:
     f_avg = sum(fetch) / len(fetch) * 1024.0 * 2.0     # KiB -> B, gfx950 x2 correction
     w_avg = sum(write) / len(write) * 1024.0
-    out = {"kernel": "zk::ntt_pass_kernel<4,false>", "workload": "2^20 x 256, mean of strided and contiguous pass",
+    out = {"kernel": "zk::ntt_pass1024x2_kernel<false> + zk::ntt_pass_kernel<4,false,1>", "workload": "2^20 x 256, mean of strided and contiguous pass",
            "fetch_size_kib_raw_mean": sum(fetch) / len(fetch), "write_size_kib_mean": sum(write) / len(write),
            "fetch_correction": "x2 (gfx950 FETCH_SIZE half-count)", "hbm_bytes_per_launch": f_avg + w_avg,
            "algorithmic_bytes_per_launch": 8.0 * (1 << 28)}
