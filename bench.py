@@ -149,7 +149,10 @@ def main():
         with torch.cuda.stream(stream):
             scratch = torch.empty(cells, dtype=torch.int32, device="cuda")
         sbuf = ctx.wrap(scratch)
-        reps = 20
+        # many isolated launches: the kernel's average in a rocprofv3 trace of this command is then
+        # dominated by launches that had the GPU to themselves (the in-proof launches overlap
+        # with kernels of the other shards in flight and are stretched by that)
+        reps = 1000
         per_which = []
         for which in (0, 1):
             for _ in range(3):

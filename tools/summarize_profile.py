@@ -16,12 +16,14 @@ tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
 dst = os.path.join(ROOT, "profiles")
 os.makedirs(dst, exist_ok=True)
 
-stats = glob.glob(os.path.join(src, "kt", "*", "*_kernel_stats.csv"))
+kt = sys.argv[2] if len(sys.argv) > 2 else "kt"
+stats = glob.glob(os.path.join(src, kt, "*", "*_kernel_stats.csv"))
 if stats:
     shutil.copy(stats[0], os.path.join(dst, tag + "_kernel_stats.csv"))
+    cmdline = open(os.path.join(src, kt + "_cmd.txt")).read().strip() if os.path.exists(os.path.join(src, kt + "_cmd.txt")) else "python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline"
     rows = list(csv.DictReader(open(stats[0])))
     with open(os.path.join(dst, tag + "_kernel_stats.md"), "w") as f:
-        f.write("# rocprofv3 --kernel-trace --stats -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline (%s)\n\n" % tag)
+        f.write("# rocprofv3 --kernel-trace --stats -- %s (%s)\n\n" % (cmdline, tag))
         f.write("| kernel | calls | total ms | avg us | % |\n|---|---|---|---|---|\n")
         for r in rows:
             f.write("| %s | %s | %.3f | %.2f | %s |\n" % (r["Name"].split("(")[0], r["Calls"], float(r["TotalDurationNs"]) / 1e6,
