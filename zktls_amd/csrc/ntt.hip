@@ -71,12 +71,14 @@ typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
 // TB/s for the same tile shapes), and halves the twiddle-table LDS reads per element.  The
 // LDS exchange then runs once per column, reusing one 64 KiB buffer, so two workgroups
 // still fit a CU.
-template <int LOG_C, bool INV, int CPT>
+// BFIX >= 0 fixes the tile height at compile time (M = 32 << BFIX): every LDS / store offset of the
+// exchange and of phase B then folds into an instruction immediate instead of a VGPR.
+template <int LOG_C, bool INV, int CPT, int BFIX = -1>
 __global__ void __launch_bounds__(32 << LOG_C, 4) ntt_pass_kernel(NttPassArgs a) {
     extern __shared__ uint32_t lds[];
     constexpr int C = 1 << LOG_C;          // lanes along the row chunk
     constexpr int TC = C * CPT;            // tile columns
-    const int b = (int)a.log_m - 5;
+    const int b = BFIX >= 0 ? BFIX : (int)a.log_m - 5;
     const int Pn = 1 << b;
     const int M = 32 << b;
     const int pitch = (Pn + 1) * C;
@@ -111,7 +113,8 @@ __global__ void __launch_bounds__(32 << LOG_C, 4) ntt_pass_kernel(NttPassArgs a)
     uint32_t x[CPT][32];
     {
         const uint32_t* ib = a.in + (uint64_t)tile * a.in_tile_mul * a.in_ld;
-        const auto rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint32_t*>(ib), 0, 0xFFFFFFFFu, 0x00020000);
+        // timing-only knob (tools/ab_ntt.sh): a zero-record descriptor drops the loads / stores
+        const auto rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint32_t*>(ib), 0, (a.debug_flags & 1u) ? 0u : 0xFFFFFFFFu, 0x00020000);
         const uint32_t voff = 4u * ((uint32_t)((uint64_t)u * a.in_stride * a.in_ld) + lcol);
         const uint32_t istep_b = (uint32_t)(4u * (uint64_t)Pn * a.in_stride * a.in_ld);
 #pragma unroll
@@ -144,7 +147,9 @@ __global__ void __launch_bounds__(32 << LOG_C, 4) ntt_pass_kernel(NttPassArgs a)
         }
     }
 
-    // ---- phase A: 32-point DIF over n1; x[r] <- A[rev5(r)]
+    // ---- phase A: 32-point DIF over n1; x[r] <- A[rev5(r)], then the tile twiddle w_M^(u*k1).
+    // One column at a time (scheduling barrier in between): interleaving the two columns of
+    // CPT = 2 for ILP is what pushed the register allocation over 128 and into scratch.
 #pragma unroll
     for (int cc = 0; cc < CPT; cc++) {
         dif_stage<INV, 0>(x[cc]);
@@ -152,16 +157,11 @@ __global__ void __launch_bounds__(32 << LOG_C, 4) ntt_pass_kernel(NttPassArgs a)
         dif_stage<INV, 2>(x[cc]);
         dif_stage<INV, 3>(x[cc]);
         dif_stage<INV, 4, true>(x[cc]);    // lazy: every output is multiplied (or reduced) next
+#pragma unroll
+        for (int r = 1; r < 32; r++) x[cc][r] = dmul(x[cc][r], stw[u * rev5(r)]);
+        x[cc][0] = dred(x[cc][0]);
+        if (CPT > 1) __builtin_amdgcn_sched_barrier(0);
     }
-    // ---- tile twiddle w_M^(u*k1)
-#pragma unroll
-    for (int r = 1; r < 32; r++) {
-        const uint32_t w = stw[u * rev5(r)];
-#pragma unroll
-        for (int cc = 0; cc < CPT; cc++) x[cc][r] = dmul(x[cc][r], w);
-    }
-#pragma unroll
-    for (int cc = 0; cc < CPT; cc++) x[cc][0] = dred(x[cc][0]);
 
     // ---- exchange through LDS, one column per round
 #pragma unroll
@@ -191,8 +191,35 @@ __global__ void __launch_bounds__(32 << LOG_C, 4) ntt_pass_kernel(NttPassArgs a)
             if (has_post) dif_stage<INV, 4, true>(x[cc]);   // outputs go straight into the post multiplication
             else dif_stage<INV, 4>(x[cc]);
         }
+        if (CPT > 1) __builtin_amdgcn_sched_barrier(0);
     }
 
+    // ---- post multiply and store
+    if (BFIX == 5) {
+        // M = 1024: element k = 32 rev5(rho) + u goes to tile row o(k) = k, or bitrev10(k) = 32 rev5(u) + rho;
+        // either way o * ostep splits into a per-lane 32-bit offset and a wave-uniform (scalar) part
+        if (has_post) {
+#pragma unroll
+            for (int rho = 0; rho < 32; rho++) {
+                const uint32_t w = spost[32 * rev5(rho) + u];
+#pragma unroll
+                for (int cc = 0; cc < CPT; cc++) x[cc][rho] = dmul(x[cc][rho], w);
+            }
+        }
+        if (active) {
+            uint32_t* ob = a.out + (uint64_t)tile * a.out_tile_mul * a.out_ld;
+            const auto ors = __builtin_amdgcn_make_buffer_rsrc(ob, 0, (a.debug_flags & 2u) ? 0u : 0xFFFFFFFFu, 0x00020000);
+            const uint32_t ostep_b = (uint32_t)(4u * a.out_stride * a.out_ld);
+            const uint32_t out_off = (a.bitrev_out ? 32u * (__brev((uint32_t)u) >> 27) : (uint32_t)u) * ostep_b + 4u * col;
+#pragma unroll
+            for (int rho = 0; rho < 32; rho++) {
+                const uint32_t ro = a.bitrev_out ? (uint32_t)rho : (uint32_t)(32 * rev5(rho));
+                if (CPT == 2) { u32x2 v; v.x = x[0][rho]; v.y = x[CPT - 1][rho]; __builtin_amdgcn_raw_buffer_store_b64(v, ors, out_off, ro * ostep_b, 0); }
+                else __builtin_amdgcn_raw_buffer_store_b32(x[0][rho], ors, out_off, ro * ostep_b, 0);
+            }
+        }
+        return;
+    }
     // ---- post multiply and store
     if (has_post) {
 #pragma unroll
@@ -208,7 +235,7 @@ __global__ void __launch_bounds__(32 << LOG_C, 4) ntt_pass_kernel(NttPassArgs a)
     if (active) {
         const int m = (int)a.log_m;
         uint32_t* ob = a.out + (uint64_t)tile * a.out_tile_mul * a.out_ld;
-        const auto ors = __builtin_amdgcn_make_buffer_rsrc(ob, 0, 0xFFFFFFFFu, 0x00020000);
+        const auto ors = __builtin_amdgcn_make_buffer_rsrc(ob, 0, (a.debug_flags & 2u) ? 0u : 0xFFFFFFFFu, 0x00020000);
         const uint32_t ostep_b = (uint32_t)(4u * a.out_stride * a.out_ld);
 #pragma unroll
         for (int rho = 0; rho < 32; rho++) {
@@ -223,6 +250,7 @@ __global__ void __launch_bounds__(32 << LOG_C, 4) ntt_pass_kernel(NttPassArgs a)
         }
     }
 }
+
 
 // ------------------------------------------------------------------ persistent fast path
 // M = 1024 rows x 32 columns per tile, one 1024-thread workgroup per CU that walks its tiles:
@@ -515,7 +543,7 @@ static size_t ntt_lds_bytes(int log_m, int log_c) {
     return (size_t)(32 * (Pn + 1) * C + 3 * M) * sizeof(uint32_t);
 }
 
-template <int LOG_C, bool INV, int CPT>
+template <int LOG_C, bool INV, int CPT, int BFIX = -1>
 static hipError_t launch_ntt_k(const NttPassArgs& a, hipStream_t s) {
     const int TC = (1 << LOG_C) * CPT;
     const uint32_t ncg = (a.ncols + TC - 1) / TC;
@@ -524,12 +552,12 @@ static hipError_t launch_ntt_k(const NttPassArgs& a, hipStream_t s) {
     const size_t lds = ntt_lds_bytes((int)a.log_m, LOG_C);
     static size_t configured = 0;      // raise the dynamic-LDS cap once per instantiation
     if (lds > configured) {
-        hipError_t e = hipFuncSetAttribute((const void*)ntt_pass_kernel<LOG_C, INV, CPT>,
+        hipError_t e = hipFuncSetAttribute((const void*)ntt_pass_kernel<LOG_C, INV, CPT, BFIX>,
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
         configured = lds;
     }
-    hipLaunchKernelGGL((ntt_pass_kernel<LOG_C, INV, CPT>), grid, block, lds, s, a);
+    hipLaunchKernelGGL((ntt_pass_kernel<LOG_C, INV, CPT, BFIX>), grid, block, lds, s, a);
     return hipGetLastError();
 }
 
@@ -543,26 +571,28 @@ hipError_t launch_ntt_pass(const NttPassArgs& a_, bool inverse, hipStream_t s) {
         if (in_span >= (1ull << 32) || out_span >= (1ull << 32)) return hipErrorInvalidValue;
     }
     if (a.map_mode == 1 && (a.num_tiles % 8u) != 0) a.map_mode = 0;
-    // headline shape: 1024-row tiles of a matrix whose width is a multiple of 32
-    // measured (2^20 x 256): the persistent 128-byte-chunk kernel wins when a side of the pass is strided
-    // (0.69 vs 0.72 ms), the two-workgroups-per-CU generic kernel when both sides are contiguous blocks
-    // (0.54 vs 0.56 ms); fast_path = 1 forces the persistent kernel for A/B runs
-    const bool strided = a.in_stride != 1 || a.out_stride != 1;
-    if (a.log_m == 10 && a.ncols >= 32 && a.ncols % 32 == 0 && a.fast_path != 2 && (strided || a.fast_path == 1 || a.fast_path == 3)) {
+    // A/B only (fast_path 1 / 3): the persistent 1024 x 32 kernels.  Measured on 2^20 x 256 they lose to the
+    // two-workgroups-per-CU kernel below once that one has compile-time tile offsets (0.62 / 0.55 ms
+    // against 0.53 / 0.46 ms for the strided / contiguous pass).
+    if (a.log_m == 10 && a.ncols >= 32 && a.ncols % 32 == 0 && (a.fast_path == 1 || a.fast_path == 3)) {
         if (a.map_mode == 1 && ((a.num_tiles % 8u) != 0 || (cu_count() % 8) != 0)) a.map_mode = 0;
         const bool al8 = a.in_ld % 2 == 0 && a.out_ld % 2 == 0 && (reinterpret_cast<uintptr_t>(a.in) & 7) == 0 &&
                          (reinterpret_cast<uintptr_t>(a.out) & 7) == 0;
         if (a.fast_path == 3 || !al8) return inverse ? launch_ntt1024<true>(a, s) : launch_ntt1024<false>(a, s);
         return inverse ? launch_ntt1024x2<true>(a, s) : launch_ntt1024x2<false>(a, s);
     }
-    // two columns per lane need 8-byte aligned row chunks
+    // two columns per lane (128-byte row chunks per 16 lanes) need 8-byte aligned row chunks.  Default for
+    // 1024-row tiles, where the compile-time tile height keeps it at 116 VGPRs (two workgroups per CU);
+    // with a run-time tile height it spills, so there it stays opt-in (cols_per_thread = 2).
     const bool pair_ok = a.ncols >= 32 && a.ncols % 2 == 0 && a.in_ld % 2 == 0 && a.out_ld % 2 == 0 &&
-                         (reinterpret_cast<uintptr_t>(a.in) & 7) == 0 && (reinterpret_cast<uintptr_t>(a.out) & 7) == 0 &&
-                         a.cols_per_thread == 2;   // opt-in: measured slower than 1 (register spills), kept for A/B
-    if (pair_ok) return inverse ? launch_ntt_k<4, true, 2>(a, s) : launch_ntt_k<4, false, 2>(a, s);
+                         (reinterpret_cast<uintptr_t>(a.in) & 7) == 0 && (reinterpret_cast<uintptr_t>(a.out) & 7) == 0;
+    if (pair_ok && a.log_m == 10 && a.cols_per_thread != 1)
+        return inverse ? launch_ntt_k<4, true, 2, 5>(a, s) : launch_ntt_k<4, false, 2, 5>(a, s);
+    if (pair_ok && a.cols_per_thread == 2) return inverse ? launch_ntt_k<4, true, 2>(a, s) : launch_ntt_k<4, false, 2>(a, s);
     // narrow matrices use narrower tiles so that lanes are not wasted on masked columns
     if (a.ncols <= 4) return inverse ? launch_ntt_k<2, true, 1>(a, s) : launch_ntt_k<2, false, 1>(a, s);
     if (a.ncols <= 8) return inverse ? launch_ntt_k<3, true, 1>(a, s) : launch_ntt_k<3, false, 1>(a, s);
+    if (a.log_m == 10) return inverse ? launch_ntt_k<4, true, 1, 5>(a, s) : launch_ntt_k<4, false, 1, 5>(a, s);
     return inverse ? launch_ntt_k<4, true, 1>(a, s) : launch_ntt_k<4, false, 1>(a, s);
 }
 
