@@ -110,6 +110,14 @@ ZK_D uint32_t dmr2(uint32_t a0, uint32_t b0, uint32_t a1, uint32_t b1) {
     return dred((uint32_t)(y >> 32));                         // y / 2^32 < 2 P
 }
 ZK_D uint32_t ddbl(uint32_t a) { return dred(a + a); }
+// Montgomery reduction of an accumulated 64-bit value x < 2^32 P, result in [0, 2P)
+ZK_D uint32_t dmred_lazy(uint64_t x) {
+    uint32_t m = (uint32_t)x * MONTY_MU_NEG;
+    uint64_t y = x + (uint64_t)m * P;
+    return (uint32_t)(y >> 32);
+}
+// a * b + c as one v_mad_u64_u32 (the 64-bit addend rides along for free)
+ZK_D uint64_t dmac(uint32_t a, uint32_t b, uint64_t c) { return (uint64_t)a * b + c; }
 #endif
 
 // ---- quartic extension, coefficients in Montgomery form ----
