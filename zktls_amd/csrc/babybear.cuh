@@ -118,6 +118,15 @@ ZK_D uint32_t dmred_lazy(uint64_t x) {
 }
 // a * b + c as one v_mad_u64_u32 (the 64-bit addend rides along for free)
 ZK_D uint64_t dmac(uint32_t a, uint32_t b, uint64_t c) { return (uint64_t)a * b + c; }
+// Running dot product in a 64-bit accumulator.  Invariant between calls: acc < 2^32 P.  Two products of
+// canonical factors add < 2 P^2, so acc < 2^32 P + 2 P^2 < 2^64 and its high word is < 2P: one conditional
+// subtraction of P from the HIGH word (= subtracting 2^32 P, a multiple of P) restores the invariant.
+// 2 x v_mad_u64_u32 + v_subrev_co + v_cndmask per pair of products; no Montgomery reduction until the end.
+ZK_D void dacc2(uint64_t& acc, uint32_t a0, uint32_t b0, uint32_t a1, uint32_t b1) {
+    const uint64_t t = dmac(a1, b1, dmac(a0, b0, acc));
+    acc = ((uint64_t)dred((uint32_t)(t >> 32)) << 32) | (uint32_t)t;
+}
+ZK_D uint32_t dacc_finish(uint64_t acc) { return dred(dmred_lazy(acc)); }    // canonical acc / 2^32 mod P
 #endif
 
 // ---- quartic extension, coefficients in Montgomery form ----

@@ -96,12 +96,13 @@ struct QuotientArgs {
     uint64_t ld;
     uint32_t width;
     int log_n;
-    int lanes_per_row;          // power of two <= 64
+    int lanes_per_row;          // power of two <= 16 (one DPP row)
     const uint32_t* xs;
     const uint32_t* sel_first;
     uint32_t wn_inv;            // w_N^-1
     uint32_t inv_zh_even, inv_zh_odd;
-    const uint32_t* alpha_pow;  // [3 G + Q + 3] ext: weight of constraint k is alpha^(K-1-k), K = 3 G + (Q ? Q + 3 : 0)
+    const uint32_t* alpha_pow;  // [G][16] words: three ext weights + (g+1, 2g+3, 5g+7, 0) in Montgomery form; then [Q + 3] ext.
+                                // weight of constraint k is alpha^(K-1-k), K = 3 G + (Q ? Q + 3 : 0)
     // LogUp part (pairs = Q > 0): permutation-trace LDE [2N][perm_ld], lookup challenges, last-row selector
     uint32_t pairs;
     const uint32_t* perm;
@@ -112,22 +113,21 @@ struct QuotientArgs {
 };
 hipError_t launch_quotient(const QuotientArgs& a, hipStream_t s);
 
-// out[k][p] = 1 / (x_p - z_k), k < npoints (<= 2), p < count
+// out[k][p] = 1 / (x_p - z_k), k < npoints (<= 2), p < count; xw (optional): xw[k][p] = x_p / (x_p - z_k), p < xw_count
 hipError_t launch_inv_denominators(const uint32_t* xs, uint64_t count, const Ext& z0, const Ext& z1, int npoints,
-                                   uint32_t* out, hipStream_t s);
+                                   uint32_t* out, uint32_t* xw, uint64_t xw_count, hipStream_t s);
 
 struct OpenArgs {
     const uint32_t* mat;        // first `rows` rows of a bit-reversed LDE
     uint64_t ld;
     uint32_t width;
     uint64_t rows;              // N
-    const uint32_t* xs;
-    const uint32_t* dinv;       // [npts][dinv_stride] ext
-    uint64_t dinv_stride;
+    const uint32_t* xw;         // [npts][xw_stride] ext: x_q / (x_q - z_k)
+    uint64_t xw_stride;
     uint32_t* partial;          // [ceil(rows/2048)][npts][width] ext
     int tx;                     // columns per workgroup (power of two <= 64)
 };
-// out[k][col] = -scale_k * sum_q mat[q][col] x_q dinv_k[q]
+// out[k][col] = -scale_k * sum_q mat[q][col] xw_k[q]
 hipError_t launch_open(const OpenArgs& a, int npts, const Ext& scale0, const Ext& scale1, uint32_t* out, hipStream_t s);
 
 struct ReducedArgs {

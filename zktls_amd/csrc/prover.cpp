@@ -104,12 +104,23 @@ static int run_quotient(zkhip_ctx* ctx, const uint32_t* lde, size_t ld, int log_
     std::vector<Ext> ap(K);
     Ext w = ext_one();
     for (size_t k = K; k-- > 0;) { ap[k] = w; w = ext_mul(w, alpha); }
+    // device table: per column group 16 words = three weights + the group's constants (g+1, 2g+3, 5g+7)
+    // in Montgomery form; then the Q + 3 LogUp weights
+    std::vector<uint32_t> tab(16 * (size_t)G + 4 * (K - 3 * (size_t)G));
+    for (uint32_t g = 0; g < G; g++) {
+        for (int t = 0; t < 3; t++) memcpy(&tab[16 * (size_t)g + 4 * t], ap[3 * (size_t)g + t].c, 16);
+        tab[16 * (size_t)g + 12] = to_monty(g + 1);
+        tab[16 * (size_t)g + 13] = to_monty(2 * g + 3);
+        tab[16 * (size_t)g + 14] = to_monty(5 * g + 7);
+        tab[16 * (size_t)g + 15] = 0;
+    }
+    for (size_t k = 3 * (size_t)G; k < K; k++) memcpy(&tab[16 * (size_t)G + 4 * (k - 3 * (size_t)G)], ap[k].c, 16);
     void* d_ap;
-    ZK_TRY(ctx_reserve(ctx, S_APOW_Q, ap.size() * 16, &d_ap));
-    ZK_TRY(h2d(ctx, d_ap, ap.data(), ap.size() * 16));
+    ZK_TRY(ctx_reserve(ctx, S_APOW_Q, tab.size() * 4, &d_ap));
+    ZK_TRY(h2d(ctx, d_ap, tab.data(), tab.size() * 4));
     QuotientArgs q{};
     q.lde = lde; q.ld = ld; q.width = width; q.log_n = log_n;
-    q.lanes_per_row = pow2ceil((int)G) > 64 ? 64 : pow2ceil((int)G);
+    q.lanes_per_row = pow2ceil((int)G) > 16 ? 16 : pow2ceil((int)G);
     q.xs = ctx->dom_xs; q.sel_first = ctx->dom_sel_first;
     q.wn_inv = finv(two_adic_generator(log_n));
     const uint32_t gn = fpow(MONTY_GEN, (uint64_t)1 << log_n);
@@ -123,12 +134,12 @@ static int run_quotient(zkhip_ctx* ctx, const uint32_t* lde, size_t ld, int log_
     return ZKHIP_OK;
 }
 
-// opens `width` columns at npts points; dinv must hold 1/(x_p - z_k) with stride `dinv_stride`
+// opens `width` columns at npts points; xw must hold x_q/(x_q - z_k) for the first N rows, stride N
 static int run_open(zkhip_ctx* ctx, const uint32_t* lde, size_t ld, int log_n, uint32_t width, const Ext* z, int npts,
-                    const uint32_t* dinv, uint64_t dinv_stride, uint32_t* d_out) {
+                    const uint32_t* xw, uint32_t* d_out) {
     const uint64_t n = (uint64_t)1 << log_n;
     OpenArgs o{};
-    o.mat = lde; o.ld = ld; o.width = width; o.rows = n; o.xs = ctx->dom_xs; o.dinv = dinv; o.dinv_stride = dinv_stride;
+    o.mat = lde; o.ld = ld; o.width = width; o.rows = n; o.xw = xw; o.xw_stride = n;
     o.tx = pow2ceil((int)width) > 64 ? 64 : pow2ceil((int)width);
     const size_t nchunks = (size_t)((n + 2047) / 2048);
     void* part;
@@ -155,7 +166,7 @@ static size_t proof_words(int log_n, uint32_t width, const zkhip_params* prm) {
 static int check_shape(int log_n, uint32_t width, const zkhip_params* prm) {
     if (!prm) return fail(ZKHIP_ERR_INVALID, "null params");
     if (log_n < 5 || log_n > 20) return fail(ZKHIP_ERR_INVALID, "log_n must be in [5, 20]");
-    if (width == 0 || width % 4 != 0) return fail(ZKHIP_ERR_INVALID, "width must be a positive multiple of 4");
+    if (width == 0 || width % 4 != 0 || width > 1024) return fail(ZKHIP_ERR_INVALID, "width must be a positive multiple of 4, at most 1024");
     if (prm->log_blowup != 1) return fail(ZKHIP_ERR_INVALID, "only log_blowup = 1 is supported by the synthetic AIR path");
     if (prm->num_queries < 1 || prm->num_queries > 4096) return fail(ZKHIP_ERR_INVALID, "num_queries out of range");
     if (prm->pow_bits < 0 || prm->pow_bits > 28) return fail(ZKHIP_ERR_INVALID, "pow_bits out of range");
@@ -233,15 +244,16 @@ int zkhip_open_at(zkhip_ctx* ctx, const uint32_t* d_lde, size_t ld, int log_n, i
     if (!d_lde || !z || !h_out || width == 0 || ld < width || npoints < 1 || npoints > 2)
         return fail(ZKHIP_ERR_INVALID, "open_at: bad arguments (1 or 2 points)");
     ZK_TRY(ensure_domain(ctx, log_n));
-    const uint64_t m = (uint64_t)2 << log_n;
+    const uint64_t m = (uint64_t)2 << log_n, n = (uint64_t)1 << log_n;
     Ext zz[2];
     for (int k = 0; k < npoints; k++) zz[k] = Ext{{z[4 * k], z[4 * k + 1], z[4 * k + 2], z[4 * k + 3]}};
     if (npoints == 1) zz[1] = zz[0];
     void *dinv, *dout;
-    ZK_TRY(ctx_reserve(ctx, S_DINV, 2 * m * 16, &dinv));
+    ZK_TRY(ctx_reserve(ctx, S_DINV, 2 * (m + n) * 16, &dinv));
     ZK_TRY(ctx_reserve(ctx, S_OPEN_OUT, (size_t)npoints * width * 16, &dout));
-    ZK_HIP(launch_inv_denominators(ctx->dom_xs, m, zz[0], zz[1], npoints, (uint32_t*)dinv, ctx->stream));
-    ZK_TRY(run_open(ctx, d_lde, ld, log_n, width, zz, npoints, (const uint32_t*)dinv, m, (uint32_t*)dout));
+    uint32_t* xw = (uint32_t*)dinv + 8 * m;
+    ZK_HIP(launch_inv_denominators(ctx->dom_xs, m, zz[0], zz[1], npoints, (uint32_t*)dinv, xw, n, ctx->stream));
+    ZK_TRY(run_open(ctx, d_lde, ld, log_n, width, zz, npoints, xw, (uint32_t*)dout));
     return d2h(ctx, h_out, dout, (size_t)npoints * width * 16);
 }
 
@@ -368,17 +380,18 @@ int zkhip_prove_shard(zkhip_ctx* ctx, const uint32_t* d_trace, size_t ld, int lo
     const Ext zeta = ch.sample_ext();
     const Ext zpts[2] = {zeta, ext_mul_base(zeta, two_adic_generator(log_n))};
     void *v_dinv, *v_open;
-    ZK_TRY(ctx_reserve(ctx, S_DINV, 2 * m * 16, &v_dinv));
+    ZK_TRY(ctx_reserve(ctx, S_DINV, 2 * (m + n) * 16, &v_dinv));
     ZK_TRY(ctx_reserve(ctx, S_OPEN_OUT, (2 * (size_t)width + 2 * wp + 8) * 16, &v_open));
     uint32_t* dinv = (uint32_t*)v_dinv; uint32_t* d_open = (uint32_t*)v_open;
-    ZK_HIP(launch_inv_denominators(ctx->dom_xs, m, zpts[0], zpts[1], 2, dinv, st));
-    ZK_TRY(run_open(ctx, tlde, width, log_n, width, zpts, 2, dinv, m, d_open));
+    uint32_t* xw = dinv + 8 * m;       // x_q / (x_q - z_k) for the N rows the openings sum over
+    ZK_HIP(launch_inv_denominators(ctx->dom_xs, m, zpts[0], zpts[1], 2, dinv, xw, n, st));
+    ZK_TRY(run_open(ctx, tlde, width, log_n, width, zpts, 2, xw, d_open));
     ZK_HIP(hipStreamSynchronize(st));   // S_PARTIAL is reused by the next call
     if (LQ) {
-        ZK_TRY(run_open(ctx, plde, wp, log_n, (uint32_t)wp, zpts, 2, dinv, m, d_open + 8 * (size_t)width));
+        ZK_TRY(run_open(ctx, plde, wp, log_n, (uint32_t)wp, zpts, 2, xw, d_open + 8 * (size_t)width));
         ZK_HIP(hipStreamSynchronize(st));
     }
-    ZK_TRY(run_open(ctx, qlde, 8, log_n, 8, zpts, 1, dinv, m, d_open + 8 * (size_t)width + 8 * wp));
+    ZK_TRY(run_open(ctx, qlde, 8, log_n, 8, zpts, 1, xw, d_open + 8 * (size_t)width + 8 * wp));
     std::vector<uint32_t> opened((2 * (size_t)width + 2 * wp + 8) * 4);
     ZK_TRY(d2h(ctx, opened.data(), d_open, opened.size() * 4));
     for (size_t i = 0; i < opened.size(); i++) { ch.observe(opened[i]); pf[pos++] = from_monty(opened[i]); }

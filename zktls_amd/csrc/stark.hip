@@ -62,99 +62,166 @@ hipError_t launch_domain_tables(uint32_t* xs, uint32_t* sel_first, uint32_t* sel
 }
 
 // ------------------------------------------------------------------ quotient
-// acc = sum_k alpha^(K-1-k) C_k(x_p), k = 3 g + type, then * 1/Z_H(x_p).  The host passes
-// the three weights of each column group (alpha_pow[g][t] = alpha^(K-1-3g-t)) so that a group
-// costs 3 base*extension products, two of them reduced together.
-// Output in NATURAL chunk order: chunk (e & 1), row (e >> 1), e = bitrev(p).
+// acc = sum_k alpha^(K-1-k) C_k(x_p), k = 3 g + type, then * 1/Z_H(x_p).  The host passes, per column
+// group, the three extension weights alpha^(K-1-3g-t) and the three constants of the group's constraints
+// in Montgomery form (16 words per group).  Output in NATURAL chunk order: chunk (e & 1), row (e >> 1),
+// e = bitrev(p).
+//
+// The transition constraint of row e reads d of row e + 2 (the next row of the trace on the blown-up
+// domain), which sits at an unrelated bit-reversed position: giving every row its own lanes would read the
+// 2 GiB LDE twice.  So a group of L <= 16 lanes walks a CHAIN e, e+2, ..., e+2(K-1) and keeps the row it
+// loaded as "next" for the following step: (K+1)/K row reads per row.  Each lane owns up to four column
+// groups, folds its constraints into four 64-bit running sums (dacc2 / dacc1), and the lanes are summed
+// with DPP row operations.
+ZK_D void dacc1(uint64_t& acc, uint32_t a0, uint32_t b0) {
+    const uint64_t t = dmac(a0, b0, acc);
+    acc = ((uint64_t)dred((uint32_t)(t >> 32)) << 32) | (uint32_t)t;
+}
+template <int CTRL>
+ZK_D uint32_t dpp_mov(uint32_t v) { return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, 0xF, 0xF, false); }
+// sum over the aligned group of L lanes (L = 1, 2, 4, 8, 16); every lane of the group ends with the total
+ZK_D uint32_t row_group_sum(uint32_t v, int L) {
+    if (L > 1) v = dadd(v, dpp_mov<0xB1>(v));        // quad_perm [1,0,3,2]
+    if (L > 2) v = dadd(v, dpp_mov<0x4E>(v));        // quad_perm [2,3,0,1]
+    if (L > 4) v = dadd(v, dpp_mov<0x141>(v));       // row_half_mirror: quads 0<->1, 2<->3 (quads are uniform by now)
+    if (L > 8) v = dadd(v, dpp_mov<0x140>(v));       // row_mirror: halves 0<->1
+    return v;
+}
+constexpr int QCHAIN = 16;
+template <int NG>
 __global__ void __launch_bounds__(256) quotient_kernel(QuotientArgs a) {
     const int L = a.lanes_per_row;
     const uint32_t gid = blockIdx.x * blockDim.x + threadIdx.x;
-    const uint32_t p = gid / L;
     const int lane = gid % L;
     const int H = a.log_n + 1;
     const uint32_t m = 1u << H;
-    if (p >= m) return;     // m*L is a multiple of the block size: whole groups exit together
-    const uint32_t e = __brev(p) >> (32 - H);
-    const uint32_t pn = __brev((e + 2) & (m - 1)) >> (32 - H);
-    const uint32_t* row = a.lde + (uint64_t)p * a.ld;
-    const uint32_t* nrow = a.lde + (uint64_t)pn * a.ld;
-    const uint32_t x = a.xs[p];
-    const uint32_t sel_first = a.sel_first[p];
-    const uint32_t sel_trans = dsub(x, a.wn_inv);
+    const uint32_t nchains = m / QCHAIN;
+    const bool live = gid / L < nchains;              // dead lanes compute chain 0 and store nothing (DPP needs them)
+    const uint32_t chain = live ? gid / L : 0u;
+    const uint32_t parity = chain & 1u;
+    uint32_t e = 2u * ((chain >> 1) * QCHAIN) + parity;
     const uint32_t G = a.width / 4;
-    Ext acc = ext_zero();
-    for (uint32_t g = lane; g < G; g += L) {
-        const uint4 v = *reinterpret_cast<const uint4*>(row + 4 * g);
-        const uint32_t dn = nrow[4 * g + 3];
-        const uint32_t k1 = dmul(g + 1, MONTY_R2), k2 = dmul(2 * g + 3, MONTY_R2), d0 = dmul(5 * g + 7, MONTY_R2);
-        // c1 = c - a a b - k1 ; c2 = sel_trans (d' - a b - c - k2) ; c3 = sel_first (d - d0)
-        const uint32_t aab = dmul(dmont_lazy(v.x, v.x), v.y);
-        const uint32_t c1 = dsub(dsub(v.z, aab), k1);
-        const uint32_t ab = dmul(v.x, v.y);
-        const uint32_t c2 = dmul(dsub_lazy(dsub(dsub(dn, ab), v.z), k2), sel_trans);
-        const uint32_t c3 = dmul(dsub_lazy(v.w, d0), sel_first);
-        const uint4* wp = reinterpret_cast<const uint4*>(a.alpha_pow + 12 * g);
-        const uint4 w0 = wp[0], w1 = wp[1], w2 = wp[2];
-        acc.c[0] = dadd(acc.c[0], dadd(dmr2(w0.x, c1, w1.x, c2), dmul(w2.x, c3)));
-        acc.c[1] = dadd(acc.c[1], dadd(dmr2(w0.y, c1, w1.y, c2), dmul(w2.y, c3)));
-        acc.c[2] = dadd(acc.c[2], dadd(dmr2(w0.z, c1, w1.z, c2), dmul(w2.z, c3)));
-        acc.c[3] = dadd(acc.c[3], dadd(dmr2(w0.w, c1, w1.w, c2), dmul(w2.w, c3)));
+    const uint32_t inv_zh = parity ? a.inv_zh_odd : a.inv_zh_even;
+
+    uint4 cur[NG], nxt[NG];
+    uint32_t p = __brev(e) >> (32 - H);
+#pragma unroll
+    for (int t = 0; t < NG; t++) {
+        const uint32_t g = lane + L * t;
+        cur[t] = g < G ? *reinterpret_cast<const uint4*>(a.lde + (uint64_t)p * a.ld + 4 * g) : make_uint4(0, 0, 0, 0);
     }
-    if (a.pairs) {
-        // LogUp constraints (weights continue after the 3 G main ones): L_q, then T1, T2, T3.
-        // The sums over q inside T1 / T2 are distributed: pair q adds -F1 phi_q - F2 phi'_q.
-        const uint32_t* prow = a.perm + (uint64_t)p * a.perm_ld;
-        const uint32_t* pnrow = a.perm + (uint64_t)pn * a.perm_ld;
-        const uint32_t* wl = a.alpha_pow + 12 * G;                 // [Q + 3] ext weights
-        const Ext F1 = ext_mul_base(ld_ext(wl + 4 * a.pairs), sel_first);
-        const Ext F2 = ext_mul_base(ld_ext(wl + 4 * (a.pairs + 1)), sel_trans);
-        for (uint32_t q = lane; q < a.pairs; q += L) {
-            const uint4 vs = *reinterpret_cast<const uint4*>(row + 8 * q);
-            const uint4 vr = *reinterpret_cast<const uint4*>(row + 8 * q + 4);
-            const Ext ds = ext_add(ext_add_base(a.gamma, vs.x), ext_mul_base(a.beta, vs.y));
-            const Ext dr = ext_add(ext_add_base(a.gamma, vr.x), ext_mul_base(a.beta, vr.y));
-            const Ext phi = ld_ext(prow + 4 * q), phin = ld_ext(pnrow + 4 * q);
-            const Ext c = ext_sub(ext_mul(ext_mul(phi, ds), dr), ext_sub(dr, ds));
-            acc = ext_add(acc, ext_mul(c, ld_ext(wl + 4 * q)));
-            acc = ext_sub(acc, ext_add(ext_mul(F1, phi), ext_mul(F2, phin)));
+    for (int step = 0; step < QCHAIN; step++) {
+        const uint32_t en = (e + 2) & (m - 1);
+        const uint32_t pn = __brev(en) >> (32 - H);
+#pragma unroll
+        for (int t = 0; t < NG; t++) {
+            const uint32_t g = lane + L * t;
+            nxt[t] = g < G ? *reinterpret_cast<const uint4*>(a.lde + (uint64_t)pn * a.ld + 4 * g) : make_uint4(0, 0, 0, 0);
         }
-        if (lane == 0) {
-            const Ext S = ld_ext(prow + 4 * a.pairs), Sn = ld_ext(pnrow + 4 * a.pairs);
-            const Ext F3 = ext_mul_base(ld_ext(wl + 4 * (a.pairs + 2)), a.sel_last[p]);
-            acc = ext_add(acc, ext_add(ext_mul(F1, S), ext_add(ext_mul(F2, ext_sub(Sn, S)), ext_mul(F3, S))));
+        const uint32_t x = a.xs[p];
+        const uint32_t sel_first = a.sel_first[p];
+        const uint32_t sel_trans = dsub(x, a.wn_inv);
+        uint64_t acc[4] = {0, 0, 0, 0};
+#pragma unroll
+        for (int t = 0; t < NG; t++) {
+            const uint32_t g = lane + L * t;
+            if (g < G) {
+                const uint4 v = cur[t];
+                const uint4* wp = reinterpret_cast<const uint4*>(a.alpha_pow + 16 * g);
+                const uint4 w0 = wp[0], w1 = wp[1], w2 = wp[2], kk = wp[3];      // kk = (g+1, 2g+3, 5g+7, -) in Montgomery form
+                // c1 = c - a a b - k1 ; c2 = sel_trans (d' - a b - c - k2) ; c3 = sel_first (d - d0)
+                const uint32_t aab = dmul(dmont_lazy(v.x, v.x), v.y);
+                const uint32_t c1 = dsub(dsub(v.z, aab), kk.x);
+                const uint32_t ab = dmul(v.x, v.y);
+                const uint32_t c2 = dmul(dsub_lazy(dsub(dsub(nxt[t].w, ab), v.z), kk.y), sel_trans);
+                const uint32_t c3 = dmul(dsub_lazy(v.w, kk.z), sel_first);
+                dacc2(acc[0], w0.x, c1, w1.x, c2); dacc1(acc[0], w2.x, c3);
+                dacc2(acc[1], w0.y, c1, w1.y, c2); dacc1(acc[1], w2.y, c3);
+                dacc2(acc[2], w0.z, c1, w1.z, c2); dacc1(acc[2], w2.z, c3);
+                dacc2(acc[3], w0.w, c1, w1.w, c2); dacc1(acc[3], w2.w, c3);
+            }
         }
-    }
-    acc = group_sum(acc, L);
-    if (lane == 0) {
-        acc = ext_mul_base(acc, (e & 1) ? a.inv_zh_odd : a.inv_zh_even);
-        const uint32_t chunk = e & 1, j = e >> 1;
-        st_ext(a.out + ((uint64_t)chunk * (m >> 1) + j) * 4, acc);
+        Ext r = Ext{{dacc_finish(acc[0]), dacc_finish(acc[1]), dacc_finish(acc[2]), dacc_finish(acc[3])}};
+        if (a.pairs) {
+            // LogUp constraints (weights continue after the G main entries): L_q, then T1, T2, T3.
+            // The sums over q inside T1 / T2 are distributed: pair q adds -F1 phi_q - F2 phi'_q.
+            const uint32_t* row = a.lde + (uint64_t)p * a.ld;
+            const uint32_t* prow = a.perm + (uint64_t)p * a.perm_ld;
+            const uint32_t* pnrow = a.perm + (uint64_t)pn * a.perm_ld;
+            const uint32_t* wl = a.alpha_pow + 16 * G;                 // [Q + 3] ext weights
+            const Ext F1 = ext_mul_base(ld_ext(wl + 4 * a.pairs), sel_first);
+            const Ext F2 = ext_mul_base(ld_ext(wl + 4 * (a.pairs + 1)), sel_trans);
+            for (uint32_t q = lane; q < a.pairs; q += L) {
+                const uint4 vs = *reinterpret_cast<const uint4*>(row + 8 * q);
+                const uint4 vr = *reinterpret_cast<const uint4*>(row + 8 * q + 4);
+                const Ext ds = ext_add(ext_add_base(a.gamma, vs.x), ext_mul_base(a.beta, vs.y));
+                const Ext dr = ext_add(ext_add_base(a.gamma, vr.x), ext_mul_base(a.beta, vr.y));
+                const Ext phi = ld_ext(prow + 4 * q), phin = ld_ext(pnrow + 4 * q);
+                const Ext c = ext_sub(ext_mul(ext_mul(phi, ds), dr), ext_sub(dr, ds));
+                r = ext_add(r, ext_mul(c, ld_ext(wl + 4 * q)));
+                r = ext_sub(r, ext_add(ext_mul(F1, phi), ext_mul(F2, phin)));
+            }
+            if (lane == 0) {
+                const Ext S = ld_ext(prow + 4 * a.pairs), Sn = ld_ext(pnrow + 4 * a.pairs);
+                const Ext F3 = ext_mul_base(ld_ext(wl + 4 * (a.pairs + 2)), a.sel_last[p]);
+                r = ext_add(r, ext_add(ext_mul(F1, S), ext_add(ext_mul(F2, ext_sub(Sn, S)), ext_mul(F3, S))));
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < 4; i++) r.c[i] = row_group_sum(r.c[i], L);
+        if (lane == 0 && live) {
+            r = ext_mul_base(r, inv_zh);
+            st_ext(a.out + ((uint64_t)parity * (m >> 1) + (e >> 1)) * 4, r);
+        }
+#pragma unroll
+        for (int t = 0; t < NG; t++) cur[t] = nxt[t];
+        e = en; p = pn;
     }
 }
 hipError_t launch_quotient(const QuotientArgs& a, hipStream_t s) {
     const uint64_t m = 2ull << a.log_n;
-    const uint64_t threads = m * a.lanes_per_row;
-    hipLaunchKernelGGL(quotient_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, s, a);
+    const uint64_t threads = (m / QCHAIN) * a.lanes_per_row;
+    const uint32_t G = a.width / 4;
+    const int ng = (int)((G + a.lanes_per_row - 1) / a.lanes_per_row);
+    const dim3 grid((unsigned)((threads + 255) / 256)), block(256);
+    switch (ng) {
+        case 1: hipLaunchKernelGGL(quotient_kernel<1>, grid, block, 0, s, a); break;
+        case 2: hipLaunchKernelGGL(quotient_kernel<2>, grid, block, 0, s, a); break;
+        case 3: hipLaunchKernelGGL(quotient_kernel<3>, grid, block, 0, s, a); break;
+        case 4: hipLaunchKernelGGL(quotient_kernel<4>, grid, block, 0, s, a); break;
+        case 5: case 6: case 7: case 8: hipLaunchKernelGGL(quotient_kernel<8>, grid, block, 0, s, a); break;
+        default: hipLaunchKernelGGL(quotient_kernel<16>, grid, block, 0, s, a); break;    // width <= 1024
+    }
     return hipGetLastError();
 }
 
 // ------------------------------------------------------------------ 1 / (x_p - z)
+// out[k][p] = 1 / (x_p - z_k) for p < count; optionally xw[k][p] = x_p / (x_p - z_k) for p < xw_count
+// (the barycentric weights of the opening kernel, which sums over the first xw_count rows only)
 __global__ void __launch_bounds__(256) inv_denominators_kernel(const uint32_t* xs, uint64_t count, Ext z0, Ext z1, int npoints,
-                                                               uint32_t* out) {
+                                                               uint32_t* out, uint32_t* xw, uint64_t xw_count) {
     const uint64_t p = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (p >= count) return;
     const uint32_t x = xs[p];
-    st_ext(out + 4 * p, ext_inv(ext_neg(ext_sub_base(z0, x))));
-    if (npoints > 1) st_ext(out + 4 * (count + p), ext_inv(ext_neg(ext_sub_base(z1, x))));
+    const Ext d0 = ext_inv(ext_neg(ext_sub_base(z0, x)));
+    st_ext(out + 4 * p, d0);
+    if (xw && p < xw_count) st_ext(xw + 4 * p, ext_mul_base(d0, x));
+    if (npoints > 1) {
+        const Ext d1 = ext_inv(ext_neg(ext_sub_base(z1, x)));
+        st_ext(out + 4 * (count + p), d1);
+        if (xw && p < xw_count) st_ext(xw + 4 * (xw_count + p), ext_mul_base(d1, x));
+    }
 }
 hipError_t launch_inv_denominators(const uint32_t* xs, uint64_t count, const Ext& z0, const Ext& z1, int npoints,
-                                   uint32_t* out, hipStream_t s) {
-    hipLaunchKernelGGL(inv_denominators_kernel, dim3((unsigned)((count + 255) / 256)), dim3(256), 0, s, xs, count, z0, z1, npoints, out);
+                                   uint32_t* out, uint32_t* xw, uint64_t xw_count, hipStream_t s) {
+    hipLaunchKernelGGL(inv_denominators_kernel, dim3((unsigned)((count + 255) / 256)), dim3(256), 0, s, xs, count, z0, z1, npoints, out, xw, xw_count);
     return hipGetLastError();
 }
 
 // ------------------------------------------------------------------ barycentric opening
-// partial[chunk][pt][col] = sum_{q in chunk} (m[q][col] * x_q) * dinv_pt[q]
+// partial[chunk][pt][col] = sum_{q in chunk} m[q][col] * xw_pt[q].  A thread owns one column and every
+// TY-th row of the chunk; the four coefficients of each point are 64-bit running sums (dacc2: two
+// products per conditional subtraction, one Montgomery reduction per chunk).
 constexpr int OPEN_ROWS = 2048;   // rows per workgroup
 template <int NPTS>
 __global__ void __launch_bounds__(256) open_partial_kernel(OpenArgs a) {
@@ -164,23 +231,42 @@ __global__ void __launch_bounds__(256) open_partial_kernel(OpenArgs a) {
     const uint32_t col = blockIdx.y * TX + tx;
     const uint64_t r0 = (uint64_t)blockIdx.x * OPEN_ROWS;
     const bool active = col < a.width;
-    Ext acc[NPTS];
+    uint64_t acc[NPTS][4];
 #pragma unroll
-    for (int k = 0; k < NPTS; k++) acc[k] = ext_zero();
-    for (int r = ty; r < OPEN_ROWS; r += TY) {
-        const uint64_t q = r0 + r;
-        if (q >= a.rows) break;
-        const uint32_t v = active ? fmul(a.mat[q * a.ld + col], a.xs[q]) : 0u;
+    for (int k = 0; k < NPTS; k++)
 #pragma unroll
-        for (int k = 0; k < NPTS; k++) acc[k] = ext_add(acc[k], ext_mul_base(ld_ext(a.dinv + 4 * ((uint64_t)k * a.dinv_stride + q)), v));
+        for (int i = 0; i < 4; i++) acc[k][i] = 0;
+    const int nr = (int)((a.rows - r0) < (uint64_t)OPEN_ROWS ? (a.rows - r0) : (uint64_t)OPEN_ROWS);
+    // four rows per trip (r, r + TY, r + 2 TY, r + 3 TY): eight independent loads in flight per lane
+    for (int r = ty; r < nr; r += 4 * TY) {
+        uint32_t v[4];
+        uint64_t q[4];
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            const bool in = r + j * TY < nr;
+            q[j] = in ? r0 + r + j * TY : r0 + r;                 // out-of-range slots re-read row r with weight 0
+            v[j] = (active && in) ? a.mat[q[j] * a.ld + col] : 0u;
+        }
+#pragma unroll
+        for (int k = 0; k < NPTS; k++) {
+            Ext w[4];
+#pragma unroll
+            for (int j = 0; j < 4; j++) w[j] = ld_ext(a.xw + 4 * ((uint64_t)k * a.xw_stride + q[j]));
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+                dacc2(acc[k][i], v[0], w[0].c[i], v[1], w[1].c[i]);
+                dacc2(acc[k][i], v[2], w[2].c[i], v[3], w[3].c[i]);
+            }
+        }
     }
 #pragma unroll
     for (int k = 0; k < NPTS; k++) {
+        const Ext mine = Ext{{dacc_finish(acc[k][0]), dacc_finish(acc[k][1]), dacc_finish(acc[k][2]), dacc_finish(acc[k][3])}};
         __syncthreads();
-        for (int i = 0; i < 4; i++) red[threadIdx.x * 4 + i] = acc[k].c[i];
+        for (int i = 0; i < 4; i++) red[threadIdx.x * 4 + i] = mine.c[i];
         __syncthreads();
         if (ty == 0 && active) {
-            Ext sum = acc[k];
+            Ext sum = mine;
             for (int y = 1; y < TY; y++) {
                 Ext o = Ext{{red[(y * TX + tx) * 4], red[(y * TX + tx) * 4 + 1], red[(y * TX + tx) * 4 + 2], red[(y * TX + tx) * 4 + 3]}};
                 sum = ext_add(sum, o);
@@ -217,26 +303,31 @@ hipError_t launch_open(const OpenArgs& a, int npts, const Ext& scale0, const Ext
 // Two launches: (1) A_T per row, a row spread over L lanes, products summed in pairs in 64
 // bits before one Montgomery reduction; (2) one lane per row for the extension-field tail,
 // so that the ~100 multiplications of the tail keep all 64 lanes busy.
+// A row is spread over L <= 16 lanes of one DPP row (a wave covers 64 / L rows); each lane keeps four
+// 64-bit running sums (dacc2) and reduces them once per row, and the lane partials are summed with
+// DPP row rotations -- no LDS, no ds_bpermute.
 __global__ void __launch_bounds__(256) rowdot_kernel(const uint32_t* __restrict__ mat, uint64_t ld, uint32_t width, uint64_t rows,
                                                      int L, const uint32_t* __restrict__ alpha_pow, uint32_t* __restrict__ out_at) {
     const uint64_t gid = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const uint64_t p = gid / L;
     const int lane = (int)(gid % L);
-    if (p >= rows) return;
+    if (p >= rows) return;              // rows * L is a multiple of 64: whole waves exit together
     const uint32_t* row = mat + p * ld;
-    Ext acc = ext_zero();
+    uint64_t acc[4] = {0, 0, 0, 0};
     const uint32_t nq = width / 4;
     for (uint32_t q = lane; q < nq; q += L) {
         const uint4 v = *reinterpret_cast<const uint4*>(row + 4 * q);
         const uint4* ap = reinterpret_cast<const uint4*>(alpha_pow + 16 * q);
         const uint4 a0 = ap[0], a1 = ap[1], a2 = ap[2], a3 = ap[3];
-        acc.c[0] = dadd(acc.c[0], dadd(dmr2(a0.x, v.x, a1.x, v.y), dmr2(a2.x, v.z, a3.x, v.w)));
-        acc.c[1] = dadd(acc.c[1], dadd(dmr2(a0.y, v.x, a1.y, v.y), dmr2(a2.y, v.z, a3.y, v.w)));
-        acc.c[2] = dadd(acc.c[2], dadd(dmr2(a0.z, v.x, a1.z, v.y), dmr2(a2.z, v.z, a3.z, v.w)));
-        acc.c[3] = dadd(acc.c[3], dadd(dmr2(a0.w, v.x, a1.w, v.y), dmr2(a2.w, v.z, a3.w, v.w)));
+        dacc2(acc[0], a0.x, v.x, a1.x, v.y); dacc2(acc[0], a2.x, v.z, a3.x, v.w);
+        dacc2(acc[1], a0.y, v.x, a1.y, v.y); dacc2(acc[1], a2.y, v.z, a3.y, v.w);
+        dacc2(acc[2], a0.z, v.x, a1.z, v.y); dacc2(acc[2], a2.z, v.z, a3.z, v.w);
+        dacc2(acc[3], a0.w, v.x, a1.w, v.y); dacc2(acc[3], a2.w, v.z, a3.w, v.w);
     }
-    acc = group_sum(acc, L);
-    if (lane == 0) st_ext(out_at + 4 * p, acc);
+    Ext r;
+#pragma unroll
+    for (int i = 0; i < 4; i++) r.c[i] = row_group_sum(dacc_finish(acc[i]), L);
+    if (lane == 0) st_ext(out_at + 4 * p, r);
 }
 __global__ void __launch_bounds__(256) reduced_combine_kernel(ReducedArgs a, const uint32_t* __restrict__ at_in, const uint32_t* __restrict__ ap_in) {
     const uint64_t p = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -259,7 +350,7 @@ __global__ void __launch_bounds__(256) reduced_combine_kernel(ReducedArgs a, con
     r = ext_add(r, ext_mul(a.off_q, ext_mul(ext_sub(aq, a.y_q), d1)));
     st_ext(a.out + 4 * p, r);
 }
-static int lanes_for(uint32_t width) { int g = (int)(width / 4), l = 1; while (l < g && l < 64) l <<= 1; return l; }
+static int lanes_for(uint32_t width) { int g = (int)(width / 4), l = 1; while (l < g && l < 16) l <<= 1; return l; }
 hipError_t launch_reduced_opening(const ReducedArgs& a, uint32_t* scratch_at, hipStream_t s) {
     int L = lanes_for(a.width);
     uint64_t threads = a.rows * L;
