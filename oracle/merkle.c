@@ -91,3 +91,40 @@ int orc_merkle_verify(const uint32_t root[8], int log_h, size_t index,
     }
     return memcmp(cur, root, 32) == 0 ? 0 : 1;
 }
+
+/* ---- single-matrix commitment with a selectable hash (hash_width 16: the functions above;
+ * 24: Poseidon2 width 24, sponge rate 16, compress(l, r) = permute(l || r || 0^8)[0..8] --
+ * RISC Zero's shape) ---- */
+void orc_merkle_tree_hw(const uint32_t* mat, size_t width, int log_h, uint32_t* tree, int hash_width) {
+    if (hash_width != 24) {
+        const uint32_t* mats[1] = {mat}; size_t ws[1] = {width};
+        orc_merkle_tree(mats, ws, 1, log_h, tree);
+        return;
+    }
+    size_t rows = (size_t)1 << log_h;
+#pragma omp parallel for schedule(static)
+    for (size_t r = 0; r < rows; r++) orc_sponge24_hash(mat + r * width, width, 1, tree + 8 * r);
+    uint32_t* prev = tree;
+    for (int lvl = log_h - 1; lvl >= 0; lvl--) {
+        size_t cnt = (size_t)1 << lvl;
+        uint32_t* cur = prev + 16 * cnt;
+#pragma omp parallel for schedule(static)
+        for (size_t i = 0; i < cnt; i++) orc_compress24(prev + 16 * i, prev + 16 * i + 8, cur + 8 * i);
+        prev = cur;
+    }
+}
+int orc_merkle_verify_hw(const uint32_t root[8], int log_h, size_t index, const uint32_t* row, size_t width,
+                         const uint32_t* siblings, int hash_width) {
+    if (hash_width != 24) {
+        const uint32_t* rows[1] = {row}; size_t ws[1] = {width};
+        return orc_merkle_verify(root, log_h, index, rows, ws, 1, siblings);
+    }
+    uint32_t cur[8];
+    orc_sponge24_hash(row, width, 1, cur);
+    for (int lvl = 0; lvl < log_h; lvl++) {
+        const uint32_t* sib = siblings + 8 * lvl;
+        if ((index >> lvl) & 1) orc_compress24(sib, cur, cur);
+        else orc_compress24(cur, sib, cur);
+    }
+    return memcmp(cur, root, 32) == 0 ? 0 : 1;
+}

@@ -74,6 +74,10 @@ void orc_merkle_tree_mixed(const uint32_t* const* mats, const size_t* widths,
 int orc_merkle_verify(const uint32_t root[8], int log_h, size_t index,
                       const uint32_t* const* rows, const size_t* widths, int nmats,
                       const uint32_t* siblings);
+/* one row-major matrix, hash selected by hash_width (16: as above; 24: Poseidon2 width 24) */
+void orc_merkle_tree_hw(const uint32_t* mat, size_t width, int log_h, uint32_t* tree, int hash_width);
+int orc_merkle_verify_hw(const uint32_t root[8], int log_h, size_t index, const uint32_t* row, size_t width,
+                         const uint32_t* siblings, int hash_width);
 
 /* ---- Fiat-Shamir duplex challenger (p3-challenger DuplexChallenger<16,8>) ---- */
 typedef struct {
@@ -113,10 +117,14 @@ size_t orc_check_trace(const uint32_t* trace, int log_n, size_t width);
 
 /* ---- STARK stages (sp1-stark / p3-uni-stark / p3-fri), exposed for parity ---- */
 typedef struct {
-    int log_blowup;       /* 1  (SP1 core)                    */
-    int num_queries;      /* 100                              */
-    int pow_bits;         /* 16                               */
+    int log_blowup;       /* 1 (SP1 core) .. 3; 2 = RISC Zero's blowup 4 */
+    int num_queries;      /* 100 (SP1 core); 50 (RISC Zero)   */
+    int pow_bits;         /* 16 (SP1 core); 0 (RISC Zero)     */
     int logup_pairs;      /* 0: no lookup argument; Q > 0: Q LogUp sender/receiver group pairs */
+    /* FRI / hash shape; 0 = the SP1 default in each field (fold by 2, constant final polynomial, width 16) */
+    int log_fold;         /* committed FRI layers fold by 2^log_fold: 1 (p3-fri) or e.g. 4 (RISC Zero folds by 16) */
+    int log_final;        /* stop folding at a polynomial of < 2^log_final coefficients, sent in clear (RISC Zero: 8) */
+    int hash_width;       /* Poseidon2 width of every Merkle tree: 16 (rate 8) or 24 (rate 16, RISC Zero) */
 } orc_params_t;
 
 /* quotient values on the LDE coset, in bit-reversed row order like the LDE:

@@ -349,14 +349,33 @@ void orc_fri_fold_k(const uint32_t* in, int log_h, int log_arity, const uint32_t
 #define PROOF_MAGIC 0x41544B5Au   /* "ZKTA" */
 #define PROOF_VERSION 1u
 
+/* shape parameters with their defaults resolved (0 = SP1 shape) */
+typedef struct { int b, K, F, hw, R, ext; } shape_t;
+static int shape_of(int log_n, size_t width, const orc_params_t* prm, shape_t* sh) {
+    sh->b = prm->log_blowup;
+    sh->K = prm->log_fold ? prm->log_fold : 1;
+    sh->F = prm->log_final;
+    sh->hw = prm->hash_width ? prm->hash_width : 16;
+    sh->ext = !(sh->b == 1 && sh->K == 1 && sh->F == 0 && sh->hw == 16);   /* extended header / transcript */
+    if (sh->b < 1 || sh->b > 3 || width % 4 != 0 || width == 0) return 0;
+    if (sh->K < 1 || sh->K > 5 || sh->F < 0 || sh->F > 10 || sh->F > log_n || (log_n - sh->F) % sh->K != 0) return 0;
+    if (sh->hw != 16 && sh->hw != 24) return 0;
+    if (prm->logup_pairs < 0 || prm->logup_pairs > 64 || (size_t)prm->logup_pairs * 8 > width) return 0;
+    if (log_n + sh->b > 27) return 0;
+    sh->R = (log_n - sh->F) / sh->K;
+    return 1;
+}
+
 size_t orc_proof_size(int log_n, size_t width, const orc_params_t* prm, size_t n_public) {
     (void)n_public;
-    size_t H = (size_t)(log_n + prm->log_blowup), L = (size_t)log_n;
+    shape_t sh;
+    if (!shape_of(log_n, width, prm, &sh)) return 0;
+    size_t H = (size_t)(log_n + sh.b);
     size_t Q = (size_t)prm->logup_pairs, wp = Q ? 4 * (Q + 1) : 0;
-    size_t words = 8 + 16 + 8 * width + 32 + 8 * L + 5;
+    size_t words = (sh.ext ? 12 : (Q ? 9 : 8)) + 16 + 8 * width + 32 + 8 * (size_t)sh.R + 4 * ((size_t)1 << sh.F) + 1;
     size_t perq = width + 8 + 16 * H;
-    if (Q) { words += 1 + 8 + 8 * wp; perq += wp + 8 * H; }
-    for (size_t l = 0; l < L; l++) perq += 4 + 8 * (H - 1 - l);
+    if (Q) { words += 8 + 8 * wp; perq += wp + 8 * H; }
+    for (int l = 0; l < sh.R; l++) perq += 4 * (((size_t)1 << sh.K) - 1) + 8 * (H - (size_t)sh.K * (l + 1));
     words += (size_t)prm->num_queries * perq;
     return words * 4;
 }
@@ -364,11 +383,10 @@ size_t orc_proof_size(int log_n, size_t width, const orc_params_t* prm, size_t n
 static __thread orc_prove_debug_t g_dbg;
 void orc_last_prove_debug(orc_prove_debug_t* out) { *out = g_dbg; }
 
-static void observe_ext(orc_challenger_t* ch, bb4_t v) { orc_chal_observe_slice(ch, v.c, 4); }
 static bb4_t sample_ext(orc_challenger_t* ch) { bb4_t r; orc_chal_sample_ext(ch, r.c); return r; }
 
 static void transcript_init(orc_challenger_t* ch, int log_n, size_t width,
-                            const orc_params_t* prm, size_t n_public) {
+                            const orc_params_t* prm, size_t n_public, const shape_t* sh) {
     orc_chal_init(ch);
     orc_chal_observe(ch, (uint32_t)log_n);
     orc_chal_observe(ch, (uint32_t)width);
@@ -376,14 +394,29 @@ static void transcript_init(orc_challenger_t* ch, int log_n, size_t width,
     orc_chal_observe(ch, (uint32_t)prm->num_queries);
     orc_chal_observe(ch, (uint32_t)prm->pow_bits);
     orc_chal_observe(ch, (uint32_t)n_public);
-    if (prm->logup_pairs) orc_chal_observe(ch, (uint32_t)prm->logup_pairs);
+    if (sh->ext) {
+        orc_chal_observe(ch, (uint32_t)prm->logup_pairs);
+        orc_chal_observe(ch, (uint32_t)sh->K);
+        orc_chal_observe(ch, (uint32_t)sh->F);
+        orc_chal_observe(ch, (uint32_t)sh->hw);
+    } else if (prm->logup_pairs) orc_chal_observe(ch, (uint32_t)prm->logup_pairs);
 }
 
-static int params_ok(int log_n, size_t width, const orc_params_t* prm) {
-    if (prm->log_blowup != 1 || width % 4 != 0 || width == 0) return 0;
-    if (prm->logup_pairs < 0 || prm->logup_pairs > 64 || (size_t)prm->logup_pairs * 8 > width) return 0;
-    (void)log_n;
-    return 1;
+/* one committed FRI layer folds a row of 2^K adjacent (bit-reversed) entries, K times by 2 with
+ * beta, beta^2, beta^4, ...: `row_index` is the row's index in the layer matrix of 2^log_rows rows */
+static bb4_t fold_row_k(size_t row_index, int log_rows, int K, bb4_t beta, const bb4_t* ev) {
+    bb4_t tmp[32];
+    size_t cnt = (size_t)1 << K;
+    for (size_t j = 0; j < cnt; j++) tmp[j] = ev[j];
+    bb4_t b = beta;
+    for (int j = 0; j < K; j++) {
+        cnt >>= 1;                                   /* pairs at this level: row_index * cnt + t */
+        int log_folded = log_rows + (K - 1 - j);
+        for (size_t t = 0; t < cnt; t++)
+            tmp[t] = fri_fold_row(row_index * cnt + t, log_folded, b, tmp[2 * t], tmp[2 * t + 1]);
+        b = bb4_mul(b, b);
+    }
+    return tmp[0];
 }
 
 /* sum_j alpha^j * row[j] over `w` base-field words */
@@ -400,28 +433,30 @@ static void copy_path(uint32_t* pf, size_t* pos, const uint32_t* tree, size_t le
 size_t orc_prove_shard(const uint32_t* trace, int log_n, size_t width,
                        const uint32_t* public_values, size_t n_public,
                        const orc_params_t* prm, uint8_t* proof_bytes, size_t cap) {
-    if (!params_ok(log_n, width, prm)) return 0;
+    shape_t sh;
+    if (!shape_of(log_n, width, prm, &sh)) return 0;
     size_t need = orc_proof_size(log_n, width, prm, n_public);
     if (cap < need) return 0;
     uint32_t* pf = (uint32_t*)proof_bytes;
     size_t pos = 0;
-    const int H = log_n + 1, Q = prm->logup_pairs;
-    const size_t n = (size_t)1 << log_n, m = (size_t)1 << H, wp = Q ? 4 * ((size_t)Q + 1) : 0;
+    const int H = log_n + sh.b, Hq = log_n + 1, Q = prm->logup_pairs;      /* LDE domain 2^H, quotient domain 2^Hq */
+    const size_t n = (size_t)1 << log_n, m = (size_t)1 << H, mq = (size_t)1 << Hq, wp = Q ? 4 * ((size_t)Q + 1) : 0;
 
-    pf[pos++] = PROOF_MAGIC; pf[pos++] = Q ? 2u : PROOF_VERSION; pf[pos++] = (uint32_t)log_n;
+    pf[pos++] = PROOF_MAGIC; pf[pos++] = sh.ext ? 3u : (Q ? 2u : PROOF_VERSION); pf[pos++] = (uint32_t)log_n;
     pf[pos++] = (uint32_t)width; pf[pos++] = (uint32_t)prm->log_blowup;
     pf[pos++] = (uint32_t)prm->num_queries; pf[pos++] = (uint32_t)prm->pow_bits;
     pf[pos++] = (uint32_t)n_public;
-    if (Q) pf[pos++] = (uint32_t)Q;
+    if (sh.ext) { pf[pos++] = (uint32_t)Q; pf[pos++] = (uint32_t)sh.K; pf[pos++] = (uint32_t)sh.F; pf[pos++] = (uint32_t)sh.hw; }
+    else if (Q) pf[pos++] = (uint32_t)Q;
 
     orc_challenger_t ch;
-    transcript_init(&ch, log_n, width, prm, n_public);
+    transcript_init(&ch, log_n, width, prm, n_public, &sh);
 
     /* 1. commit the trace: LDE on g*<w_2N>, bit-reversed rows, Merkle tree */
     uint32_t* tlde = (uint32_t*)malloc(m * width * 4);
-    orc_coset_lde(trace, tlde, log_n, width, 1, BB_GEN);
+    orc_coset_lde(trace, tlde, log_n, width, sh.b, BB_GEN);
     uint32_t* ttree = (uint32_t*)malloc((2 * m - 1) * 32);
-    { const uint32_t* mats[1] = {tlde}; size_t ws[1] = {width}; orc_merkle_tree(mats, ws, 1, H, ttree); }
+    orc_merkle_tree_hw(tlde, width, H, ttree, sh.hw);
     const uint32_t* troot = ttree + (2 * m - 2) * 8;
     memcpy(pf + pos, troot, 32); pos += 8;
     memcpy(g_dbg.trace_root, troot, 32);
@@ -437,10 +472,10 @@ size_t orc_prove_shard(const uint32_t* trace, int log_n, size_t width,
         uint32_t* perm = (uint32_t*)malloc(n * wp * 4);
         orc_perm_trace(trace, log_n, width, Q, gamma.c, beta_l.c, perm);
         plde = (uint32_t*)malloc(m * wp * 4);
-        orc_coset_lde(perm, plde, log_n, wp, 1, BB_GEN);
+        orc_coset_lde(perm, plde, log_n, wp, sh.b, BB_GEN);
         free(perm);
         ptree = (uint32_t*)malloc((2 * m - 1) * 32);
-        { const uint32_t* mats[1] = {plde}; size_t ws[1] = {wp}; orc_merkle_tree(mats, ws, 1, H, ptree); }
+        orc_merkle_tree_hw(plde, wp, H, ptree, sh.hw);
         const uint32_t* proot = ptree + (2 * m - 2) * 8;
         memcpy(pf + pos, proot, 32); pos += 8;
         orc_chal_observe_slice(&ch, proot, 8);
@@ -449,7 +484,9 @@ size_t orc_prove_shard(const uint32_t* trace, int log_n, size_t width,
     /* 2. constraint challenge, quotient, chunks, commit */
     bb4_t alpha = sample_ext(&ch);
     memcpy(g_dbg.alpha, alpha.c, 16);
-    uint32_t* qv = (uint32_t*)malloc(m * 16);          /* bit-reversed like the LDE */
+    /* The quotient domain g*<w_2N> is the first 2N rows of the bit-reversed LDE on g*<w_{2^H}>, in the
+     * bit-reversed order of its own 2N points -- so the blowup-2 routine applies to those rows as is. */
+    uint32_t* qv = (uint32_t*)malloc(mq * 16);         /* bit-reversed like the LDE */
     orc_quotient_values_logup(tlde, log_n, width, plde, Q, gamma.c, beta_l.c, alpha.c, qv);
     /* chunk k = natural rows i = 2j + k  <->  bit-reversed rows [k*N, (k+1)*N);
      * as a matrix on the coset (g w^k) * <w_N> in natural order j: */
@@ -457,22 +494,22 @@ size_t orc_prove_shard(const uint32_t* trace, int log_n, size_t width,
     {
         uint32_t* chunk = (uint32_t*)malloc(n * 4 * 4);
         uint32_t* clde = (uint32_t*)malloc(m * 4 * 4);
-        bb_t w2n = bb_two_adic_generator(H);
+        bb_t w2n = bb_two_adic_generator(Hq);
         for (int k = 0; k < 2; k++) {
             for (size_t j = 0; j < n; j++) {
-                size_t p = bb_reverse_bits((uint32_t)(2 * j + k), H);
+                size_t p = bb_reverse_bits((uint32_t)(2 * j + k), Hq);
                 memcpy(chunk + 4 * j, qv + 4 * p, 16);
             }
-            /* values on (g w^k)*<w_N> -> LDE on g*<w_2N>: shift = g / (g w^k) */
+            /* values on (g w^k)*<w_N> -> LDE on g*<w_{2^H}>: shift = g / (g w^k) */
             bb_t shift = bb_inv(bb_pow(w2n, (uint64_t)k));
-            orc_coset_lde(chunk, clde, log_n, 4, 1, shift);
+            orc_coset_lde(chunk, clde, log_n, 4, sh.b, shift);
             for (size_t r = 0; r < m; r++) memcpy(qlde + r * 8 + 4 * k, clde + r * 4, 16);
         }
         free(chunk); free(clde);
     }
     free(qv);
     uint32_t* qtree = (uint32_t*)malloc((2 * m - 1) * 32);
-    { const uint32_t* mats[1] = {qlde}; size_t ws[1] = {8}; orc_merkle_tree(mats, ws, 1, H, qtree); }
+    orc_merkle_tree_hw(qlde, 8, H, qtree, sh.hw);
     const uint32_t* qroot = qtree + (2 * m - 2) * 8;
     memcpy(pf + pos, qroot, 32); pos += 8;
     memcpy(g_dbg.quotient_root, qroot, 32);
@@ -520,10 +557,10 @@ size_t orc_prove_shard(const uint32_t* trace, int log_n, size_t width,
           off_q = bb4_pow(fa, 2 * width + 2 * wp);
     bb4_t* cur = (bb4_t*)malloc(m * sizeof(bb4_t));
     {
-        bb_t w2n = bb_two_adic_generator(H);
+        bb_t wm = bb_two_adic_generator(H);
 #pragma omp parallel for schedule(static)
         for (size_t p = 0; p < m; p++) {
-            bb_t x = bb_mul(BB_GEN, bb_pow(w2n, bb_reverse_bits((uint32_t)p, H)));
+            bb_t x = bb_mul(BB_GEN, bb_pow(wm, bb_reverse_bits((uint32_t)p, H)));
             bb4_t d1 = bb4_inv(bb4_neg(bb4_sub_base(zeta, x)));        /* 1/(x - zeta) */
             bb4_t d2 = bb4_inv(bb4_neg(bb4_sub_base(zeta_next, x)));
             bb4_t at = row_dot(fapow, tlde + p * width, width);
@@ -541,32 +578,47 @@ size_t orc_prove_shard(const uint32_t* trace, int log_n, size_t width,
     }
     free(fapow);
 
-    /* 5. FRI commit phase */
-    const int L = log_n;
-    bb4_t** layers = (bb4_t**)malloc(L * sizeof(bb4_t*));
-    uint32_t** ltrees = (uint32_t**)malloc(L * sizeof(uint32_t*));
-    uint32_t* commits = pf + pos; pos += 8 * (size_t)L;
-    for (int l = 0; l < L; l++) {
-        int lh = H - 1 - l;                      /* log rows of this layer's matrix */
+    /* 5. FRI commit phase: R committed layers, each a matrix of rows of 2^K adjacent entries */
+    const int R = sh.R, K = sh.K;
+    const size_t arity = (size_t)1 << K;
+    bb4_t** layers = (bb4_t**)malloc((R ? R : 1) * sizeof(bb4_t*));
+    uint32_t** ltrees = (uint32_t**)malloc((R ? R : 1) * sizeof(uint32_t*));
+    uint32_t* commits = pf + pos; pos += 8 * (size_t)R;
+    for (int l = 0; l < R; l++) {
+        int lh = H - K * (l + 1);                /* log rows of this layer's matrix */
         size_t rows = (size_t)1 << lh;
         layers[l] = cur;
         ltrees[l] = (uint32_t*)malloc((2 * rows - 1) * 32);
-        { const uint32_t* mats[1] = {(const uint32_t*)cur}; size_t ws[1] = {8};
-          orc_merkle_tree(mats, ws, 1, lh, ltrees[l]); }
+        orc_merkle_tree_hw((const uint32_t*)cur, 4 * arity, lh, ltrees[l], sh.hw);
         const uint32_t* root = ltrees[l] + (2 * rows - 2) * 8;
         memcpy(commits + 8 * l, root, 32);
         orc_chal_observe_slice(&ch, root, 8);
         bb4_t beta = sample_ext(&ch);
         bb4_t* nxt = (bb4_t*)malloc(rows * sizeof(bb4_t));
-        orc_fri_fold((const uint32_t*)cur, lh + 1, beta.c, (uint32_t*)nxt);
+        if (K == 1) orc_fri_fold((const uint32_t*)cur, lh + 1, beta.c, (uint32_t*)nxt);
+        else {
+#pragma omp parallel for schedule(static)
+            for (size_t i = 0; i < rows; i++) nxt[i] = fold_row_k(i, lh, K, beta, cur + i * arity);
+        }
         cur = nxt;
     }
-    /* two evaluations of a constant polynomial remain */
-    int const_ok = bb4_eq(cur[0], cur[1]);
-    bb4_t final_poly = cur[0];
+    /* 2^(F+b) evaluations (bit-reversed, on <w_{2^(F+b)}>) of a polynomial of < 2^F coefficients remain:
+     * interpolate and send the coefficients */
+    int const_ok = 1;
+    {
+        const int lf = sh.F + sh.b;
+        const size_t nf = (size_t)1 << lf, keep = (size_t)1 << sh.F;
+        uint32_t* ev = (uint32_t*)malloc(nf * 16);
+        for (size_t i = 0; i < nf; i++) st4(ev + 4 * i, cur[bb_reverse_bits((uint32_t)i, lf)]);
+        orc_ntt(ev, lf, 4, 1);                   /* the DFT is F_p-linear: the 4 coordinates transform separately */
+        for (size_t i = keep; i < nf; i++)
+            for (int e = 0; e < 4; e++) if (ev[4 * i + e] != 0) const_ok = 0;
+        memcpy(pf + pos, ev, keep * 16);
+        orc_chal_observe_slice(&ch, ev, 4 * keep);
+        pos += 4 * keep;
+        free(ev);
+    }
     free(cur);
-    st4(pf + pos, final_poly); pos += 4;
-    observe_ext(&ch, final_poly);
 
     /* 6. proof of work, queries */
     uint32_t witness = orc_chal_grind(&ch, prm->pow_bits);
@@ -580,15 +632,16 @@ size_t orc_prove_shard(const uint32_t* trace, int log_n, size_t width,
         memcpy(pf + pos, qlde + index * 8, 32); pos += 8;
         copy_path(pf, &pos, qtree, m, index, H);
         size_t idx = index;
-        for (int l = 0; l < L; l++) {
-            int lh = H - 1 - l;
-            size_t sib = idx ^ 1, pair = idx >> 1;
-            st4(pf + pos, layers[l][sib]); pos += 4;
-            copy_path(pf, &pos, ltrees[l], (size_t)1 << lh, pair, lh);
-            idx = pair;
+        for (int l = 0; l < R; l++) {
+            int lh = H - K * (l + 1);
+            size_t row = idx >> K, own = idx & (arity - 1);
+            for (size_t j = 0; j < arity; j++)
+                if (j != own) { st4(pf + pos, layers[l][row * arity + j]); pos += 4; }
+            copy_path(pf, &pos, ltrees[l], (size_t)1 << lh, row, lh);
+            idx = row;
         }
     }
-    for (int l = 0; l < L; l++) { free(layers[l]); free(ltrees[l]); }
+    for (int l = 0; l < R; l++) { free(layers[l]); free(ltrees[l]); }
     free(layers); free(ltrees); free(tlde); free(ttree); free(qlde); free(qtree); free(plde); free(ptree);
     if (!const_ok) return 0;
     return pos * 4 == need ? need : 0;
@@ -597,11 +650,6 @@ size_t orc_prove_shard(const uint32_t* trace, int log_n, size_t width,
 /* ------------------------------------------------------------------ */
 /* verifier                                                             */
 /* ------------------------------------------------------------------ */
-static int verify_path(const uint32_t root[8], int log_h, size_t index,
-                       const uint32_t* row, size_t width, const uint32_t* sibs) {
-    const uint32_t* rows[1] = {row}; size_t ws[1] = {width};
-    return orc_merkle_verify(root, log_h, index, rows, ws, 1, sibs);
-}
 /* value at zeta of an extension column committed as 4 base columns: sum_e x^e * v_e(zeta) */
 static bb4_t recombine(const uint32_t* opened4) {
     bb4_t r = bb4_zero();
@@ -615,22 +663,26 @@ static bb4_t recombine(const uint32_t* opened4) {
 int orc_verify_shard(const uint8_t* proof_bytes, size_t len, int log_n, size_t width,
                      const uint32_t* public_values, size_t n_public,
                      const orc_params_t* prm) {
-    if (!params_ok(log_n, width, prm)) return 1;
+    shape_t sh;
+    if (!shape_of(log_n, width, prm, &sh)) return 1;
     if (len != orc_proof_size(log_n, width, prm, n_public)) return 2;
     const uint32_t* pf = (const uint32_t*)proof_bytes;
     size_t pos = 0;
-    const int H = log_n + 1, L = log_n, Q = prm->logup_pairs;
-    const size_t n = (size_t)1 << log_n, wp = Q ? 4 * ((size_t)Q + 1) : 0;
-    if (pf[0] != PROOF_MAGIC || pf[1] != (Q ? 2u : PROOF_VERSION) || pf[2] != (uint32_t)log_n ||
+    const int H = log_n + sh.b, Hq = log_n + 1, R = sh.R, K = sh.K, Q = prm->logup_pairs;
+    const size_t n = (size_t)1 << log_n, wp = Q ? 4 * ((size_t)Q + 1) : 0, arity = (size_t)1 << K;
+    if (pf[0] != PROOF_MAGIC || pf[1] != (sh.ext ? 3u : (Q ? 2u : PROOF_VERSION)) || pf[2] != (uint32_t)log_n ||
         pf[3] != (uint32_t)width || pf[4] != (uint32_t)prm->log_blowup ||
         pf[5] != (uint32_t)prm->num_queries || pf[6] != (uint32_t)prm->pow_bits ||
         pf[7] != (uint32_t)n_public) return 3;
     pos = 8;
-    if (Q) { if (pf[8] != (uint32_t)Q) return 3; pos = 9; }
+    if (sh.ext) {
+        if (pf[8] != (uint32_t)Q || pf[9] != (uint32_t)sh.K || pf[10] != (uint32_t)sh.F || pf[11] != (uint32_t)sh.hw) return 3;
+        pos = 12;
+    } else if (Q) { if (pf[8] != (uint32_t)Q) return 3; pos = 9; }
     for (size_t i = pos; i < len / 4; i++) if (pf[i] >= BB_P) return 4;   /* canonical words only */
 
     orc_challenger_t ch;
-    transcript_init(&ch, log_n, width, prm, n_public);
+    transcript_init(&ch, log_n, width, prm, n_public, &sh);
     const uint32_t* troot = pf + pos; pos += 8;
     orc_chal_observe_slice(&ch, troot, 8);
     orc_chal_observe_slice(&ch, public_values, n_public);
@@ -677,7 +729,7 @@ int orc_verify_shard(const uint8_t* proof_bytes, size_t len, int log_n, size_t w
         }
         free(loc); free(nxt);
         /* quotient(zeta) = sum_k zps_k(zeta) * q_k(zeta); chunk domain k: shift s_k = g w_2N^k */
-        bb_t w2n = bb_two_adic_generator(H);
+        bb_t w2n = bb_two_adic_generator(Hq);
         bb_t s[2] = {BB_GEN, bb_mul(BB_GEN, w2n)};
         bb4_t quot = bb4_zero();
         for (int k = 0; k < 2; k++) {
@@ -711,19 +763,20 @@ int orc_verify_shard(const uint8_t* proof_bytes, size_t len, int log_n, size_t w
     bb4_t off_next = bb4_pow(fa, width), off_pl = bb4_pow(fa, 2 * width), off_pn = bb4_pow(fa, 2 * width + wp),
           off_q = bb4_pow(fa, 2 * width + 2 * wp);
 
-    const uint32_t* commits = pf + pos; pos += 8 * (size_t)L;
-    bb4_t* betas = (bb4_t*)malloc(L * sizeof(bb4_t));
-    for (int l = 0; l < L; l++) {
+    const uint32_t* commits = pf + pos; pos += 8 * (size_t)R;
+    bb4_t* betas = (bb4_t*)malloc((R ? R : 1) * sizeof(bb4_t));
+    for (int l = 0; l < R; l++) {
         orc_chal_observe_slice(&ch, commits + 8 * l, 8);
         betas[l] = sample_ext(&ch);
     }
-    bb4_t final_poly = ld4(pf + pos); pos += 4;
-    observe_ext(&ch, final_poly);
+    const size_t keep = (size_t)1 << sh.F;
+    const uint32_t* final_poly = pf + pos; pos += 4 * keep;     /* coefficients, lowest first */
+    orc_chal_observe_slice(&ch, final_poly, 4 * keep);
     uint32_t witness = pf[pos++];
     int rc = 0;
     if (!orc_chal_check_witness(&ch, prm->pow_bits, witness)) rc = 20;
 
-    bb_t w2n = bb_two_adic_generator(H);
+    bb_t wm = bb_two_adic_generator(H);
     for (int q = 0; q < prm->num_queries && rc == 0; q++) {
         size_t index = orc_chal_sample_bits(&ch, H);
         const uint32_t* trow = pf + pos; pos += width;
@@ -732,10 +785,10 @@ int orc_verify_shard(const uint8_t* proof_bytes, size_t len, int log_n, size_t w
         if (Q) { prow = pf + pos; pos += wp; ppath = pf + pos; pos += 8 * (size_t)H; }
         const uint32_t* qrow = pf + pos; pos += 8;
         const uint32_t* qpath = pf + pos; pos += 8 * (size_t)H;
-        if (verify_path(troot, H, index, trow, width, tpath)) { rc = 30; break; }
-        if (Q && verify_path(proot, H, index, prow, wp, ppath)) { rc = 32; break; }
-        if (verify_path(qroot, H, index, qrow, 8, qpath)) { rc = 31; break; }
-        bb_t x = bb_mul(BB_GEN, bb_pow(w2n, bb_reverse_bits((uint32_t)index, H)));
+        if (orc_merkle_verify_hw(troot, H, index, trow, width, tpath, sh.hw)) { rc = 30; break; }
+        if (Q && orc_merkle_verify_hw(proot, H, index, prow, wp, ppath, sh.hw)) { rc = 32; break; }
+        if (orc_merkle_verify_hw(qroot, H, index, qrow, 8, qpath, sh.hw)) { rc = 31; break; }
+        bb_t x = bb_mul(BB_GEN, bb_pow(wm, bb_reverse_bits((uint32_t)index, H)));
         bb4_t d1 = bb4_inv(bb4_neg(bb4_sub_base(zeta, x)));
         bb4_t d2 = bb4_inv(bb4_neg(bb4_sub_base(zeta_next, x)));
         bb4_t at = row_dot(fapow, trow, width), aq = row_dot(fapow, qrow, 8);
@@ -750,21 +803,30 @@ int orc_verify_shard(const uint8_t* proof_bytes, size_t len, int log_n, size_t w
 
         bb4_t folded = ro;          /* single height: the reduced opening enters at layer 0 */
         size_t idx = index;
-        for (int l = 0; l < L; l++) {
-            int lh = H - 1 - l;
-            bb4_t sib = ld4(pf + pos); pos += 4;
+        for (int l = 0; l < R; l++) {
+            int lh = H - K * (l + 1);
+            size_t row = idx >> K, own = idx & (arity - 1);
+            bb4_t ev[32];
+            for (size_t j = 0; j < arity; j++) {
+                if (j == own) ev[j] = folded;
+                else { ev[j] = ld4(pf + pos); pos += 4; }
+            }
             const uint32_t* path = pf + pos; pos += 8 * (size_t)lh;
-            bb4_t ev[2];
-            ev[idx & 1] = folded; ev[(idx & 1) ^ 1] = sib;
-            size_t pair = idx >> 1;
-            uint32_t rowbuf[8];
-            memcpy(rowbuf, ev[0].c, 16); memcpy(rowbuf + 4, ev[1].c, 16);
-            if (verify_path(commits + 8 * l, lh, pair, rowbuf, 8, path)) { rc = 40 + (l < 50 ? l : 50); break; }
-            folded = fri_fold_row(pair, lh, betas[l], ev[0], ev[1]);
-            idx = pair;
+            uint32_t rowbuf[4 * 32];
+            for (size_t j = 0; j < arity; j++) memcpy(rowbuf + 4 * j, ev[j].c, 16);
+            if (orc_merkle_verify_hw(commits + 8 * l, lh, row, rowbuf, 4 * arity, path, sh.hw)) { rc = 40 + (l < 50 ? l : 50); break; }
+            folded = fold_row_k(row, lh, K, betas[l], ev);
+            idx = row;
         }
         if (rc) break;
-        if (!bb4_eq(folded, final_poly)) { rc = 100; break; }
+        /* the final polynomial at this query's point of the last domain <w_{2^(F+b)}> (Horner) */
+        {
+            const int lf = sh.F + sh.b;
+            bb_t xf = bb_pow(bb_two_adic_generator(lf), bb_reverse_bits((uint32_t)idx, lf));
+            bb4_t v = bb4_zero();
+            for (size_t i = keep; i-- > 0;) v = bb4_add(bb4_mul_base(v, xf), ld4(final_poly + 4 * i));
+            if (!bb4_eq(folded, v)) { rc = 100; break; }
+        }
     }
     free(fapow); free(betas);
     if (rc == 0 && pos * 4 != len) rc = 5;
