@@ -63,16 +63,24 @@ typedef enum {
 
 typedef struct zkhip_ctx zkhip_ctx;
 
-/* SP1-core-like parameters (sp1-stark 4.1.4 BabyBearPoseidon2: log_blowup 1,
- * 100 queries, 16 proof-of-work bits). */
+/* Proof-system shape.  SP1-core-like (sp1-stark 4.1.4 BabyBearPoseidon2): log_blowup 1, 100 queries,
+ * 16 proof-of-work bits, the last three fields 0.  RISC-Zero-like (risc0-zkp 1.2.5, reference
+ * Cargo.lock:5057): log_blowup 2, 50 queries, 0 PoW bits, log_fold 4,
+ * log_final 8, hash_width 24. */
 typedef struct {
-    int32_t log_blowup;
+    int32_t log_blowup;         /* 1 .. 3 */
     int32_t num_queries;
     int32_t pow_bits;
     /* 0: no lookup argument.  Q > 0: the first Q pairs of column groups are tied by a LogUp
      * lookup argument (sp1-stark permutation trace): group 2q+1 must hold a
      * row permutation of group 2q's (a, b) columns, see zkhip_gen_trace_logup. */
     int32_t logup_pairs;
+    /* FRI / hash shape; 0 selects the SP1 default of each field */
+    int32_t log_fold;           /* every committed FRI layer folds by 2^log_fold (default 1; RISC Zero: 4);
+                                 * (log_n - log_final) must be a multiple of it */
+    int32_t log_final;          /* folding stops at a polynomial of < 2^log_final coefficients, sent in clear
+                                 * (default 0: a constant; RISC Zero: 8) */
+    int32_t hash_width;         /* Poseidon2 width of every Merkle tree: 16 (rate 8, default) or 24 (rate 16) */
 } zkhip_params;
 
 /* ---- library / context ---- */

@@ -158,3 +158,42 @@ def test_fri_fold_k_matches_interpolation_definition(ctx, oracle, log_h, log_ari
     beta = rng.integers(0, P, 4, dtype=np.uint32)
     got = ctx.fri_fold_k(ctx.from_numpy(v), log_h, log_arity, beta).download().reshape(-1, 4)
     assert (got == oracle.fri_fold_k(v, log_arity, beta)).all()
+
+
+# ------------------------------------------------------------------ RISC-Zero-like shape (row a11) and the shapes between
+# (log_blowup, queries, pow_bits, logup_pairs, log_fold, log_final, hash_width)
+SHAPES = [
+    (8, 8, (2, 10, 4, 0, 4, 0, 24)),
+    (10, 16, (2, 20, 0, 0, 4, 2, 24)),
+    (12, 16, (2, 50, 0, 0, 4, 8, 24)),        # RISC Zero's parameters at 2^12 rows
+    (10, 32, (2, 20, 0, 2, 4, 6, 24)),        # with lookups
+    (9, 8, (2, 10, 8, 0, 1, 0, 16)),          # only the blowup changes
+    (9, 8, (1, 10, 8, 0, 3, 0, 16)),          # only the fold arity changes
+    (9, 8, (1, 10, 8, 0, 1, 3, 24)),          # only final polynomial + hash change
+    (10, 8, (3, 10, 0, 0, 2, 4, 16)),
+    (14, 64, (2, 50, 0, 0, 4, 6, 24)),
+    (13, 256, (2, 50, 0, 16, 4, 5, 24)),
+]
+
+
+@pytest.mark.parametrize("log_n,width,shape", SHAPES)
+def test_prove_shard_other_shapes_bytes_equal_oracle(ctx, oracle, log_n, width, shape):
+    pairs = shape[3]
+    trace = ctx.gen_trace_logup(SEED, 5, log_n, width, pairs) if pairs else ctx.gen_trace(SEED, 5, log_n, width)
+    otrace = oracle.gen_trace_logup(SEED, 5, log_n, width, pairs) if pairs else oracle.gen_trace(SEED, 5, log_n, width)
+    prm, oprm = Params(*shape), oracle.default_params(*shape)
+    proof = ctx.prove_shard(trace, log_n, width, [1, 2, 3], prm)
+    oproof = oracle.prove_shard(otrace, [1, 2, 3], oprm)
+    assert proof.size == oproof.size
+    assert proof.tobytes() == oproof.tobytes()
+    assert oracle.verify_shard(proof, log_n, width, [1, 2, 3], oprm) == 0
+    assert verify_shard(proof, log_n, width, [1, 2, 3], prm) == (0, 0)
+
+
+def test_shape_that_does_not_divide_is_refused(ctx):
+    from zktls_amd._lib import ZkHipError
+    trace = ctx.gen_trace(SEED, 0, 10, 8)
+    with pytest.raises(ZkHipError):
+        ctx.prove_shard(trace, 10, 8, [], Params(2, 10, 0, 0, 4, 0, 24))     # (10 - 0) % 4 != 0
+    with pytest.raises(ZkHipError):
+        ctx.prove_shard(trace, 10, 8, [], Params(2, 10, 0, 0, 4, 2, 20))     # hash width

@@ -55,11 +55,11 @@ struct zkhip_ctx {
     zk::DeviceBuffer scratch[24];       // grow-only workspaces, indexed by role
     zkhip_prove_debug debug{};
     // domain tables of the last proved size (prover.cpp)
-    int dom_log_n = -1;
-    uint32_t* dom_xs = nullptr;        // x_p = g * w_2N^bitrev(p), p < 2N
+    int dom_log_n = -1, dom_log_blowup = 0;
+    uint32_t* dom_xs = nullptr;        // x_p = g * w_M^bitrev(p), p < M = 2^(log_n + log_blowup); selectors: p < 2N
     uint32_t* dom_sel_first = nullptr; // Z_H(x_p) / (x_p - 1)
     uint32_t* dom_sel_last = nullptr;  // Z_H(x_p) / (x_p - w_N^-1)
-    uint32_t* dom_itw = nullptr;       // w_2N^-bitrev_n(i) / 2, i < N (FRI fold)
+    uint32_t* dom_itw = nullptr;       // w_M^-bitrev(i) / 2, i < M / 2 (FRI fold)
 };
 
 namespace zk {

@@ -298,6 +298,41 @@ hipError_t launch_merkle_p24_colmajor(const uint32_t* mat, uint32_t cols, int lo
     return e;
 }
 
+// row-major matrix (rows x ld words, width % 4 == 0, 16-byte aligned rows), same hash: the leaves of the
+// RISC-Zero-shaped prover mode, whose committed matrices stay row-major like everything else in the prover
+__global__ void __launch_bounds__(256) hash_rows24_kernel(const uint32_t* __restrict__ mat, uint64_t ld, uint32_t width, uint64_t rows,
+                                                          uint32_t* __restrict__ digests) {
+    const uint64_t r = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= rows) return;
+    const uint4* row = reinterpret_cast<const uint4*>(mat + r * ld);
+    uint32_t s[24];
+#pragma unroll
+    for (int i = 0; i < 24; i++) s[i] = 0u;
+    const uint32_t nq = width / 4;                   // 16-byte groups in the row
+    for (uint32_t q = 0; q < nq; q += 4) {
+#pragma unroll
+        for (int i = 0; i < 4; i++)
+            if (q + i < nq) { const uint4 v = row[q + i]; s[4 * i] = v.x; s[4 * i + 1] = v.y; s[4 * i + 2] = v.z; s[4 * i + 3] = v.w; }
+        p24_permute_dev(s);
+    }
+    uint4* d = reinterpret_cast<uint4*>(digests + r * 8);
+    d[0] = make_uint4(s[0], s[1], s[2], s[3]);
+    d[1] = make_uint4(s[4], s[5], s[6], s[7]);
+}
+hipError_t launch_merkle_p24_rowmajor(const uint32_t* mat, uint64_t ld, uint32_t width, int log_rows, uint32_t* tree, hipStream_t s) {
+    const uint64_t rows = (uint64_t)1 << log_rows;
+    hipLaunchKernelGGL(hash_rows24_kernel, dim3((unsigned)((rows + 255) / 256)), dim3(256), 0, s, mat, ld, width, rows, tree);
+    hipError_t e = hipGetLastError();
+    uint32_t* level = tree;
+    for (uint64_t cnt = rows / 2; cnt >= 1 && e == hipSuccess; cnt >>= 1) {
+        uint32_t* next = level + 16 * cnt;
+        hipLaunchKernelGGL(compress24_level_kernel, dim3((unsigned)((cnt + 255) / 256)), dim3(256), 0, s, level, next, cnt);
+        e = hipGetLastError();
+        level = next;
+    }
+    return e;
+}
+
 __global__ void __launch_bounds__(256) permute_states_kernel(uint32_t* states, uint64_t count) {
     const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= count) return;

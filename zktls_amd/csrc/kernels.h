@@ -71,6 +71,8 @@ hipError_t launch_inject(uint32_t* nodes, const uint32_t* extra, uint64_t count,
 hipError_t launch_compress_top(uint32_t* tree, uint32_t count, hipStream_t s);
 // RISC Zero layout: column-major [cols][rows], Poseidon2 width 24 (rate 16); full tree, leaves first
 hipError_t launch_merkle_p24_colmajor(const uint32_t* mat, uint32_t cols, int log_rows, uint32_t* tree, hipStream_t s);
+// same hash over a row-major matrix (width % 4 == 0, ld % 4 == 0, 16-byte aligned)
+hipError_t launch_merkle_p24_rowmajor(const uint32_t* mat, uint64_t ld, uint32_t width, int log_rows, uint32_t* tree, hipStream_t s);
 // raw permutation on `count` states of 16 words (KAT / microbenchmark)
 hipError_t launch_permute_states(uint32_t* states, uint64_t count, hipStream_t s);
 
@@ -89,7 +91,7 @@ hipError_t launch_convert(const uint32_t* in, uint32_t* out, uint64_t n, bool to
 
 // ---------------------------------------------------------------- STARK stages (stark.hip)
 // x_p = g w_2N^bitrev(p) (p < 2N), Z_H(x_p)/(x_p - 1), and 1/(2 w_2N^bitrev_n(i)) (i < N)
-hipError_t launch_domain_tables(uint32_t* xs, uint32_t* sel_first, uint32_t* sel_last, uint32_t* itw, int log_n, hipStream_t s);
+hipError_t launch_domain_tables(uint32_t* xs, uint32_t* sel_first, uint32_t* sel_last, uint32_t* itw, int log_n, int log_blowup, hipStream_t s);
 
 struct QuotientArgs {
     const uint32_t* lde;        // [2N][ld] trace LDE, bit-reversed rows

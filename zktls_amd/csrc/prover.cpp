@@ -45,14 +45,33 @@ struct Challenger {
     uint32_t sample_bits(int bits) { return from_monty(sample()) & ((1u << bits) - 1u); }
 };
 
-static void transcript_init(Challenger& ch, int log_n, uint32_t width, const zkhip_params* prm, size_t n_public) {
+// shape parameters with their defaults resolved (0 = the SP1 shape)
+struct Shape { int b = 1, K = 1, F = 0, hw = 16, R = 0; bool ext = false; };
+static bool shape_of(int log_n, const zkhip_params* prm, Shape& sh) {
+    sh.b = prm->log_blowup;
+    sh.K = prm->log_fold ? prm->log_fold : 1;
+    sh.F = prm->log_final;
+    sh.hw = prm->hash_width ? prm->hash_width : 16;
+    sh.ext = !(sh.b == 1 && sh.K == 1 && sh.F == 0 && sh.hw == 16);
+    if (sh.b < 1 || sh.b > 3 || sh.K < 1 || sh.K > 5 || sh.F < 0 || sh.F > 10 || sh.F > log_n || (log_n - sh.F) % sh.K != 0) return false;
+    if (sh.hw != 16 && sh.hw != 24) return false;
+    sh.R = (log_n - sh.F) / sh.K;
+    return true;
+}
+
+static void transcript_init(Challenger& ch, int log_n, uint32_t width, const zkhip_params* prm, size_t n_public, const Shape& sh) {
     ch.observe_canonical((uint32_t)log_n);
     ch.observe_canonical(width);
     ch.observe_canonical((uint32_t)prm->log_blowup);
     ch.observe_canonical((uint32_t)prm->num_queries);
     ch.observe_canonical((uint32_t)prm->pow_bits);
     ch.observe_canonical((uint32_t)n_public);
-    if (prm->logup_pairs) ch.observe_canonical((uint32_t)prm->logup_pairs);
+    if (sh.ext) {
+        ch.observe_canonical((uint32_t)prm->logup_pairs);
+        ch.observe_canonical((uint32_t)sh.K);
+        ch.observe_canonical((uint32_t)sh.F);
+        ch.observe_canonical((uint32_t)sh.hw);
+    } else if (prm->logup_pairs) ch.observe_canonical((uint32_t)prm->logup_pairs);
 }
 
 constexpr uint32_t PROOF_MAGIC = 0x41544B5Au;   // "ZKTA"
@@ -63,19 +82,24 @@ enum Slot { S_COEF = 0, S_TMP = 1, S_TLDE, S_TTREE, S_QCHUNK, S_QLDE, S_QTREE, S
 
 static int pow2ceil(int v) { int r = 1; while (r < v) r <<= 1; return r; }
 
-static int ensure_domain(zkhip_ctx* ctx, int log_n) {
-    if (ctx->dom_log_n == log_n) return ZKHIP_OK;
+static int ensure_domain(zkhip_ctx* ctx, int log_n, int log_blowup = 1) {
+    if (ctx->dom_log_n == log_n && ctx->dom_log_blowup == log_blowup) return ZKHIP_OK;
     if (ctx->dom_xs) { ZK_HIP(hipStreamSynchronize(ctx->stream)); (void)hipFree(ctx->dom_xs); (void)hipFree(ctx->dom_sel_first); (void)hipFree(ctx->dom_sel_last); (void)hipFree(ctx->dom_itw); }
     ctx->dom_xs = ctx->dom_sel_first = ctx->dom_sel_last = ctx->dom_itw = nullptr;
     ctx->dom_log_n = -1;
-    const size_t m = (size_t)2 << log_n;
+    const size_t m = (size_t)1 << (log_n + log_blowup), mq = (size_t)2 << log_n;
     ZK_HIP(hipMalloc((void**)&ctx->dom_xs, m * 4));
-    ZK_HIP(hipMalloc((void**)&ctx->dom_sel_first, m * 4));
-    ZK_HIP(hipMalloc((void**)&ctx->dom_sel_last, m * 4));
+    ZK_HIP(hipMalloc((void**)&ctx->dom_sel_first, mq * 4));
+    ZK_HIP(hipMalloc((void**)&ctx->dom_sel_last, mq * 4));
     ZK_HIP(hipMalloc((void**)&ctx->dom_itw, (m / 2) * 4));
-    ZK_HIP(launch_domain_tables(ctx->dom_xs, ctx->dom_sel_first, ctx->dom_sel_last, ctx->dom_itw, log_n, ctx->stream));
-    ctx->dom_log_n = log_n;
+    ZK_HIP(launch_domain_tables(ctx->dom_xs, ctx->dom_sel_first, ctx->dom_sel_last, ctx->dom_itw, log_n, log_blowup, ctx->stream));
+    ctx->dom_log_n = log_n; ctx->dom_log_blowup = log_blowup;
     return ZKHIP_OK;
+}
+// the FRI inverse-twiddle table of a domain is a prefix of the table of any larger one
+static int ensure_fold_table(zkhip_ctx* ctx, int log_h) {
+    if (ctx->dom_log_n >= 0 && ctx->dom_log_n + ctx->dom_log_blowup >= log_h) return ZKHIP_OK;
+    return ensure_domain(ctx, log_h - 1 < 5 ? 5 : log_h - 1, 1);
 }
 
 static int d2h(zkhip_ctx* ctx, void* dst, const void* src, size_t bytes) {
@@ -96,7 +120,7 @@ struct LogupIn {
 };
 static int run_quotient(zkhip_ctx* ctx, const uint32_t* lde, size_t ld, int log_n, uint32_t width, const Ext& alpha,
                         const LogupIn& lu, uint32_t* out_chunks) {
-    ZK_TRY(ensure_domain(ctx, log_n));
+    if (ctx->dom_log_n != log_n) ZK_TRY(ensure_domain(ctx, log_n));   // any blowup serves: the quotient domain is a prefix
     const uint32_t G = width / 4;
     // weight of constraint k is alpha^(K-1-k): filled from the last constraint backwards;
     // order: 3 per column group, then (LogUp) L_0 .. L_{Q-1}, T1, T2, T3
@@ -154,12 +178,14 @@ static int run_open(zkhip_ctx* ctx, const uint32_t* lde, size_t ld, int log_n, u
 }
 
 static size_t proof_words(int log_n, uint32_t width, const zkhip_params* prm) {
-    const size_t H = (size_t)(log_n + prm->log_blowup), L = (size_t)log_n;
+    Shape sh;
+    if (!shape_of(log_n, prm, sh)) return 0;
+    const size_t H = (size_t)(log_n + sh.b);
     const size_t Q = (size_t)prm->logup_pairs, wp = Q ? 4 * (Q + 1) : 0;
-    size_t words = 8 + 16 + 8 * (size_t)width + 32 + 8 * L + 5;
+    size_t words = (sh.ext ? 12 : (Q ? 9 : 8)) + 16 + 8 * (size_t)width + 32 + 8 * (size_t)sh.R + 4 * ((size_t)1 << sh.F) + 1;
     size_t perq = width + 8 + 16 * H;
-    if (Q) { words += 1 + 8 + 8 * wp; perq += wp + 8 * H; }
-    for (size_t l = 0; l < L; l++) perq += 4 + 8 * (H - 1 - l);
+    if (Q) { words += 8 + 8 * wp; perq += wp + 8 * H; }
+    for (int l = 0; l < sh.R; l++) perq += 4 * (((size_t)1 << sh.K) - 1) + 8 * (H - (size_t)sh.K * (l + 1));
     return words + (size_t)prm->num_queries * perq;
 }
 
@@ -167,12 +193,42 @@ static int check_shape(int log_n, uint32_t width, const zkhip_params* prm) {
     if (!prm) return fail(ZKHIP_ERR_INVALID, "null params");
     if (log_n < 5 || log_n > 20) return fail(ZKHIP_ERR_INVALID, "log_n must be in [5, 20]");
     if (width == 0 || width % 4 != 0 || width > 1024) return fail(ZKHIP_ERR_INVALID, "width must be a positive multiple of 4, at most 1024");
-    if (prm->log_blowup != 1) return fail(ZKHIP_ERR_INVALID, "only log_blowup = 1 is supported by the synthetic AIR path");
+    Shape sh;
+    if (!shape_of(log_n, prm, sh))
+        return fail(ZKHIP_ERR_INVALID, "shape: log_blowup in [1,3], log_fold in [1,5] dividing log_n - log_final, log_final in [0,10], hash_width 16 or 24");
     if (prm->num_queries < 1 || prm->num_queries > 4096) return fail(ZKHIP_ERR_INVALID, "num_queries out of range");
     if (prm->pow_bits < 0 || prm->pow_bits > 28) return fail(ZKHIP_ERR_INVALID, "pow_bits out of range");
     if (prm->logup_pairs < 0 || prm->logup_pairs > 64 || (uint32_t)prm->logup_pairs * 8 > width)
         return fail(ZKHIP_ERR_INVALID, "logup_pairs out of range (each pair needs two column groups, at most 64 pairs)");
     return ZKHIP_OK;
+}
+
+// one Merkle commitment of a row-major matrix with the shape's hash
+static int commit_hw(zkhip_ctx* ctx, const uint32_t* mat, size_t ld, uint32_t width, int log_h, uint32_t* tree, int hw) {
+    if (hw == 24) { ZK_HIP(launch_merkle_p24_rowmajor(mat, ld, width, log_h, tree, ctx->stream)); return ZKHIP_OK; }
+    MatDesc md{mat, ld, width};
+    return op_merkle_commit(ctx, &md, 1, log_h, tree);
+}
+
+// in-place inverse DFT of 2^log extension elements (natural order in and out); host, tiny sizes
+static void host_intt_ext(std::vector<Ext>& a, int log) {
+    const size_t nn = (size_t)1 << log;
+    for (size_t i = 0; i < nn; i++) { size_t j = reverse_bits((uint32_t)i, log); if (i < j) std::swap(a[i], a[j]); }
+    for (int s = 1; s <= log; s++) {
+        const size_t half = (size_t)1 << (s - 1);
+        const uint32_t wl = finv(two_adic_generator(s));
+        for (size_t base = 0; base < nn; base += 2 * half) {
+            uint32_t w = MONTY_R1;
+            for (size_t j = 0; j < half; j++) {
+                const Ext u = a[base + j], v = ext_mul_base(a[base + j + half], w);
+                a[base + j] = ext_add(u, v);
+                a[base + j + half] = ext_sub(u, v);
+                w = fmul(w, wl);
+            }
+        }
+    }
+    const uint32_t ninv = finv(to_monty((uint32_t)nn));
+    for (size_t i = 0; i < nn; i++) a[i] = ext_mul_base(a[i], ninv);
 }
 
 }  // namespace zk
@@ -190,7 +246,7 @@ extern "C" {
 int zkhip_quotient_values(zkhip_ctx* ctx, const uint32_t* d_lde, size_t ld, int log_n, uint32_t width,
                           const uint32_t alpha[4], uint32_t* d_out) {
     CHECK_CTX(ctx);
-    zkhip_params prm{1, 1, 0, 0};
+    zkhip_params prm{1, 1, 0, 0, 0, 0, 0};
     ZK_TRY(check_shape(log_n, width, &prm));
     if (!d_lde || !d_out || !alpha || ld < width) return fail(ZKHIP_ERR_INVALID, "quotient_values: bad arguments");
     // kernel writes natural-order chunks; this entry point returns the bit-reversed
@@ -243,7 +299,7 @@ int zkhip_open_at(zkhip_ctx* ctx, const uint32_t* d_lde, size_t ld, int log_n, i
     if (log_n < 5 || log_n > 20 || log_blowup != 1) return fail(ZKHIP_ERR_INVALID, "open_at: log_n in [5,20], log_blowup = 1");
     if (!d_lde || !z || !h_out || width == 0 || ld < width || npoints < 1 || npoints > 2)
         return fail(ZKHIP_ERR_INVALID, "open_at: bad arguments (1 or 2 points)");
-    ZK_TRY(ensure_domain(ctx, log_n));
+    if (ctx->dom_log_n != log_n) ZK_TRY(ensure_domain(ctx, log_n));
     const uint64_t m = (uint64_t)2 << log_n, n = (uint64_t)1 << log_n;
     Ext zz[2];
     for (int k = 0; k < npoints; k++) zz[k] = Ext{{z[4 * k], z[4 * k + 1], z[4 * k + 2], z[4 * k + 3]}};
@@ -260,9 +316,7 @@ int zkhip_open_at(zkhip_ctx* ctx, const uint32_t* d_lde, size_t ld, int log_n, i
 int zkhip_fri_fold(zkhip_ctx* ctx, const uint32_t* d_in, int log_h, const uint32_t beta[4], uint32_t* d_out) {
     CHECK_CTX(ctx);
     if (!d_in || !d_out || !beta || log_h < 1 || log_h > 21) return fail(ZKHIP_ERR_INVALID, "fri_fold: bad arguments");
-    // the inverse-twiddle table of size 2^(log_h - 1) is a prefix of the table of any larger domain
-    const int need_log_n = log_h - 1 < 5 ? 5 : log_h - 1;
-    if (ctx->dom_log_n < need_log_n) ZK_TRY(ensure_domain(ctx, need_log_n));
+    ZK_TRY(ensure_fold_table(ctx, log_h));
     Ext b{{beta[0], beta[1], beta[2], beta[3]}};
     ZK_HIP(launch_fri_fold(d_in, d_out, ctx->dom_itw, (uint64_t)1 << (log_h - 1), b, ctx->stream));
     return ZKHIP_OK;
@@ -272,8 +326,7 @@ int zkhip_fri_fold_k(zkhip_ctx* ctx, const uint32_t* d_in, int log_h, int log_ar
     CHECK_CTX(ctx);
     if (!d_in || !d_out || !beta || log_arity < 1 || log_arity > 6 || log_h < log_arity || log_h > 21)
         return fail(ZKHIP_ERR_INVALID, "fri_fold_k: bad arguments");
-    const int need_log_n = log_h - 1 < 5 ? 5 : log_h - 1;
-    if (ctx->dom_log_n < need_log_n) ZK_TRY(ensure_domain(ctx, need_log_n));
+    ZK_TRY(ensure_fold_table(ctx, log_h));
     // f = sum_j X^j f_j(X^(2^k)); folding by 2 with b, then b^2, b^4, ... leaves sum_j b^j f_j
     void* tmp;
     ZK_TRY(ctx_reserve(ctx, S_PARTIAL, ((size_t)1 << log_h) * 16, &tmp));
@@ -307,21 +360,25 @@ int zkhip_prove_shard(zkhip_ctx* ctx, const uint32_t* d_trace, size_t ld, int lo
     const size_t need = proof_words(log_n, width, prm) * 4;
     if (cap < need) return fail(ZKHIP_ERR_BUFFER, "prove_shard: proof buffer too small (see zkhip_proof_size)");
     *len = 0;
-    const int H = log_n + 1, L = log_n, Q = prm->num_queries;
-    const size_t n = (size_t)1 << log_n, m = (size_t)1 << H;
+    Shape sh;
+    shape_of(log_n, prm, sh);
+    const int H = log_n + sh.b, Hq = log_n + 1, Q = prm->num_queries;     // LDE domain 2^H, quotient domain 2^Hq
+    const int RL = sh.R, K = sh.K;                                          // committed FRI layers, folds per layer
+    const size_t n = (size_t)1 << log_n, m = (size_t)1 << H, arity = (size_t)1 << K;
     hipStream_t st = ctx->stream;
-    ZK_TRY(ensure_domain(ctx, log_n));
+    ZK_TRY(ensure_domain(ctx, log_n, sh.b));
 
     uint32_t* pf = (uint32_t*)proof;
     size_t pos = 0;
     const uint32_t LQ = (uint32_t)prm->logup_pairs;          // LogUp pairs (0 = none)
     const size_t wp = LQ ? 4 * ((size_t)LQ + 1) : 0;         // permutation-trace width in words
-    pf[pos++] = PROOF_MAGIC; pf[pos++] = LQ ? 2u : PROOF_VERSION; pf[pos++] = (uint32_t)log_n; pf[pos++] = width;
+    pf[pos++] = PROOF_MAGIC; pf[pos++] = sh.ext ? 3u : (LQ ? 2u : PROOF_VERSION); pf[pos++] = (uint32_t)log_n; pf[pos++] = width;
     pf[pos++] = (uint32_t)prm->log_blowup; pf[pos++] = (uint32_t)Q; pf[pos++] = (uint32_t)prm->pow_bits; pf[pos++] = (uint32_t)n_public;
-    if (LQ) pf[pos++] = LQ;
+    if (sh.ext) { pf[pos++] = LQ; pf[pos++] = (uint32_t)sh.K; pf[pos++] = (uint32_t)sh.F; pf[pos++] = (uint32_t)sh.hw; }
+    else if (LQ) pf[pos++] = LQ;
 
     Challenger ch;
-    transcript_init(ch, log_n, width, prm, n_public);
+    transcript_init(ch, log_n, width, prm, n_public, sh);
     uint32_t root[8];
 
     // ---- 1. commit the trace: LDE on g <w_2N> (bit-reversed rows) + Merkle tree
@@ -329,8 +386,8 @@ int zkhip_prove_shard(zkhip_ctx* ctx, const uint32_t* d_trace, size_t ld, int lo
     ZK_TRY(ctx_reserve(ctx, S_TLDE, m * width * 4, &v_tlde));
     ZK_TRY(ctx_reserve(ctx, S_TTREE, (2 * m - 1) * 32, &v_ttree));
     uint32_t* tlde = (uint32_t*)v_tlde; uint32_t* ttree = (uint32_t*)v_ttree;
-    ZK_TRY(op_coset_lde(ctx, d_trace, ld, tlde, width, log_n, width, 1, MONTY_GEN));
-    { MatDesc md{tlde, width, width}; ZK_TRY(op_merkle_commit(ctx, &md, 1, H, ttree)); }
+    ZK_TRY(op_coset_lde(ctx, d_trace, ld, tlde, width, log_n, width, sh.b, MONTY_GEN));
+    ZK_TRY(commit_hw(ctx, tlde, width, width, H, ttree, sh.hw));
     ZK_TRY(d2h(ctx, root, ttree + (2 * m - 2) * 8, 32));
     for (int i = 0; i < 8; i++) { ch.observe(root[i]); pf[pos++] = ctx->debug.trace_root[i] = from_monty(root[i]); }
     for (size_t i = 0; i < n_public; i++) ch.observe_canonical(public_values[i]);
@@ -348,8 +405,8 @@ int zkhip_prove_shard(zkhip_ctx* ctx, const uint32_t* d_trace, size_t ld, int lo
         ZK_TRY(ctx_reserve(ctx, S_PTREE, (2 * m - 1) * 32, &v_ptree));
         plde = (uint32_t*)v_plde; ptree = (uint32_t*)v_ptree;
         ZK_TRY(run_perm_trace(ctx, d_trace, ld, log_n, LQ, lu.gamma, lu.beta, (uint32_t*)v_perm));
-        ZK_TRY(op_coset_lde(ctx, (const uint32_t*)v_perm, wp, plde, wp, log_n, (uint32_t)wp, 1, MONTY_GEN));
-        { MatDesc md{plde, wp, (uint32_t)wp}; ZK_TRY(op_merkle_commit(ctx, &md, 1, H, ptree)); }
+        ZK_TRY(op_coset_lde(ctx, (const uint32_t*)v_perm, wp, plde, wp, log_n, (uint32_t)wp, sh.b, MONTY_GEN));
+        ZK_TRY(commit_hw(ctx, plde, wp, (uint32_t)wp, H, ptree, sh.hw));
         ZK_TRY(d2h(ctx, root, ptree + (2 * m - 2) * 8, 32));
         for (int i = 0; i < 8; i++) { ch.observe(root[i]); pf[pos++] = from_monty(root[i]); }
         lu.perm_lde = plde;
@@ -364,14 +421,14 @@ int zkhip_prove_shard(zkhip_ctx* ctx, const uint32_t* d_trace, size_t ld, int lo
     uint32_t* qchunk = (uint32_t*)v_qchunk; uint32_t* qlde = (uint32_t*)v_qlde; uint32_t* qtree = (uint32_t*)v_qtree;
     ZK_TRY(run_quotient(ctx, tlde, width, log_n, width, alpha, lu, qchunk));
     {
-        const uint32_t w2n = two_adic_generator(H);
+        // the quotient kernel works on the first 2N rows of the LDE: they are the coset g <w_2N>, bit-reversed
+        const uint32_t w2n = two_adic_generator(Hq);
         for (int k = 0; k < 2; k++) {
-            // chunk k lives on (g w_2N^k) <w_N>; extend it to g <w_2N>: shift = g / (g w^k)
+            // chunk k lives on (g w_2N^k) <w_N>; extend it to the LDE domain g <w_M>: shift = g / (g w^k)
             const uint32_t shift = finv(fpow(w2n, (uint64_t)k));
-            ZK_TRY(op_coset_lde(ctx, qchunk + (size_t)k * n * 4, 4, qlde + 4 * k, 8, log_n, 4, 1, shift));
+            ZK_TRY(op_coset_lde(ctx, qchunk + (size_t)k * n * 4, 4, qlde + 4 * k, 8, log_n, 4, sh.b, shift));
         }
-        MatDesc md{qlde, 8, 8};
-        ZK_TRY(op_merkle_commit(ctx, &md, 1, H, qtree));
+        ZK_TRY(commit_hw(ctx, qlde, 8, 8, H, qtree, sh.hw));
     }
     ZK_TRY(d2h(ctx, root, qtree + (2 * m - 2) * 8, 32));
     for (int i = 0; i < 8; i++) { ch.observe(root[i]); pf[pos++] = ctx->debug.quotient_root[i] = from_monty(root[i]); }
@@ -437,34 +494,52 @@ int zkhip_prove_shard(zkhip_ctx* ctx, const uint32_t* d_trace, size_t ld, int lo
     ZK_TRY(ctx_reserve(ctx, S_PARTIAL, 2 * m * 16, &v_at));   // openings are done with S_PARTIAL by now
     ZK_HIP(launch_reduced_opening(ra, (uint32_t*)v_at, st));
 
-    // ---- 5. FRI commit phase: commit, challenge, fold
-    std::vector<size_t> layer_off(L + 1), tree_off(L + 1);
+    // ---- 5. FRI commit phase: RL committed layers (rows of 2^K adjacent entries): commit, challenge, fold K times
+    std::vector<size_t> layer_off(RL + 1), tree_off(RL + 1);
     {
         size_t lo = 0, to = 0;
-        for (int l = 0; l <= L; l++) {
+        for (int l = 0; l <= RL; l++) {
             layer_off[l] = lo; tree_off[l] = to;
-            lo += ((size_t)1 << (H - l)) * 4;
-            if (l < L) to += (2 * ((size_t)1 << (H - 1 - l)) - 1) * 8;
+            lo += ((size_t)1 << (H - K * l)) * 4;
+            if (l < RL) to += (2 * ((size_t)1 << (H - K * (l + 1))) - 1) * 8;
         }
     }
-    for (int l = 0; l < L; l++) {
-        const int lh = H - 1 - l;
+    uint32_t* fold_tmp = (uint32_t*)v_at;                  // S_PARTIAL: the reduced-opening scratch is free again
+    for (int l = 0; l < RL; l++) {
+        const int lh = H - K * (l + 1);
         const size_t rows = (size_t)1 << lh;
         uint32_t* cur = layers + layer_off[l];
         uint32_t* tree = ltrees + tree_off[l];
-        MatDesc md{cur, 8, 8};
-        ZK_TRY(op_merkle_commit(ctx, &md, 1, lh, tree));
+        ZK_TRY(commit_hw(ctx, cur, 4 * arity, (uint32_t)(4 * arity), lh, tree, sh.hw));
         ZK_TRY(d2h(ctx, root, tree + (2 * rows - 2) * 8, 32));
         for (int i = 0; i < 8; i++) { ch.observe(root[i]); pf[pos++] = from_monty(root[i]); }
-        const Ext beta = ch.sample_ext();
-        ZK_HIP(launch_fri_fold(cur, layers + layer_off[l + 1], ctx->dom_itw, rows, beta, st));
+        Ext beta = ch.sample_ext();
+        // fold by 2 with beta, beta^2, beta^4, ...: f = sum_j X^j f_j(X^(2^K))  ->  sum_j beta^j f_j
+        const uint32_t* src = cur;
+        for (int j = 0; j < K; j++) {
+            const size_t out_cnt = (size_t)1 << (H - K * l - j - 1);
+            uint32_t* dst = (j == K - 1) ? layers + layer_off[l + 1] : fold_tmp + ((j & 1) ? 4 * (m / 2) : 0);
+            ZK_HIP(launch_fri_fold(src, dst, ctx->dom_itw, out_cnt, beta, st));
+            src = dst;
+            beta = ext_mul(beta, beta);
+        }
     }
-    Ext fin[2];
-    ZK_TRY(d2h(ctx, fin, layers + layer_off[L], 32));
-    if (!ext_eq(fin[0], fin[1]))
-        return fail(ZKHIP_ERR_INVALID, "prove_shard: final FRI layer is not constant (the trace violates the AIR)");
-    for (int i = 0; i < 4; i++) pf[pos++] = from_monty(fin[0].c[i]);
-    ch.observe_ext(fin[0]);
+    // 2^(F+b) evaluations of a polynomial of < 2^F coefficients remain: interpolate on the host, send the coefficients
+    {
+        const int lf = sh.F + sh.b;
+        const size_t nf = (size_t)1 << lf, keep = (size_t)1 << sh.F;
+        std::vector<Ext> last(nf), nat(nf);
+        ZK_TRY(d2h(ctx, last.data(), layers + layer_off[RL], nf * 16));
+        for (size_t i = 0; i < nf; i++) nat[i] = last[reverse_bits((uint32_t)i, lf)];
+        host_intt_ext(nat, lf);
+        for (size_t i = keep; i < nf; i++)
+            if (!ext_eq(nat[i], ext_zero()))
+                return fail(ZKHIP_ERR_INVALID, "prove_shard: final FRI layer is not low-degree (the trace violates the AIR)");
+        for (size_t i = 0; i < keep; i++) {
+            for (int e = 0; e < 4; e++) pf[pos++] = from_monty(nat[i].c[e]);
+            ch.observe_ext(nat[i]);
+        }
+    }
 
     // ---- 6. proof of work: smallest witness, searched 2^20 candidates per launch
     uint32_t witness = 0xFFFFFFFFu;
@@ -491,7 +566,7 @@ int zkhip_prove_shard(zkhip_ctx* ctx, const uint32_t* d_trace, size_t ld, int lo
     // ---- 7. queries: one gather launch over (row, path, sibling) descriptors
     {
         std::vector<GatherDesc> descs;
-        descs.reserve((size_t)Q * (4 + 2 * H + (size_t)L * (H + 1)));
+        descs.reserve((size_t)Q * (4 + 3 * H + (size_t)RL * (H + arity)));
         size_t qpos = 0;   // word offset inside the query section
         auto push = [&](const uint32_t* src, size_t nwords) { descs.push_back(GatherDesc{src, (uint32_t)qpos, (uint32_t)nwords}); qpos += nwords; };
         auto push_path = [&](const uint32_t* tree, size_t leaves, size_t index, int levels) {
@@ -506,12 +581,13 @@ int zkhip_prove_shard(zkhip_ctx* ctx, const uint32_t* d_trace, size_t ld, int lo
             push(qlde + index * 8, 8);
             push_path(qtree, m, index, H);
             size_t idx = index;
-            for (int l = 0; l < L; l++) {
-                const int lh = H - 1 - l;
-                const size_t sib = idx ^ 1, pair = idx >> 1;
-                push(layers + layer_off[l] + sib * 4, 4);
-                push_path(ltrees + tree_off[l], (size_t)1 << lh, pair, lh);
-                idx = pair;
+            for (int l = 0; l < RL; l++) {
+                const int lh = H - K * (l + 1);
+                const size_t row = idx >> K, own = idx & (arity - 1);
+                for (size_t j = 0; j < arity; j++)
+                    if (j != own) push(layers + layer_off[l] + (row * arity + j) * 4, 4);
+                push_path(ltrees + tree_off[l], (size_t)1 << lh, row, lh);
+                idx = row;
             }
         }
         if (pos + qpos != need / 4) return fail(ZKHIP_ERR_INTERNAL, "prove_shard: proof layout mismatch");
@@ -534,21 +610,44 @@ int zkhip_prove_shard(zkhip_ctx* ctx, const uint32_t* d_trace, size_t ld, int lo
 
 // ---------------------------------------------------------------- verifier (host CPU)
 static bool verify_path(const uint32_t* root_m, int log_h, size_t index, const uint32_t* row_canon, size_t width,
-                        const uint32_t* sibs_canon) {
-    uint32_t s[16] = {0};
-    size_t posn = 0;
-    for (size_t i = 0; i < width; i++) {
-        s[posn++] = to_monty(row_canon[i]);
-        if (posn == 8) { p2_permute(s); posn = 0; }
-    }
-    if (posn) p2_permute(s);
+                        const uint32_t* sibs_canon, int hw) {
     uint32_t cur[8];
-    for (int i = 0; i < 8; i++) cur[i] = s[i];
-    for (int lvl = 0; lvl < log_h; lvl++) {
-        uint32_t sib[8];
-        for (int i = 0; i < 8; i++) sib[i] = to_monty(sibs_canon[8 * lvl + i]);
-        if ((index >> lvl) & 1) p2_compress(sib, cur, cur);
-        else p2_compress(cur, sib, cur);
+    if (hw == 24) {
+        // Poseidon2 width 24: sponge rate 16, compress(l, r) = permute(l || r || 0^8)[0..8]
+        uint32_t s[24] = {0};
+        size_t posn = 0;
+        for (size_t i = 0; i < width; i++) {
+            s[posn++] = to_monty(row_canon[i]);
+            if (posn == 16) { p24_permute(s); posn = 0; }
+        }
+        if (posn) p24_permute(s);
+        for (int i = 0; i < 8; i++) cur[i] = s[i];
+        for (int lvl = 0; lvl < log_h; lvl++) {
+            uint32_t t[24] = {0};
+            const bool right = (index >> lvl) & 1;
+            for (int i = 0; i < 8; i++) {
+                const uint32_t sib = to_monty(sibs_canon[8 * lvl + i]);
+                t[i] = right ? sib : cur[i];
+                t[8 + i] = right ? cur[i] : sib;
+            }
+            p24_permute(t);
+            for (int i = 0; i < 8; i++) cur[i] = t[i];
+        }
+    } else {
+        uint32_t s[16] = {0};
+        size_t posn = 0;
+        for (size_t i = 0; i < width; i++) {
+            s[posn++] = to_monty(row_canon[i]);
+            if (posn == 8) { p2_permute(s); posn = 0; }
+        }
+        if (posn) p2_permute(s);
+        for (int i = 0; i < 8; i++) cur[i] = s[i];
+        for (int lvl = 0; lvl < log_h; lvl++) {
+            uint32_t sib[8];
+            for (int i = 0; i < 8; i++) sib[i] = to_monty(sibs_canon[8 * lvl + i]);
+            if ((index >> lvl) & 1) p2_compress(sib, cur, cur);
+            else p2_compress(cur, sib, cur);
+        }
     }
     for (int i = 0; i < 8; i++) if (cur[i] != root_m[i]) return false;
     return true;
@@ -558,6 +657,21 @@ static Ext fri_fold_row(size_t index, int log_folded_h, const Ext& beta, const E
     const uint32_t x = fpow(two_adic_generator(log_folded_h + 1), reverse_bits((uint32_t)index, log_folded_h));
     const uint32_t inv = finv(fneg(fadd(x, x)));
     return ext_add(e0, ext_mul_base(ext_mul(ext_sub_base(beta, x), ext_sub(e1, e0)), inv));
+}
+
+// a committed FRI row of 2^K adjacent entries folded K times by 2 with beta, beta^2, ...; `row_index` is the
+// row's index in the layer matrix of 2^log_rows rows
+static Ext fold_row_k(size_t row_index, int log_rows, int K, Ext beta, const Ext* ev) {
+    Ext tmp[32];
+    size_t cnt = (size_t)1 << K;
+    for (size_t j = 0; j < cnt; j++) tmp[j] = ev[j];
+    for (int j = 0; j < K; j++) {
+        cnt >>= 1;
+        const int log_folded = log_rows + (K - 1 - j);
+        for (size_t t = 0; t < cnt; t++) tmp[t] = fri_fold_row(row_index * cnt + t, log_folded, beta, tmp[2 * t], tmp[2 * t + 1]);
+        beta = ext_mul(beta, beta);
+    }
+    return tmp[0];
 }
 
 // value at zeta of an extension column committed as 4 base columns: sum_e x^e * v_e(zeta)
@@ -581,19 +695,24 @@ int zkhip_verify_shard(const uint8_t* proof, size_t len, int log_n, uint32_t wid
     if (!proof || (n_public && !public_values)) return reject(1);
     if (len != proof_words(log_n, width, prm) * 4) return reject(2);
     const uint32_t* pf = (const uint32_t*)proof;
-    const int H = log_n + 1, L = log_n;
-    const size_t n = (size_t)1 << log_n;
+    Shape sh;
+    shape_of(log_n, prm, sh);
+    const int H = log_n + sh.b, Hq = log_n + 1, RL = sh.R, K = sh.K;
+    const size_t n = (size_t)1 << log_n, arity = (size_t)1 << K;
     const uint32_t LQ = (uint32_t)prm->logup_pairs;
     const size_t wp = LQ ? 4 * ((size_t)LQ + 1) : 0;
-    if (pf[0] != PROOF_MAGIC || pf[1] != (LQ ? 2u : PROOF_VERSION) || pf[2] != (uint32_t)log_n || pf[3] != width ||
+    if (pf[0] != PROOF_MAGIC || pf[1] != (sh.ext ? 3u : (LQ ? 2u : PROOF_VERSION)) || pf[2] != (uint32_t)log_n || pf[3] != width ||
         pf[4] != (uint32_t)prm->log_blowup || pf[5] != (uint32_t)prm->num_queries || pf[6] != (uint32_t)prm->pow_bits ||
         pf[7] != (uint32_t)n_public) return reject(3);
     size_t pos = 8;
-    if (LQ) { if (pf[8] != LQ) return reject(3); pos = 9; }
+    if (sh.ext) {
+        if (pf[8] != LQ || pf[9] != (uint32_t)sh.K || pf[10] != (uint32_t)sh.F || pf[11] != (uint32_t)sh.hw) return reject(3);
+        pos = 12;
+    } else if (LQ) { if (pf[8] != LQ) return reject(3); pos = 9; }
     for (size_t i = pos; i < len / 4; i++) if (pf[i] >= P) return reject(4);
     for (size_t i = 0; i < n_public; i++) if (public_values[i] >= P) return reject(4);
     Challenger ch;
-    transcript_init(ch, log_n, width, prm, n_public);
+    transcript_init(ch, log_n, width, prm, n_public, sh);
     uint32_t troot[8], proot[8], qroot[8];
     for (int i = 0; i < 8; i++) { troot[i] = to_monty(pf[pos++]); }
     for (int i = 0; i < 8; i++) ch.observe(troot[i]);
@@ -663,7 +782,7 @@ int zkhip_verify_shard(const uint8_t* proof, size_t len, int log_n, uint32_t wid
             acc = ext_add(ext_mul(acc, alpha), ext_mul(sel_trans, ext_sub(ext_sub(Sn, S), sum_n)));
             acc = ext_add(ext_mul(acc, alpha), ext_mul(sel_last, S));
         }
-        const uint32_t w2n = two_adic_generator(H);
+        const uint32_t w2n = two_adic_generator(Hq);
         const uint32_t s[2] = {MONTY_GEN, fmul(MONTY_GEN, w2n)};
         Ext quot = ext_zero();
         for (int k = 0; k < 2; k++) {
@@ -696,19 +815,19 @@ int zkhip_verify_shard(const uint8_t* proof, size_t len, int log_n, uint32_t wid
     for (int j = 0; j < 8; j++) y_q = ext_add(y_q, ext_mul(fapow[j], opq[j]));
     const Ext off_next = ext_pow(fa, width), off_pl = ext_pow(fa, 2 * (uint64_t)width),
               off_pn = ext_pow(fa, 2 * (uint64_t)width + wp), off_q = ext_pow(fa, 2 * (uint64_t)width + 2 * wp);
-    std::vector<uint32_t> commits((size_t)L * 8);
-    std::vector<Ext> betas(L);
-    for (int l = 0; l < L; l++) {
+    std::vector<uint32_t> commits((size_t)RL * 8 + 8);
+    std::vector<Ext> betas(RL + 1);
+    for (int l = 0; l < RL; l++) {
         for (int i = 0; i < 8; i++) { commits[8 * l + i] = to_monty(pf[pos++]); ch.observe(commits[8 * l + i]); }
         betas[l] = ch.sample_ext();
     }
-    const Ext final_poly = ext_from_canon(pf + pos);
-    pos += 4;
-    ch.observe_ext(final_poly);
+    const size_t keep = (size_t)1 << sh.F;
+    std::vector<Ext> final_poly(keep);            // coefficients, lowest first
+    for (size_t i = 0; i < keep; i++) { final_poly[i] = ext_from_canon(pf + pos); pos += 4; ch.observe_ext(final_poly[i]); }
     const uint32_t witness = pf[pos++];
     ch.observe_canonical(witness);
     if (ch.sample_bits(prm->pow_bits) != 0) return reject(20);
-    const uint32_t w2n = two_adic_generator(H);
+    const uint32_t wm = two_adic_generator(H);
     for (int q = 0; q < prm->num_queries; q++) {
         const size_t index = ch.sample_bits(H);
         const uint32_t* trow = pf + pos; pos += width;
@@ -717,10 +836,10 @@ int zkhip_verify_shard(const uint8_t* proof, size_t len, int log_n, uint32_t wid
         if (LQ) { prow = pf + pos; pos += wp; ppath = pf + pos; pos += 8 * (size_t)H; }
         const uint32_t* qrow = pf + pos; pos += 8;
         const uint32_t* qpath = pf + pos; pos += 8 * (size_t)H;
-        if (!verify_path(troot, H, index, trow, width, tpath)) return reject(30);
-        if (LQ && !verify_path(proot, H, index, prow, wp, ppath)) return reject(32);
-        if (!verify_path(qroot, H, index, qrow, 8, qpath)) return reject(31);
-        const uint32_t x = fmul(MONTY_GEN, fpow(w2n, reverse_bits((uint32_t)index, H)));
+        if (!verify_path(troot, H, index, trow, width, tpath, sh.hw)) return reject(30);
+        if (LQ && !verify_path(proot, H, index, prow, wp, ppath, sh.hw)) return reject(32);
+        if (!verify_path(qroot, H, index, qrow, 8, qpath, sh.hw)) return reject(31);
+        const uint32_t x = fmul(MONTY_GEN, fpow(wm, reverse_bits((uint32_t)index, H)));
         const Ext d1 = ext_inv(ext_neg(ext_sub_base(zeta, x)));
         const Ext d2 = ext_inv(ext_neg(ext_sub_base(zeta_next, x)));
         Ext at = ext_zero(), ap = ext_zero(), aq = ext_zero();
@@ -735,23 +854,28 @@ int zkhip_verify_shard(const uint8_t* proof, size_t len, int log_n, uint32_t wid
         }
         folded = ext_add(folded, ext_mul(off_q, ext_mul(ext_sub(aq, y_q), d1)));
         size_t idx = index;
-        for (int l = 0; l < L; l++) {
-            const int lh = H - 1 - l;
-            const Ext sib = ext_from_canon(pf + pos);
-            const uint32_t* sib_canon = pf + pos;
-            pos += 4;
+        for (int l = 0; l < RL; l++) {
+            const int lh = H - K * (l + 1);
+            const size_t row = idx >> K, own = idx & (arity - 1);
+            Ext ev[32];
+            uint32_t rowbuf[4 * 32];
+            for (size_t j = 0; j < arity; j++) {
+                if (j == own) { ev[j] = folded; for (int i = 0; i < 4; i++) rowbuf[4 * j + i] = from_monty(folded.c[i]); }
+                else { ev[j] = ext_from_canon(pf + pos); for (int i = 0; i < 4; i++) rowbuf[4 * j + i] = pf[pos + i]; pos += 4; }
+            }
             const uint32_t* path = pf + pos; pos += 8 * (size_t)lh;
-            Ext ev[2];
-            ev[idx & 1] = folded; ev[(idx & 1) ^ 1] = sib;
-            uint32_t rowbuf[8];
-            for (int i = 0; i < 4; i++) rowbuf[4 * (idx & 1) + i] = from_monty(folded.c[i]);
-            for (int i = 0; i < 4; i++) rowbuf[4 * ((idx & 1) ^ 1) + i] = sib_canon[i];
-            const size_t pair = idx >> 1;
-            if (!verify_path(&commits[8 * l], lh, pair, rowbuf, 8, path)) return reject(40 + (l < 50 ? l : 50));
-            folded = fri_fold_row(pair, lh, betas[l], ev[0], ev[1]);
-            idx = pair;
+            if (!verify_path(&commits[8 * l], lh, row, rowbuf, 4 * arity, path, sh.hw)) return reject(40 + (l < 50 ? l : 50));
+            folded = fold_row_k(row, lh, K, betas[l], ev);
+            idx = row;
         }
-        if (!ext_eq(folded, final_poly)) return reject(100);
+        // the final polynomial at this query's point of the last domain <w_{2^(F+b)}> (Horner)
+        {
+            const int lf = sh.F + sh.b;
+            const uint32_t xf = fpow(two_adic_generator(lf), reverse_bits((uint32_t)idx, lf));
+            Ext v = ext_zero();
+            for (size_t i = keep; i-- > 0;) v = ext_add(ext_mul_base(v, xf), final_poly[i]);
+            if (!ext_eq(folded, v)) return reject(100);
+        }
     }
     if (pos * 4 != len) return reject(5);
     return ZKHIP_OK;

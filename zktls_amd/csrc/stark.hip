@@ -37,27 +37,33 @@ ZK_D Ext group_sum(Ext v, int width) {
 }
 
 // ------------------------------------------------------------------ domain tables
-__global__ void domain_tables_kernel(uint32_t* xs, uint32_t* sel_first, uint32_t* sel_last, uint32_t* itw, int log_n, uint32_t g_pow_n) {
+// LDE domain g <w_M>, M = 2^(log_n + log_blowup), bit-reversed: x_p = g w_M^bitrev(p).  The quotient domain
+// g <w_2N> is its first 2N positions (and x_p there is g w_2N^bitrev_2N(p)), so the selector tables have 2N entries.
+__global__ void domain_tables_kernel(uint32_t* xs, uint32_t* sel_first, uint32_t* sel_last, uint32_t* itw, int log_n, int log_blowup,
+                                     uint32_t g_pow_n) {
     const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
-    const int H = log_n + 1;
+    const int H = log_n + log_blowup, Hq = log_n + 1;
     if (p >= (1u << H)) return;
     const uint32_t e = __brev(p) >> (32 - H);
-    const uint32_t w2n = two_adic_generator(H);
-    const uint32_t x = fmul(MONTY_GEN, fpow(w2n, e));
+    const uint32_t wm = two_adic_generator(H);
+    const uint32_t x = fmul(MONTY_GEN, fpow(wm, e));
     xs[p] = x;
-    const uint32_t xn = (e & 1) ? fneg(g_pow_n) : g_pow_n;        // x^N = g^N (-1)^e
-    const uint32_t zh = fsub(xn, MONTY_R1);
-    sel_first[p] = fmul(zh, finv(fsub(x, MONTY_R1)));
-    sel_last[p] = fmul(zh, finv(fsub(x, finv(two_adic_generator(log_n)))));   // Z_H(x) / (x - w_N^-1)
-    if (p < (1u << log_n)) {
-        const uint32_t ei = log_n ? (__brev(p) >> (32 - log_n)) : 0u;
-        itw[p] = fmul(finv(fpow(w2n, ei)), MONTY_INV2);            // 1 / (2 w_2N^bitrev_n(p))
+    if (p < (1u << Hq)) {
+        const uint32_t eq = __brev(p) >> (32 - Hq);
+        const uint32_t xn = (eq & 1) ? fneg(g_pow_n) : g_pow_n;       // x^N = g^N (-1)^eq
+        const uint32_t zh = fsub(xn, MONTY_R1);
+        sel_first[p] = fmul(zh, finv(fsub(x, MONTY_R1)));
+        sel_last[p] = fmul(zh, finv(fsub(x, finv(two_adic_generator(log_n)))));   // Z_H(x) / (x - w_N^-1)
+    }
+    if (p < (1u << (H - 1))) {
+        const uint32_t ei = (H > 1) ? (__brev(p) >> (32 - (H - 1))) : 0u;
+        itw[p] = fmul(finv(fpow(wm, ei)), MONTY_INV2);                  // 1 / (2 w_M^bitrev(p))
     }
 }
-hipError_t launch_domain_tables(uint32_t* xs, uint32_t* sel_first, uint32_t* sel_last, uint32_t* itw, int log_n, hipStream_t s) {
-    const uint32_t m = 2u << log_n;
+hipError_t launch_domain_tables(uint32_t* xs, uint32_t* sel_first, uint32_t* sel_last, uint32_t* itw, int log_n, int log_blowup, hipStream_t s) {
+    const uint32_t m = 1u << (log_n + log_blowup);
     const uint32_t gpn = fpow(MONTY_GEN, (uint64_t)1 << log_n);
-    hipLaunchKernelGGL(domain_tables_kernel, dim3((m + 255) / 256), dim3(256), 0, s, xs, sel_first, sel_last, itw, log_n, gpn);
+    hipLaunchKernelGGL(domain_tables_kernel, dim3((m + 255) / 256), dim3(256), 0, s, xs, sel_first, sel_last, itw, log_n, log_blowup, gpn);
     return hipGetLastError();
 }
 
