@@ -193,6 +193,13 @@ size_t zkhip_proof_size(int log_n, uint32_t width, const zkhip_params* prm, size
 int zkhip_prove_shard(zkhip_ctx* ctx, const uint32_t* d_trace, size_t ld, int log_n,
                       uint32_t width, const uint32_t* public_values, size_t n_public,
                       const zkhip_params* prm, uint8_t* proof, size_t cap, size_t* len);
+/* Segment proof from RISC Zero's data layout (risc0-zkp Hal, reference Cargo.lock:5057; call site
+ * crates/guest-prover-r0/src/prover.rs:90): d_cols holds `width` contiguous columns of 2^log_n words
+ * (column-major [width][2^log_n], Montgomery).  Same proof as zkhip_prove_shard on the transposed matrix;
+ * use the RISC-Zero-like zkhip_params for its shape.  Verified by zkhip_verify_shard. */
+int zkhip_prove_segment(zkhip_ctx* ctx, const uint32_t* d_cols, int log_n, uint32_t width,
+                        const uint32_t* public_values, size_t n_public, const zkhip_params* prm,
+                        uint8_t* proof, size_t cap, size_t* len);
 /* host-side verifier (CPU; the reference verifies on the CPU too, sp1.rs:120).
  * Returns ZKHIP_OK or ZKHIP_ERR_VERIFY; *reason (optional) gets the failing check. */
 int zkhip_verify_shard(const uint8_t* proof, size_t len, int log_n, uint32_t width,

@@ -62,6 +62,20 @@ def main():
             "pow_witness": d["pow_witness"],
         }
     out["proofs"] = proofs
+    # other proof-system shapes: (log_blowup, queries, pow_bits, logup_pairs, log_fold, log_final, hash_width);
+    # "r0_*" are RISC Zero's parameters (blowup 4, fold 16, Poseidon2 width 24, no PoW) at small sizes
+    shapes = {}
+    for name, (log_n, w, shape) in {"r0_10x16": (10, 16, (2, 50, 0, 0, 4, 2, 24)), "r0_12x32": (12, 32, (2, 50, 0, 0, 4, 8, 24)),
+                                    "r0_lookup_10x32": (10, 32, (2, 20, 0, 2, 4, 6, 24)), "blowup4_9x8": (9, 8, (2, 10, 8, 0, 1, 0, 16)),
+                                    "fold8_9x8": (9, 8, (1, 10, 8, 0, 3, 0, 16))}.items():
+        pairs = shape[3]
+        t = O.gen_trace_logup(SEED, 5, log_n, w, pairs) if pairs else O.gen_trace(SEED, 5, log_n, w)
+        prm = O.default_params(*shape)
+        pf = O.prove_shard(t, [1, 2, 3], prm)
+        assert O.verify_shard(pf, log_n, w, [1, 2, 3], prm) == 0
+        shapes[name] = {"log_n": log_n, "width": w, "shape": list(shape), "shard": 5, "public": [1, 2, 3],
+                        "bytes": int(pf.size), "sha256": hashlib.sha256(pf.tobytes()).hexdigest()}
+    out["shape_proofs"] = shapes
     with open(os.path.join(HERE, "oracle_kat.json"), "w") as f:
         json.dump(out, f, indent=1)
     print("wrote oracle_kat.json")

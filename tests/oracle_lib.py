@@ -168,6 +168,15 @@ def merkle_tree_p24_colmajor(mat):
     return out
 
 
+def merkle_tree_hw(mat, hash_width):
+    """one row-major matrix, hash selected by width (16 or 24); all levels, root last"""
+    m = _u32(mat)
+    rows, w = m.shape
+    out = np.empty((2 * rows - 1, 8), dtype=np.uint32)
+    lib().orc_merkle_tree_hw(_p(m), C.c_size_t(w), C.c_int(rows.bit_length() - 1), _p(out), C.c_int(hash_width))
+    return out
+
+
 def _mats_args(mats):
     mats = [_u32(m) for m in mats]
     ptrs = (u32p * len(mats))(*[_p(m) for m in mats])
@@ -288,6 +297,10 @@ def quotient_values_logup(lde, log_n, perm_lde, pairs, gamma, beta, alpha):
     lib().orc_quotient_values_logup(_p(lde), C.c_int(log_n), C.c_size_t(lde.shape[1]), _p(perm_lde), C.c_int(pairs),
                                     _p(g), _p(b), _p(a), _p(out))
     return out
+
+
+def proof_size(log_n, width, params, n_public=0):
+    return int(lib().orc_proof_size(C.c_int(log_n), C.c_size_t(width), C.byref(params), C.c_size_t(n_public)))
 
 
 def prove_shard(trace, public_values=(), params=None):

@@ -63,3 +63,19 @@ def test_fullsize_shard_proof_verifies(ctx, oracle):
     # proving the same shard again gives the same bytes (deterministic PoW, no races)
     again = ctx.prove_shard(trace, LOG_N, WIDTH, [1, 2, 3], prm)
     assert again.tobytes() == proof.tobytes()
+
+
+def test_fullsize_segment_proof_risc0_shape_verifies(ctx, oracle):
+    # BASELINE.json configs[4]: one 2^20-cycle segment, RISC Zero's shape (blowup 4, fold 16, final 256
+    # coefficients, 50 queries, Poseidon2 width 24); 128 columns keep the 4x LDE at 2 GiB
+    from zktls_amd._lib import segment_params
+    width = 128
+    trace = ctx.gen_trace(SEED, 6, LOG_N, width)
+    prm = segment_params()
+    proof = ctx.prove_shard(trace, LOG_N, width, [1, 2, 3], prm)
+    assert verify_shard(proof, LOG_N, width, [1, 2, 3], prm) == (0, 0)
+    assert oracle.verify_shard(proof, LOG_N, width, [1, 2, 3], oracle.segment_params()) == 0
+    bad = proof.copy().view(np.uint32)
+    bad[-3] = (int(bad[-3]) + 1) % P
+    assert verify_shard(bad.view(np.uint8), LOG_N, width, [1, 2, 3], prm)[0] == -6
+    trace.free()

@@ -197,3 +197,26 @@ def test_shape_that_does_not_divide_is_refused(ctx):
         ctx.prove_shard(trace, 10, 8, [], Params(2, 10, 0, 0, 4, 0, 24))     # (10 - 0) % 4 != 0
     with pytest.raises(ZkHipError):
         ctx.prove_shard(trace, 10, 8, [], Params(2, 10, 0, 0, 4, 2, 20))     # hash width
+
+
+@pytest.mark.parametrize("name", sorted(KAT["shape_proofs"]))
+def test_golden_shape_proofs_on_gpu(ctx, name):
+    g = KAT["shape_proofs"][name]
+    pairs = g["shape"][3]
+    trace = ctx.gen_trace_logup(SEED, g["shard"], g["log_n"], g["width"], pairs) if pairs else ctx.gen_trace(SEED, g["shard"], g["log_n"], g["width"])
+    proof = ctx.prove_shard(trace, g["log_n"], g["width"], g["public"], Params(*g["shape"]))
+    assert proof.size == g["bytes"]
+    assert hashlib.sha256(proof.tobytes()).hexdigest() == g["sha256"]
+
+
+@pytest.mark.parametrize("log_n,width", [(8, 8), (12, 32), (14, 40)])
+def test_prove_segment_from_column_major_equals_oracle(ctx, oracle, log_n, width):
+    # RISC Zero's Hal layout: `width` contiguous columns; RISC-Zero-like shape; bytes equal the oracle's proof of the same trace
+    from zktls_amd._lib import segment_params
+    t = oracle.gen_trace(SEED, 9, log_n, width)
+    cols = ctx.from_numpy(np.ascontiguousarray(t.T))
+    lf = {8: 4, 12: 8, 14: 6}[log_n]
+    proof = ctx.prove_segment(cols, log_n, width, [5], segment_params(50, 0, lf))
+    oproof = oracle.prove_shard(t, [5], oracle.segment_params(50, 0, lf))
+    assert proof.tobytes() == oproof.tobytes()
+    assert verify_shard(proof, log_n, width, [5], segment_params(50, 0, lf)) == (0, 0)

@@ -61,3 +61,21 @@ def test_host_verifier_logup_proofs(oracle, log_n, width, pairs):
         bad[i] = (int(bad[i]) + 1) % P
         rc, reason = verify_shard(bad.view(np.uint8), log_n, width, [4, 5], prm)
         assert rc == -6 and reason == oracle.verify_shard(bad.view(np.uint8), log_n, width, [4, 5], oprm), i
+
+
+@pytest.mark.parametrize("log_n,width,shape", [(8, 8, (2, 10, 4, 0, 4, 0, 24)), (10, 16, (2, 20, 0, 0, 4, 2, 24)),
+                                               (12, 16, (2, 50, 0, 0, 4, 8, 24)), (10, 32, (2, 20, 0, 2, 4, 6, 24)),
+                                               (9, 8, (2, 10, 8, 0, 1, 0, 16)), (9, 8, (1, 10, 8, 0, 3, 0, 16)),
+                                               (10, 8, (3, 10, 0, 0, 2, 4, 16))])
+def test_host_verifier_agrees_with_oracle_on_other_shapes(oracle, log_n, width, shape):
+    # RISC-Zero-like and intermediate shapes: the C++ (Montgomery) verifier of the product accepts the oracle's
+    # proofs and rejects corruptions with the same reason code
+    pairs = shape[3]
+    t = oracle.gen_trace_logup(SEED, 2, log_n, width, pairs) if pairs else oracle.gen_trace(SEED, 2, log_n, width)
+    oprm, prm = oracle.default_params(*shape), Params(*shape)
+    pf = oracle.prove_shard(t, [4, 5], oprm)
+    assert verify_shard(pf, log_n, width, [4, 5], prm) == (0, 0)
+    for frac in (0.05, 0.2, 0.4, 0.6, 0.8, 0.97):
+        bad = pf.copy(); bad[int(pf.size * frac)] ^= 2
+        rc, reason = verify_shard(bad, log_n, width, [4, 5], prm)
+        assert rc == -6 and reason == oracle.verify_shard(bad, log_n, width, [4, 5], oprm)

@@ -403,3 +403,63 @@ def test_poseidon2_width24_against_python_definition(oracle):
     assert tree[3].tolist() == pyref.sponge24(mat[:, 3].tolist())
     assert tree[8].tolist() == pyref.compress24(tree[0].tolist(), tree[1].tolist())
     assert tree[-1].tolist() == pyref.compress24(tree[-3].tolist(), tree[-2].tolist())
+
+
+# ------------------------------------------------------------------ other proof-system shapes (RISC-Zero-like: row a11)
+def test_width24_rowmajor_tree_matches_first_principles(oracle):
+    rng = np.random.default_rng(24)
+    m = rng.integers(0, P, size=(8, 20), dtype=np.uint32)
+    tree = oracle.merkle_tree_hw(m, 24)
+    leaves = [pyref.sponge24(m[r].tolist()) for r in range(8)]
+    assert tree[:8].tolist() == leaves
+    lvl = leaves
+    pos = 8
+    while len(lvl) > 1:
+        lvl = [pyref.compress24(lvl[2 * i], lvl[2 * i + 1]) for i in range(len(lvl) // 2)]
+        assert tree[pos:pos + len(lvl)].tolist() == lvl
+        pos += len(lvl)
+    assert (oracle.merkle_tree_hw(m, 16) == oracle.merkle_tree([m])).all()
+
+
+@pytest.mark.parametrize("name", sorted(KAT["shape_proofs"]))
+def test_golden_shape_proofs(oracle, name):
+    g = KAT["shape_proofs"][name]
+    pairs = g["shape"][3]
+    t = oracle.gen_trace_logup(SEED, g["shard"], g["log_n"], g["width"], pairs) if pairs else oracle.gen_trace(SEED, g["shard"], g["log_n"], g["width"])
+    prm = oracle.default_params(*g["shape"])
+    pf = oracle.prove_shard(t, g["public"], prm)
+    assert pf.size == g["bytes"] == oracle.proof_size(g["log_n"], g["width"], prm, len(g["public"]))
+    assert hashlib.sha256(pf.tobytes()).hexdigest() == g["sha256"]
+    assert oracle.verify_shard(pf, g["log_n"], g["width"], g["public"], prm) == 0
+
+
+@pytest.mark.parametrize("shape", [(2, 10, 4, 0, 4, 0, 24), (2, 10, 0, 0, 4, 4, 24), (1, 10, 4, 0, 2, 2, 16), (3, 6, 0, 1, 1, 0, 24)])
+def test_shape_verifier_rejects_corruptions_and_wrong_shape(oracle, shape):
+    log_n, w = 8, 8
+    pairs = shape[3]
+    t = oracle.gen_trace_logup(SEED, 1, log_n, w, pairs) if pairs else oracle.gen_trace(SEED, 1, log_n, w)
+    prm = oracle.default_params(*shape)
+    pf = oracle.prove_shard(t, [9], prm)
+    assert oracle.verify_shard(pf, log_n, w, [9], prm) == 0
+    assert oracle.verify_shard(pf, log_n, w, [8], prm) != 0                      # other public values
+    other = list(shape); other[6] = 16 if shape[6] == 24 else 24
+    assert oracle.verify_shard(pf, log_n, w, [9], oracle.default_params(*other)) != 0
+    step = max(1, pf.size // 97)
+    for off in range(48, pf.size, step):                                        # one flipped bit anywhere after the header
+        bad = pf.copy(); bad[off] ^= 4
+        assert oracle.verify_shard(bad, log_n, w, [9], prm) != 0, off
+    # a trace that violates the AIR: whatever the prover emits, the AIR identity at zeta fails (check 10)
+    t2 = t.copy(); t2[5, 2] = (int(t2[5, 2]) + 1) % P
+    try:
+        pf2 = oracle.prove_shard(t2, [9], prm)
+    except RuntimeError:
+        return
+    assert oracle.verify_shard(pf2, log_n, w, [9], prm) == 10
+
+
+def test_default_shape_fields_are_the_sp1_shape(oracle):
+    t = oracle.gen_trace(SEED, 0, 6, 8)
+    a = oracle.prove_shard(t, [], oracle.default_params(1, 10, 8, 0, 0, 0, 0))
+    b = oracle.prove_shard(t, [], oracle.default_params(1, 10, 8, 0, 1, 0, 16))
+    assert a.tobytes() == b.tobytes()
+    assert oracle.proof_size(10, 8, oracle.default_params(2, 10, 0, 0, 4, 0, 24), 0) == 0     # (10 - 0) % 4 != 0

@@ -608,6 +608,21 @@ int zkhip_prove_shard(zkhip_ctx* ctx, const uint32_t* d_trace, size_t ld, int lo
     return ZKHIP_OK;
 }
 
+int zkhip_prove_segment(zkhip_ctx* ctx, const uint32_t* d_cols, int log_n, uint32_t width,
+                        const uint32_t* public_values, size_t n_public, const zkhip_params* prm,
+                        uint8_t* proof, size_t cap, size_t* len) {
+    CHECK_CTX(ctx);
+    ZK_TRY(check_shape(log_n, width, prm));
+    if (!d_cols) return fail(ZKHIP_ERR_INVALID, "prove_segment: null trace");
+    // the prover's kernels stream row-major rows (leaf hashing, quotient, openings all want whole rows):
+    // one tiled transpose in HBM, then the common path
+    const uint64_t n = (uint64_t)1 << log_n;
+    void* rows;
+    ZK_TRY(ctx_reserve(ctx, 21, n * width * 4, &rows));
+    ZK_HIP(launch_transpose(d_cols, (uint32_t*)rows, width, n, 0, 0, ctx->stream));
+    return zkhip_prove_shard(ctx, (const uint32_t*)rows, width, log_n, width, public_values, n_public, prm, proof, cap, len);
+}
+
 // ---------------------------------------------------------------- verifier (host CPU)
 static bool verify_path(const uint32_t* root_m, int log_h, size_t index, const uint32_t* row_canon, size_t width,
                         const uint32_t* sibs_canon, int hw) {

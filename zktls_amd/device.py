@@ -224,6 +224,18 @@ class Context:
                                          buf.ctypes.data_as(u8p), size, C.byref(got)))
         return buf[: got.value]
 
+    def prove_segment(self, cols, log_n, width, public_values=(), params=None):
+        """cols: device buffer, column-major [width][2^log_n] (RISC Zero's Hal layout)"""
+        params = params or _lib.segment_params()
+        pv = np.ascontiguousarray(np.array(public_values, dtype=np.uint32))
+        size = self.lib.zkhip_proof_size(log_n, width, C.byref(params), pv.size)
+        buf = np.empty(size, dtype=np.uint8)
+        got = C.c_size_t(0)
+        check(self.lib.zkhip_prove_segment(self.handle, C.c_void_p(cols.ptr), log_n, width,
+                                           pv.ctypes.data_as(u32p), pv.size, C.byref(params),
+                                           buf.ctypes.data_as(u8p), size, C.byref(got)))
+        return buf[: got.value]
+
     def prove_debug(self):
         d = ProveDebug()
         check(self.lib.zkhip_last_prove_debug(self.handle, C.byref(d)))
