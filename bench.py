@@ -35,6 +35,9 @@ def main():
     ap.add_argument("--log-n", type=int, default=20)
     ap.add_argument("--width", type=int, default=256)
     ap.add_argument("--logup-pairs", type=int, default=0, help="LogUp lookup pairs (SURVEY 8a row a8); 0 = main AIR only")
+    ap.add_argument("--shape", choices=("sp1", "r0"), default="sp1",
+                    help="proof-system shape: sp1 = the headline (blowup 2, 100 queries, 16 PoW bits, fold by 2, Poseidon2-16); "
+                         "r0 = RISC-Zero-like (blowup 4, 50 queries, fold by 16, 256 final coefficients, Poseidon2-24)")
     ap.add_argument("--streams", type=int, default=3, help="shards in flight per GPU: each on its own context + HIP stream")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-log-n", type=int, default=19, help="rows of the bounded CPU-baseline sample")
@@ -68,7 +71,7 @@ def main():
     n = 1 << log_n
     cells = n * width
     LQ = args.logup_pairs
-    prm = Params(1, 100, 16, LQ)
+    prm = Params(1, 100, 16, LQ) if args.shape == "sp1" else Params(2, 50, 0, LQ, 4, 8, 24)
     # one context (= one HIP stream + its workspaces) per shard in flight: while one shard sits in a
     # latency-bound stretch (small FRI layers, host round trips) the other keeps the CUs busy
     S = max(1, args.streams)
@@ -195,12 +198,13 @@ def main():
         used = O.set_threads(args.cpu_threads if args.cpu_threads > 0 else min(cores, 64))
         cl = args.cpu_log_n
         tr = O.gen_trace_logup(SEED, 0, cl, width, LQ) if LQ else O.gen_trace(SEED, 0, cl, width)
-        oprm = O.default_params(1, 100, 16, LQ)
+        oprm = O.default_params(1, 100, 16, LQ) if args.shape == "sp1" else O.default_params(2, 50, 0, LQ, 4, 8, 24)
         tc0 = time.perf_counter()
         O.prove_shard(tr, public + [0], oprm)
         dt = time.perf_counter() - tc0
         cpu = {"value": round((width << cl) / dt, 1), "unit": "trace-cells/s", "cores": used, "kind": "port",
-               "sample": "one 2^%d x %d shard proof (same AIR, log_blowup 1, 100 queries, 16 PoW bits), %.1f s, scalar C oracle + OpenMP on %d of %d host cores" % (cl, width, dt, used, cores)}
+               "sample": "one 2^%d x %d shard proof (same AIR, %s), %.1f s, scalar C oracle + OpenMP on %d of %d host cores" % (
+                   cl, width, "log_blowup 1, 100 queries, 16 PoW bits" if args.shape == "sp1" else "RISC-Zero-like shape", dt, used, cores)}
 
     if rank == 0:
         total_cells = cells * K * world
@@ -218,7 +222,9 @@ def main():
             "dtype": "u32",
             "data": "synthetic",
             "streams_per_gpu": S,
-            "config": {"workload": "SP1-core-like synthetic shard: 2^%d rows x %d cols BabyBear, log_blowup 1, 100 queries, 16 PoW bits, %s, full prove_shard" % (log_n, width, ("LogUp x%d" % LQ) if LQ else "no lookups"),
+            "config": {"workload": ("SP1-core-like synthetic shard: 2^%d rows x %d cols BabyBear, log_blowup 1, 100 queries, 16 PoW bits, %s, full prove_shard" if args.shape == "sp1" else
+                                    "RISC-Zero-like synthetic segment: 2^%d rows x %d cols BabyBear, blowup 4, 50 queries, FRI fold 16, 256 final coefficients, Poseidon2 width 24, %s, full prove_shard")
+                                   % (log_n, width, ("LogUp x%d" % LQ) if LQ else "no lookups"),
                        "parallelism": "shard-parallel x%d" % world, "shards_per_step": world},
             "proofs_per_s": round(K * world / elapsed, 3),
             "proof_bytes": int(last.size),
