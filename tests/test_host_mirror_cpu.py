@@ -22,16 +22,19 @@ def lib():
     u8pp, szp = C.POINTER(C.POINTER(C.c_uint8)), C.POINTER(C.c_size_t)
     L.zktls_guest_prove.argtypes = [C.c_int, C.c_int, C.POINTER(Plan), C.c_char_p, C.c_size_t, C.c_char_p, C.c_size_t,
                                     u8pp, szp, u8pp, szp, C.c_char_p, C.c_size_t]
+    L.zktls_guest_prove_r0.argtypes = L.zktls_guest_prove.argtypes
+    L.zktls_current_risc0_prover_env.restype = C.c_char_p
+    L.zktls_current_risc0_dev_mode_env.restype = C.c_char_p
     L.zktls_request_digest.argtypes = [C.c_char_p, C.c_size_t, C.c_char_p, C.c_size_t, C.POINTER(C.c_uint32)]
     L.zktls_unpack_batch.argtypes = [C.c_char_p, C.c_size_t, szp, szp, C.c_int]
     L.zktls_free.argtypes = [C.c_void_p]
     return L
 
 
-def call(L, mode, cbor, elf, plan=None, device=0):
+def call(L, mode, cbor, elf, plan=None, device=0, r0=False):
     out, outn, pr, prn = C.POINTER(C.c_uint8)(), C.c_size_t(), C.POINTER(C.c_uint8)(), C.c_size_t()
     err = C.create_string_buffer(512)
-    rc = L.zktls_guest_prove(device, mode, C.byref(plan) if plan else None, cbor, len(cbor), elf, len(elf),
+    rc = (L.zktls_guest_prove_r0 if r0 else L.zktls_guest_prove)(device, mode, C.byref(plan) if plan else None, cbor, len(cbor), elf, len(elf),
                              C.byref(out), C.byref(outn), C.byref(pr), C.byref(prn), err, 512)
     if rc != 0:
         return rc, err.value.decode(), None, None
@@ -89,3 +92,35 @@ def test_hip_mode_proves_and_packs_shards(lib):
         proof = np.frombuffer(blob[offs[s]:offs[s] + lens[s]], dtype=np.uint8)
         assert verify_shard(proof, 8, 8, digest + [s], Params(1, 10, 8)) == (0, 0)
         assert verify_shard(proof, 8, 8, digest + [s + 1], Params(1, 10, 8))[0] == -6
+
+
+def test_r0_twin_sets_risc0_env_and_keeps_the_rules(lib):
+    # crates/guest-prover-r0/src/prover.rs:19-28 (env), :101-103 (<= 4-byte rule)
+    rc, err, out, proof = call(lib, 0, b"\xa2input", b"\x7fELF....", r0=True)
+    assert rc == 0 and len(out) == 32 and proof == b""
+    assert lib.zktls_current_risc0_dev_mode_env() == b"true"
+    rc, err, _, _ = call(lib, 3, b"x", b"elf", r0=True)
+    assert rc != 0 and "network" in err
+    assert lib.zktls_current_risc0_prover_env() == b"bonsai"
+    from zktls_amd import _lib
+    if _lib.device_count() == 0:
+        rc, err, _, _ = call(lib, 1, b"x", b"elf", Plan(8, 8, 1, 100, 16), r0=True)
+        assert rc != 0 and "no CPU fallback" in err
+        assert lib.zktls_current_risc0_prover_env() == b"local"
+
+
+@pytest.mark.gpu
+def test_r0_twin_proves_segments_in_risc0_shape(lib):
+    from zktls_amd._lib import Params
+    from zktls_amd.device import verify_shard
+    plan = Plan(12, 8, 2, 100, 16)            # defaults -> 50 queries, no PoW; 2^12 rows -> 256 final coefficients
+    rc, err, out, blob = call(lib, 2, b"\xa1transcript", b"\x7fELFprog", plan, r0=True)
+    assert rc == 0, err
+    offs, lens = (C.c_size_t * 8)(), (C.c_size_t * 8)()
+    assert lib.zktls_unpack_batch(blob, len(blob), offs, lens, 8) == 2
+    digest = np.frombuffer(out, dtype=np.uint32).tolist()
+    prm = Params(2, 50, 0, 0, 4, 8, 24)
+    for s in range(2):
+        proof = np.frombuffer(blob[offs[s]:offs[s] + lens[s]], dtype=np.uint8)
+        assert verify_shard(proof, 12, 8, digest + [s], prm) == (0, 0)
+        assert verify_shard(proof, 12, 8, digest + [s], Params(1, 100, 16))[0] == -6     # not an SP1-shape proof

@@ -22,6 +22,14 @@ const char* prover_type_name(ProverType mode) {
 }
 
 void set_env(ProverType mode) { setenv("SP1_PROVER", prover_type_name(mode), 1); }   // sp1.rs:23-27
+void set_env_r0(ProverType mode) {                                                    // prover.rs:19-28
+    switch (mode) {
+        case ProverType::Mock: setenv("RISC0_DEV_MODE", "true", 1); break;
+        case ProverType::Local:
+        case ProverType::Hip: setenv("RISC0_PROVER", "local", 1); break;          // like the reference's Cuda arm
+        case ProverType::Network: setenv("RISC0_PROVER", "bonsai", 1); break;
+    }
+}
 
 // sponge over 3-byte limbs, length-prefixed and domain-separated; result canonical
 std::vector<uint32_t> request_digest(const std::vector<uint8_t>& cbor, const std::vector<uint8_t>& elf) {
@@ -93,7 +101,8 @@ struct CtxGuard {
 }  // namespace
 
 ProveResult HipGuestProver::prove(const GuestInput& input, const std::vector<uint8_t>& guest_program) {
-    set_env(mode_);                                   // sp1.rs:72
+    if (backend_ == Backend::Risc0) set_env_r0(mode_);   // prover.rs:65
+    else set_env(mode_);                              // sp1.rs:72
     const std::vector<uint8_t> elf = guest_program;   // sp1.rs:74: the ELF is copied once
     ProveResult r;
     try {                                             // sp1.rs:85: nothing may unwind past here
@@ -123,7 +132,14 @@ ProveResult HipGuestProver::prove_inner(const GuestInput& input, const std::vect
     if (mode_ == ProverType::Network) throw std::runtime_error("network proving is not provided by the HIP backend");
     // Local and Hip both mean "prove on this machine"; there is no CPU path in libzkhip
     if (plan_.shards == 0) throw std::runtime_error("shard plan is empty");
-    zkhip_params prm{1, plan_.num_queries, plan_.pow_bits, 0};
+    zkhip_params prm{1, plan_.num_queries, plan_.pow_bits, 0, 0, 0, 0};
+    if (backend_ == Backend::Risc0) {
+        // RISC Zero's shape; the final polynomial shrinks for segments too small for 256 coefficients
+        int lf = 8;
+        while (lf > plan_.log_n || (plan_.log_n - lf) % 4 != 0) lf--;
+        const bool defaults = plan_.num_queries == 100 && plan_.pow_bits == 16;
+        prm = zkhip_params{2, defaults ? 50 : plan_.num_queries, defaults ? 0 : plan_.pow_bits, 0, 4, lf, 24};
+    }
     const size_t cap = zkhip_proof_size(plan_.log_n, plan_.width, &prm, 9);
     if (cap == 0) throw std::runtime_error(std::string("bad shard plan: ") + zkhip_last_error());
     CtxGuard g;
@@ -163,10 +179,10 @@ struct zktls_shard_plan { int32_t log_n; uint32_t width; uint32_t shards; int32_
 
 // mode: 0 mock, 1 local, 2 hip, 3 network.  Returns 0 on success; on failure copies the
 // message into err.  *output / *proof are malloc'd (zktls_free).
-int zktls_guest_prove(int device, int mode, const zktls_shard_plan* plan, const uint8_t* cbor, size_t cbor_len,
-                      const uint8_t* elf, size_t elf_len, uint8_t** output, size_t* output_len, uint8_t** proof,
-                      size_t* proof_len, char* err, size_t err_cap) {
-    zktls::HipGuestProver p(device);
+static int guest_prove(zktls::Backend backend, int device, int mode, const zktls_shard_plan* plan, const uint8_t* cbor, size_t cbor_len,
+                       const uint8_t* elf, size_t elf_len, uint8_t** output, size_t* output_len, uint8_t** proof,
+                       size_t* proof_len, char* err, size_t err_cap) {
+    zktls::HipGuestProver p(device, backend);
     switch (mode) {
         case 0: p.mock(); break;
         case 1: p.local(); break;
@@ -195,7 +211,20 @@ int zktls_guest_prove(int device, int mode, const zktls_shard_plan* plan, const 
     std::memcpy(*proof, r.proof.data(), r.proof.size());
     return 0;
 }
+int zktls_guest_prove(int device, int mode, const zktls_shard_plan* plan, const uint8_t* cbor, size_t cbor_len,
+                      const uint8_t* elf, size_t elf_len, uint8_t** output, size_t* output_len, uint8_t** proof,
+                      size_t* proof_len, char* err, size_t err_cap) {
+    return guest_prove(zktls::Backend::Sp1, device, mode, plan, cbor, cbor_len, elf, elf_len, output, output_len, proof, proof_len, err, err_cap);
+}
+// the `-p r0` twin (crates/guest-prover-r0): same arguments, RISC0_* environment, RISC-Zero-like segment proofs
+int zktls_guest_prove_r0(int device, int mode, const zktls_shard_plan* plan, const uint8_t* cbor, size_t cbor_len,
+                         const uint8_t* elf, size_t elf_len, uint8_t** output, size_t* output_len, uint8_t** proof,
+                         size_t* proof_len, char* err, size_t err_cap) {
+    return guest_prove(zktls::Backend::Risc0, device, mode, plan, cbor, cbor_len, elf, elf_len, output, output_len, proof, proof_len, err, err_cap);
+}
 void zktls_free(void* p) { std::free(p); }
+const char* zktls_current_risc0_prover_env(void) { const char* e = getenv("RISC0_PROVER"); return e ? e : ""; }
+const char* zktls_current_risc0_dev_mode_env(void) { const char* e = getenv("RISC0_DEV_MODE"); return e ? e : ""; }
 const char* zktls_current_sp1_prover_env(void) { const char* e = getenv("SP1_PROVER"); return e ? e : ""; }
 int zktls_request_digest(const uint8_t* cbor, size_t cbor_len, const uint8_t* elf, size_t elf_len, uint32_t out[8]) {
     std::vector<uint32_t> d = zktls::request_digest(std::vector<uint8_t>(cbor, cbor + cbor_len), std::vector<uint8_t>(elf, elf + elf_len));

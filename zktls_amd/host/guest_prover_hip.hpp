@@ -15,6 +15,12 @@
 //                                                       -> every exception becomes ProveResult.error
 //   "proof of <= 4 bytes means no proof"                sp1.rs:128-130 -> same rule
 //
+//   RISC Zero twin (crates/guest-prover-r0/src/prover.rs): ProverType::set_env (:19-28: Mock -> RISC0_DEV_MODE=true,
+//   Local/Cuda -> RISC0_PROVER=local, Network -> RISC0_PROVER=bonsai), Risc0GuestProver::{mock, local, cuda,
+//   network} (:36-57), panic_catched_prover (:70-76), the <= 4-byte rule (:101-103)
+//                                                       -> zktls::Risc0HipGuestProver (Backend::Risc0): same class,
+//                                                          other environment variables, RISC-Zero-like proof shape
+//
 // What prove() does here: the zkVM executor that turns (input, ELF) into shard traces is
 // third-party and out of scope, so this mirror derives the shard
 // list deterministically from the request -- `shards` synthetic shards of 2^log_n x width
@@ -30,9 +36,11 @@
 namespace zktls {
 
 enum class ProverType { Mock, Local, Hip, Network };
+enum class Backend { Sp1, Risc0 };
 
-// sp1.rs:20-29: the mode travels to the SDK through the process environment
+// sp1.rs:20-29 / prover.rs:19-28: the mode travels to the SDK through the process environment
 void set_env(ProverType mode);
+void set_env_r0(ProverType mode);
 const char* prover_type_name(ProverType mode);
 
 struct GuestInput {
@@ -56,26 +64,35 @@ struct ShardPlan {
     int log_n = 20;
     uint32_t width = 256;
     uint32_t shards = 1;
-    int num_queries = 100;
+    int num_queries = 100;     // Backend::Risc0 uses RISC Zero's 50 queries / no PoW when these stay at the defaults
     int pow_bits = 16;
 };
 
 class HipGuestProver : public ZkProver {
 public:
-    explicit HipGuestProver(int device = 0) : device_(device) {}
+    explicit HipGuestProver(int device = 0, Backend backend = Backend::Sp1) : device_(device), backend_(backend) {}
     HipGuestProver& mock() { mode_ = ProverType::Mock; return *this; }
     HipGuestProver& local() { mode_ = ProverType::Local; return *this; }
     HipGuestProver& hip() { mode_ = ProverType::Hip; return *this; }
     HipGuestProver& network() { mode_ = ProverType::Network; return *this; }
     HipGuestProver& with_plan(const ShardPlan& p) { plan_ = p; return *this; }
     ProverType mode() const { return mode_; }
+    Backend backend() const { return backend_; }
     ProveResult prove(const GuestInput& input, const std::vector<uint8_t>& guest_program) override;
 
 private:
     ProveResult prove_inner(const GuestInput& input, const std::vector<uint8_t>& guest_program);
     ProverType mode_ = ProverType::Mock;   // #[default] Mock, sp1.rs:12-13
     int device_ = 0;
+    Backend backend_ = Backend::Sp1;
     ShardPlan plan_;
+};
+
+// prover.rs:30-57: `Risc0GuestProver::default().local()` etc.; segments are proven in RISC Zero's shape
+// (blowup 4, fold 16, 256 final coefficients -- or fewer for tiny segments --, Poseidon2 width 24)
+class Risc0HipGuestProver : public HipGuestProver {
+public:
+    explicit Risc0HipGuestProver(int device = 0) : HipGuestProver(device, Backend::Risc0) {}
 };
 
 // 8 canonical BabyBear words binding (input, ELF): the public values of every shard
