@@ -188,6 +188,37 @@ def main():
                         "ms": round(per_which[1], 4), "GB/s": round(alg_bytes / per_which[1] / 1e6, 1),
                         "frac": round(alg_bytes / per_which[1] / 1e6 / HBM_PEAK_GBS, 4)}}}
 
+    # ---- the kernel that takes most of a proof's time is not HBM-shaped: Poseidon2 leaf hashing, priced against the
+    # measured integer-multiply roof (v_mul_lo / v_mad_u64_u32 issue at 4.2 clk per wave64 per SIMD at the
+    # nominal 2.4 GHz -> 256 CUs x 4 SIMDs x 64 / 4.2 x 2.4e9 = 37.4 T int-mul/s; tools/microbench.hip)
+    valu = None
+    if rank == 0 and args.shape == "sp1":
+        rows = 2 * n
+        with torch.cuda.stream(stream):
+            lde_t = torch.empty(rows * width, dtype=torch.int32, device="cuda")
+            dig_t = torch.empty(rows * 8, dtype=torch.int32, device="cuda")
+        lde_b, dig_b = ctx.wrap(lde_t), ctx.wrap(dig_t)
+        ctx.fill_uniform(SEED + 99, log_n + 1, width, out=lde_b)          # uniform field elements, like a real LDE
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        ctx.hash_rows([(lde_b, width)], rows, out=dig_b)
+        reps_h = 5
+        e0.record(stream)
+        for _ in range(reps_h):
+            ctx.hash_rows([(lde_b, width)], rows, out=dig_b)
+        e1.record(stream)
+        e1.synchronize()
+        ms = e0.elapsed_time(e1) / reps_h
+        perms = rows * ((width + 7) // 8)
+        # integer multiplies of one permutation as implemented (poseidon2.cuh): 141 S-boxes x 4 Montgomery products x 3,
+        # 13 internal layers x (8 + 2 + 1 + 13 x 3)
+        imul_per_perm = 141 * 4 * 3 + 13 * (8 + 2 + 1 + 13 * 3)
+        ach = perms * imul_per_perm / (ms * 1e-3) / 1e12
+        valu = {"bound": "int-mul (not in the roofline schema: reported beside it)", "kernel": "zk::hash_rows_vec_kernel, 2^%d x %d leaves" % (log_n + 1, width),
+                "ms": round(ms, 3), "perm_per_s": round(perms / (ms * 1e-3), 1), "int_mul_per_perm": imul_per_perm,
+                "achieved": round(ach, 2), "peak": 37.4, "unit": "T int-mul/s", "frac": round(ach / 37.4, 4),
+                "hbm_GB/s": round((4.0 * rows * width + 32.0 * rows) / (ms * 1e-3) / 1e9, 1)}
+        del lde_t, dig_t
+
     # ---- CPU baseline: the oracle on the host cores, bounded sample of the same workload
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
@@ -230,6 +261,7 @@ def main():
             "proof_bytes": int(last.size),
             "verified": bool(verified),
             "roofline": roof,
+            "valu_roofline": valu,
             "cpu_baseline": cpu,
         }
         print(json.dumps(out), flush=True)

@@ -2,9 +2,8 @@
 # A/B of the NTT pass kernel variants on 2^20 x 256 (exploration; bench.py is the contract benchmark)
 cd /root/repo
 run() { echo "== $*"; env "$@" python tools/ntt_pass_time.py 300 2>&1 | tail -1; }
-for i in 1 2; do
 run ZKHIP_NTT_FAST=4
-run ZKHIP_NTT_FAST=0 ZKHIP_NTT_CPT=1
-run ZKHIP_NTT_FAST=0 ZKHIP_NTT_CPT=2
-run ZKHIP_NTT_FAST=1
-done
+run ZKHIP_NTT_FAST=5
+run ZKHIP_NTT_FAST=5 ZKHIP_NTT_MAP=0
+run ZKHIP_NTT_FAST=4
+run ZKHIP_NTT_FAST=5

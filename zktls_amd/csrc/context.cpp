@@ -97,7 +97,7 @@ static NttPassArgs base_args(zkhip_ctx* ctx, const uint32_t* in, size_t in_ld, u
     static const int force_cpt = [] { const char* e = getenv("ZKHIP_NTT_CPT"); return e ? atoi(e) : 0; }();
     static const int map_mode = [] { const char* e = getenv("ZKHIP_NTT_MAP"); return e ? atoi(e) : 1; }();
     static const int fast = [] { const char* e = getenv("ZKHIP_NTT_FAST"); return e ? atoi(e) : 4; }();
-    // ZKHIP_NTT_FAST: unset/4/0 = tile-per-workgroup kernel, 1 = persistent 2-column kernel, 3 = persistent 1-column;
+    // ZKHIP_NTT_FAST: unset/4/0 = tile-per-workgroup kernel, 1 = persistent 1024 x 32 kernel (A/B only);
     // ZKHIP_NTT_CPT: 1 / 2 columns per lane (unset: 2 for 1024-row tiles of an even, 8-byte aligned shape)
     a.fast_path = fast == 4 ? 0u : (fast == 0 ? 2u : (uint32_t)fast);
     static const int dbg = [] { const char* e = getenv("ZKHIP_NTT_DEBUG"); return e ? atoi(e) : 0; }();

@@ -138,6 +138,22 @@ __global__ void __launch_bounds__(32 << LOG_C, 4) ntt_pass_kernel(NttPassArgs a)
         }
     }
     __syncthreads();
+    if (BFIX == 5 && (a.debug_flags & 4u)) {
+        // timing-only: the same loads and stores with no transform in between (the memory floor of this access pattern)
+        if (active) {
+            uint32_t* ob = a.out + (uint64_t)tile * a.out_tile_mul * a.out_ld;
+            const auto ors = __builtin_amdgcn_make_buffer_rsrc(ob, 0, 0xFFFFFFFFu, 0x00020000);
+            const uint32_t ostep_b = (uint32_t)(4u * a.out_stride * a.out_ld);
+            const uint32_t out_off = (a.bitrev_out ? 32u * (__brev((uint32_t)u) >> 27) : (uint32_t)u) * ostep_b + 4u * col;
+#pragma unroll
+            for (int rho = 0; rho < 32; rho++) {
+                const uint32_t ro = a.bitrev_out ? (uint32_t)rho : (uint32_t)(32 * rev5(rho));
+                if (CPT == 2) { u32x2 v; v.x = x[0][rho]; v.y = x[CPT - 1][rho]; __builtin_amdgcn_raw_buffer_store_b64(v, ors, out_off, ro * ostep_b, 0); }
+                else __builtin_amdgcn_raw_buffer_store_b32(x[0][rho], ors, out_off, ro * ostep_b, 0);
+            }
+        }
+        return;
+    }
     if (has_pre) {
 #pragma unroll
         for (int n1 = 0; n1 < 32; n1++) {
@@ -277,113 +293,6 @@ ZK_D ItemPos item_pos(uint32_t item, uint32_t ncg, uint32_t map_mode) {
     return p;
 }
 
-template <bool INV>
-__global__ void __launch_bounds__(1024) ntt_pass1024_kernel(NttPassArgs a, uint32_t total_items) {
-    extern __shared__ uint32_t lds[];
-    constexpr int C = 32, Pn = 32, M = 1024, pitch = (Pn + 1) * C;
-    uint32_t* sdata = lds;
-    uint32_t* stw = lds + 32 * pitch;
-    uint32_t* spost = stw + M;
-    uint32_t* spre = spost + M;
-    const int tid = threadIdx.x;
-    const int c = tid & (C - 1);
-    const int u = tid >> 5;
-    const uint32_t ncg = a.ncols / C;
-    const bool has_post = a.post != nullptr, has_pre = a.pre != nullptr;
-    const uint64_t istep = (uint64_t)Pn * a.in_stride * a.in_ld;
-    const uint64_t ostep = a.out_stride * a.out_ld;
-
-    // tile-independent tables, once per workgroup
-    stw[tid] = a.w1024[tid];
-    if (has_pre) spre[tid] = a.pre[tid];
-
-    // buffer addressing: wave-uniform descriptor (tile base) + one 32-bit per-lane byte offset +
-    // a scalar offset per row group -> no 64-bit address VGPRs, which is what lets 64 data
-    // registers (this tile + the prefetched one) fit the 128-VGPR budget of 16 waves per CU
-    const uint32_t in_off = 4u * ((uint32_t)((uint64_t)u * a.in_stride * a.in_ld) + (uint32_t)c);
-    const uint32_t istep_b = (uint32_t)(4u * istep);
-    const uint32_t ostep_b = (uint32_t)(4u * ostep);
-    uint32_t nx[32];
-    uint32_t item = blockIdx.x;
-    {
-        const ItemPos p = item_pos(item, ncg, a.map_mode);
-        const uint32_t* ib = a.in + (uint64_t)p.tile * a.in_tile_mul * a.in_ld + p.cg * C;
-        const auto rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint32_t*>(ib), 0, 0xFFFFFFFFu, 0x00020000);
-#pragma unroll
-        for (int n1 = 0; n1 < 32; n1++) nx[n1] = __builtin_amdgcn_raw_buffer_load_b32(rs, in_off, n1 * istep_b, 0);
-    }
-    wg_barrier();
-    for (; item < total_items; item += gridDim.x) {
-        const ItemPos cur = item_pos(item, ncg, a.map_mode);
-        // this tile's inter-pass twiddles (one per thread), requested before the prefetch so that
-        // the counted wait for it leaves the prefetch in flight
-        uint32_t pv = 0;
-        if (has_post) pv = a.post[(uint64_t)cur.tile * M + tid];
-        uint32_t x[32];
-#pragma unroll
-        for (int n1 = 0; n1 < 32; n1++) x[n1] = nx[n1];
-        const uint32_t nitem = item + gridDim.x;
-        if (nitem < total_items) {
-            const ItemPos p = item_pos(nitem, ncg, a.map_mode);
-            const uint32_t* ib = a.in + (uint64_t)p.tile * a.in_tile_mul * a.in_ld + p.cg * C;
-            const auto rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint32_t*>(ib), 0, 0xFFFFFFFFu, 0x00020000);
-#pragma unroll
-            for (int n1 = 0; n1 < 32; n1++) nx[n1] = __builtin_amdgcn_raw_buffer_load_b32(rs, in_off, n1 * istep_b, 0);
-        }
-        if (has_post) spost[tid] = pv;
-
-        if (has_pre) {
-#pragma unroll
-            for (int n1 = 0; n1 < 32; n1++) x[n1] = dmul(x[n1], spre[u + Pn * n1]);
-        }
-        dif_stage<INV, 0>(x);
-        dif_stage<INV, 1>(x);
-        dif_stage<INV, 2>(x);
-        dif_stage<INV, 3>(x);
-        dif_stage<INV, 4, true>(x);
-        {
-            uint32_t* wp = sdata + u * C + c;
-#pragma unroll
-            for (int r = 0; r < 32; r++) {
-                const int k1 = rev5(r);
-                wp[k1 * pitch] = (k1 == 0) ? dred(x[r]) : dmul(x[r], stw[u * k1]);
-            }
-        }
-        wg_barrier();
-        {
-            const uint32_t* rp = sdata + u * pitch + c;      // P = 32: k1 = u, t = rho
-#pragma unroll
-            for (int rho = 0; rho < 32; rho++) x[rho] = rp[rho * C];
-        }
-        dif_stage<INV, 0>(x);
-        dif_stage<INV, 1>(x);
-        dif_stage<INV, 2>(x);
-        dif_stage<INV, 3>(x);
-        // element k = 32 rev5(rho) + u goes to tile row o(k) = k, or bitrev10(k) = 32 rev5(u) + rho:
-        // either way o * ostep splits into a wave-uniform part (rho) and a per-lane 32-bit offset
-        uint32_t* ob = a.out + (uint64_t)cur.tile * a.out_tile_mul * a.out_ld + cur.cg * C;
-        const auto ors = __builtin_amdgcn_make_buffer_rsrc(ob, 0, 0xFFFFFFFFu, 0x00020000);
-        const uint32_t out_off = (a.bitrev_out ? 32u * (__brev((uint32_t)u) >> 27) : (uint32_t)u) * ostep_b + 4u * (uint32_t)c;
-        if (has_post) {
-            dif_stage<INV, 4, true>(x);
-#pragma unroll
-            for (int rho = 0; rho < 32; rho++) {
-                const uint32_t v = dmul(x[rho], spost[32 * rev5(rho) + u]);
-                const uint32_t ro = a.bitrev_out ? (uint32_t)rho : (uint32_t)(32 * rev5(rho));
-                __builtin_amdgcn_raw_buffer_store_b32(v, ors, out_off, ro * ostep_b, 0);
-            }
-        } else {
-            dif_stage<INV, 4>(x);
-#pragma unroll
-            for (int rho = 0; rho < 32; rho++) {
-                const uint32_t ro = a.bitrev_out ? (uint32_t)rho : (uint32_t)(32 * rev5(rho));
-                __builtin_amdgcn_raw_buffer_store_b32(x[rho], ors, out_off, ro * ostep_b, 0);
-            }
-        }
-        wg_barrier();          // sdata / spost are rewritten by the next tile
-    }
-}
-
 // Two columns per lane, 512 threads (2 waves per SIMD, up to 256 VGPRs): the register file
 // then holds this tile (64 values) AND the prefetched next tile (64 values) without spills,
 // loads/stores are 8 bytes per lane (a wave = 4 rows x 128 B) and the LDS exchange moves
@@ -510,20 +419,6 @@ static int cu_count() {
 }
 
 template <bool INV>
-static hipError_t launch_ntt1024(const NttPassArgs& a, hipStream_t s) {
-    const uint32_t total = a.num_tiles * (a.ncols / 32);
-    const uint32_t grid = total < (uint32_t)cu_count() ? total : (uint32_t)cu_count();
-    const size_t lds = (size_t)(32 * 33 * 32 + 3 * 1024) * sizeof(uint32_t);
-    static bool configured = false;
-    if (!configured) {
-        hipError_t e = hipFuncSetAttribute((const void*)ntt_pass1024_kernel<INV>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) return e;
-        configured = true;
-    }
-    hipLaunchKernelGGL((ntt_pass1024_kernel<INV>), dim3(grid), dim3(1024), lds, s, a, total);
-    return hipGetLastError();
-}
-template <bool INV>
 static hipError_t launch_ntt1024x2(const NttPassArgs& a, hipStream_t s) {
     const uint32_t total = a.num_tiles * (a.ncols / 32);
     const uint32_t grid = total < (uint32_t)cu_count() ? total : (uint32_t)cu_count();
@@ -571,14 +466,15 @@ hipError_t launch_ntt_pass(const NttPassArgs& a_, bool inverse, hipStream_t s) {
         if (in_span >= (1ull << 32) || out_span >= (1ull << 32)) return hipErrorInvalidValue;
     }
     if (a.map_mode == 1 && (a.num_tiles % 8u) != 0) a.map_mode = 0;
-    // A/B only (fast_path 1 / 3): the persistent 1024 x 32 kernels.  Measured on 2^20 x 256 they lose to the
-    // two-workgroups-per-CU kernel below once that one has compile-time tile offsets (0.62 / 0.55 ms
-    // against 0.53 / 0.46 ms for the strided / contiguous pass).
-    if (a.log_m == 10 && a.ncols >= 32 && a.ncols % 32 == 0 && (a.fast_path == 1 || a.fast_path == 3)) {
+    // A/B only (fast_path 1): the persistent 1024 x 32 kernel (one workgroup per CU, next tile prefetched into
+    // registers).  Measured on 2^20 x 256 it loses to the two-workgroups-per-CU kernel below once that one has
+    // compile-time tile offsets (0.62 / 0.55 ms against 0.53 / 0.46 ms for the strided / contiguous pass); so does a
+    // persistent form of the two-workgroup kernel itself (0.55 / 0.50 ms: workgroups that walk tile lists stay
+    // phase-locked across the chip, freshly dispatched ones drift apart and keep the memory pipe fed).
+    const bool al8 = a.in_ld % 2 == 0 && a.out_ld % 2 == 0 && (reinterpret_cast<uintptr_t>(a.in) & 7) == 0 &&
+                     (reinterpret_cast<uintptr_t>(a.out) & 7) == 0;
+    if (a.log_m == 10 && a.ncols >= 32 && a.ncols % 32 == 0 && a.fast_path == 1 && al8) {
         if (a.map_mode == 1 && ((a.num_tiles % 8u) != 0 || (cu_count() % 8) != 0)) a.map_mode = 0;
-        const bool al8 = a.in_ld % 2 == 0 && a.out_ld % 2 == 0 && (reinterpret_cast<uintptr_t>(a.in) & 7) == 0 &&
-                         (reinterpret_cast<uintptr_t>(a.out) & 7) == 0;
-        if (a.fast_path == 3 || !al8) return inverse ? launch_ntt1024<true>(a, s) : launch_ntt1024<false>(a, s);
         return inverse ? launch_ntt1024x2<true>(a, s) : launch_ntt1024x2<false>(a, s);
     }
     // two columns per lane (128-byte row chunks per 16 lanes) need 8-byte aligned row chunks.  Default for
