@@ -155,7 +155,7 @@ def main():
         # many isolated launches: the kernel's average in a rocprofv3 trace of this command is then
         # dominated by launches that had the GPU to themselves (the in-proof launches overlap
         # with kernels of the other shards in flight and are stretched by that)
-        reps = 1000
+        reps = 4000
         per_which = []
         for which in (0, 1):
             for _ in range(3):

@@ -17,7 +17,7 @@ dst = os.path.join(ROOT, "profiles")
 os.makedirs(dst, exist_ok=True)
 
 kt = sys.argv[2] if len(sys.argv) > 2 else "kt"
-stats = glob.glob(os.path.join(src, kt, "*", "*_kernel_stats.csv"))
+stats = glob.glob(os.path.join(src, kt, "**", "*_kernel_stats.csv"), recursive=True)
 if stats:
     shutil.copy(stats[0], os.path.join(dst, tag + "_kernel_stats.csv"))
     cmdline = open(os.path.join(src, kt + "_cmd.txt")).read().strip() if os.path.exists(os.path.join(src, kt + "_cmd.txt")) else "python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline"
@@ -28,14 +28,14 @@ if stats:
         for r in rows:
             f.write("| %s | %s | %.3f | %.2f | %s |\n" % (r["Name"].split("(")[0], r["Calls"], float(r["TotalDurationNs"]) / 1e6,
                                                          float(r["AverageNs"]) / 1e3, r["Percentage"]))
-log = os.path.join(src, "bench_under_prof.log")
+log = os.path.join(src, "bench_under_prof.log" if kt == "kt" else "bench_under_prof_s1.log")
 if os.path.exists(log):
     for line in open(log):
         if line.startswith("{"):
             open(os.path.join(dst, tag + "_bench_under_rocprof.json"), "w").write(line)
 
 def pmc(name, counter):
-    files = glob.glob(os.path.join(src, name, "*", "*_counter_collection.csv"))
+    files = glob.glob(os.path.join(src, name, "**", "*_counter_collection.csv"), recursive=True)
     vals = []
     if files:
         for r in csv.DictReader(open(files[0])):
@@ -48,7 +48,7 @@ fetch, write = pmc("pmc_fetch", "FETCH_SIZE"), pmc("pmc_write", "WRITE_SIZE")
 if fetch and write:
     f_avg = sum(fetch) / len(fetch) * 1024.0 * 2.0     # KiB -> B, gfx950 x2 correction
     w_avg = sum(write) / len(write) * 1024.0
-    out = {"kernel": "zk::ntt_pass1024x2_kernel<false> + zk::ntt_pass_kernel<4,false,1>", "workload": "2^20 x 256, mean of strided and contiguous pass",
+    out = {"kernel": "zk::ntt_pass_kernel<4,false,2,5> (both passes)", "workload": "2^20 x 256, mean of strided and contiguous pass",
            "fetch_size_kib_raw_mean": sum(fetch) / len(fetch), "write_size_kib_mean": sum(write) / len(write),
            "fetch_correction": "x2 (gfx950 FETCH_SIZE half-count)", "hbm_bytes_per_launch": f_avg + w_avg,
            "algorithmic_bytes_per_launch": 8.0 * (1 << 28)}
