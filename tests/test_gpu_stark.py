@@ -220,3 +220,30 @@ def test_prove_segment_from_column_major_equals_oracle(ctx, oracle, log_n, width
     oproof = oracle.prove_shard(t, [5], oracle.segment_params(50, 0, lf))
     assert proof.tobytes() == oproof.tobytes()
     assert verify_shard(proof, log_n, width, [5], segment_params(50, 0, lf)) == (0, 0)
+
+
+def test_concurrent_contexts_give_the_same_proofs(ctx, oracle):
+    # bench.py keeps three shards in flight per GPU, each on its own context / HIP stream / host thread:
+    # the proofs must not depend on what else is running
+    import threading
+    from zktls_amd.device import Context
+    log_n, width, prm = 12, 32, Params(1, 30, 10)
+    expected = []
+    for s in range(3):
+        expected.append(ctx.prove_shard(ctx.gen_trace(SEED, s, log_n, width), log_n, width, [s], prm).tobytes())
+    ctxs = [Context(0) for _ in range(3)]
+    got = [[None] * 4 for _ in range(3)]
+
+    def worker(w):
+        c = ctxs[w]
+        t = c.gen_trace(SEED, w, log_n, width)
+        for r in range(4):
+            got[w][r] = c.prove_shard(t, log_n, width, [w], prm).tobytes()
+    ts = [threading.Thread(target=worker, args=(w,)) for w in range(3)]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join()
+    for w in range(3):
+        assert all(g == expected[w] for g in got[w])
+        ctxs[w].close()
