@@ -176,24 +176,20 @@ ZK_D CoopConsts coop_load_consts(int lane16) {
     k.diag = P2K.diag[lane16];
     return k;
 }
-ZK_D uint32_t coop_external_linear(uint32_t x, bool even_lane) {
-    // quad_perm [0,0,2,2] [1,1,3,3] [2,2,0,0] [3,3,1,1]: lanes 2,3 of a quad see it swapped,
-    // which turns rows 2,3 of M4 into rows 0,1
-    const uint32_t p0 = dpp<0xA0>(x), p1 = dpp<0xF5>(x), p2 = dpp<0x0A>(x), p3 = dpp<0x5F>(x);
-    const uint32_t s01 = dadd(p0, p1);
-    const uint32_t q = ddbl(ddbl(s01));                                   // 4 p0 + 4 p1
-    const uint32_t base = dadd(dadd(q, ddbl(p1)), dadd(p2, p3));          // 4 p0 + 6 p1 + p2 + p3
-    const uint32_t full = dadd(base, dadd(s01, ddbl(p3)));                // 5 p0 + 7 p1 + p2 + 3 p3
-    const uint32_t y = even_lane ? full : base;
+ZK_D uint32_t coop_external_linear(uint32_t x) {
+    // M4 = circ(2,3,1,1) inside each quad: y_i = 2 x_i + 3 x_{i+1} + x_{i+2} + x_{i+3} = (quad sum) + x_i + 2 x_{i+1};
+    // quad_perm [1,2,3,0] [2,3,0,1] [3,0,1,2] are the three rotations
+    const uint32_t r1 = dpp<0x39>(x), r2 = dpp<0x4E>(x), r3 = dpp<0x93>(x);
+    const uint32_t sum = dadd(dadd(x, r1), dadd(r2, r3));
+    const uint32_t y = dadd(dadd(sum, x), ddbl(r1));
     uint32_t t = dadd(y, dpp<0x124>(y));                                  // row_ror:4
     t = dadd(t, dpp<0x128>(t));                                           // row_ror:8
     return dadd(y, t);
 }
 ZK_D uint32_t coop_permute(uint32_t x, int lane16, const CoopConsts& k) {
-    const bool even_lane = (lane16 & 1) == 0;
-    x = coop_external_linear(x, even_lane);
+    x = coop_external_linear(x);
 #pragma unroll 1
-    for (int r = 0; r < 4; r++) x = coop_external_linear(p2_sbox_dev(dadd(x, k.rc_ext[r])), even_lane);
+    for (int r = 0; r < 4; r++) x = coop_external_linear(p2_sbox_dev(dadd(x, k.rc_ext[r])));
 #pragma unroll 1
     for (int r = 0; r < 13; r++) {
         const uint32_t sb = p2_sbox_dev(dadd(x, P2K.int_rc[r]));
@@ -205,7 +201,7 @@ ZK_D uint32_t coop_permute(uint32_t x, int lane16, const CoopConsts& k) {
         x = dadd(dmul(x, k.diag), t);
     }
 #pragma unroll 1
-    for (int r = 4; r < 8; r++) x = coop_external_linear(p2_sbox_dev(dadd(x, k.rc_ext[r])), even_lane);
+    for (int r = 4; r < 8; r++) x = coop_external_linear(p2_sbox_dev(dadd(x, k.rc_ext[r])));
     return x;
 }
 
