@@ -30,15 +30,15 @@ HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: 8 TB/s spec
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=5)
-    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--log-n", type=int, default=20)
     ap.add_argument("--width", type=int, default=256)
     ap.add_argument("--logup-pairs", type=int, default=0, help="LogUp lookup pairs (SURVEY 8a row a8); 0 = main AIR only")
     ap.add_argument("--shape", choices=("sp1", "r0"), default="sp1",
                     help="proof-system shape: sp1 = the headline (blowup 2, 100 queries, 16 PoW bits, fold by 2, Poseidon2-16); "
                          "r0 = RISC-Zero-like (blowup 4, 50 queries, fold by 16, 256 final coefficients, Poseidon2-24)")
-    ap.add_argument("--streams", type=int, default=3, help="shards in flight per GPU: each on its own context + HIP stream")
+    ap.add_argument("--streams", type=int, default=4, help="shards in flight per GPU (at most --steps): each on its own context + HIP stream")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-log-n", type=int, default=19, help="rows of the bounded CPU-baseline sample")
     ap.add_argument("--cpu-threads", type=int, default=0, help="OpenMP threads of the CPU baseline (0: min(cores, 64))")
@@ -74,7 +74,7 @@ def main():
     prm = Params(1, 100, 16, LQ) if args.shape == "sp1" else Params(2, 50, 0, LQ, 4, 8, 24)
     # one context (= one HIP stream + its workspaces) per shard in flight: while one shard sits in a
     # latency-bound stretch (small FRI layers, host round trips) the other keeps the CUs busy
-    S = max(1, args.streams)
+    S = max(1, min(args.streams, max(args.steps, 1)))
     streams = [torch.cuda.Stream(device=local_rank) for _ in range(S)]
     ctxs = [Context(local_rank, stream=st.cuda_stream) for st in streams]
     stream, ctx = streams[0], ctxs[0]
@@ -84,7 +84,7 @@ def main():
     public = shards.broadcast_seed(dist, [(SEED >> (8 * i)) & 0xFF for i in range(8)], device="cuda")
 
     K, W = args.steps, args.warmup
-    nbuf = min(max(K, 1), 4)
+    nbuf = min(max(K, 1), 8)
     with torch.cuda.stream(stream):
         traces = [torch.empty(cells, dtype=torch.int32, device="cuda") for _ in range(nbuf)]
     bufs = [ctx.wrap(t) for t in traces]
@@ -109,9 +109,17 @@ def main():
         results = [None] * count
         errors = []
 
+        nxt = [0]
+        lock = threading.Lock()
+
         def worker(w):
             try:
-                for i in range(w, count, S):
+                while True:
+                    with lock:              # shards are handed out as contexts become free
+                        i = nxt[0]
+                        nxt[0] += 1
+                    if i >= count:
+                        return
                     results[i] = step(i, ctxs[w])
             except Exception as e:          # surfaced after the join
                 errors.append(e)
