@@ -9,10 +9,13 @@ PoW -> queries) of a synthetic SP1-core-like shard: 2^20 rows x 256 columns, log
 100 queries, 16 PoW bits (BASELINE.json configs[1] / SURVEY.md 8d).  The trace is resident
 in HBM before the timed region.  Shards are independent: rank r proves shards r*K..r*K+K-1
 (weak scaling, no data-path collective); RCCL broadcasts the 8-word batch transcript seed.
+Up to --streams shards are in flight per GPU, each on its own context + HIP stream + host
+thread, so the latency-bound stretches of one proof hide under the kernels of the others.
 
 Prints ONE JSON line (rank 0): metric trace-cells/s (+ proofs/s), `roofline` for the NTT
-pass kernel (HIP events on the launch stream) and `cpu_baseline` (the CPU oracle timed on
-the host cores, bounded sample, N = 1 only).
+pass kernel (HIP events on the launch stream), `valu_roofline` for the Poseidon2 leaf kernel
+(the largest share of a proof, integer-multiply bound) and `cpu_baseline` (the CPU oracle
+timed on the host cores, bounded sample, N = 1 only).
 """
 import argparse
 import json
