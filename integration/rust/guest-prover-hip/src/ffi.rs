@@ -1,0 +1,116 @@
+//! 1:1 declarations of include/zkhip.h (the subset the glue needs) and thin RAII wrappers.
+use std::ffi::CStr;
+use std::os::raw::{c_char, c_int, c_void};
+
+use anyhow::{anyhow, Result};
+
+#[repr(C)]
+pub struct ZkhipCtx {
+    _private: [u8; 0],
+}
+
+/// include/zkhip.h `zkhip_params`; the last three fields select the FRI / hash shape (0 = SP1 defaults).
+#[repr(C)]
+#[derive(Clone, Copy, Debug)]
+pub struct ZkhipParams {
+    pub log_blowup: i32,
+    pub num_queries: i32,
+    pub pow_bits: i32,
+    pub logup_pairs: i32,
+    pub log_fold: i32,
+    pub log_final: i32,
+    pub hash_width: i32,
+}
+
+impl ZkhipParams {
+    /// sp1-stark 4.1.4 core shards
+    pub const SP1_CORE: Self = Self { log_blowup: 1, num_queries: 100, pow_bits: 16, logup_pairs: 0, log_fold: 0, log_final: 0, hash_width: 0 };
+    /// risc0-zkp 1.2.5 segments: blowup 4, 50 queries, fold 16, 256 final coefficients, Poseidon2 width 24
+    pub const RISC0: Self = Self { log_blowup: 2, num_queries: 50, pow_bits: 0, logup_pairs: 0, log_fold: 4, log_final: 8, hash_width: 24 };
+}
+
+pub const ZKHIP_OK: c_int = 0;
+
+extern "C" {
+    pub fn zkhip_last_error() -> *const c_char;
+    pub fn zkhip_device_count() -> c_int;
+    pub fn zkhip_ctx_create(device: c_int, stream: *mut c_void, out: *mut *mut ZkhipCtx) -> c_int;
+    pub fn zkhip_ctx_destroy(ctx: *mut ZkhipCtx);
+    pub fn zkhip_malloc(ctx: *mut ZkhipCtx, bytes: usize, d_ptr: *mut *mut c_void) -> c_int;
+    pub fn zkhip_free(ctx: *mut ZkhipCtx, d_ptr: *mut c_void) -> c_int;
+    pub fn zkhip_memcpy_h2d(ctx: *mut ZkhipCtx, d_dst: *mut c_void, h_src: *const c_void, bytes: usize) -> c_int;
+    pub fn zkhip_to_monty(ctx: *mut ZkhipCtx, d_in: *const u32, d_out: *mut u32, n: usize) -> c_int;
+    pub fn zkhip_gen_trace(ctx: *mut ZkhipCtx, seed: u64, shard: u64, log_n: c_int, width: u32, d_out: *mut u32, ld: usize) -> c_int;
+    pub fn zkhip_proof_size(log_n: c_int, width: u32, prm: *const ZkhipParams, n_public: usize) -> usize;
+    pub fn zkhip_prove_shard(
+        ctx: *mut ZkhipCtx, d_trace: *const u32, ld: usize, log_n: c_int, width: u32,
+        public_values: *const u32, n_public: usize, prm: *const ZkhipParams,
+        proof: *mut u8, cap: usize, len: *mut usize,
+    ) -> c_int;
+    pub fn zkhip_prove_segment(
+        ctx: *mut ZkhipCtx, d_cols: *const u32, log_n: c_int, width: u32,
+        public_values: *const u32, n_public: usize, prm: *const ZkhipParams,
+        proof: *mut u8, cap: usize, len: *mut usize,
+    ) -> c_int;
+    pub fn zkhip_verify_shard(
+        proof: *const u8, len: usize, log_n: c_int, width: u32,
+        public_values: *const u32, n_public: usize, prm: *const ZkhipParams, reason: *mut c_int,
+    ) -> c_int;
+}
+
+/// status code -> anyhow error carrying the library's thread-local message
+pub fn check(rc: c_int, what: &str) -> Result<()> {
+    if rc == ZKHIP_OK {
+        return Ok(());
+    }
+    let msg = unsafe { CStr::from_ptr(zkhip_last_error()) }.to_string_lossy().into_owned();
+    Err(anyhow!("{what}: zkhip error {rc}: {msg}"))
+}
+
+/// One device + one HIP stream + its workspaces.  Not shared between threads (the C library says so).
+pub struct Context(*mut ZkhipCtx);
+
+impl Context {
+    pub fn new(device: i32) -> Result<Self> {
+        let mut raw = std::ptr::null_mut();
+        check(unsafe { zkhip_ctx_create(device, std::ptr::null_mut(), &mut raw) }, "zkhip_ctx_create")?;
+        Ok(Self(raw))
+    }
+    pub fn raw(&self) -> *mut ZkhipCtx {
+        self.0
+    }
+    pub fn alloc(&self, words: usize) -> Result<DeviceBuffer<'_>> {
+        let mut p = std::ptr::null_mut();
+        check(unsafe { zkhip_malloc(self.0, words * 4, &mut p) }, "zkhip_malloc")?;
+        Ok(DeviceBuffer { ctx: self, ptr: p as *mut u32, words })
+    }
+}
+
+impl Drop for Context {
+    fn drop(&mut self) {
+        unsafe { zkhip_ctx_destroy(self.0) }
+    }
+}
+
+pub struct DeviceBuffer<'a> {
+    ctx: &'a Context,
+    pub ptr: *mut u32,
+    pub words: usize,
+}
+
+impl DeviceBuffer<'_> {
+    /// canonical host words -> Montgomery device words (the in-memory form of p3 `MontyField31`)
+    pub fn upload_canonical(&self, host: &[u32]) -> Result<()> {
+        anyhow::ensure!(host.len() == self.words, "upload size mismatch");
+        check(unsafe { zkhip_memcpy_h2d(self.ctx.raw(), self.ptr as *mut c_void, host.as_ptr() as *const c_void, host.len() * 4) }, "zkhip_memcpy_h2d")?;
+        check(unsafe { zkhip_to_monty(self.ctx.raw(), self.ptr, self.ptr, self.words) }, "zkhip_to_monty")
+    }
+}
+
+impl Drop for DeviceBuffer<'_> {
+    fn drop(&mut self) {
+        unsafe {
+            zkhip_free(self.ctx.raw(), self.ptr as *mut c_void);
+        }
+    }
+}

@@ -1,0 +1,196 @@
+//! `HipGuestProver`: the `ZkProver` of the HIP backend.
+//!
+//! Shape of the reference glue it stands next to:
+//!   crates/guest-prover-sp1/src/sp1.rs  -- ProverType::set_env (:20-29), builder (:32-65), ZkProver impl (:66-78),
+//!                                          catch_unwind (:85), cbor input (:108-109), verify (:120), <= 4-byte rule (:128-130)
+//!   crates/guest-prover-r0/src/prover.rs -- the same for RISC Zero (:19-28, :60-67, :74, :81-86, :101-103)
+use std::{future::Future, panic};
+
+use anyhow::{anyhow, Result};
+use zktls_core::ZkProver;
+use zktls_program_core::GuestInput;
+
+use crate::ffi::{self, check, Context, ZkhipParams};
+
+#[derive(Default, Clone, Copy, PartialEq, Eq, Debug)]
+pub enum ProverType {
+    #[default]
+    Mock,
+    Local,
+    Hip,
+    Network,
+}
+
+/// Which SDK's conventions (environment variables, proof shape) the backend follows.
+#[derive(Default, Clone, Copy, PartialEq, Eq, Debug)]
+pub enum Backend {
+    #[default]
+    Sp1,
+    Risc0,
+}
+
+impl ProverType {
+    pub fn set_env(&self, backend: Backend) {
+        match (backend, self) {
+            (Backend::Sp1, ProverType::Mock) => std::env::set_var("SP1_PROVER", "mock"),
+            (Backend::Sp1, ProverType::Local) => std::env::set_var("SP1_PROVER", "local"),
+            (Backend::Sp1, ProverType::Hip) => std::env::set_var("SP1_PROVER", "hip"),
+            (Backend::Sp1, ProverType::Network) => std::env::set_var("SP1_PROVER", "network"),
+            (Backend::Risc0, ProverType::Mock) => std::env::set_var("RISC0_DEV_MODE", "true"),
+            (Backend::Risc0, ProverType::Local) | (Backend::Risc0, ProverType::Hip) => std::env::set_var("RISC0_PROVER", "local"),
+            (Backend::Risc0, ProverType::Network) => std::env::set_var("RISC0_PROVER", "bonsai"),
+        }
+    }
+}
+
+/// One shard / segment trace as the zkVM executor hands it over.
+pub struct Shard {
+    pub log_n: i32,
+    pub width: u32,
+    /// row-major (`column_major == false`, SP1 `RowMajorMatrix`) or `width` contiguous columns (RISC Zero Hal)
+    pub column_major: bool,
+    /// canonical BabyBear words, `width << log_n` of them
+    pub values: Vec<u32>,
+    pub public_values: Vec<u32>,
+}
+
+/// The executor side (sp1-core-executor / risc0 executor): turns (cbor input, ELF) into shard traces and
+/// the guest's public output.  Out of scope of the HIP library; plug the real executor in here.
+pub trait ShardSource: Send {
+    fn shards(&mut self, input_cbor: &[u8], elf: &[u8]) -> Result<(Vec<u8>, Vec<Shard>)>;
+}
+
+/// Stand-in source used until the executor is wired: `count` synthetic AIR-satisfying shards generated on
+/// the device (`zkhip_gen_trace`), seeded from the request bytes.
+pub struct SyntheticShards {
+    pub log_n: i32,
+    pub width: u32,
+    pub count: u32,
+}
+
+pub struct HipGuestProver {
+    mode: ProverType,
+    backend: Backend,
+    device: i32,
+    source: Option<Box<dyn ShardSource>>,
+    synthetic: SyntheticShards,
+}
+
+impl HipGuestProver {
+    pub fn new(device: i32) -> Self {
+        Self { mode: ProverType::default(), backend: Backend::default(), device, source: None,
+               synthetic: SyntheticShards { log_n: 20, width: 256, count: 1 } }
+    }
+    pub fn mock(mut self) -> Self { self.mode = ProverType::Mock; self }
+    pub fn local(mut self) -> Self { self.mode = ProverType::Local; self }
+    pub fn hip(mut self) -> Self { self.mode = ProverType::Hip; self }
+    pub fn network(mut self) -> Self { self.mode = ProverType::Network; self }
+    pub fn risc0(mut self) -> Self { self.backend = Backend::Risc0; self }
+    pub fn with_source(mut self, source: Box<dyn ShardSource>) -> Self { self.source = Some(source); self }
+    pub fn with_synthetic(mut self, plan: SyntheticShards) -> Self { self.synthetic = plan; self }
+
+    fn params(&self, log_n: i32) -> ZkhipParams {
+        match self.backend {
+            Backend::Sp1 => ZkhipParams::SP1_CORE,
+            Backend::Risc0 => {
+                // the final polynomial shrinks for segments too small for 256 coefficients
+                let mut lf = 8;
+                while lf > log_n || (log_n - lf) % 4 != 0 { lf -= 1; }
+                ZkhipParams { log_final: lf, ..ZkhipParams::RISC0 }
+            }
+        }
+    }
+}
+
+impl ZkProver for HipGuestProver {
+    fn prove(&mut self, input: GuestInput, guest_program: &[u8]) -> impl Future<Output = Result<(Vec<u8>, Vec<u8>)>> + Send {
+        self.mode.set_env(self.backend);
+        let elf = guest_program.to_vec();                       // copied once, like sp1.rs:74
+        let result = (|| -> Result<(Vec<u8>, Vec<u8>)> {
+            let mut cbor = Vec::new();
+            ciborium::into_writer(&input, &mut cbor)?;          // sp1.rs:108-109 / prover.rs:81-82
+            log::info!("input_len: {}", cbor.len());
+            let this = panic::AssertUnwindSafe(&mut *self);
+            panic::catch_unwind(move || { let this = this; this.0.prove_blocking(&cbor, &elf) })
+                .map_err(|e| anyhow!("{:?}", e))?               // sp1.rs:85: nothing unwinds past the glue
+        })();
+        async move { result }
+    }
+}
+
+impl HipGuestProver {
+    fn prove_blocking(&mut self, cbor: &[u8], elf: &[u8]) -> Result<(Vec<u8>, Vec<u8>)> {
+        match self.mode {
+            ProverType::Mock => return Ok((Vec::new(), Vec::new())),        // a <= 4-byte proof means "no proof"
+            ProverType::Network => return Err(anyhow!("network proving is not provided by the HIP backend")),
+            ProverType::Local | ProverType::Hip => {}
+        }
+        if unsafe { ffi::zkhip_device_count() } <= 0 {
+            return Err(anyhow!("no gfx950 device: libzkhip has no CPU fallback"));
+        }
+        let ctx = Context::new(self.device)?;
+        let (output, shards) = match self.source.as_mut() {
+            Some(src) => src.shards(cbor, elf)?,
+            None => (Vec::new(), Vec::new()),
+        };
+        let start = std::time::Instant::now();
+        let mut blob = Vec::new();                                           // "ZKTB", version, count, then (len, bytes) per shard
+        blob.extend_from_slice(&0x42544B5Au32.to_le_bytes());
+        blob.extend_from_slice(&1u32.to_le_bytes());
+        let mut count = 0u32;
+        let count_at = blob.len();
+        blob.extend_from_slice(&0u32.to_le_bytes());
+        let mut push = |proof: &[u8], blob: &mut Vec<u8>| {
+            blob.extend_from_slice(&(proof.len() as u32).to_le_bytes());
+            blob.extend_from_slice(proof);
+        };
+        if self.source.is_some() {
+            for shard in &shards {
+                let prm = self.params(shard.log_n);
+                let buf = ctx.alloc(shard.values.len())?;
+                buf.upload_canonical(&shard.values)?;
+                let proof = prove_one(&ctx, buf.ptr, shard.log_n, shard.width, shard.column_major, &shard.public_values, &prm)?;
+                push(&proof, &mut blob);
+                count += 1;
+            }
+        } else {
+            let plan = &self.synthetic;
+            let prm = self.params(plan.log_n);
+            let words = (plan.width as usize) << plan.log_n;
+            let buf = ctx.alloc(words)?;
+            let seed = cbor.iter().chain(elf.iter()).fold(0xcbf29ce484222325u64, |h, b| (h ^ *b as u64).wrapping_mul(0x100000001b3));
+            for s in 0..plan.count {
+                check(unsafe { ffi::zkhip_gen_trace(ctx.raw(), seed, s as u64, plan.log_n, plan.width, buf.ptr, plan.width as usize) }, "zkhip_gen_trace")?;
+                let proof = prove_one(&ctx, buf.ptr, plan.log_n, plan.width, false, &[s], &prm)?;
+                push(&proof, &mut blob);
+                count += 1;
+            }
+        }
+        blob[count_at..count_at + 4].copy_from_slice(&count.to_le_bytes());
+        log::info!("Proving took: {:?}", start.elapsed());
+        let mut proof = blob;
+        if proof.len() <= 4 {
+            proof = Vec::new();                                              // sp1.rs:128-130 / prover.rs:101-103
+        }
+        Ok((output, proof))
+    }
+}
+
+fn prove_one(ctx: &Context, d_trace: *const u32, log_n: i32, width: u32, column_major: bool, pv: &[u32], prm: &ZkhipParams) -> Result<Vec<u8>> {
+    let cap = unsafe { ffi::zkhip_proof_size(log_n, width, prm, pv.len()) };
+    anyhow::ensure!(cap > 0, "bad shard shape");
+    let mut proof = vec![0u8; cap];
+    let mut len = 0usize;
+    let rc = unsafe {
+        if column_major {
+            ffi::zkhip_prove_segment(ctx.raw(), d_trace, log_n, width, pv.as_ptr(), pv.len(), prm, proof.as_mut_ptr(), cap, &mut len)
+        } else {
+            ffi::zkhip_prove_shard(ctx.raw(), d_trace, width as usize, log_n, width, pv.as_ptr(), pv.len(), prm, proof.as_mut_ptr(), cap, &mut len)
+        }
+    };
+    check(rc, "zkhip_prove")?;
+    proof.truncate(len);
+    let mut reason = 0;
+    check(unsafe { ffi::zkhip_verify_shard(proof.as_ptr(), proof.len(), log_n, width, pv.as_ptr(), pv.len(), prm, &mut reason) }, "zkhip_verify_shard")?;   // sp1.rs:120
+    Ok(proof)
+}
