@@ -279,6 +279,7 @@ def main():
     for c in ctxs:
         c.close()
     if dist is not None:
+        dist.barrier()                     # rank 0 is still measuring its roofline section: leave together
         dist.destroy_process_group()
     if not verified:
         raise SystemExit("last proof failed verification (reason %d)" % reason)
