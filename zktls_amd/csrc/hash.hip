@@ -248,6 +248,48 @@ __global__ void __launch_bounds__(256) hash_rows16_kernel(LeafArgs a, uint32_t t
     if (lane16 < 8) a.digests[row * 8 + lane16] = x;
 }
 
+// ------------------------------------------------------------------ transcript step on the device
+// p3-challenger DuplexChallenger<16, 8> (the host Challenger of prover.cpp, word for word): observe the 8 root words,
+// sample 4.  One 16-lane row runs the permutation cooperatively, lane i holding state word i; the small input /
+// output buffers live in LDS.  Lets the FRI commit loop run without a host round trip per layer.
+__global__ void __launch_bounds__(64) fri_challenge_kernel(DevChallenger* c, const uint32_t* __restrict__ root, uint32_t* __restrict__ beta_out,
+                                                           uint32_t* __restrict__ root_log) {
+    __shared__ uint32_t sin[8], sout[8];
+    const int lane = threadIdx.x;                    // 64 launched, lanes 0..15 work (a DPP row)
+    if (lane >= 16) return;
+    const CoopConsts k = coop_load_consts(lane);
+    uint32_t x = c->state[lane];
+    int n_in = c->n_in, n_out = c->n_out;
+    if (lane < 8) { sin[lane] = c->in[lane]; sout[lane] = c->out[lane]; }
+    auto duplex = [&]() {
+        if (lane < n_in) x = sin[lane];              // overwrite-mode absorb
+        n_in = 0;
+        x = coop_permute(x, lane, k);
+        if (lane < 8) sout[lane] = x;
+        n_out = 8;
+    };
+    for (int w = 0; w < 8; w++) {
+        const uint32_t v = root[w];
+        if (lane == 0 && root_log) root_log[w] = v;
+        n_out = 0;
+        if (lane == 0) sin[n_in] = v;
+        n_in++;
+        if (n_in == 8) duplex();
+    }
+    for (int e = 0; e < 4; e++) {
+        if (n_in != 0 || n_out == 0) duplex();
+        --n_out;
+        if (lane == 0) beta_out[e] = sout[n_out];
+    }
+    c->state[lane] = x;
+    if (lane < 8) { c->in[lane] = sin[lane]; c->out[lane] = sout[lane]; }
+    if (lane == 0) { c->n_in = n_in; c->n_out = n_out; }
+}
+hipError_t launch_fri_challenge(DevChallenger* chal, const uint32_t* root, uint32_t* beta_out, uint32_t* root_log, hipStream_t s) {
+    hipLaunchKernelGGL(fri_challenge_kernel, dim3(1), dim3(64), 0, s, chal, root, beta_out, root_log);
+    return hipGetLastError();
+}
+
 // ------------------------------------------------------------------ RISC Zero layout (row a11)
 // column-major [cols][rows] polynomials, Poseidon2 width 24, rate 16: one row per lane, so a
 // wave reads 64 consecutive words of every column -- the layout is coalesced as it stands.

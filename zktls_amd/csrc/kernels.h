@@ -155,6 +155,20 @@ struct PermArgs {
 hipError_t launch_perm_trace(const PermArgs& a, uint32_t* block_scratch, hipStream_t s);
 
 hipError_t launch_fri_fold(const uint32_t* in, uint32_t* out, const uint32_t* itw, uint64_t half, const Ext& beta, hipStream_t s);
+// the same fold with the challenge read from device memory: beta = (*beta_ptr)^(2^squarings)
+hipError_t launch_fri_fold_dev(const uint32_t* in, uint32_t* out, const uint32_t* itw, uint64_t half, const uint32_t* beta_ptr,
+                               int squarings, hipStream_t s);
+
+// Fiat-Shamir duplex challenger state kept in device memory (same fields as the host Challenger, Montgomery words)
+struct DevChallenger {
+    uint32_t state[16];
+    uint32_t in[8];
+    uint32_t out[8];
+    int32_t n_in, n_out;
+};
+// observe the 8 words at `root`, then sample one extension element into beta_out[0..4); also copies the root to root_log
+// (one 16-lane cooperative permutation per duplexing; a single wave)
+hipError_t launch_fri_challenge(DevChallenger* chal, const uint32_t* root, uint32_t* beta_out, uint32_t* root_log, hipStream_t s);
 
 struct GrindArgs {
     uint32_t state[16];         // Montgomery

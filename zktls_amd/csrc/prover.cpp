@@ -78,7 +78,7 @@ constexpr uint32_t PROOF_MAGIC = 0x41544B5Au;   // "ZKTA"
 constexpr uint32_t PROOF_VERSION = 1u;
 
 enum Slot { S_COEF = 0, S_TMP = 1, S_TLDE, S_TTREE, S_QCHUNK, S_QLDE, S_QTREE, S_DINV, S_PARTIAL, S_OPEN_OUT,
-            S_APOW_Q, S_APOW_F, S_FRI_LAYERS, S_FRI_TREES, S_GATHER_DESC, S_GATHER_OUT, S_PERM, S_PLDE, S_PTREE };
+            S_APOW_Q, S_APOW_F, S_FRI_LAYERS, S_FRI_TREES, S_GATHER_DESC, S_GATHER_OUT, S_PERM, S_PLDE, S_PTREE, S_CHAL };
 
 static int pow2ceil(int v) { int r = 1; while (r < v) r <<= 1; return r; }
 
@@ -505,23 +505,59 @@ int zkhip_prove_shard(zkhip_ctx* ctx, const uint32_t* d_trace, size_t ld, int lo
         }
     }
     uint32_t* fold_tmp = (uint32_t*)v_at;                  // S_PARTIAL: the reduced-opening scratch is free again
+    // The per-layer transcript step (observe the root, sample beta) runs ON THE DEVICE (fri_challenge_kernel), so the
+    // whole commit loop is enqueued without a host round trip; afterwards the host replays the same steps on its own
+    // challenger from the logged roots and checks that both transcripts agree.  ZKHIP_FRI_HOST=1 keeps the round trips (A/B).
+    static const bool fri_on_host = [] { const char* e = getenv("ZKHIP_FRI_HOST"); return e && atoi(e) != 0; }();
+    void* v_chal = nullptr;
+    uint32_t *d_betas = nullptr, *d_roots = nullptr;
+    DevChallenger* d_chal = nullptr;
+    if (!fri_on_host && RL > 0) {
+        ZK_TRY(ctx_reserve(ctx, S_CHAL, sizeof(DevChallenger) + (size_t)RL * 12 * 4, &v_chal));
+        d_chal = (DevChallenger*)v_chal;
+        d_betas = (uint32_t*)((char*)v_chal + sizeof(DevChallenger));
+        d_roots = d_betas + 4 * (size_t)RL;
+        DevChallenger hc{};
+        for (int i = 0; i < 16; i++) hc.state[i] = ch.state[i];
+        for (int i = 0; i < 8; i++) { hc.in[i] = ch.in[i]; hc.out[i] = ch.out[i]; }
+        hc.n_in = ch.n_in; hc.n_out = ch.n_out;
+        ZK_TRY(h2d(ctx, d_chal, &hc, sizeof hc));
+    }
     for (int l = 0; l < RL; l++) {
         const int lh = H - K * (l + 1);
         const size_t rows = (size_t)1 << lh;
         uint32_t* cur = layers + layer_off[l];
         uint32_t* tree = ltrees + tree_off[l];
         ZK_TRY(commit_hw(ctx, cur, 4 * arity, (uint32_t)(4 * arity), lh, tree, sh.hw));
-        ZK_TRY(d2h(ctx, root, tree + (2 * rows - 2) * 8, 32));
-        for (int i = 0; i < 8; i++) { ch.observe(root[i]); pf[pos++] = from_monty(root[i]); }
-        Ext beta = ch.sample_ext();
+        Ext beta = ext_zero();
+        if (d_chal) {
+            ZK_HIP(launch_fri_challenge(d_chal, tree + (2 * rows - 2) * 8, d_betas + 4 * l, d_roots + 8 * l, st));
+        } else {
+            ZK_TRY(d2h(ctx, root, tree + (2 * rows - 2) * 8, 32));
+            for (int i = 0; i < 8; i++) { ch.observe(root[i]); pf[pos++] = from_monty(root[i]); }
+            beta = ch.sample_ext();
+        }
         // fold by 2 with beta, beta^2, beta^4, ...: f = sum_j X^j f_j(X^(2^K))  ->  sum_j beta^j f_j
         const uint32_t* src = cur;
         for (int j = 0; j < K; j++) {
             const size_t out_cnt = (size_t)1 << (H - K * l - j - 1);
             uint32_t* dst = (j == K - 1) ? layers + layer_off[l + 1] : fold_tmp + ((j & 1) ? 4 * (m / 2) : 0);
-            ZK_HIP(launch_fri_fold(src, dst, ctx->dom_itw, out_cnt, beta, st));
+            if (d_chal) ZK_HIP(launch_fri_fold_dev(src, dst, ctx->dom_itw, out_cnt, d_betas + 4 * l, j, st));
+            else ZK_HIP(launch_fri_fold(src, dst, ctx->dom_itw, out_cnt, beta, st));
             src = dst;
             beta = ext_mul(beta, beta);
+        }
+    }
+    if (d_chal) {
+        std::vector<uint32_t> log((size_t)RL * 12);
+        ZK_TRY(d2h(ctx, log.data(), d_betas, log.size() * 4));
+        for (int l = 0; l < RL; l++) {
+            const uint32_t* r = log.data() + 4 * (size_t)RL + 8 * (size_t)l;
+            for (int i = 0; i < 8; i++) { ch.observe(r[i]); pf[pos++] = from_monty(r[i]); }
+            const Ext beta = ch.sample_ext();
+            const uint32_t* b = log.data() + 4 * (size_t)l;
+            if (beta.c[0] != b[0] || beta.c[1] != b[1] || beta.c[2] != b[2] || beta.c[3] != b[3])
+                return fail(ZKHIP_ERR_INTERNAL, "prove_shard: device and host transcripts disagree in the FRI commit phase");
         }
     }
     // 2^(F+b) evaluations of a polynomial of < 2^F coefficients remain: interpolate on the host, send the coefficients

@@ -469,6 +469,23 @@ hipError_t launch_fri_fold(const uint32_t* in, uint32_t* out, const uint32_t* it
     return hipGetLastError();
 }
 
+__global__ void __launch_bounds__(256) fri_fold_dev_kernel(const uint32_t* in, uint32_t* out, const uint32_t* itw, uint64_t half,
+                                                           const uint32_t* beta_ptr, int squarings) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= half) return;
+    Ext beta = ld_ext(beta_ptr);
+    for (int j = 0; j < squarings; j++) beta = ext_mul(beta, beta);
+    const Ext e0 = ld_ext(in + 8 * i), e1 = ld_ext(in + 8 * i + 4);
+    const Ext s = ext_mul_base(ext_add(e0, e1), MONTY_INV2);
+    const Ext d = ext_mul_base(ext_sub(e0, e1), itw[i]);
+    st_ext(out + 4 * i, ext_add(s, ext_mul(beta, d)));
+}
+hipError_t launch_fri_fold_dev(const uint32_t* in, uint32_t* out, const uint32_t* itw, uint64_t half, const uint32_t* beta_ptr,
+                               int squarings, hipStream_t s) {
+    hipLaunchKernelGGL(fri_fold_dev_kernel, dim3((unsigned)((half + 255) / 256)), dim3(256), 0, s, in, out, itw, half, beta_ptr, squarings);
+    return hipGetLastError();
+}
+
 // ------------------------------------------------------------------ proof-of-work search
 // state: sponge state with the pending inputs already written to words [0, slot);
 // candidate w goes to word `slot`; hit when canonical(permute(state)[7]) & mask == 0.
