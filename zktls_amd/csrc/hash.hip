@@ -252,15 +252,9 @@ __global__ void __launch_bounds__(256) hash_rows16_kernel(LeafArgs a, uint32_t t
 // p3-challenger DuplexChallenger<16, 8> (the host Challenger of prover.cpp, word for word): observe the 8 root words,
 // sample 4.  One 16-lane row runs the permutation cooperatively, lane i holding state word i; the small input /
 // output buffers live in LDS.  Lets the FRI commit loop run without a host round trip per layer.
-__global__ void __launch_bounds__(64) fri_challenge_kernel(DevChallenger* c, const uint32_t* __restrict__ root, uint32_t* __restrict__ beta_out,
-                                                           uint32_t* __restrict__ root_log) {
-    __shared__ uint32_t sin[8], sout[8];
-    const int lane = threadIdx.x;                    // 64 launched, lanes 0..15 work (a DPP row)
-    if (lane >= 16) return;
-    const CoopConsts k = coop_load_consts(lane);
-    uint32_t x = c->state[lane];
-    int n_in = c->n_in, n_out = c->n_out;
-    if (lane < 8) { sin[lane] = c->in[lane]; sout[lane] = c->out[lane]; }
+// observe the 8 words at `root`, sample 4 into beta_out; executed by ONE 16-lane row (lane = 0..15), state word in x
+ZK_D void chal_observe_root_sample_ext(uint32_t& x, int& n_in, int& n_out, uint32_t* sin, uint32_t* sout, int lane, const CoopConsts& k,
+                                       const uint32_t* root, uint32_t* beta_out, uint32_t* root_log) {
     auto duplex = [&]() {
         if (lane < n_in) x = sin[lane];              // overwrite-mode absorb
         n_in = 0;
@@ -281,6 +275,17 @@ __global__ void __launch_bounds__(64) fri_challenge_kernel(DevChallenger* c, con
         --n_out;
         if (lane == 0) beta_out[e] = sout[n_out];
     }
+}
+__global__ void __launch_bounds__(64) fri_challenge_kernel(DevChallenger* c, const uint32_t* __restrict__ root, uint32_t* __restrict__ beta_out,
+                                                           uint32_t* __restrict__ root_log) {
+    __shared__ uint32_t sin[8], sout[8];
+    const int lane = threadIdx.x;                    // 64 launched, lanes 0..15 work (a DPP row)
+    if (lane >= 16) return;
+    const CoopConsts k = coop_load_consts(lane);
+    uint32_t x = c->state[lane];
+    int n_in = c->n_in, n_out = c->n_out;
+    if (lane < 8) { sin[lane] = c->in[lane]; sout[lane] = c->out[lane]; }
+    chal_observe_root_sample_ext(x, n_in, n_out, sin, sout, lane, k, root, beta_out, root_log);
     c->state[lane] = x;
     if (lane < 8) { c->in[lane] = sin[lane]; c->out[lane] = sout[lane]; }
     if (lane == 0) { c->n_in = n_in; c->n_out = n_out; }

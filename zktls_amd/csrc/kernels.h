@@ -170,6 +170,7 @@ struct DevChallenger {
 // (one 16-lane cooperative permutation per duplexing; a single wave)
 hipError_t launch_fri_challenge(DevChallenger* chal, const uint32_t* root, uint32_t* beta_out, uint32_t* root_log, hipStream_t s);
 
+
 struct GrindArgs {
     uint32_t state[16];         // Montgomery
     int slot;                   // where the candidate witness goes

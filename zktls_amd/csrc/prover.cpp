@@ -523,6 +523,7 @@ int zkhip_prove_shard(zkhip_ctx* ctx, const uint32_t* d_trace, size_t ld, int lo
         hc.n_in = ch.n_in; hc.n_out = ch.n_out;
         ZK_TRY(h2d(ctx, d_chal, &hc, sizeof hc));
     }
+    // (a single-workgroup kernel walking all layers of <= 512 rows was tried: no faster than these launches)
     for (int l = 0; l < RL; l++) {
         const int lh = H - K * (l + 1);
         const size_t rows = (size_t)1 << lh;
