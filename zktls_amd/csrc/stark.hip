@@ -281,15 +281,15 @@ __global__ void __launch_bounds__(256) open_partial_kernel(OpenArgs a) {
         }
     }
 }
-// out[pt][col] = -scale_pt * sum_chunk partial[chunk][pt][col]
-__global__ void __launch_bounds__(256) open_final_kernel(const uint32_t* partial, uint32_t nchunks, int npts, uint32_t width,
-                                                         Ext scale0, Ext scale1, uint32_t* out) {
-    const uint32_t idx = blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx >= (uint32_t)npts * width) return;
+// out[pt][col] = -scale_pt * sum_chunk partial[chunk][pt][col]; one wave per output, the chunks spread over its lanes
+__global__ void __launch_bounds__(64) open_final_kernel(const uint32_t* partial, uint32_t nchunks, int npts, uint32_t width,
+                                                        Ext scale0, Ext scale1, uint32_t* out) {
+    const uint32_t idx = blockIdx.x;
     const uint32_t k = idx / width, col = idx % width;
     Ext sum = ext_zero();
-    for (uint32_t c = 0; c < nchunks; c++) sum = ext_add(sum, ld_ext(partial + 4 * (((uint64_t)c * npts + k) * width + col)));
-    st_ext(out + 4 * (uint64_t)idx, ext_neg(ext_mul(sum, k ? scale1 : scale0)));
+    for (uint32_t c = threadIdx.x; c < nchunks; c += 64) sum = ext_add(sum, ld_ext(partial + 4 * (((uint64_t)c * npts + k) * width + col)));
+    sum = group_sum(sum, 64);
+    if (threadIdx.x == 0) st_ext(out + 4 * (uint64_t)idx, ext_neg(ext_mul(sum, k ? scale1 : scale0)));
 }
 hipError_t launch_open(const OpenArgs& a, int npts, const Ext& scale0, const Ext& scale1, uint32_t* out, hipStream_t s) {
     const uint32_t nchunks = (uint32_t)((a.rows + OPEN_ROWS - 1) / OPEN_ROWS);
@@ -299,7 +299,7 @@ hipError_t launch_open(const OpenArgs& a, int npts, const Ext& scale0, const Ext
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return e;
     const uint32_t n = (uint32_t)npts * a.width;
-    hipLaunchKernelGGL(open_final_kernel, dim3((n + 255) / 256), dim3(256), 0, s, a.partial, nchunks, npts, a.width, scale0, scale1, out);
+    hipLaunchKernelGGL(open_final_kernel, dim3(n), dim3(64), 0, s, a.partial, nchunks, npts, a.width, scale0, scale1, out);
     return hipGetLastError();
 }
 
