@@ -3,6 +3,7 @@ buffers.  Used by the tests, bench.py and the host-side prover mirror (prover.py
 All numpy arrays crossing this layer are CANONICAL residues unless a name says monty.
 """
 import ctypes as C
+import weakref
 
 import numpy as np
 
@@ -22,6 +23,7 @@ class DeviceBuffer:
             p = C.c_void_p()
             check(ctx.lib.zkhip_malloc(ctx.handle, C.c_size_t(self.nwords * 4), C.byref(p)))
             ptr = p.value
+            ctx._buffers.add(self)
         self.ptr = ptr
 
     def offset(self, words):
@@ -45,9 +47,9 @@ class DeviceBuffer:
         return from_monty(self.download_monty(nwords, offset))
 
     def free(self):
-        if self._owned and self.ptr:
+        if self._owned and self.ptr and self.ctx.handle:
             self.ctx.lib.zkhip_free(self.ctx.handle, C.c_void_p(self.ptr))
-            self.ptr = None
+        self.ptr = None
 
     def __del__(self):
         try:
@@ -63,9 +65,12 @@ class Context:
         check(self.lib.zkhip_ctx_create(int(device), C.c_void_p(stream) if stream else None, C.byref(h)))
         self.handle = h
         self.device = device
+        self._buffers = weakref.WeakSet()     # allocations made through this context, freed with it
 
     def close(self):
         if self.handle:
+            for b in list(self._buffers):
+                b.free()
             self.lib.zkhip_ctx_destroy(self.handle)
             self.handle = None
 
