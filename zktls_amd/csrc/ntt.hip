@@ -17,6 +17,8 @@
 //   store     * post[tile][k] (inter-pass twiddle / coset shift / 1/N, staged in LDS),
 //             written natural or bit-reversed inside the tile.
 // No MFMA: a 31-bit modular butterfly is not a dense contraction.
+#include <atomic>
+
 #include "babybear.cuh"
 #include "kernels.h"
 
@@ -410,11 +412,11 @@ __global__ void __launch_bounds__(512) ntt_pass1024x2_kernel(NttPassArgs a, uint
 }
 
 static int cu_count() {
-    static int n = 0;
-    if (n == 0) {
-        int dev = 0;
-        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
-    }
+    static const int n = [] {         // initialised once, thread-safe
+        int dev = 0, v = 0;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || v <= 0) v = 256;
+        return v;
+    }();
     return n;
 }
 
@@ -423,11 +425,11 @@ static hipError_t launch_ntt1024x2(const NttPassArgs& a, hipStream_t s) {
     const uint32_t total = a.num_tiles * (a.ncols / 32);
     const uint32_t grid = total < (uint32_t)cu_count() ? total : (uint32_t)cu_count();
     const size_t lds = (size_t)(2 * 32 * 33 * 16 + 3 * 1024) * sizeof(uint32_t);
-    static bool configured = false;
-    if (!configured) {
+    static std::atomic<bool> configured{false};       // several host threads (one context each) launch concurrently
+    if (!configured.load(std::memory_order_acquire)) {
         hipError_t e = hipFuncSetAttribute((const void*)ntt_pass1024x2_kernel<INV>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
-        configured = true;
+        configured.store(true, std::memory_order_release);
     }
     hipLaunchKernelGGL((ntt_pass1024x2_kernel<INV>), dim3(grid), dim3(512), lds, s, a, total);
     return hipGetLastError();
@@ -445,12 +447,12 @@ static hipError_t launch_ntt_k(const NttPassArgs& a, hipStream_t s) {
     const int b = (int)a.log_m - 5;
     dim3 grid(a.num_tiles * ncg), block((1 << b) << LOG_C);
     const size_t lds = ntt_lds_bytes((int)a.log_m, LOG_C);
-    static size_t configured = 0;      // raise the dynamic-LDS cap once per instantiation
-    if (lds > configured) {
+    static std::atomic<size_t> configured{0};      // raise the dynamic-LDS cap once per instantiation (thread-safe)
+    if (lds > configured.load(std::memory_order_acquire)) {
         hipError_t e = hipFuncSetAttribute((const void*)ntt_pass_kernel<LOG_C, INV, CPT, BFIX>,
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
-        configured = lds;
+        configured.store(lds, std::memory_order_release);
     }
     hipLaunchKernelGGL((ntt_pass_kernel<LOG_C, INV, CPT, BFIX>), grid, block, lds, s, a);
     return hipGetLastError();
