@@ -327,18 +327,50 @@ __global__ void __launch_bounds__(256) compress24_level_kernel(const uint32_t* _
     d[0] = make_uint4(s[0], s[1], s[2], s[3]);
     d[1] = make_uint4(s[4], s[5], s[6], s[7]);
 }
+// all levels from `count` (<= 2048) nodes down to the root in one workgroup: the small levels are pure launch latency
+__global__ void __launch_bounds__(1024) compress24_top_kernel(uint32_t* tree, uint32_t count) {
+    uint32_t* level = tree;
+    for (uint32_t n = count; n > 1; n >>= 1) {
+        uint32_t* next = level + 8 * (size_t)n;
+        for (uint32_t i = threadIdx.x; i < n / 2; i += blockDim.x) {
+            const uint4* cp = reinterpret_cast<const uint4*>(level + 16 * (size_t)i);
+            const uint4 v0 = cp[0], v1 = cp[1], v2 = cp[2], v3 = cp[3];
+            uint32_t s[24] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w, v2.x, v2.y, v2.z, v2.w, v3.x, v3.y, v3.z, v3.w,
+                              0, 0, 0, 0, 0, 0, 0, 0};
+            p24_permute_dev(s);
+            uint4* d = reinterpret_cast<uint4*>(next + 8 * (size_t)i);
+            d[0] = make_uint4(s[0], s[1], s[2], s[3]);
+            d[1] = make_uint4(s[4], s[5], s[6], s[7]);
+        }
+        __threadfence_block();
+        __syncthreads();
+        level = next;
+    }
+}
+// levels above the leaf digests of a width-24 tree: wide levels one launch each, the top 2048 nodes in one
+static hipError_t compress24_levels(uint32_t* tree, uint64_t rows, hipStream_t s) {
+    hipError_t e = hipSuccess;
+    uint32_t* level = tree;
+    uint64_t cnt = rows;
+    while (cnt > 2048 && e == hipSuccess) {
+        uint32_t* next = level + 8 * cnt;
+        hipLaunchKernelGGL(compress24_level_kernel, dim3((unsigned)((cnt / 2 + 255) / 256)), dim3(256), 0, s, level, next, cnt / 2);
+        e = hipGetLastError();
+        level = next; cnt >>= 1;
+    }
+    if (e == hipSuccess && cnt > 1) {
+        const unsigned threads = cnt / 2 < 64 ? 64 : (cnt / 2 > 1024 ? 1024 : (unsigned)(cnt / 2));
+        hipLaunchKernelGGL(compress24_top_kernel, dim3(1), dim3(threads), 0, s, level, (uint32_t)cnt);
+        e = hipGetLastError();
+    }
+    return e;
+}
 hipError_t launch_merkle_p24_colmajor(const uint32_t* mat, uint32_t cols, int log_rows, uint32_t* tree, hipStream_t s) {
     const uint64_t rows = (uint64_t)1 << log_rows;
     hipLaunchKernelGGL(hash_cols24_kernel, dim3((unsigned)((rows + 255) / 256)), dim3(256), 0, s, mat, cols, rows, tree);
     hipError_t e = hipGetLastError();
-    uint32_t* level = tree;
-    for (uint64_t cnt = rows / 2; cnt >= 1 && e == hipSuccess; cnt >>= 1) {
-        uint32_t* next = level + 16 * cnt;
-        hipLaunchKernelGGL(compress24_level_kernel, dim3((unsigned)((cnt + 255) / 256)), dim3(256), 0, s, level, next, cnt);
-        e = hipGetLastError();
-        level = next;
-    }
-    return e;
+    if (e != hipSuccess) return e;
+    return compress24_levels(tree, rows, s);
 }
 
 // row-major matrix (rows x ld words, width % 4 == 0, 16-byte aligned rows), same hash: the leaves of the
@@ -366,14 +398,8 @@ hipError_t launch_merkle_p24_rowmajor(const uint32_t* mat, uint64_t ld, uint32_t
     const uint64_t rows = (uint64_t)1 << log_rows;
     hipLaunchKernelGGL(hash_rows24_kernel, dim3((unsigned)((rows + 255) / 256)), dim3(256), 0, s, mat, ld, width, rows, tree);
     hipError_t e = hipGetLastError();
-    uint32_t* level = tree;
-    for (uint64_t cnt = rows / 2; cnt >= 1 && e == hipSuccess; cnt >>= 1) {
-        uint32_t* next = level + 16 * cnt;
-        hipLaunchKernelGGL(compress24_level_kernel, dim3((unsigned)((cnt + 255) / 256)), dim3(256), 0, s, level, next, cnt);
-        e = hipGetLastError();
-        level = next;
-    }
-    return e;
+    if (e != hipSuccess) return e;
+    return compress24_levels(tree, rows, s);
 }
 
 __global__ void __launch_bounds__(256) permute_states_kernel(uint32_t* states, uint64_t count) {
