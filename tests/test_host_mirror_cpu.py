@@ -124,3 +124,69 @@ def test_r0_twin_proves_segments_in_risc0_shape(lib):
         proof = np.frombuffer(blob[offs[s]:offs[s] + lens[s]], dtype=np.uint8)
         assert verify_shard(proof, 12, 8, digest + [s], prm) == (0, 0)
         assert verify_shard(proof, 12, 8, digest + [s], Params(1, 100, 16))[0] == -6     # not an SP1-shape proof
+
+
+# ------------------------------------------------------------------ the reference's own request fixtures (data only)
+REF = os.path.join(ROOT, "tests", "golden", "reference")
+
+
+def _cbor_top_level_map_keys(b):
+    """just enough CBOR (RFC 8949) to list the text keys of a top-level map"""
+    def head(i):
+        ib = b[i]; major, info = ib >> 5, ib & 31
+        if info < 24: return major, info, i + 1
+        n = 1 << (info - 24)
+        return major, int.from_bytes(b[i + 1:i + 1 + n], "big"), i + 1 + n
+    def skip(i):
+        major, val, i = head(i)
+        if major in (0, 1, 7): return i
+        if major in (2, 3): return i + val
+        if major == 4:
+            for _ in range(val): i = skip(i)
+            return i
+        if major == 5:
+            for _ in range(2 * val): i = skip(i)
+            return i
+        if major == 6: return skip(i)
+        raise ValueError("cbor")
+    major, n, i = head(0)
+    assert major == 5
+    keys = []
+    for _ in range(n):
+        m, ln, j = head(i)
+        assert m == 3
+        keys.append(b[j:j + ln].decode())
+        i = skip(j + ln)
+    assert i == len(b)
+    return keys
+
+
+def test_reference_transcript_fixture_is_bound_by_the_digest(lib):
+    cbor = open(os.path.join(REF, "guest_input0.cbor"), "rb").read()
+    assert len(cbor) == 13217
+    assert len(_cbor_top_level_map_keys(cbor)) >= 1          # a well-formed CBOR map: the GuestInput of sp1.rs:108-111
+    elf = b"\x7fELF" + bytes(range(64))
+    rc, err, out, proof = call(lib, 0, cbor, elf)
+    assert rc == 0 and proof == b"" and len(out) == 32       # mock mode: public output only
+    flipped = bytearray(cbor); flipped[6000] ^= 1
+    assert call(lib, 0, bytes(flipped), elf)[2] != out       # any byte of the transcript changes the public values
+    req = open(os.path.join(REF, "input.json"), "rb").read()
+    assert call(lib, 0, req, elf)[2] != out
+
+
+@pytest.mark.gpu
+def test_reference_transcript_batch_is_proven_shard_parallel(lib):
+    # BASELINE.json configs[1..3]: the recorded transcript, several shards per request, each proof bound to the request
+    from zktls_amd._lib import Params
+    from zktls_amd.device import verify_shard
+    cbor = open(os.path.join(REF, "guest_input0.cbor"), "rb").read()
+    plan = Plan(10, 16, 4, 20, 8)
+    rc, err, out, blob = call(lib, 2, cbor, b"\x7fELFguest", plan)
+    assert rc == 0, err
+    offs, lens = (C.c_size_t * 8)(), (C.c_size_t * 8)()
+    assert lib.zktls_unpack_batch(blob, len(blob), offs, lens, 8) == 4
+    digest = np.frombuffer(out, dtype=np.uint32).tolist()
+    proofs = [np.frombuffer(blob[offs[s]:offs[s] + lens[s]], dtype=np.uint8) for s in range(4)]
+    for s in range(4):
+        assert verify_shard(proofs[s], 10, 16, digest + [s], Params(1, 20, 8)) == (0, 0)
+    assert verify_shard(proofs[1], 10, 16, digest + [2], Params(1, 20, 8))[0] == -6     # a proof does not transfer to another shard
