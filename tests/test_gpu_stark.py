@@ -247,3 +247,18 @@ def test_concurrent_contexts_give_the_same_proofs(ctx, oracle):
     for w in range(3):
         assert all(g == expected[w] for g in got[w])
         ctxs[w].close()
+
+
+@pytest.mark.parametrize("log_n,width", [(8, 320), (9, 512), (8, 1024), (6, 36), (7, 100)])
+def test_prove_shard_wide_and_ragged_widths(ctx, oracle, log_n, width):
+    # widths that are not powers of two, and the widest supported trace (1024 columns: 16 column groups per lane in the quotient)
+    prm, oprm = Params(1, 8, 4), oracle.default_params(1, 8, 4)
+    proof = ctx.prove_shard(ctx.gen_trace(SEED, 2, log_n, width), log_n, width, [], prm)
+    assert proof.tobytes() == oracle.prove_shard(oracle.gen_trace(SEED, 2, log_n, width), [], oprm).tobytes()
+    assert verify_shard(proof, log_n, width, [], prm) == (0, 0)
+
+
+def test_width_above_the_limit_is_refused(ctx):
+    from zktls_amd._lib import ZkHipError
+    with pytest.raises(ZkHipError):
+        ctx.prove_shard(ctx.gen_trace(SEED, 0, 6, 1028), 6, 1028, [], Params(1, 8, 4))
