@@ -1,0 +1,384 @@
+/*
+ * oracle/chips.c -- a shard made of several chips (AIR tables) of DIFFERENT heights, proven together, CPU restatement.
+ * TEST INFRASTRUCTURE ONLY; PARITY UNPINNED (see oracle/oracle.h).
+ *
+ * This is the structure of an SP1 shard (sp1-stark 4.1.4 `ShardProof`, reference Cargo.lock:6172; call site
+ * crates/guest-prover-sp1/src/sp1.rs:116): every chip has its own trace height, but there is ONE commitment per phase
+ * and ONE FRI proof.  Restated from the published construction of p3-fri 0.2.1-succinct TwoAdicFriPcs + p3-merkle-tree
+ * FieldMerkleTreeMmcs (Cargo.lock:3930, :4013):
+ *   commit      all LDEs go into one Merkle tree: the tallest matrices form the leaves, a shorter matrix is injected at
+ *               the level that has as many nodes as it has rows (oracle/merkle.c);
+ *   quotient    per chip, on that chip's own coset g <w_2N_c>, same constraint challenge alpha; the chunk LDEs of all
+ *               chips form the second tree;
+ *   open        every chip at the same zeta, and at zeta * g_c (g_c generates the chip's trace domain);
+ *   FRI input   one reduced-opening vector PER HEIGHT (alpha powers run on across the chips of that height);
+ *   FRI         starts from the tallest vector; after each fold, the vector of the height just reached is added in;
+ *   query       one index; a chip of height 2^h is opened at index >> (Hmax - h); one Merkle path per tree.
+ * Chips use the synthetic AIR of stark.c at their own width.  Shape: the SP1 FRI shape (fold by 2, constant final
+ * polynomial, Poseidon2 width 16) at any log_blowup in [1, 3]; no lookups between chips.
+ */
+#include "oracle.h"
+#include "stark_internal.h"
+#include <stdlib.h>
+#include <string.h>
+
+#define ld4 orc__ld4
+#define st4 orc__st4
+#define CHIPS_MAGIC 0x41544B5Au
+#define CHIPS_VERSION 4u
+#define MAX_CHIPS 16
+
+static bb4_t sample_ext(orc_challenger_t* ch) { bb4_t r; orc_chal_sample_ext(ch, r.c); return r; }
+
+static int chips_ok(const int* log_ns, const size_t* widths, int n, const orc_params_t* prm) {
+    if (n < 1 || n > MAX_CHIPS) return 0;
+    if (prm->log_blowup < 1 || prm->log_blowup > 3) return 0;
+    if ((prm->log_fold != 0 && prm->log_fold != 1) || prm->log_final != 0 || (prm->hash_width != 0 && prm->hash_width != 16)) return 0;
+    if (prm->logup_pairs != 0) return 0;
+    for (int c = 0; c < n; c++) {
+        if (log_ns[c] < 5 || log_ns[c] > 20 || widths[c] == 0 || widths[c] % 4 != 0 || widths[c] > 1024) return 0;
+        if (c && log_ns[c] > log_ns[c - 1]) return 0;             /* tallest first */
+    }
+    for (int c = 0; c < n; c++) {                                  /* at most 4 chips share a height (one leaf hash) */
+        int same = 0;
+        for (int d = 0; d < n; d++) if (log_ns[d] == log_ns[c]) same++;
+        if (same > 4) return 0;
+    }
+    return 1;
+}
+
+size_t orc_chips_proof_size(const int* log_ns, const size_t* widths, int n, const orc_params_t* prm, size_t n_public) {
+    (void)n_public;
+    if (!chips_ok(log_ns, widths, n, prm)) return 0;
+    size_t b = (size_t)prm->log_blowup, Hmax = (size_t)log_ns[0] + b, L = (size_t)log_ns[0];
+    size_t words = 8 + 2 * (size_t)n + 16 + 8 * L + 4 + 1;
+    size_t perq = 16 * Hmax;
+    for (int c = 0; c < n; c++) { words += 8 * widths[c] + 32; perq += widths[c] + 8; }
+    for (size_t l = 0; l < L; l++) perq += 4 + 8 * (Hmax - 1 - l);
+    return (words + (size_t)prm->num_queries * perq) * 4;
+}
+
+static void transcript_init(orc_challenger_t* ch, const int* log_ns, const size_t* widths, int n, const orc_params_t* prm, size_t n_public) {
+    orc_chal_init(ch);
+    orc_chal_observe(ch, CHIPS_VERSION);
+    orc_chal_observe(ch, (uint32_t)n);
+    orc_chal_observe(ch, (uint32_t)prm->log_blowup);
+    orc_chal_observe(ch, (uint32_t)prm->num_queries);
+    orc_chal_observe(ch, (uint32_t)prm->pow_bits);
+    orc_chal_observe(ch, (uint32_t)n_public);
+    for (int c = 0; c < n; c++) { orc_chal_observe(ch, (uint32_t)log_ns[c]); orc_chal_observe(ch, (uint32_t)widths[c]); }
+}
+
+/* alpha-power offset of chip c inside the reduced-opening vector of its height: the chips of one height share one power
+ * sequence, each contributing [trace@zeta (W), trace@zeta*g (W), quotient chunks@zeta (8)] */
+static size_t height_offset(const int* log_ns, const size_t* widths, int c) {
+    size_t off = 0;
+    for (int d = 0; d < c; d++) if (log_ns[d] == log_ns[c]) off += 2 * widths[d] + 8;
+    return off;
+}
+
+size_t orc_prove_chips(const uint32_t* const* traces, const int* log_ns, const size_t* widths, int n,
+                       const uint32_t* public_values, size_t n_public, const orc_params_t* prm,
+                       uint8_t* proof_bytes, size_t cap) {
+    size_t need = orc_chips_proof_size(log_ns, widths, n, prm, n_public);
+    if (need == 0 || cap < need) return 0;
+    uint32_t* pf = (uint32_t*)proof_bytes;
+    size_t pos = 0;
+    const int b = prm->log_blowup, Hmax = log_ns[0] + b, L = log_ns[0];
+    pf[pos++] = CHIPS_MAGIC; pf[pos++] = CHIPS_VERSION; pf[pos++] = (uint32_t)n; pf[pos++] = (uint32_t)b;
+    pf[pos++] = (uint32_t)prm->num_queries; pf[pos++] = (uint32_t)prm->pow_bits; pf[pos++] = (uint32_t)n_public; pf[pos++] = 16u;
+    for (int c = 0; c < n; c++) { pf[pos++] = (uint32_t)log_ns[c]; pf[pos++] = (uint32_t)widths[c]; }
+    orc_challenger_t ch;
+    transcript_init(&ch, log_ns, widths, n, prm, n_public);
+
+    /* 1. trace LDEs, one mixed-height tree */
+    uint32_t* tlde[MAX_CHIPS]; uint32_t* qlde[MAX_CHIPS];
+    int lh[MAX_CHIPS]; size_t w8[MAX_CHIPS];
+    for (int c = 0; c < n; c++) {
+        lh[c] = log_ns[c] + b; w8[c] = 8;
+        tlde[c] = (uint32_t*)malloc(((size_t)1 << lh[c]) * widths[c] * 4);
+        orc_coset_lde(traces[c], tlde[c], log_ns[c], widths[c], b, BB_GEN);
+    }
+    const size_t mmax = (size_t)1 << Hmax;
+    uint32_t* ttree = (uint32_t*)malloc((2 * mmax - 1) * 32);
+    orc_merkle_tree_mixed((const uint32_t* const*)tlde, widths, lh, n, ttree);
+    const uint32_t* troot = ttree + (2 * mmax - 2) * 8;
+    memcpy(pf + pos, troot, 32); pos += 8;
+    orc_chal_observe_slice(&ch, troot, 8);
+    orc_chal_observe_slice(&ch, public_values, n_public);
+
+    /* 2. quotients, per chip on its own 2N_c coset (= the first 2N_c rows of its LDE), chunk LDEs, second tree */
+    bb4_t alpha = sample_ext(&ch);
+    for (int c = 0; c < n; c++) {
+        const int ln = log_ns[c], Hq = ln + 1;
+        const size_t nc = (size_t)1 << ln, mc = (size_t)1 << lh[c], mq = (size_t)1 << Hq;
+        uint32_t* qv = (uint32_t*)malloc(mq * 16);
+        orc_quotient_values(tlde[c], ln, widths[c], alpha.c, qv);
+        qlde[c] = (uint32_t*)malloc(mc * 8 * 4);
+        uint32_t* chunk = (uint32_t*)malloc(nc * 16);
+        uint32_t* clde = (uint32_t*)malloc(mc * 16);
+        bb_t w2n = bb_two_adic_generator(Hq);
+        for (int k = 0; k < 2; k++) {
+            for (size_t j = 0; j < nc; j++) memcpy(chunk + 4 * j, qv + 4 * bb_reverse_bits((uint32_t)(2 * j + k), Hq), 16);
+            orc_coset_lde(chunk, clde, ln, 4, b, bb_inv(bb_pow(w2n, (uint64_t)k)));
+            for (size_t r = 0; r < mc; r++) memcpy(qlde[c] + r * 8 + 4 * k, clde + r * 4, 16);
+        }
+        free(qv); free(chunk); free(clde);
+    }
+    uint32_t* qtree = (uint32_t*)malloc((2 * mmax - 1) * 32);
+    orc_merkle_tree_mixed((const uint32_t* const*)qlde, w8, lh, n, qtree);
+    const uint32_t* qroot = qtree + (2 * mmax - 2) * 8;
+    memcpy(pf + pos, qroot, 32); pos += 8;
+    orc_chal_observe_slice(&ch, qroot, 8);
+
+    /* 3. openings: one zeta for every chip, "next" point zeta * g_c */
+    bb4_t zeta = sample_ext(&ch);
+    uint32_t* op[MAX_CHIPS];                       /* per chip: local (4W) | next (4W) | quotient (32) */
+    for (int c = 0; c < n; c++) {
+        op[c] = pf + pos; pos += 8 * widths[c] + 32;
+        bb4_t zn = bb4_mul_base(zeta, bb_two_adic_generator(log_ns[c]));
+        orc_open_at(tlde[c], log_ns[c], widths[c], zeta.c, op[c]);
+        orc_open_at(tlde[c], log_ns[c], widths[c], zn.c, op[c] + 4 * widths[c]);
+        orc_open_at(qlde[c], log_ns[c], 8, zeta.c, op[c] + 8 * widths[c]);
+    }
+    for (int c = 0; c < n; c++) orc_chal_observe_slice(&ch, op[c], 8 * widths[c] + 32);
+
+    /* 4. one reduced-opening vector per height */
+    bb4_t fa = sample_ext(&ch);
+    bb4_t* ro[32];
+    for (int h = 0; h < 32; h++) ro[h] = NULL;
+    for (int c = 0; c < n; c++) {
+        const size_t W = widths[c], mc = (size_t)1 << lh[c];
+        size_t np = W > 8 ? W : 8;
+        bb4_t* fapow = (bb4_t*)malloc(np * sizeof(bb4_t));
+        fapow[0] = bb4_one();
+        for (size_t j = 1; j < np; j++) fapow[j] = bb4_mul(fapow[j - 1], fa);
+        bb4_t y_loc = bb4_zero(), y_nxt = bb4_zero(), y_q = bb4_zero();
+        for (size_t j = 0; j < W; j++) {
+            y_loc = bb4_add(y_loc, bb4_mul(fapow[j], ld4(op[c] + 4 * j)));
+            y_nxt = bb4_add(y_nxt, bb4_mul(fapow[j], ld4(op[c] + 4 * W + 4 * j)));
+        }
+        for (size_t j = 0; j < 8; j++) y_q = bb4_add(y_q, bb4_mul(fapow[j], ld4(op[c] + 8 * W + 4 * j)));
+        const size_t off = height_offset(log_ns, widths, c);
+        bb4_t s_loc = bb4_pow(fa, off), s_nxt = bb4_pow(fa, off + W), s_q = bb4_pow(fa, off + 2 * W);
+        bb4_t zn = bb4_mul_base(zeta, bb_two_adic_generator(log_ns[c]));
+        if (!ro[lh[c]]) ro[lh[c]] = (bb4_t*)calloc(mc, sizeof(bb4_t));
+        bb4_t* dst = ro[lh[c]];
+        bb_t wm = bb_two_adic_generator(lh[c]);
+#pragma omp parallel for schedule(static)
+        for (size_t p = 0; p < mc; p++) {
+            bb_t x = bb_mul(BB_GEN, bb_pow(wm, bb_reverse_bits((uint32_t)p, lh[c])));
+            bb4_t d1 = bb4_inv(bb4_neg(bb4_sub_base(zeta, x)));
+            bb4_t d2 = bb4_inv(bb4_neg(bb4_sub_base(zn, x)));
+            bb4_t at = orc__row_dot(fapow, tlde[c] + p * W, W), aq = orc__row_dot(fapow, qlde[c] + p * 8, 8);
+            bb4_t r = bb4_mul(s_loc, bb4_mul(bb4_sub(at, y_loc), d1));
+            r = bb4_add(r, bb4_mul(s_nxt, bb4_mul(bb4_sub(at, y_nxt), d2)));
+            r = bb4_add(r, bb4_mul(s_q, bb4_mul(bb4_sub(aq, y_q), d1)));
+            dst[p] = bb4_add(dst[p], r);
+        }
+        free(fapow);
+    }
+
+    /* 5. FRI commit phase with the shorter vectors joining at their height */
+    bb4_t** layers = (bb4_t**)malloc(L * sizeof(bb4_t*));
+    uint32_t** ltrees = (uint32_t**)malloc(L * sizeof(uint32_t*));
+    uint32_t* commits = pf + pos; pos += 8 * (size_t)L;
+    bb4_t* cur = ro[Hmax];
+    ro[Hmax] = NULL;
+    for (int l = 0; l < L; l++) {
+        const int rows_log = Hmax - 1 - l;
+        const size_t rows = (size_t)1 << rows_log;
+        layers[l] = cur;
+        ltrees[l] = (uint32_t*)malloc((2 * rows - 1) * 32);
+        orc_merkle_tree_hw((const uint32_t*)cur, 8, rows_log, ltrees[l], 16);
+        const uint32_t* root = ltrees[l] + (2 * rows - 2) * 8;
+        memcpy(commits + 8 * l, root, 32);
+        orc_chal_observe_slice(&ch, root, 8);
+        bb4_t beta = sample_ext(&ch);
+        bb4_t* nxt = (bb4_t*)malloc(rows * sizeof(bb4_t));
+        orc_fri_fold((const uint32_t*)cur, rows_log + 1, beta.c, (uint32_t*)nxt);
+        if (ro[rows_log]) {
+            for (size_t i = 0; i < rows; i++) nxt[i] = bb4_add(nxt[i], ro[rows_log][i]);
+            free(ro[rows_log]); ro[rows_log] = NULL;
+        }
+        cur = nxt;
+    }
+    int const_ok = 1;
+    for (size_t i = 1; i < ((size_t)1 << b); i++) if (!bb4_eq(cur[0], cur[i])) const_ok = 0;
+    st4(pf + pos, cur[0]); pos += 4;
+    orc_chal_observe_slice(&ch, cur[0].c, 4);
+    free(cur);
+
+    /* 6. proof of work, queries */
+    uint32_t witness = orc_chal_grind(&ch, prm->pow_bits);
+    pf[pos++] = witness;
+    for (int q = 0; q < prm->num_queries; q++) {
+        size_t index = orc_chal_sample_bits(&ch, Hmax);
+        for (int c = 0; c < n; c++) { memcpy(pf + pos, tlde[c] + (index >> (Hmax - lh[c])) * widths[c], widths[c] * 4); pos += widths[c]; }
+        orc__copy_path(pf, &pos, ttree, mmax, index, Hmax);
+        for (int c = 0; c < n; c++) { memcpy(pf + pos, qlde[c] + (index >> (Hmax - lh[c])) * 8, 32); pos += 8; }
+        orc__copy_path(pf, &pos, qtree, mmax, index, Hmax);
+        size_t idx = index;
+        for (int l = 0; l < L; l++) {
+            const int rows_log = Hmax - 1 - l;
+            st4(pf + pos, layers[l][idx ^ 1]); pos += 4;
+            orc__copy_path(pf, &pos, ltrees[l], (size_t)1 << rows_log, idx >> 1, rows_log);
+            idx >>= 1;
+        }
+    }
+    for (int l = 0; l < L; l++) { free(layers[l]); free(ltrees[l]); }
+    free(layers); free(ltrees); free(ttree); free(qtree);
+    for (int c = 0; c < n; c++) { free(tlde[c]); free(qlde[c]); }
+    for (int h = 0; h < 32; h++) free(ro[h]);
+    if (!const_ok) return 0;
+    return pos * 4 == need ? need : 0;
+}
+
+/* opening of a mixed-height tree: rows[c] is chip c's row at index >> (Hmax - lh[c]) */
+static int verify_mixed(const uint32_t root[8], int Hmax, size_t index, const uint32_t* const* rows, const size_t* widths,
+                        const int* lh, int n, const uint32_t* sibs) {
+    uint32_t buf[4 * 1024 + 8], cur[8];
+    size_t len = 0;
+    for (int c = 0; c < n; c++) if (lh[c] == Hmax) { memcpy(buf + len, rows[c], widths[c] * 4); len += widths[c]; }
+    orc_sponge_hash(buf, len, cur);
+    for (int lvl = 0; lvl < Hmax; lvl++) {
+        const uint32_t* sib = sibs + 8 * lvl;
+        if ((index >> lvl) & 1) orc_compress(sib, cur, cur);
+        else orc_compress(cur, sib, cur);
+        const int h = Hmax - lvl - 1;
+        len = 0;
+        for (int c = 0; c < n; c++) if (lh[c] == h) { memcpy(buf + len, rows[c], widths[c] * 4); len += widths[c]; }
+        if (len) {
+            uint32_t rh[8];
+            orc_sponge_hash(buf, len, rh);
+            orc_compress(cur, rh, cur);
+        }
+    }
+    return memcmp(cur, root, 32) == 0 ? 0 : 1;
+}
+
+int orc_verify_chips(const uint8_t* proof_bytes, size_t len, const int* log_ns, const size_t* widths, int n,
+                     const uint32_t* public_values, size_t n_public, const orc_params_t* prm) {
+    if (!chips_ok(log_ns, widths, n, prm)) return 1;
+    if (len != orc_chips_proof_size(log_ns, widths, n, prm, n_public)) return 2;
+    const uint32_t* pf = (const uint32_t*)proof_bytes;
+    const int b = prm->log_blowup, Hmax = log_ns[0] + b, L = log_ns[0];
+    if (pf[0] != CHIPS_MAGIC || pf[1] != CHIPS_VERSION || pf[2] != (uint32_t)n || pf[3] != (uint32_t)b ||
+        pf[4] != (uint32_t)prm->num_queries || pf[5] != (uint32_t)prm->pow_bits || pf[6] != (uint32_t)n_public || pf[7] != 16u) return 3;
+    size_t pos = 8;
+    for (int c = 0; c < n; c++) { if (pf[pos] != (uint32_t)log_ns[c] || pf[pos + 1] != (uint32_t)widths[c]) return 3; pos += 2; }
+    for (size_t i = pos; i < len / 4; i++) if (pf[i] >= BB_P) return 4;
+    int lh[MAX_CHIPS]; size_t w8[MAX_CHIPS];
+    for (int c = 0; c < n; c++) { lh[c] = log_ns[c] + b; w8[c] = 8; }
+
+    orc_challenger_t ch;
+    transcript_init(&ch, log_ns, widths, n, prm, n_public);
+    const uint32_t* troot = pf + pos; pos += 8;
+    orc_chal_observe_slice(&ch, troot, 8);
+    orc_chal_observe_slice(&ch, public_values, n_public);
+    bb4_t alpha = sample_ext(&ch);
+    const uint32_t* qroot = pf + pos; pos += 8;
+    orc_chal_observe_slice(&ch, qroot, 8);
+    bb4_t zeta = sample_ext(&ch);
+    const uint32_t* op[MAX_CHIPS];
+    for (int c = 0; c < n; c++) { op[c] = pf + pos; pos += 8 * widths[c] + 32; }
+    for (int c = 0; c < n; c++) orc_chal_observe_slice(&ch, op[c], 8 * widths[c] + 32);
+
+    /* (a) every chip's AIR identity at zeta */
+    for (int c = 0; c < n; c++) {
+        const size_t W = widths[c], nc = (size_t)1 << log_ns[c];
+        bb4_t* loc = (bb4_t*)malloc(W * sizeof(bb4_t));
+        bb4_t* nxt = (bb4_t*)malloc(W * sizeof(bb4_t));
+        for (size_t j = 0; j < W; j++) { loc[j] = ld4(op[c] + 4 * j); nxt[j] = ld4(op[c] + 4 * W + 4 * j); }
+        bb_t gn = bb_two_adic_generator(log_ns[c]);
+        bb4_t zn = bb4_pow(zeta, nc), zh = bb4_sub_base(zn, 1);
+        bb4_t sel_first = bb4_mul(zh, bb4_inv(bb4_sub_base(zeta, 1)));
+        bb4_t sel_trans = bb4_sub_base(zeta, bb_inv(gn));
+        bb4_t folded = orc__fold_constraints_ext(loc, nxt, W, sel_first, sel_trans, alpha);
+        free(loc); free(nxt);
+        bb_t w2n = bb_two_adic_generator(log_ns[c] + 1);
+        bb_t s[2] = {BB_GEN, bb_mul(BB_GEN, w2n)};
+        bb4_t quot = bb4_zero();
+        for (int k = 0; k < 2; k++) {
+            int j = 1 - k;
+            bb_t sjn_inv = bb_inv(bb_pow(s[j], nc));
+            bb4_t num = bb4_sub_base(bb4_mul_base(zn, sjn_inv), 1);
+            bb_t den = bb_sub(bb_mul(bb_pow(s[k], nc), sjn_inv), 1);
+            quot = bb4_add(quot, bb4_mul(bb4_mul_base(num, bb_inv(den)), orc__recombine(op[c] + 8 * W + 16 * k)));
+        }
+        if (!bb4_eq(bb4_mul(folded, bb4_inv(zh)), quot)) return 10;
+    }
+
+    /* (b) FRI */
+    bb4_t fa = sample_ext(&ch);
+    size_t npmax = 8;
+    for (int c = 0; c < n; c++) if (widths[c] > npmax) npmax = widths[c];
+    bb4_t* fapow = (bb4_t*)malloc(npmax * sizeof(bb4_t));
+    fapow[0] = bb4_one();
+    for (size_t j = 1; j < npmax; j++) fapow[j] = bb4_mul(fapow[j - 1], fa);
+    bb4_t y_loc[MAX_CHIPS], y_nxt[MAX_CHIPS], y_q[MAX_CHIPS], s_loc[MAX_CHIPS], s_nxt[MAX_CHIPS], s_q[MAX_CHIPS], zn_c[MAX_CHIPS];
+    for (int c = 0; c < n; c++) {
+        const size_t W = widths[c];
+        y_loc[c] = y_nxt[c] = y_q[c] = bb4_zero();
+        for (size_t j = 0; j < W; j++) {
+            y_loc[c] = bb4_add(y_loc[c], bb4_mul(fapow[j], ld4(op[c] + 4 * j)));
+            y_nxt[c] = bb4_add(y_nxt[c], bb4_mul(fapow[j], ld4(op[c] + 4 * W + 4 * j)));
+        }
+        for (size_t j = 0; j < 8; j++) y_q[c] = bb4_add(y_q[c], bb4_mul(fapow[j], ld4(op[c] + 8 * W + 4 * j)));
+        const size_t off = height_offset(log_ns, widths, c);
+        s_loc[c] = bb4_pow(fa, off); s_nxt[c] = bb4_pow(fa, off + W); s_q[c] = bb4_pow(fa, off + 2 * W);
+        zn_c[c] = bb4_mul_base(zeta, bb_two_adic_generator(log_ns[c]));
+    }
+    const uint32_t* commits = pf + pos; pos += 8 * (size_t)L;
+    bb4_t* betas = (bb4_t*)malloc(L * sizeof(bb4_t));
+    for (int l = 0; l < L; l++) { orc_chal_observe_slice(&ch, commits + 8 * l, 8); betas[l] = sample_ext(&ch); }
+    bb4_t final_poly = ld4(pf + pos); pos += 4;
+    orc_chal_observe_slice(&ch, final_poly.c, 4);
+    uint32_t witness = pf[pos++];
+    int rc = 0;
+    if (!orc_chal_check_witness(&ch, prm->pow_bits, witness)) rc = 20;
+    for (int q = 0; q < prm->num_queries && rc == 0; q++) {
+        size_t index = orc_chal_sample_bits(&ch, Hmax);
+        const uint32_t* trow[MAX_CHIPS]; const uint32_t* qrow[MAX_CHIPS];
+        for (int c = 0; c < n; c++) { trow[c] = pf + pos; pos += widths[c]; }
+        const uint32_t* tpath = pf + pos; pos += 8 * (size_t)Hmax;
+        for (int c = 0; c < n; c++) { qrow[c] = pf + pos; pos += 8; }
+        const uint32_t* qpath = pf + pos; pos += 8 * (size_t)Hmax;
+        if (verify_mixed(troot, Hmax, index, trow, widths, lh, n, tpath)) { rc = 30; break; }
+        if (verify_mixed(qroot, Hmax, index, qrow, w8, lh, n, qpath)) { rc = 31; break; }
+        /* reduced opening of every height at this query's point */
+        bb4_t roh[32];
+        for (int h = 0; h < 32; h++) roh[h] = bb4_zero();
+        for (int c = 0; c < n; c++) {
+            size_t ic = index >> (Hmax - lh[c]);
+            bb_t x = bb_mul(BB_GEN, bb_pow(bb_two_adic_generator(lh[c]), bb_reverse_bits((uint32_t)ic, lh[c])));
+            bb4_t d1 = bb4_inv(bb4_neg(bb4_sub_base(zeta, x)));
+            bb4_t d2 = bb4_inv(bb4_neg(bb4_sub_base(zn_c[c], x)));
+            bb4_t at = orc__row_dot(fapow, trow[c], widths[c]), aq = orc__row_dot(fapow, qrow[c], 8);
+            bb4_t r = bb4_mul(s_loc[c], bb4_mul(bb4_sub(at, y_loc[c]), d1));
+            r = bb4_add(r, bb4_mul(s_nxt[c], bb4_mul(bb4_sub(at, y_nxt[c]), d2)));
+            r = bb4_add(r, bb4_mul(s_q[c], bb4_mul(bb4_sub(aq, y_q[c]), d1)));
+            roh[lh[c]] = bb4_add(roh[lh[c]], r);
+        }
+        bb4_t folded = roh[Hmax];
+        size_t idx = index;
+        for (int l = 0; l < L; l++) {
+            const int rows_log = Hmax - 1 - l;
+            bb4_t sib = ld4(pf + pos); pos += 4;
+            const uint32_t* path = pf + pos; pos += 8 * (size_t)rows_log;
+            bb4_t ev[2];
+            ev[idx & 1] = folded; ev[(idx & 1) ^ 1] = sib;
+            uint32_t rowbuf[8];
+            memcpy(rowbuf, ev[0].c, 16); memcpy(rowbuf + 4, ev[1].c, 16);
+            if (orc_merkle_verify_hw(commits + 8 * l, rows_log, idx >> 1, rowbuf, 8, path, 16)) { rc = 40 + (l < 50 ? l : 50); break; }
+            folded = orc__fri_fold_row(idx >> 1, rows_log, betas[l], ev[0], ev[1]);
+            idx >>= 1;
+            folded = bb4_add(folded, roh[rows_log]);          /* zero unless some chip has this height */
+        }
+        if (rc) break;
+        if (!bb4_eq(folded, final_poly)) { rc = 100; break; }
+    }
+    free(fapow); free(betas);
+    if (rc == 0 && pos * 4 != len) rc = 5;
+    return rc;
+}

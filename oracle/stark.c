@@ -22,8 +22,14 @@
  * first); PoW takes the smallest witness.
  */
 #include "oracle.h"
+#include "stark_internal.h"
 #include <stdlib.h>
 #include <string.h>
+#define fold_constraints_ext orc__fold_constraints_ext
+#define fri_fold_row orc__fri_fold_row
+#define row_dot orc__row_dot
+#define copy_path orc__copy_path
+#define recombine orc__recombine
 
 /* ------------------------------------------------------------------ */
 /* synthetic data                                                      */
@@ -136,8 +142,10 @@ void orc_gen_trace_logup(uint64_t seed, uint64_t shard, int log_n, size_t width,
     }
 }
 
-static bb4_t ld4(const uint32_t* p);
-static void st4(uint32_t* p, bb4_t v);
+bb4_t orc__ld4(const uint32_t* p);
+void orc__st4(uint32_t* p, bb4_t v);
+#define ld4 orc__ld4
+#define st4 orc__st4
 
 /* N x 4 (Q + 1) words: [phi_0 | ... | phi_{Q-1} | S], extension elements flattened */
 void orc_perm_trace(const uint32_t* trace, int log_n, size_t width, int pairs,
@@ -183,7 +191,7 @@ static bb4_t fold_constraints_base(const uint32_t* local, const uint32_t* next, 
     }
     return acc;
 }
-static bb4_t fold_constraints_ext(const bb4_t* local, const bb4_t* next, size_t width,
+bb4_t orc__fold_constraints_ext(const bb4_t* local, const bb4_t* next, size_t width,
                                   bb4_t sel_first, bb4_t sel_trans, bb4_t alpha) {
     bb4_t acc = bb4_zero();
     size_t G = width / 4;
@@ -200,8 +208,8 @@ static bb4_t fold_constraints_ext(const bb4_t* local, const bb4_t* next, size_t 
     return acc;
 }
 
-static bb4_t ld4(const uint32_t* p) { bb4_t r; memcpy(r.c, p, 16); return r; }
-static void st4(uint32_t* p, bb4_t v) { memcpy(p, v.c, 16); }
+bb4_t orc__ld4(const uint32_t* p) { bb4_t r; memcpy(r.c, p, 16); return r; }
+void orc__st4(uint32_t* p, bb4_t v) { memcpy(p, v.c, 16); }
 
 /* LogUp constraints in extension arithmetic, continuing the Horner fold of `acc`.
  * as/bs/ar/br: sender / receiver tuple of pair q; perm_* hold phi_0..phi_{Q-1}, S. */
@@ -299,7 +307,7 @@ void orc_open_at(const uint32_t* lde, int log_n, size_t width, const uint32_t z_
 /* FRI fold:  out[i] = (e0+e1)/2 + beta (e0-e1)/(2 x_i),  x_i = w_{2h}^{bitrev_h(i)} */
 /* written as upstream's fold_row:  e0 + (beta - x)(e1 - e0)/(-2x)                   */
 /* ------------------------------------------------------------------ */
-static bb4_t fri_fold_row(size_t index, int log_folded_h, bb4_t beta, bb4_t e0, bb4_t e1) {
+bb4_t orc__fri_fold_row(size_t index, int log_folded_h, bb4_t beta, bb4_t e0, bb4_t e1) {
     bb_t x = bb_pow(bb_two_adic_generator(log_folded_h + 1),
                     bb_reverse_bits((uint32_t)index, log_folded_h));
     bb_t inv = bb_inv(bb_sub(0, bb_add(x, x)));            /* 1 / (x1 - x0) = 1/(-2x) */
@@ -420,12 +428,12 @@ static bb4_t fold_row_k(size_t row_index, int log_rows, int K, bb4_t beta, const
 }
 
 /* sum_j alpha^j * row[j] over `w` base-field words */
-static bb4_t row_dot(const bb4_t* pw, const uint32_t* row, size_t w) {
+bb4_t orc__row_dot(const bb4_t* pw, const uint32_t* row, size_t w) {
     bb4_t a = bb4_zero();
     for (size_t j = 0; j < w; j++) a = bb4_add(a, bb4_mul_base(pw[j], row[j]));
     return a;
 }
-static void copy_path(uint32_t* pf, size_t* pos, const uint32_t* tree, size_t leaves, size_t index, int levels) {
+void orc__copy_path(uint32_t* pf, size_t* pos, const uint32_t* tree, size_t leaves, size_t index, int levels) {
     const uint32_t* lvl = tree; size_t cnt = leaves, idx = index;
     for (int k = 0; k < levels; k++) { memcpy(pf + *pos, lvl + 8 * (idx ^ 1), 32); *pos += 8; lvl += 8 * cnt; cnt >>= 1; idx >>= 1; }
 }
@@ -651,7 +659,7 @@ size_t orc_prove_shard(const uint32_t* trace, int log_n, size_t width,
 /* verifier                                                             */
 /* ------------------------------------------------------------------ */
 /* value at zeta of an extension column committed as 4 base columns: sum_e x^e * v_e(zeta) */
-static bb4_t recombine(const uint32_t* opened4) {
+bb4_t orc__recombine(const uint32_t* opened4) {
     bb4_t r = bb4_zero();
     for (int e = 0; e < 4; e++) {
         bb4_t basis = bb4_zero(); basis.c[e] = 1;

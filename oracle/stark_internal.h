@@ -1,0 +1,13 @@
+/* oracle/stark_internal.h -- helpers shared by stark.c and chips.c.  TEST INFRASTRUCTURE ONLY (see oracle.h). */
+#ifndef ORACLE_STARK_INTERNAL_H
+#define ORACLE_STARK_INTERNAL_H
+#include "oracle.h"
+bb4_t orc__ld4(const uint32_t* p);
+void orc__st4(uint32_t* p, bb4_t v);
+/* the synthetic AIR's constraints on extension-field rows, folded with alpha (verifier side) */
+bb4_t orc__fold_constraints_ext(const bb4_t* local, const bb4_t* next, size_t width, bb4_t sel_first, bb4_t sel_trans, bb4_t alpha);
+bb4_t orc__fri_fold_row(size_t index, int log_folded_h, bb4_t beta, bb4_t e0, bb4_t e1);
+bb4_t orc__row_dot(const bb4_t* pw, const uint32_t* row, size_t w);
+void orc__copy_path(uint32_t* pf, size_t* pos, const uint32_t* tree, size_t leaves, size_t index, int levels);
+bb4_t orc__recombine(const uint32_t* opened4);
+#endif

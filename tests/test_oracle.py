@@ -463,3 +463,47 @@ def test_default_shape_fields_are_the_sp1_shape(oracle):
     b = oracle.prove_shard(t, [], oracle.default_params(1, 10, 8, 0, 1, 0, 16))
     assert a.tobytes() == b.tobytes()
     assert oracle.proof_size(10, 8, oracle.default_params(2, 10, 0, 0, 4, 0, 24), 0) == 0     # (10 - 0) % 4 != 0
+
+
+# ------------------------------------------------------------------ shards of several chips with different heights
+CHIP_SETS = [
+    ([(8, 8)], (1, 10, 4)),
+    ([(10, 16), (8, 8)], (1, 10, 4)),
+    ([(10, 16), (10, 8), (7, 12), (7, 4), (5, 8)], (1, 20, 8)),
+    ([(9, 8), (8, 8), (7, 8), (6, 8), (5, 8)], (2, 10, 0)),
+    ([(11, 32), (6, 4)], (3, 8, 4)),
+]
+
+
+@pytest.mark.parametrize("chips,prm", CHIP_SETS)
+def test_multi_chip_shard_proves_verifies_and_rejects(oracle, chips, prm):
+    # one commitment per phase over matrices of different heights, per-height reduced openings joining FRI at their layer
+    params = oracle.default_params(*prm)
+    traces = [oracle.gen_trace(SEED, i, ln, w) for i, (ln, w) in enumerate(chips)]
+    lns, ws = [c[0] for c in chips], [c[1] for c in chips]
+    pf = oracle.prove_chips(traces, [1, 2], params)
+    assert oracle.verify_chips(pf, lns, ws, [1, 2], params) == 0
+    assert oracle.verify_chips(pf, lns, ws, [1, 3], params) != 0
+    step = max(1, pf.size // 61)
+    for off in range(8 * 4 + 8 * len(chips), pf.size, step):
+        bad = pf.copy(); bad[off] ^= 2
+        assert oracle.verify_chips(bad, lns, ws, [1, 2], params) != 0, off
+    # a violated constraint in the SMALLEST chip is caught by that chip's AIR identity
+    bt = [t.copy() for t in traces]
+    bt[-1][3, 2] = (int(bt[-1][3, 2]) + 1) % P
+    try:
+        pf2 = oracle.prove_chips(bt, [1, 2], params)
+    except RuntimeError:
+        return
+    assert oracle.verify_chips(pf2, lns, ws, [1, 2], params) == 10
+
+
+def test_multi_chip_shape_rules(oracle):
+    t = [oracle.gen_trace(SEED, 0, 6, 8), oracle.gen_trace(SEED, 1, 8, 8)]
+    with pytest.raises(RuntimeError):
+        oracle.prove_chips(t, [], oracle.default_params(1, 4, 0))             # not tallest first
+    with pytest.raises(RuntimeError):
+        oracle.prove_chips(t[::-1], [], oracle.default_params(1, 4, 0, 0, 4, 0, 24))   # only the SP1 FRI shape
+    five = [oracle.gen_trace(SEED, i, 6, 4) for i in range(5)]
+    with pytest.raises(RuntimeError):
+        oracle.prove_chips(five, [], oracle.default_params(1, 4, 0))          # more than 4 chips of one height
