@@ -340,10 +340,7 @@ void zkhip_ctx_destroy(zkhip_ctx* ctx) {
     for (DeviceBuffer& b : ctx->scratch) if (b.ptr) (void)hipFree(b.ptr);
     if (ctx->w1024_fwd) (void)hipFree(ctx->w1024_fwd);
     if (ctx->w1024_inv) (void)hipFree(ctx->w1024_inv);
-    if (ctx->dom_xs) (void)hipFree(ctx->dom_xs);
-    if (ctx->dom_sel_first) (void)hipFree(ctx->dom_sel_first);
-    if (ctx->dom_sel_last) (void)hipFree(ctx->dom_sel_last);
-    if (ctx->dom_itw) (void)hipFree(ctx->dom_itw);
+    for (auto& d : ctx->domains) { (void)hipFree(d.xs); (void)hipFree(d.sel_first); (void)hipFree(d.sel_last); (void)hipFree(d.itw); }
     if (ctx->own_stream && ctx->stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;
 }

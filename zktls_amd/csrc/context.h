@@ -54,7 +54,10 @@ struct zkhip_ctx {
     std::deque<zk::NttPlan> plans;   // deque: references stay valid on push_back
     zk::DeviceBuffer scratch[24];       // grow-only workspaces, indexed by role
     zkhip_prove_debug debug{};
-    // domain tables of the last proved size (prover.cpp)
+    // domain tables (prover.cpp): the current set, and every set built so far (a multi-chip shard switches between
+    // the sets of its chips' heights; sets are small and kept until the context goes away)
+    struct DomainSet { int log_n, log_blowup; uint32_t *xs, *sel_first, *sel_last, *itw; };
+    std::vector<DomainSet> domains;
     int dom_log_n = -1, dom_log_blowup = 0;
     uint32_t* dom_xs = nullptr;        // x_p = g * w_M^bitrev(p), p < M = 2^(log_n + log_blowup); selectors: p < 2N
     uint32_t* dom_sel_first = nullptr; // Z_H(x_p) / (x_p - 1)

@@ -140,6 +140,8 @@ struct ReducedArgs {
     const uint32_t* alpha_pow;  // [max(width, p_width, 8)] ext: alpha^j
     const uint32_t* dinv;       // [2][rows] ext
     Ext y_loc, y_next, y_pl, y_pn, y_q, off_next, off_pl, off_pn, off_q;
+    Ext off_loc;                // weight of the first term (alpha^0 unless several matrices share one vector)
+    int accumulate;             // 1: out[p] += ..., 0: out[p] = ...
     uint32_t* out;              // [rows] ext
 };
 // scratch_at: [2][rows] ext workspace for the per-row alpha-dots of the trace / permutation matrices
@@ -155,6 +157,7 @@ struct PermArgs {
 hipError_t launch_perm_trace(const PermArgs& a, uint32_t* block_scratch, hipStream_t s);
 
 hipError_t launch_fri_fold(const uint32_t* in, uint32_t* out, const uint32_t* itw, uint64_t half, const Ext& beta, hipStream_t s);
+hipError_t launch_ext_add(uint32_t* dst, const uint32_t* src, uint64_t count, hipStream_t s);
 // the same fold with the challenge read from device memory: beta = (*beta_ptr)^(2^squarings)
 hipError_t launch_fri_fold_dev(const uint32_t* in, uint32_t* out, const uint32_t* itw, uint64_t half, const uint32_t* beta_ptr,
                                int squarings, hipStream_t s);

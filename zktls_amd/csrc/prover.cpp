@@ -78,21 +78,27 @@ constexpr uint32_t PROOF_MAGIC = 0x41544B5Au;   // "ZKTA"
 constexpr uint32_t PROOF_VERSION = 1u;
 
 enum Slot { S_COEF = 0, S_TMP = 1, S_TLDE, S_TTREE, S_QCHUNK, S_QLDE, S_QTREE, S_DINV, S_PARTIAL, S_OPEN_OUT,
-            S_APOW_Q, S_APOW_F, S_FRI_LAYERS, S_FRI_TREES, S_GATHER_DESC, S_GATHER_OUT, S_PERM, S_PLDE, S_PTREE, S_CHAL };
+            S_APOW_Q, S_APOW_F, S_FRI_LAYERS, S_FRI_TREES, S_GATHER_DESC, S_GATHER_OUT, S_PERM, S_PLDE, S_PTREE, S_CHAL, S_RO = 22 };
 
 static int pow2ceil(int v) { int r = 1; while (r < v) r <<= 1; return r; }
 
 static int ensure_domain(zkhip_ctx* ctx, int log_n, int log_blowup = 1) {
     if (ctx->dom_log_n == log_n && ctx->dom_log_blowup == log_blowup) return ZKHIP_OK;
-    if (ctx->dom_xs) { ZK_HIP(hipStreamSynchronize(ctx->stream)); (void)hipFree(ctx->dom_xs); (void)hipFree(ctx->dom_sel_first); (void)hipFree(ctx->dom_sel_last); (void)hipFree(ctx->dom_itw); }
-    ctx->dom_xs = ctx->dom_sel_first = ctx->dom_sel_last = ctx->dom_itw = nullptr;
-    ctx->dom_log_n = -1;
+    for (const auto& d : ctx->domains)
+        if (d.log_n == log_n && d.log_blowup == log_blowup) {
+            ctx->dom_xs = d.xs; ctx->dom_sel_first = d.sel_first; ctx->dom_sel_last = d.sel_last; ctx->dom_itw = d.itw;
+            ctx->dom_log_n = log_n; ctx->dom_log_blowup = log_blowup;
+            return ZKHIP_OK;
+        }
+    zkhip_ctx::DomainSet d{log_n, log_blowup, nullptr, nullptr, nullptr, nullptr};
     const size_t m = (size_t)1 << (log_n + log_blowup), mq = (size_t)2 << log_n;
-    ZK_HIP(hipMalloc((void**)&ctx->dom_xs, m * 4));
-    ZK_HIP(hipMalloc((void**)&ctx->dom_sel_first, mq * 4));
-    ZK_HIP(hipMalloc((void**)&ctx->dom_sel_last, mq * 4));
-    ZK_HIP(hipMalloc((void**)&ctx->dom_itw, (m / 2) * 4));
-    ZK_HIP(launch_domain_tables(ctx->dom_xs, ctx->dom_sel_first, ctx->dom_sel_last, ctx->dom_itw, log_n, log_blowup, ctx->stream));
+    ZK_HIP(hipMalloc((void**)&d.xs, m * 4));
+    ZK_HIP(hipMalloc((void**)&d.sel_first, mq * 4));
+    ZK_HIP(hipMalloc((void**)&d.sel_last, mq * 4));
+    ZK_HIP(hipMalloc((void**)&d.itw, (m / 2) * 4));
+    ZK_HIP(launch_domain_tables(d.xs, d.sel_first, d.sel_last, d.itw, log_n, log_blowup, ctx->stream));
+    ctx->domains.push_back(d);
+    ctx->dom_xs = d.xs; ctx->dom_sel_first = d.sel_first; ctx->dom_sel_last = d.sel_last; ctx->dom_itw = d.itw;
     ctx->dom_log_n = log_n; ctx->dom_log_blowup = log_blowup;
     return ZKHIP_OK;
 }
@@ -177,6 +183,107 @@ static int run_open(zkhip_ctx* ctx, const uint32_t* lde, size_t ld, int log_n, u
     return ZKHIP_OK;
 }
 
+// one Merkle commitment of a row-major matrix with the shape's hash
+static int commit_hw(zkhip_ctx* ctx, const uint32_t* mat, size_t ld, uint32_t width, int log_h, uint32_t* tree, int hw) {
+    if (hw == 24) { ZK_HIP(launch_merkle_p24_rowmajor(mat, ld, width, log_h, tree, ctx->stream)); return ZKHIP_OK; }
+    MatDesc md{mat, ld, width};
+    return op_merkle_commit(ctx, &md, 1, log_h, tree);
+}
+
+// FRI commit phase shared by the single-matrix and the multi-chip prover: RL committed layers (rows of 2^K adjacent
+// entries): commit, transcript step, fold K times.  `inject` (multi-chip, K = 1): inject[h] is the reduced-opening vector
+// of the chips whose LDE has 2^h rows; it is added to the folded vector when that reaches 2^h entries.
+static int fri_commit_phase(zkhip_ctx* ctx, Challenger& ch, const Shape& sh, int H, int RL, uint32_t* layers, uint32_t* ltrees,
+                            const std::vector<size_t>& layer_off, const std::vector<size_t>& tree_off, uint32_t* fold_tmp, size_t m,
+                            const uint32_t* const* inject, uint32_t* pf, size_t& pos) {
+    hipStream_t st = ctx->stream;
+    const int K = sh.K;
+    const size_t arity = (size_t)1 << K;
+    uint32_t root[8];
+    // The per-layer transcript step (observe the root, sample beta) runs ON THE DEVICE (fri_challenge_kernel), so the
+    // whole commit loop is enqueued without a host round trip; afterwards the host replays the same steps on its own
+    // challenger from the logged roots and checks that both transcripts agree.  ZKHIP_FRI_HOST=1 keeps the round trips (A/B).
+    static const bool fri_on_host = [] { const char* e = getenv("ZKHIP_FRI_HOST"); return e && atoi(e) != 0; }();
+    void* v_chal = nullptr;
+    uint32_t *d_betas = nullptr, *d_roots = nullptr;
+    DevChallenger* d_chal = nullptr;
+    if (!fri_on_host && RL > 0) {
+        ZK_TRY(ctx_reserve(ctx, S_CHAL, sizeof(DevChallenger) + (size_t)RL * 12 * 4, &v_chal));
+        d_chal = (DevChallenger*)v_chal;
+        d_betas = (uint32_t*)((char*)v_chal + sizeof(DevChallenger));
+        d_roots = d_betas + 4 * (size_t)RL;
+        DevChallenger hc{};
+        for (int i = 0; i < 16; i++) hc.state[i] = ch.state[i];
+        for (int i = 0; i < 8; i++) { hc.in[i] = ch.in[i]; hc.out[i] = ch.out[i]; }
+        hc.n_in = ch.n_in; hc.n_out = ch.n_out;
+        ZK_TRY(h2d(ctx, d_chal, &hc, sizeof hc));
+    }
+    // (a single-workgroup kernel walking all layers of <= 512 rows was tried: no faster than these launches)
+    for (int l = 0; l < RL; l++) {
+        const int lh = H - K * (l + 1);
+        const size_t rows = (size_t)1 << lh;
+        uint32_t* cur = layers + layer_off[l];
+        uint32_t* tree = ltrees + tree_off[l];
+        ZK_TRY(commit_hw(ctx, cur, 4 * arity, (uint32_t)(4 * arity), lh, tree, sh.hw));
+        Ext beta = ext_zero();
+        if (d_chal) {
+            ZK_HIP(launch_fri_challenge(d_chal, tree + (2 * rows - 2) * 8, d_betas + 4 * l, d_roots + 8 * l, st));
+        } else {
+            ZK_TRY(d2h(ctx, root, tree + (2 * rows - 2) * 8, 32));
+            for (int i = 0; i < 8; i++) { ch.observe(root[i]); pf[pos++] = from_monty(root[i]); }
+            beta = ch.sample_ext();
+        }
+        // fold by 2 with beta, beta^2, beta^4, ...: f = sum_j X^j f_j(X^(2^K))  ->  sum_j beta^j f_j
+        const uint32_t* src = cur;
+        for (int j = 0; j < K; j++) {
+            const size_t out_cnt = (size_t)1 << (H - K * l - j - 1);
+            uint32_t* dst = (j == K - 1) ? layers + layer_off[l + 1] : fold_tmp + ((j & 1) ? 4 * (m / 2) : 0);
+            if (d_chal) ZK_HIP(launch_fri_fold_dev(src, dst, ctx->dom_itw, out_cnt, d_betas + 4 * l, j, st));
+            else ZK_HIP(launch_fri_fold(src, dst, ctx->dom_itw, out_cnt, beta, st));
+            src = dst;
+            beta = ext_mul(beta, beta);
+        }
+        const int reached = H - K * (l + 1);
+        if (inject && inject[reached]) ZK_HIP(launch_ext_add(layers + layer_off[l + 1], inject[reached], (uint64_t)1 << reached, st));
+    }
+    if (d_chal) {
+        std::vector<uint32_t> log((size_t)RL * 12);
+        ZK_TRY(d2h(ctx, log.data(), d_betas, log.size() * 4));
+        for (int l = 0; l < RL; l++) {
+            const uint32_t* r = log.data() + 4 * (size_t)RL + 8 * (size_t)l;
+            for (int i = 0; i < 8; i++) { ch.observe(r[i]); pf[pos++] = from_monty(r[i]); }
+            const Ext beta = ch.sample_ext();
+            const uint32_t* b = log.data() + 4 * (size_t)l;
+            if (beta.c[0] != b[0] || beta.c[1] != b[1] || beta.c[2] != b[2] || beta.c[3] != b[3])
+                return fail(ZKHIP_ERR_INTERNAL, "prove: device and host transcripts disagree in the FRI commit phase");
+        }
+    }
+    return ZKHIP_OK;
+}
+
+// proof of work: smallest witness, searched 2^20 candidates per launch; observes it
+static int grind_witness(zkhip_ctx* ctx, Challenger& ch, int pow_bits, uint32_t* out) {
+    uint32_t witness = 0xFFFFFFFFu;
+    GrindArgs ga{};
+    for (int i = 0; i < 16; i++) ga.state[i] = ch.state[i];
+    for (int i = 0; i < ch.n_in; i++) ga.state[i] = ch.in[i];
+    ga.slot = ch.n_in;
+    ga.mask = (1u << pow_bits) - 1u;
+    void* v_res;
+    ZK_TRY(ctx_reserve(ctx, S_GATHER_OUT, 4, &v_res));
+    ZK_HIP(hipMemsetAsync(v_res, 0xFF, 4, ctx->stream));
+    const uint32_t batch = 1u << 20;
+    for (uint64_t base = 0; base < P && witness == 0xFFFFFFFFu; base += batch) {
+        ZK_HIP(launch_grind(ga, (uint32_t)base, batch, (uint32_t*)v_res, ctx->stream));
+        ZK_TRY(d2h(ctx, &witness, v_res, 4));
+    }
+    if (witness == 0xFFFFFFFFu) return fail(ZKHIP_ERR_INTERNAL, "prove: no proof-of-work witness found");
+    ch.observe_canonical(witness);
+    if (ch.sample_bits(pow_bits) != 0) return fail(ZKHIP_ERR_INTERNAL, "prove: device and host disagree on the PoW witness");
+    *out = witness;
+    return ZKHIP_OK;
+}
+
 static size_t proof_words(int log_n, uint32_t width, const zkhip_params* prm) {
     Shape sh;
     if (!shape_of(log_n, prm, sh)) return 0;
@@ -201,13 +308,6 @@ static int check_shape(int log_n, uint32_t width, const zkhip_params* prm) {
     if (prm->logup_pairs < 0 || prm->logup_pairs > 64 || (uint32_t)prm->logup_pairs * 8 > width)
         return fail(ZKHIP_ERR_INVALID, "logup_pairs out of range (each pair needs two column groups, at most 64 pairs)");
     return ZKHIP_OK;
-}
-
-// one Merkle commitment of a row-major matrix with the shape's hash
-static int commit_hw(zkhip_ctx* ctx, const uint32_t* mat, size_t ld, uint32_t width, int log_h, uint32_t* tree, int hw) {
-    if (hw == 24) { ZK_HIP(launch_merkle_p24_rowmajor(mat, ld, width, log_h, tree, ctx->stream)); return ZKHIP_OK; }
-    MatDesc md{mat, ld, width};
-    return op_merkle_commit(ctx, &md, 1, log_h, tree);
 }
 
 // in-place inverse DFT of 2^log extension elements (natural order in and out); host, tiny sizes
@@ -467,6 +567,7 @@ int zkhip_prove_shard(zkhip_ctx* ctx, const uint32_t* d_trace, size_t ld, int lo
     for (size_t j = 1; j < np; j++) fapow[j] = ext_mul(fapow[j - 1], fa);
     ReducedArgs ra{};
     ra.y_loc = ra.y_next = ra.y_pl = ra.y_pn = ra.y_q = ext_zero();
+    ra.off_loc = ext_one(); ra.accumulate = 0;
     for (size_t j = 0; j < width; j++) {
         ra.y_loc = ext_add(ra.y_loc, ext_mul(fapow[j], op_loc[j]));
         ra.y_next = ext_add(ra.y_next, ext_mul(fapow[j], op_nxt[j]));
@@ -504,63 +605,7 @@ int zkhip_prove_shard(zkhip_ctx* ctx, const uint32_t* d_trace, size_t ld, int lo
             if (l < RL) to += (2 * ((size_t)1 << (H - K * (l + 1))) - 1) * 8;
         }
     }
-    uint32_t* fold_tmp = (uint32_t*)v_at;                  // S_PARTIAL: the reduced-opening scratch is free again
-    // The per-layer transcript step (observe the root, sample beta) runs ON THE DEVICE (fri_challenge_kernel), so the
-    // whole commit loop is enqueued without a host round trip; afterwards the host replays the same steps on its own
-    // challenger from the logged roots and checks that both transcripts agree.  ZKHIP_FRI_HOST=1 keeps the round trips (A/B).
-    static const bool fri_on_host = [] { const char* e = getenv("ZKHIP_FRI_HOST"); return e && atoi(e) != 0; }();
-    void* v_chal = nullptr;
-    uint32_t *d_betas = nullptr, *d_roots = nullptr;
-    DevChallenger* d_chal = nullptr;
-    if (!fri_on_host && RL > 0) {
-        ZK_TRY(ctx_reserve(ctx, S_CHAL, sizeof(DevChallenger) + (size_t)RL * 12 * 4, &v_chal));
-        d_chal = (DevChallenger*)v_chal;
-        d_betas = (uint32_t*)((char*)v_chal + sizeof(DevChallenger));
-        d_roots = d_betas + 4 * (size_t)RL;
-        DevChallenger hc{};
-        for (int i = 0; i < 16; i++) hc.state[i] = ch.state[i];
-        for (int i = 0; i < 8; i++) { hc.in[i] = ch.in[i]; hc.out[i] = ch.out[i]; }
-        hc.n_in = ch.n_in; hc.n_out = ch.n_out;
-        ZK_TRY(h2d(ctx, d_chal, &hc, sizeof hc));
-    }
-    // (a single-workgroup kernel walking all layers of <= 512 rows was tried: no faster than these launches)
-    for (int l = 0; l < RL; l++) {
-        const int lh = H - K * (l + 1);
-        const size_t rows = (size_t)1 << lh;
-        uint32_t* cur = layers + layer_off[l];
-        uint32_t* tree = ltrees + tree_off[l];
-        ZK_TRY(commit_hw(ctx, cur, 4 * arity, (uint32_t)(4 * arity), lh, tree, sh.hw));
-        Ext beta = ext_zero();
-        if (d_chal) {
-            ZK_HIP(launch_fri_challenge(d_chal, tree + (2 * rows - 2) * 8, d_betas + 4 * l, d_roots + 8 * l, st));
-        } else {
-            ZK_TRY(d2h(ctx, root, tree + (2 * rows - 2) * 8, 32));
-            for (int i = 0; i < 8; i++) { ch.observe(root[i]); pf[pos++] = from_monty(root[i]); }
-            beta = ch.sample_ext();
-        }
-        // fold by 2 with beta, beta^2, beta^4, ...: f = sum_j X^j f_j(X^(2^K))  ->  sum_j beta^j f_j
-        const uint32_t* src = cur;
-        for (int j = 0; j < K; j++) {
-            const size_t out_cnt = (size_t)1 << (H - K * l - j - 1);
-            uint32_t* dst = (j == K - 1) ? layers + layer_off[l + 1] : fold_tmp + ((j & 1) ? 4 * (m / 2) : 0);
-            if (d_chal) ZK_HIP(launch_fri_fold_dev(src, dst, ctx->dom_itw, out_cnt, d_betas + 4 * l, j, st));
-            else ZK_HIP(launch_fri_fold(src, dst, ctx->dom_itw, out_cnt, beta, st));
-            src = dst;
-            beta = ext_mul(beta, beta);
-        }
-    }
-    if (d_chal) {
-        std::vector<uint32_t> log((size_t)RL * 12);
-        ZK_TRY(d2h(ctx, log.data(), d_betas, log.size() * 4));
-        for (int l = 0; l < RL; l++) {
-            const uint32_t* r = log.data() + 4 * (size_t)RL + 8 * (size_t)l;
-            for (int i = 0; i < 8; i++) { ch.observe(r[i]); pf[pos++] = from_monty(r[i]); }
-            const Ext beta = ch.sample_ext();
-            const uint32_t* b = log.data() + 4 * (size_t)l;
-            if (beta.c[0] != b[0] || beta.c[1] != b[1] || beta.c[2] != b[2] || beta.c[3] != b[3])
-                return fail(ZKHIP_ERR_INTERNAL, "prove_shard: device and host transcripts disagree in the FRI commit phase");
-        }
-    }
+    ZK_TRY(fri_commit_phase(ctx, ch, sh, H, RL, layers, ltrees, layer_off, tree_off, (uint32_t*)v_at, m, nullptr, pf, pos));
     // 2^(F+b) evaluations of a polynomial of < 2^F coefficients remain: interpolate on the host, send the coefficients
     {
         const int lf = sh.F + sh.b;
@@ -579,25 +624,8 @@ int zkhip_prove_shard(zkhip_ctx* ctx, const uint32_t* d_trace, size_t ld, int lo
     }
 
     // ---- 6. proof of work: smallest witness, searched 2^20 candidates per launch
-    uint32_t witness = 0xFFFFFFFFu;
-    {
-        GrindArgs ga{};
-        for (int i = 0; i < 16; i++) ga.state[i] = ch.state[i];
-        for (int i = 0; i < ch.n_in; i++) ga.state[i] = ch.in[i];
-        ga.slot = ch.n_in;
-        ga.mask = (1u << prm->pow_bits) - 1u;
-        void* v_res;
-        ZK_TRY(ctx_reserve(ctx, S_GATHER_OUT, 4, &v_res));
-        ZK_HIP(hipMemsetAsync(v_res, 0xFF, 4, st));
-        const uint32_t batch = 1u << 20;
-        for (uint64_t base = 0; base < P && witness == 0xFFFFFFFFu; base += batch) {
-            ZK_HIP(launch_grind(ga, (uint32_t)base, batch, (uint32_t*)v_res, st));
-            ZK_TRY(d2h(ctx, &witness, v_res, 4));
-        }
-        if (witness == 0xFFFFFFFFu) return fail(ZKHIP_ERR_INTERNAL, "prove_shard: no proof-of-work witness found");
-    }
-    ch.observe_canonical(witness);
-    if (ch.sample_bits(prm->pow_bits) != 0) return fail(ZKHIP_ERR_INTERNAL, "prove_shard: device and host disagree on the PoW witness");
+    uint32_t witness = 0;
+    ZK_TRY(grind_witness(ctx, ch, prm->pow_bits, &witness));
     pf[pos++] = ctx->debug.pow_witness = witness;
 
     // ---- 7. queries: one gather launch over (row, path, sibling) descriptors

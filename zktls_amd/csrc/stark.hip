@@ -346,7 +346,7 @@ __global__ void __launch_bounds__(256) reduced_combine_kernel(ReducedArgs a, con
 #pragma unroll
     for (int j = 0; j < 8; j++) aq = ext_add(aq, ext_mul_base(ld_ext(a.alpha_pow + 4 * j), qv[j]));
     const Ext d1 = ld_ext(a.dinv + 4 * p), d2 = ld_ext(a.dinv + 4 * (a.rows + p));
-    Ext r = ext_mul(ext_sub(at, a.y_loc), d1);
+    Ext r = ext_mul(a.off_loc, ext_mul(ext_sub(at, a.y_loc), d1));
     r = ext_add(r, ext_mul(a.off_next, ext_mul(ext_sub(at, a.y_next), d2)));
     if (a.p_width) {
         const Ext ap = ld_ext(ap_in + 4 * p);
@@ -354,6 +354,7 @@ __global__ void __launch_bounds__(256) reduced_combine_kernel(ReducedArgs a, con
         r = ext_add(r, ext_mul(a.off_pn, ext_mul(ext_sub(ap, a.y_pn), d2)));
     }
     r = ext_add(r, ext_mul(a.off_q, ext_mul(ext_sub(aq, a.y_q), d1)));
+    if (a.accumulate) r = ext_add(r, ld_ext(a.out + 4 * p));
     st_ext(a.out + 4 * p, r);
 }
 static int lanes_for(uint32_t width) { int g = (int)(width / 4), l = 1; while (l < g && l < 16) l <<= 1; return l; }
@@ -483,6 +484,17 @@ __global__ void __launch_bounds__(256) fri_fold_dev_kernel(const uint32_t* in, u
 hipError_t launch_fri_fold_dev(const uint32_t* in, uint32_t* out, const uint32_t* itw, uint64_t half, const uint32_t* beta_ptr,
                                int squarings, hipStream_t s) {
     hipLaunchKernelGGL(fri_fold_dev_kernel, dim3((unsigned)((half + 255) / 256)), dim3(256), 0, s, in, out, itw, half, beta_ptr, squarings);
+    return hipGetLastError();
+}
+
+// dst[i] += src[i] over `count` extension elements (a shorter chip's reduced openings joining the FRI vector)
+__global__ void __launch_bounds__(256) ext_add_kernel(uint32_t* dst, const uint32_t* src, uint64_t count) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= count) return;
+    st_ext(dst + 4 * i, ext_add(ld_ext(dst + 4 * i), ld_ext(src + 4 * i)));
+}
+hipError_t launch_ext_add(uint32_t* dst, const uint32_t* src, uint64_t count, hipStream_t s) {
+    hipLaunchKernelGGL(ext_add_kernel, dim3((unsigned)((count + 255) / 256)), dim3(256), 0, s, dst, src, count);
     return hipGetLastError();
 }
 
