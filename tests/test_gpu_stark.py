@@ -262,3 +262,51 @@ def test_width_above_the_limit_is_refused(ctx):
     from zktls_amd._lib import ZkHipError
     with pytest.raises(ZkHipError):
         ctx.prove_shard(ctx.gen_trace(SEED, 0, 6, 1028), 6, 1028, [], Params(1, 8, 4))
+
+
+# ------------------------------------------------------------------ shards of several chips with different heights (SP1's shard shape)
+CHIP_SETS = [
+    ([(8, 8)], (1, 10, 4)),
+    ([(10, 16), (8, 8)], (1, 10, 4)),
+    ([(10, 16), (10, 8), (7, 12), (7, 4), (5, 8)], (1, 20, 8)),
+    ([(9, 8), (8, 8), (7, 8), (6, 8), (5, 8)], (2, 10, 0)),
+    ([(11, 32), (6, 4)], (3, 8, 4)),
+    ([(14, 64), (14, 16), (12, 40), (10, 256), (10, 8), (10, 8), (6, 4)], (1, 100, 16)),
+    ([(16, 32), (13, 8), (5, 4)], (1, 30, 10)),
+]
+
+
+@pytest.mark.parametrize("chips,prm", CHIP_SETS)
+def test_prove_chips_bytes_equal_oracle(ctx, oracle, chips, prm):
+    from zktls_amd.device import verify_chips
+    params, oparams = Params(*prm), oracle.default_params(*prm)
+    dev = [(ctx.gen_trace(SEED, i, ln, w), ln, w) for i, (ln, w) in enumerate(chips)]
+    host = [oracle.gen_trace(SEED, i, ln, w) for i, (ln, w) in enumerate(chips)]
+    proof = ctx.prove_chips(dev, [3, 4], params)
+    oproof = oracle.prove_chips(host, [3, 4], oparams)
+    assert proof.size == oproof.size
+    assert proof.tobytes() == oproof.tobytes()
+    lns, ws = [c[0] for c in chips], [c[1] for c in chips]
+    assert oracle.verify_chips(proof, lns, ws, [3, 4], oparams) == 0
+    assert verify_chips(proof, lns, ws, [3, 4], params) == (0, 0)
+    for b, _, _ in dev:
+        b.free()
+
+
+def test_prove_chips_rejects_bad_sets_and_bad_traces(ctx, oracle):
+    from zktls_amd._lib import ZkHipError
+    from zktls_amd.device import verify_chips
+    a, b = ctx.gen_trace(SEED, 0, 6, 8), ctx.gen_trace(SEED, 1, 8, 8)
+    with pytest.raises(ZkHipError):
+        ctx.prove_chips([(a, 6, 8), (b, 8, 8)], [], Params(1, 4, 0))                 # not tallest first
+    with pytest.raises(ZkHipError):
+        ctx.prove_chips([(b, 8, 8), (a, 6, 8)], [], Params(1, 4, 0, 0, 4, 0, 24))    # only the SP1 FRI shape
+    t = oracle.gen_trace(SEED, 1, 6, 8)
+    t[9, 2] = (int(t[9, 2]) + 1) % P
+    prm = Params(1, 6, 2)
+    try:
+        proof = ctx.prove_chips([(b, 8, 8), (ctx.from_numpy(t), 6, 8)], [], prm)
+    except ZkHipError as e:
+        assert e.code == -1
+        return
+    assert verify_chips(proof, [8, 6], [8, 8], [], prm) == (-6, 10)

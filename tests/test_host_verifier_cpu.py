@@ -79,3 +79,20 @@ def test_host_verifier_agrees_with_oracle_on_other_shapes(oracle, log_n, width, 
         bad = pf.copy(); bad[int(pf.size * frac)] ^= 2
         rc, reason = verify_shard(bad, log_n, width, [4, 5], prm)
         assert rc == -6 and reason == oracle.verify_shard(bad, log_n, width, [4, 5], oprm)
+
+
+@pytest.mark.parametrize("chips,prm", [([(8, 8)], (1, 10, 4)), ([(10, 16), (8, 8)], (1, 10, 4)),
+                                       ([(10, 16), (10, 8), (7, 12), (7, 4), (5, 8)], (1, 20, 8)),
+                                       ([(9, 8), (8, 8), (7, 8), (6, 8), (5, 8)], (2, 10, 0)), ([(11, 32), (6, 4)], (3, 8, 4))])
+def test_host_verifier_agrees_with_oracle_on_multi_chip_shards(oracle, chips, prm):
+    from zktls_amd.device import verify_chips
+    oprm, params = oracle.default_params(*prm), Params(*prm)
+    traces = [oracle.gen_trace(SEED, i, ln, w) for i, (ln, w) in enumerate(chips)]
+    lns, ws = [c[0] for c in chips], [c[1] for c in chips]
+    pf = oracle.prove_chips(traces, [1, 2], oprm)
+    assert verify_chips(pf, lns, ws, [1, 2], params) == (0, 0)
+    assert verify_chips(pf, lns, ws, [1, 3], params)[0] == -6
+    for frac in (0.02, 0.1, 0.3, 0.5, 0.7, 0.95):
+        bad = pf.copy(); bad[int(pf.size * frac)] ^= 1
+        rc, reason = verify_chips(bad, lns, ws, [1, 2], params)
+        assert rc == -6 and reason == oracle.verify_chips(bad, lns, ws, [1, 2], oprm)

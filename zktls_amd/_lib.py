@@ -23,6 +23,7 @@ EXPORTS = [
     "zkhip_dft", "zkhip_coset_lde", "zkhip_ntt_pass", "zkhip_poseidon2_permute", "zkhip_hash_rows",
     "zkhip_merkle_commit", "zkhip_merkle_commit_mixed", "zkhip_merkle_commit_p24_colmajor", "zkhip_batch_interpolate_colmajor", "zkhip_batch_expand_colmajor", "zkhip_quotient_values", "zkhip_open_at", "zkhip_fri_fold", "zkhip_fri_fold_k",
     "zkhip_proof_size", "zkhip_prove_shard", "zkhip_prove_segment", "zkhip_verify_shard", "zkhip_last_prove_debug",
+    "zkhip_chips_proof_size", "zkhip_prove_chips", "zkhip_verify_chips",
 ]
 
 
@@ -41,6 +42,10 @@ def segment_params(num_queries=50, logup_pairs=0, log_final=8):
     """RISC-Zero-like shape (include/zkhip.h): blowup 4, fold by 16, 2^log_final final coefficients,
     Poseidon2 width 24, no proof of work."""
     return Params(2, num_queries, 0, logup_pairs, 4, log_final, 24)
+
+
+class Chip(C.Structure):
+    _fields_ = [("d_trace", C.c_void_p), ("ld", C.c_size_t), ("log_n", C.c_int32), ("width", C.c_uint32)]
 
 
 class ProveDebug(C.Structure):
@@ -105,6 +110,12 @@ def load():
                                       C.POINTER(Params), u8p, C.c_size_t, C.POINTER(C.c_size_t)]
     L.zkhip_verify_shard.argtypes = [u8p, C.c_size_t, C.c_int, C.c_uint32, u32p, C.c_size_t, C.POINTER(Params), C.POINTER(C.c_int)]
     L.zkhip_last_prove_debug.argtypes = [C.c_void_p, C.POINTER(ProveDebug)]
+    i32p = C.POINTER(C.c_int32)
+    L.zkhip_chips_proof_size.restype = C.c_size_t
+    L.zkhip_chips_proof_size.argtypes = [i32p, u32p, C.c_int, C.POINTER(Params), C.c_size_t]
+    L.zkhip_prove_chips.argtypes = [C.c_void_p, C.POINTER(Chip), C.c_int, u32p, C.c_size_t, C.POINTER(Params), u8p, C.c_size_t,
+                                    C.POINTER(C.c_size_t)]
+    L.zkhip_verify_chips.argtypes = [u8p, C.c_size_t, i32p, u32p, C.c_int, u32p, C.c_size_t, C.POINTER(Params), C.POINTER(C.c_int)]
     _LIB = L
     return L
 

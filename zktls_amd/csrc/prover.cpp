@@ -961,6 +961,449 @@ int zkhip_verify_shard(const uint8_t* proof, size_t len, int log_n, uint32_t wid
     return ZKHIP_OK;
 }
 
+// ================================================================ shards of several chips with different heights
+// The structure of an SP1 shard (sp1-stark 4.1.4 ShardProof, reference Cargo.lock:6172, behind sp1.rs:116): one Merkle
+// commitment per phase over matrices of different heights (p3-merkle-tree injection rule), one zeta, one reduced-opening
+// vector per height that joins the FRI vector when folding reaches that height (p3-fri 0.2.1 TwoAdicFriPcs), one query
+// index with chip c opened at index >> (Hmax - h_c).  Byte layout: DESIGN.md section 6.
+namespace zk {
+constexpr uint32_t CHIPS_VERSION = 4u;
+constexpr int MAX_CHIPS = 16;
+
+static int check_chips(const int32_t* log_ns, const uint32_t* widths, int n, const zkhip_params* prm) {
+    if (!prm || !log_ns || !widths) return fail(ZKHIP_ERR_INVALID, "chips: null argument");
+    if (n < 1 || n > MAX_CHIPS) return fail(ZKHIP_ERR_INVALID, "chips: 1..16 chips");
+    if (prm->log_blowup < 1 || prm->log_blowup > 3) return fail(ZKHIP_ERR_INVALID, "chips: log_blowup in [1,3]");
+    if ((prm->log_fold != 0 && prm->log_fold != 1) || prm->log_final != 0 || (prm->hash_width != 0 && prm->hash_width != 16) || prm->logup_pairs != 0)
+        return fail(ZKHIP_ERR_INVALID, "chips: the multi-chip prover uses the SP1 FRI shape (fold by 2, constant final polynomial, width-16 hash) without lookups");
+    if (prm->num_queries < 1 || prm->num_queries > 4096 || prm->pow_bits < 0 || prm->pow_bits > 28) return fail(ZKHIP_ERR_INVALID, "chips: queries / pow_bits out of range");
+    for (int c = 0; c < n; c++) {
+        if (log_ns[c] < 5 || log_ns[c] > 20 || widths[c] == 0 || widths[c] % 4 != 0 || widths[c] > 1024)
+            return fail(ZKHIP_ERR_INVALID, "chips: log_n in [5,20], width a multiple of 4 up to 1024");
+        if (c && log_ns[c] > log_ns[c - 1]) return fail(ZKHIP_ERR_INVALID, "chips: tallest first");
+        int same = 0;
+        for (int d = 0; d < n; d++) same += log_ns[d] == log_ns[c];
+        if (same > MAX_LEAF_MATS) return fail(ZKHIP_ERR_INVALID, "chips: at most 4 chips per height");
+    }
+    return ZKHIP_OK;
+}
+static size_t chips_proof_words(const int32_t* log_ns, const uint32_t* widths, int n, const zkhip_params* prm) {
+    const size_t b = (size_t)prm->log_blowup, Hmax = (size_t)log_ns[0] + b, L = (size_t)log_ns[0];
+    size_t words = 8 + 2 * (size_t)n + 16 + 8 * L + 4 + 1, perq = 16 * Hmax;
+    for (int c = 0; c < n; c++) { words += 8 * (size_t)widths[c] + 32; perq += widths[c] + 8; }
+    for (size_t l = 0; l < L; l++) perq += 4 + 8 * (Hmax - 1 - l);
+    return words + (size_t)prm->num_queries * perq;
+}
+static void chips_transcript_init(Challenger& ch, const int32_t* log_ns, const uint32_t* widths, int n, const zkhip_params* prm, size_t n_public) {
+    ch.observe_canonical(CHIPS_VERSION);
+    ch.observe_canonical((uint32_t)n);
+    ch.observe_canonical((uint32_t)prm->log_blowup);
+    ch.observe_canonical((uint32_t)prm->num_queries);
+    ch.observe_canonical((uint32_t)prm->pow_bits);
+    ch.observe_canonical((uint32_t)n_public);
+    for (int c = 0; c < n; c++) { ch.observe_canonical((uint32_t)log_ns[c]); ch.observe_canonical(widths[c]); }
+}
+// alpha-power offset of chip c inside the reduced-opening vector of its height
+static uint64_t height_offset(const int32_t* log_ns, const uint32_t* widths, int c) {
+    uint64_t off = 0;
+    for (int d = 0; d < c; d++) if (log_ns[d] == log_ns[c]) off += 2 * (uint64_t)widths[d] + 8;
+    return off;
+}
+}  // namespace zk
+
+size_t zkhip_chips_proof_size(const int32_t* log_ns, const uint32_t* widths, int n_chips, const zkhip_params* prm, size_t n_public) {
+    (void)n_public;
+    if (check_chips(log_ns, widths, n_chips, prm) != ZKHIP_OK) return 0;
+    return chips_proof_words(log_ns, widths, n_chips, prm) * 4;
+}
+
+int zkhip_prove_chips(zkhip_ctx* ctx, const zkhip_chip* chips, int n, const uint32_t* public_values, size_t n_public,
+                      const zkhip_params* prm, uint8_t* proof, size_t cap, size_t* len) {
+    CHECK_CTX(ctx);
+    if (!chips || !proof || !len || (n_public && !public_values)) return fail(ZKHIP_ERR_INVALID, "prove_chips: bad arguments");
+    int32_t log_ns[MAX_CHIPS]; uint32_t widths[MAX_CHIPS];
+    if (n < 1 || n > MAX_CHIPS) return fail(ZKHIP_ERR_INVALID, "chips: 1..16 chips");
+    for (int c = 0; c < n; c++) {
+        log_ns[c] = chips[c].log_n; widths[c] = chips[c].width;
+        if (!chips[c].d_trace || chips[c].ld < chips[c].width) return fail(ZKHIP_ERR_INVALID, "prove_chips: bad chip descriptor");
+    }
+    ZK_TRY(check_chips(log_ns, widths, n, prm));
+    for (size_t i = 0; i < n_public; i++) if (public_values[i] >= P) return fail(ZKHIP_ERR_INVALID, "prove_chips: public values must be canonical");
+    const size_t need = chips_proof_words(log_ns, widths, n, prm) * 4;
+    if (cap < need) return fail(ZKHIP_ERR_BUFFER, "prove_chips: proof buffer too small (see zkhip_chips_proof_size)");
+    *len = 0;
+    hipStream_t st = ctx->stream;
+    const int b = prm->log_blowup, Hmax = log_ns[0] + b, L = log_ns[0], Q = prm->num_queries;
+    const size_t mmax = (size_t)1 << Hmax;
+    Shape sh;                                     // SP1 FRI shape at this blowup
+    sh.b = b; sh.R = L;
+    int lh[MAX_CHIPS];
+    size_t tl_off[MAX_CHIPS + 1], ql_off[MAX_CHIPS + 1], dv_off[MAX_CHIPS + 1], op_off[MAX_CHIPS + 1], ap_off[MAX_CHIPS + 1];
+    tl_off[0] = ql_off[0] = dv_off[0] = op_off[0] = ap_off[0] = 0;
+    size_t nmax_chunk = 0;
+    for (int c = 0; c < n; c++) {
+        lh[c] = log_ns[c] + b;
+        const size_t mc = (size_t)1 << lh[c], nc = (size_t)1 << log_ns[c];
+        tl_off[c + 1] = tl_off[c] + mc * widths[c];
+        ql_off[c + 1] = ql_off[c] + mc * 8;
+        dv_off[c + 1] = dv_off[c] + 8 * (mc + nc);               // [2][mc] 1/(x - z) then [2][nc] x/(x - z), ext words
+        op_off[c + 1] = op_off[c] + 8 * (size_t)widths[c] + 32;
+        ap_off[c + 1] = ap_off[c] + 4 * (size_t)(widths[c] > 8 ? widths[c] : 8);
+        if (nc > nmax_chunk) nmax_chunk = nc;
+    }
+    uint32_t* pf = (uint32_t*)proof;
+    size_t pos = 0;
+    pf[pos++] = PROOF_MAGIC; pf[pos++] = CHIPS_VERSION; pf[pos++] = (uint32_t)n; pf[pos++] = (uint32_t)b;
+    pf[pos++] = (uint32_t)Q; pf[pos++] = (uint32_t)prm->pow_bits; pf[pos++] = (uint32_t)n_public; pf[pos++] = 16u;
+    for (int c = 0; c < n; c++) { pf[pos++] = (uint32_t)log_ns[c]; pf[pos++] = widths[c]; }
+    Challenger ch;
+    chips_transcript_init(ch, log_ns, widths, n, prm, n_public);
+    uint32_t root[8];
+
+    // ---- 1. every chip's LDE, one mixed-height tree
+    void *v_tlde, *v_ttree, *v_qlde, *v_qtree, *v_qchunk;
+    ZK_TRY(ctx_reserve(ctx, S_TLDE, tl_off[n] * 4, &v_tlde));
+    ZK_TRY(ctx_reserve(ctx, S_TTREE, (2 * mmax - 1) * 32, &v_ttree));
+    ZK_TRY(ctx_reserve(ctx, S_QLDE, ql_off[n] * 4, &v_qlde));
+    ZK_TRY(ctx_reserve(ctx, S_QTREE, (2 * mmax - 1) * 32, &v_qtree));
+    ZK_TRY(ctx_reserve(ctx, S_QCHUNK, 2 * nmax_chunk * 16, &v_qchunk));
+    uint32_t *tlde = (uint32_t*)v_tlde, *ttree = (uint32_t*)v_ttree, *qlde = (uint32_t*)v_qlde, *qtree = (uint32_t*)v_qtree, *qchunk = (uint32_t*)v_qchunk;
+    MatDesc tm[MAX_CHIPS], qm[MAX_CHIPS];
+    for (int c = 0; c < n; c++) {
+        ZK_TRY(op_coset_lde(ctx, chips[c].d_trace, chips[c].ld, tlde + tl_off[c], widths[c], log_ns[c], widths[c], b, MONTY_GEN));
+        tm[c] = MatDesc{tlde + tl_off[c], widths[c], widths[c]};
+        qm[c] = MatDesc{qlde + ql_off[c], 8, 8};
+    }
+    ZK_TRY(op_merkle_commit_mixed(ctx, tm, lh, n, ttree));
+    ZK_TRY(d2h(ctx, root, ttree + (2 * mmax - 2) * 8, 32));
+    for (int i = 0; i < 8; i++) { ch.observe(root[i]); pf[pos++] = from_monty(root[i]); }
+    for (size_t i = 0; i < n_public; i++) ch.observe_canonical(public_values[i]);
+
+    // ---- 2. per-chip quotients on the chip's own coset, chunk LDEs, second tree
+    const Ext alpha = ch.sample_ext();
+    for (int c = 0; c < n; c++) {
+        const size_t nc = (size_t)1 << log_ns[c];
+        ZK_TRY(ensure_domain(ctx, log_ns[c], b));
+        ZK_TRY(run_quotient(ctx, tlde + tl_off[c], widths[c], log_ns[c], widths[c], alpha, LogupIn{}, qchunk));
+        const uint32_t w2n = two_adic_generator(log_ns[c] + 1);
+        for (int k = 0; k < 2; k++)
+            ZK_TRY(op_coset_lde(ctx, qchunk + (size_t)k * nc * 4, 4, qlde + ql_off[c] + 4 * k, 8, log_ns[c], 4, b, finv(fpow(w2n, (uint64_t)k))));
+    }
+    ZK_TRY(op_merkle_commit_mixed(ctx, qm, lh, n, qtree));
+    ZK_TRY(d2h(ctx, root, qtree + (2 * mmax - 2) * 8, 32));
+    for (int i = 0; i < 8; i++) { ch.observe(root[i]); pf[pos++] = from_monty(root[i]); }
+
+    // ---- 3. openings: one zeta, per-chip "next" point zeta * g_c
+    const Ext zeta = ch.sample_ext();
+    void *v_dinv, *v_open;
+    ZK_TRY(ctx_reserve(ctx, S_DINV, dv_off[n] * 4, &v_dinv));
+    ZK_TRY(ctx_reserve(ctx, S_OPEN_OUT, op_off[n] * 4, &v_open));
+    uint32_t *dinv = (uint32_t*)v_dinv, *d_open = (uint32_t*)v_open;
+    Ext znext[MAX_CHIPS];
+    for (int c = 0; c < n; c++) {
+        const size_t mc = (size_t)1 << lh[c], nc = (size_t)1 << log_ns[c];
+        znext[c] = ext_mul_base(zeta, two_adic_generator(log_ns[c]));
+        const Ext zpts[2] = {zeta, znext[c]};
+        ZK_TRY(ensure_domain(ctx, log_ns[c], b));
+        uint32_t* dv = dinv + dv_off[c];
+        uint32_t* xw = dv + 8 * mc;
+        ZK_HIP(launch_inv_denominators(ctx->dom_xs, mc, zpts[0], zpts[1], 2, dv, xw, nc, st));
+        ZK_TRY(run_open(ctx, tlde + tl_off[c], widths[c], log_ns[c], widths[c], zpts, 2, xw, d_open + op_off[c]));
+        ZK_TRY(run_open(ctx, qlde + ql_off[c], 8, log_ns[c], 8, zpts, 1, xw, d_open + op_off[c] + 8 * (size_t)widths[c]));
+    }
+    std::vector<uint32_t> opened(op_off[n]);
+    ZK_TRY(d2h(ctx, opened.data(), d_open, opened.size() * 4));
+    for (size_t i = 0; i < opened.size(); i++) { ch.observe(opened[i]); pf[pos++] = from_monty(opened[i]); }
+
+    // ---- 4. one reduced-opening vector per height (alpha powers run on across the chips of a height)
+    const Ext fa = ch.sample_ext();
+    std::vector<size_t> layer_off(L + 1), tree_off(L + 1);
+    {
+        size_t lo = 0, to = 0;
+        for (int l = 0; l <= L; l++) {
+            layer_off[l] = lo; tree_off[l] = to;
+            lo += ((size_t)1 << (Hmax - l)) * 4;
+            if (l < L) to += (2 * ((size_t)1 << (Hmax - 1 - l)) - 1) * 8;
+        }
+    }
+    void *v_apf, *v_layers, *v_ltrees, *v_ro, *v_at;
+    ZK_TRY(ctx_reserve(ctx, S_APOW_F, ap_off[n] * 4, &v_apf));
+    ZK_TRY(ctx_reserve(ctx, S_FRI_LAYERS, 2 * mmax * 16, &v_layers));
+    ZK_TRY(ctx_reserve(ctx, S_FRI_TREES, 2 * mmax * 32, &v_ltrees));
+    ZK_TRY(ctx_reserve(ctx, S_RO, mmax * 16, &v_ro));             // heights below Hmax: sum of 2^h < 2^Hmax entries
+    ZK_TRY(ctx_reserve(ctx, S_PARTIAL, 2 * mmax * 16, &v_at));
+    uint32_t *layers = (uint32_t*)v_layers, *ltrees = (uint32_t*)v_ltrees;
+    const uint32_t* inject[32] = {nullptr};
+    uint32_t* ro_of[32] = {nullptr};
+    {
+        size_t used = 0;
+        for (int c = 0; c < n; c++)
+            if (lh[c] != Hmax && !ro_of[lh[c]]) { ro_of[lh[c]] = (uint32_t*)v_ro + used; used += ((size_t)1 << lh[c]) * 4; inject[lh[c]] = ro_of[lh[c]]; }
+        ro_of[Hmax] = layers;
+    }
+    std::vector<uint32_t> apows(ap_off[n]);
+    for (int c = 0; c < n; c++) {
+        const size_t np = widths[c] > 8 ? widths[c] : 8;
+        Ext* fp = (Ext*)(apows.data() + ap_off[c]);
+        fp[0] = ext_one();
+        for (size_t j = 1; j < np; j++) fp[j] = ext_mul(fp[j - 1], fa);
+    }
+    ZK_TRY(h2d(ctx, v_apf, apows.data(), apows.size() * 4));
+    bool started[32] = {false};
+    for (int c = 0; c < n; c++) {
+        const uint32_t W = widths[c];
+        const Ext* fp = (const Ext*)(apows.data() + ap_off[c]);
+        const Ext* op_loc = (const Ext*)(opened.data() + op_off[c]);
+        const Ext* op_nxt = op_loc + W;
+        const Ext* op_q = op_nxt + W;
+        ReducedArgs ra{};
+        ra.y_loc = ra.y_next = ra.y_pl = ra.y_pn = ra.y_q = ext_zero();
+        for (uint32_t j = 0; j < W; j++) {
+            ra.y_loc = ext_add(ra.y_loc, ext_mul(fp[j], op_loc[j]));
+            ra.y_next = ext_add(ra.y_next, ext_mul(fp[j], op_nxt[j]));
+        }
+        for (int j = 0; j < 8; j++) ra.y_q = ext_add(ra.y_q, ext_mul(fp[j], op_q[j]));
+        const uint64_t off = height_offset(log_ns, widths, c);
+        ra.off_loc = ext_pow(fa, off); ra.off_next = ext_pow(fa, off + W); ra.off_q = ext_pow(fa, off + 2 * (uint64_t)W);
+        ra.off_pl = ra.off_pn = ext_zero();
+        ra.tlde = tlde + tl_off[c]; ra.t_ld = W; ra.width = W; ra.qlde = qlde + ql_off[c]; ra.q_ld = 8; ra.rows = (uint64_t)1 << lh[c];
+        ra.plde = nullptr; ra.p_ld = 0; ra.p_width = 0;
+        ra.alpha_pow = (const uint32_t*)v_apf + ap_off[c]; ra.dinv = dinv + dv_off[c]; ra.out = ro_of[lh[c]];
+        ra.accumulate = started[lh[c]] ? 1 : 0;
+        started[lh[c]] = true;
+        ZK_HIP(launch_reduced_opening(ra, (uint32_t*)v_at, st));
+    }
+
+    // ---- 5. FRI commit phase; shorter vectors join at their height
+    ZK_TRY(ensure_domain(ctx, log_ns[0], b));                   // fold twiddles of the largest domain
+    ZK_TRY(fri_commit_phase(ctx, ch, sh, Hmax, L, layers, ltrees, layer_off, tree_off, (uint32_t*)v_at, mmax, inject, pf, pos));
+    {
+        std::vector<Ext> last((size_t)1 << b);
+        ZK_TRY(d2h(ctx, last.data(), layers + layer_off[L], last.size() * 16));
+        for (size_t i = 1; i < last.size(); i++)
+            if (!ext_eq(last[0], last[i])) return fail(ZKHIP_ERR_INVALID, "prove_chips: final FRI layer is not constant (a trace violates its AIR)");
+        for (int e = 0; e < 4; e++) pf[pos++] = from_monty(last[0].c[e]);
+        ch.observe_ext(last[0]);
+    }
+
+    // ---- 6. proof of work, 7. queries
+    uint32_t witness = 0;
+    ZK_TRY(grind_witness(ctx, ch, prm->pow_bits, &witness));
+    pf[pos++] = witness;
+    {
+        std::vector<GatherDesc> descs;
+        size_t qpos = 0;
+        auto push = [&](const uint32_t* src, size_t nwords) { descs.push_back(GatherDesc{src, (uint32_t)qpos, (uint32_t)nwords}); qpos += nwords; };
+        auto push_path = [&](const uint32_t* tree, size_t leaves, size_t index, int levels) {
+            const uint32_t* lvl = tree; size_t cnt = leaves, idx = index;
+            for (int k = 0; k < levels; k++) { push(lvl + 8 * (idx ^ 1), 8); lvl += 8 * cnt; cnt >>= 1; idx >>= 1; }
+        };
+        for (int q = 0; q < Q; q++) {
+            const size_t index = ch.sample_bits(Hmax);
+            for (int c = 0; c < n; c++) push(tlde + tl_off[c] + (index >> (Hmax - lh[c])) * widths[c], widths[c]);
+            push_path(ttree, mmax, index, Hmax);
+            for (int c = 0; c < n; c++) push(qlde + ql_off[c] + (index >> (Hmax - lh[c])) * 8, 8);
+            push_path(qtree, mmax, index, Hmax);
+            size_t idx = index;
+            for (int l = 0; l < L; l++) {
+                const int rows_log = Hmax - 1 - l;
+                push(layers + layer_off[l] + (idx ^ 1) * 4, 4);
+                push_path(ltrees + tree_off[l], (size_t)1 << rows_log, idx >> 1, rows_log);
+                idx >>= 1;
+            }
+        }
+        if (pos + qpos != need / 4) return fail(ZKHIP_ERR_INTERNAL, "prove_chips: proof layout mismatch");
+        void *v_desc, *v_out;
+        ZK_TRY(ctx_reserve(ctx, S_GATHER_DESC, descs.size() * sizeof(GatherDesc), &v_desc));
+        ZK_TRY(ctx_reserve(ctx, S_GATHER_OUT, qpos * 4, &v_out));
+        ZK_TRY(h2d(ctx, v_desc, descs.data(), descs.size() * sizeof(GatherDesc)));
+        ZK_HIP(launch_gather((const GatherDesc*)v_desc, (uint32_t)descs.size(), (uint32_t*)v_out, st));
+        ZK_TRY(d2h(ctx, pf + pos, v_out, qpos * 4));
+        pos += qpos;
+    }
+    *len = pos * 4;
+    return ZKHIP_OK;
+}
+
+// opening of a mixed-height tree (host): rows[c] = chip c's row at index >> (Hmax - lh[c]), canonical words
+static bool verify_mixed(const uint32_t* root_m, int Hmax, size_t index, const uint32_t* const* rows, const uint32_t* widths,
+                         const int* lh, int n, const uint32_t* sibs_canon) {
+    auto hash_height = [&](int h, uint32_t out[8]) -> bool {
+        uint32_t s[16] = {0};
+        size_t posn = 0, total = 0;
+        for (int c = 0; c < n; c++)
+            if (lh[c] == h)
+                for (uint32_t i = 0; i < widths[c]; i++) {
+                    s[posn++] = to_monty(rows[c][i]); total++;
+                    if (posn == 8) { p2_permute(s); posn = 0; }
+                }
+        if (!total) return false;
+        if (posn) p2_permute(s);
+        for (int i = 0; i < 8; i++) out[i] = s[i];
+        return true;
+    };
+    uint32_t cur[8], rh[8];
+    hash_height(Hmax, cur);
+    for (int lvl = 0; lvl < Hmax; lvl++) {
+        uint32_t sib[8];
+        for (int i = 0; i < 8; i++) sib[i] = to_monty(sibs_canon[8 * lvl + i]);
+        if ((index >> lvl) & 1) p2_compress(sib, cur, cur);
+        else p2_compress(cur, sib, cur);
+        if (hash_height(Hmax - lvl - 1, rh)) p2_compress(cur, rh, cur);
+    }
+    for (int i = 0; i < 8; i++) if (cur[i] != root_m[i]) return false;
+    return true;
+}
+
+int zkhip_verify_chips(const uint8_t* proof, size_t len, const int32_t* log_ns, const uint32_t* widths, int n,
+                       const uint32_t* public_values, size_t n_public, const zkhip_params* prm, int* reason) {
+    int dummy;
+    if (!reason) reason = &dummy;
+    *reason = 0;
+    auto reject = [&](int why) { *reason = why; return fail(ZKHIP_ERR_VERIFY, "proof rejected (check " + std::to_string(why) + ")"); };
+    if (check_chips(log_ns, widths, n, prm) != ZKHIP_OK) return reject(1);
+    if (!proof || (n_public && !public_values)) return reject(1);
+    if (len != chips_proof_words(log_ns, widths, n, prm) * 4) return reject(2);
+    const uint32_t* pf = (const uint32_t*)proof;
+    const int b = prm->log_blowup, Hmax = log_ns[0] + b, L = log_ns[0];
+    if (pf[0] != PROOF_MAGIC || pf[1] != CHIPS_VERSION || pf[2] != (uint32_t)n || pf[3] != (uint32_t)b || pf[4] != (uint32_t)prm->num_queries ||
+        pf[5] != (uint32_t)prm->pow_bits || pf[6] != (uint32_t)n_public || pf[7] != 16u) return reject(3);
+    size_t pos = 8;
+    for (int c = 0; c < n; c++) { if (pf[pos] != (uint32_t)log_ns[c] || pf[pos + 1] != widths[c]) return reject(3); pos += 2; }
+    for (size_t i = pos; i < len / 4; i++) if (pf[i] >= P) return reject(4);
+    for (size_t i = 0; i < n_public; i++) if (public_values[i] >= P) return reject(4);
+    int lh[MAX_CHIPS]; uint32_t w8[MAX_CHIPS];
+    for (int c = 0; c < n; c++) { lh[c] = log_ns[c] + b; w8[c] = 8; }
+    Challenger ch;
+    chips_transcript_init(ch, log_ns, widths, n, prm, n_public);
+    uint32_t troot[8], qroot[8];
+    for (int i = 0; i < 8; i++) { troot[i] = to_monty(pf[pos++]); ch.observe(troot[i]); }
+    for (size_t i = 0; i < n_public; i++) ch.observe_canonical(public_values[i]);
+    const Ext alpha = ch.sample_ext();
+    for (int i = 0; i < 8; i++) { qroot[i] = to_monty(pf[pos++]); ch.observe(qroot[i]); }
+    const Ext zeta = ch.sample_ext();
+    std::vector<std::vector<Ext>> loc(n), nxt(n), opq(n);
+    for (int c = 0; c < n; c++) {
+        const uint32_t W = widths[c];
+        loc[c].resize(W); nxt[c].resize(W); opq[c].resize(8);
+        for (uint32_t j = 0; j < W; j++) loc[c][j] = ext_from_canon(pf + pos + 4 * j);
+        pos += 4 * (size_t)W;
+        for (uint32_t j = 0; j < W; j++) nxt[c][j] = ext_from_canon(pf + pos + 4 * j);
+        pos += 4 * (size_t)W;
+        for (int j = 0; j < 8; j++) opq[c][j] = ext_from_canon(pf + pos + 4 * j);
+        pos += 32;
+    }
+    for (int c = 0; c < n; c++) {
+        for (const Ext& e : loc[c]) ch.observe_ext(e);
+        for (const Ext& e : nxt[c]) ch.observe_ext(e);
+        for (const Ext& e : opq[c]) ch.observe_ext(e);
+    }
+    // (a) every chip's AIR identity at zeta
+    for (int c = 0; c < n; c++) {
+        const size_t nc = (size_t)1 << log_ns[c];
+        const uint32_t gn = two_adic_generator(log_ns[c]);
+        const Ext zn = ext_pow(zeta, nc), zh = ext_sub_base(zn, MONTY_R1);
+        const Ext sel_first = ext_mul(zh, ext_inv(ext_sub_base(zeta, MONTY_R1)));
+        const Ext sel_trans = ext_sub_base(zeta, finv(gn));
+        Ext acc = ext_zero();
+        for (uint32_t g = 0; g < widths[c] / 4; g++) {
+            const Ext &a = loc[c][4 * g], &bb = loc[c][4 * g + 1], &cc = loc[c][4 * g + 2], &d = loc[c][4 * g + 3], &dn = nxt[c][4 * g + 3];
+            const uint32_t k1 = to_monty(g + 1), k2 = to_monty(2 * g + 3), d0 = to_monty(5 * g + 7);
+            const Ext c1 = ext_sub_base(ext_sub(cc, ext_mul(ext_mul(a, a), bb)), k1);
+            const Ext c2 = ext_mul(sel_trans, ext_sub_base(ext_sub(ext_sub(dn, ext_mul(a, bb)), cc), k2));
+            const Ext c3 = ext_mul(sel_first, ext_sub_base(d, d0));
+            acc = ext_add(ext_mul(acc, alpha), c1);
+            acc = ext_add(ext_mul(acc, alpha), c2);
+            acc = ext_add(ext_mul(acc, alpha), c3);
+        }
+        const uint32_t w2n = two_adic_generator(log_ns[c] + 1);
+        const uint32_t s[2] = {MONTY_GEN, fmul(MONTY_GEN, w2n)};
+        Ext quot = ext_zero();
+        for (int k = 0; k < 2; k++) {
+            const int j = 1 - k;
+            const uint32_t sjn_inv = finv(fpow(s[j], nc));
+            const Ext num = ext_sub_base(ext_mul_base(zn, sjn_inv), MONTY_R1);
+            const uint32_t den = fsub(fmul(fpow(s[k], nc), sjn_inv), MONTY_R1);
+            quot = ext_add(quot, ext_mul(ext_mul_base(num, finv(den)), recombine(&opq[c][4 * k])));
+        }
+        if (!ext_eq(ext_mul(acc, ext_inv(zh)), quot)) return reject(10);
+    }
+    // (b) FRI
+    const Ext fa = ch.sample_ext();
+    size_t npmax = 8;
+    for (int c = 0; c < n; c++) if (widths[c] > npmax) npmax = widths[c];
+    std::vector<Ext> fapow(npmax);
+    fapow[0] = ext_one();
+    for (size_t j = 1; j < npmax; j++) fapow[j] = ext_mul(fapow[j - 1], fa);
+    Ext y_loc[MAX_CHIPS], y_nxt[MAX_CHIPS], y_q[MAX_CHIPS], s_loc[MAX_CHIPS], s_nxt[MAX_CHIPS], s_q[MAX_CHIPS], znext[MAX_CHIPS];
+    for (int c = 0; c < n; c++) {
+        const uint32_t W = widths[c];
+        y_loc[c] = y_nxt[c] = y_q[c] = ext_zero();
+        for (uint32_t j = 0; j < W; j++) {
+            y_loc[c] = ext_add(y_loc[c], ext_mul(fapow[j], loc[c][j]));
+            y_nxt[c] = ext_add(y_nxt[c], ext_mul(fapow[j], nxt[c][j]));
+        }
+        for (int j = 0; j < 8; j++) y_q[c] = ext_add(y_q[c], ext_mul(fapow[j], opq[c][j]));
+        const uint64_t off = height_offset(log_ns, widths, c);
+        s_loc[c] = ext_pow(fa, off); s_nxt[c] = ext_pow(fa, off + W); s_q[c] = ext_pow(fa, off + 2 * (uint64_t)W);
+        znext[c] = ext_mul_base(zeta, two_adic_generator(log_ns[c]));
+    }
+    std::vector<uint32_t> commits((size_t)L * 8);
+    std::vector<Ext> betas(L);
+    for (int l = 0; l < L; l++) {
+        for (int i = 0; i < 8; i++) { commits[8 * l + i] = to_monty(pf[pos++]); ch.observe(commits[8 * l + i]); }
+        betas[l] = ch.sample_ext();
+    }
+    const Ext final_poly = ext_from_canon(pf + pos);
+    pos += 4;
+    ch.observe_ext(final_poly);
+    const uint32_t witness = pf[pos++];
+    ch.observe_canonical(witness);
+    if (ch.sample_bits(prm->pow_bits) != 0) return reject(20);
+    for (int q = 0; q < prm->num_queries; q++) {
+        const size_t index = ch.sample_bits(Hmax);
+        const uint32_t *trow[MAX_CHIPS], *qrow[MAX_CHIPS];
+        for (int c = 0; c < n; c++) { trow[c] = pf + pos; pos += widths[c]; }
+        const uint32_t* tpath = pf + pos; pos += 8 * (size_t)Hmax;
+        for (int c = 0; c < n; c++) { qrow[c] = pf + pos; pos += 8; }
+        const uint32_t* qpath = pf + pos; pos += 8 * (size_t)Hmax;
+        if (!verify_mixed(troot, Hmax, index, trow, widths, lh, n, tpath)) return reject(30);
+        if (!verify_mixed(qroot, Hmax, index, qrow, w8, lh, n, qpath)) return reject(31);
+        Ext roh[32];
+        for (int h = 0; h < 32; h++) roh[h] = ext_zero();
+        for (int c = 0; c < n; c++) {
+            const size_t ic = index >> (Hmax - lh[c]);
+            const uint32_t x = fmul(MONTY_GEN, fpow(two_adic_generator(lh[c]), reverse_bits((uint32_t)ic, lh[c])));
+            const Ext d1 = ext_inv(ext_neg(ext_sub_base(zeta, x))), d2 = ext_inv(ext_neg(ext_sub_base(znext[c], x)));
+            Ext at = ext_zero(), aq = ext_zero();
+            for (uint32_t j = 0; j < widths[c]; j++) at = ext_add(at, ext_mul_base(fapow[j], to_monty(trow[c][j])));
+            for (int j = 0; j < 8; j++) aq = ext_add(aq, ext_mul_base(fapow[j], to_monty(qrow[c][j])));
+            Ext r = ext_mul(s_loc[c], ext_mul(ext_sub(at, y_loc[c]), d1));
+            r = ext_add(r, ext_mul(s_nxt[c], ext_mul(ext_sub(at, y_nxt[c]), d2)));
+            r = ext_add(r, ext_mul(s_q[c], ext_mul(ext_sub(aq, y_q[c]), d1)));
+            roh[lh[c]] = ext_add(roh[lh[c]], r);
+        }
+        Ext folded = roh[Hmax];
+        size_t idx = index;
+        for (int l = 0; l < L; l++) {
+            const int rows_log = Hmax - 1 - l;
+            const Ext sib = ext_from_canon(pf + pos);
+            uint32_t rowbuf[8];
+            for (int i = 0; i < 4; i++) { rowbuf[4 * (idx & 1) + i] = from_monty(folded.c[i]); rowbuf[4 * ((idx & 1) ^ 1) + i] = pf[pos + i]; }
+            pos += 4;
+            const uint32_t* path = pf + pos; pos += 8 * (size_t)rows_log;
+            Ext ev[2];
+            ev[idx & 1] = folded; ev[(idx & 1) ^ 1] = sib;
+            if (!verify_path(&commits[8 * l], rows_log, idx >> 1, rowbuf, 8, path, 16)) return reject(40 + (l < 50 ? l : 50));
+            folded = ext_add(fri_fold_row(idx >> 1, rows_log, betas[l], ev[0], ev[1]), roh[rows_log]);
+            idx >>= 1;
+        }
+        if (!ext_eq(folded, final_poly)) return reject(100);
+    }
+    if (pos * 4 != len) return reject(5);
+    return ZKHIP_OK;
+}
+
 int zkhip_last_prove_debug(zkhip_ctx* ctx, zkhip_prove_debug* out) {
     if (!ctx || !out) return fail(ZKHIP_ERR_INVALID, "null argument");
     *out = ctx->debug;

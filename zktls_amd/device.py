@@ -241,6 +241,23 @@ class Context:
                                            buf.ctypes.data_as(u8p), size, C.byref(got)))
         return buf[: got.value]
 
+    def prove_chips(self, chips, public_values=(), params=None):
+        """chips: [(device buffer, log_n, width), ...] tallest first -- one shard of several AIR tables (SP1's shard shape)"""
+        params = params or Params(1, 100, 16, 0)
+        n = len(chips)
+        arr = (_lib.Chip * n)(*[_lib.Chip(b.ptr, w, ln, w) for b, ln, w in chips])
+        log_ns = (C.c_int32 * n)(*[ln for _, ln, _ in chips])
+        widths = (C.c_uint32 * n)(*[w for _, _, w in chips])
+        pv = np.ascontiguousarray(np.array(public_values, dtype=np.uint32))
+        size = self.lib.zkhip_chips_proof_size(log_ns, widths, n, C.byref(params), pv.size)
+        if size == 0:
+            check(-1)
+        buf = np.empty(size, dtype=np.uint8)
+        got = C.c_size_t(0)
+        check(self.lib.zkhip_prove_chips(self.handle, arr, n, pv.ctypes.data_as(u32p), pv.size, C.byref(params),
+                                         buf.ctypes.data_as(u8p), size, C.byref(got)))
+        return buf[: got.value]
+
     def prove_debug(self):
         d = ProveDebug()
         check(self.lib.zkhip_last_prove_debug(self.handle, C.byref(d)))
@@ -256,4 +273,17 @@ def verify_shard(proof, log_n, width, public_values=(), params=None):
     reason = C.c_int(0)
     rc = lib.zkhip_verify_shard(pr.ctypes.data_as(u8p), pr.size, log_n, width, pv.ctypes.data_as(u32p), pv.size,
                                 C.byref(params), C.byref(reason))
+    return rc, reason.value
+
+
+def verify_chips(proof, log_ns, widths, public_values=(), params=None):
+    params = params or Params(1, 100, 16)
+    lib = _lib.load()
+    pr = np.ascontiguousarray(proof, dtype=np.uint8)
+    pv = np.ascontiguousarray(np.array(public_values, dtype=np.uint32))
+    n = len(log_ns)
+    ln = (C.c_int32 * n)(*[int(x) for x in log_ns])
+    ws = (C.c_uint32 * n)(*[int(x) for x in widths])
+    reason = C.c_int(0)
+    rc = lib.zkhip_verify_chips(pr.ctypes.data_as(u8p), pr.size, ln, ws, n, pv.ctypes.data_as(u32p), pv.size, C.byref(params), C.byref(reason))
     return rc, reason.value
