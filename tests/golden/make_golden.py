@@ -76,6 +76,18 @@ def main():
         shapes[name] = {"log_n": log_n, "width": w, "shape": list(shape), "shard": 5, "public": [1, 2, 3],
                         "bytes": int(pf.size), "sha256": hashlib.sha256(pf.tobytes()).hexdigest()}
     out["shape_proofs"] = shapes
+    # shards of several chips with different heights (SP1's shard shape): [(log_n, width), ...] tallest first
+    chipsets = {}
+    for name, (chips, prm) in {"two_chips": ([(10, 16), (8, 8)], (1, 10, 4)),
+                               "five_chips": ([(10, 16), (10, 8), (7, 12), (7, 4), (5, 8)], (1, 20, 8)),
+                               "blowup4_chips": ([(9, 8), (8, 8), (7, 8), (6, 8), (5, 8)], (2, 10, 0))}.items():
+        traces = [O.gen_trace(SEED, i, ln, w) for i, (ln, w) in enumerate(chips)]
+        params = O.default_params(*prm)
+        pf = O.prove_chips(traces, [3, 4], params)
+        assert O.verify_chips(pf, [c[0] for c in chips], [c[1] for c in chips], [3, 4], params) == 0
+        chipsets[name] = {"chips": [list(c) for c in chips], "params": list(prm), "public": [3, 4],
+                          "bytes": int(pf.size), "sha256": hashlib.sha256(pf.tobytes()).hexdigest()}
+    out["chip_proofs"] = chipsets
     with open(os.path.join(HERE, "oracle_kat.json"), "w") as f:
         json.dump(out, f, indent=1)
     print("wrote oracle_kat.json")

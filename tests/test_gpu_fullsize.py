@@ -79,3 +79,22 @@ def test_fullsize_segment_proof_risc0_shape_verifies(ctx, oracle):
     bad[-3] = (int(bad[-3]) + 1) % P
     assert verify_shard(bad.view(np.uint8), LOG_N, width, [1, 2, 3], prm)[0] == -6
     trace.free()
+
+
+def test_fullsize_multi_chip_shard_verifies(ctx, oracle):
+    # an SP1-like shard: a 2^20-row CPU-style table next to shorter, wider and narrower ones (219 M cells, one proof)
+    from zktls_amd.device import verify_chips
+    chips = [(20, 96), (20, 32), (19, 64), (18, 128), (16, 256), (14, 40)]
+    dev = [(ctx.gen_trace(SEED, 10 + i, ln, w), ln, w) for i, (ln, w) in enumerate(chips)]
+    prm = Params(1, 100, 16)
+    proof = ctx.prove_chips(dev, [1, 2, 3], prm)
+    lns, ws = [c[0] for c in chips], [c[1] for c in chips]
+    assert verify_chips(proof, lns, ws, [1, 2, 3], prm) == (0, 0)
+    assert oracle.verify_chips(proof, lns, ws, [1, 2, 3], oracle.default_params(1, 100, 16)) == 0
+    bad = proof.copy().view(np.uint32)
+    bad[-5] = (int(bad[-5]) + 1) % P
+    assert verify_chips(bad.view(np.uint8), lns, ws, [1, 2, 3], prm)[0] == -6
+    again = ctx.prove_chips(dev, [1, 2, 3], prm)
+    assert again.tobytes() == proof.tobytes()
+    for b, _, _ in dev:
+        b.free()

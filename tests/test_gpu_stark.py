@@ -310,3 +310,11 @@ def test_prove_chips_rejects_bad_sets_and_bad_traces(ctx, oracle):
         assert e.code == -1
         return
     assert verify_chips(proof, [8, 6], [8, 8], [], prm) == (-6, 10)
+
+
+@pytest.mark.parametrize("name", sorted(KAT["chip_proofs"]))
+def test_golden_chip_proofs_on_gpu(ctx, name):
+    g = KAT["chip_proofs"][name]
+    dev = [(ctx.gen_trace(SEED, i, ln, w), ln, w) for i, (ln, w) in enumerate(g["chips"])]
+    proof = ctx.prove_chips(dev, g["public"], Params(*g["params"]))
+    assert proof.size == g["bytes"] and hashlib.sha256(proof.tobytes()).hexdigest() == g["sha256"]

@@ -507,3 +507,11 @@ def test_multi_chip_shape_rules(oracle):
     five = [oracle.gen_trace(SEED, i, 6, 4) for i in range(5)]
     with pytest.raises(RuntimeError):
         oracle.prove_chips(five, [], oracle.default_params(1, 4, 0))          # more than 4 chips of one height
+
+
+@pytest.mark.parametrize("name", sorted(KAT["chip_proofs"]))
+def test_golden_chip_proofs(oracle, name):
+    g = KAT["chip_proofs"][name]
+    traces = [oracle.gen_trace(SEED, i, ln, w) for i, (ln, w) in enumerate(g["chips"])]
+    pf = oracle.prove_chips(traces, g["public"], oracle.default_params(*g["params"]))
+    assert pf.size == g["bytes"] and hashlib.sha256(pf.tobytes()).hexdigest() == g["sha256"]
