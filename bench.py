@@ -41,6 +41,8 @@ def main():
     ap.add_argument("--shape", choices=("sp1", "r0"), default="sp1",
                     help="proof-system shape: sp1 = the headline (blowup 2, 100 queries, 16 PoW bits, fold by 2, Poseidon2-16); "
                          "r0 = RISC-Zero-like (blowup 4, 50 queries, fold by 16, 256 final coefficients, Poseidon2-24)")
+    ap.add_argument("--chips", default="", help="prove a shard of several chips instead of one matrix: 'LOGNxW,LOGNxW,...' tallest first, "
+                                                "or 'sp1like' = 20x96,20x32,19x64,18x128,16x256,14x40 (not the headline workload)")
     ap.add_argument("--streams", type=int, default=4, help="shards in flight per GPU (at most --steps): each on its own context + HIP stream")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-log-n", type=int, default=19, help="rows of the bounded CPU-baseline sample")
@@ -71,8 +73,12 @@ def main():
     from zktls_amd.device import Context, verify_shard
 
     log_n, width = args.log_n, args.width
+    chip_list = None
+    if args.chips:
+        spec = "20x96,20x32,19x64,18x128,16x256,14x40" if args.chips == "sp1like" else args.chips
+        chip_list = [tuple(int(v) for v in c.split("x")) for c in spec.split(",")]
     n = 1 << log_n
-    cells = n * width
+    cells = n * width if chip_list is None else sum(w << ln for ln, w in chip_list)
     LQ = args.logup_pairs
     prm = Params(1, 100, 16, LQ) if args.shape == "sp1" else Params(2, 50, 0, LQ, 4, 8, 24)
     # one context (= one HIP stream + its workspaces) per shard in flight: while one shard sits in a
@@ -88,17 +94,27 @@ def main():
 
     K, W = args.steps, args.warmup
     nbuf = min(max(K, 1), 8)
-    with torch.cuda.stream(stream):
-        traces = [torch.empty(cells, dtype=torch.int32, device="cuda") for _ in range(nbuf)]
-    bufs = [ctx.wrap(t) for t in traces]
-    for i, b in enumerate(bufs):
-        if LQ:
-            ctx.gen_trace_logup(SEED, rank * max(K, 1) + i, log_n, width, LQ, out=b)
-        else:
-            ctx.gen_trace(SEED, rank * max(K, 1) + i, log_n, width, out=b)
+    if chip_list is None:
+        with torch.cuda.stream(stream):
+            traces = [torch.empty(cells, dtype=torch.int32, device="cuda") for _ in range(nbuf)]
+        bufs = [ctx.wrap(t) for t in traces]
+        for i, b in enumerate(bufs):
+            if LQ:
+                ctx.gen_trace_logup(SEED, rank * max(K, 1) + i, log_n, width, LQ, out=b)
+            else:
+                ctx.gen_trace(SEED, rank * max(K, 1) + i, log_n, width, out=b)
+    else:
+        nbuf = 1
+        chip_bufs = [(ctx.gen_trace(SEED, 100 * rank + j, ln, w), ln, w) for j, (ln, w) in enumerate(chip_list)]
+        with torch.cuda.stream(stream):
+            traces = [torch.empty(n * width, dtype=torch.int32, device="cuda")]      # source of the roofline section only
+        bufs = [ctx.wrap(traces[0])]
+        ctx.fill_uniform(SEED, log_n, width, out=bufs[0])
     ctx.sync()
 
     def step(i, c=None):
+        if chip_list is not None:
+            return (c or ctx).prove_chips(chip_bufs, public + [rank * max(K, 1) + i], prm)
         return (c or ctx).prove_shard(bufs[i % nbuf], log_n, width, public + [rank * max(K, 1) + (i % nbuf)], prm)
 
     def run_steps(count):
@@ -153,7 +169,11 @@ def main():
     elapsed = shards.max_over_ranks(dist, elapsed, device="cuda")
 
     # the last proof of the timed region must verify (host verifier of the product)
-    rc, reason = verify_shard(last, log_n, width, public + [rank * max(K, 1) + ((K - 1) % nbuf)], prm)
+    if chip_list is None:
+        rc, reason = verify_shard(last, log_n, width, public + [rank * max(K, 1) + ((K - 1) % nbuf)], prm)
+    else:
+        from zktls_amd.device import verify_chips
+        rc, reason = verify_chips(last, [c[0] for c in chip_list], [c[1] for c in chip_list], public + [rank * max(K, 1) + K - 1], prm)
     verified = rc == 0
 
     # ---- roofline of the dominant kernel: one NTT pass = 8 B/element (read 4 + write 4)
@@ -161,7 +181,7 @@ def main():
     if rank == 0:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         with torch.cuda.stream(stream):
-            scratch = torch.empty(cells, dtype=torch.int32, device="cuda")
+            scratch = torch.empty(n * width, dtype=torch.int32, device="cuda")
         sbuf = ctx.wrap(scratch)
         # many isolated launches: the kernel's average in a rocprofv3 trace of this command is then
         # dominated by launches that had the GPU to themselves (the in-proof launches overlap
@@ -178,7 +198,7 @@ def main():
             e1.synchronize()
             per_which.append(e0.elapsed_time(e1) / reps)
         avg_ms = sum(per_which) / len(per_which)
-        alg_bytes = 8.0 * cells
+        alg_bytes = 8.0 * n * width
         achieved = alg_bytes / (avg_ms * 1e-3) / 1e9
         traffic = None
         pmc = os.path.join(ROOT, "profiles", "pmc_ntt_pass.json")
@@ -264,9 +284,11 @@ def main():
             "dtype": "u32",
             "data": "synthetic",
             "streams_per_gpu": S,
-            "config": {"workload": ("SP1-core-like synthetic shard: 2^%d rows x %d cols BabyBear, log_blowup 1, 100 queries, 16 PoW bits, %s, full prove_shard" if args.shape == "sp1" else
-                                    "RISC-Zero-like synthetic segment: 2^%d rows x %d cols BabyBear, blowup 4, 50 queries, FRI fold 16, 256 final coefficients, Poseidon2 width 24, %s, full prove_shard")
-                                   % (log_n, width, ("LogUp x%d" % LQ) if LQ else "no lookups"),
+            "config": {"workload": ("multi-chip shard (SP1's shard structure): chips %s, one commitment per phase, %d trace cells, log_blowup 1, 100 queries, 16 PoW bits, full prove_chips" % (args.chips, cells))
+                                   if chip_list is not None else
+                                   (("SP1-core-like synthetic shard: 2^%d rows x %d cols BabyBear, log_blowup 1, 100 queries, 16 PoW bits, %s, full prove_shard" if args.shape == "sp1" else
+                                     "RISC-Zero-like synthetic segment: 2^%d rows x %d cols BabyBear, blowup 4, 50 queries, FRI fold 16, 256 final coefficients, Poseidon2 width 24, %s, full prove_shard")
+                                    % (log_n, width, ("LogUp x%d" % LQ) if LQ else "no lookups")),
                        "parallelism": "shard-parallel x%d" % world, "shards_per_step": world},
             "proofs_per_s": round(K * world / elapsed, 3),
             "proof_bytes": int(last.size),
