@@ -43,6 +43,8 @@ def main():
                          "r0 = RISC-Zero-like (blowup 4, 50 queries, fold by 16, 256 final coefficients, Poseidon2-24)")
     ap.add_argument("--chips", default="", help="prove a shard of several chips instead of one matrix: 'LOGNxW,LOGNxW,...' tallest first, "
                                                 "or 'sp1like' = 20x96,20x32,19x64,18x128,16x256,14x40 (not the headline workload)")
+    ap.add_argument("--host-traces", action="store_true", help="traces start in (pinned) HOST memory: every step includes the 1 GiB H2D copy "
+                                                               "(the PCIe-inclusive rate quoted in DESIGN.md; never the headline value)")
     ap.add_argument("--streams", type=int, default=4, help="shards in flight per GPU (at most --steps): each on its own context + HIP stream")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-log-n", type=int, default=19, help="rows of the bounded CPU-baseline sample")
@@ -112,7 +114,19 @@ def main():
         ctx.fill_uniform(SEED, log_n, width, out=bufs[0])
     ctx.sync()
 
+    host_traces = None
+    if args.host_traces and chip_list is None:
+        host_traces = []
+        for b in bufs:
+            h = torch.empty(cells, dtype=torch.int32).pin_memory()
+            ctx.lib.zkhip_from_monty(ctx.handle, __import__("ctypes").c_void_p(b.ptr), __import__("ctypes").c_void_p(b.ptr), cells)     # canonical words on the host side
+            ctx.lib.zkhip_memcpy_d2h(ctx.handle, __import__("ctypes").c_void_p(h.data_ptr()), __import__("ctypes").c_void_p(b.ptr), cells * 4)
+            host_traces.append(h)
+        ctx.sync()
+
     def step(i, c=None):
+        if host_traces is not None:
+            return (c or ctx).prove_shard_host(None, public + [rank * max(K, 1) + (i % nbuf)], prm, host_ptr=host_traces[i % nbuf].data_ptr(), log_n=log_n, width=width)
         if chip_list is not None:
             return (c or ctx).prove_chips(chip_bufs, public + [rank * max(K, 1) + i], prm)
         return (c or ctx).prove_shard(bufs[i % nbuf], log_n, width, public + [rank * max(K, 1) + (i % nbuf)], prm)
@@ -284,6 +298,7 @@ def main():
             "dtype": "u32",
             "data": "synthetic",
             "streams_per_gpu": S,
+            "inputs": "host memory, H2D copy inside every step" if host_traces is not None else "resident in HBM",
             "config": {"workload": ("multi-chip shard (SP1's shard structure): chips %s, one commitment per phase, %d trace cells, log_blowup 1, 100 queries, 16 PoW bits, full prove_chips" % (args.chips, cells))
                                    if chip_list is not None else
                                    (("SP1-core-like synthetic shard: 2^%d rows x %d cols BabyBear, log_blowup 1, 100 queries, 16 PoW bits, %s, full prove_shard" if args.shape == "sp1" else

@@ -193,6 +193,13 @@ size_t zkhip_proof_size(int log_n, uint32_t width, const zkhip_params* prm, size
 int zkhip_prove_shard(zkhip_ctx* ctx, const uint32_t* d_trace, size_t ld, int log_n,
                       uint32_t width, const uint32_t* public_values, size_t n_public,
                       const zkhip_params* prm, uint8_t* proof, size_t cap, size_t* len);
+/* Host-pointer variant: h_trace is a HOST buffer (pageable or pinned) of 2^log_n x width CANONICAL words, row-major.
+ * The library stages it in HBM (one H2D copy + conversion to Montgomery form), then runs zkhip_prove_shard.  This is
+ * the entry for callers whose executor leaves the trace in host memory (the reference's provers all do); the copy is
+ * PCIe-bound, see DESIGN.md section 7 for the measured rate. */
+int zkhip_prove_shard_host(zkhip_ctx* ctx, const uint32_t* h_trace, int log_n, uint32_t width,
+                           const uint32_t* public_values, size_t n_public, const zkhip_params* prm,
+                           uint8_t* proof, size_t cap, size_t* len);
 /* Segment proof from RISC Zero's data layout (risc0-zkp Hal, reference Cargo.lock:5057; call site
  * crates/guest-prover-r0/src/prover.rs:90): d_cols holds `width` contiguous columns of 2^log_n words
  * (column-major [width][2^log_n], Montgomery).  Same proof as zkhip_prove_shard on the transposed matrix;

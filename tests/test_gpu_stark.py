@@ -318,3 +318,12 @@ def test_golden_chip_proofs_on_gpu(ctx, name):
     dev = [(ctx.gen_trace(SEED, i, ln, w), ln, w) for i, (ln, w) in enumerate(g["chips"])]
     proof = ctx.prove_chips(dev, g["public"], Params(*g["params"]))
     assert proof.size == g["bytes"] and hashlib.sha256(proof.tobytes()).hexdigest() == g["sha256"]
+
+
+def test_prove_shard_from_host_memory_equals_device_path(ctx, oracle):
+    log_n, width = 11, 24
+    t = oracle.gen_trace(SEED, 4, log_n, width)
+    prm = Params(1, 20, 8)
+    a = ctx.prove_shard_host(t, [6], prm)
+    b = ctx.prove_shard(ctx.from_numpy(t), log_n, width, [6], prm)
+    assert a.tobytes() == b.tobytes() == oracle.prove_shard(t, [6], oracle.default_params(1, 20, 8)).tobytes()

@@ -673,6 +673,20 @@ int zkhip_prove_shard(zkhip_ctx* ctx, const uint32_t* d_trace, size_t ld, int lo
     return ZKHIP_OK;
 }
 
+int zkhip_prove_shard_host(zkhip_ctx* ctx, const uint32_t* h_trace, int log_n, uint32_t width,
+                           const uint32_t* public_values, size_t n_public, const zkhip_params* prm,
+                           uint8_t* proof, size_t cap, size_t* len) {
+    CHECK_CTX(ctx);
+    ZK_TRY(check_shape(log_n, width, prm));
+    if (!h_trace) return fail(ZKHIP_ERR_INVALID, "prove_shard_host: null trace");
+    const size_t words = (size_t)width << log_n;
+    void* staged;
+    ZK_TRY(ctx_reserve(ctx, 21, words * 4, &staged));
+    ZK_HIP(hipMemcpyAsync(staged, h_trace, words * 4, hipMemcpyHostToDevice, ctx->stream));
+    ZK_HIP(launch_convert((const uint32_t*)staged, (uint32_t*)staged, words, true, ctx->stream));
+    return zkhip_prove_shard(ctx, (const uint32_t*)staged, width, log_n, width, public_values, n_public, prm, proof, cap, len);
+}
+
 int zkhip_prove_segment(zkhip_ctx* ctx, const uint32_t* d_cols, int log_n, uint32_t width,
                         const uint32_t* public_values, size_t n_public, const zkhip_params* prm,
                         uint8_t* proof, size_t cap, size_t* len) {

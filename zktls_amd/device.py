@@ -229,6 +229,21 @@ class Context:
                                          buf.ctypes.data_as(u8p), size, C.byref(got)))
         return buf[: got.value]
 
+    def prove_shard_host(self, host_trace, public_values=(), params=None, host_ptr=None, log_n=None, width=None):
+        """host_trace: numpy [2^log_n][width] canonical words in host memory (or a raw host pointer + shape)"""
+        params = params or Params(1, 100, 16, 0)
+        if host_ptr is None:
+            a = np.ascontiguousarray(host_trace, dtype=np.uint32)
+            log_n, width = a.shape[0].bit_length() - 1, a.shape[1]
+            host_ptr = a.ctypes.data
+        pv = np.ascontiguousarray(np.array(public_values, dtype=np.uint32))
+        size = self.lib.zkhip_proof_size(log_n, width, C.byref(params), pv.size)
+        buf = np.empty(size, dtype=np.uint8)
+        got = C.c_size_t(0)
+        check(self.lib.zkhip_prove_shard_host(self.handle, C.c_void_p(host_ptr), log_n, width, pv.ctypes.data_as(u32p), pv.size,
+                                              C.byref(params), buf.ctypes.data_as(u8p), size, C.byref(got)))
+        return buf[: got.value]
+
     def prove_segment(self, cols, log_n, width, public_values=(), params=None):
         """cols: device buffer, column-major [width][2^log_n] (RISC Zero's Hal layout)"""
         params = params or _lib.segment_params()
