@@ -130,6 +130,13 @@ int zkhip_coset_lde(zkhip_ctx* ctx, const uint32_t* d_in, size_t in_ld, uint32_t
 int zkhip_ntt_pass(zkhip_ctx* ctx, const uint32_t* d_in, uint32_t* d_out, size_t ld, int log_n,
                    uint32_t width, int which);
 
+/* ---- commit: the PCS `commit` of one trace matrix in a single call (p3-fri TwoAdicFriPcs::commit, reference
+ * Cargo.lock:3930; RISC Zero `commit_group`): coset LDE on shift * <w_{N 2^b}> (bit-reversed rows) into d_lde
+ * (2^(log_n+b) x width), Merkle tree into d_tree ((2^(log_n+b+1) - 1) * 8 words), root copied to the host
+ * (8 canonical words).  hash_width 16 or 24. ---- */
+int zkhip_commit(zkhip_ctx* ctx, const uint32_t* d_trace, size_t ld, int log_n, uint32_t width, int log_blowup,
+                 int hash_width, uint32_t* d_lde, uint32_t* d_tree, uint32_t root[8]);
+
 /* ---- Poseidon2 Merkle commitment ---- */
 /* states: count x 16 words, permuted in place (known-answer tests) */
 int zkhip_poseidon2_permute(zkhip_ctx* ctx, uint32_t* d_states, size_t count);

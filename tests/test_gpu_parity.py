@@ -204,3 +204,15 @@ def test_colmajor_interpolate_and_expand_match_oracle(ctx, oracle, count, log_si
     exp = oracle.coset_lde(evals_nat, log_blowup, 31)                         # [n << b][count]
     got_e = ctx.batch_expand_colmajor(ctx.from_numpy(np.ascontiguousarray(coeffs.T)), count, log_size, log_blowup, 31)
     assert (got_e.download().reshape(count, n << log_blowup) == exp.T).all()
+
+
+@pytest.mark.parametrize("log_n,width,log_blowup,hw", [(6, 4, 1, 16), (10, 24, 1, 16), (12, 16, 2, 24), (9, 8, 0, 16), (11, 12, 3, 24)])
+def test_commit_in_one_call_matches_oracle(ctx, oracle, log_n, width, log_blowup, hw):
+    # the PCS commit of the boundary: LDE + tree + root
+    m = oracle.fill_uniform(SEED + 3 * log_n, log_n, width)
+    lde, tree, root = ctx.commit(ctx.from_numpy(m), log_n, width, log_blowup, hw)
+    exp = oracle.coset_lde(m, log_blowup, 31)
+    assert (lde.download().reshape(-1, width) == exp).all()
+    otree = oracle.merkle_tree_hw(exp, hw)
+    assert (tree.download().reshape(-1, 8) == otree).all()
+    assert root.tolist() == otree[-1].tolist()

@@ -22,7 +22,7 @@ EXPORTS = [
     "zkhip_gen_trace_logup", "zkhip_perm_trace",
     "zkhip_dft", "zkhip_coset_lde", "zkhip_ntt_pass", "zkhip_poseidon2_permute", "zkhip_hash_rows",
     "zkhip_merkle_commit", "zkhip_merkle_commit_mixed", "zkhip_merkle_commit_p24_colmajor", "zkhip_batch_interpolate_colmajor", "zkhip_batch_expand_colmajor", "zkhip_quotient_values", "zkhip_open_at", "zkhip_fri_fold", "zkhip_fri_fold_k",
-    "zkhip_proof_size", "zkhip_prove_shard", "zkhip_prove_shard_host", "zkhip_prove_segment", "zkhip_verify_shard", "zkhip_last_prove_debug",
+    "zkhip_commit", "zkhip_proof_size", "zkhip_prove_shard", "zkhip_prove_shard_host", "zkhip_prove_segment", "zkhip_verify_shard", "zkhip_last_prove_debug",
     "zkhip_chips_proof_size", "zkhip_prove_chips", "zkhip_verify_chips",
 ]
 
@@ -106,6 +106,7 @@ def load():
     L.zkhip_proof_size.argtypes = [C.c_int, C.c_uint32, C.POINTER(Params), C.c_size_t]
     L.zkhip_prove_shard.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_uint32, u32p, C.c_size_t,
                                     C.POINTER(Params), u8p, C.c_size_t, C.POINTER(C.c_size_t)]
+    L.zkhip_commit.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_uint32, C.c_int, C.c_int, C.c_void_p, C.c_void_p, u32p]
     L.zkhip_prove_shard_host.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_uint32, u32p, C.c_size_t,
                                          C.POINTER(Params), u8p, C.c_size_t, C.POINTER(C.c_size_t)]
     L.zkhip_prove_segment.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_uint32, u32p, C.c_size_t,

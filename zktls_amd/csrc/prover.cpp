@@ -673,6 +673,21 @@ int zkhip_prove_shard(zkhip_ctx* ctx, const uint32_t* d_trace, size_t ld, int lo
     return ZKHIP_OK;
 }
 
+int zkhip_commit(zkhip_ctx* ctx, const uint32_t* d_trace, size_t ld, int log_n, uint32_t width, int log_blowup,
+                 int hash_width, uint32_t* d_lde, uint32_t* d_tree, uint32_t root[8]) {
+    CHECK_CTX(ctx);
+    if (!d_trace || !d_lde || !d_tree || !root || ld < width || width == 0 || log_n < 5 || log_n > 20 || log_blowup < 0 || log_blowup > 3 ||
+        (hash_width != 16 && hash_width != 24) || (hash_width == 24 && width % 4 != 0))
+        return fail(ZKHIP_ERR_INVALID, "commit: bad arguments (log_n in [5,20], log_blowup in [0,3], hash_width 16 or 24; width % 4 == 0 for 24)");
+    const int H = log_n + log_blowup;
+    ZK_TRY(op_coset_lde(ctx, d_trace, ld, d_lde, width, log_n, width, log_blowup, MONTY_GEN));
+    ZK_TRY(commit_hw(ctx, d_lde, width, width, H, d_tree, hash_width));
+    uint32_t r[8];
+    ZK_TRY(d2h(ctx, r, d_tree + ((size_t)2 << H) * 8 - 16, 32));
+    for (int i = 0; i < 8; i++) root[i] = from_monty(r[i]);
+    return ZKHIP_OK;
+}
+
 int zkhip_prove_shard_host(zkhip_ctx* ctx, const uint32_t* h_trace, int log_n, uint32_t width,
                            const uint32_t* public_values, size_t n_public, const zkhip_params* prm,
                            uint8_t* proof, size_t cap, size_t* len) {

@@ -217,6 +217,15 @@ class Context:
         check(self.lib.zkhip_fri_fold_k(self.handle, C.c_void_p(src.ptr), log_h, log_arity, b.ctypes.data_as(u32p), C.c_void_p(out.ptr)))
         return out
 
+    def commit(self, trace, log_n, width, log_blowup=1, hash_width=16):
+        """coset LDE + Merkle tree + root in one call; returns (lde, tree, root[8] canonical)"""
+        h = log_n + log_blowup
+        lde, tree = self.alloc(width << h), self.alloc(8 * ((2 << h) - 1))
+        root = np.zeros(8, dtype=np.uint32)
+        check(self.lib.zkhip_commit(self.handle, C.c_void_p(trace.ptr), width, log_n, width, log_blowup, hash_width,
+                                    C.c_void_p(lde.ptr), C.c_void_p(tree.ptr), root.ctypes.data_as(u32p)))
+        return lde, tree, root
+
     # ---- whole shard
     def prove_shard(self, trace, log_n, width, public_values=(), params=None):
         params = params or Params(1, 100, 16, 0)
