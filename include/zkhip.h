@@ -10,6 +10,15 @@
  *       (`client.prove`, :116) and checks at :120 (`client.verify`), reached through
  *       trait ZkProver::prove (core/src/prelude.rs:12-18); RISC Zero twin:
  *       crates/guest-prover-r0/src/prover.rs:88-93.
+ *   zkhip_prove_chips / zkhip_verify_chips
+ *       the same span for a shard made of several chips of different heights, as sp1-stark's ShardProof is
+ *       (reference Cargo.lock:6172): one mixed-height commitment per phase, one FRI proof.
+ *   zkhip_prove_segment
+ *       the span crates/guest-prover-r0/src/prover.rs:88-93 times, from RISC Zero's column-major Hal layout.
+ *   zkhip_prove_shard_host, zkhip_commit
+ *       host-pointer variant of the prove entry; TwoAdicFriPcs::commit (Cargo.lock:3930) alone.
+ *   zkhip_perm_trace, zkhip_gen_trace_logup
+ *       sp1-stark generate_permutation_trace (Cargo.lock:6172): per-row extension inverses + running sum (LogUp).
  *   zkhip_coset_lde, zkhip_dft, zkhip_ntt_pass
  *       p3-dft Radix2DitParallel::{coset_lde_batch, dft_batch} (reference
  *       Cargo.lock:3903) == risc0-zkp Hal::{batch_interpolate_ntt,
