@@ -327,3 +327,35 @@ def test_prove_shard_from_host_memory_equals_device_path(ctx, oracle):
     a = ctx.prove_shard_host(t, [6], prm)
     b = ctx.prove_shard(ctx.from_numpy(t), log_n, width, [6], prm)
     assert a.tobytes() == b.tobytes() == oracle.prove_shard(t, [6], oracle.default_params(1, 20, 8)).tobytes()
+
+
+def _random_configs(count, seed):
+    rng = np.random.default_rng(seed)
+    out = []
+    while len(out) < count:
+        log_n = int(rng.integers(5, 13))
+        width = 4 * int(rng.integers(1, 19))
+        b = int(rng.integers(1, 4))
+        K = int(rng.integers(1, 5))
+        fs = [f for f in range(0, min(log_n, 8) + 1) if (log_n - f) % K == 0]
+        if not fs:
+            continue
+        F = int(rng.choice(fs))
+        hw = int(rng.choice([16, 24]))
+        pairs = int(rng.integers(0, width // 8 + 1)) if rng.random() < 0.4 else 0
+        q, pw, npub = int(rng.integers(1, 13)), int(rng.integers(0, 7)), int(rng.integers(0, 6))
+        out.append((log_n, width, (b, q, pw, pairs, K, F, hw), npub))
+    return out
+
+
+@pytest.mark.parametrize("log_n,width,shape,npub", _random_configs(40, 20261002))
+def test_prove_shard_randomised_configurations(ctx, oracle, log_n, width, shape, npub):
+    # a fixed pseudo-random sweep over sizes, widths, blowups, fold arities, final-polynomial lengths, hashes, lookups
+    pairs = shape[3]
+    pub = list(range(11, 11 + npub))
+    trace = ctx.gen_trace_logup(SEED, 8, log_n, width, pairs) if pairs else ctx.gen_trace(SEED, 8, log_n, width)
+    otrace = oracle.gen_trace_logup(SEED, 8, log_n, width, pairs) if pairs else oracle.gen_trace(SEED, 8, log_n, width)
+    proof = ctx.prove_shard(trace, log_n, width, pub, Params(*shape))
+    assert proof.tobytes() == oracle.prove_shard(otrace, pub, oracle.default_params(*shape)).tobytes()
+    assert verify_shard(proof, log_n, width, pub, Params(*shape)) == (0, 0)
+    trace.free()
