@@ -359,3 +359,28 @@ def test_prove_shard_randomised_configurations(ctx, oracle, log_n, width, shape,
     assert proof.tobytes() == oracle.prove_shard(otrace, pub, oracle.default_params(*shape)).tobytes()
     assert verify_shard(proof, log_n, width, pub, Params(*shape)) == (0, 0)
     trace.free()
+
+
+def _random_chip_sets(count, seed):
+    rng = np.random.default_rng(seed)
+    out = []
+    for _ in range(count):
+        n = int(rng.integers(1, 8))
+        heights = sorted((int(h) for h in rng.integers(5, 12, size=n)), reverse=True)
+        while max(heights.count(h) for h in heights) > 4:
+            heights = sorted((int(h) for h in rng.integers(5, 12, size=n)), reverse=True)
+        chips = [(h, 4 * int(rng.integers(1, 12))) for h in heights]
+        out.append((chips, (int(rng.integers(1, 4)), int(rng.integers(1, 10)), int(rng.integers(0, 6)))))
+    return out
+
+
+@pytest.mark.parametrize("chips,prm", _random_chip_sets(16, 777))
+def test_prove_chips_randomised_sets(ctx, oracle, chips, prm):
+    from zktls_amd.device import verify_chips
+    dev = [(ctx.gen_trace(SEED, 30 + i, ln, w), ln, w) for i, (ln, w) in enumerate(chips)]
+    host = [oracle.gen_trace(SEED, 30 + i, ln, w) for i, (ln, w) in enumerate(chips)]
+    proof = ctx.prove_chips(dev, [5], Params(*prm))
+    assert proof.tobytes() == oracle.prove_chips(host, [5], oracle.default_params(*prm)).tobytes()
+    assert verify_chips(proof, [c[0] for c in chips], [c[1] for c in chips], [5], Params(*prm)) == (0, 0)
+    for b, _, _ in dev:
+        b.free()
