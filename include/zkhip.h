@@ -124,7 +124,8 @@ int zkhip_gen_trace(zkhip_ctx* ctx, uint64_t seed, uint64_t shard, int log_n, ui
 int zkhip_gen_trace_logup(zkhip_ctx* ctx, uint64_t seed, uint64_t shard, int log_n, uint32_t width,
                           int pairs, uint32_t* d_out, size_t ld);
 
-/* ---- NTT / LDE over the columns of a row-major matrix, 2^log_n rows, 5 <= log_n <= 20 ---- */
+/* ---- NTT / LDE over the columns of a row-major matrix, 2^log_n rows, 0 <= log_n <= 20 (fewer than 32 rows: by
+ * definition, out of place) ---- */
 /* forward DFT: natural rows in; rows out natural (bitrev_out = 0) or bit-reversed (1);
  * inverse DFT (inverse = 1): natural in, natural out, scaled by 1/N. */
 int zkhip_dft(zkhip_ctx* ctx, const uint32_t* d_in, size_t in_ld, uint32_t* d_out, size_t out_ld,

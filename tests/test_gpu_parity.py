@@ -60,7 +60,7 @@ def test_gen_trace_matches_oracle(ctx, oracle):
         assert oracle.check_trace(t) == 0
 
 
-@pytest.mark.parametrize("log_n", [5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 16])
+@pytest.mark.parametrize("log_n", [0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 16])
 @pytest.mark.parametrize("width", [1, 3, 16])
 def test_forward_dft_matches_oracle(ctx, oracle, log_n, width):
     m = oracle.fill_uniform(SEED + log_n, log_n, width)
@@ -73,7 +73,7 @@ def test_forward_dft_matches_oracle(ctx, oracle, log_n, width):
     assert (src.download().reshape(-1, width) == m).all()      # input preserved
 
 
-@pytest.mark.parametrize("log_n,width", [(5, 2), (8, 5), (10, 16), (11, 4), (13, 8), (15, 17), (18, 3)])
+@pytest.mark.parametrize("log_n,width", [(0, 3), (1, 2), (3, 5), (4, 1), (5, 2), (8, 5), (10, 16), (11, 4), (13, 8), (15, 17), (18, 3)])
 def test_inverse_dft_round_trip_and_oracle(ctx, oracle, log_n, width):
     m = oracle.fill_uniform(SEED + 100 + log_n, log_n, width)
     src = ctx.from_numpy(m)
@@ -86,7 +86,7 @@ def test_inverse_dft_round_trip_and_oracle(ctx, oracle, log_n, width):
 
 
 @pytest.mark.parametrize("log_n,width,log_blowup,shift", [
-    (5, 4, 1, 31), (6, 4, 1, 31), (8, 7, 2, 31), (10, 16, 1, 31), (11, 8, 1, 31),
+    (0, 2, 1, 31), (1, 3, 2, 31), (2, 4, 1, 5), (4, 5, 3, 31), (5, 4, 1, 31), (6, 4, 1, 31), (8, 7, 2, 31), (10, 16, 1, 31), (11, 8, 1, 31),
     (12, 24, 1, 31), (12, 4, 2, 5), (14, 33, 1, 31), (16, 16, 1, 31), (13, 8, 3, 31),
 ])
 def test_coset_lde_matches_oracle(ctx, oracle, log_n, width, log_blowup, shift):

@@ -176,9 +176,18 @@ static int run_forward_natural(zkhip_ctx* ctx, const uint32_t* in, size_t in_ld,
 
 int op_coset_lde(zkhip_ctx* ctx, const uint32_t* in, size_t in_ld, uint32_t* out, size_t out_ld,
                  int log_n, uint32_t width, int log_blowup, uint32_t shift) {
-    if (log_n < 5 || log_n > 20) return fail(ZKHIP_ERR_INVALID, "coset_lde: log_n must be in [5, 20]");
+    if (log_n < 0 || log_n > 20) return fail(ZKHIP_ERR_INVALID, "coset_lde: log_n must be in [0, 20]");
     if (log_blowup < 0 || log_blowup > 4 || log_n + log_blowup > TWO_ADICITY) return fail(ZKHIP_ERR_INVALID, "coset_lde: bad log_blowup");
     if (width == 0 || in_ld < width || out_ld < width) return fail(ZKHIP_ERR_INVALID, "coset_lde: bad width / ld");
+    if (log_n < 5) {      // below the tile minimum: coefficients and evaluation by definition
+        void* coef_s;
+        ZK_TRY(ctx_reserve(ctx, 0, ((size_t)1 << log_n) * width * 4, &coef_s));
+        ZK_HIP(launch_small_eval(in, in_ld, (uint32_t*)coef_s, width, log_n, log_n, width, finv(two_adic_generator(log_n)), MONTY_R1,
+                                 finv(to_monty(1u << log_n)), 0, ctx->stream));
+        ZK_HIP(launch_small_eval((const uint32_t*)coef_s, width, out, out_ld, log_n, log_n + log_blowup, width,
+                                 two_adic_generator(log_n + log_blowup), shift, MONTY_R1, 1, ctx->stream));
+        return ZKHIP_OK;
+    }
     const size_t n = (size_t)1 << log_n;
     const int B = 1 << log_blowup;
     int m1, m2;
@@ -414,8 +423,16 @@ int zkhip_gen_trace_logup(zkhip_ctx* ctx, uint64_t seed, uint64_t shard, int log
 int zkhip_dft(zkhip_ctx* ctx, const uint32_t* d_in, size_t in_ld, uint32_t* d_out, size_t out_ld,
               int log_n, uint32_t width, int inverse, int bitrev_out) {
     CHECK_CTX(ctx);
-    if (log_n < 5 || log_n > 20) return fail(ZKHIP_ERR_INVALID, "dft: log_n must be in [5, 20]");
+    if (log_n < 0 || log_n > 20) return fail(ZKHIP_ERR_INVALID, "dft: log_n must be in [0, 20]");
     if (!d_in || !d_out || width == 0 || in_ld < width || out_ld < width) return fail(ZKHIP_ERR_INVALID, "dft: bad arguments");
+    if (log_n < 5) {      // below the tile minimum: by definition (must not run in place)
+        if (d_in == d_out) return fail(ZKHIP_ERR_INVALID, "dft: transforms of fewer than 32 rows are out of place");
+        if (inverse && bitrev_out) return fail(ZKHIP_ERR_INVALID, "dft: inverse transform writes natural order only");
+        const uint32_t w = inverse ? finv(two_adic_generator(log_n)) : two_adic_generator(log_n);
+        const uint32_t scale = inverse ? finv(to_monty(1u << log_n)) : MONTY_R1;
+        ZK_HIP(launch_small_eval(d_in, in_ld, d_out, out_ld, log_n, log_n, width, w, MONTY_R1, scale, bitrev_out, ctx->stream));
+        return ZKHIP_OK;
+    }
     if (inverse) {
         if (bitrev_out) return fail(ZKHIP_ERR_INVALID, "dft: inverse transform writes natural order only");
         return run_inverse(ctx, d_in, in_ld, d_out, out_ld, log_n, width, false);

@@ -84,6 +84,9 @@ hipError_t launch_gen_trace(uint32_t* out, uint64_t ld, uint64_t seed, uint64_t 
 hipError_t launch_gen_trace_logup(uint32_t* out, uint64_t ld, uint64_t seed, uint64_t rows, uint32_t width,
                                   uint32_t pairs, hipStream_t s);
 // [rows][cols] -> [cols][rows], optional bit reversal of the column index on either side
+// naive evaluation for N < 32: out[row(k)] = scale * sum_j in[j] (shift w^k)^j (see util.hip)
+hipError_t launch_small_eval(const uint32_t* in, uint64_t in_ld, uint32_t* out, uint64_t out_ld, int log_n, int log_out, uint32_t width,
+                             uint32_t w, uint32_t shift, uint32_t scale, int bitrev_out, hipStream_t s);
 hipError_t launch_transpose(const uint32_t* in, uint32_t* out, uint64_t rows, uint64_t cols, int rev_bits_in, int rev_bits_out, hipStream_t s);
 // element-wise Montgomery <-> canonical conversion
 hipError_t launch_convert(const uint32_t* in, uint32_t* out, uint64_t n, bool to_monty_form,

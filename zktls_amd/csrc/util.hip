@@ -154,4 +154,28 @@ hipError_t launch_convert(const uint32_t* in, uint32_t* out, uint64_t n, bool to
     return hipGetLastError();
 }
 
+// ------------------------------------------------------------------ transforms below the tile minimum (N < 32)
+// By definition, one thread per output element: these sizes only occur at the edges of the operator API (the provers
+// need N >= 32), so O(N^2) with N <= 16 is the simplest correct thing.
+// out[row(k)][c] = scale * sum_j in[j][c] * (shift * w^k)^j,  k < 2^log_out;  w of order 2^log_out (or its inverse),
+// row(k) = k or bitrev(k).  Forward DFT: log_out = log_n, shift 1.  Inverse: w^-1, scale 1/N.  LDE: coefficients in.
+__global__ void __launch_bounds__(256) small_eval_kernel(const uint32_t* in, uint64_t in_ld, uint32_t* out, uint64_t out_ld, int log_n, int log_out,
+                                                         uint32_t width, uint32_t w, uint32_t shift, uint32_t scale, int bitrev_out) {
+    const uint32_t idx = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t rows_out = 1u << log_out, n = 1u << log_n;
+    if (idx >= rows_out * width) return;
+    const uint32_t k = idx / width, c = idx % width;
+    const uint32_t x = fmul(shift, fpow(w, k));
+    uint32_t acc = 0;
+    for (uint32_t j = n; j-- > 0;) acc = fadd(fmul(acc, x), in[(uint64_t)j * in_ld + c]);      // Horner
+    const uint32_t row = bitrev_out ? (log_out ? (__brev(k) >> (32 - log_out)) : 0u) : k;
+    out[(uint64_t)row * out_ld + c] = fmul(acc, scale);
+}
+hipError_t launch_small_eval(const uint32_t* in, uint64_t in_ld, uint32_t* out, uint64_t out_ld, int log_n, int log_out, uint32_t width,
+                             uint32_t w, uint32_t shift, uint32_t scale, int bitrev_out, hipStream_t s) {
+    const uint32_t total = (1u << log_out) * width;
+    hipLaunchKernelGGL(small_eval_kernel, dim3((total + 255) / 256), dim3(256), 0, s, in, in_ld, out, out_ld, log_n, log_out, width, w, shift, scale, bitrev_out);
+    return hipGetLastError();
+}
+
 }  // namespace zk
