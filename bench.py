@@ -131,8 +131,9 @@ def main():
             return (c or ctx).prove_chips(chip_bufs, public + [rank * max(K, 1) + i], prm)
         return (c or ctx).prove_shard(bufs[i % nbuf], log_n, width, public + [rank * max(K, 1) + (i % nbuf)], prm)
 
-    def run_steps(count):
-        """`count` shard proofs, S at a time (one host thread per context; ctypes drops the GIL)"""
+    def run_steps(count, static=False):
+        """`count` shard proofs, S at a time (one host thread per context; ctypes drops the GIL).
+        static: worker w takes items w, w + S, ... (warm-up: every context gets work); otherwise first come first served"""
         if S == 1:
             out = None
             for i in range(count):
@@ -147,6 +148,10 @@ def main():
 
         def worker(w):
             try:
+                if static:
+                    for i in range(w, count, S):
+                        results[i] = step(i, ctxs[w])
+                    return
                 while True:
                     with lock:              # shards are handed out as contexts become free
                         i = nxt[0]
@@ -165,7 +170,7 @@ def main():
             raise errors[0]
         return results[count - 1] if count else None
 
-    run_steps(max(W, S if W else 0))       # warm every context (plans, workspaces)
+    run_steps(max(W, S if W else 0), static=True)       # warm every context (plans, workspaces)
     for c in ctxs:
         c.sync()
 
