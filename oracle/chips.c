@@ -15,7 +15,10 @@
  *   FRI         starts from the tallest vector; after each fold, the vector of the height just reached is added in;
  *   query       one index; a chip of height 2^h is opened at index >> (Hmax - h); one Merkle path per tree.
  * Chips use the synthetic AIR of stark.c at their own width.  Shape: the SP1 FRI shape (fold by 2, constant final
- * polynomial, Poseidon2 width 16) at any log_blowup in [1, 3]; no lookups between chips.
+ * polynomial, Poseidon2 width 16) at any log_blowup in [1, 3].
+ * Lookups: a chip may carry in-table LogUp pairs (stark.c: pairs[c] > 0); the permutation traces of those chips form a
+ * third mixed-height tree between the trace and the quotient commitments, as sp1-stark commits the permutation traces
+ * of a shard together (proof version 5).  Lookups BETWEEN chips are not modelled.
  */
 #include "oracle.h"
 #include "stark_internal.h"
@@ -26,11 +29,13 @@
 #define st4 orc__st4
 #define CHIPS_MAGIC 0x41544B5Au
 #define CHIPS_VERSION 4u
+#define CHIPS_VERSION_LOGUP 5u
 #define MAX_CHIPS 16
 
 static bb4_t sample_ext(orc_challenger_t* ch) { bb4_t r; orc_chal_sample_ext(ch, r.c); return r; }
 
-static int chips_ok(const int* log_ns, const size_t* widths, int n, const orc_params_t* prm) {
+static int any_pairs(const int* pairs, int n) { if (pairs) for (int c = 0; c < n; c++) if (pairs[c]) return 1; return 0; }
+static int chips_ok(const int* log_ns, const size_t* widths, const int* pairs, int n, const orc_params_t* prm) {
     if (n < 1 || n > MAX_CHIPS) return 0;
     if (prm->log_blowup < 1 || prm->log_blowup > 3) return 0;
     if ((prm->log_fold != 0 && prm->log_fold != 1) || prm->log_final != 0 || (prm->hash_width != 0 && prm->hash_width != 16)) return 0;
@@ -38,6 +43,7 @@ static int chips_ok(const int* log_ns, const size_t* widths, int n, const orc_pa
     for (int c = 0; c < n; c++) {
         if (log_ns[c] < 5 || log_ns[c] > 20 || widths[c] == 0 || widths[c] % 4 != 0 || widths[c] > 1024) return 0;
         if (c && log_ns[c] > log_ns[c - 1]) return 0;             /* tallest first */
+        if (pairs && (pairs[c] < 0 || pairs[c] > 64 || (size_t)pairs[c] * 8 > widths[c])) return 0;
     }
     for (int c = 0; c < n; c++) {                                  /* at most 4 chips share a height (one leaf hash) */
         int same = 0;
@@ -47,55 +53,67 @@ static int chips_ok(const int* log_ns, const size_t* widths, int n, const orc_pa
     return 1;
 }
 
-size_t orc_chips_proof_size(const int* log_ns, const size_t* widths, int n, const orc_params_t* prm, size_t n_public) {
+size_t orc_chips_proof_size(const int* log_ns, const size_t* widths, const int* pairs, int n, const orc_params_t* prm, size_t n_public) {
     (void)n_public;
-    if (!chips_ok(log_ns, widths, n, prm)) return 0;
+    if (!chips_ok(log_ns, widths, pairs, n, prm)) return 0;
+    const int lk = any_pairs(pairs, n);
     size_t b = (size_t)prm->log_blowup, Hmax = (size_t)log_ns[0] + b, L = (size_t)log_ns[0];
-    size_t words = 8 + 2 * (size_t)n + 16 + 8 * L + 4 + 1;
-    size_t perq = 16 * Hmax;
-    for (int c = 0; c < n; c++) { words += 8 * widths[c] + 32; perq += widths[c] + 8; }
+    size_t words = 8 + (lk ? 3 : 2) * (size_t)n + 16 + (lk ? 8 : 0) + 8 * L + 4 + 1;
+    size_t perq = 16 * Hmax, hp = 0;
+    for (int c = 0; c < n; c++) {
+        size_t wp = (pairs && pairs[c]) ? 4 * ((size_t)pairs[c] + 1) : 0;
+        words += 8 * widths[c] + 8 * wp + 32;
+        perq += widths[c] + wp + 8;
+        if (wp && (size_t)log_ns[c] + b > hp) hp = (size_t)log_ns[c] + b;
+    }
+    perq += 8 * hp;                                    /* path of the permutation tree */
     for (size_t l = 0; l < L; l++) perq += 4 + 8 * (Hmax - 1 - l);
     return (words + (size_t)prm->num_queries * perq) * 4;
 }
 
-static void transcript_init(orc_challenger_t* ch, const int* log_ns, const size_t* widths, int n, const orc_params_t* prm, size_t n_public) {
+static void transcript_init(orc_challenger_t* ch, const int* log_ns, const size_t* widths, const int* pairs, int n, const orc_params_t* prm, size_t n_public) {
+    const int lk = any_pairs(pairs, n);
     orc_chal_init(ch);
-    orc_chal_observe(ch, CHIPS_VERSION);
+    orc_chal_observe(ch, lk ? CHIPS_VERSION_LOGUP : CHIPS_VERSION);
     orc_chal_observe(ch, (uint32_t)n);
     orc_chal_observe(ch, (uint32_t)prm->log_blowup);
     orc_chal_observe(ch, (uint32_t)prm->num_queries);
     orc_chal_observe(ch, (uint32_t)prm->pow_bits);
     orc_chal_observe(ch, (uint32_t)n_public);
-    for (int c = 0; c < n; c++) { orc_chal_observe(ch, (uint32_t)log_ns[c]); orc_chal_observe(ch, (uint32_t)widths[c]); }
+    for (int c = 0; c < n; c++) {
+        orc_chal_observe(ch, (uint32_t)log_ns[c]); orc_chal_observe(ch, (uint32_t)widths[c]);
+        if (lk) orc_chal_observe(ch, (uint32_t)pairs[c]);
+    }
 }
 
 /* alpha-power offset of chip c inside the reduced-opening vector of its height: the chips of one height share one power
  * sequence, each contributing [trace@zeta (W), trace@zeta*g (W), quotient chunks@zeta (8)] */
-static size_t height_offset(const int* log_ns, const size_t* widths, int c) {
+static size_t perm_width(const int* pairs, int c) { return (pairs && pairs[c]) ? 4 * ((size_t)pairs[c] + 1) : 0; }
+static size_t height_offset(const int* log_ns, const size_t* widths, const int* pairs, int c) {
     size_t off = 0;
-    for (int d = 0; d < c; d++) if (log_ns[d] == log_ns[c]) off += 2 * widths[d] + 8;
+    for (int d = 0; d < c; d++) if (log_ns[d] == log_ns[c]) off += 2 * widths[d] + 2 * perm_width(pairs, d) + 8;
     return off;
 }
 
-size_t orc_prove_chips(const uint32_t* const* traces, const int* log_ns, const size_t* widths, int n,
+size_t orc_prove_chips(const uint32_t* const* traces, const int* log_ns, const size_t* widths, const int* pairs, int n,
                        const uint32_t* public_values, size_t n_public, const orc_params_t* prm,
                        uint8_t* proof_bytes, size_t cap) {
-    size_t need = orc_chips_proof_size(log_ns, widths, n, prm, n_public);
+    size_t need = orc_chips_proof_size(log_ns, widths, pairs, n, prm, n_public);
     if (need == 0 || cap < need) return 0;
     uint32_t* pf = (uint32_t*)proof_bytes;
     size_t pos = 0;
-    const int b = prm->log_blowup, Hmax = log_ns[0] + b, L = log_ns[0];
-    pf[pos++] = CHIPS_MAGIC; pf[pos++] = CHIPS_VERSION; pf[pos++] = (uint32_t)n; pf[pos++] = (uint32_t)b;
+    const int b = prm->log_blowup, Hmax = log_ns[0] + b, L = log_ns[0], lk = any_pairs(pairs, n);
+    pf[pos++] = CHIPS_MAGIC; pf[pos++] = lk ? CHIPS_VERSION_LOGUP : CHIPS_VERSION; pf[pos++] = (uint32_t)n; pf[pos++] = (uint32_t)b;
     pf[pos++] = (uint32_t)prm->num_queries; pf[pos++] = (uint32_t)prm->pow_bits; pf[pos++] = (uint32_t)n_public; pf[pos++] = 16u;
-    for (int c = 0; c < n; c++) { pf[pos++] = (uint32_t)log_ns[c]; pf[pos++] = (uint32_t)widths[c]; }
+    for (int c = 0; c < n; c++) { pf[pos++] = (uint32_t)log_ns[c]; pf[pos++] = (uint32_t)widths[c]; if (lk) pf[pos++] = (uint32_t)pairs[c]; }
     orc_challenger_t ch;
-    transcript_init(&ch, log_ns, widths, n, prm, n_public);
+    transcript_init(&ch, log_ns, widths, pairs, n, prm, n_public);
 
     /* 1. trace LDEs, one mixed-height tree */
-    uint32_t* tlde[MAX_CHIPS]; uint32_t* qlde[MAX_CHIPS];
-    int lh[MAX_CHIPS]; size_t w8[MAX_CHIPS];
+    uint32_t* tlde[MAX_CHIPS]; uint32_t* qlde[MAX_CHIPS]; uint32_t* plde[MAX_CHIPS];
+    int lh[MAX_CHIPS]; size_t w8[MAX_CHIPS], wp[MAX_CHIPS];
     for (int c = 0; c < n; c++) {
-        lh[c] = log_ns[c] + b; w8[c] = 8;
+        lh[c] = log_ns[c] + b; w8[c] = 8; wp[c] = perm_width(pairs, c); plde[c] = NULL;
         tlde[c] = (uint32_t*)malloc(((size_t)1 << lh[c]) * widths[c] * 4);
         orc_coset_lde(traces[c], tlde[c], log_ns[c], widths[c], b, BB_GEN);
     }
@@ -107,13 +125,39 @@ size_t orc_prove_chips(const uint32_t* const* traces, const int* log_ns, const s
     orc_chal_observe_slice(&ch, troot, 8);
     orc_chal_observe_slice(&ch, public_values, n_public);
 
-    /* 2. quotients, per chip on its own 2N_c coset (= the first 2N_c rows of its LDE), chunk LDEs, second tree */
+    /* 1b. lookups: one (gamma, beta) for the shard; the permutation traces of the chips that have pairs form a third tree */
+    bb4_t gamma = bb4_zero(), beta_l = bb4_zero();
+    uint32_t* ptree = NULL;
+    const uint32_t* pm[MAX_CHIPS]; size_t pw[MAX_CHIPS]; int plh[MAX_CHIPS]; int np = 0, Hp = 0;
+    if (lk) {
+        gamma = sample_ext(&ch);
+        beta_l = sample_ext(&ch);
+        for (int c = 0; c < n; c++) {
+            if (!wp[c]) continue;
+            const size_t nc = (size_t)1 << log_ns[c], mc = (size_t)1 << lh[c];
+            uint32_t* perm = (uint32_t*)malloc(nc * wp[c] * 4);
+            orc_perm_trace(traces[c], log_ns[c], widths[c], pairs[c], gamma.c, beta_l.c, perm);
+            plde[c] = (uint32_t*)malloc(mc * wp[c] * 4);
+            orc_coset_lde(perm, plde[c], log_ns[c], wp[c], b, BB_GEN);
+            free(perm);
+            pm[np] = plde[c]; pw[np] = wp[c]; plh[np] = lh[c]; np++;
+            if (lh[c] > Hp) Hp = lh[c];
+        }
+        const size_t mp = (size_t)1 << Hp;
+        ptree = (uint32_t*)malloc((2 * mp - 1) * 32);
+        orc_merkle_tree_mixed(pm, pw, plh, np, ptree);
+        const uint32_t* proot = ptree + (2 * mp - 2) * 8;
+        memcpy(pf + pos, proot, 32); pos += 8;
+        orc_chal_observe_slice(&ch, proot, 8);
+    }
+
+    /* 2. quotients, per chip on its own 2N_c coset (= the first 2N_c rows of its LDE), chunk LDEs, quotient tree */
     bb4_t alpha = sample_ext(&ch);
     for (int c = 0; c < n; c++) {
         const int ln = log_ns[c], Hq = ln + 1;
         const size_t nc = (size_t)1 << ln, mc = (size_t)1 << lh[c], mq = (size_t)1 << Hq;
         uint32_t* qv = (uint32_t*)malloc(mq * 16);
-        orc_quotient_values(tlde[c], ln, widths[c], alpha.c, qv);
+        orc_quotient_values_logup(tlde[c], ln, widths[c], plde[c], wp[c] ? pairs[c] : 0, gamma.c, beta_l.c, alpha.c, qv);
         qlde[c] = (uint32_t*)malloc(mc * 8 * 4);
         uint32_t* chunk = (uint32_t*)malloc(nc * 16);
         uint32_t* clde = (uint32_t*)malloc(mc * 16);
@@ -131,36 +175,51 @@ size_t orc_prove_chips(const uint32_t* const* traces, const int* log_ns, const s
     memcpy(pf + pos, qroot, 32); pos += 8;
     orc_chal_observe_slice(&ch, qroot, 8);
 
-    /* 3. openings: one zeta for every chip, "next" point zeta * g_c */
+    /* 3. openings: one zeta for every chip, "next" point zeta * g_c; per chip: trace local | next | [perm local | next] | quotient */
     bb4_t zeta = sample_ext(&ch);
-    uint32_t* op[MAX_CHIPS];                       /* per chip: local (4W) | next (4W) | quotient (32) */
+    uint32_t* op[MAX_CHIPS];
+    size_t oplen[MAX_CHIPS];
     for (int c = 0; c < n; c++) {
-        op[c] = pf + pos; pos += 8 * widths[c] + 32;
+        const size_t W = widths[c];
+        oplen[c] = 8 * W + 8 * wp[c] + 32;
+        op[c] = pf + pos; pos += oplen[c];
         bb4_t zn = bb4_mul_base(zeta, bb_two_adic_generator(log_ns[c]));
-        orc_open_at(tlde[c], log_ns[c], widths[c], zeta.c, op[c]);
-        orc_open_at(tlde[c], log_ns[c], widths[c], zn.c, op[c] + 4 * widths[c]);
-        orc_open_at(qlde[c], log_ns[c], 8, zeta.c, op[c] + 8 * widths[c]);
+        orc_open_at(tlde[c], log_ns[c], W, zeta.c, op[c]);
+        orc_open_at(tlde[c], log_ns[c], W, zn.c, op[c] + 4 * W);
+        if (wp[c]) {
+            orc_open_at(plde[c], log_ns[c], wp[c], zeta.c, op[c] + 8 * W);
+            orc_open_at(plde[c], log_ns[c], wp[c], zn.c, op[c] + 8 * W + 4 * wp[c]);
+        }
+        orc_open_at(qlde[c], log_ns[c], 8, zeta.c, op[c] + 8 * W + 8 * wp[c]);
     }
-    for (int c = 0; c < n; c++) orc_chal_observe_slice(&ch, op[c], 8 * widths[c] + 32);
+    for (int c = 0; c < n; c++) orc_chal_observe_slice(&ch, op[c], oplen[c]);
 
-    /* 4. one reduced-opening vector per height */
+    /* 4. one reduced-opening vector per height; per chip the batching order is
+     * trace@zeta 0, trace@zeta*g W, [perm@zeta 2W, perm@zeta*g 2W+Wp], quotient@zeta 2W+2Wp */
     bb4_t fa = sample_ext(&ch);
     bb4_t* ro[32];
     for (int h = 0; h < 32; h++) ro[h] = NULL;
     for (int c = 0; c < n; c++) {
-        const size_t W = widths[c], mc = (size_t)1 << lh[c];
-        size_t np = W > 8 ? W : 8;
-        bb4_t* fapow = (bb4_t*)malloc(np * sizeof(bb4_t));
+        const size_t W = widths[c], Wp = wp[c], mc = (size_t)1 << lh[c];
+        size_t npw = W > 8 ? W : 8;
+        if (Wp > npw) npw = Wp;
+        bb4_t* fapow = (bb4_t*)malloc(npw * sizeof(bb4_t));
         fapow[0] = bb4_one();
-        for (size_t j = 1; j < np; j++) fapow[j] = bb4_mul(fapow[j - 1], fa);
-        bb4_t y_loc = bb4_zero(), y_nxt = bb4_zero(), y_q = bb4_zero();
+        for (size_t j = 1; j < npw; j++) fapow[j] = bb4_mul(fapow[j - 1], fa);
+        const uint32_t *o_loc = op[c], *o_nxt = op[c] + 4 * W, *o_pl = op[c] + 8 * W, *o_pn = op[c] + 8 * W + 4 * Wp, *o_q = op[c] + 8 * W + 8 * Wp;
+        bb4_t y_loc = bb4_zero(), y_nxt = bb4_zero(), y_pl = bb4_zero(), y_pn = bb4_zero(), y_q = bb4_zero();
         for (size_t j = 0; j < W; j++) {
-            y_loc = bb4_add(y_loc, bb4_mul(fapow[j], ld4(op[c] + 4 * j)));
-            y_nxt = bb4_add(y_nxt, bb4_mul(fapow[j], ld4(op[c] + 4 * W + 4 * j)));
+            y_loc = bb4_add(y_loc, bb4_mul(fapow[j], ld4(o_loc + 4 * j)));
+            y_nxt = bb4_add(y_nxt, bb4_mul(fapow[j], ld4(o_nxt + 4 * j)));
         }
-        for (size_t j = 0; j < 8; j++) y_q = bb4_add(y_q, bb4_mul(fapow[j], ld4(op[c] + 8 * W + 4 * j)));
-        const size_t off = height_offset(log_ns, widths, c);
-        bb4_t s_loc = bb4_pow(fa, off), s_nxt = bb4_pow(fa, off + W), s_q = bb4_pow(fa, off + 2 * W);
+        for (size_t j = 0; j < Wp; j++) {
+            y_pl = bb4_add(y_pl, bb4_mul(fapow[j], ld4(o_pl + 4 * j)));
+            y_pn = bb4_add(y_pn, bb4_mul(fapow[j], ld4(o_pn + 4 * j)));
+        }
+        for (size_t j = 0; j < 8; j++) y_q = bb4_add(y_q, bb4_mul(fapow[j], ld4(o_q + 4 * j)));
+        const size_t off = height_offset(log_ns, widths, pairs, c);
+        bb4_t s_loc = bb4_pow(fa, off), s_nxt = bb4_pow(fa, off + W), s_pl = bb4_pow(fa, off + 2 * W), s_pn = bb4_pow(fa, off + 2 * W + Wp),
+              s_q = bb4_pow(fa, off + 2 * W + 2 * Wp);
         bb4_t zn = bb4_mul_base(zeta, bb_two_adic_generator(log_ns[c]));
         if (!ro[lh[c]]) ro[lh[c]] = (bb4_t*)calloc(mc, sizeof(bb4_t));
         bb4_t* dst = ro[lh[c]];
@@ -173,6 +232,11 @@ size_t orc_prove_chips(const uint32_t* const* traces, const int* log_ns, const s
             bb4_t at = orc__row_dot(fapow, tlde[c] + p * W, W), aq = orc__row_dot(fapow, qlde[c] + p * 8, 8);
             bb4_t r = bb4_mul(s_loc, bb4_mul(bb4_sub(at, y_loc), d1));
             r = bb4_add(r, bb4_mul(s_nxt, bb4_mul(bb4_sub(at, y_nxt), d2)));
+            if (Wp) {
+                bb4_t ap = orc__row_dot(fapow, plde[c] + p * Wp, Wp);
+                r = bb4_add(r, bb4_mul(s_pl, bb4_mul(bb4_sub(ap, y_pl), d1)));
+                r = bb4_add(r, bb4_mul(s_pn, bb4_mul(bb4_sub(ap, y_pn), d2)));
+            }
             r = bb4_add(r, bb4_mul(s_q, bb4_mul(bb4_sub(aq, y_q), d1)));
             dst[p] = bb4_add(dst[p], r);
         }
@@ -216,6 +280,10 @@ size_t orc_prove_chips(const uint32_t* const* traces, const int* log_ns, const s
         size_t index = orc_chal_sample_bits(&ch, Hmax);
         for (int c = 0; c < n; c++) { memcpy(pf + pos, tlde[c] + (index >> (Hmax - lh[c])) * widths[c], widths[c] * 4); pos += widths[c]; }
         orc__copy_path(pf, &pos, ttree, mmax, index, Hmax);
+        if (lk) {
+            for (int c = 0; c < n; c++) if (wp[c]) { memcpy(pf + pos, plde[c] + (index >> (Hmax - lh[c])) * wp[c], wp[c] * 4); pos += wp[c]; }
+            orc__copy_path(pf, &pos, ptree, (size_t)1 << Hp, index >> (Hmax - Hp), Hp);
+        }
         for (int c = 0; c < n; c++) { memcpy(pf + pos, qlde[c] + (index >> (Hmax - lh[c])) * 8, 32); pos += 8; }
         orc__copy_path(pf, &pos, qtree, mmax, index, Hmax);
         size_t idx = index;
@@ -227,14 +295,14 @@ size_t orc_prove_chips(const uint32_t* const* traces, const int* log_ns, const s
         }
     }
     for (int l = 0; l < L; l++) { free(layers[l]); free(ltrees[l]); }
-    free(layers); free(ltrees); free(ttree); free(qtree);
-    for (int c = 0; c < n; c++) { free(tlde[c]); free(qlde[c]); }
+    free(layers); free(ltrees); free(ttree); free(qtree); free(ptree);
+    for (int c = 0; c < n; c++) { free(tlde[c]); free(qlde[c]); free(plde[c]); }
     for (int h = 0; h < 32; h++) free(ro[h]);
     if (!const_ok) return 0;
     return pos * 4 == need ? need : 0;
 }
 
-/* opening of a mixed-height tree: rows[c] is chip c's row at index >> (Hmax - lh[c]) */
+/* opening of a mixed-height tree: rows[c] is matrix c's row at index >> (Hmax - lh[c]); Hmax = the tree's own height */
 static int verify_mixed(const uint32_t root[8], int Hmax, size_t index, const uint32_t* const* rows, const size_t* widths,
                         const int* lh, int n, const uint32_t* sibs) {
     uint32_t buf[4 * 1024 + 8], cur[8];
@@ -257,36 +325,50 @@ static int verify_mixed(const uint32_t root[8], int Hmax, size_t index, const ui
     return memcmp(cur, root, 32) == 0 ? 0 : 1;
 }
 
-int orc_verify_chips(const uint8_t* proof_bytes, size_t len, const int* log_ns, const size_t* widths, int n,
+int orc_verify_chips(const uint8_t* proof_bytes, size_t len, const int* log_ns, const size_t* widths, const int* pairs, int n,
                      const uint32_t* public_values, size_t n_public, const orc_params_t* prm) {
-    if (!chips_ok(log_ns, widths, n, prm)) return 1;
-    if (len != orc_chips_proof_size(log_ns, widths, n, prm, n_public)) return 2;
+    if (!chips_ok(log_ns, widths, pairs, n, prm)) return 1;
+    if (len != orc_chips_proof_size(log_ns, widths, pairs, n, prm, n_public)) return 2;
     const uint32_t* pf = (const uint32_t*)proof_bytes;
-    const int b = prm->log_blowup, Hmax = log_ns[0] + b, L = log_ns[0];
-    if (pf[0] != CHIPS_MAGIC || pf[1] != CHIPS_VERSION || pf[2] != (uint32_t)n || pf[3] != (uint32_t)b ||
+    const int b = prm->log_blowup, Hmax = log_ns[0] + b, L = log_ns[0], lk = any_pairs(pairs, n);
+    if (pf[0] != CHIPS_MAGIC || pf[1] != (lk ? CHIPS_VERSION_LOGUP : CHIPS_VERSION) || pf[2] != (uint32_t)n || pf[3] != (uint32_t)b ||
         pf[4] != (uint32_t)prm->num_queries || pf[5] != (uint32_t)prm->pow_bits || pf[6] != (uint32_t)n_public || pf[7] != 16u) return 3;
     size_t pos = 8;
-    for (int c = 0; c < n; c++) { if (pf[pos] != (uint32_t)log_ns[c] || pf[pos + 1] != (uint32_t)widths[c]) return 3; pos += 2; }
+    for (int c = 0; c < n; c++) {
+        if (pf[pos] != (uint32_t)log_ns[c] || pf[pos + 1] != (uint32_t)widths[c]) return 3;
+        pos += 2;
+        if (lk) { if (pf[pos] != (uint32_t)pairs[c]) return 3; pos++; }
+    }
     for (size_t i = pos; i < len / 4; i++) if (pf[i] >= BB_P) return 4;
-    int lh[MAX_CHIPS]; size_t w8[MAX_CHIPS];
-    for (int c = 0; c < n; c++) { lh[c] = log_ns[c] + b; w8[c] = 8; }
+    int lh[MAX_CHIPS]; size_t w8[MAX_CHIPS], wp[MAX_CHIPS];
+    for (int c = 0; c < n; c++) { lh[c] = log_ns[c] + b; w8[c] = 8; wp[c] = perm_width(pairs, c); }
 
     orc_challenger_t ch;
-    transcript_init(&ch, log_ns, widths, n, prm, n_public);
+    transcript_init(&ch, log_ns, widths, pairs, n, prm, n_public);
     const uint32_t* troot = pf + pos; pos += 8;
     orc_chal_observe_slice(&ch, troot, 8);
     orc_chal_observe_slice(&ch, public_values, n_public);
+    bb4_t gamma = bb4_zero(), beta_l = bb4_zero();
+    const uint32_t* proot = NULL;
+    size_t pw[MAX_CHIPS]; int plh[MAX_CHIPS], pchip[MAX_CHIPS]; int np = 0, Hp = 0;
+    if (lk) {
+        gamma = sample_ext(&ch);
+        beta_l = sample_ext(&ch);
+        proot = pf + pos; pos += 8;
+        orc_chal_observe_slice(&ch, proot, 8);
+        for (int c = 0; c < n; c++) if (wp[c]) { pw[np] = wp[c]; plh[np] = lh[c]; pchip[np] = c; np++; if (lh[c] > Hp) Hp = lh[c]; }
+    }
     bb4_t alpha = sample_ext(&ch);
     const uint32_t* qroot = pf + pos; pos += 8;
     orc_chal_observe_slice(&ch, qroot, 8);
     bb4_t zeta = sample_ext(&ch);
-    const uint32_t* op[MAX_CHIPS];
-    for (int c = 0; c < n; c++) { op[c] = pf + pos; pos += 8 * widths[c] + 32; }
-    for (int c = 0; c < n; c++) orc_chal_observe_slice(&ch, op[c], 8 * widths[c] + 32);
+    const uint32_t* op[MAX_CHIPS]; size_t oplen[MAX_CHIPS];
+    for (int c = 0; c < n; c++) { oplen[c] = 8 * widths[c] + 8 * wp[c] + 32; op[c] = pf + pos; pos += oplen[c]; }
+    for (int c = 0; c < n; c++) orc_chal_observe_slice(&ch, op[c], oplen[c]);
 
     /* (a) every chip's AIR identity at zeta */
     for (int c = 0; c < n; c++) {
-        const size_t W = widths[c], nc = (size_t)1 << log_ns[c];
+        const size_t W = widths[c], Wp = wp[c], nc = (size_t)1 << log_ns[c];
         bb4_t* loc = (bb4_t*)malloc(W * sizeof(bb4_t));
         bb4_t* nxt = (bb4_t*)malloc(W * sizeof(bb4_t));
         for (size_t j = 0; j < W; j++) { loc[j] = ld4(op[c] + 4 * j); nxt[j] = ld4(op[c] + 4 * W + 4 * j); }
@@ -295,16 +377,26 @@ int orc_verify_chips(const uint8_t* proof_bytes, size_t len, const int* log_ns, 
         bb4_t sel_first = bb4_mul(zh, bb4_inv(bb4_sub_base(zeta, 1)));
         bb4_t sel_trans = bb4_sub_base(zeta, bb_inv(gn));
         bb4_t folded = orc__fold_constraints_ext(loc, nxt, W, sel_first, sel_trans, alpha);
+        if (Wp) {
+            const int Q = pairs[c];
+            bb4_t sel_last = bb4_mul(zh, bb4_inv(bb4_sub_base(zeta, bb_inv(gn))));
+            bb4_t as[64], bs[64], ar[64], br[64], pl[65], pn[65];
+            const uint32_t *o_pl = op[c] + 8 * W, *o_pn = o_pl + 4 * Wp;
+            for (int q = 0; q < Q; q++) { as[q] = loc[8 * q]; bs[q] = loc[8 * q + 1]; ar[q] = loc[8 * q + 4]; br[q] = loc[8 * q + 5]; }
+            for (int q = 0; q <= Q; q++) { pl[q] = orc__recombine(o_pl + 16 * q); pn[q] = orc__recombine(o_pn + 16 * q); }
+            folded = orc__fold_logup(folded, Q, as, bs, ar, br, pl, pn, gamma, beta_l, sel_first, sel_trans, sel_last, alpha);
+        }
         free(loc); free(nxt);
         bb_t w2n = bb_two_adic_generator(log_ns[c] + 1);
         bb_t s[2] = {BB_GEN, bb_mul(BB_GEN, w2n)};
         bb4_t quot = bb4_zero();
+        const uint32_t* o_q = op[c] + 8 * W + 8 * Wp;
         for (int k = 0; k < 2; k++) {
             int j = 1 - k;
             bb_t sjn_inv = bb_inv(bb_pow(s[j], nc));
             bb4_t num = bb4_sub_base(bb4_mul_base(zn, sjn_inv), 1);
             bb_t den = bb_sub(bb_mul(bb_pow(s[k], nc), sjn_inv), 1);
-            quot = bb4_add(quot, bb4_mul(bb4_mul_base(num, bb_inv(den)), orc__recombine(op[c] + 8 * W + 16 * k)));
+            quot = bb4_add(quot, bb4_mul(bb4_mul_base(num, bb_inv(den)), orc__recombine(o_q + 16 * k)));
         }
         if (!bb4_eq(bb4_mul(folded, bb4_inv(zh)), quot)) return 10;
     }
@@ -312,21 +404,28 @@ int orc_verify_chips(const uint8_t* proof_bytes, size_t len, const int* log_ns, 
     /* (b) FRI */
     bb4_t fa = sample_ext(&ch);
     size_t npmax = 8;
-    for (int c = 0; c < n; c++) if (widths[c] > npmax) npmax = widths[c];
+    for (int c = 0; c < n; c++) { if (widths[c] > npmax) npmax = widths[c]; if (wp[c] > npmax) npmax = wp[c]; }
     bb4_t* fapow = (bb4_t*)malloc(npmax * sizeof(bb4_t));
     fapow[0] = bb4_one();
     for (size_t j = 1; j < npmax; j++) fapow[j] = bb4_mul(fapow[j - 1], fa);
-    bb4_t y_loc[MAX_CHIPS], y_nxt[MAX_CHIPS], y_q[MAX_CHIPS], s_loc[MAX_CHIPS], s_nxt[MAX_CHIPS], s_q[MAX_CHIPS], zn_c[MAX_CHIPS];
+    bb4_t y_loc[MAX_CHIPS], y_nxt[MAX_CHIPS], y_pl[MAX_CHIPS], y_pn[MAX_CHIPS], y_q[MAX_CHIPS];
+    bb4_t s_loc[MAX_CHIPS], s_nxt[MAX_CHIPS], s_pl[MAX_CHIPS], s_pn[MAX_CHIPS], s_q[MAX_CHIPS], zn_c[MAX_CHIPS];
     for (int c = 0; c < n; c++) {
-        const size_t W = widths[c];
-        y_loc[c] = y_nxt[c] = y_q[c] = bb4_zero();
+        const size_t W = widths[c], Wp = wp[c];
+        const uint32_t *o_pl = op[c] + 8 * W, *o_pn = o_pl + 4 * Wp, *o_q = op[c] + 8 * W + 8 * Wp;
+        y_loc[c] = y_nxt[c] = y_pl[c] = y_pn[c] = y_q[c] = bb4_zero();
         for (size_t j = 0; j < W; j++) {
             y_loc[c] = bb4_add(y_loc[c], bb4_mul(fapow[j], ld4(op[c] + 4 * j)));
             y_nxt[c] = bb4_add(y_nxt[c], bb4_mul(fapow[j], ld4(op[c] + 4 * W + 4 * j)));
         }
-        for (size_t j = 0; j < 8; j++) y_q[c] = bb4_add(y_q[c], bb4_mul(fapow[j], ld4(op[c] + 8 * W + 4 * j)));
-        const size_t off = height_offset(log_ns, widths, c);
-        s_loc[c] = bb4_pow(fa, off); s_nxt[c] = bb4_pow(fa, off + W); s_q[c] = bb4_pow(fa, off + 2 * W);
+        for (size_t j = 0; j < Wp; j++) {
+            y_pl[c] = bb4_add(y_pl[c], bb4_mul(fapow[j], ld4(o_pl + 4 * j)));
+            y_pn[c] = bb4_add(y_pn[c], bb4_mul(fapow[j], ld4(o_pn + 4 * j)));
+        }
+        for (size_t j = 0; j < 8; j++) y_q[c] = bb4_add(y_q[c], bb4_mul(fapow[j], ld4(o_q + 4 * j)));
+        const size_t off = height_offset(log_ns, widths, pairs, c);
+        s_loc[c] = bb4_pow(fa, off); s_nxt[c] = bb4_pow(fa, off + W); s_pl[c] = bb4_pow(fa, off + 2 * W);
+        s_pn[c] = bb4_pow(fa, off + 2 * W + Wp); s_q[c] = bb4_pow(fa, off + 2 * W + 2 * Wp);
         zn_c[c] = bb4_mul_base(zeta, bb_two_adic_generator(log_ns[c]));
     }
     const uint32_t* commits = pf + pos; pos += 8 * (size_t)L;
@@ -339,12 +438,18 @@ int orc_verify_chips(const uint8_t* proof_bytes, size_t len, const int* log_ns, 
     if (!orc_chal_check_witness(&ch, prm->pow_bits, witness)) rc = 20;
     for (int q = 0; q < prm->num_queries && rc == 0; q++) {
         size_t index = orc_chal_sample_bits(&ch, Hmax);
-        const uint32_t* trow[MAX_CHIPS]; const uint32_t* qrow[MAX_CHIPS];
-        for (int c = 0; c < n; c++) { trow[c] = pf + pos; pos += widths[c]; }
+        const uint32_t* trow[MAX_CHIPS]; const uint32_t* qrow[MAX_CHIPS]; const uint32_t* prow[MAX_CHIPS]; const uint32_t* prow_all[MAX_CHIPS];
+        for (int c = 0; c < n; c++) { trow[c] = pf + pos; pos += widths[c]; prow_all[c] = NULL; }
         const uint32_t* tpath = pf + pos; pos += 8 * (size_t)Hmax;
+        const uint32_t* ppath = NULL;
+        if (lk) {
+            for (int k = 0; k < np; k++) { prow[k] = pf + pos; prow_all[pchip[k]] = prow[k]; pos += pw[k]; }
+            ppath = pf + pos; pos += 8 * (size_t)Hp;
+        }
         for (int c = 0; c < n; c++) { qrow[c] = pf + pos; pos += 8; }
         const uint32_t* qpath = pf + pos; pos += 8 * (size_t)Hmax;
         if (verify_mixed(troot, Hmax, index, trow, widths, lh, n, tpath)) { rc = 30; break; }
+        if (lk && verify_mixed(proot, Hp, index >> (Hmax - Hp), prow, pw, plh, np, ppath)) { rc = 32; break; }
         if (verify_mixed(qroot, Hmax, index, qrow, w8, lh, n, qpath)) { rc = 31; break; }
         /* reduced opening of every height at this query's point */
         bb4_t roh[32];
@@ -357,6 +462,11 @@ int orc_verify_chips(const uint8_t* proof_bytes, size_t len, const int* log_ns, 
             bb4_t at = orc__row_dot(fapow, trow[c], widths[c]), aq = orc__row_dot(fapow, qrow[c], 8);
             bb4_t r = bb4_mul(s_loc[c], bb4_mul(bb4_sub(at, y_loc[c]), d1));
             r = bb4_add(r, bb4_mul(s_nxt[c], bb4_mul(bb4_sub(at, y_nxt[c]), d2)));
+            if (wp[c]) {
+                bb4_t ap = orc__row_dot(fapow, prow_all[c], wp[c]);
+                r = bb4_add(r, bb4_mul(s_pl[c], bb4_mul(bb4_sub(ap, y_pl[c]), d1)));
+                r = bb4_add(r, bb4_mul(s_pn[c], bb4_mul(bb4_sub(ap, y_pn[c]), d2)));
+            }
             r = bb4_add(r, bb4_mul(s_q[c], bb4_mul(bb4_sub(aq, y_q[c]), d1)));
             roh[lh[c]] = bb4_add(roh[lh[c]], r);
         }

@@ -152,11 +152,12 @@ int orc_verify_shard(const uint8_t* proof, size_t len, int log_n, size_t width,
                      const orc_params_t* prm);
 
 /* ---- a shard of several chips with different heights (oracle/chips.c): tallest first, heights log_ns[c] in [5, 20],
- * at most 4 chips per height, SP1 FRI shape (log_fold 1, log_final 0, hash width 16) at any log_blowup, no lookups ---- */
-size_t orc_chips_proof_size(const int* log_ns, const size_t* widths, int n_chips, const orc_params_t* prm, size_t n_public);
-size_t orc_prove_chips(const uint32_t* const* traces, const int* log_ns, const size_t* widths, int n_chips,
+ * at most 4 chips per height, SP1 FRI shape (log_fold 1, log_final 0, hash width 16) at any log_blowup ---- */
+/* pairs (may be NULL): in-table LogUp pairs per chip (orc_gen_trace_logup); the permutation traces form a third tree */
+size_t orc_chips_proof_size(const int* log_ns, const size_t* widths, const int* pairs, int n_chips, const orc_params_t* prm, size_t n_public);
+size_t orc_prove_chips(const uint32_t* const* traces, const int* log_ns, const size_t* widths, const int* pairs, int n_chips,
                        const uint32_t* public_values, size_t n_public, const orc_params_t* prm, uint8_t* proof, size_t cap);
-int orc_verify_chips(const uint8_t* proof, size_t len, const int* log_ns, const size_t* widths, int n_chips,
+int orc_verify_chips(const uint8_t* proof, size_t len, const int* log_ns, const size_t* widths, const int* pairs, int n_chips,
                      const uint32_t* public_values, size_t n_public, const orc_params_t* prm);
 
 /* intermediates of the last orc_prove_shard call in this thread (for parity tests) */

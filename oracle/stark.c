@@ -30,6 +30,7 @@
 #define row_dot orc__row_dot
 #define copy_path orc__copy_path
 #define recombine orc__recombine
+#define fold_logup orc__fold_logup
 
 /* ------------------------------------------------------------------ */
 /* synthetic data                                                      */
@@ -213,7 +214,7 @@ void orc__st4(uint32_t* p, bb4_t v) { memcpy(p, v.c, 16); }
 
 /* LogUp constraints in extension arithmetic, continuing the Horner fold of `acc`.
  * as/bs/ar/br: sender / receiver tuple of pair q; perm_* hold phi_0..phi_{Q-1}, S. */
-static bb4_t fold_logup(bb4_t acc, int pairs, const bb4_t* as, const bb4_t* bs, const bb4_t* ar, const bb4_t* br,
+bb4_t orc__fold_logup(bb4_t acc, int pairs, const bb4_t* as, const bb4_t* bs, const bb4_t* ar, const bb4_t* br,
                         const bb4_t* perm_local, const bb4_t* perm_next, bb4_t gamma, bb4_t beta,
                         bb4_t sel_first, bb4_t sel_trans, bb4_t sel_last, bb4_t alpha) {
     bb4_t sum_l = bb4_zero(), sum_n = bb4_zero();

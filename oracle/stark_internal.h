@@ -10,4 +10,7 @@ bb4_t orc__fri_fold_row(size_t index, int log_folded_h, bb4_t beta, bb4_t e0, bb
 bb4_t orc__row_dot(const bb4_t* pw, const uint32_t* row, size_t w);
 void orc__copy_path(uint32_t* pf, size_t* pos, const uint32_t* tree, size_t leaves, size_t index, int levels);
 bb4_t orc__recombine(const uint32_t* opened4);
+bb4_t orc__fold_logup(bb4_t acc, int pairs, const bb4_t* as, const bb4_t* bs, const bb4_t* ar, const bb4_t* br,
+                     const bb4_t* perm_local, const bb4_t* perm_next, bb4_t gamma, bb4_t beta,
+                     bb4_t sel_first, bb4_t sel_trans, bb4_t sel_last, bb4_t alpha);
 #endif

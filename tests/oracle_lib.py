@@ -325,8 +325,8 @@ def prove_debug():
             for k, _ in ProveDebug._fields_}
 
 
-def prove_chips(traces, public_values=(), params=None):
-    """traces: list of row-major canonical matrices, tallest first"""
+def prove_chips(traces, public_values=(), params=None, pairs=None):
+    """traces: list of row-major canonical matrices, tallest first; pairs: in-table LogUp pairs per chip (or None)"""
     params = params or default_params()
     ts = [_u32(t) for t in traces]
     n = len(ts)
@@ -337,25 +337,27 @@ def prove_chips(traces, public_values=(), params=None):
     L = lib()
     L.orc_chips_proof_size.restype = C.c_size_t
     L.orc_prove_chips.restype = C.c_size_t
-    size = L.orc_chips_proof_size(log_ns, widths, C.c_int(n), C.byref(params), C.c_size_t(pv.size))
+    pr_ = (C.c_int * n)(*[int(x) for x in pairs]) if pairs is not None else None
+    size = L.orc_chips_proof_size(log_ns, widths, pr_, C.c_int(n), C.byref(params), C.c_size_t(pv.size))
     if size == 0:
         raise RuntimeError("oracle: bad chip set")
     buf = np.empty(size, dtype=np.uint8)
-    got = L.orc_prove_chips(ptrs, log_ns, widths, C.c_int(n), _p(pv), C.c_size_t(pv.size), C.byref(params),
+    got = L.orc_prove_chips(ptrs, log_ns, widths, pr_, C.c_int(n), _p(pv), C.c_size_t(pv.size), C.byref(params),
                             buf.ctypes.data_as(C.POINTER(C.c_uint8)), C.c_size_t(size))
     if got != size:
         raise RuntimeError("oracle prove_chips failed")
     return buf
 
 
-def verify_chips(proof, log_ns, widths, public_values=(), params=None):
+def verify_chips(proof, log_ns, widths, public_values=(), params=None, pairs=None):
     params = params or default_params()
     pr = np.ascontiguousarray(proof, dtype=np.uint8)
     n = len(log_ns)
     ln = (C.c_int * n)(*[int(x) for x in log_ns])
     ws = (C.c_size_t * n)(*[int(x) for x in widths])
     pv = _u32(np.array(public_values, dtype=np.uint32))
-    return int(lib().orc_verify_chips(pr.ctypes.data_as(C.POINTER(C.c_uint8)), C.c_size_t(pr.size), ln, ws, C.c_int(n),
+    pr_ = (C.c_int * n)(*[int(x) for x in pairs]) if pairs is not None else None
+    return int(lib().orc_verify_chips(pr.ctypes.data_as(C.POINTER(C.c_uint8)), C.c_size_t(pr.size), ln, ws, pr_, C.c_int(n),
                                       _p(pv), C.c_size_t(pv.size), C.byref(params)))
 
 
