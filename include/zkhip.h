@@ -234,17 +234,21 @@ int zkhip_verify_shard(const uint8_t* proof, size_t len, int log_n, uint32_t wid
  * reference Cargo.lock:6172, behind crates/guest-prover-sp1/src/sp1.rs:116): one Merkle commitment per phase over all
  * chips (shorter matrices injected at their level), one opening point, one reduced-opening vector per height joining the
  * FRI vector when folding reaches it, one FRI proof.  Chips tallest first, log_n in [5, 20], at most 4 per height and 16
- * in all; zkhip_params: any log_blowup, the SP1 FRI shape (log_fold / log_final / hash_width / logup_pairs 0). ---- */
+ * in all; zkhip_params: any log_blowup, the SP1 FRI shape (log_fold / log_final / hash_width / logup_pairs 0).
+ * A chip may carry in-table LogUp pairs (logup_pairs > 0, trace from zkhip_gen_trace_logup): the permutation traces of
+ * those chips are committed together in a third mixed-height tree (sp1-stark's permutation commitment).  `pairs` arrays
+ * below may be NULL (no lookups). ---- */
 typedef struct {
     const uint32_t* d_trace;    /* device, row-major 2^log_n x ld words, Montgomery */
     size_t ld;
     int32_t log_n;
     uint32_t width;
+    int32_t logup_pairs;        /* 0: none */
 } zkhip_chip;
-size_t zkhip_chips_proof_size(const int32_t* log_ns, const uint32_t* widths, int n_chips, const zkhip_params* prm, size_t n_public);
+size_t zkhip_chips_proof_size(const int32_t* log_ns, const uint32_t* widths, const int32_t* pairs, int n_chips, const zkhip_params* prm, size_t n_public);
 int zkhip_prove_chips(zkhip_ctx* ctx, const zkhip_chip* chips, int n_chips, const uint32_t* public_values, size_t n_public,
                       const zkhip_params* prm, uint8_t* proof, size_t cap, size_t* len);
-int zkhip_verify_chips(const uint8_t* proof, size_t len, const int32_t* log_ns, const uint32_t* widths, int n_chips,
+int zkhip_verify_chips(const uint8_t* proof, size_t len, const int32_t* log_ns, const uint32_t* widths, const int32_t* pairs, int n_chips,
                        const uint32_t* public_values, size_t n_public, const zkhip_params* prm, int* reason);
 
 /* intermediates of the last zkhip_prove_shard on this context (canonical words) */

@@ -384,3 +384,34 @@ def test_prove_chips_randomised_sets(ctx, oracle, chips, prm):
     assert verify_chips(proof, [c[0] for c in chips], [c[1] for c in chips], [5], Params(*prm)) == (0, 0)
     for b, _, _ in dev:
         b.free()
+
+
+CHIP_SETS_LOGUP = [
+    ([(8, 8, 1)], (1, 10, 4)),
+    ([(10, 16, 2), (8, 8, 0)], (1, 10, 4)),
+    ([(10, 16, 0), (8, 8, 1)], (1, 10, 4)),                      # the permutation tree is shorter than the trace tree
+    ([(10, 16, 1), (10, 8, 1), (7, 24, 3), (7, 4, 0), (5, 8, 1)], (1, 20, 8)),
+    ([(9, 8, 1), (8, 16, 2), (7, 8, 0)], (2, 10, 0)),
+    ([(14, 64, 8), (12, 256, 32), (12, 8, 0), (9, 40, 5)], (1, 50, 12)),
+]
+
+
+@pytest.mark.parametrize("chips,prm", CHIP_SETS_LOGUP)
+def test_prove_chips_with_lookups_bytes_equal_oracle(ctx, oracle, chips, prm):
+    # chips with in-table LogUp pairs: their permutation traces form a third mixed-height commitment (proof version 5)
+    from zktls_amd.device import verify_chips
+    params, oparams = Params(*prm), oracle.default_params(*prm)
+    dev, host = [], []
+    for i, (ln, w, pr) in enumerate(chips):
+        dev.append((ctx.gen_trace_logup(SEED, i, ln, w, pr) if pr else ctx.gen_trace(SEED, i, ln, w), ln, w, pr))
+        host.append(oracle.gen_trace_logup(SEED, i, ln, w, pr) if pr else oracle.gen_trace(SEED, i, ln, w))
+    pairs = [c[2] for c in chips]
+    proof = ctx.prove_chips(dev, [3, 4], params)
+    oproof = oracle.prove_chips(host, [3, 4], oparams, pairs)
+    assert proof.tobytes() == oproof.tobytes()
+    lns, ws = [c[0] for c in chips], [c[1] for c in chips]
+    assert verify_chips(proof, lns, ws, [3, 4], params, pairs) == (0, 0)
+    assert oracle.verify_chips(proof, lns, ws, [3, 4], oparams, pairs) == 0
+    assert verify_chips(proof, lns, ws, [3, 4], params, None)[0] == -6          # not a proof of the lookup-free statement
+    for d in dev:
+        d[0].free()

@@ -96,3 +96,19 @@ def test_host_verifier_agrees_with_oracle_on_multi_chip_shards(oracle, chips, pr
         bad = pf.copy(); bad[int(pf.size * frac)] ^= 1
         rc, reason = verify_chips(bad, lns, ws, [1, 2], params)
         assert rc == -6 and reason == oracle.verify_chips(bad, lns, ws, [1, 2], oprm)
+
+
+@pytest.mark.parametrize("chips,prm", [([(8, 8, 1)], (1, 10, 4)), ([(10, 16, 0), (8, 8, 1)], (1, 10, 4)),
+                                       ([(10, 16, 1), (10, 8, 1), (7, 24, 3), (7, 4, 0), (5, 8, 1)], (1, 20, 8)), ([(9, 8, 1), (8, 16, 2), (7, 8, 0)], (2, 10, 0))])
+def test_host_verifier_agrees_with_oracle_on_multi_chip_lookups(oracle, chips, prm):
+    from zktls_amd.device import verify_chips
+    oprm, params = oracle.default_params(*prm), Params(*prm)
+    pairs = [c[2] for c in chips]
+    traces = [oracle.gen_trace_logup(SEED, i, ln, w, pr) if pr else oracle.gen_trace(SEED, i, ln, w) for i, (ln, w, pr) in enumerate(chips)]
+    lns, ws = [c[0] for c in chips], [c[1] for c in chips]
+    pf = oracle.prove_chips(traces, [1, 2], oprm, pairs)
+    assert verify_chips(pf, lns, ws, [1, 2], params, pairs) == (0, 0)
+    for frac in (0.02, 0.1, 0.2, 0.3, 0.5, 0.7, 0.95):
+        bad = pf.copy(); bad[int(pf.size * frac)] ^= 1
+        rc, reason = verify_chips(bad, lns, ws, [1, 2], params, pairs)
+        assert rc == -6 and reason == oracle.verify_chips(bad, lns, ws, [1, 2], oprm, pairs)

@@ -515,3 +515,28 @@ def test_golden_chip_proofs(oracle, name):
     traces = [oracle.gen_trace(SEED, i, ln, w) for i, (ln, w) in enumerate(g["chips"])]
     pf = oracle.prove_chips(traces, g["public"], oracle.default_params(*g["params"]))
     assert pf.size == g["bytes"] and hashlib.sha256(pf.tobytes()).hexdigest() == g["sha256"]
+
+
+@pytest.mark.parametrize("chips,prm", [([(8, 8, 1)], (1, 10, 4)), ([(10, 16, 2), (8, 8, 0)], (1, 10, 4)), ([(10, 16, 0), (8, 8, 1)], (1, 10, 4)),
+                                       ([(10, 16, 1), (10, 8, 1), (7, 24, 3), (7, 4, 0), (5, 8, 1)], (1, 20, 8)), ([(9, 8, 1), (8, 16, 2), (7, 8, 0)], (2, 10, 0))])
+def test_multi_chip_shard_with_lookups(oracle, chips, prm):
+    params = oracle.default_params(*prm)
+    pairs = [c[2] for c in chips]
+    traces = [oracle.gen_trace_logup(SEED, i, ln, w, pr) if pr else oracle.gen_trace(SEED, i, ln, w) for i, (ln, w, pr) in enumerate(chips)]
+    lns, ws = [c[0] for c in chips], [c[1] for c in chips]
+    pf = oracle.prove_chips(traces, [1, 2], params, pairs)
+    assert oracle.verify_chips(pf, lns, ws, [1, 2], params, pairs) == 0
+    assert oracle.verify_chips(pf, lns, ws, [1, 2], params, None) != 0
+    step = max(1, pf.size // 53)
+    for off in range(4 * (8 + 3 * len(chips)), pf.size, step):
+        bad = pf.copy(); bad[off] ^= 8
+        assert oracle.verify_chips(bad, lns, ws, [1, 2], params, pairs) != 0, off
+    # a chip that claims lookups but does not hold the permuted columns fails its AIR identity
+    k = [i for i, p in enumerate(pairs) if p][0]
+    bt = list(traces)
+    bt[k] = oracle.gen_trace(SEED, k, chips[k][0], chips[k][1])
+    try:
+        pf2 = oracle.prove_chips(bt, [1, 2], params, pairs)
+    except RuntimeError:
+        return
+    assert oracle.verify_chips(pf2, lns, ws, [1, 2], params, pairs) == 10

@@ -45,7 +45,7 @@ def segment_params(num_queries=50, logup_pairs=0, log_final=8):
 
 
 class Chip(C.Structure):
-    _fields_ = [("d_trace", C.c_void_p), ("ld", C.c_size_t), ("log_n", C.c_int32), ("width", C.c_uint32)]
+    _fields_ = [("d_trace", C.c_void_p), ("ld", C.c_size_t), ("log_n", C.c_int32), ("width", C.c_uint32), ("logup_pairs", C.c_int32)]
 
 
 class ProveDebug(C.Structure):
@@ -115,10 +115,10 @@ def load():
     L.zkhip_last_prove_debug.argtypes = [C.c_void_p, C.POINTER(ProveDebug)]
     i32p = C.POINTER(C.c_int32)
     L.zkhip_chips_proof_size.restype = C.c_size_t
-    L.zkhip_chips_proof_size.argtypes = [i32p, u32p, C.c_int, C.POINTER(Params), C.c_size_t]
+    L.zkhip_chips_proof_size.argtypes = [i32p, u32p, i32p, C.c_int, C.POINTER(Params), C.c_size_t]
     L.zkhip_prove_chips.argtypes = [C.c_void_p, C.POINTER(Chip), C.c_int, u32p, C.c_size_t, C.POINTER(Params), u8p, C.c_size_t,
                                     C.POINTER(C.c_size_t)]
-    L.zkhip_verify_chips.argtypes = [u8p, C.c_size_t, i32p, u32p, C.c_int, u32p, C.c_size_t, C.POINTER(Params), C.POINTER(C.c_int)]
+    L.zkhip_verify_chips.argtypes = [u8p, C.c_size_t, i32p, u32p, i32p, C.c_int, u32p, C.c_size_t, C.POINTER(Params), C.POINTER(C.c_int)]
     _LIB = L
     return L
 

@@ -996,10 +996,12 @@ int zkhip_verify_shard(const uint8_t* proof, size_t len, int log_n, uint32_t wid
 // vector per height that joins the FRI vector when folding reaches that height (p3-fri 0.2.1 TwoAdicFriPcs), one query
 // index with chip c opened at index >> (Hmax - h_c).  Byte layout: DESIGN.md section 6.
 namespace zk {
-constexpr uint32_t CHIPS_VERSION = 4u;
+constexpr uint32_t CHIPS_VERSION = 4u, CHIPS_VERSION_LOGUP = 5u;
 constexpr int MAX_CHIPS = 16;
 
-static int check_chips(const int32_t* log_ns, const uint32_t* widths, int n, const zkhip_params* prm) {
+static bool any_pairs(const int32_t* pairs, int n) { if (pairs) for (int c = 0; c < n; c++) if (pairs[c]) return true; return false; }
+static size_t perm_width(const int32_t* pairs, int c) { return (pairs && pairs[c]) ? 4 * ((size_t)pairs[c] + 1) : 0; }
+static int check_chips(const int32_t* log_ns, const uint32_t* widths, const int32_t* pairs, int n, const zkhip_params* prm) {
     if (!prm || !log_ns || !widths) return fail(ZKHIP_ERR_INVALID, "chips: null argument");
     if (n < 1 || n > MAX_CHIPS) return fail(ZKHIP_ERR_INVALID, "chips: 1..16 chips");
     if (prm->log_blowup < 1 || prm->log_blowup > 3) return fail(ZKHIP_ERR_INVALID, "chips: log_blowup in [1,3]");
@@ -1010,55 +1012,68 @@ static int check_chips(const int32_t* log_ns, const uint32_t* widths, int n, con
         if (log_ns[c] < 5 || log_ns[c] > 20 || widths[c] == 0 || widths[c] % 4 != 0 || widths[c] > 1024)
             return fail(ZKHIP_ERR_INVALID, "chips: log_n in [5,20], width a multiple of 4 up to 1024");
         if (c && log_ns[c] > log_ns[c - 1]) return fail(ZKHIP_ERR_INVALID, "chips: tallest first");
+        if (pairs && (pairs[c] < 0 || pairs[c] > 64 || (uint32_t)pairs[c] * 8 > widths[c])) return fail(ZKHIP_ERR_INVALID, "chips: logup_pairs out of range");
         int same = 0;
         for (int d = 0; d < n; d++) same += log_ns[d] == log_ns[c];
         if (same > MAX_LEAF_MATS) return fail(ZKHIP_ERR_INVALID, "chips: at most 4 chips per height");
     }
     return ZKHIP_OK;
 }
-static size_t chips_proof_words(const int32_t* log_ns, const uint32_t* widths, int n, const zkhip_params* prm) {
+static size_t chips_proof_words(const int32_t* log_ns, const uint32_t* widths, const int32_t* pairs, int n, const zkhip_params* prm) {
+    const bool lk = any_pairs(pairs, n);
     const size_t b = (size_t)prm->log_blowup, Hmax = (size_t)log_ns[0] + b, L = (size_t)log_ns[0];
-    size_t words = 8 + 2 * (size_t)n + 16 + 8 * L + 4 + 1, perq = 16 * Hmax;
-    for (int c = 0; c < n; c++) { words += 8 * (size_t)widths[c] + 32; perq += widths[c] + 8; }
+    size_t words = 8 + (lk ? 3 : 2) * (size_t)n + 16 + (lk ? 8 : 0) + 8 * L + 4 + 1, perq = 16 * Hmax, hp = 0;
+    for (int c = 0; c < n; c++) {
+        const size_t wp = perm_width(pairs, c);
+        words += 8 * (size_t)widths[c] + 8 * wp + 32;
+        perq += widths[c] + wp + 8;
+        if (wp && (size_t)log_ns[c] + b > hp) hp = (size_t)log_ns[c] + b;
+    }
+    perq += 8 * hp;
     for (size_t l = 0; l < L; l++) perq += 4 + 8 * (Hmax - 1 - l);
     return words + (size_t)prm->num_queries * perq;
 }
-static void chips_transcript_init(Challenger& ch, const int32_t* log_ns, const uint32_t* widths, int n, const zkhip_params* prm, size_t n_public) {
-    ch.observe_canonical(CHIPS_VERSION);
+static void chips_transcript_init(Challenger& ch, const int32_t* log_ns, const uint32_t* widths, const int32_t* pairs, int n, const zkhip_params* prm, size_t n_public) {
+    const bool lk = any_pairs(pairs, n);
+    ch.observe_canonical(lk ? CHIPS_VERSION_LOGUP : CHIPS_VERSION);
     ch.observe_canonical((uint32_t)n);
     ch.observe_canonical((uint32_t)prm->log_blowup);
     ch.observe_canonical((uint32_t)prm->num_queries);
     ch.observe_canonical((uint32_t)prm->pow_bits);
     ch.observe_canonical((uint32_t)n_public);
-    for (int c = 0; c < n; c++) { ch.observe_canonical((uint32_t)log_ns[c]); ch.observe_canonical(widths[c]); }
+    for (int c = 0; c < n; c++) {
+        ch.observe_canonical((uint32_t)log_ns[c]); ch.observe_canonical(widths[c]);
+        if (lk) ch.observe_canonical((uint32_t)pairs[c]);
+    }
 }
 // alpha-power offset of chip c inside the reduced-opening vector of its height
-static uint64_t height_offset(const int32_t* log_ns, const uint32_t* widths, int c) {
+static uint64_t height_offset(const int32_t* log_ns, const uint32_t* widths, const int32_t* pairs, int c) {
     uint64_t off = 0;
-    for (int d = 0; d < c; d++) if (log_ns[d] == log_ns[c]) off += 2 * (uint64_t)widths[d] + 8;
+    for (int d = 0; d < c; d++) if (log_ns[d] == log_ns[c]) off += 2 * (uint64_t)widths[d] + 2 * perm_width(pairs, d) + 8;
     return off;
 }
 }  // namespace zk
 
-size_t zkhip_chips_proof_size(const int32_t* log_ns, const uint32_t* widths, int n_chips, const zkhip_params* prm, size_t n_public) {
+size_t zkhip_chips_proof_size(const int32_t* log_ns, const uint32_t* widths, const int32_t* pairs, int n_chips, const zkhip_params* prm, size_t n_public) {
     (void)n_public;
-    if (check_chips(log_ns, widths, n_chips, prm) != ZKHIP_OK) return 0;
-    return chips_proof_words(log_ns, widths, n_chips, prm) * 4;
+    if (check_chips(log_ns, widths, pairs, n_chips, prm) != ZKHIP_OK) return 0;
+    return chips_proof_words(log_ns, widths, pairs, n_chips, prm) * 4;
 }
 
 int zkhip_prove_chips(zkhip_ctx* ctx, const zkhip_chip* chips, int n, const uint32_t* public_values, size_t n_public,
                       const zkhip_params* prm, uint8_t* proof, size_t cap, size_t* len) {
     CHECK_CTX(ctx);
     if (!chips || !proof || !len || (n_public && !public_values)) return fail(ZKHIP_ERR_INVALID, "prove_chips: bad arguments");
-    int32_t log_ns[MAX_CHIPS]; uint32_t widths[MAX_CHIPS];
+    int32_t log_ns[MAX_CHIPS], pairs[MAX_CHIPS]; uint32_t widths[MAX_CHIPS];
     if (n < 1 || n > MAX_CHIPS) return fail(ZKHIP_ERR_INVALID, "chips: 1..16 chips");
     for (int c = 0; c < n; c++) {
-        log_ns[c] = chips[c].log_n; widths[c] = chips[c].width;
+        log_ns[c] = chips[c].log_n; widths[c] = chips[c].width; pairs[c] = chips[c].logup_pairs;
         if (!chips[c].d_trace || chips[c].ld < chips[c].width) return fail(ZKHIP_ERR_INVALID, "prove_chips: bad chip descriptor");
     }
-    ZK_TRY(check_chips(log_ns, widths, n, prm));
+    ZK_TRY(check_chips(log_ns, widths, pairs, n, prm));
     for (size_t i = 0; i < n_public; i++) if (public_values[i] >= P) return fail(ZKHIP_ERR_INVALID, "prove_chips: public values must be canonical");
-    const size_t need = chips_proof_words(log_ns, widths, n, prm) * 4;
+    const size_t need = chips_proof_words(log_ns, widths, pairs, n, prm) * 4;
+    const bool lk = any_pairs(pairs, n);
     if (cap < need) return fail(ZKHIP_ERR_BUFFER, "prove_chips: proof buffer too small (see zkhip_chips_proof_size)");
     *len = 0;
     hipStream_t st = ctx->stream;
@@ -1067,26 +1082,33 @@ int zkhip_prove_chips(zkhip_ctx* ctx, const zkhip_chip* chips, int n, const uint
     Shape sh;                                     // SP1 FRI shape at this blowup
     sh.b = b; sh.R = L;
     int lh[MAX_CHIPS];
-    size_t tl_off[MAX_CHIPS + 1], ql_off[MAX_CHIPS + 1], dv_off[MAX_CHIPS + 1], op_off[MAX_CHIPS + 1], ap_off[MAX_CHIPS + 1];
-    tl_off[0] = ql_off[0] = dv_off[0] = op_off[0] = ap_off[0] = 0;
-    size_t nmax_chunk = 0;
+    size_t tl_off[MAX_CHIPS + 1], ql_off[MAX_CHIPS + 1], dv_off[MAX_CHIPS + 1], op_off[MAX_CHIPS + 1], ap_off[MAX_CHIPS + 1], pl_off[MAX_CHIPS + 1], wp[MAX_CHIPS];
+    tl_off[0] = ql_off[0] = dv_off[0] = op_off[0] = ap_off[0] = pl_off[0] = 0;
+    size_t nmax_chunk = 0, perm_max = 0;
+    int Hp = 0;
     for (int c = 0; c < n; c++) {
         lh[c] = log_ns[c] + b;
         const size_t mc = (size_t)1 << lh[c], nc = (size_t)1 << log_ns[c];
         tl_off[c + 1] = tl_off[c] + mc * widths[c];
         ql_off[c + 1] = ql_off[c] + mc * 8;
         dv_off[c + 1] = dv_off[c] + 8 * (mc + nc);               // [2][mc] 1/(x - z) then [2][nc] x/(x - z), ext words
-        op_off[c + 1] = op_off[c] + 8 * (size_t)widths[c] + 32;
-        ap_off[c + 1] = ap_off[c] + 4 * (size_t)(widths[c] > 8 ? widths[c] : 8);
+        wp[c] = perm_width(pairs, c);
+        pl_off[c + 1] = pl_off[c] + mc * wp[c];
+        op_off[c + 1] = op_off[c] + 8 * (size_t)widths[c] + 8 * wp[c] + 32;
+        size_t npw = widths[c] > 8 ? widths[c] : 8;
+        if (wp[c] > npw) npw = wp[c];
+        ap_off[c + 1] = ap_off[c] + 4 * npw;
         if (nc > nmax_chunk) nmax_chunk = nc;
+        if (nc * wp[c] > perm_max) perm_max = nc * wp[c];
+        if (wp[c] && lh[c] > Hp) Hp = lh[c];
     }
     uint32_t* pf = (uint32_t*)proof;
     size_t pos = 0;
-    pf[pos++] = PROOF_MAGIC; pf[pos++] = CHIPS_VERSION; pf[pos++] = (uint32_t)n; pf[pos++] = (uint32_t)b;
+    pf[pos++] = PROOF_MAGIC; pf[pos++] = lk ? CHIPS_VERSION_LOGUP : CHIPS_VERSION; pf[pos++] = (uint32_t)n; pf[pos++] = (uint32_t)b;
     pf[pos++] = (uint32_t)Q; pf[pos++] = (uint32_t)prm->pow_bits; pf[pos++] = (uint32_t)n_public; pf[pos++] = 16u;
-    for (int c = 0; c < n; c++) { pf[pos++] = (uint32_t)log_ns[c]; pf[pos++] = widths[c]; }
+    for (int c = 0; c < n; c++) { pf[pos++] = (uint32_t)log_ns[c]; pf[pos++] = widths[c]; if (lk) pf[pos++] = (uint32_t)pairs[c]; }
     Challenger ch;
-    chips_transcript_init(ch, log_ns, widths, n, prm, n_public);
+    chips_transcript_init(ch, log_ns, widths, pairs, n, prm, n_public);
     uint32_t root[8];
 
     // ---- 1. every chip's LDE, one mixed-height tree
@@ -1108,12 +1130,37 @@ int zkhip_prove_chips(zkhip_ctx* ctx, const zkhip_chip* chips, int n, const uint
     for (int i = 0; i < 8; i++) { ch.observe(root[i]); pf[pos++] = from_monty(root[i]); }
     for (size_t i = 0; i < n_public; i++) ch.observe_canonical(public_values[i]);
 
-    // ---- 2. per-chip quotients on the chip's own coset, chunk LDEs, second tree
+    // ---- 1b. lookups: one (gamma, beta) for the shard; the permutation traces of the chips that have pairs -> third tree
+    Ext gamma = ext_zero(), beta_l = ext_zero();
+    uint32_t *plde = nullptr, *ptree = nullptr;
+    if (lk) {
+        gamma = ch.sample_ext();
+        beta_l = ch.sample_ext();
+        void *v_perm, *v_plde, *v_ptree;
+        ZK_TRY(ctx_reserve(ctx, S_PERM, perm_max * 4, &v_perm));
+        ZK_TRY(ctx_reserve(ctx, S_PLDE, pl_off[n] * 4, &v_plde));
+        ZK_TRY(ctx_reserve(ctx, S_PTREE, (2 * ((size_t)1 << Hp) - 1) * 32, &v_ptree));
+        plde = (uint32_t*)v_plde; ptree = (uint32_t*)v_ptree;
+        MatDesc pmats[MAX_CHIPS]; int plh[MAX_CHIPS]; int np = 0;
+        for (int c = 0; c < n; c++) {
+            if (!wp[c]) continue;
+            ZK_TRY(run_perm_trace(ctx, chips[c].d_trace, chips[c].ld, log_ns[c], (uint32_t)pairs[c], gamma, beta_l, (uint32_t*)v_perm));
+            ZK_TRY(op_coset_lde(ctx, (const uint32_t*)v_perm, wp[c], plde + pl_off[c], wp[c], log_ns[c], (uint32_t)wp[c], b, MONTY_GEN));
+            pmats[np] = MatDesc{plde + pl_off[c], wp[c], (uint32_t)wp[c]}; plh[np] = lh[c]; np++;
+        }
+        ZK_TRY(op_merkle_commit_mixed(ctx, pmats, plh, np, ptree));
+        ZK_TRY(d2h(ctx, root, ptree + (2 * ((size_t)1 << Hp) - 2) * 8, 32));
+        for (int i = 0; i < 8; i++) { ch.observe(root[i]); pf[pos++] = from_monty(root[i]); }
+    }
+
+    // ---- 2. per-chip quotients on the chip's own coset, chunk LDEs, quotient tree
     const Ext alpha = ch.sample_ext();
     for (int c = 0; c < n; c++) {
         const size_t nc = (size_t)1 << log_ns[c];
         ZK_TRY(ensure_domain(ctx, log_ns[c], b));
-        ZK_TRY(run_quotient(ctx, tlde + tl_off[c], widths[c], log_ns[c], widths[c], alpha, LogupIn{}, qchunk));
+        LogupIn lu;
+        if (wp[c]) { lu.pairs = (uint32_t)pairs[c]; lu.perm_lde = plde + pl_off[c]; lu.gamma = gamma; lu.beta = beta_l; }
+        ZK_TRY(run_quotient(ctx, tlde + tl_off[c], widths[c], log_ns[c], widths[c], alpha, lu, qchunk));
         const uint32_t w2n = two_adic_generator(log_ns[c] + 1);
         for (int k = 0; k < 2; k++)
             ZK_TRY(op_coset_lde(ctx, qchunk + (size_t)k * nc * 4, 4, qlde + ql_off[c] + 4 * k, 8, log_ns[c], 4, b, finv(fpow(w2n, (uint64_t)k))));
@@ -1138,7 +1185,8 @@ int zkhip_prove_chips(zkhip_ctx* ctx, const zkhip_chip* chips, int n, const uint
         uint32_t* xw = dv + 8 * mc;
         ZK_HIP(launch_inv_denominators(ctx->dom_xs, mc, zpts[0], zpts[1], 2, dv, xw, nc, st));
         ZK_TRY(run_open(ctx, tlde + tl_off[c], widths[c], log_ns[c], widths[c], zpts, 2, xw, d_open + op_off[c]));
-        ZK_TRY(run_open(ctx, qlde + ql_off[c], 8, log_ns[c], 8, zpts, 1, xw, d_open + op_off[c] + 8 * (size_t)widths[c]));
+        if (wp[c]) ZK_TRY(run_open(ctx, plde + pl_off[c], wp[c], log_ns[c], (uint32_t)wp[c], zpts, 2, xw, d_open + op_off[c] + 8 * (size_t)widths[c]));
+        ZK_TRY(run_open(ctx, qlde + ql_off[c], 8, log_ns[c], 8, zpts, 1, xw, d_open + op_off[c] + 8 * (size_t)widths[c] + 8 * wp[c]));
     }
     std::vector<uint32_t> opened(op_off[n]);
     ZK_TRY(d2h(ctx, opened.data(), d_open, opened.size() * 4));
@@ -1172,7 +1220,7 @@ int zkhip_prove_chips(zkhip_ctx* ctx, const zkhip_chip* chips, int n, const uint
     }
     std::vector<uint32_t> apows(ap_off[n]);
     for (int c = 0; c < n; c++) {
-        const size_t np = widths[c] > 8 ? widths[c] : 8;
+        const size_t np = (ap_off[c + 1] - ap_off[c]) / 4;
         Ext* fp = (Ext*)(apows.data() + ap_off[c]);
         fp[0] = ext_one();
         for (size_t j = 1; j < np; j++) fp[j] = ext_mul(fp[j - 1], fa);
@@ -1184,19 +1232,26 @@ int zkhip_prove_chips(zkhip_ctx* ctx, const zkhip_chip* chips, int n, const uint
         const Ext* fp = (const Ext*)(apows.data() + ap_off[c]);
         const Ext* op_loc = (const Ext*)(opened.data() + op_off[c]);
         const Ext* op_nxt = op_loc + W;
-        const Ext* op_q = op_nxt + W;
+        const Ext* op_pl = op_nxt + W;
+        const Ext* op_pn = op_pl + wp[c];
+        const Ext* op_q = op_pn + wp[c];
         ReducedArgs ra{};
         ra.y_loc = ra.y_next = ra.y_pl = ra.y_pn = ra.y_q = ext_zero();
         for (uint32_t j = 0; j < W; j++) {
             ra.y_loc = ext_add(ra.y_loc, ext_mul(fp[j], op_loc[j]));
             ra.y_next = ext_add(ra.y_next, ext_mul(fp[j], op_nxt[j]));
         }
+        for (size_t j = 0; j < wp[c]; j++) {
+            ra.y_pl = ext_add(ra.y_pl, ext_mul(fp[j], op_pl[j]));
+            ra.y_pn = ext_add(ra.y_pn, ext_mul(fp[j], op_pn[j]));
+        }
         for (int j = 0; j < 8; j++) ra.y_q = ext_add(ra.y_q, ext_mul(fp[j], op_q[j]));
-        const uint64_t off = height_offset(log_ns, widths, c);
-        ra.off_loc = ext_pow(fa, off); ra.off_next = ext_pow(fa, off + W); ra.off_q = ext_pow(fa, off + 2 * (uint64_t)W);
-        ra.off_pl = ra.off_pn = ext_zero();
+        const uint64_t off = height_offset(log_ns, widths, pairs, c);
+        ra.off_loc = ext_pow(fa, off); ra.off_next = ext_pow(fa, off + W);
+        ra.off_pl = ext_pow(fa, off + 2 * (uint64_t)W); ra.off_pn = ext_pow(fa, off + 2 * (uint64_t)W + wp[c]);
+        ra.off_q = ext_pow(fa, off + 2 * (uint64_t)W + 2 * wp[c]);
         ra.tlde = tlde + tl_off[c]; ra.t_ld = W; ra.width = W; ra.qlde = qlde + ql_off[c]; ra.q_ld = 8; ra.rows = (uint64_t)1 << lh[c];
-        ra.plde = nullptr; ra.p_ld = 0; ra.p_width = 0;
+        ra.plde = wp[c] ? plde + pl_off[c] : nullptr; ra.p_ld = wp[c]; ra.p_width = (uint32_t)wp[c];
         ra.alpha_pow = (const uint32_t*)v_apf + ap_off[c]; ra.dinv = dinv + dv_off[c]; ra.out = ro_of[lh[c]];
         ra.accumulate = started[lh[c]] ? 1 : 0;
         started[lh[c]] = true;
@@ -1231,6 +1286,10 @@ int zkhip_prove_chips(zkhip_ctx* ctx, const zkhip_chip* chips, int n, const uint
             const size_t index = ch.sample_bits(Hmax);
             for (int c = 0; c < n; c++) push(tlde + tl_off[c] + (index >> (Hmax - lh[c])) * widths[c], widths[c]);
             push_path(ttree, mmax, index, Hmax);
+            if (lk) {
+                for (int c = 0; c < n; c++) if (wp[c]) push(plde + pl_off[c] + (index >> (Hmax - lh[c])) * wp[c], wp[c]);
+                push_path(ptree, (size_t)1 << Hp, index >> (Hmax - Hp), Hp);
+            }
             for (int c = 0; c < n; c++) push(qlde + ql_off[c] + (index >> (Hmax - lh[c])) * 8, 8);
             push_path(qtree, mmax, index, Hmax);
             size_t idx = index;
@@ -1284,47 +1343,57 @@ static bool verify_mixed(const uint32_t* root_m, int Hmax, size_t index, const u
     return true;
 }
 
-int zkhip_verify_chips(const uint8_t* proof, size_t len, const int32_t* log_ns, const uint32_t* widths, int n,
+int zkhip_verify_chips(const uint8_t* proof, size_t len, const int32_t* log_ns, const uint32_t* widths, const int32_t* pairs, int n,
                        const uint32_t* public_values, size_t n_public, const zkhip_params* prm, int* reason) {
     int dummy;
     if (!reason) reason = &dummy;
     *reason = 0;
     auto reject = [&](int why) { *reason = why; return fail(ZKHIP_ERR_VERIFY, "proof rejected (check " + std::to_string(why) + ")"); };
-    if (check_chips(log_ns, widths, n, prm) != ZKHIP_OK) return reject(1);
+    if (check_chips(log_ns, widths, pairs, n, prm) != ZKHIP_OK) return reject(1);
     if (!proof || (n_public && !public_values)) return reject(1);
-    if (len != chips_proof_words(log_ns, widths, n, prm) * 4) return reject(2);
+    if (len != chips_proof_words(log_ns, widths, pairs, n, prm) * 4) return reject(2);
     const uint32_t* pf = (const uint32_t*)proof;
+    const bool lk = any_pairs(pairs, n);
     const int b = prm->log_blowup, Hmax = log_ns[0] + b, L = log_ns[0];
-    if (pf[0] != PROOF_MAGIC || pf[1] != CHIPS_VERSION || pf[2] != (uint32_t)n || pf[3] != (uint32_t)b || pf[4] != (uint32_t)prm->num_queries ||
-        pf[5] != (uint32_t)prm->pow_bits || pf[6] != (uint32_t)n_public || pf[7] != 16u) return reject(3);
+    if (pf[0] != PROOF_MAGIC || pf[1] != (lk ? CHIPS_VERSION_LOGUP : CHIPS_VERSION) || pf[2] != (uint32_t)n || pf[3] != (uint32_t)b ||
+        pf[4] != (uint32_t)prm->num_queries || pf[5] != (uint32_t)prm->pow_bits || pf[6] != (uint32_t)n_public || pf[7] != 16u) return reject(3);
     size_t pos = 8;
-    for (int c = 0; c < n; c++) { if (pf[pos] != (uint32_t)log_ns[c] || pf[pos + 1] != widths[c]) return reject(3); pos += 2; }
+    for (int c = 0; c < n; c++) {
+        if (pf[pos] != (uint32_t)log_ns[c] || pf[pos + 1] != widths[c]) return reject(3);
+        pos += 2;
+        if (lk) { if (pf[pos] != (uint32_t)pairs[c]) return reject(3); pos++; }
+    }
     for (size_t i = pos; i < len / 4; i++) if (pf[i] >= P) return reject(4);
     for (size_t i = 0; i < n_public; i++) if (public_values[i] >= P) return reject(4);
-    int lh[MAX_CHIPS]; uint32_t w8[MAX_CHIPS];
-    for (int c = 0; c < n; c++) { lh[c] = log_ns[c] + b; w8[c] = 8; }
+    int lh[MAX_CHIPS]; uint32_t w8[MAX_CHIPS]; size_t wp[MAX_CHIPS];
+    for (int c = 0; c < n; c++) { lh[c] = log_ns[c] + b; w8[c] = 8; wp[c] = perm_width(pairs, c); }
     Challenger ch;
-    chips_transcript_init(ch, log_ns, widths, n, prm, n_public);
-    uint32_t troot[8], qroot[8];
+    chips_transcript_init(ch, log_ns, widths, pairs, n, prm, n_public);
+    uint32_t troot[8], proot[8] = {0}, qroot[8];
     for (int i = 0; i < 8; i++) { troot[i] = to_monty(pf[pos++]); ch.observe(troot[i]); }
     for (size_t i = 0; i < n_public; i++) ch.observe_canonical(public_values[i]);
+    Ext gamma = ext_zero(), beta_l = ext_zero();
+    uint32_t pw[MAX_CHIPS]; int plh[MAX_CHIPS], pchip[MAX_CHIPS]; int np = 0, Hp = 0;
+    if (lk) {
+        gamma = ch.sample_ext();
+        beta_l = ch.sample_ext();
+        for (int i = 0; i < 8; i++) { proot[i] = to_monty(pf[pos++]); ch.observe(proot[i]); }
+        for (int c = 0; c < n; c++) if (wp[c]) { pw[np] = (uint32_t)wp[c]; plh[np] = lh[c]; pchip[np] = c; np++; if (lh[c] > Hp) Hp = lh[c]; }
+    }
     const Ext alpha = ch.sample_ext();
     for (int i = 0; i < 8; i++) { qroot[i] = to_monty(pf[pos++]); ch.observe(qroot[i]); }
     const Ext zeta = ch.sample_ext();
-    std::vector<std::vector<Ext>> loc(n), nxt(n), opq(n);
+    std::vector<std::vector<Ext>> loc(n), nxt(n), opl(n), opn(n), opq(n);
     for (int c = 0; c < n; c++) {
         const uint32_t W = widths[c];
-        loc[c].resize(W); nxt[c].resize(W); opq[c].resize(8);
-        for (uint32_t j = 0; j < W; j++) loc[c][j] = ext_from_canon(pf + pos + 4 * j);
-        pos += 4 * (size_t)W;
-        for (uint32_t j = 0; j < W; j++) nxt[c][j] = ext_from_canon(pf + pos + 4 * j);
-        pos += 4 * (size_t)W;
-        for (int j = 0; j < 8; j++) opq[c][j] = ext_from_canon(pf + pos + 4 * j);
-        pos += 32;
+        auto take = [&](std::vector<Ext>& v, size_t cnt) { v.resize(cnt); for (size_t j = 0; j < cnt; j++) v[j] = ext_from_canon(pf + pos + 4 * j); pos += 4 * cnt; };
+        take(loc[c], W); take(nxt[c], W); take(opl[c], wp[c]); take(opn[c], wp[c]); take(opq[c], 8);
     }
     for (int c = 0; c < n; c++) {
         for (const Ext& e : loc[c]) ch.observe_ext(e);
         for (const Ext& e : nxt[c]) ch.observe_ext(e);
+        for (const Ext& e : opl[c]) ch.observe_ext(e);
+        for (const Ext& e : opn[c]) ch.observe_ext(e);
         for (const Ext& e : opq[c]) ch.observe_ext(e);
     }
     // (a) every chip's AIR identity at zeta
@@ -1345,6 +1414,23 @@ int zkhip_verify_chips(const uint8_t* proof, size_t len, const int32_t* log_ns, 
             acc = ext_add(ext_mul(acc, alpha), c2);
             acc = ext_add(ext_mul(acc, alpha), c3);
         }
+        if (wp[c]) {
+            const uint32_t LQ = (uint32_t)pairs[c];
+            const Ext sel_last = ext_mul(zh, ext_inv(ext_sub_base(zeta, finv(gn))));
+            Ext sum_l = ext_zero(), sum_n = ext_zero();
+            for (uint32_t q = 0; q < LQ; q++) {
+                const Ext ds = ext_add(ext_add(gamma, loc[c][8 * q]), ext_mul(beta_l, loc[c][8 * q + 1]));
+                const Ext dr = ext_add(ext_add(gamma, loc[c][8 * q + 4]), ext_mul(beta_l, loc[c][8 * q + 5]));
+                const Ext phi = recombine(&opl[c][4 * q]), phin = recombine(&opn[c][4 * q]);
+                acc = ext_add(ext_mul(acc, alpha), ext_sub(ext_mul(ext_mul(phi, ds), dr), ext_sub(dr, ds)));
+                sum_l = ext_add(sum_l, phi);
+                sum_n = ext_add(sum_n, phin);
+            }
+            const Ext S = recombine(&opl[c][4 * LQ]), Sn = recombine(&opn[c][4 * LQ]);
+            acc = ext_add(ext_mul(acc, alpha), ext_mul(sel_first, ext_sub(S, sum_l)));
+            acc = ext_add(ext_mul(acc, alpha), ext_mul(sel_trans, ext_sub(ext_sub(Sn, S), sum_n)));
+            acc = ext_add(ext_mul(acc, alpha), ext_mul(sel_last, S));
+        }
         const uint32_t w2n = two_adic_generator(log_ns[c] + 1);
         const uint32_t s[2] = {MONTY_GEN, fmul(MONTY_GEN, w2n)};
         Ext quot = ext_zero();
@@ -1360,21 +1446,27 @@ int zkhip_verify_chips(const uint8_t* proof, size_t len, const int32_t* log_ns, 
     // (b) FRI
     const Ext fa = ch.sample_ext();
     size_t npmax = 8;
-    for (int c = 0; c < n; c++) if (widths[c] > npmax) npmax = widths[c];
+    for (int c = 0; c < n; c++) { if (widths[c] > npmax) npmax = widths[c]; if (wp[c] > npmax) npmax = wp[c]; }
     std::vector<Ext> fapow(npmax);
     fapow[0] = ext_one();
     for (size_t j = 1; j < npmax; j++) fapow[j] = ext_mul(fapow[j - 1], fa);
-    Ext y_loc[MAX_CHIPS], y_nxt[MAX_CHIPS], y_q[MAX_CHIPS], s_loc[MAX_CHIPS], s_nxt[MAX_CHIPS], s_q[MAX_CHIPS], znext[MAX_CHIPS];
+    Ext y_loc[MAX_CHIPS], y_nxt[MAX_CHIPS], y_pl[MAX_CHIPS], y_pn[MAX_CHIPS], y_q[MAX_CHIPS];
+    Ext s_loc[MAX_CHIPS], s_nxt[MAX_CHIPS], s_pl[MAX_CHIPS], s_pn[MAX_CHIPS], s_q[MAX_CHIPS], znext[MAX_CHIPS];
     for (int c = 0; c < n; c++) {
         const uint32_t W = widths[c];
-        y_loc[c] = y_nxt[c] = y_q[c] = ext_zero();
+        y_loc[c] = y_nxt[c] = y_pl[c] = y_pn[c] = y_q[c] = ext_zero();
         for (uint32_t j = 0; j < W; j++) {
             y_loc[c] = ext_add(y_loc[c], ext_mul(fapow[j], loc[c][j]));
             y_nxt[c] = ext_add(y_nxt[c], ext_mul(fapow[j], nxt[c][j]));
         }
+        for (size_t j = 0; j < wp[c]; j++) {
+            y_pl[c] = ext_add(y_pl[c], ext_mul(fapow[j], opl[c][j]));
+            y_pn[c] = ext_add(y_pn[c], ext_mul(fapow[j], opn[c][j]));
+        }
         for (int j = 0; j < 8; j++) y_q[c] = ext_add(y_q[c], ext_mul(fapow[j], opq[c][j]));
-        const uint64_t off = height_offset(log_ns, widths, c);
-        s_loc[c] = ext_pow(fa, off); s_nxt[c] = ext_pow(fa, off + W); s_q[c] = ext_pow(fa, off + 2 * (uint64_t)W);
+        const uint64_t off = height_offset(log_ns, widths, pairs, c);
+        s_loc[c] = ext_pow(fa, off); s_nxt[c] = ext_pow(fa, off + W); s_pl[c] = ext_pow(fa, off + 2 * (uint64_t)W);
+        s_pn[c] = ext_pow(fa, off + 2 * (uint64_t)W + wp[c]); s_q[c] = ext_pow(fa, off + 2 * (uint64_t)W + 2 * wp[c]);
         znext[c] = ext_mul_base(zeta, two_adic_generator(log_ns[c]));
     }
     std::vector<uint32_t> commits((size_t)L * 8);
@@ -1391,12 +1483,18 @@ int zkhip_verify_chips(const uint8_t* proof, size_t len, const int32_t* log_ns, 
     if (ch.sample_bits(prm->pow_bits) != 0) return reject(20);
     for (int q = 0; q < prm->num_queries; q++) {
         const size_t index = ch.sample_bits(Hmax);
-        const uint32_t *trow[MAX_CHIPS], *qrow[MAX_CHIPS];
-        for (int c = 0; c < n; c++) { trow[c] = pf + pos; pos += widths[c]; }
+        const uint32_t *trow[MAX_CHIPS], *qrow[MAX_CHIPS], *prow[MAX_CHIPS], *prow_all[MAX_CHIPS];
+        for (int c = 0; c < n; c++) { trow[c] = pf + pos; pos += widths[c]; prow_all[c] = nullptr; }
         const uint32_t* tpath = pf + pos; pos += 8 * (size_t)Hmax;
+        const uint32_t* ppath = nullptr;
+        if (lk) {
+            for (int k = 0; k < np; k++) { prow[k] = pf + pos; prow_all[pchip[k]] = prow[k]; pos += pw[k]; }
+            ppath = pf + pos; pos += 8 * (size_t)Hp;
+        }
         for (int c = 0; c < n; c++) { qrow[c] = pf + pos; pos += 8; }
         const uint32_t* qpath = pf + pos; pos += 8 * (size_t)Hmax;
         if (!verify_mixed(troot, Hmax, index, trow, widths, lh, n, tpath)) return reject(30);
+        if (lk && !verify_mixed(proot, Hp, index >> (Hmax - Hp), prow, pw, plh, np, ppath)) return reject(32);
         if (!verify_mixed(qroot, Hmax, index, qrow, w8, lh, n, qpath)) return reject(31);
         Ext roh[32];
         for (int h = 0; h < 32; h++) roh[h] = ext_zero();
@@ -1404,11 +1502,16 @@ int zkhip_verify_chips(const uint8_t* proof, size_t len, const int32_t* log_ns, 
             const size_t ic = index >> (Hmax - lh[c]);
             const uint32_t x = fmul(MONTY_GEN, fpow(two_adic_generator(lh[c]), reverse_bits((uint32_t)ic, lh[c])));
             const Ext d1 = ext_inv(ext_neg(ext_sub_base(zeta, x))), d2 = ext_inv(ext_neg(ext_sub_base(znext[c], x)));
-            Ext at = ext_zero(), aq = ext_zero();
+            Ext at = ext_zero(), ap = ext_zero(), aq = ext_zero();
             for (uint32_t j = 0; j < widths[c]; j++) at = ext_add(at, ext_mul_base(fapow[j], to_monty(trow[c][j])));
+            for (size_t j = 0; j < wp[c]; j++) ap = ext_add(ap, ext_mul_base(fapow[j], to_monty(prow_all[c][j])));
             for (int j = 0; j < 8; j++) aq = ext_add(aq, ext_mul_base(fapow[j], to_monty(qrow[c][j])));
             Ext r = ext_mul(s_loc[c], ext_mul(ext_sub(at, y_loc[c]), d1));
             r = ext_add(r, ext_mul(s_nxt[c], ext_mul(ext_sub(at, y_nxt[c]), d2)));
+            if (wp[c]) {
+                r = ext_add(r, ext_mul(s_pl[c], ext_mul(ext_sub(ap, y_pl[c]), d1)));
+                r = ext_add(r, ext_mul(s_pn[c], ext_mul(ext_sub(ap, y_pn[c]), d2)));
+            }
             r = ext_add(r, ext_mul(s_q[c], ext_mul(ext_sub(aq, y_q[c]), d1)));
             roh[lh[c]] = ext_add(roh[lh[c]], r);
         }
