@@ -369,21 +369,25 @@ def _random_chip_sets(count, seed):
         heights = sorted((int(h) for h in rng.integers(5, 12, size=n)), reverse=True)
         while max(heights.count(h) for h in heights) > 4:
             heights = sorted((int(h) for h in rng.integers(5, 12, size=n)), reverse=True)
-        chips = [(h, 4 * int(rng.integers(1, 12))) for h in heights]
+        chips = []
+        for h in heights:
+            w = 4 * int(rng.integers(1, 12))
+            chips.append((h, w, int(rng.integers(0, w // 8 + 1)) if rng.random() < 0.35 else 0))
         out.append((chips, (int(rng.integers(1, 4)), int(rng.integers(1, 10)), int(rng.integers(0, 6)))))
     return out
 
 
-@pytest.mark.parametrize("chips,prm", _random_chip_sets(16, 777))
+@pytest.mark.parametrize("chips,prm", _random_chip_sets(24, 777))
 def test_prove_chips_randomised_sets(ctx, oracle, chips, prm):
     from zktls_amd.device import verify_chips
-    dev = [(ctx.gen_trace(SEED, 30 + i, ln, w), ln, w) for i, (ln, w) in enumerate(chips)]
-    host = [oracle.gen_trace(SEED, 30 + i, ln, w) for i, (ln, w) in enumerate(chips)]
+    dev = [(ctx.gen_trace_logup(SEED, 30 + i, ln, w, pr) if pr else ctx.gen_trace(SEED, 30 + i, ln, w), ln, w, pr) for i, (ln, w, pr) in enumerate(chips)]
+    host = [oracle.gen_trace_logup(SEED, 30 + i, ln, w, pr) if pr else oracle.gen_trace(SEED, 30 + i, ln, w) for i, (ln, w, pr) in enumerate(chips)]
+    pairs = [c[2] for c in chips]
     proof = ctx.prove_chips(dev, [5], Params(*prm))
-    assert proof.tobytes() == oracle.prove_chips(host, [5], oracle.default_params(*prm)).tobytes()
-    assert verify_chips(proof, [c[0] for c in chips], [c[1] for c in chips], [5], Params(*prm)) == (0, 0)
-    for b, _, _ in dev:
-        b.free()
+    assert proof.tobytes() == oracle.prove_chips(host, [5], oracle.default_params(*prm), pairs).tobytes()
+    assert verify_chips(proof, [c[0] for c in chips], [c[1] for c in chips], [5], Params(*prm), pairs) == (0, 0)
+    for d in dev:
+        d[0].free()
 
 
 CHIP_SETS_LOGUP = [
