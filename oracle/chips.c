@@ -18,7 +18,9 @@
  * polynomial, Poseidon2 width 16) at any log_blowup in [1, 3].
  * Lookups: a chip may carry in-table LogUp pairs (stark.c: pairs[c] > 0); the permutation traces of those chips form a
  * third mixed-height tree between the trace and the quotient commitments, as sp1-stark commits the permutation traces
- * of a shard together (proof version 5).  Lookups BETWEEN chips are not modelled.
+ * of a shard together (proof version 5).  Lookups BETWEEN chips (partners[]): two chips of equal height hold each
+ * other's sender columns; every chip with pairs then exposes the final value C of its running sum, the last-row constraint
+ * becomes S = C and the verifier checks sum C = 0 -- sp1-stark's local cumulative sums (proof version 6).
  */
 #include "oracle.h"
 #include "stark_internal.h"
@@ -30,12 +32,17 @@
 #define CHIPS_MAGIC 0x41544B5Au
 #define CHIPS_VERSION 4u
 #define CHIPS_VERSION_LOGUP 5u
+#define CHIPS_VERSION_CROSS 6u     /* some chips look each other up: cumulative sums are part of the proof */
 #define MAX_CHIPS 16
 
 static bb4_t sample_ext(orc_challenger_t* ch) { bb4_t r; orc_chal_sample_ext(ch, r.c); return r; }
 
 static int any_pairs(const int* pairs, int n) { if (pairs) for (int c = 0; c < n; c++) if (pairs[c]) return 1; return 0; }
-static int chips_ok(const int* log_ns, const size_t* widths, const int* pairs, int n, const orc_params_t* prm) {
+static int any_cross(const int* partners, int n) { if (partners) for (int c = 0; c < n; c++) if (partners[c] >= 0) return 1; return 0; }
+static uint32_t chips_version(const int* pairs, const int* partners, int n) {
+    return any_cross(partners, n) ? CHIPS_VERSION_CROSS : (any_pairs(pairs, n) ? CHIPS_VERSION_LOGUP : CHIPS_VERSION);
+}
+static int chips_ok(const int* log_ns, const size_t* widths, const int* pairs, const int* partners, int n, const orc_params_t* prm) {
     if (n < 1 || n > MAX_CHIPS) return 0;
     if (prm->log_blowup < 1 || prm->log_blowup > 3) return 0;
     if ((prm->log_fold != 0 && prm->log_fold != 1) || prm->log_final != 0 || (prm->hash_width != 0 && prm->hash_width != 16)) return 0;
@@ -44,6 +51,10 @@ static int chips_ok(const int* log_ns, const size_t* widths, const int* pairs, i
         if (log_ns[c] < 5 || log_ns[c] > 20 || widths[c] == 0 || widths[c] % 4 != 0 || widths[c] > 1024) return 0;
         if (c && log_ns[c] > log_ns[c - 1]) return 0;             /* tallest first */
         if (pairs && (pairs[c] < 0 || pairs[c] > 64 || (size_t)pairs[c] * 8 > widths[c])) return 0;
+        if (partners && partners[c] >= 0) {                        /* mutual, equal heights and pair counts */
+            int d = partners[c];
+            if (!pairs || d >= n || d == c || partners[d] != c || pairs[c] == 0 || pairs[d] != pairs[c] || log_ns[d] != log_ns[c]) return 0;
+        } else if (partners && partners[c] < -1) return 0;
     }
     for (int c = 0; c < n; c++) {                                  /* at most 4 chips share a height (one leaf hash) */
         int same = 0;
@@ -53,16 +64,16 @@ static int chips_ok(const int* log_ns, const size_t* widths, const int* pairs, i
     return 1;
 }
 
-size_t orc_chips_proof_size(const int* log_ns, const size_t* widths, const int* pairs, int n, const orc_params_t* prm, size_t n_public) {
+size_t orc_chips_proof_size(const int* log_ns, const size_t* widths, const int* pairs, const int* partners, int n, const orc_params_t* prm, size_t n_public) {
     (void)n_public;
-    if (!chips_ok(log_ns, widths, pairs, n, prm)) return 0;
-    const int lk = any_pairs(pairs, n);
+    if (!chips_ok(log_ns, widths, pairs, partners, n, prm)) return 0;
+    const int lk = any_pairs(pairs, n), cross = any_cross(partners, n);
     size_t b = (size_t)prm->log_blowup, Hmax = (size_t)log_ns[0] + b, L = (size_t)log_ns[0];
-    size_t words = 8 + (lk ? 3 : 2) * (size_t)n + 16 + (lk ? 8 : 0) + 8 * L + 4 + 1;
+    size_t words = 8 + (cross ? 4 : (lk ? 3 : 2)) * (size_t)n + 16 + (lk ? 8 : 0) + 8 * L + 4 + 1;
     size_t perq = 16 * Hmax, hp = 0;
     for (int c = 0; c < n; c++) {
         size_t wp = (pairs && pairs[c]) ? 4 * ((size_t)pairs[c] + 1) : 0;
-        words += 8 * widths[c] + 8 * wp + 32;
+        words += 8 * widths[c] + 8 * wp + 32 + ((cross && wp) ? 4 : 0);      /* + the chip's cumulative sum */
         perq += widths[c] + wp + 8;
         if (wp && (size_t)log_ns[c] + b > hp) hp = (size_t)log_ns[c] + b;
     }
@@ -71,10 +82,10 @@ size_t orc_chips_proof_size(const int* log_ns, const size_t* widths, const int* 
     return (words + (size_t)prm->num_queries * perq) * 4;
 }
 
-static void transcript_init(orc_challenger_t* ch, const int* log_ns, const size_t* widths, const int* pairs, int n, const orc_params_t* prm, size_t n_public) {
-    const int lk = any_pairs(pairs, n);
+static void transcript_init(orc_challenger_t* ch, const int* log_ns, const size_t* widths, const int* pairs, const int* partners, int n, const orc_params_t* prm, size_t n_public) {
+    const int lk = any_pairs(pairs, n), cross = any_cross(partners, n);
     orc_chal_init(ch);
-    orc_chal_observe(ch, lk ? CHIPS_VERSION_LOGUP : CHIPS_VERSION);
+    orc_chal_observe(ch, chips_version(pairs, partners, n));
     orc_chal_observe(ch, (uint32_t)n);
     orc_chal_observe(ch, (uint32_t)prm->log_blowup);
     orc_chal_observe(ch, (uint32_t)prm->num_queries);
@@ -83,6 +94,7 @@ static void transcript_init(orc_challenger_t* ch, const int* log_ns, const size_
     for (int c = 0; c < n; c++) {
         orc_chal_observe(ch, (uint32_t)log_ns[c]); orc_chal_observe(ch, (uint32_t)widths[c]);
         if (lk) orc_chal_observe(ch, (uint32_t)pairs[c]);
+        if (cross) orc_chal_observe(ch, (uint32_t)(partners[c] + 1));
     }
 }
 
@@ -95,19 +107,25 @@ static size_t height_offset(const int* log_ns, const size_t* widths, const int* 
     return off;
 }
 
-size_t orc_prove_chips(const uint32_t* const* traces, const int* log_ns, const size_t* widths, const int* pairs, int n,
+size_t orc_prove_chips(const uint32_t* const* traces, const int* log_ns, const size_t* widths, const int* pairs, const int* partners, int n,
                        const uint32_t* public_values, size_t n_public, const orc_params_t* prm,
                        uint8_t* proof_bytes, size_t cap) {
-    size_t need = orc_chips_proof_size(log_ns, widths, pairs, n, prm, n_public);
+    size_t need = orc_chips_proof_size(log_ns, widths, pairs, partners, n, prm, n_public);
     if (need == 0 || cap < need) return 0;
     uint32_t* pf = (uint32_t*)proof_bytes;
     size_t pos = 0;
-    const int b = prm->log_blowup, Hmax = log_ns[0] + b, L = log_ns[0], lk = any_pairs(pairs, n);
-    pf[pos++] = CHIPS_MAGIC; pf[pos++] = lk ? CHIPS_VERSION_LOGUP : CHIPS_VERSION; pf[pos++] = (uint32_t)n; pf[pos++] = (uint32_t)b;
+    const int b = prm->log_blowup, Hmax = log_ns[0] + b, L = log_ns[0], lk = any_pairs(pairs, n), cross = any_cross(partners, n);
+    pf[pos++] = CHIPS_MAGIC; pf[pos++] = chips_version(pairs, partners, n); pf[pos++] = (uint32_t)n; pf[pos++] = (uint32_t)b;
     pf[pos++] = (uint32_t)prm->num_queries; pf[pos++] = (uint32_t)prm->pow_bits; pf[pos++] = (uint32_t)n_public; pf[pos++] = 16u;
-    for (int c = 0; c < n; c++) { pf[pos++] = (uint32_t)log_ns[c]; pf[pos++] = (uint32_t)widths[c]; if (lk) pf[pos++] = (uint32_t)pairs[c]; }
+    for (int c = 0; c < n; c++) {
+        pf[pos++] = (uint32_t)log_ns[c]; pf[pos++] = (uint32_t)widths[c];
+        if (lk) pf[pos++] = (uint32_t)pairs[c];
+        if (cross) pf[pos++] = (uint32_t)(partners[c] + 1);
+    }
     orc_challenger_t ch;
-    transcript_init(&ch, log_ns, widths, pairs, n, prm, n_public);
+    transcript_init(&ch, log_ns, widths, pairs, partners, n, prm, n_public);
+    bb4_t cumsum[MAX_CHIPS];
+    for (int c = 0; c < n; c++) cumsum[c] = bb4_zero();
 
     /* 1. trace LDEs, one mixed-height tree */
     uint32_t* tlde[MAX_CHIPS]; uint32_t* qlde[MAX_CHIPS]; uint32_t* plde[MAX_CHIPS];
@@ -137,6 +155,7 @@ size_t orc_prove_chips(const uint32_t* const* traces, const int* log_ns, const s
             const size_t nc = (size_t)1 << log_ns[c], mc = (size_t)1 << lh[c];
             uint32_t* perm = (uint32_t*)malloc(nc * wp[c] * 4);
             orc_perm_trace(traces[c], log_ns[c], widths[c], pairs[c], gamma.c, beta_l.c, perm);
+            if (cross) cumsum[c] = ld4(perm + (nc - 1) * wp[c] + 4 * (size_t)pairs[c]);       /* the running sum's last value */
             plde[c] = (uint32_t*)malloc(mc * wp[c] * 4);
             orc_coset_lde(perm, plde[c], log_ns[c], wp[c], b, BB_GEN);
             free(perm);
@@ -149,6 +168,8 @@ size_t orc_prove_chips(const uint32_t* const* traces, const int* log_ns, const s
         const uint32_t* proot = ptree + (2 * mp - 2) * 8;
         memcpy(pf + pos, proot, 32); pos += 8;
         orc_chal_observe_slice(&ch, proot, 8);
+        if (cross)
+            for (int c = 0; c < n; c++) if (wp[c]) { st4(pf + pos, cumsum[c]); pos += 4; orc_chal_observe_slice(&ch, cumsum[c].c, 4); }
     }
 
     /* 2. quotients, per chip on its own 2N_c coset (= the first 2N_c rows of its LDE), chunk LDEs, quotient tree */
@@ -157,7 +178,7 @@ size_t orc_prove_chips(const uint32_t* const* traces, const int* log_ns, const s
         const int ln = log_ns[c], Hq = ln + 1;
         const size_t nc = (size_t)1 << ln, mc = (size_t)1 << lh[c], mq = (size_t)1 << Hq;
         uint32_t* qv = (uint32_t*)malloc(mq * 16);
-        orc_quotient_values_logup(tlde[c], ln, widths[c], plde[c], wp[c] ? pairs[c] : 0, gamma.c, beta_l.c, alpha.c, qv);
+        orc_quotient_values_logup_c(tlde[c], ln, widths[c], plde[c], wp[c] ? pairs[c] : 0, gamma.c, beta_l.c, alpha.c, cumsum[c].c, qv);
         qlde[c] = (uint32_t*)malloc(mc * 8 * 4);
         uint32_t* chunk = (uint32_t*)malloc(nc * 16);
         uint32_t* clde = (uint32_t*)malloc(mc * 16);
@@ -325,26 +346,29 @@ static int verify_mixed(const uint32_t root[8], int Hmax, size_t index, const ui
     return memcmp(cur, root, 32) == 0 ? 0 : 1;
 }
 
-int orc_verify_chips(const uint8_t* proof_bytes, size_t len, const int* log_ns, const size_t* widths, const int* pairs, int n,
+int orc_verify_chips(const uint8_t* proof_bytes, size_t len, const int* log_ns, const size_t* widths, const int* pairs, const int* partners, int n,
                      const uint32_t* public_values, size_t n_public, const orc_params_t* prm) {
-    if (!chips_ok(log_ns, widths, pairs, n, prm)) return 1;
-    if (len != orc_chips_proof_size(log_ns, widths, pairs, n, prm, n_public)) return 2;
+    if (!chips_ok(log_ns, widths, pairs, partners, n, prm)) return 1;
+    if (len != orc_chips_proof_size(log_ns, widths, pairs, partners, n, prm, n_public)) return 2;
     const uint32_t* pf = (const uint32_t*)proof_bytes;
-    const int b = prm->log_blowup, Hmax = log_ns[0] + b, L = log_ns[0], lk = any_pairs(pairs, n);
-    if (pf[0] != CHIPS_MAGIC || pf[1] != (lk ? CHIPS_VERSION_LOGUP : CHIPS_VERSION) || pf[2] != (uint32_t)n || pf[3] != (uint32_t)b ||
+    const int b = prm->log_blowup, Hmax = log_ns[0] + b, L = log_ns[0], lk = any_pairs(pairs, n), cross = any_cross(partners, n);
+    if (pf[0] != CHIPS_MAGIC || pf[1] != chips_version(pairs, partners, n) || pf[2] != (uint32_t)n || pf[3] != (uint32_t)b ||
         pf[4] != (uint32_t)prm->num_queries || pf[5] != (uint32_t)prm->pow_bits || pf[6] != (uint32_t)n_public || pf[7] != 16u) return 3;
     size_t pos = 8;
     for (int c = 0; c < n; c++) {
         if (pf[pos] != (uint32_t)log_ns[c] || pf[pos + 1] != (uint32_t)widths[c]) return 3;
         pos += 2;
         if (lk) { if (pf[pos] != (uint32_t)pairs[c]) return 3; pos++; }
+        if (cross) { if (pf[pos] != (uint32_t)(partners[c] + 1)) return 3; pos++; }
     }
     for (size_t i = pos; i < len / 4; i++) if (pf[i] >= BB_P) return 4;
     int lh[MAX_CHIPS]; size_t w8[MAX_CHIPS], wp[MAX_CHIPS];
     for (int c = 0; c < n; c++) { lh[c] = log_ns[c] + b; w8[c] = 8; wp[c] = perm_width(pairs, c); }
 
     orc_challenger_t ch;
-    transcript_init(&ch, log_ns, widths, pairs, n, prm, n_public);
+    transcript_init(&ch, log_ns, widths, pairs, partners, n, prm, n_public);
+    bb4_t cumsum[MAX_CHIPS];
+    for (int c = 0; c < n; c++) cumsum[c] = bb4_zero();
     const uint32_t* troot = pf + pos; pos += 8;
     orc_chal_observe_slice(&ch, troot, 8);
     orc_chal_observe_slice(&ch, public_values, n_public);
@@ -357,6 +381,11 @@ int orc_verify_chips(const uint8_t* proof_bytes, size_t len, const int* log_ns, 
         proot = pf + pos; pos += 8;
         orc_chal_observe_slice(&ch, proot, 8);
         for (int c = 0; c < n; c++) if (wp[c]) { pw[np] = wp[c]; plh[np] = lh[c]; pchip[np] = c; np++; if (lh[c] > Hp) Hp = lh[c]; }
+        if (cross) {
+            bb4_t total = bb4_zero();
+            for (int c = 0; c < n; c++) if (wp[c]) { cumsum[c] = ld4(pf + pos); pos += 4; orc_chal_observe_slice(&ch, cumsum[c].c, 4); total = bb4_add(total, cumsum[c]); }
+            if (!bb4_eq(total, bb4_zero())) return 11;            /* the lookups of the shard do not balance */
+        }
     }
     bb4_t alpha = sample_ext(&ch);
     const uint32_t* qroot = pf + pos; pos += 8;
@@ -384,7 +413,7 @@ int orc_verify_chips(const uint8_t* proof_bytes, size_t len, const int* log_ns, 
             const uint32_t *o_pl = op[c] + 8 * W, *o_pn = o_pl + 4 * Wp;
             for (int q = 0; q < Q; q++) { as[q] = loc[8 * q]; bs[q] = loc[8 * q + 1]; ar[q] = loc[8 * q + 4]; br[q] = loc[8 * q + 5]; }
             for (int q = 0; q <= Q; q++) { pl[q] = orc__recombine(o_pl + 16 * q); pn[q] = orc__recombine(o_pn + 16 * q); }
-            folded = orc__fold_logup(folded, Q, as, bs, ar, br, pl, pn, gamma, beta_l, sel_first, sel_trans, sel_last, alpha);
+            folded = orc__fold_logup(folded, Q, as, bs, ar, br, pl, pn, gamma, beta_l, sel_first, sel_trans, sel_last, alpha, cumsum[c]);
         }
         free(loc); free(nxt);
         bb_t w2n = bb_two_adic_generator(log_ns[c] + 1);

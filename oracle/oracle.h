@@ -107,11 +107,17 @@ void orc_gen_trace(uint64_t seed, uint64_t shard, int log_n, size_t width, uint3
 /* trace whose odd groups (first `pairs` pairs) receive the even groups' (a, b) under the row
  * permutation 5i+3 mod N: satisfies the LogUp-extended AIR (orc_params_t.logup_pairs = pairs) */
 void orc_gen_trace_logup(uint64_t seed, uint64_t shard, int log_n, size_t width, int pairs, uint32_t* out);
+/* the same with lookups BETWEEN two tables of equal height: receiver groups read the partner table's sender groups */
+void orc_gen_trace_logup_cross(uint64_t seed, uint64_t shard, uint64_t partner_shard, int log_n, size_t width, size_t partner_width,
+                               int pairs, uint32_t* out);
 /* permutation trace [phi_0 .. phi_{Q-1} | S]: N x 4(Q+1) words */
 void orc_perm_trace(const uint32_t* trace, int log_n, size_t width, int pairs,
                     const uint32_t gamma[4], const uint32_t beta[4], uint32_t* out);
 void orc_quotient_values_logup(const uint32_t* lde, int log_n, size_t width, const uint32_t* perm_lde, int pairs,
                                const uint32_t gamma[4], const uint32_t beta[4], const uint32_t alpha[4], uint32_t* out);
+/* the same with the last-row constraint S = cumsum (tables that look each other up) */
+void orc_quotient_values_logup_c(const uint32_t* lde, int log_n, size_t width, const uint32_t* perm_lde, int pairs,
+                                 const uint32_t gamma[4], const uint32_t beta[4], const uint32_t alpha[4], const uint32_t cumsum[4], uint32_t* out);
 /* number of constraint violations of the synthetic AIR on a trace (0 = valid) */
 size_t orc_check_trace(const uint32_t* trace, int log_n, size_t width);
 
@@ -153,11 +159,14 @@ int orc_verify_shard(const uint8_t* proof, size_t len, int log_n, size_t width,
 
 /* ---- a shard of several chips with different heights (oracle/chips.c): tallest first, heights log_ns[c] in [5, 20],
  * at most 4 chips per height, SP1 FRI shape (log_fold 1, log_final 0, hash width 16) at any log_blowup ---- */
-/* pairs (may be NULL): in-table LogUp pairs per chip (orc_gen_trace_logup); the permutation traces form a third tree */
-size_t orc_chips_proof_size(const int* log_ns, const size_t* widths, const int* pairs, int n_chips, const orc_params_t* prm, size_t n_public);
-size_t orc_prove_chips(const uint32_t* const* traces, const int* log_ns, const size_t* widths, const int* pairs, int n_chips,
+/* pairs (may be NULL): LogUp pairs per chip; the permutation traces form a third tree.  partners (may be NULL):
+ * partners[c] = -1: chip c's lookups stay inside the chip (orc_gen_trace_logup); d >= 0: its receiver groups hold chip d's
+ * sender groups (orc_gen_trace_logup_cross; mutual, equal heights and pair counts) -- then every chip with pairs exposes the
+ * final value of its running sum and the verifier checks that they add up to zero (sp1-stark's local cumulative sums) */
+size_t orc_chips_proof_size(const int* log_ns, const size_t* widths, const int* pairs, const int* partners, int n_chips, const orc_params_t* prm, size_t n_public);
+size_t orc_prove_chips(const uint32_t* const* traces, const int* log_ns, const size_t* widths, const int* pairs, const int* partners, int n_chips,
                        const uint32_t* public_values, size_t n_public, const orc_params_t* prm, uint8_t* proof, size_t cap);
-int orc_verify_chips(const uint8_t* proof, size_t len, const int* log_ns, const size_t* widths, const int* pairs, int n_chips,
+int orc_verify_chips(const uint8_t* proof, size_t len, const int* log_ns, const size_t* widths, const int* pairs, const int* partners, int n_chips,
                      const uint32_t* public_values, size_t n_public, const orc_params_t* prm);
 
 /* intermediates of the last orc_prove_shard call in this thread (for parity tests) */

@@ -112,7 +112,8 @@ size_t orc_check_trace(const uint32_t* t, int log_n, size_t width) {
  *     L_q  all rows    : phi_q den_s den_r - (den_r - den_s)      = 0   (degree 3)
  *     T1   first row   : S - sum_q phi_q                           = 0
  *     T2   transition  : S' - S - sum_q phi'_q                     = 0
- *     T3   last row    : S                                         = 0   (multisets are equal) */
+ *     T3   last row    : S - C                                     = 0   (C = 0: the multisets of this table are equal;
+ *                        tables that look each other up expose C, and the C's of a shard sum to 0) */
 static inline size_t logup_perm_row(size_t i, int log_n) { return (5 * i + 3) & (((size_t)1 << log_n) - 1); }
 
 void orc_gen_trace_logup(uint64_t seed, uint64_t shard, int log_n, size_t width, int pairs, uint32_t* out) {
@@ -135,6 +136,38 @@ void orc_gen_trace_logup(uint64_t seed, uint64_t shard, int log_n, size_t width,
                 size_t pi = recv ? logup_perm_row(i - 1, log_n) : i - 1;
                 bb_t pa = orc_synth_value(s, pi * width + 4 * sg);
                 bb_t pb = orc_synth_value(s, pi * width + 4 * sg + 1);
+                bb_t pc = bb_add(bb_mul(bb_mul(pa, pa), pb), air_k1(g));
+                d = bb_add(bb_add(bb_mul(pa, pb), pc), air_k2(g));
+            }
+            row[0] = a; row[1] = b; row[2] = c; row[3] = d;
+        }
+    }
+}
+
+/* Lookups BETWEEN two tables of equal height: the receiver groups (odd g < 2 pairs) of this table hold the sender groups
+ * (g - 1) of the PARTNER table (stream seed + partner_shard, row pitch partner_width) under the same row permutation.
+ * Each table's running sum then ends at C = sum(1/den_send own) - sum(1/den_send partner) != 0; the two C's cancel. */
+void orc_gen_trace_logup_cross(uint64_t seed, uint64_t shard, uint64_t partner_shard, int log_n, size_t width, size_t partner_width,
+                               int pairs, uint32_t* out) {
+    size_t n = (size_t)1 << log_n, G = width / 4;
+#pragma omp parallel for schedule(static)
+    for (size_t i = 0; i < n; i++) {
+        for (size_t g = 0; g < G; g++) {
+            uint32_t* row = out + i * width + 4 * g;
+            int recv = (g & 1) && (int)(g / 2) < pairs;
+            uint64_t s = seed + (recv ? partner_shard : shard);
+            size_t w = recv ? partner_width : width;
+            size_t sg = recv ? g - 1 : g;
+            size_t ri = recv ? logup_perm_row(i, log_n) : i;
+            bb_t a = orc_synth_value(s, ri * w + 4 * sg);
+            bb_t b = orc_synth_value(s, ri * w + 4 * sg + 1);
+            bb_t c = bb_add(bb_mul(bb_mul(a, a), b), air_k1(g));
+            bb_t d;
+            if (i == 0) d = air_d0(g);
+            else {
+                size_t pi = recv ? logup_perm_row(i - 1, log_n) : i - 1;
+                bb_t pa = orc_synth_value(s, pi * w + 4 * sg);
+                bb_t pb = orc_synth_value(s, pi * w + 4 * sg + 1);
                 bb_t pc = bb_add(bb_mul(bb_mul(pa, pa), pb), air_k1(g));
                 d = bb_add(bb_add(bb_mul(pa, pb), pc), air_k2(g));
             }
@@ -216,7 +249,7 @@ void orc__st4(uint32_t* p, bb4_t v) { memcpy(p, v.c, 16); }
  * as/bs/ar/br: sender / receiver tuple of pair q; perm_* hold phi_0..phi_{Q-1}, S. */
 bb4_t orc__fold_logup(bb4_t acc, int pairs, const bb4_t* as, const bb4_t* bs, const bb4_t* ar, const bb4_t* br,
                         const bb4_t* perm_local, const bb4_t* perm_next, bb4_t gamma, bb4_t beta,
-                        bb4_t sel_first, bb4_t sel_trans, bb4_t sel_last, bb4_t alpha) {
+                        bb4_t sel_first, bb4_t sel_trans, bb4_t sel_last, bb4_t alpha, bb4_t cumsum) {
     bb4_t sum_l = bb4_zero(), sum_n = bb4_zero();
     for (int q = 0; q < pairs; q++) {
         bb4_t ds = bb4_add(bb4_add(gamma, as[q]), bb4_mul(beta, bs[q]));
@@ -229,7 +262,7 @@ bb4_t orc__fold_logup(bb4_t acc, int pairs, const bb4_t* as, const bb4_t* bs, co
     bb4_t S = perm_local[pairs], Sn = perm_next[pairs];
     acc = bb4_add(bb4_mul(acc, alpha), bb4_mul(sel_first, bb4_sub(S, sum_l)));
     acc = bb4_add(bb4_mul(acc, alpha), bb4_mul(sel_trans, bb4_sub(bb4_sub(Sn, S), sum_n)));
-    acc = bb4_add(bb4_mul(acc, alpha), bb4_mul(sel_last, S));
+    acc = bb4_add(bb4_mul(acc, alpha), bb4_mul(sel_last, bb4_sub(S, cumsum)));     /* cumsum = 0: lookups closed inside the table */
     return acc;
 }
 
@@ -239,6 +272,13 @@ bb4_t orc__fold_logup(bb4_t acc, int pairs, const bb4_t* as, const bb4_t* bs, co
 void orc_quotient_values_logup(const uint32_t* lde, int log_n, size_t width,
                                 const uint32_t* perm_lde, int pairs, const uint32_t gamma_[4], const uint32_t beta_[4],
                                 const uint32_t alpha_[4], uint32_t* out) {
+    const uint32_t zero[4] = {0, 0, 0, 0};
+    orc_quotient_values_logup_c(lde, log_n, width, perm_lde, pairs, gamma_, beta_, alpha_, zero, out);
+}
+void orc_quotient_values_logup_c(const uint32_t* lde, int log_n, size_t width,
+                                  const uint32_t* perm_lde, int pairs, const uint32_t gamma_[4], const uint32_t beta_[4],
+                                  const uint32_t alpha_[4], const uint32_t cumsum_[4], uint32_t* out) {
+    const bb4_t cumsum = ld4(cumsum_);
     int log_m = log_n + 1;
     size_t m = (size_t)1 << log_m, n = (size_t)1 << log_n, wp = 4 * ((size_t)pairs + 1);
     bb4_t alpha = ld4(alpha_);
@@ -266,7 +306,7 @@ void orc_quotient_values_logup(const uint32_t* lde, int log_n, size_t width,
             }
             for (int q = 0; q <= pairs; q++) { pl[q] = ld4(perm_lde + p * wp + 4 * q); pn_[q] = ld4(perm_lde + pn * wp + 4 * q); }
             acc = fold_logup(acc, pairs, as, bs, ar, br, pl, pn_, gamma, beta, bb4_from_base(sel_first),
-                             bb4_from_base(sel_trans), bb4_from_base(sel_last), alpha);
+                             bb4_from_base(sel_trans), bb4_from_base(sel_last), alpha, cumsum);
         }
         st4(out + 4 * p, bb4_mul_base(acc, inv_zh));
     }
@@ -734,7 +774,7 @@ int orc_verify_shard(const uint8_t* proof_bytes, size_t len, int log_n, size_t w
             bb4_t as[64], bs[64], ar[64], br[64], pl[65], pn[65];
             for (int q = 0; q < Q; q++) { as[q] = loc[8 * q]; bs[q] = loc[8 * q + 1]; ar[q] = loc[8 * q + 4]; br[q] = loc[8 * q + 5]; }
             for (int q = 0; q <= Q; q++) { pl[q] = recombine(op_pl + 16 * q); pn[q] = recombine(op_pn + 16 * q); }
-            folded = fold_logup(folded, Q, as, bs, ar, br, pl, pn, gamma, beta_l, sel_first, sel_trans, sel_last, alpha);
+            folded = fold_logup(folded, Q, as, bs, ar, br, pl, pn, gamma, beta_l, sel_first, sel_trans, sel_last, alpha, bb4_zero());
         }
         free(loc); free(nxt);
         /* quotient(zeta) = sum_k zps_k(zeta) * q_k(zeta); chunk domain k: shift s_k = g w_2N^k */

@@ -12,5 +12,5 @@ void orc__copy_path(uint32_t* pf, size_t* pos, const uint32_t* tree, size_t leav
 bb4_t orc__recombine(const uint32_t* opened4);
 bb4_t orc__fold_logup(bb4_t acc, int pairs, const bb4_t* as, const bb4_t* bs, const bb4_t* ar, const bb4_t* br,
                      const bb4_t* perm_local, const bb4_t* perm_next, bb4_t gamma, bb4_t beta,
-                     bb4_t sel_first, bb4_t sel_trans, bb4_t sel_last, bb4_t alpha);
+                     bb4_t sel_first, bb4_t sel_trans, bb4_t sel_last, bb4_t alpha, bb4_t cumsum);
 #endif

@@ -325,7 +325,14 @@ def prove_debug():
             for k, _ in ProveDebug._fields_}
 
 
-def prove_chips(traces, public_values=(), params=None, pairs=None):
+def gen_trace_logup_cross(seed, shard, partner_shard, log_n, width, partner_width, pairs):
+    out = np.empty(((1 << log_n), width), dtype=np.uint32)
+    lib().orc_gen_trace_logup_cross(C.c_uint64(seed), C.c_uint64(shard), C.c_uint64(partner_shard), C.c_int(log_n), C.c_size_t(width),
+                                    C.c_size_t(partner_width), C.c_int(pairs), _p(out))
+    return out
+
+
+def prove_chips(traces, public_values=(), params=None, pairs=None, partners=None):
     """traces: list of row-major canonical matrices, tallest first; pairs: in-table LogUp pairs per chip (or None)"""
     params = params or default_params()
     ts = [_u32(t) for t in traces]
@@ -338,18 +345,19 @@ def prove_chips(traces, public_values=(), params=None, pairs=None):
     L.orc_chips_proof_size.restype = C.c_size_t
     L.orc_prove_chips.restype = C.c_size_t
     pr_ = (C.c_int * n)(*[int(x) for x in pairs]) if pairs is not None else None
-    size = L.orc_chips_proof_size(log_ns, widths, pr_, C.c_int(n), C.byref(params), C.c_size_t(pv.size))
+    pa_ = (C.c_int * n)(*[int(x) for x in partners]) if partners is not None else None
+    size = L.orc_chips_proof_size(log_ns, widths, pr_, pa_, C.c_int(n), C.byref(params), C.c_size_t(pv.size))
     if size == 0:
         raise RuntimeError("oracle: bad chip set")
     buf = np.empty(size, dtype=np.uint8)
-    got = L.orc_prove_chips(ptrs, log_ns, widths, pr_, C.c_int(n), _p(pv), C.c_size_t(pv.size), C.byref(params),
+    got = L.orc_prove_chips(ptrs, log_ns, widths, pr_, pa_, C.c_int(n), _p(pv), C.c_size_t(pv.size), C.byref(params),
                             buf.ctypes.data_as(C.POINTER(C.c_uint8)), C.c_size_t(size))
     if got != size:
         raise RuntimeError("oracle prove_chips failed")
     return buf
 
 
-def verify_chips(proof, log_ns, widths, public_values=(), params=None, pairs=None):
+def verify_chips(proof, log_ns, widths, public_values=(), params=None, pairs=None, partners=None):
     params = params or default_params()
     pr = np.ascontiguousarray(proof, dtype=np.uint8)
     n = len(log_ns)
@@ -357,7 +365,8 @@ def verify_chips(proof, log_ns, widths, public_values=(), params=None, pairs=Non
     ws = (C.c_size_t * n)(*[int(x) for x in widths])
     pv = _u32(np.array(public_values, dtype=np.uint32))
     pr_ = (C.c_int * n)(*[int(x) for x in pairs]) if pairs is not None else None
-    return int(lib().orc_verify_chips(pr.ctypes.data_as(C.POINTER(C.c_uint8)), C.c_size_t(pr.size), ln, ws, pr_, C.c_int(n),
+    pa_ = (C.c_int * n)(*[int(x) for x in partners]) if partners is not None else None
+    return int(lib().orc_verify_chips(pr.ctypes.data_as(C.POINTER(C.c_uint8)), C.c_size_t(pr.size), ln, ws, pr_, pa_, C.c_int(n),
                                       _p(pv), C.c_size_t(pv.size), C.byref(params)))
 
 

@@ -27,9 +27,9 @@ int main(void) {
     for (int c = 0; c < 4; c++) { uint32_t* t = malloc(((size_t)1 << lns[c]) * ws[c] * 4); orc_gen_trace(9, c, lns[c], ws[c], t); tr[c] = t; }
     orc_params_t p = {2, 8, 4, 0, 0, 0, 0};
     zkhip_params zp = {2, 8, 4, 0, 0, 0, 0};
-    size_t sz = orc_chips_proof_size(lns, ws, NULL, 4, &p, 0);
+    size_t sz = orc_chips_proof_size(lns, ws, NULL, NULL, 4, &p, 0);
     uint8_t* pf = malloc(sz);
-    orc_prove_chips(tr, lns, ws, NULL, 4, NULL, 0, &p, pf, sz);
+    orc_prove_chips(tr, lns, ws, NULL, NULL, 4, NULL, 0, &p, pf, sz);
     int reason = 0;
     int rc = zkhip_verify_chips(pf, sz, l32, w32, NULL, 4, NULL, 0, &zp, &reason);
     printf("chips: host verifier rc %d reason %d\n", rc, reason);

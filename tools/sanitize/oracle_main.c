@@ -25,10 +25,10 @@ int main(void) {
     const uint32_t* tr[4];
     for (int c = 0; c < 4; c++) { uint32_t* t = malloc(((size_t)1 << lns[c]) * ws[c] * 4); orc_gen_trace(9, c, lns[c], ws[c], t); tr[c] = t; }
     orc_params_t p = {2, 8, 4, 0, 0, 0, 0};
-    size_t sz = orc_chips_proof_size(lns, ws, NULL, 4, &p, 0);
+    size_t sz = orc_chips_proof_size(lns, ws, NULL, NULL, 4, &p, 0);
     uint8_t* pf = malloc(sz);
-    size_t got = orc_prove_chips(tr, lns, ws, NULL, 4, NULL, 0, &p, pf, sz);
-    int rc = orc_verify_chips(pf, got, lns, ws, NULL, 4, NULL, 0, &p);
+    size_t got = orc_prove_chips(tr, lns, ws, NULL, NULL, 4, NULL, 0, &p, pf, sz);
+    int rc = orc_verify_chips(pf, got, lns, ws, NULL, NULL, 4, NULL, 0, &p);
     printf("chips: size %zu got %zu verify %d\n", sz, got, rc);
     if (got != sz || rc) fails++;
     for (int c = 0; c < 4; c++) free((void*)tr[c]);
