@@ -124,6 +124,11 @@ int zkhip_gen_trace(zkhip_ctx* ctx, uint64_t seed, uint64_t shard, int log_n, ui
 int zkhip_gen_trace_logup(zkhip_ctx* ctx, uint64_t seed, uint64_t shard, int log_n, uint32_t width,
                           int pairs, uint32_t* d_out, size_t ld);
 
+/* lookups BETWEEN two tables of equal height (zkhip_chip.partner): this table's receiver groups hold the sender groups of
+ * the partner table (stream seed + partner_shard, row pitch partner_width) under the same row permutation */
+int zkhip_gen_trace_logup_cross(zkhip_ctx* ctx, uint64_t seed, uint64_t shard, uint64_t partner_shard, int log_n, uint32_t width,
+                                uint32_t partner_width, int pairs, uint32_t* d_out, size_t ld);
+
 /* ---- NTT / LDE over the columns of a row-major matrix, 2^log_n rows, 0 <= log_n <= 20 (fewer than 32 rows: by
  * definition, out of place) ---- */
 /* forward DFT: natural rows in; rows out natural (bitrev_out = 0) or bit-reversed (1);
@@ -236,19 +241,25 @@ int zkhip_verify_shard(const uint8_t* proof, size_t len, int log_n, uint32_t wid
  * FRI vector when folding reaches it, one FRI proof.  Chips tallest first, log_n in [5, 20], at most 4 per height and 16
  * in all; zkhip_params: any log_blowup, the SP1 FRI shape (log_fold / log_final / hash_width / logup_pairs 0).
  * A chip may carry in-table LogUp pairs (logup_pairs > 0, trace from zkhip_gen_trace_logup): the permutation traces of
- * those chips are committed together in a third mixed-height tree (sp1-stark's permutation commitment).  `pairs` arrays
- * below may be NULL (no lookups). ---- */
+ * those chips are committed together in a third mixed-height tree (sp1-stark's permutation commitment).  Two chips of
+ * equal height and pair count may look EACH OTHER up (partner = the other chip's index, mutual; traces from
+ * zkhip_gen_trace_logup_cross): every chip with pairs then exposes the final value of its running sum in the proof and the
+ * verifier checks that these add up to zero (sp1-stark's local cumulative sums).  `pairs` / `partners` arrays below may be
+ * NULL (no lookups / none between chips). ---- */
 typedef struct {
     const uint32_t* d_trace;    /* device, row-major 2^log_n x ld words, Montgomery */
     size_t ld;
     int32_t log_n;
     uint32_t width;
     int32_t logup_pairs;        /* 0: none */
+    int32_t partner;            /* -1: lookups stay inside the chip; otherwise the index of the chip it exchanges lookups with */
 } zkhip_chip;
-size_t zkhip_chips_proof_size(const int32_t* log_ns, const uint32_t* widths, const int32_t* pairs, int n_chips, const zkhip_params* prm, size_t n_public);
+size_t zkhip_chips_proof_size(const int32_t* log_ns, const uint32_t* widths, const int32_t* pairs, const int32_t* partners, int n_chips,
+                              const zkhip_params* prm, size_t n_public);
 int zkhip_prove_chips(zkhip_ctx* ctx, const zkhip_chip* chips, int n_chips, const uint32_t* public_values, size_t n_public,
                       const zkhip_params* prm, uint8_t* proof, size_t cap, size_t* len);
-int zkhip_verify_chips(const uint8_t* proof, size_t len, const int32_t* log_ns, const uint32_t* widths, const int32_t* pairs, int n_chips,
+int zkhip_verify_chips(const uint8_t* proof, size_t len, const int32_t* log_ns, const uint32_t* widths, const int32_t* pairs,
+                       const int32_t* partners, int n_chips,
                        const uint32_t* public_values, size_t n_public, const zkhip_params* prm, int* reason);
 
 /* intermediates of the last zkhip_prove_shard on this context (canonical words) */

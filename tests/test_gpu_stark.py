@@ -419,3 +419,68 @@ def test_prove_chips_with_lookups_bytes_equal_oracle(ctx, oracle, chips, prm):
     assert verify_chips(proof, lns, ws, [3, 4], params, None)[0] == -6          # not a proof of the lookup-free statement
     for d in dev:
         d[0].free()
+
+
+CROSS_SETS = [
+    # (log_n, width, pairs, partner)
+    ([(9, 16, 2, 1), (9, 24, 2, 0), (7, 8, 1, -1), (6, 4, 0, -1)], (1, 12, 4)),
+    ([(8, 8, 1, 1), (8, 8, 1, 0)], (1, 8, 0)),
+    ([(11, 32, 0, -1), (10, 40, 3, 2), (10, 24, 3, 1), (10, 8, 1, -1), (6, 16, 2, 5), (6, 16, 2, 4)], (2, 20, 6)),
+]
+
+
+def _cross_traces(gen_cross, gen_logup, gen_plain, chips):
+    out = []
+    for i, (ln, w, pr, pa) in enumerate(chips):
+        if pa >= 0:
+            out.append(gen_cross(SEED, i, pa, ln, w, chips[pa][1], pr))
+        elif pr:
+            out.append(gen_logup(SEED, i, ln, w, pr))
+        else:
+            out.append(gen_plain(SEED, i, ln, w))
+    return out
+
+
+@pytest.mark.parametrize("chips,prm", CROSS_SETS)
+def test_prove_chips_with_lookups_between_chips(ctx, oracle, chips, prm):
+    # two chips of equal height hold each other's sender columns: every chip exposes the end of its running sum, the sums
+    # cancel over the shard (sp1-stark's local cumulative sums; proof version 6)
+    from zktls_amd.device import verify_chips
+    params, oparams = Params(*prm), oracle.default_params(*prm)
+    dtr = _cross_traces(ctx.gen_trace_logup_cross, ctx.gen_trace_logup, ctx.gen_trace, chips)
+    htr = _cross_traces(oracle.gen_trace_logup_cross, oracle.gen_trace_logup, oracle.gen_trace, chips)
+    for d, h in zip(dtr, htr):
+        assert (d.download().reshape(h.shape) == h).all()
+        assert oracle.check_trace(h) == 0
+    lns, ws, prs, pas = ([c[k] for c in chips] for k in range(4))
+    proof = ctx.prove_chips([(d, ln, w, pr, pa) for d, (ln, w, pr, pa) in zip(dtr, chips)], [9], params)
+    assert proof.tobytes() == oracle.prove_chips(htr, [9], oparams, prs, pas).tobytes()
+    assert verify_chips(proof, lns, ws, [9], params, prs, pas) == (0, 0)
+    assert oracle.verify_chips(proof, lns, ws, [9], oparams, prs, pas) == 0
+    for d in dtr:
+        d.free()
+
+
+def test_lookups_between_chips_must_balance(ctx, oracle):
+    from zktls_amd._lib import ZkHipError
+    from zktls_amd.device import verify_chips
+    chips = [(8, 8, 1, 1), (8, 8, 1, 0)]
+    prm = Params(1, 6, 0)
+    good = _cross_traces(ctx.gen_trace_logup_cross, ctx.gen_trace_logup, ctx.gen_trace, chips)
+    # chip 0 receives from a stream that is NOT chip 1's: the exposed sums no longer cancel (check 11)
+    bad0 = ctx.gen_trace_logup_cross(SEED, 0, 5, 8, 8, 8, 1)
+    try:
+        proof = ctx.prove_chips([(bad0, 8, 8, 1, 1), (good[1], 8, 8, 1, 0)], [], prm)
+    except ZkHipError as e:
+        assert e.code == -1
+    else:
+        assert verify_chips(proof, [8, 8], [8, 8], [], prm, [1, 1], [1, 0]) == (-6, 11)
+    # the honest cross traces claimed as lookups INSIDE each chip: the running sums do not end at zero (check 10)
+    try:
+        proof = ctx.prove_chips([(good[0], 8, 8, 1), (good[1], 8, 8, 1)], [], prm)
+    except ZkHipError as e:
+        assert e.code == -1
+    else:
+        assert verify_chips(proof, [8, 8], [8, 8], [], prm, [1, 1], None) == (-6, 10)
+    with pytest.raises(ZkHipError):
+        ctx.prove_chips([(good[0], 8, 8, 1, 1), (good[1], 8, 8, 1, -1)], [], prm)          # partnership must be mutual

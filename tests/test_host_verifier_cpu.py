@@ -112,3 +112,26 @@ def test_host_verifier_agrees_with_oracle_on_multi_chip_lookups(oracle, chips, p
         bad = pf.copy(); bad[int(pf.size * frac)] ^= 1
         rc, reason = verify_chips(bad, lns, ws, [1, 2], params, pairs)
         assert rc == -6 and reason == oracle.verify_chips(bad, lns, ws, [1, 2], oprm, pairs)
+
+
+def test_host_verifier_agrees_with_oracle_on_lookups_between_chips(oracle):
+    from zktls_amd.device import verify_chips
+    chips = [(9, 16, 2, 1), (9, 24, 2, 0), (7, 8, 1, -1), (6, 4, 0, -1)]
+    traces = []
+    for i, (ln, w, pr, pa) in enumerate(chips):
+        traces.append(oracle.gen_trace_logup_cross(SEED, i, pa, ln, w, chips[pa][1], pr) if pa >= 0 else
+                      (oracle.gen_trace_logup(SEED, i, ln, w, pr) if pr else oracle.gen_trace(SEED, i, ln, w)))
+    lns, ws, prs, pas = ([c[k] for c in chips] for k in range(4))
+    oprm, prm = oracle.default_params(1, 12, 4), Params(1, 12, 4)
+    pf = oracle.prove_chips(traces, [1], oprm, prs, pas)
+    assert verify_chips(pf, lns, ws, [1], prm, prs, pas) == (0, 0)
+    for frac in (0.01, 0.03, 0.05, 0.1, 0.2, 0.4, 0.6, 0.9):
+        bad = pf.copy(); bad[int(pf.size * frac)] ^= 1
+        rc, reason = verify_chips(bad, lns, ws, [1], prm, prs, pas)
+        assert rc == -6 and reason == oracle.verify_chips(bad, lns, ws, [1], oprm, prs, pas)
+    # an unbalanced shard: chip 0 received from somebody else
+    t2 = list(traces)
+    t2[0] = oracle.gen_trace_logup_cross(SEED, 0, 3, 9, 16, 24, 2)
+    pf2 = oracle.prove_chips(t2, [1], oprm, prs, pas)
+    assert oracle.verify_chips(pf2, lns, ws, [1], oprm, prs, pas) == 11
+    assert verify_chips(pf2, lns, ws, [1], prm, prs, pas) == (-6, 11)

@@ -31,7 +31,7 @@ int main(void) {
     uint8_t* pf = malloc(sz);
     orc_prove_chips(tr, lns, ws, NULL, NULL, 4, NULL, 0, &p, pf, sz);
     int reason = 0;
-    int rc = zkhip_verify_chips(pf, sz, l32, w32, NULL, 4, NULL, 0, &zp, &reason);
+    int rc = zkhip_verify_chips(pf, sz, l32, w32, NULL, NULL, 4, NULL, 0, &zp, &reason);
     printf("chips: host verifier rc %d reason %d\n", rc, reason);
     if (rc) fails++;
     for (int c = 0; c < 4; c++) free((void*)tr[c]);

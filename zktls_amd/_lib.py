@@ -19,7 +19,7 @@ EXPORTS = [
     "zkhip_version", "zkhip_last_error", "zkhip_device_count", "zkhip_ctx_create", "zkhip_ctx_destroy",
     "zkhip_ctx_sync", "zkhip_ctx_stream", "zkhip_malloc", "zkhip_free", "zkhip_memcpy_h2d",
     "zkhip_memcpy_d2h", "zkhip_to_monty", "zkhip_from_monty", "zkhip_fill_uniform", "zkhip_gen_trace",
-    "zkhip_gen_trace_logup", "zkhip_perm_trace",
+    "zkhip_gen_trace_logup", "zkhip_gen_trace_logup_cross", "zkhip_perm_trace",
     "zkhip_dft", "zkhip_coset_lde", "zkhip_ntt_pass", "zkhip_poseidon2_permute", "zkhip_hash_rows",
     "zkhip_merkle_commit", "zkhip_merkle_commit_mixed", "zkhip_merkle_commit_p24_colmajor", "zkhip_batch_interpolate_colmajor", "zkhip_batch_expand_colmajor", "zkhip_quotient_values", "zkhip_open_at", "zkhip_fri_fold", "zkhip_fri_fold_k",
     "zkhip_commit", "zkhip_proof_size", "zkhip_prove_shard", "zkhip_prove_shard_host", "zkhip_prove_segment", "zkhip_verify_shard", "zkhip_last_prove_debug",
@@ -45,7 +45,7 @@ def segment_params(num_queries=50, logup_pairs=0, log_final=8):
 
 
 class Chip(C.Structure):
-    _fields_ = [("d_trace", C.c_void_p), ("ld", C.c_size_t), ("log_n", C.c_int32), ("width", C.c_uint32), ("logup_pairs", C.c_int32)]
+    _fields_ = [("d_trace", C.c_void_p), ("ld", C.c_size_t), ("log_n", C.c_int32), ("width", C.c_uint32), ("logup_pairs", C.c_int32), ("partner", C.c_int32)]
 
 
 class ProveDebug(C.Structure):
@@ -115,10 +115,11 @@ def load():
     L.zkhip_last_prove_debug.argtypes = [C.c_void_p, C.POINTER(ProveDebug)]
     i32p = C.POINTER(C.c_int32)
     L.zkhip_chips_proof_size.restype = C.c_size_t
-    L.zkhip_chips_proof_size.argtypes = [i32p, u32p, i32p, C.c_int, C.POINTER(Params), C.c_size_t]
+    L.zkhip_chips_proof_size.argtypes = [i32p, u32p, i32p, i32p, C.c_int, C.POINTER(Params), C.c_size_t]
+    L.zkhip_gen_trace_logup_cross.argtypes = [C.c_void_p, C.c_uint64, C.c_uint64, C.c_uint64, C.c_int, C.c_uint32, C.c_uint32, C.c_int, C.c_void_p, C.c_size_t]
     L.zkhip_prove_chips.argtypes = [C.c_void_p, C.POINTER(Chip), C.c_int, u32p, C.c_size_t, C.POINTER(Params), u8p, C.c_size_t,
                                     C.POINTER(C.c_size_t)]
-    L.zkhip_verify_chips.argtypes = [u8p, C.c_size_t, i32p, u32p, i32p, C.c_int, u32p, C.c_size_t, C.POINTER(Params), C.POINTER(C.c_int)]
+    L.zkhip_verify_chips.argtypes = [u8p, C.c_size_t, i32p, u32p, i32p, i32p, C.c_int, u32p, C.c_size_t, C.POINTER(Params), C.POINTER(C.c_int)]
     _LIB = L
     return L
 

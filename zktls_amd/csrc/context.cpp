@@ -416,7 +416,17 @@ int zkhip_gen_trace_logup(zkhip_ctx* ctx, uint64_t seed, uint64_t shard, int log
     CHECK_CTX(ctx);
     if (log_n < 0 || log_n > 30 || width == 0 || width % 4 != 0 || ld < width || !d_out || pairs < 0 || (uint32_t)pairs * 8 > width)
         return fail(ZKHIP_ERR_INVALID, "gen_trace_logup: width must be a multiple of 4 and hold 2 groups per pair");
-    ZK_HIP(launch_gen_trace_logup(d_out, ld, seed + shard, (uint64_t)1 << log_n, width, (uint32_t)pairs, ctx->stream));
+    ZK_HIP(launch_gen_trace_logup(d_out, ld, seed + shard, (uint64_t)1 << log_n, width, (uint32_t)pairs, seed + shard, width, ctx->stream));
+    return ZKHIP_OK;
+}
+
+int zkhip_gen_trace_logup_cross(zkhip_ctx* ctx, uint64_t seed, uint64_t shard, uint64_t partner_shard, int log_n, uint32_t width,
+                                uint32_t partner_width, int pairs, uint32_t* d_out, size_t ld) {
+    CHECK_CTX(ctx);
+    if (log_n < 0 || log_n > 30 || width == 0 || width % 4 != 0 || ld < width || !d_out || pairs < 1 || (uint32_t)pairs * 8 > width ||
+        partner_width % 4 != 0 || (uint32_t)pairs * 8 > partner_width)
+        return fail(ZKHIP_ERR_INVALID, "gen_trace_logup_cross: both tables need 2 groups per pair");
+    ZK_HIP(launch_gen_trace_logup(d_out, ld, seed + shard, (uint64_t)1 << log_n, width, (uint32_t)pairs, seed + partner_shard, partner_width, ctx->stream));
     return ZKHIP_OK;
 }
 

@@ -81,8 +81,8 @@ hipError_t launch_fill_uniform(uint32_t* out, uint64_t ld, uint64_t seed, uint64
                                uint32_t width, hipStream_t s);
 hipError_t launch_gen_trace(uint32_t* out, uint64_t ld, uint64_t seed, uint64_t rows,
                             uint32_t width, hipStream_t s);
-hipError_t launch_gen_trace_logup(uint32_t* out, uint64_t ld, uint64_t seed, uint64_t rows, uint32_t width,
-                                  uint32_t pairs, hipStream_t s);
+hipError_t launch_gen_trace_logup(uint32_t* out, uint64_t ld, uint64_t seed, uint64_t rows, uint32_t width, uint32_t pairs,
+                                  uint64_t recv_seed, uint32_t recv_width, hipStream_t s);
 // [rows][cols] -> [cols][rows], optional bit reversal of the column index on either side
 // naive evaluation for N < 32: out[row(k)] = scale * sum_j in[j] (shift w^k)^j (see util.hip)
 hipError_t launch_small_eval(const uint32_t* in, uint64_t in_ld, uint32_t* out, uint64_t out_ld, int log_n, int log_out, uint32_t width,
@@ -113,6 +113,7 @@ struct QuotientArgs {
     const uint32_t* perm;
     uint64_t perm_ld;
     Ext gamma, beta;
+    Ext cumsum;                 // last-row constraint S = cumsum (zero unless tables look each other up)
     const uint32_t* sel_last;
     uint32_t* out;              // [2][N][4]: chunk k, natural row j
 };

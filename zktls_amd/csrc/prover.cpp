@@ -120,6 +120,7 @@ static int h2d(zkhip_ctx* ctx, void* dst, const void* src, size_t bytes) {
 }
 
 struct LogupIn {
+    Ext cumsum = ext_zero();              // last-row constraint S = cumsum
     uint32_t pairs = 0;
     const uint32_t* perm_lde = nullptr;   // [2N][4 (pairs + 1)]
     Ext gamma = ext_zero(), beta = ext_zero();
@@ -158,7 +159,7 @@ static int run_quotient(zkhip_ctx* ctx, const uint32_t* lde, size_t ld, int log_
     q.inv_zh_odd = finv(fsub(fneg(gn), MONTY_R1));
     q.alpha_pow = (const uint32_t*)d_ap;
     q.pairs = lu.pairs; q.perm = lu.perm_lde; q.perm_ld = 4 * ((uint64_t)lu.pairs + 1);
-    q.gamma = lu.gamma; q.beta = lu.beta; q.sel_last = ctx->dom_sel_last;
+    q.gamma = lu.gamma; q.beta = lu.beta; q.cumsum = lu.cumsum; q.sel_last = ctx->dom_sel_last;
     q.out = out_chunks;
     ZK_HIP(launch_quotient(q, ctx->stream));
     return ZKHIP_OK;
@@ -996,12 +997,16 @@ int zkhip_verify_shard(const uint8_t* proof, size_t len, int log_n, uint32_t wid
 // vector per height that joins the FRI vector when folding reaches that height (p3-fri 0.2.1 TwoAdicFriPcs), one query
 // index with chip c opened at index >> (Hmax - h_c).  Byte layout: DESIGN.md section 6.
 namespace zk {
-constexpr uint32_t CHIPS_VERSION = 4u, CHIPS_VERSION_LOGUP = 5u;
+constexpr uint32_t CHIPS_VERSION = 4u, CHIPS_VERSION_LOGUP = 5u, CHIPS_VERSION_CROSS = 6u;
 constexpr int MAX_CHIPS = 16;
 
 static bool any_pairs(const int32_t* pairs, int n) { if (pairs) for (int c = 0; c < n; c++) if (pairs[c]) return true; return false; }
 static size_t perm_width(const int32_t* pairs, int c) { return (pairs && pairs[c]) ? 4 * ((size_t)pairs[c] + 1) : 0; }
-static int check_chips(const int32_t* log_ns, const uint32_t* widths, const int32_t* pairs, int n, const zkhip_params* prm) {
+static bool any_cross(const int32_t* partners, int n) { if (partners) for (int c = 0; c < n; c++) if (partners[c] >= 0) return true; return false; }
+static uint32_t chips_version(const int32_t* pairs, const int32_t* partners, int n) {
+    return any_cross(partners, n) ? CHIPS_VERSION_CROSS : (any_pairs(pairs, n) ? CHIPS_VERSION_LOGUP : CHIPS_VERSION);
+}
+static int check_chips(const int32_t* log_ns, const uint32_t* widths, const int32_t* pairs, const int32_t* partners, int n, const zkhip_params* prm) {
     if (!prm || !log_ns || !widths) return fail(ZKHIP_ERR_INVALID, "chips: null argument");
     if (n < 1 || n > MAX_CHIPS) return fail(ZKHIP_ERR_INVALID, "chips: 1..16 chips");
     if (prm->log_blowup < 1 || prm->log_blowup > 3) return fail(ZKHIP_ERR_INVALID, "chips: log_blowup in [1,3]");
@@ -1013,19 +1018,24 @@ static int check_chips(const int32_t* log_ns, const uint32_t* widths, const int3
             return fail(ZKHIP_ERR_INVALID, "chips: log_n in [5,20], width a multiple of 4 up to 1024");
         if (c && log_ns[c] > log_ns[c - 1]) return fail(ZKHIP_ERR_INVALID, "chips: tallest first");
         if (pairs && (pairs[c] < 0 || pairs[c] > 64 || (uint32_t)pairs[c] * 8 > widths[c])) return fail(ZKHIP_ERR_INVALID, "chips: logup_pairs out of range");
+        if (partners && partners[c] >= 0) {
+            const int d = partners[c];
+            if (!pairs || d >= n || d == c || partners[d] != c || pairs[c] == 0 || pairs[d] != pairs[c] || log_ns[d] != log_ns[c])
+                return fail(ZKHIP_ERR_INVALID, "chips: partners must be mutual, of equal height and pair count");
+        } else if (partners && partners[c] < -1) return fail(ZKHIP_ERR_INVALID, "chips: bad partner index");
         int same = 0;
         for (int d = 0; d < n; d++) same += log_ns[d] == log_ns[c];
         if (same > MAX_LEAF_MATS) return fail(ZKHIP_ERR_INVALID, "chips: at most 4 chips per height");
     }
     return ZKHIP_OK;
 }
-static size_t chips_proof_words(const int32_t* log_ns, const uint32_t* widths, const int32_t* pairs, int n, const zkhip_params* prm) {
-    const bool lk = any_pairs(pairs, n);
+static size_t chips_proof_words(const int32_t* log_ns, const uint32_t* widths, const int32_t* pairs, const int32_t* partners, int n, const zkhip_params* prm) {
+    const bool lk = any_pairs(pairs, n), cross = any_cross(partners, n);
     const size_t b = (size_t)prm->log_blowup, Hmax = (size_t)log_ns[0] + b, L = (size_t)log_ns[0];
-    size_t words = 8 + (lk ? 3 : 2) * (size_t)n + 16 + (lk ? 8 : 0) + 8 * L + 4 + 1, perq = 16 * Hmax, hp = 0;
+    size_t words = 8 + (cross ? 4 : (lk ? 3 : 2)) * (size_t)n + 16 + (lk ? 8 : 0) + 8 * L + 4 + 1, perq = 16 * Hmax, hp = 0;
     for (int c = 0; c < n; c++) {
         const size_t wp = perm_width(pairs, c);
-        words += 8 * (size_t)widths[c] + 8 * wp + 32;
+        words += 8 * (size_t)widths[c] + 8 * wp + 32 + ((cross && wp) ? 4 : 0);
         perq += widths[c] + wp + 8;
         if (wp && (size_t)log_ns[c] + b > hp) hp = (size_t)log_ns[c] + b;
     }
@@ -1033,9 +1043,10 @@ static size_t chips_proof_words(const int32_t* log_ns, const uint32_t* widths, c
     for (size_t l = 0; l < L; l++) perq += 4 + 8 * (Hmax - 1 - l);
     return words + (size_t)prm->num_queries * perq;
 }
-static void chips_transcript_init(Challenger& ch, const int32_t* log_ns, const uint32_t* widths, const int32_t* pairs, int n, const zkhip_params* prm, size_t n_public) {
-    const bool lk = any_pairs(pairs, n);
-    ch.observe_canonical(lk ? CHIPS_VERSION_LOGUP : CHIPS_VERSION);
+static void chips_transcript_init(Challenger& ch, const int32_t* log_ns, const uint32_t* widths, const int32_t* pairs, const int32_t* partners, int n,
+                                  const zkhip_params* prm, size_t n_public) {
+    const bool lk = any_pairs(pairs, n), cross = any_cross(partners, n);
+    ch.observe_canonical(chips_version(pairs, partners, n));
     ch.observe_canonical((uint32_t)n);
     ch.observe_canonical((uint32_t)prm->log_blowup);
     ch.observe_canonical((uint32_t)prm->num_queries);
@@ -1044,6 +1055,7 @@ static void chips_transcript_init(Challenger& ch, const int32_t* log_ns, const u
     for (int c = 0; c < n; c++) {
         ch.observe_canonical((uint32_t)log_ns[c]); ch.observe_canonical(widths[c]);
         if (lk) ch.observe_canonical((uint32_t)pairs[c]);
+        if (cross) ch.observe_canonical((uint32_t)(partners[c] + 1));
     }
 }
 // alpha-power offset of chip c inside the reduced-opening vector of its height
@@ -1054,26 +1066,29 @@ static uint64_t height_offset(const int32_t* log_ns, const uint32_t* widths, con
 }
 }  // namespace zk
 
-size_t zkhip_chips_proof_size(const int32_t* log_ns, const uint32_t* widths, const int32_t* pairs, int n_chips, const zkhip_params* prm, size_t n_public) {
+size_t zkhip_chips_proof_size(const int32_t* log_ns, const uint32_t* widths, const int32_t* pairs, const int32_t* partners, int n_chips,
+                              const zkhip_params* prm, size_t n_public) {
     (void)n_public;
-    if (check_chips(log_ns, widths, pairs, n_chips, prm) != ZKHIP_OK) return 0;
-    return chips_proof_words(log_ns, widths, pairs, n_chips, prm) * 4;
+    if (check_chips(log_ns, widths, pairs, partners, n_chips, prm) != ZKHIP_OK) return 0;
+    return chips_proof_words(log_ns, widths, pairs, partners, n_chips, prm) * 4;
 }
 
 int zkhip_prove_chips(zkhip_ctx* ctx, const zkhip_chip* chips, int n, const uint32_t* public_values, size_t n_public,
                       const zkhip_params* prm, uint8_t* proof, size_t cap, size_t* len) {
     CHECK_CTX(ctx);
     if (!chips || !proof || !len || (n_public && !public_values)) return fail(ZKHIP_ERR_INVALID, "prove_chips: bad arguments");
-    int32_t log_ns[MAX_CHIPS], pairs[MAX_CHIPS]; uint32_t widths[MAX_CHIPS];
+    int32_t log_ns[MAX_CHIPS], pairs[MAX_CHIPS], partners[MAX_CHIPS]; uint32_t widths[MAX_CHIPS];
     if (n < 1 || n > MAX_CHIPS) return fail(ZKHIP_ERR_INVALID, "chips: 1..16 chips");
     for (int c = 0; c < n; c++) {
-        log_ns[c] = chips[c].log_n; widths[c] = chips[c].width; pairs[c] = chips[c].logup_pairs;
+        log_ns[c] = chips[c].log_n; widths[c] = chips[c].width; pairs[c] = chips[c].logup_pairs; partners[c] = chips[c].partner;
         if (!chips[c].d_trace || chips[c].ld < chips[c].width) return fail(ZKHIP_ERR_INVALID, "prove_chips: bad chip descriptor");
     }
-    ZK_TRY(check_chips(log_ns, widths, pairs, n, prm));
+    ZK_TRY(check_chips(log_ns, widths, pairs, partners, n, prm));
     for (size_t i = 0; i < n_public; i++) if (public_values[i] >= P) return fail(ZKHIP_ERR_INVALID, "prove_chips: public values must be canonical");
-    const size_t need = chips_proof_words(log_ns, widths, pairs, n, prm) * 4;
-    const bool lk = any_pairs(pairs, n);
+    const size_t need = chips_proof_words(log_ns, widths, pairs, partners, n, prm) * 4;
+    const bool lk = any_pairs(pairs, n), cross = any_cross(partners, n);
+    Ext cumsum[MAX_CHIPS];
+    for (int c = 0; c < n; c++) cumsum[c] = ext_zero();
     if (cap < need) return fail(ZKHIP_ERR_BUFFER, "prove_chips: proof buffer too small (see zkhip_chips_proof_size)");
     *len = 0;
     hipStream_t st = ctx->stream;
@@ -1104,11 +1119,15 @@ int zkhip_prove_chips(zkhip_ctx* ctx, const zkhip_chip* chips, int n, const uint
     }
     uint32_t* pf = (uint32_t*)proof;
     size_t pos = 0;
-    pf[pos++] = PROOF_MAGIC; pf[pos++] = lk ? CHIPS_VERSION_LOGUP : CHIPS_VERSION; pf[pos++] = (uint32_t)n; pf[pos++] = (uint32_t)b;
+    pf[pos++] = PROOF_MAGIC; pf[pos++] = chips_version(pairs, partners, n); pf[pos++] = (uint32_t)n; pf[pos++] = (uint32_t)b;
     pf[pos++] = (uint32_t)Q; pf[pos++] = (uint32_t)prm->pow_bits; pf[pos++] = (uint32_t)n_public; pf[pos++] = 16u;
-    for (int c = 0; c < n; c++) { pf[pos++] = (uint32_t)log_ns[c]; pf[pos++] = widths[c]; if (lk) pf[pos++] = (uint32_t)pairs[c]; }
+    for (int c = 0; c < n; c++) {
+        pf[pos++] = (uint32_t)log_ns[c]; pf[pos++] = widths[c];
+        if (lk) pf[pos++] = (uint32_t)pairs[c];
+        if (cross) pf[pos++] = (uint32_t)(partners[c] + 1);
+    }
     Challenger ch;
-    chips_transcript_init(ch, log_ns, widths, pairs, n, prm, n_public);
+    chips_transcript_init(ch, log_ns, widths, pairs, partners, n, prm, n_public);
     uint32_t root[8];
 
     // ---- 1. every chip's LDE, one mixed-height tree
@@ -1145,12 +1164,17 @@ int zkhip_prove_chips(zkhip_ctx* ctx, const zkhip_chip* chips, int n, const uint
         for (int c = 0; c < n; c++) {
             if (!wp[c]) continue;
             ZK_TRY(run_perm_trace(ctx, chips[c].d_trace, chips[c].ld, log_ns[c], (uint32_t)pairs[c], gamma, beta_l, (uint32_t*)v_perm));
+            if (cross)          // the running sum's last value: row N - 1, column S
+                ZK_TRY(d2h(ctx, &cumsum[c], (const uint32_t*)v_perm + (((size_t)1 << log_ns[c]) - 1) * wp[c] + 4 * (size_t)pairs[c], 16));
             ZK_TRY(op_coset_lde(ctx, (const uint32_t*)v_perm, wp[c], plde + pl_off[c], wp[c], log_ns[c], (uint32_t)wp[c], b, MONTY_GEN));
             pmats[np] = MatDesc{plde + pl_off[c], wp[c], (uint32_t)wp[c]}; plh[np] = lh[c]; np++;
         }
         ZK_TRY(op_merkle_commit_mixed(ctx, pmats, plh, np, ptree));
         ZK_TRY(d2h(ctx, root, ptree + (2 * ((size_t)1 << Hp) - 2) * 8, 32));
         for (int i = 0; i < 8; i++) { ch.observe(root[i]); pf[pos++] = from_monty(root[i]); }
+        if (cross)
+            for (int c = 0; c < n; c++)
+                if (wp[c]) { ch.observe_ext(cumsum[c]); for (int e = 0; e < 4; e++) pf[pos++] = from_monty(cumsum[c].c[e]); }
     }
 
     // ---- 2. per-chip quotients on the chip's own coset, chunk LDEs, quotient tree
@@ -1159,7 +1183,7 @@ int zkhip_prove_chips(zkhip_ctx* ctx, const zkhip_chip* chips, int n, const uint
         const size_t nc = (size_t)1 << log_ns[c];
         ZK_TRY(ensure_domain(ctx, log_ns[c], b));
         LogupIn lu;
-        if (wp[c]) { lu.pairs = (uint32_t)pairs[c]; lu.perm_lde = plde + pl_off[c]; lu.gamma = gamma; lu.beta = beta_l; }
+        if (wp[c]) { lu.pairs = (uint32_t)pairs[c]; lu.perm_lde = plde + pl_off[c]; lu.gamma = gamma; lu.beta = beta_l; lu.cumsum = cumsum[c]; }
         ZK_TRY(run_quotient(ctx, tlde + tl_off[c], widths[c], log_ns[c], widths[c], alpha, lu, qchunk));
         const uint32_t w2n = two_adic_generator(log_ns[c] + 1);
         for (int k = 0; k < 2; k++)
@@ -1343,32 +1367,35 @@ static bool verify_mixed(const uint32_t* root_m, int Hmax, size_t index, const u
     return true;
 }
 
-int zkhip_verify_chips(const uint8_t* proof, size_t len, const int32_t* log_ns, const uint32_t* widths, const int32_t* pairs, int n,
+int zkhip_verify_chips(const uint8_t* proof, size_t len, const int32_t* log_ns, const uint32_t* widths, const int32_t* pairs, const int32_t* partners, int n,
                        const uint32_t* public_values, size_t n_public, const zkhip_params* prm, int* reason) {
     int dummy;
     if (!reason) reason = &dummy;
     *reason = 0;
     auto reject = [&](int why) { *reason = why; return fail(ZKHIP_ERR_VERIFY, "proof rejected (check " + std::to_string(why) + ")"); };
-    if (check_chips(log_ns, widths, pairs, n, prm) != ZKHIP_OK) return reject(1);
+    if (check_chips(log_ns, widths, pairs, partners, n, prm) != ZKHIP_OK) return reject(1);
     if (!proof || (n_public && !public_values)) return reject(1);
-    if (len != chips_proof_words(log_ns, widths, pairs, n, prm) * 4) return reject(2);
+    if (len != chips_proof_words(log_ns, widths, pairs, partners, n, prm) * 4) return reject(2);
     const uint32_t* pf = (const uint32_t*)proof;
-    const bool lk = any_pairs(pairs, n);
+    const bool lk = any_pairs(pairs, n), cross = any_cross(partners, n);
     const int b = prm->log_blowup, Hmax = log_ns[0] + b, L = log_ns[0];
-    if (pf[0] != PROOF_MAGIC || pf[1] != (lk ? CHIPS_VERSION_LOGUP : CHIPS_VERSION) || pf[2] != (uint32_t)n || pf[3] != (uint32_t)b ||
+    if (pf[0] != PROOF_MAGIC || pf[1] != chips_version(pairs, partners, n) || pf[2] != (uint32_t)n || pf[3] != (uint32_t)b ||
         pf[4] != (uint32_t)prm->num_queries || pf[5] != (uint32_t)prm->pow_bits || pf[6] != (uint32_t)n_public || pf[7] != 16u) return reject(3);
     size_t pos = 8;
     for (int c = 0; c < n; c++) {
         if (pf[pos] != (uint32_t)log_ns[c] || pf[pos + 1] != widths[c]) return reject(3);
         pos += 2;
         if (lk) { if (pf[pos] != (uint32_t)pairs[c]) return reject(3); pos++; }
+        if (cross) { if (pf[pos] != (uint32_t)(partners[c] + 1)) return reject(3); pos++; }
     }
     for (size_t i = pos; i < len / 4; i++) if (pf[i] >= P) return reject(4);
     for (size_t i = 0; i < n_public; i++) if (public_values[i] >= P) return reject(4);
     int lh[MAX_CHIPS]; uint32_t w8[MAX_CHIPS]; size_t wp[MAX_CHIPS];
     for (int c = 0; c < n; c++) { lh[c] = log_ns[c] + b; w8[c] = 8; wp[c] = perm_width(pairs, c); }
     Challenger ch;
-    chips_transcript_init(ch, log_ns, widths, pairs, n, prm, n_public);
+    chips_transcript_init(ch, log_ns, widths, pairs, partners, n, prm, n_public);
+    Ext cumsum[MAX_CHIPS];
+    for (int c = 0; c < n; c++) cumsum[c] = ext_zero();
     uint32_t troot[8], proot[8] = {0}, qroot[8];
     for (int i = 0; i < 8; i++) { troot[i] = to_monty(pf[pos++]); ch.observe(troot[i]); }
     for (size_t i = 0; i < n_public; i++) ch.observe_canonical(public_values[i]);
@@ -1379,6 +1406,12 @@ int zkhip_verify_chips(const uint8_t* proof, size_t len, const int32_t* log_ns, 
         beta_l = ch.sample_ext();
         for (int i = 0; i < 8; i++) { proot[i] = to_monty(pf[pos++]); ch.observe(proot[i]); }
         for (int c = 0; c < n; c++) if (wp[c]) { pw[np] = (uint32_t)wp[c]; plh[np] = lh[c]; pchip[np] = c; np++; if (lh[c] > Hp) Hp = lh[c]; }
+        if (cross) {
+            Ext total = ext_zero();
+            for (int c = 0; c < n; c++)
+                if (wp[c]) { cumsum[c] = ext_from_canon(pf + pos); pos += 4; ch.observe_ext(cumsum[c]); total = ext_add(total, cumsum[c]); }
+            if (!ext_eq(total, ext_zero())) return reject(11);          // the lookups of the shard do not balance
+        }
     }
     const Ext alpha = ch.sample_ext();
     for (int i = 0; i < 8; i++) { qroot[i] = to_monty(pf[pos++]); ch.observe(qroot[i]); }
@@ -1429,7 +1462,7 @@ int zkhip_verify_chips(const uint8_t* proof, size_t len, const int32_t* log_ns, 
             const Ext S = recombine(&opl[c][4 * LQ]), Sn = recombine(&opn[c][4 * LQ]);
             acc = ext_add(ext_mul(acc, alpha), ext_mul(sel_first, ext_sub(S, sum_l)));
             acc = ext_add(ext_mul(acc, alpha), ext_mul(sel_trans, ext_sub(ext_sub(Sn, S), sum_n)));
-            acc = ext_add(ext_mul(acc, alpha), ext_mul(sel_last, S));
+            acc = ext_add(ext_mul(acc, alpha), ext_mul(sel_last, ext_sub(S, cumsum[c])));
         }
         const uint32_t w2n = two_adic_generator(log_ns[c] + 1);
         const uint32_t s[2] = {MONTY_GEN, fmul(MONTY_GEN, w2n)};

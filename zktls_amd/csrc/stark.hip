@@ -170,7 +170,7 @@ __global__ void __launch_bounds__(256) quotient_kernel(QuotientArgs a) {
             if (lane == 0) {
                 const Ext S = ld_ext(prow + 4 * a.pairs), Sn = ld_ext(pnrow + 4 * a.pairs);
                 const Ext F3 = ext_mul_base(ld_ext(wl + 4 * (a.pairs + 2)), a.sel_last[p]);
-                r = ext_add(r, ext_add(ext_mul(F1, S), ext_add(ext_mul(F2, ext_sub(Sn, S)), ext_mul(F3, S))));
+                r = ext_add(r, ext_add(ext_mul(F1, S), ext_add(ext_mul(F2, ext_sub(Sn, S)), ext_mul(F3, ext_sub(S, a.cumsum)))));
             }
         }
 #pragma unroll

@@ -74,7 +74,10 @@ hipError_t launch_gen_trace(uint32_t* out, uint64_t ld, uint64_t seed, uint64_t 
 
 // same AIR, but the odd group of each of the first `pairs` group pairs RECEIVES the even group's
 // (a, b) under the row permutation pi(i) = 5 i + 3 mod N (the LogUp workload)
-__global__ void gen_trace_logup_kernel(uint32_t* out, uint64_t ld, uint64_t seed, uint64_t rows, uint32_t width, uint32_t pairs) {
+// recv_seed / recv_width: the stream and row pitch the RECEIVER groups read (the table itself, or -- lookups between two
+// tables of equal height -- the partner table)
+__global__ void gen_trace_logup_kernel(uint32_t* out, uint64_t ld, uint64_t seed, uint64_t rows, uint32_t width, uint32_t pairs,
+                                       uint64_t recv_seed, uint32_t recv_width) {
     const uint32_t G = width / 4;
     const uint64_t total = rows * G;
     for (uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; t < total;
@@ -85,15 +88,17 @@ __global__ void gen_trace_logup_kernel(uint32_t* out, uint64_t ld, uint64_t seed
         const uint32_t sg = recv ? g - 1 : g;
         const uint64_t ri = recv ? ((5 * i + 3) & (rows - 1)) : i;
         const uint32_t k1 = to_monty((g + 1) % P), k2 = to_monty((2 * g + 3) % P);
-        uint32_t a = to_monty(synth_value(seed, ri * width + 4 * sg));
-        uint32_t b = to_monty(synth_value(seed, ri * width + 4 * sg + 1));
+        const uint64_t sd = recv ? recv_seed : seed;
+        const uint64_t sw = recv ? recv_width : width;
+        uint32_t a = to_monty(synth_value(sd, ri * sw + 4 * sg));
+        uint32_t b = to_monty(synth_value(sd, ri * sw + 4 * sg + 1));
         uint32_t c = fadd(fmul(fmul(a, a), b), k1);
         uint32_t d;
         if (i == 0) d = to_monty((5 * g + 7) % P);
         else {
             const uint64_t pi = recv ? ((5 * (i - 1) + 3) & (rows - 1)) : i - 1;
-            uint32_t pa = to_monty(synth_value(seed, pi * width + 4 * sg));
-            uint32_t pb = to_monty(synth_value(seed, pi * width + 4 * sg + 1));
+            uint32_t pa = to_monty(synth_value(sd, pi * sw + 4 * sg));
+            uint32_t pb = to_monty(synth_value(sd, pi * sw + 4 * sg + 1));
             uint32_t pc = fadd(fmul(fmul(pa, pa), pb), k1);
             d = fadd(fadd(fmul(pa, pb), pc), k2);
         }
@@ -101,11 +106,12 @@ __global__ void gen_trace_logup_kernel(uint32_t* out, uint64_t ld, uint64_t seed
         p[0] = a; p[1] = b; p[2] = c; p[3] = d;
     }
 }
-hipError_t launch_gen_trace_logup(uint32_t* out, uint64_t ld, uint64_t seed, uint64_t rows, uint32_t width, uint32_t pairs, hipStream_t s) {
+hipError_t launch_gen_trace_logup(uint32_t* out, uint64_t ld, uint64_t seed, uint64_t rows, uint32_t width, uint32_t pairs,
+                                  uint64_t recv_seed, uint32_t recv_width, hipStream_t s) {
     if (rows == 0 || width < 4) return hipSuccess;
     uint64_t total = rows * (width / 4);
     unsigned blocks = (unsigned)((total + 255) / 256 < 16384 ? (total + 255) / 256 : 16384);
-    hipLaunchKernelGGL(gen_trace_logup_kernel, dim3(blocks), dim3(256), 0, s, out, ld, seed, rows, width, pairs);
+    hipLaunchKernelGGL(gen_trace_logup_kernel, dim3(blocks), dim3(256), 0, s, out, ld, seed, rows, width, pairs, recv_seed, recv_width);
     return hipGetLastError();
 }
 

@@ -106,6 +106,11 @@ class Context:
         check(self.lib.zkhip_fill_uniform(self.handle, seed, log_n, width, C.c_void_p(out.ptr), width))
         return out
 
+    def gen_trace_logup_cross(self, seed, shard, partner_shard, log_n, width, partner_width, pairs, out=None):
+        out = out or self.alloc(width << log_n)
+        check(self.lib.zkhip_gen_trace_logup_cross(self.handle, seed, shard, partner_shard, log_n, width, partner_width, pairs, C.c_void_p(out.ptr), width))
+        return out
+
     def gen_trace(self, seed, shard, log_n, width, out=None):
         out = out or self.alloc(width << log_n)
         check(self.lib.zkhip_gen_trace(self.handle, seed, shard, log_n, width, C.c_void_p(out.ptr), width))
@@ -266,17 +271,19 @@ class Context:
         return buf[: got.value]
 
     def prove_chips(self, chips, public_values=(), params=None):
-        """chips: [(device buffer, log_n, width[, logup_pairs]), ...] tallest first -- one shard of several AIR tables
-        (SP1's shard shape)"""
+        """chips: [(device buffer, log_n, width[, logup_pairs[, partner]]), ...] tallest first -- one shard of several AIR
+        tables (SP1's shard shape); partner = index of the chip this one exchanges lookups with, -1 for none"""
         params = params or Params(1, 100, 16, 0)
-        chips = [tuple(c) + (0,) * (4 - len(c)) for c in chips]
+        chips = [tuple(c) + ((0,) if len(c) < 4 else ()) for c in chips]
+        chips = [tuple(c) + ((-1,) if len(c) < 5 else ()) for c in chips]
         n = len(chips)
-        arr = (_lib.Chip * n)(*[_lib.Chip(b.ptr, w, ln, w, pr) for b, ln, w, pr in chips])
+        arr = (_lib.Chip * n)(*[_lib.Chip(b.ptr, w, ln, w, pr, pa) for b, ln, w, pr, pa in chips])
         log_ns = (C.c_int32 * n)(*[c[1] for c in chips])
         widths = (C.c_uint32 * n)(*[c[2] for c in chips])
         pairs = (C.c_int32 * n)(*[c[3] for c in chips])
+        partners = (C.c_int32 * n)(*[c[4] for c in chips])
         pv = np.ascontiguousarray(np.array(public_values, dtype=np.uint32))
-        size = self.lib.zkhip_chips_proof_size(log_ns, widths, pairs, n, C.byref(params), pv.size)
+        size = self.lib.zkhip_chips_proof_size(log_ns, widths, pairs, partners, n, C.byref(params), pv.size)
         if size == 0:
             check(-1)
         buf = np.empty(size, dtype=np.uint8)
@@ -303,7 +310,7 @@ def verify_shard(proof, log_n, width, public_values=(), params=None):
     return rc, reason.value
 
 
-def verify_chips(proof, log_ns, widths, public_values=(), params=None, pairs=None):
+def verify_chips(proof, log_ns, widths, public_values=(), params=None, pairs=None, partners=None):
     params = params or Params(1, 100, 16)
     lib = _lib.load()
     pr = np.ascontiguousarray(proof, dtype=np.uint8)
@@ -312,6 +319,7 @@ def verify_chips(proof, log_ns, widths, public_values=(), params=None, pairs=Non
     ln = (C.c_int32 * n)(*[int(x) for x in log_ns])
     ws = (C.c_uint32 * n)(*[int(x) for x in widths])
     prs = (C.c_int32 * n)(*[int(x) for x in pairs]) if pairs is not None else None
+    pas = (C.c_int32 * n)(*[int(x) for x in partners]) if partners is not None else None
     reason = C.c_int(0)
-    rc = lib.zkhip_verify_chips(pr.ctypes.data_as(u8p), pr.size, ln, ws, prs, n, pv.ctypes.data_as(u32p), pv.size, C.byref(params), C.byref(reason))
+    rc = lib.zkhip_verify_chips(pr.ctypes.data_as(u8p), pr.size, ln, ws, prs, pas, n, pv.ctypes.data_as(u32p), pv.size, C.byref(params), C.byref(reason))
     return rc, reason.value
