@@ -88,6 +88,22 @@ def main():
         chipsets[name] = {"chips": [list(c) for c in chips], "params": list(prm), "public": [3, 4],
                           "bytes": int(pf.size), "sha256": hashlib.sha256(pf.tobytes()).hexdigest()}
     out["chip_proofs"] = chipsets
+    # chips with lookups: (log_n, width, pairs, partner); partner >= 0 = the two chips look each other up
+    lk = {}
+    for name, (chips, prm) in {"local_lookups": ([(10, 16, 2, -1), (8, 8, 0, -1), (7, 24, 3, -1)], (1, 12, 4)),
+                               "cross_lookups": ([(9, 16, 2, 1), (9, 24, 2, 0), (7, 8, 1, -1), (6, 4, 0, -1)], (1, 12, 4))}.items():
+        traces = []
+        for i, (ln, w, pr, pa) in enumerate(chips):
+            traces.append(O.gen_trace_logup_cross(SEED, i, pa, ln, w, chips[pa][1], pr) if pa >= 0 else
+                          (O.gen_trace_logup(SEED, i, ln, w, pr) if pr else O.gen_trace(SEED, i, ln, w)))
+        params = O.default_params(*prm)
+        prs, pas = [c[2] for c in chips], [c[3] for c in chips]
+        cross = any(p >= 0 for p in pas)
+        pf = O.prove_chips(traces, [3, 4], params, prs, pas if cross else None)
+        assert O.verify_chips(pf, [c[0] for c in chips], [c[1] for c in chips], [3, 4], params, prs, pas if cross else None) == 0
+        lk[name] = {"chips": [list(c) for c in chips], "params": list(prm), "public": [3, 4],
+                    "bytes": int(pf.size), "sha256": hashlib.sha256(pf.tobytes()).hexdigest()}
+    out["chip_lookup_proofs"] = lk
     with open(os.path.join(HERE, "oracle_kat.json"), "w") as f:
         json.dump(out, f, indent=1)
     print("wrote oracle_kat.json")

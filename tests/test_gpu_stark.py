@@ -484,3 +484,13 @@ def test_lookups_between_chips_must_balance(ctx, oracle):
         assert verify_chips(proof, [8, 8], [8, 8], [], prm, [1, 1], None) == (-6, 10)
     with pytest.raises(ZkHipError):
         ctx.prove_chips([(good[0], 8, 8, 1, 1), (good[1], 8, 8, 1, -1)], [], prm)          # partnership must be mutual
+
+
+@pytest.mark.parametrize("name", sorted(KAT["chip_lookup_proofs"]))
+def test_golden_chip_lookup_proofs_on_gpu(ctx, name):
+    g = KAT["chip_lookup_proofs"][name]
+    chips = [tuple(c) for c in g["chips"]]
+    dtr = _cross_traces(ctx.gen_trace_logup_cross, ctx.gen_trace_logup, ctx.gen_trace, chips)
+    cross = any(c[3] >= 0 for c in chips)
+    proof = ctx.prove_chips([(d, ln, w, pr) + ((pa,) if cross else ()) for d, (ln, w, pr, pa) in zip(dtr, chips)], g["public"], Params(*g["params"]))
+    assert proof.size == g["bytes"] and hashlib.sha256(proof.tobytes()).hexdigest() == g["sha256"]

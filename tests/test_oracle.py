@@ -540,3 +540,17 @@ def test_multi_chip_shard_with_lookups(oracle, chips, prm):
     except RuntimeError:
         return
     assert oracle.verify_chips(pf2, lns, ws, [1, 2], params, pairs) == 10
+
+
+@pytest.mark.parametrize("name", sorted(KAT["chip_lookup_proofs"]))
+def test_golden_chip_lookup_proofs(oracle, name):
+    g = KAT["chip_lookup_proofs"][name]
+    chips = g["chips"]
+    traces = []
+    for i, (ln, w, pr, pa) in enumerate(chips):
+        traces.append(oracle.gen_trace_logup_cross(SEED, i, pa, ln, w, chips[pa][1], pr) if pa >= 0 else
+                      (oracle.gen_trace_logup(SEED, i, ln, w, pr) if pr else oracle.gen_trace(SEED, i, ln, w)))
+    prs, pas = [c[2] for c in chips], [c[3] for c in chips]
+    cross = any(p >= 0 for p in pas)
+    pf = oracle.prove_chips(traces, g["public"], oracle.default_params(*g["params"]), prs, pas if cross else None)
+    assert pf.size == g["bytes"] and hashlib.sha256(pf.tobytes()).hexdigest() == g["sha256"]
