@@ -1,0 +1,59 @@
+"""exploration: a long pseudo-random sweep on the GPU -- every proof must equal the oracle's bytes and verify.
+usage: python tools/soak_random.py [seconds]"""
+import sys, time
+sys.path.insert(0, "/root/repo"); sys.path.insert(0, "/root/repo/tests")
+import numpy as np
+import oracle_lib as O
+from zktls_amd.device import Context, verify_shard, verify_chips
+from zktls_amd._lib import Params
+O.set_threads(8)
+budget = float(sys.argv[1]) if len(sys.argv) > 1 else 60.0
+rng = np.random.default_rng(int(time.time()))
+ctx = Context(0)
+t0 = time.time(); n_single = n_chips = 0
+SEED = int(rng.integers(1, 2**40))
+while time.time() - t0 < budget:
+    if rng.random() < 0.6:
+        log_n = int(rng.integers(5, 13)); width = 4 * int(rng.integers(1, 25)); b = int(rng.integers(1, 4)); K = int(rng.integers(1, 5))
+        fs = [f for f in range(0, min(log_n, 9) + 1) if (log_n - f) % K == 0]
+        if not fs: continue
+        F = int(rng.choice(fs)); hw = int(rng.choice([16, 24])); pairs = int(rng.integers(0, width // 8 + 1)) if rng.random() < 0.4 else 0
+        shape = (b, int(rng.integers(1, 15)), int(rng.integers(0, 8)), pairs, K, F, hw)
+        shard = int(rng.integers(0, 1000)); pub = [int(x) for x in rng.integers(0, 2013265921, int(rng.integers(0, 5)))]
+        d = ctx.gen_trace_logup(SEED, shard, log_n, width, pairs) if pairs else ctx.gen_trace(SEED, shard, log_n, width)
+        h = O.gen_trace_logup(SEED, shard, log_n, width, pairs) if pairs else O.gen_trace(SEED, shard, log_n, width)
+        pf = ctx.prove_shard(d, log_n, width, pub, Params(*shape))
+        assert pf.tobytes() == O.prove_shard(h, pub, O.default_params(*shape)).tobytes(), ("single", log_n, width, shape)
+        assert verify_shard(pf, log_n, width, pub, Params(*shape)) == (0, 0)
+        d.free(); n_single += 1
+    else:
+        n = int(rng.integers(1, 9))
+        hs = sorted((int(x) for x in rng.integers(5, 12, n)), reverse=True)
+        if max(hs.count(x) for x in hs) > 4: continue
+        chips = []
+        for hgt in hs:
+            w = 4 * int(rng.integers(1, 14)); chips.append([hgt, w, int(rng.integers(0, w // 8 + 1)) if rng.random() < 0.4 else 0, -1])
+        # make partnerships among equal-height chips with equal pair counts
+        for i in range(n):
+            for j in range(i + 1, n):
+                if chips[i][3] < 0 and chips[j][3] < 0 and chips[i][0] == chips[j][0] and chips[i][2] and rng.random() < 0.5:
+                    q = min(chips[i][2], chips[j][2], chips[i][1] // 8, chips[j][1] // 8)
+                    if q and chips[j][2]:
+                        chips[i][2] = chips[j][2] = q; chips[i][3] = j; chips[j][3] = i
+        prm = (int(rng.integers(1, 4)), int(rng.integers(1, 12)), int(rng.integers(0, 7)))
+        dev, host = [], []
+        for i, (ln, w, pr, pa) in enumerate(chips):
+            if pa >= 0:
+                dev.append(ctx.gen_trace_logup_cross(SEED, i, pa, ln, w, chips[pa][1], pr)); host.append(O.gen_trace_logup_cross(SEED, i, pa, ln, w, chips[pa][1], pr))
+            elif pr:
+                dev.append(ctx.gen_trace_logup(SEED, i, ln, w, pr)); host.append(O.gen_trace_logup(SEED, i, ln, w, pr))
+            else:
+                dev.append(ctx.gen_trace(SEED, i, ln, w)); host.append(O.gen_trace(SEED, i, ln, w))
+        prs, pas = [c[2] for c in chips], [c[3] for c in chips]
+        cross = any(p >= 0 for p in pas)
+        pf = ctx.prove_chips([(d, c[0], c[1], c[2], c[3]) for d, c in zip(dev, chips)], [7], Params(*prm))
+        assert pf.tobytes() == O.prove_chips(host, [7], O.default_params(*prm), prs, pas if cross else None).tobytes(), ("chips", chips, prm)
+        assert verify_chips(pf, [c[0] for c in chips], [c[1] for c in chips], [7], Params(*prm), prs, pas if cross else None) == (0, 0)
+        for d in dev: d.free()
+        n_chips += 1
+print("ok: %d single-matrix and %d multi-chip configurations in %.0f s" % (n_single, n_chips, time.time() - t0))
