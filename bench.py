@@ -234,7 +234,7 @@ def main():
                     "zk::ntt_pass_kernel<4,false,2,5>, strided pass": {
                         "ms": round(per_which[0], 4), "GB/s": round(alg_bytes / per_which[0] / 1e6, 1),
                         "frac": round(alg_bytes / per_which[0] / 1e6 / HBM_PEAK_GBS, 4)},
-                    "zk::ntt_pass_kernel<4,false,2,5>, contiguous pass": {
+                    "zk::ntt_pass_kernel<4,false,2,5,true>, contiguous pass": {
                         "ms": round(per_which[1], 4), "GB/s": round(alg_bytes / per_which[1] / 1e6, 1),
                         "frac": round(alg_bytes / per_which[1] / 1e6 / HBM_PEAK_GBS, 4)}}}
 

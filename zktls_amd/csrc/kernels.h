@@ -29,7 +29,7 @@ struct NttPassArgs {
     uint32_t bitrev_out;
     uint32_t map_mode;               // 0: column group fastest; 1: XCD-aware
     uint32_t fast_path;              // A/B knob: 0 / 2 tile-per-workgroup kernel (default), 1 persistent 1024 x 32 kernel
-    uint32_t debug_flags;            // timing-only: 1 drop loads, 2 drop stores (persistent x2 kernel)
+    uint32_t debug_flags;            // timing-only: 1 drop loads, 2 drop stores, 4 no transform, 8 no non-temporal policy
     uint32_t cols_per_thread;        // 2: two columns per lane when the shape allows (A/B knob); else 1
     const uint32_t* w1024;           // w_1024^e (forward) or w_1024^-e (inverse), e < 1024
     const uint32_t* pre;             // [M] or nullptr
