@@ -48,7 +48,7 @@ fetch, write = pmc("pmc_fetch", "FETCH_SIZE"), pmc("pmc_write", "WRITE_SIZE")
 if fetch and write:
     f_avg = sum(fetch) / len(fetch) * 1024.0 * 2.0     # KiB -> B, gfx950 x2 correction
     w_avg = sum(write) / len(write) * 1024.0
-    out = {"kernel": "zk::ntt_pass_kernel<4,false,2,5> (both passes)", "workload": "2^20 x 256, mean of strided and contiguous pass",
+    out = {"kernel": "zk::ntt_pass_kernel<4,false,2,5,*> (strided and contiguous pass)", "workload": "2^20 x 256, mean of strided and contiguous pass",
            "fetch_size_kib_raw_mean": sum(fetch) / len(fetch), "write_size_kib_mean": sum(write) / len(write),
            "fetch_correction": "x2 (gfx950 FETCH_SIZE half-count)", "hbm_bytes_per_launch": f_avg + w_avg,
            "algorithmic_bytes_per_launch": 8.0 * (1 << 28)}
