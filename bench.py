@@ -260,8 +260,8 @@ def main():
         ms = e0.elapsed_time(e1) / reps_h
         perms = rows * ((width + 7) // 8)
         # integer multiplies of one permutation as implemented (poseidon2.cuh): 141 S-boxes x 4 Montgomery products x 3,
-        # 13 internal layers x (8 + 2 + 1 + 13 x 3)
-        imul_per_perm = 141 * 4 * 3 + 13 * (8 + 2 + 1 + 13 * 3)
+        # 13 internal layers x (16 for the row sum + 2 for its reduction + 1 + 16 x 3)
+        imul_per_perm = 141 * 4 * 3 + 13 * (16 + 2 + 1 + 16 * 3)
         ach = perms * imul_per_perm / (ms * 1e-3) / 1e12
         valu = {"bound": "int-mul (not in the roofline schema: reported beside it)", "kernel": "zk::hash_rows_vec_kernel, 2^%d x %d leaves" % (log_n + 1, width),
                 "ms": round(ms, 3), "perm_per_s": round(perms / (ms * 1e-3), 1), "int_mul_per_perm": imul_per_perm,

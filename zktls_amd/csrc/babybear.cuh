@@ -68,6 +68,8 @@ ZK_HD constexpr uint32_t two_adic_generator(int bits) {
     for (int i = bits; i < TWO_ADICITY; i++) g = fmul(g, g);
     return g;
 }
+// representative of x (mod P) in (-P/2, P/2]
+ZK_HD constexpr int32_t centered(uint32_t x) { return x > P / 2 ? (int32_t)x - (int32_t)P : (int32_t)x; }
 constexpr uint32_t MONTY_GEN = to_monty(GEN);
 constexpr uint32_t MONTY_EXT_W = to_monty(EXT_W);
 constexpr uint32_t MONTY_INV2 = to_monty((P + 1) / 2);
@@ -126,6 +128,35 @@ ZK_D void dacc2(uint64_t& acc, uint32_t a0, uint32_t b0, uint32_t a1, uint32_t b
     const uint64_t t = dmac(a1, b1, dmac(a0, b0, acc));
     acc = ((uint64_t)dred((uint32_t)(t >> 32)) << 32) | (uint32_t)t;
 }
+// Signed Montgomery product: for ANY int32 a, b the result r = (a b - m P) / 2^32 (m = a b P^-1 mod 2^32 taken as int32) is
+// congruent to a b / 2^32 and |r| <= |a b| / 2^32 + P/2 -- so (-P, P) is closed under it (P^2 / 2^32 < 0.47 P) and a chain
+// of products needs no conditional subtraction at all: v_mad_i64_i32 + v_mul_lo_u32 + v_mad_i64_i32 (12.6 clk).
+constexpr uint32_t MONTY_MU_POS = 0x88000001u;   // P^-1 mod 2^32
+static_assert((uint32_t)(P * MONTY_MU_POS) == 1u, "P^-1 mod 2^32");
+ZK_D int32_t dsmont(int32_t a, int32_t b) {
+    const int64_t x = (int64_t)a * b;
+    const int32_t m = (int32_t)((uint32_t)x * MONTY_MU_POS);
+    const int64_t y = x + (int64_t)m * (int64_t)(-(int32_t)P);
+    return (int32_t)(y >> 32);
+}
+// Montgomery reduction of a signed 64-bit value: x / 2^32 mod P with |result| <= |x| / 2^32 + P/2
+ZK_D int32_t dsmred(int64_t x) {
+    const int32_t m = (int32_t)((uint32_t)x * MONTY_MU_POS);
+    const int64_t y = x + (int64_t)m * (int64_t)(-(int32_t)P);
+    return (int32_t)(y >> 32);
+}
+ZK_D int64_t dsmac(int32_t a, int32_t b, int64_t c) { return (int64_t)a * b + c; }     // one v_mad_i64_i32
+// the same with the instruction spelled out and a wave-uniform multiplier: for sums of the form sum_j a_j * k the compiler
+// otherwise factors k out and builds the 64-bit sum from 2 instructions per term (sign extension + 64-bit add)
+ZK_D int64_t dsmac_uniform(int32_t a, int32_t k_sgpr, int64_t c) {
+    uint64_t carry;
+    asm("v_mad_i64_i32 %0, %1, %2, %3, %0" : "+v"(c), "=s"(carry) : "v"(a), "s"(k_sgpr));
+    return c;
+}
+// (-P, P) -> [0, P): v_add + v_min_u32 (a negative value is a huge unsigned one, adding P wraps it into range)
+ZK_D uint32_t dcanon(int32_t x) { const uint32_t u = (uint32_t)x, v = u + P; return v < u ? v : u; }
+// the same product plus P: an unsigned value in (0, 2P) when |a b| < 2^31 P
+ZK_D uint32_t dsmont_plus_p(int32_t a, int32_t b) { return (uint32_t)dsmont(a, b) + P; }
 ZK_D uint32_t dacc_finish(uint64_t acc) { return dred(dmred_lazy(acc)); }    // canonical acc / 2^32 mod P
 #endif
 

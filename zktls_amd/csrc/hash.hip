@@ -172,7 +172,7 @@ struct CoopConsts { uint32_t rc_ext[8]; uint32_t diag; };
 ZK_D CoopConsts coop_load_consts(int lane16) {
     CoopConsts k;
 #pragma unroll
-    for (int r = 0; r < 8; r++) k.rc_ext[r] = P2K.ext_rc[r][lane16];
+    for (int r = 0; r < 8; r++) k.rc_ext[r] = P2K.ext_rcm[r][lane16];      // rc - P, see p2_sbox_rc_dev
     k.diag = P2K.diag[lane16];
     return k;
 }
@@ -189,10 +189,10 @@ ZK_D uint32_t coop_external_linear(uint32_t x) {
 ZK_D uint32_t coop_permute(uint32_t x, int lane16, const CoopConsts& k) {
     x = coop_external_linear(x);
 #pragma unroll 1
-    for (int r = 0; r < 4; r++) x = coop_external_linear(p2_sbox_dev(dadd(x, k.rc_ext[r])));
+    for (int r = 0; r < 4; r++) x = coop_external_linear(p2_sbox_rc_dev(x, k.rc_ext[r]));
 #pragma unroll 1
     for (int r = 0; r < 13; r++) {
-        const uint32_t sb = p2_sbox_dev(dadd(x, P2K.int_rc[r]));
+        const uint32_t sb = p2_sbox_rc_dev(x, P2K.int_rcm[r]);
         x = lane16 == 0 ? sb : x;
         uint32_t t = dadd(x, dpp<0x128>(x));
         t = dadd(t, dpp<0x124>(t));
@@ -201,7 +201,7 @@ ZK_D uint32_t coop_permute(uint32_t x, int lane16, const CoopConsts& k) {
         x = dadd(dmul(x, k.diag), t);
     }
 #pragma unroll 1
-    for (int r = 4; r < 8; r++) x = coop_external_linear(p2_sbox_dev(dadd(x, k.rc_ext[r])));
+    for (int r = 4; r < 8; r++) x = coop_external_linear(p2_sbox_rc_dev(x, k.rc_ext[r]));
     return x;
 }
 
