@@ -141,6 +141,34 @@ def test_poseidon2_known_answers(ctx, oracle):
         assert (got[i] == oracle.poseidon2(st[i])).all()
 
 
+def test_poseidon2_extreme_states(ctx, oracle):
+    """The device permutation runs on signed, unreduced representatives (poseidon2.cuh): drive it with the values that sit on
+    the edges of every range argument -- 0, 1, P-1, (P-1)/2, (P+1)/2, powers of two -- alone and mixed, plus 4096 random states."""
+    edge = np.array([0, 1, 2, P - 1, P - 2, (P - 1) // 2, (P + 1) // 2, 1 << 27, (1 << 27) - 1, 1 << 30, 0x0ffffffe, 0x78000000], dtype=np.uint32)
+    rng = np.random.default_rng(2024)
+    rows = [np.full(16, v, dtype=np.uint32) for v in edge]
+    rows += [np.where(np.arange(16) % 2 == 0, a, b).astype(np.uint32) for a in edge[:6] for b in edge[:6]]
+    rows += [rng.choice(edge, 16) for _ in range(512)]
+    rows += [rng.integers(0, P, 16, dtype=np.uint32) for _ in range(4096)]
+    st = np.stack(rows).astype(np.uint32)
+    buf = ctx.from_numpy(st)
+    ctx.poseidon2_permute(buf)
+    got = buf.download().reshape(-1, 16)
+    assert (got < P).all()
+    for i in range(st.shape[0]):
+        assert (got[i] == oracle.poseidon2(st[i])).all(), i
+
+
+@pytest.mark.parametrize("fill", [0, 1, P - 1, (P + 1) // 2])
+def test_hash_rows_and_p24_commit_of_constant_matrices(ctx, oracle, fill):
+    m = np.full((256, 40), fill, dtype=np.uint32)
+    got = ctx.hash_rows([(ctx.from_numpy(m), 40)], 256).download().reshape(-1, 8)
+    assert (got == oracle.hash_rows([m])).all()
+    cm = np.ascontiguousarray(m[:, :24].T)                      # column-major [cols][rows]
+    got24 = ctx.merkle_commit_p24_colmajor(ctx.from_numpy(cm), 24, 8).download().reshape(-1, 8)
+    assert (got24 == oracle.merkle_tree_p24_colmajor(cm)).all()
+
+
 @pytest.mark.parametrize("height,widths", [(64, [8]), (300, [5]), (1024, [16]), (1024, [20]), (257, [1]), (512, [3, 9]), (128, [8, 8, 4, 1])])
 def test_hash_rows_matches_oracle(ctx, oracle, height, widths):
     rng = np.random.default_rng(height)
