@@ -134,6 +134,7 @@ struct OpenArgs {
     int tx;                     // columns per workgroup (power of two <= 64)
 };
 // out[k][col] = -scale_k * sum_q mat[q][col] xw_k[q]
+size_t open_chunks(uint64_t rows, uint32_t width, uint64_t ld, const uint32_t* mat);   // row chunks (= partial sums per column and point) launch_open will use
 hipError_t launch_open(const OpenArgs& a, int npts, const Ext& scale0, const Ext& scale1, uint32_t* out, hipStream_t s);
 
 struct ReducedArgs {

@@ -172,7 +172,7 @@ static int run_open(zkhip_ctx* ctx, const uint32_t* lde, size_t ld, int log_n, u
     OpenArgs o{};
     o.mat = lde; o.ld = ld; o.width = width; o.rows = n; o.xw = xw; o.xw_stride = n;
     o.tx = pow2ceil((int)width) > 64 ? 64 : pow2ceil((int)width);
-    const size_t nchunks = (size_t)((n + 2047) / 2048);
+    const size_t nchunks = open_chunks(n, width, ld, lde);
     void* part;
     ZK_TRY(ctx_reserve(ctx, S_PARTIAL, nchunks * npts * width * 16, &part));
     o.partial = (uint32_t*)part;

@@ -229,6 +229,7 @@ hipError_t launch_inv_denominators(const uint32_t* xs, uint64_t count, const Ext
 // TY-th row of the chunk; the four coefficients of each point are 64-bit running sums (dacc2: two
 // products per conditional subtraction, one Montgomery reduction per chunk).
 constexpr int OPEN_ROWS = 2048;   // rows per workgroup
+constexpr int OPEN_ROWS4 = 1024;  // rows per workgroup of the four-columns-per-lane form
 template <int NPTS>
 __global__ void __launch_bounds__(256) open_partial_kernel(OpenArgs a) {
     __shared__ uint32_t red[256 * 4];
@@ -281,6 +282,68 @@ __global__ void __launch_bounds__(256) open_partial_kernel(OpenArgs a) {
         }
     }
 }
+// The same for matrices whose width and pitch are multiples of 4: a lane owns FOUR adjacent columns (16-byte loads: a wave
+// covers a whole 1 KiB row of a 256-column matrix) and the weights of a row are fetched once per four columns.
+template <int NPTS>
+__global__ void __launch_bounds__(256) open_partial4_kernel(OpenArgs a) {
+    __shared__ uint32_t red[256 * 16];
+    const int TX = a.tx, TY = 256 / TX;
+    const int tx = threadIdx.x % TX, ty = threadIdx.x / TX;
+    const uint32_t col = (blockIdx.y * TX + tx) * 4;
+    const uint64_t r0 = (uint64_t)blockIdx.x * OPEN_ROWS4;
+    const bool active = col < a.width;
+    uint64_t acc[NPTS][4][4];                       // [point][extension coefficient][column]
+#pragma unroll
+    for (int k = 0; k < NPTS; k++)
+#pragma unroll
+        for (int i = 0; i < 4; i++)
+#pragma unroll
+            for (int c = 0; c < 4; c++) acc[k][i][c] = 0;
+    const int nr = (int)((a.rows - r0) < (uint64_t)OPEN_ROWS4 ? (a.rows - r0) : (uint64_t)OPEN_ROWS4);
+    for (int r = ty; r < nr; r += 4 * TY) {
+        uint4 v[4];
+        uint64_t q[4];
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            const bool in = r + j * TY < nr;
+            q[j] = in ? r0 + r + j * TY : r0 + r;
+            v[j] = (active && in) ? *reinterpret_cast<const uint4*>(a.mat + q[j] * a.ld + col) : make_uint4(0, 0, 0, 0);
+        }
+#pragma unroll
+        for (int k = 0; k < NPTS; k++) {
+            Ext w[4];
+#pragma unroll
+            for (int j = 0; j < 4; j++) w[j] = ld_ext(a.xw + 4 * ((uint64_t)k * a.xw_stride + q[j]));
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+                dacc2(acc[k][i][0], v[0].x, w[0].c[i], v[1].x, w[1].c[i]); dacc2(acc[k][i][0], v[2].x, w[2].c[i], v[3].x, w[3].c[i]);
+                dacc2(acc[k][i][1], v[0].y, w[0].c[i], v[1].y, w[1].c[i]); dacc2(acc[k][i][1], v[2].y, w[2].c[i], v[3].y, w[3].c[i]);
+                dacc2(acc[k][i][2], v[0].z, w[0].c[i], v[1].z, w[1].c[i]); dacc2(acc[k][i][2], v[2].z, w[2].c[i], v[3].z, w[3].c[i]);
+                dacc2(acc[k][i][3], v[0].w, w[0].c[i], v[1].w, w[1].c[i]); dacc2(acc[k][i][3], v[2].w, w[2].c[i], v[3].w, w[3].c[i]);
+            }
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < NPTS; k++) {
+        uint32_t mine[16];                          // [column][coefficient]
+#pragma unroll
+        for (int c = 0; c < 4; c++)
+#pragma unroll
+            for (int i = 0; i < 4; i++) mine[4 * c + i] = dacc_finish(acc[k][i][c]);
+        __syncthreads();
+#pragma unroll
+        for (int e = 0; e < 16; e++) red[threadIdx.x * 16 + e] = mine[e];
+        __syncthreads();
+        if (ty == 0 && active) {
+            for (int y = 1; y < TY; y++)
+#pragma unroll
+                for (int e = 0; e < 16; e++) mine[e] = dadd(mine[e], red[(y * TX + tx) * 16 + e]);
+            uint4* dst = reinterpret_cast<uint4*>(a.partial + 4 * (((uint64_t)blockIdx.x * NPTS + k) * a.width + col));
+#pragma unroll
+            for (int c = 0; c < 4; c++) dst[c] = make_uint4(mine[4 * c], mine[4 * c + 1], mine[4 * c + 2], mine[4 * c + 3]);
+        }
+    }
+}
 // out[pt][col] = -scale_pt * sum_chunk partial[chunk][pt][col]; one wave per output, the chunks spread over its lanes
 __global__ void __launch_bounds__(64) open_final_kernel(const uint32_t* partial, uint32_t nchunks, int npts, uint32_t width,
                                                         Ext scale0, Ext scale1, uint32_t* out) {
@@ -291,11 +354,28 @@ __global__ void __launch_bounds__(64) open_final_kernel(const uint32_t* partial,
     sum = group_sum(sum, 64);
     if (threadIdx.x == 0) st_ext(out + 4 * (uint64_t)idx, ext_neg(ext_mul(sum, k ? scale1 : scale0)));
 }
-hipError_t launch_open(const OpenArgs& a, int npts, const Ext& scale0, const Ext& scale1, uint32_t* out, hipStream_t s) {
-    const uint32_t nchunks = (uint32_t)((a.rows + OPEN_ROWS - 1) / OPEN_ROWS);
-    dim3 grid(nchunks, (a.width + a.tx - 1) / a.tx);
-    if (npts == 1) hipLaunchKernelGGL(open_partial_kernel<1>, grid, dim3(256), 0, s, a);
-    else hipLaunchKernelGGL(open_partial_kernel<2>, grid, dim3(256), 0, s, a);
+bool open_uses_quads(uint32_t width, uint64_t ld, const uint32_t* mat) {
+    return width >= 64 && width % 4 == 0 && ld % 4 == 0 && ((uintptr_t)mat & 15u) == 0;
+}
+size_t open_chunks(uint64_t rows, uint32_t width, uint64_t ld, const uint32_t* mat) {
+    const uint64_t per = open_uses_quads(width, ld, mat) ? OPEN_ROWS4 : OPEN_ROWS;
+    return (size_t)((rows + per - 1) / per);
+}
+hipError_t launch_open(const OpenArgs& a0, int npts, const Ext& scale0, const Ext& scale1, uint32_t* out, hipStream_t s) {
+    OpenArgs a = a0;
+    const bool quads = open_uses_quads(a.width, a.ld, a.mat);
+    const uint32_t nchunks = (uint32_t)open_chunks(a.rows, a.width, a.ld, a.mat);
+    if (quads) {
+        a.tx = 1;
+        while (a.tx < (int)(a.width / 4) && a.tx < 64) a.tx <<= 1;      // lanes per row = pow2ceil(width / 4), at most 64
+        dim3 grid(nchunks, (a.width / 4 + a.tx - 1) / a.tx);
+        if (npts == 1) hipLaunchKernelGGL(open_partial4_kernel<1>, grid, dim3(256), 0, s, a);
+        else hipLaunchKernelGGL(open_partial4_kernel<2>, grid, dim3(256), 0, s, a);
+    } else {
+        dim3 grid(nchunks, (a.width + a.tx - 1) / a.tx);
+        if (npts == 1) hipLaunchKernelGGL(open_partial_kernel<1>, grid, dim3(256), 0, s, a);
+        else hipLaunchKernelGGL(open_partial_kernel<2>, grid, dim3(256), 0, s, a);
+    }
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return e;
     const uint32_t n = (uint32_t)npts * a.width;
