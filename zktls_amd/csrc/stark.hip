@@ -116,6 +116,19 @@ __global__ void __launch_bounds__(256) quotient_kernel(QuotientArgs a) {
         const uint32_t g = lane + L * t;
         cur[t] = g < G ? *reinterpret_cast<const uint4*>(a.lde + (uint64_t)p * a.ld + 4 * g) : make_uint4(0, 0, 0, 0);
     }
+    // the lane's column groups are the same for every row of the chain: up to four groups keep their weights and constants in
+    // registers (64 VGPRs); wider rows reload them from L1 per step rather than drop to one wave per SIMD
+    constexpr bool HOIST = NG <= 4;
+    uint4 W[HOIST ? NG : 1][4];
+    if (HOIST) {
+#pragma unroll
+        for (int t = 0; t < NG; t++) {
+            const uint32_t g = lane + L * t;
+            const uint4* wp = reinterpret_cast<const uint4*>(a.alpha_pow + 16 * (g < G ? g : 0u));
+#pragma unroll
+            for (int i = 0; i < 4; i++) W[HOIST ? t : 0][i] = wp[i];
+        }
+    }
     for (int step = 0; step < QCHAIN; step++) {
         const uint32_t en = (e + 2) & (m - 1);
         const uint32_t pn = __brev(en) >> (32 - H);
@@ -134,7 +147,8 @@ __global__ void __launch_bounds__(256) quotient_kernel(QuotientArgs a) {
             if (g < G) {
                 const uint4 v = cur[t];
                 const uint4* wp = reinterpret_cast<const uint4*>(a.alpha_pow + 16 * g);
-                const uint4 w0 = wp[0], w1 = wp[1], w2 = wp[2], kk = wp[3];      // kk = (g+1, 2g+3, 5g+7, -) in Montgomery form
+                const uint4 w0 = HOIST ? W[HOIST ? t : 0][0] : wp[0], w1 = HOIST ? W[HOIST ? t : 0][1] : wp[1];
+                const uint4 w2 = HOIST ? W[HOIST ? t : 0][2] : wp[2], kk = HOIST ? W[HOIST ? t : 0][3] : wp[3];   // kk = (g+1, 2g+3, 5g+7, -) in Montgomery form
                 // c1 = c - a a b - k1 ; c2 = sel_trans (d' - a b - c - k2) ; c3 = sel_first (d - d0)
                 const uint32_t aab = dmul(dmont_lazy(v.x, v.x), v.y);
                 const uint32_t c1 = dsub(dsub(v.z, aab), kk.x);
