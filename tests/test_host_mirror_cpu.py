@@ -190,3 +190,27 @@ def test_reference_transcript_batch_is_proven_shard_parallel(lib):
     for s in range(4):
         assert verify_shard(proofs[s], 10, 16, digest + [s], Params(1, 20, 8)) == (0, 0)
     assert verify_shard(proofs[1], 10, 16, digest + [2], Params(1, 20, 8))[0] == -6     # a proof does not transfer to another shard
+
+
+@pytest.mark.gpu
+def test_shards_in_flight_do_not_change_the_bytes(lib, monkeypatch):
+    # shards are proven by several host threads, each with its own context and stream; the batch must not depend on how many
+    plan = Plan(9, 16, 7, 12, 6)
+    blobs = []
+    for k in ("1", "3", "8"):
+        monkeypatch.setenv("ZKTLS_HIP_IN_FLIGHT", k)
+        rc, err, out, blob = call(lib, 2, b"\xa1transcript", b"\x7fELFprog", plan)
+        assert rc == 0, err
+        blobs.append((out, blob))
+    assert blobs[0] == blobs[1] == blobs[2]
+    offs, lens = (C.c_size_t * 8)(), (C.c_size_t * 8)()
+    assert lib.zktls_unpack_batch(blobs[0][1], len(blobs[0][1]), offs, lens, 8) == 7
+
+
+@pytest.mark.gpu
+def test_a_failing_shard_worker_reports_instead_of_unwinding(lib, monkeypatch):
+    monkeypatch.setenv("ZKTLS_HIP_IN_FLIGHT", "4")
+    rc, err, _, _ = call(lib, 2, b"x", b"elf", Plan(8, 8, 5, 100000, 8))       # more queries than the library accepts
+    assert rc != 0 and err
+    rc, err, _, _ = call(lib, 2, b"x", b"elf", Plan(8, 8, 5, 10, 8), device=99)  # every worker fails to create its context
+    assert rc != 0 and "zkhip_ctx_create" in err

@@ -3,7 +3,10 @@
 #include "guest_prover_hip.hpp"
 
 #include <cstdlib>
+#include <atomic>
 #include <cstring>
+#include <mutex>
+#include <thread>
 #include <stdexcept>
 
 #include "../../include/zkhip.h"
@@ -142,29 +145,64 @@ ProveResult HipGuestProver::prove_inner(const GuestInput& input, const std::vect
     }
     const size_t cap = zkhip_proof_size(plan_.log_n, plan_.width, &prm, 9);
     if (cap == 0) throw std::runtime_error(std::string("bad shard plan: ") + zkhip_last_error());
-    CtxGuard g;
-    if (zkhip_ctx_create(device_, nullptr, &g.ctx) != ZKHIP_OK) fail_zkhip("zkhip_ctx_create");
-    const size_t words = ((size_t)1 << plan_.log_n) * plan_.width;
-    if (zkhip_malloc(g.ctx, words * 4, &g.d_trace) != ZKHIP_OK) fail_zkhip("zkhip_malloc");
     uint64_t seed = 0;
     for (int i = 0; i < 4; i++) seed = (seed << 16) ^ digest[i];
-    std::vector<std::vector<uint8_t>> proofs;
-    for (uint32_t s = 0; s < plan_.shards; s++) {
-        std::vector<uint32_t> pv(digest);
-        pv.push_back(s);
-        if (zkhip_gen_trace(g.ctx, seed, s, plan_.log_n, plan_.width, (uint32_t*)g.d_trace, plan_.width) != ZKHIP_OK)
-            fail_zkhip("zkhip_gen_trace");
-        std::vector<uint8_t> proof(cap);
-        size_t len = 0;
-        if (zkhip_prove_shard(g.ctx, (const uint32_t*)g.d_trace, plan_.width, plan_.log_n, plan_.width, pv.data(), pv.size(),
-                              &prm, proof.data(), cap, &len) != ZKHIP_OK)
-            fail_zkhip("zkhip_prove_shard");
-        proof.resize(len);
-        int reason = 0;
-        if (zkhip_verify_shard(proof.data(), proof.size(), plan_.log_n, plan_.width, pv.data(), pv.size(), &prm, &reason) != ZKHIP_OK)
-            fail_zkhip("zkhip_verify_shard");   // sp1.rs:120: the prover checks its own proof
-        proofs.push_back(std::move(proof));
+    // Shards are independent: `in_flight` of them are proven at the same time, each on its own context (= HIP stream) and
+    // host thread, so the latency-bound stretches of one proof (small Merkle levels, transcript round trips, the CPU
+    // verification of the finished proof) hide under the throughput-bound kernels of the others.
+    uint32_t in_flight = plan_.in_flight;
+    if (in_flight == 0) {
+        const char* e = std::getenv("ZKTLS_HIP_IN_FLIGHT");
+        in_flight = e && std::atoi(e) > 0 ? (uint32_t)std::atoi(e) : 4u;
     }
+    if (in_flight > plan_.shards) in_flight = plan_.shards;
+    const size_t words = ((size_t)1 << plan_.log_n) * plan_.width;
+    std::vector<std::vector<uint8_t>> proofs(plan_.shards);
+    std::atomic<uint32_t> next{0};
+    std::atomic<bool> failed{false};
+    std::mutex err_mu;
+    std::string first_error;
+    auto worker = [&]() {
+        try {
+            CtxGuard g;
+            if (zkhip_ctx_create(device_, nullptr, &g.ctx) != ZKHIP_OK) fail_zkhip("zkhip_ctx_create");
+            if (zkhip_malloc(g.ctx, words * 4, &g.d_trace) != ZKHIP_OK) fail_zkhip("zkhip_malloc");
+            for (;;) {
+                const uint32_t s = next.fetch_add(1);
+                if (s >= plan_.shards || failed.load()) break;
+                std::vector<uint32_t> pv(digest);
+                pv.push_back(s);
+                if (zkhip_gen_trace(g.ctx, seed, s, plan_.log_n, plan_.width, (uint32_t*)g.d_trace, plan_.width) != ZKHIP_OK)
+                    fail_zkhip("zkhip_gen_trace");
+                std::vector<uint8_t> proof(cap);
+                size_t len = 0;
+                if (zkhip_prove_shard(g.ctx, (const uint32_t*)g.d_trace, plan_.width, plan_.log_n, plan_.width, pv.data(), pv.size(),
+                                      &prm, proof.data(), cap, &len) != ZKHIP_OK)
+                    fail_zkhip("zkhip_prove_shard");
+                proof.resize(len);
+                int reason = 0;
+                if (zkhip_verify_shard(proof.data(), proof.size(), plan_.log_n, plan_.width, pv.data(), pv.size(), &prm, &reason) != ZKHIP_OK)
+                    fail_zkhip("zkhip_verify_shard");   // sp1.rs:120: the prover checks its own proof
+                proofs[s] = std::move(proof);
+            }
+        } catch (const std::exception& e) {              // a panic in one worker must not escape its thread (sp1.rs:85)
+            failed.store(true);
+            std::lock_guard<std::mutex> lk(err_mu);
+            if (first_error.empty()) first_error = e.what();
+        } catch (...) {
+            failed.store(true);
+            std::lock_guard<std::mutex> lk(err_mu);
+            if (first_error.empty()) first_error = "unknown failure in a shard worker";
+        }
+    };
+    if (in_flight <= 1) {
+        worker();
+    } else {
+        std::vector<std::thread> pool;
+        for (uint32_t t = 0; t < in_flight; t++) pool.emplace_back(worker);
+        for (auto& t : pool) t.join();
+    }
+    if (failed.load()) throw std::runtime_error(first_error);
     r.proof = pack_shard_proofs(proofs);
     r.ok = true;
     return r;

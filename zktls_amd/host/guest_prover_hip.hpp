@@ -66,6 +66,7 @@ struct ShardPlan {
     uint32_t shards = 1;
     int num_queries = 100;     // Backend::Risc0 uses RISC Zero's 50 queries / no PoW when these stay at the defaults
     int pow_bits = 16;
+    uint32_t in_flight = 0;    // shards proven at the same time (own context + host thread each); 0: $ZKTLS_HIP_IN_FLIGHT or 4
 };
 
 class HipGuestProver : public ZkProver {
