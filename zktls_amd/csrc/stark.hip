@@ -171,6 +171,8 @@ __global__ void __launch_bounds__(256) quotient_kernel(QuotientArgs a) {
             const uint32_t* wl = a.alpha_pow + 16 * G;                 // [Q + 3] ext weights
             const Ext F1 = ext_mul_base(ld_ext(wl + 4 * a.pairs), sel_first);
             const Ext F2 = ext_mul_base(ld_ext(wl + 4 * (a.pairs + 1)), sel_trans);
+            // F1 and F2 multiply the SUMS of the lane's phi_q / phi'_q (two extension products per lane instead of two per pair)
+            Ext sphi = ext_zero(), sphin = ext_zero();
             for (uint32_t q = lane; q < a.pairs; q += L) {
                 const uint4 vs = *reinterpret_cast<const uint4*>(row + 8 * q);
                 const uint4 vr = *reinterpret_cast<const uint4*>(row + 8 * q + 4);
@@ -179,8 +181,10 @@ __global__ void __launch_bounds__(256) quotient_kernel(QuotientArgs a) {
                 const Ext phi = ld_ext(prow + 4 * q), phin = ld_ext(pnrow + 4 * q);
                 const Ext c = ext_sub(ext_mul(ext_mul(phi, ds), dr), ext_sub(dr, ds));
                 r = ext_add(r, ext_mul(c, ld_ext(wl + 4 * q)));
-                r = ext_sub(r, ext_add(ext_mul(F1, phi), ext_mul(F2, phin)));
+                sphi = ext_add(sphi, phi);
+                sphin = ext_add(sphin, phin);
             }
+            if ((uint32_t)lane < a.pairs) r = ext_sub(r, ext_add(ext_mul(F1, sphi), ext_mul(F2, sphin)));
             if (lane == 0) {
                 const Ext S = ld_ext(prow + 4 * a.pairs), Sn = ld_ext(pnrow + 4 * a.pairs);
                 const Ext F3 = ext_mul_base(ld_ext(wl + 4 * (a.pairs + 2)), a.sel_last[p]);
