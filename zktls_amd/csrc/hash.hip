@@ -50,7 +50,7 @@ __global__ void __launch_bounds__(256) hash_rows_generic_kernel(LeafArgs a, uint
     d[1] = make_uint4(s[4], s[5], s[6], s[7]);
 }
 
-// single matrix, width % 8 == 0, 16-byte aligned rows: 2 x dwordx4 per absorbed block
+// single matrix, width % 4 == 0, 16-byte aligned rows: 2 x dwordx4 per absorbed block
 __global__ void __launch_bounds__(256) hash_rows_vec_kernel(const uint32_t* __restrict__ mat, uint64_t ld,
                                                             uint32_t width, uint64_t height,
                                                             uint32_t* __restrict__ digests) {
@@ -64,6 +64,11 @@ __global__ void __launch_bounds__(256) hash_rows_vec_kernel(const uint32_t* __re
         uint4 v0 = rp[2 * q], v1 = rp[2 * q + 1];
         s[0] = v0.x; s[1] = v0.y; s[2] = v0.z; s[3] = v0.w;
         s[4] = v1.x; s[5] = v1.y; s[6] = v1.z; s[7] = v1.w;
+        p2_permute_dev(s);
+    }
+    if (width & 4u) {                       // a last half block: the other four rate words keep the state (overwrite mode)
+        const uint4 v0 = rp[width / 4 - 1];
+        s[0] = v0.x; s[1] = v0.y; s[2] = v0.z; s[3] = v0.w;
         p2_permute_dev(s);
     }
     uint4* d = reinterpret_cast<uint4*>(digests + row * 8);
@@ -83,7 +88,7 @@ hipError_t launch_hash_rows(const LeafArgs& a, hipStream_t s) {
     }
     dim3 block(256), grid((unsigned)((a.height + 255) / 256));
     const MatDesc& m0 = a.mats[0];
-    bool vec = a.nmats == 1 && m0.width % 8 == 0 && m0.ld % 4 == 0 &&
+    bool vec = a.nmats == 1 && m0.width % 4 == 0 && m0.ld % 4 == 0 &&
                (reinterpret_cast<uintptr_t>(m0.ptr) & 15) == 0;
     if (vec)
         hipLaunchKernelGGL(hash_rows_vec_kernel, grid, block, 0, s, m0.ptr, m0.ld, m0.width, a.height, a.digests);
