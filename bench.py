@@ -231,10 +231,10 @@ def main():
                 "kernel": "NTT pass (mean of the two passes of one 2^20-point transform)",
                 "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_ms": round(avg_ms, 4),
                 "kernels": {
-                    "zk::ntt_pass_kernel<4,false,2,5>, strided pass": {
+                    "zk::ntt_pass_kernel<4,false,2,5,2>, strided pass": {
                         "ms": round(per_which[0], 4), "GB/s": round(alg_bytes / per_which[0] / 1e6, 1),
                         "frac": round(alg_bytes / per_which[0] / 1e6 / HBM_PEAK_GBS, 4)},
-                    "zk::ntt_pass_kernel<4,false,2,5,true>, contiguous pass": {
+                    "zk::ntt_pass_kernel<4,false,2,5,1>, contiguous pass": {
                         "ms": round(per_which[1], 4), "GB/s": round(alg_bytes / per_which[1] / 1e6, 1),
                         "frac": round(alg_bytes / per_which[1] / 1e6 / HBM_PEAK_GBS, 4)}}}
 

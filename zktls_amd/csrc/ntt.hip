@@ -75,12 +75,10 @@ typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
 // still fit a CU.
 // BFIX >= 0 fixes the tile height at compile time (M = 32 << BFIX): every LDS / store offset of the
 // exchange and of phase B then folds into an instruction immediate instead of a VGPR.
-// NT: non-temporal cache policy on the tile's loads and stores.  Measured on 2^20 x 256: -3 % on a pass whose both sides
-// are contiguous blocks (nothing is reused, the lines need not stay in L2 / MALL), +5 % on a strided pass -- so it is chosen
-// per launch.
-template <int LOG_C, bool INV, int CPT, int BFIX = -1, bool NT = false>
+// NT != 0: non-temporal cache policy on the tile's LOADS (chosen per launch, see launch_ntt_pass).
+template <int LOG_C, bool INV, int CPT, int BFIX = -1, int NT = 0>
 __global__ void __launch_bounds__(32 << LOG_C, 4) ntt_pass_kernel(NttPassArgs a) {
-    constexpr int AUX = NT ? 2 : 0;
+    constexpr int AUX = NT ? 2 : 0;         // NT = 1 and NT = 2 are the same code: two names, so that a profile tells the passes apart
     extern __shared__ uint32_t lds[];
     constexpr int C = 1 << LOG_C;          // lanes along the row chunk
     constexpr int TC = C * CPT;            // tile columns
@@ -444,7 +442,7 @@ static size_t ntt_lds_bytes(int log_m, int log_c) {
     return (size_t)(32 * (Pn + 1) * C + 3 * M) * sizeof(uint32_t);
 }
 
-template <int LOG_C, bool INV, int CPT, int BFIX = -1, bool NT = false>
+template <int LOG_C, bool INV, int CPT, int BFIX = -1, int NT = 0>
 static hipError_t launch_ntt_k(const NttPassArgs& a, hipStream_t s) {
     const int TC = (1 << LOG_C) * CPT;
     const uint32_t ncg = (a.ncols + TC - 1) / TC;
@@ -489,8 +487,15 @@ hipError_t launch_ntt_pass(const NttPassArgs& a_, bool inverse, hipStream_t s) {
     const bool pair_ok = a.ncols >= 32 && a.ncols % 2 == 0 && a.in_ld % 2 == 0 && a.out_ld % 2 == 0 &&
                          (reinterpret_cast<uintptr_t>(a.in) & 7) == 0 && (reinterpret_cast<uintptr_t>(a.out) & 7) == 0;
     if (pair_ok && a.log_m == 10 && a.cols_per_thread != 1) {
+        // non-temporal LOADS (the stores keep the default policy): the tile is read once, its lines need not stay in L2 / MALL.
+        // Pays on every pass that does not write over its own input -- block passes -3 %, the strided first pass of an LDE
+        // 552 -> 492 us -- and costs 7 % on a strided pass run in place, which keeps the default policy.
         const bool contiguous = a.in_stride == 1 && a.out_stride == 1;
-        if (contiguous && !(a.debug_flags & 8u)) return inverse ? launch_ntt_k<4, true, 2, 5, true>(a, s) : launch_ntt_k<4, false, 2, 5, true>(a, s);
+        const bool in_place = a.in == a.out;
+        if (!(a.debug_flags & 8u)) {
+            if (contiguous) return inverse ? launch_ntt_k<4, true, 2, 5, 1>(a, s) : launch_ntt_k<4, false, 2, 5, 1>(a, s);
+            if (!in_place) return inverse ? launch_ntt_k<4, true, 2, 5, 2>(a, s) : launch_ntt_k<4, false, 2, 5, 2>(a, s);
+        }
         return inverse ? launch_ntt_k<4, true, 2, 5>(a, s) : launch_ntt_k<4, false, 2, 5>(a, s);
     }
     if (pair_ok && a.cols_per_thread == 2) return inverse ? launch_ntt_k<4, true, 2>(a, s) : launch_ntt_k<4, false, 2>(a, s);
