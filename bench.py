@@ -100,6 +100,8 @@ def main():
         with torch.cuda.stream(stream):
             traces = [torch.empty(cells, dtype=torch.int32, device="cuda") for _ in range(nbuf)]
         bufs = [ctx.wrap(t) for t in traces]
+        with torch.cuda.stream(stream):
+            roof_scratch = torch.empty(n * width, dtype=torch.int32, device="cuda")   # destination of the roofline passes (allocated with the traces)
         for i, b in enumerate(bufs):
             if LQ:
                 ctx.gen_trace_logup(SEED, rank * max(K, 1) + i, log_n, width, LQ, out=b)
@@ -110,6 +112,7 @@ def main():
         chip_bufs = [(ctx.gen_trace(SEED, 100 * rank + j, ln, w), ln, w) for j, (ln, w) in enumerate(chip_list)]
         with torch.cuda.stream(stream):
             traces = [torch.empty(n * width, dtype=torch.int32, device="cuda")]      # source of the roofline section only
+            roof_scratch = torch.empty(n * width, dtype=torch.int32, device="cuda")
         bufs = [ctx.wrap(traces[0])]
         ctx.fill_uniform(SEED, log_n, width, out=bufs[0])
     ctx.sync()
@@ -199,9 +202,7 @@ def main():
     roof = None
     if rank == 0:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        with torch.cuda.stream(stream):
-            scratch = torch.empty(n * width, dtype=torch.int32, device="cuda")
-        sbuf = ctx.wrap(scratch)
+        sbuf = ctx.wrap(roof_scratch)
         # many isolated launches: the kernel's average in a rocprofv3 trace of this command is then
         # dominated by launches that had the GPU to themselves (the in-proof launches overlap
         # with kernels of the other shards in flight and are stretched by that)

@@ -18,6 +18,8 @@
 //             written natural or bit-reversed inside the tile.
 // No MFMA: a 31-bit modular butterfly is not a dense contraction.
 #include <atomic>
+#include <cstdio>
+#include <cstdlib>
 
 #include "babybear.cuh"
 #include "kernels.h"
@@ -75,10 +77,13 @@ typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
 // still fit a CU.
 // BFIX >= 0 fixes the tile height at compile time (M = 32 << BFIX): every LDS / store offset of the
 // exchange and of phase B then folds into an instruction immediate instead of a VGPR.
-// NT != 0: non-temporal cache policy on the tile's LOADS (chosen per launch, see launch_ntt_pass).
+// NT != 0: non-temporal cache policy on the tile's loads and stores (chosen per launch, see launch_ntt_pass).
 template <int LOG_C, bool INV, int CPT, int BFIX = -1, int NT = 0>
 __global__ void __launch_bounds__(32 << LOG_C, 4) ntt_pass_kernel(NttPassArgs a) {
-    constexpr int AUX = NT ? 2 : 0;         // NT = 1 and NT = 2 are the same code: two names, so that a profile tells the passes apart
+    // NT = 1 and NT = 2 are the same code: two names, so that a profile tells the passes apart.  NT >= 256 (policy sweep builds
+    // only, -DNTT_POLICY_SWEEP): load policy in bits 8..15, store policy in bits 16..23 (sc0 = 1, nt = 2, sc1 = 16).
+    constexpr int AUX = NT >= 256 ? ((NT >> 8) & 0xff) : (NT ? 2 : 0);
+    constexpr int ST_AUX = NT >= 256 ? ((NT >> 16) & 0xff) : (NT ? 2 : 0);
     extern __shared__ uint32_t lds[];
     constexpr int C = 1 << LOG_C;          // lanes along the row chunk
     constexpr int TC = C * CPT;            // tile columns
@@ -234,7 +239,7 @@ __global__ void __launch_bounds__(32 << LOG_C, 4) ntt_pass_kernel(NttPassArgs a)
 #pragma unroll
             for (int rho = 0; rho < 32; rho++) {
                 const uint32_t ro = a.bitrev_out ? (uint32_t)rho : (uint32_t)(32 * rev5(rho));
-                if (CPT == 2) { u32x2 v; v.x = x[0][rho]; v.y = x[CPT - 1][rho]; __builtin_amdgcn_raw_buffer_store_b64(v, ors, out_off, ro * ostep_b, 0); }
+                if (CPT == 2) { u32x2 v; v.x = x[0][rho]; v.y = x[CPT - 1][rho]; __builtin_amdgcn_raw_buffer_store_b64(v, ors, out_off, ro * ostep_b, ST_AUX); }
                 else __builtin_amdgcn_raw_buffer_store_b32(x[0][rho], ors, out_off, ro * ostep_b, 0);
             }
         }
@@ -487,11 +492,23 @@ hipError_t launch_ntt_pass(const NttPassArgs& a_, bool inverse, hipStream_t s) {
     const bool pair_ok = a.ncols >= 32 && a.ncols % 2 == 0 && a.in_ld % 2 == 0 && a.out_ld % 2 == 0 &&
                          (reinterpret_cast<uintptr_t>(a.in) & 7) == 0 && (reinterpret_cast<uintptr_t>(a.out) & 7) == 0;
     if (pair_ok && a.log_m == 10 && a.cols_per_thread != 1) {
-        // non-temporal LOADS (the stores keep the default policy): the tile is read once, its lines need not stay in L2 / MALL.
-        // Pays on every pass that does not write over its own input -- block passes -3 %, the strided first pass of an LDE
-        // 552 -> 492 us -- and costs 7 % on a strided pass run in place, which keeps the default policy.
+        // non-temporal loads AND stores: the tile is read once and written once, its lines need not stay in L2 / MALL.
+        // Pays on every pass except a strided one run in place (+6 %), which keeps the default policy; tools/ntt_policy_sweep.sh
+        // walks the sc0 / sc1 / nt combinations (strided pass 0.537 -> 0.487 ms, block pass 0.457 -> 0.447 ms on the same box).
         const bool contiguous = a.in_stride == 1 && a.out_stride == 1;
         const bool in_place = a.in == a.out;
+#ifdef NTT_POLICY_SWEEP
+        if (const char* pol = std::getenv("ZKHIP_NTT_POL")) {       // "<load>,<store>" policy bits, forward passes only
+            int l = 0, st = 0;
+            std::sscanf(pol, "%d,%d", &l, &st);
+#define POLCASE(L, S) if (l == L && st == S && !inverse) return launch_ntt_k<4, false, 2, 5, 256 | (L << 8) | (S << 16)>(a, s);
+            POLCASE(0, 2) POLCASE(0, 3) POLCASE(0, 18) POLCASE(0, 17) POLCASE(0, 19) POLCASE(0, 1) POLCASE(0, 16)
+            POLCASE(2, 2) POLCASE(2, 3) POLCASE(2, 18) POLCASE(2, 17) POLCASE(2, 19) POLCASE(2, 1) POLCASE(2, 16)
+            POLCASE(3, 0) POLCASE(18, 0) POLCASE(19, 0) POLCASE(17, 0) POLCASE(1, 0) POLCASE(16, 0)
+            POLCASE(3, 2) POLCASE(18, 2) POLCASE(18, 18) POLCASE(3, 3)
+#undef POLCASE
+        }
+#endif
         if (!(a.debug_flags & 8u)) {
             if (contiguous) return inverse ? launch_ntt_k<4, true, 2, 5, 1>(a, s) : launch_ntt_k<4, false, 2, 5, 1>(a, s);
             if (!in_place) return inverse ? launch_ntt_k<4, true, 2, 5, 2>(a, s) : launch_ntt_k<4, false, 2, 5, 2>(a, s);
