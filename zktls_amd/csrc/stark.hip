@@ -67,6 +67,12 @@ hipError_t launch_domain_tables(uint32_t* xs, uint32_t* sel_first, uint32_t* sel
     return hipGetLastError();
 }
 
+// 16-byte load with the non-temporal policy: for matrices that are streamed once per kernel (2 GiB LDEs do not fit any cache)
+typedef uint32_t u32x4_nt __attribute__((ext_vector_type(4)));
+ZK_D uint4 ld_stream(const uint32_t* p) {
+    const u32x4_nt v = __builtin_nontemporal_load(reinterpret_cast<const u32x4_nt*>(p));
+    return make_uint4(v.x, v.y, v.z, v.w);
+}
 // ------------------------------------------------------------------ quotient
 // acc = sum_k alpha^(K-1-k) C_k(x_p), k = 3 g + type, then * 1/Z_H(x_p).  The host passes, per column
 // group, the three extension weights alpha^(K-1-3g-t) and the three constants of the group's constraints
@@ -135,7 +141,7 @@ __global__ void __launch_bounds__(256) quotient_kernel(QuotientArgs a) {
 #pragma unroll
         for (int t = 0; t < NG; t++) {
             const uint32_t g = lane + L * t;
-            nxt[t] = g < G ? *reinterpret_cast<const uint4*>(a.lde + (uint64_t)pn * a.ld + 4 * g) : make_uint4(0, 0, 0, 0);
+            nxt[t] = g < G ? ld_stream(a.lde + (uint64_t)pn * a.ld + 4 * g) : make_uint4(0, 0, 0, 0);
         }
         const uint32_t x = a.xs[p];
         const uint32_t sel_first = a.sel_first[p];
@@ -325,7 +331,7 @@ __global__ void __launch_bounds__(256) open_partial4_kernel(OpenArgs a) {
         for (int j = 0; j < 4; j++) {
             const bool in = r + j * TY < nr;
             q[j] = in ? r0 + r + j * TY : r0 + r;
-            v[j] = (active && in) ? *reinterpret_cast<const uint4*>(a.mat + q[j] * a.ld + col) : make_uint4(0, 0, 0, 0);
+            v[j] = (active && in) ? ld_stream(a.mat + q[j] * a.ld + col) : make_uint4(0, 0, 0, 0);
         }
 #pragma unroll
         for (int k = 0; k < NPTS; k++) {
@@ -420,7 +426,7 @@ __global__ void __launch_bounds__(256) rowdot_kernel(const uint32_t* __restrict_
     uint64_t acc[4] = {0, 0, 0, 0};
     const uint32_t nq = width / 4;
     for (uint32_t q = lane; q < nq; q += L) {
-        const uint4 v = *reinterpret_cast<const uint4*>(row + 4 * q);
+        const uint4 v = ld_stream(row + 4 * q);
         const uint4* ap = reinterpret_cast<const uint4*>(alpha_pow + 16 * q);
         const uint4 a0 = ap[0], a1 = ap[1], a2 = ap[2], a3 = ap[3];
         dacc2(acc[0], a0.x, v.x, a1.x, v.y); dacc2(acc[0], a2.x, v.z, a3.x, v.w);
