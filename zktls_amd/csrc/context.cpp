@@ -92,15 +92,20 @@ static NttPassArgs base_args(zkhip_ctx* ctx, const uint32_t* in, size_t in_ld, u
     NttPassArgs a{};
     a.in = in; a.out = out; a.in_ld = in_ld; a.out_ld = out_ld; a.ncols = width;
     a.w1024 = inverse ? ctx->w1024_inv : ctx->w1024_fwd;
-    a.map_mode = 1;
+    a.map_mode = 255;
     // tuning knobs for A/B runs (never needed for correctness)
     static const int force_cpt = [] { const char* e = getenv("ZKHIP_NTT_CPT"); return e ? atoi(e) : 0; }();
-    static const int map_mode = [] { const char* e = getenv("ZKHIP_NTT_MAP"); return e ? atoi(e) : 1; }();
+    static const bool has_map = getenv("ZKHIP_NTT_MAP") != nullptr;      // re-read per launch when present at start-up (A/B tools)
+    int map_mode = 255;                                                   // automatic (launch_ntt_pass)
+    if (has_map) { const char* e = getenv("ZKHIP_NTT_MAP"); map_mode = e ? atoi(e) : 255; }
     static const int fast = [] { const char* e = getenv("ZKHIP_NTT_FAST"); return e ? atoi(e) : 4; }();
     // ZKHIP_NTT_FAST: unset/4/0 = tile-per-workgroup kernel, 1 = persistent 1024 x 32 kernel (A/B only);
     // ZKHIP_NTT_CPT: 1 / 2 columns per lane (unset: 2 for 1024-row tiles of an even, 8-byte aligned shape)
     a.fast_path = fast == 4 ? 0u : (fast == 0 ? 2u : (uint32_t)fast);
-    static const int dbg = [] { const char* e = getenv("ZKHIP_NTT_DEBUG"); return e ? atoi(e) : 0; }();
+    // re-read per launch only when the variable existed at start-up (A/B tools flip it inside one process)
+    static const bool has_dbg = getenv("ZKHIP_NTT_DEBUG") != nullptr;
+    int dbg = 0;
+    if (has_dbg) { const char* e = getenv("ZKHIP_NTT_DEBUG"); dbg = e ? atoi(e) : 0; }
     a.debug_flags = (uint32_t)dbg;
     a.cols_per_thread = (uint32_t)force_cpt;
     a.map_mode = (uint32_t)map_mode;

@@ -102,12 +102,18 @@ __global__ void __launch_bounds__(32 << LOG_C, 4) ntt_pass_kernel(NttPassArgs a)
 
     const uint32_t ncg = (a.ncols + TC - 1) / TC;
     uint32_t tile, cg;
-    if (a.map_mode == 1) {
+    if (a.map_mode == 1 || a.map_mode >= 2) {
         // blocks b and b+8 share an XCD (round-robin dispatch): keep the column groups
         // of one tile on one XCD so that they share L2 lines and DRAM pages
         const uint32_t xcd = blockIdx.x & 7u, l = blockIdx.x >> 3;
         cg = l % ncg;
         tile = (l / ncg) * 8u + xcd;
+        if (a.map_mode >= 2) {
+            // A/B: spread the tiles that are resident together over the whole tile range (tile index rotated by map_mode
+            // bits inside log2(num_tiles) bits; num_tiles is a power of two here)
+            const uint32_t lt = 31u - __clz(a.num_tiles), r = a.map_mode;
+            if (lt > r) tile = ((tile << r) | (tile >> (lt - r))) & (a.num_tiles - 1u);
+        }
     } else {
         cg = blockIdx.x % ncg;
         tile = blockIdx.x / ncg;
@@ -474,7 +480,15 @@ hipError_t launch_ntt_pass(const NttPassArgs& a_, bool inverse, hipStream_t s) {
         const uint64_t out_span = 4ull * ((M - 1) * a.out_stride * a.out_ld + a.ncols);
         if (in_span >= (1ull << 32) || out_span >= (1ull << 32)) return hipErrorInvalidValue;
     }
+    // Block -> tile order.  255 = automatic: XCD-aware (1) for block passes; for a strided pass additionally the tile index rotated
+    // by 4 bits (4), so that the ~64 tiles resident at any moment are spread over the whole 1 MiB row period instead of being 64
+    // neighbouring rows.  With neighbours the reads and the writes of the chip sit in one narrow address window at a time, and when source
+    // and destination happen to map that window onto the same channels the pass drops from 0.48 to 0.53 ms (two classes of buffers,
+    // slow iff both are in the same class: tools/ntt_buffer_quality.py); spread out, both cases run at 0.486-0.494 ms (tools/ntt_map_ab.py).
+    const bool pow2_tiles = (a.num_tiles & (a.num_tiles - 1u)) == 0;
+    if (a.map_mode == 255u) a.map_mode = (a.in_stride != 1 || a.out_stride != 1) && pow2_tiles && a.num_tiles >= 1024u ? 4u : 1u;     // smaller transforms lose 3-8 % with it
     if (a.map_mode == 1 && (a.num_tiles % 8u) != 0) a.map_mode = 0;
+    if (a.map_mode >= 2 && ((a.num_tiles % 8u) != 0 || !pow2_tiles)) a.map_mode = 0;
     // A/B only (fast_path 1): the persistent 1024 x 32 kernel (one workgroup per CU, next tile prefetched into
     // registers).  Measured on 2^20 x 256 it loses to the two-workgroups-per-CU kernel below once that one has
     // compile-time tile offsets (0.62 / 0.55 ms against 0.53 / 0.46 ms for the strided / contiguous pass); so does a
@@ -483,7 +497,7 @@ hipError_t launch_ntt_pass(const NttPassArgs& a_, bool inverse, hipStream_t s) {
     const bool al8 = a.in_ld % 2 == 0 && a.out_ld % 2 == 0 && (reinterpret_cast<uintptr_t>(a.in) & 7) == 0 &&
                      (reinterpret_cast<uintptr_t>(a.out) & 7) == 0;
     if (a.log_m == 10 && a.ncols >= 32 && a.ncols % 32 == 0 && a.fast_path == 1 && al8) {
-        if (a.map_mode == 1 && ((a.num_tiles % 8u) != 0 || (cu_count() % 8) != 0)) a.map_mode = 0;
+        if (a.map_mode != 1 || (a.num_tiles % 8u) != 0 || (cu_count() % 8) != 0) a.map_mode = 0;
         return inverse ? launch_ntt1024x2<true>(a, s) : launch_ntt1024x2<false>(a, s);
     }
     // two columns per lane (128-byte row chunks per 16 lanes) need 8-byte aligned row chunks.  Default for
