@@ -109,6 +109,8 @@ static NttPassArgs base_args(zkhip_ctx* ctx, const uint32_t* in, size_t in_ld, u
     a.debug_flags = (uint32_t)dbg;
     a.cols_per_thread = (uint32_t)force_cpt;
     a.map_mode = (uint32_t)map_mode;
+    static const bool has_perm = getenv("ZKHIP_NTT_PERM") != nullptr;
+    if (has_perm) { const char* e = getenv("ZKHIP_NTT_PERM"); a.tile_perm = e ? strtoull(e, nullptr, 16) : 0; }
     return a;
 }
 

@@ -114,6 +114,12 @@ __global__ void __launch_bounds__(32 << LOG_C, 4) ntt_pass_kernel(NttPassArgs a)
             const uint32_t lt = 31u - __clz(a.num_tiles), r = a.map_mode;
             if (lt > r) tile = ((tile << r) | (tile >> (lt - r))) & (a.num_tiles - 1u);
         }
+        if (a.tile_perm) {
+            const uint32_t lt = 31u - __clz(a.num_tiles);
+            uint32_t t2 = 0;
+            for (uint32_t b = 0; b < lt; b++) t2 |= ((tile >> b) & 1u) << ((a.tile_perm >> (4u * b)) & 15u);
+            tile = t2;
+        }
     } else {
         cg = blockIdx.x % ncg;
         tile = blockIdx.x / ncg;
