@@ -118,6 +118,20 @@ def test_coset_lde_2pow20_narrow_matches_oracle(ctx, oracle):
     assert (got == exp).all()
 
 
+def test_coset_lde_and_dft_2pow20_on_the_wide_tile_kernel(ctx, oracle):
+    # 2^20 rows x 32 columns takes the 1024-row, two-columns-per-lane tile kernel of the headline shape, including its
+    # rotated tile order on the strided passes (ntt.hip, launch_ntt_pass), and is still small enough for the oracle
+    log_n, width = 20, 32
+    m = oracle.fill_uniform(SEED + 21, log_n, width)
+    d = ctx.from_numpy(m)
+    got = ctx.coset_lde(d, log_n, width).download().reshape(-1, width)
+    assert (got == oracle.coset_lde(m, 1, 31)).all()
+    exp = oracle.ntt(m)
+    assert (ctx.dft(d, log_n, width).download().reshape(-1, width) == exp).all()
+    br = ctx.dft(d, log_n, width, bitrev_out=True).download().reshape(-1, width)
+    assert (br[bitrev_perm(log_n)] == exp).all()
+
+
 def test_coset_lde_strided_output(ctx, oracle):
     # out_ld > width, as the prover uses for the two quotient chunks
     log_n = 9
