@@ -101,7 +101,10 @@ ZK_D uint32_t row_group_sum(uint32_t v, int L) {
 }
 constexpr int QCHAIN = 16;
 template <int NG>
-__global__ void __launch_bounds__(256) quotient_kernel(QuotientArgs a) {
+#ifndef QWPE
+#define QWPE 2
+#endif
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(QWPE, QWPE))) quotient_kernel(QuotientArgs a) {
     const int L = a.lanes_per_row;
     const uint32_t gid = blockIdx.x * blockDim.x + threadIdx.x;
     const int lane = gid % L;
