@@ -15,7 +15,7 @@
  *       (reference Cargo.lock:6172): one mixed-height commitment per phase, one FRI proof.
  *   zkhip_prove_segment
  *       the span crates/guest-prover-r0/src/prover.rs:88-93 times, from RISC Zero's column-major Hal layout.
- *   zkhip_prove_shard_host, zkhip_commit
+ *   zkhip_prove_shard_host, zkhip_prove_shards, zkhip_commit
  *       host-pointer variant of the prove entry; TwoAdicFriPcs::commit (Cargo.lock:3930) alone.
  *   zkhip_perm_trace, zkhip_gen_trace_logup
  *       sp1-stark generate_permutation_trace (Cargo.lock:6172): per-row extension inverses + running sum (LogUp).
@@ -222,6 +222,28 @@ int zkhip_prove_shard(zkhip_ctx* ctx, const uint32_t* d_trace, size_t ld, int lo
 int zkhip_prove_shard_host(zkhip_ctx* ctx, const uint32_t* h_trace, int log_n, uint32_t width,
                            const uint32_t* public_values, size_t n_public, const zkhip_params* prm,
                            uint8_t* proof, size_t cap, size_t* len);
+/* A whole execution at once: the shards of one `prove` call (sp1.rs:116 proves every shard of the execution; prover.rs:90 every
+ * segment) are independent, so up to `in_flight` of them are proven at the same time, each on an internal context (= HIP stream)
+ * and host thread -- the latency-bound stretches of one proof hide under the kernels of the others (14.9 ms per
+ * 2^20 x 256 shard with four in flight against 19 ms one by one).  Traces are device pointers that stay valid during the call, or HOST
+ * pointers to canonical words when `host_traces` is non-zero (as zkhip_prove_shard_host).  Every job reports its own status and proof
+ * length; the return value is ZKHIP_OK when all succeeded, else the code of the first failing job (zkhip_last_error: its message). */
+typedef struct zkhip_shard_job {
+    const uint32_t* trace;          /* 2^log_n x width, row-major; device (Montgomery, pitch ld) or host (canonical, dense) */
+    size_t ld;
+    int32_t log_n;
+    uint32_t width;
+    const uint32_t* public_values;  /* host, canonical */
+    size_t n_public;
+    uint8_t* proof;                 /* host buffer */
+    size_t proof_cap;
+    size_t proof_len;               /* out */
+    int32_t status;                 /* out */
+} zkhip_shard_job;
+int zkhip_prove_shards(int device, zkhip_shard_job* jobs, int n_jobs, const zkhip_params* prm, int in_flight, int host_traces);
+/* the internal contexts of zkhip_prove_shards stay cached between calls (creating and freeing multi-GiB workspaces costs more than
+ * a proof); this frees them */
+void zkhip_release_cached_contexts(void);
 /* Segment proof from RISC Zero's data layout (risc0-zkp Hal, reference Cargo.lock:5057; call site
  * crates/guest-prover-r0/src/prover.rs:90): d_cols holds `width` contiguous columns of 2^log_n words
  * (column-major [width][2^log_n], Montgomery).  Same proof as zkhip_prove_shard on the transposed matrix;

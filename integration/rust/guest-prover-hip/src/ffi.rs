@@ -5,6 +5,20 @@ use std::os::raw::{c_char, c_int, c_void};
 use anyhow::{anyhow, Result};
 
 #[repr(C)]
+pub struct ZkhipShardJob {
+    pub trace: *const u32,
+    pub ld: usize,
+    pub log_n: i32,
+    pub width: u32,
+    pub public_values: *const u32,
+    pub n_public: usize,
+    pub proof: *mut u8,
+    pub proof_cap: usize,
+    pub proof_len: usize,
+    pub status: i32,
+}
+
+#[repr(C)]
 pub struct ZkhipCtx {
     _private: [u8; 0],
 }
@@ -47,6 +61,11 @@ extern "C" {
         public_values: *const u32, n_public: usize, prm: *const ZkhipParams,
         proof: *mut u8, cap: usize, len: *mut usize,
     ) -> c_int;
+    /// all shards of one execution, `in_flight` at a time on internal (cached) contexts; per-job status and length in `jobs`
+    pub fn zkhip_prove_shards(
+        device: c_int, jobs: *mut ZkhipShardJob, n_jobs: c_int, prm: *const ZkhipParams, in_flight: c_int, host_traces: c_int,
+    ) -> c_int;
+    pub fn zkhip_release_cached_contexts();
     pub fn zkhip_prove_segment(
         ctx: *mut ZkhipCtx, d_cols: *const u32, log_n: c_int, width: u32,
         public_values: *const u32, n_public: usize, prm: *const ZkhipParams,

@@ -494,3 +494,31 @@ def test_golden_chip_lookup_proofs_on_gpu(ctx, name):
     cross = any(c[3] >= 0 for c in chips)
     proof = ctx.prove_chips([(d, ln, w, pr) + ((pa,) if cross else ()) for d, (ln, w, pr, pa) in zip(dtr, chips)], g["public"], Params(*g["params"]))
     assert proof.size == g["bytes"] and hashlib.sha256(proof.tobytes()).hexdigest() == g["sha256"]
+
+
+@pytest.mark.parametrize("in_flight", [1, 3, 8])
+def test_prove_shards_batch_equals_one_by_one_and_the_oracle(ctx, oracle, in_flight):
+    # zkhip_prove_shards: the shards of one execution, several in flight on internal contexts; bytes must not depend on that
+    from zktls_amd.device import prove_shards
+    log_n, width, prm = 9, 16, Params(1, 12, 6)
+    traces = [ctx.gen_trace(SEED, s, log_n, width) for s in range(7)]
+    pvs = [[5, 6, s] for s in range(7)]
+    got = prove_shards(traces, log_n, width, pvs, prm, in_flight=in_flight)
+    for s in range(7):
+        one = ctx.prove_shard(traces[s], log_n, width, pvs[s], prm)
+        assert got[s].tobytes() == one.tobytes()
+        assert verify_shard(got[s], log_n, width, pvs[s], prm) == (0, 0)
+    exp = oracle.prove_shard(oracle.gen_trace(SEED, 3, log_n, width), pvs[3], oracle.default_params(1, 12, 6))
+    assert got[3].tobytes() == exp.tobytes()
+
+
+def test_prove_shards_from_host_traces_and_failing_job(ctx, oracle):
+    from zktls_amd.device import prove_shards
+    from zktls_amd._lib import ZkHipError
+    log_n, width, prm = 8, 8, Params(1, 10, 4)
+    host = [oracle.gen_trace(SEED, s, log_n, width) for s in range(4)]
+    got = prove_shards(host, log_n, width, [[s] for s in range(4)], prm, in_flight=2, host=True)
+    for s in range(4):
+        assert got[s].tobytes() == oracle.prove_shard(host[s], [s], oracle.default_params(1, 10, 4)).tobytes()
+    with pytest.raises(ZkHipError):                       # a public value that is not canonical fails its job and the call
+        prove_shards(host, log_n, width, [[0], [2013265921], [2], [3]], prm, in_flight=2, host=True)

@@ -208,6 +208,17 @@ def test_shards_in_flight_do_not_change_the_bytes(lib, monkeypatch):
 
 
 @pytest.mark.gpu
+def test_workers_reuse_parked_contexts_and_release_them(lib):
+    plan = Plan(8, 8, 5, 10, 8)
+    first = call(lib, 2, b"\xa1transcript", b"\x7fELFprog", plan)
+    again = call(lib, 2, b"\xa1transcript", b"\x7fELFprog", plan)        # served by the parked contexts
+    assert first[0] == 0 and again == first
+    lib.zktls_release_cached()
+    assert call(lib, 2, b"\xa1transcript", b"\x7fELFprog", plan) == first   # and again from scratch
+    lib.zktls_release_cached()
+
+
+@pytest.mark.gpu
 def test_a_failing_shard_worker_reports_instead_of_unwinding(lib, monkeypatch):
     monkeypatch.setenv("ZKTLS_HIP_IN_FLIGHT", "4")
     rc, err, _, _ = call(lib, 2, b"x", b"elf", Plan(8, 8, 5, 100000, 8))       # more queries than the library accepts

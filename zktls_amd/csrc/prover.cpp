@@ -7,7 +7,11 @@
 // (DESIGN.md sections 3 and 6).  Every heavy step is a HIP kernel on the context's
 // stream; the host only runs the duplex challenger (a few dozen permutations) between
 // launches, exactly where the protocol forces a round trip (commit -> challenge).
+#include <atomic>
 #include <cstring>
+#include <mutex>
+#include <string>
+#include <thread>
 #include <vector>
 
 #include "context.h"
@@ -701,6 +705,78 @@ int zkhip_prove_shard_host(zkhip_ctx* ctx, const uint32_t* h_trace, int log_n, u
     ZK_HIP(hipMemcpyAsync(staged, h_trace, words * 4, hipMemcpyHostToDevice, ctx->stream));
     ZK_HIP(launch_convert((const uint32_t*)staged, (uint32_t*)staged, words, true, ctx->stream));
     return zkhip_prove_shard(ctx, (const uint32_t*)staged, width, log_n, width, public_values, n_public, prm, proof, cap, len);
+}
+
+// ---- a batch of independent shards, `in_flight` at a time (one internal context + host thread each)
+// Contexts (HIP stream + multi-GiB workspaces) are expensive to create and to free (hipFree synchronises the device), so the
+// batch entry keeps the ones it made in a process-wide pool per device; zkhip_release_cached_contexts() empties it.
+namespace {
+std::mutex g_pool_mu;
+std::vector<std::pair<int, zkhip_ctx*>> g_pool;
+zkhip_ctx* pool_take(int device) {
+    std::lock_guard<std::mutex> lk(g_pool_mu);
+    for (size_t i = 0; i < g_pool.size(); i++)
+        if (g_pool[i].first == device) { zkhip_ctx* c = g_pool[i].second; g_pool.erase(g_pool.begin() + (long)i); return c; }
+    return nullptr;
+}
+void pool_give(int device, zkhip_ctx* c) {
+    std::lock_guard<std::mutex> lk(g_pool_mu);
+    g_pool.emplace_back(device, c);
+}
+}  // namespace
+void zkhip_release_cached_contexts(void) {
+    std::vector<std::pair<int, zkhip_ctx*>> all;
+    { std::lock_guard<std::mutex> lk(g_pool_mu); all.swap(g_pool); }
+    for (auto& e : all) zkhip_ctx_destroy(e.second);
+}
+int zkhip_prove_shards(int device, zkhip_shard_job* jobs, int n_jobs, const zkhip_params* prm, int in_flight, int host_traces) {
+    if (!jobs || n_jobs < 0 || !prm) return fail(ZKHIP_ERR_INVALID, "prove_shards: bad arguments");
+    if (n_jobs == 0) return ZKHIP_OK;
+    if (in_flight <= 0) in_flight = 4;
+    if (in_flight > n_jobs) in_flight = n_jobs;
+    for (int i = 0; i < n_jobs; i++) { jobs[i].status = ZKHIP_ERR_INVALID; jobs[i].proof_len = 0; }
+    std::atomic<int> next{0};
+    std::mutex mu;
+    int first_rc = ZKHIP_OK, first_job = n_jobs, ctx_rc = ZKHIP_OK;
+    std::string first_msg, ctx_msg;
+    auto note = [&](int job, int rc) {                     // keep the failure of the lowest job index
+        std::lock_guard<std::mutex> lk(mu);
+        if (job < first_job) { first_job = job; first_rc = rc; first_msg = zkhip_last_error(); }
+    };
+    auto worker = [&]() {
+        zkhip_ctx* ctx = pool_take(device);
+        int rc = ctx ? ZKHIP_OK : zkhip_ctx_create(device, nullptr, &ctx);
+        if (rc != ZKHIP_OK) {                                // e.g. no memory for one more workspace: the other workers carry on
+            std::lock_guard<std::mutex> lk(mu);
+            ctx_rc = rc; ctx_msg = zkhip_last_error();
+            return;
+        }
+        for (;;) {
+            const int i = next.fetch_add(1);
+            if (i >= n_jobs) break;
+            zkhip_shard_job& j = jobs[i];
+            size_t len = 0;
+            rc = host_traces
+                     ? zkhip_prove_shard_host(ctx, j.trace, j.log_n, j.width, j.public_values, j.n_public, prm, j.proof, j.proof_cap, &len)
+                     : zkhip_prove_shard(ctx, j.trace, j.ld, j.log_n, j.width, j.public_values, j.n_public, prm, j.proof, j.proof_cap, &len);
+            j.status = rc;
+            j.proof_len = rc == ZKHIP_OK ? len : 0;
+            if (rc != ZKHIP_OK) note(i, rc);
+        }
+        zkhip_ctx_sync(ctx);
+        pool_give(device, ctx);
+    };
+    if (in_flight == 1) {
+        worker();
+    } else {
+        std::vector<std::thread> pool;
+        for (int t = 0; t < in_flight; t++) pool.emplace_back(worker);
+        for (auto& t : pool) t.join();
+    }
+    if (first_rc != ZKHIP_OK) { set_error(first_msg); return first_rc; }
+    for (int i = 0; i < n_jobs; i++)                         // jobs nobody could take: every worker failed to get a context
+        if (jobs[i].status != ZKHIP_OK) { set_error(ctx_msg.empty() ? "prove_shards: job not run" : ctx_msg); return ctx_rc != ZKHIP_OK ? ctx_rc : ZKHIP_ERR_INVALID; }
+    return ZKHIP_OK;
 }
 
 int zkhip_prove_segment(zkhip_ctx* ctx, const uint32_t* d_cols, int log_n, uint32_t width,

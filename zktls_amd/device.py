@@ -299,6 +299,32 @@ class Context:
                 for k, _ in ProveDebug._fields_}
 
 
+def prove_shards(traces, log_n, width, public_values_list, params=None, device=0, in_flight=4, host=False):
+    """zkhip_prove_shards: `traces` are DeviceBuffers (Montgomery, dense) or, with host=True, numpy arrays of canonical words.
+    Returns the list of proofs (numpy uint8 arrays)."""
+    lib = _lib.load()
+    params = params or Params(1, 100, 16, 0)
+    n = len(traces)
+    jobs = (_lib.ShardJob * n)()
+    pvs, bufs, arrs = [], [], []
+    for i, (t, pv) in enumerate(zip(traces, public_values_list)):
+        pva = np.ascontiguousarray(np.array(pv, dtype=np.uint32))
+        size = lib.zkhip_proof_size(log_n, width, C.byref(params), pva.size)
+        buf = np.empty(max(size, 1), dtype=np.uint8)
+        if host:
+            arr = np.ascontiguousarray(t, dtype=np.uint32)
+            arrs.append(arr)
+            ptr = arr.ctypes.data
+        else:
+            ptr = t.ptr
+        pvs.append(pva); bufs.append(buf)
+        jobs[i].trace = ptr; jobs[i].ld = width; jobs[i].log_n = log_n; jobs[i].width = width
+        jobs[i].public_values = pva.ctypes.data_as(u32p); jobs[i].n_public = pva.size
+        jobs[i].proof = buf.ctypes.data_as(u8p); jobs[i].proof_cap = size
+    check(lib.zkhip_prove_shards(int(device), jobs, n, C.byref(params), int(in_flight), 1 if host else 0))
+    return [bufs[i][: jobs[i].proof_len] for i in range(n)]
+
+
 def verify_shard(proof, log_n, width, public_values=(), params=None):
     params = params or Params(1, 100, 16)
     lib = _lib.load()

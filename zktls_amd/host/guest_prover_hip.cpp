@@ -92,10 +92,33 @@ bool unpack_shard_proofs(const std::vector<uint8_t>& blob, std::vector<std::vect
 }
 
 namespace {
+// A worker's context and trace buffer.  Creating and freeing a context (stream + multi-GiB workspaces) costs more than a proof,
+// and a prover serves many requests, so finished workers park them in a process-wide pool (zktls_release_cached frees it).
+struct Slot { int device; size_t trace_bytes; zkhip_ctx* ctx; void* d_trace; };
+std::mutex g_slots_mu;
+std::vector<Slot> g_slots;
 struct CtxGuard {
+    int device = 0;
+    size_t trace_bytes = 0;
     zkhip_ctx* ctx = nullptr;
     void* d_trace = nullptr;
+    bool healthy = false;               // set once the worker finished without an error: only then is the slot reused
+    bool take(int dev, size_t bytes) {
+        std::lock_guard<std::mutex> lk(g_slots_mu);
+        for (size_t i = 0; i < g_slots.size(); i++)
+            if (g_slots[i].device == dev && g_slots[i].trace_bytes == bytes) {
+                ctx = g_slots[i].ctx; d_trace = g_slots[i].d_trace; device = dev; trace_bytes = bytes;
+                g_slots.erase(g_slots.begin() + (long)i);
+                return true;
+            }
+        return false;
+    }
     ~CtxGuard() {
+        if (healthy && ctx && d_trace) {
+            std::lock_guard<std::mutex> lk(g_slots_mu);
+            g_slots.push_back(Slot{device, trace_bytes, ctx, d_trace});
+            return;
+        }
         if (ctx && d_trace) zkhip_free(ctx, d_trace);
         if (ctx) zkhip_ctx_destroy(ctx);
     }
@@ -165,8 +188,11 @@ ProveResult HipGuestProver::prove_inner(const GuestInput& input, const std::vect
     auto worker = [&]() {
         try {
             CtxGuard g;
-            if (zkhip_ctx_create(device_, nullptr, &g.ctx) != ZKHIP_OK) fail_zkhip("zkhip_ctx_create");
-            if (zkhip_malloc(g.ctx, words * 4, &g.d_trace) != ZKHIP_OK) fail_zkhip("zkhip_malloc");
+            if (!g.take(device_, words * 4)) {
+                g.device = device_; g.trace_bytes = words * 4;
+                if (zkhip_ctx_create(device_, nullptr, &g.ctx) != ZKHIP_OK) fail_zkhip("zkhip_ctx_create");
+                if (zkhip_malloc(g.ctx, words * 4, &g.d_trace) != ZKHIP_OK) fail_zkhip("zkhip_malloc");
+            }
             for (;;) {
                 const uint32_t s = next.fetch_add(1);
                 if (s >= plan_.shards || failed.load()) break;
@@ -185,6 +211,7 @@ ProveResult HipGuestProver::prove_inner(const GuestInput& input, const std::vect
                     fail_zkhip("zkhip_verify_shard");   // sp1.rs:120: the prover checks its own proof
                 proofs[s] = std::move(proof);
             }
+            g.healthy = true;
         } catch (const std::exception& e) {              // a panic in one worker must not escape its thread (sp1.rs:85)
             failed.store(true);
             std::lock_guard<std::mutex> lk(err_mu);
@@ -208,10 +235,19 @@ ProveResult HipGuestProver::prove_inner(const GuestInput& input, const std::vect
     return r;
 }
 
+void release_cached() {
+    std::vector<Slot> all;
+    { std::lock_guard<std::mutex> lk(g_slots_mu); all.swap(g_slots); }
+    for (auto& e : all) { zkhip_free(e.ctx, e.d_trace); zkhip_ctx_destroy(e.ctx); }
+}
+
 }  // namespace zktls
 
 // ---- flat C surface so the tests (ctypes) and other FFIs can drive the mirror ----
 extern "C" {
+
+// frees the contexts and trace buffers parked by finished workers
+void zktls_release_cached(void) { zktls::release_cached(); }
 
 struct zktls_shard_plan { int32_t log_n; uint32_t width; uint32_t shards; int32_t num_queries; int32_t pow_bits; };
 

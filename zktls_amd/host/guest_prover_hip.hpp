@@ -96,6 +96,9 @@ public:
     explicit Risc0HipGuestProver(int device = 0) : HipGuestProver(device, Backend::Risc0) {}
 };
 
+// workers park their context and trace buffer for the next request; this frees them
+void release_cached();
+
 // 8 canonical BabyBear words binding (input, ELF): the public values of every shard
 std::vector<uint32_t> request_digest(const std::vector<uint8_t>& cbor, const std::vector<uint8_t>& elf);
 
