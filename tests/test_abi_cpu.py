@@ -42,6 +42,15 @@ def test_no_cpu_fallback_without_device():
     from zktls_amd.device import Context
     with pytest.raises(_lib.ZkHipError):
         Context(0)
+    # the batch entry spawns workers that each need a context: without a device every job stays unproven and the call says why
+    jobs = (_lib.ShardJob * 3)()
+    prm = _lib.Params(1, 10, 4)
+    assert L.zkhip_prove_shards(0, jobs, 0, C.byref(prm), 2, 0) == 0              # an empty batch is fine
+    rc = L.zkhip_prove_shards(0, jobs, 3, C.byref(prm), 2, 0)
+    assert rc == -2 and b"no CPU fallback" in L.zkhip_last_error()
+    assert all(j.status != 0 and j.proof_len == 0 for j in jobs)
+    assert L.zkhip_prove_shards(0, None, 3, C.byref(prm), 2, 0) != 0
+    L.zkhip_release_cached_contexts()
 
 
 def test_product_does_not_import_oracle():

@@ -114,6 +114,7 @@ def load():
     L.zkhip_commit.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_uint32, C.c_int, C.c_int, C.c_void_p, C.c_void_p, u32p]
     L.zkhip_prove_shard_host.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_uint32, u32p, C.c_size_t,
                                          C.POINTER(Params), u8p, C.c_size_t, C.POINTER(C.c_size_t)]
+    L.zkhip_release_cached_contexts.restype = None
     L.zkhip_prove_shards.argtypes = [C.c_int, C.POINTER(ShardJob), C.c_int, C.POINTER(Params), C.c_int, C.c_int]
     L.zkhip_prove_segment.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_uint32, u32p, C.c_size_t,
                                       C.POINTER(Params), u8p, C.c_size_t, C.POINTER(C.c_size_t)]
