@@ -1,4 +1,6 @@
 #!/bin/bash
-# exploration: per-pass durations inside back-to-back coset LDEs (rocprofv3 kernel trace), default settings
+# exploration: per-pass durations inside back-to-back coset LDEs for several tile orders of the block-in / strided-out passes
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
-rocprofv3 --kernel-trace --output-format csv -d gpurun_out/prof_lde_0 -o run -- python3 tools/lde_loop.py > /dev/null 2>&1
+for m in 104 100 102 103 105 106; do
+  ZKHIP_NTT_MAP=$m rocprofv3 --kernel-trace --output-format csv -d gpurun_out/prof_lde_$m -o run -- python3 tools/lde_loop.py > /dev/null 2>&1
+done

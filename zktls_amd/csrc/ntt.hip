@@ -492,6 +492,10 @@ hipError_t launch_ntt_pass(const NttPassArgs& a_, bool inverse, hipStream_t s) {
     // and destination happen to map that window onto the same channels the pass drops from 0.48 to 0.53 ms (two classes of buffers,
     // slow iff both are in the same class: tools/ntt_buffer_quality.py); spread out, both cases run at 0.486-0.494 ms (tools/ntt_map_ab.py).
     const bool pow2_tiles = (a.num_tiles & (a.num_tiles - 1u)) == 0;
+    if (a.map_mode >= 100u && a.map_mode < 116u) {           // A/B: 100 + r = rotation r for block-in / strided-out passes only, automatic otherwise
+        const uint32_t r = a.map_mode - 100u;
+        a.map_mode = (a.in_stride == 1 && a.out_stride != 1) ? (r == 0 ? 1u : r) : 255u;
+    }
     if (a.map_mode == 255u) a.map_mode = (a.in_stride != 1 || a.out_stride != 1) && pow2_tiles && a.num_tiles >= 1024u ? 4u : 1u;     // smaller transforms lose 3-8 % with it
     if (a.map_mode == 1 && (a.num_tiles % 8u) != 0) a.map_mode = 0;
     if (a.map_mode >= 2 && ((a.num_tiles % 8u) != 0 || !pow2_tiles)) a.map_mode = 0;
