@@ -225,6 +225,42 @@ ZK_HD constexpr Ext ext_inv(const Ext& a) {
     return ext_mul_base(conj, finv(norm));
 }
 
+#if defined(__HIPCC__)
+// Device form of ext_mul (same value): every output coefficient is ONE running 64-bit sum of four products (dacc2) and one
+// Montgomery reduction; the x^4 = W wrap-around is folded into b beforehand (3 products).  6 multiplies + 4 conditional
+// subtractions per coefficient against roughly twice that through the portable form.
+ZK_D Ext ext_mul_dev(const Ext& a, const Ext& b) {
+    const uint32_t w1 = dmul(b.c[1], MONTY_EXT_W), w2 = dmul(b.c[2], MONTY_EXT_W), w3 = dmul(b.c[3], MONTY_EXT_W);
+    uint64_t s0 = 0, s1 = 0, s2 = 0, s3 = 0;
+    dacc2(s0, a.c[0], b.c[0], a.c[1], w3); dacc2(s0, a.c[2], w2, a.c[3], w1);
+    dacc2(s1, a.c[0], b.c[1], a.c[1], b.c[0]); dacc2(s1, a.c[2], w3, a.c[3], w2);
+    dacc2(s2, a.c[0], b.c[2], a.c[1], b.c[1]); dacc2(s2, a.c[2], b.c[0], a.c[3], w3);
+    dacc2(s3, a.c[0], b.c[3], a.c[1], b.c[2]); dacc2(s3, a.c[2], b.c[1], a.c[3], b.c[0]);
+    return Ext{{dacc_finish(s0), dacc_finish(s1), dacc_finish(s2), dacc_finish(s3)}};
+}
+ZK_D Ext ext_mul_base_dev(const Ext& a, uint32_t b) { return Ext{{dmul(a.c[0], b), dmul(a.c[1], b), dmul(a.c[2], b), dmul(a.c[3], b)}}; }
+// a^(P-2) with the tuned product: P - 2 = 0x77ffffff
+ZK_D uint32_t finv_dev(uint32_t a) {
+    uint32_t r = MONTY_R1;
+    uint32_t e = P - 2;
+#pragma unroll 1
+    while (e) { if (e & 1u) r = dmul(r, a); a = dmul(a, a); e >>= 1; }
+    return r;
+}
+// device form of ext_inv (same value, zero maps to zero)
+ZK_D Ext ext_inv_dev(const Ext& a) {
+    const Ext f1 = Ext{{a.c[0], dmul(a.c[1], FROB_Z1), dmul(a.c[2], FROB_Z2), dmul(a.c[3], FROB_Z3)}};
+    const Ext f2 = Ext{{f1.c[0], dmul(f1.c[1], FROB_Z1), dmul(f1.c[2], FROB_Z2), dmul(f1.c[3], FROB_Z3)}};
+    const Ext f3 = Ext{{f2.c[0], dmul(f2.c[1], FROB_Z1), dmul(f2.c[2], FROB_Z2), dmul(f2.c[3], FROB_Z3)}};
+    const Ext conj = ext_mul_dev(ext_mul_dev(f1, f2), f3);
+    // norm = coefficient 0 of a * conj (the others vanish)
+    uint64_t s0 = 0;
+    dacc2(s0, a.c[0], conj.c[0], a.c[1], dmul(conj.c[3], MONTY_EXT_W));
+    dacc2(s0, a.c[2], dmul(conj.c[2], MONTY_EXT_W), a.c[3], dmul(conj.c[1], MONTY_EXT_W));
+    return ext_mul_base_dev(conj, finv_dev(dacc_finish(s0)));
+}
+#endif
+
 ZK_HD constexpr uint32_t reverse_bits(uint32_t x, int bits) {
     uint32_t r = 0;
     for (int i = 0; i < bits; i++) { r = (r << 1) | (x & 1); x >>= 1; }

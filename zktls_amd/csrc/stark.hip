@@ -178,32 +178,32 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(QWPE, 
             const uint32_t* prow = a.perm + (uint64_t)p * a.perm_ld;
             const uint32_t* pnrow = a.perm + (uint64_t)pn * a.perm_ld;
             const uint32_t* wl = a.alpha_pow + 16 * G;                 // [Q + 3] ext weights
-            const Ext F1 = ext_mul_base(ld_ext(wl + 4 * a.pairs), sel_first);
-            const Ext F2 = ext_mul_base(ld_ext(wl + 4 * (a.pairs + 1)), sel_trans);
+            const Ext F1 = ext_mul_base_dev(ld_ext(wl + 4 * a.pairs), sel_first);
+            const Ext F2 = ext_mul_base_dev(ld_ext(wl + 4 * (a.pairs + 1)), sel_trans);
             // F1 and F2 multiply the SUMS of the lane's phi_q / phi'_q (two extension products per lane instead of two per pair)
             Ext sphi = ext_zero(), sphin = ext_zero();
             for (uint32_t q = lane; q < a.pairs; q += L) {
                 const uint4 vs = *reinterpret_cast<const uint4*>(row + 8 * q);
                 const uint4 vr = *reinterpret_cast<const uint4*>(row + 8 * q + 4);
-                const Ext ds = ext_add(ext_add_base(a.gamma, vs.x), ext_mul_base(a.beta, vs.y));
-                const Ext dr = ext_add(ext_add_base(a.gamma, vr.x), ext_mul_base(a.beta, vr.y));
+                const Ext ds = ext_add(ext_add_base(a.gamma, vs.x), ext_mul_base_dev(a.beta, vs.y));
+                const Ext dr = ext_add(ext_add_base(a.gamma, vr.x), ext_mul_base_dev(a.beta, vr.y));
                 const Ext phi = ld_ext(prow + 4 * q), phin = ld_ext(pnrow + 4 * q);
-                const Ext c = ext_sub(ext_mul(ext_mul(phi, ds), dr), ext_sub(dr, ds));
-                r = ext_add(r, ext_mul(c, ld_ext(wl + 4 * q)));
+                const Ext c = ext_sub(ext_mul_dev(ext_mul_dev(phi, ds), dr), ext_sub(dr, ds));
+                r = ext_add(r, ext_mul_dev(c, ld_ext(wl + 4 * q)));
                 sphi = ext_add(sphi, phi);
                 sphin = ext_add(sphin, phin);
             }
-            if ((uint32_t)lane < a.pairs) r = ext_sub(r, ext_add(ext_mul(F1, sphi), ext_mul(F2, sphin)));
+            if ((uint32_t)lane < a.pairs) r = ext_sub(r, ext_add(ext_mul_dev(F1, sphi), ext_mul_dev(F2, sphin)));
             if (lane == 0) {
                 const Ext S = ld_ext(prow + 4 * a.pairs), Sn = ld_ext(pnrow + 4 * a.pairs);
-                const Ext F3 = ext_mul_base(ld_ext(wl + 4 * (a.pairs + 2)), a.sel_last[p]);
-                r = ext_add(r, ext_add(ext_mul(F1, S), ext_add(ext_mul(F2, ext_sub(Sn, S)), ext_mul(F3, ext_sub(S, a.cumsum)))));
+                const Ext F3 = ext_mul_base_dev(ld_ext(wl + 4 * (a.pairs + 2)), a.sel_last[p]);
+                r = ext_add(r, ext_add(ext_mul_dev(F1, S), ext_add(ext_mul_dev(F2, ext_sub(Sn, S)), ext_mul_dev(F3, ext_sub(S, a.cumsum)))));
             }
         }
 #pragma unroll
         for (int i = 0; i < 4; i++) r.c[i] = row_group_sum(r.c[i], L);
         if (lane == 0 && live) {
-            r = ext_mul_base(r, inv_zh);
+            r = ext_mul_base_dev(r, inv_zh);
             st_ext(a.out + ((uint64_t)parity * (m >> 1) + (e >> 1)) * 4, r);
         }
 #pragma unroll
@@ -236,13 +236,13 @@ __global__ void __launch_bounds__(256) inv_denominators_kernel(const uint32_t* x
     const uint64_t p = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (p >= count) return;
     const uint32_t x = xs[p];
-    const Ext d0 = ext_inv(ext_neg(ext_sub_base(z0, x)));
+    const Ext d0 = ext_inv_dev(ext_neg(ext_sub_base(z0, x)));
     st_ext(out + 4 * p, d0);
-    if (xw && p < xw_count) st_ext(xw + 4 * p, ext_mul_base(d0, x));
+    if (xw && p < xw_count) st_ext(xw + 4 * p, ext_mul_base_dev(d0, x));
     if (npoints > 1) {
-        const Ext d1 = ext_inv(ext_neg(ext_sub_base(z1, x)));
+        const Ext d1 = ext_inv_dev(ext_neg(ext_sub_base(z1, x)));
         st_ext(out + 4 * (count + p), d1);
-        if (xw && p < xw_count) st_ext(xw + 4 * (xw_count + p), ext_mul_base(d1, x));
+        if (xw && p < xw_count) st_ext(xw + 4 * (xw_count + p), ext_mul_base_dev(d1, x));
     }
 }
 hipError_t launch_inv_denominators(const uint32_t* xs, uint64_t count, const Ext& z0, const Ext& z1, int npoints,
@@ -379,7 +379,7 @@ __global__ void __launch_bounds__(64) open_final_kernel(const uint32_t* partial,
     Ext sum = ext_zero();
     for (uint32_t c = threadIdx.x; c < nchunks; c += 64) sum = ext_add(sum, ld_ext(partial + 4 * (((uint64_t)c * npts + k) * width + col)));
     sum = group_sum(sum, 64);
-    if (threadIdx.x == 0) st_ext(out + 4 * (uint64_t)idx, ext_neg(ext_mul(sum, k ? scale1 : scale0)));
+    if (threadIdx.x == 0) st_ext(out + 4 * (uint64_t)idx, ext_neg(ext_mul_dev(sum, k ? scale1 : scale0)));
 }
 bool open_uses_quads(uint32_t width, uint64_t ld, const uint32_t* mat) {
     return width >= 64 && width % 4 == 0 && ld % 4 == 0 && ((uintptr_t)mat & 15u) == 0;
@@ -451,16 +451,16 @@ __global__ void __launch_bounds__(256) reduced_combine_kernel(ReducedArgs a, con
     const uint32_t qv[8] = {q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, q1.z, q1.w};
     Ext aq = ext_zero();
 #pragma unroll
-    for (int j = 0; j < 8; j++) aq = ext_add(aq, ext_mul_base(ld_ext(a.alpha_pow + 4 * j), qv[j]));
+    for (int j = 0; j < 8; j++) aq = ext_add(aq, ext_mul_base_dev(ld_ext(a.alpha_pow + 4 * j), qv[j]));
     const Ext d1 = ld_ext(a.dinv + 4 * p), d2 = ld_ext(a.dinv + 4 * (a.rows + p));
-    Ext r = ext_mul(a.off_loc, ext_mul(ext_sub(at, a.y_loc), d1));
-    r = ext_add(r, ext_mul(a.off_next, ext_mul(ext_sub(at, a.y_next), d2)));
+    Ext r = ext_mul_dev(a.off_loc, ext_mul_dev(ext_sub(at, a.y_loc), d1));
+    r = ext_add(r, ext_mul_dev(a.off_next, ext_mul_dev(ext_sub(at, a.y_next), d2)));
     if (a.p_width) {
         const Ext ap = ld_ext(ap_in + 4 * p);
-        r = ext_add(r, ext_mul(a.off_pl, ext_mul(ext_sub(ap, a.y_pl), d1)));
-        r = ext_add(r, ext_mul(a.off_pn, ext_mul(ext_sub(ap, a.y_pn), d2)));
+        r = ext_add(r, ext_mul_dev(a.off_pl, ext_mul_dev(ext_sub(ap, a.y_pl), d1)));
+        r = ext_add(r, ext_mul_dev(a.off_pn, ext_mul_dev(ext_sub(ap, a.y_pn), d2)));
     }
-    r = ext_add(r, ext_mul(a.off_q, ext_mul(ext_sub(aq, a.y_q), d1)));
+    r = ext_add(r, ext_mul_dev(a.off_q, ext_mul_dev(ext_sub(aq, a.y_q), d1)));
     if (a.accumulate) r = ext_add(r, ld_ext(a.out + 4 * p));
     st_ext(a.out + 4 * p, r);
 }
@@ -498,12 +498,12 @@ __global__ void __launch_bounds__(PERM_BLOCK) perm_rows_kernel(PermArgs a, uint3
         for (uint32_t q = 0; q < a.pairs; q++) {
             const uint4 vs = *reinterpret_cast<const uint4*>(row + 8 * q);
             const uint4 vr = *reinterpret_cast<const uint4*>(row + 8 * q + 4);
-            const Ext ds = ext_add(ext_add_base(a.gamma, vs.x), ext_mul_base(a.beta, vs.y));
-            const Ext dr = ext_add(ext_add_base(a.gamma, vr.x), ext_mul_base(a.beta, vr.y));
+            const Ext ds = ext_add(ext_add_base(a.gamma, vs.x), ext_mul_base_dev(a.beta, vs.y));
+            const Ext dr = ext_add(ext_add_base(a.gamma, vr.x), ext_mul_base_dev(a.beta, vr.y));
             // 1/ds - 1/dr = (dr - ds) / (ds dr): one extension inversion per pair instead of two (an inversion costs about six
             // extension products).  A zero denominator (1/0 = 0 by the oracle's convention) takes the direct formula.
-            const Ext d = ext_mul(ds, dr);
-            const Ext phi = ext_eq(d, ext_zero()) ? ext_sub(ext_inv(ds), ext_inv(dr)) : ext_mul(ext_sub(dr, ds), ext_inv(d));
+            const Ext d = ext_mul_dev(ds, dr);
+            const Ext phi = ext_eq(d, ext_zero()) ? ext_sub(ext_inv_dev(ds), ext_inv_dev(dr)) : ext_mul_dev(ext_sub(dr, ds), ext_inv_dev(d));
             st_ext(prow + 4 * q, phi);
             sum = ext_add(sum, phi);
         }
@@ -571,9 +571,9 @@ __global__ void __launch_bounds__(256) fri_fold_kernel(const uint32_t* in, uint3
     const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= half) return;
     const Ext e0 = ld_ext(in + 8 * i), e1 = ld_ext(in + 8 * i + 4);
-    const Ext s = ext_mul_base(ext_add(e0, e1), MONTY_INV2);
-    const Ext d = ext_mul_base(ext_sub(e0, e1), itw[i]);
-    st_ext(out + 4 * i, ext_add(s, ext_mul(beta, d)));
+    const Ext s = ext_mul_base_dev(ext_add(e0, e1), MONTY_INV2);
+    const Ext d = ext_mul_base_dev(ext_sub(e0, e1), itw[i]);
+    st_ext(out + 4 * i, ext_add(s, ext_mul_dev(beta, d)));
 }
 hipError_t launch_fri_fold(const uint32_t* in, uint32_t* out, const uint32_t* itw, uint64_t half, const Ext& beta, hipStream_t s) {
     hipLaunchKernelGGL(fri_fold_kernel, dim3((unsigned)((half + 255) / 256)), dim3(256), 0, s, in, out, itw, half, beta);
@@ -585,11 +585,11 @@ __global__ void __launch_bounds__(256) fri_fold_dev_kernel(const uint32_t* in, u
     const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= half) return;
     Ext beta = ld_ext(beta_ptr);
-    for (int j = 0; j < squarings; j++) beta = ext_mul(beta, beta);
+    for (int j = 0; j < squarings; j++) beta = ext_mul_dev(beta, beta);
     const Ext e0 = ld_ext(in + 8 * i), e1 = ld_ext(in + 8 * i + 4);
-    const Ext s = ext_mul_base(ext_add(e0, e1), MONTY_INV2);
-    const Ext d = ext_mul_base(ext_sub(e0, e1), itw[i]);
-    st_ext(out + 4 * i, ext_add(s, ext_mul(beta, d)));
+    const Ext s = ext_mul_base_dev(ext_add(e0, e1), MONTY_INV2);
+    const Ext d = ext_mul_base_dev(ext_sub(e0, e1), itw[i]);
+    st_ext(out + 4 * i, ext_add(s, ext_mul_dev(beta, d)));
 }
 hipError_t launch_fri_fold_dev(const uint32_t* in, uint32_t* out, const uint32_t* itw, uint64_t half, const uint32_t* beta_ptr,
                                int squarings, hipStream_t s) {
