@@ -1,5 +1,7 @@
 """exploration: as overlap_probe.py, but the two contexts sit on streams made with hipExtStreamCreateWithCUMask and a FULL mask
-(guaranteed separate hardware queues, no partition)"""
+(guaranteed separate hardware queues, no partition).
+The "reserved room" variant quoted in DESIGN.md section 7 additionally launched the leaf kernel with 1024 threads and 81 KiB of
+dynamic LDS per workgroup through a temporary launch knob that was not kept."""
 import ctypes as C, sys, time, threading
 sys.path.insert(0, "/root/repo")
 from zktls_amd.device import Context
