@@ -352,6 +352,7 @@ void zkhip_ctx_destroy(zkhip_ctx* ctx) {
     if (!ctx) return;
     (void)hipSetDevice(ctx->device);
     if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
+    if (ctx->fri_graph_exec) (void)hipGraphExecDestroy(ctx->fri_graph_exec);
     for (NttPlan& p : ctx->plans) { if (p.pre) (void)hipFree(p.pre); if (p.post) (void)hipFree(p.post); }
     for (DeviceBuffer& b : ctx->scratch) if (b.ptr) (void)hipFree(b.ptr);
     if (ctx->w1024_fwd) (void)hipFree(ctx->w1024_fwd);

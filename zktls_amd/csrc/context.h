@@ -63,6 +63,10 @@ struct zkhip_ctx {
     uint32_t* dom_sel_first = nullptr; // Z_H(x_p) / (x_p - 1)
     uint32_t* dom_sel_last = nullptr;  // Z_H(x_p) / (x_p - w_N^-1)
     uint32_t* dom_itw = nullptr;       // w_M^-bitrev(i) / 2, i < M / 2 (FRI fold)
+    // FRI commit phase as a HIP graph (prover.cpp): ~250 small launches of a fixed shape, replayed from one graph launch;
+    // the key is every size and pointer the launches depend on
+    std::vector<uint64_t> fri_graph_key;
+    hipGraphExec_t fri_graph_exec = nullptr;
 };
 
 namespace zk {

@@ -224,6 +224,7 @@ static int fri_commit_phase(zkhip_ctx* ctx, Challenger& ch, const Shape& sh, int
         ZK_TRY(h2d(ctx, d_chal, &hc, sizeof hc));
     }
     // (a single-workgroup kernel walking all layers of <= 512 rows was tried: no faster than these launches)
+    auto enqueue_layers = [&]() -> int {
     for (int l = 0; l < RL; l++) {
         const int lh = H - K * (l + 1);
         const size_t rows = (size_t)1 << lh;
@@ -250,6 +251,36 @@ static int fri_commit_phase(zkhip_ctx* ctx, Challenger& ch, const Shape& sh, int
         }
         const int reached = H - K * (l + 1);
         if (inject && inject[reached]) ZK_HIP(launch_ext_add(layers + layer_off[l + 1], inject[reached], (uint64_t)1 << reached, st));
+    }
+    return ZKHIP_OK;
+    };
+    // With the transcript on the device the loop above is a fixed sequence of ~12 small launches per layer that depends only on
+    // sizes and workspace addresses: it is captured once into a HIP graph and replayed with one launch per proof
+    // (ZKHIP_FRI_GRAPH=0 keeps the plain launches); capture is thread-local, other contexts' threads are not affected.
+    static const bool use_graph = [] { const char* e = getenv("ZKHIP_FRI_GRAPH"); return !e || atoi(e) != 0; }();
+    if (d_chal && use_graph) {
+        std::vector<uint64_t> key = {(uint64_t)H, (uint64_t)K, (uint64_t)RL, (uint64_t)sh.hw, (uint64_t)m, (uint64_t)(uintptr_t)layers,
+                                     (uint64_t)(uintptr_t)ltrees, (uint64_t)(uintptr_t)fold_tmp, (uint64_t)(uintptr_t)d_chal,
+                                     (uint64_t)(uintptr_t)ctx->dom_itw};
+        for (size_t o : layer_off) key.push_back(o);
+        for (size_t o : tree_off) key.push_back(o);
+        if (inject) for (int h = 0; h <= H; h++) key.push_back((uint64_t)(uintptr_t)inject[h]);
+        if (!ctx->fri_graph_exec || ctx->fri_graph_key != key) {
+            if (ctx->fri_graph_exec) { (void)hipGraphExecDestroy(ctx->fri_graph_exec); ctx->fri_graph_exec = nullptr; }
+            hipGraph_t graph = nullptr;
+            ZK_HIP(hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal));
+            const int rc = enqueue_layers();
+            const hipError_t ce = hipStreamEndCapture(st, &graph);
+            if (rc != ZKHIP_OK) { if (graph) (void)hipGraphDestroy(graph); return rc; }
+            ZK_HIP(ce);
+            const hipError_t ie = hipGraphInstantiate(&ctx->fri_graph_exec, graph, nullptr, nullptr, 0);
+            (void)hipGraphDestroy(graph);
+            ZK_HIP(ie);
+            ctx->fri_graph_key = key;
+        }
+        ZK_HIP(hipGraphLaunch(ctx->fri_graph_exec, st));
+    } else {
+        ZK_TRY(enqueue_layers());
     }
     if (d_chal) {
         std::vector<uint32_t> log((size_t)RL * 12);
