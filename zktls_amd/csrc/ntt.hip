@@ -47,8 +47,19 @@ constexpr int rev5(int r) {
 // Montgomery multiplicand), so a butterfly is add + dred, two plain adds, dmont_lazy + dred.
 // LAZY_OUT (only legal for the twiddle-free stage 4): sums and differences are left in
 // [0, 2P) because the next thing that touches them is a Montgomery multiplication.
+// (a - b) * w for canonical a, b and a compile-time twiddle, through the signed Montgomery product: the difference is taken as an
+// int32 in (-P, P) (one v_sub instead of the two additions of a - b + P), the twiddle is centred (|w| <= P/2), and the bias P 2^32
+// rides as the addend of the first v_mad_i64_i32, so the reduced value lands in (0.26 P, 1.74 P) and one conditional subtraction
+// finishes: 6 instructions instead of 7 per twiddled butterfly.
+ZK_D uint32_t dbfly_mul(uint32_t a, uint32_t b, int32_t wc, int64_t bias) {
+    const int32_t d = (int32_t)(a - b);
+    const int64_t x = (int64_t)d * wc + bias;
+    const int32_t m = (int32_t)((uint32_t)x * MONTY_MU_POS);
+    const int64_t y = x + (int64_t)m * (int64_t)(-(int32_t)P);
+    return dred((uint32_t)(y >> 32));
+}
 template <bool INV, int S, bool LAZY_OUT = false>
-ZK_D void dif_stage(uint32_t (&x)[32]) {
+ZK_D void dif_stage(uint32_t (&x)[32], int64_t bias) {
     constexpr int half = 16 >> S;
     constexpr int stride = 16 / half;
     static_assert(!LAZY_OUT || S == 4, "lazy outputs only after the twiddle-free stage");
@@ -62,7 +73,11 @@ ZK_D void dif_stage(uint32_t (&x)[32]) {
                 x[base + j + half] = dsub_lazy(a, b);
             } else {
                 x[base + j] = dadd(a, b);
+#ifdef NTT_UNSIGNED_BFLY
                 x[base + j + half] = (j == 0) ? dsub(a, b) : dmul(dsub_lazy(a, b), (INV ? TW32_INV : TW32_FWD).w[j * stride]);
+#else
+                x[base + j + half] = (j == 0) ? dsub(a, b) : dbfly_mul(a, b, centered((INV ? TW32_INV : TW32_FWD).w[j * stride]), bias);
+#endif
             }
         }
     }
@@ -96,6 +111,8 @@ __global__ void __launch_bounds__(32 << LOG_C, 4) ntt_pass_kernel(NttPassArgs a)
     uint32_t* spost = stw + M;
     uint32_t* spre = spost + M;
 
+    int64_t bias = (int64_t)((uint64_t)P << 32);     // dbfly_mul's addend: kept opaque so that it stays the addend of a mad
+    asm volatile("" : "+v"(bias));
     const int tid = threadIdx.x;
     const int c = tid & (C - 1);
     const int u = tid >> LOG_C;
@@ -189,11 +206,11 @@ __global__ void __launch_bounds__(32 << LOG_C, 4) ntt_pass_kernel(NttPassArgs a)
     // CPT = 2 for ILP is what pushed the register allocation over 128 and into scratch.
 #pragma unroll
     for (int cc = 0; cc < CPT; cc++) {
-        dif_stage<INV, 0>(x[cc]);
-        dif_stage<INV, 1>(x[cc]);
-        dif_stage<INV, 2>(x[cc]);
-        dif_stage<INV, 3>(x[cc]);
-        dif_stage<INV, 4, true>(x[cc]);    // lazy: every output is multiplied (or reduced) next
+        dif_stage<INV, 0>(x[cc], bias);
+        dif_stage<INV, 1>(x[cc], bias);
+        dif_stage<INV, 2>(x[cc], bias);
+        dif_stage<INV, 3>(x[cc], bias);
+        dif_stage<INV, 4, true>(x[cc], bias);    // lazy: every output is multiplied (or reduced) next
 #pragma unroll
         for (int r = 1; r < 32; r++) x[cc][r] = dmul(x[cc][r], stw[u * rev5(r)]);
         x[cc][0] = dred(x[cc][0]);
@@ -220,13 +237,13 @@ __global__ void __launch_bounds__(32 << LOG_C, 4) ntt_pass_kernel(NttPassArgs a)
     // ---- phase B: P-point DIFs = the last b stages of the 32-point network
 #pragma unroll
     for (int cc = 0; cc < CPT; cc++) {
-        if (b >= 5) dif_stage<INV, 0>(x[cc]);
-        if (b >= 4) dif_stage<INV, 1>(x[cc]);
-        if (b >= 3) dif_stage<INV, 2>(x[cc]);
-        if (b >= 2) dif_stage<INV, 3>(x[cc]);
+        if (b >= 5) dif_stage<INV, 0>(x[cc], bias);
+        if (b >= 4) dif_stage<INV, 1>(x[cc], bias);
+        if (b >= 3) dif_stage<INV, 2>(x[cc], bias);
+        if (b >= 2) dif_stage<INV, 3>(x[cc], bias);
         if (b >= 1) {
-            if (has_post) dif_stage<INV, 4, true>(x[cc]);   // outputs go straight into the post multiplication
-            else dif_stage<INV, 4>(x[cc]);
+            if (has_post) dif_stage<INV, 4, true>(x[cc], bias);   // outputs go straight into the post multiplication
+            else dif_stage<INV, 4>(x[cc], bias);
         }
         if (CPT > 1) __builtin_amdgcn_sched_barrier(0);
     }
@@ -320,6 +337,8 @@ ZK_D ItemPos item_pos(uint32_t item, uint32_t ncg, uint32_t map_mode) {
 // both columns with one ds_write_b64 / ds_read_b64.
 template <bool INV>
 __global__ void __launch_bounds__(512) ntt_pass1024x2_kernel(NttPassArgs a, uint32_t total_items) {
+    int64_t bias = (int64_t)((uint64_t)P << 32);
+    asm volatile("" : "+v"(bias));
     extern __shared__ uint32_t lds[];
     constexpr int C = 32, C2 = 16, Pn = 32, M = 1024, pitch2 = (Pn + 1) * C2;   // pitch in column pairs
     uint2* sdata = reinterpret_cast<uint2*>(lds);
@@ -381,11 +400,11 @@ __global__ void __launch_bounds__(512) ntt_pass1024x2_kernel(NttPassArgs a, uint
                 x0[k] = dmul(x0[k], w); x1[k] = dmul(x1[k], w);
             }
         }
-        dif_stage<INV, 0>(x0); dif_stage<INV, 0>(x1);
-        dif_stage<INV, 1>(x0); dif_stage<INV, 1>(x1);
-        dif_stage<INV, 2>(x0); dif_stage<INV, 2>(x1);
-        dif_stage<INV, 3>(x0); dif_stage<INV, 3>(x1);
-        dif_stage<INV, 4, true>(x0); dif_stage<INV, 4, true>(x1);
+        dif_stage<INV, 0>(x0, bias); dif_stage<INV, 0>(x1, bias);
+        dif_stage<INV, 1>(x0, bias); dif_stage<INV, 1>(x1, bias);
+        dif_stage<INV, 2>(x0, bias); dif_stage<INV, 2>(x1, bias);
+        dif_stage<INV, 3>(x0, bias); dif_stage<INV, 3>(x1, bias);
+        dif_stage<INV, 4, true>(x0, bias); dif_stage<INV, 4, true>(x1, bias);
         {
             uint2* wp = sdata + u * C2 + c2;
 #pragma unroll
@@ -401,15 +420,15 @@ __global__ void __launch_bounds__(512) ntt_pass1024x2_kernel(NttPassArgs a, uint
 #pragma unroll
             for (int rho = 0; rho < 32; rho++) { const uint2 v = rp[rho * C2]; x0[rho] = v.x; x1[rho] = v.y; }
         }
-        dif_stage<INV, 0>(x0); dif_stage<INV, 0>(x1);
-        dif_stage<INV, 1>(x0); dif_stage<INV, 1>(x1);
-        dif_stage<INV, 2>(x0); dif_stage<INV, 2>(x1);
-        dif_stage<INV, 3>(x0); dif_stage<INV, 3>(x1);
+        dif_stage<INV, 0>(x0, bias); dif_stage<INV, 0>(x1, bias);
+        dif_stage<INV, 1>(x0, bias); dif_stage<INV, 1>(x1, bias);
+        dif_stage<INV, 2>(x0, bias); dif_stage<INV, 2>(x1, bias);
+        dif_stage<INV, 3>(x0, bias); dif_stage<INV, 3>(x1, bias);
         uint32_t* ob = a.out + (uint64_t)cur.tile * a.out_tile_mul * a.out_ld + cur.cg * C;
         const auto ors = __builtin_amdgcn_make_buffer_rsrc(ob, 0, out_rec, 0x00020000);
         const uint32_t out_off = (a.bitrev_out ? 32u * (__brev((uint32_t)u) >> 27) : (uint32_t)u) * ostep_b + 8u * (uint32_t)c2;
         if (has_post) {
-            dif_stage<INV, 4, true>(x0); dif_stage<INV, 4, true>(x1);
+            dif_stage<INV, 4, true>(x0, bias); dif_stage<INV, 4, true>(x1, bias);
 #pragma unroll
             for (int rho = 0; rho < 32; rho++) {
                 const uint32_t w = spost[32 * rev5(rho) + u];
@@ -418,7 +437,7 @@ __global__ void __launch_bounds__(512) ntt_pass1024x2_kernel(NttPassArgs a, uint
                 __builtin_amdgcn_raw_buffer_store_b64(v, ors, out_off, ro * ostep_b, 0);
             }
         } else {
-            dif_stage<INV, 4>(x0); dif_stage<INV, 4>(x1);
+            dif_stage<INV, 4>(x0, bias); dif_stage<INV, 4>(x1, bias);
 #pragma unroll
             for (int rho = 0; rho < 32; rho++) {
                 const uint32_t ro = a.bitrev_out ? (uint32_t)rho : (uint32_t)(32 * rev5(rho));
