@@ -58,7 +58,15 @@ ZK_D uint32_t dbfly_mul(uint32_t a, uint32_t b, int32_t wc, int64_t bias) {
     const int64_t y = x + (int64_t)m * (int64_t)(-(int32_t)P);
     return dred((uint32_t)(y >> 32));
 }
-template <bool INV, int S, bool LAZY_OUT = false>
+// d * w for a signed difference d = a - b in (-P, P) left by the lazy last stage and a canonical table twiddle: result canonical
+ZK_D uint32_t dmul_sd(uint32_t d_bits, uint32_t w, int64_t bias) {
+    const int64_t x = (int64_t)(int32_t)d_bits * (int32_t)w + bias;           // |d w| < P^2 < P 2^32: positive with the bias
+    const int32_t m = (int32_t)((uint32_t)x * MONTY_MU_POS);
+    const int64_t y = x + (int64_t)m * (int64_t)(-(int32_t)P);
+    return dred((uint32_t)(y >> 32));                                          // (0.03 P, 1.97 P) -> [0, P)
+}
+// SD (with LAZY_OUT): the differences are left as int32 a - b (one instruction) for dmul_sd instead of a - b + P (two)
+template <bool INV, int S, bool LAZY_OUT = false, bool SD = false>
 ZK_D void dif_stage(uint32_t (&x)[32], int64_t bias) {
     constexpr int half = 16 >> S;
     constexpr int stride = 16 / half;
@@ -70,7 +78,7 @@ ZK_D void dif_stage(uint32_t (&x)[32], int64_t bias) {
             const uint32_t a = x[base + j], b = x[base + j + half];
             if (LAZY_OUT) {
                 x[base + j] = a + b;
-                x[base + j + half] = dsub_lazy(a, b);
+                x[base + j + half] = SD ? a - b : dsub_lazy(a, b);
             } else {
                 x[base + j] = dadd(a, b);
 #ifdef NTT_UNSIGNED_BFLY
@@ -111,6 +119,7 @@ __global__ void __launch_bounds__(32 << LOG_C, 4) ntt_pass_kernel(NttPassArgs a)
     uint32_t* spost = stw + M;
     uint32_t* spre = spost + M;
 
+    constexpr bool SD = BFIX == 5;                   // signed differences out of the lazy stages (1024-row tiles only)
     int64_t bias = (int64_t)((uint64_t)P << 32);     // dbfly_mul's addend: kept opaque so that it stays the addend of a mad
     asm volatile("" : "+v"(bias));
     const int tid = threadIdx.x;
@@ -210,9 +219,9 @@ __global__ void __launch_bounds__(32 << LOG_C, 4) ntt_pass_kernel(NttPassArgs a)
         dif_stage<INV, 1>(x[cc], bias);
         dif_stage<INV, 2>(x[cc], bias);
         dif_stage<INV, 3>(x[cc], bias);
-        dif_stage<INV, 4, true>(x[cc], bias);    // lazy: every output is multiplied (or reduced) next
+        dif_stage<INV, 4, true, SD>(x[cc], bias);    // lazy: every output is multiplied (or reduced) next
 #pragma unroll
-        for (int r = 1; r < 32; r++) x[cc][r] = dmul(x[cc][r], stw[u * rev5(r)]);
+        for (int r = 1; r < 32; r++) x[cc][r] = (SD && (r & 1)) ? dmul_sd(x[cc][r], stw[u * rev5(r)], bias) : dmul(x[cc][r], stw[u * rev5(r)]);
         x[cc][0] = dred(x[cc][0]);
         if (CPT > 1) __builtin_amdgcn_sched_barrier(0);
     }
@@ -242,7 +251,7 @@ __global__ void __launch_bounds__(32 << LOG_C, 4) ntt_pass_kernel(NttPassArgs a)
         if (b >= 3) dif_stage<INV, 2>(x[cc], bias);
         if (b >= 2) dif_stage<INV, 3>(x[cc], bias);
         if (b >= 1) {
-            if (has_post) dif_stage<INV, 4, true>(x[cc], bias);   // outputs go straight into the post multiplication
+            if (has_post) dif_stage<INV, 4, true, SD>(x[cc], bias);   // outputs go straight into the post multiplication
             else dif_stage<INV, 4>(x[cc], bias);
         }
         if (CPT > 1) __builtin_amdgcn_sched_barrier(0);
@@ -257,7 +266,7 @@ __global__ void __launch_bounds__(32 << LOG_C, 4) ntt_pass_kernel(NttPassArgs a)
             for (int rho = 0; rho < 32; rho++) {
                 const uint32_t w = spost[32 * rev5(rho) + u];
 #pragma unroll
-                for (int cc = 0; cc < CPT; cc++) x[cc][rho] = dmul(x[cc][rho], w);
+                for (int cc = 0; cc < CPT; cc++) x[cc][rho] = (SD && (rho & 1)) ? dmul_sd(x[cc][rho], w, bias) : dmul(x[cc][rho], w);
             }
         }
         if (active) {
