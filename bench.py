@@ -104,7 +104,11 @@ def main():
             # destinations of the roofline passes, allocated with the traces.  Three candidates: the strided pass runs in one of
             # two modes (0.48 / 0.53 ms) depending on where source and destination lie (tools/ntt_spacing_probe.py);
             # the section below times all three briefly, measures on the best and reports the spread.
-            roof_scratch = [torch.empty(n * width, dtype=torch.int32, device="cuda") for _ in range(3)]
+            roof_scratch, spacers = [], []
+            for _k in range(3):          # 3 GiB apart: buffer classes come in runs of a few GiB, neighbours share one
+                roof_scratch.append(torch.empty(n * width, dtype=torch.int32, device="cuda"))
+                spacers.append(torch.empty(3 * n * width, dtype=torch.int32, device="cuda"))
+            del spacers
         for i, b in enumerate(bufs):
             if LQ:
                 ctx.gen_trace_logup(SEED, rank * max(K, 1) + i, log_n, width, LQ, out=b)
@@ -115,7 +119,11 @@ def main():
         chip_bufs = [(ctx.gen_trace(SEED, 100 * rank + j, ln, w), ln, w) for j, (ln, w) in enumerate(chip_list)]
         with torch.cuda.stream(stream):
             traces = [torch.empty(n * width, dtype=torch.int32, device="cuda")]      # source of the roofline section only
-            roof_scratch = [torch.empty(n * width, dtype=torch.int32, device="cuda") for _ in range(3)]
+            roof_scratch, spacers = [], []
+            for _k in range(3):          # 3 GiB apart: buffer classes come in runs of a few GiB, neighbours share one
+                roof_scratch.append(torch.empty(n * width, dtype=torch.int32, device="cuda"))
+                spacers.append(torch.empty(3 * n * width, dtype=torch.int32, device="cuda"))
+            del spacers
         bufs = [ctx.wrap(traces[0])]
         ctx.fill_uniform(SEED, log_n, width, out=bufs[0])
     ctx.sync()
