@@ -10,12 +10,14 @@
 // owns a tile of M = 32*P rows x C columns (P = 2^b threads per column, b <= 5):
 //   load      thread (u, c) pulls x[u + P*n1], n1 = 0..31 straight into 32 VGPRs; the
 //             64 lanes of a wave cover 4 consecutive tile rows x 16 columns (4 x 64 B);
-//   phase A   32-point DIF in registers, twiddles are instruction literals;
+//   phase A   32-point DIF in registers, twiddles are compile-time constants (centred, scalar registers);
 //   twiddle   * w_M^(u*k1), table staged in LDS (broadcast reads);
 //   exchange  one pass through LDS, row pitch (P+1)*C words -> conflict-free both ways;
 //   phase B   the last b stages of the same 32-point network = P-point DIFs;
 //   store     * post[tile][k] (inter-pass twiddle / coset shift / 1/N, staged in LDS),
 //             written natural or bit-reversed inside the tile.
+// Launch side (launch_ntt_pass): cache policy (non-temporal loads and stores except on a strided pass run in place) and tile order
+// (XCD-aware; strided passes of 2^20-row transforms rotate the tile index by 4 bits) are chosen per launch.
 // No MFMA: a 31-bit modular butterfly is not a dense contraction.
 #include <atomic>
 #include <cstdio>
@@ -42,11 +44,11 @@ constexpr int rev5(int r) {
     return ((r & 1) << 4) | ((r & 2) << 2) | (r & 4) | ((r & 8) >> 2) | ((r & 16) >> 4);
 }
 
-// stage S of the 32-point decimation-in-frequency network (S = 0 pairs i, i+16).
-// Inputs are canonical.  The difference is taken lazily (a - b + P, any 32-bit value is a valid
-// Montgomery multiplicand), so a butterfly is add + dred, two plain adds, dmont_lazy + dred.
-// LAZY_OUT (only legal for the twiddle-free stage 4): sums and differences are left in
-// [0, 2P) because the next thing that touches them is a Montgomery multiplication.
+// stage S of the 32-point decimation-in-frequency network (S = 0 pairs i, i+16).  Inputs and outputs are canonical: a butterfly is
+// add + dred for the sum and, for the twiddled difference, one v_sub + a signed Montgomery product with the bias P 2^32 as its
+// addend + dred (dbfly_mul below; 3 + 6 instructions).  LAZY_OUT (only legal for the twiddle-free stage 4): the sum stays a plain
+// a + b in [0, 2P) and the difference a - b + P -- or, with SD, the int32 a - b -- because the next thing that touches them is a
+// Montgomery multiplication (dmul / dmul_sd).
 // (a - b) * w for canonical a, b and a compile-time twiddle, through the signed Montgomery product: the difference is taken as an
 // int32 in (-P, P) (one v_sub instead of the two additions of a - b + P), the twiddle is centred (|w| <= P/2), and the bias P 2^32
 // rides as the addend of the first v_mad_i64_i32, so the reduced value lands in (0.26 P, 1.74 P) and one conditional subtraction
