@@ -244,6 +244,14 @@ int op_merkle_commit(zkhip_ctx* ctx, const MatDesc* mats, int nmats, int log_h, 
     uint32_t* level = tree;
     uint64_t count = la.height;
     while (count > COOP_TOP_NODES) {
+        if (count <= COOP_MAX_NODES) {
+            // medium levels: one launch reduces the level to 32 nodes (each workgroup walks its own subtree), one more finishes
+            const uint32_t sub = (uint32_t)count / 32u;
+            ZK_HIP(launch_compress_sub(level, (uint32_t)count, sub, ctx->stream));
+            for (uint64_t c = count; c > 32; c >>= 1) level += 8 * c;
+            count = 32;
+            break;
+        }
         uint32_t* next = level + 8 * count;
         ZK_HIP(launch_compress_level(level, next, count / 2, ctx->stream));
         level = next; count >>= 1;

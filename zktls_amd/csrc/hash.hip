@@ -32,6 +32,7 @@ __device__ __forceinline__ uint32_t load_virtual(const LeafArgs& a, uint64_t row
 __global__ void hash_rows16_kernel(LeafArgs a, uint32_t total_w);
 __global__ void compress_level16_kernel(const uint32_t* __restrict__ children, uint32_t* __restrict__ parents, uint32_t count);
 __global__ void compress_top16_kernel(uint32_t* tree, uint32_t count);
+__global__ void compress_sub16_kernel(uint32_t* tree, uint32_t count, uint32_t sub);
 
 __global__ void __launch_bounds__(256) hash_rows_generic_kernel(LeafArgs a, uint32_t total_w) {
     const uint64_t row = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -163,6 +164,13 @@ hipError_t launch_compress_top(uint32_t* tree, uint32_t count, hipStream_t s) {
     return hipGetLastError();
 }
 
+hipError_t launch_compress_sub(uint32_t* tree, uint32_t count, uint32_t sub, hipStream_t s) {
+    if (sub < 2 || (sub & (sub - 1)) || count % sub || count > COOP_MAX_NODES) return hipErrorInvalidValue;
+    unsigned threads = sub * 8 < 64 ? 64 : (sub * 8 > 1024 ? 1024 : sub * 8);
+    hipLaunchKernelGGL(compress_sub16_kernel, dim3(count / sub), dim3(threads), 0, s, tree, count, sub);
+    return hipGetLastError();
+}
+
 // ------------------------------------------------------------------ latency-optimised form
 // One permutation spread over the 16 lanes of a DPP row (state word i in lane i): an
 // external round is 4 dependent products + ~13 dependent additions, an internal round one
@@ -236,6 +244,27 @@ __global__ void __launch_bounds__(1024) compress_top16_kernel(uint32_t* tree, ui
         __threadfence_block();
         __syncthreads();
         level = next;
+    }
+}
+// Several levels of a medium tree in one launch: `tree` points at a level with `count` digests (levels above follow it, as in
+// compress_top16_kernel); workgroup b reduces the `sub` consecutive digests [b sub, (b + 1) sub) of that level to one node, writing
+// its share of every level on the way.  count / sub nodes remain for compress_top16_kernel.
+__global__ void __launch_bounds__(1024) compress_sub16_kernel(uint32_t* tree, uint32_t count, uint32_t sub) {
+    const int lane16 = threadIdx.x & 15;
+    const uint32_t grp = threadIdx.x >> 4, ngrp = blockDim.x >> 4;
+    const CoopConsts k = coop_load_consts(lane16);
+    uint32_t* level = tree;
+    uint32_t n = count, mine = sub;                       // nodes in the level, nodes of this workgroup in it
+    while (mine > 1) {
+        uint32_t* next = level + 8 * (size_t)n;
+        const size_t in0 = (size_t)blockIdx.x * mine, out0 = (size_t)blockIdx.x * (mine / 2);
+        for (uint32_t i = grp; i < mine / 2; i += ngrp) {
+            const uint32_t x = coop_permute(level[16 * (in0 / 2 + i) + lane16], lane16, k);
+            if (lane16 < 8) next[8 * (out0 + i) + lane16] = x;
+        }
+        __threadfence_block();
+        __syncthreads();
+        level = next; n >>= 1; mine >>= 1;
     }
 }
 // leaf digests, one row per 16 lanes (small heights: FRI layers, tests)
