@@ -245,11 +245,13 @@ int op_merkle_commit(zkhip_ctx* ctx, const MatDesc* mats, int nmats, int log_h, 
     uint64_t count = la.height;
     while (count > COOP_TOP_NODES) {
         if (count <= COOP_MAX_NODES) {
-            // medium levels: one launch reduces the level to 32 nodes (each workgroup walks its own subtree), one more finishes
-            const uint32_t sub = (uint32_t)count / 32u;
+            // medium levels: one launch reduces the level to `rest` nodes (each workgroup walks its own subtree), one more finishes.
+            // 128 workgroups keep every level of a subtree within one sweep of a 1024-thread workgroup (64 permutations at a time)
+            const uint32_t rest = count >= 4096 ? 128u : 32u;
+            const uint32_t sub = (uint32_t)count / rest;
             ZK_HIP(launch_compress_sub(level, (uint32_t)count, sub, ctx->stream));
-            for (uint64_t c = count; c > 32; c >>= 1) level += 8 * c;
-            count = 32;
+            for (uint64_t c = count; c > rest; c >>= 1) level += 8 * c;
+            count = rest;
             break;
         }
         uint32_t* next = level + 8 * count;
