@@ -289,6 +289,20 @@ int op_merkle_commit_mixed(zkhip_ctx* ctx, const MatDesc* mats, const int* log_h
     uint32_t* level = tree;
     for (int lvl = log_h - 1; lvl >= 0; lvl--) {
         const uint64_t cnt = (uint64_t)1 << lvl;
+        // below the shortest matrix nothing is injected any more: the rest of the tree goes like a plain commitment (subtree + top launch)
+        int min_lh = log_h;
+        for (int m = 0; m < nmats; m++) if (log_heights[m] < min_lh) min_lh = log_heights[m];
+        if (lvl < min_lh && 2 * cnt <= COOP_MAX_NODES) {
+            uint64_t count = 2 * cnt;                        // nodes of the current level
+            if (count > COOP_TOP_NODES) {
+                const uint32_t rest = count >= 4096 ? 128u : 32u;
+                ZK_HIP(launch_compress_sub(level, (uint32_t)count, (uint32_t)count / rest, ctx->stream));
+                for (uint64_t c = count; c > rest; c >>= 1) level += 8 * c;
+                count = rest;
+            }
+            ZK_HIP(launch_compress_top(level, (uint32_t)count, ctx->stream));
+            return ZKHIP_OK;
+        }
         uint32_t* next = level + 16 * cnt;
         ZK_HIP(launch_compress_level(level, next, cnt, ctx->stream));
         LeafArgs inj;
