@@ -308,7 +308,11 @@ static int grind_witness(zkhip_ctx* ctx, Challenger& ch, int pow_bits, uint32_t*
     void* v_res;
     ZK_TRY(ctx_reserve(ctx, S_GATHER_OUT, 4, &v_res));
     ZK_HIP(hipMemsetAsync(v_res, 0xFF, 4, ctx->stream));
-    const uint32_t batch = 1u << 20;
+    // candidates are scanned in order, so the first batch that contains a hit contains the smallest witness; a batch of 4 * 2^bits
+    // candidates has one with probability 1 - e^-4 = 98 % (2^20 candidates = 0.12 ms of permutations would mostly be wasted)
+    uint64_t want = (uint64_t)4 << pow_bits;
+    if (want < (1u << 14)) want = 1u << 14;
+    const uint32_t batch = (uint32_t)(want > (1u << 20) ? (1u << 20) : want);
     for (uint64_t base = 0; base < P && witness == 0xFFFFFFFFu; base += batch) {
         ZK_HIP(launch_grind(ga, (uint32_t)base, batch, (uint32_t*)v_res, ctx->stream));
         ZK_TRY(d2h(ctx, &witness, v_res, 4));
