@@ -119,6 +119,8 @@ struct QuotientArgs {
     Ext cumsum;                 // last-row constraint S = cumsum (zero unless tables look each other up)
     const uint32_t* sel_last;
     uint32_t* out;              // [2][N][4]: chunk k, natural row j
+    uint32_t* lde_out;          // optional: the value of row p also goes to lde_out[p * lde_ld + 4 * chunk ...] -- on its own coset a chunk's
+    uint64_t lde_ld;            // low-degree extension IS the quotient value, so that half of the chunk LDE needs no transform
 };
 hipError_t launch_quotient(const QuotientArgs& a, hipStream_t s);
 

@@ -130,7 +130,7 @@ struct LogupIn {
     Ext gamma = ext_zero(), beta = ext_zero();
 };
 static int run_quotient(zkhip_ctx* ctx, const uint32_t* lde, size_t ld, int log_n, uint32_t width, const Ext& alpha,
-                        const LogupIn& lu, uint32_t* out_chunks) {
+                        const LogupIn& lu, uint32_t* out_chunks, uint32_t* lde_out = nullptr, size_t lde_ld = 0) {
     if (ctx->dom_log_n != log_n) ZK_TRY(ensure_domain(ctx, log_n));   // any blowup serves: the quotient domain is a prefix
     const uint32_t G = width / 4;
     // weight of constraint k is alpha^(K-1-k): filled from the last constraint backwards;
@@ -165,6 +165,7 @@ static int run_quotient(zkhip_ctx* ctx, const uint32_t* lde, size_t ld, int log_
     q.pairs = lu.pairs; q.perm = lu.perm_lde; q.perm_ld = 4 * ((uint64_t)lu.pairs + 1);
     q.gamma = lu.gamma; q.beta = lu.beta; q.cumsum = lu.cumsum; q.sel_last = ctx->dom_sel_last;
     q.out = out_chunks;
+    q.lde_out = lde_out; q.lde_ld = lde_ld;
     ZK_HIP(launch_quotient(q, ctx->stream));
     return ZKHIP_OK;
 }
@@ -559,11 +560,19 @@ int zkhip_prove_shard(zkhip_ctx* ctx, const uint32_t* d_trace, size_t ld, int lo
     ZK_TRY(ctx_reserve(ctx, S_QLDE, m * 8 * 4, &v_qlde));
     ZK_TRY(ctx_reserve(ctx, S_QTREE, (2 * m - 1) * 32, &v_qtree));
     uint32_t* qchunk = (uint32_t*)v_qchunk; uint32_t* qlde = (uint32_t*)v_qlde; uint32_t* qtree = (uint32_t*)v_qtree;
-    ZK_TRY(run_quotient(ctx, tlde, width, log_n, width, alpha, lu, qchunk));
+    // With blowup 2 the LDE domain g <w_2N> is exactly the two cosets the chunks live on: on its own coset a chunk's extension is
+    // the quotient value itself (the kernel writes it straight into the LDE matrix), only the OTHER coset needs a transform.
+    const bool own_coset_direct = sh.b == 1;
+    ZK_TRY(run_quotient(ctx, tlde, width, log_n, width, alpha, lu, qchunk, own_coset_direct ? qlde : nullptr, 8));
     {
         // the quotient kernel works on the first 2N rows of the LDE: they are the coset g <w_2N>, bit-reversed
         const uint32_t w2n = two_adic_generator(Hq);
         for (int k = 0; k < 2; k++) {
+            if (own_coset_direct) {
+                // rows [(1-k) N, (2-k) N) of the LDE = coset 1-k = (g w_2N^(1-k)) <w_N>, relative to the chunk's own coset: w_2N^(1-2k)
+                ZK_TRY(op_coset_lde(ctx, qchunk + (size_t)k * n * 4, 4, qlde + (size_t)(1 - k) * n * 8 + 4 * k, 8, log_n, 4, 0, k == 0 ? w2n : finv(w2n)));
+                continue;
+            }
             // chunk k lives on (g w_2N^k) <w_N>; extend it to the LDE domain g <w_M>: shift = g / (g w^k)
             const uint32_t shift = finv(fpow(w2n, (uint64_t)k));
             ZK_TRY(op_coset_lde(ctx, qchunk + (size_t)k * n * 4, 4, qlde + 4 * k, 8, log_n, 4, sh.b, shift));
@@ -1295,10 +1304,16 @@ int zkhip_prove_chips(zkhip_ctx* ctx, const zkhip_chip* chips, int n, const uint
         ZK_TRY(ensure_domain(ctx, log_ns[c], b));
         LogupIn lu;
         if (wp[c]) { lu.pairs = (uint32_t)pairs[c]; lu.perm_lde = plde + pl_off[c]; lu.gamma = gamma; lu.beta = beta_l; lu.cumsum = cumsum[c]; }
-        ZK_TRY(run_quotient(ctx, tlde + tl_off[c], widths[c], log_ns[c], widths[c], alpha, lu, qchunk));
+        const bool own_coset_direct = b == 1;             // as in the single-matrix prover
+        ZK_TRY(run_quotient(ctx, tlde + tl_off[c], widths[c], log_ns[c], widths[c], alpha, lu, qchunk, own_coset_direct ? qlde + ql_off[c] : nullptr, 8));
         const uint32_t w2n = two_adic_generator(log_ns[c] + 1);
-        for (int k = 0; k < 2; k++)
-            ZK_TRY(op_coset_lde(ctx, qchunk + (size_t)k * nc * 4, 4, qlde + ql_off[c] + 4 * k, 8, log_ns[c], 4, b, finv(fpow(w2n, (uint64_t)k))));
+        for (int k = 0; k < 2; k++) {
+            if (own_coset_direct)
+                ZK_TRY(op_coset_lde(ctx, qchunk + (size_t)k * nc * 4, 4, qlde + ql_off[c] + (size_t)(1 - k) * nc * 8 + 4 * k, 8, log_ns[c], 4, 0,
+                                    k == 0 ? w2n : finv(w2n)));
+            else
+                ZK_TRY(op_coset_lde(ctx, qchunk + (size_t)k * nc * 4, 4, qlde + ql_off[c] + 4 * k, 8, log_ns[c], 4, b, finv(fpow(w2n, (uint64_t)k))));
+        }
     }
     ZK_TRY(op_merkle_commit_mixed(ctx, qm, lh, n, qtree));
     ZK_TRY(d2h(ctx, root, qtree + (2 * mmax - 2) * 8, 32));

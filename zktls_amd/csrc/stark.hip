@@ -205,6 +205,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(QWPE, 
         if (lane == 0 && live) {
             r = ext_mul_base_dev(r, inv_zh);
             st_ext(a.out + ((uint64_t)parity * (m >> 1) + (e >> 1)) * 4, r);
+            if (a.lde_out) st_ext(a.lde_out + (uint64_t)p * a.lde_ld + 4u * parity, r);
         }
 #pragma unroll
         for (int t = 0; t < NG; t++) cur[t] = nxt[t];
