@@ -105,9 +105,10 @@ def main():
             # two modes (0.48 / 0.53 ms) depending on where source and destination lie (tools/ntt_spacing_probe.py);
             # the section below times all three briefly, measures on the best and reports the spread.
             roof_scratch, spacers = [], []
-            for _k in range(3):          # 3 GiB apart: buffer classes come in runs of a few GiB, neighbours share one
+            for _k in range(4):          # 2, 6, 10 GiB apart: buffer classes come in runs of several GiB, neighbours share one
                 roof_scratch.append(torch.empty(n * width, dtype=torch.int32, device="cuda"))
-                spacers.append(torch.empty(3 * n * width, dtype=torch.int32, device="cuda"))
+                if _k < 3:
+                    spacers.append(torch.empty((2 + 4 * _k) * n * width, dtype=torch.int32, device="cuda"))
             del spacers
         for i, b in enumerate(bufs):
             if LQ:
@@ -120,9 +121,10 @@ def main():
         with torch.cuda.stream(stream):
             traces = [torch.empty(n * width, dtype=torch.int32, device="cuda")]      # source of the roofline section only
             roof_scratch, spacers = [], []
-            for _k in range(3):          # 3 GiB apart: buffer classes come in runs of a few GiB, neighbours share one
+            for _k in range(4):          # 2, 6, 10 GiB apart: buffer classes come in runs of several GiB, neighbours share one
                 roof_scratch.append(torch.empty(n * width, dtype=torch.int32, device="cuda"))
-                spacers.append(torch.empty(3 * n * width, dtype=torch.int32, device="cuda"))
+                if _k < 3:
+                    spacers.append(torch.empty((2 + 4 * _k) * n * width, dtype=torch.int32, device="cuda"))
             del spacers
         bufs = [ctx.wrap(traces[0])]
         ctx.fill_uniform(SEED, log_n, width, out=bufs[0])
@@ -213,7 +215,7 @@ def main():
     roof = None
     if rank == 0:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        # placement scan: every (source, destination) pair of up to four traces and the three scratch buffers, 100 launches each
+        # placement scan: every (source, destination) pair of up to four traces and the four scratch buffers, 100 launches each
         cands = [ctx.wrap(t) for t in roof_scratch]
         srcs = bufs[:4]
         placements = []
