@@ -15,8 +15,10 @@
  *       (reference Cargo.lock:6172): one mixed-height commitment per phase, one FRI proof.
  *   zkhip_prove_segment
  *       the span crates/guest-prover-r0/src/prover.rs:88-93 times, from RISC Zero's column-major Hal layout.
- *   zkhip_prove_shard_host, zkhip_prove_shards, zkhip_commit
- *       host-pointer variant of the prove entry; TwoAdicFriPcs::commit (Cargo.lock:3930) alone.
+ *   zkhip_prove_shard_host, zkhip_prove_shards, zkhip_prove_shards_multi, zkhip_commit
+ *       host-pointer variant of the prove entry; all shards of one execution in one call (sp1.rs:116 / prover.rs:90 prove
+ *       every shard / segment inside one call), on one GPU or dealt round-robin over the GPUs of the node;
+ *       TwoAdicFriPcs::commit (Cargo.lock:3930) alone.
  *   zkhip_perm_trace, zkhip_gen_trace_logup
  *       sp1-stark generate_permutation_trace (Cargo.lock:6172): per-row extension inverses + running sum (LogUp).
  *   zkhip_coset_lde, zkhip_dft, zkhip_ntt_pass
@@ -35,7 +37,9 @@
  *     aborts or unwinds across the ABI (the Rust glue wraps calls in catch_unwind,
  *     sp1.rs:85); zkhip_last_error() gives the thread-local message;
  *   - a context is bound to one device ordinal and one HIP stream; calls on one context
- *     are serialised by the caller, separate contexts are independent; no global state;
+ *     are serialised by the caller, separate contexts are independent; no global state (one opt-in cache: the internal
+ *     contexts of zkhip_prove_shards*, see zkhip_release_cached_contexts) and NO environment variable is read: the mode
+ *     flags the reference passes through the process environment (sp1.rs:20-29) stay the caller's business;
  *   - matrices are row-major uint32 words in MONTGOMERY form (R = 2^32), canonical range
  *     [0, p), p = 2^31 - 2^27 + 1 -- the in-memory form of p3 MontyField31; `ld` is the
  *     row pitch in words; extension elements are 4 consecutive words (x^4 = 11);
@@ -241,6 +245,17 @@ typedef struct zkhip_shard_job {
     int32_t status;                 /* out */
 } zkhip_shard_job;
 int zkhip_prove_shards(int device, zkhip_shard_job* jobs, int n_jobs, const zkhip_params* prm, int in_flight, int host_traces);
+/* The same batch over SEVERAL GPUs of one node from one process and one call -- what a Rust `ZkProver::prove` needs, since the
+ * reference proves all shards of an execution inside one call (crates/guest-prover-sp1/src/sp1.rs:116; segments:
+ * crates/guest-prover-r0/src/prover.rs:90).  Shards are independent: shard s is proven on
+ * devices[s mod n_devices] (zkhip_shard_device), `in_flight_per_device` at a time on each device; there is no exchange between
+ * devices, proofs land in the jobs' host buffers.  devices == NULL with n_devices == 0 means every visible device.  With device
+ * traces (host_traces == 0) job s's trace pointer must live on the device zkhip_shard_device(s, ...) names; host traces are
+ * staged by the library on that device.  Status / error reporting as zkhip_prove_shards. */
+int zkhip_prove_shards_multi(const int* devices, int n_devices, zkhip_shard_job* jobs, int n_jobs, const zkhip_params* prm,
+                             int in_flight_per_device, int host_traces);
+/* the device ordinal shard `shard_index` of a batch is proven on (devices == NULL: ordinal shard_index mod n_devices); -1 on bad arguments */
+int zkhip_shard_device(int shard_index, const int* devices, int n_devices);
 /* the internal contexts of zkhip_prove_shards stay cached between calls (creating and freeing multi-GiB workspaces costs more than
  * a proof); this frees them */
 void zkhip_release_cached_contexts(void);

@@ -4,6 +4,8 @@ Run with ZKHIP_NTT_DEBUG=0 in the environment (the library then re-reads the var
 import ctypes as C, os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
+sys.path.insert(0, __import__('os').path.dirname(__import__('os').path.abspath(__file__)))
+import _ab  # noqa: F401  (A/B build of the library: the env knobs below exist only there)
 from zktls_amd.device import Context
 hip = C.CDLL("libamdhip64.so")
 ctx = Context(0)

@@ -3,6 +3,8 @@
 import ctypes as C, os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
+sys.path.insert(0, __import__('os').path.dirname(__import__('os').path.abspath(__file__)))
+import _ab  # noqa: F401  (A/B build of the library: the env knobs below exist only there)
 from zktls_amd.device import Context
 hip = C.CDLL("libamdhip64.so")
 reps = int(sys.argv[1]) if len(sys.argv) > 1 else 300

@@ -93,16 +93,17 @@ static NttPassArgs base_args(zkhip_ctx* ctx, const uint32_t* in, size_t in_ld, u
     a.in = in; a.out = out; a.in_ld = in_ld; a.out_ld = out_ld; a.ncols = width;
     a.w1024 = inverse ? ctx->w1024_inv : ctx->w1024_fwd;
     a.map_mode = 255;
-    // tuning knobs for A/B runs (never needed for correctness)
+#ifdef ZKHIP_AB_HOOKS
+    // A/B builds only (libzkhip_ab.so, `make ab`; tools/): tuning knobs read from the environment.  The shipped library is
+    // compiled without them: it reads no environment variable and its launches cannot be altered from outside.
     static const int force_cpt = [] { const char* e = getenv("ZKHIP_NTT_CPT"); return e ? atoi(e) : 0; }();
-    static const bool has_map = getenv("ZKHIP_NTT_MAP") != nullptr;      // re-read per launch when present at start-up (A/B tools)
+    static const bool has_map = getenv("ZKHIP_NTT_MAP") != nullptr;      // re-read per launch when present at start-up
     int map_mode = 255;                                                   // automatic (launch_ntt_pass)
     if (has_map) { const char* e = getenv("ZKHIP_NTT_MAP"); map_mode = e ? atoi(e) : 255; }
     static const int fast = [] { const char* e = getenv("ZKHIP_NTT_FAST"); return e ? atoi(e) : 4; }();
-    // ZKHIP_NTT_FAST: unset/4/0 = tile-per-workgroup kernel, 1 = persistent 1024 x 32 kernel (A/B only);
+    // ZKHIP_NTT_FAST: unset/4/0 = tile-per-workgroup kernel, 1 = persistent 1024 x 32 kernel;
     // ZKHIP_NTT_CPT: 1 / 2 columns per lane (unset: 2 for 1024-row tiles of an even, 8-byte aligned shape)
     a.fast_path = fast == 4 ? 0u : (fast == 0 ? 2u : (uint32_t)fast);
-    // re-read per launch only when the variable existed at start-up (A/B tools flip it inside one process)
     static const bool has_dbg = getenv("ZKHIP_NTT_DEBUG") != nullptr;
     int dbg = 0;
     if (has_dbg) { const char* e = getenv("ZKHIP_NTT_DEBUG"); dbg = e ? atoi(e) : 0; }
@@ -111,6 +112,7 @@ static NttPassArgs base_args(zkhip_ctx* ctx, const uint32_t* in, size_t in_ld, u
     a.map_mode = (uint32_t)map_mode;
     static const bool has_perm = getenv("ZKHIP_NTT_PERM") != nullptr;
     if (has_perm) { const char* e = getenv("ZKHIP_NTT_PERM"); a.tile_perm = e ? strtoull(e, nullptr, 16) : 0; }
+#endif
     return a;
 }
 
@@ -140,7 +142,7 @@ static int run_inverse(zkhip_ctx* ctx, const uint32_t* in, size_t in_ld, uint32_
     if (!transposed) {
         // natural output rows interleave across tiles: not in-place safe -> bounce
         void* tmp;
-        ZK_TRY(ctx_reserve(ctx, 1, ((size_t)1 << log_n) * width * 4, &tmp));
+        ZK_TRY(ctx_reserve(ctx, S_TMP, ((size_t)1 << log_n) * width * 4, &tmp));
         b.out = (uint32_t*)tmp; b.out_ld = width;
         ZK_HIP(launch_ntt_pass(b, true, ctx->stream));
         ZK_HIP(hipMemcpy2DAsync(out, out_ld * 4, tmp, (size_t)width * 4, (size_t)width * 4, (size_t)1 << log_n,
@@ -166,7 +168,7 @@ static int run_forward_natural(zkhip_ctx* ctx, const uint32_t* in, size_t in_ld,
     const uint64_t M1 = 1ull << p->m1, M2 = 1ull << p->m2;
     // pass 1 goes through a scratch matrix so that `in` is preserved and `out` may be strided
     void* tmp;
-    ZK_TRY(ctx_reserve(ctx, 1, ((size_t)1 << log_n) * width * 4, &tmp));
+    ZK_TRY(ctx_reserve(ctx, S_TMP, ((size_t)1 << log_n) * width * 4, &tmp));
     NttPassArgs a = base_args(ctx, in, in_ld, (uint32_t*)tmp, width, width, false);
     a.num_tiles = (uint32_t)M1; a.log_m = p->m2;
     a.in_tile_mul = 1; a.in_stride = M1; a.out_tile_mul = 1; a.out_stride = M1;
@@ -188,7 +190,7 @@ int op_coset_lde(zkhip_ctx* ctx, const uint32_t* in, size_t in_ld, uint32_t* out
     if (width == 0 || in_ld < width || out_ld < width) return fail(ZKHIP_ERR_INVALID, "coset_lde: bad width / ld");
     if (log_n < 5) {      // below the tile minimum: coefficients and evaluation by definition
         void* coef_s;
-        ZK_TRY(ctx_reserve(ctx, 0, ((size_t)1 << log_n) * width * 4, &coef_s));
+        ZK_TRY(ctx_reserve(ctx, S_COEF, ((size_t)1 << log_n) * width * 4, &coef_s));
         ZK_HIP(launch_small_eval(in, in_ld, (uint32_t*)coef_s, width, log_n, log_n, width, finv(two_adic_generator(log_n)), MONTY_R1,
                                  finv(to_monty(1u << log_n)), 0, ctx->stream));
         ZK_HIP(launch_small_eval((const uint32_t*)coef_s, width, out, out_ld, log_n, log_n + log_blowup, width,
@@ -201,7 +203,7 @@ int op_coset_lde(zkhip_ctx* ctx, const uint32_t* in, size_t in_ld, uint32_t* out
     split(log_n, &m1, &m2);
     // coefficients into scratch slot 0
     void* coef_v;
-    ZK_TRY(ctx_reserve(ctx, 0, n * width * 4, &coef_v));
+    ZK_TRY(ctx_reserve(ctx, S_COEF, n * width * 4, &coef_v));
     uint32_t* coef = (uint32_t*)coef_v;
     ZK_TRY(run_inverse(ctx, in, in_ld, coef, width, log_n, width, /*transposed=*/m1 != 0));
     const uint32_t wnb = two_adic_generator(log_n + log_blowup);
@@ -309,7 +311,7 @@ int op_merkle_commit_mixed(zkhip_ctx* ctx, const MatDesc* mats, const int* log_h
         if (!gather(lvl, inj)) return fail(ZKHIP_ERR_INVALID, "merkle_commit_mixed: at most 4 matrices per height");
         if (inj.nmats) {
             void* tmp;
-            ZK_TRY(ctx_reserve(ctx, 1, cnt * 32, &tmp));
+            ZK_TRY(ctx_reserve(ctx, S_TMP, cnt * 32, &tmp));
             inj.digests = (uint32_t*)tmp;
             ZK_HIP(launch_hash_rows(inj, ctx->stream));
             ZK_HIP(launch_inject(next, (const uint32_t*)tmp, cnt, ctx->stream));
@@ -553,8 +555,8 @@ int zkhip_batch_interpolate_colmajor(zkhip_ctx* ctx, const uint32_t* d_evals, ui
     if (!d_evals || !d_coeffs || count == 0 || log_size < 5 || log_size > 20) return fail(ZKHIP_ERR_INVALID, "batch_interpolate_colmajor: bad arguments");
     const uint64_t n = (uint64_t)1 << log_size;
     void *a, *b;
-    ZK_TRY(ctx_reserve(ctx, 19, n * count * 4, &a));
-    ZK_TRY(ctx_reserve(ctx, 20, n * count * 4, &b));
+    ZK_TRY(ctx_reserve(ctx, S_COL_A, n * count * 4, &a));
+    ZK_TRY(ctx_reserve(ctx, S_COL_B, n * count * 4, &b));
     // evaluations arrive bit-reversed (Hal convention): undo it while transposing
     ZK_HIP(launch_transpose(d_evals, (uint32_t*)a, count, n, log_size, 0, ctx->stream));
     ZK_TRY(run_inverse(ctx, (const uint32_t*)a, count, (uint32_t*)b, count, log_size, count, false));
@@ -570,8 +572,8 @@ int zkhip_batch_expand_colmajor(zkhip_ctx* ctx, const uint32_t* d_coeffs, uint32
         return fail(ZKHIP_ERR_INVALID, "batch_expand_colmajor: bad arguments");
     const uint64_t n = (uint64_t)1 << log_size, m = n << log_blowup;
     void *a, *b;
-    ZK_TRY(ctx_reserve(ctx, 19, n * count * 4, &a));
-    ZK_TRY(ctx_reserve(ctx, 20, m * count * 4, &b));
+    ZK_TRY(ctx_reserve(ctx, S_COL_A, n * count * 4, &a));
+    ZK_TRY(ctx_reserve(ctx, S_COL_B, m * count * 4, &b));
     ZK_HIP(launch_transpose(d_coeffs, (uint32_t*)a, count, n, 0, 0, ctx->stream));
     // zero-padded size-m transform = 2^b coset transforms of size n (as in op_coset_lde)
     const uint32_t sm = to_monty(shift), wnb = two_adic_generator(log_size + log_blowup);

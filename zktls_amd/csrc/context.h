@@ -43,6 +43,27 @@ struct DeviceBuffer {
     size_t bytes = 0;
 };
 
+// Roles of the grow-only workspaces of a context (zkhip_ctx::scratch).  One enum for context.cpp and prover.cpp, so that
+// no two roles can land on the same slot by accident; lifetimes: a slot belongs to the op that reserved it until that op
+// returns, except the S_T* / S_Q* / S_P* / S_FRI_* / S_DINV slots, which live for the whole prove call.
+enum Slot {
+    S_COEF = 0,        // coefficients of the matrix being extended (op_coset_lde)
+    S_TMP,             // bounce buffer of a transform / injected digests of a mixed-height commitment
+    S_TLDE, S_TTREE,   // trace LDE + tree
+    S_QCHUNK, S_QLDE, S_QTREE,
+    S_DINV, S_PARTIAL, S_OPEN_OUT,
+    S_APOW_Q, S_APOW_F,
+    S_FRI_LAYERS, S_FRI_TREES,
+    S_GATHER_DESC, S_GATHER_OUT,
+    S_PERM, S_PLDE, S_PTREE,
+    S_CHAL,            // device challenger + per-layer betas / roots of the FRI commit phase (part of the HIP-graph key)
+    S_COL_A, S_COL_B,  // column-major adapters (zkhip_batch_*_colmajor)
+    S_STAGE,           // staged copy of a host / column-major trace (zkhip_prove_shard_host, zkhip_prove_segment)
+    S_RO,
+    S_EXTRA_A, S_EXTRA_B,   // large-transform (2^21, 2^22 rows) bounce buffers
+    S_COUNT
+};
+
 }  // namespace zk
 
 struct zkhip_ctx {
@@ -52,7 +73,7 @@ struct zkhip_ctx {
     uint32_t* w1024_fwd = nullptr;
     uint32_t* w1024_inv = nullptr;
     std::deque<zk::NttPlan> plans;   // deque: references stay valid on push_back
-    zk::DeviceBuffer scratch[24];       // grow-only workspaces, indexed by role
+    zk::DeviceBuffer scratch[zk::S_COUNT];   // grow-only workspaces, indexed by zk::Slot
     zkhip_prove_debug debug{};
     // domain tables (prover.cpp): the current set, and every set built so far (a multi-chip shard switches between
     // the sets of its chips' heights; sets are small and kept until the context goes away)

@@ -28,9 +28,9 @@ struct NttPassArgs {
     uint64_t out_tile_mul, out_stride;
     uint32_t bitrev_out;
     uint32_t map_mode;               // 0: column group fastest; 1: XCD-aware; 2..15: XCD-aware + tile index rotated by that many bits; 255: automatic
-    uint64_t tile_perm;              // A/B only: if non-zero, tile index bit b moves to bit (tile_perm >> 4b) & 15 (after the XCD-aware map)
-    uint32_t fast_path;              // A/B knob: 0 / 2 tile-per-workgroup kernel (default), 1 persistent 1024 x 32 kernel
-    uint32_t debug_flags;            // timing-only: 1 drop loads, 2 drop stores, 4 no transform, 8 no non-temporal policy
+    uint64_t tile_perm;              // A/B builds only: if non-zero, tile index bit b moves to bit (tile_perm >> 4b) & 15 (after the XCD-aware map)
+    uint32_t fast_path;              // A/B builds only: 0 / 2 tile-per-workgroup kernel (default), 1 persistent 1024 x 32 kernel
+    uint32_t debug_flags;            // A/B builds (-DZKHIP_AB_HOOKS) only, ignored otherwise: 1 drop loads, 2 drop stores, 4 no transform, 8 no non-temporal policy
     uint32_t cols_per_thread;        // 2: two columns per lane when the shape allows (A/B knob); else 1
     const uint32_t* w1024;           // w_1024^e (forward) or w_1024^-e (inverse), e < 1024
     const uint32_t* pre;             // [M] or nullptr

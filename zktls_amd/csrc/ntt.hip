@@ -28,6 +28,8 @@
 
 namespace zk {
 
+constexpr int MAX_DEVICES = 64;     // device ordinals a process can hold contexts on
+
 struct Tw32 { uint32_t w[16]; };
 constexpr Tw32 make_tw32(bool inv) {
     Tw32 t{};
@@ -142,12 +144,14 @@ __global__ void __launch_bounds__(32 << LOG_C, 4) ntt_pass_kernel(NttPassArgs a)
             const uint32_t lt = 31u - __clz(a.num_tiles), r = a.map_mode;
             if (lt > r) tile = ((tile << r) | (tile >> (lt - r))) & (a.num_tiles - 1u);
         }
+#ifdef ZKHIP_AB_HOOKS
         if (a.tile_perm) {
             const uint32_t lt = 31u - __clz(a.num_tiles);
             uint32_t t2 = 0;
             for (uint32_t b = 0; b < lt; b++) t2 |= ((tile >> b) & 1u) << ((a.tile_perm >> (4u * b)) & 15u);
             tile = t2;
         }
+#endif
     } else {
         cg = blockIdx.x % ncg;
         tile = blockIdx.x / ncg;
@@ -162,8 +166,12 @@ __global__ void __launch_bounds__(32 << LOG_C, 4) ntt_pass_kernel(NttPassArgs a)
     uint32_t x[CPT][32];
     {
         const uint32_t* ib = a.in + (uint64_t)tile * a.in_tile_mul * a.in_ld;
-        // timing-only knob (tools/ab_ntt.sh): a zero-record descriptor drops the loads / stores
+#ifdef ZKHIP_AB_HOOKS
+        // timing-only knob of A/B builds (tools/ab_ntt2.sh): a zero-record descriptor drops the loads / stores
         const auto rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint32_t*>(ib), 0, (a.debug_flags & 1u) ? 0u : 0xFFFFFFFFu, 0x00020000);
+#else
+        const auto rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint32_t*>(ib), 0, 0xFFFFFFFFu, 0x00020000);
+#endif
         const uint32_t voff = 4u * ((uint32_t)((uint64_t)u * a.in_stride * a.in_ld) + lcol);
         const uint32_t istep_b = (uint32_t)(4u * (uint64_t)Pn * a.in_stride * a.in_ld);
 #pragma unroll
@@ -187,6 +195,7 @@ __global__ void __launch_bounds__(32 << LOG_C, 4) ntt_pass_kernel(NttPassArgs a)
         }
     }
     __syncthreads();
+#ifdef ZKHIP_AB_HOOKS
     if (BFIX == 5 && (a.debug_flags & 4u)) {
         // timing-only: the same loads and stores with no transform in between (the memory floor of this access pattern)
         if (active) {
@@ -203,6 +212,7 @@ __global__ void __launch_bounds__(32 << LOG_C, 4) ntt_pass_kernel(NttPassArgs a)
         }
         return;
     }
+#endif
     if (has_pre) {
 #pragma unroll
         for (int n1 = 0; n1 < 32; n1++) {
@@ -273,7 +283,11 @@ __global__ void __launch_bounds__(32 << LOG_C, 4) ntt_pass_kernel(NttPassArgs a)
         }
         if (active) {
             uint32_t* ob = a.out + (uint64_t)tile * a.out_tile_mul * a.out_ld;
+#ifdef ZKHIP_AB_HOOKS
             const auto ors = __builtin_amdgcn_make_buffer_rsrc(ob, 0, (a.debug_flags & 2u) ? 0u : 0xFFFFFFFFu, 0x00020000);
+#else
+            const auto ors = __builtin_amdgcn_make_buffer_rsrc(ob, 0, 0xFFFFFFFFu, 0x00020000);
+#endif
             const uint32_t ostep_b = (uint32_t)(4u * a.out_stride * a.out_ld);
             const uint32_t out_off = (a.bitrev_out ? 32u * (__brev((uint32_t)u) >> 27) : (uint32_t)u) * ostep_b + 4u * col;
 #pragma unroll
@@ -300,7 +314,11 @@ __global__ void __launch_bounds__(32 << LOG_C, 4) ntt_pass_kernel(NttPassArgs a)
     if (active) {
         const int m = (int)a.log_m;
         uint32_t* ob = a.out + (uint64_t)tile * a.out_tile_mul * a.out_ld;
+#ifdef ZKHIP_AB_HOOKS
         const auto ors = __builtin_amdgcn_make_buffer_rsrc(ob, 0, (a.debug_flags & 2u) ? 0u : 0xFFFFFFFFu, 0x00020000);
+#else
+        const auto ors = __builtin_amdgcn_make_buffer_rsrc(ob, 0, 0xFFFFFFFFu, 0x00020000);
+#endif
         const uint32_t ostep_b = (uint32_t)(4u * a.out_stride * a.out_ld);
 #pragma unroll
         for (int rho = 0; rho < 32; rho++) {
@@ -317,6 +335,7 @@ __global__ void __launch_bounds__(32 << LOG_C, 4) ntt_pass_kernel(NttPassArgs a)
 }
 
 
+#ifdef ZKHIP_AB_HOOKS
 // ------------------------------------------------------------------ persistent fast path
 // M = 1024 rows x 32 columns per tile, one 1024-thread workgroup per CU that walks its tiles:
 //   * 128-byte row chunks (a wave = 2 rows x 32 columns) -- the HBM likes them far better than
@@ -474,15 +493,19 @@ static hipError_t launch_ntt1024x2(const NttPassArgs& a, hipStream_t s) {
     const uint32_t total = a.num_tiles * (a.ncols / 32);
     const uint32_t grid = total < (uint32_t)cu_count() ? total : (uint32_t)cu_count();
     const size_t lds = (size_t)(2 * 32 * 33 * 16 + 3 * 1024) * sizeof(uint32_t);
-    static std::atomic<bool> configured{false};       // several host threads (one context each) launch concurrently
-    if (!configured.load(std::memory_order_acquire)) {
+    static std::atomic<bool> configured[MAX_DEVICES] = {};       // several host threads (one context each) launch concurrently
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= MAX_DEVICES) return hipErrorInvalidDevice;
+    if (!configured[dev].load(std::memory_order_acquire)) {
         hipError_t e = hipFuncSetAttribute((const void*)ntt_pass1024x2_kernel<INV>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
-        configured.store(true, std::memory_order_release);
+        configured[dev].store(true, std::memory_order_release);
     }
     hipLaunchKernelGGL((ntt_pass1024x2_kernel<INV>), dim3(grid), dim3(512), lds, s, a, total);
     return hipGetLastError();
 }
+
+#endif  // ZKHIP_AB_HOOKS (persistent A/B kernel)
 
 static size_t ntt_lds_bytes(int log_m, int log_c) {
     int b = log_m - 5, Pn = 1 << b, M = 32 << b, C = 1 << log_c;
@@ -496,12 +519,16 @@ static hipError_t launch_ntt_k(const NttPassArgs& a, hipStream_t s) {
     const int b = (int)a.log_m - 5;
     dim3 grid(a.num_tiles * ncg), block((1 << b) << LOG_C);
     const size_t lds = ntt_lds_bytes((int)a.log_m, LOG_C);
-    static std::atomic<size_t> configured{0};      // raise the dynamic-LDS cap once per instantiation (thread-safe)
-    if (lds > configured.load(std::memory_order_acquire)) {
+    // raise the dynamic-LDS cap once per instantiation AND per device (function attributes are per device; a process may hold
+    // contexts on every GPU of the node: zkhip_prove_shards_multi); thread-safe, several host threads launch concurrently
+    static std::atomic<size_t> configured[MAX_DEVICES] = {};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= MAX_DEVICES) return hipErrorInvalidDevice;
+    if (lds > configured[dev].load(std::memory_order_acquire)) {
         hipError_t e = hipFuncSetAttribute((const void*)ntt_pass_kernel<LOG_C, INV, CPT, BFIX, NT>,
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
-        configured.store(lds, std::memory_order_release);
+        configured[dev].store(lds, std::memory_order_release);
     }
     hipLaunchKernelGGL((ntt_pass_kernel<LOG_C, INV, CPT, BFIX, NT>), grid, block, lds, s, a);
     return hipGetLastError();
@@ -534,12 +561,14 @@ hipError_t launch_ntt_pass(const NttPassArgs& a_, bool inverse, hipStream_t s) {
     // compile-time tile offsets (0.62 / 0.55 ms against 0.53 / 0.46 ms for the strided / contiguous pass); so does a
     // persistent form of the two-workgroup kernel itself (0.55 / 0.50 ms: workgroups that walk tile lists stay
     // phase-locked across the chip, freshly dispatched ones drift apart and keep the memory pipe fed).
+#ifdef ZKHIP_AB_HOOKS
     const bool al8 = a.in_ld % 2 == 0 && a.out_ld % 2 == 0 && (reinterpret_cast<uintptr_t>(a.in) & 7) == 0 &&
                      (reinterpret_cast<uintptr_t>(a.out) & 7) == 0;
     if (a.log_m == 10 && a.ncols >= 32 && a.ncols % 32 == 0 && a.fast_path == 1 && al8) {
         if (a.map_mode != 1 || (a.num_tiles % 8u) != 0 || (cu_count() % 8) != 0) a.map_mode = 0;
         return inverse ? launch_ntt1024x2<true>(a, s) : launch_ntt1024x2<false>(a, s);
     }
+#endif
     // two columns per lane (128-byte row chunks per 16 lanes) need 8-byte aligned row chunks.  Default for
     // 1024-row tiles, where the compile-time tile height keeps it at 116 VGPRs (two workgroups per CU);
     // with a run-time tile height it spills, so there it stays opt-in (cols_per_thread = 2).
@@ -563,7 +592,10 @@ hipError_t launch_ntt_pass(const NttPassArgs& a_, bool inverse, hipStream_t s) {
 #undef POLCASE
         }
 #endif
-        if (!(a.debug_flags & 8u)) {
+#ifdef ZKHIP_AB_HOOKS
+        if (!(a.debug_flags & 8u))
+#endif
+        {
             if (contiguous) return inverse ? launch_ntt_k<4, true, 2, 5, 1>(a, s) : launch_ntt_k<4, false, 2, 5, 1>(a, s);
             if (!in_place) return inverse ? launch_ntt_k<4, true, 2, 5, 2>(a, s) : launch_ntt_k<4, false, 2, 5, 2>(a, s);
         }

@@ -81,8 +81,7 @@ static void transcript_init(Challenger& ch, int log_n, uint32_t width, const zkh
 constexpr uint32_t PROOF_MAGIC = 0x41544B5Au;   // "ZKTA"
 constexpr uint32_t PROOF_VERSION = 1u;
 
-enum Slot { S_COEF = 0, S_TMP = 1, S_TLDE, S_TTREE, S_QCHUNK, S_QLDE, S_QTREE, S_DINV, S_PARTIAL, S_OPEN_OUT,
-            S_APOW_Q, S_APOW_F, S_FRI_LAYERS, S_FRI_TREES, S_GATHER_DESC, S_GATHER_OUT, S_PERM, S_PLDE, S_PTREE, S_CHAL, S_RO = 22 };
+// workspace roles: enum Slot in context.h
 
 static int pow2ceil(int v) { int r = 1; while (r < v) r <<= 1; return r; }
 
@@ -208,8 +207,12 @@ static int fri_commit_phase(zkhip_ctx* ctx, Challenger& ch, const Shape& sh, int
     uint32_t root[8];
     // The per-layer transcript step (observe the root, sample beta) runs ON THE DEVICE (fri_challenge_kernel), so the
     // whole commit loop is enqueued without a host round trip; afterwards the host replays the same steps on its own
-    // challenger from the logged roots and checks that both transcripts agree.  ZKHIP_FRI_HOST=1 keeps the round trips (A/B).
+    // challenger from the logged roots and checks that both transcripts agree.  (A/B builds: ZKHIP_FRI_HOST=1 keeps the round trips.)
+#ifdef ZKHIP_AB_HOOKS
     static const bool fri_on_host = [] { const char* e = getenv("ZKHIP_FRI_HOST"); return e && atoi(e) != 0; }();
+#else
+    constexpr bool fri_on_host = false;
+#endif
     void* v_chal = nullptr;
     uint32_t *d_betas = nullptr, *d_roots = nullptr;
     DevChallenger* d_chal = nullptr;
@@ -257,8 +260,12 @@ static int fri_commit_phase(zkhip_ctx* ctx, Challenger& ch, const Shape& sh, int
     };
     // With the transcript on the device the loop above is a fixed sequence of ~12 small launches per layer that depends only on
     // sizes and workspace addresses: it is captured once into a HIP graph and replayed with one launch per proof
-    // (ZKHIP_FRI_GRAPH=0 keeps the plain launches); capture is thread-local, other contexts' threads are not affected.
+    // (A/B builds: ZKHIP_FRI_GRAPH=0 keeps the plain launches); capture is thread-local, other contexts' threads are not affected.
+#ifdef ZKHIP_AB_HOOKS
     static const bool use_graph = [] { const char* e = getenv("ZKHIP_FRI_GRAPH"); return !e || atoi(e) != 0; }();
+#else
+    constexpr bool use_graph = true;
+#endif
     if (d_chal && use_graph) {
         std::vector<uint64_t> key = {(uint64_t)H, (uint64_t)K, (uint64_t)RL, (uint64_t)sh.hw, (uint64_t)m, (uint64_t)(uintptr_t)layers,
                                      (uint64_t)(uintptr_t)ltrees, (uint64_t)(uintptr_t)fold_tmp, (uint64_t)(uintptr_t)d_chal,
@@ -745,7 +752,7 @@ int zkhip_prove_shard_host(zkhip_ctx* ctx, const uint32_t* h_trace, int log_n, u
     if (!h_trace) return fail(ZKHIP_ERR_INVALID, "prove_shard_host: null trace");
     const size_t words = (size_t)width << log_n;
     void* staged;
-    ZK_TRY(ctx_reserve(ctx, 21, words * 4, &staged));
+    ZK_TRY(ctx_reserve(ctx, S_STAGE, words * 4, &staged));
     ZK_HIP(hipMemcpyAsync(staged, h_trace, words * 4, hipMemcpyHostToDevice, ctx->stream));
     ZK_HIP(launch_convert((const uint32_t*)staged, (uint32_t*)staged, words, true, ctx->stream));
     return zkhip_prove_shard(ctx, (const uint32_t*)staged, width, log_n, width, public_values, n_public, prm, proof, cap, len);
@@ -773,13 +780,16 @@ void zkhip_release_cached_contexts(void) {
     { std::lock_guard<std::mutex> lk(g_pool_mu); all.swap(g_pool); }
     for (auto& e : all) zkhip_ctx_destroy(e.second);
 }
-int zkhip_prove_shards(int device, zkhip_shard_job* jobs, int n_jobs, const zkhip_params* prm, int in_flight, int host_traces) {
-    if (!jobs || n_jobs < 0 || !prm) return fail(ZKHIP_ERR_INVALID, "prove_shards: bad arguments");
+// Shard s of the batch goes to devices[s mod n_devices] (shard-parallel, no exchange step); every device runs up to
+// `in_flight` workers (context + HIP stream + host thread each) that take that device's shards in index order.  Job traces are
+// device pointers ON THE DEVICE THE SHARD IS ASSIGNED TO, or host pointers with host_traces.
+static int prove_shards_on(const int* devices, int n_devices, zkhip_shard_job* jobs, int n_jobs, const zkhip_params* prm, int in_flight,
+                           int host_traces) {
     if (n_jobs == 0) return ZKHIP_OK;
     if (in_flight <= 0) in_flight = 4;
-    if (in_flight > n_jobs) in_flight = n_jobs;
     for (int i = 0; i < n_jobs; i++) { jobs[i].status = ZKHIP_ERR_INVALID; jobs[i].proof_len = 0; }
-    std::atomic<int> next{0};
+    std::vector<std::atomic<int>> next(n_devices);            // per device: how many of ITS shards were handed out
+    for (auto& a : next) a.store(0);
     std::mutex mu;
     int first_rc = ZKHIP_OK, first_job = n_jobs, ctx_rc = ZKHIP_OK;
     std::string first_msg, ctx_msg;
@@ -787,7 +797,8 @@ int zkhip_prove_shards(int device, zkhip_shard_job* jobs, int n_jobs, const zkhi
         std::lock_guard<std::mutex> lk(mu);
         if (job < first_job) { first_job = job; first_rc = rc; first_msg = zkhip_last_error(); }
     };
-    auto worker = [&]() {
+    auto worker = [&](int slot) {
+        const int device = devices[slot];
         zkhip_ctx* ctx = pool_take(device);
         int rc = ctx ? ZKHIP_OK : zkhip_ctx_create(device, nullptr, &ctx);
         if (rc != ZKHIP_OK) {                                // e.g. no memory for one more workspace: the other workers carry on
@@ -796,7 +807,8 @@ int zkhip_prove_shards(int device, zkhip_shard_job* jobs, int n_jobs, const zkhi
             return;
         }
         for (;;) {
-            const int i = next.fetch_add(1);
+            const int k = next[slot].fetch_add(1);
+            const long i = (long)slot + (long)k * n_devices;   // the k-th shard of this device
             if (i >= n_jobs) break;
             zkhip_shard_job& j = jobs[i];
             size_t len = 0;
@@ -805,22 +817,56 @@ int zkhip_prove_shards(int device, zkhip_shard_job* jobs, int n_jobs, const zkhi
                      : zkhip_prove_shard(ctx, j.trace, j.ld, j.log_n, j.width, j.public_values, j.n_public, prm, j.proof, j.proof_cap, &len);
             j.status = rc;
             j.proof_len = rc == ZKHIP_OK ? len : 0;
-            if (rc != ZKHIP_OK) note(i, rc);
+            if (rc != ZKHIP_OK) note((int)i, rc);
         }
         zkhip_ctx_sync(ctx);
         pool_give(device, ctx);
     };
-    if (in_flight == 1) {
-        worker();
-    } else {
-        std::vector<std::thread> pool;
-        for (int t = 0; t < in_flight; t++) pool.emplace_back(worker);
-        for (auto& t : pool) t.join();
+    std::vector<std::thread> pool;
+    for (int slot = 0; slot < n_devices; slot++) {
+        const int mine = (n_jobs - slot + n_devices - 1) / n_devices;       // shards of this device
+        const int workers = mine < in_flight ? mine : in_flight;
+        for (int t = 0; t < workers; t++) pool.emplace_back(worker, slot);
     }
+    if (pool.size() == 1) { pool[0].join(); }
+    else for (auto& t : pool) t.join();
     if (first_rc != ZKHIP_OK) { set_error(first_msg); return first_rc; }
-    for (int i = 0; i < n_jobs; i++)                         // jobs nobody could take: every worker failed to get a context
+    for (int i = 0; i < n_jobs; i++)                         // jobs nobody could take: every worker of that device failed to get a context
         if (jobs[i].status != ZKHIP_OK) { set_error(ctx_msg.empty() ? "prove_shards: job not run" : ctx_msg); return ctx_rc != ZKHIP_OK ? ctx_rc : ZKHIP_ERR_INVALID; }
     return ZKHIP_OK;
+}
+
+int zkhip_prove_shards(int device, zkhip_shard_job* jobs, int n_jobs, const zkhip_params* prm, int in_flight, int host_traces) {
+    if (!jobs || n_jobs < 0 || !prm) return fail(ZKHIP_ERR_INVALID, "prove_shards: bad arguments");
+    return prove_shards_on(&device, 1, jobs, n_jobs, prm, in_flight, host_traces);
+}
+
+int zkhip_shard_device(int shard_index, const int* devices, int n_devices) {
+    if (shard_index < 0 || n_devices < 1) return -1;
+    return devices ? devices[shard_index % n_devices] : shard_index % n_devices;
+}
+
+int zkhip_prove_shards_multi(const int* devices, int n_devices, zkhip_shard_job* jobs, int n_jobs, const zkhip_params* prm,
+                             int in_flight_per_device, int host_traces) {
+    if (!jobs || n_jobs < 0 || !prm) return fail(ZKHIP_ERR_INVALID, "prove_shards_multi: bad arguments");
+    std::vector<int> devs;
+    if (!devices) {                                           // NULL: every visible device
+        if (n_devices != 0) return fail(ZKHIP_ERR_INVALID, "prove_shards_multi: n_devices must be 0 when devices is NULL (all visible devices)");
+        const int n = zkhip_device_count();
+        if (n <= 0) {
+            for (int i = 0; i < n_jobs; i++) { jobs[i].status = ZKHIP_ERR_NO_DEVICE; jobs[i].proof_len = 0; }
+            return n_jobs == 0 ? ZKHIP_OK : fail(ZKHIP_ERR_NO_DEVICE, "no HIP device visible: libzkhip has no CPU fallback");
+        }
+        for (int d = 0; d < n; d++) devs.push_back(d);
+    } else {
+        if (n_devices < 1 || n_devices > 64) return fail(ZKHIP_ERR_INVALID, "prove_shards_multi: 1..64 devices");
+        for (int d = 0; d < n_devices; d++) {
+            if (devices[d] < 0) return fail(ZKHIP_ERR_INVALID, "prove_shards_multi: negative device ordinal");
+            for (int e = 0; e < d; e++) if (devices[e] == devices[d]) return fail(ZKHIP_ERR_INVALID, "prove_shards_multi: device listed twice");
+            devs.push_back(devices[d]);
+        }
+    }
+    return prove_shards_on(devs.data(), (int)devs.size(), jobs, n_jobs, prm, in_flight_per_device, host_traces);
 }
 
 int zkhip_prove_segment(zkhip_ctx* ctx, const uint32_t* d_cols, int log_n, uint32_t width,
@@ -833,7 +879,7 @@ int zkhip_prove_segment(zkhip_ctx* ctx, const uint32_t* d_cols, int log_n, uint3
     // one tiled transpose in HBM, then the common path
     const uint64_t n = (uint64_t)1 << log_n;
     void* rows;
-    ZK_TRY(ctx_reserve(ctx, 21, n * width * 4, &rows));
+    ZK_TRY(ctx_reserve(ctx, S_STAGE, n * width * 4, &rows));
     ZK_HIP(launch_transpose(d_cols, (uint32_t*)rows, width, n, 0, 0, ctx->stream));
     return zkhip_prove_shard(ctx, (const uint32_t*)rows, width, log_n, width, public_values, n_public, prm, proof, cap, len);
 }

@@ -325,6 +325,41 @@ def prove_shards(traces, log_n, width, public_values_list, params=None, device=0
     return [bufs[i][: jobs[i].proof_len] for i in range(n)]
 
 
+def prove_shards_multi(traces, log_n, width, public_values_list, params=None, devices=None, in_flight=4, host=False):
+    """zkhip_prove_shards_multi: one call, one process, several GPUs; shard s runs on devices[s % len(devices)] (all visible
+    devices when `devices` is None).  Device traces must live on that device (see shard_device)."""
+    lib = _lib.load()
+    params = params or Params(1, 100, 16, 0)
+    n = len(traces)
+    jobs = (_lib.ShardJob * n)()
+    keep = []
+    for i, (t, pv) in enumerate(zip(traces, public_values_list)):
+        pva = np.ascontiguousarray(np.array(pv, dtype=np.uint32))
+        size = lib.zkhip_proof_size(log_n, width, C.byref(params), pva.size)
+        buf = np.empty(max(size, 1), dtype=np.uint8)
+        arr = np.ascontiguousarray(t, dtype=np.uint32) if host else None
+        keep.append((pva, buf, arr))
+        jobs[i].trace = arr.ctypes.data if host else t.ptr
+        jobs[i].ld = width; jobs[i].log_n = log_n; jobs[i].width = width
+        jobs[i].public_values = pva.ctypes.data_as(u32p); jobs[i].n_public = pva.size
+        jobs[i].proof = buf.ctypes.data_as(u8p); jobs[i].proof_cap = size
+    if devices is None:
+        dv, nd = None, 0
+    else:
+        dv, nd = (C.c_int * len(devices))(*[int(d) for d in devices]), len(devices)
+    check(lib.zkhip_prove_shards_multi(dv, nd, jobs, n, C.byref(params), int(in_flight), 1 if host else 0))
+    return [keep[i][1][: jobs[i].proof_len] for i in range(n)]
+
+
+def shard_device(shard_index, devices=None, n_devices=None):
+    """the device ordinal zkhip_prove_shards_multi proves shard `shard_index` on"""
+    lib = _lib.load()
+    if devices is None:
+        return lib.zkhip_shard_device(int(shard_index), None, int(n_devices))
+    dv = (C.c_int * len(devices))(*[int(d) for d in devices])
+    return lib.zkhip_shard_device(int(shard_index), dv, len(devices))
+
+
 def verify_shard(proof, log_n, width, public_values=(), params=None):
     params = params or Params(1, 100, 16)
     lib = _lib.load()
