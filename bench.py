@@ -2,18 +2,22 @@
 """Contract benchmark: whole-shard STARK proofs on MI355X through libzkhip's C ABI.
 
   python bench.py --gpus N --steps K --warmup W
-  (N > 1: launched by torch.distributed.run, one rank per GPU, RCCL backend)
+  (N > 1: one rank per GPU over RCCL.  Under torch.distributed.run the ranks are the launcher's; started
+   plainly, bench.py spawns its N rank processes itself BEFORE anything in the parent touches the GPU)
 
 One "step" = one complete shard proof (commit trace -> quotient -> openings -> FRI ->
 PoW -> queries) of a synthetic SP1-core-like shard: 2^20 rows x 256 columns, log_blowup 1,
 100 queries, 16 PoW bits (BASELINE.json configs[1] / SURVEY.md 8d).  The trace is resident
-in HBM before the timed region.  Shards are independent: rank r proves shards r*K..r*K+K-1
-(weak scaling, no data-path collective); RCCL broadcasts the 8-word batch transcript seed.
+in HBM before the timed region.  Shards are independent: the K*N shards of the job are dealt round-robin
+(zktls_amd.shards.shard_indices == the library's zkhip_shard_device): rank r proves shards r, r+N, ...
+(weak scaling, no data-path collective); RCCL broadcasts the 8-word batch transcript seed and, after
+the timed region, gathers the proof digests (every shard proven exactly once).
 Up to --streams shards are in flight per GPU, each on its own context + HIP stream + host
 thread, so the latency-bound stretches of one proof hide under the kernels of the others.
 
 Prints ONE JSON line (rank 0): metric trace-cells/s (+ proofs/s), `roofline` for the NTT
-pass kernel (HIP events on the launch stream), `valu_roofline` for the Poseidon2 leaf kernel
+pass kernel (HIP events on the launch stream; the four LDE launches of a proof on the proving
+context's OWN workspaces, i.e. the in-proof buffer placement), `valu_roofline` for the Poseidon2 leaf kernel
 (the largest share of a proof, integer-multiply bound) and `cpu_baseline` (the CPU oracle
 timed on the host cores, bounded sample, N = 1 only).
 """
@@ -28,6 +32,30 @@ sys.path.insert(0, ROOT)
 
 SEED = 0x5A4B544C53
 HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: 8 TB/s spec
+
+
+def _spawn_ranks(n):
+    """`python bench.py --gpus N` without a launcher: start the N ranks as fresh child processes.  Nothing in this (parent)
+    process has touched torch.cuda or HIP, and it never does: it only waits.  Rank 0 inherits stdout and prints the JSON line."""
+    import socket
+    import subprocess
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    procs = []
+    for r in range(n):
+        env = dict(os.environ)
+        env.update({"RANK": str(r), "LOCAL_RANK": str(r), "WORLD_SIZE": str(n), "LOCAL_WORLD_SIZE": str(n),
+                    "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": str(port)})
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=None if r == 0 else subprocess.DEVNULL))
+    rc = 0
+    for pr in procs:
+        code = pr.wait()
+        rc = rc or code
+    raise SystemExit(rc)
 
 
 def main():
@@ -51,6 +79,9 @@ def main():
     ap.add_argument("--cpu-threads", type=int, default=0, help="OpenMP threads of the CPU baseline (0: min(cores, 64))")
     args = ap.parse_args()
 
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        _spawn_ranks(args.gpus)             # never returns; no GPU call has happened in this process
+
     import numpy as np
     import torch
 
@@ -58,8 +89,7 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("--gpus %d needs torch.distributed.run with --nproc-per-node %d" % (args.gpus, args.gpus))
+        raise SystemExit("--gpus %d but the launcher started %d ranks" % (args.gpus, world))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: libzkhip has no CPU path")
     torch.cuda.set_device(local_rank)
@@ -96,6 +126,9 @@ def main():
 
     K, W = args.steps, args.warmup
     nbuf = min(max(K, 1), 8)
+    # this rank's shards of the K * world-shard job, dealt by the tested scheduling function (round-robin)
+    my = shards.shard_indices(max(K, 1) * world, rank, world)
+    assert len(my) == max(K, 1)
     if chip_list is None:
         with torch.cuda.stream(stream):
             traces = [torch.empty(cells, dtype=torch.int32, device="cuda") for _ in range(nbuf)]
@@ -112,9 +145,9 @@ def main():
             del spacers
         for i, b in enumerate(bufs):
             if LQ:
-                ctx.gen_trace_logup(SEED, rank * max(K, 1) + i, log_n, width, LQ, out=b)
+                ctx.gen_trace_logup(SEED, my[i], log_n, width, LQ, out=b)
             else:
-                ctx.gen_trace(SEED, rank * max(K, 1) + i, log_n, width, out=b)
+                ctx.gen_trace(SEED, my[i], log_n, width, out=b)
     else:
         nbuf = 1
         chip_bufs = [(ctx.gen_trace(SEED, 100 * rank + j, ln, w), ln, w) for j, (ln, w) in enumerate(chip_list)]
@@ -142,19 +175,16 @@ def main():
 
     def step(i, c=None):
         if host_traces is not None:
-            return (c or ctx).prove_shard_host(None, public + [rank * max(K, 1) + (i % nbuf)], prm, host_ptr=host_traces[i % nbuf].data_ptr(), log_n=log_n, width=width)
+            return (c or ctx).prove_shard_host(None, public + [my[i % nbuf]], prm, host_ptr=host_traces[i % nbuf].data_ptr(), log_n=log_n, width=width)
         if chip_list is not None:
-            return (c or ctx).prove_chips(chip_bufs, public + [rank * max(K, 1) + i], prm)
-        return (c or ctx).prove_shard(bufs[i % nbuf], log_n, width, public + [rank * max(K, 1) + (i % nbuf)], prm)
+            return (c or ctx).prove_chips(chip_bufs, public + [my[i % len(my)]], prm)
+        return (c or ctx).prove_shard(bufs[i % nbuf], log_n, width, public + [my[i % nbuf]], prm)
 
     def run_steps(count, static=False):
         """`count` shard proofs, S at a time (one host thread per context; ctypes drops the GIL).
         static: worker w takes items w, w + S, ... (warm-up: every context gets work); otherwise first come first served"""
         if S == 1:
-            out = None
-            for i in range(count):
-                out = step(i)
-            return out
+            return [step(i) for i in range(count)]
         import threading
         results = [None] * count
         errors = []
@@ -184,7 +214,7 @@ def main():
             t.join()
         if errors:
             raise errors[0]
-        return results[count - 1] if count else None
+        return results
 
     run_steps(max(W, S if W else 0), static=True)       # warm every context (plans, workspaces)
     for c in ctxs:
@@ -198,77 +228,93 @@ def main():
 
     barrier()
     t0 = time.perf_counter()
-    last = run_steps(K)
+    proofs = run_steps(K)
     barrier()
     elapsed = time.perf_counter() - t0
     elapsed = shards.max_over_ranks(dist, elapsed, device="cuda")
+    last = proofs[K - 1]
+    # after the timed region: every shard of the job was proven exactly once, on exactly one rank (digest gather over RCCL)
+    digests = shards.gather_proof_digests(dist, {my[i]: proofs[i] for i in range(K)})
+    if sorted(digests) != list(range(K * world)):
+        raise SystemExit("shard coverage broken: %d digests for %d shards" % (len(digests), K * world))
+    del proofs
+
+    # single-shard latency (one shard in flight, nothing else on the GPU): NOT the metric -- `value` is throughput with S shards in flight
+    latency_ms = None
+    if rank == 0 and chip_list is None and host_traces is None:
+        ctx.sync()
+        step(0)
+        tl = time.perf_counter()
+        for i in range(2):
+            step(i)
+        ctx.sync()
+        latency_ms = (time.perf_counter() - tl) / 2 * 1e3
 
     # the last proof of the timed region must verify (host verifier of the product)
     if chip_list is None:
-        rc, reason = verify_shard(last, log_n, width, public + [rank * max(K, 1) + ((K - 1) % nbuf)], prm)
+        rc, reason = verify_shard(last, log_n, width, public + [my[(K - 1) % nbuf]], prm)
     else:
         from zktls_amd.device import verify_chips
-        rc, reason = verify_chips(last, [c[0] for c in chip_list], [c[1] for c in chip_list], public + [rank * max(K, 1) + K - 1], prm)
+        rc, reason = verify_chips(last, [c[0] for c in chip_list], [c[1] for c in chip_list], public + [my[(K - 1) % len(my)]], prm)
     verified = rc == 0
 
-    # ---- roofline of the dominant kernel: one NTT pass = 8 B/element (read 4 + write 4)
+    # ---- roofline of the NTT pass kernel: one launch = 8 B/element (read 4 + write 4).
+    # Measured on the IN-PROOF placement: the four launches of the trace LDE (inverse strided / inverse contiguous / forward
+    # block-in strided-out / forward contiguous) exactly as zkhip_prove_shard enqueues them, on context 0's own coefficient and
+    # LDE workspaces (zkhip_ntt_pass which = 2..5).  `achieved` = algorithmic bytes / mean launch time over the six launches of one
+    # LDE (I1, I2, 2 x F1, 2 x F2).  Nothing is selected: the placement is whatever the proving context got.  A scan of the
+    # stand-alone strided pass over 16 (source, destination) buffer pairs is reported beside it (min / median / max) for context.
     roof = None
     if rank == 0:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        # placement scan: every (source, destination) pair of up to four traces and the four scratch buffers, 100 launches each
-        cands = [ctx.wrap(t) for t in roof_scratch]
-        srcs = bufs[:4]
-        placements = []
-        for _ in range(300):                      # settle clocks before comparing placements
-            ctx.ntt_pass(srcs[0], cands[0], log_n, width, 0)
-        for sb in srcs:
-            for cb in cands:
-                for _ in range(3):
-                    ctx.ntt_pass(sb, cb, log_n, width, 0)
-                e0.record(stream)
-                for _ in range(100):
-                    ctx.ntt_pass(sb, cb, log_n, width, 0)
-                e1.record(stream)
-                e1.synchronize()
-                placements.append(e0.elapsed_time(e1) / 100)
-        best = placements.index(min(placements))
-        rsrc, sbuf = srcs[best // len(cands)], cands[best % len(cands)]
-        # many isolated launches: the kernel's average in a rocprofv3 trace of this command is then
-        # dominated by launches that had the GPU to themselves (the in-proof launches overlap
-        # with kernels of the other shards in flight and are stretched by that)
-        reps = 4000
-        per_which = []
-        for which in (0, 1):
-            for _ in range(3):
-                ctx.ntt_pass(rsrc, sbuf, log_n, width, which)
+
+        def timed(fn, reps, warm=3):
+            for _ in range(warm):
+                fn()
             e0.record(stream)
             for _ in range(reps):
-                ctx.ntt_pass(rsrc, sbuf, log_n, width, which)
+                fn()
             e1.record(stream)
             e1.synchronize()
-            per_which.append(e0.elapsed_time(e1) / reps)
-        avg_ms = sum(per_which) / len(per_which)
+            return e0.elapsed_time(e1) / reps
+        for _ in range(300):                      # settle clocks
+            ctx.ntt_pass(bufs[0], None, log_n, width, 2)
+        reps = 1000
+        names = {2: "zk::ntt_pass_kernel<4,true,2,5,2>, LDE pass I1 (inverse, strided in -> strided out)",
+                 3: "zk::ntt_pass_kernel<4,true,2,5,1>, LDE pass I2 (inverse, contiguous, in place)",
+                 4: "zk::ntt_pass_kernel<4,false,2,5,2>, LDE pass F1 (forward, block in -> strided bit-reversed out)",
+                 5: "zk::ntt_pass_kernel<4,false,2,5,1>, LDE pass F2 (forward, contiguous, in place)"}
+        in_proof = {w: timed(lambda w=w: ctx.ntt_pass(bufs[0], None, log_n, width, w), reps) for w in (2, 3, 4, 5)}
+        avg_ms = (in_proof[2] + in_proof[3] + 2 * in_proof[4] + 2 * in_proof[5]) / 6.0
         alg_bytes = 8.0 * n * width
         achieved = alg_bytes / (avg_ms * 1e-3) / 1e9
-        traffic = None
+        # stand-alone passes on caller buffers, every (source, destination) pair of up to four traces and four scratch buffers
+        cands = [ctx.wrap(t) for t in roof_scratch]
+        srcs = bufs[:4]
+        placements = sorted(timed(lambda sb=sb, cb=cb: ctx.ntt_pass(sb, cb, log_n, width, 0), 100) for sb in srcs for cb in cands)
+        contiguous_ms = timed(lambda: ctx.ntt_pass(srcs[0], cands[0], log_n, width, 1), 500)
+        med = placements[len(placements) // 2]
+        traffic, traffic_src = None, None
         pmc = os.path.join(ROOT, "profiles", "pmc_ntt_pass.json")
         if os.path.exists(pmc):
             try:
-                traffic = json.load(open(pmc)).get("hbm_bytes_per_launch")
+                pj = json.load(open(pmc))
+                traffic = pj.get("hbm_bytes_per_launch")
+                traffic_src = "from profiles/pmc_ntt_pass.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, %s), not measured in this run" % pj.get("measured_at", "round 1")
             except Exception:
                 traffic = None
+
+        def gbs(ms):
+            return round(alg_bytes / ms / 1e6, 1)
         roof = {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
-                "kernel": "NTT pass (mean of the two passes of one 2^20-point transform)",
-                "strided_pass_ms_by_placement": [round(x, 4) for x in placements],
+                "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_src,
+                "kernel": "zk::ntt_pass_kernel, mean over the six launches of one 2^%d x %d trace LDE on the proving context's own workspaces (in-proof placement, nothing selected)" % (log_n, width),
                 "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_ms": round(avg_ms, 4),
-                "kernels": {
-                    "zk::ntt_pass_kernel<4,false,2,5,2>, strided pass": {
-                        "ms": round(per_which[0], 4), "GB/s": round(alg_bytes / per_which[0] / 1e6, 1),
-                        "frac": round(alg_bytes / per_which[0] / 1e6 / HBM_PEAK_GBS, 4)},
-                    "zk::ntt_pass_kernel<4,false,2,5,1>, contiguous pass": {
-                        "ms": round(per_which[1], 4), "GB/s": round(alg_bytes / per_which[1] / 1e6, 1),
-                        "frac": round(alg_bytes / per_which[1] / 1e6 / HBM_PEAK_GBS, 4)}}}
+                "kernels": {names[w]: {"ms": round(in_proof[w], 4), "GB/s": gbs(in_proof[w]), "frac": round(gbs(in_proof[w]) / HBM_PEAK_GBS, 4)} for w in (2, 3, 4, 5)},
+                "standalone_strided_pass_by_placement": {"pairs": len(placements), "min_ms": round(placements[0], 4), "median_ms": round(med, 4),
+                                                         "max_ms": round(placements[-1], 4), "median_frac": round(gbs(med) / HBM_PEAK_GBS, 4),
+                                                         "best_placement_frac": round(gbs(placements[0]) / HBM_PEAK_GBS, 4)},
+                "standalone_contiguous_pass": {"ms": round(contiguous_ms, 4), "frac": round(gbs(contiguous_ms) / HBM_PEAK_GBS, 4)}}
 
     # ---- the kernel that takes most of a proof's time is not HBM-shaped: Poseidon2 leaf hashing, priced against the
     # measured integer-multiply roof (v_mul_lo / v_mad_u64_u32 issue at 4.2 clk per wave64 per SIMD at the
@@ -335,6 +381,11 @@ def main():
             "dtype": "u32",
             "data": "synthetic",
             "streams_per_gpu": S,
+            "rccl_world_size": (dist.get_world_size() if dist is not None else 1),
+            "collective_backend": (dist.get_backend() if dist is not None else None),
+            "shards_proven": K * world, "shard_digests_gathered": len(digests), "shard_assignment": "round-robin (zktls_amd.shards.shard_indices)",
+            "timing_note": "ms_per_step is amortised throughput with %d shards in flight per GPU, not latency" % S,
+            "single_shard_latency_ms": (round(latency_ms, 3) if latency_ms is not None else None),
             "inputs": "host memory, H2D copy inside every step" if host_traces is not None else "resident in HBM",
             "config": {"workload": ("multi-chip shard (SP1's shard structure): chips %s, one commitment per phase, %d trace cells, log_blowup 1, 100 queries, 16 PoW bits, full prove_chips" % (args.chips, cells))
                                    if chip_list is not None else

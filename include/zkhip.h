@@ -143,9 +143,12 @@ int zkhip_dft(zkhip_ctx* ctx, const uint32_t* d_in, size_t in_ld, uint32_t* d_ou
  * rows; row bitrev(i) = f(shift * w^i).  `shift` is a CANONICAL field element. */
 int zkhip_coset_lde(zkhip_ctx* ctx, const uint32_t* d_in, size_t in_ld, uint32_t* d_out,
                     size_t out_ld, int log_n, uint32_t width, int log_blowup, uint32_t shift);
-/* benchmark hook: ONE launch of the NTT pass kernel (the roofline kernel) on a
- * 2^log_n x width matrix: which = 0 strided (first) pass, 1 contiguous (second) pass of
- * the forward transform.  d_out may equal d_in. */
+/* benchmark hook: ONE launch of the NTT pass kernel (the roofline kernel) on a 2^log_n x width matrix.
+ * which = 0 strided (first) pass, 1 contiguous (second) pass of a forward transform from d_in to d_out (d_out may equal d_in).
+ * which = 2..5: one of the four launches of the trace LDE exactly as zkhip_prove_shard enqueues them, on THIS context's own
+ * workspaces (the in-proof buffer placement): 2 = first inverse pass (strided, d_in = the trace -> coefficient workspace),
+ * 3 = second inverse pass (contiguous, in place), 4 = first forward pass of the coset (coefficients -> LDE workspace,
+ * strided bit-reversed stores), 5 = second forward pass (contiguous, in place); d_out is ignored, d_in only read by 2. */
 int zkhip_ntt_pass(zkhip_ctx* ctx, const uint32_t* d_in, uint32_t* d_out, size_t ld, int log_n,
                    uint32_t width, int which);
 
@@ -298,6 +301,11 @@ int zkhip_prove_chips(zkhip_ctx* ctx, const zkhip_chip* chips, int n_chips, cons
 int zkhip_verify_chips(const uint8_t* proof, size_t len, const int32_t* log_ns, const uint32_t* widths, const int32_t* pairs,
                        const int32_t* partners, int n_chips,
                        const uint32_t* public_values, size_t n_public, const zkhip_params* prm, int* reason);
+
+/* Request digest: 8 canonical BabyBear words binding the guest input (the CBOR bytes of sp1.rs:108-109 / prover.rs:81-82) and
+ * the guest program (ELF): Poseidon2 overwrite-mode sponge over 3-byte limbs, fields length-prefixed.  The glue uses them as the
+ * leading public values of every shard of the request, so a proof does not transfer to another request.  Host only. */
+int zkhip_request_digest(const uint8_t* input, size_t input_len, const uint8_t* program, size_t program_len, uint32_t out[8]);
 
 /* intermediates of the last zkhip_prove_shard on this context (canonical words) */
 typedef struct {

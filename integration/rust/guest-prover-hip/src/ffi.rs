@@ -48,6 +48,11 @@ pub const ZKHIP_OK: c_int = 0;
 extern "C" {
     pub fn zkhip_last_error() -> *const c_char;
     pub fn zkhip_device_count() -> c_int;
+    pub fn zkhip_request_digest(input: *const u8, input_len: usize, program: *const u8, program_len: usize, out: *mut u32) -> c_int;
+    /// all shards of one request over a device list, shard s on devices[s mod n] (null list + 0: every visible device)
+    pub fn zkhip_prove_shards_multi(devices: *const c_int, n_devices: c_int, jobs: *mut ZkhipShardJob, n_jobs: c_int,
+                                    prm: *const ZkhipParams, in_flight_per_device: c_int, host_traces: c_int) -> c_int;
+    pub fn zkhip_shard_device(shard_index: c_int, devices: *const c_int, n_devices: c_int) -> c_int;
     pub fn zkhip_ctx_create(device: c_int, stream: *mut c_void, out: *mut *mut ZkhipCtx) -> c_int;
     pub fn zkhip_ctx_destroy(ctx: *mut ZkhipCtx);
     pub fn zkhip_malloc(ctx: *mut ZkhipCtx, bytes: usize, d_ptr: *mut *mut c_void) -> c_int;

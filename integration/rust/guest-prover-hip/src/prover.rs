@@ -60,8 +60,9 @@ pub trait ShardSource: Send {
     fn shards(&mut self, input_cbor: &[u8], elf: &[u8]) -> Result<(Vec<u8>, Vec<Shard>)>;
 }
 
-/// Stand-in source used until the executor is wired: `count` synthetic AIR-satisfying shards generated on
-/// the device (`zkhip_gen_trace`), seeded from the request bytes.
+/// Stand-in used until the executor is wired: `count` synthetic AIR-satisfying shards generated on the device
+/// (`zkhip_gen_trace`), seed and public values bound to `zkhip_request_digest(cbor, elf)`.  EXPLICIT OPT-IN only
+/// (`with_synthetic`): such a blob attests nothing about the guest, its header carries `BATCH_FLAG_SYNTHETIC`.
 pub struct SyntheticShards {
     pub log_n: i32,
     pub width: u32,
@@ -73,13 +74,15 @@ pub struct HipGuestProver {
     backend: Backend,
     device: i32,
     source: Option<Box<dyn ShardSource>>,
-    synthetic: SyntheticShards,
+    synthetic: Option<SyntheticShards>,
 }
+
+/// batch blob header: "ZKTB", version 2, flags, shard count; then (u32 length, bytes) per shard
+pub const BATCH_FLAG_SYNTHETIC: u32 = 1;
 
 impl HipGuestProver {
     pub fn new(device: i32) -> Self {
-        Self { mode: ProverType::default(), backend: Backend::default(), device, source: None,
-               synthetic: SyntheticShards { log_n: 20, width: 256, count: 1 } }
+        Self { mode: ProverType::default(), backend: Backend::default(), device, source: None, synthetic: None }
     }
     pub fn mock(mut self) -> Self { self.mode = ProverType::Mock; self }
     pub fn local(mut self) -> Self { self.mode = ProverType::Local; self }
@@ -87,7 +90,8 @@ impl HipGuestProver {
     pub fn network(mut self) -> Self { self.mode = ProverType::Network; self }
     pub fn risc0(mut self) -> Self { self.backend = Backend::Risc0; self }
     pub fn with_source(mut self, source: Box<dyn ShardSource>) -> Self { self.source = Some(source); self }
-    pub fn with_synthetic(mut self, plan: SyntheticShards) -> Self { self.synthetic = plan; self }
+    /// opt into proving synthetic shards when no executor is wired (see `SyntheticShards`)
+    pub fn with_synthetic(mut self, plan: SyntheticShards) -> Self { self.synthetic = Some(plan); self }
 
     fn params(&self, log_n: i32) -> ZkhipParams {
         match self.backend {
@@ -120,59 +124,68 @@ impl ZkProver for HipGuestProver {
 
 impl HipGuestProver {
     fn prove_blocking(&mut self, cbor: &[u8], elf: &[u8]) -> Result<(Vec<u8>, Vec<u8>)> {
+        anyhow::ensure!(!elf.is_empty(), "guest program is empty");
+        // the request digest: 8 canonical words = the leading public values of every shard and, without an executor, the
+        // public output -- the same function the C++ mirror calls (zktls_amd/host/guest_prover_hip.cpp)
+        let mut digest = [0u32; 8];
+        check(unsafe { ffi::zkhip_request_digest(cbor.as_ptr(), cbor.len(), elf.as_ptr(), elf.len(), digest.as_mut_ptr()) }, "zkhip_request_digest")?;
+        let digest_bytes: Vec<u8> = digest.iter().flat_map(|w| w.to_le_bytes()).collect();
         match self.mode {
-            ProverType::Mock => return Ok((Vec::new(), Vec::new())),        // a <= 4-byte proof means "no proof"
+            // executes nothing: public output = the digest, proof = a <= 4-byte placeholder, i.e. "no proof" (sp1.rs:128-130)
+            ProverType::Mock => return Ok((digest_bytes, Vec::new())),
             ProverType::Network => return Err(anyhow!("network proving is not provided by the HIP backend")),
             ProverType::Local | ProverType::Hip => {}
+        }
+        // A caller applying the reference's rule "proof.len() > 4 means a real proof" must never receive bytes that attest
+        // nothing about the guest: without an executor the synthetic plan is an explicit opt-in, otherwise this is an error.
+        if self.source.is_none() && self.synthetic.is_none() {
+            return Err(anyhow!("no shard source: wire the zkVM executor with with_source(), or opt into synthetic shards with with_synthetic()"));
         }
         if unsafe { ffi::zkhip_device_count() } <= 0 {
             return Err(anyhow!("no gfx950 device: libzkhip has no CPU fallback"));
         }
         let ctx = Context::new(self.device)?;
-        let (output, shards) = match self.source.as_mut() {
-            Some(src) => src.shards(cbor, elf)?,
-            None => (Vec::new(), Vec::new()),
-        };
         let start = std::time::Instant::now();
-        let mut blob = Vec::new();                                           // "ZKTB", version, count, then (len, bytes) per shard
-        blob.extend_from_slice(&0x42544B5Au32.to_le_bytes());
-        blob.extend_from_slice(&1u32.to_le_bytes());
-        let mut count = 0u32;
-        let count_at = blob.len();
-        blob.extend_from_slice(&0u32.to_le_bytes());
-        let mut push = |proof: &[u8], blob: &mut Vec<u8>| {
-            blob.extend_from_slice(&(proof.len() as u32).to_le_bytes());
-            blob.extend_from_slice(proof);
-        };
-        if self.source.is_some() {
+        let mut proofs: Vec<Vec<u8>> = Vec::new();
+        let (output, flags) = if let Some(src) = self.source.as_mut() {
+            let (output, shards) = src.shards(cbor, elf)?;
             for shard in &shards {
                 let prm = self.params(shard.log_n);
                 let buf = ctx.alloc(shard.values.len())?;
                 buf.upload_canonical(&shard.values)?;
-                let proof = prove_one(&ctx, buf.ptr, shard.log_n, shard.width, shard.column_major, &shard.public_values, &prm)?;
-                push(&proof, &mut blob);
-                count += 1;
+                let mut pv = digest.to_vec();
+                pv.extend_from_slice(&shard.public_values);
+                proofs.push(prove_one(&ctx, buf.ptr, shard.log_n, shard.width, shard.column_major, &pv, &prm)?);
             }
+            (output, 0u32)
         } else {
-            let plan = &self.synthetic;
+            let plan = self.synthetic.as_ref().unwrap();
             let prm = self.params(plan.log_n);
             let words = (plan.width as usize) << plan.log_n;
             let buf = ctx.alloc(words)?;
-            let seed = cbor.iter().chain(elf.iter()).fold(0xcbf29ce484222325u64, |h, b| (h ^ *b as u64).wrapping_mul(0x100000001b3));
+            let seed = digest[..4].iter().fold(0u64, |h, w| (h << 16) ^ (*w as u64));      // as the C++ mirror
             for s in 0..plan.count {
                 check(unsafe { ffi::zkhip_gen_trace(ctx.raw(), seed, s as u64, plan.log_n, plan.width, buf.ptr, plan.width as usize) }, "zkhip_gen_trace")?;
-                let proof = prove_one(&ctx, buf.ptr, plan.log_n, plan.width, false, &[s], &prm)?;
-                push(&proof, &mut blob);
-                count += 1;
+                let mut pv = digest.to_vec();
+                pv.push(s);
+                proofs.push(prove_one(&ctx, buf.ptr, plan.log_n, plan.width, false, &pv, &prm)?);
             }
+            (digest_bytes, BATCH_FLAG_SYNTHETIC)
+        };
+        let mut blob = Vec::new();
+        blob.extend_from_slice(&0x42544B5Au32.to_le_bytes());               // "ZKTB"
+        blob.extend_from_slice(&2u32.to_le_bytes());
+        blob.extend_from_slice(&flags.to_le_bytes());
+        blob.extend_from_slice(&(proofs.len() as u32).to_le_bytes());
+        for p in &proofs {
+            blob.extend_from_slice(&(p.len() as u32).to_le_bytes());
+            blob.extend_from_slice(p);
         }
-        blob[count_at..count_at + 4].copy_from_slice(&count.to_le_bytes());
         log::info!("Proving took: {:?}", start.elapsed());
-        let mut proof = blob;
-        if proof.len() <= 4 {
-            proof = Vec::new();                                              // sp1.rs:128-130 / prover.rs:101-103
+        if blob.len() <= 4 {
+            blob = Vec::new();                                               // sp1.rs:128-130 / prover.rs:101-103
         }
-        Ok((output, proof))
+        Ok((output, blob))
     }
 }
 

@@ -27,6 +27,7 @@ def lib():
     L.zktls_current_risc0_dev_mode_env.restype = C.c_char_p
     L.zktls_request_digest.argtypes = [C.c_char_p, C.c_size_t, C.c_char_p, C.c_size_t, C.POINTER(C.c_uint32)]
     L.zktls_unpack_batch.argtypes = [C.c_char_p, C.c_size_t, szp, szp, C.c_int]
+    L.zktls_batch_flags.argtypes = [C.c_char_p, C.c_size_t]
     L.zktls_free.argtypes = [C.c_void_p]
     return L
 
@@ -77,6 +78,42 @@ def test_errors_come_back_as_values(lib):
         assert lib.zktls_current_sp1_prover_env() == b"hip"
 
 
+def test_local_and_hip_modes_refuse_to_prove_without_a_shard_source(lib):
+    """The reference's caller treats proof.len() > 4 as a proof of the guest execution (sp1.rs:128-130).  With no zkVM
+    executor wired, the backend must not hand out bytes that attest nothing: synthetic shards are an explicit opt-in
+    (a plan), and without it Local / Hip fail -- on any box, before a device is even looked for."""
+    for mode in (1, 2):
+        for r0 in (False, True):
+            rc, err, out, proof = call(lib, mode, b"\xa2input", b"\x7fELF....", None, r0=r0)
+            assert rc != 0 and "no shard source" in err and proof is None
+    rc, err, out, proof = call(lib, 0, b"\xa2input", b"\x7fELF....", None)      # mock needs no source
+    assert rc == 0 and proof == b""
+
+
+def test_request_digest_is_the_library_entry(lib):
+    """the mirror and the Rust shim take the public values from the same C-ABI function (zkhip_request_digest)"""
+    from zktls_amd import _lib
+    L = _lib.load()
+    a, b = (C.c_uint32 * 8)(), (C.c_uint32 * 8)()
+    cbor, elf = b"\xa2input" * 7, b"\x7fELF...."
+    assert L.zkhip_request_digest(cbor, len(cbor), elf, len(elf), a) == 0
+    lib.zktls_request_digest(cbor, len(cbor), elf, len(elf), b)
+    assert list(a) == list(b) and all(v < 2013265921 for v in a)
+    assert L.zkhip_request_digest(None, 3, elf, len(elf), a) == -1
+    # an independent restatement of the sponge (tests/pyref.py primitives)
+    import pyref
+    words = [0x5A4B54]
+    for blob in (cbor, elf):
+        words += [len(blob) & 0xFFFFFF, (len(blob) >> 24) & 0xFFFFFF]
+        words += [int.from_bytes(blob[i:i + 3], "little") for i in range(0, len(blob), 3)]
+    st = [0] * 16
+    for i in range(0, len(words), 8):
+        chunk = words[i:i + 8]
+        st[:len(chunk)] = chunk
+        st = pyref.poseidon2(st)
+    assert list(b) == st[:8]
+
+
 @pytest.mark.gpu
 def test_hip_mode_proves_and_packs_shards(lib):
     from zktls_amd._lib import Params
@@ -87,6 +124,7 @@ def test_hip_mode_proves_and_packs_shards(lib):
     offs, lens = (C.c_size_t * 8)(), (C.c_size_t * 8)()
     n = lib.zktls_unpack_batch(blob, len(blob), offs, lens, 8)
     assert n == 3
+    assert lib.zktls_batch_flags(blob, len(blob)) == 1          # flagged SYNTHETIC: attests nothing about a guest
     digest = np.frombuffer(out, dtype=np.uint32).tolist()
     for s in range(3):
         proof = np.frombuffer(blob[offs[s]:offs[s] + lens[s]], dtype=np.uint8)

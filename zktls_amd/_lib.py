@@ -23,7 +23,7 @@ EXPORTS = [
     "zkhip_dft", "zkhip_coset_lde", "zkhip_ntt_pass", "zkhip_poseidon2_permute", "zkhip_hash_rows",
     "zkhip_merkle_commit", "zkhip_merkle_commit_mixed", "zkhip_merkle_commit_p24_colmajor", "zkhip_batch_interpolate_colmajor", "zkhip_batch_expand_colmajor", "zkhip_quotient_values", "zkhip_open_at", "zkhip_fri_fold", "zkhip_fri_fold_k",
     "zkhip_commit", "zkhip_proof_size", "zkhip_prove_shard", "zkhip_prove_shard_host", "zkhip_prove_shards", "zkhip_prove_shards_multi", "zkhip_shard_device", "zkhip_release_cached_contexts", "zkhip_prove_segment", "zkhip_verify_shard", "zkhip_last_prove_debug",
-    "zkhip_chips_proof_size", "zkhip_prove_chips", "zkhip_verify_chips",
+    "zkhip_chips_proof_size", "zkhip_prove_chips", "zkhip_verify_chips", "zkhip_request_digest",
 ]
 
 
@@ -117,6 +117,7 @@ def load():
     L.zkhip_release_cached_contexts.restype = None
     L.zkhip_prove_shards.argtypes = [C.c_int, C.POINTER(ShardJob), C.c_int, C.POINTER(Params), C.c_int, C.c_int]
     L.zkhip_prove_shards_multi.argtypes = [C.POINTER(C.c_int), C.c_int, C.POINTER(ShardJob), C.c_int, C.POINTER(Params), C.c_int, C.c_int]
+    L.zkhip_request_digest.argtypes = [C.c_char_p, C.c_size_t, C.c_char_p, C.c_size_t, u32p]
     L.zkhip_shard_device.argtypes = [C.c_int, C.POINTER(C.c_int), C.c_int]
     L.zkhip_prove_segment.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_uint32, u32p, C.c_size_t,
                                       C.POINTER(Params), u8p, C.c_size_t, C.POINTER(C.c_size_t)]

@@ -87,6 +87,8 @@ int get_plan(zkhip_ctx* ctx, int log_n, int kind, uint32_t shift, const NttPlan*
     return ZKHIP_OK;
 }
 
+enum { LDE_I1 = 0, LDE_I2 = 1, LDE_F1 = 2, LDE_F2 = 3 };
+
 static NttPassArgs base_args(zkhip_ctx* ctx, const uint32_t* in, size_t in_ld, uint32_t* out, size_t out_ld,
                              uint32_t width, bool inverse) {
     NttPassArgs a{};
@@ -183,6 +185,54 @@ static int run_forward_natural(zkhip_ctx* ctx, const uint32_t* in, size_t in_ld,
     return ZKHIP_OK;
 }
 
+// The four launches of a two-pass LDE (log_n >= 11), built in ONE place: op_coset_lde enqueues them and zkhip_ntt_pass
+// (which = 2..5) replays any one of them on the context's own workspaces for the roofline measurement.
+//   I1  inverse, strided in -> strided out (trace -> coefficient workspace), post = w^-(i1 k2) / N
+//   I2  inverse, contiguous tiles in place on the coefficient workspace (coefficients left in transposed order)
+//   F1  forward, block in (transposed coefficients) -> strided bit-reversed out, pre = (s^M1')^i2', post = w^(i1' k2') s^i1'
+//   F2  forward, contiguous tiles in place on the LDE, bit-reversed inside the tile
+int lde_pass_args(zkhip_ctx* ctx, int which, const uint32_t* in, size_t in_ld, uint32_t* coef, uint32_t* dst, size_t out_ld,
+                  int log_n, uint32_t width, uint32_t coset_shift, NttPassArgs* out, bool* inverse) {
+    int m1, m2;
+    split(log_n, &m1, &m2);
+    if (m1 == 0) return fail(ZKHIP_ERR_INTERNAL, "lde_pass_args: single-pass size");
+    const uint64_t M1 = 1ull << m1, M2 = 1ull << m2;
+    const NttPlan* p;
+    if (which == LDE_I1 || which == LDE_I2) {
+        ZK_TRY(get_plan(ctx, log_n, 0, 0, &p));
+        *inverse = true;
+        if (which == LDE_I1) {
+            NttPassArgs a = base_args(ctx, in, in_ld, coef, width, width, true);
+            a.num_tiles = (uint32_t)M1; a.log_m = (uint32_t)m2;
+            a.in_tile_mul = 1; a.in_stride = M1; a.out_tile_mul = 1; a.out_stride = M1; a.post = p->post;
+            *out = a;
+        } else {
+            NttPassArgs b = base_args(ctx, coef, width, coef, width, width, true);
+            b.num_tiles = (uint32_t)M2; b.log_m = (uint32_t)m1;
+            b.in_tile_mul = M1; b.in_stride = 1; b.out_tile_mul = M1; b.out_stride = 1;
+            *out = b;
+        }
+        return ZKHIP_OK;
+    }
+    ZK_TRY(get_plan(ctx, log_n, 2, coset_shift, &p));
+    *inverse = false;
+    const uint64_t M1p = M2, M2p = M1;                               // forward factors (swapped)
+    if (which == LDE_F1) {
+        NttPassArgs a = base_args(ctx, coef, width, dst, out_ld, width, false);
+        a.num_tiles = (uint32_t)M1p; a.log_m = (uint32_t)m1;
+        a.in_tile_mul = M2p; a.in_stride = 1;
+        a.out_tile_mul = 1; a.out_stride = M1p; a.bitrev_out = 1;
+        a.pre = p->pre; a.post = p->post;
+        *out = a;
+    } else {
+        NttPassArgs b = base_args(ctx, dst, out_ld, dst, out_ld, width, false);
+        b.num_tiles = (uint32_t)M2p; b.log_m = (uint32_t)m2;
+        b.in_tile_mul = M1p; b.in_stride = 1; b.out_tile_mul = M1p; b.out_stride = 1; b.bitrev_out = 1;
+        *out = b;
+    }
+    return ZKHIP_OK;
+}
+
 int op_coset_lde(zkhip_ctx* ctx, const uint32_t* in, size_t in_ld, uint32_t* out, size_t out_ld,
                  int log_n, uint32_t width, int log_blowup, uint32_t shift) {
     if (log_n < 0 || log_n > 20) return fail(ZKHIP_ERR_INVALID, "coset_lde: log_n must be in [0, 20]");
@@ -201,37 +251,38 @@ int op_coset_lde(zkhip_ctx* ctx, const uint32_t* in, size_t in_ld, uint32_t* out
     const int B = 1 << log_blowup;
     int m1, m2;
     split(log_n, &m1, &m2);
-    // coefficients into scratch slot 0
+    // coefficients into the coefficient workspace
     void* coef_v;
     ZK_TRY(ctx_reserve(ctx, S_COEF, n * width * 4, &coef_v));
     uint32_t* coef = (uint32_t*)coef_v;
-    ZK_TRY(run_inverse(ctx, in, in_ld, coef, width, log_n, width, /*transposed=*/m1 != 0));
     const uint32_t wnb = two_adic_generator(log_n + log_blowup);
-    for (int t = 0; t < B; t++) {
-        const uint32_t st = fmul(shift, fpow(wnb, (uint64_t)t));
-        uint32_t* dst = out + (size_t)reverse_bits((uint32_t)t, log_blowup) * n * out_ld;
-        if (m1 == 0) {
+    if (m1 == 0) {
+        ZK_TRY(run_inverse(ctx, in, in_ld, coef, width, log_n, width, /*transposed=*/false));
+        for (int t = 0; t < B; t++) {
+            const uint32_t st = fmul(shift, fpow(wnb, (uint64_t)t));
+            uint32_t* dst = out + (size_t)reverse_bits((uint32_t)t, log_blowup) * n * out_ld;
             const NttPlan* p;
             ZK_TRY(get_plan(ctx, log_n, 1, st, &p));
             NttPassArgs a = base_args(ctx, coef, width, dst, out_ld, width, false);
             a.num_tiles = 1; a.log_m = log_n; a.in_tile_mul = 0; a.in_stride = 1; a.out_tile_mul = 0; a.out_stride = 1;
             a.pre = p->pre; a.bitrev_out = 1;
             ZK_HIP(launch_ntt_pass(a, false, ctx->stream));
-            continue;
         }
-        const NttPlan* p;
-        ZK_TRY(get_plan(ctx, log_n, 2, st, &p));
-        const uint64_t M1p = 1ull << p->m2, M2p = 1ull << p->m1;   // forward factors (swapped)
-        NttPassArgs a = base_args(ctx, coef, width, dst, out_ld, width, false);
-        a.num_tiles = (uint32_t)M1p; a.log_m = p->m1;
-        a.in_tile_mul = M2p; a.in_stride = 1;
-        a.out_tile_mul = 1; a.out_stride = M1p; a.bitrev_out = 1;
-        a.pre = p->pre; a.post = p->post;
-        ZK_HIP(launch_ntt_pass(a, false, ctx->stream));
-        NttPassArgs b = base_args(ctx, dst, out_ld, dst, out_ld, width, false);
-        b.num_tiles = (uint32_t)M2p; b.log_m = p->m2;
-        b.in_tile_mul = M1p; b.in_stride = 1; b.out_tile_mul = M1p; b.out_stride = 1; b.bitrev_out = 1;
-        ZK_HIP(launch_ntt_pass(b, false, ctx->stream));
+        return ZKHIP_OK;
+    }
+    NttPassArgs a;
+    bool inv;
+    ZK_TRY(lde_pass_args(ctx, LDE_I1, in, in_ld, coef, nullptr, 0, log_n, width, 0, &a, &inv));
+    ZK_HIP(launch_ntt_pass(a, inv, ctx->stream));
+    ZK_TRY(lde_pass_args(ctx, LDE_I2, nullptr, 0, coef, nullptr, 0, log_n, width, 0, &a, &inv));
+    ZK_HIP(launch_ntt_pass(a, inv, ctx->stream));
+    for (int t = 0; t < B; t++) {
+        const uint32_t st = fmul(shift, fpow(wnb, (uint64_t)t));
+        uint32_t* dst = out + (size_t)reverse_bits((uint32_t)t, log_blowup) * n * out_ld;
+        ZK_TRY(lde_pass_args(ctx, LDE_F1, nullptr, 0, coef, dst, out_ld, log_n, width, st, &a, &inv));
+        ZK_HIP(launch_ntt_pass(a, inv, ctx->stream));
+        ZK_TRY(lde_pass_args(ctx, LDE_F2, nullptr, 0, coef, dst, out_ld, log_n, width, st, &a, &inv));
+        ZK_HIP(launch_ntt_pass(a, inv, ctx->stream));
     }
     return ZKHIP_OK;
 }
@@ -495,6 +546,21 @@ int zkhip_coset_lde(zkhip_ctx* ctx, const uint32_t* d_in, size_t in_ld, uint32_t
 int zkhip_ntt_pass(zkhip_ctx* ctx, const uint32_t* d_in, uint32_t* d_out, size_t ld, int log_n, uint32_t width, int which) {
     CHECK_CTX(ctx);
     if (log_n < 11 || log_n > 20) return fail(ZKHIP_ERR_INVALID, "ntt_pass: log_n must be in [11, 20]");
+    if (which >= 2 && which <= 5) {
+        // one launch of the trace LDE exactly as zkhip_prove_shard enqueues it, on THIS context's workspaces (the buffers its
+        // proofs use: same sizes, so nothing is reallocated or moved) -- the in-proof placement of the roofline kernel
+        if (width == 0 || ld < width || (which == 2 && !d_in)) return fail(ZKHIP_ERR_INVALID, "ntt_pass: bad arguments");
+        const size_t n = (size_t)1 << log_n;
+        void *coef, *lde;
+        ZK_TRY(ctx_reserve(ctx, S_COEF, n * width * 4, &coef));
+        ZK_TRY(ctx_reserve(ctx, S_TLDE, 2 * n * width * 4, &lde));
+        NttPassArgs a;
+        bool inv;
+        ZK_TRY(lde_pass_args(ctx, which - 2, d_in, ld, (uint32_t*)coef, (uint32_t*)lde, width, log_n, width, MONTY_GEN, &a, &inv));
+        ZK_HIP(launch_ntt_pass(a, inv, ctx->stream));
+        return ZKHIP_OK;
+    }
+    if (which != 0 && which != 1) return fail(ZKHIP_ERR_INVALID, "ntt_pass: which must be 0 .. 5");
     if (!d_in || !d_out || width == 0 || ld < width) return fail(ZKHIP_ERR_INVALID, "ntt_pass: bad arguments");
     const NttPlan* p;
     ZK_TRY(get_plan(ctx, log_n, 1, MONTY_R1, &p));

@@ -492,6 +492,34 @@ int zkhip_fri_fold_k(zkhip_ctx* ctx, const uint32_t* d_in, int log_h, int log_ar
     return ZKHIP_OK;
 }
 
+// 8 canonical words binding (input, program): overwrite-mode Poseidon2 sponge over 3-byte limbs, both fields length-prefixed,
+// domain-separated by "ZKT".  Host only (no device needed): the glue on either side of the FFI derives the same public values.
+int zkhip_request_digest(const uint8_t* input, size_t input_len, const uint8_t* program, size_t program_len, uint32_t out[8]) {
+    if (!out || (input_len && !input) || (program_len && !program)) return fail(ZKHIP_ERR_INVALID, "request_digest: null pointer");
+    uint32_t st[16] = {0};
+    int pos = 0;
+    auto absorb = [&](uint32_t canonical) {
+        st[pos++] = to_monty(canonical);
+        if (pos == 8) { p2_permute(st); pos = 0; }
+    };
+    auto absorb_bytes = [&](const uint8_t* b, size_t n) {
+        absorb((uint32_t)(n & 0xFFFFFF));
+        absorb((uint32_t)((uint64_t)n >> 24) & 0xFFFFFF);
+        for (size_t i = 0; i < n; i += 3) {
+            uint32_t v = b[i];
+            if (i + 1 < n) v |= (uint32_t)b[i + 1] << 8;
+            if (i + 2 < n) v |= (uint32_t)b[i + 2] << 16;
+            absorb(v);
+        }
+    };
+    absorb(0x5A4B54);   // "ZKT"
+    absorb_bytes(input, input_len);
+    absorb_bytes(program, program_len);
+    if (pos) p2_permute(st);
+    for (int i = 0; i < 8; i++) out[i] = from_monty(st[i]);
+    return ZKHIP_OK;
+}
+
 size_t zkhip_proof_size(int log_n, uint32_t width, const zkhip_params* prm, size_t n_public) {
     (void)n_public;
     if (check_shape(log_n, width, prm) != ZKHIP_OK) return 0;

@@ -145,7 +145,9 @@ class Context:
         return out
 
     def ntt_pass(self, src, dst, log_n, width, which):
-        check(self.lib.zkhip_ntt_pass(self.handle, C.c_void_p(src.ptr), C.c_void_p(dst.ptr), width, log_n, width, which))
+        """which 0 / 1: stand-alone passes src -> dst; which 2..5: the LDE launches of a proof on this context's own workspaces (dst unused)"""
+        check(self.lib.zkhip_ntt_pass(self.handle, C.c_void_p(src.ptr) if src is not None else None,
+                                      C.c_void_p(dst.ptr) if dst is not None else None, width, log_n, width, which))
 
     # ---- Poseidon2 / Merkle
     def poseidon2_permute(self, states):

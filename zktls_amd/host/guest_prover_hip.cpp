@@ -10,7 +10,6 @@
 #include <stdexcept>
 
 #include "../../include/zkhip.h"
-#include "../csrc/poseidon2.cuh"
 
 namespace zktls {
 
@@ -34,38 +33,20 @@ void set_env_r0(ProverType mode) {                                              
     }
 }
 
-// sponge over 3-byte limbs, length-prefixed and domain-separated; result canonical
+// the digest lives in libzkhip (zkhip_request_digest) so that the Rust glue derives the very same words through its FFI
 std::vector<uint32_t> request_digest(const std::vector<uint8_t>& cbor, const std::vector<uint8_t>& elf) {
-    uint32_t st[16] = {0};
-    int pos = 0;
-    auto absorb = [&](uint32_t canonical) {
-        st[pos++] = zk::to_monty(canonical);
-        if (pos == 8) { zk::p2_permute(st); pos = 0; }
-    };
-    auto absorb_bytes = [&](const std::vector<uint8_t>& b) {
-        absorb((uint32_t)(b.size() & 0xFFFFFF));
-        absorb((uint32_t)((uint64_t)b.size() >> 24) & 0xFFFFFF);
-        for (size_t i = 0; i < b.size(); i += 3) {
-            uint32_t v = b[i];
-            if (i + 1 < b.size()) v |= (uint32_t)b[i + 1] << 8;
-            if (i + 2 < b.size()) v |= (uint32_t)b[i + 2] << 16;
-            absorb(v);
-        }
-    };
-    absorb(0x5A4B54);   // "ZKT"
-    absorb_bytes(cbor);
-    absorb_bytes(elf);
-    if (pos) zk::p2_permute(st);
     std::vector<uint32_t> out(8);
-    for (int i = 0; i < 8; i++) out[i] = zk::from_monty(st[i]);
+    if (zkhip_request_digest(cbor.data(), cbor.size(), elf.data(), elf.size(), out.data()) != ZKHIP_OK)
+        throw std::runtime_error(std::string("zkhip_request_digest: ") + zkhip_last_error());
     return out;
 }
 
-std::vector<uint8_t> pack_shard_proofs(const std::vector<std::vector<uint8_t>>& proofs) {
+std::vector<uint8_t> pack_shard_proofs(const std::vector<std::vector<uint8_t>>& proofs, uint32_t flags) {
     std::vector<uint8_t> out;
     auto put32 = [&](uint32_t v) { for (int i = 0; i < 4; i++) out.push_back((uint8_t)(v >> (8 * i))); };
     put32(0x42544B5Au);   // "ZKTB"
-    put32(1);
+    put32(2);
+    put32(flags);
     put32((uint32_t)proofs.size());
     for (const auto& p : proofs) {
         put32((uint32_t)p.size());
@@ -74,11 +55,12 @@ std::vector<uint8_t> pack_shard_proofs(const std::vector<std::vector<uint8_t>>& 
     return out;
 }
 
-bool unpack_shard_proofs(const std::vector<uint8_t>& blob, std::vector<std::vector<uint8_t>>* proofs) {
+bool unpack_shard_proofs(const std::vector<uint8_t>& blob, std::vector<std::vector<uint8_t>>* proofs, uint32_t* flags) {
     auto get32 = [&](size_t off) { uint32_t v = 0; for (int i = 0; i < 4; i++) v |= (uint32_t)blob[off + i] << (8 * i); return v; };
-    if (blob.size() < 12 || get32(0) != 0x42544B5Au || get32(4) != 1) return false;
-    const uint32_t n = get32(8);
-    size_t off = 12;
+    if (blob.size() < 16 || get32(0) != 0x42544B5Au || get32(4) != 2) return false;
+    if (flags) *flags = get32(8);
+    const uint32_t n = get32(12);
+    size_t off = 16;
     proofs->clear();
     for (uint32_t i = 0; i < n; i++) {
         if (off + 4 > blob.size()) return false;
@@ -157,7 +139,11 @@ ProveResult HipGuestProver::prove_inner(const GuestInput& input, const std::vect
     }
     if (mode_ == ProverType::Network) throw std::runtime_error("network proving is not provided by the HIP backend");
     // Local and Hip both mean "prove on this machine"; there is no CPU path in libzkhip
+    if (!synthetic_)
+        throw std::runtime_error("no shard source: the zkVM executor that turns (input, ELF) into shard traces is not part of the HIP backend; "
+                                 "with_synthetic(plan) opts into proving synthetic shards (the blob is then flagged SYNTHETIC)");
     if (plan_.shards == 0) throw std::runtime_error("shard plan is empty");
+    if (devices_.empty()) throw std::runtime_error("device list is empty");
     zkhip_params prm{1, plan_.num_queries, plan_.pow_bits, 0, 0, 0, 0};
     if (backend_ == Backend::Risc0) {
         // RISC Zero's shape; the final polynomial shrinks for segments too small for 256 coefficients
@@ -181,23 +167,28 @@ ProveResult HipGuestProver::prove_inner(const GuestInput& input, const std::vect
     if (in_flight > plan_.shards) in_flight = plan_.shards;
     const size_t words = ((size_t)1 << plan_.log_n) * plan_.width;
     std::vector<std::vector<uint8_t>> proofs(plan_.shards);
-    std::atomic<uint32_t> next{0};
+    const int n_dev = (int)devices_.size();
+    std::vector<std::atomic<uint32_t>> next(n_dev);          // per device: how many of its shards were handed out
+    for (auto& a : next) a.store(0);
     std::atomic<bool> failed{false};
     std::mutex err_mu;
     std::string first_error;
-    auto worker = [&]() {
+    auto worker = [&](int slot) {
         try {
+            const int device = devices_[slot];
             CtxGuard g;
-            if (!g.take(device_, words * 4)) {
-                g.device = device_; g.trace_bytes = words * 4;
-                if (zkhip_ctx_create(device_, nullptr, &g.ctx) != ZKHIP_OK) fail_zkhip("zkhip_ctx_create");
+            if (!g.take(device, words * 4)) {
+                g.device = device; g.trace_bytes = words * 4;
+                if (zkhip_ctx_create(device, nullptr, &g.ctx) != ZKHIP_OK) fail_zkhip("zkhip_ctx_create");
                 if (zkhip_malloc(g.ctx, words * 4, &g.d_trace) != ZKHIP_OK) fail_zkhip("zkhip_malloc");
             }
             for (;;) {
-                const uint32_t s = next.fetch_add(1);
+                // the k-th shard of this device: shard s runs on devices[s mod n], as zkhip_shard_device deals them
+                const uint64_t s = (uint64_t)slot + (uint64_t)next[slot].fetch_add(1) * (uint64_t)n_dev;
                 if (s >= plan_.shards || failed.load()) break;
+                if (zkhip_shard_device((int)s, devices_.data(), n_dev) != device) throw std::runtime_error("shard dealt to the wrong device");
                 std::vector<uint32_t> pv(digest);
-                pv.push_back(s);
+                pv.push_back((uint32_t)s);
                 if (zkhip_gen_trace(g.ctx, seed, s, plan_.log_n, plan_.width, (uint32_t*)g.d_trace, plan_.width) != ZKHIP_OK)
                     fail_zkhip("zkhip_gen_trace");
                 std::vector<uint8_t> proof(cap);
@@ -222,15 +213,18 @@ ProveResult HipGuestProver::prove_inner(const GuestInput& input, const std::vect
             if (first_error.empty()) first_error = "unknown failure in a shard worker";
         }
     };
-    if (in_flight <= 1) {
-        worker();
+    if (in_flight <= 1 && n_dev == 1) {
+        worker(0);
     } else {
         std::vector<std::thread> pool;
-        for (uint32_t t = 0; t < in_flight; t++) pool.emplace_back(worker);
+        for (int slot = 0; slot < n_dev; slot++) {
+            const uint32_t mine = (plan_.shards - (uint32_t)slot + (uint32_t)n_dev - 1) / (uint32_t)n_dev;
+            for (uint32_t t = 0; t < (mine < in_flight ? mine : in_flight); t++) pool.emplace_back(worker, slot);
+        }
         for (auto& t : pool) t.join();
     }
     if (failed.load()) throw std::runtime_error(first_error);
-    r.proof = pack_shard_proofs(proofs);
+    r.proof = pack_shard_proofs(proofs, BATCH_FLAG_SYNTHETIC);
     r.ok = true;
     return r;
 }
@@ -252,11 +246,18 @@ void zktls_release_cached(void) { zktls::release_cached(); }
 struct zktls_shard_plan { int32_t log_n; uint32_t width; uint32_t shards; int32_t num_queries; int32_t pow_bits; };
 
 // mode: 0 mock, 1 local, 2 hip, 3 network.  Returns 0 on success; on failure copies the
-// message into err.  *output / *proof are malloc'd (zktls_free).
+// message into err.  *output / *proof are malloc'd (zktls_free).  A non-null `plan` IS the explicit opt-in to synthetic
+// shards (HipGuestProver::with_synthetic); with plan == NULL modes 1 / 2 fail with "no shard source".  `device` >= 0: that
+// device; device < 0: every visible device, shards dealt round-robin.
 static int guest_prove(zktls::Backend backend, int device, int mode, const zktls_shard_plan* plan, const uint8_t* cbor, size_t cbor_len,
                        const uint8_t* elf, size_t elf_len, uint8_t** output, size_t* output_len, uint8_t** proof,
                        size_t* proof_len, char* err, size_t err_cap) {
-    zktls::HipGuestProver p(device, backend);
+    zktls::HipGuestProver p(device < 0 ? 0 : device, backend);
+    if (device < 0) {
+        std::vector<int> all;
+        for (int d = 0; d < zkhip_device_count(); d++) all.push_back(d);
+        if (!all.empty()) p.with_devices(all);
+    }
     switch (mode) {
         case 0: p.mock(); break;
         case 1: p.local(); break;
@@ -267,7 +268,7 @@ static int guest_prove(zktls::Backend backend, int device, int mode, const zktls
         zktls::ShardPlan sp;
         sp.log_n = plan->log_n; sp.width = plan->width; sp.shards = plan->shards;
         sp.num_queries = plan->num_queries; sp.pow_bits = plan->pow_bits;
-        p.with_plan(sp);
+        p.with_synthetic(sp);
     }
     zktls::GuestInput in;
     in.cbor.assign(cbor, cbor + cbor_len);
@@ -301,15 +302,20 @@ const char* zktls_current_risc0_prover_env(void) { const char* e = getenv("RISC0
 const char* zktls_current_risc0_dev_mode_env(void) { const char* e = getenv("RISC0_DEV_MODE"); return e ? e : ""; }
 const char* zktls_current_sp1_prover_env(void) { const char* e = getenv("SP1_PROVER"); return e ? e : ""; }
 int zktls_request_digest(const uint8_t* cbor, size_t cbor_len, const uint8_t* elf, size_t elf_len, uint32_t out[8]) {
-    std::vector<uint32_t> d = zktls::request_digest(std::vector<uint8_t>(cbor, cbor + cbor_len), std::vector<uint8_t>(elf, elf + elf_len));
-    std::memcpy(out, d.data(), 32);
-    return 0;
+    return zkhip_request_digest(cbor, cbor_len, elf, elf_len, out);
+}
+// header flags of a batch blob (bit 0: synthetic shards), or -1 if it is not a batch blob
+int zktls_batch_flags(const uint8_t* blob, size_t len) {
+    std::vector<std::vector<uint8_t>> proofs;
+    uint32_t flags = 0;
+    if (!zktls::unpack_shard_proofs(std::vector<uint8_t>(blob, blob + len), &proofs, &flags)) return -1;
+    return (int)flags;
 }
 // splits a batch blob; returns the shard count or -1; offsets/lengths arrays sized `cap`
 int zktls_unpack_batch(const uint8_t* blob, size_t len, size_t* offsets, size_t* lengths, int cap) {
     std::vector<std::vector<uint8_t>> proofs;
     if (!zktls::unpack_shard_proofs(std::vector<uint8_t>(blob, blob + len), &proofs)) return -1;
-    size_t off = 12;
+    size_t off = 16;
     for (size_t i = 0; i < proofs.size() && (int)i < cap; i++) { offsets[i] = off + 4; lengths[i] = proofs[i].size(); off += 4 + proofs[i].size(); }
     return (int)proofs.size();
 }

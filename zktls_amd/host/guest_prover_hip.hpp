@@ -22,12 +22,14 @@
 //                                                          other environment variables, RISC-Zero-like proof shape
 //
 // What prove() does here: the zkVM executor that turns (input, ELF) into shard traces is
-// third-party and out of scope, so this mirror derives the shard
-// list deterministically from the request -- `shards` synthetic shards of 2^log_n x width
-// whose seed and public values are bound to a digest of the CBOR input and the ELF -- and
-// proves every shard through libzkhip (zkhip_gen_trace + zkhip_prove_shard), verifying each
-// proof (zkhip_verify_shard) like sp1.rs:120.  Swap `plan_shards` for the real executor's
-// output and the rest is unchanged.
+// third-party and out of scope.  Without a shard source Local / Hip mode therefore
+// FAILS ("no shard source"): a caller applying the reference's rule "proof.len() > 4 means a real proof"
+// (sp1.rs:128-130) must never be handed bytes that attest nothing about the guest.  The synthetic stand-in
+// is an explicit opt-in, with_synthetic(plan): `shards` synthetic AIR-satisfying shards of 2^log_n x width
+// generated on the device, seed and public values bound to zkhip_request_digest(CBOR input, ELF), every
+// shard proven through libzkhip and verified (zkhip_verify_shard) like sp1.rs:120; the batch blob it returns
+// carries the SYNTHETIC flag in its header.  Shards are dealt over the prover's device list exactly as
+// zkhip_prove_shards_multi deals them (shard s -> devices[s mod n]).
 #pragma once
 #include <cstdint>
 #include <string>
@@ -71,12 +73,16 @@ struct ShardPlan {
 
 class HipGuestProver : public ZkProver {
 public:
-    explicit HipGuestProver(int device = 0, Backend backend = Backend::Sp1) : device_(device), backend_(backend) {}
+    explicit HipGuestProver(int device = 0, Backend backend = Backend::Sp1) : devices_{device}, backend_(backend) {}
+    // every shard of a request goes to devices[s mod n]; an empty list is refused at prove time
+    HipGuestProver& with_devices(const std::vector<int>& devices) { devices_ = devices; return *this; }
     HipGuestProver& mock() { mode_ = ProverType::Mock; return *this; }
     HipGuestProver& local() { mode_ = ProverType::Local; return *this; }
     HipGuestProver& hip() { mode_ = ProverType::Hip; return *this; }
     HipGuestProver& network() { mode_ = ProverType::Network; return *this; }
-    HipGuestProver& with_plan(const ShardPlan& p) { plan_ = p; return *this; }
+    // explicit opt-in to the synthetic shard plan (no zkVM executor wired): see the header comment
+    HipGuestProver& with_synthetic(const ShardPlan& p) { plan_ = p; synthetic_ = true; return *this; }
+    bool synthetic() const { return synthetic_; }
     ProverType mode() const { return mode_; }
     Backend backend() const { return backend_; }
     ProveResult prove(const GuestInput& input, const std::vector<uint8_t>& guest_program) override;
@@ -84,9 +90,10 @@ public:
 private:
     ProveResult prove_inner(const GuestInput& input, const std::vector<uint8_t>& guest_program);
     ProverType mode_ = ProverType::Mock;   // #[default] Mock, sp1.rs:12-13
-    int device_ = 0;
+    std::vector<int> devices_;
     Backend backend_ = Backend::Sp1;
     ShardPlan plan_;
+    bool synthetic_ = false;
 };
 
 // prover.rs:30-57: `Risc0GuestProver::default().local()` etc.; segments are proven in RISC Zero's shape
@@ -102,8 +109,10 @@ void release_cached();
 // 8 canonical BabyBear words binding (input, ELF): the public values of every shard
 std::vector<uint32_t> request_digest(const std::vector<uint8_t>& cbor, const std::vector<uint8_t>& elf);
 
-// batch proof container: "ZKTB", version, shard count, then per shard (u32 length, bytes)
-std::vector<uint8_t> pack_shard_proofs(const std::vector<std::vector<uint8_t>>& proofs);
-bool unpack_shard_proofs(const std::vector<uint8_t>& blob, std::vector<std::vector<uint8_t>>* proofs);
+// batch proof container: "ZKTB", version 2, flags (bit 0: SYNTHETIC shards, attests nothing about a guest), shard count,
+// then per shard (u32 length, bytes)
+constexpr uint32_t BATCH_FLAG_SYNTHETIC = 1u;
+std::vector<uint8_t> pack_shard_proofs(const std::vector<std::vector<uint8_t>>& proofs, uint32_t flags);
+bool unpack_shard_proofs(const std::vector<uint8_t>& blob, std::vector<std::vector<uint8_t>>* proofs, uint32_t* flags = nullptr);
 
 }  // namespace zktls
