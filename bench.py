@@ -75,7 +75,7 @@ def main():
                                                                "(the PCIe-inclusive rate quoted in DESIGN.md; never the headline value)")
     ap.add_argument("--streams", type=int, default=4, help="shards in flight per GPU (at most --steps): each on its own context + HIP stream")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-log-n", type=int, default=19, help="rows of the bounded CPU-baseline sample")
+    ap.add_argument("--cpu-log-n", type=int, default=20, help="rows of the bounded CPU-baseline sample")
     ap.add_argument("--cpu-threads", type=int, default=0, help="OpenMP threads of the CPU baseline (0: min(cores, 64))")
     args = ap.parse_args()
 

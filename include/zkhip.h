@@ -133,8 +133,10 @@ int zkhip_gen_trace_logup(zkhip_ctx* ctx, uint64_t seed, uint64_t shard, int log
 int zkhip_gen_trace_logup_cross(zkhip_ctx* ctx, uint64_t seed, uint64_t shard, uint64_t partner_shard, int log_n, uint32_t width,
                                 uint32_t partner_width, int pairs, uint32_t* d_out, size_t ld);
 
-/* ---- NTT / LDE over the columns of a row-major matrix, 2^log_n rows, 0 <= log_n <= 20 (fewer than 32 rows: by
- * definition, out of place) ---- */
+/* ---- NTT / LDE over the columns of a row-major matrix, 2^log_n rows, 0 <= log_n <= 22 (fewer than 32 rows: by
+ * definition, out of place).  Up to 2^20 rows a transform is two launches of the pass kernel; 2^21 and 2^22 rows (SP1 core
+ * shards reach those heights: reference benchmark.md:9) add one streaming radix-2 / radix-4 pass and take a row pitch of at
+ * most 512 / 256 words. ---- */
 /* forward DFT: natural rows in; rows out natural (bitrev_out = 0) or bit-reversed (1);
  * inverse DFT (inverse = 1): natural in, natural out, scaled by 1/N. */
 int zkhip_dft(zkhip_ctx* ctx, const uint32_t* d_in, size_t in_ld, uint32_t* d_out, size_t out_ld,

@@ -1,0 +1,107 @@
+"""Transforms, LDEs and shard proofs of 2^21 and 2^22 rows (SP1 core shards reach those heights: reference benchmark.md:9;
+SURVEY.md section 7 step 4).  Up to 2^20 rows a transform is two launches of the pass kernel; above that the rows split into
+R = 2 / 4 classes, each class runs the 2^20-point machinery on its sub-matrix, and one streaming radix-R pass combines them.
+Checked against the oracle at narrow widths (the oracle needs seconds there) and by round trips at full width."""
+import numpy as np
+import pytest
+
+from zktls_amd._lib import Params, ZkHipError
+from zktls_amd.device import verify_shard
+
+pytestmark = pytest.mark.gpu
+P = 2013265921
+SEED = 0x5A4B544C53
+
+
+@pytest.mark.parametrize("log_n,width", [(21, 4), (21, 12), (22, 4), (22, 7)])
+def test_big_dft_matches_oracle(ctx, oracle, log_n, width):
+    m = oracle.fill_uniform(SEED + log_n, log_n, width)
+    d = ctx.fill_uniform(SEED + log_n, log_n, width)
+    assert (d.download().reshape(-1, width) == m).all()
+    exp = oracle.ntt(m)
+    nat = ctx.dft(d, log_n, width)
+    assert (nat.download().reshape(-1, width) == exp).all()
+    rev = ctx.dft(d, log_n, width, bitrev_out=True).download().reshape(-1, width)
+    idx = np.arange(1 << log_n, dtype=np.uint32)
+    br = np.zeros_like(idx)
+    for b in range(log_n):
+        br |= ((idx >> b) & 1) << (log_n - 1 - b)
+    assert (rev[br] == exp).all()
+    back = ctx.dft(nat, log_n, width, inverse=True)
+    assert (back.download().reshape(-1, width) == m).all()
+    inv = ctx.dft(d, log_n, width, inverse=True)
+    assert (inv.download().reshape(-1, width) == oracle.ntt(m, inverse=True)).all()
+    # in place
+    ctx.dft(d, log_n, width, out=d)
+    assert (d.download().reshape(-1, width) == exp).all()
+    for x in (d, nat, back, inv):
+        x.free()
+
+
+@pytest.mark.parametrize("log_n,width,log_blowup", [(21, 8, 1), (21, 5, 2), (22, 8, 1), (22, 4, 0)])
+def test_big_coset_lde_matches_oracle(ctx, oracle, log_n, width, log_blowup):
+    m = oracle.fill_uniform(SEED + 3 * log_n, log_n, width)
+    d = ctx.from_numpy(m)
+    lde = ctx.coset_lde(d, log_n, width, log_blowup, 31)
+    assert (lde.download().reshape(-1, width) == oracle.coset_lde(m, log_blowup, 31)).all()
+    d.free(); lde.free()
+
+
+def test_big_lde_into_interleaved_columns(ctx, oracle):
+    # the quotient chunks are extended into the two halves of an 8-column matrix (out_ld > width): padding columns stay untouched
+    log_n = 21
+    m = oracle.fill_uniform(SEED + 9, log_n, 4)
+    d = ctx.from_numpy(m)
+    out = ctx.from_numpy(np.full((2 << log_n, 8), 7, dtype=np.uint32))
+    ctx.coset_lde(d, log_n, 4, 1, 31, out=out, out_ld=8, out_col=4)
+    got = out.download().reshape(-1, 8)
+    assert (got[:, 4:] == oracle.coset_lde(m, 1, 31)).all() and (got[:, :4] == 7).all()
+    d.free(); out.free()
+
+
+@pytest.mark.parametrize("log_n,width", [(21, 512), (22, 256)])
+def test_big_fullwidth_round_trip(ctx, log_n, width):
+    src = ctx.fill_uniform(SEED + 77, log_n, width)
+    fwd = ctx.dft(src, log_n, width, bitrev_out=True)
+    a = src.download_monty(1 << 22)
+    assert not (fwd.download_monty(1 << 22) == a).all()
+    # undo the bit reversal through a second forward/inverse pair: inverse(forward_natural(x)) == x
+    nat = ctx.dft(src, log_n, width, out=fwd)
+    back = ctx.dft(nat, log_n, width, inverse=True, out=nat)
+    n = width << log_n
+    for off in (0, n // 2 - 12345, n - (1 << 22)):
+        assert (back.download_monty(1 << 22, off) == src.download_monty(1 << 22, off)).all()
+    src.free(); fwd.free()
+
+
+def test_too_wide_big_matrix_is_refused(ctx):
+    d = ctx.alloc(1024 << 21)
+    with pytest.raises(ZkHipError):
+        ctx.dft(d, 21, 1024)
+    d.free()
+
+
+@pytest.mark.parametrize("log_n,width,shape", [(21, 16, (1, 30, 8)), (22, 8, (1, 20, 8)), (21, 8, (2, 20, 0, 0, 4, 1, 24))])
+def test_big_shard_proof_bytes_equal_the_oracles(ctx, oracle, log_n, width, shape):
+    prm, oprm = Params(*shape), oracle.default_params(*shape)
+    trace = ctx.gen_trace(SEED, 3, log_n, width)
+    proof = ctx.prove_shard(trace, log_n, width, [4, 5], prm)
+    op = oracle.prove_shard(oracle.gen_trace(SEED, 3, log_n, width), [4, 5], oprm)
+    assert proof.tobytes() == op.tobytes()
+    assert verify_shard(proof, log_n, width, [4, 5], prm) == (0, 0)
+    trace.free()
+
+
+def test_big_fullwidth_shard_proof_verifies(ctx, oracle):
+    # a 2^21 x 256 shard (4 GiB LDE, 2^22-leaf trees): accepted by both verifiers, deterministic
+    log_n, width = 21, 256
+    prm = Params(1, 100, 16)
+    trace = ctx.gen_trace(SEED, 11, log_n, width)
+    proof = ctx.prove_shard(trace, log_n, width, [1, 2, 3], prm)
+    assert verify_shard(proof, log_n, width, [1, 2, 3], prm) == (0, 0)
+    assert oracle.verify_shard(proof, log_n, width, [1, 2, 3], oracle.default_params(1, 100, 16)) == 0
+    bad = proof.copy().view(np.uint32)
+    bad[-3] = (int(bad[-3]) + 1) % P
+    assert verify_shard(bad.view(np.uint8), log_n, width, [1, 2, 3], prm)[0] == -6
+    assert ctx.prove_shard(trace, log_n, width, [1, 2, 3], prm).tobytes() == proof.tobytes()
+    trace.free()

@@ -39,7 +39,7 @@ def pmc(name, counter):
     vals = []
     if files:
         for r in csv.DictReader(open(files[0])):
-            if "ntt_pass" in r["Kernel_Name"] and r["Counter_Name"] == counter:
+            if "ntt_pass_kernel<4" in r["Kernel_Name"] and ", 2, 5, " in r["Kernel_Name"] and r["Counter_Name"] == counter:
                 vals.append(float(r["Counter_Value"]))
         shutil.copy(files[0], os.path.join(dst, "%s_%s_counter_collection.csv" % (tag, name)))
     return vals
@@ -48,7 +48,8 @@ fetch, write = pmc("pmc_fetch", "FETCH_SIZE"), pmc("pmc_write", "WRITE_SIZE")
 if fetch and write:
     f_avg = sum(fetch) / len(fetch) * 1024.0 * 2.0     # KiB -> B, gfx950 x2 correction
     w_avg = sum(write) / len(write) * 1024.0
-    out = {"kernel": "zk::ntt_pass_kernel<4,false,2,5,*> (strided and contiguous pass)", "workload": "2^20 x 256, mean of strided and contiguous pass",
+    out = {"kernel": "zk::ntt_pass_kernel<4,*,2,5,*> (the 1024-row two-column passes of a 2^20 x 256 LDE, in-proof and replayed by tools/profile_ntt.py)",
+           "workload": "2^20 x 256, mean over all such launches of the run", "measured_at": tag + (" @ " + sys.argv[3] if len(sys.argv) > 3 else ""),
            "fetch_size_kib_raw_mean": sum(fetch) / len(fetch), "write_size_kib_mean": sum(write) / len(write),
            "fetch_correction": "x2 (gfx950 FETCH_SIZE half-count)", "hbm_bytes_per_launch": f_avg + w_avg,
            "algorithmic_bytes_per_launch": 8.0 * (1 << 28)}

@@ -7,6 +7,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <string>
 
 namespace zk {
 
@@ -191,7 +192,7 @@ static int run_forward_natural(zkhip_ctx* ctx, const uint32_t* in, size_t in_ld,
 //   I2  inverse, contiguous tiles in place on the coefficient workspace (coefficients left in transposed order)
 //   F1  forward, block in (transposed coefficients) -> strided bit-reversed out, pre = (s^M1')^i2', post = w^(i1' k2') s^i1'
 //   F2  forward, contiguous tiles in place on the LDE, bit-reversed inside the tile
-int lde_pass_args(zkhip_ctx* ctx, int which, const uint32_t* in, size_t in_ld, uint32_t* coef, uint32_t* dst, size_t out_ld,
+int lde_pass_args(zkhip_ctx* ctx, int which, const uint32_t* in, size_t in_ld, uint32_t* coef, size_t coef_ld, uint32_t* dst, size_t out_ld,
                   int log_n, uint32_t width, uint32_t coset_shift, NttPassArgs* out, bool* inverse) {
     int m1, m2;
     split(log_n, &m1, &m2);
@@ -202,12 +203,12 @@ int lde_pass_args(zkhip_ctx* ctx, int which, const uint32_t* in, size_t in_ld, u
         ZK_TRY(get_plan(ctx, log_n, 0, 0, &p));
         *inverse = true;
         if (which == LDE_I1) {
-            NttPassArgs a = base_args(ctx, in, in_ld, coef, width, width, true);
+            NttPassArgs a = base_args(ctx, in, in_ld, coef, coef_ld, width, true);
             a.num_tiles = (uint32_t)M1; a.log_m = (uint32_t)m2;
             a.in_tile_mul = 1; a.in_stride = M1; a.out_tile_mul = 1; a.out_stride = M1; a.post = p->post;
             *out = a;
         } else {
-            NttPassArgs b = base_args(ctx, coef, width, coef, width, width, true);
+            NttPassArgs b = base_args(ctx, coef, coef_ld, coef, coef_ld, width, true);
             b.num_tiles = (uint32_t)M2; b.log_m = (uint32_t)m1;
             b.in_tile_mul = M1; b.in_stride = 1; b.out_tile_mul = M1; b.out_stride = 1;
             *out = b;
@@ -218,7 +219,7 @@ int lde_pass_args(zkhip_ctx* ctx, int which, const uint32_t* in, size_t in_ld, u
     *inverse = false;
     const uint64_t M1p = M2, M2p = M1;                               // forward factors (swapped)
     if (which == LDE_F1) {
-        NttPassArgs a = base_args(ctx, coef, width, dst, out_ld, width, false);
+        NttPassArgs a = base_args(ctx, coef, coef_ld, dst, out_ld, width, false);
         a.num_tiles = (uint32_t)M1p; a.log_m = (uint32_t)m1;
         a.in_tile_mul = M2p; a.in_stride = 1;
         a.out_tile_mul = 1; a.out_stride = M1p; a.bitrev_out = 1;
@@ -233,9 +234,132 @@ int lde_pass_args(zkhip_ctx* ctx, int which, const uint32_t* in, size_t in_ld, u
     return ZKHIP_OK;
 }
 
+// ---- transforms of 2^21 and 2^22 rows (SP1 core shards reach 2^21 - 2^22 rows: reference benchmark.md:9).  N = R N', N' = 2^20,
+// R = 2 or 4.  Decimation in time over the row classes j = n mod R: the class-j rows form a sub-matrix (first row j, row pitch
+// R ld) that the two-pass N'-point machinery above transforms as it stands, and one streaming radix-R pass (ntt_combine_kernel,
+// 8 B/element) finishes:   X[k1 + N' k2] = sum_j w_R^(j k2) (s^j w_N^(j k1)) Y_j[k1],   Y_j = coset-DFT_N' of class j, shift s^R.
+// The inverse runs the other way round (radix-R step first).  With bit-reversed output the R values of one k1 are R ADJACENT
+// rows (R bitrev(k1) + bitrev(k2)), so the combine pass works in place on the LDE.
+constexpr int BIG_INNER_LOG = 20;
+static int get_big_plan(zkhip_ctx* ctx, int log_n, int kind, uint32_t shift, const BigPlan** out) {
+    for (const BigPlan& p : ctx->big_plans)
+        if (p.log_n == log_n && p.kind == kind && (kind == 0 || p.shift == shift)) { *out = &p; return ZKHIP_OK; }
+    BigPlan p;
+    p.log_n = log_n; p.kind = kind; p.shift = shift;
+    const uint32_t R = 1u << (log_n - BIG_INNER_LOG);
+    const uint64_t groups = (uint64_t)1 << BIG_INNER_LOG;
+    const uint32_t w = two_adic_generator(log_n);
+    ZK_HIP(hipMalloc((void**)&p.tw, (size_t)R * groups * 4));
+    hipError_t e;
+    if (kind == 0) e = launch_combine_table(p.tw, R, groups, finv(w), MONTY_R1, finv(to_monty(R)), 0, ctx->stream);
+    else e = launch_combine_table(p.tw, R, groups, w, shift, MONTY_R1, kind == 2 ? BIG_INNER_LOG : 0, ctx->stream);
+    if (e != hipSuccess) { (void)hipFree(p.tw); return hip_fail(e, "combine_table"); }
+    ctx->big_plans.push_back(p);
+    *out = &ctx->big_plans.back();
+    return ZKHIP_OK;
+}
+// the sub-matrix passes address a tile through one 32-bit buffer offset: (M - 1) * stride * (R ld) * 4 bytes must stay below 4 GiB
+static int check_big_width(int log_n, size_t ld_a, size_t ld_b, const char* what) {
+    const size_t R = (size_t)1 << (log_n - BIG_INNER_LOG);
+    const size_t ld = ld_a > ld_b ? ld_a : ld_b;
+    if (4ull * (1023ull * 1024ull * R * ld + 1024ull) >= (1ull << 32))
+        return fail(ZKHIP_ERR_INVALID, std::string(what) + ": 2^21-row matrices take a row pitch of at most 512 words, 2^22-row matrices 256");
+    return ZKHIP_OK;
+}
+static CombineArgs combine_args(const uint32_t* in, size_t in_ld, uint32_t* out, size_t out_ld, uint32_t width, int log_n, const BigPlan* p) {
+    CombineArgs c{};
+    c.in = in; c.in_ld = in_ld; c.out = out; c.out_ld = out_ld; c.ncols = width;
+    c.groups = (uint64_t)1 << BIG_INNER_LOG; c.log_r = log_n - BIG_INNER_LOG; c.tw = p->tw;
+    return c;
+}
+static int run_inverse_big(zkhip_ctx* ctx, const uint32_t* in, size_t in_ld, uint32_t* out, size_t out_ld, int log_n, uint32_t width) {
+    ZK_TRY(check_big_width(log_n, width, out_ld, "dft"));
+    const uint64_t R = 1ull << (log_n - BIG_INNER_LOG), Np = 1ull << BIG_INNER_LOG;
+    const BigPlan* bp;
+    ZK_TRY(get_big_plan(ctx, log_n, 0, 0, &bp));
+    void* tmp;
+    ZK_TRY(ctx_reserve(ctx, S_EXTRA_A, ((size_t)1 << log_n) * width * 4, &tmp));
+    CombineArgs c = combine_args(in, in_ld, (uint32_t*)tmp, width, width, log_n, bp);
+    c.in_group_mul = 1; c.in_elem_mul = Np; c.out_group_mul = R; c.out_elem_mul = 1; c.inverse = 1;
+    ZK_HIP(launch_ntt_combine(c, ctx->stream));
+    for (uint64_t j = 0; j < R; j++)
+        ZK_TRY(run_inverse(ctx, (const uint32_t*)tmp + j * width, R * width, out + j * out_ld, R * out_ld, BIG_INNER_LOG, width, false));
+    return ZKHIP_OK;
+}
+static int run_forward_natural_big(zkhip_ctx* ctx, const uint32_t* in, size_t in_ld, uint32_t* out, size_t out_ld, int log_n, uint32_t width,
+                                   uint32_t shift, bool bitrev_out) {
+    ZK_TRY(check_big_width(log_n, in_ld, bitrev_out ? out_ld : width, "dft"));
+    const uint64_t R = 1ull << (log_n - BIG_INNER_LOG), Np = 1ull << BIG_INNER_LOG;
+    const uint32_t sR = fpow(shift, R);
+    const BigPlan* bp;
+    ZK_TRY(get_big_plan(ctx, log_n, bitrev_out ? 2 : 1, shift, &bp));
+    if (bitrev_out) {
+        for (uint64_t j = 0; j < R; j++)
+            ZK_TRY(run_forward_natural(ctx, in + j * in_ld, R * in_ld, out + j * out_ld, R * out_ld, BIG_INNER_LOG, width, sR, true));
+        CombineArgs c = combine_args(out, out_ld, out, out_ld, width, log_n, bp);
+        c.in_group_mul = R; c.in_elem_mul = 1; c.out_group_mul = R; c.out_elem_mul = 1; c.bitrev_out = 1;
+        ZK_HIP(launch_ntt_combine(c, ctx->stream));
+        return ZKHIP_OK;
+    }
+    void* tmp;
+    ZK_TRY(ctx_reserve(ctx, S_EXTRA_A, ((size_t)1 << log_n) * width * 4, &tmp));
+    for (uint64_t j = 0; j < R; j++)
+        ZK_TRY(run_forward_natural(ctx, in + j * in_ld, R * in_ld, (uint32_t*)tmp + j * width, R * width, BIG_INNER_LOG, width, sR, false));
+    CombineArgs c = combine_args((const uint32_t*)tmp, width, out, out_ld, width, log_n, bp);
+    c.in_group_mul = R; c.in_elem_mul = 1; c.out_group_mul = 1; c.out_elem_mul = Np;
+    ZK_HIP(launch_ntt_combine(c, ctx->stream));
+    return ZKHIP_OK;
+}
+static int coset_lde_big(zkhip_ctx* ctx, const uint32_t* in, size_t in_ld, uint32_t* out, size_t out_ld, int log_n, uint32_t width,
+                         int log_blowup, uint32_t shift) {
+    ZK_TRY(check_big_width(log_n, width, out_ld, "coset_lde"));
+    const size_t n = (size_t)1 << log_n;
+    const uint64_t R = 1ull << (log_n - BIG_INNER_LOG), Np = 1ull << BIG_INNER_LOG;
+    void *coef_v, *tmp;
+    ZK_TRY(ctx_reserve(ctx, S_COEF, n * width * 4, &coef_v));
+    ZK_TRY(ctx_reserve(ctx, S_EXTRA_A, n * width * 4, &tmp));
+    uint32_t* coef = (uint32_t*)coef_v;
+    const BigPlan* bp;
+    ZK_TRY(get_big_plan(ctx, log_n, 0, 0, &bp));
+    CombineArgs c = combine_args(in, in_ld, (uint32_t*)tmp, width, width, log_n, bp);
+    c.in_group_mul = 1; c.in_elem_mul = Np; c.out_group_mul = R; c.out_elem_mul = 1; c.inverse = 1;
+    ZK_HIP(launch_ntt_combine(c, ctx->stream));
+    NttPassArgs a;
+    bool inv;
+    for (uint64_t j = 0; j < R; j++) {       // class-j coefficients c[R q + j], left in the transposed order of the two-pass inverse
+        ZK_TRY(lde_pass_args(ctx, LDE_I1, (const uint32_t*)tmp + j * width, R * width, coef + j * width, R * width, nullptr, 0, BIG_INNER_LOG, width, 0, &a, &inv));
+        ZK_HIP(launch_ntt_pass(a, inv, ctx->stream));
+        ZK_TRY(lde_pass_args(ctx, LDE_I2, nullptr, 0, coef + j * width, R * width, nullptr, 0, BIG_INNER_LOG, width, 0, &a, &inv));
+        ZK_HIP(launch_ntt_pass(a, inv, ctx->stream));
+    }
+    const uint32_t wnb = two_adic_generator(log_n + log_blowup);
+    for (int t = 0; t < (1 << log_blowup); t++) {
+        const uint32_t st = fmul(shift, fpow(wnb, (uint64_t)t));
+        const uint32_t stR = fpow(st, R);
+        uint32_t* dst = out + (size_t)reverse_bits((uint32_t)t, log_blowup) * n * out_ld;
+        for (uint64_t j = 0; j < R; j++) {
+            ZK_TRY(lde_pass_args(ctx, LDE_F1, nullptr, 0, coef + j * width, R * width, dst + j * out_ld, R * out_ld, BIG_INNER_LOG, width, stR, &a, &inv));
+            ZK_HIP(launch_ntt_pass(a, inv, ctx->stream));
+            ZK_TRY(lde_pass_args(ctx, LDE_F2, nullptr, 0, coef + j * width, R * width, dst + j * out_ld, R * out_ld, BIG_INNER_LOG, width, stR, &a, &inv));
+            ZK_HIP(launch_ntt_pass(a, inv, ctx->stream));
+        }
+        const BigPlan* fp;
+        ZK_TRY(get_big_plan(ctx, log_n, 2, st, &fp));
+        CombineArgs f = combine_args(dst, out_ld, dst, out_ld, width, log_n, fp);
+        f.in_group_mul = R; f.in_elem_mul = 1; f.out_group_mul = R; f.out_elem_mul = 1; f.bitrev_out = 1;
+        ZK_HIP(launch_ntt_combine(f, ctx->stream));
+    }
+    return ZKHIP_OK;
+}
+
 int op_coset_lde(zkhip_ctx* ctx, const uint32_t* in, size_t in_ld, uint32_t* out, size_t out_ld,
                  int log_n, uint32_t width, int log_blowup, uint32_t shift) {
-    if (log_n < 0 || log_n > 20) return fail(ZKHIP_ERR_INVALID, "coset_lde: log_n must be in [0, 20]");
+    if (log_n < 0 || log_n > MAX_LOG_ROWS) return fail(ZKHIP_ERR_INVALID, "coset_lde: log_n must be in [0, 22]");
+    if (log_n > BIG_INNER_LOG) {
+        if (log_blowup < 0 || log_blowup > 4 || log_n + log_blowup > TWO_ADICITY) return fail(ZKHIP_ERR_INVALID, "coset_lde: bad log_blowup");
+        if (width == 0 || in_ld < width || out_ld < width) return fail(ZKHIP_ERR_INVALID, "coset_lde: bad width / ld");
+        return coset_lde_big(ctx, in, in_ld, out, out_ld, log_n, width, log_blowup, shift);
+    }
     if (log_blowup < 0 || log_blowup > 4 || log_n + log_blowup > TWO_ADICITY) return fail(ZKHIP_ERR_INVALID, "coset_lde: bad log_blowup");
     if (width == 0 || in_ld < width || out_ld < width) return fail(ZKHIP_ERR_INVALID, "coset_lde: bad width / ld");
     if (log_n < 5) {      // below the tile minimum: coefficients and evaluation by definition
@@ -272,16 +396,16 @@ int op_coset_lde(zkhip_ctx* ctx, const uint32_t* in, size_t in_ld, uint32_t* out
     }
     NttPassArgs a;
     bool inv;
-    ZK_TRY(lde_pass_args(ctx, LDE_I1, in, in_ld, coef, nullptr, 0, log_n, width, 0, &a, &inv));
+    ZK_TRY(lde_pass_args(ctx, LDE_I1, in, in_ld, coef, width, nullptr, 0, log_n, width, 0, &a, &inv));
     ZK_HIP(launch_ntt_pass(a, inv, ctx->stream));
-    ZK_TRY(lde_pass_args(ctx, LDE_I2, nullptr, 0, coef, nullptr, 0, log_n, width, 0, &a, &inv));
+    ZK_TRY(lde_pass_args(ctx, LDE_I2, nullptr, 0, coef, width, nullptr, 0, log_n, width, 0, &a, &inv));
     ZK_HIP(launch_ntt_pass(a, inv, ctx->stream));
     for (int t = 0; t < B; t++) {
         const uint32_t st = fmul(shift, fpow(wnb, (uint64_t)t));
         uint32_t* dst = out + (size_t)reverse_bits((uint32_t)t, log_blowup) * n * out_ld;
-        ZK_TRY(lde_pass_args(ctx, LDE_F1, nullptr, 0, coef, dst, out_ld, log_n, width, st, &a, &inv));
+        ZK_TRY(lde_pass_args(ctx, LDE_F1, nullptr, 0, coef, width, dst, out_ld, log_n, width, st, &a, &inv));
         ZK_HIP(launch_ntt_pass(a, inv, ctx->stream));
-        ZK_TRY(lde_pass_args(ctx, LDE_F2, nullptr, 0, coef, dst, out_ld, log_n, width, st, &a, &inv));
+        ZK_TRY(lde_pass_args(ctx, LDE_F2, nullptr, 0, coef, width, dst, out_ld, log_n, width, st, &a, &inv));
         ZK_HIP(launch_ntt_pass(a, inv, ctx->stream));
     }
     return ZKHIP_OK;
@@ -431,6 +555,7 @@ void zkhip_ctx_destroy(zkhip_ctx* ctx) {
     if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
     if (ctx->fri_graph_exec) (void)hipGraphExecDestroy(ctx->fri_graph_exec);
     for (NttPlan& p : ctx->plans) { if (p.pre) (void)hipFree(p.pre); if (p.post) (void)hipFree(p.post); }
+    for (BigPlan& p : ctx->big_plans) if (p.tw) (void)hipFree(p.tw);
     for (DeviceBuffer& b : ctx->scratch) if (b.ptr) (void)hipFree(b.ptr);
     if (ctx->w1024_fwd) (void)hipFree(ctx->w1024_fwd);
     if (ctx->w1024_inv) (void)hipFree(ctx->w1024_inv);
@@ -518,7 +643,7 @@ int zkhip_gen_trace_logup_cross(zkhip_ctx* ctx, uint64_t seed, uint64_t shard, u
 int zkhip_dft(zkhip_ctx* ctx, const uint32_t* d_in, size_t in_ld, uint32_t* d_out, size_t out_ld,
               int log_n, uint32_t width, int inverse, int bitrev_out) {
     CHECK_CTX(ctx);
-    if (log_n < 0 || log_n > 20) return fail(ZKHIP_ERR_INVALID, "dft: log_n must be in [0, 20]");
+    if (log_n < 0 || log_n > MAX_LOG_ROWS) return fail(ZKHIP_ERR_INVALID, "dft: log_n must be in [0, 22]");
     if (!d_in || !d_out || width == 0 || in_ld < width || out_ld < width) return fail(ZKHIP_ERR_INVALID, "dft: bad arguments");
     if (log_n < 5) {      // below the tile minimum: by definition (must not run in place)
         if (d_in == d_out) return fail(ZKHIP_ERR_INVALID, "dft: transforms of fewer than 32 rows are out of place");
@@ -530,8 +655,10 @@ int zkhip_dft(zkhip_ctx* ctx, const uint32_t* d_in, size_t in_ld, uint32_t* d_ou
     }
     if (inverse) {
         if (bitrev_out) return fail(ZKHIP_ERR_INVALID, "dft: inverse transform writes natural order only");
+        if (log_n > BIG_INNER_LOG) return run_inverse_big(ctx, d_in, in_ld, d_out, out_ld, log_n, width);
         return run_inverse(ctx, d_in, in_ld, d_out, out_ld, log_n, width, false);
     }
+    if (log_n > BIG_INNER_LOG) return run_forward_natural_big(ctx, d_in, in_ld, d_out, out_ld, log_n, width, MONTY_R1, bitrev_out != 0);
     return run_forward_natural(ctx, d_in, in_ld, d_out, out_ld, log_n, width, MONTY_R1, bitrev_out != 0);
 }
 
@@ -556,7 +683,7 @@ int zkhip_ntt_pass(zkhip_ctx* ctx, const uint32_t* d_in, uint32_t* d_out, size_t
         ZK_TRY(ctx_reserve(ctx, S_TLDE, 2 * n * width * 4, &lde));
         NttPassArgs a;
         bool inv;
-        ZK_TRY(lde_pass_args(ctx, which - 2, d_in, ld, (uint32_t*)coef, (uint32_t*)lde, width, log_n, width, MONTY_GEN, &a, &inv));
+        ZK_TRY(lde_pass_args(ctx, which - 2, d_in, ld, (uint32_t*)coef, width, (uint32_t*)lde, width, log_n, width, MONTY_GEN, &a, &inv));
         ZK_HIP(launch_ntt_pass(a, inv, ctx->stream));
         return ZKHIP_OK;
     }

@@ -38,6 +38,14 @@ struct NttPlan {
     uint32_t* post = nullptr;  // device
 };
 
+// radix-R combine twiddles of a 2^21 / 2^22-row transform (ntt.hip, ntt_combine_kernel)
+struct BigPlan {
+    int log_n = 0;
+    int kind = 0;            // 0 inverse (natural groups, carries 1/R); 1 forward, natural groups; 2 forward, bit-reversed groups
+    uint32_t shift = 0;      // Montgomery coset shift (kinds 1, 2)
+    uint32_t* tw = nullptr;  // device, [R][N / R]
+};
+
 struct DeviceBuffer {
     void* ptr = nullptr;
     size_t bytes = 0;
@@ -73,6 +81,7 @@ struct zkhip_ctx {
     uint32_t* w1024_fwd = nullptr;
     uint32_t* w1024_inv = nullptr;
     std::deque<zk::NttPlan> plans;   // deque: references stay valid on push_back
+    std::deque<zk::BigPlan> big_plans;
     zk::DeviceBuffer scratch[zk::S_COUNT];   // grow-only workspaces, indexed by zk::Slot
     zkhip_prove_debug debug{};
     // domain tables (prover.cpp): the current set, and every set built so far (a multi-chip shard switches between
@@ -91,6 +100,7 @@ struct zkhip_ctx {
 };
 
 namespace zk {
+constexpr int MAX_LOG_ROWS = 22;     // tallest matrix the transforms / the shard prover take (2^20 in two passes; 2^21, 2^22 with a radix-2 / 4 combine pass)
 int ctx_reserve(zkhip_ctx* ctx, int slot, size_t bytes, void** out);
 int get_plan(zkhip_ctx* ctx, int log_n, int kind, uint32_t shift_monty, const NttPlan** out);
 // internal op entry points shared by capi.cpp and prover.cpp (device pointers, ctx stream)

@@ -38,6 +38,28 @@ struct NttPassArgs {
 };
 hipError_t launch_ntt_pass(const NttPassArgs& a, bool inverse, hipStream_t s);
 
+// ---- transforms of 2^21 / 2^22 rows: N = R N', R = 2^log_r (1 or 2), N' <= 2^20.  The N'-point transforms of the R row classes
+// j = n mod R run through the pass kernel above on sub-matrices (row pitch R ld); this streaming pass is the remaining radix-R
+// step (one read + one write of every element, 8 B/element):
+//   forward:  out[g, k2] = sum_j w_R^(j k2) * tw[j][g] * in[g, j]                      (tw[0] is not read: it is 1)
+//   inverse:  out[g, j]  = tw[j][g] * sum_k2 w_R^-(j k2) * in[g, k2]                   (tw[j] carries 1/R)
+// element (g, e) of a side lives in row g * group_mul + slot(e) * elem_mul, slot(e) = bitrev_r(e) if bitrev else e.
+struct CombineArgs {
+    const uint32_t* in;
+    uint32_t* out;
+    uint64_t in_ld, out_ld;
+    uint32_t ncols;
+    uint64_t groups;                 // N'
+    int log_r;                       // 1 or 2
+    uint64_t in_group_mul, in_elem_mul, out_group_mul, out_elem_mul;
+    int bitrev_out;                  // forward only: output slot = bitrev_r(k2) (in-place form on a bit-reversed LDE)
+    int inverse;
+    const uint32_t* tw;              // [R][groups], Montgomery
+};
+hipError_t launch_ntt_combine(const CombineArgs& a, hipStream_t s);
+// tw[j][g] = scale * shift^j * w^(j * idx(g)), idx(g) = bitrev_bits(g) if bits > 0 else g; j < rows
+hipError_t launch_combine_table(uint32_t* out, uint32_t rows, uint64_t groups, uint32_t w, uint32_t shift, uint32_t scale, int bits, hipStream_t s);
+
 // out[i] = scale * base^i, i < n   (Montgomery form in and out)
 hipError_t launch_pow_table(uint32_t* out, size_t n, uint32_t base, uint32_t scale, hipStream_t s);
 // out[i*cols + k] = scale * omega^(i*k) * shift^i

@@ -609,6 +609,90 @@ hipError_t launch_ntt_pass(const NttPassArgs& a_, bool inverse, hipStream_t s) {
     return inverse ? launch_ntt_k<4, true, 1>(a, s) : launch_ntt_k<4, false, 1>(a, s);
 }
 
+// ------------------------------------------------------------------ radix-2 / radix-4 combine pass (2^21, 2^22 rows)
+// Streaming: a thread owns VEC adjacent columns of one group of R rows; the twiddles of a group are row-uniform.  HBM-bound,
+// 8 B/element; arithmetic is R - 1 (forward) or R (inverse) Montgomery products per element group.
+template <int LOG_R, int VEC>
+__global__ void __launch_bounds__(256) ntt_combine_kernel(CombineArgs a) {
+    constexpr int R = 1 << LOG_R;
+    const uint32_t cv = (a.ncols + VEC - 1) / VEC;                    // column vectors per row
+    const uint64_t idx = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const uint64_t g = idx / cv;
+    const uint32_t c = (uint32_t)(idx % cv) * VEC;
+    if (g >= a.groups) return;
+    uint32_t x[R][VEC];
+#pragma unroll
+    for (int e = 0; e < R; e++) {
+        const uint32_t* row = a.in + (g * a.in_group_mul + (uint64_t)e * a.in_elem_mul) * a.in_ld + c;
+        if (VEC == 4) { const uint4 v = *reinterpret_cast<const uint4*>(row); x[e][0] = v.x; x[e][1] = v.y; x[e][2] = v.z; x[e][VEC - 1] = v.w; }
+        else x[e][0] = row[0];
+    }
+    uint32_t tw[R];
+#pragma unroll
+    for (int j = 0; j < R; j++) tw[j] = (j == 0 && !a.inverse) ? MONTY_R1 : a.tw[(uint64_t)j * a.groups + g];
+    constexpr uint32_t W4 = two_adic_generator(2);                    // primitive 4th root of unity
+    const uint32_t im = a.inverse ? fneg(W4) : W4;                    // w_4^(+-1)
+    uint32_t y[R][VEC];
+#pragma unroll
+    for (int v = 0; v < VEC; v++) {
+        uint32_t t[R];
+#pragma unroll
+        for (int e = 0; e < R; e++) t[e] = (!a.inverse && e > 0) ? fmul(x[e][v], tw[e]) : x[e][v];
+        if (R == 2) {
+            y[0][v] = fadd(t[0], t[1]);
+            y[1][v] = fsub(t[0], t[1]);
+        } else {
+            const uint32_t s02 = fadd(t[0], t[2]), d02 = fsub(t[0], t[2]);
+            const uint32_t s13 = fadd(t[1], t[R - 1]), d13 = fmul(fsub(t[1], t[R - 1]), im);
+            y[0][v] = fadd(s02, s13);
+            y[1][v] = fadd(d02, d13);
+            y[2 % R][v] = fsub(s02, s13);
+            y[R - 1][v] = fsub(d02, d13);
+        }
+        if (a.inverse) {
+#pragma unroll
+            for (int e = 0; e < R; e++) y[e][v] = fmul(y[e][v], tw[e]);
+        }
+    }
+#pragma unroll
+    for (int e = 0; e < R; e++) {
+        const uint32_t slot = a.bitrev_out ? (LOG_R == 2 ? (uint32_t)(((e & 1) << 1) | (e >> 1)) : (uint32_t)e) : (uint32_t)e;
+        uint32_t* row = a.out + (g * a.out_group_mul + (uint64_t)slot * a.out_elem_mul) * a.out_ld + c;
+        if (VEC == 4) *reinterpret_cast<uint4*>(row) = make_uint4(y[e][0], y[e][1], y[e][2], y[e][VEC - 1]);
+        else row[0] = y[e][0];
+    }
+}
+hipError_t launch_ntt_combine(const CombineArgs& a, hipStream_t s) {
+    if (a.log_r != 1 && a.log_r != 2) return hipErrorInvalidValue;
+    if (a.groups == 0 || a.ncols == 0) return hipSuccess;
+    const bool vec = a.ncols % 4 == 0 && a.in_ld % 4 == 0 && a.out_ld % 4 == 0 && (reinterpret_cast<uintptr_t>(a.in) & 15) == 0 &&
+                     (reinterpret_cast<uintptr_t>(a.out) & 15) == 0;
+    const uint64_t threads = a.groups * (vec ? a.ncols / 4 : a.ncols);
+    const dim3 grid((unsigned)((threads + 255) / 256)), block(256);
+    if (a.log_r == 1) {
+        if (vec) hipLaunchKernelGGL((ntt_combine_kernel<1, 4>), grid, block, 0, s, a);
+        else hipLaunchKernelGGL((ntt_combine_kernel<1, 1>), grid, block, 0, s, a);
+    } else {
+        if (vec) hipLaunchKernelGGL((ntt_combine_kernel<2, 4>), grid, block, 0, s, a);
+        else hipLaunchKernelGGL((ntt_combine_kernel<2, 1>), grid, block, 0, s, a);
+    }
+    return hipGetLastError();
+}
+__global__ void combine_table_kernel(uint32_t* out, uint32_t rows, uint64_t groups, uint32_t w, uint32_t shift, uint32_t scale, int bits) {
+    const uint64_t idx = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (uint64_t)rows * groups) return;
+    const uint32_t j = (uint32_t)(idx / groups);
+    const uint64_t g = idx % groups;
+    const uint64_t e = bits > 0 ? (uint64_t)(__brev((uint32_t)g) >> (32 - bits)) : g;
+    out[idx] = fmul(scale, fmul(fpow(shift, j), fpow(w, (uint64_t)j * e)));
+}
+hipError_t launch_combine_table(uint32_t* out, uint32_t rows, uint64_t groups, uint32_t w, uint32_t shift, uint32_t scale, int bits, hipStream_t s) {
+    const uint64_t n = (uint64_t)rows * groups;
+    if (n == 0) return hipSuccess;
+    hipLaunchKernelGGL(combine_table_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, out, rows, groups, w, shift, scale, bits);
+    return hipGetLastError();
+}
+
 // ------------------------------------------------------------------ table generators
 __global__ void pow_table_kernel(uint32_t* out, size_t n, uint32_t base, uint32_t scale) {
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;

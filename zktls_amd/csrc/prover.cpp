@@ -346,7 +346,7 @@ static size_t proof_words(int log_n, uint32_t width, const zkhip_params* prm) {
 
 static int check_shape(int log_n, uint32_t width, const zkhip_params* prm) {
     if (!prm) return fail(ZKHIP_ERR_INVALID, "null params");
-    if (log_n < 5 || log_n > 20) return fail(ZKHIP_ERR_INVALID, "log_n must be in [5, 20]");
+    if (log_n < 5 || log_n > MAX_LOG_ROWS) return fail(ZKHIP_ERR_INVALID, "log_n must be in [5, 22]");
     if (width == 0 || width % 4 != 0 || width > 1024) return fail(ZKHIP_ERR_INVALID, "width must be a positive multiple of 4, at most 1024");
     Shape sh;
     if (!shape_of(log_n, prm, sh))
@@ -444,7 +444,7 @@ int zkhip_perm_trace(zkhip_ctx* ctx, const uint32_t* d_trace, size_t ld, int log
 int zkhip_open_at(zkhip_ctx* ctx, const uint32_t* d_lde, size_t ld, int log_n, int log_blowup, uint32_t width,
                   const uint32_t* z, int npoints, uint32_t* h_out) {
     CHECK_CTX(ctx);
-    if (log_n < 5 || log_n > 20 || log_blowup != 1) return fail(ZKHIP_ERR_INVALID, "open_at: log_n in [5,20], log_blowup = 1");
+    if (log_n < 5 || log_n > MAX_LOG_ROWS || log_blowup != 1) return fail(ZKHIP_ERR_INVALID, "open_at: log_n in [5,22], log_blowup = 1");
     if (!d_lde || !z || !h_out || width == 0 || ld < width || npoints < 1 || npoints > 2)
         return fail(ZKHIP_ERR_INVALID, "open_at: bad arguments (1 or 2 points)");
     if (ctx->dom_log_n != log_n) ZK_TRY(ensure_domain(ctx, log_n));
@@ -463,7 +463,7 @@ int zkhip_open_at(zkhip_ctx* ctx, const uint32_t* d_lde, size_t ld, int log_n, i
 
 int zkhip_fri_fold(zkhip_ctx* ctx, const uint32_t* d_in, int log_h, const uint32_t beta[4], uint32_t* d_out) {
     CHECK_CTX(ctx);
-    if (!d_in || !d_out || !beta || log_h < 1 || log_h > 21) return fail(ZKHIP_ERR_INVALID, "fri_fold: bad arguments");
+    if (!d_in || !d_out || !beta || log_h < 1 || log_h > MAX_LOG_ROWS + 3) return fail(ZKHIP_ERR_INVALID, "fri_fold: bad arguments");
     ZK_TRY(ensure_fold_table(ctx, log_h));
     Ext b{{beta[0], beta[1], beta[2], beta[3]}};
     ZK_HIP(launch_fri_fold(d_in, d_out, ctx->dom_itw, (uint64_t)1 << (log_h - 1), b, ctx->stream));
@@ -472,7 +472,7 @@ int zkhip_fri_fold(zkhip_ctx* ctx, const uint32_t* d_in, int log_h, const uint32
 
 int zkhip_fri_fold_k(zkhip_ctx* ctx, const uint32_t* d_in, int log_h, int log_arity, const uint32_t beta[4], uint32_t* d_out) {
     CHECK_CTX(ctx);
-    if (!d_in || !d_out || !beta || log_arity < 1 || log_arity > 6 || log_h < log_arity || log_h > 21)
+    if (!d_in || !d_out || !beta || log_arity < 1 || log_arity > 6 || log_h < log_arity || log_h > MAX_LOG_ROWS + 3)
         return fail(ZKHIP_ERR_INVALID, "fri_fold_k: bad arguments");
     ZK_TRY(ensure_fold_table(ctx, log_h));
     // f = sum_j X^j f_j(X^(2^k)); folding by 2 with b, then b^2, b^4, ... leaves sum_j b^j f_j
@@ -760,9 +760,9 @@ int zkhip_prove_shard(zkhip_ctx* ctx, const uint32_t* d_trace, size_t ld, int lo
 int zkhip_commit(zkhip_ctx* ctx, const uint32_t* d_trace, size_t ld, int log_n, uint32_t width, int log_blowup,
                  int hash_width, uint32_t* d_lde, uint32_t* d_tree, uint32_t root[8]) {
     CHECK_CTX(ctx);
-    if (!d_trace || !d_lde || !d_tree || !root || ld < width || width == 0 || log_n < 5 || log_n > 20 || log_blowup < 0 || log_blowup > 3 ||
+    if (!d_trace || !d_lde || !d_tree || !root || ld < width || width == 0 || log_n < 5 || log_n > MAX_LOG_ROWS || log_blowup < 0 || log_blowup > 3 ||
         (hash_width != 16 && hash_width != 24) || (hash_width == 24 && width % 4 != 0))
-        return fail(ZKHIP_ERR_INVALID, "commit: bad arguments (log_n in [5,20], log_blowup in [0,3], hash_width 16 or 24; width % 4 == 0 for 24)");
+        return fail(ZKHIP_ERR_INVALID, "commit: bad arguments (log_n in [5,22], log_blowup in [0,3], hash_width 16 or 24; width % 4 == 0 for 24)");
     const int H = log_n + log_blowup;
     ZK_TRY(op_coset_lde(ctx, d_trace, ld, d_lde, width, log_n, width, log_blowup, MONTY_GEN));
     ZK_TRY(commit_hw(ctx, d_lde, width, width, H, d_tree, hash_width));
