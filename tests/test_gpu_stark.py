@@ -106,7 +106,7 @@ def test_bad_arguments_fail_loudly(ctx):
     with pytest.raises(ZkHipError):
         ctx.prove_shard(trace, 6, 8, [P], Params(1, 10, 4))       # non-canonical public value
     with pytest.raises(ZkHipError):
-        ctx.coset_lde(trace, 21, 8)                               # log_n above the supported range
+        ctx.coset_lde(trace, 23, 8)                               # log_n above the supported range (22)
 
 
 # ------------------------------------------------------------------ LogUp

@@ -684,6 +684,7 @@ int zkhip_ntt_pass(zkhip_ctx* ctx, const uint32_t* d_in, uint32_t* d_out, size_t
         NttPassArgs a;
         bool inv;
         ZK_TRY(lde_pass_args(ctx, which - 2, d_in, ld, (uint32_t*)coef, width, (uint32_t*)lde, width, log_n, width, MONTY_GEN, &a, &inv));
+        a.bench_tag = 1;
         ZK_HIP(launch_ntt_pass(a, inv, ctx->stream));
         return ZKHIP_OK;
     }

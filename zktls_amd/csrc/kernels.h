@@ -32,6 +32,7 @@ struct NttPassArgs {
     uint32_t fast_path;              // A/B builds only: 0 / 2 tile-per-workgroup kernel (default), 1 persistent 1024 x 32 kernel
     uint32_t debug_flags;            // A/B builds (-DZKHIP_AB_HOOKS) only, ignored otherwise: 1 drop loads, 2 drop stores, 4 no transform, 8 no non-temporal policy
     uint32_t cols_per_thread;        // 2: two columns per lane when the shape allows (A/B knob); else 1
+    uint32_t bench_tag;              // 1: launched by the roofline hook (zkhip_ntt_pass): same code under its own kernel name (NT = 3 / 4)
     const uint32_t* w1024;           // w_1024^e (forward) or w_1024^-e (inverse), e < 1024
     const uint32_t* pre;             // [M] or nullptr
     const uint32_t* post;            // [num_tiles * M] or nullptr
