@@ -104,6 +104,39 @@ def main():
         lk[name] = {"chips": [list(c) for c in chips], "params": list(prm), "public": [3, 4],
                     "bytes": int(pf.size), "sha256": hashlib.sha256(pf.tobytes()).hexdigest()}
     out["chip_lookup_proofs"] = lk
+    # complete proof BYTES of small shards, one per proof version (tests/golden/proofs/*.bin): what the independent pure-Python
+    # verifier (tests/pyverify.py, written from DESIGN.md sections 3 and 6) and the product's host verifier check on the CPU, and
+    # what the HIP prover must reproduce byte for byte on the GPU.  shape = (log_blowup, queries, pow_bits, logup_pairs,
+    # log_fold, log_final, hash_width)
+    os.makedirs(os.path.join(HERE, "proofs"), exist_ok=True)
+    golden = {}
+    for name, (log_n, w, shape) in {"v1_6x8": (6, 8, (1, 4, 4, 0, 0, 0, 0)), "v1_10x16": (10, 16, (1, 6, 8, 0, 0, 0, 0)),
+                                    "v2_lookup_7x16": (7, 16, (1, 3, 4, 1, 0, 0, 0)),
+                                    "v3_r0_9x8": (9, 8, (2, 3, 0, 0, 4, 1, 24)), "v3_fold8_9x8": (9, 8, (1, 3, 5, 0, 3, 0, 16)),
+                                    "v3_blowup4_lookup_8x16": (8, 16, (2, 3, 3, 2, 1, 0, 16))}.items():
+        t = O.gen_trace_logup(SEED, 5, log_n, w, shape[3]) if shape[3] else O.gen_trace(SEED, 5, log_n, w)
+        prm = O.default_params(*shape)
+        pf = O.prove_shard(t, [1, 2, 3], prm)
+        assert O.verify_shard(pf, log_n, w, [1, 2, 3], prm) == 0
+        with open(os.path.join(HERE, "proofs", name + ".bin"), "wb") as f:
+            f.write(pf.tobytes())
+        golden[name] = {"log_n": log_n, "width": w, "shape": list(shape), "seed": SEED, "shard": 5, "public": [1, 2, 3],
+                        "bytes": int(pf.size), "sha256": hashlib.sha256(pf.tobytes()).hexdigest()}
+    out["golden_proof_files"] = golden
+    # provenance: which state of oracle/ produced this file
+    import subprocess
+    root = os.path.dirname(os.path.dirname(HERE))
+    try:
+        commit = subprocess.run(["git", "log", "-1", "--format=%H", "--", "oracle"], cwd=root, capture_output=True, text=True, check=True).stdout.strip()
+        dirty = bool(subprocess.run(["git", "status", "--porcelain", "--", "oracle"], cwd=root, capture_output=True, text=True, check=True).stdout.strip())
+    except Exception:
+        commit, dirty = "unknown", False
+    src = hashlib.sha256()
+    for fn in sorted(os.listdir(os.path.join(root, "oracle"))):
+        if fn.endswith((".c", ".h")):
+            src.update(open(os.path.join(root, "oracle", fn), "rb").read())
+    out["provenance"] = {"oracle_commit": commit, "oracle_tree_dirty": dirty, "oracle_sources_sha256": src.hexdigest(),
+                         "generator": "tests/golden/make_golden.py", "note": "every fixture in this file and in proofs/ was produced by this repo's own CPU oracle at that commit (parity unpinned)"}
     with open(os.path.join(HERE, "oracle_kat.json"), "w") as f:
         json.dump(out, f, indent=1)
     print("wrote oracle_kat.json")

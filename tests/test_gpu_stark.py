@@ -84,6 +84,20 @@ def test_golden_proofs_on_gpu(ctx, name):
     assert d["pow_witness"] == g["pow_witness"]
 
 
+@pytest.mark.parametrize("name", sorted(json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "oracle_kat.json")))["golden_proof_files"]))
+def test_hip_prover_reproduces_the_committed_golden_proof_bytes(ctx, name):
+    """tests/golden/proofs/*.bin (one per proof version; also checked on the CPU by three independent verifiers,
+    tests/test_pyverify_cpu.py): the HIP prover must produce exactly these bytes -- no oracle involved at run time"""
+    here = os.path.dirname(os.path.abspath(__file__))
+    g = json.load(open(os.path.join(here, "golden", "oracle_kat.json")))["golden_proof_files"][name]
+    want = open(os.path.join(here, "golden", "proofs", name + ".bin"), "rb").read()
+    pairs = g["shape"][3]
+    trace = (ctx.gen_trace_logup(g["seed"], g["shard"], g["log_n"], g["width"], pairs) if pairs
+             else ctx.gen_trace(g["seed"], g["shard"], g["log_n"], g["width"]))
+    proof = ctx.prove_shard(trace, g["log_n"], g["width"], g["public"], Params(*g["shape"]))
+    assert proof.tobytes() == want
+
+
 def test_invalid_trace_is_refused_or_rejected(ctx, oracle):
     log_n, width = 8, 8
     t = oracle.gen_trace(SEED, 0, log_n, width)
