@@ -195,6 +195,46 @@ int zkhip_batch_interpolate_colmajor(zkhip_ctx* ctx, const uint32_t* d_evals, ui
 int zkhip_batch_expand_colmajor(zkhip_ctx* ctx, const uint32_t* d_coeffs, uint32_t* d_evals,
                                 uint32_t count, int log_size, int log_blowup, uint32_t shift);
 
+/* ---- RISC Zero `Hal` operator set (risc0-zkp 1.2.5 trait hal::Hal, reference Cargo.lock:5057; kernels risc0-sys 1.2.5,
+ * Cargo.lock:5045; call site crates/guest-prover-r0/src/prover.rs:90).  Data as the Hal
+ * holds it: polynomials / columns are contiguous device vectors (column-major [count][size]) of Montgomery words, extension
+ * elements are 4 consecutive words, 16-byte aligned.  `ext_field` selects the extension the operator multiplies in:
+ * ZKHIP_EXT_X4_MINUS_11 = F_p[x]/(x^4 - 11) (Plonky3 / SP1, what the shard prover uses) or ZKHIP_EXT_X4_PLUS_11 =
+ * F_p[x]/(x^4 + 11) (RISC Zero).  Extension challenges passed by value (mix, mix_start) are HOST pointers, Montgomery form. ---- */
+typedef enum { ZKHIP_EXT_X4_MINUS_11 = 0, ZKHIP_EXT_X4_PLUS_11 = 1 } zkhip_ext_field;
+/* Hal::eltwise_add_elem: out[i] = a[i] + b[i] */
+int zkhip_eltwise_add(zkhip_ctx* ctx, uint32_t* d_out, const uint32_t* d_a, const uint32_t* d_b, size_t n);
+/* Hal::eltwise_copy_elem */
+int zkhip_eltwise_copy(zkhip_ctx* ctx, uint32_t* d_out, const uint32_t* d_in, size_t n);
+/* Hal::eltwise_zeroize_elem: cells still holding the "unset" marker 0xffffffff become 0 */
+int zkhip_eltwise_zeroize(zkhip_ctx* ctx, uint32_t* d_io, size_t n);
+/* Hal::eltwise_sum_extelem: out[i] = sum_j in[j * count + i] over extension elements (i < count, j < to_add) */
+int zkhip_eltwise_sum_ext(zkhip_ctx* ctx, uint32_t* d_out, const uint32_t* d_in, size_t count, size_t to_add);
+/* Hal::zk_shift: coefficient i of each of `count` polynomials of 2^log_size coefficients times shift^i (RISC Zero shifts
+ * by 3); `shift` canonical */
+int zkhip_zk_shift(zkhip_ctx* ctx, uint32_t* d_io, size_t count, int log_size, uint32_t shift);
+/* Hal::mix_poly_coeffs: d_out[combos[i] * count + idx] += mix_start * mix^i * d_in[i * count + idx], i < input_size, idx < count;
+ * d_out holds extension elements ([n_combos][count]), d_in base elements ([input_size][count]), d_combos device u32 */
+int zkhip_mix_poly_coeffs(zkhip_ctx* ctx, uint32_t* d_out, const uint32_t mix_start[4], const uint32_t mix[4], const uint32_t* d_in,
+                          const uint32_t* d_combos, size_t input_size, size_t count, int ext_field);
+/* Hal::batch_evaluate_any: d_out[e] = polynomial d_which[e] (2^log_size base coefficients, lowest first, polynomial p at
+ * d_coeffs + p * 2^log_size) evaluated at the extension point d_xs[e] */
+int zkhip_batch_evaluate_any(zkhip_ctx* ctx, const uint32_t* d_coeffs, int log_size, const uint32_t* d_which, const uint32_t* d_xs,
+                             uint32_t* d_out, size_t eval_count, int ext_field);
+/* Hal::gather_sample: d_dst[g] = d_src[g * stride + idx], g < size (row idx of a column-major matrix: a FRI query row) */
+int zkhip_gather_sample(zkhip_ctx* ctx, uint32_t* d_dst, const uint32_t* d_src, size_t idx, size_t size, size_t stride);
+/* Hal::scatter: d_into[d_offsets[k]] = d_values[k] for k in [d_index[r], d_index[r + 1]), r < rows */
+int zkhip_scatter(zkhip_ctx* ctx, uint32_t* d_into, const uint32_t* d_index, const uint32_t* d_offsets, const uint32_t* d_values, size_t rows);
+/* Hal::prefix_products: inclusive prefix products of n extension elements, in place (the accumulator columns) */
+int zkhip_prefix_products_ext(zkhip_ctx* ctx, uint32_t* d_io, size_t n, int ext_field);
+/* Hal::hash_rows / hash_fold with the SHA-256 hash suite: leaf r = SHA-256 over the CANONICAL words of row r of the
+ * column-major [cols][rows] matrix, each word serialised big-endian, FIPS 180-4 padding; a node = SHA-256 of its children's
+ * 64 bytes.  Digests are the eight 32-bit state words (plain integers, not field elements).  This byte convention is this
+ * library's own (stated in DESIGN.md 4.4); the Poseidon2 variants are zkhip_merkle_commit_p24_colmajor / zkhip_merkle_commit. */
+int zkhip_hash_rows_sha256(zkhip_ctx* ctx, const uint32_t* d_mat, size_t cols, size_t rows, uint32_t* d_digests);
+int zkhip_hash_fold_sha256(zkhip_ctx* ctx, const uint32_t* d_children, uint32_t* d_parents, size_t count);
+int zkhip_merkle_commit_sha256_colmajor(zkhip_ctx* ctx, const uint32_t* d_mat, uint32_t cols, int log_rows, uint32_t* d_tree);
+
 /* ---- STARK stages (synthetic AIR, log_blowup = 1) ---- */
 /* quotient values on the LDE coset, bit-reversed rows: d_out[2^(log_n+1)][4] */
 int zkhip_quotient_values(zkhip_ctx* ctx, const uint32_t* d_lde, size_t ld, int log_n,
@@ -303,6 +343,18 @@ int zkhip_prove_chips(zkhip_ctx* ctx, const zkhip_chip* chips, int n_chips, cons
 int zkhip_verify_chips(const uint8_t* proof, size_t len, const int32_t* log_ns, const uint32_t* widths, const int32_t* pairs,
                        const int32_t* partners, int n_chips,
                        const uint32_t* public_values, size_t n_public, const zkhip_params* prm, int* reason);
+
+/* ---- bincode-shaped form of a shard proof: the serde / bincode structure an upstream verifier
+ * deserialises -- p3-uni-stark `Proof { commitments, opened_values, opening_proof: FriProof, degree_bits }` (reference
+ * Cargo.lock:4055, 3930), which is what `proof.bytes()` carries at crates/guest-prover-sp1/src/sp1.rs:122-123.  Encoding rule:
+ * bincode 1.x defaults (little-endian, u64 length prefix per Vec, arrays and structs bare).  The FIELD ORDER is [RECALLED]
+ * (the crates are not in /root/reference): DESIGN.md section 6b spells it out.  Reader and writer are exact inverses on every
+ * proof of zkhip_prove_shard / zkhip_prove_segment (versions 1-3).  Host only. ---- */
+size_t zkhip_bincode_size(int log_n, uint32_t width, const zkhip_params* prm);
+int zkhip_proof_to_bincode(const uint8_t* proof, size_t len, int log_n, uint32_t width, const zkhip_params* prm,
+                           uint8_t* out, size_t cap, size_t* out_len);
+int zkhip_proof_from_bincode(const uint8_t* in, size_t len, int log_n, uint32_t width, const zkhip_params* prm, size_t n_public,
+                             uint8_t* proof, size_t cap, size_t* out_len);
 
 /* Request digest: 8 canonical BabyBear words binding the guest input (the CBOR bytes of sp1.rs:108-109 / prover.rs:81-82) and
  * the guest program (ELF): Poseidon2 overwrite-mode sponge over 3-byte limbs, fields length-prefixed.  The glue uses them as the

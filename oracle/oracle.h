@@ -180,6 +180,23 @@ typedef struct {
 } orc_prove_debug_t;
 void orc_last_prove_debug(orc_prove_debug_t* out);
 
+/* ---- RISC Zero Hal operators (oracle/hal.c; risc0-zkp 1.2.5 hal::Hal, reference Cargo.lock:5057): column-major
+ * [count][size] vectors, extension elements over x^4 = ext_w (11, or p - 11 for RISC Zero's x^4 + 11) ---- */
+void orc_hal_ext_mul(const uint32_t a[4], const uint32_t b[4], uint32_t ext_w, uint32_t out[4]);
+void orc_hal_eltwise_add(uint32_t* out, const uint32_t* a, const uint32_t* b, size_t n);
+void orc_hal_eltwise_sum_ext(uint32_t* out, const uint32_t* in, size_t count, size_t to_add);
+void orc_hal_eltwise_zeroize(uint32_t* io, size_t n);
+void orc_hal_zk_shift(uint32_t* io, size_t count, int log_size, uint32_t shift);
+void orc_hal_mix_poly_coeffs(uint32_t* out, const uint32_t mix_start[4], const uint32_t mix[4], const uint32_t* in,
+                             const uint32_t* combos, size_t input_size, size_t count, uint32_t ext_w);
+void orc_hal_batch_evaluate_any(const uint32_t* coeffs, int log_size, const uint32_t* which, const uint32_t* xs, uint32_t* out,
+                                size_t eval_count, uint32_t ext_w);
+void orc_hal_gather_sample(uint32_t* dst, const uint32_t* src, size_t idx, size_t size, size_t stride);
+void orc_hal_scatter(uint32_t* into, const uint32_t* index, const uint32_t* offsets, const uint32_t* values, size_t rows);
+void orc_hal_prefix_products_ext(uint32_t* io, size_t n, uint32_t ext_w);
+void orc_hal_hash_rows_sha256(const uint32_t* mat, size_t cols, size_t rows, uint32_t* digests);
+void orc_hal_hash_fold_sha256(const uint32_t* children, uint32_t* parents, size_t count);
+
 #ifdef __cplusplus
 }
 #endif

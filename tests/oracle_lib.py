@@ -401,3 +401,90 @@ class OracleChallenger:
 
     def grind(self, bits):
         return lib().orc_chal_grind(C.byref(self.c), C.c_int(bits))
+
+
+# ---- RISC Zero Hal operators (oracle/hal.c): column-major vectors, canonical words; ext_w = 11 or P - 11
+EXT_W = {0: 11, 1: P - 11}
+
+
+def hal_ext_mul(a, b, ext_field=0):
+    out = np.zeros(4, dtype=np.uint32)
+    lib().orc_hal_ext_mul(_p(_u32(a)), _p(_u32(b)), C.c_uint32(EXT_W[ext_field]), _p(out))
+    return out
+
+
+def hal_eltwise_add(a, b):
+    a, b = _u32(a).ravel(), _u32(b).ravel()
+    out = np.empty_like(a)
+    lib().orc_hal_eltwise_add(_p(out), _p(a), _p(b), C.c_size_t(a.size))
+    return out
+
+
+def hal_eltwise_sum_ext(inp, count):
+    inp = _u32(inp).ravel()
+    to_add = inp.size // (4 * count)
+    out = np.empty(4 * count, dtype=np.uint32)
+    lib().orc_hal_eltwise_sum_ext(_p(out), _p(inp), C.c_size_t(count), C.c_size_t(to_add))
+    return out
+
+
+def hal_eltwise_zeroize(io):
+    io = _u32(io).ravel().copy()
+    lib().orc_hal_eltwise_zeroize(_p(io), C.c_size_t(io.size))
+    return io
+
+
+def hal_zk_shift(io, count, log_size, shift):
+    io = _u32(io).ravel().copy()
+    lib().orc_hal_zk_shift(_p(io), C.c_size_t(count), C.c_int(log_size), C.c_uint32(shift))
+    return io
+
+
+def hal_mix_poly_coeffs(out, mix_start, mix, inp, combos, input_size, count, ext_field=0):
+    out = _u32(out).ravel().copy()
+    lib().orc_hal_mix_poly_coeffs(_p(out), _p(_u32(mix_start)), _p(_u32(mix)), _p(_u32(inp).ravel()), _p(_u32(combos)),
+                                  C.c_size_t(input_size), C.c_size_t(count), C.c_uint32(EXT_W[ext_field]))
+    return out
+
+
+def hal_batch_evaluate_any(coeffs, log_size, which, xs, ext_field=0):
+    which, xs = _u32(which), _u32(xs).ravel()
+    out = np.empty(4 * which.size, dtype=np.uint32)
+    lib().orc_hal_batch_evaluate_any(_p(_u32(coeffs).ravel()), C.c_int(log_size), _p(which), _p(xs), _p(out), C.c_size_t(which.size),
+                                     C.c_uint32(EXT_W[ext_field]))
+    return out
+
+
+def hal_gather_sample(src, idx, size, stride):
+    out = np.empty(size, dtype=np.uint32)
+    lib().orc_hal_gather_sample(_p(out), _p(_u32(src).ravel()), C.c_size_t(idx), C.c_size_t(size), C.c_size_t(stride))
+    return out
+
+
+def hal_scatter(into, index, offsets, values):
+    into = _u32(into).ravel().copy()
+    index = _u32(index)
+    lib().orc_hal_scatter(_p(into), _p(index), _p(_u32(offsets)), _p(_u32(values)), C.c_size_t(index.size - 1))
+    return into
+
+
+def hal_prefix_products_ext(io, ext_field=0):
+    io = _u32(io).ravel().copy()
+    lib().orc_hal_prefix_products_ext(_p(io), C.c_size_t(io.size // 4), C.c_uint32(EXT_W[ext_field]))
+    return io
+
+
+def hal_hash_rows_sha256(mat_colmajor):
+    m = _u32(mat_colmajor)
+    cols, rows = m.shape
+    out = np.empty(8 * rows, dtype=np.uint32)
+    lib().orc_hal_hash_rows_sha256(_p(m), C.c_size_t(cols), C.c_size_t(rows), _p(out))
+    return out.reshape(rows, 8)
+
+
+def hal_hash_fold_sha256(children):
+    ch = _u32(children).ravel()
+    count = ch.size // 16
+    out = np.empty(8 * count, dtype=np.uint32)
+    lib().orc_hal_hash_fold_sha256(_p(ch), _p(out), C.c_size_t(count))
+    return out.reshape(count, 8)

@@ -24,6 +24,10 @@ EXPORTS = [
     "zkhip_merkle_commit", "zkhip_merkle_commit_mixed", "zkhip_merkle_commit_p24_colmajor", "zkhip_batch_interpolate_colmajor", "zkhip_batch_expand_colmajor", "zkhip_quotient_values", "zkhip_open_at", "zkhip_fri_fold", "zkhip_fri_fold_k",
     "zkhip_commit", "zkhip_proof_size", "zkhip_prove_shard", "zkhip_prove_shard_host", "zkhip_prove_shards", "zkhip_prove_shards_multi", "zkhip_shard_device", "zkhip_release_cached_contexts", "zkhip_prove_segment", "zkhip_verify_shard", "zkhip_last_prove_debug",
     "zkhip_chips_proof_size", "zkhip_prove_chips", "zkhip_verify_chips", "zkhip_request_digest",
+    "zkhip_eltwise_add", "zkhip_eltwise_copy", "zkhip_eltwise_zeroize", "zkhip_eltwise_sum_ext", "zkhip_zk_shift", "zkhip_mix_poly_coeffs",
+    "zkhip_batch_evaluate_any", "zkhip_gather_sample", "zkhip_scatter", "zkhip_prefix_products_ext", "zkhip_hash_rows_sha256",
+    "zkhip_hash_fold_sha256", "zkhip_merkle_commit_sha256_colmajor",
+    "zkhip_bincode_size", "zkhip_proof_to_bincode", "zkhip_proof_from_bincode",
 ]
 
 
@@ -117,6 +121,24 @@ def load():
     L.zkhip_release_cached_contexts.restype = None
     L.zkhip_prove_shards.argtypes = [C.c_int, C.POINTER(ShardJob), C.c_int, C.POINTER(Params), C.c_int, C.c_int]
     L.zkhip_prove_shards_multi.argtypes = [C.POINTER(C.c_int), C.c_int, C.POINTER(ShardJob), C.c_int, C.POINTER(Params), C.c_int, C.c_int]
+    vp, sz = C.c_void_p, C.c_size_t
+    L.zkhip_eltwise_add.argtypes = [vp, vp, vp, vp, sz]
+    L.zkhip_eltwise_copy.argtypes = [vp, vp, vp, sz]
+    L.zkhip_eltwise_zeroize.argtypes = [vp, vp, sz]
+    L.zkhip_eltwise_sum_ext.argtypes = [vp, vp, vp, sz, sz]
+    L.zkhip_zk_shift.argtypes = [vp, vp, sz, C.c_int, C.c_uint32]
+    L.zkhip_mix_poly_coeffs.argtypes = [vp, vp, u32p, u32p, vp, vp, sz, sz, C.c_int]
+    L.zkhip_batch_evaluate_any.argtypes = [vp, vp, C.c_int, vp, vp, vp, sz, C.c_int]
+    L.zkhip_gather_sample.argtypes = [vp, vp, vp, sz, sz, sz]
+    L.zkhip_scatter.argtypes = [vp, vp, vp, vp, vp, sz]
+    L.zkhip_prefix_products_ext.argtypes = [vp, vp, sz, C.c_int]
+    L.zkhip_hash_rows_sha256.argtypes = [vp, vp, sz, sz, vp]
+    L.zkhip_hash_fold_sha256.argtypes = [vp, vp, vp, sz]
+    L.zkhip_merkle_commit_sha256_colmajor.argtypes = [vp, vp, C.c_uint32, C.c_int, vp]
+    L.zkhip_bincode_size.restype = C.c_size_t
+    L.zkhip_bincode_size.argtypes = [C.c_int, C.c_uint32, C.POINTER(Params)]
+    L.zkhip_proof_to_bincode.argtypes = [u8p, C.c_size_t, C.c_int, C.c_uint32, C.POINTER(Params), u8p, C.c_size_t, C.POINTER(C.c_size_t)]
+    L.zkhip_proof_from_bincode.argtypes = [u8p, C.c_size_t, C.c_int, C.c_uint32, C.POINTER(Params), C.c_size_t, u8p, C.c_size_t, C.POINTER(C.c_size_t)]
     L.zkhip_request_digest.argtypes = [C.c_char_p, C.c_size_t, C.c_char_p, C.c_size_t, u32p]
     L.zkhip_shard_device.argtypes = [C.c_int, C.POINTER(C.c_int), C.c_int]
     L.zkhip_prove_segment.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_uint32, u32p, C.c_size_t,

@@ -1,0 +1,403 @@
+// hal.hip -- the RISC Zero `Hal` operator set at operator level, hand-written for gfx950:
+// element-wise operators, zk_shift, mix_poly_coeffs, batch_evaluate_any, gather_sample, scatter, prefix_products and the
+// SHA-256 variant of hash_rows / hash_fold.  Kernels and their C-ABI entries (include/zkhip.h) live together here.
+//
+// Replaces the CUDA / C++ kernels of risc0-sys 1.2.5 behind risc0-zkp 1.2.5 `hal::Hal` (reference Cargo.lock:5045, 5057),
+// which the reference reaches through crates/guest-prover-r0/src/prover.rs:90.  Layout as RISC Zero's Hal holds it:
+// polynomials / columns are contiguous vectors (column-major [count][size]), base elements in Montgomery form, extension
+// elements 4 consecutive words.  The extension field is a TEMPLATE PARAMETER: x^4 = 11 (Plonky3 / SP1) or x^4 = -11
+// (RISC Zero's x^4 + 11).  All of these are HBM-bound streaming or gather kernels (no MFMA, nothing to tile): coalesced
+// accesses along the contiguous vector index, one thread per output element, 64-bit address arithmetic.
+#include "context.h"
+
+namespace zk {
+
+// ---- extension arithmetic with the non-residue as a template parameter (W in Montgomery form)
+constexpr uint32_t MONTY_W_SP1 = to_monty(EXT_W);          // x^4 = 11
+constexpr uint32_t MONTY_W_R0 = to_monty(P - EXT_W);       // x^4 = -11
+template <uint32_t W>
+ZK_D Ext ext_mul_t(const Ext& a, const Ext& b) {
+    const uint32_t w1 = dmul(b.c[1], W), w2 = dmul(b.c[2], W), w3 = dmul(b.c[3], W);
+    uint64_t s0 = 0, s1 = 0, s2 = 0, s3 = 0;
+    dacc2(s0, a.c[0], b.c[0], a.c[1], w3); dacc2(s0, a.c[2], w2, a.c[3], w1);
+    dacc2(s1, a.c[0], b.c[1], a.c[1], b.c[0]); dacc2(s1, a.c[2], w3, a.c[3], w2);
+    dacc2(s2, a.c[0], b.c[2], a.c[1], b.c[1]); dacc2(s2, a.c[2], b.c[0], a.c[3], w3);
+    dacc2(s3, a.c[0], b.c[3], a.c[1], b.c[2]); dacc2(s3, a.c[2], b.c[1], a.c[3], b.c[0]);
+    return Ext{{dacc_finish(s0), dacc_finish(s1), dacc_finish(s2), dacc_finish(s3)}};
+}
+ZK_D Ext ext_add_d(const Ext& a, const Ext& b) { return Ext{{dadd(a.c[0], b.c[0]), dadd(a.c[1], b.c[1]), dadd(a.c[2], b.c[2]), dadd(a.c[3], b.c[3])}}; }
+ZK_D Ext ld_ext(const uint32_t* p) { const uint4 v = *reinterpret_cast<const uint4*>(p); return Ext{{v.x, v.y, v.z, v.w}}; }
+ZK_D void st_ext(uint32_t* p, const Ext& e) { *reinterpret_cast<uint4*>(p) = make_uint4(e.c[0], e.c[1], e.c[2], e.c[3]); }
+
+// ---- element-wise (grid-stride, 4 B per lane: fully coalesced)
+__global__ void hal_add_kernel(uint32_t* __restrict__ out, const uint32_t* __restrict__ a, const uint32_t* __restrict__ b, uint64_t n) {
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) out[i] = dadd(a[i], b[i]);
+}
+__global__ void hal_zeroize_kernel(uint32_t* __restrict__ io, uint64_t n) {
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x)
+        if (io[i] == 0xFFFFFFFFu) io[i] = 0u;
+}
+// out[i] = sum_j in[j * count + i] (extension elements): lanes along i, the j loop walks `to_add` coalesced rows
+__global__ void hal_sum_ext_kernel(uint32_t* __restrict__ out, const uint32_t* __restrict__ in, uint64_t count, uint64_t to_add) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= count) return;
+    Ext acc = ext_zero();
+    for (uint64_t j = 0; j < to_add; j++) acc = ext_add_d(acc, ld_ext(in + 4 * (j * count + i)));
+    st_ext(out + 4 * i, acc);
+}
+// coefficient i of every polynomial times shift^i: a thread owns 16 consecutive coefficients (one fpow, then a running product)
+__global__ void hal_zk_shift_kernel(uint32_t* __restrict__ io, uint64_t count, int log_size, uint32_t shift) {
+    const uint64_t n = (uint64_t)1 << log_size, chunks = (n + 15) / 16;
+    const uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= count * chunks) return;
+    const uint64_t p = t / chunks, i0 = (t % chunks) * 16;
+    uint32_t s = fpow(shift, i0);
+    uint32_t* v = io + p * n + i0;
+    for (uint64_t k = 0; k < 16 && i0 + k < n; k++) { v[k] = dmul(v[k], s); s = dmul(s, shift); }
+}
+// out[combos[i] * count + idx] += mix_start * mix^i * in[i * count + idx]: a thread owns one idx and walks the inputs (reads coalesced
+// along idx); the accumulators of the (few) combos live in the output itself, read-modify-write per term
+template <uint32_t W>
+__global__ void hal_mix_poly_coeffs_kernel(uint32_t* __restrict__ out, Ext mix_start, Ext mix, const uint32_t* __restrict__ in,
+                                           const uint32_t* __restrict__ combos, uint64_t input_size, uint64_t count) {
+    const uint64_t idx = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= count) return;
+    Ext cur = mix_start;
+    for (uint64_t i = 0; i < input_size; i++) {
+        uint32_t* o = out + 4 * ((uint64_t)combos[i] * count + idx);
+        st_ext(o, ext_add_d(ld_ext(o), ext_mul_base_dev(cur, in[i * count + idx])));
+        cur = ext_mul_t<W>(cur, mix);
+    }
+}
+// out[e] = polynomial which[e] at xs[e]: one workgroup per evaluation.  Thread t evaluates the coefficient slice
+// [t * L, (t + 1) * L) by Horner, scales it by x^(t L) and the 256 partial values are summed in LDS.
+template <uint32_t W>
+__global__ void __launch_bounds__(256) hal_batch_evaluate_any_kernel(const uint32_t* __restrict__ coeffs, int log_size, const uint32_t* __restrict__ which,
+                                                                     const uint32_t* __restrict__ xs, uint32_t* __restrict__ out) {
+    __shared__ uint32_t part[256][4];
+    const uint64_t n = (uint64_t)1 << log_size;
+    const uint32_t e = blockIdx.x, t = threadIdx.x;
+    const uint32_t* c = coeffs + (uint64_t)which[e] * n;
+    const Ext x = ld_ext(xs + 4 * (uint64_t)e);
+    const uint64_t L = (n + 255) / 256, lo = (uint64_t)t * L;
+    Ext acc = ext_zero();
+    if (lo < n) {
+        const uint64_t hi = lo + L < n ? lo + L : n;
+        for (uint64_t i = hi; i-- > lo;) { acc = ext_mul_t<W>(acc, x); acc.c[0] = dadd(acc.c[0], c[i]); }
+        // x^lo by square and multiply
+        Ext pw = ext_one(), b = x;
+        for (uint64_t k = lo; k; k >>= 1) { if (k & 1) pw = ext_mul_t<W>(pw, b); b = ext_mul_t<W>(b, b); }
+        acc = ext_mul_t<W>(acc, pw);
+    }
+    for (int k = 0; k < 4; k++) part[t][k] = acc.c[k];
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) {
+        if ((int)t < s) for (int k = 0; k < 4; k++) part[t][k] = dadd(part[t][k], part[t + s][k]);
+        __syncthreads();
+    }
+    if (t < 4) out[4 * (uint64_t)e + t] = part[0][t];
+}
+__global__ void hal_gather_sample_kernel(uint32_t* __restrict__ dst, const uint32_t* __restrict__ src, uint64_t idx, uint64_t size, uint64_t stride) {
+    const uint64_t g = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (g < size) dst[g] = src[g * stride + idx];
+}
+__global__ void hal_scatter_kernel(uint32_t* __restrict__ into, const uint32_t* __restrict__ index, const uint32_t* __restrict__ offsets,
+                                   const uint32_t* __restrict__ values, uint64_t rows) {
+    const uint64_t r = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= rows) return;
+    for (uint32_t k = index[r]; k < index[r + 1]; k++) into[offsets[k]] = values[k];
+}
+// inclusive prefix products of extension elements in three launches: (1) every thread multiplies its chunk of CH consecutive
+// elements and the workgroup scans the 256 chunk products in LDS, leaving per-chunk exclusive prefixes and the block total;
+// (2) one workgroup scans the block totals; (3) every thread replays its chunk from (block prefix * chunk prefix).
+constexpr int SCAN_CH = 8;
+template <uint32_t W>
+__global__ void __launch_bounds__(256) hal_scan_blocks_kernel(const uint32_t* __restrict__ io, uint64_t n, uint32_t* __restrict__ chunk_pre, uint32_t* __restrict__ block_tot) {
+    __shared__ uint32_t sh[256][4];
+    const uint32_t t = threadIdx.x;
+    const uint64_t c = (uint64_t)blockIdx.x * 256 + t, i0 = c * SCAN_CH;
+    Ext prod = ext_one();
+    for (int k = 0; k < SCAN_CH; k++) if (i0 + k < n) prod = ext_mul_t<W>(prod, ld_ext(io + 4 * (i0 + k)));
+    for (int k = 0; k < 4; k++) sh[t][k] = prod.c[k];
+    __syncthreads();
+    for (int d = 1; d < 256; d <<= 1) {                      // Hillis-Steele inclusive scan (the product is not commutative-sensitive)
+        Ext v = Ext{{sh[t][0], sh[t][1], sh[t][2], sh[t][3]}};
+        Ext u = ext_one();
+        if ((int)t >= d) u = Ext{{sh[t - d][0], sh[t - d][1], sh[t - d][2], sh[t - d][3]}};
+        __syncthreads();
+        if ((int)t >= d) { v = ext_mul_t<W>(u, v); for (int k = 0; k < 4; k++) sh[t][k] = v.c[k]; }
+        __syncthreads();
+    }
+    const Ext excl = t ? Ext{{sh[t - 1][0], sh[t - 1][1], sh[t - 1][2], sh[t - 1][3]}} : ext_one();
+    st_ext(chunk_pre + 4 * c, excl);
+    if (t == 255) st_ext(block_tot + 4 * (uint64_t)blockIdx.x, Ext{{sh[255][0], sh[255][1], sh[255][2], sh[255][3]}});
+}
+template <uint32_t W>
+__global__ void __launch_bounds__(256) hal_scan_totals_kernel(uint32_t* __restrict__ block_tot, uint64_t nblocks) {
+    // exclusive scan of the block totals, in place; one workgroup, sequential over tiles of 256
+    __shared__ uint32_t sh[256][4];
+    __shared__ uint32_t carry[4];
+    const uint32_t t = threadIdx.x;
+    if (t < 4) carry[t] = t == 0 ? MONTY_R1 : 0u;
+    __syncthreads();
+    for (uint64_t base = 0; base < nblocks; base += 256) {
+        const uint64_t i = base + t;
+        Ext v = i < nblocks ? ld_ext(block_tot + 4 * i) : ext_one();
+        for (int k = 0; k < 4; k++) sh[t][k] = v.c[k];
+        __syncthreads();
+        for (int d = 1; d < 256; d <<= 1) {
+            Ext cur = Ext{{sh[t][0], sh[t][1], sh[t][2], sh[t][3]}};
+            Ext u = ext_one();
+            if ((int)t >= d) u = Ext{{sh[t - d][0], sh[t - d][1], sh[t - d][2], sh[t - d][3]}};
+            __syncthreads();
+            if ((int)t >= d) { cur = ext_mul_t<W>(u, cur); for (int k = 0; k < 4; k++) sh[t][k] = cur.c[k]; }
+            __syncthreads();
+        }
+        const Ext c0 = Ext{{carry[0], carry[1], carry[2], carry[3]}};
+        const Ext excl = t ? Ext{{sh[t - 1][0], sh[t - 1][1], sh[t - 1][2], sh[t - 1][3]}} : ext_one();
+        if (i < nblocks) st_ext(block_tot + 4 * i, ext_mul_t<W>(c0, excl));
+        __syncthreads();
+        if (t == 0) { const Ext nc = ext_mul_t<W>(c0, Ext{{sh[255][0], sh[255][1], sh[255][2], sh[255][3]}}); for (int k = 0; k < 4; k++) carry[k] = nc.c[k]; }
+        __syncthreads();
+    }
+}
+template <uint32_t W>
+__global__ void __launch_bounds__(256) hal_scan_apply_kernel(uint32_t* __restrict__ io, uint64_t n, const uint32_t* __restrict__ chunk_pre, const uint32_t* __restrict__ block_pre) {
+    const uint64_t c = (uint64_t)blockIdx.x * 256 + threadIdx.x, i0 = c * SCAN_CH;
+    if (i0 >= n) return;
+    Ext acc = ext_mul_t<W>(ld_ext(block_pre + 4 * (uint64_t)blockIdx.x), ld_ext(chunk_pre + 4 * c));
+    for (int k = 0; k < SCAN_CH; k++)
+        if (i0 + k < n) { acc = ext_mul_t<W>(acc, ld_ext(io + 4 * (i0 + k))); st_ext(io + 4 * (i0 + k), acc); }
+}
+
+// ---- SHA-256 (FIPS 180-4) over canonical words, big-endian; one row / one node per lane.  Integer-ALU bound (64 rounds of
+// rotates and adds per 64-byte block), the column-major reads are coalesced (a wave reads 64 consecutive words of a column).
+__constant__ uint32_t K256[64] = {
+    0x428a2f98, 0x71374491, 0xb5c0fbcf, 0xe9b5dba5, 0x3956c25b, 0x59f111f1, 0x923f82a4, 0xab1c5ed5, 0xd807aa98, 0x12835b01, 0x243185be,
+    0x550c7dc3, 0x72be5d74, 0x80deb1fe, 0x9bdc06a7, 0xc19bf174, 0xe49b69c1, 0xefbe4786, 0x0fc19dc6, 0x240ca1cc, 0x2de92c6f, 0x4a7484aa,
+    0x5cb0a9dc, 0x76f988da, 0x983e5152, 0xa831c66d, 0xb00327c8, 0xbf597fc7, 0xc6e00bf3, 0xd5a79147, 0x06ca6351, 0x14292967, 0x27b70a85,
+    0x2e1b2138, 0x4d2c6dfc, 0x53380d13, 0x650a7354, 0x766a0abb, 0x81c2c92e, 0x92722c85, 0xa2bfe8a1, 0xa81a664b, 0xc24b8b70, 0xc76c51a3,
+    0xd192e819, 0xd6990624, 0xf40e3585, 0x106aa070, 0x19a4c116, 0x1e376c08, 0x2748774c, 0x34b0bcb5, 0x391c0cb3, 0x4ed8aa4a, 0x5b9cca4f,
+    0x682e6ff3, 0x748f82ee, 0x78a5636f, 0x84c87814, 0x8cc70208, 0x90befffa, 0xa4506ceb, 0xbef9a3f7, 0xc67178f2};
+ZK_D uint32_t rotr32(uint32_t x, int n) { return __builtin_rotateright32(x, n); }
+ZK_D void sha256_block(uint32_t h[8], uint32_t w[16]) {
+    uint32_t a = h[0], b = h[1], c = h[2], d = h[3], e = h[4], f = h[5], g = h[6], hh = h[7];
+#pragma unroll
+    for (int i = 0; i < 64; i++) {
+        if (i >= 16) {
+            const uint32_t w15 = w[(i - 15) & 15], w2 = w[(i - 2) & 15];
+            const uint32_t s0 = rotr32(w15, 7) ^ rotr32(w15, 18) ^ (w15 >> 3);
+            const uint32_t s1 = rotr32(w2, 17) ^ rotr32(w2, 19) ^ (w2 >> 10);
+            w[i & 15] = w[i & 15] + s0 + w[(i - 7) & 15] + s1;
+        }
+        const uint32_t S1 = rotr32(e, 6) ^ rotr32(e, 11) ^ rotr32(e, 25), ch = (e & f) ^ (~e & g);
+        const uint32_t t1 = hh + S1 + ch + K256[i] + w[i & 15];
+        const uint32_t S0 = rotr32(a, 2) ^ rotr32(a, 13) ^ rotr32(a, 22), mj = (a & b) ^ (a & c) ^ (b & c);
+        const uint32_t t2 = S0 + mj;
+        hh = g; g = f; f = e; e = d + t1; d = c; c = b; b = a; a = t1 + t2;
+    }
+    h[0] += a; h[1] += b; h[2] += c; h[3] += d; h[4] += e; h[5] += f; h[6] += g; h[7] += hh;
+}
+ZK_D void sha256_init(uint32_t h[8]) {
+    h[0] = 0x6a09e667; h[1] = 0xbb67ae85; h[2] = 0x3c6ef372; h[3] = 0xa54ff53a; h[4] = 0x510e527f; h[5] = 0x9b05688c; h[6] = 0x1f83d9ab; h[7] = 0x5be0cd19;
+}
+// leaf r = SHA-256 over the canonical words of row r of a column-major [cols][rows] matrix (Montgomery in memory)
+__global__ void __launch_bounds__(256) hal_hash_rows_sha256_kernel(const uint32_t* __restrict__ mat, uint64_t cols, uint64_t rows, uint32_t* __restrict__ digests) {
+    const uint64_t r = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= rows) return;
+    uint32_t h[8], w[16];
+    sha256_init(h);
+    uint64_t i = 0;
+    for (; i + 16 <= cols; i += 16) {
+#pragma unroll
+        for (int k = 0; k < 16; k++) w[k] = from_monty(mat[(i + k) * rows + r]);
+        sha256_block(h, w);
+    }
+    int n = 0;
+#pragma unroll
+    for (int k = 0; k < 16; k++) { w[k] = 0u; if (i + k < cols) { w[k] = from_monty(mat[(i + k) * rows + r]); n = k + 1; } }
+    // padding: 0x80 byte, zeros, 64-bit message length in bits
+#pragma unroll
+    for (int k = 0; k < 16; k++) if (k == n) w[k] = 0x80000000u;
+    if (n > 13) {
+        sha256_block(h, w);
+#pragma unroll
+        for (int k = 0; k < 16; k++) w[k] = 0u;
+    }
+    const uint64_t bits = cols * 32;
+    w[14] = (uint32_t)(bits >> 32); w[15] = (uint32_t)bits;
+    sha256_block(h, w);
+    uint4* d = reinterpret_cast<uint4*>(digests + 8 * r);
+    d[0] = make_uint4(h[0], h[1], h[2], h[3]);
+    d[1] = make_uint4(h[4], h[5], h[6], h[7]);
+}
+// parents[i] = SHA-256(children[2i] || children[2i+1]): one 64-byte data block + the padding block
+__global__ void __launch_bounds__(256) hal_hash_fold_sha256_kernel(const uint32_t* __restrict__ children, uint32_t* __restrict__ parents, uint64_t count) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= count) return;
+    const uint4* cp = reinterpret_cast<const uint4*>(children + 16 * i);
+    const uint4 v0 = cp[0], v1 = cp[1], v2 = cp[2], v3 = cp[3];
+    uint32_t w[16] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w, v2.x, v2.y, v2.z, v2.w, v3.x, v3.y, v3.z, v3.w};
+    uint32_t h[8];
+    sha256_init(h);
+    sha256_block(h, w);
+#pragma unroll
+    for (int k = 0; k < 16; k++) w[k] = 0u;
+    w[0] = 0x80000000u; w[15] = 512u;
+    sha256_block(h, w);
+    uint4* d = reinterpret_cast<uint4*>(parents + 8 * i);
+    d[0] = make_uint4(h[0], h[1], h[2], h[3]);
+    d[1] = make_uint4(h[4], h[5], h[6], h[7]);
+}
+
+static unsigned grid_for(uint64_t n, unsigned cap = 65536) { const uint64_t b = (n + 255) / 256; return (unsigned)(b < cap ? (b ? b : 1) : cap); }
+
+}  // namespace zk
+
+using namespace zk;
+
+#define CHECK_CTX(ctx)                                                  \
+    do {                                                                \
+        if (!(ctx)) return fail(ZKHIP_ERR_INVALID, "null context");     \
+        ZK_HIP(hipSetDevice((ctx)->device));                            \
+    } while (0)
+#define LAUNCHED() ZK_HIP(hipGetLastError())
+
+extern "C" {
+
+int zkhip_eltwise_add(zkhip_ctx* ctx, uint32_t* d_out, const uint32_t* d_a, const uint32_t* d_b, size_t n) {
+    CHECK_CTX(ctx);
+    if (n && (!d_out || !d_a || !d_b)) return fail(ZKHIP_ERR_INVALID, "eltwise_add: null pointer");
+    if (!n) return ZKHIP_OK;
+    hipLaunchKernelGGL(hal_add_kernel, dim3(grid_for(n)), dim3(256), 0, ctx->stream, d_out, d_a, d_b, (uint64_t)n);
+    LAUNCHED();
+    return ZKHIP_OK;
+}
+int zkhip_eltwise_copy(zkhip_ctx* ctx, uint32_t* d_out, const uint32_t* d_in, size_t n) {
+    CHECK_CTX(ctx);
+    if (n && (!d_out || !d_in)) return fail(ZKHIP_ERR_INVALID, "eltwise_copy: null pointer");
+    if (n) ZK_HIP(hipMemcpyAsync(d_out, d_in, n * 4, hipMemcpyDeviceToDevice, ctx->stream));
+    return ZKHIP_OK;
+}
+int zkhip_eltwise_zeroize(zkhip_ctx* ctx, uint32_t* d_io, size_t n) {
+    CHECK_CTX(ctx);
+    if (n && !d_io) return fail(ZKHIP_ERR_INVALID, "eltwise_zeroize: null pointer");
+    if (!n) return ZKHIP_OK;
+    hipLaunchKernelGGL(hal_zeroize_kernel, dim3(grid_for(n)), dim3(256), 0, ctx->stream, d_io, (uint64_t)n);
+    LAUNCHED();
+    return ZKHIP_OK;
+}
+int zkhip_eltwise_sum_ext(zkhip_ctx* ctx, uint32_t* d_out, const uint32_t* d_in, size_t count, size_t to_add) {
+    CHECK_CTX(ctx);
+    if (count && (!d_out || !d_in)) return fail(ZKHIP_ERR_INVALID, "eltwise_sum_ext: null pointer");
+    if ((reinterpret_cast<uintptr_t>(d_out) | reinterpret_cast<uintptr_t>(d_in)) & 15) return fail(ZKHIP_ERR_INVALID, "eltwise_sum_ext: extension vectors must be 16-byte aligned");
+    if (!count) return ZKHIP_OK;
+    hipLaunchKernelGGL(hal_sum_ext_kernel, dim3((unsigned)((count + 255) / 256)), dim3(256), 0, ctx->stream, d_out, d_in, (uint64_t)count, (uint64_t)to_add);
+    LAUNCHED();
+    return ZKHIP_OK;
+}
+int zkhip_zk_shift(zkhip_ctx* ctx, uint32_t* d_io, size_t count, int log_size, uint32_t shift) {
+    CHECK_CTX(ctx);
+    if (!d_io || log_size < 0 || log_size > 30 || shift == 0 || shift >= P) return fail(ZKHIP_ERR_INVALID, "zk_shift: bad arguments (shift canonical, non-zero)");
+    const uint64_t chunks = (((uint64_t)1 << log_size) + 15) / 16, threads = (uint64_t)count * chunks;
+    if (!threads) return ZKHIP_OK;
+    hipLaunchKernelGGL(hal_zk_shift_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, ctx->stream, d_io, (uint64_t)count, log_size, to_monty(shift));
+    LAUNCHED();
+    return ZKHIP_OK;
+}
+static int ext_field_ok(int ext) { return ext == ZKHIP_EXT_X4_MINUS_11 || ext == ZKHIP_EXT_X4_PLUS_11; }
+int zkhip_mix_poly_coeffs(zkhip_ctx* ctx, uint32_t* d_out, const uint32_t mix_start[4], const uint32_t mix[4], const uint32_t* d_in,
+                          const uint32_t* d_combos, size_t input_size, size_t count, int ext_field) {
+    CHECK_CTX(ctx);
+    if (!d_out || !mix_start || !mix || !d_in || !d_combos || !ext_field_ok(ext_field) || (reinterpret_cast<uintptr_t>(d_out) & 15))
+        return fail(ZKHIP_ERR_INVALID, "mix_poly_coeffs: bad arguments");
+    if (!count || !input_size) return ZKHIP_OK;
+    const Ext ms{{mix_start[0], mix_start[1], mix_start[2], mix_start[3]}}, mx{{mix[0], mix[1], mix[2], mix[3]}};
+    const dim3 grid((unsigned)((count + 255) / 256)), block(256);
+    if (ext_field == ZKHIP_EXT_X4_PLUS_11) hipLaunchKernelGGL((hal_mix_poly_coeffs_kernel<MONTY_W_R0>), grid, block, 0, ctx->stream, d_out, ms, mx, d_in, d_combos, (uint64_t)input_size, (uint64_t)count);
+    else hipLaunchKernelGGL((hal_mix_poly_coeffs_kernel<MONTY_W_SP1>), grid, block, 0, ctx->stream, d_out, ms, mx, d_in, d_combos, (uint64_t)input_size, (uint64_t)count);
+    LAUNCHED();
+    return ZKHIP_OK;
+}
+int zkhip_batch_evaluate_any(zkhip_ctx* ctx, const uint32_t* d_coeffs, int log_size, const uint32_t* d_which, const uint32_t* d_xs,
+                             uint32_t* d_out, size_t eval_count, int ext_field) {
+    CHECK_CTX(ctx);
+    if (!d_coeffs || !d_which || !d_xs || !d_out || log_size < 0 || log_size > 30 || !ext_field_ok(ext_field) || (reinterpret_cast<uintptr_t>(d_xs) & 15))
+        return fail(ZKHIP_ERR_INVALID, "batch_evaluate_any: bad arguments");
+    if (!eval_count) return ZKHIP_OK;
+    if (ext_field == ZKHIP_EXT_X4_PLUS_11) hipLaunchKernelGGL((hal_batch_evaluate_any_kernel<MONTY_W_R0>), dim3((unsigned)eval_count), dim3(256), 0, ctx->stream, d_coeffs, log_size, d_which, d_xs, d_out);
+    else hipLaunchKernelGGL((hal_batch_evaluate_any_kernel<MONTY_W_SP1>), dim3((unsigned)eval_count), dim3(256), 0, ctx->stream, d_coeffs, log_size, d_which, d_xs, d_out);
+    LAUNCHED();
+    return ZKHIP_OK;
+}
+int zkhip_gather_sample(zkhip_ctx* ctx, uint32_t* d_dst, const uint32_t* d_src, size_t idx, size_t size, size_t stride) {
+    CHECK_CTX(ctx);
+    if (!d_dst || !d_src || idx >= stride) return fail(ZKHIP_ERR_INVALID, "gather_sample: bad arguments (idx < stride)");
+    if (!size) return ZKHIP_OK;
+    hipLaunchKernelGGL(hal_gather_sample_kernel, dim3((unsigned)((size + 255) / 256)), dim3(256), 0, ctx->stream, d_dst, d_src, (uint64_t)idx, (uint64_t)size, (uint64_t)stride);
+    LAUNCHED();
+    return ZKHIP_OK;
+}
+int zkhip_scatter(zkhip_ctx* ctx, uint32_t* d_into, const uint32_t* d_index, const uint32_t* d_offsets, const uint32_t* d_values, size_t rows) {
+    CHECK_CTX(ctx);
+    if (!d_into || !d_index || !d_offsets || !d_values) return fail(ZKHIP_ERR_INVALID, "scatter: null pointer");
+    if (!rows) return ZKHIP_OK;
+    hipLaunchKernelGGL(hal_scatter_kernel, dim3((unsigned)((rows + 255) / 256)), dim3(256), 0, ctx->stream, d_into, d_index, d_offsets, d_values, (uint64_t)rows);
+    LAUNCHED();
+    return ZKHIP_OK;
+}
+int zkhip_prefix_products_ext(zkhip_ctx* ctx, uint32_t* d_io, size_t n, int ext_field) {
+    CHECK_CTX(ctx);
+    if (!d_io || !ext_field_ok(ext_field) || (reinterpret_cast<uintptr_t>(d_io) & 15)) return fail(ZKHIP_ERR_INVALID, "prefix_products_ext: bad arguments");
+    if (!n) return ZKHIP_OK;
+    const uint64_t chunks = (n + SCAN_CH - 1) / SCAN_CH, nblocks = (chunks + 255) / 256;
+    void *v_pre, *v_tot;
+    ZK_TRY(ctx_reserve(ctx, S_COL_A, nblocks * 256 * 16, &v_pre));
+    ZK_TRY(ctx_reserve(ctx, S_COL_B, nblocks * 16, &v_tot));
+    uint32_t *pre = (uint32_t*)v_pre, *tot = (uint32_t*)v_tot;
+    const dim3 grid((unsigned)nblocks), block(256);
+    if (ext_field == ZKHIP_EXT_X4_PLUS_11) {
+        hipLaunchKernelGGL((hal_scan_blocks_kernel<MONTY_W_R0>), grid, block, 0, ctx->stream, d_io, (uint64_t)n, pre, tot);
+        hipLaunchKernelGGL((hal_scan_totals_kernel<MONTY_W_R0>), dim3(1), block, 0, ctx->stream, tot, nblocks);
+        hipLaunchKernelGGL((hal_scan_apply_kernel<MONTY_W_R0>), grid, block, 0, ctx->stream, d_io, (uint64_t)n, pre, tot);
+    } else {
+        hipLaunchKernelGGL((hal_scan_blocks_kernel<MONTY_W_SP1>), grid, block, 0, ctx->stream, d_io, (uint64_t)n, pre, tot);
+        hipLaunchKernelGGL((hal_scan_totals_kernel<MONTY_W_SP1>), dim3(1), block, 0, ctx->stream, tot, nblocks);
+        hipLaunchKernelGGL((hal_scan_apply_kernel<MONTY_W_SP1>), grid, block, 0, ctx->stream, d_io, (uint64_t)n, pre, tot);
+    }
+    LAUNCHED();
+    return ZKHIP_OK;
+}
+int zkhip_hash_rows_sha256(zkhip_ctx* ctx, const uint32_t* d_mat, size_t cols, size_t rows, uint32_t* d_digests) {
+    CHECK_CTX(ctx);
+    if (!d_mat || !d_digests || cols == 0 || (reinterpret_cast<uintptr_t>(d_digests) & 15)) return fail(ZKHIP_ERR_INVALID, "hash_rows_sha256: bad arguments");
+    if (!rows) return ZKHIP_OK;
+    hipLaunchKernelGGL(hal_hash_rows_sha256_kernel, dim3((unsigned)((rows + 255) / 256)), dim3(256), 0, ctx->stream, d_mat, (uint64_t)cols, (uint64_t)rows, d_digests);
+    LAUNCHED();
+    return ZKHIP_OK;
+}
+int zkhip_hash_fold_sha256(zkhip_ctx* ctx, const uint32_t* d_children, uint32_t* d_parents, size_t count) {
+    CHECK_CTX(ctx);
+    if (!d_children || !d_parents || ((reinterpret_cast<uintptr_t>(d_children) | reinterpret_cast<uintptr_t>(d_parents)) & 15))
+        return fail(ZKHIP_ERR_INVALID, "hash_fold_sha256: bad arguments");
+    if (!count) return ZKHIP_OK;
+    hipLaunchKernelGGL(hal_hash_fold_sha256_kernel, dim3((unsigned)((count + 255) / 256)), dim3(256), 0, ctx->stream, d_children, d_parents, (uint64_t)count);
+    LAUNCHED();
+    return ZKHIP_OK;
+}
+// full tree, leaves first (layout of zkhip_merkle_commit): leaf hashing + one fold launch per level
+int zkhip_merkle_commit_sha256_colmajor(zkhip_ctx* ctx, const uint32_t* d_mat, uint32_t cols, int log_rows, uint32_t* d_tree) {
+    CHECK_CTX(ctx);
+    if (!d_mat || !d_tree || cols == 0 || log_rows < 0 || log_rows > 28) return fail(ZKHIP_ERR_INVALID, "merkle_commit_sha256_colmajor: bad arguments");
+    const uint64_t rows = (uint64_t)1 << log_rows;
+    ZK_TRY(zkhip_hash_rows_sha256(ctx, d_mat, cols, rows, d_tree));
+    uint32_t* level = d_tree;
+    for (uint64_t cnt = rows; cnt > 1; cnt >>= 1) {
+        uint32_t* next = level + 8 * cnt;
+        ZK_TRY(zkhip_hash_fold_sha256(ctx, level, next, cnt / 2));
+        level = next;
+    }
+    return ZKHIP_OK;
+}
+
+}  // extern "C"

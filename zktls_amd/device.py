@@ -197,6 +197,80 @@ class Context:
         check(self.lib.zkhip_batch_expand_colmajor(self.handle, C.c_void_p(coeffs.ptr), C.c_void_p(out.ptr), count, log_size, log_blowup, shift))
         return out
 
+    # ---- RISC Zero Hal operators (column-major vectors; ext_field 0: x^4 = 11, 1: x^4 = -11)
+    def eltwise_add(self, a, b, out=None):
+        out = out or self.alloc(a.nwords)
+        check(self.lib.zkhip_eltwise_add(self.handle, C.c_void_p(out.ptr), C.c_void_p(a.ptr), C.c_void_p(b.ptr), a.nwords))
+        return out
+
+    def eltwise_copy(self, a, out=None):
+        out = out or self.alloc(a.nwords)
+        check(self.lib.zkhip_eltwise_copy(self.handle, C.c_void_p(out.ptr), C.c_void_p(a.ptr), a.nwords))
+        return out
+
+    def eltwise_zeroize(self, io):
+        check(self.lib.zkhip_eltwise_zeroize(self.handle, C.c_void_p(io.ptr), io.nwords))
+        return io
+
+    def eltwise_sum_ext(self, inp, count, out=None):
+        out = out or self.alloc(4 * count)
+        check(self.lib.zkhip_eltwise_sum_ext(self.handle, C.c_void_p(out.ptr), C.c_void_p(inp.ptr), count, inp.nwords // (4 * count)))
+        return out
+
+    def zk_shift(self, io, count, log_size, shift=3):
+        check(self.lib.zkhip_zk_shift(self.handle, C.c_void_p(io.ptr), count, log_size, shift))
+        return io
+
+    def mix_poly_coeffs(self, out, mix_start, mix, inp, combos, input_size, count, ext_field=0):
+        ms = to_monty(np.asarray(mix_start, dtype=np.uint32))
+        mx = to_monty(np.asarray(mix, dtype=np.uint32))
+        check(self.lib.zkhip_mix_poly_coeffs(self.handle, C.c_void_p(out.ptr), ms.ctypes.data_as(u32p), mx.ctypes.data_as(u32p),
+                                             C.c_void_p(inp.ptr), C.c_void_p(combos.ptr), input_size, count, ext_field))
+        return out
+
+    def batch_evaluate_any(self, coeffs, log_size, which, xs, ext_field=0, out=None):
+        n = which.nwords
+        out = out or self.alloc(4 * n)
+        check(self.lib.zkhip_batch_evaluate_any(self.handle, C.c_void_p(coeffs.ptr), log_size, C.c_void_p(which.ptr), C.c_void_p(xs.ptr),
+                                                C.c_void_p(out.ptr), n, ext_field))
+        return out
+
+    def gather_sample(self, src, idx, size, stride, out=None):
+        out = out or self.alloc(size)
+        check(self.lib.zkhip_gather_sample(self.handle, C.c_void_p(out.ptr), C.c_void_p(src.ptr), idx, size, stride))
+        return out
+
+    def scatter(self, into, index, offsets, values):
+        check(self.lib.zkhip_scatter(self.handle, C.c_void_p(into.ptr), C.c_void_p(index.ptr), C.c_void_p(offsets.ptr), C.c_void_p(values.ptr),
+                                     index.nwords - 1))
+        return into
+
+    def prefix_products_ext(self, io, ext_field=0):
+        check(self.lib.zkhip_prefix_products_ext(self.handle, C.c_void_p(io.ptr), io.nwords // 4, ext_field))
+        return io
+
+    def hash_rows_sha256(self, mat, cols, rows, out=None):
+        out = out or self.alloc(8 * rows)
+        check(self.lib.zkhip_hash_rows_sha256(self.handle, C.c_void_p(mat.ptr), cols, rows, C.c_void_p(out.ptr)))
+        return out
+
+    def hash_fold_sha256(self, children, count, out=None):
+        out = out or self.alloc(8 * count)
+        check(self.lib.zkhip_hash_fold_sha256(self.handle, C.c_void_p(children.ptr), C.c_void_p(out.ptr), count))
+        return out
+
+    def merkle_commit_sha256_colmajor(self, mat, cols, log_rows, out=None):
+        out = out or self.alloc(8 * ((2 << log_rows) - 1))
+        check(self.lib.zkhip_merkle_commit_sha256_colmajor(self.handle, C.c_void_p(mat.ptr), cols, log_rows, C.c_void_p(out.ptr)))
+        return out
+
+    def from_raw(self, words):
+        """upload 32-bit words as they are (indices, digests: no Montgomery conversion)"""
+        a = np.ascontiguousarray(words, dtype=np.uint32)
+        buf = self.alloc(max(a.size, 1))
+        buf.upload_monty(a)
+        return buf
+
     # ---- STARK stages
     def quotient_values(self, lde, log_n, width, alpha, out=None):
         out = out or self.alloc(4 << (log_n + 1))
