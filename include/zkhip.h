@@ -344,6 +344,17 @@ int zkhip_verify_chips(const uint8_t* proof, size_t len, const int32_t* log_ns, 
                        const int32_t* partners, int n_chips,
                        const uint32_t* public_values, size_t n_public, const zkhip_params* prm, int* reason);
 
+/* ---- Poseidon2 parameter tables from a file: the built-in sets are this repo's own
+ * ("zktls-amd/p2-bb16-v1", "...-bb24-v1"; the SP1 / RISC Zero tables of reference Cargo.lock:4030, 6172, 5057 are not
+ * obtainable offline).  zkhip_load_poseidon2_params replaces the width-16 or the width-24 set (the file says which) for the
+ * whole process -- provers, commitments, transcript and verifier alike -- without a rebuild.  File: JSON with "width" (16 | 24),
+ * "name", "external_rc" (8 x width), "internal_rc" (13 | 21), "internal_diag" (width), canonical residues
+ * (tests/golden/poseidon2*_params.json are such files).  Only while NO context exists (zkhip_ctx_destroy everything and
+ * zkhip_release_cached_contexts first): a context uploads the set in effect to its device when it is created. ---- */
+int zkhip_load_poseidon2_params(const char* path);
+int zkhip_reset_poseidon2_params(void);                 /* back to the built-in sets */
+const char* zkhip_poseidon2_params_name(int width);     /* name of the set in effect (thread-local copy) */
+
 /* ---- bincode-shaped form of a shard proof: the serde / bincode structure an upstream verifier
  * deserialises -- p3-uni-stark `Proof { commitments, opened_values, opening_proof: FriProof, degree_bits }` (reference
  * Cargo.lock:4055, 3930), which is what `proof.bytes()` carries at crates/guest-prover-sp1/src/sp1.rs:122-123.  Encoding rule:

@@ -28,6 +28,7 @@ EXPORTS = [
     "zkhip_batch_evaluate_any", "zkhip_gather_sample", "zkhip_scatter", "zkhip_prefix_products_ext", "zkhip_hash_rows_sha256",
     "zkhip_hash_fold_sha256", "zkhip_merkle_commit_sha256_colmajor",
     "zkhip_bincode_size", "zkhip_proof_to_bincode", "zkhip_proof_from_bincode",
+    "zkhip_load_poseidon2_params", "zkhip_reset_poseidon2_params", "zkhip_poseidon2_params_name",
 ]
 
 
@@ -135,6 +136,9 @@ def load():
     L.zkhip_hash_rows_sha256.argtypes = [vp, vp, sz, sz, vp]
     L.zkhip_hash_fold_sha256.argtypes = [vp, vp, vp, sz]
     L.zkhip_merkle_commit_sha256_colmajor.argtypes = [vp, vp, C.c_uint32, C.c_int, vp]
+    L.zkhip_load_poseidon2_params.argtypes = [C.c_char_p]
+    L.zkhip_poseidon2_params_name.restype = C.c_char_p
+    L.zkhip_poseidon2_params_name.argtypes = [C.c_int]
     L.zkhip_bincode_size.restype = C.c_size_t
     L.zkhip_bincode_size.argtypes = [C.c_int, C.c_uint32, C.POINTER(Params)]
     L.zkhip_proof_to_bincode.argtypes = [u8p, C.c_size_t, C.c_int, C.c_uint32, C.POINTER(Params), u8p, C.c_size_t, C.POINTER(C.c_size_t)]

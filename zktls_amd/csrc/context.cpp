@@ -3,6 +3,9 @@
 // Boundary contract: include/zkhip.h.  No CPU fallback: everything here launches gfx950
 // kernels on the context's stream and fails with ZKHIP_ERR_NO_DEVICE without a device.
 #include "context.h"
+#include "poseidon2.cuh"
+
+#include <atomic>
 
 #include <cstdio>
 #include <cstdlib>
@@ -10,6 +13,8 @@
 #include <string>
 
 namespace zk {
+
+extern std::atomic<int> g_live_contexts;       // params.cpp: the Poseidon2 parameter set may only change while this is zero
 
 static thread_local std::string g_last_error;
 
@@ -527,11 +532,12 @@ int zkhip_ctx_create(int device, void* stream, zkhip_ctx** out) {
         return fail(ZKHIP_ERR_NO_DEVICE, std::string("device is ") + prop.gcnArchName + ", libzkhip is built for gfx950 only");
     zkhip_ctx* ctx = new (std::nothrow) zkhip_ctx();
     if (!ctx) return fail(ZKHIP_ERR_NOMEM, "ctx_create: out of host memory");
+    g_live_contexts.fetch_add(1);
     ctx->device = device;
     if (stream) { ctx->stream = (hipStream_t)stream; ctx->own_stream = false; }
     else {
         hipError_t e = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking);
-        if (e != hipSuccess) { delete ctx; return hip_fail(e, "hipStreamCreate"); }
+        if (e != hipSuccess) { delete ctx; g_live_contexts.fetch_sub(1); return hip_fail(e, "hipStreamCreate"); }
         ctx->own_stream = true;
     }
     int rc = ZKHIP_OK;
@@ -542,6 +548,9 @@ int zkhip_ctx_create(int device, void* stream, zkhip_ctx** out) {
         const uint32_t w = two_adic_generator(10);
         if ((e = launch_pow_table(ctx->w1024_fwd, 1024, w, MONTY_R1, ctx->stream)) != hipSuccess) { rc = hip_fail(e, "pow_table"); break; }
         if ((e = launch_pow_table(ctx->w1024_inv, 1024, finv(w), MONTY_R1, ctx->stream)) != hipSuccess) { rc = hip_fail(e, "pow_table"); break; }
+        // the Poseidon2 tables in effect (built-in or zkhip_load_poseidon2_params) go to this device's constant memory
+        if ((e = hash_upload_p2_tables(g_p2_tables, ctx->stream)) != hipSuccess) { rc = hip_fail(e, "upload Poseidon2 tables"); break; }
+        if ((e = stark_upload_p2_tables(g_p2_tables, ctx->stream)) != hipSuccess) { rc = hip_fail(e, "upload Poseidon2 tables"); break; }
         if ((e = hipStreamSynchronize(ctx->stream)) != hipSuccess) { rc = hip_fail(e, "sync"); break; }
     } while (0);
     if (rc != ZKHIP_OK) { zkhip_ctx_destroy(ctx); return rc; }
@@ -562,6 +571,7 @@ void zkhip_ctx_destroy(zkhip_ctx* ctx) {
     for (auto& d : ctx->domains) { (void)hipFree(d.xs); (void)hipFree(d.sel_first); (void)hipFree(d.sel_last); (void)hipFree(d.itw); }
     if (ctx->own_stream && ctx->stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;
+    g_live_contexts.fetch_sub(1);
 }
 
 #define CHECK_CTX(ctx)                                                  \

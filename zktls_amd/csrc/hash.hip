@@ -15,6 +15,8 @@
 
 namespace zk {
 
+hipError_t hash_upload_p2_tables(const P2Tables& t, hipStream_t s) { return p2_upload_tables(t, s); }
+
 __device__ __forceinline__ uint32_t load_virtual(const LeafArgs& a, uint64_t row, uint32_t vc) {
     // concatenation of the rows of up to MAX_LEAF_MATS matrices; control flow is uniform
     uint32_t off = vc;

@@ -99,6 +99,10 @@ hipError_t launch_compress_sub(uint32_t* tree, uint32_t count, uint32_t sub, hip
 hipError_t launch_merkle_p24_colmajor(const uint32_t* mat, uint32_t cols, int log_rows, uint32_t* tree, hipStream_t s);
 // same hash over a row-major matrix (width % 4 == 0, ld % 4 == 0, 16-byte aligned)
 hipError_t launch_merkle_p24_rowmajor(const uint32_t* mat, uint64_t ld, uint32_t width, int log_rows, uint32_t* tree, hipStream_t s);
+// upload the Poseidon2 tables in effect (params.cpp) into the __constant__ copy of hash.hip / stark.hip on the current device
+struct P2Tables;
+hipError_t hash_upload_p2_tables(const P2Tables& t, hipStream_t s);
+hipError_t stark_upload_p2_tables(const P2Tables& t, hipStream_t s);
 // raw permutation on `count` states of 16 words (KAT / microbenchmark)
 hipError_t launch_permute_states(uint32_t* states, uint64_t count, hipStream_t s);
 

@@ -17,6 +17,9 @@
 
 namespace zk {
 
+hipError_t stark_upload_p2_tables(const P2Tables& t, hipStream_t s) { return p2_upload_tables(t, s); }
+
+
 ZK_D Ext ld_ext(const uint32_t* p) {
     uint4 v = *reinterpret_cast<const uint4*>(p);
     return Ext{{v.x, v.y, v.z, v.w}};
