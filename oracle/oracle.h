@@ -197,6 +197,18 @@ void orc_hal_prefix_products_ext(uint32_t* io, size_t n, uint32_t ext_w);
 void orc_hal_hash_rows_sha256(const uint32_t* mat, size_t cols, size_t rows, uint32_t* digests);
 void orc_hal_hash_fold_sha256(const uint32_t* children, uint32_t* parents, size_t count);
 
+/* ---- constraint programs: the AIR as data (oracle/air.c; format in its header comment) ---- */
+int orc_air_validate(const uint32_t* prog, size_t words, size_t width, size_t n_public);
+void orc_air_digest(const uint32_t* prog, size_t words, uint32_t out[8]);
+size_t orc_air_synthetic(size_t width, size_t n_public, uint32_t* out, size_t cap);
+void orc_quotient_values_air(const uint32_t* prog, const uint32_t* lde, int log_n, size_t width, const uint32_t* pub,
+                             const uint32_t alpha[4], uint32_t* out);
+size_t orc_proof_size_air(int log_n, size_t width, const orc_params_t* prm, size_t n_public);
+size_t orc_prove_shard_air(const uint32_t* prog, size_t prog_words, const uint32_t* trace, int log_n, size_t width,
+                           const uint32_t* public_values, size_t n_public, const orc_params_t* prm, uint8_t* proof_bytes, size_t cap);
+int orc_verify_shard_air(const uint32_t* prog, size_t prog_words, const uint8_t* proof_bytes, size_t len, int log_n, size_t width,
+                         const uint32_t* public_values, size_t n_public, const orc_params_t* prm);
+
 #ifdef __cplusplus
 }
 #endif

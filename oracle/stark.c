@@ -395,6 +395,10 @@ void orc_fri_fold_k(const uint32_t* in, int log_h, int log_arity, const uint32_t
 /* ------------------------------------------------------------------ */
 /* proof layout (all words little-endian u32, canonical residues)       */
 /* ------------------------------------------------------------------ */
+/* constraint program in effect for the current prove / verify call (orc_prove_shard_air, orc_verify_shard_air); NULL: the
+ * built-in synthetic AIR.  With a program the proof is version 7: extended header, then the 8-word program digest. */
+static __thread const uint32_t* g_air = NULL;
+static __thread size_t g_air_words = 0;
 #define PROOF_MAGIC 0x41544B5Au   /* "ZKTA" */
 #define PROOF_VERSION 1u
 
@@ -421,7 +425,7 @@ size_t orc_proof_size(int log_n, size_t width, const orc_params_t* prm, size_t n
     if (!shape_of(log_n, width, prm, &sh)) return 0;
     size_t H = (size_t)(log_n + sh.b);
     size_t Q = (size_t)prm->logup_pairs, wp = Q ? 4 * (Q + 1) : 0;
-    size_t words = (sh.ext ? 12 : (Q ? 9 : 8)) + 16 + 8 * width + 32 + 8 * (size_t)sh.R + 4 * ((size_t)1 << sh.F) + 1;
+    size_t words = (g_air ? 20 : (sh.ext ? 12 : (Q ? 9 : 8))) + 16 + 8 * width + 32 + 8 * (size_t)sh.R + 4 * ((size_t)1 << sh.F) + 1;
     size_t perq = width + 8 + 16 * H;
     if (Q) { words += 8 + 8 * wp; perq += wp + 8 * H; }
     for (int l = 0; l < sh.R; l++) perq += 4 * (((size_t)1 << sh.K) - 1) + 8 * (H - (size_t)sh.K * (l + 1));
@@ -443,12 +447,17 @@ static void transcript_init(orc_challenger_t* ch, int log_n, size_t width,
     orc_chal_observe(ch, (uint32_t)prm->num_queries);
     orc_chal_observe(ch, (uint32_t)prm->pow_bits);
     orc_chal_observe(ch, (uint32_t)n_public);
-    if (sh->ext) {
+    if (sh->ext || g_air) {
         orc_chal_observe(ch, (uint32_t)prm->logup_pairs);
         orc_chal_observe(ch, (uint32_t)sh->K);
         orc_chal_observe(ch, (uint32_t)sh->F);
         orc_chal_observe(ch, (uint32_t)sh->hw);
     } else if (prm->logup_pairs) orc_chal_observe(ch, (uint32_t)prm->logup_pairs);
+    if (g_air) {
+        uint32_t dg[8];
+        orc_air_digest(g_air, g_air_words, dg);
+        orc_chal_observe_slice(ch, dg, 8);
+    }
 }
 
 /* one committed FRI layer folds a row of 2^K adjacent (bit-reversed) entries, K times by 2 with
@@ -491,12 +500,13 @@ size_t orc_prove_shard(const uint32_t* trace, int log_n, size_t width,
     const int H = log_n + sh.b, Hq = log_n + 1, Q = prm->logup_pairs;      /* LDE domain 2^H, quotient domain 2^Hq */
     const size_t n = (size_t)1 << log_n, m = (size_t)1 << H, mq = (size_t)1 << Hq, wp = Q ? 4 * ((size_t)Q + 1) : 0;
 
-    pf[pos++] = PROOF_MAGIC; pf[pos++] = sh.ext ? 3u : (Q ? 2u : PROOF_VERSION); pf[pos++] = (uint32_t)log_n;
+    pf[pos++] = PROOF_MAGIC; pf[pos++] = g_air ? 7u : (sh.ext ? 3u : (Q ? 2u : PROOF_VERSION)); pf[pos++] = (uint32_t)log_n;
     pf[pos++] = (uint32_t)width; pf[pos++] = (uint32_t)prm->log_blowup;
     pf[pos++] = (uint32_t)prm->num_queries; pf[pos++] = (uint32_t)prm->pow_bits;
     pf[pos++] = (uint32_t)n_public;
-    if (sh.ext) { pf[pos++] = (uint32_t)Q; pf[pos++] = (uint32_t)sh.K; pf[pos++] = (uint32_t)sh.F; pf[pos++] = (uint32_t)sh.hw; }
+    if (sh.ext || g_air) { pf[pos++] = (uint32_t)Q; pf[pos++] = (uint32_t)sh.K; pf[pos++] = (uint32_t)sh.F; pf[pos++] = (uint32_t)sh.hw; }
     else if (Q) pf[pos++] = (uint32_t)Q;
+    if (g_air) { orc_air_digest(g_air, g_air_words, pf + pos); pos += 8; }
 
     orc_challenger_t ch;
     transcript_init(&ch, log_n, width, prm, n_public, &sh);
@@ -536,7 +546,8 @@ size_t orc_prove_shard(const uint32_t* trace, int log_n, size_t width,
     /* The quotient domain g*<w_2N> is the first 2N rows of the bit-reversed LDE on g*<w_{2^H}>, in the
      * bit-reversed order of its own 2N points -- so the blowup-2 routine applies to those rows as is. */
     uint32_t* qv = (uint32_t*)malloc(mq * 16);         /* bit-reversed like the LDE */
-    orc_quotient_values_logup(tlde, log_n, width, plde, Q, gamma.c, beta_l.c, alpha.c, qv);
+    if (g_air) orc_quotient_values_air(g_air, tlde, log_n, width, public_values, alpha.c, qv);
+    else orc_quotient_values_logup(tlde, log_n, width, plde, Q, gamma.c, beta_l.c, alpha.c, qv);
     /* chunk k = natural rows i = 2j + k  <->  bit-reversed rows [k*N, (k+1)*N);
      * as a matrix on the coset (g w^k) * <w_N> in natural order j: */
     uint32_t* qlde = (uint32_t*)malloc(m * 8 * 4);     /* [chunk0 | chunk1], width 8 */
@@ -719,15 +730,21 @@ int orc_verify_shard(const uint8_t* proof_bytes, size_t len, int log_n, size_t w
     size_t pos = 0;
     const int H = log_n + sh.b, Hq = log_n + 1, R = sh.R, K = sh.K, Q = prm->logup_pairs;
     const size_t n = (size_t)1 << log_n, wp = Q ? 4 * ((size_t)Q + 1) : 0, arity = (size_t)1 << K;
-    if (pf[0] != PROOF_MAGIC || pf[1] != (sh.ext ? 3u : (Q ? 2u : PROOF_VERSION)) || pf[2] != (uint32_t)log_n ||
+    if (pf[0] != PROOF_MAGIC || pf[1] != (g_air ? 7u : (sh.ext ? 3u : (Q ? 2u : PROOF_VERSION))) || pf[2] != (uint32_t)log_n ||
         pf[3] != (uint32_t)width || pf[4] != (uint32_t)prm->log_blowup ||
         pf[5] != (uint32_t)prm->num_queries || pf[6] != (uint32_t)prm->pow_bits ||
         pf[7] != (uint32_t)n_public) return 3;
     pos = 8;
-    if (sh.ext) {
+    if (sh.ext || g_air) {
         if (pf[8] != (uint32_t)Q || pf[9] != (uint32_t)sh.K || pf[10] != (uint32_t)sh.F || pf[11] != (uint32_t)sh.hw) return 3;
         pos = 12;
     } else if (Q) { if (pf[8] != (uint32_t)Q) return 3; pos = 9; }
+    if (g_air) {
+        uint32_t dg[8];
+        orc_air_digest(g_air, g_air_words, dg);
+        if (memcmp(dg, pf + pos, 32) != 0) return 3;
+        pos += 8;
+    }
     for (size_t i = pos; i < len / 4; i++) if (pf[i] >= BB_P) return 4;   /* canonical words only */
 
     orc_challenger_t ch;
@@ -768,7 +785,8 @@ int orc_verify_shard(const uint8_t* proof_bytes, size_t len, int log_n, size_t w
         bb4_t zh = bb4_sub_base(zn, 1);
         bb4_t sel_first = bb4_mul(zh, bb4_inv(bb4_sub_base(zeta, 1)));
         bb4_t sel_trans = bb4_sub_base(zeta, bb_inv(gn));
-        bb4_t folded = fold_constraints_ext(loc, nxt, width, sel_first, sel_trans, alpha);
+        bb4_t folded = g_air ? orc__air_fold_ext(g_air, loc, nxt, public_values, sel_first, bb4_mul(zh, bb4_inv(bb4_sub_base(zeta, bb_inv(gn)))), sel_trans, alpha)
+                             : fold_constraints_ext(loc, nxt, width, sel_first, sel_trans, alpha);
         if (Q) {
             bb4_t sel_last = bb4_mul(zh, bb4_inv(bb4_sub_base(zeta, bb_inv(gn))));
             bb4_t as[64], bs[64], ar[64], br[64], pl[65], pn[65];
@@ -880,4 +898,32 @@ int orc_verify_shard(const uint8_t* proof_bytes, size_t len, int log_n, size_t w
     free(fapow); free(betas);
     if (rc == 0 && pos * 4 != len) rc = 5;
     return rc;
+}
+
+/* ------------------------------------------------------------------ */
+/* the same prover / verifier with the AIR supplied as a constraint program (oracle/air.c); proof version 7 */
+/* ------------------------------------------------------------------ */
+size_t orc_proof_size_air(int log_n, size_t width, const orc_params_t* prm, size_t n_public) {
+    static const uint32_t marker[1] = {0};
+    const uint32_t* saved = g_air;
+    g_air = marker;
+    size_t r = prm->logup_pairs ? 0 : orc_proof_size(log_n, width, prm, n_public);
+    g_air = saved;
+    return r;
+}
+size_t orc_prove_shard_air(const uint32_t* prog, size_t prog_words, const uint32_t* trace, int log_n, size_t width,
+                           const uint32_t* public_values, size_t n_public, const orc_params_t* prm, uint8_t* proof_bytes, size_t cap) {
+    if (prm->logup_pairs || !orc_air_validate(prog, prog_words, width, n_public)) return 0;
+    g_air = prog; g_air_words = prog_words;
+    size_t r = orc_prove_shard(trace, log_n, width, public_values, n_public, prm, proof_bytes, cap);
+    g_air = NULL; g_air_words = 0;
+    return r;
+}
+int orc_verify_shard_air(const uint32_t* prog, size_t prog_words, const uint8_t* proof_bytes, size_t len, int log_n, size_t width,
+                         const uint32_t* public_values, size_t n_public, const orc_params_t* prm) {
+    if (prm->logup_pairs || !orc_air_validate(prog, prog_words, width, n_public)) return 1;
+    g_air = prog; g_air_words = prog_words;
+    int r = orc_verify_shard(proof_bytes, len, log_n, width, public_values, n_public, prm);
+    g_air = NULL; g_air_words = 0;
+    return r;
 }

@@ -13,4 +13,9 @@ bb4_t orc__recombine(const uint32_t* opened4);
 bb4_t orc__fold_logup(bb4_t acc, int pairs, const bb4_t* as, const bb4_t* bs, const bb4_t* ar, const bb4_t* br,
                      const bb4_t* perm_local, const bb4_t* perm_next, bb4_t gamma, bb4_t beta,
                      bb4_t sel_first, bb4_t sel_trans, bb4_t sel_last, bb4_t alpha, bb4_t cumsum);
+/* constraint programs (oracle/air.c) */
+bb4_t orc__air_fold_base(const uint32_t* prog, const uint32_t* local, const uint32_t* next, const uint32_t* pub,
+                         bb_t sel_first, bb_t sel_last, bb_t sel_trans, bb4_t alpha);
+bb4_t orc__air_fold_ext(const uint32_t* prog, const bb4_t* local, const bb4_t* next, const uint32_t* pub,
+                        bb4_t sel_first, bb4_t sel_last, bb4_t sel_trans, bb4_t alpha);
 #endif

@@ -1,0 +1,53 @@
+"""Constraint programs (the AIR as data) used by the tests, and host-side trace generators for them."""
+import numpy as np
+
+import oracle_lib as O
+
+P = O.P
+V = O.air_var
+
+
+def fibonacci_program():
+    """4 columns (a, b, c, s): a' = b, b' = a + b on transitions; c = a b s and s (s - 1) = 0 on every row;
+    a, b of the first row and b of the last row are public values 0, 1, 2"""
+    return O.air_program(4, 3, [
+        (O.SEL_TRANSITION, [(1, [V(0, True)]), (P - 1, [V(1)])]),
+        (O.SEL_TRANSITION, [(1, [V(1, True)]), (P - 1, [V(0)]), (P - 1, [V(1)])]),
+        (O.SEL_ALL, [(1, [V(2)]), (P - 1, [V(0), V(1), V(3)])]),
+        (O.SEL_ALL, [(1, [V(3), V(3)]), (P - 1, [V(3)])]),
+        (O.SEL_FIRST, [(1, [V(0)]), (P - 1, [V(0, public=True)])]),
+        (O.SEL_FIRST, [(1, [V(1)]), (P - 1, [V(1, public=True)])]),
+        (O.SEL_LAST, [(1, [V(1)]), (P - 1, [V(2, public=True)])]),
+    ])
+
+
+def fibonacci_trace(log_n, a0, b0):
+    n = 1 << log_n
+    t = np.zeros((n, 4), dtype=np.uint64)
+    a, b = a0 % P, b0 % P
+    for i in range(n):
+        s = i & 1
+        t[i] = [a, b, a * b * s % P, s]
+        a, b = b, (a + b) % P
+    t = t.astype(np.uint32)
+    return t, [a0 % P, b0 % P, int(t[-1, 1])]
+
+
+def counter_program(width):
+    """`width` columns (multiple of 4): column 0 counts rows from public value 0 in steps of public value 1, every other column
+    j holds (column 0)^2 * j + column (j - 1) -- a wide degree-3 AIR with a running dependency between columns"""
+    cons = [(O.SEL_FIRST, [(1, [V(0)]), (P - 1, [V(0, public=True)])]),
+            (O.SEL_TRANSITION, [(1, [V(0, True)]), (P - 1, [V(0)]), (P - 1, [V(1, public=True)])])]
+    for j in range(1, width):
+        cons.append((O.SEL_ALL, [(1, [V(j)]), (P - j, [V(0), V(0)]), (P - 1, [V(j - 1)])]))
+    return O.air_program(width, 2, cons)
+
+
+def counter_trace(log_n, width, start, step):
+    n = 1 << log_n
+    t = np.zeros((n, width), dtype=np.uint64)
+    x = (start + step * np.arange(n, dtype=np.uint64)) % P
+    t[:, 0] = x
+    for j in range(1, width):
+        t[:, j] = (x * x % P * j + t[:, j - 1]) % P
+    return t.astype(np.uint32), [start % P, step % P]

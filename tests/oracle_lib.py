@@ -488,3 +488,78 @@ def hal_hash_fold_sha256(children):
     out = np.empty(8 * count, dtype=np.uint32)
     lib().orc_hal_hash_fold_sha256(_p(ch), _p(out), C.c_size_t(count))
     return out.reshape(count, 8)
+
+
+# ---- constraint programs: the AIR as data (oracle/air.c)
+AIR_MAGIC = 0x50524941
+SEL_ALL, SEL_FIRST, SEL_LAST, SEL_TRANSITION = 0, 1, 2, 3
+
+
+def air_var(col, next_row=False, public=False):
+    return (2 << 30 | col) if public else ((1 << 30 | col) if next_row else col)
+
+
+def air_program(width, n_public, constraints):
+    """constraints: [(selector, [(coeff, [vars...]), ...]), ...] -> flat u32 program"""
+    body = []
+    for sel, terms in constraints:
+        body += [sel, len(terms)]
+        for coeff, vs in terms:
+            body += [coeff % P, len(vs)] + list(vs)
+    words = 6 + len(body)
+    return np.array([AIR_MAGIC, 1, width, len(constraints), n_public, words] + body, dtype=np.uint32)
+
+
+def air_synthetic(width, n_public):
+    out = np.empty(6 + (width // 4) * 33, dtype=np.uint32)
+    lib().orc_air_synthetic.restype = C.c_size_t
+    n = lib().orc_air_synthetic(C.c_size_t(width), C.c_size_t(n_public), _p(out), C.c_size_t(out.size))
+    assert n == out.size
+    return out
+
+
+def air_validate(prog, width, n_public):
+    prog = _u32(prog)
+    return int(lib().orc_air_validate(_p(prog), C.c_size_t(prog.size), C.c_size_t(width), C.c_size_t(n_public)))
+
+
+def air_digest(prog):
+    prog = _u32(prog)
+    out = np.empty(8, dtype=np.uint32)
+    lib().orc_air_digest(_p(prog), C.c_size_t(prog.size), _p(out))
+    return out
+
+
+def quotient_values_air(prog, lde, log_n, public_values, alpha):
+    lde, prog = _u32(lde), _u32(prog)
+    pv = _u32(np.array(list(public_values) or [0], dtype=np.uint32))
+    out = np.empty((2 << log_n, 4), dtype=np.uint32)
+    lib().orc_quotient_values_air(_p(prog), _p(lde), C.c_int(log_n), C.c_size_t(lde.shape[1]), _p(pv), _p(_u32(alpha)), _p(out))
+    return out
+
+
+def prove_shard_air(prog, trace, public_values=(), params=None):
+    params = params or default_params()
+    t, prog = _u32(trace), _u32(prog)
+    n, w = t.shape
+    log_n = n.bit_length() - 1
+    pv = _u32(np.array(list(public_values) or [0], dtype=np.uint32))
+    npub = len(public_values)
+    L = lib()
+    L.orc_proof_size_air.restype = C.c_size_t
+    L.orc_prove_shard_air.restype = C.c_size_t
+    size = L.orc_proof_size_air(C.c_int(log_n), C.c_size_t(w), C.byref(params), C.c_size_t(npub))
+    buf = np.empty(size, dtype=np.uint8)
+    got = L.orc_prove_shard_air(_p(prog), C.c_size_t(prog.size), _p(t), C.c_int(log_n), C.c_size_t(w), _p(pv), C.c_size_t(npub), C.byref(params),
+                                buf.ctypes.data_as(C.POINTER(C.c_uint8)), C.c_size_t(size))
+    if got != size or size == 0:
+        raise RuntimeError("oracle prove_shard_air failed (trace violates the program, or bad program)")
+    return buf
+
+
+def verify_shard_air(prog, proof, log_n, width, public_values=(), params=None):
+    params = params or default_params()
+    pr, prog = np.ascontiguousarray(proof, dtype=np.uint8), _u32(prog)
+    pv = _u32(np.array(list(public_values) or [0], dtype=np.uint32))
+    return int(lib().orc_verify_shard_air(_p(prog), C.c_size_t(prog.size), pr.ctypes.data_as(C.POINTER(C.c_uint8)), C.c_size_t(pr.size),
+                                          C.c_int(log_n), C.c_size_t(width), _p(pv), C.c_size_t(len(public_values)), C.byref(params)))

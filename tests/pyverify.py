@@ -102,9 +102,48 @@ class Transcript:
 
 
 # ---------------------------------------------------------------- the verifier
+AIR_MAGIC = 0x50524941         # "AIRP": a constraint program (the AIR as data)
+
+
+def air_digest(program):
+    """width-16 sponge over the 16-bit halves of every program word"""
+    limbs = []
+    for wd in program:
+        limbs += [int(wd) & 0xFFFF, int(wd) >> 16]
+    return pyref.sponge_hash(limbs)
+
+
+def air_fold(program, loc, nxt, public_values, sel_first, sel_last, sel_trans, alpha):
+    """acc = acc * alpha + selector * sum_t coeff_t * prod_j var_tj, constraint by constraint, on extension values"""
+    prog = [int(x) for x in program]
+    if prog[0] != AIR_MAGIC or prog[1] != 1 or prog[5] != len(prog):
+        raise Reject("constraint program")
+    acc, p = ZERO, 6
+    for _ in range(prog[3]):
+        sel, nt = prog[p], prog[p + 1]
+        p += 2
+        c = ZERO
+        for _t in range(nt):
+            prod, d = e_base(prog[p]), prog[p + 1]
+            p += 2
+            for _j in range(d):
+                v = prog[p]
+                p += 1
+                kind, idx = v >> 30, v & 0xFFFF
+                prod = ext_mul(prod, loc[idx] if kind == 0 else (nxt[idx] if kind == 1 else e_base(public_values[idx])))
+            c = e_add(c, prod)
+        if sel:
+            c = ext_mul(c, {1: sel_first, 2: sel_last, 3: sel_trans}[sel])
+        acc = e_add(ext_mul(acc, alpha), c)
+    if p != len(prog):
+        raise Reject("constraint program")
+    return acc
+
+
 def verify(proof_bytes, log_n, width, public_values, log_blowup=1, num_queries=100, pow_bits=16, logup_pairs=0,
-           log_fold=0, log_final=0, hash_width=0):
-    """raises Reject(reason) or returns True.  Parameter defaults = the SP1 shape."""
+           log_fold=0, log_final=0, hash_width=0, air=None):
+    """raises Reject(reason) or returns True.  Parameter defaults = the SP1 shape.
+    air: a constraint program (u32 words) replacing the built-in synthetic AIR (proof version 7)."""
     if len(proof_bytes) % 4:
         raise Reject("length")
     w = list(struct.unpack("<%dI" % (len(proof_bytes) // 4), bytes(proof_bytes)))
@@ -123,12 +162,16 @@ def verify(proof_bytes, log_n, width, public_values, log_blowup=1, num_queries=1
     hasher = Hash(hw)
 
     # ---- header
-    version = 1 if default_shape and not Q else (2 if default_shape else 3)
+    version = 7 if air is not None else (1 if default_shape and not Q else (2 if default_shape else 3))
     head = [MAGIC, version, log_n, width, b, num_queries, pow_bits, len(public_values)]
-    if version == 3:
+    if version in (3, 7):
         head += [Q, K, F, hw]
     elif version == 2:
         head += [Q]
+    if air is not None:
+        if Q:
+            raise Reject("a constraint program excludes the built-in lookup argument")
+        head += air_digest(air)
     if w[:len(head)] != head:
         raise Reject("header")
     pos = len(head)
@@ -184,7 +227,9 @@ def verify(proof_bytes, log_n, width, public_values, log_blowup=1, num_queries=1
     def fold(c):
         nonlocal acc
         acc = e_add(ext_mul(acc, alpha), c)
-    for g in range(width // 4):
+    if air is not None:
+        acc = air_fold(air, loc, nxt, public_values, sel_first, sel_last, sel_trans, alpha)
+    for g in range(width // 4 if air is None else 0):
         a, bb, c, d, dn = loc[4 * g], loc[4 * g + 1], loc[4 * g + 2], loc[4 * g + 3], nxt[4 * g + 3]
         fold(e_sub(e_sub(c, ext_mul(ext_mul(a, a), bb)), e_base(g + 1)))
         fold(ext_mul(sel_trans, e_sub(e_sub(e_sub(dn, ext_mul(a, bb)), c), e_base(2 * g + 3))))

@@ -1,0 +1,70 @@
+"""The AIR as data on the device: the quotient kernel that INTERPRETS a constraint program (stark.hip, quotient_air_kernel) and
+whole proofs against programs (zkhip_prove_shard_air), byte for byte against the oracle (oracle/air.c)."""
+import numpy as np
+import pytest
+
+import airs
+import pyverify
+from zktls_amd._lib import Params, ZkHipError
+from zktls_amd.device import air_synthetic, verify_shard, verify_shard_air
+
+pytestmark = pytest.mark.gpu
+P = 2013265921
+SEED = 0x5A4B544C53
+
+
+@pytest.mark.parametrize("log_n,width", [(5, 4), (8, 8), (10, 24), (12, 64), (14, 256)])
+def test_interpreted_synthetic_program_equals_the_specialised_kernel_and_the_oracle(ctx, oracle, log_n, width):
+    prog = air_synthetic(width, 3)
+    trace = ctx.gen_trace(SEED, 4, log_n, width)
+    lde = ctx.coset_lde(trace, log_n, width)
+    alpha = [11, 22, 33, 44]
+    got = ctx.quotient_values_air(prog, lde, log_n, width, [1, 2, 3], alpha).download().reshape(-1, 4)
+    assert (got == ctx.quotient_values(lde, log_n, width, alpha).download().reshape(-1, 4)).all()
+    olde = lde.download().reshape(-1, width)
+    assert (got == oracle.quotient_values_air(prog, olde, log_n, [1, 2, 3], alpha)).all()
+
+
+@pytest.mark.parametrize("shape", [(1, 12, 6, 0, 0, 0, 0), (2, 8, 0, 0, 4, 2, 24), (3, 6, 4, 0, 1, 0, 16)])
+def test_program_proofs_equal_the_oracles_bytes(ctx, oracle, shape):
+    prm, oprm = Params(*shape), oracle.default_params(*shape)
+    log_n = 10
+    cases = []
+    t, pub = airs.fibonacci_trace(log_n, 3, 5)
+    cases.append((airs.fibonacci_program(), t, pub, 4))
+    t, pub = airs.counter_trace(log_n, 16, 1234, 7)
+    cases.append((airs.counter_program(16), t, pub, 16))
+    cases.append((air_synthetic(32, 1), oracle.gen_trace(SEED, 2, log_n, 32), [9], 32))
+    for prog, trace, pub, width in cases:
+        proof = ctx.prove_shard_air(prog, ctx.from_numpy(trace), log_n, width, pub, prm)
+        assert proof.tobytes() == oracle.prove_shard_air(prog, trace, pub, oprm).tobytes()
+        assert verify_shard_air(prog, proof, log_n, width, pub, prm) == (0, 0)
+        assert pyverify.verify(proof.tobytes(), log_n, width, pub, *shape, air=prog) is True
+        assert verify_shard(proof, log_n, width, pub, prm)[0] == -6          # not a proof of the built-in AIR (version, digest)
+
+
+def test_program_proof_at_2_pow_18_rows(ctx, oracle):
+    log_n, width = 18, 32
+    prog = airs.counter_program(width)
+    t, pub = airs.counter_trace(log_n, width, 5, 3)
+    prm = Params(1, 40, 10)
+    proof = ctx.prove_shard_air(prog, ctx.from_numpy(t), log_n, width, pub, prm)
+    assert verify_shard_air(prog, proof, log_n, width, pub, prm) == (0, 0)
+    assert oracle.verify_shard_air(prog, proof, log_n, width, pub, oracle.default_params(1, 40, 10)) == 0
+    t[1000, 5] = (int(t[1000, 5]) + 1) % P                                  # one wrong cell: no accepted proof
+    try:
+        bad = ctx.prove_shard_air(prog, ctx.from_numpy(t), log_n, width, pub, prm)
+    except ZkHipError:
+        return
+    assert verify_shard_air(prog, bad, log_n, width, pub, prm)[0] == -6
+
+
+def test_bad_programs_fail_loudly(ctx):
+    prog = airs.fibonacci_program()
+    trace = ctx.alloc(4 << 6)
+    with pytest.raises(ZkHipError):
+        ctx.prove_shard_air(prog[:-1], trace, 6, 4, [1, 2, 3], Params(1, 6, 4))
+    with pytest.raises(ZkHipError):
+        ctx.prove_shard_air(prog, trace, 6, 4, [1, 2], Params(1, 6, 4))       # n_public does not match the program
+    with pytest.raises(ZkHipError):
+        ctx.prove_shard_air(prog, trace, 6, 4, [1, 2, 3], Params(1, 6, 4, 1))  # lookups belong to the built-in AIR

@@ -29,6 +29,8 @@ EXPORTS = [
     "zkhip_hash_fold_sha256", "zkhip_merkle_commit_sha256_colmajor",
     "zkhip_bincode_size", "zkhip_proof_to_bincode", "zkhip_proof_from_bincode",
     "zkhip_load_poseidon2_params", "zkhip_reset_poseidon2_params", "zkhip_poseidon2_params_name",
+    "zkhip_air_validate", "zkhip_air_digest", "zkhip_air_synthetic", "zkhip_proof_size_air", "zkhip_prove_shard_air", "zkhip_verify_shard_air",
+    "zkhip_quotient_values_air",
 ]
 
 
@@ -136,6 +138,15 @@ def load():
     L.zkhip_hash_rows_sha256.argtypes = [vp, vp, sz, sz, vp]
     L.zkhip_hash_fold_sha256.argtypes = [vp, vp, vp, sz]
     L.zkhip_merkle_commit_sha256_colmajor.argtypes = [vp, vp, C.c_uint32, C.c_int, vp]
+    L.zkhip_air_validate.argtypes = [u32p, C.c_size_t, C.c_uint32, C.c_size_t]
+    L.zkhip_air_digest.argtypes = [u32p, C.c_size_t, u32p]
+    L.zkhip_air_synthetic.argtypes = [C.c_uint32, C.c_size_t, u32p, C.c_size_t, C.POINTER(C.c_size_t)]
+    L.zkhip_proof_size_air.restype = C.c_size_t
+    L.zkhip_proof_size_air.argtypes = [C.c_int, C.c_uint32, C.POINTER(Params), C.c_size_t]
+    L.zkhip_prove_shard_air.argtypes = [C.c_void_p, u32p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_int, C.c_uint32, u32p, C.c_size_t,
+                                        C.POINTER(Params), u8p, C.c_size_t, C.POINTER(C.c_size_t)]
+    L.zkhip_verify_shard_air.argtypes = [u32p, C.c_size_t, u8p, C.c_size_t, C.c_int, C.c_uint32, u32p, C.c_size_t, C.POINTER(Params), C.POINTER(C.c_int)]
+    L.zkhip_quotient_values_air.argtypes = [C.c_void_p, u32p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_int, C.c_uint32, u32p, C.c_size_t, u32p, C.c_void_p]
     L.zkhip_load_poseidon2_params.argtypes = [C.c_char_p]
     L.zkhip_poseidon2_params_name.restype = C.c_char_p
     L.zkhip_poseidon2_params_name.argtypes = [C.c_int]

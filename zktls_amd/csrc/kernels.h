@@ -151,6 +151,20 @@ struct QuotientArgs {
 };
 hipError_t launch_quotient(const QuotientArgs& a, hipStream_t s);
 
+// quotient values of a constraint PROGRAM (air.h): the interpreter form of launch_quotient for an AIR supplied as data.
+struct QuotientAirArgs {
+    const uint32_t* lde; uint64_t ld; uint32_t width; int log_n;
+    const uint32_t* xs; const uint32_t* sel_first; const uint32_t* sel_last;
+    uint32_t wn_inv, inv_zh_even, inv_zh_odd;
+    const uint32_t* body;       // device: program body, Montgomery coefficients (air_device_image)
+    uint32_t n_constraints;
+    const uint32_t* weights;    // device: [K] extension weights alpha^(K-1-k)
+    const uint32_t* pub;        // device: public values, Montgomery
+    uint32_t* out;              // [2][N][4] natural chunk order, as launch_quotient
+    uint32_t* lde_out; uint64_t lde_ld;
+};
+hipError_t launch_quotient_air(const QuotientAirArgs& a, hipStream_t s);
+
 // out[k][p] = 1 / (x_p - z_k), k < npoints (<= 2), p < count; xw (optional): xw[k][p] = x_p / (x_p - z_k), p < xw_count
 hipError_t launch_inv_denominators(const uint32_t* xs, uint64_t count, const Ext& z0, const Ext& z1, int npoints,
                                    uint32_t* out, uint32_t* xw, uint64_t xw_count, hipStream_t s);

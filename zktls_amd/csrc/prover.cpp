@@ -16,6 +16,7 @@
 
 #include "context.h"
 #include "poseidon2.cuh"
+#include "air.h"
 
 namespace zk {
 
@@ -63,13 +64,26 @@ static bool shape_of(int log_n, const zkhip_params* prm, Shape& sh) {
     return true;
 }
 
-static void transcript_init(Challenger& ch, int log_n, uint32_t width, const zkhip_params* prm, size_t n_public, const Shape& sh) {
+// `air`: the constraint program in effect (air.h) or null for the built-in synthetic AIR.  With a program the header always has
+// the extended form and the 8-word program digest follows it (proof version 7), all of it observed.
+static void transcript_init(Challenger& ch, int log_n, uint32_t width, const zkhip_params* prm, size_t n_public, const Shape& sh,
+                            const AirView* air = nullptr) {
     ch.observe_canonical((uint32_t)log_n);
     ch.observe_canonical(width);
     ch.observe_canonical((uint32_t)prm->log_blowup);
     ch.observe_canonical((uint32_t)prm->num_queries);
     ch.observe_canonical((uint32_t)prm->pow_bits);
     ch.observe_canonical((uint32_t)n_public);
+    if (air) {
+        ch.observe_canonical((uint32_t)prm->logup_pairs);
+        ch.observe_canonical((uint32_t)sh.K);
+        ch.observe_canonical((uint32_t)sh.F);
+        ch.observe_canonical((uint32_t)sh.hw);
+        uint32_t dg[8];
+        air_digest(*air, dg);
+        for (int i = 0; i < 8; i++) ch.observe_canonical(dg[i]);
+        return;
+    }
     if (sh.ext) {
         ch.observe_canonical((uint32_t)prm->logup_pairs);
         ch.observe_canonical((uint32_t)sh.K);
@@ -166,6 +180,37 @@ static int run_quotient(zkhip_ctx* ctx, const uint32_t* lde, size_t ld, int log_
     q.out = out_chunks;
     q.lde_out = lde_out; q.lde_ld = lde_ld;
     ZK_HIP(launch_quotient(q, ctx->stream));
+    return ZKHIP_OK;
+}
+
+// quotient values of a constraint program (air.h): the interpreter kernel, same outputs as run_quotient
+static int run_quotient_air(zkhip_ctx* ctx, const AirView& air, const uint32_t* lde, size_t ld, int log_n, uint32_t width,
+                            const uint32_t* public_values, const Ext& alpha, uint32_t* out_chunks, uint32_t* lde_out, size_t lde_ld) {
+    if (ctx->dom_log_n != log_n) ZK_TRY(ensure_domain(ctx, log_n));
+    std::vector<uint32_t> body, weights;
+    air_device_image(air, alpha, body, weights);
+    std::vector<uint32_t> pub(air.n_public ? air.n_public : 1, 0u);
+    for (uint32_t i = 0; i < air.n_public; i++) pub[i] = to_monty(public_values[i]);
+    // one staging buffer: body | weights (16-byte aligned) | public values
+    const size_t body_w = (body.size() + 3) & ~(size_t)3;
+    std::vector<uint32_t> stage(body_w + weights.size() + pub.size(), 0u);
+    memcpy(stage.data(), body.data(), body.size() * 4);
+    memcpy(stage.data() + body_w, weights.data(), weights.size() * 4);
+    memcpy(stage.data() + body_w + weights.size(), pub.data(), pub.size() * 4);
+    void* d_stage;
+    ZK_TRY(ctx_reserve(ctx, S_APOW_Q, stage.size() * 4, &d_stage));
+    ZK_TRY(h2d(ctx, d_stage, stage.data(), stage.size() * 4));
+    QuotientAirArgs q{};
+    q.lde = lde; q.ld = ld; q.width = width; q.log_n = log_n;
+    q.xs = ctx->dom_xs; q.sel_first = ctx->dom_sel_first; q.sel_last = ctx->dom_sel_last;
+    q.wn_inv = finv(two_adic_generator(log_n));
+    const uint32_t gn = fpow(MONTY_GEN, (uint64_t)1 << log_n);
+    q.inv_zh_even = finv(fsub(gn, MONTY_R1));
+    q.inv_zh_odd = finv(fsub(fneg(gn), MONTY_R1));
+    q.body = (const uint32_t*)d_stage; q.n_constraints = air.K;
+    q.weights = (const uint32_t*)d_stage + body_w; q.pub = (const uint32_t*)d_stage + body_w + weights.size();
+    q.out = out_chunks; q.lde_out = lde_out; q.lde_ld = lde_ld;
+    ZK_HIP(launch_quotient_air(q, ctx->stream));
     return ZKHIP_OK;
 }
 
@@ -332,12 +377,12 @@ static int grind_witness(zkhip_ctx* ctx, Challenger& ch, int pow_bits, uint32_t*
     return ZKHIP_OK;
 }
 
-static size_t proof_words(int log_n, uint32_t width, const zkhip_params* prm) {
+static size_t proof_words(int log_n, uint32_t width, const zkhip_params* prm, bool air = false) {
     Shape sh;
     if (!shape_of(log_n, prm, sh)) return 0;
     const size_t H = (size_t)(log_n + sh.b);
     const size_t Q = (size_t)prm->logup_pairs, wp = Q ? 4 * (Q + 1) : 0;
-    size_t words = (sh.ext ? 12 : (Q ? 9 : 8)) + 16 + 8 * (size_t)width + 32 + 8 * (size_t)sh.R + 4 * ((size_t)1 << sh.F) + 1;
+    size_t words = (air ? 20 : (sh.ext ? 12 : (Q ? 9 : 8))) + 16 + 8 * (size_t)width + 32 + 8 * (size_t)sh.R + 4 * ((size_t)1 << sh.F) + 1;
     size_t perq = width + 8 + 16 * H;
     if (Q) { words += 8 + 8 * wp; perq += wp + 8 * H; }
     for (int l = 0; l < sh.R; l++) perq += 4 * (((size_t)1 << sh.K) - 1) + 8 * (H - (size_t)sh.K * (l + 1));
@@ -526,14 +571,15 @@ size_t zkhip_proof_size(int log_n, uint32_t width, const zkhip_params* prm, size
     return proof_words(log_n, width, prm) * 4;
 }
 
-int zkhip_prove_shard(zkhip_ctx* ctx, const uint32_t* d_trace, size_t ld, int log_n, uint32_t width,
-                      const uint32_t* public_values, size_t n_public, const zkhip_params* prm,
-                      uint8_t* proof, size_t cap, size_t* len) {
+static int prove_shard_impl(zkhip_ctx* ctx, const uint32_t* d_trace, size_t ld, int log_n, uint32_t width,
+                            const uint32_t* public_values, size_t n_public, const zkhip_params* prm,
+                            uint8_t* proof, size_t cap, size_t* len, const AirView* air) {
     CHECK_CTX(ctx);
     ZK_TRY(check_shape(log_n, width, prm));
     if (!d_trace || !proof || !len || ld < width || (n_public && !public_values)) return fail(ZKHIP_ERR_INVALID, "prove_shard: bad arguments");
     for (size_t i = 0; i < n_public; i++) if (public_values[i] >= P) return fail(ZKHIP_ERR_INVALID, "prove_shard: public values must be canonical");
-    const size_t need = proof_words(log_n, width, prm) * 4;
+    if (air && prm->logup_pairs) return fail(ZKHIP_ERR_INVALID, "prove_shard_air: a constraint program excludes the built-in lookup argument (logup_pairs must be 0)");
+    const size_t need = proof_words(log_n, width, prm, air != nullptr) * 4;
     if (cap < need) return fail(ZKHIP_ERR_BUFFER, "prove_shard: proof buffer too small (see zkhip_proof_size)");
     *len = 0;
     Shape sh;
@@ -548,13 +594,14 @@ int zkhip_prove_shard(zkhip_ctx* ctx, const uint32_t* d_trace, size_t ld, int lo
     size_t pos = 0;
     const uint32_t LQ = (uint32_t)prm->logup_pairs;          // LogUp pairs (0 = none)
     const size_t wp = LQ ? 4 * ((size_t)LQ + 1) : 0;         // permutation-trace width in words
-    pf[pos++] = PROOF_MAGIC; pf[pos++] = sh.ext ? 3u : (LQ ? 2u : PROOF_VERSION); pf[pos++] = (uint32_t)log_n; pf[pos++] = width;
+    pf[pos++] = PROOF_MAGIC; pf[pos++] = air ? 7u : (sh.ext ? 3u : (LQ ? 2u : PROOF_VERSION)); pf[pos++] = (uint32_t)log_n; pf[pos++] = width;
     pf[pos++] = (uint32_t)prm->log_blowup; pf[pos++] = (uint32_t)Q; pf[pos++] = (uint32_t)prm->pow_bits; pf[pos++] = (uint32_t)n_public;
-    if (sh.ext) { pf[pos++] = LQ; pf[pos++] = (uint32_t)sh.K; pf[pos++] = (uint32_t)sh.F; pf[pos++] = (uint32_t)sh.hw; }
+    if (sh.ext || air) { pf[pos++] = LQ; pf[pos++] = (uint32_t)sh.K; pf[pos++] = (uint32_t)sh.F; pf[pos++] = (uint32_t)sh.hw; }
     else if (LQ) pf[pos++] = LQ;
+    if (air) { air_digest(*air, pf + pos); pos += 8; }
 
     Challenger ch;
-    transcript_init(ch, log_n, width, prm, n_public, sh);
+    transcript_init(ch, log_n, width, prm, n_public, sh, air);
     uint32_t root[8];
 
     // ---- 1. commit the trace: LDE on g <w_2N> (bit-reversed rows) + Merkle tree
@@ -598,7 +645,8 @@ int zkhip_prove_shard(zkhip_ctx* ctx, const uint32_t* d_trace, size_t ld, int lo
     // With blowup 2 the LDE domain g <w_2N> is exactly the two cosets the chunks live on: on its own coset a chunk's extension is
     // the quotient value itself (the kernel writes it straight into the LDE matrix), only the OTHER coset needs a transform.
     const bool own_coset_direct = sh.b == 1;
-    ZK_TRY(run_quotient(ctx, tlde, width, log_n, width, alpha, lu, qchunk, own_coset_direct ? qlde : nullptr, 8));
+    if (air) ZK_TRY(run_quotient_air(ctx, *air, tlde, width, log_n, width, public_values, alpha, qchunk, own_coset_direct ? qlde : nullptr, 8));
+    else ZK_TRY(run_quotient(ctx, tlde, width, log_n, width, alpha, lu, qchunk, own_coset_direct ? qlde : nullptr, 8));
     {
         // the quotient kernel works on the first 2N rows of the LDE: they are the coset g <w_2N>, bit-reversed
         const uint32_t w2n = two_adic_generator(Hq);
@@ -754,6 +802,89 @@ int zkhip_prove_shard(zkhip_ctx* ctx, const uint32_t* d_trace, size_t ld, int lo
         ctx->debug.fri_alpha[i] = from_monty(fa.c[i]);
     }
     *len = pos * 4;
+    return ZKHIP_OK;
+}
+
+int zkhip_prove_shard(zkhip_ctx* ctx, const uint32_t* d_trace, size_t ld, int log_n, uint32_t width,
+                      const uint32_t* public_values, size_t n_public, const zkhip_params* prm,
+                      uint8_t* proof, size_t cap, size_t* len) {
+    return prove_shard_impl(ctx, d_trace, ld, log_n, width, public_values, n_public, prm, proof, cap, len, nullptr);
+}
+
+// ---- the AIR as data: prove / verify against a constraint program (air.h)
+size_t zkhip_proof_size_air(int log_n, uint32_t width, const zkhip_params* prm, size_t n_public) {
+    (void)n_public;
+    if (check_shape(log_n, width, prm) != ZKHIP_OK || prm->logup_pairs) return 0;
+    return proof_words(log_n, width, prm, true) * 4;
+}
+int zkhip_air_validate(const uint32_t* program, size_t words, uint32_t width, size_t n_public) {
+    if (!air_validate(program, words, width, n_public, nullptr))
+        return fail(ZKHIP_ERR_INVALID, "air_validate: malformed constraint program (header, selector, degree > 3, or a variable out of range)");
+    return ZKHIP_OK;
+}
+int zkhip_air_digest(const uint32_t* program, size_t words, uint32_t out[8]) {
+    AirView a;
+    if (!out || !program || words < 6 || !air_validate(program, words, program[2], program[4], &a)) return fail(ZKHIP_ERR_INVALID, "air_digest: malformed constraint program");
+    air_digest(a, out);
+    return ZKHIP_OK;
+}
+// the synthetic AIR of DESIGN.md section 3 (without lookups) written as a program: what zkhip_prove_shard has built in
+int zkhip_air_synthetic(uint32_t width, size_t n_public, uint32_t* out, size_t cap, size_t* words) {
+    if (!words || width == 0 || width % 4 != 0 || width > 1024) return fail(ZKHIP_ERR_INVALID, "air_synthetic: width must be a positive multiple of 4, at most 1024");
+    const size_t G = width / 4, need = 6 + G * 33;
+    *words = need;
+    if (!out) return ZKHIP_OK;                                // size query
+    if (cap < need) return fail(ZKHIP_ERR_BUFFER, "air_synthetic: buffer too small");
+    size_t p = 0;
+    out[p++] = AIR_MAGIC; out[p++] = 1; out[p++] = width; out[p++] = (uint32_t)(3 * G); out[p++] = (uint32_t)n_public; out[p++] = (uint32_t)need;
+    for (uint32_t g = 0; g < G; g++) {
+        const uint32_t a = 4 * g, b = a + 1, c = a + 2, d = a + 3, NEXT = 1u << 30;
+        out[p++] = 0; out[p++] = 3;                           // c - a a b - (g + 1) on every row
+        out[p++] = 1; out[p++] = 1; out[p++] = c;
+        out[p++] = P - 1; out[p++] = 3; out[p++] = a; out[p++] = a; out[p++] = b;
+        out[p++] = P - (g + 1); out[p++] = 0;
+        out[p++] = 3; out[p++] = 4;                           // d' - a b - c - (2g + 3) on transitions
+        out[p++] = 1; out[p++] = 1; out[p++] = NEXT | d;
+        out[p++] = P - 1; out[p++] = 2; out[p++] = a; out[p++] = b;
+        out[p++] = P - 1; out[p++] = 1; out[p++] = c;
+        out[p++] = P - (2 * g + 3); out[p++] = 0;
+        out[p++] = 1; out[p++] = 2;                           // d - (5g + 7) on the first row
+        out[p++] = 1; out[p++] = 1; out[p++] = d;
+        out[p++] = P - (5 * g + 7); out[p++] = 0;
+    }
+    return p == need ? ZKHIP_OK : fail(ZKHIP_ERR_INTERNAL, "air_synthetic: layout mismatch");
+}
+int zkhip_prove_shard_air(zkhip_ctx* ctx, const uint32_t* program, size_t program_words, const uint32_t* d_trace, size_t ld, int log_n,
+                          uint32_t width, const uint32_t* public_values, size_t n_public, const zkhip_params* prm,
+                          uint8_t* proof, size_t cap, size_t* len) {
+    AirView a;
+    if (!air_validate(program, program_words, width, n_public, &a)) return fail(ZKHIP_ERR_INVALID, "prove_shard_air: malformed constraint program");
+    return prove_shard_impl(ctx, d_trace, ld, log_n, width, public_values, n_public, prm, proof, cap, len, &a);
+}
+int zkhip_quotient_values_air(zkhip_ctx* ctx, const uint32_t* program, size_t program_words, const uint32_t* d_lde, size_t ld, int log_n,
+                              uint32_t width, const uint32_t* public_values, size_t n_public, const uint32_t alpha[4], uint32_t* d_out) {
+    CHECK_CTX(ctx);
+    zkhip_params prm{1, 1, 0, 0, 0, 0, 0};
+    ZK_TRY(check_shape(log_n, width, &prm));
+    AirView a;
+    if (!d_lde || !d_out || !alpha || ld < width || (n_public && !public_values) || !air_validate(program, program_words, width, n_public, &a))
+        return fail(ZKHIP_ERR_INVALID, "quotient_values_air: bad arguments or malformed program");
+    const size_t n = (size_t)1 << log_n;
+    void* chunks;
+    ZK_TRY(ctx_reserve(ctx, S_QCHUNK, 2 * n * 16, &chunks));
+    ZK_TRY(run_quotient_air(ctx, a, d_lde, ld, log_n, width, public_values, Ext{{alpha[0], alpha[1], alpha[2], alpha[3]}}, (uint32_t*)chunks, nullptr, 0));
+    // natural chunk order -> the bit-reversed layout of the LDE (as zkhip_quotient_values)
+    std::vector<GatherDesc> descs(2 * n);
+    for (size_t k = 0; k < 2; k++)
+        for (size_t j = 0; j < n; j++) {
+            const size_t p = k * n + reverse_bits((uint32_t)j, log_n);
+            descs[p] = GatherDesc{(const uint32_t*)chunks + (k * n + j) * 4, (uint32_t)(p * 4), 4};
+        }
+    void* dd;
+    ZK_TRY(ctx_reserve(ctx, S_GATHER_DESC, descs.size() * sizeof(GatherDesc), &dd));
+    ZK_TRY(h2d(ctx, dd, descs.data(), descs.size() * sizeof(GatherDesc)));
+    ZK_HIP(launch_gather((const GatherDesc*)dd, (uint32_t)descs.size(), d_out, ctx->stream));
+    ZK_HIP(launch_convert(d_out, d_out, 2 * n * 4, true, ctx->stream));
     return ZKHIP_OK;
 }
 
@@ -989,15 +1120,16 @@ static Ext recombine(const Ext* opened4) {
     return r;
 }
 
-int zkhip_verify_shard(const uint8_t* proof, size_t len, int log_n, uint32_t width, const uint32_t* public_values,
-                       size_t n_public, const zkhip_params* prm, int* reason) {
+static int verify_shard_impl(const uint8_t* proof, size_t len, int log_n, uint32_t width, const uint32_t* public_values,
+                             size_t n_public, const zkhip_params* prm, int* reason, const AirView* air) {
     int dummy;
     if (!reason) reason = &dummy;
     *reason = 0;
     auto reject = [&](int why) { *reason = why; return fail(ZKHIP_ERR_VERIFY, "proof rejected (check " + std::to_string(why) + ")"); };
     if (check_shape(log_n, width, prm) != ZKHIP_OK) return reject(1);
     if (!proof || (n_public && !public_values)) return reject(1);
-    if (len != proof_words(log_n, width, prm) * 4) return reject(2);
+    if (air && prm->logup_pairs) return reject(1);
+    if (len != proof_words(log_n, width, prm, air != nullptr) * 4) return reject(2);
     const uint32_t* pf = (const uint32_t*)proof;
     Shape sh;
     shape_of(log_n, prm, sh);
@@ -1005,18 +1137,24 @@ int zkhip_verify_shard(const uint8_t* proof, size_t len, int log_n, uint32_t wid
     const size_t n = (size_t)1 << log_n, arity = (size_t)1 << K;
     const uint32_t LQ = (uint32_t)prm->logup_pairs;
     const size_t wp = LQ ? 4 * ((size_t)LQ + 1) : 0;
-    if (pf[0] != PROOF_MAGIC || pf[1] != (sh.ext ? 3u : (LQ ? 2u : PROOF_VERSION)) || pf[2] != (uint32_t)log_n || pf[3] != width ||
+    if (pf[0] != PROOF_MAGIC || pf[1] != (air ? 7u : (sh.ext ? 3u : (LQ ? 2u : PROOF_VERSION))) || pf[2] != (uint32_t)log_n || pf[3] != width ||
         pf[4] != (uint32_t)prm->log_blowup || pf[5] != (uint32_t)prm->num_queries || pf[6] != (uint32_t)prm->pow_bits ||
         pf[7] != (uint32_t)n_public) return reject(3);
     size_t pos = 8;
-    if (sh.ext) {
+    if (sh.ext || air) {
         if (pf[8] != LQ || pf[9] != (uint32_t)sh.K || pf[10] != (uint32_t)sh.F || pf[11] != (uint32_t)sh.hw) return reject(3);
         pos = 12;
     } else if (LQ) { if (pf[8] != LQ) return reject(3); pos = 9; }
+    if (air) {
+        uint32_t dg[8];
+        air_digest(*air, dg);
+        for (int i = 0; i < 8; i++) if (pf[pos + i] != dg[i]) return reject(3);
+        pos += 8;
+    }
     for (size_t i = pos; i < len / 4; i++) if (pf[i] >= P) return reject(4);
     for (size_t i = 0; i < n_public; i++) if (public_values[i] >= P) return reject(4);
     Challenger ch;
-    transcript_init(ch, log_n, width, prm, n_public, sh);
+    transcript_init(ch, log_n, width, prm, n_public, sh, air);
     uint32_t troot[8], proot[8], qroot[8];
     for (int i = 0; i < 8; i++) { troot[i] = to_monty(pf[pos++]); }
     for (int i = 0; i < 8; i++) ch.observe(troot[i]);
@@ -1058,7 +1196,8 @@ int zkhip_verify_shard(const uint8_t* proof, size_t len, int log_n, uint32_t wid
         const Ext sel_first = ext_mul(zh, ext_inv(ext_sub_base(zeta, MONTY_R1)));
         const Ext sel_trans = ext_sub_base(zeta, finv(gn));
         Ext acc = ext_zero();
-        for (uint32_t g = 0; g < width / 4; g++) {
+        if (air) acc = air_fold_ext(*air, loc.data(), nxt.data(), public_values, sel_first, ext_mul(zh, ext_inv(ext_sub_base(zeta, finv(gn)))), sel_trans, alpha);
+        else for (uint32_t g = 0; g < width / 4; g++) {
             const Ext &a = loc[4 * g], &b = loc[4 * g + 1], &c = loc[4 * g + 2], &d = loc[4 * g + 3], &dn = nxt[4 * g + 3];
             const uint32_t k1 = to_monty(g + 1), k2 = to_monty(2 * g + 3), d0 = to_monty(5 * g + 7);
             const Ext c1 = ext_sub_base(ext_sub(c, ext_mul(ext_mul(a, a), b)), k1);
@@ -1183,6 +1322,20 @@ int zkhip_verify_shard(const uint8_t* proof, size_t len, int log_n, uint32_t wid
     }
     if (pos * 4 != len) return reject(5);
     return ZKHIP_OK;
+}
+
+int zkhip_verify_shard(const uint8_t* proof, size_t len, int log_n, uint32_t width, const uint32_t* public_values,
+                       size_t n_public, const zkhip_params* prm, int* reason) {
+    return verify_shard_impl(proof, len, log_n, width, public_values, n_public, prm, reason, nullptr);
+}
+int zkhip_verify_shard_air(const uint32_t* program, size_t program_words, const uint8_t* proof, size_t len, int log_n, uint32_t width,
+                           const uint32_t* public_values, size_t n_public, const zkhip_params* prm, int* reason) {
+    AirView a;
+    if (!air_validate(program, program_words, width, n_public, &a)) {
+        if (reason) *reason = 1;
+        return fail(ZKHIP_ERR_VERIFY, "verify_shard_air: malformed constraint program");
+    }
+    return verify_shard_impl(proof, len, log_n, width, public_values, n_public, prm, reason, &a);
 }
 
 // ================================================================ shards of several chips with different heights

@@ -232,6 +232,55 @@ hipError_t launch_quotient(const QuotientArgs& a, hipStream_t s) {
     return hipGetLastError();
 }
 
+// ------------------------------------------------------------------ quotient of a constraint program (the AIR as data)
+// One thread per point of the quotient domain interprets the program (air.h): every lane of a wave executes the same instruction
+// stream, so the program words and the constraint weights are wave-uniform (scalar loads) and only the trace values differ per
+// lane.  A lane reads its own row and the "next" row (row e + 2 of the blown-up domain, an unrelated bit-reversed position) word by
+// word; consecutive lanes hold consecutive bit-reversed positions, i.e. adjacent 4 * ld-byte rows, and a row's lines stay in L1 / L2
+// across the variables of a program.  This is the generic path: the synthetic AIR keeps its specialised kernel (quotient_kernel), which
+// streams rows once with 16-byte loads; bytes per point here are the same 2 * 4 * width, the instruction count is what differs.
+__global__ void __launch_bounds__(256) quotient_air_kernel(QuotientAirArgs a) {
+    const int H = a.log_n + 1;
+    const uint32_t m = 1u << H;
+    const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= m) return;
+    const uint32_t e = __brev(p) >> (32 - H);
+    const uint32_t pn = __brev((e + 2) & (m - 1)) >> (32 - H);
+    const uint32_t* local = a.lde + (uint64_t)p * a.ld;
+    const uint32_t* next = a.lde + (uint64_t)pn * a.ld;
+    const uint32_t x = a.xs[p];
+    const uint32_t sel_first = a.sel_first[p], sel_last = a.sel_last[p], sel_trans = dsub(x, a.wn_inv);
+    uint64_t acc[4] = {0, 0, 0, 0};
+    const uint32_t* w = a.body;
+    for (uint32_t k = 0; k < a.n_constraints; k++) {
+        const uint32_t sel = *w++, nt = *w++;
+        uint32_t c = 0;
+        for (uint32_t t = 0; t < nt; t++) {
+            uint32_t prod = *w++;
+            const uint32_t d = *w++;
+            for (uint32_t j = 0; j < d; j++) {
+                const uint32_t v = *w++, kind = v >> 30, idx = v & 0xFFFFu;
+                const uint32_t val = kind == 0 ? local[idx] : (kind == 1 ? next[idx] : a.pub[idx]);
+                prod = dmul(prod, val);
+            }
+            c = dadd(c, prod);
+        }
+        if (sel) c = dmul(c, sel == 1 ? sel_first : (sel == 2 ? sel_last : sel_trans));     // sel is wave-uniform
+        const uint4 wt = *reinterpret_cast<const uint4*>(a.weights + 4 * (uint64_t)k);
+        dacc1(acc[0], wt.x, c); dacc1(acc[1], wt.y, c); dacc1(acc[2], wt.z, c); dacc1(acc[3], wt.w, c);
+    }
+    const uint32_t parity = e & 1u;
+    Ext r = Ext{{dacc_finish(acc[0]), dacc_finish(acc[1]), dacc_finish(acc[2]), dacc_finish(acc[3])}};
+    r = ext_mul_base_dev(r, parity ? a.inv_zh_odd : a.inv_zh_even);
+    st_ext(a.out + ((uint64_t)parity * (m >> 1) + (e >> 1)) * 4, r);
+    if (a.lde_out) st_ext(a.lde_out + (uint64_t)p * a.lde_ld + 4u * parity, r);
+}
+hipError_t launch_quotient_air(const QuotientAirArgs& a, hipStream_t s) {
+    const uint64_t m = 2ull << a.log_n;
+    hipLaunchKernelGGL(quotient_air_kernel, dim3((unsigned)((m + 255) / 256)), dim3(256), 0, s, a);
+    return hipGetLastError();
+}
+
 // ------------------------------------------------------------------ 1 / (x_p - z)
 // out[k][p] = 1 / (x_p - z_k) for p < count; optionally xw[k][p] = x_p / (x_p - z_k) for p < xw_count
 // (the barycentric weights of the opening kernel, which sums over the first xw_count rows only)

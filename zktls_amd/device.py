@@ -319,6 +319,27 @@ class Context:
                                          buf.ctypes.data_as(u8p), size, C.byref(got)))
         return buf[: got.value]
 
+    def prove_shard_air(self, program, trace, log_n, width, public_values=(), params=None):
+        """prove against a constraint program (the AIR as data: include/zkhip.h); program: numpy u32 words"""
+        params = params or Params(1, 100, 16, 0)
+        prog = np.ascontiguousarray(program, dtype=np.uint32)
+        pv = np.ascontiguousarray(np.array(public_values, dtype=np.uint32))
+        size = self.lib.zkhip_proof_size_air(log_n, width, C.byref(params), pv.size)
+        buf = np.empty(max(size, 1), dtype=np.uint8)
+        got = C.c_size_t(0)
+        check(self.lib.zkhip_prove_shard_air(self.handle, prog.ctypes.data_as(u32p), prog.size, C.c_void_p(trace.ptr), width, log_n, width,
+                                             pv.ctypes.data_as(u32p), pv.size, C.byref(params), buf.ctypes.data_as(u8p), size, C.byref(got)))
+        return buf[: got.value]
+
+    def quotient_values_air(self, program, lde, log_n, width, public_values, alpha, out=None):
+        out = out or self.alloc(4 << (log_n + 1))
+        prog = np.ascontiguousarray(program, dtype=np.uint32)
+        pv = np.ascontiguousarray(np.array(public_values, dtype=np.uint32))
+        a = to_monty(np.asarray(alpha, dtype=np.uint32))
+        check(self.lib.zkhip_quotient_values_air(self.handle, prog.ctypes.data_as(u32p), prog.size, C.c_void_p(lde.ptr), width, log_n, width,
+                                                 pv.ctypes.data_as(u32p), pv.size, a.ctypes.data_as(u32p), C.c_void_p(out.ptr)))
+        return out
+
     def prove_shard_host(self, host_trace, public_values=(), params=None, host_ptr=None, log_n=None, width=None):
         """host_trace: numpy [2^log_n][width] canonical words in host memory (or a raw host pointer + shape)"""
         params = params or Params(1, 100, 16, 0)
@@ -445,6 +466,27 @@ def verify_shard(proof, log_n, width, public_values=(), params=None):
     rc = lib.zkhip_verify_shard(pr.ctypes.data_as(u8p), pr.size, log_n, width, pv.ctypes.data_as(u32p), pv.size,
                                 C.byref(params), C.byref(reason))
     return rc, reason.value
+
+
+def verify_shard_air(program, proof, log_n, width, public_values=(), params=None):
+    params = params or Params(1, 100, 16)
+    lib = _lib.load()
+    prog = np.ascontiguousarray(program, dtype=np.uint32)
+    pr = np.ascontiguousarray(proof, dtype=np.uint8)
+    pv = np.ascontiguousarray(np.array(public_values, dtype=np.uint32))
+    reason = C.c_int(0)
+    rc = lib.zkhip_verify_shard_air(prog.ctypes.data_as(u32p), prog.size, pr.ctypes.data_as(u8p), pr.size, log_n, width,
+                                    pv.ctypes.data_as(u32p), pv.size, C.byref(params), C.byref(reason))
+    return rc, reason.value
+
+
+def air_synthetic(width, n_public):
+    lib = _lib.load()
+    n = C.c_size_t(0)
+    check(lib.zkhip_air_synthetic(width, n_public, None, 0, C.byref(n)))
+    out = np.empty(n.value, dtype=np.uint32)
+    check(lib.zkhip_air_synthetic(width, n_public, out.ctypes.data_as(u32p), out.size, C.byref(n)))
+    return out
 
 
 def verify_chips(proof, log_ns, widths, public_values=(), params=None, pairs=None, partners=None):
