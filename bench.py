@@ -74,6 +74,9 @@ def main():
     ap.add_argument("--host-traces", action="store_true", help="traces start in (pinned) HOST memory: every step includes the 1 GiB H2D copy "
                                                                "(the PCIe-inclusive rate quoted in DESIGN.md; never the headline value)")
     ap.add_argument("--streams", type=int, default=4, help="shards in flight per GPU (at most --steps): each on its own context + HIP stream")
+    ap.add_argument("--share-gpu", action="store_true",
+                    help="TEST MODE for boxes with fewer GPUs than ranks: rank r uses device r mod (visible devices) and the collectives run "
+                         "over gloo (RCCL refuses two ranks on one GPU).  Exercises the N > 1 code path end to end; the line says so and is not a scaling result")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-log-n", type=int, default=20, help="rows of the bounded CPU-baseline sample")
     ap.add_argument("--cpu-threads", type=int, default=0, help="OpenMP threads of the CPU baseline (0: min(cores, 64))")
@@ -92,14 +95,20 @@ def main():
         raise SystemExit("--gpus %d but the launcher started %d ranks" % (args.gpus, world))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: libzkhip has no CPU path")
+    if args.share_gpu:
+        local_rank = local_rank % max(torch.cuda.device_count(), 1)
     torch.cuda.set_device(local_rank)
     dist = None
     if world > 1:
         import torch.distributed as dist_mod
         dist = dist_mod
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="nccl", rank=rank, world_size=world,
-                                device_id=torch.device("cuda", local_rank))
+        if args.share_gpu:
+            dist.init_process_group(backend="gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group(backend="nccl", rank=rank, world_size=world,
+                                    device_id=torch.device("cuda", local_rank))
+    coll_dev = "cpu" if args.share_gpu else "cuda"
 
     from zktls_amd._lib import Params
     from zktls_amd.device import Context, verify_shard
@@ -122,7 +131,7 @@ def main():
 
     # batch transcript seed: rank 0 draws it, RCCL broadcasts it (the only collective)
     from zktls_amd import shards
-    public = shards.broadcast_seed(dist, [(SEED >> (8 * i)) & 0xFF for i in range(8)], device="cuda")
+    public = shards.broadcast_seed(dist, [(SEED >> (8 * i)) & 0xFF for i in range(8)], device=coll_dev)
 
     K, W = args.steps, args.warmup
     nbuf = min(max(K, 1), 8)
@@ -231,7 +240,7 @@ def main():
     proofs = run_steps(K)
     barrier()
     elapsed = time.perf_counter() - t0
-    elapsed = shards.max_over_ranks(dist, elapsed, device="cuda")
+    elapsed = shards.max_over_ranks(dist, elapsed, device=coll_dev)
     last = proofs[K - 1]
     # after the timed region: every shard of the job was proven exactly once, on exactly one rank (digest gather over RCCL)
     digests = shards.gather_proof_digests(dist, {my[i]: proofs[i] for i in range(K)})
@@ -386,6 +395,7 @@ def main():
             "streams_per_gpu": S,
             "rccl_world_size": (dist.get_world_size() if dist is not None else 1),
             "collective_backend": (dist.get_backend() if dist is not None else None),
+            "share_gpu_test_mode": bool(args.share_gpu),
             "shards_proven": K * world, "shard_digests_gathered": len(digests), "shard_assignment": "round-robin (zktls_amd.shards.shard_indices)",
             "timing_note": "ms_per_step is amortised throughput with %d shards in flight per GPU, not latency" % S,
             "single_shard_latency_ms": (round(latency_ms, 3) if latency_ms is not None else None),
