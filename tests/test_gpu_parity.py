@@ -232,9 +232,10 @@ def test_merkle_commit_p24_colmajor_matches_oracle(ctx, oracle, cols, log_rows):
     assert (got == oracle.merkle_tree_p24_colmajor(mat)).all()
 
 
-@pytest.mark.parametrize("count,log_size,log_blowup", [(1, 5, 2), (3, 8, 2), (40, 10, 2), (17, 12, 1), (64, 14, 2)])
+@pytest.mark.parametrize("count,log_size,log_blowup", [(1, 5, 2), (3, 8, 2), (40, 10, 2), (17, 12, 1), (64, 14, 2), (1, 20, 0), (3, 20, 2), (6, 20, 1)])
 def test_colmajor_interpolate_and_expand_match_oracle(ctx, oracle, count, log_size, log_blowup):
-    # RISC Zero Hal layout: `count` contiguous polynomials
+    # RISC Zero Hal layout: `count` contiguous polynomials; 2^20-point polynomials take the NATIVE
+    # contiguous-vector passes (ntt_colpass_kernel: transposes folded into the tiles' loads / stores), the rest the transposing adapter
     rng = np.random.default_rng(count)
     n = 1 << log_size
     evals_nat = rng.integers(0, P, size=(n, count), dtype=np.uint32)          # row-major view for the oracle

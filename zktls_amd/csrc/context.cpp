@@ -565,6 +565,7 @@ void zkhip_ctx_destroy(zkhip_ctx* ctx) {
     if (ctx->fri_graph_exec) (void)hipGraphExecDestroy(ctx->fri_graph_exec);
     for (NttPlan& p : ctx->plans) { if (p.pre) (void)hipFree(p.pre); if (p.post) (void)hipFree(p.post); }
     for (BigPlan& p : ctx->big_plans) if (p.tw) (void)hipFree(p.tw);
+    for (ColPlan& p : ctx->col_plans) { if (p.pre) (void)hipFree(p.pre); if (p.post2d) (void)hipFree(p.post2d); }
     for (DeviceBuffer& b : ctx->scratch) if (b.ptr) (void)hipFree(b.ptr);
     if (ctx->w1024_fwd) (void)hipFree(ctx->w1024_fwd);
     if (ctx->w1024_inv) (void)hipFree(ctx->w1024_inv);
@@ -751,15 +752,53 @@ int zkhip_merkle_commit(zkhip_ctx* ctx, const uint32_t* const* d_mats, const siz
     return op_merkle_commit(ctx, descs, nmats, log_h, d_tree);
 }
 
-// ---- RISC Zero Hal layout (column-major [count][size]) served through a transposing adapter:
-// the polynomials become the columns of a row-major matrix, which is what the NTT kernels
-// stream at full width; natively contiguous-vector passes are a later step.
+// ---- RISC Zero Hal layout (column-major [count][size]).  2^20-point polynomials (the segment size of the reference's RISC Zero
+// backend: po2 = 20, benchmark.md:36) run NATIVELY on the contiguous vectors: two launches of ntt_colpass_kernel per transform, the
+// four-step transpose folded into the tile's load / store (ntt.hip) -- 16 B per element and transform, no transpose pass.  Other
+// sizes keep the transposing adapter (the polynomials become the columns of a row-major matrix: 32 B per element).
+static int get_col_plan(zkhip_ctx* ctx, int inverse, uint32_t shift, const ColPlan** out) {
+    for (const ColPlan& p : ctx->col_plans)
+        if (p.inverse == inverse && (inverse || p.shift == shift)) { *out = &p; return ZKHIP_OK; }
+    ColPlan p;
+    p.inverse = inverse; p.shift = shift;
+    const uint32_t w = two_adic_generator(20);
+    ZK_HIP(hipMalloc((void**)&p.post2d, (size_t)4 << 20));
+    if (inverse) {
+        // first inverse pass (over kc -> c, columns kr): times w^-(c kr) / N
+        ZK_HIP(launch_post2d_table(p.post2d, finv(w), MONTY_R1, finv(to_monty(1u << 20)), ctx->stream));
+    } else {
+        // first forward pass (over r -> kr, columns c): input row r times (s^1024)^r, output (kr, c) times w^(c kr) s^c
+        ZK_HIP(launch_post2d_table(p.post2d, w, shift, MONTY_R1, ctx->stream));
+        if (shift != MONTY_R1) {
+            ZK_HIP(hipMalloc((void**)&p.pre, 1024 * 4));
+            ZK_HIP(launch_pow_table(p.pre, 1024, fpow(shift, 1024), MONTY_R1, ctx->stream));
+        }
+    }
+    ctx->col_plans.push_back(p);
+    *out = &ctx->col_plans.back();
+    return ZKHIP_OK;
+}
+
 int zkhip_batch_interpolate_colmajor(zkhip_ctx* ctx, const uint32_t* d_evals, uint32_t* d_coeffs, uint32_t count, int log_size) {
     CHECK_CTX(ctx);
     if (!d_evals || !d_coeffs || count == 0 || log_size < 5 || log_size > 20) return fail(ZKHIP_ERR_INVALID, "batch_interpolate_colmajor: bad arguments");
     const uint64_t n = (uint64_t)1 << log_size;
     void *a, *b;
     ZK_TRY(ctx_reserve(ctx, S_COL_A, n * count * 4, &a));
+    if (log_size == 20 && (reinterpret_cast<uintptr_t>(d_evals) & 7) == 0 && (reinterpret_cast<uintptr_t>(d_coeffs) & 7) == 0) {
+        // x[c + 1024 r] = 1/N sum_kr w_R^-(r kr) [ w_N^-(c kr) sum_kc w_C^-(c kc) X[kr + 1024 kc] ],  X[k] stored at bitrev(k)
+        const ColPlan* p;
+        ZK_TRY(get_col_plan(ctx, 1, 0, &p));
+        ColPassArgs q{};
+        q.in = d_evals; q.out = (uint32_t*)a; q.in_batch = q.out_batch = n; q.count = count;
+        q.tload = 1; q.in_brev = 1; q.w1024 = ctx->w1024_inv; q.post2d = p->post2d;
+        ZK_HIP(launch_ntt_colpass(q, true, ctx->stream));
+        ColPassArgs r{};
+        r.in = (const uint32_t*)a; r.out = d_coeffs; r.in_batch = r.out_batch = n; r.count = count;
+        r.tload = 1; r.w1024 = ctx->w1024_inv;
+        ZK_HIP(launch_ntt_colpass(r, true, ctx->stream));
+        return ZKHIP_OK;
+    }
     ZK_TRY(ctx_reserve(ctx, S_COL_B, n * count * 4, &b));
     // evaluations arrive bit-reversed (Hal convention): undo it while transposing
     ZK_HIP(launch_transpose(d_evals, (uint32_t*)a, count, n, log_size, 0, ctx->stream));
@@ -775,12 +814,30 @@ int zkhip_batch_expand_colmajor(zkhip_ctx* ctx, const uint32_t* d_coeffs, uint32
         log_size + log_blowup > 24 || shift == 0 || shift >= P)
         return fail(ZKHIP_ERR_INVALID, "batch_expand_colmajor: bad arguments");
     const uint64_t n = (uint64_t)1 << log_size, m = n << log_blowup;
+    const uint32_t sm = to_monty(shift), wnb = two_adic_generator(log_size + log_blowup);
     void *a, *b;
     ZK_TRY(ctx_reserve(ctx, S_COL_A, n * count * 4, &a));
+    if (log_size == 20 && (reinterpret_cast<uintptr_t>(d_evals) & 7) == 0 && (reinterpret_cast<uintptr_t>(d_coeffs) & 7) == 0) {
+        // a zero-padded size-m transform = 2^b coset transforms of size n; coset t fills the block bitrev_b(t) of the bit-reversed output
+        for (int t = 0; t < (1 << log_blowup); t++) {
+            const uint32_t st = fmul(sm, fpow(wnb, (uint64_t)t));
+            const ColPlan* p;
+            ZK_TRY(get_col_plan(ctx, 0, st, &p));
+            ColPassArgs q{};
+            q.in = d_coeffs; q.out = (uint32_t*)a; q.in_batch = q.out_batch = n; q.count = count;
+            q.tstore = 1; q.w1024 = ctx->w1024_fwd; q.pre = p->pre; q.post2d = p->post2d;
+            ZK_HIP(launch_ntt_colpass(q, false, ctx->stream));
+            ColPassArgs r{};
+            r.in = (const uint32_t*)a; r.out = d_evals + (size_t)reverse_bits((uint32_t)t, log_blowup) * n;
+            r.in_batch = n; r.out_batch = m; r.count = count;
+            r.tstore = 1; r.out_brev = 1; r.w1024 = ctx->w1024_fwd;
+            ZK_HIP(launch_ntt_colpass(r, false, ctx->stream));
+        }
+        return ZKHIP_OK;
+    }
     ZK_TRY(ctx_reserve(ctx, S_COL_B, m * count * 4, &b));
     ZK_HIP(launch_transpose(d_coeffs, (uint32_t*)a, count, n, 0, 0, ctx->stream));
     // zero-padded size-m transform = 2^b coset transforms of size n (as in op_coset_lde)
-    const uint32_t sm = to_monty(shift), wnb = two_adic_generator(log_size + log_blowup);
     for (int t = 0; t < (1 << log_blowup); t++) {
         const uint32_t st = fmul(sm, fpow(wnb, (uint64_t)t));
         uint32_t* dst = (uint32_t*)b + (size_t)reverse_bits((uint32_t)t, log_blowup) * n * count;

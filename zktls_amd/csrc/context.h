@@ -46,6 +46,14 @@ struct BigPlan {
     uint32_t* tw = nullptr;  // device, [R][N / R]
 };
 
+// tables of the native column-major passes (2^20-point vectors): pre [1024], post2d [1024][1024]
+struct ColPlan {
+    int inverse = 0;
+    uint32_t shift = 0;      // Montgomery coset shift (forward)
+    uint32_t* pre = nullptr;
+    uint32_t* post2d = nullptr;
+};
+
 struct DeviceBuffer {
     void* ptr = nullptr;
     size_t bytes = 0;
@@ -82,6 +90,7 @@ struct zkhip_ctx {
     uint32_t* w1024_inv = nullptr;
     std::deque<zk::NttPlan> plans;   // deque: references stay valid on push_back
     std::deque<zk::BigPlan> big_plans;
+    std::deque<zk::ColPlan> col_plans;
     zk::DeviceBuffer scratch[zk::S_COUNT];   // grow-only workspaces, indexed by zk::Slot
     zkhip_prove_debug debug{};
     // domain tables (prover.cpp): the current set, and every set built so far (a multi-chip shard switches between

@@ -39,6 +39,26 @@ struct NttPassArgs {
 };
 hipError_t launch_ntt_pass(const NttPassArgs& a, bool inverse, hipStream_t s);
 
+// ---- native passes over CONTIGUOUS VECTORS (RISC Zero's Hal layout: `count` polynomials of 2^20 coefficients, column-major).
+// A polynomial is viewed as a 1024 x 1024 matrix A[r][c] = v[1024 r + c]; a pass transforms the 1024-point columns of 32
+// adjacent c at a time (the tile shape of ntt_pass_kernel<4, *, 2, 5>), and where the four-step transpose requires it the tile
+// is loaded or stored TRANSPOSED through LDS, so that every global access is still a run of >= 2 KiB: no separate transpose pass.
+//   plain side:       element (i, col) at  base + 1024 * i + col                      (lanes along the 32 columns, 128-byte chunks)
+//   transposed side:  element (i, col) at  base + 1024 * map(col) + map(i)            (lanes along i: whole 4 KiB lines), map = bitrev10 if *_brev
+struct ColPassArgs {
+    const uint32_t* in;
+    uint32_t* out;
+    uint64_t in_batch, out_batch;    // elements between consecutive polynomials on either side
+    uint32_t count;
+    uint32_t tload, tstore, in_brev, out_brev;
+    const uint32_t* w1024;           // w_1024^(+-e)
+    const uint32_t* pre;             // [1024] or null: multiplies input element i
+    const uint32_t* post2d;          // [1024][1024] or null: multiplies output element (k, col) by post2d[1024 k + col]
+};
+hipError_t launch_ntt_colpass(const ColPassArgs& a, bool inverse, hipStream_t s);
+// out[i * cols + c] = scale * base_row^i ... generic 2-D table: out[1024 k + c] = scale * w^(k c) * shift^c
+hipError_t launch_post2d_table(uint32_t* out, uint32_t w, uint32_t shift, uint32_t scale, hipStream_t s);
+
 // ---- transforms of 2^21 / 2^22 rows: N = R N', R = 2^log_r (1 or 2), N' <= 2^20.  The N'-point transforms of the R row classes
 // j = n mod R run through the pass kernel above on sub-matrices (row pitch R ld); this streaming pass is the remaining radix-R
 // step (one read + one write of every element, 8 B/element):

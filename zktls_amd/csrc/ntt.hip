@@ -616,6 +616,170 @@ hipError_t launch_ntt_pass(const NttPassArgs& a_, bool inverse, hipStream_t s) {
     return inverse ? launch_ntt_k<4, true, 1>(a, s) : launch_ntt_k<4, false, 1>(a, s);
 }
 
+// ------------------------------------------------------------------ native passes over contiguous vectors (column-major polynomials)
+// The tile arithmetic is that of ntt_pass_kernel<4, INV, 2, 5>: 512 threads, thread (u, c) holds rows u + 32 n1 of two columns,
+// 32-point DIF in registers, tile twiddle, one LDS exchange per column, 32-point DIFs again.  What differs is how a tile reaches the
+// registers and leaves them (kernels.h, ColPassArgs): on a transposed side the 16 columns of one round are moved as sixteen 4 KiB lines
+// between global memory and the exchange buffer (row pitch 1028 words: the 4-word skew spreads the sixteen lines over the banks),
+// lanes along the line; the per-element inter-pass twiddle is a full 1024 x 1024 table read like the data (4 MiB, shared by every
+// polynomial of the batch, so it lives in L2 / MALL after the first).
+constexpr int COL_PT = 1028;          // words between the lines of the transposed staging buffer
+ZK_D uint32_t brev10(uint32_t x) { return __brev(x) >> 22; }
+template <bool INV>
+__global__ void __launch_bounds__(512, 4) ntt_colpass_kernel(ColPassArgs a) {
+    extern __shared__ uint32_t lds[];
+    constexpr int C = 16, Pn = 32, M = 1024, pitch = (Pn + 1) * C;
+    uint32_t* sdata = lds;
+    uint32_t* stw = lds + 32 * pitch;
+    uint32_t* spre = stw + M;
+    int64_t bias = (int64_t)((uint64_t)P << 32);
+    asm volatile("" : "+v"(bias));
+    const int tid = threadIdx.x, c = tid & 15, u = tid >> 4;
+    const uint32_t cg = blockIdx.x, poly = blockIdx.y;
+    const uint32_t* in = a.in + (uint64_t)poly * a.in_batch;
+    uint32_t* out = a.out + (uint64_t)poly * a.out_batch;
+    const bool has_pre = a.pre != nullptr;
+    for (int i = tid; i < M; i += 512) { stw[i] = a.w1024[i]; if (has_pre) spre[i] = a.pre[i]; }
+
+    uint32_t x[2][32];
+    if (!a.tload) {
+        const uint32_t* ib = in + cg * 32 + 2 * c;
+#pragma unroll
+        for (int n1 = 0; n1 < 32; n1++) {
+            const u32x2 v = __builtin_nontemporal_load(reinterpret_cast<const u32x2*>(ib + (uint64_t)(u + 32 * n1) * 1024));
+            x[0][n1] = v.x; x[1][n1] = v.y;
+        }
+        __syncthreads();
+    } else {
+#pragma unroll
+        for (int cc = 0; cc < 2; cc++) {
+            __syncthreads();
+            // sixteen lines of 1024 words -> staging buffer, lanes along the line (8 bytes per lane)
+#pragma unroll
+            for (int i = 0; i < 16; i++) {
+                const uint32_t idx = i * 512 + tid, cs = idx >> 9, kp = idx & 511;
+                const uint32_t col = cg * 32 + 2 * cs + cc;
+                const uint32_t line = a.in_brev ? brev10(col) : col;
+                const u32x2 v = __builtin_nontemporal_load(reinterpret_cast<const u32x2*>(in + (uint64_t)line * 1024 + 2 * kp));
+                *reinterpret_cast<u32x2*>(sdata + cs * COL_PT + 2 * kp) = v;
+            }
+            __syncthreads();
+#pragma unroll
+            for (int n1 = 0; n1 < 32; n1++) {
+                const uint32_t n = u + 32 * n1;
+                x[cc][n1] = sdata[c * COL_PT + (a.in_brev ? brev10(n) : n)];
+            }
+        }
+        __syncthreads();
+    }
+    if (has_pre) {
+#pragma unroll
+        for (int n1 = 0; n1 < 32; n1++) {
+            const uint32_t w = spre[u + Pn * n1];
+            x[0][n1] = dmul(x[0][n1], w); x[1][n1] = dmul(x[1][n1], w);
+        }
+    }
+#pragma unroll
+    for (int cc = 0; cc < 2; cc++) {
+        dif_stage<INV, 0>(x[cc], bias);
+        dif_stage<INV, 1>(x[cc], bias);
+        dif_stage<INV, 2>(x[cc], bias);
+        dif_stage<INV, 3>(x[cc], bias);
+        dif_stage<INV, 4, true, true>(x[cc], bias);
+#pragma unroll
+        for (int r = 1; r < 32; r++) x[cc][r] = (r & 1) ? dmul_sd(x[cc][r], stw[u * rev5(r)], bias) : dmul(x[cc][r], stw[u * rev5(r)]);
+        x[cc][0] = dred(x[cc][0]);
+        __builtin_amdgcn_sched_barrier(0);
+    }
+#pragma unroll
+    for (int cc = 0; cc < 2; cc++) {
+        __syncthreads();
+        uint32_t* wp = sdata + u * C + c;
+#pragma unroll
+        for (int r = 0; r < 32; r++) wp[rev5(r) * pitch] = x[cc][r];
+        __syncthreads();
+        const uint32_t* rp = sdata + c;
+#pragma unroll
+        for (int rho = 0; rho < 32; rho++) x[cc][rho] = rp[u * pitch + rho * C];      // P = 32: k1 = u, t = rho
+    }
+    const bool has_post = a.post2d != nullptr;
+#pragma unroll
+    for (int cc = 0; cc < 2; cc++) {
+        dif_stage<INV, 0>(x[cc], bias);
+        dif_stage<INV, 1>(x[cc], bias);
+        dif_stage<INV, 2>(x[cc], bias);
+        dif_stage<INV, 3>(x[cc], bias);
+        if (has_post) dif_stage<INV, 4, true, true>(x[cc], bias);
+        else dif_stage<INV, 4>(x[cc], bias);
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    // element k = 32 rev5(rho) + u of column (cg 32 + 2 c + cc) now sits in x[cc][rho]
+    if (has_post) {
+        const uint32_t* pb = a.post2d + cg * 32 + 2 * c;
+#pragma unroll
+        for (int rho = 0; rho < 32; rho++) {
+            const uint32_t k = 32 * rev5(rho) + u;
+            const u32x2 w = *reinterpret_cast<const u32x2*>(pb + (uint64_t)k * 1024);
+            x[0][rho] = (rho & 1) ? dmul_sd(x[0][rho], w.x, bias) : dmul(x[0][rho], w.x);
+            x[1][rho] = (rho & 1) ? dmul_sd(x[1][rho], w.y, bias) : dmul(x[1][rho], w.y);
+        }
+    }
+    if (!a.tstore) {
+        uint32_t* ob = out + cg * 32 + 2 * c;
+#pragma unroll
+        for (int rho = 0; rho < 32; rho++) {
+            const uint32_t k = 32 * rev5(rho) + u;
+            u32x2 v; v.x = x[0][rho]; v.y = x[1][rho];
+            __builtin_nontemporal_store(v, reinterpret_cast<u32x2*>(ob + (uint64_t)k * 1024));
+        }
+    } else {
+#pragma unroll
+        for (int cc = 0; cc < 2; cc++) {
+            __syncthreads();
+#pragma unroll
+            for (int rho = 0; rho < 32; rho++) {
+                const uint32_t k = 32 * rev5(rho) + u;
+                sdata[c * COL_PT + (a.out_brev ? brev10(k) : k)] = x[cc][rho];
+            }
+            __syncthreads();
+#pragma unroll
+            for (int i = 0; i < 16; i++) {
+                const uint32_t idx = i * 512 + tid, cs = idx >> 9, kp = idx & 511;
+                const uint32_t col = cg * 32 + 2 * cs + cc;
+                const uint32_t line = a.out_brev ? brev10(col) : col;
+                const u32x2 v = *reinterpret_cast<const u32x2*>(sdata + cs * COL_PT + 2 * kp);
+                __builtin_nontemporal_store(v, reinterpret_cast<u32x2*>(out + (uint64_t)line * 1024 + 2 * kp));
+            }
+        }
+    }
+}
+hipError_t launch_ntt_colpass(const ColPassArgs& a, bool inverse, hipStream_t s) {
+    if (a.count == 0) return hipSuccess;
+    const size_t lds = ntt_lds_bytes(10, 4);
+    static std::atomic<bool> configured[2][MAX_DEVICES] = {};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= MAX_DEVICES) return hipErrorInvalidDevice;
+    if (!configured[inverse][dev].load(std::memory_order_acquire)) {
+        hipError_t e = inverse ? hipFuncSetAttribute((const void*)ntt_colpass_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)
+                               : hipFuncSetAttribute((const void*)ntt_colpass_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+        configured[inverse][dev].store(true, std::memory_order_release);
+    }
+    const dim3 grid(32, a.count), block(512);
+    if (inverse) hipLaunchKernelGGL((ntt_colpass_kernel<true>), grid, block, lds, s, a);
+    else hipLaunchKernelGGL((ntt_colpass_kernel<false>), grid, block, lds, s, a);
+    return hipGetLastError();
+}
+__global__ void post2d_table_kernel(uint32_t* out, uint32_t w, uint32_t shift, uint32_t scale) {
+    const uint32_t idx = blockIdx.x * blockDim.x + threadIdx.x;      // 2^20 entries
+    const uint32_t k = idx >> 10, c = idx & 1023;
+    out[idx] = fmul(scale, fmul(fpow(w, (uint64_t)k * c), fpow(shift, c)));
+}
+hipError_t launch_post2d_table(uint32_t* out, uint32_t w, uint32_t shift, uint32_t scale, hipStream_t s) {
+    hipLaunchKernelGGL(post2d_table_kernel, dim3(4096), dim3(256), 0, s, out, w, shift, scale);
+    return hipGetLastError();
+}
+
 // ------------------------------------------------------------------ radix-2 / radix-4 combine pass (2^21, 2^22 rows)
 // Streaming: a thread owns VEC adjacent columns of one group of R rows; the twiddles of a group are row-uniform.  HBM-bound,
 // 8 B/element; arithmetic is R - 1 (forward) or R (inverse) Montgomery products per element group.
