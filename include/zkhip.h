@@ -321,10 +321,11 @@ int zkhip_verify_shard(const uint8_t* proof, size_t len, int log_n, uint32_t wid
  * body driven through p3-uni-stark's constraint folders (p3-air, p3-uni-stark 0.2.1-succinct: reference Cargo.lock:3835, 4055;
  * sp1-stark :6172; behind sp1.rs:116): a polynomial in the local / next row, the public values and the selectors
  * is_first_row / is_last_row / is_transition, folded as acc = acc * alpha + constraint.  A program is that polynomial in
- * sum-of-products form, interpreted by the quotient kernel on the device and by the verifier at zeta; any AIR of degree <= 3
- * (log_quotient_degree 1, the bound of SP1's core machine) is proven without touching a kernel.  HOST words, canonical residues:
+ * sum-of-products form, interpreted by the quotient kernel on the device and by the verifier at zeta; any AIR of degree <= 5
+ * is proven without touching a kernel: degree <= 3 (the bound of SP1's core machine) gives two quotient chunks
+ * (log_quotient_degree 1), degree 4 or 5 four chunks (log_quotient_degree 2; needs log_blowup >= 2).  HOST words, canonical residues:
  *   [0] 0x50524941 "AIRP"  [1] 1  [2] width  [3] constraints K  [4] n_public  [5] total words
- *   K x { selector (0 every row, 1 first row, 2 last row, 3 transition), n_terms, n_terms x { coefficient, degree d <= 3, d variables } }
+ *   K x { selector (0 every row, 1 first row, 2 last row, 3 transition), n_terms, n_terms x { coefficient, degree d <= 5, d variables } }
  *   variable = kind << 30 | index;  kind 0: column of the local row, 1: column of the next row, 2: public value.
  * Value of a constraint = selector * sum_t coeff_t * prod_j var_tj (a selector counts one degree).  Proofs carry version 7: the
  * extended header, then the 8-word digest of the program (zkhip_air_digest), which the transcript observes -- a proof is bound
@@ -333,7 +334,7 @@ int zkhip_air_validate(const uint32_t* program, size_t words, uint32_t width, si
 int zkhip_air_digest(const uint32_t* program, size_t words, uint32_t out[8]);
 /* the built-in synthetic AIR written as a program; out == NULL: *words receives the size */
 int zkhip_air_synthetic(uint32_t width, size_t n_public, uint32_t* out, size_t cap, size_t* words);
-size_t zkhip_proof_size_air(int log_n, uint32_t width, const zkhip_params* prm, size_t n_public);
+size_t zkhip_proof_size_air(const uint32_t* program, size_t program_words, int log_n, uint32_t width, const zkhip_params* prm, size_t n_public);
 int zkhip_prove_shard_air(zkhip_ctx* ctx, const uint32_t* program, size_t program_words, const uint32_t* d_trace, size_t ld, int log_n,
                           uint32_t width, const uint32_t* public_values, size_t n_public, const zkhip_params* prm,
                           uint8_t* proof, size_t cap, size_t* len);

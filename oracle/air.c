@@ -10,10 +10,10 @@
  * Program (u32 words, canonical residues):
  *   [0] 0x50524941 "AIRP"   [1] 1 (format)   [2] width   [3] number of constraints K   [4] n_public   [5] total words
  *   then K constraints:  selector (0 every row, 1 first row, 2 last row, 3 transition), n_terms,
- *                        then n_terms terms:  coefficient, degree d (0..3), d variables
+ *                        then n_terms terms:  coefficient, degree d (0..5), d variables
  *   variable: bits 31..30 = kind (0 local row, 1 next row, 2 public value), bits 15..0 = column / index.
- * value of a constraint = selector * sum_t coeff_t * prod_j var_tj; its degree (largest d, + 1 with a selector) is at most 3,
- * so the quotient has two chunks (log_quotient_degree = 1).
+ * value of a constraint = selector * sum_t coeff_t * prod_j var_tj; its degree (largest d, + 1 with a selector) is at most 5:
+ * degree <= 3 gives two quotient chunks (log_quotient_degree 1), degree 4 or 5 four chunks (log_quotient_degree 2, log_blowup >= 2).
  */
 #include <stdlib.h>
 #include <string.h>
@@ -34,7 +34,7 @@ int orc_air_validate(const uint32_t* prog, size_t words, size_t width, size_t n_
         for (uint32_t t = 0; t < nt; t++) {
             if (p + 2 > words) return 0;
             uint32_t coeff = prog[p++], d = prog[p++];
-            if (coeff >= BB_P || d > 3 || d + (sel ? 1 : 0) > 3 || p + d > words) return 0;
+            if (coeff >= BB_P || d > 5 || d + (sel ? 1 : 0) > 5 || p + d > words) return 0;
             for (uint32_t j = 0; j < d; j++) {
                 uint32_t v = prog[p++], kind = v >> 30, idx = v & 0xFFFFu;
                 if ((v & 0x3FFF0000u) || kind > 2) return 0;
@@ -43,6 +43,22 @@ int orc_air_validate(const uint32_t* prog, size_t words, size_t width, size_t n_
         }
     }
     return p == words;
+}
+
+/* log2 of the number of quotient chunks: degree <= 3 -> 1 (two chunks), degree 4 or 5 -> 2 (four chunks; needs log_blowup >= 2) */
+int orc_air_log_quotient_degree(const uint32_t* prog) {
+    uint32_t maxd = 0;
+    size_t p = 6;
+    for (uint32_t k = 0; k < prog[3]; k++) {
+        uint32_t sel = prog[p++], nt = prog[p++];
+        for (uint32_t t = 0; t < nt; t++) {
+            p++;
+            uint32_t d = prog[p++];
+            if (d + (sel ? 1 : 0) > maxd) maxd = d + (sel ? 1 : 0);
+            p += d;
+        }
+    }
+    return maxd <= 3 ? 1 : 2;
 }
 
 /* digest of the program: the width-16 sponge over the 16-bit halves of every word (halves are field elements whatever the word) */
@@ -98,10 +114,11 @@ bb4_t orc__air_fold_ext(const uint32_t* prog, const bb4_t* local, const bb4_t* n
     return acc;
 }
 
-/* quotient values of a program on the coset g * <w_2N>: the first 2N rows of the bit-reversed LDE; out[p] (extension), bit-reversed */
+/* quotient values of a program on the coset g * <w_{2^lqd N}>: the first 2^lqd N rows of the bit-reversed LDE; out[p] (extension), bit-reversed */
 void orc_quotient_values_air(const uint32_t* prog, const uint32_t* lde, int log_n, size_t width, const uint32_t* pub,
-                             const uint32_t alpha_[4], uint32_t* out) {
-    const int log_m = log_n + 1;
+                             const uint32_t alpha_[4], int lqd, uint32_t* out) {
+    const int log_m = log_n + lqd;
+    const size_t step = (size_t)1 << lqd;              /* the next trace row is `step` points further on the quotient domain */
     const size_t m = (size_t)1 << log_m, n = (size_t)1 << log_n;
     const bb4_t alpha = orc__ld4(alpha_);
     const bb_t w = bb_two_adic_generator(log_m), wn_inv = bb_inv(bb_two_adic_generator(log_n));
@@ -112,7 +129,7 @@ void orc_quotient_values_air(const uint32_t* prog, const uint32_t* lde, int log_
         bb_t sel_first = bb_mul(zh, bb_inv(bb_sub(x, 1)));
         bb_t sel_last = bb_mul(zh, bb_inv(bb_sub(x, wn_inv)));
         bb_t sel_trans = bb_sub(x, wn_inv);
-        size_t p = bb_reverse_bits((uint32_t)i, log_m), pn = bb_reverse_bits((uint32_t)((i + 2) & (m - 1)), log_m);
+        size_t p = bb_reverse_bits((uint32_t)i, log_m), pn = bb_reverse_bits((uint32_t)((i + step) & (m - 1)), log_m);
         bb4_t acc = orc__air_fold_base(prog, lde + p * width, lde + pn * width, pub, sel_first, sel_last, sel_trans, alpha);
         orc__st4(out + 4 * p, bb4_mul_base(acc, bb_inv(zh)));
     }

@@ -201,9 +201,10 @@ void orc_hal_hash_fold_sha256(const uint32_t* children, uint32_t* parents, size_
 int orc_air_validate(const uint32_t* prog, size_t words, size_t width, size_t n_public);
 void orc_air_digest(const uint32_t* prog, size_t words, uint32_t out[8]);
 size_t orc_air_synthetic(size_t width, size_t n_public, uint32_t* out, size_t cap);
+int orc_air_log_quotient_degree(const uint32_t* prog);
 void orc_quotient_values_air(const uint32_t* prog, const uint32_t* lde, int log_n, size_t width, const uint32_t* pub,
-                             const uint32_t alpha[4], uint32_t* out);
-size_t orc_proof_size_air(int log_n, size_t width, const orc_params_t* prm, size_t n_public);
+                             const uint32_t alpha[4], int log_quotient_degree, uint32_t* out);
+size_t orc_proof_size_air(int log_n, size_t width, const orc_params_t* prm, size_t n_public, int log_quotient_degree);
 size_t orc_prove_shard_air(const uint32_t* prog, size_t prog_words, const uint32_t* trace, int log_n, size_t width,
                            const uint32_t* public_values, size_t n_public, const orc_params_t* prm, uint8_t* proof_bytes, size_t cap);
 int orc_verify_shard_air(const uint32_t* prog, size_t prog_words, const uint8_t* proof_bytes, size_t len, int log_n, size_t width,

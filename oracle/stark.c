@@ -399,6 +399,8 @@ void orc_fri_fold_k(const uint32_t* in, int log_h, int log_arity, const uint32_t
  * built-in synthetic AIR.  With a program the proof is version 7: extended header, then the 8-word program digest. */
 static __thread const uint32_t* g_air = NULL;
 static __thread size_t g_air_words = 0;
+static __thread int g_air_lqd = 1;      /* log2 of the number of quotient chunks: 1 (degree <= 3) or 2 (degree <= 5, needs log_blowup >= 2) */
+#define NQ_CUR ((size_t)1 << (g_air ? g_air_lqd : 1))
 #define PROOF_MAGIC 0x41544B5Au   /* "ZKTA" */
 #define PROOF_VERSION 1u
 
@@ -425,8 +427,8 @@ size_t orc_proof_size(int log_n, size_t width, const orc_params_t* prm, size_t n
     if (!shape_of(log_n, width, prm, &sh)) return 0;
     size_t H = (size_t)(log_n + sh.b);
     size_t Q = (size_t)prm->logup_pairs, wp = Q ? 4 * (Q + 1) : 0;
-    size_t words = (g_air ? 20 : (sh.ext ? 12 : (Q ? 9 : 8))) + 16 + 8 * width + 32 + 8 * (size_t)sh.R + 4 * ((size_t)1 << sh.F) + 1;
-    size_t perq = width + 8 + 16 * H;
+    size_t words = (g_air ? 20 : (sh.ext ? 12 : (Q ? 9 : 8))) + 16 + 8 * width + 16 * NQ_CUR + 8 * (size_t)sh.R + 4 * ((size_t)1 << sh.F) + 1;
+    size_t perq = width + 4 * NQ_CUR + 16 * H;
     if (Q) { words += 8 + 8 * wp; perq += wp + 8 * H; }
     for (int l = 0; l < sh.R; l++) perq += 4 * (((size_t)1 << sh.K) - 1) + 8 * (H - (size_t)sh.K * (l + 1));
     words += (size_t)prm->num_queries * perq;
@@ -497,7 +499,10 @@ size_t orc_prove_shard(const uint32_t* trace, int log_n, size_t width,
     if (cap < need) return 0;
     uint32_t* pf = (uint32_t*)proof_bytes;
     size_t pos = 0;
-    const int H = log_n + sh.b, Hq = log_n + 1, Q = prm->logup_pairs;      /* LDE domain 2^H, quotient domain 2^Hq */
+    const int lqd = g_air ? g_air_lqd : 1;
+    if (lqd > sh.b) return 0;                                              /* the quotient domain must lie inside the committed LDE domain */
+    const int H = log_n + sh.b, Hq = log_n + lqd, Q = prm->logup_pairs;    /* LDE domain 2^H, quotient domain 2^Hq */
+    const size_t NQ = (size_t)1 << lqd, QW = 4 * NQ;                       /* quotient chunks, width of the quotient matrix */
     const size_t n = (size_t)1 << log_n, m = (size_t)1 << H, mq = (size_t)1 << Hq, wp = Q ? 4 * ((size_t)Q + 1) : 0;
 
     pf[pos++] = PROOF_MAGIC; pf[pos++] = g_air ? 7u : (sh.ext ? 3u : (Q ? 2u : PROOF_VERSION)); pf[pos++] = (uint32_t)log_n;
@@ -546,30 +551,30 @@ size_t orc_prove_shard(const uint32_t* trace, int log_n, size_t width,
     /* The quotient domain g*<w_2N> is the first 2N rows of the bit-reversed LDE on g*<w_{2^H}>, in the
      * bit-reversed order of its own 2N points -- so the blowup-2 routine applies to those rows as is. */
     uint32_t* qv = (uint32_t*)malloc(mq * 16);         /* bit-reversed like the LDE */
-    if (g_air) orc_quotient_values_air(g_air, tlde, log_n, width, public_values, alpha.c, qv);
+    if (g_air) orc_quotient_values_air(g_air, tlde, log_n, width, public_values, alpha.c, lqd, qv);
     else orc_quotient_values_logup(tlde, log_n, width, plde, Q, gamma.c, beta_l.c, alpha.c, qv);
     /* chunk k = natural rows i = 2j + k  <->  bit-reversed rows [k*N, (k+1)*N);
      * as a matrix on the coset (g w^k) * <w_N> in natural order j: */
-    uint32_t* qlde = (uint32_t*)malloc(m * 8 * 4);     /* [chunk0 | chunk1], width 8 */
+    uint32_t* qlde = (uint32_t*)malloc(m * QW * 4);    /* [chunk0 | chunk1 | ...], 4 columns per chunk */
     {
         uint32_t* chunk = (uint32_t*)malloc(n * 4 * 4);
         uint32_t* clde = (uint32_t*)malloc(m * 4 * 4);
         bb_t w2n = bb_two_adic_generator(Hq);
-        for (int k = 0; k < 2; k++) {
+        for (size_t k = 0; k < NQ; k++) {
             for (size_t j = 0; j < n; j++) {
-                size_t p = bb_reverse_bits((uint32_t)(2 * j + k), Hq);
+                size_t p = bb_reverse_bits((uint32_t)(NQ * j + k), Hq);
                 memcpy(chunk + 4 * j, qv + 4 * p, 16);
             }
             /* values on (g w^k)*<w_N> -> LDE on g*<w_{2^H}>: shift = g / (g w^k) */
             bb_t shift = bb_inv(bb_pow(w2n, (uint64_t)k));
             orc_coset_lde(chunk, clde, log_n, 4, sh.b, shift);
-            for (size_t r = 0; r < m; r++) memcpy(qlde + r * 8 + 4 * k, clde + r * 4, 16);
+            for (size_t r = 0; r < m; r++) memcpy(qlde + r * QW + 4 * k, clde + r * 4, 16);
         }
         free(chunk); free(clde);
     }
     free(qv);
     uint32_t* qtree = (uint32_t*)malloc((2 * m - 1) * 32);
-    orc_merkle_tree_hw(qlde, 8, H, qtree, sh.hw);
+    orc_merkle_tree_hw(qlde, QW, H, qtree, sh.hw);
     const uint32_t* qroot = qtree + (2 * m - 2) * 8;
     memcpy(pf + pos, qroot, 32); pos += 8;
     memcpy(g_dbg.quotient_root, qroot, 32);
@@ -583,22 +588,22 @@ size_t orc_prove_shard(const uint32_t* trace, int log_n, size_t width,
     uint32_t* op_next = pf + pos; pos += 4 * width;
     uint32_t *op_pl = NULL, *op_pn = NULL;
     if (Q) { op_pl = pf + pos; pos += 4 * wp; op_pn = pf + pos; pos += 4 * wp; }
-    uint32_t* op_q = pf + pos; pos += 32;
+    uint32_t* op_q = pf + pos; pos += 4 * QW;
     orc_open_at(tlde, log_n, width, zeta.c, op_local);
     orc_open_at(tlde, log_n, width, zeta_next.c, op_next);
     if (Q) { orc_open_at(plde, log_n, wp, zeta.c, op_pl); orc_open_at(plde, log_n, wp, zeta_next.c, op_pn); }
-    orc_open_at(qlde, log_n, 8, zeta.c, op_q);
+    orc_open_at(qlde, log_n, QW, zeta.c, op_q);
     orc_chal_observe_slice(&ch, op_local, 4 * width);
     orc_chal_observe_slice(&ch, op_next, 4 * width);
     if (Q) { orc_chal_observe_slice(&ch, op_pl, 4 * wp); orc_chal_observe_slice(&ch, op_pn, 4 * wp); }
-    orc_chal_observe_slice(&ch, op_q, 32);
+    orc_chal_observe_slice(&ch, op_q, 4 * QW);
 
     /* 4. FRI input: alpha-batched reduced openings at every LDE point.
      * batching order (offsets in powers of the FRI alpha): trace@zeta 0, trace@zeta_next W,
      * [perm@zeta 2W, perm@zeta_next 2W+Wp], quotient@zeta 2W+2Wp */
     bb4_t fa = sample_ext(&ch);
     memcpy(g_dbg.fri_alpha, fa.c, 16);
-    size_t np = width > 8 ? width : 8;
+    size_t np = width > QW ? width : QW;
     if (wp > np) np = wp;
     bb4_t* fapow = (bb4_t*)malloc(np * sizeof(bb4_t));
     fapow[0] = bb4_one();
@@ -612,7 +617,7 @@ size_t orc_prove_shard(const uint32_t* trace, int log_n, size_t width,
         y_pl = bb4_add(y_pl, bb4_mul(fapow[j], ld4(op_pl + 4 * j)));
         y_pn = bb4_add(y_pn, bb4_mul(fapow[j], ld4(op_pn + 4 * j)));
     }
-    for (size_t j = 0; j < 8; j++) y_q = bb4_add(y_q, bb4_mul(fapow[j], ld4(op_q + 4 * j)));
+    for (size_t j = 0; j < QW; j++) y_q = bb4_add(y_q, bb4_mul(fapow[j], ld4(op_q + 4 * j)));
     bb4_t off_next = bb4_pow(fa, width), off_pl = bb4_pow(fa, 2 * width), off_pn = bb4_pow(fa, 2 * width + wp),
           off_q = bb4_pow(fa, 2 * width + 2 * wp);
     bb4_t* cur = (bb4_t*)malloc(m * sizeof(bb4_t));
@@ -624,7 +629,7 @@ size_t orc_prove_shard(const uint32_t* trace, int log_n, size_t width,
             bb4_t d1 = bb4_inv(bb4_neg(bb4_sub_base(zeta, x)));        /* 1/(x - zeta) */
             bb4_t d2 = bb4_inv(bb4_neg(bb4_sub_base(zeta_next, x)));
             bb4_t at = row_dot(fapow, tlde + p * width, width);
-            bb4_t aq = row_dot(fapow, qlde + p * 8, 8);
+            bb4_t aq = row_dot(fapow, qlde + p * QW, QW);
             bb4_t r = bb4_mul(bb4_sub(at, y_loc), d1);
             r = bb4_add(r, bb4_mul(off_next, bb4_mul(bb4_sub(at, y_nxt), d2)));
             if (Q) {
@@ -689,7 +694,7 @@ size_t orc_prove_shard(const uint32_t* trace, int log_n, size_t width,
         memcpy(pf + pos, tlde + index * width, width * 4); pos += width;
         copy_path(pf, &pos, ttree, m, index, H);
         if (Q) { memcpy(pf + pos, plde + index * wp, wp * 4); pos += wp; copy_path(pf, &pos, ptree, m, index, H); }
-        memcpy(pf + pos, qlde + index * 8, 32); pos += 8;
+        memcpy(pf + pos, qlde + index * QW, QW * 4); pos += QW;
         copy_path(pf, &pos, qtree, m, index, H);
         size_t idx = index;
         for (int l = 0; l < R; l++) {
@@ -728,7 +733,10 @@ int orc_verify_shard(const uint8_t* proof_bytes, size_t len, int log_n, size_t w
     if (len != orc_proof_size(log_n, width, prm, n_public)) return 2;
     const uint32_t* pf = (const uint32_t*)proof_bytes;
     size_t pos = 0;
-    const int H = log_n + sh.b, Hq = log_n + 1, R = sh.R, K = sh.K, Q = prm->logup_pairs;
+    const int lqd = g_air ? g_air_lqd : 1;
+    if (lqd > sh.b) return 1;
+    const size_t NQ = (size_t)1 << lqd, QW = 4 * NQ;
+    const int H = log_n + sh.b, Hq = log_n + lqd, R = sh.R, K = sh.K, Q = prm->logup_pairs;
     const size_t n = (size_t)1 << log_n, wp = Q ? 4 * ((size_t)Q + 1) : 0, arity = (size_t)1 << K;
     if (pf[0] != PROOF_MAGIC || pf[1] != (g_air ? 7u : (sh.ext ? 3u : (Q ? 2u : PROOF_VERSION))) || pf[2] != (uint32_t)log_n ||
         pf[3] != (uint32_t)width || pf[4] != (uint32_t)prm->log_blowup ||
@@ -770,11 +778,11 @@ int orc_verify_shard(const uint8_t* proof_bytes, size_t len, int log_n, size_t w
     const uint32_t* op_next = pf + pos; pos += 4 * width;
     const uint32_t *op_pl = NULL, *op_pn = NULL;
     if (Q) { op_pl = pf + pos; pos += 4 * wp; op_pn = pf + pos; pos += 4 * wp; }
-    const uint32_t* op_q = pf + pos; pos += 32;
+    const uint32_t* op_q = pf + pos; pos += 4 * QW;
     orc_chal_observe_slice(&ch, op_local, 4 * width);
     orc_chal_observe_slice(&ch, op_next, 4 * width);
     if (Q) { orc_chal_observe_slice(&ch, op_pl, 4 * wp); orc_chal_observe_slice(&ch, op_pn, 4 * wp); }
-    orc_chal_observe_slice(&ch, op_q, 32);
+    orc_chal_observe_slice(&ch, op_q, 4 * QW);
 
     /* (a) constraint check at zeta */
     {
@@ -795,16 +803,21 @@ int orc_verify_shard(const uint8_t* proof_bytes, size_t len, int log_n, size_t w
             folded = fold_logup(folded, Q, as, bs, ar, br, pl, pn, gamma, beta_l, sel_first, sel_trans, sel_last, alpha, bb4_zero());
         }
         free(loc); free(nxt);
-        /* quotient(zeta) = sum_k zps_k(zeta) * q_k(zeta); chunk domain k: shift s_k = g w_2N^k */
-        bb_t w2n = bb_two_adic_generator(Hq);
-        bb_t s[2] = {BB_GEN, bb_mul(BB_GEN, w2n)};
+        /* quotient(zeta) = sum_k zps_k(zeta) * q_k(zeta); chunk k lives on the coset s_k <w_N>, s_k = g w_{2^Hq}^k, and
+         * zps_k = prod_{j != k} Z_Dj(zeta) / Z_Dj(s_k) with Z_Dj(x) = (x / s_j)^N - 1 vanishes on every other chunk's coset */
+        bb_t wq = bb_two_adic_generator(Hq);
+        bb_t sN[4];
+        for (size_t k = 0; k < NQ; k++) sN[k] = bb_pow(bb_mul(BB_GEN, bb_pow(wq, k)), n);      /* s_k^N */
         bb4_t quot = bb4_zero();
-        for (int k = 0; k < 2; k++) {
-            int j = 1 - k;
-            bb_t sjn_inv = bb_inv(bb_pow(s[j], n));
-            bb4_t num = bb4_sub_base(bb4_mul_base(zn, sjn_inv), 1);                 /* Z_Dj(zeta) */
-            bb_t den = bb_sub(bb_mul(bb_pow(s[k], n), sjn_inv), 1);                 /* Z_Dj(s_k)  */
-            bb4_t zps = bb4_mul_base(num, bb_inv(den));
+        for (size_t k = 0; k < NQ; k++) {
+            bb4_t zps = bb4_one();
+            for (size_t j = 0; j < NQ; j++) {
+                if (j == k) continue;
+                bb_t sjn_inv = bb_inv(sN[j]);
+                bb4_t num = bb4_sub_base(bb4_mul_base(zn, sjn_inv), 1);                 /* Z_Dj(zeta) */
+                bb_t den = bb_sub(bb_mul(sN[k], sjn_inv), 1);                           /* Z_Dj(s_k)  */
+                zps = bb4_mul(zps, bb4_mul_base(num, bb_inv(den)));
+            }
             quot = bb4_add(quot, bb4_mul(zps, recombine(op_q + 16 * k)));
         }
         if (!bb4_eq(bb4_mul(folded, bb4_inv(zh)), quot)) return 10;
@@ -812,7 +825,7 @@ int orc_verify_shard(const uint8_t* proof_bytes, size_t len, int log_n, size_t w
 
     /* (b) FRI */
     bb4_t fa = sample_ext(&ch);
-    size_t np = width > 8 ? width : 8;
+    size_t np = width > QW ? width : QW;
     if (wp > np) np = wp;
     bb4_t* fapow = (bb4_t*)malloc(np * sizeof(bb4_t));
     fapow[0] = bb4_one();
@@ -826,7 +839,7 @@ int orc_verify_shard(const uint8_t* proof_bytes, size_t len, int log_n, size_t w
         y_pl = bb4_add(y_pl, bb4_mul(fapow[j], ld4(op_pl + 4 * j)));
         y_pn = bb4_add(y_pn, bb4_mul(fapow[j], ld4(op_pn + 4 * j)));
     }
-    for (size_t j = 0; j < 8; j++) y_q = bb4_add(y_q, bb4_mul(fapow[j], ld4(op_q + 4 * j)));
+    for (size_t j = 0; j < QW; j++) y_q = bb4_add(y_q, bb4_mul(fapow[j], ld4(op_q + 4 * j)));
     bb4_t off_next = bb4_pow(fa, width), off_pl = bb4_pow(fa, 2 * width), off_pn = bb4_pow(fa, 2 * width + wp),
           off_q = bb4_pow(fa, 2 * width + 2 * wp);
 
@@ -850,15 +863,15 @@ int orc_verify_shard(const uint8_t* proof_bytes, size_t len, int log_n, size_t w
         const uint32_t* tpath = pf + pos; pos += 8 * (size_t)H;
         const uint32_t *prow = NULL, *ppath = NULL;
         if (Q) { prow = pf + pos; pos += wp; ppath = pf + pos; pos += 8 * (size_t)H; }
-        const uint32_t* qrow = pf + pos; pos += 8;
+        const uint32_t* qrow = pf + pos; pos += QW;
         const uint32_t* qpath = pf + pos; pos += 8 * (size_t)H;
         if (orc_merkle_verify_hw(troot, H, index, trow, width, tpath, sh.hw)) { rc = 30; break; }
         if (Q && orc_merkle_verify_hw(proot, H, index, prow, wp, ppath, sh.hw)) { rc = 32; break; }
-        if (orc_merkle_verify_hw(qroot, H, index, qrow, 8, qpath, sh.hw)) { rc = 31; break; }
+        if (orc_merkle_verify_hw(qroot, H, index, qrow, QW, qpath, sh.hw)) { rc = 31; break; }
         bb_t x = bb_mul(BB_GEN, bb_pow(wm, bb_reverse_bits((uint32_t)index, H)));
         bb4_t d1 = bb4_inv(bb4_neg(bb4_sub_base(zeta, x)));
         bb4_t d2 = bb4_inv(bb4_neg(bb4_sub_base(zeta_next, x)));
-        bb4_t at = row_dot(fapow, trow, width), aq = row_dot(fapow, qrow, 8);
+        bb4_t at = row_dot(fapow, trow, width), aq = row_dot(fapow, qrow, QW);
         bb4_t ro = bb4_mul(bb4_sub(at, y_loc), d1);
         ro = bb4_add(ro, bb4_mul(off_next, bb4_mul(bb4_sub(at, y_nxt), d2)));
         if (Q) {
@@ -903,18 +916,19 @@ int orc_verify_shard(const uint8_t* proof_bytes, size_t len, int log_n, size_t w
 /* ------------------------------------------------------------------ */
 /* the same prover / verifier with the AIR supplied as a constraint program (oracle/air.c); proof version 7 */
 /* ------------------------------------------------------------------ */
-size_t orc_proof_size_air(int log_n, size_t width, const orc_params_t* prm, size_t n_public) {
+size_t orc_proof_size_air(int log_n, size_t width, const orc_params_t* prm, size_t n_public, int log_quotient_degree) {
     static const uint32_t marker[1] = {0};
     const uint32_t* saved = g_air;
-    g_air = marker;
-    size_t r = prm->logup_pairs ? 0 : orc_proof_size(log_n, width, prm, n_public);
-    g_air = saved;
+    const int saved_lqd = g_air_lqd;
+    g_air = marker; g_air_lqd = log_quotient_degree;
+    size_t r = (prm->logup_pairs || log_quotient_degree < 1 || log_quotient_degree > 2 || log_quotient_degree > prm->log_blowup) ? 0 : orc_proof_size(log_n, width, prm, n_public);
+    g_air = saved; g_air_lqd = saved_lqd;
     return r;
 }
 size_t orc_prove_shard_air(const uint32_t* prog, size_t prog_words, const uint32_t* trace, int log_n, size_t width,
                            const uint32_t* public_values, size_t n_public, const orc_params_t* prm, uint8_t* proof_bytes, size_t cap) {
     if (prm->logup_pairs || !orc_air_validate(prog, prog_words, width, n_public)) return 0;
-    g_air = prog; g_air_words = prog_words;
+    g_air = prog; g_air_words = prog_words; g_air_lqd = orc_air_log_quotient_degree(prog);
     size_t r = orc_prove_shard(trace, log_n, width, public_values, n_public, prm, proof_bytes, cap);
     g_air = NULL; g_air_words = 0;
     return r;
@@ -922,7 +936,7 @@ size_t orc_prove_shard_air(const uint32_t* prog, size_t prog_words, const uint32
 int orc_verify_shard_air(const uint32_t* prog, size_t prog_words, const uint8_t* proof_bytes, size_t len, int log_n, size_t width,
                          const uint32_t* public_values, size_t n_public, const orc_params_t* prm) {
     if (prm->logup_pairs || !orc_air_validate(prog, prog_words, width, n_public)) return 1;
-    g_air = prog; g_air_words = prog_words;
+    g_air = prog; g_air_words = prog_words; g_air_lqd = orc_air_log_quotient_degree(prog);
     int r = orc_verify_shard(proof_bytes, len, log_n, width, public_values, n_public, prm);
     g_air = NULL; g_air_words = 0;
     return r;

@@ -51,3 +51,26 @@ def counter_trace(log_n, width, start, step):
     for j in range(1, width):
         t[:, j] = (x * x % P * j + t[:, j - 1]) % P
     return t.astype(np.uint32), [start % P, step % P]
+
+
+def quintic_program():
+    """4 columns (x, y, z, w): y = x^5 on every row (degree 5), z = x y y w (degree 4), w (w - 1) = 0, x' = x + 1 on transitions,
+    x of the first row = public value 0.  Degree 5: four quotient chunks (log_quotient_degree 2), needs log_blowup >= 2."""
+    return O.air_program(4, 1, [
+        (O.SEL_ALL, [(1, [V(1)]), (P - 1, [V(0)] * 5)]),
+        (O.SEL_TRANSITION, [(1, [V(0, True)]), (P - 1, [V(0)]), (P - 1, [])]),
+        (O.SEL_ALL, [(1, [V(2)]), (P - 1, [V(0), V(1), V(1), V(3)])]),
+        (O.SEL_ALL, [(1, [V(3), V(3)]), (P - 1, [V(3)])]),
+        (O.SEL_FIRST, [(1, [V(0)]), (P - 1, [V(0, public=True)])]),
+    ])
+
+
+def quintic_trace(log_n, x0):
+    n = 1 << log_n
+    t = np.zeros((n, 4), dtype=np.uint64)
+    for i in range(n):
+        x = (x0 + i) % P
+        y = pow(x, 5, P)
+        w = (i >> 1) & 1
+        t[i] = [x, y, x * y % P * y % P * w % P, w]
+    return t.astype(np.uint32), [x0 % P]

@@ -530,11 +530,16 @@ def air_digest(prog):
     return out
 
 
+def air_log_quotient_degree(prog):
+    return int(lib().orc_air_log_quotient_degree(_p(_u32(prog))))
+
+
 def quotient_values_air(prog, lde, log_n, public_values, alpha):
     lde, prog = _u32(lde), _u32(prog)
     pv = _u32(np.array(list(public_values) or [0], dtype=np.uint32))
-    out = np.empty((2 << log_n, 4), dtype=np.uint32)
-    lib().orc_quotient_values_air(_p(prog), _p(lde), C.c_int(log_n), C.c_size_t(lde.shape[1]), _p(pv), _p(_u32(alpha)), _p(out))
+    lqd = air_log_quotient_degree(prog)
+    out = np.empty((1 << (log_n + lqd), 4), dtype=np.uint32)
+    lib().orc_quotient_values_air(_p(prog), _p(lde), C.c_int(log_n), C.c_size_t(lde.shape[1]), _p(pv), _p(_u32(alpha)), C.c_int(lqd), _p(out))
     return out
 
 
@@ -548,7 +553,7 @@ def prove_shard_air(prog, trace, public_values=(), params=None):
     L = lib()
     L.orc_proof_size_air.restype = C.c_size_t
     L.orc_prove_shard_air.restype = C.c_size_t
-    size = L.orc_proof_size_air(C.c_int(log_n), C.c_size_t(w), C.byref(params), C.c_size_t(npub))
+    size = L.orc_proof_size_air(C.c_int(log_n), C.c_size_t(w), C.byref(params), C.c_size_t(npub), C.c_int(air_log_quotient_degree(prog)))
     buf = np.empty(size, dtype=np.uint8)
     got = L.orc_prove_shard_air(_p(prog), C.c_size_t(prog.size), _p(t), C.c_int(log_n), C.c_size_t(w), _p(pv), C.c_size_t(npub), C.byref(params),
                                 buf.ctypes.data_as(C.POINTER(C.c_uint8)), C.c_size_t(size))

@@ -113,6 +113,20 @@ def air_digest(program):
     return pyref.sponge_hash(limbs)
 
 
+def air_log_quotient_degree(program):
+    """degree (largest number of factors in a term, + 1 under a selector) <= 3: two quotient chunks; 4 or 5: four"""
+    prog = [int(x) for x in program]
+    maxd, p = 0, 6
+    for _ in range(prog[3]):
+        sel, nt = prog[p], prog[p + 1]
+        p += 2
+        for _t in range(nt):
+            d = prog[p + 1]
+            maxd = max(maxd, d + (1 if sel else 0))
+            p += 2 + d
+    return 1 if maxd <= 3 else 2
+
+
 def air_fold(program, loc, nxt, public_values, sel_first, sel_last, sel_trans, alpha):
     """acc = acc * alpha + selector * sum_t coeff_t * prod_j var_tj, constraint by constraint, on extension values"""
     prog = [int(x) for x in program]
@@ -159,6 +173,11 @@ def verify(proof_bytes, log_n, width, public_values, log_blowup=1, num_queries=1
     N = 1 << log_n
     Q = logup_pairs
     Wp = 4 * (Q + 1) if Q else 0               # permutation-trace width in base columns
+    lqd = air_log_quotient_degree(air) if air is not None else 1
+    if lqd > b:
+        raise Reject("the quotient domain must lie inside the committed LDE domain")
+    NQ = 1 << lqd                              # quotient chunks, each committed as 4 base columns
+    QW = 4 * NQ
     hasher = Hash(hw)
 
     # ---- header
@@ -210,7 +229,7 @@ def verify(proof_bytes, log_n, width, public_values, log_blowup=1, num_queries=1
 
     loc, nxt = take_ext(width), take_ext(width)
     pl, pn = take_ext(Wp), take_ext(Wp)
-    qz = take_ext(8)
+    qz = take_ext(QW)
     for group in (loc, nxt, pl, pn, qz):       # opened values are observed before the FRI batching challenge is drawn
         for e in group:
             ts.observe_many(e)
@@ -246,22 +265,27 @@ def verify(proof_bytes, log_n, width, public_values, log_blowup=1, num_queries=1
         fold(ext_mul(sel_first, e_sub(S, sum_l)))
         fold(ext_mul(sel_trans, e_sub(e_sub(Sn, S), sum_n)))
         fold(ext_mul(sel_last, S))
-    # quotient = sum_k zps_k(zeta) * q_k(zeta); chunk k lives on the coset s_k <w_N>, s_k = g w_2N^k; zps_k vanishes on the other one
-    w2N = two_adic_generator(log_n + 1)
-    s = [GEN, GEN * w2N % P]
+    # quotient = sum_k zps_k(zeta) * q_k(zeta); chunk k lives on the coset s_k <w_N>, s_k = g w_{NQ N}^k; zps_k = prod_{j != k}
+    # Z_j(zeta) / Z_j(s_k) with Z_j(x) = (x / s_j)^N - 1 vanishes on every other chunk's coset
+    wq = two_adic_generator(log_n + lqd)
+    sN = [pow(GEN * pow(wq, k, P) % P, N, P) for k in range(NQ)]
     quotient = ZERO
-    for k in range(2):
-        j = 1 - k
-        sjn_inv = pow(pow(s[j], N, P), -1, P)
-        num = e_sub(e_scale(zeta_n, sjn_inv), ONE)
-        den = (pow(s[k], N, P) * sjn_inv - 1) % P
-        quotient = e_add(quotient, ext_mul(e_scale(num, pow(den, -1, P)), e_from_columns(qz[4 * k:4 * k + 4])))
+    for k in range(NQ):
+        zps = ONE
+        for j in range(NQ):
+            if j == k:
+                continue
+            sjn_inv = pow(sN[j], -1, P)
+            num = e_sub(e_scale(zeta_n, sjn_inv), ONE)
+            den = (sN[k] * sjn_inv - 1) % P
+            zps = ext_mul(zps, e_scale(num, pow(den, -1, P)))
+        quotient = e_add(quotient, ext_mul(zps, e_from_columns(qz[4 * k:4 * k + 4])))
     if ext_mul(acc, ext_inv(zh)) != quotient:
         raise Reject("constraints do not match the quotient at zeta")
 
     # ---- (b) FRI: batching challenge, layer roots, final polynomial, proof of work
     fa = ts.sample_ext()
-    npow = max(width, Wp, 8)
+    npow = max(width, Wp, QW)
     fap = [ONE]
     for _ in range(npow - 1):
         fap.append(ext_mul(fap[-1], fa))
@@ -317,7 +341,7 @@ def verify(proof_bytes, log_n, width, public_values, log_blowup=1, num_queries=1
             prow, ppath = take(Wp), [take(8) for _ in range(H)]
             if hasher.root_from_path(prow, index, ppath) != perm_root:
                 raise Reject("permutation opening")
-        qrow, qpath = take(8), [take(8) for _ in range(H)]
+        qrow, qpath = take(QW), [take(8) for _ in range(H)]
         if hasher.root_from_path(qrow, index, qpath) != quot_root:
             raise Reject("quotient opening")
         x = GEN * pow(wM, bitrev(index, H), P) % P

@@ -42,7 +42,7 @@ def test_malformed_programs_are_refused_everywhere(oracle):
     for mutate in (lambda p: p.__setitem__(0, 1), lambda p: p.__setitem__(2, 8), lambda p: p.__setitem__(5, p[5] + 1),
                    lambda p: p.__setitem__(6, 4),                       # selector out of range
                    lambda p: p.__setitem__(8, P),                       # non-canonical coefficient
-                   lambda p: p.__setitem__(9, 3),                       # degree 3 under a selector = 4
+                   lambda p: p.__setitem__(9, 6),                       # degree 6
                    lambda p: p.__setitem__(10, (1 << 30) | 4),          # column out of range
                    lambda p: p.__setitem__(10, (2 << 30) | 3),          # public value out of range
                    lambda p: p.__setitem__(10, (3 << 30))):             # unknown variable kind
@@ -80,6 +80,29 @@ def test_three_verifiers_agree_on_program_proofs(oracle, shape):
         assert verify_shard_air(prog, bad.view(np.uint8), log_n, width, pub, prm)[0] == -6
         with pytest.raises(pyverify.Reject):
             pyverify.verify(bad.tobytes(), log_n, width, pub, *shape, air=prog)
+
+
+@pytest.mark.parametrize("shape", [(2, 5, 4, 0, 0, 0, 0), (3, 4, 0, 0, 2, 0, 24)])
+def test_degree_five_programs_use_four_quotient_chunks(oracle, shape):
+    """log_quotient_degree 2 (SURVEY.md 8a row a9 lists {1, 2}): the quotient domain is 4N points, four chunks of 4 base columns"""
+    prog = airs.quintic_program()
+    assert oracle.air_log_quotient_degree(prog) == 2 and pyverify.air_log_quotient_degree(prog) == 2
+    t, pub = airs.quintic_trace(6, 9)
+    prm, oprm = Params(*shape), oracle.default_params(*shape)
+    proof = oracle.prove_shard_air(prog, t, pub, oprm)
+    assert oracle.verify_shard_air(prog, proof, 6, 4, pub, oprm) == 0
+    assert verify_shard_air(prog, proof, 6, 4, pub, prm) == (0, 0)
+    assert pyverify.verify(proof.tobytes(), 6, 4, pub, *shape, air=prog) is True
+    assert verify_shard_air(prog, proof, 6, 4, [8], prm)[0] == -6
+    bad = proof.copy().view(np.uint32)
+    bad[60] = (int(bad[60]) + 1) % P                     # one of the 16 quotient openings
+    assert verify_shard_air(prog, bad.view(np.uint8), 6, 4, pub, prm)[0] == -6
+    with pytest.raises(pyverify.Reject):
+        pyverify.verify(bad.tobytes(), 6, 4, pub, *shape, air=prog)
+    # blowup 2 cannot hold a 4N-point quotient domain
+    assert verify_shard_air(prog, proof, 6, 4, pub, Params(1, shape[1], shape[2]))[0] == -6
+    with pytest.raises(RuntimeError):
+        oracle.prove_shard_air(prog, t, pub, oracle.default_params(1, 5, 4))
 
 
 def test_a_violating_trace_never_yields_an_accepted_proof(oracle):

@@ -43,6 +43,25 @@ def test_program_proofs_equal_the_oracles_bytes(ctx, oracle, shape):
         assert verify_shard(proof, log_n, width, pub, prm)[0] == -6          # not a proof of the built-in AIR (version, digest)
 
 
+@pytest.mark.parametrize("log_n,shape", [(8, (2, 8, 4, 0, 0, 0, 0)), (11, (2, 10, 0, 0, 1, 1, 24)), (12, (3, 6, 4, 0, 3, 0, 16))])
+def test_degree_five_program_four_quotient_chunks(ctx, oracle, log_n, shape):
+    """log_quotient_degree 2: quotient domain 4N, four chunks; quotient values and proof bytes equal the oracle's"""
+    prog = airs.quintic_program()
+    t, pub = airs.quintic_trace(log_n, 3)
+    prm, oprm = Params(*shape), oracle.default_params(*shape)
+    d = ctx.from_numpy(t)
+    lde = ctx.coset_lde(d, log_n, 4, shape[0], 31)
+    alpha = [5, 6, 7, 8]
+    got = ctx.quotient_values_air(prog, lde, log_n, 4, pub, alpha, log_quotient_degree=2).download().reshape(-1, 4)
+    assert (got == oracle.quotient_values_air(prog, lde.download().reshape(-1, 4), log_n, pub, alpha)).all()
+    proof = ctx.prove_shard_air(prog, d, log_n, 4, pub, prm)
+    assert proof.tobytes() == oracle.prove_shard_air(prog, t, pub, oprm).tobytes()
+    assert verify_shard_air(prog, proof, log_n, 4, pub, prm) == (0, 0)
+    assert pyverify.verify(proof.tobytes(), log_n, 4, pub, *shape, air=prog) is True
+    with pytest.raises(ZkHipError):
+        ctx.prove_shard_air(prog, d, log_n, 4, pub, Params(1, 8, 4))          # blowup 2 cannot hold the 4N-point quotient domain
+
+
 def test_program_proof_at_2_pow_18_rows(ctx, oracle):
     log_n, width = 18, 32
     prog = airs.counter_program(width)

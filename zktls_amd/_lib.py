@@ -142,7 +142,7 @@ def load():
     L.zkhip_air_digest.argtypes = [u32p, C.c_size_t, u32p]
     L.zkhip_air_synthetic.argtypes = [C.c_uint32, C.c_size_t, u32p, C.c_size_t, C.POINTER(C.c_size_t)]
     L.zkhip_proof_size_air.restype = C.c_size_t
-    L.zkhip_proof_size_air.argtypes = [C.c_int, C.c_uint32, C.POINTER(Params), C.c_size_t]
+    L.zkhip_proof_size_air.argtypes = [u32p, C.c_size_t, C.c_int, C.c_uint32, C.POINTER(Params), C.c_size_t]
     L.zkhip_prove_shard_air.argtypes = [C.c_void_p, u32p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_int, C.c_uint32, u32p, C.c_size_t,
                                         C.POINTER(Params), u8p, C.c_size_t, C.POINTER(C.c_size_t)]
     L.zkhip_verify_shard_air.argtypes = [u32p, C.c_size_t, u8p, C.c_size_t, C.c_int, C.c_uint32, u32p, C.c_size_t, C.POINTER(Params), C.POINTER(C.c_int)]

@@ -5,12 +5,12 @@
 // Upstream a constraint is a Rust `Air::eval` body that p3-uni-stark drives through its prover / verifier constraint folders
 // (p3-air, p3-uni-stark 0.2.1-succinct: reference Cargo.lock:3835, 4055; sp1-stark :6172; behind sp1.rs:116): a polynomial in
 // the local / next row, the public values and the selectors is_first_row / is_last_row / is_transition, folded as
-// acc = acc * alpha + constraint.  A program is that polynomial written out in sum-of-products form, so any AIR of degree <= 3
-// (log_quotient_degree 1, SP1's core machine bound) can be proven without touching a kernel.
+// acc = acc * alpha + constraint.  A program is that polynomial written out in sum-of-products form, so any AIR of degree <= 5
+// (log_quotient_degree 1 for degree <= 3 -- the bound of SP1's core machine --, 2 for degree 4 and 5) is proven without touching a kernel.
 //
 // Program (u32 words, canonical residues; format declared in include/zkhip.h):
 //   [0] 0x50524941 "AIRP"  [1] 1  [2] width  [3] constraints K  [4] n_public  [5] total words
-//   K x { selector (0 every row, 1 first row, 2 last row, 3 transition), n_terms, n_terms x { coeff, degree d <= 3, d variables } }
+//   K x { selector (0 every row, 1 first row, 2 last row, 3 transition), n_terms, n_terms x { coeff, degree d <= 5, d variables } }
 //   variable = kind << 30 | index;  kind 0 local row, 1 next row, 2 public value.  A selector counts one degree.
 #pragma once
 #include <vector>
@@ -26,12 +26,14 @@ struct AirView {
     const uint32_t* w = nullptr;
     size_t words = 0;
     uint32_t width = 0, K = 0, n_public = 0;
+    int lqd = 1;             // log2 of the number of quotient chunks: degree <= 3 -> 1, degree 4 or 5 -> 2 (needs log_blowup >= 2)
 };
 
 inline bool air_validate(const uint32_t* prog, size_t words, uint32_t width, size_t n_public, AirView* out) {
     if (!prog || words < 6 || prog[0] != AIR_MAGIC || prog[1] != 1 || prog[2] != width || prog[4] != n_public || prog[5] != words) return false;
     if (prog[3] == 0 || prog[3] > (1u << 20)) return false;
     size_t p = 6;
+    uint32_t maxd = 0;
     for (uint32_t k = 0; k < prog[3]; k++) {
         if (p + 2 > words) return false;
         const uint32_t sel = prog[p++], nt = prog[p++];
@@ -39,7 +41,8 @@ inline bool air_validate(const uint32_t* prog, size_t words, uint32_t width, siz
         for (uint32_t t = 0; t < nt; t++) {
             if (p + 2 > words) return false;
             const uint32_t coeff = prog[p++], d = prog[p++];
-            if (coeff >= P || d > 3 || d + (sel ? 1u : 0u) > 3 || p + d > words) return false;
+            if (coeff >= P || d > 5 || d + (sel ? 1u : 0u) > 5 || p + d > words) return false;
+            if (d + (sel ? 1u : 0u) > maxd) maxd = d + (sel ? 1u : 0u);
             for (uint32_t j = 0; j < d; j++) {
                 const uint32_t v = prog[p++], kind = v >> 30, idx = v & 0xFFFFu;
                 if ((v & 0x3FFF0000u) || kind > 2) return false;
@@ -48,7 +51,7 @@ inline bool air_validate(const uint32_t* prog, size_t words, uint32_t width, siz
         }
     }
     if (p != words) return false;
-    if (out) { out->w = prog; out->words = words; out->width = width; out->K = prog[3]; out->n_public = (uint32_t)n_public; }
+    if (out) { out->w = prog; out->words = words; out->width = width; out->K = prog[3]; out->n_public = (uint32_t)n_public; out->lqd = maxd <= 3 ? 1 : 2; }
     return true;
 }
 

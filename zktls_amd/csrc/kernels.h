@@ -175,13 +175,15 @@ hipError_t launch_quotient(const QuotientArgs& a, hipStream_t s);
 struct QuotientAirArgs {
     const uint32_t* lde; uint64_t ld; uint32_t width; int log_n;
     const uint32_t* xs; const uint32_t* sel_first; const uint32_t* sel_last;
-    uint32_t wn_inv, inv_zh_even, inv_zh_odd;
+    uint32_t wn_inv;
+    int log_qd;                 // log2 of the number of quotient chunks (1 or 2): the quotient domain is the first 2^(log_n + log_qd) rows
+    uint32_t inv_zh[4];         // 1 / Z_H on the points e = j mod 2^log_qd
     const uint32_t* body;       // device: program body, Montgomery coefficients (air_device_image)
     uint32_t n_constraints;
     const uint32_t* weights;    // device: [K] extension weights alpha^(K-1-k)
     const uint32_t* pub;        // device: public values, Montgomery
-    uint32_t* out;              // [2][N][4] natural chunk order, as launch_quotient
-    uint32_t* lde_out; uint64_t lde_ld;
+    uint32_t* out;              // [2^log_qd][N][4] natural chunk order, as launch_quotient
+    uint32_t* lde_out; uint64_t lde_ld;     // log_qd == 1 only (as launch_quotient)
 };
 hipError_t launch_quotient_air(const QuotientAirArgs& a, hipStream_t s);
 
@@ -205,7 +207,7 @@ hipError_t launch_open(const OpenArgs& a, int npts, const Ext& scale0, const Ext
 
 struct ReducedArgs {
     const uint32_t* tlde; uint64_t t_ld; uint32_t width;
-    const uint32_t* qlde; uint64_t q_ld;
+    const uint32_t* qlde; uint64_t q_ld; uint32_t q_width;    // quotient matrix: 8 columns (two chunks) or 16 (four)
     const uint32_t* plde; uint64_t p_ld; uint32_t p_width;   // permutation trace LDE (p_width = 0: none)
     uint64_t rows;              // 2N
     const uint32_t* alpha_pow;  // [max(width, p_width, 8)] ext: alpha^j

@@ -108,7 +108,7 @@ static int ensure_domain(zkhip_ctx* ctx, int log_n, int log_blowup = 1) {
             return ZKHIP_OK;
         }
     zkhip_ctx::DomainSet d{log_n, log_blowup, nullptr, nullptr, nullptr, nullptr};
-    const size_t m = (size_t)1 << (log_n + log_blowup), mq = (size_t)2 << log_n;
+    const size_t m = (size_t)1 << (log_n + log_blowup), mq = (size_t)1 << (log_n + (log_blowup < 2 ? log_blowup : 2));
     ZK_HIP(hipMalloc((void**)&d.xs, m * 4));
     ZK_HIP(hipMalloc((void**)&d.sel_first, mq * 4));
     ZK_HIP(hipMalloc((void**)&d.sel_last, mq * 4));
@@ -186,7 +186,7 @@ static int run_quotient(zkhip_ctx* ctx, const uint32_t* lde, size_t ld, int log_
 // quotient values of a constraint program (air.h): the interpreter kernel, same outputs as run_quotient
 static int run_quotient_air(zkhip_ctx* ctx, const AirView& air, const uint32_t* lde, size_t ld, int log_n, uint32_t width,
                             const uint32_t* public_values, const Ext& alpha, uint32_t* out_chunks, uint32_t* lde_out, size_t lde_ld) {
-    if (ctx->dom_log_n != log_n) ZK_TRY(ensure_domain(ctx, log_n));
+    if (ctx->dom_log_n != log_n || ctx->dom_log_blowup < air.lqd) ZK_TRY(ensure_domain(ctx, log_n, air.lqd));
     std::vector<uint32_t> body, weights;
     air_device_image(air, alpha, body, weights);
     std::vector<uint32_t> pub(air.n_public ? air.n_public : 1, 0u);
@@ -204,9 +204,9 @@ static int run_quotient_air(zkhip_ctx* ctx, const AirView& air, const uint32_t* 
     q.lde = lde; q.ld = ld; q.width = width; q.log_n = log_n;
     q.xs = ctx->dom_xs; q.sel_first = ctx->dom_sel_first; q.sel_last = ctx->dom_sel_last;
     q.wn_inv = finv(two_adic_generator(log_n));
-    const uint32_t gn = fpow(MONTY_GEN, (uint64_t)1 << log_n);
-    q.inv_zh_even = finv(fsub(gn, MONTY_R1));
-    q.inv_zh_odd = finv(fsub(fneg(gn), MONTY_R1));
+    q.log_qd = air.lqd;
+    const uint32_t gn = fpow(MONTY_GEN, (uint64_t)1 << log_n), wq = two_adic_generator(air.lqd);
+    for (int j = 0; j < (1 << air.lqd); j++) q.inv_zh[j] = finv(fsub(fmul(gn, fpow(wq, (uint64_t)j)), MONTY_R1));   // x^N = g^N w_{2^lqd}^j on chunk j
     q.body = (const uint32_t*)d_stage; q.n_constraints = air.K;
     q.weights = (const uint32_t*)d_stage + body_w; q.pub = (const uint32_t*)d_stage + body_w + weights.size();
     q.out = out_chunks; q.lde_out = lde_out; q.lde_ld = lde_ld;
@@ -377,13 +377,14 @@ static int grind_witness(zkhip_ctx* ctx, Challenger& ch, int pow_bits, uint32_t*
     return ZKHIP_OK;
 }
 
-static size_t proof_words(int log_n, uint32_t width, const zkhip_params* prm, bool air = false) {
+static size_t proof_words(int log_n, uint32_t width, const zkhip_params* prm, bool air = false, int lqd = 1) {
     Shape sh;
     if (!shape_of(log_n, prm, sh)) return 0;
     const size_t H = (size_t)(log_n + sh.b);
     const size_t Q = (size_t)prm->logup_pairs, wp = Q ? 4 * (Q + 1) : 0;
-    size_t words = (air ? 20 : (sh.ext ? 12 : (Q ? 9 : 8))) + 16 + 8 * (size_t)width + 32 + 8 * (size_t)sh.R + 4 * ((size_t)1 << sh.F) + 1;
-    size_t perq = width + 8 + 16 * H;
+    const size_t QW = (size_t)4 << lqd;          // width of the quotient matrix: 4 base columns per chunk
+    size_t words = (air ? 20 : (sh.ext ? 12 : (Q ? 9 : 8))) + 16 + 8 * (size_t)width + 4 * QW + 8 * (size_t)sh.R + 4 * ((size_t)1 << sh.F) + 1;
+    size_t perq = width + QW + 16 * H;
     if (Q) { words += 8 + 8 * wp; perq += wp + 8 * H; }
     for (int l = 0; l < sh.R; l++) perq += 4 * (((size_t)1 << sh.K) - 1) + 8 * (H - (size_t)sh.K * (l + 1));
     return words + (size_t)prm->num_queries * perq;
@@ -579,12 +580,15 @@ static int prove_shard_impl(zkhip_ctx* ctx, const uint32_t* d_trace, size_t ld, 
     if (!d_trace || !proof || !len || ld < width || (n_public && !public_values)) return fail(ZKHIP_ERR_INVALID, "prove_shard: bad arguments");
     for (size_t i = 0; i < n_public; i++) if (public_values[i] >= P) return fail(ZKHIP_ERR_INVALID, "prove_shard: public values must be canonical");
     if (air && prm->logup_pairs) return fail(ZKHIP_ERR_INVALID, "prove_shard_air: a constraint program excludes the built-in lookup argument (logup_pairs must be 0)");
-    const size_t need = proof_words(log_n, width, prm, air != nullptr) * 4;
+    const int lqd = air ? air->lqd : 1;                      // log2 of the number of quotient chunks
+    if (lqd > prm->log_blowup) return fail(ZKHIP_ERR_INVALID, "prove_shard_air: constraints of degree 4 or 5 need log_blowup >= 2 (the quotient domain must lie inside the committed LDE domain)");
+    const size_t NQ = (size_t)1 << lqd, QW = 4 * NQ;
+    const size_t need = proof_words(log_n, width, prm, air != nullptr, lqd) * 4;
     if (cap < need) return fail(ZKHIP_ERR_BUFFER, "prove_shard: proof buffer too small (see zkhip_proof_size)");
     *len = 0;
     Shape sh;
     shape_of(log_n, prm, sh);
-    const int H = log_n + sh.b, Hq = log_n + 1, Q = prm->num_queries;     // LDE domain 2^H, quotient domain 2^Hq
+    const int H = log_n + sh.b, Hq = log_n + lqd, Q = prm->num_queries;   // LDE domain 2^H, quotient domain 2^Hq
     const int RL = sh.R, K = sh.K;                                          // committed FRI layers, folds per layer
     const size_t n = (size_t)1 << log_n, m = (size_t)1 << H, arity = (size_t)1 << K;
     hipStream_t st = ctx->stream;
@@ -638,29 +642,29 @@ static int prove_shard_impl(zkhip_ctx* ctx, const uint32_t* d_trace, size_t ld, 
     // ---- 2. constraint challenge, quotient chunks, their LDE + commitment
     const Ext alpha = ch.sample_ext();
     void *v_qchunk, *v_qlde, *v_qtree;
-    ZK_TRY(ctx_reserve(ctx, S_QCHUNK, 2 * n * 16, &v_qchunk));
-    ZK_TRY(ctx_reserve(ctx, S_QLDE, m * 8 * 4, &v_qlde));
+    ZK_TRY(ctx_reserve(ctx, S_QCHUNK, NQ * n * 16, &v_qchunk));
+    ZK_TRY(ctx_reserve(ctx, S_QLDE, m * QW * 4, &v_qlde));
     ZK_TRY(ctx_reserve(ctx, S_QTREE, (2 * m - 1) * 32, &v_qtree));
     uint32_t* qchunk = (uint32_t*)v_qchunk; uint32_t* qlde = (uint32_t*)v_qlde; uint32_t* qtree = (uint32_t*)v_qtree;
     // With blowup 2 the LDE domain g <w_2N> is exactly the two cosets the chunks live on: on its own coset a chunk's extension is
     // the quotient value itself (the kernel writes it straight into the LDE matrix), only the OTHER coset needs a transform.
-    const bool own_coset_direct = sh.b == 1;
+    const bool own_coset_direct = sh.b == 1;           // (then lqd == 1 too)
     if (air) ZK_TRY(run_quotient_air(ctx, *air, tlde, width, log_n, width, public_values, alpha, qchunk, own_coset_direct ? qlde : nullptr, 8));
     else ZK_TRY(run_quotient(ctx, tlde, width, log_n, width, alpha, lu, qchunk, own_coset_direct ? qlde : nullptr, 8));
     {
         // the quotient kernel works on the first 2N rows of the LDE: they are the coset g <w_2N>, bit-reversed
         const uint32_t w2n = two_adic_generator(Hq);
-        for (int k = 0; k < 2; k++) {
+        for (int k = 0; k < (int)NQ; k++) {
             if (own_coset_direct) {
                 // rows [(1-k) N, (2-k) N) of the LDE = coset 1-k = (g w_2N^(1-k)) <w_N>, relative to the chunk's own coset: w_2N^(1-2k)
                 ZK_TRY(op_coset_lde(ctx, qchunk + (size_t)k * n * 4, 4, qlde + (size_t)(1 - k) * n * 8 + 4 * k, 8, log_n, 4, 0, k == 0 ? w2n : finv(w2n)));
                 continue;
             }
-            // chunk k lives on (g w_2N^k) <w_N>; extend it to the LDE domain g <w_M>: shift = g / (g w^k)
+            // chunk k lives on (g w_{2^Hq}^k) <w_N>; extend it to the LDE domain g <w_M>: shift = g / (g w^k)
             const uint32_t shift = finv(fpow(w2n, (uint64_t)k));
-            ZK_TRY(op_coset_lde(ctx, qchunk + (size_t)k * n * 4, 4, qlde + 4 * k, 8, log_n, 4, sh.b, shift));
+            ZK_TRY(op_coset_lde(ctx, qchunk + (size_t)k * n * 4, 4, qlde + 4 * k, QW, log_n, 4, sh.b, shift));
         }
-        ZK_TRY(commit_hw(ctx, qlde, 8, 8, H, qtree, sh.hw));
+        ZK_TRY(commit_hw(ctx, qlde, QW, (uint32_t)QW, H, qtree, sh.hw));
     }
     ZK_TRY(d2h(ctx, root, qtree + (2 * m - 2) * 8, 32));
     for (int i = 0; i < 8; i++) { ch.observe(root[i]); pf[pos++] = ctx->debug.quotient_root[i] = from_monty(root[i]); }
@@ -670,7 +674,7 @@ static int prove_shard_impl(zkhip_ctx* ctx, const uint32_t* d_trace, size_t ld, 
     const Ext zpts[2] = {zeta, ext_mul_base(zeta, two_adic_generator(log_n))};
     void *v_dinv, *v_open;
     ZK_TRY(ctx_reserve(ctx, S_DINV, 2 * (m + n) * 16, &v_dinv));
-    ZK_TRY(ctx_reserve(ctx, S_OPEN_OUT, (2 * (size_t)width + 2 * wp + 8) * 16, &v_open));
+    ZK_TRY(ctx_reserve(ctx, S_OPEN_OUT, (2 * (size_t)width + 2 * wp + QW) * 16, &v_open));
     uint32_t* dinv = (uint32_t*)v_dinv; uint32_t* d_open = (uint32_t*)v_open;
     uint32_t* xw = dinv + 8 * m;       // x_q / (x_q - z_k) for the N rows the openings sum over
     ZK_HIP(launch_inv_denominators(ctx->dom_xs, m, zpts[0], zpts[1], 2, dinv, xw, n, st));
@@ -680,8 +684,8 @@ static int prove_shard_impl(zkhip_ctx* ctx, const uint32_t* d_trace, size_t ld, 
         ZK_TRY(run_open(ctx, plde, wp, log_n, (uint32_t)wp, zpts, 2, xw, d_open + 8 * (size_t)width));
         ZK_HIP(hipStreamSynchronize(st));
     }
-    ZK_TRY(run_open(ctx, qlde, 8, log_n, 8, zpts, 1, xw, d_open + 8 * (size_t)width + 8 * wp));
-    std::vector<uint32_t> opened((2 * (size_t)width + 2 * wp + 8) * 4);
+    ZK_TRY(run_open(ctx, qlde, QW, log_n, (uint32_t)QW, zpts, 1, xw, d_open + 8 * (size_t)width + 8 * wp));
+    std::vector<uint32_t> opened((2 * (size_t)width + 2 * wp + QW) * 4);
     ZK_TRY(d2h(ctx, opened.data(), d_open, opened.size() * 4));
     for (size_t i = 0; i < opened.size(); i++) { ch.observe(opened[i]); pf[pos++] = from_monty(opened[i]); }
     const Ext* op_loc = (const Ext*)opened.data();
@@ -692,7 +696,7 @@ static int prove_shard_impl(zkhip_ctx* ctx, const uint32_t* d_trace, size_t ld, 
 
     // ---- 4. FRI input: alpha-batched reduced openings at every LDE point
     const Ext fa = ch.sample_ext();
-    size_t np = width > 8 ? width : 8;
+    size_t np = width > QW ? width : QW;
     if (wp > np) np = wp;
     std::vector<Ext> fapow(np);
     fapow[0] = ext_one();
@@ -708,7 +712,7 @@ static int prove_shard_impl(zkhip_ctx* ctx, const uint32_t* d_trace, size_t ld, 
         ra.y_pl = ext_add(ra.y_pl, ext_mul(fapow[j], op_pl[j]));
         ra.y_pn = ext_add(ra.y_pn, ext_mul(fapow[j], op_pn[j]));
     }
-    for (size_t j = 0; j < 8; j++) ra.y_q = ext_add(ra.y_q, ext_mul(fapow[j], op_q[j]));
+    for (size_t j = 0; j < QW; j++) ra.y_q = ext_add(ra.y_q, ext_mul(fapow[j], op_q[j]));
     // batching offsets: trace@zeta 0, trace@zeta_next W, [perm@zeta 2W, perm@zeta_next 2W+Wp], quotient 2W+2Wp
     ra.off_next = ext_pow(fa, width);
     ra.off_pl = ext_pow(fa, 2 * (uint64_t)width);
@@ -720,7 +724,7 @@ static int prove_shard_impl(zkhip_ctx* ctx, const uint32_t* d_trace, size_t ld, 
     ZK_TRY(ctx_reserve(ctx, S_FRI_LAYERS, 2 * m * 16, &v_layers));
     ZK_TRY(ctx_reserve(ctx, S_FRI_TREES, 2 * m * 32, &v_ltrees));
     uint32_t* layers = (uint32_t*)v_layers; uint32_t* ltrees = (uint32_t*)v_ltrees;
-    ra.tlde = tlde; ra.t_ld = width; ra.width = width; ra.qlde = qlde; ra.q_ld = 8; ra.rows = m;
+    ra.tlde = tlde; ra.t_ld = width; ra.width = width; ra.qlde = qlde; ra.q_ld = QW; ra.q_width = (uint32_t)QW; ra.rows = m;
     ra.plde = plde; ra.p_ld = wp; ra.p_width = (uint32_t)wp;
     ra.alpha_pow = (const uint32_t*)v_apf; ra.dinv = dinv; ra.out = layers;
     void* v_at;
@@ -775,7 +779,7 @@ static int prove_shard_impl(zkhip_ctx* ctx, const uint32_t* d_trace, size_t ld, 
             push(tlde + index * width, width);
             push_path(ttree, m, index, H);
             if (LQ) { push(plde + index * wp, wp); push_path(ptree, m, index, H); }
-            push(qlde + index * 8, 8);
+            push(qlde + index * QW, QW);
             push_path(qtree, m, index, H);
             size_t idx = index;
             for (int l = 0; l < RL; l++) {
@@ -812,10 +816,10 @@ int zkhip_prove_shard(zkhip_ctx* ctx, const uint32_t* d_trace, size_t ld, int lo
 }
 
 // ---- the AIR as data: prove / verify against a constraint program (air.h)
-size_t zkhip_proof_size_air(int log_n, uint32_t width, const zkhip_params* prm, size_t n_public) {
-    (void)n_public;
-    if (check_shape(log_n, width, prm) != ZKHIP_OK || prm->logup_pairs) return 0;
-    return proof_words(log_n, width, prm, true) * 4;
+size_t zkhip_proof_size_air(const uint32_t* program, size_t program_words, int log_n, uint32_t width, const zkhip_params* prm, size_t n_public) {
+    AirView a;
+    if (check_shape(log_n, width, prm) != ZKHIP_OK || prm->logup_pairs || !air_validate(program, program_words, width, n_public, &a) || a.lqd > prm->log_blowup) return 0;
+    return proof_words(log_n, width, prm, true, a.lqd) * 4;
 }
 int zkhip_air_validate(const uint32_t* program, size_t words, uint32_t width, size_t n_public) {
     if (!air_validate(program, words, width, n_public, nullptr))
@@ -869,22 +873,23 @@ int zkhip_quotient_values_air(zkhip_ctx* ctx, const uint32_t* program, size_t pr
     AirView a;
     if (!d_lde || !d_out || !alpha || ld < width || (n_public && !public_values) || !air_validate(program, program_words, width, n_public, &a))
         return fail(ZKHIP_ERR_INVALID, "quotient_values_air: bad arguments or malformed program");
-    const size_t n = (size_t)1 << log_n;
+    const size_t n = (size_t)1 << log_n, NQ = (size_t)1 << a.lqd;
     void* chunks;
-    ZK_TRY(ctx_reserve(ctx, S_QCHUNK, 2 * n * 16, &chunks));
+    ZK_TRY(ctx_reserve(ctx, S_QCHUNK, NQ * n * 16, &chunks));
     ZK_TRY(run_quotient_air(ctx, a, d_lde, ld, log_n, width, public_values, Ext{{alpha[0], alpha[1], alpha[2], alpha[3]}}, (uint32_t*)chunks, nullptr, 0));
-    // natural chunk order -> the bit-reversed layout of the LDE (as zkhip_quotient_values)
-    std::vector<GatherDesc> descs(2 * n);
-    for (size_t k = 0; k < 2; k++)
+    // natural chunk order -> the bit-reversed layout of the quotient domain (the first 2^lqd N rows of the LDE): point e = NQ j + k sits at
+    // row bitrev(e) = bitrev_lqd(k) N + bitrev_n(j)
+    std::vector<GatherDesc> descs(NQ * n);
+    for (size_t k = 0; k < NQ; k++)
         for (size_t j = 0; j < n; j++) {
-            const size_t p = k * n + reverse_bits((uint32_t)j, log_n);
+            const size_t p = (size_t)reverse_bits((uint32_t)k, a.lqd) * n + reverse_bits((uint32_t)j, log_n);
             descs[p] = GatherDesc{(const uint32_t*)chunks + (k * n + j) * 4, (uint32_t)(p * 4), 4};
         }
     void* dd;
     ZK_TRY(ctx_reserve(ctx, S_GATHER_DESC, descs.size() * sizeof(GatherDesc), &dd));
     ZK_TRY(h2d(ctx, dd, descs.data(), descs.size() * sizeof(GatherDesc)));
     ZK_HIP(launch_gather((const GatherDesc*)dd, (uint32_t)descs.size(), d_out, ctx->stream));
-    ZK_HIP(launch_convert(d_out, d_out, 2 * n * 4, true, ctx->stream));
+    ZK_HIP(launch_convert(d_out, d_out, NQ * n * 4, true, ctx->stream));
     return ZKHIP_OK;
 }
 
@@ -1129,11 +1134,14 @@ static int verify_shard_impl(const uint8_t* proof, size_t len, int log_n, uint32
     if (check_shape(log_n, width, prm) != ZKHIP_OK) return reject(1);
     if (!proof || (n_public && !public_values)) return reject(1);
     if (air && prm->logup_pairs) return reject(1);
-    if (len != proof_words(log_n, width, prm, air != nullptr) * 4) return reject(2);
+    const int lqd = air ? air->lqd : 1;
+    if (lqd > prm->log_blowup) return reject(1);
+    const size_t NQ = (size_t)1 << lqd, QW = 4 * NQ;
+    if (len != proof_words(log_n, width, prm, air != nullptr, lqd) * 4) return reject(2);
     const uint32_t* pf = (const uint32_t*)proof;
     Shape sh;
     shape_of(log_n, prm, sh);
-    const int H = log_n + sh.b, Hq = log_n + 1, RL = sh.R, K = sh.K;
+    const int H = log_n + sh.b, Hq = log_n + lqd, RL = sh.R, K = sh.K;
     const size_t n = (size_t)1 << log_n, arity = (size_t)1 << K;
     const uint32_t LQ = (uint32_t)prm->logup_pairs;
     const size_t wp = LQ ? 4 * ((size_t)LQ + 1) : 0;
@@ -1172,7 +1180,7 @@ static int verify_shard_impl(const uint8_t* proof, size_t len, int log_n, uint32
     const uint32_t gn = two_adic_generator(log_n);
     const Ext zeta_next = ext_mul_base(zeta, gn);
     std::vector<Ext> loc(width), nxt(width), opl(wp), opn(wp);
-    Ext opq[8];
+    Ext opq[16];
     for (size_t j = 0; j < width; j++) loc[j] = ext_from_canon(pf + pos + 4 * j);
     pos += 4 * (size_t)width;
     for (size_t j = 0; j < width; j++) nxt[j] = ext_from_canon(pf + pos + 4 * j);
@@ -1181,13 +1189,13 @@ static int verify_shard_impl(const uint8_t* proof, size_t len, int log_n, uint32
     pos += 4 * wp;
     for (size_t j = 0; j < wp; j++) opn[j] = ext_from_canon(pf + pos + 4 * j);
     pos += 4 * wp;
-    for (int j = 0; j < 8; j++) opq[j] = ext_from_canon(pf + pos + 4 * j);
-    pos += 32;
+    for (size_t j = 0; j < QW; j++) opq[j] = ext_from_canon(pf + pos + 4 * j);
+    pos += 4 * QW;
     for (size_t j = 0; j < width; j++) ch.observe_ext(loc[j]);
     for (size_t j = 0; j < width; j++) ch.observe_ext(nxt[j]);
     for (size_t j = 0; j < wp; j++) ch.observe_ext(opl[j]);
     for (size_t j = 0; j < wp; j++) ch.observe_ext(opn[j]);
-    for (int j = 0; j < 8; j++) ch.observe_ext(opq[j]);
+    for (size_t j = 0; j < QW; j++) ch.observe_ext(opq[j]);
 
     // (a) the AIR identity at zeta: folded constraints / Z_H == sum_k zps_k * q_k
     {
@@ -1225,15 +1233,21 @@ static int verify_shard_impl(const uint8_t* proof, size_t len, int log_n, uint32
             acc = ext_add(ext_mul(acc, alpha), ext_mul(sel_trans, ext_sub(ext_sub(Sn, S), sum_n)));
             acc = ext_add(ext_mul(acc, alpha), ext_mul(sel_last, S));
         }
-        const uint32_t w2n = two_adic_generator(Hq);
-        const uint32_t s[2] = {MONTY_GEN, fmul(MONTY_GEN, w2n)};
+        // quotient(zeta) = sum_k zps_k(zeta) q_k(zeta): chunk k lives on the coset s_k <w_N>, s_k = g w_{2^Hq}^k, and
+        // zps_k = prod_{j != k} Z_Dj(zeta) / Z_Dj(s_k), Z_Dj(x) = (x / s_j)^N - 1, vanishes on every other chunk's coset
+        const uint32_t wq = two_adic_generator(Hq);
+        uint32_t sN[4];
+        for (size_t k = 0; k < NQ; k++) sN[k] = fpow(fmul(MONTY_GEN, fpow(wq, (uint64_t)k)), n);
         Ext quot = ext_zero();
-        for (int k = 0; k < 2; k++) {
-            const int j = 1 - k;
-            const uint32_t sjn_inv = finv(fpow(s[j], n));
-            const Ext num = ext_sub_base(ext_mul_base(zn, sjn_inv), MONTY_R1);
-            const uint32_t den = fsub(fmul(fpow(s[k], n), sjn_inv), MONTY_R1);
-            const Ext zps = ext_mul_base(num, finv(den));
+        for (size_t k = 0; k < NQ; k++) {
+            Ext zps = ext_one();
+            for (size_t j = 0; j < NQ; j++) {
+                if (j == k) continue;
+                const uint32_t sjn_inv = finv(sN[j]);
+                const Ext num = ext_sub_base(ext_mul_base(zn, sjn_inv), MONTY_R1);
+                const uint32_t den = fsub(fmul(sN[k], sjn_inv), MONTY_R1);
+                zps = ext_mul(zps, ext_mul_base(num, finv(den)));
+            }
             quot = ext_add(quot, ext_mul(zps, recombine(&opq[4 * k])));
         }
         if (!ext_eq(ext_mul(acc, ext_inv(zh)), quot)) return reject(10);
@@ -1241,7 +1255,7 @@ static int verify_shard_impl(const uint8_t* proof, size_t len, int log_n, uint32
 
     // (b) FRI
     const Ext fa = ch.sample_ext();
-    size_t np = width > 8 ? width : 8;
+    size_t np = width > QW ? width : QW;
     if (wp > np) np = wp;
     std::vector<Ext> fapow(np);
     fapow[0] = ext_one();
@@ -1255,7 +1269,7 @@ static int verify_shard_impl(const uint8_t* proof, size_t len, int log_n, uint32
         y_pl = ext_add(y_pl, ext_mul(fapow[j], opl[j]));
         y_pn = ext_add(y_pn, ext_mul(fapow[j], opn[j]));
     }
-    for (int j = 0; j < 8; j++) y_q = ext_add(y_q, ext_mul(fapow[j], opq[j]));
+    for (size_t j = 0; j < QW; j++) y_q = ext_add(y_q, ext_mul(fapow[j], opq[j]));
     const Ext off_next = ext_pow(fa, width), off_pl = ext_pow(fa, 2 * (uint64_t)width),
               off_pn = ext_pow(fa, 2 * (uint64_t)width + wp), off_q = ext_pow(fa, 2 * (uint64_t)width + 2 * wp);
     std::vector<uint32_t> commits((size_t)RL * 8 + 8);
@@ -1277,18 +1291,18 @@ static int verify_shard_impl(const uint8_t* proof, size_t len, int log_n, uint32
         const uint32_t* tpath = pf + pos; pos += 8 * (size_t)H;
         const uint32_t *prow = nullptr, *ppath = nullptr;
         if (LQ) { prow = pf + pos; pos += wp; ppath = pf + pos; pos += 8 * (size_t)H; }
-        const uint32_t* qrow = pf + pos; pos += 8;
+        const uint32_t* qrow = pf + pos; pos += QW;
         const uint32_t* qpath = pf + pos; pos += 8 * (size_t)H;
         if (!verify_path(troot, H, index, trow, width, tpath, sh.hw)) return reject(30);
         if (LQ && !verify_path(proot, H, index, prow, wp, ppath, sh.hw)) return reject(32);
-        if (!verify_path(qroot, H, index, qrow, 8, qpath, sh.hw)) return reject(31);
+        if (!verify_path(qroot, H, index, qrow, QW, qpath, sh.hw)) return reject(31);
         const uint32_t x = fmul(MONTY_GEN, fpow(wm, reverse_bits((uint32_t)index, H)));
         const Ext d1 = ext_inv(ext_neg(ext_sub_base(zeta, x)));
         const Ext d2 = ext_inv(ext_neg(ext_sub_base(zeta_next, x)));
         Ext at = ext_zero(), ap = ext_zero(), aq = ext_zero();
         for (size_t j = 0; j < width; j++) at = ext_add(at, ext_mul_base(fapow[j], to_monty(trow[j])));
         for (size_t j = 0; j < wp; j++) ap = ext_add(ap, ext_mul_base(fapow[j], to_monty(prow[j])));
-        for (int j = 0; j < 8; j++) aq = ext_add(aq, ext_mul_base(fapow[j], to_monty(qrow[j])));
+        for (size_t j = 0; j < QW; j++) aq = ext_add(aq, ext_mul_base(fapow[j], to_monty(qrow[j])));
         Ext folded = ext_mul(ext_sub(at, y_loc), d1);
         folded = ext_add(folded, ext_mul(off_next, ext_mul(ext_sub(at, y_nxt), d2)));
         if (LQ) {
@@ -1627,7 +1641,7 @@ int zkhip_prove_chips(zkhip_ctx* ctx, const zkhip_chip* chips, int n, const uint
         ra.off_loc = ext_pow(fa, off); ra.off_next = ext_pow(fa, off + W);
         ra.off_pl = ext_pow(fa, off + 2 * (uint64_t)W); ra.off_pn = ext_pow(fa, off + 2 * (uint64_t)W + wp[c]);
         ra.off_q = ext_pow(fa, off + 2 * (uint64_t)W + 2 * wp[c]);
-        ra.tlde = tlde + tl_off[c]; ra.t_ld = W; ra.width = W; ra.qlde = qlde + ql_off[c]; ra.q_ld = 8; ra.rows = (uint64_t)1 << lh[c];
+        ra.tlde = tlde + tl_off[c]; ra.t_ld = W; ra.width = W; ra.qlde = qlde + ql_off[c]; ra.q_ld = 8; ra.q_width = 8; ra.rows = (uint64_t)1 << lh[c];
         ra.plde = wp[c] ? plde + pl_off[c] : nullptr; ra.p_ld = wp[c]; ra.p_width = (uint32_t)wp[c];
         ra.alpha_pow = (const uint32_t*)v_apf + ap_off[c]; ra.dinv = dinv + dv_off[c]; ra.out = ro_of[lh[c]];
         ra.accumulate = started[lh[c]] ? 1 : 0;

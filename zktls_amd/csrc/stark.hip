@@ -45,7 +45,7 @@ ZK_D Ext group_sum(Ext v, int width) {
 __global__ void domain_tables_kernel(uint32_t* xs, uint32_t* sel_first, uint32_t* sel_last, uint32_t* itw, int log_n, int log_blowup,
                                      uint32_t g_pow_n) {
     const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
-    const int H = log_n + log_blowup, Hq = log_n + 1;
+    const int H = log_n + log_blowup, lq = log_blowup < 2 ? log_blowup : 2, Hq = log_n + lq;   // selectors on the largest quotient domain (2^lq N points)
     if (p >= (1u << H)) return;
     const uint32_t e = __brev(p) >> (32 - H);
     const uint32_t wm = two_adic_generator(H);
@@ -53,7 +53,7 @@ __global__ void domain_tables_kernel(uint32_t* xs, uint32_t* sel_first, uint32_t
     xs[p] = x;
     if (p < (1u << Hq)) {
         const uint32_t eq = __brev(p) >> (32 - Hq);
-        const uint32_t xn = (eq & 1) ? fneg(g_pow_n) : g_pow_n;       // x^N = g^N (-1)^eq
+        const uint32_t xn = fmul(g_pow_n, fpow(two_adic_generator(lq), eq & ((1u << lq) - 1u)));   // x^N = g^N w_{2^lq}^eq
         const uint32_t zh = fsub(xn, MONTY_R1);
         sel_first[p] = fmul(zh, finv(fsub(x, MONTY_R1)));
         sel_last[p] = fmul(zh, finv(fsub(x, finv(two_adic_generator(log_n)))));   // Z_H(x) / (x - w_N^-1)
@@ -240,12 +240,12 @@ hipError_t launch_quotient(const QuotientArgs& a, hipStream_t s) {
 // across the variables of a program.  This is the generic path: the synthetic AIR keeps its specialised kernel (quotient_kernel), which
 // streams rows once with 16-byte loads; bytes per point here are the same 2 * 4 * width, the instruction count is what differs.
 __global__ void __launch_bounds__(256) quotient_air_kernel(QuotientAirArgs a) {
-    const int H = a.log_n + 1;
-    const uint32_t m = 1u << H;
+    const int H = a.log_n + a.log_qd;
+    const uint32_t m = 1u << H, nq = 1u << a.log_qd;
     const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
     if (p >= m) return;
     const uint32_t e = __brev(p) >> (32 - H);
-    const uint32_t pn = __brev((e + 2) & (m - 1)) >> (32 - H);
+    const uint32_t pn = __brev((e + nq) & (m - 1)) >> (32 - H);       // the next trace row is 2^log_qd points further on the quotient domain
     const uint32_t* local = a.lde + (uint64_t)p * a.ld;
     const uint32_t* next = a.lde + (uint64_t)pn * a.ld;
     const uint32_t x = a.xs[p];
@@ -269,14 +269,15 @@ __global__ void __launch_bounds__(256) quotient_air_kernel(QuotientAirArgs a) {
         const uint4 wt = *reinterpret_cast<const uint4*>(a.weights + 4 * (uint64_t)k);
         dacc1(acc[0], wt.x, c); dacc1(acc[1], wt.y, c); dacc1(acc[2], wt.z, c); dacc1(acc[3], wt.w, c);
     }
-    const uint32_t parity = e & 1u;
+    const uint32_t chunk = e & (nq - 1u);
     Ext r = Ext{{dacc_finish(acc[0]), dacc_finish(acc[1]), dacc_finish(acc[2]), dacc_finish(acc[3])}};
-    r = ext_mul_base_dev(r, parity ? a.inv_zh_odd : a.inv_zh_even);
-    st_ext(a.out + ((uint64_t)parity * (m >> 1) + (e >> 1)) * 4, r);
-    if (a.lde_out) st_ext(a.lde_out + (uint64_t)p * a.lde_ld + 4u * parity, r);
+    const uint32_t iz = chunk == 0 ? a.inv_zh[0] : (chunk == 1 ? a.inv_zh[1] : (chunk == 2 ? a.inv_zh[2] : a.inv_zh[3]));
+    r = ext_mul_base_dev(r, iz);
+    st_ext(a.out + ((uint64_t)chunk * (m >> a.log_qd) + (e >> a.log_qd)) * 4, r);
+    if (a.lde_out) st_ext(a.lde_out + (uint64_t)p * a.lde_ld + 4u * chunk, r);
 }
 hipError_t launch_quotient_air(const QuotientAirArgs& a, hipStream_t s) {
-    const uint64_t m = 2ull << a.log_n;
+    const uint64_t m = 1ull << (a.log_n + a.log_qd);
     hipLaunchKernelGGL(quotient_air_kernel, dim3((unsigned)((m + 255) / 256)), dim3(256), 0, s, a);
     return hipGetLastError();
 }
@@ -500,11 +501,13 @@ __global__ void __launch_bounds__(256) reduced_combine_kernel(ReducedArgs a, con
     if (p >= a.rows) return;
     const Ext at = ld_ext(at_in + 4 * p);
     const uint4* qrow = reinterpret_cast<const uint4*>(a.qlde + p * a.q_ld);
-    const uint4 q0 = qrow[0], q1 = qrow[1];
-    const uint32_t qv[8] = {q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, q1.z, q1.w};
     Ext aq = ext_zero();
+    for (uint32_t h = 0; h < a.q_width / 8; h++) {              // 8 columns (two quotient chunks) per trip: one trip, or two with four chunks
+        const uint4 q0 = qrow[2 * h], q1 = qrow[2 * h + 1];
+        const uint32_t qv[8] = {q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, q1.z, q1.w};
 #pragma unroll
-    for (int j = 0; j < 8; j++) aq = ext_add(aq, ext_mul_base_dev(ld_ext(a.alpha_pow + 4 * j), qv[j]));
+        for (int j = 0; j < 8; j++) aq = ext_add(aq, ext_mul_base_dev(ld_ext(a.alpha_pow + 4 * (8 * h + j)), qv[j]));
+    }
     const Ext d1 = ld_ext(a.dinv + 4 * p), d2 = ld_ext(a.dinv + 4 * (a.rows + p));
     Ext r = ext_mul_dev(a.off_loc, ext_mul_dev(ext_sub(at, a.y_loc), d1));
     r = ext_add(r, ext_mul_dev(a.off_next, ext_mul_dev(ext_sub(at, a.y_next), d2)));

@@ -324,15 +324,18 @@ class Context:
         params = params or Params(1, 100, 16, 0)
         prog = np.ascontiguousarray(program, dtype=np.uint32)
         pv = np.ascontiguousarray(np.array(public_values, dtype=np.uint32))
-        size = self.lib.zkhip_proof_size_air(log_n, width, C.byref(params), pv.size)
+        size = self.lib.zkhip_proof_size_air(prog.ctypes.data_as(u32p), prog.size, log_n, width, C.byref(params), pv.size)
+        if size == 0:
+            check(self.lib.zkhip_air_validate(prog.ctypes.data_as(u32p), prog.size, width, pv.size))
+            raise _lib.ZkHipError(-1, "prove_shard_air: bad shape (degree 4 / 5 programs need log_blowup >= 2; no logup_pairs)")
         buf = np.empty(max(size, 1), dtype=np.uint8)
         got = C.c_size_t(0)
         check(self.lib.zkhip_prove_shard_air(self.handle, prog.ctypes.data_as(u32p), prog.size, C.c_void_p(trace.ptr), width, log_n, width,
                                              pv.ctypes.data_as(u32p), pv.size, C.byref(params), buf.ctypes.data_as(u8p), size, C.byref(got)))
         return buf[: got.value]
 
-    def quotient_values_air(self, program, lde, log_n, width, public_values, alpha, out=None):
-        out = out or self.alloc(4 << (log_n + 1))
+    def quotient_values_air(self, program, lde, log_n, width, public_values, alpha, out=None, log_quotient_degree=1):
+        out = out or self.alloc(4 << (log_n + log_quotient_degree))
         prog = np.ascontiguousarray(program, dtype=np.uint32)
         pv = np.ascontiguousarray(np.array(public_values, dtype=np.uint32))
         a = to_monty(np.asarray(alpha, dtype=np.uint32))
