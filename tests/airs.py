@@ -74,3 +74,37 @@ def quintic_trace(log_n, x0):
         w = (i >> 1) & 1
         t[i] = [x, y, x * y % P * y % P * w % P, w]
     return t.astype(np.uint32), [x0 % P]
+
+
+def random_program_and_trace(seed, log_n, width, max_degree):
+    """A pseudo-random AIR that its own trace satisfies: column 0 is a counter (first-row and transition constraints against public
+    values), every later column j is DEFINED by a random polynomial of total degree <= max_degree in earlier columns of the same row
+    and (for some terms) of the NEXT row's column 0 -- one `every row` constraint per column --, plus a last-row constraint on
+    column 0.  Returns (program, trace, public values)."""
+    rng = np.random.default_rng(seed)
+    n = 1 << log_n
+    start, step = int(rng.integers(0, P)), int(rng.integers(1, P))
+    x = (start + step * np.arange(n + 1, dtype=object)) % P          # one extra row: the "next" value of the last row wraps to row 0 below
+    t = np.zeros((n, width), dtype=object)
+    t[:, 0] = x[:n]
+    nxt0 = np.array([int(t[(i + 1) % n, 0]) for i in range(n)], dtype=object)
+    cons = [(O.SEL_FIRST, [(1, [V(0)]), (P - 1, [V(0, public=True)])]),
+            (O.SEL_TRANSITION, [(1, [V(0, True)]), (P - 1, [V(0)]), (P - 1, [V(1, public=True)])]),
+            (O.SEL_LAST, [(1, [V(0)]), (P - 1, [V(2, public=True)])])]
+    for j in range(1, width):
+        terms, val = [], np.zeros(n, dtype=object)
+        for _ in range(int(rng.integers(1, 4))):
+            d = int(rng.integers(0, max_degree + 1))
+            coeff = int(rng.integers(1, P))
+            vs, prod = [], np.full(n, coeff, dtype=object)
+            for _k in range(d):
+                if rng.random() < 0.2:
+                    vs.append(V(0, True)); prod = prod * nxt0 % P
+                else:
+                    c = int(rng.integers(0, j)); vs.append(V(c)); prod = prod * t[:, c] % P
+            terms.append(((P - coeff) % P, vs))
+            val = (val + prod) % P
+        t[:, j] = val
+        cons.append((O.SEL_ALL, [(1, [V(j)])] + terms))
+    pub = [start, step, int(t[n - 1, 0])]
+    return O.air_program(width, 3, cons), t.astype(np.uint32), pub

@@ -62,6 +62,23 @@ def test_degree_five_program_four_quotient_chunks(ctx, oracle, log_n, shape):
         ctx.prove_shard_air(prog, d, log_n, 4, pub, Params(1, 8, 4))          # blowup 2 cannot hold the 4N-point quotient domain
 
 
+@pytest.mark.parametrize("seed", range(8))
+def test_random_programs(ctx, oracle, seed):
+    """pseudo-random AIRs (tests/airs.py): degree, width, number of terms and the use of next-row / public variables vary"""
+    rng = np.random.default_rng(1000 + seed)
+    log_n, width, maxdeg = int(rng.integers(5, 12)), 4 * int(rng.integers(1, 7)), int(rng.choice([2, 3, 4, 5]))
+    prog, trace, pub = airs.random_program_and_trace(seed, log_n, width, maxdeg)
+    lqd = oracle.air_log_quotient_degree(prog)
+    b = int(rng.integers(lqd, 4))
+    shape = (b, int(rng.integers(2, 12)), int(rng.integers(0, 6)), 0, 1, 0, int(rng.choice([16, 24])))
+    prm, oprm = Params(*shape), oracle.default_params(*shape)
+    proof = ctx.prove_shard_air(prog, ctx.from_numpy(trace), log_n, width, pub, prm)
+    assert proof.tobytes() == oracle.prove_shard_air(prog, trace, pub, oprm).tobytes()
+    assert verify_shard_air(prog, proof, log_n, width, pub, prm) == (0, 0)
+    if log_n <= 8:
+        assert pyverify.verify(proof.tobytes(), log_n, width, pub, *shape, air=prog) is True
+
+
 def test_program_proof_at_2_pow_18_rows(ctx, oracle):
     log_n, width = 18, 32
     prog = airs.counter_program(width)

@@ -4,16 +4,31 @@ import sys, time
 sys.path.insert(0, "/root/repo"); sys.path.insert(0, "/root/repo/tests")
 import numpy as np
 import oracle_lib as O
-from zktls_amd.device import Context, verify_shard, verify_chips
+import airs
+from zktls_amd.device import Context, verify_shard, verify_chips, verify_shard_air
 from zktls_amd._lib import Params
 O.set_threads(8)
 budget = float(sys.argv[1]) if len(sys.argv) > 1 else 60.0
 rng = np.random.default_rng(int(time.time()))
 ctx = Context(0)
-t0 = time.time(); n_single = n_chips = 0
+t0 = time.time(); n_single = n_chips = n_air = 0
 SEED = int(rng.integers(1, 2**40))
 while time.time() - t0 < budget:
-    if rng.random() < 0.6:
+    r_kind = rng.random()
+    if r_kind < 0.2:
+        # a pseudo-random AIR supplied as a constraint program (degree 2..5: two or four quotient chunks)
+        log_n, width, maxdeg = int(rng.integers(5, 11)), 4 * int(rng.integers(1, 6)), int(rng.choice([2, 3, 4, 5]))
+        prog, trace, pub = airs.random_program_and_trace(int(rng.integers(0, 2**31)), log_n, width, maxdeg)
+        lqd = O.air_log_quotient_degree(prog)
+        K = int(rng.integers(1, 4))
+        fs = [f for f in range(0, min(log_n, 6) + 1) if (log_n - f) % K == 0]
+        if not fs: continue
+        shape = (int(rng.integers(lqd, 4)), int(rng.integers(1, 12)), int(rng.integers(0, 6)), 0, K, int(rng.choice(fs)), int(rng.choice([16, 24])))
+        pf = ctx.prove_shard_air(prog, ctx.from_numpy(trace), log_n, width, pub, Params(*shape))
+        assert pf.tobytes() == O.prove_shard_air(prog, trace, pub, O.default_params(*shape)).tobytes(), ("air", log_n, width, maxdeg, shape)
+        assert verify_shard_air(prog, pf, log_n, width, pub, Params(*shape)) == (0, 0)
+        n_air += 1
+    elif r_kind < 0.68:
         log_n = int(rng.integers(5, 13)); width = 4 * int(rng.integers(1, 25)); b = int(rng.integers(1, 4)); K = int(rng.integers(1, 5))
         fs = [f for f in range(0, min(log_n, 9) + 1) if (log_n - f) % K == 0]
         if not fs: continue
@@ -56,4 +71,4 @@ while time.time() - t0 < budget:
         assert verify_chips(pf, [c[0] for c in chips], [c[1] for c in chips], [7], Params(*prm), prs, pas if cross else None) == (0, 0)
         for d in dev: d.free()
         n_chips += 1
-print("ok: %d single-matrix and %d multi-chip configurations in %.0f s" % (n_single, n_chips, time.time() - t0))
+print("ok: %d single-matrix, %d multi-chip and %d constraint-program configurations in %.0f s" % (n_single, n_chips, n_air, time.time() - t0))
