@@ -620,10 +620,13 @@ hipError_t launch_ntt_pass(const NttPassArgs& a_, bool inverse, hipStream_t s) {
 // The tile arithmetic is that of ntt_pass_kernel<4, INV, 2, 5>: 512 threads, thread (u, c) holds rows u + 32 n1 of two columns,
 // 32-point DIF in registers, tile twiddle, one LDS exchange per column, 32-point DIFs again.  What differs is how a tile reaches the
 // registers and leaves them (kernels.h, ColPassArgs): on a transposed side the 16 columns of one round are moved as sixteen 4 KiB lines
-// between global memory and the exchange buffer (row pitch 1028 words: the 4-word skew spreads the sixteen lines over the banks),
+// between global memory and the exchange buffer (skewed line pitch, col_lidx),
 // lanes along the line; the per-element inter-pass twiddle is a full 1024 x 1024 table read like the data (4 MiB, shared by every
 // polynomial of the batch, so it lives in L2 / MALL after the first).
-constexpr int COL_PT = 1028;          // words between the lines of the transposed staging buffer
+// word index of element kk of line cs in the transposed staging buffer: line pitch 1028 and one extra word per 256 elements keep
+// BOTH access patterns of a wave (4 consecutive kk x 16 lines, and the bit-reversed form: 4 kk that are 256 apart x 16 lines) at the
+// two-way bank conflict a 64-lane access cannot avoid (pitch 1028 without the skew: 8-way for the bit-reversed form)
+ZK_D uint32_t col_lidx(uint32_t cs, uint32_t kk) { return cs * 1028u + kk + (kk >> 8); }
 ZK_D uint32_t brev10(uint32_t x) { return __brev(x) >> 22; }
 template <bool INV>
 __global__ void __launch_bounds__(512, 4) ntt_colpass_kernel(ColPassArgs a) {
@@ -661,13 +664,14 @@ __global__ void __launch_bounds__(512, 4) ntt_colpass_kernel(ColPassArgs a) {
                 const uint32_t col = cg * 32 + 2 * cs + cc;
                 const uint32_t line = a.in_brev ? brev10(col) : col;
                 const u32x2 v = __builtin_nontemporal_load(reinterpret_cast<const u32x2*>(in + (uint64_t)line * 1024 + 2 * kp));
-                *reinterpret_cast<u32x2*>(sdata + cs * COL_PT + 2 * kp) = v;
+                const uint32_t li = col_lidx(cs, 2 * kp);          // 2 kp and 2 kp + 1 share their skew
+                sdata[li] = v.x; sdata[li + 1] = v.y;
             }
             __syncthreads();
 #pragma unroll
             for (int n1 = 0; n1 < 32; n1++) {
                 const uint32_t n = u + 32 * n1;
-                x[cc][n1] = sdata[c * COL_PT + (a.in_brev ? brev10(n) : n)];
+                x[cc][n1] = sdata[col_lidx(c, a.in_brev ? brev10(n) : n)];
             }
         }
         __syncthreads();
@@ -739,7 +743,7 @@ __global__ void __launch_bounds__(512, 4) ntt_colpass_kernel(ColPassArgs a) {
 #pragma unroll
             for (int rho = 0; rho < 32; rho++) {
                 const uint32_t k = 32 * rev5(rho) + u;
-                sdata[c * COL_PT + (a.out_brev ? brev10(k) : k)] = x[cc][rho];
+                sdata[col_lidx(c, a.out_brev ? brev10(k) : k)] = x[cc][rho];
             }
             __syncthreads();
 #pragma unroll
@@ -747,7 +751,8 @@ __global__ void __launch_bounds__(512, 4) ntt_colpass_kernel(ColPassArgs a) {
                 const uint32_t idx = i * 512 + tid, cs = idx >> 9, kp = idx & 511;
                 const uint32_t col = cg * 32 + 2 * cs + cc;
                 const uint32_t line = a.out_brev ? brev10(col) : col;
-                const u32x2 v = *reinterpret_cast<const u32x2*>(sdata + cs * COL_PT + 2 * kp);
+                const uint32_t li = col_lidx(cs, 2 * kp);
+                u32x2 v; v.x = sdata[li]; v.y = sdata[li + 1];
                 __builtin_nontemporal_store(v, reinterpret_cast<u32x2*>(out + (uint64_t)line * 1024 + 2 * kp));
             }
         }
