@@ -340,7 +340,9 @@ int zkhip_prove_shard_air(zkhip_ctx* ctx, const uint32_t* program, size_t progra
                           uint8_t* proof, size_t cap, size_t* len);
 int zkhip_verify_shard_air(const uint32_t* program, size_t program_words, const uint8_t* proof, size_t len, int log_n, uint32_t width,
                            const uint32_t* public_values, size_t n_public, const zkhip_params* prm, int* reason);
-/* stage level: quotient values of a program on the LDE coset (layout of zkhip_quotient_values); alpha: host, Montgomery */
+/* stage level: quotient values of a program on its quotient domain = the first 2^(log_n + lqd) rows of the bit-reversed LDE (d_lde
+ * must hold at least that many rows; lqd = 1 for degree <= 3, 2 for degree 4 / 5); d_out: that many extension elements, in the
+ * LDE's bit-reversed row order (layout of zkhip_quotient_values); alpha: host, Montgomery */
 int zkhip_quotient_values_air(zkhip_ctx* ctx, const uint32_t* program, size_t program_words, const uint32_t* d_lde, size_t ld, int log_n,
                               uint32_t width, const uint32_t* public_values, size_t n_public, const uint32_t alpha[4], uint32_t* d_out);
 
@@ -378,6 +380,7 @@ int zkhip_verify_chips(const uint8_t* proof, size_t len, const int32_t* log_ns, 
  * "name", "external_rc" (8 x width), "internal_rc" (13 | 21), "internal_diag" (width), canonical residues
  * (tests/golden/poseidon2*_params.json are such files).  Only while NO context exists (zkhip_ctx_destroy everything and
  * zkhip_release_cached_contexts first): a context uploads the set in effect to its device when it is created. ---- */
+/* (not thread-safe against any other call into the library, host-only entries included: load at start-up) */
 int zkhip_load_poseidon2_params(const char* path);
 int zkhip_reset_poseidon2_params(void);                 /* back to the built-in sets */
 const char* zkhip_poseidon2_params_name(int width);     /* name of the set in effect (thread-local copy) */
