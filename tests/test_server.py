@@ -1,0 +1,135 @@
+"""The prover server (zktls_amd/server/moongate_hip.cpp; SURVEY.md 8b plug point 4, 8f-3): Twirp-over-HTTP transport of the
+endpoint the reference's SP1 path already calls (sp1.rs:86-90, prove.rs:45-47).  CPU part: routing, protobuf framing, Twirp error
+mapping, and the loud failure without a device.  GPU part: ProveCore returns a batch of verified proofs."""
+import http.client
+import json
+import os
+import socket
+import struct
+import subprocess
+import time
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+BIN = os.path.join(ROOT, "zktls_amd", "moongate-hip")
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+@pytest.fixture()
+def server():
+    port = _free_port()
+    proc = subprocess.Popen([BIN, "--port", str(port)], stderr=subprocess.PIPE)
+    line = proc.stderr.readline()                      # "listening on ..."
+    assert b"listening" in line, line
+    yield port
+    proc.terminate()
+    proc.wait(timeout=30)
+
+
+def pb_bytes(data):
+    n, out = len(data), bytearray([0x0A])
+    while True:
+        b = n & 0x7F
+        n >>= 7
+        out.append(b | (0x80 if n else 0))
+        if not n:
+            break
+    return bytes(out) + data
+
+
+def pb_field1(msg):
+    if not msg:
+        return b""
+    assert msg[0] == 0x0A
+    n, sh, p = 0, 0, 1
+    while True:
+        b = msg[p]; p += 1
+        n |= (b & 0x7F) << sh; sh += 7
+        if not b & 0x80:
+            break
+    assert p + n == len(msg)
+    return msg[p:p + n]
+
+
+def call(port, method, body, ctype="application/protobuf", verb="POST", path=None, timeout=600):
+    c = http.client.HTTPConnection("127.0.0.1", port, timeout=timeout)
+    c.request(verb, path or "/twirp/api.ProverService/" + method, body=body, headers={"Content-Type": ctype})
+    r = c.getresponse()
+    data = r.read()
+    c.close()
+    return r.status, r.getheader("Content-Type"), data
+
+
+def prove_payload(log_n, width, shards, queries, pow_bits, cbor, elf, backend=0, device=0):
+    return (b"ZKMG" + struct.pack("<IiIIiiIi", 1, log_n, width, shards, queries, pow_bits, backend, device)
+            + struct.pack("<I", len(cbor)) + cbor + struct.pack("<I", len(elf)) + elf)
+
+
+def test_routing_framing_and_twirp_errors(server):
+    from zktls_amd import _lib
+    port = server
+    st, ct, body = call(port, "Ready", b"")
+    assert st == 200 and ct == "application/protobuf"
+    assert body == (b"\x08\x01" if _lib.device_count() > 0 else b"")
+    # Setup: result = the request digest of the program (the same words the glue binds proofs to)
+    elf = b"\x7fELFprogram" * 3
+    st, ct, body = call(port, "Setup", pb_bytes(elf))
+    assert st == 200
+    import ctypes as C
+    d = (C.c_uint32 * 8)()
+    assert _lib.load().zkhip_request_digest(None, 0, elf, len(elf), d) == 0
+    assert pb_field1(body) == bytes(d)
+    # Twirp errors: JSON {"code", "msg"}, status by code
+    for args, status, code in ((dict(method="Nope", body=b""), 404, "bad_route"),
+                               (dict(method="Ready", body=b"", verb="GET"), 404, "bad_route"),
+                               (dict(method="Ready", body=b"{}", ctype="application/json"), 404, "bad_route"),
+                               (dict(method="Ready", body=b"", path="/other/Ready"), 404, "bad_route"),
+                               (dict(method="Compress", body=pb_bytes(b"x")), 501, "unimplemented"),
+                               (dict(method="Wrap", body=pb_bytes(b"x")), 501, "unimplemented"),
+                               (dict(method="Setup", body=b"\x0a\x05ab"), 400, "malformed"),
+                               (dict(method="Setup", body=pb_bytes(b"")), 400, "invalid_argument"),
+                               (dict(method="ProveCore", body=pb_bytes(b"not a payload")), 400, "invalid_argument"),
+                               (dict(method="ProveCore", body=pb_bytes(prove_payload(6, 8, 1, 10, 4, b"in", b"elf")[:-1])), 400, "invalid_argument")):
+        st, ct, body = call(port, **args)
+        assert st == status and ct == "application/json", (args, st, body)
+        assert json.loads(body)["code"] == code
+    if _lib.device_count() == 0:
+        st, ct, body = call(port, "ProveCore", pb_bytes(prove_payload(6, 8, 2, 10, 4, b"input", b"elf")))
+        assert st == 503 and json.loads(body)["code"] == "unavailable" and "no CPU fallback" in json.loads(body)["msg"]
+
+
+@pytest.mark.gpu
+def test_prove_core_returns_verified_proofs(server):
+    from zktls_amd._lib import Params
+    from zktls_amd.device import verify_shard
+    port = server
+    cbor, elf = b"\xa1transcript" * 9, b"\x7fELFguest"
+    st, ct, body = call(port, "ProveCore", pb_bytes(prove_payload(10, 16, 3, 20, 8, cbor, elf)))
+    assert st == 200, body
+    res = pb_field1(body)
+    on = struct.unpack_from("<I", res)[0]
+    output, blob = res[4:4 + on], res[4 + on:]
+    digest = list(struct.unpack("<8I", output))
+    magic, version, flags, count = struct.unpack_from("<4I", blob)
+    assert (magic, version, flags, count) == (0x42544B5A, 2, 1, 3)              # "ZKTB", flagged SYNTHETIC
+    off = 16
+    for s in range(3):
+        ln = struct.unpack_from("<I", blob, off)[0]
+        proof = np.frombuffer(blob[off + 4:off + 4 + ln], dtype=np.uint8)
+        assert verify_shard(proof, 10, 16, digest + [s], Params(1, 20, 8)) == (0, 0)
+        off += 4 + ln
+    assert off == len(blob)
+    # the RISC Zero shape through the same endpoint, and a second request on the same server
+    st, ct, body = call(port, "ProveCore", pb_bytes(prove_payload(12, 8, 1, 100, 16, cbor, elf, backend=1)))
+    assert st == 200
+    st, ct, body = call(port, "ProveCore", pb_bytes(prove_payload(10, 16, 1, 100000, 8, cbor, elf)))
+    assert st == 400 and json.loads(body)["code"] == "invalid_argument"           # the library's own argument check comes back as a Twirp error

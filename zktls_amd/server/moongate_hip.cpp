@@ -1,0 +1,243 @@
+// moongate_hip.cpp -- a prover SERVER in front of libzkhip, speaking the transport the reference's SP1 path already knows how to
+// call (SURVEY.md section 8b plug point 4, 8f-3).
+//
+// When `--sp1-moongate-server` / SP1_MOONGATE_SERVER is set (bins/zktls/src/commands/prove.rs:45-47) the reference builds
+// `ProverClient::builder().cuda().with_moongate_endpoint(server)` (crates/guest-prover-sp1/src/sp1.rs:86-90) and every GPU step
+// happens in another process over HTTP: sp1-cuda 4.1.4 (reference Cargo.lock:5878) is a twirp client (twirp-rs, Cargo.lock:6835).
+// A server on that endpoint is a drop-in with no Rust at all.  What is implemented here, and what is not:
+//   * the TRANSPORT, as the public Twirp v7 specification defines it: HTTP/1.1 POST /twirp/<package>.<Service>/<Method>,
+//     Content-Type application/protobuf, the request and response being one protobuf message; errors as JSON
+//     {"code", "msg"} with Twirp's HTTP status mapping (bad_route 404, malformed 400, unimplemented 501, unavailable 503, internal 500);
+//   * the service SHAPE [RECALLED from sp1-cuda; its .proto is not in /root/reference]: package `api`, service `ProverService`,
+//     methods Ready {} -> {bool ready = 1}, Setup / ProveCore / Compress / Shrink / Wrap {bytes data = 1} -> {bytes result = 1};
+//   * the PAYLOADS inside `data` upstream are bincode serialisations of sp1-prover types (proving key, stdin, shard proofs) that
+//     cannot be reproduced offline, so this server defines its own for the two methods it can serve:
+//       Setup      data = guest ELF bytes                   -> result = 32 bytes: zkhip_request_digest("", ELF) (a stand-in "vk digest")
+//       ProveCore  data = "ZKMG" u32 version(1) | i32 log_n | u32 width | u32 shards | i32 num_queries | i32 pow_bits |
+//                         u32 backend (0 SP1 shape, 1 RISC Zero shape) | i32 device (-1: all) | u32 cbor_len | cbor | u32 elf_len | elf
+//                                                            -> result = the batch blob of the host mirror (zktls_amd/host), flagged SYNTHETIC
+//       Compress / Shrink / Wrap                             -> Twirp error `unimplemented` (recursion is out of scope)
+//     Swapping in upstream's payload structs is the remaining work once they can be read; the transport does not change.
+// One request at a time per connection, connections served one after the other (proofs serialise on the GPU anyway); 127.0.0.1 only
+// unless --bind is given.  No TLS, no auth: it is meant to sit next to the client like the container it replaces.
+#include <arpa/inet.h>
+#include <netinet/in.h>
+#include <signal.h>
+#include <sys/socket.h>
+#include <unistd.h>
+
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/zkhip.h"
+#include "../host/guest_prover_hip.hpp"
+
+namespace {
+
+struct Request { std::string method, path, content_type; std::vector<uint8_t> body; bool ok = false; };
+
+bool read_exact(int fd, void* buf, size_t n) {
+    uint8_t* p = (uint8_t*)buf;
+    while (n) { ssize_t r = ::recv(fd, p, n, 0); if (r <= 0) return false; p += r; n -= (size_t)r; }
+    return true;
+}
+bool write_all(int fd, const void* buf, size_t n) {
+    const uint8_t* p = (const uint8_t*)buf;
+    while (n) { ssize_t r = ::send(fd, p, n, MSG_NOSIGNAL); if (r <= 0) return false; p += r; n -= (size_t)r; }
+    return true;
+}
+std::string lower(std::string s) { for (char& c : s) if (c >= 'A' && c <= 'Z') c = (char)(c + 32); return s; }
+
+// minimal HTTP/1.1 request reader: request line, headers (Content-Length, Content-Type), body
+Request read_request(int fd, size_t max_body) {
+    Request rq;
+    std::string head;
+    char c;
+    while (head.size() < 16384) {
+        if (!read_exact(fd, &c, 1)) return rq;
+        head.push_back(c);
+        if (head.size() >= 4 && head.compare(head.size() - 4, 4, "\r\n\r\n") == 0) break;
+    }
+    const size_t eol = head.find("\r\n");
+    if (eol == std::string::npos) return rq;
+    const std::string line = head.substr(0, eol);
+    const size_t s1 = line.find(' '), s2 = line.rfind(' ');
+    if (s1 == std::string::npos || s2 == s1) return rq;
+    rq.method = line.substr(0, s1);
+    rq.path = line.substr(s1 + 1, s2 - s1 - 1);
+    size_t content_length = 0;
+    size_t pos = eol + 2;
+    while (pos < head.size()) {
+        const size_t e = head.find("\r\n", pos);
+        if (e == std::string::npos || e == pos) break;
+        const std::string h = head.substr(pos, e - pos);
+        const size_t colon = h.find(':');
+        if (colon != std::string::npos) {
+            const std::string k = lower(h.substr(0, colon));
+            std::string v = h.substr(colon + 1);
+            while (!v.empty() && v[0] == ' ') v.erase(0, 1);
+            if (k == "content-length") content_length = (size_t)std::strtoull(v.c_str(), nullptr, 10);
+            if (k == "content-type") rq.content_type = lower(v);
+        }
+        pos = e + 2;
+    }
+    if (content_length > max_body) return rq;
+    rq.body.resize(content_length);
+    if (content_length && !read_exact(fd, rq.body.data(), content_length)) return rq;
+    rq.ok = true;
+    return rq;
+}
+
+void respond(int fd, int status, const char* reason, const char* ctype, const void* body, size_t n) {
+    char head[256];
+    const int hl = std::snprintf(head, sizeof head, "HTTP/1.1 %d %s\r\nContent-Type: %s\r\nContent-Length: %zu\r\nConnection: close\r\n\r\n", status, reason, ctype, n);
+    if (write_all(fd, head, (size_t)hl) && n) write_all(fd, body, n);
+}
+std::string json_escape(const std::string& s) {
+    std::string o;
+    for (char c : s) { if (c == '"' || c == '\\') { o.push_back('\\'); o.push_back(c); } else if ((unsigned char)c < 0x20) o.push_back(' '); else o.push_back(c); }
+    return o;
+}
+// Twirp error: JSON body, status by error code
+void twirp_error(int fd, const char* code, const std::string& msg) {
+    int status = 500; const char* reason = "Internal Server Error";
+    if (!std::strcmp(code, "bad_route")) { status = 404; reason = "Not Found"; }
+    else if (!std::strcmp(code, "malformed") || !std::strcmp(code, "invalid_argument")) { status = 400; reason = "Bad Request"; }
+    else if (!std::strcmp(code, "unimplemented")) { status = 501; reason = "Not Implemented"; }
+    else if (!std::strcmp(code, "unavailable")) { status = 503; reason = "Service Unavailable"; }
+    const std::string body = std::string("{\"code\":\"") + code + "\",\"msg\":\"" + json_escape(msg) + "\"}";
+    respond(fd, status, reason, "application/json", body.data(), body.size());
+}
+
+// protobuf: the only messages are {bytes f1 = 1} and {bool f1 = 1}
+bool pb_get_bytes1(const std::vector<uint8_t>& m, std::vector<uint8_t>* out) {
+    size_t p = 0;
+    out->clear();
+    while (p < m.size()) {
+        uint64_t key = 0; int sh = 0;
+        for (;;) { if (p >= m.size() || sh > 63) return false; const uint8_t b = m[p++]; key |= (uint64_t)(b & 0x7F) << sh; sh += 7; if (!(b & 0x80)) break; }
+        const uint32_t field = (uint32_t)(key >> 3), wt = (uint32_t)(key & 7);
+        if (wt == 0) { for (;;) { if (p >= m.size()) return false; if (!(m[p++] & 0x80)) break; } }
+        else if (wt == 2) {
+            uint64_t len = 0; sh = 0;
+            for (;;) { if (p >= m.size() || sh > 63) return false; const uint8_t b = m[p++]; len |= (uint64_t)(b & 0x7F) << sh; sh += 7; if (!(b & 0x80)) break; }
+            if (len > m.size() - p) return false;
+            if (field == 1) out->assign(m.begin() + (long)p, m.begin() + (long)(p + len));
+            p += len;
+        } else if (wt == 5) { if (m.size() - p < 4) return false; p += 4; }
+        else if (wt == 1) { if (m.size() - p < 8) return false; p += 8; }
+        else return false;
+    }
+    return true;
+}
+std::vector<uint8_t> pb_bytes1(const std::vector<uint8_t>& v) {
+    std::vector<uint8_t> o;
+    o.push_back(0x0A);
+    uint64_t n = v.size();
+    do { uint8_t b = n & 0x7F; n >>= 7; if (n) b |= 0x80; o.push_back(b); } while (n);
+    o.insert(o.end(), v.begin(), v.end());
+    return o;
+}
+
+struct Cursor {
+    const std::vector<uint8_t>& d; size_t p = 0; bool ok = true;
+    uint32_t u32() { if (d.size() - p < 4) { ok = false; return 0; } uint32_t v; std::memcpy(&v, d.data() + p, 4); p += 4; return v; }
+    std::vector<uint8_t> blob() { const uint32_t n = u32(); if (!ok || d.size() - p < n) { ok = false; return {}; } std::vector<uint8_t> v(d.begin() + (long)p, d.begin() + (long)(p + n)); p += n; return v; }
+};
+
+void handle(int fd) {
+    const Request rq = read_request(fd, (size_t)1 << 30);
+    if (!rq.ok) { twirp_error(fd, "malformed", "could not read an HTTP request"); return; }
+    const std::string prefix = "/twirp/api.ProverService/";
+    if (rq.method != "POST") { twirp_error(fd, "bad_route", "unsupported method " + rq.method + " (only POST is allowed)"); return; }
+    if (rq.path.compare(0, prefix.size(), prefix) != 0) { twirp_error(fd, "bad_route", "no handler for path " + rq.path); return; }
+    if (rq.content_type.compare(0, 20, "application/protobuf") != 0) { twirp_error(fd, "bad_route", "unexpected Content-Type: " + rq.content_type + " (this server speaks application/protobuf)"); return; }
+    const std::string method = rq.path.substr(prefix.size());
+    if (method == "Ready") {
+        const uint8_t yes[2] = {0x08, 0x01};
+        if (zkhip_device_count() > 0) respond(fd, 200, "OK", "application/protobuf", yes, 2);
+        else respond(fd, 200, "OK", "application/protobuf", nullptr, 0);        // proto3: false is the empty message
+        return;
+    }
+    if (method == "Compress" || method == "Shrink" || method == "Wrap") { twirp_error(fd, "unimplemented", method + ": recursion / wrapping is not part of the shard-prove hot path"); return; }
+    if (method != "Setup" && method != "ProveCore") { twirp_error(fd, "bad_route", "no handler for path " + rq.path); return; }
+    std::vector<uint8_t> data;
+    if (!pb_get_bytes1(rq.body, &data)) { twirp_error(fd, "malformed", "the request is not a protobuf message with a bytes field 1"); return; }
+    if (method == "Setup") {
+        if (data.empty()) { twirp_error(fd, "invalid_argument", "Setup: empty program"); return; }
+        uint32_t dg[8];
+        if (zkhip_request_digest(nullptr, 0, data.data(), data.size(), dg) != ZKHIP_OK) { twirp_error(fd, "internal", zkhip_last_error()); return; }
+        std::vector<uint8_t> res(32);
+        std::memcpy(res.data(), dg, 32);
+        const std::vector<uint8_t> msg = pb_bytes1(res);
+        respond(fd, 200, "OK", "application/protobuf", msg.data(), msg.size());
+        return;
+    }
+    Cursor c{data};
+    if (c.u32() != 0x474D4B5Au || c.u32() != 1u) { twirp_error(fd, "invalid_argument", "ProveCore: payload must start with \"ZKMG\", version 1 (see moongate_hip.cpp)"); return; }
+    zktls::ShardPlan plan;
+    plan.log_n = (int)c.u32(); plan.width = c.u32(); plan.shards = c.u32(); plan.num_queries = (int)c.u32(); plan.pow_bits = (int)c.u32();
+    const uint32_t backend = c.u32();
+    const int device = (int)c.u32();
+    zktls::GuestInput in;
+    in.cbor = c.blob();
+    const std::vector<uint8_t> elf = c.blob();
+    if (!c.ok || c.p != data.size() || backend > 1) { twirp_error(fd, "invalid_argument", "ProveCore: truncated or oversized payload"); return; }
+    zktls::HipGuestProver prover(device < 0 ? 0 : device, backend ? zktls::Backend::Risc0 : zktls::Backend::Sp1);
+    if (device < 0) { std::vector<int> all; for (int d = 0; d < zkhip_device_count(); d++) all.push_back(d); if (!all.empty()) prover.with_devices(all); }
+    prover.hip().with_synthetic(plan);
+    const zktls::ProveResult r = prover.prove(in, elf);
+    if (!r.ok) {
+        const bool nodev = r.error.find("no CPU fallback") != std::string::npos || r.error.find("NO_DEVICE") != std::string::npos;
+        twirp_error(fd, nodev ? "unavailable" : "invalid_argument", r.error);
+        return;
+    }
+    // result = u32 output length | output | proof blob
+    std::vector<uint8_t> res;
+    const uint32_t on = (uint32_t)r.output.size();
+    res.insert(res.end(), (const uint8_t*)&on, (const uint8_t*)&on + 4);
+    res.insert(res.end(), r.output.begin(), r.output.end());
+    res.insert(res.end(), r.proof.begin(), r.proof.end());
+    const std::vector<uint8_t> msg = pb_bytes1(res);
+    respond(fd, 200, "OK", "application/protobuf", msg.data(), msg.size());
+}
+
+}  // namespace
+
+int main(int argc, char** argv) {
+    int port = 3000;
+    const char* bind_addr = "127.0.0.1";
+    int max_requests = -1;                                   // tests: serve this many requests, then exit
+    for (int i = 1; i < argc; i++) {
+        if (!std::strcmp(argv[i], "--port") && i + 1 < argc) port = std::atoi(argv[++i]);
+        else if (!std::strcmp(argv[i], "--bind") && i + 1 < argc) bind_addr = argv[++i];
+        else if (!std::strcmp(argv[i], "--max-requests") && i + 1 < argc) max_requests = std::atoi(argv[++i]);
+        else { std::fprintf(stderr, "usage: %s [--port N] [--bind ADDR] [--max-requests N]\n", argv[0]); return 2; }
+    }
+    signal(SIGPIPE, SIG_IGN);
+    const int ls = ::socket(AF_INET, SOCK_STREAM, 0);
+    if (ls < 0) { std::perror("socket"); return 1; }
+    int one = 1;
+    setsockopt(ls, SOL_SOCKET, SO_REUSEADDR, &one, sizeof one);
+    sockaddr_in addr{};
+    addr.sin_family = AF_INET;
+    addr.sin_port = htons((uint16_t)port);
+    if (inet_pton(AF_INET, bind_addr, &addr.sin_addr) != 1) { std::fprintf(stderr, "bad bind address\n"); return 2; }
+    if (::bind(ls, (sockaddr*)&addr, sizeof addr) != 0 || ::listen(ls, 16) != 0) { std::perror("bind/listen"); return 1; }
+    std::fprintf(stderr, "moongate-hip: listening on %s:%d (devices: %d)\n", bind_addr, port, zkhip_device_count());
+    std::fflush(stderr);
+    for (int served = 0; max_requests < 0 || served < max_requests; served++) {
+        const int fd = ::accept(ls, nullptr, nullptr);
+        if (fd < 0) continue;
+        handle(fd);
+        ::shutdown(fd, SHUT_RDWR);
+        ::close(fd);
+    }
+    zktls::release_cached();
+    zkhip_release_cached_contexts();
+    ::close(ls);
+    return 0;
+}
