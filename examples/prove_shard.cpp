@@ -34,7 +34,7 @@ int main(int argc, char** argv) {
     void* d_trace = nullptr;
     const size_t words = (size_t)width << log_n;
     CHECK(zkhip_malloc(ctx, words * 4, &d_trace));
-    const zkhip_params prm = {1, 100, 16, 0, 0, 0, 0};            // SP1-core-like shape
+    const zkhip_params prm = {1, 100, 16, 0, 0, 0, 0, 0};            // SP1-core-like shape
     const size_t cap = zkhip_proof_size(log_n, width, &prm, 1);
     if (cap == 0) { std::fprintf(stderr, "bad shape: %s\n", zkhip_last_error()); return 1; }
     std::vector<uint8_t> proof(cap);

@@ -94,6 +94,12 @@ typedef struct {
     int32_t log_final;          /* folding stops at a polynomial of < 2^log_final coefficients, sent in clear
                                  * (default 0: a constant; RISC Zero: 8) */
     int32_t hash_width;         /* Poseidon2 width of every Merkle tree: 16 (rate 8, default) or 24 (rate 16) */
+    /* RISC Zero's group order (risc0-zkp prove::Prover commits a code, a data and an accum group: reference Cargo.lock:5057,
+     * behind crates/guest-prover-r0/src/prover.rs:90).  0: one trace commitment.  Wc > 0 (a multiple of 4, < width): the first Wc
+     * columns ("code") and the rest ("data") get a Merkle tree each, the code root committed and observed first; with
+     * logup_pairs > 0 the permutation trace is the third ("accum") group, then the quotient ("check") -- proof version 8.
+     * Only zkhip_prove_shard / zkhip_prove_segment / zkhip_verify_shard read it; leave it 0 elsewhere. */
+    int32_t code_width;
 } zkhip_params;
 
 /* ---- library / context ---- */

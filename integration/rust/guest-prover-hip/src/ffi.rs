@@ -34,13 +34,15 @@ pub struct ZkhipParams {
     pub log_fold: i32,
     pub log_final: i32,
     pub hash_width: i32,
+    /// RISC Zero's group order: > 0 commits the first `code_width` columns and the rest as two trees (code root first)
+    pub code_width: i32,
 }
 
 impl ZkhipParams {
     /// sp1-stark 4.1.4 core shards
-    pub const SP1_CORE: Self = Self { log_blowup: 1, num_queries: 100, pow_bits: 16, logup_pairs: 0, log_fold: 0, log_final: 0, hash_width: 0 };
+    pub const SP1_CORE: Self = Self { log_blowup: 1, num_queries: 100, pow_bits: 16, logup_pairs: 0, log_fold: 0, log_final: 0, hash_width: 0, code_width: 0 };
     /// risc0-zkp 1.2.5 segments: blowup 4, 50 queries, fold 16, 256 final coefficients, Poseidon2 width 24
-    pub const RISC0: Self = Self { log_blowup: 2, num_queries: 50, pow_bits: 0, logup_pairs: 0, log_fold: 4, log_final: 8, hash_width: 24 };
+    pub const RISC0: Self = Self { log_blowup: 2, num_queries: 50, pow_bits: 0, logup_pairs: 0, log_fold: 4, log_final: 8, hash_width: 24, code_width: 0 };
 }
 
 pub const ZKHIP_OK: c_int = 0;

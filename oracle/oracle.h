@@ -131,6 +131,9 @@ typedef struct {
     int log_fold;         /* committed FRI layers fold by 2^log_fold: 1 (p3-fri) or e.g. 4 (RISC Zero folds by 16) */
     int log_final;        /* stop folding at a polynomial of < 2^log_final coefficients, sent in clear (RISC Zero: 8) */
     int hash_width;       /* Poseidon2 width of every Merkle tree: 16 (rate 8) or 24 (rate 16, RISC Zero) */
+    int code_width;       /* 0: one trace commitment.  Wc > 0 (multiple of 4, < width): RISC Zero's group order -- the first Wc columns
+                           * ("code") and the rest ("data") are committed as two trees, code root first; with lookups the permutation
+                           * trace is the third ("accum") group, then the quotient ("check") */
 } orc_params_t;
 
 /* quotient values on the LDE coset, in bit-reversed row order like the LDE:

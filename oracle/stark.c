@@ -411,7 +411,8 @@ static int shape_of(int log_n, size_t width, const orc_params_t* prm, shape_t* s
     sh->K = prm->log_fold ? prm->log_fold : 1;
     sh->F = prm->log_final;
     sh->hw = prm->hash_width ? prm->hash_width : 16;
-    sh->ext = !(sh->b == 1 && sh->K == 1 && sh->F == 0 && sh->hw == 16);   /* extended header / transcript */
+    sh->ext = !(sh->b == 1 && sh->K == 1 && sh->F == 0 && sh->hw == 16) || prm->code_width != 0;   /* extended header / transcript */
+    if (prm->code_width < 0 || prm->code_width % 4 != 0 || (prm->code_width && (size_t)prm->code_width >= width)) return 0;
     if (sh->b < 1 || sh->b > 3 || width % 4 != 0 || width == 0) return 0;
     if (sh->K < 1 || sh->K > 5 || sh->F < 0 || sh->F > 10 || sh->F > log_n || (log_n - sh->F) % sh->K != 0) return 0;
     if (sh->hw != 16 && sh->hw != 24) return 0;
@@ -427,8 +428,9 @@ size_t orc_proof_size(int log_n, size_t width, const orc_params_t* prm, size_t n
     if (!shape_of(log_n, width, prm, &sh)) return 0;
     size_t H = (size_t)(log_n + sh.b);
     size_t Q = (size_t)prm->logup_pairs, wp = Q ? 4 * (Q + 1) : 0;
-    size_t words = (g_air ? 20 : (sh.ext ? 12 : (Q ? 9 : 8))) + 16 + 8 * width + 16 * NQ_CUR + 8 * (size_t)sh.R + 4 * ((size_t)1 << sh.F) + 1;
-    size_t perq = width + 4 * NQ_CUR + 16 * H;
+    const size_t CW = g_air ? 0 : (size_t)prm->code_width;                 /* code / data split: one more header word, root and path */
+    size_t words = (g_air ? 20 : (sh.ext ? 12 : (Q ? 9 : 8))) + (CW ? 9 : 0) + 16 + 8 * width + 16 * NQ_CUR + 8 * (size_t)sh.R + 4 * ((size_t)1 << sh.F) + 1;
+    size_t perq = width + 4 * NQ_CUR + 16 * H + (CW ? 8 * H : 0);
     if (Q) { words += 8 + 8 * wp; perq += wp + 8 * H; }
     for (int l = 0; l < sh.R; l++) perq += 4 * (((size_t)1 << sh.K) - 1) + 8 * (H - (size_t)sh.K * (l + 1));
     words += (size_t)prm->num_queries * perq;
@@ -455,6 +457,7 @@ static void transcript_init(orc_challenger_t* ch, int log_n, size_t width,
         orc_chal_observe(ch, (uint32_t)sh->F);
         orc_chal_observe(ch, (uint32_t)sh->hw);
     } else if (prm->logup_pairs) orc_chal_observe(ch, (uint32_t)prm->logup_pairs);
+    if (!g_air && prm->code_width) orc_chal_observe(ch, (uint32_t)prm->code_width);
     if (g_air) {
         uint32_t dg[8];
         orc_air_digest(g_air, g_air_words, dg);
@@ -505,13 +508,16 @@ size_t orc_prove_shard(const uint32_t* trace, int log_n, size_t width,
     const size_t NQ = (size_t)1 << lqd, QW = 4 * NQ;                       /* quotient chunks, width of the quotient matrix */
     const size_t n = (size_t)1 << log_n, m = (size_t)1 << H, mq = (size_t)1 << Hq, wp = Q ? 4 * ((size_t)Q + 1) : 0;
 
-    pf[pos++] = PROOF_MAGIC; pf[pos++] = g_air ? 7u : (sh.ext ? 3u : (Q ? 2u : PROOF_VERSION)); pf[pos++] = (uint32_t)log_n;
+    const size_t CW = g_air ? 0 : (size_t)prm->code_width;
+    if (g_air && prm->code_width) return 0;
+    pf[pos++] = PROOF_MAGIC; pf[pos++] = g_air ? 7u : (CW ? 8u : (sh.ext ? 3u : (Q ? 2u : PROOF_VERSION))); pf[pos++] = (uint32_t)log_n;
     pf[pos++] = (uint32_t)width; pf[pos++] = (uint32_t)prm->log_blowup;
     pf[pos++] = (uint32_t)prm->num_queries; pf[pos++] = (uint32_t)prm->pow_bits;
     pf[pos++] = (uint32_t)n_public;
     if (sh.ext || g_air) { pf[pos++] = (uint32_t)Q; pf[pos++] = (uint32_t)sh.K; pf[pos++] = (uint32_t)sh.F; pf[pos++] = (uint32_t)sh.hw; }
     else if (Q) pf[pos++] = (uint32_t)Q;
     if (g_air) { orc_air_digest(g_air, g_air_words, pf + pos); pos += 8; }
+    if (CW) pf[pos++] = (uint32_t)CW;
 
     orc_challenger_t ch;
     transcript_init(&ch, log_n, width, prm, n_public, &sh);
@@ -520,7 +526,18 @@ size_t orc_prove_shard(const uint32_t* trace, int log_n, size_t width,
     uint32_t* tlde = (uint32_t*)malloc(m * width * 4);
     orc_coset_lde(trace, tlde, log_n, width, sh.b, BB_GEN);
     uint32_t* ttree = (uint32_t*)malloc((2 * m - 1) * 32);
-    orc_merkle_tree_hw(tlde, width, H, ttree, sh.hw);
+    uint32_t* ctree = NULL;                            /* code group (columns [0, CW)): its own tree, committed and observed first */
+    if (CW) {
+        uint32_t* part = (uint32_t*)malloc(m * (width - CW > CW ? width - CW : CW) * 4);
+        ctree = (uint32_t*)malloc((2 * m - 1) * 32);
+        for (size_t r = 0; r < m; r++) memcpy(part + r * CW, tlde + r * width, CW * 4);
+        orc_merkle_tree_hw(part, CW, H, ctree, sh.hw);
+        memcpy(pf + pos, ctree + (2 * m - 2) * 8, 32); pos += 8;
+        orc_chal_observe_slice(&ch, ctree + (2 * m - 2) * 8, 8);
+        for (size_t r = 0; r < m; r++) memcpy(part + r * (width - CW), tlde + r * width + CW, (width - CW) * 4);
+        orc_merkle_tree_hw(part, width - CW, H, ttree, sh.hw);          /* data group: the remaining columns */
+        free(part);
+    } else orc_merkle_tree_hw(tlde, width, H, ttree, sh.hw);
     const uint32_t* troot = ttree + (2 * m - 2) * 8;
     memcpy(pf + pos, troot, 32); pos += 8;
     memcpy(g_dbg.trace_root, troot, 32);
@@ -692,6 +709,7 @@ size_t orc_prove_shard(const uint32_t* trace, int log_n, size_t width,
     for (int q = 0; q < prm->num_queries; q++) {
         size_t index = orc_chal_sample_bits(&ch, H);
         memcpy(pf + pos, tlde + index * width, width * 4); pos += width;
+        if (CW) copy_path(pf, &pos, ctree, m, index, H);
         copy_path(pf, &pos, ttree, m, index, H);
         if (Q) { memcpy(pf + pos, plde + index * wp, wp * 4); pos += wp; copy_path(pf, &pos, ptree, m, index, H); }
         memcpy(pf + pos, qlde + index * QW, QW * 4); pos += QW;
@@ -707,6 +725,7 @@ size_t orc_prove_shard(const uint32_t* trace, int log_n, size_t width,
         }
     }
     for (int l = 0; l < R; l++) { free(layers[l]); free(ltrees[l]); }
+    free(ctree);
     free(layers); free(ltrees); free(tlde); free(ttree); free(qlde); free(qtree); free(plde); free(ptree);
     if (!const_ok) return 0;
     return pos * 4 == need ? need : 0;
@@ -738,7 +757,9 @@ int orc_verify_shard(const uint8_t* proof_bytes, size_t len, int log_n, size_t w
     const size_t NQ = (size_t)1 << lqd, QW = 4 * NQ;
     const int H = log_n + sh.b, Hq = log_n + lqd, R = sh.R, K = sh.K, Q = prm->logup_pairs;
     const size_t n = (size_t)1 << log_n, wp = Q ? 4 * ((size_t)Q + 1) : 0, arity = (size_t)1 << K;
-    if (pf[0] != PROOF_MAGIC || pf[1] != (g_air ? 7u : (sh.ext ? 3u : (Q ? 2u : PROOF_VERSION))) || pf[2] != (uint32_t)log_n ||
+    const size_t CW = g_air ? 0 : (size_t)prm->code_width;
+    if (g_air && prm->code_width) return 1;
+    if (pf[0] != PROOF_MAGIC || pf[1] != (g_air ? 7u : (CW ? 8u : (sh.ext ? 3u : (Q ? 2u : PROOF_VERSION)))) || pf[2] != (uint32_t)log_n ||
         pf[3] != (uint32_t)width || pf[4] != (uint32_t)prm->log_blowup ||
         pf[5] != (uint32_t)prm->num_queries || pf[6] != (uint32_t)prm->pow_bits ||
         pf[7] != (uint32_t)n_public) return 3;
@@ -753,10 +774,13 @@ int orc_verify_shard(const uint8_t* proof_bytes, size_t len, int log_n, size_t w
         if (memcmp(dg, pf + pos, 32) != 0) return 3;
         pos += 8;
     }
+    if (CW) { if (pf[pos] != (uint32_t)CW) return 3; pos++; }
     for (size_t i = pos; i < len / 4; i++) if (pf[i] >= BB_P) return 4;   /* canonical words only */
 
     orc_challenger_t ch;
     transcript_init(&ch, log_n, width, prm, n_public, &sh);
+    const uint32_t* croot = NULL;
+    if (CW) { croot = pf + pos; pos += 8; orc_chal_observe_slice(&ch, croot, 8); }
     const uint32_t* troot = pf + pos; pos += 8;
     orc_chal_observe_slice(&ch, troot, 8);
     orc_chal_observe_slice(&ch, public_values, n_public);
@@ -860,12 +884,15 @@ int orc_verify_shard(const uint8_t* proof_bytes, size_t len, int log_n, size_t w
     for (int q = 0; q < prm->num_queries && rc == 0; q++) {
         size_t index = orc_chal_sample_bits(&ch, H);
         const uint32_t* trow = pf + pos; pos += width;
+        const uint32_t* cpath = NULL;
+        if (CW) { cpath = pf + pos; pos += 8 * (size_t)H; }
         const uint32_t* tpath = pf + pos; pos += 8 * (size_t)H;
         const uint32_t *prow = NULL, *ppath = NULL;
         if (Q) { prow = pf + pos; pos += wp; ppath = pf + pos; pos += 8 * (size_t)H; }
         const uint32_t* qrow = pf + pos; pos += QW;
         const uint32_t* qpath = pf + pos; pos += 8 * (size_t)H;
-        if (orc_merkle_verify_hw(troot, H, index, trow, width, tpath, sh.hw)) { rc = 30; break; }
+        if (CW && orc_merkle_verify_hw(croot, H, index, trow, CW, cpath, sh.hw)) { rc = 33; break; }
+        if (orc_merkle_verify_hw(troot, H, index, trow + CW, width - CW, tpath, sh.hw)) { rc = 30; break; }
         if (Q && orc_merkle_verify_hw(proot, H, index, prow, wp, ppath, sh.hw)) { rc = 32; break; }
         if (orc_merkle_verify_hw(qroot, H, index, qrow, QW, qpath, sh.hw)) { rc = 31; break; }
         bb_t x = bb_mul(BB_GEN, bb_pow(wm, bb_reverse_bits((uint32_t)index, H)));

@@ -67,7 +67,10 @@ def main():
     shapes = {}
     for name, (log_n, w, shape) in {"r0_10x16": (10, 16, (2, 50, 0, 0, 4, 2, 24)), "r0_12x32": (12, 32, (2, 50, 0, 0, 4, 8, 24)),
                                     "r0_lookup_10x32": (10, 32, (2, 20, 0, 2, 4, 6, 24)), "blowup4_9x8": (9, 8, (2, 10, 8, 0, 1, 0, 16)),
-                                    "fold8_9x8": (9, 8, (1, 10, 8, 0, 3, 0, 16))}.items():
+                                    "fold8_9x8": (9, 8, (1, 10, 8, 0, 3, 0, 16)),
+                                    # 8th field = code_width: RISC Zero's code / data(/ accum) / check group order (proof version 8)
+                                    "r0_groups_12x32": (12, 32, (2, 50, 0, 0, 4, 8, 24, 8)),
+                                    "r0_groups_lookup_10x32": (10, 32, (2, 20, 0, 2, 4, 6, 24, 12))}.items():
         pairs = shape[3]
         t = O.gen_trace_logup(SEED, 5, log_n, w, pairs) if pairs else O.gen_trace(SEED, 5, log_n, w)
         prm = O.default_params(*shape)
@@ -113,7 +116,8 @@ def main():
     for name, (log_n, w, shape) in {"v1_6x8": (6, 8, (1, 4, 4, 0, 0, 0, 0)), "v1_10x16": (10, 16, (1, 6, 8, 0, 0, 0, 0)),
                                     "v2_lookup_7x16": (7, 16, (1, 3, 4, 1, 0, 0, 0)),
                                     "v3_r0_9x8": (9, 8, (2, 3, 0, 0, 4, 1, 24)), "v3_fold8_9x8": (9, 8, (1, 3, 5, 0, 3, 0, 16)),
-                                    "v3_blowup4_lookup_8x16": (8, 16, (2, 3, 3, 2, 1, 0, 16))}.items():
+                                    "v3_blowup4_lookup_8x16": (8, 16, (2, 3, 3, 2, 1, 0, 16)),
+                                    "v8_groups_r0_lookup_8x16": (8, 16, (2, 3, 0, 1, 4, 0, 24, 4))}.items():
         t = O.gen_trace_logup(SEED, 5, log_n, w, shape[3]) if shape[3] else O.gen_trace(SEED, 5, log_n, w)
         prm = O.default_params(*shape)
         pf = O.prove_shard(t, [1, 2, 3], prm)

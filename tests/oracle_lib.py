@@ -20,7 +20,7 @@ u32p = C.POINTER(C.c_uint32)
 
 class Params(C.Structure):
     _fields_ = [("log_blowup", C.c_int), ("num_queries", C.c_int), ("pow_bits", C.c_int), ("logup_pairs", C.c_int),
-                ("log_fold", C.c_int), ("log_final", C.c_int), ("hash_width", C.c_int)]
+                ("log_fold", C.c_int), ("log_final", C.c_int), ("hash_width", C.c_int), ("code_width", C.c_int)]
 
 
 class ProveDebug(C.Structure):
@@ -265,14 +265,14 @@ def fri_fold_k(vals, log_arity, beta):
     return out
 
 
-def default_params(log_blowup=1, num_queries=100, pow_bits=16, logup_pairs=0, log_fold=0, log_final=0, hash_width=0):
-    return Params(log_blowup, num_queries, pow_bits, logup_pairs, log_fold, log_final, hash_width)
+def default_params(log_blowup=1, num_queries=100, pow_bits=16, logup_pairs=0, log_fold=0, log_final=0, hash_width=0, code_width=0):
+    return Params(log_blowup, num_queries, pow_bits, logup_pairs, log_fold, log_final, hash_width, code_width)
 
 
-def segment_params(num_queries=50, logup_pairs=0, log_final=8):
+def segment_params(num_queries=50, logup_pairs=0, log_final=8, code_width=0):
     """RISC Zero's shape: blowup 4, fold by 16, final polynomial of 2^log_final coefficients,
-    Poseidon2 width 24, no proof of work"""
-    return Params(2, num_queries, 0, logup_pairs, 4, log_final, 24)
+    Poseidon2 width 24, no proof of work; code_width > 0: its code / data(/ accum) / check group order"""
+    return Params(2, num_queries, 0, logup_pairs, 4, log_final, 24, code_width)
 
 
 def gen_trace_logup(seed, shard, log_n, width, pairs):

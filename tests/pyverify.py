@@ -155,9 +155,10 @@ def air_fold(program, loc, nxt, public_values, sel_first, sel_last, sel_trans, a
 
 
 def verify(proof_bytes, log_n, width, public_values, log_blowup=1, num_queries=100, pow_bits=16, logup_pairs=0,
-           log_fold=0, log_final=0, hash_width=0, air=None):
+           log_fold=0, log_final=0, hash_width=0, code_width=0, air=None):
     """raises Reject(reason) or returns True.  Parameter defaults = the SP1 shape.
-    air: a constraint program (u32 words) replacing the built-in synthetic AIR (proof version 7)."""
+    air: a constraint program (u32 words) replacing the built-in synthetic AIR (proof version 7).
+    code_width: RISC Zero's group order -- the first code_width columns and the rest are committed separately (version 8)."""
     if len(proof_bytes) % 4:
         raise Reject("length")
     w = list(struct.unpack("<%dI" % (len(proof_bytes) // 4), bytes(proof_bytes)))
@@ -181,9 +182,12 @@ def verify(proof_bytes, log_n, width, public_values, log_blowup=1, num_queries=1
     hasher = Hash(hw)
 
     # ---- header
-    version = 7 if air is not None else (1 if default_shape and not Q else (2 if default_shape else 3))
+    CW = code_width
+    if CW and (air is not None or CW % 4 or not 0 < CW < width):
+        raise Reject("shape")
+    version = 7 if air is not None else (8 if CW else (1 if default_shape and not Q else (2 if default_shape else 3)))
     head = [MAGIC, version, log_n, width, b, num_queries, pow_bits, len(public_values)]
-    if version in (3, 7):
+    if version in (3, 7, 8):
         head += [Q, K, F, hw]
     elif version == 2:
         head += [Q]
@@ -191,6 +195,8 @@ def verify(proof_bytes, log_n, width, public_values, log_blowup=1, num_queries=1
         if Q:
             raise Reject("a constraint program excludes the built-in lookup argument")
         head += air_digest(air)
+    if CW:
+        head += [CW]
     if w[:len(head)] != head:
         raise Reject("header")
     pos = len(head)
@@ -212,6 +218,10 @@ def verify(proof_bytes, log_n, width, public_values, log_blowup=1, num_queries=1
     # ---- transcript up to zeta
     ts = Transcript()
     ts.observe_many(head[2:])                  # every header word after magic and version
+    code_root = None
+    if CW:                                     # code group first, then data (then accum = permutation, then check = quotient)
+        code_root = take(8)
+        ts.observe_many(code_root)
     trace_root = take(8)
     ts.observe_many(trace_root)
     ts.observe_many(public_values)
@@ -333,8 +343,13 @@ def verify(proof_bytes, log_n, width, public_values, log_blowup=1, num_queries=1
 
     for _ in range(num_queries):
         index = ts.sample_bits(H)
-        trow, tpath = take(width), [take(8) for _ in range(H)]
-        if hasher.root_from_path(trow, index, tpath) != trace_root:
+        trow = take(width)
+        if CW:
+            cpath = [take(8) for _ in range(H)]
+            if hasher.root_from_path(trow[:CW], index, cpath) != code_root:
+                raise Reject("code path")
+        tpath = [take(8) for _ in range(H)]
+        if hasher.root_from_path(trow[CW:], index, tpath) != trace_root:
             raise Reject("trace opening")
         prow = None
         if Q:

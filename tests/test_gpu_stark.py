@@ -187,6 +187,13 @@ SHAPES = [
     (10, 8, (3, 10, 0, 0, 2, 4, 16)),
     (14, 64, (2, 50, 0, 0, 4, 6, 24)),
     (13, 256, (2, 50, 0, 16, 4, 5, 24)),
+    # code / data(/ accum) / check group order (8th field = code_width, proof version 8)
+    (8, 16, (1, 10, 4, 0, 0, 0, 0, 4)),
+    (10, 32, (2, 20, 0, 2, 4, 6, 24, 8)),
+    (12, 64, (2, 50, 0, 0, 4, 8, 24, 16)),
+    (13, 256, (2, 50, 0, 16, 4, 5, 24, 60)),  # data group width 196: the ragged tail of the width-24 sponge
+    (11, 24, (1, 12, 6, 1, 1, 0, 16, 20)),
+    (14, 128, (3, 16, 0, 0, 2, 4, 16, 124)),
 ]
 
 
@@ -211,6 +218,9 @@ def test_shape_that_does_not_divide_is_refused(ctx):
         ctx.prove_shard(trace, 10, 8, [], Params(2, 10, 0, 0, 4, 0, 24))     # (10 - 0) % 4 != 0
     with pytest.raises(ZkHipError):
         ctx.prove_shard(trace, 10, 8, [], Params(2, 10, 0, 0, 4, 2, 20))     # hash width
+    for cw in (8, 6, 12, -4):                                                  # code_width: a multiple of 4 below the width
+        with pytest.raises(ZkHipError):
+            ctx.prove_shard(trace, 10, 8, [], Params(2, 10, 0, 0, 4, 2, 24, cw))
 
 
 @pytest.mark.parametrize("name", sorted(KAT["shape_proofs"]))
@@ -223,17 +233,17 @@ def test_golden_shape_proofs_on_gpu(ctx, name):
     assert hashlib.sha256(proof.tobytes()).hexdigest() == g["sha256"]
 
 
-@pytest.mark.parametrize("log_n,width", [(8, 8), (12, 32), (14, 40)])
-def test_prove_segment_from_column_major_equals_oracle(ctx, oracle, log_n, width):
+@pytest.mark.parametrize("log_n,width,cw", [(8, 8, 0), (12, 32, 0), (14, 40, 0), (12, 32, 8), (14, 40, 12)])
+def test_prove_segment_from_column_major_equals_oracle(ctx, oracle, log_n, width, cw):
     # RISC Zero's Hal layout: `width` contiguous columns; RISC-Zero-like shape; bytes equal the oracle's proof of the same trace
     from zktls_amd._lib import segment_params
     t = oracle.gen_trace(SEED, 9, log_n, width)
     cols = ctx.from_numpy(np.ascontiguousarray(t.T))
     lf = {8: 4, 12: 8, 14: 6}[log_n]
-    proof = ctx.prove_segment(cols, log_n, width, [5], segment_params(50, 0, lf))
-    oproof = oracle.prove_shard(t, [5], oracle.segment_params(50, 0, lf))
+    proof = ctx.prove_segment(cols, log_n, width, [5], segment_params(50, 0, lf, cw))      # cw: code / data group commitments
+    oproof = oracle.prove_shard(t, [5], oracle.segment_params(50, 0, lf, cw))
     assert proof.tobytes() == oproof.tobytes()
-    assert verify_shard(proof, log_n, width, [5], segment_params(50, 0, lf)) == (0, 0)
+    assert verify_shard(proof, log_n, width, [5], segment_params(50, 0, lf, cw)) == (0, 0)
 
 
 def test_concurrent_contexts_give_the_same_proofs(ctx, oracle):

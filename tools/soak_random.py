@@ -33,7 +33,8 @@ while time.time() - t0 < budget:
         fs = [f for f in range(0, min(log_n, 9) + 1) if (log_n - f) % K == 0]
         if not fs: continue
         F = int(rng.choice(fs)); hw = int(rng.choice([16, 24])); pairs = int(rng.integers(0, width // 8 + 1)) if rng.random() < 0.4 else 0
-        shape = (b, int(rng.integers(1, 15)), int(rng.integers(0, 8)), pairs, K, F, hw)
+        cw = 4 * int(rng.integers(1, width // 4)) if width > 4 and rng.random() < 0.35 else 0     # code / data group split
+        shape = (b, int(rng.integers(1, 15)), int(rng.integers(0, 8)), pairs, K, F, hw, cw)
         shard = int(rng.integers(0, 1000)); pub = [int(x) for x in rng.integers(0, 2013265921, int(rng.integers(0, 5)))]
         d = ctx.gen_trace_logup(SEED, shard, log_n, width, pairs) if pairs else ctx.gen_trace(SEED, shard, log_n, width)
         h = O.gen_trace_logup(SEED, shard, log_n, width, pairs) if pairs else O.gen_trace(SEED, shard, log_n, width)

@@ -42,13 +42,13 @@ class ZkHipError(RuntimeError):
 
 class Params(C.Structure):
     _fields_ = [("log_blowup", C.c_int32), ("num_queries", C.c_int32), ("pow_bits", C.c_int32), ("logup_pairs", C.c_int32),
-                ("log_fold", C.c_int32), ("log_final", C.c_int32), ("hash_width", C.c_int32)]
+                ("log_fold", C.c_int32), ("log_final", C.c_int32), ("hash_width", C.c_int32), ("code_width", C.c_int32)]
 
 
-def segment_params(num_queries=50, logup_pairs=0, log_final=8):
+def segment_params(num_queries=50, logup_pairs=0, log_final=8, code_width=0):
     """RISC-Zero-like shape (include/zkhip.h): blowup 4, fold by 16, 2^log_final final coefficients,
-    Poseidon2 width 24, no proof of work."""
-    return Params(2, num_queries, 0, logup_pairs, 4, log_final, 24)
+    Poseidon2 width 24, no proof of work; code_width > 0: code / data(/ accum) group commitments."""
+    return Params(2, num_queries, 0, logup_pairs, 4, log_final, 24, code_width)
 
 
 class Chip(C.Structure):

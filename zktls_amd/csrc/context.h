@@ -65,7 +65,7 @@ struct DeviceBuffer {
 enum Slot {
     S_COEF = 0,        // coefficients of the matrix being extended (op_coset_lde)
     S_TMP,             // bounce buffer of a transform / injected digests of a mixed-height commitment
-    S_TLDE, S_TTREE,   // trace LDE + tree
+    S_TLDE, S_TTREE,   // trace LDE + tree (the data group's tree when the code / data split is on)
     S_QCHUNK, S_QLDE, S_QTREE,
     S_DINV, S_PARTIAL, S_OPEN_OUT,
     S_APOW_Q, S_APOW_F,
@@ -77,6 +77,7 @@ enum Slot {
     S_STAGE,           // staged copy of a host / column-major trace (zkhip_prove_shard_host, zkhip_prove_segment)
     S_RO,
     S_EXTRA_A, S_EXTRA_B,   // large-transform (2^21, 2^22 rows) bounce buffers
+    S_CTREE,           // tree of the code group (zkhip_params.code_width)
     S_COUNT
 };
 

@@ -51,13 +51,15 @@ struct Challenger {
 };
 
 // shape parameters with their defaults resolved (0 = the SP1 shape)
-struct Shape { int b = 1, K = 1, F = 0, hw = 16, R = 0; bool ext = false; };
+struct Shape { int b = 1, K = 1, F = 0, hw = 16, R = 0; bool ext = false; uint32_t cw = 0; };
 static bool shape_of(int log_n, const zkhip_params* prm, Shape& sh) {
     sh.b = prm->log_blowup;
     sh.K = prm->log_fold ? prm->log_fold : 1;
     sh.F = prm->log_final;
     sh.hw = prm->hash_width ? prm->hash_width : 16;
-    sh.ext = !(sh.b == 1 && sh.K == 1 && sh.F == 0 && sh.hw == 16);
+    sh.cw = (uint32_t)prm->code_width;           // code / data group split (callers check it against the width)
+    sh.ext = !(sh.b == 1 && sh.K == 1 && sh.F == 0 && sh.hw == 16) || sh.cw != 0;
+    if (prm->code_width < 0 || prm->code_width % 4 != 0) return false;
     if (sh.b < 1 || sh.b > 3 || sh.K < 1 || sh.K > 5 || sh.F < 0 || sh.F > 10 || sh.F > log_n || (log_n - sh.F) % sh.K != 0) return false;
     if (sh.hw != 16 && sh.hw != 24) return false;
     sh.R = (log_n - sh.F) / sh.K;
@@ -90,6 +92,7 @@ static void transcript_init(Challenger& ch, int log_n, uint32_t width, const zkh
         ch.observe_canonical((uint32_t)sh.F);
         ch.observe_canonical((uint32_t)sh.hw);
     } else if (prm->logup_pairs) ch.observe_canonical((uint32_t)prm->logup_pairs);
+    if (sh.cw) ch.observe_canonical(sh.cw);
 }
 
 constexpr uint32_t PROOF_MAGIC = 0x41544B5Au;   // "ZKTA"
@@ -383,8 +386,9 @@ static size_t proof_words(int log_n, uint32_t width, const zkhip_params* prm, bo
     const size_t H = (size_t)(log_n + sh.b);
     const size_t Q = (size_t)prm->logup_pairs, wp = Q ? 4 * (Q + 1) : 0;
     const size_t QW = (size_t)4 << lqd;          // width of the quotient matrix: 4 base columns per chunk
-    size_t words = (air ? 20 : (sh.ext ? 12 : (Q ? 9 : 8))) + 16 + 8 * (size_t)width + 4 * QW + 8 * (size_t)sh.R + 4 * ((size_t)1 << sh.F) + 1;
-    size_t perq = width + QW + 16 * H;
+    const size_t CW = air ? 0 : sh.cw;          // code / data split: one more header word, root, and path per query
+    size_t words = (air ? 20 : (sh.ext ? 12 : (Q ? 9 : 8))) + (CW ? 9 : 0) + 16 + 8 * (size_t)width + 4 * QW + 8 * (size_t)sh.R + 4 * ((size_t)1 << sh.F) + 1;
+    size_t perq = width + QW + 16 * H + (CW ? 8 * H : 0);
     if (Q) { words += 8 + 8 * wp; perq += wp + 8 * H; }
     for (int l = 0; l < sh.R; l++) perq += 4 * (((size_t)1 << sh.K) - 1) + 8 * (H - (size_t)sh.K * (l + 1));
     return words + (size_t)prm->num_queries * perq;
@@ -401,6 +405,7 @@ static int check_shape(int log_n, uint32_t width, const zkhip_params* prm) {
     if (prm->pow_bits < 0 || prm->pow_bits > 28) return fail(ZKHIP_ERR_INVALID, "pow_bits out of range");
     if (prm->logup_pairs < 0 || prm->logup_pairs > 64 || (uint32_t)prm->logup_pairs * 8 > width)
         return fail(ZKHIP_ERR_INVALID, "logup_pairs out of range (each pair needs two column groups, at most 64 pairs)");
+    if (prm->code_width && (uint32_t)prm->code_width >= width) return fail(ZKHIP_ERR_INVALID, "code_width must be a multiple of 4 below the width");
     return ZKHIP_OK;
 }
 
@@ -440,7 +445,7 @@ extern "C" {
 int zkhip_quotient_values(zkhip_ctx* ctx, const uint32_t* d_lde, size_t ld, int log_n, uint32_t width,
                           const uint32_t alpha[4], uint32_t* d_out) {
     CHECK_CTX(ctx);
-    zkhip_params prm{1, 1, 0, 0, 0, 0, 0};
+    zkhip_params prm{1, 1, 0, 0, 0, 0, 0, 0};
     ZK_TRY(check_shape(log_n, width, &prm));
     if (!d_lde || !d_out || !alpha || ld < width) return fail(ZKHIP_ERR_INVALID, "quotient_values: bad arguments");
     // kernel writes natural-order chunks; this entry point returns the bit-reversed
@@ -580,6 +585,7 @@ static int prove_shard_impl(zkhip_ctx* ctx, const uint32_t* d_trace, size_t ld, 
     if (!d_trace || !proof || !len || ld < width || (n_public && !public_values)) return fail(ZKHIP_ERR_INVALID, "prove_shard: bad arguments");
     for (size_t i = 0; i < n_public; i++) if (public_values[i] >= P) return fail(ZKHIP_ERR_INVALID, "prove_shard: public values must be canonical");
     if (air && prm->logup_pairs) return fail(ZKHIP_ERR_INVALID, "prove_shard_air: a constraint program excludes the built-in lookup argument (logup_pairs must be 0)");
+    if (air && prm->code_width) return fail(ZKHIP_ERR_INVALID, "prove_shard_air: the code / data group split belongs to the built-in prover (code_width must be 0)");
     const int lqd = air ? air->lqd : 1;                      // log2 of the number of quotient chunks
     if (lqd > prm->log_blowup) return fail(ZKHIP_ERR_INVALID, "prove_shard_air: constraints of degree 4 or 5 need log_blowup >= 2 (the quotient domain must lie inside the committed LDE domain)");
     const size_t NQ = (size_t)1 << lqd, QW = 4 * NQ;
@@ -598,11 +604,13 @@ static int prove_shard_impl(zkhip_ctx* ctx, const uint32_t* d_trace, size_t ld, 
     size_t pos = 0;
     const uint32_t LQ = (uint32_t)prm->logup_pairs;          // LogUp pairs (0 = none)
     const size_t wp = LQ ? 4 * ((size_t)LQ + 1) : 0;         // permutation-trace width in words
-    pf[pos++] = PROOF_MAGIC; pf[pos++] = air ? 7u : (sh.ext ? 3u : (LQ ? 2u : PROOF_VERSION)); pf[pos++] = (uint32_t)log_n; pf[pos++] = width;
+    const uint32_t CW = sh.cw;
+    pf[pos++] = PROOF_MAGIC; pf[pos++] = air ? 7u : (CW ? 8u : (sh.ext ? 3u : (LQ ? 2u : PROOF_VERSION))); pf[pos++] = (uint32_t)log_n; pf[pos++] = width;
     pf[pos++] = (uint32_t)prm->log_blowup; pf[pos++] = (uint32_t)Q; pf[pos++] = (uint32_t)prm->pow_bits; pf[pos++] = (uint32_t)n_public;
     if (sh.ext || air) { pf[pos++] = LQ; pf[pos++] = (uint32_t)sh.K; pf[pos++] = (uint32_t)sh.F; pf[pos++] = (uint32_t)sh.hw; }
     else if (LQ) pf[pos++] = LQ;
     if (air) { air_digest(*air, pf + pos); pos += 8; }
+    if (CW) pf[pos++] = CW;
 
     Challenger ch;
     transcript_init(ch, log_n, width, prm, n_public, sh, air);
@@ -614,7 +622,18 @@ static int prove_shard_impl(zkhip_ctx* ctx, const uint32_t* d_trace, size_t ld, 
     ZK_TRY(ctx_reserve(ctx, S_TTREE, (2 * m - 1) * 32, &v_ttree));
     uint32_t* tlde = (uint32_t*)v_tlde; uint32_t* ttree = (uint32_t*)v_ttree;
     ZK_TRY(op_coset_lde(ctx, d_trace, ld, tlde, width, log_n, width, sh.b, MONTY_GEN));
-    ZK_TRY(commit_hw(ctx, tlde, width, width, H, ttree, sh.hw));
+    uint32_t* ctree = nullptr;
+    if (CW) {
+        // RISC Zero's group order: the code columns [0, CW) and the data columns [CW, width) of the SAME row-major LDE get a tree
+        // each (a leaf hashes a column range of a row: row pitch `width`, no copy); the code root is committed and observed first
+        void* v_ctree;
+        ZK_TRY(ctx_reserve(ctx, S_CTREE, (2 * m - 1) * 32, &v_ctree));
+        ctree = (uint32_t*)v_ctree;
+        ZK_TRY(commit_hw(ctx, tlde, width, CW, H, ctree, sh.hw));
+        ZK_TRY(d2h(ctx, root, ctree + (2 * m - 2) * 8, 32));
+        for (int i = 0; i < 8; i++) { ch.observe(root[i]); pf[pos++] = from_monty(root[i]); }
+        ZK_TRY(commit_hw(ctx, tlde + CW, width, width - CW, H, ttree, sh.hw));
+    } else ZK_TRY(commit_hw(ctx, tlde, width, width, H, ttree, sh.hw));
     ZK_TRY(d2h(ctx, root, ttree + (2 * m - 2) * 8, 32));
     for (int i = 0; i < 8; i++) { ch.observe(root[i]); pf[pos++] = ctx->debug.trace_root[i] = from_monty(root[i]); }
     for (size_t i = 0; i < n_public; i++) ch.observe_canonical(public_values[i]);
@@ -767,7 +786,7 @@ static int prove_shard_impl(zkhip_ctx* ctx, const uint32_t* d_trace, size_t ld, 
     // ---- 7. queries: one gather launch over (row, path, sibling) descriptors
     {
         std::vector<GatherDesc> descs;
-        descs.reserve((size_t)Q * (4 + 3 * H + (size_t)RL * (H + arity)));
+        descs.reserve((size_t)Q * (4 + 4 * H + (size_t)RL * (H + arity)));
         size_t qpos = 0;   // word offset inside the query section
         auto push = [&](const uint32_t* src, size_t nwords) { descs.push_back(GatherDesc{src, (uint32_t)qpos, (uint32_t)nwords}); qpos += nwords; };
         auto push_path = [&](const uint32_t* tree, size_t leaves, size_t index, int levels) {
@@ -777,6 +796,7 @@ static int prove_shard_impl(zkhip_ctx* ctx, const uint32_t* d_trace, size_t ld, 
         for (int q = 0; q < Q; q++) {
             const size_t index = ch.sample_bits(H);
             push(tlde + index * width, width);
+            if (CW) push_path(ctree, m, index, H);
             push_path(ttree, m, index, H);
             if (LQ) { push(plde + index * wp, wp); push_path(ptree, m, index, H); }
             push(qlde + index * QW, QW);
@@ -868,7 +888,7 @@ int zkhip_prove_shard_air(zkhip_ctx* ctx, const uint32_t* program, size_t progra
 int zkhip_quotient_values_air(zkhip_ctx* ctx, const uint32_t* program, size_t program_words, const uint32_t* d_lde, size_t ld, int log_n,
                               uint32_t width, const uint32_t* public_values, size_t n_public, const uint32_t alpha[4], uint32_t* d_out) {
     CHECK_CTX(ctx);
-    zkhip_params prm{1, 1, 0, 0, 0, 0, 0};
+    zkhip_params prm{1, 1, 0, 0, 0, 0, 0, 0};
     ZK_TRY(check_shape(log_n, width, &prm));
     AirView a;
     if (!d_lde || !d_out || !alpha || ld < width || (n_public && !public_values) || !air_validate(program, program_words, width, n_public, &a))
@@ -1145,7 +1165,9 @@ static int verify_shard_impl(const uint8_t* proof, size_t len, int log_n, uint32
     const size_t n = (size_t)1 << log_n, arity = (size_t)1 << K;
     const uint32_t LQ = (uint32_t)prm->logup_pairs;
     const size_t wp = LQ ? 4 * ((size_t)LQ + 1) : 0;
-    if (pf[0] != PROOF_MAGIC || pf[1] != (air ? 7u : (sh.ext ? 3u : (LQ ? 2u : PROOF_VERSION))) || pf[2] != (uint32_t)log_n || pf[3] != width ||
+    const uint32_t CW = sh.cw;
+    if (air && CW) return reject(1);
+    if (pf[0] != PROOF_MAGIC || pf[1] != (air ? 7u : (CW ? 8u : (sh.ext ? 3u : (LQ ? 2u : PROOF_VERSION)))) || pf[2] != (uint32_t)log_n || pf[3] != width ||
         pf[4] != (uint32_t)prm->log_blowup || pf[5] != (uint32_t)prm->num_queries || pf[6] != (uint32_t)prm->pow_bits ||
         pf[7] != (uint32_t)n_public) return reject(3);
     size_t pos = 8;
@@ -1159,11 +1181,13 @@ static int verify_shard_impl(const uint8_t* proof, size_t len, int log_n, uint32
         for (int i = 0; i < 8; i++) if (pf[pos + i] != dg[i]) return reject(3);
         pos += 8;
     }
+    if (CW) { if (pf[pos] != CW) return reject(3); pos++; }
     for (size_t i = pos; i < len / 4; i++) if (pf[i] >= P) return reject(4);
     for (size_t i = 0; i < n_public; i++) if (public_values[i] >= P) return reject(4);
     Challenger ch;
     transcript_init(ch, log_n, width, prm, n_public, sh, air);
-    uint32_t troot[8], proot[8], qroot[8];
+    uint32_t croot[8], troot[8], proot[8], qroot[8];
+    if (CW) for (int i = 0; i < 8; i++) { croot[i] = to_monty(pf[pos++]); ch.observe(croot[i]); }
     for (int i = 0; i < 8; i++) { troot[i] = to_monty(pf[pos++]); }
     for (int i = 0; i < 8; i++) ch.observe(troot[i]);
     for (size_t i = 0; i < n_public; i++) ch.observe_canonical(public_values[i]);
@@ -1288,12 +1312,15 @@ static int verify_shard_impl(const uint8_t* proof, size_t len, int log_n, uint32
     for (int q = 0; q < prm->num_queries; q++) {
         const size_t index = ch.sample_bits(H);
         const uint32_t* trow = pf + pos; pos += width;
+        const uint32_t* cpath = nullptr;
+        if (CW) { cpath = pf + pos; pos += 8 * (size_t)H; }
         const uint32_t* tpath = pf + pos; pos += 8 * (size_t)H;
         const uint32_t *prow = nullptr, *ppath = nullptr;
         if (LQ) { prow = pf + pos; pos += wp; ppath = pf + pos; pos += 8 * (size_t)H; }
         const uint32_t* qrow = pf + pos; pos += QW;
         const uint32_t* qpath = pf + pos; pos += 8 * (size_t)H;
-        if (!verify_path(troot, H, index, trow, width, tpath, sh.hw)) return reject(30);
+        if (CW && !verify_path(croot, H, index, trow, CW, cpath, sh.hw)) return reject(33);
+        if (!verify_path(troot, H, index, trow + CW, width - CW, tpath, sh.hw)) return reject(30);
         if (LQ && !verify_path(proot, H, index, prow, wp, ppath, sh.hw)) return reject(32);
         if (!verify_path(qroot, H, index, qrow, QW, qpath, sh.hw)) return reject(31);
         const uint32_t x = fmul(MONTY_GEN, fpow(wm, reverse_bits((uint32_t)index, H)));
@@ -1371,7 +1398,7 @@ static int check_chips(const int32_t* log_ns, const uint32_t* widths, const int3
     if (!prm || !log_ns || !widths) return fail(ZKHIP_ERR_INVALID, "chips: null argument");
     if (n < 1 || n > MAX_CHIPS) return fail(ZKHIP_ERR_INVALID, "chips: 1..16 chips");
     if (prm->log_blowup < 1 || prm->log_blowup > 3) return fail(ZKHIP_ERR_INVALID, "chips: log_blowup in [1,3]");
-    if ((prm->log_fold != 0 && prm->log_fold != 1) || prm->log_final != 0 || (prm->hash_width != 0 && prm->hash_width != 16) || prm->logup_pairs != 0)
+    if ((prm->log_fold != 0 && prm->log_fold != 1) || prm->log_final != 0 || (prm->hash_width != 0 && prm->hash_width != 16) || prm->logup_pairs != 0 || prm->code_width != 0)
         return fail(ZKHIP_ERR_INVALID, "chips: the multi-chip prover uses the SP1 FRI shape (fold by 2, constant final polynomial, width-16 hash) without lookups");
     if (prm->num_queries < 1 || prm->num_queries > 4096 || prm->pow_bits < 0 || prm->pow_bits > 28) return fail(ZKHIP_ERR_INVALID, "chips: queries / pow_bits out of range");
     for (int c = 0; c < n; c++) {

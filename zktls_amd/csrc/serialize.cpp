@@ -39,6 +39,7 @@ struct Layout {
 };
 bool layout_of(int log_n, uint32_t width, const zkhip_params* prm, Layout& L) {
     if (!prm || log_n < 5 || log_n > MAX_LOG_ROWS || width == 0 || width % 4 != 0 || width > 1024) return false;
+    if (prm->code_width) return false;           // proof versions 1-3 only (one trace commitment)
     L.log_n = log_n; L.width = width;
     L.b = prm->log_blowup; L.K = prm->log_fold ? prm->log_fold : 1; L.F = prm->log_final; L.hw = prm->hash_width ? prm->hash_width : 16;
     if (L.b < 1 || L.b > 3 || L.K < 1 || L.K > 5 || L.F < 0 || L.F > 10 || L.F > log_n || (log_n - L.F) % L.K != 0) return false;

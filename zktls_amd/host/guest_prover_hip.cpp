@@ -144,13 +144,13 @@ ProveResult HipGuestProver::prove_inner(const GuestInput& input, const std::vect
                                  "with_synthetic(plan) opts into proving synthetic shards (the blob is then flagged SYNTHETIC)");
     if (plan_.shards == 0) throw std::runtime_error("shard plan is empty");
     if (devices_.empty()) throw std::runtime_error("device list is empty");
-    zkhip_params prm{1, plan_.num_queries, plan_.pow_bits, 0, 0, 0, 0};
+    zkhip_params prm{1, plan_.num_queries, plan_.pow_bits, 0, 0, 0, 0, 0};
     if (backend_ == Backend::Risc0) {
         // RISC Zero's shape; the final polynomial shrinks for segments too small for 256 coefficients
         int lf = 8;
         while (lf > plan_.log_n || (plan_.log_n - lf) % 4 != 0) lf--;
         const bool defaults = plan_.num_queries == 100 && plan_.pow_bits == 16;
-        prm = zkhip_params{2, defaults ? 50 : plan_.num_queries, defaults ? 0 : plan_.pow_bits, 0, 4, lf, 24};
+        prm = zkhip_params{2, defaults ? 50 : plan_.num_queries, defaults ? 0 : plan_.pow_bits, 0, 4, lf, 24, 0};
     }
     const size_t cap = zkhip_proof_size(plan_.log_n, plan_.width, &prm, 9);
     if (cap == 0) throw std::runtime_error(std::string("bad shard plan: ") + zkhip_last_error());
