@@ -319,7 +319,10 @@ def main():
         def gbs(ms):
             return round(alg_bytes / ms / 1e6, 1)
         roof = {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_src,
+                "frac": round(achieved / HBM_PEAK_GBS, 4),
+                # also against the measured float4-copy ceiling of this part (MI355X_MICROARCH.md: 6.29 TB/s)
+                "frac_of_measured_copy_ceiling": round(achieved / 6290.0, 4),
+                "traffic": traffic, "traffic_source": traffic_src,
                 "kernel": "zk::ntt_pass_kernel, mean over the six launches of one 2^%d x %d trace LDE on the proving context's own workspaces (in-proof placement, nothing selected)" % (log_n, width),
                 "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_ms": round(avg_ms, 4),
                 "kernels": {names[w]: {"ms": round(in_proof[w], 4), "GB/s": gbs(in_proof[w]), "frac": round(gbs(in_proof[w]) / HBM_PEAK_GBS, 4)} for w in (2, 3, 4, 5)},
