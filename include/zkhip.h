@@ -352,6 +352,30 @@ int zkhip_verify_shard_air(const uint32_t* program, size_t program_words, const 
 int zkhip_quotient_values_air(zkhip_ctx* ctx, const uint32_t* program, size_t program_words, const uint32_t* d_lde, size_t ld, int log_n,
                               uint32_t width, const uint32_t* public_values, size_t n_public, const uint32_t alpha[4], uint32_t* d_out);
 
+/* ---- a real chip on the constraint-program path: SHA-256 compression (the hash of the TLS transcripts the reference's guest checks;
+ * upstream SP1 proves it through the ShaExtend / ShaCompress chips of sp1-core-machine 4.1.4, reference Cargo.lock:5822, behind
+ * crates/guest-prover-sp1/src/sp1.rs:116).  One row per round, 64 rows per 64-byte block, 608 columns, degree 3, 16 public values =
+ * the digest as 16-bit limbs (low limb of word 0 first).  A proof says "I know a message of at most 2^(log_n - 6) blocks, padding
+ * included, with this SHA-256 digest"; blocks after the message are inactive rows that pass the chaining value through.
+ * Column layout and constraints: csrc/sha256_chip.hip. ---- */
+#define ZKHIP_SHA256_WIDTH 608
+#define ZKHIP_SHA256_PUBLIC 16
+/* the constraint program (a zkhip_prove_shard_air program): returns its length in words; written when cap_words suffices */
+size_t zkhip_sha256_air(uint32_t* program, size_t cap_words);
+/* FIPS 180-4 padding: returns the padded length (a multiple of 64); written when cap suffices.  Host only. */
+size_t zkhip_sha256_pad(const uint8_t* message, size_t len, uint8_t* blocks, size_t cap);
+/* trace generation on the device: blocks = n_active padded 64-byte blocks (host memory), n_blocks = a power of two >= n_active;
+ * d_trace [64 n_blocks][ld >= 608] Montgomery; digest_limbs (host) = the public values */
+int zkhip_sha256_gen_trace(zkhip_ctx* ctx, const uint8_t* blocks, size_t n_active, size_t n_blocks, uint32_t* d_trace, size_t ld,
+                           uint32_t digest_limbs[16]);
+/* message in, digest (32 bytes, as SHA-256 prints it) and proof out: pad, generate the trace on the device, zkhip_prove_shard_air.
+ * zkhip_params: any shape zkhip_prove_shard_air takes (logup_pairs = code_width = 0). */
+size_t zkhip_sha256_proof_size(size_t message_len, const zkhip_params* prm);
+int zkhip_prove_sha256(zkhip_ctx* ctx, const uint8_t* message, size_t message_len, const zkhip_params* prm, uint8_t digest[32],
+                       uint8_t* proof, size_t cap, size_t* len);
+/* host-side verifier: the block bound 2^(log_n - 6) is read from the proof header (and bound by the proof's transcript) */
+int zkhip_verify_sha256(const uint8_t* proof, size_t len, const uint8_t digest[32], const zkhip_params* prm, int* reason);
+
 /* ---- a shard made of several chips (AIR tables) of different heights, as an SP1 shard is (sp1-stark 4.1.4 ShardProof,
  * reference Cargo.lock:6172, behind crates/guest-prover-sp1/src/sp1.rs:116): one Merkle commitment per phase over all
  * chips (shorter matrices injected at their level), one opening point, one reduced-opening vector per height joining the

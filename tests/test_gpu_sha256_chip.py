@@ -1,0 +1,60 @@
+"""The SHA-256 compression chip on the GPU: on-device trace generation against the test-side restatement (cell for cell), digests
+against hashlib, proof bytes against the oracle's generic constraint-program prover on the same trace, the product's and the
+oracle's verifiers, and the independent pure-Python verifier."""
+import hashlib
+
+import numpy as np
+import pytest
+
+import pyverify
+import sha256_air as S
+from zktls_amd._lib import Params, ZkHipError
+from zktls_amd.device import sha256_air, verify_sha256
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("n,total", [(0, None), (3, None), (56, None), (150, None), (500, None), (3, 4), (700, 16)])
+def test_device_trace_equals_the_restatement(ctx, n, total):
+    msg = bytes((11 * i + 3) & 0xff for i in range(n))
+    t, pub = S.trace(S.pad(msg), total)
+    d, limbs = ctx.sha256_gen_trace(S.pad(msg), total)
+    got = d.download().reshape(-1, S.WIDTH)
+    assert got.shape == t.shape and (got == t).all()
+    assert limbs.tolist() == pub and S.digest_bytes(limbs.tolist()) == hashlib.sha256(msg).digest()
+
+
+# (log_blowup, queries, pow_bits, logup_pairs, log_fold, log_final, hash_width)
+@pytest.mark.parametrize("n,shape", [(3, (1, 10, 4)), (150, (1, 8, 0)), (150, (2, 6, 0, 0, 2, 2, 24)), (1000, (2, 5, 3, 0, 4, 2, 24))])
+def test_prove_sha256_bytes_equal_the_oracles(ctx, oracle, n, shape):
+    O = oracle
+    msg = bytes((5 * i + 9) & 0xff for i in range(n))
+    digest, proof = ctx.prove_sha256(msg, Params(*shape))
+    assert digest == hashlib.sha256(msg).digest()
+    prog = S.program()
+    t, pub = S.trace(S.pad(msg))
+    log_n = t.shape[0].bit_length() - 1
+    oproof = O.prove_shard_air(prog, t, pub, O.default_params(*shape))
+    assert proof.tobytes() == oproof.tobytes()
+    assert verify_sha256(proof, digest, Params(*shape)) == (0, 0)
+    assert O.verify_shard_air(prog, proof, log_n, S.WIDTH, pub, O.default_params(*shape)) == 0
+    if n <= 150:
+        assert pyverify.verify(proof.tobytes(), log_n, S.WIDTH, pub, *shape, air=sha256_air()) is True
+    wrong = bytearray(digest)
+    wrong[31] ^= 0x80
+    assert verify_sha256(proof, bytes(wrong), Params(*shape))[0] == -6
+
+
+def test_a_megabyte_transcript(ctx):
+    """1 MiB - 9 bytes: 2^14 blocks, 2^20 rows x 608 columns (2.4 GiB trace, 4.9 GiB LDE): digest against hashlib, proof verified"""
+    msg = np.random.default_rng(7).integers(0, 256, (1 << 20) - 9, dtype=np.uint8).tobytes()
+    digest, proof = ctx.prove_sha256(msg, Params(1, 100, 16))
+    assert digest == hashlib.sha256(msg).digest()
+    assert verify_sha256(proof, digest, Params(1, 100, 16)) == (0, 0)
+
+
+def test_misuse_fails_loudly(ctx):
+    with pytest.raises(ZkHipError):
+        ctx.prove_sha256(b"abc", Params(1, 10, 4, 1))            # no lookup argument with a constraint program
+    with pytest.raises(ZkHipError):
+        ctx.sha256_gen_trace(S.pad(b"abc"), 3)                    # block count must be a power of two

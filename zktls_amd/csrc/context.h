@@ -78,6 +78,7 @@ enum Slot {
     S_RO,
     S_EXTRA_A, S_EXTRA_B,   // large-transform (2^21, 2^22 rows) bounce buffers
     S_CTREE,           // tree of the code group (zkhip_params.code_width)
+    S_CHIP,            // trace of a built-in chip (sha256_chip.hip)
     S_COUNT
 };
 

@@ -1,0 +1,452 @@
+// sha256_chip.hip -- a real chip AIR on the constraint-program path: SHA-256 compression, the hash of the
+// TLS transcripts the reference's guest program checks (the guest ELF itself is not in /root/reference; upstream, SP1 proves
+// SHA-256 through its ShaExtend / ShaCompress precompile chips: sp1-core-machine 4.1.4, reference Cargo.lock:5822, behind
+// crates/guest-prover-sp1/src/sp1.rs:116).  This is not SP1's chip pair (those exchange memory through lookups with the CPU chip);
+// it is a self-contained AIR for the same function, written out as a constraint program (air.h) plus its on-device trace
+// generator, proven and verified by zkhip_prove_shard_air / zkhip_verify_shard_air like any other program.
+//
+// One row per round, 64 rows per 64-byte block, blocks one after the other; 608 columns, every constraint of degree <= 3.
+// A proof says: "I know at most 2^k blocks whose SHA-256 chaining value, from the standard IV, is the 16 public 16-bit limbs"
+// -- with FIPS 180-4 padding inside the blocks, the SHA-256 digest of a message.  Blocks after the message are INACTIVE and
+// pass the chaining value through (the trace height is a power of two, a block count is not).
+//
+// Columns (bit i of a word = base + i, least significant first; a limb pair = low 16 bits, high 16 bits):
+//   SEL 64 one-hot round selector | A B C E F G 32 bits each (working variables before the round) | D HV limb pairs (d, h)
+//   S1 CH S0 MJ 32 bits each (Sigma1(e), Ch, Sigma0(a), Maj) | HC 8 limb pairs (chaining value of the block)
+//   OUT 8 limb pairs (variables after the round, + chaining value in round 63, mod 2^32) | X0 X13 32 bits (W_t, W_{t+13})
+//   XL 14 limb pairs (W_{t+j}, j = 1..12, 14, 15) | SG0 SG1 32 bits (sigma0(W_t), sigma1(W_{t+13})) | CY 28 carry bits
+//   ACT (block belongs to the message) | SKIP = s_63 (1 - ACT) | 2 unused
+#include <cstring>
+#include <vector>
+
+#include "air.h"
+#include "context.h"
+
+namespace zk {
+namespace sha {
+
+constexpr uint32_t SEL = 0, A = 64, B = 96, C = 128, E = 160, F = 192, G = 224, D = 256, HV = 258;
+constexpr uint32_t S1 = 260, CH = 292, S0 = 324, MJ = 356, HC = 388, OUT = 404, X0 = 420, X13 = 452, XL = 484;
+constexpr uint32_t SG0 = 512, SG1 = 544, CY = 576, ACT = 604, SKIP = 605, WIDTH = 608, N_PUBLIC = 16;
+constexpr uint32_t CY_A = CY, CY_E = CY + 6, CY_W6 = CY + 12, CY_SCHED = CY + 24;
+
+constexpr uint32_t IV[8] = {0x6a09e667u, 0xbb67ae85u, 0x3c6ef372u, 0xa54ff53au, 0x510e527fu, 0x9b05688cu, 0x1f83d9abu, 0x5be0cd19u};
+
+// K_t = first 32 bits of the fractional part of the cube root of the t-th prime (FIPS 180-4, 4.2.2), from integers
+struct RoundConstants {
+    uint32_t k[64];
+    RoundConstants() {
+        int found = 0;
+        for (uint32_t n = 2; found < 64; n++) {
+            bool prime = true;
+            for (uint32_t q = 2; q * q <= n; q++) if (n % q == 0) { prime = false; break; }
+            if (!prime) continue;
+            unsigned __int128 lo = 0, hi = (unsigned __int128)1 << 40;           // floor(cbrt(n) 2^32) by bisection
+            while (hi - lo > 1) {
+                const unsigned __int128 mid = (lo + hi) / 2;
+                if (mid * mid * mid <= ((unsigned __int128)n << 96)) lo = mid; else hi = mid;
+            }
+            k[found++] = (uint32_t)lo;
+        }
+    }
+};
+static const RoundConstants& round_constants() { static const RoundConstants rc; return rc; }
+
+__host__ __device__ inline uint32_t rotr(uint32_t x, int r) { return (x >> r) | (x << (32 - r)); }
+__host__ __device__ inline uint32_t big_sigma0(uint32_t a) { return rotr(a, 2) ^ rotr(a, 13) ^ rotr(a, 22); }
+__host__ __device__ inline uint32_t big_sigma1(uint32_t e) { return rotr(e, 6) ^ rotr(e, 11) ^ rotr(e, 25); }
+__host__ __device__ inline uint32_t small_sigma0(uint32_t w) { return rotr(w, 7) ^ rotr(w, 18) ^ (w >> 3); }
+__host__ __device__ inline uint32_t small_sigma1(uint32_t w) { return rotr(w, 17) ^ rotr(w, 19) ^ (w >> 10); }
+
+// ---- the constraint program ------------------------------------------------------------------------------------------
+struct Term { uint32_t coeff; std::vector<uint32_t> vars; };
+typedef std::vector<Term> Terms;
+inline uint32_t var(uint32_t col, bool next = false) { return next ? ((1u << 30) | col) : col; }
+inline uint32_t pub(uint32_t idx) { return (2u << 30) | idx; }
+inline uint32_t neg(uint32_t c) { return c ? P - c : 0u; }
+__host__ __device__ inline uint32_t xl(int j) { return XL + 2 * (j >= 14 ? j - 2 : j - 1); }          // limb pair of W_{t+j}, j in 1..12, 14, 15
+
+struct Word { bool bits; uint32_t base; };
+inline Terms limb(Word w, int l, bool next = false) {
+    Terms t;
+    if (w.bits) for (int i = 0; i < 16; i++) t.push_back(Term{1u << i, {var(w.base + 16 * l + i, next)}});
+    else t.push_back(Term{1u, {var(w.base + l, next)}});
+    return t;
+}
+inline Terms negated(const Terms& in) { Terms t = in; for (Term& x : t) x.coeff = neg(x.coeff); return t; }
+inline Terms times(const Terms& in, uint32_t v, bool negate) {
+    Terms t = in;
+    for (Term& x : t) { x.vars.insert(x.vars.begin(), v); if (negate) x.coeff = neg(x.coeff); }
+    return t;
+}
+inline void append(Terms& a, const Terms& b) { a.insert(a.end(), b.begin(), b.end()); }
+inline Terms xor3(uint32_t x, uint32_t y, uint32_t z) {
+    return Terms{{1, {x}}, {1, {y}}, {1, {z}}, {P - 2, {x, y}}, {P - 2, {y, z}}, {P - 2, {x, z}}, {4, {x, y, z}}};
+}
+inline Terms xor2(uint32_t x, uint32_t y) { return Terms{{1, {x}}, {1, {y}}, {P - 2, {x, y}}}; }
+
+struct Builder {
+    std::vector<uint32_t> body;
+    uint32_t count = 0;
+    void add(uint32_t selector, const Terms& terms) {
+        body.push_back(selector);
+        body.push_back((uint32_t)terms.size());
+        for (const Term& t : terms) {
+            body.push_back(t.coeff % P);
+            body.push_back((uint32_t)t.vars.size());
+            for (uint32_t v : t.vars) body.push_back(v);
+        }
+        count++;
+    }
+};
+enum : uint32_t { ALL = 0, FIRST = 1, LAST = 2, TRANSITION = 3 };
+
+static const std::vector<uint32_t>& program() {
+    static const std::vector<uint32_t> prog = [] {
+        const uint32_t* K = round_constants().k;
+        const Word words[8] = {{true, A}, {true, B}, {true, C}, {false, D}, {true, E}, {true, F}, {true, G}, {false, HV}};   // a .. h
+        auto xw = [](int j) { return j == 0 ? Word{true, X0} : (j == 13 ? Word{true, X13} : Word{false, xl(j)}); };
+        const uint32_t s63 = var(SEL + 63);
+        Builder b;
+        // round selector: s_0 = 1 on the first row, cyclic shift on transitions
+        b.add(FIRST, Terms{{1, {var(SEL)}}, {P - 1, {}}});
+        for (uint32_t t = 1; t < 64; t++) b.add(FIRST, Terms{{1, {var(SEL + t)}}});
+        for (uint32_t t = 0; t < 64; t++) b.add(TRANSITION, Terms{{1, {var(SEL + (t + 1) % 64, true)}}, {P - 1, {var(SEL + t)}}});
+        // bits are bits
+        for (uint32_t base : {A, B, C, E, F, G, X0, X13})
+            for (uint32_t i = 0; i < 32; i++) b.add(ALL, Terms{{1, {var(base + i), var(base + i)}}, {P - 1, {var(base + i)}}});
+        for (uint32_t i = 0; i < 28; i++) b.add(ALL, Terms{{1, {var(CY + i), var(CY + i)}}, {P - 1, {var(CY + i)}}});
+        // the bitwise functions of the round
+        for (uint32_t i = 0; i < 32; i++) {
+            Terms t{{1, {var(S1 + i)}}};
+            append(t, negated(xor3(var(E + (i + 6) % 32), var(E + (i + 11) % 32), var(E + (i + 25) % 32))));
+            b.add(ALL, t);
+        }
+        for (uint32_t i = 0; i < 32; i++)
+            b.add(ALL, Terms{{1, {var(CH + i)}}, {P - 1, {var(G + i)}}, {P - 1, {var(E + i), var(F + i)}}, {1, {var(E + i), var(G + i)}}});
+        for (uint32_t i = 0; i < 32; i++) {
+            Terms t{{1, {var(S0 + i)}}};
+            append(t, negated(xor3(var(A + (i + 2) % 32), var(A + (i + 13) % 32), var(A + (i + 22) % 32))));
+            b.add(ALL, t);
+        }
+        for (uint32_t i = 0; i < 32; i++) {
+            const uint32_t x = var(A + i), y = var(B + i), z = var(C + i);
+            b.add(ALL, Terms{{1, {var(MJ + i)}}, {P - 1, {x, y}}, {P - 1, {x, z}}, {P - 1, {y, z}}, {2, {x, y, z}}});
+        }
+        // the schedule's bitwise functions: sigma0 = rotr 7 ^ rotr 18 ^ shr 3 of W_t, sigma1 = rotr 17 ^ rotr 19 ^ shr 10 of W_{t+13}
+        const uint32_t sg[2][5] = {{SG0, X0, 7, 18, 3}, {SG1, X13, 17, 19, 10}};
+        for (const auto& s : sg)
+            for (uint32_t i = 0; i < 32; i++) {
+                const uint32_t x = var(s[1] + (i + s[2]) % 32), y = var(s[1] + (i + s[3]) % 32);
+                Terms t{{1, {var(s[0] + i)}}};
+                append(t, negated(i + s[4] < 32 ? xor3(x, y, var(s[1] + i + s[4])) : xor2(x, y)));
+                b.add(ALL, t);
+            }
+        // the round: OUT = (1 - SKIP) (new working variable) + s_63 (chaining value), mod 2^32, limb by limb with carry bits
+        for (int l = 0; l < 2; l++) {
+            Terms t1 = limb(Word{false, HV}, l);
+            append(t1, limb(Word{true, S1}, l));
+            append(t1, limb(Word{true, CH}, l));
+            for (uint32_t t = 0; t < 64; t++) t1.push_back(Term{(K[t] >> (16 * l)) & 0xffffu, {var(SEL + t)}});
+            append(t1, limb(Word{true, X0}, l));
+            Terms new_a = t1;
+            append(new_a, limb(Word{true, S0}, l));
+            append(new_a, limb(Word{true, MJ}, l));
+            Terms new_e = limb(Word{false, D}, l);
+            append(new_e, t1);
+            const Terms rhs[8] = {new_a, limb(words[0], l), limb(words[1], l), limb(words[2], l), new_e, limb(words[4], l), limb(words[5], l), limb(words[6], l)};
+            const uint32_t cy[8] = {CY_A, CY_W6, CY_W6 + 2, CY_W6 + 4, CY_E, CY_W6 + 6, CY_W6 + 8, CY_W6 + 10};
+            for (int w = 0; w < 8; w++) {
+                const uint32_t ncy = (w == 0 || w == 4) ? 3 : 1;
+                Terms t{{1, {var(OUT + 2 * w + l)}}};
+                for (uint32_t k = 0; k < ncy; k++) t.push_back(Term{(uint32_t)(((uint64_t)1 << (16 + k)) % P), {var(cy[w] + ncy * l + k)}});
+                append(t, negated(rhs[w]));
+                append(t, times(rhs[w], var(SKIP), false));
+                t.push_back(Term{P - 1, {s63, var(HC + 2 * w + l)}});
+                if (l == 1) for (uint32_t k = 0; k < ncy; k++) t.push_back(Term{P - (1u << k), {var(cy[w] + k)}});     // carry out of the low limb
+                b.add(ALL, t);
+            }
+        }
+        // activity: a bit, 1 on the first row, never back from 0 to 1; SKIP = s_63 (1 - ACT)
+        b.add(ALL, Terms{{1, {var(ACT), var(ACT)}}, {P - 1, {var(ACT)}}});
+        b.add(FIRST, Terms{{1, {var(ACT)}}, {P - 1, {}}});
+        b.add(TRANSITION, Terms{{1, {var(ACT, true)}}, {P - 1, {var(ACT, true), var(ACT)}}});
+        b.add(ALL, Terms{{1, {var(SKIP)}}, {P - 1, {s63}}, {1, {s63, var(ACT)}}});
+        // the next row starts from OUT
+        for (int w = 0; w < 8; w++)
+            for (int l = 0; l < 2; l++) {
+                Terms t = limb(words[w], l, true);
+                t.push_back(Term{P - 1, {var(OUT + 2 * w + l)}});
+                b.add(TRANSITION, t);
+            }
+        // chaining value: equals the working variables where a block starts, constant inside a block
+        for (int w = 0; w < 8; w++)
+            for (int l = 0; l < 2; l++) {
+                Terms t{{1, {var(SEL), var(HC + 2 * w + l)}}};
+                append(t, times(limb(words[w], l), var(SEL), true));
+                b.add(ALL, t);
+            }
+        for (uint32_t i = 0; i < 16; i++) {
+            const uint32_t h = var(HC + i), hn = var(HC + i, true);
+            b.add(TRANSITION, Terms{{1, {hn}}, {P - 1, {h}}, {P - 1, {s63, hn}}, {1, {s63, h}}});
+        }
+        // first row: the IV; last row: the public digest
+        for (int w = 0; w < 8; w++)
+            for (int l = 0; l < 2; l++) {
+                Terms t = limb(words[w], l);
+                t.push_back(Term{neg((IV[w] >> (16 * l)) & 0xffffu), {}});
+                b.add(FIRST, t);
+            }
+        for (uint32_t i = 0; i < 16; i++) b.add(LAST, Terms{{1, {var(OUT + i)}}, {P - 1, {pub(i)}}});
+        // message schedule window: shifts and the recurrence, both off in round 63 (the next block brings its own 16 words)
+        auto gated = [&](const Terms& in) { Terms t = in; append(t, times(in, s63, true)); return t; };
+        for (int j = 0; j < 15; j++)
+            for (int l = 0; l < 2; l++) {
+                Terms t = limb(xw(j), l, true);
+                append(t, negated(limb(xw(j + 1), l)));
+                b.add(TRANSITION, gated(t));
+            }
+        for (int l = 0; l < 2; l++) {
+            Terms t = limb(Word{false, xl(15)}, l, true);
+            for (uint32_t k = 0; k < 2; k++) t.push_back(Term{(uint32_t)(((uint64_t)1 << (16 + k)) % P), {var(CY_SCHED + 2 * l + k)}});
+            Terms sum = limb(Word{true, SG1}, l, true);
+            append(sum, limb(Word{false, xl(8)}, l, true));
+            append(sum, limb(Word{true, SG0}, l, true));
+            append(sum, limb(Word{true, X0}, l));
+            append(t, negated(sum));
+            if (l == 1) for (uint32_t k = 0; k < 2; k++) t.push_back(Term{P - (1u << k), {var(CY_SCHED + k)}});
+            b.add(TRANSITION, gated(t));
+        }
+        std::vector<uint32_t> p{AIR_MAGIC, 1u, WIDTH, b.count, N_PUBLIC, (uint32_t)(6 + b.body.size())};
+        p.insert(p.end(), b.body.begin(), b.body.end());
+        return p;
+    }();
+    return prog;
+}
+
+// ---- host side: padding and the chaining values the blocks start from ---------------------------------------------------
+static void compress(uint32_t h[8], const uint8_t* block) {
+    const uint32_t* K = round_constants().k;
+    uint32_t w[64];
+    for (int i = 0; i < 16; i++) w[i] = ((uint32_t)block[4 * i] << 24) | ((uint32_t)block[4 * i + 1] << 16) | ((uint32_t)block[4 * i + 2] << 8) | block[4 * i + 3];
+    for (int i = 16; i < 64; i++) w[i] = w[i - 16] + small_sigma0(w[i - 15]) + w[i - 7] + small_sigma1(w[i - 2]);
+    uint32_t v[8];
+    std::memcpy(v, h, 32);
+    for (int r = 0; r < 64; r++) {
+        const uint32_t t1 = v[7] + big_sigma1(v[4]) + ((v[4] & v[5]) ^ (~v[4] & v[6])) + K[r] + w[r];
+        const uint32_t t2 = big_sigma0(v[0]) + ((v[0] & v[1]) ^ (v[0] & v[2]) ^ (v[1] & v[2]));
+        v[7] = v[6]; v[6] = v[5]; v[5] = v[4]; v[4] = v[3] + t1; v[3] = v[2]; v[2] = v[1]; v[1] = v[0]; v[0] = t1 + t2;
+    }
+    for (int i = 0; i < 8; i++) h[i] += v[i];
+}
+
+// ---- device side: one workgroup (one wavefront) per block, lane r writes the row of round r ----------------------------------
+struct TraceArgs {
+    const uint32_t* words;     // [n_blocks][16] message words (big-endian already resolved); inactive blocks: zeros
+    const uint32_t* chain;     // [n_blocks][8] chaining value each block starts from
+    uint32_t* out;
+    uint64_t ld;
+    uint32_t active;           // blocks [0, active) belong to the message
+    uint32_t k[64];
+};
+
+__device__ __forceinline__ uint32_t mbit(uint32_t x, int i) { return ((x >> i) & 1u) ? MONTY_R1 : 0u; }
+__device__ __forceinline__ uint32_t mlimb(uint32_t x) { return dmul(x, MONTY_R2); }                    // x < 2^16 -> Montgomery form
+__device__ __forceinline__ void put_bits(uint32_t* row, uint32_t base, uint32_t x) {
+#pragma unroll
+    for (int i = 0; i < 32; i++) row[base + i] = mbit(x, i);
+}
+__device__ __forceinline__ void put_limbs(uint32_t* row, uint32_t base, uint32_t x) { row[base] = mlimb(x & 0xffffu); row[base + 1] = mlimb(x >> 16); }
+// OUT limb pair + carry bits of a sum of up to 8 words: returns nothing, writes columns
+__device__ __forceinline__ void put_sum(uint32_t* row, uint32_t out_col, uint32_t cy, uint32_t ncy, const uint32_t* src, int n) {
+    uint32_t lo = 0, hi = 0;
+    for (int i = 0; i < n; i++) { lo += src[i] & 0xffffu; hi += src[i] >> 16; }
+    hi += lo >> 16;
+    row[out_col] = mlimb(lo & 0xffffu);
+    row[out_col + 1] = mlimb(hi & 0xffffu);
+    for (uint32_t q = 0; q < ncy; q++) { row[cy + q] = mbit(lo >> 16, q); row[cy + ncy + q] = mbit(hi >> 16, q); }
+}
+
+__global__ void __launch_bounds__(64) sha256_trace_kernel(TraceArgs a) {
+    __shared__ uint32_t w[80];
+    __shared__ uint32_t st[64][8];
+    const uint32_t blk = blockIdx.x, r = threadIdx.x;
+    const bool act = blk < a.active;
+    if (r < 16) w[r] = a.words[(uint64_t)blk * 16 + r];
+    __syncthreads();
+    if (r == 0) {
+        for (int i = 16; i < 80; i++) w[i] = w[i - 16] + small_sigma0(w[i - 15]) + w[i - 7] + small_sigma1(w[i - 2]);
+        uint32_t v[8];
+        for (int i = 0; i < 8; i++) v[i] = a.chain[(uint64_t)blk * 8 + i];
+        for (int t = 0; t < 64; t++) {
+            for (int i = 0; i < 8; i++) st[t][i] = v[i];
+            const uint32_t t1 = v[7] + big_sigma1(v[4]) + ((v[4] & v[5]) ^ (~v[4] & v[6])) + a.k[t] + w[t];
+            const uint32_t t2 = big_sigma0(v[0]) + ((v[0] & v[1]) ^ (v[0] & v[2]) ^ (v[1] & v[2]));
+            v[7] = v[6]; v[6] = v[5]; v[5] = v[4]; v[4] = v[3] + t1; v[3] = v[2]; v[2] = v[1]; v[1] = v[0]; v[0] = t1 + t2;
+        }
+    }
+    __syncthreads();
+    uint32_t* row = a.out + ((uint64_t)blk * 64 + r) * a.ld;
+    const uint32_t va = st[r][0], vb = st[r][1], vc = st[r][2], vd = st[r][3], ve = st[r][4], vf = st[r][5], vg = st[r][6], vh = st[r][7];
+    for (uint32_t t = 0; t < 64; t++) row[SEL + t] = t == r ? MONTY_R1 : 0u;
+    put_bits(row, A, va); put_bits(row, B, vb); put_bits(row, C, vc);
+    put_bits(row, E, ve); put_bits(row, F, vf); put_bits(row, G, vg);
+    put_limbs(row, D, vd); put_limbs(row, HV, vh);
+    const uint32_t s1 = big_sigma1(ve), ch = (ve & vf) ^ (~ve & vg), s0 = big_sigma0(va), mj = (va & vb) ^ (va & vc) ^ (vb & vc);
+    put_bits(row, S1, s1); put_bits(row, CH, ch); put_bits(row, S0, s0); put_bits(row, MJ, mj);
+    uint32_t hc[8];
+    for (int i = 0; i < 8; i++) { hc[i] = a.chain[(uint64_t)blk * 8 + i]; put_limbs(row, HC + 2 * i, hc[i]); }
+    const bool last = r == 63, skip = last && !act;
+    const uint32_t cy[8] = {CY_A, CY_W6, CY_W6 + 2, CY_W6 + 4, CY_E, CY_W6 + 6, CY_W6 + 8, CY_W6 + 10};
+    for (int i = 0; i < 8; i++) {
+        uint32_t src[8];
+        int n = 0;
+        if (!skip) {
+            if (i == 0) { src[n++] = vh; src[n++] = s1; src[n++] = ch; src[n++] = a.k[r]; src[n++] = w[r]; src[n++] = s0; src[n++] = mj; }
+            else if (i == 4) { src[n++] = vd; src[n++] = vh; src[n++] = s1; src[n++] = ch; src[n++] = a.k[r]; src[n++] = w[r]; }
+            else src[n++] = st[r][i - 1];
+        }
+        if (last) src[n++] = hc[i];
+        put_sum(row, OUT + 2 * i, cy[i], (i == 0 || i == 4) ? 3u : 1u, src, n);
+    }
+    put_bits(row, X0, w[r]); put_bits(row, X13, w[r + 13]);
+    for (int j = 1; j < 16; j++) if (j != 13) put_limbs(row, xl(j), w[r + j]);
+    put_bits(row, SG0, small_sigma0(w[r])); put_bits(row, SG1, small_sigma1(w[r + 13]));
+    {
+        uint32_t lo = 0, hi = 0;
+        if (!last) {
+            const uint32_t parts[4] = {small_sigma1(w[r + 14]), w[r + 9], small_sigma0(w[r + 1]), w[r]};
+            for (int i = 0; i < 4; i++) { lo += parts[i] & 0xffffu; hi += parts[i] >> 16; }
+            hi += lo >> 16;
+        }
+        for (uint32_t q = 0; q < 2; q++) { row[CY_SCHED + q] = mbit(lo >> 16, q); row[CY_SCHED + 2 + q] = mbit(hi >> 16, q); }
+    }
+    row[ACT] = act ? MONTY_R1 : 0u;
+    row[SKIP] = skip ? MONTY_R1 : 0u;
+    row[SKIP + 1] = 0u;
+    row[SKIP + 2] = 0u;
+}
+
+}  // namespace sha
+}  // namespace zk
+
+using namespace zk;
+
+#define CHECK_CTX(ctx)                                                  \
+    do {                                                                \
+        if (!(ctx)) return fail(ZKHIP_ERR_INVALID, "null context");     \
+        ZK_HIP(hipSetDevice((ctx)->device));                            \
+    } while (0)
+
+static int log2_exact(size_t n) { int l = 0; while (((size_t)1 << l) < n) l++; return ((size_t)1 << l) == n ? l : -1; }
+
+extern "C" {
+
+size_t zkhip_sha256_air(uint32_t* program, size_t cap_words) {
+    const std::vector<uint32_t>& p = sha::program();
+    if (program && cap_words >= p.size()) std::memcpy(program, p.data(), p.size() * 4);
+    return p.size();
+}
+
+size_t zkhip_sha256_pad(const uint8_t* message, size_t len, uint8_t* blocks, size_t cap) {
+    const size_t padded = ((len + 9 + 63) / 64) * 64;
+    if (!blocks || cap < padded || (len && !message)) return padded;
+    if (len) std::memcpy(blocks, message, len);
+    std::memset(blocks + len, 0, padded - len);
+    blocks[len] = 0x80;
+    const uint64_t bits = (uint64_t)len * 8;
+    for (int i = 0; i < 8; i++) blocks[padded - 1 - i] = (uint8_t)(bits >> (8 * i));
+    return padded;
+}
+
+int zkhip_sha256_gen_trace(zkhip_ctx* ctx, const uint8_t* blocks, size_t n_active, size_t n_blocks, uint32_t* d_trace, size_t ld,
+                           uint32_t digest_limbs[16]) {
+    CHECK_CTX(ctx);
+    const int lb = log2_exact(n_blocks);
+    if (!blocks || !d_trace || !digest_limbs || n_active == 0 || n_active > n_blocks || lb < 0 || lb + 6 > MAX_LOG_ROWS || ld < sha::WIDTH)
+        return fail(ZKHIP_ERR_INVALID, "sha256_gen_trace: 1 <= n_active <= n_blocks = 2^k <= 2^16, ld >= 608");
+    std::vector<uint32_t> host((size_t)n_blocks * 24, 0u);             // [n_blocks][16] words, then [n_blocks][8] chaining values
+    uint32_t* words = host.data();
+    uint32_t* chain = host.data() + n_blocks * 16;
+    uint32_t h[8];
+    std::memcpy(h, sha::IV, 32);
+    for (size_t k = 0; k < n_blocks; k++) {
+        std::memcpy(chain + 8 * k, h, 32);
+        if (k < n_active) {
+            const uint8_t* b = blocks + 64 * k;
+            for (int i = 0; i < 16; i++) words[16 * k + i] = ((uint32_t)b[4 * i] << 24) | ((uint32_t)b[4 * i + 1] << 16) | ((uint32_t)b[4 * i + 2] << 8) | b[4 * i + 3];
+            sha::compress(h, b);
+        }
+    }
+    for (int i = 0; i < 8; i++) { digest_limbs[2 * i] = h[i] & 0xffffu; digest_limbs[2 * i + 1] = h[i] >> 16; }
+    void* stage;
+    ZK_TRY(ctx_reserve(ctx, S_STAGE, host.size() * 4, &stage));
+    ZK_HIP(hipMemcpyAsync(stage, host.data(), host.size() * 4, hipMemcpyHostToDevice, ctx->stream));
+    ZK_HIP(hipStreamSynchronize(ctx->stream));                         // `host` goes out of scope
+    sha::TraceArgs a;
+    a.words = (const uint32_t*)stage;
+    a.chain = (const uint32_t*)stage + n_blocks * 16;
+    a.out = d_trace;
+    a.ld = ld;
+    a.active = (uint32_t)n_active;
+    std::memcpy(a.k, sha::round_constants().k, sizeof(a.k));
+    hipLaunchKernelGGL(sha::sha256_trace_kernel, dim3((unsigned)n_blocks), dim3(64), 0, ctx->stream, a);
+    ZK_HIP(hipGetLastError());
+    return ZKHIP_OK;
+}
+
+static int sha_shape(size_t message_len, size_t* padded, size_t* n_active, size_t* n_blocks, int* log_n) {
+    *padded = ((message_len + 9 + 63) / 64) * 64;
+    *n_active = *padded / 64;
+    size_t nb = 1;
+    while (nb < *n_active) nb <<= 1;
+    *n_blocks = nb;
+    *log_n = 6 + log2_exact(nb);
+    return *log_n <= MAX_LOG_ROWS ? ZKHIP_OK : fail(ZKHIP_ERR_INVALID, "sha256: message longer than 2^16 blocks");
+}
+
+size_t zkhip_sha256_proof_size(size_t message_len, const zkhip_params* prm) {
+    size_t padded, na, nb;
+    int log_n;
+    if (sha_shape(message_len, &padded, &na, &nb, &log_n) != ZKHIP_OK) return 0;
+    const std::vector<uint32_t>& p = sha::program();
+    return zkhip_proof_size_air(p.data(), p.size(), log_n, sha::WIDTH, prm, sha::N_PUBLIC);
+}
+
+int zkhip_prove_sha256(zkhip_ctx* ctx, const uint8_t* message, size_t message_len, const zkhip_params* prm, uint8_t digest[32],
+                       uint8_t* proof, size_t cap, size_t* len) {
+    CHECK_CTX(ctx);
+    if ((message_len && !message) || !digest || !proof || !len || !prm) return fail(ZKHIP_ERR_INVALID, "prove_sha256: null argument");
+    size_t padded, na, nb;
+    int log_n;
+    ZK_TRY(sha_shape(message_len, &padded, &na, &nb, &log_n));
+    std::vector<uint8_t> blocks(padded);
+    zkhip_sha256_pad(message, message_len, blocks.data(), padded);
+    void* trace;
+    ZK_TRY(ctx_reserve(ctx, S_CHIP, ((size_t)sha::WIDTH << log_n) * 4, &trace));
+    uint32_t limbs[16];
+    ZK_TRY(zkhip_sha256_gen_trace(ctx, blocks.data(), na, nb, (uint32_t*)trace, sha::WIDTH, limbs));
+    for (int i = 0; i < 8; i++) {
+        const uint32_t w = limbs[2 * i] | (limbs[2 * i + 1] << 16);
+        digest[4 * i] = (uint8_t)(w >> 24); digest[4 * i + 1] = (uint8_t)(w >> 16); digest[4 * i + 2] = (uint8_t)(w >> 8); digest[4 * i + 3] = (uint8_t)w;
+    }
+    const std::vector<uint32_t>& p = sha::program();
+    return zkhip_prove_shard_air(ctx, p.data(), p.size(), (const uint32_t*)trace, sha::WIDTH, log_n, sha::WIDTH, limbs, sha::N_PUBLIC, prm, proof, cap, len);
+}
+
+int zkhip_verify_sha256(const uint8_t* proof, size_t len, const uint8_t digest[32], const zkhip_params* prm, int* reason) {
+    if (!proof || !digest || !prm || len < 16) return fail(ZKHIP_ERR_INVALID, "verify_sha256: null argument");
+    uint32_t head[4];
+    std::memcpy(head, proof, 16);
+    const int log_n = (int)head[2];                                    // the block count 2^(log_n - 6) is read from the proof and bound by its transcript
+    if (log_n < 6 || log_n > MAX_LOG_ROWS) { if (reason) *reason = 1; return fail(ZKHIP_ERR_VERIFY, "verify_sha256: not a SHA-256 chip proof"); }
+    uint32_t limbs[16];
+    for (int i = 0; i < 8; i++) {
+        const uint32_t w = ((uint32_t)digest[4 * i] << 24) | ((uint32_t)digest[4 * i + 1] << 16) | ((uint32_t)digest[4 * i + 2] << 8) | digest[4 * i + 3];
+        limbs[2 * i] = w & 0xffffu; limbs[2 * i + 1] = w >> 16;
+    }
+    const std::vector<uint32_t>& p = sha::program();
+    return zkhip_verify_shard_air(p.data(), p.size(), proof, len, log_n, sha::WIDTH, limbs, sha::N_PUBLIC, prm, reason);
+}
+
+}  // extern "C"

@@ -334,6 +334,31 @@ class Context:
                                              pv.ctypes.data_as(u32p), pv.size, C.byref(params), buf.ctypes.data_as(u8p), size, C.byref(got)))
         return buf[: got.value]
 
+    # ---- the SHA-256 compression chip (csrc/sha256_chip.hip)
+    def sha256_gen_trace(self, blocks, n_blocks=None):
+        """blocks: bytes, a multiple of 64 long (padding included) -> (device trace [64 n_blocks][608], digest limbs [16])"""
+        b = np.frombuffer(bytes(blocks), dtype=np.uint8)
+        active = b.size // 64
+        n_blocks = n_blocks or 1 << max(active - 1, 0).bit_length()
+        out = self.alloc(64 * n_blocks * 608)
+        limbs = np.zeros(16, dtype=np.uint32)
+        check(self.lib.zkhip_sha256_gen_trace(self.handle, b.ctypes.data_as(u8p), active, n_blocks, C.c_void_p(out.ptr), 608, limbs.ctypes.data_as(u32p)))
+        return out, limbs
+
+    def prove_sha256(self, message, params=None):
+        """-> (digest bytes, proof bytes): "I know a message with this SHA-256 digest" """
+        params = params or Params(1, 100, 16)
+        m = np.frombuffer(bytes(message), dtype=np.uint8) if len(message) else np.zeros(1, dtype=np.uint8)
+        size = self.lib.zkhip_sha256_proof_size(len(message), C.byref(params))
+        if size == 0:
+            raise _lib.ZkHipError(-1, "prove_sha256: bad shape or message too long")
+        buf = np.empty(size, dtype=np.uint8)
+        digest = np.zeros(32, dtype=np.uint8)
+        got = C.c_size_t(0)
+        check(self.lib.zkhip_prove_sha256(self.handle, m.ctypes.data_as(u8p), len(message), C.byref(params), digest.ctypes.data_as(u8p),
+                                          buf.ctypes.data_as(u8p), size, C.byref(got)))
+        return digest.tobytes(), buf[: got.value]
+
     def quotient_values_air(self, program, lde, log_n, width, public_values, alpha, out=None, log_quotient_degree=1):
         out = out or self.alloc(4 << (log_n + log_quotient_degree))
         prog = np.ascontiguousarray(program, dtype=np.uint32)
@@ -480,6 +505,34 @@ def verify_shard_air(program, proof, log_n, width, public_values=(), params=None
     reason = C.c_int(0)
     rc = lib.zkhip_verify_shard_air(prog.ctypes.data_as(u32p), prog.size, pr.ctypes.data_as(u8p), pr.size, log_n, width,
                                     pv.ctypes.data_as(u32p), pv.size, C.byref(params), C.byref(reason))
+    return rc, reason.value
+
+
+def sha256_air():
+    """the SHA-256 compression chip's constraint program (u32 words)"""
+    lib = _lib.load()
+    n = lib.zkhip_sha256_air(None, 0)
+    out = np.empty(n, dtype=np.uint32)
+    assert lib.zkhip_sha256_air(out.ctypes.data_as(u32p), n) == n
+    return out
+
+
+def sha256_pad(message):
+    lib = _lib.load()
+    m = np.frombuffer(bytes(message), dtype=np.uint8) if len(message) else np.zeros(1, dtype=np.uint8)
+    n = lib.zkhip_sha256_pad(m.ctypes.data_as(u8p), len(message), None, 0)
+    out = np.empty(n, dtype=np.uint8)
+    assert lib.zkhip_sha256_pad(m.ctypes.data_as(u8p), len(message), out.ctypes.data_as(u8p), n) == n
+    return out.tobytes()
+
+
+def verify_sha256(proof, digest, params=None):
+    params = params or Params(1, 100, 16)
+    lib = _lib.load()
+    pr = np.ascontiguousarray(proof, dtype=np.uint8)
+    dg = np.frombuffer(bytes(digest), dtype=np.uint8)
+    reason = C.c_int(0)
+    rc = lib.zkhip_verify_sha256(pr.ctypes.data_as(u8p), pr.size, dg.ctypes.data_as(u8p), C.byref(params), C.byref(reason))
     return rc, reason.value
 
 
