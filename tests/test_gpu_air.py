@@ -104,3 +104,28 @@ def test_bad_programs_fail_loudly(ctx):
         ctx.prove_shard_air(prog, trace, 6, 4, [1, 2], Params(1, 6, 4))       # n_public does not match the program
     with pytest.raises(ZkHipError):
         ctx.prove_shard_air(prog, trace, 6, 4, [1, 2, 3], Params(1, 6, 4, 1))  # lookups belong to the built-in AIR
+
+
+def test_many_public_values_take_the_row_per_lane_interpreter(ctx, oracle):
+    """more than 64 public values do not fit the per-point LDS slots of the term-parallel kernel (stark.hip): the row-per-lane
+    interpreter proves those programs -- same bytes as the oracle either way"""
+    O = oracle
+    V = O.air_var
+    width, n_pub, log_n = 8, 80, 9
+    cons = [(O.SEL_FIRST, [(1, [V(0)]), (P - 1, [V(79, public=True)])]),
+            (O.SEL_TRANSITION, [(1, [V(0, True)]), (P - 1, [V(0)]), (P - 1, [V(3, public=True)])])]
+    for j in range(1, width):
+        cons.append((O.SEL_ALL, [(1, [V(j)]), (P - j, [V(0), V(0), V(70, public=True)]), (P - 1, [V(j - 1)])]))
+    prog = O.air_program(width, n_pub, cons)
+    pub = [(7 * i + 1) % P for i in range(n_pub)]
+    n = 1 << log_n
+    t = np.zeros((n, width), dtype=np.uint64)
+    x = (pub[79] + pub[3] * np.arange(n, dtype=np.uint64)) % P
+    t[:, 0] = x
+    for j in range(1, width):
+        t[:, j] = (x * x % P * pub[70] % P * j + t[:, j - 1]) % P
+    t = t.astype(np.uint32)
+    shape = (1, 9, 5)
+    proof = ctx.prove_shard_air(prog, ctx.from_numpy(t), log_n, width, pub, Params(*shape))
+    assert proof.tobytes() == O.prove_shard_air(prog, t, pub, O.default_params(*shape)).tobytes()
+    assert verify_shard_air(prog, proof, log_n, width, pub, Params(*shape)) == (0, 0)

@@ -16,6 +16,7 @@
 #include <vector>
 
 #include "babybear.cuh"
+#include "kernels.h"
 #include "poseidon2.cuh"
 
 namespace zk {
@@ -102,6 +103,39 @@ inline void air_device_image(const AirView& a, const Ext& alpha, std::vector<uin
     weights.resize(4 * (size_t)a.K);
     Ext w = ext_one();
     for (size_t k = a.K; k-- > 0;) { for (int i = 0; i < 4; i++) weights[4 * k + i] = w.c[i]; w = ext_mul(w, alpha); }
+}
+
+// Term records for the term-parallel quotient kernel (stark.hip, quotient_air_terms_kernel): the program flattened into one
+// record per TERM, the constraint's weight alpha^(K-1-k) folded into the coefficient (extension, Montgomery) and the constraint's
+// selector appended as one more factor, so that the quotient numerator is one flat sum  sum_t coeff_t * prod_j slot[off_tj]  over
+// a per-point array of slots: [0, W) local row, [W, 2W) next row, 2W is_first, 2W+1 is_last, 2W+2 is_transition, 2W+3 the constant 1,
+// 2W+4+i public value i.  Record = 8 words: coefficient (4), off0 | off1 << 16, off2 | off3 << 16, off4 | nvars << 16, 0; nvars in
+// [1, 5] (a constant term reads the slot of 1).  Sorted by nvars, so that the lanes of a wavefront run the same number of products.
+inline uint32_t air_slots(const AirView& a) { return 2 * a.width + AIR_SLOT_EXTRA + a.n_public; }
+inline void air_term_records(const AirView& a, const Ext& alpha, std::vector<uint32_t>& recs) {
+    std::vector<Ext> wts(a.K);
+    Ext w = ext_one();
+    for (size_t k = a.K; k-- > 0;) { wts[k] = w; w = ext_mul(w, alpha); }
+    std::vector<std::vector<uint32_t>> by_n[6];
+    size_t p = 6;
+    const uint32_t W = a.width;
+    for (uint32_t k = 0; k < a.K; k++) {
+        const uint32_t sel = a.w[p++], nt = a.w[p++];
+        for (uint32_t t = 0; t < nt; t++) {
+            const Ext c = ext_mul_base(wts[k], to_monty(a.w[p++]));
+            const uint32_t d = a.w[p++];
+            uint32_t off[5] = {0, 0, 0, 0, 0}, n = 0;
+            for (uint32_t j = 0; j < d; j++) {
+                const uint32_t v = a.w[p++], kind = v >> 30, idx = v & 0xFFFFu;
+                off[n++] = kind == 0 ? idx : (kind == 1 ? W + idx : 2 * W + AIR_SLOT_EXTRA + idx);
+            }
+            if (sel) off[n++] = 2 * W + (sel - 1);
+            if (n == 0) off[n++] = 2 * W + 3;
+            by_n[n].push_back({c.c[0], c.c[1], c.c[2], c.c[3], off[0] | off[1] << 16, off[2] | off[3] << 16, off[4] | n << 16, 0u});
+        }
+    }
+    recs.clear();
+    for (int n = 1; n <= 5; n++) for (const auto& r : by_n[n]) recs.insert(recs.end(), r.begin(), r.end());
 }
 
 }  // namespace zk

@@ -172,6 +172,7 @@ struct QuotientArgs {
 hipError_t launch_quotient(const QuotientArgs& a, hipStream_t s);
 
 // quotient values of a constraint PROGRAM (air.h): the interpreter form of launch_quotient for an AIR supplied as data.
+constexpr uint32_t AIR_SLOT_EXTRA = 4;      // per-point slots after the two rows: is_first, is_last, is_transition, 1 (then the public values)
 struct QuotientAirArgs {
     const uint32_t* lde; uint64_t ld; uint32_t width; int log_n;
     const uint32_t* xs; const uint32_t* sel_first; const uint32_t* sel_last;
@@ -184,6 +185,8 @@ struct QuotientAirArgs {
     const uint32_t* pub;        // device: public values, Montgomery
     uint32_t* out;              // [2^log_qd][N][4] natural chunk order, as launch_quotient
     uint32_t* lde_out; uint64_t lde_ld;     // log_qd == 1 only (as launch_quotient)
+    // term-parallel form (air_term_records): used when recs != nullptr and the slots of 8 points fit the LDS
+    const uint32_t* recs; uint32_t n_terms; uint32_t n_public;
 };
 hipError_t launch_quotient_air(const QuotientAirArgs& a, hipStream_t s);
 

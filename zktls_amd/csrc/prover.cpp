@@ -194,12 +194,16 @@ static int run_quotient_air(zkhip_ctx* ctx, const AirView& air, const uint32_t* 
     air_device_image(air, alpha, body, weights);
     std::vector<uint32_t> pub(air.n_public ? air.n_public : 1, 0u);
     for (uint32_t i = 0; i < air.n_public; i++) pub[i] = to_monty(public_values[i]);
-    // one staging buffer: body | weights (16-byte aligned) | public values
-    const size_t body_w = (body.size() + 3) & ~(size_t)3;
-    std::vector<uint32_t> stage(body_w + weights.size() + pub.size(), 0u);
+    // the flattened form for the term-parallel kernel (up to 64 public values: they travel in every point's LDS slots)
+    std::vector<uint32_t> recs;
+    if (air.n_public <= 64) air_term_records(air, alpha, recs);
+    // one staging buffer: body | weights (16-byte aligned) | public values | term records (16-byte aligned)
+    const size_t body_w = (body.size() + 3) & ~(size_t)3, pub_w = (pub.size() + 3) & ~(size_t)3;
+    std::vector<uint32_t> stage(body_w + weights.size() + pub_w + recs.size(), 0u);
     memcpy(stage.data(), body.data(), body.size() * 4);
     memcpy(stage.data() + body_w, weights.data(), weights.size() * 4);
     memcpy(stage.data() + body_w + weights.size(), pub.data(), pub.size() * 4);
+    if (!recs.empty()) memcpy(stage.data() + body_w + weights.size() + pub_w, recs.data(), recs.size() * 4);
     void* d_stage;
     ZK_TRY(ctx_reserve(ctx, S_APOW_Q, stage.size() * 4, &d_stage));
     ZK_TRY(h2d(ctx, d_stage, stage.data(), stage.size() * 4));
@@ -213,6 +217,8 @@ static int run_quotient_air(zkhip_ctx* ctx, const AirView& air, const uint32_t* 
     q.body = (const uint32_t*)d_stage; q.n_constraints = air.K;
     q.weights = (const uint32_t*)d_stage + body_w; q.pub = (const uint32_t*)d_stage + body_w + weights.size();
     q.out = out_chunks; q.lde_out = lde_out; q.lde_ld = lde_ld;
+    q.recs = recs.empty() ? nullptr : (const uint32_t*)d_stage + body_w + weights.size() + pub_w;
+    q.n_terms = (uint32_t)(recs.size() / 8); q.n_public = air.n_public;
     ZK_HIP(launch_quotient_air(q, ctx->stream));
     return ZKHIP_OK;
 }

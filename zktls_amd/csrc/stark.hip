@@ -12,6 +12,8 @@
 // the point x_p = g * w_2N^bitrev(p)); extension elements are 4 consecutive words.
 // Row-wise kernels give a row to a group of L <= 64 adjacent lanes so that a wave reads
 // whole rows with 16-byte loads and reduces with cross-lane shuffles (no LDS traffic).
+#include <atomic>
+
 #include "poseidon2.cuh"
 #include "kernels.h"
 
@@ -276,8 +278,118 @@ __global__ void __launch_bounds__(256) quotient_air_kernel(QuotientAirArgs a) {
     st_ext(a.out + ((uint64_t)chunk * (m >> a.log_qd) + (e >> a.log_qd)) * 4, r);
     if (a.lde_out) st_ext(a.lde_out + (uint64_t)p * a.lde_ld + 4u * chunk, r);
 }
+// The term-parallel form: a workgroup owns PTS adjacent points of the quotient domain and its 256 lanes split the TERMS of the
+// flattened program (air.h, air_term_records).  The two rows of every point are staged into LDS once with 16-byte coalesced loads
+// (together with the point's selector values, the constant 1 and the public values: "slots"), a lane loads its 32-byte term record
+// once and applies it to all PTS points (ds_read gathers; the record table stays in L2), and the extension coefficient rides in
+// four 64-bit running sums per point (dacc1: one conditional subtraction per product, one Montgomery reduction at the end).  The
+// 256 partial sums per point are then added through LDS.  Against the row-per-lane interpreter above: no strided global gathers
+// (a lane there touches 64 cache lines per load instruction) and ~8 x less program traffic per point; 40 - 50 x faster on the
+// 608-column SHA-256 chip.
+template <int PTS>
+__global__ void __launch_bounds__(256) quotient_air_terms_kernel(QuotientAirArgs a, uint32_t stride) {
+    extern __shared__ uint32_t slots[];
+    const int H = a.log_n + a.log_qd;
+    const uint32_t m = 1u << H, nq = 1u << a.log_qd, W = a.width;
+    const uint32_t p0 = blockIdx.x * PTS, tid = threadIdx.x;
+    for (int q = 0; q < PTS; q++) {
+        const uint32_t p = p0 + q;
+        const uint32_t e = __brev(p) >> (32 - H);
+        const uint32_t pn = __brev((e + nq) & (m - 1)) >> (32 - H);
+        const uint4* lrow = reinterpret_cast<const uint4*>(a.lde + (uint64_t)p * a.ld);
+        const uint4* nrow = reinterpret_cast<const uint4*>(a.lde + (uint64_t)pn * a.ld);
+        uint4* dl = reinterpret_cast<uint4*>(slots + (size_t)q * stride);
+        uint4* dn = reinterpret_cast<uint4*>(slots + (size_t)q * stride + W);
+        for (uint32_t c = tid; c < W / 4; c += 256) { dl[c] = lrow[c]; dn[c] = nrow[c]; }
+        uint32_t* ex = slots + (size_t)q * stride + 2 * W;
+        if (tid == 0) { ex[0] = a.sel_first[p]; ex[1] = a.sel_last[p]; ex[2] = dsub(a.xs[p], a.wn_inv); ex[3] = MONTY_R1; }
+        for (uint32_t i = tid; i < a.n_public; i += 256) ex[AIR_SLOT_EXTRA + i] = a.pub[i];
+    }
+    __syncthreads();
+    uint64_t acc[PTS][4];
+#pragma unroll
+    for (int q = 0; q < PTS; q++)
+#pragma unroll
+        for (int i = 0; i < 4; i++) acc[q][i] = 0;
+    const uint4* recs = reinterpret_cast<const uint4*>(a.recs);
+    for (uint32_t t = tid; t < a.n_terms; t += 256) {
+        const uint4 c = recs[2 * (size_t)t], o = recs[2 * (size_t)t + 1];
+        const uint32_t n = o.z >> 16;
+        const uint32_t o0 = o.x & 0xFFFFu, o1 = o.x >> 16, o2 = o.y & 0xFFFFu, o3 = o.y >> 16, o4 = o.z & 0xFFFFu;
+        uint32_t prod[PTS];
+#pragma unroll
+        for (int q = 0; q < PTS; q++) prod[q] = slots[(size_t)q * stride + o0];
+        if (n > 1) {
+#pragma unroll
+            for (int q = 0; q < PTS; q++) prod[q] = dmul(prod[q], slots[(size_t)q * stride + o1]);
+        }
+        if (n > 2) {
+#pragma unroll
+            for (int q = 0; q < PTS; q++) prod[q] = dmul(prod[q], slots[(size_t)q * stride + o2]);
+        }
+        if (n > 3) {
+#pragma unroll
+            for (int q = 0; q < PTS; q++) prod[q] = dmul(prod[q], slots[(size_t)q * stride + o3]);
+        }
+        if (n > 4) {
+#pragma unroll
+            for (int q = 0; q < PTS; q++) prod[q] = dmul(prod[q], slots[(size_t)q * stride + o4]);
+        }
+#pragma unroll
+        for (int q = 0; q < PTS; q++) {
+            dacc1(acc[q][0], c.x, prod[q]); dacc1(acc[q][1], c.y, prod[q]); dacc1(acc[q][2], c.z, prod[q]); dacc1(acc[q][3], c.w, prod[q]);
+        }
+    }
+    __syncthreads();                                   // the slots are dead: the same LDS now carries the partial sums
+    constexpr int NV = PTS * 4;                        // values to total, 256 partials each; row pitch 257 words
+#pragma unroll
+    for (int q = 0; q < PTS; q++)
+#pragma unroll
+        for (int i = 0; i < 4; i++) slots[(size_t)(q * 4 + i) * 257 + tid] = dacc_finish(acc[q][i]);
+    __syncthreads();
+    constexpr int SL = 256 / NV;                       // lanes per value in the first round (8 for PTS = 8)
+    {
+        const uint32_t j = tid / SL, sl = tid % SL;
+        uint32_t sum = 0;
+        for (uint32_t i = sl; i < 256; i += SL) sum = dadd(sum, slots[(size_t)j * 257 + i]);
+        __syncthreads();
+        slots[(size_t)j * 257 + sl] = sum;
+    }
+    __syncthreads();
+    if (tid < (uint32_t)PTS) {
+        const uint32_t p = p0 + tid;
+        const uint32_t e = __brev(p) >> (32 - H);
+        Ext r;
+        for (int i = 0; i < 4; i++) {
+            uint32_t sum = 0;
+            for (int k = 0; k < SL; k++) sum = dadd(sum, slots[(size_t)(tid * 4 + i) * 257 + k]);
+            r.c[i] = sum;
+        }
+        const uint32_t chunk = e & (nq - 1u);
+        const uint32_t iz = chunk == 0 ? a.inv_zh[0] : (chunk == 1 ? a.inv_zh[1] : (chunk == 2 ? a.inv_zh[2] : a.inv_zh[3]));
+        r = ext_mul_base_dev(r, iz);
+        st_ext(a.out + ((uint64_t)chunk * (m >> a.log_qd) + (e >> a.log_qd)) * 4, r);
+        if (a.lde_out) st_ext(a.lde_out + (uint64_t)p * a.lde_ld + 4u * chunk, r);
+    }
+}
 hipError_t launch_quotient_air(const QuotientAirArgs& a, hipStream_t s) {
     const uint64_t m = 1ull << (a.log_n + a.log_qd);
+    constexpr int PTS = 8;
+    const uint32_t stride = 2 * a.width + AIR_SLOT_EXTRA + ((a.n_public + 3u) & ~3u);     // a multiple of 4 words: 16-byte row copies
+    const size_t lds_rows = (size_t)PTS * stride * 4, lds_red = (size_t)PTS * 4 * 257 * 4;
+    const size_t lds = lds_rows > lds_red ? lds_rows : lds_red;
+    if (a.recs && lds <= 72 * 1024 && m >= (uint64_t)PTS && stride < 65536 && (a.ld % 4) == 0 && (reinterpret_cast<uintptr_t>(a.lde) & 15) == 0) {
+        static std::atomic<size_t> configured[64] = {};
+        int dev = 0;
+        if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return hipErrorInvalidDevice;
+        if (lds > configured[dev].load(std::memory_order_acquire)) {
+            hipError_t e = hipFuncSetAttribute((const void*)quotient_air_terms_kernel<PTS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            if (e != hipSuccess) return e;
+            configured[dev].store(lds, std::memory_order_release);
+        }
+        hipLaunchKernelGGL(quotient_air_terms_kernel<PTS>, dim3((unsigned)(m / PTS)), dim3(256), lds, s, a, stride);
+        return hipGetLastError();
+    }
     hipLaunchKernelGGL(quotient_air_kernel, dim3((unsigned)((m + 255) / 256)), dim3(256), 0, s, a);
     return hipGetLastError();
 }
