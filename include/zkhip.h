@@ -362,6 +362,8 @@ int zkhip_quotient_values_air(zkhip_ctx* ctx, const uint32_t* program, size_t pr
 #define ZKHIP_SHA256_PUBLIC 16
 /* the constraint program (a zkhip_prove_shard_air program): returns its length in words; written when cap_words suffices */
 size_t zkhip_sha256_air(uint32_t* program, size_t cap_words);
+/* the digest itself, on the host (what a verifier compares the proof's public values with) */
+void zkhip_sha256_digest(const uint8_t* message, size_t len, uint8_t digest[32]);
 /* FIPS 180-4 padding: returns the padded length (a multiple of 64); written when cap suffices.  Host only. */
 size_t zkhip_sha256_pad(const uint8_t* message, size_t len, uint8_t* blocks, size_t cap);
 /* trace generation on the device: blocks = n_active padded 64-byte blocks (host memory), n_blocks = a power of two >= n_active;

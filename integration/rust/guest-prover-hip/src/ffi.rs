@@ -82,6 +82,14 @@ extern "C" {
         proof: *const u8, len: usize, log_n: c_int, width: u32,
         public_values: *const u32, n_public: usize, prm: *const ZkhipParams, reason: *mut c_int,
     ) -> c_int;
+    // the SHA-256 compression chip (include/zkhip.h): message in, digest and proof out
+    pub fn zkhip_sha256_digest(message: *const u8, len: usize, digest: *mut u8);
+    pub fn zkhip_sha256_proof_size(message_len: usize, prm: *const ZkhipParams) -> usize;
+    pub fn zkhip_prove_sha256(
+        ctx: *mut ZkhipCtx, message: *const u8, message_len: usize, prm: *const ZkhipParams, digest: *mut u8,
+        proof: *mut u8, cap: usize, len: *mut usize,
+    ) -> c_int;
+    pub fn zkhip_verify_sha256(proof: *const u8, len: usize, digest: *const u8, prm: *const ZkhipParams, reason: *mut c_int) -> c_int;
 }
 
 /// status code -> anyhow error carrying the library's thread-local message

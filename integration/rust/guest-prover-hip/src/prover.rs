@@ -75,14 +75,17 @@ pub struct HipGuestProver {
     device: i32,
     source: Option<Box<dyn ShardSource>>,
     synthetic: Option<SyntheticShards>,
+    commitment: bool,
 }
 
 /// batch blob header: "ZKTB", version 2, flags, shard count; then (u32 length, bytes) per shard
 pub const BATCH_FLAG_SYNTHETIC: u32 = 1;
+/// one proof of the SHA-256 chip over the request's input bytes (`with_input_commitment`)
+pub const BATCH_FLAG_INPUT_SHA256: u32 = 2;
 
 impl HipGuestProver {
     pub fn new(device: i32) -> Self {
-        Self { mode: ProverType::default(), backend: Backend::default(), device, source: None, synthetic: None }
+        Self { mode: ProverType::default(), backend: Backend::default(), device, source: None, synthetic: None, commitment: false }
     }
     pub fn mock(mut self) -> Self { self.mode = ProverType::Mock; self }
     pub fn local(mut self) -> Self { self.mode = ProverType::Local; self }
@@ -92,6 +95,9 @@ impl HipGuestProver {
     pub fn with_source(mut self, source: Box<dyn ShardSource>) -> Self { self.source = Some(source); self }
     /// opt into proving synthetic shards when no executor is wired (see `SyntheticShards`)
     pub fn with_synthetic(mut self, plan: SyntheticShards) -> Self { self.synthetic = Some(plan); self }
+    /// the input-commitment guest: prove "I know the request's input and its SHA-256 is `output`" through the SHA-256
+    /// compression chip of libzkhip -- a real statement that needs no executor (not the zkTLS verifier guest)
+    pub fn with_input_commitment(mut self) -> Self { self.commitment = true; self }
 
     fn params(&self, log_n: i32) -> ZkhipParams {
         match self.backend {
@@ -132,14 +138,19 @@ impl HipGuestProver {
         let digest_bytes: Vec<u8> = digest.iter().flat_map(|w| w.to_le_bytes()).collect();
         match self.mode {
             // executes nothing: public output = the digest, proof = a <= 4-byte placeholder, i.e. "no proof" (sp1.rs:128-130)
+            ProverType::Mock if self.commitment => {
+                let mut d = [0u8; 32];
+                unsafe { ffi::zkhip_sha256_digest(cbor.as_ptr(), cbor.len(), d.as_mut_ptr()) };
+                return Ok((d.to_vec(), Vec::new()));
+            }
             ProverType::Mock => return Ok((digest_bytes, Vec::new())),
             ProverType::Network => return Err(anyhow!("network proving is not provided by the HIP backend")),
             ProverType::Local | ProverType::Hip => {}
         }
         // A caller applying the reference's rule "proof.len() > 4 means a real proof" must never receive bytes that attest
         // nothing about the guest: without an executor the synthetic plan is an explicit opt-in, otherwise this is an error.
-        if self.source.is_none() && self.synthetic.is_none() {
-            return Err(anyhow!("no shard source: wire the zkVM executor with with_source(), or opt into synthetic shards with with_synthetic()"));
+        if self.source.is_none() && self.synthetic.is_none() && !self.commitment {
+            return Err(anyhow!("no shard source: wire the zkVM executor with with_source(), or opt into synthetic shards with with_synthetic() / the input-commitment guest with with_input_commitment()"));
         }
         if unsafe { ffi::zkhip_device_count() } <= 0 {
             return Err(anyhow!("no gfx950 device: libzkhip has no CPU fallback"));
@@ -147,7 +158,21 @@ impl HipGuestProver {
         let ctx = Context::new(self.device)?;
         let start = std::time::Instant::now();
         let mut proofs: Vec<Vec<u8>> = Vec::new();
-        let (output, flags) = if let Some(src) = self.source.as_mut() {
+        let (output, flags) = if self.commitment {
+            // 64 rows per 64-byte block, block count (padding included) rounded up to a power of two
+            let blocks = (cbor.len() + 9 + 63) / 64;
+            let log_n = 6 + (blocks.next_power_of_two().trailing_zeros() as i32);
+            let prm = self.params(log_n);
+            let cap = unsafe { ffi::zkhip_sha256_proof_size(cbor.len(), &prm) };
+            anyhow::ensure!(cap > 0, "input too long for the SHA-256 chip");
+            let (mut proof, mut len, mut d) = (vec![0u8; cap], 0usize, [0u8; 32]);
+            check(unsafe { ffi::zkhip_prove_sha256(ctx.raw(), cbor.as_ptr(), cbor.len(), &prm, d.as_mut_ptr(), proof.as_mut_ptr(), cap, &mut len) }, "zkhip_prove_sha256")?;
+            proof.truncate(len);
+            let mut reason = 0;
+            check(unsafe { ffi::zkhip_verify_sha256(proof.as_ptr(), proof.len(), d.as_ptr(), &prm, &mut reason) }, "zkhip_verify_sha256")?;   // sp1.rs:120
+            proofs.push(proof);
+            (d.to_vec(), BATCH_FLAG_INPUT_SHA256)
+        } else if let Some(src) = self.source.as_mut() {
             let (output, shards) = src.shards(cbor, elf)?;
             for shard in &shards {
                 let prm = self.params(shard.log_n);

@@ -263,3 +263,50 @@ def test_a_failing_shard_worker_reports_instead_of_unwinding(lib, monkeypatch):
     assert rc != 0 and err
     rc, err, _, _ = call(lib, 2, b"x", b"elf", Plan(8, 8, 5, 10, 8), device=99)  # every worker fails to create its context
     assert rc != 0 and "zkhip_ctx_create" in err
+
+
+# ---- the input-commitment guest: SHA-256 of the request's input through the chip (HipGuestProver::with_input_commitment)
+def call_commitment(L, mode, cbor, elf, backend=0, queries=20, pow_bits=6, device=0):
+    L.zktls_guest_prove_commitment.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_char_p, C.c_size_t, C.c_char_p, C.c_size_t,
+                                               C.POINTER(C.POINTER(C.c_uint8)), C.POINTER(C.c_size_t), C.POINTER(C.POINTER(C.c_uint8)),
+                                               C.POINTER(C.c_size_t), C.c_char_p, C.c_size_t]
+    out, outn, pr, prn = C.POINTER(C.c_uint8)(), C.c_size_t(), C.POINTER(C.c_uint8)(), C.c_size_t()
+    err = C.create_string_buffer(512)
+    rc = L.zktls_guest_prove_commitment(backend, device, mode, queries, pow_bits, cbor, len(cbor), elf, len(elf),
+                                        C.byref(out), C.byref(outn), C.byref(pr), C.byref(prn), err, 512)
+    if rc != 0:
+        return rc, err.value.decode(), None, None
+    o = bytes(bytearray(out[i] for i in range(outn.value)))
+    p = bytes(bytearray(pr[i] for i in range(prn.value)))
+    L.zktls_free(out)
+    L.zktls_free(pr)
+    return 0, "", o, p
+
+
+def test_commitment_guest_mock_mode_outputs_the_sha256_of_the_input(lib):
+    import hashlib
+    cbor = open(os.path.join(REF, "guest_input0.cbor"), "rb").read()
+    rc, err, out, proof = call_commitment(lib, 0, cbor, b"\x7fELFguest")
+    assert rc == 0 and proof == b"" and out == hashlib.sha256(cbor).digest()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("backend", [0, 1])
+def test_commitment_guest_proves_the_reference_transcript(lib, backend):
+    """the recorded 13 217-byte transcript: 207 blocks -> 2^14 rows x 608 columns; the proof is a real statement about the
+    request (SHA-256 chip), checked by the library's verifier against hashlib's digest"""
+    import hashlib
+    from zktls_amd._lib import Params
+    from zktls_amd.device import verify_sha256
+    cbor = open(os.path.join(REF, "guest_input0.cbor"), "rb").read()
+    rc, err, out, blob = call_commitment(lib, 2, cbor, b"\x7fELFguest", backend)
+    assert rc == 0, err
+    assert out == hashlib.sha256(cbor).digest()
+    assert lib.zktls_batch_flags(blob, len(blob)) == 2           # INPUT_SHA256, not SYNTHETIC
+    offs, lens = (C.c_size_t * 2)(), (C.c_size_t * 2)()
+    assert lib.zktls_unpack_batch(blob, len(blob), offs, lens, 2) == 1
+    proof = np.frombuffer(blob[offs[0]:offs[0] + lens[0]], dtype=np.uint8)
+    prm = Params(1, 20, 6) if backend == 0 else Params(2, 20, 6, 0, 4, 6, 24)      # 2^14 rows: 64 final coefficients
+    assert verify_sha256(proof, out, prm) == (0, 0)
+    other = hashlib.sha256(cbor + b"x").digest()
+    assert verify_sha256(proof, other, prm)[0] == -6

@@ -22,10 +22,21 @@ for log_blocks in ([int(x) for x in sys.argv[1:]] or (4, 8, 10, 12, 14)):
     for _ in range(reps):
         digest, proof = ctx.prove_sha256(msg, prm)
     dt = (time.perf_counter() - t0) / reps
+    from zktls_amd.device import sha256_air, sha256_pad
+    blocks = sha256_pad(msg)
+    buf, limbs = ctx.sha256_gen_trace(blocks, 1 << log_blocks)
+    ctx.sync()
     t1 = time.perf_counter()
-    padded = ctx.sha256_gen_trace(msg + b"\x80" + bytes(8), 1 << log_blocks)
+    ctx.sha256_gen_trace(blocks, 1 << log_blocks, out=buf)
     ctx.sync()
     tg = time.perf_counter() - t1
+    prog = sha256_air()
+    ctx.prove_shard_air(prog, buf, log_blocks + 6, 608, limbs.tolist(), prm)
+    t2 = time.perf_counter()
+    ctx.prove_shard_air(prog, buf, log_blocks + 6, 608, limbs.tolist(), prm)
+    tp = time.perf_counter() - t2
+    print("   prove_shard_air on the resident trace alone: %.1f ms" % (tp * 1e3))
+    buf.free()
     assert digest == hashlib.sha256(msg).digest() and verify_sha256(proof, digest, prm) == (0, 0)
     print("2^%d blocks (%d bytes): rows 2^%d x 608, prove %.1f ms (trace gen alone %.1f ms), %.1f MB/s of message, %.2f G cells/s, proof %d bytes"
           % (log_blocks, n, log_blocks + 6, dt * 1e3, tg * 1e3, n / dt / 1e6, (608 << (log_blocks + 6)) / dt / 1e9, proof.size))

@@ -359,6 +359,15 @@ size_t zkhip_sha256_pad(const uint8_t* message, size_t len, uint8_t* blocks, siz
     return padded;
 }
 
+void zkhip_sha256_digest(const uint8_t* message, size_t len, uint8_t digest[32]) {
+    std::vector<uint8_t> blocks(((len + 9 + 63) / 64) * 64);
+    zkhip_sha256_pad(message, len, blocks.data(), blocks.size());
+    uint32_t h[8];
+    std::memcpy(h, sha::IV, 32);
+    for (size_t k = 0; k < blocks.size() / 64; k++) sha::compress(h, blocks.data() + 64 * k);
+    for (int i = 0; i < 8; i++) { digest[4 * i] = (uint8_t)(h[i] >> 24); digest[4 * i + 1] = (uint8_t)(h[i] >> 16); digest[4 * i + 2] = (uint8_t)(h[i] >> 8); digest[4 * i + 3] = (uint8_t)h[i]; }
+}
+
 int zkhip_sha256_gen_trace(zkhip_ctx* ctx, const uint8_t* blocks, size_t n_active, size_t n_blocks, uint32_t* d_trace, size_t ld,
                            uint32_t digest_limbs[16]) {
     CHECK_CTX(ctx);

@@ -335,12 +335,12 @@ class Context:
         return buf[: got.value]
 
     # ---- the SHA-256 compression chip (csrc/sha256_chip.hip)
-    def sha256_gen_trace(self, blocks, n_blocks=None):
+    def sha256_gen_trace(self, blocks, n_blocks=None, out=None):
         """blocks: bytes, a multiple of 64 long (padding included) -> (device trace [64 n_blocks][608], digest limbs [16])"""
         b = np.frombuffer(bytes(blocks), dtype=np.uint8)
         active = b.size // 64
         n_blocks = n_blocks or 1 << max(active - 1, 0).bit_length()
-        out = self.alloc(64 * n_blocks * 608)
+        out = out or self.alloc(64 * n_blocks * 608)
         limbs = np.zeros(16, dtype=np.uint32)
         check(self.lib.zkhip_sha256_gen_trace(self.handle, b.ctypes.data_as(u8p), active, n_blocks, C.c_void_p(out.ptr), 608, limbs.ctypes.data_as(u32p)))
         return out, limbs

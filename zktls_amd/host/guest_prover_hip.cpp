@@ -133,15 +133,51 @@ ProveResult HipGuestProver::prove_inner(const GuestInput& input, const std::vect
     r.output.resize(32);
     std::memcpy(r.output.data(), digest.data(), 32);
     if (mode_ == ProverType::Mock) {                  // executes nothing, returns a placeholder
+        if (commitment_) {                            // the commitment guest's output is cheap enough to compute without proving
+            r.output.assign(32, 0);
+            zkhip_sha256_digest(input.cbor.data(), input.cbor.size(), r.output.data());
+        }
         r.proof = {0, 0, 0, 0};
         r.ok = true;
         return r;
     }
     if (mode_ == ProverType::Network) throw std::runtime_error("network proving is not provided by the HIP backend");
     // Local and Hip both mean "prove on this machine"; there is no CPU path in libzkhip
+    if (commitment_) {
+        // the input-commitment guest: SHA-256 of the CBOR input through the chip, one proof, verified like sp1.rs:120
+        if (devices_.empty()) throw std::runtime_error("device list is empty");
+        const size_t padded = ((input.cbor.size() + 9 + 63) / 64) * 64;
+        int log_n = 6;                                   // 64 rows per block, block count rounded up to a power of two
+        while (((size_t)1 << (log_n - 6)) < padded / 64) log_n++;
+        zkhip_params prm{1, plan_.num_queries, plan_.pow_bits, 0, 0, 0, 0, 0};
+        if (backend_ == Backend::Risc0) {
+            int lf = 8;
+            while (lf > log_n || (log_n - lf) % 4 != 0) lf--;
+            const bool defaults = plan_.num_queries == 100 && plan_.pow_bits == 16;
+            prm = zkhip_params{2, defaults ? 50 : plan_.num_queries, defaults ? 0 : plan_.pow_bits, 0, 4, lf, 24, 0};
+        }
+        const size_t cap = zkhip_sha256_proof_size(input.cbor.size(), &prm);
+        if (cap == 0) throw std::runtime_error(std::string("input commitment: ") + zkhip_last_error());
+        zkhip_ctx* ctx = nullptr;
+        if (zkhip_ctx_create(devices_[0], nullptr, &ctx) != ZKHIP_OK) fail_zkhip("zkhip_ctx_create");
+        std::vector<uint8_t> proof(cap);
+        size_t len = 0;
+        uint8_t digest32[32];
+        const int rc = zkhip_prove_sha256(ctx, input.cbor.data(), input.cbor.size(), &prm, digest32, proof.data(), cap, &len);
+        const std::string msg = rc == ZKHIP_OK ? "" : zkhip_last_error();
+        zkhip_ctx_destroy(ctx);
+        if (rc != ZKHIP_OK) throw std::runtime_error("zkhip_prove_sha256: " + msg);
+        proof.resize(len);
+        int reason = 0;
+        if (zkhip_verify_sha256(proof.data(), proof.size(), digest32, &prm, &reason) != ZKHIP_OK) fail_zkhip("zkhip_verify_sha256");
+        r.output.assign(digest32, digest32 + 32);
+        r.proof = pack_shard_proofs({proof}, BATCH_FLAG_INPUT_SHA256);
+        r.ok = true;
+        return r;
+    }
     if (!synthetic_)
         throw std::runtime_error("no shard source: the zkVM executor that turns (input, ELF) into shard traces is not part of the HIP backend; "
-                                 "with_synthetic(plan) opts into proving synthetic shards (the blob is then flagged SYNTHETIC)");
+                                 "with_synthetic(plan) opts into proving synthetic shards (the blob is then flagged SYNTHETIC), with_input_commitment() into the SHA-256-of-the-input guest");
     if (plan_.shards == 0) throw std::runtime_error("shard plan is empty");
     if (devices_.empty()) throw std::runtime_error("device list is empty");
     zkhip_params prm{1, plan_.num_queries, plan_.pow_bits, 0, 0, 0, 0, 0};
@@ -296,6 +332,36 @@ int zktls_guest_prove_r0(int device, int mode, const zktls_shard_plan* plan, con
                          const uint8_t* elf, size_t elf_len, uint8_t** output, size_t* output_len, uint8_t** proof,
                          size_t* proof_len, char* err, size_t err_cap) {
     return guest_prove(zktls::Backend::Risc0, device, mode, plan, cbor, cbor_len, elf, elf_len, output, output_len, proof, proof_len, err, err_cap);
+}
+// the input-commitment guest (HipGuestProver::with_input_commitment): output = SHA-256 of the CBOR input, proof = a batch blob
+// flagged INPUT_SHA256 holding one SHA-256 chip proof; backend 0 SP1 shape, 1 RISC Zero shape
+int zktls_guest_prove_commitment(int backend, int device, int mode, int num_queries, int pow_bits, const uint8_t* cbor, size_t cbor_len,
+                                 const uint8_t* elf, size_t elf_len, uint8_t** output, size_t* output_len, uint8_t** proof,
+                                 size_t* proof_len, char* err, size_t err_cap) {
+    zktls::HipGuestProver p(device < 0 ? 0 : device, backend ? zktls::Backend::Risc0 : zktls::Backend::Sp1);
+    switch (mode) {
+        case 0: p.mock(); break;
+        case 1: p.local(); break;
+        case 2: p.hip(); break;
+        default: p.network(); break;
+    }
+    zktls::ShardPlan sp;
+    sp.num_queries = num_queries; sp.pow_bits = pow_bits;
+    p.with_input_commitment(sp);
+    zktls::GuestInput in;
+    in.cbor.assign(cbor, cbor + cbor_len);
+    zktls::ProveResult r = p.prove(in, std::vector<uint8_t>(elf, elf + elf_len));
+    if (!r.ok) {
+        if (err && err_cap) { std::strncpy(err, r.error.c_str(), err_cap - 1); err[err_cap - 1] = 0; }
+        return -1;
+    }
+    *output_len = r.output.size();
+    *output = (uint8_t*)std::malloc(r.output.size() ? r.output.size() : 1);
+    std::memcpy(*output, r.output.data(), r.output.size());
+    *proof_len = r.proof.size();
+    *proof = (uint8_t*)std::malloc(r.proof.size() ? r.proof.size() : 1);
+    std::memcpy(*proof, r.proof.data(), r.proof.size());
+    return 0;
 }
 void zktls_free(void* p) { std::free(p); }
 const char* zktls_current_risc0_prover_env(void) { const char* e = getenv("RISC0_PROVER"); return e ? e : ""; }

@@ -82,6 +82,8 @@ public:
     HipGuestProver& network() { mode_ = ProverType::Network; return *this; }
     // explicit opt-in to the synthetic shard plan (no zkVM executor wired): see the header comment
     HipGuestProver& with_synthetic(const ShardPlan& p) { plan_ = p; synthetic_ = true; return *this; }
+    // the input-commitment guest (see the header comment); num_queries / pow_bits of the proof come from `p`
+    HipGuestProver& with_input_commitment(const ShardPlan& p = ShardPlan{}) { plan_ = p; commitment_ = true; return *this; }
     bool synthetic() const { return synthetic_; }
     ProverType mode() const { return mode_; }
     Backend backend() const { return backend_; }
@@ -94,6 +96,7 @@ private:
     Backend backend_ = Backend::Sp1;
     ShardPlan plan_;
     bool synthetic_ = false;
+    bool commitment_ = false;
 };
 
 // prover.rs:30-57: `Risc0GuestProver::default().local()` etc.; segments are proven in RISC Zero's shape
@@ -109,9 +112,10 @@ void release_cached();
 // 8 canonical BabyBear words binding (input, ELF): the public values of every shard
 std::vector<uint32_t> request_digest(const std::vector<uint8_t>& cbor, const std::vector<uint8_t>& elf);
 
-// batch proof container: "ZKTB", version 2, flags (bit 0: SYNTHETIC shards, attests nothing about a guest), shard count,
+// batch proof container: "ZKTB", version 2, flags (bit 0: SYNTHETIC shards, attests nothing about a guest; bit 1: INPUT_SHA256), shard count,
 // then per shard (u32 length, bytes)
 constexpr uint32_t BATCH_FLAG_SYNTHETIC = 1u;
+constexpr uint32_t BATCH_FLAG_INPUT_SHA256 = 2u;     // one proof of the SHA-256 chip over the request's input bytes
 std::vector<uint8_t> pack_shard_proofs(const std::vector<std::vector<uint8_t>>& proofs, uint32_t flags);
 bool unpack_shard_proofs(const std::vector<uint8_t>& blob, std::vector<std::vector<uint8_t>>* proofs, uint32_t* flags = nullptr);
 
