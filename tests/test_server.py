@@ -133,3 +133,23 @@ def test_prove_core_returns_verified_proofs(server):
     assert st == 200
     st, ct, body = call(port, "ProveCore", pb_bytes(prove_payload(10, 16, 1, 100000, 8, cbor, elf)))
     assert st == 400 and json.loads(body)["code"] == "invalid_argument"           # the library's own argument check comes back as a Twirp error
+
+
+@pytest.mark.gpu
+def test_prove_core_input_commitment_guest(server):
+    """shards = 0 in the payload: the SHA-256-of-the-input guest; output = the digest, one chip proof in the blob"""
+    import hashlib
+    from zktls_amd._lib import Params
+    from zktls_amd.device import verify_sha256
+    cbor = bytes((3 * i + 1) & 0xff for i in range(5000))
+    st, ct, body = call(server, "ProveCore", pb_bytes(prove_payload(0, 0, 0, 16, 5, cbor, b"\x7fELFguest")))
+    assert st == 200, body
+    res = pb_field1(body)
+    on = struct.unpack_from("<I", res)[0]
+    output, blob = res[4:4 + on], res[4 + on:]
+    assert output == hashlib.sha256(cbor).digest()
+    magic, version, flags, count = struct.unpack_from("<4I", blob)
+    assert (magic, version, flags, count) == (0x42544B5A, 2, 2, 1)              # "ZKTB", flagged INPUT_SHA256
+    ln = struct.unpack_from("<I", blob, 16)[0]
+    assert 20 + ln == len(blob)
+    assert verify_sha256(np.frombuffer(blob[20:], dtype=np.uint8), output, Params(1, 16, 5)) == (0, 0)

@@ -15,7 +15,10 @@
 //       Setup      data = guest ELF bytes                   -> result = 32 bytes: zkhip_request_digest("", ELF) (a stand-in "vk digest")
 //       ProveCore  data = "ZKMG" u32 version(1) | i32 log_n | u32 width | u32 shards | i32 num_queries | i32 pow_bits |
 //                         u32 backend (0 SP1 shape, 1 RISC Zero shape) | i32 device (-1: all) | u32 cbor_len | cbor | u32 elf_len | elf
-//                                                            -> result = the batch blob of the host mirror (zktls_amd/host), flagged SYNTHETIC
+//                                                            -> result = u32 output length | output | the batch blob of the host mirror
+//                                                               (zktls_amd/host): flagged SYNTHETIC for shards > 0; shards = 0 asks for the
+//                                                               input-commitment guest (SHA-256 chip over the CBOR input, flag INPUT_SHA256,
+//                                                               output = the digest; log_n / width are ignored)
 //       Compress / Shrink / Wrap                             -> Twirp error `unimplemented` (recursion is out of scope)
 //     Swapping in upstream's payload structs is the remaining work once they can be read; the transport does not change.
 // One request at a time per connection, connections served one after the other (proofs serialise on the GPU anyway); 127.0.0.1 only
@@ -188,7 +191,8 @@ void handle(int fd) {
     if (!c.ok || c.p != data.size() || backend > 1) { twirp_error(fd, "invalid_argument", "ProveCore: truncated or oversized payload"); return; }
     zktls::HipGuestProver prover(device < 0 ? 0 : device, backend ? zktls::Backend::Risc0 : zktls::Backend::Sp1);
     if (device < 0) { std::vector<int> all; for (int d = 0; d < zkhip_device_count(); d++) all.push_back(d); if (!all.empty()) prover.with_devices(all); }
-    prover.hip().with_synthetic(plan);
+    if (plan.shards == 0) prover.hip().with_input_commitment(plan);
+    else prover.hip().with_synthetic(plan);
     const zktls::ProveResult r = prover.prove(in, elf);
     if (!r.ok) {
         const bool nodev = r.error.find("no CPU fallback") != std::string::npos || r.error.find("NO_DEVICE") != std::string::npos;
