@@ -72,6 +72,7 @@ def test_loader_changes_the_host_side_and_reset_restores_it(tmp_path):
     g = json.load(open(os.path.join(HERE, "golden", "oracle_kat.json")))["golden_proof_files"]["v1_6x8"]
     proof = np.frombuffer(open(os.path.join(HERE, "golden", "proofs", "v1_6x8.bin"), "rb").read(), dtype=np.uint8)
     assert verify_shard(proof, g["log_n"], g["width"], g["public"], Params(*g["shape"])) == (0, 0)
+    assert _air_verdict(L) == 0
     try:
         # the committed file IS the built-in set: loading it changes nothing
         assert L.zkhip_load_poseidon2_params(os.path.join(HERE, "golden", "poseidon2_params.json").encode()) == 0
@@ -83,10 +84,27 @@ def test_loader_changes_the_host_side_and_reset_restores_it(tmp_path):
         assert got != builtin and got == _py_digest(d, cbor, elf)          # follows the file, value pinned by the Python permutation
         # a proof made under the built-in set no longer verifies: transcript and Merkle hashes changed
         assert verify_shard(proof, g["log_n"], g["width"], g["public"], Params(*g["shape"]))[0] == -6
+        # the program-digest cache of the prover / verifier follows the table set (it is keyed by the set's generation)
+        assert _air_verdict(L) == -6
     finally:
         assert L.zkhip_reset_poseidon2_params() == 0
     assert _digest(L, cbor, elf) == builtin
     assert verify_shard(proof, g["log_n"], g["width"], g["public"], Params(*g["shape"])) == (0, 0)
+    assert _air_verdict(L) == 0
+
+
+def _air_verdict(L):
+    """a constraint-program proof made by the oracle under the BUILT-IN set, through the product's verifier (whose program digest
+    comes from its cache): 0 = accepted"""
+    import airs
+    import oracle_lib as O
+    from zktls_amd.device import verify_shard_air
+    prog = airs.fibonacci_program()
+    if not hasattr(_air_verdict, "proof"):
+        t, pub = airs.fibonacci_trace(6, 3, 5)
+        _air_verdict.pub = pub
+        _air_verdict.proof = O.prove_shard_air(prog, t, pub, O.default_params(1, 4, 4))
+    return verify_shard_air(prog, _air_verdict.proof, 6, 4, _air_verdict.pub, Params(1, 4, 4))[0]
 
 
 def test_loader_rejects_bad_files(tmp_path):

@@ -26,6 +26,7 @@ static P2Raw g_p2_raw = P2_BUILTIN_RAW;
 static std::string g_name16 = "zktls-amd/p2-bb16-v1", g_name24 = "zktls-amd/p2-bb24-v1";
 static std::mutex g_params_mu;
 std::atomic<int> g_live_contexts{0};
+std::atomic<uint64_t> g_p2_generation{0};     // bumped whenever the table set changes (caches of values derived from it check it)
 
 // every integer of the (possibly nested) JSON array that follows "key":
 static bool json_array(const std::string& text, const char* key, std::vector<uint64_t>& out) {
@@ -122,6 +123,7 @@ int zkhip_load_poseidon2_params(const char* path) {
     if (!tables_ok(raw, t)) return fail(ZKHIP_ERR_INTERNAL, "load_poseidon2_params: derived tables failed their self-check");
     g_p2_raw = raw;
     g_p2_tables = t;
+    g_p2_generation.fetch_add(1);
     const std::string name = json_string(text, "name");
     (width == 16 ? g_name16 : g_name24) = name.empty() ? std::string(path) : name;
     return ZKHIP_OK;
@@ -132,6 +134,7 @@ int zkhip_reset_poseidon2_params(void) {
     if (g_live_contexts.load() != 0) return fail(ZKHIP_ERR_INVALID, "reset_poseidon2_params: contexts exist");
     g_p2_raw = P2_BUILTIN_RAW;
     g_p2_tables = P2_BUILTIN;
+    g_p2_generation.fetch_add(1);
     g_name16 = "zktls-amd/p2-bb16-v1"; g_name24 = "zktls-amd/p2-bb24-v1";
     return ZKHIP_OK;
 }

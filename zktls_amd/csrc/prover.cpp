@@ -66,6 +66,30 @@ static bool shape_of(int log_n, const zkhip_params* prm, Shape& sh) {
     return true;
 }
 
+// The program digest is a sponge over every 16-bit half of the program (4 500 permutations for the 18 000-word SHA-256 chip: 6.5 ms
+// on the host), needed by the header and the transcript of every proof and verification: the last few programs' digests are kept,
+// keyed by the program's full contents (an exact comparison, ~5 us for that program).
+extern std::atomic<uint64_t> g_p2_generation;      // params.cpp: bumped when the Poseidon2 table set changes
+static void air_digest_cached(const AirView& a, uint32_t out[8]) {
+    struct Entry { std::vector<uint32_t> words; uint64_t generation; uint32_t dg[8]; };
+    static std::mutex mu;
+    static std::vector<Entry> cache;
+    const uint64_t gen = g_p2_generation.load();
+    {
+        std::lock_guard<std::mutex> lk(mu);
+        for (const Entry& e : cache)
+            if (e.generation == gen && e.words.size() == a.words && memcmp(e.words.data(), a.w, a.words * 4) == 0) { memcpy(out, e.dg, 32); return; }
+    }
+    air_digest(a, out);
+    std::lock_guard<std::mutex> lk(mu);
+    if (cache.size() >= 8) cache.erase(cache.begin());
+    Entry e;
+    e.words.assign(a.w, a.w + a.words);
+    e.generation = gen;
+    memcpy(e.dg, out, 32);
+    cache.push_back(std::move(e));
+}
+
 // `air`: the constraint program in effect (air.h) or null for the built-in synthetic AIR.  With a program the header always has
 // the extended form and the 8-word program digest follows it (proof version 7), all of it observed.
 static void transcript_init(Challenger& ch, int log_n, uint32_t width, const zkhip_params* prm, size_t n_public, const Shape& sh,
@@ -82,7 +106,7 @@ static void transcript_init(Challenger& ch, int log_n, uint32_t width, const zkh
         ch.observe_canonical((uint32_t)sh.F);
         ch.observe_canonical((uint32_t)sh.hw);
         uint32_t dg[8];
-        air_digest(*air, dg);
+        air_digest_cached(*air, dg);
         for (int i = 0; i < 8; i++) ch.observe_canonical(dg[i]);
         return;
     }
@@ -615,7 +639,7 @@ static int prove_shard_impl(zkhip_ctx* ctx, const uint32_t* d_trace, size_t ld, 
     pf[pos++] = (uint32_t)prm->log_blowup; pf[pos++] = (uint32_t)Q; pf[pos++] = (uint32_t)prm->pow_bits; pf[pos++] = (uint32_t)n_public;
     if (sh.ext || air) { pf[pos++] = LQ; pf[pos++] = (uint32_t)sh.K; pf[pos++] = (uint32_t)sh.F; pf[pos++] = (uint32_t)sh.hw; }
     else if (LQ) pf[pos++] = LQ;
-    if (air) { air_digest(*air, pf + pos); pos += 8; }
+    if (air) { air_digest_cached(*air, pf + pos); pos += 8; }
     if (CW) pf[pos++] = CW;
 
     Challenger ch;
@@ -1183,7 +1207,7 @@ static int verify_shard_impl(const uint8_t* proof, size_t len, int log_n, uint32
     } else if (LQ) { if (pf[8] != LQ) return reject(3); pos = 9; }
     if (air) {
         uint32_t dg[8];
-        air_digest(*air, dg);
+        air_digest_cached(*air, dg);
         for (int i = 0; i < 8; i++) if (pf[pos + i] != dg[i]) return reject(3);
         pos += 8;
     }
