@@ -405,6 +405,17 @@ int zkhip_verify_chips(const uint8_t* proof, size_t len, const int32_t* log_ns, 
                        const int32_t* partners, int n_chips,
                        const uint32_t* public_values, size_t n_public, const zkhip_params* prm, int* reason);
 
+/* chips with their own AIR: programs[c] is a constraint program (zkhip_prove_shard_air's format, degree <= 3, its n_public = the
+ * shard's) or NULL for the built-in synthetic AIR -- a machine of different tables in one proof (one commitment per phase, one FRI
+ * proof), as an SP1 shard is.  Proof version 9: each chip's header entry gains a has-program flag and the programs' digests follow
+ * the entries, all observed.  No lookups in this version (logup_pairs = 0, partner = -1 in every zkhip_chip). */
+size_t zkhip_chips_proof_size_air(const int32_t* log_ns, const uint32_t* widths, const uint32_t* const* programs, const size_t* program_words,
+                                  int n_chips, const zkhip_params* prm, size_t n_public);
+int zkhip_prove_chips_air(zkhip_ctx* ctx, const zkhip_chip* chips, const uint32_t* const* programs, const size_t* program_words, int n_chips,
+                          const uint32_t* public_values, size_t n_public, const zkhip_params* prm, uint8_t* proof, size_t cap, size_t* len);
+int zkhip_verify_chips_air(const uint8_t* proof, size_t len, const int32_t* log_ns, const uint32_t* widths, const uint32_t* const* programs,
+                           const size_t* program_words, int n_chips, const uint32_t* public_values, size_t n_public, const zkhip_params* prm, int* reason);
+
 /* ---- Poseidon2 parameter tables from a file: the built-in sets are this repo's own
  * ("zktls-amd/p2-bb16-v1", "...-bb24-v1"; the SP1 / RISC Zero tables of reference Cargo.lock:4030, 6172, 5057 are not
  * obtainable offline).  zkhip_load_poseidon2_params replaces the width-16 or the width-24 set (the file says which) for the

@@ -21,6 +21,9 @@
  * of a shard together (proof version 5).  Lookups BETWEEN chips (partners[]): two chips of equal height hold each
  * other's sender columns; every chip with pairs then exposes the final value C of its running sum, the last-row constraint
  * becomes S = C and the verifier checks sum C = 0 -- sp1-stark's local cumulative sums (proof version 6).
+ * Chips with their own AIR (orc_prove_chips_air): any chip may bring a constraint program (oracle/air.c, degree <= 3) instead of
+ * the synthetic AIR -- a machine of different tables, as an SP1 shard is.  Proof version 9: every chip's header entry gains a
+ * has-program flag and the 8-word digests of the programs follow the entries, all observed; no lookups in this version.
  */
 #include "oracle.h"
 #include "stark_internal.h"
@@ -33,13 +36,21 @@
 #define CHIPS_VERSION 4u
 #define CHIPS_VERSION_LOGUP 5u
 #define CHIPS_VERSION_CROSS 6u     /* some chips look each other up: cumulative sums are part of the proof */
+#define CHIPS_VERSION_AIR 9u       /* some chips carry a constraint program */
 #define MAX_CHIPS 16
+
+/* the programs in effect for the running orc_*_chips_air call (NULL: every chip uses the synthetic AIR) */
+static _Thread_local const uint32_t* const* g_progs = NULL;
+static _Thread_local const size_t* g_prog_words = NULL;
+static int any_prog(int n) { if (g_progs) for (int c = 0; c < n; c++) if (g_progs[c]) return 1; return 0; }
+static const uint32_t* prog_of(int c) { return g_progs ? g_progs[c] : NULL; }
 
 static bb4_t sample_ext(orc_challenger_t* ch) { bb4_t r; orc_chal_sample_ext(ch, r.c); return r; }
 
 static int any_pairs(const int* pairs, int n) { if (pairs) for (int c = 0; c < n; c++) if (pairs[c]) return 1; return 0; }
 static int any_cross(const int* partners, int n) { if (partners) for (int c = 0; c < n; c++) if (partners[c] >= 0) return 1; return 0; }
 static uint32_t chips_version(const int* pairs, const int* partners, int n) {
+    if (any_prog(n)) return CHIPS_VERSION_AIR;
     return any_cross(partners, n) ? CHIPS_VERSION_CROSS : (any_pairs(pairs, n) ? CHIPS_VERSION_LOGUP : CHIPS_VERSION);
 }
 static int chips_ok(const int* log_ns, const size_t* widths, const int* pairs, const int* partners, int n, const orc_params_t* prm) {
@@ -47,6 +58,7 @@ static int chips_ok(const int* log_ns, const size_t* widths, const int* pairs, c
     if (prm->log_blowup < 1 || prm->log_blowup > 3) return 0;
     if ((prm->log_fold != 0 && prm->log_fold != 1) || prm->log_final != 0 || (prm->hash_width != 0 && prm->hash_width != 16)) return 0;
     if (prm->logup_pairs != 0) return 0;
+    if (any_prog(n) && (any_pairs(pairs, n) || any_cross(partners, n))) return 0;      /* no lookups next to programs */
     for (int c = 0; c < n; c++) {
         if (log_ns[c] < 5 || log_ns[c] > 20 || widths[c] == 0 || widths[c] % 4 != 0 || widths[c] > 1024) return 0;
         if (c && log_ns[c] > log_ns[c - 1]) return 0;             /* tallest first */
@@ -70,6 +82,7 @@ size_t orc_chips_proof_size(const int* log_ns, const size_t* widths, const int* 
     const int lk = any_pairs(pairs, n), cross = any_cross(partners, n);
     size_t b = (size_t)prm->log_blowup, Hmax = (size_t)log_ns[0] + b, L = (size_t)log_ns[0];
     size_t words = 8 + (cross ? 4 : (lk ? 3 : 2)) * (size_t)n + 16 + (lk ? 8 : 0) + 8 * L + 4 + 1;
+    if (any_prog(n)) { words += (size_t)n; for (int c = 0; c < n; c++) if (prog_of(c)) words += 8; }
     size_t perq = 16 * Hmax, hp = 0;
     for (int c = 0; c < n; c++) {
         size_t wp = (pairs && pairs[c]) ? 4 * ((size_t)pairs[c] + 1) : 0;
@@ -95,7 +108,14 @@ static void transcript_init(orc_challenger_t* ch, const int* log_ns, const size_
         orc_chal_observe(ch, (uint32_t)log_ns[c]); orc_chal_observe(ch, (uint32_t)widths[c]);
         if (lk) orc_chal_observe(ch, (uint32_t)pairs[c]);
         if (cross) orc_chal_observe(ch, (uint32_t)(partners[c] + 1));
+        if (any_prog(n)) orc_chal_observe(ch, prog_of(c) ? 1u : 0u);
     }
+    for (int c = 0; c < n; c++)
+        if (prog_of(c)) {
+            uint32_t dg[8];
+            orc_air_digest(prog_of(c), g_prog_words[c], dg);
+            orc_chal_observe_slice(ch, dg, 8);
+        }
 }
 
 /* alpha-power offset of chip c inside the reduced-opening vector of its height: the chips of one height share one power
@@ -121,7 +141,9 @@ size_t orc_prove_chips(const uint32_t* const* traces, const int* log_ns, const s
         pf[pos++] = (uint32_t)log_ns[c]; pf[pos++] = (uint32_t)widths[c];
         if (lk) pf[pos++] = (uint32_t)pairs[c];
         if (cross) pf[pos++] = (uint32_t)(partners[c] + 1);
+        if (any_prog(n)) pf[pos++] = prog_of(c) ? 1u : 0u;
     }
+    for (int c = 0; c < n; c++) if (prog_of(c)) { orc_air_digest(prog_of(c), g_prog_words[c], pf + pos); pos += 8; }
     orc_challenger_t ch;
     transcript_init(&ch, log_ns, widths, pairs, partners, n, prm, n_public);
     bb4_t cumsum[MAX_CHIPS];
@@ -178,7 +200,8 @@ size_t orc_prove_chips(const uint32_t* const* traces, const int* log_ns, const s
         const int ln = log_ns[c], Hq = ln + 1;
         const size_t nc = (size_t)1 << ln, mc = (size_t)1 << lh[c], mq = (size_t)1 << Hq;
         uint32_t* qv = (uint32_t*)malloc(mq * 16);
-        orc_quotient_values_logup_c(tlde[c], ln, widths[c], plde[c], wp[c] ? pairs[c] : 0, gamma.c, beta_l.c, alpha.c, cumsum[c].c, qv);
+        if (prog_of(c)) orc_quotient_values_air(prog_of(c), tlde[c], ln, widths[c], public_values, alpha.c, 1, qv);
+        else orc_quotient_values_logup_c(tlde[c], ln, widths[c], plde[c], wp[c] ? pairs[c] : 0, gamma.c, beta_l.c, alpha.c, cumsum[c].c, qv);
         qlde[c] = (uint32_t*)malloc(mc * 8 * 4);
         uint32_t* chunk = (uint32_t*)malloc(nc * 16);
         uint32_t* clde = (uint32_t*)malloc(mc * 16);
@@ -360,7 +383,15 @@ int orc_verify_chips(const uint8_t* proof_bytes, size_t len, const int* log_ns, 
         pos += 2;
         if (lk) { if (pf[pos] != (uint32_t)pairs[c]) return 3; pos++; }
         if (cross) { if (pf[pos] != (uint32_t)(partners[c] + 1)) return 3; pos++; }
+        if (any_prog(n)) { if (pf[pos] != (prog_of(c) ? 1u : 0u)) return 3; pos++; }
     }
+    for (int c = 0; c < n; c++)
+        if (prog_of(c)) {
+            uint32_t dg[8];
+            orc_air_digest(prog_of(c), g_prog_words[c], dg);
+            if (memcmp(pf + pos, dg, 32) != 0) return 3;
+            pos += 8;
+        }
     for (size_t i = pos; i < len / 4; i++) if (pf[i] >= BB_P) return 4;
     int lh[MAX_CHIPS]; size_t w8[MAX_CHIPS], wp[MAX_CHIPS];
     for (int c = 0; c < n; c++) { lh[c] = log_ns[c] + b; w8[c] = 8; wp[c] = perm_width(pairs, c); }
@@ -405,7 +436,9 @@ int orc_verify_chips(const uint8_t* proof_bytes, size_t len, const int* log_ns, 
         bb4_t zn = bb4_pow(zeta, nc), zh = bb4_sub_base(zn, 1);
         bb4_t sel_first = bb4_mul(zh, bb4_inv(bb4_sub_base(zeta, 1)));
         bb4_t sel_trans = bb4_sub_base(zeta, bb_inv(gn));
-        bb4_t folded = orc__fold_constraints_ext(loc, nxt, W, sel_first, sel_trans, alpha);
+        bb4_t folded = prog_of(c) ? orc__air_fold_ext(prog_of(c), loc, nxt, public_values, sel_first,
+                                                        bb4_mul(zh, bb4_inv(bb4_sub_base(zeta, bb_inv(gn)))), sel_trans, alpha)
+                                  : orc__fold_constraints_ext(loc, nxt, W, sel_first, sel_trans, alpha);
         if (Wp) {
             const int Q = pairs[c];
             bb4_t sel_last = bb4_mul(zh, bb4_inv(bb4_sub_base(zeta, bb_inv(gn))));
@@ -520,4 +553,38 @@ int orc_verify_chips(const uint8_t* proof_bytes, size_t len, const int* log_ns, 
     free(fapow); free(betas);
     if (rc == 0 && pos * 4 != len) rc = 5;
     return rc;
+}
+
+
+/* ---- chips with their own constraint programs (progs[c] NULL: the synthetic AIR); every program of degree <= 3 ---- */
+static int progs_ok(const uint32_t* const* progs, const size_t* prog_words, const size_t* widths, int n, size_t n_public) {
+    if (!progs || !prog_words || n < 1 || n > MAX_CHIPS) return 0;
+    for (int c = 0; c < n; c++)
+        if (progs[c] && (!orc_air_validate(progs[c], prog_words[c], widths[c], n_public) || orc_air_log_quotient_degree(progs[c]) != 1)) return 0;
+    return 1;
+}
+size_t orc_chips_proof_size_air(const int* log_ns, const size_t* widths, const uint32_t* const* progs, const size_t* prog_words, int n,
+                                const orc_params_t* prm, size_t n_public) {
+    if (!progs_ok(progs, prog_words, widths, n, n_public)) return 0;
+    g_progs = progs; g_prog_words = prog_words;
+    size_t r = orc_chips_proof_size(log_ns, widths, NULL, NULL, n, prm, n_public);
+    g_progs = NULL; g_prog_words = NULL;
+    return r;
+}
+size_t orc_prove_chips_air(const uint32_t* const* traces, const int* log_ns, const size_t* widths, const uint32_t* const* progs,
+                           const size_t* prog_words, int n, const uint32_t* public_values, size_t n_public, const orc_params_t* prm,
+                           uint8_t* proof_bytes, size_t cap) {
+    if (!progs_ok(progs, prog_words, widths, n, n_public)) return 0;
+    g_progs = progs; g_prog_words = prog_words;
+    size_t r = orc_prove_chips(traces, log_ns, widths, NULL, NULL, n, public_values, n_public, prm, proof_bytes, cap);
+    g_progs = NULL; g_prog_words = NULL;
+    return r;
+}
+int orc_verify_chips_air(const uint8_t* proof_bytes, size_t len, const int* log_ns, const size_t* widths, const uint32_t* const* progs,
+                         const size_t* prog_words, int n, const uint32_t* public_values, size_t n_public, const orc_params_t* prm) {
+    if (!progs_ok(progs, prog_words, widths, n, n_public)) return 1;
+    g_progs = progs; g_prog_words = prog_words;
+    int r = orc_verify_chips(proof_bytes, len, log_ns, widths, NULL, NULL, n, public_values, n_public, prm);
+    g_progs = NULL; g_prog_words = NULL;
+    return r;
 }

@@ -357,6 +357,50 @@ def prove_chips(traces, public_values=(), params=None, pairs=None, partners=None
     return buf
 
 
+def _progs_args(progs):
+    n = len(progs)
+    keep = [(_u32(p) if p is not None else None) for p in progs]
+    ptrs = (u32p * n)(*[(_p(p) if p is not None else None) for p in keep])
+    words = (C.c_size_t * n)(*[(p.size if p is not None else 0) for p in keep])
+    return keep, ptrs, words
+
+
+def prove_chips_air(traces, progs, public_values=(), params=None):
+    """chips with their own constraint programs (progs[c] None: the synthetic AIR), tallest first; proof version 9"""
+    params = params or default_params()
+    ts = [_u32(t) for t in traces]
+    n = len(ts)
+    log_ns = (C.c_int * n)(*[t.shape[0].bit_length() - 1 for t in ts])
+    widths = (C.c_size_t * n)(*[t.shape[1] for t in ts])
+    ptrs = (u32p * n)(*[_p(t) for t in ts])
+    pv = _u32(np.array(public_values, dtype=np.uint32))
+    keep, pp, pw = _progs_args(progs)
+    L = lib()
+    L.orc_chips_proof_size_air.restype = C.c_size_t
+    L.orc_prove_chips_air.restype = C.c_size_t
+    size = L.orc_chips_proof_size_air(log_ns, widths, pp, pw, C.c_int(n), C.byref(params), C.c_size_t(pv.size))
+    if size == 0:
+        raise RuntimeError("oracle: bad chip set or program")
+    buf = np.empty(size, dtype=np.uint8)
+    got = L.orc_prove_chips_air(ptrs, log_ns, widths, pp, pw, C.c_int(n), _p(pv), C.c_size_t(pv.size), C.byref(params),
+                                buf.ctypes.data_as(C.POINTER(C.c_uint8)), C.c_size_t(size))
+    if got != size:
+        raise RuntimeError("oracle prove_chips_air failed")
+    return buf
+
+
+def verify_chips_air(proof, log_ns, widths, progs, public_values=(), params=None):
+    params = params or default_params()
+    pr = np.ascontiguousarray(proof, dtype=np.uint8)
+    n = len(log_ns)
+    ln = (C.c_int * n)(*[int(x) for x in log_ns])
+    ws = (C.c_size_t * n)(*[int(x) for x in widths])
+    pv = _u32(np.array(public_values, dtype=np.uint32))
+    keep, pp, pw = _progs_args(progs)
+    return int(lib().orc_verify_chips_air(pr.ctypes.data_as(C.POINTER(C.c_uint8)), C.c_size_t(pr.size), ln, ws, pp, pw, C.c_int(n),
+                                          _p(pv), C.c_size_t(pv.size), C.byref(params)))
+
+
 def verify_chips(proof, log_ns, widths, public_values=(), params=None, pairs=None, partners=None):
     params = params or default_params()
     pr = np.ascontiguousarray(proof, dtype=np.uint8)

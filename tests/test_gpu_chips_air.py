@@ -1,0 +1,66 @@
+"""Chips with their own constraint programs on the GPU (zkhip_prove_chips_air, proof version 9): bytes against the oracle on mixed
+sets, and a machine with the SHA-256 compression chip as one of its tables."""
+import hashlib
+
+import numpy as np
+import pytest
+
+import airs
+import sha256_air as S
+from zktls_amd._lib import Params, ZkHipError
+from zktls_amd.device import sha256_air, verify_chips_air
+
+pytestmark = pytest.mark.gpu
+SEED = 0x5A4B544C53
+P = 2013265921
+
+
+@pytest.mark.parametrize("shape", [(1, 8, 4), (2, 6, 0), (3, 5, 2)])
+def test_mixed_chip_set_bytes_equal_the_oracles(ctx, oracle, shape):
+    O = oracle
+    fib = airs.fibonacci_program()
+    ft, pub = airs.fibonacci_trace(6, 3, 5)
+    cnt = airs.counter_program(16).copy()
+    cnt[4] = 3
+    ct, _ = airs.counter_trace(10, 16, 3, 5)
+    syn = O.gen_trace(SEED, 2, 9, 12)
+    syn2 = O.gen_trace(SEED, 3, 9, 8)
+    traces, progs = [ct, syn, syn2, ft], [cnt, None, None, fib]
+    chips = [(ctx.from_numpy(t), t.shape[0].bit_length() - 1, t.shape[1]) for t in traces]
+    proof = ctx.prove_chips_air(chips, progs, pub, Params(*shape))
+    oproof = O.prove_chips_air(traces, progs, pub, O.default_params(*shape))
+    assert proof.tobytes() == oproof.tobytes()
+    log_ns, widths = [c[1] for c in chips], [c[2] for c in chips]
+    assert verify_chips_air(proof, log_ns, widths, progs, pub, Params(*shape)) == (0, 0)
+    assert O.verify_chips_air(proof, log_ns, widths, progs, pub, O.default_params(*shape)) == 0
+
+
+def test_a_machine_with_the_sha256_chip(ctx, oracle):
+    """the SHA-256 chip (2^10 rows x 608) next to a counter table and a synthetic table: one proof, bytes equal the oracle's"""
+    O = oracle
+    msg = bytes(range(200)) * 4                                    # 800 bytes -> 13 blocks -> 16 blocks
+    sha_t, sha_pub = S.trace(S.pad(msg))
+    assert S.digest_bytes(sha_pub) == hashlib.sha256(msg).digest()
+    d_sha, limbs = ctx.sha256_gen_trace(S.pad(msg))
+    assert limbs.tolist() == sha_pub
+    cnt = airs.counter_program(8).copy()
+    cnt[4] = 16                                                    # over the shard's 16 public values: start = limb 0, step = limb 1
+    ct, _ = airs.counter_trace(8, 8, sha_pub[0], sha_pub[1])
+    syn = O.gen_trace(SEED, 5, 6, 4)
+    progs = [sha256_air(), cnt, None]
+    chips = [(d_sha, 10, 608), (ctx.from_numpy(ct), 8, 8), (ctx.from_numpy(syn), 6, 4)]
+    proof = ctx.prove_chips_air(chips, progs, sha_pub, Params(1, 10, 4))
+    oproof = O.prove_chips_air([sha_t, ct, syn], [S.program(), cnt, None], sha_pub, O.default_params(1, 10, 4))
+    assert proof.tobytes() == oproof.tobytes()
+    assert verify_chips_air(proof, [10, 8, 6], [608, 8, 4], progs, sha_pub, Params(1, 10, 4)) == (0, 0)
+    wrong = list(sha_pub)
+    wrong[7] ^= 1
+    assert verify_chips_air(proof, [10, 8, 6], [608, 8, 4], progs, wrong, Params(1, 10, 4))[0] == -6
+
+
+def test_misuse_fails_loudly(ctx, oracle):
+    t = ctx.from_numpy(oracle.gen_trace(SEED, 1, 6, 4))
+    with pytest.raises(ZkHipError):
+        ctx.prove_chips_air([(t, 6, 4)], [airs.quintic_program()], [1], Params(2, 5, 3))          # degree 5
+    with pytest.raises(ZkHipError):
+        ctx.prove_chips_air([(t, 6, 4)], [airs.fibonacci_program()], [1, 2], Params(1, 5, 3))     # n_public mismatch

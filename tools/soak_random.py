@@ -5,17 +5,41 @@ sys.path.insert(0, "/root/repo"); sys.path.insert(0, "/root/repo/tests")
 import numpy as np
 import oracle_lib as O
 import airs
-from zktls_amd.device import Context, verify_shard, verify_chips, verify_shard_air
+from zktls_amd.device import Context, verify_shard, verify_chips, verify_shard_air, verify_chips_air
 from zktls_amd._lib import Params
 O.set_threads(8)
 budget = float(sys.argv[1]) if len(sys.argv) > 1 else 60.0
 rng = np.random.default_rng(int(time.time()))
 ctx = Context(0)
-t0 = time.time(); n_single = n_chips = n_air = 0
+t0 = time.time(); n_single = n_chips = n_air = n_machine = 0
 SEED = int(rng.integers(1, 2**40))
 while time.time() - t0 < budget:
     r_kind = rng.random()
-    if r_kind < 0.2:
+    if r_kind < 0.1:
+        # a machine: several tables with their own constraint programs (or the synthetic AIR) in one proof -- version 9.
+        # Table 0 is a pseudo-random degree-<=3 AIR; counter tables and synthetic tables share its three public values.
+        n = int(rng.integers(1, 7))
+        hs = sorted((int(x) for x in rng.integers(5, 11, n)), reverse=True)
+        if max(hs.count(x) for x in hs) > 4: continue
+        w0 = 4 * int(rng.integers(1, 6))
+        prog0, t0_, pub = airs.random_program_and_trace(int(rng.integers(0, 2**31)), hs[0], w0, int(rng.choice([2, 3])))
+        traces, progs = [t0_], [prog0]
+        for i, hgt in enumerate(hs[1:], 1):
+            w = 4 * int(rng.integers(1, 10))
+            if rng.random() < 0.5:
+                cp = airs.counter_program(w).copy(); cp[4] = 3
+                traces.append(airs.counter_trace(hgt, w, pub[0], pub[1])[0]); progs.append(cp)
+            else:
+                traces.append(O.gen_trace(SEED, i, hgt, w)); progs.append(None)
+        prm = (int(rng.integers(1, 4)), int(rng.integers(1, 12)), int(rng.integers(0, 7)))
+        dev = [ctx.from_numpy(t) for t in traces]
+        lns, ws = [t.shape[0].bit_length() - 1 for t in traces], [t.shape[1] for t in traces]
+        pf = ctx.prove_chips_air(list(zip(dev, lns, ws)), progs, pub, Params(*prm))
+        assert pf.tobytes() == O.prove_chips_air(traces, progs, pub, O.default_params(*prm)).tobytes(), ("machine", lns, ws, prm)
+        assert verify_chips_air(pf, lns, ws, progs, pub, Params(*prm)) == (0, 0)
+        for d in dev: d.free()
+        n_machine += 1
+    elif r_kind < 0.25:
         # a pseudo-random AIR supplied as a constraint program (degree 2..5: two or four quotient chunks)
         log_n, width, maxdeg = int(rng.integers(5, 11)), 4 * int(rng.integers(1, 6)), int(rng.choice([2, 3, 4, 5]))
         prog, trace, pub = airs.random_program_and_trace(int(rng.integers(0, 2**31)), log_n, width, maxdeg)
@@ -72,4 +96,5 @@ while time.time() - t0 < budget:
         assert verify_chips(pf, [c[0] for c in chips], [c[1] for c in chips], [7], Params(*prm), prs, pas if cross else None) == (0, 0)
         for d in dev: d.free()
         n_chips += 1
-print("ok: %d single-matrix, %d multi-chip and %d constraint-program configurations in %.0f s" % (n_single, n_chips, n_air, time.time() - t0))
+print("ok: %d single-matrix, %d multi-chip, %d constraint-program and %d machine (chips with programs) configurations in %.0f s"
+      % (n_single, n_chips, n_air, n_machine, time.time() - t0))

@@ -31,6 +31,7 @@ EXPORTS = [
     "zkhip_load_poseidon2_params", "zkhip_reset_poseidon2_params", "zkhip_poseidon2_params_name",
     "zkhip_air_validate", "zkhip_air_digest", "zkhip_air_synthetic", "zkhip_proof_size_air", "zkhip_prove_shard_air", "zkhip_verify_shard_air",
     "zkhip_quotient_values_air",
+    "zkhip_chips_proof_size_air", "zkhip_prove_chips_air", "zkhip_verify_chips_air",
     "zkhip_sha256_air", "zkhip_sha256_digest", "zkhip_sha256_pad", "zkhip_sha256_gen_trace", "zkhip_sha256_proof_size", "zkhip_prove_sha256", "zkhip_verify_sha256",
 ]
 
@@ -148,6 +149,12 @@ def load():
                                         C.POINTER(Params), u8p, C.c_size_t, C.POINTER(C.c_size_t)]
     L.zkhip_verify_shard_air.argtypes = [u32p, C.c_size_t, u8p, C.c_size_t, C.c_int, C.c_uint32, u32p, C.c_size_t, C.POINTER(Params), C.POINTER(C.c_int)]
     L.zkhip_quotient_values_air.argtypes = [C.c_void_p, u32p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_int, C.c_uint32, u32p, C.c_size_t, u32p, C.c_void_p]
+    u32pp, szp = C.POINTER(u32p), C.POINTER(C.c_size_t)
+    L.zkhip_chips_proof_size_air.restype = C.c_size_t
+    L.zkhip_chips_proof_size_air.argtypes = [C.POINTER(C.c_int32), C.POINTER(C.c_uint32), u32pp, szp, C.c_int, C.POINTER(Params), C.c_size_t]
+    L.zkhip_prove_chips_air.argtypes = [C.c_void_p, C.POINTER(Chip), u32pp, szp, C.c_int, u32p, C.c_size_t, C.POINTER(Params), u8p, C.c_size_t, szp]
+    L.zkhip_verify_chips_air.argtypes = [u8p, C.c_size_t, C.POINTER(C.c_int32), C.POINTER(C.c_uint32), u32pp, szp, C.c_int, u32p, C.c_size_t,
+                                         C.POINTER(Params), C.POINTER(C.c_int)]
     L.zkhip_sha256_air.restype = C.c_size_t
     L.zkhip_sha256_air.argtypes = [u32p, C.c_size_t]
     L.zkhip_sha256_digest.restype = None

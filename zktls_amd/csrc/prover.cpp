@@ -1415,13 +1415,24 @@ int zkhip_verify_shard_air(const uint32_t* program, size_t program_words, const 
 // vector per height that joins the FRI vector when folding reaches that height (p3-fri 0.2.1 TwoAdicFriPcs), one query
 // index with chip c opened at index >> (Hmax - h_c).  Byte layout: DESIGN.md section 6.
 namespace zk {
-constexpr uint32_t CHIPS_VERSION = 4u, CHIPS_VERSION_LOGUP = 5u, CHIPS_VERSION_CROSS = 6u;
+constexpr uint32_t CHIPS_VERSION = 4u, CHIPS_VERSION_LOGUP = 5u, CHIPS_VERSION_CROSS = 6u, CHIPS_VERSION_AIR = 9u;
 constexpr int MAX_CHIPS = 16;
+
+// The constraint programs in effect for the running zkhip_*_chips_air call on this thread (nullptr: every chip uses the built-in
+// synthetic AIR).  Version 9: each chip's header entry gains a has-program flag, the programs' digests follow the entries.
+static thread_local const AirView* const* t_chip_air = nullptr;
+static bool any_prog(int n) { if (t_chip_air) for (int c = 0; c < n; c++) if (t_chip_air[c]) return true; return false; }
+static const AirView* prog_of(int c) { return t_chip_air ? t_chip_air[c] : nullptr; }
+struct ChipAirScope {
+    explicit ChipAirScope(const AirView* const* table) { t_chip_air = table; }
+    ~ChipAirScope() { t_chip_air = nullptr; }
+};
 
 static bool any_pairs(const int32_t* pairs, int n) { if (pairs) for (int c = 0; c < n; c++) if (pairs[c]) return true; return false; }
 static size_t perm_width(const int32_t* pairs, int c) { return (pairs && pairs[c]) ? 4 * ((size_t)pairs[c] + 1) : 0; }
 static bool any_cross(const int32_t* partners, int n) { if (partners) for (int c = 0; c < n; c++) if (partners[c] >= 0) return true; return false; }
 static uint32_t chips_version(const int32_t* pairs, const int32_t* partners, int n) {
+    if (any_prog(n)) return CHIPS_VERSION_AIR;
     return any_cross(partners, n) ? CHIPS_VERSION_CROSS : (any_pairs(pairs, n) ? CHIPS_VERSION_LOGUP : CHIPS_VERSION);
 }
 static int check_chips(const int32_t* log_ns, const uint32_t* widths, const int32_t* pairs, const int32_t* partners, int n, const zkhip_params* prm) {
@@ -1431,6 +1442,7 @@ static int check_chips(const int32_t* log_ns, const uint32_t* widths, const int3
     if ((prm->log_fold != 0 && prm->log_fold != 1) || prm->log_final != 0 || (prm->hash_width != 0 && prm->hash_width != 16) || prm->logup_pairs != 0 || prm->code_width != 0)
         return fail(ZKHIP_ERR_INVALID, "chips: the multi-chip prover uses the SP1 FRI shape (fold by 2, constant final polynomial, width-16 hash) without lookups");
     if (prm->num_queries < 1 || prm->num_queries > 4096 || prm->pow_bits < 0 || prm->pow_bits > 28) return fail(ZKHIP_ERR_INVALID, "chips: queries / pow_bits out of range");
+    if (any_prog(n) && (any_pairs(pairs, n) || any_cross(partners, n))) return fail(ZKHIP_ERR_INVALID, "chips: no lookups next to constraint programs");
     for (int c = 0; c < n; c++) {
         if (log_ns[c] < 5 || log_ns[c] > 20 || widths[c] == 0 || widths[c] % 4 != 0 || widths[c] > 1024)
             return fail(ZKHIP_ERR_INVALID, "chips: log_n in [5,20], width a multiple of 4 up to 1024");
@@ -1451,6 +1463,7 @@ static size_t chips_proof_words(const int32_t* log_ns, const uint32_t* widths, c
     const bool lk = any_pairs(pairs, n), cross = any_cross(partners, n);
     const size_t b = (size_t)prm->log_blowup, Hmax = (size_t)log_ns[0] + b, L = (size_t)log_ns[0];
     size_t words = 8 + (cross ? 4 : (lk ? 3 : 2)) * (size_t)n + 16 + (lk ? 8 : 0) + 8 * L + 4 + 1, perq = 16 * Hmax, hp = 0;
+    if (any_prog(n)) { words += (size_t)n; for (int c = 0; c < n; c++) if (prog_of(c)) words += 8; }
     for (int c = 0; c < n; c++) {
         const size_t wp = perm_width(pairs, c);
         words += 8 * (size_t)widths[c] + 8 * wp + 32 + ((cross && wp) ? 4 : 0);
@@ -1474,7 +1487,14 @@ static void chips_transcript_init(Challenger& ch, const int32_t* log_ns, const u
         ch.observe_canonical((uint32_t)log_ns[c]); ch.observe_canonical(widths[c]);
         if (lk) ch.observe_canonical((uint32_t)pairs[c]);
         if (cross) ch.observe_canonical((uint32_t)(partners[c] + 1));
+        if (any_prog(n)) ch.observe_canonical(prog_of(c) ? 1u : 0u);
     }
+    for (int c = 0; c < n; c++)
+        if (prog_of(c)) {
+            uint32_t dg[8];
+            air_digest_cached(*prog_of(c), dg);
+            for (int i = 0; i < 8; i++) ch.observe_canonical(dg[i]);
+        }
 }
 // alpha-power offset of chip c inside the reduced-opening vector of its height
 static uint64_t height_offset(const int32_t* log_ns, const uint32_t* widths, const int32_t* pairs, int c) {
@@ -1543,7 +1563,9 @@ int zkhip_prove_chips(zkhip_ctx* ctx, const zkhip_chip* chips, int n, const uint
         pf[pos++] = (uint32_t)log_ns[c]; pf[pos++] = widths[c];
         if (lk) pf[pos++] = (uint32_t)pairs[c];
         if (cross) pf[pos++] = (uint32_t)(partners[c] + 1);
+        if (any_prog(n)) pf[pos++] = prog_of(c) ? 1u : 0u;
     }
+    for (int c = 0; c < n; c++) if (prog_of(c)) { air_digest_cached(*prog_of(c), pf + pos); pos += 8; }
     Challenger ch;
     chips_transcript_init(ch, log_ns, widths, pairs, partners, n, prm, n_public);
     uint32_t root[8];
@@ -1603,7 +1625,9 @@ int zkhip_prove_chips(zkhip_ctx* ctx, const zkhip_chip* chips, int n, const uint
         LogupIn lu;
         if (wp[c]) { lu.pairs = (uint32_t)pairs[c]; lu.perm_lde = plde + pl_off[c]; lu.gamma = gamma; lu.beta = beta_l; lu.cumsum = cumsum[c]; }
         const bool own_coset_direct = b == 1;             // as in the single-matrix prover
-        ZK_TRY(run_quotient(ctx, tlde + tl_off[c], widths[c], log_ns[c], widths[c], alpha, lu, qchunk, own_coset_direct ? qlde + ql_off[c] : nullptr, 8));
+        if (prog_of(c)) ZK_TRY(run_quotient_air(ctx, *prog_of(c), tlde + tl_off[c], widths[c], log_ns[c], widths[c], public_values, alpha, qchunk,
+                                                own_coset_direct ? qlde + ql_off[c] : nullptr, 8));
+        else ZK_TRY(run_quotient(ctx, tlde + tl_off[c], widths[c], log_ns[c], widths[c], alpha, lu, qchunk, own_coset_direct ? qlde + ql_off[c] : nullptr, 8));
         const uint32_t w2n = two_adic_generator(log_ns[c] + 1);
         for (int k = 0; k < 2; k++) {
             if (own_coset_direct)
@@ -1811,7 +1835,15 @@ int zkhip_verify_chips(const uint8_t* proof, size_t len, const int32_t* log_ns, 
         pos += 2;
         if (lk) { if (pf[pos] != (uint32_t)pairs[c]) return reject(3); pos++; }
         if (cross) { if (pf[pos] != (uint32_t)(partners[c] + 1)) return reject(3); pos++; }
+        if (any_prog(n)) { if (pf[pos] != (prog_of(c) ? 1u : 0u)) return reject(3); pos++; }
     }
+    for (int c = 0; c < n; c++)
+        if (prog_of(c)) {
+            uint32_t dg[8];
+            air_digest_cached(*prog_of(c), dg);
+            for (int i = 0; i < 8; i++) if (pf[pos + i] != dg[i]) return reject(3);
+            pos += 8;
+        }
     for (size_t i = pos; i < len / 4; i++) if (pf[i] >= P) return reject(4);
     for (size_t i = 0; i < n_public; i++) if (public_values[i] >= P) return reject(4);
     int lh[MAX_CHIPS]; uint32_t w8[MAX_CHIPS]; size_t wp[MAX_CHIPS];
@@ -1861,7 +1893,9 @@ int zkhip_verify_chips(const uint8_t* proof, size_t len, const int32_t* log_ns, 
         const Ext sel_first = ext_mul(zh, ext_inv(ext_sub_base(zeta, MONTY_R1)));
         const Ext sel_trans = ext_sub_base(zeta, finv(gn));
         Ext acc = ext_zero();
-        for (uint32_t g = 0; g < widths[c] / 4; g++) {
+        if (prog_of(c))
+            acc = air_fold_ext(*prog_of(c), loc[c].data(), nxt[c].data(), public_values, sel_first, ext_mul(zh, ext_inv(ext_sub_base(zeta, finv(gn)))), sel_trans, alpha);
+        else for (uint32_t g = 0; g < widths[c] / 4; g++) {
             const Ext &a = loc[c][4 * g], &bb = loc[c][4 * g + 1], &cc = loc[c][4 * g + 2], &d = loc[c][4 * g + 3], &dn = nxt[c][4 * g + 3];
             const uint32_t k1 = to_monty(g + 1), k2 = to_monty(2 * g + 3), d0 = to_monty(5 * g + 7);
             const Ext c1 = ext_sub_base(ext_sub(cc, ext_mul(ext_mul(a, a), bb)), k1);
@@ -1991,6 +2025,50 @@ int zkhip_verify_chips(const uint8_t* proof, size_t len, const int32_t* log_ns, 
     }
     if (pos * 4 != len) return reject(5);
     return ZKHIP_OK;
+}
+
+// ---- chips with their own constraint programs (programs[c] == NULL: the built-in synthetic AIR); degree <= 3, no lookups ----
+static int chip_programs(const uint32_t* const* programs, const size_t* program_words, const uint32_t* widths, int n, size_t n_public,
+                         AirView* views, const AirView** table) {
+    if (!programs || !program_words || !widths || n < 1 || n > MAX_CHIPS) return fail(ZKHIP_ERR_INVALID, "chips_air: bad arguments");
+    for (int c = 0; c < n; c++) {
+        table[c] = nullptr;
+        if (!programs[c]) continue;
+        if (!air_validate(programs[c], program_words[c], widths[c], n_public, &views[c])) return fail(ZKHIP_ERR_INVALID, "chips_air: malformed constraint program (or its n_public differs from the shard's)");
+        if (views[c].lqd != 1) return fail(ZKHIP_ERR_INVALID, "chips_air: programs of degree 4 / 5 need four quotient chunks; the multi-chip prover commits two");
+        table[c] = &views[c];
+    }
+    return ZKHIP_OK;
+}
+size_t zkhip_chips_proof_size_air(const int32_t* log_ns, const uint32_t* widths, const uint32_t* const* programs, const size_t* program_words,
+                                  int n_chips, const zkhip_params* prm, size_t n_public) {
+    AirView views[MAX_CHIPS];
+    const AirView* table[MAX_CHIPS];
+    if (chip_programs(programs, program_words, widths, n_chips, n_public, views, table) != ZKHIP_OK) return 0;
+    ChipAirScope scope(table);
+    return zkhip_chips_proof_size(log_ns, widths, nullptr, nullptr, n_chips, prm, n_public);
+}
+int zkhip_prove_chips_air(zkhip_ctx* ctx, const zkhip_chip* chips, const uint32_t* const* programs, const size_t* program_words, int n_chips,
+                          const uint32_t* public_values, size_t n_public, const zkhip_params* prm, uint8_t* proof, size_t cap, size_t* len) {
+    if (!chips || n_chips < 1 || n_chips > MAX_CHIPS) return fail(ZKHIP_ERR_INVALID, "prove_chips_air: bad arguments");
+    uint32_t widths[MAX_CHIPS];
+    for (int c = 0; c < n_chips; c++) {
+        widths[c] = chips[c].width;
+        if (chips[c].logup_pairs || chips[c].partner >= 0) return fail(ZKHIP_ERR_INVALID, "prove_chips_air: no lookups next to constraint programs");
+    }
+    AirView views[MAX_CHIPS];
+    const AirView* table[MAX_CHIPS];
+    ZK_TRY(chip_programs(programs, program_words, widths, n_chips, n_public, views, table));
+    ChipAirScope scope(table);
+    return zkhip_prove_chips(ctx, chips, n_chips, public_values, n_public, prm, proof, cap, len);
+}
+int zkhip_verify_chips_air(const uint8_t* proof, size_t len, const int32_t* log_ns, const uint32_t* widths, const uint32_t* const* programs,
+                           const size_t* program_words, int n_chips, const uint32_t* public_values, size_t n_public, const zkhip_params* prm, int* reason) {
+    AirView views[MAX_CHIPS];
+    const AirView* table[MAX_CHIPS];
+    if (chip_programs(programs, program_words, widths, n_chips, n_public, views, table) != ZKHIP_OK) { if (reason) *reason = 1; return ZKHIP_ERR_VERIFY; }
+    ChipAirScope scope(table);
+    return zkhip_verify_chips(proof, len, log_ns, widths, nullptr, nullptr, n_chips, public_values, n_public, prm, reason);
 }
 
 int zkhip_last_prove_debug(zkhip_ctx* ctx, zkhip_prove_debug* out) {

@@ -417,6 +417,25 @@ class Context:
                                          buf.ctypes.data_as(u8p), size, C.byref(got)))
         return buf[: got.value]
 
+    def prove_chips_air(self, chips, programs, public_values=(), params=None):
+        """chips: [(device buffer, log_n, width), ...] tallest first; programs[c]: a constraint program (numpy u32 words, degree <= 3)
+        or None for the built-in synthetic AIR -- several different AIR tables in one proof (version 9)"""
+        params = params or Params(1, 100, 16, 0)
+        n = len(chips)
+        arr = (_lib.Chip * n)(*[_lib.Chip(b.ptr, w, ln, w, 0, -1) for b, ln, w in chips])
+        log_ns = (C.c_int32 * n)(*[c[1] for c in chips])
+        widths = (C.c_uint32 * n)(*[c[2] for c in chips])
+        keep, pp, pw = _program_table(programs)
+        pv = np.ascontiguousarray(np.array(public_values, dtype=np.uint32))
+        size = self.lib.zkhip_chips_proof_size_air(log_ns, widths, pp, pw, n, C.byref(params), pv.size)
+        if size == 0:
+            check(-1)
+        buf = np.empty(size, dtype=np.uint8)
+        got = C.c_size_t(0)
+        check(self.lib.zkhip_prove_chips_air(self.handle, arr, pp, pw, n, pv.ctypes.data_as(u32p), pv.size, C.byref(params),
+                                             buf.ctypes.data_as(u8p), size, C.byref(got)))
+        return buf[: got.value]
+
     def prove_debug(self):
         d = ProveDebug()
         check(self.lib.zkhip_last_prove_debug(self.handle, C.byref(d)))
@@ -543,6 +562,28 @@ def air_synthetic(width, n_public):
     out = np.empty(n.value, dtype=np.uint32)
     check(lib.zkhip_air_synthetic(width, n_public, out.ctypes.data_as(u32p), out.size, C.byref(n)))
     return out
+
+
+def _program_table(programs):
+    n = len(programs)
+    keep = [(np.ascontiguousarray(p, dtype=np.uint32) if p is not None else None) for p in programs]
+    pp = (u32p * n)(*[(p.ctypes.data_as(u32p) if p is not None else None) for p in keep])
+    pw = (C.c_size_t * n)(*[(p.size if p is not None else 0) for p in keep])
+    return keep, pp, pw
+
+
+def verify_chips_air(proof, log_ns, widths, programs, public_values=(), params=None):
+    params = params or Params(1, 100, 16)
+    lib = _lib.load()
+    pr = np.ascontiguousarray(proof, dtype=np.uint8)
+    pv = np.ascontiguousarray(np.array(public_values, dtype=np.uint32))
+    n = len(log_ns)
+    ln = (C.c_int32 * n)(*[int(x) for x in log_ns])
+    ws = (C.c_uint32 * n)(*[int(x) for x in widths])
+    keep, pp, pw = _program_table(programs)
+    reason = C.c_int(0)
+    rc = lib.zkhip_verify_chips_air(pr.ctypes.data_as(u8p), pr.size, ln, ws, pp, pw, n, pv.ctypes.data_as(u32p), pv.size, C.byref(params), C.byref(reason))
+    return rc, reason.value
 
 
 def verify_chips(proof, log_ns, widths, public_values=(), params=None, pairs=None, partners=None):
