@@ -416,6 +416,27 @@ int zkhip_prove_chips_air(zkhip_ctx* ctx, const zkhip_chip* chips, const uint32_
 int zkhip_verify_chips_air(const uint8_t* proof, size_t len, const int32_t* log_ns, const uint32_t* widths, const uint32_t* const* programs,
                            const size_t* program_words, int n_chips, const uint32_t* public_values, size_t n_public, const zkhip_params* prm, int* reason);
 
+/* The machine: chips with their own programs AND lookups as DATA (sp1-stark's permutation argument -- generate_permutation_trace /
+ * eval_permutation_constraints, batch size 2, reference Cargo.lock:6172 -- with the interactions written out).  tables[c] is an
+ * interaction table or NULL:
+ *   [0] 0x50554B4C "LKUP"  [1] interactions I (1..64)  [2] total words
+ *   I x { sign (0 send, 1 receive), multiplicity (0xFFFFFFFF: the constant 1, else a column), bus (a field element), values V (1..8), V columns }
+ * A tuple's fingerprint is d = gamma + bus + sum_t beta^(t+1) v_t.  The chip's permutation trace has one extension column per pair
+ * of interactions, phi_j = s_a m_a / d_a + s_b m_b / d_b (s = +1 send, -1 receive; 1/0 = 0), and the running sum of the row sums;
+ * the constraints phi_j d_a d_b = s_a m_a d_b + s_b m_b d_a, S_0 = sum phi, S' = S + sum phi', S_last = C fold after the program's;
+ * every chip with a table exposes its cumulative sum C and the verifier checks that the sums of the machine add up to zero:
+ * every tuple sent on a bus is received with the same total multiplicity (a range table, a memory bus, a permutation ...).
+ * programs[c] NULL: the built-in synthetic AIR.  Proof version 10 = version 6's layout with header entries
+ * (log_n, width, has_program, interactions), then the programs' and the tables' digests.  Shape limits as zkhip_prove_chips. */
+size_t zkhip_machine_proof_size(const int32_t* log_ns, const uint32_t* widths, const uint32_t* const* programs, const size_t* program_words,
+                                const uint32_t* const* tables, const size_t* table_words, int n_chips, const zkhip_params* prm, size_t n_public);
+int zkhip_prove_machine(zkhip_ctx* ctx, const zkhip_chip* chips, const uint32_t* const* programs, const size_t* program_words,
+                        const uint32_t* const* tables, const size_t* table_words, int n_chips, const uint32_t* public_values, size_t n_public,
+                        const zkhip_params* prm, uint8_t* proof, size_t cap, size_t* len);
+int zkhip_verify_machine(const uint8_t* proof, size_t len, const int32_t* log_ns, const uint32_t* widths, const uint32_t* const* programs,
+                         const size_t* program_words, const uint32_t* const* tables, const size_t* table_words, int n_chips,
+                         const uint32_t* public_values, size_t n_public, const zkhip_params* prm, int* reason);
+
 /* ---- Poseidon2 parameter tables from a file: the built-in sets are this repo's own
  * ("zktls-amd/p2-bb16-v1", "...-bb24-v1"; the SP1 / RISC Zero tables of reference Cargo.lock:4030, 6172, 5057 are not
  * obtainable offline).  zkhip_load_poseidon2_params replaces the width-16 or the width-24 set (the file says which) for the

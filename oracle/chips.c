@@ -45,11 +45,107 @@ static _Thread_local const size_t* g_prog_words = NULL;
 static int any_prog(int n) { if (g_progs) for (int c = 0; c < n; c++) if (g_progs[c]) return 1; return 0; }
 static const uint32_t* prog_of(int c) { return g_progs ? g_progs[c] : NULL; }
 
+/* ---- machine mode (orc_*_machine): lookups as DATA.  Every chip may bring an interaction table next to its program:
+ *   [0] "LKUP" 0x50554B4C  [1] interactions I (1..64)  [2] total words
+ *   I x { sign (0 send, 1 receive), multiplicity (0xFFFFFFFF: the constant 1, else a column), bus (a field element), values V (1..8), V columns }
+ * Fingerprint of a tuple: d = gamma + bus + sum_t beta^(t+1) v_t.  The permutation trace has one extension column per PAIR of
+ * interactions (2j, 2j+1): phi_j = s_a m_a / d_a + s_b m_b / d_b (s = +1 send, -1 receive; 1/0 = 0), then the running sum S of the row
+ * sums.  Constraints, folded after the program's: phi_j d_a d_b - (s_a m_a d_b + s_b m_b d_a) per column; is_first (S - sum phi);
+ * is_transition (S' - S - sum phi'); is_last (S - C), C = the chip's exposed cumulative sum; the verifier checks sum_chips C = 0.
+ * This is sp1-stark's permutation argument (generate_permutation_trace / eval_permutation_constraints, batch size 2) with the
+ * interactions written out as data.  Proof version 10: header entry (log_n, width, has_program, interactions), then the programs'
+ * digests, then the tables' digests. ---- */
+#define LKUP_MAGIC 0x50554B4Cu
+#define CHIPS_VERSION_MACHINE 10u
+typedef struct { uint32_t sign, mult, bus, nv; const uint32_t* cols; } inter_t;
+static _Thread_local const uint32_t* const* g_tables = NULL;
+static _Thread_local const size_t* g_table_words = NULL;
+static _Thread_local int g_machine = 0;
+static const uint32_t* table_of(int c) { return g_tables ? g_tables[c] : NULL; }
+static int table_parse(const uint32_t* t, size_t words, size_t width, inter_t* out, int* n_out) {
+    if (!t || words < 3 || t[0] != LKUP_MAGIC || t[1] < 1 || t[1] > 64 || t[2] != words) return 0;
+    size_t p = 3;
+    for (uint32_t i = 0; i < t[1]; i++) {
+        if (p + 4 > words) return 0;
+        inter_t it = {t[p], t[p + 1], t[p + 2], t[p + 3], t + p + 4};
+        p += 4;
+        if (it.sign > 1 || (it.mult != 0xFFFFFFFFu && it.mult >= width) || it.bus >= BB_P || it.nv < 1 || it.nv > 8 || p + it.nv > words) return 0;
+        for (uint32_t v = 0; v < it.nv; v++) if (t[p + v] >= width) return 0;
+        p += it.nv;
+        if (out) out[i] = it;
+    }
+    if (p != words) return 0;
+    if (n_out) *n_out = (int)t[1];
+    return 1;
+}
+static bb4_t fingerprint(const inter_t* it, const bb4_t* row, bb4_t gamma, const bb4_t* bpow) {
+    bb4_t d = bb4_add_base(gamma, it->bus);
+    for (uint32_t v = 0; v < it->nv; v++) d = bb4_add(d, bb4_mul(bpow[v + 1], row[it->cols[v]]));
+    return d;
+}
+static bb4_t signed_mult(const inter_t* it, const bb4_t* row) {
+    bb4_t m = it->mult == 0xFFFFFFFFu ? bb4_from_base(1) : row[it->mult];
+    return it->sign ? bb4_sub(bb4_zero(), m) : m;
+}
+/* permutation trace of a chip with an interaction table: [n][4 (cols + 1)], extension columns as 4 base words */
+static void perm_trace_machine(const uint32_t* trace, int log_n, size_t width, const inter_t* its, int ni, bb4_t gamma, bb4_t beta, uint32_t* out) {
+    const size_t n = (size_t)1 << log_n, cols = ((size_t)ni + 1) / 2, wp = 4 * (cols + 1);
+    bb4_t bpow[10];
+    bpow[0] = bb4_from_base(1);
+    for (int t = 1; t < 10; t++) bpow[t] = bb4_mul(bpow[t - 1], beta);
+#pragma omp parallel for schedule(static)
+    for (size_t i = 0; i < n; i++) {
+        bb4_t* row = (bb4_t*)malloc(width * sizeof(bb4_t));
+        for (size_t j = 0; j < width; j++) row[j] = bb4_from_base(trace[i * width + j]);
+        bb4_t sum = bb4_zero();
+        for (size_t j = 0; j < cols; j++) {
+            bb4_t phi = bb4_mul(signed_mult(&its[2 * j], row), bb4_inv(fingerprint(&its[2 * j], row, gamma, bpow)));
+            if (2 * j + 1 < (size_t)ni) phi = bb4_add(phi, bb4_mul(signed_mult(&its[2 * j + 1], row), bb4_inv(fingerprint(&its[2 * j + 1], row, gamma, bpow))));
+            st4(out + i * wp + 4 * j, phi);
+            sum = bb4_add(sum, phi);
+        }
+        st4(out + i * wp + 4 * cols, sum);
+        free(row);
+    }
+    bb4_t run = bb4_zero();
+    for (size_t i = 0; i < n; i++) { run = bb4_add(run, ld4(out + i * wp + 4 * cols)); st4(out + i * wp + 4 * cols, run); }
+}
+/* the lookup constraints folded onto acc (prover on the quotient domain and verifier at zeta alike: extension arithmetic) */
+static bb4_t fold_interactions(bb4_t acc, const inter_t* its, int ni, const bb4_t* row, const bb4_t* pl, const bb4_t* pn, bb4_t gamma, bb4_t beta,
+                               bb4_t sel_first, bb4_t sel_trans, bb4_t sel_last, bb4_t alpha, bb4_t cumsum) {
+    const size_t cols = ((size_t)ni + 1) / 2;
+    bb4_t bpow[10];
+    bpow[0] = bb4_from_base(1);
+    for (int t = 1; t < 10; t++) bpow[t] = bb4_mul(bpow[t - 1], beta);
+    bb4_t sum_l = bb4_zero(), sum_n = bb4_zero();
+    for (size_t j = 0; j < cols; j++) {
+        const bb4_t da = fingerprint(&its[2 * j], row, gamma, bpow), ma = signed_mult(&its[2 * j], row);
+        bb4_t c;
+        if (2 * j + 1 < (size_t)ni) {
+            const bb4_t db = fingerprint(&its[2 * j + 1], row, gamma, bpow), mb = signed_mult(&its[2 * j + 1], row);
+            c = bb4_sub(bb4_mul(bb4_mul(pl[j], da), db), bb4_add(bb4_mul(ma, db), bb4_mul(mb, da)));
+        } else c = bb4_sub(bb4_mul(pl[j], da), ma);
+        acc = bb4_add(bb4_mul(acc, alpha), c);
+        sum_l = bb4_add(sum_l, pl[j]);
+        sum_n = bb4_add(sum_n, pn[j]);
+    }
+    const bb4_t S = pl[cols], Sn = pn[cols];
+    acc = bb4_add(bb4_mul(acc, alpha), bb4_mul(sel_first, bb4_sub(S, sum_l)));
+    acc = bb4_add(bb4_mul(acc, alpha), bb4_mul(sel_trans, bb4_sub(bb4_sub(Sn, S), sum_n)));
+    acc = bb4_add(bb4_mul(acc, alpha), bb4_mul(sel_last, bb4_sub(S, cumsum)));
+    return acc;
+}
+
 static bb4_t sample_ext(orc_challenger_t* ch) { bb4_t r; orc_chal_sample_ext(ch, r.c); return r; }
 
 static int any_pairs(const int* pairs, int n) { if (pairs) for (int c = 0; c < n; c++) if (pairs[c]) return 1; return 0; }
-static int any_cross(const int* partners, int n) { if (partners) for (int c = 0; c < n; c++) if (partners[c] >= 0) return 1; return 0; }
+static int any_cross(const int* partners, int n) {
+    if (g_machine) { for (int c = 0; c < n; c++) if (table_of(c)) return 1; return 0; }       /* machine mode: sums are always exposed */
+    if (partners) for (int c = 0; c < n; c++) if (partners[c] >= 0) return 1;
+    return 0;
+}
 static uint32_t chips_version(const int* pairs, const int* partners, int n) {
+    if (g_machine) return CHIPS_VERSION_MACHINE;
     if (any_prog(n)) return CHIPS_VERSION_AIR;
     return any_cross(partners, n) ? CHIPS_VERSION_CROSS : (any_pairs(pairs, n) ? CHIPS_VERSION_LOGUP : CHIPS_VERSION);
 }
@@ -58,11 +154,11 @@ static int chips_ok(const int* log_ns, const size_t* widths, const int* pairs, c
     if (prm->log_blowup < 1 || prm->log_blowup > 3) return 0;
     if ((prm->log_fold != 0 && prm->log_fold != 1) || prm->log_final != 0 || (prm->hash_width != 0 && prm->hash_width != 16)) return 0;
     if (prm->logup_pairs != 0) return 0;
-    if (any_prog(n) && (any_pairs(pairs, n) || any_cross(partners, n))) return 0;      /* no lookups next to programs */
+    if (!g_machine && any_prog(n) && (any_pairs(pairs, n) || any_cross(partners, n))) return 0;      /* version 9: no lookups next to programs */
     for (int c = 0; c < n; c++) {
         if (log_ns[c] < 5 || log_ns[c] > 20 || widths[c] == 0 || widths[c] % 4 != 0 || widths[c] > 1024) return 0;
         if (c && log_ns[c] > log_ns[c - 1]) return 0;             /* tallest first */
-        if (pairs && (pairs[c] < 0 || pairs[c] > 64 || (size_t)pairs[c] * 8 > widths[c])) return 0;
+        if (pairs && (pairs[c] < 0 || pairs[c] > 64 || (!g_machine && (size_t)pairs[c] * 8 > widths[c]))) return 0;
         if (partners && partners[c] >= 0) {                        /* mutual, equal heights and pair counts */
             int d = partners[c];
             if (!pairs || d >= n || d == c || partners[d] != c || pairs[c] == 0 || pairs[d] != pairs[c] || log_ns[d] != log_ns[c]) return 0;
@@ -82,7 +178,10 @@ size_t orc_chips_proof_size(const int* log_ns, const size_t* widths, const int* 
     const int lk = any_pairs(pairs, n), cross = any_cross(partners, n);
     size_t b = (size_t)prm->log_blowup, Hmax = (size_t)log_ns[0] + b, L = (size_t)log_ns[0];
     size_t words = 8 + (cross ? 4 : (lk ? 3 : 2)) * (size_t)n + 16 + (lk ? 8 : 0) + 8 * L + 4 + 1;
-    if (any_prog(n)) { words += (size_t)n; for (int c = 0; c < n; c++) if (prog_of(c)) words += 8; }
+    if (g_machine) {
+        words = 8 + 4 * (size_t)n + 16 + (lk ? 8 : 0) + 8 * L + 4 + 1;
+        for (int c = 0; c < n; c++) words += (prog_of(c) ? 8 : 0) + (table_of(c) ? 8 : 0);
+    } else if (any_prog(n)) { words += (size_t)n; for (int c = 0; c < n; c++) if (prog_of(c)) words += 8; }
     size_t perq = 16 * Hmax, hp = 0;
     for (int c = 0; c < n; c++) {
         size_t wp = (pairs && pairs[c]) ? 4 * ((size_t)pairs[c] + 1) : 0;
@@ -106,6 +205,7 @@ static void transcript_init(orc_challenger_t* ch, const int* log_ns, const size_
     orc_chal_observe(ch, (uint32_t)n_public);
     for (int c = 0; c < n; c++) {
         orc_chal_observe(ch, (uint32_t)log_ns[c]); orc_chal_observe(ch, (uint32_t)widths[c]);
+        if (g_machine) { orc_chal_observe(ch, prog_of(c) ? 1u : 0u); orc_chal_observe(ch, table_of(c) ? table_of(c)[1] : 0u); continue; }
         if (lk) orc_chal_observe(ch, (uint32_t)pairs[c]);
         if (cross) orc_chal_observe(ch, (uint32_t)(partners[c] + 1));
         if (any_prog(n)) orc_chal_observe(ch, prog_of(c) ? 1u : 0u);
@@ -114,6 +214,12 @@ static void transcript_init(orc_challenger_t* ch, const int* log_ns, const size_
         if (prog_of(c)) {
             uint32_t dg[8];
             orc_air_digest(prog_of(c), g_prog_words[c], dg);
+            orc_chal_observe_slice(ch, dg, 8);
+        }
+    for (int c = 0; c < n; c++)
+        if (table_of(c)) {
+            uint32_t dg[8];
+            orc_air_digest(table_of(c), g_table_words[c], dg);          /* the same sponge over 16-bit halves */
             orc_chal_observe_slice(ch, dg, 8);
         }
 }
@@ -125,6 +231,46 @@ static size_t height_offset(const int* log_ns, const size_t* widths, const int* 
     size_t off = 0;
     for (int d = 0; d < c; d++) if (log_ns[d] == log_ns[c]) off += 2 * widths[d] + 2 * perm_width(pairs, d) + 8;
     return off;
+}
+
+/* quotient values of chip c in machine mode: its program (the synthetic AIR written as a program when it has none), then its lookups */
+static void quotient_values_machine(int c, const uint32_t* lde, int log_n, size_t width, const uint32_t* plde, bb4_t gamma, bb4_t beta,
+                                    bb4_t alpha, bb4_t cumsum, const uint32_t* pub, size_t n_public, uint32_t* out) {
+    const uint32_t* prog = prog_of(c);
+    uint32_t* synth = NULL;
+    if (!prog) {
+        const size_t cap = 6 + (width / 4) * 33;
+        synth = (uint32_t*)malloc(cap * 4);
+        orc_air_synthetic(width, n_public, synth, cap);
+        prog = synth;
+    }
+    inter_t its[64]; int ni = 0;
+    if (table_of(c)) table_parse(table_of(c), g_table_words[c], width, its, &ni);
+    const size_t cols = ((size_t)ni + 1) / 2, wp = ni ? 4 * (cols + 1) : 0;
+    const int log_m = log_n + 1;
+    const size_t m = (size_t)1 << log_m, n = (size_t)1 << log_n;
+    const bb_t w = bb_two_adic_generator(log_m), wn_inv = bb_inv(bb_two_adic_generator(log_n));
+#pragma omp parallel for schedule(static)
+    for (size_t i = 0; i < m; i++) {
+        bb_t x = bb_mul(BB_GEN, bb_pow(w, i));
+        bb_t zh = bb_sub(bb_pow(x, n), 1);
+        bb_t sel_first = bb_mul(zh, bb_inv(bb_sub(x, 1)));
+        bb_t sel_last = bb_mul(zh, bb_inv(bb_sub(x, wn_inv)));
+        bb_t sel_trans = bb_sub(x, wn_inv);
+        size_t p = bb_reverse_bits((uint32_t)i, log_m), pn = bb_reverse_bits((uint32_t)((i + 2) & (m - 1)), log_m);
+        bb4_t acc = orc__air_fold_base(prog, lde + p * width, lde + pn * width, pub, sel_first, sel_last, sel_trans, alpha);
+        if (ni) {
+            bb4_t* row = (bb4_t*)malloc(width * sizeof(bb4_t));
+            for (size_t j = 0; j < width; j++) row[j] = bb4_from_base(lde[p * width + j]);
+            bb4_t pl[33], pnx[33];
+            for (size_t q = 0; q <= cols; q++) { pl[q] = ld4(plde + p * wp + 4 * q); pnx[q] = ld4(plde + pn * wp + 4 * q); }
+            acc = fold_interactions(acc, its, ni, row, pl, pnx, gamma, beta, bb4_from_base(sel_first), bb4_from_base(sel_trans),
+                                    bb4_from_base(sel_last), alpha, cumsum);
+            free(row);
+        }
+        st4(out + 4 * p, bb4_mul_base(acc, bb_inv(zh)));
+    }
+    free(synth);
 }
 
 size_t orc_prove_chips(const uint32_t* const* traces, const int* log_ns, const size_t* widths, const int* pairs, const int* partners, int n,
@@ -139,11 +285,13 @@ size_t orc_prove_chips(const uint32_t* const* traces, const int* log_ns, const s
     pf[pos++] = (uint32_t)prm->num_queries; pf[pos++] = (uint32_t)prm->pow_bits; pf[pos++] = (uint32_t)n_public; pf[pos++] = 16u;
     for (int c = 0; c < n; c++) {
         pf[pos++] = (uint32_t)log_ns[c]; pf[pos++] = (uint32_t)widths[c];
+        if (g_machine) { pf[pos++] = prog_of(c) ? 1u : 0u; pf[pos++] = table_of(c) ? table_of(c)[1] : 0u; continue; }
         if (lk) pf[pos++] = (uint32_t)pairs[c];
         if (cross) pf[pos++] = (uint32_t)(partners[c] + 1);
         if (any_prog(n)) pf[pos++] = prog_of(c) ? 1u : 0u;
     }
     for (int c = 0; c < n; c++) if (prog_of(c)) { orc_air_digest(prog_of(c), g_prog_words[c], pf + pos); pos += 8; }
+    for (int c = 0; c < n; c++) if (table_of(c)) { orc_air_digest(table_of(c), g_table_words[c], pf + pos); pos += 8; }
     orc_challenger_t ch;
     transcript_init(&ch, log_ns, widths, pairs, partners, n, prm, n_public);
     bb4_t cumsum[MAX_CHIPS];
@@ -176,7 +324,11 @@ size_t orc_prove_chips(const uint32_t* const* traces, const int* log_ns, const s
             if (!wp[c]) continue;
             const size_t nc = (size_t)1 << log_ns[c], mc = (size_t)1 << lh[c];
             uint32_t* perm = (uint32_t*)malloc(nc * wp[c] * 4);
-            orc_perm_trace(traces[c], log_ns[c], widths[c], pairs[c], gamma.c, beta_l.c, perm);
+            if (g_machine) {
+                inter_t its[64]; int ni = 0;
+                table_parse(table_of(c), g_table_words[c], widths[c], its, &ni);
+                perm_trace_machine(traces[c], log_ns[c], widths[c], its, ni, gamma, beta_l, perm);
+            } else orc_perm_trace(traces[c], log_ns[c], widths[c], pairs[c], gamma.c, beta_l.c, perm);
             if (cross) cumsum[c] = ld4(perm + (nc - 1) * wp[c] + 4 * (size_t)pairs[c]);       /* the running sum's last value */
             plde[c] = (uint32_t*)malloc(mc * wp[c] * 4);
             orc_coset_lde(perm, plde[c], log_ns[c], wp[c], b, BB_GEN);
@@ -200,7 +352,8 @@ size_t orc_prove_chips(const uint32_t* const* traces, const int* log_ns, const s
         const int ln = log_ns[c], Hq = ln + 1;
         const size_t nc = (size_t)1 << ln, mc = (size_t)1 << lh[c], mq = (size_t)1 << Hq;
         uint32_t* qv = (uint32_t*)malloc(mq * 16);
-        if (prog_of(c)) orc_quotient_values_air(prog_of(c), tlde[c], ln, widths[c], public_values, alpha.c, 1, qv);
+        if (g_machine) quotient_values_machine(c, tlde[c], ln, widths[c], plde[c], gamma, beta_l, alpha, cumsum[c], public_values, n_public, qv);
+        else if (prog_of(c)) orc_quotient_values_air(prog_of(c), tlde[c], ln, widths[c], public_values, alpha.c, 1, qv);
         else orc_quotient_values_logup_c(tlde[c], ln, widths[c], plde[c], wp[c] ? pairs[c] : 0, gamma.c, beta_l.c, alpha.c, cumsum[c].c, qv);
         qlde[c] = (uint32_t*)malloc(mc * 8 * 4);
         uint32_t* chunk = (uint32_t*)malloc(nc * 16);
@@ -381,6 +534,7 @@ int orc_verify_chips(const uint8_t* proof_bytes, size_t len, const int* log_ns, 
     for (int c = 0; c < n; c++) {
         if (pf[pos] != (uint32_t)log_ns[c] || pf[pos + 1] != (uint32_t)widths[c]) return 3;
         pos += 2;
+        if (g_machine) { if (pf[pos] != (prog_of(c) ? 1u : 0u) || pf[pos + 1] != (table_of(c) ? table_of(c)[1] : 0u)) return 3; pos += 2; continue; }
         if (lk) { if (pf[pos] != (uint32_t)pairs[c]) return 3; pos++; }
         if (cross) { if (pf[pos] != (uint32_t)(partners[c] + 1)) return 3; pos++; }
         if (any_prog(n)) { if (pf[pos] != (prog_of(c) ? 1u : 0u)) return 3; pos++; }
@@ -389,6 +543,13 @@ int orc_verify_chips(const uint8_t* proof_bytes, size_t len, const int* log_ns, 
         if (prog_of(c)) {
             uint32_t dg[8];
             orc_air_digest(prog_of(c), g_prog_words[c], dg);
+            if (memcmp(pf + pos, dg, 32) != 0) return 3;
+            pos += 8;
+        }
+    for (int c = 0; c < n; c++)
+        if (table_of(c)) {
+            uint32_t dg[8];
+            orc_air_digest(table_of(c), g_table_words[c], dg);
             if (memcmp(pf + pos, dg, 32) != 0) return 3;
             pos += 8;
         }
@@ -439,7 +600,16 @@ int orc_verify_chips(const uint8_t* proof_bytes, size_t len, const int* log_ns, 
         bb4_t folded = prog_of(c) ? orc__air_fold_ext(prog_of(c), loc, nxt, public_values, sel_first,
                                                         bb4_mul(zh, bb4_inv(bb4_sub_base(zeta, bb_inv(gn)))), sel_trans, alpha)
                                   : orc__fold_constraints_ext(loc, nxt, W, sel_first, sel_trans, alpha);
-        if (Wp) {
+        if (Wp && g_machine) {
+            inter_t its[64]; int ni = 0;
+            table_parse(table_of(c), g_table_words[c], W, its, &ni);
+            const size_t cols = ((size_t)ni + 1) / 2;
+            bb4_t sel_last = bb4_mul(zh, bb4_inv(bb4_sub_base(zeta, bb_inv(gn))));
+            bb4_t pl[33], pn[33];
+            const uint32_t *o_pl = op[c] + 8 * W, *o_pn = o_pl + 4 * Wp;
+            for (size_t q = 0; q <= cols; q++) { pl[q] = orc__recombine(o_pl + 16 * q); pn[q] = orc__recombine(o_pn + 16 * q); }
+            folded = fold_interactions(folded, its, ni, loc, pl, pn, gamma, beta_l, sel_first, sel_trans, sel_last, alpha, cumsum[c]);
+        } else if (Wp) {
             const int Q = pairs[c];
             bb4_t sel_last = bb4_mul(zh, bb4_inv(bb4_sub_base(zeta, bb_inv(gn))));
             bb4_t as[64], bs[64], ar[64], br[64], pl[65], pn[65];
@@ -586,5 +756,51 @@ int orc_verify_chips_air(const uint8_t* proof_bytes, size_t len, const int* log_
     g_progs = progs; g_prog_words = prog_words;
     int r = orc_verify_chips(proof_bytes, len, log_ns, widths, NULL, NULL, n, public_values, n_public, prm);
     g_progs = NULL; g_prog_words = NULL;
+    return r;
+}
+
+
+/* ---- the machine: every chip with its program (or the synthetic AIR) AND its interaction table (or none); proof version 10 ---- */
+static int machine_ok(const uint32_t* const* progs, const size_t* prog_words, const uint32_t* const* tables, const size_t* table_words,
+                      const size_t* widths, int n, size_t n_public, int* cols) {
+    if (!tables || !table_words || !progs_ok(progs, prog_words, widths, n, n_public)) return 0;
+    for (int c = 0; c < n; c++) {
+        cols[c] = 0;
+        if (!tables[c]) continue;
+        int ni = 0;
+        if (!table_parse(tables[c], table_words[c], widths[c], NULL, &ni)) return 0;
+        cols[c] = (ni + 1) / 2;
+    }
+    return 1;
+}
+#define MACHINE_ENTER g_progs = progs; g_prog_words = prog_words; g_tables = tables; g_table_words = table_words; g_machine = 1
+#define MACHINE_LEAVE g_progs = NULL; g_prog_words = NULL; g_tables = NULL; g_table_words = NULL; g_machine = 0
+size_t orc_machine_proof_size(const int* log_ns, const size_t* widths, const uint32_t* const* progs, const size_t* prog_words,
+                              const uint32_t* const* tables, const size_t* table_words, int n, const orc_params_t* prm, size_t n_public) {
+    int cols[MAX_CHIPS];
+    if (n < 1 || n > MAX_CHIPS || !machine_ok(progs, prog_words, tables, table_words, widths, n, n_public, cols)) return 0;
+    MACHINE_ENTER;
+    size_t r = orc_chips_proof_size(log_ns, widths, cols, NULL, n, prm, n_public);
+    MACHINE_LEAVE;
+    return r;
+}
+size_t orc_prove_machine(const uint32_t* const* traces, const int* log_ns, const size_t* widths, const uint32_t* const* progs,
+                         const size_t* prog_words, const uint32_t* const* tables, const size_t* table_words, int n,
+                         const uint32_t* public_values, size_t n_public, const orc_params_t* prm, uint8_t* proof_bytes, size_t cap) {
+    int cols[MAX_CHIPS];
+    if (n < 1 || n > MAX_CHIPS || !machine_ok(progs, prog_words, tables, table_words, widths, n, n_public, cols)) return 0;
+    MACHINE_ENTER;
+    size_t r = orc_prove_chips(traces, log_ns, widths, cols, NULL, n, public_values, n_public, prm, proof_bytes, cap);
+    MACHINE_LEAVE;
+    return r;
+}
+int orc_verify_machine(const uint8_t* proof_bytes, size_t len, const int* log_ns, const size_t* widths, const uint32_t* const* progs,
+                       const size_t* prog_words, const uint32_t* const* tables, const size_t* table_words, int n,
+                       const uint32_t* public_values, size_t n_public, const orc_params_t* prm) {
+    int cols[MAX_CHIPS];
+    if (n < 1 || n > MAX_CHIPS || !machine_ok(progs, prog_words, tables, table_words, widths, n, n_public, cols)) return 1;
+    MACHINE_ENTER;
+    int r = orc_verify_chips(proof_bytes, len, log_ns, widths, cols, NULL, n, public_values, n_public, prm);
+    MACHINE_LEAVE;
     return r;
 }

@@ -174,6 +174,15 @@ size_t orc_prove_chips_air(const uint32_t* const* traces, const int* log_ns, con
                            uint8_t* proof, size_t cap);
 int orc_verify_chips_air(const uint8_t* proof, size_t len, const int* log_ns, const size_t* widths, const uint32_t* const* progs,
                          const size_t* prog_words, int n_chips, const uint32_t* public_values, size_t n_public, const orc_params_t* prm);
+/* the machine: chips with programs AND interaction tables (lookups as data, multiplicities, buses; format in chips.c); version 10 */
+size_t orc_machine_proof_size(const int* log_ns, const size_t* widths, const uint32_t* const* progs, const size_t* prog_words,
+                              const uint32_t* const* tables, const size_t* table_words, int n_chips, const orc_params_t* prm, size_t n_public);
+size_t orc_prove_machine(const uint32_t* const* traces, const int* log_ns, const size_t* widths, const uint32_t* const* progs,
+                         const size_t* prog_words, const uint32_t* const* tables, const size_t* table_words, int n_chips,
+                         const uint32_t* public_values, size_t n_public, const orc_params_t* prm, uint8_t* proof, size_t cap);
+int orc_verify_machine(const uint8_t* proof, size_t len, const int* log_ns, const size_t* widths, const uint32_t* const* progs,
+                       const size_t* prog_words, const uint32_t* const* tables, const size_t* table_words, int n_chips,
+                       const uint32_t* public_values, size_t n_public, const orc_params_t* prm);
 size_t orc_chips_proof_size(const int* log_ns, const size_t* widths, const int* pairs, const int* partners, int n_chips, const orc_params_t* prm, size_t n_public);
 size_t orc_prove_chips(const uint32_t* const* traces, const int* log_ns, const size_t* widths, const int* pairs, const int* partners, int n_chips,
                        const uint32_t* public_values, size_t n_public, const orc_params_t* prm, uint8_t* proof, size_t cap);

@@ -401,6 +401,61 @@ def verify_chips_air(proof, log_ns, widths, progs, public_values=(), params=None
                                           _p(pv), C.c_size_t(pv.size), C.byref(params)))
 
 
+LKUP_MAGIC = 0x50554B4C
+SEND, RECEIVE = 0, 1
+
+
+def interaction_table(interactions):
+    """interactions: [(SEND | RECEIVE, multiplicity column or None for the constant 1, bus, [value columns]), ...] -> flat u32 table"""
+    body = []
+    for sign, mult, bus, cols in interactions:
+        body += [sign, 0xFFFFFFFF if mult is None else mult, bus % P, len(cols)] + list(cols)
+    return np.array([LKUP_MAGIC, len(interactions), 3 + len(body)] + body, dtype=np.uint32)
+
+
+def _machine_args(traces, progs, tables):
+    ts = [_u32(t) for t in traces]
+    n = len(ts)
+    log_ns = (C.c_int * n)(*[t.shape[0].bit_length() - 1 for t in ts])
+    widths = (C.c_size_t * n)(*[t.shape[1] for t in ts])
+    ptrs = (u32p * n)(*[_p(t) for t in ts])
+    kp, pp, pw = _progs_args(progs)
+    kt, tp, tw = _progs_args(tables)
+    return ts, n, log_ns, widths, ptrs, (kp, pp, pw), (kt, tp, tw)
+
+
+def prove_machine(traces, progs, tables, public_values=(), params=None):
+    """chips with programs (None: the synthetic AIR) and interaction tables (None: no lookups), tallest first; proof version 10"""
+    params = params or default_params()
+    ts, n, log_ns, widths, ptrs, (kp, pp, pw), (kt, tp, tw) = _machine_args(traces, progs, tables)
+    pv = _u32(np.array(public_values, dtype=np.uint32))
+    L = lib()
+    L.orc_machine_proof_size.restype = C.c_size_t
+    L.orc_prove_machine.restype = C.c_size_t
+    size = L.orc_machine_proof_size(log_ns, widths, pp, pw, tp, tw, C.c_int(n), C.byref(params), C.c_size_t(pv.size))
+    if size == 0:
+        raise RuntimeError("oracle: bad machine")
+    buf = np.empty(size, dtype=np.uint8)
+    got = L.orc_prove_machine(ptrs, log_ns, widths, pp, pw, tp, tw, C.c_int(n), _p(pv), C.c_size_t(pv.size), C.byref(params),
+                              buf.ctypes.data_as(C.POINTER(C.c_uint8)), C.c_size_t(size))
+    if got != size:
+        raise RuntimeError("oracle prove_machine failed")
+    return buf
+
+
+def verify_machine(proof, log_ns, widths, progs, tables, public_values=(), params=None):
+    params = params or default_params()
+    pr = np.ascontiguousarray(proof, dtype=np.uint8)
+    n = len(log_ns)
+    ln = (C.c_int * n)(*[int(x) for x in log_ns])
+    ws = (C.c_size_t * n)(*[int(x) for x in widths])
+    pv = _u32(np.array(public_values, dtype=np.uint32))
+    kp, pp, pw = _progs_args(progs)
+    kt, tp, tw = _progs_args(tables)
+    return int(lib().orc_verify_machine(pr.ctypes.data_as(C.POINTER(C.c_uint8)), C.c_size_t(pr.size), ln, ws, pp, pw, tp, tw, C.c_int(n),
+                                        _p(pv), C.c_size_t(pv.size), C.byref(params)))
+
+
 def verify_chips(proof, log_ns, widths, public_values=(), params=None, pairs=None, partners=None):
     params = params or default_params()
     pr = np.ascontiguousarray(proof, dtype=np.uint8)

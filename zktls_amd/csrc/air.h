@@ -92,7 +92,7 @@ inline Ext air_fold_ext(const AirView& a, const Ext* local, const Ext* next, con
 // device image: the program with Montgomery coefficients and the public values resolved into constants is not possible for
 // products (a public value is a factor), so variables keep their kinds; layout = the program body (from word 6) with
 // coefficients converted to Montgomery form.  weights[k] = alpha^(K-1-k) (extension, Montgomery).
-inline void air_device_image(const AirView& a, const Ext& alpha, std::vector<uint32_t>& body, std::vector<uint32_t>& weights) {
+inline void air_device_image(const AirView& a, const Ext& alpha, std::vector<uint32_t>& body, std::vector<uint32_t>& weights, const Ext& scale = ext_one()) {
     body.assign(a.w + 6, a.w + a.words);
     size_t p = 0;
     for (uint32_t k = 0; k < a.K; k++) {
@@ -101,7 +101,7 @@ inline void air_device_image(const AirView& a, const Ext& alpha, std::vector<uin
         for (uint32_t t = 0; t < nt; t++) { body[p] = to_monty(body[p]); p++; const uint32_t d = body[p++]; p += d; }
     }
     weights.resize(4 * (size_t)a.K);
-    Ext w = ext_one();
+    Ext w = scale;                             // alpha^(number of constraints folded after the program's: a chip's lookups)
     for (size_t k = a.K; k-- > 0;) { for (int i = 0; i < 4; i++) weights[4 * k + i] = w.c[i]; w = ext_mul(w, alpha); }
 }
 
@@ -112,9 +112,9 @@ inline void air_device_image(const AirView& a, const Ext& alpha, std::vector<uin
 // 2W+4+i public value i.  Record = 8 words: coefficient (4), off0 | off1 << 16, off2 | off3 << 16, off4 | nvars << 16, 0; nvars in
 // [1, 5] (a constant term reads the slot of 1).  Sorted by nvars, so that the lanes of a wavefront run the same number of products.
 inline uint32_t air_slots(const AirView& a) { return 2 * a.width + AIR_SLOT_EXTRA + a.n_public; }
-inline void air_term_records(const AirView& a, const Ext& alpha, std::vector<uint32_t>& recs) {
+inline void air_term_records(const AirView& a, const Ext& alpha, std::vector<uint32_t>& recs, const Ext& scale = ext_one()) {
     std::vector<Ext> wts(a.K);
-    Ext w = ext_one();
+    Ext w = scale;
     for (size_t k = a.K; k-- > 0;) { wts[k] = w; w = ext_mul(w, alpha); }
     std::vector<std::vector<uint32_t>> by_n[6];
     size_t p = 6;
@@ -136,6 +136,82 @@ inline void air_term_records(const AirView& a, const Ext& alpha, std::vector<uin
     }
     recs.clear();
     for (int n = 1; n <= 5; n++) for (const auto& r : by_n[n]) recs.insert(recs.end(), r.begin(), r.end());
+}
+
+// ---- lookups as data: a chip's interaction table (machine mode; format declared in include/zkhip.h) ------------------------------
+//   [0] 0x50554B4C "LKUP"  [1] interactions I (1..64)  [2] total words
+//   I x { sign (0 send, 1 receive), multiplicity (0xFFFFFFFF: the constant 1, else a column), bus (canonical), values V (1..8), V columns }
+// Fingerprint d = gamma + bus + sum_t beta^(t+1) v_t; one extension column phi_j per pair of interactions (2j, 2j+1):
+// phi_j = s_a m_a / d_a + s_b m_b / d_b; then the running sum.  Constraints (folded after the program's): per column
+// phi_j d_a d_b - (s_a m_a d_b + s_b m_b d_a); is_first (S - sum phi); is_transition (S' - S - sum phi'); is_last (S - C).
+// Upstream: sp1-stark's generate_permutation_trace / eval_permutation_constraints with batch size 2 (reference Cargo.lock:6172).
+constexpr uint32_t LOOKUP_MAGIC = 0x50554B4Cu;
+struct LookupView {
+    const uint32_t* w = nullptr;
+    size_t words = 0;
+    uint32_t ni = 0, cols = 0;                 // interactions, extension columns = ceil(ni / 2)
+};
+inline bool lookup_validate(const uint32_t* t, size_t words, uint32_t width, LookupView* out) {
+    if (!t || words < 3 || t[0] != LOOKUP_MAGIC || t[1] < 1 || t[1] > 64 || t[2] != words) return false;
+    size_t p = 3;
+    for (uint32_t i = 0; i < t[1]; i++) {
+        if (p + 4 > words) return false;
+        const uint32_t sign = t[p], mult = t[p + 1], bus = t[p + 2], nv = t[p + 3];
+        p += 4;
+        if (sign > 1 || (mult != 0xFFFFFFFFu && mult >= width) || bus >= P || nv < 1 || nv > 8 || p + nv > words) return false;
+        for (uint32_t v = 0; v < nv; v++) if (t[p + v] >= width) return false;
+        p += nv;
+    }
+    if (p != words) return false;
+    if (out) { out->w = t; out->words = words; out->ni = t[1]; out->cols = (t[1] + 1) / 2; }
+    return true;
+}
+// device records (kernels.h LOOKUP_REC_WORDS): bus in Montgomery form, columns padded to 8
+inline void lookup_device_records(const LookupView& v, std::vector<uint32_t>& recs) {
+    recs.assign((size_t)v.ni * LOOKUP_REC_WORDS, 0u);
+    size_t p = 3;
+    for (uint32_t i = 0; i < v.ni; i++) {
+        uint32_t* r = recs.data() + (size_t)i * LOOKUP_REC_WORDS;
+        r[0] = v.w[p]; r[1] = v.w[p + 1]; r[2] = to_monty(v.w[p + 2]); r[3] = v.w[p + 3];
+        for (uint32_t k = 0; k < r[3]; k++) r[4 + k] = v.w[p + 4 + k];
+        p += 4 + r[3];
+    }
+}
+// verifier side: the lookup constraints on opened (extension) values, folded onto acc
+inline Ext lookup_fold_ext(Ext acc, const LookupView& v, const Ext* row, const Ext* pl, const Ext* pn, const Ext& gamma, const Ext& beta,
+                           const Ext& sel_first, const Ext& sel_trans, const Ext& sel_last, const Ext& alpha, const Ext& cumsum) {
+    Ext bpow[10];
+    bpow[0] = ext_one();
+    for (int t = 1; t < 10; t++) bpow[t] = ext_mul(bpow[t - 1], beta);
+    auto finger = [&](size_t p) {
+        Ext d = ext_add_base(gamma, to_monty(v.w[p + 2]));
+        for (uint32_t k = 0; k < v.w[p + 3]; k++) d = ext_add(d, ext_mul(bpow[k + 1], row[v.w[p + 4 + k]]));
+        return d;
+    };
+    auto mult = [&](size_t p) {
+        const Ext m = v.w[p + 1] == 0xFFFFFFFFu ? ext_one() : row[v.w[p + 1]];
+        return v.w[p] ? ext_neg(m) : m;
+    };
+    Ext sum_l = ext_zero(), sum_n = ext_zero();
+    size_t p = 3;
+    for (uint32_t j = 0; j < v.cols; j++) {
+        const Ext da = finger(p), ma = mult(p);
+        p += 4 + v.w[p + 3];
+        Ext c;
+        if (2 * j + 1 < v.ni) {
+            const Ext db = finger(p), mb = mult(p);
+            p += 4 + v.w[p + 3];
+            c = ext_sub(ext_mul(ext_mul(pl[j], da), db), ext_add(ext_mul(ma, db), ext_mul(mb, da)));
+        } else c = ext_sub(ext_mul(pl[j], da), ma);
+        acc = ext_add(ext_mul(acc, alpha), c);
+        sum_l = ext_add(sum_l, pl[j]);
+        sum_n = ext_add(sum_n, pn[j]);
+    }
+    const Ext S = pl[v.cols], Sn = pn[v.cols];
+    acc = ext_add(ext_mul(acc, alpha), ext_mul(sel_first, ext_sub(S, sum_l)));
+    acc = ext_add(ext_mul(acc, alpha), ext_mul(sel_trans, ext_sub(ext_sub(Sn, S), sum_n)));
+    acc = ext_add(ext_mul(acc, alpha), ext_mul(sel_last, ext_sub(S, cumsum)));
+    return acc;
 }
 
 }  // namespace zk

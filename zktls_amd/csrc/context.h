@@ -79,6 +79,8 @@ enum Slot {
     S_EXTRA_A, S_EXTRA_B,   // large-transform (2^21, 2^22 rows) bounce buffers
     S_CTREE,           // tree of the code group (zkhip_params.code_width)
     S_CHIP,            // trace of a built-in chip (sha256_chip.hip)
+    S_LOOKUP,          // machine mode: a chip's interaction records + lookup weights
+    S_ADDEND,          // machine mode: the folded lookup constraints of a chip on its quotient domain
     S_COUNT
 };
 

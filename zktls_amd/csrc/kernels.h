@@ -187,6 +187,7 @@ struct QuotientAirArgs {
     uint32_t* lde_out; uint64_t lde_ld;     // log_qd == 1 only (as launch_quotient)
     // term-parallel form (air_term_records): used when recs != nullptr and the slots of 8 points fit the LDS
     const uint32_t* recs; uint32_t n_terms; uint32_t n_public;
+    const uint32_t* addend;     // optional [2^(log_n + log_qd)][4]: added to the folded constraints before the division by Z_H (lookups)
 };
 hipError_t launch_quotient_air(const QuotientAirArgs& a, hipStream_t s);
 
@@ -231,6 +232,33 @@ struct PermArgs {
 };
 // block_scratch: ceil(rows / 256) ext values
 hipError_t launch_perm_trace(const PermArgs& a, uint32_t* block_scratch, hipStream_t s);
+
+// ---- lookups as data (machine mode, prover.cpp): a chip's interaction table on the device = ni records of 12 words
+// {sign (0 send, 1 receive), multiplicity column or 0xFFFFFFFF for the constant 1, bus (Montgomery), values nv, nv columns, padding};
+// fingerprint of a tuple d = gamma + bus + sum_t beta^(t+1) v_t; one extension column phi_j per pair of interactions (2j, 2j+1).
+constexpr int LOOKUP_REC_WORDS = 12;
+struct LookupArgs {
+    const uint32_t* table; uint32_t ni, cols;      // device records; cols = ceil(ni / 2)
+    Ext gamma, bpow[9];                            // beta^0 .. beta^8
+};
+struct MachinePermArgs {
+    LookupArgs lk;
+    const uint32_t* trace; uint64_t ld; uint64_t rows;
+    uint32_t* out; uint64_t out_ld;                // [rows][4 (cols + 1)]
+};
+hipError_t launch_perm_trace_machine(const MachinePermArgs& a, uint32_t* block_scratch, hipStream_t s);
+// the lookup constraints of one chip on its quotient domain (the first 2N rows of the bit-reversed LDEs), folded with their
+// weights: addend[p] (extension) = sum_j w_j (phi_j d_a d_b - (m_a d_b + m_b d_a)) + w_F1 is_first (S - sum phi)
+// + w_F2 is_transition (S' - S - sum phi') + w_F3 is_last (S - cumsum); the program kernel adds it before dividing by Z_H
+struct MachineQuotArgs {
+    LookupArgs lk;
+    const uint32_t* lde; uint64_t ld; const uint32_t* perm; uint64_t perm_ld; int log_n;
+    const uint32_t* xs; const uint32_t* sel_first; const uint32_t* sel_last; uint32_t wn_inv;
+    const uint32_t* weights;                       // device: [cols + 3] extension weights, in constraint order
+    Ext cumsum;
+    uint32_t* addend;                              // [2N][4]
+};
+hipError_t launch_lookup_addend(const MachineQuotArgs& a, hipStream_t s);
 
 hipError_t launch_fri_fold(const uint32_t* in, uint32_t* out, const uint32_t* itw, uint64_t half, const Ext& beta, hipStream_t s);
 hipError_t launch_ext_add(uint32_t* dst, const uint32_t* src, uint64_t count, hipStream_t s);

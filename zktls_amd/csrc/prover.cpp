@@ -212,15 +212,16 @@ static int run_quotient(zkhip_ctx* ctx, const uint32_t* lde, size_t ld, int log_
 
 // quotient values of a constraint program (air.h): the interpreter kernel, same outputs as run_quotient
 static int run_quotient_air(zkhip_ctx* ctx, const AirView& air, const uint32_t* lde, size_t ld, int log_n, uint32_t width,
-                            const uint32_t* public_values, const Ext& alpha, uint32_t* out_chunks, uint32_t* lde_out, size_t lde_ld) {
+                            const uint32_t* public_values, const Ext& alpha, uint32_t* out_chunks, uint32_t* lde_out, size_t lde_ld,
+                            const Ext& scale = ext_one(), const uint32_t* addend = nullptr) {
     if (ctx->dom_log_n != log_n || ctx->dom_log_blowup < air.lqd) ZK_TRY(ensure_domain(ctx, log_n, air.lqd));
     std::vector<uint32_t> body, weights;
-    air_device_image(air, alpha, body, weights);
+    air_device_image(air, alpha, body, weights, scale);
     std::vector<uint32_t> pub(air.n_public ? air.n_public : 1, 0u);
     for (uint32_t i = 0; i < air.n_public; i++) pub[i] = to_monty(public_values[i]);
     // the flattened form for the term-parallel kernel (up to 64 public values: they travel in every point's LDS slots)
     std::vector<uint32_t> recs;
-    if (air.n_public <= 64) air_term_records(air, alpha, recs);
+    if (air.n_public <= 64) air_term_records(air, alpha, recs, scale);
     // one staging buffer: body | weights (16-byte aligned) | public values | term records (16-byte aligned)
     const size_t body_w = (body.size() + 3) & ~(size_t)3, pub_w = (pub.size() + 3) & ~(size_t)3;
     std::vector<uint32_t> stage(body_w + weights.size() + pub_w + recs.size(), 0u);
@@ -243,6 +244,7 @@ static int run_quotient_air(zkhip_ctx* ctx, const AirView& air, const uint32_t* 
     q.out = out_chunks; q.lde_out = lde_out; q.lde_ld = lde_ld;
     q.recs = recs.empty() ? nullptr : (const uint32_t*)d_stage + body_w + weights.size() + pub_w;
     q.n_terms = (uint32_t)(recs.size() / 8); q.n_public = air.n_public;
+    q.addend = addend;
     ZK_HIP(launch_quotient_air(q, ctx->stream));
     return ZKHIP_OK;
 }
@@ -509,6 +511,51 @@ static int run_perm_trace(zkhip_ctx* ctx, const uint32_t* d_trace, size_t ld, in
     void* scratch;
     ZK_TRY(ctx_reserve(ctx, S_GATHER_OUT, ((pa.rows + 255) / 256) * 16, &scratch));
     ZK_HIP(launch_perm_trace(pa, (uint32_t*)scratch, ctx->stream));
+    return ZKHIP_OK;
+}
+
+// lookups as data (machine mode): the interaction records of one chip on the device, then the generic permutation trace
+static int lookup_args(zkhip_ctx* ctx, const LookupView& lv, const Ext& gamma, const Ext& beta, const std::vector<uint32_t>& weights, LookupArgs* lk,
+                       const uint32_t** d_weights) {
+    std::vector<uint32_t> recs;
+    lookup_device_records(lv, recs);
+    const size_t rec_w = (recs.size() + 3) & ~(size_t)3;
+    std::vector<uint32_t> stage(rec_w + weights.size(), 0u);
+    memcpy(stage.data(), recs.data(), recs.size() * 4);
+    if (!weights.empty()) memcpy(stage.data() + rec_w, weights.data(), weights.size() * 4);
+    void* d_stage;
+    ZK_TRY(ctx_reserve(ctx, S_LOOKUP, stage.size() * 4, &d_stage));
+    ZK_TRY(h2d(ctx, d_stage, stage.data(), stage.size() * 4));
+    lk->table = (const uint32_t*)d_stage; lk->ni = lv.ni; lk->cols = lv.cols; lk->gamma = gamma;
+    lk->bpow[0] = ext_one();
+    for (int t = 1; t < 9; t++) lk->bpow[t] = ext_mul(lk->bpow[t - 1], beta);
+    if (d_weights) *d_weights = (const uint32_t*)d_stage + rec_w;
+    return ZKHIP_OK;
+}
+static int run_lookup_perm(zkhip_ctx* ctx, const uint32_t* d_trace, size_t ld, int log_n, const LookupView& lv, const Ext& gamma, const Ext& beta,
+                           uint32_t* d_out) {
+    MachinePermArgs a{};
+    ZK_TRY(lookup_args(ctx, lv, gamma, beta, {}, &a.lk, nullptr));
+    a.trace = d_trace; a.ld = ld; a.rows = (uint64_t)1 << log_n; a.out = d_out; a.out_ld = 4 * ((uint64_t)lv.cols + 1);
+    void* scratch;
+    ZK_TRY(ctx_reserve(ctx, S_GATHER_OUT, ((a.rows + 255) / 256) * 16, &scratch));
+    ZK_HIP(launch_perm_trace_machine(a, (uint32_t*)scratch, ctx->stream));
+    return ZKHIP_OK;
+}
+// the chip's lookup constraints on its quotient domain, folded with the LAST cols + 3 powers of alpha (column j: alpha^(cols + 2 - j);
+// is_first, is_transition, is_last rows: alpha^2, alpha, 1)
+static int run_lookup_addend(zkhip_ctx* ctx, const uint32_t* lde, size_t ld, const uint32_t* perm_lde, size_t perm_ld, int log_n, const LookupView& lv,
+                             const Ext& gamma, const Ext& beta, const Ext& alpha, const Ext& cumsum, uint32_t* d_addend) {
+    if (ctx->dom_log_n != log_n) ZK_TRY(ensure_domain(ctx, log_n));
+    std::vector<uint32_t> weights(4 * ((size_t)lv.cols + 3));
+    Ext w = ext_one();
+    for (size_t k = lv.cols + 3; k-- > 0;) { for (int i = 0; i < 4; i++) weights[4 * k + i] = w.c[i]; w = ext_mul(w, alpha); }
+    MachineQuotArgs a{};
+    ZK_TRY(lookup_args(ctx, lv, gamma, beta, weights, &a.lk, &a.weights));
+    a.lde = lde; a.ld = ld; a.perm = perm_lde; a.perm_ld = perm_ld; a.log_n = log_n;
+    a.xs = ctx->dom_xs; a.sel_first = ctx->dom_sel_first; a.sel_last = ctx->dom_sel_last; a.wn_inv = finv(two_adic_generator(log_n));
+    a.cumsum = cumsum; a.addend = d_addend;
+    ZK_HIP(launch_lookup_addend(a, ctx->stream));
     return ZKHIP_OK;
 }
 
@@ -1415,7 +1462,7 @@ int zkhip_verify_shard_air(const uint32_t* program, size_t program_words, const 
 // vector per height that joins the FRI vector when folding reaches that height (p3-fri 0.2.1 TwoAdicFriPcs), one query
 // index with chip c opened at index >> (Hmax - h_c).  Byte layout: DESIGN.md section 6.
 namespace zk {
-constexpr uint32_t CHIPS_VERSION = 4u, CHIPS_VERSION_LOGUP = 5u, CHIPS_VERSION_CROSS = 6u, CHIPS_VERSION_AIR = 9u;
+constexpr uint32_t CHIPS_VERSION = 4u, CHIPS_VERSION_LOGUP = 5u, CHIPS_VERSION_CROSS = 6u, CHIPS_VERSION_AIR = 9u, CHIPS_VERSION_MACHINE = 10u;
 constexpr int MAX_CHIPS = 16;
 
 // The constraint programs in effect for the running zkhip_*_chips_air call on this thread (nullptr: every chip uses the built-in
@@ -1427,11 +1474,32 @@ struct ChipAirScope {
     explicit ChipAirScope(const AirView* const* table) { t_chip_air = table; }
     ~ChipAirScope() { t_chip_air = nullptr; }
 };
+// Machine mode (zkhip_*_machine, proof version 10): every chip runs through a program (its own, or the synthetic AIR written as one:
+// has_prog says which, for the header) and may bring an interaction table (air.h, LookupView).  The number of extension columns of
+// its permutation trace travels in the `pairs` slot of the chip arrays, so the layout code of versions 5 / 6 serves unchanged.
+struct MachineTables { const LookupView* lk[16]; bool has_prog[16]; };
+static thread_local const MachineTables* t_machine = nullptr;
+static const LookupView* lookup_of(int c) { return t_machine ? t_machine->lk[c] : nullptr; }
+static bool header_has_prog(int c) { return t_machine ? t_machine->has_prog[c] : prog_of(c) != nullptr; }
+struct MachineScope {
+    MachineScope(const AirView* const* progs, const MachineTables* m) { t_chip_air = progs; t_machine = m; }
+    ~MachineScope() { t_chip_air = nullptr; t_machine = nullptr; }
+};
+static void lookup_digest(const LookupView& v, uint32_t out[8]) {      // the program-digest sponge over the table's words (cached alike)
+    AirView a;
+    a.w = v.w; a.words = v.words;
+    air_digest_cached(a, out);
+}
 
 static bool any_pairs(const int32_t* pairs, int n) { if (pairs) for (int c = 0; c < n; c++) if (pairs[c]) return true; return false; }
 static size_t perm_width(const int32_t* pairs, int c) { return (pairs && pairs[c]) ? 4 * ((size_t)pairs[c] + 1) : 0; }
-static bool any_cross(const int32_t* partners, int n) { if (partners) for (int c = 0; c < n; c++) if (partners[c] >= 0) return true; return false; }
+static bool any_cross(const int32_t* partners, int n) {
+    if (t_machine) { for (int c = 0; c < n; c++) if (t_machine->lk[c]) return true; return false; }     // machine mode: the sums are always exposed
+    if (partners) for (int c = 0; c < n; c++) if (partners[c] >= 0) return true;
+    return false;
+}
 static uint32_t chips_version(const int32_t* pairs, const int32_t* partners, int n) {
+    if (t_machine) return CHIPS_VERSION_MACHINE;
     if (any_prog(n)) return CHIPS_VERSION_AIR;
     return any_cross(partners, n) ? CHIPS_VERSION_CROSS : (any_pairs(pairs, n) ? CHIPS_VERSION_LOGUP : CHIPS_VERSION);
 }
@@ -1442,12 +1510,12 @@ static int check_chips(const int32_t* log_ns, const uint32_t* widths, const int3
     if ((prm->log_fold != 0 && prm->log_fold != 1) || prm->log_final != 0 || (prm->hash_width != 0 && prm->hash_width != 16) || prm->logup_pairs != 0 || prm->code_width != 0)
         return fail(ZKHIP_ERR_INVALID, "chips: the multi-chip prover uses the SP1 FRI shape (fold by 2, constant final polynomial, width-16 hash) without lookups");
     if (prm->num_queries < 1 || prm->num_queries > 4096 || prm->pow_bits < 0 || prm->pow_bits > 28) return fail(ZKHIP_ERR_INVALID, "chips: queries / pow_bits out of range");
-    if (any_prog(n) && (any_pairs(pairs, n) || any_cross(partners, n))) return fail(ZKHIP_ERR_INVALID, "chips: no lookups next to constraint programs");
+    if (!t_machine && any_prog(n) && (any_pairs(pairs, n) || any_cross(partners, n))) return fail(ZKHIP_ERR_INVALID, "chips: no lookups next to constraint programs (use the machine entries)");
     for (int c = 0; c < n; c++) {
         if (log_ns[c] < 5 || log_ns[c] > 20 || widths[c] == 0 || widths[c] % 4 != 0 || widths[c] > 1024)
             return fail(ZKHIP_ERR_INVALID, "chips: log_n in [5,20], width a multiple of 4 up to 1024");
         if (c && log_ns[c] > log_ns[c - 1]) return fail(ZKHIP_ERR_INVALID, "chips: tallest first");
-        if (pairs && (pairs[c] < 0 || pairs[c] > 64 || (uint32_t)pairs[c] * 8 > widths[c])) return fail(ZKHIP_ERR_INVALID, "chips: logup_pairs out of range");
+        if (pairs && (pairs[c] < 0 || pairs[c] > 64 || (!t_machine && (uint32_t)pairs[c] * 8 > widths[c]))) return fail(ZKHIP_ERR_INVALID, "chips: logup_pairs out of range");
         if (partners && partners[c] >= 0) {
             const int d = partners[c];
             if (!pairs || d >= n || d == c || partners[d] != c || pairs[c] == 0 || pairs[d] != pairs[c] || log_ns[d] != log_ns[c])
@@ -1463,7 +1531,10 @@ static size_t chips_proof_words(const int32_t* log_ns, const uint32_t* widths, c
     const bool lk = any_pairs(pairs, n), cross = any_cross(partners, n);
     const size_t b = (size_t)prm->log_blowup, Hmax = (size_t)log_ns[0] + b, L = (size_t)log_ns[0];
     size_t words = 8 + (cross ? 4 : (lk ? 3 : 2)) * (size_t)n + 16 + (lk ? 8 : 0) + 8 * L + 4 + 1, perq = 16 * Hmax, hp = 0;
-    if (any_prog(n)) { words += (size_t)n; for (int c = 0; c < n; c++) if (prog_of(c)) words += 8; }
+    if (t_machine) {
+        words = 8 + 4 * (size_t)n + 16 + (lk ? 8 : 0) + 8 * L + 4 + 1;
+        for (int c = 0; c < n; c++) words += (header_has_prog(c) ? 8 : 0) + (lookup_of(c) ? 8 : 0);
+    } else if (any_prog(n)) { words += (size_t)n; for (int c = 0; c < n; c++) if (prog_of(c)) words += 8; }
     for (int c = 0; c < n; c++) {
         const size_t wp = perm_width(pairs, c);
         words += 8 * (size_t)widths[c] + 8 * wp + 32 + ((cross && wp) ? 4 : 0);
@@ -1485,14 +1556,21 @@ static void chips_transcript_init(Challenger& ch, const int32_t* log_ns, const u
     ch.observe_canonical((uint32_t)n_public);
     for (int c = 0; c < n; c++) {
         ch.observe_canonical((uint32_t)log_ns[c]); ch.observe_canonical(widths[c]);
+        if (t_machine) { ch.observe_canonical(header_has_prog(c) ? 1u : 0u); ch.observe_canonical(lookup_of(c) ? lookup_of(c)->ni : 0u); continue; }
         if (lk) ch.observe_canonical((uint32_t)pairs[c]);
         if (cross) ch.observe_canonical((uint32_t)(partners[c] + 1));
         if (any_prog(n)) ch.observe_canonical(prog_of(c) ? 1u : 0u);
     }
     for (int c = 0; c < n; c++)
-        if (prog_of(c)) {
+        if (header_has_prog(c)) {
             uint32_t dg[8];
             air_digest_cached(*prog_of(c), dg);
+            for (int i = 0; i < 8; i++) ch.observe_canonical(dg[i]);
+        }
+    for (int c = 0; c < n; c++)
+        if (lookup_of(c)) {
+            uint32_t dg[8];
+            lookup_digest(*lookup_of(c), dg);
             for (int i = 0; i < 8; i++) ch.observe_canonical(dg[i]);
         }
 }
@@ -1561,11 +1639,13 @@ int zkhip_prove_chips(zkhip_ctx* ctx, const zkhip_chip* chips, int n, const uint
     pf[pos++] = (uint32_t)Q; pf[pos++] = (uint32_t)prm->pow_bits; pf[pos++] = (uint32_t)n_public; pf[pos++] = 16u;
     for (int c = 0; c < n; c++) {
         pf[pos++] = (uint32_t)log_ns[c]; pf[pos++] = widths[c];
+        if (t_machine) { pf[pos++] = header_has_prog(c) ? 1u : 0u; pf[pos++] = lookup_of(c) ? lookup_of(c)->ni : 0u; continue; }
         if (lk) pf[pos++] = (uint32_t)pairs[c];
         if (cross) pf[pos++] = (uint32_t)(partners[c] + 1);
         if (any_prog(n)) pf[pos++] = prog_of(c) ? 1u : 0u;
     }
-    for (int c = 0; c < n; c++) if (prog_of(c)) { air_digest_cached(*prog_of(c), pf + pos); pos += 8; }
+    for (int c = 0; c < n; c++) if (header_has_prog(c)) { air_digest_cached(*prog_of(c), pf + pos); pos += 8; }
+    for (int c = 0; c < n; c++) if (lookup_of(c)) { lookup_digest(*lookup_of(c), pf + pos); pos += 8; }
     Challenger ch;
     chips_transcript_init(ch, log_ns, widths, pairs, partners, n, prm, n_public);
     uint32_t root[8];
@@ -1603,7 +1683,8 @@ int zkhip_prove_chips(zkhip_ctx* ctx, const zkhip_chip* chips, int n, const uint
         MatDesc pmats[MAX_CHIPS]; int plh[MAX_CHIPS]; int np = 0;
         for (int c = 0; c < n; c++) {
             if (!wp[c]) continue;
-            ZK_TRY(run_perm_trace(ctx, chips[c].d_trace, chips[c].ld, log_ns[c], (uint32_t)pairs[c], gamma, beta_l, (uint32_t*)v_perm));
+            if (t_machine) ZK_TRY(run_lookup_perm(ctx, chips[c].d_trace, chips[c].ld, log_ns[c], *lookup_of(c), gamma, beta_l, (uint32_t*)v_perm));
+            else ZK_TRY(run_perm_trace(ctx, chips[c].d_trace, chips[c].ld, log_ns[c], (uint32_t)pairs[c], gamma, beta_l, (uint32_t*)v_perm));
             if (cross)          // the running sum's last value: row N - 1, column S
                 ZK_TRY(d2h(ctx, &cumsum[c], (const uint32_t*)v_perm + (((size_t)1 << log_ns[c]) - 1) * wp[c] + 4 * (size_t)pairs[c], 16));
             ZK_TRY(op_coset_lde(ctx, (const uint32_t*)v_perm, wp[c], plde + pl_off[c], wp[c], log_ns[c], (uint32_t)wp[c], b, MONTY_GEN));
@@ -1625,7 +1706,15 @@ int zkhip_prove_chips(zkhip_ctx* ctx, const zkhip_chip* chips, int n, const uint
         LogupIn lu;
         if (wp[c]) { lu.pairs = (uint32_t)pairs[c]; lu.perm_lde = plde + pl_off[c]; lu.gamma = gamma; lu.beta = beta_l; lu.cumsum = cumsum[c]; }
         const bool own_coset_direct = b == 1;             // as in the single-matrix prover
-        if (prog_of(c)) ZK_TRY(run_quotient_air(ctx, *prog_of(c), tlde + tl_off[c], widths[c], log_ns[c], widths[c], public_values, alpha, qchunk,
+        if (t_machine && lookup_of(c)) {
+            // the chip's lookup constraints fold after its program's: the program's weights move up by alpha^(cols + 3)
+            const LookupView& lv = *lookup_of(c);
+            void* v_add;
+            ZK_TRY(ctx_reserve(ctx, S_ADDEND, ((size_t)2 << log_ns[c]) * 16, &v_add));
+            ZK_TRY(run_lookup_addend(ctx, tlde + tl_off[c], widths[c], plde + pl_off[c], wp[c], log_ns[c], lv, gamma, beta_l, alpha, cumsum[c], (uint32_t*)v_add));
+            ZK_TRY(run_quotient_air(ctx, *prog_of(c), tlde + tl_off[c], widths[c], log_ns[c], widths[c], public_values, alpha, qchunk,
+                                    own_coset_direct ? qlde + ql_off[c] : nullptr, 8, ext_pow(alpha, lv.cols + 3), (const uint32_t*)v_add));
+        } else if (prog_of(c)) ZK_TRY(run_quotient_air(ctx, *prog_of(c), tlde + tl_off[c], widths[c], log_ns[c], widths[c], public_values, alpha, qchunk,
                                                 own_coset_direct ? qlde + ql_off[c] : nullptr, 8));
         else ZK_TRY(run_quotient(ctx, tlde + tl_off[c], widths[c], log_ns[c], widths[c], alpha, lu, qchunk, own_coset_direct ? qlde + ql_off[c] : nullptr, 8));
         const uint32_t w2n = two_adic_generator(log_ns[c] + 1);
@@ -1833,14 +1922,22 @@ int zkhip_verify_chips(const uint8_t* proof, size_t len, const int32_t* log_ns, 
     for (int c = 0; c < n; c++) {
         if (pf[pos] != (uint32_t)log_ns[c] || pf[pos + 1] != widths[c]) return reject(3);
         pos += 2;
+        if (t_machine) { if (pf[pos] != (header_has_prog(c) ? 1u : 0u) || pf[pos + 1] != (lookup_of(c) ? lookup_of(c)->ni : 0u)) return reject(3); pos += 2; continue; }
         if (lk) { if (pf[pos] != (uint32_t)pairs[c]) return reject(3); pos++; }
         if (cross) { if (pf[pos] != (uint32_t)(partners[c] + 1)) return reject(3); pos++; }
         if (any_prog(n)) { if (pf[pos] != (prog_of(c) ? 1u : 0u)) return reject(3); pos++; }
     }
     for (int c = 0; c < n; c++)
-        if (prog_of(c)) {
+        if (header_has_prog(c)) {
             uint32_t dg[8];
             air_digest_cached(*prog_of(c), dg);
+            for (int i = 0; i < 8; i++) if (pf[pos + i] != dg[i]) return reject(3);
+            pos += 8;
+        }
+    for (int c = 0; c < n; c++)
+        if (lookup_of(c)) {
+            uint32_t dg[8];
+            lookup_digest(*lookup_of(c), dg);
             for (int i = 0; i < 8; i++) if (pf[pos + i] != dg[i]) return reject(3);
             pos += 8;
         }
@@ -1905,7 +2002,13 @@ int zkhip_verify_chips(const uint8_t* proof, size_t len, const int32_t* log_ns, 
             acc = ext_add(ext_mul(acc, alpha), c2);
             acc = ext_add(ext_mul(acc, alpha), c3);
         }
-        if (wp[c]) {
+        if (wp[c] && t_machine) {
+            const LookupView& lv = *lookup_of(c);
+            const Ext sel_last = ext_mul(zh, ext_inv(ext_sub_base(zeta, finv(gn))));
+            std::vector<Ext> pl(lv.cols + 1), pn(lv.cols + 1);
+            for (uint32_t q = 0; q <= lv.cols; q++) { pl[q] = recombine(&opl[c][4 * q]); pn[q] = recombine(&opn[c][4 * q]); }
+            acc = lookup_fold_ext(acc, lv, loc[c].data(), pl.data(), pn.data(), gamma, beta_l, sel_first, sel_trans, sel_last, alpha, cumsum[c]);
+        } else if (wp[c]) {
             const uint32_t LQ = (uint32_t)pairs[c];
             const Ext sel_last = ext_mul(zh, ext_inv(ext_sub_base(zeta, finv(gn))));
             Ext sum_l = ext_zero(), sum_n = ext_zero();
@@ -2069,6 +2172,71 @@ int zkhip_verify_chips_air(const uint8_t* proof, size_t len, const int32_t* log_
     if (chip_programs(programs, program_words, widths, n_chips, n_public, views, table) != ZKHIP_OK) { if (reason) *reason = 1; return ZKHIP_ERR_VERIFY; }
     ChipAirScope scope(table);
     return zkhip_verify_chips(proof, len, log_ns, widths, nullptr, nullptr, n_chips, public_values, n_public, prm, reason);
+}
+
+// ---- the machine: chips with programs AND interaction tables (lookups as data); proof version 10 ----
+struct MachineSetup {
+    AirView views[MAX_CHIPS];
+    const AirView* table[MAX_CHIPS];
+    LookupView lks[MAX_CHIPS];
+    MachineTables mt;
+    std::vector<uint32_t> synthetic[MAX_CHIPS];       // the built-in AIR written as a program, for chips that bring none
+    int32_t cols[MAX_CHIPS];
+};
+static int machine_setup(const uint32_t* const* programs, const size_t* program_words, const uint32_t* const* tables, const size_t* table_words,
+                         const uint32_t* widths, int n, size_t n_public, MachineSetup& m) {
+    if (!programs || !program_words || !tables || !table_words || !widths || n < 1 || n > MAX_CHIPS) return fail(ZKHIP_ERR_INVALID, "machine: bad arguments");
+    for (int c = 0; c < n; c++) {
+        const uint32_t* prog = programs[c];
+        size_t words = program_words[c];
+        m.mt.has_prog[c] = prog != nullptr;
+        if (!prog) {
+            size_t need = 0;
+            if (zkhip_air_synthetic(widths[c], n_public, nullptr, 0, &need) != ZKHIP_OK) return ZKHIP_ERR_INVALID;
+            m.synthetic[c].resize(need);
+            ZK_TRY(zkhip_air_synthetic(widths[c], n_public, m.synthetic[c].data(), need, &need));
+            prog = m.synthetic[c].data(); words = need;
+        }
+        if (!air_validate(prog, words, widths[c], n_public, &m.views[c])) return fail(ZKHIP_ERR_INVALID, "machine: malformed constraint program (or its n_public differs from the shard's)");
+        if (m.views[c].lqd != 1) return fail(ZKHIP_ERR_INVALID, "machine: programs of degree 4 / 5 need four quotient chunks; the multi-chip prover commits two");
+        m.table[c] = &m.views[c];
+        m.mt.lk[c] = nullptr;
+        m.cols[c] = 0;
+        if (tables[c]) {
+            if (!lookup_validate(tables[c], table_words[c], widths[c], &m.lks[c])) return fail(ZKHIP_ERR_INVALID, "machine: malformed interaction table");
+            m.mt.lk[c] = &m.lks[c];
+            m.cols[c] = (int32_t)m.lks[c].cols;
+        }
+    }
+    return ZKHIP_OK;
+}
+size_t zkhip_machine_proof_size(const int32_t* log_ns, const uint32_t* widths, const uint32_t* const* programs, const size_t* program_words,
+                                const uint32_t* const* tables, const size_t* table_words, int n_chips, const zkhip_params* prm, size_t n_public) {
+    MachineSetup m;
+    if (machine_setup(programs, program_words, tables, table_words, widths, n_chips, n_public, m) != ZKHIP_OK) return 0;
+    MachineScope scope(m.table, &m.mt);
+    return zkhip_chips_proof_size(log_ns, widths, m.cols, nullptr, n_chips, prm, n_public);
+}
+int zkhip_prove_machine(zkhip_ctx* ctx, const zkhip_chip* chips, const uint32_t* const* programs, const size_t* program_words,
+                        const uint32_t* const* tables, const size_t* table_words, int n_chips, const uint32_t* public_values, size_t n_public,
+                        const zkhip_params* prm, uint8_t* proof, size_t cap, size_t* len) {
+    if (!chips || n_chips < 1 || n_chips > MAX_CHIPS) return fail(ZKHIP_ERR_INVALID, "prove_machine: bad arguments");
+    uint32_t widths[MAX_CHIPS];
+    for (int c = 0; c < n_chips; c++) widths[c] = chips[c].width;
+    MachineSetup m;
+    ZK_TRY(machine_setup(programs, program_words, tables, table_words, widths, n_chips, n_public, m));
+    zkhip_chip mine[MAX_CHIPS];
+    for (int c = 0; c < n_chips; c++) { mine[c] = chips[c]; mine[c].logup_pairs = m.cols[c]; mine[c].partner = -1; }
+    MachineScope scope(m.table, &m.mt);
+    return zkhip_prove_chips(ctx, mine, n_chips, public_values, n_public, prm, proof, cap, len);
+}
+int zkhip_verify_machine(const uint8_t* proof, size_t len, const int32_t* log_ns, const uint32_t* widths, const uint32_t* const* programs,
+                         const size_t* program_words, const uint32_t* const* tables, const size_t* table_words, int n_chips,
+                         const uint32_t* public_values, size_t n_public, const zkhip_params* prm, int* reason) {
+    MachineSetup m;
+    if (machine_setup(programs, program_words, tables, table_words, widths, n_chips, n_public, m) != ZKHIP_OK) { if (reason) *reason = 1; return ZKHIP_ERR_VERIFY; }
+    MachineScope scope(m.table, &m.mt);
+    return zkhip_verify_chips(proof, len, log_ns, widths, m.cols, nullptr, n_chips, public_values, n_public, prm, reason);
 }
 
 int zkhip_last_prove_debug(zkhip_ctx* ctx, zkhip_prove_debug* out) {

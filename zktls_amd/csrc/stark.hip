@@ -273,6 +273,7 @@ __global__ void __launch_bounds__(256) quotient_air_kernel(QuotientAirArgs a) {
     }
     const uint32_t chunk = e & (nq - 1u);
     Ext r = Ext{{dacc_finish(acc[0]), dacc_finish(acc[1]), dacc_finish(acc[2]), dacc_finish(acc[3])}};
+    if (a.addend) r = ext_add(r, ld_ext(a.addend + 4 * (uint64_t)p));
     const uint32_t iz = chunk == 0 ? a.inv_zh[0] : (chunk == 1 ? a.inv_zh[1] : (chunk == 2 ? a.inv_zh[2] : a.inv_zh[3]));
     r = ext_mul_base_dev(r, iz);
     st_ext(a.out + ((uint64_t)chunk * (m >> a.log_qd) + (e >> a.log_qd)) * 4, r);
@@ -365,6 +366,7 @@ __global__ void __launch_bounds__(256) quotient_air_terms_kernel(QuotientAirArgs
             for (int k = 0; k < SL; k++) sum = dadd(sum, slots[(size_t)(tid * 4 + i) * 257 + k]);
             r.c[i] = sum;
         }
+        if (a.addend) r = ext_add(r, ld_ext(a.addend + 4 * (uint64_t)p));
         const uint32_t chunk = e & (nq - 1u);
         const uint32_t iz = chunk == 0 ? a.inv_zh[0] : (chunk == 1 ? a.inv_zh[1] : (chunk == 2 ? a.inv_zh[2] : a.inv_zh[3]));
         r = ext_mul_base_dev(r, iz);
@@ -730,6 +732,110 @@ hipError_t launch_perm_trace(const PermArgs& a, uint32_t* block_scratch, hipStre
     e = hipGetLastError();
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL(perm_fixup_kernel, dim3(nblocks), dim3(PERM_BLOCK), 0, s, a, block_scratch);
+    return hipGetLastError();
+}
+
+// ---- lookups as data (kernels.h, LookupArgs): the same three launches with the interactions read from a table
+ZK_D Ext lookup_fingerprint(const LookupArgs& lk, const uint32_t* rec, const uint32_t* row) {
+    Ext d = ext_add_base(lk.gamma, rec[2]);
+    for (uint32_t v = 0; v < rec[3]; v++) d = ext_add(d, ext_mul_base_dev(lk.bpow[v + 1], row[rec[4 + v]]));
+    return d;
+}
+ZK_D uint32_t lookup_mult(const uint32_t* rec, const uint32_t* row) {       // signed multiplicity, base field
+    const uint32_t m = rec[1] == 0xFFFFFFFFu ? MONTY_R1 : row[rec[1]];
+    return rec[0] ? (m ? P - m : 0u) : m;
+}
+__global__ void __launch_bounds__(PERM_BLOCK) perm_rows_machine_kernel(MachinePermArgs a, uint32_t* __restrict__ block_tot) {
+    __shared__ uint32_t sh[PERM_BLOCK * 4];
+    const uint64_t i = (uint64_t)blockIdx.x * PERM_BLOCK + threadIdx.x;
+    Ext sum = ext_zero();
+    if (i < a.rows) {
+        const uint32_t* row = a.trace + i * a.ld;
+        uint32_t* prow = a.out + i * a.out_ld;
+        for (uint32_t j = 0; j < a.lk.cols; j++) {
+            const uint32_t* ra = a.lk.table + (size_t)(2 * j) * LOOKUP_REC_WORDS;
+            const Ext da = lookup_fingerprint(a.lk, ra, row);
+            const uint32_t ma = lookup_mult(ra, row);
+            Ext phi;
+            if (2 * j + 1 < a.lk.ni) {
+                const uint32_t* rb = ra + LOOKUP_REC_WORDS;
+                const Ext db = lookup_fingerprint(a.lk, rb, row);
+                const uint32_t mb = lookup_mult(rb, row);
+                // m_a / d_a + m_b / d_b = (m_a d_b + m_b d_a) / (d_a d_b): one inversion per column; 1/0 = 0 takes the direct formula
+                const Ext d = ext_mul_dev(da, db);
+                phi = ext_eq(d, ext_zero()) ? ext_add(ext_mul_base_dev(ext_inv_dev(da), ma), ext_mul_base_dev(ext_inv_dev(db), mb))
+                                            : ext_mul_dev(ext_add(ext_mul_base_dev(db, ma), ext_mul_base_dev(da, mb)), ext_inv_dev(d));
+            } else phi = ext_mul_base_dev(ext_inv_dev(da), ma);
+            st_ext(prow + 4 * j, phi);
+            sum = ext_add(sum, phi);
+        }
+    }
+    for (int k = 0; k < 4; k++) sh[threadIdx.x * 4 + k] = sum.c[k];
+    __syncthreads();
+    for (int off = 1; off < PERM_BLOCK; off <<= 1) {
+        Ext o = ext_zero();
+        if ((int)threadIdx.x >= off) o = Ext{{sh[(threadIdx.x - off) * 4], sh[(threadIdx.x - off) * 4 + 1], sh[(threadIdx.x - off) * 4 + 2], sh[(threadIdx.x - off) * 4 + 3]}};
+        __syncthreads();
+        sum = ext_add(sum, o);
+        for (int k = 0; k < 4; k++) sh[threadIdx.x * 4 + k] = sum.c[k];
+        __syncthreads();
+    }
+    if (i < a.rows) st_ext(a.out + i * a.out_ld + 4 * a.lk.cols, sum);
+    if (threadIdx.x == PERM_BLOCK - 1) st_ext(block_tot + 4 * (uint64_t)blockIdx.x, sum);
+}
+hipError_t launch_perm_trace_machine(const MachinePermArgs& a, uint32_t* block_scratch, hipStream_t s) {
+    const uint32_t nblocks = (uint32_t)((a.rows + PERM_BLOCK - 1) / PERM_BLOCK);
+    hipLaunchKernelGGL(perm_rows_machine_kernel, dim3(nblocks), dim3(PERM_BLOCK), 0, s, a, block_scratch);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(perm_scan_blocks_kernel, dim3(1), dim3(1024), 0, s, block_scratch, nblocks);
+    e = hipGetLastError();
+    if (e != hipSuccess) return e;
+    PermArgs fix{};                                   // the fix-up only needs where the running-sum column lives
+    fix.rows = a.rows; fix.pairs = a.lk.cols; fix.out = a.out; fix.out_ld = a.out_ld;
+    hipLaunchKernelGGL(perm_fixup_kernel, dim3(nblocks), dim3(PERM_BLOCK), 0, s, fix, block_scratch);
+    return hipGetLastError();
+}
+__global__ void __launch_bounds__(256) lookup_addend_kernel(MachineQuotArgs a) {
+    const int H = a.log_n + 1;
+    const uint32_t m = 1u << H;
+    const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= m) return;
+    const uint32_t e = __brev(p) >> (32 - H);
+    const uint32_t pn = __brev((e + 2u) & (m - 1)) >> (32 - H);
+    const uint32_t* row = a.lde + (uint64_t)p * a.ld;
+    const uint32_t* prow = a.perm + (uint64_t)p * a.perm_ld;
+    const uint32_t* pnrow = a.perm + (uint64_t)pn * a.perm_ld;
+    Ext r = ext_zero(), sphi = ext_zero(), sphin = ext_zero();
+    for (uint32_t j = 0; j < a.lk.cols; j++) {
+        const uint32_t* ra = a.lk.table + (size_t)(2 * j) * LOOKUP_REC_WORDS;
+        const Ext da = lookup_fingerprint(a.lk, ra, row);
+        const uint32_t ma = lookup_mult(ra, row);
+        const Ext phi = ld_ext(prow + 4 * j);
+        Ext c;
+        if (2 * j + 1 < a.lk.ni) {
+            const uint32_t* rb = ra + LOOKUP_REC_WORDS;
+            const Ext db = lookup_fingerprint(a.lk, rb, row);
+            const uint32_t mb = lookup_mult(rb, row);
+            c = ext_sub(ext_mul_dev(ext_mul_dev(phi, da), db), ext_add(ext_mul_base_dev(db, ma), ext_mul_base_dev(da, mb)));
+        } else c = ext_sub_base(ext_mul_dev(phi, da), ma);
+        r = ext_add(r, ext_mul_dev(c, ld_ext(a.weights + 4 * j)));
+        sphi = ext_add(sphi, phi);
+        sphin = ext_add(sphin, ld_ext(pnrow + 4 * j));
+    }
+    const Ext S = ld_ext(prow + 4 * a.lk.cols), Sn = ld_ext(pnrow + 4 * a.lk.cols);
+    const uint32_t sel_trans = dsub(a.xs[p], a.wn_inv);
+    const Ext F1 = ext_mul_base_dev(ld_ext(a.weights + 4 * a.lk.cols), a.sel_first[p]);
+    const Ext F2 = ext_mul_base_dev(ld_ext(a.weights + 4 * (a.lk.cols + 1)), sel_trans);
+    const Ext F3 = ext_mul_base_dev(ld_ext(a.weights + 4 * (a.lk.cols + 2)), a.sel_last[p]);
+    r = ext_add(r, ext_mul_dev(F1, ext_sub(S, sphi)));
+    r = ext_add(r, ext_mul_dev(F2, ext_sub(ext_sub(Sn, S), sphin)));
+    r = ext_add(r, ext_mul_dev(F3, ext_sub(S, a.cumsum)));
+    st_ext(a.addend + 4 * (uint64_t)p, r);
+}
+hipError_t launch_lookup_addend(const MachineQuotArgs& a, hipStream_t s) {
+    const uint64_t m = 2ull << a.log_n;
+    hipLaunchKernelGGL(lookup_addend_kernel, dim3((unsigned)((m + 255) / 256)), dim3(256), 0, s, a);
     return hipGetLastError();
 }
 

@@ -436,6 +436,26 @@ class Context:
                                              buf.ctypes.data_as(u8p), size, C.byref(got)))
         return buf[: got.value]
 
+    def prove_machine(self, chips, programs, tables, public_values=(), params=None):
+        """chips: [(device buffer, log_n, width), ...] tallest first; programs[c] / tables[c]: the chip's constraint program and its
+        interaction table (numpy u32 words) or None -- a machine whose tables look each other up (lookups as data, version 10)"""
+        params = params or Params(1, 100, 16, 0)
+        n = len(chips)
+        arr = (_lib.Chip * n)(*[_lib.Chip(b.ptr, w, ln, w, 0, -1) for b, ln, w in chips])
+        log_ns = (C.c_int32 * n)(*[c[1] for c in chips])
+        widths = (C.c_uint32 * n)(*[c[2] for c in chips])
+        kp, pp, pw = _program_table(programs)
+        kt, tp, tw = _program_table(tables)
+        pv = np.ascontiguousarray(np.array(public_values, dtype=np.uint32))
+        size = self.lib.zkhip_machine_proof_size(log_ns, widths, pp, pw, tp, tw, n, C.byref(params), pv.size)
+        if size == 0:
+            check(-1)
+        buf = np.empty(size, dtype=np.uint8)
+        got = C.c_size_t(0)
+        check(self.lib.zkhip_prove_machine(self.handle, arr, pp, pw, tp, tw, n, pv.ctypes.data_as(u32p), pv.size, C.byref(params),
+                                           buf.ctypes.data_as(u8p), size, C.byref(got)))
+        return buf[: got.value]
+
     def prove_debug(self):
         d = ProveDebug()
         check(self.lib.zkhip_last_prove_debug(self.handle, C.byref(d)))
@@ -570,6 +590,21 @@ def _program_table(programs):
     pp = (u32p * n)(*[(p.ctypes.data_as(u32p) if p is not None else None) for p in keep])
     pw = (C.c_size_t * n)(*[(p.size if p is not None else 0) for p in keep])
     return keep, pp, pw
+
+
+def verify_machine(proof, log_ns, widths, programs, tables, public_values=(), params=None):
+    params = params or Params(1, 100, 16)
+    lib = _lib.load()
+    pr = np.ascontiguousarray(proof, dtype=np.uint8)
+    pv = np.ascontiguousarray(np.array(public_values, dtype=np.uint32))
+    n = len(log_ns)
+    ln = (C.c_int32 * n)(*[int(x) for x in log_ns])
+    ws = (C.c_uint32 * n)(*[int(x) for x in widths])
+    kp, pp, pw = _program_table(programs)
+    kt, tp, tw = _program_table(tables)
+    reason = C.c_int(0)
+    rc = lib.zkhip_verify_machine(pr.ctypes.data_as(u8p), pr.size, ln, ws, pp, pw, tp, tw, n, pv.ctypes.data_as(u32p), pv.size, C.byref(params), C.byref(reason))
+    return rc, reason.value
 
 
 def verify_chips_air(proof, log_ns, widths, programs, public_values=(), params=None):
