@@ -49,3 +49,34 @@ def test_a_prover_cannot_hide_an_unbalanced_lookup(ctx, oracle):
     chips = [(ctx.from_numpy(t), ln, w) for t, ln, w in zip(traces, lns, ws)]
     proof = ctx.prove_machine(chips, progs, tables, pub, Params(1, 6, 4))
     assert verify_machine(proof, lns, ws, progs, tables, pub, Params(1, 6, 4)) == (-6, 11)
+
+
+def test_sha256_chip_with_its_limbs_range_checked_by_a_table(ctx, oracle):
+    """a machine of two real tables: the SHA-256 compression chip sends the four 16-bit limbs its own constraints do not range-check
+    (OUT of d and h) to a 2^16-row range table with multiplicities; bytes equal the oracle's, digest against hashlib"""
+    import hashlib
+    import sha256_air as S
+    from zktls_amd.device import sha256_air
+    O = oracle
+    V = O.air_var
+    msg = bytes(range(251)) * 3                                              # 753 bytes -> 12 blocks -> 16 blocks, 2^10 rows
+    sha_t, sha_pub = S.trace(S.pad(msg))
+    assert S.digest_bytes(sha_pub) == hashlib.sha256(msg).digest()
+    d_sha, limbs = ctx.sha256_gen_trace(S.pad(msg))
+    sent = [S.OUT + 6, S.OUT + 7, S.OUT + 14, S.OUT + 15]                    # OUT limb pairs of d (word 3) and h (word 7)
+    sha_tab = O.interaction_table([(O.SEND, None, 16, [c]) for c in sent])
+    table = np.zeros((1 << 16, 4), dtype=np.uint32)
+    table[:, 0] = np.arange(1 << 16)
+    table[:, 1] = np.bincount(sha_t[:, sent].ravel(), minlength=1 << 16)
+    table_prog = O.air_program(4, 16, [(O.SEL_FIRST, [(1, [V(0)])]),
+                                       (O.SEL_TRANSITION, [(1, [V(0, True)]), (O.P - 1, [V(0)]), (O.P - 1, [])])])
+    table_tab = O.interaction_table([(O.RECEIVE, 1, 16, [0])])
+    progs, tables = [table_prog, sha256_air()], [table_tab, sha_tab]
+    chips = [(ctx.from_numpy(table), 16, 4), (d_sha, 10, 608)]
+    proof = ctx.prove_machine(chips, progs, tables, sha_pub, Params(1, 12, 4))
+    oproof = O.prove_machine([table, sha_t], [table_prog, S.program()], tables, sha_pub, O.default_params(1, 12, 4))
+    assert proof.tobytes() == oproof.tobytes()
+    assert verify_machine(proof, [16, 10], [4, 608], progs, tables, sha_pub, Params(1, 12, 4)) == (0, 0)
+    wrong = list(sha_pub)
+    wrong[0] ^= 1
+    assert verify_machine(proof, [16, 10], [4, 608], progs, tables, wrong, Params(1, 12, 4))[0] == -6

@@ -5,17 +5,36 @@ sys.path.insert(0, "/root/repo"); sys.path.insert(0, "/root/repo/tests")
 import numpy as np
 import oracle_lib as O
 import airs
-from zktls_amd.device import Context, verify_shard, verify_chips, verify_shard_air, verify_chips_air
+from zktls_amd.device import Context, verify_shard, verify_chips, verify_shard_air, verify_chips_air, verify_machine
+import machines
 from zktls_amd._lib import Params
 O.set_threads(8)
 budget = float(sys.argv[1]) if len(sys.argv) > 1 else 60.0
 rng = np.random.default_rng(int(time.time()))
 ctx = Context(0)
-t0 = time.time(); n_single = n_chips = n_air = n_machine = 0
+t0 = time.time(); n_single = n_chips = n_air = n_machine = n_lookup = 0
 SEED = int(rng.integers(1, 2**40))
 while time.time() - t0 < budget:
     r_kind = rng.random()
-    if r_kind < 0.1:
+    if r_kind < 0.05:
+        # a machine whose tables look each other up (interaction tables: multiplicities, buses, 1- and 2-tuples), plus bystanders
+        lt = int(rng.integers(5, 9)); lu = int(rng.integers(lt, 11))
+        traces, progs, tables, pub = machines.range_machine(lt, lu, seed=int(rng.integers(0, 2**31)))
+        extra = []
+        for i in range(int(rng.integers(0, 3))):
+            hgt = int(rng.integers(5, lu + 2)); extra.append(O.gen_trace(SEED, 50 + i, hgt, 4 * int(rng.integers(1, 6))))
+        allt = sorted([(t, p_, tb) for t, p_, tb in zip(traces, progs, tables)] + [(t, None, None) for t in extra], key=lambda e: -e[0].shape[0])
+        traces, progs, tables = [e[0] for e in allt], [e[1] for e in allt], [e[2] for e in allt]
+        lns, ws = [t.shape[0].bit_length() - 1 for t in traces], [t.shape[1] for t in traces]
+        if max(lns.count(x) for x in lns) > 4: continue
+        prm = (int(rng.integers(1, 4)), int(rng.integers(1, 12)), int(rng.integers(0, 7)))
+        dev = [ctx.from_numpy(t) for t in traces]
+        pf = ctx.prove_machine(list(zip(dev, lns, ws)), progs, tables, pub, Params(*prm))
+        assert pf.tobytes() == O.prove_machine(traces, progs, tables, pub, O.default_params(*prm)).tobytes(), ("lookup machine", lns, ws, prm)
+        assert verify_machine(pf, lns, ws, progs, tables, pub, Params(*prm)) == (0, 0)
+        for d in dev: d.free()
+        n_lookup += 1
+    elif r_kind < 0.1:
         # a machine: several tables with their own constraint programs (or the synthetic AIR) in one proof -- version 9.
         # Table 0 is a pseudo-random degree-<=3 AIR; counter tables and synthetic tables share its three public values.
         n = int(rng.integers(1, 7))
@@ -96,5 +115,5 @@ while time.time() - t0 < budget:
         assert verify_chips(pf, [c[0] for c in chips], [c[1] for c in chips], [7], Params(*prm), prs, pas if cross else None) == (0, 0)
         for d in dev: d.free()
         n_chips += 1
-print("ok: %d single-matrix, %d multi-chip, %d constraint-program and %d machine (chips with programs) configurations in %.0f s"
-      % (n_single, n_chips, n_air, n_machine, time.time() - t0))
+print("ok: %d single-matrix, %d multi-chip, %d constraint-program, %d chips-with-programs and %d lookup-machine configurations in %.0f s"
+      % (n_single, n_chips, n_air, n_machine, n_lookup, time.time() - t0))
