@@ -82,6 +82,25 @@ extern "C" {
         proof: *const u8, len: usize, log_n: c_int, width: u32,
         public_values: *const u32, n_public: usize, prm: *const ZkhipParams, reason: *mut c_int,
     ) -> c_int;
+    // chips with their own constraint programs / the machine with interaction tables (include/zkhip.h; NULL entries: the synthetic AIR / no lookups)
+    pub fn zkhip_prove_chips_air(
+        ctx: *mut ZkhipCtx, chips: *const ZkhipChip, programs: *const *const u32, program_words: *const usize, n_chips: c_int,
+        public_values: *const u32, n_public: usize, prm: *const ZkhipParams, proof: *mut u8, cap: usize, len: *mut usize,
+    ) -> c_int;
+    pub fn zkhip_machine_proof_size(
+        log_ns: *const i32, widths: *const u32, programs: *const *const u32, program_words: *const usize,
+        tables: *const *const u32, table_words: *const usize, n_chips: c_int, prm: *const ZkhipParams, n_public: usize,
+    ) -> usize;
+    pub fn zkhip_prove_machine(
+        ctx: *mut ZkhipCtx, chips: *const ZkhipChip, programs: *const *const u32, program_words: *const usize,
+        tables: *const *const u32, table_words: *const usize, n_chips: c_int,
+        public_values: *const u32, n_public: usize, prm: *const ZkhipParams, proof: *mut u8, cap: usize, len: *mut usize,
+    ) -> c_int;
+    pub fn zkhip_verify_machine(
+        proof: *const u8, len: usize, log_ns: *const i32, widths: *const u32, programs: *const *const u32, program_words: *const usize,
+        tables: *const *const u32, table_words: *const usize, n_chips: c_int,
+        public_values: *const u32, n_public: usize, prm: *const ZkhipParams, reason: *mut c_int,
+    ) -> c_int;
     // the SHA-256 compression chip (include/zkhip.h): message in, digest and proof out
     pub fn zkhip_sha256_digest(message: *const u8, len: usize, digest: *mut u8);
     pub fn zkhip_sha256_proof_size(message_len: usize, prm: *const ZkhipParams) -> usize;
@@ -90,6 +109,18 @@ extern "C" {
         proof: *mut u8, cap: usize, len: *mut usize,
     ) -> c_int;
     pub fn zkhip_verify_sha256(proof: *const u8, len: usize, digest: *const u8, prm: *const ZkhipParams, reason: *mut c_int) -> c_int;
+}
+
+/// one table of a multi-chip shard (zkhip_chip)
+#[repr(C)]
+#[derive(Clone, Copy, Debug)]
+pub struct ZkhipChip {
+    pub d_trace: *const u32,
+    pub ld: usize,
+    pub log_n: i32,
+    pub width: u32,
+    pub logup_pairs: i32,
+    pub partner: i32,
 }
 
 /// status code -> anyhow error carrying the library's thread-local message
