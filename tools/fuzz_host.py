@@ -1,0 +1,99 @@
+"""Malformed input against every HOST entry that takes untrusted bytes (verifiers, program / table validators, the bincode reader).
+Nothing may crash or read out of bounds: run it against the AddressSanitizer build (tools/asan_cpu.sh).  usage: fuzz_host.py [seconds]"""
+import ctypes as C
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path[:0] = [ROOT, os.path.join(ROOT, "tests")]
+import zktls_amd._lib as _lib
+if os.environ.get("ZKHIP_FUZZ_LIB"):                       # the sanitizer build (this tool only; the package never reads the environment)
+    _lib.LIB_PATH = os.environ["ZKHIP_FUZZ_LIB"]
+import airs
+import machines
+import oracle_lib as O
+import sha256_air as S
+from zktls_amd._lib import Params
+from zktls_amd.device import verify_chips, verify_chips_air, verify_machine, verify_sha256, verify_shard, verify_shard_air
+
+budget = float(sys.argv[1]) if len(sys.argv) > 1 else 30.0
+rng = np.random.default_rng(int(os.environ.get("ZKHIP_FUZZ_SEED", "1")))
+L = _lib.load()
+u8p, u32p = _lib.u8p, _lib.u32p
+
+
+def mutate(b):
+    b = bytearray(b)
+    kind = rng.integers(0, 6)
+    if kind == 0 and len(b) > 8:
+        del b[int(rng.integers(0, len(b))):]                                   # truncate
+    elif kind == 1:
+        b += bytes(rng.integers(0, 256, int(rng.integers(1, 64)), dtype=np.uint8))
+    elif kind == 2 and len(b) >= 4:
+        for _ in range(int(rng.integers(1, 8))):
+            off = 4 * int(rng.integers(0, len(b) // 4))
+            b[off:off + 4] = int(rng.integers(0, 2**32)).to_bytes(4, "little")
+    elif kind == 3 and len(b) >= 4:
+        off = 4 * int(rng.integers(0, min(len(b) // 4, 40)))                   # header area
+        b[off:off + 4] = int(rng.choice([0, 1, 5, 31, 32, 2**31, 2**32 - 1, 2013265920, 2013265921])).to_bytes(4, "little")
+    elif kind == 4 and len(b) > 0:
+        for _ in range(int(rng.integers(1, 16))):
+            b[int(rng.integers(0, len(b)))] ^= 1 << int(rng.integers(0, 8))
+    else:
+        b = bytearray(rng.integers(0, 256, int(rng.integers(0, 4096)), dtype=np.uint8).tobytes())
+    return bytes(b)
+
+
+def arr(b):
+    return np.frombuffer(b, dtype=np.uint8) if len(b) else np.zeros(0, dtype=np.uint8)
+
+
+def words(b):
+    b = b[:len(b) // 4 * 4]
+    return np.frombuffer(b, dtype=np.uint32).copy() if len(b) else np.zeros(1, dtype=np.uint32)
+
+
+# valid material from the oracle
+prm, oprm = Params(1, 4, 3), O.default_params(1, 4, 3)
+t1 = O.gen_trace(7, 1, 6, 8)
+p_single = O.prove_shard(t1, [1, 2], oprm).tobytes()
+fib = airs.fibonacci_program()
+ft, fpub = airs.fibonacci_trace(6, 3, 5)
+p_air = O.prove_shard_air(fib, ft, fpub, oprm).tobytes()
+p_chips = O.prove_chips([O.gen_trace(7, 2, 7, 8), O.gen_trace(7, 3, 6, 4)], [1], oprm).tobytes()
+cnt = airs.counter_program(8).copy(); cnt[4] = 3
+p_chips_air = O.prove_chips_air([airs.counter_trace(7, 8, 3, 5)[0], ft], [cnt, fib], fpub, oprm).tobytes()
+mt, mp, mtab, mpub = machines.range_machine(5, 6)
+p_machine = O.prove_machine(mt, mp, mtab, mpub, oprm).tobytes()
+mln, mws = [t.shape[0].bit_length() - 1 for t in mt], [t.shape[1] for t in mt]
+sha_t, sha_pub = S.trace(S.pad(b"abc"))
+p_sha = O.prove_shard_air(S.program(), sha_t, sha_pub, oprm).tobytes()
+bc_size = L.zkhip_bincode_size(6, 8, C.byref(prm))
+bc = np.zeros(bc_size, dtype=np.uint8)
+got = C.c_size_t(0)
+src = arr(p_single)
+assert L.zkhip_proof_to_bincode(src.ctypes.data_as(u8p), src.size, 6, 8, C.byref(prm), bc.ctypes.data_as(u8p), bc_size, C.byref(got)) == 0
+
+t0, n = time.time(), 0
+while time.time() - t0 < budget:
+    verify_shard(arr(mutate(p_single)), int(rng.choice([6, 6, 6, 5, 7])), int(rng.choice([8, 8, 4, 12])), [1, 2], prm)
+    verify_shard_air(fib, arr(mutate(p_air)), 6, 4, fpub, prm)
+    verify_shard_air(words(mutate(fib.tobytes())), arr(p_air), 6, 4, fpub, prm)
+    verify_chips(arr(mutate(p_chips)), [7, 6], [8, 4], [1], prm)
+    verify_chips_air(arr(mutate(p_chips_air)), [7, 6], [8, 4], [cnt, fib], fpub, prm)
+    verify_chips_air(arr(p_chips_air), [7, 6], [8, 4], [words(mutate(cnt.tobytes())), fib], fpub, prm)
+    verify_machine(arr(mutate(p_machine)), mln, mws, mp, mtab, mpub, prm)
+    verify_machine(arr(p_machine), mln, mws, mp, [words(mutate(mtab[0].tobytes())), mtab[1], mtab[2]], mpub, prm)
+    verify_sha256(arr(mutate(p_sha)) if rng.random() < 0.7 else arr(p_sha), bytes(rng.integers(0, 256, 32, dtype=np.uint8)), prm)
+    w = words(mutate(fib.tobytes()))
+    L.zkhip_air_validate(w.ctypes.data_as(u32p), w.size, int(rng.choice([4, 8])), int(rng.choice([3, 0])))
+    out8 = (C.c_uint32 * 8)()
+    L.zkhip_air_digest(w.ctypes.data_as(u32p), w.size, out8)
+    m = arr(mutate(bc.tobytes()))
+    back = np.zeros(len(p_single) + 64, dtype=np.uint8)
+    L.zkhip_proof_from_bincode(m.ctypes.data_as(u8p), m.size, 6, 8, C.byref(prm), 2, back.ctypes.data_as(u8p), int(rng.choice([back.size, 16, 0])), C.byref(got))
+    n += 1
+print("fuzz ok: %d rounds of 12 malformed calls in %.0f s (no crash; run under the sanitizer build for out-of-bounds reads)" % (n, time.time() - t0))
