@@ -26,6 +26,9 @@ def test_range_machine_bytes_equal_the_oracles(ctx, oracle, log_table, log_users
     assert proof.tobytes() == oproof.tobytes()
     assert verify_machine(proof, lns, ws, progs, tables, pub, Params(*shape)) == (0, 0)
     assert O.verify_machine(proof, lns, ws, progs, tables, pub, O.default_params(*shape)) == 0
+    if log_users <= 8:
+        import pyverify_chips
+        assert pyverify_chips.verify(proof.tobytes(), lns, ws, pub, *shape, programs=progs, tables=tables) is True
 
 
 def test_machine_with_synthetic_chips_and_an_odd_number_of_interactions(ctx, oracle):
