@@ -428,6 +428,11 @@ int zkhip_verify_chips_air(const uint8_t* proof, size_t len, const int32_t* log_
  * every tuple sent on a bus is received with the same total multiplicity (a range table, a memory bus, a permutation ...).
  * programs[c] NULL: the built-in synthetic AIR.  Proof version 10 = version 6's layout with header entries
  * (log_n, width, has_program, interactions), then the programs' and the tables' digests.  Shape limits as zkhip_prove_chips. */
+/* a range table's two columns on the device: d_table[v][value_col] = v and d_table[v][mult_col] = how often v appears in the listed
+ * `columns` of d_trace (the multiplicities a `receive` interaction of the table needs), v < 2^log_table; the other columns of d_table are
+ * left as they are.  Fails if a looked-up value lies outside the table. */
+int zkhip_range_table(zkhip_ctx* ctx, const uint32_t* d_trace, size_t ld, size_t rows, const uint32_t* columns, int n_columns, int log_table,
+                      uint32_t* d_table, size_t table_ld, uint32_t value_col, uint32_t mult_col);
 size_t zkhip_machine_proof_size(const int32_t* log_ns, const uint32_t* widths, const uint32_t* const* programs, const size_t* program_words,
                                 const uint32_t* const* tables, const size_t* table_words, int n_chips, const zkhip_params* prm, size_t n_public);
 int zkhip_prove_machine(zkhip_ctx* ctx, const zkhip_chip* chips, const uint32_t* const* programs, const size_t* program_words,

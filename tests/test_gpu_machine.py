@@ -71,11 +71,13 @@ def test_sha256_chip_with_its_limbs_range_checked_by_a_table(ctx, oracle):
     table = np.zeros((1 << 16, 4), dtype=np.uint32)
     table[:, 0] = np.arange(1 << 16)
     table[:, 1] = np.bincount(sha_t[:, sent].ravel(), minlength=1 << 16)
+    d_table = ctx.range_table(d_sha, 608, 1 << 10, sent, 16)                 # the same table, counted on the device
+    assert (d_table.download().reshape(-1, 4) == table).all()
     table_prog = O.air_program(4, 16, [(O.SEL_FIRST, [(1, [V(0)])]),
                                        (O.SEL_TRANSITION, [(1, [V(0, True)]), (O.P - 1, [V(0)]), (O.P - 1, [])])])
     table_tab = O.interaction_table([(O.RECEIVE, 1, 16, [0])])
     progs, tables = [table_prog, sha256_air()], [table_tab, sha_tab]
-    chips = [(ctx.from_numpy(table), 16, 4), (d_sha, 10, 608)]
+    chips = [(d_table, 16, 4), (d_sha, 10, 608)]
     proof = ctx.prove_machine(chips, progs, tables, sha_pub, Params(1, 12, 4))
     oproof = O.prove_machine([table, sha_t], [table_prog, S.program()], tables, sha_pub, O.default_params(1, 12, 4))
     assert proof.tobytes() == oproof.tobytes()
@@ -83,3 +85,11 @@ def test_sha256_chip_with_its_limbs_range_checked_by_a_table(ctx, oracle):
     wrong = list(sha_pub)
     wrong[0] ^= 1
     assert verify_machine(proof, [16, 10], [4, 608], progs, tables, wrong, Params(1, 12, 4))[0] == -6
+
+
+def test_range_table_refuses_values_it_does_not_hold(ctx):
+    from zktls_amd._lib import ZkHipError
+    t = ctx.from_numpy(np.array([[1, 2, 3, 40]], dtype=np.uint32).repeat(32, axis=0))
+    assert (ctx.range_table(t, 4, 32, [0, 1, 2], 5).download().reshape(-1, 4)[:4, 1] == [0, 32, 32, 32]).all()
+    with pytest.raises(ZkHipError):
+        ctx.range_table(t, 4, 32, [3], 5)                                    # 40 >= 2^5

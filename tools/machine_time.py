@@ -26,11 +26,7 @@ for log_blocks in ([int(x) for x in sys.argv[1:]] or (4, 8, 12)):
     n = (64 << log_blocks) - 9
     msg = np.random.default_rng(log_blocks).integers(0, 256, n, dtype=np.uint8).tobytes()
     d_sha, limbs = ctx.sha256_gen_trace(sha256_pad(msg), 1 << log_blocks)
-    t = d_sha.download().reshape(-1, 608)                      # multiplicities on the host (a histogram of four columns)
-    table = np.zeros((1 << 16, 4), dtype=np.uint32)
-    table[:, 0] = np.arange(1 << 16)
-    table[:, 1] = np.bincount(t[:, sent].ravel(), minlength=1 << 16)
-    d_table = ctx.from_numpy(table)
+    d_table = ctx.range_table(d_sha, 608, 64 << log_blocks, sent, 16)     # values + multiplicities counted on the device
     lns, ws = [16, log_blocks + 6], [4, 608]
     chips, progs, tables = [(d_table, 16, 4), (d_sha, log_blocks + 6, 608)], [table_prog, prog], [table_tab, sha_tab]
     if log_blocks + 6 > 16:

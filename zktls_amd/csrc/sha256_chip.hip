@@ -17,6 +17,7 @@
 //   XL 14 limb pairs (W_{t+j}, j = 1..12, 14, 15) | SG0 SG1 32 bits (sigma0(W_t), sigma1(W_{t+13})) | CY 28 carry bits
 //   ACT (block belongs to the message) | SKIP = s_63 (1 - ACT) | 2 unused
 #include <cstring>
+#include <string>
 #include <vector>
 
 #include "air.h"
@@ -327,6 +328,27 @@ __global__ void __launch_bounds__(64) sha256_trace_kernel(TraceArgs a) {
     row[SKIP + 2] = 0u;
 }
 
+
+// ---- multiplicities of a range table on the device: count how often every value of [0, 2^log_table) appears in the listed columns
+// of a trace (Montgomery words), then write the table's two columns: value v = row index, multiplicity m = the count
+struct HistArgs { const uint32_t* trace; uint64_t ld; uint64_t rows; uint32_t cols[16]; uint32_t n_cols; uint32_t log_table; uint32_t* counts; uint32_t* bad; };
+__global__ void __launch_bounds__(256) lookup_hist_kernel(HistArgs a) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= a.rows) return;
+    const uint32_t* row = a.trace + i * a.ld;
+    for (uint32_t k = 0; k < a.n_cols; k++) {
+        const uint32_t v = from_monty(row[a.cols[k]]);
+        if (v >> a.log_table) atomicAdd(a.bad, 1u);          // a value the table does not hold: the caller hears about it
+        else atomicAdd(a.counts + v, 1u);
+    }
+}
+__global__ void __launch_bounds__(256) range_table_kernel(const uint32_t* counts, uint32_t rows, uint32_t* out, uint64_t ld, uint32_t value_col, uint32_t mult_col) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= rows) return;
+    out[(uint64_t)i * ld + value_col] = dmul(i, MONTY_R2);
+    out[(uint64_t)i * ld + mult_col] = dmul(counts[i] % P, MONTY_R2);
+}
+
 }  // namespace sha
 }  // namespace zk
 
@@ -341,6 +363,31 @@ using namespace zk;
 static int log2_exact(size_t n) { int l = 0; while (((size_t)1 << l) < n) l++; return ((size_t)1 << l) == n ? l : -1; }
 
 extern "C" {
+
+int zkhip_range_table(zkhip_ctx* ctx, const uint32_t* d_trace, size_t ld, size_t rows, const uint32_t* columns, int n_columns, int log_table,
+                      uint32_t* d_table, size_t table_ld, uint32_t value_col, uint32_t mult_col) {
+    CHECK_CTX(ctx);
+    if (!d_trace || !columns || !d_table || n_columns < 1 || n_columns > 16 || log_table < 5 || log_table > 22 || rows == 0 ||
+        value_col >= table_ld || mult_col >= table_ld || value_col == mult_col)
+        return fail(ZKHIP_ERR_INVALID, "range_table: 1..16 columns, log_table in [5, 22], distinct value / multiplicity columns inside the row pitch");
+    const size_t n = (size_t)1 << log_table;
+    void* v_counts;
+    ZK_TRY(ctx_reserve(ctx, S_ADDEND, (n + 1) * 4, &v_counts));
+    ZK_HIP(hipMemsetAsync(v_counts, 0, (n + 1) * 4, ctx->stream));
+    sha::HistArgs a{};
+    a.trace = d_trace; a.ld = ld; a.rows = rows; a.n_cols = (uint32_t)n_columns; a.log_table = (uint32_t)log_table;
+    for (int k = 0; k < n_columns; k++) { if (columns[k] >= ld) return fail(ZKHIP_ERR_INVALID, "range_table: column outside the row pitch"); a.cols[k] = columns[k]; }
+    a.counts = (uint32_t*)v_counts; a.bad = (uint32_t*)v_counts + n;
+    hipLaunchKernelGGL(sha::lookup_hist_kernel, dim3((unsigned)((rows + 255) / 256)), dim3(256), 0, ctx->stream, a);
+    ZK_HIP(hipGetLastError());
+    hipLaunchKernelGGL(sha::range_table_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, (const uint32_t*)v_counts, (uint32_t)n, d_table, (uint64_t)table_ld, value_col, mult_col);
+    ZK_HIP(hipGetLastError());
+    uint32_t bad = 0;
+    ZK_HIP(hipMemcpyAsync(&bad, a.bad, 4, hipMemcpyDeviceToHost, ctx->stream));
+    ZK_HIP(hipStreamSynchronize(ctx->stream));
+    if (bad) return fail(ZKHIP_ERR_INVALID, "range_table: " + std::to_string(bad) + " looked-up values lie outside [0, 2^log_table)");
+    return ZKHIP_OK;
+}
 
 size_t zkhip_sha256_air(uint32_t* program, size_t cap_words) {
     const std::vector<uint32_t>& p = sha::program();

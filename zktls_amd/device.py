@@ -436,6 +436,14 @@ class Context:
                                              buf.ctypes.data_as(u8p), size, C.byref(got)))
         return buf[: got.value]
 
+    def range_table(self, trace, ld, rows, columns, log_table, width=4, value_col=0, mult_col=1):
+        """a 2^log_table x width range table on the device: value column = row index, multiplicity column = how often the value
+        appears in `columns` of `trace` (the other columns zero)"""
+        out = self.from_raw(np.zeros(width << log_table, dtype=np.uint32))
+        cols = (C.c_uint32 * len(columns))(*[int(c) for c in columns])
+        check(self.lib.zkhip_range_table(self.handle, C.c_void_p(trace.ptr), ld, rows, cols, len(columns), log_table, C.c_void_p(out.ptr), width, value_col, mult_col))
+        return out
+
     def prove_machine(self, chips, programs, tables, public_values=(), params=None):
         """chips: [(device buffer, log_n, width), ...] tallest first; programs[c] / tables[c]: the chip's constraint program and its
         interaction table (numpy u32 words) or None -- a machine whose tables look each other up (lookups as data, version 10)"""
