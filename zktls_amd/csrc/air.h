@@ -136,6 +136,10 @@ inline void air_term_records(const AirView& a, const Ext& alpha, std::vector<uin
     }
     recs.clear();
     for (int n = 1; n <= 5; n++) for (const auto& r : by_n[n]) recs.insert(recs.end(), r.begin(), r.end());
+    if ((recs.size() / 8) & 1) {                 // the kernel takes terms in pairs: pad with 0 * (the constant 1)
+        const uint32_t pad[8] = {0, 0, 0, 0, 2 * W + 3, 0, 1u << 16, 0};
+        recs.insert(recs.end(), pad, pad + 8);
+    }
 }
 
 // ---- lookups as data: a chip's interaction table (machine mode; format declared in include/zkhip.h) ------------------------------

@@ -280,31 +280,37 @@ __global__ void __launch_bounds__(256) quotient_air_kernel(QuotientAirArgs a) {
     if (a.lde_out) st_ext(a.lde_out + (uint64_t)p * a.lde_ld + 4u * chunk, r);
 }
 // The term-parallel form: a workgroup owns PTS adjacent points of the quotient domain and its 256 lanes split the TERMS of the
-// flattened program (air.h, air_term_records).  The two rows of every point are staged into LDS once with 16-byte coalesced loads
+// flattened program (air.h, air_term_records).  The two rows of every point are staged into LDS once (point-minor: the 8 points of a slot side by side)
 // (together with the point's selector values, the constant 1 and the public values: "slots"), a lane loads its 32-byte term record
-// once and applies it to all PTS points (ds_read gathers; the record table stays in L2), and the extension coefficient rides in
-// four 64-bit running sums per point (dacc1: one conditional subtraction per product, one Montgomery reduction at the end).  The
+// once and applies it to all PTS points (two 16-byte ds_reads fetch a slot of all 8 points; the record table stays in L2), and the
+// extension coefficients ride in four 64-bit running sums per point (dacc2: terms go in pairs, one conditional subtraction per two
+// products, one Montgomery reduction at the end).  The
 // 256 partial sums per point are then added through LDS.  Against the row-per-lane interpreter above: no strided global gathers
 // (a lane there touches 64 cache lines per load instruction) and ~8 x less program traffic per point; 40 - 50 x faster on the
 // 608-column SHA-256 chip.
 template <int PTS>
 __global__ void __launch_bounds__(256) quotient_air_terms_kernel(QuotientAirArgs a, uint32_t stride) {
-    extern __shared__ uint32_t slots[];
+    static_assert(PTS == 8, "the slot layout below holds the 8 points of a slot in two 16-byte words");
+    extern __shared__ uint32_t slots[];                // [slot][point]: slot s of point q at slots[8 s + q]; `stride` = slots per point
     const int H = a.log_n + a.log_qd;
     const uint32_t m = 1u << H, nq = 1u << a.log_qd, W = a.width;
     const uint32_t p0 = blockIdx.x * PTS, tid = threadIdx.x;
-    for (int q = 0; q < PTS; q++) {
-        const uint32_t p = p0 + q;
+    {
+        // staging: lane = (point q = tid & 7, column c = tid >> 3 (+ 32 per trip)): the 8 lanes of a column write 8 adjacent LDS words
+        const uint32_t q = tid & 7u, p = p0 + q;
         const uint32_t e = __brev(p) >> (32 - H);
         const uint32_t pn = __brev((e + nq) & (m - 1)) >> (32 - H);
-        const uint4* lrow = reinterpret_cast<const uint4*>(a.lde + (uint64_t)p * a.ld);
-        const uint4* nrow = reinterpret_cast<const uint4*>(a.lde + (uint64_t)pn * a.ld);
-        uint4* dl = reinterpret_cast<uint4*>(slots + (size_t)q * stride);
-        uint4* dn = reinterpret_cast<uint4*>(slots + (size_t)q * stride + W);
-        for (uint32_t c = tid; c < W / 4; c += 256) { dl[c] = lrow[c]; dn[c] = nrow[c]; }
-        uint32_t* ex = slots + (size_t)q * stride + 2 * W;
-        if (tid == 0) { ex[0] = a.sel_first[p]; ex[1] = a.sel_last[p]; ex[2] = dsub(a.xs[p], a.wn_inv); ex[3] = MONTY_R1; }
-        for (uint32_t i = tid; i < a.n_public; i += 256) ex[AIR_SLOT_EXTRA + i] = a.pub[i];
+        const uint32_t* lrow = a.lde + (uint64_t)p * a.ld;
+        const uint32_t* nrow = a.lde + (uint64_t)pn * a.ld;
+        for (uint32_t c = tid >> 3; c < W; c += 32) {
+            slots[8 * c + q] = lrow[c];
+            slots[8 * (W + c) + q] = nrow[c];
+        }
+        if (tid < 8) {
+            uint32_t* ex = slots + 8 * (size_t)(2 * W);
+            ex[q] = a.sel_first[p]; ex[8 + q] = a.sel_last[p]; ex[16 + q] = dsub(a.xs[p], a.wn_inv); ex[24 + q] = MONTY_R1;
+        }
+        for (uint32_t i = tid >> 3; i < a.n_public; i += 32) slots[8 * (size_t)(2 * W + AIR_SLOT_EXTRA + i) + q] = a.pub[i];
     }
     __syncthreads();
     uint64_t acc[PTS][4];
@@ -313,32 +319,47 @@ __global__ void __launch_bounds__(256) quotient_air_terms_kernel(QuotientAirArgs
 #pragma unroll
         for (int i = 0; i < 4; i++) acc[q][i] = 0;
     const uint4* recs = reinterpret_cast<const uint4*>(a.recs);
-    for (uint32_t t = tid; t < a.n_terms; t += 256) {
-        const uint4 c = recs[2 * (size_t)t], o = recs[2 * (size_t)t + 1];
+    // the 8 points of slot o: two 16-byte LDS reads
+    auto load8 = [&](uint32_t o, uint32_t (&v)[PTS]) {
+        const uint4* s4 = reinterpret_cast<const uint4*>(slots + 8 * (size_t)o);
+        const uint4 lo = s4[0], hi = s4[1];
+        v[0] = lo.x; v[1] = lo.y; v[2] = lo.z; v[3] = lo.w; v[4] = hi.x; v[5] = hi.y; v[6] = hi.z; v[7] = hi.w;
+    };
+    auto product = [&](const uint4& o, uint32_t (&prod)[PTS]) {
         const uint32_t n = o.z >> 16;
-        const uint32_t o0 = o.x & 0xFFFFu, o1 = o.x >> 16, o2 = o.y & 0xFFFFu, o3 = o.y >> 16, o4 = o.z & 0xFFFFu;
-        uint32_t prod[PTS];
-#pragma unroll
-        for (int q = 0; q < PTS; q++) prod[q] = slots[(size_t)q * stride + o0];
+        uint32_t v[PTS];
+        load8(o.x & 0xFFFFu, prod);
         if (n > 1) {
+            load8(o.x >> 16, v);
 #pragma unroll
-            for (int q = 0; q < PTS; q++) prod[q] = dmul(prod[q], slots[(size_t)q * stride + o1]);
+            for (int q = 0; q < PTS; q++) prod[q] = dmul(prod[q], v[q]);
         }
         if (n > 2) {
+            load8(o.y & 0xFFFFu, v);
 #pragma unroll
-            for (int q = 0; q < PTS; q++) prod[q] = dmul(prod[q], slots[(size_t)q * stride + o2]);
+            for (int q = 0; q < PTS; q++) prod[q] = dmul(prod[q], v[q]);
         }
         if (n > 3) {
+            load8(o.y >> 16, v);
 #pragma unroll
-            for (int q = 0; q < PTS; q++) prod[q] = dmul(prod[q], slots[(size_t)q * stride + o3]);
+            for (int q = 0; q < PTS; q++) prod[q] = dmul(prod[q], v[q]);
         }
         if (n > 4) {
+            load8(o.z & 0xFFFFu, v);
 #pragma unroll
-            for (int q = 0; q < PTS; q++) prod[q] = dmul(prod[q], slots[(size_t)q * stride + o4]);
+            for (int q = 0; q < PTS; q++) prod[q] = dmul(prod[q], v[q]);
         }
+    };
+    // terms go in PAIRS (the table is padded to an even count): two products share one conditional subtraction per running sum (dacc2)
+    for (uint32_t t = 2 * tid; t < a.n_terms; t += 512) {
+        const uint4 ca = recs[2 * (size_t)t], oa = recs[2 * (size_t)t + 1], cb = recs[2 * (size_t)t + 2], ob = recs[2 * (size_t)t + 3];
+        uint32_t pa[PTS], pb[PTS];
+        product(oa, pa);
+        product(ob, pb);
 #pragma unroll
         for (int q = 0; q < PTS; q++) {
-            dacc1(acc[q][0], c.x, prod[q]); dacc1(acc[q][1], c.y, prod[q]); dacc1(acc[q][2], c.z, prod[q]); dacc1(acc[q][3], c.w, prod[q]);
+            dacc2(acc[q][0], ca.x, pa[q], cb.x, pb[q]); dacc2(acc[q][1], ca.y, pa[q], cb.y, pb[q]);
+            dacc2(acc[q][2], ca.z, pa[q], cb.z, pb[q]); dacc2(acc[q][3], ca.w, pa[q], cb.w, pb[q]);
         }
     }
     __syncthreads();                                   // the slots are dead: the same LDS now carries the partial sums
@@ -380,7 +401,7 @@ hipError_t launch_quotient_air(const QuotientAirArgs& a, hipStream_t s) {
     const uint32_t stride = 2 * a.width + AIR_SLOT_EXTRA + ((a.n_public + 3u) & ~3u);     // a multiple of 4 words: 16-byte row copies
     const size_t lds_rows = (size_t)PTS * stride * 4, lds_red = (size_t)PTS * 4 * 257 * 4;
     const size_t lds = lds_rows > lds_red ? lds_rows : lds_red;
-    if (a.recs && lds <= 72 * 1024 && m >= (uint64_t)PTS && stride < 65536 && (a.ld % 4) == 0 && (reinterpret_cast<uintptr_t>(a.lde) & 15) == 0) {
+    if (a.recs && (a.n_terms & 1u) == 0 && lds <= 72 * 1024 && m >= (uint64_t)PTS && stride < 8192) {
         static std::atomic<size_t> configured[64] = {};
         int dev = 0;
         if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return hipErrorInvalidDevice;
