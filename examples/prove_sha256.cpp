@@ -23,7 +23,7 @@ static bool read_file(const char* path, std::vector<uint8_t>& out) {
 }
 
 int main(int argc, char** argv) {
-    const zkhip_params prm = {1, 100, 16, 0, 0, 0, 0, 0};            // SP1-core-like shape: blowup 2, 100 queries, 16 PoW bits
+    const zkhip_params prm = ZKHIP_PARAMS_SP1_CORE;                        // blowup 2, 100 queries, 16 PoW bits
     if (argc == 4 && !std::strcmp(argv[1], "--verify")) {            // host only: no GPU needed to check a proof
         std::vector<uint8_t> proof;
         if (!read_file(argv[2], proof)) { std::fprintf(stderr, "cannot read %s\n", argv[2]); return 1; }

@@ -101,6 +101,15 @@ typedef struct {
      * Only zkhip_prove_shard / zkhip_prove_segment / zkhip_verify_shard read it; leave it 0 elsewhere. */
     int32_t code_width;
 } zkhip_params;
+/* FRI configurations of the two SDKs the reference drives, as initialisers.  [RECALLED]: sp1-stark 4.1.4 /
+ * risc0-zkp 1.2.5 are not in /root/reference (Cargo.lock:6172, 5057) -- to be checked against them before any wire-compatibility claim.
+ *   SP1 core shards (sp1.rs:116, first stage of `prove`):   blowup 2,  100 queries, 16 proof-of-work bits, fold by 2, constant final polynomial
+ *   SP1 compress / recursion stage:                         blowup 4,  50 queries, 16 bits            (same FRI shape)
+ *   SP1 shrink / wrap stage: blowup 16, 25 queries -- log_blowup 4 is beyond this library's [1, 3]
+ *   RISC Zero segments (prover.rs:90):                      blowup 4,  50 queries, no proof of work, fold by 16, 256 final coefficients, Poseidon2 width 24 */
+#define ZKHIP_PARAMS_SP1_CORE     {1, 100, 16, 0, 0, 0, 0, 0}
+#define ZKHIP_PARAMS_SP1_COMPRESS {2, 50, 16, 0, 0, 0, 0, 0}
+#define ZKHIP_PARAMS_RISC0        {2, 50, 0, 0, 4, 8, 24, 0}
 
 /* ---- library / context ---- */
 int zkhip_version(void);
