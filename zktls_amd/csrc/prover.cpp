@@ -9,6 +9,7 @@
 // launches, exactly where the protocol forces a round trip (commit -> challenge).
 #include <atomic>
 #include <cstring>
+#include <functional>
 #include <mutex>
 #include <string>
 #include <thread>
@@ -1222,6 +1223,27 @@ static Ext recombine(const Ext* opened4) {
     return r;
 }
 
+// runs check(q) for q in [0, n) on up to 8 host threads; returns the failure code of the LOWEST failing query (0: all passed), so the
+// verdict does not depend on the thread count
+static int run_queries(int n, const std::function<int(int)>& check) {
+    unsigned hw = std::thread::hardware_concurrency();
+    int threads = (int)(hw ? (hw < 8 ? hw : 8) : 1);
+    if (threads > n / 4) threads = n / 4;
+    if (threads <= 1) {
+        for (int q = 0; q < n; q++) { const int r = check(q); if (r) return r; }
+        return 0;
+    }
+    std::vector<int> result(n, 0);
+    std::atomic<int> next{0};
+    auto worker = [&]() { for (;;) { const int q = next.fetch_add(1); if (q >= n) return; result[q] = check(q); } };
+    std::vector<std::thread> pool;
+    for (int t = 1; t < threads; t++) pool.emplace_back(worker);
+    worker();
+    for (auto& t : pool) t.join();
+    for (int q = 0; q < n; q++) if (result[q]) return result[q];
+    return 0;
+}
+
 static int verify_shard_impl(const uint8_t* proof, size_t len, int log_n, uint32_t width, const uint32_t* public_values,
                              size_t n_public, const zkhip_params* prm, int* reason, const AirView* air) {
     int dummy;
@@ -1386,8 +1408,18 @@ static int verify_shard_impl(const uint8_t* proof, size_t len, int log_n, uint32
     ch.observe_canonical(witness);
     if (ch.sample_bits(prm->pow_bits) != 0) return reject(20);
     const uint32_t wm = two_adic_generator(H);
-    for (int q = 0; q < prm->num_queries; q++) {
-        const size_t index = ch.sample_bits(H);
+    // The query indices come out of the transcript one after the other; the checks of a query read only its own slice of the proof
+    // (every query has the same length), so they run on a few host threads -- a verifier spends its time in the ~200 Poseidon2
+    // permutations per query (leaf of the trace row, Merkle paths, FRI layers).
+    const int NQ_ = prm->num_queries;
+    std::vector<size_t> indices(NQ_);
+    for (int q = 0; q < NQ_; q++) indices[q] = ch.sample_bits(H);
+    const size_t pos0 = pos, words_total = len / 4;
+    if ((words_total - pos0) % (size_t)NQ_ != 0) return reject(5);
+    const size_t perq = (words_total - pos0) / (size_t)NQ_;
+    auto check_query = [&](int q) -> int {
+        size_t pos = pos0 + (size_t)q * perq;
+        const size_t index = indices[q];
         const uint32_t* trow = pf + pos; pos += width;
         const uint32_t* cpath = nullptr;
         if (CW) { cpath = pf + pos; pos += 8 * (size_t)H; }
@@ -1396,10 +1428,10 @@ static int verify_shard_impl(const uint8_t* proof, size_t len, int log_n, uint32
         if (LQ) { prow = pf + pos; pos += wp; ppath = pf + pos; pos += 8 * (size_t)H; }
         const uint32_t* qrow = pf + pos; pos += QW;
         const uint32_t* qpath = pf + pos; pos += 8 * (size_t)H;
-        if (CW && !verify_path(croot, H, index, trow, CW, cpath, sh.hw)) return reject(33);
-        if (!verify_path(troot, H, index, trow + CW, width - CW, tpath, sh.hw)) return reject(30);
-        if (LQ && !verify_path(proot, H, index, prow, wp, ppath, sh.hw)) return reject(32);
-        if (!verify_path(qroot, H, index, qrow, QW, qpath, sh.hw)) return reject(31);
+        if (CW && !verify_path(croot, H, index, trow, CW, cpath, sh.hw)) return 33;
+        if (!verify_path(troot, H, index, trow + CW, width - CW, tpath, sh.hw)) return 30;
+        if (LQ && !verify_path(proot, H, index, prow, wp, ppath, sh.hw)) return 32;
+        if (!verify_path(qroot, H, index, qrow, QW, qpath, sh.hw)) return 31;
         const uint32_t x = fmul(MONTY_GEN, fpow(wm, reverse_bits((uint32_t)index, H)));
         const Ext d1 = ext_inv(ext_neg(ext_sub_base(zeta, x)));
         const Ext d2 = ext_inv(ext_neg(ext_sub_base(zeta_next, x)));
@@ -1425,7 +1457,7 @@ static int verify_shard_impl(const uint8_t* proof, size_t len, int log_n, uint32
                 else { ev[j] = ext_from_canon(pf + pos); for (int i = 0; i < 4; i++) rowbuf[4 * j + i] = pf[pos + i]; pos += 4; }
             }
             const uint32_t* path = pf + pos; pos += 8 * (size_t)lh;
-            if (!verify_path(&commits[8 * l], lh, row, rowbuf, 4 * arity, path, sh.hw)) return reject(40 + (l < 50 ? l : 50));
+            if (!verify_path(&commits[8 * l], lh, row, rowbuf, 4 * arity, path, sh.hw)) return 40 + (l < 50 ? l : 50);
             folded = fold_row_k(row, lh, K, betas[l], ev);
             idx = row;
         }
@@ -1435,9 +1467,15 @@ static int verify_shard_impl(const uint8_t* proof, size_t len, int log_n, uint32
             const uint32_t xf = fpow(two_adic_generator(lf), reverse_bits((uint32_t)idx, lf));
             Ext v = ext_zero();
             for (size_t i = keep; i-- > 0;) v = ext_add(ext_mul_base(v, xf), final_poly[i]);
-            if (!ext_eq(folded, v)) return reject(100);
+            if (!ext_eq(folded, v)) return 100;
         }
+        return pos == pos0 + (size_t)(q + 1) * perq ? 0 : 5;
+    };
+    {
+        const int why = run_queries(NQ_, check_query);
+        if (why) return reject(why);
     }
+    pos = pos0 + (size_t)NQ_ * perq;
     if (pos * 4 != len) return reject(5);
     return ZKHIP_OK;
 }
@@ -2075,8 +2113,16 @@ int zkhip_verify_chips(const uint8_t* proof, size_t len, const int32_t* log_ns, 
     const uint32_t witness = pf[pos++];
     ch.observe_canonical(witness);
     if (ch.sample_bits(prm->pow_bits) != 0) return reject(20);
-    for (int q = 0; q < prm->num_queries; q++) {
-        const size_t index = ch.sample_bits(Hmax);
+    // as in the single-matrix verifier: indices from the transcript first, then the queries on a few host threads
+    const int NQ_ = prm->num_queries;
+    std::vector<size_t> indices(NQ_);
+    for (int q = 0; q < NQ_; q++) indices[q] = ch.sample_bits(Hmax);
+    const size_t pos0 = pos, words_total = len / 4;
+    if ((words_total - pos0) % (size_t)NQ_ != 0) return 5;
+    const size_t perq = (words_total - pos0) / (size_t)NQ_;
+    auto check_query = [&](int q) -> int {
+        size_t pos = pos0 + (size_t)q * perq;
+        const size_t index = indices[q];
         const uint32_t *trow[MAX_CHIPS], *qrow[MAX_CHIPS], *prow[MAX_CHIPS], *prow_all[MAX_CHIPS];
         for (int c = 0; c < n; c++) { trow[c] = pf + pos; pos += widths[c]; prow_all[c] = nullptr; }
         const uint32_t* tpath = pf + pos; pos += 8 * (size_t)Hmax;
@@ -2087,9 +2133,9 @@ int zkhip_verify_chips(const uint8_t* proof, size_t len, const int32_t* log_ns, 
         }
         for (int c = 0; c < n; c++) { qrow[c] = pf + pos; pos += 8; }
         const uint32_t* qpath = pf + pos; pos += 8 * (size_t)Hmax;
-        if (!verify_mixed(troot, Hmax, index, trow, widths, lh, n, tpath)) return reject(30);
-        if (lk && !verify_mixed(proot, Hp, index >> (Hmax - Hp), prow, pw, plh, np, ppath)) return reject(32);
-        if (!verify_mixed(qroot, Hmax, index, qrow, w8, lh, n, qpath)) return reject(31);
+        if (!verify_mixed(troot, Hmax, index, trow, widths, lh, n, tpath)) return 30;
+        if (lk && !verify_mixed(proot, Hp, index >> (Hmax - Hp), prow, pw, plh, np, ppath)) return 32;
+        if (!verify_mixed(qroot, Hmax, index, qrow, w8, lh, n, qpath)) return 31;
         Ext roh[32];
         for (int h = 0; h < 32; h++) roh[h] = ext_zero();
         for (int c = 0; c < n; c++) {
@@ -2120,12 +2166,18 @@ int zkhip_verify_chips(const uint8_t* proof, size_t len, const int32_t* log_ns, 
             const uint32_t* path = pf + pos; pos += 8 * (size_t)rows_log;
             Ext ev[2];
             ev[idx & 1] = folded; ev[(idx & 1) ^ 1] = sib;
-            if (!verify_path(&commits[8 * l], rows_log, idx >> 1, rowbuf, 8, path, 16)) return reject(40 + (l < 50 ? l : 50));
+            if (!verify_path(&commits[8 * l], rows_log, idx >> 1, rowbuf, 8, path, 16)) return 40 + (l < 50 ? l : 50);
             folded = ext_add(fri_fold_row(idx >> 1, rows_log, betas[l], ev[0], ev[1]), roh[rows_log]);
             idx >>= 1;
         }
-        if (!ext_eq(folded, final_poly)) return reject(100);
+        if (!ext_eq(folded, final_poly)) return 100;
+        return pos == pos0 + (size_t)(q + 1) * perq ? 0 : 5;
+    };
+    {
+        const int why = run_queries(NQ_, check_query);
+        if (why) return reject(why);
     }
+    pos = pos0 + (size_t)NQ_ * perq;
     if (pos * 4 != len) return reject(5);
     return ZKHIP_OK;
 }
