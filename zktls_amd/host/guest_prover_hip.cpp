@@ -158,15 +158,20 @@ ProveResult HipGuestProver::prove_inner(const GuestInput& input, const std::vect
         }
         const size_t cap = zkhip_sha256_proof_size(input.cbor.size(), &prm);
         if (cap == 0) throw std::runtime_error(std::string("input commitment: ") + zkhip_last_error());
-        zkhip_ctx* ctx = nullptr;
-        if (zkhip_ctx_create(devices_[0], nullptr, &ctx) != ZKHIP_OK) fail_zkhip("zkhip_ctx_create");
+        // a parked context when there is one (the chip keeps its trace in the context's own workspaces: a 256-byte placeholder
+        // stands in for the trace buffer the pool is keyed by)
+        CtxGuard g;
+        constexpr size_t PLACEHOLDER = 256;
+        if (!g.take(devices_[0], PLACEHOLDER)) {
+            g.device = devices_[0]; g.trace_bytes = PLACEHOLDER;
+            if (zkhip_ctx_create(devices_[0], nullptr, &g.ctx) != ZKHIP_OK) fail_zkhip("zkhip_ctx_create");
+            if (zkhip_malloc(g.ctx, PLACEHOLDER, &g.d_trace) != ZKHIP_OK) fail_zkhip("zkhip_malloc");
+        }
         std::vector<uint8_t> proof(cap);
         size_t len = 0;
         uint8_t digest32[32];
-        const int rc = zkhip_prove_sha256(ctx, input.cbor.data(), input.cbor.size(), &prm, digest32, proof.data(), cap, &len);
-        const std::string msg = rc == ZKHIP_OK ? "" : zkhip_last_error();
-        zkhip_ctx_destroy(ctx);
-        if (rc != ZKHIP_OK) throw std::runtime_error("zkhip_prove_sha256: " + msg);
+        if (zkhip_prove_sha256(g.ctx, input.cbor.data(), input.cbor.size(), &prm, digest32, proof.data(), cap, &len) != ZKHIP_OK) fail_zkhip("zkhip_prove_sha256");
+        g.healthy = true;
         proof.resize(len);
         int reason = 0;
         if (zkhip_verify_sha256(proof.data(), proof.size(), digest32, &prm, &reason) != ZKHIP_OK) fail_zkhip("zkhip_verify_sha256");
