@@ -38,3 +38,48 @@ def range_machine(log_table=6, log_users=7, seed=1):
     table_tab = O.interaction_table([(O.RECEIVE, 1, BUS_RANGE, [0])])
     traces = [pick.astype(np.uint32), user.astype(np.uint32), table.astype(np.uint32)]
     return traces, [pick_prog, user_prog, table_prog], [pick_tab, user_tab, table_tab], [11, 22, 33]
+
+
+def random_machine(seed):
+    """A pseudo-random machine: 2..5 tables of random heights and widths; every bus carries tuples of a random length 1..8 from
+    one SENDER table (every row sends one tuple of a pool, some rows send a second one with a 0 / 1 multiplicity column) to one
+    RECEIVER table (one row per pool tuple, with the total multiplicity in a column; its other rows hold junk with multiplicity 0).
+    Each table's program: its last column is a bit.  -> (traces, programs, tables, public values), tallest first"""
+    rng = np.random.default_rng(seed)
+    n = int(rng.integers(2, 6))
+    heights = sorted((int(h) for h in rng.integers(5, 10, n)), reverse=True)
+    while max(heights.count(h) for h in heights) > 4:
+        heights = sorted((int(h) for h in rng.integers(5, 10, n)), reverse=True)
+    widths = [4 * int(rng.integers(6, 12)) for _ in range(n)]                   # room for several tuples of up to 8 values
+    traces = [rng.integers(0, P, (1 << h, w)).astype(np.uint64) for h, w in zip(heights, widths)]
+    for t in traces:
+        t[:, -1] = rng.integers(0, 2, t.shape[0])
+    inter = [[] for _ in range(n)]
+    used = [0] * n                                                               # next free column per table
+    for bus in range(int(rng.integers(1, 4))):
+        a, b = (int(x) for x in rng.choice(n, 2, replace=False))
+        nv = int(rng.integers(1, 9))
+        if used[a] + nv + 1 >= widths[a] - 1 or used[b] + nv + 1 >= widths[b] - 1:
+            continue
+        ra, rb = traces[a].shape[0], traces[b].shape[0]
+        pool_n = int(rng.integers(1, min(rb, 40) + 1))
+        pool = rng.integers(0, P, (pool_n, nv)).astype(np.uint64)
+        pick = rng.integers(0, pool_n, ra)
+        ca, cb = used[a], used[b]
+        traces[a][:, ca:ca + nv] = pool[pick]
+        flag = rng.integers(0, 2, ra).astype(np.uint64)                         # a multiplicity column on the sending side too
+        traces[a][:, ca + nv] = flag
+        counts = np.bincount(pick, weights=flag.astype(np.float64), minlength=pool_n).astype(np.uint64)
+        inter[a].append((O.SEND, ca + nv, 100 + bus, list(range(ca, ca + nv))))
+        if rng.random() < 0.5:                                                   # and once more with the constant multiplicity
+            inter[a].append((O.SEND, None, 100 + bus, list(range(ca, ca + nv))))
+            counts = counts + np.bincount(pick, minlength=pool_n).astype(np.uint64)
+        rows = rng.permutation(rb)[:pool_n]
+        traces[b][:, cb + nv] = 0
+        traces[b][rows, cb:cb + nv] = pool
+        traces[b][rows, cb + nv] = counts % P
+        inter[b].append((O.RECEIVE, cb + nv, 100 + bus, list(range(cb, cb + nv))))
+        used[a], used[b] = ca + nv + 1, cb + nv + 1
+    progs = [O.air_program(w, 2, [(O.SEL_ALL, [(1, [V(w - 1), V(w - 1)]), (P - 1, [V(w - 1)])])]) for w in widths]
+    tables = [O.interaction_table(it) if it else None for it in inter]
+    return [t.astype(np.uint32) for t in traces], progs, tables, [int(rng.integers(0, P)), int(rng.integers(0, P))]

@@ -93,3 +93,15 @@ def test_range_table_refuses_values_it_does_not_hold(ctx):
     assert (ctx.range_table(t, 4, 32, [0, 1, 2], 5).download().reshape(-1, 4)[:4, 1] == [0, 32, 32, 32]).all()
     with pytest.raises(ZkHipError):
         ctx.range_table(t, 4, 32, [3], 5)                                    # 40 >= 2^5
+
+
+@pytest.mark.parametrize("seed", range(12))
+def test_random_machines_bytes_equal_the_oracles(ctx, oracle, seed):
+    O = oracle
+    traces, progs, tables, pub = M.random_machine(100 + seed)
+    lns, ws = shape_of(traces)
+    shape = (1 + seed % 3, 6, 3)
+    chips = [(ctx.from_numpy(t), ln, w) for t, ln, w in zip(traces, lns, ws)]
+    proof = ctx.prove_machine(chips, progs, tables, pub, Params(*shape))
+    assert proof.tobytes() == O.prove_machine(traces, progs, tables, pub, O.default_params(*shape)).tobytes()
+    assert verify_machine(proof, lns, ws, progs, tables, pub, Params(*shape)) == (0, 0)

@@ -95,3 +95,24 @@ def test_malformed_tables_are_refused():
         mutate(t)
         kt, tp, tw = _program_table([t])
         assert lib.zkhip_machine_proof_size(ln, ws, pp, pw, tp, tw, 1, _lib.C.byref(Params(1, 5, 3)), 0) == 0
+
+
+@pytest.mark.parametrize("seed", range(10))
+def test_random_machines_under_three_verifiers(oracle, seed):
+    """tuples of 1..8 values, several buses, multiplicity columns on both sides, odd interaction counts, tables of equal height"""
+    import pyverify_chips
+    O = oracle
+    traces, progs, tables, pub = M.random_machine(seed)
+    lns, ws = shape_of(traces)
+    shape = (1 + seed % 3, 3, 2)
+    proof = O.prove_machine(traces, progs, tables, pub, O.default_params(*shape))
+    assert O.verify_machine(proof, lns, ws, progs, tables, pub, O.default_params(*shape)) == 0
+    assert verify_machine(proof, lns, ws, progs, tables, pub, Params(*shape)) == (0, 0)
+    if seed < 5:
+        assert pyverify_chips.verify(proof.tobytes(), lns, ws, pub, *shape, programs=progs, tables=tables) is True
+    # one multiplicity off by one somewhere: the sums no longer balance
+    c = next(i for i, t in enumerate(tables) if t is not None and int(t[3]) == O.RECEIVE)
+    bad = [t.copy() for t in traces]
+    mcol = int(tables[c][4])
+    bad[c][0, mcol] = (int(bad[c][0, mcol]) + 1) % P
+    assert verify_machine(O.prove_machine(bad, progs, tables, pub, O.default_params(*shape)), lns, ws, progs, tables, pub, Params(*shape)) == (-6, 11)

@@ -19,9 +19,12 @@ while time.time() - t0 < budget:
     if r_kind < 0.05:
         # a machine whose tables look each other up (interaction tables: multiplicities, buses, 1- and 2-tuples), plus bystanders
         lt = int(rng.integers(5, 9)); lu = int(rng.integers(lt, 11))
-        traces, progs, tables, pub = machines.range_machine(lt, lu, seed=int(rng.integers(0, 2**31)))
+        if rng.random() < 0.5:
+            traces, progs, tables, pub = machines.range_machine(lt, lu, seed=int(rng.integers(0, 2**31)))
+        else:
+            traces, progs, tables, pub = machines.random_machine(int(rng.integers(0, 2**31)))
         extra = []
-        for i in range(int(rng.integers(0, 3))):
+        for i in range(int(rng.integers(0, 3)) if len(pub) == 3 else 0):        # synthetic bystanders (range machine only: they share its public values)
             hgt = int(rng.integers(5, lu + 2)); extra.append(O.gen_trace(SEED, 50 + i, hgt, 4 * int(rng.integers(1, 6))))
         allt = sorted([(t, p_, tb) for t, p_, tb in zip(traces, progs, tables)] + [(t, None, None) for t in extra], key=lambda e: -e[0].shape[0])
         traces, progs, tables = [e[0] for e in allt], [e[1] for e in allt], [e[2] for e in allt]
