@@ -490,6 +490,13 @@ typedef struct {
     uint32_t pow_witness;
 } zkhip_prove_debug;
 int zkhip_last_prove_debug(zkhip_ctx* ctx, zkhip_prove_debug* out);
+/* Host verifiers hash the Merkle openings of 16 queries in lockstep, one query per AVX-512 lane, when the CPU has AVX-512 F + DQ
+ * (checked at run time; otherwise query by query), and spread the query groups over up to 8 host threads.  This checks the batched
+ * permutation against the scalar one: 1 = in use and equal, 0 = not available on this CPU, negative = mismatch; the optional outputs
+ * receive the time per permutation of either form in nanoseconds. */
+int zkhip_selftest_host_simd(double* ns_x16, double* ns_scalar);
+/* switch the batched form off (0) or back on (1) for the whole process; returns the previous setting.  For tests and A/B timing. */
+int zkhip_host_simd(int enable);
 
 #ifdef __cplusplus
 }

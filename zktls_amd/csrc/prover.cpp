@@ -8,6 +8,7 @@
 // stream; the host only runs the duplex challenger (a few dozen permutations) between
 // launches, exactly where the protocol forces a round trip (commit -> challenge).
 #include <atomic>
+#include <chrono>
 #include <cstring>
 #include <functional>
 #include <mutex>
@@ -18,6 +19,7 @@
 #include "context.h"
 #include "poseidon2.cuh"
 #include "air.h"
+#include "p2_x16.h"
 
 namespace zk {
 
@@ -1190,6 +1192,55 @@ static bool verify_path(const uint32_t* root_m, int log_h, size_t index, const u
     for (int i = 0; i < 8; i++) if (cur[i] != root_m[i]) return false;
     return true;
 }
+
+// ---- up to sixteen openings of ONE tree at once (p2_x16.cpp: one query per AVX-512 lane).  A verifier's time goes into Poseidon2
+// (the leaf of the opened row, then one compression per level), and a single opening is one dependency chain -- so the queries of a
+// group are hashed in lockstep.  Returns a bit mask: bit j set = opening j FAILED.  Width-24 trees and CPUs without AVX-512 take the
+// scalar verify_path per opening.
+struct PathBatch { int count; size_t index[16]; const uint32_t* row[16]; const uint32_t* path[16]; };
+static void sponge_x16(uint32_t st[16][16], int count, const uint32_t* const* rows, size_t width, size_t& posn, size_t& total) {
+    for (size_t i = 0; i < width; i++) {
+        for (int j = 0; j < count; j++) st[posn][j] = rows[j][i];
+        p2x16_to_monty(st[posn]);
+        posn++; total++;
+        if (posn == 8) { p2x16_permute(st); posn = 0; }
+    }
+}
+static void compress_x16(uint32_t cur[8][16], uint32_t other[8][16], int count, const size_t* index, int lvl, bool other_is_sibling) {
+    // other_is_sibling: a path step (the sibling goes left when bit `lvl` of the index is set); otherwise cur || other (an injected row hash)
+    uint32_t st[16][16];
+    for (int e = 0; e < 8; e++)
+        for (int j = 0; j < 16; j++) {
+            const bool right = other_is_sibling && j < count && ((index[j] >> lvl) & 1);
+            st[e][j] = right ? other[e][j] : cur[e][j];
+            st[8 + e][j] = right ? cur[e][j] : other[e][j];
+        }
+    p2x16_permute(st);
+    memcpy(cur, st, 8 * 16 * 4);
+}
+static uint32_t verify_paths_x16(const uint32_t* root_m, int log_h, const PathBatch& b, size_t width, int hw) {
+    uint32_t failed = 0;
+    if (hw != 16 || !p2x16_available()) {
+        for (int j = 0; j < b.count; j++) if (!verify_path(root_m, log_h, b.index[j], b.row[j], width, b.path[j], hw)) failed |= 1u << j;
+        return failed;
+    }
+    uint32_t st[16][16] = {};
+    size_t posn = 0, total = 0;
+    sponge_x16(st, b.count, b.row, width, posn, total);
+    if (posn) p2x16_permute(st);
+    uint32_t cur[8][16], sib[8][16];
+    memcpy(cur, st, sizeof(cur));
+    for (int lvl = 0; lvl < log_h; lvl++) {
+        for (int e = 0; e < 8; e++) {
+            for (int j = 0; j < 16; j++) sib[e][j] = j < b.count ? b.path[j][8 * lvl + e] : 0u;
+            p2x16_to_monty(sib[e]);
+        }
+        compress_x16(cur, sib, b.count, b.index, lvl, true);
+    }
+    for (int j = 0; j < b.count; j++)
+        for (int e = 0; e < 8; e++) if (cur[e][j] != root_m[e]) { failed |= 1u << j; break; }
+    return failed;
+}
 static Ext ext_from_canon(const uint32_t* p) { return Ext{{to_monty(p[0]), to_monty(p[1]), to_monty(p[2]), to_monty(p[3])}}; }
 static Ext fri_fold_row(size_t index, int log_folded_h, const Ext& beta, const Ext& e0, const Ext& e1) {
     const uint32_t x = fpow(two_adic_generator(log_folded_h + 1), reverse_bits((uint32_t)index, log_folded_h));
@@ -1225,10 +1276,10 @@ static Ext recombine(const Ext* opened4) {
 
 // runs check(q) for q in [0, n) on up to 8 host threads; returns the failure code of the LOWEST failing query (0: all passed), so the
 // verdict does not depend on the thread count
-static int run_queries(int n, const std::function<int(int)>& check) {
+static int run_queries(int n, const std::function<int(int)>& check, int min_per_thread = 4) {
     unsigned hw = std::thread::hardware_concurrency();
     int threads = (int)(hw ? (hw < 8 ? hw : 8) : 1);
-    if (threads > n / 4) threads = n / 4;
+    if (threads > n / min_per_thread) threads = n / min_per_thread;
     if (threads <= 1) {
         for (int q = 0; q < n; q++) { const int r = check(q); if (r) return r; }
         return 0;
@@ -1417,64 +1468,91 @@ static int verify_shard_impl(const uint8_t* proof, size_t len, int log_n, uint32
     const size_t pos0 = pos, words_total = len / 4;
     if ((words_total - pos0) % (size_t)NQ_ != 0) return reject(5);
     const size_t perq = (words_total - pos0) / (size_t)NQ_;
-    auto check_query = [&](int q) -> int {
-        size_t pos = pos0 + (size_t)q * perq;
-        const size_t index = indices[q];
-        const uint32_t* trow = pf + pos; pos += width;
-        const uint32_t* cpath = nullptr;
-        if (CW) { cpath = pf + pos; pos += 8 * (size_t)H; }
-        const uint32_t* tpath = pf + pos; pos += 8 * (size_t)H;
-        const uint32_t *prow = nullptr, *ppath = nullptr;
-        if (LQ) { prow = pf + pos; pos += wp; ppath = pf + pos; pos += 8 * (size_t)H; }
-        const uint32_t* qrow = pf + pos; pos += QW;
-        const uint32_t* qpath = pf + pos; pos += 8 * (size_t)H;
-        if (CW && !verify_path(croot, H, index, trow, CW, cpath, sh.hw)) return 33;
-        if (!verify_path(troot, H, index, trow + CW, width - CW, tpath, sh.hw)) return 30;
-        if (LQ && !verify_path(proot, H, index, prow, wp, ppath, sh.hw)) return 32;
-        if (!verify_path(qroot, H, index, qrow, QW, qpath, sh.hw)) return 31;
-        const uint32_t x = fmul(MONTY_GEN, fpow(wm, reverse_bits((uint32_t)index, H)));
-        const Ext d1 = ext_inv(ext_neg(ext_sub_base(zeta, x)));
-        const Ext d2 = ext_inv(ext_neg(ext_sub_base(zeta_next, x)));
-        Ext at = ext_zero(), ap = ext_zero(), aq = ext_zero();
-        for (size_t j = 0; j < width; j++) at = ext_add(at, ext_mul_base(fapow[j], to_monty(trow[j])));
-        for (size_t j = 0; j < wp; j++) ap = ext_add(ap, ext_mul_base(fapow[j], to_monty(prow[j])));
-        for (size_t j = 0; j < QW; j++) aq = ext_add(aq, ext_mul_base(fapow[j], to_monty(qrow[j])));
-        Ext folded = ext_mul(ext_sub(at, y_loc), d1);
-        folded = ext_add(folded, ext_mul(off_next, ext_mul(ext_sub(at, y_nxt), d2)));
-        if (LQ) {
-            folded = ext_add(folded, ext_mul(off_pl, ext_mul(ext_sub(ap, y_pl), d1)));
-            folded = ext_add(folded, ext_mul(off_pn, ext_mul(ext_sub(ap, y_pn), d2)));
+    // queries go in groups of 16: the Merkle openings of a group are hashed in lockstep (verify_paths_x16), the field arithmetic in
+    // between stays per query.  code[j] = the first check query j fails, in the order a query-by-query verifier meets them.
+    const int NG = (NQ_ + 15) / 16;
+    std::vector<int> qcode(NQ_, 0);
+    auto check_group = [&](int g) -> int {
+        const int q0 = 16 * g, cnt = NQ_ - q0 < 16 ? NQ_ - q0 : 16;
+        const uint32_t *trow[16], *cpath[16], *tpath[16], *prow[16], *ppath[16], *qrow[16], *qpath[16];
+        size_t qpos[16], index[16];
+        int code[16] = {0};
+        auto mark = [&](uint32_t mask, int why) { for (int j = 0; j < cnt; j++) if (((mask >> j) & 1u) && !code[j]) code[j] = why; };
+        for (int j = 0; j < cnt; j++) {
+            size_t pos = pos0 + (size_t)(q0 + j) * perq;
+            index[j] = indices[q0 + j];
+            trow[j] = pf + pos; pos += width;
+            cpath[j] = nullptr;
+            if (CW) { cpath[j] = pf + pos; pos += 8 * (size_t)H; }
+            tpath[j] = pf + pos; pos += 8 * (size_t)H;
+            prow[j] = ppath[j] = nullptr;
+            if (LQ) { prow[j] = pf + pos; pos += wp; ppath[j] = pf + pos; pos += 8 * (size_t)H; }
+            qrow[j] = pf + pos; pos += QW;
+            qpath[j] = pf + pos; pos += 8 * (size_t)H;
+            qpos[j] = pos;
         }
-        folded = ext_add(folded, ext_mul(off_q, ext_mul(ext_sub(aq, y_q), d1)));
-        size_t idx = index;
+        auto batch = [&](const uint32_t* const* rows, size_t row_off, const uint32_t* const* paths, const size_t* idx) {
+            PathBatch b;
+            b.count = cnt;
+            for (int j = 0; j < cnt; j++) { b.index[j] = idx[j]; b.row[j] = rows[j] + row_off; b.path[j] = paths[j]; }
+            return b;
+        };
+        if (CW) mark(verify_paths_x16(croot, H, batch(trow, 0, cpath, index), CW, sh.hw), 33);
+        mark(verify_paths_x16(troot, H, batch(trow, CW, tpath, index), width - CW, sh.hw), 30);
+        if (LQ) mark(verify_paths_x16(proot, H, batch(prow, 0, ppath, index), wp, sh.hw), 32);
+        mark(verify_paths_x16(qroot, H, batch(qrow, 0, qpath, index), QW, sh.hw), 31);
+        Ext folded[16];
+        size_t idx[16];
+        for (int j = 0; j < cnt; j++) {
+            const uint32_t x = fmul(MONTY_GEN, fpow(wm, reverse_bits((uint32_t)index[j], H)));
+            const Ext d1 = ext_inv(ext_neg(ext_sub_base(zeta, x)));
+            const Ext d2 = ext_inv(ext_neg(ext_sub_base(zeta_next, x)));
+            Ext at = ext_zero(), ap = ext_zero(), aq = ext_zero();
+            for (size_t k = 0; k < width; k++) at = ext_add(at, ext_mul_base(fapow[k], to_monty(trow[j][k])));
+            for (size_t k = 0; k < wp; k++) ap = ext_add(ap, ext_mul_base(fapow[k], to_monty(prow[j][k])));
+            for (size_t k = 0; k < QW; k++) aq = ext_add(aq, ext_mul_base(fapow[k], to_monty(qrow[j][k])));
+            Ext f = ext_mul(ext_sub(at, y_loc), d1);
+            f = ext_add(f, ext_mul(off_next, ext_mul(ext_sub(at, y_nxt), d2)));
+            if (LQ) {
+                f = ext_add(f, ext_mul(off_pl, ext_mul(ext_sub(ap, y_pl), d1)));
+                f = ext_add(f, ext_mul(off_pn, ext_mul(ext_sub(ap, y_pn), d2)));
+            }
+            folded[j] = ext_add(f, ext_mul(off_q, ext_mul(ext_sub(aq, y_q), d1)));
+            idx[j] = index[j];
+        }
+        std::vector<uint32_t> rowbuf((size_t)16 * 4 * arity);
+        std::vector<Ext> ev((size_t)16 * arity);
         for (int l = 0; l < RL; l++) {
             const int lh = H - K * (l + 1);
-            const size_t row = idx >> K, own = idx & (arity - 1);
-            Ext ev[32];
-            uint32_t rowbuf[4 * 32];
-            for (size_t j = 0; j < arity; j++) {
-                if (j == own) { ev[j] = folded; for (int i = 0; i < 4; i++) rowbuf[4 * j + i] = from_monty(folded.c[i]); }
-                else { ev[j] = ext_from_canon(pf + pos); for (int i = 0; i < 4; i++) rowbuf[4 * j + i] = pf[pos + i]; pos += 4; }
+            const uint32_t *rows[16], *paths[16];
+            size_t rowidx[16];
+            for (int j = 0; j < cnt; j++) {
+                const size_t row = idx[j] >> K, own = idx[j] & (arity - 1);
+                uint32_t* rb = rowbuf.data() + (size_t)j * 4 * arity;
+                Ext* e = ev.data() + (size_t)j * arity;
+                for (size_t k = 0; k < arity; k++) {
+                    if (k == own) { e[k] = folded[j]; for (int i = 0; i < 4; i++) rb[4 * k + i] = from_monty(folded[j].c[i]); }
+                    else { e[k] = ext_from_canon(pf + qpos[j]); for (int i = 0; i < 4; i++) rb[4 * k + i] = pf[qpos[j] + i]; qpos[j] += 4; }
+                }
+                rows[j] = rb; paths[j] = pf + qpos[j]; qpos[j] += 8 * (size_t)lh; rowidx[j] = row;
             }
-            const uint32_t* path = pf + pos; pos += 8 * (size_t)lh;
-            if (!verify_path(&commits[8 * l], lh, row, rowbuf, 4 * arity, path, sh.hw)) return 40 + (l < 50 ? l : 50);
-            folded = fold_row_k(row, lh, K, betas[l], ev);
-            idx = row;
+            mark(verify_paths_x16(&commits[8 * l], lh, batch(rows, 0, paths, rowidx), 4 * arity, sh.hw), 40 + (l < 50 ? l : 50));
+            for (int j = 0; j < cnt; j++) { folded[j] = fold_row_k(rowidx[j], lh, K, betas[l], ev.data() + (size_t)j * arity); idx[j] = rowidx[j]; }
         }
-        // the final polynomial at this query's point of the last domain <w_{2^(F+b)}> (Horner)
-        {
+        // the final polynomial at every query's point of the last domain <w_{2^(F+b)}> (Horner)
+        for (int j = 0; j < cnt; j++) {
             const int lf = sh.F + sh.b;
-            const uint32_t xf = fpow(two_adic_generator(lf), reverse_bits((uint32_t)idx, lf));
+            const uint32_t xf = fpow(two_adic_generator(lf), reverse_bits((uint32_t)idx[j], lf));
             Ext v = ext_zero();
             for (size_t i = keep; i-- > 0;) v = ext_add(ext_mul_base(v, xf), final_poly[i]);
-            if (!ext_eq(folded, v)) return 100;
+            if (!ext_eq(folded[j], v) && !code[j]) code[j] = 100;
+            if (qpos[j] != pos0 + (size_t)(q0 + j + 1) * perq && !code[j]) code[j] = 5;
+            qcode[q0 + j] = code[j];
         }
-        return pos == pos0 + (size_t)(q + 1) * perq ? 0 : 5;
+        return 0;
     };
-    {
-        const int why = run_queries(NQ_, check_query);
-        if (why) return reject(why);
-    }
+    run_queries(NG, check_group, 1);
+    for (int q = 0; q < NQ_; q++) if (qcode[q]) return reject(qcode[q]);
     pos = pos0 + (size_t)NQ_ * perq;
     if (pos * 4 != len) return reject(5);
     return ZKHIP_OK;
@@ -1942,6 +2020,43 @@ static bool verify_mixed(const uint32_t* root_m, int Hmax, size_t index, const u
     return true;
 }
 
+// sixteen openings of one mixed-height tree at once (as verify_paths_x16): rows[j][c] = the row of chip c in query j
+static uint32_t verify_mixed_x16(const uint32_t* root_m, int Hmax, int count, const size_t* index, const uint32_t* const (*rows)[16],
+                                 const uint32_t* widths, const int* lh, int n, const uint32_t* const* paths) {
+    uint32_t failed = 0;
+    if (!p2x16_available()) {
+        for (int j = 0; j < count; j++) if (!verify_mixed(root_m, Hmax, index[j], rows[j], widths, lh, n, paths[j])) failed |= 1u << j;
+        return failed;
+    }
+    auto hash_height = [&](int h, uint32_t out[8][16]) -> bool {
+        uint32_t st[16][16] = {};
+        size_t posn = 0, total = 0;
+        for (int c = 0; c < n; c++)
+            if (lh[c] == h) {
+                const uint32_t* r[16];
+                for (int j = 0; j < count; j++) r[j] = rows[j][c];
+                sponge_x16(st, count, r, widths[c], posn, total);
+            }
+        if (!total) return false;
+        if (posn) p2x16_permute(st);
+        memcpy(out, st, 8 * 16 * 4);
+        return true;
+    };
+    uint32_t cur[8][16], other[8][16];
+    hash_height(Hmax, cur);
+    for (int lvl = 0; lvl < Hmax; lvl++) {
+        for (int e = 0; e < 8; e++) {
+            for (int j = 0; j < 16; j++) other[e][j] = j < count ? paths[j][8 * lvl + e] : 0u;
+            p2x16_to_monty(other[e]);
+        }
+        compress_x16(cur, other, count, index, lvl, true);
+        if (hash_height(Hmax - lvl - 1, other)) compress_x16(cur, other, count, index, lvl, false);
+    }
+    for (int j = 0; j < count; j++)
+        for (int e = 0; e < 8; e++) if (cur[e][j] != root_m[e]) { failed |= 1u << j; break; }
+    return failed;
+}
+
 int zkhip_verify_chips(const uint8_t* proof, size_t len, const int32_t* log_ns, const uint32_t* widths, const int32_t* pairs, const int32_t* partners, int n,
                        const uint32_t* public_values, size_t n_public, const zkhip_params* prm, int* reason) {
     int dummy;
@@ -2120,63 +2235,89 @@ int zkhip_verify_chips(const uint8_t* proof, size_t len, const int32_t* log_ns, 
     const size_t pos0 = pos, words_total = len / 4;
     if ((words_total - pos0) % (size_t)NQ_ != 0) return 5;
     const size_t perq = (words_total - pos0) / (size_t)NQ_;
-    auto check_query = [&](int q) -> int {
-        size_t pos = pos0 + (size_t)q * perq;
-        const size_t index = indices[q];
-        const uint32_t *trow[MAX_CHIPS], *qrow[MAX_CHIPS], *prow[MAX_CHIPS], *prow_all[MAX_CHIPS];
-        for (int c = 0; c < n; c++) { trow[c] = pf + pos; pos += widths[c]; prow_all[c] = nullptr; }
-        const uint32_t* tpath = pf + pos; pos += 8 * (size_t)Hmax;
-        const uint32_t* ppath = nullptr;
-        if (lk) {
-            for (int k = 0; k < np; k++) { prow[k] = pf + pos; prow_all[pchip[k]] = prow[k]; pos += pw[k]; }
-            ppath = pf + pos; pos += 8 * (size_t)Hp;
-        }
-        for (int c = 0; c < n; c++) { qrow[c] = pf + pos; pos += 8; }
-        const uint32_t* qpath = pf + pos; pos += 8 * (size_t)Hmax;
-        if (!verify_mixed(troot, Hmax, index, trow, widths, lh, n, tpath)) return 30;
-        if (lk && !verify_mixed(proot, Hp, index >> (Hmax - Hp), prow, pw, plh, np, ppath)) return 32;
-        if (!verify_mixed(qroot, Hmax, index, qrow, w8, lh, n, qpath)) return 31;
-        Ext roh[32];
-        for (int h = 0; h < 32; h++) roh[h] = ext_zero();
-        for (int c = 0; c < n; c++) {
-            const size_t ic = index >> (Hmax - lh[c]);
-            const uint32_t x = fmul(MONTY_GEN, fpow(two_adic_generator(lh[c]), reverse_bits((uint32_t)ic, lh[c])));
-            const Ext d1 = ext_inv(ext_neg(ext_sub_base(zeta, x))), d2 = ext_inv(ext_neg(ext_sub_base(znext[c], x)));
-            Ext at = ext_zero(), ap = ext_zero(), aq = ext_zero();
-            for (uint32_t j = 0; j < widths[c]; j++) at = ext_add(at, ext_mul_base(fapow[j], to_monty(trow[c][j])));
-            for (size_t j = 0; j < wp[c]; j++) ap = ext_add(ap, ext_mul_base(fapow[j], to_monty(prow_all[c][j])));
-            for (int j = 0; j < 8; j++) aq = ext_add(aq, ext_mul_base(fapow[j], to_monty(qrow[c][j])));
-            Ext r = ext_mul(s_loc[c], ext_mul(ext_sub(at, y_loc[c]), d1));
-            r = ext_add(r, ext_mul(s_nxt[c], ext_mul(ext_sub(at, y_nxt[c]), d2)));
-            if (wp[c]) {
-                r = ext_add(r, ext_mul(s_pl[c], ext_mul(ext_sub(ap, y_pl[c]), d1)));
-                r = ext_add(r, ext_mul(s_pn[c], ext_mul(ext_sub(ap, y_pn[c]), d2)));
+    // groups of 16 queries: the three mixed-height openings and every FRI layer's opening are hashed in lockstep
+    const int NG = (NQ_ + 15) / 16;
+    std::vector<int> qcode(NQ_, 0);
+    auto check_group = [&](int g) -> int {
+        const int q0 = 16 * g, cnt = NQ_ - q0 < 16 ? NQ_ - q0 : 16;
+        const uint32_t *trow[16][16], *qrow[16][16], *prow[16][16], *prow_all[16][MAX_CHIPS];
+        const uint32_t *tpath[16], *ppath[16], *qpath[16];
+        size_t qpos[16], index[16], pindex[16];
+        int code[16] = {0};
+        auto mark = [&](uint32_t mask, int why) { for (int j = 0; j < cnt; j++) if (((mask >> j) & 1u) && !code[j]) code[j] = why; };
+        for (int j = 0; j < cnt; j++) {
+            size_t pos = pos0 + (size_t)(q0 + j) * perq;
+            index[j] = indices[q0 + j];
+            pindex[j] = lk ? index[j] >> (Hmax - Hp) : 0;
+            for (int c = 0; c < n; c++) { trow[j][c] = pf + pos; pos += widths[c]; prow_all[j][c] = nullptr; }
+            tpath[j] = pf + pos; pos += 8 * (size_t)Hmax;
+            ppath[j] = nullptr;
+            if (lk) {
+                for (int k = 0; k < np; k++) { prow[j][k] = pf + pos; prow_all[j][pchip[k]] = prow[j][k]; pos += pw[k]; }
+                ppath[j] = pf + pos; pos += 8 * (size_t)Hp;
             }
-            r = ext_add(r, ext_mul(s_q[c], ext_mul(ext_sub(aq, y_q[c]), d1)));
-            roh[lh[c]] = ext_add(roh[lh[c]], r);
+            for (int c = 0; c < n; c++) { qrow[j][c] = pf + pos; pos += 8; }
+            qpath[j] = pf + pos; pos += 8 * (size_t)Hmax;
+            qpos[j] = pos;
         }
-        Ext folded = roh[Hmax];
-        size_t idx = index;
+        mark(verify_mixed_x16(troot, Hmax, cnt, index, trow, widths, lh, n, tpath), 30);
+        if (lk) mark(verify_mixed_x16(proot, Hp, cnt, pindex, prow, pw, plh, np, ppath), 32);
+        mark(verify_mixed_x16(qroot, Hmax, cnt, index, qrow, w8, lh, n, qpath), 31);
+        Ext folded[16];
+        size_t idx[16];
+        std::vector<Ext> roh((size_t)16 * 32);
+        for (int j = 0; j < cnt; j++) {
+            Ext* r_h = roh.data() + (size_t)j * 32;
+            for (int h = 0; h < 32; h++) r_h[h] = ext_zero();
+            for (int c = 0; c < n; c++) {
+                const size_t ic = index[j] >> (Hmax - lh[c]);
+                const uint32_t x = fmul(MONTY_GEN, fpow(two_adic_generator(lh[c]), reverse_bits((uint32_t)ic, lh[c])));
+                const Ext d1 = ext_inv(ext_neg(ext_sub_base(zeta, x))), d2 = ext_inv(ext_neg(ext_sub_base(znext[c], x)));
+                Ext at = ext_zero(), ap = ext_zero(), aq = ext_zero();
+                for (uint32_t k = 0; k < widths[c]; k++) at = ext_add(at, ext_mul_base(fapow[k], to_monty(trow[j][c][k])));
+                for (size_t k = 0; k < wp[c]; k++) ap = ext_add(ap, ext_mul_base(fapow[k], to_monty(prow_all[j][c][k])));
+                for (int k = 0; k < 8; k++) aq = ext_add(aq, ext_mul_base(fapow[k], to_monty(qrow[j][c][k])));
+                Ext r = ext_mul(s_loc[c], ext_mul(ext_sub(at, y_loc[c]), d1));
+                r = ext_add(r, ext_mul(s_nxt[c], ext_mul(ext_sub(at, y_nxt[c]), d2)));
+                if (wp[c]) {
+                    r = ext_add(r, ext_mul(s_pl[c], ext_mul(ext_sub(ap, y_pl[c]), d1)));
+                    r = ext_add(r, ext_mul(s_pn[c], ext_mul(ext_sub(ap, y_pn[c]), d2)));
+                }
+                r = ext_add(r, ext_mul(s_q[c], ext_mul(ext_sub(aq, y_q[c]), d1)));
+                r_h[lh[c]] = ext_add(r_h[lh[c]], r);
+            }
+            folded[j] = r_h[Hmax];
+            idx[j] = index[j];
+        }
+        uint32_t rowbuf[16][8];
+        Ext ev[16][2];
         for (int l = 0; l < L; l++) {
             const int rows_log = Hmax - 1 - l;
-            const Ext sib = ext_from_canon(pf + pos);
-            uint32_t rowbuf[8];
-            for (int i = 0; i < 4; i++) { rowbuf[4 * (idx & 1) + i] = from_monty(folded.c[i]); rowbuf[4 * ((idx & 1) ^ 1) + i] = pf[pos + i]; }
-            pos += 4;
-            const uint32_t* path = pf + pos; pos += 8 * (size_t)rows_log;
-            Ext ev[2];
-            ev[idx & 1] = folded; ev[(idx & 1) ^ 1] = sib;
-            if (!verify_path(&commits[8 * l], rows_log, idx >> 1, rowbuf, 8, path, 16)) return 40 + (l < 50 ? l : 50);
-            folded = ext_add(fri_fold_row(idx >> 1, rows_log, betas[l], ev[0], ev[1]), roh[rows_log]);
-            idx >>= 1;
+            PathBatch b;
+            b.count = cnt;
+            for (int j = 0; j < cnt; j++) {
+                const Ext sib = ext_from_canon(pf + qpos[j]);
+                for (int i = 0; i < 4; i++) { rowbuf[j][4 * (idx[j] & 1) + i] = from_monty(folded[j].c[i]); rowbuf[j][4 * ((idx[j] & 1) ^ 1) + i] = pf[qpos[j] + i]; }
+                qpos[j] += 4;
+                ev[j][idx[j] & 1] = folded[j]; ev[j][(idx[j] & 1) ^ 1] = sib;
+                b.index[j] = idx[j] >> 1; b.row[j] = rowbuf[j]; b.path[j] = pf + qpos[j];
+                qpos[j] += 8 * (size_t)rows_log;
+            }
+            mark(verify_paths_x16(&commits[8 * l], rows_log, b, 8, 16), 40 + (l < 50 ? l : 50));
+            for (int j = 0; j < cnt; j++) {
+                folded[j] = ext_add(fri_fold_row(idx[j] >> 1, rows_log, betas[l], ev[j][0], ev[j][1]), roh[(size_t)j * 32 + rows_log]);
+                idx[j] >>= 1;
+            }
         }
-        if (!ext_eq(folded, final_poly)) return 100;
-        return pos == pos0 + (size_t)(q + 1) * perq ? 0 : 5;
+        for (int j = 0; j < cnt; j++) {
+            if (!ext_eq(folded[j], final_poly) && !code[j]) code[j] = 100;
+            if (qpos[j] != pos0 + (size_t)(q0 + j + 1) * perq && !code[j]) code[j] = 5;
+            qcode[q0 + j] = code[j];
+        }
+        return 0;
     };
-    {
-        const int why = run_queries(NQ_, check_query);
-        if (why) return reject(why);
-    }
+    run_queries(NG, check_group, 1);
+    for (int q = 0; q < NQ_; q++) if (qcode[q]) return reject(qcode[q]);
     pos = pos0 + (size_t)NQ_ * perq;
     if (pos * 4 != len) return reject(5);
     return ZKHIP_OK;
@@ -2289,6 +2430,45 @@ int zkhip_verify_machine(const uint8_t* proof, size_t len, const int32_t* log_ns
     if (machine_setup(programs, program_words, tables, table_words, widths, n_chips, n_public, m) != ZKHIP_OK) { if (reason) *reason = 1; return ZKHIP_ERR_VERIFY; }
     MachineScope scope(m.table, &m.mt);
     return zkhip_verify_chips(proof, len, log_ns, widths, m.cols, nullptr, n_chips, public_values, n_public, prm, reason);
+}
+
+// the verifier's batched host permutation (p2_x16.cpp) against the scalar one on pseudo-random states: 1 = AVX-512 in use and equal,
+// 0 = this CPU lacks it (the verifiers then hash query by query), negative = mismatch.  *ns_x16 / *ns_scalar (optional): time per
+// permutation of either form.
+int zkhip_host_simd(int enable) { return p2x16_enable(enable != 0) ? 1 : 0; }
+int zkhip_selftest_host_simd(double* ns_x16, double* ns_scalar) {
+    if (ns_x16) *ns_x16 = 0;
+    if (ns_scalar) *ns_scalar = 0;
+    if (!p2x16_available()) return 0;
+    uint32_t st[16][16], ref[16][16];
+    uint64_t z = 0x9E3779B97F4A7C15ull;
+    for (int round = 0; round < 8; round++) {
+        for (int e = 0; e < 16; e++)
+            for (int j = 0; j < 16; j++) {
+                z = z * 6364136223846793005ull + 1442695040888963407ull;
+                st[e][j] = round == 0 && e < 2 ? (e ? P - 1 : 0u) : (uint32_t)((z >> 33) % P);     // extremes in the first round
+                ref[e][j] = st[e][j];
+            }
+        p2x16_permute(st);
+        for (int j = 0; j < 16; j++) {
+            uint32_t s1[16];
+            for (int e = 0; e < 16; e++) s1[e] = ref[e][j];
+            p2_permute(s1);
+            for (int e = 0; e < 16; e++) if (s1[e] != st[e][j]) return fail(ZKHIP_ERR_INTERNAL, "host SIMD permutation differs from the scalar one");
+        }
+    }
+    const int reps = 2000;
+    auto t0 = std::chrono::steady_clock::now();
+    for (int k = 0; k < reps; k++) p2x16_permute(st);
+    const double a = std::chrono::duration<double, std::nano>(std::chrono::steady_clock::now() - t0).count() / (16.0 * reps);
+    uint32_t s1[16];
+    for (int e = 0; e < 16; e++) s1[e] = st[e][0];
+    t0 = std::chrono::steady_clock::now();
+    for (int k = 0; k < reps; k++) p2_permute(s1);
+    const double b = std::chrono::duration<double, std::nano>(std::chrono::steady_clock::now() - t0).count() / reps;
+    if (ns_x16) *ns_x16 = a;
+    if (ns_scalar) *ns_scalar = b + (s1[0] == 0xFFFFFFFFu ? 1 : 0);
+    return 1;
 }
 
 int zkhip_last_prove_debug(zkhip_ctx* ctx, zkhip_prove_debug* out) {
