@@ -1,11 +1,11 @@
 #!/bin/bash
 # AddressSanitizer on the HOST code of libzkhip (verifiers, validators, serialisation, argument checks): builds
-# zktls_amd/libzkhip_asan.so (host objects with -fsanitize=address, device objects as shipped; GPU ASan is not available on this
+# zktls_amd/libzkhip_asan.so (host objects built with the address sanitizer, device objects as shipped; GPU ASan is not available on this
 # pool) and runs the CPU test files that exercise host entries plus tools/fuzz_host.py against it.  usage: tools/asan_cpu.sh [fuzz seconds]
 set -e
 cd "$(dirname "$0")/.."
 make -C zktls_amd/csrc -j8 > /dev/null
-make -C zktls_amd/csrc asan
+make -C zktls_amd/csrc -f asan.mk asan
 RT=$(/opt/rocm/lib/llvm/bin/clang -print-file-name=libclang_rt.asan-x86_64.so)
 export ASAN_OPTIONS=detect_leaks=0
 LD_PRELOAD=$RT python -c "
