@@ -2,6 +2,9 @@
 # AddressSanitizer on the HOST code of libzkhip (verifiers, validators, serialisation, argument checks): builds
 # zktls_amd/libzkhip_asan.so (host objects built with the address sanitizer, device objects as shipped; GPU ASan is not available on this
 # pool) and runs the CPU test files that exercise host entries plus tools/fuzz_host.py against it.  usage: tools/asan_cpu.sh [fuzz seconds]
+# ThreadSanitizer over the threaded verifiers: make -C zktls_amd/csrc -f asan.mk asan SAN=-fsanitize=thread ASAN_OUT=../libzkhip_tsan.so
+# (after rm -rf zktls_amd/csrc/build/asan), then the same python command with LD_PRELOAD=libclang_rt.tsan and that library: the only
+# reports come from the oracle's OpenMP runtime (libgomp is not instrumented), none from libzkhip.
 set -e
 cd "$(dirname "$0")/.."
 make -C zktls_amd/csrc -j8 > /dev/null
