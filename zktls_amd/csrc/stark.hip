@@ -631,6 +631,50 @@ __global__ void __launch_bounds__(256) rowdot_kernel(const uint32_t* __restrict_
     for (int i = 0; i < 4; i++) r.c[i] = row_group_sum(dacc_finish(acc[i]), L);
     if (lane == 0) st_ext(out_at + 4 * p, r);
 }
+// The same dot product with the powers of alpha kept in REGISTERS: a lane owns the column quads q = lane + L k, k < NK, of EVERY row its
+// wavefront visits (64 / L rows per trip, ROWDOT_TRIPS trips), so a row costs its own 16-byte loads only.  In the form above every
+// 16 bytes of a row came with 64 bytes of powers from L1 -- five load instructions per payload load: the kernel was bound by the
+// texture path at 4.0 TB/s of HBM traffic.  Used for widths up to 1024 / (16 / NK_MAX) = 256 columns per 16 lanes (NK <= 4).
+constexpr int ROWDOT_TRIPS = 16;
+template <int NK>
+__global__ void __launch_bounds__(256) rowdot_regs_kernel(const uint32_t* __restrict__ mat, uint64_t ld, uint32_t width, uint64_t rows,
+                                                          int L, const uint32_t* __restrict__ alpha_pow, uint32_t* __restrict__ out_at) {
+    const int lane = (int)(threadIdx.x % L);
+    const uint32_t nq = width / 4;
+    const uint64_t rows_per_trip = 256 / L;                       // rows a workgroup covers per trip
+    const uint64_t r0 = (uint64_t)blockIdx.x * rows_per_trip * ROWDOT_TRIPS + threadIdx.x / L;
+    uint4 a0[NK], a1[NK], a2[NK], a3[NK];
+#pragma unroll
+    for (int k = 0; k < NK; k++) {
+        const uint32_t q = lane + (uint32_t)L * k;
+        const uint4* ap = reinterpret_cast<const uint4*>(alpha_pow + 16 * (q < nq ? q : 0));
+        a0[k] = ap[0]; a1[k] = ap[1]; a2[k] = ap[2]; a3[k] = ap[3];
+    }
+    for (int t = 0; t < ROWDOT_TRIPS; t++) {
+        const uint64_t p = r0 + (uint64_t)t * rows_per_trip;
+        if (p >= rows) return;                                    // rows_per_trip divides the row count of every caller: whole waves leave together
+        const uint32_t* row = mat + p * ld;
+        uint4 v[NK];
+#pragma unroll
+        for (int k = 0; k < NK; k++) {
+            const uint32_t q = lane + (uint32_t)L * k;
+            v[k] = q < nq ? ld_stream(row + 4 * q) : make_uint4(0, 0, 0, 0);
+        }
+        uint64_t acc[4] = {0, 0, 0, 0};
+#pragma unroll
+        for (int k = 0; k < NK; k++) {
+            dacc2(acc[0], a0[k].x, v[k].x, a1[k].x, v[k].y); dacc2(acc[0], a2[k].x, v[k].z, a3[k].x, v[k].w);
+            dacc2(acc[1], a0[k].y, v[k].x, a1[k].y, v[k].y); dacc2(acc[1], a2[k].y, v[k].z, a3[k].y, v[k].w);
+            dacc2(acc[2], a0[k].z, v[k].x, a1[k].z, v[k].y); dacc2(acc[2], a2[k].z, v[k].z, a3[k].z, v[k].w);
+            dacc2(acc[3], a0[k].w, v[k].x, a1[k].w, v[k].y); dacc2(acc[3], a2[k].w, v[k].z, a3[k].w, v[k].w);
+        }
+        Ext r;
+#pragma unroll
+        for (int i = 0; i < 4; i++) r.c[i] = row_group_sum(dacc_finish(acc[i]), L);
+        if (lane == 0) st_ext(out_at + 4 * p, r);
+    }
+}
+static hipError_t launch_rowdot(const uint32_t* mat, uint64_t ld, uint32_t width, uint64_t rows, const uint32_t* alpha_pow, uint32_t* out_at, hipStream_t s);
 __global__ void __launch_bounds__(256) reduced_combine_kernel(ReducedArgs a, const uint32_t* __restrict__ at_in, const uint32_t* __restrict__ ap_in) {
     const uint64_t p = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (p >= a.rows) return;
@@ -656,18 +700,31 @@ __global__ void __launch_bounds__(256) reduced_combine_kernel(ReducedArgs a, con
     st_ext(a.out + 4 * p, r);
 }
 static int lanes_for(uint32_t width) { int g = (int)(width / 4), l = 1; while (l < g && l < 16) l <<= 1; return l; }
+static hipError_t launch_rowdot(const uint32_t* mat, uint64_t ld, uint32_t width, uint64_t rows, const uint32_t* alpha_pow, uint32_t* out_at, hipStream_t s) {
+    const int L = lanes_for(width);
+    const uint32_t nq = width / 4;
+    const int nk = (int)((nq + L - 1) / L);
+    const uint64_t rows_per_wg = (uint64_t)(256 / L) * ROWDOT_TRIPS;
+    if (nk <= 4 && rows % (256 / L) == 0 && rows >= rows_per_wg) {
+        const dim3 grid((unsigned)((rows + rows_per_wg - 1) / rows_per_wg)), block(256);
+        switch (nk) {
+            case 1: hipLaunchKernelGGL(rowdot_regs_kernel<1>, grid, block, 0, s, mat, ld, width, rows, L, alpha_pow, out_at); break;
+            case 2: hipLaunchKernelGGL(rowdot_regs_kernel<2>, grid, block, 0, s, mat, ld, width, rows, L, alpha_pow, out_at); break;
+            case 3: hipLaunchKernelGGL(rowdot_regs_kernel<3>, grid, block, 0, s, mat, ld, width, rows, L, alpha_pow, out_at); break;
+            default: hipLaunchKernelGGL(rowdot_regs_kernel<4>, grid, block, 0, s, mat, ld, width, rows, L, alpha_pow, out_at); break;
+        }
+        return hipGetLastError();
+    }
+    const uint64_t threads = rows * L;
+    hipLaunchKernelGGL(rowdot_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, s, mat, ld, width, rows, L, alpha_pow, out_at);
+    return hipGetLastError();
+}
 hipError_t launch_reduced_opening(const ReducedArgs& a, uint32_t* scratch_at, hipStream_t s) {
-    int L = lanes_for(a.width);
-    uint64_t threads = a.rows * L;
-    hipLaunchKernelGGL(rowdot_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, s, a.tlde, a.t_ld, a.width, a.rows, L, a.alpha_pow, scratch_at);
-    hipError_t e = hipGetLastError();
+    hipError_t e = launch_rowdot(a.tlde, a.t_ld, a.width, a.rows, a.alpha_pow, scratch_at, s);
     if (e != hipSuccess) return e;
     uint32_t* scratch_ap = scratch_at + 4 * a.rows;
     if (a.p_width) {
-        L = lanes_for(a.p_width);
-        threads = a.rows * L;
-        hipLaunchKernelGGL(rowdot_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, s, a.plde, a.p_ld, a.p_width, a.rows, L, a.alpha_pow, scratch_ap);
-        e = hipGetLastError();
+        e = launch_rowdot(a.plde, a.p_ld, a.p_width, a.rows, a.alpha_pow, scratch_ap, s);
         if (e != hipSuccess) return e;
     }
     hipLaunchKernelGGL(reduced_combine_kernel, dim3((unsigned)((a.rows + 255) / 256)), dim3(256), 0, s, a, scratch_at, scratch_ap);
