@@ -314,6 +314,10 @@ int zkhip_prove_shards(int device, zkhip_shard_job* jobs, int n_jobs, const zkhi
  * staged by the library on that device.  Status / error reporting as zkhip_prove_shards. */
 int zkhip_prove_shards_multi(const int* devices, int n_devices, zkhip_shard_job* jobs, int n_jobs, const zkhip_params* prm,
                              int in_flight_per_device, int host_traces);
+/* The same batch when every job is a trace of ONE constraint program (zkhip_prove_shard_air's format): e.g. the SHA-256 chip traces of
+ * sixty-four transcripts dealt over the GPUs of a node.  Device traces only; each job brings its own public values. */
+int zkhip_prove_shards_air_multi(const int* devices, int n_devices, zkhip_shard_job* jobs, int n_jobs, const uint32_t* program, size_t program_words,
+                                 const zkhip_params* prm, int in_flight_per_device);
 /* the device ordinal shard `shard_index` of a batch is proven on (devices == NULL: ordinal shard_index mod n_devices); -1 on bad arguments */
 int zkhip_shard_device(int shard_index, const int* devices, int n_devices);
 /* the internal contexts of zkhip_prove_shards stay cached between calls (creating and freeing multi-GiB workspaces costs more than

@@ -54,6 +54,8 @@ extern "C" {
     /// all shards of one request over a device list, shard s on devices[s mod n] (null list + 0: every visible device)
     pub fn zkhip_prove_shards_multi(devices: *const c_int, n_devices: c_int, jobs: *mut ZkhipShardJob, n_jobs: c_int,
                                     prm: *const ZkhipParams, in_flight_per_device: c_int, host_traces: c_int) -> c_int;
+    pub fn zkhip_prove_shards_air_multi(devices: *const c_int, n_devices: c_int, jobs: *mut ZkhipShardJob, n_jobs: c_int,
+                                        program: *const u32, program_words: usize, prm: *const ZkhipParams, in_flight_per_device: c_int) -> c_int;
     pub fn zkhip_shard_device(shard_index: c_int, devices: *const c_int, n_devices: c_int) -> c_int;
     pub fn zkhip_ctx_create(device: c_int, stream: *mut c_void, out: *mut *mut ZkhipCtx) -> c_int;
     pub fn zkhip_ctx_destroy(ctx: *mut ZkhipCtx);

@@ -83,6 +83,11 @@ def test_multi_device_entry_argument_handling_and_dealing():
         assert all(j.status == -2 and j.proof_len == 0 for j in jobs)
         rc = L.zkhip_prove_shards_multi(two, 2, jobs, 5, C.byref(prm), 2, 0)              # explicit list: every worker fails to get a context
         assert rc == -2 and all(j.status != 0 for j in jobs)
+        # the program variant: same argument rules, same loud failure
+        import numpy as np
+        prog = np.array([0x50524941, 1, 4, 1, 0, 11, 0, 1, 1, 1, 0], dtype=np.uint32)      # one constraint: column 0 = 0 on every row
+        assert L.zkhip_prove_shards_air_multi(None, 0, jobs, 5, None, 0, C.byref(prm), 2) == -1
+        assert L.zkhip_prove_shards_air_multi(None, 0, jobs, 5, prog.ctypes.data_as(_lib.u32p), prog.size, C.byref(prm), 2) == -2
     L.zkhip_release_cached_contexts()
 
 

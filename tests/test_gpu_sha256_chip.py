@@ -58,3 +58,27 @@ def test_misuse_fails_loudly(ctx):
         ctx.prove_sha256(b"abc", Params(1, 10, 4, 1))            # no lookup argument with a constraint program
     with pytest.raises(ZkHipError):
         ctx.sha256_gen_trace(S.pad(b"abc"), 3)                    # block count must be a power of two
+
+
+def test_sixty_four_transcripts_in_one_call(ctx):
+    """BASELINE configs[2] with a REAL statement per transcript: 64 distinct 13 KB inputs, each a SHA-256 chip trace generated on the
+    device, proven by ONE zkhip_prove_shards_air_multi call (four in flight per device), every digest against hashlib, every proof
+    accepted by the host verifier and bound to its own digest"""
+    from zktls_amd.device import prove_shards_air_multi
+    import os
+    base = open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "reference", "guest_input0.cbor"), "rb").read()
+    prm = Params(1, 40, 8)
+    traces, pubs, digests = [], [], []
+    for i in range(64):
+        msg = base + i.to_bytes(4, "little")
+        d, limbs = ctx.sha256_gen_trace(S.pad(msg))
+        traces.append(d)
+        pubs.append(limbs.tolist())
+        digests.append(hashlib.sha256(msg).digest())
+        assert S.digest_bytes(pubs[-1]) == digests[-1]
+    ctx.sync()
+    proofs = prove_shards_air_multi(sha256_air(), traces, 14, 608, pubs, prm, devices=[0], in_flight=4)
+    assert len(proofs) == 64 and len({p.tobytes() for p in proofs}) == 64
+    for i, p in enumerate(proofs):
+        assert verify_sha256(p, digests[i], prm) == (0, 0)
+    assert verify_sha256(proofs[3], digests[4], prm)[0] == -6

@@ -32,7 +32,7 @@ EXPORTS = [
     "zkhip_air_validate", "zkhip_air_digest", "zkhip_air_synthetic", "zkhip_proof_size_air", "zkhip_prove_shard_air", "zkhip_verify_shard_air",
     "zkhip_quotient_values_air",
     "zkhip_chips_proof_size_air", "zkhip_prove_chips_air", "zkhip_verify_chips_air",
-    "zkhip_selftest_host_simd", "zkhip_host_simd", "zkhip_machine_proof_size", "zkhip_prove_machine", "zkhip_verify_machine", "zkhip_range_table",
+    "zkhip_prove_shards_air_multi", "zkhip_selftest_host_simd", "zkhip_host_simd", "zkhip_machine_proof_size", "zkhip_prove_machine", "zkhip_verify_machine", "zkhip_range_table",
     "zkhip_sha256_air", "zkhip_sha256_digest", "zkhip_sha256_pad", "zkhip_sha256_gen_trace", "zkhip_sha256_proof_size", "zkhip_prove_sha256", "zkhip_verify_sha256",
 ]
 
@@ -156,6 +156,7 @@ def load():
     L.zkhip_prove_chips_air.argtypes = [C.c_void_p, C.POINTER(Chip), u32pp, szp, C.c_int, u32p, C.c_size_t, C.POINTER(Params), u8p, C.c_size_t, szp]
     L.zkhip_verify_chips_air.argtypes = [u8p, C.c_size_t, C.POINTER(C.c_int32), C.POINTER(C.c_uint32), u32pp, szp, C.c_int, u32p, C.c_size_t,
                                          C.POINTER(Params), C.POINTER(C.c_int)]
+    L.zkhip_prove_shards_air_multi.argtypes = [C.POINTER(C.c_int), C.c_int, C.POINTER(ShardJob), C.c_int, u32p, C.c_size_t, C.POINTER(Params), C.c_int]
     L.zkhip_selftest_host_simd.argtypes = [C.POINTER(C.c_double), C.POINTER(C.c_double)]
     L.zkhip_range_table.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_size_t, C.POINTER(C.c_uint32), C.c_int, C.c_int, C.c_void_p, C.c_size_t,
                                     C.c_uint32, C.c_uint32]

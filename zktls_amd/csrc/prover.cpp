@@ -1048,7 +1048,7 @@ void zkhip_release_cached_contexts(void) {
 // `in_flight` workers (context + HIP stream + host thread each) that take that device's shards in index order.  Job traces are
 // device pointers ON THE DEVICE THE SHARD IS ASSIGNED TO, or host pointers with host_traces.
 static int prove_shards_on(const int* devices, int n_devices, zkhip_shard_job* jobs, int n_jobs, const zkhip_params* prm, int in_flight,
-                           int host_traces) {
+                           int host_traces, const uint32_t* program = nullptr, size_t program_words = 0) {
     if (n_jobs == 0) return ZKHIP_OK;
     if (in_flight <= 0) in_flight = 4;
     for (int i = 0; i < n_jobs; i++) { jobs[i].status = ZKHIP_ERR_INVALID; jobs[i].proof_len = 0; }
@@ -1076,9 +1076,12 @@ static int prove_shards_on(const int* devices, int n_devices, zkhip_shard_job* j
             if (i >= n_jobs) break;
             zkhip_shard_job& j = jobs[i];
             size_t len = 0;
-            rc = host_traces
-                     ? zkhip_prove_shard_host(ctx, j.trace, j.log_n, j.width, j.public_values, j.n_public, prm, j.proof, j.proof_cap, &len)
-                     : zkhip_prove_shard(ctx, j.trace, j.ld, j.log_n, j.width, j.public_values, j.n_public, prm, j.proof, j.proof_cap, &len);
+            if (program)             // every job of the batch is a trace of the same constraint program (device traces)
+                rc = zkhip_prove_shard_air(ctx, program, program_words, j.trace, j.ld, j.log_n, j.width, j.public_values, j.n_public, prm, j.proof, j.proof_cap, &len);
+            else
+                rc = host_traces
+                         ? zkhip_prove_shard_host(ctx, j.trace, j.log_n, j.width, j.public_values, j.n_public, prm, j.proof, j.proof_cap, &len)
+                         : zkhip_prove_shard(ctx, j.trace, j.ld, j.log_n, j.width, j.public_values, j.n_public, prm, j.proof, j.proof_cap, &len);
             j.status = rc;
             j.proof_len = rc == ZKHIP_OK ? len : 0;
             if (rc != ZKHIP_OK) note((int)i, rc);
@@ -1131,6 +1134,32 @@ int zkhip_prove_shards_multi(const int* devices, int n_devices, zkhip_shard_job*
         }
     }
     return prove_shards_on(devs.data(), (int)devs.size(), jobs, n_jobs, prm, in_flight_per_device, host_traces);
+}
+
+// the same batch when every job is a trace of ONE constraint program (e.g. sixty-four SHA-256 chip traces: sixty-four transcripts)
+int zkhip_prove_shards_air_multi(const int* devices, int n_devices, zkhip_shard_job* jobs, int n_jobs, const uint32_t* program, size_t program_words,
+                                 const zkhip_params* prm, int in_flight_per_device) {
+    const int host_traces = 0;
+    if (!program || program_words < 6) return fail(ZKHIP_ERR_INVALID, "prove_shards_air_multi: null program");
+    if (!jobs || n_jobs < 0 || !prm) return fail(ZKHIP_ERR_INVALID, "prove_shards_air_multi: bad arguments");
+    std::vector<int> devs;
+    if (!devices) {                                           // NULL: every visible device
+        if (n_devices != 0) return fail(ZKHIP_ERR_INVALID, "prove_shards_air_multi: n_devices must be 0 when devices is NULL (all visible devices)");
+        const int n = zkhip_device_count();
+        if (n <= 0) {
+            for (int i = 0; i < n_jobs; i++) { jobs[i].status = ZKHIP_ERR_NO_DEVICE; jobs[i].proof_len = 0; }
+            return n_jobs == 0 ? ZKHIP_OK : fail(ZKHIP_ERR_NO_DEVICE, "no HIP device visible: libzkhip has no CPU fallback");
+        }
+        for (int d = 0; d < n; d++) devs.push_back(d);
+    } else {
+        if (n_devices < 1 || n_devices > 64) return fail(ZKHIP_ERR_INVALID, "prove_shards_air_multi: 1..64 devices");
+        for (int d = 0; d < n_devices; d++) {
+            if (devices[d] < 0) return fail(ZKHIP_ERR_INVALID, "prove_shards_air_multi: negative device ordinal");
+            for (int e = 0; e < d; e++) if (devices[e] == devices[d]) return fail(ZKHIP_ERR_INVALID, "prove_shards_air_multi: device listed twice");
+            devs.push_back(devices[d]);
+        }
+    }
+    return prove_shards_on(devs.data(), (int)devs.size(), jobs, n_jobs, prm, in_flight_per_device, host_traces, program, program_words);
 }
 
 int zkhip_prove_segment(zkhip_ctx* ctx, const uint32_t* d_cols, int log_n, uint32_t width,

@@ -523,6 +523,31 @@ def prove_shards_multi(traces, log_n, width, public_values_list, params=None, de
     return [keep[i][1][: jobs[i].proof_len] for i in range(n)]
 
 
+def prove_shards_air_multi(program, traces, log_n, width, public_values_list, params=None, devices=None, in_flight=4):
+    """zkhip_prove_shards_air_multi: a batch of device traces of ONE constraint program, dealt over `devices` like prove_shards_multi"""
+    lib = _lib.load()
+    params = params or Params(1, 100, 16, 0)
+    prog = np.ascontiguousarray(program, dtype=np.uint32)
+    n = len(traces)
+    jobs = (_lib.ShardJob * n)()
+    keep = []
+    for i, (t, pv) in enumerate(zip(traces, public_values_list)):
+        pva = np.ascontiguousarray(np.array(pv, dtype=np.uint32))
+        size = lib.zkhip_proof_size_air(prog.ctypes.data_as(u32p), prog.size, log_n, width, C.byref(params), pva.size)
+        buf = np.empty(max(size, 1), dtype=np.uint8)
+        keep.append((pva, buf))
+        jobs[i].trace = t.ptr
+        jobs[i].ld = width; jobs[i].log_n = log_n; jobs[i].width = width
+        jobs[i].public_values = pva.ctypes.data_as(u32p); jobs[i].n_public = pva.size
+        jobs[i].proof = buf.ctypes.data_as(u8p); jobs[i].proof_cap = size
+    if devices is None:
+        dv, nd = None, 0
+    else:
+        dv, nd = (C.c_int * len(devices))(*[int(d) for d in devices]), len(devices)
+    check(lib.zkhip_prove_shards_air_multi(dv, nd, jobs, n, prog.ctypes.data_as(u32p), prog.size, C.byref(params), int(in_flight)))
+    return [keep[i][1][: jobs[i].proof_len] for i in range(n)]
+
+
 def shard_device(shard_index, devices=None, n_devices=None):
     """the device ordinal zkhip_prove_shards_multi proves shard `shard_index` on"""
     lib = _lib.load()
