@@ -37,7 +37,7 @@
 #define CHIPS_VERSION_LOGUP 5u
 #define CHIPS_VERSION_CROSS 6u     /* some chips look each other up: cumulative sums are part of the proof */
 #define CHIPS_VERSION_AIR 9u       /* some chips carry a constraint program */
-#define MAX_CHIPS 16
+#define MAX_CHIPS 32
 
 /* the programs in effect for the running orc_*_chips_air call (NULL: every chip uses the synthetic AIR) */
 static _Thread_local const uint32_t* const* g_progs = NULL;
@@ -164,10 +164,10 @@ static int chips_ok(const int* log_ns, const size_t* widths, const int* pairs, c
             if (!pairs || d >= n || d == c || partners[d] != c || pairs[c] == 0 || pairs[d] != pairs[c] || log_ns[d] != log_ns[c]) return 0;
         } else if (partners && partners[c] < -1) return 0;
     }
-    for (int c = 0; c < n; c++) {                                  /* at most 4 chips share a height (one leaf hash) */
+    for (int c = 0; c < n; c++) {                                  /* at most 8 chips share a height (one leaf hash) */
         int same = 0;
         for (int d = 0; d < n; d++) if (log_ns[d] == log_ns[c]) same++;
-        if (same > 4) return 0;
+        if (same > 8) return 0;
     }
     return 1;
 }
@@ -502,7 +502,7 @@ size_t orc_prove_chips(const uint32_t* const* traces, const int* log_ns, const s
 /* opening of a mixed-height tree: rows[c] is matrix c's row at index >> (Hmax - lh[c]); Hmax = the tree's own height */
 static int verify_mixed(const uint32_t root[8], int Hmax, size_t index, const uint32_t* const* rows, const size_t* widths,
                         const int* lh, int n, const uint32_t* sibs) {
-    uint32_t buf[4 * 1024 + 8], cur[8];
+    uint32_t buf[8 * 1024 + 8], cur[8];
     size_t len = 0;
     for (int c = 0; c < n; c++) if (lh[c] == Hmax) { memcpy(buf + len, rows[c], widths[c] * 4); len += widths[c]; }
     orc_sponge_hash(buf, len, cur);

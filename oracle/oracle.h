@@ -161,7 +161,7 @@ int orc_verify_shard(const uint8_t* proof, size_t len, int log_n, size_t width,
                      const orc_params_t* prm);
 
 /* ---- a shard of several chips with different heights (oracle/chips.c): tallest first, heights log_ns[c] in [5, 20],
- * at most 4 chips per height, SP1 FRI shape (log_fold 1, log_final 0, hash width 16) at any log_blowup ---- */
+ * at most 8 chips per height (32 in all), SP1 FRI shape (log_fold 1, log_final 0, hash width 16) at any log_blowup ---- */
 /* pairs (may be NULL): LogUp pairs per chip; the permutation traces form a third tree.  partners (may be NULL):
  * partners[c] = -1: chip c's lookups stay inside the chip (orc_gen_trace_logup); d >= 0: its receiver groups hold chip d's
  * sender groups (orc_gen_trace_logup_cross; mutual, equal heights and pair counts) -- then every chip with pairs exposes the

@@ -105,3 +105,25 @@ def test_random_machines_bytes_equal_the_oracles(ctx, oracle, seed):
     proof = ctx.prove_machine(chips, progs, tables, pub, Params(*shape))
     assert proof.tobytes() == O.prove_machine(traces, progs, tables, pub, O.default_params(*shape)).tobytes()
     assert verify_machine(proof, lns, ws, progs, tables, pub, Params(*shape)) == (0, 0)
+
+
+def test_a_machine_of_thirty_tables(ctx, oracle):
+    """an SP1 shard holds two to three dozen chips: 30 tables, eight of them of one height, a range machine among synthetic tables"""
+    O = oracle
+    traces, progs, tables, pub = M.range_machine(6, 8, seed=9)               # heights 9, 8, 6
+    extra = [(10, 8)] * 3 + [(9, 4)] * 6 + [(8, 12)] * 7 + [(7, 4)] * 8 + [(5, 8)] * 3          # 27 synthetic tables
+    allt = [(t, p_, tb) for t, p_, tb in zip(traces, progs, tables)] + [(O.gen_trace(5, 70 + i, h, w), None, None) for i, (h, w) in enumerate(extra)]
+    allt.sort(key=lambda e: -e[0].shape[0])
+    traces, progs, tables = [e[0] for e in allt], [e[1] for e in allt], [e[2] for e in allt]
+    lns, ws = shape_of(traces)
+    assert len(traces) == 30 and max(lns.count(h) for h in lns) == 8
+    chips = [(ctx.from_numpy(t), ln, w) for t, ln, w in zip(traces, lns, ws)]
+    proof = ctx.prove_machine(chips, progs, tables, pub, Params(1, 8, 4))
+    assert proof.tobytes() == O.prove_machine(traces, progs, tables, pub, O.default_params(1, 8, 4)).tobytes()
+    assert verify_machine(proof, lns, ws, progs, tables, pub, Params(1, 8, 4)) == (0, 0)
+    # one more table of the crowded height is refused
+    from zktls_amd._lib import ZkHipError
+    t9 = O.gen_trace(5, 99, 7, 4)
+    i = lns.index(7)
+    with pytest.raises(ZkHipError):
+        ctx.prove_machine(chips[:i] + [(ctx.from_numpy(t9), 7, 4)] + chips[i:], progs[:i] + [None] + progs[i:], tables[:i] + [None] + tables[i:], pub, Params(1, 8, 4))

@@ -504,9 +504,11 @@ def test_multi_chip_shape_rules(oracle):
         oracle.prove_chips(t, [], oracle.default_params(1, 4, 0))             # not tallest first
     with pytest.raises(RuntimeError):
         oracle.prove_chips(t[::-1], [], oracle.default_params(1, 4, 0, 0, 4, 0, 24))   # only the SP1 FRI shape
-    five = [oracle.gen_trace(SEED, i, 6, 4) for i in range(5)]
+    nine = [oracle.gen_trace(SEED, i, 6, 4) for i in range(9)]
     with pytest.raises(RuntimeError):
-        oracle.prove_chips(five, [], oracle.default_params(1, 4, 0))          # more than 4 chips of one height
+        oracle.prove_chips(nine, [], oracle.default_params(1, 4, 0))          # more than 8 chips of one height
+    eight = oracle.prove_chips(nine[:8], [], oracle.default_params(1, 4, 0))
+    assert oracle.verify_chips(eight, [6] * 8, [4] * 8, [], oracle.default_params(1, 4, 0)) == 0
 
 
 @pytest.mark.parametrize("name", sorted(KAT["chip_proofs"]))

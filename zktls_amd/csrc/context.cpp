@@ -417,7 +417,7 @@ int op_coset_lde(zkhip_ctx* ctx, const uint32_t* in, size_t in_ld, uint32_t* out
 }
 
 int op_merkle_commit(zkhip_ctx* ctx, const MatDesc* mats, int nmats, int log_h, uint32_t* tree) {
-    if (nmats < 1 || nmats > MAX_LEAF_MATS) return fail(ZKHIP_ERR_INVALID, "merkle_commit: 1..4 matrices");
+    if (nmats < 1 || nmats > MAX_LEAF_MATS) return fail(ZKHIP_ERR_INVALID, "merkle_commit: 1..8 matrices");
     if (log_h < 0 || log_h > 30) return fail(ZKHIP_ERR_INVALID, "merkle_commit: bad log_h");
     LeafArgs la{};
     for (int m = 0; m < nmats; m++) la.mats[m] = mats[m];
@@ -448,7 +448,7 @@ int op_merkle_commit(zkhip_ctx* ctx, const MatDesc* mats, int nmats, int log_h, 
 // the tallest ones form the leaves; a shorter matrix is injected at the level with as many
 // nodes as it has rows: node = compress(node, sponge(row)).
 int op_merkle_commit_mixed(zkhip_ctx* ctx, const MatDesc* mats, const int* log_heights, int nmats, uint32_t* tree) {
-    if (nmats < 1 || nmats > 16) return fail(ZKHIP_ERR_INVALID, "merkle_commit_mixed: 1..16 matrices");
+    if (nmats < 1 || nmats > 32) return fail(ZKHIP_ERR_INVALID, "merkle_commit_mixed: 1..32 matrices");
     int log_h = 0;
     for (int m = 0; m < nmats; m++) {
         if (log_heights[m] < 0 || log_heights[m] > 30) return fail(ZKHIP_ERR_INVALID, "merkle_commit_mixed: bad height");
@@ -465,7 +465,7 @@ int op_merkle_commit_mixed(zkhip_ctx* ctx, const MatDesc* mats, const int* log_h
         return true;
     };
     LeafArgs la;
-    if (!gather(log_h, la)) return fail(ZKHIP_ERR_INVALID, "merkle_commit_mixed: at most 4 matrices per height");
+    if (!gather(log_h, la)) return fail(ZKHIP_ERR_INVALID, "merkle_commit_mixed: at most 8 matrices per height");
     la.digests = tree;
     ZK_HIP(launch_hash_rows(la, ctx->stream));
     uint32_t* level = tree;
@@ -488,7 +488,7 @@ int op_merkle_commit_mixed(zkhip_ctx* ctx, const MatDesc* mats, const int* log_h
         uint32_t* next = level + 16 * cnt;
         ZK_HIP(launch_compress_level(level, next, cnt, ctx->stream));
         LeafArgs inj;
-        if (!gather(lvl, inj)) return fail(ZKHIP_ERR_INVALID, "merkle_commit_mixed: at most 4 matrices per height");
+        if (!gather(lvl, inj)) return fail(ZKHIP_ERR_INVALID, "merkle_commit_mixed: at most 8 matrices per height");
         if (inj.nmats) {
             void* tmp;
             ZK_TRY(ctx_reserve(ctx, S_TMP, cnt * 32, &tmp));
@@ -724,7 +724,7 @@ int zkhip_poseidon2_permute(zkhip_ctx* ctx, uint32_t* d_states, size_t count) {
 }
 
 static int make_descs(const uint32_t* const* d_mats, const size_t* lds, const uint32_t* widths, int nmats, MatDesc* out) {
-    if (nmats < 1 || nmats > MAX_LEAF_MATS || !d_mats || !lds || !widths) return fail(ZKHIP_ERR_INVALID, "1..4 matrices required");
+    if (nmats < 1 || nmats > MAX_LEAF_MATS || !d_mats || !lds || !widths) return fail(ZKHIP_ERR_INVALID, "1..8 matrices required");
     for (int m = 0; m < nmats; m++) {
         if (!d_mats[m] || lds[m] < widths[m]) return fail(ZKHIP_ERR_INVALID, "bad matrix descriptor");
         out[m].ptr = d_mats[m]; out[m].ld = lds[m]; out[m].width = widths[m];

@@ -93,7 +93,7 @@ struct MatDesc {
     uint64_t ld;       // row pitch in elements
     uint32_t width;
 };
-constexpr int MAX_LEAF_MATS = 4;
+constexpr int MAX_LEAF_MATS = 8;
 // levels / heights up to this many nodes use the 16-lanes-per-permutation kernels (latency-bound regime)
 constexpr uint32_t COOP_MAX_NODES = 16384;
 // the single-workgroup kernel finishes a tree from this many nodes down to the root

@@ -1608,7 +1608,7 @@ int zkhip_verify_shard_air(const uint32_t* program, size_t program_words, const 
 // index with chip c opened at index >> (Hmax - h_c).  Byte layout: DESIGN.md section 6.
 namespace zk {
 constexpr uint32_t CHIPS_VERSION = 4u, CHIPS_VERSION_LOGUP = 5u, CHIPS_VERSION_CROSS = 6u, CHIPS_VERSION_AIR = 9u, CHIPS_VERSION_MACHINE = 10u;
-constexpr int MAX_CHIPS = 16;
+constexpr int MAX_CHIPS = 32;
 
 // The constraint programs in effect for the running zkhip_*_chips_air call on this thread (nullptr: every chip uses the built-in
 // synthetic AIR).  Version 9: each chip's header entry gains a has-program flag, the programs' digests follow the entries.
@@ -1622,7 +1622,7 @@ struct ChipAirScope {
 // Machine mode (zkhip_*_machine, proof version 10): every chip runs through a program (its own, or the synthetic AIR written as one:
 // has_prog says which, for the header) and may bring an interaction table (air.h, LookupView).  The number of extension columns of
 // its permutation trace travels in the `pairs` slot of the chip arrays, so the layout code of versions 5 / 6 serves unchanged.
-struct MachineTables { const LookupView* lk[16]; bool has_prog[16]; };
+struct MachineTables { const LookupView* lk[32]; bool has_prog[32]; };
 static thread_local const MachineTables* t_machine = nullptr;
 static const LookupView* lookup_of(int c) { return t_machine ? t_machine->lk[c] : nullptr; }
 static bool header_has_prog(int c) { return t_machine ? t_machine->has_prog[c] : prog_of(c) != nullptr; }
@@ -1650,7 +1650,7 @@ static uint32_t chips_version(const int32_t* pairs, const int32_t* partners, int
 }
 static int check_chips(const int32_t* log_ns, const uint32_t* widths, const int32_t* pairs, const int32_t* partners, int n, const zkhip_params* prm) {
     if (!prm || !log_ns || !widths) return fail(ZKHIP_ERR_INVALID, "chips: null argument");
-    if (n < 1 || n > MAX_CHIPS) return fail(ZKHIP_ERR_INVALID, "chips: 1..16 chips");
+    if (n < 1 || n > MAX_CHIPS) return fail(ZKHIP_ERR_INVALID, "chips: 1..32 chips");
     if (prm->log_blowup < 1 || prm->log_blowup > 3) return fail(ZKHIP_ERR_INVALID, "chips: log_blowup in [1,3]");
     if ((prm->log_fold != 0 && prm->log_fold != 1) || prm->log_final != 0 || (prm->hash_width != 0 && prm->hash_width != 16) || prm->logup_pairs != 0 || prm->code_width != 0)
         return fail(ZKHIP_ERR_INVALID, "chips: the multi-chip prover uses the SP1 FRI shape (fold by 2, constant final polynomial, width-16 hash) without lookups");
@@ -1668,7 +1668,7 @@ static int check_chips(const int32_t* log_ns, const uint32_t* widths, const int3
         } else if (partners && partners[c] < -1) return fail(ZKHIP_ERR_INVALID, "chips: bad partner index");
         int same = 0;
         for (int d = 0; d < n; d++) same += log_ns[d] == log_ns[c];
-        if (same > MAX_LEAF_MATS) return fail(ZKHIP_ERR_INVALID, "chips: at most 4 chips per height");
+        if (same > MAX_LEAF_MATS) return fail(ZKHIP_ERR_INVALID, "chips: at most 8 chips per height");
     }
     return ZKHIP_OK;
 }
@@ -1739,7 +1739,7 @@ int zkhip_prove_chips(zkhip_ctx* ctx, const zkhip_chip* chips, int n, const uint
     CHECK_CTX(ctx);
     if (!chips || !proof || !len || (n_public && !public_values)) return fail(ZKHIP_ERR_INVALID, "prove_chips: bad arguments");
     int32_t log_ns[MAX_CHIPS], pairs[MAX_CHIPS], partners[MAX_CHIPS]; uint32_t widths[MAX_CHIPS];
-    if (n < 1 || n > MAX_CHIPS) return fail(ZKHIP_ERR_INVALID, "chips: 1..16 chips");
+    if (n < 1 || n > MAX_CHIPS) return fail(ZKHIP_ERR_INVALID, "chips: 1..32 chips");
     for (int c = 0; c < n; c++) {
         log_ns[c] = chips[c].log_n; widths[c] = chips[c].width; pairs[c] = chips[c].logup_pairs; partners[c] = chips[c].partner;
         if (!chips[c].d_trace || chips[c].ld < chips[c].width) return fail(ZKHIP_ERR_INVALID, "prove_chips: bad chip descriptor");
@@ -2050,7 +2050,7 @@ static bool verify_mixed(const uint32_t* root_m, int Hmax, size_t index, const u
 }
 
 // sixteen openings of one mixed-height tree at once (as verify_paths_x16): rows[j][c] = the row of chip c in query j
-static uint32_t verify_mixed_x16(const uint32_t* root_m, int Hmax, int count, const size_t* index, const uint32_t* const (*rows)[16],
+static uint32_t verify_mixed_x16(const uint32_t* root_m, int Hmax, int count, const size_t* index, const uint32_t* const (*rows)[32],
                                  const uint32_t* widths, const int* lh, int n, const uint32_t* const* paths) {
     uint32_t failed = 0;
     if (!p2x16_available()) {
@@ -2269,7 +2269,7 @@ int zkhip_verify_chips(const uint8_t* proof, size_t len, const int32_t* log_ns, 
     std::vector<int> qcode(NQ_, 0);
     auto check_group = [&](int g) -> int {
         const int q0 = 16 * g, cnt = NQ_ - q0 < 16 ? NQ_ - q0 : 16;
-        const uint32_t *trow[16][16], *qrow[16][16], *prow[16][16], *prow_all[16][MAX_CHIPS];
+        const uint32_t *trow[16][MAX_CHIPS], *qrow[16][MAX_CHIPS], *prow[16][MAX_CHIPS], *prow_all[16][MAX_CHIPS];
         const uint32_t *tpath[16], *ppath[16], *qpath[16];
         size_t qpos[16], index[16], pindex[16];
         int code[16] = {0};
