@@ -127,3 +127,33 @@ def test_a_machine_of_thirty_tables(ctx, oracle):
     i = lns.index(7)
     with pytest.raises(ZkHipError):
         ctx.prove_machine(chips[:i] + [(ctx.from_numpy(t9), 7, 4)] + chips[i:], progs[:i] + [None] + progs[i:], tables[:i] + [None] + tables[i:], pub, Params(1, 8, 4))
+
+
+def test_sha256_machine_at_2_18_rows_bytes_equal_the_oracles(ctx, oracle):
+    """the SHA-256 chip (2^18 rows x 608) + its 2^16-row range table, both generated / counted on the device: bytes against the oracle
+    proving the downloaded tables on all host cores"""
+    import hashlib
+    import os
+    import sha256_air as S
+    from zktls_amd.device import sha256_air, sha256_pad
+    O = oracle
+    V = O.air_var
+    prev = min(8, os.cpu_count() or 1)
+    O.set_threads(min(os.cpu_count() or 1, 96))
+    try:
+        msg = np.random.default_rng(8).integers(0, 256, (256 << 10) - 9, dtype=np.uint8).tobytes()
+        d_sha, limbs = ctx.sha256_gen_trace(sha256_pad(msg))
+        pub = limbs.tolist()
+        assert S.digest_bytes(pub) == hashlib.sha256(msg).digest()
+        sent = [S.OUT + 6, S.OUT + 7, S.OUT + 14, S.OUT + 15]
+        d_table = ctx.range_table(d_sha, 608, 1 << 18, sent, 16)
+        sha_tab = O.interaction_table([(O.SEND, None, 16, [c]) for c in sent])
+        table_prog = O.air_program(4, 16, [(O.SEL_FIRST, [(1, [V(0)])]), (O.SEL_TRANSITION, [(1, [V(0, True)]), (O.P - 1, [V(0)]), (O.P - 1, [])])])
+        table_tab = O.interaction_table([(O.RECEIVE, 1, 16, [0])])
+        progs, tables = [sha256_air(), table_prog], [sha_tab, table_tab]
+        proof = ctx.prove_machine([(d_sha, 18, 608), (d_table, 16, 4)], progs, tables, pub, Params(1, 16, 4))
+        host = [d_sha.download().reshape(-1, 608), d_table.download().reshape(-1, 4)]
+        assert proof.tobytes() == O.prove_machine(host, progs, tables, pub, O.default_params(1, 16, 4)).tobytes()
+        assert verify_machine(proof, [18, 16], [608, 4], progs, tables, pub, Params(1, 16, 4)) == (0, 0)
+    finally:
+        O.set_threads(prev)

@@ -82,3 +82,41 @@ def test_sixty_four_transcripts_in_one_call(ctx):
     for i, p in enumerate(proofs):
         assert verify_sha256(p, digests[i], prm) == (0, 0)
     assert verify_sha256(proofs[3], digests[4], prm)[0] == -6
+
+
+def test_a_64_kib_message_bytes_equal_the_oracles(ctx, oracle):
+    """2^10 blocks -> 2^16 rows x 608 columns: the program kernel, the LDE and the openings at a size where every kernel runs many
+    workgroups; the oracle proves the same trace on all host cores"""
+    import os
+    O = oracle
+    prev = min(8, os.cpu_count() or 1)
+    O.set_threads(min(os.cpu_count() or 1, 96))
+    try:
+        msg = np.random.default_rng(3).integers(0, 256, (64 << 10) - 9, dtype=np.uint8).tobytes()
+        digest, proof = ctx.prove_sha256(msg, Params(1, 30, 8))
+        assert digest == hashlib.sha256(msg).digest()
+        t, pub = S.trace(S.pad(msg))
+        assert proof.tobytes() == O.prove_shard_air(S.program(), t, pub, O.default_params(1, 30, 8)).tobytes()
+    finally:
+        O.set_threads(prev)
+
+
+@pytest.mark.parametrize("kib", [256, 1024])
+def test_large_messages_bytes_equal_the_oracles(ctx, oracle, kib):
+    """2^18 and 2^20 rows x 608 (the chip at the headline height): the oracle proves the trace the DEVICE generated (its cells are checked against the restatement at the
+    smaller sizes above; the pure-Python generator would take minutes here)"""
+    import os
+    from zktls_amd.device import sha256_pad
+    O = oracle
+    prev = min(8, os.cpu_count() or 1)
+    O.set_threads(min(os.cpu_count() or 1, 96))
+    try:
+        msg = np.random.default_rng(4).integers(0, 256, (kib << 10) - 9, dtype=np.uint8).tobytes()
+        digest, proof = ctx.prove_sha256(msg, Params(1, 20, 4))
+        assert digest == hashlib.sha256(msg).digest()
+        d, limbs = ctx.sha256_gen_trace(sha256_pad(msg))
+        t = d.download().reshape(-1, S.WIDTH)
+        d.free()
+        assert proof.tobytes() == O.prove_shard_air(S.program(), t, limbs.tolist(), O.default_params(1, 20, 4)).tobytes()
+    finally:
+        O.set_threads(prev)
