@@ -13,6 +13,13 @@
  *   zkhip_prove_chips / zkhip_verify_chips
  *       the same span for a shard made of several chips of different heights, as sp1-stark's ShardProof is
  *       (reference Cargo.lock:6172): one mixed-height commitment per phase, one FRI proof.
+ *   zkhip_prove_shard_air, zkhip_prove_chips_air, zkhip_prove_machine (+ their verifiers)
+ *       the same span with the AIR supplied as DATA: a constraint program per table (what p3-air `Air::eval` bodies state,
+ *       Cargo.lock:3835), several tables of different heights in one proof, and the tables' lookups as interaction tables
+ *       (sp1-stark's permutation argument, Cargo.lock:6172) -- the structure of an SP1 shard proof without its chips.
+ *   zkhip_prove_sha256 / zkhip_verify_sha256, zkhip_sha256_gen_trace, zkhip_range_table
+ *       one real chip on that path -- SHA-256 compression, the hash of the transcripts the guest checks (upstream: the
+ *       ShaExtend / ShaCompress chips of sp1-core-machine, Cargo.lock:5822) -- with its trace generated on the device.
  *   zkhip_prove_segment
  *       the span crates/guest-prover-r0/src/prover.rs:88-93 times, from RISC Zero's column-major Hal layout.
  *   zkhip_prove_shard_host, zkhip_prove_shards, zkhip_prove_shards_multi, zkhip_commit
