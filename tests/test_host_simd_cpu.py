@@ -62,3 +62,14 @@ def test_same_verdicts_with_and_without_the_batched_form(oracle):
             arr = np.frombuffer(bytes(bad), dtype=np.uint8)
             a, b = verdicts(lambda: check(arr))
             assert a == b and a[0] == -6, (name, off, a, b)
+
+
+def test_malformed_input_fuzzer_runs():
+    """tools/fuzz_host.py (normally run under the sanitizer build, tools/asan_cpu.sh) for two seconds against the shipped library:
+    no crash, and the tool itself stays runnable"""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "fuzz_host.py"), "2"], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "fuzz ok" in r.stdout, r.stdout + r.stderr
