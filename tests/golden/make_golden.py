@@ -107,6 +107,18 @@ def main():
         lk[name] = {"chips": [list(c) for c in chips], "params": list(prm), "public": [3, 4],
                     "bytes": int(pf.size), "sha256": hashlib.sha256(pf.tobytes()).hexdigest()}
     out["chip_lookup_proofs"] = lk
+    # machines: tables with their own constraint programs that look each other up (tests/machines.py); proof versions 9 and 10
+    import machines
+    mach = {}
+    for name, (args, prm) in {"range_5_6": (("range", 5, 6, 1), (1, 8, 4)), "range_6_8_blowup4": (("range", 6, 8, 2), (2, 6, 0)),
+                              "random_3": (("random", 3), (1, 5, 3)), "random_7": (("random", 7), (3, 4, 2))}.items():
+        tr, pg, tb, pub = machines.range_machine(*args[1:]) if args[0] == "range" else machines.random_machine(args[1])
+        params = O.default_params(*prm)
+        pf = O.prove_machine(tr, pg, tb, pub, params)
+        lns, ws = [t.shape[0].bit_length() - 1 for t in tr], [t.shape[1] for t in tr]
+        assert O.verify_machine(pf, lns, ws, pg, tb, pub, params) == 0
+        mach[name] = {"machine": list(args), "params": list(prm), "bytes": int(pf.size), "sha256": hashlib.sha256(pf.tobytes()).hexdigest()}
+    out["machine_proofs"] = mach
     # complete proof BYTES of small shards, one per proof version (tests/golden/proofs/*.bin): what the independent pure-Python
     # verifier (tests/pyverify.py, written from DESIGN.md sections 3 and 6) and the product's host verifier check on the CPU, and
     # what the HIP prover must reproduce byte for byte on the GPU.  shape = (log_blowup, queries, pow_bits, logup_pairs,

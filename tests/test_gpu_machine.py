@@ -157,3 +157,21 @@ def test_sha256_machine_at_2_18_rows_bytes_equal_the_oracles(ctx, oracle):
         assert verify_machine(proof, [18, 16], [608, 4], progs, tables, pub, Params(1, 16, 4)) == (0, 0)
     finally:
         O.set_threads(prev)
+
+
+import hashlib
+import json
+import os
+
+KAT = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "oracle_kat.json")))
+
+
+@pytest.mark.parametrize("name", sorted(KAT["machine_proofs"]))
+def test_golden_machine_proofs_on_gpu(ctx, name):
+    """the committed machine proofs (sizes and SHA-256 of the bytes) reproduced by the HIP prover without the oracle in the loop"""
+    g = KAT["machine_proofs"][name]
+    a = g["machine"]
+    tr, pg, tb, pub = M.range_machine(*a[1:]) if a[0] == "range" else M.random_machine(a[1])
+    lns, ws = shape_of(tr)
+    proof = ctx.prove_machine([(ctx.from_numpy(t), ln, w) for t, ln, w in zip(tr, lns, ws)], pg, tb, pub, Params(*g["params"]))
+    assert proof.size == g["bytes"] and hashlib.sha256(proof.tobytes()).hexdigest() == g["sha256"]

@@ -116,3 +116,24 @@ def test_random_machines_under_three_verifiers(oracle, seed):
     mcol = int(tables[c][4])
     bad[c][0, mcol] = (int(bad[c][0, mcol]) + 1) % P
     assert verify_machine(O.prove_machine(bad, progs, tables, pub, O.default_params(*shape)), lns, ws, progs, tables, pub, Params(*shape)) == (-6, 11)
+
+
+import hashlib
+import json
+import os
+
+KAT = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "oracle_kat.json")))
+
+
+def golden_machine(g):
+    a = g["machine"]
+    return M.range_machine(*a[1:]) if a[0] == "range" else M.random_machine(a[1])
+
+
+@pytest.mark.parametrize("name", sorted(KAT["machine_proofs"]))
+def test_golden_machine_proofs(oracle, name):
+    """the oracle still produces the committed machine proofs (tests/golden/make_golden.py)"""
+    g = KAT["machine_proofs"][name]
+    tr, pg, tb, pub = golden_machine(g)
+    pf = oracle.prove_machine(tr, pg, tb, pub, oracle.default_params(*g["params"]))
+    assert pf.size == g["bytes"] and hashlib.sha256(pf.tobytes()).hexdigest() == g["sha256"]
