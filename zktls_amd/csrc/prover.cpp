@@ -1851,7 +1851,10 @@ int zkhip_prove_chips(zkhip_ctx* ctx, const zkhip_chip* chips, int n, const uint
         LogupIn lu;
         if (wp[c]) { lu.pairs = (uint32_t)pairs[c]; lu.perm_lde = plde + pl_off[c]; lu.gamma = gamma; lu.beta = beta_l; lu.cumsum = cumsum[c]; }
         const bool own_coset_direct = b == 1;             // as in the single-matrix prover
-        if (t_machine && lookup_of(c)) {
+        if (t_machine && !lookup_of(c) && !header_has_prog(c)) {
+            // a synthetic table without lookups inside a machine: the specialised kernel (same values as its program form, bit for bit)
+            ZK_TRY(run_quotient(ctx, tlde + tl_off[c], widths[c], log_ns[c], widths[c], alpha, lu, qchunk, own_coset_direct ? qlde + ql_off[c] : nullptr, 8));
+        } else if (t_machine && lookup_of(c)) {
             // the chip's lookup constraints fold after its program's: the program's weights move up by alpha^(cols + 3)
             const LookupView& lv = *lookup_of(c);
             void* v_add;

@@ -401,7 +401,12 @@ hipError_t launch_quotient_air(const QuotientAirArgs& a, hipStream_t s) {
     const uint32_t stride = 2 * a.width + AIR_SLOT_EXTRA + ((a.n_public + 3u) & ~3u);     // a multiple of 4 words: 16-byte row copies
     const size_t lds_rows = (size_t)PTS * stride * 4, lds_red = (size_t)PTS * 4 * 257 * 4;
     const size_t lds = lds_rows > lds_red ? lds_rows : lds_red;
-    if (a.recs && (a.n_terms & 1u) == 0 && lds <= 72 * 1024 && m >= (uint64_t)PTS && stride < 8192) {
+    // Small programs over rows of at most 16 columns keep the row-per-lane interpreter: a whole row sits in one cache line, its gathers
+    // are cheap, and the term-parallel kernel's fixed cost per group of 8 points (staging, two barriers, the 256-way reduction) would be
+    // all of its time -- 0.35 ms per 2^19 points whatever the program, against 13 - 37 us (tools/airq_time.py).  From 32 columns on the
+    // strided gathers lose (0.56 ms at 32 columns, 2.0 ms at 64, against 0.37 / 0.39 ms).
+    const bool small = a.n_terms <= 512 && a.width <= 16;
+    if (a.recs && !small && (a.n_terms & 1u) == 0 && lds <= 72 * 1024 && m >= (uint64_t)PTS && stride < 8192) {
         static std::atomic<size_t> configured[64] = {};
         int dev = 0;
         if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return hipErrorInvalidDevice;
