@@ -395,6 +395,89 @@ __global__ void __launch_bounds__(256) quotient_air_terms_kernel(QuotientAirArgs
         if (a.lde_out) st_ext(a.lde_out + (uint64_t)p * a.lde_ld + 4u * chunk, r);
     }
 }
+// The same for programs over rows of moderate width: ONE wavefront per group of 8 points.  The 256-lane form pays a fixed price per
+// group -- two workgroup barriers and a 256-way reduction of 32 values through 33 KB of LDS, four workgroups per CU -- that is all
+// of its time for programs of a few hundred terms (0.35 ms per 2^19 points); with one wavefront the reduction is 64-way through 8 KB,
+// the barriers are wave-local, and twenty groups share a CU.  Used while the 8 points' slots fit 16 KB of LDS.
+__global__ void __launch_bounds__(64) quotient_air_terms_wave_kernel(QuotientAirArgs a, uint32_t stride) {
+    constexpr int PTS = 8;
+    extern __shared__ uint32_t slots[];
+    const int H = a.log_n + a.log_qd;
+    const uint32_t m = 1u << H, nq = 1u << a.log_qd, W = a.width;
+    const uint32_t p0 = blockIdx.x * PTS, tid = threadIdx.x;
+    {
+        const uint32_t q = tid & 7u, p = p0 + q;
+        const uint32_t e = __brev(p) >> (32 - H);
+        const uint32_t pn = __brev((e + nq) & (m - 1)) >> (32 - H);
+        const uint32_t* lrow = a.lde + (uint64_t)p * a.ld;
+        const uint32_t* nrow = a.lde + (uint64_t)pn * a.ld;
+        for (uint32_t c = tid >> 3; c < W; c += 8) {
+            slots[8 * c + q] = lrow[c];
+            slots[8 * (W + c) + q] = nrow[c];
+        }
+        if (tid < 8) {
+            uint32_t* ex = slots + 8 * (size_t)(2 * W);
+            ex[q] = a.sel_first[p]; ex[8 + q] = a.sel_last[p]; ex[16 + q] = dsub(a.xs[p], a.wn_inv); ex[24 + q] = MONTY_R1;
+        }
+        for (uint32_t i = tid >> 3; i < a.n_public; i += 8) slots[8 * (size_t)(2 * W + AIR_SLOT_EXTRA + i) + q] = a.pub[i];
+    }
+    __syncthreads();
+    uint64_t acc[PTS][4];
+#pragma unroll
+    for (int q = 0; q < PTS; q++)
+#pragma unroll
+        for (int i = 0; i < 4; i++) acc[q][i] = 0;
+    const uint4* recs = reinterpret_cast<const uint4*>(a.recs);
+    auto load8 = [&](uint32_t o, uint32_t (&v)[PTS]) {
+        const uint4* s4 = reinterpret_cast<const uint4*>(slots + 8 * (size_t)o);
+        const uint4 lo = s4[0], hi = s4[1];
+        v[0] = lo.x; v[1] = lo.y; v[2] = lo.z; v[3] = lo.w; v[4] = hi.x; v[5] = hi.y; v[6] = hi.z; v[7] = hi.w;
+    };
+    auto product = [&](const uint4& o, uint32_t (&prod)[PTS]) {
+        const uint32_t n = o.z >> 16;
+        uint32_t v[PTS];
+        load8(o.x & 0xFFFFu, prod);
+        const uint32_t offs[4] = {o.x >> 16, o.y & 0xFFFFu, o.y >> 16, o.z & 0xFFFFu};
+        for (uint32_t k = 1; k < n; k++) {
+            load8(offs[k - 1], v);
+#pragma unroll
+            for (int q = 0; q < PTS; q++) prod[q] = dmul(prod[q], v[q]);
+        }
+    };
+    for (uint32_t t = 2 * tid; t < a.n_terms; t += 128) {
+        const uint4 ca = recs[2 * (size_t)t], oa = recs[2 * (size_t)t + 1], cb = recs[2 * (size_t)t + 2], ob = recs[2 * (size_t)t + 3];
+        uint32_t pa[PTS], pb[PTS];
+        product(oa, pa);
+        product(ob, pb);
+#pragma unroll
+        for (int q = 0; q < PTS; q++) {
+            dacc2(acc[q][0], ca.x, pa[q], cb.x, pb[q]); dacc2(acc[q][1], ca.y, pa[q], cb.y, pb[q]);
+            dacc2(acc[q][2], ca.z, pa[q], cb.z, pb[q]); dacc2(acc[q][3], ca.w, pa[q], cb.w, pb[q]);
+        }
+    }
+    __syncthreads();                                   // the slots are dead: 32 values x 64 partials, row pitch 65 words
+#pragma unroll
+    for (int q = 0; q < PTS; q++)
+#pragma unroll
+        for (int i = 0; i < 4; i++) slots[(size_t)(q * 4 + i) * 65 + tid] = dacc_finish(acc[q][i]);
+    __syncthreads();
+    uint32_t sum = 0;
+    if (tid < 32) for (uint32_t i = 0; i < 64; i++) sum = dadd(sum, slots[(size_t)tid * 65 + i]);
+    __syncthreads();
+    if (tid < 32) slots[tid] = sum;
+    __syncthreads();
+    if (tid < (uint32_t)PTS) {
+        const uint32_t p = p0 + tid;
+        const uint32_t e = __brev(p) >> (32 - H);
+        Ext r = Ext{{slots[4 * tid], slots[4 * tid + 1], slots[4 * tid + 2], slots[4 * tid + 3]}};
+        if (a.addend) r = ext_add(r, ld_ext(a.addend + 4 * (uint64_t)p));
+        const uint32_t chunk = e & (nq - 1u);
+        const uint32_t iz = chunk == 0 ? a.inv_zh[0] : (chunk == 1 ? a.inv_zh[1] : (chunk == 2 ? a.inv_zh[2] : a.inv_zh[3]));
+        r = ext_mul_base_dev(r, iz);
+        st_ext(a.out + ((uint64_t)chunk * (m >> a.log_qd) + (e >> a.log_qd)) * 4, r);
+        if (a.lde_out) st_ext(a.lde_out + (uint64_t)p * a.lde_ld + 4u * chunk, r);
+    }
+}
 hipError_t launch_quotient_air(const QuotientAirArgs& a, hipStream_t s) {
     const uint64_t m = 1ull << (a.log_n + a.log_qd);
     constexpr int PTS = 8;
@@ -406,6 +489,11 @@ hipError_t launch_quotient_air(const QuotientAirArgs& a, hipStream_t s) {
     // all of its time -- 0.35 ms per 2^19 points whatever the program, against 13 - 37 us (tools/airq_time.py).  From 32 columns on the
     // strided gathers lose (0.56 ms at 32 columns, 2.0 ms at 64, against 0.37 / 0.39 ms).
     const bool small = a.n_terms <= 512 && a.width <= 16;
+    if (a.recs && !small && (a.n_terms & 1u) == 0 && m >= (uint64_t)PTS && lds_rows <= 16 * 1024) {
+        const size_t wl = lds_rows > 32 * 65 * 4 ? lds_rows : 32 * 65 * 4;
+        hipLaunchKernelGGL(quotient_air_terms_wave_kernel, dim3((unsigned)(m / PTS)), dim3(64), wl, s, a, stride);
+        return hipGetLastError();
+    }
     if (a.recs && !small && (a.n_terms & 1u) == 0 && lds <= 72 * 1024 && m >= (uint64_t)PTS && stride < 8192) {
         static std::atomic<size_t> configured[64] = {};
         int dev = 0;
