@@ -462,6 +462,33 @@ int zkhip_verify_machine(const uint8_t* proof, size_t len, const int32_t* log_ns
                          const size_t* program_words, const uint32_t* const* tables, const size_t* table_words, int n_chips,
                          const uint32_t* public_values, size_t n_public, const zkhip_params* prm, int* reason);
 
+/* The keyed machine: setup, then prove.  The reference calls `client.setup(guest_program) -> (pk, vk)` before every prove
+ * (crates/guest-prover-sp1/src/sp1.rs:113) and hands vk to verify (:120); in sp1-stark (StarkMachine::setup, reference Cargo.lock:6172)
+ * setup generates the chips' PREPROCESSED traces -- program ROM, byte-operation tables: columns fixed by the program, not by the
+ * execution -- and commits them once: the commitment is the verifying key's, the traces and their LDEs the proving key's.
+ * zkhip_machine_setup does that on the device: pre[c] describes chip c's preprocessed trace (d_trace, ld, log_n, width = preprocessed
+ * width, a multiple of 4; width 0: the chip has none; logup_pairs / partner unused), chips tallest first as in the machine.  The key
+ * keeps device copies of the traces, their LDEs and the mixed-height tree until zkhip_machine_key_destroy; root[8] (canonical words)
+ * is what a verifier needs.  A key belongs to the context it was made with.
+ * In a keyed machine a chip's program and interaction table address the COMBINED row [preprocessed | main] (program width =
+ * preprocessed + main width); a chip with preprocessed columns brings its own program.  Proof version 11 = version 10 with header
+ * entries (log_n, width, has_program, interactions, pre_width), the key's root after the digests (observed before the trace
+ * commitment), every chip's openings preceded by its preprocessed columns at zeta and zeta g, every query preceded by the
+ * preprocessed rows and their path in the key's tree.  Verifier reject 33: a preprocessed row does not open the key's root. */
+typedef struct zkhip_machine_key zkhip_machine_key;
+int zkhip_machine_setup(zkhip_ctx* ctx, const zkhip_chip* pre, int n_chips, const zkhip_params* prm, zkhip_machine_key** key, uint32_t root[8]);
+void zkhip_machine_key_destroy(zkhip_machine_key* key);
+size_t zkhip_machine_proof_size_keyed(const int32_t* log_ns, const uint32_t* widths, const uint32_t* pre_widths, const uint32_t* const* programs,
+                                      const size_t* program_words, const uint32_t* const* tables, const size_t* table_words, int n_chips,
+                                      const zkhip_params* prm, size_t n_public);
+int zkhip_prove_machine_keyed(zkhip_ctx* ctx, const zkhip_machine_key* key, const zkhip_chip* chips, const uint32_t* const* programs,
+                              const size_t* program_words, const uint32_t* const* tables, const size_t* table_words, int n_chips,
+                              const uint32_t* public_values, size_t n_public, const zkhip_params* prm, uint8_t* proof, size_t cap, size_t* len);
+int zkhip_verify_machine_keyed(const uint8_t* proof, size_t len, const int32_t* log_ns, const uint32_t* widths, const uint32_t* pre_widths,
+                               const uint32_t root[8], const uint32_t* const* programs, const size_t* program_words, const uint32_t* const* tables,
+                               const size_t* table_words, int n_chips, const uint32_t* public_values, size_t n_public, const zkhip_params* prm,
+                               int* reason);
+
 /* ---- Poseidon2 parameter tables from a file: the built-in sets are this repo's own
  * ("zktls-amd/p2-bb16-v1", "...-bb24-v1"; the SP1 / RISC Zero tables of reference Cargo.lock:4030, 6172, 5057 are not
  * obtainable offline).  zkhip_load_poseidon2_params replaces the width-16 or the width-24 set (the file says which) for the

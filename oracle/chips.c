@@ -62,6 +62,20 @@ static _Thread_local const uint32_t* const* g_tables = NULL;
 static _Thread_local const size_t* g_table_words = NULL;
 static _Thread_local int g_machine = 0;
 static const uint32_t* table_of(int c) { return g_tables ? g_tables[c] : NULL; }
+/* ---- keyed machine (orc_*_machine_keyed): PREPROCESSED columns.  sp1-stark's setup (StarkMachine::setup, called by the reference at
+ * crates/guest-prover-sp1/src/sp1.rs:113) commits the chips' preprocessed traces -- program ROM, byte-operation tables -- once; the
+ * root is the verifying key's commitment, and every proof opens those columns beside the main ones.  Here: chip c has pre_widths[c]
+ * preprocessed columns (0: none; a chip that has some brings its own program).  Programs and interaction tables address the
+ * COMBINED row [preprocessed | main].  The preprocessed LDEs of all chips form one mixed-height tree (the key); its root is observed
+ * right after the header.  Proof version 11: header entry (log_n, width, has_program, interactions, pre_width), digests as in 10, then
+ * the key's root; every chip's openings start with its preprocessed columns at zeta and zeta g; every query starts with the
+ * preprocessed rows and their path.  In a height's reduced opening a chip contributes pre@zeta, pre@zeta g, then as before. ---- */
+#define CHIPS_VERSION_KEYED 11u
+static _Thread_local const size_t* g_pre_widths = NULL;
+static _Thread_local const uint32_t* const* g_pre_traces = NULL;     /* prover only */
+static _Thread_local const uint32_t* g_pre_root = NULL;              /* 8 canonical words */
+static int keyed(void) { return g_pre_widths != NULL; }
+static size_t pre_w(int c) { return g_pre_widths ? g_pre_widths[c] : 0; }
 static int table_parse(const uint32_t* t, size_t words, size_t width, inter_t* out, int* n_out) {
     if (!t || words < 3 || t[0] != LKUP_MAGIC || t[1] < 1 || t[1] > 64 || t[2] != words) return 0;
     size_t p = 3;
@@ -145,7 +159,7 @@ static int any_cross(const int* partners, int n) {
     return 0;
 }
 static uint32_t chips_version(const int* pairs, const int* partners, int n) {
-    if (g_machine) return CHIPS_VERSION_MACHINE;
+    if (g_machine) return keyed() ? CHIPS_VERSION_KEYED : CHIPS_VERSION_MACHINE;
     if (any_prog(n)) return CHIPS_VERSION_AIR;
     return any_cross(partners, n) ? CHIPS_VERSION_CROSS : (any_pairs(pairs, n) ? CHIPS_VERSION_LOGUP : CHIPS_VERSION);
 }
@@ -164,6 +178,15 @@ static int chips_ok(const int* log_ns, const size_t* widths, const int* pairs, c
             if (!pairs || d >= n || d == c || partners[d] != c || pairs[c] == 0 || pairs[d] != pairs[c] || log_ns[d] != log_ns[c]) return 0;
         } else if (partners && partners[c] < -1) return 0;
     }
+    if (keyed()) {
+        int some = 0;
+        for (int c = 0; c < n; c++) {
+            const size_t pw = pre_w(c);
+            if (pw % 4 != 0 || pw + widths[c] > 1024 || (pw && !prog_of(c))) return 0;
+            if (pw) some = 1;
+        }
+        if (!some) return 0;
+    }
     for (int c = 0; c < n; c++) {                                  /* at most 8 chips share a height (one leaf hash) */
         int same = 0;
         for (int d = 0; d < n; d++) if (log_ns[d] == log_ns[c]) same++;
@@ -179,17 +202,18 @@ size_t orc_chips_proof_size(const int* log_ns, const size_t* widths, const int* 
     size_t b = (size_t)prm->log_blowup, Hmax = (size_t)log_ns[0] + b, L = (size_t)log_ns[0];
     size_t words = 8 + (cross ? 4 : (lk ? 3 : 2)) * (size_t)n + 16 + (lk ? 8 : 0) + 8 * L + 4 + 1;
     if (g_machine) {
-        words = 8 + 4 * (size_t)n + 16 + (lk ? 8 : 0) + 8 * L + 4 + 1;
+        words = 8 + (keyed() ? 5 : 4) * (size_t)n + 16 + (lk ? 8 : 0) + 8 * L + 4 + 1 + (keyed() ? 8 : 0);
         for (int c = 0; c < n; c++) words += (prog_of(c) ? 8 : 0) + (table_of(c) ? 8 : 0);
     } else if (any_prog(n)) { words += (size_t)n; for (int c = 0; c < n; c++) if (prog_of(c)) words += 8; }
-    size_t perq = 16 * Hmax, hp = 0;
+    size_t perq = 16 * Hmax, hp = 0, he = 0;
     for (int c = 0; c < n; c++) {
         size_t wp = (pairs && pairs[c]) ? 4 * ((size_t)pairs[c] + 1) : 0;
-        words += 8 * widths[c] + 8 * wp + 32 + ((cross && wp) ? 4 : 0);      /* + the chip's cumulative sum */
-        perq += widths[c] + wp + 8;
+        words += 8 * widths[c] + 8 * wp + 32 + ((cross && wp) ? 4 : 0) + 8 * pre_w(c);      /* + the chip's cumulative sum */
+        perq += widths[c] + wp + 8 + pre_w(c);
         if (wp && (size_t)log_ns[c] + b > hp) hp = (size_t)log_ns[c] + b;
+        if (pre_w(c) && (size_t)log_ns[c] + b > he) he = (size_t)log_ns[c] + b;
     }
-    perq += 8 * hp;                                    /* path of the permutation tree */
+    perq += 8 * hp + 8 * he;                           /* paths of the permutation tree and of the key's tree */
     for (size_t l = 0; l < L; l++) perq += 4 + 8 * (Hmax - 1 - l);
     return (words + (size_t)prm->num_queries * perq) * 4;
 }
@@ -205,7 +229,11 @@ static void transcript_init(orc_challenger_t* ch, const int* log_ns, const size_
     orc_chal_observe(ch, (uint32_t)n_public);
     for (int c = 0; c < n; c++) {
         orc_chal_observe(ch, (uint32_t)log_ns[c]); orc_chal_observe(ch, (uint32_t)widths[c]);
-        if (g_machine) { orc_chal_observe(ch, prog_of(c) ? 1u : 0u); orc_chal_observe(ch, table_of(c) ? table_of(c)[1] : 0u); continue; }
+        if (g_machine) {
+            orc_chal_observe(ch, prog_of(c) ? 1u : 0u); orc_chal_observe(ch, table_of(c) ? table_of(c)[1] : 0u);
+            if (keyed()) orc_chal_observe(ch, (uint32_t)pre_w(c));
+            continue;
+        }
         if (lk) orc_chal_observe(ch, (uint32_t)pairs[c]);
         if (cross) orc_chal_observe(ch, (uint32_t)(partners[c] + 1));
         if (any_prog(n)) orc_chal_observe(ch, prog_of(c) ? 1u : 0u);
@@ -222,6 +250,7 @@ static void transcript_init(orc_challenger_t* ch, const int* log_ns, const size_
             orc_air_digest(table_of(c), g_table_words[c], dg);          /* the same sponge over 16-bit halves */
             orc_chal_observe_slice(ch, dg, 8);
         }
+    if (keyed()) orc_chal_observe_slice(ch, g_pre_root, 8);
 }
 
 /* alpha-power offset of chip c inside the reduced-opening vector of its height: the chips of one height share one power
@@ -229,7 +258,7 @@ static void transcript_init(orc_challenger_t* ch, const int* log_ns, const size_
 static size_t perm_width(const int* pairs, int c) { return (pairs && pairs[c]) ? 4 * ((size_t)pairs[c] + 1) : 0; }
 static size_t height_offset(const int* log_ns, const size_t* widths, const int* pairs, int c) {
     size_t off = 0;
-    for (int d = 0; d < c; d++) if (log_ns[d] == log_ns[c]) off += 2 * widths[d] + 2 * perm_width(pairs, d) + 8;
+    for (int d = 0; d < c; d++) if (log_ns[d] == log_ns[c]) off += 2 * pre_w(d) + 2 * widths[d] + 2 * perm_width(pairs, d) + 8;
     return off;
 }
 
@@ -281,17 +310,42 @@ size_t orc_prove_chips(const uint32_t* const* traces, const int* log_ns, const s
     uint32_t* pf = (uint32_t*)proof_bytes;
     size_t pos = 0;
     const int b = prm->log_blowup, Hmax = log_ns[0] + b, L = log_ns[0], lk = any_pairs(pairs, n), cross = any_cross(partners, n);
+    /* 0. keyed machine: the preprocessed LDEs and their tree (what setup computes once), combined traces [pre | main] */
+    uint32_t* elde[MAX_CHIPS]; uint32_t* ctrace[MAX_CHIPS]; uint32_t* clde[MAX_CHIPS];
+    uint32_t* etree = NULL; uint32_t eroot[8];
+    const uint32_t* em[MAX_CHIPS]; size_t ew[MAX_CHIPS]; int elh[MAX_CHIPS]; int ne = 0, He = 0;
+    for (int c = 0; c < n; c++) { elde[c] = NULL; ctrace[c] = NULL; clde[c] = NULL; }
+    if (keyed()) {
+        for (int c = 0; c < n; c++) {
+            const size_t pw = pre_w(c), W = widths[c], nc = (size_t)1 << log_ns[c];
+            if (!pw) continue;
+            elde[c] = (uint32_t*)malloc(((size_t)1 << (log_ns[c] + b)) * pw * 4);
+            orc_coset_lde(g_pre_traces[c], elde[c], log_ns[c], pw, b, BB_GEN);
+            em[ne] = elde[c]; ew[ne] = pw; elh[ne] = log_ns[c] + b; ne++;
+            if (log_ns[c] + b > He) He = log_ns[c] + b;
+            ctrace[c] = (uint32_t*)malloc(nc * (pw + W) * 4);
+            for (size_t i = 0; i < nc; i++) {
+                memcpy(ctrace[c] + i * (pw + W), g_pre_traces[c] + i * pw, pw * 4);
+                memcpy(ctrace[c] + i * (pw + W) + pw, traces[c] + i * W, W * 4);
+            }
+        }
+        etree = (uint32_t*)malloc((2 * ((size_t)1 << He) - 1) * 32);
+        orc_merkle_tree_mixed(em, ew, elh, ne, etree);
+        memcpy(eroot, etree + (2 * ((size_t)1 << He) - 2) * 8, 32);
+        g_pre_root = eroot;
+    }
     pf[pos++] = CHIPS_MAGIC; pf[pos++] = chips_version(pairs, partners, n); pf[pos++] = (uint32_t)n; pf[pos++] = (uint32_t)b;
     pf[pos++] = (uint32_t)prm->num_queries; pf[pos++] = (uint32_t)prm->pow_bits; pf[pos++] = (uint32_t)n_public; pf[pos++] = 16u;
     for (int c = 0; c < n; c++) {
         pf[pos++] = (uint32_t)log_ns[c]; pf[pos++] = (uint32_t)widths[c];
-        if (g_machine) { pf[pos++] = prog_of(c) ? 1u : 0u; pf[pos++] = table_of(c) ? table_of(c)[1] : 0u; continue; }
+        if (g_machine) { pf[pos++] = prog_of(c) ? 1u : 0u; pf[pos++] = table_of(c) ? table_of(c)[1] : 0u; if (keyed()) pf[pos++] = (uint32_t)pre_w(c); continue; }
         if (lk) pf[pos++] = (uint32_t)pairs[c];
         if (cross) pf[pos++] = (uint32_t)(partners[c] + 1);
         if (any_prog(n)) pf[pos++] = prog_of(c) ? 1u : 0u;
     }
     for (int c = 0; c < n; c++) if (prog_of(c)) { orc_air_digest(prog_of(c), g_prog_words[c], pf + pos); pos += 8; }
     for (int c = 0; c < n; c++) if (table_of(c)) { orc_air_digest(table_of(c), g_table_words[c], pf + pos); pos += 8; }
+    if (keyed()) { memcpy(pf + pos, eroot, 32); pos += 8; }
     orc_challenger_t ch;
     transcript_init(&ch, log_ns, widths, pairs, partners, n, prm, n_public);
     bb4_t cumsum[MAX_CHIPS];
@@ -304,6 +358,14 @@ size_t orc_prove_chips(const uint32_t* const* traces, const int* log_ns, const s
         lh[c] = log_ns[c] + b; w8[c] = 8; wp[c] = perm_width(pairs, c); plde[c] = NULL;
         tlde[c] = (uint32_t*)malloc(((size_t)1 << lh[c]) * widths[c] * 4);
         orc_coset_lde(traces[c], tlde[c], log_ns[c], widths[c], b, BB_GEN);
+        if (elde[c]) {                                 /* what the chip's program and interactions read: [pre | main] rows of the LDE */
+            const size_t pw = pre_w(c), W = widths[c], mc = (size_t)1 << lh[c];
+            clde[c] = (uint32_t*)malloc(mc * (pw + W) * 4);
+            for (size_t i = 0; i < mc; i++) {
+                memcpy(clde[c] + i * (pw + W), elde[c] + i * pw, pw * 4);
+                memcpy(clde[c] + i * (pw + W) + pw, tlde[c] + i * W, W * 4);
+            }
+        }
     }
     const size_t mmax = (size_t)1 << Hmax;
     uint32_t* ttree = (uint32_t*)malloc((2 * mmax - 1) * 32);
@@ -326,8 +388,8 @@ size_t orc_prove_chips(const uint32_t* const* traces, const int* log_ns, const s
             uint32_t* perm = (uint32_t*)malloc(nc * wp[c] * 4);
             if (g_machine) {
                 inter_t its[64]; int ni = 0;
-                table_parse(table_of(c), g_table_words[c], widths[c], its, &ni);
-                perm_trace_machine(traces[c], log_ns[c], widths[c], its, ni, gamma, beta_l, perm);
+                table_parse(table_of(c), g_table_words[c], pre_w(c) + widths[c], its, &ni);
+                perm_trace_machine(ctrace[c] ? ctrace[c] : traces[c], log_ns[c], pre_w(c) + widths[c], its, ni, gamma, beta_l, perm);
             } else orc_perm_trace(traces[c], log_ns[c], widths[c], pairs[c], gamma.c, beta_l.c, perm);
             if (cross) cumsum[c] = ld4(perm + (nc - 1) * wp[c] + 4 * (size_t)pairs[c]);       /* the running sum's last value */
             plde[c] = (uint32_t*)malloc(mc * wp[c] * 4);
@@ -352,7 +414,7 @@ size_t orc_prove_chips(const uint32_t* const* traces, const int* log_ns, const s
         const int ln = log_ns[c], Hq = ln + 1;
         const size_t nc = (size_t)1 << ln, mc = (size_t)1 << lh[c], mq = (size_t)1 << Hq;
         uint32_t* qv = (uint32_t*)malloc(mq * 16);
-        if (g_machine) quotient_values_machine(c, tlde[c], ln, widths[c], plde[c], gamma, beta_l, alpha, cumsum[c], public_values, n_public, qv);
+        if (g_machine) quotient_values_machine(c, clde[c] ? clde[c] : tlde[c], ln, pre_w(c) + widths[c], plde[c], gamma, beta_l, alpha, cumsum[c], public_values, n_public, qv);
         else if (prog_of(c)) orc_quotient_values_air(prog_of(c), tlde[c], ln, widths[c], public_values, alpha.c, 1, qv);
         else orc_quotient_values_logup_c(tlde[c], ln, widths[c], plde[c], wp[c] ? pairs[c] : 0, gamma.c, beta_l.c, alpha.c, cumsum[c].c, qv);
         qlde[c] = (uint32_t*)malloc(mc * 8 * 4);
@@ -374,13 +436,18 @@ size_t orc_prove_chips(const uint32_t* const* traces, const int* log_ns, const s
 
     /* 3. openings: one zeta for every chip, "next" point zeta * g_c; per chip: trace local | next | [perm local | next] | quotient */
     bb4_t zeta = sample_ext(&ch);
-    uint32_t* op[MAX_CHIPS];
+    uint32_t* op[MAX_CHIPS]; uint32_t* opre[MAX_CHIPS];      /* op[c]: the chip's main openings; opre[c]: its preprocessed ones, just before */
     size_t oplen[MAX_CHIPS];
     for (int c = 0; c < n; c++) {
-        const size_t W = widths[c];
-        oplen[c] = 8 * W + 8 * wp[c] + 32;
-        op[c] = pf + pos; pos += oplen[c];
+        const size_t W = widths[c], pw = pre_w(c);
+        oplen[c] = 8 * pw + 8 * W + 8 * wp[c] + 32;
         bb4_t zn = bb4_mul_base(zeta, bb_two_adic_generator(log_ns[c]));
+        if (pw) {
+            orc_open_at(elde[c], log_ns[c], pw, zeta.c, pf + pos);
+            orc_open_at(elde[c], log_ns[c], pw, zn.c, pf + pos + 4 * pw);
+        }
+        opre[c] = pf + pos;
+        op[c] = pf + pos + 8 * pw; pos += oplen[c];
         orc_open_at(tlde[c], log_ns[c], W, zeta.c, op[c]);
         orc_open_at(tlde[c], log_ns[c], W, zn.c, op[c] + 4 * W);
         if (wp[c]) {
@@ -389,17 +456,18 @@ size_t orc_prove_chips(const uint32_t* const* traces, const int* log_ns, const s
         }
         orc_open_at(qlde[c], log_ns[c], 8, zeta.c, op[c] + 8 * W + 8 * wp[c]);
     }
-    for (int c = 0; c < n; c++) orc_chal_observe_slice(&ch, op[c], oplen[c]);
+    for (int c = 0; c < n; c++) orc_chal_observe_slice(&ch, opre[c], oplen[c]);
 
     /* 4. one reduced-opening vector per height; per chip the batching order is
-     * trace@zeta 0, trace@zeta*g W, [perm@zeta 2W, perm@zeta*g 2W+Wp], quotient@zeta 2W+2Wp */
+     * [pre@zeta, pre@zeta*g (2 Pw powers)], trace@zeta 0, trace@zeta*g W, [perm@zeta 2W, perm@zeta*g 2W+Wp], quotient@zeta 2W+2Wp */
     bb4_t fa = sample_ext(&ch);
     bb4_t* ro[32];
     for (int h = 0; h < 32; h++) ro[h] = NULL;
     for (int c = 0; c < n; c++) {
-        const size_t W = widths[c], Wp = wp[c], mc = (size_t)1 << lh[c];
+        const size_t W = widths[c], Wp = wp[c], mc = (size_t)1 << lh[c], Pw = pre_w(c);
         size_t npw = W > 8 ? W : 8;
         if (Wp > npw) npw = Wp;
+        if (Pw > npw) npw = Pw;
         bb4_t* fapow = (bb4_t*)malloc(npw * sizeof(bb4_t));
         fapow[0] = bb4_one();
         for (size_t j = 1; j < npw; j++) fapow[j] = bb4_mul(fapow[j - 1], fa);
@@ -414,7 +482,13 @@ size_t orc_prove_chips(const uint32_t* const* traces, const int* log_ns, const s
             y_pn = bb4_add(y_pn, bb4_mul(fapow[j], ld4(o_pn + 4 * j)));
         }
         for (size_t j = 0; j < 8; j++) y_q = bb4_add(y_q, bb4_mul(fapow[j], ld4(o_q + 4 * j)));
-        const size_t off = height_offset(log_ns, widths, pairs, c);
+        bb4_t y_el = bb4_zero(), y_en = bb4_zero();
+        for (size_t j = 0; j < Pw; j++) {
+            y_el = bb4_add(y_el, bb4_mul(fapow[j], ld4(opre[c] + 4 * j)));
+            y_en = bb4_add(y_en, bb4_mul(fapow[j], ld4(opre[c] + 4 * Pw + 4 * j)));
+        }
+        const size_t off0 = height_offset(log_ns, widths, pairs, c), off = off0 + 2 * Pw;
+        bb4_t s_el = bb4_pow(fa, off0), s_en = bb4_pow(fa, off0 + Pw);
         bb4_t s_loc = bb4_pow(fa, off), s_nxt = bb4_pow(fa, off + W), s_pl = bb4_pow(fa, off + 2 * W), s_pn = bb4_pow(fa, off + 2 * W + Wp),
               s_q = bb4_pow(fa, off + 2 * W + 2 * Wp);
         bb4_t zn = bb4_mul_base(zeta, bb_two_adic_generator(log_ns[c]));
@@ -435,6 +509,11 @@ size_t orc_prove_chips(const uint32_t* const* traces, const int* log_ns, const s
                 r = bb4_add(r, bb4_mul(s_pn, bb4_mul(bb4_sub(ap, y_pn), d2)));
             }
             r = bb4_add(r, bb4_mul(s_q, bb4_mul(bb4_sub(aq, y_q), d1)));
+            if (Pw) {
+                bb4_t ae = orc__row_dot(fapow, elde[c] + p * Pw, Pw);
+                r = bb4_add(r, bb4_mul(s_el, bb4_mul(bb4_sub(ae, y_el), d1)));
+                r = bb4_add(r, bb4_mul(s_en, bb4_mul(bb4_sub(ae, y_en), d2)));
+            }
             dst[p] = bb4_add(dst[p], r);
         }
         free(fapow);
@@ -475,6 +554,10 @@ size_t orc_prove_chips(const uint32_t* const* traces, const int* log_ns, const s
     pf[pos++] = witness;
     for (int q = 0; q < prm->num_queries; q++) {
         size_t index = orc_chal_sample_bits(&ch, Hmax);
+        if (keyed()) {
+            for (int c = 0; c < n; c++) if (elde[c]) { memcpy(pf + pos, elde[c] + (index >> (Hmax - lh[c])) * pre_w(c), pre_w(c) * 4); pos += pre_w(c); }
+            orc__copy_path(pf, &pos, etree, (size_t)1 << He, index >> (Hmax - He), He);
+        }
         for (int c = 0; c < n; c++) { memcpy(pf + pos, tlde[c] + (index >> (Hmax - lh[c])) * widths[c], widths[c] * 4); pos += widths[c]; }
         orc__copy_path(pf, &pos, ttree, mmax, index, Hmax);
         if (lk) {
@@ -493,7 +576,9 @@ size_t orc_prove_chips(const uint32_t* const* traces, const int* log_ns, const s
     }
     for (int l = 0; l < L; l++) { free(layers[l]); free(ltrees[l]); }
     free(layers); free(ltrees); free(ttree); free(qtree); free(ptree);
-    for (int c = 0; c < n; c++) { free(tlde[c]); free(qlde[c]); free(plde[c]); }
+    for (int c = 0; c < n; c++) { free(tlde[c]); free(qlde[c]); free(plde[c]); free(elde[c]); free(ctrace[c]); free(clde[c]); }
+    free(etree);
+    if (keyed()) g_pre_root = NULL;
     for (int h = 0; h < 32; h++) free(ro[h]);
     if (!const_ok) return 0;
     return pos * 4 == need ? need : 0;
@@ -534,7 +619,12 @@ int orc_verify_chips(const uint8_t* proof_bytes, size_t len, const int* log_ns, 
     for (int c = 0; c < n; c++) {
         if (pf[pos] != (uint32_t)log_ns[c] || pf[pos + 1] != (uint32_t)widths[c]) return 3;
         pos += 2;
-        if (g_machine) { if (pf[pos] != (prog_of(c) ? 1u : 0u) || pf[pos + 1] != (table_of(c) ? table_of(c)[1] : 0u)) return 3; pos += 2; continue; }
+        if (g_machine) {
+            if (pf[pos] != (prog_of(c) ? 1u : 0u) || pf[pos + 1] != (table_of(c) ? table_of(c)[1] : 0u)) return 3;
+            pos += 2;
+            if (keyed()) { if (pf[pos] != (uint32_t)pre_w(c)) return 3; pos++; }
+            continue;
+        }
         if (lk) { if (pf[pos] != (uint32_t)pairs[c]) return 3; pos++; }
         if (cross) { if (pf[pos] != (uint32_t)(partners[c] + 1)) return 3; pos++; }
         if (any_prog(n)) { if (pf[pos] != (prog_of(c) ? 1u : 0u)) return 3; pos++; }
@@ -553,6 +643,7 @@ int orc_verify_chips(const uint8_t* proof_bytes, size_t len, const int* log_ns, 
             if (memcmp(pf + pos, dg, 32) != 0) return 3;
             pos += 8;
         }
+    if (keyed()) { if (memcmp(pf + pos, g_pre_root, 32) != 0) return 3; pos += 8; }       /* a proof under another key */
     for (size_t i = pos; i < len / 4; i++) if (pf[i] >= BB_P) return 4;
     int lh[MAX_CHIPS]; size_t w8[MAX_CHIPS], wp[MAX_CHIPS];
     for (int c = 0; c < n; c++) { lh[c] = log_ns[c] + b; w8[c] = 8; wp[c] = perm_width(pairs, c); }
@@ -583,16 +674,19 @@ int orc_verify_chips(const uint8_t* proof_bytes, size_t len, const int* log_ns, 
     const uint32_t* qroot = pf + pos; pos += 8;
     orc_chal_observe_slice(&ch, qroot, 8);
     bb4_t zeta = sample_ext(&ch);
-    const uint32_t* op[MAX_CHIPS]; size_t oplen[MAX_CHIPS];
-    for (int c = 0; c < n; c++) { oplen[c] = 8 * widths[c] + 8 * wp[c] + 32; op[c] = pf + pos; pos += oplen[c]; }
-    for (int c = 0; c < n; c++) orc_chal_observe_slice(&ch, op[c], oplen[c]);
+    const uint32_t* op[MAX_CHIPS]; const uint32_t* opre[MAX_CHIPS]; size_t oplen[MAX_CHIPS];
+    for (int c = 0; c < n; c++) { oplen[c] = 8 * pre_w(c) + 8 * widths[c] + 8 * wp[c] + 32; opre[c] = pf + pos; op[c] = pf + pos + 8 * pre_w(c); pos += oplen[c]; }
+    for (int c = 0; c < n; c++) orc_chal_observe_slice(&ch, opre[c], oplen[c]);
+    size_t ew[MAX_CHIPS]; int elh[MAX_CHIPS], echip[MAX_CHIPS]; int ne = 0, He = 0;
+    for (int c = 0; c < n; c++) if (pre_w(c)) { ew[ne] = pre_w(c); elh[ne] = log_ns[c] + b; echip[ne] = c; ne++; if (log_ns[c] + b > He) He = log_ns[c] + b; }
 
     /* (a) every chip's AIR identity at zeta */
     for (int c = 0; c < n; c++) {
-        const size_t W = widths[c], Wp = wp[c], nc = (size_t)1 << log_ns[c];
-        bb4_t* loc = (bb4_t*)malloc(W * sizeof(bb4_t));
+        const size_t W0 = widths[c], Pw = pre_w(c), W = Pw + W0, Wp = wp[c], nc = (size_t)1 << log_ns[c];
+        bb4_t* loc = (bb4_t*)malloc(W * sizeof(bb4_t));          /* the combined row [pre | main] at zeta, and at zeta g */
         bb4_t* nxt = (bb4_t*)malloc(W * sizeof(bb4_t));
-        for (size_t j = 0; j < W; j++) { loc[j] = ld4(op[c] + 4 * j); nxt[j] = ld4(op[c] + 4 * W + 4 * j); }
+        for (size_t j = 0; j < Pw; j++) { loc[j] = ld4(opre[c] + 4 * j); nxt[j] = ld4(opre[c] + 4 * Pw + 4 * j); }
+        for (size_t j = 0; j < W0; j++) { loc[Pw + j] = ld4(op[c] + 4 * j); nxt[Pw + j] = ld4(op[c] + 4 * W0 + 4 * j); }
         bb_t gn = bb_two_adic_generator(log_ns[c]);
         bb4_t zn = bb4_pow(zeta, nc), zh = bb4_sub_base(zn, 1);
         bb4_t sel_first = bb4_mul(zh, bb4_inv(bb4_sub_base(zeta, 1)));
@@ -606,14 +700,14 @@ int orc_verify_chips(const uint8_t* proof_bytes, size_t len, const int* log_ns, 
             const size_t cols = ((size_t)ni + 1) / 2;
             bb4_t sel_last = bb4_mul(zh, bb4_inv(bb4_sub_base(zeta, bb_inv(gn))));
             bb4_t pl[33], pn[33];
-            const uint32_t *o_pl = op[c] + 8 * W, *o_pn = o_pl + 4 * Wp;
+            const uint32_t *o_pl = op[c] + 8 * W0, *o_pn = o_pl + 4 * Wp;
             for (size_t q = 0; q <= cols; q++) { pl[q] = orc__recombine(o_pl + 16 * q); pn[q] = orc__recombine(o_pn + 16 * q); }
             folded = fold_interactions(folded, its, ni, loc, pl, pn, gamma, beta_l, sel_first, sel_trans, sel_last, alpha, cumsum[c]);
         } else if (Wp) {
             const int Q = pairs[c];
             bb4_t sel_last = bb4_mul(zh, bb4_inv(bb4_sub_base(zeta, bb_inv(gn))));
             bb4_t as[64], bs[64], ar[64], br[64], pl[65], pn[65];
-            const uint32_t *o_pl = op[c] + 8 * W, *o_pn = o_pl + 4 * Wp;
+            const uint32_t *o_pl = op[c] + 8 * W0, *o_pn = o_pl + 4 * Wp;
             for (int q = 0; q < Q; q++) { as[q] = loc[8 * q]; bs[q] = loc[8 * q + 1]; ar[q] = loc[8 * q + 4]; br[q] = loc[8 * q + 5]; }
             for (int q = 0; q <= Q; q++) { pl[q] = orc__recombine(o_pl + 16 * q); pn[q] = orc__recombine(o_pn + 16 * q); }
             folded = orc__fold_logup(folded, Q, as, bs, ar, br, pl, pn, gamma, beta_l, sel_first, sel_trans, sel_last, alpha, cumsum[c]);
@@ -622,7 +716,7 @@ int orc_verify_chips(const uint8_t* proof_bytes, size_t len, const int* log_ns, 
         bb_t w2n = bb_two_adic_generator(log_ns[c] + 1);
         bb_t s[2] = {BB_GEN, bb_mul(BB_GEN, w2n)};
         bb4_t quot = bb4_zero();
-        const uint32_t* o_q = op[c] + 8 * W + 8 * Wp;
+        const uint32_t* o_q = op[c] + 8 * W0 + 8 * Wp;
         for (int k = 0; k < 2; k++) {
             int j = 1 - k;
             bb_t sjn_inv = bb_inv(bb_pow(s[j], nc));
@@ -636,14 +730,20 @@ int orc_verify_chips(const uint8_t* proof_bytes, size_t len, const int* log_ns, 
     /* (b) FRI */
     bb4_t fa = sample_ext(&ch);
     size_t npmax = 8;
-    for (int c = 0; c < n; c++) { if (widths[c] > npmax) npmax = widths[c]; if (wp[c] > npmax) npmax = wp[c]; }
+    for (int c = 0; c < n; c++) { if (widths[c] > npmax) npmax = widths[c]; if (wp[c] > npmax) npmax = wp[c]; if (pre_w(c) > npmax) npmax = pre_w(c); }
     bb4_t* fapow = (bb4_t*)malloc(npmax * sizeof(bb4_t));
     fapow[0] = bb4_one();
     for (size_t j = 1; j < npmax; j++) fapow[j] = bb4_mul(fapow[j - 1], fa);
     bb4_t y_loc[MAX_CHIPS], y_nxt[MAX_CHIPS], y_pl[MAX_CHIPS], y_pn[MAX_CHIPS], y_q[MAX_CHIPS];
     bb4_t s_loc[MAX_CHIPS], s_nxt[MAX_CHIPS], s_pl[MAX_CHIPS], s_pn[MAX_CHIPS], s_q[MAX_CHIPS], zn_c[MAX_CHIPS];
+    bb4_t y_el[MAX_CHIPS], y_en[MAX_CHIPS], s_el[MAX_CHIPS], s_en[MAX_CHIPS];
     for (int c = 0; c < n; c++) {
-        const size_t W = widths[c], Wp = wp[c];
+        const size_t W = widths[c], Wp = wp[c], Pw = pre_w(c);
+        y_el[c] = y_en[c] = bb4_zero();
+        for (size_t j = 0; j < Pw; j++) {
+            y_el[c] = bb4_add(y_el[c], bb4_mul(fapow[j], ld4(opre[c] + 4 * j)));
+            y_en[c] = bb4_add(y_en[c], bb4_mul(fapow[j], ld4(opre[c] + 4 * Pw + 4 * j)));
+        }
         const uint32_t *o_pl = op[c] + 8 * W, *o_pn = o_pl + 4 * Wp, *o_q = op[c] + 8 * W + 8 * Wp;
         y_loc[c] = y_nxt[c] = y_pl[c] = y_pn[c] = y_q[c] = bb4_zero();
         for (size_t j = 0; j < W; j++) {
@@ -655,7 +755,8 @@ int orc_verify_chips(const uint8_t* proof_bytes, size_t len, const int* log_ns, 
             y_pn[c] = bb4_add(y_pn[c], bb4_mul(fapow[j], ld4(o_pn + 4 * j)));
         }
         for (size_t j = 0; j < 8; j++) y_q[c] = bb4_add(y_q[c], bb4_mul(fapow[j], ld4(o_q + 4 * j)));
-        const size_t off = height_offset(log_ns, widths, pairs, c);
+        const size_t off0 = height_offset(log_ns, widths, pairs, c), off = off0 + 2 * Pw;
+        s_el[c] = bb4_pow(fa, off0); s_en[c] = bb4_pow(fa, off0 + Pw);
         s_loc[c] = bb4_pow(fa, off); s_nxt[c] = bb4_pow(fa, off + W); s_pl[c] = bb4_pow(fa, off + 2 * W);
         s_pn[c] = bb4_pow(fa, off + 2 * W + Wp); s_q[c] = bb4_pow(fa, off + 2 * W + 2 * Wp);
         zn_c[c] = bb4_mul_base(zeta, bb_two_adic_generator(log_ns[c]));
@@ -671,6 +772,13 @@ int orc_verify_chips(const uint8_t* proof_bytes, size_t len, const int* log_ns, 
     for (int q = 0; q < prm->num_queries && rc == 0; q++) {
         size_t index = orc_chal_sample_bits(&ch, Hmax);
         const uint32_t* trow[MAX_CHIPS]; const uint32_t* qrow[MAX_CHIPS]; const uint32_t* prow[MAX_CHIPS]; const uint32_t* prow_all[MAX_CHIPS];
+        const uint32_t* erow[MAX_CHIPS]; const uint32_t* erow_all[MAX_CHIPS];
+        for (int c = 0; c < n; c++) erow_all[c] = NULL;
+        if (keyed()) {
+            for (int k = 0; k < ne; k++) { erow[k] = pf + pos; erow_all[echip[k]] = erow[k]; pos += ew[k]; }
+            const uint32_t* epath = pf + pos; pos += 8 * (size_t)He;
+            if (verify_mixed(g_pre_root, He, index >> (Hmax - He), erow, ew, elh, ne, epath)) { rc = 33; break; }
+        }
         for (int c = 0; c < n; c++) { trow[c] = pf + pos; pos += widths[c]; prow_all[c] = NULL; }
         const uint32_t* tpath = pf + pos; pos += 8 * (size_t)Hmax;
         const uint32_t* ppath = NULL;
@@ -700,6 +808,11 @@ int orc_verify_chips(const uint8_t* proof_bytes, size_t len, const int* log_ns, 
                 r = bb4_add(r, bb4_mul(s_pn[c], bb4_mul(bb4_sub(ap, y_pn[c]), d2)));
             }
             r = bb4_add(r, bb4_mul(s_q[c], bb4_mul(bb4_sub(aq, y_q[c]), d1)));
+            if (pre_w(c)) {
+                bb4_t ae = orc__row_dot(fapow, erow_all[c], pre_w(c));
+                r = bb4_add(r, bb4_mul(s_el[c], bb4_mul(bb4_sub(ae, y_el[c]), d1)));
+                r = bb4_add(r, bb4_mul(s_en[c], bb4_mul(bb4_sub(ae, y_en[c]), d2)));
+            }
             roh[lh[c]] = bb4_add(roh[lh[c]], r);
         }
         bb4_t folded = roh[Hmax];
@@ -802,5 +915,66 @@ int orc_verify_machine(const uint8_t* proof_bytes, size_t len, const int* log_ns
     MACHINE_ENTER;
     int r = orc_verify_chips(proof_bytes, len, log_ns, widths, cols, NULL, n, public_values, n_public, prm);
     MACHINE_LEAVE;
+    return r;
+}
+
+
+/* ---- the keyed machine: preprocessed columns committed once (setup), proof version 11 ---- */
+int orc_machine_setup(const uint32_t* const* pre_traces, const int* log_ns, const size_t* pre_widths, int n, const orc_params_t* prm, uint32_t root[8]) {
+    if (!pre_traces || !log_ns || !pre_widths || n < 1 || n > MAX_CHIPS || prm->log_blowup < 1 || prm->log_blowup > 3) return 1;
+    const int b = prm->log_blowup;
+    uint32_t* elde[MAX_CHIPS]; const uint32_t* em[MAX_CHIPS]; size_t ew[MAX_CHIPS]; int elh[MAX_CHIPS]; int ne = 0, He = 0;
+    for (int c = 0; c < n; c++) {
+        if (log_ns[c] < 5 || log_ns[c] > 20 || (c && log_ns[c] > log_ns[c - 1]) || pre_widths[c] % 4 != 0 || pre_widths[c] > 1024) return 1;
+        if (!pre_widths[c]) continue;
+        if (!pre_traces[c]) return 1;
+        elde[ne] = (uint32_t*)malloc(((size_t)1 << (log_ns[c] + b)) * pre_widths[c] * 4);
+        orc_coset_lde(pre_traces[c], elde[ne], log_ns[c], pre_widths[c], b, BB_GEN);
+        em[ne] = elde[ne]; ew[ne] = pre_widths[c]; elh[ne] = log_ns[c] + b; ne++;
+        if (log_ns[c] + b > He) He = log_ns[c] + b;
+    }
+    if (!ne) return 1;
+    uint32_t* etree = (uint32_t*)malloc((2 * ((size_t)1 << He) - 1) * 32);
+    orc_merkle_tree_mixed(em, ew, elh, ne, etree);
+    memcpy(root, etree + (2 * ((size_t)1 << He) - 2) * 8, 32);
+    free(etree);
+    for (int k = 0; k < ne; k++) free(elde[k]);
+    return 0;
+}
+static int keyed_ok(const size_t* widths, const size_t* pre_widths, int n, size_t* combined) {
+    if (!pre_widths || n < 1 || n > MAX_CHIPS) return 0;
+    for (int c = 0; c < n; c++) { if (pre_widths[c] > 1024 || widths[c] > 1024) return 0; combined[c] = pre_widths[c] + widths[c]; }
+    return 1;
+}
+#define KEYED_LEAVE MACHINE_LEAVE; g_pre_widths = NULL; g_pre_traces = NULL; g_pre_root = NULL
+size_t orc_machine_proof_size_keyed(const int* log_ns, const size_t* widths, const size_t* pre_widths, const uint32_t* const* progs, const size_t* prog_words,
+                                    const uint32_t* const* tables, const size_t* table_words, int n, const orc_params_t* prm, size_t n_public) {
+    int cols[MAX_CHIPS]; size_t cw[MAX_CHIPS];
+    if (!keyed_ok(widths, pre_widths, n, cw) || !machine_ok(progs, prog_words, tables, table_words, cw, n, n_public, cols)) return 0;
+    MACHINE_ENTER; g_pre_widths = pre_widths;
+    size_t r = orc_chips_proof_size(log_ns, widths, cols, NULL, n, prm, n_public);
+    KEYED_LEAVE;
+    return r;
+}
+size_t orc_prove_machine_keyed(const uint32_t* const* traces, const uint32_t* const* pre_traces, const int* log_ns, const size_t* widths, const size_t* pre_widths,
+                               const uint32_t* const* progs, const size_t* prog_words, const uint32_t* const* tables, const size_t* table_words, int n,
+                               const uint32_t* public_values, size_t n_public, const orc_params_t* prm, uint8_t* proof_bytes, size_t cap) {
+    int cols[MAX_CHIPS]; size_t cw[MAX_CHIPS];
+    if (!pre_traces || !keyed_ok(widths, pre_widths, n, cw) || !machine_ok(progs, prog_words, tables, table_words, cw, n, n_public, cols)) return 0;
+    for (int c = 0; c < n; c++) if (pre_widths[c] && !pre_traces[c]) return 0;
+    MACHINE_ENTER; g_pre_widths = pre_widths; g_pre_traces = pre_traces;
+    size_t r = orc_prove_chips(traces, log_ns, widths, cols, NULL, n, public_values, n_public, prm, proof_bytes, cap);
+    KEYED_LEAVE;
+    return r;
+}
+int orc_verify_machine_keyed(const uint8_t* proof_bytes, size_t len, const int* log_ns, const size_t* widths, const size_t* pre_widths, const uint32_t pre_root[8],
+                             const uint32_t* const* progs, const size_t* prog_words, const uint32_t* const* tables, const size_t* table_words, int n,
+                             const uint32_t* public_values, size_t n_public, const orc_params_t* prm) {
+    int cols[MAX_CHIPS]; size_t cw[MAX_CHIPS];
+    if (!pre_root || !keyed_ok(widths, pre_widths, n, cw) || !machine_ok(progs, prog_words, tables, table_words, cw, n, n_public, cols)) return 1;
+    for (int i = 0; i < 8; i++) if (pre_root[i] >= BB_P) return 1;
+    MACHINE_ENTER; g_pre_widths = pre_widths; g_pre_root = pre_root;
+    int r = orc_verify_chips(proof_bytes, len, log_ns, widths, cols, NULL, n, public_values, n_public, prm);
+    KEYED_LEAVE;
     return r;
 }

@@ -183,6 +183,18 @@ size_t orc_prove_machine(const uint32_t* const* traces, const int* log_ns, const
 int orc_verify_machine(const uint8_t* proof, size_t len, const int* log_ns, const size_t* widths, const uint32_t* const* progs,
                        const size_t* prog_words, const uint32_t* const* tables, const size_t* table_words, int n_chips,
                        const uint32_t* public_values, size_t n_public, const orc_params_t* prm);
+/* the keyed machine (proof version 11): chip c has pre_widths[c] PREPROCESSED columns (0: none), committed once by setup -- sp1-stark's
+ * StarkMachine::setup, which the reference calls at crates/guest-prover-sp1/src/sp1.rs:113; the root is the verifying key's commitment.
+ * Programs and interaction tables address the combined row [preprocessed | main].  orc_machine_setup returns 0 and the root. */
+int orc_machine_setup(const uint32_t* const* pre_traces, const int* log_ns, const size_t* pre_widths, int n_chips, const orc_params_t* prm, uint32_t root[8]);
+size_t orc_machine_proof_size_keyed(const int* log_ns, const size_t* widths, const size_t* pre_widths, const uint32_t* const* progs, const size_t* prog_words,
+                                    const uint32_t* const* tables, const size_t* table_words, int n_chips, const orc_params_t* prm, size_t n_public);
+size_t orc_prove_machine_keyed(const uint32_t* const* traces, const uint32_t* const* pre_traces, const int* log_ns, const size_t* widths, const size_t* pre_widths,
+                               const uint32_t* const* progs, const size_t* prog_words, const uint32_t* const* tables, const size_t* table_words, int n_chips,
+                               const uint32_t* public_values, size_t n_public, const orc_params_t* prm, uint8_t* proof, size_t cap);
+int orc_verify_machine_keyed(const uint8_t* proof, size_t len, const int* log_ns, const size_t* widths, const size_t* pre_widths, const uint32_t pre_root[8],
+                             const uint32_t* const* progs, const size_t* prog_words, const uint32_t* const* tables, const size_t* table_words, int n_chips,
+                             const uint32_t* public_values, size_t n_public, const orc_params_t* prm);
 size_t orc_chips_proof_size(const int* log_ns, const size_t* widths, const int* pairs, const int* partners, int n_chips, const orc_params_t* prm, size_t n_public);
 size_t orc_prove_chips(const uint32_t* const* traces, const int* log_ns, const size_t* widths, const int* pairs, const int* partners, int n_chips,
                        const uint32_t* public_values, size_t n_public, const orc_params_t* prm, uint8_t* proof, size_t cap);

@@ -83,3 +83,48 @@ def random_machine(seed):
     progs = [O.air_program(w, 2, [(O.SEL_ALL, [(1, [V(w - 1), V(w - 1)]), (P - 1, [V(w - 1)])])]) for w in widths]
     tables = [O.interaction_table(it) if it else None for it in inter]
     return [t.astype(np.uint32) for t in traces], progs, tables, [int(rng.integers(0, P)), int(rng.integers(0, P))]
+
+
+BUS_BYTE = 21
+
+
+def byte_machine(log_users=7, bits=4, seed=1):
+    """A machine with PREPROCESSED columns, as SP1's byte chip is: (the combined row of a chip is [preprocessed | main])
+         USER   2^log_users rows, no preprocessed columns, main (a, b, x, o): claims x = a XOR b and o = a OR b for `bits`-bit a, b by
+                sending (1, [a, b, x, o]) on the byte bus; its program: x + 2 (a AND b) = a + b with a AND b = a + b - o, i.e.
+                x + 2 (a + b - o) = a + b -- a relation the table's rows satisfy too, so this constraint alone proves nothing new; it is
+                there to have a program next to the lookup;
+         TABLE  2^(2 bits) rows, preprocessed (a, b, a XOR b, a OR b) for every pair, main (m, 0, 0, 0): receives (m, [pre 0..3]);
+                its program: first row's preprocessed a is 0 (a harmless identity: the table's contents are fixed by the KEY, not by
+                constraints).
+       -> (traces, preprocessed traces, programs, tables, public values), tallest first"""
+    rng = np.random.default_rng(seed)
+    nu, nb = 1 << log_users, 1 << bits
+    a, b = rng.integers(0, nb, nu), rng.integers(0, nb, nu)
+    user = np.stack([a, b, a ^ b, a | b], axis=1).astype(np.uint32)
+    user_prog = O.air_program(4, 1, [(O.SEL_ALL, [(1, [V(2)]), (1, [V(0)]), (1, [V(1)]), (P - 2, [V(3)])])])
+    user_tab = O.interaction_table([(O.SEND, None, BUS_BYTE, [0, 1, 2, 3])])
+    aa, bb = np.divmod(np.arange(nb * nb), nb)
+    pre = np.stack([aa, bb, aa ^ bb, aa | bb], axis=1).astype(np.uint32)
+    main = np.zeros((nb * nb, 4), dtype=np.uint32)
+    main[:, 0] = np.bincount(a * nb + b, minlength=nb * nb)
+    table_prog = O.air_program(8, 1, [(O.SEL_FIRST, [(1, [V(0)])])])
+    table_tab = O.interaction_table([(O.RECEIVE, 4, BUS_BYTE, [0, 1, 2, 3])])
+    chips = [(log_users, user, None, user_prog, user_tab), (2 * bits, main, pre, table_prog, table_tab)]
+    chips.sort(key=lambda c: -c[0])
+    return [c[1] for c in chips], [c[2] for c in chips], [c[3] for c in chips], [c[4] for c in chips], [5]
+
+
+def random_keyed_machine(seed):
+    """random_machine(seed) with the leading columns of some tables declared PREPROCESSED: the combined row [pre | main] is the original
+    row, so programs and interaction tables stay as they are.  -> (main traces, preprocessed traces or None, programs, tables, public values)"""
+    traces, progs, tables, pub = random_machine(seed)
+    rng = np.random.default_rng(seed + 77)
+    pre, main = [], []
+    for t in traces:
+        pw = 4 * int(rng.integers(0, t.shape[1] // 4))                       # 0 .. width - 4
+        pre.append(np.ascontiguousarray(t[:, :pw]) if pw else None)
+        main.append(np.ascontiguousarray(t[:, pw:]))
+    if all(p is None for p in pre):
+        pre[0], main[0] = np.ascontiguousarray(traces[0][:, :4]), np.ascontiguousarray(traces[0][:, 4:])
+    return main, pre, progs, tables, pub

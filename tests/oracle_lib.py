@@ -456,6 +456,62 @@ def verify_machine(proof, log_ns, widths, progs, tables, public_values=(), param
                                         _p(pv), C.c_size_t(pv.size), C.byref(params)))
 
 
+def _pre_args(pre_traces, n):
+    """preprocessed traces (None: the chip has none) -> (kept arrays, pointer array, width array)"""
+    keep = [None if t is None else _u32(t) for t in pre_traces]
+    assert len(keep) == n
+    ptrs = (u32p * n)(*[None if t is None else _p(t) for t in keep])
+    widths = (C.c_size_t * n)(*[0 if t is None else t.shape[1] for t in keep])
+    return keep, ptrs, widths
+
+
+def machine_setup(pre_traces, log_ns, params=None):
+    """the keyed machine's setup: commitment to the preprocessed traces (None: the chip has none), tallest chip first -> 8-word root"""
+    params = params or default_params()
+    n = len(pre_traces)
+    keep, ptrs, pws = _pre_args(pre_traces, n)
+    ln = (C.c_int * n)(*[int(x) for x in log_ns])
+    root = np.zeros(8, dtype=np.uint32)
+    if lib().orc_machine_setup(ptrs, ln, pws, C.c_int(n), C.byref(params), _p(root)) != 0:
+        raise RuntimeError("oracle: bad preprocessed traces")
+    return root
+
+
+def prove_machine_keyed(traces, pre_traces, progs, tables, public_values=(), params=None):
+    """a machine whose chips may have preprocessed columns (pre_traces[c], None: none); programs and tables address [pre | main]; version 11"""
+    params = params or default_params()
+    ts, n, log_ns, widths, ptrs, (kp, pp, pw), (kt, tp, tw) = _machine_args(traces, progs, tables)
+    keep, eptrs, pws = _pre_args(pre_traces, n)
+    pv = _u32(np.array(public_values, dtype=np.uint32))
+    L = lib()
+    L.orc_machine_proof_size_keyed.restype = C.c_size_t
+    L.orc_prove_machine_keyed.restype = C.c_size_t
+    size = L.orc_machine_proof_size_keyed(log_ns, widths, pws, pp, pw, tp, tw, C.c_int(n), C.byref(params), C.c_size_t(pv.size))
+    if size == 0:
+        raise RuntimeError("oracle: bad keyed machine")
+    buf = np.empty(size, dtype=np.uint8)
+    got = L.orc_prove_machine_keyed(ptrs, eptrs, log_ns, widths, pws, pp, pw, tp, tw, C.c_int(n), _p(pv), C.c_size_t(pv.size), C.byref(params),
+                                    buf.ctypes.data_as(C.POINTER(C.c_uint8)), C.c_size_t(size))
+    if got != size:
+        raise RuntimeError("oracle prove_machine_keyed failed")
+    return buf
+
+
+def verify_machine_keyed(proof, log_ns, widths, pre_widths, root, progs, tables, public_values=(), params=None):
+    params = params or default_params()
+    pr = np.ascontiguousarray(proof, dtype=np.uint8)
+    n = len(log_ns)
+    ln = (C.c_int * n)(*[int(x) for x in log_ns])
+    ws = (C.c_size_t * n)(*[int(x) for x in widths])
+    pws = (C.c_size_t * n)(*[int(x) for x in pre_widths])
+    rt = _u32(np.array(root, dtype=np.uint32))
+    pv = _u32(np.array(public_values, dtype=np.uint32))
+    kp, pp, pw = _progs_args(progs)
+    kt, tp, tw = _progs_args(tables)
+    return int(lib().orc_verify_machine_keyed(pr.ctypes.data_as(C.POINTER(C.c_uint8)), C.c_size_t(pr.size), ln, ws, pws, _p(rt), pp, pw, tp, tw, C.c_int(n),
+                                              _p(pv), C.c_size_t(pv.size), C.byref(params)))
+
+
 def verify_chips(proof, log_ns, widths, public_values=(), params=None, pairs=None, partners=None):
     params = params or default_params()
     pr = np.ascontiguousarray(proof, dtype=np.uint8)

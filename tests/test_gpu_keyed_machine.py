@@ -1,0 +1,108 @@
+"""The keyed machine on the GPU (proof version 11): zkhip_machine_setup commits the preprocessed traces once, zkhip_prove_machine_keyed
+proves against the key.  Roots and proof bytes against the oracle; the SHA-256 chip with a range table whose values are preprocessed."""
+import numpy as np
+import pytest
+
+import machines as M
+from zktls_amd._lib import Params, ZkHipError
+from zktls_amd.device import verify_machine_keyed
+
+pytestmark = pytest.mark.gpu
+
+
+def shape_of(traces, pre):
+    return ([t.shape[0].bit_length() - 1 for t in traces], [t.shape[1] for t in traces], [0 if p is None else p.shape[1] for p in pre])
+
+
+def on_device(ctx, traces, pre, lns, ws, pws):
+    chips = [(ctx.from_numpy(t), ln, w) for t, ln, w in zip(traces, lns, ws)]
+    pre_chips = [(None if p is None else ctx.from_numpy(p), ln, pw) for p, ln, pw in zip(pre, lns, pws)]
+    return chips, pre_chips
+
+
+@pytest.mark.parametrize("shape", [(1, 6, 4), (2, 5, 0), (3, 4, 2)])
+@pytest.mark.parametrize("size", [(6, 3), (9, 4), (7, 5)])
+def test_byte_machine_bytes_equal_the_oracles(ctx, oracle, shape, size):
+    O = oracle
+    traces, pre, progs, tables, pub = M.byte_machine(*size)
+    lns, ws, pws = shape_of(traces, pre)
+    chips, pre_chips = on_device(ctx, traces, pre, lns, ws, pws)
+    key = ctx.machine_setup(pre_chips, Params(*shape))
+    assert (key.root == O.machine_setup(pre, lns, O.default_params(*shape))).all()
+    proof = ctx.prove_machine_keyed(key, chips, progs, tables, pub, Params(*shape))
+    assert proof.tobytes() == O.prove_machine_keyed(traces, pre, progs, tables, pub, O.default_params(*shape)).tobytes()
+    assert verify_machine_keyed(proof, lns, ws, pws, key.root, progs, tables, pub, Params(*shape)) == (0, 0)
+    # the key serves any number of proofs: another execution against the same table
+    t2, pre2, _, _, _ = M.byte_machine(*size, seed=2)
+    assert all((a is None and b is None) or (a == b).all() for a, b in zip(pre, pre2))
+    chips2, _ = on_device(ctx, t2, pre, lns, ws, pws)
+    proof2 = ctx.prove_machine_keyed(key, chips2, progs, tables, pub, Params(*shape))
+    assert proof2.tobytes() == O.prove_machine_keyed(t2, pre, progs, tables, pub, O.default_params(*shape)).tobytes()
+    key.close()
+
+
+@pytest.mark.parametrize("seed", range(10))
+def test_random_keyed_machines_bytes_equal_the_oracles(ctx, oracle, seed):
+    O = oracle
+    traces, pre, progs, tables, pub = M.random_keyed_machine(300 + seed)
+    lns, ws, pws = shape_of(traces, pre)
+    shape = [(1, 7, 3), (2, 5, 0), (3, 4, 2)][seed % 3]
+    chips, pre_chips = on_device(ctx, traces, pre, lns, ws, pws)
+    key = ctx.machine_setup(pre_chips, Params(*shape))
+    assert (key.root == O.machine_setup(pre, lns, O.default_params(*shape))).all()
+    proof = ctx.prove_machine_keyed(key, chips, progs, tables, pub, Params(*shape))
+    assert proof.tobytes() == O.prove_machine_keyed(traces, pre, progs, tables, pub, O.default_params(*shape)).tobytes()
+    assert verify_machine_keyed(proof, lns, ws, pws, key.root, progs, tables, pub, Params(*shape)) == (0, 0)
+    assert O.verify_machine_keyed(proof, lns, ws, pws, key.root, progs, tables, pub, O.default_params(*shape)) == 0
+
+
+def test_key_and_machine_must_agree(ctx, oracle):
+    traces, pre, progs, tables, pub = M.byte_machine(6, 3)
+    lns, ws, pws = shape_of(traces, pre)
+    chips, pre_chips = on_device(ctx, traces, pre, lns, ws, pws)
+    key = ctx.machine_setup(pre_chips, Params(1, 6, 4))
+    with pytest.raises(ZkHipError):
+        ctx.prove_machine_keyed(key, chips, progs, tables, pub, Params(2, 6, 4))           # another blowup than the key's
+    with pytest.raises(ZkHipError):
+        ctx.prove_machine_keyed(key, chips[:1], progs[:1], tables[:1], pub, Params(1, 6, 4))
+    from zktls_amd import device as D
+    other = D.Context(0)
+    try:
+        with pytest.raises(ZkHipError):
+            other.prove_machine_keyed(key, chips, progs, tables, pub, Params(1, 6, 4))      # a key belongs to its context
+    finally:
+        other.close()
+    with pytest.raises(ZkHipError):
+        ctx.machine_setup([(None, ln, 0) for ln in lns], Params(1, 6, 4))                   # nothing to commit
+
+
+def test_sha256_chip_with_a_preprocessed_range_table(ctx, oracle):
+    """the SHA-256 compression chip sends four 16-bit limbs to a 2^16-row range table whose VALUES are preprocessed (fixed by the key, no
+    counter constraints) and whose multiplicities are main columns; bytes equal the oracle's"""
+    import hashlib
+    import sha256_air as S
+    from zktls_amd.device import sha256_air
+    O = oracle
+    V = O.air_var
+    msg = bytes(range(251)) * 3
+    d_sha, limbs = ctx.sha256_gen_trace(S.pad(msg))
+    sha_pub = limbs.tolist()
+    assert S.digest_bytes(sha_pub) == hashlib.sha256(msg).digest()
+    sent = [S.OUT + 6, S.OUT + 7, S.OUT + 14, S.OUT + 15]
+    sha_tab = O.interaction_table([(O.SEND, None, 16, [c]) for c in sent])
+    values = np.zeros((1 << 16, 4), dtype=np.uint32)
+    values[:, 0] = np.arange(1 << 16)
+    d_counts = ctx.range_table(d_sha, 608, 1 << 10, sent, 16)                 # main columns (v, multiplicity, 0, 0)
+    # combined row of the table: [v 0 0 0 | v m 0 0]; the program: a harmless first-row identity, the key fixes the values
+    table_prog = O.air_program(8, 16, [(O.SEL_FIRST, [(1, [V(0)])])])
+    table_tab = O.interaction_table([(O.RECEIVE, 5, 16, [0])])
+    progs, tables = [table_prog, sha256_air()], [table_tab, sha_tab]
+    prm, oprm = Params(1, 12, 4), O.default_params(1, 12, 4)
+    key = ctx.machine_setup([(ctx.from_numpy(values), 16, 4), (None, 10, 0)], prm)
+    proof = ctx.prove_machine_keyed(key, [(d_counts, 16, 4), (d_sha, 10, 608)], progs, tables, sha_pub, prm)
+    host = [d_counts.download().reshape(-1, 4), d_sha.download().reshape(-1, 608)]
+    assert proof.tobytes() == O.prove_machine_keyed(host, [values, None], progs, tables, sha_pub, oprm).tobytes()
+    assert verify_machine_keyed(proof, [16, 10], [4, 608], [4, 0], key.root, progs, tables, sha_pub, prm) == (0, 0)
+    wrong = list(sha_pub)
+    wrong[0] ^= 1
+    assert verify_machine_keyed(proof, [16, 10], [4, 608], [4, 0], key.root, progs, tables, wrong, prm)[0] == -6

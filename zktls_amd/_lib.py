@@ -33,6 +33,7 @@ EXPORTS = [
     "zkhip_quotient_values_air",
     "zkhip_chips_proof_size_air", "zkhip_prove_chips_air", "zkhip_verify_chips_air",
     "zkhip_prove_shards_air_multi", "zkhip_selftest_host_simd", "zkhip_host_simd", "zkhip_machine_proof_size", "zkhip_prove_machine", "zkhip_verify_machine", "zkhip_range_table",
+    "zkhip_machine_setup", "zkhip_machine_key_destroy", "zkhip_machine_proof_size_keyed", "zkhip_prove_machine_keyed", "zkhip_verify_machine_keyed",
     "zkhip_sha256_air", "zkhip_sha256_digest", "zkhip_sha256_pad", "zkhip_sha256_gen_trace", "zkhip_sha256_proof_size", "zkhip_prove_sha256", "zkhip_verify_sha256",
 ]
 
@@ -165,6 +166,16 @@ def load():
     L.zkhip_prove_machine.argtypes = [C.c_void_p, C.POINTER(Chip), u32pp, szp, u32pp, szp, C.c_int, u32p, C.c_size_t, C.POINTER(Params), u8p, C.c_size_t, szp]
     L.zkhip_verify_machine.argtypes = [u8p, C.c_size_t, C.POINTER(C.c_int32), C.POINTER(C.c_uint32), u32pp, szp, u32pp, szp, C.c_int, u32p, C.c_size_t,
                                        C.POINTER(Params), C.POINTER(C.c_int)]
+    L.zkhip_machine_setup.argtypes = [C.c_void_p, C.POINTER(Chip), C.c_int, C.POINTER(Params), C.POINTER(C.c_void_p), u32p]
+    L.zkhip_machine_key_destroy.restype = None
+    L.zkhip_machine_key_destroy.argtypes = [C.c_void_p]
+    L.zkhip_machine_proof_size_keyed.restype = C.c_size_t
+    L.zkhip_machine_proof_size_keyed.argtypes = [C.POINTER(C.c_int32), C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), u32pp, szp, u32pp, szp, C.c_int,
+                                                 C.POINTER(Params), C.c_size_t]
+    L.zkhip_prove_machine_keyed.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(Chip), u32pp, szp, u32pp, szp, C.c_int, u32p, C.c_size_t, C.POINTER(Params),
+                                            u8p, C.c_size_t, szp]
+    L.zkhip_verify_machine_keyed.argtypes = [u8p, C.c_size_t, C.POINTER(C.c_int32), C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), u32p, u32pp, szp, u32pp, szp,
+                                             C.c_int, u32p, C.c_size_t, C.POINTER(Params), C.POINTER(C.c_int)]
     L.zkhip_sha256_air.restype = C.c_size_t
     L.zkhip_sha256_air.argtypes = [u32p, C.c_size_t]
     L.zkhip_sha256_digest.restype = None

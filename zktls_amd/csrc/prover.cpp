@@ -1607,7 +1607,8 @@ int zkhip_verify_shard_air(const uint32_t* program, size_t program_words, const 
 // vector per height that joins the FRI vector when folding reaches that height (p3-fri 0.2.1 TwoAdicFriPcs), one query
 // index with chip c opened at index >> (Hmax - h_c).  Byte layout: DESIGN.md section 6.
 namespace zk {
-constexpr uint32_t CHIPS_VERSION = 4u, CHIPS_VERSION_LOGUP = 5u, CHIPS_VERSION_CROSS = 6u, CHIPS_VERSION_AIR = 9u, CHIPS_VERSION_MACHINE = 10u;
+constexpr uint32_t CHIPS_VERSION = 4u, CHIPS_VERSION_LOGUP = 5u, CHIPS_VERSION_CROSS = 6u, CHIPS_VERSION_AIR = 9u, CHIPS_VERSION_MACHINE = 10u,
+                   CHIPS_VERSION_KEYED = 11u;
 constexpr int MAX_CHIPS = 32;
 
 // The constraint programs in effect for the running zkhip_*_chips_air call on this thread (nullptr: every chip uses the built-in
@@ -1630,6 +1631,24 @@ struct MachineScope {
     MachineScope(const AirView* const* progs, const MachineTables* m) { t_chip_air = progs; t_machine = m; }
     ~MachineScope() { t_chip_air = nullptr; t_machine = nullptr; }
 };
+// Keyed machine (zkhip_*_machine_keyed, proof version 11): chips with PREPROCESSED columns, committed once by zkhip_machine_setup --
+// sp1-stark's StarkMachine::setup, which the reference calls before every prove (crates/guest-prover-sp1/src/sp1.rs:113).  pw[c] is
+// chip c's preprocessed width (0: none); its program and interaction table address the combined row [preprocessed | main].  The
+// prover side carries the key's device data, the verifier side only the widths and the root.
+struct KeyView {
+    uint32_t pw[32];
+    uint32_t root_m[8];                 // the key's commitment, Montgomery
+    const uint32_t* d_trace[32];        // prover: preprocessed traces [2^log_n][pw], their LDEs [2^(log_n + b)][pw], the mixed-height tree
+    const uint32_t* d_lde[32];
+    const uint32_t* d_tree;
+    int He;                             // height of the tallest preprocessed LDE = height of the key's tree
+};
+static thread_local const KeyView* t_key = nullptr;
+static uint32_t pre_w(int c) { return t_key ? t_key->pw[c] : 0u; }
+struct KeyScope {
+    explicit KeyScope(const KeyView* k) { t_key = k; }
+    ~KeyScope() { t_key = nullptr; }
+};
 static void lookup_digest(const LookupView& v, uint32_t out[8]) {      // the program-digest sponge over the table's words (cached alike)
     AirView a;
     a.w = v.w; a.words = v.words;
@@ -1644,7 +1663,7 @@ static bool any_cross(const int32_t* partners, int n) {
     return false;
 }
 static uint32_t chips_version(const int32_t* pairs, const int32_t* partners, int n) {
-    if (t_machine) return CHIPS_VERSION_MACHINE;
+    if (t_machine) return t_key ? CHIPS_VERSION_KEYED : CHIPS_VERSION_MACHINE;
     if (any_prog(n)) return CHIPS_VERSION_AIR;
     return any_cross(partners, n) ? CHIPS_VERSION_CROSS : (any_pairs(pairs, n) ? CHIPS_VERSION_LOGUP : CHIPS_VERSION);
 }
@@ -1670,6 +1689,16 @@ static int check_chips(const int32_t* log_ns, const uint32_t* widths, const int3
         for (int d = 0; d < n; d++) same += log_ns[d] == log_ns[c];
         if (same > MAX_LEAF_MATS) return fail(ZKHIP_ERR_INVALID, "chips: at most 8 chips per height");
     }
+    if (t_key) {
+        bool some = false;
+        for (int c = 0; c < n; c++) {
+            const uint32_t pw = pre_w(c);
+            if (pw % 4 != 0 || pw + widths[c] > 1024) return fail(ZKHIP_ERR_INVALID, "keyed machine: preprocessed width a multiple of 4, preprocessed + main columns at most 1024");
+            if (pw && !header_has_prog(c)) return fail(ZKHIP_ERR_INVALID, "keyed machine: a chip with preprocessed columns brings its own program");
+            some = some || pw != 0;
+        }
+        if (!some) return fail(ZKHIP_ERR_INVALID, "keyed machine: no chip has preprocessed columns (use the plain machine entries)");
+    }
     return ZKHIP_OK;
 }
 static size_t chips_proof_words(const int32_t* log_ns, const uint32_t* widths, const int32_t* pairs, const int32_t* partners, int n, const zkhip_params* prm) {
@@ -1677,16 +1706,18 @@ static size_t chips_proof_words(const int32_t* log_ns, const uint32_t* widths, c
     const size_t b = (size_t)prm->log_blowup, Hmax = (size_t)log_ns[0] + b, L = (size_t)log_ns[0];
     size_t words = 8 + (cross ? 4 : (lk ? 3 : 2)) * (size_t)n + 16 + (lk ? 8 : 0) + 8 * L + 4 + 1, perq = 16 * Hmax, hp = 0;
     if (t_machine) {
-        words = 8 + 4 * (size_t)n + 16 + (lk ? 8 : 0) + 8 * L + 4 + 1;
+        words = 8 + (t_key ? 5 : 4) * (size_t)n + 16 + (lk ? 8 : 0) + 8 * L + 4 + 1 + (t_key ? 8 : 0);
         for (int c = 0; c < n; c++) words += (header_has_prog(c) ? 8 : 0) + (lookup_of(c) ? 8 : 0);
     } else if (any_prog(n)) { words += (size_t)n; for (int c = 0; c < n; c++) if (prog_of(c)) words += 8; }
+    size_t he = 0;
     for (int c = 0; c < n; c++) {
         const size_t wp = perm_width(pairs, c);
-        words += 8 * (size_t)widths[c] + 8 * wp + 32 + ((cross && wp) ? 4 : 0);
-        perq += widths[c] + wp + 8;
+        words += 8 * (size_t)widths[c] + 8 * wp + 32 + ((cross && wp) ? 4 : 0) + 8 * (size_t)pre_w(c);
+        perq += widths[c] + wp + 8 + pre_w(c);
         if (wp && (size_t)log_ns[c] + b > hp) hp = (size_t)log_ns[c] + b;
+        if (pre_w(c) && (size_t)log_ns[c] + b > he) he = (size_t)log_ns[c] + b;
     }
-    perq += 8 * hp;
+    perq += 8 * hp + 8 * he;
     for (size_t l = 0; l < L; l++) perq += 4 + 8 * (Hmax - 1 - l);
     return words + (size_t)prm->num_queries * perq;
 }
@@ -1701,7 +1732,11 @@ static void chips_transcript_init(Challenger& ch, const int32_t* log_ns, const u
     ch.observe_canonical((uint32_t)n_public);
     for (int c = 0; c < n; c++) {
         ch.observe_canonical((uint32_t)log_ns[c]); ch.observe_canonical(widths[c]);
-        if (t_machine) { ch.observe_canonical(header_has_prog(c) ? 1u : 0u); ch.observe_canonical(lookup_of(c) ? lookup_of(c)->ni : 0u); continue; }
+        if (t_machine) {
+            ch.observe_canonical(header_has_prog(c) ? 1u : 0u); ch.observe_canonical(lookup_of(c) ? lookup_of(c)->ni : 0u);
+            if (t_key) ch.observe_canonical(pre_w(c));
+            continue;
+        }
         if (lk) ch.observe_canonical((uint32_t)pairs[c]);
         if (cross) ch.observe_canonical((uint32_t)(partners[c] + 1));
         if (any_prog(n)) ch.observe_canonical(prog_of(c) ? 1u : 0u);
@@ -1718,11 +1753,12 @@ static void chips_transcript_init(Challenger& ch, const int32_t* log_ns, const u
             lookup_digest(*lookup_of(c), dg);
             for (int i = 0; i < 8; i++) ch.observe_canonical(dg[i]);
         }
+    if (t_key) for (int i = 0; i < 8; i++) ch.observe(t_key->root_m[i]);
 }
 // alpha-power offset of chip c inside the reduced-opening vector of its height
 static uint64_t height_offset(const int32_t* log_ns, const uint32_t* widths, const int32_t* pairs, int c) {
     uint64_t off = 0;
-    for (int d = 0; d < c; d++) if (log_ns[d] == log_ns[c]) off += 2 * (uint64_t)widths[d] + 2 * perm_width(pairs, d) + 8;
+    for (int d = 0; d < c; d++) if (log_ns[d] == log_ns[c]) off += 2 * (uint64_t)pre_w(d) + 2 * (uint64_t)widths[d] + 2 * perm_width(pairs, d) + 8;
     return off;
 }
 }  // namespace zk
@@ -1765,14 +1801,15 @@ int zkhip_prove_chips(zkhip_ctx* ctx, const zkhip_chip* chips, int n, const uint
     for (int c = 0; c < n; c++) {
         lh[c] = log_ns[c] + b;
         const size_t mc = (size_t)1 << lh[c], nc = (size_t)1 << log_ns[c];
-        tl_off[c + 1] = tl_off[c] + mc * widths[c];
+        tl_off[c + 1] = tl_off[c] + mc * (pre_w(c) + widths[c]);     // a keyed chip's LDE rows are [preprocessed | main]
         ql_off[c + 1] = ql_off[c] + mc * 8;
         dv_off[c + 1] = dv_off[c] + 8 * (mc + nc);               // [2][mc] 1/(x - z) then [2][nc] x/(x - z), ext words
         wp[c] = perm_width(pairs, c);
         pl_off[c + 1] = pl_off[c] + mc * wp[c];
-        op_off[c + 1] = op_off[c] + 8 * (size_t)widths[c] + 8 * wp[c] + 32;
+        op_off[c + 1] = op_off[c] + 8 * (size_t)pre_w(c) + 8 * (size_t)widths[c] + 8 * wp[c] + 32;
         size_t npw = widths[c] > 8 ? widths[c] : 8;
         if (wp[c] > npw) npw = wp[c];
+        if (pre_w(c) > npw) npw = pre_w(c);
         ap_off[c + 1] = ap_off[c] + 4 * npw;
         if (nc > nmax_chunk) nmax_chunk = nc;
         if (nc * wp[c] > perm_max) perm_max = nc * wp[c];
@@ -1784,13 +1821,14 @@ int zkhip_prove_chips(zkhip_ctx* ctx, const zkhip_chip* chips, int n, const uint
     pf[pos++] = (uint32_t)Q; pf[pos++] = (uint32_t)prm->pow_bits; pf[pos++] = (uint32_t)n_public; pf[pos++] = 16u;
     for (int c = 0; c < n; c++) {
         pf[pos++] = (uint32_t)log_ns[c]; pf[pos++] = widths[c];
-        if (t_machine) { pf[pos++] = header_has_prog(c) ? 1u : 0u; pf[pos++] = lookup_of(c) ? lookup_of(c)->ni : 0u; continue; }
+        if (t_machine) { pf[pos++] = header_has_prog(c) ? 1u : 0u; pf[pos++] = lookup_of(c) ? lookup_of(c)->ni : 0u; if (t_key) pf[pos++] = pre_w(c); continue; }
         if (lk) pf[pos++] = (uint32_t)pairs[c];
         if (cross) pf[pos++] = (uint32_t)(partners[c] + 1);
         if (any_prog(n)) pf[pos++] = prog_of(c) ? 1u : 0u;
     }
     for (int c = 0; c < n; c++) if (header_has_prog(c)) { air_digest_cached(*prog_of(c), pf + pos); pos += 8; }
     for (int c = 0; c < n; c++) if (lookup_of(c)) { lookup_digest(*lookup_of(c), pf + pos); pos += 8; }
+    if (t_key) for (int i = 0; i < 8; i++) pf[pos++] = from_monty(t_key->root_m[i]);
     Challenger ch;
     chips_transcript_init(ch, log_ns, widths, pairs, partners, n, prm, n_public);
     uint32_t root[8];
@@ -1804,9 +1842,14 @@ int zkhip_prove_chips(zkhip_ctx* ctx, const zkhip_chip* chips, int n, const uint
     ZK_TRY(ctx_reserve(ctx, S_QCHUNK, 2 * nmax_chunk * 16, &v_qchunk));
     uint32_t *tlde = (uint32_t*)v_tlde, *ttree = (uint32_t*)v_ttree, *qlde = (uint32_t*)v_qlde, *qtree = (uint32_t*)v_qtree, *qchunk = (uint32_t*)v_qchunk;
     MatDesc tm[MAX_CHIPS], qm[MAX_CHIPS];
+    size_t cw[MAX_CHIPS];                          // row pitch of a chip's LDE: preprocessed + main columns
     for (int c = 0; c < n; c++) {
-        ZK_TRY(op_coset_lde(ctx, chips[c].d_trace, chips[c].ld, tlde + tl_off[c], widths[c], log_ns[c], widths[c], b, MONTY_GEN));
-        tm[c] = MatDesc{tlde + tl_off[c], widths[c], widths[c]};
+        const uint32_t pw = pre_w(c);
+        cw[c] = (size_t)pw + widths[c];
+        if (pw)                                    // the key's LDE columns beside the main ones: what the program and the interactions read
+            ZK_HIP(hipMemcpy2DAsync(tlde + tl_off[c], cw[c] * 4, t_key->d_lde[c], (size_t)pw * 4, (size_t)pw * 4, (size_t)1 << lh[c], hipMemcpyDeviceToDevice, st));
+        ZK_TRY(op_coset_lde(ctx, chips[c].d_trace, chips[c].ld, tlde + tl_off[c] + pw, cw[c], log_ns[c], widths[c], b, MONTY_GEN));
+        tm[c] = MatDesc{tlde + tl_off[c] + pw, cw[c], widths[c]};
         qm[c] = MatDesc{qlde + ql_off[c], 8, 8};
     }
     ZK_TRY(op_merkle_commit_mixed(ctx, tm, lh, n, ttree));
@@ -1828,7 +1871,15 @@ int zkhip_prove_chips(zkhip_ctx* ctx, const zkhip_chip* chips, int n, const uint
         MatDesc pmats[MAX_CHIPS]; int plh[MAX_CHIPS]; int np = 0;
         for (int c = 0; c < n; c++) {
             if (!wp[c]) continue;
-            if (t_machine) ZK_TRY(run_lookup_perm(ctx, chips[c].d_trace, chips[c].ld, log_ns[c], *lookup_of(c), gamma, beta_l, (uint32_t*)v_perm));
+            if (t_machine && pre_w(c)) {           // the interactions address [preprocessed | main] rows of the trace domain
+                const size_t nc = (size_t)1 << log_ns[c], pw = pre_w(c);
+                void* v_ct;
+                ZK_TRY(ctx_reserve(ctx, S_KEYTRACE, nc * cw[c] * 4, &v_ct));
+                uint32_t* ct = (uint32_t*)v_ct;
+                ZK_HIP(hipMemcpy2DAsync(ct, cw[c] * 4, t_key->d_trace[c], pw * 4, pw * 4, nc, hipMemcpyDeviceToDevice, st));
+                ZK_HIP(hipMemcpy2DAsync(ct + pw, cw[c] * 4, chips[c].d_trace, chips[c].ld * 4, (size_t)widths[c] * 4, nc, hipMemcpyDeviceToDevice, st));
+                ZK_TRY(run_lookup_perm(ctx, ct, cw[c], log_ns[c], *lookup_of(c), gamma, beta_l, (uint32_t*)v_perm));
+            } else if (t_machine) ZK_TRY(run_lookup_perm(ctx, chips[c].d_trace, chips[c].ld, log_ns[c], *lookup_of(c), gamma, beta_l, (uint32_t*)v_perm));
             else ZK_TRY(run_perm_trace(ctx, chips[c].d_trace, chips[c].ld, log_ns[c], (uint32_t)pairs[c], gamma, beta_l, (uint32_t*)v_perm));
             if (cross)          // the running sum's last value: row N - 1, column S
                 ZK_TRY(d2h(ctx, &cumsum[c], (const uint32_t*)v_perm + (((size_t)1 << log_ns[c]) - 1) * wp[c] + 4 * (size_t)pairs[c], 16));
@@ -1859,10 +1910,10 @@ int zkhip_prove_chips(zkhip_ctx* ctx, const zkhip_chip* chips, int n, const uint
             const LookupView& lv = *lookup_of(c);
             void* v_add;
             ZK_TRY(ctx_reserve(ctx, S_ADDEND, ((size_t)2 << log_ns[c]) * 16, &v_add));
-            ZK_TRY(run_lookup_addend(ctx, tlde + tl_off[c], widths[c], plde + pl_off[c], wp[c], log_ns[c], lv, gamma, beta_l, alpha, cumsum[c], (uint32_t*)v_add));
-            ZK_TRY(run_quotient_air(ctx, *prog_of(c), tlde + tl_off[c], widths[c], log_ns[c], widths[c], public_values, alpha, qchunk,
+            ZK_TRY(run_lookup_addend(ctx, tlde + tl_off[c], cw[c], plde + pl_off[c], wp[c], log_ns[c], lv, gamma, beta_l, alpha, cumsum[c], (uint32_t*)v_add));
+            ZK_TRY(run_quotient_air(ctx, *prog_of(c), tlde + tl_off[c], cw[c], log_ns[c], (uint32_t)cw[c], public_values, alpha, qchunk,
                                     own_coset_direct ? qlde + ql_off[c] : nullptr, 8, ext_pow(alpha, lv.cols + 3), (const uint32_t*)v_add));
-        } else if (prog_of(c)) ZK_TRY(run_quotient_air(ctx, *prog_of(c), tlde + tl_off[c], widths[c], log_ns[c], widths[c], public_values, alpha, qchunk,
+        } else if (prog_of(c)) ZK_TRY(run_quotient_air(ctx, *prog_of(c), tlde + tl_off[c], cw[c], log_ns[c], (uint32_t)cw[c], public_values, alpha, qchunk,
                                                 own_coset_direct ? qlde + ql_off[c] : nullptr, 8));
         else ZK_TRY(run_quotient(ctx, tlde + tl_off[c], widths[c], log_ns[c], widths[c], alpha, lu, qchunk, own_coset_direct ? qlde + ql_off[c] : nullptr, 8));
         const uint32_t w2n = two_adic_generator(log_ns[c] + 1);
@@ -1893,9 +1944,12 @@ int zkhip_prove_chips(zkhip_ctx* ctx, const zkhip_chip* chips, int n, const uint
         uint32_t* dv = dinv + dv_off[c];
         uint32_t* xw = dv + 8 * mc;
         ZK_HIP(launch_inv_denominators(ctx->dom_xs, mc, zpts[0], zpts[1], 2, dv, xw, nc, st));
-        ZK_TRY(run_open(ctx, tlde + tl_off[c], widths[c], log_ns[c], widths[c], zpts, 2, xw, d_open + op_off[c]));
-        if (wp[c]) ZK_TRY(run_open(ctx, plde + pl_off[c], wp[c], log_ns[c], (uint32_t)wp[c], zpts, 2, xw, d_open + op_off[c] + 8 * (size_t)widths[c]));
-        ZK_TRY(run_open(ctx, qlde + ql_off[c], 8, log_ns[c], 8, zpts, 1, xw, d_open + op_off[c] + 8 * (size_t)widths[c] + 8 * wp[c]));
+        const size_t pw = pre_w(c);
+        uint32_t* oc = d_open + op_off[c] + 8 * pw;                       // the chip's openings: [preprocessed local | next] first
+        if (pw) ZK_TRY(run_open(ctx, tlde + tl_off[c], cw[c], log_ns[c], (uint32_t)pw, zpts, 2, xw, d_open + op_off[c]));
+        ZK_TRY(run_open(ctx, tlde + tl_off[c] + pw, cw[c], log_ns[c], widths[c], zpts, 2, xw, oc));
+        if (wp[c]) ZK_TRY(run_open(ctx, plde + pl_off[c], wp[c], log_ns[c], (uint32_t)wp[c], zpts, 2, xw, oc + 8 * (size_t)widths[c]));
+        ZK_TRY(run_open(ctx, qlde + ql_off[c], 8, log_ns[c], 8, zpts, 1, xw, oc + 8 * (size_t)widths[c] + 8 * wp[c]));
     }
     std::vector<uint32_t> opened(op_off[n]);
     ZK_TRY(d2h(ctx, opened.data(), d_open, opened.size() * 4));
@@ -1939,7 +1993,10 @@ int zkhip_prove_chips(zkhip_ctx* ctx, const zkhip_chip* chips, int n, const uint
     for (int c = 0; c < n; c++) {
         const uint32_t W = widths[c];
         const Ext* fp = (const Ext*)(apows.data() + ap_off[c]);
-        const Ext* op_loc = (const Ext*)(opened.data() + op_off[c]);
+        const uint32_t Pw = pre_w(c);
+        const Ext* op_el = (const Ext*)(opened.data() + op_off[c]);
+        const Ext* op_en = op_el + Pw;
+        const Ext* op_loc = op_en + Pw;
         const Ext* op_nxt = op_loc + W;
         const Ext* op_pl = op_nxt + W;
         const Ext* op_pn = op_pl + wp[c];
@@ -1955,16 +2012,28 @@ int zkhip_prove_chips(zkhip_ctx* ctx, const zkhip_chip* chips, int n, const uint
             ra.y_pn = ext_add(ra.y_pn, ext_mul(fp[j], op_pn[j]));
         }
         for (int j = 0; j < 8; j++) ra.y_q = ext_add(ra.y_q, ext_mul(fp[j], op_q[j]));
-        const uint64_t off = height_offset(log_ns, widths, pairs, c);
+        const uint64_t off0 = height_offset(log_ns, widths, pairs, c), off = off0 + 2 * (uint64_t)Pw;
         ra.off_loc = ext_pow(fa, off); ra.off_next = ext_pow(fa, off + W);
         ra.off_pl = ext_pow(fa, off + 2 * (uint64_t)W); ra.off_pn = ext_pow(fa, off + 2 * (uint64_t)W + wp[c]);
         ra.off_q = ext_pow(fa, off + 2 * (uint64_t)W + 2 * wp[c]);
-        ra.tlde = tlde + tl_off[c]; ra.t_ld = W; ra.width = W; ra.qlde = qlde + ql_off[c]; ra.q_ld = 8; ra.q_width = 8; ra.rows = (uint64_t)1 << lh[c];
+        ra.tlde = tlde + tl_off[c] + Pw; ra.t_ld = cw[c]; ra.width = W; ra.qlde = qlde + ql_off[c]; ra.q_ld = 8; ra.q_width = 8; ra.rows = (uint64_t)1 << lh[c];
         ra.plde = wp[c] ? plde + pl_off[c] : nullptr; ra.p_ld = wp[c]; ra.p_width = (uint32_t)wp[c];
         ra.alpha_pow = (const uint32_t*)v_apf + ap_off[c]; ra.dinv = dinv + dv_off[c]; ra.out = ro_of[lh[c]];
         ra.accumulate = started[lh[c]] ? 1 : 0;
         started[lh[c]] = true;
         ZK_HIP(launch_reduced_opening(ra, (uint32_t*)v_at, st));
+        if (Pw) {                                  // the preprocessed columns' two terms, added on: the same kernel without permutation / quotient parts
+            ReducedArgs re = ra;
+            re.tlde = tlde + tl_off[c]; re.width = Pw; re.p_width = 0; re.plde = nullptr; re.q_width = 0;
+            re.y_loc = re.y_next = re.y_q = ext_zero();
+            for (uint32_t j = 0; j < Pw; j++) {
+                re.y_loc = ext_add(re.y_loc, ext_mul(fp[j], op_el[j]));
+                re.y_next = ext_add(re.y_next, ext_mul(fp[j], op_en[j]));
+            }
+            re.off_loc = ext_pow(fa, off0); re.off_next = ext_pow(fa, off0 + Pw);
+            re.accumulate = 1;
+            ZK_HIP(launch_reduced_opening(re, (uint32_t*)v_at, st));
+        }
     }
 
     // ---- 5. FRI commit phase; shorter vectors join at their height
@@ -1993,7 +2062,11 @@ int zkhip_prove_chips(zkhip_ctx* ctx, const zkhip_chip* chips, int n, const uint
         };
         for (int q = 0; q < Q; q++) {
             const size_t index = ch.sample_bits(Hmax);
-            for (int c = 0; c < n; c++) push(tlde + tl_off[c] + (index >> (Hmax - lh[c])) * widths[c], widths[c]);
+            if (t_key) {
+                for (int c = 0; c < n; c++) if (pre_w(c)) push(tlde + tl_off[c] + (index >> (Hmax - lh[c])) * cw[c], pre_w(c));
+                push_path(t_key->d_tree, (size_t)1 << t_key->He, index >> (Hmax - t_key->He), t_key->He);
+            }
+            for (int c = 0; c < n; c++) push(tlde + tl_off[c] + (index >> (Hmax - lh[c])) * cw[c] + pre_w(c), widths[c]);
             push_path(ttree, mmax, index, Hmax);
             if (lk) {
                 for (int c = 0; c < n; c++) if (wp[c]) push(plde + pl_off[c] + (index >> (Hmax - lh[c])) * wp[c], wp[c]);
@@ -2107,7 +2180,12 @@ int zkhip_verify_chips(const uint8_t* proof, size_t len, const int32_t* log_ns, 
     for (int c = 0; c < n; c++) {
         if (pf[pos] != (uint32_t)log_ns[c] || pf[pos + 1] != widths[c]) return reject(3);
         pos += 2;
-        if (t_machine) { if (pf[pos] != (header_has_prog(c) ? 1u : 0u) || pf[pos + 1] != (lookup_of(c) ? lookup_of(c)->ni : 0u)) return reject(3); pos += 2; continue; }
+        if (t_machine) {
+            if (pf[pos] != (header_has_prog(c) ? 1u : 0u) || pf[pos + 1] != (lookup_of(c) ? lookup_of(c)->ni : 0u)) return reject(3);
+            pos += 2;
+            if (t_key) { if (pf[pos] != pre_w(c)) return reject(3); pos++; }
+            continue;
+        }
         if (lk) { if (pf[pos] != (uint32_t)pairs[c]) return reject(3); pos++; }
         if (cross) { if (pf[pos] != (uint32_t)(partners[c] + 1)) return reject(3); pos++; }
         if (any_prog(n)) { if (pf[pos] != (prog_of(c) ? 1u : 0u)) return reject(3); pos++; }
@@ -2126,6 +2204,7 @@ int zkhip_verify_chips(const uint8_t* proof, size_t len, const int32_t* log_ns, 
             for (int i = 0; i < 8; i++) if (pf[pos + i] != dg[i]) return reject(3);
             pos += 8;
         }
+    if (t_key) { for (int i = 0; i < 8; i++) if (pf[pos + i] != from_monty(t_key->root_m[i])) return reject(3); pos += 8; }     // a proof under another key
     for (size_t i = pos; i < len / 4; i++) if (pf[i] >= P) return reject(4);
     for (size_t i = 0; i < n_public; i++) if (public_values[i] >= P) return reject(4);
     int lh[MAX_CHIPS]; uint32_t w8[MAX_CHIPS]; size_t wp[MAX_CHIPS];
@@ -2154,13 +2233,21 @@ int zkhip_verify_chips(const uint8_t* proof, size_t len, const int32_t* log_ns, 
     const Ext alpha = ch.sample_ext();
     for (int i = 0; i < 8; i++) { qroot[i] = to_monty(pf[pos++]); ch.observe(qroot[i]); }
     const Ext zeta = ch.sample_ext();
-    std::vector<std::vector<Ext>> loc(n), nxt(n), opl(n), opn(n), opq(n);
+    std::vector<std::vector<Ext>> loc(n), nxt(n), opl(n), opn(n), opq(n), oel(n), oen(n);
     for (int c = 0; c < n; c++) {
         const uint32_t W = widths[c];
         auto take = [&](std::vector<Ext>& v, size_t cnt) { v.resize(cnt); for (size_t j = 0; j < cnt; j++) v[j] = ext_from_canon(pf + pos + 4 * j); pos += 4 * cnt; };
+        take(oel[c], pre_w(c)); take(oen[c], pre_w(c));
         take(loc[c], W); take(nxt[c], W); take(opl[c], wp[c]); take(opn[c], wp[c]); take(opq[c], 8);
     }
+    // (the query groups run on worker threads, which do not see this thread's key: widths and root by value from here on)
+    uint32_t ew[MAX_CHIPS], pwv[MAX_CHIPS]; int elh[MAX_CHIPS], echip[MAX_CHIPS]; int ne = 0, He = 0;
+    const uint32_t* const eroot = t_key ? t_key->root_m : nullptr;
+    for (int c = 0; c < n; c++) pwv[c] = pre_w(c);
+    for (int c = 0; c < n; c++) if (pre_w(c)) { ew[ne] = pre_w(c); elh[ne] = lh[c]; echip[ne] = c; ne++; if (lh[c] > He) He = lh[c]; }
     for (int c = 0; c < n; c++) {
+        for (const Ext& e : oel[c]) ch.observe_ext(e);
+        for (const Ext& e : oen[c]) ch.observe_ext(e);
         for (const Ext& e : loc[c]) ch.observe_ext(e);
         for (const Ext& e : nxt[c]) ch.observe_ext(e);
         for (const Ext& e : opl[c]) ch.observe_ext(e);
@@ -2175,8 +2262,16 @@ int zkhip_verify_chips(const uint8_t* proof, size_t len, const int32_t* log_ns, 
         const Ext sel_first = ext_mul(zh, ext_inv(ext_sub_base(zeta, MONTY_R1)));
         const Ext sel_trans = ext_sub_base(zeta, finv(gn));
         Ext acc = ext_zero();
+        // what the chip's program and interactions read: the combined row [preprocessed | main] at zeta, and at zeta g
+        std::vector<Ext> cl_, cn_;
+        const Ext *row_l = loc[c].data(), *row_n = nxt[c].data();
+        if (pre_w(c)) {
+            cl_ = oel[c]; cl_.insert(cl_.end(), loc[c].begin(), loc[c].end());
+            cn_ = oen[c]; cn_.insert(cn_.end(), nxt[c].begin(), nxt[c].end());
+            row_l = cl_.data(); row_n = cn_.data();
+        }
         if (prog_of(c))
-            acc = air_fold_ext(*prog_of(c), loc[c].data(), nxt[c].data(), public_values, sel_first, ext_mul(zh, ext_inv(ext_sub_base(zeta, finv(gn)))), sel_trans, alpha);
+            acc = air_fold_ext(*prog_of(c), row_l, row_n, public_values, sel_first, ext_mul(zh, ext_inv(ext_sub_base(zeta, finv(gn)))), sel_trans, alpha);
         else for (uint32_t g = 0; g < widths[c] / 4; g++) {
             const Ext &a = loc[c][4 * g], &bb = loc[c][4 * g + 1], &cc = loc[c][4 * g + 2], &d = loc[c][4 * g + 3], &dn = nxt[c][4 * g + 3];
             const uint32_t k1 = to_monty(g + 1), k2 = to_monty(2 * g + 3), d0 = to_monty(5 * g + 7);
@@ -2192,7 +2287,7 @@ int zkhip_verify_chips(const uint8_t* proof, size_t len, const int32_t* log_ns, 
             const Ext sel_last = ext_mul(zh, ext_inv(ext_sub_base(zeta, finv(gn))));
             std::vector<Ext> pl(lv.cols + 1), pn(lv.cols + 1);
             for (uint32_t q = 0; q <= lv.cols; q++) { pl[q] = recombine(&opl[c][4 * q]); pn[q] = recombine(&opn[c][4 * q]); }
-            acc = lookup_fold_ext(acc, lv, loc[c].data(), pl.data(), pn.data(), gamma, beta_l, sel_first, sel_trans, sel_last, alpha, cumsum[c]);
+            acc = lookup_fold_ext(acc, lv, row_l, pl.data(), pn.data(), gamma, beta_l, sel_first, sel_trans, sel_last, alpha, cumsum[c]);
         } else if (wp[c]) {
             const uint32_t LQ = (uint32_t)pairs[c];
             const Ext sel_last = ext_mul(zh, ext_inv(ext_sub_base(zeta, finv(gn))));
@@ -2225,15 +2320,20 @@ int zkhip_verify_chips(const uint8_t* proof, size_t len, const int32_t* log_ns, 
     // (b) FRI
     const Ext fa = ch.sample_ext();
     size_t npmax = 8;
-    for (int c = 0; c < n; c++) { if (widths[c] > npmax) npmax = widths[c]; if (wp[c] > npmax) npmax = wp[c]; }
+    for (int c = 0; c < n; c++) { if (widths[c] > npmax) npmax = widths[c]; if (wp[c] > npmax) npmax = wp[c]; if (pre_w(c) > npmax) npmax = pre_w(c); }
     std::vector<Ext> fapow(npmax);
     fapow[0] = ext_one();
     for (size_t j = 1; j < npmax; j++) fapow[j] = ext_mul(fapow[j - 1], fa);
     Ext y_loc[MAX_CHIPS], y_nxt[MAX_CHIPS], y_pl[MAX_CHIPS], y_pn[MAX_CHIPS], y_q[MAX_CHIPS];
     Ext s_loc[MAX_CHIPS], s_nxt[MAX_CHIPS], s_pl[MAX_CHIPS], s_pn[MAX_CHIPS], s_q[MAX_CHIPS], znext[MAX_CHIPS];
+    Ext y_el[MAX_CHIPS], y_en[MAX_CHIPS], s_el[MAX_CHIPS], s_en[MAX_CHIPS];
     for (int c = 0; c < n; c++) {
-        const uint32_t W = widths[c];
-        y_loc[c] = y_nxt[c] = y_pl[c] = y_pn[c] = y_q[c] = ext_zero();
+        const uint32_t W = widths[c], Pw = pre_w(c);
+        y_loc[c] = y_nxt[c] = y_pl[c] = y_pn[c] = y_q[c] = y_el[c] = y_en[c] = ext_zero();
+        for (uint32_t j = 0; j < Pw; j++) {
+            y_el[c] = ext_add(y_el[c], ext_mul(fapow[j], oel[c][j]));
+            y_en[c] = ext_add(y_en[c], ext_mul(fapow[j], oen[c][j]));
+        }
         for (uint32_t j = 0; j < W; j++) {
             y_loc[c] = ext_add(y_loc[c], ext_mul(fapow[j], loc[c][j]));
             y_nxt[c] = ext_add(y_nxt[c], ext_mul(fapow[j], nxt[c][j]));
@@ -2243,7 +2343,8 @@ int zkhip_verify_chips(const uint8_t* proof, size_t len, const int32_t* log_ns, 
             y_pn[c] = ext_add(y_pn[c], ext_mul(fapow[j], opn[c][j]));
         }
         for (int j = 0; j < 8; j++) y_q[c] = ext_add(y_q[c], ext_mul(fapow[j], opq[c][j]));
-        const uint64_t off = height_offset(log_ns, widths, pairs, c);
+        const uint64_t off0 = height_offset(log_ns, widths, pairs, c), off = off0 + 2 * (uint64_t)Pw;
+        s_el[c] = ext_pow(fa, off0); s_en[c] = ext_pow(fa, off0 + Pw);
         s_loc[c] = ext_pow(fa, off); s_nxt[c] = ext_pow(fa, off + W); s_pl[c] = ext_pow(fa, off + 2 * (uint64_t)W);
         s_pn[c] = ext_pow(fa, off + 2 * (uint64_t)W + wp[c]); s_q[c] = ext_pow(fa, off + 2 * (uint64_t)W + 2 * wp[c]);
         znext[c] = ext_mul_base(zeta, two_adic_generator(log_ns[c]));
@@ -2273,14 +2374,22 @@ int zkhip_verify_chips(const uint8_t* proof, size_t len, const int32_t* log_ns, 
     auto check_group = [&](int g) -> int {
         const int q0 = 16 * g, cnt = NQ_ - q0 < 16 ? NQ_ - q0 : 16;
         const uint32_t *trow[16][MAX_CHIPS], *qrow[16][MAX_CHIPS], *prow[16][MAX_CHIPS], *prow_all[16][MAX_CHIPS];
-        const uint32_t *tpath[16], *ppath[16], *qpath[16];
-        size_t qpos[16], index[16], pindex[16];
+        const uint32_t *erow[16][MAX_CHIPS], *erow_all[16][MAX_CHIPS];
+        const uint32_t *tpath[16], *ppath[16], *qpath[16], *epath[16];
+        size_t qpos[16], index[16], pindex[16], eindex[16];
         int code[16] = {0};
         auto mark = [&](uint32_t mask, int why) { for (int j = 0; j < cnt; j++) if (((mask >> j) & 1u) && !code[j]) code[j] = why; };
         for (int j = 0; j < cnt; j++) {
             size_t pos = pos0 + (size_t)(q0 + j) * perq;
             index[j] = indices[q0 + j];
             pindex[j] = lk ? index[j] >> (Hmax - Hp) : 0;
+            eindex[j] = ne ? index[j] >> (Hmax - He) : 0;
+            epath[j] = nullptr;
+            for (int c = 0; c < n; c++) erow_all[j][c] = nullptr;
+            if (ne) {
+                for (int k = 0; k < ne; k++) { erow[j][k] = pf + pos; erow_all[j][echip[k]] = erow[j][k]; pos += ew[k]; }
+                epath[j] = pf + pos; pos += 8 * (size_t)He;
+            }
             for (int c = 0; c < n; c++) { trow[j][c] = pf + pos; pos += widths[c]; prow_all[j][c] = nullptr; }
             tpath[j] = pf + pos; pos += 8 * (size_t)Hmax;
             ppath[j] = nullptr;
@@ -2292,6 +2401,7 @@ int zkhip_verify_chips(const uint8_t* proof, size_t len, const int32_t* log_ns, 
             qpath[j] = pf + pos; pos += 8 * (size_t)Hmax;
             qpos[j] = pos;
         }
+        if (ne) mark(verify_mixed_x16(eroot, He, cnt, eindex, erow, ew, elh, ne, epath), 33);
         mark(verify_mixed_x16(troot, Hmax, cnt, index, trow, widths, lh, n, tpath), 30);
         if (lk) mark(verify_mixed_x16(proot, Hp, cnt, pindex, prow, pw, plh, np, ppath), 32);
         mark(verify_mixed_x16(qroot, Hmax, cnt, index, qrow, w8, lh, n, qpath), 31);
@@ -2316,6 +2426,12 @@ int zkhip_verify_chips(const uint8_t* proof, size_t len, const int32_t* log_ns, 
                     r = ext_add(r, ext_mul(s_pn[c], ext_mul(ext_sub(ap, y_pn[c]), d2)));
                 }
                 r = ext_add(r, ext_mul(s_q[c], ext_mul(ext_sub(aq, y_q[c]), d1)));
+                if (pwv[c]) {
+                    Ext ae = ext_zero();
+                    for (uint32_t k = 0; k < pwv[c]; k++) ae = ext_add(ae, ext_mul_base(fapow[k], to_monty(erow_all[j][c][k])));
+                    r = ext_add(r, ext_mul(s_el[c], ext_mul(ext_sub(ae, y_el[c]), d1)));
+                    r = ext_add(r, ext_mul(s_en[c], ext_mul(ext_sub(ae, y_en[c]), d2)));
+                }
                 r_h[lh[c]] = ext_add(r_h[lh[c]], r);
             }
             folded[j] = r_h[Hmax];
@@ -2461,6 +2577,126 @@ int zkhip_verify_machine(const uint8_t* proof, size_t len, const int32_t* log_ns
     MachineSetup m;
     if (machine_setup(programs, program_words, tables, table_words, widths, n_chips, n_public, m) != ZKHIP_OK) { if (reason) *reason = 1; return ZKHIP_ERR_VERIFY; }
     MachineScope scope(m.table, &m.mt);
+    return zkhip_verify_chips(proof, len, log_ns, widths, m.cols, nullptr, n_chips, public_values, n_public, prm, reason);
+}
+
+// ---- the keyed machine: preprocessed columns committed once; proof version 11 ----
+struct zkhip_machine_key {
+    zkhip_ctx* ctx = nullptr;            // identity only (a key serves the context it was made with)
+    int device = 0;
+    int n = 0, b = 0;
+    int32_t log_ns[MAX_CHIPS];
+    KeyView view{};
+    std::vector<void*> owned;           // device allocations of the key
+};
+void zkhip_machine_key_destroy(zkhip_machine_key* key) {
+    if (!key) return;
+    if (!key->owned.empty()) {          // the context may be gone by now: only the device is needed (hipFree waits for work in flight)
+        (void)hipSetDevice(key->device);
+        for (void* p : key->owned) (void)hipFree(p);
+    }
+    delete key;
+}
+int zkhip_machine_setup(zkhip_ctx* ctx, const zkhip_chip* pre, int n_chips, const zkhip_params* prm, zkhip_machine_key** key_out, uint32_t root[8]) {
+    CHECK_CTX(ctx);
+    if (!pre || !prm || !key_out || !root || n_chips < 1 || n_chips > MAX_CHIPS) return fail(ZKHIP_ERR_INVALID, "machine_setup: bad arguments");
+    if (prm->log_blowup < 1 || prm->log_blowup > 3) return fail(ZKHIP_ERR_INVALID, "machine_setup: log_blowup in [1,3]");
+    *key_out = nullptr;
+    zkhip_machine_key* key = new (std::nothrow) zkhip_machine_key;
+    if (!key) return fail(ZKHIP_ERR_INTERNAL, "machine_setup: out of memory");
+    struct Guard { zkhip_machine_key* k; ~Guard() { if (k) zkhip_machine_key_destroy(k); } } guard{key};
+    key->ctx = ctx; key->device = ctx->device; key->n = n_chips; key->b = prm->log_blowup;
+    const int b = prm->log_blowup;
+    MatDesc mats[MAX_CHIPS]; int lhs[MAX_CHIPS]; int ne = 0, He = 0;
+    auto dev_alloc = [&](size_t bytes, uint32_t** out) -> int {
+        void* p = nullptr;
+        ZK_HIP(hipMalloc(&p, bytes));
+        key->owned.push_back(p);
+        *out = (uint32_t*)p;
+        return ZKHIP_OK;
+    };
+    for (int c = 0; c < n_chips; c++) {
+        const uint32_t pw = pre[c].width;
+        key->log_ns[c] = pre[c].log_n; key->view.pw[c] = pw; key->view.d_trace[c] = nullptr; key->view.d_lde[c] = nullptr;
+        if (pre[c].log_n < 5 || pre[c].log_n > 20 || (c && pre[c].log_n > pre[c - 1].log_n)) return fail(ZKHIP_ERR_INVALID, "machine_setup: log_n in [5,20], tallest first");
+        if (pw % 4 != 0 || pw > 1024) return fail(ZKHIP_ERR_INVALID, "machine_setup: preprocessed width a multiple of 4 up to 1024 (0: none)");
+        if (!pw) continue;
+        if (!pre[c].d_trace || pre[c].ld < pw) return fail(ZKHIP_ERR_INVALID, "machine_setup: bad preprocessed trace descriptor");
+        const size_t nc = (size_t)1 << pre[c].log_n, mc = nc << b;
+        uint32_t *tr, *lde;
+        ZK_TRY(dev_alloc(nc * pw * 4, &tr));
+        ZK_TRY(dev_alloc(mc * pw * 4, &lde));
+        ZK_HIP(hipMemcpy2DAsync(tr, (size_t)pw * 4, pre[c].d_trace, pre[c].ld * 4, (size_t)pw * 4, nc, hipMemcpyDeviceToDevice, ctx->stream));
+        ZK_TRY(op_coset_lde(ctx, tr, pw, lde, pw, pre[c].log_n, pw, b, MONTY_GEN));
+        key->view.d_trace[c] = tr; key->view.d_lde[c] = lde;
+        mats[ne] = MatDesc{lde, pw, pw}; lhs[ne] = pre[c].log_n + b; ne++;
+        if (pre[c].log_n + b > He) He = pre[c].log_n + b;
+    }
+    if (!ne) return fail(ZKHIP_ERR_INVALID, "machine_setup: no chip has preprocessed columns");
+    uint32_t* tree;
+    ZK_TRY(dev_alloc((2 * ((size_t)1 << He) - 1) * 32, &tree));
+    ZK_TRY(op_merkle_commit_mixed(ctx, mats, lhs, ne, tree));
+    ZK_TRY(d2h(ctx, key->view.root_m, tree + (2 * ((size_t)1 << He) - 2) * 8, 32));
+    key->view.d_tree = tree; key->view.He = He;
+    for (int i = 0; i < 8; i++) root[i] = from_monty(key->view.root_m[i]);
+    guard.k = nullptr;
+    *key_out = key;
+    return ZKHIP_OK;
+}
+static int keyed_widths(const uint32_t* widths, const uint32_t* pre_widths, int n, uint32_t* combined) {
+    if (!widths || !pre_widths || n < 1 || n > MAX_CHIPS) return fail(ZKHIP_ERR_INVALID, "keyed machine: bad arguments");
+    for (int c = 0; c < n; c++) {
+        if (widths[c] > 1024 || pre_widths[c] > 1024) return fail(ZKHIP_ERR_INVALID, "keyed machine: widths up to 1024");
+        combined[c] = widths[c] + pre_widths[c];
+    }
+    return ZKHIP_OK;
+}
+size_t zkhip_machine_proof_size_keyed(const int32_t* log_ns, const uint32_t* widths, const uint32_t* pre_widths, const uint32_t* const* programs,
+                                      const size_t* program_words, const uint32_t* const* tables, const size_t* table_words, int n_chips,
+                                      const zkhip_params* prm, size_t n_public) {
+    uint32_t cw[MAX_CHIPS];
+    if (keyed_widths(widths, pre_widths, n_chips, cw) != ZKHIP_OK) return 0;
+    MachineSetup m;
+    if (machine_setup(programs, program_words, tables, table_words, cw, n_chips, n_public, m) != ZKHIP_OK) return 0;
+    KeyView kv{};
+    for (int c = 0; c < n_chips; c++) kv.pw[c] = pre_widths[c];
+    MachineScope scope(m.table, &m.mt);
+    KeyScope ks(&kv);
+    return zkhip_chips_proof_size(log_ns, widths, m.cols, nullptr, n_chips, prm, n_public);
+}
+int zkhip_prove_machine_keyed(zkhip_ctx* ctx, const zkhip_machine_key* key, const zkhip_chip* chips, const uint32_t* const* programs,
+                              const size_t* program_words, const uint32_t* const* tables, const size_t* table_words, int n_chips,
+                              const uint32_t* public_values, size_t n_public, const zkhip_params* prm, uint8_t* proof, size_t cap, size_t* len) {
+    CHECK_CTX(ctx);
+    if (!key || !chips || !prm || n_chips < 1 || n_chips > MAX_CHIPS) return fail(ZKHIP_ERR_INVALID, "prove_machine_keyed: bad arguments");
+    if (key->ctx != ctx) return fail(ZKHIP_ERR_INVALID, "prove_machine_keyed: the key belongs to another context");
+    if (key->n != n_chips || key->b != prm->log_blowup) return fail(ZKHIP_ERR_INVALID, "prove_machine_keyed: the key was set up for another machine shape (chips / log_blowup)");
+    uint32_t widths[MAX_CHIPS], cw[MAX_CHIPS];
+    for (int c = 0; c < n_chips; c++) {
+        widths[c] = chips[c].width;
+        if (chips[c].log_n != key->log_ns[c]) return fail(ZKHIP_ERR_INVALID, "prove_machine_keyed: a chip's height differs from the key's");
+    }
+    ZK_TRY(keyed_widths(widths, key->view.pw, n_chips, cw));
+    MachineSetup m;
+    ZK_TRY(machine_setup(programs, program_words, tables, table_words, cw, n_chips, n_public, m));
+    zkhip_chip mine[MAX_CHIPS];
+    for (int c = 0; c < n_chips; c++) { mine[c] = chips[c]; mine[c].logup_pairs = m.cols[c]; mine[c].partner = -1; }
+    MachineScope scope(m.table, &m.mt);
+    KeyScope ks(&key->view);
+    return zkhip_prove_chips(ctx, mine, n_chips, public_values, n_public, prm, proof, cap, len);
+}
+int zkhip_verify_machine_keyed(const uint8_t* proof, size_t len, const int32_t* log_ns, const uint32_t* widths, const uint32_t* pre_widths,
+                               const uint32_t root[8], const uint32_t* const* programs, const size_t* program_words, const uint32_t* const* tables,
+                               const size_t* table_words, int n_chips, const uint32_t* public_values, size_t n_public, const zkhip_params* prm, int* reason) {
+    uint32_t cw[MAX_CHIPS];
+    MachineSetup m;
+    KeyView kv{};
+    if (!root || keyed_widths(widths, pre_widths, n_chips, cw) != ZKHIP_OK ||
+        machine_setup(programs, program_words, tables, table_words, cw, n_chips, n_public, m) != ZKHIP_OK) { if (reason) *reason = 1; return ZKHIP_ERR_VERIFY; }
+    for (int i = 0; i < 8; i++) { if (root[i] >= P) { if (reason) *reason = 1; return ZKHIP_ERR_VERIFY; } kv.root_m[i] = to_monty(root[i]); }
+    for (int c = 0; c < n_chips; c++) kv.pw[c] = pre_widths[c];
+    MachineScope scope(m.table, &m.mt);
+    KeyScope ks(&kv);
     return zkhip_verify_chips(proof, len, log_ns, widths, m.cols, nullptr, n_chips, public_values, n_public, prm, reason);
 }
 

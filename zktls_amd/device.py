@@ -464,6 +464,36 @@ class Context:
                                            buf.ctypes.data_as(u8p), size, C.byref(got)))
         return buf[: got.value]
 
+    def machine_setup(self, pre_chips, params=None):
+        """zkhip_machine_setup: pre_chips = [(device buffer or None, log_n, preprocessed width), ...] tallest first -> MachineKey
+        (.root: the 8 canonical words a verifier needs; .pre_widths)"""
+        params = params or Params(1, 100, 16, 0)
+        n = len(pre_chips)
+        arr = (_lib.Chip * n)(*[_lib.Chip(b.ptr if b is not None else None, w, ln, w, 0, -1) for b, ln, w in pre_chips])
+        handle = C.c_void_p()
+        root = np.zeros(8, dtype=np.uint32)
+        check(self.lib.zkhip_machine_setup(self.handle, arr, n, C.byref(params), C.byref(handle), root.ctypes.data_as(u32p)))
+        return MachineKey(self, handle, root, [int(c[2]) for c in pre_chips])
+
+    def prove_machine_keyed(self, key, chips, programs, tables, public_values=(), params=None):
+        """a machine with preprocessed columns (proof version 11): `key` from machine_setup; chips as in prove_machine (main columns);
+        programs / tables address the combined row [preprocessed | main]"""
+        params = params or Params(1, 100, 16, 0)
+        n = len(chips)
+        arr = (_lib.Chip * n)(*[_lib.Chip(b.ptr, w, ln, w, 0, -1) for b, ln, w in chips])
+        log_ns = (C.c_int32 * n)(*[c[1] for c in chips])
+        widths = (C.c_uint32 * n)(*[c[2] for c in chips])
+        pws = (C.c_uint32 * n)(*(list(key.pre_widths) + [0] * n)[:n])      # (a key of another shape is the library's to refuse)
+        kp, pp, pw = _program_table(programs)
+        kt, tp, tw = _program_table(tables)
+        pv = np.ascontiguousarray(np.array(public_values, dtype=np.uint32))
+        size = self.lib.zkhip_machine_proof_size_keyed(log_ns, widths, pws, pp, pw, tp, tw, n, C.byref(params), pv.size)
+        buf = np.empty(max(size, 1), dtype=np.uint8)
+        got = C.c_size_t(0)
+        check(self.lib.zkhip_prove_machine_keyed(self.handle, key.handle, arr, pp, pw, tp, tw, n, pv.ctypes.data_as(u32p), pv.size, C.byref(params),
+                                                 buf.ctypes.data_as(u8p), size, C.byref(got)))
+        return buf[: got.value]
+
     def prove_debug(self):
         d = ProveDebug()
         check(self.lib.zkhip_last_prove_debug(self.handle, C.byref(d)))
@@ -623,6 +653,42 @@ def _program_table(programs):
     pp = (u32p * n)(*[(p.ctypes.data_as(u32p) if p is not None else None) for p in keep])
     pw = (C.c_size_t * n)(*[(p.size if p is not None else 0) for p in keep])
     return keep, pp, pw
+
+
+class MachineKey:
+    """the proving key of a keyed machine (device-resident preprocessed traces, LDEs and tree) + what the verifier needs of it"""
+
+    def __init__(self, ctx, handle, root, pre_widths):
+        self.ctx, self.handle, self.root, self.pre_widths = ctx, handle, root, pre_widths
+
+    def close(self):
+        if self.handle:
+            self.ctx.lib.zkhip_machine_key_destroy(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def verify_machine_keyed(proof, log_ns, widths, pre_widths, root, programs, tables, public_values=(), params=None):
+    params = params or Params(1, 100, 16)
+    lib = _lib.load()
+    pr = np.ascontiguousarray(proof, dtype=np.uint8)
+    pv = np.ascontiguousarray(np.array(public_values, dtype=np.uint32))
+    rt = np.ascontiguousarray(np.array(root, dtype=np.uint32))
+    n = len(log_ns)
+    ln = (C.c_int32 * n)(*[int(x) for x in log_ns])
+    ws = (C.c_uint32 * n)(*[int(x) for x in widths])
+    pws = (C.c_uint32 * n)(*[int(x) for x in pre_widths])
+    kp, pp, pw = _program_table(programs)
+    kt, tp, tw = _program_table(tables)
+    reason = C.c_int(0)
+    rc = lib.zkhip_verify_machine_keyed(pr.ctypes.data_as(u8p), pr.size, ln, ws, pws, rt.ctypes.data_as(u32p), pp, pw, tp, tw, n,
+                                        pv.ctypes.data_as(u32p), pv.size, C.byref(params), C.byref(reason))
+    return rc, reason.value
 
 
 def verify_machine(proof, log_ns, widths, programs, tables, public_values=(), params=None):
