@@ -119,6 +119,20 @@ def main():
         assert O.verify_machine(pf, lns, ws, pg, tb, pub, params) == 0
         mach[name] = {"machine": list(args), "params": list(prm), "bytes": int(pf.size), "sha256": hashlib.sha256(pf.tobytes()).hexdigest()}
     out["machine_proofs"] = mach
+    # keyed machines: tables with preprocessed columns, committed once by setup (proof version 11); the key's root is part of the fixture
+    keyed = {}
+    for name, (args, prm) in {"byte_6_3": (("byte", 6, 3, 1), (1, 8, 4)), "byte_8_4_blowup8": (("byte", 8, 4, 2), (3, 4, 0)),
+                              "random_keyed_301": (("random_keyed", 301), (1, 5, 3)), "random_keyed_305": (("random_keyed", 305), (2, 4, 2))}.items():
+        tr, pre, pg, tb, pub = machines.byte_machine(*args[1:]) if args[0] == "byte" else machines.random_keyed_machine(args[1])
+        params = O.default_params(*prm)
+        lns, ws = [t.shape[0].bit_length() - 1 for t in tr], [t.shape[1] for t in tr]
+        pws = [0 if p is None else p.shape[1] for p in pre]
+        root = O.machine_setup(pre, lns, params)
+        pf = O.prove_machine_keyed(tr, pre, pg, tb, pub, params)
+        assert O.verify_machine_keyed(pf, lns, ws, pws, root, pg, tb, pub, params) == 0
+        keyed[name] = {"machine": list(args), "params": list(prm), "root": [int(v) for v in root], "bytes": int(pf.size),
+                       "sha256": hashlib.sha256(pf.tobytes()).hexdigest()}
+    out["keyed_machine_proofs"] = keyed
     # complete proof BYTES of small shards, one per proof version (tests/golden/proofs/*.bin): what the independent pure-Python
     # verifier (tests/pyverify.py, written from DESIGN.md sections 3 and 6) and the product's host verifier check on the CPU, and
     # what the HIP prover must reproduce byte for byte on the GPU.  shape = (log_blowup, queries, pow_bits, logup_pairs,

@@ -1,5 +1,6 @@
 """Independent pure-Python VERIFIER for multi-chip proofs: versions 4 (several tables of different heights), 5 (in-table lookups),
-6 (lookups between tables), 9 (tables with their own constraint programs) and 10 (the machine: programs + interaction tables).
+6 (lookups between tables), 9 (tables with their own constraint programs), 10 (the machine: programs + interaction tables) and 11 (the
+keyed machine: some tables have preprocessed columns, committed once; the commitment is an argument of the verifier).
 Written from the protocol description in DESIGN.md sections 3, 3b and 6 on top of tests/pyref.py and the helpers of
 tests/pyverify.py; it shares no code with oracle/chips.c or with the product's host verifier.  Test infrastructure only.
 """
@@ -45,16 +46,23 @@ def mixed_root(rows_by_height, h_max, index, siblings):
 
 
 def verify(proof_bytes, log_ns, widths, public_values, log_blowup=1, num_queries=100, pow_bits=16, pairs=None, partners=None,
-           programs=None, tables=None):
+           programs=None, tables=None, pre_widths=None, pre_root=None):
     """raises Reject(reason) or returns True.  pairs / partners: versions 5 / 6; programs: version 9; programs + tables (a list,
-    entries may be None): version 10."""
+    entries may be None): version 10; with pre_widths (per chip, 0: none) and pre_root (the key's 8 words): version 11, where
+    programs and tables address the combined row [preprocessed | main]."""
     if len(proof_bytes) % 4:
         raise Reject("length")
     w = list(struct.unpack("<%dI" % (len(proof_bytes) // 4), bytes(proof_bytes)))
     n, b = len(log_ns), log_blowup
     machine = tables is not None
+    keyed = pre_widths is not None
+    if keyed and (not machine or pre_root is None or len(pre_root) != 8 or any(v >= P for v in pre_root) or not any(pre_widths)):
+        raise Reject("key")
+    pws = [int(x) for x in pre_widths] if keyed else [0] * n
+    if any(pw % 4 or pw + widths[c] > 1024 or (pw and (programs or [None] * n)[c] is None) for c, pw in enumerate(pws)):
+        raise Reject("preprocessed widths")
     programs = programs or [None] * n
-    inter = [parse_table(t, widths[c]) if (machine and t is not None) else None for c, t in enumerate(tables or [None] * n)]
+    inter = [parse_table(t, pws[c] + widths[c]) if (machine and t is not None) else None for c, t in enumerate(tables or [None] * n)]
     if machine:
         cols = [(len(it) + 1) // 2 if it else 0 for it in inter]
     else:
@@ -62,7 +70,7 @@ def verify(proof_bytes, log_ns, widths, public_values, log_blowup=1, num_queries
     lk = any(cols)
     cross = (machine and lk) or (partners is not None and any(p_ >= 0 for p_ in partners))
     any_prog = any(p_ is not None for p_ in programs)
-    version = 10 if machine else (9 if any_prog else (6 if cross else (5 if lk else 4)))
+    version = (11 if keyed else 10) if machine else (9 if any_prog else (6 if cross else (5 if lk else 4)))
     wp = [4 * (q + 1) if q else 0 for q in cols]
     lh = [ln + b for ln in log_ns]
     h_max, L = lh[0], log_ns[0]
@@ -76,6 +84,8 @@ def verify(proof_bytes, log_ns, widths, public_values, log_blowup=1, num_queries
         entries += [log_ns[c], widths[c]]
         if machine:
             entries += [1 if programs[c] is not None else 0, len(inter[c]) if inter[c] else 0]
+            if keyed:
+                entries.append(pws[c])
             continue
         if lk:
             entries.append(cols[c])
@@ -91,6 +101,8 @@ def verify(proof_bytes, log_ns, widths, public_values, log_blowup=1, num_queries
         for c in range(n):
             if inter[c]:
                 digests += air_digest(tables[c])
+    if keyed:
+        digests += [int(v) for v in pre_root]            # the key's commitment sits after the digests and is observed with them
     pos = len(head) + len(entries) + len(digests)
     if w[:pos] != head + entries + digests:
         raise Reject("header")
@@ -137,16 +149,18 @@ def verify(proof_bytes, log_ns, widths, public_values, log_blowup=1, num_queries
     zeta = ts.sample_ext()
     opened = []
     for c in range(n):
-        opened.append((take_ext(widths[c]), take_ext(widths[c]), take_ext(wp[c]), take_ext(wp[c]), take_ext(8)))
+        pre_parts = (take_ext(pws[c]), take_ext(pws[c]))                      # preprocessed columns at zeta, at zeta g: first
+        opened.append((take_ext(widths[c]), take_ext(widths[c]), take_ext(wp[c]), take_ext(wp[c]), take_ext(8)) + pre_parts)
     for c in range(n):
-        for part in opened[c]:
+        for part in opened[c][5:] + opened[c][:5]:
             for e in part:
                 ts.observe_many(e)
 
     # ---- (a) every chip's AIR identity at zeta (same alpha for every chip; its own trace domain)
     zeta_next = []
     for c in range(n):
-        loc, nxt, pl, pn, qz = opened[c]
+        loc, nxt, pl, pn, qz, pre_l, pre_n = opened[c]
+        loc, nxt = pre_l + loc, pre_n + nxt             # what programs and interactions address: [preprocessed | main]
         N = 1 << log_ns[c]
         wN = two_adic_generator(log_ns[c])
         wN_inv = pow(wN, -1, P)
@@ -164,7 +178,7 @@ def verify(proof_bytes, log_ns, widths, public_values, log_blowup=1, num_queries
         if programs[c] is not None:
             acc = air_fold(programs[c], loc, nxt, public_values, sel_first, sel_last, sel_trans, alpha)
         else:
-            for g in range(widths[c] // 4):
+            for g in range(widths[c] // 4):             # (a chip without a program has no preprocessed columns)
                 a, bb, cc, d, dn = loc[4 * g], loc[4 * g + 1], loc[4 * g + 2], loc[4 * g + 3], nxt[4 * g + 3]
                 fold(e_sub(e_sub(cc, ext_mul(ext_mul(a, a), bb)), e_base(g + 1)))
                 fold(ext_mul(sel_trans, e_sub(e_sub(e_sub(dn, ext_mul(a, bb)), cc), e_base(2 * g + 3))))
@@ -220,7 +234,7 @@ def verify(proof_bytes, log_ns, widths, public_values, log_blowup=1, num_queries
 
     # ---- (b) FRI: one reduced-opening vector per height; the batching powers run on across the chips of a height
     fa = ts.sample_ext()
-    npow = max([8] + list(widths) + wp)
+    npow = max([8] + list(widths) + wp + pws)
     fap = [ONE]
     for _ in range(npow - 1):
         fap.append(ext_mul(fap[-1], fa))
@@ -239,9 +253,11 @@ def verify(proof_bytes, log_ns, widths, public_values, log_blowup=1, num_queries
     ys, offs = [], []
     for c in range(n):
         ys.append([batch(part) for part in opened[c]])
-        off = sum(2 * widths[d] + 2 * wp[d] + 8 for d in range(c) if log_ns[d] == log_ns[c])
-        W, Wp = widths[c], wp[c]
-        offs.append([ext_pow(fa, off), ext_pow(fa, off + W), ext_pow(fa, off + 2 * W), ext_pow(fa, off + 2 * W + Wp), ext_pow(fa, off + 2 * W + 2 * Wp)])
+        off0 = sum(2 * pws[d] + 2 * widths[d] + 2 * wp[d] + 8 for d in range(c) if log_ns[d] == log_ns[c])
+        W, Wp, Pw = widths[c], wp[c], pws[c]
+        off = off0 + 2 * Pw                              # the chip's preprocessed columns take the first 2 Pw powers of its stretch
+        offs.append([ext_pow(fa, off), ext_pow(fa, off + W), ext_pow(fa, off + 2 * W), ext_pow(fa, off + 2 * W + Wp), ext_pow(fa, off + 2 * W + 2 * Wp),
+                     ext_pow(fa, off0), ext_pow(fa, off0 + Pw)])
     layer_roots, betas = [], []
     for _ in range(L):
         r = take(8)
@@ -257,9 +273,16 @@ def verify(proof_bytes, log_ns, widths, public_values, log_blowup=1, num_queries
 
     perm_chips = [c for c in range(n) if wp[c]]
     h_perm = max([lh[c] for c in perm_chips], default=0)
+    pre_chips = [c for c in range(n) if pws[c]]
+    h_pre = max([lh[c] for c in pre_chips], default=0)
     half = pow(2, -1, P)
     for _ in range(num_queries):
         index = ts.sample_bits(h_max)
+        erows = {}
+        if keyed:
+            for c in pre_chips:
+                erows[c] = take(pws[c])
+            epath = [take(8) for _ in range(h_pre)]
         trows = [take(widths[c]) for c in range(n)]
         tpath = [take(8) for _ in range(h_max)]
         prows = {}
@@ -275,6 +298,8 @@ def verify(proof_bytes, log_ns, widths, public_values, log_blowup=1, num_queries
             for c in chips:
                 out.setdefault(lh[c], []).extend(rows[c])
             return out
+        if keyed and mixed_root(by_height(erows, pre_chips), h_pre, index >> (h_max - h_pre), epath) != [int(v) for v in pre_root]:
+            raise Reject("preprocessed opening")
         if mixed_root(by_height(trows, range(n)), h_max, index, tpath) != trace_root:
             raise Reject("trace opening")
         if lk and mixed_root(by_height(prows, perm_chips), h_perm, index >> (h_max - h_perm), ppath) != perm_root:
@@ -288,7 +313,7 @@ def verify(proof_bytes, log_ns, widths, public_values, log_blowup=1, num_queries
             inv1 = ext_inv(e_sub(e_base(x), zeta))
             inv2 = ext_inv(e_sub(e_base(x), zeta_next[c]))
             at, aq = batch_base(trows[c]), batch_base(qrows[c])
-            y_loc, y_nxt, y_pl, y_pn, y_q = ys[c]
+            y_loc, y_nxt, y_pl, y_pn, y_q, y_el, y_en = ys[c]
             r = ext_mul(offs[c][0], ext_mul(e_sub(at, y_loc), inv1))
             r = e_add(r, ext_mul(offs[c][1], ext_mul(e_sub(at, y_nxt), inv2)))
             if wp[c]:
@@ -296,6 +321,10 @@ def verify(proof_bytes, log_ns, widths, public_values, log_blowup=1, num_queries
                 r = e_add(r, ext_mul(offs[c][2], ext_mul(e_sub(ap, y_pl), inv1)))
                 r = e_add(r, ext_mul(offs[c][3], ext_mul(e_sub(ap, y_pn), inv2)))
             r = e_add(r, ext_mul(offs[c][4], ext_mul(e_sub(aq, y_q), inv1)))
+            if pws[c]:
+                ae = batch_base(erows[c])
+                r = e_add(r, ext_mul(offs[c][5], ext_mul(e_sub(ae, y_el), inv1)))
+                r = e_add(r, ext_mul(offs[c][6], ext_mul(e_sub(ae, y_en), inv2)))
             roh[lh[c]] = e_add(roh.get(lh[c], ZERO), r)
         val, idx = roh.get(h_max, ZERO), index
         for l in range(L):

@@ -106,3 +106,24 @@ def test_sha256_chip_with_a_preprocessed_range_table(ctx, oracle):
     wrong = list(sha_pub)
     wrong[0] ^= 1
     assert verify_machine_keyed(proof, [16, 10], [4, 608], [4, 0], key.root, progs, tables, wrong, prm)[0] == -6
+
+
+import hashlib
+import json
+import os
+
+KAT = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "oracle_kat.json")))
+
+
+@pytest.mark.parametrize("name", sorted(KAT["keyed_machine_proofs"]))
+def test_golden_keyed_machine_proofs_on_gpu(ctx, name):
+    """the committed keys (roots) and proofs (sizes, SHA-256 of the bytes) reproduced by the HIP path without the oracle in the loop"""
+    g = KAT["keyed_machine_proofs"][name]
+    a = g["machine"]
+    tr, pre, pg, tb, pub = M.byte_machine(*a[1:]) if a[0] == "byte" else M.random_keyed_machine(a[1])
+    lns, ws, pws = shape_of(tr, pre)
+    chips, pre_chips = on_device(ctx, tr, pre, lns, ws, pws)
+    key = ctx.machine_setup(pre_chips, Params(*g["params"]))
+    assert key.root.tolist() == g["root"]
+    proof = ctx.prove_machine_keyed(key, chips, pg, tb, pub, Params(*g["params"]))
+    assert proof.size == g["bytes"] and hashlib.sha256(proof.tobytes()).hexdigest() == g["sha256"]

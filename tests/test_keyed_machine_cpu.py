@@ -2,6 +2,9 @@
 crates/guest-prover-sp1/src/sp1.rs:113; sp1-stark StarkMachine::setup).  CPU side: the oracle's setup and prover under the oracle's and
 the product's verifiers, the rejections either gives, the argument checks of the C entries."""
 import ctypes as C
+import hashlib
+import json
+import os
 import struct
 
 import numpy as np
@@ -13,6 +16,25 @@ from zktls_amd._lib import Params
 from zktls_amd.device import verify_machine_keyed
 
 P = 2013265921
+KAT = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "oracle_kat.json")))
+
+
+def golden_keyed_machine(g):
+    a = g["machine"]
+    return M.byte_machine(*a[1:]) if a[0] == "byte" else M.random_keyed_machine(a[1])
+
+
+@pytest.mark.parametrize("name", sorted(KAT["keyed_machine_proofs"]))
+def test_golden_keyed_machine_proofs(oracle, name):
+    """the oracle still produces the committed keys and proofs (tests/golden/make_golden.py); the product's verifier accepts them"""
+    g = KAT["keyed_machine_proofs"][name]
+    tr, pre, pg, tb, pub = golden_keyed_machine(g)
+    lns, ws, pws = shape_of(tr, pre)
+    oprm = oracle.default_params(*g["params"])
+    assert oracle.machine_setup(pre, lns, oprm).tolist() == g["root"]
+    pf = oracle.prove_machine_keyed(tr, pre, pg, tb, pub, oprm)
+    assert pf.size == g["bytes"] and hashlib.sha256(pf.tobytes()).hexdigest() == g["sha256"]
+    assert verify_machine_keyed(pf, lns, ws, pws, g["root"], pg, tb, pub, Params(*g["params"])) == (0, 0)
 
 
 def shape_of(traces, pre):

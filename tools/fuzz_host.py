@@ -17,7 +17,7 @@ import machines
 import oracle_lib as O
 import sha256_air as S
 from zktls_amd._lib import Params
-from zktls_amd.device import verify_chips, verify_chips_air, verify_machine, verify_sha256, verify_shard, verify_shard_air
+from zktls_amd.device import verify_chips, verify_chips_air, verify_machine, verify_machine_keyed, verify_sha256, verify_shard, verify_shard_air
 
 budget = float(sys.argv[1]) if len(sys.argv) > 1 else 30.0
 rng = np.random.default_rng(int(os.environ.get("ZKHIP_FUZZ_SEED", "1")))
@@ -69,6 +69,10 @@ p_chips_air = O.prove_chips_air([airs.counter_trace(7, 8, 3, 5)[0], ft], [cnt, f
 mt, mp, mtab, mpub = machines.range_machine(5, 6)
 p_machine = O.prove_machine(mt, mp, mtab, mpub, oprm).tobytes()
 mln, mws = [t.shape[0].bit_length() - 1 for t in mt], [t.shape[1] for t in mt]
+kt, kpre, kp, ktab, kpub = machines.byte_machine(6, 3)
+kln, kws, kpw = [t.shape[0].bit_length() - 1 for t in kt], [t.shape[1] for t in kt], [0 if p_ is None else p_.shape[1] for p_ in kpre]
+kroot = O.machine_setup(kpre, kln, oprm)
+p_keyed = O.prove_machine_keyed(kt, kpre, kp, ktab, kpub, oprm).tobytes()
 sha_t, sha_pub = S.trace(S.pad(b"abc"))
 p_sha = O.prove_shard_air(S.program(), sha_t, sha_pub, oprm).tobytes()
 bc_size = L.zkhip_bincode_size(6, 8, C.byref(prm))
@@ -87,6 +91,8 @@ while time.time() - t0 < budget:
     verify_chips_air(arr(p_chips_air), [7, 6], [8, 4], [words(mutate(cnt.tobytes())), fib], fpub, prm)
     verify_machine(arr(mutate(p_machine)), mln, mws, mp, mtab, mpub, prm)
     verify_machine(arr(p_machine), mln, mws, mp, [words(mutate(mtab[0].tobytes())), mtab[1], mtab[2]], mpub, prm)
+    verify_machine_keyed(arr(mutate(p_keyed)), kln, kws, kpw, kroot, kp, ktab, kpub, prm)
+    verify_machine_keyed(arr(p_keyed), kln, kws, [int(x) for x in rng.choice([0, 4, 8, 1020, 1024, 2**31], len(kpw))], rng.integers(0, 2**32, 8, dtype=np.uint64).astype(np.uint32), kp, ktab, kpub, prm)
     verify_sha256(arr(mutate(p_sha)) if rng.random() < 0.7 else arr(p_sha), bytes(rng.integers(0, 256, 32, dtype=np.uint8)), prm)
     w = words(mutate(fib.tobytes()))
     L.zkhip_air_validate(w.ctypes.data_as(u32p), w.size, int(rng.choice([4, 8])), int(rng.choice([3, 0])))
@@ -96,4 +102,4 @@ while time.time() - t0 < budget:
     back = np.zeros(len(p_single) + 64, dtype=np.uint8)
     L.zkhip_proof_from_bincode(m.ctypes.data_as(u8p), m.size, 6, 8, C.byref(prm), 2, back.ctypes.data_as(u8p), int(rng.choice([back.size, 16, 0])), C.byref(got))
     n += 1
-print("fuzz ok: %d rounds of 12 malformed calls in %.0f s (no crash; run under the sanitizer build for out-of-bounds reads)" % (n, time.time() - t0))
+print("fuzz ok: %d rounds of 14 malformed calls in %.0f s (no crash; run under the sanitizer build for out-of-bounds reads)" % (n, time.time() - t0))

@@ -5,18 +5,41 @@ sys.path.insert(0, "/root/repo"); sys.path.insert(0, "/root/repo/tests")
 import numpy as np
 import oracle_lib as O
 import airs
-from zktls_amd.device import Context, verify_shard, verify_chips, verify_shard_air, verify_chips_air, verify_machine
+from zktls_amd.device import Context, verify_shard, verify_chips, verify_shard_air, verify_chips_air, verify_machine, verify_machine_keyed
 import machines
 from zktls_amd._lib import Params
 O.set_threads(8)
 budget = float(sys.argv[1]) if len(sys.argv) > 1 else 60.0
 rng = np.random.default_rng(int(time.time()))
 ctx = Context(0)
-t0 = time.time(); n_single = n_chips = n_air = n_machine = n_lookup = 0
+t0 = time.time(); n_single = n_chips = n_air = n_machine = n_lookup = n_keyed = 0
 SEED = int(rng.integers(1, 2**40))
 while time.time() - t0 < budget:
     r_kind = rng.random()
-    if r_kind < 0.05:
+    if r_kind < 0.03:
+        # a keyed machine: some tables have preprocessed columns, committed once by setup (version 11); two proofs against one key
+        if rng.random() < 0.4:
+            traces, pre, progs, tables, pub = machines.byte_machine(int(rng.integers(5, 11)), int(rng.integers(3, 6)), seed=int(rng.integers(0, 2**31)))
+        else:
+            traces, pre, progs, tables, pub = machines.random_keyed_machine(int(rng.integers(0, 2**31)))
+        lns, ws = [t.shape[0].bit_length() - 1 for t in traces], [t.shape[1] for t in traces]
+        pws = [0 if p_ is None else p_.shape[1] for p_ in pre]
+        prm = (int(rng.integers(1, 4)), int(rng.integers(1, 12)), int(rng.integers(0, 7)))
+        dev = [ctx.from_numpy(t) for t in traces]
+        dpre = [None if p_ is None else ctx.from_numpy(p_) for p_ in pre]
+        key = ctx.machine_setup(list(zip(dpre, lns, pws)), Params(*prm))
+        assert key.root.tolist() == O.machine_setup(pre, lns, O.default_params(*prm)).tolist(), ("key", lns, pws, prm)
+        for d in dpre:
+            if d is not None: d.free()                                           # the key holds its own copies
+        want = O.prove_machine_keyed(traces, pre, progs, tables, pub, O.default_params(*prm)).tobytes()
+        for _ in range(2):
+            pf = ctx.prove_machine_keyed(key, list(zip(dev, lns, ws)), progs, tables, pub, Params(*prm))
+            assert pf.tobytes() == want, ("keyed machine", lns, ws, pws, prm)
+        assert verify_machine_keyed(pf, lns, ws, pws, key.root, progs, tables, pub, Params(*prm)) == (0, 0)
+        key.close()
+        for d in dev: d.free()
+        n_keyed += 1
+    elif r_kind < 0.05:
         # a machine whose tables look each other up (interaction tables: multiplicities, buses, 1- and 2-tuples), plus bystanders
         lt = int(rng.integers(5, 9)); lu = int(rng.integers(lt, 11))
         if rng.random() < 0.5:
@@ -118,5 +141,5 @@ while time.time() - t0 < budget:
         assert verify_chips(pf, [c[0] for c in chips], [c[1] for c in chips], [7], Params(*prm), prs, pas if cross else None) == (0, 0)
         for d in dev: d.free()
         n_chips += 1
-print("ok: %d single-matrix, %d multi-chip, %d constraint-program, %d chips-with-programs and %d lookup-machine configurations in %.0f s"
-      % (n_single, n_chips, n_air, n_machine, n_lookup, time.time() - t0))
+print("ok: %d single-matrix, %d multi-chip, %d constraint-program, %d chips-with-programs, %d lookup-machine and %d keyed-machine configurations in %.0f s"
+      % (n_single, n_chips, n_air, n_machine, n_lookup, n_keyed, time.time() - t0))
