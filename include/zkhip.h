@@ -484,10 +484,31 @@ size_t zkhip_machine_proof_size_keyed(const int32_t* log_ns, const uint32_t* wid
 int zkhip_prove_machine_keyed(zkhip_ctx* ctx, const zkhip_machine_key* key, const zkhip_chip* chips, const uint32_t* const* programs,
                               const size_t* program_words, const uint32_t* const* tables, const size_t* table_words, int n_chips,
                               const uint32_t* public_values, size_t n_public, const zkhip_params* prm, uint8_t* proof, size_t cap, size_t* len);
+/* the same with the key's entries assigned to the machine's chips explicitly: chip c uses entry key_entries[c] of the key (-1: the chip has
+ * no preprocessed columns).  The key may then hold fewer entries than the machine has chips -- a key of tables only, used by machines
+ * whose other chips change height from proof to proof (sp1-stark matches preprocessed traces to a shard's chips by name).  Every entry
+ * with columns is used exactly once and in the key's order. */
+int zkhip_prove_machine_keyed_at(zkhip_ctx* ctx, const zkhip_machine_key* key, const int32_t* key_entries, const zkhip_chip* chips,
+                                 const uint32_t* const* programs, const size_t* program_words, const uint32_t* const* tables, const size_t* table_words,
+                                 int n_chips, const uint32_t* public_values, size_t n_public, const zkhip_params* prm, uint8_t* proof, size_t cap,
+                                 size_t* len);
 int zkhip_verify_machine_keyed(const uint8_t* proof, size_t len, const int32_t* log_ns, const uint32_t* widths, const uint32_t* pre_widths,
                                const uint32_t root[8], const uint32_t* const* programs, const size_t* program_words, const uint32_t* const* tables,
                                const size_t* table_words, int n_chips, const uint32_t* public_values, size_t n_public, const zkhip_params* prm,
                                int* reason);
+
+/* The SHA-256 guest as a keyed machine: setup once, then one proof per message -- the reference's setup -> prove -> verify
+ * (sp1.rs:113, :116, :120) on this repo's stand-in guest.  Two chips: the SHA-256 compression chip (zkhip_sha256_air, 608 columns) and a
+ * 2^16-row range table that receives the four 16-bit limbs per row the chip's own constraints do not range-check (the OUT limbs of d and
+ * h); the table's values are a PREPROCESSED column committed by zkhip_sha256_setup (vk = that commitment, 8 canonical words; the key holds
+ * the device data), its multiplicities are counted on the device per proof.  Messages up to 2^14 blocks (1 MiB).  A proof is a version-11
+ * machine proof with public values = the digest's 16 limbs; zkhip_verify_sha256_machine reads the chip's height from the proof, rebuilds
+ * the machine and runs zkhip_verify_machine_keyed. */
+int zkhip_sha256_setup(zkhip_ctx* ctx, const zkhip_params* prm, zkhip_machine_key** key, uint32_t vk[8]);
+size_t zkhip_sha256_machine_proof_size(size_t message_len, const zkhip_params* prm);
+int zkhip_prove_sha256_machine(zkhip_ctx* ctx, const zkhip_machine_key* key, const uint8_t* message, size_t message_len, const zkhip_params* prm,
+                               uint8_t digest[32], uint8_t* proof, size_t cap, size_t* len);
+int zkhip_verify_sha256_machine(const uint8_t* proof, size_t len, const uint8_t digest[32], const uint32_t vk[8], const zkhip_params* prm, int* reason);
 
 /* ---- Poseidon2 parameter tables from a file: the built-in sets are this repo's own
  * ("zktls-amd/p2-bb16-v1", "...-bb24-v1"; the SP1 / RISC Zero tables of reference Cargo.lock:4030, 6172, 5057 are not

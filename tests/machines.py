@@ -128,3 +128,23 @@ def random_keyed_machine(seed):
     if all(p is None for p in pre):
         pre[0], main[0] = np.ascontiguousarray(traces[0][:, :4]), np.ascontiguousarray(traces[0][:, 4:])
     return main, pre, progs, tables, pub
+
+
+def sha256_machine(message):
+    """the SHA-256 guest as a keyed machine, rebuilt independently of zkhip_prove_sha256_machine: the compression chip (tests/sha256_air.py)
+    sends the OUT limbs of d and h to a 2^16-row range table whose values are preprocessed and whose multiplicities are main columns.
+    -> (traces, preprocessed traces, programs, tables, public values), tallest first"""
+    import sha256_air as S
+    sha_t, pub = S.trace(S.pad(message))
+    sent = [S.OUT + 6, S.OUT + 7, S.OUT + 14, S.OUT + 15]
+    sha_tab = O.interaction_table([(O.SEND, None, 16, [c]) for c in sent])
+    values = np.zeros((1 << 16, 4), dtype=np.uint32)
+    values[:, 0] = np.arange(1 << 16)
+    main = values.copy()
+    main[:, 1] = np.bincount(sha_t[:, sent].ravel(), minlength=1 << 16)
+    table_prog = O.air_program(8, 16, [(O.SEL_FIRST, [(1, [V(0)])])])
+    table_tab = O.interaction_table([(O.RECEIVE, 5, 16, [0])])
+    chips = [(sha_t, None, S.program(), sha_tab), (main, values, table_prog, table_tab)]
+    if sha_t.shape[0] <= 1 << 16:
+        chips.reverse()
+    return [c[0] for c in chips], [c[1] for c in chips], [c[2] for c in chips], [c[3] for c in chips], list(pub)

@@ -127,3 +127,44 @@ def test_golden_keyed_machine_proofs_on_gpu(ctx, name):
     assert key.root.tolist() == g["root"]
     proof = ctx.prove_machine_keyed(key, chips, pg, tb, pub, Params(*g["params"]))
     assert proof.size == g["bytes"] and hashlib.sha256(proof.tobytes()).hexdigest() == g["sha256"]
+
+
+@pytest.mark.parametrize("n_bytes", [0, 55, 753, 13217])
+def test_sha256_machine_setup_prove_verify(ctx, oracle, n_bytes):
+    """setup -> prove -> verify, the reference's three calls (sp1.rs:113, :116, :120), on the SHA-256 machine: the key and the proof bytes
+    against the oracle proving the same machine rebuilt in Python, the digest against hashlib"""
+    from zktls_amd.device import verify_sha256_machine
+    O = oracle
+    msg = np.random.default_rng(n_bytes).integers(0, 256, n_bytes, dtype=np.uint8).tobytes()
+    prm, oprm = Params(1, 10, 4), O.default_params(1, 10, 4)
+    key = ctx.sha256_setup(prm)
+    digest, proof = ctx.prove_sha256_machine(key, msg, prm)
+    assert digest == hashlib.sha256(msg).digest()
+    tr, pre, pg, tb, pub = M.sha256_machine(msg)
+    lns, ws, pws = shape_of(tr, pre)
+    assert key.root.tolist() == O.machine_setup(pre, lns, oprm).tolist()
+    assert proof.tobytes() == O.prove_machine_keyed(tr, pre, pg, tb, pub, oprm).tobytes()
+    assert verify_sha256_machine(proof, digest, key.root, prm) == (0, 0)
+    assert O.verify_machine_keyed(proof, lns, ws, pws, key.root, pg, tb, pub, oprm) == 0
+    other = bytearray(digest)
+    other[5] ^= 1
+    assert verify_sha256_machine(proof, bytes(other), key.root, prm)[0] == -6
+    vk2 = key.root.copy()
+    vk2[0] = (int(vk2[0]) + 1) % 2013265921
+    assert verify_sha256_machine(proof, digest, vk2, prm) == (-6, 3)
+    # the same key proves the next message
+    digest2, proof2 = ctx.prove_sha256_machine(key, msg + b"x", prm)
+    assert digest2 == hashlib.sha256(msg + b"x").digest() and verify_sha256_machine(proof2, digest2, key.root, prm) == (0, 0)
+
+
+def test_sha256_machine_above_the_table_height(ctx):
+    """2^17 rows: the chip is taller than its 2^16-row table and comes first; accepted by the host verifier, digest against hashlib"""
+    from zktls_amd.device import verify_sha256_machine
+    msg = np.random.default_rng(5).integers(0, 256, (128 << 10) - 9, dtype=np.uint8).tobytes()
+    prm = Params(1, 16, 4)
+    key = ctx.sha256_setup(prm)
+    digest, proof = ctx.prove_sha256_machine(key, msg, prm)
+    assert digest == hashlib.sha256(msg).digest()
+    w = np.frombuffer(proof.tobytes(), dtype=np.uint32)
+    assert list(w[8:18]) == [17, 608, 1, 4, 0, 16, 4, 1, 1, 4]
+    assert verify_sha256_machine(proof, digest, key.root, prm) == (0, 0)

@@ -33,7 +33,8 @@ EXPORTS = [
     "zkhip_quotient_values_air",
     "zkhip_chips_proof_size_air", "zkhip_prove_chips_air", "zkhip_verify_chips_air",
     "zkhip_prove_shards_air_multi", "zkhip_selftest_host_simd", "zkhip_host_simd", "zkhip_machine_proof_size", "zkhip_prove_machine", "zkhip_verify_machine", "zkhip_range_table",
-    "zkhip_machine_setup", "zkhip_machine_key_destroy", "zkhip_machine_proof_size_keyed", "zkhip_prove_machine_keyed", "zkhip_verify_machine_keyed",
+    "zkhip_machine_setup", "zkhip_machine_key_destroy", "zkhip_machine_proof_size_keyed", "zkhip_prove_machine_keyed", "zkhip_verify_machine_keyed", "zkhip_prove_machine_keyed_at",
+    "zkhip_sha256_setup", "zkhip_sha256_machine_proof_size", "zkhip_prove_sha256_machine", "zkhip_verify_sha256_machine",
     "zkhip_sha256_air", "zkhip_sha256_digest", "zkhip_sha256_pad", "zkhip_sha256_gen_trace", "zkhip_sha256_proof_size", "zkhip_prove_sha256", "zkhip_verify_sha256",
 ]
 
@@ -176,6 +177,13 @@ def load():
                                             u8p, C.c_size_t, szp]
     L.zkhip_verify_machine_keyed.argtypes = [u8p, C.c_size_t, C.POINTER(C.c_int32), C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), u32p, u32pp, szp, u32pp, szp,
                                              C.c_int, u32p, C.c_size_t, C.POINTER(Params), C.POINTER(C.c_int)]
+    L.zkhip_prove_machine_keyed_at.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(C.c_int32), C.POINTER(Chip), u32pp, szp, u32pp, szp, C.c_int, u32p, C.c_size_t,
+                                               C.POINTER(Params), u8p, C.c_size_t, szp]
+    L.zkhip_sha256_setup.argtypes = [C.c_void_p, C.POINTER(Params), C.POINTER(C.c_void_p), u32p]
+    L.zkhip_sha256_machine_proof_size.restype = C.c_size_t
+    L.zkhip_sha256_machine_proof_size.argtypes = [C.c_size_t, C.POINTER(Params)]
+    L.zkhip_prove_sha256_machine.argtypes = [C.c_void_p, C.c_void_p, u8p, C.c_size_t, C.POINTER(Params), u8p, u8p, C.c_size_t, szp]
+    L.zkhip_verify_sha256_machine.argtypes = [u8p, C.c_size_t, u8p, u32p, C.POINTER(Params), C.POINTER(C.c_int)]
     L.zkhip_sha256_air.restype = C.c_size_t
     L.zkhip_sha256_air.argtypes = [u32p, C.c_size_t]
     L.zkhip_sha256_digest.restype = None

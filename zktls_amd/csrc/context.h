@@ -81,6 +81,7 @@ enum Slot {
     S_CHIP,            // trace of a built-in chip (sha256_chip.hip)
     S_LOOKUP,          // machine mode: a chip's interaction records + lookup weights
     S_ADDEND,          // machine mode: the folded lookup constraints of a chip on its quotient domain
+    S_CHIP_B,          // second table of a built-in machine (the SHA-256 machine's range table: values at setup, multiplicities per proof)
     S_KEYTRACE,        // keyed machine: a chip's trace rows [preprocessed | main] for its permutation trace
     S_COUNT
 };

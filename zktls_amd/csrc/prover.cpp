@@ -2664,26 +2664,44 @@ size_t zkhip_machine_proof_size_keyed(const int32_t* log_ns, const uint32_t* wid
     KeyScope ks(&kv);
     return zkhip_chips_proof_size(log_ns, widths, m.cols, nullptr, n_chips, prm, n_public);
 }
-int zkhip_prove_machine_keyed(zkhip_ctx* ctx, const zkhip_machine_key* key, const zkhip_chip* chips, const uint32_t* const* programs,
-                              const size_t* program_words, const uint32_t* const* tables, const size_t* table_words, int n_chips,
-                              const uint32_t* public_values, size_t n_public, const zkhip_params* prm, uint8_t* proof, size_t cap, size_t* len) {
+int zkhip_prove_machine_keyed_at(zkhip_ctx* ctx, const zkhip_machine_key* key, const int32_t* key_entries, const zkhip_chip* chips,
+                                 const uint32_t* const* programs, const size_t* program_words, const uint32_t* const* tables, const size_t* table_words,
+                                 int n_chips, const uint32_t* public_values, size_t n_public, const zkhip_params* prm, uint8_t* proof, size_t cap, size_t* len) {
     CHECK_CTX(ctx);
     if (!key || !chips || !prm || n_chips < 1 || n_chips > MAX_CHIPS) return fail(ZKHIP_ERR_INVALID, "prove_machine_keyed: bad arguments");
     if (key->ctx != ctx) return fail(ZKHIP_ERR_INVALID, "prove_machine_keyed: the key belongs to another context");
-    if (key->n != n_chips || key->b != prm->log_blowup) return fail(ZKHIP_ERR_INVALID, "prove_machine_keyed: the key was set up for another machine shape (chips / log_blowup)");
+    if (key->b != prm->log_blowup || (!key_entries && key->n != n_chips))
+        return fail(ZKHIP_ERR_INVALID, "prove_machine_keyed: the key was set up for another machine shape (chips / log_blowup)");
+    // the machine's view of the key: chip c uses entry key_entries[c] (none: -1); every entry that has columns is used once, in the
+    // key's order (the rows of equally tall entries are hashed in that order)
+    KeyView kv = key->view;
     uint32_t widths[MAX_CHIPS], cw[MAX_CHIPS];
+    int last = -1, used = 0, have = 0;
+    for (int e = 0; e < key->n; e++) have += key->view.pw[e] != 0;
     for (int c = 0; c < n_chips; c++) {
         widths[c] = chips[c].width;
-        if (chips[c].log_n != key->log_ns[c]) return fail(ZKHIP_ERR_INVALID, "prove_machine_keyed: a chip's height differs from the key's");
+        const int e = key_entries ? key_entries[c] : c;
+        kv.pw[c] = 0; kv.d_trace[c] = nullptr; kv.d_lde[c] = nullptr;
+        if (e < 0 || (e < key->n && key->view.pw[e] == 0)) continue;
+        if (e >= key->n || e <= last) return fail(ZKHIP_ERR_INVALID, "prove_machine_keyed: key entries must be used once each, in the key's order");
+        if (chips[c].log_n != key->log_ns[e]) return fail(ZKHIP_ERR_INVALID, "prove_machine_keyed: a chip's height differs from the key's");
+        kv.pw[c] = key->view.pw[e]; kv.d_trace[c] = key->view.d_trace[e]; kv.d_lde[c] = key->view.d_lde[e];
+        last = e; used++;
     }
-    ZK_TRY(keyed_widths(widths, key->view.pw, n_chips, cw));
+    if (used != have) return fail(ZKHIP_ERR_INVALID, "prove_machine_keyed: the machine leaves out a preprocessed table of the key");
+    ZK_TRY(keyed_widths(widths, kv.pw, n_chips, cw));
     MachineSetup m;
     ZK_TRY(machine_setup(programs, program_words, tables, table_words, cw, n_chips, n_public, m));
     zkhip_chip mine[MAX_CHIPS];
     for (int c = 0; c < n_chips; c++) { mine[c] = chips[c]; mine[c].logup_pairs = m.cols[c]; mine[c].partner = -1; }
     MachineScope scope(m.table, &m.mt);
-    KeyScope ks(&key->view);
+    KeyScope ks(&kv);
     return zkhip_prove_chips(ctx, mine, n_chips, public_values, n_public, prm, proof, cap, len);
+}
+int zkhip_prove_machine_keyed(zkhip_ctx* ctx, const zkhip_machine_key* key, const zkhip_chip* chips, const uint32_t* const* programs,
+                              const size_t* program_words, const uint32_t* const* tables, const size_t* table_words, int n_chips,
+                              const uint32_t* public_values, size_t n_public, const zkhip_params* prm, uint8_t* proof, size_t cap, size_t* len) {
+    return zkhip_prove_machine_keyed_at(ctx, key, nullptr, chips, programs, program_words, tables, table_words, n_chips, public_values, n_public, prm, proof, cap, len);
 }
 int zkhip_verify_machine_keyed(const uint8_t* proof, size_t len, const int32_t* log_ns, const uint32_t* widths, const uint32_t* pre_widths,
                                const uint32_t root[8], const uint32_t* const* programs, const size_t* program_words, const uint32_t* const* tables,

@@ -505,4 +505,125 @@ int zkhip_verify_sha256(const uint8_t* proof, size_t len, const uint8_t digest[3
     return zkhip_verify_shard_air(p.data(), p.size(), proof, len, log_n, sha::WIDTH, limbs, sha::N_PUBLIC, prm, reason);
 }
 
+// ---- the SHA-256 guest as a keyed machine: setup once, then one proof per message ------------------------------------------
+// The compression chip's own constraints range-check every limb except four (OUT of d and h: they are only added, never
+// decomposed).  In the machine form those four go to a 2^16-row range table, as SP1's chips send their limbs to the byte / range
+// tables: the table's VALUES are a preprocessed column (fixed by the key, no counter constraints), its multiplicities a main column.
+// setup = the reference's client.setup (sp1.rs:113): commits the table once; the root is the verifying key.
+}  // extern "C"
+namespace zk {
+namespace sha {
+constexpr uint32_t RANGE_BUS = 16, RANGE_LOG = 16;
+static const uint32_t SENT[4] = {OUT + 6, OUT + 7, OUT + 14, OUT + 15};
+static const std::vector<uint32_t>& range_program() {          // combined row [v 0 0 0 | v m 0 0]: one harmless first-row identity
+    static const std::vector<uint32_t> p{AIR_MAGIC, 1u, 8u, 1u, N_PUBLIC, 6u + 5u, FIRST, 1u, 1u, 1u, var(0)};
+    return p;
+}
+static const std::vector<uint32_t>& sha_interactions() {
+    static const std::vector<uint32_t> t = [] {
+        std::vector<uint32_t> v{LOOKUP_MAGIC, 4u, 3u + 4u * 5u};
+        for (uint32_t c : SENT) { v.push_back(0u); v.push_back(0xFFFFFFFFu); v.push_back(RANGE_BUS); v.push_back(1u); v.push_back(c); }
+        return v;
+    }();
+    return t;
+}
+static const std::vector<uint32_t>& range_interactions() {     // receive (multiplicity = combined column 5, [preprocessed value])
+    static const std::vector<uint32_t> t{LOOKUP_MAGIC, 1u, 3u + 5u, 1u, 5u, RANGE_BUS, 1u, 0u};
+    return t;
+}
+// the machine of a message: chips tallest first -- the chip before the table once it is taller than 2^16 rows
+struct MachineShape {
+    int n = 2, sha_at, table_at;
+    int32_t log_ns[2]; uint32_t widths[2], pre_widths[2]; int32_t entries[2];
+    const uint32_t* progs[2]; size_t prog_words[2]; const uint32_t* tabs[2]; size_t tab_words[2];
+};
+static MachineShape machine_shape(int log_n) {
+    MachineShape m;
+    m.sha_at = log_n > (int)RANGE_LOG ? 0 : 1; m.table_at = 1 - m.sha_at;
+    m.log_ns[m.sha_at] = log_n; m.widths[m.sha_at] = WIDTH; m.pre_widths[m.sha_at] = 0; m.entries[m.sha_at] = -1;
+    m.progs[m.sha_at] = program().data(); m.prog_words[m.sha_at] = program().size();
+    m.tabs[m.sha_at] = sha_interactions().data(); m.tab_words[m.sha_at] = sha_interactions().size();
+    m.log_ns[m.table_at] = (int)RANGE_LOG; m.widths[m.table_at] = 4; m.pre_widths[m.table_at] = 4; m.entries[m.table_at] = 0;
+    m.progs[m.table_at] = range_program().data(); m.prog_words[m.table_at] = range_program().size();
+    m.tabs[m.table_at] = range_interactions().data(); m.tab_words[m.table_at] = range_interactions().size();
+    return m;
+}
+}  // namespace sha
+}  // namespace zk
+extern "C" {
+
+int zkhip_sha256_setup(zkhip_ctx* ctx, const zkhip_params* prm, zkhip_machine_key** key, uint32_t vk[8]) {
+    CHECK_CTX(ctx);
+    if (!prm || !key || !vk) return fail(ZKHIP_ERR_INVALID, "sha256_setup: null argument");
+    const size_t n = (size_t)1 << sha::RANGE_LOG;
+    std::vector<uint32_t> values(n * 4, 0u);
+    for (size_t v = 0; v < n; v++) values[4 * v] = to_monty((uint32_t)v);
+    void* d;
+    ZK_TRY(ctx_reserve(ctx, S_CHIP_B, n * 16, &d));
+    ZK_HIP(hipMemcpyAsync(d, values.data(), n * 16, hipMemcpyHostToDevice, ctx->stream));
+    ZK_HIP(hipStreamSynchronize(ctx->stream));
+    zkhip_chip pre{};
+    pre.d_trace = (const uint32_t*)d; pre.ld = 4; pre.log_n = (int)sha::RANGE_LOG; pre.width = 4; pre.logup_pairs = 0; pre.partner = -1;
+    return zkhip_machine_setup(ctx, &pre, 1, prm, key, vk);
+}
+
+size_t zkhip_sha256_machine_proof_size(size_t message_len, const zkhip_params* prm) {
+    size_t padded, na, nb;
+    int log_n;
+    if (sha_shape(message_len, &padded, &na, &nb, &log_n) != ZKHIP_OK || log_n > 20) return 0;
+    const sha::MachineShape m = sha::machine_shape(log_n);
+    return zkhip_machine_proof_size_keyed(m.log_ns, m.widths, m.pre_widths, m.progs, m.prog_words, m.tabs, m.tab_words, 2, prm, sha::N_PUBLIC);
+}
+
+int zkhip_prove_sha256_machine(zkhip_ctx* ctx, const zkhip_machine_key* key, const uint8_t* message, size_t message_len, const zkhip_params* prm,
+                               uint8_t digest[32], uint8_t* proof, size_t cap, size_t* len) {
+    CHECK_CTX(ctx);
+    if (!key || (message_len && !message) || !digest || !proof || !len || !prm) return fail(ZKHIP_ERR_INVALID, "prove_sha256_machine: null argument");
+    size_t padded, na, nb;
+    int log_n;
+    ZK_TRY(sha_shape(message_len, &padded, &na, &nb, &log_n));
+    if (log_n > 20) return fail(ZKHIP_ERR_INVALID, "prove_sha256_machine: the machine prover takes chips of up to 2^20 rows (2^14 blocks, 1 MiB)");
+    std::vector<uint8_t> blocks(padded);
+    zkhip_sha256_pad(message, message_len, blocks.data(), padded);
+    void *trace, *counts;
+    ZK_TRY(ctx_reserve(ctx, S_CHIP, ((size_t)sha::WIDTH << log_n) * 4, &trace));
+    ZK_TRY(ctx_reserve(ctx, S_CHIP_B, ((size_t)1 << sha::RANGE_LOG) * 16, &counts));
+    uint32_t limbs[16];
+    ZK_TRY(zkhip_sha256_gen_trace(ctx, blocks.data(), na, nb, (uint32_t*)trace, sha::WIDTH, limbs));
+    for (int i = 0; i < 8; i++) {
+        const uint32_t w = limbs[2 * i] | (limbs[2 * i + 1] << 16);
+        digest[4 * i] = (uint8_t)(w >> 24); digest[4 * i + 1] = (uint8_t)(w >> 16); digest[4 * i + 2] = (uint8_t)(w >> 8); digest[4 * i + 3] = (uint8_t)w;
+    }
+    // the table's main columns (v, multiplicity, 0, 0), counted on the device
+    ZK_HIP(hipMemsetAsync(counts, 0, ((size_t)1 << sha::RANGE_LOG) * 16, ctx->stream));
+    ZK_TRY(zkhip_range_table(ctx, (const uint32_t*)trace, sha::WIDTH, (size_t)1 << log_n, sha::SENT, 4, (int)sha::RANGE_LOG, (uint32_t*)counts, 4, 0, 1));
+    const sha::MachineShape m = sha::machine_shape(log_n);
+    zkhip_chip chips[2]{};
+    chips[m.sha_at].d_trace = (const uint32_t*)trace; chips[m.sha_at].ld = sha::WIDTH; chips[m.sha_at].log_n = log_n; chips[m.sha_at].width = sha::WIDTH;
+    chips[m.table_at].d_trace = (const uint32_t*)counts; chips[m.table_at].ld = 4; chips[m.table_at].log_n = (int)sha::RANGE_LOG; chips[m.table_at].width = 4;
+    chips[0].partner = chips[1].partner = -1;
+    return zkhip_prove_machine_keyed_at(ctx, key, m.entries, chips, m.progs, m.prog_words, m.tabs, m.tab_words, 2, limbs, sha::N_PUBLIC, prm, proof, cap, len);
+}
+
+int zkhip_verify_sha256_machine(const uint8_t* proof, size_t len, const uint8_t digest[32], const uint32_t vk[8], const zkhip_params* prm, int* reason) {
+    if (!proof || !digest || !vk || !prm || len < 4 * 18) return fail(ZKHIP_ERR_INVALID, "verify_sha256_machine: null argument");
+    uint32_t head[18];
+    std::memcpy(head, proof, sizeof head);
+    // two header entries (log_n, width, has-program, interactions, preprocessed width): the chip's height is read from the proof
+    // and bound by its transcript; everything else about the machine is fixed here
+    const int sha_at = head[8 + 1] == sha::WIDTH ? 0 : 1;
+    const int log_n = (int)head[8 + 5 * sha_at];
+    if (head[2] != 2u || log_n < 6 || log_n > 20 || (sha_at == 0) != (log_n > (int)sha::RANGE_LOG)) {
+        if (reason) *reason = 1;
+        return fail(ZKHIP_ERR_VERIFY, "verify_sha256_machine: not a proof of the SHA-256 machine");
+    }
+    uint32_t limbs[16];
+    for (int i = 0; i < 8; i++) {
+        const uint32_t w = ((uint32_t)digest[4 * i] << 24) | ((uint32_t)digest[4 * i + 1] << 16) | ((uint32_t)digest[4 * i + 2] << 8) | digest[4 * i + 3];
+        limbs[2 * i] = w & 0xffffu; limbs[2 * i + 1] = w >> 16;
+    }
+    const sha::MachineShape m = sha::machine_shape(log_n);
+    return zkhip_verify_machine_keyed(proof, len, m.log_ns, m.widths, m.pre_widths, vk, m.progs, m.prog_words, m.tabs, m.tab_words, 2, limbs, sha::N_PUBLIC, prm, reason);
+}
+
 }  // extern "C"

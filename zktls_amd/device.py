@@ -359,6 +359,28 @@ class Context:
                                           buf.ctypes.data_as(u8p), size, C.byref(got)))
         return digest.tobytes(), buf[: got.value]
 
+    def sha256_setup(self, params=None):
+        """zkhip_sha256_setup: the SHA-256 machine's key (the range table's preprocessed values, committed once) -> MachineKey; .root is the vk"""
+        params = params or Params(1, 100, 16)
+        handle = C.c_void_p()
+        root = np.zeros(8, dtype=np.uint32)
+        check(self.lib.zkhip_sha256_setup(self.handle, C.byref(params), C.byref(handle), root.ctypes.data_as(u32p)))
+        return MachineKey(self, handle, root, [4])
+
+    def prove_sha256_machine(self, key, message, params=None):
+        """-> (digest bytes, proof bytes): the SHA-256 chip + its range table as a keyed machine (proof version 11)"""
+        params = params or Params(1, 100, 16)
+        m = np.frombuffer(bytes(message), dtype=np.uint8) if len(message) else np.zeros(1, dtype=np.uint8)
+        size = self.lib.zkhip_sha256_machine_proof_size(len(message), C.byref(params))
+        if size == 0:
+            raise _lib.ZkHipError(-1, "prove_sha256_machine: bad shape or message too long")
+        buf = np.empty(size, dtype=np.uint8)
+        digest = np.zeros(32, dtype=np.uint8)
+        got = C.c_size_t(0)
+        check(self.lib.zkhip_prove_sha256_machine(self.handle, key.handle, m.ctypes.data_as(u8p), len(message), C.byref(params), digest.ctypes.data_as(u8p),
+                                                  buf.ctypes.data_as(u8p), size, C.byref(got)))
+        return digest.tobytes(), buf[: got.value]
+
     def quotient_values_air(self, program, lde, log_n, width, public_values, alpha, out=None, log_quotient_degree=1):
         out = out or self.alloc(4 << (log_n + log_quotient_degree))
         prog = np.ascontiguousarray(program, dtype=np.uint32)
@@ -635,6 +657,17 @@ def verify_sha256(proof, digest, params=None):
     dg = np.frombuffer(bytes(digest), dtype=np.uint8)
     reason = C.c_int(0)
     rc = lib.zkhip_verify_sha256(pr.ctypes.data_as(u8p), pr.size, dg.ctypes.data_as(u8p), C.byref(params), C.byref(reason))
+    return rc, reason.value
+
+
+def verify_sha256_machine(proof, digest, vk, params=None):
+    params = params or Params(1, 100, 16)
+    lib = _lib.load()
+    pr = np.ascontiguousarray(proof, dtype=np.uint8)
+    dg = np.frombuffer(bytes(digest), dtype=np.uint8)
+    k = np.ascontiguousarray(np.array(vk, dtype=np.uint32))
+    reason = C.c_int(0)
+    rc = lib.zkhip_verify_sha256_machine(pr.ctypes.data_as(u8p), pr.size, dg.ctypes.data_as(u8p), k.ctypes.data_as(u32p), C.byref(params), C.byref(reason))
     return rc, reason.value
 
 
