@@ -3,6 +3,7 @@
 errors returned (never thrown across the boundary), request digest determinism."""
 import ctypes as C
 import os
+import struct
 
 import numpy as np
 import pytest
@@ -310,3 +311,101 @@ def test_commitment_guest_proves_the_reference_transcript(lib, backend):
     assert verify_sha256(proof, out, prm) == (0, 0)
     other = hashlib.sha256(cbor + b"x").digest()
     assert verify_sha256(proof, other, prm)[0] == -6
+
+
+# ---- setup -> prove -> verify (sp1.rs:113, :116, :120): the input-commitment guest as a keyed machine (HipGuestProver::setup)
+def call_commitment_keyed(L, mode, cbor, elf, queries=20, pow_bits=6, device=0):
+    L.zktls_guest_prove_commitment_keyed.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, C.c_char_p, C.c_size_t, C.c_char_p, C.c_size_t,
+                                                     C.POINTER(C.POINTER(C.c_uint8)), C.POINTER(C.c_size_t), C.POINTER(C.POINTER(C.c_uint8)),
+                                                     C.POINTER(C.c_size_t), C.c_char_p, C.c_char_p, C.c_size_t]
+    out, outn, pr, prn = C.POINTER(C.c_uint8)(), C.c_size_t(), C.POINTER(C.c_uint8)(), C.c_size_t()
+    err, vk = C.create_string_buffer(512), C.create_string_buffer(64)
+    rc = L.zktls_guest_prove_commitment_keyed(device, mode, queries, pow_bits, cbor, len(cbor), elf, len(elf),
+                                              C.byref(out), C.byref(outn), C.byref(pr), C.byref(prn), vk, err, 512)
+    if rc != 0:
+        return rc, err.value.decode(), None, None, None
+    o = bytes(bytearray(out[i] for i in range(outn.value)))
+    p = bytes(bytearray(pr[i] for i in range(prn.value)))
+    L.zktls_free(out)
+    L.zktls_free(pr)
+    return 0, "", o, p, vk.raw
+
+
+def verify_blob(L, blob, output, vk, queries=20, pow_bits=6):
+    L.zktls_verify_commitment_blob.argtypes = [C.c_char_p, C.c_size_t, C.c_char_p, C.c_char_p, C.c_size_t, C.c_int, C.c_int, C.POINTER(C.c_int)]
+    reason = C.c_int(0)
+    rc = L.zktls_verify_commitment_blob(blob, len(blob), output, vk, len(vk) if vk else 0, queries, pow_bits, C.byref(reason))
+    return rc, reason.value
+
+
+def program_digest_bytes(elf):
+    from zktls_amd import _lib
+    u32p = C.POINTER(C.c_uint32)
+    dg = (C.c_uint32 * 8)()
+    L = _lib.load()
+    L.zkhip_request_digest.argtypes = [C.c_char_p, C.c_size_t, C.c_char_p, C.c_size_t, u32p]
+    assert L.zkhip_request_digest(b"", 0, elf, len(elf), dg) == 0
+    return struct.pack("<8I", *dg)
+
+
+def test_setup_in_mock_mode_returns_the_program_digest(lib):
+    import hashlib
+    cbor = open(os.path.join(REF, "guest_input0.cbor"), "rb").read()
+    elf = b"\x7fELFguest"
+    rc, err, out, proof, vk = call_commitment_keyed(lib, 0, cbor, elf)
+    assert rc == 0 and proof == b"" and out == hashlib.sha256(cbor).digest()
+    assert vk[:32] == bytes(32) and vk[32:] == program_digest_bytes(elf)
+    rc, err, *_ = call_commitment_keyed(lib, 3, cbor, elf)                      # network
+    assert rc != 0 and "network" in err
+    rc, err, *_ = call_commitment_keyed(lib, 0, cbor, b"")
+    assert rc != 0 and "empty" in err
+
+
+def test_a_consumer_checks_a_keyed_commitment_blob_on_the_cpu(lib, oracle):
+    """what a holder of (output, proof blob, vk) does without a GPU: the blob here is built from the ORACLE's proof of the same machine
+    (tests/machines.py: sha256_machine), the vk from the oracle's setup"""
+    import hashlib
+    import machines as M
+    O = oracle
+    msg = bytes(range(200)) * 3
+    tr, pre, pg, tb, pub = M.sha256_machine(msg)
+    lns = [t.shape[0].bit_length() - 1 for t in tr]
+    oprm = O.default_params(1, 8, 4)
+    root = O.machine_setup(pre, lns, oprm)
+    proof = O.prove_machine_keyed(tr, pre, pg, tb, pub, oprm).tobytes()
+    blob = struct.pack("<4sIII", b"ZKTB", 2, 2 | 4, 1) + struct.pack("<I", len(proof)) + proof
+    assert lib.zktls_batch_flags(blob, len(blob)) == 6
+    vk = struct.pack("<8I", *[int(v) for v in root]) + program_digest_bytes(b"\x7fELFguest")
+    out = hashlib.sha256(msg).digest()
+    assert verify_blob(lib, blob, out, vk, 8, 4) == (0, 0)
+    assert verify_blob(lib, blob, hashlib.sha256(msg + b"x").digest(), vk, 8, 4)[0] == -6
+    other = bytearray(vk)
+    other[1] ^= 1
+    assert verify_blob(lib, blob, out, bytes(other), 8, 4) == (-6, 3)           # another key
+    assert verify_blob(lib, blob, out, None, 8, 4)[0] == -1                     # a keyed blob needs its vk
+    unkeyed = struct.pack("<4sIII", b"ZKTB", 2, 2, 1) + struct.pack("<I", len(proof)) + proof
+    assert verify_blob(lib, unkeyed, out, vk, 8, 4)[0] != 0                     # the machine's proof is not a single-chip proof
+
+
+@pytest.mark.gpu
+def test_setup_prove_verify_on_the_reference_transcript(lib, oracle):
+    """the recorded 13 217-byte transcript through setup -> prove -> verify: vk = the oracle's commitment to the range table, the blob's
+    proof = the oracle's proof of the same machine byte for byte; a second request reuses the parked proving key"""
+    import hashlib
+    import machines as M
+    O = oracle
+    cbor = open(os.path.join(REF, "guest_input0.cbor"), "rb").read()
+    elf = b"\x7fELFguest"
+    rc, err, out, blob, vk = call_commitment_keyed(lib, 2, cbor, elf)
+    assert rc == 0, err
+    assert out == hashlib.sha256(cbor).digest() and lib.zktls_batch_flags(blob, len(blob)) == 6
+    assert verify_blob(lib, blob, out, vk) == (0, 0)
+    tr, pre, pg, tb, pub = M.sha256_machine(cbor)
+    lns = [t.shape[0].bit_length() - 1 for t in tr]
+    oprm = O.default_params(1, 20, 6)
+    assert vk[:32] == struct.pack("<8I", *[int(v) for v in O.machine_setup(pre, lns, oprm)]) and vk[32:] == program_digest_bytes(elf)
+    offs, lens = (C.c_size_t * 2)(), (C.c_size_t * 2)()
+    assert lib.zktls_unpack_batch(blob, len(blob), offs, lens, 2) == 1
+    assert blob[offs[0]:offs[0] + lens[0]] == O.prove_machine_keyed(tr, pre, pg, tb, pub, oprm).tobytes()
+    rc, err, out2, blob2, vk2 = call_commitment_keyed(lib, 2, cbor + b"more", elf)
+    assert rc == 0 and vk2 == vk and verify_blob(lib, blob2, out2, vk) == (0, 0) and out2 == hashlib.sha256(cbor + b"more").digest()

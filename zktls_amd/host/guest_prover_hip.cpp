@@ -76,7 +76,7 @@ bool unpack_shard_proofs(const std::vector<uint8_t>& blob, std::vector<std::vect
 namespace {
 // A worker's context and trace buffer.  Creating and freeing a context (stream + multi-GiB workspaces) costs more than a proof,
 // and a prover serves many requests, so finished workers park them in a process-wide pool (zktls_release_cached frees it).
-struct Slot { int device; size_t trace_bytes; zkhip_ctx* ctx; void* d_trace; };
+struct Slot { int device; size_t trace_bytes; zkhip_ctx* ctx; void* d_trace; zkhip_machine_key* key; uint32_t key_root[8]; };
 std::mutex g_slots_mu;
 std::vector<Slot> g_slots;
 struct CtxGuard {
@@ -84,12 +84,15 @@ struct CtxGuard {
     size_t trace_bytes = 0;
     zkhip_ctx* ctx = nullptr;
     void* d_trace = nullptr;
+    zkhip_machine_key* key = nullptr;   // the SHA-256 machine's proving key made on this context (setup), parked with it
+    uint32_t key_root[8] = {0};
     bool healthy = false;               // set once the worker finished without an error: only then is the slot reused
     bool take(int dev, size_t bytes) {
         std::lock_guard<std::mutex> lk(g_slots_mu);
         for (size_t i = 0; i < g_slots.size(); i++)
             if (g_slots[i].device == dev && g_slots[i].trace_bytes == bytes) {
                 ctx = g_slots[i].ctx; d_trace = g_slots[i].d_trace; device = dev; trace_bytes = bytes;
+                key = g_slots[i].key; std::memcpy(key_root, g_slots[i].key_root, sizeof key_root);
                 g_slots.erase(g_slots.begin() + (long)i);
                 return true;
             }
@@ -98,9 +101,12 @@ struct CtxGuard {
     ~CtxGuard() {
         if (healthy && ctx && d_trace) {
             std::lock_guard<std::mutex> lk(g_slots_mu);
-            g_slots.push_back(Slot{device, trace_bytes, ctx, d_trace});
+            Slot s{device, trace_bytes, ctx, d_trace, key, {0}};
+            std::memcpy(s.key_root, key_root, sizeof key_root);
+            g_slots.push_back(s);
             return;
         }
+        if (key) zkhip_machine_key_destroy(key);
         if (ctx && d_trace) zkhip_free(ctx, d_trace);
         if (ctx) zkhip_ctx_destroy(ctx);
     }
@@ -124,6 +130,54 @@ ProveResult HipGuestProver::prove(const GuestInput& input, const std::vector<uin
     }
     if (r.ok && r.proof.size() <= 4) r.proof.clear();   // sp1.rs:128-130
     return r;
+}
+
+SetupResult HipGuestProver::setup(const std::vector<uint8_t>& guest_program) {
+    SetupResult s;
+    try {
+        if (guest_program.empty()) throw std::runtime_error("guest program is empty");
+        if (!commitment_) throw std::runtime_error("setup: only the input-commitment guest has preprocessed tables (with_input_commitment())");
+        if (backend_ != Backend::Sp1) throw std::runtime_error("setup: the keyed machine uses the SP1 proof shape");
+        if (mode_ == ProverType::Network) throw std::runtime_error("network proving is not provided by the HIP backend");
+        std::vector<uint8_t> vk(64, 0);
+        const std::vector<uint32_t> pd = request_digest({}, guest_program);
+        std::memcpy(vk.data() + 32, pd.data(), 32);
+        if (mode_ != ProverType::Mock) {
+            if (devices_.empty()) throw std::runtime_error("device list is empty");
+            const zkhip_params prm{1, plan_.num_queries, plan_.pow_bits, 0, 0, 0, 0, 0};
+            CtxGuard g;
+            constexpr size_t PLACEHOLDER = 256;
+            if (!g.take(devices_[0], PLACEHOLDER)) {
+                g.device = devices_[0]; g.trace_bytes = PLACEHOLDER;
+                if (zkhip_ctx_create(devices_[0], nullptr, &g.ctx) != ZKHIP_OK) fail_zkhip("zkhip_ctx_create");
+                if (zkhip_malloc(g.ctx, PLACEHOLDER, &g.d_trace) != ZKHIP_OK) fail_zkhip("zkhip_malloc");
+            }
+            if (!g.key && zkhip_sha256_setup(g.ctx, &prm, &g.key, g.key_root) != ZKHIP_OK) fail_zkhip("zkhip_sha256_setup");
+            g.healthy = true;
+            std::memcpy(vk.data(), g.key_root, 32);
+        }
+        vk_ = vk;
+        s.vk = vk;
+        s.ok = true;
+    } catch (const std::exception& e) {
+        s = SetupResult{};
+        s.error = e.what();
+    }
+    return s;
+}
+
+int verify_commitment_blob(const std::vector<uint8_t>& blob, const std::vector<uint8_t>& output, const std::vector<uint8_t>& vk,
+                           int num_queries, int pow_bits, int* reason) {
+    std::vector<std::vector<uint8_t>> proofs;
+    uint32_t flags = 0;
+    if (reason) *reason = 0;
+    if (!unpack_shard_proofs(blob, &proofs, &flags) || proofs.size() != 1 || !(flags & BATCH_FLAG_INPUT_SHA256) || output.size() != 32) return -1;
+    const zkhip_params prm{1, num_queries, pow_bits, 0, 0, 0, 0, 0};
+    if (flags & BATCH_FLAG_KEYED) {
+        if (vk.size() != 64) return -1;
+        return zkhip_verify_sha256_machine(proofs[0].data(), proofs[0].size(), output.data(), (const uint32_t*)vk.data(), &prm, reason);
+    }
+    return zkhip_verify_sha256(proofs[0].data(), proofs[0].size(), output.data(), &prm, reason);
 }
 
 ProveResult HipGuestProver::prove_inner(const GuestInput& input, const std::vector<uint8_t>& elf) {
@@ -156,7 +210,13 @@ ProveResult HipGuestProver::prove_inner(const GuestInput& input, const std::vect
             const bool defaults = plan_.num_queries == 100 && plan_.pow_bits == 16;
             prm = zkhip_params{2, defaults ? 50 : plan_.num_queries, defaults ? 0 : plan_.pow_bits, 0, 4, lf, 24, 0};
         }
-        const size_t cap = zkhip_sha256_proof_size(input.cbor.size(), &prm);
+        const bool keyed = !vk_.empty();
+        if (keyed) {
+            if (backend_ != Backend::Sp1) throw std::runtime_error("setup: the keyed machine uses the SP1 proof shape");
+            const std::vector<uint32_t> pd = request_digest({}, elf);
+            if (std::memcmp(vk_.data() + 32, pd.data(), 32) != 0) throw std::runtime_error("prove: the guest program is not the one setup() was called with");
+        }
+        const size_t cap = keyed ? zkhip_sha256_machine_proof_size(input.cbor.size(), &prm) : zkhip_sha256_proof_size(input.cbor.size(), &prm);
         if (cap == 0) throw std::runtime_error(std::string("input commitment: ") + zkhip_last_error());
         // a parked context when there is one (the chip keeps its trace in the context's own workspaces: a 256-byte placeholder
         // stands in for the trace buffer the pool is keyed by)
@@ -170,13 +230,27 @@ ProveResult HipGuestProver::prove_inner(const GuestInput& input, const std::vect
         std::vector<uint8_t> proof(cap);
         size_t len = 0;
         uint8_t digest32[32];
-        if (zkhip_prove_sha256(g.ctx, input.cbor.data(), input.cbor.size(), &prm, digest32, proof.data(), cap, &len) != ZKHIP_OK) fail_zkhip("zkhip_prove_sha256");
-        g.healthy = true;
-        proof.resize(len);
         int reason = 0;
-        if (zkhip_verify_sha256(proof.data(), proof.size(), digest32, &prm, &reason) != ZKHIP_OK) fail_zkhip("zkhip_verify_sha256");
+        if (keyed) {
+            // pk: this context's key, made on first use (the commitment is a function of the proof shape alone: every context arrives
+            // at the vk setup() returned, which is checked)
+            if (!g.key && zkhip_sha256_setup(g.ctx, &prm, &g.key, g.key_root) != ZKHIP_OK) fail_zkhip("zkhip_sha256_setup");
+            if (std::memcmp(g.key_root, vk_.data(), 32) != 0) throw std::runtime_error("prove: this context's key does not match the verifying key of setup()");
+            if (zkhip_prove_sha256_machine(g.ctx, g.key, input.cbor.data(), input.cbor.size(), &prm, digest32, proof.data(), cap, &len) != ZKHIP_OK)
+                fail_zkhip("zkhip_prove_sha256_machine");
+            g.healthy = true;
+            proof.resize(len);
+            if (zkhip_verify_sha256_machine(proof.data(), proof.size(), digest32, (const uint32_t*)vk_.data(), &prm, &reason) != ZKHIP_OK)   // sp1.rs:120
+                fail_zkhip("zkhip_verify_sha256_machine");
+            r.vk = vk_;
+        } else {
+            if (zkhip_prove_sha256(g.ctx, input.cbor.data(), input.cbor.size(), &prm, digest32, proof.data(), cap, &len) != ZKHIP_OK) fail_zkhip("zkhip_prove_sha256");
+            g.healthy = true;
+            proof.resize(len);
+            if (zkhip_verify_sha256(proof.data(), proof.size(), digest32, &prm, &reason) != ZKHIP_OK) fail_zkhip("zkhip_verify_sha256");
+        }
         r.output.assign(digest32, digest32 + 32);
-        r.proof = pack_shard_proofs({proof}, BATCH_FLAG_INPUT_SHA256);
+        r.proof = pack_shard_proofs({proof}, BATCH_FLAG_INPUT_SHA256 | (keyed ? BATCH_FLAG_KEYED : 0u));
         r.ok = true;
         return r;
     }
@@ -273,7 +347,7 @@ ProveResult HipGuestProver::prove_inner(const GuestInput& input, const std::vect
 void release_cached() {
     std::vector<Slot> all;
     { std::lock_guard<std::mutex> lk(g_slots_mu); all.swap(g_slots); }
-    for (auto& e : all) { zkhip_free(e.ctx, e.d_trace); zkhip_ctx_destroy(e.ctx); }
+    for (auto& e : all) { if (e.key) zkhip_machine_key_destroy(e.key); zkhip_free(e.ctx, e.d_trace); zkhip_ctx_destroy(e.ctx); }
 }
 
 }  // namespace zktls
@@ -367,6 +441,44 @@ int zktls_guest_prove_commitment(int backend, int device, int mode, int num_quer
     *proof = (uint8_t*)std::malloc(r.proof.size() ? r.proof.size() : 1);
     std::memcpy(*proof, r.proof.data(), r.proof.size());
     return 0;
+}
+// setup -> prove -> verify as the reference calls them (sp1.rs:113, :116, :120) on the input-commitment guest, SP1 backend: vk_out
+// receives the 64-byte verifying key, the blob is flagged INPUT_SHA256 | KEYED
+int zktls_guest_prove_commitment_keyed(int device, int mode, int num_queries, int pow_bits, const uint8_t* cbor, size_t cbor_len,
+                                       const uint8_t* elf, size_t elf_len, uint8_t** output, size_t* output_len, uint8_t** proof,
+                                       size_t* proof_len, uint8_t vk_out[64], char* err, size_t err_cap) {
+    zktls::HipGuestProver p(device < 0 ? 0 : device, zktls::Backend::Sp1);
+    switch (mode) {
+        case 0: p.mock(); break;
+        case 1: p.local(); break;
+        case 2: p.hip(); break;
+        default: p.network(); break;
+    }
+    zktls::ShardPlan sp;
+    sp.num_queries = num_queries; sp.pow_bits = pow_bits;
+    p.with_input_commitment(sp);
+    const std::vector<uint8_t> program(elf, elf + elf_len);
+    auto report = [&](const std::string& e) { if (err && err_cap) { std::strncpy(err, e.c_str(), err_cap - 1); err[err_cap - 1] = 0; } return -1; };
+    const zktls::SetupResult s = p.setup(program);
+    if (!s.ok) return report(s.error);
+    zktls::GuestInput in;
+    in.cbor.assign(cbor, cbor + cbor_len);
+    zktls::ProveResult r = p.prove(in, program);
+    if (!r.ok) return report(r.error);
+    if (vk_out) std::memcpy(vk_out, s.vk.data(), 64);
+    *output_len = r.output.size();
+    *output = (uint8_t*)std::malloc(r.output.size() ? r.output.size() : 1);
+    std::memcpy(*output, r.output.data(), r.output.size());
+    *proof_len = r.proof.size();
+    *proof = (uint8_t*)std::malloc(r.proof.size() ? r.proof.size() : 1);
+    std::memcpy(*proof, r.proof.data(), r.proof.size());
+    return 0;
+}
+int zktls_verify_commitment_blob(const uint8_t* blob, size_t len, const uint8_t output[32], const uint8_t* vk, size_t vk_len, int num_queries,
+                                 int pow_bits, int* reason) {
+    if (!blob || !output) return -1;
+    return zktls::verify_commitment_blob(std::vector<uint8_t>(blob, blob + len), std::vector<uint8_t>(output, output + 32),
+                                         vk ? std::vector<uint8_t>(vk, vk + vk_len) : std::vector<uint8_t>(), num_queries, pow_bits, reason);
 }
 void zktls_free(void* p) { std::free(p); }
 const char* zktls_current_risc0_prover_env(void) { const char* e = getenv("RISC0_PROVER"); return e ? e : ""; }

@@ -54,6 +54,16 @@ struct ProveResult {
     std::string error;               // anyhow-style message when !ok
     std::vector<uint8_t> output;     // public values
     std::vector<uint8_t> proof;      // empty when the backend produced <= 4 bytes (mock)
+    std::vector<uint8_t> vk;         // after setup(): the verifying key the proof was checked against (64 bytes, see SetupResult)
+};
+
+// `let (pk, vk) = client.setup(guest_program)` (sp1.rs:113).  The proving key stays inside the prover (device-resident preprocessed
+// traces, their LDEs and Merkle tree: zkhip_machine_key, parked with the worker's context); vk is what a verifier needs:
+// 8 LE words = the commitment to the machine's preprocessed tables, then 8 LE words = zkhip_request_digest("", guest_program).
+struct SetupResult {
+    bool ok = false;
+    std::string error;
+    std::vector<uint8_t> vk;
 };
 
 class ZkProver {
@@ -88,6 +98,10 @@ public:
     ProverType mode() const { return mode_; }
     Backend backend() const { return backend_; }
     ProveResult prove(const GuestInput& input, const std::vector<uint8_t>& guest_program) override;
+    // sp1.rs:113.  For the input-commitment guest on the SP1 backend: commits the SHA-256 machine's range table on the device (once per
+    // parked context) and switches prove() to the keyed machine (chip + table, proof version 11, blob flag KEYED), verified against vk
+    // like sp1.rs:120.  Mock mode returns the program digest with a zero commitment.  Other guests have no preprocessed tables: an error.
+    SetupResult setup(const std::vector<uint8_t>& guest_program);
 
 private:
     ProveResult prove_inner(const GuestInput& input, const std::vector<uint8_t>& guest_program);
@@ -97,6 +111,7 @@ private:
     ShardPlan plan_;
     bool synthetic_ = false;
     bool commitment_ = false;
+    std::vector<uint8_t> vk_;              // non-empty after setup()
 };
 
 // prover.rs:30-57: `Risc0GuestProver::default().local()` etc.; segments are proven in RISC Zero's shape
@@ -116,6 +131,11 @@ std::vector<uint32_t> request_digest(const std::vector<uint8_t>& cbor, const std
 // then per shard (u32 length, bytes)
 constexpr uint32_t BATCH_FLAG_SYNTHETIC = 1u;
 constexpr uint32_t BATCH_FLAG_INPUT_SHA256 = 2u;     // one proof of the SHA-256 chip over the request's input bytes
+constexpr uint32_t BATCH_FLAG_KEYED = 4u;            // with INPUT_SHA256: the proof is the keyed SHA-256 MACHINE's (chip + range table), checked against a vk
+// a consumer's check of an input-commitment blob on the CPU: the blob's one proof against the claimed output (SHA-256 of the input);
+// `vk` (64 bytes from setup) is required for KEYED blobs.  -> 0 or a negative value; *reason as the zkhip verifiers
+int verify_commitment_blob(const std::vector<uint8_t>& blob, const std::vector<uint8_t>& output, const std::vector<uint8_t>& vk,
+                           int num_queries, int pow_bits, int* reason = nullptr);
 std::vector<uint8_t> pack_shard_proofs(const std::vector<std::vector<uint8_t>>& proofs, uint32_t flags);
 bool unpack_shard_proofs(const std::vector<uint8_t>& blob, std::vector<std::vector<uint8_t>>* proofs, uint32_t* flags = nullptr);
 
