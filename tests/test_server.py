@@ -153,3 +153,43 @@ def test_prove_core_input_commitment_guest(server):
     ln = struct.unpack_from("<I", blob, 16)[0]
     assert 20 + ln == len(blob)
     assert verify_sha256(np.frombuffer(blob[20:], dtype=np.uint8), output, Params(1, 16, 5)) == (0, 0)
+
+
+def prove_payload_v2(shards, queries, pow_bits, cbor, elf, flags, backend=0, device=0):
+    return (b"ZKMG" + struct.pack("<IiIIiiIiI", 2, 0, 0, shards, queries, pow_bits, backend, device, flags)
+            + struct.pack("<I", len(cbor)) + cbor + struct.pack("<I", len(elf)) + elf)
+
+
+def test_prove_core_v2_argument_checks(server):
+    for payload in (prove_payload_v2(1, 10, 4, b"in", b"elf", 1),            # KEYED with shards > 0
+                    prove_payload_v2(0, 10, 4, b"in", b"elf", 1, backend=1),   # KEYED in the RISC Zero shape
+                    prove_payload_v2(0, 10, 4, b"in", b"elf", 2)):             # unknown flag
+        st, ct, body = call(server, "ProveCore", pb_bytes(payload))
+        assert st == 400 and json.loads(body)["code"] == "invalid_argument"
+
+
+@pytest.mark.gpu
+def test_prove_core_keyed_commitment_guest(server):
+    """payload version 2 with KEYED: setup -> prove -> verify in the server; the response carries the 64-byte vk a CPU-only client needs"""
+    import ctypes as C
+    import hashlib
+    L = C.CDLL(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "zktls_amd", "libzktls_guest_prover.so"))
+    L.zktls_verify_commitment_blob.argtypes = [C.c_char_p, C.c_size_t, C.c_char_p, C.c_char_p, C.c_size_t, C.c_int, C.c_int, C.POINTER(C.c_int)]
+    cbor = bytes((5 * i + 2) & 0xff for i in range(7000))
+    st, ct, body = call(server, "ProveCore", pb_bytes(prove_payload_v2(0, 16, 5, cbor, b"\x7fELFguest", 1)))
+    assert st == 200, body
+    res = pb_field1(body)
+    on = struct.unpack_from("<I", res)[0]
+    output = res[4:4 + on]
+    vn = struct.unpack_from("<I", res, 4 + on)[0]
+    vk, blob = res[8 + on:8 + on + vn], res[8 + on + vn:]
+    assert output == hashlib.sha256(cbor).digest() and vn == 64
+    assert struct.unpack_from("<4I", blob) == (0x42544B5A, 2, 6, 1)                # INPUT_SHA256 | KEYED
+    reason = C.c_int(0)
+    assert L.zktls_verify_commitment_blob(blob, len(blob), output, vk, 64, 16, 5, C.byref(reason)) == 0
+    assert L.zktls_verify_commitment_blob(blob, len(blob), hashlib.sha256(b"x").digest(), vk, 64, 16, 5, C.byref(reason)) != 0
+    # version 2 without the flag: the plain chip proof, an empty vk
+    st, ct, body = call(server, "ProveCore", pb_bytes(prove_payload_v2(0, 16, 5, cbor, b"\x7fELFguest", 0)))
+    res = pb_field1(body)
+    on = struct.unpack_from("<I", res)[0]
+    assert st == 200 and struct.unpack_from("<I", res, 4 + on)[0] == 0 and struct.unpack_from("<4I", res, 8 + on) == (0x42544B5A, 2, 2, 1)

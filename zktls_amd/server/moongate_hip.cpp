@@ -19,6 +19,9 @@
 //                                                               (zktls_amd/host): flagged SYNTHETIC for shards > 0; shards = 0 asks for the
 //                                                               input-commitment guest (SHA-256 chip over the CBOR input, flag INPUT_SHA256,
 //                                                               output = the digest; log_n / width are ignored)
+//                  version 2 = version 1 + u32 flags after `device` (bit 0 KEYED: shards must be 0; the mirror's setup() runs first -- the
+//                         reference's setup -> prove -> verify, sp1.rs:113-120 -- and the commitment guest is proven as the keyed SHA-256
+//                         machine)       -> result = u32 output length | output | u32 vk length | vk (64 bytes, or 0) | batch blob
 //       Compress / Shrink / Wrap                             -> Twirp error `unimplemented` (recursion is out of scope)
 //     Swapping in upstream's payload structs is the remaining work once they can be read; the transport does not change.
 // One request at a time per connection, connections served one after the other (proofs serialise on the GPU anyway); 127.0.0.1 only
@@ -180,19 +183,30 @@ void handle(int fd) {
         return;
     }
     Cursor c{data};
-    if (c.u32() != 0x474D4B5Au || c.u32() != 1u) { twirp_error(fd, "invalid_argument", "ProveCore: payload must start with \"ZKMG\", version 1 (see moongate_hip.cpp)"); return; }
+    const uint32_t magic = c.u32(), version = c.u32();
+    if (magic != 0x474D4B5Au || (version != 1u && version != 2u)) { twirp_error(fd, "invalid_argument", "ProveCore: payload must start with \"ZKMG\", version 1 or 2 (see moongate_hip.cpp)"); return; }
     zktls::ShardPlan plan;
     plan.log_n = (int)c.u32(); plan.width = c.u32(); plan.shards = c.u32(); plan.num_queries = (int)c.u32(); plan.pow_bits = (int)c.u32();
     const uint32_t backend = c.u32();
     const int device = (int)c.u32();
+    const uint32_t flags = version >= 2 ? c.u32() : 0u;
     zktls::GuestInput in;
     in.cbor = c.blob();
     const std::vector<uint8_t> elf = c.blob();
-    if (!c.ok || c.p != data.size() || backend > 1) { twirp_error(fd, "invalid_argument", "ProveCore: truncated or oversized payload"); return; }
+    if (!c.ok || c.p != data.size() || backend > 1 || flags > 1) { twirp_error(fd, "invalid_argument", "ProveCore: truncated or oversized payload"); return; }
+    if ((flags & 1u) && (plan.shards != 0 || backend != 0)) { twirp_error(fd, "invalid_argument", "ProveCore: KEYED asks for the input-commitment guest (shards = 0) in the SP1 shape"); return; }
     zktls::HipGuestProver prover(device < 0 ? 0 : device, backend ? zktls::Backend::Risc0 : zktls::Backend::Sp1);
     if (device < 0) { std::vector<int> all; for (int d = 0; d < zkhip_device_count(); d++) all.push_back(d); if (!all.empty()) prover.with_devices(all); }
     if (plan.shards == 0) prover.hip().with_input_commitment(plan);
     else prover.hip().with_synthetic(plan);
+    if (flags & 1u) {
+        const zktls::SetupResult s = prover.setup(elf);                                // sp1.rs:113
+        if (!s.ok) {
+            const bool nodev = s.error.find("no CPU fallback") != std::string::npos || s.error.find("NO_DEVICE") != std::string::npos;
+            twirp_error(fd, nodev ? "unavailable" : "invalid_argument", s.error);
+            return;
+        }
+    }
     const zktls::ProveResult r = prover.prove(in, elf);
     if (!r.ok) {
         const bool nodev = r.error.find("no CPU fallback") != std::string::npos || r.error.find("NO_DEVICE") != std::string::npos;
@@ -204,6 +218,11 @@ void handle(int fd) {
     const uint32_t on = (uint32_t)r.output.size();
     res.insert(res.end(), (const uint8_t*)&on, (const uint8_t*)&on + 4);
     res.insert(res.end(), r.output.begin(), r.output.end());
+    if (version >= 2) {
+        const uint32_t vn = (uint32_t)r.vk.size();
+        res.insert(res.end(), (const uint8_t*)&vn, (const uint8_t*)&vn + 4);
+        res.insert(res.end(), r.vk.begin(), r.vk.end());
+    }
     res.insert(res.end(), r.proof.begin(), r.proof.end());
     const std::vector<uint8_t> msg = pb_bytes1(res);
     respond(fd, 200, "OK", "application/protobuf", msg.data(), msg.size());
