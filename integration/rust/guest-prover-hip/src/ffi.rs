@@ -111,6 +111,33 @@ extern "C" {
         proof: *mut u8, cap: usize, len: *mut usize,
     ) -> c_int;
     pub fn zkhip_verify_sha256(proof: *const u8, len: usize, digest: *const u8, prm: *const ZkhipParams, reason: *mut c_int) -> c_int;
+    // setup -> prove -> verify (sp1.rs:113, :116, :120): preprocessed columns committed once, the key's root is the verifying key
+    pub fn zkhip_machine_setup(ctx: *mut ZkhipCtx, pre: *const ZkhipChip, n_chips: c_int, prm: *const ZkhipParams, key: *mut *mut ZkhipMachineKey, root: *mut u32) -> c_int;
+    pub fn zkhip_machine_key_destroy(key: *mut ZkhipMachineKey);
+    pub fn zkhip_prove_machine_keyed(
+        ctx: *mut ZkhipCtx, key: *const ZkhipMachineKey, chips: *const ZkhipChip, programs: *const *const u32, program_words: *const usize,
+        tables: *const *const u32, table_words: *const usize, n_chips: c_int,
+        public_values: *const u32, n_public: usize, prm: *const ZkhipParams, proof: *mut u8, cap: usize, len: *mut usize,
+    ) -> c_int;
+    pub fn zkhip_verify_machine_keyed(
+        proof: *const u8, len: usize, log_ns: *const i32, widths: *const u32, pre_widths: *const u32, root: *const u32,
+        programs: *const *const u32, program_words: *const usize, tables: *const *const u32, table_words: *const usize, n_chips: c_int,
+        public_values: *const u32, n_public: usize, prm: *const ZkhipParams, reason: *mut c_int,
+    ) -> c_int;
+    // the SHA-256 guest as a keyed machine (chip + preprocessed range table)
+    pub fn zkhip_sha256_setup(ctx: *mut ZkhipCtx, prm: *const ZkhipParams, key: *mut *mut ZkhipMachineKey, vk: *mut u32) -> c_int;
+    pub fn zkhip_sha256_machine_proof_size(message_len: usize, prm: *const ZkhipParams) -> usize;
+    pub fn zkhip_prove_sha256_machine(
+        ctx: *mut ZkhipCtx, key: *const ZkhipMachineKey, message: *const u8, message_len: usize, prm: *const ZkhipParams, digest: *mut u8,
+        proof: *mut u8, cap: usize, len: *mut usize,
+    ) -> c_int;
+    pub fn zkhip_verify_sha256_machine(proof: *const u8, len: usize, digest: *const u8, vk: *const u32, prm: *const ZkhipParams, reason: *mut c_int) -> c_int;
+}
+
+/// opaque proving key of a keyed machine (zkhip_machine_key)
+#[repr(C)]
+pub struct ZkhipMachineKey {
+    _private: [u8; 0],
 }
 
 /// one table of a multi-chip shard (zkhip_chip)

@@ -76,16 +76,32 @@ pub struct HipGuestProver {
     source: Option<Box<dyn ShardSource>>,
     synthetic: Option<SyntheticShards>,
     commitment: bool,
+    vk: Option<Vec<u8>>,               // Some after setup()
+    keyed: Option<KeyedContext>,       // the proving key of setup() (None in mock mode)
 }
 
 /// batch blob header: "ZKTB", version 2, flags, shard count; then (u32 length, bytes) per shard
 pub const BATCH_FLAG_SYNTHETIC: u32 = 1;
 /// one proof of the SHA-256 chip over the request's input bytes (`with_input_commitment`)
 pub const BATCH_FLAG_INPUT_SHA256: u32 = 2;
+/// with INPUT_SHA256: the proof is the keyed SHA-256 machine's (chip + range table), to be checked against the vk of `setup`
+pub const BATCH_FLAG_KEYED: u32 = 4;
+
+/// the proving key of `setup`: a context and the machine key made on it (destroyed together, key first)
+pub struct KeyedContext {
+    ctx: Context,
+    key: *mut ffi::ZkhipMachineKey,
+}
+impl Drop for KeyedContext {
+    fn drop(&mut self) {
+        unsafe { ffi::zkhip_machine_key_destroy(self.key) };
+    }
+}
+unsafe impl Send for KeyedContext {}
 
 impl HipGuestProver {
     pub fn new(device: i32) -> Self {
-        Self { mode: ProverType::default(), backend: Backend::default(), device, source: None, synthetic: None, commitment: false }
+        Self { mode: ProverType::default(), backend: Backend::default(), device, source: None, synthetic: None, commitment: false, vk: None, keyed: None }
     }
     pub fn mock(mut self) -> Self { self.mode = ProverType::Mock; self }
     pub fn local(mut self) -> Self { self.mode = ProverType::Local; self }
@@ -129,6 +145,30 @@ impl ZkProver for HipGuestProver {
 }
 
 impl HipGuestProver {
+    /// `let (pk, vk) = client.setup(guest_program)` (sp1.rs:113) for the input-commitment guest: commits the SHA-256 machine's range table
+    /// on the device; the proving key stays in the prover, the returned 64 bytes are the verifying key (8 LE words commitment, 8 LE words
+    /// request digest of the program), as the C++ mirror's `HipGuestProver::setup`.  After it, `prove` produces the keyed machine's proof
+    /// (blob flags INPUT_SHA256 | KEYED) and checks it against this vk.
+    pub fn setup(&mut self, guest_program: &[u8]) -> Result<Vec<u8>> {
+        anyhow::ensure!(!guest_program.is_empty(), "guest program is empty");
+        anyhow::ensure!(self.commitment, "setup: only the input-commitment guest has preprocessed tables (with_input_commitment())");
+        let mut pd = [0u32; 8];
+        check(unsafe { ffi::zkhip_request_digest(std::ptr::null(), 0, guest_program.as_ptr(), guest_program.len(), pd.as_mut_ptr()) }, "zkhip_request_digest")?;
+        let mut vk = vec![0u8; 32];
+        if !matches!(self.mode, ProverType::Mock) {
+            anyhow::ensure!(!matches!(self.mode, ProverType::Network), "network proving is not provided by the HIP backend");
+            let ctx = Context::new(self.device)?;
+            let prm = self.params(16);
+            let (mut key, mut root) = (std::ptr::null_mut(), [0u32; 8]);
+            check(unsafe { ffi::zkhip_sha256_setup(ctx.raw(), &prm, &mut key, root.as_mut_ptr()) }, "zkhip_sha256_setup")?;
+            vk = root.iter().flat_map(|w| w.to_le_bytes()).collect();
+            self.keyed = Some(KeyedContext { ctx, key });                  // pk: lives as long as the prover
+        }
+        vk.extend(pd.iter().flat_map(|w| w.to_le_bytes()));
+        self.vk = Some(vk.clone());
+        Ok(vk)
+    }
+
     fn prove_blocking(&mut self, cbor: &[u8], elf: &[u8]) -> Result<(Vec<u8>, Vec<u8>)> {
         anyhow::ensure!(!elf.is_empty(), "guest program is empty");
         // the request digest: 8 canonical words = the leading public values of every shard and, without an executor, the
@@ -158,7 +198,25 @@ impl HipGuestProver {
         let ctx = Context::new(self.device)?;
         let start = std::time::Instant::now();
         let mut proofs: Vec<Vec<u8>> = Vec::new();
-        let (output, flags) = if self.commitment {
+        let (output, flags) = if self.commitment && self.vk.is_some() {
+            // after setup(): the keyed SHA-256 machine (chip + preprocessed range table), verified against the vk (sp1.rs:120)
+            let vk = self.vk.as_ref().unwrap();
+            let mut pd = [0u32; 8];
+            check(unsafe { ffi::zkhip_request_digest(std::ptr::null(), 0, elf.as_ptr(), elf.len(), pd.as_mut_ptr()) }, "zkhip_request_digest")?;
+            let pd_bytes: Vec<u8> = pd.iter().flat_map(|w| w.to_le_bytes()).collect();
+            anyhow::ensure!(vk[32..] == pd_bytes[..], "prove: the guest program is not the one setup() was called with");
+            let keyed = self.keyed.as_ref().ok_or_else(|| anyhow!("prove: setup() ran in mock mode"))?;
+            let prm = self.params(16);
+            let cap = unsafe { ffi::zkhip_sha256_machine_proof_size(cbor.len(), &prm) };
+            anyhow::ensure!(cap > 0, "input too long for the SHA-256 machine");
+            let (mut proof, mut len, mut d) = (vec![0u8; cap], 0usize, [0u8; 32]);
+            check(unsafe { ffi::zkhip_prove_sha256_machine(keyed.ctx.raw(), keyed.key, cbor.as_ptr(), cbor.len(), &prm, d.as_mut_ptr(), proof.as_mut_ptr(), cap, &mut len) }, "zkhip_prove_sha256_machine")?;
+            proof.truncate(len);
+            let mut reason = 0;
+            check(unsafe { ffi::zkhip_verify_sha256_machine(proof.as_ptr(), proof.len(), d.as_ptr(), vk.as_ptr() as *const u32, &prm, &mut reason) }, "zkhip_verify_sha256_machine")?;
+            proofs.push(proof);
+            (d.to_vec(), BATCH_FLAG_INPUT_SHA256 | BATCH_FLAG_KEYED)
+        } else if self.commitment {
             // 64 rows per 64-byte block, block count (padding included) rounded up to a power of two
             let blocks = (cbor.len() + 9 + 63) / 64;
             let log_n = 6 + (blocks.next_power_of_two().trailing_zeros() as i32);
