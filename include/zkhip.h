@@ -534,6 +534,20 @@ int zkhip_proof_to_bincode(const uint8_t* proof, size_t len, int log_n, uint32_t
 int zkhip_proof_from_bincode(const uint8_t* in, size_t len, int log_n, uint32_t width, const zkhip_params* prm, size_t n_public,
                              uint8_t* proof, size_t cap, size_t* out_len);
 
+/* The same for MULTI-CHIP proofs (versions 4-6, 9-11), in the shape of sp1-stark's `ShardProof` ([RECALLED]: reference Cargo.lock:6172 is not
+ * in /root/reference): commitment { main, permutation?, quotient }, opened_values.chips[ { preprocessed{local,next}, main{local,next},
+ * permutation{local,next}, quotient chunks, cumulative_sum, log_degree } ], opening_proof { fri_proof { commit_phase_commits,
+ * query_proofs[ commit_phase_openings[ { sibling_value, opening_proof } ] ], final_poly, pow_witness }, query_openings[ per query one
+ * BatchOpening { opened_values, opening_proof } per commitment round: preprocessed?, main, permutation?, quotient ] }, public_values --
+ * preceded by this library's header words as a `Vec<u32>` envelope (upstream takes that information from the machine and the vk).
+ * A multi-chip proof describes itself (its header names every chip), so no shape arguments: zkhip_chips_bincode_size(proof, len) is 0 for
+ * anything that is not a complete multi-chip proof.  Writer and reader are exact inverses; the reader rebuilds the flat proof and
+ * returns the public values (n_public receives their count).  Host code only. */
+size_t zkhip_chips_bincode_size(const uint8_t* proof, size_t len);
+int zkhip_chips_proof_to_bincode(const uint8_t* proof, size_t len, const uint32_t* public_values, size_t n_public, uint8_t* out, size_t cap, size_t* out_len);
+int zkhip_chips_proof_from_bincode(const uint8_t* in, size_t len, uint8_t* proof, size_t cap, size_t* out_len,
+                                   uint32_t* public_values, size_t public_cap, size_t* n_public);
+
 /* Request digest: 8 canonical BabyBear words binding the guest input (the CBOR bytes of sp1.rs:108-109 / prover.rs:81-82) and
  * the guest program (ELF): Poseidon2 overwrite-mode sponge over 3-byte limbs, fields length-prefixed.  The glue uses them as the
  * leading public values of every shard of the request, so a proof does not transfer to another request.  Host only. */

@@ -81,6 +81,13 @@ got = C.c_size_t(0)
 src = arr(p_single)
 assert L.zkhip_proof_to_bincode(src.ctypes.data_as(u8p), src.size, 6, 8, C.byref(prm), bc.ctypes.data_as(u8p), bc_size, C.byref(got)) == 0
 
+ksrc = arr(p_keyed)
+L.zkhip_chips_bincode_size.restype = C.c_size_t
+cbc = np.zeros(L.zkhip_chips_bincode_size(ksrc.ctypes.data_as(u8p), ksrc.size), dtype=np.uint8)
+kpv = np.array(kpub, dtype=np.uint32)
+assert L.zkhip_chips_proof_to_bincode(ksrc.ctypes.data_as(u8p), ksrc.size, kpv.ctypes.data_as(u32p), kpv.size, cbc.ctypes.data_as(u8p), cbc.size, C.byref(got)) == 0
+back2, pub2, got2 = np.zeros(len(p_keyed) + 64, dtype=np.uint8), np.zeros(8, dtype=np.uint32), C.c_size_t(0)
+
 t0, n = time.time(), 0
 while time.time() - t0 < budget:
     verify_shard(arr(mutate(p_single)), int(rng.choice([6, 6, 6, 5, 7])), int(rng.choice([8, 8, 4, 12])), [1, 2], prm)
@@ -101,5 +108,10 @@ while time.time() - t0 < budget:
     m = arr(mutate(bc.tobytes()))
     back = np.zeros(len(p_single) + 64, dtype=np.uint8)
     L.zkhip_proof_from_bincode(m.ctypes.data_as(u8p), m.size, 6, 8, C.byref(prm), 2, back.ctypes.data_as(u8p), int(rng.choice([back.size, 16, 0])), C.byref(got))
+    cm = arr(mutate(p_keyed if rng.random() < 0.5 else p_machine))
+    L.zkhip_chips_bincode_size(cm.ctypes.data_as(u8p), cm.size)
+    cb = arr(mutate(cbc.tobytes()))
+    L.zkhip_chips_proof_from_bincode(cb.ctypes.data_as(u8p), cb.size, back2.ctypes.data_as(u8p), int(rng.choice([back2.size, 64, 0])), C.byref(got),
+                                     pub2.ctypes.data_as(u32p), int(rng.choice([8, 0])), C.byref(got2))
     n += 1
-print("fuzz ok: %d rounds of 14 malformed calls in %.0f s (no crash; run under the sanitizer build for out-of-bounds reads)" % (n, time.time() - t0))
+print("fuzz ok: %d rounds of 16 malformed calls in %.0f s (no crash; run under the sanitizer build for out-of-bounds reads)" % (n, time.time() - t0))

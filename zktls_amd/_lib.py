@@ -28,6 +28,7 @@ EXPORTS = [
     "zkhip_batch_evaluate_any", "zkhip_gather_sample", "zkhip_scatter", "zkhip_prefix_products_ext", "zkhip_hash_rows_sha256",
     "zkhip_hash_fold_sha256", "zkhip_merkle_commit_sha256_colmajor",
     "zkhip_bincode_size", "zkhip_proof_to_bincode", "zkhip_proof_from_bincode",
+    "zkhip_chips_bincode_size", "zkhip_chips_proof_to_bincode", "zkhip_chips_proof_from_bincode",
     "zkhip_load_poseidon2_params", "zkhip_reset_poseidon2_params", "zkhip_poseidon2_params_name",
     "zkhip_air_validate", "zkhip_air_digest", "zkhip_air_synthetic", "zkhip_proof_size_air", "zkhip_prove_shard_air", "zkhip_verify_shard_air",
     "zkhip_quotient_values_air",
@@ -184,6 +185,10 @@ def load():
     L.zkhip_sha256_machine_proof_size.argtypes = [C.c_size_t, C.POINTER(Params)]
     L.zkhip_prove_sha256_machine.argtypes = [C.c_void_p, C.c_void_p, u8p, C.c_size_t, C.POINTER(Params), u8p, u8p, C.c_size_t, szp]
     L.zkhip_verify_sha256_machine.argtypes = [u8p, C.c_size_t, u8p, u32p, C.POINTER(Params), C.POINTER(C.c_int)]
+    L.zkhip_chips_bincode_size.restype = C.c_size_t
+    L.zkhip_chips_bincode_size.argtypes = [u8p, C.c_size_t]
+    L.zkhip_chips_proof_to_bincode.argtypes = [u8p, C.c_size_t, u32p, C.c_size_t, u8p, C.c_size_t, szp]
+    L.zkhip_chips_proof_from_bincode.argtypes = [u8p, C.c_size_t, u8p, C.c_size_t, szp, u32p, C.c_size_t, szp]
     L.zkhip_sha256_air.restype = C.c_size_t
     L.zkhip_sha256_air.argtypes = [u32p, C.c_size_t]
     L.zkhip_sha256_digest.restype = None

@@ -77,6 +77,99 @@ struct Reader {
     bool words(uint32_t* w, size_t n) { return raw(w, 4 * n); }
 };
 
+
+// ---- multi-chip proofs (versions 4-6, 9-11): the shape of sp1-stark's ShardProof [RECALLED] ----------------------------------------
+//   ChipsProof {
+//     header: Vec<u32>,                         -- THIS library's header words verbatim (version, shape, chip entries, program / table digests,
+//                                                  key root): an envelope, not part of upstream's ShardProof, which gets that information from the
+//                                                  machine and the verifying key
+//     commitment: ShardCommitment { main_commit: [u32; 8], permutation_commit: Option<[u32; 8]>, quotient_commit: [u32; 8] },
+//     opened_values: ShardOpenedValues { chips: Vec<ChipOpenedValues {
+//         preprocessed: AirOpenedValues { local: Vec<Ext>, next: Vec<Ext> },   -- empty without a key
+//         main: AirOpenedValues { local, next }, permutation: AirOpenedValues { local, next },
+//         quotient: Vec<Vec<Ext>>,                                             -- 2 chunks x 4 base columns
+//         cumulative_sum: Ext,                                                 -- zero for a chip without lookups
+//         log_degree: u64 }> },
+//     opening_proof: TwoAdicFriPcsProof {
+//         fri_proof: FriProof { commit_phase_commits: Vec<[u32; 8]>,
+//                               query_proofs: Vec<QueryProof { commit_phase_openings: Vec<CommitPhaseProofStep { sibling_value: Ext, opening_proof: Vec<[u32; 8]> }> }>,
+//                               final_poly: Ext, pow_witness: u32 },
+//         query_openings: Vec<Vec<BatchOpening { opened_values: Vec<Vec<u32>>, opening_proof: Vec<[u32; 8]> }>> },
+//                                               -- per query one BatchOpening per commitment round: [preprocessed], main, [permutation], quotient;
+//                                                  opened_values = one row per matrix of the round, chip order
+//     public_values: Vec<u32> }
+struct ChipsLayout {
+    uint32_t version = 0, n = 0, b = 0, Q = 0, pow_bits = 0, n_public = 0;
+    int log_ns[32]; uint32_t widths[32], pw[32]; size_t wp[32];
+    bool lk = false, cross = false, keyed = false;
+    size_t head = 0;                      // header words incl. digests and the key root
+    int Hmax = 0, L = 0, Hp = 0, He = 0;
+};
+// the flat proof describes itself: every count below comes from its header (validated: the words are untrusted)
+bool parse_chips_header(const uint32_t* pf, size_t words, ChipsLayout& C) {
+    if (words < 10 || pf[0] != 0x41544B5Au) return false;
+    C.version = pf[1]; C.n = pf[2]; C.b = pf[3]; C.Q = pf[4]; C.pow_bits = pf[5]; C.n_public = pf[6];
+    const uint32_t v = C.version;
+    if ((v != 4 && v != 5 && v != 6 && v != 9 && v != 10 && v != 11) || pf[7] != 16u) return false;
+    if (C.n < 1 || C.n > 32 || C.b < 1 || C.b > 3 || C.Q < 1 || C.Q > 4096 || C.pow_bits > 28 || C.n_public > 4096) return false;
+    const size_t per = v == 4 ? 2 : (v == 5 || v == 9 ? 3 : (v == 11 ? 5 : 4));
+    if (words < 8 + per * C.n) return false;
+    size_t p = 8, digests = 0;
+    for (uint32_t c = 0; c < C.n; c++) {
+        const uint32_t* e = pf + p; p += per;
+        if (e[0] < 5 || e[0] > 20 || e[1] == 0 || e[1] % 4 != 0 || e[1] > 1024 || (c && (int)e[0] > C.log_ns[c - 1])) return false;
+        C.log_ns[c] = (int)e[0]; C.widths[c] = e[1]; C.pw[c] = 0; C.wp[c] = 0;
+        if (v == 5 || v == 6) { if (e[2] > 64) return false; C.wp[c] = e[2] ? 4 * ((size_t)e[2] + 1) : 0; }
+        if (v == 6) { if (e[3] > C.n) return false; if (e[3]) C.cross = true; }
+        if (v == 9) { if (e[2] > 1) return false; digests += e[2]; }
+        if (v >= 10) {
+            if (e[2] > 1 || e[3] > 64) return false;
+            digests += e[2] + (e[3] ? 1 : 0);
+            C.wp[c] = e[3] ? 4 * (((size_t)e[3] + 1) / 2 + 1) : 0;
+            if (e[3]) C.cross = true;
+        }
+        if (v == 11) { if (e[4] % 4 != 0 || e[4] + e[1] > 1024) return false; C.pw[c] = e[4]; if (e[4]) C.keyed = true; }
+        if (C.wp[c]) { C.lk = true; if (C.log_ns[c] + (int)C.b > C.Hp) C.Hp = C.log_ns[c] + (int)C.b; }
+        if (C.pw[c] && C.log_ns[c] + (int)C.b > C.He) C.He = C.log_ns[c] + (int)C.b;
+    }
+    if (v == 11 && !C.keyed) return false;
+    C.head = p + 8 * digests + (v == 11 ? 8 : 0);
+    C.Hmax = C.log_ns[0] + (int)C.b; C.L = C.log_ns[0];
+    return C.head <= words;
+}
+size_t chips_flat_words(const ChipsLayout& C) {
+    size_t words = C.head + 16 + (C.lk ? 8 : 0) + 8 * (size_t)C.L + 4 + 1, perq = 16 * (size_t)C.Hmax + 8 * (size_t)C.Hp + 8 * (size_t)C.He;
+    for (uint32_t c = 0; c < C.n; c++) {
+        words += 8 * (size_t)C.pw[c] + 8 * (size_t)C.widths[c] + 8 * C.wp[c] + 32 + ((C.cross && C.wp[c]) ? 4 : 0);
+        perq += C.pw[c] + C.widths[c] + C.wp[c] + 8;
+    }
+    for (int l = 0; l < C.L; l++) perq += 4 + 8 * ((size_t)C.Hmax - 1 - l);
+    return words + (size_t)C.Q * perq;
+}
+size_t chips_bincode_bytes(const ChipsLayout& C) {
+    size_t n = 8 + 4 * C.head;                                   // header envelope
+    n += 32 + 1 + (C.lk ? 32 : 0) + 32;                          // commitment (Option tag: one byte)
+    n += 8;                                                      // chips
+    for (uint32_t c = 0; c < C.n; c++)
+        n += 2 * (8 + 16 * (size_t)C.pw[c]) + 2 * (8 + 16 * (size_t)C.widths[c]) + 2 * (8 + 16 * C.wp[c]) + 8 + 2 * (8 + 64) + 16 + 8;
+    n += 8 + 32 * (size_t)C.L;                                   // commit_phase_commits
+    size_t perq = 8;                                             // commit_phase_openings
+    for (int l = 0; l < C.L; l++) perq += 16 + 8 + 32 * ((size_t)C.Hmax - 1 - l);
+    n += 8 + (size_t)C.Q * perq + 16 + 4;                        // query_proofs, final_poly, pow_witness
+    size_t perq_open = 8;                                        // rounds of one query
+    auto round = [&](auto width_of, int height) {
+        size_t r = 8;                                            // opened_values: Vec<Vec<u32>>
+        bool any = false;
+        for (uint32_t c = 0; c < C.n; c++) if (width_of(c)) { r += 8 + 4 * (size_t)width_of(c); any = true; }
+        return any ? r + 8 + 32 * (size_t)height : 0;
+    };
+    perq_open += round([&](uint32_t c) { return (size_t)C.pw[c]; }, C.He) + round([&](uint32_t c) { return (size_t)C.widths[c]; }, C.Hmax) +
+                 round([&](uint32_t c) { return C.wp[c]; }, C.Hp) + round([&](uint32_t) { return (size_t)8; }, C.Hmax);
+    n += 8 + (size_t)C.Q * perq_open;
+    n += 8 + 4 * (size_t)C.n_public;
+    return n;
+}
+
 }  // namespace
 }  // namespace zk
 
@@ -205,6 +298,172 @@ int zkhip_proof_from_bincode(const uint8_t* in, size_t len, int log_n, uint32_t 
     pf[witness_at] = r.u32();
     if (r.u64() != (uint64_t)log_n) r.ok = false;
     if (!r.ok || r.pos != len || p != words) return fail(ZKHIP_ERR_INVALID, "proof_from_bincode: malformed input (a length prefix or the degree does not match the shape)");
+    *out_len = words * 4;
+    return ZKHIP_OK;
+}
+
+// ---- multi-chip proofs in the shape of sp1-stark's ShardProof (layout in the comment above ChipsLayout) ----
+size_t zkhip_chips_bincode_size(const uint8_t* proof, size_t len) {
+    ChipsLayout C;
+    if (!proof || len % 4 || !parse_chips_header((const uint32_t*)proof, len / 4, C) || chips_flat_words(C) * 4 != len) return 0;
+    return chips_bincode_bytes(C);
+}
+
+int zkhip_chips_proof_to_bincode(const uint8_t* proof, size_t len, const uint32_t* public_values, size_t n_public, uint8_t* out, size_t cap, size_t* out_len) {
+    ChipsLayout C;
+    if (!proof || !out || !out_len || (n_public && !public_values) || len % 4) return fail(ZKHIP_ERR_INVALID, "chips_proof_to_bincode: bad arguments");
+    const uint32_t* pf = (const uint32_t*)proof;
+    if (!parse_chips_header(pf, len / 4, C) || chips_flat_words(C) * 4 != len) return fail(ZKHIP_ERR_INVALID, "chips_proof_to_bincode: not a multi-chip proof (or its length does not match its header)");
+    if (n_public != C.n_public) return fail(ZKHIP_ERR_INVALID, "chips_proof_to_bincode: the proof was made for another number of public values");
+    const size_t need = chips_bincode_bytes(C);
+    if (cap < need) return fail(ZKHIP_ERR_BUFFER, "chips_proof_to_bincode: output buffer too small (see zkhip_chips_bincode_size)");
+    Writer w{out, cap};
+    size_t p = 0;
+    w.u64(C.head); w.words(pf, C.head); p = C.head;
+    const uint32_t* troot = pf + p; p += 8;
+    const uint32_t* proot = nullptr;
+    if (C.lk) { proot = pf + p; p += 8; }
+    const uint32_t* sums[32] = {nullptr};
+    if (C.cross) for (uint32_t c = 0; c < C.n; c++) if (C.wp[c]) { sums[c] = pf + p; p += 4; }
+    const uint32_t* qroot = pf + p; p += 8;
+    w.words(troot, 8);
+    { const uint8_t tag = proot ? 1 : 0; w.raw(&tag, 1); }
+    if (proot) w.words(proot, 8);
+    w.words(qroot, 8);
+    w.u64(C.n);
+    static const uint32_t zero4[4] = {0, 0, 0, 0};
+    for (uint32_t c = 0; c < C.n; c++) {
+        for (int k = 0; k < 2; k++) { w.vec_ext(pf + p, C.pw[c]); p += 4 * (size_t)C.pw[c]; }
+        for (int k = 0; k < 2; k++) { w.vec_ext(pf + p, C.widths[c]); p += 4 * (size_t)C.widths[c]; }
+        for (int k = 0; k < 2; k++) { w.vec_ext(pf + p, C.wp[c]); p += 4 * C.wp[c]; }
+        w.u64(2);
+        for (int k = 0; k < 2; k++) { w.vec_ext(pf + p, 4); p += 16; }
+        w.words(sums[c] ? sums[c] : zero4, 4);
+        w.u64((uint64_t)C.log_ns[c]);
+    }
+    const uint32_t* commits = pf + p; p += 8 * (size_t)C.L;
+    const uint32_t* final_poly = pf + p; p += 4;
+    const uint32_t witness = pf[p++];
+    const size_t q0 = p;
+    size_t perq = 16 * (size_t)C.Hmax + 8 * (size_t)C.Hp + 8 * (size_t)C.He, fri_per = 0;
+    for (uint32_t c = 0; c < C.n; c++) perq += C.pw[c] + C.widths[c] + C.wp[c] + 8;
+    for (int l = 0; l < C.L; l++) fri_per += 4 + 8 * ((size_t)C.Hmax - 1 - l);
+    const size_t open_per = perq;
+    perq += fri_per;
+    w.vec_digests(commits, C.L);
+    w.u64(C.Q);
+    for (uint32_t q = 0; q < C.Q; q++) {                         // fri_proof.query_proofs: the tail of every query
+        size_t t = q0 + (size_t)q * perq + open_per;
+        w.u64(C.L);
+        for (int l = 0; l < C.L; l++) {
+            w.words(pf + t, 4); t += 4;
+            w.vec_digests(pf + t, (size_t)C.Hmax - 1 - l); t += 8 * ((size_t)C.Hmax - 1 - l);
+        }
+    }
+    w.words(final_poly, 4);
+    w.u32(witness);
+    w.u64(C.Q);
+    for (uint32_t q = 0; q < C.Q; q++) {                         // query_openings: the head of every query
+        size_t t = q0 + (size_t)q * perq;
+        w.u64((C.keyed ? 1 : 0) + 1 + (C.lk ? 1 : 0) + 1);
+        auto round = [&](auto width_of, int height) {
+            size_t mats = 0;
+            for (uint32_t c = 0; c < C.n; c++) mats += width_of(c) ? 1 : 0;
+            if (!mats) return;
+            w.u64(mats);
+            for (uint32_t c = 0; c < C.n; c++) if (width_of(c)) { w.u64(width_of(c)); w.words(pf + t, width_of(c)); t += width_of(c); }
+            w.vec_digests(pf + t, (size_t)height); t += 8 * (size_t)height;
+        };
+        round([&](uint32_t c) { return (size_t)C.pw[c]; }, C.He);
+        round([&](uint32_t c) { return (size_t)C.widths[c]; }, C.Hmax);
+        round([&](uint32_t c) { return C.wp[c]; }, C.Hp);
+        round([&](uint32_t) { return (size_t)8; }, C.Hmax);
+    }
+    w.u64(n_public);
+    w.words(public_values, n_public);
+    if (!w.ok || w.pos != need) return fail(ZKHIP_ERR_INTERNAL, "chips_proof_to_bincode: layout mismatch");
+    *out_len = w.pos;
+    return ZKHIP_OK;
+}
+
+int zkhip_chips_proof_from_bincode(const uint8_t* in, size_t len, uint8_t* proof, size_t cap, size_t* out_len,
+                                   uint32_t* public_values, size_t public_cap, size_t* n_public) {
+    if (!in || !proof || !out_len || !n_public) return fail(ZKHIP_ERR_INVALID, "chips_proof_from_bincode: bad arguments");
+    auto bad = [&]() { return fail(ZKHIP_ERR_INVALID, "chips_proof_from_bincode: malformed input (a length prefix does not match the header's shape)"); };
+    Reader r{in, len};
+    const uint64_t head = r.u64();
+    if (!r.ok || head < 10 || head > 8 + 5 * 32 + 8 * 64 + 8 || len < 8 + 4 * head) return bad();
+    std::vector<uint32_t> hw((size_t)head);
+    r.words(hw.data(), (size_t)head);
+    ChipsLayout C;
+    // the header must parse as a complete header of exactly this many words (the flat proof behind it is rebuilt, not trusted)
+    if (!parse_chips_header(hw.data(), (size_t)head, C) || C.head != head) return bad();
+    if (len != chips_bincode_bytes(C)) return bad();
+    const size_t words = chips_flat_words(C);
+    if (cap < words * 4) return fail(ZKHIP_ERR_BUFFER, "chips_proof_from_bincode: output buffer too small");
+    if (public_cap < C.n_public || (C.n_public && !public_values)) return fail(ZKHIP_ERR_BUFFER, "chips_proof_from_bincode: public value buffer too small");
+    uint32_t* pf = (uint32_t*)proof;
+    std::memcpy(pf, hw.data(), 4 * (size_t)head);
+    size_t p = (size_t)head;
+    auto vec_ext = [&](size_t n) { r.expect_len(n); r.words(pf + p, 4 * n); p += 4 * n; };
+    auto vec_digests = [&](size_t n) { r.expect_len(n); r.words(pf + p, 8 * n); p += 8 * n; };
+    r.words(pf + p, 8); p += 8;                                  // main commit
+    uint8_t tag = 0;
+    r.raw(&tag, 1);
+    if (tag != (C.lk ? 1 : 0)) return bad();
+    if (C.lk) { r.words(pf + p, 8); p += 8; }
+    // the cumulative sums sit between the permutation and the quotient commitments in the flat form, inside the chips in this one
+    const size_t sums_at = p;
+    for (uint32_t c = 0; c < C.n; c++) if (C.cross && C.wp[c]) p += 4;
+    r.words(pf + p, 8); p += 8;                                  // quotient commit
+    r.expect_len(C.n);
+    size_t sum_slot = sums_at;
+    for (uint32_t c = 0; c < C.n && r.ok; c++) {
+        vec_ext(C.pw[c]); vec_ext(C.pw[c]); vec_ext(C.widths[c]); vec_ext(C.widths[c]); vec_ext(C.wp[c]); vec_ext(C.wp[c]);
+        r.expect_len(2); vec_ext(4); vec_ext(4);
+        uint32_t sum[4];
+        r.words(sum, 4);
+        if (C.cross && C.wp[c]) { std::memcpy(pf + sum_slot, sum, 16); sum_slot += 4; }
+        else if (sum[0] | sum[1] | sum[2] | sum[3]) return bad();
+        if (r.u64() != (uint64_t)C.log_ns[c]) return bad();
+    }
+    vec_digests(C.L);
+    const size_t final_at = p; p += 4;
+    const size_t witness_at = p; p += 1;
+    const size_t q0 = p;
+    size_t open_per = 16 * (size_t)C.Hmax + 8 * (size_t)C.Hp + 8 * (size_t)C.He, fri_per = 0;
+    for (uint32_t c = 0; c < C.n; c++) open_per += C.pw[c] + C.widths[c] + C.wp[c] + 8;
+    for (int l = 0; l < C.L; l++) fri_per += 4 + 8 * ((size_t)C.Hmax - 1 - l);
+    const size_t perq = open_per + fri_per;
+    r.expect_len(C.Q);
+    for (uint32_t q = 0; q < C.Q && r.ok; q++) {
+        p = q0 + (size_t)q * perq + open_per;
+        r.expect_len(C.L);
+        for (int l = 0; l < C.L; l++) { r.words(pf + p, 4); p += 4; vec_digests((size_t)C.Hmax - 1 - l); }
+    }
+    r.words(pf + final_at, 4);
+    pf[witness_at] = r.u32();
+    r.expect_len(C.Q);
+    for (uint32_t q = 0; q < C.Q && r.ok; q++) {
+        p = q0 + (size_t)q * perq;
+        r.expect_len((C.keyed ? 1 : 0) + 1 + (C.lk ? 1 : 0) + 1);
+        auto round = [&](auto width_of, int height) {
+            size_t mats = 0;
+            for (uint32_t c = 0; c < C.n; c++) mats += width_of(c) ? 1 : 0;
+            if (!mats) return;
+            r.expect_len(mats);
+            for (uint32_t c = 0; c < C.n; c++) if (width_of(c)) { r.expect_len(width_of(c)); r.words(pf + p, width_of(c)); p += width_of(c); }
+            vec_digests((size_t)height);
+        };
+        round([&](uint32_t c) { return (size_t)C.pw[c]; }, C.He);
+        round([&](uint32_t c) { return (size_t)C.widths[c]; }, C.Hmax);
+        round([&](uint32_t c) { return C.wp[c]; }, C.Hp);
+        round([&](uint32_t) { return (size_t)8; }, C.Hmax);
+    }
+    r.expect_len(C.n_public);
+    if (C.n_public) r.words(public_values, C.n_public);
+    if (!r.ok || r.pos != len) return bad();
+    *n_public = C.n_public;
     *out_len = words * 4;
     return ZKHIP_OK;
 }
