@@ -401,7 +401,7 @@ int zkhip_verify_sha256(const uint8_t* proof, size_t len, const uint8_t digest[3
 /* ---- a shard made of several chips (AIR tables) of different heights, as an SP1 shard is (sp1-stark 4.1.4 ShardProof,
  * reference Cargo.lock:6172, behind crates/guest-prover-sp1/src/sp1.rs:116): one Merkle commitment per phase over all
  * chips (shorter matrices injected at their level), one opening point, one reduced-opening vector per height joining the
- * FRI vector when folding reaches it, one FRI proof.  Chips tallest first, log_n in [5, 20], at most 8 per height and 32
+ * FRI vector when folding reaches it, one FRI proof.  Chips tallest first, log_n in [5, 22] (above 2^20 rows a chip's row pitch is limited as in zkhip_coset_lde: 512 words at 2^21, 256 at 2^22), at most 8 per height and 32
  * in all; zkhip_params: any log_blowup, the SP1 FRI shape (log_fold / log_final / hash_width / logup_pairs 0).
  * A chip may carry in-table LogUp pairs (logup_pairs > 0, trace from zkhip_gen_trace_logup): the permutation traces of
  * those chips are committed together in a third mixed-height tree (sp1-stark's permutation commitment).  Two chips of

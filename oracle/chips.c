@@ -170,7 +170,7 @@ static int chips_ok(const int* log_ns, const size_t* widths, const int* pairs, c
     if (prm->logup_pairs != 0) return 0;
     if (!g_machine && any_prog(n) && (any_pairs(pairs, n) || any_cross(partners, n))) return 0;      /* version 9: no lookups next to programs */
     for (int c = 0; c < n; c++) {
-        if (log_ns[c] < 5 || log_ns[c] > 20 || widths[c] == 0 || widths[c] % 4 != 0 || widths[c] > 1024) return 0;
+        if (log_ns[c] < 5 || log_ns[c] > 22 || widths[c] == 0 || widths[c] % 4 != 0 || widths[c] > 1024) return 0;
         if (c && log_ns[c] > log_ns[c - 1]) return 0;             /* tallest first */
         if (pairs && (pairs[c] < 0 || pairs[c] > 64 || (!g_machine && (size_t)pairs[c] * 8 > widths[c]))) return 0;
         if (partners && partners[c] >= 0) {                        /* mutual, equal heights and pair counts */
@@ -925,7 +925,7 @@ int orc_machine_setup(const uint32_t* const* pre_traces, const int* log_ns, cons
     const int b = prm->log_blowup;
     uint32_t* elde[MAX_CHIPS]; const uint32_t* em[MAX_CHIPS]; size_t ew[MAX_CHIPS]; int elh[MAX_CHIPS]; int ne = 0, He = 0;
     for (int c = 0; c < n; c++) {
-        if (log_ns[c] < 5 || log_ns[c] > 20 || (c && log_ns[c] > log_ns[c - 1]) || pre_widths[c] % 4 != 0 || pre_widths[c] > 1024) return 1;
+        if (log_ns[c] < 5 || log_ns[c] > 22 || (c && log_ns[c] > log_ns[c - 1]) || pre_widths[c] % 4 != 0 || pre_widths[c] > 1024) return 1;
         if (!pre_widths[c]) continue;
         if (!pre_traces[c]) return 1;
         elde[ne] = (uint32_t*)malloc(((size_t)1 << (log_ns[c] + b)) * pre_widths[c] * 4);

@@ -105,3 +105,69 @@ def test_big_fullwidth_shard_proof_verifies(ctx, oracle):
     assert verify_shard(bad.view(np.uint8), log_n, width, [1, 2, 3], prm)[0] == -6
     assert ctx.prove_shard(trace, log_n, width, [1, 2, 3], prm).tobytes() == proof.tobytes()
     trace.free()
+
+
+def test_big_multichip_shard_bytes_equal_the_oracles(ctx, oracle):
+    """chips above 2^20 rows in a multi-chip shard, as SP1's tallest chips are (benchmark.md:9: shards of 2^21 - 2^22 rows): a 2^22-row and
+    a 2^21-row table next to small ones, proof bytes against the oracle"""
+    from zktls_amd.device import verify_chips
+    shapes = [(22, 8), (21, 16), (18, 32), (12, 4)]
+    prm, oprm = Params(1, 20, 8), oracle.default_params(1, 20, 8)
+    host = [oracle.gen_trace(SEED, 20 + i, ln, w) for i, (ln, w) in enumerate(shapes)]
+    chips = [(ctx.from_numpy(t), ln, w) for t, (ln, w) in zip(host, shapes)]
+    proof = ctx.prove_chips(chips, [7, 8], prm)
+    assert proof.tobytes() == oracle.prove_chips(host, [7, 8], oprm).tobytes()
+    assert verify_chips(proof, [s[0] for s in shapes], [s[1] for s in shapes], [7, 8], prm) == (0, 0)
+    for c in chips:
+        c[0].free()
+
+
+def test_big_machine_with_lookups_bytes_equal_the_oracles(ctx, oracle):
+    """the range machine with 2^21 users (its PICK table has 2^22 rows): interaction tables, permutation traces and cumulative sums above
+    2^20 rows"""
+    import machines as M
+    from zktls_amd.device import verify_machine
+    import os
+    prev = min(8, os.cpu_count() or 1)
+    oracle.set_threads(min(os.cpu_count() or 1, 96))
+    try:
+        traces, progs, tables, pub = M.range_machine(10, 21)
+        lns, ws = [t.shape[0].bit_length() - 1 for t in traces], [t.shape[1] for t in traces]
+        assert lns == [22, 21, 10]
+        prm, oprm = Params(1, 16, 6), oracle.default_params(1, 16, 6)
+        chips = [(ctx.from_numpy(t), ln, w) for t, ln, w in zip(traces, lns, ws)]
+        proof = ctx.prove_machine(chips, progs, tables, pub, prm)
+        assert proof.tobytes() == oracle.prove_machine(traces, progs, tables, pub, oprm).tobytes()
+        assert verify_machine(proof, lns, ws, progs, tables, pub, prm) == (0, 0)
+        for c in chips:
+            c[0].free()
+    finally:
+        oracle.set_threads(prev)
+
+
+@pytest.mark.parametrize("size", [(21, 4), (12, 11)])
+def test_big_keyed_machine_bytes_equal_the_oracles(ctx, oracle, size):
+    """keyed machines above 2^20 rows: 2^21 users of a small preprocessed byte table, and a 2^22-row PREPROCESSED table (setup commits a
+    2^23-row LDE); keys and proof bytes against the oracle"""
+    import machines as M
+    from zktls_amd.device import verify_machine_keyed
+    import os
+    prev = min(8, os.cpu_count() or 1)
+    oracle.set_threads(min(os.cpu_count() or 1, 96))
+    try:
+        traces, pre, progs, tables, pub = M.byte_machine(*size)
+        lns, ws = [t.shape[0].bit_length() - 1 for t in traces], [t.shape[1] for t in traces]
+        pws = [0 if p is None else p.shape[1] for p in pre]
+        assert max(lns) == max(size[0], 2 * size[1]) >= 21
+        prm, oprm = Params(1, 16, 6), oracle.default_params(1, 16, 6)
+        chips = [(ctx.from_numpy(t), ln, w) for t, ln, w in zip(traces, lns, ws)]
+        key = ctx.machine_setup([(None if p is None else ctx.from_numpy(p), ln, pw) for p, ln, pw in zip(pre, lns, pws)], prm)
+        assert key.root.tolist() == oracle.machine_setup(pre, lns, oprm).tolist()
+        proof = ctx.prove_machine_keyed(key, chips, progs, tables, pub, prm)
+        assert proof.tobytes() == oracle.prove_machine_keyed(traces, pre, progs, tables, pub, oprm).tobytes()
+        assert verify_machine_keyed(proof, lns, ws, pws, key.root, progs, tables, pub, prm) == (0, 0)
+        key.close()
+        for c in chips:
+            c[0].free()
+    finally:
+        oracle.set_threads(prev)

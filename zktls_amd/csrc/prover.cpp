@@ -1676,8 +1676,8 @@ static int check_chips(const int32_t* log_ns, const uint32_t* widths, const int3
     if (prm->num_queries < 1 || prm->num_queries > 4096 || prm->pow_bits < 0 || prm->pow_bits > 28) return fail(ZKHIP_ERR_INVALID, "chips: queries / pow_bits out of range");
     if (!t_machine && any_prog(n) && (any_pairs(pairs, n) || any_cross(partners, n))) return fail(ZKHIP_ERR_INVALID, "chips: no lookups next to constraint programs (use the machine entries)");
     for (int c = 0; c < n; c++) {
-        if (log_ns[c] < 5 || log_ns[c] > 20 || widths[c] == 0 || widths[c] % 4 != 0 || widths[c] > 1024)
-            return fail(ZKHIP_ERR_INVALID, "chips: log_n in [5,20], width a multiple of 4 up to 1024");
+        if (log_ns[c] < 5 || log_ns[c] > MAX_LOG_ROWS || widths[c] == 0 || widths[c] % 4 != 0 || widths[c] > 1024)
+            return fail(ZKHIP_ERR_INVALID, "chips: log_n in [5,22], width a multiple of 4 up to 1024");
         if (c && log_ns[c] > log_ns[c - 1]) return fail(ZKHIP_ERR_INVALID, "chips: tallest first");
         if (pairs && (pairs[c] < 0 || pairs[c] > 64 || (!t_machine && (uint32_t)pairs[c] * 8 > widths[c]))) return fail(ZKHIP_ERR_INVALID, "chips: logup_pairs out of range");
         if (partners && partners[c] >= 0) {
@@ -2618,7 +2618,7 @@ int zkhip_machine_setup(zkhip_ctx* ctx, const zkhip_chip* pre, int n_chips, cons
     for (int c = 0; c < n_chips; c++) {
         const uint32_t pw = pre[c].width;
         key->log_ns[c] = pre[c].log_n; key->view.pw[c] = pw; key->view.d_trace[c] = nullptr; key->view.d_lde[c] = nullptr;
-        if (pre[c].log_n < 5 || pre[c].log_n > 20 || (c && pre[c].log_n > pre[c - 1].log_n)) return fail(ZKHIP_ERR_INVALID, "machine_setup: log_n in [5,20], tallest first");
+        if (pre[c].log_n < 5 || pre[c].log_n > MAX_LOG_ROWS || (c && pre[c].log_n > pre[c - 1].log_n)) return fail(ZKHIP_ERR_INVALID, "machine_setup: log_n in [5,22], tallest first");
         if (pw % 4 != 0 || pw > 1024) return fail(ZKHIP_ERR_INVALID, "machine_setup: preprocessed width a multiple of 4 up to 1024 (0: none)");
         if (!pw) continue;
         if (!pre[c].d_trace || pre[c].ld < pw) return fail(ZKHIP_ERR_INVALID, "machine_setup: bad preprocessed trace descriptor");

@@ -117,7 +117,7 @@ bool parse_chips_header(const uint32_t* pf, size_t words, ChipsLayout& C) {
     size_t p = 8, digests = 0;
     for (uint32_t c = 0; c < C.n; c++) {
         const uint32_t* e = pf + p; p += per;
-        if (e[0] < 5 || e[0] > 20 || e[1] == 0 || e[1] % 4 != 0 || e[1] > 1024 || (c && (int)e[0] > C.log_ns[c - 1])) return false;
+        if (e[0] < 5 || e[0] > (uint32_t)MAX_LOG_ROWS || e[1] == 0 || e[1] % 4 != 0 || e[1] > 1024 || (c && (int)e[0] > C.log_ns[c - 1])) return false;
         C.log_ns[c] = (int)e[0]; C.widths[c] = e[1]; C.pw[c] = 0; C.wp[c] = 0;
         if (v == 5 || v == 6) { if (e[2] > 64) return false; C.wp[c] = e[2] ? 4 * ((size_t)e[2] + 1) : 0; }
         if (v == 6) { if (e[3] > C.n) return false; if (e[3]) C.cross = true; }
