@@ -509,6 +509,22 @@ size_t zkhip_sha256_machine_proof_size(size_t message_len, const zkhip_params* p
 int zkhip_prove_sha256_machine(zkhip_ctx* ctx, const zkhip_machine_key* key, const uint8_t* message, size_t message_len, const zkhip_params* prm,
                                uint8_t digest[32], uint8_t* proof, size_t cap, size_t* len);
 int zkhip_verify_sha256_machine(const uint8_t* proof, size_t len, const uint8_t digest[32], const uint32_t vk[8], const zkhip_params* prm, int* reason);
+/* A batch of transcripts in one call -- the reference's batch configuration (BASELINE.json configs[2]: 64 independent transcripts), each proven
+ * as the keyed SHA-256 machine: job i runs on devices[i mod n_devices] (NULL / 0: every visible device), `in_flight_per_device` at a time per
+ * device, on pooled contexts that keep their proving key between calls (setup once per context).  Messages are host bytes; every job
+ * reports its digest, proof length and status; vk receives the verifying key all proofs check against (zkhip_verify_sha256_machine).
+ * proof_cap >= zkhip_sha256_machine_proof_size(message_len, prm).  Returns ZKHIP_OK or the status of the lowest failing job. */
+typedef struct zkhip_transcript_job {
+    const uint8_t* message;         /* host */
+    size_t message_len;
+    uint8_t digest[32];             /* out: SHA-256 of the message */
+    uint8_t* proof;                 /* host buffer */
+    size_t proof_cap;
+    size_t proof_len;               /* out */
+    int32_t status;                 /* out */
+} zkhip_transcript_job;
+int zkhip_prove_transcripts(const int* devices, int n_devices, zkhip_transcript_job* jobs, int n_jobs, const zkhip_params* prm,
+                            int in_flight_per_device, uint32_t vk[8]);
 
 /* ---- Poseidon2 parameter tables from a file: the built-in sets are this repo's own
  * ("zktls-amd/p2-bb16-v1", "...-bb24-v1"; the SP1 / RISC Zero tables of reference Cargo.lock:4030, 6172, 5057 are not

@@ -168,3 +168,33 @@ def test_sha256_machine_above_the_table_height(ctx):
     w = np.frombuffer(proof.tobytes(), dtype=np.uint32)
     assert list(w[8:18]) == [17, 608, 1, 4, 0, 16, 4, 1, 1, 4]
     assert verify_sha256_machine(proof, digest, key.root, prm) == (0, 0)
+
+
+def test_a_batch_of_transcripts_in_one_call(ctx, oracle):
+    """BASELINE configs[2] in its honest form: 64 independent transcripts (the recorded 13 217-byte input with a counter appended), each
+    proven as the keyed SHA-256 machine inside ONE library call; every digest against hashlib, every proof accepted under the one vk,
+    three of them byte-equal to the oracle's proof of the same machine; a second call reuses the pooled contexts and their keys"""
+    import time
+    from zktls_amd.device import prove_transcripts, verify_sha256_machine
+    base = open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "reference", "guest_input0.cbor"), "rb").read()
+    msgs = [base + i.to_bytes(4, "little") for i in range(64)]
+    prm, oprm = Params(1, 20, 8), oracle.default_params(1, 20, 8)
+    vk, res = prove_transcripts(msgs, prm, devices=[0], in_flight=4)
+    assert len(res) == 64
+    for m, (digest, proof) in zip(msgs, res):
+        assert digest == hashlib.sha256(m).digest()
+        assert verify_sha256_machine(proof, digest, vk, prm) == (0, 0)
+    for i in (0, 31, 63):
+        tr, pre, pg, tb, pub = M.sha256_machine(msgs[i])
+        assert res[i][1].tobytes() == oracle.prove_machine_keyed(tr, pre, pg, tb, pub, oprm).tobytes()
+        if i == 0:
+            assert vk.tolist() == oracle.machine_setup(pre, [t.shape[0].bit_length() - 1 for t in tr], oprm).tolist()
+    t0 = time.perf_counter()
+    vk2, res2 = prove_transcripts(msgs, prm, devices=[0], in_flight=4)
+    dt = time.perf_counter() - t0
+    assert vk2.tolist() == vk.tolist() and all(a[1].tobytes() == b[1].tobytes() for a, b in zip(res, res2))
+    print("64 transcripts, second call: %.1f ms" % (dt * 1e3))
+    # a failing job (a message beyond 1 MiB) is reported by index; the others are proven
+    from zktls_amd._lib import ZkHipError
+    with pytest.raises(ZkHipError):
+        prove_transcripts([b"ok", bytes((1 << 20) + 1), b"fine"], prm, devices=[0], in_flight=2)

@@ -32,3 +32,17 @@ for rep in range(3):
 t0 = time.perf_counter()
 assert all(verify_sha256(p, digests[i], prm) == (0, 0) for i, p in enumerate(proofs))
 print("all 64 verified on the host in %.1f ms" % ((time.perf_counter() - t0) * 1e3))
+
+# the same batch as KEYED MACHINES through one call of zkhip_prove_transcripts: padding, trace generation, the range table's multiplicities
+# and the proof per transcript all inside the library (host bytes in, proofs out), setup once per pooled context
+from zktls_amd.device import prove_transcripts, verify_sha256_machine
+msgs = [base + i.to_bytes(4, "little") for i in range(64)]
+prove_transcripts(msgs[:8], prm, devices=[0], in_flight=inflight)
+for rep in range(3):
+    t0 = time.perf_counter()
+    vk, res = prove_transcripts(msgs, prm, devices=[0], in_flight=inflight)
+    dt = time.perf_counter() - t0
+    print("64 transcripts as keyed SHA-256 machines (chip + range table), host bytes in: %.1f ms = %.2f ms per transcript (%d in flight)" % (dt * 1e3, dt * 1e3 / 64, inflight))
+t0 = time.perf_counter()
+assert all(verify_sha256_machine(p, d, vk, prm) == (0, 0) and d == hashlib.sha256(m).digest() for m, (d, p) in zip(msgs, res))
+print("all 64 verified against the vk on the host in %.1f ms" % ((time.perf_counter() - t0) * 1e3))

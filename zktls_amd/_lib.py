@@ -35,7 +35,7 @@ EXPORTS = [
     "zkhip_chips_proof_size_air", "zkhip_prove_chips_air", "zkhip_verify_chips_air",
     "zkhip_prove_shards_air_multi", "zkhip_selftest_host_simd", "zkhip_host_simd", "zkhip_machine_proof_size", "zkhip_prove_machine", "zkhip_verify_machine", "zkhip_range_table",
     "zkhip_machine_setup", "zkhip_machine_key_destroy", "zkhip_machine_proof_size_keyed", "zkhip_prove_machine_keyed", "zkhip_verify_machine_keyed", "zkhip_prove_machine_keyed_at",
-    "zkhip_sha256_setup", "zkhip_sha256_machine_proof_size", "zkhip_prove_sha256_machine", "zkhip_verify_sha256_machine",
+    "zkhip_sha256_setup", "zkhip_sha256_machine_proof_size", "zkhip_prove_sha256_machine", "zkhip_verify_sha256_machine", "zkhip_prove_transcripts",
     "zkhip_sha256_air", "zkhip_sha256_digest", "zkhip_sha256_pad", "zkhip_sha256_gen_trace", "zkhip_sha256_proof_size", "zkhip_prove_sha256", "zkhip_verify_sha256",
 ]
 
@@ -59,6 +59,11 @@ def segment_params(num_queries=50, logup_pairs=0, log_final=8, code_width=0):
 
 class Chip(C.Structure):
     _fields_ = [("d_trace", C.c_void_p), ("ld", C.c_size_t), ("log_n", C.c_int32), ("width", C.c_uint32), ("logup_pairs", C.c_int32), ("partner", C.c_int32)]
+
+
+class TranscriptJob(C.Structure):
+    _fields_ = [("message", u8p), ("message_len", C.c_size_t), ("digest", C.c_uint8 * 32), ("proof", u8p), ("proof_cap", C.c_size_t),
+                ("proof_len", C.c_size_t), ("status", C.c_int32)]
 
 
 class ShardJob(C.Structure):
@@ -189,6 +194,7 @@ def load():
     L.zkhip_chips_bincode_size.argtypes = [u8p, C.c_size_t]
     L.zkhip_chips_proof_to_bincode.argtypes = [u8p, C.c_size_t, u32p, C.c_size_t, u8p, C.c_size_t, szp]
     L.zkhip_chips_proof_from_bincode.argtypes = [u8p, C.c_size_t, u8p, C.c_size_t, szp, u32p, C.c_size_t, szp]
+    L.zkhip_prove_transcripts.argtypes = [C.POINTER(C.c_int), C.c_int, C.POINTER(TranscriptJob), C.c_int, C.POINTER(Params), C.c_int, u32p]
     L.zkhip_sha256_air.restype = C.c_size_t
     L.zkhip_sha256_air.argtypes = [u32p, C.c_size_t]
     L.zkhip_sha256_digest.restype = None

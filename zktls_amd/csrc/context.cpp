@@ -562,6 +562,7 @@ void zkhip_ctx_destroy(zkhip_ctx* ctx) {
     if (!ctx) return;
     (void)hipSetDevice(ctx->device);
     if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
+    if (ctx->sha_key) zkhip_machine_key_destroy(ctx->sha_key);
     if (ctx->fri_graph_exec) (void)hipGraphExecDestroy(ctx->fri_graph_exec);
     for (NttPlan& p : ctx->plans) { if (p.pre) (void)hipFree(p.pre); if (p.post) (void)hipFree(p.post); }
     for (BigPlan& p : ctx->big_plans) if (p.tw) (void)hipFree(p.tw);

@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 
 #include <deque>
+#include <functional>
 #include <new>
 #include <string>
 #include <vector>
@@ -112,6 +113,10 @@ struct zkhip_ctx {
     // the key is every size and pointer the launches depend on
     std::vector<uint64_t> fri_graph_key;
     hipGraphExec_t fri_graph_exec = nullptr;
+    // the SHA-256 machine's proving key made on this context by a batch entry (zkhip_prove_transcripts): kept with the pooled context
+    zkhip_machine_key* sha_key = nullptr;
+    int sha_key_blowup = 0;
+    uint32_t sha_vk[8] = {0};
 };
 
 namespace zk {
@@ -123,4 +128,7 @@ int op_coset_lde(zkhip_ctx* ctx, const uint32_t* d_in, size_t in_ld, uint32_t* d
                  int log_n, uint32_t width, int log_blowup, uint32_t shift_monty);
 int op_merkle_commit(zkhip_ctx* ctx, const MatDesc* mats, int nmats, int log_h, uint32_t* d_tree);
 int op_merkle_commit_mixed(zkhip_ctx* ctx, const MatDesc* mats, const int* log_heights, int nmats, uint32_t* d_tree);
+// batch entries (prover.cpp): job i -> devices[i mod n], up to `in_flight` pooled contexts per device, run(ctx, i) -> status
+int deal_jobs(const int* devices, int n_devices, int n_jobs, int in_flight, const std::function<int(zkhip_ctx*, int)>& run, std::vector<char>& ran);
+int resolve_devices(const int* devices, int n_devices, const char* what, std::vector<int>& devs);
 }  // namespace zk

@@ -1044,15 +1044,17 @@ void zkhip_release_cached_contexts(void) {
     { std::lock_guard<std::mutex> lk(g_pool_mu); all.swap(g_pool); }
     for (auto& e : all) zkhip_ctx_destroy(e.second);
 }
-// Shard s of the batch goes to devices[s mod n_devices] (shard-parallel, no exchange step); every device runs up to
-// `in_flight` workers (context + HIP stream + host thread each) that take that device's shards in index order.  Job traces are
-// device pointers ON THE DEVICE THE SHARD IS ASSIGNED TO, or host pointers with host_traces.
-static int prove_shards_on(const int* devices, int n_devices, zkhip_shard_job* jobs, int n_jobs, const zkhip_params* prm, int in_flight,
-                           int host_traces, const uint32_t* program = nullptr, size_t program_words = 0) {
+// Job i of a batch goes to devices[i mod n_devices] (shard-parallel, no exchange step); every device runs up to
+// `in_flight` workers (a pooled context + HIP stream + host thread each) that take that device's jobs in index order and call
+// run(ctx, i) -> status.  Returns the status of the lowest failing job (its message in zkhip_last_error), and tells through `ran`
+// which jobs a worker reached at all (none when every worker of a device failed to get a context).
+extern "C++" {
+namespace zk {
+int deal_jobs(const int* devices, int n_devices, int n_jobs, int in_flight, const std::function<int(zkhip_ctx*, int)>& run, std::vector<char>& ran) {
+    ran.assign((size_t)n_jobs, 0);
     if (n_jobs == 0) return ZKHIP_OK;
     if (in_flight <= 0) in_flight = 4;
-    for (int i = 0; i < n_jobs; i++) { jobs[i].status = ZKHIP_ERR_INVALID; jobs[i].proof_len = 0; }
-    std::vector<std::atomic<int>> next(n_devices);            // per device: how many of ITS shards were handed out
+    std::vector<std::atomic<int>> next(n_devices);            // per device: how many of ITS jobs were handed out
     for (auto& a : next) a.store(0);
     std::mutex mu;
     int first_rc = ZKHIP_OK, first_job = n_jobs, ctx_rc = ZKHIP_OK;
@@ -1072,18 +1074,10 @@ static int prove_shards_on(const int* devices, int n_devices, zkhip_shard_job* j
         }
         for (;;) {
             const int k = next[slot].fetch_add(1);
-            const long i = (long)slot + (long)k * n_devices;   // the k-th shard of this device
+            const long i = (long)slot + (long)k * n_devices;   // the k-th job of this device
             if (i >= n_jobs) break;
-            zkhip_shard_job& j = jobs[i];
-            size_t len = 0;
-            if (program)             // every job of the batch is a trace of the same constraint program (device traces)
-                rc = zkhip_prove_shard_air(ctx, program, program_words, j.trace, j.ld, j.log_n, j.width, j.public_values, j.n_public, prm, j.proof, j.proof_cap, &len);
-            else
-                rc = host_traces
-                         ? zkhip_prove_shard_host(ctx, j.trace, j.log_n, j.width, j.public_values, j.n_public, prm, j.proof, j.proof_cap, &len)
-                         : zkhip_prove_shard(ctx, j.trace, j.ld, j.log_n, j.width, j.public_values, j.n_public, prm, j.proof, j.proof_cap, &len);
-            j.status = rc;
-            j.proof_len = rc == ZKHIP_OK ? len : 0;
+            rc = run(ctx, (int)i);
+            ran[(size_t)i] = 1;
             if (rc != ZKHIP_OK) note((int)i, rc);
         }
         zkhip_ctx_sync(ctx);
@@ -1091,16 +1085,57 @@ static int prove_shards_on(const int* devices, int n_devices, zkhip_shard_job* j
     };
     std::vector<std::thread> pool;
     for (int slot = 0; slot < n_devices; slot++) {
-        const int mine = (n_jobs - slot + n_devices - 1) / n_devices;       // shards of this device
+        const int mine = (n_jobs - slot + n_devices - 1) / n_devices;       // jobs of this device
         const int workers = mine < in_flight ? mine : in_flight;
         for (int t = 0; t < workers; t++) pool.emplace_back(worker, slot);
     }
-    if (pool.size() == 1) { pool[0].join(); }
-    else for (auto& t : pool) t.join();
+    for (auto& t : pool) t.join();
     if (first_rc != ZKHIP_OK) { set_error(first_msg); return first_rc; }
     for (int i = 0; i < n_jobs; i++)                         // jobs nobody could take: every worker of that device failed to get a context
-        if (jobs[i].status != ZKHIP_OK) { set_error(ctx_msg.empty() ? "prove_shards: job not run" : ctx_msg); return ctx_rc != ZKHIP_OK ? ctx_rc : ZKHIP_ERR_INVALID; }
+        if (!ran[(size_t)i]) { set_error(ctx_msg.empty() ? "prove_shards: job not run" : ctx_msg); return ctx_rc != ZKHIP_OK ? ctx_rc : ZKHIP_ERR_INVALID; }
     return ZKHIP_OK;
+}
+// the device list of a batch entry: NULL (with n_devices == 0) = every visible device; ordinals non-negative and distinct.
+// ZKHIP_ERR_NO_DEVICE when nothing is visible (the caller marks its jobs)
+int resolve_devices(const int* devices, int n_devices, const char* what, std::vector<int>& devs) {
+    devs.clear();
+    if (!devices) {
+        if (n_devices != 0) return fail(ZKHIP_ERR_INVALID, std::string(what) + ": n_devices must be 0 when devices is NULL (all visible devices)");
+        const int n = zkhip_device_count();
+        if (n <= 0) return fail(ZKHIP_ERR_NO_DEVICE, "no HIP device visible: libzkhip has no CPU fallback");
+        for (int d = 0; d < n; d++) devs.push_back(d);
+        return ZKHIP_OK;
+    }
+    if (n_devices < 1 || n_devices > 64) return fail(ZKHIP_ERR_INVALID, std::string(what) + ": 1..64 devices");
+    for (int d = 0; d < n_devices; d++) {
+        if (devices[d] < 0) return fail(ZKHIP_ERR_INVALID, std::string(what) + ": negative device ordinal");
+        for (int e = 0; e < d; e++) if (devices[e] == devices[d]) return fail(ZKHIP_ERR_INVALID, std::string(what) + ": device listed twice");
+        devs.push_back(devices[d]);
+    }
+    return ZKHIP_OK;
+}
+}  // namespace zk
+}  // extern "C++"
+
+// Job traces are device pointers ON THE DEVICE THE SHARD IS ASSIGNED TO, or host pointers with host_traces.
+static int prove_shards_on(const int* devices, int n_devices, zkhip_shard_job* jobs, int n_jobs, const zkhip_params* prm, int in_flight,
+                           int host_traces, const uint32_t* program = nullptr, size_t program_words = 0) {
+    for (int i = 0; i < n_jobs; i++) { jobs[i].status = ZKHIP_ERR_INVALID; jobs[i].proof_len = 0; }
+    std::vector<char> ran;
+    return deal_jobs(devices, n_devices, n_jobs, in_flight, [&](zkhip_ctx* ctx, int i) {
+        zkhip_shard_job& j = jobs[i];
+        size_t len = 0;
+        int rc;
+        if (program)             // every job of the batch is a trace of the same constraint program (device traces)
+            rc = zkhip_prove_shard_air(ctx, program, program_words, j.trace, j.ld, j.log_n, j.width, j.public_values, j.n_public, prm, j.proof, j.proof_cap, &len);
+        else
+            rc = host_traces
+                     ? zkhip_prove_shard_host(ctx, j.trace, j.log_n, j.width, j.public_values, j.n_public, prm, j.proof, j.proof_cap, &len)
+                     : zkhip_prove_shard(ctx, j.trace, j.ld, j.log_n, j.width, j.public_values, j.n_public, prm, j.proof, j.proof_cap, &len);
+        j.status = rc;
+        j.proof_len = rc == ZKHIP_OK ? len : 0;
+        return rc;
+    }, ran);
 }
 
 int zkhip_prove_shards(int device, zkhip_shard_job* jobs, int n_jobs, const zkhip_params* prm, int in_flight, int host_traces) {
@@ -1117,49 +1152,28 @@ int zkhip_prove_shards_multi(const int* devices, int n_devices, zkhip_shard_job*
                              int in_flight_per_device, int host_traces) {
     if (!jobs || n_jobs < 0 || !prm) return fail(ZKHIP_ERR_INVALID, "prove_shards_multi: bad arguments");
     std::vector<int> devs;
-    if (!devices) {                                           // NULL: every visible device
-        if (n_devices != 0) return fail(ZKHIP_ERR_INVALID, "prove_shards_multi: n_devices must be 0 when devices is NULL (all visible devices)");
-        const int n = zkhip_device_count();
-        if (n <= 0) {
-            for (int i = 0; i < n_jobs; i++) { jobs[i].status = ZKHIP_ERR_NO_DEVICE; jobs[i].proof_len = 0; }
-            return n_jobs == 0 ? ZKHIP_OK : fail(ZKHIP_ERR_NO_DEVICE, "no HIP device visible: libzkhip has no CPU fallback");
-        }
-        for (int d = 0; d < n; d++) devs.push_back(d);
-    } else {
-        if (n_devices < 1 || n_devices > 64) return fail(ZKHIP_ERR_INVALID, "prove_shards_multi: 1..64 devices");
-        for (int d = 0; d < n_devices; d++) {
-            if (devices[d] < 0) return fail(ZKHIP_ERR_INVALID, "prove_shards_multi: negative device ordinal");
-            for (int e = 0; e < d; e++) if (devices[e] == devices[d]) return fail(ZKHIP_ERR_INVALID, "prove_shards_multi: device listed twice");
-            devs.push_back(devices[d]);
-        }
+    const int rc = resolve_devices(devices, n_devices, "prove_shards_multi", devs);
+    if (rc == ZKHIP_ERR_NO_DEVICE) {
+        for (int i = 0; i < n_jobs; i++) { jobs[i].status = ZKHIP_ERR_NO_DEVICE; jobs[i].proof_len = 0; }
+        return n_jobs == 0 ? ZKHIP_OK : rc;
     }
+    if (rc != ZKHIP_OK) return rc;
     return prove_shards_on(devs.data(), (int)devs.size(), jobs, n_jobs, prm, in_flight_per_device, host_traces);
 }
 
 // the same batch when every job is a trace of ONE constraint program (e.g. sixty-four SHA-256 chip traces: sixty-four transcripts)
 int zkhip_prove_shards_air_multi(const int* devices, int n_devices, zkhip_shard_job* jobs, int n_jobs, const uint32_t* program, size_t program_words,
                                  const zkhip_params* prm, int in_flight_per_device) {
-    const int host_traces = 0;
     if (!program || program_words < 6) return fail(ZKHIP_ERR_INVALID, "prove_shards_air_multi: null program");
     if (!jobs || n_jobs < 0 || !prm) return fail(ZKHIP_ERR_INVALID, "prove_shards_air_multi: bad arguments");
     std::vector<int> devs;
-    if (!devices) {                                           // NULL: every visible device
-        if (n_devices != 0) return fail(ZKHIP_ERR_INVALID, "prove_shards_air_multi: n_devices must be 0 when devices is NULL (all visible devices)");
-        const int n = zkhip_device_count();
-        if (n <= 0) {
-            for (int i = 0; i < n_jobs; i++) { jobs[i].status = ZKHIP_ERR_NO_DEVICE; jobs[i].proof_len = 0; }
-            return n_jobs == 0 ? ZKHIP_OK : fail(ZKHIP_ERR_NO_DEVICE, "no HIP device visible: libzkhip has no CPU fallback");
-        }
-        for (int d = 0; d < n; d++) devs.push_back(d);
-    } else {
-        if (n_devices < 1 || n_devices > 64) return fail(ZKHIP_ERR_INVALID, "prove_shards_air_multi: 1..64 devices");
-        for (int d = 0; d < n_devices; d++) {
-            if (devices[d] < 0) return fail(ZKHIP_ERR_INVALID, "prove_shards_air_multi: negative device ordinal");
-            for (int e = 0; e < d; e++) if (devices[e] == devices[d]) return fail(ZKHIP_ERR_INVALID, "prove_shards_air_multi: device listed twice");
-            devs.push_back(devices[d]);
-        }
+    const int rc = resolve_devices(devices, n_devices, "prove_shards_air_multi", devs);
+    if (rc == ZKHIP_ERR_NO_DEVICE) {
+        for (int i = 0; i < n_jobs; i++) { jobs[i].status = ZKHIP_ERR_NO_DEVICE; jobs[i].proof_len = 0; }
+        return n_jobs == 0 ? ZKHIP_OK : rc;
     }
-    return prove_shards_on(devs.data(), (int)devs.size(), jobs, n_jobs, prm, in_flight_per_device, host_traces, program, program_words);
+    if (rc != ZKHIP_OK) return rc;
+    return prove_shards_on(devs.data(), (int)devs.size(), jobs, n_jobs, prm, in_flight_per_device, 0, program, program_words);
 }
 
 int zkhip_prove_segment(zkhip_ctx* ctx, const uint32_t* d_cols, int log_n, uint32_t width,

@@ -16,6 +16,7 @@
 //   OUT 8 limb pairs (variables after the round, + chaining value in round 63, mod 2^32) | X0 X13 32 bits (W_t, W_{t+13})
 //   XL 14 limb pairs (W_{t+j}, j = 1..12, 14, 15) | SG0 SG1 32 bits (sigma0(W_t), sigma1(W_{t+13})) | CY 28 carry bits
 //   ACT (block belongs to the message) | SKIP = s_63 (1 - ACT) | 2 unused
+#include <mutex>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -624,6 +625,46 @@ int zkhip_verify_sha256_machine(const uint8_t* proof, size_t len, const uint8_t 
     }
     const sha::MachineShape m = sha::machine_shape(log_n);
     return zkhip_verify_machine_keyed(proof, len, m.log_ns, m.widths, m.pre_widths, vk, m.progs, m.prog_words, m.tabs, m.tab_words, 2, limbs, sha::N_PUBLIC, prm, reason);
+}
+
+// A batch of transcripts in ONE call (BASELINE configs[2]: sixty-four independent TLS transcripts, shard-parallel over the GPUs): job i is
+// proven on devices[i mod n_devices], `in_flight_per_device` at a time on each, every worker on a pooled context that keeps its own
+// proving key (setup runs once per context and proof shape; every context arrives at the same vk).  Per job: padding, trace generation
+// and the range table's multiplicities on the device, the keyed machine's proof into the job's host buffer, the digest.
+int zkhip_prove_transcripts(const int* devices, int n_devices, zkhip_transcript_job* jobs, int n_jobs, const zkhip_params* prm,
+                            int in_flight_per_device, uint32_t vk[8]) {
+    if (!jobs || n_jobs < 0 || !prm || !vk) return fail(ZKHIP_ERR_INVALID, "prove_transcripts: bad arguments");
+    for (int i = 0; i < n_jobs; i++) { jobs[i].status = ZKHIP_ERR_INVALID; jobs[i].proof_len = 0; }
+    std::vector<int> devs;
+    const int rc = resolve_devices(devices, n_devices, "prove_transcripts", devs);
+    if (rc == ZKHIP_ERR_NO_DEVICE) {
+        for (int i = 0; i < n_jobs; i++) jobs[i].status = ZKHIP_ERR_NO_DEVICE;
+        return n_jobs == 0 ? ZKHIP_OK : rc;
+    }
+    if (rc != ZKHIP_OK) return rc;
+    std::mutex mu;
+    bool have_vk = false;
+    std::memset(vk, 0, 32);
+    std::vector<char> ran;
+    return deal_jobs(devs.data(), (int)devs.size(), n_jobs, in_flight_per_device, [&](zkhip_ctx* ctx, int i) {
+        zkhip_transcript_job& j = jobs[i];
+        int r = ZKHIP_OK;
+        if (ctx->sha_key && ctx->sha_key_blowup != prm->log_blowup) { zkhip_machine_key_destroy(ctx->sha_key); ctx->sha_key = nullptr; }
+        if (!ctx->sha_key) {
+            r = zkhip_sha256_setup(ctx, prm, &ctx->sha_key, ctx->sha_vk);
+            ctx->sha_key_blowup = prm->log_blowup;
+        }
+        if (r == ZKHIP_OK) {
+            std::lock_guard<std::mutex> lk(mu);
+            if (!have_vk) { std::memcpy(vk, ctx->sha_vk, 32); have_vk = true; }
+            else if (std::memcmp(vk, ctx->sha_vk, 32) != 0) r = fail(ZKHIP_ERR_INTERNAL, "prove_transcripts: two contexts disagree about the verifying key");
+        }
+        size_t len = 0;
+        if (r == ZKHIP_OK) r = zkhip_prove_sha256_machine(ctx, ctx->sha_key, j.message, j.message_len, prm, j.digest, j.proof, j.proof_cap, &len);
+        j.status = r;
+        j.proof_len = r == ZKHIP_OK ? len : 0;
+        return r;
+    }, ran);
 }
 
 }  // extern "C"

@@ -660,6 +660,27 @@ def verify_sha256(proof, digest, params=None):
     return rc, reason.value
 
 
+def prove_transcripts(messages, params=None, devices=None, in_flight=4):
+    """zkhip_prove_transcripts: every message proven as the keyed SHA-256 machine in one call, dealt over `devices` (None: all visible)
+    -> (vk, [(digest bytes, proof bytes), ...])"""
+    lib = _lib.load()
+    params = params or Params(1, 100, 16)
+    n = len(messages)
+    jobs = (_lib.TranscriptJob * max(n, 1))()
+    keep = []
+    for i, m in enumerate(messages):
+        msg = np.frombuffer(bytes(m), dtype=np.uint8) if len(m) else np.zeros(1, dtype=np.uint8)
+        size = lib.zkhip_sha256_machine_proof_size(len(m), C.byref(params))
+        buf = np.empty(max(size, 1), dtype=np.uint8)
+        keep.append((msg, buf))
+        jobs[i].message = msg.ctypes.data_as(u8p); jobs[i].message_len = len(m)
+        jobs[i].proof = buf.ctypes.data_as(u8p); jobs[i].proof_cap = size
+    vk = np.zeros(8, dtype=np.uint32)
+    devs = (C.c_int * len(devices))(*devices) if devices else None
+    check(lib.zkhip_prove_transcripts(devs, len(devices) if devices else 0, jobs, n, C.byref(params), in_flight, vk.ctypes.data_as(u32p)))
+    return vk, [(bytes(jobs[i].digest), keep[i][1][: jobs[i].proof_len]) for i in range(n)]
+
+
 def verify_sha256_machine(proof, digest, vk, params=None):
     params = params or Params(1, 100, 16)
     lib = _lib.load()
