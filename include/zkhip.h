@@ -526,6 +526,26 @@ typedef struct zkhip_transcript_job {
 int zkhip_prove_transcripts(const int* devices, int n_devices, zkhip_transcript_job* jobs, int n_jobs, const zkhip_params* prm,
                             int in_flight_per_device, uint32_t vk[8]);
 
+/* A second real chip: the width-16 Poseidon2 permutation with Merkle-path chaining -- what a recursion machine (a STARK verifier proven
+ * inside a STARK: the compress / shrink / wrap stages behind SP1ProofMode::Groth16, crates/guest-prover-sp1/src/sp1.rs:116; sp1-recursion's
+ * Poseidon2 chips, reference Cargo.lock:6172 ff.) spends its rows on.  One row = one permutation of the parameter set in effect, every
+ * intermediate in a column (ZKHIP_P2CHIP_WIDTH = 356 columns, degree <= 3); flag columns chain rows into Merkle paths (a row's
+ * digest-carrying input half = the previous row's digest) and count the paths that end in the public root.  Public values: root[8],
+ * count.  zkhip_p2chip_air writes the constraint program (returns its size in words; the program follows the Poseidon2 tables, so reload
+ * it after zkhip_load_poseidon2_params).  zkhip_p2chip_gen_merkle_trace fills a device trace of 2^log_n rows from host arrays: path p =
+ * rows [p depth, (p + 1) depth), leaves[p][8] its leaf digest, siblings[p][l][8] the sibling at level l, bit l of indices[p] = "the node is a
+ * right child at level l" (canonical words); roots[p][8] receives where each path ends.  zkhip_prove_merkle_paths = trace + proof of
+ * "I know n_paths Merkle paths that end in root" (refuses paths that do not); zkhip_verify_merkle_paths checks one (the trace height is
+ * read from the proof).  The proofs are zkhip_prove_shard_air proofs (version 7). */
+#define ZKHIP_P2CHIP_WIDTH 356
+size_t zkhip_p2chip_air(uint32_t* program, size_t cap_words);
+int zkhip_p2chip_gen_merkle_trace(zkhip_ctx* ctx, const uint32_t* leaves, const uint32_t* siblings, const uint32_t* indices, size_t n_paths, int depth,
+                                  int log_n, uint32_t* d_trace, size_t ld, uint32_t* roots);
+size_t zkhip_merkle_paths_proof_size(size_t n_paths, int depth, const zkhip_params* prm);
+int zkhip_prove_merkle_paths(zkhip_ctx* ctx, const uint32_t* leaves, const uint32_t* siblings, const uint32_t* indices, size_t n_paths, int depth,
+                             const uint32_t root[8], const zkhip_params* prm, uint8_t* proof, size_t cap, size_t* len);
+int zkhip_verify_merkle_paths(const uint8_t* proof, size_t len, const uint32_t root[8], size_t n_paths, const zkhip_params* prm, int* reason);
+
 /* ---- Poseidon2 parameter tables from a file: the built-in sets are this repo's own
  * ("zktls-amd/p2-bb16-v1", "...-bb24-v1"; the SP1 / RISC Zero tables of reference Cargo.lock:4030, 6172, 5057 are not
  * obtainable offline).  zkhip_load_poseidon2_params replaces the width-16 or the width-24 set (the file says which) for the

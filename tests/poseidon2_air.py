@@ -1,0 +1,198 @@
+"""The width-16 Poseidon2 permutation as a constraint program, with Merkle-path chaining (test-side restatement; the product's generator
+is csrc/poseidon2_chip.hip).  This is the workhorse of a recursion machine: a STARK verifier inside a STARK spends its rows on Poseidon2
+(Merkle paths of the FRI queries, the transcript) -- sp1-recursion's Poseidon2 chips, reference Cargo.lock:6172 ff.
+
+One row = one permutation `out = poseidon2(in)` of tests/pyref.py (this repo's parameter set).  356 columns, every constraint of degree
+<= 3 including its selector (log_quotient_degree 1):
+  IN   16   the input state
+  S0   16   the state after the initial external layer
+  X3E[r] 16, OUTE[r] 16 for the eight external rounds r: (y + rc)^3 of the round's input y, and the state after the round
+            (S-box x^7 = x^3 * x^3 * x, then the external matrix): inputs are S0 (r = 0), OUTE[r-1] (r = 1..3, 5..7), SP (r = 4)
+  S0P[r], X3P[r], SBP[r] for the thirteen internal rounds: element 0 before the S-box, its cube, its seventh power; the other elements
+            stay LINEAR FORMS over OUTE[3] and the SBP columns so far (no columns needed)
+  SP   16   the state after the internal rounds
+  D    8    the digest-carrying half of the input: D[j] = IN[j] (1 - BIT) + IN[8 + j] BIT
+  BIT, CH, END  booleans: the node of this row is a RIGHT child; the row continues the path of the previous row (D = the previous
+            row's digest OUTE[7][0..8]); the row ends a path (its digest is the public root)
+  CNT       running count of END rows; the last row's CNT is the public count
+Public values: root[8], count.  What a proof says: "I know `count` Merkle paths -- leaves, siblings and positions are the prover's --
+that end in `root`" (truncated-permutation compression, as the commitments of this repo and of p3-merkle-tree).
+"""
+import numpy as np
+
+import oracle_lib as O
+import pyref
+
+P = O.P
+V = O.air_var
+PARAMS = pyref.PARAMS
+
+IN, S0 = 0, 16
+SP, D = 327, 343
+BIT, CH, END, CNT = 351, 352, 353, 354
+WIDTH = 356
+N_PUBLIC = 9
+
+
+def X3E(r):
+    return 32 + 32 * r
+
+
+def OUTE(r):
+    return 48 + 32 * r
+
+
+def S0P(r):
+    return 288 + 3 * r
+
+
+def X3P(r):
+    return 289 + 3 * r
+
+
+def SBP(r):
+    return 290 + 3 * r
+
+
+def ext_input(r):
+    return S0 if r == 0 else (SP if r == 4 else OUTE(r - 1))
+
+
+def _term(coeff, vs):
+    return (coeff % P, list(vs))
+
+
+def _cube_def(x3, c, k):
+    """x3 - (c + k)^3 = 0, zero coefficients omitted"""
+    t = [_term(1, [V(x3)]), _term(P - 1, [V(c)] * 3), _term(P - 3 * k, [V(c)] * 2), _term(P - 3 * k * k, [V(c)]), _term(P - pow(k, 3, P), [])]
+    return [x for x in t if x[0]]
+
+
+def _linear_def(col, form):
+    """col - sum coeff * column = 0; form: {column: coeff}, ascending column order"""
+    return [_term(1, [V(col)])] + [_term(P - form[c], [V(c)]) for c in sorted(form) if form[c] % P]
+
+
+def program():
+    ME, rc_e, rc_i, diag = pyref.ME, PARAMS["external_rc"], PARAMS["internal_rc"], PARAMS["internal_diag"]
+    cons = []
+    for i in range(16):
+        cons.append((O.SEL_ALL, _linear_def(S0 + i, {IN + j: ME[i][j] for j in range(16)})))
+
+    def external_round(r):
+        c0 = ext_input(r)
+        for i in range(16):
+            cons.append((O.SEL_ALL, _cube_def(X3E(r) + i, c0 + i, rc_e[r][i])))
+        for i in range(16):
+            t = [_term(1, [V(OUTE(r) + i)])]
+            for j in range(16):
+                x3, c, k = V(X3E(r) + j), V(c0 + j), rc_e[r][j]
+                t.append(_term(P - ME[i][j], [x3, x3, c]))
+                if ME[i][j] * k % P:
+                    t.append(_term(P - ME[i][j] * k, [x3, x3]))
+            cons.append((O.SEL_ALL, t))
+    for r in range(4):
+        external_round(r)
+    lin = [{OUTE(3) + i: 1} for i in range(16)]
+    for r in range(13):
+        k = rc_i[r]
+        cons.append((O.SEL_ALL, _linear_def(S0P(r), lin[0])))
+        cons.append((O.SEL_ALL, _cube_def(X3P(r), S0P(r), k)))
+        t = [_term(1, [V(SBP(r))]), _term(P - 1, [V(X3P(r)), V(X3P(r)), V(S0P(r))])]
+        if k % P:
+            t.append(_term(P - k, [V(X3P(r)), V(X3P(r))]))
+        cons.append((O.SEL_ALL, t))
+        lin[0] = {SBP(r): 1}
+        total = {}
+        for f in lin:
+            for c, v in f.items():
+                total[c] = (total.get(c, 0) + v) % P
+        lin = [{c: (diag[i] * lin[i].get(c, 0) + total.get(c, 0)) % P for c in set(lin[i]) | set(total)} for i in range(16)]
+    for i in range(16):
+        cons.append((O.SEL_ALL, _linear_def(SP + i, lin[i])))
+    for r in range(4, 8):
+        external_round(r)
+    for j in range(8):
+        cons.append((O.SEL_ALL, [_term(1, [V(D + j)]), _term(P - 1, [V(IN + j)]), _term(1, [V(BIT), V(IN + j)]), _term(P - 1, [V(BIT), V(IN + 8 + j)])]))
+    for b in (BIT, CH, END):
+        cons.append((O.SEL_ALL, [_term(1, [V(b), V(b)]), _term(P - 1, [V(b)])]))
+    cons.append((O.SEL_FIRST, [_term(1, [V(CH)])]))
+    for j in range(8):
+        cons.append((O.SEL_TRANSITION, [_term(1, [V(CH, True), V(D + j, True)]), _term(P - 1, [V(CH, True), V(OUTE(7) + j)])]))
+    for j in range(8):
+        cons.append((O.SEL_ALL, [_term(1, [V(END), V(OUTE(7) + j)]), _term(P - 1, [V(END), V(j, public=True)])]))
+    cons.append((O.SEL_FIRST, [_term(1, [V(CNT)]), _term(P - 1, [V(END)])]))
+    cons.append((O.SEL_TRANSITION, [_term(1, [V(CNT, True)]), _term(P - 1, [V(CNT)]), _term(P - 1, [V(END, True)])]))
+    cons.append((O.SEL_LAST, [_term(1, [V(CNT)]), _term(P - 1, [V(8, public=True)])]))
+    return O.air_program(WIDTH, N_PUBLIC, cons)
+
+
+def row(state_in, bit=0, ch=0, end=0, cnt=0):
+    """one trace row: every intermediate of poseidon2(state_in) -> (row, output state)"""
+    ME, MI, rc_e, rc_i = pyref.ME, pyref.MI, PARAMS["external_rc"], PARAMS["internal_rc"]
+    t = [0] * WIDTH
+    s = [x % P for x in state_in]
+    t[IN:IN + 16] = s
+    s = pyref._matvec(ME, s)
+    t[S0:S0 + 16] = s
+
+    def external_round(r, s):
+        y = [(s[i] + rc_e[r][i]) % P for i in range(16)]
+        x3 = [pow(v, 3, P) for v in y]
+        t[X3E(r):X3E(r) + 16] = x3
+        s = pyref._matvec(ME, [x3[i] * x3[i] % P * y[i] % P for i in range(16)])
+        t[OUTE(r):OUTE(r) + 16] = s
+        return s
+    for r in range(4):
+        s = external_round(r, s)
+    for r in range(13):
+        t[S0P(r)] = s[0]
+        y = (s[0] + rc_i[r]) % P
+        t[X3P(r)] = pow(y, 3, P)
+        s[0] = t[SBP(r)] = pow(y, 7, P)
+        s = pyref._matvec(MI, s)
+    t[SP:SP + 16] = s
+    for r in range(4, 8):
+        s = external_round(r, s)
+    for j in range(8):
+        t[D + j] = state_in[8 + j] % P if bit else state_in[j] % P
+    t[BIT], t[CH], t[END], t[CNT] = bit, ch, end, cnt % P
+    return t, s
+
+
+def merkle_trace(leaves, siblings, indices, log_n=None):
+    """paths p: leaf digest leaves[p] (8 values), siblings[p][level] (8 values each), indices[p] (bit `level`: the node is a right child)
+    -> (trace [2^log_n][WIDTH], roots [n_paths][8]); rows after the paths are permutations of the zero state with no flags"""
+    n_paths, depth = len(leaves), len(siblings[0])
+    rows, roots, cnt = [], [], 0
+    for p in range(n_paths):
+        digest = [int(v) % P for v in leaves[p]]
+        for lvl in range(depth):
+            bit = (int(indices[p]) >> lvl) & 1
+            sib = [int(v) % P for v in siblings[p][lvl]]
+            end = 1 if lvl == depth - 1 else 0
+            cnt += end
+            r, out = row(sib + digest if bit else digest + sib, bit, 1 if lvl else 0, end, cnt)
+            rows.append(r)
+            digest = out[:8]
+        roots.append(digest)
+    need = max(len(rows), 32)
+    if log_n is None:
+        log_n = max(5, (need - 1).bit_length())
+    pad, _ = row([0] * 16, 0, 0, 0, cnt)
+    rows += [pad] * ((1 << log_n) - len(rows))
+    return np.array(rows, dtype=np.uint64).astype(np.uint32), roots
+
+
+def tree_paths(n_leaves_log, n_paths, seed=1):
+    """a random tree of 2^n_leaves_log leaf digests and n_paths openings of it -> (leaves, siblings, indices, root)"""
+    rng = np.random.default_rng(seed)
+    level = [[int(v) for v in rng.integers(0, P, 8)] for _ in range(1 << n_leaves_log)]
+    levels = [level]
+    while len(level) > 1:
+        level = [pyref.compress(level[2 * i], level[2 * i + 1]) for i in range(len(level) // 2)]
+        levels.append(level)
+    idx = [int(v) for v in rng.integers(0, 1 << n_leaves_log, n_paths)]
+    leaves = [levels[0][i] for i in idx]
+    sibs = [[levels[l][(i >> l) ^ 1] for l in range(n_leaves_log)] for i in idx]
+    return leaves, sibs, idx, levels[-1][0]

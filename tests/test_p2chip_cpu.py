@@ -1,0 +1,98 @@
+"""The Poseidon2 permutation chip with Merkle-path chaining (csrc/poseidon2_chip.cpp), CPU side: the product's program generator against
+the independent Python restatement (tests/poseidon2_air.py, on tests/pyref.py's Poseidon2), the oracle proving the Python-generated trace,
+both verifiers, what the chip's constraints catch."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+import poseidon2_air as A
+from zktls_amd import _lib
+from zktls_amd._lib import Params
+from zktls_amd.device import p2chip_air, verify_merkle_paths, verify_shard_air
+
+P = 2013265921
+
+
+def test_program_equals_the_python_restatement(oracle):
+    prog = A.program()
+    assert prog.tolist() == p2chip_air().tolist()
+    assert oracle.air_validate(prog, A.WIDTH, A.N_PUBLIC) == 1 and oracle.air_log_quotient_degree(prog) == 1
+    assert A.WIDTH == 356 and prog[3] == 358 and prog.size == 25400
+
+
+def test_program_follows_the_poseidon2_tables(tmp_path):
+    """the round constants are coefficients of the program: another table set, another program (and another digest in every proof)"""
+    import json
+    import os
+    L = _lib.load()
+    before = p2chip_air()
+    params = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "poseidon2_params.json")))
+    f = {"width": 16, "name": "test/p2chip", "external_rc": params["external_rc"], "internal_rc": list(params["internal_rc"]), "internal_diag": params["internal_diag"]}
+    f["internal_rc"][3] = (f["internal_rc"][3] + 1) % P
+    path = tmp_path / "p2.json"
+    path.write_text(json.dumps(f))
+    try:
+        assert L.zkhip_load_poseidon2_params(str(path).encode()) == 0
+        other = p2chip_air()
+        assert other.size == before.size and other.tolist() != before.tolist()
+    finally:
+        L.zkhip_reset_poseidon2_params()
+    assert p2chip_air().tolist() == before.tolist()
+
+
+@pytest.mark.parametrize("shape", [(1, 6, 4), (2, 4, 0)])
+def test_paths_proven_by_the_oracle_verify_everywhere(oracle, shape):
+    O = oracle
+    leaves, sibs, idx, root = A.tree_paths(4, 6, seed=3)
+    trace, roots = A.merkle_trace(leaves, sibs, idx)
+    assert all(r == root for r in roots) and trace.shape == (32, A.WIDTH)
+    prog, pub = A.program(), root + [6]
+    oprm, prm = O.default_params(*shape), Params(*shape)
+    proof = O.prove_shard_air(prog, trace, pub, oprm)
+    assert O.verify_shard_air(prog, proof, 5, A.WIDTH, pub, oprm) == 0
+    assert verify_shard_air(prog, proof, 5, A.WIDTH, pub, prm) == (0, 0)
+    assert verify_merkle_paths(proof, root, 6, prm) == (0, 0)
+    # another count, another root
+    assert verify_merkle_paths(proof, root, 5, prm) == (-6, 10)
+    assert verify_merkle_paths(proof, [root[0] ^ 1] + root[1:], 6, prm) == (-6, 10)
+
+
+def test_what_the_constraints_catch(oracle):
+    """a wrong sibling (the path no longer reaches the root), a broken chain, a forged intermediate, a miscounted END: each makes the AIR
+    identity fail at zeta (check 10) although the FRI part of such a proof is fine"""
+    O = oracle
+    leaves, sibs, idx, root = A.tree_paths(3, 5, seed=8)
+    trace, _ = A.merkle_trace(leaves, sibs, idx)
+    prog, pub = A.program(), root + [5]
+    oprm, prm = O.default_params(1, 5, 3), Params(1, 5, 3)
+
+    def verdict(t):
+        return verify_shard_air(prog, O.prove_shard_air(prog, t, pub, oprm), trace.shape[0].bit_length() - 1, A.WIDTH, pub, prm)
+    assert verdict(trace) == (0, 0)
+    for row, col in ((1, A.IN + 9), (4, A.D + 2), (7, A.X3E(5) + 3), (2, A.SBP(6)), (9, A.SP + 11), (5, A.CNT), (3, A.BIT), (14, A.END), (0, A.CH)):
+        bad = trace.copy()
+        bad[row, col] = (int(bad[row, col]) + 1) % P
+        assert verdict(bad) == (-6, 10), (row, col)
+    # a path spliced from two trees: the chain constraint ties a row's digest-carrying half to the previous row's output
+    l2, s2, i2, r2 = A.tree_paths(3, 5, seed=9)
+    t2, _ = A.merkle_trace(l2, s2, i2)
+    spliced = trace.copy()
+    spliced[1] = t2[1]
+    assert verdict(spliced) == (-6, 10)
+
+
+def test_entries_check_their_arguments():
+    L = _lib.load()
+    prm = Params(1, 10, 4)
+    assert L.zkhip_merkle_paths_proof_size(0, 4, C.byref(prm)) == 0
+    assert L.zkhip_merkle_paths_proof_size(4, 0, C.byref(prm)) == 0
+    assert L.zkhip_merkle_paths_proof_size(4, 33, C.byref(prm)) == 0
+    assert L.zkhip_merkle_paths_proof_size(1 << 22, 2, C.byref(prm)) == 0
+    assert L.zkhip_merkle_paths_proof_size(100, 10, C.byref(prm)) > 0
+    # without a GPU the device entries fail loudly
+    z = (C.c_uint32 * 8)()
+    got = C.c_size_t(0)
+    buf = (C.c_uint8 * 16)()
+    assert L.zkhip_prove_merkle_paths(None, z, z, z, 1, 1, z, C.byref(prm), buf, 16, C.byref(got)) != 0
+    assert L.zkhip_verify_merkle_paths(buf, 16, z, 1, C.byref(prm), None) != 0

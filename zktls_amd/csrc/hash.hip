@@ -12,6 +12,7 @@
 // traffic is needed.
 #include "poseidon2.cuh"
 #include "kernels.h"
+#include "p2chip.h"
 
 namespace zk {
 
@@ -451,6 +452,69 @@ __global__ void __launch_bounds__(256) permute_states_kernel(uint32_t* states, u
 hipError_t launch_permute_states(uint32_t* states, uint64_t count, hipStream_t s) {
     if (count == 0) return hipSuccess;
     hipLaunchKernelGGL(permute_states_kernel, dim3((unsigned)((count + 255) / 256)), dim3(256), 0, s, states, count);
+    return hipGetLastError();
+}
+
+// ------------------------------------------------------------------ trace of the Poseidon2 permutation chip (p2chip.h)
+// One row = one permutation with every intermediate the chip's constraints name (poseidon2_chip.cpp); Merkle paths: one lane walks one
+// path from its leaf to the root, a row per level (the levels of a path depend on each other; the paths do not).
+__device__ void p2chip_fill_row(uint32_t* t, const uint32_t in[16], uint32_t bit, uint32_t ch, uint32_t end, uint32_t cnt, uint32_t out8[8]) {
+    using namespace p2chip;
+    uint32_t s[16];
+    for (int i = 0; i < 16; i++) { s[i] = in[i]; t[IN + i] = in[i]; }
+    p2_external_linear(s);
+    for (int i = 0; i < 16; i++) t[S0 + i] = s[i];
+    auto external_round = [&](int r) {
+        for (int i = 0; i < 16; i++) {
+            const uint32_t y = fadd(s[i], P2K.ext_rc[r][i]);
+            const uint32_t x3 = fmul(fmul(y, y), y);
+            t[x3e(r) + i] = x3;
+            s[i] = fmul(fmul(x3, x3), y);
+        }
+        p2_external_linear(s);
+        for (int i = 0; i < 16; i++) t[oute(r) + i] = s[i];
+    };
+    for (int r = 0; r < 4; r++) external_round(r);
+    for (int r = 0; r < 13; r++) {
+        t[s0p(r)] = s[0];
+        const uint32_t y = fadd(s[0], P2K.int_rc[r]);
+        const uint32_t x3 = fmul(fmul(y, y), y);
+        t[x3p(r)] = x3;
+        s[0] = fmul(fmul(x3, x3), y);
+        t[sbp(r)] = s[0];
+        p2_internal_linear(s);
+    }
+    for (int i = 0; i < 16; i++) t[SP + i] = s[i];
+    for (int r = 4; r < 8; r++) external_round(r);
+    for (int j = 0; j < 8; j++) { t[D + j] = bit ? in[8 + j] : in[j]; out8[j] = s[j]; }
+    t[BIT] = bit ? MONTY_R1 : 0u; t[CH] = ch ? MONTY_R1 : 0u; t[END] = end ? MONTY_R1 : 0u; t[CNT] = to_monty(cnt);
+    t[CNT + 1] = 0u;
+}
+__global__ void __launch_bounds__(64) p2chip_merkle_kernel(p2chip::MerkleTraceArgs a) {
+    const uint64_t p = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const uint64_t path_rows = a.n_paths * a.depth;
+    if (p < a.n_paths) {
+        uint32_t digest[8], in[16];
+        for (int j = 0; j < 8; j++) digest[j] = to_monty(a.leaves[8 * p + j]);
+        const uint32_t index = a.indices[p];
+        for (uint32_t lvl = 0; lvl < a.depth; lvl++) {
+            const uint32_t bit = (index >> lvl) & 1u;
+            const uint32_t* sib = a.siblings + 8 * (p * a.depth + lvl);
+            for (int j = 0; j < 8; j++) { in[bit ? 8 + j : j] = digest[j]; in[bit ? j : 8 + j] = to_monty(sib[j]); }
+            const uint32_t end = lvl + 1 == a.depth ? 1u : 0u;
+            p2chip_fill_row(a.trace + (p * a.depth + lvl) * a.ld, in, bit, lvl ? 1u : 0u, end, (uint32_t)p + end, digest);
+        }
+        for (int j = 0; j < 8; j++) a.roots[8 * p + j] = from_monty(digest[j]);
+        return;
+    }
+    const uint64_t row = path_rows + (p - a.n_paths);          // the rows after the paths: permutations of the zero state, no flags
+    if (row >= a.rows) return;
+    uint32_t zero[16] = {0}, out8[8];
+    p2chip_fill_row(a.trace + row * a.ld, zero, 0u, 0u, 0u, (uint32_t)a.n_paths, out8);
+}
+hipError_t launch_p2chip_merkle(const p2chip::MerkleTraceArgs& a, hipStream_t s) {
+    const uint64_t lanes = a.n_paths + (a.rows - a.n_paths * a.depth);
+    hipLaunchKernelGGL(p2chip_merkle_kernel, dim3((unsigned)((lanes + 63) / 64)), dim3(64), 0, s, a);
     return hipGetLastError();
 }
 

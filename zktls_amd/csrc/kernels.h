@@ -123,6 +123,9 @@ hipError_t launch_merkle_p24_rowmajor(const uint32_t* mat, uint64_t ld, uint32_t
 struct P2Tables;
 hipError_t hash_upload_p2_tables(const P2Tables& t, hipStream_t s);
 hipError_t stark_upload_p2_tables(const P2Tables& t, hipStream_t s);
+// trace of the Poseidon2 permutation chip for a set of Merkle paths (p2chip.h)
+namespace p2chip { struct MerkleTraceArgs; }
+hipError_t launch_p2chip_merkle(const p2chip::MerkleTraceArgs& a, hipStream_t s);
 // raw permutation on `count` states of 16 words (KAT / microbenchmark)
 hipError_t launch_permute_states(uint32_t* states, uint64_t count, hipStream_t s);
 

@@ -359,6 +359,36 @@ class Context:
                                           buf.ctypes.data_as(u8p), size, C.byref(got)))
         return digest.tobytes(), buf[: got.value]
 
+    def p2chip_gen_merkle_trace(self, leaves, siblings, indices, log_n=None):
+        """the Poseidon2 chip's trace for a set of Merkle paths (numpy arrays of canonical words: leaves [n][8], siblings [n][depth][8],
+        indices [n]) -> (device buffer [2^log_n][356], roots [n][8], log_n)"""
+        lv = np.ascontiguousarray(leaves, dtype=np.uint32)
+        sb = np.ascontiguousarray(siblings, dtype=np.uint32)
+        ix = np.ascontiguousarray(indices, dtype=np.uint32)
+        n, depth = lv.shape[0], sb.shape[1]
+        if log_n is None:
+            log_n = max(5, (n * depth - 1).bit_length())
+        out = self.alloc(356 << log_n)
+        roots = np.zeros((n, 8), dtype=np.uint32)
+        check(self.lib.zkhip_p2chip_gen_merkle_trace(self.handle, lv.ctypes.data_as(u32p), sb.ctypes.data_as(u32p), ix.ctypes.data_as(u32p), n, depth, log_n,
+                                                     C.c_void_p(out.ptr), 356, roots.ctypes.data_as(u32p)))
+        return out, roots, log_n
+
+    def prove_merkle_paths(self, leaves, siblings, indices, root, params=None):
+        """-> proof bytes of "I know len(leaves) Merkle paths that end in root" (the Poseidon2 chip)"""
+        params = params or Params(1, 100, 16)
+        lv = np.ascontiguousarray(leaves, dtype=np.uint32)
+        sb = np.ascontiguousarray(siblings, dtype=np.uint32)
+        ix = np.ascontiguousarray(indices, dtype=np.uint32)
+        rt = np.ascontiguousarray(root, dtype=np.uint32)
+        n, depth = lv.shape[0], sb.shape[1]
+        size = self.lib.zkhip_merkle_paths_proof_size(n, depth, C.byref(params))
+        buf = np.empty(max(size, 1), dtype=np.uint8)
+        got = C.c_size_t(0)
+        check(self.lib.zkhip_prove_merkle_paths(self.handle, lv.ctypes.data_as(u32p), sb.ctypes.data_as(u32p), ix.ctypes.data_as(u32p), n, depth,
+                                                rt.ctypes.data_as(u32p), C.byref(params), buf.ctypes.data_as(u8p), size, C.byref(got)))
+        return buf[: got.value]
+
     def sha256_setup(self, params=None):
         """zkhip_sha256_setup: the SHA-256 machine's key (the range table's preprocessed values, committed once) -> MachineKey; .root is the vk"""
         params = params or Params(1, 100, 16)
@@ -679,6 +709,25 @@ def prove_transcripts(messages, params=None, devices=None, in_flight=4):
     devs = (C.c_int * len(devices))(*devices) if devices else None
     check(lib.zkhip_prove_transcripts(devs, len(devices) if devices else 0, jobs, n, C.byref(params), in_flight, vk.ctypes.data_as(u32p)))
     return vk, [(bytes(jobs[i].digest), keep[i][1][: jobs[i].proof_len]) for i in range(n)]
+
+
+def p2chip_air():
+    """the Poseidon2 chip's constraint program for the parameter set in effect"""
+    lib = _lib.load()
+    n = lib.zkhip_p2chip_air(None, 0)
+    out = np.empty(n, dtype=np.uint32)
+    assert lib.zkhip_p2chip_air(out.ctypes.data_as(u32p), n) == n
+    return out
+
+
+def verify_merkle_paths(proof, root, n_paths, params=None):
+    params = params or Params(1, 100, 16)
+    lib = _lib.load()
+    pr = np.ascontiguousarray(proof, dtype=np.uint8)
+    rt = np.ascontiguousarray(root, dtype=np.uint32)
+    reason = C.c_int(0)
+    rc = lib.zkhip_verify_merkle_paths(pr.ctypes.data_as(u8p), pr.size, rt.ctypes.data_as(u32p), n_paths, C.byref(params), C.byref(reason))
+    return rc, reason.value
 
 
 def verify_sha256_machine(proof, digest, vk, params=None):
