@@ -133,6 +133,16 @@ def main():
         keyed[name] = {"machine": list(args), "params": list(prm), "root": [int(v) for v in root], "bytes": int(pf.size),
                        "sha256": hashlib.sha256(pf.tobytes()).hexdigest()}
     out["keyed_machine_proofs"] = keyed
+    # the Poseidon2 chip (tests/poseidon2_air.py): its program's digest and one proof of Merkle paths
+    import poseidon2_air
+    leaves, sibs, idx, root = poseidon2_air.tree_paths(4, 7, seed=11)
+    trace, _ = poseidon2_air.merkle_trace(leaves, sibs, idx)
+    prog = poseidon2_air.program()
+    params = O.default_params(1, 8, 4)
+    pf = O.prove_shard_air(prog, trace, root + [7], params)
+    assert O.verify_shard_air(prog, pf, 5, poseidon2_air.WIDTH, root + [7], params) == 0
+    out["p2chip"] = {"paths": [4, 7, 11], "params": [1, 8, 4], "program_words": int(prog.size), "program_digest": [int(v) for v in O.air_digest(prog)],
+                     "root": [int(v) for v in root], "bytes": int(pf.size), "sha256": hashlib.sha256(pf.tobytes()).hexdigest()}
     # complete proof BYTES of small shards, one per proof version (tests/golden/proofs/*.bin): what the independent pure-Python
     # verifier (tests/pyverify.py, written from DESIGN.md sections 3 and 6) and the product's host verifier check on the CPU, and
     # what the HIP prover must reproduce byte for byte on the GPU.  shape = (log_blowup, queries, pow_bits, logup_pairs,

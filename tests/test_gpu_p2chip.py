@@ -68,3 +68,14 @@ def test_openings_of_the_librarys_own_commitment_in_circuit(ctx, oracle):
     # the leaf digest of an opened row is the sponge of that row: the first path's leaf against the oracle's hash of the LDE row
     row = lde.download().reshape(-1, 16)[int(idx[0])]
     assert (O.sponge_hash(row) == leaves[0]).all()
+
+
+def test_golden_proof_on_gpu(ctx):
+    """the committed proof (size, SHA-256 of the bytes) reproduced by the HIP path without the oracle in the loop"""
+    import hashlib
+    import json
+    import os
+    g = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "oracle_kat.json")))["p2chip"]
+    leaves, sibs, idx, root = A.tree_paths(*g["paths"][:2], seed=g["paths"][2])
+    proof = ctx.prove_merkle_paths(leaves, sibs, idx, root, Params(*g["params"]))
+    assert proof.size == g["bytes"] and hashlib.sha256(proof.tobytes()).hexdigest() == g["sha256"]

@@ -96,3 +96,20 @@ def test_entries_check_their_arguments():
     buf = (C.c_uint8 * 16)()
     assert L.zkhip_prove_merkle_paths(None, z, z, z, 1, 1, z, C.byref(prm), buf, 16, C.byref(got)) != 0
     assert L.zkhip_verify_merkle_paths(buf, 16, z, 1, C.byref(prm), None) != 0
+
+
+def test_golden_program_digest_and_proof(oracle):
+    """the committed fixture (tests/golden/make_golden.py): the program's digest -- the words every proof of the chip carries -- and one
+    proof of seven paths, reproduced by the oracle from the Python restatement and accepted by the product's verifier"""
+    import hashlib
+    import json
+    import os
+    g = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "oracle_kat.json")))["p2chip"]
+    prog = p2chip_air()
+    assert prog.size == g["program_words"] and oracle.air_digest(prog).tolist() == g["program_digest"]
+    leaves, sibs, idx, root = A.tree_paths(*g["paths"][:2], seed=g["paths"][2])
+    assert root == g["root"]
+    trace, _ = A.merkle_trace(leaves, sibs, idx)
+    pf = oracle.prove_shard_air(A.program(), trace, root + [g["paths"][1]], oracle.default_params(*g["params"]))
+    assert pf.size == g["bytes"] and hashlib.sha256(pf.tobytes()).hexdigest() == g["sha256"]
+    assert verify_merkle_paths(pf, root, g["paths"][1], Params(*g["params"])) == (0, 0)

@@ -7,16 +7,29 @@ import oracle_lib as O
 import airs
 from zktls_amd.device import Context, verify_shard, verify_chips, verify_shard_air, verify_chips_air, verify_machine, verify_machine_keyed
 import machines
+import poseidon2_air
 from zktls_amd._lib import Params
 O.set_threads(8)
 budget = float(sys.argv[1]) if len(sys.argv) > 1 else 60.0
 rng = np.random.default_rng(int(time.time()))
 ctx = Context(0)
-t0 = time.time(); n_single = n_chips = n_air = n_machine = n_lookup = n_keyed = 0
+t0 = time.time(); n_single = n_chips = n_air = n_machine = n_lookup = n_keyed = n_p2 = 0
 SEED = int(rng.integers(1, 2**40))
 while time.time() - t0 < budget:
     r_kind = rng.random()
-    if r_kind < 0.03:
+    if r_kind < 0.01:
+        # the Poseidon2 chip: random Merkle paths of a random tree; device trace against the Python restatement, proof bytes against the oracle
+        depth, n_paths = int(rng.integers(1, 6)), int(rng.integers(1, 12))
+        leaves, sibs, idx, root = poseidon2_air.tree_paths(depth, n_paths, seed=int(rng.integers(0, 2**31)))
+        trace, _ = poseidon2_air.merkle_trace(leaves, sibs, idx)
+        shape = (int(rng.integers(1, 4)), int(rng.integers(1, 12)), int(rng.integers(0, 7)))
+        d, droots, log_n = ctx.p2chip_gen_merkle_trace(leaves, sibs, idx)
+        assert (d.download().reshape(-1, poseidon2_air.WIDTH) == trace).all(), ("p2chip trace", depth, n_paths)
+        d.free()
+        pf = ctx.prove_merkle_paths(leaves, sibs, idx, root, Params(*shape))
+        assert pf.tobytes() == O.prove_shard_air(poseidon2_air.program(), trace, root + [n_paths], O.default_params(*shape)).tobytes(), ("p2chip", depth, n_paths, shape)
+        n_p2 += 1
+    elif r_kind < 0.03:
         # a keyed machine: some tables have preprocessed columns, committed once by setup (version 11); two proofs against one key
         if rng.random() < 0.4:
             traces, pre, progs, tables, pub = machines.byte_machine(int(rng.integers(5, 11)), int(rng.integers(3, 6)), seed=int(rng.integers(0, 2**31)))
@@ -141,5 +154,5 @@ while time.time() - t0 < budget:
         assert verify_chips(pf, [c[0] for c in chips], [c[1] for c in chips], [7], Params(*prm), prs, pas if cross else None) == (0, 0)
         for d in dev: d.free()
         n_chips += 1
-print("ok: %d single-matrix, %d multi-chip, %d constraint-program, %d chips-with-programs, %d lookup-machine and %d keyed-machine configurations in %.0f s"
-      % (n_single, n_chips, n_air, n_machine, n_lookup, n_keyed, time.time() - t0))
+print("ok: %d single-matrix, %d multi-chip, %d constraint-program, %d chips-with-programs, %d lookup-machine, %d keyed-machine and %d Poseidon2-chip configurations in %.0f s"
+      % (n_single, n_chips, n_air, n_machine, n_lookup, n_keyed, n_p2, time.time() - t0))
