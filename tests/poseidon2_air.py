@@ -2,7 +2,7 @@
 is csrc/poseidon2_chip.hip).  This is the workhorse of a recursion machine: a STARK verifier inside a STARK spends its rows on Poseidon2
 (Merkle paths of the FRI queries, the transcript) -- sp1-recursion's Poseidon2 chips, reference Cargo.lock:6172 ff.
 
-One row = one permutation `out = poseidon2(in)` of tests/pyref.py (this repo's parameter set).  356 columns, every constraint of degree
+One row = one permutation `out = poseidon2(in)` of tests/pyref.py (this repo's parameter set).  360 columns, every constraint of degree
 <= 3 including its selector (log_quotient_degree 1):
   IN   16   the input state
   S0   16   the state after the initial external layer
@@ -15,8 +15,11 @@ One row = one permutation `out = poseidon2(in)` of tests/pyref.py (this repo's p
   BIT, CH, END  booleans: the node of this row is a RIGHT child; the row continues the path of the previous row (D = the previous
             row's digest OUTE[7][0..8]); the row ends a path (its digest is the public root)
   CNT       running count of END rows; the last row's CNT is the public count
-Public values: root[8], count.  What a proof says: "I know `count` Merkle paths -- leaves, siblings and positions are the prover's --
-that end in `root`" (truncated-permutation compression, as the commitments of this repo and of p3-merkle-tree).
+  SPG, SS   booleans for LEAF HASHING (the overwrite-mode sponge over a row of 8 k values): SS = the row absorbs the first 8 values of a leaf
+            (its capacity half IN[8..16] is zero); SPG = the row absorbs the next 8 values (its capacity half is the previous row's
+            OUTE[7][8..16]).  The row after a leaf's last sponge row starts the path with CH = 1: its D is the leaf digest.
+Public values: root[8], count.  What a proof says: "I know `count` openings -- rows or leaf digests, siblings and positions are the
+prover's -- that end in `root`" (sponge + truncated-permutation compression, as the commitments of this repo and of p3-merkle-tree).
 """
 import numpy as np
 
@@ -29,8 +32,8 @@ PARAMS = pyref.PARAMS
 
 IN, S0 = 0, 16
 SP, D = 327, 343
-BIT, CH, END, CNT = 351, 352, 353, 354
-WIDTH = 356
+BIT, CH, END, CNT, SPG, SS = 351, 352, 353, 354, 355, 356
+WIDTH = 360
 N_PUBLIC = 9
 
 
@@ -114,9 +117,14 @@ def program():
         external_round(r)
     for j in range(8):
         cons.append((O.SEL_ALL, [_term(1, [V(D + j)]), _term(P - 1, [V(IN + j)]), _term(1, [V(BIT), V(IN + j)]), _term(P - 1, [V(BIT), V(IN + 8 + j)])]))
-    for b in (BIT, CH, END):
+    for b in (BIT, CH, END, SPG, SS):
         cons.append((O.SEL_ALL, [_term(1, [V(b), V(b)]), _term(P - 1, [V(b)])]))
     cons.append((O.SEL_FIRST, [_term(1, [V(CH)])]))
+    cons.append((O.SEL_FIRST, [_term(1, [V(SPG)])]))
+    for j in range(8):
+        cons.append((O.SEL_TRANSITION, [_term(1, [V(SPG, True), V(IN + 8 + j, True)]), _term(P - 1, [V(SPG, True), V(OUTE(7) + 8 + j)])]))
+    for j in range(8):
+        cons.append((O.SEL_ALL, [_term(1, [V(SS), V(IN + 8 + j)])]))
     for j in range(8):
         cons.append((O.SEL_TRANSITION, [_term(1, [V(CH, True), V(D + j, True)]), _term(P - 1, [V(CH, True), V(OUTE(7) + j)])]))
     for j in range(8):
@@ -127,7 +135,7 @@ def program():
     return O.air_program(WIDTH, N_PUBLIC, cons)
 
 
-def row(state_in, bit=0, ch=0, end=0, cnt=0):
+def row(state_in, bit=0, ch=0, end=0, cnt=0, spg=0, ss=0):
     """one trace row: every intermediate of poseidon2(state_in) -> (row, output state)"""
     ME, MI, rc_e, rc_i = pyref.ME, pyref.MI, PARAMS["external_rc"], PARAMS["internal_rc"]
     t = [0] * WIDTH
@@ -156,23 +164,32 @@ def row(state_in, bit=0, ch=0, end=0, cnt=0):
         s = external_round(r, s)
     for j in range(8):
         t[D + j] = state_in[8 + j] % P if bit else state_in[j] % P
-    t[BIT], t[CH], t[END], t[CNT] = bit, ch, end, cnt % P
+    t[BIT], t[CH], t[END], t[CNT], t[SPG], t[SS] = bit, ch, end, cnt % P, spg, ss
     return t, s
 
 
-def merkle_trace(leaves, siblings, indices, log_n=None):
-    """paths p: leaf digest leaves[p] (8 values), siblings[p][level] (8 values each), indices[p] (bit `level`: the node is a right child)
+def merkle_trace(leaves, siblings, indices, log_n=None, hashed_rows=False):
+    """paths p: leaf digest leaves[p] (8 values) -- or, with hashed_rows, the opened ROW leaves[p] (8 k values), hashed by k sponge rows
+    first --, siblings[p][level] (8 values each), indices[p] (bit `level`: the node is a right child)
     -> (trace [2^log_n][WIDTH], roots [n_paths][8]); rows after the paths are permutations of the zero state with no flags"""
     n_paths, depth = len(leaves), len(siblings[0])
     rows, roots, cnt = [], [], 0
     for p in range(n_paths):
         digest = [int(v) % P for v in leaves[p]]
+        if hashed_rows:
+            vals, cap = digest, [0] * 8
+            assert len(vals) % 8 == 0 and vals
+            for k in range(0, len(vals), 8):
+                r, out = row(vals[k:k + 8] + cap, 0, 0, 0, cnt, 1 if k else 0, 0 if k else 1)
+                rows.append(r)
+                cap = out[8:]
+            digest = out[:8]
         for lvl in range(depth):
             bit = (int(indices[p]) >> lvl) & 1
             sib = [int(v) % P for v in siblings[p][lvl]]
             end = 1 if lvl == depth - 1 else 0
             cnt += end
-            r, out = row(sib + digest if bit else digest + sib, bit, 1 if lvl else 0, end, cnt)
+            r, out = row(sib + digest if bit else digest + sib, bit, 1 if (lvl or hashed_rows) else 0, end, cnt)
             rows.append(r)
             digest = out[:8]
         roots.append(digest)

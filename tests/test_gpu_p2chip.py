@@ -70,6 +70,54 @@ def test_openings_of_the_librarys_own_commitment_in_circuit(ctx, oracle):
     assert (O.sponge_hash(row) == leaves[0]).all()
 
 
+@pytest.mark.parametrize("case", [(3, 3, 8, 1), (2, 5, 24, 2), (4, 2, 64, 3)])
+def test_hashed_row_trace_equals_the_python_restatement(ctx, case):
+    depth, n_paths, row_width, seed = case
+    rng = np.random.default_rng(seed)
+    rows_ = rng.integers(0, 2013265921, (n_paths, row_width)).astype(np.uint32)
+    sibs = rng.integers(0, 2013265921, (n_paths, depth, 8)).astype(np.uint32)
+    idx = rng.integers(0, 1 << depth, n_paths).astype(np.uint32)
+    trace, roots = A.merkle_trace(rows_.tolist(), sibs.tolist(), idx.tolist(), hashed_rows=True)
+    d, droots, log_n = ctx.p2chip_gen_merkle_trace(rows_, sibs, idx, hashed_rows=True)
+    assert (droots == np.array(roots, dtype=np.uint32)).all()
+    assert (d.download().reshape(-1, A.WIDTH) == trace).all()
+    d.free()
+
+
+def test_the_trace_openings_of_a_real_proof_checked_in_circuit(ctx, oracle):
+    """one step of a recursive verifier on real data: take a shard proof, and prove through the chip what its verifier does for the trace
+    commitment of every query -- hash the opened row (sponge) and walk the path to the committed root"""
+    from zktls_amd.device import verify_shard
+    O = oracle
+    log_n, W, Q = 10, 16, 40
+    H = log_n + 1
+    prm = Params(1, Q, 8)
+    t = ctx.gen_trace(SEED, 0, log_n, W)
+    proof = ctx.prove_shard(t, log_n, W, [1, 2, 3], prm)
+    assert verify_shard(proof, log_n, W, [1, 2, 3], prm) == (0, 0)
+    w = np.frombuffer(proof.tobytes(), dtype=np.uint32)
+    troot = w[8:16]
+    pos = 8 + 16 + 8 * W + 32 + 8 * log_n + 4 + 1                    # header, two roots, openings, FRI commitments, final value, witness
+    perq = W + 8 * H + 8 + 8 * H + sum(4 + 8 * (H - 1 - l) for l in range(log_n))
+    assert pos + Q * perq == w.size
+    lde = ctx.coset_lde(t, log_n, W).download().reshape(-1, W)
+    where = {r.tobytes(): i for i, r in enumerate(lde)}
+    rows_, sibs, idx = [], [], []
+    for q in range(Q):
+        base = pos + q * perq
+        row = w[base:base + W]
+        rows_.append(row)
+        sibs.append(w[base + W:base + W + 8 * H].reshape(H, 8))
+        idx.append(where[row.tobytes()])                                 # the query's position: where the opened row sits in the LDE
+    cproof = ctx.prove_merkle_paths(np.array(rows_), np.array(sibs), np.array(idx, dtype=np.uint32), troot, Params(1, 30, 8), hashed_rows=True)
+    assert verify_merkle_paths(cproof, troot, Q, Params(1, 30, 8)) == (0, 0)
+    assert O.verify_shard_air(p2chip_air(), cproof, (Q * (W // 8 + H) - 1).bit_length(), A.WIDTH, troot.tolist() + [Q], O.default_params(1, 30, 8)) == 0
+    # against another root (the quotient commitment's) the same openings are refused by the prover and by the verifier
+    with pytest.raises(ZkHipError):
+        ctx.prove_merkle_paths(np.array(rows_), np.array(sibs), np.array(idx, dtype=np.uint32), w[16:24], Params(1, 30, 8), hashed_rows=True)
+    assert verify_merkle_paths(cproof, w[16:24], Q, Params(1, 30, 8))[0] == -6
+
+
 def test_golden_proof_on_gpu(ctx):
     """the committed proof (size, SHA-256 of the bytes) reproduced by the HIP path without the oracle in the loop"""
     import hashlib

@@ -18,7 +18,7 @@ def test_program_equals_the_python_restatement(oracle):
     prog = A.program()
     assert prog.tolist() == p2chip_air().tolist()
     assert oracle.air_validate(prog, A.WIDTH, A.N_PUBLIC) == 1 and oracle.air_log_quotient_degree(prog) == 1
-    assert A.WIDTH == 356 and prog[3] == 358 and prog.size == 25400
+    assert A.WIDTH == 360 and prog[3] == 377 and prog.size == 25551
 
 
 def test_program_follows_the_poseidon2_tables(tmp_path):
@@ -58,6 +58,36 @@ def test_paths_proven_by_the_oracle_verify_everywhere(oracle, shape):
     assert verify_merkle_paths(proof, [root[0] ^ 1] + root[1:], 6, prm) == (-6, 10)
 
 
+def test_openings_of_whole_rows_hash_the_leaf_in_circuit(oracle):
+    """hashed_rows: a path starts with the sponge rows over the opened row (capacity half chained from row to row), its digest feeds the
+    first compression row; the leaf digests equal pyref's sponge_hash"""
+    import pyref
+    O = oracle
+    rng = np.random.default_rng(5)
+    depth, n = 3, 3
+    rows_ = [[int(v) for v in rng.integers(0, P, 24)] for _ in range(1 << depth)]
+    level = [pyref.sponge_hash(r) for r in rows_]
+    levels = [level]
+    while len(level) > 1:
+        level = [pyref.compress(level[2 * i], level[2 * i + 1]) for i in range(len(level) // 2)]
+        levels.append(level)
+    idx = [5, 0, 6]
+    sibs = [[levels[l][(i >> l) ^ 1] for l in range(depth)] for i in idx]
+    trace, roots = A.merkle_trace([rows_[i] for i in idx], sibs, idx, hashed_rows=True)
+    root = levels[-1][0]
+    assert all(r == root for r in roots) and trace.shape == (32, A.WIDTH)
+    assert trace[:, A.SS].sum() == 3 and trace[:, A.SPG].sum() == 6 and trace[:, A.CH].sum() == 9 and trace[:, A.END].sum() == 3
+    prog, pub = A.program(), root + [n]
+    oprm, prm = O.default_params(1, 5, 3), Params(1, 5, 3)
+    proof = O.prove_shard_air(prog, trace, pub, oprm)
+    assert verify_merkle_paths(proof, root, n, prm) == (0, 0)
+    # an opened value changed without re-hashing, a capacity half that does not follow, a first sponge row with a non-zero capacity half
+    for row, col in ((1, A.IN + 2), (2, A.IN + 12), (0, A.IN + 9), (7, A.SPG), (6, A.SS)):
+        bad = trace.copy()
+        bad[row, col] = (int(bad[row, col]) + 1) % P
+        assert verify_shard_air(prog, O.prove_shard_air(prog, bad, pub, oprm), 5, A.WIDTH, pub, prm) == (-6, 10), (row, col)
+
+
 def test_what_the_constraints_catch(oracle):
     """a wrong sibling (the path no longer reaches the root), a broken chain, a forged intermediate, a miscounted END: each makes the AIR
     identity fail at zeta (check 10) although the FRI part of such a proof is fine"""
@@ -85,16 +115,18 @@ def test_what_the_constraints_catch(oracle):
 def test_entries_check_their_arguments():
     L = _lib.load()
     prm = Params(1, 10, 4)
-    assert L.zkhip_merkle_paths_proof_size(0, 4, C.byref(prm)) == 0
-    assert L.zkhip_merkle_paths_proof_size(4, 0, C.byref(prm)) == 0
-    assert L.zkhip_merkle_paths_proof_size(4, 33, C.byref(prm)) == 0
-    assert L.zkhip_merkle_paths_proof_size(1 << 22, 2, C.byref(prm)) == 0
-    assert L.zkhip_merkle_paths_proof_size(100, 10, C.byref(prm)) > 0
+    assert L.zkhip_merkle_paths_proof_size(0, 4, 0, C.byref(prm)) == 0
+    assert L.zkhip_merkle_paths_proof_size(4, 0, 0, C.byref(prm)) == 0
+    assert L.zkhip_merkle_paths_proof_size(4, 33, 0, C.byref(prm)) == 0
+    assert L.zkhip_merkle_paths_proof_size(1 << 22, 2, 0, C.byref(prm)) == 0
+    assert L.zkhip_merkle_paths_proof_size(100, 10, 12, C.byref(prm)) == 0          # an opened row of 12 values: not a multiple of 8
+    assert L.zkhip_merkle_paths_proof_size(100, 10, 0, C.byref(prm)) > 0
+    assert L.zkhip_merkle_paths_proof_size(100, 10, 256, C.byref(prm)) > L.zkhip_merkle_paths_proof_size(100, 10, 0, C.byref(prm))
     # without a GPU the device entries fail loudly
     z = (C.c_uint32 * 8)()
     got = C.c_size_t(0)
     buf = (C.c_uint8 * 16)()
-    assert L.zkhip_prove_merkle_paths(None, z, z, z, 1, 1, z, C.byref(prm), buf, 16, C.byref(got)) != 0
+    assert L.zkhip_prove_merkle_paths(None, z, 0, z, z, 1, 1, z, C.byref(prm), buf, 16, C.byref(got)) != 0
     assert L.zkhip_verify_merkle_paths(buf, 16, z, 1, C.byref(prm), None) != 0
 
 

@@ -42,5 +42,5 @@ for lp in sorted({10, 14, log_paths}):
     assert verify_merkle_paths(proof, root, n, prm) == (0, 0)
     tv = time.perf_counter() - t0
     rows = 1 << log_n
-    print("2^%d openings of depth %d = 2^%d rows x 356: trace (H2D of paths + kernel) %.1f ms, trace + proof %.1f ms (%.1f M permutations/s proven, %.2f G cells/s), proof %d bytes, verified in %.1f ms"
-          % (lp, depth, log_n, tg * 1e3, dt * 1e3, n * depth / dt / 1e6, rows * 356 / dt / 1e9, proof.size, tv * 1e3))
+    print("2^%d openings of depth %d = 2^%d rows x 360: trace (H2D of paths + kernel) %.1f ms, trace + proof %.1f ms (%.1f M permutations/s proven, %.2f G cells/s), proof %d bytes, verified in %.1f ms"
+          % (lp, depth, log_n, tg * 1e3, dt * 1e3, n * depth / dt / 1e6, rows * 360 / dt / 1e9, proof.size, tv * 1e3))

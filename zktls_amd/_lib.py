@@ -198,10 +198,10 @@ def load():
     L.zkhip_prove_transcripts.argtypes = [C.POINTER(C.c_int), C.c_int, C.POINTER(TranscriptJob), C.c_int, C.POINTER(Params), C.c_int, u32p]
     L.zkhip_p2chip_air.restype = C.c_size_t
     L.zkhip_p2chip_air.argtypes = [u32p, C.c_size_t]
-    L.zkhip_p2chip_gen_merkle_trace.argtypes = [C.c_void_p, u32p, u32p, u32p, C.c_size_t, C.c_int, C.c_int, C.c_void_p, C.c_size_t, u32p]
+    L.zkhip_p2chip_gen_merkle_trace.argtypes = [C.c_void_p, u32p, C.c_uint32, u32p, u32p, C.c_size_t, C.c_int, C.c_int, C.c_void_p, C.c_size_t, u32p]
     L.zkhip_merkle_paths_proof_size.restype = C.c_size_t
-    L.zkhip_merkle_paths_proof_size.argtypes = [C.c_size_t, C.c_int, C.POINTER(Params)]
-    L.zkhip_prove_merkle_paths.argtypes = [C.c_void_p, u32p, u32p, u32p, C.c_size_t, C.c_int, u32p, C.POINTER(Params), u8p, C.c_size_t, szp]
+    L.zkhip_merkle_paths_proof_size.argtypes = [C.c_size_t, C.c_int, C.c_uint32, C.POINTER(Params)]
+    L.zkhip_prove_merkle_paths.argtypes = [C.c_void_p, u32p, C.c_uint32, u32p, u32p, C.c_size_t, C.c_int, u32p, C.POINTER(Params), u8p, C.c_size_t, szp]
     L.zkhip_verify_merkle_paths.argtypes = [u8p, C.c_size_t, u32p, C.c_size_t, C.POINTER(Params), C.POINTER(C.c_int)]
     L.zkhip_sha256_air.restype = C.c_size_t
     L.zkhip_sha256_air.argtypes = [u32p, C.c_size_t]

@@ -458,7 +458,8 @@ hipError_t launch_permute_states(uint32_t* states, uint64_t count, hipStream_t s
 // ------------------------------------------------------------------ trace of the Poseidon2 permutation chip (p2chip.h)
 // One row = one permutation with every intermediate the chip's constraints name (poseidon2_chip.cpp); Merkle paths: one lane walks one
 // path from its leaf to the root, a row per level (the levels of a path depend on each other; the paths do not).
-__device__ void p2chip_fill_row(uint32_t* t, const uint32_t in[16], uint32_t bit, uint32_t ch, uint32_t end, uint32_t cnt, uint32_t out8[8]) {
+__device__ void p2chip_fill_row(uint32_t* t, const uint32_t in[16], uint32_t bit, uint32_t ch, uint32_t end, uint32_t cnt, uint32_t spg, uint32_t ss,
+                                uint32_t out16[16]) {
     using namespace p2chip;
     uint32_t s[16];
     for (int i = 0; i < 16; i++) { s[i] = in[i]; t[IN + i] = in[i]; }
@@ -486,34 +487,46 @@ __device__ void p2chip_fill_row(uint32_t* t, const uint32_t in[16], uint32_t bit
     }
     for (int i = 0; i < 16; i++) t[SP + i] = s[i];
     for (int r = 4; r < 8; r++) external_round(r);
-    for (int j = 0; j < 8; j++) { t[D + j] = bit ? in[8 + j] : in[j]; out8[j] = s[j]; }
+    for (int j = 0; j < 8; j++) t[D + j] = bit ? in[8 + j] : in[j];
+    for (int j = 0; j < 16; j++) out16[j] = s[j];
     t[BIT] = bit ? MONTY_R1 : 0u; t[CH] = ch ? MONTY_R1 : 0u; t[END] = end ? MONTY_R1 : 0u; t[CNT] = to_monty(cnt);
-    t[CNT + 1] = 0u;
+    t[SPG] = spg ? MONTY_R1 : 0u; t[SS] = ss ? MONTY_R1 : 0u;
+    for (uint32_t c = SS + 1; c < WIDTH; c++) t[c] = 0u;
 }
 __global__ void __launch_bounds__(64) p2chip_merkle_kernel(p2chip::MerkleTraceArgs a) {
     const uint64_t p = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    const uint64_t path_rows = a.n_paths * a.depth;
+    const uint32_t sponge_rows = a.row_width / 8;
+    const uint64_t per_path = (uint64_t)sponge_rows + a.depth, path_rows = a.n_paths * per_path;
     if (p < a.n_paths) {
-        uint32_t digest[8], in[16];
-        for (int j = 0; j < 8; j++) digest[j] = to_monty(a.leaves[8 * p + j]);
+        uint32_t out[16], in[16];
+        uint32_t* t = a.trace + p * per_path * a.ld;
+        if (sponge_rows) {                                       // the leaf: the overwrite-mode sponge over the opened row, 8 values per row
+            const uint32_t* vals = a.leaves + p * a.row_width;
+            for (int j = 0; j < 16; j++) out[j] = 0u;
+            for (uint32_t k = 0; k < sponge_rows; k++, t += a.ld) {
+                for (int j = 0; j < 8; j++) { in[j] = to_monty(vals[8 * k + j]); in[8 + j] = out[8 + j]; }
+                p2chip_fill_row(t, in, 0u, 0u, 0u, (uint32_t)p, k ? 1u : 0u, k ? 0u : 1u, out);
+            }
+        } else
+            for (int j = 0; j < 8; j++) out[j] = to_monty(a.leaves[8 * p + j]);
         const uint32_t index = a.indices[p];
-        for (uint32_t lvl = 0; lvl < a.depth; lvl++) {
+        for (uint32_t lvl = 0; lvl < a.depth; lvl++, t += a.ld) {
             const uint32_t bit = (index >> lvl) & 1u;
             const uint32_t* sib = a.siblings + 8 * (p * a.depth + lvl);
-            for (int j = 0; j < 8; j++) { in[bit ? 8 + j : j] = digest[j]; in[bit ? j : 8 + j] = to_monty(sib[j]); }
+            for (int j = 0; j < 8; j++) { in[bit ? 8 + j : j] = out[j]; in[bit ? j : 8 + j] = to_monty(sib[j]); }
             const uint32_t end = lvl + 1 == a.depth ? 1u : 0u;
-            p2chip_fill_row(a.trace + (p * a.depth + lvl) * a.ld, in, bit, lvl ? 1u : 0u, end, (uint32_t)p + end, digest);
+            p2chip_fill_row(t, in, bit, (lvl || sponge_rows) ? 1u : 0u, end, (uint32_t)p + end, 0u, 0u, out);
         }
-        for (int j = 0; j < 8; j++) a.roots[8 * p + j] = from_monty(digest[j]);
+        for (int j = 0; j < 8; j++) a.roots[8 * p + j] = from_monty(out[j]);
         return;
     }
     const uint64_t row = path_rows + (p - a.n_paths);          // the rows after the paths: permutations of the zero state, no flags
     if (row >= a.rows) return;
-    uint32_t zero[16] = {0}, out8[8];
-    p2chip_fill_row(a.trace + row * a.ld, zero, 0u, 0u, 0u, (uint32_t)a.n_paths, out8);
+    uint32_t zero[16] = {0}, out[16];
+    p2chip_fill_row(a.trace + row * a.ld, zero, 0u, 0u, 0u, (uint32_t)a.n_paths, 0u, 0u, out);
 }
 hipError_t launch_p2chip_merkle(const p2chip::MerkleTraceArgs& a, hipStream_t s) {
-    const uint64_t lanes = a.n_paths + (a.rows - a.n_paths * a.depth);
+    const uint64_t lanes = a.n_paths + (a.rows - a.n_paths * ((uint64_t)a.row_width / 8 + a.depth));
     hipLaunchKernelGGL(p2chip_merkle_kernel, dim3((unsigned)((lanes + 63) / 64)), dim3(64), 0, s, a);
     return hipGetLastError();
 }

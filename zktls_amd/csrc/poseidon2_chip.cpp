@@ -5,16 +5,18 @@
 // the first thing it is used for, Merkle openings in-circuit -- not a recursion machine.
 //
 // One row = one permutation of THIS library's parameter set (whatever zkhip_load_poseidon2_params left in effect: the round constants
-// are coefficients of the program, so the program -- and its digest in every proof -- follows the tables).  356 columns, every
+// are coefficients of the program, so the program -- and its digest in every proof -- follows the tables).  360 columns, every
 // constraint of degree <= 3 with its selector:
 //   IN 16 | S0 16 (after the initial external layer) | per external round r: X3E[r] 16 = (y + rc)^3, OUTE[r] 16 = the state after the round
 //   (x^7 = x^3 x^3 x, then the external matrix) | per internal round r: S0P[r], X3P[r], SBP[r] = element 0 before the S-box, its cube, its
 //   seventh power -- the other fifteen elements stay linear forms over OUTE[3] and the SBP columns so far | SP 16 (after the internal rounds)
 //   | D 8 = the digest-carrying half of the input, IN[j] (1 - BIT) + IN[8 + j] BIT | BIT CH END booleans: right child, continues the
 //   previous row's digest (D = previous OUTE[7][0..8]), ends a path (OUTE[7][0..8] = the public root) | CNT running count of END rows,
-//   the last row's is the public count | one unused column.
-// Public values: root[8], count.  A proof says: "I know `count` Merkle paths that end in `root`" (truncated-permutation compression: the
-// commitments of this library and of p3-merkle-tree); leaves, siblings and positions are the prover's.  tests/poseidon2_air.py writes the
+//   the last row's is the public count | SPG SS booleans for LEAF HASHING, the overwrite-mode sponge over an opened row of 8 k values:
+//   SS = the row absorbs a leaf's first 8 values (capacity half IN[8..16] zero), SPG = it absorbs the next 8 (capacity half = the previous
+//   row's OUTE[7][8..16]); the row after the last sponge row starts the path with CH = 1, its D being the leaf digest | three unused.
+// Public values: root[8], count.  A proof says: "I know `count` openings that end in `root`" (sponge + truncated-permutation compression:
+// the commitments of this library and of p3-merkle-tree); rows or leaf digests, siblings and positions are the prover's.  tests/poseidon2_air.py writes the
 // same program and trace independently (on tests/pyref.py's Poseidon2); the words must be equal.
 #include <atomic>
 #include <cstring>
@@ -123,8 +125,11 @@ std::vector<uint32_t> build_program() {
     for (uint32_t r = 4; r < 8; r++) external_round(r);
     for (uint32_t j = 0; j < 8; j++)
         b.add(ALL, Terms{{1u, {var(D + j)}}, {P - 1, {var(IN + j)}}, {1u, {var(BIT), var(IN + j)}}, {P - 1, {var(BIT), var(IN + 8 + j)}}});
-    for (uint32_t f : {BIT, CH, END}) b.add(ALL, Terms{{1u, {var(f), var(f)}}, {P - 1, {var(f)}}});
+    for (uint32_t f : {BIT, CH, END, SPG, SS}) b.add(ALL, Terms{{1u, {var(f), var(f)}}, {P - 1, {var(f)}}});
     b.add(FIRST, Terms{{1u, {var(CH)}}});
+    b.add(FIRST, Terms{{1u, {var(SPG)}}});
+    for (uint32_t j = 0; j < 8; j++) b.add(TRANSITION, Terms{{1u, {var(SPG, true), var(IN + 8 + j, true)}}, {P - 1, {var(SPG, true), var(oute(7) + 8 + j)}}});
+    for (uint32_t j = 0; j < 8; j++) b.add(ALL, Terms{{1u, {var(SS), var(IN + 8 + j)}}});
     for (uint32_t j = 0; j < 8; j++) b.add(TRANSITION, Terms{{1u, {var(CH, true), var(D + j, true)}}, {P - 1, {var(CH, true), var(oute(7) + j)}}});
     for (uint32_t j = 0; j < 8; j++) b.add(ALL, Terms{{1u, {var(END), var(oute(7) + j)}}, {P - 1, {var(END), pub(j)}}});
     b.add(FIRST, Terms{{1u, {var(CNT)}}, {P - 1, {var(END)}}});
@@ -146,10 +151,12 @@ std::shared_ptr<const std::vector<uint32_t>> program() {
     return cached;
 }
 
-int paths_shape(size_t n_paths, int depth, int* log_n) {
-    if (n_paths < 1 || depth < 1 || depth > 32 || n_paths > ((size_t)1 << MAX_LOG_ROWS) / (size_t)depth) return fail(ZKHIP_ERR_INVALID, "merkle paths: 1..2^22 rows of paths, depth 1..32");
+int paths_shape(size_t n_paths, int depth, uint32_t row_width, int* log_n) {
+    if (row_width % 8 != 0 || row_width > 1024) return fail(ZKHIP_ERR_INVALID, "merkle paths: the opened row width is 0 (leaf digests are given) or a multiple of 8 up to 1024");
+    const size_t per = (size_t)row_width / 8 + (size_t)(depth > 0 ? depth : 0);
+    if (n_paths < 1 || depth < 1 || depth > 32 || n_paths > ((size_t)1 << MAX_LOG_ROWS) / per) return fail(ZKHIP_ERR_INVALID, "merkle paths: 1..2^22 rows of paths, depth 1..32");
     int ln = 5;
-    while (((size_t)1 << ln) < n_paths * (size_t)depth) ln++;
+    while (((size_t)1 << ln) < n_paths * per) ln++;
     *log_n = ln;
     return ln <= MAX_LOG_ROWS ? ZKHIP_OK : fail(ZKHIP_ERR_INVALID, "merkle paths: more than 2^22 rows");
 }
@@ -174,48 +181,48 @@ size_t zkhip_p2chip_air(uint32_t* program, size_t cap_words) {
     return p->size();
 }
 
-int zkhip_p2chip_gen_merkle_trace(zkhip_ctx* ctx, const uint32_t* leaves, const uint32_t* siblings, const uint32_t* indices, size_t n_paths, int depth,
-                                  int log_n, uint32_t* d_trace, size_t ld, uint32_t* roots) {
+int zkhip_p2chip_gen_merkle_trace(zkhip_ctx* ctx, const uint32_t* leaves, uint32_t row_width, const uint32_t* siblings, const uint32_t* indices, size_t n_paths,
+                                  int depth, int log_n, uint32_t* d_trace, size_t ld, uint32_t* roots) {
     CHECK_CTX(ctx);
     if (!leaves || !siblings || !indices || !d_trace || !roots || ld < p2chip::WIDTH) return fail(ZKHIP_ERR_INVALID, "p2chip_gen_merkle_trace: bad arguments");
     int need;
-    ZK_TRY(p2chip::paths_shape(n_paths, depth, &need));
+    ZK_TRY(p2chip::paths_shape(n_paths, depth, row_width, &need));
     if (log_n < need || log_n > MAX_LOG_ROWS) return fail(ZKHIP_ERR_INVALID, "p2chip_gen_merkle_trace: 2^log_n rows do not hold the paths");
-    const size_t nl = n_paths * 8, ns = n_paths * (size_t)depth * 8;
+    const size_t nl = n_paths * (row_width ? row_width : 8), ns = n_paths * (size_t)depth * 8, nr = n_paths * 8;
     for (size_t i = 0; i < nl; i++) if (leaves[i] >= P) return fail(ZKHIP_ERR_INVALID, "p2chip_gen_merkle_trace: leaves must be canonical");
     for (size_t i = 0; i < ns; i++) if (siblings[i] >= P) return fail(ZKHIP_ERR_INVALID, "p2chip_gen_merkle_trace: siblings must be canonical");
     void* stage;
-    ZK_TRY(ctx_reserve(ctx, S_STAGE, (nl + ns + n_paths + nl) * 4, &stage));
+    ZK_TRY(ctx_reserve(ctx, S_STAGE, (nl + ns + n_paths + nr) * 4, &stage));
     uint32_t* d = (uint32_t*)stage;
     ZK_HIP(hipMemcpyAsync(d, leaves, nl * 4, hipMemcpyHostToDevice, ctx->stream));
     ZK_HIP(hipMemcpyAsync(d + nl, siblings, ns * 4, hipMemcpyHostToDevice, ctx->stream));
     ZK_HIP(hipMemcpyAsync(d + nl + ns, indices, n_paths * 4, hipMemcpyHostToDevice, ctx->stream));
     p2chip::MerkleTraceArgs a{};
-    a.leaves = d; a.siblings = d + nl; a.indices = d + nl + ns; a.n_paths = n_paths; a.rows = (uint64_t)1 << log_n; a.depth = (uint32_t)depth;
+    a.leaves = d; a.row_width = row_width; a.siblings = d + nl; a.indices = d + nl + ns; a.n_paths = n_paths; a.rows = (uint64_t)1 << log_n; a.depth = (uint32_t)depth;
     a.trace = d_trace; a.ld = ld; a.roots = d + nl + ns + n_paths;
     ZK_HIP(launch_p2chip_merkle(a, ctx->stream));
-    ZK_HIP(hipMemcpyAsync(roots, a.roots, nl * 4, hipMemcpyDeviceToHost, ctx->stream));
+    ZK_HIP(hipMemcpyAsync(roots, a.roots, nr * 4, hipMemcpyDeviceToHost, ctx->stream));
     ZK_HIP(hipStreamSynchronize(ctx->stream));
     return ZKHIP_OK;
 }
 
-size_t zkhip_merkle_paths_proof_size(size_t n_paths, int depth, const zkhip_params* prm) {
+size_t zkhip_merkle_paths_proof_size(size_t n_paths, int depth, uint32_t row_width, const zkhip_params* prm) {
     int log_n;
-    if (p2chip::paths_shape(n_paths, depth, &log_n) != ZKHIP_OK) return 0;
+    if (p2chip::paths_shape(n_paths, depth, row_width, &log_n) != ZKHIP_OK) return 0;
     const auto p = p2chip::program();
     return zkhip_proof_size_air(p->data(), p->size(), log_n, p2chip::WIDTH, prm, p2chip::N_PUBLIC);
 }
 
-int zkhip_prove_merkle_paths(zkhip_ctx* ctx, const uint32_t* leaves, const uint32_t* siblings, const uint32_t* indices, size_t n_paths, int depth,
+int zkhip_prove_merkle_paths(zkhip_ctx* ctx, const uint32_t* leaves, uint32_t row_width, const uint32_t* siblings, const uint32_t* indices, size_t n_paths, int depth,
                              const uint32_t root[8], const zkhip_params* prm, uint8_t* proof, size_t cap, size_t* len) {
     CHECK_CTX(ctx);
     if (!root || !prm || !proof || !len) return fail(ZKHIP_ERR_INVALID, "prove_merkle_paths: null argument");
     int log_n;
-    ZK_TRY(p2chip::paths_shape(n_paths, depth, &log_n));
+    ZK_TRY(p2chip::paths_shape(n_paths, depth, row_width, &log_n));
     void* trace;
     ZK_TRY(ctx_reserve(ctx, S_CHIP, ((size_t)p2chip::WIDTH << log_n) * 4, &trace));
     std::vector<uint32_t> roots(n_paths * 8);
-    ZK_TRY(zkhip_p2chip_gen_merkle_trace(ctx, leaves, siblings, indices, n_paths, depth, log_n, (uint32_t*)trace, p2chip::WIDTH, roots.data()));
+    ZK_TRY(zkhip_p2chip_gen_merkle_trace(ctx, leaves, row_width, siblings, indices, n_paths, depth, log_n, (uint32_t*)trace, p2chip::WIDTH, roots.data()));
     for (size_t p = 0; p < n_paths; p++)
         if (std::memcmp(roots.data() + 8 * p, root, 32) != 0) return fail(ZKHIP_ERR_INVALID, "prove_merkle_paths: path " + std::to_string(p) + " does not end in the root");
     uint32_t pv[p2chip::N_PUBLIC];

@@ -359,33 +359,35 @@ class Context:
                                           buf.ctypes.data_as(u8p), size, C.byref(got)))
         return digest.tobytes(), buf[: got.value]
 
-    def p2chip_gen_merkle_trace(self, leaves, siblings, indices, log_n=None):
-        """the Poseidon2 chip's trace for a set of Merkle paths (numpy arrays of canonical words: leaves [n][8], siblings [n][depth][8],
-        indices [n]) -> (device buffer [2^log_n][356], roots [n][8], log_n)"""
+    def p2chip_gen_merkle_trace(self, leaves, siblings, indices, log_n=None, hashed_rows=False):
+        """the Poseidon2 chip's trace for a set of Merkle paths (numpy arrays of canonical words: leaves [n][8] -- or, with hashed_rows, the
+        opened rows [n][8 k], hashed in-circuit --, siblings [n][depth][8], indices [n]) -> (device buffer [2^log_n][360], roots [n][8], log_n)"""
         lv = np.ascontiguousarray(leaves, dtype=np.uint32)
         sb = np.ascontiguousarray(siblings, dtype=np.uint32)
         ix = np.ascontiguousarray(indices, dtype=np.uint32)
         n, depth = lv.shape[0], sb.shape[1]
+        rw = lv.shape[1] if hashed_rows else 0
         if log_n is None:
-            log_n = max(5, (n * depth - 1).bit_length())
-        out = self.alloc(356 << log_n)
+            log_n = max(5, (n * (depth + rw // 8) - 1).bit_length())
+        out = self.alloc(360 << log_n)
         roots = np.zeros((n, 8), dtype=np.uint32)
-        check(self.lib.zkhip_p2chip_gen_merkle_trace(self.handle, lv.ctypes.data_as(u32p), sb.ctypes.data_as(u32p), ix.ctypes.data_as(u32p), n, depth, log_n,
-                                                     C.c_void_p(out.ptr), 356, roots.ctypes.data_as(u32p)))
+        check(self.lib.zkhip_p2chip_gen_merkle_trace(self.handle, lv.ctypes.data_as(u32p), rw, sb.ctypes.data_as(u32p), ix.ctypes.data_as(u32p), n, depth, log_n,
+                                                     C.c_void_p(out.ptr), 360, roots.ctypes.data_as(u32p)))
         return out, roots, log_n
 
-    def prove_merkle_paths(self, leaves, siblings, indices, root, params=None):
-        """-> proof bytes of "I know len(leaves) Merkle paths that end in root" (the Poseidon2 chip)"""
+    def prove_merkle_paths(self, leaves, siblings, indices, root, params=None, hashed_rows=False):
+        """-> proof bytes of "I know len(leaves) Merkle paths (with hashed_rows: openings of whole rows) that end in root" (the Poseidon2 chip)"""
         params = params or Params(1, 100, 16)
         lv = np.ascontiguousarray(leaves, dtype=np.uint32)
         sb = np.ascontiguousarray(siblings, dtype=np.uint32)
         ix = np.ascontiguousarray(indices, dtype=np.uint32)
         rt = np.ascontiguousarray(root, dtype=np.uint32)
         n, depth = lv.shape[0], sb.shape[1]
-        size = self.lib.zkhip_merkle_paths_proof_size(n, depth, C.byref(params))
+        rw = lv.shape[1] if hashed_rows else 0
+        size = self.lib.zkhip_merkle_paths_proof_size(n, depth, rw, C.byref(params))
         buf = np.empty(max(size, 1), dtype=np.uint8)
         got = C.c_size_t(0)
-        check(self.lib.zkhip_prove_merkle_paths(self.handle, lv.ctypes.data_as(u32p), sb.ctypes.data_as(u32p), ix.ctypes.data_as(u32p), n, depth,
+        check(self.lib.zkhip_prove_merkle_paths(self.handle, lv.ctypes.data_as(u32p), rw, sb.ctypes.data_as(u32p), ix.ctypes.data_as(u32p), n, depth,
                                                 rt.ctypes.data_as(u32p), C.byref(params), buf.ctypes.data_as(u8p), size, C.byref(got)))
         return buf[: got.value]
 
