@@ -425,7 +425,9 @@ int zkhip_verify_chips(const uint8_t* proof, size_t len, const int32_t* log_ns, 
                        const int32_t* partners, int n_chips,
                        const uint32_t* public_values, size_t n_public, const zkhip_params* prm, int* reason);
 
-/* chips with their own AIR: programs[c] is a constraint program (zkhip_prove_shard_air's format, degree <= 3, its n_public = the
+/* chips with their own AIR: programs[c] is a constraint program (zkhip_prove_shard_air's format; degree <= 5: a chip whose program has
+ * degree 4 or 5 gets four quotient chunks -- its own quotient domain of four cosets, 16 quotient columns -- and needs log_blowup >= 2; the
+ * header's has-program word carries the program's log_quotient_degree, 1 or 2; its n_public = the
  * shard's) or NULL for the built-in synthetic AIR -- a machine of different tables in one proof (one commitment per phase, one FRI
  * proof), as an SP1 shard is.  Proof version 9: each chip's header entry gains a has-program flag and the programs' digests follow
  * the entries, all observed.  No lookups in this version (logup_pairs = 0, partner = -1 in every zkhip_chip). */

@@ -21,7 +21,7 @@
  * of a shard together (proof version 5).  Lookups BETWEEN chips (partners[]): two chips of equal height hold each
  * other's sender columns; every chip with pairs then exposes the final value C of its running sum, the last-row constraint
  * becomes S = C and the verifier checks sum C = 0 -- sp1-stark's local cumulative sums (proof version 6).
- * Chips with their own AIR (orc_prove_chips_air): any chip may bring a constraint program (oracle/air.c, degree <= 3) instead of
+ * Chips with their own AIR (orc_prove_chips_air): any chip may bring a constraint program (oracle/air.c; degree 4 / 5: four quotient chunks) instead of
  * the synthetic AIR -- a machine of different tables, as an SP1 shard is.  Proof version 9: every chip's header entry gains a
  * has-program flag and the 8-word digests of the programs follow the entries, all observed; no lookups in this version.
  */
@@ -42,8 +42,13 @@
 /* the programs in effect for the running orc_*_chips_air call (NULL: every chip uses the synthetic AIR) */
 static _Thread_local const uint32_t* const* g_progs = NULL;
 static _Thread_local const size_t* g_prog_words = NULL;
+/* log2 of chip c's number of quotient chunks: 2 for a program of degree 4 or 5 (needs log_blowup >= 2), else 1; its quotient matrix has
+ * 4 * 2^lq columns.  The header's has-program word carries it (0: no program, 1 or 2: the program's log_quotient_degree). */
+static int lq_of(int c);
+static size_t qw_of(int c) { return (size_t)4 << lq_of(c); }
 static int any_prog(int n) { if (g_progs) for (int c = 0; c < n; c++) if (g_progs[c]) return 1; return 0; }
 static const uint32_t* prog_of(int c) { return g_progs ? g_progs[c] : NULL; }
+static int lq_of(int c) { return prog_of(c) ? orc_air_log_quotient_degree(prog_of(c)) : 1; }
 
 /* ---- machine mode (orc_*_machine): lookups as DATA.  Every chip may bring an interaction table next to its program:
  *   [0] "LKUP" 0x50554B4C  [1] interactions I (1..64)  [2] total words
@@ -178,6 +183,7 @@ static int chips_ok(const int* log_ns, const size_t* widths, const int* pairs, c
             if (!pairs || d >= n || d == c || partners[d] != c || pairs[c] == 0 || pairs[d] != pairs[c] || log_ns[d] != log_ns[c]) return 0;
         } else if (partners && partners[c] < -1) return 0;
     }
+    for (int c = 0; c < n; c++) if (lq_of(c) > prm->log_blowup) return 0;      /* the quotient domain must lie inside the committed LDE domain */
     if (keyed()) {
         int some = 0;
         for (int c = 0; c < n; c++) {
@@ -208,8 +214,8 @@ size_t orc_chips_proof_size(const int* log_ns, const size_t* widths, const int* 
     size_t perq = 16 * Hmax, hp = 0, he = 0;
     for (int c = 0; c < n; c++) {
         size_t wp = (pairs && pairs[c]) ? 4 * ((size_t)pairs[c] + 1) : 0;
-        words += 8 * widths[c] + 8 * wp + 32 + ((cross && wp) ? 4 : 0) + 8 * pre_w(c);      /* + the chip's cumulative sum */
-        perq += widths[c] + wp + 8 + pre_w(c);
+        words += 8 * widths[c] + 8 * wp + 4 * qw_of(c) + ((cross && wp) ? 4 : 0) + 8 * pre_w(c);      /* + the chip's cumulative sum */
+        perq += widths[c] + wp + qw_of(c) + pre_w(c);
         if (wp && (size_t)log_ns[c] + b > hp) hp = (size_t)log_ns[c] + b;
         if (pre_w(c) && (size_t)log_ns[c] + b > he) he = (size_t)log_ns[c] + b;
     }
@@ -230,13 +236,13 @@ static void transcript_init(orc_challenger_t* ch, const int* log_ns, const size_
     for (int c = 0; c < n; c++) {
         orc_chal_observe(ch, (uint32_t)log_ns[c]); orc_chal_observe(ch, (uint32_t)widths[c]);
         if (g_machine) {
-            orc_chal_observe(ch, prog_of(c) ? 1u : 0u); orc_chal_observe(ch, table_of(c) ? table_of(c)[1] : 0u);
+            orc_chal_observe(ch, prog_of(c) ? (uint32_t)lq_of(c) : 0u); orc_chal_observe(ch, table_of(c) ? table_of(c)[1] : 0u);
             if (keyed()) orc_chal_observe(ch, (uint32_t)pre_w(c));
             continue;
         }
         if (lk) orc_chal_observe(ch, (uint32_t)pairs[c]);
         if (cross) orc_chal_observe(ch, (uint32_t)(partners[c] + 1));
-        if (any_prog(n)) orc_chal_observe(ch, prog_of(c) ? 1u : 0u);
+        if (any_prog(n)) orc_chal_observe(ch, prog_of(c) ? (uint32_t)lq_of(c) : 0u);
     }
     for (int c = 0; c < n; c++)
         if (prog_of(c)) {
@@ -258,7 +264,7 @@ static void transcript_init(orc_challenger_t* ch, const int* log_ns, const size_
 static size_t perm_width(const int* pairs, int c) { return (pairs && pairs[c]) ? 4 * ((size_t)pairs[c] + 1) : 0; }
 static size_t height_offset(const int* log_ns, const size_t* widths, const int* pairs, int c) {
     size_t off = 0;
-    for (int d = 0; d < c; d++) if (log_ns[d] == log_ns[c]) off += 2 * pre_w(d) + 2 * widths[d] + 2 * perm_width(pairs, d) + 8;
+    for (int d = 0; d < c; d++) if (log_ns[d] == log_ns[c]) off += 2 * pre_w(d) + 2 * widths[d] + 2 * perm_width(pairs, d) + qw_of(d);
     return off;
 }
 
@@ -276,8 +282,8 @@ static void quotient_values_machine(int c, const uint32_t* lde, int log_n, size_
     inter_t its[64]; int ni = 0;
     if (table_of(c)) table_parse(table_of(c), g_table_words[c], width, its, &ni);
     const size_t cols = ((size_t)ni + 1) / 2, wp = ni ? 4 * (cols + 1) : 0;
-    const int log_m = log_n + 1;
-    const size_t m = (size_t)1 << log_m, n = (size_t)1 << log_n;
+    const int lq = lq_of(c), log_m = log_n + lq;
+    const size_t m = (size_t)1 << log_m, n = (size_t)1 << log_n, step = (size_t)1 << lq;
     const bb_t w = bb_two_adic_generator(log_m), wn_inv = bb_inv(bb_two_adic_generator(log_n));
 #pragma omp parallel for schedule(static)
     for (size_t i = 0; i < m; i++) {
@@ -286,7 +292,7 @@ static void quotient_values_machine(int c, const uint32_t* lde, int log_n, size_
         bb_t sel_first = bb_mul(zh, bb_inv(bb_sub(x, 1)));
         bb_t sel_last = bb_mul(zh, bb_inv(bb_sub(x, wn_inv)));
         bb_t sel_trans = bb_sub(x, wn_inv);
-        size_t p = bb_reverse_bits((uint32_t)i, log_m), pn = bb_reverse_bits((uint32_t)((i + 2) & (m - 1)), log_m);
+        size_t p = bb_reverse_bits((uint32_t)i, log_m), pn = bb_reverse_bits((uint32_t)((i + step) & (m - 1)), log_m);
         bb4_t acc = orc__air_fold_base(prog, lde + p * width, lde + pn * width, pub, sel_first, sel_last, sel_trans, alpha);
         if (ni) {
             bb4_t* row = (bb4_t*)malloc(width * sizeof(bb4_t));
@@ -338,10 +344,10 @@ size_t orc_prove_chips(const uint32_t* const* traces, const int* log_ns, const s
     pf[pos++] = (uint32_t)prm->num_queries; pf[pos++] = (uint32_t)prm->pow_bits; pf[pos++] = (uint32_t)n_public; pf[pos++] = 16u;
     for (int c = 0; c < n; c++) {
         pf[pos++] = (uint32_t)log_ns[c]; pf[pos++] = (uint32_t)widths[c];
-        if (g_machine) { pf[pos++] = prog_of(c) ? 1u : 0u; pf[pos++] = table_of(c) ? table_of(c)[1] : 0u; if (keyed()) pf[pos++] = (uint32_t)pre_w(c); continue; }
+        if (g_machine) { pf[pos++] = prog_of(c) ? (uint32_t)lq_of(c) : 0u; pf[pos++] = table_of(c) ? table_of(c)[1] : 0u; if (keyed()) pf[pos++] = (uint32_t)pre_w(c); continue; }
         if (lk) pf[pos++] = (uint32_t)pairs[c];
         if (cross) pf[pos++] = (uint32_t)(partners[c] + 1);
-        if (any_prog(n)) pf[pos++] = prog_of(c) ? 1u : 0u;
+        if (any_prog(n)) pf[pos++] = prog_of(c) ? (uint32_t)lq_of(c) : 0u;
     }
     for (int c = 0; c < n; c++) if (prog_of(c)) { orc_air_digest(prog_of(c), g_prog_words[c], pf + pos); pos += 8; }
     for (int c = 0; c < n; c++) if (table_of(c)) { orc_air_digest(table_of(c), g_table_words[c], pf + pos); pos += 8; }
@@ -355,7 +361,7 @@ size_t orc_prove_chips(const uint32_t* const* traces, const int* log_ns, const s
     uint32_t* tlde[MAX_CHIPS]; uint32_t* qlde[MAX_CHIPS]; uint32_t* plde[MAX_CHIPS];
     int lh[MAX_CHIPS]; size_t w8[MAX_CHIPS], wp[MAX_CHIPS];
     for (int c = 0; c < n; c++) {
-        lh[c] = log_ns[c] + b; w8[c] = 8; wp[c] = perm_width(pairs, c); plde[c] = NULL;
+        lh[c] = log_ns[c] + b; w8[c] = qw_of(c); wp[c] = perm_width(pairs, c); plde[c] = NULL;
         tlde[c] = (uint32_t*)malloc(((size_t)1 << lh[c]) * widths[c] * 4);
         orc_coset_lde(traces[c], tlde[c], log_ns[c], widths[c], b, BB_GEN);
         if (elde[c]) {                                 /* what the chip's program and interactions read: [pre | main] rows of the LDE */
@@ -411,20 +417,20 @@ size_t orc_prove_chips(const uint32_t* const* traces, const int* log_ns, const s
     /* 2. quotients, per chip on its own 2N_c coset (= the first 2N_c rows of its LDE), chunk LDEs, quotient tree */
     bb4_t alpha = sample_ext(&ch);
     for (int c = 0; c < n; c++) {
-        const int ln = log_ns[c], Hq = ln + 1;
-        const size_t nc = (size_t)1 << ln, mc = (size_t)1 << lh[c], mq = (size_t)1 << Hq;
+        const int ln = log_ns[c], lq = lq_of(c), Hq = ln + lq;
+        const size_t nc = (size_t)1 << ln, mc = (size_t)1 << lh[c], mq = (size_t)1 << Hq, NQ = (size_t)1 << lq, QW = 4 * NQ;
         uint32_t* qv = (uint32_t*)malloc(mq * 16);
         if (g_machine) quotient_values_machine(c, clde[c] ? clde[c] : tlde[c], ln, pre_w(c) + widths[c], plde[c], gamma, beta_l, alpha, cumsum[c], public_values, n_public, qv);
-        else if (prog_of(c)) orc_quotient_values_air(prog_of(c), tlde[c], ln, widths[c], public_values, alpha.c, 1, qv);
+        else if (prog_of(c)) orc_quotient_values_air(prog_of(c), tlde[c], ln, widths[c], public_values, alpha.c, lq, qv);
         else orc_quotient_values_logup_c(tlde[c], ln, widths[c], plde[c], wp[c] ? pairs[c] : 0, gamma.c, beta_l.c, alpha.c, cumsum[c].c, qv);
-        qlde[c] = (uint32_t*)malloc(mc * 8 * 4);
+        qlde[c] = (uint32_t*)malloc(mc * QW * 4);
         uint32_t* chunk = (uint32_t*)malloc(nc * 16);
         uint32_t* clde = (uint32_t*)malloc(mc * 16);
         bb_t w2n = bb_two_adic_generator(Hq);
-        for (int k = 0; k < 2; k++) {
-            for (size_t j = 0; j < nc; j++) memcpy(chunk + 4 * j, qv + 4 * bb_reverse_bits((uint32_t)(2 * j + k), Hq), 16);
+        for (size_t k = 0; k < NQ; k++) {
+            for (size_t j = 0; j < nc; j++) memcpy(chunk + 4 * j, qv + 4 * bb_reverse_bits((uint32_t)(NQ * j + k), Hq), 16);
             orc_coset_lde(chunk, clde, ln, 4, b, bb_inv(bb_pow(w2n, (uint64_t)k)));
-            for (size_t r = 0; r < mc; r++) memcpy(qlde[c] + r * 8 + 4 * k, clde + r * 4, 16);
+            for (size_t r = 0; r < mc; r++) memcpy(qlde[c] + r * QW + 4 * k, clde + r * 4, 16);
         }
         free(qv); free(chunk); free(clde);
     }
@@ -440,7 +446,7 @@ size_t orc_prove_chips(const uint32_t* const* traces, const int* log_ns, const s
     size_t oplen[MAX_CHIPS];
     for (int c = 0; c < n; c++) {
         const size_t W = widths[c], pw = pre_w(c);
-        oplen[c] = 8 * pw + 8 * W + 8 * wp[c] + 32;
+        oplen[c] = 8 * pw + 8 * W + 8 * wp[c] + 4 * qw_of(c);
         bb4_t zn = bb4_mul_base(zeta, bb_two_adic_generator(log_ns[c]));
         if (pw) {
             orc_open_at(elde[c], log_ns[c], pw, zeta.c, pf + pos);
@@ -454,7 +460,7 @@ size_t orc_prove_chips(const uint32_t* const* traces, const int* log_ns, const s
             orc_open_at(plde[c], log_ns[c], wp[c], zeta.c, op[c] + 8 * W);
             orc_open_at(plde[c], log_ns[c], wp[c], zn.c, op[c] + 8 * W + 4 * wp[c]);
         }
-        orc_open_at(qlde[c], log_ns[c], 8, zeta.c, op[c] + 8 * W + 8 * wp[c]);
+        orc_open_at(qlde[c], log_ns[c], qw_of(c), zeta.c, op[c] + 8 * W + 8 * wp[c]);
     }
     for (int c = 0; c < n; c++) orc_chal_observe_slice(&ch, opre[c], oplen[c]);
 
@@ -465,7 +471,8 @@ size_t orc_prove_chips(const uint32_t* const* traces, const int* log_ns, const s
     for (int h = 0; h < 32; h++) ro[h] = NULL;
     for (int c = 0; c < n; c++) {
         const size_t W = widths[c], Wp = wp[c], mc = (size_t)1 << lh[c], Pw = pre_w(c);
-        size_t npw = W > 8 ? W : 8;
+        const size_t QW = qw_of(c);
+        size_t npw = W > QW ? W : QW;
         if (Wp > npw) npw = Wp;
         if (Pw > npw) npw = Pw;
         bb4_t* fapow = (bb4_t*)malloc(npw * sizeof(bb4_t));
@@ -481,7 +488,7 @@ size_t orc_prove_chips(const uint32_t* const* traces, const int* log_ns, const s
             y_pl = bb4_add(y_pl, bb4_mul(fapow[j], ld4(o_pl + 4 * j)));
             y_pn = bb4_add(y_pn, bb4_mul(fapow[j], ld4(o_pn + 4 * j)));
         }
-        for (size_t j = 0; j < 8; j++) y_q = bb4_add(y_q, bb4_mul(fapow[j], ld4(o_q + 4 * j)));
+        for (size_t j = 0; j < QW; j++) y_q = bb4_add(y_q, bb4_mul(fapow[j], ld4(o_q + 4 * j)));
         bb4_t y_el = bb4_zero(), y_en = bb4_zero();
         for (size_t j = 0; j < Pw; j++) {
             y_el = bb4_add(y_el, bb4_mul(fapow[j], ld4(opre[c] + 4 * j)));
@@ -500,7 +507,7 @@ size_t orc_prove_chips(const uint32_t* const* traces, const int* log_ns, const s
             bb_t x = bb_mul(BB_GEN, bb_pow(wm, bb_reverse_bits((uint32_t)p, lh[c])));
             bb4_t d1 = bb4_inv(bb4_neg(bb4_sub_base(zeta, x)));
             bb4_t d2 = bb4_inv(bb4_neg(bb4_sub_base(zn, x)));
-            bb4_t at = orc__row_dot(fapow, tlde[c] + p * W, W), aq = orc__row_dot(fapow, qlde[c] + p * 8, 8);
+            bb4_t at = orc__row_dot(fapow, tlde[c] + p * W, W), aq = orc__row_dot(fapow, qlde[c] + p * QW, QW);
             bb4_t r = bb4_mul(s_loc, bb4_mul(bb4_sub(at, y_loc), d1));
             r = bb4_add(r, bb4_mul(s_nxt, bb4_mul(bb4_sub(at, y_nxt), d2)));
             if (Wp) {
@@ -564,7 +571,7 @@ size_t orc_prove_chips(const uint32_t* const* traces, const int* log_ns, const s
             for (int c = 0; c < n; c++) if (wp[c]) { memcpy(pf + pos, plde[c] + (index >> (Hmax - lh[c])) * wp[c], wp[c] * 4); pos += wp[c]; }
             orc__copy_path(pf, &pos, ptree, (size_t)1 << Hp, index >> (Hmax - Hp), Hp);
         }
-        for (int c = 0; c < n; c++) { memcpy(pf + pos, qlde[c] + (index >> (Hmax - lh[c])) * 8, 32); pos += 8; }
+        for (int c = 0; c < n; c++) { memcpy(pf + pos, qlde[c] + (index >> (Hmax - lh[c])) * qw_of(c), qw_of(c) * 4); pos += qw_of(c); }
         orc__copy_path(pf, &pos, qtree, mmax, index, Hmax);
         size_t idx = index;
         for (int l = 0; l < L; l++) {
@@ -620,14 +627,14 @@ int orc_verify_chips(const uint8_t* proof_bytes, size_t len, const int* log_ns, 
         if (pf[pos] != (uint32_t)log_ns[c] || pf[pos + 1] != (uint32_t)widths[c]) return 3;
         pos += 2;
         if (g_machine) {
-            if (pf[pos] != (prog_of(c) ? 1u : 0u) || pf[pos + 1] != (table_of(c) ? table_of(c)[1] : 0u)) return 3;
+            if (pf[pos] != (prog_of(c) ? (uint32_t)lq_of(c) : 0u) || pf[pos + 1] != (table_of(c) ? table_of(c)[1] : 0u)) return 3;
             pos += 2;
             if (keyed()) { if (pf[pos] != (uint32_t)pre_w(c)) return 3; pos++; }
             continue;
         }
         if (lk) { if (pf[pos] != (uint32_t)pairs[c]) return 3; pos++; }
         if (cross) { if (pf[pos] != (uint32_t)(partners[c] + 1)) return 3; pos++; }
-        if (any_prog(n)) { if (pf[pos] != (prog_of(c) ? 1u : 0u)) return 3; pos++; }
+        if (any_prog(n)) { if (pf[pos] != (prog_of(c) ? (uint32_t)lq_of(c) : 0u)) return 3; pos++; }
     }
     for (int c = 0; c < n; c++)
         if (prog_of(c)) {
@@ -646,7 +653,7 @@ int orc_verify_chips(const uint8_t* proof_bytes, size_t len, const int* log_ns, 
     if (keyed()) { if (memcmp(pf + pos, g_pre_root, 32) != 0) return 3; pos += 8; }       /* a proof under another key */
     for (size_t i = pos; i < len / 4; i++) if (pf[i] >= BB_P) return 4;
     int lh[MAX_CHIPS]; size_t w8[MAX_CHIPS], wp[MAX_CHIPS];
-    for (int c = 0; c < n; c++) { lh[c] = log_ns[c] + b; w8[c] = 8; wp[c] = perm_width(pairs, c); }
+    for (int c = 0; c < n; c++) { lh[c] = log_ns[c] + b; w8[c] = qw_of(c); wp[c] = perm_width(pairs, c); }
 
     orc_challenger_t ch;
     transcript_init(&ch, log_ns, widths, pairs, partners, n, prm, n_public);
@@ -675,7 +682,7 @@ int orc_verify_chips(const uint8_t* proof_bytes, size_t len, const int* log_ns, 
     orc_chal_observe_slice(&ch, qroot, 8);
     bb4_t zeta = sample_ext(&ch);
     const uint32_t* op[MAX_CHIPS]; const uint32_t* opre[MAX_CHIPS]; size_t oplen[MAX_CHIPS];
-    for (int c = 0; c < n; c++) { oplen[c] = 8 * pre_w(c) + 8 * widths[c] + 8 * wp[c] + 32; opre[c] = pf + pos; op[c] = pf + pos + 8 * pre_w(c); pos += oplen[c]; }
+    for (int c = 0; c < n; c++) { oplen[c] = 8 * pre_w(c) + 8 * widths[c] + 8 * wp[c] + 4 * qw_of(c); opre[c] = pf + pos; op[c] = pf + pos + 8 * pre_w(c); pos += oplen[c]; }
     for (int c = 0; c < n; c++) orc_chal_observe_slice(&ch, opre[c], oplen[c]);
     size_t ew[MAX_CHIPS]; int elh[MAX_CHIPS], echip[MAX_CHIPS]; int ne = 0, He = 0;
     for (int c = 0; c < n; c++) if (pre_w(c)) { ew[ne] = pre_w(c); elh[ne] = log_ns[c] + b; echip[ne] = c; ne++; if (log_ns[c] + b > He) He = log_ns[c] + b; }
@@ -713,16 +720,24 @@ int orc_verify_chips(const uint8_t* proof_bytes, size_t len, const int* log_ns, 
             folded = orc__fold_logup(folded, Q, as, bs, ar, br, pl, pn, gamma, beta_l, sel_first, sel_trans, sel_last, alpha, cumsum[c]);
         }
         free(loc); free(nxt);
-        bb_t w2n = bb_two_adic_generator(log_ns[c] + 1);
-        bb_t s[2] = {BB_GEN, bb_mul(BB_GEN, w2n)};
+        /* quotient(zeta) = sum_k zps_k(zeta) q_k(zeta), zps_k = prod_{j != k} ((zeta / s_j)^N - 1) / ((s_k / s_j)^N - 1), s_k = g w^k on the
+         * chip's own quotient domain of 2^lq cosets */
+        const size_t NQ = (size_t)1 << lq_of(c);
+        bb_t wq = bb_two_adic_generator(log_ns[c] + lq_of(c));
+        bb_t sN[4];
+        for (size_t k = 0; k < NQ; k++) sN[k] = bb_pow(bb_mul(BB_GEN, bb_pow(wq, k)), nc);
         bb4_t quot = bb4_zero();
         const uint32_t* o_q = op[c] + 8 * W0 + 8 * Wp;
-        for (int k = 0; k < 2; k++) {
-            int j = 1 - k;
-            bb_t sjn_inv = bb_inv(bb_pow(s[j], nc));
-            bb4_t num = bb4_sub_base(bb4_mul_base(zn, sjn_inv), 1);
-            bb_t den = bb_sub(bb_mul(bb_pow(s[k], nc), sjn_inv), 1);
-            quot = bb4_add(quot, bb4_mul(bb4_mul_base(num, bb_inv(den)), orc__recombine(o_q + 16 * k)));
+        for (size_t k = 0; k < NQ; k++) {
+            bb4_t zps = bb4_one();
+            for (size_t j = 0; j < NQ; j++) {
+                if (j == k) continue;
+                bb_t sjn_inv = bb_inv(sN[j]);
+                bb4_t num = bb4_sub_base(bb4_mul_base(zn, sjn_inv), 1);
+                bb_t den = bb_sub(bb_mul(sN[k], sjn_inv), 1);
+                zps = bb4_mul(zps, bb4_mul_base(num, bb_inv(den)));
+            }
+            quot = bb4_add(quot, bb4_mul(zps, orc__recombine(o_q + 16 * k)));
         }
         if (!bb4_eq(bb4_mul(folded, bb4_inv(zh)), quot)) return 10;
     }
@@ -730,7 +745,7 @@ int orc_verify_chips(const uint8_t* proof_bytes, size_t len, const int* log_ns, 
     /* (b) FRI */
     bb4_t fa = sample_ext(&ch);
     size_t npmax = 8;
-    for (int c = 0; c < n; c++) { if (widths[c] > npmax) npmax = widths[c]; if (wp[c] > npmax) npmax = wp[c]; if (pre_w(c) > npmax) npmax = pre_w(c); }
+    for (int c = 0; c < n; c++) { if (widths[c] > npmax) npmax = widths[c]; if (wp[c] > npmax) npmax = wp[c]; if (pre_w(c) > npmax) npmax = pre_w(c); if (qw_of(c) > npmax) npmax = qw_of(c); }
     bb4_t* fapow = (bb4_t*)malloc(npmax * sizeof(bb4_t));
     fapow[0] = bb4_one();
     for (size_t j = 1; j < npmax; j++) fapow[j] = bb4_mul(fapow[j - 1], fa);
@@ -754,7 +769,7 @@ int orc_verify_chips(const uint8_t* proof_bytes, size_t len, const int* log_ns, 
             y_pl[c] = bb4_add(y_pl[c], bb4_mul(fapow[j], ld4(o_pl + 4 * j)));
             y_pn[c] = bb4_add(y_pn[c], bb4_mul(fapow[j], ld4(o_pn + 4 * j)));
         }
-        for (size_t j = 0; j < 8; j++) y_q[c] = bb4_add(y_q[c], bb4_mul(fapow[j], ld4(o_q + 4 * j)));
+        for (size_t j = 0; j < qw_of(c); j++) y_q[c] = bb4_add(y_q[c], bb4_mul(fapow[j], ld4(o_q + 4 * j)));
         const size_t off0 = height_offset(log_ns, widths, pairs, c), off = off0 + 2 * Pw;
         s_el[c] = bb4_pow(fa, off0); s_en[c] = bb4_pow(fa, off0 + Pw);
         s_loc[c] = bb4_pow(fa, off); s_nxt[c] = bb4_pow(fa, off + W); s_pl[c] = bb4_pow(fa, off + 2 * W);
@@ -786,7 +801,7 @@ int orc_verify_chips(const uint8_t* proof_bytes, size_t len, const int* log_ns, 
             for (int k = 0; k < np; k++) { prow[k] = pf + pos; prow_all[pchip[k]] = prow[k]; pos += pw[k]; }
             ppath = pf + pos; pos += 8 * (size_t)Hp;
         }
-        for (int c = 0; c < n; c++) { qrow[c] = pf + pos; pos += 8; }
+        for (int c = 0; c < n; c++) { qrow[c] = pf + pos; pos += qw_of(c); }
         const uint32_t* qpath = pf + pos; pos += 8 * (size_t)Hmax;
         if (verify_mixed(troot, Hmax, index, trow, widths, lh, n, tpath)) { rc = 30; break; }
         if (lk && verify_mixed(proot, Hp, index >> (Hmax - Hp), prow, pw, plh, np, ppath)) { rc = 32; break; }
@@ -799,7 +814,7 @@ int orc_verify_chips(const uint8_t* proof_bytes, size_t len, const int* log_ns, 
             bb_t x = bb_mul(BB_GEN, bb_pow(bb_two_adic_generator(lh[c]), bb_reverse_bits((uint32_t)ic, lh[c])));
             bb4_t d1 = bb4_inv(bb4_neg(bb4_sub_base(zeta, x)));
             bb4_t d2 = bb4_inv(bb4_neg(bb4_sub_base(zn_c[c], x)));
-            bb4_t at = orc__row_dot(fapow, trow[c], widths[c]), aq = orc__row_dot(fapow, qrow[c], 8);
+            bb4_t at = orc__row_dot(fapow, trow[c], widths[c]), aq = orc__row_dot(fapow, qrow[c], qw_of(c));
             bb4_t r = bb4_mul(s_loc[c], bb4_mul(bb4_sub(at, y_loc[c]), d1));
             r = bb4_add(r, bb4_mul(s_nxt[c], bb4_mul(bb4_sub(at, y_nxt[c]), d2)));
             if (wp[c]) {
@@ -839,11 +854,11 @@ int orc_verify_chips(const uint8_t* proof_bytes, size_t len, const int* log_ns, 
 }
 
 
-/* ---- chips with their own constraint programs (progs[c] NULL: the synthetic AIR); every program of degree <= 3 ---- */
+/* ---- chips with their own constraint programs (progs[c] NULL: the synthetic AIR); a program of degree 4 / 5 needs log_blowup >= 2 ---- */
 static int progs_ok(const uint32_t* const* progs, const size_t* prog_words, const size_t* widths, int n, size_t n_public) {
     if (!progs || !prog_words || n < 1 || n > MAX_CHIPS) return 0;
     for (int c = 0; c < n; c++)
-        if (progs[c] && (!orc_air_validate(progs[c], prog_words[c], widths[c], n_public) || orc_air_log_quotient_degree(progs[c]) != 1)) return 0;
+        if (progs[c] && !orc_air_validate(progs[c], prog_words[c], widths[c], n_public)) return 0;
     return 1;
 }
 size_t orc_chips_proof_size_air(const int* log_ns, const size_t* widths, const uint32_t* const* progs, const size_t* prog_words, int n,

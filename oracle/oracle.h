@@ -166,7 +166,8 @@ int orc_verify_shard(const uint8_t* proof, size_t len, int log_n, size_t width,
  * partners[c] = -1: chip c's lookups stay inside the chip (orc_gen_trace_logup); d >= 0: its receiver groups hold chip d's
  * sender groups (orc_gen_trace_logup_cross; mutual, equal heights and pair counts) -- then every chip with pairs exposes the
  * final value of its running sum and the verifier checks that they add up to zero (sp1-stark's local cumulative sums) */
-/* chips with their own constraint programs (progs[c] NULL: the synthetic AIR); degree <= 3; no lookups (proof version 9) */
+/* chips with their own constraint programs (progs[c] NULL: the synthetic AIR); degree <= 5 (4 / 5: four quotient chunks for that chip,
+ * log_blowup >= 2); no lookups (proof version 9) */
 size_t orc_chips_proof_size_air(const int* log_ns, const size_t* widths, const uint32_t* const* progs, const size_t* prog_words, int n_chips,
                                 const orc_params_t* prm, size_t n_public);
 size_t orc_prove_chips_air(const uint32_t* const* traces, const int* log_ns, const size_t* widths, const uint32_t* const* progs,

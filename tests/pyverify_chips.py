@@ -31,6 +31,20 @@ def parse_table(table, width):
     return out
 
 
+def program_degree(program):
+    """largest degree of a term of a constraint program, its selector counted"""
+    w = [int(x) for x in program]
+    pos, deg = 6, 0
+    for _ in range(w[3]):
+        sel, nt = w[pos], w[pos + 1]
+        pos += 2
+        for _ in range(nt):
+            d = w[pos + 1]
+            deg = max(deg, d + (1 if sel else 0))
+            pos += 2 + d
+    return deg
+
+
 def mixed_root(rows_by_height, h_max, index, siblings):
     """Merkle root of a mixed-height commitment from one opening: the rows of the tallest matrices (concatenated in chip order)
     form the leaf; after the node with 2^h siblings below it has been formed, the rows of the matrices of height 2^h join as
@@ -70,6 +84,12 @@ def verify(proof_bytes, log_ns, widths, public_values, log_blowup=1, num_queries
     lk = any(cols)
     cross = (machine and lk) or (partners is not None and any(p_ >= 0 for p_ in partners))
     any_prog = any(p_ is not None for p_ in programs)
+    # a program of degree 4 or 5 (a selector counts one degree) has four quotient chunks instead of two: its log_quotient_degree is what
+    # the header's has-program word carries
+    lqs = [(2 if program_degree(p_) > 3 else 1) if p_ is not None else 1 for p_ in programs]
+    if any(q > b for q in lqs):
+        raise Reject("a program of degree 4 or 5 needs log_blowup >= 2")
+    qws = [4 << q for q in lqs]
     version = (11 if keyed else 10) if machine else (9 if any_prog else (6 if cross else (5 if lk else 4)))
     wp = [4 * (q + 1) if q else 0 for q in cols]
     lh = [ln + b for ln in log_ns]
@@ -83,7 +103,7 @@ def verify(proof_bytes, log_ns, widths, public_values, log_blowup=1, num_queries
     for c in range(n):
         entries += [log_ns[c], widths[c]]
         if machine:
-            entries += [1 if programs[c] is not None else 0, len(inter[c]) if inter[c] else 0]
+            entries += [lqs[c] if programs[c] is not None else 0, len(inter[c]) if inter[c] else 0]
             if keyed:
                 entries.append(pws[c])
             continue
@@ -92,7 +112,7 @@ def verify(proof_bytes, log_ns, widths, public_values, log_blowup=1, num_queries
         if cross:
             entries.append(partners[c] + 1)
         if any_prog:
-            entries.append(1 if programs[c] is not None else 0)
+            entries.append(lqs[c] if programs[c] is not None else 0)
     digests = []
     for c in range(n):
         if programs[c] is not None:
@@ -150,7 +170,7 @@ def verify(proof_bytes, log_ns, widths, public_values, log_blowup=1, num_queries
     opened = []
     for c in range(n):
         pre_parts = (take_ext(pws[c]), take_ext(pws[c]))                      # preprocessed columns at zeta, at zeta g: first
-        opened.append((take_ext(widths[c]), take_ext(widths[c]), take_ext(wp[c]), take_ext(wp[c]), take_ext(8)) + pre_parts)
+        opened.append((take_ext(widths[c]), take_ext(widths[c]), take_ext(wp[c]), take_ext(wp[c]), take_ext(qws[c])) + pre_parts)
     for c in range(n):
         for part in opened[c][5:] + opened[c][:5]:
             for e in part:
@@ -220,21 +240,26 @@ def verify(proof_bytes, log_ns, widths, public_values, log_blowup=1, num_queries
             fold(ext_mul(sel_first, e_sub(phis[Q], sum_l)))
             fold(ext_mul(sel_trans, e_sub(e_sub(phins[Q], phis[Q]), sum_n)))
             fold(ext_mul(sel_last, e_sub(phis[Q], cumsum[c])))
-        w2n = two_adic_generator(log_ns[c] + 1)
-        sN = [pow(GEN * pow(w2n, k, P) % P, N, P) for k in range(2)]
+        nq = 1 << lqs[c]
+        wq = two_adic_generator(log_ns[c] + lqs[c])
+        sN = [pow(GEN * pow(wq, k, P) % P, N, P) for k in range(nq)]
         quotient = ZERO
-        for k in range(2):
-            j = 1 - k
-            sjn_inv = pow(sN[j], -1, P)
-            num = e_sub(e_scale(zeta_n, sjn_inv), ONE)
-            den = (sN[k] * sjn_inv - 1) % P
-            quotient = e_add(quotient, ext_mul(e_scale(num, pow(den, -1, P)), e_from_columns(qz[4 * k:4 * k + 4])))
+        for k in range(nq):                              # chunk k lives on the coset s_k <w_N>; zps_k vanishes on the other chunks' cosets
+            zps = ONE
+            for j in range(nq):
+                if j == k:
+                    continue
+                sjn_inv = pow(sN[j], -1, P)
+                num = e_sub(e_scale(zeta_n, sjn_inv), ONE)
+                den = (sN[k] * sjn_inv - 1) % P
+                zps = ext_mul(zps, e_scale(num, pow(den, -1, P)))
+            quotient = e_add(quotient, ext_mul(zps, e_from_columns(qz[4 * k:4 * k + 4])))
         if ext_mul(acc, ext_inv(zh)) != quotient:
             raise Reject("chip %d: constraints do not match the quotient at zeta" % c)
 
     # ---- (b) FRI: one reduced-opening vector per height; the batching powers run on across the chips of a height
     fa = ts.sample_ext()
-    npow = max([8] + list(widths) + wp + pws)
+    npow = max(qws + list(widths) + wp + pws)
     fap = [ONE]
     for _ in range(npow - 1):
         fap.append(ext_mul(fap[-1], fa))
@@ -253,7 +278,7 @@ def verify(proof_bytes, log_ns, widths, public_values, log_blowup=1, num_queries
     ys, offs = [], []
     for c in range(n):
         ys.append([batch(part) for part in opened[c]])
-        off0 = sum(2 * pws[d] + 2 * widths[d] + 2 * wp[d] + 8 for d in range(c) if log_ns[d] == log_ns[c])
+        off0 = sum(2 * pws[d] + 2 * widths[d] + 2 * wp[d] + qws[d] for d in range(c) if log_ns[d] == log_ns[c])
         W, Wp, Pw = widths[c], wp[c], pws[c]
         off = off0 + 2 * Pw                              # the chip's preprocessed columns take the first 2 Pw powers of its stretch
         offs.append([ext_pow(fa, off), ext_pow(fa, off + W), ext_pow(fa, off + 2 * W), ext_pow(fa, off + 2 * W + Wp), ext_pow(fa, off + 2 * W + 2 * Wp),
@@ -290,7 +315,7 @@ def verify(proof_bytes, log_ns, widths, public_values, log_blowup=1, num_queries
             for c in perm_chips:
                 prows[c] = take(wp[c])
             ppath = [take(8) for _ in range(h_perm)]
-        qrows = [take(8) for c in range(n)]
+        qrows = [take(qws[c]) for c in range(n)]
         qpath = [take(8) for _ in range(h_max)]
 
         def by_height(rows, chips):

@@ -10,6 +10,17 @@ import machines
 import poseidon2_air
 from zktls_amd._lib import Params
 O.set_threads(8)
+P = O.P
+
+
+def with_quintic_identity(prog, col):
+    """the program with one more constraint, x^5 - x^5 = 0 on column `col` written as two degree-5 terms: true on every trace, and enough
+    to give the table four quotient chunks"""
+    extra = [O.SEL_ALL, 2, 1, 5] + [O.air_var(col)] * 5 + [P - 1, 5] + [O.air_var(col)] * 5
+    out = np.concatenate([prog, np.array(extra, dtype=np.uint32)])
+    out[3] += 1
+    out[5] = out.size
+    return out
 budget = float(sys.argv[1]) if len(sys.argv) > 1 else 60.0
 rng = np.random.default_rng(int(time.time()))
 ctx = Context(0)
@@ -38,6 +49,10 @@ while time.time() - t0 < budget:
         lns, ws = [t.shape[0].bit_length() - 1 for t in traces], [t.shape[1] for t in traces]
         pws = [0 if p_ is None else p_.shape[1] for p_ in pre]
         prm = (int(rng.integers(1, 4)), int(rng.integers(1, 12)), int(rng.integers(0, 7)))
+        if prm[0] >= 2 and rng.random() < 0.5:                                   # one table's program gains a degree-5 constraint: four quotient chunks for that table
+            k = int(rng.integers(0, len(traces)))
+            progs = list(progs)
+            progs[k] = with_quintic_identity(progs[k], 0)
         dev = [ctx.from_numpy(t) for t in traces]
         dpre = [None if p_ is None else ctx.from_numpy(p_) for p_ in pre]
         key = ctx.machine_setup(list(zip(dpre, lns, pws)), Params(*prm))

@@ -256,10 +256,11 @@ hipError_t launch_perm_trace_machine(const MachinePermArgs& a, uint32_t* block_s
 struct MachineQuotArgs {
     LookupArgs lk;
     const uint32_t* lde; uint64_t ld; const uint32_t* perm; uint64_t perm_ld; int log_n;
+    int log_qd;                                    // the chip's quotient domain has 2^(log_n + log_qd) points (1, or 2 for a program of degree 4 / 5)
     const uint32_t* xs; const uint32_t* sel_first; const uint32_t* sel_last; uint32_t wn_inv;
     const uint32_t* weights;                       // device: [cols + 3] extension weights, in constraint order
     Ext cumsum;
-    uint32_t* addend;                              // [2N][4]
+    uint32_t* addend;                              // [2^log_qd N][4]
 };
 hipError_t launch_lookup_addend(const MachineQuotArgs& a, hipStream_t s);
 

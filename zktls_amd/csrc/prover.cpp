@@ -547,15 +547,15 @@ static int run_lookup_perm(zkhip_ctx* ctx, const uint32_t* d_trace, size_t ld, i
 }
 // the chip's lookup constraints on its quotient domain, folded with the LAST cols + 3 powers of alpha (column j: alpha^(cols + 2 - j);
 // is_first, is_transition, is_last rows: alpha^2, alpha, 1)
-static int run_lookup_addend(zkhip_ctx* ctx, const uint32_t* lde, size_t ld, const uint32_t* perm_lde, size_t perm_ld, int log_n, const LookupView& lv,
+static int run_lookup_addend(zkhip_ctx* ctx, const uint32_t* lde, size_t ld, const uint32_t* perm_lde, size_t perm_ld, int log_n, int log_qd, const LookupView& lv,
                              const Ext& gamma, const Ext& beta, const Ext& alpha, const Ext& cumsum, uint32_t* d_addend) {
-    if (ctx->dom_log_n != log_n) ZK_TRY(ensure_domain(ctx, log_n));
+    if (ctx->dom_log_n != log_n || ctx->dom_log_blowup < log_qd) ZK_TRY(ensure_domain(ctx, log_n, log_qd));
     std::vector<uint32_t> weights(4 * ((size_t)lv.cols + 3));
     Ext w = ext_one();
     for (size_t k = lv.cols + 3; k-- > 0;) { for (int i = 0; i < 4; i++) weights[4 * k + i] = w.c[i]; w = ext_mul(w, alpha); }
     MachineQuotArgs a{};
     ZK_TRY(lookup_args(ctx, lv, gamma, beta, weights, &a.lk, &a.weights));
-    a.lde = lde; a.ld = ld; a.perm = perm_lde; a.perm_ld = perm_ld; a.log_n = log_n;
+    a.lde = lde; a.ld = ld; a.perm = perm_lde; a.perm_ld = perm_ld; a.log_n = log_n; a.log_qd = log_qd;
     a.xs = ctx->dom_xs; a.sel_first = ctx->dom_sel_first; a.sel_last = ctx->dom_sel_last; a.wn_inv = finv(two_adic_generator(log_n));
     a.cumsum = cumsum; a.addend = d_addend;
     ZK_HIP(launch_lookup_addend(a, ctx->stream));
@@ -1641,6 +1641,11 @@ struct MachineTables { const LookupView* lk[32]; bool has_prog[32]; };
 static thread_local const MachineTables* t_machine = nullptr;
 static const LookupView* lookup_of(int c) { return t_machine ? t_machine->lk[c] : nullptr; }
 static bool header_has_prog(int c) { return t_machine ? t_machine->has_prog[c] : prog_of(c) != nullptr; }
+// log2 of chip c's number of quotient chunks: 2 for a program of degree 4 or 5 (needs log_blowup >= 2), else 1; the chip's quotient matrix
+// has 4 * 2^lq columns.  The header's has-program word carries it: 0 = no program, else the program's log_quotient_degree.
+static int lq_of(int c) { return prog_of(c) ? prog_of(c)->lqd : 1; }
+static size_t qw_of(int c) { return (size_t)4 << lq_of(c); }
+static uint32_t header_prog_word(int c) { return header_has_prog(c) ? (uint32_t)lq_of(c) : 0u; }
 struct MachineScope {
     MachineScope(const AirView* const* progs, const MachineTables* m) { t_chip_air = progs; t_machine = m; }
     ~MachineScope() { t_chip_air = nullptr; t_machine = nullptr; }
@@ -1703,6 +1708,8 @@ static int check_chips(const int32_t* log_ns, const uint32_t* widths, const int3
         for (int d = 0; d < n; d++) same += log_ns[d] == log_ns[c];
         if (same > MAX_LEAF_MATS) return fail(ZKHIP_ERR_INVALID, "chips: at most 8 chips per height");
     }
+    for (int c = 0; c < n; c++)
+        if (lq_of(c) > prm->log_blowup) return fail(ZKHIP_ERR_INVALID, "chips: a program of degree 4 or 5 needs log_blowup >= 2 (its quotient domain must lie inside the committed LDE domain)");
     if (t_key) {
         bool some = false;
         for (int c = 0; c < n; c++) {
@@ -1726,8 +1733,8 @@ static size_t chips_proof_words(const int32_t* log_ns, const uint32_t* widths, c
     size_t he = 0;
     for (int c = 0; c < n; c++) {
         const size_t wp = perm_width(pairs, c);
-        words += 8 * (size_t)widths[c] + 8 * wp + 32 + ((cross && wp) ? 4 : 0) + 8 * (size_t)pre_w(c);
-        perq += widths[c] + wp + 8 + pre_w(c);
+        words += 8 * (size_t)widths[c] + 8 * wp + 4 * qw_of(c) + ((cross && wp) ? 4 : 0) + 8 * (size_t)pre_w(c);
+        perq += widths[c] + wp + qw_of(c) + pre_w(c);
         if (wp && (size_t)log_ns[c] + b > hp) hp = (size_t)log_ns[c] + b;
         if (pre_w(c) && (size_t)log_ns[c] + b > he) he = (size_t)log_ns[c] + b;
     }
@@ -1747,13 +1754,13 @@ static void chips_transcript_init(Challenger& ch, const int32_t* log_ns, const u
     for (int c = 0; c < n; c++) {
         ch.observe_canonical((uint32_t)log_ns[c]); ch.observe_canonical(widths[c]);
         if (t_machine) {
-            ch.observe_canonical(header_has_prog(c) ? 1u : 0u); ch.observe_canonical(lookup_of(c) ? lookup_of(c)->ni : 0u);
+            ch.observe_canonical(header_prog_word(c)); ch.observe_canonical(lookup_of(c) ? lookup_of(c)->ni : 0u);
             if (t_key) ch.observe_canonical(pre_w(c));
             continue;
         }
         if (lk) ch.observe_canonical((uint32_t)pairs[c]);
         if (cross) ch.observe_canonical((uint32_t)(partners[c] + 1));
-        if (any_prog(n)) ch.observe_canonical(prog_of(c) ? 1u : 0u);
+        if (any_prog(n)) ch.observe_canonical(header_prog_word(c));
     }
     for (int c = 0; c < n; c++)
         if (header_has_prog(c)) {
@@ -1772,7 +1779,7 @@ static void chips_transcript_init(Challenger& ch, const int32_t* log_ns, const u
 // alpha-power offset of chip c inside the reduced-opening vector of its height
 static uint64_t height_offset(const int32_t* log_ns, const uint32_t* widths, const int32_t* pairs, int c) {
     uint64_t off = 0;
-    for (int d = 0; d < c; d++) if (log_ns[d] == log_ns[c]) off += 2 * (uint64_t)pre_w(d) + 2 * (uint64_t)widths[d] + 2 * perm_width(pairs, d) + 8;
+    for (int d = 0; d < c; d++) if (log_ns[d] == log_ns[c]) off += 2 * (uint64_t)pre_w(d) + 2 * (uint64_t)widths[d] + 2 * perm_width(pairs, d) + qw_of(d);
     return off;
 }
 }  // namespace zk
@@ -1816,16 +1823,16 @@ int zkhip_prove_chips(zkhip_ctx* ctx, const zkhip_chip* chips, int n, const uint
         lh[c] = log_ns[c] + b;
         const size_t mc = (size_t)1 << lh[c], nc = (size_t)1 << log_ns[c];
         tl_off[c + 1] = tl_off[c] + mc * (pre_w(c) + widths[c]);     // a keyed chip's LDE rows are [preprocessed | main]
-        ql_off[c + 1] = ql_off[c] + mc * 8;
+        ql_off[c + 1] = ql_off[c] + mc * qw_of(c);
         dv_off[c + 1] = dv_off[c] + 8 * (mc + nc);               // [2][mc] 1/(x - z) then [2][nc] x/(x - z), ext words
         wp[c] = perm_width(pairs, c);
         pl_off[c + 1] = pl_off[c] + mc * wp[c];
-        op_off[c + 1] = op_off[c] + 8 * (size_t)pre_w(c) + 8 * (size_t)widths[c] + 8 * wp[c] + 32;
-        size_t npw = widths[c] > 8 ? widths[c] : 8;
+        op_off[c + 1] = op_off[c] + 8 * (size_t)pre_w(c) + 8 * (size_t)widths[c] + 8 * wp[c] + 4 * qw_of(c);
+        size_t npw = widths[c] > qw_of(c) ? widths[c] : qw_of(c);
         if (wp[c] > npw) npw = wp[c];
         if (pre_w(c) > npw) npw = pre_w(c);
         ap_off[c + 1] = ap_off[c] + 4 * npw;
-        if (nc > nmax_chunk) nmax_chunk = nc;
+        if ((nc << lq_of(c)) > nmax_chunk) nmax_chunk = nc << lq_of(c);       // quotient values of the chip: 2^lq chunks of nc points
         if (nc * wp[c] > perm_max) perm_max = nc * wp[c];
         if (wp[c] && lh[c] > Hp) Hp = lh[c];
     }
@@ -1835,10 +1842,10 @@ int zkhip_prove_chips(zkhip_ctx* ctx, const zkhip_chip* chips, int n, const uint
     pf[pos++] = (uint32_t)Q; pf[pos++] = (uint32_t)prm->pow_bits; pf[pos++] = (uint32_t)n_public; pf[pos++] = 16u;
     for (int c = 0; c < n; c++) {
         pf[pos++] = (uint32_t)log_ns[c]; pf[pos++] = widths[c];
-        if (t_machine) { pf[pos++] = header_has_prog(c) ? 1u : 0u; pf[pos++] = lookup_of(c) ? lookup_of(c)->ni : 0u; if (t_key) pf[pos++] = pre_w(c); continue; }
+        if (t_machine) { pf[pos++] = header_prog_word(c); pf[pos++] = lookup_of(c) ? lookup_of(c)->ni : 0u; if (t_key) pf[pos++] = pre_w(c); continue; }
         if (lk) pf[pos++] = (uint32_t)pairs[c];
         if (cross) pf[pos++] = (uint32_t)(partners[c] + 1);
-        if (any_prog(n)) pf[pos++] = prog_of(c) ? 1u : 0u;
+        if (any_prog(n)) pf[pos++] = header_prog_word(c);
     }
     for (int c = 0; c < n; c++) if (header_has_prog(c)) { air_digest_cached(*prog_of(c), pf + pos); pos += 8; }
     for (int c = 0; c < n; c++) if (lookup_of(c)) { lookup_digest(*lookup_of(c), pf + pos); pos += 8; }
@@ -1853,7 +1860,7 @@ int zkhip_prove_chips(zkhip_ctx* ctx, const zkhip_chip* chips, int n, const uint
     ZK_TRY(ctx_reserve(ctx, S_TTREE, (2 * mmax - 1) * 32, &v_ttree));
     ZK_TRY(ctx_reserve(ctx, S_QLDE, ql_off[n] * 4, &v_qlde));
     ZK_TRY(ctx_reserve(ctx, S_QTREE, (2 * mmax - 1) * 32, &v_qtree));
-    ZK_TRY(ctx_reserve(ctx, S_QCHUNK, 2 * nmax_chunk * 16, &v_qchunk));
+    ZK_TRY(ctx_reserve(ctx, S_QCHUNK, nmax_chunk * 16, &v_qchunk));
     uint32_t *tlde = (uint32_t*)v_tlde, *ttree = (uint32_t*)v_ttree, *qlde = (uint32_t*)v_qlde, *qtree = (uint32_t*)v_qtree, *qchunk = (uint32_t*)v_qchunk;
     MatDesc tm[MAX_CHIPS], qm[MAX_CHIPS];
     size_t cw[MAX_CHIPS];                          // row pitch of a chip's LDE: preprocessed + main columns
@@ -1864,7 +1871,7 @@ int zkhip_prove_chips(zkhip_ctx* ctx, const zkhip_chip* chips, int n, const uint
             ZK_HIP(hipMemcpy2DAsync(tlde + tl_off[c], cw[c] * 4, t_key->d_lde[c], (size_t)pw * 4, (size_t)pw * 4, (size_t)1 << lh[c], hipMemcpyDeviceToDevice, st));
         ZK_TRY(op_coset_lde(ctx, chips[c].d_trace, chips[c].ld, tlde + tl_off[c] + pw, cw[c], log_ns[c], widths[c], b, MONTY_GEN));
         tm[c] = MatDesc{tlde + tl_off[c] + pw, cw[c], widths[c]};
-        qm[c] = MatDesc{qlde + ql_off[c], 8, 8};
+        qm[c] = MatDesc{qlde + ql_off[c], qw_of(c), (uint32_t)qw_of(c)};
     }
     ZK_TRY(op_merkle_commit_mixed(ctx, tm, lh, n, ttree));
     ZK_TRY(d2h(ctx, root, ttree + (2 * mmax - 2) * 8, 32));
@@ -1923,20 +1930,20 @@ int zkhip_prove_chips(zkhip_ctx* ctx, const zkhip_chip* chips, int n, const uint
             // the chip's lookup constraints fold after its program's: the program's weights move up by alpha^(cols + 3)
             const LookupView& lv = *lookup_of(c);
             void* v_add;
-            ZK_TRY(ctx_reserve(ctx, S_ADDEND, ((size_t)2 << log_ns[c]) * 16, &v_add));
-            ZK_TRY(run_lookup_addend(ctx, tlde + tl_off[c], cw[c], plde + pl_off[c], wp[c], log_ns[c], lv, gamma, beta_l, alpha, cumsum[c], (uint32_t*)v_add));
+            ZK_TRY(ctx_reserve(ctx, S_ADDEND, ((size_t)1 << (log_ns[c] + lq_of(c))) * 16, &v_add));
+            ZK_TRY(run_lookup_addend(ctx, tlde + tl_off[c], cw[c], plde + pl_off[c], wp[c], log_ns[c], lq_of(c), lv, gamma, beta_l, alpha, cumsum[c], (uint32_t*)v_add));
             ZK_TRY(run_quotient_air(ctx, *prog_of(c), tlde + tl_off[c], cw[c], log_ns[c], (uint32_t)cw[c], public_values, alpha, qchunk,
                                     own_coset_direct ? qlde + ql_off[c] : nullptr, 8, ext_pow(alpha, lv.cols + 3), (const uint32_t*)v_add));
         } else if (prog_of(c)) ZK_TRY(run_quotient_air(ctx, *prog_of(c), tlde + tl_off[c], cw[c], log_ns[c], (uint32_t)cw[c], public_values, alpha, qchunk,
                                                 own_coset_direct ? qlde + ql_off[c] : nullptr, 8));
         else ZK_TRY(run_quotient(ctx, tlde + tl_off[c], widths[c], log_ns[c], widths[c], alpha, lu, qchunk, own_coset_direct ? qlde + ql_off[c] : nullptr, 8));
-        const uint32_t w2n = two_adic_generator(log_ns[c] + 1);
-        for (int k = 0; k < 2; k++) {
-            if (own_coset_direct)
+        const uint32_t w2n = two_adic_generator(log_ns[c] + lq_of(c));
+        for (int k = 0; k < (1 << lq_of(c)); k++) {
+            if (own_coset_direct)                              // (blowup 2: every chip has two chunks)
                 ZK_TRY(op_coset_lde(ctx, qchunk + (size_t)k * nc * 4, 4, qlde + ql_off[c] + (size_t)(1 - k) * nc * 8 + 4 * k, 8, log_ns[c], 4, 0,
                                     k == 0 ? w2n : finv(w2n)));
             else
-                ZK_TRY(op_coset_lde(ctx, qchunk + (size_t)k * nc * 4, 4, qlde + ql_off[c] + 4 * k, 8, log_ns[c], 4, b, finv(fpow(w2n, (uint64_t)k))));
+                ZK_TRY(op_coset_lde(ctx, qchunk + (size_t)k * nc * 4, 4, qlde + ql_off[c] + 4 * k, qw_of(c), log_ns[c], 4, b, finv(fpow(w2n, (uint64_t)k))));
         }
     }
     ZK_TRY(op_merkle_commit_mixed(ctx, qm, lh, n, qtree));
@@ -1963,7 +1970,7 @@ int zkhip_prove_chips(zkhip_ctx* ctx, const zkhip_chip* chips, int n, const uint
         if (pw) ZK_TRY(run_open(ctx, tlde + tl_off[c], cw[c], log_ns[c], (uint32_t)pw, zpts, 2, xw, d_open + op_off[c]));
         ZK_TRY(run_open(ctx, tlde + tl_off[c] + pw, cw[c], log_ns[c], widths[c], zpts, 2, xw, oc));
         if (wp[c]) ZK_TRY(run_open(ctx, plde + pl_off[c], wp[c], log_ns[c], (uint32_t)wp[c], zpts, 2, xw, oc + 8 * (size_t)widths[c]));
-        ZK_TRY(run_open(ctx, qlde + ql_off[c], 8, log_ns[c], 8, zpts, 1, xw, oc + 8 * (size_t)widths[c] + 8 * wp[c]));
+        ZK_TRY(run_open(ctx, qlde + ql_off[c], qw_of(c), log_ns[c], (uint32_t)qw_of(c), zpts, 1, xw, oc + 8 * (size_t)widths[c] + 8 * wp[c]));
     }
     std::vector<uint32_t> opened(op_off[n]);
     ZK_TRY(d2h(ctx, opened.data(), d_open, opened.size() * 4));
@@ -2025,12 +2032,12 @@ int zkhip_prove_chips(zkhip_ctx* ctx, const zkhip_chip* chips, int n, const uint
             ra.y_pl = ext_add(ra.y_pl, ext_mul(fp[j], op_pl[j]));
             ra.y_pn = ext_add(ra.y_pn, ext_mul(fp[j], op_pn[j]));
         }
-        for (int j = 0; j < 8; j++) ra.y_q = ext_add(ra.y_q, ext_mul(fp[j], op_q[j]));
+        for (size_t j = 0; j < qw_of(c); j++) ra.y_q = ext_add(ra.y_q, ext_mul(fp[j], op_q[j]));
         const uint64_t off0 = height_offset(log_ns, widths, pairs, c), off = off0 + 2 * (uint64_t)Pw;
         ra.off_loc = ext_pow(fa, off); ra.off_next = ext_pow(fa, off + W);
         ra.off_pl = ext_pow(fa, off + 2 * (uint64_t)W); ra.off_pn = ext_pow(fa, off + 2 * (uint64_t)W + wp[c]);
         ra.off_q = ext_pow(fa, off + 2 * (uint64_t)W + 2 * wp[c]);
-        ra.tlde = tlde + tl_off[c] + Pw; ra.t_ld = cw[c]; ra.width = W; ra.qlde = qlde + ql_off[c]; ra.q_ld = 8; ra.q_width = 8; ra.rows = (uint64_t)1 << lh[c];
+        ra.tlde = tlde + tl_off[c] + Pw; ra.t_ld = cw[c]; ra.width = W; ra.qlde = qlde + ql_off[c]; ra.q_ld = qw_of(c); ra.q_width = (uint32_t)qw_of(c); ra.rows = (uint64_t)1 << lh[c];
         ra.plde = wp[c] ? plde + pl_off[c] : nullptr; ra.p_ld = wp[c]; ra.p_width = (uint32_t)wp[c];
         ra.alpha_pow = (const uint32_t*)v_apf + ap_off[c]; ra.dinv = dinv + dv_off[c]; ra.out = ro_of[lh[c]];
         ra.accumulate = started[lh[c]] ? 1 : 0;
@@ -2086,7 +2093,7 @@ int zkhip_prove_chips(zkhip_ctx* ctx, const zkhip_chip* chips, int n, const uint
                 for (int c = 0; c < n; c++) if (wp[c]) push(plde + pl_off[c] + (index >> (Hmax - lh[c])) * wp[c], wp[c]);
                 push_path(ptree, (size_t)1 << Hp, index >> (Hmax - Hp), Hp);
             }
-            for (int c = 0; c < n; c++) push(qlde + ql_off[c] + (index >> (Hmax - lh[c])) * 8, 8);
+            for (int c = 0; c < n; c++) push(qlde + ql_off[c] + (index >> (Hmax - lh[c])) * qw_of(c), qw_of(c));
             push_path(qtree, mmax, index, Hmax);
             size_t idx = index;
             for (int l = 0; l < L; l++) {
@@ -2195,14 +2202,14 @@ int zkhip_verify_chips(const uint8_t* proof, size_t len, const int32_t* log_ns, 
         if (pf[pos] != (uint32_t)log_ns[c] || pf[pos + 1] != widths[c]) return reject(3);
         pos += 2;
         if (t_machine) {
-            if (pf[pos] != (header_has_prog(c) ? 1u : 0u) || pf[pos + 1] != (lookup_of(c) ? lookup_of(c)->ni : 0u)) return reject(3);
+            if (pf[pos] != header_prog_word(c) || pf[pos + 1] != (lookup_of(c) ? lookup_of(c)->ni : 0u)) return reject(3);
             pos += 2;
             if (t_key) { if (pf[pos] != pre_w(c)) return reject(3); pos++; }
             continue;
         }
         if (lk) { if (pf[pos] != (uint32_t)pairs[c]) return reject(3); pos++; }
         if (cross) { if (pf[pos] != (uint32_t)(partners[c] + 1)) return reject(3); pos++; }
-        if (any_prog(n)) { if (pf[pos] != (prog_of(c) ? 1u : 0u)) return reject(3); pos++; }
+        if (any_prog(n)) { if (pf[pos] != header_prog_word(c)) return reject(3); pos++; }
     }
     for (int c = 0; c < n; c++)
         if (header_has_prog(c)) {
@@ -2222,7 +2229,7 @@ int zkhip_verify_chips(const uint8_t* proof, size_t len, const int32_t* log_ns, 
     for (size_t i = pos; i < len / 4; i++) if (pf[i] >= P) return reject(4);
     for (size_t i = 0; i < n_public; i++) if (public_values[i] >= P) return reject(4);
     int lh[MAX_CHIPS]; uint32_t w8[MAX_CHIPS]; size_t wp[MAX_CHIPS];
-    for (int c = 0; c < n; c++) { lh[c] = log_ns[c] + b; w8[c] = 8; wp[c] = perm_width(pairs, c); }
+    for (int c = 0; c < n; c++) { lh[c] = log_ns[c] + b; w8[c] = (uint32_t)qw_of(c); wp[c] = perm_width(pairs, c); }
     Challenger ch;
     chips_transcript_init(ch, log_ns, widths, pairs, partners, n, prm, n_public);
     Ext cumsum[MAX_CHIPS];
@@ -2252,7 +2259,7 @@ int zkhip_verify_chips(const uint8_t* proof, size_t len, const int32_t* log_ns, 
         const uint32_t W = widths[c];
         auto take = [&](std::vector<Ext>& v, size_t cnt) { v.resize(cnt); for (size_t j = 0; j < cnt; j++) v[j] = ext_from_canon(pf + pos + 4 * j); pos += 4 * cnt; };
         take(oel[c], pre_w(c)); take(oen[c], pre_w(c));
-        take(loc[c], W); take(nxt[c], W); take(opl[c], wp[c]); take(opn[c], wp[c]); take(opq[c], 8);
+        take(loc[c], W); take(nxt[c], W); take(opl[c], wp[c]); take(opn[c], wp[c]); take(opq[c], w8[c]);
     }
     // (the query groups run on worker threads, which do not see this thread's key: widths and root by value from here on)
     uint32_t ew[MAX_CHIPS], pwv[MAX_CHIPS]; int elh[MAX_CHIPS], echip[MAX_CHIPS]; int ne = 0, He = 0;
@@ -2319,22 +2326,29 @@ int zkhip_verify_chips(const uint8_t* proof, size_t len, const int32_t* log_ns, 
             acc = ext_add(ext_mul(acc, alpha), ext_mul(sel_trans, ext_sub(ext_sub(Sn, S), sum_n)));
             acc = ext_add(ext_mul(acc, alpha), ext_mul(sel_last, ext_sub(S, cumsum[c])));
         }
-        const uint32_t w2n = two_adic_generator(log_ns[c] + 1);
-        const uint32_t s[2] = {MONTY_GEN, fmul(MONTY_GEN, w2n)};
+        // quotient(zeta) = sum_k zps_k(zeta) q_k(zeta) over the chip's own 2^lq cosets s_k <w_N>, s_k = g w^k (as in the single-matrix verifier)
+        const size_t NQc = w8[c] / 4;
+        const uint32_t wq = two_adic_generator(log_ns[c] + (NQc == 4 ? 2 : 1));
+        uint32_t sN[4];
+        for (size_t k = 0; k < NQc; k++) sN[k] = fpow(fmul(MONTY_GEN, fpow(wq, (uint64_t)k)), nc);
         Ext quot = ext_zero();
-        for (int k = 0; k < 2; k++) {
-            const int j = 1 - k;
-            const uint32_t sjn_inv = finv(fpow(s[j], nc));
-            const Ext num = ext_sub_base(ext_mul_base(zn, sjn_inv), MONTY_R1);
-            const uint32_t den = fsub(fmul(fpow(s[k], nc), sjn_inv), MONTY_R1);
-            quot = ext_add(quot, ext_mul(ext_mul_base(num, finv(den)), recombine(&opq[c][4 * k])));
+        for (size_t k = 0; k < NQc; k++) {
+            Ext zps = ext_one();
+            for (size_t j = 0; j < NQc; j++) {
+                if (j == k) continue;
+                const uint32_t sjn_inv = finv(sN[j]);
+                const Ext num = ext_sub_base(ext_mul_base(zn, sjn_inv), MONTY_R1);
+                const uint32_t den = fsub(fmul(sN[k], sjn_inv), MONTY_R1);
+                zps = ext_mul(zps, ext_mul_base(num, finv(den)));
+            }
+            quot = ext_add(quot, ext_mul(zps, recombine(&opq[c][4 * k])));
         }
         if (!ext_eq(ext_mul(acc, ext_inv(zh)), quot)) return reject(10);
     }
     // (b) FRI
     const Ext fa = ch.sample_ext();
     size_t npmax = 8;
-    for (int c = 0; c < n; c++) { if (widths[c] > npmax) npmax = widths[c]; if (wp[c] > npmax) npmax = wp[c]; if (pre_w(c) > npmax) npmax = pre_w(c); }
+    for (int c = 0; c < n; c++) { if (widths[c] > npmax) npmax = widths[c]; if (wp[c] > npmax) npmax = wp[c]; if (pre_w(c) > npmax) npmax = pre_w(c); if (w8[c] > npmax) npmax = w8[c]; }
     std::vector<Ext> fapow(npmax);
     fapow[0] = ext_one();
     for (size_t j = 1; j < npmax; j++) fapow[j] = ext_mul(fapow[j - 1], fa);
@@ -2356,7 +2370,7 @@ int zkhip_verify_chips(const uint8_t* proof, size_t len, const int32_t* log_ns, 
             y_pl[c] = ext_add(y_pl[c], ext_mul(fapow[j], opl[c][j]));
             y_pn[c] = ext_add(y_pn[c], ext_mul(fapow[j], opn[c][j]));
         }
-        for (int j = 0; j < 8; j++) y_q[c] = ext_add(y_q[c], ext_mul(fapow[j], opq[c][j]));
+        for (uint32_t j = 0; j < w8[c]; j++) y_q[c] = ext_add(y_q[c], ext_mul(fapow[j], opq[c][j]));
         const uint64_t off0 = height_offset(log_ns, widths, pairs, c), off = off0 + 2 * (uint64_t)Pw;
         s_el[c] = ext_pow(fa, off0); s_en[c] = ext_pow(fa, off0 + Pw);
         s_loc[c] = ext_pow(fa, off); s_nxt[c] = ext_pow(fa, off + W); s_pl[c] = ext_pow(fa, off + 2 * (uint64_t)W);
@@ -2411,7 +2425,7 @@ int zkhip_verify_chips(const uint8_t* proof, size_t len, const int32_t* log_ns, 
                 for (int k = 0; k < np; k++) { prow[j][k] = pf + pos; prow_all[j][pchip[k]] = prow[j][k]; pos += pw[k]; }
                 ppath[j] = pf + pos; pos += 8 * (size_t)Hp;
             }
-            for (int c = 0; c < n; c++) { qrow[j][c] = pf + pos; pos += 8; }
+            for (int c = 0; c < n; c++) { qrow[j][c] = pf + pos; pos += w8[c]; }
             qpath[j] = pf + pos; pos += 8 * (size_t)Hmax;
             qpos[j] = pos;
         }
@@ -2432,7 +2446,7 @@ int zkhip_verify_chips(const uint8_t* proof, size_t len, const int32_t* log_ns, 
                 Ext at = ext_zero(), ap = ext_zero(), aq = ext_zero();
                 for (uint32_t k = 0; k < widths[c]; k++) at = ext_add(at, ext_mul_base(fapow[k], to_monty(trow[j][c][k])));
                 for (size_t k = 0; k < wp[c]; k++) ap = ext_add(ap, ext_mul_base(fapow[k], to_monty(prow_all[j][c][k])));
-                for (int k = 0; k < 8; k++) aq = ext_add(aq, ext_mul_base(fapow[k], to_monty(qrow[j][c][k])));
+                for (uint32_t k = 0; k < w8[c]; k++) aq = ext_add(aq, ext_mul_base(fapow[k], to_monty(qrow[j][c][k])));
                 Ext r = ext_mul(s_loc[c], ext_mul(ext_sub(at, y_loc[c]), d1));
                 r = ext_add(r, ext_mul(s_nxt[c], ext_mul(ext_sub(at, y_nxt[c]), d2)));
                 if (wp[c]) {
@@ -2493,7 +2507,6 @@ static int chip_programs(const uint32_t* const* programs, const size_t* program_
         table[c] = nullptr;
         if (!programs[c]) continue;
         if (!air_validate(programs[c], program_words[c], widths[c], n_public, &views[c])) return fail(ZKHIP_ERR_INVALID, "chips_air: malformed constraint program (or its n_public differs from the shard's)");
-        if (views[c].lqd != 1) return fail(ZKHIP_ERR_INVALID, "chips_air: programs of degree 4 / 5 need four quotient chunks; the multi-chip prover commits two");
         table[c] = &views[c];
     }
     return ZKHIP_OK;
@@ -2553,7 +2566,6 @@ static int machine_setup(const uint32_t* const* programs, const size_t* program_
             prog = m.synthetic[c].data(); words = need;
         }
         if (!air_validate(prog, words, widths[c], n_public, &m.views[c])) return fail(ZKHIP_ERR_INVALID, "machine: malformed constraint program (or its n_public differs from the shard's)");
-        if (m.views[c].lqd != 1) return fail(ZKHIP_ERR_INVALID, "machine: programs of degree 4 / 5 need four quotient chunks; the multi-chip prover commits two");
         m.table[c] = &m.views[c];
         m.mt.lk[c] = nullptr;
         m.cols[c] = 0;

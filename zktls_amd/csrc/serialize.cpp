@@ -100,7 +100,7 @@ struct Reader {
 //     public_values: Vec<u32> }
 struct ChipsLayout {
     uint32_t version = 0, n = 0, b = 0, Q = 0, pow_bits = 0, n_public = 0;
-    int log_ns[32]; uint32_t widths[32], pw[32]; size_t wp[32];
+    int log_ns[32]; uint32_t widths[32], pw[32], qw[32]; size_t wp[32];      // qw: columns of the chip's quotient matrix, 4 per chunk (8 or 16)
     bool lk = false, cross = false, keyed = false;
     size_t head = 0;                      // header words incl. digests and the key root
     int Hmax = 0, L = 0, Hp = 0, He = 0;
@@ -118,13 +118,15 @@ bool parse_chips_header(const uint32_t* pf, size_t words, ChipsLayout& C) {
     for (uint32_t c = 0; c < C.n; c++) {
         const uint32_t* e = pf + p; p += per;
         if (e[0] < 5 || e[0] > (uint32_t)MAX_LOG_ROWS || e[1] == 0 || e[1] % 4 != 0 || e[1] > 1024 || (c && (int)e[0] > C.log_ns[c - 1])) return false;
-        C.log_ns[c] = (int)e[0]; C.widths[c] = e[1]; C.pw[c] = 0; C.wp[c] = 0;
+        C.log_ns[c] = (int)e[0]; C.widths[c] = e[1]; C.pw[c] = 0; C.wp[c] = 0; C.qw[c] = 8;
         if (v == 5 || v == 6) { if (e[2] > 64) return false; C.wp[c] = e[2] ? 4 * ((size_t)e[2] + 1) : 0; }
         if (v == 6) { if (e[3] > C.n) return false; if (e[3]) C.cross = true; }
-        if (v == 9) { if (e[2] > 1) return false; digests += e[2]; }
+        // the has-program word: 0 none, else the program's log_quotient_degree (2: four quotient chunks, needs log_blowup >= 2)
+        if (v == 9) { if (e[2] > 2 || (e[2] == 2 && C.b < 2)) return false; digests += e[2] ? 1 : 0; if (e[2] == 2) C.qw[c] = 16; }
         if (v >= 10) {
-            if (e[2] > 1 || e[3] > 64) return false;
-            digests += e[2] + (e[3] ? 1 : 0);
+            if (e[2] > 2 || (e[2] == 2 && C.b < 2) || e[3] > 64) return false;
+            if (e[2] == 2) C.qw[c] = 16;
+            digests += (e[2] ? 1 : 0) + (e[3] ? 1 : 0);
             C.wp[c] = e[3] ? 4 * (((size_t)e[3] + 1) / 2 + 1) : 0;
             if (e[3]) C.cross = true;
         }
@@ -140,8 +142,8 @@ bool parse_chips_header(const uint32_t* pf, size_t words, ChipsLayout& C) {
 size_t chips_flat_words(const ChipsLayout& C) {
     size_t words = C.head + 16 + (C.lk ? 8 : 0) + 8 * (size_t)C.L + 4 + 1, perq = 16 * (size_t)C.Hmax + 8 * (size_t)C.Hp + 8 * (size_t)C.He;
     for (uint32_t c = 0; c < C.n; c++) {
-        words += 8 * (size_t)C.pw[c] + 8 * (size_t)C.widths[c] + 8 * C.wp[c] + 32 + ((C.cross && C.wp[c]) ? 4 : 0);
-        perq += C.pw[c] + C.widths[c] + C.wp[c] + 8;
+        words += 8 * (size_t)C.pw[c] + 8 * (size_t)C.widths[c] + 8 * C.wp[c] + 4 * (size_t)C.qw[c] + ((C.cross && C.wp[c]) ? 4 : 0);
+        perq += C.pw[c] + C.widths[c] + C.wp[c] + C.qw[c];
     }
     for (int l = 0; l < C.L; l++) perq += 4 + 8 * ((size_t)C.Hmax - 1 - l);
     return words + (size_t)C.Q * perq;
@@ -151,7 +153,7 @@ size_t chips_bincode_bytes(const ChipsLayout& C) {
     n += 32 + 1 + (C.lk ? 32 : 0) + 32;                          // commitment (Option tag: one byte)
     n += 8;                                                      // chips
     for (uint32_t c = 0; c < C.n; c++)
-        n += 2 * (8 + 16 * (size_t)C.pw[c]) + 2 * (8 + 16 * (size_t)C.widths[c]) + 2 * (8 + 16 * C.wp[c]) + 8 + 2 * (8 + 64) + 16 + 8;
+        n += 2 * (8 + 16 * (size_t)C.pw[c]) + 2 * (8 + 16 * (size_t)C.widths[c]) + 2 * (8 + 16 * C.wp[c]) + 8 + (C.qw[c] / 4) * (8 + 64) + 16 + 8;
     n += 8 + 32 * (size_t)C.L;                                   // commit_phase_commits
     size_t perq = 8;                                             // commit_phase_openings
     for (int l = 0; l < C.L; l++) perq += 16 + 8 + 32 * ((size_t)C.Hmax - 1 - l);
@@ -164,7 +166,7 @@ size_t chips_bincode_bytes(const ChipsLayout& C) {
         return any ? r + 8 + 32 * (size_t)height : 0;
     };
     perq_open += round([&](uint32_t c) { return (size_t)C.pw[c]; }, C.He) + round([&](uint32_t c) { return (size_t)C.widths[c]; }, C.Hmax) +
-                 round([&](uint32_t c) { return C.wp[c]; }, C.Hp) + round([&](uint32_t) { return (size_t)8; }, C.Hmax);
+                 round([&](uint32_t c) { return C.wp[c]; }, C.Hp) + round([&](uint32_t c) { return (size_t)C.qw[c]; }, C.Hmax);
     n += 8 + (size_t)C.Q * perq_open;
     n += 8 + 4 * (size_t)C.n_public;
     return n;
@@ -336,8 +338,8 @@ int zkhip_chips_proof_to_bincode(const uint8_t* proof, size_t len, const uint32_
         for (int k = 0; k < 2; k++) { w.vec_ext(pf + p, C.pw[c]); p += 4 * (size_t)C.pw[c]; }
         for (int k = 0; k < 2; k++) { w.vec_ext(pf + p, C.widths[c]); p += 4 * (size_t)C.widths[c]; }
         for (int k = 0; k < 2; k++) { w.vec_ext(pf + p, C.wp[c]); p += 4 * C.wp[c]; }
-        w.u64(2);
-        for (int k = 0; k < 2; k++) { w.vec_ext(pf + p, 4); p += 16; }
+        w.u64(C.qw[c] / 4);
+        for (uint32_t k = 0; k < C.qw[c] / 4; k++) { w.vec_ext(pf + p, 4); p += 16; }
         w.words(sums[c] ? sums[c] : zero4, 4);
         w.u64((uint64_t)C.log_ns[c]);
     }
@@ -346,7 +348,7 @@ int zkhip_chips_proof_to_bincode(const uint8_t* proof, size_t len, const uint32_
     const uint32_t witness = pf[p++];
     const size_t q0 = p;
     size_t perq = 16 * (size_t)C.Hmax + 8 * (size_t)C.Hp + 8 * (size_t)C.He, fri_per = 0;
-    for (uint32_t c = 0; c < C.n; c++) perq += C.pw[c] + C.widths[c] + C.wp[c] + 8;
+    for (uint32_t c = 0; c < C.n; c++) perq += C.pw[c] + C.widths[c] + C.wp[c] + C.qw[c];
     for (int l = 0; l < C.L; l++) fri_per += 4 + 8 * ((size_t)C.Hmax - 1 - l);
     const size_t open_per = perq;
     perq += fri_per;
@@ -377,7 +379,7 @@ int zkhip_chips_proof_to_bincode(const uint8_t* proof, size_t len, const uint32_
         round([&](uint32_t c) { return (size_t)C.pw[c]; }, C.He);
         round([&](uint32_t c) { return (size_t)C.widths[c]; }, C.Hmax);
         round([&](uint32_t c) { return C.wp[c]; }, C.Hp);
-        round([&](uint32_t) { return (size_t)8; }, C.Hmax);
+        round([&](uint32_t c) { return (size_t)C.qw[c]; }, C.Hmax);
     }
     w.u64(n_public);
     w.words(public_values, n_public);
@@ -420,7 +422,8 @@ int zkhip_chips_proof_from_bincode(const uint8_t* in, size_t len, uint8_t* proof
     size_t sum_slot = sums_at;
     for (uint32_t c = 0; c < C.n && r.ok; c++) {
         vec_ext(C.pw[c]); vec_ext(C.pw[c]); vec_ext(C.widths[c]); vec_ext(C.widths[c]); vec_ext(C.wp[c]); vec_ext(C.wp[c]);
-        r.expect_len(2); vec_ext(4); vec_ext(4);
+        r.expect_len(C.qw[c] / 4);
+        for (uint32_t k = 0; k < C.qw[c] / 4; k++) vec_ext(4);
         uint32_t sum[4];
         r.words(sum, 4);
         if (C.cross && C.wp[c]) { std::memcpy(pf + sum_slot, sum, 16); sum_slot += 4; }
@@ -432,7 +435,7 @@ int zkhip_chips_proof_from_bincode(const uint8_t* in, size_t len, uint8_t* proof
     const size_t witness_at = p; p += 1;
     const size_t q0 = p;
     size_t open_per = 16 * (size_t)C.Hmax + 8 * (size_t)C.Hp + 8 * (size_t)C.He, fri_per = 0;
-    for (uint32_t c = 0; c < C.n; c++) open_per += C.pw[c] + C.widths[c] + C.wp[c] + 8;
+    for (uint32_t c = 0; c < C.n; c++) open_per += C.pw[c] + C.widths[c] + C.wp[c] + C.qw[c];
     for (int l = 0; l < C.L; l++) fri_per += 4 + 8 * ((size_t)C.Hmax - 1 - l);
     const size_t perq = open_per + fri_per;
     r.expect_len(C.Q);
@@ -458,7 +461,7 @@ int zkhip_chips_proof_from_bincode(const uint8_t* in, size_t len, uint8_t* proof
         round([&](uint32_t c) { return (size_t)C.pw[c]; }, C.He);
         round([&](uint32_t c) { return (size_t)C.widths[c]; }, C.Hmax);
         round([&](uint32_t c) { return C.wp[c]; }, C.Hp);
-        round([&](uint32_t) { return (size_t)8; }, C.Hmax);
+        round([&](uint32_t c) { return (size_t)C.qw[c]; }, C.Hmax);
     }
     r.expect_len(C.n_public);
     if (C.n_public) r.words(public_values, C.n_public);

@@ -968,12 +968,12 @@ hipError_t launch_perm_trace_machine(const MachinePermArgs& a, uint32_t* block_s
     return hipGetLastError();
 }
 __global__ void __launch_bounds__(256) lookup_addend_kernel(MachineQuotArgs a) {
-    const int H = a.log_n + 1;
+    const int H = a.log_n + a.log_qd;
     const uint32_t m = 1u << H;
     const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
     if (p >= m) return;
     const uint32_t e = __brev(p) >> (32 - H);
-    const uint32_t pn = __brev((e + 2u) & (m - 1)) >> (32 - H);
+    const uint32_t pn = __brev((e + (1u << a.log_qd)) & (m - 1)) >> (32 - H);
     const uint32_t* row = a.lde + (uint64_t)p * a.ld;
     const uint32_t* prow = a.perm + (uint64_t)p * a.perm_ld;
     const uint32_t* pnrow = a.perm + (uint64_t)pn * a.perm_ld;
@@ -1005,7 +1005,7 @@ __global__ void __launch_bounds__(256) lookup_addend_kernel(MachineQuotArgs a) {
     st_ext(a.addend + 4 * (uint64_t)p, r);
 }
 hipError_t launch_lookup_addend(const MachineQuotArgs& a, hipStream_t s) {
-    const uint64_t m = 2ull << a.log_n;
+    const uint64_t m = 1ull << (a.log_n + a.log_qd);
     hipLaunchKernelGGL(lookup_addend_kernel, dim3((unsigned)((m + 255) / 256)), dim3(256), 0, s, a);
     return hipGetLastError();
 }

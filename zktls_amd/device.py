@@ -472,7 +472,7 @@ class Context:
         return buf[: got.value]
 
     def prove_chips_air(self, chips, programs, public_values=(), params=None):
-        """chips: [(device buffer, log_n, width), ...] tallest first; programs[c]: a constraint program (numpy u32 words, degree <= 3)
+        """chips: [(device buffer, log_n, width), ...] tallest first; programs[c]: a constraint program (numpy u32 words; degree 4 / 5 needs log_blowup >= 2)
         or None for the built-in synthetic AIR -- several different AIR tables in one proof (version 9)"""
         params = params or Params(1, 100, 16, 0)
         n = len(chips)
