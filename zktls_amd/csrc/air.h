@@ -13,6 +13,12 @@
 //   K x { selector (0 every row, 1 first row, 2 last row, 3 transition), n_terms, n_terms x { coeff, degree d <= 5, d variables } }
 //   variable = kind << 30 | index;  kind 0 local row, 1 next row, 2 public value.  A selector counts one degree.
 #pragma once
+#include <algorithm>
+#include <array>
+#include <cstring>
+#include <map>
+#include <memory>
+#include <mutex>
 #include <vector>
 
 #include "babybear.cuh"
@@ -112,33 +118,83 @@ inline void air_device_image(const AirView& a, const Ext& alpha, std::vector<uin
 // 2W+4+i public value i.  Record = 8 words: coefficient (4), off0 | off1 << 16, off2 | off3 << 16, off4 | nvars << 16, 0; nvars in
 // [1, 5] (a constant term reads the slot of 1).  Sorted by nvars, so that the lanes of a wavefront run the same number of products.
 inline uint32_t air_slots(const AirView& a) { return 2 * a.width + AIR_SLOT_EXTRA + a.n_public; }
-inline void air_term_records(const AirView& a, const Ext& alpha, std::vector<uint32_t>& recs, const Ext& scale = ext_one()) {
-    std::vector<Ext> wts(a.K);
-    Ext w = scale;
-    for (size_t k = a.K; k-- > 0;) { wts[k] = w; w = ext_mul(w, alpha); }
-    std::vector<std::vector<uint32_t>> by_n[6];
+// Terms with the SAME monomial (the same factors, selector included) are merged: their weighted coefficients add up, the flat sum is
+// the same field element.  Real chips repeat monomials across constraints -- the S-box output x3 x3 y of the Poseidon2 chip enters all
+// sixteen elements of the next state: 6 130 terms, 1 008 monomials; the SHA-256 chip: 5 900 terms, 3 366 -- and a record costs the same
+// whatever its coefficient.  Which terms share a monomial depends on the program alone, so that plan is built once per program
+// (kept by content) and a proof only adds up weighted coefficients.
+struct AirTermPlan {
+    std::vector<std::array<uint32_t, 6>> monomials;    // n, then the n slot offsets in ascending order; sorted (by n first)
+    struct Src { uint32_t monomial, constraint, coeff_monty; };
+    std::vector<Src> terms;                            // every term of the program, in program order
+};
+inline std::shared_ptr<const AirTermPlan> air_term_plan(const AirView& a) {
+    struct Entry { uint64_t hash; size_t words; std::vector<uint32_t> prog; std::shared_ptr<const AirTermPlan> plan; };
+    static std::mutex mu;
+    static std::vector<Entry> cache;                   // a handful of programs per process; newest last
+    uint64_t h = 1469598103934665603ull;
+    for (size_t i = 0; i < a.words; i++) h = (h ^ a.w[i]) * 1099511628211ull;
+    {
+        std::lock_guard<std::mutex> lk(mu);
+        for (const Entry& e : cache)
+            if (e.hash == h && e.words == a.words && std::memcmp(e.prog.data(), a.w, a.words * 4) == 0) return e.plan;
+    }
+    auto plan = std::make_shared<AirTermPlan>();
+    std::map<std::array<uint32_t, 6>, uint32_t> index;
+    std::vector<std::array<uint32_t, 6>> keys;
     size_t p = 6;
     const uint32_t W = a.width;
     for (uint32_t k = 0; k < a.K; k++) {
         const uint32_t sel = a.w[p++], nt = a.w[p++];
         for (uint32_t t = 0; t < nt; t++) {
-            const Ext c = ext_mul_base(wts[k], to_monty(a.w[p++]));
-            const uint32_t d = a.w[p++];
-            uint32_t off[5] = {0, 0, 0, 0, 0}, n = 0;
+            const uint32_t coeff = to_monty(a.w[p++]), d = a.w[p++];
+            std::array<uint32_t, 6> key = {0, 0, 0, 0, 0, 0};
+            uint32_t n = 0;
             for (uint32_t j = 0; j < d; j++) {
                 const uint32_t v = a.w[p++], kind = v >> 30, idx = v & 0xFFFFu;
-                off[n++] = kind == 0 ? idx : (kind == 1 ? W + idx : 2 * W + AIR_SLOT_EXTRA + idx);
+                key[1 + n++] = kind == 0 ? idx : (kind == 1 ? W + idx : 2 * W + AIR_SLOT_EXTRA + idx);
             }
-            if (sel) off[n++] = 2 * W + (sel - 1);
-            if (n == 0) off[n++] = 2 * W + 3;
-            by_n[n].push_back({c.c[0], c.c[1], c.c[2], c.c[3], off[0] | off[1] << 16, off[2] | off[3] << 16, off[4] | n << 16, 0u});
+            if (sel) key[1 + n++] = 2 * W + (sel - 1);
+            if (n == 0) key[1 + n++] = 2 * W + 3;
+            std::sort(key.begin() + 1, key.begin() + 1 + n);
+            key[0] = n;
+            auto it = index.find(key);
+            if (it == index.end()) { it = index.emplace(key, (uint32_t)keys.size()).first; keys.push_back(key); }
+            plan->terms.push_back(AirTermPlan::Src{it->second, k, coeff});
         }
     }
-    recs.clear();
-    for (int n = 1; n <= 5; n++) for (const auto& r : by_n[n]) recs.insert(recs.end(), r.begin(), r.end());
-    if ((recs.size() / 8) & 1) {                 // the kernel takes terms in pairs: pad with 0 * (the constant 1)
-        const uint32_t pad[8] = {0, 0, 0, 0, 2 * W + 3, 0, 1u << 16, 0};
-        recs.insert(recs.end(), pad, pad + 8);
+    // records in sorted key order (by n first: the lanes of a wavefront run the same number of products)
+    std::vector<uint32_t> order(keys.size()), rank(keys.size());
+    for (uint32_t i = 0; i < order.size(); i++) order[i] = i;
+    std::sort(order.begin(), order.end(), [&](uint32_t x, uint32_t y) { return keys[x] < keys[y]; });
+    for (uint32_t r = 0; r < order.size(); r++) { rank[order[r]] = r; plan->monomials.push_back(keys[order[r]]); }
+    for (AirTermPlan::Src& t : plan->terms) t.monomial = rank[t.monomial];
+    std::lock_guard<std::mutex> lk(mu);
+    if (cache.size() >= 32) cache.erase(cache.begin());
+    cache.push_back(Entry{h, a.words, std::vector<uint32_t>(a.w, a.w + a.words), plan});
+    return plan;
+}
+inline void air_term_records(const AirView& a, const Ext& alpha, std::vector<uint32_t>& recs, const Ext& scale = ext_one()) {
+    std::vector<Ext> wts(a.K);
+    Ext w = scale;
+    for (size_t k = a.K; k-- > 0;) { wts[k] = w; w = ext_mul(w, alpha); }
+    const std::shared_ptr<const AirTermPlan> plan = air_term_plan(a);
+    const uint32_t W = a.width;
+    const size_t nm = plan->monomials.size();
+    recs.assign((nm + (nm & 1)) * 8, 0u);
+    for (size_t m = 0; m < nm; m++) {
+        const std::array<uint32_t, 6>& k = plan->monomials[m];
+        uint32_t* r = recs.data() + 8 * m;
+        r[4] = k[1] | k[2] << 16; r[5] = k[3] | k[4] << 16; r[6] = k[5] | k[0] << 16;
+    }
+    for (const AirTermPlan::Src& t : plan->terms) {
+        uint32_t* r = recs.data() + 8 * (size_t)t.monomial;
+        const Ext c = ext_mul_base(wts[t.constraint], t.coeff_monty);
+        for (int i = 0; i < 4; i++) r[i] = fadd(r[i], c.c[i]);
+    }
+    if (nm & 1) {                                // the kernel takes terms in pairs: pad with 0 * (the constant 1)
+        uint32_t* r = recs.data() + 8 * nm;
+        r[4] = 2 * W + 3; r[6] = 1u << 16;
     }
 }
 
