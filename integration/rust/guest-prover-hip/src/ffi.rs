@@ -132,6 +132,31 @@ extern "C" {
         proof: *mut u8, cap: usize, len: *mut usize,
     ) -> c_int;
     pub fn zkhip_verify_sha256_machine(proof: *const u8, len: usize, digest: *const u8, vk: *const u32, prm: *const ZkhipParams, reason: *mut c_int) -> c_int;
+    // a batch of transcripts in one call (BASELINE configs[2]): job i on devices[i mod n], pooled contexts keep their proving key
+    pub fn zkhip_prove_transcripts(
+        devices: *const c_int, n_devices: c_int, jobs: *mut ZkhipTranscriptJob, n_jobs: c_int, prm: *const ZkhipParams,
+        in_flight_per_device: c_int, vk: *mut u32,
+    ) -> c_int;
+    // the Poseidon2 permutation chip: Merkle openings (of whole rows when row_width > 0) proven in-circuit
+    pub fn zkhip_p2chip_air(program: *mut u32, cap_words: usize) -> usize;
+    pub fn zkhip_merkle_paths_proof_size(n_paths: usize, depth: c_int, row_width: u32, prm: *const ZkhipParams) -> usize;
+    pub fn zkhip_prove_merkle_paths(
+        ctx: *mut ZkhipCtx, leaves: *const u32, row_width: u32, siblings: *const u32, indices: *const u32, n_paths: usize, depth: c_int,
+        root: *const u32, prm: *const ZkhipParams, proof: *mut u8, cap: usize, len: *mut usize,
+    ) -> c_int;
+    pub fn zkhip_verify_merkle_paths(proof: *const u8, len: usize, root: *const u32, n_paths: usize, prm: *const ZkhipParams, reason: *mut c_int) -> c_int;
+}
+
+/// one transcript of a batch (zkhip_transcript_job)
+#[repr(C)]
+pub struct ZkhipTranscriptJob {
+    pub message: *const u8,
+    pub message_len: usize,
+    pub digest: [u8; 32],
+    pub proof: *mut u8,
+    pub proof_cap: usize,
+    pub proof_len: usize,
+    pub status: i32,
 }
 
 /// opaque proving key of a keyed machine (zkhip_machine_key)
