@@ -515,6 +515,8 @@ int zkhip_verify_sha256_machine(const uint8_t* proof, size_t len, const uint8_t 
  * as the keyed SHA-256 machine: job i runs on devices[i mod n_devices] (NULL / 0: every visible device), `in_flight_per_device` at a time per
  * device, on pooled contexts that keep their proving key between calls (setup once per context).  Messages are host bytes; every job
  * reports its digest, proof length and status; vk receives the verifying key all proofs check against (zkhip_verify_sha256_machine).
+ * verify != 0: every proof is also checked against the key on its worker's host thread before the job reports success, as the reference
+ * verifies right after proving (sp1.rs:120) -- the check overlaps with the other workers' GPU work.
  * proof_cap >= zkhip_sha256_machine_proof_size(message_len, prm).  Returns ZKHIP_OK or the status of the lowest failing job. */
 typedef struct zkhip_transcript_job {
     const uint8_t* message;         /* host */
@@ -526,7 +528,7 @@ typedef struct zkhip_transcript_job {
     int32_t status;                 /* out */
 } zkhip_transcript_job;
 int zkhip_prove_transcripts(const int* devices, int n_devices, zkhip_transcript_job* jobs, int n_jobs, const zkhip_params* prm,
-                            int in_flight_per_device, uint32_t vk[8]);
+                            int in_flight_per_device, int verify, uint32_t vk[8]);
 
 /* A second real chip: the width-16 Poseidon2 permutation with Merkle-path chaining -- what a recursion machine (a STARK verifier proven
  * inside a STARK: the compress / shrink / wrap stages behind SP1ProofMode::Groth16, crates/guest-prover-sp1/src/sp1.rs:116; sp1-recursion's

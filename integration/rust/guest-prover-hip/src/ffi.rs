@@ -135,7 +135,7 @@ extern "C" {
     // a batch of transcripts in one call (BASELINE configs[2]): job i on devices[i mod n], pooled contexts keep their proving key
     pub fn zkhip_prove_transcripts(
         devices: *const c_int, n_devices: c_int, jobs: *mut ZkhipTranscriptJob, n_jobs: c_int, prm: *const ZkhipParams,
-        in_flight_per_device: c_int, vk: *mut u32,
+        in_flight_per_device: c_int, verify: c_int, vk: *mut u32,
     ) -> c_int;
     // the Poseidon2 permutation chip: Merkle openings (of whole rows when row_width > 0) proven in-circuit
     pub fn zkhip_p2chip_air(program: *mut u32, cap_words: usize) -> usize;

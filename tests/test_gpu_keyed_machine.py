@@ -190,7 +190,7 @@ def test_a_batch_of_transcripts_in_one_call(ctx, oracle):
         if i == 0:
             assert vk.tolist() == oracle.machine_setup(pre, [t.shape[0].bit_length() - 1 for t in tr], oprm).tolist()
     t0 = time.perf_counter()
-    vk2, res2 = prove_transcripts(msgs, prm, devices=[0], in_flight=4)
+    vk2, res2 = prove_transcripts(msgs, prm, devices=[0], in_flight=4, verify=True)       # each proof checked inside the call, as sp1.rs:120
     dt = time.perf_counter() - t0
     assert vk2.tolist() == vk.tolist() and all(a[1].tobytes() == b[1].tobytes() for a, b in zip(res, res2))
     print("64 transcripts, second call: %.1f ms" % (dt * 1e3))

@@ -146,8 +146,8 @@ def test_transcript_batch_without_a_gpu_fails_loudly():
         j.message = msg.ctypes.data_as(lib_mod.u8p); j.message_len = msg.size; j.proof = buf.ctypes.data_as(lib_mod.u8p); j.proof_cap = 16
     vk = (C.c_uint32 * 8)()
     prm = Params(1, 10, 4)
-    assert L.zkhip_prove_transcripts(None, 0, jobs, 2, C.byref(prm), 4, vk) == -2           # ZKHIP_ERR_NO_DEVICE
+    assert L.zkhip_prove_transcripts(None, 0, jobs, 2, C.byref(prm), 4, 1, vk) == -2        # ZKHIP_ERR_NO_DEVICE
     assert [j.status for j in jobs] == [-2, -2] and all(j.proof_len == 0 for j in jobs)
-    assert L.zkhip_prove_transcripts(None, 0, jobs, 0, C.byref(prm), 4, vk) == 0              # an empty batch is fine anywhere
-    assert L.zkhip_prove_transcripts(None, 3, jobs, 2, C.byref(prm), 4, vk) == -1             # NULL device list with a count
-    assert L.zkhip_prove_transcripts((C.c_int * 2)(0, 0), 2, jobs, 2, C.byref(prm), 4, vk) == -1   # a device listed twice
+    assert L.zkhip_prove_transcripts(None, 0, jobs, 0, C.byref(prm), 4, 0, vk) == 0           # an empty batch is fine anywhere
+    assert L.zkhip_prove_transcripts(None, 3, jobs, 2, C.byref(prm), 4, 0, vk) == -1          # NULL device list with a count
+    assert L.zkhip_prove_transcripts((C.c_int * 2)(0, 0), 2, jobs, 2, C.byref(prm), 4, 0, vk) == -1   # a device listed twice

@@ -195,7 +195,7 @@ def load():
     L.zkhip_chips_bincode_size.argtypes = [u8p, C.c_size_t]
     L.zkhip_chips_proof_to_bincode.argtypes = [u8p, C.c_size_t, u32p, C.c_size_t, u8p, C.c_size_t, szp]
     L.zkhip_chips_proof_from_bincode.argtypes = [u8p, C.c_size_t, u8p, C.c_size_t, szp, u32p, C.c_size_t, szp]
-    L.zkhip_prove_transcripts.argtypes = [C.POINTER(C.c_int), C.c_int, C.POINTER(TranscriptJob), C.c_int, C.POINTER(Params), C.c_int, u32p]
+    L.zkhip_prove_transcripts.argtypes = [C.POINTER(C.c_int), C.c_int, C.POINTER(TranscriptJob), C.c_int, C.POINTER(Params), C.c_int, C.c_int, u32p]
     L.zkhip_p2chip_air.restype = C.c_size_t
     L.zkhip_p2chip_air.argtypes = [u32p, C.c_size_t]
     L.zkhip_p2chip_gen_merkle_trace.argtypes = [C.c_void_p, u32p, C.c_uint32, u32p, u32p, C.c_size_t, C.c_int, C.c_int, C.c_void_p, C.c_size_t, u32p]

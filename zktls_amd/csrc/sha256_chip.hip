@@ -632,7 +632,7 @@ int zkhip_verify_sha256_machine(const uint8_t* proof, size_t len, const uint8_t 
 // proving key (setup runs once per context and proof shape; every context arrives at the same vk).  Per job: padding, trace generation
 // and the range table's multiplicities on the device, the keyed machine's proof into the job's host buffer, the digest.
 int zkhip_prove_transcripts(const int* devices, int n_devices, zkhip_transcript_job* jobs, int n_jobs, const zkhip_params* prm,
-                            int in_flight_per_device, uint32_t vk[8]) {
+                            int in_flight_per_device, int verify, uint32_t vk[8]) {
     if (!jobs || n_jobs < 0 || !prm || !vk) return fail(ZKHIP_ERR_INVALID, "prove_transcripts: bad arguments");
     for (int i = 0; i < n_jobs; i++) { jobs[i].status = ZKHIP_ERR_INVALID; jobs[i].proof_len = 0; }
     std::vector<int> devs;
@@ -661,6 +661,8 @@ int zkhip_prove_transcripts(const int* devices, int n_devices, zkhip_transcript_
         }
         size_t len = 0;
         if (r == ZKHIP_OK) r = zkhip_prove_sha256_machine(ctx, ctx->sha_key, j.message, j.message_len, prm, j.digest, j.proof, j.proof_cap, &len);
+        // the reference checks every proof right after proving it (sp1.rs:120): on this worker's host thread, while the GPU runs the other workers' proofs
+        if (r == ZKHIP_OK && verify) r = zkhip_verify_sha256_machine(j.proof, len, j.digest, ctx->sha_vk, prm, nullptr);
         j.status = r;
         j.proof_len = r == ZKHIP_OK ? len : 0;
         return r;

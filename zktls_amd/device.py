@@ -692,9 +692,9 @@ def verify_sha256(proof, digest, params=None):
     return rc, reason.value
 
 
-def prove_transcripts(messages, params=None, devices=None, in_flight=4):
-    """zkhip_prove_transcripts: every message proven as the keyed SHA-256 machine in one call, dealt over `devices` (None: all visible)
-    -> (vk, [(digest bytes, proof bytes), ...])"""
+def prove_transcripts(messages, params=None, devices=None, in_flight=4, verify=False):
+    """zkhip_prove_transcripts: every message proven as the keyed SHA-256 machine in one call, dealt over `devices` (None: all visible);
+    verify: each proof is checked against the key inside the call -> (vk, [(digest bytes, proof bytes), ...])"""
     lib = _lib.load()
     params = params or Params(1, 100, 16)
     n = len(messages)
@@ -709,7 +709,7 @@ def prove_transcripts(messages, params=None, devices=None, in_flight=4):
         jobs[i].proof = buf.ctypes.data_as(u8p); jobs[i].proof_cap = size
     vk = np.zeros(8, dtype=np.uint32)
     devs = (C.c_int * len(devices))(*devices) if devices else None
-    check(lib.zkhip_prove_transcripts(devs, len(devices) if devices else 0, jobs, n, C.byref(params), in_flight, vk.ctypes.data_as(u32p)))
+    check(lib.zkhip_prove_transcripts(devs, len(devices) if devices else 0, jobs, n, C.byref(params), in_flight, 1 if verify else 0, vk.ctypes.data_as(u32p)))
     return vk, [(bytes(jobs[i].digest), keep[i][1][: jobs[i].proof_len]) for i in range(n)]
 
 
