@@ -499,6 +499,25 @@ int zkhip_verify_machine_keyed(const uint8_t* proof, size_t len, const int32_t* 
                                const size_t* table_words, int n_chips, const uint32_t* public_values, size_t n_public, const zkhip_params* prm,
                                int* reason);
 
+/* A message of ANY length as a CHAIN of shard proofs -- the reference's large-transcript configuration (BASELINE.json configs[3]: a
+ * megabyte-scale response body, 1 -> 8 GPUs) with a real statement per shard.  The chained program (zkhip_sha256_air_chained) is the chip
+ * with its initial chaining value PUBLIC as well: 32 public values = the final chaining value's 16 limbs, then the initial one's.  Shard s
+ * covers blocks [s 2^k, (s + 1) 2^k) of the padded message and proves chain[s] -> chain[s + 1]; chain[0] is the standard initial value,
+ * chain[n_shards] the digest.  The chaining values come from one pass of plain compression on the host, after which the shards are
+ * independent: zkhip_prove_sha256_sharded deals them over the devices (shard s on devices[s mod n], in_flight_per_device at a time) like
+ * zkhip_prove_shards_multi.  chain: (n_shards + 1) x 8 words out; proofs: n_shards x proof_stride bytes (proof_stride >=
+ * zkhip_sha256_shard_proof_size(k, prm)), proof_lens[s] out.  zkhip_verify_sha256_sharded checks the whole chain on the host (bad_shard /
+ * reason name the first failing shard).  zkhip_sha256_gen_trace_chained = zkhip_sha256_gen_trace from a given chaining value. */
+size_t zkhip_sha256_air_chained(uint32_t* program, size_t cap_words);
+int zkhip_sha256_gen_trace_chained(zkhip_ctx* ctx, const uint32_t chain_in[8], const uint8_t* blocks, size_t n_active, size_t n_blocks, uint32_t* d_trace,
+                                   size_t ld, uint32_t digest_limbs[16]);
+size_t zkhip_sha256_sharded_count(size_t message_len, int log_blocks_per_shard);
+size_t zkhip_sha256_shard_proof_size(int log_blocks, const zkhip_params* prm);
+int zkhip_prove_sha256_sharded(const int* devices, int n_devices, const uint8_t* message, size_t message_len, int log_blocks_per_shard, const zkhip_params* prm,
+                               int in_flight_per_device, uint8_t digest[32], uint32_t* chain, uint8_t* proofs, size_t proof_stride, size_t* proof_lens);
+int zkhip_verify_sha256_sharded(const uint8_t* proofs, size_t proof_stride, const size_t* proof_lens, size_t n_shards, const uint32_t* chain,
+                                int log_blocks_per_shard, const uint8_t digest[32], const zkhip_params* prm, size_t* bad_shard, int* reason);
+
 /* The SHA-256 guest as a keyed machine: setup once, then one proof per message -- the reference's setup -> prove -> verify
  * (sp1.rs:113, :116, :120) on this repo's stand-in guest.  Two chips: the SHA-256 compression chip (zkhip_sha256_air, 608 columns) and a
  * 2^16-row range table that receives the four 16-bit limbs per row the chip's own constraints do not range-check (the OUT limbs of d and

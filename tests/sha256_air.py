@@ -97,7 +97,9 @@ def _xor2(x, y):
     return [(1, [x]), (1, [y]), (P - 2, [x, y])]
 
 
-def program():
+def program(chained=False):
+    """chained: the chaining value of the first row is PUBLIC too (32 public values: final limbs, then initial limbs) instead of the
+    standard initial value -- a shard of a longer message"""
     cons = []
     s63 = V(SEL + 63)
     # round selector: s_0 = 1 on the first row, cyclic shift on transitions
@@ -162,7 +164,10 @@ def program():
     # first row: the IV; last row: the public digest
     for w, (kind, base) in enumerate(WORDS):
         for l in range(2):
-            cons.append((O.SEL_FIRST, _limb(kind, base, l) + [((P - ((IV[w] >> (16 * l)) & 0xffff)) % P, [])]))
+            if chained:
+                cons.append((O.SEL_FIRST, _limb(kind, base, l) + [(P - 1, [V(16 + 2 * w + l, public=True)])]))
+            else:
+                cons.append((O.SEL_FIRST, _limb(kind, base, l) + [((P - ((IV[w] >> (16 * l)) & 0xffff)) % P, [])]))
     for i in range(16):
         cons.append((O.SEL_LAST, [(1, [V(OUT + i)]), (P - 1, [V(i, public=True)])]))
     # message schedule window: shifts and the recurrence, both off in round 63 (the next block brings its own 16 words)
@@ -178,7 +183,7 @@ def program():
         if l == 1:
             terms += [((P - (1 << k)) % P, [V(CY_SCHED + k)]) for k in range(2)]
         cons.append((O.SEL_TRANSITION, gated(terms)))
-    return O.air_program(WIDTH, N_PUBLIC, cons)
+    return O.air_program(WIDTH, 2 * N_PUBLIC if chained else N_PUBLIC, cons)
 
 
 def _rotr(x, r):
@@ -192,7 +197,7 @@ def pad(message):
     return m
 
 
-def trace(blocks, total_blocks=None):
+def trace(blocks, total_blocks=None, chain_in=None):
     """blocks: bytes, a multiple of 64 long (the message's blocks); total_blocks: a power of two >= their number (default: the
     next one), the rest are inactive all-zero blocks -> (trace [64 total_blocks][608] canonical, public values [16])"""
     assert len(blocks) % 64 == 0 and len(blocks) > 0
@@ -201,7 +206,7 @@ def trace(blocks, total_blocks=None):
     assert nb & (nb - 1) == 0 and nb >= active
     blocks = bytes(blocks) + bytes(64 * (nb - active))
     t = np.zeros((64 * nb, WIDTH), dtype=np.uint32)
-    h = list(IV)
+    h = list(chain_in) if chain_in is not None else list(IV)
 
     def bits(row, base, x):
         t[row, base:base + 32] = [(x >> i) & 1 for i in range(32)]

@@ -120,3 +120,51 @@ def test_large_messages_bytes_equal_the_oracles(ctx, oracle, kib):
         assert proof.tobytes() == O.prove_shard_air(S.program(), t, limbs.tolist(), O.default_params(1, 20, 4)).tobytes()
     finally:
         O.set_threads(prev)
+
+
+# ---- a message of any length as a chain of shard proofs (zkhip_prove_sha256_sharded)
+def test_sharded_proofs_bytes_equal_the_oracles(ctx, oracle):
+    """1 000 bytes in shards of 4 blocks: 16 blocks with padding -> 4 shards; every shard's proof equals the oracle's proof of the Python
+    restatement's trace from the same chaining value; the chain verifies; digest against hashlib"""
+    from zktls_amd.device import prove_sha256_sharded, verify_sha256_sharded
+    O = oracle
+    msg = bytes((7 * i + 3) & 0xff for i in range(1000))
+    prm, oprm = Params(1, 8, 4), O.default_params(1, 8, 4)
+    res = prove_sha256_sharded(msg, 2, prm, devices=[0], in_flight=2)
+    assert res.digest == hashlib.sha256(msg).digest() and len(res.proofs) == 4
+    assert (res.chain[0] == np.array(S.IV, dtype=np.uint32)).all()
+    assert verify_sha256_sharded(res, params=prm) == (0, 0, 0)
+    blocks = S.pad(msg)
+    prog = S.program(chained=True)
+    for s, proof in enumerate(res.proofs):
+        t, out = S.trace(blocks[256 * s:256 * (s + 1)], chain_in=[int(v) for v in res.chain[s]])
+        pin = []
+        for x in res.chain[s]:
+            pin += [int(x) & 0xffff, int(x) >> 16]
+        assert [int(out[2 * k] | (out[2 * k + 1] << 16)) for k in range(8)] == [int(v) for v in res.chain[s + 1]]
+        assert proof.tobytes() == O.prove_shard_air(prog, t, out + pin, oprm).tobytes(), s
+    # another digest, a swapped pair of shards, a shard from another message
+    assert verify_sha256_sharded(res, digest=hashlib.sha256(b"other").digest(), params=prm)[0] == -6
+    swapped = res.buf.copy()
+    swapped[:res.stride], swapped[res.stride:2 * res.stride] = res.buf[res.stride:2 * res.stride], res.buf[:res.stride]
+    assert verify_sha256_sharded(res, params=prm, proofs=swapped)[:2] == (-6, 0)
+    res2 = prove_sha256_sharded(msg[:-1] + b"!", 2, prm, devices=[0], in_flight=2)
+    mixed = res.buf.copy()
+    mixed[3 * res.stride:] = res2.buf[3 * res.stride:]
+    assert verify_sha256_sharded(res, params=prm, proofs=mixed)[:2] == (-6, 3)
+
+
+def test_a_three_megabyte_body_as_a_chain_of_shards(ctx):
+    """BASELINE configs[3] with a real statement: a 3 MiB body = 49 153 blocks -> three shards of 2^14 blocks (2^20 rows x 608 each) and a
+    one-block shard; digest against hashlib, the chain accepted by the host verifier; a corrupted shard is named"""
+    from zktls_amd.device import prove_sha256_sharded, verify_sha256_sharded
+    msg = np.random.default_rng(9).integers(0, 256, 3 << 20, dtype=np.uint8).tobytes()
+    prm = Params(1, 30, 8)
+    res = prove_sha256_sharded(msg, 14, prm, devices=[0], in_flight=2)
+    assert res.digest == hashlib.sha256(msg).digest() and len(res.proofs) == 4
+    heights = [int(np.frombuffer(p[8:12].tobytes(), dtype=np.uint32)[0]) for p in res.proofs]
+    assert heights == [20, 20, 20, 6]
+    assert verify_sha256_sharded(res, params=prm) == (0, 0, 0)
+    bad = res.buf.copy()
+    bad[2 * res.stride + 5000] ^= 1
+    assert verify_sha256_sharded(res, params=prm, proofs=bad)[:2] == (-6, 2)

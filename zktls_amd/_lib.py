@@ -36,6 +36,8 @@ EXPORTS = [
     "zkhip_prove_shards_air_multi", "zkhip_selftest_host_simd", "zkhip_host_simd", "zkhip_machine_proof_size", "zkhip_prove_machine", "zkhip_verify_machine", "zkhip_range_table",
     "zkhip_machine_setup", "zkhip_machine_key_destroy", "zkhip_machine_proof_size_keyed", "zkhip_prove_machine_keyed", "zkhip_verify_machine_keyed", "zkhip_prove_machine_keyed_at",
     "zkhip_sha256_setup", "zkhip_sha256_machine_proof_size", "zkhip_prove_sha256_machine", "zkhip_verify_sha256_machine", "zkhip_prove_transcripts",
+    "zkhip_sha256_air_chained", "zkhip_sha256_gen_trace_chained", "zkhip_sha256_sharded_count", "zkhip_sha256_shard_proof_size", "zkhip_prove_sha256_sharded",
+    "zkhip_verify_sha256_sharded",
     "zkhip_p2chip_air", "zkhip_p2chip_gen_merkle_trace", "zkhip_merkle_paths_proof_size", "zkhip_prove_merkle_paths", "zkhip_verify_merkle_paths",
     "zkhip_sha256_air", "zkhip_sha256_digest", "zkhip_sha256_pad", "zkhip_sha256_gen_trace", "zkhip_sha256_proof_size", "zkhip_prove_sha256", "zkhip_verify_sha256",
 ]
@@ -203,6 +205,15 @@ def load():
     L.zkhip_merkle_paths_proof_size.argtypes = [C.c_size_t, C.c_int, C.c_uint32, C.POINTER(Params)]
     L.zkhip_prove_merkle_paths.argtypes = [C.c_void_p, u32p, C.c_uint32, u32p, u32p, C.c_size_t, C.c_int, u32p, C.POINTER(Params), u8p, C.c_size_t, szp]
     L.zkhip_verify_merkle_paths.argtypes = [u8p, C.c_size_t, u32p, C.c_size_t, C.POINTER(Params), C.POINTER(C.c_int)]
+    L.zkhip_sha256_air_chained.restype = C.c_size_t
+    L.zkhip_sha256_air_chained.argtypes = [u32p, C.c_size_t]
+    L.zkhip_sha256_gen_trace_chained.argtypes = [C.c_void_p, u32p, u8p, C.c_size_t, C.c_size_t, C.c_void_p, C.c_size_t, u32p]
+    L.zkhip_sha256_sharded_count.restype = C.c_size_t
+    L.zkhip_sha256_sharded_count.argtypes = [C.c_size_t, C.c_int]
+    L.zkhip_sha256_shard_proof_size.restype = C.c_size_t
+    L.zkhip_sha256_shard_proof_size.argtypes = [C.c_int, C.POINTER(Params)]
+    L.zkhip_prove_sha256_sharded.argtypes = [C.POINTER(C.c_int), C.c_int, u8p, C.c_size_t, C.c_int, C.POINTER(Params), C.c_int, u8p, u32p, u8p, C.c_size_t, szp]
+    L.zkhip_verify_sha256_sharded.argtypes = [u8p, C.c_size_t, szp, C.c_size_t, u32p, C.c_int, u8p, C.POINTER(Params), szp, C.POINTER(C.c_int)]
     L.zkhip_sha256_air.restype = C.c_size_t
     L.zkhip_sha256_air.argtypes = [u32p, C.c_size_t]
     L.zkhip_sha256_digest.restype = None

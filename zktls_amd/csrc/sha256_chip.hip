@@ -103,8 +103,10 @@ struct Builder {
 };
 enum : uint32_t { ALL = 0, FIRST = 1, LAST = 2, TRANSITION = 3 };
 
-static const std::vector<uint32_t>& program() {
-    static const std::vector<uint32_t> prog = [] {
+// chained = false: the chaining value of the first row is the standard IV (16 public values: the final chaining value's limbs);
+// chained = true: it is PUBLIC too (32 public values: final limbs, then initial limbs) -- a shard of a longer message
+static std::vector<uint32_t> build_program(bool chained) {
+    {
         const uint32_t* K = round_constants().k;
         const Word words[8] = {{true, A}, {true, B}, {true, C}, {false, D}, {true, E}, {true, F}, {true, G}, {false, HV}};   // a .. h
         auto xw = [](int j) { return j == 0 ? Word{true, X0} : (j == 13 ? Word{true, X13} : Word{false, xl(j)}); };
@@ -196,7 +198,8 @@ static const std::vector<uint32_t>& program() {
         for (int w = 0; w < 8; w++)
             for (int l = 0; l < 2; l++) {
                 Terms t = limb(words[w], l);
-                t.push_back(Term{neg((IV[w] >> (16 * l)) & 0xffffu), {}});
+                if (chained) t.push_back(Term{P - 1, {pub(16 + 2 * w + l)}});
+                else t.push_back(Term{neg((IV[w] >> (16 * l)) & 0xffffu), {}});
                 b.add(FIRST, t);
             }
         for (uint32_t i = 0; i < 16; i++) b.add(LAST, Terms{{1, {var(OUT + i)}}, {P - 1, {pub(i)}}});
@@ -219,12 +222,13 @@ static const std::vector<uint32_t>& program() {
             if (l == 1) for (uint32_t k = 0; k < 2; k++) t.push_back(Term{P - (1u << k), {var(CY_SCHED + k)}});
             b.add(TRANSITION, gated(t));
         }
-        std::vector<uint32_t> p{AIR_MAGIC, 1u, WIDTH, b.count, N_PUBLIC, (uint32_t)(6 + b.body.size())};
+        std::vector<uint32_t> p{AIR_MAGIC, 1u, WIDTH, b.count, chained ? 2 * N_PUBLIC : N_PUBLIC, (uint32_t)(6 + b.body.size())};
         p.insert(p.end(), b.body.begin(), b.body.end());
         return p;
-    }();
-    return prog;
+    }
 }
+static const std::vector<uint32_t>& program() { static const std::vector<uint32_t> prog = build_program(false); return prog; }
+static const std::vector<uint32_t>& program_chained() { static const std::vector<uint32_t> prog = build_program(true); return prog; }
 
 // ---- host side: padding and the chaining values the blocks start from ---------------------------------------------------
 static void compress(uint32_t h[8], const uint8_t* block) {
@@ -418,7 +422,12 @@ void zkhip_sha256_digest(const uint8_t* message, size_t len, uint8_t digest[32])
 
 int zkhip_sha256_gen_trace(zkhip_ctx* ctx, const uint8_t* blocks, size_t n_active, size_t n_blocks, uint32_t* d_trace, size_t ld,
                            uint32_t digest_limbs[16]) {
+    return zkhip_sha256_gen_trace_chained(ctx, sha::IV, blocks, n_active, n_blocks, d_trace, ld, digest_limbs);
+}
+int zkhip_sha256_gen_trace_chained(zkhip_ctx* ctx, const uint32_t chain_in[8], const uint8_t* blocks, size_t n_active, size_t n_blocks, uint32_t* d_trace,
+                                   size_t ld, uint32_t digest_limbs[16]) {
     CHECK_CTX(ctx);
+    if (!chain_in) return fail(ZKHIP_ERR_INVALID, "sha256_gen_trace: null chaining value");
     const int lb = log2_exact(n_blocks);
     if (!blocks || !d_trace || !digest_limbs || n_active == 0 || n_active > n_blocks || lb < 0 || lb + 6 > MAX_LOG_ROWS || ld < sha::WIDTH)
         return fail(ZKHIP_ERR_INVALID, "sha256_gen_trace: 1 <= n_active <= n_blocks = 2^k <= 2^16, ld >= 608");
@@ -426,7 +435,7 @@ int zkhip_sha256_gen_trace(zkhip_ctx* ctx, const uint8_t* blocks, size_t n_activ
     uint32_t* words = host.data();
     uint32_t* chain = host.data() + n_blocks * 16;
     uint32_t h[8];
-    std::memcpy(h, sha::IV, 32);
+    std::memcpy(h, chain_in, 32);
     for (size_t k = 0; k < n_blocks; k++) {
         std::memcpy(chain + 8 * k, h, 32);
         if (k < n_active) {
@@ -667,6 +676,113 @@ int zkhip_prove_transcripts(const int* devices, int n_devices, zkhip_transcript_
         j.proof_len = r == ZKHIP_OK ? len : 0;
         return r;
     }, ran);
+}
+
+// ---- a message of ANY length as a chain of shards (BASELINE configs[3]: a megabyte-scale transcript over several GPUs) ------------------
+// Shard s covers blocks [s 2^k, (s + 1) 2^k) of the padded message; its proof says "from chaining value c_s these blocks lead to c_{s+1}"
+// (the chained program: 32 public values).  c_0 = the standard IV, c_last = the digest.  Given the chaining values -- plain SHA-256
+// compression on the host, one pass over the message -- the shards are INDEPENDENT: dealt over the devices like any other batch.
+size_t zkhip_sha256_air_chained(uint32_t* program, size_t cap_words) {
+    const std::vector<uint32_t>& p = sha::program_chained();
+    if (program && cap_words >= p.size()) std::memcpy(program, p.data(), p.size() * 4);
+    return p.size();
+}
+static int sharded_shape(size_t message_len, int log_blocks_per_shard, size_t* padded, size_t* n_shards, int* last_log_blocks) {
+    if (log_blocks_per_shard < 0 || log_blocks_per_shard > 14) return fail(ZKHIP_ERR_INVALID, "sha256_sharded: 2^0 .. 2^14 blocks per shard (a shard is one chip proof of up to 2^20 rows)");
+    *padded = ((message_len + 9 + 63) / 64) * 64;
+    const size_t blocks = *padded / 64, per = (size_t)1 << log_blocks_per_shard;
+    *n_shards = (blocks + per - 1) / per;
+    const size_t rest = blocks - (*n_shards - 1) * per;           // blocks of the last shard: its trace holds the next power of two
+    int lb = 0;
+    while (((size_t)1 << lb) < rest) lb++;
+    *last_log_blocks = lb;
+    return *n_shards <= 4096 ? ZKHIP_OK : fail(ZKHIP_ERR_INVALID, "sha256_sharded: more than 4096 shards");
+}
+size_t zkhip_sha256_sharded_count(size_t message_len, int log_blocks_per_shard) {
+    size_t padded, n;
+    int lb;
+    return sharded_shape(message_len, log_blocks_per_shard, &padded, &n, &lb) == ZKHIP_OK ? n : 0;
+}
+size_t zkhip_sha256_shard_proof_size(int log_blocks, const zkhip_params* prm) {
+    const std::vector<uint32_t>& p = sha::program_chained();
+    if (log_blocks < 0 || log_blocks > 14) return 0;
+    return zkhip_proof_size_air(p.data(), p.size(), 6 + log_blocks, sha::WIDTH, prm, 2 * sha::N_PUBLIC);
+}
+static void chain_limbs(const uint32_t in[8], const uint32_t out[8], uint32_t pv[32]) {      // public values of a shard: final limbs, then initial limbs
+    for (int i = 0; i < 8; i++) { pv[2 * i] = out[i] & 0xffffu; pv[2 * i + 1] = out[i] >> 16; pv[16 + 2 * i] = in[i] & 0xffffu; pv[16 + 2 * i + 1] = in[i] >> 16; }
+}
+int zkhip_prove_sha256_sharded(const int* devices, int n_devices, const uint8_t* message, size_t message_len, int log_blocks_per_shard, const zkhip_params* prm,
+                               int in_flight_per_device, uint8_t digest[32], uint32_t* chain, uint8_t* proofs, size_t proof_stride, size_t* proof_lens) {
+    if ((message_len && !message) || !prm || !digest || !chain || !proofs || !proof_lens) return fail(ZKHIP_ERR_INVALID, "prove_sha256_sharded: null argument");
+    size_t padded, n_shards;
+    int last_lb;
+    ZK_TRY(sharded_shape(message_len, log_blocks_per_shard, &padded, &n_shards, &last_lb));
+    if (proof_stride < zkhip_sha256_shard_proof_size(log_blocks_per_shard, prm) || zkhip_sha256_shard_proof_size(log_blocks_per_shard, prm) == 0)
+        return fail(ZKHIP_ERR_BUFFER, "prove_sha256_sharded: proof_stride is smaller than zkhip_sha256_shard_proof_size (or the proof shape is invalid)");
+    std::vector<int> devs;
+    ZK_TRY(resolve_devices(devices, n_devices, "prove_sha256_sharded", devs));
+    std::vector<uint8_t> blocks(padded);
+    zkhip_sha256_pad(message, message_len, blocks.data(), padded);
+    // one pass of plain compression over the message: the chaining value every shard starts from
+    const size_t per = (size_t)1 << log_blocks_per_shard, n_blocks = padded / 64;
+    uint32_t h[8];
+    std::memcpy(h, sha::IV, 32);
+    for (size_t k = 0; k < n_blocks; k++) {
+        if (k % per == 0) std::memcpy(chain + 8 * (k / per), h, 32);
+        sha::compress(h, blocks.data() + 64 * k);
+    }
+    std::memcpy(chain + 8 * n_shards, h, 32);
+    for (int i = 0; i < 8; i++) { digest[4 * i] = (uint8_t)(h[i] >> 24); digest[4 * i + 1] = (uint8_t)(h[i] >> 16); digest[4 * i + 2] = (uint8_t)(h[i] >> 8); digest[4 * i + 3] = (uint8_t)h[i]; }
+    const std::vector<uint32_t>& prog = sha::program_chained();
+    std::vector<char> ran;
+    for (size_t s = 0; s < n_shards; s++) proof_lens[s] = 0;
+    return deal_jobs(devs.data(), (int)devs.size(), (int)n_shards, in_flight_per_device, [&](zkhip_ctx* ctx, int s) {
+        const size_t first = (size_t)s * per, active = (size_t)s + 1 == n_shards ? n_blocks - first : per;
+        const int lb = (size_t)s + 1 == n_shards ? last_lb : log_blocks_per_shard;
+        void* trace;
+        ZK_TRY(ctx_reserve(ctx, S_CHIP, ((size_t)sha::WIDTH << (6 + lb)) * 4, &trace));
+        uint32_t out_limbs[16], pv[32];
+        ZK_TRY(zkhip_sha256_gen_trace_chained(ctx, chain + 8 * s, blocks.data() + 64 * first, active, (size_t)1 << lb, (uint32_t*)trace, sha::WIDTH, out_limbs));
+        chain_limbs(chain + 8 * s, chain + 8 * (s + 1), pv);
+        for (int i = 0; i < 16; i++) if (out_limbs[i] != pv[i]) return fail(ZKHIP_ERR_INTERNAL, "prove_sha256_sharded: a shard's trace does not end in the next chaining value");
+        return zkhip_prove_shard_air(ctx, prog.data(), prog.size(), (const uint32_t*)trace, sha::WIDTH, 6 + lb, sha::WIDTH, pv, 32, prm,
+                                     proofs + (size_t)s * proof_stride, proof_stride, &proof_lens[s]);
+    }, ran);
+}
+// checks a chain of shard proofs: chain[0] = the standard IV, chain[n] = the digest, shard s proves chain[s] -> chain[s + 1]; every shard but
+// the last covers 2^log_blocks_per_shard blocks (the last proof's own header says how many rows it has).  *reason: the failing shard's check
+int zkhip_verify_sha256_sharded(const uint8_t* proofs, size_t proof_stride, const size_t* proof_lens, size_t n_shards, const uint32_t* chain,
+                                int log_blocks_per_shard, const uint8_t digest[32], const zkhip_params* prm, size_t* bad_shard, int* reason) {
+    if (!proofs || !proof_lens || !chain || !digest || !prm || n_shards < 1 || n_shards > 4096 || log_blocks_per_shard < 0 || log_blocks_per_shard > 14)
+        return fail(ZKHIP_ERR_INVALID, "verify_sha256_sharded: bad arguments");
+    if (bad_shard) *bad_shard = 0;
+    if (reason) *reason = 0;
+    auto reject = [&](size_t s, int why, const char* msg) { if (bad_shard) *bad_shard = s; if (reason) *reason = why; return fail(ZKHIP_ERR_VERIFY, msg); };
+    if (std::memcmp(chain, sha::IV, 32) != 0) return reject(0, 1, "verify_sha256_sharded: the chain does not start from the SHA-256 initial value");
+    for (int i = 0; i < 8; i++) {
+        const uint32_t w = ((uint32_t)digest[4 * i] << 24) | ((uint32_t)digest[4 * i + 1] << 16) | ((uint32_t)digest[4 * i + 2] << 8) | digest[4 * i + 3];
+        if (chain[8 * n_shards + i] != w) return reject(n_shards - 1, 1, "verify_sha256_sharded: the chain does not end in the digest");
+    }
+    const std::vector<uint32_t>& prog = sha::program_chained();
+    for (size_t s = 0; s < n_shards; s++) {
+        const uint8_t* pf = proofs + s * proof_stride;
+        if (proof_lens[s] < 16 || proof_lens[s] > proof_stride) return reject(s, 2, "verify_sha256_sharded: bad proof length");
+        uint32_t head[4];
+        std::memcpy(head, pf, 16);
+        const int log_n = (int)head[2];
+        const bool last = s + 1 == n_shards;
+        if (log_n < 6 || log_n > 20 || (!last && log_n != 6 + log_blocks_per_shard) || (last && log_n > 6 + log_blocks_per_shard))
+            return reject(s, 3, "verify_sha256_sharded: a shard has the wrong height");
+        uint32_t pv[32];
+        chain_limbs(chain + 8 * s, chain + 8 * (s + 1), pv);
+        int why = 0;
+        if (zkhip_verify_shard_air(prog.data(), prog.size(), pf, proof_lens[s], log_n, sha::WIDTH, pv, 32, prm, &why) != ZKHIP_OK) {
+            if (bad_shard) *bad_shard = s;
+            if (reason) *reason = why;
+            return ZKHIP_ERR_VERIFY;
+        }
+    }
+    return ZKHIP_OK;
 }
 
 }  // extern "C"

@@ -664,6 +664,60 @@ def verify_shard_air(program, proof, log_n, width, public_values=(), params=None
     return rc, reason.value
 
 
+def sha256_air_chained():
+    """the chip with its initial chaining value public too (32 public values): the program of one shard of a longer message"""
+    lib = _lib.load()
+    n = lib.zkhip_sha256_air_chained(None, 0)
+    out = np.empty(n, dtype=np.uint32)
+    assert lib.zkhip_sha256_air_chained(out.ctypes.data_as(u32p), n) == n
+    return out
+
+
+class ShardedSha256:
+    """the result of prove_sha256_sharded: digest, chaining values [n + 1][8], the shard proofs"""
+
+    def __init__(self, digest, chain, proofs, stride, lens, log_blocks):
+        self.digest, self.chain, self.buf, self.stride, self.lens, self.log_blocks = digest, chain, proofs, stride, lens, log_blocks
+
+    @property
+    def proofs(self):
+        return [self.buf[i * self.stride:i * self.stride + int(n)] for i, n in enumerate(self.lens)]
+
+
+def prove_sha256_sharded(message, log_blocks_per_shard, params=None, devices=None, in_flight=2):
+    """zkhip_prove_sha256_sharded: SHA-256 of a message of any length as a chain of shard proofs dealt over `devices` (None: all visible)"""
+    lib = _lib.load()
+    params = params or Params(1, 100, 16)
+    m = np.frombuffer(bytes(message), dtype=np.uint8) if len(message) else np.zeros(1, dtype=np.uint8)
+    n = lib.zkhip_sha256_sharded_count(len(message), log_blocks_per_shard)
+    stride = lib.zkhip_sha256_shard_proof_size(log_blocks_per_shard, C.byref(params))
+    if n == 0 or stride == 0:
+        raise _lib.ZkHipError(-1, "prove_sha256_sharded: bad shape")
+    proofs = np.empty(n * stride, dtype=np.uint8)
+    lens = (C.c_size_t * n)()
+    chain = np.zeros((n + 1, 8), dtype=np.uint32)
+    digest = np.zeros(32, dtype=np.uint8)
+    devs = (C.c_int * len(devices))(*devices) if devices else None
+    check(lib.zkhip_prove_sha256_sharded(devs, len(devices) if devices else 0, m.ctypes.data_as(u8p), len(message), log_blocks_per_shard, C.byref(params), in_flight,
+                                         digest.ctypes.data_as(u8p), chain.ctypes.data_as(u32p), proofs.ctypes.data_as(u8p), stride, lens))
+    return ShardedSha256(digest.tobytes(), chain, proofs, stride, list(lens), log_blocks_per_shard)
+
+
+def verify_sha256_sharded(result, digest=None, params=None, chain=None, proofs=None):
+    """-> (rc, failing shard, reason); digest / chain / proofs default to the result's own"""
+    lib = _lib.load()
+    params = params or Params(1, 100, 16)
+    n = len(result.lens)
+    lens = (C.c_size_t * n)(*result.lens)
+    ch = np.ascontiguousarray(result.chain if chain is None else chain, dtype=np.uint32)
+    buf = np.ascontiguousarray(result.buf if proofs is None else proofs, dtype=np.uint8)
+    dg = np.frombuffer(bytes(result.digest if digest is None else digest), dtype=np.uint8)
+    bad, reason = C.c_size_t(0), C.c_int(0)
+    rc = lib.zkhip_verify_sha256_sharded(buf.ctypes.data_as(u8p), result.stride, lens, n, ch.ctypes.data_as(u32p), result.log_blocks, dg.ctypes.data_as(u8p),
+                                         C.byref(params), C.byref(bad), C.byref(reason))
+    return rc, bad.value, reason.value
+
+
 def sha256_air():
     """the SHA-256 compression chip's constraint program (u32 words)"""
     lib = _lib.load()
