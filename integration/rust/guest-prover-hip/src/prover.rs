@@ -86,6 +86,8 @@ pub const BATCH_FLAG_SYNTHETIC: u32 = 1;
 pub const BATCH_FLAG_INPUT_SHA256: u32 = 2;
 /// with INPUT_SHA256: the proof is the keyed SHA-256 machine's (chip + range table), to be checked against the vk of `setup`
 pub const BATCH_FLAG_KEYED: u32 = 4;
+/// with INPUT_SHA256: an input beyond one chip proof -- entry 0 holds the chaining values, entries 1..n the shard proofs (C++ mirror: zkhip_prove_sha256_sharded)
+pub const BATCH_FLAG_CHAINED: u32 = 8;
 
 /// the proving key of `setup`: a context and the machine key made on it (destroyed together, key first)
 pub struct KeyedContext {

@@ -409,3 +409,22 @@ def test_setup_prove_verify_on_the_reference_transcript(lib, oracle):
     assert blob[offs[0]:offs[0] + lens[0]] == O.prove_machine_keyed(tr, pre, pg, tb, pub, oprm).tobytes()
     rc, err, out2, blob2, vk2 = call_commitment_keyed(lib, 2, cbor + b"more", elf)
     assert rc == 0 and vk2 == vk and verify_blob(lib, blob2, out2, vk) == (0, 0) and out2 == hashlib.sha256(cbor + b"more").digest()
+
+
+@pytest.mark.gpu
+def test_a_large_transcript_is_proven_as_a_chain_of_shards(lib):
+    """BASELINE configs[3] through the mirror: a 2.5 MiB input is beyond one chip proof, so the commitment guest proves SHA-256 as a chain
+    of shard proofs (blob flags INPUT_SHA256 | CHAINED: the chaining values, then the shards); a CPU-only consumer checks the blob"""
+    import hashlib
+    cbor = np.random.default_rng(3).integers(0, 256, (5 << 19) + 77, dtype=np.uint8).tobytes()
+    rc, err, out, blob = call_commitment(lib, 2, cbor, b"\x7fELFguest")
+    assert rc == 0, err
+    assert out == hashlib.sha256(cbor).digest() and lib.zktls_batch_flags(blob, len(blob)) == 2 | 8
+    offs, lens = (C.c_size_t * 8)(), (C.c_size_t * 8)()
+    assert lib.zktls_unpack_batch(blob, len(blob), offs, lens, 8) == 4            # the chaining values + three shards
+    assert lens[0] == 4 * 32
+    assert verify_blob(lib, blob, out, None) == (0, 0)
+    assert verify_blob(lib, blob, hashlib.sha256(b"other").digest(), None)[0] != 0
+    tampered = bytearray(blob)
+    tampered[offs[2] + 4000] ^= 1
+    assert verify_blob(lib, bytes(tampered), out, None)[0] != 0

@@ -4,6 +4,7 @@
 
 #include <cstdlib>
 #include <atomic>
+#include <algorithm>
 #include <cstring>
 #include <mutex>
 #include <thread>
@@ -171,8 +172,22 @@ int verify_commitment_blob(const std::vector<uint8_t>& blob, const std::vector<u
     std::vector<std::vector<uint8_t>> proofs;
     uint32_t flags = 0;
     if (reason) *reason = 0;
-    if (!unpack_shard_proofs(blob, &proofs, &flags) || proofs.size() != 1 || !(flags & BATCH_FLAG_INPUT_SHA256) || output.size() != 32) return -1;
+    if (!unpack_shard_proofs(blob, &proofs, &flags) || proofs.empty() || !(flags & BATCH_FLAG_INPUT_SHA256) || output.size() != 32) return -1;
     const zkhip_params prm{1, num_queries, pow_bits, 0, 0, 0, 0, 0};
+    if (flags & BATCH_FLAG_CHAINED) {                    // entry 0: the chaining values; entries 1..n: the shard proofs
+        const size_t n = proofs.size() - 1;
+        if (n < 1 || proofs[0].size() != (n + 1) * 32) return -1;
+        size_t stride = 0;
+        for (size_t s = 1; s <= n; s++) stride = std::max(stride, proofs[s].size());
+        std::vector<uint8_t> buf(n * stride);
+        std::vector<size_t> lens(n);
+        for (size_t s = 0; s < n; s++) { std::memcpy(buf.data() + s * stride, proofs[s + 1].data(), proofs[s + 1].size()); lens[s] = proofs[s + 1].size(); }
+        std::vector<uint32_t> chain((n + 1) * 8);
+        std::memcpy(chain.data(), proofs[0].data(), proofs[0].size());
+        size_t bad = 0;
+        return zkhip_verify_sha256_sharded(buf.data(), stride, lens.data(), n, chain.data(), 14, output.data(), &prm, &bad, reason);
+    }
+    if (proofs.size() != 1) return -1;
     if (flags & BATCH_FLAG_KEYED) {
         if (vk.size() != 64) return -1;
         return zkhip_verify_sha256_machine(proofs[0].data(), proofs[0].size(), output.data(), (const uint32_t*)vk.data(), &prm, reason);
@@ -209,6 +224,30 @@ ProveResult HipGuestProver::prove_inner(const GuestInput& input, const std::vect
             while (lf > log_n || (log_n - lf) % 4 != 0) lf--;
             const bool defaults = plan_.num_queries == 100 && plan_.pow_bits == 16;
             prm = zkhip_params{2, defaults ? 50 : plan_.num_queries, defaults ? 0 : plan_.pow_bits, 0, 4, lf, 24, 0};
+        }
+        constexpr size_t ONE_PROOF = ((size_t)1 << 20) - 9;          // bytes whose padded form fits 2^14 blocks = one chip proof of 2^20 rows
+        if (input.cbor.size() > ONE_PROOF && backend_ == Backend::Sp1) {
+            // a large transcript (BASELINE configs[3]): SHA-256 as a CHAIN of shard proofs, dealt over the prover's devices; verified like sp1.rs:120
+            if (!vk_.empty()) throw std::runtime_error("setup: the keyed machine takes inputs of up to 1 MiB");
+            const int k = 14;
+            const size_t n = zkhip_sha256_sharded_count(input.cbor.size(), k), stride = zkhip_sha256_shard_proof_size(k, &prm);
+            if (n == 0 || stride == 0) throw std::runtime_error(std::string("input commitment: ") + zkhip_last_error());
+            std::vector<uint8_t> buf(n * stride);
+            std::vector<size_t> lens(n);
+            std::vector<uint32_t> chain((n + 1) * 8);
+            uint8_t digest32[32];
+            if (zkhip_prove_sha256_sharded(devices_.data(), (int)devices_.size(), input.cbor.data(), input.cbor.size(), k, &prm, 2, digest32, chain.data(), buf.data(), stride, lens.data()) != ZKHIP_OK)
+                fail_zkhip("zkhip_prove_sha256_sharded");
+            size_t bad = 0;
+            int reason = 0;
+            if (zkhip_verify_sha256_sharded(buf.data(), stride, lens.data(), n, chain.data(), k, digest32, &prm, &bad, &reason) != ZKHIP_OK) fail_zkhip("zkhip_verify_sha256_sharded");
+            std::vector<std::vector<uint8_t>> entries;
+            entries.emplace_back((const uint8_t*)chain.data(), (const uint8_t*)chain.data() + chain.size() * 4);
+            for (size_t s = 0; s < n; s++) entries.emplace_back(buf.begin() + (long)(s * stride), buf.begin() + (long)(s * stride + lens[s]));
+            r.output.assign(digest32, digest32 + 32);
+            r.proof = pack_shard_proofs(entries, BATCH_FLAG_INPUT_SHA256 | BATCH_FLAG_CHAINED);
+            r.ok = true;
+            return r;
         }
         const bool keyed = !vk_.empty();
         if (keyed) {

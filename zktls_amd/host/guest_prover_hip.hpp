@@ -131,6 +131,7 @@ std::vector<uint32_t> request_digest(const std::vector<uint8_t>& cbor, const std
 // then per shard (u32 length, bytes)
 constexpr uint32_t BATCH_FLAG_SYNTHETIC = 1u;
 constexpr uint32_t BATCH_FLAG_INPUT_SHA256 = 2u;     // one proof of the SHA-256 chip over the request's input bytes
+constexpr uint32_t BATCH_FLAG_CHAINED = 8u;          // with INPUT_SHA256: an input beyond one chip proof (1 MiB): entry 0 = the chaining values ((n + 1) x 8 LE words), entries 1..n = the shard proofs of zkhip_prove_sha256_sharded (2^14 blocks per shard)
 constexpr uint32_t BATCH_FLAG_KEYED = 4u;            // with INPUT_SHA256: the proof is the keyed SHA-256 MACHINE's (chip + range table), checked against a vk
 // a consumer's check of an input-commitment blob on the CPU: the blob's one proof against the claimed output (SHA-256 of the input);
 // `vk` (64 bytes from setup) is required for KEYED blobs.  -> 0 or a negative value; *reason as the zkhip verifiers
