@@ -1,6 +1,7 @@
 """Malformed input against every HOST entry that takes untrusted bytes (verifiers, program / table validators, the bincode reader).
 Nothing may crash or read out of bounds: run it against the AddressSanitizer build (tools/asan_cpu.sh).  usage: fuzz_host.py [seconds]"""
 import ctypes as C
+import hashlib
 import os
 import sys
 import time
@@ -81,6 +82,21 @@ got = C.c_size_t(0)
 src = arr(p_single)
 assert L.zkhip_proof_to_bincode(src.ctypes.data_as(u8p), src.size, 6, 8, C.byref(prm), bc.ctypes.data_as(u8p), bc_size, C.byref(got)) == 0
 
+# a chain of two SHA-256 shard proofs (chained chip) for zkhip_verify_sha256_sharded
+cblocks = S.pad(bytes(range(190)))
+ct0, cout0 = S.trace(cblocks[:128])
+civ1 = [cout0[2 * k] | (cout0[2 * k + 1] << 16) for k in range(8)]
+ct1, cout1 = S.trace(cblocks[128:], chain_in=civ1)
+civ = []
+for x in S.IV:
+    civ += [x & 0xffff, x >> 16]
+cprog = S.program(chained=True)
+cp0, cp1 = O.prove_shard_air(cprog, ct0, cout0 + civ, oprm), O.prove_shard_air(cprog, ct1, cout1 + cout0, oprm)
+cstride = max(cp0.size, cp1.size)
+cbuf = np.zeros(2 * cstride, dtype=np.uint8); cbuf[:cp0.size] = cp0; cbuf[cstride:cstride + cp1.size] = cp1
+cchain = np.array([S.IV, civ1, [cout1[2 * k] | (cout1[2 * k + 1] << 16) for k in range(8)]], dtype=np.uint32)
+cdigest = np.frombuffer(hashlib.sha256(bytes(range(190))).digest(), dtype=np.uint8)
+szp = C.POINTER(C.c_size_t)
 ksrc = arr(p_keyed)
 L.zkhip_chips_bincode_size.restype = C.c_size_t
 cbc = np.zeros(L.zkhip_chips_bincode_size(ksrc.ctypes.data_as(u8p), ksrc.size), dtype=np.uint8)
@@ -108,10 +124,18 @@ while time.time() - t0 < budget:
     m = arr(mutate(bc.tobytes()))
     back = np.zeros(len(p_single) + 64, dtype=np.uint8)
     L.zkhip_proof_from_bincode(m.ctypes.data_as(u8p), m.size, 6, 8, C.byref(prm), 2, back.ctypes.data_as(u8p), int(rng.choice([back.size, 16, 0])), C.byref(got))
+    mb = np.frombuffer(mutate(cbuf.tobytes())[:cbuf.size].ljust(cbuf.size, b"\0"), dtype=np.uint8).copy()
+    mc = cchain.copy()
+    if rng.random() < 0.3:
+        mc[int(rng.integers(0, 3)), int(rng.integers(0, 8))] ^= 1 << int(rng.integers(0, 32))
+    clens = (C.c_size_t * 2)(int(rng.choice([cp0.size, 0, 15, cstride, cstride + 1, 2**40])), cp1.size)
+    bad_s, why = C.c_size_t(0), C.c_int(0)
+    L.zkhip_verify_sha256_sharded(mb.ctypes.data_as(u8p), cstride, clens, int(rng.choice([2, 2, 1])), mc.ctypes.data_as(u32p), int(rng.choice([1, 1, 0, 14, 99])),
+                                  cdigest.ctypes.data_as(u8p), C.byref(prm), C.byref(bad_s), C.byref(why))
     cm = arr(mutate(p_keyed if rng.random() < 0.5 else p_machine))
     L.zkhip_chips_bincode_size(cm.ctypes.data_as(u8p), cm.size)
     cb = arr(mutate(cbc.tobytes()))
     L.zkhip_chips_proof_from_bincode(cb.ctypes.data_as(u8p), cb.size, back2.ctypes.data_as(u8p), int(rng.choice([back2.size, 64, 0])), C.byref(got),
                                      pub2.ctypes.data_as(u32p), int(rng.choice([8, 0])), C.byref(got2))
     n += 1
-print("fuzz ok: %d rounds of 16 malformed calls in %.0f s (no crash; run under the sanitizer build for out-of-bounds reads)" % (n, time.time() - t0))
+print("fuzz ok: %d rounds of 17 malformed calls in %.0f s (no crash; run under the sanitizer build for out-of-bounds reads)" % (n, time.time() - t0))
