@@ -16,7 +16,9 @@
 //   OUT 8 limb pairs (variables after the round, + chaining value in round 63, mod 2^32) | X0 X13 32 bits (W_t, W_{t+13})
 //   XL 14 limb pairs (W_{t+j}, j = 1..12, 14, 15) | SG0 SG1 32 bits (sigma0(W_t), sigma1(W_{t+13})) | CY 28 carry bits
 //   ACT (block belongs to the message) | SKIP = s_63 (1 - ACT) | 2 unused
+#include <atomic>
 #include <mutex>
+#include <thread>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -723,20 +725,27 @@ int zkhip_prove_sha256_sharded(const int* devices, int n_devices, const uint8_t*
     ZK_TRY(resolve_devices(devices, n_devices, "prove_sha256_sharded", devs));
     std::vector<uint8_t> blocks(padded);
     zkhip_sha256_pad(message, message_len, blocks.data(), padded);
-    // one pass of plain compression over the message: the chaining value every shard starts from
+    // one pass of plain compression over the message gives the chaining value every shard starts from -- the only sequential part (about
+    // 3 ms per MiB).  It runs on a thread of its own while the first shards are already being proven: shard s waits for chain[s + 1] only.
     const size_t per = (size_t)1 << log_blocks_per_shard, n_blocks = padded / 64;
-    uint32_t h[8];
-    std::memcpy(h, sha::IV, 32);
-    for (size_t k = 0; k < n_blocks; k++) {
-        if (k % per == 0) std::memcpy(chain + 8 * (k / per), h, 32);
-        sha::compress(h, blocks.data() + 64 * k);
-    }
-    std::memcpy(chain + 8 * n_shards, h, 32);
-    for (int i = 0; i < 8; i++) { digest[4 * i] = (uint8_t)(h[i] >> 24); digest[4 * i + 1] = (uint8_t)(h[i] >> 16); digest[4 * i + 2] = (uint8_t)(h[i] >> 8); digest[4 * i + 3] = (uint8_t)h[i]; }
+    std::atomic<size_t> ready{0};                          // chain[0 .. ready) are final
+    std::thread hasher([&] {
+        uint32_t h[8];
+        std::memcpy(h, sha::IV, 32);
+        for (size_t k = 0; k < n_blocks; k++) {
+            if (k % per == 0) { std::memcpy(chain + 8 * (k / per), h, 32); ready.store(k / per + 1, std::memory_order_release); }
+            sha::compress(h, blocks.data() + 64 * k);
+        }
+        std::memcpy(chain + 8 * n_shards, h, 32);
+        for (int i = 0; i < 8; i++) { digest[4 * i] = (uint8_t)(h[i] >> 24); digest[4 * i + 1] = (uint8_t)(h[i] >> 16); digest[4 * i + 2] = (uint8_t)(h[i] >> 8); digest[4 * i + 3] = (uint8_t)h[i]; }
+        ready.store(n_shards + 1, std::memory_order_release);
+    });
+    struct Join { std::thread& t; ~Join() { if (t.joinable()) t.join(); } } join{hasher};
     const std::vector<uint32_t>& prog = sha::program_chained();
     std::vector<char> ran;
     for (size_t s = 0; s < n_shards; s++) proof_lens[s] = 0;
     return deal_jobs(devs.data(), (int)devs.size(), (int)n_shards, in_flight_per_device, [&](zkhip_ctx* ctx, int s) {
+        while (ready.load(std::memory_order_acquire) < (size_t)s + 2) std::this_thread::yield();
         const size_t first = (size_t)s * per, active = (size_t)s + 1 == n_shards ? n_blocks - first : per;
         const int lb = (size_t)s + 1 == n_shards ? last_lb : log_blocks_per_shard;
         void* trace;
