@@ -116,7 +116,7 @@ inline void air_device_image(const AirView& a, const Ext& alpha, std::vector<uin
 // selector appended as one more factor, so that the quotient numerator is one flat sum  sum_t coeff_t * prod_j slot[off_tj]  over
 // a per-point array of slots: [0, W) local row, [W, 2W) next row, 2W is_first, 2W+1 is_last, 2W+2 is_transition, 2W+3 the constant 1,
 // 2W+4+i public value i.  Record = 8 words: coefficient (4), off0 | off1 << 16, off2 | off3 << 16, off4 | nvars << 16, 0; nvars in
-// [1, 5] (a constant term reads the slot of 1).  Sorted by nvars, so that the lanes of a wavefront run the same number of products.
+// [1, 5] (a constant term reads the slot of 1); off = the slot's LDS word for point 0 (kernels.h, air_lds_base).  Sorted by nvars, so that the lanes of a wavefront run the same number of products.
 inline uint32_t air_slots(const AirView& a) { return 2 * a.width + AIR_SLOT_EXTRA + a.n_public; }
 // Terms with the SAME monomial (the same factors, selector included) are merged: their weighted coefficients add up, the flat sum is
 // the same field element.  Real chips repeat monomials across constraints -- the S-box output x3 x3 y of the Poseidon2 chip enters all
@@ -182,10 +182,12 @@ inline void air_term_records(const AirView& a, const Ext& alpha, std::vector<uin
     const uint32_t W = a.width;
     const size_t nm = plan->monomials.size();
     recs.assign((nm + (nm & 1)) * 8, 0u);
-    for (size_t m = 0; m < nm; m++) {
+    for (size_t m = 0; m < nm; m++) {                // a factor travels as its LDS word for point 0 (kernels.h, air_lds_base)
         const std::array<uint32_t, 6>& k = plan->monomials[m];
         uint32_t* r = recs.data() + 8 * m;
-        r[4] = k[1] | k[2] << 16; r[5] = k[3] | k[4] << 16; r[6] = k[5] | k[0] << 16;
+        uint32_t o[5] = {0, 0, 0, 0, 0};
+        for (uint32_t j = 0; j < k[0]; j++) o[j] = air_lds_base(k[1 + j], W);
+        r[4] = o[0] | o[1] << 16; r[5] = o[2] | o[3] << 16; r[6] = o[4] | k[0] << 16;
     }
     for (const AirTermPlan::Src& t : plan->terms) {
         uint32_t* r = recs.data() + 8 * (size_t)t.monomial;
@@ -194,7 +196,7 @@ inline void air_term_records(const AirView& a, const Ext& alpha, std::vector<uin
     }
     if (nm & 1) {                                // the kernel takes terms in pairs: pad with 0 * (the constant 1)
         uint32_t* r = recs.data() + 8 * nm;
-        r[4] = 2 * W + 3; r[6] = 1u << 16;
+        r[4] = air_lds_base(2 * W + 3, W); r[6] = 1u << 16;
     }
 }
 

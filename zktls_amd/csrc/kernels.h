@@ -176,6 +176,22 @@ hipError_t launch_quotient(const QuotientArgs& a, hipStream_t s);
 
 // quotient values of a constraint PROGRAM (air.h): the interpreter form of launch_quotient for an AIR supplied as data.
 constexpr uint32_t AIR_SLOT_EXTRA = 4;      // per-point slots after the two rows: is_first, is_last, is_transition, 1 (then the public values)
+// LDS layout of the term-parallel kernels (stark.hip): a group of 8 points = 8 CONSECUTIVE rows of the trace domain on one coset of the
+// quotient domain, so the next row of point q is the local row of point q + 1 and 9 rows serve the 8 points.  Columns are kept in groups
+// of four: column c of row r (r < 9) at AIR_GP (c >> 2) + 4 r + (c & 3) -- a lane holding four consecutive columns of a row (one 16-byte
+// global load) stores them with one 16-byte LDS write, and the pitch of 36 words spreads the lanes of a row over all banks.  The selector
+// / constant / public-value slots follow in groups of their own (rows 0..7).  A term record carries, per factor, the LDS word of that
+// factor for point 0 (air_lds_base); point q is 4 q words further.
+constexpr uint32_t AIR_GP = 36;
+#if defined(__HIPCC__)
+__host__ __device__
+#endif
+inline uint32_t air_lds_base(uint32_t slot, uint32_t W) {
+    if (slot < W) return AIR_GP * (slot >> 2) + (slot & 3u);
+    if (slot < 2 * W) { const uint32_t c = slot - W; return AIR_GP * (c >> 2) + (c & 3u) + 4u; }
+    const uint32_t x = slot - 2 * W;
+    return AIR_GP * ((W >> 2) + (x >> 2)) + (x & 3u);
+}
 struct QuotientAirArgs {
     const uint32_t* lde; uint64_t ld; uint32_t width; int log_n;
     const uint32_t* xs; const uint32_t* sel_first; const uint32_t* sel_last;

@@ -279,148 +279,68 @@ __global__ void __launch_bounds__(256) quotient_air_kernel(QuotientAirArgs a) {
     st_ext(a.out + ((uint64_t)chunk * (m >> a.log_qd) + (e >> a.log_qd)) * 4, r);
     if (a.lde_out) st_ext(a.lde_out + (uint64_t)p * a.lde_ld + 4u * chunk, r);
 }
-// The term-parallel form: a workgroup owns PTS adjacent points of the quotient domain and its 256 lanes split the TERMS of the
-// flattened program (air.h, air_term_records).  The two rows of every point are staged into LDS once (point-minor: the 8 points of a slot side by side)
-// (together with the point's selector values, the constant 1 and the public values: "slots"), a lane loads its 32-byte term record
-// once and applies it to all PTS points (two 16-byte ds_reads fetch a slot of all 8 points; the record table stays in L2), and the
-// extension coefficients ride in four 64-bit running sums per point (dacc2: terms go in pairs, one conditional subtraction per two
-// products, one Montgomery reduction at the end).  The
-// 256 partial sums per point are then added through LDS.  Against the row-per-lane interpreter above: no strided global gathers
-// (a lane there touches 64 cache lines per load instruction) and ~8 x less program traffic per point; 40 - 50 x faster on the
-// 608-column SHA-256 chip.
-template <int PTS>
-__global__ void __launch_bounds__(256) quotient_air_terms_kernel(QuotientAirArgs a, uint32_t stride) {
-    static_assert(PTS == 8, "the slot layout below holds the 8 points of a slot in two 16-byte words");
-    extern __shared__ uint32_t slots[];                // [slot][point]: slot s of point q at slots[8 s + q]; `stride` = slots per point
+// The term-parallel form: a workgroup owns a GROUP of 8 points of the quotient domain and its lanes split the TERMS of the flattened
+// program (air.h, air_term_records: one record per distinct monomial).  The 8 points are 8 consecutive rows of the trace domain on one
+// coset, so 9 rows of the LDE serve them (the next row of point q is the local row of point q + 1); the rows are staged into LDS once,
+// 16 bytes per lane and row (kernels.h, AIR_GP: column groups of four, the 9 rows of a group 4 words apart), together with the points'
+// selector values, the constant 1 and the public values.  A lane loads its 32-byte record once and applies it to all 8 points (a factor
+// of the 8 points: 8 LDS words 4 apart; the record table stays in L2), and the extension coefficients ride in four 64-bit running sums
+// per point (dacc2: terms go in pairs, one conditional subtraction per two products, one Montgomery reduction at the end).  The lanes'
+// partial sums are then added through LDS.  Against the row-per-lane interpreter above: no strided global gathers (a lane there
+// touches 64 cache lines per load instruction) and ~8 x less program traffic per point; 40 - 50 x faster on the 608-column SHA-256
+// chip.
+// first natural index of group g: cosets interleave (groups g, g + 1 are the same 8 trace rows on neighbouring cosets)
+__device__ __forceinline__ uint32_t air_group_e0(const QuotientAirArgs& a, uint32_t g) { return ((g >> a.log_qd) * 8u << a.log_qd) + (g & ((1u << a.log_qd) - 1u)); }
+__device__ __forceinline__ uint32_t air_row_of(const QuotientAirArgs& a, uint32_t e0, uint32_t r) {      // LDE row of the group's r-th trace row
     const int H = a.log_n + a.log_qd;
-    const uint32_t m = 1u << H, nq = 1u << a.log_qd, W = a.width;
-    const uint32_t p0 = blockIdx.x * PTS, tid = threadIdx.x;
-    {
-        // staging: lane = (point q = tid & 7, column c = tid >> 3 (+ 32 per trip)): the 8 lanes of a column write 8 adjacent LDS words
-        const uint32_t q = tid & 7u, p = p0 + q;
-        const uint32_t e = __brev(p) >> (32 - H);
-        const uint32_t pn = __brev((e + nq) & (m - 1)) >> (32 - H);
-        const uint32_t* lrow = a.lde + (uint64_t)p * a.ld;
-        const uint32_t* nrow = a.lde + (uint64_t)pn * a.ld;
-        for (uint32_t c = tid >> 3; c < W; c += 32) {
-            slots[8 * c + q] = lrow[c];
-            slots[8 * (W + c) + q] = nrow[c];
-        }
-        if (tid < 8) {
-            uint32_t* ex = slots + 8 * (size_t)(2 * W);
-            ex[q] = a.sel_first[p]; ex[8 + q] = a.sel_last[p]; ex[16 + q] = dsub(a.xs[p], a.wn_inv); ex[24 + q] = MONTY_R1;
-        }
-        for (uint32_t i = tid >> 3; i < a.n_public; i += 32) slots[8 * (size_t)(2 * W + AIR_SLOT_EXTRA + i) + q] = a.pub[i];
-    }
-    __syncthreads();
-    uint64_t acc[PTS][4];
-#pragma unroll
-    for (int q = 0; q < PTS; q++)
-#pragma unroll
-        for (int i = 0; i < 4; i++) acc[q][i] = 0;
-    const uint4* recs = reinterpret_cast<const uint4*>(a.recs);
-    // the 8 points of slot o: two 16-byte LDS reads
-    auto load8 = [&](uint32_t o, uint32_t (&v)[PTS]) {
-        const uint4* s4 = reinterpret_cast<const uint4*>(slots + 8 * (size_t)o);
-        const uint4 lo = s4[0], hi = s4[1];
-        v[0] = lo.x; v[1] = lo.y; v[2] = lo.z; v[3] = lo.w; v[4] = hi.x; v[5] = hi.y; v[6] = hi.z; v[7] = hi.w;
-    };
-    auto product = [&](const uint4& o, uint32_t (&prod)[PTS]) {
-        const uint32_t n = o.z >> 16;
-        uint32_t v[PTS];
-        load8(o.x & 0xFFFFu, prod);
-        if (n > 1) {
-            load8(o.x >> 16, v);
-#pragma unroll
-            for (int q = 0; q < PTS; q++) prod[q] = dmul(prod[q], v[q]);
-        }
-        if (n > 2) {
-            load8(o.y & 0xFFFFu, v);
-#pragma unroll
-            for (int q = 0; q < PTS; q++) prod[q] = dmul(prod[q], v[q]);
-        }
-        if (n > 3) {
-            load8(o.y >> 16, v);
-#pragma unroll
-            for (int q = 0; q < PTS; q++) prod[q] = dmul(prod[q], v[q]);
-        }
-        if (n > 4) {
-            load8(o.z & 0xFFFFu, v);
-#pragma unroll
-            for (int q = 0; q < PTS; q++) prod[q] = dmul(prod[q], v[q]);
-        }
-    };
-    // terms go in PAIRS (the table is padded to an even count): two products share one conditional subtraction per running sum (dacc2)
-    for (uint32_t t = 2 * tid; t < a.n_terms; t += 512) {
-        const uint4 ca = recs[2 * (size_t)t], oa = recs[2 * (size_t)t + 1], cb = recs[2 * (size_t)t + 2], ob = recs[2 * (size_t)t + 3];
-        uint32_t pa[PTS], pb[PTS];
-        product(oa, pa);
-        product(ob, pb);
-#pragma unroll
-        for (int q = 0; q < PTS; q++) {
-            dacc2(acc[q][0], ca.x, pa[q], cb.x, pb[q]); dacc2(acc[q][1], ca.y, pa[q], cb.y, pb[q]);
-            dacc2(acc[q][2], ca.z, pa[q], cb.z, pb[q]); dacc2(acc[q][3], ca.w, pa[q], cb.w, pb[q]);
-        }
-    }
-    __syncthreads();                                   // the slots are dead: the same LDS now carries the partial sums
-    constexpr int NV = PTS * 4;                        // values to total, 256 partials each; row pitch 257 words
-#pragma unroll
-    for (int q = 0; q < PTS; q++)
-#pragma unroll
-        for (int i = 0; i < 4; i++) slots[(size_t)(q * 4 + i) * 257 + tid] = dacc_finish(acc[q][i]);
-    __syncthreads();
-    constexpr int SL = 256 / NV;                       // lanes per value in the first round (8 for PTS = 8)
-    {
-        const uint32_t j = tid / SL, sl = tid % SL;
-        uint32_t sum = 0;
-        for (uint32_t i = sl; i < 256; i += SL) sum = dadd(sum, slots[(size_t)j * 257 + i]);
-        __syncthreads();
-        slots[(size_t)j * 257 + sl] = sum;
-    }
-    __syncthreads();
-    if (tid < (uint32_t)PTS) {
-        const uint32_t p = p0 + tid;
-        const uint32_t e = __brev(p) >> (32 - H);
-        Ext r;
-        for (int i = 0; i < 4; i++) {
-            uint32_t sum = 0;
-            for (int k = 0; k < SL; k++) sum = dadd(sum, slots[(size_t)(tid * 4 + i) * 257 + k]);
-            r.c[i] = sum;
-        }
-        if (a.addend) r = ext_add(r, ld_ext(a.addend + 4 * (uint64_t)p));
-        const uint32_t chunk = e & (nq - 1u);
-        const uint32_t iz = chunk == 0 ? a.inv_zh[0] : (chunk == 1 ? a.inv_zh[1] : (chunk == 2 ? a.inv_zh[2] : a.inv_zh[3]));
-        r = ext_mul_base_dev(r, iz);
-        st_ext(a.out + ((uint64_t)chunk * (m >> a.log_qd) + (e >> a.log_qd)) * 4, r);
-        if (a.lde_out) st_ext(a.lde_out + (uint64_t)p * a.lde_ld + 4u * chunk, r);
-    }
+    return __brev((e0 + (r << a.log_qd)) & ((1u << H) - 1u)) >> (32 - H);
 }
-// The same for programs over rows of moderate width: ONE wavefront per group of 8 points.  The 256-lane form pays a fixed price per
-// group -- two workgroup barriers and a 256-way reduction of 32 values through 33 KB of LDS, four workgroups per CU -- that is all
-// of its time for programs of a few hundred terms (0.35 ms per 2^19 points); with one wavefront the reduction is 64-way through 8 KB,
-// the barriers are wave-local, and twenty groups share a CU.  Used while the 8 points' slots fit 16 KB of LDS.
-__global__ void __launch_bounds__(64) quotient_air_terms_wave_kernel(QuotientAirArgs a, uint32_t stride) {
-    constexpr int PTS = 8;
-    extern __shared__ uint32_t slots[];
-    const int H = a.log_n + a.log_qd;
-    const uint32_t m = 1u << H, nq = 1u << a.log_qd, W = a.width;
-    const uint32_t p0 = blockIdx.x * PTS, tid = threadIdx.x;
-    {
-        const uint32_t q = tid & 7u, p = p0 + q;
-        const uint32_t e = __brev(p) >> (32 - H);
-        const uint32_t pn = __brev((e + nq) & (m - 1)) >> (32 - H);
-        const uint32_t* lrow = a.lde + (uint64_t)p * a.ld;
-        const uint32_t* nrow = a.lde + (uint64_t)pn * a.ld;
-        for (uint32_t c = tid >> 3; c < W; c += 8) {
-            slots[8 * c + q] = lrow[c];
-            slots[8 * (W + c) + q] = nrow[c];
-        }
-        if (tid < 8) {
-            uint32_t* ex = slots + 8 * (size_t)(2 * W);
-            ex[q] = a.sel_first[p]; ex[8 + q] = a.sel_last[p]; ex[16 + q] = dsub(a.xs[p], a.wn_inv); ex[24 + q] = MONTY_R1;
-        }
-        for (uint32_t i = tid >> 3; i < a.n_public; i += 8) slots[8 * (size_t)(2 * W + AIR_SLOT_EXTRA + i) + q] = a.pub[i];
+__device__ __forceinline__ void air_load8(const uint32_t* slots, uint32_t base, uint32_t (&v)[8]) {
+    const uint32_t* b = slots + base;
+#pragma unroll
+    for (int q = 0; q < 8; q++) v[q] = b[4 * q];
+}
+// selector / constant / public-value slots of the group's 8 points
+template <int NT>
+__device__ __forceinline__ void air_stage_extras(const QuotientAirArgs& a, uint32_t* slots, uint32_t e0, uint32_t tid) {
+    const uint32_t W4 = a.width >> 2;
+    if (tid < 8) {
+        const uint32_t p = air_row_of(a, e0, tid);
+        const uint4 ex = {a.sel_first[p], a.sel_last[p], dsub(a.xs[p], a.wn_inv), MONTY_R1};
+        *reinterpret_cast<uint4*>(slots + AIR_GP * W4 + 4u * tid) = ex;      // slots 2W .. 2W + 3: the first group after the columns
     }
+    for (uint32_t i = tid >> 3; i < a.n_public; i += NT / 8) slots[air_lds_base(2 * a.width + AIR_SLOT_EXTRA + i, a.width) + 4u * (tid & 7u)] = a.pub[i];
+}
+__device__ __forceinline__ void air_store_point(const QuotientAirArgs& a, uint32_t e, Ext r) {
+    const int H = a.log_n + a.log_qd;
+    const uint32_t m = 1u << H, nq = 1u << a.log_qd;
+    const uint32_t p = __brev(e) >> (32 - H);
+    if (a.addend) r = ext_add(r, ld_ext(a.addend + 4 * (uint64_t)p));
+    const uint32_t chunk = e & (nq - 1u);
+    const uint32_t iz = chunk == 0 ? a.inv_zh[0] : (chunk == 1 ? a.inv_zh[1] : (chunk == 2 ? a.inv_zh[2] : a.inv_zh[3]));
+    r = ext_mul_base_dev(r, iz);
+    st_ext(a.out + ((uint64_t)chunk * (m >> a.log_qd) + (e >> a.log_qd)) * 4, r);
+    if (a.lde_out) st_ext(a.lde_out + (uint64_t)p * a.lde_ld + 4u * chunk, r);
+}
+// One group of 8 points per workgroup of NT lanes (64, 128 or 256: one, two or four wavefronts).  What limits this kernel is not
+// arithmetic but how many groups a CU holds while their rows are on the way (PMC on the first form, 256 lanes and 16 staged rows per
+// group: SQ_WAIT_ANY 65 - 86 % of the wave cycles): a group's footprint is its 9 rows in LDS (23 KB at 608 columns), so the FEWER lanes
+// a group takes the more groups are resident -- seven single wavefronts per CU against three or four 256-lane workgroups.  Lanes beyond
+// one wavefront only pay when a program has enough terms per point to keep them busy; the launcher picks NT from the record count.
+template <int NT>
+__global__ void __launch_bounds__(NT) quotient_air_terms_kernel(QuotientAirArgs a) {
+    constexpr int PTS = 8;
+    static_assert(NT == 64 || NT == 128 || NT == 256, "one, two or four wavefronts per group");
+    extern __shared__ uint32_t slots[];
+    const uint32_t tid = threadIdx.x, W4 = a.width >> 2;
+    const uint32_t mask = (1u << (a.log_n + a.log_qd)) - 1u;
+    const uint32_t e0 = air_group_e0(a, blockIdx.x);
+#pragma unroll
+    for (int r = 0; r < 9; r++) {
+        const uint4* row = reinterpret_cast<const uint4*>(a.lde + (uint64_t)air_row_of(a, e0, r) * a.ld);
+        for (uint32_t cg = tid; cg < W4; cg += NT) *reinterpret_cast<uint4*>(slots + AIR_GP * cg + 4u * r) = row[cg];
+    }
+    air_stage_extras<NT>(a, slots, e0, tid);
     __syncthreads();
     uint64_t acc[PTS][4];
 #pragma unroll
@@ -428,11 +348,7 @@ __global__ void __launch_bounds__(64) quotient_air_terms_wave_kernel(QuotientAir
 #pragma unroll
         for (int i = 0; i < 4; i++) acc[q][i] = 0;
     const uint4* recs = reinterpret_cast<const uint4*>(a.recs);
-    auto load8 = [&](uint32_t o, uint32_t (&v)[PTS]) {
-        const uint4* s4 = reinterpret_cast<const uint4*>(slots + 8 * (size_t)o);
-        const uint4 lo = s4[0], hi = s4[1];
-        v[0] = lo.x; v[1] = lo.y; v[2] = lo.z; v[3] = lo.w; v[4] = hi.x; v[5] = hi.y; v[6] = hi.z; v[7] = hi.w;
-    };
+    auto load8 = [&](uint32_t o, uint32_t (&v)[PTS]) { air_load8(slots, o, v); };
     auto product = [&](const uint4& o, uint32_t (&prod)[PTS]) {
         const uint32_t n = o.z >> 16;
         uint32_t v[PTS];
@@ -444,7 +360,8 @@ __global__ void __launch_bounds__(64) quotient_air_terms_wave_kernel(QuotientAir
             for (int q = 0; q < PTS; q++) prod[q] = dmul(prod[q], v[q]);
         }
     };
-    for (uint32_t t = 2 * tid; t < a.n_terms; t += 128) {
+    // terms go in PAIRS (the table is padded to an even count): two products share one conditional subtraction per running sum (dacc2)
+    for (uint32_t t = 2 * tid; t < a.n_terms; t += 2 * NT) {
         const uint4 ca = recs[2 * (size_t)t], oa = recs[2 * (size_t)t + 1], cb = recs[2 * (size_t)t + 2], ob = recs[2 * (size_t)t + 3];
         uint32_t pa[PTS], pb[PTS];
         product(oa, pa);
@@ -455,56 +372,66 @@ __global__ void __launch_bounds__(64) quotient_air_terms_wave_kernel(QuotientAir
             dacc2(acc[q][2], ca.z, pa[q], cb.z, pb[q]); dacc2(acc[q][3], ca.w, pa[q], cb.w, pb[q]);
         }
     }
-    __syncthreads();                                   // the slots are dead: 32 values x 64 partials, row pitch 65 words
+    __syncthreads();                                   // the slots are dead: the same LDS now carries 32 values x NT partials, row pitch NT + 1
+    constexpr int PITCH = NT + 1, SL = NT / 32;        // SL lanes per value in the first round
 #pragma unroll
     for (int q = 0; q < PTS; q++)
 #pragma unroll
-        for (int i = 0; i < 4; i++) slots[(size_t)(q * 4 + i) * 65 + tid] = dacc_finish(acc[q][i]);
+        for (int i = 0; i < 4; i++) slots[(size_t)(q * 4 + i) * PITCH + tid] = dacc_finish(acc[q][i]);
     __syncthreads();
-    uint32_t sum = 0;
-    if (tid < 32) for (uint32_t i = 0; i < 64; i++) sum = dadd(sum, slots[(size_t)tid * 65 + i]);
-    __syncthreads();
-    if (tid < 32) slots[tid] = sum;
+    {
+        const uint32_t j = tid / SL, sl = tid % SL;
+        uint32_t sum = 0;
+        for (uint32_t i = sl; i < (uint32_t)NT; i += SL) sum = dadd(sum, slots[(size_t)j * PITCH + i]);
+        __syncthreads();
+        slots[(size_t)j * PITCH + sl] = sum;
+    }
     __syncthreads();
     if (tid < (uint32_t)PTS) {
-        const uint32_t p = p0 + tid;
-        const uint32_t e = __brev(p) >> (32 - H);
-        Ext r = Ext{{slots[4 * tid], slots[4 * tid + 1], slots[4 * tid + 2], slots[4 * tid + 3]}};
-        if (a.addend) r = ext_add(r, ld_ext(a.addend + 4 * (uint64_t)p));
-        const uint32_t chunk = e & (nq - 1u);
-        const uint32_t iz = chunk == 0 ? a.inv_zh[0] : (chunk == 1 ? a.inv_zh[1] : (chunk == 2 ? a.inv_zh[2] : a.inv_zh[3]));
-        r = ext_mul_base_dev(r, iz);
-        st_ext(a.out + ((uint64_t)chunk * (m >> a.log_qd) + (e >> a.log_qd)) * 4, r);
-        if (a.lde_out) st_ext(a.lde_out + (uint64_t)p * a.lde_ld + 4u * chunk, r);
+        Ext r;
+        for (int i = 0; i < 4; i++) {
+            uint32_t sum = 0;
+            for (int k = 0; k < SL; k++) sum = dadd(sum, slots[(size_t)(tid * 4 + i) * PITCH + k]);
+            r.c[i] = sum;
+        }
+        air_store_point(a, (e0 + (tid << a.log_qd)) & mask, r);
     }
 }
-hipError_t launch_quotient_air(const QuotientAirArgs& a, hipStream_t s) {
-    const uint64_t m = 1ull << (a.log_n + a.log_qd);
-    constexpr int PTS = 8;
-    const uint32_t stride = 2 * a.width + AIR_SLOT_EXTRA + ((a.n_public + 3u) & ~3u);     // a multiple of 4 words: 16-byte row copies
-    const size_t lds_rows = (size_t)PTS * stride * 4, lds_red = (size_t)PTS * 4 * 257 * 4;
-    const size_t lds = lds_rows > lds_red ? lds_rows : lds_red;
-    // Small programs over rows of at most 16 columns keep the row-per-lane interpreter: a whole row sits in one cache line, its gathers
-    // are cheap, and the term-parallel kernel's fixed cost per group of 8 points (staging, two barriers, the 256-way reduction) would be
-    // all of its time -- 0.35 ms per 2^19 points whatever the program, against 13 - 37 us (tools/airq_time.py).  From 32 columns on the
-    // strided gathers lose (0.56 ms at 32 columns, 2.0 ms at 64, against 0.37 / 0.39 ms).
-    const bool small = a.n_terms <= 512 && a.width <= 16;
-    if (a.recs && !small && (a.n_terms & 1u) == 0 && m >= (uint64_t)PTS && lds_rows <= 16 * 1024) {
-        const size_t wl = lds_rows > 32 * 65 * 4 ? lds_rows : 32 * 65 * 4;
-        hipLaunchKernelGGL(quotient_air_terms_wave_kernel, dim3((unsigned)(m / PTS)), dim3(64), wl, s, a, stride);
-        return hipGetLastError();
-    }
-    if (a.recs && !small && (a.n_terms & 1u) == 0 && lds <= 72 * 1024 && m >= (uint64_t)PTS && stride < 8192) {
+template <int NT>
+static hipError_t launch_terms(const QuotientAirArgs& a, uint32_t n_groups, size_t lds_rows, hipStream_t s) {
+    const size_t lds_red = (size_t)32 * (NT + 1) * 4, lds = lds_rows > lds_red ? lds_rows : lds_red;
+    if (lds > 64 * 1024) {                              // beyond the default dynamic LDS limit: raise it once per device
         static std::atomic<size_t> configured[64] = {};
         int dev = 0;
         if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return hipErrorInvalidDevice;
         if (lds > configured[dev].load(std::memory_order_acquire)) {
-            hipError_t e = hipFuncSetAttribute((const void*)quotient_air_terms_kernel<PTS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            hipError_t e = hipFuncSetAttribute((const void*)quotient_air_terms_kernel<NT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
             if (e != hipSuccess) return e;
             configured[dev].store(lds, std::memory_order_release);
         }
-        hipLaunchKernelGGL(quotient_air_terms_kernel<PTS>, dim3((unsigned)(m / PTS)), dim3(256), lds, s, a, stride);
-        return hipGetLastError();
+    }
+    hipLaunchKernelGGL(quotient_air_terms_kernel<NT>, dim3(n_groups), dim3(NT), lds, s, a);
+    return hipGetLastError();
+}
+hipError_t launch_quotient_air(const QuotientAirArgs& a, hipStream_t s) {
+    const uint64_t m = 1ull << (a.log_n + a.log_qd);
+    constexpr int PTS = 8;
+    const uint32_t groups4 = (a.width >> 2) + (AIR_SLOT_EXTRA + ((a.n_public + 3u) & ~3u)) / 4;      // column groups + selector / public groups
+    const size_t lds_rows = (size_t)AIR_GP * groups4 * 4;
+    // the term-parallel kernel reads rows 16 bytes per lane: rows start on 16-byte boundaries, and a record addresses LDS words in 16 bits
+    const bool fits = a.width % 4 == 0 && a.ld % 4 == 0 && (reinterpret_cast<uintptr_t>(a.lde) & 15u) == 0 && a.width <= 1024 &&
+                      lds_rows <= 72 * 1024 && m >= ((uint64_t)PTS << a.log_qd);
+    // Small programs over rows of at most 16 columns keep the row-per-lane interpreter: a whole row sits in one cache line, its gathers
+    // are cheap, and the term-parallel kernel's fixed cost per group of 8 points would be all of its time (tools/airq_time.py).
+    const bool small = a.n_terms <= 512 && a.width <= 16;
+    if (a.recs && fits && !small && (a.n_terms & 1u) == 0) {
+        const uint32_t n_groups = (uint32_t)(m / PTS);
+        // lanes per group by the work per point: one wavefront keeps the most groups resident; more only for programs with many records
+        // (same box, 2^21 points: the SHA-256 chip's 3 366 records 7.3 / 5.7 / 6.1 ms with 64 / 128 / 256 lanes, the Poseidon2 chip's 1 008
+        // records 2.4 / 2.2 ms with 64 / 128; the first form of this kernel, 256 lanes and 16 staged rows: 7.4 and 3.9 ms)
+        if (a.n_terms <= 512) return launch_terms<64>(a, n_groups, lds_rows, s);
+        if (a.n_terms <= 8192) return launch_terms<128>(a, n_groups, lds_rows, s);
+        return launch_terms<256>(a, n_groups, lds_rows, s);
     }
     hipLaunchKernelGGL(quotient_air_kernel, dim3((unsigned)((m + 255) / 256)), dim3(256), 0, s, a);
     return hipGetLastError();
