@@ -129,3 +129,33 @@ def test_many_public_values_take_the_row_per_lane_interpreter(ctx, oracle):
     proof = ctx.prove_shard_air(prog, ctx.from_numpy(t), log_n, width, pub, Params(*shape))
     assert proof.tobytes() == O.prove_shard_air(prog, t, pub, O.default_params(*shape)).tobytes()
     assert verify_shard_air(prog, proof, log_n, width, pub, Params(*shape)) == (0, 0)
+
+
+@pytest.mark.parametrize("n_monomials,lanes", [(300, 64), (3000, 128), (9000, 256)])
+def test_term_kernel_with_64_128_and_256_lanes_per_group(ctx, oracle, n_monomials, lanes):
+    """the term-parallel kernel takes one, two or four wavefronts per group of 8 points by the program's record count (one record per
+    distinct monomial).  Programs with that many distinct monomials on any trace: constraint k = m_k - m_k over a monomial m_k of its own
+    (the two terms merge into one record whose coefficient happens to be zero) next to a real counter constraint; quotient values
+    against the oracle, which evaluates the program term by term"""
+    import itertools
+    O = oracle
+    V = O.air_var
+    width, log_n = 48, 7
+    cons = [(O.SEL_FIRST, [(1, [V(0)]), (P - 1, [V(0, public=True)])]),
+            (O.SEL_TRANSITION, [(1, [V(0, True)]), (P - 1, [V(0)]), (P - 1, [])])]
+    for i, j, k in itertools.islice(itertools.combinations(range(width), 3), n_monomials):
+        cons.append((O.SEL_ALL, [(5, [V(i), V(j), V(k, (i + j) % 3 == 0)]), (P - 5, [V(k, (i + j) % 3 == 0), V(i), V(j)])]))
+    prog = O.air_program(width, 1, cons)
+    rng = np.random.default_rng(n_monomials)
+    n = 1 << log_n
+    t = rng.integers(0, P, (n, width)).astype(np.uint64)
+    t[:, 0] = (11 + np.arange(n)) % P
+    t = t.astype(np.uint32)
+    alpha = [3, 1, 4, 1]
+    lde = ctx.coset_lde(ctx.from_numpy(t), log_n, width)
+    got = ctx.quotient_values_air(prog, lde, log_n, width, [11], alpha).download().reshape(-1, 4)
+    assert (got == O.quotient_values_air(prog, lde.download().reshape(-1, width), log_n, [11], alpha)).all()
+    # and a whole proof through that path
+    prm = Params(1, 6, 4)
+    proof = ctx.prove_shard_air(prog, ctx.from_numpy(t), log_n, width, [11], prm)
+    assert proof.tobytes() == O.prove_shard_air(prog, t, [11], O.default_params(1, 6, 4)).tobytes()
