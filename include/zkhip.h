@@ -20,6 +20,17 @@
  *   zkhip_prove_sha256 / zkhip_verify_sha256, zkhip_sha256_gen_trace, zkhip_range_table
  *       one real chip on that path -- SHA-256 compression, the hash of the transcripts the guest checks (upstream: the
  *       ShaExtend / ShaCompress chips of sp1-core-machine, Cargo.lock:5822) -- with its trace generated on the device.
+ *   zkhip_machine_setup / zkhip_prove_machine_keyed / zkhip_verify_machine_keyed, zkhip_sha256_setup / zkhip_prove_sha256_machine
+ *       `let (pk, vk) = client.setup(guest_program)` (sp1.rs:113) and the prove / verify calls that take pk / vk (:116, :120): the
+ *       chips' preprocessed columns committed once (sp1-stark StarkMachine::setup, Cargo.lock:6172), proofs opened against that key.
+ *   zkhip_prove_transcripts, zkhip_prove_sha256_sharded / zkhip_verify_sha256_sharded
+ *       the reference's batch and large-transcript configurations (BASELINE.json configs[2], configs[3]) with a real statement per proof:
+ *       many transcripts, or the shards of one long message, dealt over the GPUs of the node by one call.
+ *   zkhip_p2chip_air, zkhip_prove_merkle_paths / zkhip_verify_merkle_paths
+ *       a second real chip -- the Poseidon2 permutation with Merkle-path / leaf-hash chaining, what the recursion stages behind
+ *       SP1ProofMode::Groth16 (sp1.rs:116) spend their rows on (sp1-recursion's Poseidon2 chips, Cargo.lock:6172 ff.).
+ *   zkhip_proof_to_bincode / zkhip_chips_proof_to_bincode (+ _from_bincode)
+ *       what `prover_output.bytes()` carries (sp1.rs:122-123): bincode-shaped forms of the proofs ([RECALLED] field order).
  *   zkhip_prove_segment
  *       the span crates/guest-prover-r0/src/prover.rs:88-93 times, from RISC Zero's column-major Hal layout.
  *   zkhip_prove_shard_host, zkhip_prove_shards, zkhip_prove_shards_multi, zkhip_commit
