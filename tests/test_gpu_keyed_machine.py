@@ -198,3 +198,29 @@ def test_a_batch_of_transcripts_in_one_call(ctx, oracle):
     from zktls_amd._lib import ZkHipError
     with pytest.raises(ZkHipError):
         prove_transcripts([b"ok", bytes((1 << 20) + 1), b"fine"], prm, devices=[0], in_flight=2)
+
+
+def test_a_key_of_tables_only_serves_machines_of_other_shapes(ctx, oracle):
+    """zkhip_prove_machine_keyed_at: the key holds ONE entry (the byte table); machines whose user chip is shorter or taller than the table
+    -- so that the table is the first chip or the second -- use it through an explicit assignment; bytes against the oracle either way"""
+    O = oracle
+    prm, oprm = Params(1, 6, 4), O.default_params(1, 6, 4)
+    _, pre7, _, _, _ = M.byte_machine(7, 3)
+    table_pre = [p for p in pre7 if p is not None][0]
+    key = ctx.machine_setup([(ctx.from_numpy(table_pre), 6, 4)], prm)             # one entry: the 2^6-row table's preprocessed columns
+    for log_users in (5, 6, 9):
+        traces, pre, progs, tables, pub = M.byte_machine(log_users, 3)
+        lns, ws, pws = shape_of(traces, pre)
+        entries = [-1 if p is None else 0 for p in pre]
+        chips = [(ctx.from_numpy(t), ln, w) for t, ln, w in zip(traces, lns, ws)]
+        assert key.root.tolist() == O.machine_setup(pre, lns, oprm).tolist()      # the commitment does not depend on the other chips
+        proof = ctx.prove_machine_keyed(key, chips, progs, tables, pub, prm, key_entries=entries)
+        assert proof.tobytes() == O.prove_machine_keyed(traces, pre, progs, tables, pub, oprm).tobytes(), log_users
+        assert verify_machine_keyed(proof, lns, ws, pws, key.root, progs, tables, pub, prm) == (0, 0)
+    # an assignment that leaves the table out, uses it twice, or gives it to a chip of another height
+    traces, pre, progs, tables, pub = M.byte_machine(9, 3)
+    lns, ws, pws = shape_of(traces, pre)
+    chips = [(ctx.from_numpy(t), ln, w) for t, ln, w in zip(traces, lns, ws)]
+    for bad in ([-1, -1], [0, 0], [0, -1], [3, -1]):
+        with pytest.raises(ZkHipError):
+            ctx.prove_machine_keyed(key, chips, progs, tables, pub, prm, key_entries=bad)

@@ -529,23 +529,33 @@ class Context:
         check(self.lib.zkhip_machine_setup(self.handle, arr, n, C.byref(params), C.byref(handle), root.ctypes.data_as(u32p)))
         return MachineKey(self, handle, root, [int(c[2]) for c in pre_chips])
 
-    def prove_machine_keyed(self, key, chips, programs, tables, public_values=(), params=None):
+    def prove_machine_keyed(self, key, chips, programs, tables, public_values=(), params=None, key_entries=None):
         """a machine with preprocessed columns (proof version 11): `key` from machine_setup; chips as in prove_machine (main columns);
-        programs / tables address the combined row [preprocessed | main]"""
+        programs / tables address the combined row [preprocessed | main].  key_entries: per chip the key entry it uses (-1: none) when the
+        key holds tables only (zkhip_prove_machine_keyed_at); its preprocessed widths then come from the entries"""
         params = params or Params(1, 100, 16, 0)
         n = len(chips)
         arr = (_lib.Chip * n)(*[_lib.Chip(b.ptr, w, ln, w, 0, -1) for b, ln, w in chips])
         log_ns = (C.c_int32 * n)(*[c[1] for c in chips])
         widths = (C.c_uint32 * n)(*[c[2] for c in chips])
-        pws = (C.c_uint32 * n)(*(list(key.pre_widths) + [0] * n)[:n])      # (a key of another shape is the library's to refuse)
+        if key_entries is not None:
+            per_chip = [key.pre_widths[e] if 0 <= e < len(key.pre_widths) else 0 for e in key_entries]
+        else:
+            per_chip = (list(key.pre_widths) + [0] * n)[:n]                  # (a key of another shape is the library's to refuse)
+        pws = (C.c_uint32 * n)(*per_chip)
         kp, pp, pw = _program_table(programs)
         kt, tp, tw = _program_table(tables)
         pv = np.ascontiguousarray(np.array(public_values, dtype=np.uint32))
         size = self.lib.zkhip_machine_proof_size_keyed(log_ns, widths, pws, pp, pw, tp, tw, n, C.byref(params), pv.size)
         buf = np.empty(max(size, 1), dtype=np.uint8)
         got = C.c_size_t(0)
-        check(self.lib.zkhip_prove_machine_keyed(self.handle, key.handle, arr, pp, pw, tp, tw, n, pv.ctypes.data_as(u32p), pv.size, C.byref(params),
-                                                 buf.ctypes.data_as(u8p), size, C.byref(got)))
+        if key_entries is not None:
+            ke = (C.c_int32 * n)(*[int(e) for e in key_entries])
+            check(self.lib.zkhip_prove_machine_keyed_at(self.handle, key.handle, ke, arr, pp, pw, tp, tw, n, pv.ctypes.data_as(u32p), pv.size, C.byref(params),
+                                                        buf.ctypes.data_as(u8p), size, C.byref(got)))
+        else:
+            check(self.lib.zkhip_prove_machine_keyed(self.handle, key.handle, arr, pp, pw, tp, tw, n, pv.ctypes.data_as(u32p), pv.size, C.byref(params),
+                                                     buf.ctypes.data_as(u8p), size, C.byref(got)))
         return buf[: got.value]
 
     def prove_debug(self):
