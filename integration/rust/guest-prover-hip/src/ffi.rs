@@ -119,6 +119,11 @@ extern "C" {
         tables: *const *const u32, table_words: *const usize, n_chips: c_int,
         public_values: *const u32, n_public: usize, prm: *const ZkhipParams, proof: *mut u8, cap: usize, len: *mut usize,
     ) -> c_int;
+    pub fn zkhip_prove_machine_keyed_at(
+        ctx: *mut ZkhipCtx, key: *const ZkhipMachineKey, key_entries: *const i32, chips: *const ZkhipChip, programs: *const *const u32,
+        program_words: *const usize, tables: *const *const u32, table_words: *const usize, n_chips: c_int,
+        public_values: *const u32, n_public: usize, prm: *const ZkhipParams, proof: *mut u8, cap: usize, len: *mut usize,
+    ) -> c_int;
     pub fn zkhip_verify_machine_keyed(
         proof: *const u8, len: usize, log_ns: *const i32, widths: *const u32, pre_widths: *const u32, root: *const u32,
         programs: *const *const u32, program_words: *const usize, tables: *const *const u32, table_words: *const usize, n_chips: c_int,
@@ -143,6 +148,17 @@ extern "C" {
     pub fn zkhip_prove_merkle_paths(
         ctx: *mut ZkhipCtx, leaves: *const u32, row_width: u32, siblings: *const u32, indices: *const u32, n_paths: usize, depth: c_int,
         root: *const u32, prm: *const ZkhipParams, proof: *mut u8, cap: usize, len: *mut usize,
+    ) -> c_int;
+    // SHA-256 of a message of any length as a chain of shard proofs dealt over the devices
+    pub fn zkhip_sha256_sharded_count(message_len: usize, log_blocks_per_shard: c_int) -> usize;
+    pub fn zkhip_sha256_shard_proof_size(log_blocks: c_int, prm: *const ZkhipParams) -> usize;
+    pub fn zkhip_prove_sha256_sharded(
+        devices: *const c_int, n_devices: c_int, message: *const u8, message_len: usize, log_blocks_per_shard: c_int, prm: *const ZkhipParams,
+        in_flight_per_device: c_int, digest: *mut u8, chain: *mut u32, proofs: *mut u8, proof_stride: usize, proof_lens: *mut usize,
+    ) -> c_int;
+    pub fn zkhip_verify_sha256_sharded(
+        proofs: *const u8, proof_stride: usize, proof_lens: *const usize, n_shards: usize, chain: *const u32, log_blocks_per_shard: c_int,
+        digest: *const u8, prm: *const ZkhipParams, bad_shard: *mut usize, reason: *mut c_int,
     ) -> c_int;
     pub fn zkhip_verify_merkle_paths(proof: *const u8, len: usize, root: *const u32, n_paths: usize, prm: *const ZkhipParams, reason: *mut c_int) -> c_int;
 }
