@@ -218,6 +218,24 @@ impl HipGuestProver {
             check(unsafe { ffi::zkhip_verify_sha256_machine(proof.as_ptr(), proof.len(), d.as_ptr(), vk.as_ptr() as *const u32, &prm, &mut reason) }, "zkhip_verify_sha256_machine")?;
             proofs.push(proof);
             (d.to_vec(), BATCH_FLAG_INPUT_SHA256 | BATCH_FLAG_KEYED)
+        } else if self.commitment && cbor.len() > (1usize << 20) - 9 && matches!(self.backend, Backend::Sp1) {
+            // a large transcript: SHA-256 as a CHAIN of shard proofs over the device list (as the C++ mirror): entry 0 of the blob
+            // holds the chaining values, entries 1..n the shards; blob flags INPUT_SHA256 | CHAINED
+            let k = 14;
+            let prm = self.params(20);
+            let n = unsafe { ffi::zkhip_sha256_sharded_count(cbor.len(), k) };
+            let stride = unsafe { ffi::zkhip_sha256_shard_proof_size(k, &prm) };
+            anyhow::ensure!(n > 0 && stride > 0, "input commitment: bad shard shape");
+            let (mut buf, mut lens, mut chain, mut d) = (vec![0u8; n * stride], vec![0usize; n], vec![0u32; (n + 1) * 8], [0u8; 32]);
+            let devices = [self.device];
+            check(unsafe { ffi::zkhip_prove_sha256_sharded(devices.as_ptr(), 1, cbor.as_ptr(), cbor.len(), k, &prm, 2, d.as_mut_ptr(), chain.as_mut_ptr(), buf.as_mut_ptr(), stride, lens.as_mut_ptr()) }, "zkhip_prove_sha256_sharded")?;
+            let (mut bad, mut reason) = (0usize, 0);
+            check(unsafe { ffi::zkhip_verify_sha256_sharded(buf.as_ptr(), stride, lens.as_ptr(), n, chain.as_ptr(), k, d.as_ptr(), &prm, &mut bad, &mut reason) }, "zkhip_verify_sha256_sharded")?;   // sp1.rs:120
+            proofs.push(chain.iter().flat_map(|w| w.to_le_bytes()).collect());
+            for s in 0..n {
+                proofs.push(buf[s * stride..s * stride + lens[s]].to_vec());
+            }
+            (d.to_vec(), BATCH_FLAG_INPUT_SHA256 | BATCH_FLAG_CHAINED)
         } else if self.commitment {
             // 64 rows per 64-byte block, block count (padding included) rounded up to a power of two
             let blocks = (cbor.len() + 9 + 63) / 64;
