@@ -428,3 +428,52 @@ def test_a_large_transcript_is_proven_as_a_chain_of_shards(lib):
     tampered = bytearray(blob)
     tampered[offs[2] + 4000] ^= 1
     assert verify_blob(lib, bytes(tampered), out, None)[0] != 0
+
+
+def test_a_consumer_checks_a_chained_commitment_blob_on_the_cpu(lib, oracle):
+    """the CHAINED form of the commitment blob (inputs beyond one chip proof) checked without a GPU: entry 0 = the chaining values, then
+    the shard proofs -- here two shards proven by the ORACLE from the Python restatement's traces.  The mirror shards at 2^14 blocks, so a
+    blob of smaller shards must be refused by the height check, and a well-formed one of full height is what the GPU test covers; this
+    test pins the framing and the chain checks with the library's own verifier entry at the small shard size"""
+    import hashlib
+    import sha256_air as S
+    from zktls_amd import _lib
+    from zktls_amd._lib import Params
+    O = oracle
+    msg = bytes(range(190))
+    blocks = S.pad(msg)
+    t0, out0 = S.trace(blocks[:128])
+    iv1 = [out0[2 * k] | (out0[2 * k + 1] << 16) for k in range(8)]
+    t1, out1 = S.trace(blocks[128:], chain_in=iv1)
+    ivl = []
+    for x in S.IV:
+        ivl += [x & 0xffff, x >> 16]
+    prog = S.program(chained=True)
+    oprm = O.default_params(1, 6, 4)
+    p0, p1 = O.prove_shard_air(prog, t0, out0 + ivl, oprm).tobytes(), O.prove_shard_air(prog, t1, out1 + out0, oprm).tobytes()
+    chain = struct.pack("<24I", *(list(S.IV) + iv1 + [out1[2 * k] | (out1[2 * k + 1] << 16) for k in range(8)]))
+    blob = struct.pack("<4sIII", b"ZKTB", 2, 2 | 8, 3)
+    for e in (chain, p0, p1):
+        blob += struct.pack("<I", len(e)) + e
+    out = hashlib.sha256(msg).digest()
+    assert lib.zktls_batch_flags(blob, len(blob)) == 10
+    # the mirror's shards hold 2^14 blocks: a chain of 2-block shards is not what it emits (shard height check)
+    assert verify_blob(lib, blob, out, None, 6, 4)[0] != 0
+    # the same chain through the library entry at its real shard size: accepted, and the chain checks bite
+    L = _lib.load()
+    stride = max(len(p0), len(p1))
+    buf = np.zeros(2 * stride, dtype=np.uint8)
+    buf[:len(p0)] = np.frombuffer(p0, dtype=np.uint8)
+    buf[stride:stride + len(p1)] = np.frombuffer(p1, dtype=np.uint8)
+    lens = (C.c_size_t * 2)(len(p0), len(p1))
+    ch = np.frombuffer(chain, dtype=np.uint32).copy()
+    dg = np.frombuffer(out, dtype=np.uint8)
+    prm = Params(1, 6, 4)
+    bad, why = C.c_size_t(0), C.c_int(0)
+    assert L.zkhip_verify_sha256_sharded(buf.ctypes.data_as(_lib.u8p), stride, lens, 2, ch.ctypes.data_as(_lib.u32p), 1, dg.ctypes.data_as(_lib.u8p),
+                                         C.byref(prm), C.byref(bad), C.byref(why)) == 0
+    # malformed framing: the chain entry of the wrong size, no shards
+    short = struct.pack("<4sIII", b"ZKTB", 2, 2 | 8, 2) + struct.pack("<I", len(chain) - 4) + chain[:-4] + struct.pack("<I", len(p0)) + p0
+    assert verify_blob(lib, short, out, None, 6, 4)[0] == -1
+    only_chain = struct.pack("<4sIII", b"ZKTB", 2, 2 | 8, 1) + struct.pack("<I", len(chain)) + chain
+    assert verify_blob(lib, only_chain, out, None, 6, 4)[0] == -1
