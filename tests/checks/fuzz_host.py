@@ -1,5 +1,5 @@
 """Malformed input against every HOST entry that takes untrusted bytes (verifiers, program / table validators, the bincode reader).
-Nothing may crash or read out of bounds: run it against the AddressSanitizer build (tools/asan_cpu.sh).  usage: fuzz_host.py [seconds]"""
+Nothing may crash or read out of bounds: run it against the AddressSanitizer build (tests/checks/asan_cpu.sh).  usage: fuzz_host.py [seconds]"""
 import ctypes as C
 import hashlib
 import os
@@ -8,7 +8,7 @@ import time
 
 import numpy as np
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path[:0] = [ROOT, os.path.join(ROOT, "tests")]
 import zktls_amd._lib as _lib
 if os.environ.get("ZKHIP_FUZZ_LIB"):                       # the sanitizer build (this tool only; the package never reads the environment)

@@ -1,7 +1,9 @@
 """exploration: a long pseudo-random sweep on the GPU -- every proof must equal the oracle's bytes and verify.
-usage: python tools/soak_random.py [seconds]"""
+usage: python tests/checks/soak_random.py [seconds]"""
 import sys, time
-sys.path.insert(0, "/root/repo"); sys.path.insert(0, "/root/repo/tests")
+import os
+_ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, _ROOT); sys.path.insert(0, os.path.join(_ROOT, "tests"))
 import numpy as np
 import oracle_lib as O
 import airs

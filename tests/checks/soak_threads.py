@@ -1,7 +1,9 @@
 """exploration: four host threads, each with its own context, proving shards of DIFFERENT random shapes at the same time (HIP-graph
 re-capture, workspace growth and kernel launches interleave across threads); every proof must equal the oracle's bytes."""
 import sys, threading, time
-sys.path.insert(0, "/root/repo"); sys.path.insert(0, "/root/repo/tests")
+import os
+_ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, _ROOT); sys.path.insert(0, os.path.join(_ROOT, "tests"))
 import numpy as np
 import oracle_lib as O
 from zktls_amd.device import Context, verify_shard

@@ -65,11 +65,11 @@ def test_same_verdicts_with_and_without_the_batched_form(oracle):
 
 
 def test_malformed_input_fuzzer_runs():
-    """tools/fuzz_host.py (normally run under the sanitizer build, tools/asan_cpu.sh) for two seconds against the shipped library:
+    """tests/checks/fuzz_host.py (normally run under the sanitizer build, tests/checks/asan_cpu.sh) for two seconds against the shipped library:
     no crash, and the tool itself stays runnable"""
     import os
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    r = subprocess.run([sys.executable, os.path.join(root, "tools", "fuzz_host.py"), "2"], capture_output=True, text=True, timeout=300)
+    r = subprocess.run([sys.executable, os.path.join(root, "tests", "checks", "fuzz_host.py"), "2"], capture_output=True, text=True, timeout=300)
     assert r.returncode == 0 and "fuzz ok" in r.stdout, r.stdout + r.stderr
