@@ -769,7 +769,7 @@ __global__ void __launch_bounds__(PERM_BLOCK) perm_rows_kernel(PermArgs a, uint3
             const Ext ds = ext_add(ext_add_base(a.gamma, vs.x), ext_mul_base_dev(a.beta, vs.y));
             const Ext dr = ext_add(ext_add_base(a.gamma, vr.x), ext_mul_base_dev(a.beta, vr.y));
             // 1/ds - 1/dr = (dr - ds) / (ds dr): one extension inversion per pair instead of two (an inversion costs about six
-            // extension products).  A zero denominator (1/0 = 0 by the oracle's convention) takes the direct formula.
+            // extension products).  A zero denominator (1/0 = 0 by the protocol convention) takes the direct formula.
             const Ext d = ext_mul_dev(ds, dr);
             const Ext phi = ext_eq(d, ext_zero()) ? ext_sub(ext_inv_dev(ds), ext_inv_dev(dr)) : ext_mul_dev(ext_sub(dr, ds), ext_inv_dev(d));
             st_ext(prow + 4 * q, phi);
