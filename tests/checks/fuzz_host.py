@@ -1,5 +1,5 @@
 """Malformed input against every HOST entry that takes untrusted bytes (verifiers, program / table validators, the bincode reader).
-Nothing may crash or read out of bounds: run it against the AddressSanitizer build (tests/checks/asan_cpu.sh).  usage: fuzz_host.py [seconds]"""
+Nothing may crash or read out of bounds: run it against the AddressSanitizer build (tools/asan_cpu.sh).  usage: fuzz_host.py [seconds]"""
 import ctypes as C
 import hashlib
 import os

@@ -65,7 +65,7 @@ def test_same_verdicts_with_and_without_the_batched_form(oracle):
 
 
 def test_malformed_input_fuzzer_runs():
-    """tests/checks/fuzz_host.py (normally run under the sanitizer build, tests/checks/asan_cpu.sh) for two seconds against the shipped library:
+    """tests/checks/fuzz_host.py (normally run under the sanitizer build, tools/asan_cpu.sh) for two seconds against the shipped library:
     no crash, and the tool itself stays runnable"""
     import os
     import subprocess

@@ -1,12 +1,12 @@
 #!/bin/bash
 # AddressSanitizer on the HOST code of libzkhip (verifiers, validators, serialisation, argument checks): builds
 # zktls_amd/libzkhip_asan.so (host objects built with the address sanitizer, device objects as shipped; GPU ASan is not available on this
-# pool) and runs the CPU test files that exercise host entries plus tests/checks/fuzz_host.py against it.  usage: tests/checks/asan_cpu.sh [fuzz seconds]
+# pool) and runs the CPU test files that exercise host entries plus tests/checks/fuzz_host.py against it.  usage: tools/asan_cpu.sh [fuzz seconds]
 # ThreadSanitizer over the threaded verifiers: make -C zktls_amd/csrc -f asan.mk asan SAN=-fsanitize=thread ASAN_OUT=../libzkhip_tsan.so
 # (after rm -rf zktls_amd/csrc/build/asan), then the same python command with LD_PRELOAD=libclang_rt.tsan and that library: the only
 # reports come from the oracle's OpenMP runtime (libgomp is not instrumented), none from libzkhip.
 set -e
-cd "$(dirname "$0")/../.."
+cd "$(dirname "$0")/.."
 make -C zktls_amd/csrc -j8 > /dev/null
 make -C zktls_amd/csrc -f asan.mk asan
 RT=$(/opt/rocm/lib/llvm/bin/clang -print-file-name=libclang_rt.asan-x86_64.so)

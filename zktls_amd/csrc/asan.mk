@@ -1,4 +1,4 @@
-# Sanitizer build of the HOST code of libzkhip (CPU only; tests/checks/asan_cpu.sh drives it: make -f asan.mk).  Kept out of the Makefile and
+# Sanitizer build of the HOST code of libzkhip (CPU only; tools/asan_cpu.sh drives it: make -f asan.mk).  Kept out of the Makefile and
 # listed in .gpurunignore: GPU sanitizer builds are not available on the pool, and nothing on the GPU box needs this file.
 include Makefile
 SAN = -fsanitize=address

@@ -422,9 +422,17 @@ int op_merkle_commit(zkhip_ctx* ctx, const MatDesc* mats, int nmats, int log_h, 
     LeafArgs la{};
     for (int m = 0; m < nmats; m++) la.mats[m] = mats[m];
     la.nmats = nmats; la.height = (uint64_t)1 << log_h; la.digests = tree;
-    ZK_HIP(launch_hash_rows(la, ctx->stream));
     uint32_t* level = tree;
     uint64_t count = la.height;
+    if (count > COOP_TOP_NODES && count <= COOP_MAX_NODES) {
+        // a medium tree: the workgroups that walk the subtrees hash their own leaves first (one launch less than leaves + subtrees + top)
+        const uint32_t rest = count >= 4096 ? 128u : 32u;
+        ZK_HIP(launch_hash_sub(la, (uint32_t)count / rest, ctx->stream));
+        for (uint64_t c = count; c > rest; c >>= 1) level += 8 * c;
+        ZK_HIP(launch_compress_top(level, rest, ctx->stream));
+        return ZKHIP_OK;
+    }
+    ZK_HIP(launch_hash_rows(la, ctx->stream));
     while (count > COOP_TOP_NODES) {
         if (count <= COOP_MAX_NODES) {
             // medium levels: one launch reduces the level to `rest` nodes (each workgroup walks its own subtree), one more finishes.

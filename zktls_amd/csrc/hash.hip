@@ -36,6 +36,7 @@ __global__ void hash_rows16_kernel(LeafArgs a, uint32_t total_w);
 __global__ void compress_level16_kernel(const uint32_t* __restrict__ children, uint32_t* __restrict__ parents, uint32_t count);
 __global__ void compress_top16_kernel(uint32_t* tree, uint32_t count);
 __global__ void compress_sub16_kernel(uint32_t* tree, uint32_t count, uint32_t sub);
+__global__ void hash_sub16_kernel(LeafArgs a, uint32_t total_w, uint32_t sub);
 
 __global__ void __launch_bounds__(256) hash_rows_generic_kernel(LeafArgs a, uint32_t total_w) {
     const uint64_t row = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -167,6 +168,14 @@ hipError_t launch_compress_top(uint32_t* tree, uint32_t count, hipStream_t s) {
     return hipGetLastError();
 }
 
+hipError_t launch_hash_sub(const LeafArgs& a, uint32_t sub, hipStream_t s) {
+    if (sub < 2 || (sub & (sub - 1)) || a.height % sub || a.height > COOP_MAX_NODES || a.nmats < 1 || a.nmats > MAX_LEAF_MATS) return hipErrorInvalidValue;
+    uint32_t total = 0;
+    for (int m = 0; m < a.nmats; m++) total += a.mats[m].width;
+    unsigned threads = sub * 8 < 64 ? 64 : (sub * 8 > 1024 ? 1024 : sub * 8);
+    hipLaunchKernelGGL(hash_sub16_kernel, dim3((unsigned)(a.height / sub)), dim3(threads), 0, s, a, total, sub);
+    return hipGetLastError();
+}
 hipError_t launch_compress_sub(uint32_t* tree, uint32_t count, uint32_t sub, hipStream_t s) {
     if (sub < 2 || (sub & (sub - 1)) || count % sub || count > COOP_MAX_NODES) return hipErrorInvalidValue;
     unsigned threads = sub * 8 < 64 ? 64 : (sub * 8 > 1024 ? 1024 : sub * 8);
@@ -258,6 +267,38 @@ __global__ void __launch_bounds__(1024) compress_sub16_kernel(uint32_t* tree, ui
     const CoopConsts k = coop_load_consts(lane16);
     uint32_t* level = tree;
     uint32_t n = count, mine = sub;                       // nodes in the level, nodes of this workgroup in it
+    while (mine > 1) {
+        uint32_t* next = level + 8 * (size_t)n;
+        const size_t in0 = (size_t)blockIdx.x * mine, out0 = (size_t)blockIdx.x * (mine / 2);
+        for (uint32_t i = grp; i < mine / 2; i += ngrp) {
+            const uint32_t x = coop_permute(level[16 * (in0 / 2 + i) + lane16], lane16, k);
+            if (lane16 < 8) next[8 * (out0 + i) + lane16] = x;
+        }
+        __threadfence_block();
+        __syncthreads();
+        level = next; n >>= 1; mine >>= 1;
+    }
+}
+// The same with the LEAVES hashed by the workgroup that owns them: a medium tree (512 < leaves <= 16 384: the FRI layers, the trees of small
+// proofs) is one launch less -- workgroup b hashes rows [b sub, (b + 1) sub) into the leaf level (one row per 16 lanes, as
+// hash_rows16_kernel) and walks its subtree from there.
+__global__ void __launch_bounds__(1024) hash_sub16_kernel(LeafArgs a, uint32_t total_w, uint32_t sub) {
+    const int lane16 = threadIdx.x & 15;
+    const uint32_t grp = threadIdx.x >> 4, ngrp = blockDim.x >> 4;
+    const CoopConsts k = coop_load_consts(lane16);
+    for (uint32_t i = grp; i < sub; i += ngrp) {
+        const uint64_t row = (uint64_t)blockIdx.x * sub + i;
+        uint32_t x = 0;
+        for (uint32_t q = 0; q < total_w; q += 8) {
+            if (lane16 < 8 && q + lane16 < total_w) x = load_virtual(a, row, q + lane16);
+            x = coop_permute(x, lane16, k);
+        }
+        if (lane16 < 8) a.digests[row * 8 + lane16] = x;
+    }
+    __threadfence_block();
+    __syncthreads();
+    uint32_t* level = a.digests;
+    uint32_t n = (uint32_t)a.height, mine = sub;
     while (mine > 1) {
         uint32_t* next = level + 8 * (size_t)n;
         const size_t in0 = (size_t)blockIdx.x * mine, out0 = (size_t)blockIdx.x * (mine / 2);

@@ -115,6 +115,8 @@ hipError_t launch_inject(uint32_t* nodes, const uint32_t* extra, uint64_t count,
 hipError_t launch_compress_top(uint32_t* tree, uint32_t count, hipStream_t s);
 // log2(sub) levels of a medium tree (count <= COOP_MAX_NODES) in one launch: every workgroup reduces `sub` consecutive digests to one
 hipError_t launch_compress_sub(uint32_t* tree, uint32_t count, uint32_t sub, hipStream_t s);
+// the leaf digests AND log2(sub) levels of a medium tree (height <= COOP_MAX_NODES) in one launch: workgroup b hashes the rows it owns
+hipError_t launch_hash_sub(const LeafArgs& a, uint32_t sub, hipStream_t s);
 // RISC Zero layout: column-major [cols][rows], Poseidon2 width 24 (rate 16); full tree, leaves first
 hipError_t launch_merkle_p24_colmajor(const uint32_t* mat, uint32_t cols, int log_rows, uint32_t* tree, hipStream_t s);
 // same hash over a row-major matrix (width % 4 == 0, ld % 4 == 0, 16-byte aligned)
