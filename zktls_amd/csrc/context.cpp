@@ -474,6 +474,7 @@ int op_merkle_commit_mixed(zkhip_ctx* ctx, const MatDesc* mats, const int* log_h
     };
     LeafArgs la;
     if (!gather(log_h, la)) return fail(ZKHIP_ERR_INVALID, "merkle_commit_mixed: at most 8 matrices per height");
+    if (la.nmats == nmats) return op_merkle_commit(ctx, la.mats, nmats, log_h, tree);      // one height: a plain commitment (and its fused launches)
     la.digests = tree;
     ZK_HIP(launch_hash_rows(la, ctx->stream));
     uint32_t* level = tree;
