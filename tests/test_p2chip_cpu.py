@@ -145,3 +145,39 @@ def test_golden_program_digest_and_proof(oracle):
     pf = oracle.prove_shard_air(A.program(), trace, root + [g["paths"][1]], oracle.default_params(*g["params"]))
     assert pf.size == g["bytes"] and hashlib.sha256(pf.tobytes()).hexdigest() == g["sha256"]
     assert verify_merkle_paths(pf, root, g["paths"][1], Params(*g["params"])) == (0, 0)
+
+
+def test_the_python_verifier_accepts_the_chips_proofs(oracle):
+    """the third, independent verifier (tests/pyverify.py, written from DESIGN.md) on proofs of the two real chips' NEW forms: the Poseidon2
+    chip with leaf hashing, and a shard of the chained SHA-256 chip -- both are version-7 proofs of a constraint program"""
+    import pyverify
+    import sha256_air as S
+    O = oracle
+    shape = (1, 3, 2)
+    oprm = O.default_params(*shape)
+    # Poseidon2 chip: two openings of whole rows
+    rng = np.random.default_rng(2)
+    rows_ = [[int(v) for v in rng.integers(0, P, 16)] for _ in range(4)]
+    import pyref
+    level = [pyref.sponge_hash(r) for r in rows_]
+    l1 = [pyref.compress(level[0], level[1]), pyref.compress(level[2], level[3])]
+    root = pyref.compress(l1[0], l1[1])
+    idx = [2, 1]
+    sibs = [[level[i ^ 1], l1[(i >> 1) ^ 1]] for i in idx]
+    trace, roots = A.merkle_trace([rows_[i] for i in idx], sibs, idx, hashed_rows=True)
+    assert all(r == root for r in roots)
+    proof = O.prove_shard_air(A.program(), trace, root + [2], oprm)
+    assert pyverify.verify(proof.tobytes(), 5, A.WIDTH, root + [2], *shape, air=A.program()) is True
+    with pytest.raises(pyverify.Reject):
+        pyverify.verify(proof.tobytes(), 5, A.WIDTH, root + [3], *shape, air=A.program())
+    # chained SHA-256 chip: the second shard of a two-shard message
+    blocks = S.pad(bytes(range(100)))
+    assert len(blocks) == 128
+    t0, out0 = S.trace(blocks[:64])
+    iv1 = [out0[2 * k] | (out0[2 * k + 1] << 16) for k in range(8)]
+    t1, out1 = S.trace(blocks[64:], chain_in=iv1)
+    prog = S.program(chained=True)
+    p1 = O.prove_shard_air(prog, t1, out1 + out0, oprm)
+    assert pyverify.verify(p1.tobytes(), 6, S.WIDTH, out1 + out0, *shape, air=prog) is True
+    with pytest.raises(pyverify.Reject):
+        pyverify.verify(p1.tobytes(), 6, S.WIDTH, out1 + [(out0[0] + 1) % P] + out0[1:], *shape, air=prog)
