@@ -773,24 +773,43 @@ int zkhip_verify_sha256_sharded(const uint8_t* proofs, size_t proof_stride, cons
         if (chain[8 * n_shards + i] != w) return reject(n_shards - 1, 1, "verify_sha256_sharded: the chain does not end in the digest");
     }
     const std::vector<uint32_t>& prog = sha::program_chained();
-    for (size_t s = 0; s < n_shards; s++) {
-        const uint8_t* pf = proofs + s * proof_stride;
-        if (proof_lens[s] < 16 || proof_lens[s] > proof_stride) return reject(s, 2, "verify_sha256_sharded: bad proof length");
-        uint32_t head[4];
-        std::memcpy(head, pf, 16);
-        const int log_n = (int)head[2];
-        const bool last = s + 1 == n_shards;
-        if (log_n < 6 || log_n > 20 || (!last && log_n != 6 + log_blocks_per_shard) || (last && log_n > 6 + log_blocks_per_shard))
-            return reject(s, 3, "verify_sha256_sharded: a shard has the wrong height");
-        uint32_t pv[32];
-        chain_limbs(chain + 8 * s, chain + 8 * (s + 1), pv);
-        int why = 0;
-        if (zkhip_verify_shard_air(prog.data(), prog.size(), pf, proof_lens[s], log_n, sha::WIDTH, pv, 32, prm, &why) != ZKHIP_OK) {
-            if (bad_shard) *bad_shard = s;
-            if (reason) *reason = why;
-            return ZKHIP_ERR_VERIFY;
+    // the shards are independent: a few host threads take them in turn (each verification spreads its queries over threads of its own);
+    // the verdict is that of the LOWEST failing shard, whatever the order the threads finished in
+    std::vector<int> rc(n_shards, ZKHIP_OK), why(n_shards, 0);
+    std::vector<std::string> msg(n_shards);
+    std::atomic<size_t> next{0};
+    auto work = [&]() {
+        for (;;) {
+            const size_t s = next.fetch_add(1);
+            if (s >= n_shards) return;
+            const uint8_t* pf = proofs + s * proof_stride;
+            auto bad = [&](int w, const char* m) { rc[s] = ZKHIP_ERR_VERIFY; why[s] = w; msg[s] = m; };
+            if (proof_lens[s] < 16 || proof_lens[s] > proof_stride) { bad(2, "verify_sha256_sharded: bad proof length"); continue; }
+            uint32_t head[4];
+            std::memcpy(head, pf, 16);
+            const int log_n = (int)head[2];
+            const bool last = s + 1 == n_shards;
+            if (log_n < 6 || log_n > 20 || (!last && log_n != 6 + log_blocks_per_shard) || (last && log_n > 6 + log_blocks_per_shard)) {
+                bad(3, "verify_sha256_sharded: a shard has the wrong height");
+                continue;
+            }
+            uint32_t pv[32];
+            chain_limbs(chain + 8 * s, chain + 8 * (s + 1), pv);
+            int w = 0;
+            if (zkhip_verify_shard_air(prog.data(), prog.size(), pf, proof_lens[s], log_n, sha::WIDTH, pv, 32, prm, &w) != ZKHIP_OK) { rc[s] = ZKHIP_ERR_VERIFY; why[s] = w; msg[s] = zkhip_last_error(); }
         }
-    }
+    };
+    const size_t nt = n_shards < 4 ? n_shards : 4;
+    std::vector<std::thread> pool;
+    for (size_t t = 1; t < nt; t++) pool.emplace_back(work);
+    work();
+    for (auto& t : pool) t.join();
+    for (size_t s = 0; s < n_shards; s++)
+        if (rc[s] != ZKHIP_OK) {
+            if (bad_shard) *bad_shard = s;
+            if (reason) *reason = why[s];
+            return fail(ZKHIP_ERR_VERIFY, msg[s]);
+        }
     return ZKHIP_OK;
 }
 
