@@ -186,6 +186,15 @@ int zkhip_coset_lde(zkhip_ctx* ctx, const uint32_t* d_in, size_t in_ld, uint32_t
  * strided bit-reversed stores), 5 = second forward pass (contiguous, in place); d_out is ignored, d_in only read by 2. */
 int zkhip_ntt_pass(zkhip_ctx* ctx, const uint32_t* d_in, uint32_t* d_out, size_t ld, int log_n,
                    uint32_t width, int which);
+/* The launches of the trace LDE as the prover enqueues them TODAY for 2^20 rows x a multiple of 32 columns (same workspaces as
+ * which = 2..5 above): which = 6 first inverse pass in its block form (strided in -> one contiguous block per tile), 7 the FUSED
+ * middle launch (second inverse pass + first forward pass of both cosets of a blowup-2 LDE: reads the blocks once, writes both
+ * cosets; 12 B per trace cell), 5 the second forward pass of a coset.  One LDE = 6, 7, 5, 5 (36 B per trace cell; the unfused
+ * sequence 2, 3, 4, 5, 4, 5 moves 48 B and remains in use for every other shape). */
+/* LDE fusion switch of a context (default 1 = on where the shape allows): 0 forces the unfused four-pass sequence everywhere.
+ * Returns the previous setting, or a negative status.  Both settings produce bit-identical matrices (tests/test_gpu_parity.py);
+ * the switch exists for that test and for A/B timing. */
+int zkhip_ctx_set_lde_fusion(zkhip_ctx* ctx, int on);
 
 /* ---- commit: the PCS `commit` of one trace matrix in a single call (p3-fri TwoAdicFriPcs::commit, reference
  * Cargo.lock:3930; RISC Zero `commit_group`): coset LDE on shift * <w_{N 2^b}> (bit-reversed rows) into d_lde

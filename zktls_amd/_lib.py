@@ -17,7 +17,7 @@ u8p = C.POINTER(C.c_uint8)
 
 EXPORTS = [
     "zkhip_version", "zkhip_last_error", "zkhip_device_count", "zkhip_ctx_create", "zkhip_ctx_destroy",
-    "zkhip_ctx_sync", "zkhip_ctx_stream", "zkhip_malloc", "zkhip_free", "zkhip_memcpy_h2d",
+    "zkhip_ctx_sync", "zkhip_ctx_set_lde_fusion", "zkhip_ctx_stream", "zkhip_malloc", "zkhip_free", "zkhip_memcpy_h2d",
     "zkhip_memcpy_d2h", "zkhip_to_monty", "zkhip_from_monty", "zkhip_fill_uniform", "zkhip_gen_trace",
     "zkhip_gen_trace_logup", "zkhip_gen_trace_logup_cross", "zkhip_perm_trace",
     "zkhip_dft", "zkhip_coset_lde", "zkhip_ntt_pass", "zkhip_poseidon2_permute", "zkhip_hash_rows",
@@ -104,6 +104,7 @@ def load():
     L.zkhip_ctx_destroy.argtypes = [C.c_void_p]
     L.zkhip_ctx_destroy.restype = None
     L.zkhip_ctx_sync.argtypes = [C.c_void_p]
+    L.zkhip_ctx_set_lde_fusion.argtypes = [C.c_void_p, C.c_int]
     L.zkhip_malloc.argtypes = [C.c_void_p, C.c_size_t, C.POINTER(C.c_void_p)]
     L.zkhip_free.argtypes = [C.c_void_p, C.c_void_p]
     L.zkhip_memcpy_h2d.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t]

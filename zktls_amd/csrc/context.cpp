@@ -93,7 +93,7 @@ int get_plan(zkhip_ctx* ctx, int log_n, int kind, uint32_t shift, const NttPlan*
     return ZKHIP_OK;
 }
 
-enum { LDE_I1 = 0, LDE_I2 = 1, LDE_F1 = 2, LDE_F2 = 3 };
+enum { LDE_I1 = 0, LDE_I2 = 1, LDE_F1 = 2, LDE_F2 = 3, LDE_I1_BLOCKS = 4 };
 
 static NttPassArgs base_args(zkhip_ctx* ctx, const uint32_t* in, size_t in_ld, uint32_t* out, size_t out_ld,
                              uint32_t width, bool inverse) {
@@ -204,13 +204,16 @@ int lde_pass_args(zkhip_ctx* ctx, int which, const uint32_t* in, size_t in_ld, u
     if (m1 == 0) return fail(ZKHIP_ERR_INTERNAL, "lde_pass_args: single-pass size");
     const uint64_t M1 = 1ull << m1, M2 = 1ull << m2;
     const NttPlan* p;
-    if (which == LDE_I1 || which == LDE_I2) {
+    if (which == LDE_I1 || which == LDE_I2 || which == LDE_I1_BLOCKS) {
         ZK_TRY(get_plan(ctx, log_n, 0, 0, &p));
         *inverse = true;
-        if (which == LDE_I1) {
+        if (which == LDE_I1 || which == LDE_I1_BLOCKS) {
             NttPassArgs a = base_args(ctx, in, in_ld, coef, coef_ld, width, true);
             a.num_tiles = (uint32_t)M1; a.log_m = (uint32_t)m2;
             a.in_tile_mul = 1; a.in_stride = M1; a.out_tile_mul = 1; a.out_stride = M1; a.post = p->post;
+            // in front of the fused middle launch a tile leaves as ONE contiguous block of the (private) workspace: the strided
+            // side of the transposition moves into the fused launch, which has the slack for it
+            if (which == LDE_I1_BLOCKS) { a.out_tile_mul = M2; a.out_stride = 1; }
             *out = a;
         } else {
             NttPassArgs b = base_args(ctx, coef, coef_ld, coef, coef_ld, width, true);
@@ -235,6 +238,68 @@ int lde_pass_args(zkhip_ctx* ctx, int which, const uint32_t* in, size_t in_ld, u
         b.num_tiles = (uint32_t)M2p; b.log_m = (uint32_t)m2;
         b.in_tile_mul = M1p; b.in_stride = 1; b.out_tile_mul = M1p; b.out_stride = 1; b.bitrev_out = 1;
         *out = b;
+    }
+    return ZKHIP_OK;
+}
+
+// The middle of a 2^20-row LDE as one launch (ntt_fused.hip): second inverse pass + first forward pass of two cosets, reading the
+// blocks LDE_I1_BLOCKS left (tile k1 = rows n2 * 1024 + k1) and writing what LDE_F1 would have written for each coset.
+static bool lde_fused_shape(int log_n, uint32_t width, size_t coef_ld, size_t out_ld, int cosets) {
+    return log_n == 20 && width % 32 == 0 && coef_ld % 2 == 0 && out_ld % 2 == 0 && cosets >= 2 && cosets % 2 == 0;
+}
+int lde_fused_args(zkhip_ctx* ctx, const uint32_t* coef, size_t coef_ld, uint32_t* const* dsts, size_t out_ld, int log_n, uint32_t width,
+                   const uint32_t* coset_shifts, LdeFusedArgs* out) {
+    int m1, m2;
+    split(log_n, &m1, &m2);
+    if (m1 != 10 || m2 != 10) return fail(ZKHIP_ERR_INTERNAL, "lde_fused_args: 1024 x 1024 transforms only");
+    LdeFusedArgs f{};
+    f.in = coef; f.in_ld = coef_ld; f.out_ld = out_ld; f.ncols = width; f.num_tiles = 1024;
+    f.in_tile_mul = 1; f.in_stride = 1024; f.out_tile_mul = 1; f.out_stride = 1024;
+    f.w1024_inv = ctx->w1024_inv; f.w1024_fwd = ctx->w1024_fwd;
+    for (int t = 0; t < FUSED_COSETS; t++) {
+        const NttPlan* p;
+        ZK_TRY(get_plan(ctx, log_n, 2, coset_shifts[t], &p));
+        f.out[t] = dsts[t]; f.pre[t] = p->pre; f.post[t] = p->post;
+    }
+#ifdef ZKHIP_AB_HOOKS
+    static const bool has_rot = getenv("ZKHIP_FUSED_ROT") != nullptr, has_grid = getenv("ZKHIP_FUSED_GRID") != nullptr;
+    if (has_rot) { const char* e = getenv("ZKHIP_FUSED_ROT"); f.map_rot = e ? (uint32_t)atoi(e) : 0u; }
+    if (has_grid) { const char* e = getenv("ZKHIP_FUSED_GRID"); f.grid = e ? (uint32_t)atoi(e) : 0u; }
+#endif
+    if (!lde_fused_supported(f)) return fail(ZKHIP_ERR_INTERNAL, "lde_fused_args: unsupported shape");
+    *out = f;
+    return ZKHIP_OK;
+}
+
+// A two-pass LDE (2^11 .. 2^20 rows) of one matrix onto `cosets` destinations with their shifts.  2^20 rows x a multiple of 32
+// columns, even coset count: I1 (strided in -> blocks), the fused middle launch per pair of cosets, F2 per coset = 36 B per
+// trace cell at blowup 2.  Everything else: I1, I2, and F1 + F2 per coset (48 B).
+static int lde_two_pass(zkhip_ctx* ctx, const uint32_t* in, size_t in_ld, uint32_t* coef, size_t coef_ld, uint32_t* const* dsts, size_t out_ld,
+                        int log_n, uint32_t width, const uint32_t* coset_shifts, int cosets, bool run_f2 = true) {
+    NttPassArgs a;
+    bool inv;
+    if (lde_fused_shape(log_n, width, coef_ld, out_ld, cosets) && ctx->lde_fusion) {
+        ZK_TRY(lde_pass_args(ctx, LDE_I1_BLOCKS, in, in_ld, coef, coef_ld, nullptr, 0, log_n, width, 0, &a, &inv));
+        ZK_HIP(launch_ntt_pass(a, inv, ctx->stream));
+        for (int t = 0; t < cosets; t += FUSED_COSETS) {
+            LdeFusedArgs f;
+            ZK_TRY(lde_fused_args(ctx, coef, coef_ld, dsts + t, out_ld, log_n, width, coset_shifts + t, &f));
+            ZK_HIP(launch_lde_fused(f, ctx->stream));
+        }
+    } else {
+        ZK_TRY(lde_pass_args(ctx, LDE_I1, in, in_ld, coef, coef_ld, nullptr, 0, log_n, width, 0, &a, &inv));
+        ZK_HIP(launch_ntt_pass(a, inv, ctx->stream));
+        ZK_TRY(lde_pass_args(ctx, LDE_I2, nullptr, 0, coef, coef_ld, nullptr, 0, log_n, width, 0, &a, &inv));
+        ZK_HIP(launch_ntt_pass(a, inv, ctx->stream));
+        for (int t = 0; t < cosets; t++) {
+            ZK_TRY(lde_pass_args(ctx, LDE_F1, nullptr, 0, coef, coef_ld, dsts[t], out_ld, log_n, width, coset_shifts[t], &a, &inv));
+            ZK_HIP(launch_ntt_pass(a, inv, ctx->stream));
+        }
+    }
+    if (!run_f2) return ZKHIP_OK;
+    for (int t = 0; t < cosets; t++) {
+        ZK_TRY(lde_pass_args(ctx, LDE_F2, nullptr, 0, coef, coef_ld, dsts[t], out_ld, log_n, width, coset_shifts[t], &a, &inv));
+        ZK_HIP(launch_ntt_pass(a, inv, ctx->stream));
     }
     return ZKHIP_OK;
 }
@@ -331,20 +396,25 @@ static int coset_lde_big(zkhip_ctx* ctx, const uint32_t* in, size_t in_ld, uint3
     ZK_HIP(launch_ntt_combine(c, ctx->stream));
     NttPassArgs a;
     bool inv;
-    for (uint64_t j = 0; j < R; j++) {       // class-j coefficients c[R q + j], left in the transposed order of the two-pass inverse
-        ZK_TRY(lde_pass_args(ctx, LDE_I1, (const uint32_t*)tmp + j * width, R * width, coef + j * width, R * width, nullptr, 0, BIG_INNER_LOG, width, 0, &a, &inv));
-        ZK_HIP(launch_ntt_pass(a, inv, ctx->stream));
-        ZK_TRY(lde_pass_args(ctx, LDE_I2, nullptr, 0, coef + j * width, R * width, nullptr, 0, BIG_INNER_LOG, width, 0, &a, &inv));
-        ZK_HIP(launch_ntt_pass(a, inv, ctx->stream));
-    }
+    const int B = 1 << log_blowup;
     const uint32_t wnb = two_adic_generator(log_n + log_blowup);
-    for (int t = 0; t < (1 << log_blowup); t++) {
-        const uint32_t st = fmul(shift, fpow(wnb, (uint64_t)t));
-        const uint32_t stR = fpow(st, R);
-        uint32_t* dst = out + (size_t)reverse_bits((uint32_t)t, log_blowup) * n * out_ld;
+    uint32_t st_all[16], stR_all[16];
+    uint32_t* dst_all[16];
+    for (int t = 0; t < B; t++) {
+        st_all[t] = fmul(shift, fpow(wnb, (uint64_t)t));
+        stR_all[t] = fpow(st_all[t], R);
+        dst_all[t] = out + (size_t)reverse_bits((uint32_t)t, log_blowup) * n * out_ld;
+    }
+    for (uint64_t j = 0; j < R; j++) {       // class j: coefficients c[R q + j] -> the first forward pass of every coset (no F2 yet)
+        uint32_t* dj[16];
+        for (int t = 0; t < B; t++) dj[t] = dst_all[t] + j * out_ld;
+        ZK_TRY(lde_two_pass(ctx, (const uint32_t*)tmp + j * width, R * width, coef + j * width, R * width, dj, R * out_ld, BIG_INNER_LOG, width,
+                            stR_all, B, /*run_f2=*/false));
+    }
+    for (int t = 0; t < B; t++) {
+        const uint32_t st = st_all[t], stR = stR_all[t];
+        uint32_t* dst = dst_all[t];
         for (uint64_t j = 0; j < R; j++) {
-            ZK_TRY(lde_pass_args(ctx, LDE_F1, nullptr, 0, coef + j * width, R * width, dst + j * out_ld, R * out_ld, BIG_INNER_LOG, width, stR, &a, &inv));
-            ZK_HIP(launch_ntt_pass(a, inv, ctx->stream));
             ZK_TRY(lde_pass_args(ctx, LDE_F2, nullptr, 0, coef + j * width, R * width, dst + j * out_ld, R * out_ld, BIG_INNER_LOG, width, stR, &a, &inv));
             ZK_HIP(launch_ntt_pass(a, inv, ctx->stream));
         }
@@ -399,21 +469,13 @@ int op_coset_lde(zkhip_ctx* ctx, const uint32_t* in, size_t in_ld, uint32_t* out
         }
         return ZKHIP_OK;
     }
-    NttPassArgs a;
-    bool inv;
-    ZK_TRY(lde_pass_args(ctx, LDE_I1, in, in_ld, coef, width, nullptr, 0, log_n, width, 0, &a, &inv));
-    ZK_HIP(launch_ntt_pass(a, inv, ctx->stream));
-    ZK_TRY(lde_pass_args(ctx, LDE_I2, nullptr, 0, coef, width, nullptr, 0, log_n, width, 0, &a, &inv));
-    ZK_HIP(launch_ntt_pass(a, inv, ctx->stream));
+    uint32_t* dsts[16];
+    uint32_t shifts[16];
     for (int t = 0; t < B; t++) {
-        const uint32_t st = fmul(shift, fpow(wnb, (uint64_t)t));
-        uint32_t* dst = out + (size_t)reverse_bits((uint32_t)t, log_blowup) * n * out_ld;
-        ZK_TRY(lde_pass_args(ctx, LDE_F1, nullptr, 0, coef, width, dst, out_ld, log_n, width, st, &a, &inv));
-        ZK_HIP(launch_ntt_pass(a, inv, ctx->stream));
-        ZK_TRY(lde_pass_args(ctx, LDE_F2, nullptr, 0, coef, width, dst, out_ld, log_n, width, st, &a, &inv));
-        ZK_HIP(launch_ntt_pass(a, inv, ctx->stream));
+        shifts[t] = fmul(shift, fpow(wnb, (uint64_t)t));
+        dsts[t] = out + (size_t)reverse_bits((uint32_t)t, log_blowup) * n * out_ld;
     }
-    return ZKHIP_OK;
+    return lde_two_pass(ctx, in, in_ld, coef, width, dsts, out_ld, log_n, width, shifts, B);
 }
 
 int op_merkle_commit(zkhip_ctx* ctx, const MatDesc* mats, int nmats, int log_h, uint32_t* tree) {
@@ -591,6 +653,12 @@ void zkhip_ctx_destroy(zkhip_ctx* ctx) {
         ZK_HIP(hipSetDevice((ctx)->device));                            \
     } while (0)
 
+int zkhip_ctx_set_lde_fusion(zkhip_ctx* ctx, int on) {
+    CHECK_CTX(ctx);
+    const int prev = ctx->lde_fusion ? 1 : 0;
+    ctx->lde_fusion = on != 0;
+    return prev;
+}
 int zkhip_ctx_sync(zkhip_ctx* ctx) { CHECK_CTX(ctx); ZK_HIP(hipStreamSynchronize(ctx->stream)); return ZKHIP_OK; }
 void* zkhip_ctx_stream(zkhip_ctx* ctx) { return ctx ? (void*)ctx->stream : nullptr; }
 
@@ -709,7 +777,32 @@ int zkhip_ntt_pass(zkhip_ctx* ctx, const uint32_t* d_in, uint32_t* d_out, size_t
         ZK_HIP(launch_ntt_pass(a, inv, ctx->stream));
         return ZKHIP_OK;
     }
-    if (which != 0 && which != 1) return fail(ZKHIP_ERR_INVALID, "ntt_pass: which must be 0 .. 5");
+    if (which == 6 || which == 7) {
+        // the block-form first inverse pass and the fused middle launch, on the same workspaces
+        if (width == 0 || ld < width || (which == 6 && !d_in)) return fail(ZKHIP_ERR_INVALID, "ntt_pass: bad arguments");
+        const size_t n = (size_t)1 << log_n;
+        if (!lde_fused_shape(log_n, width, width, width, 2)) return fail(ZKHIP_ERR_INVALID, "ntt_pass: which = 6, 7 take 2^20 rows x a multiple of 32 columns");
+        void *coef, *lde;
+        ZK_TRY(ctx_reserve(ctx, S_COEF, n * width * 4, &coef));
+        ZK_TRY(ctx_reserve(ctx, S_TLDE, 2 * n * width * 4, &lde));
+        if (which == 6) {
+            NttPassArgs a;
+            bool inv;
+            ZK_TRY(lde_pass_args(ctx, LDE_I1_BLOCKS, d_in, ld, (uint32_t*)coef, width, nullptr, 0, log_n, width, 0, &a, &inv));
+            a.bench_tag = 1;
+            ZK_HIP(launch_ntt_pass(a, inv, ctx->stream));
+            return ZKHIP_OK;
+        }
+        const uint32_t wnb = two_adic_generator(log_n + 1);
+        const uint32_t shifts[2] = {MONTY_GEN, fmul(MONTY_GEN, wnb)};
+        uint32_t* dsts[2] = {(uint32_t*)lde, (uint32_t*)lde + n * width};
+        LdeFusedArgs f;
+        ZK_TRY(lde_fused_args(ctx, (const uint32_t*)coef, width, dsts, width, log_n, width, shifts, &f));
+        f.bench_tag = 1;
+        ZK_HIP(launch_lde_fused(f, ctx->stream));
+        return ZKHIP_OK;
+    }
+    if (which != 0 && which != 1) return fail(ZKHIP_ERR_INVALID, "ntt_pass: which must be 0 .. 7");
     if (!d_in || !d_out || width == 0 || ld < width) return fail(ZKHIP_ERR_INVALID, "ntt_pass: bad arguments");
     const NttPlan* p;
     ZK_TRY(get_plan(ctx, log_n, 1, MONTY_R1, &p));

@@ -100,6 +100,7 @@ struct zkhip_ctx {
     std::deque<zk::ColPlan> col_plans;
     zk::DeviceBuffer scratch[zk::S_COUNT];   // grow-only workspaces, indexed by zk::Slot
     zkhip_prove_debug debug{};
+    bool lde_fusion = true;              // zkhip_ctx_set_lde_fusion: fused middle launch of 2^20-row LDEs (ntt_fused.hip)
     // domain tables (prover.cpp): the current set, and every set built so far (a multi-chip shard switches between
     // the sets of its chips' heights; sets are small and kept until the context goes away)
     struct DomainSet { int log_n, log_blowup; uint32_t *xs, *sel_first, *sel_last, *itw; };

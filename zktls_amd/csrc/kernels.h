@@ -39,6 +39,32 @@ struct NttPassArgs {
 };
 hipError_t launch_ntt_pass(const NttPassArgs& a, bool inverse, hipStream_t s);
 
+// ---- fused inverse-second / forward-first pass of a two-pass LDE with 1024-row tiles (ntt_fused.hip).  One workgroup reads a tile
+// once, finishes the inverse transform in registers (the coefficients never reach memory), and for each of TWO cosets t runs
+// the first forward pass on them:  out_t[k] = post_t[tile * 1024 + k] * NTT_1024( pre_t[n] * INTT_1024( in )[n] )[k].
+//   in row of tile element n     = tile * in_tile_mul + n * in_stride           (intermediate left by the first inverse pass)
+//   out_t row of tile element k  = tile * out_tile_mul + bitrev10(k) * out_stride
+// 12 B per tile element at two cosets (read 4, write 2 x 4) against 24 B for the three launches it replaces.
+constexpr int FUSED_COSETS = 2;           // cosets per launch (a blowup of 4 is two launches)
+struct LdeFusedArgs {
+    const uint32_t* in;
+    uint64_t in_ld, out_ld;
+    uint32_t ncols;                  // multiple of 32
+    uint32_t num_tiles;              // multiple of 8
+    uint32_t map_rot;                // tile index rotated by this many bits after the XCD-aware map (0: none)
+    uint32_t grid;                   // workgroups to launch (0: automatic = one per CU, walking the tile list); >= items: one tile each
+    uint32_t bench_tag;              // 1: launched by the roofline hook under its own kernel name
+    uint64_t in_tile_mul, in_stride;
+    uint64_t out_tile_mul, out_stride;
+    const uint32_t* w1024_inv;       // w_1024^-e
+    const uint32_t* w1024_fwd;       // w_1024^e
+    uint32_t* out[FUSED_COSETS];
+    const uint32_t* pre[FUSED_COSETS];    // [1024] each
+    const uint32_t* post[FUSED_COSETS];   // [num_tiles * 1024] each
+};
+hipError_t launch_lde_fused(const LdeFusedArgs& a, hipStream_t s);
+bool lde_fused_supported(const LdeFusedArgs& a);      // shape / alignment / 32-bit tile span
+
 // ---- native passes over CONTIGUOUS VECTORS (RISC Zero's Hal layout: `count` polynomials of 2^20 coefficients, column-major).
 // A polynomial is viewed as a 1024 x 1024 matrix A[r][c] = v[1024 r + c]; a pass transforms the 1024-point columns of 32
 // adjacent c at a time (the tile shape of ntt_pass_kernel<4, *, 2, 5>), and where the four-step transpose requires it the tile

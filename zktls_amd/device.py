@@ -83,6 +83,13 @@ class Context:
     def sync(self):
         check(self.lib.zkhip_ctx_sync(self.handle))
 
+    def set_lde_fusion(self, on):
+        """fused middle launch of 2^20-row LDEs on (default) / off; returns the previous setting"""
+        r = self.lib.zkhip_ctx_set_lde_fusion(self.handle, 1 if on else 0)
+        if r < 0:
+            check(r)
+        return bool(r)
+
     @property
     def stream(self):
         return self.lib.zkhip_ctx_stream(self.handle)
