@@ -255,11 +255,28 @@ int lde_fused_args(zkhip_ctx* ctx, const uint32_t* coef, size_t coef_ld, uint32_
     LdeFusedArgs f{};
     f.in = coef; f.in_ld = coef_ld; f.out_ld = out_ld; f.ncols = width; f.num_tiles = 1024;
     f.in_tile_mul = 1; f.in_stride = 1024; f.out_tile_mul = 1; f.out_stride = 1024;
-    f.w1024_inv = ctx->w1024_inv; f.w1024_fwd = ctx->w1024_fwd;
+    if (!ctx->w1024f_fwd) {
+        uint32_t *a = nullptr, *b = nullptr;
+        ZK_HIP(hipMalloc((void**)&a, 1024 * 4));
+        if (hipMalloc((void**)&b, 1024 * 4) != hipSuccess) { (void)hipFree(a); return fail(ZKHIP_ERR_HIP, "hipMalloc (fused twiddles)"); }
+        ctx->w1024f_fwd = a; ctx->w1024f_inv = b;
+        ZK_HIP(launch_fused_table(a, ctx->w1024_fwd, 1, 0, ctx->stream));
+        ZK_HIP(launch_fused_table(b, ctx->w1024_inv, 1, 0, ctx->stream));
+    }
+    f.w1024_inv = ctx->w1024f_inv; f.w1024_fwd = ctx->w1024f_fwd;
     for (int t = 0; t < FUSED_COSETS; t++) {
         const NttPlan* p;
         ZK_TRY(get_plan(ctx, log_n, 2, coset_shifts[t], &p));
-        f.out[t] = dsts[t]; f.pre[t] = p->pre; f.post[t] = p->post;
+        if (!p->post_f) {
+            NttPlan* mp = const_cast<NttPlan*>(p);       // plans live in the context's deque; the thread-order copies are filled in lazily
+            uint32_t *a = nullptr, *b = nullptr;
+            ZK_HIP(hipMalloc((void**)&a, 1024 * 4));
+            if (hipMalloc((void**)&b, (size_t)1024 * 1024 * 4) != hipSuccess) { (void)hipFree(a); return fail(ZKHIP_ERR_HIP, "hipMalloc (fused tables)"); }
+            mp->pre_f = a; mp->post_f = b;
+            ZK_HIP(launch_fused_table(a, p->pre, 1, 1, ctx->stream));
+            ZK_HIP(launch_fused_table(b, p->post, 1024, 2, ctx->stream));
+        }
+        f.out[t] = dsts[t]; f.pre[t] = p->pre_f; f.post[t] = p->post_f;
     }
 #ifdef ZKHIP_AB_HOOKS
     static const bool has_rot = getenv("ZKHIP_FUSED_ROT") != nullptr, has_grid = getenv("ZKHIP_FUSED_GRID") != nullptr;
@@ -635,7 +652,9 @@ void zkhip_ctx_destroy(zkhip_ctx* ctx) {
     if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
     if (ctx->sha_key) zkhip_machine_key_destroy(ctx->sha_key);
     if (ctx->fri_graph_exec) (void)hipGraphExecDestroy(ctx->fri_graph_exec);
-    for (NttPlan& p : ctx->plans) { if (p.pre) (void)hipFree(p.pre); if (p.post) (void)hipFree(p.post); }
+    for (NttPlan& p : ctx->plans) { if (p.pre) (void)hipFree(p.pre); if (p.post) (void)hipFree(p.post); if (p.pre_f) (void)hipFree(p.pre_f); if (p.post_f) (void)hipFree(p.post_f); }
+    if (ctx->w1024f_fwd) (void)hipFree(ctx->w1024f_fwd);
+    if (ctx->w1024f_inv) (void)hipFree(ctx->w1024f_inv);
     for (BigPlan& p : ctx->big_plans) if (p.tw) (void)hipFree(p.tw);
     for (ColPlan& p : ctx->col_plans) { if (p.pre) (void)hipFree(p.pre); if (p.post2d) (void)hipFree(p.post2d); }
     for (DeviceBuffer& b : ctx->scratch) if (b.ptr) (void)hipFree(b.ptr);

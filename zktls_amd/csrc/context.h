@@ -37,6 +37,8 @@ struct NttPlan {
     int m1 = 0, m2 = 0;      // log sizes of the two factors (m1 = 0: single pass)
     uint32_t* pre = nullptr;   // device
     uint32_t* post = nullptr;  // device
+    uint32_t* pre_f = nullptr;   // kind 2, 2^20 rows: the same tables in the fused launch's thread order (built on first use)
+    uint32_t* post_f = nullptr;
 };
 
 // radix-R combine twiddles of a 2^21 / 2^22-row transform (ntt.hip, ntt_combine_kernel)
@@ -95,6 +97,8 @@ struct zkhip_ctx {
     bool own_stream = false;
     uint32_t* w1024_fwd = nullptr;
     uint32_t* w1024_inv = nullptr;
+    uint32_t* w1024f_fwd = nullptr;      // w_1024^(+-u k1) in the fused launch's thread order
+    uint32_t* w1024f_inv = nullptr;
     std::deque<zk::NttPlan> plans;   // deque: references stay valid on push_back
     std::deque<zk::BigPlan> big_plans;
     std::deque<zk::ColPlan> col_plans;

@@ -56,13 +56,18 @@ struct LdeFusedArgs {
     uint32_t bench_tag;              // 1: launched by the roofline hook under its own kernel name
     uint64_t in_tile_mul, in_stride;
     uint64_t out_tile_mul, out_stride;
-    const uint32_t* w1024_inv;       // w_1024^-e
-    const uint32_t* w1024_fwd;       // w_1024^e
+    const uint32_t* w1024_inv;       // w_1024^-(u k1) in thread order (launch_fused_table mode 0)
+    const uint32_t* w1024_fwd;       // w_1024^(u k1), thread order
     uint32_t* out[FUSED_COSETS];
-    const uint32_t* pre[FUSED_COSETS];    // [1024] each
-    const uint32_t* post[FUSED_COSETS];   // [num_tiles * 1024] each
+    const uint32_t* pre[FUSED_COSETS];    // [1024] each, thread order (mode 1)
+    const uint32_t* post[FUSED_COSETS];   // [num_tiles * 1024] each, thread order (mode 2)
 };
 hipError_t launch_lde_fused(const LdeFusedArgs& a, hipStream_t s);
+// the fused launch reads its tables in THREAD order (thread u's 32 entries contiguous, 16-byte loads): per block of 1024 words
+//   mode 0: out[32 u + r]   = in[u * rev5(r)]          (tile twiddles w_1024^(+-u k1), one block)
+//   mode 1: out[32 u + n1]  = in[u + 32 n1]            (coset powers, one block)
+//   mode 2: out[32 u + rho] = in[32 rev5(rho) + u]     (post table, one block per tile)
+hipError_t launch_fused_table(uint32_t* out, const uint32_t* in, uint32_t blocks, int mode, hipStream_t s);
 bool lde_fused_supported(const LdeFusedArgs& a);      // shape / alignment / 32-bit tile span
 
 // ---- native passes over CONTIGUOUS VECTORS (RISC Zero's Hal layout: `count` polynomials of 2^20 coefficients, column-major).

@@ -38,20 +38,38 @@ constexpr size_t FUSED_LDS_BYTES = (size_t)XCHG_WORDS * 4 + (size_t)(2 + 4) * 10
 // LDS-only workgroup barrier: outstanding global loads (the prefetched tile) and stores stay in flight across it
 ZK_D void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
-// first five stages over n1 and the tile twiddle w_1024^(+-u k1); x[r] then holds A[k1 = rev5(r)]
+// 16 table words of thread u (half H of its row of 32, in register order) as four 16-byte LDS loads; all lanes of a half-wave read
+// the same words.  Halves, with a scheduling barrier between them, keep the table at 16 live registers instead of 32.
+template <int H>
+ZK_D void load_half16(uint32_t (&t)[16], const uint32_t* table, int u) {
+    const uint4* tp = reinterpret_cast<const uint4*>(table + 32 * u + 16 * H);
+#pragma unroll
+    for (int i = 0; i < 4; i++) { const uint4 v = tp[i]; t[4 * i] = v.x; t[4 * i + 1] = v.y; t[4 * i + 2] = v.z; t[4 * i + 3] = v.w; }
+}
+// first five stages over n1 and the tile twiddle w_1024^(+-u k1) (stw in thread order: stw[32 u + r] = w^(u rev5(r)));
+// x[r] then holds A[k1 = rev5(r)]
 template <bool INV>
 ZK_D void tile_phase_a(uint32_t (&x)[32], const uint32_t* stw, int u, int64_t bias) {
-    // opaque copy: the 31 table addresses u * k1 are loop invariants, and hoisted out of the tile loop they would occupy 31
-    // registers (x 2 directions) for the whole kernel
-    asm volatile("" : "+v"(u));
     dif_stage<INV, 0>(x, bias);
     dif_stage<INV, 1>(x, bias);
     dif_stage<INV, 2>(x, bias);
     dif_stage<INV, 3>(x, bias);
     dif_stage<INV, 4, true, true>(x, bias);
+    __builtin_amdgcn_sched_barrier(0);       // the table words are fetched here, not above the butterflies (32 live registers)
+    {
+        uint32_t tw[16];
+        load_half16<0>(tw, stw, u);
 #pragma unroll
-    for (int r = 1; r < 32; r++) x[r] = (r & 1) ? dmul_sd(x[r], stw[u * rev5(r)], bias) : dmul(x[r], stw[u * rev5(r)]);
-    x[0] = dred(x[0]);
+        for (int r = 1; r < 16; r++) x[r] = (r & 1) ? dmul_sd(x[r], tw[r], bias) : dmul(x[r], tw[r]);
+        x[0] = dred(x[0]);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    {
+        uint32_t tw[16];
+        load_half16<1>(tw, stw, u);
+#pragma unroll
+        for (int r = 16; r < 32; r++) x[r] = (r & 1) ? dmul_sd(x[r], tw[r - 16], bias) : dmul(x[r], tw[r - 16]);
+    }
 }
 // last five stages; outputs lazy (sums in [0, 2P), odd slots signed differences): a multiplication follows.
 // Element k = 32 rev5(rho) + u of the transform ends in x[rho].
@@ -166,11 +184,24 @@ __global__ void __launch_bounds__(1024, 4) lde_fused_kernel(LdeFusedArgs a, uint
             }
             // forward input n = u + 32 n1 is coefficient k = n: register rev5(n1); times the coset's power pre_t[n]
             uint32_t w[32];
+            {
+                uint32_t pw[16];                 // pre_t[u + 32 n1] at slot[32 u + n1]
+                load_half16<0>(pw, slot, u);
 #pragma unroll
-            for (int n1 = 0; n1 < 32; n1++) {
-                const uint32_t pw = slot[u + 32 * n1];
-                const int r = rev5(n1);
-                w[n1] = (r & 1) ? dmul_sd(s[r], pw, bias) : dmul(s[r], pw);
+                for (int n1 = 0; n1 < 16; n1++) {
+                    const int r = rev5(n1);
+                    w[n1] = (r & 1) ? dmul_sd(s[r], pw[n1], bias) : dmul(s[r], pw[n1]);
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            {
+                uint32_t pw[16];
+                load_half16<1>(pw, slot, u);
+#pragma unroll
+                for (int n1 = 16; n1 < 32; n1++) {
+                    const int r = rev5(n1);
+                    w[n1] = (r & 1) ? dmul_sd(s[r], pw[n1 - 16], bias) : dmul(s[r], pw[n1 - 16]);
+                }
             }
             __builtin_amdgcn_sched_barrier(0);      // the loads below must not move up beside the coefficients they replace
             if (PREFETCH) {
@@ -196,10 +227,19 @@ __global__ void __launch_bounds__(1024, 4) lde_fused_kernel(LdeFusedArgs a, uint
             const auto ors = __builtin_amdgcn_make_buffer_rsrc(ob, 0, 0xFFFFFFFFu, 0x00020000);
             uint32_t ostep = ostep_b;
             asm volatile("" : "+s"(ostep));
+            __builtin_amdgcn_sched_barrier(0);
+            uint32_t qw[16];                     // post_t[tile][32 rev5(rho) + u] at slot[1024 + 32 u + rho]
+            load_half16<0>(qw, slot + 1024, u);
 #pragma unroll
-            for (int rho = 0; rho < 32; rho++) {
-                const uint32_t pw = slot[1024 + 32 * rev5(rho) + u];
-                const uint32_t v = (rho & 1) ? dmul_sd(w[rho], pw, bias) : dmul(w[rho], pw);
+            for (int rho = 0; rho < 16; rho++) {
+                const uint32_t v = (rho & 1) ? dmul_sd(w[rho], qw[rho], bias) : dmul(w[rho], qw[rho]);
+                __builtin_amdgcn_raw_buffer_store_b32(v, ors, out_off, rho * ostep, 2);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            load_half16<1>(qw, slot + 1024, u);
+#pragma unroll
+            for (int rho = 16; rho < 32; rho++) {
+                const uint32_t v = (rho & 1) ? dmul_sd(w[rho], qw[rho - 16], bias) : dmul(w[rho], qw[rho - 16]);
                 __builtin_amdgcn_raw_buffer_store_b32(v, ors, out_off, rho * ostep, 2);
             }
             lds_barrier();                       // exchange buffer free, the other slot's tables visible
@@ -211,6 +251,13 @@ __global__ void __launch_bounds__(1024, 4) lde_fused_kernel(LdeFusedArgs a, uint
         coset(1u, std::true_type{});
         cur = nxt;
     }
+}
+
+__global__ void fused_table_kernel(uint32_t* out, const uint32_t* in, int mode) {
+    const uint32_t b = blockIdx.x, p = threadIdx.x;          // 1024 threads: one block of 1024 words
+    const uint32_t u = p >> 5, r = p & 31u;
+    const uint32_t src = mode == 0 ? u * (uint32_t)rev5((int)r) : mode == 1 ? u + 32u * r : 32u * (uint32_t)rev5((int)r) + u;
+    out[(uint64_t)b * 1024u + p] = in[(uint64_t)b * 1024u + src];
 }
 
 int cu_count_of(int dev) {
@@ -244,6 +291,12 @@ bool lde_fused_supported(const LdeFusedArgs& a) {
     const uint64_t in_span = 4ull * (1023ull * a.in_stride * a.in_ld + a.ncols);
     const uint64_t out_span = 4ull * (1023ull * a.out_stride * a.out_ld + a.ncols);
     return in_span < (1ull << 32) && out_span < (1ull << 32);
+}
+
+hipError_t launch_fused_table(uint32_t* out, const uint32_t* in, uint32_t blocks, int mode, hipStream_t s) {
+    if (blocks == 0) return hipSuccess;
+    hipLaunchKernelGGL(fused_table_kernel, dim3(blocks), dim3(1024), 0, s, out, in, mode);
+    return hipGetLastError();
 }
 
 hipError_t launch_lde_fused(const LdeFusedArgs& a, hipStream_t s) {
