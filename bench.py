@@ -11,13 +11,15 @@ PoW -> queries) of a synthetic SP1-core-like shard: 2^20 rows x 256 columns, log
 in HBM before the timed region.  Shards are independent: the K*N shards of the job are dealt round-robin
 (zktls_amd.shards.shard_indices == the library's zkhip_shard_device): rank r proves shards r, r+N, ...
 (weak scaling, no data-path collective); RCCL broadcasts the 8-word batch transcript seed and, after
-the timed region, gathers the proof digests (every shard proven exactly once).
+the timed region, gathers the proof digests (every timed step proves a different shard, up to 48 per rank;
+beyond that shards repeat and `distinct_shards_proven` says so).
 Up to --streams shards are in flight per GPU, each on its own context + HIP stream + host
 thread, so the latency-bound stretches of one proof hide under the kernels of the others.
 
 Prints ONE JSON line (rank 0): metric trace-cells/s (+ proofs/s), `roofline` for the NTT
-pass kernel (HIP events on the launch stream; the four LDE launches of a proof on the proving
-context's OWN workspaces, i.e. the in-proof buffer placement), `valu_roofline` for the Poseidon2 leaf kernel
+pass kernel (HIP events on the launch stream; the LDE launches of a proof -- first inverse pass, the fused
+middle launch, second forward pass per coset -- on the proving context's OWN workspaces, i.e. the in-proof
+buffer placement), `valu_roofline` for the Poseidon2 leaf kernel
 (the largest share of a proof, integer-multiply bound) and `cpu_baseline` (the CPU oracle
 timed on the host cores, bounded sample, N = 1 only).
 """
@@ -134,7 +136,7 @@ def main():
     public = shards.broadcast_seed(dist, [(SEED >> (8 * i)) & 0xFF for i in range(8)], device=coll_dev)
 
     K, W = args.steps, args.warmup
-    nbuf = min(max(K, 1), 8)
+    nbuf = min(max(K, 1), 48)      # every timed step proves a DIFFERENT shard up to 48 steps (48 GiB of traces at the headline shape)
     # this rank's shards of the K * world-shard job, dealt by the tested scheduling function (round-robin)
     my = shards.shard_indices(max(K, 1) * world, rank, world)
     assert len(my) == max(K, 1)
@@ -143,9 +145,9 @@ def main():
             traces = [torch.empty(cells, dtype=torch.int32, device="cuda") for _ in range(nbuf)]
         bufs = [ctx.wrap(t) for t in traces]
         with torch.cuda.stream(stream):
-            # destinations of the roofline passes, allocated with the traces.  Three candidates: the strided pass runs in one of
-            # two modes (0.48 / 0.53 ms) depending on where source and destination lie (tools/ntt_spacing_probe.py);
-            # the section below times all three briefly, measures on the best and reports the spread.
+            # destinations of the stand-alone strided-pass scan of the roofline section (context only: the roofline itself is
+            # measured on the proving context's own workspaces).  The strided pass runs in one of two modes depending on where
+            # source and destination lie; the scan reports the spread over 16 pairs.
             roof_scratch, spacers = [], []
             for _k in range(4):          # 2, 6, 10 GiB apart: buffer classes come in runs of several GiB, neighbours share one
                 roof_scratch.append(torch.empty(n * width, dtype=torch.int32, device="cuda"))
@@ -242,10 +244,13 @@ def main():
     elapsed = time.perf_counter() - t0
     elapsed = shards.max_over_ranks(dist, elapsed, device=coll_dev)
     last = proofs[K - 1]
-    # after the timed region: every shard of the job was proven exactly once, on exactly one rank (digest gather over RCCL)
-    digests = shards.gather_proof_digests(dist, {my[i]: proofs[i] for i in range(K)})
-    if sorted(digests) != list(range(K * world)):
-        raise SystemExit("shard coverage broken: %d digests for %d shards" % (len(digests), K * world))
+    # after the timed region: every distinct shard of the job was proven on exactly one rank (digest gather over RCCL)
+    # (keyed by the shard actually proven: step i proves shard my[i % nbuf], so beyond nbuf steps shards repeat and only the distinct ones count)
+    distinct = min(K, nbuf) if chip_list is None else K
+    digests = shards.gather_proof_digests(dist, {(my[i % nbuf] if chip_list is None else my[i]): proofs[i] for i in range(K)})
+    expect = sorted(s_ for r_ in range(world) for s_ in shards.shard_indices(max(K, 1) * world, r_, world)[:distinct])
+    if sorted(digests) != expect:
+        raise SystemExit("shard coverage broken: %d digests for %d distinct shards" % (len(digests), len(expect)))
     del proofs
 
     # single-shard latency (one shard in flight, nothing else on the GPU): NOT the metric -- `value` is throughput with S shards in flight
@@ -295,15 +300,44 @@ def main():
             ctx.ntt_pass(bufs[0], None, log_n, width, 2)
         reps = 1000
         # kernel names as a rocprofv3 summary of this command lists them: the launches of this section run under their own
-        # template tag (last argument 3 / 4 = the same code as the in-proof 1 / 2), so the profile keeps the isolated launches
-        # apart from the in-proof ones, which overlap with the other shards in flight
-        names = {2: "zk::ntt_pass_kernel<4,true,2,5,4>, LDE pass I1 (inverse, strided in -> strided out)",
-                 3: "zk::ntt_pass_kernel<4,true,2,5,3>, LDE pass I2 (inverse, contiguous, in place)",
-                 4: "zk::ntt_pass_kernel<4,false,2,5,4>, LDE pass F1 (forward, block in -> strided bit-reversed out)",
-                 5: "zk::ntt_pass_kernel<4,false,2,5,3>, LDE pass F2 (forward, contiguous, in place)"}
-        in_proof = {w: timed(lambda w=w: ctx.ntt_pass(bufs[0], None, log_n, width, w), reps) for w in (2, 3, 4, 5)}
-        avg_ms = (in_proof[2] + in_proof[3] + 2 * in_proof[4] + 2 * in_proof[5]) / 6.0
+        # template tag, so the profile keeps the isolated launches apart from the in-proof ones, which overlap with the other
+        # shards in flight
+        fused_lde = log_n == 20 and width % 32 == 0
         alg_bytes = 8.0 * n * width
+        fused_info = None
+        if fused_lde:
+            # one LDE = I1 (block form), the FUSED middle launch (second inverse pass + first forward pass of both cosets: the
+            # coefficients never reach memory; 12 B per cell, bound by its butterflies, not by HBM), F2 per coset.  The roofline
+            # kernel is the pass kernel: its three launches of the LDE.
+            names = {6: "zk::ntt_pass_kernel<4,true,2,5,4>, LDE pass I1 (inverse, strided in -> one contiguous block per tile)",
+                     5: "zk::ntt_pass_kernel<4,false,2,5,3>, LDE pass F2 (forward, contiguous, in place)"}
+            in_proof = {w: timed(lambda w=w: ctx.ntt_pass(bufs[0], None, log_n, width, w), reps) for w in (6, 7, 5)}
+            avg_ms = (in_proof[6] + 2 * in_proof[5]) / 3.0
+            launches_note = "mean over the three pass-kernel launches of one 2^%d x %d trace LDE (I1, F2, F2)" % (log_n, width)
+            fb = 12.0 * n * width
+            lde_ms = in_proof[6] + in_proof[7] + 2 * in_proof[5]
+            unfused = {w: timed(lambda w=w: ctx.ntt_pass(bufs[0], None, log_n, width, w), 200) for w in (2, 3, 4)}
+            unfused_ms = unfused[2] + unfused[3] + 2 * unfused[4] + 2 * in_proof[5]
+            fused_info = {"kernel": "zk::lde_fused_kernel<1>, second inverse pass + first forward pass of both cosets in one launch",
+                          "ms": round(in_proof[7], 4), "algorithmic_bytes_per_launch": fb, "GB/s": round(fb / in_proof[7] / 1e6, 1),
+                          "frac_of_hbm_peak": round(fb / in_proof[7] / 1e6 / HBM_PEAK_GBS, 4),
+                          "bound": "integer VALU: three 1024-point tile transforms per 12 B (DESIGN.md 4.1); it replaces three pass launches of 8 B per cell each",
+                          "replaces_ms": round(unfused[3] + 2 * unfused[4], 4)}
+            lde_info = {"launches": "I1 + fused + 2 x F2", "ms": round(lde_ms, 4), "bytes_per_trace_cell": 36,
+                        "GB/s": round(36.0 * n * width / lde_ms / 1e6, 1), "unfused_six_launch_ms": round(unfused_ms, 4), "unfused_bytes_per_trace_cell": 48}
+            detail = (6, 5)
+        else:
+            names = {2: "zk::ntt_pass_kernel<4,true,2,5,4>, LDE pass I1 (inverse, strided in -> strided out)",
+                     3: "zk::ntt_pass_kernel<4,true,2,5,3>, LDE pass I2 (inverse, contiguous, in place)",
+                     4: "zk::ntt_pass_kernel<4,false,2,5,4>, LDE pass F1 (forward, block in -> strided bit-reversed out)",
+                     5: "zk::ntt_pass_kernel<4,false,2,5,3>, LDE pass F2 (forward, contiguous, in place)"}
+            in_proof = {w: timed(lambda w=w: ctx.ntt_pass(bufs[0], None, log_n, width, w), reps) for w in (2, 3, 4, 5)}
+            avg_ms = (in_proof[2] + in_proof[3] + 2 * in_proof[4] + 2 * in_proof[5]) / 6.0
+            launches_note = "mean over the six launches of one 2^%d x %d trace LDE" % (log_n, width)
+            lde_ms = in_proof[2] + in_proof[3] + 2 * in_proof[4] + 2 * in_proof[5]
+            lde_info = {"launches": "I1 + I2 + 2 x (F1 + F2)", "ms": round(lde_ms, 4), "bytes_per_trace_cell": 48,
+                        "GB/s": round(48.0 * n * width / lde_ms / 1e6, 1)}
+            detail = (2, 3, 4, 5)
         achieved = alg_bytes / (avg_ms * 1e-3) / 1e9
         # stand-alone passes on caller buffers, every (source, destination) pair of up to four traces and four scratch buffers
         cands = [ctx.wrap(t) for t in roof_scratch]
@@ -328,9 +362,10 @@ def main():
                 # also against the measured float4-copy ceiling of this part (MI355X_MICROARCH.md: 6.29 TB/s)
                 "frac_of_measured_copy_ceiling": round(achieved / 6290.0, 4),
                 "traffic": traffic, "traffic_source": traffic_src,
-                "kernel": "zk::ntt_pass_kernel, mean over the six launches of one 2^%d x %d trace LDE on the proving context's own workspaces (in-proof placement, nothing selected)" % (log_n, width),
+                "kernel": "zk::ntt_pass_kernel, %s on the proving context's own workspaces (in-proof placement, nothing selected)" % launches_note,
                 "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_ms": round(avg_ms, 4),
-                "kernels": {names[w]: {"ms": round(in_proof[w], 4), "GB/s": gbs(in_proof[w]), "frac": round(gbs(in_proof[w]) / HBM_PEAK_GBS, 4)} for w in (2, 3, 4, 5)},
+                "kernels": {names[w]: {"ms": round(in_proof[w], 4), "GB/s": gbs(in_proof[w]), "frac": round(gbs(in_proof[w]) / HBM_PEAK_GBS, 4)} for w in detail},
+                "fused_middle_launch": fused_info, "lde": lde_info,
                 "standalone_strided_pass_by_placement": {"pairs": len(placements), "min_ms": round(placements[0], 4), "median_ms": round(med, 4),
                                                          "max_ms": round(placements[-1], 4), "median_frac": round(gbs(med) / HBM_PEAK_GBS, 4),
                                                          "best_placement_frac": round(gbs(placements[0]) / HBM_PEAK_GBS, 4)},
@@ -404,7 +439,7 @@ def main():
             "rccl_world_size": (dist.get_world_size() if dist is not None else 1),
             "collective_backend": (dist.get_backend() if dist is not None else None),
             "share_gpu_test_mode": bool(args.share_gpu),
-            "shards_proven": K * world, "shard_digests_gathered": len(digests), "shard_assignment": "round-robin (zktls_amd.shards.shard_indices)",
+            "shards_proven": K * world, "distinct_shards_proven": len(digests), "shard_digests_gathered": len(digests), "shard_assignment": "round-robin (zktls_amd.shards.shard_indices)",
             "timing_note": "ms_per_step is amortised throughput with %d shards in flight per GPU, not latency" % S,
             "single_shard_latency_ms": (round(latency_ms, 3) if latency_ms is not None else None),
             "inputs": "host memory, H2D copy inside every step" if host_traces is not None else "resident in HBM",

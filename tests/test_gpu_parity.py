@@ -132,6 +132,33 @@ def test_coset_lde_and_dft_2pow20_on_the_wide_tile_kernel(ctx, oracle):
     assert (br[bitrev_perm(log_n)] == exp).all()
 
 
+@pytest.mark.parametrize("width,log_blowup,out_ld", [(32, 1, None), (64, 1, 96), (96, 2, None)])
+def test_fused_lde_equals_the_four_pass_sequence(ctx, oracle, width, log_blowup, out_ld):
+    """2^20 rows x a multiple of 32 columns takes the fused middle launch (ntt_fused.hip: second inverse pass + first forward
+    pass of two cosets in one kernel, coefficients never written); zkhip_ctx_set_lde_fusion(0) forces the unfused sequence.
+    Both must give the same matrix bit for bit -- also with a padded output pitch and with four cosets (two fused launches) --
+    and (narrowest case) the oracle's."""
+    log_n = 20
+    src = ctx.fill_uniform(SEED + 300 + width, log_n, width)
+    ld = out_ld or width
+    out_a = ctx.alloc(ld << (log_n + log_blowup))
+    out_b = ctx.alloc(ld << (log_n + log_blowup))
+    try:
+        assert ctx.set_lde_fusion(True) is True           # on by default
+        ctx.coset_lde(src, log_n, width, log_blowup, out=out_a, out_ld=ld)
+        ctx.set_lde_fusion(False)
+        ctx.coset_lde(src, log_n, width, log_blowup, out=out_b, out_ld=ld)
+    finally:
+        ctx.set_lde_fusion(True)
+    a = out_a.download().reshape(-1, ld)[:, :width]
+    b = out_b.download().reshape(-1, ld)[:, :width]
+    assert (a == b).all()
+    if width == 32:
+        assert (a == oracle.coset_lde(src.download().reshape(-1, width), log_blowup, 31)).all()
+    for x in (src, out_a, out_b):
+        x.free()
+
+
 def test_coset_lde_strided_output(ctx, oracle):
     # out_ld > width, as the prover uses for the two quotient chunks
     log_n = 9

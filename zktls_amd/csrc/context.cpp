@@ -255,14 +255,6 @@ int lde_fused_args(zkhip_ctx* ctx, const uint32_t* coef, size_t coef_ld, uint32_
     LdeFusedArgs f{};
     f.in = coef; f.in_ld = coef_ld; f.out_ld = out_ld; f.ncols = width; f.num_tiles = 1024;
     f.in_tile_mul = 1; f.in_stride = 1024; f.out_tile_mul = 1; f.out_stride = 1024;
-    if (!ctx->w1024f_fwd) {
-        uint32_t *a = nullptr, *b = nullptr;
-        ZK_HIP(hipMalloc((void**)&a, 1024 * 4));
-        if (hipMalloc((void**)&b, 1024 * 4) != hipSuccess) { (void)hipFree(a); return fail(ZKHIP_ERR_HIP, "hipMalloc (fused twiddles)"); }
-        ctx->w1024f_fwd = a; ctx->w1024f_inv = b;
-        ZK_HIP(launch_fused_table(a, ctx->w1024_fwd, 1, 0, ctx->stream));
-        ZK_HIP(launch_fused_table(b, ctx->w1024_inv, 1, 0, ctx->stream));
-    }
     f.w1024_inv = ctx->w1024f_inv; f.w1024_fwd = ctx->w1024f_fwd;
     for (int t = 0; t < FUSED_COSETS; t++) {
         const NttPlan* p;
@@ -636,6 +628,10 @@ int zkhip_ctx_create(int device, void* stream, zkhip_ctx** out) {
         const uint32_t w = two_adic_generator(10);
         if ((e = launch_pow_table(ctx->w1024_fwd, 1024, w, MONTY_R1, ctx->stream)) != hipSuccess) { rc = hip_fail(e, "pow_table"); break; }
         if ((e = launch_pow_table(ctx->w1024_inv, 1024, finv(w), MONTY_R1, ctx->stream)) != hipSuccess) { rc = hip_fail(e, "pow_table"); break; }
+        if ((e = hipMalloc((void**)&ctx->w1024f_fwd, 1024 * 4)) != hipSuccess) { rc = hip_fail(e, "hipMalloc"); break; }
+        if ((e = hipMalloc((void**)&ctx->w1024f_inv, 1024 * 4)) != hipSuccess) { rc = hip_fail(e, "hipMalloc"); break; }
+        if ((e = launch_fused_table(ctx->w1024f_fwd, ctx->w1024_fwd, 1, 0, ctx->stream)) != hipSuccess) { rc = hip_fail(e, "fused_table"); break; }
+        if ((e = launch_fused_table(ctx->w1024f_inv, ctx->w1024_inv, 1, 0, ctx->stream)) != hipSuccess) { rc = hip_fail(e, "fused_table"); break; }
         // the Poseidon2 tables in effect (built-in or zkhip_load_poseidon2_params) go to this device's constant memory
         if ((e = hash_upload_p2_tables(g_p2_tables, ctx->stream)) != hipSuccess) { rc = hip_fail(e, "upload Poseidon2 tables"); break; }
         if ((e = stark_upload_p2_tables(g_p2_tables, ctx->stream)) != hipSuccess) { rc = hip_fail(e, "upload Poseidon2 tables"); break; }
