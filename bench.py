@@ -79,6 +79,9 @@ def main():
     ap.add_argument("--share-gpu", action="store_true",
                     help="TEST MODE for boxes with fewer GPUs than ranks: rank r uses device r mod (visible devices) and the collectives run "
                          "over gloo (RCCL refuses two ranks on one GPU).  Exercises the N > 1 code path end to end; the line says so and is not a scaling result")
+    ap.add_argument("--force-collective", action="store_true",
+                    help="with --gpus 1: initialise the RCCL ('nccl') process group at world size 1 and run the seed broadcast, the MAX "
+                         "all-reduce and a barrier through it, so that RCCL is loaded and called on hardware even on a one-GPU box")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-log-n", type=int, default=20, help="rows of the bounded CPU-baseline sample")
     ap.add_argument("--cpu-threads", type=int, default=0, help="OpenMP threads of the CPU baseline (0: min(cores, 64))")
@@ -110,7 +113,30 @@ def main():
         else:
             dist.init_process_group(backend="nccl", rank=rank, world_size=world,
                                     device_id=torch.device("cuda", local_rank))
+    elif args.force_collective:
+        import torch.distributed as dist_mod
+        dist = dist_mod
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if "MASTER_PORT" not in os.environ:
+            import socket
+            sk = socket.socket()
+            sk.bind(("127.0.0.1", 0))
+            os.environ["MASTER_PORT"] = str(sk.getsockname()[1])
+            sk.close()
+        dist.init_process_group(backend="nccl", rank=0, world_size=1, device_id=torch.device("cuda", local_rank))
     coll_dev = "cpu" if args.share_gpu else "cuda"
+    rccl_calls = 0
+    if dist is not None and not args.share_gpu:
+        # RCCL on hardware, whatever the world size: one broadcast, one MAX all-reduce, one barrier through the 'nccl' backend
+        t_ = torch.tensor([rank + 7], dtype=torch.int32, device="cuda")
+        dist.broadcast(t_, src=0)
+        a_ = torch.tensor([float(rank)], dtype=torch.float64, device="cuda")
+        dist.all_reduce(a_, op=dist.ReduceOp.MAX)
+        dist.barrier()
+        torch.cuda.synchronize()
+        if int(t_.item()) != 7 or float(a_.item()) != float(world - 1):
+            raise SystemExit("RCCL self-check failed: broadcast %d, max %f" % (int(t_.item()), float(a_.item())))
+        rccl_calls = 3
 
     from zktls_amd._lib import Params
     from zktls_amd.device import Context, verify_shard
@@ -437,7 +463,7 @@ def main():
             "data": "synthetic",
             "streams_per_gpu": S,
             "rccl_world_size": (dist.get_world_size() if dist is not None else 1),
-            "collective_backend": (dist.get_backend() if dist is not None else None),
+            "collective_backend": (dist.get_backend() if dist is not None else None), "rccl_selfcheck_calls": rccl_calls,
             "share_gpu_test_mode": bool(args.share_gpu),
             "shards_proven": K * world, "distinct_shards_proven": len(digests), "shard_digests_gathered": len(digests), "shard_assignment": "round-robin (zktls_amd.shards.shard_indices)",
             "timing_note": "ms_per_step is amortised throughput with %d shards in flight per GPU, not latency" % S,
