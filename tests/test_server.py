@@ -107,6 +107,50 @@ def test_routing_framing_and_twirp_errors(server):
         assert st == 503 and json.loads(body)["code"] == "unavailable" and "no CPU fallback" in json.loads(body)["msg"]
 
 
+def test_plan_from_the_wire_is_bounded_before_anything_is_sized_by_it(server):
+    """advice r2 (medium): the plan fields come from an unauthenticated peer -- shards = 2^32 - 1 used to value-initialise ~100 GB
+    of proof slots.  Every out-of-range field is an invalid_argument, answered at once, and the server keeps serving."""
+    port = server
+    bad = [dict(shards=0xFFFFFFFF), dict(shards=5000), dict(log_n=40), dict(log_n=2), dict(width=0), dict(width=4096), dict(queries=0),
+           dict(queries=100000), dict(pow_bits=64), dict(device=1 << 20), dict(device=-7), dict(shards=4096, log_n=22, width=1024)]
+    for kw in bad:
+        a = dict(log_n=10, width=16, shards=2, queries=10, pow_bits=4, device=0)
+        a.update(kw)
+        t0 = time.time()
+        st, ct, body = call(port, "ProveCore", pb_bytes(prove_payload(a["log_n"], a["width"], a["shards"], a["queries"], a["pow_bits"], b"in", b"elf",
+                                                                      device=a["device"])), timeout=30)
+        assert st == 400 and json.loads(body)["code"] == "invalid_argument", (kw, st, body)
+        assert time.time() - t0 < 5
+    st, _, _ = call(port, "Ready", b"")
+    assert st == 200
+
+
+def test_declared_body_that_never_arrives_allocates_nothing_and_times_out():
+    """a peer that announces a large body and stalls: the reader grows its buffer only with bytes that arrive, the socket has a
+    receive timeout, and the next client is served"""
+    port = _free_port()
+    proc = subprocess.Popen([BIN, "--port", str(port)], stderr=subprocess.PIPE)
+    try:
+        assert b"listening" in proc.stderr.readline()
+        s = socket.create_connection(("127.0.0.1", port))
+        s.sendall(b"POST /twirp/api.ProverService/Setup HTTP/1.1\r\nContent-Type: application/protobuf\r\nContent-Length: 60000000\r\n\r\nabc")
+        time.sleep(0.5)
+        import resource  # noqa: F401  (the check below reads the server's RSS from /proc)
+        rss_kb = int([ln for ln in open("/proc/%d/status" % proc.pid) if ln.startswith("VmRSS")][0].split()[1])
+        assert rss_kb < 200 * 1024, rss_kb            # 60 MB announced, nothing allocated for it
+        s.close()                                      # the stalled peer goes away (otherwise SO_RCVTIMEO ends the wait after 20 s)
+        st, _, _ = call(port, "Ready", b"", timeout=60)
+        assert st == 200
+        # over the cap: refused outright
+        s = socket.create_connection(("127.0.0.1", port))
+        s.sendall(b"POST /twirp/api.ProverService/Setup HTTP/1.1\r\nContent-Type: application/protobuf\r\nContent-Length: 99999999999\r\n\r\n")
+        assert b"malformed" in s.recv(4096)
+        s.close()
+    finally:
+        proc.terminate()
+        proc.wait(timeout=30)
+
+
 @pytest.mark.gpu
 def test_prove_core_returns_verified_proofs(server):
     from zktls_amd._lib import Params

@@ -30,6 +30,7 @@
 #include <netinet/in.h>
 #include <signal.h>
 #include <sys/socket.h>
+#include <sys/time.h>
 #include <unistd.h>
 
 #include <cstdio>
@@ -57,15 +58,30 @@ bool write_all(int fd, const void* buf, size_t n) {
 }
 std::string lower(std::string s) { for (char& c : s) if (c >= 'A' && c <= 'Z') c = (char)(c + 32); return s; }
 
-// minimal HTTP/1.1 request reader: request line, headers (Content-Length, Content-Type), body
+// minimal HTTP/1.1 request reader: request line, headers (Content-Length, Content-Type), body.  The caller has set receive / send
+// timeouts on the socket, so a stalled peer costs the accept loop a bounded wait.  Headers arrive through a buffer (not a recv per
+// byte); the body is read in chunks into a vector that grows with the bytes that actually arrive, so a large Content-Length
+// alone allocates nothing.
+constexpr size_t MAX_HEAD = 16384;
+constexpr size_t BODY_CHUNK = (size_t)1 << 20;
 Request read_request(int fd, size_t max_body) {
     Request rq;
     std::string head;
-    char c;
-    while (head.size() < 16384) {
-        if (!read_exact(fd, &c, 1)) return rq;
-        head.push_back(c);
-        if (head.size() >= 4 && head.compare(head.size() - 4, 4, "\r\n\r\n") == 0) break;
+    std::vector<uint8_t> extra;                       // bytes received past the header terminator: the start of the body
+    {
+        char buf[4096];
+        size_t end = std::string::npos;
+        while (head.size() < MAX_HEAD) {
+            const ssize_t r = ::recv(fd, buf, sizeof buf, 0);
+            if (r <= 0) return rq;
+            const size_t from = head.size() >= 3 ? head.size() - 3 : 0;
+            head.append(buf, (size_t)r);
+            end = head.find("\r\n\r\n", from);
+            if (end != std::string::npos) break;
+        }
+        if (end == std::string::npos) return rq;
+        extra.assign(head.begin() + (long)end + 4, head.end());
+        head.resize(end + 4);
     }
     const size_t eol = head.find("\r\n");
     if (eol == std::string::npos) return rq;
@@ -90,9 +106,16 @@ Request read_request(int fd, size_t max_body) {
         }
         pos = e + 2;
     }
-    if (content_length > max_body) return rq;
-    rq.body.resize(content_length);
-    if (content_length && !read_exact(fd, rq.body.data(), content_length)) return rq;
+    if (content_length > max_body || extra.size() > content_length) return rq;
+    rq.body = std::move(extra);
+    while (rq.body.size() < content_length) {
+        const size_t have = rq.body.size();
+        const size_t want = content_length - have < BODY_CHUNK ? content_length - have : BODY_CHUNK;
+        rq.body.resize(have + want);
+        const ssize_t r = ::recv(fd, rq.body.data() + have, want, 0);
+        if (r <= 0) { rq.body.clear(); return rq; }
+        rq.body.resize(have + (size_t)r);
+    }
     rq.ok = true;
     return rq;
 }
@@ -155,7 +178,8 @@ struct Cursor {
 };
 
 void handle(int fd) {
-    const Request rq = read_request(fd, (size_t)1 << 30);
+    // a request carries one CBOR input and one ELF (tens of KB to a few MB): 64 MiB is generous
+    const Request rq = read_request(fd, (size_t)64 << 20);
     if (!rq.ok) { twirp_error(fd, "malformed", "could not read an HTTP request"); return; }
     const std::string prefix = "/twirp/api.ProverService/";
     if (rq.method != "POST") { twirp_error(fd, "bad_route", "unsupported method " + rq.method + " (only POST is allowed)"); return; }
@@ -194,6 +218,20 @@ void handle(int fd) {
     in.cbor = c.blob();
     const std::vector<uint8_t> elf = c.blob();
     if (!c.ok || c.p != data.size() || backend > 1 || flags > 1) { twirp_error(fd, "invalid_argument", "ProveCore: truncated or oversized payload"); return; }
+    // the plan comes from an unauthenticated peer: bound every field before anything is sized by it (advice r2: shards = 2^32 - 1
+    // value-initialised ~100 GB of proof slots).  Ranges are the library's own (include/zkhip.h) with a batch cap on top.
+    {
+        const int ndev = zkhip_device_count();
+        std::string bad;
+        if (plan.shards > 4096u) bad = "shards must be in [0, 4096]";
+        else if (plan.shards != 0 && (plan.log_n < 5 || plan.log_n > 22)) bad = "log_n must be in [5, 22]";
+        else if (plan.shards != 0 && (plan.width < 4u || plan.width > 1024u)) bad = "width must be in [4, 1024]";
+        else if (plan.num_queries < 1 || plan.num_queries > 256) bad = "num_queries must be in [1, 256]";
+        else if (plan.pow_bits < 0 || plan.pow_bits > 24) bad = "pow_bits must be in [0, 24]";
+        else if (device < -1 || device >= (ndev > 0 ? ndev : 1)) bad = "device must be -1 (every GPU) or a visible device ordinal";
+        else if (plan.shards != 0 && ((uint64_t)plan.shards << plan.log_n) * plan.width > ((uint64_t)1 << 36)) bad = "the batch exceeds 2^36 trace cells";
+        if (!bad.empty()) { twirp_error(fd, "invalid_argument", "ProveCore: " + bad); return; }
+    }
     if ((flags & 1u) && (plan.shards != 0 || backend != 0)) { twirp_error(fd, "invalid_argument", "ProveCore: KEYED asks for the input-commitment guest (shards = 0) in the SP1 shape"); return; }
     zktls::HipGuestProver prover(device < 0 ? 0 : device, backend ? zktls::Backend::Risc0 : zktls::Backend::Sp1);
     if (device < 0) { std::vector<int> all; for (int d = 0; d < zkhip_device_count(); d++) all.push_back(d); if (!all.empty()) prover.with_devices(all); }
@@ -255,6 +293,12 @@ int main(int argc, char** argv) {
     for (int served = 0; max_requests < 0 || served < max_requests; served++) {
         const int fd = ::accept(ls, nullptr, nullptr);
         if (fd < 0) continue;
+        {   // one stalled connection must not hold the (single) accept loop
+            timeval tv{};
+            tv.tv_sec = 20;
+            setsockopt(fd, SOL_SOCKET, SO_RCVTIMEO, &tv, sizeof tv);
+            setsockopt(fd, SOL_SOCKET, SO_SNDTIMEO, &tv, sizeof tv);
+        }
         handle(fd);
         ::shutdown(fd, SHUT_RDWR);
         ::close(fd);
