@@ -1072,22 +1072,29 @@ int deal_jobs(const int* devices, int n_devices, int n_jobs, int in_flight, cons
             ctx_rc = rc; ctx_msg = zkhip_last_error();
             return;
         }
-        for (;;) {
+        bool healthy = true;                                 // a context that saw a failing job does not go back to the pool:
+        for (;;) {                                           // a sticky HIP error or a half-built key would fail unrelated jobs later
             const int k = next[slot].fetch_add(1);
             const long i = (long)slot + (long)k * n_devices;   // the k-th job of this device
             if (i >= n_jobs) break;
             rc = run(ctx, (int)i);
             ran[(size_t)i] = 1;
-            if (rc != ZKHIP_OK) note((int)i, rc);
+            if (rc != ZKHIP_OK) { note((int)i, rc); healthy = false; }
         }
-        zkhip_ctx_sync(ctx);
-        pool_give(device, ctx);
+        if (zkhip_ctx_sync(ctx) != ZKHIP_OK) healthy = false;
+        if (healthy) pool_give(device, ctx);
+        else zkhip_ctx_destroy(ctx);
     };
     std::vector<std::thread> pool;
     for (int slot = 0; slot < n_devices; slot++) {
         const int mine = (n_jobs - slot + n_devices - 1) / n_devices;       // jobs of this device
         const int workers = mine < in_flight ? mine : in_flight;
-        for (int t = 0; t < workers; t++) pool.emplace_back(worker, slot);
+        for (int t = 0; t < workers; t++) {
+            // thread creation can throw (resource limits): never let that unwind through joinable threads into the C ABI --
+            // the workers already started (or, with none, this thread) take the jobs instead
+            try { pool.emplace_back(worker, slot); }
+            catch (...) { if (t == 0) worker(slot); break; }
+        }
     }
     for (auto& t : pool) t.join();
     if (first_rc != ZKHIP_OK) { set_error(first_msg); return first_rc; }
@@ -1331,7 +1338,7 @@ static int run_queries(int n, const std::function<int(int)>& check, int min_per_
     std::atomic<int> next{0};
     auto worker = [&]() { for (;;) { const int q = next.fetch_add(1); if (q >= n) return; result[q] = check(q); } };
     std::vector<std::thread> pool;
-    for (int t = 1; t < threads; t++) pool.emplace_back(worker);
+    for (int t = 1; t < threads; t++) { try { pool.emplace_back(worker); } catch (...) { break; } }     // fewer threads, same verdict: this thread works too
     worker();
     for (auto& t : pool) t.join();
     for (int q = 0; q < n; q++) if (result[q]) return result[q];

@@ -729,7 +729,7 @@ int zkhip_prove_sha256_sharded(const int* devices, int n_devices, const uint8_t*
     // 3 ms per MiB).  It runs on a thread of its own while the first shards are already being proven: shard s waits for chain[s + 1] only.
     const size_t per = (size_t)1 << log_blocks_per_shard, n_blocks = padded / 64;
     std::atomic<size_t> ready{0};                          // chain[0 .. ready) are final
-    std::thread hasher([&] {
+    auto hash_all = [&] {
         uint32_t h[8];
         std::memcpy(h, sha::IV, 32);
         for (size_t k = 0; k < n_blocks; k++) {
@@ -739,7 +739,9 @@ int zkhip_prove_sha256_sharded(const int* devices, int n_devices, const uint8_t*
         std::memcpy(chain + 8 * n_shards, h, 32);
         for (int i = 0; i < 8; i++) { digest[4 * i] = (uint8_t)(h[i] >> 24); digest[4 * i + 1] = (uint8_t)(h[i] >> 16); digest[4 * i + 2] = (uint8_t)(h[i] >> 8); digest[4 * i + 3] = (uint8_t)h[i]; }
         ready.store(n_shards + 1, std::memory_order_release);
-    });
+    };
+    std::thread hasher;
+    try { hasher = std::thread(hash_all); } catch (...) { hash_all(); }      // no thread to be had: hash first, then prove (never throw across the C ABI)
     struct Join { std::thread& t; ~Join() { if (t.joinable()) t.join(); } } join{hasher};
     const std::vector<uint32_t>& prog = sha::program_chained();
     std::vector<char> ran;
@@ -801,7 +803,7 @@ int zkhip_verify_sha256_sharded(const uint8_t* proofs, size_t proof_stride, cons
     };
     const size_t nt = n_shards < 4 ? n_shards : 4;
     std::vector<std::thread> pool;
-    for (size_t t = 1; t < nt; t++) pool.emplace_back(work);
+    for (size_t t = 1; t < nt; t++) { try { pool.emplace_back(work); } catch (...) { break; } }          // fewer threads, same verdict
     work();
     for (auto& t : pool) t.join();
     for (size_t s = 0; s < n_shards; s++)
