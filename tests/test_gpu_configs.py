@@ -7,7 +7,10 @@
               generated on the device), every proof accepted by the ORACLE's verifier, three sampled ones byte-equal to the
               oracle's proofs; the same batch through zkhip_prove_shards_multi (device list) gives the same bytes;
   configs[3]  one request whose execution spans 4 shards of 2^20 rows (the "~2^22-row transcript"), through the host mirror
-              of the reference's ZkProver (sp1.rs:102-133): 4 verified proofs bound to the request, one byte-equal to the oracle's.
+              of the reference's ZkProver (sp1.rs:102-133): 4 verified proofs bound to the request, one byte-equal to the oracle's;
+  configs[4]  RISC Zero continuations at 2^20 cycles per segment (prover.rs:88-93): one 2^20 x 128 segment in RISC Zero's shape
+              with proof bytes == the oracle's; four segments in one zkhip_prove_shards call; the same four through the `-p r0`
+              host mirror -- all accepted by the oracle's verifier, one byte-equal each.
 """
 import ctypes as C
 import os
@@ -148,4 +151,82 @@ def test_config3_one_request_of_four_2_20_row_shards_through_the_host_mirror(big
         seed = ((seed << 16) ^ digest[i]) & 0xFFFFFFFFFFFFFFFF
     op = O.prove_shard(O.gen_trace(seed, 3, LOG_N, WIDTH), digest + [3], oprm)
     assert proofs[3].tobytes() == op.tobytes()
+    L.zktls_release_cached()
+
+
+# ------------------------------------------------------------------ configs[4]: RISC Zero continuations (prover.rs:88-93)
+SEG_WIDTH = 128          # blowup 4: a 2^20 x 128 segment has the 2^22 x 128 LDE (2 GiB) of the headline shard
+
+
+def test_config4_segment_proof_bytes_equal_the_oracles(ctx, big_oracle):
+    """one 2^20-cycle segment in RISC Zero's shape (blowup 4, fold by 16, 256 final coefficients, 50 queries, Poseidon2 width 24):
+    proof bytes == the CPU oracle's.  The LDE of this shape takes the fused middle launch twice (four cosets)."""
+    from zktls_amd._lib import segment_params
+    O = big_oracle
+    pv = [4, 5, 6]
+    trace = ctx.gen_trace(SEED, 11, LOG_N, SEG_WIDTH)
+    proof = ctx.prove_shard(trace, LOG_N, SEG_WIDTH, pv, segment_params())
+    trace.free()
+    oproof = O.prove_shard(O.gen_trace(SEED, 11, LOG_N, SEG_WIDTH), pv, O.segment_params())
+    assert proof.size == oproof.size
+    assert proof.tobytes() == oproof.tobytes(), "2^20 x 128 segment proof bytes differ from the oracle's"
+
+
+def test_config4_four_segments_in_one_call(ctx, big_oracle):
+    """a multi-segment proof at 2^20 cycles per segment: four segments through ONE zkhip_prove_shards call with the segment
+    parameters, every proof accepted by the oracle's verifier, one byte-equal to the oracle's proof"""
+    from zktls_amd._lib import segment_params
+    O = big_oracle
+    n_seg = 4
+    prm, oprm = segment_params(), O.segment_params()
+    traces = [ctx.gen_trace(SEED, 2000 + s, LOG_N, SEG_WIDTH) for s in range(n_seg)]
+    pvs = [[3, 1, 4, s] for s in range(n_seg)]
+    ctx.sync()
+    proofs = prove_shards(traces, LOG_N, SEG_WIDTH, pvs, prm, device=0, in_flight=4)
+    assert len({p.tobytes() for p in proofs}) == n_seg
+    for s, p in enumerate(proofs):
+        assert verify_shard(p, LOG_N, SEG_WIDTH, pvs[s], prm) == (0, 0)
+        assert O.verify_shard(p, LOG_N, SEG_WIDTH, pvs[s], oprm) == 0, "oracle verifier rejects segment %d" % s
+    assert O.verify_shard(proofs[1], LOG_N, SEG_WIDTH, pvs[2], oprm) != 0
+    op = O.prove_shard(O.gen_trace(SEED, 2002, LOG_N, SEG_WIDTH), pvs[2], oprm)
+    assert proofs[2].tobytes() == op.tobytes()
+    for t in traces:
+        t.free()
+    _lib.load().zkhip_release_cached_contexts()
+
+
+def test_config4_four_segments_through_the_r0_host_mirror(big_oracle):
+    """the same through the `-p r0` twin of the reference's ZkProver (prover.rs:9-106): Risc0HipGuestProver proves the four
+    segments of one request; every proof verifies in the RISC Zero shape, bound to the request, one byte-equal to the oracle's"""
+    O = big_oracle
+    L = C.CDLL(os.path.join(ROOT, "zktls_amd", "libzktls_guest_prover.so"))
+    u8pp, szp = C.POINTER(C.POINTER(C.c_uint8)), C.POINTER(C.c_size_t)
+    L.zktls_guest_prove_r0.argtypes = [C.c_int, C.c_int, C.POINTER(Plan), C.c_char_p, C.c_size_t, C.c_char_p, C.c_size_t,
+                                       u8pp, szp, u8pp, szp, C.c_char_p, C.c_size_t]
+    L.zktls_unpack_batch.argtypes = [C.c_char_p, C.c_size_t, szp, szp, C.c_int]
+    L.zktls_free.argtypes = [C.c_void_p]
+    cbor = open(os.path.join(ROOT, "tests", "golden", "reference", "guest_input0.cbor"), "rb").read()
+    elf = b"\x7fELFr0guest" + bytes(range(100))
+    plan = Plan(LOG_N, SEG_WIDTH, 4, 100, 16)          # the defaults (100, 16) select RISC Zero's own 50 queries, no PoW
+    out, outn, pr, prn = C.POINTER(C.c_uint8)(), C.c_size_t(), C.POINTER(C.c_uint8)(), C.c_size_t()
+    err = C.create_string_buffer(512)
+    rc = L.zktls_guest_prove_r0(0, 2, C.byref(plan), cbor, len(cbor), elf, len(elf), C.byref(out), C.byref(outn), C.byref(pr), C.byref(prn), err, 512)
+    assert rc == 0, err.value
+    output, blob = C.string_at(out, outn.value), C.string_at(pr, prn.value)
+    L.zktls_free(out)
+    L.zktls_free(pr)
+    offs, lens = (C.c_size_t * 8)(), (C.c_size_t * 8)()
+    assert L.zktls_unpack_batch(blob, len(blob), offs, lens, 8) == 4
+    digest = np.frombuffer(output, dtype=np.uint32).tolist()
+    prm, oprm = Params(2, 50, 0, 0, 4, 8, 24), O.segment_params()
+    proofs = [np.frombuffer(blob[offs[s]:offs[s] + lens[s]], dtype=np.uint8) for s in range(4)]
+    for s in range(4):
+        assert verify_shard(proofs[s], LOG_N, SEG_WIDTH, digest + [s], prm) == (0, 0)
+        assert O.verify_shard(proofs[s], LOG_N, SEG_WIDTH, digest + [s], oprm) == 0
+    assert verify_shard(proofs[0], LOG_N, SEG_WIDTH, digest + [0], Params(1, 100, 16))[0] == -6      # not an SP1-shape proof
+    seed = 0
+    for i in range(4):
+        seed = ((seed << 16) ^ digest[i]) & 0xFFFFFFFFFFFFFFFF
+    op = O.prove_shard(O.gen_trace(seed, 1, LOG_N, SEG_WIDTH), digest + [1], oprm)
+    assert proofs[1].tobytes() == op.tobytes()
     L.zktls_release_cached()
