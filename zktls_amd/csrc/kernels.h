@@ -240,6 +240,7 @@ struct QuotientAirArgs {
     // term-parallel form (air_term_records): used when recs != nullptr and the slots of 8 points fit the LDS
     const uint32_t* recs; uint32_t n_terms; uint32_t n_public;
     const uint32_t* addend;     // optional [2^(log_n + log_qd)][4]: added to the folded constraints before the division by Z_H (lookups)
+    uint32_t no_chain;          // A/B: 1 keeps the one-group-per-workgroup kernel
 };
 hipError_t launch_quotient_air(const QuotientAirArgs& a, hipStream_t s);
 

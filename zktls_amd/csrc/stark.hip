@@ -397,6 +397,175 @@ __global__ void __launch_bounds__(NT) quotient_air_terms_kernel(QuotientAirArgs 
         air_store_point(a, (e0 + (tid << a.log_qd)) & mask, r);
     }
 }
+// The chained form of the same kernel.  What the kernel above spends its time on is not terms but rows: every workgroup stages 9
+// rows, waits for them with nothing else to do, and leaves again (a 608-column program of 8 terms: 4.3 ms per 2^21 points = 1.2 TB/s).
+// Here a workgroup walks CHAIN consecutive groups of one coset:
+//   * the 9th row of a group is the first row of the next, so every LDE row is fetched ONCE (8 rows per group instead of 9);
+//   * the next group's 8 rows are in flight (registers, 16 bytes per lane and load, NPF loads per lane) while the current group's
+//     terms are evaluated, and so are its selector values;
+//   * the lanes' partial sums are combined by a reduce-scatter through the wavefront's cross-lane network (32 values per lane ->
+//     one value per lane pair, 32 shuffles + 32 additions) instead of three barriers around an LDS transpose, so the staged rows
+//     stay valid (row 8 becomes row 0 by a copy inside LDS) and a group costs two barriers;
+//   * 32 lanes finish one coefficient of one point each (addend, 1 / Z_H, the two stores), 128 contiguous bytes per store.
+// idx -> (row, column group) of the lane's k-th prefetch slot: idx = tid + k NT < 8 W4, row = 1 + idx / W4.
+template <int NT, int NPF>
+__global__ void __launch_bounds__(NT, 2) quotient_air_chain_kernel(QuotientAirArgs a, uint32_t chain_len, uint32_t w4_recip) {
+    constexpr int PTS = 8;
+    static_assert(NT == 64 || NT == 128 || NT == 256, "one, two or four wavefronts per group");
+    extern __shared__ uint32_t slots[];
+    const uint32_t tid = threadIdx.x, W4 = a.width >> 2, lane = tid & 63u, wave = tid >> 6;
+    const uint32_t mask = (1u << (a.log_n + a.log_qd)) - 1u;
+    const uint32_t nq = 1u << a.log_qd;
+    const uint32_t coset = blockIdx.x & (nq - 1u), blk0 = (blockIdx.x >> a.log_qd) * chain_len;
+    const size_t lds_rows_words = (size_t)AIR_GP * (W4 + (AIR_SLOT_EXTRA + ((a.n_public + 3u) & ~3u)) / 4);
+    uint32_t* red = slots + lds_rows_words;          // [NT / 64][32] cross-wave partial sums
+    // the lane's prefetch slots: LDS word and (row, column group) packed
+    uint32_t pf_rc[NPF];
+#pragma unroll
+    for (int k = 0; k < NPF; k++) {
+        // slots past the end repeat the last one (two lanes then move the same 16 bytes to the same place): no lane-dependent
+        // branch around a load, which the compiler would serialise behind a wait each
+        const uint32_t raw = tid + (uint32_t)k * NT;
+        const uint32_t idx = min(raw, 8u * W4 - 1u);
+        const uint32_t r = __umulhi(idx, w4_recip);              // idx / W4 (exact below 2^16)
+        const uint32_t cg = idx - r * W4;
+        pf_rc[k] = (raw < 8u * W4 ? 0u : 0x80000000u) | ((r + 1u) << 16) | cg;      // top bit: a repeat, loaded but not stored
+    }
+    uint32_t e0 = air_group_e0(a, (blk0 << a.log_qd) | coset);
+    // the first group: all 9 rows, as the unchained kernel
+#pragma unroll
+    for (int r = 0; r < 9; r++) {
+        const uint4* row = reinterpret_cast<const uint4*>(a.lde + (uint64_t)air_row_of(a, e0, r) * a.ld);
+        for (uint32_t cg = tid; cg < W4; cg += NT) *reinterpret_cast<uint4*>(slots + AIR_GP * cg + 4u * r) = row[cg];
+    }
+    air_stage_extras<NT>(a, slots, e0, tid);
+    const uint4* recs = reinterpret_cast<const uint4*>(a.recs);
+    for (uint32_t i = 0; i < chain_len; i++) {
+        const bool more = i + 1 < chain_len;
+        const uint32_t e0n = air_group_e0(a, ((blk0 + i + 1u) << a.log_qd) | coset);
+        // ---- next group's rows 1..8 and selector values: on their way while this group's terms run
+        uint4 pf[NPF];
+        uint4 exn = make_uint4(0, 0, 0, 0);
+        if (more) {
+#pragma unroll
+            for (int k = 0; k < NPF; k++) {
+                const uint32_t r = (pf_rc[k] >> 16) & 0xFFu, cg = pf_rc[k] & 0xFFFFu;
+                pf[k] = ld_stream(a.lde + (uint64_t)air_row_of(a, e0n, r) * a.ld + 4u * cg);
+            }
+            if (tid < 8) {
+                const uint32_t p = air_row_of(a, e0n, tid);
+                exn = make_uint4(a.sel_first[p], a.sel_last[p], dsub(a.xs[p], a.wn_inv), MONTY_R1);
+            }
+        }
+        __syncthreads();                               // this group's slots are staged
+        uint64_t acc[PTS][4];
+#pragma unroll
+        for (int q = 0; q < PTS; q++)
+#pragma unroll
+            for (int c = 0; c < 4; c++) acc[q][c] = 0;
+        auto product = [&](const uint4& o, uint32_t (&prod)[PTS]) {
+            const uint32_t n = o.z >> 16;
+            uint32_t v[PTS];
+            air_load8(slots, o.x & 0xFFFFu, prod);
+            const uint32_t offs[4] = {o.x >> 16, o.y & 0xFFFFu, o.y >> 16, o.z & 0xFFFFu};
+            for (uint32_t k = 1; k < n; k++) {
+                air_load8(slots, offs[k - 1], v);
+#pragma unroll
+                for (int q = 0; q < PTS; q++) prod[q] = dmul(prod[q], v[q]);
+            }
+        };
+        for (uint32_t t = 2 * tid; t < a.n_terms; t += 2 * NT) {
+            const uint4 ca = recs[2 * (size_t)t], oa = recs[2 * (size_t)t + 1], cb = recs[2 * (size_t)t + 2], ob = recs[2 * (size_t)t + 3];
+            uint32_t pa[PTS], pb[PTS];
+            product(oa, pa);
+            product(ob, pb);
+#pragma unroll
+            for (int q = 0; q < PTS; q++) {
+                dacc2(acc[q][0], ca.x, pa[q], cb.x, pb[q]); dacc2(acc[q][1], ca.y, pa[q], cb.y, pb[q]);
+                dacc2(acc[q][2], ca.z, pa[q], cb.z, pb[q]); dacc2(acc[q][3], ca.w, pa[q], cb.w, pb[q]);
+            }
+        }
+        // ---- 32 values per lane -> one per lane pair: reduce-scatter over the wavefront (value v = 4 q + c ends on lanes 2 v, 2 v + 1)
+        uint32_t val[32];
+#pragma unroll
+        for (int q = 0; q < PTS; q++)
+#pragma unroll
+            for (int c = 0; c < 4; c++) val[4 * q + c] = dacc_finish(acc[q][c]);
+#pragma unroll
+        for (int half = 16; half >= 1; half >>= 1) {
+            const uint32_t bit = 2u * (uint32_t)half;              // lane bit that decides which half a lane keeps: 32, 16, 8, 4, 2
+            const bool upper = (lane & bit) != 0;
+#pragma unroll
+            for (int j = 0; j < half; j++) {
+                const uint32_t give = upper ? val[j] : val[half + j];
+                const uint32_t keep = upper ? val[half + j] : val[j];
+                val[j] = dadd(keep, (uint32_t)__shfl_xor((int)give, (int)bit, 64));
+            }
+        }
+        uint32_t total = dadd(val[0], (uint32_t)__shfl_xor((int)val[0], 1, 64));
+        if (NT > 64) {
+            if (wave != 0 && (lane & 1u) == 0) red[(wave - 1u) * 32u + (lane >> 1)] = total;
+        }
+        __syncthreads();                               // every lane is done with this group's slots; the other waves' sums are in LDS
+        if (wave == 0 && (lane & 1u) == 0) {
+            const uint32_t v = lane >> 1, q = v >> 2, c = v & 3u;
+            if (NT > 64) {
+#pragma unroll
+                for (int w = 1; w < NT / 64; w++) total = dadd(total, red[(w - 1) * 32 + v]);
+            }
+            const int H = a.log_n + a.log_qd;
+            const uint32_t e = (e0 + (q << a.log_qd)) & mask;
+            const uint32_t p = __brev(e) >> (32 - H);
+            if (a.addend) total = dadd(total, a.addend[4 * (uint64_t)p + c]);
+            const uint32_t chunk = e & (nq - 1u);
+            const uint32_t iz = chunk == 0 ? a.inv_zh[0] : (chunk == 1 ? a.inv_zh[1] : (chunk == 2 ? a.inv_zh[2] : a.inv_zh[3]));
+            total = dmul(total, iz);
+            a.out[((uint64_t)chunk * ((1ull << H) >> a.log_qd) + (e >> a.log_qd)) * 4 + c] = total;
+            if (a.lde_out) a.lde_out[(uint64_t)p * a.lde_ld + 4u * chunk + c] = total;
+        }
+        if (more) {
+            // row 8 -> row 0, the fetched rows -> rows 1..8, the selector values of the next group's points.  The lane that brings
+            // the new row 8 of a column group moves the old one to row 0 first (no other lane touches those words: no barrier)
+#pragma unroll
+            for (int k = 0; k < NPF; k++) {
+                const uint32_t r = (pf_rc[k] >> 16) & 0xFFu, cg = pf_rc[k] & 0xFFFFu;
+                if (!(pf_rc[k] >> 31)) {
+                    uint4* dst = reinterpret_cast<uint4*>(slots + AIR_GP * cg + 4u * r);
+                    if (r == 8u) *reinterpret_cast<uint4*>(slots + AIR_GP * cg) = *dst;
+                    *dst = pf[k];
+                }
+            }
+            if (tid < 8) *reinterpret_cast<uint4*>(slots + AIR_GP * W4 + 4u * tid) = exn;
+            e0 = e0n;
+        }
+    }
+}
+template <int NT, int NPF>
+static hipError_t launch_chain(const QuotientAirArgs& a, uint32_t n_chains, uint32_t chain_len, size_t lds, hipStream_t s) {
+    if (lds > 64 * 1024) {
+        static std::atomic<size_t> configured[64] = {};
+        int dev = 0;
+        if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return hipErrorInvalidDevice;
+        if (lds > configured[dev].load(std::memory_order_acquire)) {
+            hipError_t e = hipFuncSetAttribute((const void*)quotient_air_chain_kernel<NT, NPF>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            if (e != hipSuccess) return e;
+            configured[dev].store(lds, std::memory_order_release);
+        }
+    }
+    const uint32_t W4 = a.width >> 2;
+    const uint32_t recip = (uint32_t)(((1ull << 32) + W4 - 1) / W4);        // ceil(2^32 / W4): idx / W4 = umulhi(idx, recip) for idx < 2^16
+    hipLaunchKernelGGL((quotient_air_chain_kernel<NT, NPF>), dim3(n_chains), dim3(NT), lds, s, a, chain_len, recip);
+    return hipGetLastError();
+}
+template <int NT>
+static hipError_t launch_chain_nt(const QuotientAirArgs& a, uint32_t n_chains, uint32_t chain_len, size_t lds, hipStream_t s) {
+    const uint32_t need = (8u * (a.width >> 2) + NT - 1) / NT;               // prefetch loads per lane
+    if (need <= 4) return launch_chain<NT, 4>(a, n_chains, chain_len, lds, s);
+    if (need <= 8) return launch_chain<NT, 8>(a, n_chains, chain_len, lds, s);
+    if (need <= 12) return launch_chain<NT, 12>(a, n_chains, chain_len, lds, s);
+    if (need <= 16) return launch_chain<NT, 16>(a, n_chains, chain_len, lds, s);
+    return hipErrorInvalidValue;
+}
 template <int NT>
 static hipError_t launch_terms(const QuotientAirArgs& a, uint32_t n_groups, size_t lds_rows, hipStream_t s) {
     const size_t lds_red = (size_t)32 * (NT + 1) * 4, lds = lds_rows > lds_red ? lds_rows : lds_red;
@@ -426,6 +595,28 @@ hipError_t launch_quotient_air(const QuotientAirArgs& a, hipStream_t s) {
     const bool small = a.n_terms <= 512 && a.width <= 16;
     if (a.recs && fits && !small && (a.n_terms & 1u) == 0) {
         const uint32_t n_groups = (uint32_t)(m / PTS);
+        {   // the chained form: CHAIN consecutive groups of one coset per workgroup (every row fetched once, the next group's rows in
+            // flight under the current group's terms).  Lanes per group: enough to keep the prefetch at <= 16 loads per lane, and by
+            // the work per point as below.
+            const uint32_t blocks = (uint32_t)((1ull << a.log_n) / PTS);        // groups per coset
+            uint32_t chain_len = 32;
+            while (chain_len > blocks) chain_len >>= 1;
+            const uint32_t W4 = a.width >> 2;
+            int nt = a.n_terms <= 512 ? 64 : (a.n_terms <= 8192 ? 128 : 256);
+            while (nt < 256 && 8u * W4 > (nt == 64 ? 12u : 16u) * (uint32_t)nt) nt *= 2;      // one wavefront holds at most 12 prefetch loads per lane without spilling
+            // Term-heavy programs keep the one-group-per-workgroup kernel: their time goes into the terms (record traffic from L2,
+            // LDS reads with random banks), which want four waves per SIMD, and the chained form's prefetch registers cost half of
+            // that (SHA-256 chip, 3 366 records: 6.3 ms chained against 5.7; Poseidon2 chip, 1 008 records: 2.5 against 2.2).  Light
+            // programs are all staging: 8 terms over 608 columns 4.3 -> 1.37 ms per 2^21 points, 360 columns 0.78, 128 columns 0.44.
+            const bool light = a.n_terms <= 512;
+            if (light && chain_len >= 2 && 8u * W4 <= 16u * (uint32_t)nt && 8u * W4 < 65536u && !a.no_chain) {
+                const uint32_t n_chains = (blocks / chain_len) << a.log_qd;
+                const size_t lds = lds_rows + (size_t)(nt / 64) * 32 * 4;
+                if (nt == 64) return launch_chain_nt<64>(a, n_chains, chain_len, lds, s);
+                if (nt == 128) return launch_chain_nt<128>(a, n_chains, chain_len, lds, s);
+                return launch_chain_nt<256>(a, n_chains, chain_len, lds, s);
+            }
+        }
         // lanes per group by the work per point: one wavefront keeps the most groups resident; more only for programs with many records
         // (same box, 2^21 points: the SHA-256 chip's 3 366 records 7.3 / 5.7 / 6.1 ms with 64 / 128 / 256 lanes, the Poseidon2 chip's 1 008
         // records 2.4 / 2.2 ms with 64 / 128; the first form of this kernel, 256 lanes and 16 staged rows: 7.4 and 3.9 ms)
