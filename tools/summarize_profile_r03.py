@@ -26,7 +26,7 @@ for name in ("kt", "kt1", "r0", "big21", "big22"):
         f.write("# rocprofv3 --kernel-trace --stats -- %s (%s%s)\n\n" % (cmd, tag, " @ " + commit if commit else ""))
         f.write("| kernel | calls | total ms | avg us | % |\n|---|---|---|---|---|\n")
         for r in rows:
-            f.write("| %s | %s | %.3f | %.2f | %s |\n" % (r["Name"].split("(")[0], r["Calls"], float(r["TotalDurationNs"]) / 1e6,
+            f.write("| %s | %s | %.3f | %.2f | %s |\n" % ((r["Name"][:r["Name"].rfind("(")] if r["Name"].endswith(")") else r["Name"]), r["Calls"], float(r["TotalDurationNs"]) / 1e6,
                                                          float(r["AverageNs"]) / 1e3, r["Percentage"]))
     for line in open(os.path.join(src, name + ".log")):
         if line.startswith("{"):

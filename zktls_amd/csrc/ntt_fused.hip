@@ -108,6 +108,8 @@ ZK_D TilePos item_pos(uint32_t j, uint32_t xcd, uint32_t ncg, uint32_t log_tiles
 // waves (4 per SIMD) at <= 128 VGPRs.  One wave alone issues a vector instruction every 4 cycles, a SIMD can take one every 2:
 // with only two waves per SIMD (the 512-thread, two-columns-per-lane form of this kernel: 1.32 ms) every stall of one wave
 // halves the SIMD's rate.
+}  // namespace
+
 template <int TAG>
 __global__ void __launch_bounds__(1024, 4) lde_fused_kernel(LdeFusedArgs a, uint32_t items_per_xcd, uint32_t wgs_per_xcd, uint32_t log_tiles) {
     extern __shared__ uint32_t lds[];
@@ -252,6 +254,8 @@ __global__ void __launch_bounds__(1024, 4) lde_fused_kernel(LdeFusedArgs a, uint
         cur = nxt;
     }
 }
+
+namespace {
 
 __global__ void fused_table_kernel(uint32_t* out, const uint32_t* in, int mode) {
     const uint32_t b = blockIdx.x, p = threadIdx.x;          // 1024 threads: one block of 1024 words
