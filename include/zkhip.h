@@ -27,6 +27,9 @@
  *       the reference's batch and large-transcript configurations (BASELINE.json configs[2], configs[3]) with a real statement per proof:
  *       many transcripts, or the shards of one long message, dealt over the GPUs of the node by one call.
  *   zkhip_p2chip_air, zkhip_prove_merkle_paths / zkhip_verify_merkle_paths
+ *   zkhip_fri_view_shard, zkhip_fri_chip_air, zkhip_fri_queries_key, zkhip_prove_fri_queries / zkhip_verify_fri_queries
+ *       a first recursion step: the FRI folds of a shard proof checked inside a (keyed machine) proof -- what `compress` behind
+ *       SP1ProofMode::Groth16 (sp1.rs:116) spends its rows on besides Poseidon2.
  *       a second real chip -- the Poseidon2 permutation with Merkle-path / leaf-hash chaining, what the recursion stages behind
  *       SP1ProofMode::Groth16 (sp1.rs:116) spend their rows on (sp1-recursion's Poseidon2 chips, Cargo.lock:6172 ff.).
  *   zkhip_proof_to_bincode / zkhip_chips_proof_to_bincode (+ _from_bincode)
@@ -590,6 +593,35 @@ size_t zkhip_merkle_paths_proof_size(size_t n_paths, int depth, uint32_t row_wid
 int zkhip_prove_merkle_paths(zkhip_ctx* ctx, const uint32_t* leaves, uint32_t row_width, const uint32_t* siblings, const uint32_t* indices, size_t n_paths, int depth,
                              const uint32_t root[8], const zkhip_params* prm, uint8_t* proof, size_t cap, size_t* len);
 int zkhip_verify_merkle_paths(const uint8_t* proof, size_t len, const uint32_t root[8], size_t n_paths, const zkhip_params* prm, int* reason);
+
+/* ---- a first step of recursion: the FRI part of a shard proof checked INSIDE a proof (second half).  The reference's
+ * hot call is client.prove(.., SP1ProofMode::Groth16) (crates/guest-prover-sp1/src/sp1.rs:116): core -> compress -> shrink -> wrap, and
+ * compress verifies shard proofs in-circuit (sp1-recursion, reference Cargo.lock:6172 ff.; RISC Zero lift -> join, prover.rs:90).
+ * zkhip_fri_view_shard runs the verifier of a zkhip_prove_shard proof (fold by 2, constant final value: the SP1 shape) and hands out what
+ * its FRI check reads: layers = log_n folding challenges (4 words each), the final value, and per query the index (layers + 1 bits), the
+ * reduced opening it starts from and one sibling per layer -- canonical words; fails like zkhip_verify_shard if the proof is rejected.
+ * The FRI-fold chip (fri_chip.hip; 32 + layers columns rounded up to a multiple of 4, one row per (query, layer), degree 3) folds these
+ * chains; its rows send the layer pairs on two lookup buses to a PREPROCESSED table that lists every distinct pair of the view with the
+ * number of queries reading it -- fixed multiplicities, so every listed pair is folded exactly as often as the inner proof reads it.
+ * zkhip_fri_queries_key commits that table (zkhip_machine_setup): vk is what a verifier recomputes from the inner proof; final_value is
+ * what the chains end in.  zkhip_prove_fri_queries generates the chip's trace on the device and proves the two-chip keyed machine
+ * (proof version 11; public values: the challenges, then the final value); zkhip_verify_fri_queries checks it on the host.
+ * NOT in-circuit yet: the Merkle paths of the pairs (the Poseidon2 chip above proves such paths, it is not on this bus yet), the reduced
+ * openings, the transcript.  zkhip_fri_chip_air writes the chip's constraint program (its size in words), zkhip_fri_chip_gen_trace the
+ * trace alone (finals: [n_queries][4], the value each chain ends in). */
+int zkhip_fri_view_shard(const uint8_t* proof, size_t len, int log_n, uint32_t width, const uint32_t* public_values, size_t n_public,
+                         const zkhip_params* prm, uint32_t* betas, uint32_t final_value[4], uint32_t* indices, uint32_t* values, uint32_t* siblings);
+uint32_t zkhip_fri_chip_width(int layers);
+size_t zkhip_fri_chip_air(int layers, uint32_t* program, size_t cap_words);
+int zkhip_fri_chip_gen_trace(zkhip_ctx* ctx, int layers, size_t n_queries, const uint32_t* betas, const uint32_t* indices, const uint32_t* values,
+                             const uint32_t* siblings, int log_rows, uint32_t* d_trace, size_t ld, uint32_t* finals);
+int zkhip_fri_queries_key(zkhip_ctx* ctx, int layers, size_t n_queries, const uint32_t* betas, const uint32_t* indices, const uint32_t* values,
+                          const uint32_t* siblings, const zkhip_params* prm, zkhip_machine_key** key, uint32_t vk[8], uint32_t final_value[4]);
+size_t zkhip_fri_queries_proof_size(int layers, size_t n_queries, const zkhip_params* prm);
+int zkhip_prove_fri_queries(zkhip_ctx* ctx, const zkhip_machine_key* key, int layers, size_t n_queries, const uint32_t* betas, const uint32_t* indices,
+                            const uint32_t* values, const uint32_t* siblings, const zkhip_params* prm, uint8_t* proof, size_t cap, size_t* len);
+int zkhip_verify_fri_queries(const uint8_t* proof, size_t len, int layers, size_t n_queries, const uint32_t* betas, const uint32_t final_value[4],
+                             const uint32_t vk[8], const zkhip_params* prm, int* reason);
 
 /* ---- Poseidon2 parameter tables from a file: the built-in sets are this repo's own
  * ("zktls-amd/p2-bb16-v1", "...-bb24-v1"; the SP1 / RISC Zero tables of reference Cargo.lock:4030, 6172, 5057 are not

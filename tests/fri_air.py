@@ -1,0 +1,197 @@
+"""The FRI-fold chip and its machine, written a second time (the first is zktls_amd/csrc/fri_chip.hip): the constraint program, the
+trace of a view, the OPENINGS table and the two-chip keyed machine -- in plain Python on tests/pyref.py's field arithmetic.  The tests
+require the program words, the trace and the table to be EQUAL to the library's, and the oracle's generic keyed-machine prover on
+these arrays to produce the library's proof bytes.
+
+A view = what the FRI check of a shard proof reads (fold by 2, constant final value): betas[R] (extension elements), final value,
+per query (index, reduced opening, R siblings).  tests/pyverify.py hands one out while verifying (view=...), and so does the
+library (zkhip_fri_view_shard): the two must agree before anything is built on them."""
+import numpy as np
+
+import oracle_lib as O
+from pyref import P, bitrev, ext_mul, two_adic_generator
+
+V = O.air_var
+E0, E1, BIT, K, X, XI, S, T, B, BETA, FOLD, ACTIVE, LN, G, GS, GT, OWN, L = 0, 4, 8, 9, 10, 11, 12, 13, 14, 15, 19, 23, 24, 25, 26, 27, 28, 32
+BUS_E0, BUS_E1 = 40, 41
+OPEN_PRE, OPEN_MAIN = 12, 4
+INV2 = (P + 1) // 2
+EXT_W = 11
+
+
+def width_of(layers):
+    return (32 + layers + 3) & ~3
+
+
+def n_public_of(layers):
+    return 4 * layers + 4
+
+
+def root_const(l):
+    """c_l = w_{2^(l+1)}: what bit l of a query index contributes to its evaluation point"""
+    return two_adic_generator(l + 1)
+
+
+def program(layers):
+    R = layers
+    END = L + R - 1
+    cons = []
+
+    def add(sel, terms):
+        cons.append((sel, [(c % P, list(vs)) for c, vs in terms if c % P]))
+
+    def gated(terms):
+        """G * terms, G = ACTIVE - END: an active row that is not the last of its query (a column: a selector counts one degree)"""
+        return [(c, [V(G)] + list(vs)) for c, vs in terms]
+    add(O.SEL_ALL, [(1, [V(ACTIVE)])] + [(P - 1, [V(L + l)]) for l in range(R)])
+    add(O.SEL_ALL, [(1, [V(LN)])] + [(P - l, [V(L + l)]) for l in range(R)])
+    add(O.SEL_ALL, [(1, [V(ACTIVE), V(ACTIVE)]), (P - 1, [V(ACTIVE)])])
+    add(O.SEL_ALL, [(1, [V(BIT), V(BIT)]), (P - 1, [V(BIT)])])
+    for l in range(R):
+        add(O.SEL_ALL, [(1, [V(L + l), V(L + l)]), (P - 1, [V(L + l)])])
+    for j in range(4):
+        add(O.SEL_ALL, [(1, [V(BETA + j)])] + [(P - 1, [V(L + l), V(4 * l + j, public=True)]) for l in range(R)])
+    add(O.SEL_ALL, [(1, [V(G)]), (P - 1, [V(ACTIVE)]), (1, [V(END)])])
+    add(O.SEL_ALL, [(1, [V(S)]), (P - 1, [V(X), V(X)])])
+    add(O.SEL_ALL, [(1, [V(GS)]), (P - 1, [V(G), V(S)])])
+    add(O.SEL_ALL, [(1, [V(GT)]), (P - 1, [V(G), V(T)])])
+    for j in range(4):
+        add(O.SEL_ALL, [(1, [V(OWN + j)]), (P - 1, [V(E0 + j)]), (1, [V(BIT), V(E0 + j)]), (P - 1, [V(BIT), V(E1 + j)])])
+    add(O.SEL_ALL, [(1, [V(ACTIVE), V(X), V(XI)]), (P - 1, [V(ACTIVE)])])
+    add(O.SEL_ALL, [(1, [V(T)]), (P - 1, []), (1, [V(BIT)])] + [(P - root_const(l), [V(BIT), V(L + l)]) for l in range(R)])
+    for j in range(4):
+        t = [(1, [V(FOLD + j)]), (P - INV2, [V(E0 + j)]), (P - INV2, [V(E1 + j)])]
+        for a in range(4):
+            for d in range(4):
+                if (a + d) % 4 != j:
+                    continue
+                w = INV2 * EXT_W % P if a + d >= 4 else INV2
+                t.append((P - w, [V(BETA + a), V(E0 + d), V(XI)]))
+                t.append((w, [V(BETA + a), V(E1 + d), V(XI)]))
+        add(O.SEL_ALL, t)
+    for l in range(R - 1):
+        add(O.SEL_TRANSITION, [(1, [V(L + l + 1, True)]), (P - 1, [V(L + l)])])
+    add(O.SEL_TRANSITION, gated([(1, [V(K)]), (P - 2, [V(K, True)]), (P - 1, [V(BIT, True)])]))
+    add(O.SEL_ALL, [(1, [V(END), V(K), V(K)]), (P - 1, [V(END), V(K)])])
+    add(O.SEL_TRANSITION, [(1, [V(G), V(X, True)]), (P - 1, [V(GS)]), (2, [V(GS), V(BIT, True)])])
+    add(O.SEL_TRANSITION, [(1, [V(G), V(B)]), (P - 1, [V(GT), V(B, True)])])
+    add(O.SEL_ALL, [(1, [V(END), V(B)]), (P - 1, [V(END), V(T)]), (P - (root_const(R) - 1), [V(END), V(T), V(K)])])
+    add(O.SEL_TRANSITION, [(1, [V(L), V(X)]), (P - 1, [V(L), V(B, True)])])
+    for j in range(4):
+        add(O.SEL_TRANSITION, gated([(1, [V(FOLD + j)]), (P - 1, [V(OWN + j, True)])]))
+    for j in range(4):
+        add(O.SEL_ALL, [(1, [V(END), V(FOLD + j)]), (P - 1, [V(END), V(4 * R + j, public=True)])])
+    return O.air_program(width_of(R), n_public_of(R), cons)
+
+
+def fold_pair(k, lh, beta, e0, e1):
+    """(e0 + e1)/2 + beta (e0 - e1)/(2 x), x = w_{2^(lh+1)}^bitrev_lh(k); -> (folded, x)"""
+    x = pow(two_adic_generator(lh + 1), bitrev(k, lh), P)
+    xi = pow(x, P - 2, P)
+    even = [(a + b) * INV2 % P for a, b in zip(e0, e1)]
+    odd = [(a - b) * INV2 % P * xi % P for a, b in zip(e0, e1)]
+    return [(a + b) % P for a, b in zip(even, ext_mul(beta, odd))], x, xi
+
+
+def log_rows_of(layers, n_queries):
+    lr = 5
+    while (1 << lr) < n_queries * layers:
+        lr += 1
+    return lr
+
+
+def trace(view, log_rows=None):
+    """-> (trace [2^log_rows][width] canonical, final value): one row per (query, layer), padding rows zero with T = 1"""
+    betas, queries = view["betas"], view["queries"]
+    R = len(betas)
+    H = R + 1
+    W = width_of(R)
+    lr = log_rows if log_rows is not None else log_rows_of(R, len(queries))
+    t = np.zeros((1 << lr, W), dtype=np.uint64)
+    t[:, T] = 1
+    final = None
+    for q, (index, value, sibs) in enumerate(queries):
+        idx, own = index, list(value)
+        tcol = []
+        for l in range(R):
+            row = t[q * R + l]
+            bit, k = idx & 1, idx >> 1
+            e0, e1 = (sibs[l], own) if bit else (own, sibs[l])
+            fold, x, xi = fold_pair(k, H - (l + 1), betas[l], e0, e1)
+            row[E0:E0 + 4], row[E1:E1 + 4], row[BETA:BETA + 4], row[FOLD:FOLD + 4] = e0, e1, betas[l], fold
+            row[BIT], row[K], row[X], row[XI], row[S] = bit, k, x, xi, x * x % P
+            tcol.append(root_const(l) if bit else 1)
+            row[T], row[ACTIVE], row[LN], row[L + l] = tcol[-1], 1, l, 1
+            if l + 1 < R:
+                row[G], row[GS], row[GT] = 1, x * x % P, tcol[-1]
+            row[OWN:OWN + 4] = own
+            own, idx = fold, k
+        acc = root_const(R) if idx else 1
+        for l in reversed(range(R)):
+            acc = acc * tcol[l] % P
+            t[q * R + l, B] = acc
+        assert final is None or final == own, "the chains do not end in one value"
+        final = own
+    return t.astype(np.uint32), final
+
+
+def openings(view, log_rows):
+    """the preprocessed table: one row per distinct (layer, pair), ascending, (ln, k, e0[4], e1[4], multiplicity, 0)"""
+    betas, queries = view["betas"], view["queries"]
+    R = len(betas)
+    H = R + 1
+    rows = {}
+    for index, value, sibs in queries:
+        idx, own = index, list(value)
+        for l in range(R):
+            bit, k = idx & 1, idx >> 1
+            e0, e1 = (sibs[l], own) if bit else (own, sibs[l])
+            key = (l, k)
+            if key in rows:
+                assert rows[key][0] == list(e0) + list(e1)
+                rows[key][1] += 1
+            else:
+                rows[key] = [list(e0) + list(e1), 1]
+            own, idx = fold_pair(k, H - (l + 1), betas[l], e0, e1)[0], k
+    t = np.zeros((1 << log_rows, OPEN_PRE), dtype=np.uint32)
+    for r, key in enumerate(sorted(rows)):
+        t[r, 0], t[r, 1], t[r, 2:10], t[r, 10] = key[0], key[1], rows[key][0], rows[key][1]
+    return t
+
+
+def machine(view):
+    """-> (main traces, preprocessed traces, programs, interaction tables, public values), the FRI chip first"""
+    R = len(view["betas"])
+    lr = log_rows_of(R, len(view["queries"]))
+    tr, final = trace(view, lr)
+    pre = openings(view, lr)
+    open_prog = O.air_program(OPEN_PRE + OPEN_MAIN, n_public_of(R), [(O.SEL_FIRST, [(1, [V(OPEN_PRE + 3)])])])
+    fri_tab = O.interaction_table([(O.SEND, ACTIVE, BUS_E0, [LN, K, E0, E0 + 1, E0 + 2, E0 + 3]), (O.SEND, ACTIVE, BUS_E1, [LN, K, E1, E1 + 1, E1 + 2, E1 + 3])])
+    open_tab = O.interaction_table([(O.RECEIVE, 10, BUS_E0, [0, 1, 2, 3, 4, 5]), (O.RECEIVE, 10, BUS_E1, [0, 1, 6, 7, 8, 9])])
+    pub = [c for b in view["betas"] for c in b] + list(final)
+    return [tr, np.zeros((1 << lr, OPEN_MAIN), dtype=np.uint32)], [None, pre], [program(R), open_prog], [fri_tab, open_tab], pub
+
+
+def random_view(layers, n_queries, seed=1):
+    """a consistent view that belongs to no proof: random layer vectors folded honestly (queries that meet share their pairs)"""
+    rng = np.random.default_rng(seed)
+    H = layers + 1
+    betas = [[int(v) for v in rng.integers(0, P, 4)] for _ in range(layers)]
+    vec = [[int(v) for v in rng.integers(0, P, 4)] for _ in range(1 << H)]
+    layers_vec = [vec]
+    for l in range(layers):
+        cur = layers_vec[-1]
+        lh = H - (l + 1)
+        layers_vec.append([fold_pair(k, lh, betas[l], cur[2 * k], cur[2 * k + 1])[0] for k in range(len(cur) // 2)])
+    # a constant final value needs a low-degree start; instead of constructing one, fold to the top and require nothing of the final
+    # layer beyond what the chip checks per query: the chains of all queries must END IN ONE VALUE, so pick queries in one top half
+    top = int(rng.integers(0, 2))
+    queries = []
+    for _ in range(n_queries):
+        index = (top << layers) | int(rng.integers(0, 1 << layers))
+        idx, sibs = index, []
+        for l in range(layers):
+            sibs.append(layers_vec[l][idx ^ 1])
+            idx >>= 1
+        queries.append((index, layers_vec[0][index], sibs))
+    return {"betas": betas, "queries": queries, "final": layers_vec[layers][top]}

@@ -155,8 +155,10 @@ def air_fold(program, loc, nxt, public_values, sel_first, sel_last, sel_trans, a
 
 
 def verify(proof_bytes, log_n, width, public_values, log_blowup=1, num_queries=100, pow_bits=16, logup_pairs=0,
-           log_fold=0, log_final=0, hash_width=0, code_width=0, air=None):
+           log_fold=0, log_final=0, hash_width=0, code_width=0, air=None, view=None):
     """raises Reject(reason) or returns True.  Parameter defaults = the SP1 shape.
+    view: a dict that receives what the FRI check reads -- {"betas", "final", "queries": [(index, reduced opening, siblings)]} --
+    for fold-by-2 proofs (tests/fri_air.py builds the FRI-fold chip's trace from it).
     air: a constraint program (u32 words) replacing the built-in synthetic AIR (proof version 7).
     code_width: RISC Zero's group order -- the first code_width columns and the rest are committed separately (version 8)."""
     if len(proof_bytes) % 4:
@@ -371,12 +373,15 @@ def verify(proof_bytes, log_n, width, public_values, log_blowup=1, num_queries=1
             val = e_add(val, ext_mul(off_pn, ext_mul(e_sub(ap, y_pn), inv2)))
         val = e_add(val, ext_mul(off_q, ext_mul(e_sub(aq, y_q), inv1)))
         idx = index
+        seen = (index, list(val), [])
         for l in range(R):
             lh = H - K * (l + 1)                # log2 of the rows of this layer's matrix (rows of 2^K adjacent entries)
             row, own = idx >> K, idx & (arity - 1)
             entries = []
             for j in range(arity):
                 entries.append(val if j == own else take(4))
+            if K == 1:
+                seen[2].append(list(entries[1 - own]))
             path = [take(8) for _ in range(lh)]
             flat = [c for e in entries for c in e]
             if hasher.root_from_path(flat, row, path) != layer_roots[l]:
@@ -394,6 +399,11 @@ def verify(proof_bytes, log_n, width, public_values, log_blowup=1, num_queries=1
             v = e_add(e_scale(v, xf), c)
         if v != val:
             raise Reject("final polynomial")
+        if view is not None:
+            view.setdefault("queries", []).append(seen)
     if pos != len(w):
         raise Reject("trailing words")
+    if view is not None:
+        view["betas"] = [list(x) for x in betas]
+        view["final"] = list(final_poly[0])
     return True

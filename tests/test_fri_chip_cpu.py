@@ -1,0 +1,149 @@
+"""The FRI-fold chip (zktls_amd/csrc/fri_chip.hip; SURVEY.md 8f-4, second half: a first step of the recursion behind
+SP1ProofMode::Groth16, sp1.rs:116), CPU side: the library's constraint program against the independent Python restatement
+(tests/fri_air.py); the view of a golden shard proof as the library's verifier and the pure-Python verifier hand it out; the two-chip
+keyed machine on the restated trace under the oracle's prover and three verifiers; and what the machine refuses."""
+import hashlib
+import json
+import os
+
+import numpy as np
+import pytest
+
+import fri_air as F
+import pyverify
+import pyverify_chips
+from zktls_amd import _lib
+from zktls_amd._lib import Params
+from zktls_amd.device import fri_chip_air, fri_view_shard, verify_fri_queries, verify_machine_keyed
+
+P = 2013265921
+HERE = os.path.dirname(os.path.abspath(__file__))
+KAT = json.load(open(os.path.join(HERE, "golden", "oracle_kat.json")))
+GOLDEN = KAT["golden_proof_files"]
+
+
+def load(name):
+    return np.frombuffer(open(os.path.join(HERE, "golden", "proofs", name + ".bin"), "rb").read(), dtype=np.uint8)
+
+
+def shape_of(traces, pre):
+    return ([t.shape[0].bit_length() - 1 for t in traces], [t.shape[1] for t in traces], [0 if p is None else p.shape[1] for p in pre])
+
+
+@pytest.mark.parametrize("layers", [2, 3, 6, 10, 14, 20, 22])
+def test_program_words_equal_the_python_restatement(oracle, layers):
+    prog = fri_chip_air(layers)
+    mine = F.program(layers)
+    assert prog.tolist() == mine.tolist()
+    assert oracle.air_validate(prog, F.width_of(layers), F.n_public_of(layers)) == 1
+    assert oracle.air_log_quotient_degree(prog) == 1                 # degree 3 with the selectors: two quotient chunks, blowup 2 is enough
+    lib = _lib.load()
+    assert lib.zkhip_fri_chip_width(layers) == F.width_of(layers) and lib.zkhip_fri_chip_air(1, None, 0) == 0 and lib.zkhip_fri_chip_air(23, None, 0) == 0
+
+
+@pytest.mark.parametrize("name", ["v1_6x8", "v1_10x16"])
+def test_view_of_a_golden_proof_agrees_between_the_library_and_the_python_verifier(name):
+    g = GOLDEN[name]
+    b = load(name)
+    view = {}
+    assert pyverify.verify(b.tobytes(), g["log_n"], g["width"], g["public"], *g["shape"], view=view) is True
+    lib_view = fri_view_shard(b, g["log_n"], g["width"], g["public"], Params(*g["shape"]))
+    assert lib_view["betas"] == view["betas"] and lib_view["final"] == view["final"]
+    assert [(q[0], list(q[1]), [list(s) for s in q[2]]) for q in view["queries"]] == lib_view["queries"]
+    assert len(view["queries"]) == g["shape"][1] and len(view["betas"]) == g["log_n"]
+    # a rejected proof has no view
+    bad = b.copy()
+    bad[-5] ^= 1
+    with pytest.raises(_lib.ZkHipError):
+        fri_view_shard(bad, g["log_n"], g["width"], g["public"], Params(*g["shape"]))
+    # the chains of the view fold to its final value (what the chip will prove), by the restatement's own arithmetic
+    tr, final = F.trace(view)
+    assert list(final) == view["final"]
+
+
+@pytest.mark.parametrize("name,shape", [("v1_6x8", (1, 12, 4)), ("v1_10x16", (1, 10, 6)), ("v1_10x16", (2, 7, 0))])
+def test_machine_of_a_golden_proofs_view_under_the_oracle_prover_and_three_verifiers(oracle, name, shape):
+    O = oracle
+    g = GOLDEN[name]
+    view = fri_view_shard(load(name), g["log_n"], g["width"], g["public"], Params(*g["shape"]))
+    traces, pre, progs, tables, pub = F.machine(view)
+    lns, ws, pws = shape_of(traces, pre)
+    oprm, prm = O.default_params(*shape), Params(*shape)
+    root = O.machine_setup(pre, lns, oprm)
+    proof = O.prove_machine_keyed(traces, pre, progs, tables, pub, oprm)
+    assert O.verify_machine_keyed(proof, lns, ws, pws, root, progs, tables, pub, oprm) == 0
+    assert verify_machine_keyed(proof, lns, ws, pws, root, progs, tables, pub, prm) == (0, 0)
+    assert pyverify_chips.verify(proof.tobytes(), lns, ws, pub, shape[0], shape[1], shape[2], programs=progs, tables=tables, pre_widths=pws, pre_root=[int(v) for v in root]) is True
+    # the named entry: challenges + final value + key
+    assert verify_fri_queries(proof, view["betas"], view["final"], len(view["queries"]), root, prm) == (0, 0)
+    # another final value, another challenge, another key, another query count: refused
+    other = list(view["final"])
+    other[2] = (other[2] + 1) % P
+    assert verify_fri_queries(proof, view["betas"], other, len(view["queries"]), root, prm)[0] == -6
+    betas = [list(x) for x in view["betas"]]
+    betas[1][0] = (betas[1][0] + 1) % P
+    assert verify_fri_queries(proof, betas, view["final"], len(view["queries"]), root, prm)[0] == -6
+    r2 = root.copy()
+    r2[0] = (int(r2[0]) + 1) % P
+    assert verify_fri_queries(proof, view["betas"], view["final"], len(view["queries"]), r2, prm)[0] == -6
+    assert verify_fri_queries(proof, view["betas"], view["final"], 4 * len(view["queries"]) + 40, root, prm)[0] == -6
+
+
+def _machine_rejected(O, traces, pre, progs, tables, pub, shape, root=None):
+    """the oracle proves whatever it is given; an unsatisfied constraint or an unbalanced bus shows in the verifiers"""
+    lns, ws, pws = shape_of(traces, pre)
+    oprm = O.default_params(*shape)
+    root = O.machine_setup(pre, lns, oprm) if root is None else root
+    proof = O.prove_machine_keyed(traces, pre, progs, tables, pub, oprm)
+    a = O.verify_machine_keyed(proof, lns, ws, pws, root, progs, tables, pub, oprm)
+    b = verify_machine_keyed(proof, lns, ws, pws, root, progs, tables, pub, Params(*shape))
+    assert (a != 0) == (b[0] != 0)
+    return a != 0
+
+
+def test_what_the_machine_refuses(oracle):
+    O = oracle
+    shape = (1, 16, 2)
+    view = F.random_view(5, 9, seed=4)
+    traces, pre, progs, tables, pub = F.machine(view)
+    assert not _machine_rejected(O, traces, pre, progs, tables, pub, shape)
+    honest_root = O.machine_setup(pre, shape_of(traces, pre)[0], O.default_params(*shape))
+    R = 5
+
+    def tampered(fn):
+        t = [x.copy() for x in traces]
+        fn(t[0])
+        return t
+    # a wrong fold; the other square root for X (with its inverse and square kept consistent); a sibling that is not the listed one
+    assert _machine_rejected(O, tampered(lambda t: t.__setitem__((3, F.FOLD), (int(t[3, F.FOLD]) + 1) % P)), pre, progs, tables, pub, shape)
+
+    def flip_x(t):
+        t[0, F.X] = (P - int(t[0, F.X])) % P
+        t[0, F.XI] = (P - int(t[0, F.XI])) % P
+    assert _machine_rejected(O, tampered(flip_x), pre, progs, tables, pub, shape)
+    assert _machine_rejected(O, tampered(lambda t: t.__setitem__((2 * R + 1, F.E1 + 2), (int(t[2 * R + 1, F.E1 + 2]) + 1) % P)), pre, progs, tables, pub, shape)
+    # a query left out: its rows turned into padding -- the table's multiplicities are part of the KEY, so the buses no longer balance
+    def drop_last_query(t):
+        rows = slice(8 * R, 9 * R)
+        t[rows] = 0
+        t[rows, F.T] = 1
+    assert _machine_rejected(O, tampered(drop_last_query), pre, progs, tables, pub, shape)
+    # ... and a prover who ALSO rewrites the table (fewer reads listed) is proving against another key
+    fewer = {"betas": view["betas"], "queries": view["queries"][:8]}
+    t2, pre2, _, _, pub2 = F.machine(fewer)
+    if t2[0].shape == traces[0].shape:
+        assert _machine_rejected(O, t2, pre2, progs, tables, pub2, shape, root=honest_root)
+    # a chain that ends elsewhere: the public final value is what every END row must show
+    pub_bad = list(pub)
+    pub_bad[-1] = (pub_bad[-1] + 1) % P
+    assert _machine_rejected(O, traces, pre, progs, tables, pub_bad, shape)
+
+
+def test_entry_point_argument_checks():
+    lib = _lib.load()
+    prm = Params(1, 8, 2)
+    assert lib.zkhip_fri_queries_proof_size(1, 8, prm) == 0 and lib.zkhip_fri_queries_proof_size(6, 0, prm) == 0
+    assert lib.zkhip_fri_queries_proof_size(6, 8, prm) > 0
+    g = GOLDEN["v3_r0_9x8"]                       # fold by 16: no view
+    with pytest.raises(_lib.ZkHipError):
+        fri_view_shard(load("v3_r0_9x8"), g["log_n"], g["width"], g["public"], Params(*g["shape"]))

@@ -1,0 +1,103 @@
+"""The FRI-fold chip on the GPU (zkhip_prove_fri_queries; SURVEY.md 8f-4, second half): a shard is proven on the device, the verifier
+hands out the view of its FRI part, and a second proof -- a keyed machine of the FRI-fold chip and the preprocessed OPENINGS table --
+states that every query chain of that view folds to the final value.  The chip's trace comes from the device generator and must equal
+the independent Python restatement (tests/fri_air.py) word for word; the machine proof must equal, byte for byte, what the oracle's
+generic keyed-machine prover makes of the restated arrays; three verifiers accept it."""
+import time
+
+import numpy as np
+import pytest
+
+import fri_air as F
+import pyverify
+import pyverify_chips
+from zktls_amd._lib import Params
+from zktls_amd.device import fri_view_shard, verify_fri_queries, verify_machine_keyed, verify_shard
+
+pytestmark = pytest.mark.gpu
+SEED = 0x5A4B544C53
+P = 2013265921
+
+
+def shape_of(traces, pre):
+    return ([t.shape[0].bit_length() - 1 for t in traces], [t.shape[1] for t in traces], [0 if p is None else p.shape[1] for p in pre])
+
+
+@pytest.mark.parametrize("log_n,width,inner,outer", [(6, 8, (1, 9, 4), (1, 12, 4)), (10, 16, (1, 25, 8), (1, 20, 8)), (13, 32, (1, 40, 8), (2, 12, 0))])
+def test_fri_queries_of_a_shard_proof_fold_in_circuit(ctx, oracle, log_n, width, inner, outer):
+    O = oracle
+    iprm, oprm, prm = Params(*inner), O.default_params(*outer), Params(*outer)
+    pv = [7, 8, 9]
+    trace = ctx.gen_trace(SEED, 21, log_n, width)
+    shard_proof = ctx.prove_shard(trace, log_n, width, pv, iprm)
+    assert verify_shard(shard_proof, log_n, width, pv, iprm) == (0, 0)
+    view = fri_view_shard(shard_proof, log_n, width, pv, iprm)
+    pview = {}
+    assert pyverify.verify(shard_proof.tobytes(), log_n, width, pv, *inner, view=pview) is True
+    assert pview["betas"] == view["betas"] and pview["final"] == view["final"]
+    assert [(q[0], list(q[1]), [list(s) for s in q[2]]) for q in pview["queries"]] == view["queries"]
+    # the chip's trace: device generator == Python restatement
+    traces, pre, progs, tables, pub = F.machine(view)
+    lns, ws, pws = shape_of(traces, pre)
+    d_trace, finals = ctx.fri_chip_gen_trace(view, lns[0])
+    assert (d_trace.download().reshape(-1, ws[0]) == traces[0]).all()
+    assert (finals == np.array(view["final"], dtype=np.uint32)).all()
+    d_trace.free()
+    # key and proof: bytes equal to the oracle's generic keyed-machine prover on the restated arrays
+    key, final = ctx.fri_queries_key(view, prm)
+    assert final == view["final"]
+    assert key.root.tolist() == O.machine_setup(pre, lns, oprm).tolist()
+    proof = ctx.prove_fri_queries(key, view, prm)
+    oproof = O.prove_machine_keyed(traces, pre, progs, tables, pub, oprm)
+    assert proof.tobytes() == oproof.tobytes(), "FRI-queries machine proof differs from the oracle's"
+    # three verifiers
+    nq = len(view["queries"])
+    assert verify_fri_queries(proof, view["betas"], view["final"], nq, key.root, prm) == (0, 0)
+    assert verify_machine_keyed(proof, lns, ws, pws, key.root, progs, tables, pub, prm) == (0, 0)
+    assert O.verify_machine_keyed(proof, lns, ws, pws, key.root, progs, tables, pub, oprm) == 0
+    assert pyverify_chips.verify(proof.tobytes(), lns, ws, pub, outer[0], outer[1], outer[2], programs=progs, tables=tables, pre_widths=pws,
+                                 pre_root=[int(v) for v in key.root]) is True
+    # the statement is about THIS proof's view: another proof of the same shape has another key and other challenges
+    other = ctx.prove_shard(trace, log_n, width, [7, 8, 10], iprm)
+    oview = fri_view_shard(other, log_n, width, [7, 8, 10], iprm)
+    okey, _ = ctx.fri_queries_key(oview, prm)
+    assert okey.root.tolist() != key.root.tolist()
+    assert verify_fri_queries(proof, oview["betas"], oview["final"], nq, okey.root, prm)[0] == -6
+    assert verify_fri_queries(proof, view["betas"], view["final"], nq, okey.root, prm)[0] == -6
+    # a view that was tampered with (a sibling changed) is refused before anything is proven: its chains no longer end in one value
+    bad = {"betas": view["betas"], "queries": [(q[0], q[1], [list(s) for s in q[2]]) for q in view["queries"]]}
+    bad["queries"][0][2][1][0] = (bad["queries"][0][2][1][0] + 1) % P
+    with pytest.raises(Exception):
+        ctx.prove_fri_queries(key, bad, prm)
+    key.close()
+    okey.close()
+    trace.free()
+
+
+def test_fullsize_fri_queries_of_the_headline_shard(ctx, oracle):
+    """the 100 queries x 20 layers of a 2^20 x 256 SP1-shape shard proof: 2 000 rows of the chip, a 2^11-row machine"""
+    O = oracle
+    log_n, width = 20, 256
+    iprm, prm, oprm = Params(1, 100, 16), Params(1, 100, 16), O.default_params(1, 100, 16)
+    trace = ctx.gen_trace(SEED, 31, log_n, width)
+    shard_proof = ctx.prove_shard(trace, log_n, width, [1, 2, 3], iprm)
+    trace.free()
+    t0 = time.perf_counter()
+    view = fri_view_shard(shard_proof, log_n, width, [1, 2, 3], iprm)
+    t1 = time.perf_counter()
+    key, final = ctx.fri_queries_key(view, prm)
+    t2 = time.perf_counter()
+    proof = ctx.prove_fri_queries(key, view, prm)
+    t3 = time.perf_counter()
+    proof = ctx.prove_fri_queries(key, view, prm)
+    t4 = time.perf_counter()
+    assert verify_fri_queries(proof, view["betas"], view["final"], 100, key.root, prm) == (0, 0)
+    t5 = time.perf_counter()
+    print("\nFRI queries of a 2^20 x 256 shard proof: view (host verifier) %.1f ms, key %.1f ms, machine proof %.1f ms (first %.1f), %d bytes, host verification %.1f ms"
+          % ((t1 - t0) * 1e3, (t2 - t1) * 1e3, (t4 - t3) * 1e3, (t3 - t2) * 1e3, proof.size, (t5 - t4) * 1e3))
+    traces, pre, progs, tables, pub = F.machine(view)
+    lns, ws, pws = shape_of(traces, pre)
+    assert lns == [11, 11] and ws[0] == 52
+    assert proof.tobytes() == O.prove_machine_keyed(traces, pre, progs, tables, pub, oprm).tobytes()
+    assert O.verify_machine_keyed(proof, lns, ws, pws, key.root, progs, tables, pub, oprm) == 0
+    key.close()

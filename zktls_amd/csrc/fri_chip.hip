@@ -1,0 +1,425 @@
+// fri_chip.hip -- the first piece of a verifier inside a proof (second half): the FRI-fold chip.
+//
+// The reference's one hot call is `client.prove(&pk, &stdin, SP1ProofMode::Groth16)` (crates/guest-prover-sp1/src/sp1.rs:116):
+// core -> compress -> shrink -> wrap, and compress is a machine that VERIFIES shard proofs (sp1-recursion, reference Cargo.lock:6172 ff.;
+// RISC Zero: lift -> join behind prover.rs:90).  A FRI verifier spends its rows on two things: Poseidon2 (Merkle paths -- the
+// Poseidon2 chip, poseidon2_chip.cpp) and extension-field folding -- this chip.  The statement proven here, about ONE shard proof of
+// this library (fold by 2, constant final value):
+//     "every query's chain of layer pairs folds, under the challenges beta_l, from its reduced opening to the final value, and the
+//      pairs are exactly the ones listed in the key"
+// as a keyed machine of two chips:
+//   FRI   one row per (query, layer).  Columns: E0 E1 (the pair at positions 2k, 2k + 1 of the layer's vector, extension elements),
+//         BIT (own position's parity), K (the pair's index), X = w^(bitrev K) and XI = 1/X, S = X^2, T = 1 + BIT (c_l - 1) and
+//         B = suffix product of the T's (binds X of the first layer to the index bits), BETA, FOLD = (E0 + E1)/2 + BETA (E0 - E1)/(2 X),
+//         ACTIVE, LN (layer number), G = ACTIVE - END with G S, G T and OWN (the row's own entry) as helper columns, L (one-hot
+//         layer).  Every constraint has degree <= 3, its selector included.  The row sends (LN, K, E0) and (LN, K, E1)
+//         on two buses.
+//   OPENINGS   a PREPROCESSED table (setup commits it; its root is the verifying key): one row per distinct (layer, pair) with both
+//         entries and the number of queries that read it.  It receives the tuples with those FIXED multiplicities, so the FRI chip
+//         must send every listed pair exactly as often as the proof's queries read it: no query can be left out, none invented.
+// Public values: beta_l (4 words each), then the final value.  What is NOT yet in-circuit: the Merkle paths of the pairs (the
+// Poseidon2 chip proves such paths, but is not wired to this bus yet), the reduced openings themselves, the transcript.  A verifier of
+// this machine proof recomputes the key from the inner proof's openings (zkhip_fri_queries_key) -- it still reads them, but no longer
+// folds them.  tests/fri_air.py writes the same program, trace and table independently; the words must be equal.
+#include <cstring>
+#include <map>
+#include <memory>
+#include <mutex>
+#include <vector>
+
+#include "air.h"
+#include "context.h"
+
+namespace zk {
+namespace frichip {
+
+constexpr uint32_t E0 = 0, E1 = 4, BIT = 8, K = 9, X = 10, XI = 11, S = 12, T = 13, B = 14, BETA = 15, FOLD = 19, ACTIVE = 23, LN = 24, G = 25, GS = 26, GT = 27,
+                   OWN = 28, L = 32;
+constexpr uint32_t BUS_E0 = 40, BUS_E1 = 41;
+constexpr uint32_t OPEN_PRE = 12, OPEN_MAIN = 4;             // OPENINGS: preprocessed (ln, k, e0[4], e1[4], m, 0), main 4 unused columns
+constexpr int MIN_LAYERS = 2, MAX_LAYERS = 22;
+inline uint32_t width_of(int layers) { return (32u + (uint32_t)layers + 3u) & ~3u; }
+inline uint32_t n_public_of(int layers) { return 4u * (uint32_t)layers + 4u; }
+
+namespace {
+inline Ext ext_from_canon(const uint32_t* p);
+struct Term { uint32_t coeff; std::vector<uint32_t> vars; };
+typedef std::vector<Term> Terms;
+inline uint32_t var(uint32_t col, bool next = false) { return next ? ((1u << 30) | col) : col; }
+inline uint32_t pub(uint32_t idx) { return (2u << 30) | idx; }
+inline uint32_t neg(uint64_t c) { c %= P; return c ? (uint32_t)(P - c) : 0u; }
+inline uint32_t mulm(uint64_t a, uint64_t b) { return (uint32_t)((a % P) * (b % P) % P); }
+enum : uint32_t { ALL = 0, FIRST = 1, LAST = 2, TRANSITION = 3 };
+struct Builder {
+    std::vector<uint32_t> body;
+    uint32_t count = 0;
+    void add(uint32_t selector, const Terms& terms) {
+        Terms kept;
+        for (const Term& t : terms) if (t.coeff % P) kept.push_back(t);
+        body.push_back(selector);
+        body.push_back((uint32_t)kept.size());
+        for (const Term& t : kept) {
+            body.push_back(t.coeff % P);
+            body.push_back((uint32_t)t.vars.size());
+            for (uint32_t v : t.vars) body.push_back(v);
+        }
+        count++;
+    }
+};
+// c_l = w_{2^(l+1)} canonical: the factor bit l of a query index contributes to its evaluation point
+inline uint32_t root_const(int l) { return from_monty(two_adic_generator(l + 1)); }
+
+std::vector<uint32_t> build_program(int RL) {
+    const uint32_t W = width_of(RL), NP = n_public_of(RL), END = L + (uint32_t)RL - 1u;
+    const uint32_t inv2 = (P + 1) / 2;
+    Builder b;
+    // G * t for the gate G = ACTIVE - END ("an active row that is not the last of its query").  A selector counts one degree, so a
+    // transition constraint may multiply two columns only: G, G S, G T and the row's own entry OWN are columns of their own.
+    auto gated = [&](const Terms& ts) {
+        Terms out;
+        for (const Term& t : ts) {
+            Term a = t;
+            a.vars.insert(a.vars.begin(), var(G));
+            out.push_back(a);
+        }
+        return out;
+    };
+    {   // ACTIVE = sum L_l, a bit; LN = sum l L_l
+        Terms t{{1u, {var(ACTIVE)}}}, n{{1u, {var(LN)}}};
+        for (int l = 0; l < RL; l++) { t.push_back(Term{P - 1, {var(L + l)}}); n.push_back(Term{neg((uint64_t)l), {var(L + l)}}); }
+        b.add(ALL, t);
+        b.add(ALL, n);
+    }
+    b.add(ALL, Terms{{1u, {var(ACTIVE), var(ACTIVE)}}, {P - 1, {var(ACTIVE)}}});
+    b.add(ALL, Terms{{1u, {var(BIT), var(BIT)}}, {P - 1, {var(BIT)}}});
+    for (int l = 0; l < RL; l++) b.add(ALL, Terms{{1u, {var(L + l), var(L + l)}}, {P - 1, {var(L + l)}}});
+    for (uint32_t j = 0; j < 4; j++) {      // BETA = the layer's public challenge
+        Terms t{{1u, {var(BETA + j)}}};
+        for (int l = 0; l < RL; l++) t.push_back(Term{P - 1, {var(L + l), pub(4u * (uint32_t)l + j)}});
+        b.add(ALL, t);
+    }
+    b.add(ALL, Terms{{1u, {var(G)}}, {P - 1, {var(ACTIVE)}}, {1u, {var(END)}}});
+    b.add(ALL, Terms{{1u, {var(S)}}, {P - 1, {var(X), var(X)}}});
+    b.add(ALL, Terms{{1u, {var(GS)}}, {P - 1, {var(G), var(S)}}});
+    b.add(ALL, Terms{{1u, {var(GT)}}, {P - 1, {var(G), var(T)}}});
+    for (uint32_t j = 0; j < 4; j++)        // OWN = E0 (1 - BIT) + E1 BIT
+        b.add(ALL, Terms{{1u, {var(OWN + j)}}, {P - 1, {var(E0 + j)}}, {1u, {var(BIT), var(E0 + j)}}, {P - 1, {var(BIT), var(E1 + j)}}});
+    b.add(ALL, Terms{{1u, {var(ACTIVE), var(X), var(XI)}}, {P - 1, {var(ACTIVE)}}});
+    {   // T = 1 - BIT + BIT c_l
+        Terms t{{1u, {var(T)}}, {P - 1, {}}, {1u, {var(BIT)}}};
+        for (int l = 0; l < RL; l++) t.push_back(Term{neg(root_const(l)), {var(BIT), var(L + l)}});
+        b.add(ALL, t);
+    }
+    for (uint32_t j = 0; j < 4; j++) {      // FOLD = (E0 + E1)/2 + BETA (E0 - E1) XI / 2 in F_p[x] / (x^4 - 11)
+        Terms t{{1u, {var(FOLD + j)}}, {neg(inv2), {var(E0 + j)}}, {neg(inv2), {var(E1 + j)}}};
+        for (uint32_t a = 0; a < 4; a++)
+            for (uint32_t d = 0; d < 4; d++) {
+                if ((a + d) % 4 != j) continue;
+                const uint32_t w = a + d >= 4 ? mulm(inv2, EXT_W) : inv2;
+                t.push_back(Term{neg(w), {var(BETA + a), var(E0 + d), var(XI)}});
+                t.push_back(Term{w, {var(BETA + a), var(E1 + d), var(XI)}});
+            }
+        b.add(ALL, t);
+    }
+    for (int l = 0; l + 1 < RL; l++) b.add(TRANSITION, Terms{{1u, {var(L + l + 1, true)}}, {P - 1, {var(L + l)}}});
+    b.add(TRANSITION, gated(Terms{{1u, {var(K)}}, {P - 2, {var(K, true)}}, {P - 1, {var(BIT, true)}}}));           // K = 2 K' + BIT'
+    b.add(ALL, Terms{{1u, {var(END), var(K), var(K)}}, {P - 1, {var(END), var(K)}}});                              // the bit above the folded ones
+    b.add(TRANSITION, Terms{{1u, {var(G), var(X, true)}}, {P - 1, {var(GS)}}, {2u, {var(GS), var(BIT, true)}}});           // X' = X^2 (1 - 2 BIT')
+    b.add(TRANSITION, Terms{{1u, {var(G), var(B)}}, {P - 1, {var(GT), var(B, true)}}});                                    // B = B' T
+    b.add(ALL, Terms{{1u, {var(END), var(B)}}, {P - 1, {var(END), var(T)}}, {neg((uint64_t)root_const(RL) + P - 1), {var(END), var(T), var(K)}}});
+    b.add(TRANSITION, Terms{{1u, {var(L), var(X)}}, {P - 1, {var(L), var(B, true)}}});                             // first layer: X = product over the higher bits
+    for (uint32_t j = 0; j < 4; j++)        // the folded value is the next layer's own entry
+        b.add(TRANSITION, gated(Terms{{1u, {var(FOLD + j)}}, {P - 1, {var(OWN + j, true)}}}));
+    for (uint32_t j = 0; j < 4; j++) b.add(ALL, Terms{{1u, {var(END), var(FOLD + j)}}, {P - 1, {var(END), pub(4u * (uint32_t)RL + j)}}});
+    std::vector<uint32_t> p{AIR_MAGIC, 1u, W, b.count, NP, (uint32_t)(6 + b.body.size())};
+    p.insert(p.end(), b.body.begin(), b.body.end());
+    return p;
+}
+std::shared_ptr<const std::vector<uint32_t>> program(int RL) {
+    static std::mutex mu;
+    static std::map<int, std::shared_ptr<const std::vector<uint32_t>>> cache;
+    std::lock_guard<std::mutex> lk(mu);
+    auto it = cache.find(RL);
+    if (it == cache.end()) it = cache.emplace(RL, std::make_shared<const std::vector<uint32_t>>(build_program(RL))).first;
+    return it->second;
+}
+// OPENINGS: combined row [ln k e0 e1 m 0 | 0 0 0 0]; its program is one harmless identity (the contents are fixed by the KEY)
+std::shared_ptr<const std::vector<uint32_t>> openings_program(int RL) {
+    static std::mutex mu;
+    static std::map<int, std::shared_ptr<const std::vector<uint32_t>>> cache;
+    std::lock_guard<std::mutex> lk(mu);
+    auto it = cache.find(RL);
+    if (it == cache.end())
+        it = cache.emplace(RL, std::make_shared<const std::vector<uint32_t>>(std::vector<uint32_t>{AIR_MAGIC, 1u, OPEN_PRE + OPEN_MAIN, 1u, n_public_of(RL), 6u + 5u,
+                                                                                                    FIRST, 1u, 1u, 1u, var(OPEN_PRE + 3)})).first;
+    return it->second;
+}
+const std::vector<uint32_t>& fri_interactions() {       // two sends with multiplicity ACTIVE
+    static const std::vector<uint32_t> t{LOOKUP_MAGIC, 2u, 3u + 2u * 10u,
+                                         0u, ACTIVE, BUS_E0, 6u, LN, K, E0, E0 + 1, E0 + 2, E0 + 3,
+                                         0u, ACTIVE, BUS_E1, 6u, LN, K, E1, E1 + 1, E1 + 2, E1 + 3};
+    return t;
+}
+const std::vector<uint32_t>& openings_interactions() {  // two receives with the preprocessed multiplicity (column 10)
+    static const std::vector<uint32_t> t{LOOKUP_MAGIC, 2u, 3u + 2u * 10u,
+                                         1u, 10u, BUS_E0, 6u, 0u, 1u, 2u, 3u, 4u, 5u,
+                                         1u, 10u, BUS_E1, 6u, 0u, 1u, 6u, 7u, 8u, 9u};
+    return t;
+}
+
+struct TraceArgs {
+    const uint32_t *betas, *indices, *values, *siblings;    // canonical, on the device
+    uint32_t n_queries, layers, width, log_h;               // log_h = layers + 1: bits of a query index
+    uint64_t rows;
+    uint32_t* trace; uint64_t ld;                           // Montgomery
+    uint32_t* finals;                                       // [n_queries][4] canonical: the value every chain ends in
+};
+// one thread per query walks its layers (the folded value of a layer is the next layer's own entry); threads past the queries fill
+// the padding rows: zeros with T = 1
+__global__ void __launch_bounds__(64) fri_trace_kernel(TraceArgs a) {
+    const uint32_t q = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t RL = a.layers, W = a.width;
+    const uint64_t used = (uint64_t)a.n_queries * RL;
+    if (q >= a.n_queries) {
+        for (uint64_t r = used + (q - a.n_queries); r < a.rows; r += (uint64_t)gridDim.x * blockDim.x - a.n_queries) {
+            uint32_t* row = a.trace + r * a.ld;
+            for (uint32_t c = 0; c < W; c++) row[c] = c == T ? MONTY_R1 : 0u;
+        }
+        return;
+    }
+    uint32_t idx = a.indices[q];
+    Ext own;
+    for (int i = 0; i < 4; i++) own.c[i] = to_monty(a.values[4 * q + i]);
+    uint32_t tcol[MAX_LAYERS];
+    for (uint32_t l = 0; l < RL; l++) {
+        uint32_t* row = a.trace + ((uint64_t)q * RL + l) * a.ld;
+        const uint32_t bit = idx & 1u, k = idx >> 1;
+        Ext sib, beta;
+        for (int i = 0; i < 4; i++) { sib.c[i] = to_monty(a.siblings[4 * ((uint64_t)q * RL + l) + i]); beta.c[i] = to_monty(a.betas[4 * l + i]); }
+        const Ext e0 = bit ? sib : own, e1 = bit ? own : sib;
+        const int lh = (int)a.log_h - (int)(l + 1);                       // the layer's vector has 2^(lh + 1) entries
+        const uint32_t x = fpow(two_adic_generator(lh + 1), reverse_bits(k, lh));
+        const uint32_t xi = finv(x);
+        const Ext even = ext_mul_base(ext_add(e0, e1), MONTY_INV2);
+        const Ext odd = ext_mul_base(ext_sub(e0, e1), fmul(MONTY_INV2, xi));
+        const Ext fold = ext_add(even, ext_mul(beta, odd));
+        for (uint32_t c = 0; c < W; c++) row[c] = 0u;
+        for (int i = 0; i < 4; i++) { row[E0 + i] = e0.c[i]; row[E1 + i] = e1.c[i]; row[BETA + i] = beta.c[i]; row[FOLD + i] = fold.c[i]; }
+        row[BIT] = bit ? MONTY_R1 : 0u;
+        row[K] = to_monty(k);
+        row[X] = x; row[XI] = xi; row[S] = fmul(x, x);
+        tcol[l] = bit ? two_adic_generator((int)l + 1) : MONTY_R1;
+        row[T] = tcol[l];
+        row[ACTIVE] = MONTY_R1;
+        row[LN] = to_monty(l);
+        row[L + l] = MONTY_R1;
+        if (l + 1 < RL) { row[G] = MONTY_R1; row[GS] = row[S]; row[GT] = tcol[l]; }
+        for (int i = 0; i < 4; i++) row[OWN + i] = own.c[i];
+        own = fold;
+        idx = k;
+    }
+    // B: suffix products of T, the last row's including the factor of the one index bit above the folded ones (idx is that bit now)
+    uint32_t bacc = idx ? two_adic_generator((int)RL + 1) : MONTY_R1;
+    for (int l = (int)RL - 1; l >= 0; l--) {
+        bacc = fmul(bacc, tcol[l]);
+        a.trace[((uint64_t)q * RL + (uint32_t)l) * a.ld + B] = bacc;
+    }
+    for (int i = 0; i < 4; i++) a.finals[4 * q + i] = from_monty(own.c[i]);
+}
+
+int shape_ok(int layers, size_t n_queries, int* log_rows) {
+    if (layers < MIN_LAYERS || layers > MAX_LAYERS || n_queries < 1 || n_queries > ((size_t)1 << 16))
+        return fail(ZKHIP_ERR_INVALID, "fri queries: 2..22 layers, 1..65536 queries");
+    int lr = 5;
+    while (((size_t)1 << lr) < n_queries * (size_t)layers) lr++;
+    *log_rows = lr;
+    return ZKHIP_OK;
+}
+struct Machine {
+    int32_t log_ns[2]; uint32_t widths[2], pre_widths[2];
+    const uint32_t* progs[2]; size_t prog_words[2]; const uint32_t* tabs[2]; size_t tab_words[2];
+    std::shared_ptr<const std::vector<uint32_t>> p0, p1;
+};
+Machine machine_of(int layers, int log_rows) {
+    Machine m;
+    m.p0 = program(layers); m.p1 = openings_program(layers);
+    m.log_ns[0] = m.log_ns[1] = log_rows;
+    m.widths[0] = width_of(layers); m.widths[1] = OPEN_MAIN;
+    m.pre_widths[0] = 0; m.pre_widths[1] = OPEN_PRE;
+    m.progs[0] = m.p0->data(); m.prog_words[0] = m.p0->size(); m.progs[1] = m.p1->data(); m.prog_words[1] = m.p1->size();
+    m.tabs[0] = fri_interactions().data(); m.tab_words[0] = fri_interactions().size();
+    m.tabs[1] = openings_interactions().data(); m.tab_words[1] = openings_interactions().size();
+    return m;
+}
+// the OPENINGS table of a view: one row per distinct (layer, pair) in ascending (layer, pair) order, the pair's two entries, and how
+// many queries read it; the remaining rows are zero (multiplicity 0).  Host, canonical -> Montgomery.  Also checks that the chains are
+// consistent (the same pair read by two queries holds the same entries): a view taken from an accepted proof always is.
+int build_openings(int layers, size_t n_queries, const uint32_t* betas, const uint32_t* indices, const uint32_t* values, const uint32_t* siblings,
+                   int log_rows, std::vector<uint32_t>& table, uint32_t final_value[4]) {
+    const int H = layers + 1;
+    std::map<uint64_t, std::vector<uint32_t>> rows;          // key = layer << 32 | pair -> e0[4] e1[4] count
+    bool have_final = false;
+    for (size_t q = 0; q < n_queries; q++) {
+        uint32_t idx = indices[q];
+        if (idx >> H) return fail(ZKHIP_ERR_INVALID, "fri queries: a query index has more than layers + 1 bits");
+        Ext own = ext_from_canon(values + 4 * q);
+        for (int l = 0; l < layers; l++) {
+            const uint32_t bit = idx & 1u, k = idx >> 1;
+            const Ext sib = ext_from_canon(siblings + 4 * (q * (size_t)layers + l));
+            const Ext e0 = bit ? sib : own, e1 = bit ? own : sib;
+            std::vector<uint32_t> r(9);
+            for (int i = 0; i < 4; i++) { r[i] = e0.c[i]; r[4 + i] = e1.c[i]; }
+            auto it = rows.find(((uint64_t)l << 32) | k);
+            if (it == rows.end()) { r[8] = 1; rows.emplace(((uint64_t)l << 32) | k, r); }
+            else {
+                for (int i = 0; i < 8; i++) if (it->second[i] != r[i]) return fail(ZKHIP_ERR_INVALID, "fri queries: two queries disagree about a layer pair");
+                it->second[8]++;
+            }
+            const int lh = H - (l + 1);
+            const uint32_t xi = finv(fpow(two_adic_generator(lh + 1), reverse_bits(k, lh)));
+            const Ext beta = ext_from_canon(betas + 4 * l);
+            own = ext_add(ext_mul_base(ext_add(e0, e1), MONTY_INV2), ext_mul(beta, ext_mul_base(ext_sub(e0, e1), fmul(MONTY_INV2, xi))));
+            idx = k;
+        }
+        uint32_t fv[4];
+        for (int i = 0; i < 4; i++) fv[i] = from_monty(own.c[i]);
+        if (!have_final) { std::memcpy(final_value, fv, 16); have_final = true; }
+        else if (std::memcmp(final_value, fv, 16) != 0) return fail(ZKHIP_ERR_INVALID, "fri queries: the chains do not end in one value");
+    }
+    if (rows.size() > ((size_t)1 << log_rows)) return fail(ZKHIP_ERR_INTERNAL, "fri queries: more pairs than rows");
+    table.assign(((size_t)OPEN_PRE) << log_rows, 0u);
+    size_t r = 0;
+    for (const auto& e : rows) {
+        uint32_t* row = table.data() + OPEN_PRE * r++;
+        row[0] = to_monty((uint32_t)(e.first >> 32));
+        row[1] = to_monty((uint32_t)e.first);
+        for (int i = 0; i < 8; i++) row[2 + i] = e.second[i];
+        row[10] = to_monty(e.second[8]);
+    }
+    return ZKHIP_OK;
+}
+inline Ext ext_from_canon(const uint32_t* p) { return Ext{{to_monty(p[0]), to_monty(p[1]), to_monty(p[2]), to_monty(p[3])}}; }
+bool canonical(const uint32_t* v, size_t n) { for (size_t i = 0; i < n; i++) if (v[i] >= P) return false; return true; }
+
+}  // namespace
+}  // namespace frichip
+}  // namespace zk
+
+using namespace zk;
+
+#define CHECK_CTX(ctx)                                                  \
+    do {                                                                \
+        if (!(ctx)) return fail(ZKHIP_ERR_INVALID, "null context");     \
+        ZK_HIP(hipSetDevice((ctx)->device));                            \
+    } while (0)
+
+extern "C" {
+
+uint32_t zkhip_fri_chip_width(int layers) { return layers >= frichip::MIN_LAYERS && layers <= frichip::MAX_LAYERS ? frichip::width_of(layers) : 0u; }
+
+size_t zkhip_fri_chip_air(int layers, uint32_t* program, size_t cap_words) {
+    if (layers < frichip::MIN_LAYERS || layers > frichip::MAX_LAYERS) return 0;
+    const auto p = frichip::program(layers);
+    if (program && cap_words >= p->size()) std::memcpy(program, p->data(), p->size() * 4);
+    return p->size();
+}
+
+int zkhip_fri_chip_gen_trace(zkhip_ctx* ctx, int layers, size_t n_queries, const uint32_t* betas, const uint32_t* indices, const uint32_t* values,
+                             const uint32_t* siblings, int log_rows, uint32_t* d_trace, size_t ld, uint32_t* finals) {
+    CHECK_CTX(ctx);
+    int need;
+    ZK_TRY(frichip::shape_ok(layers, n_queries, &need));
+    const uint32_t W = frichip::width_of(layers);
+    if (!betas || !indices || !values || !siblings || !d_trace || !finals || ld < W || log_rows < need || log_rows > MAX_LOG_ROWS)
+        return fail(ZKHIP_ERR_INVALID, "fri_chip_gen_trace: bad arguments");
+    const size_t nb = 4 * (size_t)layers, nv = 4 * n_queries, ns = nv * (size_t)layers;
+    if (!frichip::canonical(betas, nb) || !frichip::canonical(values, nv) || !frichip::canonical(siblings, ns)) return fail(ZKHIP_ERR_INVALID, "fri_chip_gen_trace: values must be canonical");
+    for (size_t q = 0; q < n_queries; q++) if (indices[q] >> (layers + 1)) return fail(ZKHIP_ERR_INVALID, "fri_chip_gen_trace: a query index has more than layers + 1 bits");
+    void* stage;
+    ZK_TRY(ctx_reserve(ctx, S_STAGE, (nb + n_queries + nv + ns + nv) * 4, &stage));
+    uint32_t* d = (uint32_t*)stage;
+    ZK_HIP(hipMemcpyAsync(d, betas, nb * 4, hipMemcpyHostToDevice, ctx->stream));
+    ZK_HIP(hipMemcpyAsync(d + nb, indices, n_queries * 4, hipMemcpyHostToDevice, ctx->stream));
+    ZK_HIP(hipMemcpyAsync(d + nb + n_queries, values, nv * 4, hipMemcpyHostToDevice, ctx->stream));
+    ZK_HIP(hipMemcpyAsync(d + nb + n_queries + nv, siblings, ns * 4, hipMemcpyHostToDevice, ctx->stream));
+    frichip::TraceArgs a{};
+    a.betas = d; a.indices = d + nb; a.values = d + nb + n_queries; a.siblings = d + nb + n_queries + nv;
+    a.n_queries = (uint32_t)n_queries; a.layers = (uint32_t)layers; a.width = W; a.log_h = (uint32_t)layers + 1u;
+    a.rows = (uint64_t)1 << log_rows; a.trace = d_trace; a.ld = ld; a.finals = d + nb + n_queries + nv + ns;
+    const size_t pad = a.rows - n_queries * (size_t)layers;
+    const size_t threads = n_queries + (pad < 4096 ? pad : 4096);            // the padding rows are shared among up to 4096 extra threads
+    hipLaunchKernelGGL(frichip::fri_trace_kernel, dim3((unsigned)((threads + 63) / 64)), dim3(64), 0, ctx->stream, a);
+    ZK_HIP(hipGetLastError());
+    ZK_HIP(hipMemcpyAsync(finals, a.finals, nv * 4, hipMemcpyDeviceToHost, ctx->stream));
+    ZK_HIP(hipStreamSynchronize(ctx->stream));
+    return ZKHIP_OK;
+}
+
+// the key of a view: the commitment to its OPENINGS table (zkhip_machine_setup).  A verifier recomputes it from the inner proof.
+int zkhip_fri_queries_key(zkhip_ctx* ctx, int layers, size_t n_queries, const uint32_t* betas, const uint32_t* indices, const uint32_t* values,
+                          const uint32_t* siblings, const zkhip_params* prm, zkhip_machine_key** key, uint32_t vk[8], uint32_t final_value[4]) {
+    CHECK_CTX(ctx);
+    if (!betas || !indices || !values || !siblings || !prm || !key || !vk || !final_value) return fail(ZKHIP_ERR_INVALID, "fri_queries_key: null argument");
+    int log_rows;
+    ZK_TRY(frichip::shape_ok(layers, n_queries, &log_rows));
+    if (!frichip::canonical(betas, 4 * (size_t)layers) || !frichip::canonical(values, 4 * n_queries) || !frichip::canonical(siblings, 4 * n_queries * (size_t)layers))
+        return fail(ZKHIP_ERR_INVALID, "fri_queries_key: values must be canonical");
+    std::vector<uint32_t> table;
+    ZK_TRY(frichip::build_openings(layers, n_queries, betas, indices, values, siblings, log_rows, table, final_value));
+    void* d;
+    ZK_TRY(ctx_reserve(ctx, S_CHIP_B, table.size() * 4, &d));
+    ZK_HIP(hipMemcpyAsync(d, table.data(), table.size() * 4, hipMemcpyHostToDevice, ctx->stream));
+    ZK_HIP(hipStreamSynchronize(ctx->stream));
+    zkhip_chip pre[2]{};
+    pre[0].log_n = log_rows; pre[0].width = 0; pre[0].partner = -1;                  // the FRI chip has no preprocessed columns
+    pre[1].d_trace = (const uint32_t*)d; pre[1].ld = frichip::OPEN_PRE; pre[1].log_n = log_rows; pre[1].width = frichip::OPEN_PRE; pre[1].partner = -1;
+    return zkhip_machine_setup(ctx, pre, 2, prm, key, vk);
+}
+
+size_t zkhip_fri_queries_proof_size(int layers, size_t n_queries, const zkhip_params* prm) {
+    int log_rows;
+    if (!prm || frichip::shape_ok(layers, n_queries, &log_rows) != ZKHIP_OK) return 0;
+    const frichip::Machine m = frichip::machine_of(layers, log_rows);
+    return zkhip_machine_proof_size_keyed(m.log_ns, m.widths, m.pre_widths, m.progs, m.prog_words, m.tabs, m.tab_words, 2, prm, frichip::n_public_of(layers));
+}
+
+int zkhip_prove_fri_queries(zkhip_ctx* ctx, const zkhip_machine_key* key, int layers, size_t n_queries, const uint32_t* betas, const uint32_t* indices,
+                            const uint32_t* values, const uint32_t* siblings, const zkhip_params* prm, uint8_t* proof, size_t cap, size_t* len) {
+    CHECK_CTX(ctx);
+    if (!key || !prm || !proof || !len) return fail(ZKHIP_ERR_INVALID, "prove_fri_queries: null argument");
+    int log_rows;
+    ZK_TRY(frichip::shape_ok(layers, n_queries, &log_rows));
+    const uint32_t W = frichip::width_of(layers);
+    void *trace, *zeros;
+    ZK_TRY(ctx_reserve(ctx, S_CHIP, ((size_t)W << log_rows) * 4, &trace));
+    std::vector<uint32_t> finals(4 * n_queries);
+    ZK_TRY(zkhip_fri_chip_gen_trace(ctx, layers, n_queries, betas, indices, values, siblings, log_rows, (uint32_t*)trace, W, finals.data()));
+    for (size_t q = 1; q < n_queries; q++)
+        if (std::memcmp(finals.data(), finals.data() + 4 * q, 16) != 0) return fail(ZKHIP_ERR_INVALID, "prove_fri_queries: the chains do not end in one value");
+    ZK_TRY(ctx_reserve(ctx, S_LOOKUP, ((size_t)frichip::OPEN_MAIN << log_rows) * 4, &zeros));      // the table's (unused) main columns
+    ZK_HIP(hipMemsetAsync(zeros, 0, ((size_t)frichip::OPEN_MAIN << log_rows) * 4, ctx->stream));
+    std::vector<uint32_t> pv(frichip::n_public_of(layers));
+    std::memcpy(pv.data(), betas, 16 * (size_t)layers);
+    std::memcpy(pv.data() + 4 * (size_t)layers, finals.data(), 16);
+    const frichip::Machine m = frichip::machine_of(layers, log_rows);
+    zkhip_chip chips[2]{};
+    chips[0].d_trace = (const uint32_t*)trace; chips[0].ld = W; chips[0].log_n = log_rows; chips[0].width = W; chips[0].partner = -1;
+    chips[1].d_trace = (const uint32_t*)zeros; chips[1].ld = frichip::OPEN_MAIN; chips[1].log_n = log_rows; chips[1].width = frichip::OPEN_MAIN; chips[1].partner = -1;
+    return zkhip_prove_machine_keyed(ctx, key, chips, m.progs, m.prog_words, m.tabs, m.tab_words, 2, pv.data(), pv.size(), prm, proof, cap, len);
+}
+
+int zkhip_verify_fri_queries(const uint8_t* proof, size_t len, int layers, size_t n_queries, const uint32_t* betas, const uint32_t final_value[4],
+                             const uint32_t vk[8], const zkhip_params* prm, int* reason) {
+    int log_rows;
+    if (!proof || !betas || !final_value || !vk || !prm || frichip::shape_ok(layers, n_queries, &log_rows) != ZKHIP_OK) {
+        if (reason) *reason = 1;
+        return fail(ZKHIP_ERR_VERIFY, "verify_fri_queries: bad arguments");
+    }
+    std::vector<uint32_t> pv(frichip::n_public_of(layers));
+    std::memcpy(pv.data(), betas, 16 * (size_t)layers);
+    std::memcpy(pv.data() + 4 * (size_t)layers, final_value, 16);
+    const frichip::Machine m = frichip::machine_of(layers, log_rows);
+    return zkhip_verify_machine_keyed(proof, len, m.log_ns, m.widths, m.pre_widths, vk, m.progs, m.prog_words, m.tabs, m.tab_words, 2, pv.data(), pv.size(), prm, reason);
+}
+
+}  // extern "C"

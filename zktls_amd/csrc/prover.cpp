@@ -1345,6 +1345,13 @@ static int run_queries(int n, const std::function<int(int)>& check, int min_per_
     return 0;
 }
 
+// What the FRI part of a (fold-by-2, constant final value) shard proof consists of, as the verifier meets it: the folding
+// challenges, the final value, and per query the index, the reduced opening it starts from and the sibling of every layer.
+// zkhip_fri_view_shard points this at its caller's buffers and runs the verifier; the FRI-fold chip (fri_chip.hip) proves
+// statements about exactly these values.  Canonical words.
+struct FriViewSink { uint32_t *betas, *final_value, *indices, *values, *siblings; int layers; };
+static thread_local FriViewSink* t_fri_sink = nullptr;
+
 static int verify_shard_impl(const uint8_t* proof, size_t len, int log_n, uint32_t width, const uint32_t* public_values,
                              size_t n_public, const zkhip_params* prm, int* reason, const AirView* air) {
     int dummy;
@@ -1515,6 +1522,13 @@ static int verify_shard_impl(const uint8_t* proof, size_t len, int log_n, uint32
     const int NQ_ = prm->num_queries;
     std::vector<size_t> indices(NQ_);
     for (int q = 0; q < NQ_; q++) indices[q] = ch.sample_bits(H);
+    FriViewSink* const sink = t_fri_sink;
+    if (sink) {
+        if (K != 1 || sh.F != 0 || RL != sink->layers) return reject(1);
+        for (int l = 0; l < RL; l++) for (int i = 0; i < 4; i++) sink->betas[4 * l + i] = from_monty(betas[l].c[i]);
+        for (int i = 0; i < 4; i++) sink->final_value[i] = from_monty(final_poly[0].c[i]);
+        for (int q = 0; q < NQ_; q++) sink->indices[q] = (uint32_t)indices[q];
+    }
     const size_t pos0 = pos, words_total = len / 4;
     if ((words_total - pos0) % (size_t)NQ_ != 0) return reject(5);
     const size_t perq = (words_total - pos0) / (size_t)NQ_;
@@ -1569,6 +1583,7 @@ static int verify_shard_impl(const uint8_t* proof, size_t len, int log_n, uint32
             }
             folded[j] = ext_add(f, ext_mul(off_q, ext_mul(ext_sub(aq, y_q), d1)));
             idx[j] = index[j];
+            if (sink) for (int i = 0; i < 4; i++) sink->values[4 * (size_t)(q0 + j) + i] = from_monty(folded[j].c[i]);
         }
         std::vector<uint32_t> rowbuf((size_t)16 * 4 * arity);
         std::vector<Ext> ev((size_t)16 * arity);
@@ -1582,7 +1597,12 @@ static int verify_shard_impl(const uint8_t* proof, size_t len, int log_n, uint32
                 Ext* e = ev.data() + (size_t)j * arity;
                 for (size_t k = 0; k < arity; k++) {
                     if (k == own) { e[k] = folded[j]; for (int i = 0; i < 4; i++) rb[4 * k + i] = from_monty(folded[j].c[i]); }
-                    else { e[k] = ext_from_canon(pf + qpos[j]); for (int i = 0; i < 4; i++) rb[4 * k + i] = pf[qpos[j] + i]; qpos[j] += 4; }
+                    else {
+                        e[k] = ext_from_canon(pf + qpos[j]);
+                        for (int i = 0; i < 4; i++) rb[4 * k + i] = pf[qpos[j] + i];
+                        if (sink) for (int i = 0; i < 4; i++) sink->siblings[4 * ((size_t)(q0 + j) * RL + l) + i] = pf[qpos[j] + i];
+                        qpos[j] += 4;
+                    }
                 }
                 rows[j] = rb; paths[j] = pf + qpos[j]; qpos[j] += 8 * (size_t)lh; rowidx[j] = row;
             }
@@ -1620,6 +1640,19 @@ int zkhip_verify_shard_air(const uint32_t* program, size_t program_words, const 
         return fail(ZKHIP_ERR_VERIFY, "verify_shard_air: malformed constraint program");
     }
     return verify_shard_impl(proof, len, log_n, width, public_values, n_public, prm, reason, &a);
+}
+
+int zkhip_fri_view_shard(const uint8_t* proof, size_t len, int log_n, uint32_t width, const uint32_t* public_values, size_t n_public,
+                         const zkhip_params* prm, uint32_t* betas, uint32_t final_value[4], uint32_t* indices, uint32_t* values, uint32_t* siblings) {
+    if (!prm || !betas || !final_value || !indices || !values || !siblings) return fail(ZKHIP_ERR_INVALID, "fri_view_shard: null argument");
+    Shape sh;
+    if (check_shape(log_n, width, prm) != ZKHIP_OK) return ZKHIP_ERR_INVALID;
+    shape_of(log_n, prm, sh);
+    if (sh.K != 1 || sh.F != 0) return fail(ZKHIP_ERR_INVALID, "fri_view_shard: fold-by-2 proofs with a constant final value only");
+    FriViewSink sink{betas, final_value, indices, values, siblings, sh.R};
+    struct Scope { explicit Scope(FriViewSink* s) { t_fri_sink = s; } ~Scope() { t_fri_sink = nullptr; } } scope(&sink);
+    int why = 0;
+    return verify_shard_impl(proof, len, log_n, width, public_values, n_public, prm, &why, nullptr);
 }
 
 // ================================================================ shards of several chips with different heights

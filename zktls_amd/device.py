@@ -536,6 +536,36 @@ class Context:
         check(self.lib.zkhip_machine_setup(self.handle, arr, n, C.byref(params), C.byref(handle), root.ctypes.data_as(u32p)))
         return MachineKey(self, handle, root, [int(c[2]) for c in pre_chips])
 
+    # ---- the FRI-fold chip (a first recursion step): trace, key, proof
+    def fri_chip_gen_trace(self, view, log_rows):
+        """-> (device trace [2^log_rows][width] Montgomery, finals [Q][4])"""
+        R, Q, betas, idx, vals, sibs = _fri_view_arrays(view)
+        W = int(self.lib.zkhip_fri_chip_width(R))
+        out = self.alloc(W << log_rows)
+        finals = np.zeros(4 * Q, dtype=np.uint32)
+        check(self.lib.zkhip_fri_chip_gen_trace(self.handle, R, Q, betas.ctypes.data_as(u32p), idx.ctypes.data_as(u32p), vals.ctypes.data_as(u32p),
+                                                sibs.ctypes.data_as(u32p), log_rows, C.c_void_p(out.ptr), W, finals.ctypes.data_as(u32p)))
+        return out, finals.reshape(Q, 4)
+
+    def fri_queries_key(self, view, params=None):
+        """zkhip_fri_queries_key -> (MachineKey, final value): the commitment to the view's OPENINGS table"""
+        params = params or Params(1, 100, 16)
+        R, Q, betas, idx, vals, sibs = _fri_view_arrays(view)
+        handle, root, final = C.c_void_p(), np.zeros(8, dtype=np.uint32), np.zeros(4, dtype=np.uint32)
+        check(self.lib.zkhip_fri_queries_key(self.handle, R, Q, betas.ctypes.data_as(u32p), idx.ctypes.data_as(u32p), vals.ctypes.data_as(u32p),
+                                             sibs.ctypes.data_as(u32p), C.byref(params), C.byref(handle), root.ctypes.data_as(u32p), final.ctypes.data_as(u32p)))
+        return MachineKey(self, handle, root, [0, 12]), final.tolist()
+
+    def prove_fri_queries(self, key, view, params=None):
+        params = params or Params(1, 100, 16)
+        R, Q, betas, idx, vals, sibs = _fri_view_arrays(view)
+        size = self.lib.zkhip_fri_queries_proof_size(R, Q, C.byref(params))
+        buf = np.empty(size, dtype=np.uint8)
+        got = C.c_size_t(0)
+        check(self.lib.zkhip_prove_fri_queries(self.handle, key.handle, R, Q, betas.ctypes.data_as(u32p), idx.ctypes.data_as(u32p), vals.ctypes.data_as(u32p),
+                                               sibs.ctypes.data_as(u32p), C.byref(params), buf.ctypes.data_as(u8p), size, C.byref(got)))
+        return buf[: got.value]
+
     def prove_machine_keyed(self, key, chips, programs, tables, public_values=(), params=None, key_entries=None):
         """a machine with preprocessed columns (proof version 11): `key` from machine_setup; chips as in prove_machine (main columns);
         programs / tables address the combined row [preprocessed | main].  key_entries: per chip the key entry it uses (-1: none) when the
@@ -829,6 +859,54 @@ def _program_table(programs):
     pp = (u32p * n)(*[(p.ctypes.data_as(u32p) if p is not None else None) for p in keep])
     pw = (C.c_size_t * n)(*[(p.size if p is not None else 0) for p in keep])
     return keep, pp, pw
+
+
+def fri_view_shard(proof, log_n, width, public_values=(), params=None):
+    """zkhip_fri_view_shard: what the FRI check of a fold-by-2 shard proof reads -> {"betas": [R][4], "final": [4], "queries": [(index, value[4],
+    siblings [R][4])]} (canonical), or raises if the proof is rejected.  Host only."""
+    params = params or Params(1, 100, 16)
+    lib = _lib.load()
+    pr = np.ascontiguousarray(proof, dtype=np.uint8)
+    pv = np.ascontiguousarray(np.array(public_values, dtype=np.uint32))
+    R, Q = log_n, params.num_queries
+    betas, final = np.zeros(4 * R, dtype=np.uint32), np.zeros(4, dtype=np.uint32)
+    idx, vals, sibs = np.zeros(Q, dtype=np.uint32), np.zeros(4 * Q, dtype=np.uint32), np.zeros(4 * Q * R, dtype=np.uint32)
+    check(lib.zkhip_fri_view_shard(pr.ctypes.data_as(u8p), pr.size, log_n, width, pv.ctypes.data_as(u32p), pv.size, C.byref(params),
+                                   betas.ctypes.data_as(u32p), final.ctypes.data_as(u32p), idx.ctypes.data_as(u32p), vals.ctypes.data_as(u32p),
+                                   sibs.ctypes.data_as(u32p)))
+    return {"betas": betas.reshape(R, 4).tolist(), "final": final.tolist(),
+            "queries": [(int(idx[q]), vals[4 * q:4 * q + 4].tolist(), sibs[4 * q * R:4 * (q + 1) * R].reshape(R, 4).tolist()) for q in range(Q)]}
+
+
+def _fri_view_arrays(view):
+    R, Q = len(view["betas"]), len(view["queries"])
+    betas = np.ascontiguousarray(np.array(view["betas"], dtype=np.uint32).reshape(-1))
+    idx = np.ascontiguousarray(np.array([q[0] for q in view["queries"]], dtype=np.uint32))
+    vals = np.ascontiguousarray(np.array([q[1] for q in view["queries"]], dtype=np.uint32).reshape(-1))
+    sibs = np.ascontiguousarray(np.array([q[2] for q in view["queries"]], dtype=np.uint32).reshape(-1))
+    return R, Q, betas, idx, vals, sibs
+
+
+def fri_chip_air(layers):
+    lib = _lib.load()
+    n = lib.zkhip_fri_chip_air(layers, None, 0)
+    out = np.zeros(n, dtype=np.uint32)
+    assert n and lib.zkhip_fri_chip_air(layers, out.ctypes.data_as(u32p), n) == n
+    return out
+
+
+def verify_fri_queries(proof, view_betas, final, n_queries, vk, params=None):
+    """zkhip_verify_fri_queries (host): the machine proof against the challenges, the final value and the key's root"""
+    params = params or Params(1, 100, 16)
+    lib = _lib.load()
+    pr = np.ascontiguousarray(proof, dtype=np.uint8)
+    b = np.ascontiguousarray(np.array(view_betas, dtype=np.uint32).reshape(-1))
+    f = np.ascontiguousarray(np.array(final, dtype=np.uint32))
+    k = np.ascontiguousarray(np.array(vk, dtype=np.uint32))
+    reason = C.c_int(0)
+    rc = lib.zkhip_verify_fri_queries(pr.ctypes.data_as(u8p), pr.size, b.size // 4, n_queries, b.ctypes.data_as(u32p), f.ctypes.data_as(u32p),
+                                      k.ctypes.data_as(u32p), C.byref(params), C.byref(reason))
+    return rc, reason.value
 
 
 class MachineKey:
