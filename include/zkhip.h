@@ -27,7 +27,8 @@
  *       the reference's batch and large-transcript configurations (BASELINE.json configs[2], configs[3]) with a real statement per proof:
  *       many transcripts, or the shards of one long message, dealt over the GPUs of the node by one call.
  *   zkhip_p2chip_air, zkhip_prove_merkle_paths / zkhip_verify_merkle_paths
- *   zkhip_fri_view_shard, zkhip_fri_chip_air, zkhip_fri_queries_key, zkhip_prove_fri_queries / zkhip_verify_fri_queries
+ *   zkhip_fri_view_shard, zkhip_fri_chip_air, zkhip_fri_queries_key, zkhip_prove_fri_queries / zkhip_verify_fri_queries,
+ *   zkhip_fri_view_shard_paths, zkhip_fri_layers_key, zkhip_prove_fri_layers / zkhip_verify_fri_layers
  *       a first recursion step: the FRI folds of a shard proof checked inside a (keyed machine) proof -- what `compress` behind
  *       SP1ProofMode::Groth16 (sp1.rs:116) spends its rows on besides Poseidon2.
  *       a second real chip -- the Poseidon2 permutation with Merkle-path / leaf-hash chaining, what the recursion stages behind
@@ -622,6 +623,33 @@ int zkhip_prove_fri_queries(zkhip_ctx* ctx, const zkhip_machine_key* key, int la
                             const uint32_t* values, const uint32_t* siblings, const zkhip_params* prm, uint8_t* proof, size_t cap, size_t* len);
 int zkhip_verify_fri_queries(const uint8_t* proof, size_t len, int layers, size_t n_queries, const uint32_t* betas, const uint32_t final_value[4],
                              const uint32_t vk[8], const zkhip_params* prm, int* reason);
+/* The same with the Merkle paths of the pairs IN-CIRCUIT (blowup-2 proofs): the FRI-fold chip wired by lookups to the Poseidon2 chip.
+ * zkhip_fri_view_shard_paths also hands out the layer roots ([layers][8]) and, per query, the layers' authentication paths one after the
+ * other (8 (layers - l) words for layer l; zkhip_fri_view_path_words(layers) words per query).  The machine has four chips: the Poseidon2
+ * chip's FRI-layers variant (zkhip_p2chip_air_fri_layers: one path per (query, layer) -- a leaf row hashing the pair, then the compression
+ * rows up to the layer's root; leaf rows receive the pairs from the bus, END rows send (layer, root) to the ROOTS table), the fold chip
+ * in its wired form (zkhip_fri_layers_chip_air: sends the pairs, and (index, reduced opening) on a query's first row), and two
+ * PREPROCESSED tables: QUERIES (index, reduced opening) and ROOTS (layer, root).  The key (zkhip_fri_layers_key) therefore holds no FRI
+ * layer value any more: a verifier needs the layer roots of the inner proof and the reduced openings it computes itself.  Statement: "for
+ * the layer commitments and the (index, reduced opening) pairs in the key, every query's chain opens the commitments layer by layer and
+ * folds, under the public challenges, to the public final value."  Still outside: the trace / quotient openings, the reduced openings,
+ * the transcript. */
+size_t zkhip_fri_view_path_words(int layers);
+int zkhip_fri_view_shard_paths(const uint8_t* proof, size_t len, int log_n, uint32_t width, const uint32_t* public_values, size_t n_public,
+                               const zkhip_params* prm, uint32_t* betas, uint32_t final_value[4], uint32_t* indices, uint32_t* values, uint32_t* siblings,
+                               uint32_t* roots, uint32_t* paths);
+size_t zkhip_fri_layers_chip_air(int layers, uint32_t* program, size_t cap_words);
+size_t zkhip_p2chip_air_fri_layers(int layers, uint32_t* program, size_t cap_words);
+int zkhip_fri_layers_gen_paths_trace(zkhip_ctx* ctx, int layers, size_t n_queries, const uint32_t* betas, const uint32_t* indices, const uint32_t* values,
+                                     const uint32_t* siblings, const uint32_t* roots, const uint32_t* paths, int log_rows, uint32_t* d_trace, size_t ld);
+int zkhip_fri_layers_key(zkhip_ctx* ctx, int layers, size_t n_queries, const uint32_t* indices, const uint32_t* values, const uint32_t* roots,
+                         const zkhip_params* prm, zkhip_machine_key** key, uint32_t vk[8]);
+size_t zkhip_fri_layers_proof_size(int layers, size_t n_queries, const zkhip_params* prm);
+int zkhip_prove_fri_layers(zkhip_ctx* ctx, const zkhip_machine_key* key, int layers, size_t n_queries, const uint32_t* betas, const uint32_t* indices,
+                           const uint32_t* values, const uint32_t* siblings, const uint32_t* roots, const uint32_t* paths, const zkhip_params* prm,
+                           uint8_t* proof, size_t cap, size_t* len);
+int zkhip_verify_fri_layers(const uint8_t* proof, size_t len, int layers, size_t n_queries, const uint32_t* betas, const uint32_t final_value[4],
+                            const uint32_t vk[8], const zkhip_params* prm, int* reason);
 
 /* ---- Poseidon2 parameter tables from a file: the built-in sets are this repo's own
  * ("zktls-amd/p2-bb16-v1", "...-bb24-v1"; the SP1 / RISC Zero tables of reference Cargo.lock:4030, 6172, 5057 are not

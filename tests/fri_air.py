@@ -13,14 +13,16 @@ from pyref import P, bitrev, ext_mul, two_adic_generator
 
 V = O.air_var
 E0, E1, BIT, K, X, XI, S, T, B, BETA, FOLD, ACTIVE, LN, G, GS, GT, OWN, L = 0, 4, 8, 9, 10, 11, 12, 13, 14, 15, 19, 23, 24, 25, 26, 27, 28, 32
-BUS_E0, BUS_E1 = 40, 41
+BUS_E0, BUS_E1, BUS_R0, BUS_R1, BUS_Q = 40, 41, 42, 43, 44
+K2, IDX, L_WIRED = 32, 33, 34                  # the wired form's extra columns, its layer selectors start two columns later
+QUERIES_PRE, ROOTS_PRE = 8, 12
 OPEN_PRE, OPEN_MAIN = 12, 4
 INV2 = (P + 1) // 2
 EXT_W = 11
 
 
-def width_of(layers):
-    return (32 + layers + 3) & ~3
+def width_of(layers, wired=False):
+    return ((L_WIRED if wired else L) + layers + 3) & ~3
 
 
 def n_public_of(layers):
@@ -32,8 +34,9 @@ def root_const(l):
     return two_adic_generator(l + 1)
 
 
-def program(layers):
+def program(layers, wired=False):
     R = layers
+    L = L_WIRED if wired else globals()["L"]
     END = L + R - 1
     cons = []
 
@@ -81,7 +84,10 @@ def program(layers):
         add(O.SEL_TRANSITION, gated([(1, [V(FOLD + j)]), (P - 1, [V(OWN + j, True)])]))
     for j in range(4):
         add(O.SEL_ALL, [(1, [V(END), V(FOLD + j)]), (P - 1, [V(END), V(4 * R + j, public=True)])])
-    return O.air_program(width_of(R), n_public_of(R), cons)
+    if wired:
+        add(O.SEL_ALL, [(1, [V(K2)]), (P - 2, [V(K)])])
+        add(O.SEL_ALL, [(1, [V(IDX)]), (P - 1, [V(K2)]), (P - 1, [V(BIT)])])
+    return O.air_program(width_of(R, wired), n_public_of(R), cons)
 
 
 def fold_pair(k, lh, beta, e0, e1):
@@ -100,12 +106,13 @@ def log_rows_of(layers, n_queries):
     return lr
 
 
-def trace(view, log_rows=None):
+def trace(view, log_rows=None, wired=False):
     """-> (trace [2^log_rows][width] canonical, final value): one row per (query, layer), padding rows zero with T = 1"""
     betas, queries = view["betas"], view["queries"]
     R = len(betas)
     H = R + 1
-    W = width_of(R)
+    W = width_of(R, wired)
+    L = L_WIRED if wired else globals()["L"]
     lr = log_rows if log_rows is not None else log_rows_of(R, len(queries))
     t = np.zeros((1 << lr, W), dtype=np.uint64)
     t[:, T] = 1
@@ -125,6 +132,8 @@ def trace(view, log_rows=None):
             if l + 1 < R:
                 row[G], row[GS], row[GT] = 1, x * x % P, tcol[-1]
             row[OWN:OWN + 4] = own
+            if wired:
+                row[K2], row[IDX] = 2 * k, 2 * k + bit
             own, idx = fold, k
         acc = root_const(R) if idx else 1
         for l in reversed(range(R)):
@@ -195,3 +204,60 @@ def random_view(layers, n_queries, seed=1):
             idx >>= 1
         queries.append((index, layers_vec[0][index], sibs))
     return {"betas": betas, "queries": queries, "final": layers_vec[layers][top]}
+
+
+def machine_layers(view):
+    """the wired machine (zkhip_prove_fri_layers): the Poseidon2 chip's FRI-layers variant (one Merkle path per (query, layer)), the fold
+    chip in its wired form, and the preprocessed QUERIES / ROOTS tables -> (main traces, preprocessed traces, programs, tables, public values)"""
+    import poseidon2_air as P2
+    betas, queries, roots, paths = view["betas"], view["queries"], view["roots"], view["paths"]
+    R, Q = len(betas), len(queries)
+    H = R + 1
+    NP = n_public_of(R)
+
+    def lg(n, lo=5):
+        l = lo
+        while (1 << l) < n:
+            l += 1
+        return l
+    # the pairs of every (query, layer) and their paths
+    plist = []
+    for q, (index, value, sibs) in enumerate(queries):
+        idx, own = index, list(value)
+        for l in range(R):
+            bit, k = idx & 1, idx >> 1
+            e0, e1 = (sibs[l], own) if bit else (own, sibs[l])
+            plist.append((l, k, list(e0) + list(e1), paths[q][l], 1))
+            own, idx = fold_pair(k, H - (l + 1), betas[l], e0, e1)[0], k
+    lr_p2 = lg(Q * (R + R * (R + 1) // 2))
+    p2_trace, p2_roots = P2.layer_paths_trace(plist, lr_p2)
+    for i, (l, k, pair, sibs, mult) in enumerate(plist):
+        assert p2_roots[i] == list(roots[l]), "a path does not end in its layer's root"
+    lr_fri = lg(Q * R)
+    fri_trace, final = trace(view, lr_fri, wired=True)
+    lr_r = lg(R)
+    lr_q = max(lg(Q), lr_r)
+    qpre = np.zeros((1 << lr_q, QUERIES_PRE), dtype=np.uint32)
+    for q, (index, value, _) in enumerate(queries):
+        qpre[q, 0], qpre[q, 1:5], qpre[q, 5] = index, value, 1
+    rpre = np.zeros((1 << lr_r, ROOTS_PRE), dtype=np.uint32)
+    rmain = np.zeros((1 << lr_r, 4), dtype=np.uint32)
+    for l in range(R):
+        rpre[l, 0], rpre[l, 1:9] = l, roots[l]
+        rmain[l, 0] = Q
+    o7 = P2.OUTE(7)
+    p2_tab = O.interaction_table([(O.RECEIVE, P2.M, BUS_E0, [P2.LNP, P2.KP, P2.IN, P2.IN + 1, P2.IN + 2, P2.IN + 3]),
+                                  (O.RECEIVE, P2.M, BUS_E1, [P2.LNP, P2.KP, P2.IN + 4, P2.IN + 5, P2.IN + 6, P2.IN + 7]),
+                                  (O.SEND, P2.END, BUS_R0, [P2.LNP, o7, o7 + 1, o7 + 2, o7 + 3]),
+                                  (O.SEND, P2.END, BUS_R1, [P2.LNP, o7 + 4, o7 + 5, o7 + 6, o7 + 7])])
+    fri_tab = O.interaction_table([(O.SEND, ACTIVE, BUS_E0, [LN, K2, E0, E0 + 1, E0 + 2, E0 + 3]), (O.SEND, ACTIVE, BUS_E1, [LN, K2, E1, E1 + 1, E1 + 2, E1 + 3]),
+                                   (O.SEND, L_WIRED, BUS_Q, [IDX, OWN, OWN + 1, OWN + 2, OWN + 3])])
+    q_tab = O.interaction_table([(O.RECEIVE, 5, BUS_Q, [0, 1, 2, 3, 4])])
+    r_tab = O.interaction_table([(O.RECEIVE, ROOTS_PRE, BUS_R0, [0, 1, 2, 3, 4]), (O.RECEIVE, ROOTS_PRE, BUS_R1, [0, 5, 6, 7, 8])])
+
+    def table_prog(pre_width):
+        return O.air_program(pre_width + 4, NP, [(O.SEL_FIRST, [(1, [V(pre_width + 3)])])])
+    pub = [c for b in betas for c in b] + list(final)
+    return ([p2_trace, fri_trace, np.zeros((1 << lr_q, 4), dtype=np.uint32), rmain], [None, None, qpre, rpre],
+            [P2.program(fri_layers=True, n_public=NP), program(R, wired=True), table_prog(QUERIES_PRE), table_prog(ROOTS_PRE)],
+            [p2_tab, fri_tab, q_tab, r_tab], pub)

@@ -35,6 +35,7 @@ SP, D = 327, 343
 BIT, CH, END, CNT, SPG, SS = 351, 352, 353, 354, 355, 356
 WIDTH = 360
 N_PUBLIC = 9
+LNP, KP, M = 357, 358, 359          # the FRI-layers variant's use of the three spare columns (program(fri_layers=True))
 
 
 def X3E(r):
@@ -76,7 +77,9 @@ def _linear_def(col, form):
     return [_term(1, [V(col)])] + [_term(P - form[c], [V(c)]) for c in sorted(form) if form[c] % P]
 
 
-def program():
+def program(fri_layers=False, n_public=N_PUBLIC):
+    """fri_layers: the variant wired to the FRI-fold chip (tests/fri_air.py): paths of different depths, no public root (END rows send
+    their digest on a bus instead), LNP / KP / M in the spare columns"""
     ME, rc_e, rc_i, diag = pyref.ME, PARAMS["external_rc"], PARAMS["internal_rc"], PARAMS["internal_diag"]
     cons = []
     for i in range(16):
@@ -127,12 +130,51 @@ def program():
         cons.append((O.SEL_ALL, [_term(1, [V(SS), V(IN + 8 + j)])]))
     for j in range(8):
         cons.append((O.SEL_TRANSITION, [_term(1, [V(CH, True), V(D + j, True)]), _term(P - 1, [V(CH, True), V(OUTE(7) + j)])]))
-    for j in range(8):
-        cons.append((O.SEL_ALL, [_term(1, [V(END), V(OUTE(7) + j)]), _term(P - 1, [V(END), V(j, public=True)])]))
+    if not fri_layers:
+        for j in range(8):
+            cons.append((O.SEL_ALL, [_term(1, [V(END), V(OUTE(7) + j)]), _term(P - 1, [V(END), V(j, public=True)])]))
     cons.append((O.SEL_FIRST, [_term(1, [V(CNT)]), _term(P - 1, [V(END)])]))
     cons.append((O.SEL_TRANSITION, [_term(1, [V(CNT, True)]), _term(P - 1, [V(CNT)]), _term(P - 1, [V(END, True)])]))
-    cons.append((O.SEL_LAST, [_term(1, [V(CNT)]), _term(P - 1, [V(8, public=True)])]))
-    return O.air_program(WIDTH, N_PUBLIC, cons)
+    if not fri_layers:
+        cons.append((O.SEL_LAST, [_term(1, [V(CNT)]), _term(P - 1, [V(8, public=True)])]))
+    else:
+        cons.append((O.SEL_TRANSITION, [_term(1, [V(SS)]), _term(P - 1, [V(SS), V(CH, True)]), _term(1, [V(CH)]), _term(P - 1, [V(CH), V(CH, True)]),
+                                        _term(P - 1, [V(END)]), _term(1, [V(END), V(CH, True)])]))
+        cons.append((O.SEL_LAST, [_term(1, [V(SS)]), _term(1, [V(CH)]), _term(P - 1, [V(END)])]))
+        cons.append((O.SEL_ALL, [_term(1, [V(END)]), _term(P - 1, [V(END), V(CH)])]))
+        cons.append((O.SEL_ALL, [_term(1, [V(SS), V(BIT)])]))
+        cons.append((O.SEL_ALL, [_term(1, [V(SS), V(CH)])]))
+        cons.append((O.SEL_TRANSITION, [_term(1, [V(CH, True), V(LNP, True)]), _term(P - 1, [V(CH, True), V(LNP)])]))
+        cons.append((O.SEL_TRANSITION, [_term(1, [V(CH, True), V(KP)]), _term(P - 2, [V(CH, True), V(KP, True)]), _term(P - 1, [V(CH, True), V(BIT)])]))
+        cons.append((O.SEL_ALL, [_term(1, [V(END), V(KP)]), _term(P - 1, [V(END), V(BIT)])]))
+        cons.append((O.SEL_ALL, [_term(1, [V(M)]), _term(P - 1, [V(M), V(SS)])]))
+    return O.air_program(WIDTH, n_public, cons)
+
+
+def layer_paths_trace(paths, log_n):
+    """the FRI-layers variant's trace: paths = [(layer, leaf index, pair [8 values], siblings [[8] x depth], multiplicity)], one leaf row
+    (the sponge over the pair) + depth compression rows each -> (trace [2^log_n][WIDTH], roots)"""
+    rows, roots, cnt = [], [], 0
+    for layer, index, pair, sibs, mult in paths:
+        r, out = row([int(v) % P for v in pair] + [0] * 8, 0, 0, 0, cnt, 0, 1)
+        r[LNP], r[KP], r[M] = layer, 2 * index % P, mult
+        rows.append(r)
+        digest = out[:8]
+        depth = len(sibs)
+        for lvl in range(depth):
+            bit = (index >> lvl) & 1
+            sib = [int(v) % P for v in sibs[lvl]]
+            end = 1 if lvl == depth - 1 else 0
+            cnt += end
+            r, out = row(sib + digest if bit else digest + sib, bit, 1, end, cnt)
+            r[LNP], r[KP] = layer, index >> lvl
+            rows.append(r)
+            digest = out[:8]
+        roots.append(digest)
+    pad, _ = row([0] * 16, 0, 0, 0, cnt)
+    assert len(rows) <= 1 << log_n
+    rows += [pad] * ((1 << log_n) - len(rows))
+    return np.array(rows, dtype=np.uint64).astype(np.uint32), roots
 
 
 def row(state_in, bit=0, ch=0, end=0, cnt=0, spg=0, ss=0):

@@ -373,16 +373,18 @@ def verify(proof_bytes, log_n, width, public_values, log_blowup=1, num_queries=1
             val = e_add(val, ext_mul(off_pn, ext_mul(e_sub(ap, y_pn), inv2)))
         val = e_add(val, ext_mul(off_q, ext_mul(e_sub(aq, y_q), inv1)))
         idx = index
-        seen = (index, list(val), [])
+        seen = (index, list(val), [], [])
         for l in range(R):
             lh = H - K * (l + 1)                # log2 of the rows of this layer's matrix (rows of 2^K adjacent entries)
             row, own = idx >> K, idx & (arity - 1)
             entries = []
             for j in range(arity):
                 entries.append(val if j == own else take(4))
+
+            path = [take(8) for _ in range(lh)]
             if K == 1:
                 seen[2].append(list(entries[1 - own]))
-            path = [take(8) for _ in range(lh)]
+                seen[3].append([list(d) for d in path])
             flat = [c for e in entries for c in e]
             if hasher.root_from_path(flat, row, path) != layer_roots[l]:
                 raise Reject("FRI layer %d opening" % l)
@@ -400,10 +402,12 @@ def verify(proof_bytes, log_n, width, public_values, log_blowup=1, num_queries=1
         if v != val:
             raise Reject("final polynomial")
         if view is not None:
-            view.setdefault("queries", []).append(seen)
+            view.setdefault("queries", []).append(seen[:3])
+            view.setdefault("paths", []).append(seen[3])
     if pos != len(w):
         raise Reject("trailing words")
     if view is not None:
         view["betas"] = [list(x) for x in betas]
+        view["roots"] = [list(r) for r in layer_roots]
         view["final"] = list(final_poly[0])
     return True

@@ -147,3 +147,66 @@ def test_entry_point_argument_checks():
     g = GOLDEN["v3_r0_9x8"]                       # fold by 16: no view
     with pytest.raises(_lib.ZkHipError):
         fri_view_shard(load("v3_r0_9x8"), g["log_n"], g["width"], g["public"], Params(*g["shape"]))
+
+
+# ------------------------------------------------------------------ the wired machine: Merkle paths of the pairs in-circuit
+@pytest.mark.parametrize("layers", [2, 6, 10, 20])
+def test_wired_programs_equal_the_python_restatements(oracle, layers):
+    import poseidon2_air as P2
+    from zktls_amd.device import fri_layers_programs
+    p2f, fri = fri_layers_programs(layers)
+    assert p2f.tolist() == P2.program(fri_layers=True, n_public=F.n_public_of(layers)).tolist()
+    assert fri.tolist() == F.program(layers, wired=True).tolist()
+    for prog, w in ((p2f, 360), (fri, F.width_of(layers, True))):
+        assert oracle.air_validate(prog, w, F.n_public_of(layers)) == 1 and oracle.air_log_quotient_degree(prog) == 1
+
+
+@pytest.mark.parametrize("name,shape", [("v1_6x8", (1, 10, 4)), ("v1_10x16", (1, 8, 6))])
+def test_wired_machine_of_a_golden_proofs_view(oracle, name, shape):
+    """view with roots and paths (library == Python verifier), the four-chip machine on the restated arrays under the oracle's prover and
+    three verifiers, and what it refuses: a sibling digest that is not the committed one, a pair that is not the opened one, a query
+    left out, other roots in the key"""
+    from zktls_amd.device import fri_view_shard_paths, verify_fri_layers
+    O = oracle
+    g = GOLDEN[name]
+    b = load(name)
+    view = fri_view_shard_paths(b, g["log_n"], g["width"], g["public"], Params(*g["shape"]))
+    pview = {}
+    assert pyverify.verify(b.tobytes(), g["log_n"], g["width"], g["public"], *g["shape"], view=pview) is True
+    assert pview["roots"] == view["roots"] and pview["paths"] == view["paths"] and pview["betas"] == view["betas"]
+    traces, pre, progs, tables, pub = F.machine_layers(view)
+    lns, ws, pws = shape_of(traces, pre)
+    assert ws[0] == 360 and pws == [0, 0, 8, 12] and lns == sorted(lns, reverse=True)
+    oprm, prm = O.default_params(*shape), Params(*shape)
+    root = O.machine_setup(pre, lns, oprm)
+    proof = O.prove_machine_keyed(traces, pre, progs, tables, pub, oprm)
+    nq = len(view["queries"])
+    assert O.verify_machine_keyed(proof, lns, ws, pws, root, progs, tables, pub, oprm) == 0
+    assert verify_machine_keyed(proof, lns, ws, pws, root, progs, tables, pub, prm) == (0, 0)
+    assert verify_fri_layers(proof, view["betas"], view["final"], nq, root, prm) == (0, 0)
+    assert pyverify_chips.verify(proof.tobytes(), lns, ws, pub, shape[0], shape[1], shape[2], programs=progs, tables=tables, pre_widths=pws,
+                                 pre_root=[int(v) for v in root]) is True
+    assert verify_fri_layers(proof, view["betas"], view["final"], nq + 1 if (nq + 1) * g["log_n"] <= (1 << lns[1]) else nq * 3, root, prm)[0] in (0, -6)
+    import poseidon2_air as P2
+    R = g["log_n"]
+
+    def tampered(chip, fn):
+        t = [x.copy() for x in traces]
+        fn(t[chip])
+        return t
+    # a sibling digest on a path that is not the committed one: the END row's digest is no longer the layer's root -> the ROOTS bus does not balance
+    assert _machine_rejected(O, tampered(0, lambda t: t.__setitem__((1, P2.IN + 8), (int(t[1, P2.IN + 8]) + 1) % P)), pre, progs, tables, pub, shape)
+    # the fold chip claims another pair than the one whose path is shown
+    assert _machine_rejected(O, tampered(1, lambda t: t.__setitem__((R + 2, F.E0 + 1), (int(t[R + 2, F.E0 + 1]) + 1) % P)), pre, progs, tables, pub, shape)
+    # a path shown for another leaf index than the one the fold chip uses
+    assert _machine_rejected(O, tampered(0, lambda t: t.__setitem__((0, P2.KP), (int(t[0, P2.KP]) + 2) % P)), pre, progs, tables, pub, shape)
+
+    # a query left out of the fold chip: the QUERIES table still expects its start
+    def drop(t):
+        t[(nq - 1) * R:nq * R] = 0
+        t[(nq - 1) * R:nq * R, F.T] = 1
+    assert _machine_rejected(O, tampered(1, drop), pre, progs, tables, pub, shape)
+    # other roots in the key
+    pre2 = [None, None, pre[2], pre[3].copy()]
+    pre2[3][0, 1] = (int(pre2[3][0, 1]) + 1) % P
+    assert _machine_rejected(O, traces, pre2, progs, tables, pub, shape)

@@ -101,3 +101,82 @@ def test_fullsize_fri_queries_of_the_headline_shard(ctx, oracle):
     assert proof.tobytes() == O.prove_machine_keyed(traces, pre, progs, tables, pub, oprm).tobytes()
     assert O.verify_machine_keyed(proof, lns, ws, pws, key.root, progs, tables, pub, oprm) == 0
     key.close()
+
+
+# ------------------------------------------------------------------ the wired machine: Merkle paths of the pairs in-circuit
+@pytest.mark.parametrize("log_n,width,inner,outer", [(6, 8, (1, 9, 4), (1, 12, 4)), (11, 16, (1, 20, 8), (1, 16, 6))])
+def test_fri_layers_of_a_shard_proof_open_and_fold_in_circuit(ctx, oracle, log_n, width, inner, outer):
+    """zkhip_prove_fri_layers: the Poseidon2 chip's FRI-layers variant authenticates every layer pair of every query against the layer's
+    root, the fold chip folds them; both traces come from the device generators and equal the Python restatements; the four-chip machine
+    proof equals the oracle's bytes; three verifiers accept it; the key holds only (index, reduced opening) and the layer roots."""
+    from zktls_amd.device import fri_view_shard_paths, verify_fri_layers
+    O = oracle
+    iprm, oprm, prm = Params(*inner), O.default_params(*outer), Params(*outer)
+    pv = [3, 1, 4]
+    trace = ctx.gen_trace(SEED, 41, log_n, width)
+    shard_proof = ctx.prove_shard(trace, log_n, width, pv, iprm)
+    trace.free()
+    view = fri_view_shard_paths(shard_proof, log_n, width, pv, iprm)
+    pview = {}
+    assert pyverify.verify(shard_proof.tobytes(), log_n, width, pv, *inner, view=pview) is True
+    assert pview["roots"] == view["roots"] and pview["paths"] == view["paths"]
+    traces, pre, progs, tables, pub = F.machine_layers(view)
+    lns, ws, pws = shape_of(traces, pre)
+    d_p2 = ctx.fri_layers_gen_paths_trace(view, lns[0])
+    assert (d_p2.download().reshape(-1, 360) == traces[0]).all()
+    d_p2.free()
+    key = ctx.fri_layers_key(view, prm)
+    assert key.root.tolist() == O.machine_setup(pre, lns, oprm).tolist()
+    proof = ctx.prove_fri_layers(key, view, prm)
+    oproof = O.prove_machine_keyed(traces, pre, progs, tables, pub, oprm)
+    assert proof.tobytes() == oproof.tobytes(), "FRI-layers machine proof differs from the oracle's"
+    nq = len(view["queries"])
+    assert verify_fri_layers(proof, view["betas"], view["final"], nq, key.root, prm) == (0, 0)
+    assert verify_machine_keyed(proof, lns, ws, pws, key.root, progs, tables, pub, prm) == (0, 0)
+    assert O.verify_machine_keyed(proof, lns, ws, pws, key.root, progs, tables, pub, oprm) == 0
+    assert pyverify_chips.verify(proof.tobytes(), lns, ws, pub, outer[0], outer[1], outer[2], programs=progs, tables=tables, pre_widths=pws,
+                                 pre_root=[int(v) for v in key.root]) is True
+    # a path that does not end in its layer's root is refused before anything is proven
+    bad = dict(view)
+    bad["paths"] = [[[list(d) for d in layer] for layer in pq] for pq in view["paths"]]
+    bad["paths"][1][0][0][3] = (bad["paths"][1][0][0][3] + 1) % P
+    with pytest.raises(Exception):
+        ctx.prove_fri_layers(key, bad, prm)
+    # a key made from other reduced openings does not accept this proof
+    other = dict(view)
+    other["queries"] = [(q[0], [(q[1][0] + 1) % P] + list(q[1][1:]), q[2]) for q in view["queries"]]
+    okey = ctx.fri_layers_key(other, prm)
+    assert okey.root.tolist() != key.root.tolist()
+    assert verify_fri_layers(proof, view["betas"], view["final"], nq, okey.root, prm)[0] == -6
+    key.close()
+    okey.close()
+
+
+def test_fullsize_fri_layers_of_the_headline_shard(ctx, oracle):
+    """100 queries x 20 layers of a 2^20 x 256 shard proof: 23 000 rows of Poseidon2 permutations (2^15 x 360), 2 000 rows of folds"""
+    from zktls_amd.device import fri_view_shard_paths, verify_fri_layers
+    O = oracle
+    log_n, width = 20, 256
+    iprm, prm, oprm = Params(1, 100, 16), Params(1, 100, 16), O.default_params(1, 100, 16)
+    trace = ctx.gen_trace(SEED, 32, log_n, width)
+    shard_proof = ctx.prove_shard(trace, log_n, width, [1, 2, 3], iprm)
+    trace.free()
+    t0 = time.perf_counter()
+    view = fri_view_shard_paths(shard_proof, log_n, width, [1, 2, 3], iprm)
+    t1 = time.perf_counter()
+    key = ctx.fri_layers_key(view, prm)
+    t2 = time.perf_counter()
+    proof = ctx.prove_fri_layers(key, view, prm)
+    t3 = time.perf_counter()
+    proof = ctx.prove_fri_layers(key, view, prm)
+    t4 = time.perf_counter()
+    assert verify_fri_layers(proof, view["betas"], view["final"], 100, key.root, prm) == (0, 0)
+    t5 = time.perf_counter()
+    print("\nFRI layers of a 2^20 x 256 shard proof (Merkle paths + folds in-circuit): view %.1f ms, key %.1f ms, machine proof %.1f ms (first %.1f), %d bytes, host verification %.1f ms"
+          % ((t1 - t0) * 1e3, (t2 - t1) * 1e3, (t4 - t3) * 1e3, (t3 - t2) * 1e3, proof.size, (t5 - t4) * 1e3))
+    traces, pre, progs, tables, pub = F.machine_layers(view)
+    lns, ws, pws = shape_of(traces, pre)
+    assert lns == [15, 11, 7, 5]
+    assert proof.tobytes() == O.prove_machine_keyed(traces, pre, progs, tables, pub, oprm).tobytes()
+    assert O.verify_machine_keyed(proof, lns, ws, pws, key.root, progs, tables, pub, oprm) == 0
+    key.close()

@@ -29,16 +29,22 @@
 
 #include "air.h"
 #include "context.h"
+#include "p2chip.h"
 
 namespace zk {
 namespace frichip {
 
 constexpr uint32_t E0 = 0, E1 = 4, BIT = 8, K = 9, X = 10, XI = 11, S = 12, T = 13, B = 14, BETA = 15, FOLD = 19, ACTIVE = 23, LN = 24, G = 25, GS = 26, GT = 27,
                    OWN = 28, L = 32;
-constexpr uint32_t BUS_E0 = 40, BUS_E1 = 41;
+// the wired form (zkhip_prove_fri_layers: the Poseidon2 chip authenticates every pair by its Merkle path) has two more columns in front
+// of the layer selectors: K2 = 2 K (the bus key the Poseidon2 chip's index walk produces on a leaf row) and IDX = K2 + BIT (the query
+// index on a query's first row)
+constexpr uint32_t K2 = 32, IDX = 33, L_WIRED = 34;
+constexpr uint32_t BUS_E0 = 40, BUS_E1 = 41, BUS_R0 = 42, BUS_R1 = 43, BUS_Q = 44;
+constexpr uint32_t QUERIES_PRE = 8, ROOTS_PRE = 12;          // QUERIES: (index, value[4], 1, 0, 0); ROOTS: (layer, root[8], 0, 0, 0) + main (count, 0, 0, 0)
 constexpr uint32_t OPEN_PRE = 12, OPEN_MAIN = 4;             // OPENINGS: preprocessed (ln, k, e0[4], e1[4], m, 0), main 4 unused columns
 constexpr int MIN_LAYERS = 2, MAX_LAYERS = 22;
-inline uint32_t width_of(int layers) { return (32u + (uint32_t)layers + 3u) & ~3u; }
+inline uint32_t width_of(int layers, bool wired = false) { return ((wired ? L_WIRED : L) + (uint32_t)layers + 3u) & ~3u; }
 inline uint32_t n_public_of(int layers) { return 4u * (uint32_t)layers + 4u; }
 
 namespace {
@@ -69,8 +75,9 @@ struct Builder {
 // c_l = w_{2^(l+1)} canonical: the factor bit l of a query index contributes to its evaluation point
 inline uint32_t root_const(int l) { return from_monty(two_adic_generator(l + 1)); }
 
-std::vector<uint32_t> build_program(int RL) {
-    const uint32_t W = width_of(RL), NP = n_public_of(RL), END = L + (uint32_t)RL - 1u;
+std::vector<uint32_t> build_program(int RL, bool wired) {
+    const uint32_t L = wired ? L_WIRED : frichip::L;       // first layer-selector column of this form
+    const uint32_t W = width_of(RL, wired), NP = n_public_of(RL), END = L + (uint32_t)RL - 1u;
     const uint32_t inv2 = (P + 1) / 2;
     Builder b;
     // G * t for the gate G = ACTIVE - END ("an active row that is not the last of its query").  A selector counts one degree, so a
@@ -131,16 +138,33 @@ std::vector<uint32_t> build_program(int RL) {
     for (uint32_t j = 0; j < 4; j++)        // the folded value is the next layer's own entry
         b.add(TRANSITION, gated(Terms{{1u, {var(FOLD + j)}}, {P - 1, {var(OWN + j, true)}}}));
     for (uint32_t j = 0; j < 4; j++) b.add(ALL, Terms{{1u, {var(END), var(FOLD + j)}}, {P - 1, {var(END), pub(4u * (uint32_t)RL + j)}}});
+    if (wired) {
+        b.add(ALL, Terms{{1u, {var(K2)}}, {P - 2, {var(K)}}});
+        b.add(ALL, Terms{{1u, {var(IDX)}}, {P - 1, {var(K2)}}, {P - 1, {var(BIT)}}});
+    }
     std::vector<uint32_t> p{AIR_MAGIC, 1u, W, b.count, NP, (uint32_t)(6 + b.body.size())};
     p.insert(p.end(), b.body.begin(), b.body.end());
     return p;
 }
-std::shared_ptr<const std::vector<uint32_t>> program(int RL) {
+std::shared_ptr<const std::vector<uint32_t>> program(int RL, bool wired = false) {
     static std::mutex mu;
     static std::map<int, std::shared_ptr<const std::vector<uint32_t>>> cache;
     std::lock_guard<std::mutex> lk(mu);
-    auto it = cache.find(RL);
-    if (it == cache.end()) it = cache.emplace(RL, std::make_shared<const std::vector<uint32_t>>(build_program(RL))).first;
+    const int key = 2 * RL + (wired ? 1 : 0);
+    auto it = cache.find(key);
+    if (it == cache.end()) it = cache.emplace(key, std::make_shared<const std::vector<uint32_t>>(build_program(RL, wired))).first;
+    return it->second;
+}
+// a table whose contents are fixed by the KEY: combined row [pre | 4 main columns], one harmless first-row identity on the last main column
+std::shared_ptr<const std::vector<uint32_t>> table_program(int RL, uint32_t pre_width) {
+    static std::mutex mu;
+    static std::map<uint64_t, std::shared_ptr<const std::vector<uint32_t>>> cache;
+    std::lock_guard<std::mutex> lk(mu);
+    const uint64_t key = ((uint64_t)RL << 32) | pre_width;
+    auto it = cache.find(key);
+    if (it == cache.end())
+        it = cache.emplace(key, std::make_shared<const std::vector<uint32_t>>(std::vector<uint32_t>{AIR_MAGIC, 1u, pre_width + 4u, 1u, n_public_of(RL), 6u + 5u,
+                                                                                                     FIRST, 1u, 1u, 1u, var(pre_width + 3u)})).first;
     return it->second;
 }
 // OPENINGS: combined row [ln k e0 e1 m 0 | 0 0 0 0]; its program is one harmless identity (the contents are fixed by the KEY)
@@ -167,9 +191,36 @@ const std::vector<uint32_t>& openings_interactions() {  // two receives with the
     return t;
 }
 
+std::vector<uint32_t> fri_interactions_wired(int RL) {     // pairs to the Poseidon2 chip (key = 2 K), the query's start to the QUERIES table
+    (void)RL;
+    return std::vector<uint32_t>{LOOKUP_MAGIC, 3u, 3u + 2u * 10u + 9u,
+                                 0u, ACTIVE, BUS_E0, 6u, LN, K2, E0, E0 + 1, E0 + 2, E0 + 3,
+                                 0u, ACTIVE, BUS_E1, 6u, LN, K2, E1, E1 + 1, E1 + 2, E1 + 3,
+                                 0u, L_WIRED, BUS_Q, 5u, IDX, OWN, OWN + 1, OWN + 2, OWN + 3};
+}
+const std::vector<uint32_t>& p2_interactions() {          // leaf rows receive the pairs; END rows send (layer, digest) in two halves
+    using namespace p2chip;
+    static const std::vector<uint32_t> t{LOOKUP_MAGIC, 4u, 3u + 2u * 10u + 2u * 9u,
+                                         1u, M, BUS_E0, 6u, LNP, KP, IN, IN + 1, IN + 2, IN + 3,
+                                         1u, M, BUS_E1, 6u, LNP, KP, IN + 4, IN + 5, IN + 6, IN + 7,
+                                         0u, END, BUS_R0, 5u, LNP, oute(7), oute(7) + 1, oute(7) + 2, oute(7) + 3,
+                                         0u, END, BUS_R1, 5u, LNP, oute(7) + 4, oute(7) + 5, oute(7) + 6, oute(7) + 7};
+    return t;
+}
+const std::vector<uint32_t>& queries_interactions() {     // receive (preprocessed multiplicity column 5, [index, value])
+    static const std::vector<uint32_t> t{LOOKUP_MAGIC, 1u, 3u + 9u, 1u, 5u, BUS_Q, 5u, 0u, 1u, 2u, 3u, 4u};
+    return t;
+}
+const std::vector<uint32_t>& roots_interactions() {       // receive (main count column = combined column 12, [layer, half of the root])
+    static const std::vector<uint32_t> t{LOOKUP_MAGIC, 2u, 3u + 2u * 9u,
+                                         1u, ROOTS_PRE, BUS_R0, 5u, 0u, 1u, 2u, 3u, 4u,
+                                         1u, ROOTS_PRE, BUS_R1, 5u, 0u, 5u, 6u, 7u, 8u};
+    return t;
+}
+
 struct TraceArgs {
     const uint32_t *betas, *indices, *values, *siblings;    // canonical, on the device
-    uint32_t n_queries, layers, width, log_h;               // log_h = layers + 1: bits of a query index
+    uint32_t n_queries, layers, width, log_h, wired;        // log_h = layers + 1: bits of a query index
     uint64_t rows;
     uint32_t* trace; uint64_t ld;                           // Montgomery
     uint32_t* finals;                                       // [n_queries][4] canonical: the value every chain ends in
@@ -178,7 +229,7 @@ struct TraceArgs {
 // the padding rows: zeros with T = 1
 __global__ void __launch_bounds__(64) fri_trace_kernel(TraceArgs a) {
     const uint32_t q = blockIdx.x * blockDim.x + threadIdx.x;
-    const uint32_t RL = a.layers, W = a.width;
+    const uint32_t RL = a.layers, W = a.width, L = a.wired ? L_WIRED : frichip::L;
     const uint64_t used = (uint64_t)a.n_queries * RL;
     if (q >= a.n_queries) {
         for (uint64_t r = used + (q - a.n_queries); r < a.rows; r += (uint64_t)gridDim.x * blockDim.x - a.n_queries) {
@@ -215,6 +266,7 @@ __global__ void __launch_bounds__(64) fri_trace_kernel(TraceArgs a) {
         row[L + l] = MONTY_R1;
         if (l + 1 < RL) { row[G] = MONTY_R1; row[GS] = row[S]; row[GT] = tcol[l]; }
         for (int i = 0; i < 4; i++) row[OWN + i] = own.c[i];
+        if (a.wired) { row[K2] = to_monty(2u * k); row[IDX] = to_monty(2u * k + bit); }
         own = fold;
         idx = k;
     }
@@ -324,12 +376,13 @@ size_t zkhip_fri_chip_air(int layers, uint32_t* program, size_t cap_words) {
     return p->size();
 }
 
-int zkhip_fri_chip_gen_trace(zkhip_ctx* ctx, int layers, size_t n_queries, const uint32_t* betas, const uint32_t* indices, const uint32_t* values,
-                             const uint32_t* siblings, int log_rows, uint32_t* d_trace, size_t ld, uint32_t* finals) {
+}  // extern "C"
+static int fri_gen_trace(zkhip_ctx* ctx, int layers, size_t n_queries, const uint32_t* betas, const uint32_t* indices, const uint32_t* values,
+                         const uint32_t* siblings, int log_rows, uint32_t* d_trace, size_t ld, uint32_t* finals, bool wired) {
     CHECK_CTX(ctx);
     int need;
     ZK_TRY(frichip::shape_ok(layers, n_queries, &need));
-    const uint32_t W = frichip::width_of(layers);
+    const uint32_t W = frichip::width_of(layers, wired);
     if (!betas || !indices || !values || !siblings || !d_trace || !finals || ld < W || log_rows < need || log_rows > MAX_LOG_ROWS)
         return fail(ZKHIP_ERR_INVALID, "fri_chip_gen_trace: bad arguments");
     const size_t nb = 4 * (size_t)layers, nv = 4 * n_queries, ns = nv * (size_t)layers;
@@ -344,7 +397,7 @@ int zkhip_fri_chip_gen_trace(zkhip_ctx* ctx, int layers, size_t n_queries, const
     ZK_HIP(hipMemcpyAsync(d + nb + n_queries + nv, siblings, ns * 4, hipMemcpyHostToDevice, ctx->stream));
     frichip::TraceArgs a{};
     a.betas = d; a.indices = d + nb; a.values = d + nb + n_queries; a.siblings = d + nb + n_queries + nv;
-    a.n_queries = (uint32_t)n_queries; a.layers = (uint32_t)layers; a.width = W; a.log_h = (uint32_t)layers + 1u;
+    a.n_queries = (uint32_t)n_queries; a.layers = (uint32_t)layers; a.width = W; a.log_h = (uint32_t)layers + 1u; a.wired = wired ? 1u : 0u;
     a.rows = (uint64_t)1 << log_rows; a.trace = d_trace; a.ld = ld; a.finals = d + nb + n_queries + nv + ns;
     const size_t pad = a.rows - n_queries * (size_t)layers;
     const size_t threads = n_queries + (pad < 4096 ? pad : 4096);            // the padding rows are shared among up to 4096 extra threads
@@ -353,6 +406,11 @@ int zkhip_fri_chip_gen_trace(zkhip_ctx* ctx, int layers, size_t n_queries, const
     ZK_HIP(hipMemcpyAsync(finals, a.finals, nv * 4, hipMemcpyDeviceToHost, ctx->stream));
     ZK_HIP(hipStreamSynchronize(ctx->stream));
     return ZKHIP_OK;
+}
+extern "C" {
+int zkhip_fri_chip_gen_trace(zkhip_ctx* ctx, int layers, size_t n_queries, const uint32_t* betas, const uint32_t* indices, const uint32_t* values,
+                             const uint32_t* siblings, int log_rows, uint32_t* d_trace, size_t ld, uint32_t* finals) {
+    return fri_gen_trace(ctx, layers, n_queries, betas, indices, values, siblings, log_rows, d_trace, ld, finals, false);
 }
 
 // the key of a view: the commitment to its OPENINGS table (zkhip_machine_setup).  A verifier recomputes it from the inner proof.
@@ -420,6 +478,214 @@ int zkhip_verify_fri_queries(const uint8_t* proof, size_t len, int layers, size_
     std::memcpy(pv.data() + 4 * (size_t)layers, final_value, 16);
     const frichip::Machine m = frichip::machine_of(layers, log_rows);
     return zkhip_verify_machine_keyed(proof, len, m.log_ns, m.widths, m.pre_widths, vk, m.progs, m.prog_words, m.tabs, m.tab_words, 2, pv.data(), pv.size(), prm, reason);
+}
+
+}  // extern "C"
+
+// ================================================================ the wired machine: Merkle paths of the pairs in-circuit
+// Four chips, tallest first:
+//   P2F      the Poseidon2 chip's FRI-layers variant (poseidon2_chip.cpp): one path per (query, layer) -- a leaf row hashing the pair, then
+//            layers - l compression rows up to the layer's root.  Leaf rows RECEIVE (layer, 2 pair-index, E0) and (.., E1); END rows SEND
+//            (layer, root half) twice.
+//   FRI      the fold chip in its wired form: sends the pairs, and on a query's first row (index, reduced opening).
+//   QUERIES  preprocessed (index, reduced opening, 1): receives the starts -- what the verifier computed itself for every query.
+//   ROOTS    preprocessed (layer, root): receives the path ends with a main count column (= queries per layer).
+// Statement: "for the FRI layer commitments and the (index, reduced opening) pairs in the key, every query's chain opens those
+// commitments layer by layer and folds, under the public challenges, to the public final value."  The key no longer holds any FRI
+// layer VALUE: a verifier needs the layer roots from the inner proof and its own reduced openings.
+namespace zk {
+namespace p2chip { std::shared_ptr<const std::vector<uint32_t>> program_fri_layers(uint32_t n_public); }
+namespace frichip {
+namespace {
+struct WiredMachine {
+    int32_t log_ns[4]; uint32_t widths[4], pre_widths[4];
+    const uint32_t* progs[4]; size_t prog_words[4]; const uint32_t* tabs[4]; size_t tab_words[4];
+    std::shared_ptr<const std::vector<uint32_t>> p[4];
+    std::vector<uint32_t> fri_tab;
+};
+inline int log2_ceil(size_t n, int lo) { int l = lo; while (((size_t)1 << l) < n) l++; return l; }
+inline size_t p2_rows(int layers, size_t nq) { return nq * ((size_t)layers + (size_t)layers * ((size_t)layers + 1) / 2); }
+void wired_machine(int layers, size_t nq, WiredMachine& m) {
+    m.p[0] = p2chip::program_fri_layers(n_public_of(layers));
+    m.p[1] = program(layers, true);
+    m.p[2] = table_program(layers, QUERIES_PRE);
+    m.p[3] = table_program(layers, ROOTS_PRE);
+    m.fri_tab = fri_interactions_wired(layers);
+    m.log_ns[0] = log2_ceil(p2_rows(layers, nq), 5); m.log_ns[1] = log2_ceil(nq * (size_t)layers, 5);
+    m.log_ns[2] = log2_ceil(nq, 5); m.log_ns[3] = log2_ceil((size_t)layers, 5);
+    if (m.log_ns[3] > m.log_ns[2]) m.log_ns[2] = m.log_ns[3];                // tallest first also for few queries
+    m.widths[0] = p2chip::WIDTH; m.widths[1] = width_of(layers, true); m.widths[2] = 4; m.widths[3] = 4;
+    m.pre_widths[0] = 0; m.pre_widths[1] = 0; m.pre_widths[2] = QUERIES_PRE; m.pre_widths[3] = ROOTS_PRE;
+    const std::vector<uint32_t>* tabs[4] = {&p2_interactions(), &m.fri_tab, &queries_interactions(), &roots_interactions()};
+    for (int c = 0; c < 4; c++) { m.progs[c] = m.p[c]->data(); m.prog_words[c] = m.p[c]->size(); m.tabs[c] = tabs[c]->data(); m.tab_words[c] = tabs[c]->size(); }
+}
+}  // namespace
+}  // namespace frichip
+}  // namespace zk
+
+extern "C" {
+
+size_t zkhip_fri_layers_chip_air(int layers, uint32_t* program, size_t cap_words) {
+    if (layers < frichip::MIN_LAYERS || layers > frichip::MAX_LAYERS) return 0;
+    const auto p = frichip::program(layers, true);
+    if (program && cap_words >= p->size()) std::memcpy(program, p->data(), p->size() * 4);
+    return p->size();
+}
+size_t zkhip_p2chip_air_fri_layers(int layers, uint32_t* program, size_t cap_words) {
+    if (layers < frichip::MIN_LAYERS || layers > frichip::MAX_LAYERS) return 0;
+    const auto p = p2chip::program_fri_layers(frichip::n_public_of(layers));
+    if (program && cap_words >= p->size()) std::memcpy(program, p->data(), p->size() * 4);
+    return p->size();
+}
+
+// the key: QUERIES (index, reduced opening, 1) and ROOTS (layer, root) committed by zkhip_machine_setup
+int zkhip_fri_layers_key(zkhip_ctx* ctx, int layers, size_t n_queries, const uint32_t* indices, const uint32_t* values, const uint32_t* roots,
+                         const zkhip_params* prm, zkhip_machine_key** key, uint32_t vk[8]) {
+    CHECK_CTX(ctx);
+    if (!indices || !values || !roots || !prm || !key || !vk) return fail(ZKHIP_ERR_INVALID, "fri_layers_key: null argument");
+    int lr;
+    ZK_TRY(frichip::shape_ok(layers, n_queries, &lr));
+    if (!frichip::canonical(values, 4 * n_queries) || !frichip::canonical(roots, 8 * (size_t)layers)) return fail(ZKHIP_ERR_INVALID, "fri_layers_key: values must be canonical");
+    frichip::WiredMachine m;
+    frichip::wired_machine(layers, n_queries, m);
+    std::vector<uint32_t> qt(((size_t)frichip::QUERIES_PRE) << m.log_ns[2], 0u), rt(((size_t)frichip::ROOTS_PRE) << m.log_ns[3], 0u);
+    for (size_t q = 0; q < n_queries; q++) {
+        if (indices[q] >> (layers + 1)) return fail(ZKHIP_ERR_INVALID, "fri_layers_key: a query index has more than layers + 1 bits");
+        uint32_t* r = qt.data() + frichip::QUERIES_PRE * q;
+        r[0] = to_monty(indices[q]);
+        for (int i = 0; i < 4; i++) r[1 + i] = to_monty(values[4 * q + i]);
+        r[5] = MONTY_R1;
+    }
+    for (int l = 0; l < layers; l++) {
+        uint32_t* r = rt.data() + frichip::ROOTS_PRE * (size_t)l;
+        r[0] = to_monty((uint32_t)l);
+        for (int i = 0; i < 8; i++) r[1 + i] = to_monty(roots[8 * l + i]);
+    }
+    void *dq, *dr;
+    ZK_TRY(ctx_reserve(ctx, S_REC_C, qt.size() * 4, &dq));
+    ZK_TRY(ctx_reserve(ctx, S_REC_D, rt.size() * 4, &dr));
+    ZK_HIP(hipMemcpyAsync(dq, qt.data(), qt.size() * 4, hipMemcpyHostToDevice, ctx->stream));
+    ZK_HIP(hipMemcpyAsync(dr, rt.data(), rt.size() * 4, hipMemcpyHostToDevice, ctx->stream));
+    ZK_HIP(hipStreamSynchronize(ctx->stream));
+    zkhip_chip pre[4]{};
+    for (int c = 0; c < 4; c++) { pre[c].log_n = m.log_ns[c]; pre[c].width = m.pre_widths[c]; pre[c].ld = m.pre_widths[c]; pre[c].partner = -1; }
+    pre[2].d_trace = (const uint32_t*)dq; pre[3].d_trace = (const uint32_t*)dr;
+    return zkhip_machine_setup(ctx, pre, 4, prm, key, vk);
+}
+
+size_t zkhip_fri_layers_proof_size(int layers, size_t n_queries, const zkhip_params* prm) {
+    int lr;
+    if (!prm || frichip::shape_ok(layers, n_queries, &lr) != ZKHIP_OK) return 0;
+    frichip::WiredMachine m;
+    frichip::wired_machine(layers, n_queries, m);
+    return zkhip_machine_proof_size_keyed(m.log_ns, m.widths, m.pre_widths, m.progs, m.prog_words, m.tabs, m.tab_words, 4, prm, frichip::n_public_of(layers));
+}
+
+// the Poseidon2 chip's trace for the layer paths of a view, generated on the device (d_trace: [2^log_rows][360], Montgomery)
+int zkhip_fri_layers_gen_paths_trace(zkhip_ctx* ctx, int layers, size_t n_queries, const uint32_t* betas, const uint32_t* indices, const uint32_t* values,
+                                     const uint32_t* siblings, const uint32_t* roots, const uint32_t* paths, int log_rows, uint32_t* d_trace, size_t ld) {
+    CHECK_CTX(ctx);
+    int lr;
+    ZK_TRY(frichip::shape_ok(layers, n_queries, &lr));
+    if (!betas || !indices || !values || !siblings || !roots || !paths || !d_trace || ld < p2chip::WIDTH) return fail(ZKHIP_ERR_INVALID, "fri_layers_gen_paths_trace: bad arguments");
+    const size_t R = (size_t)layers, np = n_queries * R, used = frichip::p2_rows(layers, n_queries), per_q = 4 * R * (R + 1);
+    if (log_rows > MAX_LOG_ROWS || ((size_t)1 << log_rows) < used) return fail(ZKHIP_ERR_INVALID, "fri_layers_gen_paths_trace: 2^log_rows rows do not hold the paths");
+    if (!frichip::canonical(betas, 4 * R) || !frichip::canonical(values, 4 * n_queries) || !frichip::canonical(siblings, 4 * np) || !frichip::canonical(paths, per_q * n_queries))
+        return fail(ZKHIP_ERR_INVALID, "fri_layers_gen_paths_trace: values must be canonical");
+    // the pairs of every (query, layer): fold the chain on the host (canonical words), as build_openings does
+    std::vector<uint32_t> leaves(8 * np), sib_off(np), idx(np), depths(np), lay(np), mults(np, 1u), starts(np);
+    const int H = layers + 1;
+    size_t row = 0;
+    for (size_t q = 0; q < n_queries; q++) {
+        uint32_t i = indices[q];
+        if (i >> H) return fail(ZKHIP_ERR_INVALID, "fri_layers_gen_paths_trace: a query index has more than layers + 1 bits");
+        Ext own = frichip::ext_from_canon(values + 4 * q);
+        for (int l = 0; l < layers; l++) {
+            const size_t p = q * R + (size_t)l;
+            const uint32_t bit = i & 1u, k = i >> 1;
+            const Ext sib = frichip::ext_from_canon(siblings + 4 * p);
+            const Ext e0 = bit ? sib : own, e1 = bit ? own : sib;
+            for (int c = 0; c < 4; c++) { leaves[8 * p + c] = from_monty(e0.c[c]); leaves[8 * p + 4 + c] = from_monty(e1.c[c]); }
+            const int lh = H - (l + 1);
+            sib_off[p] = (uint32_t)(q * per_q + 8 * ((size_t)l * R - (size_t)l * ((size_t)l - 1) / 2));
+            idx[p] = k; depths[p] = (uint32_t)lh; lay[p] = (uint32_t)l; starts[p] = (uint32_t)row;
+            row += 1 + (size_t)lh;
+            const uint32_t xi = finv(fpow(two_adic_generator(lh + 1), reverse_bits(k, lh)));
+            const Ext beta = frichip::ext_from_canon(betas + 4 * l);
+            own = ext_add(ext_mul_base(ext_add(e0, e1), MONTY_INV2), ext_mul(beta, ext_mul_base(ext_sub(e0, e1), fmul(MONTY_INV2, xi))));
+            i = k;
+        }
+    }
+    const size_t np8 = 8 * np, npaths_words = per_q * n_queries;
+    void* stage;
+    ZK_TRY(ctx_reserve(ctx, S_STAGE, (np8 + npaths_words + 6 * np + np8) * 4, &stage));
+    uint32_t* d = (uint32_t*)stage;
+    uint32_t *d_leaves = d, *d_sibs = d + np8, *d_meta = d_sibs + npaths_words, *d_roots = d_meta + 6 * np;
+    ZK_HIP(hipMemcpyAsync(d_leaves, leaves.data(), np8 * 4, hipMemcpyHostToDevice, ctx->stream));
+    ZK_HIP(hipMemcpyAsync(d_sibs, paths, npaths_words * 4, hipMemcpyHostToDevice, ctx->stream));
+    const std::vector<uint32_t>* meta[6] = {&sib_off, &idx, &depths, &lay, &mults, &starts};
+    for (int k = 0; k < 6; k++) ZK_HIP(hipMemcpyAsync(d_meta + (size_t)k * np, meta[k]->data(), np * 4, hipMemcpyHostToDevice, ctx->stream));
+    p2chip::LayerPathsArgs a{};
+    a.leaves = d_leaves; a.siblings = d_sibs; a.sib_off = d_meta; a.indices = d_meta + np; a.depths = d_meta + 2 * np; a.layers = d_meta + 3 * np;
+    a.mults = d_meta + 4 * np; a.starts = d_meta + 5 * np; a.n_paths = np; a.rows = (uint64_t)1 << log_rows; a.used_rows = used;
+    a.trace = d_trace; a.ld = ld; a.roots = d_roots;
+    ZK_HIP(launch_p2chip_layer_paths(a, ctx->stream));
+    std::vector<uint32_t> got(np8);
+    ZK_HIP(hipMemcpyAsync(got.data(), d_roots, np8 * 4, hipMemcpyDeviceToHost, ctx->stream));
+    ZK_HIP(hipStreamSynchronize(ctx->stream));
+    for (size_t p = 0; p < np; p++)
+        if (std::memcmp(got.data() + 8 * p, roots + 8 * (p % R), 32) != 0)
+            return fail(ZKHIP_ERR_INVALID, "fri_layers: the path of query " + std::to_string(p / R) + ", layer " + std::to_string(p % R) + " does not end in the layer's root");
+    return ZKHIP_OK;
+}
+
+int zkhip_prove_fri_layers(zkhip_ctx* ctx, const zkhip_machine_key* key, int layers, size_t n_queries, const uint32_t* betas, const uint32_t* indices,
+                           const uint32_t* values, const uint32_t* siblings, const uint32_t* roots, const uint32_t* paths, const zkhip_params* prm,
+                           uint8_t* proof, size_t cap, size_t* len) {
+    CHECK_CTX(ctx);
+    if (!key || !prm || !proof || !len) return fail(ZKHIP_ERR_INVALID, "prove_fri_layers: null argument");
+    int lr;
+    ZK_TRY(frichip::shape_ok(layers, n_queries, &lr));
+    frichip::WiredMachine m;
+    frichip::wired_machine(layers, n_queries, m);
+    void *t_p2, *t_fri, *t_q, *t_r;
+    ZK_TRY(ctx_reserve(ctx, S_REC_A, ((size_t)m.widths[0] << m.log_ns[0]) * 4, &t_p2));
+    ZK_TRY(ctx_reserve(ctx, S_REC_B, ((size_t)m.widths[1] << m.log_ns[1]) * 4, &t_fri));
+    ZK_TRY(ctx_reserve(ctx, S_CHIP, ((size_t)4 << m.log_ns[2]) * 4, &t_q));
+    ZK_TRY(ctx_reserve(ctx, S_CHIP_B, ((size_t)4 << m.log_ns[3]) * 4, &t_r));
+    ZK_TRY(zkhip_fri_layers_gen_paths_trace(ctx, layers, n_queries, betas, indices, values, siblings, roots, paths, m.log_ns[0], (uint32_t*)t_p2, m.widths[0]));
+    std::vector<uint32_t> finals(4 * n_queries);
+    ZK_TRY(fri_gen_trace(ctx, layers, n_queries, betas, indices, values, siblings, m.log_ns[1], (uint32_t*)t_fri, m.widths[1], finals.data(), true));
+    for (size_t q = 1; q < n_queries; q++)
+        if (std::memcmp(finals.data(), finals.data() + 4 * q, 16) != 0) return fail(ZKHIP_ERR_INVALID, "prove_fri_layers: the chains do not end in one value");
+    // main columns of the tables: QUERIES none (zeros), ROOTS the number of paths per layer
+    std::vector<uint32_t> rmain((size_t)4 << m.log_ns[3], 0u);
+    for (int l = 0; l < layers; l++) rmain[4 * (size_t)l] = to_monty((uint32_t)n_queries);
+    ZK_HIP(hipMemsetAsync(t_q, 0, ((size_t)4 << m.log_ns[2]) * 4, ctx->stream));
+    ZK_HIP(hipMemcpyAsync(t_r, rmain.data(), rmain.size() * 4, hipMemcpyHostToDevice, ctx->stream));
+    ZK_HIP(hipStreamSynchronize(ctx->stream));
+    std::vector<uint32_t> pv(frichip::n_public_of(layers));
+    std::memcpy(pv.data(), betas, 16 * (size_t)layers);
+    std::memcpy(pv.data() + 4 * (size_t)layers, finals.data(), 16);
+    zkhip_chip chips[4]{};
+    void* tr[4] = {t_p2, t_fri, t_q, t_r};
+    for (int c = 0; c < 4; c++) { chips[c].d_trace = (const uint32_t*)tr[c]; chips[c].ld = m.widths[c]; chips[c].log_n = m.log_ns[c]; chips[c].width = m.widths[c]; chips[c].partner = -1; }
+    return zkhip_prove_machine_keyed(ctx, key, chips, m.progs, m.prog_words, m.tabs, m.tab_words, 4, pv.data(), pv.size(), prm, proof, cap, len);
+}
+
+int zkhip_verify_fri_layers(const uint8_t* proof, size_t len, int layers, size_t n_queries, const uint32_t* betas, const uint32_t final_value[4],
+                            const uint32_t vk[8], const zkhip_params* prm, int* reason) {
+    int lr;
+    if (!proof || !betas || !final_value || !vk || !prm || frichip::shape_ok(layers, n_queries, &lr) != ZKHIP_OK) {
+        if (reason) *reason = 1;
+        return fail(ZKHIP_ERR_VERIFY, "verify_fri_layers: bad arguments");
+    }
+    std::vector<uint32_t> pv(frichip::n_public_of(layers));
+    std::memcpy(pv.data(), betas, 16 * (size_t)layers);
+    std::memcpy(pv.data() + 4 * (size_t)layers, final_value, 16);
+    frichip::WiredMachine m;
+    frichip::wired_machine(layers, n_queries, m);
+    return zkhip_verify_machine_keyed(proof, len, m.log_ns, m.widths, m.pre_widths, vk, m.progs, m.prog_words, m.tabs, m.tab_words, 4, pv.data(), pv.size(), prm, reason);
 }
 
 }  // extern "C"

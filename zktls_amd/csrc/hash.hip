@@ -566,6 +566,42 @@ __global__ void __launch_bounds__(64) p2chip_merkle_kernel(p2chip::MerkleTraceAr
     uint32_t zero[16] = {0}, out[16];
     p2chip_fill_row(a.trace + row * a.ld, zero, 0u, 0u, 0u, (uint32_t)a.n_paths, 0u, 0u, out);
 }
+// the FRI-layers variant (p2chip.h): paths of different depths, one leaf row + depth compression rows each, with the layer number,
+// the index walk and the receive multiplicity in the three spare columns
+__global__ void __launch_bounds__(64) p2chip_layer_paths_kernel(p2chip::LayerPathsArgs a) {
+    using namespace p2chip;
+    const uint64_t p = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (p < a.n_paths) {
+        uint32_t out[16], in[16];
+        uint32_t* t = a.trace + (uint64_t)a.starts[p] * a.ld;
+        const uint32_t depth = a.depths[p], index = a.indices[p], layer = to_monty(a.layers[p]);
+        for (int j = 0; j < 8; j++) { in[j] = to_monty(a.leaves[8 * p + j]); in[8 + j] = 0u; }
+        p2chip_fill_row(t, in, 0u, 0u, 0u, (uint32_t)p, 0u, 1u, out);
+        t[LNP] = layer; t[KP] = to_monty(2u * index); t[M] = to_monty(a.mults[p]);
+        t += a.ld;
+        const uint32_t* sib = a.siblings + a.sib_off[p];
+        for (uint32_t lvl = 0; lvl < depth; lvl++, t += a.ld) {
+            const uint32_t bit = (index >> lvl) & 1u;
+            for (int j = 0; j < 8; j++) { in[bit ? 8 + j : j] = out[j]; in[bit ? j : 8 + j] = to_monty(sib[8 * lvl + j]); }
+            const uint32_t end = lvl + 1 == depth ? 1u : 0u;
+            p2chip_fill_row(t, in, bit, 1u, end, (uint32_t)p + end, 0u, 0u, out);
+            t[LNP] = layer; t[KP] = to_monty(index >> lvl); t[M] = 0u;
+        }
+        for (int j = 0; j < 8; j++) a.roots[8 * p + j] = from_monty(out[j]);
+        return;
+    }
+    const uint64_t row = a.used_rows + (p - a.n_paths);
+    if (row >= a.rows) return;
+    uint32_t zero[16] = {0}, out[16];
+    uint32_t* t = a.trace + row * a.ld;
+    p2chip_fill_row(t, zero, 0u, 0u, 0u, (uint32_t)a.n_paths, 0u, 0u, out);
+    t[LNP] = 0u; t[KP] = 0u; t[M] = 0u;
+}
+hipError_t launch_p2chip_layer_paths(const p2chip::LayerPathsArgs& a, hipStream_t s) {
+    const uint64_t lanes = a.n_paths + (a.rows - a.used_rows);
+    hipLaunchKernelGGL(p2chip_layer_paths_kernel, dim3((unsigned)((lanes + 63) / 64)), dim3(64), 0, s, a);
+    return hipGetLastError();
+}
 hipError_t launch_p2chip_merkle(const p2chip::MerkleTraceArgs& a, hipStream_t s) {
     const uint64_t lanes = a.n_paths + (a.rows - a.n_paths * ((uint64_t)a.row_width / 8 + a.depth));
     hipLaunchKernelGGL(p2chip_merkle_kernel, dim3((unsigned)((lanes + 63) / 64)), dim3(64), 0, s, a);

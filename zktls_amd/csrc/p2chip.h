@@ -15,6 +15,28 @@ constexpr uint32_t x3p(uint32_t r) { return 289 + 3 * r; }      // its cube,
 constexpr uint32_t sbp(uint32_t r) { return 290 + 3 * r; }      // its seventh power
 constexpr uint32_t ext_input(uint32_t r) { return r == 0 ? S0 : (r == 4 ? SP : oute(r - 1)); }
 
+// The FRI-layers variant of the chip (fri_chip.hip wires it to the FRI-fold chip): the three spare columns carry
+//   LNP  the path's layer number (constant along a path),
+//   KP   on the leaf row twice the leaf's index; every later row of the path: KP = 2 KP' + BIT walks the index down bit by bit,
+//   M    how many times the leaf's tuple is received from the bus (non-zero on leaf rows only),
+// paths of DIFFERENT depths end in different roots: an END row sends (LNP, digest) to a preprocessed table of layer roots instead
+// of comparing with one public root.  Public values: those of the machine it sits in (none of its own).
+constexpr uint32_t LNP = 357, KP = 358, M = 359;
+// variable-depth paths, one leaf row (the sponge over 8 values) + depth compression rows each; path p starts at row start[p]
+struct LayerPathsArgs {
+    const uint32_t* leaves;      // [n_paths][8] the opened pairs, canonical
+    const uint32_t* siblings;    // concatenated per path: depth[p] x 8 words
+    const uint32_t* sib_off;     // [n_paths] word offset of path p's siblings
+    const uint32_t* indices;     // [n_paths] leaf index (bit l = right child at level l)
+    const uint32_t* depths;      // [n_paths]
+    const uint32_t* layers;      // [n_paths] layer number
+    const uint32_t* mults;       // [n_paths] receive multiplicity
+    const uint32_t* starts;      // [n_paths] first row
+    uint64_t n_paths, rows, used_rows;
+    uint32_t* trace; uint64_t ld;   // [rows][ld], Montgomery
+    uint32_t* roots;             // [n_paths][8], canonical
+};
+
 // paths: path p = rows [p (row_width / 8 + depth), ...): row_width / 8 sponge rows over its opened row (none when row_width = 0: the
 // leaf digest is given), then depth compression rows; leaves / siblings / indices are canonical words already on the device
 struct MerkleTraceArgs {

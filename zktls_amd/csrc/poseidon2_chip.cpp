@@ -69,7 +69,7 @@ Terms linear_def(uint32_t col, const Form& f) {
     return t;
 }
 
-std::vector<uint32_t> build_program() {
+std::vector<uint32_t> build_program(bool fri_layers = false, uint32_t n_public = N_PUBLIC) {
     // the matrices and constants of the tables in effect, canonical
     uint32_t ME[16][16], rc_e[8][16], rc_i[13], diag[16];
     for (int j = 0; j < 16; j++) {
@@ -131,11 +131,24 @@ std::vector<uint32_t> build_program() {
     for (uint32_t j = 0; j < 8; j++) b.add(TRANSITION, Terms{{1u, {var(SPG, true), var(IN + 8 + j, true)}}, {P - 1, {var(SPG, true), var(oute(7) + 8 + j)}}});
     for (uint32_t j = 0; j < 8; j++) b.add(ALL, Terms{{1u, {var(SS), var(IN + 8 + j)}}});
     for (uint32_t j = 0; j < 8; j++) b.add(TRANSITION, Terms{{1u, {var(CH, true), var(D + j, true)}}, {P - 1, {var(CH, true), var(oute(7) + j)}}});
-    for (uint32_t j = 0; j < 8; j++) b.add(ALL, Terms{{1u, {var(END), var(oute(7) + j)}}, {P - 1, {var(END), pub(j)}}});
+    if (!fri_layers) for (uint32_t j = 0; j < 8; j++) b.add(ALL, Terms{{1u, {var(END), var(oute(7) + j)}}, {P - 1, {var(END), pub(j)}}});
     b.add(FIRST, Terms{{1u, {var(CNT)}}, {P - 1, {var(END)}}});
     b.add(TRANSITION, Terms{{1u, {var(CNT, true)}}, {P - 1, {var(CNT)}}, {P - 1, {var(END, true)}}});
-    b.add(LAST, Terms{{1u, {var(CNT)}}, {P - 1, {pub(8)}}});
-    std::vector<uint32_t> p{AIR_MAGIC, 1u, WIDTH, b.count, N_PUBLIC, (uint32_t)(6 + b.body.size())};
+    if (!fri_layers) b.add(LAST, Terms{{1u, {var(CNT)}}, {P - 1, {pub(8)}}});
+    if (fri_layers) {
+        // a row inside a path (leaf or compression, not the last) is followed by a row that continues it; the trace does not end inside one
+        b.add(TRANSITION, Terms{{1u, {var(SS)}}, {P - 1, {var(SS), var(CH, true)}}, {1u, {var(CH)}}, {P - 1, {var(CH), var(CH, true)}},
+                                {P - 1, {var(END)}}, {1u, {var(END), var(CH, true)}}});
+        b.add(LAST, Terms{{1u, {var(SS)}}, {1u, {var(CH)}}, {P - 1, {var(END)}}});
+        b.add(ALL, Terms{{1u, {var(END)}}, {P - 1, {var(END), var(CH)}}});                                   // a path ends on a compression row
+        b.add(ALL, Terms{{1u, {var(SS), var(BIT)}}});
+        b.add(ALL, Terms{{1u, {var(SS), var(CH)}}});
+        b.add(TRANSITION, Terms{{1u, {var(CH, true), var(LNP, true)}}, {P - 1, {var(CH, true), var(LNP)}}});   // one layer per path
+        b.add(TRANSITION, Terms{{1u, {var(CH, true), var(KP)}}, {P - 2, {var(CH, true), var(KP, true)}}, {P - 1, {var(CH, true), var(BIT)}}});   // KP = 2 KP' + BIT
+        b.add(ALL, Terms{{1u, {var(END), var(KP)}}, {P - 1, {var(END), var(BIT)}}});                           // exactly depth bits
+        b.add(ALL, Terms{{1u, {var(M)}}, {P - 1, {var(M), var(SS)}}});                                         // tuples are received on leaf rows only
+    }
+    std::vector<uint32_t> p{AIR_MAGIC, 1u, WIDTH, b.count, n_public, (uint32_t)(6 + b.body.size())};
     p.insert(p.end(), b.body.begin(), b.body.end());
     return p;
 }
@@ -150,6 +163,21 @@ std::shared_ptr<const std::vector<uint32_t>> program() {
     if (!cached || cached_gen != gen) { cached = std::make_shared<const std::vector<uint32_t>>(build_program()); cached_gen = gen; }
     return cached;
 }
+
+}  // namespace
+// the FRI-layers variant for a machine with n_public public values (fri_chip.hip); follows the Poseidon2 tables in effect like program()
+std::shared_ptr<const std::vector<uint32_t>> program_fri_layers(uint32_t n_public) {
+    static std::mutex mu;
+    static std::map<uint32_t, std::shared_ptr<const std::vector<uint32_t>>> cache;
+    static uint64_t cached_gen = ~0ull;
+    std::lock_guard<std::mutex> lk(mu);
+    const uint64_t gen = g_p2_generation.load();
+    if (cached_gen != gen) { cache.clear(); cached_gen = gen; }
+    auto it = cache.find(n_public);
+    if (it == cache.end()) it = cache.emplace(n_public, std::make_shared<const std::vector<uint32_t>>(build_program(true, n_public))).first;
+    return it->second;
+}
+namespace {
 
 int paths_shape(size_t n_paths, int depth, uint32_t row_width, int* log_n) {
     if (row_width % 8 != 0 || row_width > 1024) return fail(ZKHIP_ERR_INVALID, "merkle paths: the opened row width is 0 (leaf digests are given) or a multiple of 8 up to 1024");

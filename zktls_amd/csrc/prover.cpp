@@ -1349,7 +1349,7 @@ static int run_queries(int n, const std::function<int(int)>& check, int min_per_
 // challenges, the final value, and per query the index, the reduced opening it starts from and the sibling of every layer.
 // zkhip_fri_view_shard points this at its caller's buffers and runs the verifier; the FRI-fold chip (fri_chip.hip) proves
 // statements about exactly these values.  Canonical words.
-struct FriViewSink { uint32_t *betas, *final_value, *indices, *values, *siblings; int layers; };
+struct FriViewSink { uint32_t *betas, *final_value, *indices, *values, *siblings; int layers; uint32_t *roots, *paths; };      // roots / paths optional
 static thread_local FriViewSink* t_fri_sink = nullptr;
 
 static int verify_shard_impl(const uint8_t* proof, size_t len, int log_n, uint32_t width, const uint32_t* public_values,
@@ -1528,6 +1528,7 @@ static int verify_shard_impl(const uint8_t* proof, size_t len, int log_n, uint32
         for (int l = 0; l < RL; l++) for (int i = 0; i < 4; i++) sink->betas[4 * l + i] = from_monty(betas[l].c[i]);
         for (int i = 0; i < 4; i++) sink->final_value[i] = from_monty(final_poly[0].c[i]);
         for (int q = 0; q < NQ_; q++) sink->indices[q] = (uint32_t)indices[q];
+        if (sink->roots) for (int l = 0; l < RL; l++) for (int i = 0; i < 8; i++) sink->roots[8 * l + i] = from_monty(commits[8 * l + i]);
     }
     const size_t pos0 = pos, words_total = len / 4;
     if ((words_total - pos0) % (size_t)NQ_ != 0) return reject(5);
@@ -1604,7 +1605,12 @@ static int verify_shard_impl(const uint8_t* proof, size_t len, int log_n, uint32
                         qpos[j] += 4;
                     }
                 }
-                rows[j] = rb; paths[j] = pf + qpos[j]; qpos[j] += 8 * (size_t)lh; rowidx[j] = row;
+                rows[j] = rb; paths[j] = pf + qpos[j]; rowidx[j] = row;
+                if (sink && sink->paths) {       // per query: the layers' paths one after the other, 8 (RL - l) words for layer l (fold by 2, H = RL + 1)
+                    const size_t per_query = 4 * (size_t)RL * ((size_t)RL + 1), before = 8 * ((size_t)l * RL - (size_t)l * ((size_t)l - 1) / 2);
+                    std::memcpy(sink->paths + (size_t)(q0 + j) * per_query + before, pf + qpos[j], 32 * (size_t)lh);
+                }
+                qpos[j] += 8 * (size_t)lh;
             }
             mark(verify_paths_x16(&commits[8 * l], lh, batch(rows, 0, paths, rowidx), 4 * arity, sh.hw), 40 + (l < 50 ? l : 50));
             for (int j = 0; j < cnt; j++) { folded[j] = fold_row_k(rowidx[j], lh, K, betas[l], ev.data() + (size_t)j * arity); idx[j] = rowidx[j]; }
@@ -1649,7 +1655,21 @@ int zkhip_fri_view_shard(const uint8_t* proof, size_t len, int log_n, uint32_t w
     if (check_shape(log_n, width, prm) != ZKHIP_OK) return ZKHIP_ERR_INVALID;
     shape_of(log_n, prm, sh);
     if (sh.K != 1 || sh.F != 0) return fail(ZKHIP_ERR_INVALID, "fri_view_shard: fold-by-2 proofs with a constant final value only");
-    FriViewSink sink{betas, final_value, indices, values, siblings, sh.R};
+    FriViewSink sink{betas, final_value, indices, values, siblings, sh.R, nullptr, nullptr};
+    struct Scope { explicit Scope(FriViewSink* s) { t_fri_sink = s; } ~Scope() { t_fri_sink = nullptr; } } scope(&sink);
+    int why = 0;
+    return verify_shard_impl(proof, len, log_n, width, public_values, n_public, prm, &why, nullptr);
+}
+size_t zkhip_fri_view_path_words(int layers) { return layers >= 1 && layers <= 22 ? 4 * (size_t)layers * ((size_t)layers + 1) : 0; }
+int zkhip_fri_view_shard_paths(const uint8_t* proof, size_t len, int log_n, uint32_t width, const uint32_t* public_values, size_t n_public,
+                               const zkhip_params* prm, uint32_t* betas, uint32_t final_value[4], uint32_t* indices, uint32_t* values, uint32_t* siblings,
+                               uint32_t* roots, uint32_t* paths) {
+    if (!prm || !betas || !final_value || !indices || !values || !siblings || !roots || !paths) return fail(ZKHIP_ERR_INVALID, "fri_view_shard_paths: null argument");
+    Shape sh;
+    if (check_shape(log_n, width, prm) != ZKHIP_OK) return ZKHIP_ERR_INVALID;
+    shape_of(log_n, prm, sh);
+    if (sh.K != 1 || sh.F != 0 || sh.b != 1) return fail(ZKHIP_ERR_INVALID, "fri_view_shard_paths: fold-by-2, blowup-2 proofs with a constant final value only");
+    FriViewSink sink{betas, final_value, indices, values, siblings, sh.R, roots, paths};
     struct Scope { explicit Scope(FriViewSink* s) { t_fri_sink = s; } ~Scope() { t_fri_sink = nullptr; } } scope(&sink);
     int why = 0;
     return verify_shard_impl(proof, len, log_n, width, public_values, n_public, prm, &why, nullptr);

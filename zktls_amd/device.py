@@ -566,6 +566,33 @@ class Context:
                                                sibs.ctypes.data_as(u32p), C.byref(params), buf.ctypes.data_as(u8p), size, C.byref(got)))
         return buf[: got.value]
 
+    def fri_layers_gen_paths_trace(self, view, log_rows):
+        R, Q, betas, idx, vals, sibs, roots, paths = _fri_layers_arrays(view)
+        out = self.alloc(360 << log_rows)
+        check(self.lib.zkhip_fri_layers_gen_paths_trace(self.handle, R, Q, betas.ctypes.data_as(u32p), idx.ctypes.data_as(u32p), vals.ctypes.data_as(u32p),
+                                                        sibs.ctypes.data_as(u32p), roots.ctypes.data_as(u32p), paths.ctypes.data_as(u32p), log_rows,
+                                                        C.c_void_p(out.ptr), 360))
+        return out
+
+    def fri_layers_key(self, view, params=None):
+        params = params or Params(1, 100, 16)
+        R, Q, betas, idx, vals, sibs, roots, paths = _fri_layers_arrays(view)
+        handle, root = C.c_void_p(), np.zeros(8, dtype=np.uint32)
+        check(self.lib.zkhip_fri_layers_key(self.handle, R, Q, idx.ctypes.data_as(u32p), vals.ctypes.data_as(u32p), roots.ctypes.data_as(u32p), C.byref(params),
+                                            C.byref(handle), root.ctypes.data_as(u32p)))
+        return MachineKey(self, handle, root, [0, 0, 8, 12])
+
+    def prove_fri_layers(self, key, view, params=None):
+        params = params or Params(1, 100, 16)
+        R, Q, betas, idx, vals, sibs, roots, paths = _fri_layers_arrays(view)
+        size = self.lib.zkhip_fri_layers_proof_size(R, Q, C.byref(params))
+        buf = np.empty(size, dtype=np.uint8)
+        got = C.c_size_t(0)
+        check(self.lib.zkhip_prove_fri_layers(self.handle, key.handle, R, Q, betas.ctypes.data_as(u32p), idx.ctypes.data_as(u32p), vals.ctypes.data_as(u32p),
+                                              sibs.ctypes.data_as(u32p), roots.ctypes.data_as(u32p), paths.ctypes.data_as(u32p), C.byref(params),
+                                              buf.ctypes.data_as(u8p), size, C.byref(got)))
+        return buf[: got.value]
+
     def prove_machine_keyed(self, key, chips, programs, tables, public_values=(), params=None, key_entries=None):
         """a machine with preprocessed columns (proof version 11): `key` from machine_setup; chips as in prove_machine (main columns);
         programs / tables address the combined row [preprocessed | main].  key_entries: per chip the key entry it uses (-1: none) when the
@@ -876,6 +903,64 @@ def fri_view_shard(proof, log_n, width, public_values=(), params=None):
                                    sibs.ctypes.data_as(u32p)))
     return {"betas": betas.reshape(R, 4).tolist(), "final": final.tolist(),
             "queries": [(int(idx[q]), vals[4 * q:4 * q + 4].tolist(), sibs[4 * q * R:4 * (q + 1) * R].reshape(R, 4).tolist()) for q in range(Q)]}
+
+
+def fri_view_shard_paths(proof, log_n, width, public_values=(), params=None):
+    """zkhip_fri_view_shard_paths: the view of fri_view_shard plus "roots": [R][8] and, per query, "paths": [R] lists of (R - l) digests"""
+    params = params or Params(1, 100, 16)
+    lib = _lib.load()
+    pr = np.ascontiguousarray(proof, dtype=np.uint8)
+    pv = np.ascontiguousarray(np.array(public_values, dtype=np.uint32))
+    R, Q = log_n, params.num_queries
+    per = int(lib.zkhip_fri_view_path_words(R))
+    betas, final = np.zeros(4 * R, dtype=np.uint32), np.zeros(4, dtype=np.uint32)
+    idx, vals, sibs = np.zeros(Q, dtype=np.uint32), np.zeros(4 * Q, dtype=np.uint32), np.zeros(4 * Q * R, dtype=np.uint32)
+    roots, paths = np.zeros(8 * R, dtype=np.uint32), np.zeros(per * Q, dtype=np.uint32)
+    check(lib.zkhip_fri_view_shard_paths(pr.ctypes.data_as(u8p), pr.size, log_n, width, pv.ctypes.data_as(u32p), pv.size, C.byref(params),
+                                         betas.ctypes.data_as(u32p), final.ctypes.data_as(u32p), idx.ctypes.data_as(u32p), vals.ctypes.data_as(u32p),
+                                         sibs.ctypes.data_as(u32p), roots.ctypes.data_as(u32p), paths.ctypes.data_as(u32p)))
+    view = {"betas": betas.reshape(R, 4).tolist(), "final": final.tolist(), "roots": roots.reshape(R, 8).tolist(),
+            "queries": [(int(idx[q]), vals[4 * q:4 * q + 4].tolist(), sibs[4 * q * R:4 * (q + 1) * R].reshape(R, 4).tolist()) for q in range(Q)], "paths": []}
+    for q in range(Q):
+        off, pq = q * per, []
+        for l in range(R):
+            n = 8 * (R - l)
+            pq.append(paths[off:off + n].reshape(R - l, 8).tolist())
+            off += n
+        view["paths"].append(pq)
+    return view
+
+
+def _fri_layers_arrays(view):
+    R, Q, betas, idx, vals, sibs = _fri_view_arrays(view)
+    roots = np.ascontiguousarray(np.array(view["roots"], dtype=np.uint32).reshape(-1))
+    paths = np.ascontiguousarray(np.array([w for pq in view["paths"] for layer in pq for dg in layer for w in dg], dtype=np.uint32))
+    return R, Q, betas, idx, vals, sibs, roots, paths
+
+
+def fri_layers_programs(layers):
+    """-> (the Poseidon2 chip's FRI-layers variant, the fold chip's wired form) as the library builds them"""
+    lib = _lib.load()
+    out = []
+    for f in (lib.zkhip_p2chip_air_fri_layers, lib.zkhip_fri_layers_chip_air):
+        n = f(layers, None, 0)
+        buf = np.zeros(n, dtype=np.uint32)
+        assert n and f(layers, buf.ctypes.data_as(u32p), n) == n
+        out.append(buf)
+    return out
+
+
+def verify_fri_layers(proof, view_betas, final, n_queries, vk, params=None):
+    params = params or Params(1, 100, 16)
+    lib = _lib.load()
+    pr = np.ascontiguousarray(proof, dtype=np.uint8)
+    b = np.ascontiguousarray(np.array(view_betas, dtype=np.uint32).reshape(-1))
+    f = np.ascontiguousarray(np.array(final, dtype=np.uint32))
+    k = np.ascontiguousarray(np.array(vk, dtype=np.uint32))
+    reason = C.c_int(0)
+    rc = lib.zkhip_verify_fri_layers(pr.ctypes.data_as(u8p), pr.size, b.size // 4, n_queries, b.ctypes.data_as(u32p), f.ctypes.data_as(u32p),
+                                     k.ctypes.data_as(u32p), C.byref(params), C.byref(reason))
+    return rc, reason.value
 
 
 def _fri_view_arrays(view):
