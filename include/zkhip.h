@@ -572,6 +572,16 @@ typedef struct zkhip_transcript_job {
 } zkhip_transcript_job;
 int zkhip_prove_transcripts(const int* devices, int n_devices, zkhip_transcript_job* jobs, int n_jobs, const zkhip_params* prm,
                             int in_flight_per_device, int verify, uint32_t vk[8]);
+/* Small transcripts are launch-bound: a proof of a 13 KB message is a few hundred kernels of microseconds each, and the GPU retires such
+ * kernels at a fixed rate however many streams feed it.  zkhip_prove_transcripts therefore proves the transcripts of ONE trace height
+ * (up to 2^16 rows) in lock-step batches: `max_batch` host threads on pooled contexts sharing one stream, whose launches of the same
+ * kernel merge into one launch (gridDim.z = members; csrc/batch.h), `lanes` batches in flight per device.  The proofs are byte for byte
+ * those of the unbatched path.  max_batch 0 or 1 switches lock-step off (default 32, lanes 2; lanes <= 0 keeps the current value).
+ * Process-wide.  zkhip_lockstep_stats: merged launches issued, member launch requests served, rendezvous whose members asked for
+ * different launches, then nanoseconds members spent waiting at a rendezvous, issuing merged launches, and in votes -- totals since the library was loaded.
+ * (The reference proves its batch one transcript after the other, each a full `client.prove` call: sp1.rs:116, BASELINE configs[2].) */
+void zkhip_set_lockstep(int max_batch, int lanes);
+void zkhip_lockstep_stats(uint64_t out[6]);
 
 /* A second real chip: the width-16 Poseidon2 permutation with Merkle-path chaining -- what a recursion machine (a STARK verifier proven
  * inside a STARK: the compress / shrink / wrap stages behind SP1ProofMode::Groth16, crates/guest-prover-sp1/src/sp1.rs:116; sp1-recursion's

@@ -136,5 +136,13 @@ int op_merkle_commit(zkhip_ctx* ctx, const MatDesc* mats, int nmats, int log_h, 
 int op_merkle_commit_mixed(zkhip_ctx* ctx, const MatDesc* mats, const int* log_heights, int nmats, uint32_t* d_tree);
 // batch entries (prover.cpp): job i -> devices[i mod n], up to `in_flight` pooled contexts per device, run(ctx, i) -> status
 int deal_jobs(const int* devices, int n_devices, int n_jobs, int in_flight, const std::function<int(zkhip_ctx*, int)>& run, std::vector<char>& ran);
+// copies, memsets and waits on the context's stream; inside a lock-step batch (batch.h) their merged forms.  dev_d2h returns with the
+// data in dst; dev_h2d returns when src may be reused
+int dev_sync(zkhip_ctx* ctx);
+int dev_d2h(zkhip_ctx* ctx, void* dst, const void* src, size_t bytes);
+int dev_h2d(zkhip_ctx* ctx, void* dst, const void* src, size_t bytes);
+int dev_memset(zkhip_ctx* ctx, void* dst, int byte, size_t bytes);
+int deal_jobs_lockstep(const int* devices, int n_devices, int n_jobs, const int* shape, int max_batch, int lanes,
+                       const std::function<int(zkhip_ctx*, int)>& run, std::vector<char>& ran);
 int resolve_devices(const int* devices, int n_devices, const char* what, std::vector<int>& devs);
 }  // namespace zk

@@ -29,6 +29,7 @@
 
 #include "air.h"
 #include "context.h"
+#include "batch.h"
 #include "p2chip.h"
 
 namespace zk {
@@ -227,7 +228,7 @@ struct TraceArgs {
 };
 // one thread per query walks its layers (the folded value of a layer is the next layer's own entry); threads past the queries fill
 // the padding rows: zeros with T = 1
-__global__ void __launch_bounds__(64) fri_trace_kernel(TraceArgs a) {
+__device__ __forceinline__ void fri_trace_kernel_body(const TraceArgs& a) {
     const uint32_t q = blockIdx.x * blockDim.x + threadIdx.x;
     const uint32_t RL = a.layers, W = a.width, L = a.wired ? L_WIRED : frichip::L;
     const uint64_t used = (uint64_t)a.n_queries * RL;
@@ -278,6 +279,10 @@ __global__ void __launch_bounds__(64) fri_trace_kernel(TraceArgs a) {
     }
     for (int i = 0; i < 4; i++) a.finals[4 * q + i] = from_monty(own.c[i]);
 }
+__global__ void __launch_bounds__(64) fri_trace_kernel(TraceArgs a) { fri_trace_kernel_body(a); }
+struct fri_trace_kernel_bargs { TraceArgs a; static fri_trace_kernel_bargs make(TraceArgs a) { return fri_trace_kernel_bargs{a}; } };
+__global__ void __launch_bounds__(64) fri_trace_kernel_batch(const fri_trace_kernel_bargs* __restrict__ zk_arr) { const fri_trace_kernel_bargs& zk_b = zk_arr[blockIdx.z]; fri_trace_kernel_body(zk_b.a); }
+
 
 int shape_ok(int layers, size_t n_queries, int* log_rows) {
     if (layers < MIN_LAYERS || layers > MAX_LAYERS || n_queries < 1 || n_queries > ((size_t)1 << 16))
@@ -401,7 +406,7 @@ static int fri_gen_trace(zkhip_ctx* ctx, int layers, size_t n_queries, const uin
     a.rows = (uint64_t)1 << log_rows; a.trace = d_trace; a.ld = ld; a.finals = d + nb + n_queries + nv + ns;
     const size_t pad = a.rows - n_queries * (size_t)layers;
     const size_t threads = n_queries + (pad < 4096 ? pad : 4096);            // the padding rows are shared among up to 4096 extra threads
-    hipLaunchKernelGGL(frichip::fri_trace_kernel, dim3((unsigned)((threads + 63) / 64)), dim3(64), 0, ctx->stream, a);
+    ZK_LAUNCH(frichip::fri_trace_kernel, frichip::fri_trace_kernel_batch, frichip::fri_trace_kernel_bargs, dim3((unsigned)((threads + 63) / 64)), dim3(64), 0, ctx->stream, a);
     ZK_HIP(hipGetLastError());
     ZK_HIP(hipMemcpyAsync(finals, a.finals, nv * 4, hipMemcpyDeviceToHost, ctx->stream));
     ZK_HIP(hipStreamSynchronize(ctx->stream));

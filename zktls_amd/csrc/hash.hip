@@ -12,6 +12,7 @@
 // traffic is needed.
 #include "poseidon2.cuh"
 #include "kernels.h"
+#include "batch.h"
 #include "p2chip.h"
 
 namespace zk {
@@ -33,12 +34,22 @@ __device__ __forceinline__ uint32_t load_virtual(const LeafArgs& a, uint64_t row
 
 // 16-lanes-per-permutation kernels, defined further down
 __global__ void hash_rows16_kernel(LeafArgs a, uint32_t total_w);
+struct hash_rows16_kernel_bargs { LeafArgs a; uint32_t total_w; static hash_rows16_kernel_bargs make(LeafArgs a, uint32_t total_w) { return hash_rows16_kernel_bargs{a, total_w}; } };
+__global__ void hash_rows16_kernel_batch(const hash_rows16_kernel_bargs* __restrict__ zk_arr);
 __global__ void compress_level16_kernel(const uint32_t* __restrict__ children, uint32_t* __restrict__ parents, uint32_t count);
+struct compress_level16_kernel_bargs { const uint32_t* children; uint32_t* parents; uint32_t count; static compress_level16_kernel_bargs make(const uint32_t* children, uint32_t* parents, uint32_t count) { return compress_level16_kernel_bargs{children, parents, count}; } };
+__global__ void compress_level16_kernel_batch(const compress_level16_kernel_bargs* __restrict__ zk_arr);
 __global__ void compress_top16_kernel(uint32_t* tree, uint32_t count);
+struct compress_top16_kernel_bargs { uint32_t* tree; uint32_t count; static compress_top16_kernel_bargs make(uint32_t* tree, uint32_t count) { return compress_top16_kernel_bargs{tree, count}; } };
+__global__ void compress_top16_kernel_batch(const compress_top16_kernel_bargs* __restrict__ zk_arr);
 __global__ void compress_sub16_kernel(uint32_t* tree, uint32_t count, uint32_t sub);
+struct compress_sub16_kernel_bargs { uint32_t* tree; uint32_t count; uint32_t sub; static compress_sub16_kernel_bargs make(uint32_t* tree, uint32_t count, uint32_t sub) { return compress_sub16_kernel_bargs{tree, count, sub}; } };
+__global__ void compress_sub16_kernel_batch(const compress_sub16_kernel_bargs* __restrict__ zk_arr);
 __global__ void hash_sub16_kernel(LeafArgs a, uint32_t total_w, uint32_t sub);
+struct hash_sub16_kernel_bargs { LeafArgs a; uint32_t total_w; uint32_t sub; static hash_sub16_kernel_bargs make(LeafArgs a, uint32_t total_w, uint32_t sub) { return hash_sub16_kernel_bargs{a, total_w, sub}; } };
+__global__ void hash_sub16_kernel_batch(const hash_sub16_kernel_bargs* __restrict__ zk_arr);
 
-__global__ void __launch_bounds__(256) hash_rows_generic_kernel(LeafArgs a, uint32_t total_w) {
+__device__ __forceinline__ void hash_rows_generic_kernel_body(const LeafArgs& a, uint32_t total_w) {
     const uint64_t row = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (row >= a.height) return;
     uint32_t s[16];
@@ -54,11 +65,13 @@ __global__ void __launch_bounds__(256) hash_rows_generic_kernel(LeafArgs a, uint
     d[0] = make_uint4(s[0], s[1], s[2], s[3]);
     d[1] = make_uint4(s[4], s[5], s[6], s[7]);
 }
+__global__ void __launch_bounds__(256) hash_rows_generic_kernel(LeafArgs a, uint32_t total_w) { hash_rows_generic_kernel_body(a, total_w); }
+struct hash_rows_generic_kernel_bargs { LeafArgs a; uint32_t total_w; static hash_rows_generic_kernel_bargs make(LeafArgs a, uint32_t total_w) { return hash_rows_generic_kernel_bargs{a, total_w}; } };
+__global__ void __launch_bounds__(256) hash_rows_generic_kernel_batch(const hash_rows_generic_kernel_bargs* __restrict__ zk_arr) { const hash_rows_generic_kernel_bargs& zk_b = zk_arr[blockIdx.z]; hash_rows_generic_kernel_body(zk_b.a, zk_b.total_w); }
+
 
 // single matrix, width % 4 == 0, 16-byte aligned rows: 2 x dwordx4 per absorbed block
-__global__ void __launch_bounds__(256) hash_rows_vec_kernel(const uint32_t* __restrict__ mat, uint64_t ld,
-                                                            uint32_t width, uint64_t height,
-                                                            uint32_t* __restrict__ digests) {
+__device__ __forceinline__ void hash_rows_vec_kernel_body(const uint32_t* __restrict__ mat, uint64_t ld, uint32_t width, uint64_t height, uint32_t* __restrict__ digests) {
     const uint64_t row = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (row >= height) return;
     const uint4* rp = reinterpret_cast<const uint4*>(mat + row * ld);
@@ -80,6 +93,10 @@ __global__ void __launch_bounds__(256) hash_rows_vec_kernel(const uint32_t* __re
     d[0] = make_uint4(s[0], s[1], s[2], s[3]);
     d[1] = make_uint4(s[4], s[5], s[6], s[7]);
 }
+__global__ void __launch_bounds__(256) hash_rows_vec_kernel(const uint32_t* __restrict__ mat, uint64_t ld, uint32_t width, uint64_t height, uint32_t* __restrict__ digests) { hash_rows_vec_kernel_body(mat, ld, width, height, digests); }
+struct hash_rows_vec_kernel_bargs { const uint32_t* mat; uint64_t ld; uint32_t width; uint64_t height; uint32_t* digests; static hash_rows_vec_kernel_bargs make(const uint32_t* mat, uint64_t ld, uint32_t width, uint64_t height, uint32_t* digests) { return hash_rows_vec_kernel_bargs{mat, ld, width, height, digests}; } };
+__global__ void __launch_bounds__(256) hash_rows_vec_kernel_batch(const hash_rows_vec_kernel_bargs* __restrict__ zk_arr) { const hash_rows_vec_kernel_bargs& zk_b = zk_arr[blockIdx.z]; hash_rows_vec_kernel_body(zk_b.mat, zk_b.ld, zk_b.width, zk_b.height, zk_b.digests); }
+
 
 hipError_t launch_hash_rows(const LeafArgs& a, hipStream_t s) {
     if (a.height == 0) return hipSuccess;
@@ -88,7 +105,7 @@ hipError_t launch_hash_rows(const LeafArgs& a, hipStream_t s) {
     for (int m = 0; m < a.nmats; m++) total += a.mats[m].width;
     if (a.height <= COOP_MAX_NODES) {
         const uint64_t threads = a.height * 16;
-        hipLaunchKernelGGL(hash_rows16_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, s, a, total);
+        ZK_LAUNCH(hash_rows16_kernel, hash_rows16_kernel_batch, hash_rows16_kernel_bargs, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, s, a, total);
         return hipGetLastError();
     }
     dim3 block(256), grid((unsigned)((a.height + 255) / 256));
@@ -96,9 +113,9 @@ hipError_t launch_hash_rows(const LeafArgs& a, hipStream_t s) {
     bool vec = a.nmats == 1 && m0.width % 4 == 0 && m0.ld % 4 == 0 &&
                (reinterpret_cast<uintptr_t>(m0.ptr) & 15) == 0;
     if (vec)
-        hipLaunchKernelGGL(hash_rows_vec_kernel, grid, block, 0, s, m0.ptr, m0.ld, m0.width, a.height, a.digests);
+        ZK_LAUNCH(hash_rows_vec_kernel, hash_rows_vec_kernel_batch, hash_rows_vec_kernel_bargs, grid, block, 0, s, m0.ptr, m0.ld, m0.width, a.height, a.digests);
     else
-        hipLaunchKernelGGL(hash_rows_generic_kernel, grid, block, 0, s, a, total);
+        ZK_LAUNCH(hash_rows_generic_kernel, hash_rows_generic_kernel_batch, hash_rows_generic_kernel_bargs, grid, block, 0, s, a, total);
     return hipGetLastError();
 }
 
@@ -113,25 +130,28 @@ __device__ __forceinline__ void compress_node(const uint32_t* children, uint32_t
     d[1] = make_uint4(s[4], s[5], s[6], s[7]);
 }
 
-__global__ void __launch_bounds__(256) compress_level_kernel(const uint32_t* __restrict__ children,
-                                                             uint32_t* __restrict__ parents, uint64_t count) {
+__device__ __forceinline__ void compress_level_kernel_body(const uint32_t* __restrict__ children, uint32_t* __restrict__ parents, uint64_t count) {
     const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= count) return;
     compress_node(children + 16 * i, parents + 8 * i);
 }
+__global__ void __launch_bounds__(256) compress_level_kernel(const uint32_t* __restrict__ children, uint32_t* __restrict__ parents, uint64_t count) { compress_level_kernel_body(children, parents, count); }
+struct compress_level_kernel_bargs { const uint32_t* children; uint32_t* parents; uint64_t count; static compress_level_kernel_bargs make(const uint32_t* children, uint32_t* parents, uint64_t count) { return compress_level_kernel_bargs{children, parents, count}; } };
+__global__ void __launch_bounds__(256) compress_level_kernel_batch(const compress_level_kernel_bargs* __restrict__ zk_arr) { const compress_level_kernel_bargs& zk_b = zk_arr[blockIdx.z]; compress_level_kernel_body(zk_b.children, zk_b.parents, zk_b.count); }
+
 hipError_t launch_compress_level(const uint32_t* children, uint32_t* parents, uint64_t count, hipStream_t s) {
     if (count == 0) return hipSuccess;
     if (count <= COOP_MAX_NODES) {
         const uint64_t threads = count * 16;
-        hipLaunchKernelGGL(compress_level16_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, s, children, parents, (uint32_t)count);
+        ZK_LAUNCH(compress_level16_kernel, compress_level16_kernel_batch, compress_level16_kernel_bargs, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, s, children, parents, (uint32_t)count);
         return hipGetLastError();
     }
-    hipLaunchKernelGGL(compress_level_kernel, dim3((unsigned)((count + 255) / 256)), dim3(256), 0, s, children, parents, count);
+    ZK_LAUNCH(compress_level_kernel, compress_level_kernel_batch, compress_level_kernel_bargs, dim3((unsigned)((count + 255) / 256)), dim3(256), 0, s, children, parents, count);
     return hipGetLastError();
 }
 
 // node[i] = compress(node[i], extra[i]): injection of a shorter matrix's row digests at its level
-__global__ void __launch_bounds__(256) inject_kernel(uint32_t* __restrict__ nodes, const uint32_t* __restrict__ extra, uint64_t count) {
+__device__ __forceinline__ void inject_kernel_body(uint32_t* __restrict__ nodes, const uint32_t* __restrict__ extra, uint64_t count) {
     const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= count) return;
     const uint4* a = reinterpret_cast<const uint4*>(nodes + 8 * i);
@@ -143,14 +163,18 @@ __global__ void __launch_bounds__(256) inject_kernel(uint32_t* __restrict__ node
     d[0] = make_uint4(s[0], s[1], s[2], s[3]);
     d[1] = make_uint4(s[4], s[5], s[6], s[7]);
 }
+__global__ void __launch_bounds__(256) inject_kernel(uint32_t* __restrict__ nodes, const uint32_t* __restrict__ extra, uint64_t count) { inject_kernel_body(nodes, extra, count); }
+struct inject_kernel_bargs { uint32_t* nodes; const uint32_t* extra; uint64_t count; static inject_kernel_bargs make(uint32_t* nodes, const uint32_t* extra, uint64_t count) { return inject_kernel_bargs{nodes, extra, count}; } };
+__global__ void __launch_bounds__(256) inject_kernel_batch(const inject_kernel_bargs* __restrict__ zk_arr) { const inject_kernel_bargs& zk_b = zk_arr[blockIdx.z]; inject_kernel_body(zk_b.nodes, zk_b.extra, zk_b.count); }
+
 hipError_t launch_inject(uint32_t* nodes, const uint32_t* extra, uint64_t count, hipStream_t s) {
     if (count == 0) return hipSuccess;
-    hipLaunchKernelGGL(inject_kernel, dim3((unsigned)((count + 255) / 256)), dim3(256), 0, s, nodes, extra, count);
+    ZK_LAUNCH(inject_kernel, inject_kernel_batch, inject_kernel_bargs, dim3((unsigned)((count + 255) / 256)), dim3(256), 0, s, nodes, extra, count);
     return hipGetLastError();
 }
 
 // levels count -> count/2 -> ... -> 1 inside one workgroup (count <= 2048)
-__global__ void __launch_bounds__(1024) compress_top_kernel(uint32_t* tree, uint32_t count) {
+__device__ __forceinline__ void compress_top_kernel_body(uint32_t* tree, uint32_t count) {
     uint32_t* level = tree;
     for (uint32_t n = count; n > 1; n >>= 1) {
         uint32_t* next = level + 8 * (size_t)n;
@@ -160,11 +184,15 @@ __global__ void __launch_bounds__(1024) compress_top_kernel(uint32_t* tree, uint
         level = next;
     }
 }
+__global__ void __launch_bounds__(1024) compress_top_kernel(uint32_t* tree, uint32_t count) { compress_top_kernel_body(tree, count); }
+struct compress_top_kernel_bargs { uint32_t* tree; uint32_t count; static compress_top_kernel_bargs make(uint32_t* tree, uint32_t count) { return compress_top_kernel_bargs{tree, count}; } };
+__global__ void __launch_bounds__(1024) compress_top_kernel_batch(const compress_top_kernel_bargs* __restrict__ zk_arr) { const compress_top_kernel_bargs& zk_b = zk_arr[blockIdx.z]; compress_top_kernel_body(zk_b.tree, zk_b.count); }
+
 hipError_t launch_compress_top(uint32_t* tree, uint32_t count, hipStream_t s) {
     if (count <= 1) return hipSuccess;
     if (count > COOP_TOP_NODES) return hipErrorInvalidValue;
     unsigned threads = count * 8 < 64 ? 64 : (count * 8 > 1024 ? 1024 : count * 8);
-    hipLaunchKernelGGL(compress_top16_kernel, dim3(1), dim3(threads), 0, s, tree, count);
+    ZK_LAUNCH(compress_top16_kernel, compress_top16_kernel_batch, compress_top16_kernel_bargs, dim3(1), dim3(threads), 0, s, tree, count);
     return hipGetLastError();
 }
 
@@ -173,13 +201,13 @@ hipError_t launch_hash_sub(const LeafArgs& a, uint32_t sub, hipStream_t s) {
     uint32_t total = 0;
     for (int m = 0; m < a.nmats; m++) total += a.mats[m].width;
     unsigned threads = sub * 8 < 64 ? 64 : (sub * 8 > 1024 ? 1024 : sub * 8);
-    hipLaunchKernelGGL(hash_sub16_kernel, dim3((unsigned)(a.height / sub)), dim3(threads), 0, s, a, total, sub);
+    ZK_LAUNCH(hash_sub16_kernel, hash_sub16_kernel_batch, hash_sub16_kernel_bargs, dim3((unsigned)(a.height / sub)), dim3(threads), 0, s, a, total, sub);
     return hipGetLastError();
 }
 hipError_t launch_compress_sub(uint32_t* tree, uint32_t count, uint32_t sub, hipStream_t s) {
     if (sub < 2 || (sub & (sub - 1)) || count % sub || count > COOP_MAX_NODES) return hipErrorInvalidValue;
     unsigned threads = sub * 8 < 64 ? 64 : (sub * 8 > 1024 ? 1024 : sub * 8);
-    hipLaunchKernelGGL(compress_sub16_kernel, dim3(count / sub), dim3(threads), 0, s, tree, count, sub);
+    ZK_LAUNCH(compress_sub16_kernel, compress_sub16_kernel_batch, compress_sub16_kernel_bargs, dim3(count / sub), dim3(threads), 0, s, tree, count, sub);
     return hipGetLastError();
 }
 
@@ -231,8 +259,7 @@ ZK_D uint32_t coop_permute(uint32_t x, int lane16, const CoopConsts& k) {
 }
 
 // parents[i] = compress(children[2i], children[2i+1]); one node per 16 lanes
-__global__ void __launch_bounds__(256) compress_level16_kernel(const uint32_t* __restrict__ children,
-                                                               uint32_t* __restrict__ parents, uint32_t count) {
+__device__ __forceinline__ void compress_level16_kernel_body(const uint32_t* __restrict__ children, uint32_t* __restrict__ parents, uint32_t count) {
     const uint32_t gid = blockIdx.x * blockDim.x + threadIdx.x;
     const uint32_t node = gid >> 4;
     const int lane16 = threadIdx.x & 15;
@@ -241,8 +268,11 @@ __global__ void __launch_bounds__(256) compress_level16_kernel(const uint32_t* _
     const uint32_t x = coop_permute(children[16 * (size_t)node + lane16], lane16, k);
     if (lane16 < 8) parents[8 * (size_t)node + lane16] = x;
 }
+__global__ void __launch_bounds__(256) compress_level16_kernel(const uint32_t* __restrict__ children, uint32_t* __restrict__ parents, uint32_t count) { compress_level16_kernel_body(children, parents, count); }
+__global__ void __launch_bounds__(256) compress_level16_kernel_batch(const compress_level16_kernel_bargs* __restrict__ zk_arr) { const compress_level16_kernel_bargs& zk_b = zk_arr[blockIdx.z]; compress_level16_kernel_body(zk_b.children, zk_b.parents, zk_b.count); }
+
 // all levels count -> 1 in one workgroup of 1024 threads (count <= 512), 64 nodes per step
-__global__ void __launch_bounds__(1024) compress_top16_kernel(uint32_t* tree, uint32_t count) {
+__device__ __forceinline__ void compress_top16_kernel_body(uint32_t* tree, uint32_t count) {
     const int lane16 = threadIdx.x & 15;
     const uint32_t grp = threadIdx.x >> 4, ngrp = blockDim.x >> 4;
     const CoopConsts k = coop_load_consts(lane16);
@@ -258,10 +288,13 @@ __global__ void __launch_bounds__(1024) compress_top16_kernel(uint32_t* tree, ui
         level = next;
     }
 }
+__global__ void __launch_bounds__(1024) compress_top16_kernel(uint32_t* tree, uint32_t count) { compress_top16_kernel_body(tree, count); }
+__global__ void __launch_bounds__(1024) compress_top16_kernel_batch(const compress_top16_kernel_bargs* __restrict__ zk_arr) { const compress_top16_kernel_bargs& zk_b = zk_arr[blockIdx.z]; compress_top16_kernel_body(zk_b.tree, zk_b.count); }
+
 // Several levels of a medium tree in one launch: `tree` points at a level with `count` digests (levels above follow it, as in
 // compress_top16_kernel); workgroup b reduces the `sub` consecutive digests [b sub, (b + 1) sub) of that level to one node, writing
 // its share of every level on the way.  count / sub nodes remain for compress_top16_kernel.
-__global__ void __launch_bounds__(1024) compress_sub16_kernel(uint32_t* tree, uint32_t count, uint32_t sub) {
+__device__ __forceinline__ void compress_sub16_kernel_body(uint32_t* tree, uint32_t count, uint32_t sub) {
     const int lane16 = threadIdx.x & 15;
     const uint32_t grp = threadIdx.x >> 4, ngrp = blockDim.x >> 4;
     const CoopConsts k = coop_load_consts(lane16);
@@ -279,10 +312,13 @@ __global__ void __launch_bounds__(1024) compress_sub16_kernel(uint32_t* tree, ui
         level = next; n >>= 1; mine >>= 1;
     }
 }
+__global__ void __launch_bounds__(1024) compress_sub16_kernel(uint32_t* tree, uint32_t count, uint32_t sub) { compress_sub16_kernel_body(tree, count, sub); }
+__global__ void __launch_bounds__(1024) compress_sub16_kernel_batch(const compress_sub16_kernel_bargs* __restrict__ zk_arr) { const compress_sub16_kernel_bargs& zk_b = zk_arr[blockIdx.z]; compress_sub16_kernel_body(zk_b.tree, zk_b.count, zk_b.sub); }
+
 // The same with the LEAVES hashed by the workgroup that owns them: a medium tree (512 < leaves <= 16 384: the FRI layers, the trees of small
 // proofs) is one launch less -- workgroup b hashes rows [b sub, (b + 1) sub) into the leaf level (one row per 16 lanes, as
 // hash_rows16_kernel) and walks its subtree from there.
-__global__ void __launch_bounds__(1024) hash_sub16_kernel(LeafArgs a, uint32_t total_w, uint32_t sub) {
+__device__ __forceinline__ void hash_sub16_kernel_body(const LeafArgs& a, uint32_t total_w, uint32_t sub) {
     const int lane16 = threadIdx.x & 15;
     const uint32_t grp = threadIdx.x >> 4, ngrp = blockDim.x >> 4;
     const CoopConsts k = coop_load_consts(lane16);
@@ -311,8 +347,11 @@ __global__ void __launch_bounds__(1024) hash_sub16_kernel(LeafArgs a, uint32_t t
         level = next; n >>= 1; mine >>= 1;
     }
 }
+__global__ void __launch_bounds__(1024) hash_sub16_kernel(LeafArgs a, uint32_t total_w, uint32_t sub) { hash_sub16_kernel_body(a, total_w, sub); }
+__global__ void __launch_bounds__(1024) hash_sub16_kernel_batch(const hash_sub16_kernel_bargs* __restrict__ zk_arr) { const hash_sub16_kernel_bargs& zk_b = zk_arr[blockIdx.z]; hash_sub16_kernel_body(zk_b.a, zk_b.total_w, zk_b.sub); }
+
 // leaf digests, one row per 16 lanes (small heights: FRI layers, tests)
-__global__ void __launch_bounds__(256) hash_rows16_kernel(LeafArgs a, uint32_t total_w) {
+__device__ __forceinline__ void hash_rows16_kernel_body(const LeafArgs& a, uint32_t total_w) {
     const uint32_t gid = blockIdx.x * blockDim.x + threadIdx.x;
     const uint64_t row = gid >> 4;
     const int lane16 = threadIdx.x & 15;
@@ -325,6 +364,9 @@ __global__ void __launch_bounds__(256) hash_rows16_kernel(LeafArgs a, uint32_t t
     }
     if (lane16 < 8) a.digests[row * 8 + lane16] = x;
 }
+__global__ void __launch_bounds__(256) hash_rows16_kernel(LeafArgs a, uint32_t total_w) { hash_rows16_kernel_body(a, total_w); }
+__global__ void __launch_bounds__(256) hash_rows16_kernel_batch(const hash_rows16_kernel_bargs* __restrict__ zk_arr) { const hash_rows16_kernel_bargs& zk_b = zk_arr[blockIdx.z]; hash_rows16_kernel_body(zk_b.a, zk_b.total_w); }
+
 
 // ------------------------------------------------------------------ transcript step on the device
 // p3-challenger DuplexChallenger<16, 8> (the host Challenger of prover.cpp, word for word): observe the 8 root words,
@@ -354,8 +396,7 @@ ZK_D void chal_observe_root_sample_ext(uint32_t& x, int& n_in, int& n_out, uint3
         if (lane == 0) beta_out[e] = sout[n_out];
     }
 }
-__global__ void __launch_bounds__(64) fri_challenge_kernel(DevChallenger* c, const uint32_t* __restrict__ root, uint32_t* __restrict__ beta_out,
-                                                           uint32_t* __restrict__ root_log) {
+__device__ __forceinline__ void fri_challenge_kernel_body(DevChallenger* c, const uint32_t* __restrict__ root, uint32_t* __restrict__ beta_out, uint32_t* __restrict__ root_log) {
     __shared__ uint32_t sin[8], sout[8];
     const int lane = threadIdx.x;                    // 64 launched, lanes 0..15 work (a DPP row)
     if (lane >= 16) return;
@@ -368,16 +409,19 @@ __global__ void __launch_bounds__(64) fri_challenge_kernel(DevChallenger* c, con
     if (lane < 8) { c->in[lane] = sin[lane]; c->out[lane] = sout[lane]; }
     if (lane == 0) { c->n_in = n_in; c->n_out = n_out; }
 }
+__global__ void __launch_bounds__(64) fri_challenge_kernel(DevChallenger* c, const uint32_t* __restrict__ root, uint32_t* __restrict__ beta_out, uint32_t* __restrict__ root_log) { fri_challenge_kernel_body(c, root, beta_out, root_log); }
+struct fri_challenge_kernel_bargs { DevChallenger* c; const uint32_t* root; uint32_t* beta_out; uint32_t* root_log; static fri_challenge_kernel_bargs make(DevChallenger* c, const uint32_t* root, uint32_t* beta_out, uint32_t* root_log) { return fri_challenge_kernel_bargs{c, root, beta_out, root_log}; } };
+__global__ void __launch_bounds__(64) fri_challenge_kernel_batch(const fri_challenge_kernel_bargs* __restrict__ zk_arr) { const fri_challenge_kernel_bargs& zk_b = zk_arr[blockIdx.z]; fri_challenge_kernel_body(zk_b.c, zk_b.root, zk_b.beta_out, zk_b.root_log); }
+
 hipError_t launch_fri_challenge(DevChallenger* chal, const uint32_t* root, uint32_t* beta_out, uint32_t* root_log, hipStream_t s) {
-    hipLaunchKernelGGL(fri_challenge_kernel, dim3(1), dim3(64), 0, s, chal, root, beta_out, root_log);
+    ZK_LAUNCH(fri_challenge_kernel, fri_challenge_kernel_batch, fri_challenge_kernel_bargs, dim3(1), dim3(64), 0, s, chal, root, beta_out, root_log);
     return hipGetLastError();
 }
 
 // ------------------------------------------------------------------ RISC Zero layout (row a11)
 // column-major [cols][rows] polynomials, Poseidon2 width 24, rate 16: one row per lane, so a
 // wave reads 64 consecutive words of every column -- the layout is coalesced as it stands.
-__global__ void __launch_bounds__(256) hash_cols24_kernel(const uint32_t* __restrict__ mat, uint32_t cols, uint64_t rows,
-                                                          uint32_t* __restrict__ digests) {
+__device__ __forceinline__ void hash_cols24_kernel_body(const uint32_t* __restrict__ mat, uint32_t cols, uint64_t rows, uint32_t* __restrict__ digests) {
     const uint64_t r = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (r >= rows) return;
     uint32_t s[24];
@@ -393,7 +437,11 @@ __global__ void __launch_bounds__(256) hash_cols24_kernel(const uint32_t* __rest
     d[0] = make_uint4(s[0], s[1], s[2], s[3]);
     d[1] = make_uint4(s[4], s[5], s[6], s[7]);
 }
-__global__ void __launch_bounds__(256) compress24_level_kernel(const uint32_t* __restrict__ children, uint32_t* __restrict__ parents, uint64_t count) {
+__global__ void __launch_bounds__(256) hash_cols24_kernel(const uint32_t* __restrict__ mat, uint32_t cols, uint64_t rows, uint32_t* __restrict__ digests) { hash_cols24_kernel_body(mat, cols, rows, digests); }
+struct hash_cols24_kernel_bargs { const uint32_t* mat; uint32_t cols; uint64_t rows; uint32_t* digests; static hash_cols24_kernel_bargs make(const uint32_t* mat, uint32_t cols, uint64_t rows, uint32_t* digests) { return hash_cols24_kernel_bargs{mat, cols, rows, digests}; } };
+__global__ void __launch_bounds__(256) hash_cols24_kernel_batch(const hash_cols24_kernel_bargs* __restrict__ zk_arr) { const hash_cols24_kernel_bargs& zk_b = zk_arr[blockIdx.z]; hash_cols24_kernel_body(zk_b.mat, zk_b.cols, zk_b.rows, zk_b.digests); }
+
+__device__ __forceinline__ void compress24_level_kernel_body(const uint32_t* __restrict__ children, uint32_t* __restrict__ parents, uint64_t count) {
     const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= count) return;
     const uint4* cp = reinterpret_cast<const uint4*>(children + 16 * i);
@@ -405,8 +453,12 @@ __global__ void __launch_bounds__(256) compress24_level_kernel(const uint32_t* _
     d[0] = make_uint4(s[0], s[1], s[2], s[3]);
     d[1] = make_uint4(s[4], s[5], s[6], s[7]);
 }
+__global__ void __launch_bounds__(256) compress24_level_kernel(const uint32_t* __restrict__ children, uint32_t* __restrict__ parents, uint64_t count) { compress24_level_kernel_body(children, parents, count); }
+struct compress24_level_kernel_bargs { const uint32_t* children; uint32_t* parents; uint64_t count; static compress24_level_kernel_bargs make(const uint32_t* children, uint32_t* parents, uint64_t count) { return compress24_level_kernel_bargs{children, parents, count}; } };
+__global__ void __launch_bounds__(256) compress24_level_kernel_batch(const compress24_level_kernel_bargs* __restrict__ zk_arr) { const compress24_level_kernel_bargs& zk_b = zk_arr[blockIdx.z]; compress24_level_kernel_body(zk_b.children, zk_b.parents, zk_b.count); }
+
 // all levels from `count` (<= 2048) nodes down to the root in one workgroup: the small levels are pure launch latency
-__global__ void __launch_bounds__(1024) compress24_top_kernel(uint32_t* tree, uint32_t count) {
+__device__ __forceinline__ void compress24_top_kernel_body(uint32_t* tree, uint32_t count) {
     uint32_t* level = tree;
     for (uint32_t n = count; n > 1; n >>= 1) {
         uint32_t* next = level + 8 * (size_t)n;
@@ -425,6 +477,10 @@ __global__ void __launch_bounds__(1024) compress24_top_kernel(uint32_t* tree, ui
         level = next;
     }
 }
+__global__ void __launch_bounds__(1024) compress24_top_kernel(uint32_t* tree, uint32_t count) { compress24_top_kernel_body(tree, count); }
+struct compress24_top_kernel_bargs { uint32_t* tree; uint32_t count; static compress24_top_kernel_bargs make(uint32_t* tree, uint32_t count) { return compress24_top_kernel_bargs{tree, count}; } };
+__global__ void __launch_bounds__(1024) compress24_top_kernel_batch(const compress24_top_kernel_bargs* __restrict__ zk_arr) { const compress24_top_kernel_bargs& zk_b = zk_arr[blockIdx.z]; compress24_top_kernel_body(zk_b.tree, zk_b.count); }
+
 // levels above the leaf digests of a width-24 tree: wide levels one launch each, the top 2048 nodes in one
 static hipError_t compress24_levels(uint32_t* tree, uint64_t rows, hipStream_t s) {
     hipError_t e = hipSuccess;
@@ -432,20 +488,20 @@ static hipError_t compress24_levels(uint32_t* tree, uint64_t rows, hipStream_t s
     uint64_t cnt = rows;
     while (cnt > 2048 && e == hipSuccess) {
         uint32_t* next = level + 8 * cnt;
-        hipLaunchKernelGGL(compress24_level_kernel, dim3((unsigned)((cnt / 2 + 255) / 256)), dim3(256), 0, s, level, next, cnt / 2);
+        ZK_LAUNCH(compress24_level_kernel, compress24_level_kernel_batch, compress24_level_kernel_bargs, dim3((unsigned)((cnt / 2 + 255) / 256)), dim3(256), 0, s, level, next, cnt / 2);
         e = hipGetLastError();
         level = next; cnt >>= 1;
     }
     if (e == hipSuccess && cnt > 1) {
         const unsigned threads = cnt / 2 < 64 ? 64 : (cnt / 2 > 1024 ? 1024 : (unsigned)(cnt / 2));
-        hipLaunchKernelGGL(compress24_top_kernel, dim3(1), dim3(threads), 0, s, level, (uint32_t)cnt);
+        ZK_LAUNCH(compress24_top_kernel, compress24_top_kernel_batch, compress24_top_kernel_bargs, dim3(1), dim3(threads), 0, s, level, (uint32_t)cnt);
         e = hipGetLastError();
     }
     return e;
 }
 hipError_t launch_merkle_p24_colmajor(const uint32_t* mat, uint32_t cols, int log_rows, uint32_t* tree, hipStream_t s) {
     const uint64_t rows = (uint64_t)1 << log_rows;
-    hipLaunchKernelGGL(hash_cols24_kernel, dim3((unsigned)((rows + 255) / 256)), dim3(256), 0, s, mat, cols, rows, tree);
+    ZK_LAUNCH(hash_cols24_kernel, hash_cols24_kernel_batch, hash_cols24_kernel_bargs, dim3((unsigned)((rows + 255) / 256)), dim3(256), 0, s, mat, cols, rows, tree);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return e;
     return compress24_levels(tree, rows, s);
@@ -453,8 +509,7 @@ hipError_t launch_merkle_p24_colmajor(const uint32_t* mat, uint32_t cols, int lo
 
 // row-major matrix (rows x ld words, width % 4 == 0, 16-byte aligned rows), same hash: the leaves of the
 // RISC-Zero-shaped prover mode, whose committed matrices stay row-major like everything else in the prover
-__global__ void __launch_bounds__(256) hash_rows24_kernel(const uint32_t* __restrict__ mat, uint64_t ld, uint32_t width, uint64_t rows,
-                                                          uint32_t* __restrict__ digests) {
+__device__ __forceinline__ void hash_rows24_kernel_body(const uint32_t* __restrict__ mat, uint64_t ld, uint32_t width, uint64_t rows, uint32_t* __restrict__ digests) {
     const uint64_t r = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (r >= rows) return;
     const uint4* row = reinterpret_cast<const uint4*>(mat + r * ld);
@@ -472,15 +527,19 @@ __global__ void __launch_bounds__(256) hash_rows24_kernel(const uint32_t* __rest
     d[0] = make_uint4(s[0], s[1], s[2], s[3]);
     d[1] = make_uint4(s[4], s[5], s[6], s[7]);
 }
+__global__ void __launch_bounds__(256) hash_rows24_kernel(const uint32_t* __restrict__ mat, uint64_t ld, uint32_t width, uint64_t rows, uint32_t* __restrict__ digests) { hash_rows24_kernel_body(mat, ld, width, rows, digests); }
+struct hash_rows24_kernel_bargs { const uint32_t* mat; uint64_t ld; uint32_t width; uint64_t rows; uint32_t* digests; static hash_rows24_kernel_bargs make(const uint32_t* mat, uint64_t ld, uint32_t width, uint64_t rows, uint32_t* digests) { return hash_rows24_kernel_bargs{mat, ld, width, rows, digests}; } };
+__global__ void __launch_bounds__(256) hash_rows24_kernel_batch(const hash_rows24_kernel_bargs* __restrict__ zk_arr) { const hash_rows24_kernel_bargs& zk_b = zk_arr[blockIdx.z]; hash_rows24_kernel_body(zk_b.mat, zk_b.ld, zk_b.width, zk_b.rows, zk_b.digests); }
+
 hipError_t launch_merkle_p24_rowmajor(const uint32_t* mat, uint64_t ld, uint32_t width, int log_rows, uint32_t* tree, hipStream_t s) {
     const uint64_t rows = (uint64_t)1 << log_rows;
-    hipLaunchKernelGGL(hash_rows24_kernel, dim3((unsigned)((rows + 255) / 256)), dim3(256), 0, s, mat, ld, width, rows, tree);
+    ZK_LAUNCH(hash_rows24_kernel, hash_rows24_kernel_batch, hash_rows24_kernel_bargs, dim3((unsigned)((rows + 255) / 256)), dim3(256), 0, s, mat, ld, width, rows, tree);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return e;
     return compress24_levels(tree, rows, s);
 }
 
-__global__ void __launch_bounds__(256) permute_states_kernel(uint32_t* states, uint64_t count) {
+__device__ __forceinline__ void permute_states_kernel_body(uint32_t* states, uint64_t count) {
     const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= count) return;
     uint32_t s[16];
@@ -490,9 +549,13 @@ __global__ void __launch_bounds__(256) permute_states_kernel(uint32_t* states, u
 #pragma unroll
     for (int k = 0; k < 16; k++) states[16 * i + k] = s[k];
 }
+__global__ void __launch_bounds__(256) permute_states_kernel(uint32_t* states, uint64_t count) { permute_states_kernel_body(states, count); }
+struct permute_states_kernel_bargs { uint32_t* states; uint64_t count; static permute_states_kernel_bargs make(uint32_t* states, uint64_t count) { return permute_states_kernel_bargs{states, count}; } };
+__global__ void __launch_bounds__(256) permute_states_kernel_batch(const permute_states_kernel_bargs* __restrict__ zk_arr) { const permute_states_kernel_bargs& zk_b = zk_arr[blockIdx.z]; permute_states_kernel_body(zk_b.states, zk_b.count); }
+
 hipError_t launch_permute_states(uint32_t* states, uint64_t count, hipStream_t s) {
     if (count == 0) return hipSuccess;
-    hipLaunchKernelGGL(permute_states_kernel, dim3((unsigned)((count + 255) / 256)), dim3(256), 0, s, states, count);
+    ZK_LAUNCH(permute_states_kernel, permute_states_kernel_batch, permute_states_kernel_bargs, dim3((unsigned)((count + 255) / 256)), dim3(256), 0, s, states, count);
     return hipGetLastError();
 }
 
@@ -534,7 +597,7 @@ __device__ void p2chip_fill_row(uint32_t* t, const uint32_t in[16], uint32_t bit
     t[SPG] = spg ? MONTY_R1 : 0u; t[SS] = ss ? MONTY_R1 : 0u;
     for (uint32_t c = SS + 1; c < WIDTH; c++) t[c] = 0u;
 }
-__global__ void __launch_bounds__(64) p2chip_merkle_kernel(p2chip::MerkleTraceArgs a) {
+__device__ __forceinline__ void p2chip_merkle_kernel_body(const p2chip::MerkleTraceArgs& a) {
     const uint64_t p = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const uint32_t sponge_rows = a.row_width / 8;
     const uint64_t per_path = (uint64_t)sponge_rows + a.depth, path_rows = a.n_paths * per_path;
@@ -566,9 +629,13 @@ __global__ void __launch_bounds__(64) p2chip_merkle_kernel(p2chip::MerkleTraceAr
     uint32_t zero[16] = {0}, out[16];
     p2chip_fill_row(a.trace + row * a.ld, zero, 0u, 0u, 0u, (uint32_t)a.n_paths, 0u, 0u, out);
 }
+__global__ void __launch_bounds__(64) p2chip_merkle_kernel(p2chip::MerkleTraceArgs a) { p2chip_merkle_kernel_body(a); }
+struct p2chip_merkle_kernel_bargs { p2chip::MerkleTraceArgs a; static p2chip_merkle_kernel_bargs make(p2chip::MerkleTraceArgs a) { return p2chip_merkle_kernel_bargs{a}; } };
+__global__ void __launch_bounds__(64) p2chip_merkle_kernel_batch(const p2chip_merkle_kernel_bargs* __restrict__ zk_arr) { const p2chip_merkle_kernel_bargs& zk_b = zk_arr[blockIdx.z]; p2chip_merkle_kernel_body(zk_b.a); }
+
 // the FRI-layers variant (p2chip.h): paths of different depths, one leaf row + depth compression rows each, with the layer number,
 // the index walk and the receive multiplicity in the three spare columns
-__global__ void __launch_bounds__(64) p2chip_layer_paths_kernel(p2chip::LayerPathsArgs a) {
+__device__ __forceinline__ void p2chip_layer_paths_kernel_body(const p2chip::LayerPathsArgs& a) {
     using namespace p2chip;
     const uint64_t p = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (p < a.n_paths) {
@@ -597,14 +664,18 @@ __global__ void __launch_bounds__(64) p2chip_layer_paths_kernel(p2chip::LayerPat
     p2chip_fill_row(t, zero, 0u, 0u, 0u, (uint32_t)a.n_paths, 0u, 0u, out);
     t[LNP] = 0u; t[KP] = 0u; t[M] = 0u;
 }
+__global__ void __launch_bounds__(64) p2chip_layer_paths_kernel(p2chip::LayerPathsArgs a) { p2chip_layer_paths_kernel_body(a); }
+struct p2chip_layer_paths_kernel_bargs { p2chip::LayerPathsArgs a; static p2chip_layer_paths_kernel_bargs make(p2chip::LayerPathsArgs a) { return p2chip_layer_paths_kernel_bargs{a}; } };
+__global__ void __launch_bounds__(64) p2chip_layer_paths_kernel_batch(const p2chip_layer_paths_kernel_bargs* __restrict__ zk_arr) { const p2chip_layer_paths_kernel_bargs& zk_b = zk_arr[blockIdx.z]; p2chip_layer_paths_kernel_body(zk_b.a); }
+
 hipError_t launch_p2chip_layer_paths(const p2chip::LayerPathsArgs& a, hipStream_t s) {
     const uint64_t lanes = a.n_paths + (a.rows - a.used_rows);
-    hipLaunchKernelGGL(p2chip_layer_paths_kernel, dim3((unsigned)((lanes + 63) / 64)), dim3(64), 0, s, a);
+    ZK_LAUNCH(p2chip_layer_paths_kernel, p2chip_layer_paths_kernel_batch, p2chip_layer_paths_kernel_bargs, dim3((unsigned)((lanes + 63) / 64)), dim3(64), 0, s, a);
     return hipGetLastError();
 }
 hipError_t launch_p2chip_merkle(const p2chip::MerkleTraceArgs& a, hipStream_t s) {
     const uint64_t lanes = a.n_paths + (a.rows - a.n_paths * ((uint64_t)a.row_width / 8 + a.depth));
-    hipLaunchKernelGGL(p2chip_merkle_kernel, dim3((unsigned)((lanes + 63) / 64)), dim3(64), 0, s, a);
+    ZK_LAUNCH(p2chip_merkle_kernel, p2chip_merkle_kernel_batch, p2chip_merkle_kernel_bargs, dim3((unsigned)((lanes + 63) / 64)), dim3(64), 0, s, a);
     return hipGetLastError();
 }
 

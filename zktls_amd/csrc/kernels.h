@@ -348,4 +348,7 @@ struct GatherDesc {
 };
 hipError_t launch_gather(const GatherDesc* descs, uint32_t ndesc, uint32_t* dst, hipStream_t s);
 
+// plain copy / fill as kernels (util.hip): what the members of a lock-step batch use instead of hipMemcpyAsync / hipMemsetAsync
+hipError_t launch_copy_bytes(void* dst, const void* src, size_t bytes, hipStream_t s);
+hipError_t launch_fill_bytes(void* dst, int byte, size_t bytes, hipStream_t s);
 }  // namespace zk

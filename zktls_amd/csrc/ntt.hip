@@ -25,6 +25,7 @@
 
 #include "babybear.cuh"
 #include "kernels.h"
+#include "batch.h"
 #include "ntt_bfly.cuh"
 
 namespace zk {
@@ -40,7 +41,7 @@ constexpr int MAX_DEVICES = 64;     // device ordinals a process can hold contex
 // exchange and of phase B then folds into an instruction immediate instead of a VGPR.
 // NT != 0: non-temporal cache policy on the tile's loads and stores (chosen per launch, see launch_ntt_pass).
 template <int LOG_C, bool INV, int CPT, int BFIX = -1, int NT = 0>
-__global__ void __launch_bounds__(32 << LOG_C, 4) ntt_pass_kernel(NttPassArgs a) {
+__device__ __forceinline__ void ntt_pass_kernel_body(const NttPassArgs& a) {
     // NT = 1 and NT = 2 are the same code: two names, so that a profile tells the passes apart.  NT = 3 / 4 are again the same
     // code as 1 / 2: the names under which zkhip_ntt_pass (the roofline hook) launches, so that a rocprofv3 summary of bench.py
     // lists the isolated, event-timed launches apart from the in-proof ones (which overlap with the other shards in flight and
@@ -270,6 +271,12 @@ __global__ void __launch_bounds__(32 << LOG_C, 4) ntt_pass_kernel(NttPassArgs a)
         }
     }
 }
+template <int LOG_C, bool INV, int CPT, int BFIX = -1, int NT = 0>
+__global__ void __launch_bounds__(32 << LOG_C, 4) ntt_pass_kernel(NttPassArgs a) { ntt_pass_kernel_body<LOG_C, INV, CPT, BFIX, NT>(a); }
+struct ntt_pass_kernel_bargs { NttPassArgs a; static ntt_pass_kernel_bargs make(NttPassArgs a) { return ntt_pass_kernel_bargs{a}; } };
+template <int LOG_C, bool INV, int CPT, int BFIX = -1, int NT = 0>
+__global__ void __launch_bounds__(32 << LOG_C, 4) ntt_pass_kernel_batch(const ntt_pass_kernel_bargs* __restrict__ zk_arr) { const ntt_pass_kernel_bargs& zk_b = zk_arr[blockIdx.z]; ntt_pass_kernel_body<LOG_C, INV, CPT, BFIX, NT>(zk_b.a); }
+
 
 
 #ifdef ZKHIP_AB_HOOKS
@@ -465,9 +472,11 @@ static hipError_t launch_ntt_k(const NttPassArgs& a, hipStream_t s) {
         hipError_t e = hipFuncSetAttribute((const void*)ntt_pass_kernel<LOG_C, INV, CPT, BFIX, NT>,
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
+        e = hipFuncSetAttribute((const void*)ntt_pass_kernel_batch<LOG_C, INV, CPT, BFIX, NT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
         configured[dev].store(lds, std::memory_order_release);
     }
-    hipLaunchKernelGGL((ntt_pass_kernel<LOG_C, INV, CPT, BFIX, NT>), grid, block, lds, s, a);
+    ZK_LAUNCH((ntt_pass_kernel<LOG_C, INV, CPT, BFIX, NT>), (ntt_pass_kernel_batch<LOG_C, INV, CPT, BFIX, NT>), ntt_pass_kernel_bargs, grid, block, lds, s, a);
     return hipGetLastError();
 }
 
@@ -723,7 +732,7 @@ hipError_t launch_post2d_table(uint32_t* out, uint32_t w, uint32_t shift, uint32
 // Streaming: a thread owns VEC adjacent columns of one group of R rows; the twiddles of a group are row-uniform.  HBM-bound,
 // 8 B/element; arithmetic is R - 1 (forward) or R (inverse) Montgomery products per element group.
 template <int LOG_R, int VEC>
-__global__ void __launch_bounds__(256) ntt_combine_kernel(CombineArgs a) {
+__device__ __forceinline__ void ntt_combine_kernel_body(const CombineArgs& a) {
     constexpr int R = 1 << LOG_R;
     const uint32_t cv = (a.ncols + VEC - 1) / VEC;                    // column vectors per row
     const uint64_t idx = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -772,6 +781,12 @@ __global__ void __launch_bounds__(256) ntt_combine_kernel(CombineArgs a) {
         else row[0] = y[e][0];
     }
 }
+template <int LOG_R, int VEC>
+__global__ void __launch_bounds__(256) ntt_combine_kernel(CombineArgs a) { ntt_combine_kernel_body<LOG_R, VEC>(a); }
+struct ntt_combine_kernel_bargs { CombineArgs a; static ntt_combine_kernel_bargs make(CombineArgs a) { return ntt_combine_kernel_bargs{a}; } };
+template <int LOG_R, int VEC>
+__global__ void __launch_bounds__(256) ntt_combine_kernel_batch(const ntt_combine_kernel_bargs* __restrict__ zk_arr) { const ntt_combine_kernel_bargs& zk_b = zk_arr[blockIdx.z]; ntt_combine_kernel_body<LOG_R, VEC>(zk_b.a); }
+
 hipError_t launch_ntt_combine(const CombineArgs& a, hipStream_t s) {
     if (a.log_r != 1 && a.log_r != 2) return hipErrorInvalidValue;
     if (a.groups == 0 || a.ncols == 0) return hipSuccess;
@@ -780,11 +795,11 @@ hipError_t launch_ntt_combine(const CombineArgs& a, hipStream_t s) {
     const uint64_t threads = a.groups * (vec ? a.ncols / 4 : a.ncols);
     const dim3 grid((unsigned)((threads + 255) / 256)), block(256);
     if (a.log_r == 1) {
-        if (vec) hipLaunchKernelGGL((ntt_combine_kernel<1, 4>), grid, block, 0, s, a);
-        else hipLaunchKernelGGL((ntt_combine_kernel<1, 1>), grid, block, 0, s, a);
+        if (vec) ZK_LAUNCH((ntt_combine_kernel<1, 4>), (ntt_combine_kernel_batch<1, 4>), ntt_combine_kernel_bargs, grid, block, 0, s, a);
+        else ZK_LAUNCH((ntt_combine_kernel<1, 1>), (ntt_combine_kernel_batch<1, 1>), ntt_combine_kernel_bargs, grid, block, 0, s, a);
     } else {
-        if (vec) hipLaunchKernelGGL((ntt_combine_kernel<2, 4>), grid, block, 0, s, a);
-        else hipLaunchKernelGGL((ntt_combine_kernel<2, 1>), grid, block, 0, s, a);
+        if (vec) ZK_LAUNCH((ntt_combine_kernel<2, 4>), (ntt_combine_kernel_batch<2, 4>), ntt_combine_kernel_bargs, grid, block, 0, s, a);
+        else ZK_LAUNCH((ntt_combine_kernel<2, 1>), (ntt_combine_kernel_batch<2, 1>), ntt_combine_kernel_bargs, grid, block, 0, s, a);
     }
     return hipGetLastError();
 }

@@ -17,6 +17,7 @@
 #include <vector>
 
 #include "context.h"
+#include "batch.h"
 #include "poseidon2.cuh"
 #include "air.h"
 #include "p2_x16.h"
@@ -155,16 +156,8 @@ static int ensure_fold_table(zkhip_ctx* ctx, int log_h) {
     return ensure_domain(ctx, log_h - 1 < 5 ? 5 : log_h - 1, 1);
 }
 
-static int d2h(zkhip_ctx* ctx, void* dst, const void* src, size_t bytes) {
-    ZK_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, ctx->stream));
-    ZK_HIP(hipStreamSynchronize(ctx->stream));
-    return ZKHIP_OK;
-}
-static int h2d(zkhip_ctx* ctx, void* dst, const void* src, size_t bytes) {
-    ZK_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, ctx->stream));
-    ZK_HIP(hipStreamSynchronize(ctx->stream));   // source is pageable host memory that may go out of scope
-    return ZKHIP_OK;
-}
+static int d2h(zkhip_ctx* ctx, void* dst, const void* src, size_t bytes) { return dev_d2h(ctx, dst, src, bytes); }
+static int h2d(zkhip_ctx* ctx, void* dst, const void* src, size_t bytes) { return dev_h2d(ctx, dst, src, bytes); }
 
 struct LogupIn {
     Ext cumsum = ext_zero();              // last-row constraint S = cumsum
@@ -349,7 +342,7 @@ static int fri_commit_phase(zkhip_ctx* ctx, Challenger& ch, const Shape& sh, int
 #else
     constexpr bool use_graph = true;
 #endif
-    if (d_chal && use_graph) {
+    if (d_chal && use_graph && !t_batcher) {                   // lock-step members launch one by one: their launches merge across the batch
         std::vector<uint64_t> key = {(uint64_t)H, (uint64_t)K, (uint64_t)RL, (uint64_t)sh.hw, (uint64_t)m, (uint64_t)(uintptr_t)layers,
                                      (uint64_t)(uintptr_t)ltrees, (uint64_t)(uintptr_t)fold_tmp, (uint64_t)(uintptr_t)d_chal,
                                      (uint64_t)(uintptr_t)ctx->dom_itw};
@@ -398,15 +391,19 @@ static int grind_witness(zkhip_ctx* ctx, Challenger& ch, int pow_bits, uint32_t*
     ga.mask = (1u << pow_bits) - 1u;
     void* v_res;
     ZK_TRY(ctx_reserve(ctx, S_GATHER_OUT, 4, &v_res));
-    ZK_HIP(hipMemsetAsync(v_res, 0xFF, 4, ctx->stream));
+    ZK_TRY(dev_memset(ctx, v_res, 0xFF, 4));
     // candidates are scanned in order, so the first batch that contains a hit contains the smallest witness; a batch of 4 * 2^bits
     // candidates has one with probability 1 - e^-4 = 98 % (2^20 candidates = 0.12 ms of permutations would mostly be wasted)
     uint64_t want = (uint64_t)4 << pow_bits;
     if (want < (1u << 14)) want = 1u << 14;
     const uint32_t batch = (uint32_t)(want > (1u << 20) ? (1u << 20) : want);
-    for (uint64_t base = 0; base < P && witness == 0xFFFFFFFFu; base += batch) {
+    // (lock-step batches, batch.h: members loop until EVERY member has its witness -- later launches cannot lower a minimum found
+    // among smaller candidates -- so that the launch sequences stay identical)
+    for (uint64_t base = 0; base < P; base += batch) {
         ZK_HIP(launch_grind(ga, (uint32_t)base, batch, (uint32_t*)v_res, ctx->stream));
         ZK_TRY(d2h(ctx, &witness, v_res, 4));
+        const bool found = witness != 0xFFFFFFFFu;
+        if (t_batcher ? t_batcher->all(found) : found) break;
     }
     if (witness == 0xFFFFFFFFu) return fail(ZKHIP_ERR_INTERNAL, "prove: no proof-of-work witness found");
     ch.observe_canonical(witness);
@@ -778,10 +775,10 @@ static int prove_shard_impl(zkhip_ctx* ctx, const uint32_t* d_trace, size_t ld, 
     uint32_t* xw = dinv + 8 * m;       // x_q / (x_q - z_k) for the N rows the openings sum over
     ZK_HIP(launch_inv_denominators(ctx->dom_xs, m, zpts[0], zpts[1], 2, dinv, xw, n, st));
     ZK_TRY(run_open(ctx, tlde, width, log_n, width, zpts, 2, xw, d_open));
-    ZK_HIP(hipStreamSynchronize(st));   // S_PARTIAL is reused by the next call
+    ZK_TRY(dev_sync(ctx));   // S_PARTIAL is reused by the next call
     if (LQ) {
         ZK_TRY(run_open(ctx, plde, wp, log_n, (uint32_t)wp, zpts, 2, xw, d_open + 8 * (size_t)width));
-        ZK_HIP(hipStreamSynchronize(st));
+        ZK_TRY(dev_sync(ctx));
     }
     ZK_TRY(run_open(ctx, qlde, QW, log_n, (uint32_t)QW, zpts, 1, xw, d_open + 8 * (size_t)width + 8 * wp));
     std::vector<uint32_t> opened((2 * (size_t)width + 2 * wp + QW) * 4);
@@ -1100,6 +1097,127 @@ int deal_jobs(const int* devices, int n_devices, int n_jobs, int in_flight, cons
     if (first_rc != ZKHIP_OK) { set_error(first_msg); return first_rc; }
     for (int i = 0; i < n_jobs; i++)                         // jobs nobody could take: every worker of that device failed to get a context
         if (!ran[(size_t)i]) { set_error(ctx_msg.empty() ? "prove_shards: job not run" : ctx_msg); return ctx_rc != ZKHIP_OK ? ctx_rc : ZKHIP_ERR_INVALID; }
+    return ZKHIP_OK;
+}
+// Lock-step variant for SMALL proofs (batch.h): the jobs of a device are grouped by `shape[i]` (jobs of one shape run the same launch
+// sequence), groups are cut into batches of up to `max_batch`, and a batch is proven by that many host threads on pooled contexts that
+// share ONE stream and merge their kernel launches through a LaunchBatcher.  `lanes` batches are in flight per device, so that the
+// host-side work around one batch (padding, transcripts, verification) overlaps the other's kernels.  Same contract as deal_jobs.
+int deal_jobs_lockstep(const int* devices, int n_devices, int n_jobs, const int* shape, int max_batch, int lanes,
+                       const std::function<int(zkhip_ctx*, int)>& run, std::vector<char>& ran) {
+    ran.assign((size_t)n_jobs, 0);
+    if (n_jobs == 0) return ZKHIP_OK;
+    if (max_batch < 1) max_batch = 1;
+    if (max_batch > LaunchBatcher::MAX_MEMBERS) max_batch = LaunchBatcher::MAX_MEMBERS;
+    if (lanes < 1) lanes = 1;
+    std::mutex mu;
+    int first_rc = ZKHIP_OK, first_job = n_jobs, ctx_rc = ZKHIP_OK;
+    std::string first_msg, ctx_msg;
+    auto note = [&](int job, int rc, const std::string& msg) {
+        std::lock_guard<std::mutex> lk(mu);
+        if (job < first_job) { first_job = job; first_rc = rc; first_msg = msg; }
+    };
+    // batches per device, in job order
+    std::vector<std::vector<std::vector<int>>> batches((size_t)n_devices);
+    for (int d = 0; d < n_devices; d++) {
+        std::vector<std::pair<int, std::vector<int>>> groups;
+        for (int i = d; i < n_jobs; i += n_devices) {
+            size_t g = 0;
+            while (g < groups.size() && groups[g].first != shape[i]) g++;
+            if (g == groups.size()) groups.emplace_back(shape[i], std::vector<int>());
+            groups[g].second.push_back(i);
+        }
+        for (auto& g : groups) {
+            // equal cuts: sixty-four jobs on two lanes are two batches of thirty-two, not one of max_batch and a remainder
+            const size_t n = g.second.size();
+            size_t cuts = (n + (size_t)max_batch - 1) / (size_t)max_batch;
+            if (cuts < (size_t)lanes && n >= 2 * (size_t)lanes) cuts = (size_t)lanes;
+            for (size_t c = 0; c < cuts; c++) {
+                const size_t lo = n * c / cuts, hi = n * (c + 1) / cuts;
+                if (hi > lo) batches[(size_t)d].emplace_back(g.second.begin() + (long)lo, g.second.begin() + (long)hi);
+            }
+        }
+    }
+    std::vector<std::atomic<int>> next((size_t)n_devices);
+    for (auto& a : next) a.store(0);
+    auto lane = [&](int slot) {
+        const int device = devices[slot];
+        for (;;) {
+            const int k = next[(size_t)slot].fetch_add(1);
+            if (k >= (int)batches[(size_t)slot].size()) break;
+            const std::vector<int>& jobs = batches[(size_t)slot][(size_t)k];
+            const int B = (int)jobs.size();
+            std::vector<zkhip_ctx*> ctxs;
+            for (int b = 0; b < B; b++) {
+                zkhip_ctx* c = pool_take(device);
+                if (!c && zkhip_ctx_create(device, nullptr, &c) != ZKHIP_OK) {
+                    std::lock_guard<std::mutex> lk(mu);
+                    ctx_rc = ZKHIP_ERR_HIP; ctx_msg = zkhip_last_error();
+                    break;
+                }
+                ctxs.push_back(c);
+            }
+            if (ctxs.empty()) continue;                          // no context at all: the jobs stay unrun
+            // fewer contexts than jobs (memory): the batch runs in rounds of ctxs.size()
+            const int W = (int)ctxs.size();
+            std::vector<hipStream_t> own((size_t)W);
+            for (int b = 0; b < W; b++) own[(size_t)b] = ctxs[(size_t)b]->stream;
+            const hipStream_t shared = own[0];
+            std::vector<char> healthy((size_t)W, 1);
+            for (int at = 0; at < B; at += W) {
+                const int n = B - at < W ? B - at : W;
+                if (n == 1) {                                    // nothing to merge with
+                    const int i = jobs[(size_t)at];
+                    const int rc = run(ctxs[0], i);
+                    ran[(size_t)i] = 1;
+                    if (rc != ZKHIP_OK) { note(i, rc, zkhip_last_error()); healthy[0] = 0; }
+                    continue;
+                }
+                for (int b = 0; b < n; b++) ctxs[(size_t)b]->stream = shared;
+                LaunchBatcher lb(n, shared);
+                std::vector<std::thread> th;
+                std::vector<char> started((size_t)n, 0);
+                auto member = [&](int b, bool joined) {
+                    BatchMember m(joined && lb.ok() ? &lb : nullptr);
+                    const int i = jobs[(size_t)(at + b)];
+                    const int rc = run(ctxs[(size_t)b], i);
+                    ran[(size_t)i] = 1;
+                    if (rc != ZKHIP_OK) { note(i, rc, zkhip_last_error()); healthy[(size_t)b] = 0; }
+                };
+                for (int b = 0; b < n; b++) {
+                    try { th.emplace_back(member, b, true); started[(size_t)b] = 1; }
+                    catch (...) { if (lb.ok()) lb.leave(); }     // no thread for this member: the others must not wait for it
+                }
+                for (auto& t : th) t.join();
+                for (int b = 0; b < n; b++) if (!started[(size_t)b]) member(b, false);       // ... and its job runs here, on its own
+                if (hipStreamSynchronize(shared) != hipSuccess) { (void)hipGetLastError(); for (int b = 0; b < n; b++) healthy[(size_t)b] = 0; }
+                if (lb.failed()) {                                // a merged launch failed: every proof of the batch is suspect
+                    for (int b = 0; b < n; b++) {
+                        healthy[(size_t)b] = 0;
+                        note(jobs[(size_t)(at + b)], ZKHIP_ERR_HIP, "lock-step batch: a merged kernel launch failed");
+                    }
+                }
+                for (int b = 0; b < n; b++) ctxs[(size_t)b]->stream = own[(size_t)b];
+            }
+            for (int b = 0; b < W; b++) {
+                if (healthy[(size_t)b] && zkhip_ctx_sync(ctxs[(size_t)b]) == ZKHIP_OK) pool_give(device, ctxs[(size_t)b]);
+                else zkhip_ctx_destroy(ctxs[(size_t)b]);
+            }
+        }
+    };
+    std::vector<std::thread> pool;
+    for (int slot = 0; slot < n_devices; slot++) {
+        const int nb = (int)batches[(size_t)slot].size();
+        const int workers = nb < lanes ? nb : lanes;
+        for (int t = 0; t < workers; t++) {
+            try { pool.emplace_back(lane, slot); }
+            catch (...) { if (t == 0) lane(slot); break; }
+        }
+    }
+    for (auto& t : pool) t.join();
+    if (first_rc != ZKHIP_OK) { set_error(first_msg); return first_rc; }
+    for (int i = 0; i < n_jobs; i++)
+        if (!ran[(size_t)i]) { set_error(ctx_msg.empty() ? "prove (lock-step): job not run" : ctx_msg); return ctx_rc != ZKHIP_OK ? ctx_rc : ZKHIP_ERR_INVALID; }
     return ZKHIP_OK;
 }
 // the device list of a batch entry: NULL (with n_devices == 0) = every visible device; ordinals non-negative and distinct.

@@ -16,6 +16,7 @@
 //   OUT 8 limb pairs (variables after the round, + chaining value in round 63, mod 2^32) | X0 X13 32 bits (W_t, W_{t+13})
 //   XL 14 limb pairs (W_{t+j}, j = 1..12, 14, 15) | SG0 SG1 32 bits (sigma0(W_t), sigma1(W_{t+13})) | CY 28 carry bits
 //   ACT (block belongs to the message) | SKIP = s_63 (1 - ACT) | 2 unused
+#include <algorithm>
 #include <atomic>
 #include <mutex>
 #include <thread>
@@ -25,6 +26,7 @@
 
 #include "air.h"
 #include "context.h"
+#include "batch.h"
 
 namespace zk {
 namespace sha {
@@ -275,7 +277,7 @@ __device__ __forceinline__ void put_sum(uint32_t* row, uint32_t out_col, uint32_
     for (uint32_t q = 0; q < ncy; q++) { row[cy + q] = mbit(lo >> 16, q); row[cy + ncy + q] = mbit(hi >> 16, q); }
 }
 
-__global__ void __launch_bounds__(64) sha256_trace_kernel(TraceArgs a) {
+__device__ __forceinline__ void sha256_trace_kernel_body(const TraceArgs& a) {
     __shared__ uint32_t w[80];
     __shared__ uint32_t st[64][8];
     const uint32_t blk = blockIdx.x, r = threadIdx.x;
@@ -334,12 +336,16 @@ __global__ void __launch_bounds__(64) sha256_trace_kernel(TraceArgs a) {
     row[SKIP + 1] = 0u;
     row[SKIP + 2] = 0u;
 }
+__global__ void __launch_bounds__(64) sha256_trace_kernel(TraceArgs a) { sha256_trace_kernel_body(a); }
+struct sha256_trace_kernel_bargs { TraceArgs a; static sha256_trace_kernel_bargs make(TraceArgs a) { return sha256_trace_kernel_bargs{a}; } };
+__global__ void __launch_bounds__(64) sha256_trace_kernel_batch(const sha256_trace_kernel_bargs* __restrict__ zk_arr) { const sha256_trace_kernel_bargs& zk_b = zk_arr[blockIdx.z]; sha256_trace_kernel_body(zk_b.a); }
+
 
 
 // ---- multiplicities of a range table on the device: count how often every value of [0, 2^log_table) appears in the listed columns
 // of a trace (Montgomery words), then write the table's two columns: value v = row index, multiplicity m = the count
 struct HistArgs { const uint32_t* trace; uint64_t ld; uint64_t rows; uint32_t cols[16]; uint32_t n_cols; uint32_t log_table; uint32_t* counts; uint32_t* bad; };
-__global__ void __launch_bounds__(256) lookup_hist_kernel(HistArgs a) {
+__device__ __forceinline__ void lookup_hist_kernel_body(const HistArgs& a) {
     const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= a.rows) return;
     const uint32_t* row = a.trace + i * a.ld;
@@ -349,12 +355,20 @@ __global__ void __launch_bounds__(256) lookup_hist_kernel(HistArgs a) {
         else atomicAdd(a.counts + v, 1u);
     }
 }
-__global__ void __launch_bounds__(256) range_table_kernel(const uint32_t* counts, uint32_t rows, uint32_t* out, uint64_t ld, uint32_t value_col, uint32_t mult_col) {
+__global__ void __launch_bounds__(256) lookup_hist_kernel(HistArgs a) { lookup_hist_kernel_body(a); }
+struct lookup_hist_kernel_bargs { HistArgs a; static lookup_hist_kernel_bargs make(HistArgs a) { return lookup_hist_kernel_bargs{a}; } };
+__global__ void __launch_bounds__(256) lookup_hist_kernel_batch(const lookup_hist_kernel_bargs* __restrict__ zk_arr) { const lookup_hist_kernel_bargs& zk_b = zk_arr[blockIdx.z]; lookup_hist_kernel_body(zk_b.a); }
+
+__device__ __forceinline__ void range_table_kernel_body(const uint32_t* counts, uint32_t rows, uint32_t* out, uint64_t ld, uint32_t value_col, uint32_t mult_col) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= rows) return;
     out[(uint64_t)i * ld + value_col] = dmul(i, MONTY_R2);
     out[(uint64_t)i * ld + mult_col] = dmul(counts[i] % P, MONTY_R2);
 }
+__global__ void __launch_bounds__(256) range_table_kernel(const uint32_t* counts, uint32_t rows, uint32_t* out, uint64_t ld, uint32_t value_col, uint32_t mult_col) { range_table_kernel_body(counts, rows, out, ld, value_col, mult_col); }
+struct range_table_kernel_bargs { const uint32_t* counts; uint32_t rows; uint32_t* out; uint64_t ld; uint32_t value_col; uint32_t mult_col; static range_table_kernel_bargs make(const uint32_t* counts, uint32_t rows, uint32_t* out, uint64_t ld, uint32_t value_col, uint32_t mult_col) { return range_table_kernel_bargs{counts, rows, out, ld, value_col, mult_col}; } };
+__global__ void __launch_bounds__(256) range_table_kernel_batch(const range_table_kernel_bargs* __restrict__ zk_arr) { const range_table_kernel_bargs& zk_b = zk_arr[blockIdx.z]; range_table_kernel_body(zk_b.counts, zk_b.rows, zk_b.out, zk_b.ld, zk_b.value_col, zk_b.mult_col); }
+
 
 }  // namespace sha
 }  // namespace zk
@@ -380,18 +394,17 @@ int zkhip_range_table(zkhip_ctx* ctx, const uint32_t* d_trace, size_t ld, size_t
     const size_t n = (size_t)1 << log_table;
     void* v_counts;
     ZK_TRY(ctx_reserve(ctx, S_ADDEND, (n + 1) * 4, &v_counts));
-    ZK_HIP(hipMemsetAsync(v_counts, 0, (n + 1) * 4, ctx->stream));
+    ZK_TRY(dev_memset(ctx, v_counts, 0, (n + 1) * 4));
     sha::HistArgs a{};
     a.trace = d_trace; a.ld = ld; a.rows = rows; a.n_cols = (uint32_t)n_columns; a.log_table = (uint32_t)log_table;
     for (int k = 0; k < n_columns; k++) { if (columns[k] >= ld) return fail(ZKHIP_ERR_INVALID, "range_table: column outside the row pitch"); a.cols[k] = columns[k]; }
     a.counts = (uint32_t*)v_counts; a.bad = (uint32_t*)v_counts + n;
-    hipLaunchKernelGGL(sha::lookup_hist_kernel, dim3((unsigned)((rows + 255) / 256)), dim3(256), 0, ctx->stream, a);
+    ZK_LAUNCH(sha::lookup_hist_kernel, sha::lookup_hist_kernel_batch, sha::lookup_hist_kernel_bargs, dim3((unsigned)((rows + 255) / 256)), dim3(256), 0, ctx->stream, a);
     ZK_HIP(hipGetLastError());
-    hipLaunchKernelGGL(sha::range_table_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, (const uint32_t*)v_counts, (uint32_t)n, d_table, (uint64_t)table_ld, value_col, mult_col);
+    ZK_LAUNCH(sha::range_table_kernel, sha::range_table_kernel_batch, sha::range_table_kernel_bargs, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, (const uint32_t*)v_counts, (uint32_t)n, d_table, (uint64_t)table_ld, value_col, mult_col);
     ZK_HIP(hipGetLastError());
     uint32_t bad = 0;
-    ZK_HIP(hipMemcpyAsync(&bad, a.bad, 4, hipMemcpyDeviceToHost, ctx->stream));
-    ZK_HIP(hipStreamSynchronize(ctx->stream));
+    ZK_TRY(dev_d2h(ctx, &bad, a.bad, 4));
     if (bad) return fail(ZKHIP_ERR_INVALID, "range_table: " + std::to_string(bad) + " looked-up values lie outside [0, 2^log_table)");
     return ZKHIP_OK;
 }
@@ -449,8 +462,7 @@ int zkhip_sha256_gen_trace_chained(zkhip_ctx* ctx, const uint32_t chain_in[8], c
     for (int i = 0; i < 8; i++) { digest_limbs[2 * i] = h[i] & 0xffffu; digest_limbs[2 * i + 1] = h[i] >> 16; }
     void* stage;
     ZK_TRY(ctx_reserve(ctx, S_STAGE, host.size() * 4, &stage));
-    ZK_HIP(hipMemcpyAsync(stage, host.data(), host.size() * 4, hipMemcpyHostToDevice, ctx->stream));
-    ZK_HIP(hipStreamSynchronize(ctx->stream));                         // `host` goes out of scope
+    ZK_TRY(dev_h2d(ctx, stage, host.data(), host.size() * 4));           // (returns when `host` may go out of scope)
     sha::TraceArgs a;
     a.words = (const uint32_t*)stage;
     a.chain = (const uint32_t*)stage + n_blocks * 16;
@@ -458,7 +470,7 @@ int zkhip_sha256_gen_trace_chained(zkhip_ctx* ctx, const uint32_t chain_in[8], c
     a.ld = ld;
     a.active = (uint32_t)n_active;
     std::memcpy(a.k, sha::round_constants().k, sizeof(a.k));
-    hipLaunchKernelGGL(sha::sha256_trace_kernel, dim3((unsigned)n_blocks), dim3(64), 0, ctx->stream, a);
+    ZK_LAUNCH(sha::sha256_trace_kernel, sha::sha256_trace_kernel_batch, sha::sha256_trace_kernel_bargs, dim3((unsigned)n_blocks), dim3(64), 0, ctx->stream, a);
     ZK_HIP(hipGetLastError());
     return ZKHIP_OK;
 }
@@ -562,6 +574,10 @@ static MachineShape machine_shape(int log_n) {
 }
 }  // namespace sha
 }  // namespace zk
+// lock-step batches of small transcripts (batch.h): members per batch (0 / 1: off), batches in flight per device, tallest chip
+static std::atomic<int> g_lockstep_batch{32}, g_lockstep_lanes{2};
+constexpr int LOCKSTEP_MAX_LOG_N = 16;
+namespace zk { extern std::atomic<uint64_t> g_lockstep_stats[6]; }
 extern "C" {
 
 int zkhip_sha256_setup(zkhip_ctx* ctx, const zkhip_params* prm, zkhip_machine_key** key, uint32_t vk[8]) {
@@ -607,7 +623,7 @@ int zkhip_prove_sha256_machine(zkhip_ctx* ctx, const zkhip_machine_key* key, con
         digest[4 * i] = (uint8_t)(w >> 24); digest[4 * i + 1] = (uint8_t)(w >> 16); digest[4 * i + 2] = (uint8_t)(w >> 8); digest[4 * i + 3] = (uint8_t)w;
     }
     // the table's main columns (v, multiplicity, 0, 0), counted on the device
-    ZK_HIP(hipMemsetAsync(counts, 0, ((size_t)1 << sha::RANGE_LOG) * 16, ctx->stream));
+    ZK_TRY(dev_memset(ctx, counts, 0, ((size_t)1 << sha::RANGE_LOG) * 16));
     ZK_TRY(zkhip_range_table(ctx, (const uint32_t*)trace, sha::WIDTH, (size_t)1 << log_n, sha::SENT, 4, (int)sha::RANGE_LOG, (uint32_t*)counts, 4, 0, 1));
     const sha::MachineShape m = sha::machine_shape(log_n);
     zkhip_chip chips[2]{};
@@ -657,7 +673,7 @@ int zkhip_prove_transcripts(const int* devices, int n_devices, zkhip_transcript_
     bool have_vk = false;
     std::memset(vk, 0, 32);
     std::vector<char> ran;
-    return deal_jobs(devs.data(), (int)devs.size(), n_jobs, in_flight_per_device, [&](zkhip_ctx* ctx, int i) {
+    auto run = [&](zkhip_ctx* ctx, int i) {
         zkhip_transcript_job& j = jobs[i];
         int r = ZKHIP_OK;
         if (ctx->sha_key && ctx->sha_key_blowup != prm->log_blowup) { zkhip_machine_key_destroy(ctx->sha_key); ctx->sha_key = nullptr; }
@@ -672,12 +688,46 @@ int zkhip_prove_transcripts(const int* devices, int n_devices, zkhip_transcript_
         }
         size_t len = 0;
         if (r == ZKHIP_OK) r = zkhip_prove_sha256_machine(ctx, ctx->sha_key, j.message, j.message_len, prm, j.digest, j.proof, j.proof_cap, &len);
+        batch_leave();                                           // (lock-step batch: the rest is host work, nobody waits for this member any more)
         // the reference checks every proof right after proving it (sp1.rs:120): on this worker's host thread, while the GPU runs the other workers' proofs
         if (r == ZKHIP_OK && verify) r = zkhip_verify_sha256_machine(j.proof, len, j.digest, ctx->sha_vk, prm, nullptr);
         j.status = r;
         j.proof_len = r == ZKHIP_OK ? len : 0;
         return r;
-    }, ran);
+    };
+    // Small transcripts are launch-bound (a few hundred kernels of microseconds each): those of one trace height are proven in
+    // lock-step batches whose kernel launches merge (batch.h); the others -- and everything when lock-step is switched off -- are
+    // dealt one context, one stream each.  The proofs are the same bytes either way.
+    const int max_batch = g_lockstep_batch.load();
+    std::vector<int> small, big, shape;
+    for (int i = 0; i < n_jobs; i++) {
+        size_t padded, na, nb;
+        int log_n = 0;
+        const bool ok = sha_shape(jobs[i].message_len, &padded, &na, &nb, &log_n) == ZKHIP_OK;
+        if (ok && max_batch > 1 && log_n <= LOCKSTEP_MAX_LOG_N) { small.push_back(i); shape.push_back(log_n); }
+        else big.push_back(i);
+    }
+    const int nd = (int)devs.size();
+    if ((int)small.size() < 2 * nd) { big.insert(big.end(), small.begin(), small.end()); std::sort(big.begin(), big.end()); small.clear(); }
+    int rc_small = ZKHIP_OK, rc_big = ZKHIP_OK;
+    std::string msg_small;
+    if (!small.empty()) {
+        rc_small = deal_jobs_lockstep(devs.data(), nd, (int)small.size(), shape.data(), max_batch, g_lockstep_lanes.load(),
+                                      [&](zkhip_ctx* ctx, int k) { return run(ctx, small[(size_t)k]); }, ran);
+        if (rc_small != ZKHIP_OK) msg_small = zkhip_last_error();
+    }
+    if (!big.empty())
+        rc_big = deal_jobs(devs.data(), nd, (int)big.size(), in_flight_per_device, [&](zkhip_ctx* ctx, int k) { return run(ctx, big[(size_t)k]); }, ran);
+    if (rc_small != ZKHIP_OK && (rc_big == ZKHIP_OK || small[0] < big[0])) { set_error(msg_small); return rc_small; }
+    return rc_big;
+}
+
+void zkhip_set_lockstep(int max_batch, int lanes) {
+    g_lockstep_batch.store(max_batch < 0 ? 0 : (max_batch > LaunchBatcher::MAX_MEMBERS ? LaunchBatcher::MAX_MEMBERS : max_batch));
+    if (lanes > 0) g_lockstep_lanes.store(lanes > 8 ? 8 : lanes);
+}
+void zkhip_lockstep_stats(uint64_t out[6]) {
+    for (int i = 0; i < 6; i++) out[i] = g_lockstep_stats[i].load();
 }
 
 // ---- a message of ANY length as a chain of shards (BASELINE configs[3]: a megabyte-scale transcript over several GPUs) ------------------

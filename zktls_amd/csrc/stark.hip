@@ -16,6 +16,7 @@
 
 #include "poseidon2.cuh"
 #include "kernels.h"
+#include "batch.h"
 
 namespace zk {
 
@@ -44,8 +45,7 @@ ZK_D Ext group_sum(Ext v, int width) {
 // ------------------------------------------------------------------ domain tables
 // LDE domain g <w_M>, M = 2^(log_n + log_blowup), bit-reversed: x_p = g w_M^bitrev(p).  The quotient domain
 // g <w_2N> is its first 2N positions (and x_p there is g w_2N^bitrev_2N(p)), so the selector tables have 2N entries.
-__global__ void domain_tables_kernel(uint32_t* xs, uint32_t* sel_first, uint32_t* sel_last, uint32_t* itw, int log_n, int log_blowup,
-                                     uint32_t g_pow_n) {
+__device__ __forceinline__ void domain_tables_kernel_body(uint32_t* xs, uint32_t* sel_first, uint32_t* sel_last, uint32_t* itw, int log_n, int log_blowup, uint32_t g_pow_n) {
     const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
     const int H = log_n + log_blowup, lq = log_blowup < 2 ? log_blowup : 2, Hq = log_n + lq;   // selectors on the largest quotient domain (2^lq N points)
     if (p >= (1u << H)) return;
@@ -65,10 +65,14 @@ __global__ void domain_tables_kernel(uint32_t* xs, uint32_t* sel_first, uint32_t
         itw[p] = fmul(finv(fpow(wm, ei)), MONTY_INV2);                  // 1 / (2 w_M^bitrev(p))
     }
 }
+__global__ void domain_tables_kernel(uint32_t* xs, uint32_t* sel_first, uint32_t* sel_last, uint32_t* itw, int log_n, int log_blowup, uint32_t g_pow_n) { domain_tables_kernel_body(xs, sel_first, sel_last, itw, log_n, log_blowup, g_pow_n); }
+struct domain_tables_kernel_bargs { uint32_t* xs; uint32_t* sel_first; uint32_t* sel_last; uint32_t* itw; int log_n; int log_blowup; uint32_t g_pow_n; static domain_tables_kernel_bargs make(uint32_t* xs, uint32_t* sel_first, uint32_t* sel_last, uint32_t* itw, int log_n, int log_blowup, uint32_t g_pow_n) { return domain_tables_kernel_bargs{xs, sel_first, sel_last, itw, log_n, log_blowup, g_pow_n}; } };
+__global__ void domain_tables_kernel_batch(const domain_tables_kernel_bargs* __restrict__ zk_arr) { const domain_tables_kernel_bargs& zk_b = zk_arr[blockIdx.z]; domain_tables_kernel_body(zk_b.xs, zk_b.sel_first, zk_b.sel_last, zk_b.itw, zk_b.log_n, zk_b.log_blowup, zk_b.g_pow_n); }
+
 hipError_t launch_domain_tables(uint32_t* xs, uint32_t* sel_first, uint32_t* sel_last, uint32_t* itw, int log_n, int log_blowup, hipStream_t s) {
     const uint32_t m = 1u << (log_n + log_blowup);
     const uint32_t gpn = fpow(MONTY_GEN, (uint64_t)1 << log_n);
-    hipLaunchKernelGGL(domain_tables_kernel, dim3((m + 255) / 256), dim3(256), 0, s, xs, sel_first, sel_last, itw, log_n, log_blowup, gpn);
+    ZK_LAUNCH(domain_tables_kernel, domain_tables_kernel_batch, domain_tables_kernel_bargs, dim3((m + 255) / 256), dim3(256), 0, s, xs, sel_first, sel_last, itw, log_n, log_blowup, gpn);
     return hipGetLastError();
 }
 
@@ -109,7 +113,7 @@ template <int NG>
 #ifndef QWPE
 #define QWPE 2
 #endif
-__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(QWPE, QWPE))) quotient_kernel(QuotientArgs a) {
+__device__ __forceinline__ void quotient_kernel_body(const QuotientArgs& a) {
     const int L = a.lanes_per_row;
     const uint32_t gid = blockIdx.x * blockDim.x + threadIdx.x;
     const int lane = gid % L;
@@ -217,6 +221,18 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(QWPE, 
         e = en; p = pn;
     }
 }
+template <int NG>
+#ifndef QWPE
+#define QWPE 2
+#endif
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(QWPE, QWPE))) quotient_kernel(QuotientArgs a) { quotient_kernel_body<NG>(a); }
+struct quotient_kernel_bargs { QuotientArgs a; static quotient_kernel_bargs make(QuotientArgs a) { return quotient_kernel_bargs{a}; } };
+template <int NG>
+#ifndef QWPE
+#define QWPE 2
+#endif
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(QWPE, QWPE))) quotient_kernel_batch(const quotient_kernel_bargs* __restrict__ zk_arr) { const quotient_kernel_bargs& zk_b = zk_arr[blockIdx.z]; quotient_kernel_body<NG>(zk_b.a); }
+
 hipError_t launch_quotient(const QuotientArgs& a, hipStream_t s) {
     const uint64_t m = 2ull << a.log_n;
     const uint64_t threads = (m / QCHAIN) * a.lanes_per_row;
@@ -224,12 +240,12 @@ hipError_t launch_quotient(const QuotientArgs& a, hipStream_t s) {
     const int ng = (int)((G + a.lanes_per_row - 1) / a.lanes_per_row);
     const dim3 grid((unsigned)((threads + 255) / 256)), block(256);
     switch (ng) {
-        case 1: hipLaunchKernelGGL(quotient_kernel<1>, grid, block, 0, s, a); break;
-        case 2: hipLaunchKernelGGL(quotient_kernel<2>, grid, block, 0, s, a); break;
-        case 3: hipLaunchKernelGGL(quotient_kernel<3>, grid, block, 0, s, a); break;
-        case 4: hipLaunchKernelGGL(quotient_kernel<4>, grid, block, 0, s, a); break;
-        case 5: case 6: case 7: case 8: hipLaunchKernelGGL(quotient_kernel<8>, grid, block, 0, s, a); break;
-        default: hipLaunchKernelGGL(quotient_kernel<16>, grid, block, 0, s, a); break;    // width <= 1024
+        case 1: ZK_LAUNCH(quotient_kernel<1>, quotient_kernel_batch<1>, quotient_kernel_bargs, grid, block, 0, s, a); break;
+        case 2: ZK_LAUNCH(quotient_kernel<2>, quotient_kernel_batch<2>, quotient_kernel_bargs, grid, block, 0, s, a); break;
+        case 3: ZK_LAUNCH(quotient_kernel<3>, quotient_kernel_batch<3>, quotient_kernel_bargs, grid, block, 0, s, a); break;
+        case 4: ZK_LAUNCH(quotient_kernel<4>, quotient_kernel_batch<4>, quotient_kernel_bargs, grid, block, 0, s, a); break;
+        case 5: case 6: case 7: case 8: ZK_LAUNCH(quotient_kernel<8>, quotient_kernel_batch<8>, quotient_kernel_bargs, grid, block, 0, s, a); break;
+        default: ZK_LAUNCH(quotient_kernel<16>, quotient_kernel_batch<16>, quotient_kernel_bargs, grid, block, 0, s, a); break;    // width <= 1024
     }
     return hipGetLastError();
 }
@@ -241,7 +257,7 @@ hipError_t launch_quotient(const QuotientArgs& a, hipStream_t s) {
 // word; consecutive lanes hold consecutive bit-reversed positions, i.e. adjacent 4 * ld-byte rows, and a row's lines stay in L1 / L2
 // across the variables of a program.  This is the generic path: the synthetic AIR keeps its specialised kernel (quotient_kernel), which
 // streams rows once with 16-byte loads; bytes per point here are the same 2 * 4 * width, the instruction count is what differs.
-__global__ void __launch_bounds__(256) quotient_air_kernel(QuotientAirArgs a) {
+__device__ __forceinline__ void quotient_air_kernel_body(const QuotientAirArgs& a) {
     const int H = a.log_n + a.log_qd;
     const uint32_t m = 1u << H, nq = 1u << a.log_qd;
     const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
@@ -279,6 +295,10 @@ __global__ void __launch_bounds__(256) quotient_air_kernel(QuotientAirArgs a) {
     st_ext(a.out + ((uint64_t)chunk * (m >> a.log_qd) + (e >> a.log_qd)) * 4, r);
     if (a.lde_out) st_ext(a.lde_out + (uint64_t)p * a.lde_ld + 4u * chunk, r);
 }
+__global__ void __launch_bounds__(256) quotient_air_kernel(QuotientAirArgs a) { quotient_air_kernel_body(a); }
+struct quotient_air_kernel_bargs { QuotientAirArgs a; static quotient_air_kernel_bargs make(QuotientAirArgs a) { return quotient_air_kernel_bargs{a}; } };
+__global__ void __launch_bounds__(256) quotient_air_kernel_batch(const quotient_air_kernel_bargs* __restrict__ zk_arr) { const quotient_air_kernel_bargs& zk_b = zk_arr[blockIdx.z]; quotient_air_kernel_body(zk_b.a); }
+
 // The term-parallel form: a workgroup owns a GROUP of 8 points of the quotient domain and its lanes split the TERMS of the flattened
 // program (air.h, air_term_records: one record per distinct monomial).  The 8 points are 8 consecutive rows of the trace domain on one
 // coset, so 9 rows of the LDE serve them (the next row of point q is the local row of point q + 1); the rows are staged into LDS once,
@@ -328,7 +348,7 @@ __device__ __forceinline__ void air_store_point(const QuotientAirArgs& a, uint32
 // a group takes the more groups are resident -- seven single wavefronts per CU against three or four 256-lane workgroups.  Lanes beyond
 // one wavefront only pay when a program has enough terms per point to keep them busy; the launcher picks NT from the record count.
 template <int NT>
-__global__ void __launch_bounds__(NT) quotient_air_terms_kernel(QuotientAirArgs a) {
+__device__ __forceinline__ void quotient_air_terms_kernel_body(const QuotientAirArgs& a) {
     constexpr int PTS = 8;
     static_assert(NT == 64 || NT == 128 || NT == 256, "one, two or four wavefronts per group");
     extern __shared__ uint32_t slots[];
@@ -397,6 +417,12 @@ __global__ void __launch_bounds__(NT) quotient_air_terms_kernel(QuotientAirArgs 
         air_store_point(a, (e0 + (tid << a.log_qd)) & mask, r);
     }
 }
+template <int NT>
+__global__ void __launch_bounds__(NT) quotient_air_terms_kernel(QuotientAirArgs a) { quotient_air_terms_kernel_body<NT>(a); }
+struct quotient_air_terms_kernel_bargs { QuotientAirArgs a; static quotient_air_terms_kernel_bargs make(QuotientAirArgs a) { return quotient_air_terms_kernel_bargs{a}; } };
+template <int NT>
+__global__ void __launch_bounds__(NT) quotient_air_terms_kernel_batch(const quotient_air_terms_kernel_bargs* __restrict__ zk_arr) { const quotient_air_terms_kernel_bargs& zk_b = zk_arr[blockIdx.z]; quotient_air_terms_kernel_body<NT>(zk_b.a); }
+
 // The chained form of the same kernel.  What the kernel above spends its time on is not terms but rows: every workgroup stages 9
 // rows, waits for them with nothing else to do, and leaves again (a 608-column program of 8 terms: 4.3 ms per 2^21 points = 1.2 TB/s).
 // Here a workgroup walks CHAIN consecutive groups of one coset:
@@ -409,7 +435,7 @@ __global__ void __launch_bounds__(NT) quotient_air_terms_kernel(QuotientAirArgs 
 //   * 32 lanes finish one coefficient of one point each (addend, 1 / Z_H, the two stores), 128 contiguous bytes per store.
 // idx -> (row, column group) of the lane's k-th prefetch slot: idx = tid + k NT < 8 W4, row = 1 + idx / W4.
 template <int NT, int NPF>
-__global__ void __launch_bounds__(NT, 2) quotient_air_chain_kernel(QuotientAirArgs a, uint32_t chain_len, uint32_t w4_recip) {
+__device__ __forceinline__ void quotient_air_chain_kernel_body(const QuotientAirArgs& a, uint32_t chain_len, uint32_t w4_recip) {
     constexpr int PTS = 8;
     static_assert(NT == 64 || NT == 128 || NT == 256, "one, two or four wavefronts per group");
     extern __shared__ uint32_t slots[];
@@ -541,6 +567,12 @@ __global__ void __launch_bounds__(NT, 2) quotient_air_chain_kernel(QuotientAirAr
     }
 }
 template <int NT, int NPF>
+__global__ void __launch_bounds__(NT, 2) quotient_air_chain_kernel(QuotientAirArgs a, uint32_t chain_len, uint32_t w4_recip) { quotient_air_chain_kernel_body<NT, NPF>(a, chain_len, w4_recip); }
+struct quotient_air_chain_kernel_bargs { QuotientAirArgs a; uint32_t chain_len; uint32_t w4_recip; static quotient_air_chain_kernel_bargs make(QuotientAirArgs a, uint32_t chain_len, uint32_t w4_recip) { return quotient_air_chain_kernel_bargs{a, chain_len, w4_recip}; } };
+template <int NT, int NPF>
+__global__ void __launch_bounds__(NT, 2) quotient_air_chain_kernel_batch(const quotient_air_chain_kernel_bargs* __restrict__ zk_arr) { const quotient_air_chain_kernel_bargs& zk_b = zk_arr[blockIdx.z]; quotient_air_chain_kernel_body<NT, NPF>(zk_b.a, zk_b.chain_len, zk_b.w4_recip); }
+
+template <int NT, int NPF>
 static hipError_t launch_chain(const QuotientAirArgs& a, uint32_t n_chains, uint32_t chain_len, size_t lds, hipStream_t s) {
     if (lds > 64 * 1024) {
         static std::atomic<size_t> configured[64] = {};
@@ -549,12 +581,14 @@ static hipError_t launch_chain(const QuotientAirArgs& a, uint32_t n_chains, uint
         if (lds > configured[dev].load(std::memory_order_acquire)) {
             hipError_t e = hipFuncSetAttribute((const void*)quotient_air_chain_kernel<NT, NPF>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
             if (e != hipSuccess) return e;
+            e = hipFuncSetAttribute((const void*)quotient_air_chain_kernel_batch<NT, NPF>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            if (e != hipSuccess) return e;
             configured[dev].store(lds, std::memory_order_release);
         }
     }
     const uint32_t W4 = a.width >> 2;
     const uint32_t recip = (uint32_t)(((1ull << 32) + W4 - 1) / W4);        // ceil(2^32 / W4): idx / W4 = umulhi(idx, recip) for idx < 2^16
-    hipLaunchKernelGGL((quotient_air_chain_kernel<NT, NPF>), dim3(n_chains), dim3(NT), lds, s, a, chain_len, recip);
+    ZK_LAUNCH((quotient_air_chain_kernel<NT, NPF>), (quotient_air_chain_kernel_batch<NT, NPF>), quotient_air_chain_kernel_bargs, dim3(n_chains), dim3(NT), lds, s, a, chain_len, recip);
     return hipGetLastError();
 }
 template <int NT>
@@ -576,10 +610,12 @@ static hipError_t launch_terms(const QuotientAirArgs& a, uint32_t n_groups, size
         if (lds > configured[dev].load(std::memory_order_acquire)) {
             hipError_t e = hipFuncSetAttribute((const void*)quotient_air_terms_kernel<NT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
             if (e != hipSuccess) return e;
+            e = hipFuncSetAttribute((const void*)quotient_air_terms_kernel_batch<NT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            if (e != hipSuccess) return e;
             configured[dev].store(lds, std::memory_order_release);
         }
     }
-    hipLaunchKernelGGL(quotient_air_terms_kernel<NT>, dim3(n_groups), dim3(NT), lds, s, a);
+    ZK_LAUNCH(quotient_air_terms_kernel<NT>, quotient_air_terms_kernel_batch<NT>, quotient_air_terms_kernel_bargs, dim3(n_groups), dim3(NT), lds, s, a);
     return hipGetLastError();
 }
 hipError_t launch_quotient_air(const QuotientAirArgs& a, hipStream_t s) {
@@ -624,15 +660,14 @@ hipError_t launch_quotient_air(const QuotientAirArgs& a, hipStream_t s) {
         if (a.n_terms <= 8192) return launch_terms<128>(a, n_groups, lds_rows, s);
         return launch_terms<256>(a, n_groups, lds_rows, s);
     }
-    hipLaunchKernelGGL(quotient_air_kernel, dim3((unsigned)((m + 255) / 256)), dim3(256), 0, s, a);
+    ZK_LAUNCH(quotient_air_kernel, quotient_air_kernel_batch, quotient_air_kernel_bargs, dim3((unsigned)((m + 255) / 256)), dim3(256), 0, s, a);
     return hipGetLastError();
 }
 
 // ------------------------------------------------------------------ 1 / (x_p - z)
 // out[k][p] = 1 / (x_p - z_k) for p < count; optionally xw[k][p] = x_p / (x_p - z_k) for p < xw_count
 // (the barycentric weights of the opening kernel, which sums over the first xw_count rows only)
-__global__ void __launch_bounds__(256) inv_denominators_kernel(const uint32_t* xs, uint64_t count, Ext z0, Ext z1, int npoints,
-                                                               uint32_t* out, uint32_t* xw, uint64_t xw_count) {
+__device__ __forceinline__ void inv_denominators_kernel_body(const uint32_t* xs, uint64_t count, const Ext& z0, const Ext& z1, int npoints, uint32_t* out, uint32_t* xw, uint64_t xw_count) {
     const uint64_t p = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (p >= count) return;
     const uint32_t x = xs[p];
@@ -645,9 +680,13 @@ __global__ void __launch_bounds__(256) inv_denominators_kernel(const uint32_t* x
         if (xw && p < xw_count) st_ext(xw + 4 * (xw_count + p), ext_mul_base_dev(d1, x));
     }
 }
+__global__ void __launch_bounds__(256) inv_denominators_kernel(const uint32_t* xs, uint64_t count, Ext z0, Ext z1, int npoints, uint32_t* out, uint32_t* xw, uint64_t xw_count) { inv_denominators_kernel_body(xs, count, z0, z1, npoints, out, xw, xw_count); }
+struct inv_denominators_kernel_bargs { const uint32_t* xs; uint64_t count; Ext z0; Ext z1; int npoints; uint32_t* out; uint32_t* xw; uint64_t xw_count; static inv_denominators_kernel_bargs make(const uint32_t* xs, uint64_t count, Ext z0, Ext z1, int npoints, uint32_t* out, uint32_t* xw, uint64_t xw_count) { return inv_denominators_kernel_bargs{xs, count, z0, z1, npoints, out, xw, xw_count}; } };
+__global__ void __launch_bounds__(256) inv_denominators_kernel_batch(const inv_denominators_kernel_bargs* __restrict__ zk_arr) { const inv_denominators_kernel_bargs& zk_b = zk_arr[blockIdx.z]; inv_denominators_kernel_body(zk_b.xs, zk_b.count, zk_b.z0, zk_b.z1, zk_b.npoints, zk_b.out, zk_b.xw, zk_b.xw_count); }
+
 hipError_t launch_inv_denominators(const uint32_t* xs, uint64_t count, const Ext& z0, const Ext& z1, int npoints,
                                    uint32_t* out, uint32_t* xw, uint64_t xw_count, hipStream_t s) {
-    hipLaunchKernelGGL(inv_denominators_kernel, dim3((unsigned)((count + 255) / 256)), dim3(256), 0, s, xs, count, z0, z1, npoints, out, xw, xw_count);
+    ZK_LAUNCH(inv_denominators_kernel, inv_denominators_kernel_batch, inv_denominators_kernel_bargs, dim3((unsigned)((count + 255) / 256)), dim3(256), 0, s, xs, count, z0, z1, npoints, out, xw, xw_count);
     return hipGetLastError();
 }
 
@@ -658,7 +697,7 @@ hipError_t launch_inv_denominators(const uint32_t* xs, uint64_t count, const Ext
 constexpr int OPEN_ROWS = 2048;   // rows per workgroup
 constexpr int OPEN_ROWS4 = 1024;  // rows per workgroup of the four-columns-per-lane form
 template <int NPTS>
-__global__ void __launch_bounds__(256) open_partial_kernel(OpenArgs a) {
+__device__ __forceinline__ void open_partial_kernel_body(const OpenArgs& a) {
     __shared__ uint32_t red[256 * 4];
     const int TX = a.tx, TY = 256 / TX;
     const int tx = threadIdx.x % TX, ty = threadIdx.x / TX;
@@ -709,10 +748,16 @@ __global__ void __launch_bounds__(256) open_partial_kernel(OpenArgs a) {
         }
     }
 }
+template <int NPTS>
+__global__ void __launch_bounds__(256) open_partial_kernel(OpenArgs a) { open_partial_kernel_body<NPTS>(a); }
+struct open_partial_kernel_bargs { OpenArgs a; static open_partial_kernel_bargs make(OpenArgs a) { return open_partial_kernel_bargs{a}; } };
+template <int NPTS>
+__global__ void __launch_bounds__(256) open_partial_kernel_batch(const open_partial_kernel_bargs* __restrict__ zk_arr) { const open_partial_kernel_bargs& zk_b = zk_arr[blockIdx.z]; open_partial_kernel_body<NPTS>(zk_b.a); }
+
 // The same for matrices whose width and pitch are multiples of 4: a lane owns FOUR adjacent columns (16-byte loads: a wave
 // covers a whole 1 KiB row of a 256-column matrix) and the weights of a row are fetched once per four columns.
 template <int NPTS>
-__global__ void __launch_bounds__(256) open_partial4_kernel(OpenArgs a) {
+__device__ __forceinline__ void open_partial4_kernel_body(const OpenArgs& a) {
     __shared__ uint32_t red[256 * 16];
     const int TX = a.tx, TY = 256 / TX;
     const int tx = threadIdx.x % TX, ty = threadIdx.x / TX;
@@ -771,9 +816,14 @@ __global__ void __launch_bounds__(256) open_partial4_kernel(OpenArgs a) {
         }
     }
 }
+template <int NPTS>
+__global__ void __launch_bounds__(256) open_partial4_kernel(OpenArgs a) { open_partial4_kernel_body<NPTS>(a); }
+struct open_partial4_kernel_bargs { OpenArgs a; static open_partial4_kernel_bargs make(OpenArgs a) { return open_partial4_kernel_bargs{a}; } };
+template <int NPTS>
+__global__ void __launch_bounds__(256) open_partial4_kernel_batch(const open_partial4_kernel_bargs* __restrict__ zk_arr) { const open_partial4_kernel_bargs& zk_b = zk_arr[blockIdx.z]; open_partial4_kernel_body<NPTS>(zk_b.a); }
+
 // out[pt][col] = -scale_pt * sum_chunk partial[chunk][pt][col]; one wave per output, the chunks spread over its lanes
-__global__ void __launch_bounds__(64) open_final_kernel(const uint32_t* partial, uint32_t nchunks, int npts, uint32_t width,
-                                                        Ext scale0, Ext scale1, uint32_t* out) {
+__device__ __forceinline__ void open_final_kernel_body(const uint32_t* partial, uint32_t nchunks, int npts, uint32_t width, const Ext& scale0, const Ext& scale1, uint32_t* out) {
     const uint32_t idx = blockIdx.x;
     const uint32_t k = idx / width, col = idx % width;
     Ext sum = ext_zero();
@@ -781,6 +831,10 @@ __global__ void __launch_bounds__(64) open_final_kernel(const uint32_t* partial,
     sum = group_sum(sum, 64);
     if (threadIdx.x == 0) st_ext(out + 4 * (uint64_t)idx, ext_neg(ext_mul_dev(sum, k ? scale1 : scale0)));
 }
+__global__ void __launch_bounds__(64) open_final_kernel(const uint32_t* partial, uint32_t nchunks, int npts, uint32_t width, Ext scale0, Ext scale1, uint32_t* out) { open_final_kernel_body(partial, nchunks, npts, width, scale0, scale1, out); }
+struct open_final_kernel_bargs { const uint32_t* partial; uint32_t nchunks; int npts; uint32_t width; Ext scale0; Ext scale1; uint32_t* out; static open_final_kernel_bargs make(const uint32_t* partial, uint32_t nchunks, int npts, uint32_t width, Ext scale0, Ext scale1, uint32_t* out) { return open_final_kernel_bargs{partial, nchunks, npts, width, scale0, scale1, out}; } };
+__global__ void __launch_bounds__(64) open_final_kernel_batch(const open_final_kernel_bargs* __restrict__ zk_arr) { const open_final_kernel_bargs& zk_b = zk_arr[blockIdx.z]; open_final_kernel_body(zk_b.partial, zk_b.nchunks, zk_b.npts, zk_b.width, zk_b.scale0, zk_b.scale1, zk_b.out); }
+
 bool open_uses_quads(uint32_t width, uint64_t ld, const uint32_t* mat) {
     return width >= 64 && width % 4 == 0 && ld % 4 == 0 && ((uintptr_t)mat & 15u) == 0;
 }
@@ -796,17 +850,17 @@ hipError_t launch_open(const OpenArgs& a0, int npts, const Ext& scale0, const Ex
         a.tx = 1;
         while (a.tx < (int)(a.width / 4) && a.tx < 64) a.tx <<= 1;      // lanes per row = pow2ceil(width / 4), at most 64
         dim3 grid(nchunks, (a.width / 4 + a.tx - 1) / a.tx);
-        if (npts == 1) hipLaunchKernelGGL(open_partial4_kernel<1>, grid, dim3(256), 0, s, a);
-        else hipLaunchKernelGGL(open_partial4_kernel<2>, grid, dim3(256), 0, s, a);
+        if (npts == 1) ZK_LAUNCH(open_partial4_kernel<1>, open_partial4_kernel_batch<1>, open_partial4_kernel_bargs, grid, dim3(256), 0, s, a);
+        else ZK_LAUNCH(open_partial4_kernel<2>, open_partial4_kernel_batch<2>, open_partial4_kernel_bargs, grid, dim3(256), 0, s, a);
     } else {
         dim3 grid(nchunks, (a.width + a.tx - 1) / a.tx);
-        if (npts == 1) hipLaunchKernelGGL(open_partial_kernel<1>, grid, dim3(256), 0, s, a);
-        else hipLaunchKernelGGL(open_partial_kernel<2>, grid, dim3(256), 0, s, a);
+        if (npts == 1) ZK_LAUNCH(open_partial_kernel<1>, open_partial_kernel_batch<1>, open_partial_kernel_bargs, grid, dim3(256), 0, s, a);
+        else ZK_LAUNCH(open_partial_kernel<2>, open_partial_kernel_batch<2>, open_partial_kernel_bargs, grid, dim3(256), 0, s, a);
     }
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return e;
     const uint32_t n = (uint32_t)npts * a.width;
-    hipLaunchKernelGGL(open_final_kernel, dim3(n), dim3(64), 0, s, a.partial, nchunks, npts, a.width, scale0, scale1, out);
+    ZK_LAUNCH(open_final_kernel, open_final_kernel_batch, open_final_kernel_bargs, dim3(n), dim3(64), 0, s, a.partial, nchunks, npts, a.width, scale0, scale1, out);
     return hipGetLastError();
 }
 
@@ -819,8 +873,7 @@ hipError_t launch_open(const OpenArgs& a0, int npts, const Ext& scale0, const Ex
 // A row is spread over L <= 16 lanes of one DPP row (a wave covers 64 / L rows); each lane keeps four
 // 64-bit running sums (dacc2) and reduces them once per row, and the lane partials are summed with
 // DPP row rotations -- no LDS, no ds_bpermute.
-__global__ void __launch_bounds__(256) rowdot_kernel(const uint32_t* __restrict__ mat, uint64_t ld, uint32_t width, uint64_t rows,
-                                                     int L, const uint32_t* __restrict__ alpha_pow, uint32_t* __restrict__ out_at) {
+__device__ __forceinline__ void rowdot_kernel_body(const uint32_t* __restrict__ mat, uint64_t ld, uint32_t width, uint64_t rows, int L, const uint32_t* __restrict__ alpha_pow, uint32_t* __restrict__ out_at) {
     const uint64_t gid = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const uint64_t p = gid / L;
     const int lane = (int)(gid % L);
@@ -842,14 +895,17 @@ __global__ void __launch_bounds__(256) rowdot_kernel(const uint32_t* __restrict_
     for (int i = 0; i < 4; i++) r.c[i] = row_group_sum(dacc_finish(acc[i]), L);
     if (lane == 0) st_ext(out_at + 4 * p, r);
 }
+__global__ void __launch_bounds__(256) rowdot_kernel(const uint32_t* __restrict__ mat, uint64_t ld, uint32_t width, uint64_t rows, int L, const uint32_t* __restrict__ alpha_pow, uint32_t* __restrict__ out_at) { rowdot_kernel_body(mat, ld, width, rows, L, alpha_pow, out_at); }
+struct rowdot_kernel_bargs { const uint32_t* mat; uint64_t ld; uint32_t width; uint64_t rows; int L; const uint32_t* alpha_pow; uint32_t* out_at; static rowdot_kernel_bargs make(const uint32_t* mat, uint64_t ld, uint32_t width, uint64_t rows, int L, const uint32_t* alpha_pow, uint32_t* out_at) { return rowdot_kernel_bargs{mat, ld, width, rows, L, alpha_pow, out_at}; } };
+__global__ void __launch_bounds__(256) rowdot_kernel_batch(const rowdot_kernel_bargs* __restrict__ zk_arr) { const rowdot_kernel_bargs& zk_b = zk_arr[blockIdx.z]; rowdot_kernel_body(zk_b.mat, zk_b.ld, zk_b.width, zk_b.rows, zk_b.L, zk_b.alpha_pow, zk_b.out_at); }
+
 // The same dot product with the powers of alpha kept in REGISTERS: a lane owns the column quads q = lane + L k, k < NK, of EVERY row its
 // wavefront visits (64 / L rows per trip, ROWDOT_TRIPS trips), so a row costs its own 16-byte loads only.  In the form above every
 // 16 bytes of a row came with 64 bytes of powers from L1 -- five load instructions per payload load: the kernel was bound by the
 // texture path at 4.0 TB/s of HBM traffic.  Used for widths up to 1024 / (16 / NK_MAX) = 256 columns per 16 lanes (NK <= 4).
 constexpr int ROWDOT_TRIPS = 16;
 template <int NK>
-__global__ void __launch_bounds__(256) rowdot_regs_kernel(const uint32_t* __restrict__ mat, uint64_t ld, uint32_t width, uint64_t rows,
-                                                          int L, const uint32_t* __restrict__ alpha_pow, uint32_t* __restrict__ out_at) {
+__device__ __forceinline__ void rowdot_regs_kernel_body(const uint32_t* __restrict__ mat, uint64_t ld, uint32_t width, uint64_t rows, int L, const uint32_t* __restrict__ alpha_pow, uint32_t* __restrict__ out_at) {
     const int lane = (int)(threadIdx.x % L);
     const uint32_t nq = width / 4;
     const uint64_t rows_per_trip = 256 / L;                       // rows a workgroup covers per trip
@@ -885,8 +941,14 @@ __global__ void __launch_bounds__(256) rowdot_regs_kernel(const uint32_t* __rest
         if (lane == 0) st_ext(out_at + 4 * p, r);
     }
 }
+template <int NK>
+__global__ void __launch_bounds__(256) rowdot_regs_kernel(const uint32_t* __restrict__ mat, uint64_t ld, uint32_t width, uint64_t rows, int L, const uint32_t* __restrict__ alpha_pow, uint32_t* __restrict__ out_at) { rowdot_regs_kernel_body<NK>(mat, ld, width, rows, L, alpha_pow, out_at); }
+struct rowdot_regs_kernel_bargs { const uint32_t* mat; uint64_t ld; uint32_t width; uint64_t rows; int L; const uint32_t* alpha_pow; uint32_t* out_at; static rowdot_regs_kernel_bargs make(const uint32_t* mat, uint64_t ld, uint32_t width, uint64_t rows, int L, const uint32_t* alpha_pow, uint32_t* out_at) { return rowdot_regs_kernel_bargs{mat, ld, width, rows, L, alpha_pow, out_at}; } };
+template <int NK>
+__global__ void __launch_bounds__(256) rowdot_regs_kernel_batch(const rowdot_regs_kernel_bargs* __restrict__ zk_arr) { const rowdot_regs_kernel_bargs& zk_b = zk_arr[blockIdx.z]; rowdot_regs_kernel_body<NK>(zk_b.mat, zk_b.ld, zk_b.width, zk_b.rows, zk_b.L, zk_b.alpha_pow, zk_b.out_at); }
+
 static hipError_t launch_rowdot(const uint32_t* mat, uint64_t ld, uint32_t width, uint64_t rows, const uint32_t* alpha_pow, uint32_t* out_at, hipStream_t s);
-__global__ void __launch_bounds__(256) reduced_combine_kernel(ReducedArgs a, const uint32_t* __restrict__ at_in, const uint32_t* __restrict__ ap_in) {
+__device__ __forceinline__ void reduced_combine_kernel_body(const ReducedArgs& a, const uint32_t* __restrict__ at_in, const uint32_t* __restrict__ ap_in) {
     const uint64_t p = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (p >= a.rows) return;
     const Ext at = ld_ext(at_in + 4 * p);
@@ -910,6 +972,10 @@ __global__ void __launch_bounds__(256) reduced_combine_kernel(ReducedArgs a, con
     if (a.accumulate) r = ext_add(r, ld_ext(a.out + 4 * p));
     st_ext(a.out + 4 * p, r);
 }
+__global__ void __launch_bounds__(256) reduced_combine_kernel(ReducedArgs a, const uint32_t* __restrict__ at_in, const uint32_t* __restrict__ ap_in) { reduced_combine_kernel_body(a, at_in, ap_in); }
+struct reduced_combine_kernel_bargs { ReducedArgs a; const uint32_t* at_in; const uint32_t* ap_in; static reduced_combine_kernel_bargs make(ReducedArgs a, const uint32_t* at_in, const uint32_t* ap_in) { return reduced_combine_kernel_bargs{a, at_in, ap_in}; } };
+__global__ void __launch_bounds__(256) reduced_combine_kernel_batch(const reduced_combine_kernel_bargs* __restrict__ zk_arr) { const reduced_combine_kernel_bargs& zk_b = zk_arr[blockIdx.z]; reduced_combine_kernel_body(zk_b.a, zk_b.at_in, zk_b.ap_in); }
+
 static int lanes_for(uint32_t width) { int g = (int)(width / 4), l = 1; while (l < g && l < 16) l <<= 1; return l; }
 static hipError_t launch_rowdot(const uint32_t* mat, uint64_t ld, uint32_t width, uint64_t rows, const uint32_t* alpha_pow, uint32_t* out_at, hipStream_t s) {
     const int L = lanes_for(width);
@@ -919,15 +985,15 @@ static hipError_t launch_rowdot(const uint32_t* mat, uint64_t ld, uint32_t width
     if (nk <= 4 && rows % (256 / L) == 0 && rows >= rows_per_wg) {
         const dim3 grid((unsigned)((rows + rows_per_wg - 1) / rows_per_wg)), block(256);
         switch (nk) {
-            case 1: hipLaunchKernelGGL(rowdot_regs_kernel<1>, grid, block, 0, s, mat, ld, width, rows, L, alpha_pow, out_at); break;
-            case 2: hipLaunchKernelGGL(rowdot_regs_kernel<2>, grid, block, 0, s, mat, ld, width, rows, L, alpha_pow, out_at); break;
-            case 3: hipLaunchKernelGGL(rowdot_regs_kernel<3>, grid, block, 0, s, mat, ld, width, rows, L, alpha_pow, out_at); break;
-            default: hipLaunchKernelGGL(rowdot_regs_kernel<4>, grid, block, 0, s, mat, ld, width, rows, L, alpha_pow, out_at); break;
+            case 1: ZK_LAUNCH(rowdot_regs_kernel<1>, rowdot_regs_kernel_batch<1>, rowdot_regs_kernel_bargs, grid, block, 0, s, mat, ld, width, rows, L, alpha_pow, out_at); break;
+            case 2: ZK_LAUNCH(rowdot_regs_kernel<2>, rowdot_regs_kernel_batch<2>, rowdot_regs_kernel_bargs, grid, block, 0, s, mat, ld, width, rows, L, alpha_pow, out_at); break;
+            case 3: ZK_LAUNCH(rowdot_regs_kernel<3>, rowdot_regs_kernel_batch<3>, rowdot_regs_kernel_bargs, grid, block, 0, s, mat, ld, width, rows, L, alpha_pow, out_at); break;
+            default: ZK_LAUNCH(rowdot_regs_kernel<4>, rowdot_regs_kernel_batch<4>, rowdot_regs_kernel_bargs, grid, block, 0, s, mat, ld, width, rows, L, alpha_pow, out_at); break;
         }
         return hipGetLastError();
     }
     const uint64_t threads = rows * L;
-    hipLaunchKernelGGL(rowdot_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, s, mat, ld, width, rows, L, alpha_pow, out_at);
+    ZK_LAUNCH(rowdot_kernel, rowdot_kernel_batch, rowdot_kernel_bargs, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, s, mat, ld, width, rows, L, alpha_pow, out_at);
     return hipGetLastError();
 }
 hipError_t launch_reduced_opening(const ReducedArgs& a, uint32_t* scratch_at, hipStream_t s) {
@@ -938,7 +1004,7 @@ hipError_t launch_reduced_opening(const ReducedArgs& a, uint32_t* scratch_at, hi
         e = launch_rowdot(a.plde, a.p_ld, a.p_width, a.rows, a.alpha_pow, scratch_ap, s);
         if (e != hipSuccess) return e;
     }
-    hipLaunchKernelGGL(reduced_combine_kernel, dim3((unsigned)((a.rows + 255) / 256)), dim3(256), 0, s, a, scratch_at, scratch_ap);
+    ZK_LAUNCH(reduced_combine_kernel, reduced_combine_kernel_batch, reduced_combine_kernel_bargs, dim3((unsigned)((a.rows + 255) / 256)), dim3(256), 0, s, a, scratch_at, scratch_ap);
     return hipGetLastError();
 }
 
@@ -947,7 +1013,7 @@ hipError_t launch_reduced_opening(const ReducedArgs& a, uint32_t* scratch_at, hi
 // (sp1-stark generate_permutation_trace, reference Cargo.lock:6172: per-row extension inverses,
 // then a prefix sum.)  Three launches: rows + block-local scan, scan of the block totals, fix-up.
 constexpr int PERM_BLOCK = 256;
-__global__ void __launch_bounds__(PERM_BLOCK) perm_rows_kernel(PermArgs a, uint32_t* __restrict__ block_tot) {
+__device__ __forceinline__ void perm_rows_kernel_body(const PermArgs& a, uint32_t* __restrict__ block_tot) {
     __shared__ uint32_t sh[PERM_BLOCK * 4];
     const uint64_t i = (uint64_t)blockIdx.x * PERM_BLOCK + threadIdx.x;
     Ext sum = ext_zero();
@@ -981,8 +1047,12 @@ __global__ void __launch_bounds__(PERM_BLOCK) perm_rows_kernel(PermArgs a, uint3
     if (i < a.rows) st_ext(a.out + i * a.out_ld + 4 * a.pairs, sum);
     if (threadIdx.x == PERM_BLOCK - 1) st_ext(block_tot + 4 * (uint64_t)blockIdx.x, sum);
 }
+__global__ void __launch_bounds__(PERM_BLOCK) perm_rows_kernel(PermArgs a, uint32_t* __restrict__ block_tot) { perm_rows_kernel_body(a, block_tot); }
+struct perm_rows_kernel_bargs { PermArgs a; uint32_t* block_tot; static perm_rows_kernel_bargs make(PermArgs a, uint32_t* block_tot) { return perm_rows_kernel_bargs{a, block_tot}; } };
+__global__ void __launch_bounds__(PERM_BLOCK) perm_rows_kernel_batch(const perm_rows_kernel_bargs* __restrict__ zk_arr) { const perm_rows_kernel_bargs& zk_b = zk_arr[blockIdx.z]; perm_rows_kernel_body(zk_b.a, zk_b.block_tot); }
+
 // exclusive scan of the block totals, one workgroup (nblocks <= 65536)
-__global__ void __launch_bounds__(1024) perm_scan_blocks_kernel(uint32_t* block_tot, uint32_t nblocks) {
+__device__ __forceinline__ void perm_scan_blocks_kernel_body(uint32_t* block_tot, uint32_t nblocks) {
     __shared__ uint32_t sh[1024 * 4];
     const uint32_t per = (nblocks + 1023) / 1024;
     const uint32_t b0 = threadIdx.x * per;
@@ -1006,21 +1076,29 @@ __global__ void __launch_bounds__(1024) perm_scan_blocks_kernel(uint32_t* block_
         run = ext_add(run, t);
     }
 }
-__global__ void __launch_bounds__(PERM_BLOCK) perm_fixup_kernel(PermArgs a, const uint32_t* __restrict__ block_off) {
+__global__ void __launch_bounds__(1024) perm_scan_blocks_kernel(uint32_t* block_tot, uint32_t nblocks) { perm_scan_blocks_kernel_body(block_tot, nblocks); }
+struct perm_scan_blocks_kernel_bargs { uint32_t* block_tot; uint32_t nblocks; static perm_scan_blocks_kernel_bargs make(uint32_t* block_tot, uint32_t nblocks) { return perm_scan_blocks_kernel_bargs{block_tot, nblocks}; } };
+__global__ void __launch_bounds__(1024) perm_scan_blocks_kernel_batch(const perm_scan_blocks_kernel_bargs* __restrict__ zk_arr) { const perm_scan_blocks_kernel_bargs& zk_b = zk_arr[blockIdx.z]; perm_scan_blocks_kernel_body(zk_b.block_tot, zk_b.nblocks); }
+
+__device__ __forceinline__ void perm_fixup_kernel_body(const PermArgs& a, const uint32_t* __restrict__ block_off) {
     const uint64_t i = (uint64_t)blockIdx.x * PERM_BLOCK + threadIdx.x;
     if (i >= a.rows) return;
     uint32_t* sp = a.out + i * a.out_ld + 4 * a.pairs;
     st_ext(sp, ext_add(ld_ext(sp), ld_ext(block_off + 4 * (uint64_t)blockIdx.x)));
 }
+__global__ void __launch_bounds__(PERM_BLOCK) perm_fixup_kernel(PermArgs a, const uint32_t* __restrict__ block_off) { perm_fixup_kernel_body(a, block_off); }
+struct perm_fixup_kernel_bargs { PermArgs a; const uint32_t* block_off; static perm_fixup_kernel_bargs make(PermArgs a, const uint32_t* block_off) { return perm_fixup_kernel_bargs{a, block_off}; } };
+__global__ void __launch_bounds__(PERM_BLOCK) perm_fixup_kernel_batch(const perm_fixup_kernel_bargs* __restrict__ zk_arr) { const perm_fixup_kernel_bargs& zk_b = zk_arr[blockIdx.z]; perm_fixup_kernel_body(zk_b.a, zk_b.block_off); }
+
 hipError_t launch_perm_trace(const PermArgs& a, uint32_t* block_scratch, hipStream_t s) {
     const uint32_t nblocks = (uint32_t)((a.rows + PERM_BLOCK - 1) / PERM_BLOCK);
-    hipLaunchKernelGGL(perm_rows_kernel, dim3(nblocks), dim3(PERM_BLOCK), 0, s, a, block_scratch);
+    ZK_LAUNCH(perm_rows_kernel, perm_rows_kernel_batch, perm_rows_kernel_bargs, dim3(nblocks), dim3(PERM_BLOCK), 0, s, a, block_scratch);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(perm_scan_blocks_kernel, dim3(1), dim3(1024), 0, s, block_scratch, nblocks);
+    ZK_LAUNCH(perm_scan_blocks_kernel, perm_scan_blocks_kernel_batch, perm_scan_blocks_kernel_bargs, dim3(1), dim3(1024), 0, s, block_scratch, nblocks);
     e = hipGetLastError();
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(perm_fixup_kernel, dim3(nblocks), dim3(PERM_BLOCK), 0, s, a, block_scratch);
+    ZK_LAUNCH(perm_fixup_kernel, perm_fixup_kernel_batch, perm_fixup_kernel_bargs, dim3(nblocks), dim3(PERM_BLOCK), 0, s, a, block_scratch);
     return hipGetLastError();
 }
 
@@ -1034,7 +1112,7 @@ ZK_D uint32_t lookup_mult(const uint32_t* rec, const uint32_t* row) {       // s
     const uint32_t m = rec[1] == 0xFFFFFFFFu ? MONTY_R1 : row[rec[1]];
     return rec[0] ? (m ? P - m : 0u) : m;
 }
-__global__ void __launch_bounds__(PERM_BLOCK) perm_rows_machine_kernel(MachinePermArgs a, uint32_t* __restrict__ block_tot) {
+__device__ __forceinline__ void perm_rows_machine_kernel_body(const MachinePermArgs& a, uint32_t* __restrict__ block_tot) {
     __shared__ uint32_t sh[PERM_BLOCK * 4];
     const uint64_t i = (uint64_t)blockIdx.x * PERM_BLOCK + threadIdx.x;
     Ext sum = ext_zero();
@@ -1072,20 +1150,24 @@ __global__ void __launch_bounds__(PERM_BLOCK) perm_rows_machine_kernel(MachinePe
     if (i < a.rows) st_ext(a.out + i * a.out_ld + 4 * a.lk.cols, sum);
     if (threadIdx.x == PERM_BLOCK - 1) st_ext(block_tot + 4 * (uint64_t)blockIdx.x, sum);
 }
+__global__ void __launch_bounds__(PERM_BLOCK) perm_rows_machine_kernel(MachinePermArgs a, uint32_t* __restrict__ block_tot) { perm_rows_machine_kernel_body(a, block_tot); }
+struct perm_rows_machine_kernel_bargs { MachinePermArgs a; uint32_t* block_tot; static perm_rows_machine_kernel_bargs make(MachinePermArgs a, uint32_t* block_tot) { return perm_rows_machine_kernel_bargs{a, block_tot}; } };
+__global__ void __launch_bounds__(PERM_BLOCK) perm_rows_machine_kernel_batch(const perm_rows_machine_kernel_bargs* __restrict__ zk_arr) { const perm_rows_machine_kernel_bargs& zk_b = zk_arr[blockIdx.z]; perm_rows_machine_kernel_body(zk_b.a, zk_b.block_tot); }
+
 hipError_t launch_perm_trace_machine(const MachinePermArgs& a, uint32_t* block_scratch, hipStream_t s) {
     const uint32_t nblocks = (uint32_t)((a.rows + PERM_BLOCK - 1) / PERM_BLOCK);
-    hipLaunchKernelGGL(perm_rows_machine_kernel, dim3(nblocks), dim3(PERM_BLOCK), 0, s, a, block_scratch);
+    ZK_LAUNCH(perm_rows_machine_kernel, perm_rows_machine_kernel_batch, perm_rows_machine_kernel_bargs, dim3(nblocks), dim3(PERM_BLOCK), 0, s, a, block_scratch);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(perm_scan_blocks_kernel, dim3(1), dim3(1024), 0, s, block_scratch, nblocks);
+    ZK_LAUNCH(perm_scan_blocks_kernel, perm_scan_blocks_kernel_batch, perm_scan_blocks_kernel_bargs, dim3(1), dim3(1024), 0, s, block_scratch, nblocks);
     e = hipGetLastError();
     if (e != hipSuccess) return e;
     PermArgs fix{};                                   // the fix-up only needs where the running-sum column lives
     fix.rows = a.rows; fix.pairs = a.lk.cols; fix.out = a.out; fix.out_ld = a.out_ld;
-    hipLaunchKernelGGL(perm_fixup_kernel, dim3(nblocks), dim3(PERM_BLOCK), 0, s, fix, block_scratch);
+    ZK_LAUNCH(perm_fixup_kernel, perm_fixup_kernel_batch, perm_fixup_kernel_bargs, dim3(nblocks), dim3(PERM_BLOCK), 0, s, fix, block_scratch);
     return hipGetLastError();
 }
-__global__ void __launch_bounds__(256) lookup_addend_kernel(MachineQuotArgs a) {
+__device__ __forceinline__ void lookup_addend_kernel_body(const MachineQuotArgs& a) {
     const int H = a.log_n + a.log_qd;
     const uint32_t m = 1u << H;
     const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
@@ -1122,15 +1204,19 @@ __global__ void __launch_bounds__(256) lookup_addend_kernel(MachineQuotArgs a) {
     r = ext_add(r, ext_mul_dev(F3, ext_sub(S, a.cumsum)));
     st_ext(a.addend + 4 * (uint64_t)p, r);
 }
+__global__ void __launch_bounds__(256) lookup_addend_kernel(MachineQuotArgs a) { lookup_addend_kernel_body(a); }
+struct lookup_addend_kernel_bargs { MachineQuotArgs a; static lookup_addend_kernel_bargs make(MachineQuotArgs a) { return lookup_addend_kernel_bargs{a}; } };
+__global__ void __launch_bounds__(256) lookup_addend_kernel_batch(const lookup_addend_kernel_bargs* __restrict__ zk_arr) { const lookup_addend_kernel_bargs& zk_b = zk_arr[blockIdx.z]; lookup_addend_kernel_body(zk_b.a); }
+
 hipError_t launch_lookup_addend(const MachineQuotArgs& a, hipStream_t s) {
     const uint64_t m = 1ull << (a.log_n + a.log_qd);
-    hipLaunchKernelGGL(lookup_addend_kernel, dim3((unsigned)((m + 255) / 256)), dim3(256), 0, s, a);
+    ZK_LAUNCH(lookup_addend_kernel, lookup_addend_kernel_batch, lookup_addend_kernel_bargs, dim3((unsigned)((m + 255) / 256)), dim3(256), 0, s, a);
     return hipGetLastError();
 }
 
 // ------------------------------------------------------------------ FRI fold (arity 2)
 // out[i] = (e0 + e1)/2 + beta (e0 - e1) / (2 x_i),  itw[i] = 1 / (2 x_i)
-__global__ void __launch_bounds__(256) fri_fold_kernel(const uint32_t* in, uint32_t* out, const uint32_t* itw, uint64_t half, Ext beta) {
+__device__ __forceinline__ void fri_fold_kernel_body(const uint32_t* in, uint32_t* out, const uint32_t* itw, uint64_t half, const Ext& beta) {
     const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= half) return;
     const Ext e0 = ld_ext(in + 8 * i), e1 = ld_ext(in + 8 * i + 4);
@@ -1138,13 +1224,16 @@ __global__ void __launch_bounds__(256) fri_fold_kernel(const uint32_t* in, uint3
     const Ext d = ext_mul_base_dev(ext_sub(e0, e1), itw[i]);
     st_ext(out + 4 * i, ext_add(s, ext_mul_dev(beta, d)));
 }
+__global__ void __launch_bounds__(256) fri_fold_kernel(const uint32_t* in, uint32_t* out, const uint32_t* itw, uint64_t half, Ext beta) { fri_fold_kernel_body(in, out, itw, half, beta); }
+struct fri_fold_kernel_bargs { const uint32_t* in; uint32_t* out; const uint32_t* itw; uint64_t half; Ext beta; static fri_fold_kernel_bargs make(const uint32_t* in, uint32_t* out, const uint32_t* itw, uint64_t half, Ext beta) { return fri_fold_kernel_bargs{in, out, itw, half, beta}; } };
+__global__ void __launch_bounds__(256) fri_fold_kernel_batch(const fri_fold_kernel_bargs* __restrict__ zk_arr) { const fri_fold_kernel_bargs& zk_b = zk_arr[blockIdx.z]; fri_fold_kernel_body(zk_b.in, zk_b.out, zk_b.itw, zk_b.half, zk_b.beta); }
+
 hipError_t launch_fri_fold(const uint32_t* in, uint32_t* out, const uint32_t* itw, uint64_t half, const Ext& beta, hipStream_t s) {
-    hipLaunchKernelGGL(fri_fold_kernel, dim3((unsigned)((half + 255) / 256)), dim3(256), 0, s, in, out, itw, half, beta);
+    ZK_LAUNCH(fri_fold_kernel, fri_fold_kernel_batch, fri_fold_kernel_bargs, dim3((unsigned)((half + 255) / 256)), dim3(256), 0, s, in, out, itw, half, beta);
     return hipGetLastError();
 }
 
-__global__ void __launch_bounds__(256) fri_fold_dev_kernel(const uint32_t* in, uint32_t* out, const uint32_t* itw, uint64_t half,
-                                                           const uint32_t* beta_ptr, int squarings) {
+__device__ __forceinline__ void fri_fold_dev_kernel_body(const uint32_t* in, uint32_t* out, const uint32_t* itw, uint64_t half, const uint32_t* beta_ptr, int squarings) {
     const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= half) return;
     Ext beta = ld_ext(beta_ptr);
@@ -1154,27 +1243,35 @@ __global__ void __launch_bounds__(256) fri_fold_dev_kernel(const uint32_t* in, u
     const Ext d = ext_mul_base_dev(ext_sub(e0, e1), itw[i]);
     st_ext(out + 4 * i, ext_add(s, ext_mul_dev(beta, d)));
 }
+__global__ void __launch_bounds__(256) fri_fold_dev_kernel(const uint32_t* in, uint32_t* out, const uint32_t* itw, uint64_t half, const uint32_t* beta_ptr, int squarings) { fri_fold_dev_kernel_body(in, out, itw, half, beta_ptr, squarings); }
+struct fri_fold_dev_kernel_bargs { const uint32_t* in; uint32_t* out; const uint32_t* itw; uint64_t half; const uint32_t* beta_ptr; int squarings; static fri_fold_dev_kernel_bargs make(const uint32_t* in, uint32_t* out, const uint32_t* itw, uint64_t half, const uint32_t* beta_ptr, int squarings) { return fri_fold_dev_kernel_bargs{in, out, itw, half, beta_ptr, squarings}; } };
+__global__ void __launch_bounds__(256) fri_fold_dev_kernel_batch(const fri_fold_dev_kernel_bargs* __restrict__ zk_arr) { const fri_fold_dev_kernel_bargs& zk_b = zk_arr[blockIdx.z]; fri_fold_dev_kernel_body(zk_b.in, zk_b.out, zk_b.itw, zk_b.half, zk_b.beta_ptr, zk_b.squarings); }
+
 hipError_t launch_fri_fold_dev(const uint32_t* in, uint32_t* out, const uint32_t* itw, uint64_t half, const uint32_t* beta_ptr,
                                int squarings, hipStream_t s) {
-    hipLaunchKernelGGL(fri_fold_dev_kernel, dim3((unsigned)((half + 255) / 256)), dim3(256), 0, s, in, out, itw, half, beta_ptr, squarings);
+    ZK_LAUNCH(fri_fold_dev_kernel, fri_fold_dev_kernel_batch, fri_fold_dev_kernel_bargs, dim3((unsigned)((half + 255) / 256)), dim3(256), 0, s, in, out, itw, half, beta_ptr, squarings);
     return hipGetLastError();
 }
 
 // dst[i] += src[i] over `count` extension elements (a shorter chip's reduced openings joining the FRI vector)
-__global__ void __launch_bounds__(256) ext_add_kernel(uint32_t* dst, const uint32_t* src, uint64_t count) {
+__device__ __forceinline__ void ext_add_kernel_body(uint32_t* dst, const uint32_t* src, uint64_t count) {
     const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= count) return;
     st_ext(dst + 4 * i, ext_add(ld_ext(dst + 4 * i), ld_ext(src + 4 * i)));
 }
+__global__ void __launch_bounds__(256) ext_add_kernel(uint32_t* dst, const uint32_t* src, uint64_t count) { ext_add_kernel_body(dst, src, count); }
+struct ext_add_kernel_bargs { uint32_t* dst; const uint32_t* src; uint64_t count; static ext_add_kernel_bargs make(uint32_t* dst, const uint32_t* src, uint64_t count) { return ext_add_kernel_bargs{dst, src, count}; } };
+__global__ void __launch_bounds__(256) ext_add_kernel_batch(const ext_add_kernel_bargs* __restrict__ zk_arr) { const ext_add_kernel_bargs& zk_b = zk_arr[blockIdx.z]; ext_add_kernel_body(zk_b.dst, zk_b.src, zk_b.count); }
+
 hipError_t launch_ext_add(uint32_t* dst, const uint32_t* src, uint64_t count, hipStream_t s) {
-    hipLaunchKernelGGL(ext_add_kernel, dim3((unsigned)((count + 255) / 256)), dim3(256), 0, s, dst, src, count);
+    ZK_LAUNCH(ext_add_kernel, ext_add_kernel_batch, ext_add_kernel_bargs, dim3((unsigned)((count + 255) / 256)), dim3(256), 0, s, dst, src, count);
     return hipGetLastError();
 }
 
 // ------------------------------------------------------------------ proof-of-work search
 // state: sponge state with the pending inputs already written to words [0, slot);
 // candidate w goes to word `slot`; hit when canonical(permute(state)[7]) & mask == 0.
-__global__ void __launch_bounds__(256) grind_kernel(GrindArgs a, uint32_t base, uint32_t* result) {
+__device__ __forceinline__ void grind_kernel_body(const GrindArgs& a, uint32_t base, uint32_t* result) {
     const uint32_t w = base + blockIdx.x * blockDim.x + threadIdx.x;
     if (w >= P) return;
     uint32_t s[16];
@@ -1186,24 +1283,32 @@ __global__ void __launch_bounds__(256) grind_kernel(GrindArgs a, uint32_t base, 
     p2_permute_dev(s);
     if ((from_monty(s[7]) & a.mask) == 0) atomicMin(result, w);
 }
+__global__ void __launch_bounds__(256) grind_kernel(GrindArgs a, uint32_t base, uint32_t* result) { grind_kernel_body(a, base, result); }
+struct grind_kernel_bargs { GrindArgs a; uint32_t base; uint32_t* result; static grind_kernel_bargs make(GrindArgs a, uint32_t base, uint32_t* result) { return grind_kernel_bargs{a, base, result}; } };
+__global__ void __launch_bounds__(256) grind_kernel_batch(const grind_kernel_bargs* __restrict__ zk_arr) { const grind_kernel_bargs& zk_b = zk_arr[blockIdx.z]; grind_kernel_body(zk_b.a, zk_b.base, zk_b.result); }
+
 hipError_t launch_grind(const GrindArgs& a, uint32_t base, uint32_t count, uint32_t* result, hipStream_t s) {
-    hipLaunchKernelGGL(grind_kernel, dim3((count + 255) / 256), dim3(256), 0, s, a, base, result);
+    ZK_LAUNCH(grind_kernel, grind_kernel_batch, grind_kernel_bargs, dim3((count + 255) / 256), dim3(256), 0, s, a, base, result);
     return hipGetLastError();
 }
 
 // ------------------------------------------------------------------ query gather
 // one wave per descriptor: copy nwords from src, Montgomery -> canonical, to dst + off
-__global__ void __launch_bounds__(256) gather_kernel(const GatherDesc* descs, uint32_t ndesc, uint32_t* dst) {
+__device__ __forceinline__ void gather_kernel_body(const GatherDesc* descs, uint32_t ndesc, uint32_t* dst) {
     const uint32_t d = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     const uint32_t lane = threadIdx.x & 63;
     if (d >= ndesc) return;
     const GatherDesc g = descs[d];
     for (uint32_t i = lane; i < g.nwords; i += 64) dst[g.dst_off + i] = from_monty(g.src[i]);
 }
+__global__ void __launch_bounds__(256) gather_kernel(const GatherDesc* descs, uint32_t ndesc, uint32_t* dst) { gather_kernel_body(descs, ndesc, dst); }
+struct gather_kernel_bargs { const GatherDesc* descs; uint32_t ndesc; uint32_t* dst; static gather_kernel_bargs make(const GatherDesc* descs, uint32_t ndesc, uint32_t* dst) { return gather_kernel_bargs{descs, ndesc, dst}; } };
+__global__ void __launch_bounds__(256) gather_kernel_batch(const gather_kernel_bargs* __restrict__ zk_arr) { const gather_kernel_bargs& zk_b = zk_arr[blockIdx.z]; gather_kernel_body(zk_b.descs, zk_b.ndesc, zk_b.dst); }
+
 hipError_t launch_gather(const GatherDesc* descs, uint32_t ndesc, uint32_t* dst, hipStream_t s) {
     if (ndesc == 0) return hipSuccess;
     const uint64_t threads = (uint64_t)ndesc * 64;
-    hipLaunchKernelGGL(gather_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, s, descs, ndesc, dst);
+    ZK_LAUNCH(gather_kernel, gather_kernel_batch, gather_kernel_bargs, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, s, descs, ndesc, dst);
     return hipGetLastError();
 }
 

@@ -7,6 +7,7 @@
 // Values are a counter-based splitmix64 stream reduced mod p, written in Montgomery form.
 #include "babybear.cuh"
 #include "kernels.h"
+#include "batch.h"
 
 namespace zk {
 
@@ -21,7 +22,7 @@ __device__ __forceinline__ uint32_t synth_value(uint64_t seed, uint64_t index) {
     return (uint32_t)(mix64(seed + index * 0x9E3779B97F4A7C15ull) % P);
 }
 
-__global__ void fill_uniform_kernel(uint32_t* out, uint64_t ld, uint64_t seed, uint64_t rows, uint32_t width) {
+__device__ __forceinline__ void fill_uniform_kernel_body(uint32_t* out, uint64_t ld, uint64_t seed, uint64_t rows, uint32_t width) {
     const uint64_t total = rows * width;
     for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total;
          i += (uint64_t)gridDim.x * blockDim.x) {
@@ -29,17 +30,21 @@ __global__ void fill_uniform_kernel(uint32_t* out, uint64_t ld, uint64_t seed, u
         out[r * ld + c] = to_monty(synth_value(seed, i));
     }
 }
+__global__ void fill_uniform_kernel(uint32_t* out, uint64_t ld, uint64_t seed, uint64_t rows, uint32_t width) { fill_uniform_kernel_body(out, ld, seed, rows, width); }
+struct fill_uniform_kernel_bargs { uint32_t* out; uint64_t ld; uint64_t seed; uint64_t rows; uint32_t width; static fill_uniform_kernel_bargs make(uint32_t* out, uint64_t ld, uint64_t seed, uint64_t rows, uint32_t width) { return fill_uniform_kernel_bargs{out, ld, seed, rows, width}; } };
+__global__ void fill_uniform_kernel_batch(const fill_uniform_kernel_bargs* __restrict__ zk_arr) { const fill_uniform_kernel_bargs& zk_b = zk_arr[blockIdx.z]; fill_uniform_kernel_body(zk_b.out, zk_b.ld, zk_b.seed, zk_b.rows, zk_b.width); }
+
 hipError_t launch_fill_uniform(uint32_t* out, uint64_t ld, uint64_t seed, uint64_t rows, uint32_t width, hipStream_t s) {
     if (rows == 0 || width == 0) return hipSuccess;
     uint64_t total = rows * width;
     unsigned blocks = (unsigned)((total + 255) / 256 < 16384 ? (total + 255) / 256 : 16384);
-    hipLaunchKernelGGL(fill_uniform_kernel, dim3(blocks), dim3(256), 0, s, out, ld, seed, rows, width);
+    ZK_LAUNCH(fill_uniform_kernel, fill_uniform_kernel_batch, fill_uniform_kernel_bargs, dim3(blocks), dim3(256), 0, s, out, ld, seed, rows, width);
     return hipGetLastError();
 }
 
 // synthetic AIR trace: group g = columns 4g..4g+3 = (a, b, c, d)
 //   a, b uniform;  c = a*a*b + (g+1);  d[0] = 5g+7;  d[i] = a[i-1]*b[i-1] + c[i-1] + (2g+3)
-__global__ void gen_trace_kernel(uint32_t* out, uint64_t ld, uint64_t seed, uint64_t rows, uint32_t width) {
+__device__ __forceinline__ void gen_trace_kernel_body(uint32_t* out, uint64_t ld, uint64_t seed, uint64_t rows, uint32_t width) {
     const uint32_t G = width / 4;
     const uint64_t total = rows * G;
     for (uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; t < total;
@@ -64,11 +69,15 @@ __global__ void gen_trace_kernel(uint32_t* out, uint64_t ld, uint64_t seed, uint
         else { p[0] = a; p[1] = b; p[2] = c; p[3] = d; }
     }
 }
+__global__ void gen_trace_kernel(uint32_t* out, uint64_t ld, uint64_t seed, uint64_t rows, uint32_t width) { gen_trace_kernel_body(out, ld, seed, rows, width); }
+struct gen_trace_kernel_bargs { uint32_t* out; uint64_t ld; uint64_t seed; uint64_t rows; uint32_t width; static gen_trace_kernel_bargs make(uint32_t* out, uint64_t ld, uint64_t seed, uint64_t rows, uint32_t width) { return gen_trace_kernel_bargs{out, ld, seed, rows, width}; } };
+__global__ void gen_trace_kernel_batch(const gen_trace_kernel_bargs* __restrict__ zk_arr) { const gen_trace_kernel_bargs& zk_b = zk_arr[blockIdx.z]; gen_trace_kernel_body(zk_b.out, zk_b.ld, zk_b.seed, zk_b.rows, zk_b.width); }
+
 hipError_t launch_gen_trace(uint32_t* out, uint64_t ld, uint64_t seed, uint64_t rows, uint32_t width, hipStream_t s) {
     if (rows == 0 || width < 4) return hipSuccess;
     uint64_t total = rows * (width / 4);
     unsigned blocks = (unsigned)((total + 255) / 256 < 16384 ? (total + 255) / 256 : 16384);
-    hipLaunchKernelGGL(gen_trace_kernel, dim3(blocks), dim3(256), 0, s, out, ld, seed, rows, width);
+    ZK_LAUNCH(gen_trace_kernel, gen_trace_kernel_batch, gen_trace_kernel_bargs, dim3(blocks), dim3(256), 0, s, out, ld, seed, rows, width);
     return hipGetLastError();
 }
 
@@ -76,8 +85,7 @@ hipError_t launch_gen_trace(uint32_t* out, uint64_t ld, uint64_t seed, uint64_t 
 // (a, b) under the row permutation pi(i) = 5 i + 3 mod N (the LogUp workload)
 // recv_seed / recv_width: the stream and row pitch the RECEIVER groups read (the table itself, or -- lookups between two
 // tables of equal height -- the partner table)
-__global__ void gen_trace_logup_kernel(uint32_t* out, uint64_t ld, uint64_t seed, uint64_t rows, uint32_t width, uint32_t pairs,
-                                       uint64_t recv_seed, uint32_t recv_width) {
+__device__ __forceinline__ void gen_trace_logup_kernel_body(uint32_t* out, uint64_t ld, uint64_t seed, uint64_t rows, uint32_t width, uint32_t pairs, uint64_t recv_seed, uint32_t recv_width) {
     const uint32_t G = width / 4;
     const uint64_t total = rows * G;
     for (uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; t < total;
@@ -106,12 +114,16 @@ __global__ void gen_trace_logup_kernel(uint32_t* out, uint64_t ld, uint64_t seed
         p[0] = a; p[1] = b; p[2] = c; p[3] = d;
     }
 }
+__global__ void gen_trace_logup_kernel(uint32_t* out, uint64_t ld, uint64_t seed, uint64_t rows, uint32_t width, uint32_t pairs, uint64_t recv_seed, uint32_t recv_width) { gen_trace_logup_kernel_body(out, ld, seed, rows, width, pairs, recv_seed, recv_width); }
+struct gen_trace_logup_kernel_bargs { uint32_t* out; uint64_t ld; uint64_t seed; uint64_t rows; uint32_t width; uint32_t pairs; uint64_t recv_seed; uint32_t recv_width; static gen_trace_logup_kernel_bargs make(uint32_t* out, uint64_t ld, uint64_t seed, uint64_t rows, uint32_t width, uint32_t pairs, uint64_t recv_seed, uint32_t recv_width) { return gen_trace_logup_kernel_bargs{out, ld, seed, rows, width, pairs, recv_seed, recv_width}; } };
+__global__ void gen_trace_logup_kernel_batch(const gen_trace_logup_kernel_bargs* __restrict__ zk_arr) { const gen_trace_logup_kernel_bargs& zk_b = zk_arr[blockIdx.z]; gen_trace_logup_kernel_body(zk_b.out, zk_b.ld, zk_b.seed, zk_b.rows, zk_b.width, zk_b.pairs, zk_b.recv_seed, zk_b.recv_width); }
+
 hipError_t launch_gen_trace_logup(uint32_t* out, uint64_t ld, uint64_t seed, uint64_t rows, uint32_t width, uint32_t pairs,
                                   uint64_t recv_seed, uint32_t recv_width, hipStream_t s) {
     if (rows == 0 || width < 4) return hipSuccess;
     uint64_t total = rows * (width / 4);
     unsigned blocks = (unsigned)((total + 255) / 256 < 16384 ? (total + 255) / 256 : 16384);
-    hipLaunchKernelGGL(gen_trace_logup_kernel, dim3(blocks), dim3(256), 0, s, out, ld, seed, rows, width, pairs, recv_seed, recv_width);
+    ZK_LAUNCH(gen_trace_logup_kernel, gen_trace_logup_kernel_batch, gen_trace_logup_kernel_bargs, dim3(blocks), dim3(256), 0, s, out, ld, seed, rows, width, pairs, recv_seed, recv_width);
     return hipGetLastError();
 }
 
@@ -119,8 +131,7 @@ hipError_t launch_gen_trace_logup(uint32_t* out, uint64_t ld, uint64_t seed, uin
 // out[c][r'] = in[r][c] with r' = r or bitrev(r): moves between RISC Zero's column-major
 // [count][size] polynomials and the row-major [size][count] matrices the NTT kernels stream.
 // 32 x 32 tiles through LDS (pitch 33): 128-byte segments on both sides.
-__global__ void __launch_bounds__(256) transpose_kernel(const uint32_t* __restrict__ in, uint32_t* __restrict__ out,
-                                                        uint64_t rows, uint64_t cols, int rev_bits_in, int rev_bits_out) {
+__device__ __forceinline__ void transpose_kernel_body(const uint32_t* __restrict__ in, uint32_t* __restrict__ out, uint64_t rows, uint64_t cols, int rev_bits_in, int rev_bits_out) {
     __shared__ uint32_t tile[32][33];
     const uint64_t r0 = (uint64_t)blockIdx.y * 32, c0 = (uint64_t)blockIdx.x * 32;
     const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;     // 32 x 8
@@ -140,23 +151,31 @@ __global__ void __launch_bounds__(256) transpose_kernel(const uint32_t* __restri
         }
     }
 }
+__global__ void __launch_bounds__(256) transpose_kernel(const uint32_t* __restrict__ in, uint32_t* __restrict__ out, uint64_t rows, uint64_t cols, int rev_bits_in, int rev_bits_out) { transpose_kernel_body(in, out, rows, cols, rev_bits_in, rev_bits_out); }
+struct transpose_kernel_bargs { const uint32_t* in; uint32_t* out; uint64_t rows; uint64_t cols; int rev_bits_in; int rev_bits_out; static transpose_kernel_bargs make(const uint32_t* in, uint32_t* out, uint64_t rows, uint64_t cols, int rev_bits_in, int rev_bits_out) { return transpose_kernel_bargs{in, out, rows, cols, rev_bits_in, rev_bits_out}; } };
+__global__ void __launch_bounds__(256) transpose_kernel_batch(const transpose_kernel_bargs* __restrict__ zk_arr) { const transpose_kernel_bargs& zk_b = zk_arr[blockIdx.z]; transpose_kernel_body(zk_b.in, zk_b.out, zk_b.rows, zk_b.cols, zk_b.rev_bits_in, zk_b.rev_bits_out); }
+
 // in: [rows][cols] row-major; out: [cols][rows].  rev_bits_in / rev_bits_out (0 = off) bit-reverse the
 // COLUMN index of `in` on the read side / on the write side (it becomes the row index of `out`).
 hipError_t launch_transpose(const uint32_t* in, uint32_t* out, uint64_t rows, uint64_t cols, int rev_bits_in, int rev_bits_out, hipStream_t s) {
     if (rows == 0 || cols == 0) return hipSuccess;
     dim3 grid((unsigned)((cols + 31) / 32), (unsigned)((rows + 31) / 32));
-    hipLaunchKernelGGL(transpose_kernel, grid, dim3(256), 0, s, in, out, rows, cols, rev_bits_in, rev_bits_out);
+    ZK_LAUNCH(transpose_kernel, transpose_kernel_batch, transpose_kernel_bargs, grid, dim3(256), 0, s, in, out, rows, cols, rev_bits_in, rev_bits_out);
     return hipGetLastError();
 }
 
-__global__ void convert_kernel(const uint32_t* in, uint32_t* out, uint64_t n, bool to_m) {
+__device__ __forceinline__ void convert_kernel_body(const uint32_t* in, uint32_t* out, uint64_t n, bool to_m) {
     for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x)
         out[i] = to_m ? fmul(in[i], MONTY_R2) : from_monty(in[i]);
 }
+__global__ void convert_kernel(const uint32_t* in, uint32_t* out, uint64_t n, bool to_m) { convert_kernel_body(in, out, n, to_m); }
+struct convert_kernel_bargs { const uint32_t* in; uint32_t* out; uint64_t n; bool to_m; static convert_kernel_bargs make(const uint32_t* in, uint32_t* out, uint64_t n, bool to_m) { return convert_kernel_bargs{in, out, n, to_m}; } };
+__global__ void convert_kernel_batch(const convert_kernel_bargs* __restrict__ zk_arr) { const convert_kernel_bargs& zk_b = zk_arr[blockIdx.z]; convert_kernel_body(zk_b.in, zk_b.out, zk_b.n, zk_b.to_m); }
+
 hipError_t launch_convert(const uint32_t* in, uint32_t* out, uint64_t n, bool to_monty_form, hipStream_t s) {
     if (n == 0) return hipSuccess;
     unsigned blocks = (unsigned)((n + 255) / 256 < 16384 ? (n + 255) / 256 : 16384);
-    hipLaunchKernelGGL(convert_kernel, dim3(blocks), dim3(256), 0, s, in, out, n, to_monty_form);
+    ZK_LAUNCH(convert_kernel, convert_kernel_batch, convert_kernel_bargs, dim3(blocks), dim3(256), 0, s, in, out, n, to_monty_form);
     return hipGetLastError();
 }
 
@@ -165,8 +184,7 @@ hipError_t launch_convert(const uint32_t* in, uint32_t* out, uint64_t n, bool to
 // need N >= 32), so O(N^2) with N <= 16 is the simplest correct thing.
 // out[row(k)][c] = scale * sum_j in[j][c] * (shift * w^k)^j,  k < 2^log_out;  w of order 2^log_out (or its inverse),
 // row(k) = k or bitrev(k).  Forward DFT: log_out = log_n, shift 1.  Inverse: w^-1, scale 1/N.  LDE: coefficients in.
-__global__ void __launch_bounds__(256) small_eval_kernel(const uint32_t* in, uint64_t in_ld, uint32_t* out, uint64_t out_ld, int log_n, int log_out,
-                                                         uint32_t width, uint32_t w, uint32_t shift, uint32_t scale, int bitrev_out) {
+__device__ __forceinline__ void small_eval_kernel_body(const uint32_t* in, uint64_t in_ld, uint32_t* out, uint64_t out_ld, int log_n, int log_out, uint32_t width, uint32_t w, uint32_t shift, uint32_t scale, int bitrev_out) {
     const uint32_t idx = blockIdx.x * blockDim.x + threadIdx.x;
     const uint32_t rows_out = 1u << log_out, n = 1u << log_n;
     if (idx >= rows_out * width) return;
@@ -177,11 +195,60 @@ __global__ void __launch_bounds__(256) small_eval_kernel(const uint32_t* in, uin
     const uint32_t row = bitrev_out ? (log_out ? (__brev(k) >> (32 - log_out)) : 0u) : k;
     out[(uint64_t)row * out_ld + c] = fmul(acc, scale);
 }
+__global__ void __launch_bounds__(256) small_eval_kernel(const uint32_t* in, uint64_t in_ld, uint32_t* out, uint64_t out_ld, int log_n, int log_out, uint32_t width, uint32_t w, uint32_t shift, uint32_t scale, int bitrev_out) { small_eval_kernel_body(in, in_ld, out, out_ld, log_n, log_out, width, w, shift, scale, bitrev_out); }
+struct small_eval_kernel_bargs { const uint32_t* in; uint64_t in_ld; uint32_t* out; uint64_t out_ld; int log_n; int log_out; uint32_t width; uint32_t w; uint32_t shift; uint32_t scale; int bitrev_out; static small_eval_kernel_bargs make(const uint32_t* in, uint64_t in_ld, uint32_t* out, uint64_t out_ld, int log_n, int log_out, uint32_t width, uint32_t w, uint32_t shift, uint32_t scale, int bitrev_out) { return small_eval_kernel_bargs{in, in_ld, out, out_ld, log_n, log_out, width, w, shift, scale, bitrev_out}; } };
+__global__ void __launch_bounds__(256) small_eval_kernel_batch(const small_eval_kernel_bargs* __restrict__ zk_arr) { const small_eval_kernel_bargs& zk_b = zk_arr[blockIdx.z]; small_eval_kernel_body(zk_b.in, zk_b.in_ld, zk_b.out, zk_b.out_ld, zk_b.log_n, zk_b.log_out, zk_b.width, zk_b.w, zk_b.shift, zk_b.scale, zk_b.bitrev_out); }
+
 hipError_t launch_small_eval(const uint32_t* in, uint64_t in_ld, uint32_t* out, uint64_t out_ld, int log_n, int log_out, uint32_t width,
                              uint32_t w, uint32_t shift, uint32_t scale, int bitrev_out, hipStream_t s) {
     const uint32_t total = (1u << log_out) * width;
-    hipLaunchKernelGGL(small_eval_kernel, dim3((total + 255) / 256), dim3(256), 0, s, in, in_ld, out, out_ld, log_n, log_out, width, w, shift, scale, bitrev_out);
+    ZK_LAUNCH(small_eval_kernel, small_eval_kernel_batch, small_eval_kernel_bargs, dim3((total + 255) / 256), dim3(256), 0, s, in, in_ld, out, out_ld, log_n, log_out, width, w, shift, scale, bitrev_out);
     return hipGetLastError();
 }
 
+
+// ---- plain copies and fills as kernels: in a lock-step batch (batch.h) the members' small copies and memsets merge into one launch
+__device__ __forceinline__ void copy_bytes_kernel_body(uint8_t* dst, const uint8_t* src, uint64_t bytes) {
+    const uint64_t tid = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x, nthr = (uint64_t)gridDim.x * blockDim.x;
+    if ((((uintptr_t)dst | (uintptr_t)src) & 3) == 0) {
+        const uint64_t words = bytes >> 2;
+        for (uint64_t i = tid; i < words; i += nthr) ((uint32_t*)dst)[i] = ((const uint32_t*)src)[i];
+        for (uint64_t i = (words << 2) + tid; i < bytes; i += nthr) dst[i] = src[i];
+    } else {
+        for (uint64_t i = tid; i < bytes; i += nthr) dst[i] = src[i];
+    }
+}
+__global__ void __launch_bounds__(256) copy_bytes_kernel(uint8_t* dst, const uint8_t* src, uint64_t bytes) { copy_bytes_kernel_body(dst, src, bytes); }
+struct copy_bytes_kernel_bargs { uint8_t* dst; const uint8_t* src; uint64_t bytes; static copy_bytes_kernel_bargs make(uint8_t* dst, const uint8_t* src, uint64_t bytes) { return copy_bytes_kernel_bargs{dst, src, bytes}; } };
+__global__ void __launch_bounds__(256) copy_bytes_kernel_batch(const copy_bytes_kernel_bargs* __restrict__ zk_arr) { const copy_bytes_kernel_bargs& zk_b = zk_arr[blockIdx.z]; copy_bytes_kernel_body(zk_b.dst, zk_b.src, zk_b.bytes); }
+
+hipError_t launch_copy_bytes(void* dst, const void* src, size_t bytes, hipStream_t s) {
+    if (bytes == 0) return hipSuccess;
+    uint64_t blocks = (bytes / 4 + 255) / 256;
+    if (blocks > 2048) blocks = 2048;
+    ZK_LAUNCH(copy_bytes_kernel, copy_bytes_kernel_batch, copy_bytes_kernel_bargs, dim3((unsigned)blocks), dim3(256), 0, s, (uint8_t*)dst, (const uint8_t*)src, (uint64_t)bytes);
+    return hipGetLastError();
+}
+__device__ __forceinline__ void fill_bytes_kernel_body(uint8_t* dst, uint32_t byte, uint64_t bytes) {
+    const uint64_t tid = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x, nthr = (uint64_t)gridDim.x * blockDim.x;
+    if (((uintptr_t)dst & 3) == 0) {
+        const uint64_t words = bytes >> 2;
+        const uint32_t w = byte * 0x01010101u;
+        for (uint64_t i = tid; i < words; i += nthr) ((uint32_t*)dst)[i] = w;
+        for (uint64_t i = (words << 2) + tid; i < bytes; i += nthr) dst[i] = (uint8_t)byte;
+    } else {
+        for (uint64_t i = tid; i < bytes; i += nthr) dst[i] = (uint8_t)byte;
+    }
+}
+__global__ void __launch_bounds__(256) fill_bytes_kernel(uint8_t* dst, uint32_t byte, uint64_t bytes) { fill_bytes_kernel_body(dst, byte, bytes); }
+struct fill_bytes_kernel_bargs { uint8_t* dst; uint32_t byte; uint64_t bytes; static fill_bytes_kernel_bargs make(uint8_t* dst, uint32_t byte, uint64_t bytes) { return fill_bytes_kernel_bargs{dst, byte, bytes}; } };
+__global__ void __launch_bounds__(256) fill_bytes_kernel_batch(const fill_bytes_kernel_bargs* __restrict__ zk_arr) { const fill_bytes_kernel_bargs& zk_b = zk_arr[blockIdx.z]; fill_bytes_kernel_body(zk_b.dst, zk_b.byte, zk_b.bytes); }
+
+hipError_t launch_fill_bytes(void* dst, int byte, size_t bytes, hipStream_t s) {
+    if (bytes == 0) return hipSuccess;
+    uint64_t blocks = (bytes / 4 + 255) / 256;
+    if (blocks > 2048) blocks = 2048;
+    ZK_LAUNCH(fill_bytes_kernel, fill_bytes_kernel_batch, fill_bytes_kernel_bargs, dim3((unsigned)blocks), dim3(256), 0, s, (uint8_t*)dst, (uint32_t)(byte & 0xff), (uint64_t)bytes);
+    return hipGetLastError();
+}
 }  // namespace zk

@@ -841,6 +841,19 @@ def prove_transcripts(messages, params=None, devices=None, in_flight=4, verify=F
     return vk, [(bytes(jobs[i].digest), keep[i][1][: jobs[i].proof_len]) for i in range(n)]
 
 
+def set_lockstep(max_batch, lanes=0):
+    """zkhip_set_lockstep: members per lock-step batch of small transcripts (0 / 1 = off), batches in flight per device (0 = keep)"""
+    _lib.load().zkhip_set_lockstep(int(max_batch), int(lanes))
+
+
+def lockstep_stats():
+    """(merged launches, member launch requests, rendezvous with differing requests, ns waited at rendezvous, ns issuing merged
+    launches, ns in votes) since the library was loaded"""
+    out = (C.c_uint64 * 6)()
+    _lib.load().zkhip_lockstep_stats(out)
+    return tuple(int(v) for v in out)
+
+
 def p2chip_air():
     """the Poseidon2 chip's constraint program for the parameter set in effect"""
     lib = _lib.load()
