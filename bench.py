@@ -83,6 +83,7 @@ def main():
                     help="with --gpus 1: initialise the RCCL ('nccl') process group at world size 1 and run the seed broadcast, the MAX "
                          "all-reduce and a barrier through it, so that RCCL is loaded and called on hardware even on a one-GPU box")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-batch64", action="store_true", help="skip the 64-transcript batch (BASELINE configs[2]) measured beside the headline")
     ap.add_argument("--cpu-log-n", type=int, default=20, help="rows of the bounded CPU-baseline sample")
     ap.add_argument("--cpu-threads", type=int, default=0, help="OpenMP threads of the CPU baseline (0: min(cores, 64))")
     args = ap.parse_args()
@@ -452,6 +453,43 @@ def main():
                 "hbm_GB/s": round((4.0 * rows * width + 32.0 * rows) / (ms * 1e-3) / 1e9, 1)}
         del lde_t, dig_t
 
+    # ---- BASELINE configs[2]: sixty-four 13 KB transcripts in ONE call, each a keyed SHA-256 machine proof (padding, trace, range table,
+    # proof; host bytes in, proofs out), in lock-step batches (csrc/batch.h) and, beside it, one context + stream per worker
+    batch64 = None
+    if rank == 0 and not args.no_batch64 and chip_list is None:
+        import hashlib
+        from zktls_amd.device import lockstep_stats, prove_transcripts, set_lockstep, verify_sha256_machine
+        base = open(os.path.join(ROOT, "tests", "golden", "reference", "guest_input0.cbor"), "rb").read()
+        msgs = [base + i.to_bytes(4, "little") for i in range(64)]
+        tprm = Params(1, 100, 16)
+
+        def best_of(reps, **kw):
+            best, res = 1e9, None
+            for _ in range(reps):
+                tb0 = time.perf_counter()
+                res = prove_transcripts(msgs, tprm, devices=[local_rank], **kw)
+                best = min(best, time.perf_counter() - tb0)
+            return best, res
+
+        set_lockstep(0)
+        best_of(1, in_flight=16)
+        t_plain, (vk_p, res_p) = best_of(3, in_flight=16)
+        set_lockstep(16, 6)
+        best_of(1)
+        st0 = lockstep_stats()
+        t_lock, (vk_l, res_l) = best_of(3)
+        st1 = lockstep_stats()
+        t_lock_v, _ = best_of(2, verify=True)
+        same = vk_p.tolist() == vk_l.tolist() and all(a[0] == b[0] and a[1].tobytes() == b[1].tobytes() for a, b in zip(res_p, res_l))
+        ok64 = all(d == hashlib.sha256(m).digest() for m, (d, _) in zip(msgs, res_l)) and verify_sha256_machine(res_l[63][1], res_l[63][0], vk_l, tprm) == (0, 0)
+        batch64 = {"workload": "64 transcripts of %d bytes, one zkhip_prove_transcripts call, keyed SHA-256 machine (chip 2^14 x 608 + range table 2^16), log_blowup 1, 100 queries, 16 PoW bits" % len(msgs[0]),
+                   "ms": round(t_lock * 1e3, 2), "transcripts_per_s": round(64 / t_lock, 1), "mode": "lock-step: 6 lanes x up to 16 members, launches merged",
+                   "ms_with_verify_inside": round(t_lock_v * 1e3, 2),
+                   "merged_launches_per_call": (st1[0] - st0[0]) // 3, "member_launch_requests_per_call": (st1[1] - st0[1]) // 3,
+                   "one_stream_per_worker_ms": round(t_plain * 1e3, 2), "one_stream_per_worker_in_flight": 16,
+                   "same_bytes_both_ways": bool(same), "digests_and_last_proof_verified": bool(ok64),
+                   "proof_bytes": int(res_l[0][1].size)}
+
     # ---- CPU baseline: the oracle on the host cores, bounded sample of the same workload
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
@@ -504,6 +542,8 @@ def main():
             "verified": bool(verified), "host_verify_ms": round(host_verify_ms, 2),
             "roofline": roof,
             "valu_roofline": valu,
+            "transcripts_per_s": (batch64["transcripts_per_s"] if batch64 else None),
+            "batch64": batch64,
             "cpu_baseline": cpu,
         }
         print(json.dumps(out), flush=True)

@@ -572,13 +572,16 @@ typedef struct zkhip_transcript_job {
 } zkhip_transcript_job;
 int zkhip_prove_transcripts(const int* devices, int n_devices, zkhip_transcript_job* jobs, int n_jobs, const zkhip_params* prm,
                             int in_flight_per_device, int verify, uint32_t vk[8]);
-/* Small transcripts are launch-bound: a proof of a 13 KB message is a few hundred kernels of microseconds each, and the GPU retires such
- * kernels at a fixed rate however many streams feed it.  zkhip_prove_transcripts therefore proves the transcripts of ONE trace height
- * (up to 2^16 rows) in lock-step batches: `max_batch` host threads on pooled contexts sharing one stream, whose launches of the same
- * kernel merge into one launch (gridDim.z = members; csrc/batch.h), `lanes` batches in flight per device.  The proofs are byte for byte
- * those of the unbatched path.  max_batch 0 or 1 switches lock-step off (default 32, lanes 2; lanes <= 0 keeps the current value).
- * Process-wide.  zkhip_lockstep_stats: merged launches issued, member launch requests served, rendezvous whose members asked for
- * different launches, then nanoseconds members spent waiting at a rendezvous, issuing merged launches, and in votes -- totals since the library was loaded.
+/* Small proofs are launch-bound: a proof of a 13 KB message is ~200 kernels, most of a few microseconds, and the GPU retires such kernels
+ * at a fixed rate however many streams feed it.  The batch entries therefore prove small jobs OF ONE SHAPE in lock-step (csrc/batch.h):
+ * up to `max_batch` provers run as fibers of one host thread on pooled contexts that share one stream, and their launches of the same
+ * kernel merge into one launch (gridDim.z = members; their small copies, memsets and waits merge too); `lanes` such batches are in
+ * flight per device.  Used by zkhip_prove_transcripts for traces of up to 2^16 rows and by zkhip_prove_shards / _multi / _air_multi for
+ * shards of up to 2^26 cells, when a device gets at least two such jobs.  The proofs are byte for byte those of the unbatched path.
+ * max_batch 0 or 1 switches lock-step off (defaults: 16 members, 6 lanes; lanes <= 0 keeps the current value).  Process-wide.
+ * zkhip_lockstep_stats: merged launches issued, member launch requests served, rounds whose members asked for different launches, then
+ * nanoseconds (summed over the lanes) spent issuing launches, waiting for the stream, and in the members' own host code -- totals since
+ * the library was loaded.
  * (The reference proves its batch one transcript after the other, each a full `client.prove` call: sp1.rs:116, BASELINE configs[2].) */
 void zkhip_set_lockstep(int max_batch, int lanes);
 void zkhip_lockstep_stats(uint64_t out[6]);

@@ -30,7 +30,7 @@ set_lockstep(0)
 prove_transcripts(msgs[:16], prm, devices=[0], in_flight=16)
 vk0, ref = timed("one stream per worker, 16 in flight", in_flight=16)
 timed("... proven and verified inside the call", verify=True, in_flight=16)
-for batch, lanes in ((64, 1), (32, 2), (16, 4), (22, 3), (16, 2), (8, 4)):
+for batch, lanes in ((16, 4), (8, 8), (6, 11), (4, 16), (8, 4), (11, 6)):
     set_lockstep(batch, lanes)
     prove_transcripts(msgs, prm, devices=[0])               # contexts, keys, plans
     s0 = lockstep_stats()

@@ -20,5 +20,5 @@ prove_transcripts(msgs, prm, devices=[0], in_flight=16)
 dt = time.perf_counter() - t0
 s1 = lockstep_stats()
 d = [b - a for a, b in zip(s0, s1)]
-print("batch %d lanes %d: %.1f ms; merged launches %d, requests %d, mixed %d; per member: waiting %.1f ms, flushing (sum) %.1f ms" % (
-    batch, lanes, dt * 1e3, d[0], d[1], d[2], d[3] / 1e6 / n, d[4] / 1e6))
+print("batch %d lanes %d: %.1f ms; merged launches %d, requests %d, mixed %d; summed over the lanes: issuing launches %.1f ms, waiting for the stream %.1f ms, members' host code %.1f ms" % (
+    batch, lanes, dt * 1e3, d[0], d[1], d[2], d[3] / 1e6, d[4] / 1e6, d[5] / 1e6))

@@ -19,6 +19,7 @@ extern std::atomic<int> g_live_contexts;       // params.cpp: the Poseidon2 para
 static thread_local std::string g_last_error;
 
 void set_error(const std::string& msg) { g_last_error = msg; }
+void fiber_tls_swap_error(std::string& err) { g_last_error.swap(err); }
 int fail(int code, const std::string& msg) { g_last_error = msg; return code; }
 int hip_fail(hipError_t e, const char* what) {
     g_last_error = std::string("HIP error ") + hipGetErrorName(e) + " (" + hipGetErrorString(e) + ") in " + what;

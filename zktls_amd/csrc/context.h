@@ -136,12 +136,28 @@ int op_merkle_commit(zkhip_ctx* ctx, const MatDesc* mats, int nmats, int log_h, 
 int op_merkle_commit_mixed(zkhip_ctx* ctx, const MatDesc* mats, const int* log_heights, int nmats, uint32_t* d_tree);
 // batch entries (prover.cpp): job i -> devices[i mod n], up to `in_flight` pooled contexts per device, run(ctx, i) -> status
 int deal_jobs(const int* devices, int n_devices, int n_jobs, int in_flight, const std::function<int(zkhip_ctx*, int)>& run, std::vector<char>& ran);
+// a few host threads for work that should not hold up a prover (checking a proof right after it was made): submit() never blocks,
+// wait() returns when everything submitted has run
+class HostPool {
+public:
+    explicit HostPool(int threads);
+    ~HostPool();
+    void submit(std::function<void()> job);
+    void wait();
+private:
+    struct Impl;
+    Impl* impl_;
+};
 // copies, memsets and waits on the context's stream; inside a lock-step batch (batch.h) their merged forms.  dev_d2h returns with the
 // data in dst; dev_h2d returns when src may be reused
 int dev_sync(zkhip_ctx* ctx);
 int dev_d2h(zkhip_ctx* ctx, void* dst, const void* src, size_t bytes);
 int dev_h2d(zkhip_ctx* ctx, void* dst, const void* src, size_t bytes);
 int dev_memset(zkhip_ctx* ctx, void* dst, int byte, size_t bytes);
+int lockstep_batch();
+int lockstep_lanes();
+void lockstep_set(int max_batch, int lanes);
+constexpr uint64_t LOCKSTEP_MAX_CELLS = (uint64_t)1 << 26;   // trace cells of a shard that still counts as small (2^16 rows x 1024 columns)
 int deal_jobs_lockstep(const int* devices, int n_devices, int n_jobs, const int* shape, int max_batch, int lanes,
                        const std::function<int(zkhip_ctx*, int)>& run, std::vector<char>& ran);
 int resolve_devices(const int* devices, int n_devices, const char* what, std::vector<int>& devs);

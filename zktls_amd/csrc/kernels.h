@@ -351,4 +351,5 @@ hipError_t launch_gather(const GatherDesc* descs, uint32_t ndesc, uint32_t* dst,
 // plain copy / fill as kernels (util.hip): what the members of a lock-step batch use instead of hipMemcpyAsync / hipMemsetAsync
 hipError_t launch_copy_bytes(void* dst, const void* src, size_t bytes, hipStream_t s);
 hipError_t launch_fill_bytes(void* dst, int byte, size_t bytes, hipStream_t s);
+hipError_t launch_copy2d(uint32_t* dst, uint64_t dst_ld, const uint32_t* src, uint64_t src_ld, uint32_t width, uint64_t rows, hipStream_t s);
 }  // namespace zk

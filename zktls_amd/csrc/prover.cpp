@@ -9,6 +9,8 @@
 // launches, exactly where the protocol forces a round trip (commit -> challenge).
 #include <atomic>
 #include <chrono>
+#include <condition_variable>
+#include <deque>
 #include <cstring>
 #include <functional>
 #include <mutex>
@@ -1099,10 +1101,64 @@ int deal_jobs(const int* devices, int n_devices, int n_jobs, int in_flight, cons
         if (!ran[(size_t)i]) { set_error(ctx_msg.empty() ? "prove_shards: job not run" : ctx_msg); return ctx_rc != ZKHIP_OK ? ctx_rc : ZKHIP_ERR_INVALID; }
     return ZKHIP_OK;
 }
+// lock-step batches (batch.h): members per batch (0 / 1: off) and batches in flight per device; process-wide
+static std::atomic<int> g_lockstep_batch{16}, g_lockstep_lanes{6};
+int lockstep_batch() { return g_lockstep_batch.load(); }
+int lockstep_lanes() { return g_lockstep_lanes.load(); }
+void lockstep_set(int max_batch, int lanes) {
+    g_lockstep_batch.store(max_batch < 0 ? 0 : (max_batch > LaunchBatcher::MAX_MEMBERS ? LaunchBatcher::MAX_MEMBERS : max_batch));
+    if (lanes > 0) g_lockstep_lanes.store(lanes > 32 ? 32 : lanes);
+}
+struct HostPool::Impl {
+    std::mutex mu;
+    std::condition_variable cv, idle;
+    std::deque<std::function<void()>> queue;
+    std::vector<std::thread> threads;
+    int running = 0;
+    bool stop = false;
+    void loop() {
+        std::unique_lock<std::mutex> lk(mu);
+        for (;;) {
+            cv.wait(lk, [&] { return stop || !queue.empty(); });
+            if (queue.empty()) return;
+            std::function<void()> job = std::move(queue.front());
+            queue.pop_front();
+            running++;
+            lk.unlock();
+            job();
+            lk.lock();
+            running--;
+            if (queue.empty() && running == 0) idle.notify_all();
+        }
+    }
+};
+HostPool::HostPool(int threads) : impl_(new Impl) {
+    for (int t = 0; t < threads; t++) {
+        try { impl_->threads.emplace_back([this] { impl_->loop(); }); } catch (...) { break; }
+    }
+}
+HostPool::~HostPool() {
+    wait();
+    { std::lock_guard<std::mutex> lk(impl_->mu); impl_->stop = true; }
+    impl_->cv.notify_all();
+    for (auto& t : impl_->threads) t.join();
+    delete impl_;
+}
+void HostPool::submit(std::function<void()> job) {
+    if (impl_->threads.empty()) { job(); return; }              // no thread could be made: the caller does it
+    { std::lock_guard<std::mutex> lk(impl_->mu); impl_->queue.push_back(std::move(job)); }
+    impl_->cv.notify_one();
+}
+void HostPool::wait() {
+    std::unique_lock<std::mutex> lk(impl_->mu);
+    impl_->idle.wait(lk, [&] { return impl_->queue.empty() && impl_->running == 0; });
+}
+
 // Lock-step variant for SMALL proofs (batch.h): the jobs of a device are grouped by `shape[i]` (jobs of one shape run the same launch
-// sequence), groups are cut into batches of up to `max_batch`, and a batch is proven by that many host threads on pooled contexts that
-// share ONE stream and merge their kernel launches through a LaunchBatcher.  `lanes` batches are in flight per device, so that the
-// host-side work around one batch (padding, transcripts, verification) overlaps the other's kernels.  Same contract as deal_jobs.
+// sequence), groups are cut into batches of up to `max_batch`, and a batch is proven by that many provers on pooled contexts that
+// share ONE stream and merge their kernel launches through a LaunchBatcher.  `lanes` batches are in flight per device (a host thread
+// each; the members of a batch are fibers of that thread), so that the host-side work around one batch (padding, transcripts,
+// verification) overlaps the other batches' kernels.  Same contract as deal_jobs.
 int deal_jobs_lockstep(const int* devices, int n_devices, int n_jobs, const int* shape, int max_batch, int lanes,
                        const std::function<int(zkhip_ctx*, int)>& run, std::vector<char>& ran) {
     ran.assign((size_t)n_jobs, 0);
@@ -1174,27 +1230,22 @@ int deal_jobs_lockstep(const int* devices, int n_devices, int n_jobs, const int*
                     continue;
                 }
                 for (int b = 0; b < n; b++) ctxs[(size_t)b]->stream = shared;
-                LaunchBatcher lb(n, shared);
-                std::vector<std::thread> th;
-                std::vector<char> started((size_t)n, 0);
-                auto member = [&](int b, bool joined) {
-                    BatchMember m(joined && lb.ok() ? &lb : nullptr);
-                    const int i = jobs[(size_t)(at + b)];
-                    const int rc = run(ctxs[(size_t)b], i);
-                    ran[(size_t)i] = 1;
-                    if (rc != ZKHIP_OK) { note(i, rc, zkhip_last_error()); healthy[(size_t)b] = 0; }
-                };
-                for (int b = 0; b < n; b++) {
-                    try { th.emplace_back(member, b, true); started[(size_t)b] = 1; }
-                    catch (...) { if (lb.ok()) lb.leave(); }     // no thread for this member: the others must not wait for it
-                }
-                for (auto& t : th) t.join();
-                for (int b = 0; b < n; b++) if (!started[(size_t)b]) member(b, false);       // ... and its job runs here, on its own
-                if (hipStreamSynchronize(shared) != hipSuccess) { (void)hipGetLastError(); for (int b = 0; b < n; b++) healthy[(size_t)b] = 0; }
-                if (lb.failed()) {                                // a merged launch failed: every proof of the batch is suspect
-                    for (int b = 0; b < n; b++) {
-                        healthy[(size_t)b] = 0;
-                        note(jobs[(size_t)(at + b)], ZKHIP_ERR_HIP, "lock-step batch: a merged kernel launch failed");
+                {
+                    LaunchBatcher lb(n, shared);
+                    auto member = [&](int b) {
+                        const int i = jobs[(size_t)(at + b)];
+                        const int rc = run(ctxs[(size_t)b], i);
+                        ran[(size_t)i] = 1;
+                        if (rc != ZKHIP_OK) { note(i, rc, zkhip_last_error()); healthy[(size_t)b] = 0; }
+                    };
+                    if (lb.ok()) lb.run(member);                 // the members as fibers of this thread, their launches merged
+                    else for (int b = 0; b < n; b++) member(b);  // (no pinned memory / stacks: one after the other, unmerged)
+                    if (hipStreamSynchronize(shared) != hipSuccess) { (void)hipGetLastError(); for (int b = 0; b < n; b++) healthy[(size_t)b] = 0; }
+                    if (lb.failed()) {                            // a merged launch failed: every proof of the batch is suspect
+                        for (int b = 0; b < n; b++) {
+                            healthy[(size_t)b] = 0;
+                            note(jobs[(size_t)(at + b)], ZKHIP_ERR_HIP, "lock-step batch: a merged kernel launch failed");
+                        }
                     }
                 }
                 for (int b = 0; b < n; b++) ctxs[(size_t)b]->stream = own[(size_t)b];
@@ -1247,7 +1298,7 @@ static int prove_shards_on(const int* devices, int n_devices, zkhip_shard_job* j
                            int host_traces, const uint32_t* program = nullptr, size_t program_words = 0) {
     for (int i = 0; i < n_jobs; i++) { jobs[i].status = ZKHIP_ERR_INVALID; jobs[i].proof_len = 0; }
     std::vector<char> ran;
-    return deal_jobs(devices, n_devices, n_jobs, in_flight, [&](zkhip_ctx* ctx, int i) {
+    auto run = [&](zkhip_ctx* ctx, int i) {
         zkhip_shard_job& j = jobs[i];
         size_t len = 0;
         int rc;
@@ -1260,7 +1311,18 @@ static int prove_shards_on(const int* devices, int n_devices, zkhip_shard_job* j
         j.status = rc;
         j.proof_len = rc == ZKHIP_OK ? len : 0;
         return rc;
-    }, ran);
+    };
+    // a batch of SMALL shards is launch-bound: lock-step lanes (batch.h) when every job is small, one context and stream each otherwise
+    const int max_batch = lockstep_batch();
+    bool small = max_batch > 1 && n_jobs >= 2 * n_devices;
+    std::vector<int> shape((size_t)n_jobs);
+    for (int i = 0; i < n_jobs && small; i++) {
+        const zkhip_shard_job& j = jobs[i];
+        if (j.log_n < 1 || j.log_n > 24 || j.width == 0 || ((uint64_t)j.width << j.log_n) > LOCKSTEP_MAX_CELLS) small = false;
+        shape[(size_t)i] = (int)(((uint32_t)j.log_n << 24) ^ j.width);
+    }
+    if (small) return deal_jobs_lockstep(devices, n_devices, n_jobs, shape.data(), max_batch, lockstep_lanes(), run, ran);
+    return deal_jobs(devices, n_devices, n_jobs, in_flight, run, ran);
 }
 
 int zkhip_prove_shards(int device, zkhip_shard_job* jobs, int n_jobs, const zkhip_params* prm, int in_flight, int host_traces) {
@@ -1841,6 +1903,14 @@ struct KeyView {
     int He;                             // height of the tallest preprocessed LDE = height of the key's tree
 };
 static thread_local const KeyView* t_key = nullptr;
+// the four thread-local scopes above are per-proof state: a lane that runs several provers as fibers (batch.h) exchanges them on
+// every switch
+extern "C++" void fiber_tls_swap_prover(const void* slots[4]) {
+    const void* mine[4] = {t_fri_sink, t_chip_air, t_machine, t_key};
+    t_fri_sink = (FriViewSink*)slots[0]; t_chip_air = (const AirView* const*)slots[1];
+    t_machine = (const MachineTables*)slots[2]; t_key = (const KeyView*)slots[3];
+    for (int i = 0; i < 4; i++) slots[i] = mine[i];
+}
 static uint32_t pre_w(int c) { return t_key ? t_key->pw[c] : 0u; }
 struct KeyScope {
     explicit KeyScope(const KeyView* k) { t_key = k; }
@@ -2046,7 +2116,7 @@ int zkhip_prove_chips(zkhip_ctx* ctx, const zkhip_chip* chips, int n, const uint
         const uint32_t pw = pre_w(c);
         cw[c] = (size_t)pw + widths[c];
         if (pw)                                    // the key's LDE columns beside the main ones: what the program and the interactions read
-            ZK_HIP(hipMemcpy2DAsync(tlde + tl_off[c], cw[c] * 4, t_key->d_lde[c], (size_t)pw * 4, (size_t)pw * 4, (size_t)1 << lh[c], hipMemcpyDeviceToDevice, st));
+            ZK_HIP(launch_copy2d(tlde + tl_off[c], cw[c], t_key->d_lde[c], pw, (uint32_t)pw, (uint64_t)1 << lh[c], st));
         ZK_TRY(op_coset_lde(ctx, chips[c].d_trace, chips[c].ld, tlde + tl_off[c] + pw, cw[c], log_ns[c], widths[c], b, MONTY_GEN));
         tm[c] = MatDesc{tlde + tl_off[c] + pw, cw[c], widths[c]};
         qm[c] = MatDesc{qlde + ql_off[c], qw_of(c), (uint32_t)qw_of(c)};
@@ -2075,8 +2145,8 @@ int zkhip_prove_chips(zkhip_ctx* ctx, const zkhip_chip* chips, int n, const uint
                 void* v_ct;
                 ZK_TRY(ctx_reserve(ctx, S_KEYTRACE, nc * cw[c] * 4, &v_ct));
                 uint32_t* ct = (uint32_t*)v_ct;
-                ZK_HIP(hipMemcpy2DAsync(ct, cw[c] * 4, t_key->d_trace[c], pw * 4, pw * 4, nc, hipMemcpyDeviceToDevice, st));
-                ZK_HIP(hipMemcpy2DAsync(ct + pw, cw[c] * 4, chips[c].d_trace, chips[c].ld * 4, (size_t)widths[c] * 4, nc, hipMemcpyDeviceToDevice, st));
+                ZK_HIP(launch_copy2d(ct, cw[c], t_key->d_trace[c], pw, (uint32_t)pw, nc, st));
+                ZK_HIP(launch_copy2d(ct + pw, cw[c], chips[c].d_trace, chips[c].ld, widths[c], nc, st));
                 ZK_TRY(run_lookup_perm(ctx, ct, cw[c], log_ns[c], *lookup_of(c), gamma, beta_l, (uint32_t*)v_perm));
             } else if (t_machine) ZK_TRY(run_lookup_perm(ctx, chips[c].d_trace, chips[c].ld, log_ns[c], *lookup_of(c), gamma, beta_l, (uint32_t*)v_perm));
             else ZK_TRY(run_perm_trace(ctx, chips[c].d_trace, chips[c].ld, log_ns[c], (uint32_t)pairs[c], gamma, beta_l, (uint32_t*)v_perm));

@@ -18,6 +18,7 @@
 //   ACT (block belongs to the message) | SKIP = s_63 (1 - ACT) | 2 unused
 #include <algorithm>
 #include <atomic>
+#include <memory>
 #include <mutex>
 #include <thread>
 #include <cstring>
@@ -574,8 +575,7 @@ static MachineShape machine_shape(int log_n) {
 }
 }  // namespace sha
 }  // namespace zk
-// lock-step batches of small transcripts (batch.h): members per batch (0 / 1: off), batches in flight per device, tallest chip
-static std::atomic<int> g_lockstep_batch{32}, g_lockstep_lanes{2};
+// lock-step batches of small transcripts (batch.h): the tallest chip that still counts as small
 constexpr int LOCKSTEP_MAX_LOG_N = 16;
 namespace zk { extern std::atomic<uint64_t> g_lockstep_stats[6]; }
 extern "C" {
@@ -673,6 +673,8 @@ int zkhip_prove_transcripts(const int* devices, int n_devices, zkhip_transcript_
     bool have_vk = false;
     std::memset(vk, 0, 32);
     std::vector<char> ran;
+    std::unique_ptr<HostPool> checkers;                          // made below when lock-step lanes run with verify
+    std::vector<std::string> check_msg((size_t)n_jobs);
     auto run = [&](zkhip_ctx* ctx, int i) {
         zkhip_transcript_job& j = jobs[i];
         int r = ZKHIP_OK;
@@ -688,17 +690,34 @@ int zkhip_prove_transcripts(const int* devices, int n_devices, zkhip_transcript_
         }
         size_t len = 0;
         if (r == ZKHIP_OK) r = zkhip_prove_sha256_machine(ctx, ctx->sha_key, j.message, j.message_len, prm, j.digest, j.proof, j.proof_cap, &len);
-        batch_leave();                                           // (lock-step batch: the rest is host work, nobody waits for this member any more)
-        // the reference checks every proof right after proving it (sp1.rs:120): on this worker's host thread, while the GPU runs the other workers' proofs
-        if (r == ZKHIP_OK && verify) r = zkhip_verify_sha256_machine(j.proof, len, j.digest, ctx->sha_vk, prm, nullptr);
+        batch_leave();                                           // (lock-step batch: the rest is host work)
+        // the reference checks every proof right after proving it (sp1.rs:120): on a host thread, while the GPU runs the other proofs --
+        // this worker's own thread, or (lock-step lanes, whose members share one thread) a small pool beside the lanes
         j.status = r;
         j.proof_len = r == ZKHIP_OK ? len : 0;
+        if (r == ZKHIP_OK && verify) {
+            if (checkers && t_batcher) {
+                uint32_t key[8];
+                std::memcpy(key, ctx->sha_vk, 32);
+                const zkhip_params p = *prm;
+                zkhip_transcript_job* jp = &j;
+                std::string* msg = &check_msg[(size_t)i];
+                checkers->submit([jp, len, p, msg, key] {
+                    const int v = zkhip_verify_sha256_machine(jp->proof, len, jp->digest, key, &p, nullptr);
+                    if (v != ZKHIP_OK) { jp->status = v; jp->proof_len = 0; *msg = zkhip_last_error(); }
+                });
+            } else {
+                r = zkhip_verify_sha256_machine(j.proof, len, j.digest, ctx->sha_vk, prm, nullptr);
+                j.status = r;
+                j.proof_len = r == ZKHIP_OK ? len : 0;
+            }
+        }
         return r;
     };
     // Small transcripts are launch-bound (a few hundred kernels of microseconds each): those of one trace height are proven in
     // lock-step batches whose kernel launches merge (batch.h); the others -- and everything when lock-step is switched off -- are
     // dealt one context, one stream each.  The proofs are the same bytes either way.
-    const int max_batch = g_lockstep_batch.load();
+    const int max_batch = lockstep_batch();
     std::vector<int> small, big, shape;
     for (int i = 0; i < n_jobs; i++) {
         size_t padded, na, nb;
@@ -712,20 +731,23 @@ int zkhip_prove_transcripts(const int* devices, int n_devices, zkhip_transcript_
     int rc_small = ZKHIP_OK, rc_big = ZKHIP_OK;
     std::string msg_small;
     if (!small.empty()) {
-        rc_small = deal_jobs_lockstep(devs.data(), nd, (int)small.size(), shape.data(), max_batch, g_lockstep_lanes.load(),
+        if (verify) checkers.reset(new HostPool(8));
+        rc_small = deal_jobs_lockstep(devs.data(), nd, (int)small.size(), shape.data(), max_batch, lockstep_lanes(),
                                       [&](zkhip_ctx* ctx, int k) { return run(ctx, small[(size_t)k]); }, ran);
         if (rc_small != ZKHIP_OK) msg_small = zkhip_last_error();
     }
     if (!big.empty())
         rc_big = deal_jobs(devs.data(), nd, (int)big.size(), in_flight_per_device, [&](zkhip_ctx* ctx, int k) { return run(ctx, big[(size_t)k]); }, ran);
+    if (checkers) {                                             // the checks made beside the lanes: the lowest rejected job speaks
+        checkers->wait();
+        for (int i = 0; i < n_jobs && rc_small == ZKHIP_OK; i++)
+            if (!check_msg[(size_t)i].empty()) { rc_small = jobs[i].status; msg_small = check_msg[(size_t)i]; }
+    }
     if (rc_small != ZKHIP_OK && (rc_big == ZKHIP_OK || small[0] < big[0])) { set_error(msg_small); return rc_small; }
     return rc_big;
 }
 
-void zkhip_set_lockstep(int max_batch, int lanes) {
-    g_lockstep_batch.store(max_batch < 0 ? 0 : (max_batch > LaunchBatcher::MAX_MEMBERS ? LaunchBatcher::MAX_MEMBERS : max_batch));
-    if (lanes > 0) g_lockstep_lanes.store(lanes > 8 ? 8 : lanes);
-}
+void zkhip_set_lockstep(int max_batch, int lanes) { lockstep_set(max_batch, lanes); }
 void zkhip_lockstep_stats(uint64_t out[6]) {
     for (int i = 0; i < 6; i++) out[i] = g_lockstep_stats[i].load();
 }

@@ -1272,7 +1272,10 @@ hipError_t launch_ext_add(uint32_t* dst, const uint32_t* src, uint64_t count, hi
 // state: sponge state with the pending inputs already written to words [0, slot);
 // candidate w goes to word `slot`; hit when canonical(permute(state)[7]) & mask == 0.
 __device__ __forceinline__ void grind_kernel_body(const GrindArgs& a, uint32_t base, uint32_t* result) {
-    const uint32_t w = base + blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t w0 = base + blockIdx.x * blockDim.x, w = w0 + threadIdx.x;
+    // the smallest witness is wanted and candidates are scanned in order: a block whose candidates all lie above a hit already
+    // recorded cannot lower it (workgroups start roughly in index order, so most of a launch ends here once a hit is in)
+    if (__atomic_load_n(result, __ATOMIC_RELAXED) <= w0) return;
     if (w >= P) return;
     uint32_t s[16];
 #pragma unroll

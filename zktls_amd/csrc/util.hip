@@ -251,4 +251,24 @@ hipError_t launch_fill_bytes(void* dst, int byte, size_t bytes, hipStream_t s) {
     ZK_LAUNCH(fill_bytes_kernel, fill_bytes_kernel_batch, fill_bytes_kernel_bargs, dim3((unsigned)blocks), dim3(256), 0, s, (uint8_t*)dst, (uint32_t)(byte & 0xff), (uint64_t)bytes);
     return hipGetLastError();
 }
+
+// rows x width words between pitched matrices (what hipMemcpy2DAsync does, as a kernel that merges in a lock-step batch)
+__device__ __forceinline__ void copy2d_kernel_body(uint32_t* dst, uint64_t dst_ld, const uint32_t* src, uint64_t src_ld, uint32_t width, uint64_t rows) {
+    const uint64_t total = rows * width, nthr = (uint64_t)gridDim.x * blockDim.x;
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += nthr) {
+        const uint64_t r = i / width, c = i - r * width;
+        dst[r * dst_ld + c] = src[r * src_ld + c];
+    }
+}
+__global__ void __launch_bounds__(256) copy2d_kernel(uint32_t* dst, uint64_t dst_ld, const uint32_t* src, uint64_t src_ld, uint32_t width, uint64_t rows) { copy2d_kernel_body(dst, dst_ld, src, src_ld, width, rows); }
+struct copy2d_kernel_bargs { uint32_t* dst; uint64_t dst_ld; const uint32_t* src; uint64_t src_ld; uint32_t width; uint64_t rows; static copy2d_kernel_bargs make(uint32_t* dst, uint64_t dst_ld, const uint32_t* src, uint64_t src_ld, uint32_t width, uint64_t rows) { return copy2d_kernel_bargs{dst, dst_ld, src, src_ld, width, rows}; } };
+__global__ void __launch_bounds__(256) copy2d_kernel_batch(const copy2d_kernel_bargs* __restrict__ zk_arr) { const copy2d_kernel_bargs& zk_b = zk_arr[blockIdx.z]; copy2d_kernel_body(zk_b.dst, zk_b.dst_ld, zk_b.src, zk_b.src_ld, zk_b.width, zk_b.rows); }
+
+hipError_t launch_copy2d(uint32_t* dst, uint64_t dst_ld, const uint32_t* src, uint64_t src_ld, uint32_t width, uint64_t rows, hipStream_t s) {
+    if (rows == 0 || width == 0) return hipSuccess;
+    uint64_t blocks = (rows * width + 255) / 256;
+    if (blocks > 8192) blocks = 8192;
+    ZK_LAUNCH(copy2d_kernel, copy2d_kernel_batch, copy2d_kernel_bargs, dim3((unsigned)blocks), dim3(256), 0, s, dst, dst_ld, src, src_ld, width, rows);
+    return hipGetLastError();
+}
 }  // namespace zk
