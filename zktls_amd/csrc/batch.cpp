@@ -74,12 +74,10 @@ void LaunchBatcher::trampoline() {
 void LaunchBatcher::switch_to(int b) {
     Fiber& f = fibers_[(size_t)b];
     current_ = b;
-    fiber_tls_swap_prover(f.tls.slots);
     fiber_tls_swap_error(f.tls.last_error);
     const auto t0 = Clock::now();
     swapcontext(&lane_, &f.ctx);
     host_ns += ns_since(t0);
-    fiber_tls_swap_prover(f.tls.slots);
     fiber_tls_swap_error(f.tls.last_error);
     current_ = -1;
 }

@@ -1530,10 +1530,9 @@ static int run_queries(int n, const std::function<int(int)>& check, int min_per_
 // zkhip_fri_view_shard points this at its caller's buffers and runs the verifier; the FRI-fold chip (fri_chip.hip) proves
 // statements about exactly these values.  Canonical words.
 struct FriViewSink { uint32_t *betas, *final_value, *indices, *values, *siblings; int layers; uint32_t *roots, *paths; };      // roots / paths optional
-static thread_local FriViewSink* t_fri_sink = nullptr;
 
 static int verify_shard_impl(const uint8_t* proof, size_t len, int log_n, uint32_t width, const uint32_t* public_values,
-                             size_t n_public, const zkhip_params* prm, int* reason, const AirView* air) {
+                             size_t n_public, const zkhip_params* prm, int* reason, const AirView* air, FriViewSink* sink = nullptr) {
     int dummy;
     if (!reason) reason = &dummy;
     *reason = 0;
@@ -1702,7 +1701,6 @@ static int verify_shard_impl(const uint8_t* proof, size_t len, int log_n, uint32
     const int NQ_ = prm->num_queries;
     std::vector<size_t> indices(NQ_);
     for (int q = 0; q < NQ_; q++) indices[q] = ch.sample_bits(H);
-    FriViewSink* const sink = t_fri_sink;
     if (sink) {
         if (K != 1 || sh.F != 0 || RL != sink->layers) return reject(1);
         for (int l = 0; l < RL; l++) for (int i = 0; i < 4; i++) sink->betas[4 * l + i] = from_monty(betas[l].c[i]);
@@ -1836,9 +1834,8 @@ int zkhip_fri_view_shard(const uint8_t* proof, size_t len, int log_n, uint32_t w
     shape_of(log_n, prm, sh);
     if (sh.K != 1 || sh.F != 0) return fail(ZKHIP_ERR_INVALID, "fri_view_shard: fold-by-2 proofs with a constant final value only");
     FriViewSink sink{betas, final_value, indices, values, siblings, sh.R, nullptr, nullptr};
-    struct Scope { explicit Scope(FriViewSink* s) { t_fri_sink = s; } ~Scope() { t_fri_sink = nullptr; } } scope(&sink);
     int why = 0;
-    return verify_shard_impl(proof, len, log_n, width, public_values, n_public, prm, &why, nullptr);
+    return verify_shard_impl(proof, len, log_n, width, public_values, n_public, prm, &why, nullptr, &sink);
 }
 size_t zkhip_fri_view_path_words(int layers) { return layers >= 1 && layers <= 22 ? 4 * (size_t)layers * ((size_t)layers + 1) : 0; }
 int zkhip_fri_view_shard_paths(const uint8_t* proof, size_t len, int log_n, uint32_t width, const uint32_t* public_values, size_t n_public,
@@ -1850,9 +1847,8 @@ int zkhip_fri_view_shard_paths(const uint8_t* proof, size_t len, int log_n, uint
     shape_of(log_n, prm, sh);
     if (sh.K != 1 || sh.F != 0 || sh.b != 1) return fail(ZKHIP_ERR_INVALID, "fri_view_shard_paths: fold-by-2, blowup-2 proofs with a constant final value only");
     FriViewSink sink{betas, final_value, indices, values, siblings, sh.R, roots, paths};
-    struct Scope { explicit Scope(FriViewSink* s) { t_fri_sink = s; } ~Scope() { t_fri_sink = nullptr; } } scope(&sink);
     int why = 0;
-    return verify_shard_impl(proof, len, log_n, width, public_values, n_public, prm, &why, nullptr);
+    return verify_shard_impl(proof, len, log_n, width, public_values, n_public, prm, &why, nullptr, &sink);
 }
 
 // ================================================================ shards of several chips with different heights
@@ -1865,35 +1861,19 @@ constexpr uint32_t CHIPS_VERSION = 4u, CHIPS_VERSION_LOGUP = 5u, CHIPS_VERSION_C
                    CHIPS_VERSION_KEYED = 11u;
 constexpr int MAX_CHIPS = 32;
 
-// The constraint programs in effect for the running zkhip_*_chips_air call on this thread (nullptr: every chip uses the built-in
-// synthetic AIR).  Version 9: each chip's header entry gains a has-program flag, the programs' digests follow the entries.
-static thread_local const AirView* const* t_chip_air = nullptr;
-static bool any_prog(int n) { if (t_chip_air) for (int c = 0; c < n; c++) if (t_chip_air[c]) return true; return false; }
-static const AirView* prog_of(int c) { return t_chip_air ? t_chip_air[c] : nullptr; }
-struct ChipAirScope {
-    explicit ChipAirScope(const AirView* const* table) { t_chip_air = table; }
-    ~ChipAirScope() { t_chip_air = nullptr; }
-};
-// Machine mode (zkhip_*_machine, proof version 10): every chip runs through a program (its own, or the synthetic AIR written as one:
-// has_prog says which, for the header) and may bring an interaction table (air.h, LookupView).  The number of extension columns of
-// its permutation trace travels in the `pairs` slot of the chip arrays, so the layout code of versions 5 / 6 serves unchanged.
+// What a multi-chip call proves beside the plain chips, handed down explicitly from the entry point that parsed it:
+//   air      the chips' constraint programs (nullptr, or nullptr per chip: the built-in synthetic AIR).  Version 9: each chip's header
+//            entry gains a has-program flag, the programs' digests follow the entries.
+//   machine  machine mode (zkhip_*_machine, proof version 10): every chip runs through a program (its own, or the synthetic AIR
+//            written as one: has_prog says which, for the header) and may bring an interaction table (air.h, LookupView).  The
+//            number of extension columns of its permutation trace travels in the `pairs` slot of the chip arrays, so the layout
+//            code of versions 5 / 6 serves unchanged.
+//   key      keyed machine (zkhip_*_machine_keyed, proof version 11): chips with PREPROCESSED columns, committed once by
+//            zkhip_machine_setup -- sp1-stark's StarkMachine::setup, which the reference calls before every prove
+//            (crates/guest-prover-sp1/src/sp1.rs:113).  pw[c] is chip c's preprocessed width (0: none); its program and interaction
+//            table address the combined row [preprocessed | main].  The prover side carries the key's device data, the verifier
+//            side only the widths and the root.
 struct MachineTables { const LookupView* lk[32]; bool has_prog[32]; };
-static thread_local const MachineTables* t_machine = nullptr;
-static const LookupView* lookup_of(int c) { return t_machine ? t_machine->lk[c] : nullptr; }
-static bool header_has_prog(int c) { return t_machine ? t_machine->has_prog[c] : prog_of(c) != nullptr; }
-// log2 of chip c's number of quotient chunks: 2 for a program of degree 4 or 5 (needs log_blowup >= 2), else 1; the chip's quotient matrix
-// has 4 * 2^lq columns.  The header's has-program word carries it: 0 = no program, else the program's log_quotient_degree.
-static int lq_of(int c) { return prog_of(c) ? prog_of(c)->lqd : 1; }
-static size_t qw_of(int c) { return (size_t)4 << lq_of(c); }
-static uint32_t header_prog_word(int c) { return header_has_prog(c) ? (uint32_t)lq_of(c) : 0u; }
-struct MachineScope {
-    MachineScope(const AirView* const* progs, const MachineTables* m) { t_chip_air = progs; t_machine = m; }
-    ~MachineScope() { t_chip_air = nullptr; t_machine = nullptr; }
-};
-// Keyed machine (zkhip_*_machine_keyed, proof version 11): chips with PREPROCESSED columns, committed once by zkhip_machine_setup --
-// sp1-stark's StarkMachine::setup, which the reference calls before every prove (crates/guest-prover-sp1/src/sp1.rs:113).  pw[c] is
-// chip c's preprocessed width (0: none); its program and interaction table address the combined row [preprocessed | main].  The
-// prover side carries the key's device data, the verifier side only the widths and the root.
 struct KeyView {
     uint32_t pw[32];
     uint32_t root_m[8];                 // the key's commitment, Montgomery
@@ -1902,20 +1882,21 @@ struct KeyView {
     const uint32_t* d_tree;
     int He;                             // height of the tallest preprocessed LDE = height of the key's tree
 };
-static thread_local const KeyView* t_key = nullptr;
-// the four thread-local scopes above are per-proof state: a lane that runs several provers as fibers (batch.h) exchanges them on
-// every switch
-extern "C++" void fiber_tls_swap_prover(const void* slots[4]) {
-    const void* mine[4] = {t_fri_sink, t_chip_air, t_machine, t_key};
-    t_fri_sink = (FriViewSink*)slots[0]; t_chip_air = (const AirView* const*)slots[1];
-    t_machine = (const MachineTables*)slots[2]; t_key = (const KeyView*)slots[3];
-    for (int i = 0; i < 4; i++) slots[i] = mine[i];
-}
-static uint32_t pre_w(int c) { return t_key ? t_key->pw[c] : 0u; }
-struct KeyScope {
-    explicit KeyScope(const KeyView* k) { t_key = k; }
-    ~KeyScope() { t_key = nullptr; }
+struct ChipSet {
+    const AirView* const* air = nullptr;
+    const MachineTables* machine = nullptr;
+    const KeyView* key = nullptr;
 };
+static bool any_prog(const ChipSet& cs, int n) { if (cs.air) for (int c = 0; c < n; c++) if (cs.air[c]) return true; return false; }
+static const AirView* prog_of(const ChipSet& cs, int c) { return cs.air ? cs.air[c] : nullptr; }
+static const LookupView* lookup_of(const ChipSet& cs, int c) { return cs.machine ? cs.machine->lk[c] : nullptr; }
+static bool header_has_prog(const ChipSet& cs, int c) { return cs.machine ? cs.machine->has_prog[c] : prog_of(cs, c) != nullptr; }
+// log2 of chip c's number of quotient chunks: 2 for a program of degree 4 or 5 (needs log_blowup >= 2), else 1; the chip's quotient matrix
+// has 4 * 2^lq columns.  The header's has-program word carries it: 0 = no program, else the program's log_quotient_degree.
+static int lq_of(const ChipSet& cs, int c) { return prog_of(cs, c) ? prog_of(cs, c)->lqd : 1; }
+static size_t qw_of(const ChipSet& cs, int c) { return (size_t)4 << lq_of(cs, c); }
+static uint32_t header_prog_word(const ChipSet& cs, int c) { return header_has_prog(cs, c) ? (uint32_t)lq_of(cs, c) : 0u; }
+static uint32_t pre_w(const ChipSet& cs, int c) { return cs.key ? cs.key->pw[c] : 0u; }
 static void lookup_digest(const LookupView& v, uint32_t out[8]) {      // the program-digest sponge over the table's words (cached alike)
     AirView a;
     a.w = v.w; a.words = v.words;
@@ -1924,29 +1905,29 @@ static void lookup_digest(const LookupView& v, uint32_t out[8]) {      // the pr
 
 static bool any_pairs(const int32_t* pairs, int n) { if (pairs) for (int c = 0; c < n; c++) if (pairs[c]) return true; return false; }
 static size_t perm_width(const int32_t* pairs, int c) { return (pairs && pairs[c]) ? 4 * ((size_t)pairs[c] + 1) : 0; }
-static bool any_cross(const int32_t* partners, int n) {
-    if (t_machine) { for (int c = 0; c < n; c++) if (t_machine->lk[c]) return true; return false; }     // machine mode: the sums are always exposed
+static bool any_cross(const ChipSet& cs, const int32_t* partners, int n) {
+    if (cs.machine) { for (int c = 0; c < n; c++) if (cs.machine->lk[c]) return true; return false; }     // machine mode: the sums are always exposed
     if (partners) for (int c = 0; c < n; c++) if (partners[c] >= 0) return true;
     return false;
 }
-static uint32_t chips_version(const int32_t* pairs, const int32_t* partners, int n) {
-    if (t_machine) return t_key ? CHIPS_VERSION_KEYED : CHIPS_VERSION_MACHINE;
-    if (any_prog(n)) return CHIPS_VERSION_AIR;
-    return any_cross(partners, n) ? CHIPS_VERSION_CROSS : (any_pairs(pairs, n) ? CHIPS_VERSION_LOGUP : CHIPS_VERSION);
+static uint32_t chips_version(const ChipSet& cs, const int32_t* pairs, const int32_t* partners, int n) {
+    if (cs.machine) return cs.key ? CHIPS_VERSION_KEYED : CHIPS_VERSION_MACHINE;
+    if (any_prog(cs, n)) return CHIPS_VERSION_AIR;
+    return any_cross(cs, partners, n) ? CHIPS_VERSION_CROSS : (any_pairs(pairs, n) ? CHIPS_VERSION_LOGUP : CHIPS_VERSION);
 }
-static int check_chips(const int32_t* log_ns, const uint32_t* widths, const int32_t* pairs, const int32_t* partners, int n, const zkhip_params* prm) {
+static int check_chips(const ChipSet& cs, const int32_t* log_ns, const uint32_t* widths, const int32_t* pairs, const int32_t* partners, int n, const zkhip_params* prm) {
     if (!prm || !log_ns || !widths) return fail(ZKHIP_ERR_INVALID, "chips: null argument");
     if (n < 1 || n > MAX_CHIPS) return fail(ZKHIP_ERR_INVALID, "chips: 1..32 chips");
     if (prm->log_blowup < 1 || prm->log_blowup > 3) return fail(ZKHIP_ERR_INVALID, "chips: log_blowup in [1,3]");
     if ((prm->log_fold != 0 && prm->log_fold != 1) || prm->log_final != 0 || (prm->hash_width != 0 && prm->hash_width != 16) || prm->logup_pairs != 0 || prm->code_width != 0)
         return fail(ZKHIP_ERR_INVALID, "chips: the multi-chip prover uses the SP1 FRI shape (fold by 2, constant final polynomial, width-16 hash) without lookups");
     if (prm->num_queries < 1 || prm->num_queries > 4096 || prm->pow_bits < 0 || prm->pow_bits > 28) return fail(ZKHIP_ERR_INVALID, "chips: queries / pow_bits out of range");
-    if (!t_machine && any_prog(n) && (any_pairs(pairs, n) || any_cross(partners, n))) return fail(ZKHIP_ERR_INVALID, "chips: no lookups next to constraint programs (use the machine entries)");
+    if (!cs.machine && any_prog(cs, n) && (any_pairs(pairs, n) || any_cross(cs, partners, n))) return fail(ZKHIP_ERR_INVALID, "chips: no lookups next to constraint programs (use the machine entries)");
     for (int c = 0; c < n; c++) {
         if (log_ns[c] < 5 || log_ns[c] > MAX_LOG_ROWS || widths[c] == 0 || widths[c] % 4 != 0 || widths[c] > 1024)
             return fail(ZKHIP_ERR_INVALID, "chips: log_n in [5,22], width a multiple of 4 up to 1024");
         if (c && log_ns[c] > log_ns[c - 1]) return fail(ZKHIP_ERR_INVALID, "chips: tallest first");
-        if (pairs && (pairs[c] < 0 || pairs[c] > 64 || (!t_machine && (uint32_t)pairs[c] * 8 > widths[c]))) return fail(ZKHIP_ERR_INVALID, "chips: logup_pairs out of range");
+        if (pairs && (pairs[c] < 0 || pairs[c] > 64 || (!cs.machine && (uint32_t)pairs[c] * 8 > widths[c]))) return fail(ZKHIP_ERR_INVALID, "chips: logup_pairs out of range");
         if (partners && partners[c] >= 0) {
             const int d = partners[c];
             if (!pairs || d >= n || d == c || partners[d] != c || pairs[c] == 0 || pairs[d] != pairs[c] || log_ns[d] != log_ns[c])
@@ -1957,43 +1938,43 @@ static int check_chips(const int32_t* log_ns, const uint32_t* widths, const int3
         if (same > MAX_LEAF_MATS) return fail(ZKHIP_ERR_INVALID, "chips: at most 8 chips per height");
     }
     for (int c = 0; c < n; c++)
-        if (lq_of(c) > prm->log_blowup) return fail(ZKHIP_ERR_INVALID, "chips: a program of degree 4 or 5 needs log_blowup >= 2 (its quotient domain must lie inside the committed LDE domain)");
-    if (t_key) {
+        if (lq_of(cs, c) > prm->log_blowup) return fail(ZKHIP_ERR_INVALID, "chips: a program of degree 4 or 5 needs log_blowup >= 2 (its quotient domain must lie inside the committed LDE domain)");
+    if (cs.key) {
         bool some = false;
         for (int c = 0; c < n; c++) {
-            const uint32_t pw = pre_w(c);
+            const uint32_t pw = pre_w(cs, c);
             if (pw % 4 != 0 || pw + widths[c] > 1024) return fail(ZKHIP_ERR_INVALID, "keyed machine: preprocessed width a multiple of 4, preprocessed + main columns at most 1024");
-            if (pw && !header_has_prog(c)) return fail(ZKHIP_ERR_INVALID, "keyed machine: a chip with preprocessed columns brings its own program");
+            if (pw && !header_has_prog(cs, c)) return fail(ZKHIP_ERR_INVALID, "keyed machine: a chip with preprocessed columns brings its own program");
             some = some || pw != 0;
         }
         if (!some) return fail(ZKHIP_ERR_INVALID, "keyed machine: no chip has preprocessed columns (use the plain machine entries)");
     }
     return ZKHIP_OK;
 }
-static size_t chips_proof_words(const int32_t* log_ns, const uint32_t* widths, const int32_t* pairs, const int32_t* partners, int n, const zkhip_params* prm) {
-    const bool lk = any_pairs(pairs, n), cross = any_cross(partners, n);
+static size_t chips_proof_words(const ChipSet& cs, const int32_t* log_ns, const uint32_t* widths, const int32_t* pairs, const int32_t* partners, int n, const zkhip_params* prm) {
+    const bool lk = any_pairs(pairs, n), cross = any_cross(cs, partners, n);
     const size_t b = (size_t)prm->log_blowup, Hmax = (size_t)log_ns[0] + b, L = (size_t)log_ns[0];
     size_t words = 8 + (cross ? 4 : (lk ? 3 : 2)) * (size_t)n + 16 + (lk ? 8 : 0) + 8 * L + 4 + 1, perq = 16 * Hmax, hp = 0;
-    if (t_machine) {
-        words = 8 + (t_key ? 5 : 4) * (size_t)n + 16 + (lk ? 8 : 0) + 8 * L + 4 + 1 + (t_key ? 8 : 0);
-        for (int c = 0; c < n; c++) words += (header_has_prog(c) ? 8 : 0) + (lookup_of(c) ? 8 : 0);
-    } else if (any_prog(n)) { words += (size_t)n; for (int c = 0; c < n; c++) if (prog_of(c)) words += 8; }
+    if (cs.machine) {
+        words = 8 + (cs.key ? 5 : 4) * (size_t)n + 16 + (lk ? 8 : 0) + 8 * L + 4 + 1 + (cs.key ? 8 : 0);
+        for (int c = 0; c < n; c++) words += (header_has_prog(cs, c) ? 8 : 0) + (lookup_of(cs, c) ? 8 : 0);
+    } else if (any_prog(cs, n)) { words += (size_t)n; for (int c = 0; c < n; c++) if (prog_of(cs, c)) words += 8; }
     size_t he = 0;
     for (int c = 0; c < n; c++) {
         const size_t wp = perm_width(pairs, c);
-        words += 8 * (size_t)widths[c] + 8 * wp + 4 * qw_of(c) + ((cross && wp) ? 4 : 0) + 8 * (size_t)pre_w(c);
-        perq += widths[c] + wp + qw_of(c) + pre_w(c);
+        words += 8 * (size_t)widths[c] + 8 * wp + 4 * qw_of(cs, c) + ((cross && wp) ? 4 : 0) + 8 * (size_t)pre_w(cs, c);
+        perq += widths[c] + wp + qw_of(cs, c) + pre_w(cs, c);
         if (wp && (size_t)log_ns[c] + b > hp) hp = (size_t)log_ns[c] + b;
-        if (pre_w(c) && (size_t)log_ns[c] + b > he) he = (size_t)log_ns[c] + b;
+        if (pre_w(cs, c) && (size_t)log_ns[c] + b > he) he = (size_t)log_ns[c] + b;
     }
     perq += 8 * hp + 8 * he;
     for (size_t l = 0; l < L; l++) perq += 4 + 8 * (Hmax - 1 - l);
     return words + (size_t)prm->num_queries * perq;
 }
-static void chips_transcript_init(Challenger& ch, const int32_t* log_ns, const uint32_t* widths, const int32_t* pairs, const int32_t* partners, int n,
+static void chips_transcript_init(const ChipSet& cs, Challenger& ch, const int32_t* log_ns, const uint32_t* widths, const int32_t* pairs, const int32_t* partners, int n,
                                   const zkhip_params* prm, size_t n_public) {
-    const bool lk = any_pairs(pairs, n), cross = any_cross(partners, n);
-    ch.observe_canonical(chips_version(pairs, partners, n));
+    const bool lk = any_pairs(pairs, n), cross = any_cross(cs, partners, n);
+    ch.observe_canonical(chips_version(cs, pairs, partners, n));
     ch.observe_canonical((uint32_t)n);
     ch.observe_canonical((uint32_t)prm->log_blowup);
     ch.observe_canonical((uint32_t)prm->num_queries);
@@ -2001,46 +1982,51 @@ static void chips_transcript_init(Challenger& ch, const int32_t* log_ns, const u
     ch.observe_canonical((uint32_t)n_public);
     for (int c = 0; c < n; c++) {
         ch.observe_canonical((uint32_t)log_ns[c]); ch.observe_canonical(widths[c]);
-        if (t_machine) {
-            ch.observe_canonical(header_prog_word(c)); ch.observe_canonical(lookup_of(c) ? lookup_of(c)->ni : 0u);
-            if (t_key) ch.observe_canonical(pre_w(c));
+        if (cs.machine) {
+            ch.observe_canonical(header_prog_word(cs, c)); ch.observe_canonical(lookup_of(cs, c) ? lookup_of(cs, c)->ni : 0u);
+            if (cs.key) ch.observe_canonical(pre_w(cs, c));
             continue;
         }
         if (lk) ch.observe_canonical((uint32_t)pairs[c]);
         if (cross) ch.observe_canonical((uint32_t)(partners[c] + 1));
-        if (any_prog(n)) ch.observe_canonical(header_prog_word(c));
+        if (any_prog(cs, n)) ch.observe_canonical(header_prog_word(cs, c));
     }
     for (int c = 0; c < n; c++)
-        if (header_has_prog(c)) {
+        if (header_has_prog(cs, c)) {
             uint32_t dg[8];
-            air_digest_cached(*prog_of(c), dg);
+            air_digest_cached(*prog_of(cs, c), dg);
             for (int i = 0; i < 8; i++) ch.observe_canonical(dg[i]);
         }
     for (int c = 0; c < n; c++)
-        if (lookup_of(c)) {
+        if (lookup_of(cs, c)) {
             uint32_t dg[8];
-            lookup_digest(*lookup_of(c), dg);
+            lookup_digest(*lookup_of(cs, c), dg);
             for (int i = 0; i < 8; i++) ch.observe_canonical(dg[i]);
         }
-    if (t_key) for (int i = 0; i < 8; i++) ch.observe(t_key->root_m[i]);
+    if (cs.key) for (int i = 0; i < 8; i++) ch.observe(cs.key->root_m[i]);
 }
 // alpha-power offset of chip c inside the reduced-opening vector of its height
-static uint64_t height_offset(const int32_t* log_ns, const uint32_t* widths, const int32_t* pairs, int c) {
+static uint64_t height_offset(const ChipSet& cs, const int32_t* log_ns, const uint32_t* widths, const int32_t* pairs, int c) {
     uint64_t off = 0;
-    for (int d = 0; d < c; d++) if (log_ns[d] == log_ns[c]) off += 2 * (uint64_t)pre_w(d) + 2 * (uint64_t)widths[d] + 2 * perm_width(pairs, d) + qw_of(d);
+    for (int d = 0; d < c; d++) if (log_ns[d] == log_ns[c]) off += 2 * (uint64_t)pre_w(cs, d) + 2 * (uint64_t)widths[d] + 2 * perm_width(pairs, d) + qw_of(cs, d);
     return off;
 }
 }  // namespace zk
 
-size_t zkhip_chips_proof_size(const int32_t* log_ns, const uint32_t* widths, const int32_t* pairs, const int32_t* partners, int n_chips,
-                              const zkhip_params* prm, size_t n_public) {
+static size_t chips_proof_size_impl(const ChipSet& cs, const int32_t* log_ns, const uint32_t* widths, const int32_t* pairs, const int32_t* partners, int n_chips,
+                                    const zkhip_params* prm, size_t n_public) {
     (void)n_public;
-    if (check_chips(log_ns, widths, pairs, partners, n_chips, prm) != ZKHIP_OK) return 0;
-    return chips_proof_words(log_ns, widths, pairs, partners, n_chips, prm) * 4;
+    if (check_chips(cs, log_ns, widths, pairs, partners, n_chips, prm) != ZKHIP_OK) return 0;
+    return chips_proof_words(cs, log_ns, widths, pairs, partners, n_chips, prm) * 4;
 }
 
-int zkhip_prove_chips(zkhip_ctx* ctx, const zkhip_chip* chips, int n, const uint32_t* public_values, size_t n_public,
-                      const zkhip_params* prm, uint8_t* proof, size_t cap, size_t* len) {
+size_t zkhip_chips_proof_size(const int32_t* log_ns, const uint32_t* widths, const int32_t* pairs, const int32_t* partners, int n_chips,
+                              const zkhip_params* prm, size_t n_public) {
+    return chips_proof_size_impl(ChipSet{}, log_ns, widths, pairs, partners, n_chips, prm, n_public);
+}
+
+static int prove_chips_impl(const ChipSet& cs, zkhip_ctx* ctx, const zkhip_chip* chips, int n, const uint32_t* public_values, size_t n_public,
+                            const zkhip_params* prm, uint8_t* proof, size_t cap, size_t* len) {
     CHECK_CTX(ctx);
     if (!chips || !proof || !len || (n_public && !public_values)) return fail(ZKHIP_ERR_INVALID, "prove_chips: bad arguments");
     int32_t log_ns[MAX_CHIPS], pairs[MAX_CHIPS], partners[MAX_CHIPS]; uint32_t widths[MAX_CHIPS];
@@ -2049,10 +2035,10 @@ int zkhip_prove_chips(zkhip_ctx* ctx, const zkhip_chip* chips, int n, const uint
         log_ns[c] = chips[c].log_n; widths[c] = chips[c].width; pairs[c] = chips[c].logup_pairs; partners[c] = chips[c].partner;
         if (!chips[c].d_trace || chips[c].ld < chips[c].width) return fail(ZKHIP_ERR_INVALID, "prove_chips: bad chip descriptor");
     }
-    ZK_TRY(check_chips(log_ns, widths, pairs, partners, n, prm));
+    ZK_TRY(check_chips(cs, log_ns, widths, pairs, partners, n, prm));
     for (size_t i = 0; i < n_public; i++) if (public_values[i] >= P) return fail(ZKHIP_ERR_INVALID, "prove_chips: public values must be canonical");
-    const size_t need = chips_proof_words(log_ns, widths, pairs, partners, n, prm) * 4;
-    const bool lk = any_pairs(pairs, n), cross = any_cross(partners, n);
+    const size_t need = chips_proof_words(cs, log_ns, widths, pairs, partners, n, prm) * 4;
+    const bool lk = any_pairs(pairs, n), cross = any_cross(cs, partners, n);
     Ext cumsum[MAX_CHIPS];
     for (int c = 0; c < n; c++) cumsum[c] = ext_zero();
     if (cap < need) return fail(ZKHIP_ERR_BUFFER, "prove_chips: proof buffer too small (see zkhip_chips_proof_size)");
@@ -2070,36 +2056,36 @@ int zkhip_prove_chips(zkhip_ctx* ctx, const zkhip_chip* chips, int n, const uint
     for (int c = 0; c < n; c++) {
         lh[c] = log_ns[c] + b;
         const size_t mc = (size_t)1 << lh[c], nc = (size_t)1 << log_ns[c];
-        tl_off[c + 1] = tl_off[c] + mc * (pre_w(c) + widths[c]);     // a keyed chip's LDE rows are [preprocessed | main]
-        ql_off[c + 1] = ql_off[c] + mc * qw_of(c);
+        tl_off[c + 1] = tl_off[c] + mc * (pre_w(cs, c) + widths[c]);     // a keyed chip's LDE rows are [preprocessed | main]
+        ql_off[c + 1] = ql_off[c] + mc * qw_of(cs, c);
         dv_off[c + 1] = dv_off[c] + 8 * (mc + nc);               // [2][mc] 1/(x - z) then [2][nc] x/(x - z), ext words
         wp[c] = perm_width(pairs, c);
         pl_off[c + 1] = pl_off[c] + mc * wp[c];
-        op_off[c + 1] = op_off[c] + 8 * (size_t)pre_w(c) + 8 * (size_t)widths[c] + 8 * wp[c] + 4 * qw_of(c);
-        size_t npw = widths[c] > qw_of(c) ? widths[c] : qw_of(c);
+        op_off[c + 1] = op_off[c] + 8 * (size_t)pre_w(cs, c) + 8 * (size_t)widths[c] + 8 * wp[c] + 4 * qw_of(cs, c);
+        size_t npw = widths[c] > qw_of(cs, c) ? widths[c] : qw_of(cs, c);
         if (wp[c] > npw) npw = wp[c];
-        if (pre_w(c) > npw) npw = pre_w(c);
+        if (pre_w(cs, c) > npw) npw = pre_w(cs, c);
         ap_off[c + 1] = ap_off[c] + 4 * npw;
-        if ((nc << lq_of(c)) > nmax_chunk) nmax_chunk = nc << lq_of(c);       // quotient values of the chip: 2^lq chunks of nc points
+        if ((nc << lq_of(cs, c)) > nmax_chunk) nmax_chunk = nc << lq_of(cs, c);       // quotient values of the chip: 2^lq chunks of nc points
         if (nc * wp[c] > perm_max) perm_max = nc * wp[c];
         if (wp[c] && lh[c] > Hp) Hp = lh[c];
     }
     uint32_t* pf = (uint32_t*)proof;
     size_t pos = 0;
-    pf[pos++] = PROOF_MAGIC; pf[pos++] = chips_version(pairs, partners, n); pf[pos++] = (uint32_t)n; pf[pos++] = (uint32_t)b;
+    pf[pos++] = PROOF_MAGIC; pf[pos++] = chips_version(cs, pairs, partners, n); pf[pos++] = (uint32_t)n; pf[pos++] = (uint32_t)b;
     pf[pos++] = (uint32_t)Q; pf[pos++] = (uint32_t)prm->pow_bits; pf[pos++] = (uint32_t)n_public; pf[pos++] = 16u;
     for (int c = 0; c < n; c++) {
         pf[pos++] = (uint32_t)log_ns[c]; pf[pos++] = widths[c];
-        if (t_machine) { pf[pos++] = header_prog_word(c); pf[pos++] = lookup_of(c) ? lookup_of(c)->ni : 0u; if (t_key) pf[pos++] = pre_w(c); continue; }
+        if (cs.machine) { pf[pos++] = header_prog_word(cs, c); pf[pos++] = lookup_of(cs, c) ? lookup_of(cs, c)->ni : 0u; if (cs.key) pf[pos++] = pre_w(cs, c); continue; }
         if (lk) pf[pos++] = (uint32_t)pairs[c];
         if (cross) pf[pos++] = (uint32_t)(partners[c] + 1);
-        if (any_prog(n)) pf[pos++] = header_prog_word(c);
+        if (any_prog(cs, n)) pf[pos++] = header_prog_word(cs, c);
     }
-    for (int c = 0; c < n; c++) if (header_has_prog(c)) { air_digest_cached(*prog_of(c), pf + pos); pos += 8; }
-    for (int c = 0; c < n; c++) if (lookup_of(c)) { lookup_digest(*lookup_of(c), pf + pos); pos += 8; }
-    if (t_key) for (int i = 0; i < 8; i++) pf[pos++] = from_monty(t_key->root_m[i]);
+    for (int c = 0; c < n; c++) if (header_has_prog(cs, c)) { air_digest_cached(*prog_of(cs, c), pf + pos); pos += 8; }
+    for (int c = 0; c < n; c++) if (lookup_of(cs, c)) { lookup_digest(*lookup_of(cs, c), pf + pos); pos += 8; }
+    if (cs.key) for (int i = 0; i < 8; i++) pf[pos++] = from_monty(cs.key->root_m[i]);
     Challenger ch;
-    chips_transcript_init(ch, log_ns, widths, pairs, partners, n, prm, n_public);
+    chips_transcript_init(cs, ch, log_ns, widths, pairs, partners, n, prm, n_public);
     uint32_t root[8];
 
     // ---- 1. every chip's LDE, one mixed-height tree
@@ -2113,13 +2099,13 @@ int zkhip_prove_chips(zkhip_ctx* ctx, const zkhip_chip* chips, int n, const uint
     MatDesc tm[MAX_CHIPS], qm[MAX_CHIPS];
     size_t cw[MAX_CHIPS];                          // row pitch of a chip's LDE: preprocessed + main columns
     for (int c = 0; c < n; c++) {
-        const uint32_t pw = pre_w(c);
+        const uint32_t pw = pre_w(cs, c);
         cw[c] = (size_t)pw + widths[c];
         if (pw)                                    // the key's LDE columns beside the main ones: what the program and the interactions read
-            ZK_HIP(launch_copy2d(tlde + tl_off[c], cw[c], t_key->d_lde[c], pw, (uint32_t)pw, (uint64_t)1 << lh[c], st));
+            ZK_HIP(launch_copy2d(tlde + tl_off[c], cw[c], cs.key->d_lde[c], pw, (uint32_t)pw, (uint64_t)1 << lh[c], st));
         ZK_TRY(op_coset_lde(ctx, chips[c].d_trace, chips[c].ld, tlde + tl_off[c] + pw, cw[c], log_ns[c], widths[c], b, MONTY_GEN));
         tm[c] = MatDesc{tlde + tl_off[c] + pw, cw[c], widths[c]};
-        qm[c] = MatDesc{qlde + ql_off[c], qw_of(c), (uint32_t)qw_of(c)};
+        qm[c] = MatDesc{qlde + ql_off[c], qw_of(cs, c), (uint32_t)qw_of(cs, c)};
     }
     ZK_TRY(op_merkle_commit_mixed(ctx, tm, lh, n, ttree));
     ZK_TRY(d2h(ctx, root, ttree + (2 * mmax - 2) * 8, 32));
@@ -2140,15 +2126,15 @@ int zkhip_prove_chips(zkhip_ctx* ctx, const zkhip_chip* chips, int n, const uint
         MatDesc pmats[MAX_CHIPS]; int plh[MAX_CHIPS]; int np = 0;
         for (int c = 0; c < n; c++) {
             if (!wp[c]) continue;
-            if (t_machine && pre_w(c)) {           // the interactions address [preprocessed | main] rows of the trace domain
-                const size_t nc = (size_t)1 << log_ns[c], pw = pre_w(c);
+            if (cs.machine && pre_w(cs, c)) {           // the interactions address [preprocessed | main] rows of the trace domain
+                const size_t nc = (size_t)1 << log_ns[c], pw = pre_w(cs, c);
                 void* v_ct;
                 ZK_TRY(ctx_reserve(ctx, S_KEYTRACE, nc * cw[c] * 4, &v_ct));
                 uint32_t* ct = (uint32_t*)v_ct;
-                ZK_HIP(launch_copy2d(ct, cw[c], t_key->d_trace[c], pw, (uint32_t)pw, nc, st));
+                ZK_HIP(launch_copy2d(ct, cw[c], cs.key->d_trace[c], pw, (uint32_t)pw, nc, st));
                 ZK_HIP(launch_copy2d(ct + pw, cw[c], chips[c].d_trace, chips[c].ld, widths[c], nc, st));
-                ZK_TRY(run_lookup_perm(ctx, ct, cw[c], log_ns[c], *lookup_of(c), gamma, beta_l, (uint32_t*)v_perm));
-            } else if (t_machine) ZK_TRY(run_lookup_perm(ctx, chips[c].d_trace, chips[c].ld, log_ns[c], *lookup_of(c), gamma, beta_l, (uint32_t*)v_perm));
+                ZK_TRY(run_lookup_perm(ctx, ct, cw[c], log_ns[c], *lookup_of(cs, c), gamma, beta_l, (uint32_t*)v_perm));
+            } else if (cs.machine) ZK_TRY(run_lookup_perm(ctx, chips[c].d_trace, chips[c].ld, log_ns[c], *lookup_of(cs, c), gamma, beta_l, (uint32_t*)v_perm));
             else ZK_TRY(run_perm_trace(ctx, chips[c].d_trace, chips[c].ld, log_ns[c], (uint32_t)pairs[c], gamma, beta_l, (uint32_t*)v_perm));
             if (cross)          // the running sum's last value: row N - 1, column S
                 ZK_TRY(d2h(ctx, &cumsum[c], (const uint32_t*)v_perm + (((size_t)1 << log_ns[c]) - 1) * wp[c] + 4 * (size_t)pairs[c], 16));
@@ -2171,27 +2157,27 @@ int zkhip_prove_chips(zkhip_ctx* ctx, const zkhip_chip* chips, int n, const uint
         LogupIn lu;
         if (wp[c]) { lu.pairs = (uint32_t)pairs[c]; lu.perm_lde = plde + pl_off[c]; lu.gamma = gamma; lu.beta = beta_l; lu.cumsum = cumsum[c]; }
         const bool own_coset_direct = b == 1;             // as in the single-matrix prover
-        if (t_machine && !lookup_of(c) && !header_has_prog(c)) {
+        if (cs.machine && !lookup_of(cs, c) && !header_has_prog(cs, c)) {
             // a synthetic table without lookups inside a machine: the specialised kernel (same values as its program form, bit for bit)
             ZK_TRY(run_quotient(ctx, tlde + tl_off[c], widths[c], log_ns[c], widths[c], alpha, lu, qchunk, own_coset_direct ? qlde + ql_off[c] : nullptr, 8));
-        } else if (t_machine && lookup_of(c)) {
+        } else if (cs.machine && lookup_of(cs, c)) {
             // the chip's lookup constraints fold after its program's: the program's weights move up by alpha^(cols + 3)
-            const LookupView& lv = *lookup_of(c);
+            const LookupView& lv = *lookup_of(cs, c);
             void* v_add;
-            ZK_TRY(ctx_reserve(ctx, S_ADDEND, ((size_t)1 << (log_ns[c] + lq_of(c))) * 16, &v_add));
-            ZK_TRY(run_lookup_addend(ctx, tlde + tl_off[c], cw[c], plde + pl_off[c], wp[c], log_ns[c], lq_of(c), lv, gamma, beta_l, alpha, cumsum[c], (uint32_t*)v_add));
-            ZK_TRY(run_quotient_air(ctx, *prog_of(c), tlde + tl_off[c], cw[c], log_ns[c], (uint32_t)cw[c], public_values, alpha, qchunk,
+            ZK_TRY(ctx_reserve(ctx, S_ADDEND, ((size_t)1 << (log_ns[c] + lq_of(cs, c))) * 16, &v_add));
+            ZK_TRY(run_lookup_addend(ctx, tlde + tl_off[c], cw[c], plde + pl_off[c], wp[c], log_ns[c], lq_of(cs, c), lv, gamma, beta_l, alpha, cumsum[c], (uint32_t*)v_add));
+            ZK_TRY(run_quotient_air(ctx, *prog_of(cs, c), tlde + tl_off[c], cw[c], log_ns[c], (uint32_t)cw[c], public_values, alpha, qchunk,
                                     own_coset_direct ? qlde + ql_off[c] : nullptr, 8, ext_pow(alpha, lv.cols + 3), (const uint32_t*)v_add));
-        } else if (prog_of(c)) ZK_TRY(run_quotient_air(ctx, *prog_of(c), tlde + tl_off[c], cw[c], log_ns[c], (uint32_t)cw[c], public_values, alpha, qchunk,
+        } else if (prog_of(cs, c)) ZK_TRY(run_quotient_air(ctx, *prog_of(cs, c), tlde + tl_off[c], cw[c], log_ns[c], (uint32_t)cw[c], public_values, alpha, qchunk,
                                                 own_coset_direct ? qlde + ql_off[c] : nullptr, 8));
         else ZK_TRY(run_quotient(ctx, tlde + tl_off[c], widths[c], log_ns[c], widths[c], alpha, lu, qchunk, own_coset_direct ? qlde + ql_off[c] : nullptr, 8));
-        const uint32_t w2n = two_adic_generator(log_ns[c] + lq_of(c));
-        for (int k = 0; k < (1 << lq_of(c)); k++) {
+        const uint32_t w2n = two_adic_generator(log_ns[c] + lq_of(cs, c));
+        for (int k = 0; k < (1 << lq_of(cs, c)); k++) {
             if (own_coset_direct)                              // (blowup 2: every chip has two chunks)
                 ZK_TRY(op_coset_lde(ctx, qchunk + (size_t)k * nc * 4, 4, qlde + ql_off[c] + (size_t)(1 - k) * nc * 8 + 4 * k, 8, log_ns[c], 4, 0,
                                     k == 0 ? w2n : finv(w2n)));
             else
-                ZK_TRY(op_coset_lde(ctx, qchunk + (size_t)k * nc * 4, 4, qlde + ql_off[c] + 4 * k, qw_of(c), log_ns[c], 4, b, finv(fpow(w2n, (uint64_t)k))));
+                ZK_TRY(op_coset_lde(ctx, qchunk + (size_t)k * nc * 4, 4, qlde + ql_off[c] + 4 * k, qw_of(cs, c), log_ns[c], 4, b, finv(fpow(w2n, (uint64_t)k))));
         }
     }
     ZK_TRY(op_merkle_commit_mixed(ctx, qm, lh, n, qtree));
@@ -2213,12 +2199,12 @@ int zkhip_prove_chips(zkhip_ctx* ctx, const zkhip_chip* chips, int n, const uint
         uint32_t* dv = dinv + dv_off[c];
         uint32_t* xw = dv + 8 * mc;
         ZK_HIP(launch_inv_denominators(ctx->dom_xs, mc, zpts[0], zpts[1], 2, dv, xw, nc, st));
-        const size_t pw = pre_w(c);
+        const size_t pw = pre_w(cs, c);
         uint32_t* oc = d_open + op_off[c] + 8 * pw;                       // the chip's openings: [preprocessed local | next] first
         if (pw) ZK_TRY(run_open(ctx, tlde + tl_off[c], cw[c], log_ns[c], (uint32_t)pw, zpts, 2, xw, d_open + op_off[c]));
         ZK_TRY(run_open(ctx, tlde + tl_off[c] + pw, cw[c], log_ns[c], widths[c], zpts, 2, xw, oc));
         if (wp[c]) ZK_TRY(run_open(ctx, plde + pl_off[c], wp[c], log_ns[c], (uint32_t)wp[c], zpts, 2, xw, oc + 8 * (size_t)widths[c]));
-        ZK_TRY(run_open(ctx, qlde + ql_off[c], qw_of(c), log_ns[c], (uint32_t)qw_of(c), zpts, 1, xw, oc + 8 * (size_t)widths[c] + 8 * wp[c]));
+        ZK_TRY(run_open(ctx, qlde + ql_off[c], qw_of(cs, c), log_ns[c], (uint32_t)qw_of(cs, c), zpts, 1, xw, oc + 8 * (size_t)widths[c] + 8 * wp[c]));
     }
     std::vector<uint32_t> opened(op_off[n]);
     ZK_TRY(d2h(ctx, opened.data(), d_open, opened.size() * 4));
@@ -2262,7 +2248,7 @@ int zkhip_prove_chips(zkhip_ctx* ctx, const zkhip_chip* chips, int n, const uint
     for (int c = 0; c < n; c++) {
         const uint32_t W = widths[c];
         const Ext* fp = (const Ext*)(apows.data() + ap_off[c]);
-        const uint32_t Pw = pre_w(c);
+        const uint32_t Pw = pre_w(cs, c);
         const Ext* op_el = (const Ext*)(opened.data() + op_off[c]);
         const Ext* op_en = op_el + Pw;
         const Ext* op_loc = op_en + Pw;
@@ -2280,12 +2266,12 @@ int zkhip_prove_chips(zkhip_ctx* ctx, const zkhip_chip* chips, int n, const uint
             ra.y_pl = ext_add(ra.y_pl, ext_mul(fp[j], op_pl[j]));
             ra.y_pn = ext_add(ra.y_pn, ext_mul(fp[j], op_pn[j]));
         }
-        for (size_t j = 0; j < qw_of(c); j++) ra.y_q = ext_add(ra.y_q, ext_mul(fp[j], op_q[j]));
-        const uint64_t off0 = height_offset(log_ns, widths, pairs, c), off = off0 + 2 * (uint64_t)Pw;
+        for (size_t j = 0; j < qw_of(cs, c); j++) ra.y_q = ext_add(ra.y_q, ext_mul(fp[j], op_q[j]));
+        const uint64_t off0 = height_offset(cs, log_ns, widths, pairs, c), off = off0 + 2 * (uint64_t)Pw;
         ra.off_loc = ext_pow(fa, off); ra.off_next = ext_pow(fa, off + W);
         ra.off_pl = ext_pow(fa, off + 2 * (uint64_t)W); ra.off_pn = ext_pow(fa, off + 2 * (uint64_t)W + wp[c]);
         ra.off_q = ext_pow(fa, off + 2 * (uint64_t)W + 2 * wp[c]);
-        ra.tlde = tlde + tl_off[c] + Pw; ra.t_ld = cw[c]; ra.width = W; ra.qlde = qlde + ql_off[c]; ra.q_ld = qw_of(c); ra.q_width = (uint32_t)qw_of(c); ra.rows = (uint64_t)1 << lh[c];
+        ra.tlde = tlde + tl_off[c] + Pw; ra.t_ld = cw[c]; ra.width = W; ra.qlde = qlde + ql_off[c]; ra.q_ld = qw_of(cs, c); ra.q_width = (uint32_t)qw_of(cs, c); ra.rows = (uint64_t)1 << lh[c];
         ra.plde = wp[c] ? plde + pl_off[c] : nullptr; ra.p_ld = wp[c]; ra.p_width = (uint32_t)wp[c];
         ra.alpha_pow = (const uint32_t*)v_apf + ap_off[c]; ra.dinv = dinv + dv_off[c]; ra.out = ro_of[lh[c]];
         ra.accumulate = started[lh[c]] ? 1 : 0;
@@ -2331,17 +2317,17 @@ int zkhip_prove_chips(zkhip_ctx* ctx, const zkhip_chip* chips, int n, const uint
         };
         for (int q = 0; q < Q; q++) {
             const size_t index = ch.sample_bits(Hmax);
-            if (t_key) {
-                for (int c = 0; c < n; c++) if (pre_w(c)) push(tlde + tl_off[c] + (index >> (Hmax - lh[c])) * cw[c], pre_w(c));
-                push_path(t_key->d_tree, (size_t)1 << t_key->He, index >> (Hmax - t_key->He), t_key->He);
+            if (cs.key) {
+                for (int c = 0; c < n; c++) if (pre_w(cs, c)) push(tlde + tl_off[c] + (index >> (Hmax - lh[c])) * cw[c], pre_w(cs, c));
+                push_path(cs.key->d_tree, (size_t)1 << cs.key->He, index >> (Hmax - cs.key->He), cs.key->He);
             }
-            for (int c = 0; c < n; c++) push(tlde + tl_off[c] + (index >> (Hmax - lh[c])) * cw[c] + pre_w(c), widths[c]);
+            for (int c = 0; c < n; c++) push(tlde + tl_off[c] + (index >> (Hmax - lh[c])) * cw[c] + pre_w(cs, c), widths[c]);
             push_path(ttree, mmax, index, Hmax);
             if (lk) {
                 for (int c = 0; c < n; c++) if (wp[c]) push(plde + pl_off[c] + (index >> (Hmax - lh[c])) * wp[c], wp[c]);
                 push_path(ptree, (size_t)1 << Hp, index >> (Hmax - Hp), Hp);
             }
-            for (int c = 0; c < n; c++) push(qlde + ql_off[c] + (index >> (Hmax - lh[c])) * qw_of(c), qw_of(c));
+            for (int c = 0; c < n; c++) push(qlde + ql_off[c] + (index >> (Hmax - lh[c])) * qw_of(cs, c), qw_of(cs, c));
             push_path(qtree, mmax, index, Hmax);
             size_t idx = index;
             for (int l = 0; l < L; l++) {
@@ -2431,55 +2417,55 @@ static uint32_t verify_mixed_x16(const uint32_t* root_m, int Hmax, int count, co
     return failed;
 }
 
-int zkhip_verify_chips(const uint8_t* proof, size_t len, const int32_t* log_ns, const uint32_t* widths, const int32_t* pairs, const int32_t* partners, int n,
-                       const uint32_t* public_values, size_t n_public, const zkhip_params* prm, int* reason) {
+static int verify_chips_impl(const ChipSet& cs, const uint8_t* proof, size_t len, const int32_t* log_ns, const uint32_t* widths, const int32_t* pairs, const int32_t* partners, int n,
+                             const uint32_t* public_values, size_t n_public, const zkhip_params* prm, int* reason) {
     int dummy;
     if (!reason) reason = &dummy;
     *reason = 0;
     auto reject = [&](int why) { *reason = why; return fail(ZKHIP_ERR_VERIFY, "proof rejected (check " + std::to_string(why) + ")"); };
-    if (check_chips(log_ns, widths, pairs, partners, n, prm) != ZKHIP_OK) return reject(1);
+    if (check_chips(cs, log_ns, widths, pairs, partners, n, prm) != ZKHIP_OK) return reject(1);
     if (!proof || (n_public && !public_values)) return reject(1);
-    if (len != chips_proof_words(log_ns, widths, pairs, partners, n, prm) * 4) return reject(2);
+    if (len != chips_proof_words(cs, log_ns, widths, pairs, partners, n, prm) * 4) return reject(2);
     const uint32_t* pf = (const uint32_t*)proof;
-    const bool lk = any_pairs(pairs, n), cross = any_cross(partners, n);
+    const bool lk = any_pairs(pairs, n), cross = any_cross(cs, partners, n);
     const int b = prm->log_blowup, Hmax = log_ns[0] + b, L = log_ns[0];
-    if (pf[0] != PROOF_MAGIC || pf[1] != chips_version(pairs, partners, n) || pf[2] != (uint32_t)n || pf[3] != (uint32_t)b ||
+    if (pf[0] != PROOF_MAGIC || pf[1] != chips_version(cs, pairs, partners, n) || pf[2] != (uint32_t)n || pf[3] != (uint32_t)b ||
         pf[4] != (uint32_t)prm->num_queries || pf[5] != (uint32_t)prm->pow_bits || pf[6] != (uint32_t)n_public || pf[7] != 16u) return reject(3);
     size_t pos = 8;
     for (int c = 0; c < n; c++) {
         if (pf[pos] != (uint32_t)log_ns[c] || pf[pos + 1] != widths[c]) return reject(3);
         pos += 2;
-        if (t_machine) {
-            if (pf[pos] != header_prog_word(c) || pf[pos + 1] != (lookup_of(c) ? lookup_of(c)->ni : 0u)) return reject(3);
+        if (cs.machine) {
+            if (pf[pos] != header_prog_word(cs, c) || pf[pos + 1] != (lookup_of(cs, c) ? lookup_of(cs, c)->ni : 0u)) return reject(3);
             pos += 2;
-            if (t_key) { if (pf[pos] != pre_w(c)) return reject(3); pos++; }
+            if (cs.key) { if (pf[pos] != pre_w(cs, c)) return reject(3); pos++; }
             continue;
         }
         if (lk) { if (pf[pos] != (uint32_t)pairs[c]) return reject(3); pos++; }
         if (cross) { if (pf[pos] != (uint32_t)(partners[c] + 1)) return reject(3); pos++; }
-        if (any_prog(n)) { if (pf[pos] != header_prog_word(c)) return reject(3); pos++; }
+        if (any_prog(cs, n)) { if (pf[pos] != header_prog_word(cs, c)) return reject(3); pos++; }
     }
     for (int c = 0; c < n; c++)
-        if (header_has_prog(c)) {
+        if (header_has_prog(cs, c)) {
             uint32_t dg[8];
-            air_digest_cached(*prog_of(c), dg);
+            air_digest_cached(*prog_of(cs, c), dg);
             for (int i = 0; i < 8; i++) if (pf[pos + i] != dg[i]) return reject(3);
             pos += 8;
         }
     for (int c = 0; c < n; c++)
-        if (lookup_of(c)) {
+        if (lookup_of(cs, c)) {
             uint32_t dg[8];
-            lookup_digest(*lookup_of(c), dg);
+            lookup_digest(*lookup_of(cs, c), dg);
             for (int i = 0; i < 8; i++) if (pf[pos + i] != dg[i]) return reject(3);
             pos += 8;
         }
-    if (t_key) { for (int i = 0; i < 8; i++) if (pf[pos + i] != from_monty(t_key->root_m[i])) return reject(3); pos += 8; }     // a proof under another key
+    if (cs.key) { for (int i = 0; i < 8; i++) if (pf[pos + i] != from_monty(cs.key->root_m[i])) return reject(3); pos += 8; }     // a proof under another key
     for (size_t i = pos; i < len / 4; i++) if (pf[i] >= P) return reject(4);
     for (size_t i = 0; i < n_public; i++) if (public_values[i] >= P) return reject(4);
     int lh[MAX_CHIPS]; uint32_t w8[MAX_CHIPS]; size_t wp[MAX_CHIPS];
-    for (int c = 0; c < n; c++) { lh[c] = log_ns[c] + b; w8[c] = (uint32_t)qw_of(c); wp[c] = perm_width(pairs, c); }
+    for (int c = 0; c < n; c++) { lh[c] = log_ns[c] + b; w8[c] = (uint32_t)qw_of(cs, c); wp[c] = perm_width(pairs, c); }
     Challenger ch;
-    chips_transcript_init(ch, log_ns, widths, pairs, partners, n, prm, n_public);
+    chips_transcript_init(cs, ch, log_ns, widths, pairs, partners, n, prm, n_public);
     Ext cumsum[MAX_CHIPS];
     for (int c = 0; c < n; c++) cumsum[c] = ext_zero();
     uint32_t troot[8], proot[8] = {0}, qroot[8];
@@ -2506,14 +2492,14 @@ int zkhip_verify_chips(const uint8_t* proof, size_t len, const int32_t* log_ns, 
     for (int c = 0; c < n; c++) {
         const uint32_t W = widths[c];
         auto take = [&](std::vector<Ext>& v, size_t cnt) { v.resize(cnt); for (size_t j = 0; j < cnt; j++) v[j] = ext_from_canon(pf + pos + 4 * j); pos += 4 * cnt; };
-        take(oel[c], pre_w(c)); take(oen[c], pre_w(c));
+        take(oel[c], pre_w(cs, c)); take(oen[c], pre_w(cs, c));
         take(loc[c], W); take(nxt[c], W); take(opl[c], wp[c]); take(opn[c], wp[c]); take(opq[c], w8[c]);
     }
     // (the query groups run on worker threads, which do not see this thread's key: widths and root by value from here on)
     uint32_t ew[MAX_CHIPS], pwv[MAX_CHIPS]; int elh[MAX_CHIPS], echip[MAX_CHIPS]; int ne = 0, He = 0;
-    const uint32_t* const eroot = t_key ? t_key->root_m : nullptr;
-    for (int c = 0; c < n; c++) pwv[c] = pre_w(c);
-    for (int c = 0; c < n; c++) if (pre_w(c)) { ew[ne] = pre_w(c); elh[ne] = lh[c]; echip[ne] = c; ne++; if (lh[c] > He) He = lh[c]; }
+    const uint32_t* const eroot = cs.key ? cs.key->root_m : nullptr;
+    for (int c = 0; c < n; c++) pwv[c] = pre_w(cs, c);
+    for (int c = 0; c < n; c++) if (pre_w(cs, c)) { ew[ne] = pre_w(cs, c); elh[ne] = lh[c]; echip[ne] = c; ne++; if (lh[c] > He) He = lh[c]; }
     for (int c = 0; c < n; c++) {
         for (const Ext& e : oel[c]) ch.observe_ext(e);
         for (const Ext& e : oen[c]) ch.observe_ext(e);
@@ -2534,13 +2520,13 @@ int zkhip_verify_chips(const uint8_t* proof, size_t len, const int32_t* log_ns, 
         // what the chip's program and interactions read: the combined row [preprocessed | main] at zeta, and at zeta g
         std::vector<Ext> cl_, cn_;
         const Ext *row_l = loc[c].data(), *row_n = nxt[c].data();
-        if (pre_w(c)) {
+        if (pre_w(cs, c)) {
             cl_ = oel[c]; cl_.insert(cl_.end(), loc[c].begin(), loc[c].end());
             cn_ = oen[c]; cn_.insert(cn_.end(), nxt[c].begin(), nxt[c].end());
             row_l = cl_.data(); row_n = cn_.data();
         }
-        if (prog_of(c))
-            acc = air_fold_ext(*prog_of(c), row_l, row_n, public_values, sel_first, ext_mul(zh, ext_inv(ext_sub_base(zeta, finv(gn)))), sel_trans, alpha);
+        if (prog_of(cs, c))
+            acc = air_fold_ext(*prog_of(cs, c), row_l, row_n, public_values, sel_first, ext_mul(zh, ext_inv(ext_sub_base(zeta, finv(gn)))), sel_trans, alpha);
         else for (uint32_t g = 0; g < widths[c] / 4; g++) {
             const Ext &a = loc[c][4 * g], &bb = loc[c][4 * g + 1], &cc = loc[c][4 * g + 2], &d = loc[c][4 * g + 3], &dn = nxt[c][4 * g + 3];
             const uint32_t k1 = to_monty(g + 1), k2 = to_monty(2 * g + 3), d0 = to_monty(5 * g + 7);
@@ -2551,8 +2537,8 @@ int zkhip_verify_chips(const uint8_t* proof, size_t len, const int32_t* log_ns, 
             acc = ext_add(ext_mul(acc, alpha), c2);
             acc = ext_add(ext_mul(acc, alpha), c3);
         }
-        if (wp[c] && t_machine) {
-            const LookupView& lv = *lookup_of(c);
+        if (wp[c] && cs.machine) {
+            const LookupView& lv = *lookup_of(cs, c);
             const Ext sel_last = ext_mul(zh, ext_inv(ext_sub_base(zeta, finv(gn))));
             std::vector<Ext> pl(lv.cols + 1), pn(lv.cols + 1);
             for (uint32_t q = 0; q <= lv.cols; q++) { pl[q] = recombine(&opl[c][4 * q]); pn[q] = recombine(&opn[c][4 * q]); }
@@ -2596,7 +2582,7 @@ int zkhip_verify_chips(const uint8_t* proof, size_t len, const int32_t* log_ns, 
     // (b) FRI
     const Ext fa = ch.sample_ext();
     size_t npmax = 8;
-    for (int c = 0; c < n; c++) { if (widths[c] > npmax) npmax = widths[c]; if (wp[c] > npmax) npmax = wp[c]; if (pre_w(c) > npmax) npmax = pre_w(c); if (w8[c] > npmax) npmax = w8[c]; }
+    for (int c = 0; c < n; c++) { if (widths[c] > npmax) npmax = widths[c]; if (wp[c] > npmax) npmax = wp[c]; if (pre_w(cs, c) > npmax) npmax = pre_w(cs, c); if (w8[c] > npmax) npmax = w8[c]; }
     std::vector<Ext> fapow(npmax);
     fapow[0] = ext_one();
     for (size_t j = 1; j < npmax; j++) fapow[j] = ext_mul(fapow[j - 1], fa);
@@ -2604,7 +2590,7 @@ int zkhip_verify_chips(const uint8_t* proof, size_t len, const int32_t* log_ns, 
     Ext s_loc[MAX_CHIPS], s_nxt[MAX_CHIPS], s_pl[MAX_CHIPS], s_pn[MAX_CHIPS], s_q[MAX_CHIPS], znext[MAX_CHIPS];
     Ext y_el[MAX_CHIPS], y_en[MAX_CHIPS], s_el[MAX_CHIPS], s_en[MAX_CHIPS];
     for (int c = 0; c < n; c++) {
-        const uint32_t W = widths[c], Pw = pre_w(c);
+        const uint32_t W = widths[c], Pw = pre_w(cs, c);
         y_loc[c] = y_nxt[c] = y_pl[c] = y_pn[c] = y_q[c] = y_el[c] = y_en[c] = ext_zero();
         for (uint32_t j = 0; j < Pw; j++) {
             y_el[c] = ext_add(y_el[c], ext_mul(fapow[j], oel[c][j]));
@@ -2619,7 +2605,7 @@ int zkhip_verify_chips(const uint8_t* proof, size_t len, const int32_t* log_ns, 
             y_pn[c] = ext_add(y_pn[c], ext_mul(fapow[j], opn[c][j]));
         }
         for (uint32_t j = 0; j < w8[c]; j++) y_q[c] = ext_add(y_q[c], ext_mul(fapow[j], opq[c][j]));
-        const uint64_t off0 = height_offset(log_ns, widths, pairs, c), off = off0 + 2 * (uint64_t)Pw;
+        const uint64_t off0 = height_offset(cs, log_ns, widths, pairs, c), off = off0 + 2 * (uint64_t)Pw;
         s_el[c] = ext_pow(fa, off0); s_en[c] = ext_pow(fa, off0 + Pw);
         s_loc[c] = ext_pow(fa, off); s_nxt[c] = ext_pow(fa, off + W); s_pl[c] = ext_pow(fa, off + 2 * (uint64_t)W);
         s_pn[c] = ext_pow(fa, off + 2 * (uint64_t)W + wp[c]); s_q[c] = ext_pow(fa, off + 2 * (uint64_t)W + 2 * wp[c]);
@@ -2748,6 +2734,14 @@ int zkhip_verify_chips(const uint8_t* proof, size_t len, const int32_t* log_ns, 
 }
 
 // ---- chips with their own constraint programs (programs[c] == NULL: the built-in synthetic AIR); degree <= 3, no lookups ----
+int zkhip_prove_chips(zkhip_ctx* ctx, const zkhip_chip* chips, int n, const uint32_t* public_values, size_t n_public,
+                      const zkhip_params* prm, uint8_t* proof, size_t cap, size_t* len) {
+    return prove_chips_impl(ChipSet{}, ctx, chips, n, public_values, n_public, prm, proof, cap, len);
+}
+int zkhip_verify_chips(const uint8_t* proof, size_t len, const int32_t* log_ns, const uint32_t* widths, const int32_t* pairs, const int32_t* partners, int n,
+                       const uint32_t* public_values, size_t n_public, const zkhip_params* prm, int* reason) {
+    return verify_chips_impl(ChipSet{}, proof, len, log_ns, widths, pairs, partners, n, public_values, n_public, prm, reason);
+}
 static int chip_programs(const uint32_t* const* programs, const size_t* program_words, const uint32_t* widths, int n, size_t n_public,
                          AirView* views, const AirView** table) {
     if (!programs || !program_words || !widths || n < 1 || n > MAX_CHIPS) return fail(ZKHIP_ERR_INVALID, "chips_air: bad arguments");
@@ -2764,8 +2758,9 @@ size_t zkhip_chips_proof_size_air(const int32_t* log_ns, const uint32_t* widths,
     AirView views[MAX_CHIPS];
     const AirView* table[MAX_CHIPS];
     if (chip_programs(programs, program_words, widths, n_chips, n_public, views, table) != ZKHIP_OK) return 0;
-    ChipAirScope scope(table);
-    return zkhip_chips_proof_size(log_ns, widths, nullptr, nullptr, n_chips, prm, n_public);
+    ChipSet cs;
+    cs.air = table;
+    return chips_proof_size_impl(cs, log_ns, widths, nullptr, nullptr, n_chips, prm, n_public);
 }
 int zkhip_prove_chips_air(zkhip_ctx* ctx, const zkhip_chip* chips, const uint32_t* const* programs, const size_t* program_words, int n_chips,
                           const uint32_t* public_values, size_t n_public, const zkhip_params* prm, uint8_t* proof, size_t cap, size_t* len) {
@@ -2778,16 +2773,18 @@ int zkhip_prove_chips_air(zkhip_ctx* ctx, const zkhip_chip* chips, const uint32_
     AirView views[MAX_CHIPS];
     const AirView* table[MAX_CHIPS];
     ZK_TRY(chip_programs(programs, program_words, widths, n_chips, n_public, views, table));
-    ChipAirScope scope(table);
-    return zkhip_prove_chips(ctx, chips, n_chips, public_values, n_public, prm, proof, cap, len);
+    ChipSet cs;
+    cs.air = table;
+    return prove_chips_impl(cs, ctx, chips, n_chips, public_values, n_public, prm, proof, cap, len);
 }
 int zkhip_verify_chips_air(const uint8_t* proof, size_t len, const int32_t* log_ns, const uint32_t* widths, const uint32_t* const* programs,
                            const size_t* program_words, int n_chips, const uint32_t* public_values, size_t n_public, const zkhip_params* prm, int* reason) {
     AirView views[MAX_CHIPS];
     const AirView* table[MAX_CHIPS];
     if (chip_programs(programs, program_words, widths, n_chips, n_public, views, table) != ZKHIP_OK) { if (reason) *reason = 1; return ZKHIP_ERR_VERIFY; }
-    ChipAirScope scope(table);
-    return zkhip_verify_chips(proof, len, log_ns, widths, nullptr, nullptr, n_chips, public_values, n_public, prm, reason);
+    ChipSet cs;
+    cs.air = table;
+    return verify_chips_impl(cs, proof, len, log_ns, widths, nullptr, nullptr, n_chips, public_values, n_public, prm, reason);
 }
 
 // ---- the machine: chips with programs AND interaction tables (lookups as data); proof version 10 ----
@@ -2829,8 +2826,9 @@ size_t zkhip_machine_proof_size(const int32_t* log_ns, const uint32_t* widths, c
                                 const uint32_t* const* tables, const size_t* table_words, int n_chips, const zkhip_params* prm, size_t n_public) {
     MachineSetup m;
     if (machine_setup(programs, program_words, tables, table_words, widths, n_chips, n_public, m) != ZKHIP_OK) return 0;
-    MachineScope scope(m.table, &m.mt);
-    return zkhip_chips_proof_size(log_ns, widths, m.cols, nullptr, n_chips, prm, n_public);
+    ChipSet cs;
+    cs.air = m.table; cs.machine = &m.mt;
+    return chips_proof_size_impl(cs, log_ns, widths, m.cols, nullptr, n_chips, prm, n_public);
 }
 int zkhip_prove_machine(zkhip_ctx* ctx, const zkhip_chip* chips, const uint32_t* const* programs, const size_t* program_words,
                         const uint32_t* const* tables, const size_t* table_words, int n_chips, const uint32_t* public_values, size_t n_public,
@@ -2842,16 +2840,18 @@ int zkhip_prove_machine(zkhip_ctx* ctx, const zkhip_chip* chips, const uint32_t*
     ZK_TRY(machine_setup(programs, program_words, tables, table_words, widths, n_chips, n_public, m));
     zkhip_chip mine[MAX_CHIPS];
     for (int c = 0; c < n_chips; c++) { mine[c] = chips[c]; mine[c].logup_pairs = m.cols[c]; mine[c].partner = -1; }
-    MachineScope scope(m.table, &m.mt);
-    return zkhip_prove_chips(ctx, mine, n_chips, public_values, n_public, prm, proof, cap, len);
+    ChipSet cs;
+    cs.air = m.table; cs.machine = &m.mt;
+    return prove_chips_impl(cs, ctx, mine, n_chips, public_values, n_public, prm, proof, cap, len);
 }
 int zkhip_verify_machine(const uint8_t* proof, size_t len, const int32_t* log_ns, const uint32_t* widths, const uint32_t* const* programs,
                          const size_t* program_words, const uint32_t* const* tables, const size_t* table_words, int n_chips,
                          const uint32_t* public_values, size_t n_public, const zkhip_params* prm, int* reason) {
     MachineSetup m;
     if (machine_setup(programs, program_words, tables, table_words, widths, n_chips, n_public, m) != ZKHIP_OK) { if (reason) *reason = 1; return ZKHIP_ERR_VERIFY; }
-    MachineScope scope(m.table, &m.mt);
-    return zkhip_verify_chips(proof, len, log_ns, widths, m.cols, nullptr, n_chips, public_values, n_public, prm, reason);
+    ChipSet cs;
+    cs.air = m.table; cs.machine = &m.mt;
+    return verify_chips_impl(cs, proof, len, log_ns, widths, m.cols, nullptr, n_chips, public_values, n_public, prm, reason);
 }
 
 // ---- the keyed machine: preprocessed columns committed once; proof version 11 ----
@@ -2934,9 +2934,9 @@ size_t zkhip_machine_proof_size_keyed(const int32_t* log_ns, const uint32_t* wid
     if (machine_setup(programs, program_words, tables, table_words, cw, n_chips, n_public, m) != ZKHIP_OK) return 0;
     KeyView kv{};
     for (int c = 0; c < n_chips; c++) kv.pw[c] = pre_widths[c];
-    MachineScope scope(m.table, &m.mt);
-    KeyScope ks(&kv);
-    return zkhip_chips_proof_size(log_ns, widths, m.cols, nullptr, n_chips, prm, n_public);
+    ChipSet cs;
+    cs.air = m.table; cs.machine = &m.mt; cs.key = &kv;
+    return chips_proof_size_impl(cs, log_ns, widths, m.cols, nullptr, n_chips, prm, n_public);
 }
 int zkhip_prove_machine_keyed_at(zkhip_ctx* ctx, const zkhip_machine_key* key, const int32_t* key_entries, const zkhip_chip* chips,
                                  const uint32_t* const* programs, const size_t* program_words, const uint32_t* const* tables, const size_t* table_words,
@@ -2968,9 +2968,9 @@ int zkhip_prove_machine_keyed_at(zkhip_ctx* ctx, const zkhip_machine_key* key, c
     ZK_TRY(machine_setup(programs, program_words, tables, table_words, cw, n_chips, n_public, m));
     zkhip_chip mine[MAX_CHIPS];
     for (int c = 0; c < n_chips; c++) { mine[c] = chips[c]; mine[c].logup_pairs = m.cols[c]; mine[c].partner = -1; }
-    MachineScope scope(m.table, &m.mt);
-    KeyScope ks(&kv);
-    return zkhip_prove_chips(ctx, mine, n_chips, public_values, n_public, prm, proof, cap, len);
+    ChipSet cs;
+    cs.air = m.table; cs.machine = &m.mt; cs.key = &kv;
+    return prove_chips_impl(cs, ctx, mine, n_chips, public_values, n_public, prm, proof, cap, len);
 }
 int zkhip_prove_machine_keyed(zkhip_ctx* ctx, const zkhip_machine_key* key, const zkhip_chip* chips, const uint32_t* const* programs,
                               const size_t* program_words, const uint32_t* const* tables, const size_t* table_words, int n_chips,
@@ -2987,9 +2987,9 @@ int zkhip_verify_machine_keyed(const uint8_t* proof, size_t len, const int32_t* 
         machine_setup(programs, program_words, tables, table_words, cw, n_chips, n_public, m) != ZKHIP_OK) { if (reason) *reason = 1; return ZKHIP_ERR_VERIFY; }
     for (int i = 0; i < 8; i++) { if (root[i] >= P) { if (reason) *reason = 1; return ZKHIP_ERR_VERIFY; } kv.root_m[i] = to_monty(root[i]); }
     for (int c = 0; c < n_chips; c++) kv.pw[c] = pre_widths[c];
-    MachineScope scope(m.table, &m.mt);
-    KeyScope ks(&kv);
-    return zkhip_verify_chips(proof, len, log_ns, widths, m.cols, nullptr, n_chips, public_values, n_public, prm, reason);
+    ChipSet cs;
+    cs.air = m.table; cs.machine = &m.mt; cs.key = &kv;
+    return verify_chips_impl(cs, proof, len, log_ns, widths, m.cols, nullptr, n_chips, public_values, n_public, prm, reason);
 }
 
 // the verifier's batched host permutation (p2_x16.cpp) against the scalar one on pseudo-random states: 1 = AVX-512 in use and equal,
