@@ -99,7 +99,7 @@ def test_shipped_library_reads_no_environment_variable():
     assert "getenv" not in und
     blob = open(_lib.LIB_PATH, "rb").read()
     assert b"ZKHIP_NTT_" not in blob and b"ZKHIP_FRI_" not in blob
-    for f in ("context.cpp", "prover.cpp", "ntt.hip"):
+    for f in ("context.cpp", "batch.cpp", "prover.cpp", "verifier.cpp", "jobs.cpp", "proof_common.h", "ntt.hip"):
         text = open(os.path.join(ROOT, "zktls_amd", "csrc", f)).read()
         outside, depth = [], 0
         for line in text.splitlines():

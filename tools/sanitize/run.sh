@@ -13,7 +13,7 @@ SAN="-O1 -g -fsanitize=address,undefined -fno-omit-frame-pointer"
 ORC="$ROOT/oracle/ntt.c $ROOT/oracle/poseidon2.c $ROOT/oracle/merkle.c $ROOT/oracle/challenger.c $ROOT/oracle/stark.c $ROOT/oracle/chips.c $ROOT/oracle/air.c $ROOT/oracle/hal.c"
 $CLANG $SAN -march=x86-64-v3 -Wno-unknown-pragmas -I$ROOT/oracle -o $OUT/oracle_main $ROOT/tools/sanitize/oracle_main.c $ORC -lm
 ASAN_OPTIONS=detect_leaks=1 $OUT/oracle_main
-for f in ntt.hip hash.hip util.hip stark.hip hal.hip sha256_chip.hip context.cpp prover.cpp serialize.cpp params.cpp; do
+for f in ntt.hip ntt_fused.hip hash.hip util.hip stark.hip hal.hip sha256_chip.hip fri_chip.hip context.cpp batch.cpp prover.cpp verifier.cpp jobs.cpp serialize.cpp params.cpp poseidon2_chip.cpp; do
   /opt/rocm/bin/hipcc $SAN -std=c++17 -fPIC --offload-arch=gfx950 -Wno-option-ignored -x hip -c $ROOT/zktls_amd/csrc/$f -o $OUT/$f.o
 done
 /opt/rocm/bin/hipcc $SAN -std=c++17 -fPIC -mavx512f -mavx512dq -x c++ -c $ROOT/zktls_amd/csrc/p2_x16.cpp -o $OUT/p2_x16.cpp.o
