@@ -174,6 +174,7 @@ inline std::shared_ptr<const AirTermPlan> air_term_plan(const AirView& a) {
     cache.push_back(Entry{h, a.words, std::vector<uint32_t>(a.w, a.w + a.words), plan});
     return plan;
 }
+inline size_t air_term_count(const AirView& a) { const size_t nm = air_term_plan(a)->monomials.size(); return nm + (nm & 1); }
 inline void air_term_records(const AirView& a, const Ext& alpha, std::vector<uint32_t>& recs, const Ext& scale = ext_one()) {
     std::vector<Ext> wts(a.K);
     Ext w = scale;
@@ -197,6 +198,45 @@ inline void air_term_records(const AirView& a, const Ext& alpha, std::vector<uin
     if (nm & 1) {                                // the kernel takes terms in pairs: pad with 0 * (the constant 1)
         uint32_t* r = recs.data() + 8 * nm;
         r[4] = air_lds_base(2 * W + 3, W); r[6] = 1u << 16;
+    }
+}
+
+// The records of the WIDE kernel (stark.hip, quotient_air_wide_kernel: a lane per point, the wavefront walks one record): the same
+// monomials, grouped by their number of factors -- cls[n - 1] .. cls[n] are the records of n factors, every class padded to an even
+// count (the kernel takes records in pairs) with a zero-weight record -- so that the kernel runs one branch-free loop per class.  A
+// factor travels as the LDS word of its column in the kernel's column-major tile (kernels.h, air_wide_word).
+inline void air_term_records_wide(const AirView& a, const Ext& alpha, std::vector<uint32_t>& recs, uint32_t cls[6], const Ext& scale = ext_one()) {
+    std::vector<Ext> wts(a.K);
+    Ext w = scale;
+    for (size_t k = a.K; k-- > 0;) { wts[k] = w; w = ext_mul(w, alpha); }
+    const std::shared_ptr<const AirTermPlan> plan = air_term_plan(a);
+    const uint32_t W = a.width, one = air_wide_word(2 * W + 3, W);
+    const size_t nm = plan->monomials.size();
+    std::vector<uint32_t> pos(nm);
+    recs.clear();
+    recs.reserve((nm + 5) * 8);
+    uint32_t cur = 1;
+    cls[0] = 0;
+    auto pad_to_even = [&](uint32_t n) {
+        if ((recs.size() / 8) & 1) {
+            uint32_t r[8] = {0, 0, 0, 0, one | one << 16, one | one << 16, one | n << 16, 0};
+            recs.insert(recs.end(), r, r + 8);
+        }
+    };
+    for (size_t m = 0; m < nm; m++) {                // monomials come sorted by their factor count
+        const std::array<uint32_t, 6>& k = plan->monomials[m];
+        while (cur < k[0]) { pad_to_even(cur); cls[cur] = (uint32_t)(recs.size() / 8); cur++; }
+        uint32_t o[5] = {one, one, one, one, one};
+        for (uint32_t j = 0; j < k[0]; j++) o[j] = air_wide_word(k[1 + j], W);
+        pos[m] = (uint32_t)(recs.size() / 8);
+        const uint32_t r[8] = {0, 0, 0, 0, o[0] | o[1] << 16, o[2] | o[3] << 16, o[4] | k[0] << 16, 0};
+        recs.insert(recs.end(), r, r + 8);
+    }
+    while (cur <= 5) { pad_to_even(cur); cls[cur] = (uint32_t)(recs.size() / 8); cur++; }
+    for (const AirTermPlan::Src& t : plan->terms) {
+        uint32_t* r = recs.data() + 8 * (size_t)pos[t.monomial];
+        const Ext c = ext_mul_base(wts[t.constraint], t.coeff_monty);
+        for (int i = 0; i < 4; i++) r[i] = fadd(r[i], c.c[i]);
     }
 }
 

@@ -242,7 +242,22 @@ struct QuotientAirArgs {
     const uint32_t* recs; uint32_t n_terms; uint32_t n_public;
     const uint32_t* addend;     // optional [2^(log_n + log_qd)][4]: added to the folded constraints before the division by Z_H (lookups)
     uint32_t no_chain;          // A/B: 1 keeps the one-group-per-workgroup kernel
+    uint32_t wide;              // the records are those of the wide form (air_term_records_wide; stark.hip quotient_air_wide_kernel)
+    uint32_t cls[6];            // wide form: records of n factors are cls[n - 1] .. cls[n]
 };
+// The wide form of the term kernel (a lane per point, 64 points + 1 row per tile, column-major in LDS with the selector / constant /
+// public-value slots as further columns): for term-heavy programs (SHA-256 chip, 3 366 records: 5.0 against 5.7 ms per 2^21 points; the
+// Poseidon2 chip's 1 008 records are a draw, 2.3 against 2.2, and stay with the 8-point form) whose tile fits the LDS and traces of at
+// least 64 rows.  The host decides with this predicate when it builds the records.  air_wide_word: LDS word of a slot for point 0.
+constexpr uint32_t AIR_WIDE_POINTS = 64, AIR_WIDE_PITCH = 65;
+inline bool air_wide_form(uint32_t width, uint32_t n_terms, int log_n, uint32_t n_public) {
+    return n_terms >= 2048 && width % 4 == 0 && (size_t)AIR_WIDE_PITCH * (width + AIR_SLOT_EXTRA + n_public) * 4 <= 160 * 1024 && log_n >= 6;
+}
+ZK_HD uint32_t air_wide_word(uint32_t slot, uint32_t W) {
+    if (slot < W) return AIR_WIDE_PITCH * slot;
+    if (slot < 2 * W) return AIR_WIDE_PITCH * (slot - W) + 1u;
+    return AIR_WIDE_PITCH * (W + (slot - 2 * W));
+}
 hipError_t launch_quotient_air(const QuotientAirArgs& a, hipStream_t s);
 
 // out[k][p] = 1 / (x_p - z_k), k < npoints (<= 2), p < count; xw (optional): xw[k][p] = x_p / (x_p - z_k), p < xw_count

@@ -135,7 +135,13 @@ static int run_quotient_air(zkhip_ctx* ctx, const AirView& air, const uint32_t* 
     for (uint32_t i = 0; i < air.n_public; i++) pub[i] = to_monty(public_values[i]);
     // the flattened form for the term-parallel kernel (up to 64 public values: they travel in every point's LDS slots)
     std::vector<uint32_t> recs;
-    if (air.n_public <= 64) air_term_records(air, alpha, recs, scale);
+    uint32_t cls[6] = {0, 0, 0, 0, 0, 0};
+    // (not inside a lock-step batch: the batched twin takes its arguments from memory, its record loads then are per-lane loads of one
+    // address instead of scalar loads, and that form is slower than the 8-point kernel)
+    const bool wide = !t_batcher && ld % 4 == 0 && (reinterpret_cast<uintptr_t>(lde) & 15u) == 0 &&
+                      air_wide_form(width, (uint32_t)air_term_count(air), log_n, air.n_public);
+    if (wide) air_term_records_wide(air, alpha, recs, cls, scale);
+    else if (air.n_public <= 64) air_term_records(air, alpha, recs, scale);
     // one staging buffer: body | weights (16-byte aligned) | public values | term records (16-byte aligned)
     const size_t body_w = (body.size() + 3) & ~(size_t)3, pub_w = (pub.size() + 3) & ~(size_t)3;
     std::vector<uint32_t> stage(body_w + weights.size() + pub_w + recs.size(), 0u);
@@ -158,6 +164,8 @@ static int run_quotient_air(zkhip_ctx* ctx, const AirView& air, const uint32_t* 
     q.out = out_chunks; q.lde_out = lde_out; q.lde_ld = lde_ld;
     q.recs = recs.empty() ? nullptr : (const uint32_t*)d_stage + body_w + weights.size() + pub_w;
     q.n_terms = (uint32_t)(recs.size() / 8); q.n_public = air.n_public;
+    q.wide = wide ? 1u : 0u;
+    for (int i = 0; i < 6; i++) q.cls[i] = cls[i];
     q.addend = addend;
     ZK_HIP(launch_quotient_air(q, ctx->stream));
     return ZKHIP_OK;

@@ -423,6 +423,153 @@ struct quotient_air_terms_kernel_bargs { QuotientAirArgs a; static quotient_air_
 template <int NT>
 __global__ void __launch_bounds__(NT) quotient_air_terms_kernel_batch(const quotient_air_terms_kernel_bargs* __restrict__ zk_arr) { const quotient_air_terms_kernel_bargs& zk_b = zk_arr[blockIdx.z]; quotient_air_terms_kernel_body<NT>(zk_b.a); }
 
+// The WIDE form, for term-heavy programs (SHA-256 chip: 3 366 records).  The kernel above gives a lane a RECORD and 8 points: its 8
+// LDS reads per factor hit random banks (every lane another column), and that, not arithmetic, is its time (the four SIMDs of a CU
+// share one LDS: ~1 000 clk per record and wavefront, of which ~400 are VALU).  Here a lane owns a POINT and the whole wavefront walks
+// the SAME record:
+//   * a workgroup stages 65 consecutive trace rows of one coset as a COLUMN-major tile (pitch 65 words): lane p reads column c of its
+//     point at word 65 c + p, its next row at 65 c + p + 1 -- consecutive banks across the wavefront, one ds_read_b32 per factor for
+//     64 points (the form above: 32 reads for 64 points, conflicting); the selector values, the constant 1 and the public values are
+//     further columns of the tile, so a factor is an LDS word whatever its kind;
+//   * the records are wave-uniform: scalar loads, no vector memory traffic for the program at all, coefficients as SGPR operands;
+//   * records come grouped by their number of factors (air_term_records_wide): one branch-free loop per class, so that the reads of
+//     several records are in flight under the products of the previous ones -- with branches on the factor count the same kernel was
+//     latency-bound at 8.7 ms per 2^21 points of the SHA-256 chip;
+//   * the NW wavefronts of the workgroup (8 or 16: one tile fills the LDS, so the workgroup IS the CU's occupancy) split the records
+//     and add their four 64-bit sums through LDS at the end.
+// w4_recip = ceil(2^32 / (width / 4)).
+typedef uint32_t air_u32x16 __attribute__((ext_vector_type(16)));      // a pair of records: one 64-byte scalar load
+template <int N>
+__device__ __forceinline__ uint32_t air_wide_product(const uint32_t* mine, uint32_t o0, uint32_t o1, uint32_t o2) {
+    uint32_t v[5];                                      // all reads first, then the products
+    v[0] = mine[o0 & 0xFFFFu];
+    if (N > 1) v[1] = mine[o0 >> 16];
+    if (N > 2) v[2] = mine[o1 & 0xFFFFu];
+    if (N > 3) v[3] = mine[o1 >> 16];
+    if (N > 4) v[4] = mine[o2 & 0xFFFFu];
+    uint32_t prod = v[0];
+#pragma unroll
+    for (int k = 1; k < N; k++) prod = dmul(prod, v[k]);
+    return prod;
+}
+// PAIRS pairs of records (a pair: coefficients a, offsets a, coefficients b, offsets b = 64 contiguous bytes; records go in pairs:
+// dacc2) starting at r: all their LDS reads go out together, then the products, then the sums
+template <int N, int PAIRS>
+__device__ __forceinline__ void air_wide_trip(const uint32_t* mine, const uint4* r, uint64_t (&acc)[4]) {
+    air_u32x16 rec[PAIRS];
+#pragma unroll
+    for (int i = 0; i < PAIRS; i++) rec[i] = reinterpret_cast<const air_u32x16*>(r)[i];          // wave-uniform address: scalar loads
+    uint32_t pa[PAIRS], pb[PAIRS];
+#pragma unroll
+    for (int i = 0; i < PAIRS; i++) {
+        pa[i] = air_wide_product<N>(mine, rec[i][4], rec[i][5], rec[i][6]);
+        pb[i] = air_wide_product<N>(mine, rec[i][12], rec[i][13], rec[i][14]);
+    }
+#pragma unroll
+    for (int i = 0; i < PAIRS; i++) {
+        dacc2(acc[0], rec[i][0], pa[i], rec[i][8], pb[i]); dacc2(acc[1], rec[i][1], pa[i], rec[i][9], pb[i]);
+        dacc2(acc[2], rec[i][2], pa[i], rec[i][10], pb[i]); dacc2(acc[3], rec[i][3], pa[i], rec[i][11], pb[i]);
+    }
+}
+// The wavefront's share of one class: a CONTIGUOUS run of pairs (so that a trip's records are one contiguous block), whole trips of
+// four pairs per wavefront (a remainder trip costs a full load latency for a quarter of the work); the classes start their deal at
+// different wavefronts, so that the short ends do not all fall on the last one.  ~450 clk of arithmetic per trip against one
+// scalar-load latency and one LDS latency: four wavefronts per SIMD cover that without software prefetch (scalar loads share the
+// LDS counter and return out of order, so a prefetch would be waited for with the first LDS value anyway).
+// Tried and slower: branches on the factor count inside one loop (no load can move above a branch: 8.7 ms per 2^21 points of the
+// SHA-256 chip); records through broadcast vector loads (64 lanes x 16 bytes occupy the vector memory pipe like any load: 8.1 ms);
+// records as one 16-byte load per lane handed round with v_readlane (6.2 ms).
+template <int N, int NW>
+__device__ __forceinline__ void air_wide_class(const uint32_t* mine, const uint4* recs, uint32_t begin, uint32_t end, uint32_t wave, uint32_t same, uint64_t (&acc)[4]) {
+    const uint32_t pairs = (end - begin) >> 1, per = ((pairs + 4u * NW - 1u) / (4u * NW)) * 4u;
+    const uint32_t slot = (wave + 3u * N) % NW;
+    uint32_t p = slot * per;
+    const uint32_t pe = p + per < pairs ? p + per : pairs;
+    const uint4* r = recs + 2 * (size_t)begin + 4 * (size_t)(same ? 0u : p);          // (A/B: every wavefront walks the first run)
+    for (; p + 4u <= pe; p += 4u, r += 16) air_wide_trip<N, 4>(mine, r, acc);
+    if (p + 2u <= pe) { air_wide_trip<N, 2>(mine, r, acc); p += 2u; r += 8; }
+    if (p < pe) air_wide_trip<N, 1>(mine, r, acc);
+}
+// (A chained variant -- a workgroup walking 16 consecutive tiles, the next tile's rows prefetched into registers under the records of
+// the current one, as quotient_air_chain_kernel does -- was built and measured: with 1 024 lanes per workgroup the 40 prefetch
+// registers do not fit beside the term loop's, it spills, 6.5 ms.  Staging stays un-overlapped: ~0.65 of the 5.0 ms.)
+template <int NW>
+__device__ __forceinline__ void quotient_air_wide_kernel_body(const QuotientAirArgs& a, uint32_t w4_recip) {
+    constexpr uint32_t NT = 64u * NW, PITCH = AIR_WIDE_PITCH, ROWS = AIR_WIDE_POINTS + 1u;
+    extern __shared__ uint32_t tile[];
+    const uint32_t tid = threadIdx.x, lane = tid & 63u;
+    const uint32_t wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const uint32_t W = a.width, W4 = W >> 2;
+    const uint32_t mask = (1u << (a.log_n + a.log_qd)) - 1u, nq = 1u << a.log_qd;
+    const uint32_t coset = blockIdx.x & (nq - 1u), blk = blockIdx.x >> a.log_qd;
+    const uint32_t e0 = ((blk * AIR_WIDE_POINTS) << a.log_qd) + coset;
+    // ---- the tile: 65 rows x W columns, transposed on the way in (a lane moves 16 bytes = 4 columns of one row)
+    const uint32_t total = ROWS * W4;
+#ifdef ZKHIP_AB_HOOKS
+    if (!(a.no_chain & 2u))                              // A/B: no staging (the tile holds whatever the LDS held)
+#endif
+#pragma unroll 4
+    for (uint32_t idx = tid; idx < total; idx += NT) {
+        const uint32_t r = __umulhi(idx, w4_recip);              // idx / W4 (exact: idx < 2^16)
+        const uint32_t cg = idx - r * W4;
+        const uint4 v = ld_stream(a.lde + (uint64_t)air_row_of(a, e0, r) * a.ld + 4u * cg);
+        uint32_t* d = tile + 4u * cg * PITCH + r;
+        d[0] = v.x; d[PITCH] = v.y; d[2 * PITCH] = v.z; d[3 * PITCH] = v.w;
+    }
+    // ---- the extra columns: is_first, is_last, is_transition, 1, then the public values
+    if (tid < ROWS) {
+        const uint32_t p = air_row_of(a, e0, tid);
+        uint32_t* d = tile + W * PITCH + tid;
+        d[0] = a.sel_first[p]; d[PITCH] = a.sel_last[p]; d[2 * PITCH] = dsub(a.xs[p], a.wn_inv); d[3 * PITCH] = MONTY_R1;
+    }
+    for (uint32_t idx = tid; idx < a.n_public * ROWS; idx += NT) {
+        const uint32_t i = idx / ROWS, r = idx - i * ROWS;
+        tile[(W + AIR_SLOT_EXTRA + i) * PITCH + r] = a.pub[i];
+    }
+    __syncthreads();
+    const uint32_t* mine = tile + lane;
+    uint64_t acc[4] = {0, 0, 0, 0};
+    const uint4* recs = reinterpret_cast<const uint4*>(a.recs);
+    const uint32_t* cls = a.cls;
+#ifdef ZKHIP_AB_HOOKS
+    const uint32_t same = a.no_chain & 8u;               // A/B: all wavefronts read the same records (scalar-cache hits)
+    if (!(a.no_chain & 4u)) {                            // A/B: no terms
+#else
+    constexpr uint32_t same = 0;
+#endif
+    air_wide_class<1, NW>(mine, recs, cls[0], cls[1], wave, same, acc);
+    air_wide_class<2, NW>(mine, recs, cls[1], cls[2], wave, same, acc);
+    air_wide_class<3, NW>(mine, recs, cls[2], cls[3], wave, same, acc);
+    air_wide_class<4, NW>(mine, recs, cls[3], cls[4], wave, same, acc);
+    air_wide_class<5, NW>(mine, recs, cls[4], cls[5], wave, same, acc);
+#ifdef ZKHIP_AB_HOOKS
+    }
+#endif
+    __syncthreads();                                   // the tile is dead: the LDS now carries [NW][4][64] partial sums
+#pragma unroll
+    for (int c = 0; c < 4; c++) tile[(wave * 4u + c) * 64u + lane] = dacc_finish(acc[c]);
+    __syncthreads();
+    if (tid < AIR_WIDE_POINTS) {
+        Ext r;
+#pragma unroll
+        for (int c = 0; c < 4; c++) {
+            uint32_t sum = 0;
+            for (uint32_t w = 0; w < (uint32_t)NW; w++) sum = dadd(sum, tile[(w * 4u + c) * 64u + tid]);
+            r.c[c] = sum;
+        }
+        air_store_point(a, (e0 + (tid << a.log_qd)) & mask, r);
+    }
+}
+template <int NW>
+__global__ void __launch_bounds__(64 * NW) quotient_air_wide_kernel(QuotientAirArgs a, uint32_t w4_recip) { quotient_air_wide_kernel_body<NW>(a, w4_recip); }
+struct quotient_air_wide_kernel_bargs { QuotientAirArgs a; uint32_t w4_recip; static quotient_air_wide_kernel_bargs make(QuotientAirArgs a, uint32_t w4_recip) { return quotient_air_wide_kernel_bargs{a, w4_recip}; } };
+template <int NW>
+__global__ void __launch_bounds__(64 * NW) quotient_air_wide_kernel_batch(const quotient_air_wide_kernel_bargs* __restrict__ zk_arr) {
+    // (by value, unlike the generated twins: the record table's address must end up in SGPRs for the records to be scalar loads)
+    const quotient_air_wide_kernel_bargs zk_b = zk_arr[blockIdx.z];
+    quotient_air_wide_kernel_body<NW>(zk_b.a, zk_b.w4_recip);
+}
+
 // The chained form of the same kernel.  What the kernel above spends its time on is not terms but rows: every workgroup stages 9
 // rows, waits for them with nothing else to do, and leaves again (a 608-column program of 8 terms: 4.3 ms per 2^21 points = 1.2 TB/s).
 // Here a workgroup walks CHAIN consecutive groups of one coset:
@@ -618,9 +765,40 @@ static hipError_t launch_terms(const QuotientAirArgs& a, uint32_t n_groups, size
     ZK_LAUNCH(quotient_air_terms_kernel<NT>, quotient_air_terms_kernel_batch<NT>, quotient_air_terms_kernel_bargs, dim3(n_groups), dim3(NT), lds, s, a);
     return hipGetLastError();
 }
+template <int NW>
+static hipError_t launch_wide(const QuotientAirArgs& a, hipStream_t s) {
+    const size_t lds_tile = (size_t)AIR_WIDE_PITCH * (a.width + AIR_SLOT_EXTRA + a.n_public) * 4, lds_red = (size_t)NW * 4 * 64 * 4, lds = lds_tile > lds_red ? lds_tile : lds_red;
+    if (lds > 64 * 1024) {
+        static std::atomic<size_t> configured[64] = {};
+        int dev = 0;
+        if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return hipErrorInvalidDevice;
+        if (lds > configured[dev].load(std::memory_order_acquire)) {
+            hipError_t e = hipFuncSetAttribute((const void*)quotient_air_wide_kernel<NW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            if (e != hipSuccess) return e;
+            e = hipFuncSetAttribute((const void*)quotient_air_wide_kernel_batch<NW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            if (e != hipSuccess) return e;
+            configured[dev].store(lds, std::memory_order_release);
+        }
+    }
+    const uint32_t W4 = a.width >> 2, recip = (uint32_t)((((uint64_t)1 << 32) + W4 - 1) / W4);
+    const uint32_t tiles = (uint32_t)(((uint64_t)1 << a.log_n) / AIR_WIDE_POINTS) << a.log_qd;
+    ZK_LAUNCH(quotient_air_wide_kernel<NW>, quotient_air_wide_kernel_batch<NW>, quotient_air_wide_kernel_bargs, dim3(tiles), dim3(64 * NW), lds, s, a, recip);
+    return hipGetLastError();
+}
 hipError_t launch_quotient_air(const QuotientAirArgs& a, hipStream_t s) {
     const uint64_t m = 1ull << (a.log_n + a.log_qd);
     constexpr int PTS = 8;
+#ifdef ZKHIP_AB_HOOKS
+    if (a.recs && a.wide) {
+        static const int abl = [] { const char* e = getenv("ZKHIP_AIRQ_ABL"); return e ? atoi(e) : 0; }();
+        if (abl) { QuotientAirArgs b = a; b.no_chain |= (uint32_t)abl; return launch_wide<16>(b, s); }
+    }
+#endif
+    if (a.recs && a.wide) {                              // the host built the records for the wide form (air_wide_form said so)
+        if (!air_wide_form(a.width, a.n_terms, a.log_n, a.n_public) || a.ld % 4 != 0 || (reinterpret_cast<uintptr_t>(a.lde) & 15u) != 0 || (a.n_terms & 1u))
+            return hipErrorInvalidValue;
+        return launch_wide<16>(a, s);
+    }
     const uint32_t groups4 = (a.width >> 2) + (AIR_SLOT_EXTRA + ((a.n_public + 3u) & ~3u)) / 4;      // column groups + selector / public groups
     const size_t lds_rows = (size_t)AIR_GP * groups4 * 4;
     // the term-parallel kernel reads rows 16 bytes per lane: rows start on 16-byte boundaries, and a record addresses LDS words in 16 bits
