@@ -399,9 +399,17 @@ int zkhip_quotient_values_air(zkhip_ctx* ctx, const uint32_t* program, size_t pr
 /* ---- a real chip on the constraint-program path: SHA-256 compression (the hash of the TLS transcripts the reference's guest checks;
  * upstream SP1 proves it through the ShaExtend / ShaCompress chips of sp1-core-machine 4.1.4, reference Cargo.lock:5822, behind
  * crates/guest-prover-sp1/src/sp1.rs:116).  One row per round, 64 rows per 64-byte block, 608 columns, degree 3, 16 public values =
- * the digest as 16-bit limbs (low limb of word 0 first).  A proof says "I know a message of at most 2^(log_n - 6) blocks, padding
- * included, with this SHA-256 digest"; blocks after the message are inactive rows that pass the chaining value through.
- * Column layout and constraints: csrc/sha256_chip.hip. ---- */
+ * the digest as 16-bit limbs (low limb of word 0 first).
+ * THE EXACT RELATION a proof attests: "I know k <= 2^(log_n - 6) 64-byte blocks whose compression chain, started from the standard
+ * initial value (chained form: from the public chaining value c_s), ends in this digest (c_(s+1))"; blocks after the k-th are
+ * inactive rows that pass the chaining value through, and ACT may drop after ANY block.  The FIPS 180-4 padding and length field are
+ * applied by zkhip_prove_sha256 on the host and are NOT constrained: a verifier learns that a block sequence with this chain value
+ * exists, not that its last block is a well-formed padding block -- which is what "SHA-256 of a message" would add.  For the use made
+ * of it here (a commitment to the request's input bytes, which the party that checks the proof can hash itself) that is the
+ * relation needed; a consumer that needs the padded form must check the last block outside the proof.  In the unkeyed program the
+ * OUT limbs of the working variables d and h are not range-checked either: their integer value mod 2^32 is what the next round
+ * consumes and the three-bit carries bound their growth; the keyed machine (zkhip_sha256_setup) looks every 16-bit limb up in a
+ * range table.  Column layout and constraints: csrc/sha256_chip.hip. ---- */
 #define ZKHIP_SHA256_WIDTH 608
 #define ZKHIP_SHA256_PUBLIC 16
 /* the constraint program (a zkhip_prove_shard_air program): returns its length in words; written when cap_words suffices */

@@ -311,6 +311,12 @@ def test_commitment_guest_proves_the_reference_transcript(lib, backend):
     assert verify_sha256(proof, out, prm) == (0, 0)
     other = hashlib.sha256(cbor + b"x").digest()
     assert verify_sha256(proof, other, prm)[0] == -6
+    # the consumer's check of the blob, told which backend's shape to expect (the SP1-shape check cannot accept a RISC-Zero-shape proof)
+    lib.zktls_verify_commitment_blob_for.argtypes = [C.c_int, C.c_char_p, C.c_size_t, C.c_char_p, C.c_char_p, C.c_size_t, C.c_int, C.c_int, C.POINTER(C.c_int)]
+    reason = C.c_int(0)
+    assert lib.zktls_verify_commitment_blob_for(backend, blob, len(blob), out, None, 0, 20, 6, C.byref(reason)) == 0
+    assert lib.zktls_verify_commitment_blob_for(backend, blob, len(blob), other, None, 0, 20, 6, C.byref(reason)) != 0
+    assert lib.zktls_verify_commitment_blob_for(1 - backend, blob, len(blob), out, None, 0, 20, 6, C.byref(reason)) != 0
 
 
 # ---- setup -> prove -> verify (sp1.rs:113, :116, :120): the input-commitment guest as a keyed machine (HipGuestProver::setup)
@@ -382,9 +388,10 @@ def test_a_consumer_checks_a_keyed_commitment_blob_on_the_cpu(lib, oracle):
     other = bytearray(vk)
     other[1] ^= 1
     assert verify_blob(lib, blob, out, bytes(other), 8, 4) == (-6, 3)           # another key
-    assert verify_blob(lib, blob, out, None, 8, 4)[0] == -1                     # a keyed blob needs its vk
+    assert verify_blob(lib, blob, out, None, 8, 4) == (-1, 2)                   # a keyed blob needs its vk
     unkeyed = struct.pack("<4sIII", b"ZKTB", 2, 2, 1) + struct.pack("<I", len(proof)) + proof
-    assert verify_blob(lib, unkeyed, out, vk, 8, 4)[0] != 0                     # the machine's proof is not a single-chip proof
+    assert verify_blob(lib, unkeyed, out, vk, 8, 4) == (-1, 2)                  # a vk was given: a blob that does not claim to be keyed is refused, not checked without the key
+    assert verify_blob(lib, unkeyed, out, None, 8, 4)[0] != 0                   # ... and as a single-chip proof the machine's proof fails
 
 
 @pytest.mark.gpu

@@ -168,12 +168,26 @@ SetupResult HipGuestProver::setup(const std::vector<uint8_t>& guest_program) {
 }
 
 int verify_commitment_blob(const std::vector<uint8_t>& blob, const std::vector<uint8_t>& output, const std::vector<uint8_t>& vk,
-                           int num_queries, int pow_bits, int* reason) {
+                           int num_queries, int pow_bits, int* reason, Backend backend) {
     std::vector<std::vector<uint8_t>> proofs;
     uint32_t flags = 0;
     if (reason) *reason = 0;
     if (!unpack_shard_proofs(blob, &proofs, &flags) || proofs.empty() || !(flags & BATCH_FLAG_INPUT_SHA256) || output.size() != 32) return -1;
-    const zkhip_params prm{1, num_queries, pow_bits, 0, 0, 0, 0, 0};
+    // what the caller expects decides the path; the blob's flags must agree
+    const bool want_keyed = !vk.empty();
+    if (want_keyed && (vk.size() != 64 || !(flags & BATCH_FLAG_KEYED) || (flags & BATCH_FLAG_CHAINED))) { if (reason) *reason = 2; return -1; }
+    if (!want_keyed && (flags & BATCH_FLAG_KEYED)) { if (reason) *reason = 2; return -1; }
+    zkhip_params prm{1, num_queries, pow_bits, 0, 0, 0, 0, 0};
+    if (backend == Backend::Risc0) {                     // the shape prove_inner uses for this backend; log_n is the proof's (header word 2)
+        if ((flags & (BATCH_FLAG_CHAINED | BATCH_FLAG_KEYED)) || proofs[0].size() < 12) { if (reason) *reason = 2; return -1; }
+        uint32_t log_n = 0;
+        std::memcpy(&log_n, proofs[0].data() + 8, 4);
+        if (log_n < 6 || log_n > 22) return -1;
+        int lf = 8;
+        while (lf > (int)log_n || ((int)log_n - lf) % 4 != 0) lf--;
+        const bool defaults = num_queries == 100 && pow_bits == 16;
+        prm = zkhip_params{2, defaults ? 50 : num_queries, defaults ? 0 : pow_bits, 0, 4, lf, 24, 0};
+    }
     if (flags & BATCH_FLAG_CHAINED) {                    // entry 0: the chaining values; entries 1..n: the shard proofs
         const size_t n = proofs.size() - 1;
         if (n < 1 || proofs[0].size() != (n + 1) * 32) return -1;
@@ -188,10 +202,7 @@ int verify_commitment_blob(const std::vector<uint8_t>& blob, const std::vector<u
         return zkhip_verify_sha256_sharded(buf.data(), stride, lens.data(), n, chain.data(), 14, output.data(), &prm, &bad, reason);
     }
     if (proofs.size() != 1) return -1;
-    if (flags & BATCH_FLAG_KEYED) {
-        if (vk.size() != 64) return -1;
-        return zkhip_verify_sha256_machine(proofs[0].data(), proofs[0].size(), output.data(), (const uint32_t*)vk.data(), &prm, reason);
-    }
+    if (want_keyed) return zkhip_verify_sha256_machine(proofs[0].data(), proofs[0].size(), output.data(), (const uint32_t*)vk.data(), &prm, reason);
     return zkhip_verify_sha256(proofs[0].data(), proofs[0].size(), output.data(), &prm, reason);
 }
 
@@ -518,6 +529,14 @@ int zktls_verify_commitment_blob(const uint8_t* blob, size_t len, const uint8_t 
     if (!blob || !output) return -1;
     return zktls::verify_commitment_blob(std::vector<uint8_t>(blob, blob + len), std::vector<uint8_t>(output, output + 32),
                                          vk ? std::vector<uint8_t>(vk, vk + vk_len) : std::vector<uint8_t>(), num_queries, pow_bits, reason);
+}
+// the same check for either backend's proof shape (0: SP1, 1: RISC Zero), as zktls_guest_prove_commitment takes it
+int zktls_verify_commitment_blob_for(int backend, const uint8_t* blob, size_t len, const uint8_t output[32], const uint8_t* vk, size_t vk_len,
+                                     int num_queries, int pow_bits, int* reason) {
+    if (!blob || !output || backend < 0 || backend > 1) return -1;
+    return zktls::verify_commitment_blob(std::vector<uint8_t>(blob, blob + len), std::vector<uint8_t>(output, output + 32),
+                                         vk ? std::vector<uint8_t>(vk, vk + vk_len) : std::vector<uint8_t>(), num_queries, pow_bits, reason,
+                                         backend == 1 ? zktls::Backend::Risc0 : zktls::Backend::Sp1);
 }
 void zktls_free(void* p) { std::free(p); }
 const char* zktls_current_risc0_prover_env(void) { const char* e = getenv("RISC0_PROVER"); return e ? e : ""; }

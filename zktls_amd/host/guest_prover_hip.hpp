@@ -133,10 +133,14 @@ constexpr uint32_t BATCH_FLAG_SYNTHETIC = 1u;
 constexpr uint32_t BATCH_FLAG_INPUT_SHA256 = 2u;     // one proof of the SHA-256 chip over the request's input bytes
 constexpr uint32_t BATCH_FLAG_CHAINED = 8u;          // with INPUT_SHA256: an input beyond one chip proof (1 MiB): entry 0 = the chaining values ((n + 1) x 8 LE words), entries 1..n = the shard proofs of zkhip_prove_sha256_sharded (2^14 blocks per shard)
 constexpr uint32_t BATCH_FLAG_KEYED = 4u;            // with INPUT_SHA256: the proof is the keyed SHA-256 MACHINE's (chip + range table), checked against a vk
-// a consumer's check of an input-commitment blob on the CPU: the blob's one proof against the claimed output (SHA-256 of the input);
-// `vk` (64 bytes from setup) is required for KEYED blobs.  -> 0 or a negative value; *reason as the zkhip verifiers
+// a consumer's check of an input-commitment blob on the CPU: the blob's proof(s) against the claimed output (SHA-256 of the input).
+// The caller says what it EXPECTS, the blob's own flags only have to agree: a 64-byte `vk` (from setup) means "a KEYED proof under this
+// key" -- a plain or CHAINED blob is then refused (*reason = 2) instead of being accepted with the key ignored; without a vk a KEYED blob
+// is refused.  `backend` picks the proof shape the prover used (Backend::Sp1: blowup 2, `num_queries`, `pow_bits`; Backend::Risc0: its
+// segment shape, fold 16).  Bytes 32..63 of a vk are the guest program's digest: the PROVER refuses a program that differs from the one
+// setup() saw, the proof itself does not bind it.  -> 0 or a negative value; *reason as the zkhip verifiers
 int verify_commitment_blob(const std::vector<uint8_t>& blob, const std::vector<uint8_t>& output, const std::vector<uint8_t>& vk,
-                           int num_queries, int pow_bits, int* reason = nullptr);
+                           int num_queries, int pow_bits, int* reason = nullptr, Backend backend = Backend::Sp1);
 std::vector<uint8_t> pack_shard_proofs(const std::vector<std::vector<uint8_t>>& proofs, uint32_t flags);
 bool unpack_shard_proofs(const std::vector<uint8_t>& blob, std::vector<std::vector<uint8_t>>* proofs, uint32_t* flags = nullptr);
 
