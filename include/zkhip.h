@@ -592,6 +592,9 @@ int zkhip_prove_transcripts(const int* devices, int n_devices, zkhip_transcript_
  * the library was loaded.
  * (The reference proves its batch one transcript after the other, each a full `client.prove` call: sp1.rs:116, BASELINE configs[2].) */
 void zkhip_set_lockstep(int max_batch, int lanes);
+/* the lanes' fiber scheduler on its own (needs no device): `members` fibers wait, vote and leave for `rounds` rounds and check that the
+ * per-thread error string stays theirs across switches.  0, or the number of the first check that failed. */
+int zkhip_selftest_lockstep(int members, int rounds);
 void zkhip_lockstep_stats(uint64_t out[6]);
 
 /* A second real chip: the width-16 Poseidon2 permutation with Merkle-path chaining -- what a recursion machine (a STARK verifier proven

@@ -45,15 +45,17 @@ LaunchBatcher::LaunchBatcher(int members, hipStream_t stream) : members_(members
         (void)mprotect(p, 4096, PROT_NONE);                      // guard page: an overflow faults instead of corrupting a neighbour
         f.stack = p;
     }
-    if (ring_) return;
+    if (ring_ || !stream_) return;                           // (no stream: the scheduler alone, see zkhip_selftest_lockstep)
     void* p = nullptr;
     if (hipHostMalloc(&p, RING_BYTES, hipHostMallocDefault) != hipSuccess) { (void)hipGetLastError(); return; }
     ring_ = (uint8_t*)p;
 }
 
 LaunchBatcher::~LaunchBatcher() {
-    g_lockstep_stats[0] += launches; g_lockstep_stats[1] += requests; g_lockstep_stats[2] += mixed;
-    g_lockstep_stats[3] += flush_ns; g_lockstep_stats[4] += sync_ns; g_lockstep_stats[5] += host_ns;
+    if (stream_) {
+        g_lockstep_stats[0] += launches; g_lockstep_stats[1] += requests; g_lockstep_stats[2] += mixed;
+        g_lockstep_stats[3] += flush_ns; g_lockstep_stats[4] += sync_ns; g_lockstep_stats[5] += host_ns;
+    }
     if (ring_) (void)hipStreamSynchronize(stream_);            // the last launches may still read the ring
     std::lock_guard<std::mutex> lk(g_pool_mu);
     if (ring_) { if (g_rings.size() < 16) g_rings.push_back(ring_); else (void)hipHostFree(ring_); }
@@ -145,7 +147,7 @@ void LaunchBatcher::resolve() {
     for (int b = 0; b < members_; b++) if (fibers_[(size_t)b].state == AT_SYNC) idx[n++] = b;
     if (n > 0) {
         const auto t0 = Clock::now();
-        const hipError_t e = hipStreamSynchronize(stream_);
+        const hipError_t e = stream_ ? hipStreamSynchronize(stream_) : hipSuccess;
         if (e != hipSuccess) sticky_ = e;
         for (int k = 0; k < n; k++) { fibers_[(size_t)idx[k]].status = e; fibers_[(size_t)idx[k]].state = RUNNABLE; }
         sync_ns += ns_since(t0);
@@ -206,7 +208,7 @@ bool LaunchBatcher::all(bool mine) {
 }
 
 hipError_t LaunchBatcher::sync_all() {
-    if (current_ < 0) return hipStreamSynchronize(stream_);
+    if (current_ < 0) return stream_ ? hipStreamSynchronize(stream_) : hipSuccess;
     const int me = current_;
     park(AT_SYNC);
     return fibers_[(size_t)me].status;
@@ -237,6 +239,34 @@ uint8_t* LaunchBatcher::stage_up(size_t bytes) {
 uint8_t* LaunchBatcher::stage_down(size_t bytes) {
     const size_t region = (DOWN_BYTES / (size_t)members_) & ~(size_t)63;
     return current_ < 0 ? nullptr : stage(bytes, ARG_BYTES + UP_BYTES, region, fibers_[(size_t)current_].down_pos, false);
+}
+
+// The lane's scheduler on its own (no device, no stream): `members` fibers run `rounds` rounds of {set the thread's error string to
+// a value of their own, wait for the stream, vote, check that the string is still theirs}; one member votes "no" in one round and
+// every member must see that round's verdict; members leave at different rounds.  0, or the number of the first check that failed.
+int lockstep_selftest(int members, int rounds) {
+    if (members < 1 || members > LaunchBatcher::MAX_MEMBERS || rounds < 1) return 1;
+    LaunchBatcher lb(members, nullptr);
+    if (!lb.ok_scheduler()) return 2;
+    std::vector<int> bad((size_t)members, 0), done((size_t)members, 0);
+    const int no_round = rounds / 2, no_member = members / 3;
+    lb.run([&](int b) {
+        const int mine = rounds - (b % 3 == 2 ? rounds / 4 : 0);          // a third of the members leave early
+        for (int r = 0; r < mine; r++) {
+            const std::string tag = "member " + std::to_string(b) + " round " + std::to_string(r);
+            set_error(tag);
+            if (lb.sync_all() != hipSuccess) bad[(size_t)b] = 3;
+            if (tag != zkhip_last_error()) bad[(size_t)b] = 4;             // another fiber's string leaked into this one
+            if (r < rounds - rounds / 4) {                                 // rounds in which every member is still here: a vote
+                const bool verdict = lb.all(!(r == no_round && b == no_member));
+                if (verdict != (r != no_round)) bad[(size_t)b] = 5;
+                if (tag != zkhip_last_error()) bad[(size_t)b] = 6;
+            }
+        }
+        done[(size_t)b] = 1;
+    });
+    for (int b = 0; b < members; b++) { if (bad[(size_t)b]) return bad[(size_t)b]; if (!done[(size_t)b]) return 7; }
+    return 0;
 }
 
 // ---- the prover's copies, memsets and waits: plain stream operations, or their merged forms inside a lock-step batch

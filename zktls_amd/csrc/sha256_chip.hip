@@ -748,6 +748,7 @@ int zkhip_prove_transcripts(const int* devices, int n_devices, zkhip_transcript_
 }
 
 void zkhip_set_lockstep(int max_batch, int lanes) { lockstep_set(max_batch, lanes); }
+int zkhip_selftest_lockstep(int members, int rounds) { return lockstep_selftest(members, rounds); }
 void zkhip_lockstep_stats(uint64_t out[6]) {
     for (int i = 0; i < 6; i++) out[i] = g_lockstep_stats[i].load();
 }
