@@ -142,6 +142,11 @@ extern "C" {
         devices: *const c_int, n_devices: c_int, jobs: *mut ZkhipTranscriptJob, n_jobs: c_int, prm: *const ZkhipParams,
         in_flight_per_device: c_int, verify: c_int, vk: *mut u32,
     ) -> c_int;
+    // small jobs of a batch are proven in lock-step lanes (fibers of one thread per lane, merged kernel launches): members per batch
+    // (0 / 1 = off; default 16) and lanes per device (default 6); same proof bytes either way
+    pub fn zkhip_set_lockstep(max_batch: c_int, lanes: c_int);
+    pub fn zkhip_lockstep_stats(out: *mut u64);
+    pub fn zkhip_selftest_lockstep(members: c_int, rounds: c_int) -> c_int;
     // the Poseidon2 permutation chip: Merkle openings (of whole rows when row_width > 0) proven in-circuit
     pub fn zkhip_p2chip_air(program: *mut u32, cap_words: usize) -> usize;
     pub fn zkhip_merkle_paths_proof_size(n_paths: usize, depth: c_int, row_width: u32, prm: *const ZkhipParams) -> usize;
