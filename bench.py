@@ -83,6 +83,9 @@ def main():
                     help="with --gpus 1: initialise the RCCL ('nccl') process group at world size 1 and run the seed broadcast, the MAX "
                          "all-reduce and a barrier through it, so that RCCL is loaded and called on hardware even on a one-GPU box")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--wait", choices=("auto", "poll", "block"), default="auto",
+                    help="how the prover's host threads wait for their streams (zkhip_set_wait_mode): poll = hipStreamSynchronize, block = sleep "
+                         "on an event; auto = block when the ranks' waiting threads outnumber the cores this container may use")
     ap.add_argument("--no-batch64", action="store_true", help="skip the 64-transcript batch (BASELINE configs[2]) measured beside the headline")
     ap.add_argument("--cpu-log-n", type=int, default=20, help="rows of the bounded CPU-baseline sample")
     ap.add_argument("--cpu-threads", type=int, default=0, help="OpenMP threads of the CPU baseline (0: min(cores, 64))")
@@ -99,6 +102,28 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus:
         raise SystemExit("--gpus %d but the launcher started %d ranks" % (args.gpus, world))
+
+    def usable_cores():
+        """cores this process may keep busy: the cgroup CPU quota when there is one, else the affinity mask"""
+        n = len(os.sched_getaffinity(0))
+        try:
+            quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+            if quota != "max":
+                n = min(n, max(1, int(quota) // int(period)))
+        except (OSError, ValueError):
+            pass
+        return n
+    # How the prover's host threads wait for the GPU.  The runtime's default polls: ~1.2 busy cores per shard in flight (measured: 4.7 per
+    # rank at four in flight).  When all ranks of this node together would need more cores than the container may use, polling threads
+    # get throttled together with the ones that prepare launches: then the waits sleep (hipDeviceScheduleBlockingSync, set through the
+    # library BEFORE anything initialises the device -- torch.cuda.is_available() below does).
+    cores_ok = usable_cores()
+    wait_block = args.wait == "block" or (args.wait == "auto" and world * (min(args.streams, args.steps) * 1.2 + 1.0) > cores_ok)
+    from zktls_amd import _lib as zk_lib
+    wait_rc = zk_lib.load().zkhip_set_wait_mode(1 if wait_block else 0)
+    if wait_rc != 0 and wait_block:
+        sys.stderr.write("bench.py: blocking waits could not be set (%d): polling\n" % wait_rc)
+        wait_block = False
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: libzkhip has no CPU path")
     if args.share_gpu:
@@ -266,9 +291,11 @@ def main():
 
     barrier()
     t0 = time.perf_counter()
+    cpu0 = time.process_time()                          # CPU time of all threads of this rank
     proofs = run_steps(K)
     barrier()
     elapsed = time.perf_counter() - t0
+    host_cores_busy = (time.process_time() - cpu0) / elapsed
     elapsed = shards.max_over_ranks(dist, elapsed, device=coll_dev)
     last = proofs[K - 1]
     # after the timed region: every distinct shard of the job was proven on exactly one rank (digest gather over RCCL)
@@ -523,7 +550,8 @@ def main():
             "vs_baseline": None,
             "dtype": "u32",
             "data": "synthetic",
-            "streams_per_gpu": S,
+            "streams_per_gpu": S, "host_wait": "block" if wait_block else "poll", "host_cores_usable": cores_ok,
+            "host_cores_busy_per_rank": round(host_cores_busy, 2),
             "rccl_world_size": (dist.get_world_size() if dist is not None else 1),
             "collective_backend": (dist.get_backend() if dist is not None else None), "rccl_selfcheck_calls": rccl_calls,
             "share_gpu_test_mode": bool(args.share_gpu),

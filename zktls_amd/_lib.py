@@ -35,7 +35,7 @@ EXPORTS = [
     "zkhip_chips_proof_size_air", "zkhip_prove_chips_air", "zkhip_verify_chips_air",
     "zkhip_prove_shards_air_multi", "zkhip_selftest_host_simd", "zkhip_host_simd", "zkhip_machine_proof_size", "zkhip_prove_machine", "zkhip_verify_machine", "zkhip_range_table",
     "zkhip_machine_setup", "zkhip_machine_key_destroy", "zkhip_machine_proof_size_keyed", "zkhip_prove_machine_keyed", "zkhip_verify_machine_keyed", "zkhip_prove_machine_keyed_at",
-    "zkhip_sha256_setup", "zkhip_sha256_machine_proof_size", "zkhip_prove_sha256_machine", "zkhip_verify_sha256_machine", "zkhip_prove_transcripts", "zkhip_set_lockstep", "zkhip_lockstep_stats", "zkhip_selftest_lockstep",
+    "zkhip_sha256_setup", "zkhip_sha256_machine_proof_size", "zkhip_prove_sha256_machine", "zkhip_verify_sha256_machine", "zkhip_prove_transcripts", "zkhip_set_wait_mode", "zkhip_set_lockstep", "zkhip_lockstep_stats", "zkhip_selftest_lockstep",
     "zkhip_sha256_air_chained", "zkhip_sha256_gen_trace_chained", "zkhip_sha256_sharded_count", "zkhip_sha256_shard_proof_size", "zkhip_prove_sha256_sharded",
     "zkhip_verify_sha256_sharded",
     "zkhip_fri_view_shard", "zkhip_fri_chip_width", "zkhip_fri_chip_air", "zkhip_fri_chip_gen_trace", "zkhip_fri_queries_key", "zkhip_fri_queries_proof_size",
@@ -202,6 +202,8 @@ def load():
     L.zkhip_chips_bincode_size.argtypes = [u8p, C.c_size_t]
     L.zkhip_chips_proof_to_bincode.argtypes = [u8p, C.c_size_t, u32p, C.c_size_t, u8p, C.c_size_t, szp]
     L.zkhip_chips_proof_from_bincode.argtypes = [u8p, C.c_size_t, u8p, C.c_size_t, szp, u32p, C.c_size_t, szp]
+    L.zkhip_set_wait_mode.argtypes = [C.c_int]
+    L.zkhip_set_wait_mode.restype = C.c_int
     L.zkhip_selftest_lockstep.argtypes = [C.c_int, C.c_int]
     L.zkhip_selftest_lockstep.restype = C.c_int
     L.zkhip_set_lockstep.argtypes = [C.c_int, C.c_int]

@@ -26,7 +26,8 @@ constexpr size_t STACK_BYTES = (size_t)1 << 20;
 using Clock = std::chrono::steady_clock;
 uint64_t ns_since(Clock::time_point t0) { return (uint64_t)std::chrono::duration_cast<std::chrono::nanoseconds>(Clock::now() - t0).count(); }
 }  // namespace
-std::atomic<uint64_t> g_lockstep_stats[6];      // launches, requests, mixed rounds; ns: issuing launches, waiting for the stream, members' host code
+std::atomic<uint64_t> g_lockstep_stats[6];
+hipError_t wait_for_stream(hipStream_t s, hipEvent_t* ev);      // launches, requests, mixed rounds; ns: issuing launches, waiting for the stream, members' host code
 
 LaunchBatcher::LaunchBatcher(int members, hipStream_t stream) : members_(members), stream_(stream) {
     if (members < 1 || members > MAX_MEMBERS) return;
