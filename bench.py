@@ -120,7 +120,8 @@ def main():
     cores_ok = usable_cores()
     wait_block = args.wait == "block" or (args.wait == "auto" and world * (min(args.streams, args.steps) * 1.2 + 1.0) > cores_ok)
     from zktls_amd import _lib as zk_lib
-    wait_rc = zk_lib.load().zkhip_set_wait_mode(1 if wait_block else 0)
+    n_vis = torch.cuda.device_count()                    # (counting devices does not initialise them)
+    wait_rc = zk_lib.load().zkhip_set_wait_mode(1 if wait_block else 0, (local_rank % max(n_vis, 1)) if args.share_gpu else local_rank)
     if wait_rc != 0 and wait_block:
         sys.stderr.write("bench.py: blocking waits could not be set (%d): polling\n" % wait_rc)
         wait_block = False

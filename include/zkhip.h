@@ -145,9 +145,10 @@ int zkhip_ctx_sync(zkhip_ctx* ctx);
 /* How this PROCESS's host threads wait for the GPU: 0 = the runtime's default, which polls -- lowest latency, one busy core per waiting
  * thread (a rank with four shards in flight keeps ~4.7 cores busy); 1 = hipDeviceScheduleBlockingSync on every visible device: a waiting
  * thread sleeps until the interrupt (tens of microseconds more per wait).  For hosts that give the process fewer cores than it has waiting
- * threads -- a container CPU quota, eight ranks on one node.  Must be called before any HIP device is used by the process (before the
- * first context, and before another library initialises the device); ZKHIP_ERR_INVALID / ZKHIP_ERR_HIP when it is too late. */
-int zkhip_set_wait_mode(int blocking);
+ * threads -- a container CPU quota, eight ranks on one node.  `device`: the ordinal the process will use, or -1 for every visible device
+ * (a rank of eight should name its own).  Must be called before that device is used by the process (before the first context, and
+ * before another library initialises the device); ZKHIP_ERR_INVALID / ZKHIP_ERR_HIP when it is too late. */
+int zkhip_set_wait_mode(int blocking, int device);
 void* zkhip_ctx_stream(zkhip_ctx* ctx);
 
 /* ---- device memory helpers (for callers without their own allocator) ---- */

@@ -144,7 +144,7 @@ extern "C" {
     ) -> c_int;
     // small jobs of a batch are proven in lock-step lanes (fibers of one thread per lane, merged kernel launches): members per batch
     // (0 / 1 = off; default 16) and lanes per device (default 6); same proof bytes either way
-    pub fn zkhip_set_wait_mode(blocking: c_int) -> c_int;
+    pub fn zkhip_set_wait_mode(blocking: c_int, device: c_int) -> c_int;
     pub fn zkhip_set_lockstep(max_batch: c_int, lanes: c_int);
     pub fn zkhip_lockstep_stats(out: *mut u64);
     pub fn zkhip_selftest_lockstep(members: c_int, rounds: c_int) -> c_int;

@@ -17,10 +17,10 @@ from zktls_amd import _lib
 from zktls_amd._lib import Params
 L = _lib.load()
 mode = int(sys.argv[1])
-rc = L.zkhip_set_wait_mode(mode)
+rc = L.zkhip_set_wait_mode(mode, 0)
 from zktls_amd.device import Context
 ctx = Context(0)
-late = L.zkhip_set_wait_mode(mode)            # a context exists: refused
+late = L.zkhip_set_wait_mode(mode, -1)        # a context exists: refused
 tr = ctx.gen_trace(11, 3, 16, 64)
 prm = Params(1, 20, 8)
 p = ctx.prove_shard(tr, 16, 64, [5, 6], prm)

@@ -202,7 +202,7 @@ def load():
     L.zkhip_chips_bincode_size.argtypes = [u8p, C.c_size_t]
     L.zkhip_chips_proof_to_bincode.argtypes = [u8p, C.c_size_t, u32p, C.c_size_t, u8p, C.c_size_t, szp]
     L.zkhip_chips_proof_from_bincode.argtypes = [u8p, C.c_size_t, u8p, C.c_size_t, szp, u32p, C.c_size_t, szp]
-    L.zkhip_set_wait_mode.argtypes = [C.c_int]
+    L.zkhip_set_wait_mode.argtypes = [C.c_int, C.c_int]
     L.zkhip_set_wait_mode.restype = C.c_int
     L.zkhip_selftest_lockstep.argtypes = [C.c_int, C.c_int]
     L.zkhip_selftest_lockstep.restype = C.c_int

@@ -679,19 +679,20 @@ int zkhip_ctx_sync(zkhip_ctx* ctx) { CHECK_CTX(ctx); return dev_sync(ctx); }
 // hipDeviceScheduleBlockingSync is the one switch this runtime honours (measured, tools/waitprobe: with it a waiting thread uses
 // 0.001 s of CPU per 0.2 s waited, without it 0.2 s -- hipStreamSynchronize, hipEventSynchronize and the wait inside a copy to
 // pageable memory alike; the per-event flag hipEventBlockingSync changes nothing).  It must be set before the device is first used.
-int zkhip_set_wait_mode(int blocking) {
+int zkhip_set_wait_mode(int blocking, int device) {
     int n = 0;
     if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) { (void)hipGetLastError(); return fail(ZKHIP_ERR_NO_DEVICE, "set_wait_mode: no HIP device visible"); }
+    if (device >= n) return fail(ZKHIP_ERR_INVALID, "set_wait_mode: no such device");
     if (g_live_contexts.load() != 0) return fail(ZKHIP_ERR_INVALID, "set_wait_mode: contexts exist (the mode is fixed when a device is first used)");
     int cur = 0;
     (void)hipGetDevice(&cur);
     int rc = ZKHIP_OK;
-    for (int d = 0; d < n; d++) {
+    for (int d = device < 0 ? 0 : device; d < (device < 0 ? n : device + 1); d++) {      // (a rank of eight should not touch the other seven devices)
         hipError_t e = hipSetDevice(d);
         if (e == hipSuccess) e = hipSetDeviceFlags(blocking ? hipDeviceScheduleBlockingSync : hipDeviceScheduleAuto);
         if (e != hipSuccess) { (void)hipGetLastError(); rc = hip_fail(e, "hipSetDeviceFlags (too late: the device is already in use?)"); }
     }
-    (void)hipSetDevice(cur);
+    (void)hipSetDevice(device < 0 ? cur : device);
     return rc;
 }
 void* zkhip_ctx_stream(zkhip_ctx* ctx) { return ctx ? (void*)ctx->stream : nullptr; }
