@@ -669,6 +669,13 @@ size_t zkhip_fri_view_path_words(int layers);
 int zkhip_fri_view_shard_paths(const uint8_t* proof, size_t len, int log_n, uint32_t width, const uint32_t* public_values, size_t n_public,
                                const zkhip_params* prm, uint32_t* betas, uint32_t final_value[4], uint32_t* indices, uint32_t* values, uint32_t* siblings,
                                uint32_t* roots, uint32_t* paths);
+/* the Fiat-Shamir side of the view: the layer roots (8 words each), the challenges they lead to (4 words each), and the duplex
+ * challenger as the commit phase finds it -- transcript[0..8) = the capacity half of its state, transcript[8] = pending inputs (0).
+ * With these every challenge is one step of a sponge chain over the roots: state <- (root_l | capacity), permute,
+ * beta_l = (state[7], state[6], state[5], state[4]), capacity <- state[8..16) -- what a transcript chip has to prove next
+ * (docs/RECURSION_NEXT.md; p3-challenger DuplexChallenger, reference Cargo.lock:3875).  Canonical words; host only. */
+int zkhip_fri_view_transcript(const uint8_t* proof, size_t len, int log_n, uint32_t width, const uint32_t* public_values, size_t n_public,
+                              const zkhip_params* prm, uint32_t* roots, uint32_t* betas, uint32_t transcript[9]);
 size_t zkhip_fri_layers_chip_air(int layers, uint32_t* program, size_t cap_words);
 size_t zkhip_p2chip_air_fri_layers(int layers, uint32_t* program, size_t cap_words);
 int zkhip_fri_layers_gen_paths_trace(zkhip_ctx* ctx, int layers, size_t n_queries, const uint32_t* betas, const uint32_t* indices, const uint32_t* values,

@@ -61,6 +61,30 @@ def test_view_of_a_golden_proof_agrees_between_the_library_and_the_python_verifi
     assert list(final) == view["final"]
 
 
+@pytest.mark.parametrize("name", ["v1_6x8", "v1_10x16"])
+def test_the_challenges_of_a_golden_proof_are_a_sponge_chain_over_its_layer_roots(name):
+    """zkhip_fri_view_transcript: roots, challenges and the duplex challenger's capacity as the commit phase finds it.  By the
+    independent Poseidon2 of tests/pyref.py every challenge is ONE sponge step: state <- (root_l | capacity), permute,
+    beta_l = (state[7], state[6], state[5], state[4]) -- the statement a transcript chip will prove (docs/RECURSION_NEXT.md)"""
+    import pyref
+    from zktls_amd.device import fri_view_transcript
+    g = GOLDEN[name]
+    b = load(name)
+    prm = Params(*g["shape"])
+    roots, betas, capacity, pending = fri_view_transcript(b, g["log_n"], g["width"], g["public"], prm)
+    view = fri_view_shard(b, g["log_n"], g["width"], g["public"], prm)
+    assert betas == view["betas"] and pending == 0 and len(roots) == g["log_n"]
+    cap = list(capacity)
+    for root, beta in zip(roots, betas):
+        state = pyref.poseidon2(list(root) + cap)
+        assert [state[7], state[6], state[5], state[4]] == list(beta)
+        cap = state[8:]
+    bad = b.copy()
+    bad[-9] ^= 4
+    with pytest.raises(_lib.ZkHipError):
+        fri_view_transcript(bad, g["log_n"], g["width"], g["public"], prm)
+
+
 @pytest.mark.parametrize("name,shape", [("v1_6x8", (1, 12, 4)), ("v1_10x16", (1, 10, 6)), ("v1_10x16", (2, 7, 0))])
 def test_machine_of_a_golden_proofs_view_under_the_oracle_prover_and_three_verifiers(oracle, name, shape):
     O = oracle

@@ -40,7 +40,7 @@ EXPORTS = [
     "zkhip_verify_sha256_sharded",
     "zkhip_fri_view_shard", "zkhip_fri_chip_width", "zkhip_fri_chip_air", "zkhip_fri_chip_gen_trace", "zkhip_fri_queries_key", "zkhip_fri_queries_proof_size",
     "zkhip_prove_fri_queries", "zkhip_verify_fri_queries",
-    "zkhip_fri_view_path_words", "zkhip_fri_view_shard_paths", "zkhip_fri_layers_chip_air", "zkhip_p2chip_air_fri_layers", "zkhip_fri_layers_gen_paths_trace",
+    "zkhip_fri_view_path_words", "zkhip_fri_view_shard_paths", "zkhip_fri_view_transcript", "zkhip_fri_layers_chip_air", "zkhip_p2chip_air_fri_layers", "zkhip_fri_layers_gen_paths_trace",
     "zkhip_fri_layers_key", "zkhip_fri_layers_proof_size", "zkhip_prove_fri_layers", "zkhip_verify_fri_layers",
     "zkhip_p2chip_air", "zkhip_p2chip_gen_merkle_trace", "zkhip_merkle_paths_proof_size", "zkhip_prove_merkle_paths", "zkhip_verify_merkle_paths",
     "zkhip_sha256_air", "zkhip_sha256_digest", "zkhip_sha256_pad", "zkhip_sha256_gen_trace", "zkhip_sha256_proof_size", "zkhip_prove_sha256", "zkhip_verify_sha256",
@@ -225,6 +225,7 @@ def load():
     L.zkhip_fri_view_path_words.restype = C.c_size_t
     L.zkhip_fri_view_path_words.argtypes = [C.c_int]
     L.zkhip_fri_view_shard_paths.argtypes = [u8p, C.c_size_t, C.c_int, C.c_uint32, u32p, C.c_size_t, C.POINTER(Params), u32p, u32p, u32p, u32p, u32p, u32p, u32p]
+    L.zkhip_fri_view_transcript.argtypes = [u8p, C.c_size_t, C.c_int, C.c_uint32, u32p, C.c_size_t, C.POINTER(Params), u32p, u32p, u32p]
     for f in (L.zkhip_fri_layers_chip_air, L.zkhip_p2chip_air_fri_layers):
         f.restype = C.c_size_t
         f.argtypes = [C.c_int, u32p, C.c_size_t]

@@ -164,7 +164,7 @@ static int run_queries(int n, const std::function<int(int)>& check, int min_per_
 // challenges, the final value, and per query the index, the reduced opening it starts from and the sibling of every layer.
 // zkhip_fri_view_shard points this at its caller's buffers and runs the verifier; the FRI-fold chip (fri_chip.hip) proves
 // statements about exactly these values.  Canonical words.
-struct FriViewSink { uint32_t *betas, *final_value, *indices, *values, *siblings; int layers; uint32_t *roots, *paths; };      // roots / paths optional
+struct FriViewSink { uint32_t *betas, *final_value, *indices, *values, *siblings; int layers; uint32_t *roots, *paths; uint32_t* transcript; };      // roots / paths / transcript optional
 
 static int verify_shard_impl(const uint8_t* proof, size_t len, int log_n, uint32_t width, const uint32_t* public_values,
                              size_t n_public, const zkhip_params* prm, int* reason, const AirView* air, FriViewSink* sink = nullptr) {
@@ -319,6 +319,10 @@ static int verify_shard_impl(const uint8_t* proof, size_t len, int log_n, uint32
               off_pn = ext_pow(fa, 2 * (uint64_t)width + wp), off_q = ext_pow(fa, 2 * (uint64_t)width + 2 * wp);
     std::vector<uint32_t> commits((size_t)RL * 8 + 8);
     std::vector<Ext> betas(RL + 1);
+    if (sink && sink->transcript) {               // the challenger as the commit phase finds it: capacity half of the state, pending inputs
+        for (int i = 0; i < 8; i++) sink->transcript[i] = from_monty(ch.state[8 + i]);
+        sink->transcript[8] = (uint32_t)ch.n_in;
+    }
     for (int l = 0; l < RL; l++) {
         for (int i = 0; i < 8; i++) { commits[8 * l + i] = to_monty(pf[pos++]); ch.observe(commits[8 * l + i]); }
         betas[l] = ch.sample_ext();
@@ -468,7 +472,7 @@ int zkhip_fri_view_shard(const uint8_t* proof, size_t len, int log_n, uint32_t w
     if (check_shape(log_n, width, prm) != ZKHIP_OK) return ZKHIP_ERR_INVALID;
     shape_of(log_n, prm, sh);
     if (sh.K != 1 || sh.F != 0) return fail(ZKHIP_ERR_INVALID, "fri_view_shard: fold-by-2 proofs with a constant final value only");
-    FriViewSink sink{betas, final_value, indices, values, siblings, sh.R, nullptr, nullptr};
+    FriViewSink sink{betas, final_value, indices, values, siblings, sh.R, nullptr, nullptr, nullptr};
     int why = 0;
     return verify_shard_impl(proof, len, log_n, width, public_values, n_public, prm, &why, nullptr, &sink);
 }
@@ -481,7 +485,25 @@ int zkhip_fri_view_shard_paths(const uint8_t* proof, size_t len, int log_n, uint
     if (check_shape(log_n, width, prm) != ZKHIP_OK) return ZKHIP_ERR_INVALID;
     shape_of(log_n, prm, sh);
     if (sh.K != 1 || sh.F != 0 || sh.b != 1) return fail(ZKHIP_ERR_INVALID, "fri_view_shard_paths: fold-by-2, blowup-2 proofs with a constant final value only");
-    FriViewSink sink{betas, final_value, indices, values, siblings, sh.R, roots, paths};
+    FriViewSink sink{betas, final_value, indices, values, siblings, sh.R, roots, paths, nullptr};
+    int why = 0;
+    return verify_shard_impl(proof, len, log_n, width, public_values, n_public, prm, &why, nullptr, &sink);
+}
+// The Fiat-Shamir side of the same view: the layer roots, the challenges, and the duplex challenger's state as the commit phase finds
+// it -- transcript[0..8) = the capacity half of its state (canonical), transcript[8] = inputs pending (0 for every proof shape of this
+// library: the step before is a sample).  With these the challenges are a SPONGE CHAIN over the roots: state <- (root_l | capacity),
+// permute, beta_l = (state[7], state[6], state[5], state[4]), capacity <- state[8..16) -- the rows a Poseidon2 chip in sponge mode
+// already has; what a transcript chip has to prove (docs/RECURSION_NEXT.md).
+int zkhip_fri_view_transcript(const uint8_t* proof, size_t len, int log_n, uint32_t width, const uint32_t* public_values, size_t n_public,
+                              const zkhip_params* prm, uint32_t* roots, uint32_t* betas, uint32_t transcript[9]) {
+    if (!prm || !roots || !betas || !transcript) return fail(ZKHIP_ERR_INVALID, "fri_view_transcript: null argument");
+    Shape sh;
+    if (check_shape(log_n, width, prm) != ZKHIP_OK) return ZKHIP_ERR_INVALID;
+    shape_of(log_n, prm, sh);
+    if (sh.K != 1 || sh.F != 0) return fail(ZKHIP_ERR_INVALID, "fri_view_transcript: fold-by-2 proofs with a constant final value only");
+    std::vector<uint32_t> final_value(4), indices((size_t)prm->num_queries), values((size_t)prm->num_queries * 4),
+        siblings((size_t)prm->num_queries * (size_t)sh.R * 4);
+    FriViewSink sink{betas, final_value.data(), indices.data(), values.data(), siblings.data(), sh.R, roots, nullptr, transcript};
     int why = 0;
     return verify_shard_impl(proof, len, log_n, width, public_values, n_public, prm, &why, nullptr, &sink);
 }

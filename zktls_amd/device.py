@@ -918,6 +918,19 @@ def fri_view_shard(proof, log_n, width, public_values=(), params=None):
             "queries": [(int(idx[q]), vals[4 * q:4 * q + 4].tolist(), sibs[4 * q * R:4 * (q + 1) * R].reshape(R, 4).tolist()) for q in range(Q)]}
 
 
+def fri_view_transcript(proof, log_n, width, public_values=(), params=None):
+    """zkhip_fri_view_transcript -> (roots [R][8], betas [R][4], capacity [8], pending inputs): the Fiat-Shamir side of the FRI view"""
+    params = params or Params(1, 100, 16)
+    lib = _lib.load()
+    pr = np.ascontiguousarray(proof, dtype=np.uint8)
+    pv = np.ascontiguousarray(np.array(public_values, dtype=np.uint32))
+    R = log_n
+    roots, betas, tr = np.zeros(8 * R, dtype=np.uint32), np.zeros(4 * R, dtype=np.uint32), np.zeros(9, dtype=np.uint32)
+    check(lib.zkhip_fri_view_transcript(pr.ctypes.data_as(u8p), pr.size, log_n, width, pv.ctypes.data_as(u32p), pv.size, C.byref(params),
+                                        roots.ctypes.data_as(u32p), betas.ctypes.data_as(u32p), tr.ctypes.data_as(u32p)))
+    return roots.reshape(R, 8).tolist(), betas.reshape(R, 4).tolist(), tr[:8].tolist(), int(tr[8])
+
+
 def fri_view_shard_paths(proof, log_n, width, public_values=(), params=None):
     """zkhip_fri_view_shard_paths: the view of fri_view_shard plus "roots": [R][8] and, per query, "paths": [R] lists of (R - l) digests"""
     params = params or Params(1, 100, 16)
