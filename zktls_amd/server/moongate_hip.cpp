@@ -46,11 +46,6 @@ namespace {
 
 struct Request { std::string method, path, content_type; std::vector<uint8_t> body; bool ok = false; };
 
-bool read_exact(int fd, void* buf, size_t n) {
-    uint8_t* p = (uint8_t*)buf;
-    while (n) { ssize_t r = ::recv(fd, p, n, 0); if (r <= 0) return false; p += r; n -= (size_t)r; }
-    return true;
-}
 bool write_all(int fd, const void* buf, size_t n) {
     const uint8_t* p = (const uint8_t*)buf;
     while (n) { ssize_t r = ::send(fd, p, n, MSG_NOSIGNAL); if (r <= 0) return false; p += r; n -= (size_t)r; }
