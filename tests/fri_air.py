@@ -14,6 +14,8 @@ from pyref import P, bitrev, ext_mul, two_adic_generator
 V = O.air_var
 E0, E1, BIT, K, X, XI, S, T, B, BETA, FOLD, ACTIVE, LN, G, GS, GT, OWN, L = 0, 4, 8, 9, 10, 11, 12, 13, 14, 15, 19, 23, 24, 25, 26, 27, 28, 32
 BUS_E0, BUS_E1, BUS_R0, BUS_R1, BUS_Q = 40, 41, 42, 43, 44
+BUS_B = 45                                     # the transcript machine: (layer, beta) from the Poseidon2 chip's transcript rows to the ROOTS table
+ROOTS_PRE_T = 16                               # ... whose preprocessed row is then (layer, root[8], beta[4], 1, 0, 0)
 K2, IDX, L_WIRED = 32, 33, 34                  # the wired form's extra columns, its layer selectors start two columns later
 QUERIES_PRE, ROOTS_PRE = 8, 12
 OPEN_PRE, OPEN_MAIN = 12, 4
@@ -34,7 +36,7 @@ def root_const(l):
     return two_adic_generator(l + 1)
 
 
-def program(layers, wired=False):
+def program(layers, wired=False, n_public=None):
     R = layers
     L = L_WIRED if wired else globals()["L"]
     END = L + R - 1
@@ -87,7 +89,7 @@ def program(layers, wired=False):
     if wired:
         add(O.SEL_ALL, [(1, [V(K2)]), (P - 2, [V(K)])])
         add(O.SEL_ALL, [(1, [V(IDX)]), (P - 1, [V(K2)]), (P - 1, [V(BIT)])])
-    return O.air_program(width_of(R, wired), n_public_of(R), cons)
+    return O.air_program(width_of(R, wired), n_public_of(R) if n_public is None else n_public, cons)
 
 
 def fold_pair(k, lh, beta, e0, e1):
@@ -206,14 +208,17 @@ def random_view(layers, n_queries, seed=1):
     return {"betas": betas, "queries": queries, "final": layers_vec[layers][top]}
 
 
-def machine_layers(view):
+def machine_layers(view, capacity=None):
     """the wired machine (zkhip_prove_fri_layers): the Poseidon2 chip's FRI-layers variant (one Merkle path per (query, layer)), the fold
-    chip in its wired form, and the preprocessed QUERIES / ROOTS tables -> (main traces, preprocessed traces, programs, tables, public values)"""
+    chip in its wired form, and the preprocessed QUERIES / ROOTS tables -> (main traces, preprocessed traces, programs, tables, public values).
+    capacity (8 words: the duplex challenger's capacity as the commit phase finds it): the TRANSCRIPT machine (zkhip_prove_fri_transcript)
+    -- the Poseidon2 chip's trace starts with a sponge chain over the layer roots whose outputs must be the betas of the ROOTS table"""
     import poseidon2_air as P2
     betas, queries, roots, paths = view["betas"], view["queries"], view["roots"], view["paths"]
     R, Q = len(betas), len(queries)
     H = R + 1
-    NP = n_public_of(R)
+    T = capacity is not None
+    NP = n_public_of(R) + (8 if T else 0)
 
     def lg(n, lo=5):
         l = lo
@@ -229,8 +234,12 @@ def machine_layers(view):
             e0, e1 = (sibs[l], own) if bit else (own, sibs[l])
             plist.append((l, k, list(e0) + list(e1), paths[q][l], 1))
             own, idx = fold_pair(k, H - (l + 1), betas[l], e0, e1)[0], k
-    lr_p2 = lg(Q * (R + R * (R + 1) // 2))
-    p2_trace, p2_roots = P2.layer_paths_trace(plist, lr_p2)
+    lr_p2 = lg(Q * (R + R * (R + 1) // 2) + (R if T else 0))
+    if T:
+        p2_trace, p2_roots, chain = P2.layer_paths_trace(plist, lr_p2, transcript=(capacity, roots))
+        assert chain == [list(b) for b in betas], "the challenges are not the sponge chain over the roots"
+    else:
+        p2_trace, p2_roots = P2.layer_paths_trace(plist, lr_p2)
     for i, (l, k, pair, sibs, mult) in enumerate(plist):
         assert p2_roots[i] == list(roots[l]), "a path does not end in its layer's root"
     lr_fri = lg(Q * R)
@@ -240,24 +249,36 @@ def machine_layers(view):
     qpre = np.zeros((1 << lr_q, QUERIES_PRE), dtype=np.uint32)
     for q, (index, value, _) in enumerate(queries):
         qpre[q, 0], qpre[q, 1:5], qpre[q, 5] = index, value, 1
-    rpre = np.zeros((1 << lr_r, ROOTS_PRE), dtype=np.uint32)
+    RP = ROOTS_PRE_T if T else ROOTS_PRE
+    rpre = np.zeros((1 << lr_r, RP), dtype=np.uint32)
     rmain = np.zeros((1 << lr_r, 4), dtype=np.uint32)
     for l in range(R):
         rpre[l, 0], rpre[l, 1:9] = l, roots[l]
-        rmain[l, 0] = Q
+        rmain[l, 0] = Q + (1 if T else 0)              # the paths that end in the root, and the transcript row that absorbs it
+        if T:
+            rpre[l, 9:13], rpre[l, 13] = betas[l], 1
     o7 = P2.OUTE(7)
-    p2_tab = O.interaction_table([(O.RECEIVE, P2.M, BUS_E0, [P2.LNP, P2.KP, P2.IN, P2.IN + 1, P2.IN + 2, P2.IN + 3]),
-                                  (O.RECEIVE, P2.M, BUS_E1, [P2.LNP, P2.KP, P2.IN + 4, P2.IN + 5, P2.IN + 6, P2.IN + 7]),
-                                  (O.SEND, P2.END, BUS_R0, [P2.LNP, o7, o7 + 1, o7 + 2, o7 + 3]),
-                                  (O.SEND, P2.END, BUS_R1, [P2.LNP, o7 + 4, o7 + 5, o7 + 6, o7 + 7])])
+    p2_inter = [(O.RECEIVE, P2.M, BUS_E0, [P2.LNP, P2.KP, P2.IN, P2.IN + 1, P2.IN + 2, P2.IN + 3]),
+                (O.RECEIVE, P2.M, BUS_E1, [P2.LNP, P2.KP, P2.IN + 4, P2.IN + 5, P2.IN + 6, P2.IN + 7]),
+                (O.SEND, P2.END, BUS_R0, [P2.LNP, o7, o7 + 1, o7 + 2, o7 + 3]),
+                (O.SEND, P2.END, BUS_R1, [P2.LNP, o7 + 4, o7 + 5, o7 + 6, o7 + 7])]
+    if T:
+        p2_inter += [(O.SEND, P2.TRS, BUS_R0, [P2.LNP, P2.IN, P2.IN + 1, P2.IN + 2, P2.IN + 3]),
+                     (O.SEND, P2.TRS, BUS_R1, [P2.LNP, P2.IN + 4, P2.IN + 5, P2.IN + 6, P2.IN + 7]),
+                     (O.SEND, P2.TRS, BUS_B, [P2.LNP, o7 + 7, o7 + 6, o7 + 5, o7 + 4])]
+    p2_tab = O.interaction_table(p2_inter)
     fri_tab = O.interaction_table([(O.SEND, ACTIVE, BUS_E0, [LN, K2, E0, E0 + 1, E0 + 2, E0 + 3]), (O.SEND, ACTIVE, BUS_E1, [LN, K2, E1, E1 + 1, E1 + 2, E1 + 3]),
                                    (O.SEND, L_WIRED, BUS_Q, [IDX, OWN, OWN + 1, OWN + 2, OWN + 3])])
     q_tab = O.interaction_table([(O.RECEIVE, 5, BUS_Q, [0, 1, 2, 3, 4])])
-    r_tab = O.interaction_table([(O.RECEIVE, ROOTS_PRE, BUS_R0, [0, 1, 2, 3, 4]), (O.RECEIVE, ROOTS_PRE, BUS_R1, [0, 5, 6, 7, 8])])
+    r_inter = [(O.RECEIVE, RP, BUS_R0, [0, 1, 2, 3, 4]), (O.RECEIVE, RP, BUS_R1, [0, 5, 6, 7, 8])]
+    if T:
+        r_inter.append((O.RECEIVE, 13, BUS_B, [0, 9, 10, 11, 12]))
+    r_tab = O.interaction_table(r_inter)
 
     def table_prog(pre_width):
         return O.air_program(pre_width + 4, NP, [(O.SEL_FIRST, [(1, [V(pre_width + 3)])])])
-    pub = [c for b in betas for c in b] + list(final)
+    pub = [c for b in betas for c in b] + list(final) + ([int(v) for v in capacity] if T else [])
     return ([p2_trace, fri_trace, np.zeros((1 << lr_q, 4), dtype=np.uint32), rmain], [None, None, qpre, rpre],
-            [P2.program(fri_layers=True, n_public=NP), program(R, wired=True), table_prog(QUERIES_PRE), table_prog(ROOTS_PRE)],
+            [P2.program(fri_layers=True, n_public=NP, transcript=n_public_of(R) if T else None), program(R, wired=True, n_public=NP),
+             table_prog(QUERIES_PRE), table_prog(RP)],
             [p2_tab, fri_tab, q_tab, r_tab], pub)

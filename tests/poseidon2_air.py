@@ -36,6 +36,7 @@ BIT, CH, END, CNT, SPG, SS = 351, 352, 353, 354, 355, 356
 WIDTH = 360
 N_PUBLIC = 9
 LNP, KP, M = 357, 358, 359          # the FRI-layers variant's use of the three spare columns (program(fri_layers=True))
+TRS, WIDTH_T = 360, 364             # the transcript variant (program(fri_layers=True, transcript=cap_pub)): one more flag column
 
 
 def X3E(r):
@@ -77,9 +78,13 @@ def _linear_def(col, form):
     return [_term(1, [V(col)])] + [_term(P - form[c], [V(c)]) for c in sorted(form) if form[c] % P]
 
 
-def program(fri_layers=False, n_public=N_PUBLIC):
+def program(fri_layers=False, n_public=N_PUBLIC, transcript=None):
     """fri_layers: the variant wired to the FRI-fold chip (tests/fri_air.py): paths of different depths, no public root (END rows send
-    their digest on a bus instead), LNP / KP / M in the spare columns"""
+    their digest on a bus instead), LNP / KP / M in the spare columns.
+    transcript = index of the first of 8 public values (the duplex challenger's capacity as the FRI commit phase finds it): the trace
+    then STARTS with transcript rows (TRS = 1, LNP = 0, 1, 2, ...), a sponge chain over the layer roots -- row l absorbs root_l into the
+    rate half (sent to the ROOTS table like a path's digest), keeps the capacity of row l - 1 (row 0: the public one), and sends
+    (l, out[7], out[6], out[5], out[4]) = the challenge beta_l on a bus of its own"""
     ME, rc_e, rc_i, diag = pyref.ME, PARAMS["external_rc"], PARAMS["internal_rc"], PARAMS["internal_diag"]
     cons = []
     for i in range(16):
@@ -148,13 +153,38 @@ def program(fri_layers=False, n_public=N_PUBLIC):
         cons.append((O.SEL_TRANSITION, [_term(1, [V(CH, True), V(KP)]), _term(P - 2, [V(CH, True), V(KP, True)]), _term(P - 1, [V(CH, True), V(BIT)])]))
         cons.append((O.SEL_ALL, [_term(1, [V(END), V(KP)]), _term(P - 1, [V(END), V(BIT)])]))
         cons.append((O.SEL_ALL, [_term(1, [V(M)]), _term(P - 1, [V(M), V(SS)])]))
+    if transcript is not None:
+        assert fri_layers
+        cons.append((O.SEL_ALL, [_term(1, [V(TRS), V(TRS)]), _term(P - 1, [V(TRS)])]))
+        cons.append((O.SEL_FIRST, [_term(1, [V(TRS)]), _term(P - 1, [])]))                                   # the trace starts with the transcript
+        cons.append((O.SEL_FIRST, [_term(1, [V(LNP)])]))
+        for j in range(8):
+            cons.append((O.SEL_FIRST, [_term(1, [V(IN + 8 + j)]), _term(P - 1, [V(transcript + j, public=True)])]))
+        cons.append((O.SEL_TRANSITION, [_term(1, [V(TRS, True)]), _term(P - 1, [V(TRS), V(TRS, True)])]))      # transcript rows are a prefix
+        cons.append((O.SEL_TRANSITION, [_term(1, [V(TRS, True), V(LNP, True)]), _term(P - 1, [V(TRS, True), V(LNP)]), _term(P - 1, [V(TRS, True)])]))
+        cons.append((O.SEL_TRANSITION, [_term(1, [V(TRS, True)]), _term(P - 1, [V(TRS, True), V(SPG, True)])]))   # ... chained through the capacity
+        cons.append((O.SEL_ALL, [_term(1, [V(SPG)]), _term(P - 1, [V(SPG), V(TRS)])]))                         # and nothing else is
+        for f in (CH, END, SS, BIT, M):
+            cons.append((O.SEL_ALL, [_term(1, [V(TRS), V(f)])]))
+        return O.air_program(WIDTH_T, n_public, cons)
     return O.air_program(WIDTH, n_public, cons)
 
 
-def layer_paths_trace(paths, log_n):
+def layer_paths_trace(paths, log_n, transcript=None):
     """the FRI-layers variant's trace: paths = [(layer, leaf index, pair [8 values], siblings [[8] x depth], multiplicity)], one leaf row
-    (the sponge over the pair) + depth compression rows each -> (trace [2^log_n][WIDTH], roots)"""
+    (the sponge over the pair) + depth compression rows each -> (trace [2^log_n][WIDTH], roots).
+    transcript = (capacity [8], layer roots [[8] x R]): the transcript variant -- R sponge rows over the roots come first, the rows are
+    WIDTH_T wide -> (trace, roots, betas)"""
     rows, roots, cnt = [], [], 0
+    betas = []
+    if transcript is not None:
+        cap, layer_roots = [int(v) % P for v in transcript[0]], transcript[1]
+        for l, root in enumerate(layer_roots):
+            r, out = row([int(v) % P for v in root] + cap, 0, 0, 0, 0, 1 if l else 0, 0)
+            r[LNP] = l
+            rows.append(r + [1, 0, 0, 0])
+            betas.append([out[7], out[6], out[5], out[4]])
+            cap = out[8:]
     for layer, index, pair, sibs, mult in paths:
         r, out = row([int(v) % P for v in pair] + [0] * 8, 0, 0, 0, cnt, 0, 1)
         r[LNP], r[KP], r[M] = layer, 2 * index % P, mult
@@ -172,8 +202,13 @@ def layer_paths_trace(paths, log_n):
             digest = out[:8]
         roots.append(digest)
     pad, _ = row([0] * 16, 0, 0, 0, cnt)
+    if transcript is not None:
+        rows = [r if len(r) == WIDTH_T else r + [0, 0, 0, 0] for r in rows]
+        pad = pad + [0, 0, 0, 0]
     assert len(rows) <= 1 << log_n
     rows += [pad] * ((1 << log_n) - len(rows))
+    if transcript is not None:
+        return np.array(rows, dtype=np.uint64).astype(np.uint32), roots, betas
     return np.array(rows, dtype=np.uint64).astype(np.uint32), roots
 
 

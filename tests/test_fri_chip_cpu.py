@@ -234,3 +234,54 @@ def test_wired_machine_of_a_golden_proofs_view(oracle, name, shape):
     pre2 = [None, None, pre[2], pre[3].copy()]
     pre2[3][0, 1] = (int(pre2[3][0, 1]) + 1) % P
     assert _machine_rejected(O, traces, pre2, progs, tables, pub, shape)
+
+
+# ------------------------------------------------------------------ the transcript machine: the challenges derived in-circuit
+@pytest.mark.parametrize("name,shape", [("v1_6x8", (1, 10, 4)), ("v1_10x16", (1, 8, 6))])
+def test_transcript_machine_of_a_golden_proofs_view(oracle, name, shape):
+    """the wired machine whose Poseidon2 chip starts with transcript rows: a sponge chain over the layer roots, from the challenger's
+    capacity (8 more public values), whose outputs must be the challenges of the key.  Under the oracle's prover and three verifiers;
+    refused: a challenge in the key that the chain does not produce, another capacity, a root absorbed that is not the layer's, a
+    transcript row left out"""
+    from zktls_amd.device import fri_view_shard_paths, fri_view_transcript
+    import poseidon2_air as P2
+    O = oracle
+    g = GOLDEN[name]
+    b = load(name)
+    prm0 = Params(*g["shape"])
+    view = fri_view_shard_paths(b, g["log_n"], g["width"], g["public"], prm0)
+    roots, betas, capacity, pending = fri_view_transcript(b, g["log_n"], g["width"], g["public"], prm0)
+    assert roots == view["roots"] and betas == view["betas"] and pending == 0
+    traces, pre, progs, tables, pub = F.machine_layers(view, capacity=capacity)
+    lns, ws, pws = shape_of(traces, pre)
+    R = g["log_n"]
+    assert ws[0] == P2.WIDTH_T and pws == [0, 0, 8, 16] and lns == sorted(lns, reverse=True) and len(pub) == 4 * R + 12
+    assert all(int(traces[0][l, P2.TRS]) == 1 and int(traces[0][l, P2.LNP]) == l for l in range(R)) and int(traces[0][R, P2.TRS]) == 0
+    for prog, w in zip(progs, ws):
+        assert O.air_log_quotient_degree(prog) == 1
+    oprm, prm = O.default_params(*shape), Params(*shape)
+    root = O.machine_setup(pre, lns, oprm)
+    proof = O.prove_machine_keyed(traces, pre, progs, tables, pub, oprm)
+    assert O.verify_machine_keyed(proof, lns, ws, pws, root, progs, tables, pub, oprm) == 0
+    assert verify_machine_keyed(proof, lns, ws, pws, root, progs, tables, pub, prm) == (0, 0)
+    assert pyverify_chips.verify(proof.tobytes(), lns, ws, pub, shape[0], shape[1], shape[2], programs=progs, tables=tables, pre_widths=pws,
+                                 pre_root=[int(v) for v in root]) is True
+
+    def tampered(chip, fn):
+        t = [x.copy() for x in traces]
+        fn(t[chip])
+        return t
+    # a challenge in the key that the sponge chain does not produce
+    pre2 = [None, None, pre[2], pre[3].copy()]
+    pre2[3][1, 9] = (int(pre2[3][1, 9]) + 1) % P
+    assert _machine_rejected(O, traces, pre2, progs, tables, pub, shape)
+    # another capacity than the public one on the first transcript row
+    pub2 = list(pub)
+    pub2[-3] = (pub2[-3] + 1) % P
+    assert _machine_rejected(O, traces, pre, progs, tables, pub2, shape)
+    # a transcript row that absorbs something else than its layer's root
+    assert _machine_rejected(O, tampered(0, lambda t: t.__setitem__((2, P2.IN + 3), (int(t[2, P2.IN + 3]) + 1) % P)), pre, progs, tables, pub, shape)
+    # a transcript row that claims another layer number
+    assert _machine_rejected(O, tampered(0, lambda t: t.__setitem__((1, P2.LNP), 3)), pre, progs, tables, pub, shape)
+    # the last transcript row left out (its flag cleared): the ROOTS table still expects its root and its challenge
+    assert _machine_rejected(O, tampered(0, lambda t: t.__setitem__((R - 1, P2.TRS), 0)), pre, progs, tables, pub, shape)
