@@ -28,7 +28,8 @@
  *       many transcripts, or the shards of one long message, dealt over the GPUs of the node by one call.
  *   zkhip_p2chip_air, zkhip_prove_merkle_paths / zkhip_verify_merkle_paths
  *   zkhip_fri_view_shard, zkhip_fri_chip_air, zkhip_fri_queries_key, zkhip_prove_fri_queries / zkhip_verify_fri_queries,
- *   zkhip_fri_view_shard_paths, zkhip_fri_layers_key, zkhip_prove_fri_layers / zkhip_verify_fri_layers
+ *   zkhip_fri_view_shard_paths, zkhip_fri_layers_key, zkhip_prove_fri_layers / zkhip_verify_fri_layers,
+ *   zkhip_fri_view_transcript, zkhip_fri_transcript_key, zkhip_prove_fri_transcript / zkhip_verify_fri_transcript
  *       a first recursion step: the FRI folds of a shard proof checked inside a (keyed machine) proof -- what `compress` behind
  *       SP1ProofMode::Groth16 (sp1.rs:116) spends its rows on besides Poseidon2.
  *       a second real chip -- the Poseidon2 permutation with Merkle-path / leaf-hash chaining, what the recursion stages behind
@@ -688,6 +689,24 @@ int zkhip_prove_fri_layers(zkhip_ctx* ctx, const zkhip_machine_key* key, int lay
                            uint8_t* proof, size_t cap, size_t* len);
 int zkhip_verify_fri_layers(const uint8_t* proof, size_t len, int layers, size_t n_queries, const uint32_t* betas, const uint32_t final_value[4],
                             const uint32_t vk[8], const zkhip_params* prm, int* reason);
+/* The same machine with the FRI TRANSCRIPT in-circuit: the Poseidon2 chip's trace starts with transcript rows (zkhip_p2chip_air_fri_transcript,
+ * 364 columns) -- a sponge chain over the layer roots from the duplex challenger's capacity (zkhip_fri_view_transcript; eight more public
+ * values): row l absorbs root_l (sent to the ROOTS table like a path's end), keeps the capacity of row l - 1 and sends
+ * (l, out[7], out[6], out[5], out[4]) on a bus of its own; the ROOTS table's preprocessed rows carry the challenges beside the roots and
+ * receive those tuples once each.  Statement added to the one above: "... and the challenges are the ones the transcript derives from
+ * these layer roots, starting from this challenger state."  Still outside: how that state came about (the transcript before the commit
+ * phase), the query indices, the trace / quotient openings and the reduced openings.  Ref: p3-challenger DuplexChallenger
+ * (reference Cargo.lock:3875) behind sp1.rs:116. */
+size_t zkhip_fri_transcript_chip_air(int layers, uint32_t* program, size_t cap_words);
+size_t zkhip_p2chip_air_fri_transcript(int layers, uint32_t* program, size_t cap_words);
+int zkhip_fri_transcript_key(zkhip_ctx* ctx, int layers, size_t n_queries, const uint32_t* indices, const uint32_t* values, const uint32_t* roots,
+                             const uint32_t* betas, const zkhip_params* prm, zkhip_machine_key** key, uint32_t vk[8]);
+size_t zkhip_fri_transcript_proof_size(int layers, size_t n_queries, const zkhip_params* prm);
+int zkhip_prove_fri_transcript(zkhip_ctx* ctx, const zkhip_machine_key* key, int layers, size_t n_queries, const uint32_t* betas, const uint32_t* indices,
+                               const uint32_t* values, const uint32_t* siblings, const uint32_t* roots, const uint32_t* paths, const uint32_t capacity[8],
+                               const zkhip_params* prm, uint8_t* proof, size_t cap, size_t* len);
+int zkhip_verify_fri_transcript(const uint8_t* proof, size_t len, int layers, size_t n_queries, const uint32_t* betas, const uint32_t final_value[4],
+                                const uint32_t capacity[8], const uint32_t vk[8], const zkhip_params* prm, int* reason);
 
 /* ---- Poseidon2 parameter tables from a file: the built-in sets are this repo's own
  * ("zktls-amd/p2-bb16-v1", "...-bb24-v1"; the SP1 / RISC Zero tables of reference Cargo.lock:4030, 6172, 5057 are not

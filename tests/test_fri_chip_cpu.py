@@ -266,6 +266,15 @@ def test_transcript_machine_of_a_golden_proofs_view(oracle, name, shape):
     assert verify_machine_keyed(proof, lns, ws, pws, root, progs, tables, pub, prm) == (0, 0)
     assert pyverify_chips.verify(proof.tobytes(), lns, ws, pub, shape[0], shape[1], shape[2], programs=progs, tables=tables, pre_widths=pws,
                                  pre_root=[int(v) for v in root]) is True
+    # the library builds the same two chip programs, and its entry point for this machine accepts the oracle's proof
+    from zktls_amd.device import fri_transcript_programs, verify_fri_transcript
+    p2t, frit = fri_transcript_programs(R)
+    assert p2t.tolist() == progs[0].tolist() and frit.tolist() == progs[1].tolist()
+    nq = len(view["queries"])
+    assert verify_fri_transcript(proof, view["betas"], view["final"], capacity, nq, root, prm) == (0, 0)
+    other = list(capacity)
+    other[0] = (other[0] + 1) % P
+    assert verify_fri_transcript(proof, view["betas"], view["final"], other, nq, root, prm)[0] == -6
 
     def tampered(chip, fn):
         t = [x.copy() for x in traces]

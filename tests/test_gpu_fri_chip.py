@@ -180,3 +180,78 @@ def test_fullsize_fri_layers_of_the_headline_shard(ctx, oracle):
     assert proof.tobytes() == O.prove_machine_keyed(traces, pre, progs, tables, pub, oprm).tobytes()
     assert O.verify_machine_keyed(proof, lns, ws, pws, key.root, progs, tables, pub, oprm) == 0
     key.close()
+
+
+# ------------------------------------------------------------------ the transcript machine: the challenges derived in-circuit
+@pytest.mark.parametrize("log_n,width,inner,outer", [(6, 8, (1, 9, 4), (1, 12, 4)), (11, 16, (1, 20, 8), (1, 16, 6))])
+def test_fri_transcript_of_a_shard_proof_in_circuit(ctx, oracle, log_n, width, inner, outer):
+    """a shard proof made here; its FRI view with the challenger's capacity; the wired machine whose Poseidon2 chip starts with the
+    sponge chain over the layer roots: key and proof bytes against the oracle on the independently restated arrays, four verifiers;
+    challenges that the transcript does not produce are refused before anything is proven"""
+    from zktls_amd.device import fri_view_shard_paths, fri_view_transcript, verify_fri_transcript
+    import poseidon2_air as P2
+    O = oracle
+    iprm, prm, oprm = Params(*inner), Params(*outer), O.default_params(*outer)
+    pv = [4, 5]
+    trace = ctx.gen_trace(SEED, 5, log_n, width)
+    shard_proof = ctx.prove_shard(trace, log_n, width, pv, iprm)
+    trace.free()
+    view = fri_view_shard_paths(shard_proof, log_n, width, pv, iprm)
+    roots, betas, capacity, pending = fri_view_transcript(shard_proof, log_n, width, pv, iprm)
+    assert roots == view["roots"] and betas == view["betas"] and pending == 0
+    traces, pre, progs, tables, pub = F.machine_layers(view, capacity=capacity)
+    lns, ws, pws = shape_of(traces, pre)
+    assert ws[0] == P2.WIDTH_T and pws == [0, 0, 8, 16]
+    key = ctx.fri_transcript_key(view, prm)
+    assert key.root.tolist() == O.machine_setup(pre, lns, oprm).tolist()
+    proof = ctx.prove_fri_transcript(key, view, capacity, prm)
+    oproof = O.prove_machine_keyed(traces, pre, progs, tables, pub, oprm)
+    assert proof.tobytes() == oproof.tobytes(), "transcript machine proof differs from the oracle's"
+    nq = len(view["queries"])
+    assert verify_fri_transcript(proof, view["betas"], view["final"], capacity, nq, key.root, prm) == (0, 0)
+    assert verify_machine_keyed(proof, lns, ws, pws, key.root, progs, tables, pub, prm) == (0, 0)
+    assert O.verify_machine_keyed(proof, lns, ws, pws, key.root, progs, tables, pub, oprm) == 0
+    assert pyverify_chips.verify(proof.tobytes(), lns, ws, pub, outer[0], outer[1], outer[2], programs=progs, tables=tables, pre_widths=pws,
+                                 pre_root=[int(v) for v in key.root]) is True
+    # another capacity: the chain no longer produces the view's challenges -- refused by the prover, and by the verifier of the good proof
+    other = list(capacity)
+    other[5] = (other[5] + 1) % P
+    with pytest.raises(Exception):
+        ctx.prove_fri_transcript(key, view, other, prm)
+    assert verify_fri_transcript(proof, view["betas"], view["final"], other, nq, key.root, prm)[0] == -6
+    # a key with another challenge does not accept the proof
+    bad = dict(view)
+    bad["betas"] = [list(b) for b in view["betas"]]
+    bad["betas"][1][2] = (bad["betas"][1][2] + 1) % P
+    okey = ctx.fri_transcript_key(bad, prm)
+    assert okey.root.tolist() != key.root.tolist()
+    assert verify_fri_transcript(proof, view["betas"], view["final"], capacity, nq, okey.root, prm)[0] == -6
+    key.close()
+    okey.close()
+
+
+def test_fullsize_fri_transcript_of_the_headline_shard(ctx, oracle):
+    """the headline shard proof's 100 queries x 20 layers with the FRI transcript in-circuit: bytes against the oracle, timing"""
+    from zktls_amd.device import fri_view_shard_paths, fri_view_transcript, verify_fri_transcript
+    O = oracle
+    log_n, width = 20, 256
+    iprm, prm, oprm = Params(1, 100, 16), Params(1, 100, 16), O.default_params(1, 100, 16)
+    trace = ctx.gen_trace(SEED, 32, log_n, width)
+    shard_proof = ctx.prove_shard(trace, log_n, width, [1, 2, 3], iprm)
+    trace.free()
+    view = fri_view_shard_paths(shard_proof, log_n, width, [1, 2, 3], iprm)
+    _, _, capacity, _ = fri_view_transcript(shard_proof, log_n, width, [1, 2, 3], iprm)
+    key = ctx.fri_transcript_key(view, prm)
+    proof = ctx.prove_fri_transcript(key, view, capacity, prm)
+    t0 = time.perf_counter()
+    proof = ctx.prove_fri_transcript(key, view, capacity, prm)
+    t1 = time.perf_counter()
+    assert verify_fri_transcript(proof, view["betas"], view["final"], capacity, 100, key.root, prm) == (0, 0)
+    t2 = time.perf_counter()
+    print("\nFRI layers + transcript of a 2^20 x 256 shard proof in-circuit: machine proof %.1f ms, %d bytes, host verification %.1f ms"
+          % ((t1 - t0) * 1e3, proof.size, (t2 - t1) * 1e3))
+    traces, pre, progs, tables, pub = F.machine_layers(view, capacity=capacity)
+    lns, ws, pws = shape_of(traces, pre)
+    assert proof.tobytes() == O.prove_machine_keyed(traces, pre, progs, tables, pub, oprm).tobytes()
+    assert O.verify_machine_keyed(proof, lns, ws, pws, key.root, progs, tables, pub, oprm) == 0
+    key.close()

@@ -42,11 +42,13 @@ constexpr uint32_t E0 = 0, E1 = 4, BIT = 8, K = 9, X = 10, XI = 11, S = 12, T = 
 // index on a query's first row)
 constexpr uint32_t K2 = 32, IDX = 33, L_WIRED = 34;
 constexpr uint32_t BUS_E0 = 40, BUS_E1 = 41, BUS_R0 = 42, BUS_R1 = 43, BUS_Q = 44;
+constexpr uint32_t BUS_B = 45;                               // transcript machine: (layer, beta) from the Poseidon2 chip's transcript rows to the ROOTS table
+constexpr uint32_t ROOTS_PRE_T = 16;                         // ... whose preprocessed row is then (layer, root[8], beta[4], 1, 0, 0)
 constexpr uint32_t QUERIES_PRE = 8, ROOTS_PRE = 12;          // QUERIES: (index, value[4], 1, 0, 0); ROOTS: (layer, root[8], 0, 0, 0) + main (count, 0, 0, 0)
 constexpr uint32_t OPEN_PRE = 12, OPEN_MAIN = 4;             // OPENINGS: preprocessed (ln, k, e0[4], e1[4], m, 0), main 4 unused columns
 constexpr int MIN_LAYERS = 2, MAX_LAYERS = 22;
 inline uint32_t width_of(int layers, bool wired = false) { return ((wired ? L_WIRED : L) + (uint32_t)layers + 3u) & ~3u; }
-inline uint32_t n_public_of(int layers) { return 4u * (uint32_t)layers + 4u; }
+inline uint32_t n_public_of(int layers, bool transcript = false) { return 4u * (uint32_t)layers + 4u + (transcript ? 8u : 0u); }   // betas, final value (, capacity)
 
 namespace {
 inline Ext ext_from_canon(const uint32_t* p);
@@ -76,9 +78,9 @@ struct Builder {
 // c_l = w_{2^(l+1)} canonical: the factor bit l of a query index contributes to its evaluation point
 inline uint32_t root_const(int l) { return from_monty(two_adic_generator(l + 1)); }
 
-std::vector<uint32_t> build_program(int RL, bool wired) {
+std::vector<uint32_t> build_program(int RL, bool wired, bool transcript = false) {
     const uint32_t L = wired ? L_WIRED : frichip::L;       // first layer-selector column of this form
-    const uint32_t W = width_of(RL, wired), NP = n_public_of(RL), END = L + (uint32_t)RL - 1u;
+    const uint32_t W = width_of(RL, wired), NP = n_public_of(RL, transcript), END = L + (uint32_t)RL - 1u;
     const uint32_t inv2 = (P + 1) / 2;
     Builder b;
     // G * t for the gate G = ACTIVE - END ("an active row that is not the last of its query").  A selector counts one degree, so a
@@ -147,24 +149,24 @@ std::vector<uint32_t> build_program(int RL, bool wired) {
     p.insert(p.end(), b.body.begin(), b.body.end());
     return p;
 }
-std::shared_ptr<const std::vector<uint32_t>> program(int RL, bool wired = false) {
+std::shared_ptr<const std::vector<uint32_t>> program(int RL, bool wired = false, bool transcript = false) {
     static std::mutex mu;
     static std::map<int, std::shared_ptr<const std::vector<uint32_t>>> cache;
     std::lock_guard<std::mutex> lk(mu);
-    const int key = 2 * RL + (wired ? 1 : 0);
+    const int key = 4 * RL + (wired ? 1 : 0) + (transcript ? 2 : 0);
     auto it = cache.find(key);
-    if (it == cache.end()) it = cache.emplace(key, std::make_shared<const std::vector<uint32_t>>(build_program(RL, wired))).first;
+    if (it == cache.end()) it = cache.emplace(key, std::make_shared<const std::vector<uint32_t>>(build_program(RL, wired, transcript))).first;
     return it->second;
 }
 // a table whose contents are fixed by the KEY: combined row [pre | 4 main columns], one harmless first-row identity on the last main column
-std::shared_ptr<const std::vector<uint32_t>> table_program(int RL, uint32_t pre_width) {
+std::shared_ptr<const std::vector<uint32_t>> table_program(int RL, uint32_t pre_width, bool transcript = false) {
     static std::mutex mu;
     static std::map<uint64_t, std::shared_ptr<const std::vector<uint32_t>>> cache;
     std::lock_guard<std::mutex> lk(mu);
-    const uint64_t key = ((uint64_t)RL << 32) | pre_width;
+    const uint64_t key = ((uint64_t)RL << 32) | ((uint64_t)(transcript ? 1 : 0) << 31) | pre_width;
     auto it = cache.find(key);
     if (it == cache.end())
-        it = cache.emplace(key, std::make_shared<const std::vector<uint32_t>>(std::vector<uint32_t>{AIR_MAGIC, 1u, pre_width + 4u, 1u, n_public_of(RL), 6u + 5u,
+        it = cache.emplace(key, std::make_shared<const std::vector<uint32_t>>(std::vector<uint32_t>{AIR_MAGIC, 1u, pre_width + 4u, 1u, n_public_of(RL, transcript), 6u + 5u,
                                                                                                      FIRST, 1u, 1u, 1u, var(pre_width + 3u)})).first;
     return it->second;
 }
@@ -208,6 +210,18 @@ const std::vector<uint32_t>& p2_interactions() {          // leaf rows receive t
                                          0u, END, BUS_R1, 5u, LNP, oute(7) + 4, oute(7) + 5, oute(7) + 6, oute(7) + 7};
     return t;
 }
+const std::vector<uint32_t>& p2_interactions_transcript() {   // ... and the transcript rows send the root they absorb and the challenge they produce
+    using namespace p2chip;
+    static const std::vector<uint32_t> t{LOOKUP_MAGIC, 7u, 3u + 2u * 10u + 5u * 9u,
+                                         1u, M, BUS_E0, 6u, LNP, KP, IN, IN + 1, IN + 2, IN + 3,
+                                         1u, M, BUS_E1, 6u, LNP, KP, IN + 4, IN + 5, IN + 6, IN + 7,
+                                         0u, END, BUS_R0, 5u, LNP, oute(7), oute(7) + 1, oute(7) + 2, oute(7) + 3,
+                                         0u, END, BUS_R1, 5u, LNP, oute(7) + 4, oute(7) + 5, oute(7) + 6, oute(7) + 7,
+                                         0u, TRS, BUS_R0, 5u, LNP, IN, IN + 1, IN + 2, IN + 3,
+                                         0u, TRS, BUS_R1, 5u, LNP, IN + 4, IN + 5, IN + 6, IN + 7,
+                                         0u, TRS, BUS_B, 5u, LNP, oute(7) + 7, oute(7) + 6, oute(7) + 5, oute(7) + 4};
+    return t;
+}
 const std::vector<uint32_t>& queries_interactions() {     // receive (preprocessed multiplicity column 5, [index, value])
     static const std::vector<uint32_t> t{LOOKUP_MAGIC, 1u, 3u + 9u, 1u, 5u, BUS_Q, 5u, 0u, 1u, 2u, 3u, 4u};
     return t;
@@ -216,6 +230,14 @@ const std::vector<uint32_t>& roots_interactions() {       // receive (main count
     static const std::vector<uint32_t> t{LOOKUP_MAGIC, 2u, 3u + 2u * 9u,
                                          1u, ROOTS_PRE, BUS_R0, 5u, 0u, 1u, 2u, 3u, 4u,
                                          1u, ROOTS_PRE, BUS_R1, 5u, 0u, 5u, 6u, 7u, 8u};
+    return t;
+}
+
+const std::vector<uint32_t>& roots_interactions_transcript() {   // ... and the challenges with the preprocessed multiplicity 1 (column 13)
+    static const std::vector<uint32_t> t{LOOKUP_MAGIC, 3u, 3u + 3u * 9u,
+                                         1u, ROOTS_PRE_T, BUS_R0, 5u, 0u, 1u, 2u, 3u, 4u,
+                                         1u, ROOTS_PRE_T, BUS_R1, 5u, 0u, 5u, 6u, 7u, 8u,
+                                         1u, 13u, BUS_B, 5u, 0u, 9u, 10u, 11u, 12u};
     return t;
 }
 
@@ -499,7 +521,10 @@ int zkhip_verify_fri_queries(const uint8_t* proof, size_t len, int layers, size_
 // commitments layer by layer and folds, under the public challenges, to the public final value."  The key no longer holds any FRI
 // layer VALUE: a verifier needs the layer roots from the inner proof and its own reduced openings.
 namespace zk {
-namespace p2chip { std::shared_ptr<const std::vector<uint32_t>> program_fri_layers(uint32_t n_public); }
+namespace p2chip {
+std::shared_ptr<const std::vector<uint32_t>> program_fri_layers(uint32_t n_public);
+std::shared_ptr<const std::vector<uint32_t>> program_fri_transcript(uint32_t n_public, uint32_t cap_pub);
+}
 namespace frichip {
 namespace {
 struct WiredMachine {
@@ -509,19 +534,26 @@ struct WiredMachine {
     std::vector<uint32_t> fri_tab;
 };
 inline int log2_ceil(size_t n, int lo) { int l = lo; while (((size_t)1 << l) < n) l++; return l; }
-inline size_t p2_rows(int layers, size_t nq) { return nq * ((size_t)layers + (size_t)layers * ((size_t)layers + 1) / 2); }
-void wired_machine(int layers, size_t nq, WiredMachine& m) {
-    m.p[0] = p2chip::program_fri_layers(n_public_of(layers));
-    m.p[1] = program(layers, true);
-    m.p[2] = table_program(layers, QUERIES_PRE);
-    m.p[3] = table_program(layers, ROOTS_PRE);
+inline size_t p2_rows(int layers, size_t nq, bool transcript = false) {
+    return nq * ((size_t)layers + (size_t)layers * ((size_t)layers + 1) / 2) + (transcript ? (size_t)layers : 0);
+}
+// transcript: the TRANSCRIPT machine (zkhip_prove_fri_transcript) -- the same four chips, the Poseidon2 chip in its transcript variant
+// (its trace starts with a sponge chain over the layer roots), the ROOTS table with the challenges beside the roots, eight more public
+// values (the challenger's capacity).  Statement added: "the challenges are the ones the transcript derives from these roots".
+void wired_machine(int layers, size_t nq, WiredMachine& m, bool transcript = false) {
+    const uint32_t NP = n_public_of(layers, transcript), RP = transcript ? ROOTS_PRE_T : ROOTS_PRE;
+    m.p[0] = transcript ? p2chip::program_fri_transcript(NP, n_public_of(layers)) : p2chip::program_fri_layers(NP);
+    m.p[1] = program(layers, true, transcript);
+    m.p[2] = table_program(layers, QUERIES_PRE, transcript);
+    m.p[3] = table_program(layers, RP, transcript);
     m.fri_tab = fri_interactions_wired(layers);
-    m.log_ns[0] = log2_ceil(p2_rows(layers, nq), 5); m.log_ns[1] = log2_ceil(nq * (size_t)layers, 5);
+    m.log_ns[0] = log2_ceil(p2_rows(layers, nq, transcript), 5); m.log_ns[1] = log2_ceil(nq * (size_t)layers, 5);
     m.log_ns[2] = log2_ceil(nq, 5); m.log_ns[3] = log2_ceil((size_t)layers, 5);
     if (m.log_ns[3] > m.log_ns[2]) m.log_ns[2] = m.log_ns[3];                // tallest first also for few queries
-    m.widths[0] = p2chip::WIDTH; m.widths[1] = width_of(layers, true); m.widths[2] = 4; m.widths[3] = 4;
-    m.pre_widths[0] = 0; m.pre_widths[1] = 0; m.pre_widths[2] = QUERIES_PRE; m.pre_widths[3] = ROOTS_PRE;
-    const std::vector<uint32_t>* tabs[4] = {&p2_interactions(), &m.fri_tab, &queries_interactions(), &roots_interactions()};
+    m.widths[0] = transcript ? p2chip::WIDTH_T : p2chip::WIDTH; m.widths[1] = width_of(layers, true); m.widths[2] = 4; m.widths[3] = 4;
+    m.pre_widths[0] = 0; m.pre_widths[1] = 0; m.pre_widths[2] = QUERIES_PRE; m.pre_widths[3] = RP;
+    const std::vector<uint32_t>* tabs[4] = {transcript ? &p2_interactions_transcript() : &p2_interactions(), &m.fri_tab, &queries_interactions(),
+                                            transcript ? &roots_interactions_transcript() : &roots_interactions()};
     for (int c = 0; c < 4; c++) { m.progs[c] = m.p[c]->data(); m.prog_words[c] = m.p[c]->size(); m.tabs[c] = tabs[c]->data(); m.tab_words[c] = tabs[c]->size(); }
 }
 }  // namespace
@@ -544,16 +576,20 @@ size_t zkhip_p2chip_air_fri_layers(int layers, uint32_t* program, size_t cap_wor
 }
 
 // the key: QUERIES (index, reduced opening, 1) and ROOTS (layer, root) committed by zkhip_machine_setup
-int zkhip_fri_layers_key(zkhip_ctx* ctx, int layers, size_t n_queries, const uint32_t* indices, const uint32_t* values, const uint32_t* roots,
-                         const zkhip_params* prm, zkhip_machine_key** key, uint32_t vk[8]) {
+// betas != NULL: the key of the TRANSCRIPT machine (the ROOTS table carries the challenges beside the roots)
+static int fri_layers_key_impl(zkhip_ctx* ctx, int layers, size_t n_queries, const uint32_t* indices, const uint32_t* values, const uint32_t* roots,
+                               const uint32_t* betas, const zkhip_params* prm, zkhip_machine_key** key, uint32_t vk[8]) {
     CHECK_CTX(ctx);
     if (!indices || !values || !roots || !prm || !key || !vk) return fail(ZKHIP_ERR_INVALID, "fri_layers_key: null argument");
     int lr;
     ZK_TRY(frichip::shape_ok(layers, n_queries, &lr));
-    if (!frichip::canonical(values, 4 * n_queries) || !frichip::canonical(roots, 8 * (size_t)layers)) return fail(ZKHIP_ERR_INVALID, "fri_layers_key: values must be canonical");
+    if (!frichip::canonical(values, 4 * n_queries) || !frichip::canonical(roots, 8 * (size_t)layers) || (betas && !frichip::canonical(betas, 4 * (size_t)layers)))
+        return fail(ZKHIP_ERR_INVALID, "fri_layers_key: values must be canonical");
+    const bool T = betas != nullptr;
+    const uint32_t RP = T ? frichip::ROOTS_PRE_T : frichip::ROOTS_PRE;
     frichip::WiredMachine m;
-    frichip::wired_machine(layers, n_queries, m);
-    std::vector<uint32_t> qt(((size_t)frichip::QUERIES_PRE) << m.log_ns[2], 0u), rt(((size_t)frichip::ROOTS_PRE) << m.log_ns[3], 0u);
+    frichip::wired_machine(layers, n_queries, m, T);
+    std::vector<uint32_t> qt(((size_t)frichip::QUERIES_PRE) << m.log_ns[2], 0u), rt(((size_t)RP) << m.log_ns[3], 0u);
     for (size_t q = 0; q < n_queries; q++) {
         if (indices[q] >> (layers + 1)) return fail(ZKHIP_ERR_INVALID, "fri_layers_key: a query index has more than layers + 1 bits");
         uint32_t* r = qt.data() + frichip::QUERIES_PRE * q;
@@ -562,9 +598,10 @@ int zkhip_fri_layers_key(zkhip_ctx* ctx, int layers, size_t n_queries, const uin
         r[5] = MONTY_R1;
     }
     for (int l = 0; l < layers; l++) {
-        uint32_t* r = rt.data() + frichip::ROOTS_PRE * (size_t)l;
+        uint32_t* r = rt.data() + RP * (size_t)l;
         r[0] = to_monty((uint32_t)l);
         for (int i = 0; i < 8; i++) r[1 + i] = to_monty(roots[8 * l + i]);
+        if (T) { for (int i = 0; i < 4; i++) r[9 + i] = to_monty(betas[4 * l + i]); r[13] = MONTY_R1; }
     }
     void *dq, *dr;
     ZK_TRY(ctx_reserve(ctx, S_REC_C, qt.size() * 4, &dq));
@@ -577,30 +614,59 @@ int zkhip_fri_layers_key(zkhip_ctx* ctx, int layers, size_t n_queries, const uin
     pre[2].d_trace = (const uint32_t*)dq; pre[3].d_trace = (const uint32_t*)dr;
     return zkhip_machine_setup(ctx, pre, 4, prm, key, vk);
 }
+int zkhip_fri_layers_key(zkhip_ctx* ctx, int layers, size_t n_queries, const uint32_t* indices, const uint32_t* values, const uint32_t* roots,
+                         const zkhip_params* prm, zkhip_machine_key** key, uint32_t vk[8]) {
+    return fri_layers_key_impl(ctx, layers, n_queries, indices, values, roots, nullptr, prm, key, vk);
+}
+int zkhip_fri_transcript_key(zkhip_ctx* ctx, int layers, size_t n_queries, const uint32_t* indices, const uint32_t* values, const uint32_t* roots,
+                             const uint32_t* betas, const zkhip_params* prm, zkhip_machine_key** key, uint32_t vk[8]) {
+    if (!betas) return fail(ZKHIP_ERR_INVALID, "fri_transcript_key: null argument");
+    return fri_layers_key_impl(ctx, layers, n_queries, indices, values, roots, betas, prm, key, vk);
+}
 
-size_t zkhip_fri_layers_proof_size(int layers, size_t n_queries, const zkhip_params* prm) {
+static size_t fri_layers_proof_size_impl(int layers, size_t n_queries, const zkhip_params* prm, bool transcript) {
     int lr;
     if (!prm || frichip::shape_ok(layers, n_queries, &lr) != ZKHIP_OK) return 0;
     frichip::WiredMachine m;
-    frichip::wired_machine(layers, n_queries, m);
-    return zkhip_machine_proof_size_keyed(m.log_ns, m.widths, m.pre_widths, m.progs, m.prog_words, m.tabs, m.tab_words, 4, prm, frichip::n_public_of(layers));
+    frichip::wired_machine(layers, n_queries, m, transcript);
+    return zkhip_machine_proof_size_keyed(m.log_ns, m.widths, m.pre_widths, m.progs, m.prog_words, m.tabs, m.tab_words, 4, prm, frichip::n_public_of(layers, transcript));
+}
+size_t zkhip_fri_layers_proof_size(int layers, size_t n_queries, const zkhip_params* prm) { return fri_layers_proof_size_impl(layers, n_queries, prm, false); }
+size_t zkhip_fri_transcript_proof_size(int layers, size_t n_queries, const zkhip_params* prm) { return fri_layers_proof_size_impl(layers, n_queries, prm, true); }
+// the transcript machine's two chip programs (the tables' are one identity each)
+size_t zkhip_fri_transcript_chip_air(int layers, uint32_t* program, size_t cap_words) {
+    if (layers < frichip::MIN_LAYERS || layers > frichip::MAX_LAYERS) return 0;
+    const auto p = frichip::program(layers, true, true);
+    if (program && cap_words >= p->size()) std::memcpy(program, p->data(), p->size() * 4);
+    return p->size();
+}
+size_t zkhip_p2chip_air_fri_transcript(int layers, uint32_t* program, size_t cap_words) {
+    if (layers < frichip::MIN_LAYERS || layers > frichip::MAX_LAYERS) return 0;
+    const auto p = p2chip::program_fri_transcript(frichip::n_public_of(layers, true), frichip::n_public_of(layers));
+    if (program && cap_words >= p->size()) std::memcpy(program, p->data(), p->size() * 4);
+    return p->size();
 }
 
 // the Poseidon2 chip's trace for the layer paths of a view, generated on the device (d_trace: [2^log_rows][360], Montgomery)
-int zkhip_fri_layers_gen_paths_trace(zkhip_ctx* ctx, int layers, size_t n_queries, const uint32_t* betas, const uint32_t* indices, const uint32_t* values,
-                                     const uint32_t* siblings, const uint32_t* roots, const uint32_t* paths, int log_rows, uint32_t* d_trace, size_t ld) {
+// capacity != NULL: the transcript variant -- rows 0 .. layers - 1 are the sponge chain over `roots` from `capacity` (ld >= 364), and the
+// chain must produce `betas`
+static int fri_layers_gen_paths_trace_impl(zkhip_ctx* ctx, int layers, size_t n_queries, const uint32_t* betas, const uint32_t* indices, const uint32_t* values,
+                                           const uint32_t* siblings, const uint32_t* roots, const uint32_t* paths, const uint32_t* capacity, int log_rows,
+                                           uint32_t* d_trace, size_t ld) {
     CHECK_CTX(ctx);
     int lr;
     ZK_TRY(frichip::shape_ok(layers, n_queries, &lr));
-    if (!betas || !indices || !values || !siblings || !roots || !paths || !d_trace || ld < p2chip::WIDTH) return fail(ZKHIP_ERR_INVALID, "fri_layers_gen_paths_trace: bad arguments");
-    const size_t R = (size_t)layers, np = n_queries * R, used = frichip::p2_rows(layers, n_queries), per_q = 4 * R * (R + 1);
+    const bool T = capacity != nullptr;
+    if (!betas || !indices || !values || !siblings || !roots || !paths || !d_trace || ld < (T ? p2chip::WIDTH_T : p2chip::WIDTH)) return fail(ZKHIP_ERR_INVALID, "fri_layers_gen_paths_trace: bad arguments");
+    if (T && (!frichip::canonical(capacity, 8) || !frichip::canonical(roots, 8 * (size_t)layers))) return fail(ZKHIP_ERR_INVALID, "fri_transcript: values must be canonical");
+    const size_t R = (size_t)layers, np = n_queries * R, used = frichip::p2_rows(layers, n_queries, T), per_q = 4 * R * (R + 1);
     if (log_rows > MAX_LOG_ROWS || ((size_t)1 << log_rows) < used) return fail(ZKHIP_ERR_INVALID, "fri_layers_gen_paths_trace: 2^log_rows rows do not hold the paths");
     if (!frichip::canonical(betas, 4 * R) || !frichip::canonical(values, 4 * n_queries) || !frichip::canonical(siblings, 4 * np) || !frichip::canonical(paths, per_q * n_queries))
         return fail(ZKHIP_ERR_INVALID, "fri_layers_gen_paths_trace: values must be canonical");
     // the pairs of every (query, layer): fold the chain on the host (canonical words), as build_openings does
     std::vector<uint32_t> leaves(8 * np), sib_off(np), idx(np), depths(np), lay(np), mults(np, 1u), starts(np);
     const int H = layers + 1;
-    size_t row = 0;
+    size_t row = T ? R : 0;                              // the paths lie behind the transcript rows
     for (size_t q = 0; q < n_queries; q++) {
         uint32_t i = indices[q];
         if (i >> H) return fail(ZKHIP_ERR_INVALID, "fri_layers_gen_paths_trace: a query index has more than layers + 1 bits");
@@ -623,9 +689,14 @@ int zkhip_fri_layers_gen_paths_trace(zkhip_ctx* ctx, int layers, size_t n_querie
     }
     const size_t np8 = 8 * np, npaths_words = per_q * n_queries;
     void* stage;
-    ZK_TRY(ctx_reserve(ctx, S_STAGE, (np8 + npaths_words + 6 * np + np8) * 4, &stage));
+    ZK_TRY(ctx_reserve(ctx, S_STAGE, (np8 + npaths_words + 6 * np + np8 + 8 + 12 * R) * 4, &stage));
     uint32_t* d = (uint32_t*)stage;
     uint32_t *d_leaves = d, *d_sibs = d + np8, *d_meta = d_sibs + npaths_words, *d_roots = d_meta + 6 * np;
+    uint32_t *d_cap = d_roots + np8, *d_lroots = d_cap + 8, *d_betas = d_lroots + 8 * R;
+    if (T) {
+        ZK_HIP(hipMemcpyAsync(d_cap, capacity, 32, hipMemcpyHostToDevice, ctx->stream));
+        ZK_HIP(hipMemcpyAsync(d_lroots, roots, 32 * R, hipMemcpyHostToDevice, ctx->stream));
+    }
     ZK_HIP(hipMemcpyAsync(d_leaves, leaves.data(), np8 * 4, hipMemcpyHostToDevice, ctx->stream));
     ZK_HIP(hipMemcpyAsync(d_sibs, paths, npaths_words * 4, hipMemcpyHostToDevice, ctx->stream));
     const std::vector<uint32_t>* meta[6] = {&sib_off, &idx, &depths, &lay, &mults, &starts};
@@ -634,63 +705,95 @@ int zkhip_fri_layers_gen_paths_trace(zkhip_ctx* ctx, int layers, size_t n_querie
     a.leaves = d_leaves; a.siblings = d_sibs; a.sib_off = d_meta; a.indices = d_meta + np; a.depths = d_meta + 2 * np; a.layers = d_meta + 3 * np;
     a.mults = d_meta + 4 * np; a.starts = d_meta + 5 * np; a.n_paths = np; a.rows = (uint64_t)1 << log_rows; a.used_rows = used;
     a.trace = d_trace; a.ld = ld; a.roots = d_roots;
+    if (T) { a.n_transcript = (uint32_t)layers; a.capacity = d_cap; a.layer_roots = d_lroots; a.betas = d_betas; }
     ZK_HIP(launch_p2chip_layer_paths(a, ctx->stream));
-    std::vector<uint32_t> got(np8);
+    std::vector<uint32_t> got(np8), chain(4 * R);
     ZK_HIP(hipMemcpyAsync(got.data(), d_roots, np8 * 4, hipMemcpyDeviceToHost, ctx->stream));
+    if (T) ZK_HIP(hipMemcpyAsync(chain.data(), d_betas, 16 * R, hipMemcpyDeviceToHost, ctx->stream));
     ZK_HIP(hipStreamSynchronize(ctx->stream));
+    if (T && std::memcmp(chain.data(), betas, 16 * R) != 0)
+        return fail(ZKHIP_ERR_INVALID, "fri_transcript: the challenges are not the ones the transcript derives from these roots and this capacity");
     for (size_t p = 0; p < np; p++)
         if (std::memcmp(got.data() + 8 * p, roots + 8 * (p % R), 32) != 0)
             return fail(ZKHIP_ERR_INVALID, "fri_layers: the path of query " + std::to_string(p / R) + ", layer " + std::to_string(p % R) + " does not end in the layer's root");
     return ZKHIP_OK;
 }
+int zkhip_fri_layers_gen_paths_trace(zkhip_ctx* ctx, int layers, size_t n_queries, const uint32_t* betas, const uint32_t* indices, const uint32_t* values,
+                                     const uint32_t* siblings, const uint32_t* roots, const uint32_t* paths, int log_rows, uint32_t* d_trace, size_t ld) {
+    return fri_layers_gen_paths_trace_impl(ctx, layers, n_queries, betas, indices, values, siblings, roots, paths, nullptr, log_rows, d_trace, ld);
+}
 
-int zkhip_prove_fri_layers(zkhip_ctx* ctx, const zkhip_machine_key* key, int layers, size_t n_queries, const uint32_t* betas, const uint32_t* indices,
-                           const uint32_t* values, const uint32_t* siblings, const uint32_t* roots, const uint32_t* paths, const zkhip_params* prm,
-                           uint8_t* proof, size_t cap, size_t* len) {
+static int prove_fri_layers_impl(zkhip_ctx* ctx, const zkhip_machine_key* key, int layers, size_t n_queries, const uint32_t* betas, const uint32_t* indices,
+                                 const uint32_t* values, const uint32_t* siblings, const uint32_t* roots, const uint32_t* paths, const uint32_t* capacity,
+                                 const zkhip_params* prm, uint8_t* proof, size_t cap, size_t* len) {
     CHECK_CTX(ctx);
     if (!key || !prm || !proof || !len) return fail(ZKHIP_ERR_INVALID, "prove_fri_layers: null argument");
     int lr;
     ZK_TRY(frichip::shape_ok(layers, n_queries, &lr));
+    const bool T = capacity != nullptr;
     frichip::WiredMachine m;
-    frichip::wired_machine(layers, n_queries, m);
+    frichip::wired_machine(layers, n_queries, m, T);
     void *t_p2, *t_fri, *t_q, *t_r;
     ZK_TRY(ctx_reserve(ctx, S_REC_A, ((size_t)m.widths[0] << m.log_ns[0]) * 4, &t_p2));
     ZK_TRY(ctx_reserve(ctx, S_REC_B, ((size_t)m.widths[1] << m.log_ns[1]) * 4, &t_fri));
     ZK_TRY(ctx_reserve(ctx, S_CHIP, ((size_t)4 << m.log_ns[2]) * 4, &t_q));
     ZK_TRY(ctx_reserve(ctx, S_CHIP_B, ((size_t)4 << m.log_ns[3]) * 4, &t_r));
-    ZK_TRY(zkhip_fri_layers_gen_paths_trace(ctx, layers, n_queries, betas, indices, values, siblings, roots, paths, m.log_ns[0], (uint32_t*)t_p2, m.widths[0]));
+    ZK_TRY(fri_layers_gen_paths_trace_impl(ctx, layers, n_queries, betas, indices, values, siblings, roots, paths, capacity, m.log_ns[0], (uint32_t*)t_p2, m.widths[0]));
     std::vector<uint32_t> finals(4 * n_queries);
     ZK_TRY(fri_gen_trace(ctx, layers, n_queries, betas, indices, values, siblings, m.log_ns[1], (uint32_t*)t_fri, m.widths[1], finals.data(), true));
     for (size_t q = 1; q < n_queries; q++)
         if (std::memcmp(finals.data(), finals.data() + 4 * q, 16) != 0) return fail(ZKHIP_ERR_INVALID, "prove_fri_layers: the chains do not end in one value");
     // main columns of the tables: QUERIES none (zeros), ROOTS the number of paths per layer
     std::vector<uint32_t> rmain((size_t)4 << m.log_ns[3], 0u);
-    for (int l = 0; l < layers; l++) rmain[4 * (size_t)l] = to_monty((uint32_t)n_queries);
+    for (int l = 0; l < layers; l++) rmain[4 * (size_t)l] = to_monty((uint32_t)n_queries + (T ? 1u : 0u));     // the paths, and the transcript row that absorbs the root
     ZK_HIP(hipMemsetAsync(t_q, 0, ((size_t)4 << m.log_ns[2]) * 4, ctx->stream));
     ZK_HIP(hipMemcpyAsync(t_r, rmain.data(), rmain.size() * 4, hipMemcpyHostToDevice, ctx->stream));
     ZK_HIP(hipStreamSynchronize(ctx->stream));
-    std::vector<uint32_t> pv(frichip::n_public_of(layers));
+    std::vector<uint32_t> pv(frichip::n_public_of(layers, T));
     std::memcpy(pv.data(), betas, 16 * (size_t)layers);
     std::memcpy(pv.data() + 4 * (size_t)layers, finals.data(), 16);
+    if (T) std::memcpy(pv.data() + 4 * (size_t)layers + 4, capacity, 32);
     zkhip_chip chips[4]{};
     void* tr[4] = {t_p2, t_fri, t_q, t_r};
     for (int c = 0; c < 4; c++) { chips[c].d_trace = (const uint32_t*)tr[c]; chips[c].ld = m.widths[c]; chips[c].log_n = m.log_ns[c]; chips[c].width = m.widths[c]; chips[c].partner = -1; }
     return zkhip_prove_machine_keyed(ctx, key, chips, m.progs, m.prog_words, m.tabs, m.tab_words, 4, pv.data(), pv.size(), prm, proof, cap, len);
 }
+int zkhip_prove_fri_layers(zkhip_ctx* ctx, const zkhip_machine_key* key, int layers, size_t n_queries, const uint32_t* betas, const uint32_t* indices,
+                           const uint32_t* values, const uint32_t* siblings, const uint32_t* roots, const uint32_t* paths, const zkhip_params* prm,
+                           uint8_t* proof, size_t cap, size_t* len) {
+    return prove_fri_layers_impl(ctx, key, layers, n_queries, betas, indices, values, siblings, roots, paths, nullptr, prm, proof, cap, len);
+}
+int zkhip_prove_fri_transcript(zkhip_ctx* ctx, const zkhip_machine_key* key, int layers, size_t n_queries, const uint32_t* betas, const uint32_t* indices,
+                               const uint32_t* values, const uint32_t* siblings, const uint32_t* roots, const uint32_t* paths, const uint32_t capacity[8],
+                               const zkhip_params* prm, uint8_t* proof, size_t cap, size_t* len) {
+    if (!capacity) return fail(ZKHIP_ERR_INVALID, "prove_fri_transcript: null argument");
+    return prove_fri_layers_impl(ctx, key, layers, n_queries, betas, indices, values, siblings, roots, paths, capacity, prm, proof, cap, len);
+}
 
-int zkhip_verify_fri_layers(const uint8_t* proof, size_t len, int layers, size_t n_queries, const uint32_t* betas, const uint32_t final_value[4],
-                            const uint32_t vk[8], const zkhip_params* prm, int* reason) {
+static int verify_fri_layers_impl(const uint8_t* proof, size_t len, int layers, size_t n_queries, const uint32_t* betas, const uint32_t final_value[4],
+                                  const uint32_t* capacity, const uint32_t vk[8], const zkhip_params* prm, int* reason) {
     int lr;
     if (!proof || !betas || !final_value || !vk || !prm || frichip::shape_ok(layers, n_queries, &lr) != ZKHIP_OK) {
         if (reason) *reason = 1;
         return fail(ZKHIP_ERR_VERIFY, "verify_fri_layers: bad arguments");
     }
-    std::vector<uint32_t> pv(frichip::n_public_of(layers));
+    const bool T = capacity != nullptr;
+    std::vector<uint32_t> pv(frichip::n_public_of(layers, T));
     std::memcpy(pv.data(), betas, 16 * (size_t)layers);
     std::memcpy(pv.data() + 4 * (size_t)layers, final_value, 16);
+    if (T) std::memcpy(pv.data() + 4 * (size_t)layers + 4, capacity, 32);
     frichip::WiredMachine m;
-    frichip::wired_machine(layers, n_queries, m);
+    frichip::wired_machine(layers, n_queries, m, T);
     return zkhip_verify_machine_keyed(proof, len, m.log_ns, m.widths, m.pre_widths, vk, m.progs, m.prog_words, m.tabs, m.tab_words, 4, pv.data(), pv.size(), prm, reason);
+}
+int zkhip_verify_fri_layers(const uint8_t* proof, size_t len, int layers, size_t n_queries, const uint32_t* betas, const uint32_t final_value[4],
+                            const uint32_t vk[8], const zkhip_params* prm, int* reason) {
+    return verify_fri_layers_impl(proof, len, layers, n_queries, betas, final_value, nullptr, vk, prm, reason);
+}
+int zkhip_verify_fri_transcript(const uint8_t* proof, size_t len, int layers, size_t n_queries, const uint32_t* betas, const uint32_t final_value[4],
+                                const uint32_t capacity[8], const uint32_t vk[8], const zkhip_params* prm, int* reason) {
+    if (!capacity) { if (reason) *reason = 1; return fail(ZKHIP_ERR_VERIFY, "verify_fri_transcript: bad arguments"); }
+    return verify_fri_layers_impl(proof, len, layers, n_queries, betas, final_value, capacity, vk, prm, reason);
 }
 
 }  // extern "C"

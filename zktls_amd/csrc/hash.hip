@@ -638,6 +638,24 @@ __global__ void __launch_bounds__(64) p2chip_merkle_kernel_batch(const p2chip_me
 __device__ __forceinline__ void p2chip_layer_paths_kernel_body(const p2chip::LayerPathsArgs& a) {
     using namespace p2chip;
     const uint64_t p = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    // transcript variant: four more columns per row (TRS and three unused); the one lane past the paths and the padding walks the sponge
+    // chain over the layer roots (a chain: <= 22 permutations one after the other)
+    const bool tv = a.n_transcript != 0;
+    auto tail = [&](uint32_t* t, uint32_t trs) { if (tv) { t[TRS] = trs; t[TRS + 1] = 0u; t[TRS + 2] = 0u; t[TRS + 3] = 0u; } };
+    if (tv && p == a.n_paths + (a.rows - a.used_rows)) {
+        uint32_t in[16], out[16];
+        for (int j = 0; j < 8; j++) in[8 + j] = to_monty(a.capacity[j]);
+        uint32_t* t = a.trace;
+        for (uint32_t l = 0; l < a.n_transcript; l++, t += a.ld) {
+            for (int j = 0; j < 8; j++) in[j] = to_monty(a.layer_roots[8 * l + j]);
+            p2chip_fill_row(t, in, 0u, 0u, 0u, 0u, l ? 1u : 0u, 0u, out);
+            t[LNP] = to_monty(l); t[KP] = 0u; t[M] = 0u;
+            tail(t, MONTY_R1);
+            for (int j = 0; j < 4; j++) a.betas[4 * l + j] = from_monty(out[7 - j]);
+            for (int j = 0; j < 8; j++) in[8 + j] = out[8 + j];
+        }
+        return;
+    }
     if (p < a.n_paths) {
         uint32_t out[16], in[16];
         uint32_t* t = a.trace + (uint64_t)a.starts[p] * a.ld;
@@ -645,6 +663,7 @@ __device__ __forceinline__ void p2chip_layer_paths_kernel_body(const p2chip::Lay
         for (int j = 0; j < 8; j++) { in[j] = to_monty(a.leaves[8 * p + j]); in[8 + j] = 0u; }
         p2chip_fill_row(t, in, 0u, 0u, 0u, (uint32_t)p, 0u, 1u, out);
         t[LNP] = layer; t[KP] = to_monty(2u * index); t[M] = to_monty(a.mults[p]);
+        tail(t, 0u);
         t += a.ld;
         const uint32_t* sib = a.siblings + a.sib_off[p];
         for (uint32_t lvl = 0; lvl < depth; lvl++, t += a.ld) {
@@ -653,6 +672,7 @@ __device__ __forceinline__ void p2chip_layer_paths_kernel_body(const p2chip::Lay
             const uint32_t end = lvl + 1 == depth ? 1u : 0u;
             p2chip_fill_row(t, in, bit, 1u, end, (uint32_t)p + end, 0u, 0u, out);
             t[LNP] = layer; t[KP] = to_monty(index >> lvl); t[M] = 0u;
+            tail(t, 0u);
         }
         for (int j = 0; j < 8; j++) a.roots[8 * p + j] = from_monty(out[j]);
         return;
@@ -663,13 +683,14 @@ __device__ __forceinline__ void p2chip_layer_paths_kernel_body(const p2chip::Lay
     uint32_t* t = a.trace + row * a.ld;
     p2chip_fill_row(t, zero, 0u, 0u, 0u, (uint32_t)a.n_paths, 0u, 0u, out);
     t[LNP] = 0u; t[KP] = 0u; t[M] = 0u;
+    tail(t, 0u);
 }
 __global__ void __launch_bounds__(64) p2chip_layer_paths_kernel(p2chip::LayerPathsArgs a) { p2chip_layer_paths_kernel_body(a); }
 struct p2chip_layer_paths_kernel_bargs { p2chip::LayerPathsArgs a; static p2chip_layer_paths_kernel_bargs make(p2chip::LayerPathsArgs a) { return p2chip_layer_paths_kernel_bargs{a}; } };
 __global__ void __launch_bounds__(64) p2chip_layer_paths_kernel_batch(const p2chip_layer_paths_kernel_bargs* __restrict__ zk_arr) { const p2chip_layer_paths_kernel_bargs& zk_b = zk_arr[blockIdx.z]; p2chip_layer_paths_kernel_body(zk_b.a); }
 
 hipError_t launch_p2chip_layer_paths(const p2chip::LayerPathsArgs& a, hipStream_t s) {
-    const uint64_t lanes = a.n_paths + (a.rows - a.used_rows);
+    const uint64_t lanes = a.n_paths + (a.rows - a.used_rows) + (a.n_transcript ? 1u : 0u);
     ZK_LAUNCH(p2chip_layer_paths_kernel, p2chip_layer_paths_kernel_batch, p2chip_layer_paths_kernel_bargs, dim3((unsigned)((lanes + 63) / 64)), dim3(64), 0, s, a);
     return hipGetLastError();
 }

@@ -22,6 +22,11 @@ constexpr uint32_t ext_input(uint32_t r) { return r == 0 ? S0 : (r == 4 ? SP : o
 // paths of DIFFERENT depths end in different roots: an END row sends (LNP, digest) to a preprocessed table of layer roots instead
 // of comparing with one public root.  Public values: those of the machine it sits in (none of its own).
 constexpr uint32_t LNP = 357, KP = 358, M = 359;
+// The transcript variant of that variant (one more flag column, 364 columns): the trace STARTS with transcript rows -- TRS = 1,
+// LNP = 0, 1, 2, ... -- a sponge chain over the FRI layer roots: row l absorbs root_l into the rate half (and sends it to the ROOTS
+// table like a path's digest), keeps the capacity of row l - 1 (row 0: eight public values, the duplex challenger's capacity as the
+// commit phase finds it) and sends (l, out[7], out[6], out[5], out[4]) = the challenge beta_l on a bus of its own.
+constexpr uint32_t TRS = 360, WIDTH_T = 364;
 // variable-depth paths, one leaf row (the sponge over 8 values) + depth compression rows each; path p starts at row start[p]
 struct LayerPathsArgs {
     const uint32_t* leaves;      // [n_paths][8] the opened pairs, canonical
@@ -35,6 +40,11 @@ struct LayerPathsArgs {
     uint64_t n_paths, rows, used_rows;
     uint32_t* trace; uint64_t ld;   // [rows][ld], Montgomery
     uint32_t* roots;             // [n_paths][8], canonical
+    // transcript variant (n_transcript > 0: rows 0 .. n_transcript - 1, the paths' starts lie behind them; ld >= WIDTH_T)
+    uint32_t n_transcript;       // layers
+    const uint32_t* capacity;    // [8] canonical
+    const uint32_t* layer_roots; // [n_transcript][8] canonical
+    uint32_t* betas;             // out [n_transcript][4] canonical: what the chain produces
 };
 
 // paths: path p = rows [p (row_width / 8 + depth), ...): row_width / 8 sponge rows over its opened row (none when row_width = 0: the

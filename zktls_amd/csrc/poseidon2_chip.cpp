@@ -69,7 +69,7 @@ Terms linear_def(uint32_t col, const Form& f) {
     return t;
 }
 
-std::vector<uint32_t> build_program(bool fri_layers = false, uint32_t n_public = N_PUBLIC) {
+std::vector<uint32_t> build_program(bool fri_layers = false, uint32_t n_public = N_PUBLIC, int transcript = -1) {
     // the matrices and constants of the tables in effect, canonical
     uint32_t ME[16][16], rc_e[8][16], rc_i[13], diag[16];
     for (int j = 0; j < 16; j++) {
@@ -148,7 +148,18 @@ std::vector<uint32_t> build_program(bool fri_layers = false, uint32_t n_public =
         b.add(ALL, Terms{{1u, {var(END), var(KP)}}, {P - 1, {var(END), var(BIT)}}});                           // exactly depth bits
         b.add(ALL, Terms{{1u, {var(M)}}, {P - 1, {var(M), var(SS)}}});                                         // tuples are received on leaf rows only
     }
-    std::vector<uint32_t> p{AIR_MAGIC, 1u, WIDTH, b.count, n_public, (uint32_t)(6 + b.body.size())};
+    if (transcript >= 0) {                                  // the transcript variant (p2chip.h): public values transcript .. transcript + 7 = the capacity
+        b.add(ALL, Terms{{1u, {var(TRS), var(TRS)}}, {P - 1, {var(TRS)}}});
+        b.add(FIRST, Terms{{1u, {var(TRS)}}, {P - 1, {}}});                                                    // the trace starts with the transcript
+        b.add(FIRST, Terms{{1u, {var(LNP)}}});
+        for (uint32_t j = 0; j < 8; j++) b.add(FIRST, Terms{{1u, {var(IN + 8 + j)}}, {P - 1, {pub((uint32_t)transcript + j)}}});
+        b.add(TRANSITION, Terms{{1u, {var(TRS, true)}}, {P - 1, {var(TRS), var(TRS, true)}}});                 // transcript rows are a prefix
+        b.add(TRANSITION, Terms{{1u, {var(TRS, true), var(LNP, true)}}, {P - 1, {var(TRS, true), var(LNP)}}, {P - 1, {var(TRS, true)}}});
+        b.add(TRANSITION, Terms{{1u, {var(TRS, true)}}, {P - 1, {var(TRS, true), var(SPG, true)}}});           // ... chained through the capacity
+        b.add(ALL, Terms{{1u, {var(SPG)}}, {P - 1, {var(SPG), var(TRS)}}});                                    // and nothing else is
+        for (uint32_t f : {CH, END, SS, BIT, M}) b.add(ALL, Terms{{1u, {var(TRS), var(f)}}});
+    }
+    std::vector<uint32_t> p{AIR_MAGIC, 1u, transcript >= 0 ? WIDTH_T : WIDTH, b.count, n_public, (uint32_t)(6 + b.body.size())};
     p.insert(p.end(), b.body.begin(), b.body.end());
     return p;
 }
@@ -175,6 +186,19 @@ std::shared_ptr<const std::vector<uint32_t>> program_fri_layers(uint32_t n_publi
     if (cached_gen != gen) { cache.clear(); cached_gen = gen; }
     auto it = cache.find(n_public);
     if (it == cache.end()) it = cache.emplace(n_public, std::make_shared<const std::vector<uint32_t>>(build_program(true, n_public))).first;
+    return it->second;
+}
+// ... and its transcript variant: the capacity = public values cap_pub .. cap_pub + 7 of n_public
+std::shared_ptr<const std::vector<uint32_t>> program_fri_transcript(uint32_t n_public, uint32_t cap_pub) {
+    static std::mutex mu;
+    static std::map<uint64_t, std::shared_ptr<const std::vector<uint32_t>>> cache;
+    static uint64_t cached_gen = ~0ull;
+    std::lock_guard<std::mutex> lk(mu);
+    const uint64_t gen = g_p2_generation.load();
+    if (cached_gen != gen) { cache.clear(); cached_gen = gen; }
+    const uint64_t key = ((uint64_t)n_public << 32) | cap_pub;
+    auto it = cache.find(key);
+    if (it == cache.end()) it = cache.emplace(key, std::make_shared<const std::vector<uint32_t>>(build_program(true, n_public, (int)cap_pub))).first;
     return it->second;
 }
 namespace {

@@ -593,6 +593,27 @@ class Context:
                                               buf.ctypes.data_as(u8p), size, C.byref(got)))
         return buf[: got.value]
 
+    def fri_transcript_key(self, view, params=None):
+        params = params or Params(1, 100, 16)
+        R, Q, betas, idx, vals, sibs, roots, paths = _fri_layers_arrays(view)
+        handle, root = C.c_void_p(), np.zeros(8, dtype=np.uint32)
+        check(self.lib.zkhip_fri_transcript_key(self.handle, R, Q, idx.ctypes.data_as(u32p), vals.ctypes.data_as(u32p), roots.ctypes.data_as(u32p),
+                                                betas.ctypes.data_as(u32p), C.byref(params), C.byref(handle), root.ctypes.data_as(u32p)))
+        return MachineKey(self, handle, root, [0, 0, 8, 16])
+
+    def prove_fri_transcript(self, key, view, capacity, params=None):
+        """zkhip_prove_fri_transcript: the wired machine with the FRI transcript in-circuit (capacity: zkhip_fri_view_transcript)"""
+        params = params or Params(1, 100, 16)
+        R, Q, betas, idx, vals, sibs, roots, paths = _fri_layers_arrays(view)
+        cap8 = np.ascontiguousarray(np.array(capacity, dtype=np.uint32))
+        size = self.lib.zkhip_fri_transcript_proof_size(R, Q, C.byref(params))
+        buf = np.empty(size, dtype=np.uint8)
+        got = C.c_size_t(0)
+        check(self.lib.zkhip_prove_fri_transcript(self.handle, key.handle, R, Q, betas.ctypes.data_as(u32p), idx.ctypes.data_as(u32p), vals.ctypes.data_as(u32p),
+                                                  sibs.ctypes.data_as(u32p), roots.ctypes.data_as(u32p), paths.ctypes.data_as(u32p), cap8.ctypes.data_as(u32p),
+                                                  C.byref(params), buf.ctypes.data_as(u8p), size, C.byref(got)))
+        return buf[: got.value]
+
     def prove_machine_keyed(self, key, chips, programs, tables, public_values=(), params=None, key_entries=None):
         """a machine with preprocessed columns (proof version 11): `key` from machine_setup; chips as in prove_machine (main columns);
         programs / tables address the combined row [preprocessed | main].  key_entries: per chip the key entry it uses (-1: none) when the
@@ -974,6 +995,32 @@ def fri_layers_programs(layers):
         assert n and f(layers, buf.ctypes.data_as(u32p), n) == n
         out.append(buf)
     return out
+
+
+def fri_transcript_programs(layers):
+    """-> (the Poseidon2 chip's transcript variant, the fold chip's wired form with the transcript machine's public values)"""
+    lib = _lib.load()
+    out = []
+    for f in (lib.zkhip_p2chip_air_fri_transcript, lib.zkhip_fri_transcript_chip_air):
+        n = f(layers, None, 0)
+        buf = np.zeros(n, dtype=np.uint32)
+        assert n and f(layers, buf.ctypes.data_as(u32p), n) == n
+        out.append(buf)
+    return out
+
+
+def verify_fri_transcript(proof, view_betas, final, capacity, n_queries, vk, params=None):
+    params = params or Params(1, 100, 16)
+    lib = _lib.load()
+    pr = np.ascontiguousarray(proof, dtype=np.uint8)
+    b = np.ascontiguousarray(np.array(view_betas, dtype=np.uint32).reshape(-1))
+    f = np.ascontiguousarray(np.array(final, dtype=np.uint32))
+    c8 = np.ascontiguousarray(np.array(capacity, dtype=np.uint32))
+    k = np.ascontiguousarray(np.array(vk, dtype=np.uint32))
+    reason = C.c_int(0)
+    rc = lib.zkhip_verify_fri_transcript(pr.ctypes.data_as(u8p), pr.size, b.size // 4, n_queries, b.ctypes.data_as(u32p), f.ctypes.data_as(u32p),
+                                         c8.ctypes.data_as(u32p), k.ctypes.data_as(u32p), C.byref(params), C.byref(reason))
+    return rc, reason.value
 
 
 def verify_fri_layers(proof, view_betas, final, n_queries, vk, params=None):
