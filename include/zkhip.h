@@ -690,23 +690,26 @@ int zkhip_prove_fri_layers(zkhip_ctx* ctx, const zkhip_machine_key* key, int lay
 int zkhip_verify_fri_layers(const uint8_t* proof, size_t len, int layers, size_t n_queries, const uint32_t* betas, const uint32_t final_value[4],
                             const uint32_t vk[8], const zkhip_params* prm, int* reason);
 /* The same machine with the FRI TRANSCRIPT in-circuit: the Poseidon2 chip's trace starts with transcript rows (zkhip_p2chip_air_fri_transcript,
- * 364 columns) -- a sponge chain over the layer roots from the duplex challenger's capacity (zkhip_fri_view_transcript; eight more public
- * values): row l absorbs root_l (sent to the ROOTS table like a path's end), keeps the capacity of row l - 1 and sends
- * (l, out[7], out[6], out[5], out[4]) on a bus of its own; the ROOTS table's preprocessed rows carry the challenges beside the roots and
- * receive those tuples once each.  Statement added to the one above: "... and the challenges are the ones the transcript derives from
- * these layer roots, starting from this challenger state."  Still outside: how that state came about (the transcript before the commit
- * phase), the query indices, the trace / quotient openings and the reduced openings.  Ref: p3-challenger DuplexChallenger
- * (reference Cargo.lock:3875) behind sp1.rs:116. */
+ * 364 columns) -- a sponge chain over the layer roots from the duplex challenger's capacity (zkhip_fri_view_transcript): row l absorbs
+ * root_l (sent to the ROOTS table like a path's end), keeps the capacity of row l - 1 (row 0: public) and sends
+ * (l, out[7], out[6], out[5], out[4]) on a bus of its own.  The ROOTS table holds the challenges in its MAIN columns (the prover's),
+ * receives each once from its transcript row and hands it to the layer's fold rows (zkhip_fri_transcript_chip_air: the fold chip without
+ * public challenges).  Public values: the final value and the capacity.  NEITHER THE KEY NOR THE VERIFIER HOLDS A CHALLENGE -- statement:
+ * "for the layer commitments and the (index, reduced opening) pairs in the key, every query's chain opens the commitments and folds to the
+ * public final value under the challenges the transcript derives from these commitments, starting from this challenger state."  The
+ * prover is still handed the view's challenges and refuses when its chain disagrees.  Still outside: how the challenger state came about
+ * (the transcript before the commit phase), the query indices, the trace / quotient openings and the reduced openings.  Ref: p3-challenger
+ * DuplexChallenger (reference Cargo.lock:3875) behind sp1.rs:116. */
 size_t zkhip_fri_transcript_chip_air(int layers, uint32_t* program, size_t cap_words);
 size_t zkhip_p2chip_air_fri_transcript(int layers, uint32_t* program, size_t cap_words);
 int zkhip_fri_transcript_key(zkhip_ctx* ctx, int layers, size_t n_queries, const uint32_t* indices, const uint32_t* values, const uint32_t* roots,
-                             const uint32_t* betas, const zkhip_params* prm, zkhip_machine_key** key, uint32_t vk[8]);
+                             const zkhip_params* prm, zkhip_machine_key** key, uint32_t vk[8]);
 size_t zkhip_fri_transcript_proof_size(int layers, size_t n_queries, const zkhip_params* prm);
 int zkhip_prove_fri_transcript(zkhip_ctx* ctx, const zkhip_machine_key* key, int layers, size_t n_queries, const uint32_t* betas, const uint32_t* indices,
                                const uint32_t* values, const uint32_t* siblings, const uint32_t* roots, const uint32_t* paths, const uint32_t capacity[8],
                                const zkhip_params* prm, uint8_t* proof, size_t cap, size_t* len);
-int zkhip_verify_fri_transcript(const uint8_t* proof, size_t len, int layers, size_t n_queries, const uint32_t* betas, const uint32_t final_value[4],
-                                const uint32_t capacity[8], const uint32_t vk[8], const zkhip_params* prm, int* reason);
+int zkhip_verify_fri_transcript(const uint8_t* proof, size_t len, int layers, size_t n_queries, const uint32_t final_value[4], const uint32_t capacity[8],
+                                const uint32_t vk[8], const zkhip_params* prm, int* reason);
 
 /* ---- Poseidon2 parameter tables from a file: the built-in sets are this repo's own
  * ("zktls-amd/p2-bb16-v1", "...-bb24-v1"; the SP1 / RISC Zero tables of reference Cargo.lock:4030, 6172, 5057 are not

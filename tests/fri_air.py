@@ -14,8 +14,9 @@ from pyref import P, bitrev, ext_mul, two_adic_generator
 V = O.air_var
 E0, E1, BIT, K, X, XI, S, T, B, BETA, FOLD, ACTIVE, LN, G, GS, GT, OWN, L = 0, 4, 8, 9, 10, 11, 12, 13, 14, 15, 19, 23, 24, 25, 26, 27, 28, 32
 BUS_E0, BUS_E1, BUS_R0, BUS_R1, BUS_Q = 40, 41, 42, 43, 44
-BUS_B = 45                                     # the transcript machine: (layer, beta) from the Poseidon2 chip's transcript rows to the ROOTS table
-ROOTS_PRE_T = 16                               # ... whose preprocessed row is then (layer, root[8], beta[4], 1, 0, 0)
+BUS_B, BUS_BF = 45, 46                         # the transcript machine: (layer, beta) from the Poseidon2 chip's transcript rows to the ROOTS table, and from there to the fold rows
+ROOTS_MAIN_T = 8                               # ... whose MAIN row is then (paths + 1, beta[4], queries, 0, 0); preprocessed (layer, root[8], 1, 0, 0)
+N_PUBLIC_T = 12                                # final value, the challenger's capacity
 K2, IDX, L_WIRED = 32, 33, 34                  # the wired form's extra columns, its layer selectors start two columns later
 QUERIES_PRE, ROOTS_PRE = 8, 12
 OPEN_PRE, OPEN_MAIN = 12, 4
@@ -36,7 +37,10 @@ def root_const(l):
     return two_adic_generator(l + 1)
 
 
-def program(layers, wired=False, n_public=None):
+def program(layers, wired=False, transcript=False):
+    """transcript: the fold chip of the TRANSCRIPT machine -- the challenges are no public values any more (the rows receive
+    (layer, beta) on a bus from the ROOTS table, which has them from the Poseidon2 chip's transcript rows); public values: the final
+    value, then the challenger's capacity (8 words, read by the Poseidon2 chip)"""
     R = layers
     L = L_WIRED if wired else globals()["L"]
     END = L + R - 1
@@ -54,8 +58,9 @@ def program(layers, wired=False, n_public=None):
     add(O.SEL_ALL, [(1, [V(BIT), V(BIT)]), (P - 1, [V(BIT)])])
     for l in range(R):
         add(O.SEL_ALL, [(1, [V(L + l), V(L + l)]), (P - 1, [V(L + l)])])
-    for j in range(4):
-        add(O.SEL_ALL, [(1, [V(BETA + j)])] + [(P - 1, [V(L + l), V(4 * l + j, public=True)]) for l in range(R)])
+    if not transcript:
+        for j in range(4):
+            add(O.SEL_ALL, [(1, [V(BETA + j)])] + [(P - 1, [V(L + l), V(4 * l + j, public=True)]) for l in range(R)])
     add(O.SEL_ALL, [(1, [V(G)]), (P - 1, [V(ACTIVE)]), (1, [V(END)])])
     add(O.SEL_ALL, [(1, [V(S)]), (P - 1, [V(X), V(X)])])
     add(O.SEL_ALL, [(1, [V(GS)]), (P - 1, [V(G), V(S)])])
@@ -85,11 +90,11 @@ def program(layers, wired=False, n_public=None):
     for j in range(4):
         add(O.SEL_TRANSITION, gated([(1, [V(FOLD + j)]), (P - 1, [V(OWN + j, True)])]))
     for j in range(4):
-        add(O.SEL_ALL, [(1, [V(END), V(FOLD + j)]), (P - 1, [V(END), V(4 * R + j, public=True)])])
+        add(O.SEL_ALL, [(1, [V(END), V(FOLD + j)]), (P - 1, [V(END), V((0 if transcript else 4 * R) + j, public=True)])])
     if wired:
         add(O.SEL_ALL, [(1, [V(K2)]), (P - 2, [V(K)])])
         add(O.SEL_ALL, [(1, [V(IDX)]), (P - 1, [V(K2)]), (P - 1, [V(BIT)])])
-    return O.air_program(width_of(R, wired), n_public_of(R) if n_public is None else n_public, cons)
+    return O.air_program(width_of(R, wired), N_PUBLIC_T if transcript else n_public_of(R), cons)
 
 
 def fold_pair(k, lh, beta, e0, e1):
@@ -218,7 +223,7 @@ def machine_layers(view, capacity=None):
     R, Q = len(betas), len(queries)
     H = R + 1
     T = capacity is not None
-    NP = n_public_of(R) + (8 if T else 0)
+    NP = N_PUBLIC_T if T else n_public_of(R)
 
     def lg(n, lo=5):
         l = lo
@@ -249,14 +254,14 @@ def machine_layers(view, capacity=None):
     qpre = np.zeros((1 << lr_q, QUERIES_PRE), dtype=np.uint32)
     for q, (index, value, _) in enumerate(queries):
         qpre[q, 0], qpre[q, 1:5], qpre[q, 5] = index, value, 1
-    RP = ROOTS_PRE_T if T else ROOTS_PRE
+    RP = ROOTS_PRE
     rpre = np.zeros((1 << lr_r, RP), dtype=np.uint32)
-    rmain = np.zeros((1 << lr_r, 4), dtype=np.uint32)
+    rmain = np.zeros((1 << lr_r, ROOTS_MAIN_T if T else 4), dtype=np.uint32)
     for l in range(R):
         rpre[l, 0], rpre[l, 1:9] = l, roots[l]
         rmain[l, 0] = Q + (1 if T else 0)              # the paths that end in the root, and the transcript row that absorbs it
-        if T:
-            rpre[l, 9:13], rpre[l, 13] = betas[l], 1
+        if T:                                          # the challenge is the PROVER's (main columns): the buses tie it to the transcript rows
+            rpre[l, 9], rmain[l, 1:5], rmain[l, 5] = 1, betas[l], Q
     o7 = P2.OUTE(7)
     p2_inter = [(O.RECEIVE, P2.M, BUS_E0, [P2.LNP, P2.KP, P2.IN, P2.IN + 1, P2.IN + 2, P2.IN + 3]),
                 (O.RECEIVE, P2.M, BUS_E1, [P2.LNP, P2.KP, P2.IN + 4, P2.IN + 5, P2.IN + 6, P2.IN + 7]),
@@ -267,18 +272,21 @@ def machine_layers(view, capacity=None):
                      (O.SEND, P2.TRS, BUS_R1, [P2.LNP, P2.IN + 4, P2.IN + 5, P2.IN + 6, P2.IN + 7]),
                      (O.SEND, P2.TRS, BUS_B, [P2.LNP, o7 + 7, o7 + 6, o7 + 5, o7 + 4])]
     p2_tab = O.interaction_table(p2_inter)
-    fri_tab = O.interaction_table([(O.SEND, ACTIVE, BUS_E0, [LN, K2, E0, E0 + 1, E0 + 2, E0 + 3]), (O.SEND, ACTIVE, BUS_E1, [LN, K2, E1, E1 + 1, E1 + 2, E1 + 3]),
-                                   (O.SEND, L_WIRED, BUS_Q, [IDX, OWN, OWN + 1, OWN + 2, OWN + 3])])
+    fri_inter = [(O.SEND, ACTIVE, BUS_E0, [LN, K2, E0, E0 + 1, E0 + 2, E0 + 3]), (O.SEND, ACTIVE, BUS_E1, [LN, K2, E1, E1 + 1, E1 + 2, E1 + 3]),
+                 (O.SEND, L_WIRED, BUS_Q, [IDX, OWN, OWN + 1, OWN + 2, OWN + 3])]
+    if T:
+        fri_inter.append((O.RECEIVE, ACTIVE, BUS_BF, [LN, BETA, BETA + 1, BETA + 2, BETA + 3]))
+    fri_tab = O.interaction_table(fri_inter)
     q_tab = O.interaction_table([(O.RECEIVE, 5, BUS_Q, [0, 1, 2, 3, 4])])
     r_inter = [(O.RECEIVE, RP, BUS_R0, [0, 1, 2, 3, 4]), (O.RECEIVE, RP, BUS_R1, [0, 5, 6, 7, 8])]
     if T:
-        r_inter.append((O.RECEIVE, 13, BUS_B, [0, 9, 10, 11, 12]))
+        r_inter += [(O.RECEIVE, 9, BUS_B, [0, RP + 1, RP + 2, RP + 3, RP + 4]), (O.SEND, RP + 5, BUS_BF, [0, RP + 1, RP + 2, RP + 3, RP + 4])]
     r_tab = O.interaction_table(r_inter)
 
-    def table_prog(pre_width):
-        return O.air_program(pre_width + 4, NP, [(O.SEL_FIRST, [(1, [V(pre_width + 3)])])])
-    pub = [c for b in betas for c in b] + list(final) + ([int(v) for v in capacity] if T else [])
+    def table_prog(pre_width, main_width=4):
+        return O.air_program(pre_width + main_width, NP, [(O.SEL_FIRST, [(1, [V(pre_width + main_width - 1)])])])
+    pub = (list(final) + [int(v) for v in capacity]) if T else ([c for b in betas for c in b] + list(final))
     return ([p2_trace, fri_trace, np.zeros((1 << lr_q, 4), dtype=np.uint32), rmain], [None, None, qpre, rpre],
-            [P2.program(fri_layers=True, n_public=NP, transcript=n_public_of(R) if T else None), program(R, wired=True, n_public=NP),
-             table_prog(QUERIES_PRE), table_prog(RP)],
+            [P2.program(fri_layers=True, n_public=NP, transcript=4 if T else None), program(R, wired=True, transcript=T),
+             table_prog(QUERIES_PRE), table_prog(RP, ROOTS_MAIN_T if T else 4)],
             [p2_tab, fri_tab, q_tab, r_tab], pub)

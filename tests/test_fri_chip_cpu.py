@@ -240,9 +240,9 @@ def test_wired_machine_of_a_golden_proofs_view(oracle, name, shape):
 @pytest.mark.parametrize("name,shape", [("v1_6x8", (1, 10, 4)), ("v1_10x16", (1, 8, 6))])
 def test_transcript_machine_of_a_golden_proofs_view(oracle, name, shape):
     """the wired machine whose Poseidon2 chip starts with transcript rows: a sponge chain over the layer roots, from the challenger's
-    capacity (8 more public values), whose outputs must be the challenges of the key.  Under the oracle's prover and three verifiers;
-    refused: a challenge in the key that the chain does not produce, another capacity, a root absorbed that is not the layer's, a
-    transcript row left out"""
+    capacity (public), whose outputs reach the fold rows through the ROOTS table's main columns: the challenges are neither public
+    values nor part of the key.  Under the oracle's prover and three verifiers; refused: a challenge the chain does not produce, fold
+    rows with another challenge, another capacity, other roots, a root absorbed that is not the layer's, a transcript row left out"""
     from zktls_amd.device import fri_view_shard_paths, fri_view_transcript
     import poseidon2_air as P2
     O = oracle
@@ -255,7 +255,7 @@ def test_transcript_machine_of_a_golden_proofs_view(oracle, name, shape):
     traces, pre, progs, tables, pub = F.machine_layers(view, capacity=capacity)
     lns, ws, pws = shape_of(traces, pre)
     R = g["log_n"]
-    assert ws[0] == P2.WIDTH_T and pws == [0, 0, 8, 16] and lns == sorted(lns, reverse=True) and len(pub) == 4 * R + 12
+    assert ws[0] == P2.WIDTH_T and ws[3] == 8 and pws == [0, 0, 8, 12] and lns == sorted(lns, reverse=True) and len(pub) == 12
     assert all(int(traces[0][l, P2.TRS]) == 1 and int(traces[0][l, P2.LNP]) == l for l in range(R)) and int(traces[0][R, P2.TRS]) == 0
     for prog, w in zip(progs, ws):
         assert O.air_log_quotient_degree(prog) == 1
@@ -271,23 +271,27 @@ def test_transcript_machine_of_a_golden_proofs_view(oracle, name, shape):
     p2t, frit = fri_transcript_programs(R)
     assert p2t.tolist() == progs[0].tolist() and frit.tolist() == progs[1].tolist()
     nq = len(view["queries"])
-    assert verify_fri_transcript(proof, view["betas"], view["final"], capacity, nq, root, prm) == (0, 0)
+    assert verify_fri_transcript(proof, view["final"], capacity, R, nq, root, prm) == (0, 0)          # no challenge is handed to the verifier
     other = list(capacity)
     other[0] = (other[0] + 1) % P
-    assert verify_fri_transcript(proof, view["betas"], view["final"], other, nq, root, prm)[0] == -6
+    assert verify_fri_transcript(proof, view["final"], other, R, nq, root, prm)[0] == -6
 
     def tampered(chip, fn):
         t = [x.copy() for x in traces]
         fn(t[chip])
         return t
-    # a challenge in the key that the sponge chain does not produce
-    pre2 = [None, None, pre[2], pre[3].copy()]
-    pre2[3][1, 9] = (int(pre2[3][1, 9]) + 1) % P
-    assert _machine_rejected(O, traces, pre2, progs, tables, pub, shape)
+    # a challenge in the ROOTS table's main columns that the sponge chain does not produce (the fold rows would take it from there)
+    assert _machine_rejected(O, tampered(3, lambda t: t.__setitem__((1, 2), (int(t[1, 2]) + 1) % P)), pre, progs, tables, pub, shape)
+    # fold rows that use another challenge than the table's
+    assert _machine_rejected(O, tampered(1, lambda t: t.__setitem__((R + 1, F.BETA), (int(t[R + 1, F.BETA]) + 1) % P)), pre, progs, tables, pub, shape)
     # another capacity than the public one on the first transcript row
     pub2 = list(pub)
     pub2[-3] = (pub2[-3] + 1) % P
     assert _machine_rejected(O, traces, pre, progs, tables, pub2, shape)
+    # other roots in the key: the transcript rows absorb what the table does not hold
+    pre2 = [None, None, pre[2], pre[3].copy()]
+    pre2[3][1, 4] = (int(pre2[3][1, 4]) + 1) % P
+    assert _machine_rejected(O, traces, pre2, progs, tables, pub, shape)
     # a transcript row that absorbs something else than its layer's root
     assert _machine_rejected(O, tampered(0, lambda t: t.__setitem__((2, P2.IN + 3), (int(t[2, P2.IN + 3]) + 1) % P)), pre, progs, tables, pub, shape)
     # a transcript row that claims another layer number

@@ -201,14 +201,14 @@ def test_fri_transcript_of_a_shard_proof_in_circuit(ctx, oracle, log_n, width, i
     assert roots == view["roots"] and betas == view["betas"] and pending == 0
     traces, pre, progs, tables, pub = F.machine_layers(view, capacity=capacity)
     lns, ws, pws = shape_of(traces, pre)
-    assert ws[0] == P2.WIDTH_T and pws == [0, 0, 8, 16]
+    assert ws[0] == P2.WIDTH_T and ws[3] == 8 and pws == [0, 0, 8, 12] and len(pub) == 12
     key = ctx.fri_transcript_key(view, prm)
     assert key.root.tolist() == O.machine_setup(pre, lns, oprm).tolist()
     proof = ctx.prove_fri_transcript(key, view, capacity, prm)
     oproof = O.prove_machine_keyed(traces, pre, progs, tables, pub, oprm)
     assert proof.tobytes() == oproof.tobytes(), "transcript machine proof differs from the oracle's"
     nq = len(view["queries"])
-    assert verify_fri_transcript(proof, view["betas"], view["final"], capacity, nq, key.root, prm) == (0, 0)
+    assert verify_fri_transcript(proof, view["final"], capacity, log_n, nq, key.root, prm) == (0, 0)        # no challenge is handed to the verifier
     assert verify_machine_keyed(proof, lns, ws, pws, key.root, progs, tables, pub, prm) == (0, 0)
     assert O.verify_machine_keyed(proof, lns, ws, pws, key.root, progs, tables, pub, oprm) == 0
     assert pyverify_chips.verify(proof.tobytes(), lns, ws, pub, outer[0], outer[1], outer[2], programs=progs, tables=tables, pre_widths=pws,
@@ -218,16 +218,25 @@ def test_fri_transcript_of_a_shard_proof_in_circuit(ctx, oracle, log_n, width, i
     other[5] = (other[5] + 1) % P
     with pytest.raises(Exception):
         ctx.prove_fri_transcript(key, view, other, prm)
-    assert verify_fri_transcript(proof, view["betas"], view["final"], other, nq, key.root, prm)[0] == -6
-    # a key with another challenge does not accept the proof
+    assert verify_fri_transcript(proof, view["final"], other, log_n, nq, key.root, prm)[0] == -6
+    # challenges that the transcript does not produce: the key does not depend on them, the prover refuses
     bad = dict(view)
     bad["betas"] = [list(b) for b in view["betas"]]
     bad["betas"][1][2] = (bad["betas"][1][2] + 1) % P
     okey = ctx.fri_transcript_key(bad, prm)
-    assert okey.root.tolist() != key.root.tolist()
-    assert verify_fri_transcript(proof, view["betas"], view["final"], capacity, nq, okey.root, prm)[0] == -6
+    assert okey.root.tolist() == key.root.tolist()
+    with pytest.raises(Exception):
+        ctx.prove_fri_transcript(key, bad, capacity, prm)
+    # a key made from other layer roots does not accept the proof
+    bad2 = dict(view)
+    bad2["roots"] = [list(r) for r in view["roots"]]
+    bad2["roots"][0][0] = (bad2["roots"][0][0] + 1) % P
+    okey2 = ctx.fri_transcript_key(bad2, prm)
+    assert okey2.root.tolist() != key.root.tolist()
+    assert verify_fri_transcript(proof, view["final"], capacity, log_n, nq, okey2.root, prm)[0] == -6
     key.close()
     okey.close()
+    okey2.close()
 
 
 def test_fullsize_fri_transcript_of_the_headline_shard(ctx, oracle):
@@ -246,7 +255,7 @@ def test_fullsize_fri_transcript_of_the_headline_shard(ctx, oracle):
     t0 = time.perf_counter()
     proof = ctx.prove_fri_transcript(key, view, capacity, prm)
     t1 = time.perf_counter()
-    assert verify_fri_transcript(proof, view["betas"], view["final"], capacity, 100, key.root, prm) == (0, 0)
+    assert verify_fri_transcript(proof, view["final"], capacity, log_n, 100, key.root, prm) == (0, 0)
     t2 = time.perf_counter()
     print("\nFRI layers + transcript of a 2^20 x 256 shard proof in-circuit: machine proof %.1f ms, %d bytes, host verification %.1f ms"
           % ((t1 - t0) * 1e3, proof.size, (t2 - t1) * 1e3))

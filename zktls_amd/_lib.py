@@ -228,11 +228,11 @@ def load():
     L.zkhip_fri_view_path_words.argtypes = [C.c_int]
     L.zkhip_fri_view_shard_paths.argtypes = [u8p, C.c_size_t, C.c_int, C.c_uint32, u32p, C.c_size_t, C.POINTER(Params), u32p, u32p, u32p, u32p, u32p, u32p, u32p]
     L.zkhip_fri_view_transcript.argtypes = [u8p, C.c_size_t, C.c_int, C.c_uint32, u32p, C.c_size_t, C.POINTER(Params), u32p, u32p, u32p]
-    L.zkhip_fri_transcript_key.argtypes = [C.c_void_p, C.c_int, C.c_size_t, u32p, u32p, u32p, u32p, C.POINTER(Params), C.POINTER(C.c_void_p), u32p]
+    L.zkhip_fri_transcript_key.argtypes = [C.c_void_p, C.c_int, C.c_size_t, u32p, u32p, u32p, C.POINTER(Params), C.POINTER(C.c_void_p), u32p]
     L.zkhip_fri_transcript_proof_size.restype = C.c_size_t
     L.zkhip_fri_transcript_proof_size.argtypes = [C.c_int, C.c_size_t, C.POINTER(Params)]
     L.zkhip_prove_fri_transcript.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_size_t, u32p, u32p, u32p, u32p, u32p, u32p, u32p, C.POINTER(Params), u8p, C.c_size_t, C.POINTER(C.c_size_t)]
-    L.zkhip_verify_fri_transcript.argtypes = [u8p, C.c_size_t, C.c_int, C.c_size_t, u32p, u32p, u32p, u32p, C.POINTER(Params), C.POINTER(C.c_int)]
+    L.zkhip_verify_fri_transcript.argtypes = [u8p, C.c_size_t, C.c_int, C.c_size_t, u32p, u32p, u32p, C.POINTER(Params), C.POINTER(C.c_int)]
     for f in (L.zkhip_fri_layers_chip_air, L.zkhip_p2chip_air_fri_layers, L.zkhip_fri_transcript_chip_air, L.zkhip_p2chip_air_fri_transcript):
         f.restype = C.c_size_t
         f.argtypes = [C.c_int, u32p, C.c_size_t]

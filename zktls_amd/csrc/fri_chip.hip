@@ -42,13 +42,14 @@ constexpr uint32_t E0 = 0, E1 = 4, BIT = 8, K = 9, X = 10, XI = 11, S = 12, T = 
 // index on a query's first row)
 constexpr uint32_t K2 = 32, IDX = 33, L_WIRED = 34;
 constexpr uint32_t BUS_E0 = 40, BUS_E1 = 41, BUS_R0 = 42, BUS_R1 = 43, BUS_Q = 44;
-constexpr uint32_t BUS_B = 45;                               // transcript machine: (layer, beta) from the Poseidon2 chip's transcript rows to the ROOTS table
-constexpr uint32_t ROOTS_PRE_T = 16;                         // ... whose preprocessed row is then (layer, root[8], beta[4], 1, 0, 0)
+constexpr uint32_t BUS_B = 45, BUS_BF = 46;                  // transcript machine: (layer, beta) from the Poseidon2 chip's transcript rows to the ROOTS table, and from there to the fold rows
+constexpr uint32_t ROOTS_MAIN_T = 8;                         // ... whose MAIN row is then (paths + 1, beta[4], queries, 0, 0); preprocessed (layer, root[8], 1, 0, 0)
+constexpr uint32_t N_PUBLIC_T = 12;                          // ... and whose public values are the final value and the challenger's capacity
 constexpr uint32_t QUERIES_PRE = 8, ROOTS_PRE = 12;          // QUERIES: (index, value[4], 1, 0, 0); ROOTS: (layer, root[8], 0, 0, 0) + main (count, 0, 0, 0)
 constexpr uint32_t OPEN_PRE = 12, OPEN_MAIN = 4;             // OPENINGS: preprocessed (ln, k, e0[4], e1[4], m, 0), main 4 unused columns
 constexpr int MIN_LAYERS = 2, MAX_LAYERS = 22;
 inline uint32_t width_of(int layers, bool wired = false) { return ((wired ? L_WIRED : L) + (uint32_t)layers + 3u) & ~3u; }
-inline uint32_t n_public_of(int layers, bool transcript = false) { return 4u * (uint32_t)layers + 4u + (transcript ? 8u : 0u); }   // betas, final value (, capacity)
+inline uint32_t n_public_of(int layers, bool transcript = false) { return transcript ? N_PUBLIC_T : 4u * (uint32_t)layers + 4u; }   // betas, final value -- or final value, capacity
 
 namespace {
 inline Ext ext_from_canon(const uint32_t* p);
@@ -103,6 +104,7 @@ std::vector<uint32_t> build_program(int RL, bool wired, bool transcript = false)
     b.add(ALL, Terms{{1u, {var(ACTIVE), var(ACTIVE)}}, {P - 1, {var(ACTIVE)}}});
     b.add(ALL, Terms{{1u, {var(BIT), var(BIT)}}, {P - 1, {var(BIT)}}});
     for (int l = 0; l < RL; l++) b.add(ALL, Terms{{1u, {var(L + l), var(L + l)}}, {P - 1, {var(L + l)}}});
+    if (!transcript)                        // (transcript machine: the rows receive (layer, BETA) on a bus from the ROOTS table instead)
     for (uint32_t j = 0; j < 4; j++) {      // BETA = the layer's public challenge
         Terms t{{1u, {var(BETA + j)}}};
         for (int l = 0; l < RL; l++) t.push_back(Term{P - 1, {var(L + l), pub(4u * (uint32_t)l + j)}});
@@ -140,7 +142,7 @@ std::vector<uint32_t> build_program(int RL, bool wired, bool transcript = false)
     b.add(TRANSITION, Terms{{1u, {var(L), var(X)}}, {P - 1, {var(L), var(B, true)}}});                             // first layer: X = product over the higher bits
     for (uint32_t j = 0; j < 4; j++)        // the folded value is the next layer's own entry
         b.add(TRANSITION, gated(Terms{{1u, {var(FOLD + j)}}, {P - 1, {var(OWN + j, true)}}}));
-    for (uint32_t j = 0; j < 4; j++) b.add(ALL, Terms{{1u, {var(END), var(FOLD + j)}}, {P - 1, {var(END), pub(4u * (uint32_t)RL + j)}}});
+    for (uint32_t j = 0; j < 4; j++) b.add(ALL, Terms{{1u, {var(END), var(FOLD + j)}}, {P - 1, {var(END), pub((transcript ? 0u : 4u * (uint32_t)RL) + j)}}});
     if (wired) {
         b.add(ALL, Terms{{1u, {var(K2)}}, {P - 2, {var(K)}}});
         b.add(ALL, Terms{{1u, {var(IDX)}}, {P - 1, {var(K2)}}, {P - 1, {var(BIT)}}});
@@ -159,15 +161,15 @@ std::shared_ptr<const std::vector<uint32_t>> program(int RL, bool wired = false,
     return it->second;
 }
 // a table whose contents are fixed by the KEY: combined row [pre | 4 main columns], one harmless first-row identity on the last main column
-std::shared_ptr<const std::vector<uint32_t>> table_program(int RL, uint32_t pre_width, bool transcript = false) {
+std::shared_ptr<const std::vector<uint32_t>> table_program(int RL, uint32_t pre_width, bool transcript = false, uint32_t main_width = 4) {
     static std::mutex mu;
     static std::map<uint64_t, std::shared_ptr<const std::vector<uint32_t>>> cache;
     std::lock_guard<std::mutex> lk(mu);
-    const uint64_t key = ((uint64_t)RL << 32) | ((uint64_t)(transcript ? 1 : 0) << 31) | pre_width;
+    const uint64_t key = ((uint64_t)RL << 32) | ((uint64_t)(transcript ? 1 : 0) << 31) | ((uint64_t)main_width << 16) | pre_width;
     auto it = cache.find(key);
     if (it == cache.end())
-        it = cache.emplace(key, std::make_shared<const std::vector<uint32_t>>(std::vector<uint32_t>{AIR_MAGIC, 1u, pre_width + 4u, 1u, n_public_of(RL, transcript), 6u + 5u,
-                                                                                                     FIRST, 1u, 1u, 1u, var(pre_width + 3u)})).first;
+        it = cache.emplace(key, std::make_shared<const std::vector<uint32_t>>(std::vector<uint32_t>{AIR_MAGIC, 1u, pre_width + main_width, 1u, n_public_of(RL, transcript), 6u + 5u,
+                                                                                                     FIRST, 1u, 1u, 1u, var(pre_width + main_width - 1u)})).first;
     return it->second;
 }
 // OPENINGS: combined row [ln k e0 e1 m 0 | 0 0 0 0]; its program is one harmless identity (the contents are fixed by the KEY)
@@ -194,8 +196,14 @@ const std::vector<uint32_t>& openings_interactions() {  // two receives with the
     return t;
 }
 
-std::vector<uint32_t> fri_interactions_wired(int RL) {     // pairs to the Poseidon2 chip (key = 2 K), the query's start to the QUERIES table
+std::vector<uint32_t> fri_interactions_wired(int RL, bool transcript = false) {     // pairs to the Poseidon2 chip (key = 2 K), the query's start to the QUERIES table
     (void)RL;
+    if (transcript)                                         // ... and every active row receives its layer's challenge from the ROOTS table
+        return std::vector<uint32_t>{LOOKUP_MAGIC, 4u, 3u + 2u * 10u + 2u * 9u,
+                                     0u, ACTIVE, BUS_E0, 6u, LN, K2, E0, E0 + 1, E0 + 2, E0 + 3,
+                                     0u, ACTIVE, BUS_E1, 6u, LN, K2, E1, E1 + 1, E1 + 2, E1 + 3,
+                                     0u, L_WIRED, BUS_Q, 5u, IDX, OWN, OWN + 1, OWN + 2, OWN + 3,
+                                     1u, ACTIVE, BUS_BF, 5u, LN, BETA, BETA + 1, BETA + 2, BETA + 3};
     return std::vector<uint32_t>{LOOKUP_MAGIC, 3u, 3u + 2u * 10u + 9u,
                                  0u, ACTIVE, BUS_E0, 6u, LN, K2, E0, E0 + 1, E0 + 2, E0 + 3,
                                  0u, ACTIVE, BUS_E1, 6u, LN, K2, E1, E1 + 1, E1 + 2, E1 + 3,
@@ -233,11 +241,12 @@ const std::vector<uint32_t>& roots_interactions() {       // receive (main count
     return t;
 }
 
-const std::vector<uint32_t>& roots_interactions_transcript() {   // ... and the challenges with the preprocessed multiplicity 1 (column 13)
-    static const std::vector<uint32_t> t{LOOKUP_MAGIC, 3u, 3u + 3u * 9u,
-                                         1u, ROOTS_PRE_T, BUS_R0, 5u, 0u, 1u, 2u, 3u, 4u,
-                                         1u, ROOTS_PRE_T, BUS_R1, 5u, 0u, 5u, 6u, 7u, 8u,
-                                         1u, 13u, BUS_B, 5u, 0u, 9u, 10u, 11u, 12u};
+const std::vector<uint32_t>& roots_interactions_transcript() {   // ... the challenge (MAIN columns 13 .. 16: the prover's) received once from the transcript
+    static const std::vector<uint32_t> t{LOOKUP_MAGIC, 4u, 3u + 4u * 9u,                                // row (preprocessed multiplicity 1, column 9) and sent
+                                         1u, ROOTS_PRE, BUS_R0, 5u, 0u, 1u, 2u, 3u, 4u,                 // to the fold rows (main multiplicity column 17 = queries)
+                                         1u, ROOTS_PRE, BUS_R1, 5u, 0u, 5u, 6u, 7u, 8u,
+                                         1u, 9u, BUS_B, 5u, 0u, ROOTS_PRE + 1, ROOTS_PRE + 2, ROOTS_PRE + 3, ROOTS_PRE + 4,
+                                         0u, ROOTS_PRE + 5, BUS_BF, 5u, 0u, ROOTS_PRE + 1, ROOTS_PRE + 2, ROOTS_PRE + 3, ROOTS_PRE + 4};
     return t;
 }
 
@@ -537,21 +546,23 @@ inline int log2_ceil(size_t n, int lo) { int l = lo; while (((size_t)1 << l) < n
 inline size_t p2_rows(int layers, size_t nq, bool transcript = false) {
     return nq * ((size_t)layers + (size_t)layers * ((size_t)layers + 1) / 2) + (transcript ? (size_t)layers : 0);
 }
-// transcript: the TRANSCRIPT machine (zkhip_prove_fri_transcript) -- the same four chips, the Poseidon2 chip in its transcript variant
-// (its trace starts with a sponge chain over the layer roots), the ROOTS table with the challenges beside the roots, eight more public
-// values (the challenger's capacity).  Statement added: "the challenges are the ones the transcript derives from these roots".
+// transcript: the TRANSCRIPT machine (zkhip_prove_fri_transcript) -- the same four chips; the Poseidon2 chip in its transcript variant
+// (its trace starts with a sponge chain over the layer roots); the ROOTS table with the challenges in its MAIN columns, received once
+// from the transcript row of the layer and handed to the layer's fold rows; the fold chip without public challenges.  Public values:
+// the final value and the challenger's capacity.  Neither the key nor the verifier holds a challenge: "... under the challenges the
+// transcript derives from these layer roots, starting from this challenger state".
 void wired_machine(int layers, size_t nq, WiredMachine& m, bool transcript = false) {
-    const uint32_t NP = n_public_of(layers, transcript), RP = transcript ? ROOTS_PRE_T : ROOTS_PRE;
-    m.p[0] = transcript ? p2chip::program_fri_transcript(NP, n_public_of(layers)) : p2chip::program_fri_layers(NP);
+    const uint32_t NP = n_public_of(layers, transcript);
+    m.p[0] = transcript ? p2chip::program_fri_transcript(NP, 4u) : p2chip::program_fri_layers(NP);       // (the capacity follows the final value)
     m.p[1] = program(layers, true, transcript);
     m.p[2] = table_program(layers, QUERIES_PRE, transcript);
-    m.p[3] = table_program(layers, RP, transcript);
-    m.fri_tab = fri_interactions_wired(layers);
+    m.p[3] = table_program(layers, ROOTS_PRE, transcript, transcript ? ROOTS_MAIN_T : 4u);
+    m.fri_tab = fri_interactions_wired(layers, transcript);
     m.log_ns[0] = log2_ceil(p2_rows(layers, nq, transcript), 5); m.log_ns[1] = log2_ceil(nq * (size_t)layers, 5);
     m.log_ns[2] = log2_ceil(nq, 5); m.log_ns[3] = log2_ceil((size_t)layers, 5);
     if (m.log_ns[3] > m.log_ns[2]) m.log_ns[2] = m.log_ns[3];                // tallest first also for few queries
-    m.widths[0] = transcript ? p2chip::WIDTH_T : p2chip::WIDTH; m.widths[1] = width_of(layers, true); m.widths[2] = 4; m.widths[3] = 4;
-    m.pre_widths[0] = 0; m.pre_widths[1] = 0; m.pre_widths[2] = QUERIES_PRE; m.pre_widths[3] = RP;
+    m.widths[0] = transcript ? p2chip::WIDTH_T : p2chip::WIDTH; m.widths[1] = width_of(layers, true); m.widths[2] = 4; m.widths[3] = transcript ? ROOTS_MAIN_T : 4u;
+    m.pre_widths[0] = 0; m.pre_widths[1] = 0; m.pre_widths[2] = QUERIES_PRE; m.pre_widths[3] = ROOTS_PRE;
     const std::vector<uint32_t>* tabs[4] = {transcript ? &p2_interactions_transcript() : &p2_interactions(), &m.fri_tab, &queries_interactions(),
                                             transcript ? &roots_interactions_transcript() : &roots_interactions()};
     for (int c = 0; c < 4; c++) { m.progs[c] = m.p[c]->data(); m.prog_words[c] = m.p[c]->size(); m.tabs[c] = tabs[c]->data(); m.tab_words[c] = tabs[c]->size(); }
@@ -576,17 +587,16 @@ size_t zkhip_p2chip_air_fri_layers(int layers, uint32_t* program, size_t cap_wor
 }
 
 // the key: QUERIES (index, reduced opening, 1) and ROOTS (layer, root) committed by zkhip_machine_setup
-// betas != NULL: the key of the TRANSCRIPT machine (the ROOTS table carries the challenges beside the roots)
+// T: the key of the TRANSCRIPT machine (the ROOTS rows carry the multiplicity 1 of their challenge, which itself is not in the key)
 static int fri_layers_key_impl(zkhip_ctx* ctx, int layers, size_t n_queries, const uint32_t* indices, const uint32_t* values, const uint32_t* roots,
-                               const uint32_t* betas, const zkhip_params* prm, zkhip_machine_key** key, uint32_t vk[8]) {
+                               bool T, const zkhip_params* prm, zkhip_machine_key** key, uint32_t vk[8]) {
     CHECK_CTX(ctx);
     if (!indices || !values || !roots || !prm || !key || !vk) return fail(ZKHIP_ERR_INVALID, "fri_layers_key: null argument");
     int lr;
     ZK_TRY(frichip::shape_ok(layers, n_queries, &lr));
-    if (!frichip::canonical(values, 4 * n_queries) || !frichip::canonical(roots, 8 * (size_t)layers) || (betas && !frichip::canonical(betas, 4 * (size_t)layers)))
+    if (!frichip::canonical(values, 4 * n_queries) || !frichip::canonical(roots, 8 * (size_t)layers))
         return fail(ZKHIP_ERR_INVALID, "fri_layers_key: values must be canonical");
-    const bool T = betas != nullptr;
-    const uint32_t RP = T ? frichip::ROOTS_PRE_T : frichip::ROOTS_PRE;
+    const uint32_t RP = frichip::ROOTS_PRE;
     frichip::WiredMachine m;
     frichip::wired_machine(layers, n_queries, m, T);
     std::vector<uint32_t> qt(((size_t)frichip::QUERIES_PRE) << m.log_ns[2], 0u), rt(((size_t)RP) << m.log_ns[3], 0u);
@@ -601,7 +611,7 @@ static int fri_layers_key_impl(zkhip_ctx* ctx, int layers, size_t n_queries, con
         uint32_t* r = rt.data() + RP * (size_t)l;
         r[0] = to_monty((uint32_t)l);
         for (int i = 0; i < 8; i++) r[1 + i] = to_monty(roots[8 * l + i]);
-        if (T) { for (int i = 0; i < 4; i++) r[9 + i] = to_monty(betas[4 * l + i]); r[13] = MONTY_R1; }
+        if (T) r[9] = MONTY_R1;
     }
     void *dq, *dr;
     ZK_TRY(ctx_reserve(ctx, S_REC_C, qt.size() * 4, &dq));
@@ -616,12 +626,11 @@ static int fri_layers_key_impl(zkhip_ctx* ctx, int layers, size_t n_queries, con
 }
 int zkhip_fri_layers_key(zkhip_ctx* ctx, int layers, size_t n_queries, const uint32_t* indices, const uint32_t* values, const uint32_t* roots,
                          const zkhip_params* prm, zkhip_machine_key** key, uint32_t vk[8]) {
-    return fri_layers_key_impl(ctx, layers, n_queries, indices, values, roots, nullptr, prm, key, vk);
+    return fri_layers_key_impl(ctx, layers, n_queries, indices, values, roots, false, prm, key, vk);
 }
 int zkhip_fri_transcript_key(zkhip_ctx* ctx, int layers, size_t n_queries, const uint32_t* indices, const uint32_t* values, const uint32_t* roots,
-                             const uint32_t* betas, const zkhip_params* prm, zkhip_machine_key** key, uint32_t vk[8]) {
-    if (!betas) return fail(ZKHIP_ERR_INVALID, "fri_transcript_key: null argument");
-    return fri_layers_key_impl(ctx, layers, n_queries, indices, values, roots, betas, prm, key, vk);
+                             const zkhip_params* prm, zkhip_machine_key** key, uint32_t vk[8]) {
+    return fri_layers_key_impl(ctx, layers, n_queries, indices, values, roots, true, prm, key, vk);
 }
 
 static size_t fri_layers_proof_size_impl(int layers, size_t n_queries, const zkhip_params* prm, bool transcript) {
@@ -642,7 +651,7 @@ size_t zkhip_fri_transcript_chip_air(int layers, uint32_t* program, size_t cap_w
 }
 size_t zkhip_p2chip_air_fri_transcript(int layers, uint32_t* program, size_t cap_words) {
     if (layers < frichip::MIN_LAYERS || layers > frichip::MAX_LAYERS) return 0;
-    const auto p = p2chip::program_fri_transcript(frichip::n_public_of(layers, true), frichip::n_public_of(layers));
+    const auto p = p2chip::program_fri_transcript(frichip::n_public_of(layers, true), 4u);
     if (program && cap_words >= p->size()) std::memcpy(program, p->data(), p->size() * 4);
     return p->size();
 }
@@ -737,22 +746,25 @@ static int prove_fri_layers_impl(zkhip_ctx* ctx, const zkhip_machine_key* key, i
     ZK_TRY(ctx_reserve(ctx, S_REC_A, ((size_t)m.widths[0] << m.log_ns[0]) * 4, &t_p2));
     ZK_TRY(ctx_reserve(ctx, S_REC_B, ((size_t)m.widths[1] << m.log_ns[1]) * 4, &t_fri));
     ZK_TRY(ctx_reserve(ctx, S_CHIP, ((size_t)4 << m.log_ns[2]) * 4, &t_q));
-    ZK_TRY(ctx_reserve(ctx, S_CHIP_B, ((size_t)4 << m.log_ns[3]) * 4, &t_r));
+    ZK_TRY(ctx_reserve(ctx, S_CHIP_B, ((size_t)m.widths[3] << m.log_ns[3]) * 4, &t_r));
     ZK_TRY(fri_layers_gen_paths_trace_impl(ctx, layers, n_queries, betas, indices, values, siblings, roots, paths, capacity, m.log_ns[0], (uint32_t*)t_p2, m.widths[0]));
     std::vector<uint32_t> finals(4 * n_queries);
     ZK_TRY(fri_gen_trace(ctx, layers, n_queries, betas, indices, values, siblings, m.log_ns[1], (uint32_t*)t_fri, m.widths[1], finals.data(), true));
     for (size_t q = 1; q < n_queries; q++)
         if (std::memcmp(finals.data(), finals.data() + 4 * q, 16) != 0) return fail(ZKHIP_ERR_INVALID, "prove_fri_layers: the chains do not end in one value");
     // main columns of the tables: QUERIES none (zeros), ROOTS the number of paths per layer
-    std::vector<uint32_t> rmain((size_t)4 << m.log_ns[3], 0u);
-    for (int l = 0; l < layers; l++) rmain[4 * (size_t)l] = to_monty((uint32_t)n_queries + (T ? 1u : 0u));     // the paths, and the transcript row that absorbs the root
+    std::vector<uint32_t> rmain((size_t)m.widths[3] << m.log_ns[3], 0u);
+    for (int l = 0; l < layers; l++) {
+        uint32_t* r = rmain.data() + (size_t)m.widths[3] * (size_t)l;
+        r[0] = to_monty((uint32_t)n_queries + (T ? 1u : 0u));     // the paths, and the transcript row that absorbs the root
+        if (T) { for (int i = 0; i < 4; i++) r[1 + i] = to_monty(betas[4 * l + i]); r[5] = to_monty((uint32_t)n_queries); }
+    }
     ZK_HIP(hipMemsetAsync(t_q, 0, ((size_t)4 << m.log_ns[2]) * 4, ctx->stream));
     ZK_HIP(hipMemcpyAsync(t_r, rmain.data(), rmain.size() * 4, hipMemcpyHostToDevice, ctx->stream));
     ZK_HIP(hipStreamSynchronize(ctx->stream));
     std::vector<uint32_t> pv(frichip::n_public_of(layers, T));
-    std::memcpy(pv.data(), betas, 16 * (size_t)layers);
-    std::memcpy(pv.data() + 4 * (size_t)layers, finals.data(), 16);
-    if (T) std::memcpy(pv.data() + 4 * (size_t)layers + 4, capacity, 32);
+    if (T) { std::memcpy(pv.data(), finals.data(), 16); std::memcpy(pv.data() + 4, capacity, 32); }
+    else { std::memcpy(pv.data(), betas, 16 * (size_t)layers); std::memcpy(pv.data() + 4 * (size_t)layers, finals.data(), 16); }
     zkhip_chip chips[4]{};
     void* tr[4] = {t_p2, t_fri, t_q, t_r};
     for (int c = 0; c < 4; c++) { chips[c].d_trace = (const uint32_t*)tr[c]; chips[c].ld = m.widths[c]; chips[c].log_n = m.log_ns[c]; chips[c].width = m.widths[c]; chips[c].partner = -1; }
@@ -773,15 +785,14 @@ int zkhip_prove_fri_transcript(zkhip_ctx* ctx, const zkhip_machine_key* key, int
 static int verify_fri_layers_impl(const uint8_t* proof, size_t len, int layers, size_t n_queries, const uint32_t* betas, const uint32_t final_value[4],
                                   const uint32_t* capacity, const uint32_t vk[8], const zkhip_params* prm, int* reason) {
     int lr;
-    if (!proof || !betas || !final_value || !vk || !prm || frichip::shape_ok(layers, n_queries, &lr) != ZKHIP_OK) {
+    if (!proof || (!betas && !capacity) || !final_value || !vk || !prm || frichip::shape_ok(layers, n_queries, &lr) != ZKHIP_OK) {
         if (reason) *reason = 1;
         return fail(ZKHIP_ERR_VERIFY, "verify_fri_layers: bad arguments");
     }
     const bool T = capacity != nullptr;
     std::vector<uint32_t> pv(frichip::n_public_of(layers, T));
-    std::memcpy(pv.data(), betas, 16 * (size_t)layers);
-    std::memcpy(pv.data() + 4 * (size_t)layers, final_value, 16);
-    if (T) std::memcpy(pv.data() + 4 * (size_t)layers + 4, capacity, 32);
+    if (T) { std::memcpy(pv.data(), final_value, 16); std::memcpy(pv.data() + 4, capacity, 32); }
+    else { std::memcpy(pv.data(), betas, 16 * (size_t)layers); std::memcpy(pv.data() + 4 * (size_t)layers, final_value, 16); }
     frichip::WiredMachine m;
     frichip::wired_machine(layers, n_queries, m, T);
     return zkhip_verify_machine_keyed(proof, len, m.log_ns, m.widths, m.pre_widths, vk, m.progs, m.prog_words, m.tabs, m.tab_words, 4, pv.data(), pv.size(), prm, reason);
@@ -790,10 +801,10 @@ int zkhip_verify_fri_layers(const uint8_t* proof, size_t len, int layers, size_t
                             const uint32_t vk[8], const zkhip_params* prm, int* reason) {
     return verify_fri_layers_impl(proof, len, layers, n_queries, betas, final_value, nullptr, vk, prm, reason);
 }
-int zkhip_verify_fri_transcript(const uint8_t* proof, size_t len, int layers, size_t n_queries, const uint32_t* betas, const uint32_t final_value[4],
-                                const uint32_t capacity[8], const uint32_t vk[8], const zkhip_params* prm, int* reason) {
+int zkhip_verify_fri_transcript(const uint8_t* proof, size_t len, int layers, size_t n_queries, const uint32_t final_value[4], const uint32_t capacity[8],
+                                const uint32_t vk[8], const zkhip_params* prm, int* reason) {
     if (!capacity) { if (reason) *reason = 1; return fail(ZKHIP_ERR_VERIFY, "verify_fri_transcript: bad arguments"); }
-    return verify_fri_layers_impl(proof, len, layers, n_queries, betas, final_value, capacity, vk, prm, reason);
+    return verify_fri_layers_impl(proof, len, layers, n_queries, nullptr, final_value, capacity, vk, prm, reason);
 }
 
 }  // extern "C"

@@ -598,8 +598,8 @@ class Context:
         R, Q, betas, idx, vals, sibs, roots, paths = _fri_layers_arrays(view)
         handle, root = C.c_void_p(), np.zeros(8, dtype=np.uint32)
         check(self.lib.zkhip_fri_transcript_key(self.handle, R, Q, idx.ctypes.data_as(u32p), vals.ctypes.data_as(u32p), roots.ctypes.data_as(u32p),
-                                                betas.ctypes.data_as(u32p), C.byref(params), C.byref(handle), root.ctypes.data_as(u32p)))
-        return MachineKey(self, handle, root, [0, 0, 8, 16])
+                                                C.byref(params), C.byref(handle), root.ctypes.data_as(u32p)))
+        return MachineKey(self, handle, root, [0, 0, 8, 12])
 
     def prove_fri_transcript(self, key, view, capacity, params=None):
         """zkhip_prove_fri_transcript: the wired machine with the FRI transcript in-circuit (capacity: zkhip_fri_view_transcript)"""
@@ -1009,17 +1009,17 @@ def fri_transcript_programs(layers):
     return out
 
 
-def verify_fri_transcript(proof, view_betas, final, capacity, n_queries, vk, params=None):
+def verify_fri_transcript(proof, final, capacity, layers, n_queries, vk, params=None):
+    """zkhip_verify_fri_transcript: the verifier is handed no challenge -- the final value, the challenger's capacity, the key"""
     params = params or Params(1, 100, 16)
     lib = _lib.load()
     pr = np.ascontiguousarray(proof, dtype=np.uint8)
-    b = np.ascontiguousarray(np.array(view_betas, dtype=np.uint32).reshape(-1))
     f = np.ascontiguousarray(np.array(final, dtype=np.uint32))
     c8 = np.ascontiguousarray(np.array(capacity, dtype=np.uint32))
     k = np.ascontiguousarray(np.array(vk, dtype=np.uint32))
     reason = C.c_int(0)
-    rc = lib.zkhip_verify_fri_transcript(pr.ctypes.data_as(u8p), pr.size, b.size // 4, n_queries, b.ctypes.data_as(u32p), f.ctypes.data_as(u32p),
-                                         c8.ctypes.data_as(u32p), k.ctypes.data_as(u32p), C.byref(params), C.byref(reason))
+    rc = lib.zkhip_verify_fri_transcript(pr.ctypes.data_as(u8p), pr.size, layers, n_queries, f.ctypes.data_as(u32p), c8.ctypes.data_as(u32p),
+                                         k.ctypes.data_as(u32p), C.byref(params), C.byref(reason))
     return rc, reason.value
 
 
