@@ -48,7 +48,7 @@ LaunchBatcher::LaunchBatcher(int members, hipStream_t stream) : members_(members
     }
     if (ring_ || !stream_) return;                           // (no stream: the scheduler alone, see zkhip_selftest_lockstep)
     void* p = nullptr;
-    if (hipHostMalloc(&p, RING_BYTES, hipHostMallocDefault) != hipSuccess) { (void)hipGetLastError(); return; }
+    if (hipHostMalloc(&p, RING_BYTES, hipHostMallocPortable | hipHostMallocMapped) != hipSuccess) { (void)hipGetLastError(); return; }
     ring_ = (uint8_t*)p;
 }
 
