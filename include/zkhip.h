@@ -29,7 +29,8 @@
  *   zkhip_p2chip_air, zkhip_prove_merkle_paths / zkhip_verify_merkle_paths
  *   zkhip_fri_view_shard, zkhip_fri_chip_air, zkhip_fri_queries_key, zkhip_prove_fri_queries / zkhip_verify_fri_queries,
  *   zkhip_fri_view_shard_paths, zkhip_fri_layers_key, zkhip_prove_fri_layers / zkhip_verify_fri_layers,
- *   zkhip_fri_view_transcript, zkhip_fri_transcript_key, zkhip_prove_fri_transcript / zkhip_verify_fri_transcript
+ *   zkhip_fri_view_transcript, zkhip_fri_transcript_key, zkhip_prove_fri_transcript / zkhip_verify_fri_transcript,
+ *   zkhip_fri_indices_key, zkhip_prove_fri_indices / zkhip_verify_fri_indices
  *       a first recursion step: the FRI folds of a shard proof checked inside a (keyed machine) proof -- what `compress` behind
  *       SP1ProofMode::Groth16 (sp1.rs:116) spends its rows on besides Poseidon2.
  *       a second real chip -- the Poseidon2 permutation with Merkle-path / leaf-hash chaining, what the recursion stages behind
@@ -671,12 +672,13 @@ int zkhip_fri_view_shard_paths(const uint8_t* proof, size_t len, int log_n, uint
                                const zkhip_params* prm, uint32_t* betas, uint32_t final_value[4], uint32_t* indices, uint32_t* values, uint32_t* siblings,
                                uint32_t* roots, uint32_t* paths);
 /* the Fiat-Shamir side of the view: the layer roots (8 words each), the challenges they lead to (4 words each), and the duplex
- * challenger as the commit phase finds it -- transcript[0..8) = the capacity half of its state, transcript[8] = pending inputs (0).
+ * challenger as the commit phase finds it -- transcript[0..8) = the capacity half of its state, transcript[8] = pending inputs (0);
+ * transcript[9] = the proof-of-work witness the query phase absorbs behind the final value.
  * With these every challenge is one step of a sponge chain over the roots: state <- (root_l | capacity), permute,
  * beta_l = (state[7], state[6], state[5], state[4]), capacity <- state[8..16) -- what a transcript chip has to prove next
  * (docs/RECURSION_NEXT.md; p3-challenger DuplexChallenger, reference Cargo.lock:3875).  Canonical words; host only. */
 int zkhip_fri_view_transcript(const uint8_t* proof, size_t len, int log_n, uint32_t width, const uint32_t* public_values, size_t n_public,
-                              const zkhip_params* prm, uint32_t* roots, uint32_t* betas, uint32_t transcript[9]);
+                              const zkhip_params* prm, uint32_t* roots, uint32_t* betas, uint32_t transcript[10]);
 size_t zkhip_fri_layers_chip_air(int layers, uint32_t* program, size_t cap_words);
 size_t zkhip_p2chip_air_fri_layers(int layers, uint32_t* program, size_t cap_words);
 int zkhip_fri_layers_gen_paths_trace(zkhip_ctx* ctx, int layers, size_t n_queries, const uint32_t* betas, const uint32_t* indices, const uint32_t* values,
@@ -710,6 +712,27 @@ int zkhip_prove_fri_transcript(zkhip_ctx* ctx, const zkhip_machine_key* key, int
                                const zkhip_params* prm, uint8_t* proof, size_t cap, size_t* len);
 int zkhip_verify_fri_transcript(const uint8_t* proof, size_t len, int layers, size_t n_queries, const uint32_t final_value[4], const uint32_t capacity[8],
                                 const uint32_t vk[8], const zkhip_params* prm, int* reason);
+/* The QUERY PHASE of the transcript in-circuit (zkhip_prove_fri_indices): the sponge chain of the transcript machine goes on as the inner
+ * proof's verifier does (p3-fri verifier: observe the final polynomial, check the proof-of-work witness, sample the query indices;
+ * reference Cargo.lock:3930, 3875) -- one row absorbs the final value and the witness over the front of the rate, further rows only
+ * permute; a fifth chip, SAMPLES, takes the 31 bits of every word these rows hand out (canonical decomposition): the first word's low
+ * inner_pow_bits bits must be zero, the low layers + 1 bits of the others are the query indices, which reach the QUERIES table's MAIN
+ * column by query number and from there the first fold row of the query.  The key holds (query number, reduced opening) and the layer
+ * roots -- no index; the verifier is handed the final value and the challenger's capacity: "every query, AT THE INDEX THE TRANSCRIPT
+ * DRAWS FOR IT, opens these commitments and folds to this final value, and the transcript's proof of work holds."  inner_pow_bits = the
+ * grinding bits of the INNER proof (zkhip_params.pow_bits of the proof the view was taken from); witness = its proof-of-work witness
+ * (zkhip_fri_view_transcript: transcript[9]).  zkhip_fri_indices_program: the two programs that differ from the transcript machine's
+ * (which = 0: the Poseidon2 chip with query-phase rows, 1: the SAMPLES chip).  Still outside: the transcript before the commit phase,
+ * the trace / quotient openings and the reduced openings. */
+size_t zkhip_fri_indices_program(int which, int layers, int inner_pow_bits, uint32_t* program, size_t cap_words);
+int zkhip_fri_indices_key(zkhip_ctx* ctx, int layers, size_t n_queries, int inner_pow_bits, const uint32_t* values, const uint32_t* roots,
+                          const zkhip_params* prm, zkhip_machine_key** key, uint32_t vk[8]);
+size_t zkhip_fri_indices_proof_size(int layers, size_t n_queries, int inner_pow_bits, const zkhip_params* prm);
+int zkhip_prove_fri_indices(zkhip_ctx* ctx, const zkhip_machine_key* key, int layers, size_t n_queries, int inner_pow_bits, const uint32_t* betas,
+                            const uint32_t* indices, const uint32_t* values, const uint32_t* siblings, const uint32_t* roots, const uint32_t* paths,
+                            const uint32_t capacity[8], uint32_t witness, const zkhip_params* prm, uint8_t* proof, size_t cap, size_t* len);
+int zkhip_verify_fri_indices(const uint8_t* proof, size_t len, int layers, size_t n_queries, int inner_pow_bits, const uint32_t final_value[4],
+                             const uint32_t capacity[8], const uint32_t vk[8], const zkhip_params* prm, int* reason);
 
 /* ---- Poseidon2 parameter tables from a file: the built-in sets are this repo's own
  * ("zktls-amd/p2-bb16-v1", "...-bb24-v1"; the SP1 / RISC Zero tables of reference Cargo.lock:4030, 6172, 5057 are not

@@ -17,6 +17,11 @@ BUS_E0, BUS_E1, BUS_R0, BUS_R1, BUS_Q = 40, 41, 42, 43, 44
 BUS_B, BUS_BF = 45, 46                         # the transcript machine: (layer, beta) from the Poseidon2 chip's transcript rows to the ROOTS table, and from there to the fold rows
 ROOTS_MAIN_T = 8                               # ... whose MAIN row is then (paths + 1, beta[4], queries, 0, 0); preprocessed (layer, root[8], 1, 0, 0)
 N_PUBLIC_T = 12                                # final value, the challenger's capacity
+BUS_S0, BUS_S1, BUS_I = 47, 48, 49             # the query-phase machine: the sampled words of a sponge row (two halves) to the SAMPLES chip, (query, index) from there to QUERIES
+# SAMPLES chip (one row per query-phase sponge row): preprocessed C (the sponge row's number), ROW, ACT[8] (word j is a query index), POW (row 0: word 0
+# is the proof-of-work sample), KQ[8] (the query's number); main W[8] (the words), IDX[8] (their low bits), H1 H2 HH [8] (canonical-form helpers), bits [8][31]
+S_PRE, S_C, S_ROW, S_ACT, S_POW, S_KQ = 20, 0, 1, 2, 10, 11
+S_W, S_IDX, S_H1, S_H2, S_HH, S_BITS, S_MAIN = 0, 8, 16, 24, 32, 40, 288
 K2, IDX, L_WIRED = 32, 33, 34                  # the wired form's extra columns, its layer selectors start two columns later
 QUERIES_PRE, ROOTS_PRE = 8, 12
 OPEN_PRE, OPEN_MAIN = 12, 4
@@ -213,11 +218,66 @@ def random_view(layers, n_queries, seed=1):
     return {"betas": betas, "queries": queries, "final": layers_vec[layers][top]}
 
 
-def machine_layers(view, capacity=None):
+def sample_rows(n_queries):
+    """sponge rows of the query phase: one proof-of-work word, then one word per query, 8 words per row"""
+    return (1 + n_queries + 7) // 8
+
+
+def samples_program(layers, n_queries, pow_bits, n_public):
+    """every word = sum of 31 bits, canonical (bits 27..30 all set -> bits 0..26 clear: P = 2^31 - 2^27 + 1), IDX = the low layers + 1 bits; the
+    proof-of-work word's low pow_bits bits are zero.  Columns: the preprocessed ones first"""
+    cons = []
+
+    def add(sel, terms):
+        cons.append((sel, [(c % P, list(vs)) for c, vs in terms if c % P]))
+    M0 = S_PRE
+    for j in range(8):
+        bits = [M0 + S_BITS + 31 * j + i for i in range(31)]
+        for b in bits:
+            add(O.SEL_ALL, [(1, [V(b), V(b)]), (P - 1, [V(b)])])
+        add(O.SEL_ALL, [(1, [V(M0 + S_W + j)])] + [(P - (1 << i), [V(bits[i])]) for i in range(31)])
+        add(O.SEL_ALL, [(1, [V(M0 + S_H1 + j)]), (P - 1, [V(bits[30]), V(bits[29])])])
+        add(O.SEL_ALL, [(1, [V(M0 + S_H2 + j)]), (P - 1, [V(bits[28]), V(bits[27])])])
+        add(O.SEL_ALL, [(1, [V(M0 + S_HH + j)]), (P - 1, [V(M0 + S_H1 + j), V(M0 + S_H2 + j)])])
+        add(O.SEL_ALL, [(1, [V(M0 + S_HH + j), V(bits[i])]) for i in range(27)])
+        add(O.SEL_ALL, [(1, [V(M0 + S_IDX + j)])] + [(P - (1 << i), [V(bits[i])]) for i in range(layers + 1)])
+    if pow_bits:
+        add(O.SEL_ALL, [(1, [V(S_POW), V(M0 + S_BITS + i)]) for i in range(pow_bits)])
+    return O.air_program(S_PRE + S_MAIN, n_public, cons)
+
+
+def samples_tables(layers, n_queries, words, log_rows):
+    """-> (preprocessed, main) of the SAMPLES chip; words = [rows][8] sampled words, canonical"""
+    n_rows = sample_rows(n_queries)
+    pre = np.zeros((1 << log_rows, S_PRE), dtype=np.uint32)
+    main = np.zeros((1 << log_rows, S_MAIN), dtype=np.uint32)
+    indices = []
+    for r in range(n_rows):
+        pre[r, S_C], pre[r, S_ROW] = layers + r, 1
+        for j in range(8):
+            slot = 8 * r + j
+            w = int(words[r][j])
+            assert 0 <= w < P
+            if slot == 0:
+                pre[r, S_POW] = 1
+            elif slot <= n_queries:
+                pre[r, S_ACT + j], pre[r, S_KQ + j] = 1, slot - 1
+                indices.append(w & ((1 << (layers + 1)) - 1))
+            main[r, S_W + j], main[r, S_IDX + j] = w, w & ((1 << (layers + 1)) - 1)
+            b = [(w >> i) & 1 for i in range(31)]
+            main[r, S_BITS + 31 * j:S_BITS + 31 * j + 31] = b
+            main[r, S_H1 + j], main[r, S_H2 + j], main[r, S_HH + j] = b[30] & b[29], b[28] & b[27], b[30] & b[29] & b[28] & b[27]
+    return pre, main, indices
+
+
+def machine_layers(view, capacity=None, query_phase=None):
     """the wired machine (zkhip_prove_fri_layers): the Poseidon2 chip's FRI-layers variant (one Merkle path per (query, layer)), the fold
     chip in its wired form, and the preprocessed QUERIES / ROOTS tables -> (main traces, preprocessed traces, programs, tables, public values).
     capacity (8 words: the duplex challenger's capacity as the commit phase finds it): the TRANSCRIPT machine (zkhip_prove_fri_transcript)
-    -- the Poseidon2 chip's trace starts with a sponge chain over the layer roots whose outputs must be the betas of the ROOTS table"""
+    -- the Poseidon2 chip's trace starts with a sponge chain over the layer roots whose outputs must be the betas of the ROOTS table.
+    query_phase = (proof-of-work witness, pow_bits): the QUERY-PHASE machine (zkhip_prove_fri_indices) -- the chain goes on through the final value
+    and the witness, a fifth chip (SAMPLES) takes the bits of the sampled words, and the QUERIES table's index column is the prover's, tied to them:
+    the key holds no index any more"""
     import poseidon2_air as P2
     betas, queries, roots, paths = view["betas"], view["queries"], view["roots"], view["paths"]
     R, Q = len(betas), len(queries)
@@ -239,8 +299,17 @@ def machine_layers(view, capacity=None):
             e0, e1 = (sibs[l], own) if bit else (own, sibs[l])
             plist.append((l, k, list(e0) + list(e1), paths[q][l], 1))
             own, idx = fold_pair(k, H - (l + 1), betas[l], e0, e1)[0], k
-    lr_p2 = lg(Q * (R + R * (R + 1) // 2) + (R if T else 0))
-    if T:
+    QM = query_phase is not None
+    assert T or not QM
+    lr_p2 = lg(Q * (R + R * (R + 1) // 2) + (R if T else 0) + (sample_rows(Q) if QM else 0))
+    if QM:
+        p2_trace, p2_roots, chain, words = P2.layer_paths_trace(plist, lr_p2, transcript=(capacity, roots), queries=(view["final"], query_phase[0], sample_rows(Q)))
+        assert chain == [list(b) for b in betas], "the challenges are not the sponge chain over the roots"
+        lr_s = lg(sample_rows(Q))
+        spre, smain, drawn = samples_tables(R, Q, words, lr_s)
+        assert drawn == [index for index, _, _ in view["queries"]], "the query indices are not the ones the transcript draws"
+        assert query_phase[1] == 0 or words[0][0] & ((1 << query_phase[1]) - 1) == 0, "the witness does not satisfy the proof of work"
+    elif T:
         p2_trace, p2_roots, chain = P2.layer_paths_trace(plist, lr_p2, transcript=(capacity, roots))
         assert chain == [list(b) for b in betas], "the challenges are not the sponge chain over the roots"
     else:
@@ -249,11 +318,14 @@ def machine_layers(view, capacity=None):
         assert p2_roots[i] == list(roots[l]), "a path does not end in its layer's root"
     lr_fri = lg(Q * R)
     fri_trace, final = trace(view, lr_fri, wired=True)
-    lr_r = lg(R)
+    lr_r = max(lg(R), lg(sample_rows(Q))) if QM else lg(R)       # tallest first: the SAMPLES chip comes last
     lr_q = max(lg(Q), lr_r)
     qpre = np.zeros((1 << lr_q, QUERIES_PRE), dtype=np.uint32)
-    for q, (index, value, _) in enumerate(queries):
-        qpre[q, 0], qpre[q, 1:5], qpre[q, 5] = index, value, 1
+    qmain = np.zeros((1 << lr_q, 4), dtype=np.uint32)
+    for q, (index, value, _) in enumerate(view["queries"]):
+        qpre[q, 0], qpre[q, 1:5], qpre[q, 5] = (q if QM else index), value, 1
+        if QM:
+            qmain[q, 0] = index
     RP = ROOTS_PRE
     rpre = np.zeros((1 << lr_r, RP), dtype=np.uint32)
     rmain = np.zeros((1 << lr_r, ROOTS_MAIN_T if T else 4), dtype=np.uint32)
@@ -271,13 +343,15 @@ def machine_layers(view, capacity=None):
         p2_inter += [(O.SEND, P2.TRS, BUS_R0, [P2.LNP, P2.IN, P2.IN + 1, P2.IN + 2, P2.IN + 3]),
                      (O.SEND, P2.TRS, BUS_R1, [P2.LNP, P2.IN + 4, P2.IN + 5, P2.IN + 6, P2.IN + 7]),
                      (O.SEND, P2.TRS, BUS_B, [P2.LNP, o7 + 7, o7 + 6, o7 + 5, o7 + 4])]
+    if QM:
+        p2_inter += [(O.SEND, P2.QP, BUS_S0, [P2.LNP, o7 + 7, o7 + 6, o7 + 5, o7 + 4]), (O.SEND, P2.QP, BUS_S1, [P2.LNP, o7 + 3, o7 + 2, o7 + 1, o7])]
     p2_tab = O.interaction_table(p2_inter)
     fri_inter = [(O.SEND, ACTIVE, BUS_E0, [LN, K2, E0, E0 + 1, E0 + 2, E0 + 3]), (O.SEND, ACTIVE, BUS_E1, [LN, K2, E1, E1 + 1, E1 + 2, E1 + 3]),
                  (O.SEND, L_WIRED, BUS_Q, [IDX, OWN, OWN + 1, OWN + 2, OWN + 3])]
     if T:
         fri_inter.append((O.RECEIVE, ACTIVE, BUS_BF, [LN, BETA, BETA + 1, BETA + 2, BETA + 3]))
     fri_tab = O.interaction_table(fri_inter)
-    q_tab = O.interaction_table([(O.RECEIVE, 5, BUS_Q, [0, 1, 2, 3, 4])])
+    q_tab = O.interaction_table([(O.RECEIVE, 5, BUS_Q, [QUERIES_PRE, 1, 2, 3, 4]), (O.RECEIVE, 5, BUS_I, [0, QUERIES_PRE])] if QM else [(O.RECEIVE, 5, BUS_Q, [0, 1, 2, 3, 4])])
     r_inter = [(O.RECEIVE, RP, BUS_R0, [0, 1, 2, 3, 4]), (O.RECEIVE, RP, BUS_R1, [0, 5, 6, 7, 8])]
     if T:
         r_inter += [(O.RECEIVE, 9, BUS_B, [0, RP + 1, RP + 2, RP + 3, RP + 4]), (O.SEND, RP + 5, BUS_BF, [0, RP + 1, RP + 2, RP + 3, RP + 4])]
@@ -286,6 +360,14 @@ def machine_layers(view, capacity=None):
     def table_prog(pre_width, main_width=4):
         return O.air_program(pre_width + main_width, NP, [(O.SEL_FIRST, [(1, [V(pre_width + main_width - 1)])])])
     pub = (list(final) + [int(v) for v in capacity]) if T else ([c for b in betas for c in b] + list(final))
+    if QM:
+        M0 = S_PRE
+        s_tab = O.interaction_table([(O.RECEIVE, S_ROW, BUS_S0, [S_C] + [M0 + S_W + j for j in range(4)]), (O.RECEIVE, S_ROW, BUS_S1, [S_C] + [M0 + S_W + j for j in range(4, 8)])]
+                                    + [(O.SEND, S_ACT + j, BUS_I, [S_KQ + j, M0 + S_IDX + j]) for j in range(8)])
+        return ([p2_trace, fri_trace, qmain, rmain, smain], [None, None, qpre, rpre, spre],
+                [P2.program(fri_layers=True, n_public=NP, transcript=4, queries=0), program(R, wired=True, transcript=True),
+                 table_prog(QUERIES_PRE), table_prog(RP, ROOTS_MAIN_T), samples_program(R, Q, query_phase[1], NP)],
+                [p2_tab, fri_tab, q_tab, r_tab, s_tab], pub)
     return ([p2_trace, fri_trace, np.zeros((1 << lr_q, 4), dtype=np.uint32), rmain], [None, None, qpre, rpre],
             [P2.program(fri_layers=True, n_public=NP, transcript=4 if T else None), program(R, wired=True, transcript=T),
              table_prog(QUERIES_PRE), table_prog(RP, ROOTS_MAIN_T if T else 4)],

@@ -37,6 +37,7 @@ WIDTH = 360
 N_PUBLIC = 9
 LNP, KP, M = 357, 358, 359          # the FRI-layers variant's use of the three spare columns (program(fri_layers=True))
 TRS, WIDTH_T = 360, 364             # the transcript variant (program(fri_layers=True, transcript=cap_pub)): one more flag column
+QP, QF = 361, 362                   # ... and its query-phase rows (program(..., queries=final_pub)): a sponge row whose outputs are sampled; the first of them
 
 
 def X3E(r):
@@ -78,13 +79,18 @@ def _linear_def(col, form):
     return [_term(1, [V(col)])] + [_term(P - form[c], [V(c)]) for c in sorted(form) if form[c] % P]
 
 
-def program(fri_layers=False, n_public=N_PUBLIC, transcript=None):
+def program(fri_layers=False, n_public=N_PUBLIC, transcript=None, queries=None):
     """fri_layers: the variant wired to the FRI-fold chip (tests/fri_air.py): paths of different depths, no public root (END rows send
     their digest on a bus instead), LNP / KP / M in the spare columns.
     transcript = index of the first of 8 public values (the duplex challenger's capacity as the FRI commit phase finds it): the trace
     then STARTS with transcript rows (TRS = 1, LNP = 0, 1, 2, ...), a sponge chain over the layer roots -- row l absorbs root_l into the
     rate half (sent to the ROOTS table like a path's digest), keeps the capacity of row l - 1 (row 0: the public one), and sends
-    (l, out[7], out[6], out[5], out[4]) = the challenge beta_l on a bus of its own"""
+    (l, out[7], out[6], out[5], out[4]) = the challenge beta_l on a bus of its own.
+    queries = index of the first of 4 public values (the final value): the QUERY PHASE of the transcript follows the chain -- row R (QF)
+    absorbs (final value [4], proof-of-work witness) over the rate words 0..4 and keeps the rest of the previous row's output (duplex
+    challenger: inputs overwrite the front of the rate); every further QP row permutes the previous row's whole output.  The rate
+    outputs of the QP rows are the sampled words (out[7] first): the proof-of-work word, then one word per query index -- sent to the
+    SAMPLES chip (tests/fri_air.py), which takes their bits"""
     ME, rc_e, rc_i, diag = pyref.ME, PARAMS["external_rc"], PARAMS["internal_rc"], PARAMS["internal_diag"]
     cons = []
     for i in range(16):
@@ -161,20 +167,47 @@ def program(fri_layers=False, n_public=N_PUBLIC, transcript=None):
         for j in range(8):
             cons.append((O.SEL_FIRST, [_term(1, [V(IN + 8 + j)]), _term(P - 1, [V(transcript + j, public=True)])]))
         cons.append((O.SEL_TRANSITION, [_term(1, [V(TRS, True)]), _term(P - 1, [V(TRS), V(TRS, True)])]))      # transcript rows are a prefix
-        cons.append((O.SEL_TRANSITION, [_term(1, [V(TRS, True), V(LNP, True)]), _term(P - 1, [V(TRS, True), V(LNP)]), _term(P - 1, [V(TRS, True)])]))
+        if queries is None:
+            cons.append((O.SEL_TRANSITION, [_term(1, [V(TRS, True), V(LNP, True)]), _term(P - 1, [V(TRS, True), V(LNP)]), _term(P - 1, [V(TRS, True)])]))
         cons.append((O.SEL_TRANSITION, [_term(1, [V(TRS, True)]), _term(P - 1, [V(TRS, True), V(SPG, True)])]))   # ... chained through the capacity
-        cons.append((O.SEL_ALL, [_term(1, [V(SPG)]), _term(P - 1, [V(SPG), V(TRS)])]))                         # and nothing else is
+        if queries is None:
+            cons.append((O.SEL_ALL, [_term(1, [V(SPG)]), _term(P - 1, [V(SPG), V(TRS)])]))                     # and nothing else is
         for f in (CH, END, SS, BIT, M):
             cons.append((O.SEL_ALL, [_term(1, [V(TRS), V(f)])]))
+        if queries is not None:
+            o7 = OUTE(7)
+            for f in (QP, QF):
+                cons.append((O.SEL_ALL, [_term(1, [V(f), V(f)]), _term(P - 1, [V(f)])]))
+            cons.append((O.SEL_ALL, [_term(1, [V(QF)]), _term(P - 1, [V(QF), V(QP)])]))                          # the first query row is one
+            cons.append((O.SEL_ALL, [_term(1, [V(QP), V(TRS)])]))
+            cons.append((O.SEL_FIRST, [_term(1, [V(QF)])]))
+            cons.append((O.SEL_TRANSITION, [_term(1, [V(QF, True)]), _term(P - 1, [V(TRS)]), _term(1, [V(TRS), V(TRS, True)])]))      # QF' = TRS (1 - TRS'): right behind the chain
+            cons.append((O.SEL_TRANSITION, [_term(1, [V(QP, True)]), _term(P - 1, [V(QP, True), V(QP)]), _term(P - 1, [V(QF, True)])]))  # a query row is the first or follows one
+            # the row counter runs on through both kinds of rows
+            cons.append((O.SEL_TRANSITION, [_term(1, [V(TRS, True), V(LNP, True)]), _term(P - 1, [V(TRS, True), V(LNP)]), _term(P - 1, [V(TRS, True)]),
+                                            _term(1, [V(QP, True), V(LNP, True)]), _term(P - 1, [V(QP, True), V(LNP)]), _term(P - 1, [V(QP, True)])]))
+            cons.append((O.SEL_TRANSITION, [_term(1, [V(QP, True)]), _term(P - 1, [V(QP, True), V(SPG, True)])]))  # the capacity is kept
+            cons.append((O.SEL_ALL, [_term(1, [V(SPG)]), _term(P - 1, [V(SPG), V(TRS)]), _term(P - 1, [V(SPG), V(QP)])]))
+            for j in range(5, 8):                                                                                # rate words the inputs do not reach
+                cons.append((O.SEL_TRANSITION, [_term(1, [V(QP, True), V(IN + j, True)]), _term(P - 1, [V(QP, True), V(o7 + j)])]))
+            for j in range(5):                                                                                   # later rows: nothing absorbed
+                cons.append((O.SEL_TRANSITION, [_term(1, [V(QP, True), V(IN + j, True)]), _term(P - 1, [V(QP, True), V(o7 + j)]),
+                                                _term(P - 1, [V(QF, True), V(IN + j, True)]), _term(1, [V(QF, True), V(o7 + j)])]))
+            for j in range(4):                                                                                   # the first absorbs the final value (and a free witness)
+                cons.append((O.SEL_ALL, [_term(1, [V(QF), V(IN + j)]), _term(P - 1, [V(QF), V(queries + j, public=True)])]))
+            for f in (CH, END, SS, BIT, M):
+                cons.append((O.SEL_ALL, [_term(1, [V(QP), V(f)])]))
         return O.air_program(WIDTH_T, n_public, cons)
     return O.air_program(WIDTH, n_public, cons)
 
 
-def layer_paths_trace(paths, log_n, transcript=None):
+def layer_paths_trace(paths, log_n, transcript=None, queries=None):
     """the FRI-layers variant's trace: paths = [(layer, leaf index, pair [8 values], siblings [[8] x depth], multiplicity)], one leaf row
     (the sponge over the pair) + depth compression rows each -> (trace [2^log_n][WIDTH], roots).
     transcript = (capacity [8], layer roots [[8] x R]): the transcript variant -- R sponge rows over the roots come first, the rows are
-    WIDTH_T wide -> (trace, roots, betas)"""
+    WIDTH_T wide -> (trace, roots, betas)
+    queries = (final value [4], witness, rows): `rows` query-phase sponge rows follow the chain -> (trace, roots, betas, samples), samples
+    = [rows][8] in the order the challenger hands them out (out[7] first)"""
     rows, roots, cnt = [], [], 0
     betas = []
     if transcript is not None:
@@ -185,6 +218,16 @@ def layer_paths_trace(paths, log_n, transcript=None):
             rows.append(r + [1, 0, 0, 0])
             betas.append([out[7], out[6], out[5], out[4]])
             cap = out[8:]
+        samples = []
+        if queries is not None:
+            final, witness, n_rows = queries
+            state = [int(v) % P for v in final] + [int(witness) % P] + out[5:8] + cap
+            for i in range(n_rows):
+                r, out = row(state, 0, 0, 0, 0, 1, 0)
+                r[LNP] = len(layer_roots) + i
+                rows.append(r + [0, 1, 1 if i == 0 else 0, 0])
+                samples.append([out[7 - j] for j in range(8)])
+                state = list(out)
     for layer, index, pair, sibs, mult in paths:
         r, out = row([int(v) % P for v in pair] + [0] * 8, 0, 0, 0, cnt, 0, 1)
         r[LNP], r[KP], r[M] = layer, 2 * index % P, mult
@@ -207,6 +250,8 @@ def layer_paths_trace(paths, log_n, transcript=None):
         pad = pad + [0, 0, 0, 0]
     assert len(rows) <= 1 << log_n
     rows += [pad] * ((1 << log_n) - len(rows))
+    if queries is not None:
+        return np.array(rows, dtype=np.uint64).astype(np.uint32), roots, betas, samples
     if transcript is not None:
         return np.array(rows, dtype=np.uint64).astype(np.uint32), roots, betas
     return np.array(rows, dtype=np.uint64).astype(np.uint32), roots

@@ -298,3 +298,98 @@ def test_transcript_machine_of_a_golden_proofs_view(oracle, name, shape):
     assert _machine_rejected(O, tampered(0, lambda t: t.__setitem__((1, P2.LNP), 3)), pre, progs, tables, pub, shape)
     # the last transcript row left out (its flag cleared): the ROOTS table still expects its root and its challenge
     assert _machine_rejected(O, tampered(0, lambda t: t.__setitem__((R - 1, P2.TRS), 0)), pre, progs, tables, pub, shape)
+
+
+# ------------------------------------------------------------------ the query-phase machine: proof of work and query indices in-circuit
+@pytest.mark.parametrize("name,shape", [("v1_6x8", (1, 10, 4)), ("v1_10x16", (1, 8, 6))])
+def test_query_phase_machine_of_a_golden_proofs_view(oracle, name, shape):
+    """the transcript machine whose sponge chain goes on through the final value and the proof-of-work witness: the words it then hands
+    out are decomposed by a fifth chip (SAMPLES) -- the first one's low bits must be zero (proof of work), the others' low bits are the
+    query indices, which reach the QUERIES table's MAIN column and from there the fold rows.  The key holds no index any more.  Under
+    the oracle's prover and three verifiers; refused: another index in the table, a query walked from another index, another witness,
+    a word that is not the sponge's, a non-canonical decomposition, a proof-of-work word with a low bit set, a query row left out"""
+    from zktls_amd.device import fri_view_shard_paths, fri_view_transcript, fri_view_witness
+    import poseidon2_air as P2
+    O = oracle
+    g = GOLDEN[name]
+    b = load(name)
+    prm0 = Params(*g["shape"])
+    view = fri_view_shard_paths(b, g["log_n"], g["width"], g["public"], prm0)
+    _, _, capacity, _ = fri_view_transcript(b, g["log_n"], g["width"], g["public"], prm0)
+    witness = fri_view_witness(b, g["log_n"], g["width"], g["public"], prm0)
+    pow_bits, nq, R = g["shape"][2], len(view["queries"]), g["log_n"]
+    traces, pre, progs, tables, pub = F.machine_layers(view, capacity=capacity, query_phase=(witness, pow_bits))
+    lns, ws, pws = shape_of(traces, pre)
+    assert ws == [P2.WIDTH_T, F.width_of(R, True), 4, 8, F.S_MAIN] and pws == [0, 0, 8, 12, F.S_PRE] and lns == sorted(lns, reverse=True) and len(pub) == 12
+    n_rows = F.sample_rows(nq)
+    assert all(int(traces[0][R + i, P2.QP]) == 1 and int(traces[0][R + i, P2.LNP]) == R + i for i in range(n_rows)) and int(traces[0][R + n_rows, P2.QP]) == 0
+    assert [int(v) for v in pre[2][:nq, 0]] == list(range(nq))                     # the key lists the queries by number, not by index
+    for prog in progs:
+        assert O.air_log_quotient_degree(prog) == 1
+    oprm, prm = O.default_params(*shape), Params(*shape)
+    root = O.machine_setup(pre, lns, oprm)
+    proof = O.prove_machine_keyed(traces, pre, progs, tables, pub, oprm)
+    assert O.verify_machine_keyed(proof, lns, ws, pws, root, progs, tables, pub, oprm) == 0
+    assert verify_machine_keyed(proof, lns, ws, pws, root, progs, tables, pub, prm) == (0, 0)
+    assert pyverify_chips.verify(proof.tobytes(), lns, ws, pub, shape[0], shape[1], shape[2], programs=progs, tables=tables, pre_widths=pws,
+                                 pre_root=[int(v) for v in root]) is True
+
+    # the library builds the same programs, and its entry point for this machine accepts the oracle's proof
+    from zktls_amd.device import fri_indices_programs, fri_transcript_programs, verify_fri_indices
+    p2q, smp = fri_indices_programs(R, pow_bits)
+    assert p2q.tolist() == progs[0].tolist() and smp.tolist() == progs[4].tolist() and fri_transcript_programs(R)[1].tolist() == progs[1].tolist()
+    assert verify_fri_indices(proof, view["final"], capacity, R, nq, pow_bits, root, prm) == (0, 0)          # neither a challenge nor an index is handed over
+    assert verify_fri_indices(proof, view["final"], capacity, R, nq, pow_bits + 1, root, prm)[0] == -6       # (another proof-of-work claim: another program)
+    other = list(view["final"])
+    other[2] = (other[2] + 1) % P
+    assert verify_fri_indices(proof, other, capacity, R, nq, pow_bits, root, prm)[0] == -6
+
+    def tampered(chip, fn):
+        t = [x.copy() for x in traces]
+        fn(t[chip])
+        return t
+
+    def bump(r, c, d=1):
+        return lambda t: t.__setitem__((r, c), (int(t[r, c]) + d) % P)
+    # another index in the QUERIES table than the one the SAMPLES chip derives
+    assert _machine_rejected(O, tampered(2, bump(1, 0)), pre, progs, tables, pub, shape)
+    # a query whose fold rows start from another index
+    assert _machine_rejected(O, tampered(1, bump(R, F.IDX)), pre, progs, tables, pub, shape)
+    # another witness on the first query row
+    assert _machine_rejected(O, tampered(0, bump(R, P2.IN + 4)), pre, progs, tables, pub, shape)
+    # the first query row does not keep the chain's rate word 5 / the second does not start from the first's output
+    assert _machine_rejected(O, tampered(0, bump(R, P2.IN + 5)), pre, progs, tables, pub, shape)
+    assert _machine_rejected(O, tampered(0, bump(R + 1, P2.IN + 2)), pre, progs, tables, pub, shape)
+    # a sampled word in the SAMPLES chip that is not the sponge's
+    assert _machine_rejected(O, tampered(4, bump(0, F.S_W + 3)), pre, progs, tables, pub, shape)
+
+    # a decomposition of w + P instead of w (non-canonical): find a word below 2^31 - P
+    def noncanonical(t):
+        for j in range(1, 8):
+            w = int(t[0, F.S_W + j])
+            if w + P < (1 << 31):
+                v = w + P
+                bits = [(v >> i) & 1 for i in range(31)]
+                t[0, F.S_BITS + 31 * j:F.S_BITS + 31 * j + 31] = bits
+                t[0, F.S_H1 + j], t[0, F.S_H2 + j], t[0, F.S_HH + j] = bits[30] & bits[29], bits[28] & bits[27], bits[30] & bits[29] & bits[28] & bits[27]
+                t[0, F.S_IDX + j] = v & ((1 << (R + 1)) - 1)
+                return
+        raise AssertionError("no small word on the first row")
+    try:
+        bad = tampered(4, noncanonical)
+    except AssertionError:
+        bad = None                                                                  # (w < 2^27 - 1 happens with probability 1/15 per word)
+    if bad is not None:
+        assert _machine_rejected(O, bad, pre, progs, tables, pub, shape)
+    # a proof-of-work word with a low bit set (and the word adjusted to match its bits): the sponge's word is another
+    if pow_bits:
+        def pow_bit(t):
+            t[0, F.S_BITS] = 1
+            t[0, F.S_W] = (int(t[0, F.S_W]) + 1) % P
+        assert _machine_rejected(O, tampered(4, pow_bit), pre, progs, tables, pub, shape)
+    # the last query row left out: the SAMPLES chip still expects its words
+    assert _machine_rejected(O, tampered(0, lambda t: t.__setitem__((R + n_rows - 1, P2.QP), 0)), pre, progs, tables, pub, shape)
+    # another final value than the one absorbed
+    pub2 = list(pub)
+    pub2[1] = (pub2[1] + 1) % P
+    assert _machine_rejected(O, traces, pre, progs, tables, pub2, shape)

@@ -264,3 +264,83 @@ def test_fullsize_fri_transcript_of_the_headline_shard(ctx, oracle):
     assert proof.tobytes() == O.prove_machine_keyed(traces, pre, progs, tables, pub, oprm).tobytes()
     assert O.verify_machine_keyed(proof, lns, ws, pws, key.root, progs, tables, pub, oprm) == 0
     key.close()
+
+
+# ------------------------------------------------------------------ the query-phase machine: proof of work and query indices in-circuit
+@pytest.mark.parametrize("log_n,width,inner,outer", [(6, 8, (1, 9, 4), (1, 12, 4)), (11, 16, (1, 20, 8), (1, 16, 6)), (8, 8, (1, 40, 0), (1, 10, 4))])
+def test_fri_indices_of_a_shard_proof_in_circuit(ctx, oracle, log_n, width, inner, outer):
+    """a shard proof made here; the machine whose sponge chain runs on through the final value and the proof-of-work witness and whose
+    SAMPLES chip takes the bits of the words it then hands out: key (no index in it) and proof bytes against the oracle on the
+    independently restated arrays, four verifiers; indices or a witness that the transcript does not produce are refused by the prover"""
+    from zktls_amd.device import fri_view_shard_paths, fri_view_transcript, fri_view_witness, verify_fri_indices
+    import poseidon2_air as P2
+    O = oracle
+    iprm, prm, oprm = Params(*inner), Params(*outer), O.default_params(*outer)
+    pv = [4, 5]
+    trace = ctx.gen_trace(SEED, 6, log_n, width)
+    shard_proof = ctx.prove_shard(trace, log_n, width, pv, iprm)
+    trace.free()
+    view = fri_view_shard_paths(shard_proof, log_n, width, pv, iprm)
+    _, _, capacity, _ = fri_view_transcript(shard_proof, log_n, width, pv, iprm)
+    witness = fri_view_witness(shard_proof, log_n, width, pv, iprm)
+    pow_bits, nq = inner[2], len(view["queries"])
+    traces, pre, progs, tables, pub = F.machine_layers(view, capacity=capacity, query_phase=(witness, pow_bits))
+    lns, ws, pws = shape_of(traces, pre)
+    assert ws[0] == P2.WIDTH_T and ws[4] == F.S_MAIN and pws == [0, 0, 8, 12, F.S_PRE] and len(pub) == 12 and lns == sorted(lns, reverse=True)
+    key = ctx.fri_indices_key(view, pow_bits, prm)
+    assert key.root.tolist() == O.machine_setup(pre, lns, oprm).tolist()
+    proof = ctx.prove_fri_indices(key, view, capacity, witness, pow_bits, prm)
+    oproof = O.prove_machine_keyed(traces, pre, progs, tables, pub, oprm)
+    assert proof.tobytes() == oproof.tobytes(), "query-phase machine proof differs from the oracle's"
+    assert verify_fri_indices(proof, view["final"], capacity, log_n, nq, pow_bits, key.root, prm) == (0, 0)
+    assert verify_machine_keyed(proof, lns, ws, pws, key.root, progs, tables, pub, prm) == (0, 0)
+    assert O.verify_machine_keyed(proof, lns, ws, pws, key.root, progs, tables, pub, oprm) == 0
+    assert pyverify_chips.verify(proof.tobytes(), lns, ws, pub, outer[0], outer[1], outer[2], programs=progs, tables=tables, pre_widths=pws,
+                                 pre_root=[int(v) for v in key.root]) is True
+    # the key does not depend on the indices: a view with another index has the same key, and the prover refuses it
+    bad = dict(view)
+    bad["queries"] = [tuple(q) for q in view["queries"]]
+    i0, v0, s0 = bad["queries"][0]
+    bad["queries"][0] = (i0 ^ 1, v0, s0)
+    okey = ctx.fri_indices_key(bad, pow_bits, prm)
+    assert okey.root.tolist() == key.root.tolist()
+    with pytest.raises(Exception):
+        ctx.prove_fri_indices(key, bad, capacity, witness, pow_bits, prm)
+    # another witness: other words come out of the sponge
+    with pytest.raises(Exception):
+        ctx.prove_fri_indices(key, view, capacity, (witness + 1) % P, pow_bits, prm)
+    # another capacity / final value / proof-of-work claim at the verifier
+    other = list(capacity)
+    other[5] = (other[5] + 1) % P
+    assert verify_fri_indices(proof, view["final"], other, log_n, nq, pow_bits, key.root, prm)[0] == -6
+    assert verify_fri_indices(proof, view["final"], capacity, log_n, nq, pow_bits + 1, key.root, prm)[0] == -6
+    key.close()
+    okey.close()
+
+
+def test_fullsize_fri_indices_of_the_headline_shard(ctx, oracle):
+    """the headline shard proof's 100 queries x 20 layers with the transcript's commit AND query phase in-circuit: bytes against the oracle, timing"""
+    from zktls_amd.device import fri_view_shard_paths, fri_view_transcript, fri_view_witness, verify_fri_indices
+    O = oracle
+    log_n, width = 20, 256
+    iprm, prm, oprm = Params(1, 100, 16), Params(1, 100, 16), O.default_params(1, 100, 16)
+    trace = ctx.gen_trace(SEED, 33, log_n, width)
+    shard_proof = ctx.prove_shard(trace, log_n, width, [1, 2, 3], iprm)
+    trace.free()
+    view = fri_view_shard_paths(shard_proof, log_n, width, [1, 2, 3], iprm)
+    _, _, capacity, _ = fri_view_transcript(shard_proof, log_n, width, [1, 2, 3], iprm)
+    witness = fri_view_witness(shard_proof, log_n, width, [1, 2, 3], iprm)
+    key = ctx.fri_indices_key(view, 16, prm)
+    proof = ctx.prove_fri_indices(key, view, capacity, witness, 16, prm)
+    t0 = time.perf_counter()
+    proof = ctx.prove_fri_indices(key, view, capacity, witness, 16, prm)
+    t1 = time.perf_counter()
+    assert verify_fri_indices(proof, view["final"], capacity, log_n, 100, 16, key.root, prm) == (0, 0)
+    t2 = time.perf_counter()
+    print("\nFRI layers + transcript (commit and query phase) of a 2^20 x 256 shard proof in-circuit: machine proof %.1f ms, %d bytes, host verification %.1f ms"
+          % ((t1 - t0) * 1e3, proof.size, (t2 - t1) * 1e3))
+    traces, pre, progs, tables, pub = F.machine_layers(view, capacity=capacity, query_phase=(witness, 16))
+    lns, ws, pws = shape_of(traces, pre)
+    assert proof.tobytes() == O.prove_machine_keyed(traces, pre, progs, tables, pub, oprm).tobytes()
+    assert O.verify_machine_keyed(proof, lns, ws, pws, key.root, progs, tables, pub, oprm) == 0
+    key.close()

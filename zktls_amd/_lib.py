@@ -44,6 +44,7 @@ EXPORTS = [
     "zkhip_fri_layers_key", "zkhip_fri_layers_proof_size", "zkhip_prove_fri_layers", "zkhip_verify_fri_layers",
     "zkhip_fri_transcript_chip_air", "zkhip_p2chip_air_fri_transcript", "zkhip_fri_transcript_key", "zkhip_fri_transcript_proof_size",
     "zkhip_prove_fri_transcript", "zkhip_verify_fri_transcript",
+    "zkhip_fri_indices_program", "zkhip_fri_indices_key", "zkhip_fri_indices_proof_size", "zkhip_prove_fri_indices", "zkhip_verify_fri_indices",
     "zkhip_p2chip_air", "zkhip_p2chip_gen_merkle_trace", "zkhip_merkle_paths_proof_size", "zkhip_prove_merkle_paths", "zkhip_verify_merkle_paths",
     "zkhip_sha256_air", "zkhip_sha256_digest", "zkhip_sha256_pad", "zkhip_sha256_gen_trace", "zkhip_sha256_proof_size", "zkhip_prove_sha256", "zkhip_verify_sha256",
 ]
@@ -233,6 +234,14 @@ def load():
     L.zkhip_fri_transcript_proof_size.argtypes = [C.c_int, C.c_size_t, C.POINTER(Params)]
     L.zkhip_prove_fri_transcript.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_size_t, u32p, u32p, u32p, u32p, u32p, u32p, u32p, C.POINTER(Params), u8p, C.c_size_t, C.POINTER(C.c_size_t)]
     L.zkhip_verify_fri_transcript.argtypes = [u8p, C.c_size_t, C.c_int, C.c_size_t, u32p, u32p, u32p, C.POINTER(Params), C.POINTER(C.c_int)]
+    L.zkhip_fri_indices_program.restype = C.c_size_t
+    L.zkhip_fri_indices_program.argtypes = [C.c_int, C.c_int, C.c_int, u32p, C.c_size_t]
+    L.zkhip_fri_indices_key.argtypes = [C.c_void_p, C.c_int, C.c_size_t, C.c_int, u32p, u32p, C.POINTER(Params), C.POINTER(C.c_void_p), u32p]
+    L.zkhip_fri_indices_proof_size.restype = C.c_size_t
+    L.zkhip_fri_indices_proof_size.argtypes = [C.c_int, C.c_size_t, C.c_int, C.POINTER(Params)]
+    L.zkhip_prove_fri_indices.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_size_t, C.c_int, u32p, u32p, u32p, u32p, u32p, u32p, u32p, C.c_uint32,
+                                          C.POINTER(Params), u8p, C.c_size_t, C.POINTER(C.c_size_t)]
+    L.zkhip_verify_fri_indices.argtypes = [u8p, C.c_size_t, C.c_int, C.c_size_t, C.c_int, u32p, u32p, u32p, C.POINTER(Params), C.POINTER(C.c_int)]
     for f in (L.zkhip_fri_layers_chip_air, L.zkhip_p2chip_air_fri_layers, L.zkhip_fri_transcript_chip_air, L.zkhip_p2chip_air_fri_transcript):
         f.restype = C.c_size_t
         f.argtypes = [C.c_int, u32p, C.c_size_t]

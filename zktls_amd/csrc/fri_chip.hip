@@ -43,6 +43,12 @@ constexpr uint32_t E0 = 0, E1 = 4, BIT = 8, K = 9, X = 10, XI = 11, S = 12, T = 
 constexpr uint32_t K2 = 32, IDX = 33, L_WIRED = 34;
 constexpr uint32_t BUS_E0 = 40, BUS_E1 = 41, BUS_R0 = 42, BUS_R1 = 43, BUS_Q = 44;
 constexpr uint32_t BUS_B = 45, BUS_BF = 46;                  // transcript machine: (layer, beta) from the Poseidon2 chip's transcript rows to the ROOTS table, and from there to the fold rows
+constexpr uint32_t BUS_S0 = 47, BUS_S1 = 48, BUS_I = 49;     // query-phase machine: a sponge row's sampled words (two halves) to the SAMPLES chip, (query, index) from there to QUERIES
+// SAMPLES chip, one row per query-phase sponge row.  Preprocessed: C (the sponge row's number), ROW, ACT[8] (word j is a query index), POW (row 0: word 0
+// is the proof-of-work sample), KQ[8] (the query's number).  Main: W[8] the words, IDX[8] their low layers + 1 bits, H1 H2 HH [8] (canonical-form
+// helpers), 8 x 31 bits.
+constexpr uint32_t S_PRE = 20, S_C = 0, S_ROW = 1, S_ACT = 2, S_POW = 10, S_KQ = 11;
+constexpr uint32_t S_W = 0, S_IDX = 8, S_H1 = 16, S_H2 = 24, S_HH = 32, S_BITS = 40, S_MAIN = 288;
 constexpr uint32_t ROOTS_MAIN_T = 8;                         // ... whose MAIN row is then (paths + 1, beta[4], queries, 0, 0); preprocessed (layer, root[8], 1, 0, 0)
 constexpr uint32_t N_PUBLIC_T = 12;                          // ... and whose public values are the final value and the challenger's capacity
 constexpr uint32_t QUERIES_PRE = 8, ROOTS_PRE = 12;          // QUERIES: (index, value[4], 1, 0, 0); ROOTS: (layer, root[8], 0, 0, 0) + main (count, 0, 0, 0)
@@ -248,6 +254,103 @@ const std::vector<uint32_t>& roots_interactions_transcript() {   // ... the chal
                                          1u, 9u, BUS_B, 5u, 0u, ROOTS_PRE + 1, ROOTS_PRE + 2, ROOTS_PRE + 3, ROOTS_PRE + 4,
                                          0u, ROOTS_PRE + 5, BUS_BF, 5u, 0u, ROOTS_PRE + 1, ROOTS_PRE + 2, ROOTS_PRE + 3, ROOTS_PRE + 4};
     return t;
+}
+
+// ---- the query-phase machine's tables
+const std::vector<uint32_t>& p2_interactions_indices() {      // ... and the query-phase rows send the words they hand out, out[7] first
+    using namespace p2chip;
+    static const std::vector<uint32_t> t = [] {
+        std::vector<uint32_t> v = p2_interactions_transcript();
+        const uint32_t o = oute(7);
+        const uint32_t more[18] = {0u, QP, BUS_S0, 5u, LNP, o + 7, o + 6, o + 5, o + 4, 0u, QP, BUS_S1, 5u, LNP, o + 3, o + 2, o + 1, o};
+        v.insert(v.end(), more, more + 18);
+        v[1] += 2u; v[2] = (uint32_t)v.size();
+        return v;
+    }();
+    return t;
+}
+const std::vector<uint32_t>& queries_interactions_indices() {  // the start of query k: (main index, preprocessed value); and (preprocessed k, main index) from the SAMPLES chip
+    static const std::vector<uint32_t> t{LOOKUP_MAGIC, 2u, 3u + 9u + 6u, 1u, 5u, BUS_Q, 5u, QUERIES_PRE, 1u, 2u, 3u, 4u, 1u, 5u, BUS_I, 2u, 0u, QUERIES_PRE};
+    return t;
+}
+const std::vector<uint32_t>& samples_interactions() {
+    static const std::vector<uint32_t> t = [] {
+        std::vector<uint32_t> v{LOOKUP_MAGIC, 10u, 0u,
+                                1u, S_ROW, BUS_S0, 5u, S_C, S_PRE + S_W, S_PRE + S_W + 1, S_PRE + S_W + 2, S_PRE + S_W + 3,
+                                1u, S_ROW, BUS_S1, 5u, S_C, S_PRE + S_W + 4, S_PRE + S_W + 5, S_PRE + S_W + 6, S_PRE + S_W + 7};
+        for (uint32_t j = 0; j < 8; j++) { const uint32_t e[6] = {0u, S_ACT + j, BUS_I, 2u, S_KQ + j, S_PRE + S_IDX + j}; v.insert(v.end(), e, e + 6); }
+        v[2] = (uint32_t)v.size();
+        return v;
+    }();
+    return t;
+}
+inline size_t sample_rows(size_t nq) { return (1 + nq + 7) / 8; }
+// every word = sum of its 31 bits, in canonical form (P = 2^31 - 2^27 + 1: bits 27..30 all set -> bits 0..26 clear); IDX = the low layers + 1 bits;
+// the proof-of-work word's low pow_bits bits are zero
+std::shared_ptr<const std::vector<uint32_t>> samples_program(int RL, int pow_bits) {
+    static std::mutex mu;
+    static std::map<uint32_t, std::shared_ptr<const std::vector<uint32_t>>> cache;
+    std::lock_guard<std::mutex> lk(mu);
+    const uint32_t key = ((uint32_t)RL << 8) | (uint32_t)pow_bits;
+    auto it = cache.find(key);
+    if (it != cache.end()) return it->second;
+    Builder b;
+    const uint32_t M0 = S_PRE;
+    for (uint32_t j = 0; j < 8; j++) {
+        auto bit = [&](uint32_t i) { return var(M0 + S_BITS + 31u * j + i); };
+        for (uint32_t i = 0; i < 31; i++) b.add(ALL, Terms{{1u, {bit(i), bit(i)}}, {P - 1, {bit(i)}}});
+        Terms w{{1u, {var(M0 + S_W + j)}}};
+        for (uint32_t i = 0; i < 31; i++) w.push_back(Term{neg(1ull << i), {bit(i)}});
+        b.add(ALL, w);
+        b.add(ALL, Terms{{1u, {var(M0 + S_H1 + j)}}, {P - 1, {bit(30), bit(29)}}});
+        b.add(ALL, Terms{{1u, {var(M0 + S_H2 + j)}}, {P - 1, {bit(28), bit(27)}}});
+        b.add(ALL, Terms{{1u, {var(M0 + S_HH + j)}}, {P - 1, {var(M0 + S_H1 + j), var(M0 + S_H2 + j)}}});
+        Terms c;
+        for (uint32_t i = 0; i < 27; i++) c.push_back(Term{1u, {var(M0 + S_HH + j), bit(i)}});
+        b.add(ALL, c);
+        Terms x{{1u, {var(M0 + S_IDX + j)}}};
+        for (uint32_t i = 0; i < (uint32_t)RL + 1u; i++) x.push_back(Term{neg(1ull << i), {bit(i)}});
+        b.add(ALL, x);
+    }
+    if (pow_bits) {
+        Terms c;
+        for (uint32_t i = 0; i < (uint32_t)pow_bits; i++) c.push_back(Term{1u, {var(S_POW), var(M0 + S_BITS + i)}});
+        b.add(ALL, c);
+    }
+    std::vector<uint32_t> p{AIR_MAGIC, 1u, S_PRE + S_MAIN, b.count, N_PUBLIC_T, (uint32_t)(6 + b.body.size())};
+    p.insert(p.end(), b.body.begin(), b.body.end());
+    return cache.emplace(key, std::make_shared<const std::vector<uint32_t>>(std::move(p))).first->second;
+}
+// the chip's preprocessed rows (Montgomery): fixed by the shape alone
+void samples_pre(int RL, size_t nq, int log_rows, std::vector<uint32_t>& t) {
+    t.assign(((size_t)S_PRE) << log_rows, 0u);
+    for (size_t r = 0; r < sample_rows(nq); r++) {
+        uint32_t* row = t.data() + S_PRE * r;
+        row[S_C] = to_monty((uint32_t)RL + (uint32_t)r); row[S_ROW] = MONTY_R1;
+        for (uint32_t j = 0; j < 8; j++) {
+            const size_t slot = 8 * r + j;
+            if (slot == 0) row[S_POW] = MONTY_R1;
+            else if (slot <= nq) { row[S_ACT + j] = MONTY_R1; row[S_KQ + j] = to_monty((uint32_t)(slot - 1)); }
+        }
+    }
+}
+// ... and its main rows from the sampled words (canonical); the low bits of the query words -> drawn
+void samples_main(int RL, size_t nq, int log_rows, const uint32_t* words, std::vector<uint32_t>& t, std::vector<uint32_t>& drawn) {
+    t.assign(((size_t)S_MAIN) << log_rows, 0u);
+    drawn.clear();
+    const uint32_t mask = (1u << (RL + 1)) - 1u;
+    for (size_t r = 0; r < sample_rows(nq); r++) {
+        uint32_t* row = t.data() + S_MAIN * r;
+        for (uint32_t j = 0; j < 8; j++) {
+            const uint32_t w = words[8 * r + j];
+            row[S_W + j] = to_monty(w); row[S_IDX + j] = to_monty(w & mask);
+            for (uint32_t i = 0; i < 31; i++) row[S_BITS + 31 * j + i] = (w >> i) & 1u ? MONTY_R1 : 0u;
+            const uint32_t h1 = (w >> 30) & (w >> 29) & 1u, h2 = (w >> 28) & (w >> 27) & 1u;
+            row[S_H1 + j] = h1 ? MONTY_R1 : 0u; row[S_H2 + j] = h2 ? MONTY_R1 : 0u; row[S_HH + j] = h1 & h2 ? MONTY_R1 : 0u;
+            const size_t slot = 8 * r + j;
+            if (slot >= 1 && slot <= nq) drawn.push_back(w & mask);
+        }
+    }
 }
 
 struct TraceArgs {
@@ -533,39 +636,50 @@ namespace zk {
 namespace p2chip {
 std::shared_ptr<const std::vector<uint32_t>> program_fri_layers(uint32_t n_public);
 std::shared_ptr<const std::vector<uint32_t>> program_fri_transcript(uint32_t n_public, uint32_t cap_pub);
+std::shared_ptr<const std::vector<uint32_t>> program_fri_indices(uint32_t n_public, uint32_t cap_pub, uint32_t final_pub);
 }
 namespace frichip {
 namespace {
 struct WiredMachine {
-    int32_t log_ns[4]; uint32_t widths[4], pre_widths[4];
-    const uint32_t* progs[4]; size_t prog_words[4]; const uint32_t* tabs[4]; size_t tab_words[4];
-    std::shared_ptr<const std::vector<uint32_t>> p[4];
+    int n = 4;                                                 // chips: 5 with the SAMPLES chip of the query-phase machine
+    int32_t log_ns[5]; uint32_t widths[5], pre_widths[5];
+    const uint32_t* progs[5]; size_t prog_words[5]; const uint32_t* tabs[5]; size_t tab_words[5];
+    std::shared_ptr<const std::vector<uint32_t>> p[5];
     std::vector<uint32_t> fri_tab;
 };
 inline int log2_ceil(size_t n, int lo) { int l = lo; while (((size_t)1 << l) < n) l++; return l; }
-inline size_t p2_rows(int layers, size_t nq, bool transcript = false) {
-    return nq * ((size_t)layers + (size_t)layers * ((size_t)layers + 1) / 2) + (transcript ? (size_t)layers : 0);
+inline size_t p2_rows(int layers, size_t nq, bool transcript = false, bool indices = false) {
+    return nq * ((size_t)layers + (size_t)layers * ((size_t)layers + 1) / 2) + (transcript ? (size_t)layers : 0) + (indices ? sample_rows(nq) : 0);
 }
 // transcript: the TRANSCRIPT machine (zkhip_prove_fri_transcript) -- the same four chips; the Poseidon2 chip in its transcript variant
 // (its trace starts with a sponge chain over the layer roots); the ROOTS table with the challenges in its MAIN columns, received once
 // from the transcript row of the layer and handed to the layer's fold rows; the fold chip without public challenges.  Public values:
 // the final value and the challenger's capacity.  Neither the key nor the verifier holds a challenge: "... under the challenges the
 // transcript derives from these layer roots, starting from this challenger state".
-void wired_machine(int layers, size_t nq, WiredMachine& m, bool transcript = false) {
+// pow_bits >= 0: the QUERY-PHASE machine (zkhip_prove_fri_indices) -- the transcript machine whose sponge chain goes on through the final value and the
+// proof-of-work witness of the inner proof (pow_bits: ITS grinding bits); a fifth chip, SAMPLES, takes the bits of the words the chain then hands out:
+// the first one's low bits are zero, the others' low bits are the query indices, which the QUERIES table holds in a MAIN column (received from SAMPLES
+// by query number, handed to the query's first fold row).  The key holds no index any more: "... at the indices the transcript draws".
+void wired_machine(int layers, size_t nq, WiredMachine& m, bool transcript = false, int pow_bits = -1) {
     const uint32_t NP = n_public_of(layers, transcript);
-    m.p[0] = transcript ? p2chip::program_fri_transcript(NP, 4u) : p2chip::program_fri_layers(NP);       // (the capacity follows the final value)
+    const bool QM = pow_bits >= 0;
+    m.p[0] = QM ? p2chip::program_fri_indices(NP, 4u, 0u) : transcript ? p2chip::program_fri_transcript(NP, 4u) : p2chip::program_fri_layers(NP);       // (the capacity follows the final value)
     m.p[1] = program(layers, true, transcript);
     m.p[2] = table_program(layers, QUERIES_PRE, transcript);
     m.p[3] = table_program(layers, ROOTS_PRE, transcript, transcript ? ROOTS_MAIN_T : 4u);
     m.fri_tab = fri_interactions_wired(layers, transcript);
-    m.log_ns[0] = log2_ceil(p2_rows(layers, nq, transcript), 5); m.log_ns[1] = log2_ceil(nq * (size_t)layers, 5);
+    m.log_ns[0] = log2_ceil(p2_rows(layers, nq, transcript, QM), 5); m.log_ns[1] = log2_ceil(nq * (size_t)layers, 5);
     m.log_ns[2] = log2_ceil(nq, 5); m.log_ns[3] = log2_ceil((size_t)layers, 5);
+    if (QM) { m.log_ns[4] = log2_ceil(sample_rows(nq), 5); if (m.log_ns[4] > m.log_ns[3]) m.log_ns[3] = m.log_ns[4]; }
     if (m.log_ns[3] > m.log_ns[2]) m.log_ns[2] = m.log_ns[3];                // tallest first also for few queries
     m.widths[0] = transcript ? p2chip::WIDTH_T : p2chip::WIDTH; m.widths[1] = width_of(layers, true); m.widths[2] = 4; m.widths[3] = transcript ? ROOTS_MAIN_T : 4u;
     m.pre_widths[0] = 0; m.pre_widths[1] = 0; m.pre_widths[2] = QUERIES_PRE; m.pre_widths[3] = ROOTS_PRE;
-    const std::vector<uint32_t>* tabs[4] = {transcript ? &p2_interactions_transcript() : &p2_interactions(), &m.fri_tab, &queries_interactions(),
-                                            transcript ? &roots_interactions_transcript() : &roots_interactions()};
-    for (int c = 0; c < 4; c++) { m.progs[c] = m.p[c]->data(); m.prog_words[c] = m.p[c]->size(); m.tabs[c] = tabs[c]->data(); m.tab_words[c] = tabs[c]->size(); }
+    const std::vector<uint32_t>* tabs[5] = {QM ? &p2_interactions_indices() : transcript ? &p2_interactions_transcript() : &p2_interactions(), &m.fri_tab,
+                                            QM ? &queries_interactions_indices() : &queries_interactions(),
+                                            transcript ? &roots_interactions_transcript() : &roots_interactions(), &samples_interactions()};
+    m.n = QM ? 5 : 4;
+    if (QM) { m.p[4] = samples_program(layers, pow_bits); m.widths[4] = S_MAIN; m.pre_widths[4] = S_PRE; }
+    for (int c = 0; c < m.n; c++) { m.progs[c] = m.p[c]->data(); m.prog_words[c] = m.p[c]->size(); m.tabs[c] = tabs[c]->data(); m.tab_words[c] = tabs[c]->size(); }
 }
 }  // namespace
 }  // namespace frichip
@@ -588,22 +702,25 @@ size_t zkhip_p2chip_air_fri_layers(int layers, uint32_t* program, size_t cap_wor
 
 // the key: QUERIES (index, reduced opening, 1) and ROOTS (layer, root) committed by zkhip_machine_setup
 // T: the key of the TRANSCRIPT machine (the ROOTS rows carry the multiplicity 1 of their challenge, which itself is not in the key)
+// pow_bits >= 0: the key of the QUERY-PHASE machine: QUERIES lists (query number, reduced opening) -- no index -- and the SAMPLES chip's fixed columns join
 static int fri_layers_key_impl(zkhip_ctx* ctx, int layers, size_t n_queries, const uint32_t* indices, const uint32_t* values, const uint32_t* roots,
-                               bool T, const zkhip_params* prm, zkhip_machine_key** key, uint32_t vk[8]) {
+                               bool T, const zkhip_params* prm, zkhip_machine_key** key, uint32_t vk[8], int pow_bits = -1) {
     CHECK_CTX(ctx);
-    if (!indices || !values || !roots || !prm || !key || !vk) return fail(ZKHIP_ERR_INVALID, "fri_layers_key: null argument");
+    const bool QM = pow_bits >= 0;
+    if ((!indices && !QM) || !values || !roots || !prm || !key || !vk) return fail(ZKHIP_ERR_INVALID, "fri_layers_key: null argument");
+    if (pow_bits > 30) return fail(ZKHIP_ERR_INVALID, "fri_indices_key: 0..30 proof-of-work bits");
     int lr;
     ZK_TRY(frichip::shape_ok(layers, n_queries, &lr));
     if (!frichip::canonical(values, 4 * n_queries) || !frichip::canonical(roots, 8 * (size_t)layers))
         return fail(ZKHIP_ERR_INVALID, "fri_layers_key: values must be canonical");
     const uint32_t RP = frichip::ROOTS_PRE;
     frichip::WiredMachine m;
-    frichip::wired_machine(layers, n_queries, m, T);
-    std::vector<uint32_t> qt(((size_t)frichip::QUERIES_PRE) << m.log_ns[2], 0u), rt(((size_t)RP) << m.log_ns[3], 0u);
+    frichip::wired_machine(layers, n_queries, m, T, pow_bits);
+    std::vector<uint32_t> qt(((size_t)frichip::QUERIES_PRE) << m.log_ns[2], 0u), rt(((size_t)RP) << m.log_ns[3], 0u), st;
     for (size_t q = 0; q < n_queries; q++) {
-        if (indices[q] >> (layers + 1)) return fail(ZKHIP_ERR_INVALID, "fri_layers_key: a query index has more than layers + 1 bits");
+        if (!QM && indices[q] >> (layers + 1)) return fail(ZKHIP_ERR_INVALID, "fri_layers_key: a query index has more than layers + 1 bits");
         uint32_t* r = qt.data() + frichip::QUERIES_PRE * q;
-        r[0] = to_monty(indices[q]);
+        r[0] = to_monty(QM ? (uint32_t)q : indices[q]);
         for (int i = 0; i < 4; i++) r[1 + i] = to_monty(values[4 * q + i]);
         r[5] = MONTY_R1;
     }
@@ -616,13 +733,19 @@ static int fri_layers_key_impl(zkhip_ctx* ctx, int layers, size_t n_queries, con
     void *dq, *dr;
     ZK_TRY(ctx_reserve(ctx, S_REC_C, qt.size() * 4, &dq));
     ZK_TRY(ctx_reserve(ctx, S_REC_D, rt.size() * 4, &dr));
+    void* ds = nullptr;
+    if (QM) {
+        frichip::samples_pre(layers, n_queries, m.log_ns[4], st);
+        ZK_TRY(ctx_reserve(ctx, S_REC_E, st.size() * 4, &ds));
+        ZK_HIP(hipMemcpyAsync(ds, st.data(), st.size() * 4, hipMemcpyHostToDevice, ctx->stream));
+    }
     ZK_HIP(hipMemcpyAsync(dq, qt.data(), qt.size() * 4, hipMemcpyHostToDevice, ctx->stream));
     ZK_HIP(hipMemcpyAsync(dr, rt.data(), rt.size() * 4, hipMemcpyHostToDevice, ctx->stream));
     ZK_HIP(hipStreamSynchronize(ctx->stream));
-    zkhip_chip pre[4]{};
-    for (int c = 0; c < 4; c++) { pre[c].log_n = m.log_ns[c]; pre[c].width = m.pre_widths[c]; pre[c].ld = m.pre_widths[c]; pre[c].partner = -1; }
-    pre[2].d_trace = (const uint32_t*)dq; pre[3].d_trace = (const uint32_t*)dr;
-    return zkhip_machine_setup(ctx, pre, 4, prm, key, vk);
+    zkhip_chip pre[5]{};
+    for (int c = 0; c < m.n; c++) { pre[c].log_n = m.log_ns[c]; pre[c].width = m.pre_widths[c]; pre[c].ld = m.pre_widths[c]; pre[c].partner = -1; }
+    pre[2].d_trace = (const uint32_t*)dq; pre[3].d_trace = (const uint32_t*)dr; pre[4].d_trace = (const uint32_t*)ds;
+    return zkhip_machine_setup(ctx, pre, (size_t)m.n, prm, key, vk);
 }
 int zkhip_fri_layers_key(zkhip_ctx* ctx, int layers, size_t n_queries, const uint32_t* indices, const uint32_t* values, const uint32_t* roots,
                          const zkhip_params* prm, zkhip_machine_key** key, uint32_t vk[8]) {
@@ -632,13 +755,28 @@ int zkhip_fri_transcript_key(zkhip_ctx* ctx, int layers, size_t n_queries, const
                              const zkhip_params* prm, zkhip_machine_key** key, uint32_t vk[8]) {
     return fri_layers_key_impl(ctx, layers, n_queries, indices, values, roots, true, prm, key, vk);
 }
+int zkhip_fri_indices_key(zkhip_ctx* ctx, int layers, size_t n_queries, int inner_pow_bits, const uint32_t* values, const uint32_t* roots,
+                          const zkhip_params* prm, zkhip_machine_key** key, uint32_t vk[8]) {
+    if (inner_pow_bits < 0) return fail(ZKHIP_ERR_INVALID, "fri_indices_key: 0..30 proof-of-work bits");
+    return fri_layers_key_impl(ctx, layers, n_queries, nullptr, values, roots, true, prm, key, vk, inner_pow_bits);
+}
 
-static size_t fri_layers_proof_size_impl(int layers, size_t n_queries, const zkhip_params* prm, bool transcript) {
+static size_t fri_layers_proof_size_impl(int layers, size_t n_queries, const zkhip_params* prm, bool transcript, int pow_bits = -1) {
     int lr;
-    if (!prm || frichip::shape_ok(layers, n_queries, &lr) != ZKHIP_OK) return 0;
+    if (!prm || pow_bits > 30 || frichip::shape_ok(layers, n_queries, &lr) != ZKHIP_OK) return 0;
     frichip::WiredMachine m;
-    frichip::wired_machine(layers, n_queries, m, transcript);
-    return zkhip_machine_proof_size_keyed(m.log_ns, m.widths, m.pre_widths, m.progs, m.prog_words, m.tabs, m.tab_words, 4, prm, frichip::n_public_of(layers, transcript));
+    frichip::wired_machine(layers, n_queries, m, transcript, pow_bits);
+    return zkhip_machine_proof_size_keyed(m.log_ns, m.widths, m.pre_widths, m.progs, m.prog_words, m.tabs, m.tab_words, (size_t)m.n, prm, frichip::n_public_of(layers, transcript));
+}
+size_t zkhip_fri_indices_proof_size(int layers, size_t n_queries, int inner_pow_bits, const zkhip_params* prm) {
+    return inner_pow_bits < 0 ? 0 : fri_layers_proof_size_impl(layers, n_queries, prm, true, inner_pow_bits);
+}
+// the query-phase machine's programs that differ from the transcript machine's: which = 0 the Poseidon2 chip (query-phase rows), 1 the SAMPLES chip
+size_t zkhip_fri_indices_program(int which, int layers, int inner_pow_bits, uint32_t* program, size_t cap_words) {
+    if (layers < frichip::MIN_LAYERS || layers > frichip::MAX_LAYERS || inner_pow_bits < 0 || inner_pow_bits > 30 || which < 0 || which > 1) return 0;
+    const auto p = which == 0 ? p2chip::program_fri_indices(frichip::N_PUBLIC_T, 4u, 0u) : frichip::samples_program(layers, inner_pow_bits);
+    if (program && cap_words >= p->size()) std::memcpy(program, p->data(), p->size() * 4);
+    return p->size();
 }
 size_t zkhip_fri_layers_proof_size(int layers, size_t n_queries, const zkhip_params* prm) { return fri_layers_proof_size_impl(layers, n_queries, prm, false); }
 size_t zkhip_fri_transcript_proof_size(int layers, size_t n_queries, const zkhip_params* prm) { return fri_layers_proof_size_impl(layers, n_queries, prm, true); }
@@ -661,21 +799,23 @@ size_t zkhip_p2chip_air_fri_transcript(int layers, uint32_t* program, size_t cap
 // chain must produce `betas`
 static int fri_layers_gen_paths_trace_impl(zkhip_ctx* ctx, int layers, size_t n_queries, const uint32_t* betas, const uint32_t* indices, const uint32_t* values,
                                            const uint32_t* siblings, const uint32_t* roots, const uint32_t* paths, const uint32_t* capacity, int log_rows,
-                                           uint32_t* d_trace, size_t ld) {
+                                           uint32_t* d_trace, size_t ld, const uint32_t* final_witness = nullptr, std::vector<uint32_t>* samples = nullptr) {
     CHECK_CTX(ctx);
     int lr;
     ZK_TRY(frichip::shape_ok(layers, n_queries, &lr));
-    const bool T = capacity != nullptr;
+    const bool T = capacity != nullptr, QM = final_witness != nullptr;           // QM: query-phase rows behind the chain (final value [4], witness -> the sampled words)
+    if (QM && (!T || !samples || !frichip::canonical(final_witness, 5))) return fail(ZKHIP_ERR_INVALID, "fri_indices: bad arguments");
+    const size_t NQR = QM ? frichip::sample_rows(n_queries) : 0;
     if (!betas || !indices || !values || !siblings || !roots || !paths || !d_trace || ld < (T ? p2chip::WIDTH_T : p2chip::WIDTH)) return fail(ZKHIP_ERR_INVALID, "fri_layers_gen_paths_trace: bad arguments");
     if (T && (!frichip::canonical(capacity, 8) || !frichip::canonical(roots, 8 * (size_t)layers))) return fail(ZKHIP_ERR_INVALID, "fri_transcript: values must be canonical");
-    const size_t R = (size_t)layers, np = n_queries * R, used = frichip::p2_rows(layers, n_queries, T), per_q = 4 * R * (R + 1);
+    const size_t R = (size_t)layers, np = n_queries * R, used = frichip::p2_rows(layers, n_queries, T, QM), per_q = 4 * R * (R + 1);
     if (log_rows > MAX_LOG_ROWS || ((size_t)1 << log_rows) < used) return fail(ZKHIP_ERR_INVALID, "fri_layers_gen_paths_trace: 2^log_rows rows do not hold the paths");
     if (!frichip::canonical(betas, 4 * R) || !frichip::canonical(values, 4 * n_queries) || !frichip::canonical(siblings, 4 * np) || !frichip::canonical(paths, per_q * n_queries))
         return fail(ZKHIP_ERR_INVALID, "fri_layers_gen_paths_trace: values must be canonical");
     // the pairs of every (query, layer): fold the chain on the host (canonical words), as build_openings does
     std::vector<uint32_t> leaves(8 * np), sib_off(np), idx(np), depths(np), lay(np), mults(np, 1u), starts(np);
     const int H = layers + 1;
-    size_t row = T ? R : 0;                              // the paths lie behind the transcript rows
+    size_t row = T ? R + NQR : 0;                        // the paths lie behind the transcript rows
     for (size_t q = 0; q < n_queries; q++) {
         uint32_t i = indices[q];
         if (i >> H) return fail(ZKHIP_ERR_INVALID, "fri_layers_gen_paths_trace: a query index has more than layers + 1 bits");
@@ -698,10 +838,11 @@ static int fri_layers_gen_paths_trace_impl(zkhip_ctx* ctx, int layers, size_t n_
     }
     const size_t np8 = 8 * np, npaths_words = per_q * n_queries;
     void* stage;
-    ZK_TRY(ctx_reserve(ctx, S_STAGE, (np8 + npaths_words + 6 * np + np8 + 8 + 12 * R) * 4, &stage));
+    ZK_TRY(ctx_reserve(ctx, S_STAGE, (np8 + npaths_words + 6 * np + np8 + 8 + 12 * R + 8 + 8 * NQR) * 4, &stage));
     uint32_t* d = (uint32_t*)stage;
     uint32_t *d_leaves = d, *d_sibs = d + np8, *d_meta = d_sibs + npaths_words, *d_roots = d_meta + 6 * np;
-    uint32_t *d_cap = d_roots + np8, *d_lroots = d_cap + 8, *d_betas = d_lroots + 8 * R;
+    uint32_t *d_cap = d_roots + np8, *d_lroots = d_cap + 8, *d_betas = d_lroots + 8 * R, *d_fw = d_betas + 4 * R, *d_samples = d_fw + 8;
+    if (QM) ZK_HIP(hipMemcpyAsync(d_fw, final_witness, 20, hipMemcpyHostToDevice, ctx->stream));
     if (T) {
         ZK_HIP(hipMemcpyAsync(d_cap, capacity, 32, hipMemcpyHostToDevice, ctx->stream));
         ZK_HIP(hipMemcpyAsync(d_lroots, roots, 32 * R, hipMemcpyHostToDevice, ctx->stream));
@@ -715,8 +856,10 @@ static int fri_layers_gen_paths_trace_impl(zkhip_ctx* ctx, int layers, size_t n_
     a.mults = d_meta + 4 * np; a.starts = d_meta + 5 * np; a.n_paths = np; a.rows = (uint64_t)1 << log_rows; a.used_rows = used;
     a.trace = d_trace; a.ld = ld; a.roots = d_roots;
     if (T) { a.n_transcript = (uint32_t)layers; a.capacity = d_cap; a.layer_roots = d_lroots; a.betas = d_betas; }
+    if (QM) { a.n_query_rows = (uint32_t)NQR; a.final_witness = d_fw; a.samples = d_samples; samples->resize(8 * NQR); }
     ZK_HIP(launch_p2chip_layer_paths(a, ctx->stream));
     std::vector<uint32_t> got(np8), chain(4 * R);
+    if (QM) ZK_HIP(hipMemcpyAsync(samples->data(), d_samples, 32 * NQR, hipMemcpyDeviceToHost, ctx->stream));
     ZK_HIP(hipMemcpyAsync(got.data(), d_roots, np8 * 4, hipMemcpyDeviceToHost, ctx->stream));
     if (T) ZK_HIP(hipMemcpyAsync(chain.data(), d_betas, 16 * R, hipMemcpyDeviceToHost, ctx->stream));
     ZK_HIP(hipStreamSynchronize(ctx->stream));
@@ -734,24 +877,36 @@ int zkhip_fri_layers_gen_paths_trace(zkhip_ctx* ctx, int layers, size_t n_querie
 
 static int prove_fri_layers_impl(zkhip_ctx* ctx, const zkhip_machine_key* key, int layers, size_t n_queries, const uint32_t* betas, const uint32_t* indices,
                                  const uint32_t* values, const uint32_t* siblings, const uint32_t* roots, const uint32_t* paths, const uint32_t* capacity,
-                                 const zkhip_params* prm, uint8_t* proof, size_t cap, size_t* len) {
+                                 const zkhip_params* prm, uint8_t* proof, size_t cap, size_t* len, const uint32_t* witness = nullptr, int pow_bits = -1) {
     CHECK_CTX(ctx);
     if (!key || !prm || !proof || !len) return fail(ZKHIP_ERR_INVALID, "prove_fri_layers: null argument");
     int lr;
     ZK_TRY(frichip::shape_ok(layers, n_queries, &lr));
-    const bool T = capacity != nullptr;
+    const bool T = capacity != nullptr, QM = pow_bits >= 0;
+    if (QM && (!T || !witness || pow_bits > 30)) return fail(ZKHIP_ERR_INVALID, "prove_fri_indices: bad arguments");
     frichip::WiredMachine m;
-    frichip::wired_machine(layers, n_queries, m, T);
-    void *t_p2, *t_fri, *t_q, *t_r;
+    frichip::wired_machine(layers, n_queries, m, T, pow_bits);
+    void *t_p2, *t_fri, *t_q, *t_r, *t_s = nullptr;
     ZK_TRY(ctx_reserve(ctx, S_REC_A, ((size_t)m.widths[0] << m.log_ns[0]) * 4, &t_p2));
     ZK_TRY(ctx_reserve(ctx, S_REC_B, ((size_t)m.widths[1] << m.log_ns[1]) * 4, &t_fri));
     ZK_TRY(ctx_reserve(ctx, S_CHIP, ((size_t)4 << m.log_ns[2]) * 4, &t_q));
     ZK_TRY(ctx_reserve(ctx, S_CHIP_B, ((size_t)m.widths[3] << m.log_ns[3]) * 4, &t_r));
-    ZK_TRY(fri_layers_gen_paths_trace_impl(ctx, layers, n_queries, betas, indices, values, siblings, roots, paths, capacity, m.log_ns[0], (uint32_t*)t_p2, m.widths[0]));
     std::vector<uint32_t> finals(4 * n_queries);
     ZK_TRY(fri_gen_trace(ctx, layers, n_queries, betas, indices, values, siblings, m.log_ns[1], (uint32_t*)t_fri, m.widths[1], finals.data(), true));
     for (size_t q = 1; q < n_queries; q++)
         if (std::memcmp(finals.data(), finals.data() + 4 * q, 16) != 0) return fail(ZKHIP_ERR_INVALID, "prove_fri_layers: the chains do not end in one value");
+    std::vector<uint32_t> words, smain, drawn;
+    uint32_t fw[5];
+    if (QM) { std::memcpy(fw, finals.data(), 16); fw[4] = *witness; }
+    ZK_TRY(fri_layers_gen_paths_trace_impl(ctx, layers, n_queries, betas, indices, values, siblings, roots, paths, capacity, m.log_ns[0], (uint32_t*)t_p2, m.widths[0],
+                                           QM ? fw : nullptr, QM ? &words : nullptr));
+    if (QM) {                                            // the SAMPLES chip's rows; the words must be the ones the inner proof's verifier drew
+        frichip::samples_main(layers, n_queries, m.log_ns[4], words.data(), smain, drawn);
+        if (pow_bits && (words[0] & ((1u << pow_bits) - 1u))) return fail(ZKHIP_ERR_INVALID, "prove_fri_indices: the witness does not satisfy the proof of work");
+        if (std::memcmp(drawn.data(), indices, 4 * n_queries) != 0) return fail(ZKHIP_ERR_INVALID, "prove_fri_indices: the query indices are not the ones the transcript draws");
+        ZK_TRY(ctx_reserve(ctx, S_REC_C, smain.size() * 4, &t_s));
+        ZK_HIP(hipMemcpyAsync(t_s, smain.data(), smain.size() * 4, hipMemcpyHostToDevice, ctx->stream));
+    }
     // main columns of the tables: QUERIES none (zeros), ROOTS the number of paths per layer
     std::vector<uint32_t> rmain((size_t)m.widths[3] << m.log_ns[3], 0u);
     for (int l = 0; l < layers; l++) {
@@ -759,16 +914,28 @@ static int prove_fri_layers_impl(zkhip_ctx* ctx, const zkhip_machine_key* key, i
         r[0] = to_monty((uint32_t)n_queries + (T ? 1u : 0u));     // the paths, and the transcript row that absorbs the root
         if (T) { for (int i = 0; i < 4; i++) r[1 + i] = to_monty(betas[4 * l + i]); r[5] = to_monty((uint32_t)n_queries); }
     }
-    ZK_HIP(hipMemsetAsync(t_q, 0, ((size_t)4 << m.log_ns[2]) * 4, ctx->stream));
+    std::vector<uint32_t> qmain;
+    if (QM) {                                            // QUERIES main column 0: the index of query q
+        qmain.assign((size_t)4 << m.log_ns[2], 0u);
+        for (size_t q = 0; q < n_queries; q++) qmain[4 * q] = to_monty(indices[q]);
+        ZK_HIP(hipMemcpyAsync(t_q, qmain.data(), qmain.size() * 4, hipMemcpyHostToDevice, ctx->stream));
+    } else
+        ZK_HIP(hipMemsetAsync(t_q, 0, ((size_t)4 << m.log_ns[2]) * 4, ctx->stream));
     ZK_HIP(hipMemcpyAsync(t_r, rmain.data(), rmain.size() * 4, hipMemcpyHostToDevice, ctx->stream));
     ZK_HIP(hipStreamSynchronize(ctx->stream));
     std::vector<uint32_t> pv(frichip::n_public_of(layers, T));
     if (T) { std::memcpy(pv.data(), finals.data(), 16); std::memcpy(pv.data() + 4, capacity, 32); }
     else { std::memcpy(pv.data(), betas, 16 * (size_t)layers); std::memcpy(pv.data() + 4 * (size_t)layers, finals.data(), 16); }
-    zkhip_chip chips[4]{};
-    void* tr[4] = {t_p2, t_fri, t_q, t_r};
-    for (int c = 0; c < 4; c++) { chips[c].d_trace = (const uint32_t*)tr[c]; chips[c].ld = m.widths[c]; chips[c].log_n = m.log_ns[c]; chips[c].width = m.widths[c]; chips[c].partner = -1; }
-    return zkhip_prove_machine_keyed(ctx, key, chips, m.progs, m.prog_words, m.tabs, m.tab_words, 4, pv.data(), pv.size(), prm, proof, cap, len);
+    zkhip_chip chips[5]{};
+    void* tr[5] = {t_p2, t_fri, t_q, t_r, t_s};
+    for (int c = 0; c < m.n; c++) { chips[c].d_trace = (const uint32_t*)tr[c]; chips[c].ld = m.widths[c]; chips[c].log_n = m.log_ns[c]; chips[c].width = m.widths[c]; chips[c].partner = -1; }
+    return zkhip_prove_machine_keyed(ctx, key, chips, m.progs, m.prog_words, m.tabs, m.tab_words, (size_t)m.n, pv.data(), pv.size(), prm, proof, cap, len);
+}
+int zkhip_prove_fri_indices(zkhip_ctx* ctx, const zkhip_machine_key* key, int layers, size_t n_queries, int inner_pow_bits, const uint32_t* betas, const uint32_t* indices,
+                            const uint32_t* values, const uint32_t* siblings, const uint32_t* roots, const uint32_t* paths, const uint32_t capacity[8], uint32_t witness,
+                            const zkhip_params* prm, uint8_t* proof, size_t cap, size_t* len) {
+    if (!capacity || inner_pow_bits < 0) return fail(ZKHIP_ERR_INVALID, "prove_fri_indices: bad arguments");
+    return prove_fri_layers_impl(ctx, key, layers, n_queries, betas, indices, values, siblings, roots, paths, capacity, prm, proof, cap, len, &witness, inner_pow_bits);
 }
 int zkhip_prove_fri_layers(zkhip_ctx* ctx, const zkhip_machine_key* key, int layers, size_t n_queries, const uint32_t* betas, const uint32_t* indices,
                            const uint32_t* values, const uint32_t* siblings, const uint32_t* roots, const uint32_t* paths, const zkhip_params* prm,
@@ -783,9 +950,9 @@ int zkhip_prove_fri_transcript(zkhip_ctx* ctx, const zkhip_machine_key* key, int
 }
 
 static int verify_fri_layers_impl(const uint8_t* proof, size_t len, int layers, size_t n_queries, const uint32_t* betas, const uint32_t final_value[4],
-                                  const uint32_t* capacity, const uint32_t vk[8], const zkhip_params* prm, int* reason) {
+                                  const uint32_t* capacity, const uint32_t vk[8], const zkhip_params* prm, int* reason, int pow_bits = -1) {
     int lr;
-    if (!proof || (!betas && !capacity) || !final_value || !vk || !prm || frichip::shape_ok(layers, n_queries, &lr) != ZKHIP_OK) {
+    if (!proof || (!betas && !capacity) || !final_value || !vk || !prm || pow_bits > 30 || frichip::shape_ok(layers, n_queries, &lr) != ZKHIP_OK) {
         if (reason) *reason = 1;
         return fail(ZKHIP_ERR_VERIFY, "verify_fri_layers: bad arguments");
     }
@@ -794,8 +961,13 @@ static int verify_fri_layers_impl(const uint8_t* proof, size_t len, int layers, 
     if (T) { std::memcpy(pv.data(), final_value, 16); std::memcpy(pv.data() + 4, capacity, 32); }
     else { std::memcpy(pv.data(), betas, 16 * (size_t)layers); std::memcpy(pv.data() + 4 * (size_t)layers, final_value, 16); }
     frichip::WiredMachine m;
-    frichip::wired_machine(layers, n_queries, m, T);
-    return zkhip_verify_machine_keyed(proof, len, m.log_ns, m.widths, m.pre_widths, vk, m.progs, m.prog_words, m.tabs, m.tab_words, 4, pv.data(), pv.size(), prm, reason);
+    frichip::wired_machine(layers, n_queries, m, T, pow_bits);
+    return zkhip_verify_machine_keyed(proof, len, m.log_ns, m.widths, m.pre_widths, vk, m.progs, m.prog_words, m.tabs, m.tab_words, (size_t)m.n, pv.data(), pv.size(), prm, reason);
+}
+int zkhip_verify_fri_indices(const uint8_t* proof, size_t len, int layers, size_t n_queries, int inner_pow_bits, const uint32_t final_value[4], const uint32_t capacity[8],
+                             const uint32_t vk[8], const zkhip_params* prm, int* reason) {
+    if (!capacity || inner_pow_bits < 0) { if (reason) *reason = 1; return fail(ZKHIP_ERR_VERIFY, "verify_fri_indices: bad arguments"); }
+    return verify_fri_layers_impl(proof, len, layers, n_queries, nullptr, final_value, capacity, vk, prm, reason, inner_pow_bits);
 }
 int zkhip_verify_fri_layers(const uint8_t* proof, size_t len, int layers, size_t n_queries, const uint32_t* betas, const uint32_t final_value[4],
                             const uint32_t vk[8], const zkhip_params* prm, int* reason) {

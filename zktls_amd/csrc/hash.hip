@@ -641,7 +641,7 @@ __device__ __forceinline__ void p2chip_layer_paths_kernel_body(const p2chip::Lay
     // transcript variant: four more columns per row (TRS and three unused); the one lane past the paths and the padding walks the sponge
     // chain over the layer roots (a chain: <= 22 permutations one after the other)
     const bool tv = a.n_transcript != 0;
-    auto tail = [&](uint32_t* t, uint32_t trs) { if (tv) { t[TRS] = trs; t[TRS + 1] = 0u; t[TRS + 2] = 0u; t[TRS + 3] = 0u; } };
+    auto tail = [&](uint32_t* t, uint32_t trs, uint32_t qp = 0u, uint32_t qf = 0u) { if (tv) { t[TRS] = trs; t[QP] = qp; t[QF] = qf; t[TRS + 3] = 0u; } };
     if (tv && p == a.n_paths + (a.rows - a.used_rows)) {
         uint32_t in[16], out[16];
         for (int j = 0; j < 8; j++) in[8 + j] = to_monty(a.capacity[j]);
@@ -653,6 +653,15 @@ __device__ __forceinline__ void p2chip_layer_paths_kernel_body(const p2chip::Lay
             tail(t, MONTY_R1);
             for (int j = 0; j < 4; j++) a.betas[4 * l + j] = from_monty(out[7 - j]);
             for (int j = 0; j < 8; j++) in[8 + j] = out[8 + j];
+        }
+        // the query phase: the final value and the witness over the front of the rate (the rest of the last output stays), then plain permutations
+        for (uint32_t i = 0; i < a.n_query_rows; i++, t += a.ld) {
+            for (int j = 0; j < 16; j++) in[j] = out[j];
+            if (i == 0) for (int j = 0; j < 5; j++) in[j] = to_monty(a.final_witness[j]);
+            p2chip_fill_row(t, in, 0u, 0u, 0u, 0u, 1u, 0u, out);
+            t[LNP] = to_monty(a.n_transcript + i); t[KP] = 0u; t[M] = 0u;
+            tail(t, 0u, MONTY_R1, i == 0 ? MONTY_R1 : 0u);
+            for (int j = 0; j < 8; j++) a.samples[8 * i + j] = from_monty(out[7 - j]);
         }
         return;
     }

@@ -27,6 +27,11 @@ constexpr uint32_t LNP = 357, KP = 358, M = 359;
 // table like a path's digest), keeps the capacity of row l - 1 (row 0: eight public values, the duplex challenger's capacity as the
 // commit phase finds it) and sends (l, out[7], out[6], out[5], out[4]) = the challenge beta_l on a bus of its own.
 constexpr uint32_t TRS = 360, WIDTH_T = 364;
+// ... and its query-phase rows (the machine of zkhip_prove_fri_indices): behind the chain the duplex challenger absorbs the final
+// value and the proof-of-work witness (row QF: rate words 0..4, the rest of the previous output kept) and then only permutes (QP rows:
+// the whole previous output).  The rate outputs of these rows are the sampled words, out[7] first: the proof-of-work word, then one
+// word per query index; they go to the SAMPLES chip (fri_chip.hip) in two halves.
+constexpr uint32_t QP = 361, QF = 362;
 // variable-depth paths, one leaf row (the sponge over 8 values) + depth compression rows each; path p starts at row start[p]
 struct LayerPathsArgs {
     const uint32_t* leaves;      // [n_paths][8] the opened pairs, canonical
@@ -45,6 +50,10 @@ struct LayerPathsArgs {
     const uint32_t* capacity;    // [8] canonical
     const uint32_t* layer_roots; // [n_transcript][8] canonical
     uint32_t* betas;             // out [n_transcript][4] canonical: what the chain produces
+    // query-phase rows (n_query_rows > 0: rows n_transcript .. n_transcript + n_query_rows - 1)
+    uint32_t n_query_rows;
+    const uint32_t* final_witness;   // [5] canonical: the final value, the proof-of-work witness
+    uint32_t* samples;           // out [n_query_rows][8] canonical, in the order the challenger hands them out (out[7] first)
 };
 
 // paths: path p = rows [p (row_width / 8 + depth), ...): row_width / 8 sponge rows over its opened row (none when row_width = 0: the

@@ -69,7 +69,7 @@ Terms linear_def(uint32_t col, const Form& f) {
     return t;
 }
 
-std::vector<uint32_t> build_program(bool fri_layers = false, uint32_t n_public = N_PUBLIC, int transcript = -1) {
+std::vector<uint32_t> build_program(bool fri_layers = false, uint32_t n_public = N_PUBLIC, int transcript = -1, int queries = -1) {
     // the matrices and constants of the tables in effect, canonical
     uint32_t ME[16][16], rc_e[8][16], rc_i[13], diag[16];
     for (int j = 0; j < 16; j++) {
@@ -154,10 +154,31 @@ std::vector<uint32_t> build_program(bool fri_layers = false, uint32_t n_public =
         b.add(FIRST, Terms{{1u, {var(LNP)}}});
         for (uint32_t j = 0; j < 8; j++) b.add(FIRST, Terms{{1u, {var(IN + 8 + j)}}, {P - 1, {pub((uint32_t)transcript + j)}}});
         b.add(TRANSITION, Terms{{1u, {var(TRS, true)}}, {P - 1, {var(TRS), var(TRS, true)}}});                 // transcript rows are a prefix
-        b.add(TRANSITION, Terms{{1u, {var(TRS, true), var(LNP, true)}}, {P - 1, {var(TRS, true), var(LNP)}}, {P - 1, {var(TRS, true)}}});
+        if (queries < 0) b.add(TRANSITION, Terms{{1u, {var(TRS, true), var(LNP, true)}}, {P - 1, {var(TRS, true), var(LNP)}}, {P - 1, {var(TRS, true)}}});
         b.add(TRANSITION, Terms{{1u, {var(TRS, true)}}, {P - 1, {var(TRS, true), var(SPG, true)}}});           // ... chained through the capacity
-        b.add(ALL, Terms{{1u, {var(SPG)}}, {P - 1, {var(SPG), var(TRS)}}});                                    // and nothing else is
+        if (queries < 0) b.add(ALL, Terms{{1u, {var(SPG)}}, {P - 1, {var(SPG), var(TRS)}}});                   // and nothing else is
         for (uint32_t f : {CH, END, SS, BIT, M}) b.add(ALL, Terms{{1u, {var(TRS), var(f)}}});
+    }
+    if (queries >= 0) {                                     // the query-phase rows (p2chip.h): public values queries .. queries + 3 = the final value
+        const uint32_t o7 = oute(7);
+        for (uint32_t f : {QP, QF}) b.add(ALL, Terms{{1u, {var(f), var(f)}}, {P - 1, {var(f)}}});
+        b.add(ALL, Terms{{1u, {var(QF)}}, {P - 1, {var(QF), var(QP)}}});                                       // the first query row is one
+        b.add(ALL, Terms{{1u, {var(QP), var(TRS)}}});
+        b.add(FIRST, Terms{{1u, {var(QF)}}});
+        b.add(TRANSITION, Terms{{1u, {var(QF, true)}}, {P - 1, {var(TRS)}}, {1u, {var(TRS), var(TRS, true)}}});                   // QF' = TRS (1 - TRS'): right behind the chain
+        b.add(TRANSITION, Terms{{1u, {var(QP, true)}}, {P - 1, {var(QP, true), var(QP)}}, {P - 1, {var(QF, true)}}});             // a query row is the first or follows one
+        b.add(TRANSITION, Terms{{1u, {var(TRS, true), var(LNP, true)}}, {P - 1, {var(TRS, true), var(LNP)}}, {P - 1, {var(TRS, true)}},    // the row counter runs on
+                                {1u, {var(QP, true), var(LNP, true)}}, {P - 1, {var(QP, true), var(LNP)}}, {P - 1, {var(QP, true)}}});
+        b.add(TRANSITION, Terms{{1u, {var(QP, true)}}, {P - 1, {var(QP, true), var(SPG, true)}}});             // the capacity is kept
+        b.add(ALL, Terms{{1u, {var(SPG)}}, {P - 1, {var(SPG), var(TRS)}}, {P - 1, {var(SPG), var(QP)}}});
+        for (uint32_t j = 5; j < 8; j++)                                                                       // rate words the inputs do not reach
+            b.add(TRANSITION, Terms{{1u, {var(QP, true), var(IN + j, true)}}, {P - 1, {var(QP, true), var(o7 + j)}}});
+        for (uint32_t j = 0; j < 5; j++)                                                                       // later rows: nothing absorbed
+            b.add(TRANSITION, Terms{{1u, {var(QP, true), var(IN + j, true)}}, {P - 1, {var(QP, true), var(o7 + j)}},
+                                    {P - 1, {var(QF, true), var(IN + j, true)}}, {1u, {var(QF, true), var(o7 + j)}}});
+        for (uint32_t j = 0; j < 4; j++)                                                                       // the first absorbs the final value (and a free witness)
+            b.add(ALL, Terms{{1u, {var(QF), var(IN + j)}}, {P - 1, {var(QF), pub((uint32_t)queries + j)}}});
+        for (uint32_t f : {CH, END, SS, BIT, M}) b.add(ALL, Terms{{1u, {var(QP), var(f)}}});
     }
     std::vector<uint32_t> p{AIR_MAGIC, 1u, transcript >= 0 ? WIDTH_T : WIDTH, b.count, n_public, (uint32_t)(6 + b.body.size())};
     p.insert(p.end(), b.body.begin(), b.body.end());
@@ -199,6 +220,19 @@ std::shared_ptr<const std::vector<uint32_t>> program_fri_transcript(uint32_t n_p
     const uint64_t key = ((uint64_t)n_public << 32) | cap_pub;
     auto it = cache.find(key);
     if (it == cache.end()) it = cache.emplace(key, std::make_shared<const std::vector<uint32_t>>(build_program(true, n_public, (int)cap_pub))).first;
+    return it->second;
+}
+// ... and the query-phase variant of that: the final value = public values final_pub .. final_pub + 3
+std::shared_ptr<const std::vector<uint32_t>> program_fri_indices(uint32_t n_public, uint32_t cap_pub, uint32_t final_pub) {
+    static std::mutex mu;
+    static std::map<uint64_t, std::shared_ptr<const std::vector<uint32_t>>> cache;
+    static uint64_t cached_gen = ~0ull;
+    std::lock_guard<std::mutex> lk(mu);
+    const uint64_t gen = g_p2_generation.load();
+    if (cached_gen != gen) { cache.clear(); cached_gen = gen; }
+    const uint64_t key = ((uint64_t)n_public << 32) | (cap_pub << 16) | final_pub;
+    auto it = cache.find(key);
+    if (it == cache.end()) it = cache.emplace(key, std::make_shared<const std::vector<uint32_t>>(build_program(true, n_public, (int)cap_pub, (int)final_pub))).first;
     return it->second;
 }
 namespace {

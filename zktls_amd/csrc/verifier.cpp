@@ -331,6 +331,7 @@ static int verify_shard_impl(const uint8_t* proof, size_t len, int log_n, uint32
     std::vector<Ext> final_poly(keep);            // coefficients, lowest first
     for (size_t i = 0; i < keep; i++) { final_poly[i] = ext_from_canon(pf + pos); pos += 4; ch.observe_ext(final_poly[i]); }
     const uint32_t witness = pf[pos++];
+    if (sink && sink->transcript) sink->transcript[9] = witness;
     ch.observe_canonical(witness);
     if (ch.sample_bits(prm->pow_bits) != 0) return reject(20);
     const uint32_t wm = two_adic_generator(H);
@@ -491,11 +492,11 @@ int zkhip_fri_view_shard_paths(const uint8_t* proof, size_t len, int log_n, uint
 }
 // The Fiat-Shamir side of the same view: the layer roots, the challenges, and the duplex challenger's state as the commit phase finds
 // it -- transcript[0..8) = the capacity half of its state (canonical), transcript[8] = inputs pending (0 for every proof shape of this
-// library: the step before is a sample).  With these the challenges are a SPONGE CHAIN over the roots: state <- (root_l | capacity),
+// library: the step before is a sample), transcript[9] = the proof-of-work witness (absorbed behind the final value by the query phase).  With these the challenges are a SPONGE CHAIN over the roots: state <- (root_l | capacity),
 // permute, beta_l = (state[7], state[6], state[5], state[4]), capacity <- state[8..16) -- the rows a Poseidon2 chip in sponge mode
 // already has; what a transcript chip has to prove (docs/RECURSION_NEXT.md).
 int zkhip_fri_view_transcript(const uint8_t* proof, size_t len, int log_n, uint32_t width, const uint32_t* public_values, size_t n_public,
-                              const zkhip_params* prm, uint32_t* roots, uint32_t* betas, uint32_t transcript[9]) {
+                              const zkhip_params* prm, uint32_t* roots, uint32_t* betas, uint32_t transcript[10]) {
     if (!prm || !roots || !betas || !transcript) return fail(ZKHIP_ERR_INVALID, "fri_view_transcript: null argument");
     Shape sh;
     if (check_shape(log_n, width, prm) != ZKHIP_OK) return ZKHIP_ERR_INVALID;

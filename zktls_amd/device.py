@@ -614,6 +614,28 @@ class Context:
                                                   C.byref(params), buf.ctypes.data_as(u8p), size, C.byref(got)))
         return buf[: got.value]
 
+    def fri_indices_key(self, view, inner_pow_bits, params=None):
+        """zkhip_fri_indices_key: (query number, reduced opening), the layer roots, the SAMPLES chip's fixed columns -- no index"""
+        params = params or Params(1, 100, 16)
+        R, Q, betas, idx, vals, sibs, roots, paths = _fri_layers_arrays(view)
+        handle, root = C.c_void_p(), np.zeros(8, dtype=np.uint32)
+        check(self.lib.zkhip_fri_indices_key(self.handle, R, Q, inner_pow_bits, vals.ctypes.data_as(u32p), roots.ctypes.data_as(u32p),
+                                             C.byref(params), C.byref(handle), root.ctypes.data_as(u32p)))
+        return MachineKey(self, handle, root, [0, 0, 8, 12, 20])
+
+    def prove_fri_indices(self, key, view, capacity, witness, inner_pow_bits, params=None):
+        """zkhip_prove_fri_indices: the transcript machine with the query phase (proof of work, query indices) in-circuit"""
+        params = params or Params(1, 100, 16)
+        R, Q, betas, idx, vals, sibs, roots, paths = _fri_layers_arrays(view)
+        cap8 = np.ascontiguousarray(np.array(capacity, dtype=np.uint32))
+        size = self.lib.zkhip_fri_indices_proof_size(R, Q, inner_pow_bits, C.byref(params))
+        buf = np.empty(size, dtype=np.uint8)
+        got = C.c_size_t(0)
+        check(self.lib.zkhip_prove_fri_indices(self.handle, key.handle, R, Q, inner_pow_bits, betas.ctypes.data_as(u32p), idx.ctypes.data_as(u32p),
+                                               vals.ctypes.data_as(u32p), sibs.ctypes.data_as(u32p), roots.ctypes.data_as(u32p), paths.ctypes.data_as(u32p),
+                                               cap8.ctypes.data_as(u32p), int(witness), C.byref(params), buf.ctypes.data_as(u8p), size, C.byref(got)))
+        return buf[: got.value]
+
     def prove_machine_keyed(self, key, chips, programs, tables, public_values=(), params=None, key_entries=None):
         """a machine with preprocessed columns (proof version 11): `key` from machine_setup; chips as in prove_machine (main columns);
         programs / tables address the combined row [preprocessed | main].  key_entries: per chip the key entry it uses (-1: none) when the
@@ -940,16 +962,29 @@ def fri_view_shard(proof, log_n, width, public_values=(), params=None):
 
 
 def fri_view_transcript(proof, log_n, width, public_values=(), params=None):
-    """zkhip_fri_view_transcript -> (roots [R][8], betas [R][4], capacity [8], pending inputs): the Fiat-Shamir side of the FRI view"""
+    """zkhip_fri_view_transcript -> (roots [R][8], betas [R][4], capacity [8], pending inputs): the Fiat-Shamir side of the FRI view
+    (fri_view_witness: the proof-of-work witness, the transcript array's last word)"""
     params = params or Params(1, 100, 16)
     lib = _lib.load()
     pr = np.ascontiguousarray(proof, dtype=np.uint8)
     pv = np.ascontiguousarray(np.array(public_values, dtype=np.uint32))
     R = log_n
-    roots, betas, tr = np.zeros(8 * R, dtype=np.uint32), np.zeros(4 * R, dtype=np.uint32), np.zeros(9, dtype=np.uint32)
+    roots, betas, tr = np.zeros(8 * R, dtype=np.uint32), np.zeros(4 * R, dtype=np.uint32), np.zeros(10, dtype=np.uint32)
     check(lib.zkhip_fri_view_transcript(pr.ctypes.data_as(u8p), pr.size, log_n, width, pv.ctypes.data_as(u32p), pv.size, C.byref(params),
                                         roots.ctypes.data_as(u32p), betas.ctypes.data_as(u32p), tr.ctypes.data_as(u32p)))
     return roots.reshape(R, 8).tolist(), betas.reshape(R, 4).tolist(), tr[:8].tolist(), int(tr[8])
+
+
+def fri_view_witness(proof, log_n, width, public_values=(), params=None):
+    """the proof-of-work witness of a shard proof (zkhip_fri_view_transcript's transcript[9])"""
+    params = params or Params(1, 100, 16)
+    lib = _lib.load()
+    pr = np.ascontiguousarray(proof, dtype=np.uint8)
+    pv = np.ascontiguousarray(np.array(public_values, dtype=np.uint32))
+    roots, betas, tr = np.zeros(8 * log_n, dtype=np.uint32), np.zeros(4 * log_n, dtype=np.uint32), np.zeros(10, dtype=np.uint32)
+    check(lib.zkhip_fri_view_transcript(pr.ctypes.data_as(u8p), pr.size, log_n, width, pv.ctypes.data_as(u32p), pv.size, C.byref(params),
+                                        roots.ctypes.data_as(u32p), betas.ctypes.data_as(u32p), tr.ctypes.data_as(u32p)))
+    return int(tr[9])
 
 
 def fri_view_shard_paths(proof, log_n, width, public_values=(), params=None):
@@ -1007,6 +1042,32 @@ def fri_transcript_programs(layers):
         assert n and f(layers, buf.ctypes.data_as(u32p), n) == n
         out.append(buf)
     return out
+
+
+def fri_indices_programs(layers, inner_pow_bits):
+    """-> (the Poseidon2 chip with query-phase rows, the SAMPLES chip): what the query-phase machine adds to the transcript machine"""
+    lib = _lib.load()
+    out = []
+    for which in (0, 1):
+        n = lib.zkhip_fri_indices_program(which, layers, inner_pow_bits, None, 0)
+        buf = np.zeros(n, dtype=np.uint32)
+        assert n and lib.zkhip_fri_indices_program(which, layers, inner_pow_bits, buf.ctypes.data_as(u32p), n) == n
+        out.append(buf)
+    return out
+
+
+def verify_fri_indices(proof, final, capacity, layers, n_queries, inner_pow_bits, vk, params=None):
+    """zkhip_verify_fri_indices: the final value, the challenger's capacity, the key -- no challenge, no index"""
+    params = params or Params(1, 100, 16)
+    lib = _lib.load()
+    pr = np.ascontiguousarray(proof, dtype=np.uint8)
+    f = np.ascontiguousarray(np.array(final, dtype=np.uint32))
+    c8 = np.ascontiguousarray(np.array(capacity, dtype=np.uint32))
+    k = np.ascontiguousarray(np.array(vk, dtype=np.uint32))
+    reason = C.c_int(0)
+    rc = lib.zkhip_verify_fri_indices(pr.ctypes.data_as(u8p), pr.size, layers, n_queries, inner_pow_bits, f.ctypes.data_as(u32p), c8.ctypes.data_as(u32p),
+                                      k.ctypes.data_as(u32p), C.byref(params), C.byref(reason))
+    return rc, reason.value
 
 
 def verify_fri_transcript(proof, final, capacity, layers, n_queries, vk, params=None):
