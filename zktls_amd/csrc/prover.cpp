@@ -39,7 +39,7 @@ void air_digest_cached(const AirView& a, uint32_t out[8]) {
     }
     air_digest(a, out);
     std::lock_guard<std::mutex> lk(mu);
-    if (cache.size() >= 8) cache.erase(cache.begin());
+    if (cache.size() >= 64) cache.erase(cache.begin());      // (a five-chip machine alone has ten: programs and interaction tables)
     Entry e;
     e.words.assign(a.w, a.w + a.words);
     e.generation = gen;
