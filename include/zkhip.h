@@ -733,6 +733,22 @@ int zkhip_prove_fri_indices(zkhip_ctx* ctx, const zkhip_machine_key* key, int la
                             const uint32_t capacity[8], uint32_t witness, const zkhip_params* prm, uint8_t* proof, size_t cap, size_t* len);
 int zkhip_verify_fri_indices(const uint8_t* proof, size_t len, int layers, size_t n_queries, int inner_pow_bits, const uint32_t final_value[4],
                              const uint32_t capacity[8], const uint32_t vk[8], const zkhip_params* prm, int* reason);
+/* Many shard proofs in one call -- the compress-like step of the path (sp1.rs:116: core -> COMPRESS verifies the shard proofs; prover.rs:90:
+ * lift): per job the FRI view of the shard proof (host), the key of its query-phase machine and the machine's proof; jobs are dealt over
+ * `devices` (NULL / 0: every visible device) like every batch of this library -- lock-step lanes for the launch-bound sizes
+ * (zkhip_set_lockstep), otherwise `in_flight_per_device` contexts per device.  All jobs share (log_n, width, inner).  Out per job: the
+ * proof, and what zkhip_verify_fri_indices takes beside it (vk, final value, capacity).  verify != 0: every proof is checked on the host
+ * right after it was made (sp1.rs:120).  Returns the status of the lowest failing job (every job still gets its own). */
+typedef struct zkhip_fri_job {
+    const uint8_t* shard_proof; size_t shard_proof_len;     /* in: a shard proof of this library (fold by 2, blowup 2, constant final value) */
+    const uint32_t* public_values; size_t n_public;
+    uint8_t* proof; size_t proof_cap;                       /* in: >= zkhip_fri_indices_proof_size(log_n, inner->num_queries, inner->pow_bits, outer) */
+    size_t proof_len;                                       /* out */
+    uint32_t vk[8], final_value[4], capacity[8];            /* out */
+    int status;                                             /* out */
+} zkhip_fri_job;
+int zkhip_prove_fri_indices_batch(const int* devices, int n_devices, zkhip_fri_job* jobs, int n_jobs, int log_n, uint32_t width,
+                                  const zkhip_params* inner, const zkhip_params* outer, int in_flight_per_device, int verify);
 
 /* ---- Poseidon2 parameter tables from a file: the built-in sets are this repo's own
  * ("zktls-amd/p2-bb16-v1", "...-bb24-v1"; the SP1 / RISC Zero tables of reference Cargo.lock:4030, 6172, 5057 are not

@@ -344,3 +344,42 @@ def test_fullsize_fri_indices_of_the_headline_shard(ctx, oracle):
     assert proof.tobytes() == O.prove_machine_keyed(traces, pre, progs, tables, pub, oprm).tobytes()
     assert O.verify_machine_keyed(proof, lns, ws, pws, key.root, progs, tables, pub, oprm) == 0
     key.close()
+
+
+@pytest.mark.parametrize("log_n,width,inner,outer,n", [(8, 8, (1, 12, 4), (1, 10, 4), 12), (11, 16, (1, 20, 8), (1, 16, 6), 5)])
+def test_fri_indices_batch_equals_the_single_calls(ctx, oracle, log_n, width, inner, outer, n):
+    """zkhip_prove_fri_indices_batch (lock-step lanes, and one context per worker): every proof the bytes of the step-by-step path
+    (view -> key -> prove), every (vk, final value, capacity) what that path hands the verifier; a shard proof that does not verify fails its
+    own job only"""
+    from zktls_amd.device import (fri_view_shard_paths, fri_view_transcript, fri_view_witness, prove_fri_indices_batch, set_lockstep,
+                                  verify_fri_indices)
+    iprm, prm = Params(*inner), Params(*outer)
+    shard_proofs, pvs = [], []
+    for k in range(n):
+        trace = ctx.gen_trace(SEED, 50 + k, log_n, width)
+        pvs.append([k, 7])
+        shard_proofs.append(ctx.prove_shard(trace, log_n, width, pvs[-1], iprm))
+        trace.free()
+    want = []
+    for sp, pv in zip(shard_proofs, pvs):
+        view = fri_view_shard_paths(sp, log_n, width, pv, iprm)
+        _, _, capacity, _ = fri_view_transcript(sp, log_n, width, pv, iprm)
+        witness = fri_view_witness(sp, log_n, width, pv, iprm)
+        key = ctx.fri_indices_key(view, inner[2], prm)
+        want.append((ctx.prove_fri_indices(key, view, capacity, witness, inner[2], prm).tobytes(), key.root.tolist(), view["final"], capacity))
+        key.close()
+    for batch in (16, 0):
+        set_lockstep(batch)
+        try:
+            got = prove_fri_indices_batch(shard_proofs, log_n, width, pvs, iprm, prm, devices=[0], verify=True)
+        finally:
+            set_lockstep(16)
+        assert len(got) == n
+        for (proof, vk, final, cap), (wproof, wvk, wfinal, wcap) in zip(got, want):
+            assert proof.tobytes() == wproof and vk == wvk and final == list(wfinal) and cap == list(wcap)
+            assert verify_fri_indices(proof, final, cap, log_n, inner[1], inner[2], vk, prm) == (0, 0)
+    # a corrupted shard proof: its job fails, the call reports it
+    bad = [sp.copy() for sp in shard_proofs]
+    bad[1][len(bad[1]) // 2] ^= 1
+    with pytest.raises(Exception):
+        prove_fri_indices_batch(bad, log_n, width, pvs, iprm, prm, devices=[0])

@@ -45,6 +45,7 @@ EXPORTS = [
     "zkhip_fri_transcript_chip_air", "zkhip_p2chip_air_fri_transcript", "zkhip_fri_transcript_key", "zkhip_fri_transcript_proof_size",
     "zkhip_prove_fri_transcript", "zkhip_verify_fri_transcript",
     "zkhip_fri_indices_program", "zkhip_fri_indices_key", "zkhip_fri_indices_proof_size", "zkhip_prove_fri_indices", "zkhip_verify_fri_indices",
+    "zkhip_prove_fri_indices_batch",
     "zkhip_p2chip_air", "zkhip_p2chip_gen_merkle_trace", "zkhip_merkle_paths_proof_size", "zkhip_prove_merkle_paths", "zkhip_verify_merkle_paths",
     "zkhip_sha256_air", "zkhip_sha256_digest", "zkhip_sha256_pad", "zkhip_sha256_gen_trace", "zkhip_sha256_proof_size", "zkhip_prove_sha256", "zkhip_verify_sha256",
 ]
@@ -74,6 +75,12 @@ class Chip(C.Structure):
 class TranscriptJob(C.Structure):
     _fields_ = [("message", u8p), ("message_len", C.c_size_t), ("digest", C.c_uint8 * 32), ("proof", u8p), ("proof_cap", C.c_size_t),
                 ("proof_len", C.c_size_t), ("status", C.c_int32)]
+
+
+class FriJob(C.Structure):
+    _fields_ = [("shard_proof", u8p), ("shard_proof_len", C.c_size_t), ("public_values", u32p), ("n_public", C.c_size_t), ("proof", u8p),
+                ("proof_cap", C.c_size_t), ("proof_len", C.c_size_t), ("vk", C.c_uint32 * 8), ("final_value", C.c_uint32 * 4),
+                ("capacity", C.c_uint32 * 8), ("status", C.c_int32)]
 
 
 class ShardJob(C.Structure):
@@ -242,6 +249,8 @@ def load():
     L.zkhip_prove_fri_indices.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_size_t, C.c_int, u32p, u32p, u32p, u32p, u32p, u32p, u32p, C.c_uint32,
                                           C.POINTER(Params), u8p, C.c_size_t, C.POINTER(C.c_size_t)]
     L.zkhip_verify_fri_indices.argtypes = [u8p, C.c_size_t, C.c_int, C.c_size_t, C.c_int, u32p, u32p, u32p, C.POINTER(Params), C.POINTER(C.c_int)]
+    L.zkhip_prove_fri_indices_batch.argtypes = [C.POINTER(C.c_int), C.c_int, C.POINTER(FriJob), C.c_int, C.c_int, C.c_uint32, C.POINTER(Params), C.POINTER(Params),
+                                                C.c_int, C.c_int]
     for f in (L.zkhip_fri_layers_chip_air, L.zkhip_p2chip_air_fri_layers, L.zkhip_fri_transcript_chip_air, L.zkhip_p2chip_air_fri_transcript):
         f.restype = C.c_size_t
         f.argtypes = [C.c_int, u32p, C.c_size_t]

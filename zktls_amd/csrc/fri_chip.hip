@@ -530,10 +530,14 @@ static int fri_gen_trace(zkhip_ctx* ctx, int layers, size_t n_queries, const uin
     void* stage;
     ZK_TRY(ctx_reserve(ctx, S_STAGE, (nb + n_queries + nv + ns + nv) * 4, &stage));
     uint32_t* d = (uint32_t*)stage;
-    ZK_HIP(hipMemcpyAsync(d, betas, nb * 4, hipMemcpyHostToDevice, ctx->stream));
-    ZK_HIP(hipMemcpyAsync(d + nb, indices, n_queries * 4, hipMemcpyHostToDevice, ctx->stream));
-    ZK_HIP(hipMemcpyAsync(d + nb + n_queries, values, nv * 4, hipMemcpyHostToDevice, ctx->stream));
-    ZK_HIP(hipMemcpyAsync(d + nb + n_queries + nv, siblings, ns * 4, hipMemcpyHostToDevice, ctx->stream));
+    {   // one upload: betas | indices | values | siblings
+        std::vector<uint32_t> up(nb + n_queries + nv + ns);
+        std::memcpy(up.data(), betas, nb * 4);
+        std::memcpy(up.data() + nb, indices, n_queries * 4);
+        std::memcpy(up.data() + nb + n_queries, values, nv * 4);
+        std::memcpy(up.data() + nb + n_queries + nv, siblings, ns * 4);
+        ZK_TRY(dev_h2d(ctx, d, up.data(), up.size() * 4));
+    }
     frichip::TraceArgs a{};
     a.betas = d; a.indices = d + nb; a.values = d + nb + n_queries; a.siblings = d + nb + n_queries + nv;
     a.n_queries = (uint32_t)n_queries; a.layers = (uint32_t)layers; a.width = W; a.log_h = (uint32_t)layers + 1u; a.wired = wired ? 1u : 0u;
@@ -542,9 +546,7 @@ static int fri_gen_trace(zkhip_ctx* ctx, int layers, size_t n_queries, const uin
     const size_t threads = n_queries + (pad < 4096 ? pad : 4096);            // the padding rows are shared among up to 4096 extra threads
     ZK_LAUNCH(frichip::fri_trace_kernel, frichip::fri_trace_kernel_batch, frichip::fri_trace_kernel_bargs, dim3((unsigned)((threads + 63) / 64)), dim3(64), 0, ctx->stream, a);
     ZK_HIP(hipGetLastError());
-    ZK_HIP(hipMemcpyAsync(finals, a.finals, nv * 4, hipMemcpyDeviceToHost, ctx->stream));
-    ZK_HIP(hipStreamSynchronize(ctx->stream));
-    return ZKHIP_OK;
+    return dev_d2h(ctx, finals, a.finals, nv * 4);
 }
 extern "C" {
 int zkhip_fri_chip_gen_trace(zkhip_ctx* ctx, int layers, size_t n_queries, const uint32_t* betas, const uint32_t* indices, const uint32_t* values,
@@ -565,8 +567,7 @@ int zkhip_fri_queries_key(zkhip_ctx* ctx, int layers, size_t n_queries, const ui
     ZK_TRY(frichip::build_openings(layers, n_queries, betas, indices, values, siblings, log_rows, table, final_value));
     void* d;
     ZK_TRY(ctx_reserve(ctx, S_CHIP_B, table.size() * 4, &d));
-    ZK_HIP(hipMemcpyAsync(d, table.data(), table.size() * 4, hipMemcpyHostToDevice, ctx->stream));
-    ZK_HIP(hipStreamSynchronize(ctx->stream));
+    ZK_TRY(dev_h2d(ctx, d, table.data(), table.size() * 4));
     zkhip_chip pre[2]{};
     pre[0].log_n = log_rows; pre[0].width = 0; pre[0].partner = -1;                  // the FRI chip has no preprocessed columns
     pre[1].d_trace = (const uint32_t*)d; pre[1].ld = frichip::OPEN_PRE; pre[1].log_n = log_rows; pre[1].width = frichip::OPEN_PRE; pre[1].partner = -1;
@@ -594,7 +595,7 @@ int zkhip_prove_fri_queries(zkhip_ctx* ctx, const zkhip_machine_key* key, int la
     for (size_t q = 1; q < n_queries; q++)
         if (std::memcmp(finals.data(), finals.data() + 4 * q, 16) != 0) return fail(ZKHIP_ERR_INVALID, "prove_fri_queries: the chains do not end in one value");
     ZK_TRY(ctx_reserve(ctx, S_LOOKUP, ((size_t)frichip::OPEN_MAIN << log_rows) * 4, &zeros));      // the table's (unused) main columns
-    ZK_HIP(hipMemsetAsync(zeros, 0, ((size_t)frichip::OPEN_MAIN << log_rows) * 4, ctx->stream));
+    ZK_TRY(dev_memset(ctx, zeros, 0, ((size_t)frichip::OPEN_MAIN << log_rows) * 4));
     std::vector<uint32_t> pv(frichip::n_public_of(layers));
     std::memcpy(pv.data(), betas, 16 * (size_t)layers);
     std::memcpy(pv.data() + 4 * (size_t)layers, finals.data(), 16);
@@ -737,11 +738,10 @@ static int fri_layers_key_impl(zkhip_ctx* ctx, int layers, size_t n_queries, con
     if (QM) {
         frichip::samples_pre(layers, n_queries, m.log_ns[4], st);
         ZK_TRY(ctx_reserve(ctx, S_REC_E, st.size() * 4, &ds));
-        ZK_HIP(hipMemcpyAsync(ds, st.data(), st.size() * 4, hipMemcpyHostToDevice, ctx->stream));
+        ZK_TRY(dev_h2d(ctx, ds, st.data(), st.size() * 4));
     }
-    ZK_HIP(hipMemcpyAsync(dq, qt.data(), qt.size() * 4, hipMemcpyHostToDevice, ctx->stream));
-    ZK_HIP(hipMemcpyAsync(dr, rt.data(), rt.size() * 4, hipMemcpyHostToDevice, ctx->stream));
-    ZK_HIP(hipStreamSynchronize(ctx->stream));
+    ZK_TRY(dev_h2d(ctx, dq, qt.data(), qt.size() * 4));
+    ZK_TRY(dev_h2d(ctx, dr, rt.data(), rt.size() * 4));
     zkhip_chip pre[5]{};
     for (int c = 0; c < m.n; c++) { pre[c].log_n = m.log_ns[c]; pre[c].width = m.pre_widths[c]; pre[c].ld = m.pre_widths[c]; pre[c].partner = -1; }
     pre[2].d_trace = (const uint32_t*)dq; pre[3].d_trace = (const uint32_t*)dr; pre[4].d_trace = (const uint32_t*)ds;
@@ -837,20 +837,24 @@ static int fri_layers_gen_paths_trace_impl(zkhip_ctx* ctx, int layers, size_t n_
         }
     }
     const size_t np8 = 8 * np, npaths_words = per_q * n_queries;
+    // staging, one upload and one download: [leaves | path siblings | 6 x meta | capacity | layer roots | final value, witness] [roots | betas | samples]
+    const size_t up_words = np8 + npaths_words + 6 * np + 8 + 8 * R + 8, down_words = np8 + 4 * R + 8 * NQR;
     void* stage;
-    ZK_TRY(ctx_reserve(ctx, S_STAGE, (np8 + npaths_words + 6 * np + np8 + 8 + 12 * R + 8 + 8 * NQR) * 4, &stage));
+    ZK_TRY(ctx_reserve(ctx, S_STAGE, (up_words + down_words) * 4, &stage));
     uint32_t* d = (uint32_t*)stage;
-    uint32_t *d_leaves = d, *d_sibs = d + np8, *d_meta = d_sibs + npaths_words, *d_roots = d_meta + 6 * np;
-    uint32_t *d_cap = d_roots + np8, *d_lroots = d_cap + 8, *d_betas = d_lroots + 8 * R, *d_fw = d_betas + 4 * R, *d_samples = d_fw + 8;
-    if (QM) ZK_HIP(hipMemcpyAsync(d_fw, final_witness, 20, hipMemcpyHostToDevice, ctx->stream));
-    if (T) {
-        ZK_HIP(hipMemcpyAsync(d_cap, capacity, 32, hipMemcpyHostToDevice, ctx->stream));
-        ZK_HIP(hipMemcpyAsync(d_lroots, roots, 32 * R, hipMemcpyHostToDevice, ctx->stream));
+    uint32_t *d_leaves = d, *d_sibs = d + np8, *d_meta = d_sibs + npaths_words, *d_cap = d_meta + 6 * np, *d_lroots = d_cap + 8, *d_fw = d_lroots + 8 * R;
+    uint32_t *d_roots = d + up_words, *d_betas = d_roots + np8, *d_samples = d_betas + 4 * R;
+    {
+        std::vector<uint32_t> up(up_words, 0u);
+        std::memcpy(up.data(), leaves.data(), np8 * 4);
+        std::memcpy(up.data() + np8, paths, npaths_words * 4);
+        const std::vector<uint32_t>* meta[6] = {&sib_off, &idx, &depths, &lay, &mults, &starts};
+        for (int k = 0; k < 6; k++) std::memcpy(up.data() + np8 + npaths_words + (size_t)k * np, meta[k]->data(), np * 4);
+        uint32_t* tail = up.data() + np8 + npaths_words + 6 * np;
+        if (T) { std::memcpy(tail, capacity, 32); std::memcpy(tail + 8, roots, 32 * R); }
+        if (QM) std::memcpy(tail + 8 + 8 * R, final_witness, 20);
+        ZK_TRY(dev_h2d(ctx, d, up.data(), up_words * 4));
     }
-    ZK_HIP(hipMemcpyAsync(d_leaves, leaves.data(), np8 * 4, hipMemcpyHostToDevice, ctx->stream));
-    ZK_HIP(hipMemcpyAsync(d_sibs, paths, npaths_words * 4, hipMemcpyHostToDevice, ctx->stream));
-    const std::vector<uint32_t>* meta[6] = {&sib_off, &idx, &depths, &lay, &mults, &starts};
-    for (int k = 0; k < 6; k++) ZK_HIP(hipMemcpyAsync(d_meta + (size_t)k * np, meta[k]->data(), np * 4, hipMemcpyHostToDevice, ctx->stream));
     p2chip::LayerPathsArgs a{};
     a.leaves = d_leaves; a.siblings = d_sibs; a.sib_off = d_meta; a.indices = d_meta + np; a.depths = d_meta + 2 * np; a.layers = d_meta + 3 * np;
     a.mults = d_meta + 4 * np; a.starts = d_meta + 5 * np; a.n_paths = np; a.rows = (uint64_t)1 << log_rows; a.used_rows = used;
@@ -858,15 +862,14 @@ static int fri_layers_gen_paths_trace_impl(zkhip_ctx* ctx, int layers, size_t n_
     if (T) { a.n_transcript = (uint32_t)layers; a.capacity = d_cap; a.layer_roots = d_lroots; a.betas = d_betas; }
     if (QM) { a.n_query_rows = (uint32_t)NQR; a.final_witness = d_fw; a.samples = d_samples; samples->resize(8 * NQR); }
     ZK_HIP(launch_p2chip_layer_paths(a, ctx->stream));
-    std::vector<uint32_t> got(np8), chain(4 * R);
-    if (QM) ZK_HIP(hipMemcpyAsync(samples->data(), d_samples, 32 * NQR, hipMemcpyDeviceToHost, ctx->stream));
-    ZK_HIP(hipMemcpyAsync(got.data(), d_roots, np8 * 4, hipMemcpyDeviceToHost, ctx->stream));
-    if (T) ZK_HIP(hipMemcpyAsync(chain.data(), d_betas, 16 * R, hipMemcpyDeviceToHost, ctx->stream));
-    ZK_HIP(hipStreamSynchronize(ctx->stream));
-    if (T && std::memcmp(chain.data(), betas, 16 * R) != 0)
+    std::vector<uint32_t> down(down_words);
+    ZK_TRY(dev_d2h(ctx, down.data(), d_roots, down_words * 4));
+    const uint32_t *got = down.data(), *chain = down.data() + np8;
+    if (QM) std::memcpy(samples->data(), down.data() + np8 + 4 * R, 32 * NQR);
+    if (T && std::memcmp(chain, betas, 16 * R) != 0)
         return fail(ZKHIP_ERR_INVALID, "fri_transcript: the challenges are not the ones the transcript derives from these roots and this capacity");
     for (size_t p = 0; p < np; p++)
-        if (std::memcmp(got.data() + 8 * p, roots + 8 * (p % R), 32) != 0)
+        if (std::memcmp(got + 8 * p, roots + 8 * (p % R), 32) != 0)
             return fail(ZKHIP_ERR_INVALID, "fri_layers: the path of query " + std::to_string(p / R) + ", layer " + std::to_string(p % R) + " does not end in the layer's root");
     return ZKHIP_OK;
 }
@@ -905,7 +908,7 @@ static int prove_fri_layers_impl(zkhip_ctx* ctx, const zkhip_machine_key* key, i
         if (pow_bits && (words[0] & ((1u << pow_bits) - 1u))) return fail(ZKHIP_ERR_INVALID, "prove_fri_indices: the witness does not satisfy the proof of work");
         if (std::memcmp(drawn.data(), indices, 4 * n_queries) != 0) return fail(ZKHIP_ERR_INVALID, "prove_fri_indices: the query indices are not the ones the transcript draws");
         ZK_TRY(ctx_reserve(ctx, S_REC_C, smain.size() * 4, &t_s));
-        ZK_HIP(hipMemcpyAsync(t_s, smain.data(), smain.size() * 4, hipMemcpyHostToDevice, ctx->stream));
+        ZK_TRY(dev_h2d(ctx, t_s, smain.data(), smain.size() * 4));
     }
     // main columns of the tables: QUERIES none (zeros), ROOTS the number of paths per layer
     std::vector<uint32_t> rmain((size_t)m.widths[3] << m.log_ns[3], 0u);
@@ -918,11 +921,10 @@ static int prove_fri_layers_impl(zkhip_ctx* ctx, const zkhip_machine_key* key, i
     if (QM) {                                            // QUERIES main column 0: the index of query q
         qmain.assign((size_t)4 << m.log_ns[2], 0u);
         for (size_t q = 0; q < n_queries; q++) qmain[4 * q] = to_monty(indices[q]);
-        ZK_HIP(hipMemcpyAsync(t_q, qmain.data(), qmain.size() * 4, hipMemcpyHostToDevice, ctx->stream));
+        ZK_TRY(dev_h2d(ctx, t_q, qmain.data(), qmain.size() * 4));
     } else
-        ZK_HIP(hipMemsetAsync(t_q, 0, ((size_t)4 << m.log_ns[2]) * 4, ctx->stream));
-    ZK_HIP(hipMemcpyAsync(t_r, rmain.data(), rmain.size() * 4, hipMemcpyHostToDevice, ctx->stream));
-    ZK_HIP(hipStreamSynchronize(ctx->stream));
+        ZK_TRY(dev_memset(ctx, t_q, 0, ((size_t)4 << m.log_ns[2]) * 4));
+    ZK_TRY(dev_h2d(ctx, t_r, rmain.data(), rmain.size() * 4));
     std::vector<uint32_t> pv(frichip::n_public_of(layers, T));
     if (T) { std::memcpy(pv.data(), finals.data(), 16); std::memcpy(pv.data() + 4, capacity, 32); }
     else { std::memcpy(pv.data(), betas, 16 * (size_t)layers); std::memcpy(pv.data() + 4 * (size_t)layers, finals.data(), 16); }
@@ -977,6 +979,103 @@ int zkhip_verify_fri_transcript(const uint8_t* proof, size_t len, int layers, si
                                 const uint32_t vk[8], const zkhip_params* prm, int* reason) {
     if (!capacity) { if (reason) *reason = 1; return fail(ZKHIP_ERR_VERIFY, "verify_fri_transcript: bad arguments"); }
     return verify_fri_layers_impl(proof, len, layers, n_queries, nullptr, final_value, capacity, vk, prm, reason);
+}
+
+
+// ---- many shard proofs in one call: the compress-like step of the path (sp1.rs:116: core -> COMPRESS verifies the shard proofs; BASELINE
+// configs[3]: a proof of many shards).  Per job: the FRI view of the shard proof (host, on a small pool before any device work), the key of
+// its query-phase machine and the machine's proof -- dealt over the devices like every batch of this library: lock-step lanes (batch.h) for
+// the launch-bound sizes, one context per worker otherwise.  All jobs share (log_n, width, inner): one machine shape.
+int zkhip_prove_fri_indices_batch(const int* devices, int n_devices, zkhip_fri_job* jobs, int n_jobs, int log_n, uint32_t width,
+                                  const zkhip_params* inner, const zkhip_params* outer, int in_flight_per_device, int verify) {
+    if (!jobs || n_jobs < 0 || !inner || !outer) return fail(ZKHIP_ERR_INVALID, "prove_fri_indices_batch: bad arguments");
+    for (int i = 0; i < n_jobs; i++) { jobs[i].status = ZKHIP_ERR_INVALID; jobs[i].proof_len = 0; }
+    const int layers = log_n;
+    const size_t nq = (size_t)inner->num_queries;
+    int lr;
+    if (inner->log_blowup != 1 || inner->pow_bits < 0 || inner->pow_bits > 30 || frichip::shape_ok(layers, nq, &lr) != ZKHIP_OK)
+        return fail(ZKHIP_ERR_INVALID, "prove_fri_indices_batch: fold-by-2, blowup-2 shard proofs of 2^2 .. 2^22 rows");
+    std::vector<int> devs;
+    const int rc = resolve_devices(devices, n_devices, "prove_fri_indices_batch", devs);
+    if (rc == ZKHIP_ERR_NO_DEVICE) {
+        for (int i = 0; i < n_jobs; i++) jobs[i].status = ZKHIP_ERR_NO_DEVICE;
+        return n_jobs == 0 ? ZKHIP_OK : rc;
+    }
+    if (rc != ZKHIP_OK) return rc;
+    // (a) the views: host passes over the shard proofs, in parallel
+    struct View { std::vector<uint32_t> betas, indices, values, siblings, roots, paths; uint32_t fin[4], tr[10]; int rc = ZKHIP_OK; std::string msg; };
+    std::vector<View> views((size_t)n_jobs);
+    const size_t R = (size_t)layers;
+    {
+        HostPool pool(8);
+        for (int i = 0; i < n_jobs; i++)
+            pool.submit([&, i] {
+                View& v = views[(size_t)i];
+                const zkhip_fri_job& j = jobs[i];
+                v.betas.resize(4 * R); v.indices.resize(nq); v.values.resize(4 * nq); v.siblings.resize(4 * nq * R); v.roots.resize(8 * R);
+                v.paths.resize(zkhip_fri_view_path_words(layers) * nq);
+                std::vector<uint32_t> r2(8 * R), b2(4 * R);
+                v.rc = zkhip_fri_view_shard_paths(j.shard_proof, j.shard_proof_len, log_n, width, j.public_values, j.n_public, inner, v.betas.data(), v.fin,
+                                                  v.indices.data(), v.values.data(), v.siblings.data(), v.roots.data(), v.paths.data());
+                if (v.rc == ZKHIP_OK)
+                    v.rc = zkhip_fri_view_transcript(j.shard_proof, j.shard_proof_len, log_n, width, j.public_values, j.n_public, inner, r2.data(), b2.data(), v.tr);
+                if (v.rc != ZKHIP_OK) v.msg = zkhip_last_error();
+            });
+        pool.wait();
+    }
+    // (b) key + proof per job on the devices
+    std::unique_ptr<HostPool> checkers;
+    std::vector<std::string> check_msg((size_t)n_jobs);
+    std::vector<char> ran;
+    const size_t need = zkhip_fri_indices_proof_size(layers, nq, inner->pow_bits, outer);
+    auto run = [&](zkhip_ctx* ctx, int i) {
+        zkhip_fri_job& j = jobs[i];
+        const View& v = views[(size_t)i];
+        if (v.rc != ZKHIP_OK) { batch_leave(); j.status = v.rc; set_error(v.msg); return v.rc; }
+        int r = j.proof && j.proof_cap >= need ? ZKHIP_OK : fail(ZKHIP_ERR_INVALID, "prove_fri_indices_batch: proof buffer too small (zkhip_fri_indices_proof_size)");
+        zkhip_machine_key* key = nullptr;
+        size_t len = 0;
+        if (r == ZKHIP_OK) r = zkhip_fri_indices_key(ctx, layers, nq, inner->pow_bits, v.values.data(), v.roots.data(), outer, &key, j.vk);
+        if (r == ZKHIP_OK)
+            r = zkhip_prove_fri_indices(ctx, key, layers, nq, inner->pow_bits, v.betas.data(), v.indices.data(), v.values.data(), v.siblings.data(), v.roots.data(),
+                                        v.paths.data(), v.tr, v.tr[9], outer, j.proof, j.proof_cap, &len);
+        if (key) { (void)dev_sync(ctx); zkhip_machine_key_destroy(key); }
+        batch_leave();                                           // (lock-step batch: the rest is host work)
+        std::memcpy(j.final_value, v.fin, 16);
+        std::memcpy(j.capacity, v.tr, 32);
+        j.status = r;
+        j.proof_len = r == ZKHIP_OK ? len : 0;
+        if (r == ZKHIP_OK && verify) {
+            auto check = [&jobs, &check_msg, i, len, layers, nq, ipow = inner->pow_bits, p = *outer] {
+                zkhip_fri_job& jj = jobs[i];
+                const int c = zkhip_verify_fri_indices(jj.proof, len, layers, nq, ipow, jj.final_value, jj.capacity, jj.vk, &p, nullptr);
+                if (c != ZKHIP_OK) { jj.status = c; jj.proof_len = 0; check_msg[(size_t)i] = zkhip_last_error(); }
+            };
+            if (checkers && t_batcher) checkers->submit(check);
+            else { check(); r = j.status; if (r != ZKHIP_OK) set_error(check_msg[(size_t)i]); }
+        }
+        return r;
+    };
+    frichip::WiredMachine m;
+    frichip::wired_machine(layers, nq, m, true, inner->pow_bits);
+    uint64_t cells = 0;
+    for (int c = 0; c < m.n; c++) cells += ((uint64_t)(m.widths[c] + m.pre_widths[c])) << m.log_ns[c];
+    const int nd = (int)devs.size(), max_batch = lockstep_batch();
+    int rcj;
+    if (max_batch > 1 && cells <= LOCKSTEP_MAX_CELLS && n_jobs >= 2 * nd) {
+        if (verify) checkers.reset(new HostPool(8));
+        std::vector<int> shape((size_t)n_jobs, 0);
+        rcj = deal_jobs_lockstep(devs.data(), nd, n_jobs, shape.data(), max_batch, lockstep_lanes(), run, ran);
+    } else
+        rcj = deal_jobs(devs.data(), nd, n_jobs, in_flight_per_device, run, ran);
+    std::string msg = rcj != ZKHIP_OK ? zkhip_last_error() : "";
+    if (checkers) {
+        checkers->wait();
+        for (int i = 0; i < n_jobs && rcj == ZKHIP_OK; i++)
+            if (!check_msg[(size_t)i].empty()) { rcj = jobs[i].status; msg = check_msg[(size_t)i]; }
+    }
+    if (rcj != ZKHIP_OK) set_error(msg);
+    return rcj;
 }
 
 }  // extern "C"

@@ -884,6 +884,28 @@ def prove_transcripts(messages, params=None, devices=None, in_flight=4, verify=F
     return vk, [(bytes(jobs[i].digest), keep[i][1][: jobs[i].proof_len]) for i in range(n)]
 
 
+def prove_fri_indices_batch(shard_proofs, log_n, width, public_values, inner=None, outer=None, devices=None, in_flight=4, verify=False):
+    """zkhip_prove_fri_indices_batch: the query-phase machine of every shard proof in one call (the compress-like step), dealt over `devices`
+    -> [(proof bytes, vk [8], final value [4], capacity [8]), ...]; public_values: one list per shard proof"""
+    lib = _lib.load()
+    inner, outer = inner or Params(1, 100, 16), outer or Params(1, 100, 16)
+    n = len(shard_proofs)
+    size = lib.zkhip_fri_indices_proof_size(log_n, inner.num_queries, inner.pow_bits, C.byref(outer))
+    jobs = (_lib.FriJob * max(n, 1))()
+    keep = []
+    for i, sp in enumerate(shard_proofs):
+        a = np.ascontiguousarray(sp, dtype=np.uint8)
+        pv = np.ascontiguousarray(np.array(public_values[i], dtype=np.uint32))
+        buf = np.empty(max(size, 1), dtype=np.uint8)
+        keep.append((a, pv, buf))
+        jobs[i].shard_proof = a.ctypes.data_as(u8p); jobs[i].shard_proof_len = a.size
+        jobs[i].public_values = pv.ctypes.data_as(u32p); jobs[i].n_public = pv.size
+        jobs[i].proof = buf.ctypes.data_as(u8p); jobs[i].proof_cap = size
+    devs = (C.c_int * len(devices))(*devices) if devices else None
+    check(lib.zkhip_prove_fri_indices_batch(devs, len(devices) if devices else 0, jobs, n, log_n, width, C.byref(inner), C.byref(outer), in_flight, 1 if verify else 0))
+    return [(keep[i][2][: jobs[i].proof_len], list(jobs[i].vk), list(jobs[i].final_value), list(jobs[i].capacity)) for i in range(n)]
+
+
 def set_lockstep(max_batch, lanes=0):
     """zkhip_set_lockstep: members per lock-step batch of small transcripts (0 / 1 = off), batches in flight per device (0 = keep)"""
     _lib.load().zkhip_set_lockstep(int(max_batch), int(lanes))
