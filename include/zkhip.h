@@ -679,6 +679,10 @@ int zkhip_fri_view_shard_paths(const uint8_t* proof, size_t len, int log_n, uint
  * (docs/RECURSION_NEXT.md; p3-challenger DuplexChallenger, reference Cargo.lock:3875).  Canonical words; host only. */
 int zkhip_fri_view_transcript(const uint8_t* proof, size_t len, int log_n, uint32_t width, const uint32_t* public_values, size_t n_public,
                               const zkhip_params* prm, uint32_t* roots, uint32_t* betas, uint32_t transcript[10]);
+/* ... and both in ONE pass over the proof (what zkhip_prove_fri_indices_batch runs per shard proof) */
+int zkhip_fri_view_all(const uint8_t* proof, size_t len, int log_n, uint32_t width, const uint32_t* public_values, size_t n_public,
+                       const zkhip_params* prm, uint32_t* betas, uint32_t final_value[4], uint32_t* indices, uint32_t* values, uint32_t* siblings,
+                       uint32_t* roots, uint32_t* paths, uint32_t transcript[10]);
 size_t zkhip_fri_layers_chip_air(int layers, uint32_t* program, size_t cap_words);
 size_t zkhip_p2chip_air_fri_layers(int layers, uint32_t* program, size_t cap_words);
 int zkhip_fri_layers_gen_paths_trace(zkhip_ctx* ctx, int layers, size_t n_queries, const uint32_t* betas, const uint32_t* indices, const uint32_t* values,

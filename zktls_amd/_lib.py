@@ -45,7 +45,7 @@ EXPORTS = [
     "zkhip_fri_transcript_chip_air", "zkhip_p2chip_air_fri_transcript", "zkhip_fri_transcript_key", "zkhip_fri_transcript_proof_size",
     "zkhip_prove_fri_transcript", "zkhip_verify_fri_transcript",
     "zkhip_fri_indices_program", "zkhip_fri_indices_key", "zkhip_fri_indices_proof_size", "zkhip_prove_fri_indices", "zkhip_verify_fri_indices",
-    "zkhip_prove_fri_indices_batch",
+    "zkhip_prove_fri_indices_batch", "zkhip_fri_view_all",
     "zkhip_p2chip_air", "zkhip_p2chip_gen_merkle_trace", "zkhip_merkle_paths_proof_size", "zkhip_prove_merkle_paths", "zkhip_verify_merkle_paths",
     "zkhip_sha256_air", "zkhip_sha256_digest", "zkhip_sha256_pad", "zkhip_sha256_gen_trace", "zkhip_sha256_proof_size", "zkhip_prove_sha256", "zkhip_verify_sha256",
 ]

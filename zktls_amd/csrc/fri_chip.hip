@@ -21,6 +21,7 @@
 // Poseidon2 chip proves such paths, but is not wired to this bus yet), the reduced openings themselves, the transcript.  A verifier of
 // this machine proof recomputes the key from the inner proof's openings (zkhip_fri_queries_key) -- it still reads them, but no longer
 // folds them.  tests/fri_air.py writes the same program, trace and table independently; the words must be equal.
+#include <condition_variable>
 #include <cstring>
 #include <map>
 #include <memory>
@@ -1002,27 +1003,26 @@ int zkhip_prove_fri_indices_batch(const int* devices, int n_devices, zkhip_fri_j
         return n_jobs == 0 ? ZKHIP_OK : rc;
     }
     if (rc != ZKHIP_OK) return rc;
-    // (a) the views: host passes over the shard proofs, in parallel
-    struct View { std::vector<uint32_t> betas, indices, values, siblings, roots, paths; uint32_t fin[4], tr[10]; int rc = ZKHIP_OK; std::string msg; };
+    // (a) the views: one host pass over every shard proof, on a small pool that runs AHEAD of the device work (job i waits for view i only)
+    struct View {
+        std::vector<uint32_t> betas, indices, values, siblings, roots, paths; uint32_t fin[4], tr[10]; int rc = ZKHIP_OK; std::string msg;
+        std::mutex mu; std::condition_variable cv; bool done = false;
+    };
     std::vector<View> views((size_t)n_jobs);
     const size_t R = (size_t)layers;
-    {
-        HostPool pool(8);
-        for (int i = 0; i < n_jobs; i++)
-            pool.submit([&, i] {
-                View& v = views[(size_t)i];
-                const zkhip_fri_job& j = jobs[i];
-                v.betas.resize(4 * R); v.indices.resize(nq); v.values.resize(4 * nq); v.siblings.resize(4 * nq * R); v.roots.resize(8 * R);
-                v.paths.resize(zkhip_fri_view_path_words(layers) * nq);
-                std::vector<uint32_t> r2(8 * R), b2(4 * R);
-                v.rc = zkhip_fri_view_shard_paths(j.shard_proof, j.shard_proof_len, log_n, width, j.public_values, j.n_public, inner, v.betas.data(), v.fin,
-                                                  v.indices.data(), v.values.data(), v.siblings.data(), v.roots.data(), v.paths.data());
-                if (v.rc == ZKHIP_OK)
-                    v.rc = zkhip_fri_view_transcript(j.shard_proof, j.shard_proof_len, log_n, width, j.public_values, j.n_public, inner, r2.data(), b2.data(), v.tr);
-                if (v.rc != ZKHIP_OK) v.msg = zkhip_last_error();
-            });
-        pool.wait();
-    }
+    HostPool viewers(8);
+    for (int i = 0; i < n_jobs; i++)
+        viewers.submit([&, i] {
+            View& v = views[(size_t)i];
+            const zkhip_fri_job& j = jobs[i];
+            v.betas.resize(4 * R); v.indices.resize(nq); v.values.resize(4 * nq); v.siblings.resize(4 * nq * R); v.roots.resize(8 * R);
+            v.paths.resize(zkhip_fri_view_path_words(layers) * nq);
+            v.rc = zkhip_fri_view_all(j.shard_proof, j.shard_proof_len, log_n, width, j.public_values, j.n_public, inner, v.betas.data(), v.fin,
+                                      v.indices.data(), v.values.data(), v.siblings.data(), v.roots.data(), v.paths.data(), v.tr);
+            if (v.rc != ZKHIP_OK) v.msg = zkhip_last_error();
+            { std::lock_guard<std::mutex> lk(v.mu); v.done = true; }
+            v.cv.notify_all();
+        });
     // (b) key + proof per job on the devices
     std::unique_ptr<HostPool> checkers;
     std::vector<std::string> check_msg((size_t)n_jobs);
@@ -1030,7 +1030,8 @@ int zkhip_prove_fri_indices_batch(const int* devices, int n_devices, zkhip_fri_j
     const size_t need = zkhip_fri_indices_proof_size(layers, nq, inner->pow_bits, outer);
     auto run = [&](zkhip_ctx* ctx, int i) {
         zkhip_fri_job& j = jobs[i];
-        const View& v = views[(size_t)i];
+        View& v = views[(size_t)i];
+        { std::unique_lock<std::mutex> lk(v.mu); v.cv.wait(lk, [&] { return v.done; }); }
         if (v.rc != ZKHIP_OK) { batch_leave(); j.status = v.rc; set_error(v.msg); return v.rc; }
         int r = j.proof && j.proof_cap >= need ? ZKHIP_OK : fail(ZKHIP_ERR_INVALID, "prove_fri_indices_batch: proof buffer too small (zkhip_fri_indices_proof_size)");
         zkhip_machine_key* key = nullptr;
@@ -1069,6 +1070,7 @@ int zkhip_prove_fri_indices_batch(const int* devices, int n_devices, zkhip_fri_j
     } else
         rcj = deal_jobs(devs.data(), nd, n_jobs, in_flight_per_device, run, ran);
     std::string msg = rcj != ZKHIP_OK ? zkhip_last_error() : "";
+    viewers.wait();                                              // (a failing call may return before every view was looked at)
     if (checkers) {
         checkers->wait();
         for (int i = 0; i < n_jobs && rcj == ZKHIP_OK; i++)

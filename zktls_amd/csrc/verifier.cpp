@@ -509,6 +509,20 @@ int zkhip_fri_view_transcript(const uint8_t* proof, size_t len, int log_n, uint3
     return verify_shard_impl(proof, len, log_n, width, public_values, n_public, prm, &why, nullptr, &sink);
 }
 
+// everything the recursion machines read, from ONE pass over the proof: the view with roots and paths, and the challenger's side
+int zkhip_fri_view_all(const uint8_t* proof, size_t len, int log_n, uint32_t width, const uint32_t* public_values, size_t n_public,
+                       const zkhip_params* prm, uint32_t* betas, uint32_t final_value[4], uint32_t* indices, uint32_t* values, uint32_t* siblings,
+                       uint32_t* roots, uint32_t* paths, uint32_t transcript[10]) {
+    if (!prm || !betas || !final_value || !indices || !values || !siblings || !roots || !paths || !transcript) return fail(ZKHIP_ERR_INVALID, "fri_view_all: null argument");
+    Shape sh;
+    if (check_shape(log_n, width, prm) != ZKHIP_OK) return ZKHIP_ERR_INVALID;
+    shape_of(log_n, prm, sh);
+    if (sh.K != 1 || sh.F != 0 || sh.b != 1) return fail(ZKHIP_ERR_INVALID, "fri_view_all: fold-by-2, blowup-2 proofs with a constant final value only");
+    FriViewSink sink{betas, final_value, indices, values, siblings, sh.R, roots, paths, transcript};
+    int why = 0;
+    return verify_shard_impl(proof, len, log_n, width, public_values, n_public, prm, &why, nullptr, &sink);
+}
+
 // opening of a mixed-height tree (host): rows[c] = chip c's row at index >> (Hmax - lh[c]), canonical words
 static bool verify_mixed(const uint32_t* root_m, int Hmax, size_t index, const uint32_t* const* rows, const uint32_t* widths,
                          const int* lh, int n, const uint32_t* sibs_canon) {
