@@ -86,6 +86,7 @@ def main():
     ap.add_argument("--wait", choices=("auto", "poll", "block"), default="auto",
                     help="how the prover's host threads wait for their streams (zkhip_set_wait_mode): poll = hipStreamSynchronize, block = sleep "
                          "on an event; auto = block when the ranks' waiting threads outnumber the cores this container may use")
+    ap.add_argument("--no-recursion16", action="store_true", help="skip the 16 recursion proofs (the FRI check of 16 shard proofs of the headline shape proven in-circuit, one call) measured beside the headline")
     ap.add_argument("--no-batch64", action="store_true", help="skip the 64-transcript batch (BASELINE configs[2]) measured beside the headline")
     ap.add_argument("--cpu-log-n", type=int, default=20, help="rows of the bounded CPU-baseline sample")
     ap.add_argument("--cpu-threads", type=int, default=0, help="OpenMP threads of the CPU baseline (0: min(cores, 64))")
@@ -518,6 +519,26 @@ def main():
                    "same_bytes_both_ways": bool(same), "digests_and_last_proof_verified": bool(ok64),
                    "proof_bytes": int(res_l[0][1].size)}
 
+    # ---- the compress-like step (sp1.rs:116: core -> compress verifies the shard proofs): the FRI check of sixteen shard proofs of the headline
+    # shape proven in-circuit (Merkle paths, folds, challenges, proof of work, query indices) by ONE call of zkhip_prove_fri_indices_batch
+    recursion16 = None
+    if rank == 0 and not args.no_recursion16 and chip_list is None and host_traces is None and args.shape == "sp1" and LQ == 0 and 6 <= log_n <= 20:
+        from zktls_amd.device import prove_fri_indices_batch, set_lockstep, verify_fri_indices
+        sps, spv = [], []
+        for i in range(16):
+            spv.append(public + [1000 + i])
+            sps.append(ctx.prove_shard(bufs[i % nbuf], log_n, width, spv[-1], prm))
+        set_lockstep(16, 6)
+        prove_fri_indices_batch(sps, log_n, width, spv, prm, prm, devices=[local_rank])
+        t_rec, rec = 1e9, None
+        for _ in range(3):
+            tb0 = time.perf_counter()
+            rec = prove_fri_indices_batch(sps, log_n, width, spv, prm, prm, devices=[local_rank])
+            t_rec = min(t_rec, time.perf_counter() - tb0)
+        ok_rec = all(verify_fri_indices(p, fin, cap, log_n, prm.num_queries, prm.pow_bits, vk, prm) == (0, 0) for p, vk, fin, cap in rec)
+        recursion16 = {"workload": "the FRI check of 16 shard proofs (2^%d x %d, 100 queries x %d layers each) proven in-circuit: Poseidon2 chip (Merkle paths + transcript) + FRI-fold chip + SAMPLES chip + two tables per proof, one zkhip_prove_fri_indices_batch call, shard proofs in as bytes (host view included)" % (log_n, width, log_n),
+                       "ms": round(t_rec * 1e3, 2), "recursion_proofs_per_s": round(16 / t_rec, 1), "proof_bytes": int(rec[0][0].size), "all_verified": bool(ok_rec)}
+
     # ---- CPU baseline: the oracle on the host cores, bounded sample of the same workload
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
@@ -573,6 +594,8 @@ def main():
             "valu_roofline": valu,
             "transcripts_per_s": (batch64["transcripts_per_s"] if batch64 else None),
             "batch64": batch64,
+            "recursion_proofs_per_s": (recursion16["recursion_proofs_per_s"] if recursion16 else None),
+            "recursion16": recursion16,
             "cpu_baseline": cpu,
         }
         print(json.dumps(out), flush=True)

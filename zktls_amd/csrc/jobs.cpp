@@ -25,7 +25,7 @@ std::mutex g_pool_mu;
 std::vector<std::pair<int, zkhip_ctx*>> g_pool;
 zkhip_ctx* pool_take(int device) {
     std::lock_guard<std::mutex> lk(g_pool_mu);
-    for (size_t i = 0; i < g_pool.size(); i++)
+    for (size_t i = g_pool.size(); i-- > 0;)                    // the context returned last first: its workspaces and keys fit the work that is running now
         if (g_pool[i].first == device) { zkhip_ctx* c = g_pool[i].second; g_pool.erase(g_pool.begin() + (long)i); return c; }
     return nullptr;
 }
