@@ -271,6 +271,15 @@ int lockstep_selftest(int members, int rounds) {
 }
 
 // ---- the prover's copies, memsets and waits: plain stream operations, or their merged forms inside a lock-step batch
+uint32_t coop_max_nodes() {
+    if (!t_batcher) return COOP_MAX_NODES;
+#ifdef ZKHIP_AB_HOOKS
+    static const int keep = getenv("ZKHIP_COOP_KEEP") ? atoi(getenv("ZKHIP_COOP_KEEP")) : 0;
+    if (keep) return COOP_MAX_NODES;
+#endif
+    const uint32_t m = (uint32_t)t_batcher->members(), v = COOP_MAX_NODES / (m ? m : 1u);      // (a bound 2x / 4x lower: 1 - 2 ms slower)
+    return v < COOP_TOP_NODES ? COOP_TOP_NODES : v;
+}
 int dev_sync(zkhip_ctx* ctx) {
     const hipError_t e = t_batcher && t_batcher->stream() == ctx->stream ? t_batcher->sync_all() : hipStreamSynchronize(ctx->stream);
     return e == hipSuccess ? ZKHIP_OK : hip_fail(e, "stream synchronize");

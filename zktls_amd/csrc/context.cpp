@@ -496,7 +496,7 @@ int op_merkle_commit(zkhip_ctx* ctx, const MatDesc* mats, int nmats, int log_h, 
     la.nmats = nmats; la.height = (uint64_t)1 << log_h; la.digests = tree;
     uint32_t* level = tree;
     uint64_t count = la.height;
-    if (count > COOP_TOP_NODES && count <= COOP_MAX_NODES) {
+    if (count > COOP_TOP_NODES && count <= coop_max_nodes()) {
         // a medium tree: the workgroups that walk the subtrees hash their own leaves first (one launch less than leaves + subtrees + top)
         const uint32_t rest = count >= 4096 ? 128u : 32u;
         ZK_HIP(launch_hash_sub(la, (uint32_t)count / rest, ctx->stream));
@@ -506,7 +506,7 @@ int op_merkle_commit(zkhip_ctx* ctx, const MatDesc* mats, int nmats, int log_h, 
     }
     ZK_HIP(launch_hash_rows(la, ctx->stream));
     while (count > COOP_TOP_NODES) {
-        if (count <= COOP_MAX_NODES) {
+        if (count <= coop_max_nodes()) {
             // medium levels: one launch reduces the level to `rest` nodes (each workgroup walks its own subtree), one more finishes.
             // 128 workgroups keep every level of a subtree within one sweep of a 1024-thread workgroup (64 permutations at a time)
             const uint32_t rest = count >= 4096 ? 128u : 32u;
@@ -555,7 +555,7 @@ int op_merkle_commit_mixed(zkhip_ctx* ctx, const MatDesc* mats, const int* log_h
         // below the shortest matrix nothing is injected any more: the rest of the tree goes like a plain commitment (subtree + top launch)
         int min_lh = log_h;
         for (int m = 0; m < nmats; m++) if (log_heights[m] < min_lh) min_lh = log_heights[m];
-        if (lvl < min_lh && 2 * cnt <= COOP_MAX_NODES) {
+        if (lvl < min_lh && 2 * cnt <= coop_max_nodes()) {
             uint64_t count = 2 * cnt;                        // nodes of the current level
             if (count > COOP_TOP_NODES) {
                 const uint32_t rest = count >= 4096 ? 128u : 32u;

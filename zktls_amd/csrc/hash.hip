@@ -103,7 +103,7 @@ hipError_t launch_hash_rows(const LeafArgs& a, hipStream_t s) {
     if (a.nmats < 1 || a.nmats > MAX_LEAF_MATS) return hipErrorInvalidValue;
     uint32_t total = 0;
     for (int m = 0; m < a.nmats; m++) total += a.mats[m].width;
-    if (a.height <= COOP_MAX_NODES) {
+    if (a.height <= coop_max_nodes()) {
         const uint64_t threads = a.height * 16;
         ZK_LAUNCH(hash_rows16_kernel, hash_rows16_kernel_batch, hash_rows16_kernel_bargs, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, s, a, total);
         return hipGetLastError();
@@ -141,7 +141,7 @@ __global__ void __launch_bounds__(256) compress_level_kernel_batch(const compres
 
 hipError_t launch_compress_level(const uint32_t* children, uint32_t* parents, uint64_t count, hipStream_t s) {
     if (count == 0) return hipSuccess;
-    if (count <= COOP_MAX_NODES) {
+    if (count <= coop_max_nodes()) {
         const uint64_t threads = count * 16;
         ZK_LAUNCH(compress_level16_kernel, compress_level16_kernel_batch, compress_level16_kernel_bargs, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, s, children, parents, (uint32_t)count);
         return hipGetLastError();

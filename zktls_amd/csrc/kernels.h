@@ -127,6 +127,9 @@ struct MatDesc {
 constexpr int MAX_LEAF_MATS = 8;
 // levels / heights up to this many nodes use the 16-lanes-per-permutation kernels (latency-bound regime)
 constexpr uint32_t COOP_MAX_NODES = 16384;
+// ... as the calling prover sees it: those kernels trade throughput for latency, which pays while the WHOLE launch is small -- inside a
+// lock-step batch (batch.h) a merged launch carries every member's nodes, so the bound is divided by the members (batch.cpp)
+uint32_t coop_max_nodes();
 // the single-workgroup kernel finishes a tree from this many nodes down to the root
 constexpr uint32_t COOP_TOP_NODES = 512;
 struct LeafArgs {
