@@ -167,6 +167,33 @@ extern "C" {
         digest: *const u8, prm: *const ZkhipParams, bad_shard: *mut usize, reason: *mut c_int,
     ) -> c_int;
     pub fn zkhip_verify_merkle_paths(proof: *const u8, len: usize, root: *const u32, n_paths: usize, prm: *const ZkhipParams, reason: *mut c_int) -> c_int;
+    // the first piece of the compress stage (sp1.rs:116): the FRI check of many shard proofs proven in-circuit by one call; the outer
+    // proofs are verified with (vk, final value, challenger capacity) beside them
+    pub fn zkhip_fri_indices_proof_size(layers: c_int, n_queries: usize, inner_pow_bits: c_int, prm: *const ZkhipParams) -> usize;
+    pub fn zkhip_prove_fri_indices_batch(
+        devices: *const c_int, n_devices: c_int, jobs: *mut ZkhipFriJob, n_jobs: c_int, log_n: c_int, width: u32, inner: *const ZkhipParams,
+        outer: *const ZkhipParams, in_flight_per_device: c_int, verify: c_int,
+    ) -> c_int;
+    pub fn zkhip_verify_fri_indices(
+        proof: *const u8, len: usize, layers: c_int, n_queries: usize, inner_pow_bits: c_int, final_value: *const u32, capacity: *const u32,
+        vk: *const u32, prm: *const ZkhipParams, reason: *mut c_int,
+    ) -> c_int;
+}
+
+/// one shard proof of a recursion batch (zkhip_fri_job)
+#[repr(C)]
+pub struct ZkhipFriJob {
+    pub shard_proof: *const u8,
+    pub shard_proof_len: usize,
+    pub public_values: *const u32,
+    pub n_public: usize,
+    pub proof: *mut u8,
+    pub proof_cap: usize,
+    pub proof_len: usize,
+    pub vk: [u32; 8],
+    pub final_value: [u32; 4],
+    pub capacity: [u32; 8],
+    pub status: i32,
 }
 
 /// one transcript of a batch (zkhip_transcript_job)

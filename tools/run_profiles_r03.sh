@@ -11,10 +11,10 @@ run_kt() {   # name, command...
     rocprofv3 --kernel-trace --stats --output-format csv -d $P/$name -o run -- "$@" > $P/${name}.log 2>&1
 }
 run_kt kt python3 bench.py --steps 10 --warmup 2 --no-cpu-baseline
-run_kt kt1 python3 bench.py --steps 10 --warmup 2 --no-cpu-baseline --streams 1
-run_kt r0 python3 bench.py --shape r0 --width 128 --steps 8 --warmup 2 --no-cpu-baseline --streams 1
-run_kt big21 python3 bench.py --log-n 21 --width 256 --steps 4 --warmup 1 --no-cpu-baseline --streams 1
-run_kt big22 python3 bench.py --log-n 22 --width 128 --steps 4 --warmup 1 --no-cpu-baseline --streams 1
+run_kt kt1 python3 bench.py --steps 10 --warmup 2 --no-cpu-baseline --streams 1 --no-batch64 --no-recursion16
+run_kt r0 python3 bench.py --shape r0 --width 128 --steps 8 --warmup 2 --no-cpu-baseline --streams 1 --no-batch64
+run_kt big21 python3 bench.py --log-n 21 --width 256 --steps 4 --warmup 1 --no-cpu-baseline --streams 1 --no-batch64
+run_kt big22 python3 bench.py --log-n 22 --width 128 --steps 4 --warmup 1 --no-cpu-baseline --streams 1 --no-batch64
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $P/pmc_fetch -o run -- python3 tools/profile_fused.py > $P/pmc_fetch.log 2>&1
 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $P/pmc_write -o run -- python3 tools/profile_fused.py > $P/pmc_write.log 2>&1
 python3 bench.py > $P/bench_default.json 2> $P/bench_default.err
