@@ -25,6 +25,12 @@ std::mutex g_pool_mu;
 std::vector<std::pair<int, zkhip_ctx*>> g_pool;
 zkhip_ctx* pool_take(int device) {
     std::lock_guard<std::mutex> lk(g_pool_mu);
+#ifdef ZKHIP_AB_HOOKS
+    static const bool fifo = getenv("ZKHIP_POOL_FIFO") != nullptr;
+    if (fifo)
+        for (size_t i = 0; i < g_pool.size(); i++)
+            if (g_pool[i].first == device) { zkhip_ctx* c = g_pool[i].second; g_pool.erase(g_pool.begin() + (long)i); return c; }
+#endif
     for (size_t i = g_pool.size(); i-- > 0;)                    // the context returned last first: its workspaces and keys fit the work that is running now
         if (g_pool[i].first == device) { zkhip_ctx* c = g_pool[i].second; g_pool.erase(g_pool.begin() + (long)i); return c; }
     return nullptr;
