@@ -838,37 +838,53 @@ static int fri_layers_gen_paths_trace_impl(zkhip_ctx* ctx, int layers, size_t n_
         }
     }
     const size_t np8 = 8 * np, npaths_words = per_q * n_queries;
-    // staging, one upload and one download: [leaves | path siblings | 6 x meta | capacity | layer roots | final value, witness] [roots | betas | samples]
-    const size_t up_words = np8 + npaths_words + 6 * np + 8 + 8 * R + 8, down_words = np8 + 4 * R + 8 * NQR;
+    // the sponge chain of the transcript rows, walked on the host (layers + query rows permutations): the input state of every row, the
+    // challenges and the sampled words it produces
+    const size_t n_chain = T ? R + NQR : 0;
+    std::vector<uint32_t> chain_in(16 * n_chain);
+    if (T) {
+        uint32_t st[16];
+        for (int j = 0; j < 8; j++) st[8 + j] = to_monty(capacity[j]);
+        for (size_t l = 0; l < R; l++) {
+            for (int j = 0; j < 8; j++) st[j] = to_monty(roots[8 * l + j]);
+            for (int j = 0; j < 16; j++) chain_in[16 * l + j] = from_monty(st[j]);
+            p2_permute(st);
+            for (int j = 0; j < 4; j++)
+                if (from_monty(st[7 - j]) != betas[4 * l + j])
+                    return fail(ZKHIP_ERR_INVALID, "fri_transcript: the challenges are not the ones the transcript derives from these roots and this capacity");
+        }
+        if (QM) samples->resize(8 * NQR);
+        for (size_t i = 0; i < NQR; i++) {
+            if (i == 0) for (int j = 0; j < 5; j++) st[j] = to_monty(final_witness[j]);
+            for (int j = 0; j < 16; j++) chain_in[16 * (R + i) + j] = from_monty(st[j]);
+            p2_permute(st);
+            for (int j = 0; j < 8; j++) (*samples)[8 * i + j] = from_monty(st[7 - j]);
+        }
+    }
+    // staging, one upload and one download: [leaves | path siblings | 6 x meta | chain inputs] [roots]
+    const size_t up_words = np8 + npaths_words + 6 * np + 16 * n_chain, down_words = np8;
     void* stage;
     ZK_TRY(ctx_reserve(ctx, S_STAGE, (up_words + down_words) * 4, &stage));
     uint32_t* d = (uint32_t*)stage;
-    uint32_t *d_leaves = d, *d_sibs = d + np8, *d_meta = d_sibs + npaths_words, *d_cap = d_meta + 6 * np, *d_lroots = d_cap + 8, *d_fw = d_lroots + 8 * R;
-    uint32_t *d_roots = d + up_words, *d_betas = d_roots + np8, *d_samples = d_betas + 4 * R;
+    uint32_t *d_leaves = d, *d_sibs = d + np8, *d_meta = d_sibs + npaths_words, *d_chain = d_meta + 6 * np, *d_roots = d + up_words;
     {
         std::vector<uint32_t> up(up_words, 0u);
         std::memcpy(up.data(), leaves.data(), np8 * 4);
         std::memcpy(up.data() + np8, paths, npaths_words * 4);
         const std::vector<uint32_t>* meta[6] = {&sib_off, &idx, &depths, &lay, &mults, &starts};
         for (int k = 0; k < 6; k++) std::memcpy(up.data() + np8 + npaths_words + (size_t)k * np, meta[k]->data(), np * 4);
-        uint32_t* tail = up.data() + np8 + npaths_words + 6 * np;
-        if (T) { std::memcpy(tail, capacity, 32); std::memcpy(tail + 8, roots, 32 * R); }
-        if (QM) std::memcpy(tail + 8 + 8 * R, final_witness, 20);
+        if (n_chain) std::memcpy(up.data() + np8 + npaths_words + 6 * np, chain_in.data(), 64 * n_chain);
         ZK_TRY(dev_h2d(ctx, d, up.data(), up_words * 4));
     }
     p2chip::LayerPathsArgs a{};
     a.leaves = d_leaves; a.siblings = d_sibs; a.sib_off = d_meta; a.indices = d_meta + np; a.depths = d_meta + 2 * np; a.layers = d_meta + 3 * np;
     a.mults = d_meta + 4 * np; a.starts = d_meta + 5 * np; a.n_paths = np; a.rows = (uint64_t)1 << log_rows; a.used_rows = used;
     a.trace = d_trace; a.ld = ld; a.roots = d_roots;
-    if (T) { a.n_transcript = (uint32_t)layers; a.capacity = d_cap; a.layer_roots = d_lroots; a.betas = d_betas; }
-    if (QM) { a.n_query_rows = (uint32_t)NQR; a.final_witness = d_fw; a.samples = d_samples; samples->resize(8 * NQR); }
+    if (T) { a.n_transcript = (uint32_t)layers; a.n_query_rows = (uint32_t)NQR; a.chain_inputs = d_chain; }
     ZK_HIP(launch_p2chip_layer_paths(a, ctx->stream));
     std::vector<uint32_t> down(down_words);
     ZK_TRY(dev_d2h(ctx, down.data(), d_roots, down_words * 4));
-    const uint32_t *got = down.data(), *chain = down.data() + np8;
-    if (QM) std::memcpy(samples->data(), down.data() + np8 + 4 * R, 32 * NQR);
-    if (T && std::memcmp(chain, betas, 16 * R) != 0)
-        return fail(ZKHIP_ERR_INVALID, "fri_transcript: the challenges are not the ones the transcript derives from these roots and this capacity");
+    const uint32_t* got = down.data();
     for (size_t p = 0; p < np; p++)
         if (std::memcmp(got + 8 * p, roots + 8 * (p % R), 32) != 0)
             return fail(ZKHIP_ERR_INVALID, "fri_layers: the path of query " + std::to_string(p / R) + ", layer " + std::to_string(p % R) + " does not end in the layer's root");

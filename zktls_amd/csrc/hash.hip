@@ -638,31 +638,21 @@ __global__ void __launch_bounds__(64) p2chip_merkle_kernel_batch(const p2chip_me
 __device__ __forceinline__ void p2chip_layer_paths_kernel_body(const p2chip::LayerPathsArgs& a) {
     using namespace p2chip;
     const uint64_t p = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    // transcript variant: four more columns per row (TRS and three unused); the one lane past the paths and the padding walks the sponge
-    // chain over the layer roots (a chain: <= 22 permutations one after the other)
+    // transcript variant: four more columns per row (TRS, QP, QF and one unused); the lanes past the paths and the padding fill the rows of
+    // the sponge chain, one row each, from the input states the host walked
     const bool tv = a.n_transcript != 0;
     auto tail = [&](uint32_t* t, uint32_t trs, uint32_t qp = 0u, uint32_t qf = 0u) { if (tv) { t[TRS] = trs; t[QP] = qp; t[QF] = qf; t[TRS + 3] = 0u; } };
-    if (tv && p == a.n_paths + (a.rows - a.used_rows)) {
+    const uint64_t chain0 = a.n_paths + (a.rows - a.used_rows);
+    if (tv && p >= chain0) {
+        const uint32_t r = (uint32_t)(p - chain0);
+        if (r >= a.n_transcript + a.n_query_rows) return;
         uint32_t in[16], out[16];
-        for (int j = 0; j < 8; j++) in[8 + j] = to_monty(a.capacity[j]);
-        uint32_t* t = a.trace;
-        for (uint32_t l = 0; l < a.n_transcript; l++, t += a.ld) {
-            for (int j = 0; j < 8; j++) in[j] = to_monty(a.layer_roots[8 * l + j]);
-            p2chip_fill_row(t, in, 0u, 0u, 0u, 0u, l ? 1u : 0u, 0u, out);
-            t[LNP] = to_monty(l); t[KP] = 0u; t[M] = 0u;
-            tail(t, MONTY_R1);
-            for (int j = 0; j < 4; j++) a.betas[4 * l + j] = from_monty(out[7 - j]);
-            for (int j = 0; j < 8; j++) in[8 + j] = out[8 + j];
-        }
-        // the query phase: the final value and the witness over the front of the rate (the rest of the last output stays), then plain permutations
-        for (uint32_t i = 0; i < a.n_query_rows; i++, t += a.ld) {
-            for (int j = 0; j < 16; j++) in[j] = out[j];
-            if (i == 0) for (int j = 0; j < 5; j++) in[j] = to_monty(a.final_witness[j]);
-            p2chip_fill_row(t, in, 0u, 0u, 0u, 0u, 1u, 0u, out);
-            t[LNP] = to_monty(a.n_transcript + i); t[KP] = 0u; t[M] = 0u;
-            tail(t, 0u, MONTY_R1, i == 0 ? MONTY_R1 : 0u);
-            for (int j = 0; j < 8; j++) a.samples[8 * i + j] = from_monty(out[7 - j]);
-        }
+        for (int j = 0; j < 16; j++) in[j] = to_monty(a.chain_inputs[16 * r + j]);
+        uint32_t* t = a.trace + (uint64_t)r * a.ld;
+        p2chip_fill_row(t, in, 0u, 0u, 0u, 0u, r ? 1u : 0u, 0u, out);
+        t[LNP] = to_monty(r); t[KP] = 0u; t[M] = 0u;
+        if (r < a.n_transcript) tail(t, MONTY_R1);
+        else tail(t, 0u, MONTY_R1, r == a.n_transcript ? MONTY_R1 : 0u);
         return;
     }
     if (p < a.n_paths) {
@@ -699,7 +689,7 @@ struct p2chip_layer_paths_kernel_bargs { p2chip::LayerPathsArgs a; static p2chip
 __global__ void __launch_bounds__(64) p2chip_layer_paths_kernel_batch(const p2chip_layer_paths_kernel_bargs* __restrict__ zk_arr) { const p2chip_layer_paths_kernel_bargs& zk_b = zk_arr[blockIdx.z]; p2chip_layer_paths_kernel_body(zk_b.a); }
 
 hipError_t launch_p2chip_layer_paths(const p2chip::LayerPathsArgs& a, hipStream_t s) {
-    const uint64_t lanes = a.n_paths + (a.rows - a.used_rows) + (a.n_transcript ? 1u : 0u);
+    const uint64_t lanes = a.n_paths + (a.rows - a.used_rows) + a.n_transcript + a.n_query_rows;
     ZK_LAUNCH(p2chip_layer_paths_kernel, p2chip_layer_paths_kernel_batch, p2chip_layer_paths_kernel_bargs, dim3((unsigned)((lanes + 63) / 64)), dim3(64), 0, s, a);
     return hipGetLastError();
 }

@@ -45,15 +45,12 @@ struct LayerPathsArgs {
     uint64_t n_paths, rows, used_rows;
     uint32_t* trace; uint64_t ld;   // [rows][ld], Montgomery
     uint32_t* roots;             // [n_paths][8], canonical
-    // transcript variant (n_transcript > 0: rows 0 .. n_transcript - 1, the paths' starts lie behind them; ld >= WIDTH_T)
+    // transcript variant (n_transcript > 0: rows 0 .. n_transcript - 1, the paths' starts lie behind them; ld >= WIDTH_T) and its query-phase
+    // rows (n_query_rows > 0: rows n_transcript .. n_transcript + n_query_rows - 1).  The sponge chain is a chain: its states are walked on
+    // the host (a few dozen permutations) and handed over as the INPUT state of every row, so that the rows are filled side by side
     uint32_t n_transcript;       // layers
-    const uint32_t* capacity;    // [8] canonical
-    const uint32_t* layer_roots; // [n_transcript][8] canonical
-    uint32_t* betas;             // out [n_transcript][4] canonical: what the chain produces
-    // query-phase rows (n_query_rows > 0: rows n_transcript .. n_transcript + n_query_rows - 1)
     uint32_t n_query_rows;
-    const uint32_t* final_witness;   // [5] canonical: the final value, the proof-of-work witness
-    uint32_t* samples;           // out [n_query_rows][8] canonical, in the order the challenger hands them out (out[7] first)
+    const uint32_t* chain_inputs;   // [n_transcript + n_query_rows][16] canonical
 };
 
 // paths: path p = rows [p (row_width / 8 + depth), ...): row_width / 8 sponge rows over its opened row (none when row_width = 0: the
