@@ -545,8 +545,10 @@ def main():
         sys.path.insert(0, os.path.join(ROOT, "tests"))
         import oracle_lib as O
         cores = os.cpu_count() or 1
-        # the scalar oracle's loops stop scaling long before 256 threads: cap, and say so
-        used = O.set_threads(args.cpu_threads if args.cpu_threads > 0 else min(cores, 64))
+        # the scalar oracle's loops stop scaling long before 256 threads, and a container may be allowed fewer cores than it sees (cgroup
+        # quota: 16 of 256 on the MI355X boxes of this pool; a team of 64 threads on 16 cores is 12 % slower than one of 16): cap, and say so
+        quota = int(cores_ok) if cores_ok and cores_ok >= 1 else cores
+        used = O.set_threads(args.cpu_threads if args.cpu_threads > 0 else max(1, min(cores, 64, quota)))
         cl = args.cpu_log_n
         tr = O.gen_trace_logup(SEED, 0, cl, width, LQ) if LQ else O.gen_trace(SEED, 0, cl, width)
         oprm = O.default_params(1, 100, 16, LQ) if args.shape == "sp1" else O.default_params(2, 50, 0, LQ, 4, 8, 24)
@@ -554,8 +556,9 @@ def main():
         O.prove_shard(tr, public + [0], oprm)
         dt = time.perf_counter() - tc0
         cpu = {"value": round((width << cl) / dt, 1), "unit": "trace-cells/s", "cores": used, "kind": "port",
-               "sample": "one 2^%d x %d shard proof (same AIR, %s), %.1f s, scalar C oracle + OpenMP on %d of %d host cores" % (
-                   cl, width, "log_blowup 1, 100 queries, 16 PoW bits" if args.shape == "sp1" else "RISC-Zero-like shape", dt, used, cores)}
+               "sample": "one 2^%d x %d shard proof (same AIR, %s), %.1f s, scalar C oracle + OpenMP on %d threads (%d host CPUs visible, CPU quota of the container %s cores)" % (
+                   cl, width, "log_blowup 1, 100 queries, 16 PoW bits" if args.shape == "sp1" else "RISC-Zero-like shape", dt, used, cores,
+                   ("%g" % cores_ok) if cores_ok else "none")}
 
     if rank == 0:
         total_cells = cells * K * world

@@ -1,3 +1,4 @@
 #!/bin/bash
 cd "$GRAFT_REPO_ROOT" || exit 1
-time (timeout 600 python3 -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" 2>&1 | tail -3)
+for t in 16 32 64; do timeout 600 python3 bench.py --steps 4 --warmup 1 --no-batch64 --no-recursion16 --cpu-threads $t 2>/dev/null | python3 -c "import sys,json; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print($t, d['cpu_baseline'])"; done
+cat /sys/fs/cgroup/cpu.max
