@@ -393,3 +393,19 @@ def test_query_phase_machine_of_a_golden_proofs_view(oracle, name, shape):
     pub2 = list(pub)
     pub2[1] = (pub2[1] + 1) % P
     assert _machine_rejected(O, traces, pre, progs, tables, pub2, shape)
+
+
+@pytest.mark.parametrize("layers,pow_bits", [(2, 0), (6, 4), (20, 16), (22, 30)])
+def test_query_phase_programs_equal_the_python_restatements(oracle, layers, pow_bits):
+    import poseidon2_air as P2
+    from zktls_amd.device import fri_indices_programs
+    p2q, smp = fri_indices_programs(layers, pow_bits)
+    assert p2q.tolist() == P2.program(fri_layers=True, n_public=F.N_PUBLIC_T, transcript=4, queries=0).tolist()
+    assert smp.tolist() == F.samples_program(layers, 100, pow_bits, F.N_PUBLIC_T).tolist()
+    for prog, w in ((p2q, P2.WIDTH_T), (smp, F.S_PRE + F.S_MAIN)):
+        assert oracle.air_validate(prog, w, F.N_PUBLIC_T) == 1 and oracle.air_log_quotient_degree(prog) == 1
+    lib = _lib.load()
+    prm = Params(1, 8, 2)
+    assert lib.zkhip_fri_indices_proof_size(layers, 100, pow_bits, prm) > lib.zkhip_fri_transcript_proof_size(layers, 100, prm) > 0
+    assert lib.zkhip_fri_indices_proof_size(layers, 100, 31, prm) == 0 and lib.zkhip_fri_indices_proof_size(layers, 100, -1, prm) == 0
+    assert lib.zkhip_fri_indices_program(2, layers, pow_bits, None, 0) == 0 and lib.zkhip_fri_indices_program(0, 1, pow_bits, None, 0) == 0
