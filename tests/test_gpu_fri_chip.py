@@ -267,7 +267,8 @@ def test_fullsize_fri_transcript_of_the_headline_shard(ctx, oracle):
 
 
 # ------------------------------------------------------------------ the query-phase machine: proof of work and query indices in-circuit
-@pytest.mark.parametrize("log_n,width,inner,outer", [(6, 8, (1, 9, 4), (1, 12, 4)), (11, 16, (1, 20, 8), (1, 16, 6)), (8, 8, (1, 40, 0), (1, 10, 4))])
+@pytest.mark.parametrize("log_n,width,inner,outer", [(6, 8, (1, 9, 4), (1, 12, 4)), (11, 16, (1, 20, 8), (1, 16, 6)), (8, 8, (1, 40, 0), (1, 10, 4)),
+                                                     (6, 8, (1, 300, 3), (1, 8, 2))])       # (300 queries: 38 sponge rows, the SAMPLES chip taller than the ROOTS table needs to be)
 def test_fri_indices_of_a_shard_proof_in_circuit(ctx, oracle, log_n, width, inner, outer):
     """a shard proof made here; the machine whose sponge chain runs on through the final value and the proof-of-work witness and whose
     SAMPLES chip takes the bits of the words it then hands out: key (no index in it) and proof bytes against the oracle on the
