@@ -104,8 +104,36 @@ kpv = np.array(kpub, dtype=np.uint32)
 assert L.zkhip_chips_proof_to_bincode(ksrc.ctypes.data_as(u8p), ksrc.size, kpv.ctypes.data_as(u32p), kpv.size, cbc.ctypes.data_as(u8p), cbc.size, C.byref(got)) == 0
 back2, pub2, got2 = np.zeros(len(p_keyed) + 64, dtype=np.uint8), np.zeros(8, dtype=np.uint32), C.c_size_t(0)
 
+# a golden shard proof, its FRI view, and the oracle's proof of its query-phase machine (the recursion entries' host side)
+import json
+import fri_air as F
+from zktls_amd.device import fri_view_shard_paths, fri_view_transcript, fri_view_witness
+_kat = json.load(open(os.path.join(ROOT, "tests", "golden", "oracle_kat.json")))["golden_proof_files"]["v1_6x8"]
+g_proof = np.fromfile(os.path.join(ROOT, "tests", "golden", "proofs", "v1_6x8.bin"), dtype=np.uint8)
+g_prm = Params(*_kat["shape"])
+g_view = fri_view_shard_paths(g_proof, _kat["log_n"], _kat["width"], _kat["public"], g_prm)
+_, _, g_cap, _ = fri_view_transcript(g_proof, _kat["log_n"], _kat["width"], _kat["public"], g_prm)
+g_wit = fri_view_witness(g_proof, _kat["log_n"], _kat["width"], _kat["public"], g_prm)
+q_tr, q_pre, q_pg, q_tb, q_pub = F.machine_layers(g_view, capacity=g_cap, query_phase=(g_wit, _kat["shape"][2]))
+q_lns = [t.shape[0].bit_length() - 1 for t in q_tr]
+q_root = O.machine_setup(q_pre, q_lns, oprm)
+p_query = O.prove_machine_keyed(q_tr, q_pre, q_pg, q_tb, q_pub, oprm).tobytes()
+g_R, g_Q = _kat["log_n"], _kat["shape"][1]
+g_pv = np.array(_kat["public"], dtype=np.uint32)
+L.zkhip_fri_view_path_words.restype = C.c_size_t
+# (sized for the largest shape the loop asks for: the entry fills what the ARGUMENTS say, the bytes only decide whether it gets there)
+g_out = [np.zeros(n_, dtype=np.uint32) for n_ in (4 * 8, 4, g_Q, 4 * g_Q, 4 * g_Q * 8, 8 * 8, L.zkhip_fri_view_path_words(8) * g_Q, 10)]
+q_fin, q_capv, q_vk = np.array(g_view["final"], dtype=np.uint32), np.array(g_cap, dtype=np.uint32), np.array(q_root, dtype=np.uint32)
+
 t0, n = time.time(), 0
 while time.time() - t0 < budget:
+    gm = arr(mutate(g_proof.tobytes()))
+    L.zkhip_fri_view_all(gm.ctypes.data_as(u8p), gm.size, int(rng.choice([g_R, g_R, g_R + 1, 2])), int(rng.choice([_kat["width"], 4])), g_pv.ctypes.data_as(u32p), g_pv.size,
+                         C.byref(g_prm), *[a.ctypes.data_as(u32p) for a in g_out])
+    qm = arr(mutate(p_query))
+    why_q = C.c_int(0)
+    L.zkhip_verify_fri_indices(qm.ctypes.data_as(u8p), qm.size, int(rng.choice([g_R, g_R, 2, 22, 23])), int(rng.choice([g_Q, g_Q, 1, 65536, 2**40])), int(rng.choice([_kat["shape"][2], 0, 30, 31, -1])),
+                               q_fin.ctypes.data_as(u32p), q_capv.ctypes.data_as(u32p), q_vk.ctypes.data_as(u32p), C.byref(prm), C.byref(why_q))
     verify_shard(arr(mutate(p_single)), int(rng.choice([6, 6, 6, 5, 7])), int(rng.choice([8, 8, 4, 12])), [1, 2], prm)
     verify_shard_air(fib, arr(mutate(p_air)), 6, 4, fpub, prm)
     verify_shard_air(words(mutate(fib.tobytes())), arr(p_air), 6, 4, fpub, prm)
@@ -138,4 +166,4 @@ while time.time() - t0 < budget:
     L.zkhip_chips_proof_from_bincode(cb.ctypes.data_as(u8p), cb.size, back2.ctypes.data_as(u8p), int(rng.choice([back2.size, 64, 0])), C.byref(got),
                                      pub2.ctypes.data_as(u32p), int(rng.choice([8, 0])), C.byref(got2))
     n += 1
-print("fuzz ok: %d rounds of 17 malformed calls in %.0f s (no crash; run under the sanitizer build for out-of-bounds reads)" % (n, time.time() - t0))
+print("fuzz ok: %d rounds of 19 malformed calls in %.0f s (no crash; run under the sanitizer build for out-of-bounds reads)" % (n, time.time() - t0))

@@ -409,3 +409,18 @@ def test_query_phase_programs_equal_the_python_restatements(oracle, layers, pow_
     assert lib.zkhip_fri_indices_proof_size(layers, 100, pow_bits, prm) > lib.zkhip_fri_transcript_proof_size(layers, 100, prm) > 0
     assert lib.zkhip_fri_indices_proof_size(layers, 100, 31, prm) == 0 and lib.zkhip_fri_indices_proof_size(layers, 100, -1, prm) == 0
     assert lib.zkhip_fri_indices_program(2, layers, pow_bits, None, 0) == 0 and lib.zkhip_fri_indices_program(0, 1, pow_bits, None, 0) == 0
+
+
+@pytest.mark.parametrize("name", ["v1_6x8", "v1_10x16"])
+def test_the_one_pass_view_equals_the_three_views(name):
+    from zktls_amd.device import fri_view_all, fri_view_shard_paths, fri_view_transcript, fri_view_witness
+    g = GOLDEN[name]
+    b = load(name)
+    prm0 = Params(*g["shape"])
+    view, cap, wit = fri_view_all(b, g["log_n"], g["width"], g["public"], prm0)
+    assert view == fri_view_shard_paths(b, g["log_n"], g["width"], g["public"], prm0)
+    assert cap == fri_view_transcript(b, g["log_n"], g["width"], g["public"], prm0)[2] and wit == fri_view_witness(b, g["log_n"], g["width"], g["public"], prm0)
+    bad = b.copy()
+    bad[len(bad) // 3] ^= 4
+    with pytest.raises(_lib.ZkHipError):
+        fri_view_all(bad, g["log_n"], g["width"], g["public"], prm0)

@@ -236,6 +236,7 @@ def load():
     L.zkhip_fri_view_path_words.argtypes = [C.c_int]
     L.zkhip_fri_view_shard_paths.argtypes = [u8p, C.c_size_t, C.c_int, C.c_uint32, u32p, C.c_size_t, C.POINTER(Params), u32p, u32p, u32p, u32p, u32p, u32p, u32p]
     L.zkhip_fri_view_transcript.argtypes = [u8p, C.c_size_t, C.c_int, C.c_uint32, u32p, C.c_size_t, C.POINTER(Params), u32p, u32p, u32p]
+    L.zkhip_fri_view_all.argtypes = [u8p, C.c_size_t, C.c_int, C.c_uint32, u32p, C.c_size_t, C.POINTER(Params), u32p, u32p, u32p, u32p, u32p, u32p, u32p, u32p]
     L.zkhip_fri_transcript_key.argtypes = [C.c_void_p, C.c_int, C.c_size_t, u32p, u32p, u32p, C.POINTER(Params), C.POINTER(C.c_void_p), u32p]
     L.zkhip_fri_transcript_proof_size.restype = C.c_size_t
     L.zkhip_fri_transcript_proof_size.argtypes = [C.c_int, C.c_size_t, C.POINTER(Params)]

@@ -1009,6 +1009,32 @@ def fri_view_witness(proof, log_n, width, public_values=(), params=None):
     return int(tr[9])
 
 
+def fri_view_all(proof, log_n, width, public_values=(), params=None):
+    """zkhip_fri_view_all: the view of fri_view_shard_paths, the challenger's capacity and the proof-of-work witness from ONE pass over the proof
+    -> (view, capacity [8], witness)"""
+    params = params or Params(1, 100, 16)
+    lib = _lib.load()
+    pr = np.ascontiguousarray(proof, dtype=np.uint8)
+    pv = np.ascontiguousarray(np.array(public_values, dtype=np.uint32))
+    R, Q = log_n, params.num_queries
+    pw = lib.zkhip_fri_view_path_words(R)
+    betas, final, idx, vals, sibs = (np.zeros(n, dtype=np.uint32) for n in (4 * R, 4, Q, 4 * Q, 4 * Q * R))
+    roots, paths, tr = np.zeros(8 * R, dtype=np.uint32), np.zeros(pw * Q, dtype=np.uint32), np.zeros(10, dtype=np.uint32)
+    check(lib.zkhip_fri_view_all(pr.ctypes.data_as(u8p), pr.size, log_n, width, pv.ctypes.data_as(u32p), pv.size, C.byref(params),
+                                 *[a.ctypes.data_as(u32p) for a in (betas, final, idx, vals, sibs, roots, paths, tr)]))
+    view = {"betas": betas.reshape(R, 4).tolist(), "final": final.tolist(),
+            "queries": [(int(idx[q]), vals[4 * q:4 * q + 4].tolist(), sibs[4 * q * R:4 * (q + 1) * R].reshape(R, 4).tolist()) for q in range(Q)],
+            "roots": roots.reshape(R, 8).tolist(), "paths": []}
+    per_q = paths.reshape(Q, pw) if Q else paths
+    for q in range(Q):
+        off, pq = 0, []
+        for l in range(R):
+            pq.append(per_q[q, off:off + 8 * (R - l)].reshape(R - l, 8).tolist())
+            off += 8 * (R - l)
+        view["paths"].append(pq)
+    return view, tr[:8].tolist(), int(tr[9])
+
+
 def fri_view_shard_paths(proof, log_n, width, public_values=(), params=None):
     """zkhip_fri_view_shard_paths: the view of fri_view_shard plus "roots": [R][8] and, per query, "paths": [R] lists of (R - l) digests"""
     params = params or Params(1, 100, 16)
