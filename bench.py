@@ -384,14 +384,24 @@ def main():
         # shards in flight
         fused_lde = log_n == 20 and width % 32 == 0
         alg_bytes = 8.0 * n * width
+
+        def i1_over_traces(which):
+            """the LDE's first pass reads the shard's trace: its duration depends on where THAT trace lies relative to the context's
+            workspace (0.46 ... 0.52 ms over the pairs of one process, tools/i1_sources.py) -- timed over the traces of all timed shards,
+            the same number of launches each, mean reported (and the spread beside it); nothing is selected"""
+            per = max(10, reps // len(bufs))
+            ms = [timed(lambda b=b: ctx.ntt_pass(b, None, log_n, width, which), per) for b in bufs]
+            srt = sorted(ms)
+            return sum(ms) / len(ms), {"traces": len(ms), "launches_each": per, "min_ms": round(srt[0], 4), "median_ms": round(srt[len(srt) // 2], 4), "max_ms": round(srt[-1], 4)}
         fused_info = None
         if fused_lde:
             # one LDE = I1 (block form), the FUSED middle launch (second inverse pass + first forward pass of both cosets: the
             # coefficients never reach memory; 12 B per cell, bound by its butterflies, not by HBM), F2 per coset.  The roofline
             # kernel is the pass kernel: its three launches of the LDE.
-            names = {6: "zk::ntt_pass_kernel<4,true,2,5,4>, LDE pass I1 (inverse, strided in -> one contiguous block per tile)",
+            names = {6: "zk::ntt_pass_kernel<4,true,2,5,4>, LDE pass I1 (inverse, strided in -> one contiguous block per tile; mean over the traces of all timed shards)",
                      5: "zk::ntt_pass_kernel<4,false,2,5,3>, LDE pass F2 (forward, contiguous, in place)"}
-            in_proof = {w: timed(lambda w=w: ctx.ntt_pass(bufs[0], None, log_n, width, w), reps) for w in (6, 7, 5)}
+            in_proof = {w: timed(lambda w=w: ctx.ntt_pass(bufs[0], None, log_n, width, w), reps) for w in (7, 5)}
+            in_proof[6], i1_spread = i1_over_traces(6)
             avg_ms = (in_proof[6] + 2 * in_proof[5]) / 3.0
             launches_note = "mean over the three pass-kernel launches of one 2^%d x %d trace LDE (I1, F2, F2)" % (log_n, width)
             fb = 12.0 * n * width
@@ -411,7 +421,8 @@ def main():
                      3: "zk::ntt_pass_kernel<4,true,2,5,3>, LDE pass I2 (inverse, contiguous, in place)",
                      4: "zk::ntt_pass_kernel<4,false,2,5,4>, LDE pass F1 (forward, block in -> strided bit-reversed out)",
                      5: "zk::ntt_pass_kernel<4,false,2,5,3>, LDE pass F2 (forward, contiguous, in place)"}
-            in_proof = {w: timed(lambda w=w: ctx.ntt_pass(bufs[0], None, log_n, width, w), reps) for w in (2, 3, 4, 5)}
+            in_proof = {w: timed(lambda w=w: ctx.ntt_pass(bufs[0], None, log_n, width, w), reps) for w in (3, 4, 5)}
+            in_proof[2], i1_spread = i1_over_traces(2)
             avg_ms = (in_proof[2] + in_proof[3] + 2 * in_proof[4] + 2 * in_proof[5]) / 6.0
             launches_note = "mean over the six launches of one 2^%d x %d trace LDE" % (log_n, width)
             lde_ms = in_proof[2] + in_proof[3] + 2 * in_proof[4] + 2 * in_proof[5]
@@ -445,6 +456,7 @@ def main():
                 "kernel": "zk::ntt_pass_kernel, %s on the proving context's own workspaces (in-proof placement, nothing selected)" % launches_note,
                 "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_ms": round(avg_ms, 4),
                 "kernels": {names[w]: {"ms": round(in_proof[w], 4), "GB/s": gbs(in_proof[w]), "frac": round(gbs(in_proof[w]) / HBM_PEAK_GBS, 4)} for w in detail},
+                "first_pass_over_the_timed_shards_traces": i1_spread,
                 "fused_middle_launch": fused_info, "lde": lde_info,
                 "standalone_strided_pass_by_placement": {"pairs": len(placements), "min_ms": round(placements[0], 4), "median_ms": round(med, 4),
                                                          "max_ms": round(placements[-1], 4), "median_frac": round(gbs(med) / HBM_PEAK_GBS, 4),
