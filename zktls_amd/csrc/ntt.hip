@@ -499,7 +499,11 @@ hipError_t launch_ntt_pass(const NttPassArgs& a_, bool inverse, hipStream_t s) {
         const uint32_t r = a.map_mode - 100u;
         a.map_mode = (a.in_stride == 1 && a.out_stride != 1) ? (r == 0 ? 1u : r) : 255u;
     }
-    if (a.map_mode == 255u) a.map_mode = (a.in_stride != 1 || a.out_stride != 1) && pow2_tiles && a.num_tiles >= 1024u ? 4u : 1u;     // smaller transforms lose 3-8 % with it
+    // A pass that reads strided but writes every tile as ONE block (the LDE's first pass in front of the fused launch) is the exception: its
+    // writes are streams of their own, the rotation only scatters its reads -- 0.45 ms with plain XCD order on every (trace, workspace) pair
+    // against 0.46 ... 0.52 ms rotated (tools/i1_map_sweep.py); strided -> strided keeps the rotation (0.50 against 0.52), block -> strided is indifferent.
+    const bool strided_in_block_out = a.in_stride != 1 && a.out_stride == 1;
+    if (a.map_mode == 255u) a.map_mode = (a.in_stride != 1 || a.out_stride != 1) && !strided_in_block_out && pow2_tiles && a.num_tiles >= 1024u ? 4u : 1u;     // smaller transforms lose 3-8 % with it
     if (a.map_mode == 1 && (a.num_tiles % 8u) != 0) a.map_mode = 0;
     if (a.map_mode >= 2 && ((a.num_tiles % 8u) != 0 || !pow2_tiles)) a.map_mode = 0;
     // A/B only (fast_path 1): the persistent 1024 x 32 kernel (one workgroup per CU, next tile prefetched into
