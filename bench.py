@@ -82,6 +82,15 @@ def main():
     ap.add_argument("--force-collective", action="store_true",
                     help="with --gpus 1: initialise the RCCL ('nccl') process group at world size 1 and run the seed broadcast, the MAX "
                          "all-reduce and a barrier through it, so that RCCL is loaded and called on hardware even on a one-GPU box")
+    ap.add_argument("--one-process", action="store_true",
+                    help="ONE process deals the N x K shards over the N devices through the library's own multi-GPU entry "
+                         "(zkhip_prove_shards_multi(NULL, 0, ...): shard s on device s mod N, traces generated where zkhip_shard_device puts them, "
+                         "--streams pooled contexts per device) instead of one rank per GPU; same JSON line, parallelism 'one process, device list'")
+    ap.add_argument("--logical-devices", type=int, default=0,
+                    help="TEST MODE with --one-process on a box with fewer GPUs than --gpus: load the A/B build (libzkhip_ab.so) with "
+                         "ZKHIP_LOGICAL_DEVICES=K, whose device ordinals 0..K-1 are logical devices on the physical ones (own pools, own workers, "
+                         "traces checked to live where their shard is dealt); the line says so and is not a scaling result")
+    ap.add_argument("--no-multichip", action="store_true", help="skip the multi-chip shard with LogUp pairs (SP1's shard structure, rows a7 mixed heights + a8) measured beside the headline")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--wait", choices=("auto", "poll", "block"), default="auto",
                     help="how the prover's host threads wait for their streams (zkhip_set_wait_mode): poll = hipStreamSynchronize, block = sleep "
@@ -92,7 +101,13 @@ def main():
     ap.add_argument("--cpu-threads", type=int, default=0, help="OpenMP threads of the CPU baseline (0: min(cores, 64))")
     args = ap.parse_args()
 
-    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+    if args.logical_devices:
+        if not args.one_process:
+            raise SystemExit("--logical-devices goes with --one-process")
+        os.environ["ZKHIP_LOGICAL_DEVICES"] = str(args.logical_devices)
+        sys.path.insert(0, os.path.join(ROOT, "tools"))
+        import _ab  # noqa: F401  (points the binding at libzkhip_ab.so; nothing has loaded the library yet)
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1 and not args.one_process:
         _spawn_ranks(args.gpus)             # never returns; no GPU call has happened in this process
 
     import numpy as np
@@ -101,7 +116,12 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world != args.gpus:
+    one_proc = args.one_process
+    if one_proc:
+        if world != 1:
+            raise SystemExit("--one-process is ONE process: start it plainly, not under a launcher")
+        n_dev = args.gpus                   # devices of the job (the library's device list); `world` stays 1: no ranks, no collective
+    elif world != args.gpus:
         raise SystemExit("--gpus %d but the launcher started %d ranks" % (args.gpus, world))
 
     def usable_cores():
@@ -119,10 +139,14 @@ def main():
     # get throttled together with the ones that prepare launches: then the waits sleep (hipDeviceScheduleBlockingSync, set through the
     # library BEFORE anything initialises the device -- torch.cuda.is_available() below does).
     cores_ok = usable_cores()
-    wait_block = args.wait == "block" or (args.wait == "auto" and world * (min(args.streams, args.steps) * 1.2 + 1.0) > cores_ok)
+    # Host-thread budget: a rank with four shards in flight has 4 proving threads + the Python main thread; polling, each
+    # proving thread keeps ~1.2 cores busy.  Eight ranks x four in flight = 32 proving threads = ~38 cores' worth of polling under the
+    # 16-core quota of the boxes of this pool: from four GPUs on the waits sleep by default (1.0 core per rank, same ms per step at N = 1).
+    gpus_of_node = args.gpus if one_proc else world
+    wait_block = args.wait == "block" or (args.wait == "auto" and (gpus_of_node >= 4 or gpus_of_node * (min(args.streams, args.steps) * 1.2 + 1.0) > cores_ok))
     from zktls_amd import _lib as zk_lib
     n_vis = torch.cuda.device_count()                    # (counting devices does not initialise them)
-    wait_rc = zk_lib.load().zkhip_set_wait_mode(1 if wait_block else 0, (local_rank % max(n_vis, 1)) if args.share_gpu else local_rank)
+    wait_rc = zk_lib.load().zkhip_set_wait_mode(1 if wait_block else 0, -1 if one_proc else ((local_rank % max(n_vis, 1)) if args.share_gpu else local_rank))
     if wait_rc != 0 and wait_block:
         sys.stderr.write("bench.py: blocking waits could not be set (%d): polling\n" % wait_rc)
         wait_block = False
@@ -181,6 +205,9 @@ def main():
     # one context (= one HIP stream + its workspaces) per shard in flight: while one shard sits in a
     # latency-bound stretch (small FRI layers, host round trips) the other keeps the CUs busy
     S = max(1, min(args.streams, max(args.steps, 1)))
+    in_flight = S                          # shards in flight per GPU (one-process mode: the library's pooled contexts per device)
+    if one_proc:
+        S = 1                              # this process's own context serves the roofline sections only
     streams = [torch.cuda.Stream(device=local_rank) for _ in range(S)]
     ctxs = [Context(local_rank, stream=st.cuda_stream) for st in streams]
     stream, ctx = streams[0], ctxs[0]
@@ -194,7 +221,40 @@ def main():
     # this rank's shards of the K * world-shard job, dealt by the tested scheduling function (round-robin)
     my = shards.shard_indices(max(K, 1) * world, rank, world)
     assert len(my) == max(K, 1)
-    if chip_list is None:
+    op = None
+    if one_proc:
+        # ---- ONE process, the library's device list (what a ZkProver::prove binds on a multi-GPU node).  Shard s of the
+        # N x K-shard job is proven on device zkhip_shard_device(s) = s mod N; its trace is generated THERE, through a context of that device.
+        if chip_list is not None or args.host_traces or LQ:
+            raise SystemExit("--one-process measures the headline shard (no --chips / --host-traces / --logup-pairs)")
+        from zktls_amd.device import prove_shards_multi, shard_device
+        vis = zk_lib.device_count()
+        if n_dev > vis:
+            raise SystemExit("--gpus %d but %d device(s) visible%s" % (n_dev, vis, "" if args.logical_devices else " (--logical-devices K runs the path on fewer GPUs, test mode)"))
+        dev_list = None if n_dev == vis else list(range(n_dev))     # NULL, 0 = every visible device
+        dev_ctx = {0: ctx}
+        for d in range(1, n_dev):
+            dev_ctx[d] = Context(d)
+        job_shards = list(range(max(K, 1) * n_dev))
+        op_traces = {}
+        for s_ in job_shards:
+            d = shard_device(s_, dev_list, n_dev)
+            slot = (s_ // n_dev) % nbuf
+            if (d, slot) not in op_traces:
+                op_traces[(d, slot)] = (dev_ctx[d].gen_trace(SEED, s_, log_n, width), s_)
+        for c in dev_ctx.values():
+            c.sync()
+        bufs = [op_traces[(0, k)][0] for k in range(nbuf)]
+        my = [op_traces[(0, k)][1] for k in range(nbuf)]
+        with torch.cuda.stream(stream):
+            roof_scratch = [torch.empty(n * width, dtype=torch.int32, device="cuda") for _k in range(4)]
+        op = {"dev_list": dev_list, "shards": job_shards}
+
+        def op_run(count_per_dev):
+            ids = list(range(count_per_dev * n_dev))
+            trs = [op_traces[(shard_device(s_, dev_list, n_dev), (s_ // n_dev) % nbuf)] for s_ in ids]
+            return trs, prove_shards_multi([t for t, _ in trs], log_n, width, [public + [sid] for _, sid in trs], prm, devices=dev_list, in_flight=in_flight)
+    elif chip_list is None:
         with torch.cuda.stream(stream):
             traces = [torch.empty(cells, dtype=torch.int32, device="cuda") for _ in range(nbuf)]
         bufs = [ctx.wrap(t) for t in traces]
@@ -281,7 +341,10 @@ def main():
             raise errors[0]
         return results
 
-    run_steps(max(W, S if W else 0), static=True)       # warm every context (plans, workspaces)
+    if one_proc:
+        op_run(max(W, in_flight if W else 0))            # warm every pooled context of every device
+    else:
+        run_steps(max(W, S if W else 0), static=True)       # warm every context (plans, workspaces)
     for c in ctxs:
         c.sync()
 
@@ -294,20 +357,53 @@ def main():
     barrier()
     t0 = time.perf_counter()
     cpu0 = time.process_time()                          # CPU time of all threads of this rank
-    proofs = run_steps(K)
-    barrier()
-    elapsed = time.perf_counter() - t0
-    host_cores_busy = (time.process_time() - cpu0) / elapsed
-    elapsed = shards.max_over_ranks(dist, elapsed, device=coll_dev)
-    last = proofs[K - 1]
-    # after the timed region: every distinct shard of the job was proven on exactly one rank (digest gather over RCCL)
-    # (keyed by the shard actually proven: step i proves shard my[i % nbuf], so beyond nbuf steps shards repeat and only the distinct ones count)
-    distinct = min(K, nbuf) if chip_list is None else K
-    digests = shards.gather_proof_digests(dist, {(my[i % nbuf] if chip_list is None else my[i]): proofs[i] for i in range(K)})
-    expect = sorted(s_ for r_ in range(world) for s_ in shards.shard_indices(max(K, 1) * world, r_, world)[:distinct])
-    if sorted(digests) != expect:
-        raise SystemExit("shard coverage broken: %d digests for %d distinct shards" % (len(digests), len(expect)))
-    del proofs
+    if one_proc:
+        op_trs, proofs = op_run(K)                         # ONE call: N x K shards over the device list
+        for c in dev_ctx.values():
+            c.sync()
+        elapsed = time.perf_counter() - t0
+        host_cores_busy = (time.process_time() - cpu0) / elapsed
+        import hashlib
+        digests = {sid: hashlib.sha256(p_.tobytes()).hexdigest() for (_, sid), p_ in zip(op_trs, proofs)}
+        if len(set(digests.values())) != len(digests) or len(digests) != min(K, nbuf) * n_dev:
+            raise SystemExit("shard coverage broken: %d distinct proofs for %d distinct shards" % (len(set(digests.values())), min(K, nbuf) * n_dev))
+        last = proofs[-1]
+        last_public = public + [op_trs[-1][1]]
+        world_eff = n_dev
+        del proofs
+    else:
+        proofs = run_steps(K)
+        barrier()
+        elapsed = time.perf_counter() - t0
+        host_cores_busy = (time.process_time() - cpu0) / elapsed
+        elapsed = shards.max_over_ranks(dist, elapsed, device=coll_dev)
+        last = proofs[K - 1]
+        last_public = public + [my[(K - 1) % nbuf]] if chip_list is None else public + [my[(K - 1) % len(my)]]
+        world_eff = world
+        # after the timed region: every distinct shard of the job was proven on exactly one rank (digest gather over RCCL)
+        # (keyed by the shard actually proven: step i proves shard my[i % nbuf], so beyond nbuf steps shards repeat and only the distinct ones count)
+        distinct = min(K, nbuf) if chip_list is None else K
+        digests = shards.gather_proof_digests(dist, {(my[i % nbuf] if chip_list is None else my[i]): proofs[i] for i in range(K)})
+        expect = sorted(s_ for r_ in range(world) for s_ in shards.shard_indices(max(K, 1) * world, r_, world)[:distinct])
+        if sorted(digests) != expect:
+            raise SystemExit("shard coverage broken: %d digests for %d distinct shards" % (len(digests), len(expect)))
+        del proofs
+
+    # the library's own multi-GPU entry on the same shards (one process, device list [this GPU]): the path a ZkProver::prove binds
+    # (INTEGRATION.md 2), measured beside the rank-per-GPU path whenever this rank is alone on the node
+    one_process = None
+    if not one_proc and world == 1 and chip_list is None and host_traces is None and LQ == 0:
+        from zktls_amd.device import prove_shards_multi
+        ids = [i % nbuf for i in range(K)]
+        prove_shards_multi([bufs[i] for i in ids[:max(S, 1)]], log_n, width, [public + [my[i]] for i in ids[:max(S, 1)]], prm, devices=None if zk_lib.device_count() == 1 else [local_rank], in_flight=S)
+        to0 = time.perf_counter()
+        pm = prove_shards_multi([bufs[i] for i in ids], log_n, width, [public + [my[i]] for i in ids], prm, devices=None if zk_lib.device_count() == 1 else [local_rank], in_flight=S)
+        dto = time.perf_counter() - to0
+        one_process = {"entry": "zkhip_prove_shards_multi(NULL, 0, ...), %d pooled contexts per device" % S, "ms_per_step": round(dto / K * 1e3, 3),
+                       "value": round(cells * K / dto, 1), "shards_proven": K, "distinct_proofs": len({p_.tobytes() for p_ in pm}),
+                       "same_bytes_as_the_timed_step": bool(pm[K - 1].tobytes() == last.tobytes())}
+        del pm
+        zk_lib.load().zkhip_release_cached_contexts()
 
     # single-shard latency (one shard in flight, nothing else on the GPU): NOT the metric -- `value` is throughput with S shards in flight
     latency_ms = None
@@ -324,12 +420,12 @@ def main():
     # every proof on the CPU inside `prove` (sp1.rs:120), outside the span it times
     tv = time.perf_counter()
     if chip_list is None:
-        rc, reason = verify_shard(last, log_n, width, public + [my[(K - 1) % nbuf]], prm)
+        rc, reason = verify_shard(last, log_n, width, last_public, prm)
         tv = time.perf_counter()
-        rc, reason = verify_shard(last, log_n, width, public + [my[(K - 1) % nbuf]], prm)
+        rc, reason = verify_shard(last, log_n, width, last_public, prm)
     else:
         from zktls_amd.device import verify_chips
-        rc, reason = verify_chips(last, [c[0] for c in chip_list], [c[1] for c in chip_list], public + [my[(K - 1) % len(my)]], prm)
+        rc, reason = verify_chips(last, [c[0] for c in chip_list], [c[1] for c in chip_list], last_public, prm)
     verified = rc == 0
     host_verify_ms = (time.perf_counter() - tv) * 1e3
 
@@ -394,28 +490,37 @@ def main():
             srt = sorted(ms)
             return sum(ms) / len(ms), {"traces": len(ms), "launches_each": per, "min_ms": round(srt[0], 4), "median_ms": round(srt[len(srt) // 2], 4), "max_ms": round(srt[-1], 4)}
         fused_info = None
+        # the LDE of THIS proof shape: 2^log_blowup cosets (sp1: 2, r0: 4).  Fused (2^20 rows x a multiple of 32 columns): I1 once, one
+        # fused middle launch per PAIR of cosets (read 4 B + write 8 B per cell), F2 per coset:
+        #     bytes per trace cell = 8 + (cosets / 2) x 12 + cosets x 8     (sp1: 36, r0: 64)
+        # unfused: I1 + I2 once, F1 + F2 per coset = 16 + cosets x 16      (sp1: 48, r0: 80)
+        cosets = 1 << prm.log_blowup
         if fused_lde:
-            # one LDE = I1 (block form), the FUSED middle launch (second inverse pass + first forward pass of both cosets: the
-            # coefficients never reach memory; 12 B per cell, bound by its butterflies, not by HBM), F2 per coset.  The roofline
-            # kernel is the pass kernel: its three launches of the LDE.
+            # The roofline kernel is the pass kernel: its 1 + cosets launches of the LDE (I1, F2 per coset); the fused launch is bound by
+            # its butterflies, not by HBM, and is reported beside it together with the whole LDE (`lde`, `lde_frac`).
             names = {6: "zk::ntt_pass_kernel<4,true,2,5,4>, LDE pass I1 (inverse, strided in -> one contiguous block per tile; mean over the traces of all timed shards)",
                      5: "zk::ntt_pass_kernel<4,false,2,5,3>, LDE pass F2 (forward, contiguous, in place)"}
             in_proof = {w: timed(lambda w=w: ctx.ntt_pass(bufs[0], None, log_n, width, w), reps) for w in (7, 5)}
             in_proof[6], i1_spread = i1_over_traces(6)
-            avg_ms = (in_proof[6] + 2 * in_proof[5]) / 3.0
-            launches_note = "mean over the three pass-kernel launches of one 2^%d x %d trace LDE (I1, F2, F2)" % (log_n, width)
+            avg_ms = (in_proof[6] + cosets * in_proof[5]) / (1.0 + cosets)
+            launches_note = "mean over the %d pass-kernel launches of one 2^%d x %d trace LDE (I1, %d x F2)" % (1 + cosets, log_n, width, cosets)
             fb = 12.0 * n * width
-            lde_ms = in_proof[6] + in_proof[7] + 2 * in_proof[5]
+            n_fused = cosets // 2
+            lde_bpc = 8 + n_fused * 12 + cosets * 8
+            lde_ms = in_proof[6] + n_fused * in_proof[7] + cosets * in_proof[5]
             # (the unfused launches for comparison: few of them -- the strided -> strided first pass runs under the same kernel name as I1)
             unfused = {w: timed(lambda w=w: ctx.ntt_pass(bufs[0], None, log_n, width, w), 20) for w in (2, 3, 4)}
-            unfused_ms = unfused[2] + unfused[3] + 2 * unfused[4] + 2 * in_proof[5]
-            fused_info = {"kernel": "zk::lde_fused_kernel<1>, second inverse pass + first forward pass of both cosets in one launch",
+            unfused_ms = unfused[2] + unfused[3] + cosets * unfused[4] + cosets * in_proof[5]
+            fused_info = {"kernel": "zk::lde_fused_kernel<1>, second inverse pass + first forward pass of two cosets in one launch (%d per LDE)" % n_fused,
                           "ms": round(in_proof[7], 4), "algorithmic_bytes_per_launch": fb, "GB/s": round(fb / in_proof[7] / 1e6, 1),
                           "frac_of_hbm_peak": round(fb / in_proof[7] / 1e6 / HBM_PEAK_GBS, 4),
                           "bound": "integer VALU: three 1024-point tile transforms per 12 B (DESIGN.md 4.1); it replaces three pass launches of 8 B per cell each",
                           "replaces_ms": round(unfused[3] + 2 * unfused[4], 4)}
-            lde_info = {"launches": "I1 + fused + 2 x F2", "ms": round(lde_ms, 4), "bytes_per_trace_cell": 36,
-                        "GB/s": round(36.0 * n * width / lde_ms / 1e6, 1), "unfused_six_launch_ms": round(unfused_ms, 4), "unfused_bytes_per_trace_cell": 48}
+            lde_info = {"launches": "I1 + %s fused + %d x F2" % ("" if n_fused == 1 else "%d x" % n_fused, cosets), "cosets": cosets, "ms": round(lde_ms, 4),
+                        "bytes_per_trace_cell": lde_bpc, "bytes_formula": "8 + (cosets / 2) x 12 + cosets x 8",
+                        "GB/s": round(float(lde_bpc) * n * width / lde_ms / 1e6, 1), "unfused_launches_ms": round(unfused_ms, 4),
+                        "unfused_bytes_per_trace_cell": 16 + 16 * cosets,
+                        "information_minimum_bytes_per_trace_cell": 4 + 4 * cosets}
             detail = (6, 5)
         else:
             names = {2: "zk::ntt_pass_kernel<4,true,2,5,4>, LDE pass I1 (inverse, strided in -> strided out)",
@@ -424,11 +529,13 @@ def main():
                      5: "zk::ntt_pass_kernel<4,false,2,5,3>, LDE pass F2 (forward, contiguous, in place)"}
             in_proof = {w: timed(lambda w=w: ctx.ntt_pass(bufs[0], None, log_n, width, w), reps) for w in (3, 4, 5)}
             in_proof[2], i1_spread = i1_over_traces(2)
-            avg_ms = (in_proof[2] + in_proof[3] + 2 * in_proof[4] + 2 * in_proof[5]) / 6.0
-            launches_note = "mean over the six launches of one 2^%d x %d trace LDE" % (log_n, width)
-            lde_ms = in_proof[2] + in_proof[3] + 2 * in_proof[4] + 2 * in_proof[5]
-            lde_info = {"launches": "I1 + I2 + 2 x (F1 + F2)", "ms": round(lde_ms, 4), "bytes_per_trace_cell": 48,
-                        "GB/s": round(48.0 * n * width / lde_ms / 1e6, 1)}
+            avg_ms = (in_proof[2] + in_proof[3] + cosets * in_proof[4] + cosets * in_proof[5]) / (2.0 + 2 * cosets)
+            launches_note = "mean over the %d launches of one 2^%d x %d trace LDE" % (2 + 2 * cosets, log_n, width)
+            lde_ms = in_proof[2] + in_proof[3] + cosets * in_proof[4] + cosets * in_proof[5]
+            lde_bpc = 16 + 16 * cosets
+            lde_info = {"launches": "I1 + I2 + %d x (F1 + F2)" % cosets, "cosets": cosets, "ms": round(lde_ms, 4), "bytes_per_trace_cell": lde_bpc,
+                        "bytes_formula": "16 + cosets x 16", "GB/s": round(float(lde_bpc) * n * width / lde_ms / 1e6, 1),
+                        "information_minimum_bytes_per_trace_cell": 4 + 4 * cosets}
             detail = (2, 3, 4, 5)
         achieved = alg_bytes / (avg_ms * 1e-3) / 1e9
         # stand-alone passes on caller buffers, every (source, destination) pair of up to four traces and four scratch buffers
@@ -453,6 +560,10 @@ def main():
                 "frac": round(achieved / HBM_PEAK_GBS, 4),
                 # also against the measured float4-copy ceiling of this part (MI355X_MICROARCH.md: 6.29 TB/s)
                 "frac_of_measured_copy_ceiling": round(achieved / 6290.0, 4),
+                # the WHOLE LDE against the peak: every byte its launches move (lde.bytes_per_trace_cell) over the sum of their durations --
+                # `frac` above covers the pass kernel only (the fused middle launch is VALU-bound and excluded from it)
+                "lde_frac": round(lde_info["GB/s"] / HBM_PEAK_GBS, 4),
+                "lde_frac_of_information_minimum": round(lde_info["information_minimum_bytes_per_trace_cell"] * n * width / lde_ms / 1e6 / HBM_PEAK_GBS, 4),
                 "traffic": traffic, "traffic_source": traffic_src,
                 "kernel": "zk::ntt_pass_kernel, %s on the proving context's own workspaces (in-proof placement, nothing selected)" % launches_note,
                 "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_ms": round(avg_ms, 4),
@@ -552,6 +663,47 @@ def main():
         recursion16 = {"workload": "the FRI check of 16 shard proofs (2^%d x %d, 100 queries x %d layers each) proven in-circuit: Poseidon2 chip (Merkle paths + transcript) + FRI-fold chip + SAMPLES chip + two tables per proof, one zkhip_prove_fri_indices_batch call, shard proofs in as bytes (host view included)" % (log_n, width, log_n),
                        "ms": round(t_rec * 1e3, 2), "recursion_proofs_per_s": round(16 / t_rec, 1), "proof_bytes": int(rec[0][0].size), "all_verified": bool(ok_rec)}
 
+    # ---- SP1's real shard structure beside the headline: six chips of different heights in ONE proof (mixed-height commitments, row a7)
+    # with in-table LogUp pairs (permutation traces + their commitment, row a8), proven with the same number of shards in flight
+    multichip = None
+    if rank == 0 and not args.no_multichip and chip_list is None and host_traces is None and args.shape == "sp1" and LQ == 0 and log_n == 20 and not one_proc:
+        from zktls_amd.device import verify_chips
+        mc_spec = [(20, 96), (20, 32), (19, 64), (18, 128), (16, 256), (14, 40)]
+        mc_pairs = [max(1, w_ // 32) for _, w_ in mc_spec]
+        mc_cells = sum(w_ << ln_ for ln_, w_ in mc_spec)
+        mc_bufs = [(ctx.gen_trace_logup(SEED, 7000 + j_, ln_, w_, q_), ln_, w_, q_) for j_, ((ln_, w_), q_) in enumerate(zip(mc_spec, mc_pairs))]
+        ctx.sync()
+        import threading
+        mc_n = 2 * S
+        mc_out = [None] * (mc_n + S)
+
+        def mc_worker(w_, lo_, cnt_):
+            for i_ in range(lo_ + w_, lo_ + cnt_, S):
+                mc_out[i_] = ctxs[w_].prove_chips(mc_bufs, public + [i_], prm)
+
+        def mc_round(lo_, cnt_):
+            ts_ = [threading.Thread(target=mc_worker, args=(w_, lo_, cnt_)) for w_ in range(S)]
+            for t_ in ts_:
+                t_.start()
+            for t_ in ts_:
+                t_.join()
+        mc_round(0, S)                                        # warm every context at these shapes
+        for c_ in ctxs:
+            c_.sync()
+        tm0 = time.perf_counter()
+        mc_round(S, mc_n)
+        for c_ in ctxs:
+            c_.sync()
+        mc_dt = (time.perf_counter() - tm0) / mc_n
+        mc_rc, _ = verify_chips(mc_out[S + mc_n - 1], [c_[0] for c_ in mc_spec], [c_[1] for c_ in mc_spec], public + [S + mc_n - 1], prm, pairs=mc_pairs)
+        multichip = {"workload": "one shard of six chips %s with in-table LogUp pairs %s (three commitments: main, permutation, quotient; mixed heights), %d trace cells + the permutation traces, log_blowup 1, 100 queries, 16 PoW bits, full zkhip_prove_chips, %d in flight" % (
+                         ",".join("%dx%d" % c_ for c_ in mc_spec), mc_pairs, mc_cells, S),
+                     "ms_per_shard": round(mc_dt * 1e3, 3), "trace_cells_per_s": round(mc_cells / mc_dt, 1), "shards_timed": mc_n,
+                     "proof_bytes": int(mc_out[S + mc_n - 1].size), "verified": bool(mc_rc == 0)}
+        for b_ in mc_bufs:
+            b_[0].free()
+        del mc_out
+
     # ---- CPU baseline: the oracle on the host cores, bounded sample of the same workload
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
@@ -574,6 +726,7 @@ def main():
                    ("%g" % cores_ok) if cores_ok else "none")}
 
     if rank == 0:
+        world = world_eff                               # (one-process mode: the devices of the job)
         total_cells = cells * K * world
         out = {
             "metric": "trace-cells/s",
@@ -588,13 +741,15 @@ def main():
             "vs_baseline": None,
             "dtype": "u32",
             "data": "synthetic",
-            "streams_per_gpu": S, "host_wait": "block" if wait_block else "poll", "host_cores_usable": cores_ok,
+            "streams_per_gpu": in_flight, "host_wait": "block" if wait_block else "poll", "host_cores_usable": cores_ok,
             "host_cores_busy_per_rank": round(host_cores_busy, 2),
+            "one_process_mode": bool(one_proc), "logical_devices_test_mode": int(args.logical_devices),
             "rccl_world_size": (dist.get_world_size() if dist is not None else 1),
             "collective_backend": (dist.get_backend() if dist is not None else None), "rccl_selfcheck_calls": rccl_calls,
             "share_gpu_test_mode": bool(args.share_gpu),
-            "shards_proven": K * world, "distinct_shards_proven": len(digests), "shard_digests_gathered": len(digests), "shard_assignment": "round-robin (zktls_amd.shards.shard_indices)",
-            "timing_note": "ms_per_step is amortised throughput with %d shards in flight per GPU, not latency" % S,
+            "shards_proven": K * world, "distinct_shards_proven": len(digests), "shard_digests_gathered": len(digests),
+            "shard_assignment": "round-robin (zkhip_shard_device: shard s on device s mod N, inside zkhip_prove_shards_multi)" if one_proc else "round-robin (zktls_amd.shards.shard_indices)",
+            "timing_note": "ms_per_step is amortised throughput with %d shards in flight per GPU, not latency" % in_flight,
             "single_shard_latency_ms": (round(latency_ms, 3) if latency_ms is not None else None),
             "inputs": "host memory, H2D copy inside every step" if host_traces is not None else "resident in HBM",
             "config": {"workload": ("multi-chip shard (SP1's shard structure): chips %s, one commitment per phase, %d trace cells, log_blowup 1, 100 queries, 16 PoW bits, full prove_chips" % (args.chips, cells))
@@ -602,7 +757,8 @@ def main():
                                    (("SP1-core-like synthetic shard: 2^%d rows x %d cols BabyBear, log_blowup 1, 100 queries, 16 PoW bits, %s, full prove_shard" if args.shape == "sp1" else
                                      "RISC-Zero-like synthetic segment: 2^%d rows x %d cols BabyBear, blowup 4, 50 queries, FRI fold 16, 256 final coefficients, Poseidon2 width 24, %s, full prove_shard")
                                     % (log_n, width, ("LogUp x%d" % LQ) if LQ else "no lookups")),
-                       "parallelism": "shard-parallel x%d" % world, "shards_per_step": world},
+                       "parallelism": ("one process, device list (zkhip_prove_shards_multi), shard-parallel x%d" % world) if one_proc else "shard-parallel x%d" % world,
+                       "shards_per_step": world},
             "proofs_per_s": round(K * world / elapsed, 3),
             "proof_bytes": int(last.size),
             "verified": bool(verified), "host_verify_ms": round(host_verify_ms, 2),
@@ -612,11 +768,21 @@ def main():
             "batch64": batch64,
             "recursion_proofs_per_s": (recursion16["recursion_proofs_per_s"] if recursion16 else None),
             "recursion16": recursion16,
+            "multichip": multichip,
+            "one_process": one_process,
+            "one_process_value": (one_process["value"] if one_process else None),
             "cpu_baseline": cpu,
         }
         print(json.dumps(out), flush=True)
     for c in ctxs:
         c.close()
+    if one_proc:
+        for t_, _ in op_traces.values():
+            t_.free()
+        for d_, c_ in dev_ctx.items():
+            if d_ != 0:
+                c_.close()
+        zk_lib.load().zkhip_release_cached_contexts()
     if dist is not None:
         dist.barrier()                     # rank 0 is still measuring its roofline section: leave together
         dist.destroy_process_group()

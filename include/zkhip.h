@@ -593,9 +593,14 @@ int zkhip_prove_transcripts(const int* devices, int n_devices, zkhip_transcript_
  * at a fixed rate however many streams feed it.  The batch entries therefore prove small jobs OF ONE SHAPE in lock-step (csrc/batch.h):
  * up to `max_batch` provers run as fibers of one host thread on pooled contexts that share one stream, and their launches of the same
  * kernel merge into one launch (gridDim.z = members; their small copies, memsets and waits merge too); `lanes` such batches are in
- * flight per device.  Used by zkhip_prove_transcripts for traces of up to 2^16 rows and by zkhip_prove_shards / _multi / _air_multi for
- * shards of up to 2^26 cells, when a device gets at least two such jobs.  The proofs are byte for byte those of the unbatched path.
+ * flight per device.  Used by zkhip_prove_transcripts for traces of up to 2^14 rows and by zkhip_prove_shards / _multi / _air_multi for
+ * shards of up to 2^24 cells (the sizes measured as launch-bound), when a device gets at least two such jobs.  The proofs are byte for
+ * byte those of the unbatched path.
  * max_batch 0 or 1 switches lock-step off (defaults: 16 members, 6 lanes; lanes <= 0 keeps the current value).  Process-wide.
+ * Memory: lanes x max_batch contexts per device are in use at once, NOT `in_flight` (which bounds the unbatched path only); the dealer
+ * sizes both against the device's free memory (48 bytes of workspace per trace cell and member) and shrinks the batches, then the lanes,
+ * when they would not fit; a member that still runs out of device memory is proven once more on its own instead of failing, and after
+ * the call the process-wide context pool keeps at most that many contexts and an eighth of the device's memory.
  * zkhip_lockstep_stats: merged launches issued, member launch requests served, rounds whose members asked for different launches, then
  * nanoseconds (summed over the lanes) spent issuing launches, waiting for the stream, and in the members' own host code -- totals since
  * the library was loaded.
@@ -605,6 +610,9 @@ void zkhip_set_lockstep(int max_batch, int lanes);
  * per-thread error string stays theirs across switches.  0, or the number of the first check that failed. */
 int zkhip_selftest_lockstep(int members, int rounds);
 void zkhip_lockstep_stats(uint64_t out[6]);
+/* the most bytes of a member's (fiber's) 2 MiB stack touched so far in this process, page granularity (guard pages at both ends of
+ * every stack turn an overflow into a fault; this says how far from it the provers run).  0 before the first lock-step batch. */
+uint64_t zkhip_lockstep_stack_high_water(void);
 
 /* A second real chip: the width-16 Poseidon2 permutation with Merkle-path chaining -- what a recursion machine (a STARK verifier proven
  * inside a STARK: the compress / shrink / wrap stages behind SP1ProofMode::Groth16, crates/guest-prover-sp1/src/sp1.rs:116; sp1-recursion's

@@ -147,6 +147,7 @@ extern "C" {
     pub fn zkhip_set_wait_mode(blocking: c_int, device: c_int) -> c_int;
     pub fn zkhip_set_lockstep(max_batch: c_int, lanes: c_int);
     pub fn zkhip_lockstep_stats(out: *mut u64);
+    pub fn zkhip_lockstep_stack_high_water() -> u64;
     pub fn zkhip_selftest_lockstep(members: c_int, rounds: c_int) -> c_int;
     // the Poseidon2 permutation chip: Merkle openings (of whole rows when row_width > 0) proven in-circuit
     pub fn zkhip_p2chip_air(program: *mut u32, cap_words: usize) -> usize;

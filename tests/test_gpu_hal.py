@@ -36,7 +36,7 @@ def test_zk_shift(ctx, oracle, count, log_size):
 @pytest.mark.parametrize("ext_field", [0, 1])
 def test_mix_poly_coeffs_and_batch_evaluate_any(ctx, oracle, ext_field):
     rng = np.random.default_rng(20 + ext_field)
-    for count, input_size, ncombo in ((6, 5, 3), (1 << 12, 40, 4), ((1 << 16) + 5, 9, 2)):
+    for count, input_size, ncombo in ((6, 5, 3), (1 << 12, 40, 4), ((1 << 16) + 5, 9, 2), (777, 150, 11), (64, 1, 1)):      # (11 combos: beyond the register accumulators)
         inp = rng.integers(0, P, (input_size, count), dtype=np.uint32)
         combos = rng.integers(0, ncombo, input_size, dtype=np.uint32)
         start, mix = rng.integers(0, P, 4, dtype=np.uint32), rng.integers(0, P, 4, dtype=np.uint32)

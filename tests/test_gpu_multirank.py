@@ -42,3 +42,41 @@ def test_rccl_is_initialised_and_called_at_world_size_one():
     r = run_bench("--gpus", "1", "--force-collective", "--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--log-n", "18", "--width", "64")
     assert r["collective_backend"] == "nccl" and r["rccl_selfcheck_calls"] == 3
     assert r["rccl_world_size"] == 1 and r["shards_proven"] == 2 and r["verified"] is True
+
+
+def test_one_process_deals_the_shards_through_the_librarys_device_list():
+    """bench.py --one-process: zkhip_prove_shards_multi(NULL, 0, ...) is the measuring path (the entry a ZkProver::prove binds on a multi-GPU node)"""
+    r = run_bench("--gpus", "1", "--one-process", "--steps", "3", "--warmup", "1", "--no-cpu-baseline", "--no-batch64", "--no-recursion16",
+                  "--log-n", "18", "--width", "128")
+    assert r["one_process_mode"] is True and r["n_gpus"] == 1 and r["logical_devices_test_mode"] == 0
+    assert r["shards_proven"] == 3 and r["distinct_shards_proven"] == 3
+    assert r["config"]["parallelism"].startswith("one process, device list")
+    assert r["verified"] is True and r["value"] > 0
+
+
+def test_one_process_over_two_logical_devices():
+    """the same with a device list of TWO: the A/B build's logical devices (own pools, own workers, traces generated where their shard is dealt)"""
+    r = run_bench("--gpus", "2", "--one-process", "--logical-devices", "2", "--steps", "3", "--warmup", "1", "--no-cpu-baseline", "--no-batch64",
+                  "--no-recursion16", "--log-n", "18", "--width", "128")
+    assert r["one_process_mode"] is True and r["n_gpus"] == 2 and r["logical_devices_test_mode"] == 2
+    assert r["shards_proven"] == 6 and r["distinct_shards_proven"] == 6
+    assert r["verified"] is True
+
+
+def test_the_rank_per_gpu_line_carries_the_one_process_entry_too():
+    r = run_bench("--gpus", "1", "--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--no-batch64", "--no-recursion16", "--log-n", "18", "--width", "128")
+    assert r["one_process"]["shards_proven"] == 2 and r["one_process"]["distinct_proofs"] == 2 and r["one_process"]["same_bytes_as_the_timed_step"] is True
+    assert r["one_process_value"] > 0
+
+
+def test_multi_device_entries_on_two_logical_devices():
+    """tests/checks/multi_device_logical.py: device traces dealt where they live (and refused where they do not), the NULL device list, the
+    lock-step dealer, host traces and a transcript batch -- all over a device list of two, bytes against the oracle"""
+    env = dict(os.environ)
+    env["ZKHIP_LOGICAL_DEVICES"] = "2"
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "checks", "multi_device_logical.py")], env=env, cwd=ROOT, timeout=900,
+                       stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+    assert p.returncode == 0, p.stderr.decode()[-3000:]
+    r = json.loads([ln for ln in p.stdout.decode().splitlines() if ln.startswith("{")][-1])
+    assert r["logical_devices"] == 2 and r["device_traces_dealt_where_they_live"] == 6 and r["misplaced_trace_refused"] is True
+    assert r["null_device_list_same_bytes"] is True and r["lockstep_small_shards"] == 16 and r["host_traces"] == 5 and r["transcripts_over_the_device_list"] == 8

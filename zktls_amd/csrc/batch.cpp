@@ -22,12 +22,24 @@ std::vector<void*> g_stacks;
 // one pinned allocation: [argument ring | staging up | staging down]
 constexpr size_t ARG_BYTES = (size_t)8 << 20, UP_BYTES = (size_t)8 << 20, DOWN_BYTES = (size_t)48 << 20;
 constexpr size_t RING_BYTES = ARG_BYTES + UP_BYTES + DOWN_BYTES;
-constexpr size_t STACK_BYTES = (size_t)1 << 20;
+// a fiber's stack: [guard page | 2 MiB | guard page] -- an overflow AND an underflow fault instead of corrupting a neighbour.  The
+// provers keep their big arrays in std::vector; HIP runtime calls (hipMalloc in ctx_reserve, lazy plan builds) run on these stacks too,
+// which is what the size is for (measured high-water mark of the recursion and transcript batches: zkhip_lockstep_stack_high_water).
+constexpr size_t GUARD_BYTES = 4096, STACK_USABLE = (size_t)2 << 20, STACK_BYTES = STACK_USABLE + 2 * GUARD_BYTES;
+std::atomic<uint64_t> g_stack_high_water{0};
+// bytes of the usable area that were ever touched, from the resident pages (the area is fresh zero-fill mmap memory; a stack grows down)
+size_t stack_touched(void* stack) {
+    unsigned char vec[STACK_USABLE / 4096];
+    if (mincore((char*)stack + GUARD_BYTES, STACK_USABLE, vec) != 0) return 0;
+    size_t first = 0;
+    while (first < sizeof(vec) && !(vec[first] & 1)) first++;
+    return STACK_USABLE - first * 4096;
+}
 using Clock = std::chrono::steady_clock;
 uint64_t ns_since(Clock::time_point t0) { return (uint64_t)std::chrono::duration_cast<std::chrono::nanoseconds>(Clock::now() - t0).count(); }
 }  // namespace
-std::atomic<uint64_t> g_lockstep_stats[6];
-hipError_t wait_for_stream(hipStream_t s, hipEvent_t* ev);      // launches, requests, mixed rounds; ns: issuing launches, waiting for the stream, members' host code
+std::atomic<uint64_t> g_lockstep_stats[6];                     // launches, requests, mixed rounds; ns: issuing launches, waiting for the stream, members' host code
+uint64_t lockstep_stack_high_water() { return g_stack_high_water.load(); }
 
 LaunchBatcher::LaunchBatcher(int members, hipStream_t stream) : members_(members), stream_(stream) {
     if (members < 1 || members > MAX_MEMBERS) return;
@@ -43,7 +55,8 @@ LaunchBatcher::LaunchBatcher(int members, hipStream_t stream) : members_(members
         if (f.stack) continue;
         void* p = mmap(nullptr, STACK_BYTES, PROT_READ | PROT_WRITE, MAP_PRIVATE | MAP_ANONYMOUS | MAP_STACK, -1, 0);
         if (p == MAP_FAILED) { stacks_ok_ = false; continue; }
-        (void)mprotect(p, 4096, PROT_NONE);                      // guard page: an overflow faults instead of corrupting a neighbour
+        (void)mprotect(p, GUARD_BYTES, PROT_NONE);               // guard pages at BOTH ends
+        (void)mprotect((char*)p + GUARD_BYTES + STACK_USABLE, GUARD_BYTES, PROT_NONE);
         f.stack = p;
     }
     if (ring_ || !stream_) return;                           // (no stream: the scheduler alone, see zkhip_selftest_lockstep)
@@ -57,7 +70,14 @@ LaunchBatcher::~LaunchBatcher() {
         g_lockstep_stats[0] += launches; g_lockstep_stats[1] += requests; g_lockstep_stats[2] += mixed;
         g_lockstep_stats[3] += flush_ns; g_lockstep_stats[4] += sync_ns; g_lockstep_stats[5] += host_ns;
     }
-    if (ring_) (void)hipStreamSynchronize(stream_);            // the last launches may still read the ring
+    // the last launches may still read the ring -- on the shared stream, or on a member's own stream ("loose" launches)
+    if (ring_) { if (loose_used_) (void)hipDeviceSynchronize(); else (void)hipStreamSynchronize(stream_); }
+    if (ran_) {
+        uint64_t hw = 0;
+        for (auto& f : fibers_) if (f.stack) { const uint64_t t = stack_touched(f.stack); if (t > hw) hw = t; }
+        uint64_t cur = g_stack_high_water.load();
+        while (hw > cur && !g_stack_high_water.compare_exchange_weak(cur, hw)) {}
+    }
     std::lock_guard<std::mutex> lk(g_pool_mu);
     if (ring_) { if (g_rings.size() < 16) g_rings.push_back(ring_); else (void)hipHostFree(ring_); }
     for (auto& f : fibers_)
@@ -68,9 +88,12 @@ LaunchBatcher::~LaunchBatcher() {
 void LaunchBatcher::trampoline() {
     LaunchBatcher* self = t_batcher;
     const int b = self->current_;
-    (*self->fn_)(b);
+    // nothing may unwind past this frame (there is no caller above it: uc_link is null): an exception that escapes a member --
+    // std::bad_alloc from a prover's vectors, std::system_error from a mutex -- fails THAT member and marks the batch, not the process
+    try { (*self->fn_)(b); }
+    catch (const std::exception& e) { self->threw_ = true; self->sticky_ = hipErrorUnknown; set_error(std::string("lock-step member: ") + e.what()); }
+    catch (...) { self->threw_ = true; self->sticky_ = hipErrorUnknown; set_error("lock-step member: unknown exception"); }
     self->fibers_[(size_t)b].state = DONE;
-    self->fibers_[(size_t)b].left = true;
     swapcontext(&self->fibers_[(size_t)b].ctx, &self->lane_);  // never resumed
 }
 
@@ -93,13 +116,14 @@ void LaunchBatcher::park(State s) {
 
 void LaunchBatcher::run(const std::function<void(int)>& fn) {
     fn_ = &fn;
+    ran_ = true;
     LaunchBatcher* outer = t_batcher;
     t_batcher = this;
     for (int b = 0; b < members_; b++) {
         Fiber& f = fibers_[(size_t)b];
         getcontext(&f.ctx);
-        f.ctx.uc_stack.ss_sp = (char*)f.stack + 4096;
-        f.ctx.uc_stack.ss_size = STACK_BYTES - 4096;
+        f.ctx.uc_stack.ss_sp = (char*)f.stack + GUARD_BYTES;
+        f.ctx.uc_stack.ss_size = STACK_USABLE;
         f.ctx.uc_link = nullptr;
         makecontext(&f.ctx, (void (*)())&LaunchBatcher::trampoline, 0);
         f.state = RUNNABLE;
@@ -215,9 +239,9 @@ hipError_t LaunchBatcher::sync_all() {
     return fibers_[(size_t)me].status;
 }
 
-void LaunchBatcher::leave() {
-    if (current_ >= 0) fibers_[(size_t)current_].left = true;
-}
+// (A hint only: a member that has left never parks again, so the lane runs it to its end like any runnable fiber and the votes of
+// the others -- taken when nobody can run -- never wait for it.)
+void LaunchBatcher::leave() {}
 
 // A member's staging areas are rings of its own inside the pinned block.  up: the data is consumed by a kernel launched after the
 // member wrote it, so a wrap waits for the stream; down: written by a kernel launched after the member read what it was given

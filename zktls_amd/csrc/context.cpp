@@ -6,6 +6,8 @@
 #include "poseidon2.cuh"
 
 #include <atomic>
+#include <mutex>
+#include <vector>
 
 #include <cstdio>
 #include <cstdlib>
@@ -95,6 +97,7 @@ int get_plan(zkhip_ctx* ctx, int log_n, int kind, uint32_t shift, const NttPlan*
 }
 
 enum { LDE_I1 = 0, LDE_I2 = 1, LDE_F1 = 2, LDE_F2 = 3, LDE_I1_BLOCKS = 4 };
+constexpr int ZKHIP_ERR_UNSUPPORTED_FUSION = -100;     // private to this file: lde_fused_args -> lde_two_pass (take the four-pass sequence)
 
 static NttPassArgs base_args(zkhip_ctx* ctx, const uint32_t* in, size_t in_ld, uint32_t* out, size_t out_ld,
                              uint32_t width, bool inverse) {
@@ -265,9 +268,11 @@ int lde_fused_args(zkhip_ctx* ctx, const uint32_t* coef, size_t coef_ld, uint32_
             uint32_t *a = nullptr, *b = nullptr;
             ZK_HIP(hipMalloc((void**)&a, 1024 * 4));
             if (hipMalloc((void**)&b, (size_t)1024 * 1024 * 4) != hipSuccess) { (void)hipFree(a); return fail(ZKHIP_ERR_HIP, "hipMalloc (fused tables)"); }
+            // the plan owns the tables only once BOTH are filled: a failed launch must not leave pointers to garbage behind
+            hipError_t e = launch_fused_table(a, p->pre, 1, 1, ctx->stream);
+            if (e == hipSuccess) e = launch_fused_table(b, p->post, 1024, 2, ctx->stream);
+            if (e != hipSuccess) { (void)hipFree(a); (void)hipFree(b); return hip_fail(e, "fused tables"); }
             mp->pre_f = a; mp->post_f = b;
-            ZK_HIP(launch_fused_table(a, p->pre, 1, 1, ctx->stream));
-            ZK_HIP(launch_fused_table(b, p->post, 1024, 2, ctx->stream));
         }
         f.out[t] = dsts[t]; f.pre[t] = p->pre_f; f.post[t] = p->post_f;
     }
@@ -276,7 +281,7 @@ int lde_fused_args(zkhip_ctx* ctx, const uint32_t* coef, size_t coef_ld, uint32_
     if (has_rot) { const char* e = getenv("ZKHIP_FUSED_ROT"); f.map_rot = e ? (uint32_t)atoi(e) : 0u; }
     if (has_grid) { const char* e = getenv("ZKHIP_FUSED_GRID"); f.grid = e ? (uint32_t)atoi(e) : 0u; }
 #endif
-    if (!lde_fused_supported(f)) return fail(ZKHIP_ERR_INTERNAL, "lde_fused_args: unsupported shape");
+    if (!lde_fused_supported(f)) return fail(ZKHIP_ERR_UNSUPPORTED_FUSION, "lde_fused_args: unsupported shape");
     *out = f;
     return ZKHIP_OK;
 }
@@ -288,14 +293,17 @@ static int lde_two_pass(zkhip_ctx* ctx, const uint32_t* in, size_t in_ld, uint32
                         int log_n, uint32_t width, const uint32_t* coset_shifts, int cosets, bool run_f2 = true) {
     NttPassArgs a;
     bool inv;
-    if (lde_fused_shape(log_n, width, coef_ld, out_ld, cosets) && ctx->lde_fusion) {
+    bool fused = lde_fused_shape(log_n, width, coef_ld, out_ld, cosets) && ctx->lde_fusion;
+    LdeFusedArgs fargs[16 / FUSED_COSETS];
+    for (int t = 0; fused && t < cosets; t += FUSED_COSETS) {        // all launches of the middle are built BEFORE the first pass is enqueued:
+        const int rc = lde_fused_args(ctx, coef, coef_ld, dsts + t, out_ld, log_n, width, coset_shifts + t, &fargs[t / FUSED_COSETS]);
+        if (rc == ZKHIP_ERR_UNSUPPORTED_FUSION) fused = false;       // a shape the fused kernel refuses takes the four-pass sequence, it is not an error
+        else if (rc != ZKHIP_OK) return rc;
+    }
+    if (fused) {
         ZK_TRY(lde_pass_args(ctx, LDE_I1_BLOCKS, in, in_ld, coef, coef_ld, nullptr, 0, log_n, width, 0, &a, &inv));
         ZK_HIP(launch_ntt_pass(a, inv, ctx->stream));
-        for (int t = 0; t < cosets; t += FUSED_COSETS) {
-            LdeFusedArgs f;
-            ZK_TRY(lde_fused_args(ctx, coef, coef_ld, dsts + t, out_ld, log_n, width, coset_shifts + t, &f));
-            ZK_HIP(launch_lde_fused(f, ctx->stream));
-        }
+        for (int t = 0; t < cosets; t += FUSED_COSETS) ZK_HIP(launch_lde_fused(fargs[t / FUSED_COSETS], ctx->stream));
     } else {
         ZK_TRY(lde_pass_args(ctx, LDE_I1, in, in_ld, coef, coef_ld, nullptr, 0, log_n, width, 0, &a, &inv));
         ZK_HIP(launch_ntt_pass(a, inv, ctx->stream));
@@ -591,9 +599,49 @@ extern "C" {
 int zkhip_version(void) { return ZKHIP_VERSION; }
 const char* zkhip_last_error(void) { return g_last_error.c_str(); }
 
+// ---- LOGICAL devices (A/B build only, never in libzkhip.so).  The multi-device entries (jobs.cpp) deal shards over a device list, keep
+// one context pool per listed device and expect a shard's trace to live on the device the shard is dealt to.  On a one-GPU box that
+// code path cannot run (the list refuses a repeated ordinal).  With ZKHIP_LOGICAL_DEVICES=K in the environment of a process that
+// loaded libzkhip_ab.so, ordinals 0 .. K-1 are K LOGICAL devices on the physical ones (ordinal d -> physical d mod visible): own
+// pools, own workers and lanes, and allocations made through zkhip_malloc remember the logical device of their context, so that
+// "the trace lives where the shard is dealt" is checked by logical ordinal (prove_shards_on).
+extern "C++" {
+#ifdef ZKHIP_AB_HOOKS
+namespace zk {
+int logical_devices() {
+    static const int k = [] { const char* e = getenv("ZKHIP_LOGICAL_DEVICES"); const int v = e ? atoi(e) : 0; return v > 0 && v <= 64 ? v : 0; }();
+    return k;
+}
+static std::mutex g_alloc_mu;
+static std::vector<std::pair<std::pair<uintptr_t, size_t>, int>> g_allocs;     // ((base, bytes), logical device)
+int logical_device_of(const void* p) {
+    std::lock_guard<std::mutex> lk(g_alloc_mu);
+    const uintptr_t a = (uintptr_t)p;
+    for (auto& e : g_allocs) if (a >= e.first.first && a < e.first.first + e.first.second) return e.second;
+    return -1;
+}
+}  // namespace zk
+#endif
+namespace zk {
+int physical_device(int device) {
+#ifdef ZKHIP_AB_HOOKS
+    if (logical_devices() > 0 && device >= 0) {
+        int n = 0;
+        if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) { (void)hipGetLastError(); return device; }
+        return device % n;
+    }
+#endif
+    return device;
+}
+}  // namespace zk
+}  // extern "C++"
+
 int zkhip_device_count(void) {
     int n = 0;
     if (hipGetDeviceCount(&n) != hipSuccess) { (void)hipGetLastError(); return 0; }
+#ifdef ZKHIP_AB_HOOKS
+    if (n > 0 && logical_devices() > 0) return logical_devices();
+#endif
     return n;
 }
 
@@ -605,6 +653,13 @@ int zkhip_ctx_create(int device, void* stream, zkhip_ctx** out) {
         (void)hipGetLastError();
         return fail(ZKHIP_ERR_NO_DEVICE, "no HIP device visible: libzkhip has no CPU fallback");
     }
+    const int logical = device;
+#ifdef ZKHIP_AB_HOOKS
+    if (logical_devices() > 0) {
+        if (device < 0 || device >= logical_devices()) return fail(ZKHIP_ERR_INVALID, "ctx_create: logical device ordinal out of range");
+        device = physical_device(device);
+    }
+#endif
     if (device < 0 || device >= n) return fail(ZKHIP_ERR_INVALID, "ctx_create: device ordinal out of range");
     ZK_HIP(hipSetDevice(device));
     hipDeviceProp_t prop;
@@ -615,6 +670,7 @@ int zkhip_ctx_create(int device, void* stream, zkhip_ctx** out) {
     if (!ctx) return fail(ZKHIP_ERR_NOMEM, "ctx_create: out of host memory");
     g_live_contexts.fetch_add(1);
     ctx->device = device;
+    ctx->logical_device = logical;
     if (stream) { ctx->stream = (hipStream_t)stream; ctx->own_stream = false; }
     else {
         hipError_t e = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking);
@@ -701,11 +757,20 @@ int zkhip_malloc(zkhip_ctx* ctx, size_t bytes, void** d_ptr) {
     CHECK_CTX(ctx);
     if (!d_ptr) return fail(ZKHIP_ERR_INVALID, "malloc: null out pointer");
     ZK_HIP(hipMalloc(d_ptr, bytes ? bytes : 4));
+#ifdef ZKHIP_AB_HOOKS
+    if (logical_devices() > 0) { std::lock_guard<std::mutex> lk(g_alloc_mu); g_allocs.push_back({{(uintptr_t)*d_ptr, bytes ? bytes : 4}, ctx->logical_device}); }
+#endif
     return ZKHIP_OK;
 }
 int zkhip_free(zkhip_ctx* ctx, void* d_ptr) {
     CHECK_CTX(ctx);
     ZK_HIP(hipStreamSynchronize(ctx->stream));
+#ifdef ZKHIP_AB_HOOKS
+    if (logical_devices() > 0 && d_ptr) {
+        std::lock_guard<std::mutex> lk(g_alloc_mu);
+        for (size_t i = 0; i < g_allocs.size(); i++) if (g_allocs[i].first.first == (uintptr_t)d_ptr) { g_allocs.erase(g_allocs.begin() + (long)i); break; }
+    }
+#endif
     if (d_ptr) ZK_HIP(hipFree(d_ptr));
     return ZKHIP_OK;
 }
@@ -832,7 +897,8 @@ int zkhip_ntt_pass(zkhip_ctx* ctx, const uint32_t* d_in, uint32_t* d_out, size_t
         const uint32_t shifts[2] = {MONTY_GEN, fmul(MONTY_GEN, wnb)};
         uint32_t* dsts[2] = {(uint32_t*)lde, (uint32_t*)lde + n * width};
         LdeFusedArgs f;
-        ZK_TRY(lde_fused_args(ctx, (const uint32_t*)coef, width, dsts, width, log_n, width, shifts, &f));
+        const int frc = lde_fused_args(ctx, (const uint32_t*)coef, width, dsts, width, log_n, width, shifts, &f);
+        if (frc != ZKHIP_OK) return frc == ZKHIP_ERR_UNSUPPORTED_FUSION ? ZKHIP_ERR_INVALID : frc;      // (the private code never crosses the ABI)
         f.bench_tag = 1;
         ZK_HIP(launch_lde_fused(f, ctx->stream));
         return ZKHIP_OK;

@@ -93,7 +93,8 @@ enum Slot {
 }  // namespace zk
 
 struct zkhip_ctx {
-    int device = 0;
+    int device = 0;                      // physical HIP ordinal
+    int logical_device = 0;              // the ordinal the caller named (== device except under the A/B build's ZKHIP_LOGICAL_DEVICES)
     hipStream_t stream = nullptr;
     bool own_stream = false;
     uint32_t* w1024_fwd = nullptr;
@@ -157,8 +158,18 @@ int dev_memset(zkhip_ctx* ctx, void* dst, int byte, size_t bytes);
 int lockstep_batch();
 int lockstep_lanes();
 void lockstep_set(int max_batch, int lanes);
-constexpr uint64_t LOCKSTEP_MAX_CELLS = (uint64_t)1 << 26;   // trace cells of a shard that still counts as small (2^16 rows x 1024 columns)
+// trace cells of a proof that still counts as small.  Measured as launch-bound (lock-step pays): the 13 KB transcript machine (2^14 x 608 +
+// a 2^16-row table = 10 M cells), the query-phase recursion machine (2^15 x 364 + four small chips = 12 M cells).  A proof of 2^26 cells
+// (256 MiB of trace) is not launch-bound and takes one context + stream per worker (`in_flight` of them) instead.
+constexpr uint64_t LOCKSTEP_MAX_CELLS = (uint64_t)1 << 24;
+constexpr size_t LOCKSTEP_BYTES_PER_CELL = 48;               // workspace estimate per trace cell of a member (blowup 2: ~20 measured)
+// job_cells: trace cells of the largest job (x 2^(log_blowup - 1)), for the memory budget: lanes x max_batch contexts must fit the device
 int deal_jobs_lockstep(const int* devices, int n_devices, int n_jobs, const int* shape, int max_batch, int lanes,
-                       const std::function<int(zkhip_ctx*, int)>& run, std::vector<char>& ran);
+                       const std::function<int(zkhip_ctx*, int)>& run, std::vector<char>& ran, uint64_t job_cells = 0);
 int resolve_devices(const int* devices, int n_devices, const char* what, std::vector<int>& devs);
+int physical_device(int device);     // the HIP ordinal behind a device-list entry (identity in the shipped library)
+#ifdef ZKHIP_AB_HOOKS
+int logical_devices();               // ZKHIP_LOGICAL_DEVICES (0: off)
+int logical_device_of(const void* p);   // logical device of the zkhip_malloc allocation that holds p, or -1
+#endif
 }  // namespace zk

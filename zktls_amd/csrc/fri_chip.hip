@@ -1082,7 +1082,8 @@ int zkhip_prove_fri_indices_batch(const int* devices, int n_devices, zkhip_fri_j
     if (max_batch > 1 && cells <= LOCKSTEP_MAX_CELLS && n_jobs >= 2 * nd) {
         if (verify) checkers.reset(new HostPool(8));
         std::vector<int> shape((size_t)n_jobs, 0);
-        rcj = deal_jobs_lockstep(devs.data(), nd, n_jobs, shape.data(), max_batch, lockstep_lanes(), run, ran);
+        rcj = deal_jobs_lockstep(devs.data(), nd, n_jobs, shape.data(), max_batch, lockstep_lanes(), run, ran,
+                                 cells << (outer->log_blowup > 1 ? outer->log_blowup - 1 : 0));
     } else
         rcj = deal_jobs(devs.data(), nd, n_jobs, in_flight_per_device, run, ran);
     std::string msg = rcj != ZKHIP_OK ? zkhip_last_error() : "";

@@ -6,8 +6,10 @@
 // which the reference reaches through crates/guest-prover-r0/src/prover.rs:90.  Layout as RISC Zero's Hal holds it:
 // polynomials / columns are contiguous vectors (column-major [count][size]), base elements in Montgomery form, extension
 // elements 4 consecutive words.  The extension field is a TEMPLATE PARAMETER: x^4 = 11 (Plonky3 / SP1) or x^4 = -11
-// (RISC Zero's x^4 + 11).  All of these are HBM-bound streaming or gather kernels (no MFMA, nothing to tile): coalesced
-// accesses along the contiguous vector index, one thread per output element, 64-bit address arithmetic.
+// (RISC Zero's x^4 + 11).  All of these are HBM-bound streaming or gather kernels (no MFMA, nothing to tile).  The streaming ones
+// move 16 bytes per lane and instruction where alignment allows (add, zeroize, zk_shift, sum), mix_poly_coeffs keeps its
+// accumulators in registers and reads the (wave-uniform) mix powers from a small table, batch_evaluate_any reads its coefficients
+// coalesced (lane t takes coefficients t mod 256).  Measured per operator at RISC Zero's sizes: profiles/r04_hal_ops.md.
 #include "context.h"
 
 namespace zk {
@@ -29,12 +31,46 @@ ZK_D Ext ext_add_d(const Ext& a, const Ext& b) { return Ext{{dadd(a.c[0], b.c[0]
 ZK_D Ext ld_ext(const uint32_t* p) { const uint4 v = *reinterpret_cast<const uint4*>(p); return Ext{{v.x, v.y, v.z, v.w}}; }
 ZK_D void st_ext(uint32_t* p, const Ext& e) { *reinterpret_cast<uint4*>(p) = make_uint4(e.c[0], e.c[1], e.c[2], e.c[3]); }
 
-// ---- element-wise (grid-stride, 4 B per lane: fully coalesced)
-__global__ void hal_add_kernel(uint32_t* __restrict__ out, const uint32_t* __restrict__ a, const uint32_t* __restrict__ b, uint64_t n) {
-    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) out[i] = dadd(a[i], b[i]);
+typedef uint32_t hal_u32x4 __attribute__((ext_vector_type(4)));
+// ---- element-wise (grid-stride; 16 B per lane when the vectors are 16-byte aligned, the tail and unaligned vectors 4 B per lane)
+__global__ void hal_add_kernel(uint32_t* __restrict__ out, const uint32_t* __restrict__ a, const uint32_t* __restrict__ b, uint64_t n, int vec) {
+    const uint64_t tid = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x, nth = (uint64_t)gridDim.x * blockDim.x;
+    uint64_t done = 0;
+    if (vec) {
+        const uint64_t n4 = n / 4;
+        const hal_u32x4* a4 = reinterpret_cast<const hal_u32x4*>(a);
+        const hal_u32x4* b4 = reinterpret_cast<const hal_u32x4*>(b);
+        hal_u32x4* o4 = reinterpret_cast<hal_u32x4*>(out);
+        for (uint64_t i = tid; i < n4; i += nth) {
+            const hal_u32x4 x = __builtin_nontemporal_load(a4 + i), y = __builtin_nontemporal_load(b4 + i);
+            hal_u32x4 r;
+            r.x = dadd(x.x, y.x); r.y = dadd(x.y, y.y); r.z = dadd(x.z, y.z); r.w = dadd(x.w, y.w);
+            __builtin_nontemporal_store(r, o4 + i);
+        }
+        done = n4 * 4;
+    }
+    for (uint64_t i = done + tid; i < n; i += nth) out[i] = dadd(a[i], b[i]);
 }
-__global__ void hal_zeroize_kernel(uint32_t* __restrict__ io, uint64_t n) {
-    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x)
+__global__ void hal_zeroize_kernel(uint32_t* __restrict__ io, uint64_t n, int vec) {
+    const uint64_t tid = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x, nth = (uint64_t)gridDim.x * blockDim.x;
+    uint64_t done = 0;
+    if (vec) {
+        const uint64_t n4 = n / 4;
+        uint4* p = reinterpret_cast<uint4*>(io);
+        for (uint64_t i = tid; i < n4; i += nth) {
+            uint4 v = p[i];
+            const bool hit = v.x == 0xFFFFFFFFu || v.y == 0xFFFFFFFFu || v.z == 0xFFFFFFFFu || v.w == 0xFFFFFFFFu;
+            if (hit) {                                         // (rare: only touched lines are written back)
+                if (v.x == 0xFFFFFFFFu) v.x = 0u;
+                if (v.y == 0xFFFFFFFFu) v.y = 0u;
+                if (v.z == 0xFFFFFFFFu) v.z = 0u;
+                if (v.w == 0xFFFFFFFFu) v.w = 0u;
+                p[i] = v;
+            }
+        }
+        done = n4 * 4;
+    }
+    for (uint64_t i = done + tid; i < n; i += nth)
         if (io[i] == 0xFFFFFFFFu) io[i] = 0u;
 }
 // out[i] = sum_j in[j * count + i] (extension elements): lanes along i, the j loop walks `to_add` coalesced rows
@@ -45,32 +81,84 @@ __global__ void hal_sum_ext_kernel(uint32_t* __restrict__ out, const uint32_t* _
     for (uint64_t j = 0; j < to_add; j++) acc = ext_add_d(acc, ld_ext(in + 4 * (j * count + i)));
     st_ext(out + 4 * i, acc);
 }
-// coefficient i of every polynomial times shift^i: a thread owns 16 consecutive coefficients (one fpow, then a running product)
-__global__ void hal_zk_shift_kernel(uint32_t* __restrict__ io, uint64_t count, int log_size, uint32_t shift) {
-    const uint64_t n = (uint64_t)1 << log_size, chunks = (n + 15) / 16;
-    const uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= count * chunks) return;
-    const uint64_t p = t / chunks, i0 = (t % chunks) * 16;
-    uint32_t s = fpow(shift, i0);
-    uint32_t* v = io + p * n + i0;
-    for (uint64_t k = 0; k < 16 && i0 + k < n; k++) { v[k] = dmul(v[k], s); s = dmul(s, shift); }
-}
-// out[combos[i] * count + idx] += mix_start * mix^i * in[i * count + idx]: a thread owns one idx and walks the inputs (reads coalesced
-// along idx); the accumulators of the (few) combos live in the output itself, read-modify-write per term
-template <uint32_t W>
-__global__ void hal_mix_poly_coeffs_kernel(uint32_t* __restrict__ out, Ext mix_start, Ext mix, const uint32_t* __restrict__ in,
-                                           const uint32_t* __restrict__ combos, uint64_t input_size, uint64_t count) {
-    const uint64_t idx = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx >= count) return;
-    Ext cur = mix_start;
-    for (uint64_t i = 0; i < input_size; i++) {
-        uint32_t* o = out + 4 * ((uint64_t)combos[i] * count + idx);
-        st_ext(o, ext_add_d(ld_ext(o), ext_mul_base_dev(cur, in[i * count + idx])));
-        cur = ext_mul_t<W>(cur, mix);
+// coefficient i of every polynomial times shift^i.  blockIdx.y = the polynomial; a lane owns FOUR consecutive coefficients (one
+// 16-byte load and store, the lanes of a wave 1 KiB of consecutive memory) and walks the polynomial with the grid's stride: one
+// fpow at its first position, then its running power moves on by shift^(4 * threads) -- `step`, the same for every lane, with
+// s1 .. s3 = shift^1 .. shift^3 computed once on the host.  Polynomials shorter than 4 coefficients: one lane each.
+__global__ void hal_zk_shift_kernel(uint32_t* __restrict__ io, int log_size, uint32_t shift, uint32_t s1, uint32_t s2, uint32_t s3, uint32_t step) {
+    const uint64_t n = (uint64_t)1 << log_size;
+    uint32_t* v = io + (uint64_t)blockIdx.y * n;
+    const uint64_t tid = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x, nth = (uint64_t)gridDim.x * blockDim.x;
+    if (n < 4) {
+        if (tid == 0) { uint32_t s = MONTY_R1; for (uint64_t k = 0; k < n; k++) { v[k] = dmul(v[k], s); s = dmul(s, shift); } }
+        return;
+    }
+    uint64_t i = 4 * tid;
+    if (i >= n) return;
+    uint32_t s = fpow(shift, i);
+    uint4* p = reinterpret_cast<uint4*>(v);
+    for (; i < n; i += 4 * nth) {
+        uint4 x = p[i / 4];
+        x.x = dmul(x.x, s); x.y = dmul(x.y, dmul(s, s1)); x.z = dmul(x.z, dmul(s, s2)); x.w = dmul(x.w, dmul(s, s3));
+        p[i / 4] = x;
+        s = dmul(s, step);
     }
 }
-// out[e] = polynomial which[e] at xs[e]: one workgroup per evaluation.  Thread t evaluates the coefficient slice
-// [t * L, (t + 1) * L) by Horner, scales it by x^(t L) and the 256 partial values are summed in LDS.
+// mix_poly_coeffs: out[combos[i] * count + idx] += mix_start * mix^i * in[i * count + idx].
+// (1) the powers mix_start * mix^i are the same for every idx: one small launch writes them to a table (a wave's scan: lane l takes
+//     i = l, l + 64, ...; its start mix^l by square-and-multiply, its stride mix^64);
+// (2) a lane owns one idx and walks the inputs (reads coalesced along idx, 4 B per lane, the power of the step from the table through
+//     scalar loads -- the index is wave-uniform).  Up to MIX_REGS combos accumulate in REGISTERS (the combo number is wave-uniform: a
+//     scalar branch picks the accumulator) and reach the output once, at the end; combos beyond that are added in memory per term.
+constexpr int MIX_REGS = 8;
+template <uint32_t W>
+__global__ void __launch_bounds__(64) hal_mix_powers_kernel(uint32_t* __restrict__ table, Ext mix_start, Ext mix, uint64_t input_size) {
+    const uint32_t l = threadIdx.x;
+    Ext pw = ext_one(), b = mix;
+    for (uint32_t k = l; k; k >>= 1) { if (k & 1) pw = ext_mul_t<W>(pw, b); b = ext_mul_t<W>(b, b); }
+    Ext stride = mix;                                          // mix^64
+    for (int k = 0; k < 6; k++) stride = ext_mul_t<W>(stride, stride);
+    Ext cur = ext_mul_t<W>(mix_start, pw);
+    for (uint64_t i = l; i < input_size; i += 64) { st_ext(table + 4 * i, cur); cur = ext_mul_t<W>(cur, stride); }
+}
+__global__ void __launch_bounds__(256) hal_mix_poly_coeffs_kernel(uint32_t* __restrict__ out, const uint32_t* __restrict__ powers, const uint32_t* __restrict__ in,
+                                                                  const uint32_t* __restrict__ combos, uint64_t input_size, uint64_t count) {
+    const uint64_t idx = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= count) return;
+    Ext acc[MIX_REGS];
+#pragma unroll
+    for (int c = 0; c < MIX_REGS; c++) acc[c] = ext_zero();
+    uint32_t touched = 0;
+    for (uint64_t i = 0; i < input_size; i++) {
+        const uint32_t combo = __builtin_amdgcn_readfirstlane(combos[i]);
+        const uint4 pv = *reinterpret_cast<const uint4*>(powers + 4 * i);          // uniform address: scalar loads
+        const Ext cur{{(uint32_t)__builtin_amdgcn_readfirstlane(pv.x), (uint32_t)__builtin_amdgcn_readfirstlane(pv.y),
+                       (uint32_t)__builtin_amdgcn_readfirstlane(pv.z), (uint32_t)__builtin_amdgcn_readfirstlane(pv.w)}};
+        const Ext term = ext_mul_base_dev(cur, __builtin_nontemporal_load(in + i * count + idx));
+        if (combo < (uint32_t)MIX_REGS) {
+            touched |= 1u << combo;
+            switch (combo) {                                   // wave-uniform: one scalar branch, statically indexed registers
+                case 0: acc[0] = ext_add_d(acc[0], term); break;
+                case 1: acc[1] = ext_add_d(acc[1], term); break;
+                case 2: acc[2] = ext_add_d(acc[2], term); break;
+                case 3: acc[3] = ext_add_d(acc[3], term); break;
+                case 4: acc[4] = ext_add_d(acc[4], term); break;
+                case 5: acc[5] = ext_add_d(acc[5], term); break;
+                case 6: acc[6] = ext_add_d(acc[6], term); break;
+                default: acc[7] = ext_add_d(acc[7], term); break;
+            }
+        } else {
+            uint32_t* o = out + 4 * ((uint64_t)combo * count + idx);
+            st_ext(o, ext_add_d(ld_ext(o), term));
+        }
+    }
+#pragma unroll
+    for (int c = 0; c < MIX_REGS; c++)
+        if (touched & (1u << c)) { uint32_t* o = out + 4 * ((uint64_t)c * count + idx); st_ext(o, ext_add_d(ld_ext(o), acc[c])); }
+}
+// out[e] = polynomial which[e] at xs[e]: one workgroup per evaluation.  Lane t takes the coefficients i = t mod 256 (a wave reads 256
+// consecutive bytes per step): Horner in y = x^256 over c[t], c[t + 256], ..., from the top; the partial value is scaled by x^t and
+// the 256 partial values are summed in LDS.
 template <uint32_t W>
 __global__ void __launch_bounds__(256) hal_batch_evaluate_any_kernel(const uint32_t* __restrict__ coeffs, int log_size, const uint32_t* __restrict__ which,
                                                                      const uint32_t* __restrict__ xs, uint32_t* __restrict__ out) {
@@ -79,14 +167,18 @@ __global__ void __launch_bounds__(256) hal_batch_evaluate_any_kernel(const uint3
     const uint32_t e = blockIdx.x, t = threadIdx.x;
     const uint32_t* c = coeffs + (uint64_t)which[e] * n;
     const Ext x = ld_ext(xs + 4 * (uint64_t)e);
-    const uint64_t L = (n + 255) / 256, lo = (uint64_t)t * L;
     Ext acc = ext_zero();
-    if (lo < n) {
-        const uint64_t hi = lo + L < n ? lo + L : n;
-        for (uint64_t i = hi; i-- > lo;) { acc = ext_mul_t<W>(acc, x); acc.c[0] = dadd(acc.c[0], c[i]); }
-        // x^lo by square and multiply
-        Ext pw = ext_one(), b = x;
-        for (uint64_t k = lo; k; k >>= 1) { if (k & 1) pw = ext_mul_t<W>(pw, b); b = ext_mul_t<W>(b, b); }
+    if (t < n) {
+        Ext y = x;                                             // x^256
+        for (int k = 0; k < 8; k++) y = ext_mul_t<W>(y, y);
+        const uint64_t top = t + ((n - 1 - t) / 256) * 256;    // the largest i = t mod 256 below n
+        for (uint64_t i = top;; i -= 256) {
+            acc = ext_mul_t<W>(acc, y);
+            acc.c[0] = dadd(acc.c[0], c[i]);
+            if (i < 256) break;
+        }
+        Ext pw = ext_one(), b = x;                             // x^t by square and multiply
+        for (uint32_t k = t; k; k >>= 1) { if (k & 1) pw = ext_mul_t<W>(pw, b); b = ext_mul_t<W>(b, b); }
         acc = ext_mul_t<W>(acc, pw);
     }
     for (int k = 0; k < 4; k++) part[t][k] = acc.c[k];
@@ -269,7 +361,8 @@ int zkhip_eltwise_add(zkhip_ctx* ctx, uint32_t* d_out, const uint32_t* d_a, cons
     CHECK_CTX(ctx);
     if (n && (!d_out || !d_a || !d_b)) return fail(ZKHIP_ERR_INVALID, "eltwise_add: null pointer");
     if (!n) return ZKHIP_OK;
-    hipLaunchKernelGGL(hal_add_kernel, dim3(grid_for(n)), dim3(256), 0, ctx->stream, d_out, d_a, d_b, (uint64_t)n);
+    const int vec = ((reinterpret_cast<uintptr_t>(d_out) | reinterpret_cast<uintptr_t>(d_a) | reinterpret_cast<uintptr_t>(d_b)) & 15) == 0;
+    hipLaunchKernelGGL(hal_add_kernel, dim3(grid_for(vec ? (n + 3) / 4 : n, 8192)), dim3(256), 0, ctx->stream, d_out, d_a, d_b, (uint64_t)n, vec);
     LAUNCHED();
     return ZKHIP_OK;
 }
@@ -283,7 +376,8 @@ int zkhip_eltwise_zeroize(zkhip_ctx* ctx, uint32_t* d_io, size_t n) {
     CHECK_CTX(ctx);
     if (n && !d_io) return fail(ZKHIP_ERR_INVALID, "eltwise_zeroize: null pointer");
     if (!n) return ZKHIP_OK;
-    hipLaunchKernelGGL(hal_zeroize_kernel, dim3(grid_for(n)), dim3(256), 0, ctx->stream, d_io, (uint64_t)n);
+    const int vec = (reinterpret_cast<uintptr_t>(d_io) & 15) == 0;
+    hipLaunchKernelGGL(hal_zeroize_kernel, dim3(grid_for(vec ? (n + 3) / 4 : n, 8192)), dim3(256), 0, ctx->stream, d_io, (uint64_t)n, vec);
     LAUNCHED();
     return ZKHIP_OK;
 }
@@ -299,9 +393,16 @@ int zkhip_eltwise_sum_ext(zkhip_ctx* ctx, uint32_t* d_out, const uint32_t* d_in,
 int zkhip_zk_shift(zkhip_ctx* ctx, uint32_t* d_io, size_t count, int log_size, uint32_t shift) {
     CHECK_CTX(ctx);
     if (!d_io || log_size < 0 || log_size > 30 || shift == 0 || shift >= P) return fail(ZKHIP_ERR_INVALID, "zk_shift: bad arguments (shift canonical, non-zero)");
-    const uint64_t chunks = (((uint64_t)1 << log_size) + 15) / 16, threads = (uint64_t)count * chunks;
-    if (!threads) return ZKHIP_OK;
-    hipLaunchKernelGGL(hal_zk_shift_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, ctx->stream, d_io, (uint64_t)count, log_size, to_monty(shift));
+    if (!count) return ZKHIP_OK;
+    if (count > 65535) return fail(ZKHIP_ERR_INVALID, "zk_shift: at most 65535 polynomials per call");
+    if (log_size >= 2 && (reinterpret_cast<uintptr_t>(d_io) & 15)) return fail(ZKHIP_ERR_INVALID, "zk_shift: the vector must be 16-byte aligned");
+    // a lane owns 4 coefficients per step; ~16 steps per lane amortise its fpow; whole polynomials per grid row
+    const uint64_t quads = log_size >= 2 ? ((uint64_t)1 << log_size) / 4 : 1;
+    uint64_t blocks = (quads + 256 * 16 - 1) / (256 * 16);
+    if (blocks < 1) blocks = 1;
+    if (blocks > 1024) blocks = 1024;
+    const uint32_t sm = to_monty(shift), s2 = fmul(sm, sm), s3 = fmul(s2, sm), step = fpow(sm, 4 * blocks * 256);
+    hipLaunchKernelGGL(hal_zk_shift_kernel, dim3((unsigned)blocks, (unsigned)count), dim3(256), 0, ctx->stream, d_io, log_size, sm, sm, s2, s3, step);
     LAUNCHED();
     return ZKHIP_OK;
 }
@@ -313,9 +414,13 @@ int zkhip_mix_poly_coeffs(zkhip_ctx* ctx, uint32_t* d_out, const uint32_t mix_st
         return fail(ZKHIP_ERR_INVALID, "mix_poly_coeffs: bad arguments");
     if (!count || !input_size) return ZKHIP_OK;
     const Ext ms{{mix_start[0], mix_start[1], mix_start[2], mix_start[3]}}, mx{{mix[0], mix[1], mix[2], mix[3]}};
-    const dim3 grid((unsigned)((count + 255) / 256)), block(256);
-    if (ext_field == ZKHIP_EXT_X4_PLUS_11) hipLaunchKernelGGL((hal_mix_poly_coeffs_kernel<MONTY_W_R0>), grid, block, 0, ctx->stream, d_out, ms, mx, d_in, d_combos, (uint64_t)input_size, (uint64_t)count);
-    else hipLaunchKernelGGL((hal_mix_poly_coeffs_kernel<MONTY_W_SP1>), grid, block, 0, ctx->stream, d_out, ms, mx, d_in, d_combos, (uint64_t)input_size, (uint64_t)count);
+    void* v_pow;
+    ZK_TRY(ctx_reserve(ctx, S_COL_B, input_size * 16, &v_pow));
+    uint32_t* powers = (uint32_t*)v_pow;
+    if (ext_field == ZKHIP_EXT_X4_PLUS_11) hipLaunchKernelGGL((hal_mix_powers_kernel<MONTY_W_R0>), dim3(1), dim3(64), 0, ctx->stream, powers, ms, mx, (uint64_t)input_size);
+    else hipLaunchKernelGGL((hal_mix_powers_kernel<MONTY_W_SP1>), dim3(1), dim3(64), 0, ctx->stream, powers, ms, mx, (uint64_t)input_size);
+    LAUNCHED();
+    hipLaunchKernelGGL(hal_mix_poly_coeffs_kernel, dim3((unsigned)((count + 255) / 256)), dim3(256), 0, ctx->stream, d_out, powers, d_in, d_combos, (uint64_t)input_size, (uint64_t)count);
     LAUNCHED();
     return ZKHIP_OK;
 }

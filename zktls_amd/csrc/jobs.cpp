@@ -39,6 +39,33 @@ void pool_give(int device, zkhip_ctx* c) {
     std::lock_guard<std::mutex> lk(g_pool_mu);
     g_pool.emplace_back(device, c);
 }
+size_t ctx_workspace_bytes(const zkhip_ctx* c) {
+    size_t b = 0;
+    for (int s = 0; s < S_COUNT; s++) b += c->scratch[s].bytes;
+    return b;
+}
+size_t pool_bytes(int device) {
+    std::lock_guard<std::mutex> lk(g_pool_mu);
+    size_t b = 0;
+    for (auto& e : g_pool) if (e.first == device) b += ctx_workspace_bytes(e.second);
+    return b;
+}
+// A lock-step call may leave lanes x members contexts behind.  The pool keeps the ones returned last while their workspaces stay within
+// `budget` bytes and their number within `max_count`; the others are destroyed (outside the lock: hipFree synchronises the device).
+void pool_trim(int device, size_t budget, size_t max_count) {
+    std::vector<zkhip_ctx*> drop;
+    {
+        std::lock_guard<std::mutex> lk(g_pool_mu);
+        size_t kept = 0, bytes = 0;
+        for (size_t i = g_pool.size(); i-- > 0;) {
+            if (g_pool[i].first != device) continue;
+            const size_t b = ctx_workspace_bytes(g_pool[i].second);
+            if (kept + 1 > max_count || bytes + b > budget) { drop.push_back(g_pool[i].second); g_pool.erase(g_pool.begin() + (long)i); }
+            else { kept++; bytes += b; }
+        }
+    }
+    for (zkhip_ctx* c : drop) zkhip_ctx_destroy(c);
+}
 }  // namespace
 void zkhip_release_cached_contexts(void) {
     std::vector<std::pair<int, zkhip_ctx*>> all;
@@ -162,12 +189,30 @@ void HostPool::wait() {
 // each; the members of a batch are fibers of that thread), so that the host-side work around one batch (padding, transcripts,
 // verification) overlaps the other batches' kernels.  Same contract as deal_jobs.
 int deal_jobs_lockstep(const int* devices, int n_devices, int n_jobs, const int* shape, int max_batch, int lanes,
-                       const std::function<int(zkhip_ctx*, int)>& run, std::vector<char>& ran) {
+                       const std::function<int(zkhip_ctx*, int)>& run, std::vector<char>& ran, uint64_t job_cells) {
     ran.assign((size_t)n_jobs, 0);
     if (n_jobs == 0) return ZKHIP_OK;
     if (max_batch < 1) max_batch = 1;
     if (max_batch > LaunchBatcher::MAX_MEMBERS) max_batch = LaunchBatcher::MAX_MEMBERS;
     if (lanes < 1) lanes = 1;
+    // Memory budget.  Every member of every lane owns a context whose workspaces grow to what its proof needs (LOCKSTEP_BYTES_PER_CELL
+    // per trace cell, the measured footprint of the provers at blowup 2 .. 4 with room to spare).  lanes x max_batch members must fit
+    // in what the device has free plus what this process's pool already holds for it; otherwise the batches get smaller, then the
+    // lanes fewer.  (A member that still runs out of memory is retried on its own below.)
+    size_t pool_budget = (size_t)4 << 30;
+    if (job_cells) {
+        const size_t est = (size_t)job_cells * LOCKSTEP_BYTES_PER_CELL + ((size_t)16 << 20);
+        for (int d = 0; d < n_devices; d++) {
+            size_t free_b = 0, total_b = 0;
+            if (hipSetDevice(physical_device(devices[d])) != hipSuccess || hipMemGetInfo(&free_b, &total_b) != hipSuccess) { (void)hipGetLastError(); continue; }
+            const size_t allow = free_b / 10 * 8 + pool_bytes(devices[d]);
+            size_t cap = allow / est;
+            if (cap < 2) cap = 2;
+            while ((size_t)lanes * (size_t)max_batch > cap && max_batch > 2) max_batch = (max_batch + 1) / 2;
+            while ((size_t)lanes * (size_t)max_batch > cap && lanes > 1) lanes--;
+            if (d == 0 || total_b / 8 < pool_budget) pool_budget = total_b / 8;
+        }
+    }
     std::mutex mu;
     int first_rc = ZKHIP_OK, first_job = n_jobs, ctx_rc = ZKHIP_OK;
     std::string first_msg, ctx_msg;
@@ -222,13 +267,15 @@ int deal_jobs_lockstep(const int* devices, int n_devices, int n_jobs, const int*
             for (int b = 0; b < W; b++) own[(size_t)b] = ctxs[(size_t)b]->stream;
             const hipStream_t shared = own[0];
             std::vector<char> healthy((size_t)W, 1);
+            std::vector<int> retry;                              // jobs whose member ran out of device memory: once more, alone, at the end
             for (int at = 0; at < B; at += W) {
                 const int n = B - at < W ? B - at : W;
                 if (n == 1) {                                    // nothing to merge with
                     const int i = jobs[(size_t)at];
                     const int rc = run(ctxs[0], i);
                     ran[(size_t)i] = 1;
-                    if (rc != ZKHIP_OK) { note(i, rc, zkhip_last_error()); healthy[0] = 0; }
+                    if (rc == ZKHIP_ERR_NOMEM) { retry.push_back(i); healthy[0] = 0; }
+                    else if (rc != ZKHIP_OK) { note(i, rc, zkhip_last_error()); healthy[0] = 0; }
                     continue;
                 }
                 for (int b = 0; b < n; b++) ctxs[(size_t)b]->stream = shared;
@@ -238,7 +285,8 @@ int deal_jobs_lockstep(const int* devices, int n_devices, int n_jobs, const int*
                         const int i = jobs[(size_t)(at + b)];
                         const int rc = run(ctxs[(size_t)b], i);
                         ran[(size_t)i] = 1;
-                        if (rc != ZKHIP_OK) { note(i, rc, zkhip_last_error()); healthy[(size_t)b] = 0; }
+                        if (rc == ZKHIP_ERR_NOMEM) { retry.push_back(i); healthy[(size_t)b] = 0; }      // (fibers of ONE thread: no lock)
+                        else if (rc != ZKHIP_OK) { note(i, rc, zkhip_last_error()); healthy[(size_t)b] = 0; }
                     };
                     if (lb.ok()) lb.run(member);                 // the members as fibers of this thread, their launches merged
                     else for (int b = 0; b < n; b++) member(b);  // (no pinned memory / stacks: one after the other, unmerged)
@@ -252,9 +300,27 @@ int deal_jobs_lockstep(const int* devices, int n_devices, int n_jobs, const int*
                 }
                 for (int b = 0; b < n; b++) ctxs[(size_t)b]->stream = own[(size_t)b];
             }
+            zkhip_ctx* solo = nullptr;                           // a healthy context stays with this lane while jobs wait for their second try
             for (int b = 0; b < W; b++) {
-                if (healthy[(size_t)b] && zkhip_ctx_sync(ctxs[(size_t)b]) == ZKHIP_OK) pool_give(device, ctxs[(size_t)b]);
-                else zkhip_ctx_destroy(ctxs[(size_t)b]);
+                if (healthy[(size_t)b] && zkhip_ctx_sync(ctxs[(size_t)b]) == ZKHIP_OK) {
+                    if (!retry.empty() && !solo) solo = ctxs[(size_t)b];
+                    else pool_give(device, ctxs[(size_t)b]);
+                } else zkhip_ctx_destroy(ctxs[(size_t)b]);       // (frees the workspaces of the members that failed)
+            }
+            if (!retry.empty()) {
+                // out of memory inside a member: the job is not lost -- the idle contexts of the pool give their memory back and the job
+                // runs once more without a batch around it
+                pool_trim(device, 0, 0);
+                if (!solo && zkhip_ctx_create(device, nullptr, &solo) != ZKHIP_OK) solo = nullptr;
+                for (int i : retry) {
+                    const int rc = solo ? run(solo, i) : ZKHIP_ERR_NOMEM;
+                    if (rc != ZKHIP_OK) {
+                        note(i, rc, solo ? zkhip_last_error() : "lock-step batch: out of device memory, and no context for a second try");
+                        if (solo) { zkhip_ctx_destroy(solo); solo = nullptr; }
+                        if (zkhip_ctx_create(device, nullptr, &solo) != ZKHIP_OK) solo = nullptr;
+                    }
+                }
+                if (solo) { if (zkhip_ctx_sync(solo) == ZKHIP_OK) pool_give(device, solo); else zkhip_ctx_destroy(solo); }
             }
         }
     };
@@ -268,6 +334,8 @@ int deal_jobs_lockstep(const int* devices, int n_devices, int n_jobs, const int*
         }
     }
     for (auto& t : pool) t.join();
+    // what the call leaves in the pool: at most lanes x max_batch contexts per device and an eighth of the device's memory
+    for (int d = 0; d < n_devices; d++) pool_trim(devices[d], pool_budget, (size_t)lanes * (size_t)max_batch);
     if (first_rc != ZKHIP_OK) { set_error(first_msg); return first_rc; }
     for (int i = 0; i < n_jobs; i++)
         if (!ran[(size_t)i]) { set_error(ctx_msg.empty() ? "prove (lock-step): job not run" : ctx_msg); return ctx_rc != ZKHIP_OK ? ctx_rc : ZKHIP_ERR_INVALID; }
@@ -299,9 +367,23 @@ int resolve_devices(const int* devices, int n_devices, const char* what, std::ve
 static int prove_shards_on(const int* devices, int n_devices, zkhip_shard_job* jobs, int n_jobs, const zkhip_params* prm, int in_flight,
                            int host_traces, const uint32_t* program = nullptr, size_t program_words = 0) {
     for (int i = 0; i < n_jobs; i++) { jobs[i].status = ZKHIP_ERR_INVALID; jobs[i].proof_len = 0; }
+#ifdef ZKHIP_AB_HOOKS
+    // logical devices (context.cpp): a device trace must have been allocated on the (logical) device its shard is dealt to -- what two
+    // physical devices enforce by themselves
+    if (logical_devices() > 0 && !host_traces)
+        for (int i = 0; i < n_jobs; i++) {
+            const int at = logical_device_of(jobs[i].trace), want = zkhip_shard_device(i, devices, n_devices);
+            if (at >= 0 && at != want)
+                return fail(ZKHIP_ERR_INVALID, "prove_shards: the trace of shard " + std::to_string(i) + " lives on device " + std::to_string(at) +
+                                                   ", the shard is dealt to device " + std::to_string(want));
+        }
+#endif
     std::vector<char> ran;
     auto run = [&](zkhip_ctx* ctx, int i) {
         zkhip_shard_job& j = jobs[i];
+#ifdef ZKHIP_AB_HOOKS
+        if (logical_devices() > 0 && ctx->logical_device != zkhip_shard_device(i, devices, n_devices)) { j.status = ZKHIP_ERR_INTERNAL; return fail(ZKHIP_ERR_INTERNAL, "prove_shards: a shard ran on a context of another device"); }
+#endif
         size_t len = 0;
         int rc;
         if (program)             // every job of the batch is a trace of the same constraint program (device traces)
@@ -318,12 +400,15 @@ static int prove_shards_on(const int* devices, int n_devices, zkhip_shard_job* j
     const int max_batch = lockstep_batch();
     bool small = max_batch > 1 && n_jobs >= 2 * n_devices;
     std::vector<int> shape((size_t)n_jobs);
+    uint64_t max_cells = 0;
     for (int i = 0; i < n_jobs && small; i++) {
         const zkhip_shard_job& j = jobs[i];
-        if (j.log_n < 1 || j.log_n > 24 || j.width == 0 || ((uint64_t)j.width << j.log_n) > LOCKSTEP_MAX_CELLS) small = false;
+        if (j.log_n < 1 || j.log_n > 24 || j.width == 0 || ((uint64_t)j.width << j.log_n) > LOCKSTEP_MAX_CELLS) { small = false; break; }
         shape[(size_t)i] = (int)(((uint32_t)j.log_n << 24) ^ j.width);
+        const uint64_t cells = ((uint64_t)j.width << j.log_n) << (prm->log_blowup > 1 ? prm->log_blowup - 1 : 0);
+        if (cells > max_cells) max_cells = cells;
     }
-    if (small) return deal_jobs_lockstep(devices, n_devices, n_jobs, shape.data(), max_batch, lockstep_lanes(), run, ran);
+    if (small) return deal_jobs_lockstep(devices, n_devices, n_jobs, shape.data(), max_batch, lockstep_lanes(), run, ran, max_cells);
     return deal_jobs(devices, n_devices, n_jobs, in_flight, run, ran);
 }
 

@@ -575,8 +575,9 @@ static MachineShape machine_shape(int log_n) {
 }
 }  // namespace sha
 }  // namespace zk
-// lock-step batches of small transcripts (batch.h): the tallest chip that still counts as small
-constexpr int LOCKSTEP_MAX_LOG_N = 16;
+// lock-step batches of small transcripts (batch.h): the tallest chip that still counts as small (2^14 rows x 608 columns = 10 M cells, a
+// 16 KB transcript -- the size measured as launch-bound; context.h LOCKSTEP_MAX_CELLS)
+constexpr int LOCKSTEP_MAX_LOG_N = 14;
 namespace zk { extern std::atomic<uint64_t> g_lockstep_stats[6]; }
 extern "C" {
 
@@ -732,8 +733,11 @@ int zkhip_prove_transcripts(const int* devices, int n_devices, zkhip_transcript_
     std::string msg_small;
     if (!small.empty()) {
         if (verify) checkers.reset(new HostPool(8));
+        int tallest = 0;
+        for (int ln : shape) if (ln > tallest) tallest = ln;
+        const uint64_t cells = (((uint64_t)sha::WIDTH << tallest) + ((uint64_t)8 << 16)) << (prm->log_blowup > 1 ? prm->log_blowup - 1 : 0);
         rc_small = deal_jobs_lockstep(devs.data(), nd, (int)small.size(), shape.data(), max_batch, lockstep_lanes(),
-                                      [&](zkhip_ctx* ctx, int k) { return run(ctx, small[(size_t)k]); }, ran);
+                                      [&](zkhip_ctx* ctx, int k) { return run(ctx, small[(size_t)k]); }, ran, cells);
         if (rc_small != ZKHIP_OK) msg_small = zkhip_last_error();
     }
     if (!big.empty())
@@ -752,6 +756,7 @@ int zkhip_selftest_lockstep(int members, int rounds) { return lockstep_selftest(
 void zkhip_lockstep_stats(uint64_t out[6]) {
     for (int i = 0; i < 6; i++) out[i] = g_lockstep_stats[i].load();
 }
+uint64_t zkhip_lockstep_stack_high_water(void) { return lockstep_stack_high_water(); }
 
 // ---- a message of ANY length as a chain of shards (BASELINE configs[3]: a megabyte-scale transcript over several GPUs) ------------------
 // Shard s covers blocks [s 2^k, (s + 1) 2^k) of the padded message; its proof says "from chaining value c_s these blocks lead to c_{s+1}"
