@@ -600,7 +600,7 @@ int zkhip_prove_transcripts(const int* devices, int n_devices, zkhip_transcript_
  * Memory: lanes x max_batch contexts per device are in use at once, NOT `in_flight` (which bounds the unbatched path only); the dealer
  * sizes both against the device's free memory (48 bytes of workspace per trace cell and member) and shrinks the batches, then the lanes,
  * when they would not fit; a member that still runs out of device memory is proven once more on its own instead of failing, and after
- * the call the process-wide context pool keeps at most that many contexts and an eighth of the device's memory.
+ * the call the process-wide context pool keeps at most that many contexts and a quarter of the device's memory.
  * zkhip_lockstep_stats: merged launches issued, member launch requests served, rounds whose members asked for different launches, then
  * nanoseconds (summed over the lanes) spent issuing launches, waiting for the stream, and in the members' own host code -- totals since
  * the library was loaded.
@@ -761,6 +761,28 @@ typedef struct zkhip_fri_job {
 } zkhip_fri_job;
 int zkhip_prove_fri_indices_batch(const int* devices, int n_devices, zkhip_fri_job* jobs, int n_jobs, int log_n, uint32_t width,
                                   const zkhip_params* inner, const zkhip_params* outer, int in_flight_per_device, int verify);
+
+/* ---- THE SHARD VERIFIER AS A MACHINE: a whole shard proof checked in-circuit (csrc/shard_verifier.inl).
+ * What the reference asks for behind `client.prove(&pk, &stdin, SP1ProofMode::Groth16)` (crates/guest-prover-sp1/src/sp1.rs:116: core ->
+ * COMPRESS verifies the shard proofs; RISC Zero: lift -> join behind crates/guest-prover-r0/src/prover.rs:90).  Inner proofs: version 1 of
+ * this library (zkhip_prove_shard with the SP1 shape -- blowup 2, fold by 2, constant final value, Poseidon2 width 16, no lookups), 2^2 ..
+ * 2^20 rows, a width that is a multiple of 8.  The machine has eight chips -- the Poseidon2 chip (transcript sponge rows, every Merkle path
+ * of every query), ROWSUM (the opened rows and their batched sums), the fold chip, the transcript table, QUERY (reduced openings), OPENED
+ * (opened values, the AIR's constraints at zeta), SAMPLES (proof of work, query indices), SCALARS (zeta^N, selectors, the quotient
+ * identity) -- and EVERY structural fact is a preprocessed column: the key (zkhip_shard_verifier_setup) is a function of the inner
+ * proof's SHAPE alone.  Statement of an outer proof: "a shard proof of this shape exists that the verifier accepts for these public
+ * values".  zkhip_verify_shard_recursive takes the shape, the inner proof's public values and the key -- no byte of the inner proof.
+ * zkhip_shard_verifier_describe hands out the machine as data (position `which`, tallest chip first; kind 0 program, 1 interaction table,
+ * 2 preprocessed trace as canonical words): tests/recursion_air.py writes the same independently, the words are compared. */
+int zkhip_shard_verifier_setup(zkhip_ctx* ctx, int log_n, uint32_t width, size_t n_queries, int inner_pow_bits, size_t n_public, const zkhip_params* outer,
+                               zkhip_machine_key** key, uint32_t vk[8]);
+size_t zkhip_shard_verifier_proof_size(int log_n, uint32_t width, size_t n_queries, int inner_pow_bits, size_t n_public, const zkhip_params* outer);
+int zkhip_prove_shard_verifier(zkhip_ctx* ctx, const zkhip_machine_key* key, const uint8_t* shard_proof, size_t shard_proof_len, int log_n, uint32_t width,
+                               const uint32_t* public_values, size_t n_public, const zkhip_params* inner, const zkhip_params* outer, uint8_t* proof, size_t cap, size_t* len);
+int zkhip_verify_shard_recursive(const uint8_t* proof, size_t len, int log_n, uint32_t width, size_t n_queries, int inner_pow_bits, const uint32_t* public_values,
+                                 size_t n_public, const uint32_t vk[8], const zkhip_params* outer, int* reason);
+size_t zkhip_shard_verifier_describe(int log_n, uint32_t width, size_t n_queries, int inner_pow_bits, size_t n_public, int which, int kind, uint32_t* out, size_t cap_words,
+                                     int* log_rows, uint32_t* main_width, uint32_t* pre_width);
 
 /* ---- Poseidon2 parameter tables from a file: the built-in sets are this repo's own
  * ("zktls-amd/p2-bb16-v1", "...-bb24-v1"; the SP1 / RISC Zero tables of reference Cargo.lock:4030, 6172, 5057 are not

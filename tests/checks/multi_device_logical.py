@@ -33,7 +33,7 @@ def main():
     ctxs = {d: Context(d) for d in devs}
     prm, oprm = Params(1, 30, 8), O.default_params(1, 30, 8)
     # (1) device traces that live where zkhip_shard_device deals the shard; one context + stream per worker (big enough not to be "small")
-    log_n, width, n_shards = 14, 1088, 3 * K
+    log_n, width, n_shards = 15, 544, 3 * K          # 2^15 x 544 = 17.8 M cells: above the lock-step threshold
     traces = [ctxs[shard_device(s, devs)].gen_trace(SEED, 70 + s, log_n, width) for s in range(n_shards)]
     for c in ctxs.values():
         c.sync()

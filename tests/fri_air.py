@@ -23,14 +23,16 @@ BUS_S0, BUS_S1, BUS_I = 47, 48, 49             # the query-phase machine: the sa
 S_PRE, S_C, S_ROW, S_ACT, S_POW, S_KQ = 20, 0, 1, 2, 10, 11
 S_W, S_IDX, S_H1, S_H2, S_HH, S_BITS, S_MAIN = 0, 8, 16, 24, 32, 40, 288
 K2, IDX, L_WIRED = 32, 33, 34                  # the wired form's extra columns, its layer selectors start two columns later
+XS, L_REC = 34, 35                             # the recursion machine's form (tests/recursion_air.py): XS = X (1 - 2 BIT), the query's point / g on its first row
+BUS_FIN = 60                                   # ... whose END rows send their folded value (the final value is an observed word of the transcript, no public value)
 QUERIES_PRE, ROOTS_PRE = 8, 12
 OPEN_PRE, OPEN_MAIN = 12, 4
 INV2 = (P + 1) // 2
 EXT_W = 11
 
 
-def width_of(layers, wired=False):
-    return ((L_WIRED if wired else L) + layers + 3) & ~3
+def width_of(layers, wired=False, rec=False):
+    return ((L_REC if rec else L_WIRED if wired else L) + layers + 3) & ~3
 
 
 def n_public_of(layers):
@@ -42,14 +44,15 @@ def root_const(l):
     return two_adic_generator(l + 1)
 
 
-def program(layers, wired=False, transcript=False):
+def program(layers, wired=False, transcript=False, rec=None):
     """transcript: the fold chip of the TRANSCRIPT machine -- the challenges are no public values any more (the rows receive
     (layer, beta) on a bus from the ROOTS table, which has them from the Poseidon2 chip's transcript rows); public values: the final
     value, then the challenger's capacity (8 words, read by the Poseidon2 chip)"""
     R = layers
-    L = L_WIRED if wired else globals()["L"]
+    L = L_REC if rec is not None else L_WIRED if wired else globals()["L"]
     END = L + R - 1
     cons = []
+    assert rec is None or (wired and transcript)          # rec = the number of public values of the recursion machine's programs
 
     def add(sel, terms):
         cons.append((sel, [(c % P, list(vs)) for c, vs in terms if c % P]))
@@ -94,11 +97,15 @@ def program(layers, wired=False, transcript=False):
     add(O.SEL_TRANSITION, [(1, [V(L), V(X)]), (P - 1, [V(L), V(B, True)])])
     for j in range(4):
         add(O.SEL_TRANSITION, gated([(1, [V(FOLD + j)]), (P - 1, [V(OWN + j, True)])]))
-    for j in range(4):
-        add(O.SEL_ALL, [(1, [V(END), V(FOLD + j)]), (P - 1, [V(END), V((0 if transcript else 4 * R) + j, public=True)])])
+    if rec is None:
+        for j in range(4):
+            add(O.SEL_ALL, [(1, [V(END), V(FOLD + j)]), (P - 1, [V(END), V((0 if transcript else 4 * R) + j, public=True)])])
     if wired:
         add(O.SEL_ALL, [(1, [V(K2)]), (P - 2, [V(K)])])
         add(O.SEL_ALL, [(1, [V(IDX)]), (P - 1, [V(K2)]), (P - 1, [V(BIT)])])
+    if rec is not None:
+        add(O.SEL_ALL, [(1, [V(XS)]), (P - 1, [V(X)]), (2, [V(X), V(BIT)])])
+        return O.air_program(width_of(R, rec=True), rec, cons)
     return O.air_program(width_of(R, wired), N_PUBLIC_T if transcript else n_public_of(R), cons)
 
 
@@ -118,13 +125,13 @@ def log_rows_of(layers, n_queries):
     return lr
 
 
-def trace(view, log_rows=None, wired=False):
+def trace(view, log_rows=None, wired=False, rec=False):
     """-> (trace [2^log_rows][width] canonical, final value): one row per (query, layer), padding rows zero with T = 1"""
     betas, queries = view["betas"], view["queries"]
     R = len(betas)
     H = R + 1
-    W = width_of(R, wired)
-    L = L_WIRED if wired else globals()["L"]
+    W = width_of(R, wired, rec)
+    L = L_REC if rec else L_WIRED if wired else globals()["L"]
     lr = log_rows if log_rows is not None else log_rows_of(R, len(queries))
     t = np.zeros((1 << lr, W), dtype=np.uint64)
     t[:, T] = 1
@@ -146,6 +153,8 @@ def trace(view, log_rows=None, wired=False):
             row[OWN:OWN + 4] = own
             if wired:
                 row[K2], row[IDX] = 2 * k, 2 * k + bit
+            if rec:
+                row[XS] = (P - x) % P if bit else x
             own, idx = fold, k
         acc = root_const(R) if idx else 1
         for l in reversed(range(R)):
@@ -246,14 +255,15 @@ def samples_program(layers, n_queries, pow_bits, n_public):
     return O.air_program(S_PRE + S_MAIN, n_public, cons)
 
 
-def samples_tables(layers, n_queries, words, log_rows):
-    """-> (preprocessed, main) of the SAMPLES chip; words = [rows][8] sampled words, canonical"""
+def samples_tables(layers, n_queries, words, log_rows, base=None):
+    """-> (preprocessed, main) of the SAMPLES chip; words = [rows][8] sampled words, canonical; base: the number of the first query-phase
+    sponge row (the machines of this file: `layers`)"""
     n_rows = sample_rows(n_queries)
     pre = np.zeros((1 << log_rows, S_PRE), dtype=np.uint32)
     main = np.zeros((1 << log_rows, S_MAIN), dtype=np.uint32)
     indices = []
     for r in range(n_rows):
-        pre[r, S_C], pre[r, S_ROW] = layers + r, 1
+        pre[r, S_C], pre[r, S_ROW] = (layers if base is None else base) + r, 1
         for j in range(8):
             slot = 8 * r + j
             w = int(words[r][j])

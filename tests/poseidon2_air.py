@@ -91,6 +91,13 @@ def program(fri_layers=False, n_public=N_PUBLIC, transcript=None, queries=None):
     challenger: inputs overwrite the front of the rate); every further QP row permutes the previous row's whole output.  The rate
     outputs of the QP rows are the sampled words (out[7] first): the proof-of-work word, then one word per query index -- sent to the
     SAMPLES chip (tests/fri_air.py), which takes their bits"""
+    cons = permutation_constraints()
+    return _program_flags(cons, fri_layers, n_public, transcript, queries)
+
+
+def permutation_constraints():
+    """the constraints that make a row ONE permutation out = poseidon2(in): columns IN .. SP (343 columns), shared by every variant of the
+    chip (and by the recursion machine's chip, tests/recursion_air.py)"""
     ME, rc_e, rc_i, diag = pyref.ME, PARAMS["external_rc"], PARAMS["internal_rc"], PARAMS["internal_diag"]
     cons = []
     for i in range(16):
@@ -129,6 +136,10 @@ def program(fri_layers=False, n_public=N_PUBLIC, transcript=None, queries=None):
         cons.append((O.SEL_ALL, _linear_def(SP + i, lin[i])))
     for r in range(4, 8):
         external_round(r)
+    return cons
+
+
+def _program_flags(cons, fri_layers, n_public, transcript, queries):
     for j in range(8):
         cons.append((O.SEL_ALL, [_term(1, [V(D + j)]), _term(P - 1, [V(IN + j)]), _term(1, [V(BIT), V(IN + j)]), _term(P - 1, [V(BIT), V(IN + 8 + j)])]))
     for b in (BIT, CH, END, SPG, SS):

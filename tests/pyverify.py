@@ -404,10 +404,16 @@ def verify(proof_bytes, log_n, width, public_values, log_blowup=1, num_queries=1
         if view is not None:
             view.setdefault("queries", []).append(seen[:3])
             view.setdefault("paths", []).append(seen[3])
+            # what a verifier INSIDE a proof needs besides (tests/recursion_air.py): the opened rows with their paths
+            view.setdefault("openings", []).append({"index": index, "trow": list(trow), "tpath": [list(d) for d in tpath],
+                                                    "qrow": list(qrow), "qpath": [list(d) for d in qpath]})
     if pos != len(w):
         raise Reject("trailing words")
     if view is not None:
         view["betas"] = [list(x) for x in betas]
         view["roots"] = [list(r) for r in layer_roots]
         view["final"] = list(final_poly[0])
+        view["trace_root"], view["quot_root"], view["witness"] = list(trace_root), list(quot_root), witness
+        view["loc"], view["nxt"], view["qz"] = [list(e) for e in loc], [list(e) for e in nxt], [list(e) for e in qz]
+        view["alpha"], view["zeta"], view["fa"] = list(alpha), list(zeta), list(fa)
     return True

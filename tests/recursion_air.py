@@ -1,0 +1,995 @@
+"""The SHARD VERIFIER as a machine, written a second time (the first is zktls_amd/csrc/recursion.hip): a keyed machine of eight chips that
+checks a WHOLE shard proof of this library (version 1: the synthetic AIR, SP1 shape -- blowup 2, fold by 2, constant final value, Poseidon2
+width 16) in-circuit: the transcript from the header to the last query index, the AIR identity at zeta, every Merkle opening, the reduced
+openings and the FRI folds.  What the reference asks for behind `client.prove(.., Groth16)` (crates/guest-prover-sp1/src/sp1.rs:116: core ->
+COMPRESS verifies the shard proofs; RISC Zero: lift -> join, prover.rs:90).
+
+Every structural fact -- which row absorbs what, which path belongs to which query, which words are constants of the shape -- is a
+PREPROCESSED column: the key (the commitment to them) depends on the inner proof's SHAPE (log_n, width, queries, proof-of-work bits,
+number of public values) and on nothing else, and the verifier of the outer proof is handed the key and the inner proof's PUBLIC VALUES --
+no byte of the inner proof.  docs/PROTOCOL.md section 3c describes the chips; tests/pyverify.py is the verifier that is restated.
+
+Chips, tallest first for the shapes of the tests (machine() sorts by height):
+  P2R      one Poseidon2 permutation per row.  The sponge rows of the transcript first, then per query the FRI layer paths, then the
+           trace opening (the opened row hashed by sponge rows, then its path), then the quotient opening.
+  ROWSUM   one row per 8 values of an opened row: hands them to the P2R sponge rows and accumulates sum_j fa^j row[j] (Horner).
+  FOLD     tests/fri_air.py's fold chip in its `rec` form.
+  TS       the transcript as a table: one row per absorbing sponge row -- the observed words, the challenge sampled behind it.
+  QUERY    one row per query: index, point, the reduced opening from ROWSUM's sums and the opened values' sums.
+  OPENED   one row per column group (a, b, c, d) of the synthetic AIR: the opened values at zeta and zeta g, their fa-weighted sums, the
+           AIR's constraints folded with alpha.
+  SAMPLES  tests/fri_air.py's chip: the bits of the sampled words (proof of work, query indices).
+  SCALARS  the verifier's scalars: zeta^N, the selectors, powers of fa, the quotient recombination, the AIR identity."""
+import numpy as np
+
+import fri_air as F
+import oracle_lib as O
+import poseidon2_air as P2
+import pyref
+from pyref import P, ext_mul, two_adic_generator
+
+V = O.air_var
+GEN, EXT_W = 31, 11
+SEND, RECV = O.SEND, O.RECEIVE
+# buses (F.BUS_E0 / E1 / R0 / R1 / Q / S0 / S1 / I keep their meaning from tests/fri_air.py)
+BUS_IN0, BUS_IN1, BUS_TC, BUS_BETA, BUS_SC, BUS_QI, BUS_AT, BUS_AQ = 61, 62, 63, 64, 65, 66, 67, 68
+BUS_K0, BUS_K1, BUS_K2, BUS_K3, BUS_KFA, BUS_KO0, BUS_KO1, BUS_KO2, BUS_OY, BUS_OA = 70, 71, 72, 73, 74, 75, 76, 77, 78, 79
+BUS_FIN = F.BUS_FIN
+
+
+# ---------------------------------------------------------------------------------------------------------------- polynomials over columns
+# a polynomial = a list of (coefficient, [variables]); an extension expression = four of them (x^4 = 11).  No merging of like terms: the order
+# in which terms are produced IS the program (csrc/recursion.hip produces them in the same order; the words are compared).
+def pc(c):
+    return [(c % P, [])] if c % P else []
+
+
+def pv(col, nxt=False):
+    return [(1, [V(col, nxt)])]
+
+
+def padd(*ps):
+    out = []
+    for p in ps:
+        out += p
+    return out
+
+
+def pscale(p, k):
+    return [(c * k % P, vs) for c, vs in p if c * k % P]
+
+
+def pneg(p):
+    return pscale(p, P - 1)
+
+
+def pmul(a, b):
+    return [(ca * cb % P, va + vb) for ca, va in a for cb, vb in b if ca * cb % P]
+
+
+def ev(col, nxt=False):
+    return [pv(col + i, nxt) for i in range(4)]
+
+
+def ec(c):
+    """an extension constant (4 ints), or a base constant"""
+    c = list(c) if isinstance(c, (list, tuple)) else [c, 0, 0, 0]
+    return [pc(x) for x in c]
+
+
+def eb(p):
+    """a base-field polynomial as an extension expression"""
+    return [p, [], [], []]
+
+
+def eadd(*es):
+    return [padd(*[e[i] for e in es]) for i in range(4)]
+
+
+def esub(a, b):
+    return [padd(a[i], pneg(b[i])) for i in range(4)]
+
+
+def escale(a, k):
+    return [pscale(a[i], k) for i in range(4)]
+
+
+def emul(a, b):
+    out = [[], [], [], []]
+    for j in range(4):
+        for i in range(4):
+            for k in range(4):
+                if (i + k) % 4 != j:
+                    continue
+                t = pmul(a[i], b[k])
+                out[j] += pscale(t, EXT_W) if i + k >= 4 else t
+    return out
+
+
+def egate(flag, e):
+    """flag * e, flag a polynomial"""
+    return [pmul(flag, e[i]) for i in range(4)]
+
+
+class Cons:
+    def __init__(self):
+        self.c = []
+
+    def add(self, sel, poly):
+        self.c.append((sel, [(c % P, list(vs)) for c, vs in poly if c % P]))
+
+    def ext(self, sel, e):
+        for i in range(4):
+            self.add(sel, e[i])
+
+
+class Cols:
+    """a running column allocator; names -> first column"""
+    def __init__(self, start=0):
+        self.n = start
+        self.at = {}
+
+    def __call__(self, name, width=4):
+        self.at[name] = self.n
+        self.n += width
+        return self.at[name]
+
+    def __getitem__(self, name):
+        return self.at[name]
+
+
+def rup4(n):
+    return (n + 3) & ~3
+
+
+def lg(n, lo=5):
+    l = lo
+    while (1 << l) < n:
+        l += 1
+    return l
+
+
+# ---------------------------------------------------------------------------------------------------------------- the shape of an inner proof
+class Shape:
+    """everything the machine's structure depends on: (log_n, width, queries, pow_bits, n_public) of a version-1 shard proof"""
+    def __init__(self, log_n, width, n_queries, pow_bits, n_public):
+        assert width % 8 == 0 and width >= 8 and 2 <= log_n <= 22 and n_queries >= 1
+        self.n, self.W, self.Q, self.PB, self.NPUB = log_n, width, n_queries, pow_bits, n_public
+        self.R, self.H, self.G, self.WB = log_n, log_n + 1, width // 4, width // 8
+        self.head = [log_n, width, 1, n_queries, pow_bits, n_public]           # the header words the transcript observes
+        n0 = 6 + 8 + n_public
+        self.f0, self.r0 = n0 // 8, n0 % 8
+        self.TA = self.f0 if self.r0 else self.f0 - 1                          # the sponge row alpha is sampled behind
+        self.TQ = self.TA + 1                                                  # absorbs the quotient root; zeta
+        self.TO0 = self.TQ + 1                                                 # first block of the opened values (W / 2 blocks at zeta, W / 2 at zeta g, 4 quotient)
+        self.TF = self.TO0 + width + 3                                         # the last of them; fa
+        self.TL0 = self.TF + 1                                                 # layer roots; beta_l
+        self.TP = self.TL0 + self.R                                            # final value + witness; the proof-of-work word and 7 index words
+        self.NS = F.sample_rows(n_queries)
+        self.NT = self.TP + self.NS                                            # sponge rows of the transcript
+        self.NTS = self.TP + 1                                                 # rows of the TS table (the absorbing ones)
+        self.pub_rows = sorted({(14 + i) // 8 for i in range(n_public)})       # TS rows that hold public values
+        # P2R row layout
+        self.fri_rows = self.R + self.R * (self.R + 1) // 2                    # per query: a leaf row + the path, every layer
+        self.p2_fri0 = self.NT
+        self.p2_tr0 = self.p2_fri0 + self.Q * self.fri_rows                    # trace openings: WB sponge rows + H path rows per query
+        self.p2_q0 = self.p2_tr0 + self.Q * (self.WB + self.H)                 # quotient openings: 1 sponge row + H path rows
+        self.p2_rows = self.p2_q0 + self.Q * (1 + self.H)
+        self.tag0 = self.NT                                                    # ROWSUM tags follow the transcript's
+
+    def row_tag(self, q, b):
+        return self.tag0 + q * (self.WB + 1) + b                              # b = WB: the quotient row
+
+
+def absorbed(sh, T):
+    """how many rate words sponge row T absorbs (8: all; the others keep the previous output there)"""
+    if T < sh.f0 or sh.TQ <= T < sh.TP:
+        return 8
+    if T == sh.f0 and sh.r0:
+        return sh.r0
+    if T == sh.TP:
+        return 5
+    return 0
+
+
+# ---------------------------------------------------------------------------------------------------------------- P2R
+P2_PRE = 24
+PP_SS, PP_SPG, PP_CH, PP_END, PP_K, PP_RIN, PP_TAG, PP_SROOT, PP_TREE, PP_SCH, PP_SSMP, PP_QIDX, PP_QN, PP_RPAIR = 0, 1, 2, 3, 4, 12, 13, 14, 15, 16, 17, 18, 19, 20
+P2_MAIN = 360
+M_KP = 352                                                                      # main columns: P2.IN .. P2.SP, P2.D (343), P2.BIT (351), KP (352)
+
+
+def p2r_program(sh):
+    M0 = P2_PRE
+    cons = Cons()
+    for sel, terms in P2.permutation_constraints():
+        cons.add(sel, [(c, [v + M0 if (v >> 30) == 0 else v for v in vs]) for c, vs in terms])
+    IN, OUT, D, BIT, KP = M0 + P2.IN, M0 + P2.OUTE(7), M0 + P2.D, M0 + P2.BIT, M0 + M_KP
+    for j in range(8):
+        cons.add(O.SEL_ALL, padd(pv(D + j), pneg(pv(IN + j)), pmul(pv(BIT), pv(IN + j)), pneg(pmul(pv(BIT), pv(IN + 8 + j)))))
+    cons.add(O.SEL_ALL, padd(pmul(pv(BIT), pv(BIT)), pneg(pv(BIT))))
+    cons.add(O.SEL_ALL, pmul(padd(pv(PP_SS), pv(PP_SPG)), pv(BIT)))             # leaf and transcript rows: no direction
+    for j in range(8):
+        cons.add(O.SEL_ALL, pmul(pv(PP_SS), pv(IN + 8 + j)))                     # a sponge starts with the zero capacity
+    for j in range(8):
+        cons.add(O.SEL_TRANSITION, pmul(pv(PP_SPG, True), padd(pv(IN + 8 + j, True), pneg(pv(OUT + 8 + j)))))
+    for j in range(8):
+        cons.add(O.SEL_TRANSITION, pmul(pv(PP_CH, True), padd(pv(D + j, True), pneg(pv(OUT + j)))))
+    for j in range(8):
+        cons.add(O.SEL_TRANSITION, pmul(pv(PP_K + j, True), padd(pv(IN + j, True), pneg(pv(OUT + j)))))
+    cons.add(O.SEL_TRANSITION, pmul(pv(PP_CH, True), padd(pv(KP), pscale(pv(KP, True), P - 2), pneg(pv(BIT)))))
+    cons.add(O.SEL_ALL, pmul(pv(PP_END), padd(pv(KP), pneg(pv(BIT)))))
+    return O.air_program(P2_PRE + P2_MAIN, sh.NPUB, cons.c)
+
+
+def p2r_table():
+    M0, o = P2_PRE, P2_PRE + P2.OUTE(7)
+    IN, KP = M0 + P2.IN, M0 + M_KP
+    return O.interaction_table([
+        (RECV, PP_RIN, BUS_IN0, [PP_TAG, IN, IN + 1, IN + 2, IN + 3]), (RECV, PP_RIN, BUS_IN1, [PP_TAG, IN + 4, IN + 5, IN + 6, IN + 7]),
+        (RECV, PP_RPAIR, F.BUS_E0, [PP_TREE, KP, IN, IN + 1, IN + 2, IN + 3]), (RECV, PP_RPAIR, F.BUS_E1, [PP_TREE, KP, IN + 4, IN + 5, IN + 6, IN + 7]),
+        (SEND, PP_SROOT, F.BUS_R0, [PP_TREE, o, o + 1, o + 2, o + 3]), (SEND, PP_SROOT, F.BUS_R1, [PP_TREE, o + 4, o + 5, o + 6, o + 7]),
+        (SEND, PP_SCH, BUS_TC, [PP_TAG, o + 7, o + 6, o + 5, o + 4]),
+        (SEND, PP_SSMP, F.BUS_S0, [PP_TAG, o + 7, o + 6, o + 5, o + 4]), (SEND, PP_SSMP, F.BUS_S1, [PP_TAG, o + 3, o + 2, o + 1, o]),
+        (RECV, PP_QIDX, BUS_QI, [PP_QN, KP])])
+
+
+def p2r_pre(sh, log_rows):
+    """the structure of the chip: fixed by the shape"""
+    t = np.zeros((1 << log_rows, P2_PRE), dtype=np.uint32)
+    for T in range(sh.NT):
+        r = t[T]
+        k = absorbed(sh, T)
+        if T == 0:
+            r[PP_SS] = 1
+        else:
+            r[PP_SPG] = 1
+            for j in range(k, 8):
+                r[PP_K + j] = 1
+        r[PP_TAG] = T
+        if k:
+            r[PP_RIN] = 1
+        if T in (sh.TA, sh.TQ, sh.TF) or sh.TL0 <= T < sh.TP:
+            r[PP_SCH] = 1
+        if T >= sh.TP:
+            r[PP_SSMP] = 1
+    row = sh.p2_fri0
+    for q in range(sh.Q):
+        for l in range(sh.R):
+            t[row, PP_SS], t[row, PP_RPAIR], t[row, PP_TREE] = 1, 1, l
+            row += 1
+            depth = sh.H - (l + 1)
+            for lvl in range(depth):
+                t[row, PP_CH], t[row, PP_TREE] = 1, l
+                if lvl == depth - 1:
+                    t[row, PP_END] = t[row, PP_SROOT] = 1
+                row += 1
+    assert row == sh.p2_tr0
+    for tree, blocks in ((sh.R, sh.WB), (sh.R + 1, 1)):
+        for q in range(sh.Q):
+            for b in range(blocks):
+                t[row, PP_SS if b == 0 else PP_SPG] = 1
+                t[row, PP_RIN], t[row, PP_TAG] = 1, sh.row_tag(q, b if tree == sh.R else sh.WB)
+                row += 1
+            for lvl in range(sh.H):
+                t[row, PP_CH], t[row, PP_TREE] = 1, tree
+                if lvl == 0:
+                    t[row, PP_QIDX], t[row, PP_QN] = 1, q
+                if lvl == sh.H - 1:
+                    t[row, PP_END] = t[row, PP_SROOT] = 1
+                row += 1
+    assert row == sh.p2_rows
+    return t
+
+
+def _p2row(state, bit=0, kp=0):
+    r, out = P2.row(state, bit)
+    return r[:M_KP] + [kp % P] + [0] * 7, out                                    # (the old chip's flag columns behind BIT are not this chip's)
+
+
+def p2r_main(sh, w, log_rows):
+    """w = the witness (see witness()) -> (main trace, sampled words [NS][8], challenges {T: out[7..4]})"""
+    rows, chal, samples = [], {}, []
+    state = [0] * 16
+    for T in range(sh.NT):
+        k = absorbed(sh, T)
+        blk = w["blocks"].get(T, [])
+        state = [blk[j] if j < k else state[j] for j in range(8)] + (state[8:] if T else [0] * 8)
+        r, out = _p2row(state)
+        rows.append(r)
+        chal[T] = [out[7], out[6], out[5], out[4]]
+        if T >= sh.TP:
+            samples.append([out[7 - j] for j in range(8)])
+        state = list(out)
+    for q in range(sh.Q):
+        for l in range(sh.R):
+            k, pair, sibs = w["fri"][q][l]
+            r, out = _p2row(list(pair) + [0] * 8, 0, 2 * k)
+            rows.append(r)
+            digest = out[:8]
+            for lvl, sib in enumerate(sibs):
+                bit = (k >> lvl) & 1
+                r, out = _p2row(list(sib) + digest if bit else digest + list(sib), bit, k >> lvl)
+                rows.append(r)
+                digest = out[:8]
+            assert digest == w["layer_roots"][l], "a FRI layer path does not end in the layer's root"
+    for key_row, key_path, root in (("trow", "tpath", w["trace_root"]), ("qrow", "qpath", w["quot_root"])):
+        for q in range(sh.Q):
+            op = w["openings"][q]
+            vals, cap, index = op[key_row], [0] * 8, op["index"]
+            nb = len(vals) // 8
+            for b in range(nb):
+                r, out = _p2row(list(vals[8 * b:8 * b + 8]) + cap, 0, 2 * index if b == nb - 1 else 0)
+                rows.append(r)
+                cap = out[8:]
+            digest = out[:8]
+            for lvl, sib in enumerate(op[key_path]):
+                bit = (index >> lvl) & 1
+                r, out = _p2row(list(sib) + digest if bit else digest + list(sib), bit, index >> lvl)
+                rows.append(r)
+                digest = out[:8]
+            assert digest == root, "an opening does not end in its root"
+    assert len(rows) == sh.p2_rows
+    pad, _ = _p2row([0] * 16)
+    rows += [pad] * ((1 << log_rows) - len(rows))
+    return np.array(rows, dtype=np.uint64).astype(np.uint32), samples, chal
+
+
+# ---------------------------------------------------------------------------------------------------------------- TS
+def ts_cols(sh):
+    c = Cols()
+    for name, w in (("T", 1), ("ACT", 1), ("NSEND", 1), ("CF", 8), ("CV", 8), ("IND0", 1), ("IP", len(sh.pub_rows)), ("NROOT", 1), ("NTR", 1), ("TREE", 1),
+                    ("HASCH", 1), ("NBETA", 1), ("NSC", 1), ("KIND", 1), ("NFIN", 1)):
+        c(name, w)
+    pre = rup4(c.n)
+    m = Cols(pre)
+    m("W", 8), m("TR", 8), m("CH", 4)
+    return c, m, pre
+
+
+TS_MAIN = 20
+
+
+def ts_program(sh):
+    c, m, pre = ts_cols(sh)
+    cons = Cons()
+    W, TR = m["W"], m["TR"]
+    for j in range(8):
+        cons.add(O.SEL_ALL, pmul(pv(c["CF"] + j), padd(pv(W + j), pneg(pv(c["CV"] + j)))))
+    for i in range(sh.NPUB):
+        pos = 14 + i
+        cons.add(O.SEL_ALL, pmul(pv(c["IP"] + sh.pub_rows.index(pos // 8)), padd(pv(W + pos % 8), [(P - 1, [V(i, public=True)])])))
+    cons.add(O.SEL_ALL, pmul(pv(c["IND0"]), padd(pv(W + 6), pneg(pv(TR)))))
+    cons.add(O.SEL_ALL, pmul(pv(c["IND0"]), padd(pv(W + 7), pneg(pv(TR + 1)))))
+    for j in range(6):
+        cons.add(O.SEL_TRANSITION, pmul(pv(c["IND0"]), padd(pv(W + j, True), pneg(pv(TR + 2 + j)))))
+    return O.air_program(pre + TS_MAIN, sh.NPUB, cons.c)
+
+
+def ts_table(sh):
+    c, m, _ = ts_cols(sh)
+    W, TR, CH = m["W"], m["TR"], m["CH"]
+    return O.interaction_table([
+        (SEND, c["NSEND"], BUS_IN0, [c["T"], W, W + 1, W + 2, W + 3]), (SEND, c["NSEND"], BUS_IN1, [c["T"], W + 4, W + 5, W + 6, W + 7]),
+        (RECV, c["HASCH"], BUS_TC, [c["T"], CH, CH + 1, CH + 2, CH + 3]),
+        (SEND, c["NBETA"], BUS_BETA, [c["TREE"], CH, CH + 1, CH + 2, CH + 3]),
+        (SEND, c["NSC"], BUS_SC, [c["KIND"], CH, CH + 1, CH + 2, CH + 3]),
+        (RECV, c["NROOT"], F.BUS_R0, [c["TREE"], W, W + 1, W + 2, W + 3]), (RECV, c["NROOT"], F.BUS_R1, [c["TREE"], W + 4, W + 5, W + 6, W + 7]),
+        (RECV, c["NTR"], F.BUS_R0, [c["TREE"], TR, TR + 1, TR + 2, TR + 3]), (RECV, c["NTR"], F.BUS_R1, [c["TREE"], TR + 4, TR + 5, TR + 6, TR + 7]),
+        (RECV, c["NFIN"], BUS_FIN, [W, W + 1, W + 2, W + 3])])
+
+
+def ts_pre(sh, log_rows):
+    c, _, pre = ts_cols(sh)
+    t = np.zeros((1 << log_rows, pre), dtype=np.uint32)
+    for T in range(sh.NTS):
+        r = t[T]
+        r[c["T"]], r[c["ACT"]], r[c["NSEND"]] = T, 1, 2 if sh.TO0 <= T <= sh.TF else 1
+        for j in range(8):
+            if 8 * T + j < 6:
+                r[c["CF"] + j], r[c["CV"] + j] = 1, sh.head[8 * T + j]
+        if T in sh.pub_rows:
+            r[c["IP"] + sh.pub_rows.index(T)] = 1
+        if T == 0:
+            r[c["IND0"]], r[c["NTR"]], r[c["TREE"]] = 1, sh.Q, sh.R
+        if T == sh.TQ:
+            r[c["NROOT"]], r[c["TREE"]] = sh.Q, sh.R + 1
+        if sh.TL0 <= T < sh.TP:
+            r[c["NROOT"]], r[c["TREE"]], r[c["NBETA"]] = sh.Q, T - sh.TL0, sh.Q
+        for kind, Tk in enumerate((sh.TA, sh.TQ, sh.TF)):
+            if T == Tk:
+                r[c["NSC"]], r[c["KIND"]] = 1, kind
+        if T in (sh.TA, sh.TQ, sh.TF) or sh.TL0 <= T < sh.TP:
+            r[c["HASCH"]] = 1
+        if T == sh.TP:
+            r[c["NFIN"]] = sh.Q
+    return t
+
+
+def ts_main(sh, w, chal, p2_main, log_rows):
+    t = np.zeros((1 << log_rows, TS_MAIN), dtype=np.uint32)
+    for T in range(sh.NTS):
+        t[T, 0:8] = p2_main[T, P2.IN:P2.IN + 8]                                 # the absorbed words, and whatever the kept ones are
+        if T in (sh.TA, sh.TQ, sh.TF) or sh.TL0 <= T < sh.TP:
+            t[T, 16:20] = chal[T]
+    t[0, 8:16] = w["trace_root"]
+    return t
+
+
+# ---------------------------------------------------------------------------------------------------------------- ROWSUM
+RS_PRE = 8
+RP_TAG, RP_ACT, RP_NOTFIRST, RP_LAST0, RP_LAST1, RP_QN, RP_FIRST = 0, 1, 2, 3, 4, 5, 6
+RS_V, RS_ACCIN, RS_T, RS_FA, RS_MAIN = 0, 8, 12, 44, 48
+
+
+def rowsum_program(sh):
+    M0 = RS_PRE
+    cons = Cons()
+    fa = ev(M0 + RS_FA)
+    cons.ext(O.SEL_TRANSITION, esub(ev(M0 + RS_FA, True), fa))
+    prev = ev(M0 + RS_ACCIN)
+    for s in range(7, -1, -1):
+        cur = ev(M0 + RS_T + 4 * s)
+        cons.ext(O.SEL_ALL, esub(cur, eadd(emul(prev, fa), eb(pv(M0 + RS_V + s)))))
+        prev = cur
+    cons.ext(O.SEL_TRANSITION, egate(pv(RP_NOTFIRST, True), esub(ev(M0 + RS_ACCIN, True), ev(M0 + RS_T))))
+    cons.ext(O.SEL_ALL, egate(padd(pv(RP_ACT), pneg(pv(RP_NOTFIRST))), ev(M0 + RS_ACCIN)))
+    return O.air_program(RS_PRE + RS_MAIN, sh.NPUB, cons.c)
+
+
+def rowsum_table():
+    M0 = RS_PRE
+    v, t0, fa = M0 + RS_V, M0 + RS_T, M0 + RS_FA
+    return O.interaction_table([
+        (SEND, RP_ACT, BUS_IN0, [RP_TAG, v, v + 1, v + 2, v + 3]), (SEND, RP_ACT, BUS_IN1, [RP_TAG, v + 4, v + 5, v + 6, v + 7]),
+        (SEND, RP_LAST0, BUS_AT, [RP_QN, t0, t0 + 1, t0 + 2, t0 + 3]), (SEND, RP_LAST1, BUS_AQ, [RP_QN, t0, t0 + 1, t0 + 2, t0 + 3]),
+        (RECV, RP_FIRST, BUS_KFA, [fa, fa + 1, fa + 2, fa + 3])])
+
+
+def rowsum_rows(sh):
+    """(q, block) in trace order: a query's trace blocks from the last to the first, then its quotient block"""
+    return [(q, b) for q in range(sh.Q) for b in list(range(sh.WB - 1, -1, -1)) + [sh.WB]]
+
+
+def rowsum_pre(sh, log_rows):
+    t = np.zeros((1 << log_rows, RS_PRE), dtype=np.uint32)
+    for r, (q, b) in enumerate(rowsum_rows(sh)):
+        t[r, RP_TAG], t[r, RP_ACT], t[r, RP_QN] = sh.row_tag(q, b), 1, q
+        t[r, RP_NOTFIRST] = 0 if b in (sh.WB - 1, sh.WB) else 1
+        t[r, RP_LAST0], t[r, RP_LAST1] = (1 if b == 0 else 0), (1 if b == sh.WB else 0)
+    t[0, RP_FIRST] = 1
+    return t
+
+
+def _horner8(acc, vals, fa):
+    steps = [None] * 8
+    for s in range(7, -1, -1):
+        acc = ext_mul(acc, fa)
+        acc = [(acc[0] + vals[s]) % P] + acc[1:]
+        steps[s] = acc
+    return steps
+
+
+def rowsum_main(sh, w, fa, log_rows):
+    t = np.zeros((1 << log_rows, RS_MAIN), dtype=np.uint64)
+    t[:, RS_FA:RS_FA + 4] = fa
+    at, aq, acc = {}, {}, [0, 0, 0, 0]
+    for r, (q, b) in enumerate(rowsum_rows(sh)):
+        op = w["openings"][q]
+        vals = op["qrow"] if b == sh.WB else op["trow"][8 * b:8 * b + 8]
+        if b in (sh.WB - 1, sh.WB):
+            acc = [0, 0, 0, 0]
+        t[r, RS_V:RS_V + 8], t[r, RS_ACCIN:RS_ACCIN + 4] = vals, acc
+        steps = _horner8(acc, vals, fa)
+        for s in range(8):
+            t[r, RS_T + 4 * s:RS_T + 4 * s + 4] = steps[s]
+        acc = steps[0]
+        if b == 0:
+            at[q] = acc
+        if b == sh.WB:
+            aq[q] = acc
+    return t.astype(np.uint32), at, aq
+
+
+# ---------------------------------------------------------------------------------------------------------------- QUERY
+Q_PRE = 4
+QP_QN, QP_ACT, QP_ACT2, QP_FIRST = 0, 1, 2, 3
+
+
+def query_cols():
+    m = Cols(Q_PRE)
+    m("IDX", 1), m("XQ", 1)
+    for name in ("RO", "AT", "AQ", "I1", "I2", "P1", "P2", "P2O", "P3", "P3O", "ZETA", "ZNX", "YL", "YN", "YQ", "OFFN", "OFFQ"):
+        m(name)
+    return m
+
+
+QUERY_CONSTS = ("ZETA", "ZNX", "YL", "YN", "YQ", "OFFN", "OFFQ")
+Q_MAIN = rup4(query_cols().n - Q_PRE)
+
+
+def query_program(sh):
+    m = query_cols()
+    cons = Cons()
+    for name in QUERY_CONSTS:
+        cons.ext(O.SEL_TRANSITION, esub(ev(m[name], True), ev(m[name])))
+    x = eb(pscale(pv(m["XQ"]), GEN))
+    act = pv(QP_ACT)
+    cons.ext(O.SEL_ALL, egate(act, esub(emul(esub(x, ev(m["ZETA"])), ev(m["I1"])), ec(1))))
+    cons.ext(O.SEL_ALL, egate(act, esub(emul(esub(x, ev(m["ZNX"])), ev(m["I2"])), ec(1))))
+    cons.ext(O.SEL_ALL, esub(ev(m["P1"]), emul(esub(ev(m["AT"]), ev(m["YL"])), ev(m["I1"]))))
+    cons.ext(O.SEL_ALL, esub(ev(m["P2"]), emul(esub(ev(m["AT"]), ev(m["YN"])), ev(m["I2"]))))
+    cons.ext(O.SEL_ALL, esub(ev(m["P2O"]), emul(ev(m["OFFN"]), ev(m["P2"]))))
+    cons.ext(O.SEL_ALL, esub(ev(m["P3"]), emul(esub(ev(m["AQ"]), ev(m["YQ"])), ev(m["I1"]))))
+    cons.ext(O.SEL_ALL, esub(ev(m["P3O"]), emul(ev(m["OFFQ"]), ev(m["P3"]))))
+    cons.ext(O.SEL_ALL, esub(ev(m["RO"]), eadd(ev(m["P1"]), ev(m["P2O"]), ev(m["P3O"]))))
+    return O.air_program(Q_PRE + Q_MAIN, sh.NPUB, cons.c)
+
+
+def _e4(c):
+    return [c, c + 1, c + 2, c + 3]
+
+
+def query_table():
+    m = query_cols()
+    return O.interaction_table([
+        (RECV, QP_ACT, F.BUS_I, [QP_QN, m["IDX"]]),
+        (RECV, QP_ACT, F.BUS_Q, [m["IDX"], m["XQ"]] + _e4(m["RO"])),
+        (RECV, QP_ACT, BUS_AT, [QP_QN] + _e4(m["AT"])), (RECV, QP_ACT, BUS_AQ, [QP_QN] + _e4(m["AQ"])),
+        (SEND, QP_ACT2, BUS_QI, [QP_QN, m["IDX"]]),
+        (RECV, QP_FIRST, BUS_K0, _e4(m["ZETA"]) + _e4(m["ZNX"])), (RECV, QP_FIRST, BUS_K1, _e4(m["YL"]) + _e4(m["YN"])),
+        (RECV, QP_FIRST, BUS_K2, _e4(m["YQ"]) + _e4(m["OFFN"])), (RECV, QP_FIRST, BUS_K3, _e4(m["OFFQ"]))])
+
+
+def query_pre(sh, log_rows):
+    t = np.zeros((1 << log_rows, Q_PRE), dtype=np.uint32)
+    for q in range(sh.Q):
+        t[q] = [q, 1, 2, 0]
+    t[0, QP_FIRST] = 1
+    return t
+
+
+def e_sub(a, b):
+    return [(x - y) % P for x, y in zip(a, b)]
+
+
+def e_add(a, b):
+    return [(x + y) % P for x, y in zip(a, b)]
+
+
+def query_main(sh, w, sc, at, aq, log_rows):
+    m = query_cols()
+    t = np.zeros((1 << log_rows, Q_MAIN), dtype=np.uint64)
+    for name in QUERY_CONSTS:
+        t[:, m[name] - Q_PRE:m[name] - Q_PRE + 4] = sc[name]
+    ros = []
+    wM = two_adic_generator(sh.H)
+    for q in range(sh.Q):
+        index = w["openings"][q]["index"]
+        xq = pow(wM, pyref.bitrev(index, sh.H), P)
+        x = [GEN * xq % P, 0, 0, 0]
+        i1, i2 = pyref.ext_inv(e_sub(x, sc["ZETA"])), pyref.ext_inv(e_sub(x, sc["ZNX"]))
+        p1 = ext_mul(e_sub(at[q], sc["YL"]), i1)
+        p2 = ext_mul(e_sub(at[q], sc["YN"]), i2)
+        p2o = ext_mul(sc["OFFN"], p2)
+        p3 = ext_mul(e_sub(aq[q], sc["YQ"]), i1)
+        p3o = ext_mul(sc["OFFQ"], p3)
+        ro = e_add(e_add(p1, p2o), p3o)
+        ros.append(ro)
+        r = t[q]
+        r[m["IDX"] - Q_PRE], r[m["XQ"] - Q_PRE] = index, xq
+        for name, val in (("RO", ro), ("AT", at[q]), ("AQ", aq[q]), ("I1", i1), ("I2", i2), ("P1", p1), ("P2", p2), ("P2O", p2o), ("P3", p3), ("P3O", p3o)):
+            r[m[name] - Q_PRE:m[name] - Q_PRE + 4] = val
+    return t.astype(np.uint32), ros                                            # (padding rows: everything but the constants zero -- every product has a zero factor)
+
+
+# ---------------------------------------------------------------------------------------------------------------- OPENED
+OP_PRE = 12
+OP_ACT, OP_FIRST, OP_LASTG, OP_NOTFIRST, OP_K1, OP_K2, OP_K3, OP_TL0, OP_TL1, OP_TN0, OP_TN1 = range(11)
+
+
+def opened_cols():
+    m = Cols(OP_PRE)
+    for name in ("A", "B", "C", "D", "AN", "BN", "CN", "DN", "FA", "FA4", "ALPHA", "SELT", "SELF", "PW", "PWN", "H2", "H1", "IL", "G2", "G1", "INX",
+                 "YLIN", "YLO", "YNIN", "YNO", "A2", "AB", "ACCIN", "U1", "U2", "ACCO"):
+        m(name)
+    return m
+
+
+OPENED_CONSTS = ("FA", "FA4", "ALPHA", "SELT", "SELF")
+OP_MAIN = opened_cols().n - OP_PRE
+
+
+def opened_program(sh):
+    m = opened_cols()
+    cons = Cons()
+    e = lambda name, nxt=False: ev(m[name], nxt)
+    for name in OPENED_CONSTS:
+        cons.ext(O.SEL_TRANSITION, esub(e(name, True), e(name)))
+    first, nf = pv(OP_FIRST), pv(OP_NOTFIRST, True)
+    cons.ext(O.SEL_ALL, egate(first, esub(e("PW"), ec(1))))
+    cons.ext(O.SEL_ALL, esub(e("PWN"), emul(e("PW"), e("FA4"))))
+    cons.ext(O.SEL_TRANSITION, egate(nf, esub(e("PW", True), e("PWN"))))
+    fa = e("FA")
+    for h2, h1, il, (a, b, c, d) in (("H2", "H1", "IL", ("A", "B", "C", "D")), ("G2", "G1", "INX", ("AN", "BN", "CN", "DN"))):
+        cons.ext(O.SEL_ALL, esub(e(h2), eadd(e(c), emul(fa, e(d)))))
+        cons.ext(O.SEL_ALL, esub(e(h1), eadd(e(b), emul(fa, e(h2)))))
+        cons.ext(O.SEL_ALL, esub(e(il), eadd(e(a), emul(fa, e(h1)))))
+    for yin, yo, il in (("YLIN", "YLO", "IL"), ("YNIN", "YNO", "INX")):
+        cons.ext(O.SEL_ALL, egate(first, e(yin)))
+        cons.ext(O.SEL_ALL, esub(e(yo), eadd(e(yin), emul(e("PW"), e(il)))))
+        cons.ext(O.SEL_TRANSITION, egate(nf, esub(e(yin, True), e(yo))))
+    # the synthetic AIR on the opened values (docs/PROTOCOL.md section 3): C1 = c - a^2 b - (g + 1), C2 = sel_transition (d' - a b - c - (2 g + 3)),
+    # C3 = sel_first (d - (5 g + 7)), folded acc = acc alpha + C in this order, group after group
+    cons.ext(O.SEL_ALL, esub(e("A2"), emul(e("A"), e("A"))))
+    cons.ext(O.SEL_ALL, esub(e("AB"), emul(e("A"), e("B"))))
+    al = e("ALPHA")
+    cons.ext(O.SEL_ALL, egate(first, e("ACCIN")))
+    cons.ext(O.SEL_ALL, esub(e("U1"), eadd(emul(e("ACCIN"), al), esub(esub(e("C"), emul(e("A2"), e("B"))), eb(pv(OP_K1))))))
+    cons.ext(O.SEL_ALL, esub(e("U2"), eadd(emul(e("U1"), al), emul(e("SELT"), esub(esub(esub(e("DN"), e("AB")), e("C")), eb(pv(OP_K2)))))))
+    cons.ext(O.SEL_ALL, esub(e("ACCO"), eadd(emul(e("U2"), al), emul(e("SELF"), esub(e("D"), eb(pv(OP_K3)))))))
+    cons.ext(O.SEL_TRANSITION, egate(nf, esub(e("ACCIN", True), e("ACCO"))))
+    return O.air_program(OP_PRE + OP_MAIN, sh.NPUB, cons.c)
+
+
+def opened_table():
+    m = opened_cols()
+    it = []
+    for tag, lo, hi in ((OP_TL0, "A", "B"), (OP_TL1, "C", "D"), (OP_TN0, "AN", "BN"), (OP_TN1, "CN", "DN")):
+        it += [(RECV, OP_ACT, BUS_IN0, [tag] + _e4(m[lo])), (RECV, OP_ACT, BUS_IN1, [tag] + _e4(m[hi]))]
+    it += [(SEND, OP_LASTG, BUS_OY, _e4(m["YLO"]) + _e4(m["YNO"])), (SEND, OP_LASTG, BUS_OA, _e4(m["ACCO"])),
+           (RECV, OP_FIRST, BUS_KO0, _e4(m["FA"]) + _e4(m["FA4"])), (RECV, OP_FIRST, BUS_KO1, _e4(m["ALPHA"]) + _e4(m["SELT"])),
+           (RECV, OP_FIRST, BUS_KO2, _e4(m["SELF"]))]
+    return O.interaction_table(it)
+
+
+def opened_pre(sh, log_rows):
+    t = np.zeros((1 << log_rows, OP_PRE), dtype=np.uint32)
+    for g in range(sh.G):
+        t[g, OP_ACT], t[g, OP_NOTFIRST] = 1, 1 if g else 0
+        t[g, OP_K1], t[g, OP_K2], t[g, OP_K3] = g + 1, 2 * g + 3, 5 * g + 7
+        t[g, OP_TL0], t[g, OP_TL1] = sh.TO0 + 2 * g, sh.TO0 + 2 * g + 1
+        t[g, OP_TN0], t[g, OP_TN1] = sh.TO0 + sh.W // 2 + 2 * g, sh.TO0 + sh.W // 2 + 2 * g + 1
+    t[0, OP_FIRST], t[sh.G - 1, OP_LASTG] = 1, 1
+    return t
+
+
+def opened_main(sh, w, sc, log_rows):
+    m = opened_cols()
+    t = np.zeros((1 << log_rows, OP_MAIN), dtype=np.uint64)
+    put = lambda r, name, val: r.__setitem__(slice(m[name] - OP_PRE, m[name] - OP_PRE + 4), val)
+    fa, fa4, al, selt, self_ = sc["FA"], sc["FA4"], sc["ALPHA"], sc["SELT"], sc["SELF"]
+    pw, yl, yn, acc = [1, 0, 0, 0], [0] * 4, [0] * 4, [0] * 4
+    for g in range(1 << log_rows):
+        r = t[g]
+        for name, val in zip(OPENED_CONSTS, (fa, fa4, al, selt, self_)):
+            put(r, name, val)
+        if g < sh.G:
+            a, b, c, d = w["loc"][4 * g:4 * g + 4]
+            an, bn, cn, dn = w["nxt"][4 * g:4 * g + 4]
+        else:
+            a = b = c = d = an = bn = cn = dn = [0] * 4
+            pw, yl, yn, acc = [0] * 4, [0] * 4, [0] * 4, [0] * 4
+        for name, val in zip(("A", "B", "C", "D", "AN", "BN", "CN", "DN"), (a, b, c, d, an, bn, cn, dn)):
+            put(r, name, val)
+        put(r, "PW", pw)
+        pwn = ext_mul(pw, fa4)
+        put(r, "PWN", pwn)
+        outs = []
+        for h2n, h1n, iln, (x0, x1, x2, x3) in (("H2", "H1", "IL", (a, b, c, d)), ("G2", "G1", "INX", (an, bn, cn, dn))):
+            h2 = e_add(x2, ext_mul(fa, x3))
+            h1 = e_add(x1, ext_mul(fa, h2))
+            il = e_add(x0, ext_mul(fa, h1))
+            put(r, h2n, h2), put(r, h1n, h1), put(r, iln, il)
+            outs.append(il)
+        put(r, "YLIN", yl), put(r, "YNIN", yn)
+        yl, yn = e_add(yl, ext_mul(pw, outs[0])), e_add(yn, ext_mul(pw, outs[1]))
+        put(r, "YLO", yl), put(r, "YNO", yn)
+        a2, ab = ext_mul(a, a), ext_mul(a, b)
+        put(r, "A2", a2), put(r, "AB", ab), put(r, "ACCIN", acc)
+        k1, k2, k3 = (g + 1, 2 * g + 3, 5 * g + 7) if g < sh.G else (0, 0, 0)
+        u1 = e_add(ext_mul(acc, al), e_sub(e_sub(c, ext_mul(a2, b)), [k1, 0, 0, 0]))
+        u2 = e_add(ext_mul(u1, al), ext_mul(selt, e_sub(e_sub(e_sub(dn, ab), c), [k2, 0, 0, 0])))
+        acc = e_add(ext_mul(u2, al), ext_mul(self_, e_sub(d, [k3, 0, 0, 0])))
+        put(r, "U1", u1), put(r, "U2", u2), put(r, "ACCO", acc)
+        pw = pwn
+        if g == sh.G - 1:
+            result = (yl, yn, acc)
+    return t.astype(np.uint32), result
+
+
+# ---------------------------------------------------------------------------------------------------------------- SCALARS
+SC_PRE = 8
+SP_FIRST, SP_KA, SP_KZ, SP_KF, SP_TQZ = 0, 1, 2, 3, 4
+
+
+def scalars_cols(sh):
+    m = Cols(SC_PRE)
+    for name in ("ALPHA", "ZETA", "FA"):
+        m(name)
+    for i in range(1, sh.n + 1):
+        m("ZP%d" % i)
+    for name in ("INVF", "SELF", "SELT", "ZNX"):
+        m(name)
+    mb = sh.W.bit_length() - 1
+    for i in range(1, mb + 1):
+        m("FP%d" % i)
+    bits = [i for i in range(mb + 1) if (sh.W >> i) & 1]
+    for k in range(1, len(bits)):
+        m("PR%d" % k)
+    m("OFFN"), m("OFFQ")
+    for j in range(8):
+        m("QZ%d" % j)
+    for j in range(7):
+        m("HQ%d" % j)
+    for name in ("QK0", "QK1", "QUO", "YL", "YN", "ACC"):
+        m(name)
+    return m
+
+
+def zps_consts(sh):
+    """zps_k(zeta) = a_k zeta^N + b_k for the two quotient chunks (tests/pyverify.py, the recombination)"""
+    N = 1 << sh.n
+    wq = two_adic_generator(sh.n + 1)
+    sN = [pow(GEN * pow(wq, k, P) % P, N, P) for k in range(2)]
+    out = []
+    for k in range(2):
+        j = 1 - k
+        sj_inv = pow(sN[j], -1, P)
+        den_inv = pow((sN[k] * sj_inv - 1) % P, -1, P)
+        out.append((sj_inv * den_inv % P, (P - den_inv) % P))
+    return out
+
+
+def scalars_program(sh):
+    m = scalars_cols(sh)
+    cons = Cons()
+    e = lambda name: ev(m[name])
+    prev = e("ZETA")
+    for i in range(1, sh.n + 1):
+        cons.ext(O.SEL_ALL, esub(e("ZP%d" % i), emul(prev, prev)))
+        prev = e("ZP%d" % i)
+    znn = prev
+    wni = pow(two_adic_generator(sh.n), -1, P)
+    cons.ext(O.SEL_ALL, esub(emul(esub(e("ZETA"), ec(1)), e("INVF")), ec(1)))
+    cons.ext(O.SEL_ALL, esub(e("SELF"), emul(esub(znn, ec(1)), e("INVF"))))
+    cons.ext(O.SEL_ALL, esub(e("SELT"), esub(e("ZETA"), ec(wni))))
+    cons.ext(O.SEL_ALL, esub(e("ZNX"), escale(e("ZETA"), two_adic_generator(sh.n))))
+    mb = sh.W.bit_length() - 1
+    prev = e("FA")
+    fp = [prev]
+    for i in range(1, mb + 1):
+        cons.ext(O.SEL_ALL, esub(e("FP%d" % i), emul(prev, prev)))
+        prev = e("FP%d" % i)
+        fp.append(prev)
+    bits = [i for i in range(mb + 1) if (sh.W >> i) & 1]
+    acc = fp[bits[0]]
+    for k in range(1, len(bits)):
+        cons.ext(O.SEL_ALL, esub(e("PR%d" % k), emul(acc, fp[bits[k]])))
+        acc = e("PR%d" % k)
+    cons.ext(O.SEL_ALL, esub(e("OFFN"), acc))
+    cons.ext(O.SEL_ALL, esub(e("OFFQ"), emul(e("OFFN"), e("OFFN"))))
+    prev = e("QZ7")
+    for j in range(6, -1, -1):
+        cons.ext(O.SEL_ALL, esub(e("HQ%d" % j), eadd(e("QZ%d" % j), emul(e("FA"), prev))))
+        prev = e("HQ%d" % j)
+    for k in range(2):
+        q = ec(0)
+        for t in range(4):
+            basis = [0, 0, 0, 0]
+            basis[t] = 1
+            q = eadd(q, emul(ec(basis), e("QZ%d" % (4 * k + t))))
+        cons.ext(O.SEL_ALL, esub(e("QK%d" % k), q))
+    (a0, b0), (a1, b1) = zps_consts(sh)
+    z0, z1 = eadd(escale(znn, a0), ec(b0)), eadd(escale(znn, a1), ec(b1))
+    cons.ext(O.SEL_ALL, esub(e("QUO"), eadd(emul(z0, e("QK0")), emul(z1, e("QK1")))))
+    cons.ext(O.SEL_ALL, esub(e("ACC"), emul(e("QUO"), esub(znn, ec(1)))))
+    return O.air_program(SC_PRE + rup4(m.n - SC_PRE), sh.NPUB, cons.c)
+
+
+def scalars_table(sh):
+    m = scalars_cols(sh)
+    it = [(RECV, SP_FIRST, BUS_SC, [SP_KA] + _e4(m["ALPHA"])), (RECV, SP_FIRST, BUS_SC, [SP_KZ] + _e4(m["ZETA"])), (RECV, SP_FIRST, BUS_SC, [SP_KF] + _e4(m["FA"]))]
+    for i in range(4):
+        it += [(RECV, SP_FIRST, BUS_IN0, [SP_TQZ + i] + _e4(m["QZ%d" % (2 * i)])), (RECV, SP_FIRST, BUS_IN1, [SP_TQZ + i] + _e4(m["QZ%d" % (2 * i + 1)]))]
+    it += [(RECV, SP_FIRST, BUS_OY, _e4(m["YL"]) + _e4(m["YN"])), (RECV, SP_FIRST, BUS_OA, _e4(m["ACC"])),
+           (SEND, SP_FIRST, BUS_K0, _e4(m["ZETA"]) + _e4(m["ZNX"])), (SEND, SP_FIRST, BUS_K1, _e4(m["YL"]) + _e4(m["YN"])),
+           (SEND, SP_FIRST, BUS_K2, _e4(m["HQ0"]) + _e4(m["OFFN"])), (SEND, SP_FIRST, BUS_K3, _e4(m["OFFQ"])),
+           (SEND, SP_FIRST, BUS_KFA, _e4(m["FA"])),
+           (SEND, SP_FIRST, BUS_KO0, _e4(m["FA"]) + _e4(m["FP2"])), (SEND, SP_FIRST, BUS_KO1, _e4(m["ALPHA"]) + _e4(m["SELT"])),
+           (SEND, SP_FIRST, BUS_KO2, _e4(m["SELF"]))]
+    return O.interaction_table(it)
+
+
+def scalars_pre(sh, log_rows):
+    t = np.zeros((1 << log_rows, SC_PRE), dtype=np.uint32)
+    t[:, SP_KA], t[:, SP_KZ], t[:, SP_KF] = 0, 1, 2
+    for i in range(4):
+        t[:, SP_TQZ + i] = sh.TO0 + sh.W + i
+    t[0, SP_FIRST] = 1
+    return t
+
+
+def scalars_values(sh, w, chal):
+    """the verifier's scalars up to what the OPENED chip needs (everything but YL, YN, ACC)"""
+    m = {}
+    m["ALPHA"], m["ZETA"], m["FA"] = chal[sh.TA], chal[sh.TQ], chal[sh.TF]
+    prev = m["ZETA"]
+    for i in range(1, sh.n + 1):
+        prev = m["ZP%d" % i] = ext_mul(prev, prev)
+    znn = prev
+    wn = two_adic_generator(sh.n)
+    wni = pow(wn, -1, P)
+    m["INVF"] = pyref.ext_inv(e_sub(m["ZETA"], [1, 0, 0, 0]))
+    m["SELF"] = ext_mul(e_sub(znn, [1, 0, 0, 0]), m["INVF"])
+    m["SELT"] = e_sub(m["ZETA"], [wni, 0, 0, 0])
+    m["ZNX"] = [x * wn % P for x in m["ZETA"]]
+    mb = sh.W.bit_length() - 1
+    prev = m["FA"]
+    fp = [prev]
+    for i in range(1, mb + 1):
+        prev = m["FP%d" % i] = ext_mul(prev, prev)
+        fp.append(prev)
+    bits = [i for i in range(mb + 1) if (sh.W >> i) & 1]
+    acc = fp[bits[0]]
+    for k in range(1, len(bits)):
+        acc = m["PR%d" % k] = ext_mul(acc, fp[bits[k]])
+    m["OFFN"] = acc
+    m["OFFQ"] = ext_mul(acc, acc)
+    for j in range(8):
+        m["QZ%d" % j] = list(w["qz"][j])
+    prev = m["QZ7"]
+    for j in range(6, -1, -1):
+        prev = m["HQ%d" % j] = e_add(m["QZ%d" % j], ext_mul(m["FA"], prev))
+    for k in range(2):
+        q = [0] * 4
+        for t in range(4):
+            basis = [0, 0, 0, 0]
+            basis[t] = 1
+            q = e_add(q, ext_mul(basis, m["QZ%d" % (4 * k + t)]))
+        m["QK%d" % k] = q
+    (a0, b0), (a1, b1) = zps_consts(sh)
+    z0 = e_add([x * a0 % P for x in znn], [b0, 0, 0, 0])
+    z1 = e_add([x * a1 % P for x in znn], [b1, 0, 0, 0])
+    m["QUO"] = e_add(ext_mul(z0, m["QK0"]), ext_mul(z1, m["QK1"]))
+    m["FA4"], m["YQ"] = m["FP2"], m["HQ0"]
+    m["ZNN"] = znn
+    return m
+
+
+def scalars_main(sh, sc, log_rows):
+    m = scalars_cols(sh)
+    width = rup4(m.n - SC_PRE)
+    row = np.zeros(width, dtype=np.uint64)
+    for name, col in m.at.items():
+        row[col - SC_PRE:col - SC_PRE + 4] = sc[name]
+    return np.tile(row, (1 << log_rows, 1)).astype(np.uint32)
+
+
+# ---------------------------------------------------------------------------------------------------------------- FOLD (tests/fri_air.py, rec form)
+def fold_table(layers):
+    t = [(SEND, F.ACTIVE, F.BUS_E0, [F.LN, F.K2, F.E0, F.E0 + 1, F.E0 + 2, F.E0 + 3]), (SEND, F.ACTIVE, F.BUS_E1, [F.LN, F.K2, F.E1, F.E1 + 1, F.E1 + 2, F.E1 + 3]),
+         (SEND, F.L_REC, F.BUS_Q, [F.IDX, F.XS, F.OWN, F.OWN + 1, F.OWN + 2, F.OWN + 3]),
+         (RECV, F.ACTIVE, BUS_BETA, [F.LN, F.BETA, F.BETA + 1, F.BETA + 2, F.BETA + 3]),
+         (SEND, F.L_REC + layers - 1, BUS_FIN, [F.FOLD, F.FOLD + 1, F.FOLD + 2, F.FOLD + 3])]
+    return O.interaction_table(t)
+
+
+# ---------------------------------------------------------------------------------------------------------------- the witness and the machine
+def witness(proof, log_n, width, public_values, n_queries, pow_bits):
+    """everything the machine's main columns hold, taken from the inner proof by the Python verifier (which must accept it)"""
+    import pyverify
+    view = {}
+    pyverify.verify(proof, log_n, width, public_values, num_queries=n_queries, pow_bits=pow_bits, view=view)
+    sh = Shape(log_n, width, n_queries, pow_bits, len(public_values))
+    w = {"trace_root": view["trace_root"], "quot_root": view["quot_root"], "layer_roots": view["roots"], "final": view["final"], "witness": view["witness"],
+         "loc": view["loc"], "nxt": view["nxt"], "qz": view["qz"], "openings": view["openings"], "betas": view["betas"], "view": view}
+    # the blocks the transcript absorbs, by sponge row
+    seq0 = sh.head + list(view["trace_root"]) + [int(v) % P for v in public_values]
+    blocks = {}
+    for T in range(sh.f0 + (1 if sh.r0 else 0)):
+        blocks[T] = seq0[8 * T:8 * T + 8]
+    blocks[sh.TQ] = list(view["quot_root"])
+    opened = [c for e in view["loc"] for c in e] + [c for e in view["nxt"] for c in e] + [c for e in view["qz"] for c in e]
+    for i in range(width + 4):
+        blocks[sh.TO0 + i] = opened[8 * i:8 * i + 8]
+    for l in range(sh.R):
+        blocks[sh.TL0 + l] = list(view["roots"][l])
+    blocks[sh.TP] = list(view["final"]) + [view["witness"]]
+    w["blocks"] = blocks
+    # the FRI pairs of every (query, layer): (pair index, the two entries, the path)
+    fri = []
+    for q, (index, value, sibs) in enumerate(view["queries"]):
+        idx, own, per = index, list(value), []
+        for l in range(sh.R):
+            bit, k = idx & 1, idx >> 1
+            e0, e1 = (sibs[l], own) if bit else (own, sibs[l])
+            per.append((k, list(e0) + list(e1), view["paths"][q][l]))
+            own, idx = F.fold_pair(k, sh.H - (l + 1), view["betas"][l], e0, e1)[0], k
+        fri.append(per)
+    w["fri"] = fri
+    return sh, w
+
+
+CHIPS = ("P2R", "ROWSUM", "FOLD", "TS", "QUERY", "OPENED", "SAMPLES", "SCALARS")
+
+
+def heights(sh):
+    return {"P2R": lg(sh.p2_rows), "ROWSUM": lg(sh.Q * (sh.WB + 1)), "FOLD": lg(sh.Q * sh.R), "TS": lg(sh.NTS), "QUERY": lg(sh.Q), "OPENED": lg(sh.G),
+            "SAMPLES": lg(sh.NS), "SCALARS": 5}
+
+
+def order(sh):
+    """tallest first; equal heights in the order of CHIPS"""
+    h = heights(sh)
+    return sorted(CHIPS, key=lambda c: (-h[c], CHIPS.index(c)))
+
+
+def programs(sh):
+    return {"P2R": p2r_program(sh), "ROWSUM": rowsum_program(sh), "FOLD": F.program(sh.R, wired=True, transcript=True, rec=sh.NPUB), "TS": ts_program(sh),
+            "QUERY": query_program(sh), "OPENED": opened_program(sh), "SAMPLES": F.samples_program(sh.R, sh.Q, sh.PB, sh.NPUB), "SCALARS": scalars_program(sh)}
+
+
+def tables(sh):
+    M0 = F.S_PRE
+    s_tab = O.interaction_table([(RECV, F.S_ROW, F.BUS_S0, [F.S_C] + [M0 + F.S_W + j for j in range(4)]), (RECV, F.S_ROW, F.BUS_S1, [F.S_C] + [M0 + F.S_W + j for j in range(4, 8)])]
+                                + [(SEND, F.S_ACT + j, F.BUS_I, [F.S_KQ + j, M0 + F.S_IDX + j]) for j in range(8)])
+    return {"P2R": p2r_table(), "ROWSUM": rowsum_table(), "FOLD": fold_table(sh.R), "TS": ts_table(sh), "QUERY": query_table(), "OPENED": opened_table(),
+            "SAMPLES": s_tab, "SCALARS": scalars_table(sh)}
+
+
+def preprocessed(sh):
+    """the key material: every chip's preprocessed trace (None: the chip has none) -- a function of the shape"""
+    h = heights(sh)
+    spre, _, _ = F.samples_tables(sh.R, sh.Q, [[0] * 8] * sh.NS, h["SAMPLES"], base=sh.TP)
+    return {"P2R": p2r_pre(sh, h["P2R"]), "ROWSUM": rowsum_pre(sh, h["ROWSUM"]), "FOLD": None, "TS": ts_pre(sh, h["TS"]), "QUERY": query_pre(sh, h["QUERY"]),
+            "OPENED": opened_pre(sh, h["OPENED"]), "SAMPLES": spre, "SCALARS": scalars_pre(sh, h["SCALARS"])}
+
+
+def main_traces(sh, w):
+    h = heights(sh)
+    p2, samples, chal = p2r_main(sh, w, h["P2R"])
+    assert chal[sh.TA] == w["view"]["alpha"] and chal[sh.TQ] == w["view"]["zeta"] and chal[sh.TF] == w["view"]["fa"], "the sponge rows do not reproduce the verifier's challenges"
+    assert [chal[sh.TL0 + l] for l in range(sh.R)] == w["betas"]
+    sc = scalars_values(sh, w, chal)
+    opened, (yl, yn, acc) = opened_main(sh, w, sc, h["OPENED"])
+    sc["YL"], sc["YN"], sc["ACC"] = yl, yn, acc
+    assert acc == ext_mul(sc["QUO"], e_sub(sc["ZNN"], [1, 0, 0, 0])), "the AIR identity at zeta does not hold"
+    rs, at, aq = rowsum_main(sh, w, sc["FA"], h["ROWSUM"])
+    qm, ros = query_main(sh, w, sc, at, aq, h["QUERY"])
+    assert ros == [list(v) for _, v, _ in w["view"]["queries"]], "the reduced openings are not the verifier's"
+    fold, final = F.trace(w["view"], h["FOLD"], wired=True, rec=True)
+    assert list(final) == list(w["final"])
+    _, smain, drawn = F.samples_tables(sh.R, sh.Q, samples, h["SAMPLES"], base=sh.TP)
+    assert drawn == [op["index"] for op in w["openings"]], "the query indices are not the ones the transcript draws"
+    ts = ts_main(sh, w, chal, p2, h["TS"])
+    return {"P2R": p2, "ROWSUM": rs, "FOLD": fold, "TS": ts, "QUERY": qm, "OPENED": opened, "SAMPLES": smain, "SCALARS": scalars_main(sh, sc, h["SCALARS"])}
+
+
+def machine(proof, log_n, width, public_values, n_queries, pow_bits):
+    """-> (shape, main traces, preprocessed traces, programs, interaction tables, public values), chips tallest first"""
+    sh, w = witness(proof, log_n, width, public_values, n_queries, pow_bits)
+    names = order(sh)
+    mt, pre, prog, tab = main_traces(sh, w), preprocessed(sh), programs(sh), tables(sh)
+    return sh, [mt[c] for c in names], [pre[c] for c in names], [prog[c] for c in names], [tab[c] for c in names], [int(v) % P for v in public_values]
+
+
+# ---------------------------------------------------------------------------------------------------------------- checks in plain integers
+def bus_balance(mains, pres, tabs):
+    """every tuple sent on a bus is received with the same total multiplicity -> the list of (bus, tuple) that do not balance"""
+    tot = {}
+    for main, pre, tab in zip(mains, pres, tabs):
+        rows = main if pre is None else np.concatenate([pre, main], axis=1)
+        rows = rows.astype(np.int64)
+        t = [int(x) for x in tab]
+        p = 3
+        for _ in range(t[1]):
+            sign, mult, bus, nv = t[p:p + 4]
+            cols = t[p + 4:p + 4 + nv]
+            p += 4 + nv
+            for r in rows:
+                mu = 1 if mult == 0xFFFFFFFF else int(r[mult])
+                if mu:
+                    key = (bus, tuple(int(r[c]) for c in cols))
+                    tot[key] = (tot.get(key, 0) + (mu if sign == SEND else -mu)) % P
+    return [k for k, v in tot.items() if v]

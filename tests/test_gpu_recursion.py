@@ -1,0 +1,78 @@
+"""The shard verifier as a machine on the GPU (csrc/shard_verifier.inl through the C ABI): the key of a shape, the outer proof of a real shard
+proof -- bytes against the oracle's generic keyed-machine prover run on the Python restatement's arrays (tests/recursion_air.py) -- and the
+verifier that is handed the shape, the inner proof's public values and the key: no byte of the inner proof."""
+import numpy as np
+import pytest
+
+from zktls_amd._lib import Params, ZkHipError
+from zktls_amd.device import shard_verifier_describe, verify_shard, verify_shard_recursive
+
+pytestmark = pytest.mark.gpu
+SEED = 0x5A4B544C53
+
+
+@pytest.mark.parametrize("log_n,width,q,pb,pubs", [(5, 8, 4, 3, [1, 2, 3]), (6, 16, 5, 0, []), (9, 64, 12, 5, [7, 8, 9, 10, 11, 12, 13, 14, 15])])
+def test_key_and_proof_bytes_equal_the_oracles(ctx, oracle, log_n, width, q, pb, pubs):
+    import recursion_air as R
+    O = oracle
+    iprm, oprm, prm = Params(1, q, pb), O.default_params(1, 20, 8), Params(1, 20, 8)
+    trace = ctx.gen_trace(SEED, 3, log_n, width)
+    inner = ctx.prove_shard(trace, log_n, width, pubs, iprm)
+    assert verify_shard(inner, log_n, width, pubs, iprm)[0] == 0
+    key = ctx.shard_verifier_setup(log_n, width, q, pb, len(pubs), prm)
+    sh, mains, pres, progs, tabs, pv = R.machine(inner.tobytes(), log_n, width, pubs, q, pb)
+    lns = [m.shape[0].bit_length() - 1 for m in mains]
+    assert key.root.tolist() == O.machine_setup(pres, lns, oprm).tolist(), "the key differs from the oracle's commitment to the restatement's preprocessed traces"
+    outer = ctx.prove_shard_verifier(key, inner, log_n, width, pubs, iprm, prm)
+    assert outer.tobytes() == O.prove_machine_keyed(mains, pres, progs, tabs, pv, oprm).tobytes(), "outer proof bytes differ from the oracle's"
+    assert verify_shard_recursive(outer, log_n, width, q, pb, pubs, key.root, prm) == (0, 0)
+    assert O.verify_machine_keyed(outer, lns, [m.shape[1] for m in mains], [0 if p is None else p.shape[1] for p in pres], key.root, progs, tabs, pv, oprm) == 0
+    if pubs:
+        other = list(pubs)
+        other[-1] += 1
+        assert verify_shard_recursive(outer, log_n, width, q, pb, other, key.root, prm)[0] != 0
+    # a second shard proof of the shape under the SAME key
+    inner2 = ctx.prove_shard(ctx.gen_trace(SEED, 4, log_n, width), log_n, width, pubs, iprm)
+    outer2 = ctx.prove_shard_verifier(key, inner2, log_n, width, pubs, iprm, prm)
+    assert outer2.tobytes() != outer.tobytes() and verify_shard_recursive(outer2, log_n, width, q, pb, pubs, key.root, prm) == (0, 0)
+    key.close()
+
+
+def test_a_tampered_inner_proof_is_refused_by_the_prover(ctx):
+    log_n, width, q, pb, pubs = 6, 16, 5, 2, [4, 5]
+    iprm, prm = Params(1, q, pb), Params(1, 20, 8)
+    inner = ctx.prove_shard(ctx.gen_trace(SEED, 9, log_n, width), log_n, width, pubs, iprm)
+    key = ctx.shard_verifier_setup(log_n, width, q, pb, len(pubs), prm)
+    for at in (40, 200, inner.size // 2, inner.size - 8):
+        bad = inner.copy()
+        bad[at] ^= 1
+        with pytest.raises(ZkHipError):
+            ctx.prove_shard_verifier(key, bad, log_n, width, pubs, iprm, prm)
+    with pytest.raises(ZkHipError):
+        ctx.prove_shard_verifier(key, inner, log_n, width, [4, 6], iprm, prm)          # other public values than the proof's
+    key.close()
+
+
+def test_headline_shard_proof_verified_in_circuit(ctx, oracle):
+    """the 2^20 x 256 shard proof of BASELINE configs[1] (100 queries, 16 proof-of-work bits): its whole verification in ONE outer proof; the
+    oracle's verifier and the host verifier accept it with the machine as the library describes it, the shape's key and the public values"""
+    O = oracle
+    log_n, width, q, pb = 20, 256, 100, 16
+    pubs = [11, 12, 13, 14, 15, 16, 17, 18, 19]
+    iprm, prm, oprm = Params(1, q, pb), Params(1, 100, 16), O.default_params(1, 100, 16)
+    trace = ctx.gen_trace(SEED, 0, log_n, width)
+    inner = ctx.prove_shard(trace, log_n, width, pubs, iprm)
+    trace.free()
+    key = ctx.shard_verifier_setup(log_n, width, q, pb, len(pubs), prm)
+    outer = ctx.prove_shard_verifier(key, inner, log_n, width, pubs, iprm, prm)
+    assert ctx.prove_shard_verifier(key, inner, log_n, width, pubs, iprm, prm).tobytes() == outer.tobytes()
+    assert verify_shard_recursive(outer, log_n, width, q, pb, pubs, key.root, prm) == (0, 0)
+    progs, tabs, lns, widths, pws = [], [], [], [], []
+    for i in range(8):
+        p, ln, mw, pw = shard_verifier_describe(log_n, width, q, pb, len(pubs), i, 0)
+        t, _, _, _ = shard_verifier_describe(log_n, width, q, pb, len(pubs), i, 1)
+        progs.append(p), tabs.append(t), lns.append(ln), widths.append(mw), pws.append(pw)
+    assert O.verify_machine_keyed(outer, lns, widths, pws, key.root, progs, tabs, pubs, oprm) == 0
+    assert verify_shard_recursive(outer, log_n, width, q, pb, pubs[:-1] + [0], key.root, prm)[0] != 0
+    print("headline: inner %d bytes, outer %d bytes, P2R 2^%d rows" % (inner.size, outer.size, lns[0]))
+    key.close()

@@ -1,0 +1,104 @@
+"""The shard verifier as a machine (csrc/shard_verifier.inl, restated in tests/recursion_air.py), on the CPU:
+  * the restatement's programs hold row by row in plain integers on the witness of a real (oracle-made) shard proof, every bus balances, and a
+    flipped cell breaks a constraint or a bus;
+  * the product's machine -- programs, interaction tables, preprocessed traces, all host code -- equals the restatement word for word;
+  * the key (the commitment to the preprocessed traces) does not depend on the inner proof;
+  * the oracle's generic keyed-machine prover proves the machine, and three verifiers (oracle, product host verifier through
+    zkhip_verify_shard_recursive, the pure-Python multi-chip verifier) accept -- handed the shape, the inner proof's public values and the key,
+    no byte of the inner proof -- and refuse other public values, another key, another shape."""
+import numpy as np
+import pytest
+
+import recursion_air as R
+import sha256_air as S
+
+SEED = 0x5A4B544C53
+SHAPES = [(5, 8, 4, 3, [1, 2, 3]), (6, 16, 5, 0, []), (5, 40, 3, 2, list(range(20, 31)))]
+
+
+def inner_proof(O, log_n, width, q, pb, pubs, shard=0):
+    return O.prove_shard(O.gen_trace(SEED, shard, log_n, width), pubs, O.default_params(1, q, pb)).tobytes()
+
+
+@pytest.mark.parametrize("log_n,width,q,pb,pubs", SHAPES)
+def test_programs_hold_and_buses_balance(oracle, log_n, width, q, pb, pubs):
+    proof = inner_proof(oracle, log_n, width, q, pb, pubs)
+    sh, mains, pres, progs, tabs, pv = R.machine(proof, log_n, width, pubs, q, pb)
+    for name, main, pre, prog in zip(R.order(sh), mains, pres, progs):
+        rows = main if pre is None else np.concatenate([pre, main], axis=1)
+        assert rows.shape[1] == int(prog[2])
+        assert S.check_rows(prog, rows, pv) == [], name
+    assert R.bus_balance(mains, pres, tabs) == []
+
+
+def test_a_flipped_cell_breaks_a_constraint_or_a_bus(oracle):
+    log_n, width, q, pb, pubs = SHAPES[0]
+    proof = inner_proof(oracle, log_n, width, q, pb, pubs)
+    sh, mains, pres, progs, tabs, pv = R.machine(proof, log_n, width, pubs, q, pb)
+    names = R.order(sh)
+    rng = np.random.default_rng(5)
+    tried = 0
+    for name in names:
+        i = names.index(name)
+        used = {"P2R": sh.p2_rows, "ROWSUM": sh.Q * (sh.WB + 1), "FOLD": sh.Q * sh.R, "TS": sh.NTS, "QUERY": sh.Q, "OPENED": sh.G, "SAMPLES": sh.NS, "SCALARS": 1}[name]
+        for _ in range(6):
+            r, c = int(rng.integers(0, used)), int(rng.integers(0, mains[i].shape[1]))
+            keep = int(mains[i][r, c])
+            mains[i][r, c] = (keep + 1) % R.P
+            rows = mains[i] if pres[i] is None else np.concatenate([pres[i], mains[i]], axis=1)
+            broken = bool(S.check_rows(progs[i], rows, pv)) or bool(R.bus_balance(mains, pres, tabs))
+            mains[i][r, c] = keep
+            # (cells no constraint reads: unused padding columns of a chip, and the TS rows' copies of kept sponge words that are balanced by construction)
+            unused = {"P2R": c > R.M_KP, "FOLD": c >= R.F.L_REC + sh.R, "QUERY": c >= R.query_cols().n - R.Q_PRE, "SCALARS": c >= R.scalars_cols(sh).n - R.SC_PRE,
+                      "TS": (c >= 8 and c < 16 and r != 0) or (c >= 16 and not (r in (sh.TA, sh.TQ, sh.TF) or sh.TL0 <= r < sh.TP))}.get(name, False)
+            assert broken or unused, (name, r, c)
+            tried += 1
+    assert tried == 48
+
+
+def test_product_machine_equals_the_restatement_word_for_word():
+    from zktls_amd.device import shard_verifier_describe
+    for log_n, width, q, pb, npub in ((5, 8, 4, 3, 3), (6, 16, 5, 0, 0), (7, 24, 9, 4, 9), (5, 40, 3, 2, 11), (8, 64, 12, 5, 2)):
+        sh = R.Shape(log_n, width, q, pb, npub)
+        names, progs, tabs, pres, h = R.order(sh), R.programs(sh), R.tables(sh), R.preprocessed(sh), R.heights(sh)
+        for i, nm in enumerate(names):
+            p, ln, mw, pw = shard_verifier_describe(log_n, width, q, pb, npub, i, 0)
+            t, _, _, _ = shard_verifier_describe(log_n, width, q, pb, npub, i, 1)
+            e, _, _, _ = shard_verifier_describe(log_n, width, q, pb, npub, i, 2)
+            assert ln == h[nm] and p.tolist() == [int(x) for x in progs[nm]], (nm, "program")
+            assert t.tolist() == [int(x) for x in tabs[nm]], (nm, "table")
+            want = np.zeros(0, dtype=np.uint32) if pres[nm] is None else pres[nm].ravel()
+            assert e.tolist() == want.tolist() and pw == (0 if pres[nm] is None else pres[nm].shape[1]), (nm, "preprocessed")
+
+
+def test_oracle_proves_the_machine_and_three_verifiers_take_no_byte_of_the_inner_proof(oracle):
+    import pyverify_chips
+    from zktls_amd._lib import Params
+    from zktls_amd.device import verify_shard_recursive
+    O = oracle
+    log_n, width, q, pb, pubs = SHAPES[0]
+    oprm, prm = O.default_params(1, 20, 8), Params(1, 20, 8)
+    outers, roots = [], []
+    for shard in (0, 1):
+        proof = inner_proof(O, log_n, width, q, pb, pubs[:2] + [shard])
+        sh, mains, pres, progs, tabs, pv = R.machine(proof, log_n, width, pubs[:2] + [shard], q, pb)
+        lns = [m.shape[0].bit_length() - 1 for m in mains]
+        roots.append(O.machine_setup(pres, lns, oprm))
+        outers.append((O.prove_machine_keyed(mains, pres, progs, tabs, pv, oprm), pv, lns, [m.shape[1] for m in mains], [0 if p is None else p.shape[1] for p in pres], progs, tabs))
+    assert roots[0].tolist() == roots[1].tolist(), "the key depends on the inner proof"
+    vk = roots[0]
+    for op, pv, lns, widths, pws, progs, tabs in outers:
+        assert O.verify_machine_keyed(op, lns, widths, pws, vk, progs, tabs, pv, oprm) == 0
+        assert verify_shard_recursive(op, log_n, width, q, pb, pv, vk, prm) == (0, 0)
+        assert pyverify_chips.verify(op.tobytes(), lns, widths, pv, log_blowup=1, num_queries=20, pow_bits=8, programs=progs, tables=tabs, pre_widths=pws, pre_root=[int(x) for x in vk]) is True
+    op, pv = outers[0][0], outers[0][1]
+    assert verify_shard_recursive(op, log_n, width, q, pb, outers[1][1], vk, prm)[0] != 0                 # the other proof's public values
+    assert verify_shard_recursive(op, log_n, width, q, pb, pv, (vk + 1) % R.P, prm)[0] != 0               # another key
+    # another shape, where the shape shows in a program or a height (the number of queries of this small machine lives in the KEY alone: the key is
+    # what binds a proof to its shape, and a verifier takes the key of the shape it means)
+    assert verify_shard_recursive(op, log_n + 1, width, q, pb, pv, vk, prm)[0] != 0
+    assert verify_shard_recursive(op, log_n, width + 8, q, pb, pv, vk, prm)[0] != 0
+    assert verify_shard_recursive(op, log_n, width, q, pb + 1, pv, vk, prm)[0] != 0
+    bad = op.copy()
+    bad[len(bad) // 2] ^= 1
+    assert verify_shard_recursive(bad, log_n, width, q, pb, pv, vk, prm)[0] != 0

@@ -6,6 +6,8 @@
 //     mode f: per round, 6 threads ("lanes"), each running 16 FIBERS (ucontext, mmap'ed 1 MiB stacks) that take turns launching from
 //             their fiber stacks with arguments read from a pinned ring (what batch.cpp does)
 //     mode p: like t, but the 16 threads are created ONCE and reused for every round (is thread churn the trigger?)
+//     mode g: per round, 4 short-lived threads; each captures 200 trivial launches into a HIP GRAPH (thread-local capture), instantiates it
+//             and launches it 20 times -- what the library's FRI commit phase does outside lock-step batches (csrc/prover.cpp)
 #include <hip/hip_runtime.h>
 #include <sys/mman.h>
 #include <ucontext.h>
@@ -32,6 +34,27 @@ static void worker_plain(int launches) {
         if (i % 20 == 19) (void)hipStreamSynchronize(s);
     }
     (void)hipStreamSynchronize(s);
+    (void)hipFree(d);
+    (void)hipStreamDestroy(s);
+}
+
+static void worker_graph(int launches) {
+    hipStream_t s;
+    if (hipStreamCreateWithFlags(&s, hipStreamNonBlocking) != hipSuccess) std::abort();
+    uint32_t* d;
+    if (hipMalloc((void**)&d, 64 * 256 * 4) != hipSuccess) std::abort();
+    hipGraph_t graph = nullptr;
+    hipGraphExec_t exec = nullptr;
+    if (hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal) != hipSuccess) std::abort();
+    for (int i = 0; i < launches; i++) hipLaunchKernelGGL(tiny, dim3(64), dim3(256), 0, s, d, (uint32_t)i);
+    if (hipStreamEndCapture(s, &graph) != hipSuccess) std::abort();
+    if (hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0) != hipSuccess) std::abort();
+    (void)hipGraphDestroy(graph);
+    for (int r = 0; r < 20; r++) {
+        if (hipGraphLaunch(exec, s) != hipSuccess) std::abort();
+        (void)hipStreamSynchronize(s);
+    }
+    (void)hipGraphExecDestroy(exec);
     (void)hipFree(d);
     (void)hipStreamDestroy(s);
 }
@@ -90,7 +113,7 @@ static void worker_lane(int launches) {
 }
 
 int main(int argc, char** argv) {
-    if (argc < 3) { std::fprintf(stderr, "usage: %s t|f|p <rounds>\n", argv[0]); return 1; }
+    if (argc < 3) { std::fprintf(stderr, "usage: %s t|f|p|g <rounds>\n", argv[0]); return 1; }
     const char mode = argv[1][0];
     const int rounds = std::atoi(argv[2]);
     std::atomic<bool> stop{false};
@@ -117,8 +140,8 @@ int main(int argc, char** argv) {
     } else {
         for (int r = 0; r < rounds; r++) {
             std::vector<std::thread> ts;
-            const int nt = mode == 'f' ? 6 : 16;
-            for (int t = 0; t < nt; t++) ts.emplace_back(mode == 'f' ? worker_lane : worker_plain, 200);
+            const int nt = mode == 'f' ? 6 : mode == 'g' ? 4 : 16;
+            for (int t = 0; t < nt; t++) ts.emplace_back(mode == 'f' ? worker_lane : mode == 'g' ? worker_graph : worker_plain, 200);
             for (auto& t : ts) t.join();
         }
     }

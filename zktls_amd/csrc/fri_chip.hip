@@ -21,6 +21,9 @@
 // Poseidon2 chip proves such paths, but is not wired to this bus yet), the reduced openings themselves, the transcript.  A verifier of
 // this machine proof recomputes the key from the inner proof's openings (zkhip_fri_queries_key) -- it still reads them, but no longer
 // folds them.  tests/fri_air.py writes the same program, trace and table independently; the words must be equal.
+#include <algorithm>
+#include <array>
+#include <atomic>
 #include <condition_variable>
 #include <cstring>
 #include <map>
@@ -42,6 +45,9 @@ constexpr uint32_t E0 = 0, E1 = 4, BIT = 8, K = 9, X = 10, XI = 11, S = 12, T = 
 // of the layer selectors: K2 = 2 K (the bus key the Poseidon2 chip's index walk produces on a leaf row) and IDX = K2 + BIT (the query
 // index on a query's first row)
 constexpr uint32_t K2 = 32, IDX = 33, L_WIRED = 34;
+// the shard verifier's form (shard_verifier.inl): one more column, XS = X (1 - 2 BIT) -- on a query's first row the query's evaluation point
+// divided by the coset shift; no public final value (END rows send their folded value to the transcript table instead)
+constexpr uint32_t XS = 34, L_REC = 35, BUS_FIN = 60;
 constexpr uint32_t BUS_E0 = 40, BUS_E1 = 41, BUS_R0 = 42, BUS_R1 = 43, BUS_Q = 44;
 constexpr uint32_t BUS_B = 45, BUS_BF = 46;                  // transcript machine: (layer, beta) from the Poseidon2 chip's transcript rows to the ROOTS table, and from there to the fold rows
 constexpr uint32_t BUS_S0 = 47, BUS_S1 = 48, BUS_I = 49;     // query-phase machine: a sponge row's sampled words (two halves) to the SAMPLES chip, (query, index) from there to QUERIES
@@ -55,7 +61,7 @@ constexpr uint32_t N_PUBLIC_T = 12;                          // ... and whose pu
 constexpr uint32_t QUERIES_PRE = 8, ROOTS_PRE = 12;          // QUERIES: (index, value[4], 1, 0, 0); ROOTS: (layer, root[8], 0, 0, 0) + main (count, 0, 0, 0)
 constexpr uint32_t OPEN_PRE = 12, OPEN_MAIN = 4;             // OPENINGS: preprocessed (ln, k, e0[4], e1[4], m, 0), main 4 unused columns
 constexpr int MIN_LAYERS = 2, MAX_LAYERS = 22;
-inline uint32_t width_of(int layers, bool wired = false) { return ((wired ? L_WIRED : L) + (uint32_t)layers + 3u) & ~3u; }
+inline uint32_t width_of(int layers, bool wired = false, bool rec = false) { return ((rec ? L_REC : wired ? L_WIRED : L) + (uint32_t)layers + 3u) & ~3u; }
 inline uint32_t n_public_of(int layers, bool transcript = false) { return transcript ? N_PUBLIC_T : 4u * (uint32_t)layers + 4u; }   // betas, final value -- or final value, capacity
 
 namespace {
@@ -86,9 +92,11 @@ struct Builder {
 // c_l = w_{2^(l+1)} canonical: the factor bit l of a query index contributes to its evaluation point
 inline uint32_t root_const(int l) { return from_monty(two_adic_generator(l + 1)); }
 
-std::vector<uint32_t> build_program(int RL, bool wired, bool transcript = false) {
-    const uint32_t L = wired ? L_WIRED : frichip::L;       // first layer-selector column of this form
-    const uint32_t W = width_of(RL, wired), NP = n_public_of(RL, transcript), END = L + (uint32_t)RL - 1u;
+// rec_public >= 0: the shard verifier's form, a program with that many public values (none of them its own)
+std::vector<uint32_t> build_program(int RL, bool wired, bool transcript = false, int rec_public = -1) {
+    const bool rec = rec_public >= 0;
+    const uint32_t L = rec ? L_REC : wired ? L_WIRED : frichip::L;       // first layer-selector column of this form
+    const uint32_t W = width_of(RL, wired, rec), NP = rec ? (uint32_t)rec_public : n_public_of(RL, transcript), END = L + (uint32_t)RL - 1u;
     const uint32_t inv2 = (P + 1) / 2;
     Builder b;
     // G * t for the gate G = ACTIVE - END ("an active row that is not the last of its query").  A selector counts one degree, so a
@@ -149,22 +157,23 @@ std::vector<uint32_t> build_program(int RL, bool wired, bool transcript = false)
     b.add(TRANSITION, Terms{{1u, {var(L), var(X)}}, {P - 1, {var(L), var(B, true)}}});                             // first layer: X = product over the higher bits
     for (uint32_t j = 0; j < 4; j++)        // the folded value is the next layer's own entry
         b.add(TRANSITION, gated(Terms{{1u, {var(FOLD + j)}}, {P - 1, {var(OWN + j, true)}}}));
-    for (uint32_t j = 0; j < 4; j++) b.add(ALL, Terms{{1u, {var(END), var(FOLD + j)}}, {P - 1, {var(END), pub((transcript ? 0u : 4u * (uint32_t)RL) + j)}}});
+    if (!rec) for (uint32_t j = 0; j < 4; j++) b.add(ALL, Terms{{1u, {var(END), var(FOLD + j)}}, {P - 1, {var(END), pub((transcript ? 0u : 4u * (uint32_t)RL) + j)}}});
     if (wired) {
         b.add(ALL, Terms{{1u, {var(K2)}}, {P - 2, {var(K)}}});
         b.add(ALL, Terms{{1u, {var(IDX)}}, {P - 1, {var(K2)}}, {P - 1, {var(BIT)}}});
     }
+    if (rec) b.add(ALL, Terms{{1u, {var(XS)}}, {P - 1, {var(X)}}, {2u, {var(X), var(BIT)}}});
     std::vector<uint32_t> p{AIR_MAGIC, 1u, W, b.count, NP, (uint32_t)(6 + b.body.size())};
     p.insert(p.end(), b.body.begin(), b.body.end());
     return p;
 }
-std::shared_ptr<const std::vector<uint32_t>> program(int RL, bool wired = false, bool transcript = false) {
+std::shared_ptr<const std::vector<uint32_t>> program(int RL, bool wired = false, bool transcript = false, int rec_public = -1) {
     static std::mutex mu;
     static std::map<int, std::shared_ptr<const std::vector<uint32_t>>> cache;
     std::lock_guard<std::mutex> lk(mu);
-    const int key = 4 * RL + (wired ? 1 : 0) + (transcript ? 2 : 0);
+    const int key = 4 * RL + (wired ? 1 : 0) + (transcript ? 2 : 0) + 1024 * (rec_public + 1);
     auto it = cache.find(key);
-    if (it == cache.end()) it = cache.emplace(key, std::make_shared<const std::vector<uint32_t>>(build_program(RL, wired, transcript))).first;
+    if (it == cache.end()) it = cache.emplace(key, std::make_shared<const std::vector<uint32_t>>(build_program(RL, wired, transcript, rec_public))).first;
     return it->second;
 }
 // a table whose contents are fixed by the KEY: combined row [pre | 4 main columns], one harmless first-row identity on the last main column
@@ -288,11 +297,11 @@ const std::vector<uint32_t>& samples_interactions() {
 inline size_t sample_rows(size_t nq) { return (1 + nq + 7) / 8; }
 // every word = sum of its 31 bits, in canonical form (P = 2^31 - 2^27 + 1: bits 27..30 all set -> bits 0..26 clear); IDX = the low layers + 1 bits;
 // the proof-of-work word's low pow_bits bits are zero
-std::shared_ptr<const std::vector<uint32_t>> samples_program(int RL, int pow_bits) {
+std::shared_ptr<const std::vector<uint32_t>> samples_program(int RL, int pow_bits, uint32_t n_public = N_PUBLIC_T) {
     static std::mutex mu;
-    static std::map<uint32_t, std::shared_ptr<const std::vector<uint32_t>>> cache;
+    static std::map<uint64_t, std::shared_ptr<const std::vector<uint32_t>>> cache;
     std::lock_guard<std::mutex> lk(mu);
-    const uint32_t key = ((uint32_t)RL << 8) | (uint32_t)pow_bits;
+    const uint64_t key = ((uint64_t)n_public << 32) | ((uint32_t)RL << 8) | (uint32_t)pow_bits;
     auto it = cache.find(key);
     if (it != cache.end()) return it->second;
     Builder b;
@@ -318,16 +327,16 @@ std::shared_ptr<const std::vector<uint32_t>> samples_program(int RL, int pow_bit
         for (uint32_t i = 0; i < (uint32_t)pow_bits; i++) c.push_back(Term{1u, {var(S_POW), var(M0 + S_BITS + i)}});
         b.add(ALL, c);
     }
-    std::vector<uint32_t> p{AIR_MAGIC, 1u, S_PRE + S_MAIN, b.count, N_PUBLIC_T, (uint32_t)(6 + b.body.size())};
+    std::vector<uint32_t> p{AIR_MAGIC, 1u, S_PRE + S_MAIN, b.count, n_public, (uint32_t)(6 + b.body.size())};
     p.insert(p.end(), b.body.begin(), b.body.end());
     return cache.emplace(key, std::make_shared<const std::vector<uint32_t>>(std::move(p))).first->second;
 }
 // the chip's preprocessed rows (Montgomery): fixed by the shape alone
-void samples_pre(int RL, size_t nq, int log_rows, std::vector<uint32_t>& t) {
+void samples_pre(int RL, size_t nq, int log_rows, std::vector<uint32_t>& t, int base = -1) {      // base: the number of the first query-phase sponge row (default: RL)
     t.assign(((size_t)S_PRE) << log_rows, 0u);
     for (size_t r = 0; r < sample_rows(nq); r++) {
         uint32_t* row = t.data() + S_PRE * r;
-        row[S_C] = to_monty((uint32_t)RL + (uint32_t)r); row[S_ROW] = MONTY_R1;
+        row[S_C] = to_monty((uint32_t)(base < 0 ? RL : base) + (uint32_t)r); row[S_ROW] = MONTY_R1;
         for (uint32_t j = 0; j < 8; j++) {
             const size_t slot = 8 * r + j;
             if (slot == 0) row[S_POW] = MONTY_R1;
@@ -365,7 +374,7 @@ struct TraceArgs {
 // the padding rows: zeros with T = 1
 __device__ __forceinline__ void fri_trace_kernel_body(const TraceArgs& a) {
     const uint32_t q = blockIdx.x * blockDim.x + threadIdx.x;
-    const uint32_t RL = a.layers, W = a.width, L = a.wired ? L_WIRED : frichip::L;
+    const uint32_t RL = a.layers, W = a.width, L = a.wired == 2u ? L_REC : a.wired ? L_WIRED : frichip::L;
     const uint64_t used = (uint64_t)a.n_queries * RL;
     if (q >= a.n_queries) {
         for (uint64_t r = used + (q - a.n_queries); r < a.rows; r += (uint64_t)gridDim.x * blockDim.x - a.n_queries) {
@@ -403,6 +412,7 @@ __device__ __forceinline__ void fri_trace_kernel_body(const TraceArgs& a) {
         if (l + 1 < RL) { row[G] = MONTY_R1; row[GS] = row[S]; row[GT] = tcol[l]; }
         for (int i = 0; i < 4; i++) row[OWN + i] = own.c[i];
         if (a.wired) { row[K2] = to_monty(2u * k); row[IDX] = to_monty(2u * k + bit); }
+        if (a.wired == 2u) row[XS] = bit ? fsub(0u, x) : x;
         own = fold;
         idx = k;
     }
@@ -518,11 +528,11 @@ size_t zkhip_fri_chip_air(int layers, uint32_t* program, size_t cap_words) {
 
 }  // extern "C"
 static int fri_gen_trace(zkhip_ctx* ctx, int layers, size_t n_queries, const uint32_t* betas, const uint32_t* indices, const uint32_t* values,
-                         const uint32_t* siblings, int log_rows, uint32_t* d_trace, size_t ld, uint32_t* finals, bool wired) {
+                         const uint32_t* siblings, int log_rows, uint32_t* d_trace, size_t ld, uint32_t* finals, bool wired, bool rec = false) {
     CHECK_CTX(ctx);
     int need;
     ZK_TRY(frichip::shape_ok(layers, n_queries, &need));
-    const uint32_t W = frichip::width_of(layers, wired);
+    const uint32_t W = frichip::width_of(layers, wired, rec);
     if (!betas || !indices || !values || !siblings || !d_trace || !finals || ld < W || log_rows < need || log_rows > MAX_LOG_ROWS)
         return fail(ZKHIP_ERR_INVALID, "fri_chip_gen_trace: bad arguments");
     const size_t nb = 4 * (size_t)layers, nv = 4 * n_queries, ns = nv * (size_t)layers;
@@ -541,7 +551,7 @@ static int fri_gen_trace(zkhip_ctx* ctx, int layers, size_t n_queries, const uin
     }
     frichip::TraceArgs a{};
     a.betas = d; a.indices = d + nb; a.values = d + nb + n_queries; a.siblings = d + nb + n_queries + nv;
-    a.n_queries = (uint32_t)n_queries; a.layers = (uint32_t)layers; a.width = W; a.log_h = (uint32_t)layers + 1u; a.wired = wired ? 1u : 0u;
+    a.n_queries = (uint32_t)n_queries; a.layers = (uint32_t)layers; a.width = W; a.log_h = (uint32_t)layers + 1u; a.wired = rec ? 2u : wired ? 1u : 0u;
     a.rows = (uint64_t)1 << log_rows; a.trace = d_trace; a.ld = ld; a.finals = d + nb + n_queries + nv + ns;
     const size_t pad = a.rows - n_queries * (size_t)layers;
     const size_t threads = n_queries + (pad < 4096 ? pad : 4096);            // the padding rows are shared among up to 4096 extra threads
@@ -639,7 +649,9 @@ namespace p2chip {
 std::shared_ptr<const std::vector<uint32_t>> program_fri_layers(uint32_t n_public);
 std::shared_ptr<const std::vector<uint32_t>> program_fri_transcript(uint32_t n_public, uint32_t cap_pub);
 std::shared_ptr<const std::vector<uint32_t>> program_fri_indices(uint32_t n_public, uint32_t cap_pub, uint32_t final_pub);
+std::vector<uint32_t> permutation_body(uint32_t col_offset, uint32_t* count);      // (shard_verifier.inl: the permutation's constraints behind preprocessed columns)
 }
+extern std::atomic<uint64_t> g_p2_generation;      // params.cpp
 namespace frichip {
 namespace {
 struct WiredMachine {
@@ -1098,3 +1110,5 @@ int zkhip_prove_fri_indices_batch(const int* devices, int n_devices, zkhip_fri_j
 }
 
 }  // extern "C"
+
+#include "shard_verifier.inl"

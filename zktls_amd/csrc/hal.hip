@@ -129,12 +129,20 @@ __global__ void __launch_bounds__(256) hal_mix_poly_coeffs_kernel(uint32_t* __re
 #pragma unroll
     for (int c = 0; c < MIX_REGS; c++) acc[c] = ext_zero();
     uint32_t touched = 0;
-    for (uint64_t i = 0; i < input_size; i++) {
+    constexpr int AHEAD = 8;                                    // input words in flight per lane: the loop is latency-bound otherwise
+    uint32_t vin[AHEAD];
+    for (uint64_t i0 = 0; i0 < input_size; i0 += AHEAD) {
+#pragma unroll
+      for (int u = 0; u < AHEAD; u++) vin[u] = i0 + u < input_size ? __builtin_nontemporal_load(in + (i0 + u) * count + idx) : 0u;
+#pragma unroll
+      for (int u = 0; u < AHEAD; u++) {
+        const uint64_t i = i0 + u;
+        if (i >= input_size) break;
         const uint32_t combo = __builtin_amdgcn_readfirstlane(combos[i]);
         const uint4 pv = *reinterpret_cast<const uint4*>(powers + 4 * i);          // uniform address: scalar loads
         const Ext cur{{(uint32_t)__builtin_amdgcn_readfirstlane(pv.x), (uint32_t)__builtin_amdgcn_readfirstlane(pv.y),
                        (uint32_t)__builtin_amdgcn_readfirstlane(pv.z), (uint32_t)__builtin_amdgcn_readfirstlane(pv.w)}};
-        const Ext term = ext_mul_base_dev(cur, __builtin_nontemporal_load(in + i * count + idx));
+        const Ext term = ext_mul_base_dev(cur, vin[u]);
         if (combo < (uint32_t)MIX_REGS) {
             touched |= 1u << combo;
             switch (combo) {                                   // wave-uniform: one scalar branch, statically indexed registers
@@ -151,31 +159,34 @@ __global__ void __launch_bounds__(256) hal_mix_poly_coeffs_kernel(uint32_t* __re
             uint32_t* o = out + 4 * ((uint64_t)combo * count + idx);
             st_ext(o, ext_add_d(ld_ext(o), term));
         }
+      }
     }
 #pragma unroll
     for (int c = 0; c < MIX_REGS; c++)
         if (touched & (1u << c)) { uint32_t* o = out + 4 * ((uint64_t)c * count + idx); st_ext(o, ext_add_d(ld_ext(o), acc[c])); }
 }
-// out[e] = polynomial which[e] at xs[e]: one workgroup per evaluation.  Lane t takes the coefficients i = t mod 256 (a wave reads 256
-// consecutive bytes per step): Horner in y = x^256 over c[t], c[t + 256], ..., from the top; the partial value is scaled by x^t and
-// the 256 partial values are summed in LDS.
+// out[e] = polynomial which[e] at xs[e]: one workgroup of 1024 lanes per evaluation (the Horner chains are sequential: sixteen waves
+// per evaluation keep the SIMDs of a CU fed).  Lane t takes the coefficients i = t mod 1024 (a wave reads 256 consecutive bytes per
+// step): Horner in y = x^1024 over c[t], c[t + 1024], ..., from the top; the partial value is scaled by x^t and the partial values
+// are summed in LDS.
+constexpr uint32_t EVAL_T = 1024, EVAL_LOG_T = 10;
 template <uint32_t W>
-__global__ void __launch_bounds__(256) hal_batch_evaluate_any_kernel(const uint32_t* __restrict__ coeffs, int log_size, const uint32_t* __restrict__ which,
-                                                                     const uint32_t* __restrict__ xs, uint32_t* __restrict__ out) {
-    __shared__ uint32_t part[256][4];
+__global__ void __launch_bounds__(EVAL_T) hal_batch_evaluate_any_kernel(const uint32_t* __restrict__ coeffs, int log_size, const uint32_t* __restrict__ which,
+                                                                        const uint32_t* __restrict__ xs, uint32_t* __restrict__ out) {
+    __shared__ uint32_t part[EVAL_T][4];
     const uint64_t n = (uint64_t)1 << log_size;
     const uint32_t e = blockIdx.x, t = threadIdx.x;
     const uint32_t* c = coeffs + (uint64_t)which[e] * n;
     const Ext x = ld_ext(xs + 4 * (uint64_t)e);
     Ext acc = ext_zero();
     if (t < n) {
-        Ext y = x;                                             // x^256
-        for (int k = 0; k < 8; k++) y = ext_mul_t<W>(y, y);
-        const uint64_t top = t + ((n - 1 - t) / 256) * 256;    // the largest i = t mod 256 below n
-        for (uint64_t i = top;; i -= 256) {
+        Ext y = x;                                             // x^1024
+        for (uint32_t k = 0; k < EVAL_LOG_T; k++) y = ext_mul_t<W>(y, y);
+        const uint64_t top = t + ((n - 1 - t) / EVAL_T) * EVAL_T;    // the largest i = t mod 1024 below n
+        for (uint64_t i = top;; i -= EVAL_T) {
             acc = ext_mul_t<W>(acc, y);
-            acc.c[0] = dadd(acc.c[0], c[i]);
-            if (i < 256) break;
+            acc.c[0] = dadd(acc.c[0], __builtin_nontemporal_load(c + i));
+            if (i < EVAL_T) break;
         }
         Ext pw = ext_one(), b = x;                             // x^t by square and multiply
         for (uint32_t k = t; k; k >>= 1) { if (k & 1) pw = ext_mul_t<W>(pw, b); b = ext_mul_t<W>(b, b); }
@@ -183,7 +194,7 @@ __global__ void __launch_bounds__(256) hal_batch_evaluate_any_kernel(const uint3
     }
     for (int k = 0; k < 4; k++) part[t][k] = acc.c[k];
     __syncthreads();
-    for (int s = 128; s > 0; s >>= 1) {
+    for (int s = EVAL_T / 2; s > 0; s >>= 1) {
         if ((int)t < s) for (int k = 0; k < 4; k++) part[t][k] = dadd(part[t][k], part[t + s][k]);
         __syncthreads();
     }
@@ -430,8 +441,8 @@ int zkhip_batch_evaluate_any(zkhip_ctx* ctx, const uint32_t* d_coeffs, int log_s
     if (!d_coeffs || !d_which || !d_xs || !d_out || log_size < 0 || log_size > 30 || !ext_field_ok(ext_field) || (reinterpret_cast<uintptr_t>(d_xs) & 15))
         return fail(ZKHIP_ERR_INVALID, "batch_evaluate_any: bad arguments");
     if (!eval_count) return ZKHIP_OK;
-    if (ext_field == ZKHIP_EXT_X4_PLUS_11) hipLaunchKernelGGL((hal_batch_evaluate_any_kernel<MONTY_W_R0>), dim3((unsigned)eval_count), dim3(256), 0, ctx->stream, d_coeffs, log_size, d_which, d_xs, d_out);
-    else hipLaunchKernelGGL((hal_batch_evaluate_any_kernel<MONTY_W_SP1>), dim3((unsigned)eval_count), dim3(256), 0, ctx->stream, d_coeffs, log_size, d_which, d_xs, d_out);
+    if (ext_field == ZKHIP_EXT_X4_PLUS_11) hipLaunchKernelGGL((hal_batch_evaluate_any_kernel<MONTY_W_R0>), dim3((unsigned)eval_count), dim3(EVAL_T), 0, ctx->stream, d_coeffs, log_size, d_which, d_xs, d_out);
+    else hipLaunchKernelGGL((hal_batch_evaluate_any_kernel<MONTY_W_SP1>), dim3((unsigned)eval_count), dim3(EVAL_T), 0, ctx->stream, d_coeffs, log_size, d_which, d_xs, d_out);
     LAUNCHED();
     return ZKHIP_OK;
 }

@@ -688,6 +688,51 @@ __global__ void __launch_bounds__(64) p2chip_layer_paths_kernel(p2chip::LayerPat
 struct p2chip_layer_paths_kernel_bargs { p2chip::LayerPathsArgs a; static p2chip_layer_paths_kernel_bargs make(p2chip::LayerPathsArgs a) { return p2chip_layer_paths_kernel_bargs{a}; } };
 __global__ void __launch_bounds__(64) p2chip_layer_paths_kernel_batch(const p2chip_layer_paths_kernel_bargs* __restrict__ zk_arr) { const p2chip_layer_paths_kernel_bargs& zk_b = zk_arr[blockIdx.z]; p2chip_layer_paths_kernel_body(zk_b.a); }
 
+// the shard verifier's chip (p2chip.h, P2RArgs): one lane per chain, one per transcript row, the rest share the padding rows
+__device__ __forceinline__ void p2r_rows_kernel_body(const p2chip::P2RArgs& a) {
+    using namespace p2chip;
+    const uint64_t p = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    uint32_t in[16], out[16];
+    if (p < a.n_chains) {
+        const uint32_t* d = a.desc + 6 * p;
+        uint32_t* t = a.trace + (uint64_t)d[0] * a.ld;
+        const uint32_t blocks = d[1], depth = d[3], index = d[4];
+        const uint32_t *vals = a.data + d[2], *sib = a.data + d[5];
+        for (int j = 0; j < 16; j++) out[j] = 0u;
+        for (uint32_t k = 0; k < blocks; k++, t += a.ld) {
+            for (int j = 0; j < 8; j++) { in[j] = to_monty(vals[8 * k + j]); in[8 + j] = out[8 + j]; }
+            p2chip_fill_row(t, in, 0u, 0u, 0u, 0u, 0u, 0u, out);
+            t[R_KP] = k + 1 == blocks ? to_monty(2u * index) : 0u;
+        }
+        for (uint32_t lvl = 0; lvl < depth; lvl++, t += a.ld) {
+            const uint32_t bit = (index >> lvl) & 1u;
+            for (int j = 0; j < 8; j++) { in[bit ? 8 + j : j] = out[j]; in[bit ? j : 8 + j] = to_monty(sib[8 * lvl + j]); }
+            p2chip_fill_row(t, in, bit, 0u, 0u, 0u, 0u, 0u, out);
+            t[R_KP] = to_monty(index >> lvl);
+        }
+        for (int j = 0; j < 8; j++) a.roots[8 * p + j] = from_monty(out[j]);
+        return;
+    }
+    const uint64_t r = p - a.n_chains;
+    if (r < a.n_transcript) {
+        for (int j = 0; j < 16; j++) in[j] = to_monty(a.chain_inputs[16 * r + j]);
+        p2chip_fill_row(a.trace + r * a.ld, in, 0u, 0u, 0u, 0u, 0u, 0u, out);
+        return;
+    }
+    const uint64_t row = a.used_rows + (r - a.n_transcript);
+    if (row >= a.rows) return;
+    for (int j = 0; j < 16; j++) in[j] = 0u;
+    p2chip_fill_row(a.trace + row * a.ld, in, 0u, 0u, 0u, 0u, 0u, 0u, out);
+}
+__global__ void __launch_bounds__(64) p2r_rows_kernel(p2chip::P2RArgs a) { p2r_rows_kernel_body(a); }
+struct p2r_rows_kernel_bargs { p2chip::P2RArgs a; static p2r_rows_kernel_bargs make(p2chip::P2RArgs a) { return p2r_rows_kernel_bargs{a}; } };
+__global__ void __launch_bounds__(64) p2r_rows_kernel_batch(const p2r_rows_kernel_bargs* __restrict__ zk_arr) { const p2r_rows_kernel_bargs& zk_b = zk_arr[blockIdx.z]; p2r_rows_kernel_body(zk_b.a); }
+hipError_t launch_p2r_rows(const p2chip::P2RArgs& a, hipStream_t s) {
+    const uint64_t lanes = (uint64_t)a.n_chains + a.n_transcript + (a.rows - a.used_rows);
+    ZK_LAUNCH(p2r_rows_kernel, p2r_rows_kernel_batch, p2r_rows_kernel_bargs, dim3((unsigned)((lanes + 63) / 64)), dim3(64), 0, s, a);
+    return hipGetLastError();
+}
+
 hipError_t launch_p2chip_layer_paths(const p2chip::LayerPathsArgs& a, hipStream_t s) {
     const uint64_t lanes = a.n_paths + (a.rows - a.used_rows) + a.n_transcript + a.n_query_rows;
     ZK_LAUNCH(p2chip_layer_paths_kernel, p2chip_layer_paths_kernel_batch, p2chip_layer_paths_kernel_bargs, dim3((unsigned)((lanes + 63) / 64)), dim3(64), 0, s, a);

@@ -210,7 +210,7 @@ int deal_jobs_lockstep(const int* devices, int n_devices, int n_jobs, const int*
             if (cap < 2) cap = 2;
             while ((size_t)lanes * (size_t)max_batch > cap && max_batch > 2) max_batch = (max_batch + 1) / 2;
             while ((size_t)lanes * (size_t)max_batch > cap && lanes > 1) lanes--;
-            if (d == 0 || total_b / 8 < pool_budget) pool_budget = total_b / 8;
+            if (d == 0 || total_b / 4 < pool_budget) pool_budget = total_b / 4;
         }
     }
     std::mutex mu;
@@ -334,7 +334,7 @@ int deal_jobs_lockstep(const int* devices, int n_devices, int n_jobs, const int*
         }
     }
     for (auto& t : pool) t.join();
-    // what the call leaves in the pool: at most lanes x max_batch contexts per device and an eighth of the device's memory
+    // what the call leaves in the pool: at most lanes x max_batch contexts per device and a quarter of the device's memory
     for (int d = 0; d < n_devices; d++) pool_trim(devices[d], pool_budget, (size_t)lanes * (size_t)max_batch);
     if (first_rc != ZKHIP_OK) { set_error(first_msg); return first_rc; }
     for (int i = 0; i < n_jobs; i++)

@@ -53,6 +53,22 @@ struct LayerPathsArgs {
     const uint32_t* chain_inputs;   // [n_transcript + n_query_rows][16] canonical
 };
 
+// The shard verifier's chip (fri_chip.hip / shard_verifier.inl: P2R): the same 352 permutation columns (IN .. BIT), KP in column 352, nothing else
+// in the main trace (every flag is a PREPROCESSED column there).  Rows are filled by CHAINS: chain c starts at row desc[6 c], hashes
+// desc[6 c + 1] blocks of 8 words (data + desc[6 c + 2]) with the overwrite-mode sponge (KP = 2 index on the last of them), then walks
+// desc[6 c + 3] path levels with the leaf index desc[6 c + 4] and the siblings at data + desc[6 c + 5]; the first n_transcript rows are the
+// transcript's sponge rows, filled side by side from the input states the host walked.
+constexpr uint32_t R_KP = 352, R_WIDTH = 360;
+struct P2RArgs {
+    const uint32_t* desc;            // [n_chains][6]
+    const uint32_t* data;            // canonical words
+    const uint32_t* chain_inputs;    // [n_transcript][16] canonical
+    uint32_t n_chains, n_transcript;
+    uint64_t rows, used_rows;
+    uint32_t* trace; uint64_t ld;    // [rows][ld >= R_WIDTH], Montgomery
+    uint32_t* roots;                 // [n_chains][8] canonical: where every chain ends
+};
+
 // paths: path p = rows [p (row_width / 8 + depth), ...): row_width / 8 sponge rows over its opened row (none when row_width = 0: the
 // leaf digest is given), then depth compression rows; leaves / siblings / indices are canonical words already on the device
 struct MerkleTraceArgs {

@@ -69,7 +69,8 @@ Terms linear_def(uint32_t col, const Form& f) {
     return t;
 }
 
-std::vector<uint32_t> build_program(bool fri_layers = false, uint32_t n_public = N_PUBLIC, int transcript = -1, int queries = -1) {
+// the constraints that make a row ONE permutation out = poseidon2(in): columns IN .. SP, shared by every variant of the chip
+void permutation_part(Builder& b) {
     // the matrices and constants of the tables in effect, canonical
     uint32_t ME[16][16], rc_e[8][16], rc_i[13], diag[16];
     for (int j = 0; j < 16; j++) {
@@ -81,7 +82,6 @@ std::vector<uint32_t> build_program(bool fri_layers = false, uint32_t n_public =
     for (int r = 0; r < 8; r++) for (int i = 0; i < 16; i++) rc_e[r][i] = from_monty(g_p2_tables.k16.ext_rc[r][i]);
     for (int r = 0; r < 13; r++) rc_i[r] = from_monty(g_p2_tables.k16.int_rc[r]);
     for (int i = 0; i < 16; i++) diag[i] = from_monty(g_p2_tables.k16.diag[i]);
-    Builder b;
     for (uint32_t i = 0; i < 16; i++) {
         Form f;
         for (uint32_t j = 0; j < 16; j++) f[IN + j] = ME[i][j];
@@ -123,6 +123,11 @@ std::vector<uint32_t> build_program(bool fri_layers = false, uint32_t n_public =
     }
     for (uint32_t i = 0; i < 16; i++) b.add(ALL, linear_def(SP + i, lin[i]));
     for (uint32_t r = 4; r < 8; r++) external_round(r);
+}
+
+std::vector<uint32_t> build_program(bool fri_layers = false, uint32_t n_public = N_PUBLIC, int transcript = -1, int queries = -1) {
+    Builder b;
+    permutation_part(b);
     for (uint32_t j = 0; j < 8; j++)
         b.add(ALL, Terms{{1u, {var(D + j)}}, {P - 1, {var(IN + j)}}, {1u, {var(BIT), var(IN + j)}}, {P - 1, {var(BIT), var(IN + 8 + j)}}});
     for (uint32_t f : {BIT, CH, END, SPG, SS}) b.add(ALL, Terms{{1u, {var(f), var(f)}}, {P - 1, {var(f)}}});
@@ -197,6 +202,25 @@ std::shared_ptr<const std::vector<uint32_t>> program() {
 }
 
 }  // namespace
+// the permutation's constraints alone, as program body words with every column moved up by `col_offset` (the recursion machine's chip has
+// preprocessed columns in front, fri_chip.hip / shard_verifier.inl); *count = the number of constraints
+std::vector<uint32_t> permutation_body(uint32_t col_offset, uint32_t* count) {
+    Builder b;
+    permutation_part(b);
+    std::vector<uint32_t>& w = b.body;
+    size_t p = 0;
+    for (uint32_t k = 0; k < b.count; k++) {
+        const uint32_t nt = w[p + 1];
+        p += 2;
+        for (uint32_t t = 0; t < nt; t++) {
+            const uint32_t d = w[p + 1];
+            p += 2;
+            for (uint32_t j = 0; j < d; j++, p++) if ((w[p] >> 30) < 2u) w[p] += col_offset;
+        }
+    }
+    *count = b.count;
+    return w;
+}
 // the FRI-layers variant for a machine with n_public public values (fri_chip.hip); follows the Poseidon2 tables in effect like program()
 std::shared_ptr<const std::vector<uint32_t>> program_fri_layers(uint32_t n_public) {
     static std::mutex mu;

@@ -1,0 +1,989 @@
+// shard_verifier.inl -- included at the end of fri_chip.hip (it builds on that file's fold chip, SAMPLES chip and trace kernel).
+//
+// THE SHARD VERIFIER AS A MACHINE (second half).  The reference's one hot call is
+// `client.prove(&pk, &stdin, SP1ProofMode::Groth16)` (crates/guest-prover-sp1/src/sp1.rs:116): core -> COMPRESS -> shrink -> wrap, where
+// compress is a machine that verifies shard proofs (sp1-recursion, reference Cargo.lock:6172 ff.; RISC Zero: lift -> join behind
+// crates/guest-prover-r0/src/prover.rs:90).  The machines above this line check the FRI part of a shard proof and leave the rest to a
+// verifier that still reads the inner proof.  This one checks ALL of it in-circuit -- a version-1 shard proof of this library (the synthetic
+// AIR, SP1 shape: blowup 2, fold by 2, constant final value, Poseidon2 width 16):
+//     the transcript from the header words to the last query index (every challenge a sponge output), the AIR identity at zeta on the
+//     opened values, every Merkle opening of trace, quotient and FRI layers, the reduced openings, the folds, the proof of work.
+// Every structural fact -- which sponge row absorbs what, which path belongs to which query and tree, which words are constants of the
+// shape -- is a PREPROCESSED column.  The key therefore depends on the inner proof's SHAPE (log_n, width, queries, proof-of-work bits,
+// number of public values) and on nothing else, and zkhip_verify_shard_recursive is handed the key, the shape and the inner proof's
+// PUBLIC VALUES: no byte of the inner proof.
+//
+// Eight chips (tests/recursion_air.py writes the same programs, tables and traces independently; the words must be equal):
+//   P2R      one Poseidon2 permutation per row (p2chip.h, P2RArgs): the transcript's sponge rows, then per query the FRI layer paths, the
+//            trace opening (the opened row hashed by sponge rows, then its path) and the quotient opening.  24 preprocessed flag / tag columns.
+//   ROWSUM   one row per 8 values of an opened row: hands them to the P2R sponge rows, accumulates sum_j fa^j row[j] (Horner in fa).
+//   FOLD     the fold chip (above) in its `rec` form: sends its folded END value to the transcript table, its first rows (index, point, value).
+//   TS       the transcript as a table: one row per absorbing sponge row -- the observed words (header words fixed by the key, public values
+//            tied to the outer proof's, roots received from the paths' ends), the challenge sampled behind the row (handed to its users).
+//   QUERY    one row per query: index (from SAMPLES), point (from FOLD), the reduced opening
+//            (at - y_loc)/(x - zeta) + fa^W (at - y_nxt)/(x - zeta g) + fa^2W (aq - y_q)/(x - zeta).
+//   OPENED   one row per column group (a, b, c, d) of the synthetic AIR: the opened values at zeta and zeta g (from TS), their fa-weighted
+//            sums, the AIR's three constraints per group folded with alpha.
+//   SAMPLES  the SAMPLES chip (above): bits of the sampled words -- proof of work, query indices.
+//   SCALARS  the verifier's scalars in one row: zeta^N, selectors, powers of fa, the quotient recombination, and the identity
+//            fold(zeta) = quotient(zeta) Z_H(zeta).
+namespace zk {
+namespace rec {
+namespace {
+using frichip::Builder;
+using frichip::ALL; using frichip::FIRST; using frichip::LAST; using frichip::TRANSITION;
+
+// ---- polynomials over columns: a list of (coefficient, variables); an extension expression = four of them (x^4 = 11).  No merging of
+// like terms: the order in which terms are produced IS the program (tests/recursion_air.py produces them in the same order).
+struct PT { uint32_t c; std::vector<uint32_t> v; };
+typedef std::vector<PT> Poly;
+typedef std::array<Poly, 4> EE;
+inline uint32_t mulp(uint64_t a, uint64_t b) { return (uint32_t)((a % P) * (b % P) % P); }
+inline Poly pc(uint64_t c) { c %= P; return c ? Poly{PT{(uint32_t)c, {}}} : Poly{}; }
+inline Poly pv(uint32_t col, bool nxt = false) { return Poly{PT{1u, {nxt ? ((1u << 30) | col) : col}}}; }
+inline Poly ppub(uint32_t i) { return Poly{PT{1u, {(2u << 30) | i}}}; }
+inline Poly padd(const Poly& a, const Poly& b) { Poly o = a; o.insert(o.end(), b.begin(), b.end()); return o; }
+inline Poly pscale(const Poly& a, uint64_t k) { Poly o; for (const PT& t : a) { const uint32_t c = mulp(t.c, k); if (c) o.push_back(PT{c, t.v}); } return o; }
+inline Poly pneg(const Poly& a) { return pscale(a, P - 1); }
+inline Poly pmul(const Poly& a, const Poly& b) {
+    Poly o;
+    for (const PT& x : a) for (const PT& y : b) { const uint32_t c = mulp(x.c, y.c); if (!c) continue; PT t{c, x.v}; t.v.insert(t.v.end(), y.v.begin(), y.v.end()); o.push_back(t); }
+    return o;
+}
+inline EE ev(uint32_t col, bool nxt = false) { return EE{pv(col, nxt), pv(col + 1, nxt), pv(col + 2, nxt), pv(col + 3, nxt)}; }
+inline EE ec(uint64_t c0, uint64_t c1 = 0, uint64_t c2 = 0, uint64_t c3 = 0) { return EE{pc(c0), pc(c1), pc(c2), pc(c3)}; }
+inline EE eb(const Poly& p) { return EE{p, Poly{}, Poly{}, Poly{}}; }
+inline EE eadd(const EE& a, const EE& b) { return EE{padd(a[0], b[0]), padd(a[1], b[1]), padd(a[2], b[2]), padd(a[3], b[3])}; }
+inline EE eadd(const EE& a, const EE& b, const EE& c) { return eadd(eadd(a, b), c); }
+inline EE esub(const EE& a, const EE& b) { return EE{padd(a[0], pneg(b[0])), padd(a[1], pneg(b[1])), padd(a[2], pneg(b[2])), padd(a[3], pneg(b[3]))}; }
+inline EE escale(const EE& a, uint64_t k) { return EE{pscale(a[0], k), pscale(a[1], k), pscale(a[2], k), pscale(a[3], k)}; }
+inline EE emul(const EE& a, const EE& b) {
+    EE o;
+    for (int j = 0; j < 4; j++)
+        for (int i = 0; i < 4; i++)
+            for (int k = 0; k < 4; k++) {
+                if ((i + k) % 4 != j) continue;
+                Poly t = pmul(a[i], b[k]);
+                if (i + k >= 4) t = pscale(t, EXT_W);
+                o[j].insert(o[j].end(), t.begin(), t.end());
+            }
+    return o;
+}
+inline EE egate(const Poly& f, const EE& e) { return EE{pmul(f, e[0]), pmul(f, e[1]), pmul(f, e[2]), pmul(f, e[3])}; }
+struct Cons {
+    Builder b;
+    void add(uint32_t sel, const Poly& p) {
+        frichip::Terms ts;
+        for (const PT& t : p) ts.push_back(frichip::Term{t.c, t.v});
+        b.add(sel, ts);
+    }
+    void ext(uint32_t sel, const EE& e) { for (int i = 0; i < 4; i++) add(sel, e[i]); }
+    std::vector<uint32_t> program(uint32_t width, uint32_t n_public) const {
+        std::vector<uint32_t> p{AIR_MAGIC, 1u, width, b.count, n_public, (uint32_t)(6 + b.body.size())};
+        p.insert(p.end(), b.body.begin(), b.body.end());
+        return p;
+    }
+};
+inline uint32_t rup4(uint32_t n) { return (n + 3u) & ~3u; }
+inline int lg(size_t n, int lo = 5) { int l = lo; while (((size_t)1 << l) < n) l++; return l; }
+
+// ---- buses (BUS_E0 / E1 / R0 / R1 / Q / S0 / S1 / I keep their meaning from the machines above)
+constexpr uint32_t BUS_IN0 = 61, BUS_IN1 = 62, BUS_TC = 63, BUS_BETA = 64, BUS_SC = 65, BUS_QI = 66, BUS_AT = 67, BUS_AQ = 68;
+constexpr uint32_t BUS_K0 = 70, BUS_K1 = 71, BUS_K2 = 72, BUS_K3 = 73, BUS_KFA = 74, BUS_KO0 = 75, BUS_KO1 = 76, BUS_KO2 = 77, BUS_OY = 78, BUS_OA = 79;
+using frichip::BUS_FIN; using frichip::BUS_E0; using frichip::BUS_E1; using frichip::BUS_R0; using frichip::BUS_R1; using frichip::BUS_Q;
+using frichip::BUS_S0; using frichip::BUS_S1; using frichip::BUS_I;
+
+// ---- the shape of an inner proof: everything the machine's structure depends on
+struct Shape {
+    int n, W, Q, PB, NPUB, R, H, G, WB;
+    uint32_t head[6];
+    int f0, r0, TA, TQ, TO0, TF, TL0, TP, NS, NT, NTS;
+    std::vector<int> pub_rows;
+    size_t fri_rows, p2_fri0, p2_tr0, p2_q0, p2_rows;
+    int tag0;
+    uint32_t row_tag(int q, int b) const { return (uint32_t)(tag0 + q * (WB + 1) + b); }
+    int absorbed(int T) const {
+        if (T < f0 || (TQ <= T && T < TP)) return 8;
+        if (T == f0 && r0) return r0;
+        if (T == TP) return 5;
+        return 0;
+    }
+    bool has_challenge(int T) const { return T == TA || T == TQ || T == TF || (TL0 <= T && T < TP); }
+};
+int make_shape(int log_n, uint32_t width, size_t n_queries, int pow_bits, size_t n_public, Shape& s) {
+    if (log_n < frichip::MIN_LAYERS || log_n > 20 || width < 8 || width > 1024 || width % 8 || n_queries < 1 || n_queries > 1024 || pow_bits < 0 || pow_bits > 30 || n_public > 64)
+        return fail(ZKHIP_ERR_INVALID, "shard verifier: 2^2 .. 2^20 rows, a width of 8 .. 1024 in multiples of 8, 1 .. 1024 queries, 0 .. 30 proof-of-work bits, at most 64 public values");
+    s.n = log_n; s.W = (int)width; s.Q = (int)n_queries; s.PB = pow_bits; s.NPUB = (int)n_public;
+    s.R = log_n; s.H = log_n + 1; s.G = s.W / 4; s.WB = s.W / 8;
+    const uint32_t head[6] = {(uint32_t)log_n, width, 1u, (uint32_t)n_queries, (uint32_t)pow_bits, (uint32_t)n_public};
+    std::memcpy(s.head, head, sizeof head);
+    const int n0 = 6 + 8 + s.NPUB;
+    s.f0 = n0 / 8; s.r0 = n0 % 8;
+    s.TA = s.r0 ? s.f0 : s.f0 - 1; s.TQ = s.TA + 1; s.TO0 = s.TQ + 1; s.TF = s.TO0 + s.W + 3; s.TL0 = s.TF + 1; s.TP = s.TL0 + s.R;
+    s.NS = (int)frichip::sample_rows(n_queries); s.NT = s.TP + s.NS; s.NTS = s.TP + 1;
+    s.pub_rows.clear();
+    for (int i = 0; i < s.NPUB; i++) { const int r = (14 + i) / 8; if (s.pub_rows.empty() || s.pub_rows.back() != r) s.pub_rows.push_back(r); }
+    s.fri_rows = (size_t)s.R + (size_t)s.R * (size_t)(s.R + 1) / 2;
+    s.p2_fri0 = (size_t)s.NT; s.p2_tr0 = s.p2_fri0 + (size_t)s.Q * s.fri_rows; s.p2_q0 = s.p2_tr0 + (size_t)s.Q * (size_t)(s.WB + s.H);
+    s.p2_rows = s.p2_q0 + (size_t)s.Q * (size_t)(1 + s.H);
+    s.tag0 = s.NT;
+    if (lg(s.p2_rows) > MAX_LOG_ROWS) return fail(ZKHIP_ERR_INVALID, "shard verifier: the Poseidon2 chip would need more than 2^22 rows");
+    return ZKHIP_OK;
+}
+
+// ============================================================================================================ P2R
+constexpr uint32_t P2_PRE = 24, P2_MAIN = p2chip::R_WIDTH;
+constexpr uint32_t PP_SS = 0, PP_SPG = 1, PP_CH = 2, PP_END = 3, PP_K = 4, PP_RIN = 12, PP_TAG = 13, PP_SROOT = 14, PP_TREE = 15, PP_SCH = 16, PP_SSMP = 17, PP_QIDX = 18,
+                   PP_QN = 19, PP_RPAIR = 20;
+std::vector<uint32_t> p2r_program(const Shape& sh) {
+    using namespace p2chip;
+    const uint32_t M0 = P2_PRE, IN_ = M0 + IN, OUT = M0 + oute(7), D_ = M0 + D, BIT_ = M0 + BIT, KP_ = M0 + R_KP;
+    Cons c;
+    c.b.body = permutation_body(M0, &c.b.count);
+    for (uint32_t j = 0; j < 8; j++) c.add(ALL, padd(padd(pv(D_ + j), pneg(pv(IN_ + j))), padd(pmul(pv(BIT_), pv(IN_ + j)), pneg(pmul(pv(BIT_), pv(IN_ + 8 + j))))));
+    c.add(ALL, padd(pmul(pv(BIT_), pv(BIT_)), pneg(pv(BIT_))));
+    c.add(ALL, pmul(padd(pv(PP_SS), pv(PP_SPG)), pv(BIT_)));
+    for (uint32_t j = 0; j < 8; j++) c.add(ALL, pmul(pv(PP_SS), pv(IN_ + 8 + j)));
+    for (uint32_t j = 0; j < 8; j++) c.add(TRANSITION, pmul(pv(PP_SPG, true), padd(pv(IN_ + 8 + j, true), pneg(pv(OUT + 8 + j)))));
+    for (uint32_t j = 0; j < 8; j++) c.add(TRANSITION, pmul(pv(PP_CH, true), padd(pv(D_ + j, true), pneg(pv(OUT + j)))));
+    for (uint32_t j = 0; j < 8; j++) c.add(TRANSITION, pmul(pv(PP_K + j, true), padd(pv(IN_ + j, true), pneg(pv(OUT + j)))));
+    c.add(TRANSITION, pmul(pv(PP_CH, true), padd(padd(pv(KP_), pscale(pv(KP_, true), P - 2)), pneg(pv(BIT_)))));
+    c.add(ALL, pmul(pv(PP_END), padd(pv(KP_), pneg(pv(BIT_)))));
+    return c.program(P2_PRE + P2_MAIN, (uint32_t)sh.NPUB);
+}
+// interaction tables: {sign, multiplicity column, bus, n, columns...}
+struct Tab {
+    std::vector<uint32_t> w{LOOKUP_MAGIC, 0u, 0u};
+    void add(uint32_t sign, uint32_t mult, uint32_t bus, std::initializer_list<uint32_t> cols) {
+        w.push_back(sign); w.push_back(mult); w.push_back(bus); w.push_back((uint32_t)cols.size());
+        for (uint32_t c : cols) w.push_back(c);
+        w[1]++; w[2] = (uint32_t)w.size();
+    }
+    void add8(uint32_t sign, uint32_t mult, uint32_t bus, uint32_t a, uint32_t b) { add(sign, mult, bus, {a, a + 1, a + 2, a + 3, b, b + 1, b + 2, b + 3}); }
+    void add4(uint32_t sign, uint32_t mult, uint32_t bus, uint32_t a) { add(sign, mult, bus, {a, a + 1, a + 2, a + 3}); }
+    void add5(uint32_t sign, uint32_t mult, uint32_t bus, uint32_t key, uint32_t a) { add(sign, mult, bus, {key, a, a + 1, a + 2, a + 3}); }
+};
+constexpr uint32_t SEND = 0, RECV = 1;
+std::vector<uint32_t> p2r_table() {
+    using namespace p2chip;
+    const uint32_t M0 = P2_PRE, o = M0 + oute(7), IN_ = M0 + IN, KP_ = M0 + R_KP;
+    Tab t;
+    t.add5(RECV, PP_RIN, BUS_IN0, PP_TAG, IN_); t.add5(RECV, PP_RIN, BUS_IN1, PP_TAG, IN_ + 4);
+    t.add(RECV, PP_RPAIR, BUS_E0, {PP_TREE, KP_, IN_, IN_ + 1, IN_ + 2, IN_ + 3}); t.add(RECV, PP_RPAIR, BUS_E1, {PP_TREE, KP_, IN_ + 4, IN_ + 5, IN_ + 6, IN_ + 7});
+    t.add5(SEND, PP_SROOT, BUS_R0, PP_TREE, o); t.add5(SEND, PP_SROOT, BUS_R1, PP_TREE, o + 4);
+    t.add(SEND, PP_SCH, BUS_TC, {PP_TAG, o + 7, o + 6, o + 5, o + 4});
+    t.add(SEND, PP_SSMP, BUS_S0, {PP_TAG, o + 7, o + 6, o + 5, o + 4}); t.add(SEND, PP_SSMP, BUS_S1, {PP_TAG, o + 3, o + 2, o + 1, o});
+    t.add(RECV, PP_QIDX, BUS_QI, {PP_QN, KP_});
+    return t.w;
+}
+// preprocessed traces are built canonical and turned into Montgomery form in one pass (monty_all)
+void monty_all(std::vector<uint32_t>& t) { for (uint32_t& v : t) v = to_monty(v); }
+void p2r_pre(const Shape& sh, int log_rows, std::vector<uint32_t>& t) {
+    t.assign((size_t)P2_PRE << log_rows, 0u);
+    auto row = [&](size_t r) { return t.data() + (size_t)P2_PRE * r; };
+    for (int T = 0; T < sh.NT; T++) {
+        uint32_t* r = row((size_t)T);
+        const int k = sh.absorbed(T);
+        if (T == 0) r[PP_SS] = 1;
+        else { r[PP_SPG] = 1; for (int j = k; j < 8; j++) r[PP_K + j] = 1; }
+        r[PP_TAG] = (uint32_t)T;
+        if (k) r[PP_RIN] = 1;
+        if (sh.has_challenge(T)) r[PP_SCH] = 1;
+        if (T >= sh.TP) r[PP_SSMP] = 1;
+    }
+    size_t at = sh.p2_fri0;
+    for (int q = 0; q < sh.Q; q++)
+        for (int l = 0; l < sh.R; l++) {
+            uint32_t* r = row(at++);
+            r[PP_SS] = 1; r[PP_RPAIR] = 1; r[PP_TREE] = (uint32_t)l;
+            const int depth = sh.H - (l + 1);
+            for (int lvl = 0; lvl < depth; lvl++) {
+                r = row(at++);
+                r[PP_CH] = 1; r[PP_TREE] = (uint32_t)l;
+                if (lvl == depth - 1) r[PP_END] = r[PP_SROOT] = 1;
+            }
+        }
+    for (int which = 0; which < 2; which++) {
+        const int tree = sh.R + which, blocks = which ? 1 : sh.WB;
+        for (int q = 0; q < sh.Q; q++) {
+            for (int b = 0; b < blocks; b++) {
+                uint32_t* r = row(at++);
+                r[b == 0 ? PP_SS : PP_SPG] = 1;
+                r[PP_RIN] = 1; r[PP_TAG] = sh.row_tag(q, which ? sh.WB : b);
+            }
+            for (int lvl = 0; lvl < sh.H; lvl++) {
+                uint32_t* r = row(at++);
+                r[PP_CH] = 1; r[PP_TREE] = (uint32_t)tree;
+                if (lvl == 0) { r[PP_QIDX] = 1; r[PP_QN] = (uint32_t)q; }
+                if (lvl == sh.H - 1) r[PP_END] = r[PP_SROOT] = 1;
+            }
+        }
+    }
+    monty_all(t);
+}
+
+// ============================================================================================================ TS
+struct TsCols { uint32_t T, ACT, NSEND, CF, CV, IND0, IP, NROOT, NTR, TREE, HASCH, NBETA, NSC, KIND, NFIN, pre, W, TR, CH; };
+constexpr uint32_t TS_MAIN = 20;
+TsCols ts_cols(const Shape& sh) {
+    TsCols c{};
+    uint32_t n = 0;
+    auto take = [&](uint32_t w) { const uint32_t at = n; n += w; return at; };
+    c.T = take(1); c.ACT = take(1); c.NSEND = take(1); c.CF = take(8); c.CV = take(8); c.IND0 = take(1); c.IP = take((uint32_t)sh.pub_rows.size());
+    c.NROOT = take(1); c.NTR = take(1); c.TREE = take(1); c.HASCH = take(1); c.NBETA = take(1); c.NSC = take(1); c.KIND = take(1); c.NFIN = take(1);
+    c.pre = rup4(n);
+    c.W = c.pre; c.TR = c.pre + 8; c.CH = c.pre + 16;
+    return c;
+}
+int pub_row_index(const Shape& sh, int row) { for (size_t i = 0; i < sh.pub_rows.size(); i++) if (sh.pub_rows[i] == row) return (int)i; return -1; }
+std::vector<uint32_t> ts_program(const Shape& sh) {
+    const TsCols c = ts_cols(sh);
+    Cons k;
+    for (uint32_t j = 0; j < 8; j++) k.add(ALL, pmul(pv(c.CF + j), padd(pv(c.W + j), pneg(pv(c.CV + j)))));
+    for (int i = 0; i < sh.NPUB; i++) {
+        const int pos = 14 + i;
+        k.add(ALL, pmul(pv(c.IP + (uint32_t)pub_row_index(sh, pos / 8)), padd(pv(c.W + (uint32_t)(pos % 8)), pneg(ppub((uint32_t)i)))));
+    }
+    k.add(ALL, pmul(pv(c.IND0), padd(pv(c.W + 6), pneg(pv(c.TR)))));
+    k.add(ALL, pmul(pv(c.IND0), padd(pv(c.W + 7), pneg(pv(c.TR + 1)))));
+    for (uint32_t j = 0; j < 6; j++) k.add(TRANSITION, pmul(pv(c.IND0), padd(pv(c.W + j, true), pneg(pv(c.TR + 2 + j)))));
+    return k.program(c.pre + TS_MAIN, (uint32_t)sh.NPUB);
+}
+std::vector<uint32_t> ts_table(const Shape& sh) {
+    const TsCols c = ts_cols(sh);
+    Tab t;
+    t.add5(SEND, c.NSEND, BUS_IN0, c.T, c.W); t.add5(SEND, c.NSEND, BUS_IN1, c.T, c.W + 4);
+    t.add5(RECV, c.HASCH, BUS_TC, c.T, c.CH);
+    t.add5(SEND, c.NBETA, BUS_BETA, c.TREE, c.CH);
+    t.add5(SEND, c.NSC, BUS_SC, c.KIND, c.CH);
+    t.add5(RECV, c.NROOT, BUS_R0, c.TREE, c.W); t.add5(RECV, c.NROOT, BUS_R1, c.TREE, c.W + 4);
+    t.add5(RECV, c.NTR, BUS_R0, c.TREE, c.TR); t.add5(RECV, c.NTR, BUS_R1, c.TREE, c.TR + 4);
+    t.add4(RECV, c.NFIN, BUS_FIN, c.W);
+    return t.w;
+}
+void ts_pre(const Shape& sh, int log_rows, std::vector<uint32_t>& t) {
+    const TsCols c = ts_cols(sh);
+    t.assign((size_t)c.pre << log_rows, 0u);
+    for (int T = 0; T < sh.NTS; T++) {
+        uint32_t* r = t.data() + (size_t)c.pre * (size_t)T;
+        r[c.T] = (uint32_t)T; r[c.ACT] = 1; r[c.NSEND] = (sh.TO0 <= T && T <= sh.TF) ? 2u : 1u;
+        for (int j = 0; j < 8; j++) if (8 * T + j < 6) { r[c.CF + j] = 1; r[c.CV + j] = sh.head[8 * T + j]; }
+        const int pi = pub_row_index(sh, T);
+        if (pi >= 0) r[c.IP + (uint32_t)pi] = 1;
+        if (T == 0) { r[c.IND0] = 1; r[c.NTR] = (uint32_t)sh.Q; r[c.TREE] = (uint32_t)sh.R; }
+        if (T == sh.TQ) { r[c.NROOT] = (uint32_t)sh.Q; r[c.TREE] = (uint32_t)sh.R + 1u; }
+        if (sh.TL0 <= T && T < sh.TP) { r[c.NROOT] = (uint32_t)sh.Q; r[c.TREE] = (uint32_t)(T - sh.TL0); r[c.NBETA] = (uint32_t)sh.Q; }
+        const int kinds[3] = {sh.TA, sh.TQ, sh.TF};
+        for (int kd = 0; kd < 3; kd++) if (T == kinds[kd]) { r[c.NSC] = 1; r[c.KIND] = (uint32_t)kd; }
+        if (sh.has_challenge(T)) r[c.HASCH] = 1;
+        if (T == sh.TP) r[c.NFIN] = (uint32_t)sh.Q;
+    }
+    monty_all(t);
+}
+
+// ============================================================================================================ ROWSUM
+constexpr uint32_t RS_PRE = 8, RP_TAG = 0, RP_ACT = 1, RP_NOTFIRST = 2, RP_LAST0 = 3, RP_LAST1 = 4, RP_QN = 5, RP_FIRST = 6;
+constexpr uint32_t RS_V = 0, RS_ACCIN = 8, RS_T = 12, RS_FA = 44, RS_MAIN = 48;
+std::vector<uint32_t> rowsum_program(const Shape& sh) {
+    const uint32_t M0 = RS_PRE;
+    Cons c;
+    const EE fa = ev(M0 + RS_FA);
+    c.ext(TRANSITION, esub(ev(M0 + RS_FA, true), fa));
+    EE prev = ev(M0 + RS_ACCIN);
+    for (int s = 7; s >= 0; s--) {
+        const EE cur = ev(M0 + RS_T + 4u * (uint32_t)s);
+        c.ext(ALL, esub(cur, eadd(emul(prev, fa), eb(pv(M0 + RS_V + (uint32_t)s)))));
+        prev = cur;
+    }
+    c.ext(TRANSITION, egate(pv(RP_NOTFIRST, true), esub(ev(M0 + RS_ACCIN, true), ev(M0 + RS_T))));
+    c.ext(ALL, egate(padd(pv(RP_ACT), pneg(pv(RP_NOTFIRST))), ev(M0 + RS_ACCIN)));
+    return c.program(RS_PRE + RS_MAIN, (uint32_t)sh.NPUB);
+}
+std::vector<uint32_t> rowsum_table() {
+    const uint32_t M0 = RS_PRE, v = M0 + RS_V, t0 = M0 + RS_T, fa = M0 + RS_FA;
+    Tab t;
+    t.add5(SEND, RP_ACT, BUS_IN0, RP_TAG, v); t.add5(SEND, RP_ACT, BUS_IN1, RP_TAG, v + 4);
+    t.add5(SEND, RP_LAST0, BUS_AT, RP_QN, t0); t.add5(SEND, RP_LAST1, BUS_AQ, RP_QN, t0);
+    t.add4(RECV, RP_FIRST, BUS_KFA, fa);
+    return t.w;
+}
+// (q, block) in trace order: a query's trace blocks from the last to the first, then its quotient block (block number WB)
+inline void rowsum_row(const Shape& sh, size_t r, int* q, int* b) {
+    const size_t per = (size_t)sh.WB + 1;
+    *q = (int)(r / per);
+    const int i = (int)(r % per);
+    *b = i < sh.WB ? sh.WB - 1 - i : sh.WB;
+}
+void rowsum_pre(const Shape& sh, int log_rows, std::vector<uint32_t>& t) {
+    t.assign((size_t)RS_PRE << log_rows, 0u);
+    const size_t used = (size_t)sh.Q * (size_t)(sh.WB + 1);
+    for (size_t r = 0; r < used; r++) {
+        int q, b;
+        rowsum_row(sh, r, &q, &b);
+        uint32_t* row = t.data() + RS_PRE * r;
+        row[RP_TAG] = sh.row_tag(q, b); row[RP_ACT] = 1; row[RP_QN] = (uint32_t)q;
+        row[RP_NOTFIRST] = (b == sh.WB - 1 || b == sh.WB) ? 0u : 1u;
+        row[RP_LAST0] = b == 0 ? 1u : 0u; row[RP_LAST1] = b == sh.WB ? 1u : 0u;
+    }
+    t[RP_FIRST] = 1;
+    monty_all(t);
+}
+
+// ============================================================================================================ QUERY
+constexpr uint32_t Q_PRE = 4, QP_QN = 0, QP_ACT = 1, QP_ACT2 = 2, QP_FIRST = 3;
+struct QCols { uint32_t IDX, XQ, RO, AT, AQ, I1, I2, P1, P2, P2O, P3, P3O, ZETA, ZNX, YL, YN, YQ, OFFN, OFFQ, end; };
+constexpr QCols qcols() {
+    QCols c{};
+    uint32_t n = Q_PRE;
+    c.IDX = n++; c.XQ = n++;
+    uint32_t* f[] = {&c.RO, &c.AT, &c.AQ, &c.I1, &c.I2, &c.P1, &c.P2, &c.P2O, &c.P3, &c.P3O, &c.ZETA, &c.ZNX, &c.YL, &c.YN, &c.YQ, &c.OFFN, &c.OFFQ};
+    for (uint32_t* p : f) { *p = n; n += 4; }
+    c.end = n;
+    return c;
+}
+constexpr uint32_t Q_MAIN = ((qcols().end - Q_PRE) + 3u) & ~3u;
+std::vector<uint32_t> query_program(const Shape& sh) {
+    constexpr QCols m = qcols();
+    Cons c;
+    const uint32_t consts[7] = {m.ZETA, m.ZNX, m.YL, m.YN, m.YQ, m.OFFN, m.OFFQ};
+    for (uint32_t col : consts) c.ext(TRANSITION, esub(ev(col, true), ev(col)));
+    const EE x = eb(pscale(pv(m.XQ), GEN));
+    const Poly act = pv(QP_ACT);
+    c.ext(ALL, egate(act, esub(emul(esub(x, ev(m.ZETA)), ev(m.I1)), ec(1))));
+    c.ext(ALL, egate(act, esub(emul(esub(x, ev(m.ZNX)), ev(m.I2)), ec(1))));
+    c.ext(ALL, esub(ev(m.P1), emul(esub(ev(m.AT), ev(m.YL)), ev(m.I1))));
+    c.ext(ALL, esub(ev(m.P2), emul(esub(ev(m.AT), ev(m.YN)), ev(m.I2))));
+    c.ext(ALL, esub(ev(m.P2O), emul(ev(m.OFFN), ev(m.P2))));
+    c.ext(ALL, esub(ev(m.P3), emul(esub(ev(m.AQ), ev(m.YQ)), ev(m.I1))));
+    c.ext(ALL, esub(ev(m.P3O), emul(ev(m.OFFQ), ev(m.P3))));
+    c.ext(ALL, esub(ev(m.RO), eadd(ev(m.P1), ev(m.P2O), ev(m.P3O))));
+    return c.program(Q_PRE + Q_MAIN, (uint32_t)sh.NPUB);
+}
+std::vector<uint32_t> query_table() {
+    constexpr QCols m = qcols();
+    Tab t;
+    t.add(RECV, QP_ACT, BUS_I, {QP_QN, m.IDX});
+    t.add(RECV, QP_ACT, BUS_Q, {m.IDX, m.XQ, m.RO, m.RO + 1, m.RO + 2, m.RO + 3});
+    t.add5(RECV, QP_ACT, BUS_AT, QP_QN, m.AT); t.add5(RECV, QP_ACT, BUS_AQ, QP_QN, m.AQ);
+    t.add(SEND, QP_ACT2, BUS_QI, {QP_QN, m.IDX});
+    t.add8(RECV, QP_FIRST, BUS_K0, m.ZETA, m.ZNX); t.add8(RECV, QP_FIRST, BUS_K1, m.YL, m.YN); t.add8(RECV, QP_FIRST, BUS_K2, m.YQ, m.OFFN);
+    t.add4(RECV, QP_FIRST, BUS_K3, m.OFFQ);
+    return t.w;
+}
+void query_pre(const Shape& sh, int log_rows, std::vector<uint32_t>& t) {
+    t.assign((size_t)Q_PRE << log_rows, 0u);
+    for (int q = 0; q < sh.Q; q++) { uint32_t* r = t.data() + Q_PRE * (size_t)q; r[QP_QN] = (uint32_t)q; r[QP_ACT] = 1; r[QP_ACT2] = 2; }
+    t[QP_FIRST] = 1;
+    monty_all(t);
+}
+
+// ============================================================================================================ OPENED
+constexpr uint32_t OP_PRE = 12, OP_ACT = 0, OP_FIRST = 1, OP_LASTG = 2, OP_NOTFIRST = 3, OP_K1 = 4, OP_K2 = 5, OP_K3 = 6, OP_TL0 = 7, OP_TL1 = 8, OP_TN0 = 9, OP_TN1 = 10;
+enum OpCol : uint32_t { O_A, O_B, O_C, O_D, O_AN, O_BN, O_CN, O_DN, O_FA, O_FA4, O_ALPHA, O_SELT, O_SELF, O_PW, O_PWN, O_H2, O_H1, O_IL, O_G2, O_G1, O_INX,
+                        O_YLIN, O_YLO, O_YNIN, O_YNO, O_A2, O_AB, O_ACCIN, O_U1, O_U2, O_ACCO, O_COUNT };
+constexpr uint32_t oc(uint32_t name) { return OP_PRE + 4u * name; }
+constexpr uint32_t OP_MAIN = 4u * O_COUNT;
+std::vector<uint32_t> opened_program(const Shape& sh) {
+    Cons c;
+    auto e = [&](uint32_t name, bool nxt = false) { return ev(oc(name), nxt); };
+    const uint32_t consts[5] = {O_FA, O_FA4, O_ALPHA, O_SELT, O_SELF};
+    for (uint32_t nm : consts) c.ext(TRANSITION, esub(e(nm, true), e(nm)));
+    const Poly first = pv(OP_FIRST), nf = pv(OP_NOTFIRST, true);
+    c.ext(ALL, egate(first, esub(e(O_PW), ec(1))));
+    c.ext(ALL, esub(e(O_PWN), emul(e(O_PW), e(O_FA4))));
+    c.ext(TRANSITION, egate(nf, esub(e(O_PW, true), e(O_PWN))));
+    const EE fa = e(O_FA);
+    const uint32_t sets[2][7] = {{O_H2, O_H1, O_IL, O_A, O_B, O_C, O_D}, {O_G2, O_G1, O_INX, O_AN, O_BN, O_CN, O_DN}};
+    for (const auto& s : sets) {
+        c.ext(ALL, esub(e(s[0]), eadd(e(s[5]), emul(fa, e(s[6])))));
+        c.ext(ALL, esub(e(s[1]), eadd(e(s[4]), emul(fa, e(s[0])))));
+        c.ext(ALL, esub(e(s[2]), eadd(e(s[3]), emul(fa, e(s[1])))));
+    }
+    const uint32_t ys[2][3] = {{O_YLIN, O_YLO, O_IL}, {O_YNIN, O_YNO, O_INX}};
+    for (const auto& y : ys) {
+        c.ext(ALL, egate(first, e(y[0])));
+        c.ext(ALL, esub(e(y[1]), eadd(e(y[0]), emul(e(O_PW), e(y[2])))));
+        c.ext(TRANSITION, egate(nf, esub(e(y[0], true), e(y[1]))));
+    }
+    c.ext(ALL, esub(e(O_A2), emul(e(O_A), e(O_A))));
+    c.ext(ALL, esub(e(O_AB), emul(e(O_A), e(O_B))));
+    const EE al = e(O_ALPHA);
+    c.ext(ALL, egate(first, e(O_ACCIN)));
+    c.ext(ALL, esub(e(O_U1), eadd(emul(e(O_ACCIN), al), esub(esub(e(O_C), emul(e(O_A2), e(O_B))), eb(pv(OP_K1))))));
+    c.ext(ALL, esub(e(O_U2), eadd(emul(e(O_U1), al), emul(e(O_SELT), esub(esub(esub(e(O_DN), e(O_AB)), e(O_C)), eb(pv(OP_K2)))))));
+    c.ext(ALL, esub(e(O_ACCO), eadd(emul(e(O_U2), al), emul(e(O_SELF), esub(e(O_D), eb(pv(OP_K3)))))));
+    c.ext(TRANSITION, egate(nf, esub(e(O_ACCIN, true), e(O_ACCO))));
+    return c.program(OP_PRE + OP_MAIN, (uint32_t)sh.NPUB);
+}
+std::vector<uint32_t> opened_table() {
+    Tab t;
+    const uint32_t tags[4] = {OP_TL0, OP_TL1, OP_TN0, OP_TN1}, lo[4] = {O_A, O_C, O_AN, O_CN}, hi[4] = {O_B, O_D, O_BN, O_DN};
+    for (int i = 0; i < 4; i++) { t.add5(RECV, OP_ACT, BUS_IN0, tags[i], oc(lo[i])); t.add5(RECV, OP_ACT, BUS_IN1, tags[i], oc(hi[i])); }
+    t.add8(SEND, OP_LASTG, BUS_OY, oc(O_YLO), oc(O_YNO)); t.add4(SEND, OP_LASTG, BUS_OA, oc(O_ACCO));
+    t.add8(RECV, OP_FIRST, BUS_KO0, oc(O_FA), oc(O_FA4)); t.add8(RECV, OP_FIRST, BUS_KO1, oc(O_ALPHA), oc(O_SELT)); t.add4(RECV, OP_FIRST, BUS_KO2, oc(O_SELF));
+    return t.w;
+}
+void opened_pre(const Shape& sh, int log_rows, std::vector<uint32_t>& t) {
+    t.assign((size_t)OP_PRE << log_rows, 0u);
+    for (int g = 0; g < sh.G; g++) {
+        uint32_t* r = t.data() + OP_PRE * (size_t)g;
+        r[OP_ACT] = 1; r[OP_NOTFIRST] = g ? 1u : 0u;
+        r[OP_K1] = (uint32_t)g + 1u; r[OP_K2] = 2u * (uint32_t)g + 3u; r[OP_K3] = 5u * (uint32_t)g + 7u;
+        r[OP_TL0] = (uint32_t)(sh.TO0 + 2 * g); r[OP_TL1] = (uint32_t)(sh.TO0 + 2 * g + 1);
+        r[OP_TN0] = (uint32_t)(sh.TO0 + sh.W / 2 + 2 * g); r[OP_TN1] = (uint32_t)(sh.TO0 + sh.W / 2 + 2 * g + 1);
+    }
+    t[OP_FIRST] = 1; t[OP_PRE * (size_t)(sh.G - 1) + OP_LASTG] = 1;
+    monty_all(t);
+}
+
+// ============================================================================================================ SCALARS
+constexpr uint32_t SC_PRE = 8, SP_FIRST = 0, SP_KA = 1, SP_KZ = 2, SP_KF = 3, SP_TQZ = 4;
+struct ScCols {
+    uint32_t ALPHA, ZETA, FA, ZP1, INVF, SELF, SELT, ZNX, FP1, PR1, OFFN, OFFQ, QZ0, HQ0, QK0, QK1, QUO, YL, YN, ACC, end;
+    int mb, nbits; int bits[12];
+    uint32_t zp(int i) const { return ZP1 + 4u * (uint32_t)(i - 1); }       // ZP_i = zeta^(2^i), i = 1 .. n
+    uint32_t fp(int i) const { return i == 0 ? FA : FP1 + 4u * (uint32_t)(i - 1); }
+    uint32_t pr(int k) const { return PR1 + 4u * (uint32_t)(k - 1); }
+    uint32_t qz(int j) const { return QZ0 + 4u * (uint32_t)j; }
+    uint32_t hq(int j) const { return HQ0 + 4u * (uint32_t)j; }
+};
+ScCols sc_cols(const Shape& sh) {
+    ScCols c{};
+    uint32_t n = SC_PRE;
+    auto take = [&](uint32_t k = 1) { const uint32_t at = n; n += 4 * k; return at; };
+    c.ALPHA = take(); c.ZETA = take(); c.FA = take();
+    c.ZP1 = take((uint32_t)sh.n);
+    c.INVF = take(); c.SELF = take(); c.SELT = take(); c.ZNX = take();
+    c.mb = 31 - __builtin_clz((unsigned)sh.W);
+    c.FP1 = take((uint32_t)c.mb);
+    c.nbits = 0;
+    for (int i = 0; i <= c.mb; i++) if ((sh.W >> i) & 1) c.bits[c.nbits++] = i;
+    c.PR1 = take((uint32_t)(c.nbits - 1));
+    c.OFFN = take(); c.OFFQ = take();
+    c.QZ0 = take(8); c.HQ0 = take(7);
+    c.QK0 = take(); c.QK1 = take(); c.QUO = take(); c.YL = take(); c.YN = take(); c.ACC = take();
+    c.end = n;
+    return c;
+}
+// zps_k(zeta) = a_k zeta^N + b_k for the two quotient chunks (canonical)
+void zps_consts(const Shape& sh, uint32_t a[2], uint32_t b[2]) {
+    const uint64_t N = (uint64_t)1 << sh.n;
+    const uint32_t wq = two_adic_generator(sh.n + 1);
+    uint32_t sN[2];
+    for (int k = 0; k < 2; k++) sN[k] = fpow(fmul(MONTY_GEN, fpow(wq, (uint64_t)k)), N);
+    for (int k = 0; k < 2; k++) {
+        const int j = 1 - k;
+        const uint32_t sj_inv = finv(sN[j]);
+        const uint32_t den_inv = finv(fsub(fmul(sN[k], sj_inv), MONTY_R1));
+        a[k] = from_monty(fmul(sj_inv, den_inv));
+        b[k] = from_monty(fneg(den_inv));
+    }
+}
+std::vector<uint32_t> scalars_program(const Shape& sh) {
+    const ScCols m = sc_cols(sh);
+    Cons c;
+    EE prev = ev(m.ZETA);
+    for (int i = 1; i <= sh.n; i++) { c.ext(ALL, esub(ev(m.zp(i)), emul(prev, prev))); prev = ev(m.zp(i)); }
+    const EE znn = prev;
+    const uint32_t wn = from_monty(two_adic_generator(sh.n)), wni = from_monty(finv(two_adic_generator(sh.n)));
+    c.ext(ALL, esub(emul(esub(ev(m.ZETA), ec(1)), ev(m.INVF)), ec(1)));
+    c.ext(ALL, esub(ev(m.SELF), emul(esub(znn, ec(1)), ev(m.INVF))));
+    c.ext(ALL, esub(ev(m.SELT), esub(ev(m.ZETA), ec(wni))));
+    c.ext(ALL, esub(ev(m.ZNX), escale(ev(m.ZETA), wn)));
+    prev = ev(m.FA);
+    for (int i = 1; i <= m.mb; i++) { c.ext(ALL, esub(ev(m.fp(i)), emul(prev, prev))); prev = ev(m.fp(i)); }
+    EE acc = ev(m.fp(m.bits[0]));
+    for (int k = 1; k < m.nbits; k++) { c.ext(ALL, esub(ev(m.pr(k)), emul(acc, ev(m.fp(m.bits[k]))))); acc = ev(m.pr(k)); }
+    c.ext(ALL, esub(ev(m.OFFN), acc));
+    c.ext(ALL, esub(ev(m.OFFQ), emul(ev(m.OFFN), ev(m.OFFN))));
+    prev = ev(m.qz(7));
+    for (int j = 6; j >= 0; j--) { c.ext(ALL, esub(ev(m.hq(j)), eadd(ev(m.qz(j)), emul(ev(m.FA), prev)))); prev = ev(m.hq(j)); }
+    for (int k = 0; k < 2; k++) {
+        EE q = ec(0);
+        for (int t = 0; t < 4; t++) {
+            uint64_t basis[4] = {0, 0, 0, 0};
+            basis[t] = 1;
+            q = eadd(q, emul(ec(basis[0], basis[1], basis[2], basis[3]), ev(m.qz(4 * k + t))));
+        }
+        c.ext(ALL, esub(ev(k ? m.QK1 : m.QK0), q));
+    }
+    uint32_t za[2], zb[2];
+    zps_consts(sh, za, zb);
+    const EE z0 = eadd(escale(znn, za[0]), ec(zb[0])), z1 = eadd(escale(znn, za[1]), ec(zb[1]));
+    c.ext(ALL, esub(ev(m.QUO), eadd(emul(z0, ev(m.QK0)), emul(z1, ev(m.QK1)))));
+    c.ext(ALL, esub(ev(m.ACC), emul(ev(m.QUO), esub(znn, ec(1)))));
+    return c.program(SC_PRE + rup4(m.end - SC_PRE), (uint32_t)sh.NPUB);
+}
+std::vector<uint32_t> scalars_table(const Shape& sh) {
+    const ScCols m = sc_cols(sh);
+    Tab t;
+    t.add5(RECV, SP_FIRST, BUS_SC, SP_KA, m.ALPHA); t.add5(RECV, SP_FIRST, BUS_SC, SP_KZ, m.ZETA); t.add5(RECV, SP_FIRST, BUS_SC, SP_KF, m.FA);
+    for (int i = 0; i < 4; i++) { t.add5(RECV, SP_FIRST, BUS_IN0, SP_TQZ + (uint32_t)i, m.qz(2 * i)); t.add5(RECV, SP_FIRST, BUS_IN1, SP_TQZ + (uint32_t)i, m.qz(2 * i + 1)); }
+    t.add8(RECV, SP_FIRST, BUS_OY, m.YL, m.YN); t.add4(RECV, SP_FIRST, BUS_OA, m.ACC);
+    t.add8(SEND, SP_FIRST, BUS_K0, m.ZETA, m.ZNX); t.add8(SEND, SP_FIRST, BUS_K1, m.YL, m.YN); t.add8(SEND, SP_FIRST, BUS_K2, m.hq(0), m.OFFN); t.add4(SEND, SP_FIRST, BUS_K3, m.OFFQ);
+    t.add4(SEND, SP_FIRST, BUS_KFA, m.FA);
+    t.add8(SEND, SP_FIRST, BUS_KO0, m.FA, m.fp(2)); t.add8(SEND, SP_FIRST, BUS_KO1, m.ALPHA, m.SELT); t.add4(SEND, SP_FIRST, BUS_KO2, m.SELF);
+    return t.w;
+}
+void scalars_pre(const Shape& sh, int log_rows, std::vector<uint32_t>& t) {
+    t.assign((size_t)SC_PRE << log_rows, 0u);
+    for (size_t r = 0; r < ((size_t)1 << log_rows); r++) {
+        uint32_t* row = t.data() + SC_PRE * r;
+        row[SP_KA] = 0; row[SP_KZ] = 1; row[SP_KF] = 2;
+        for (int i = 0; i < 4; i++) row[SP_TQZ + i] = (uint32_t)(sh.TO0 + sh.W + i);
+    }
+    t[SP_FIRST] = 1;
+    monty_all(t);
+}
+
+// ============================================================================================================ the machine
+enum Chip : int { C_P2R, C_ROWSUM, C_FOLD, C_TS, C_QUERY, C_OPENED, C_SAMPLES, C_SCALARS, N_CHIPS };
+struct Machine {
+    Shape sh;
+    int order[N_CHIPS];                         // position -> chip, tallest first (equal heights in the order of the enum)
+    int32_t log_ns[N_CHIPS]; uint32_t widths[N_CHIPS], pre_widths[N_CHIPS];
+    std::vector<uint32_t> prog[N_CHIPS], tab[N_CHIPS];     // by position
+    const uint32_t* progs[N_CHIPS]; size_t prog_words[N_CHIPS]; const uint32_t* tabs[N_CHIPS]; size_t tab_words[N_CHIPS];
+    int height[N_CHIPS];                        // by chip
+    int pos_of(int chip) const { for (int i = 0; i < N_CHIPS; i++) if (order[i] == chip) return i; return -1; }
+};
+std::vector<uint32_t> samples_table_words() { return frichip::samples_interactions(); }
+std::vector<uint32_t> fold_table(const Shape& sh) {
+    using namespace frichip;
+    Tab t;
+    t.add(SEND, ACTIVE, BUS_E0, {LN, K2, E0, E0 + 1, E0 + 2, E0 + 3}); t.add(SEND, ACTIVE, BUS_E1, {LN, K2, E1, E1 + 1, E1 + 2, E1 + 3});
+    t.add(SEND, L_REC, BUS_Q, {IDX, XS, OWN, OWN + 1, OWN + 2, OWN + 3});
+    t.add5(RECV, ACTIVE, BUS_BETA, LN, BETA);
+    t.add4(SEND, L_REC + (uint32_t)sh.R - 1u, BUS_FIN, FOLD);
+    return t.w;
+}
+// the machine of a shape: programs, tables, heights.  Built once per (shape, Poseidon2 tables) and kept.
+std::shared_ptr<const Machine> machine_of(const Shape& sh) {
+    static std::mutex mu;
+    static std::map<std::vector<uint64_t>, std::shared_ptr<const Machine>> cache;
+    const std::vector<uint64_t> key{(uint64_t)sh.n, (uint64_t)sh.W, (uint64_t)sh.Q, (uint64_t)sh.PB, (uint64_t)sh.NPUB, g_p2_generation.load()};
+    std::lock_guard<std::mutex> lk(mu);
+    auto it = cache.find(key);
+    if (it != cache.end()) return it->second;
+    auto m = std::make_shared<Machine>();
+    m->sh = sh;
+    const int h[N_CHIPS] = {lg(sh.p2_rows), lg((size_t)sh.Q * (size_t)(sh.WB + 1)), lg((size_t)sh.Q * (size_t)sh.R), lg((size_t)sh.NTS), lg((size_t)sh.Q), lg((size_t)sh.G),
+                            lg((size_t)sh.NS), 5};
+    for (int c = 0; c < N_CHIPS; c++) { m->height[c] = h[c]; m->order[c] = c; }
+    std::stable_sort(m->order, m->order + N_CHIPS, [&](int a, int b) { return h[a] > h[b]; });
+    const ScCols scc = sc_cols(sh);
+    const TsCols tsc = ts_cols(sh);
+    const uint32_t w_main[N_CHIPS] = {P2_MAIN, RS_MAIN, frichip::width_of(sh.R, true, true), TS_MAIN, Q_MAIN, OP_MAIN, frichip::S_MAIN, rup4(scc.end - SC_PRE)};
+    const uint32_t w_pre[N_CHIPS] = {P2_PRE, RS_PRE, 0u, tsc.pre, Q_PRE, OP_PRE, frichip::S_PRE, SC_PRE};
+    for (int i = 0; i < N_CHIPS; i++) {
+        const int c = m->order[i];
+        switch (c) {
+            case C_P2R: m->prog[i] = p2r_program(sh); m->tab[i] = p2r_table(); break;
+            case C_ROWSUM: m->prog[i] = rowsum_program(sh); m->tab[i] = rowsum_table(); break;
+            case C_FOLD: m->prog[i] = *frichip::program(sh.R, true, true, sh.NPUB); m->tab[i] = fold_table(sh); break;
+            case C_TS: m->prog[i] = ts_program(sh); m->tab[i] = ts_table(sh); break;
+            case C_QUERY: m->prog[i] = query_program(sh); m->tab[i] = query_table(); break;
+            case C_OPENED: m->prog[i] = opened_program(sh); m->tab[i] = opened_table(); break;
+            case C_SAMPLES: m->prog[i] = *frichip::samples_program(sh.R, sh.PB, (uint32_t)sh.NPUB); m->tab[i] = samples_table_words(); break;
+            default: m->prog[i] = scalars_program(sh); m->tab[i] = scalars_table(sh); break;
+        }
+        m->log_ns[i] = h[c]; m->widths[i] = w_main[c]; m->pre_widths[i] = w_pre[c];
+    }
+    for (int i = 0; i < N_CHIPS; i++) { m->progs[i] = m->prog[i].data(); m->prog_words[i] = m->prog[i].size(); m->tabs[i] = m->tab[i].data(); m->tab_words[i] = m->tab[i].size(); }
+    if (cache.size() > 16) cache.clear();
+    cache.emplace(key, m);
+    return m;
+}
+
+// ---- the witness: everything the main columns hold, read off the inner proof (which the host verifier has accepted)
+struct Witness {
+    const uint32_t* w = nullptr;                // the proof's words (canonical)
+    size_t o_troot, o_qroot, o_loc, o_nxt, o_qz, o_lroots, o_final, o_wit, o_queries, per_query;
+    std::vector<uint32_t> betas, indices, values, siblings, lroots, paths;     // zkhip_fri_view_all
+    uint32_t fin[4], tr[10];
+    size_t q_trow(int q) const { return o_queries + (size_t)q * per_query; }
+};
+inline Ext ext_canon(const uint32_t* p) { return Ext{{to_monty(p[0]), to_monty(p[1]), to_monty(p[2]), to_monty(p[3])}}; }
+inline void put_ext(uint32_t* row, uint32_t col, const Ext& e) { for (int i = 0; i < 4; i++) row[col + i] = e.c[i]; }
+
+}  // namespace
+}  // namespace rec
+}  // namespace zk
+
+// ---- main traces + proof.  Host-side tables (TS, ROWSUM, QUERY, OPENED, SAMPLES, SCALARS: a few thousand rows together) are filled on the
+// host in Montgomery form and uploaded; the Poseidon2 chip's 2^15 rows and the fold chip's rows are filled on the device.
+static int shard_verifier_prove_impl(zkhip_ctx* ctx, const zkhip_machine_key* key, const uint8_t* inner, size_t inner_len, int log_n, uint32_t width,
+                                     const uint32_t* public_values, size_t n_public, const zkhip_params* inner_prm, const zkhip_params* outer,
+                                     uint8_t* proof, size_t cap, size_t* len) {
+    using namespace zk::rec;
+    CHECK_CTX(ctx);
+    if (!key || !inner || !inner_prm || !outer || !proof || !len || (n_public && !public_values)) return fail(ZKHIP_ERR_INVALID, "prove_shard_verifier: null argument");
+    if (inner_prm->log_blowup != 1 || inner_prm->logup_pairs != 0 || inner_prm->log_fold > 1 || inner_prm->log_final != 0 || (inner_prm->hash_width != 0 && inner_prm->hash_width != 16) ||
+        inner_prm->code_width != 0)
+        return fail(ZKHIP_ERR_INVALID, "prove_shard_verifier: version-1 shard proofs (SP1 shape: blowup 2, fold by 2, constant final value, no lookups)");
+    Shape sh;
+    ZK_TRY(make_shape(log_n, width, (size_t)inner_prm->num_queries, inner_prm->pow_bits, n_public, sh));
+    const auto mp = machine_of(sh);
+    const Machine& m = *mp;
+    const int R = sh.R, H = sh.H, Q = sh.Q, W = sh.W;
+    // (a) one host pass: the verifier accepts the proof and hands out the FRI side; the rest is read off the words (docs/PROTOCOL.md section 6)
+    Witness wt;
+    wt.betas.resize(4 * (size_t)R); wt.indices.resize((size_t)Q); wt.values.resize(4 * (size_t)Q); wt.siblings.resize(4 * (size_t)Q * (size_t)R); wt.lroots.resize(8 * (size_t)R);
+    wt.paths.resize(zkhip_fri_view_path_words(R) * (size_t)Q);
+    ZK_TRY(zkhip_fri_view_all(inner, inner_len, log_n, width, public_values, n_public, inner_prm, wt.betas.data(), wt.fin, wt.indices.data(), wt.values.data(),
+                              wt.siblings.data(), wt.lroots.data(), wt.paths.data(), wt.tr));
+    std::vector<uint32_t> words(inner_len / 4);
+    std::memcpy(words.data(), inner, words.size() * 4);
+    wt.w = words.data();
+    wt.o_troot = 8; wt.o_qroot = 16; wt.o_loc = 24; wt.o_nxt = wt.o_loc + 4 * (size_t)W; wt.o_qz = wt.o_nxt + 4 * (size_t)W; wt.o_lroots = wt.o_qz + 32;
+    wt.o_final = wt.o_lroots + 8 * (size_t)R; wt.o_wit = wt.o_final + 4; wt.o_queries = wt.o_wit + 1;
+    wt.per_query = (size_t)W + 8 * (size_t)H + 8 + 8 * (size_t)H;
+    for (int l = 0; l < R; l++) wt.per_query += 4 + 8 * (size_t)(H - 1 - l);
+    if (words.size() != wt.o_queries + (size_t)Q * wt.per_query) return fail(ZKHIP_ERR_INTERNAL, "prove_shard_verifier: unexpected proof length");
+    const uint32_t* pw = wt.w;
+    // (b) the transcript's sponge chain on the host (NT permutations): the input state of every row, the challenges, the sampled words
+    std::vector<uint32_t> chain_in(16 * (size_t)sh.NT), samples(8 * (size_t)sh.NS);
+    std::vector<Ext> chal((size_t)sh.NT);
+    std::vector<std::array<uint32_t, 8>> blocks((size_t)sh.NTS);      // observed words per absorbing row (canonical; absent ones zero)
+    {
+        std::vector<uint32_t> seq0(sh.head, sh.head + 6);
+        seq0.insert(seq0.end(), pw + wt.o_troot, pw + wt.o_troot + 8);
+        for (size_t i = 0; i < n_public; i++) seq0.push_back(public_values[i] % P);
+        for (auto& b : blocks) b.fill(0u);
+        for (int T = 0; T < sh.f0 + (sh.r0 ? 1 : 0); T++) for (int j = 0; j < 8 && 8 * (size_t)T + j < seq0.size(); j++) blocks[(size_t)T][j] = seq0[8 * (size_t)T + j];
+        for (int j = 0; j < 8; j++) blocks[(size_t)sh.TQ][j] = pw[wt.o_qroot + j];
+        for (int i = 0; i < W + 4; i++) for (int j = 0; j < 8; j++) blocks[(size_t)(sh.TO0 + i)][j] = pw[wt.o_loc + 8 * (size_t)i + j];
+        for (int l = 0; l < R; l++) for (int j = 0; j < 8; j++) blocks[(size_t)(sh.TL0 + l)][j] = pw[wt.o_lroots + 8 * (size_t)l + j];
+        for (int j = 0; j < 4; j++) blocks[(size_t)sh.TP][j] = pw[wt.o_final + j];
+        blocks[(size_t)sh.TP][4] = pw[wt.o_wit];
+        uint32_t st[16] = {0};
+        for (int T = 0; T < sh.NT; T++) {
+            const int k = sh.absorbed(T);
+            for (int j = 0; j < k; j++) st[j] = to_monty(blocks[(size_t)T][j]);
+            for (int j = 0; j < 16; j++) chain_in[16 * (size_t)T + j] = from_monty(st[j]);
+            p2_permute(st);
+            chal[(size_t)T] = Ext{{st[7], st[6], st[5], st[4]}};
+            if (T >= sh.TP) for (int j = 0; j < 8; j++) samples[8 * (size_t)(T - sh.TP) + j] = from_monty(st[7 - j]);
+        }
+        for (int l = 0; l < R; l++) for (int j = 0; j < 4; j++)
+            if (from_monty(chal[(size_t)(sh.TL0 + l)].c[j]) != wt.betas[4 * (size_t)l + j]) return fail(ZKHIP_ERR_INTERNAL, "prove_shard_verifier: the sponge rows do not reproduce the verifier's challenges");
+    }
+    const Ext alpha = chal[(size_t)sh.TA], zeta = chal[(size_t)sh.TQ], fa = chal[(size_t)sh.TF];
+    // (c) the scalars
+    const ScCols scc = sc_cols(sh);
+    const uint32_t sc_w = rup4(scc.end - SC_PRE);
+    std::vector<uint32_t> sc_row(sc_w, 0u);
+    auto scput = [&](uint32_t col, const Ext& e) { put_ext(sc_row.data(), col - SC_PRE, e); };
+    Ext znn = zeta;
+    scput(scc.ALPHA, alpha); scput(scc.ZETA, zeta); scput(scc.FA, fa);
+    for (int i = 1; i <= sh.n; i++) { znn = ext_mul(znn, znn); scput(scc.zp(i), znn); }
+    const uint32_t wn = two_adic_generator(sh.n), wni = finv(wn);
+    const Ext invf = ext_inv(ext_sub_base(zeta, MONTY_R1)), self_ = ext_mul(ext_sub_base(znn, MONTY_R1), invf), selt = ext_sub_base(zeta, wni), znx = ext_mul_base(zeta, wn);
+    scput(scc.INVF, invf); scput(scc.SELF, self_); scput(scc.SELT, selt); scput(scc.ZNX, znx);
+    std::vector<Ext> fp{fa};
+    for (int i = 1; i <= scc.mb; i++) { fp.push_back(ext_mul(fp.back(), fp.back())); scput(scc.fp(i), fp.back()); }
+    Ext offn = fp[(size_t)scc.bits[0]];
+    for (int k = 1; k < scc.nbits; k++) { offn = ext_mul(offn, fp[(size_t)scc.bits[k]]); scput(scc.pr(k), offn); }
+    const Ext offq = ext_mul(offn, offn), fa4 = fp[2];
+    scput(scc.OFFN, offn); scput(scc.OFFQ, offq);
+    Ext qz[8], hq[8];
+    for (int j = 0; j < 8; j++) { qz[j] = ext_canon(pw + wt.o_qz + 4 * (size_t)j); scput(scc.qz(j), qz[j]); }
+    hq[7] = qz[7];
+    for (int j = 6; j >= 0; j--) { hq[j] = ext_add(qz[j], ext_mul(fa, hq[j + 1])); scput(scc.hq(j), hq[j]); }
+    const Ext yq = hq[0];
+    Ext qk[2];
+    for (int k = 0; k < 2; k++) {
+        Ext q = ext_zero();
+        for (int t = 0; t < 4; t++) { Ext basis = ext_zero(); basis.c[t] = MONTY_R1; q = ext_add(q, ext_mul(basis, qz[4 * k + t])); }
+        qk[k] = q;
+        scput(k ? scc.QK1 : scc.QK0, q);
+    }
+    uint32_t za[2], zb[2];
+    zps_consts(sh, za, zb);
+    const Ext quo = ext_add(ext_mul(ext_add_base(ext_mul_base(znn, to_monty(za[0])), to_monty(zb[0])), qk[0]), ext_mul(ext_add_base(ext_mul_base(znn, to_monty(za[1])), to_monty(zb[1])), qk[1]));
+    scput(scc.QUO, quo);
+    // (d) OPENED: the opened values, their fa-weighted sums, the AIR folded with alpha
+    const int h_op = m.height[C_OPENED];
+    std::vector<uint32_t> t_op((size_t)OP_MAIN << h_op, 0u);
+    Ext yl = ext_zero(), yn = ext_zero(), acc = ext_zero(), pwr = ext_one(), res_yl = yl, res_yn = yn, res_acc = acc;
+    for (size_t g = 0; g < ((size_t)1 << h_op); g++) {
+        uint32_t* r = t_op.data() + (size_t)OP_MAIN * g;
+        auto put = [&](uint32_t name, const Ext& e) { put_ext(r, 4u * name, e); };
+        put(O_FA, fa); put(O_FA4, fa4); put(O_ALPHA, alpha); put(O_SELT, selt); put(O_SELF, self_);
+        Ext v[8];
+        uint32_t k1 = 0, k2 = 0, k3 = 0;
+        if (g < (size_t)sh.G) {
+            for (int i = 0; i < 4; i++) { v[i] = ext_canon(pw + wt.o_loc + 4 * (4 * g + (size_t)i)); v[4 + i] = ext_canon(pw + wt.o_nxt + 4 * (4 * g + (size_t)i)); }
+            k1 = to_monty((uint32_t)g + 1u); k2 = to_monty(2u * (uint32_t)g + 3u); k3 = to_monty(5u * (uint32_t)g + 7u);
+        } else {
+            for (auto& e : v) e = ext_zero();
+            pwr = yl = yn = acc = ext_zero();
+        }
+        for (uint32_t i = 0; i < 8; i++) put(O_A + i, v[i]);
+        put(O_PW, pwr);
+        const Ext pwn = ext_mul(pwr, fa4);
+        put(O_PWN, pwn);
+        Ext il[2];
+        for (int s = 0; s < 2; s++) {
+            const Ext* x = v + 4 * s;
+            const Ext h2 = ext_add(x[2], ext_mul(fa, x[3])), h1 = ext_add(x[1], ext_mul(fa, h2));
+            il[s] = ext_add(x[0], ext_mul(fa, h1));
+            put(s ? O_G2 : O_H2, h2); put(s ? O_G1 : O_H1, h1); put(s ? O_INX : O_IL, il[s]);
+        }
+        put(O_YLIN, yl); put(O_YNIN, yn);
+        yl = ext_add(yl, ext_mul(pwr, il[0])); yn = ext_add(yn, ext_mul(pwr, il[1]));
+        put(O_YLO, yl); put(O_YNO, yn);
+        const Ext a2 = ext_mul(v[0], v[0]), ab = ext_mul(v[0], v[1]);
+        put(O_A2, a2); put(O_AB, ab); put(O_ACCIN, acc);
+        const Ext u1 = ext_add(ext_mul(acc, alpha), ext_sub_base(ext_sub(v[2], ext_mul(a2, v[1])), k1));
+        const Ext u2 = ext_add(ext_mul(u1, alpha), ext_mul(selt, ext_sub_base(ext_sub(ext_sub(v[7], ab), v[2]), k2)));
+        acc = ext_add(ext_mul(u2, alpha), ext_mul(self_, ext_sub_base(v[3], k3)));
+        put(O_U1, u1); put(O_U2, u2); put(O_ACCO, acc);
+        pwr = pwn;
+        if (g + 1 == (size_t)sh.G) { res_yl = yl; res_yn = yn; res_acc = acc; }
+    }
+    scput(scc.YL, res_yl); scput(scc.YN, res_yn); scput(scc.ACC, res_acc);
+    if (!ext_eq(res_acc, ext_mul(quo, ext_sub_base(znn, MONTY_R1)))) return fail(ZKHIP_ERR_INTERNAL, "prove_shard_verifier: the AIR identity at zeta does not hold");
+    const int h_sc = m.height[C_SCALARS];
+    std::vector<uint32_t> t_sc((size_t)sc_w << h_sc);
+    for (size_t r = 0; r < ((size_t)1 << h_sc); r++) std::memcpy(t_sc.data() + sc_w * r, sc_row.data(), sc_w * 4);
+    // (e) ROWSUM
+    const int h_rs = m.height[C_ROWSUM];
+    std::vector<uint32_t> t_rs((size_t)RS_MAIN << h_rs, 0u);
+    std::vector<Ext> at((size_t)Q), aq((size_t)Q);
+    {
+        const size_t used = (size_t)Q * (size_t)(sh.WB + 1);
+        Ext a = ext_zero();
+        for (size_t r = 0; r < ((size_t)1 << h_rs); r++) {
+            uint32_t* row = t_rs.data() + (size_t)RS_MAIN * r;
+            put_ext(row, RS_FA, fa);
+            if (r >= used) continue;
+            int q, b;
+            rowsum_row(sh, r, &q, &b);
+            const uint32_t* vals = b == sh.WB ? pw + wt.q_trow(q) + (size_t)W + 8 * (size_t)H : pw + wt.q_trow(q) + 8 * (size_t)b;
+            if (b == sh.WB - 1 || b == sh.WB) a = ext_zero();
+            put_ext(row, RS_ACCIN, a);
+            for (int s = 7; s >= 0; s--) {
+                const uint32_t v = to_monty(vals[s]);
+                row[RS_V + s] = v;
+                a = ext_add_base(ext_mul(a, fa), v);
+                put_ext(row, RS_T + 4u * (uint32_t)s, a);
+            }
+            if (b == 0) at[(size_t)q] = a;
+            if (b == sh.WB) aq[(size_t)q] = a;
+        }
+    }
+    // (f) QUERY
+    constexpr QCols qc = qcols();
+    const int h_q = m.height[C_QUERY];
+    std::vector<uint32_t> t_q((size_t)Q_MAIN << h_q, 0u);
+    for (size_t r = 0; r < ((size_t)1 << h_q); r++) {
+        uint32_t* row = t_q.data() + (size_t)Q_MAIN * r;
+        auto put = [&](uint32_t col, const Ext& e) { put_ext(row, col - Q_PRE, e); };
+        put(qc.ZETA, zeta); put(qc.ZNX, znx); put(qc.YL, res_yl); put(qc.YN, res_yn); put(qc.YQ, yq); put(qc.OFFN, offn); put(qc.OFFQ, offq);
+        if (r >= (size_t)Q) continue;
+        const uint32_t index = wt.indices[r];
+        const uint32_t xq = fpow(two_adic_generator(H), reverse_bits(index, H));
+        const Ext x = ext_from_base(fmul(MONTY_GEN, xq));
+        const Ext i1 = ext_inv(ext_sub(x, zeta)), i2 = ext_inv(ext_sub(x, znx));
+        const Ext p1 = ext_mul(ext_sub(at[r], res_yl), i1), p2 = ext_mul(ext_sub(at[r], res_yn), i2), p2o = ext_mul(offn, p2);
+        const Ext p3 = ext_mul(ext_sub(aq[r], yq), i1), p3o = ext_mul(offq, p3), ro = ext_add(ext_add(p1, p2o), p3o);
+        for (int i = 0; i < 4; i++) if (from_monty(ro.c[i]) != wt.values[4 * r + (size_t)i]) return fail(ZKHIP_ERR_INTERNAL, "prove_shard_verifier: a reduced opening is not the verifier's");
+        row[qc.IDX - Q_PRE] = to_monty(index); row[qc.XQ - Q_PRE] = xq;
+        put(qc.RO, ro); put(qc.AT, at[r]); put(qc.AQ, aq[r]); put(qc.I1, i1); put(qc.I2, i2); put(qc.P1, p1); put(qc.P2, p2); put(qc.P2O, p2o); put(qc.P3, p3); put(qc.P3O, p3o);
+    }
+    // (g) TS
+    const TsCols tsc = ts_cols(sh);
+    const int h_ts = m.height[C_TS];
+    std::vector<uint32_t> t_ts((size_t)TS_MAIN << h_ts, 0u);
+    for (int T = 0; T < sh.NTS; T++) {
+        uint32_t* row = t_ts.data() + (size_t)TS_MAIN * (size_t)T;
+        for (int j = 0; j < 8; j++) row[j] = to_monty(chain_in[16 * (size_t)T + (size_t)j]);       // the absorbed words, and whatever the kept ones are
+        if (sh.has_challenge(T)) put_ext(row, 16, chal[(size_t)T]);
+    }
+    for (int j = 0; j < 8; j++) t_ts[8 + (size_t)j] = to_monty(pw[wt.o_troot + j]);
+    // (h) SAMPLES
+    std::vector<uint32_t> t_sm, drawn;
+    frichip::samples_main(R, (size_t)Q, m.height[C_SAMPLES], samples.data(), t_sm, drawn);
+    if (sh.PB && (samples[0] & ((1u << sh.PB) - 1u))) return fail(ZKHIP_ERR_INTERNAL, "prove_shard_verifier: the witness does not satisfy the proof of work");
+    if (std::memcmp(drawn.data(), wt.indices.data(), 4 * (size_t)Q) != 0) return fail(ZKHIP_ERR_INTERNAL, "prove_shard_verifier: the query indices are not the ones the transcript draws");
+    // (i) device: P2R rows (chains) and the fold rows
+    void* dev[N_CHIPS] = {nullptr};
+    const int slots[N_CHIPS] = {S_REC_A, S_REC_C, S_REC_B, S_REC_D, S_REC_E, S_REC_F, S_REC_G, S_REC_H};
+    const uint32_t w_main[N_CHIPS] = {P2_MAIN, RS_MAIN, frichip::width_of(R, true, true), TS_MAIN, Q_MAIN, OP_MAIN, frichip::S_MAIN, sc_w};
+    for (int c = 0; c < N_CHIPS; c++) ZK_TRY(ctx_reserve(ctx, slots[c], ((size_t)w_main[c] << m.height[c]) * 4, &dev[c]));
+    {
+        std::vector<uint32_t> finals(4 * (size_t)Q);
+        ZK_TRY(fri_gen_trace(ctx, R, (size_t)Q, wt.betas.data(), wt.indices.data(), wt.values.data(), wt.siblings.data(), m.height[C_FOLD], (uint32_t*)dev[C_FOLD],
+                             w_main[C_FOLD], finals.data(), true, true));
+        for (int q = 0; q < Q; q++) if (std::memcmp(finals.data() + 4 * (size_t)q, pw + wt.o_final, 16) != 0) return fail(ZKHIP_ERR_INTERNAL, "prove_shard_verifier: a chain does not end in the final value");
+    }
+    {
+        // chains: Q R FRI paths (leaf block = the pair), Q trace openings, Q quotient openings; data = [pairs | fri siblings | proof words]
+        const size_t n_chains = (size_t)Q * (size_t)R + 2 * (size_t)Q, per_q_paths = zkhip_fri_view_path_words(R);
+        std::vector<uint32_t> desc(6 * n_chains), data;
+        data.reserve(8 * (size_t)Q * (size_t)R + wt.paths.size() + words.size());
+        data.resize(8 * (size_t)Q * (size_t)R);
+        const size_t off_paths = data.size();
+        data.insert(data.end(), wt.paths.begin(), wt.paths.end());
+        const size_t off_words = data.size();
+        data.insert(data.end(), words.begin(), words.end());
+        size_t row = sh.p2_fri0, ch = 0;
+        for (int q = 0; q < Q; q++) {
+            uint32_t idx = wt.indices[(size_t)q];
+            Ext own = ext_canon(wt.values.data() + 4 * (size_t)q);
+            for (int l = 0; l < R; l++, ch++) {
+                const uint32_t bit = idx & 1u, k = idx >> 1;
+                const Ext sib = ext_canon(wt.siblings.data() + 4 * ((size_t)q * (size_t)R + (size_t)l));
+                const Ext e0 = bit ? sib : own, e1 = bit ? own : sib;
+                uint32_t* pair = data.data() + 8 * ch;
+                for (int i = 0; i < 4; i++) { pair[i] = from_monty(e0.c[i]); pair[4 + i] = from_monty(e1.c[i]); }
+                const int lh = H - (l + 1);
+                uint32_t* d = desc.data() + 6 * ch;
+                d[0] = (uint32_t)row; d[1] = 1; d[2] = (uint32_t)(8 * ch); d[3] = (uint32_t)lh; d[4] = k;
+                d[5] = (uint32_t)(off_paths + (size_t)q * per_q_paths + 8 * ((size_t)l * (size_t)R - (size_t)l * ((size_t)l - 1) / 2));
+                row += 1 + (size_t)lh;
+                const uint32_t xi = finv(fpow(two_adic_generator(lh + 1), reverse_bits(k, lh)));
+                const Ext beta = ext_canon(wt.betas.data() + 4 * (size_t)l);
+                own = ext_add(ext_mul_base(ext_add(e0, e1), MONTY_INV2), ext_mul(beta, ext_mul_base(ext_sub(e0, e1), fmul(MONTY_INV2, xi))));
+                idx = k;
+            }
+        }
+        for (int which = 0; which < 2; which++)
+            for (int q = 0; q < Q; q++, ch++) {
+                uint32_t* d = desc.data() + 6 * ch;
+                const size_t trow = wt.q_trow(q), tpath = trow + (size_t)W, qrow = tpath + 8 * (size_t)H, qpath = qrow + 8;
+                d[0] = (uint32_t)row; d[1] = which ? 1u : (uint32_t)sh.WB; d[2] = (uint32_t)(off_words + (which ? qrow : trow)); d[3] = (uint32_t)H; d[4] = wt.indices[(size_t)q];
+                d[5] = (uint32_t)(off_words + (which ? qpath : tpath));
+                row += (which ? 1 : (size_t)sh.WB) + (size_t)H;
+            }
+        if (row != sh.p2_rows || ch != n_chains) return fail(ZKHIP_ERR_INTERNAL, "prove_shard_verifier: row layout");
+        const size_t up_words = desc.size() + data.size() + chain_in.size(), down_words = 8 * n_chains;
+        void* stage;
+        ZK_TRY(ctx_reserve(ctx, S_STAGE, (up_words + down_words) * 4, &stage));
+        uint32_t* d = (uint32_t*)stage;
+        {
+            std::vector<uint32_t> up;
+            up.reserve(up_words);
+            up.insert(up.end(), desc.begin(), desc.end()); up.insert(up.end(), data.begin(), data.end()); up.insert(up.end(), chain_in.begin(), chain_in.end());
+            ZK_TRY(dev_h2d(ctx, d, up.data(), up_words * 4));
+        }
+        p2chip::P2RArgs a{};
+        a.desc = d; a.data = d + desc.size(); a.chain_inputs = d + desc.size() + data.size();
+        a.n_chains = (uint32_t)n_chains; a.n_transcript = (uint32_t)sh.NT; a.rows = (uint64_t)1 << m.height[C_P2R]; a.used_rows = sh.p2_rows;
+        a.trace = (uint32_t*)dev[C_P2R]; a.ld = P2_MAIN; a.roots = d + up_words;
+        ZK_HIP(launch_p2r_rows(a, ctx->stream));
+        std::vector<uint32_t> down(down_words);
+        ZK_TRY(dev_d2h(ctx, down.data(), a.roots, down_words * 4));
+        for (size_t c = 0; c < n_chains; c++) {
+            const uint32_t* want = c < (size_t)Q * (size_t)R ? wt.lroots.data() + 8 * (c % (size_t)R) : pw + (c < (size_t)Q * (size_t)R + (size_t)Q ? wt.o_troot : wt.o_qroot);
+            if (std::memcmp(down.data() + 8 * c, want, 32) != 0) return fail(ZKHIP_ERR_INTERNAL, "prove_shard_verifier: an opening does not end in its root");
+        }
+    }
+    // (j) the host tables up, then the machine's proof
+    const std::vector<uint32_t>* host[N_CHIPS] = {nullptr, &t_rs, nullptr, &t_ts, &t_q, &t_op, &t_sm, &t_sc};
+    for (int c = 0; c < N_CHIPS; c++) if (host[c]) ZK_TRY(dev_h2d(ctx, dev[c], host[c]->data(), host[c]->size() * 4));
+    zkhip_chip chips[N_CHIPS]{};
+    for (int i = 0; i < N_CHIPS; i++) {
+        const int c = m.order[i];
+        chips[i].d_trace = (const uint32_t*)dev[c]; chips[i].ld = w_main[c]; chips[i].log_n = m.height[c]; chips[i].width = w_main[c]; chips[i].partner = -1;
+    }
+    std::vector<uint32_t> pv(n_public);
+    for (size_t i = 0; i < n_public; i++) pv[i] = public_values[i] % P;
+    return zkhip_prove_machine_keyed(ctx, key, chips, m.progs, m.prog_words, m.tabs, m.tab_words, N_CHIPS, pv.data(), pv.size(), outer, proof, cap, len);
+}
+
+extern "C" {
+
+// the key of a SHAPE: the commitment to the eight chips' preprocessed columns -- no inner proof is involved
+int zkhip_shard_verifier_setup(zkhip_ctx* ctx, int log_n, uint32_t width, size_t n_queries, int inner_pow_bits, size_t n_public, const zkhip_params* outer,
+                               zkhip_machine_key** key, uint32_t vk[8]) {
+    using namespace zk::rec;
+    CHECK_CTX(ctx);
+    if (!outer || !key || !vk) return fail(ZKHIP_ERR_INVALID, "shard_verifier_setup: null argument");
+    Shape sh;
+    ZK_TRY(make_shape(log_n, width, n_queries, inner_pow_bits, n_public, sh));
+    const auto mp = machine_of(sh);
+    const Machine& m = *mp;
+    std::vector<uint32_t> pre[N_CHIPS];
+    p2r_pre(sh, m.height[C_P2R], pre[C_P2R]); rowsum_pre(sh, m.height[C_ROWSUM], pre[C_ROWSUM]); ts_pre(sh, m.height[C_TS], pre[C_TS]);
+    query_pre(sh, m.height[C_QUERY], pre[C_QUERY]); opened_pre(sh, m.height[C_OPENED], pre[C_OPENED]); scalars_pre(sh, m.height[C_SCALARS], pre[C_SCALARS]);
+    frichip::samples_pre(sh.R, (size_t)sh.Q, m.height[C_SAMPLES], pre[C_SAMPLES], sh.TP);
+    size_t total = 0;
+    for (int c = 0; c < N_CHIPS; c++) total += pre[c].size();
+    void* d;
+    ZK_TRY(ctx_reserve(ctx, S_REC_A, total * 4, &d));       // (staging: the key keeps its own copies)
+    zkhip_chip chips[N_CHIPS]{};
+    size_t at = 0;
+    for (int i = 0; i < N_CHIPS; i++) {
+        const int c = m.order[i];
+        chips[i].log_n = m.height[c]; chips[i].width = m.pre_widths[i]; chips[i].ld = m.pre_widths[i]; chips[i].partner = -1;
+        if (pre[c].empty()) continue;
+        ZK_TRY(dev_h2d(ctx, (uint32_t*)d + at, pre[c].data(), pre[c].size() * 4));
+        chips[i].d_trace = (const uint32_t*)d + at;
+        at += pre[c].size();
+    }
+    return zkhip_machine_setup(ctx, chips, N_CHIPS, outer, key, vk);
+}
+
+size_t zkhip_shard_verifier_proof_size(int log_n, uint32_t width, size_t n_queries, int inner_pow_bits, size_t n_public, const zkhip_params* outer) {
+    using namespace zk::rec;
+    Shape sh;
+    if (!outer || make_shape(log_n, width, n_queries, inner_pow_bits, n_public, sh) != ZKHIP_OK) return 0;
+    const auto m = machine_of(sh);
+    return zkhip_machine_proof_size_keyed(m->log_ns, m->widths, m->pre_widths, m->progs, m->prog_words, m->tabs, m->tab_words, N_CHIPS, outer, n_public);
+}
+
+int zkhip_prove_shard_verifier(zkhip_ctx* ctx, const zkhip_machine_key* key, const uint8_t* shard_proof, size_t shard_proof_len, int log_n, uint32_t width,
+                               const uint32_t* public_values, size_t n_public, const zkhip_params* inner, const zkhip_params* outer, uint8_t* proof, size_t cap, size_t* len) {
+    return shard_verifier_prove_impl(ctx, key, shard_proof, shard_proof_len, log_n, width, public_values, n_public, inner, outer, proof, cap, len);
+}
+
+// The verifier of the outer proof: the shape of the inner proof, ITS public values, the key of the shape.  No byte of the inner proof.
+int zkhip_verify_shard_recursive(const uint8_t* proof, size_t len, int log_n, uint32_t width, size_t n_queries, int inner_pow_bits, const uint32_t* public_values,
+                                 size_t n_public, const uint32_t vk[8], const zkhip_params* outer, int* reason) {
+    using namespace zk::rec;
+    Shape sh;
+    if (!proof || !vk || !outer || (n_public && !public_values) || make_shape(log_n, width, n_queries, inner_pow_bits, n_public, sh) != ZKHIP_OK) {
+        if (reason) *reason = 1;
+        return fail(ZKHIP_ERR_VERIFY, "verify_shard_recursive: bad arguments");
+    }
+    const auto m = machine_of(sh);
+    std::vector<uint32_t> pv(n_public);
+    for (size_t i = 0; i < n_public; i++) pv[i] = public_values[i];
+    return zkhip_verify_machine_keyed(proof, len, m->log_ns, m->widths, m->pre_widths, vk, m->progs, m->prog_words, m->tabs, m->tab_words, N_CHIPS, pv.data(), pv.size(), outer, reason);
+}
+
+// the machine as data (tests compare with tests/recursion_air.py word for word): which = position (tallest chip first); kind 0 = the chip's
+// program, 1 = its interaction table, 2 = its preprocessed trace (canonical words, row-major); *log_rows, *main_width, *pre_width describe the chip
+size_t zkhip_shard_verifier_describe(int log_n, uint32_t width, size_t n_queries, int inner_pow_bits, size_t n_public, int which, int kind, uint32_t* out, size_t cap_words,
+                                     int* log_rows, uint32_t* main_width, uint32_t* pre_width) {
+    using namespace zk::rec;
+    Shape sh;
+    if (which < 0 || which >= N_CHIPS || kind < 0 || kind > 2 || make_shape(log_n, width, n_queries, inner_pow_bits, n_public, sh) != ZKHIP_OK) return 0;
+    const auto m = machine_of(sh);
+    if (log_rows) *log_rows = m->log_ns[which];
+    if (main_width) *main_width = m->widths[which];
+    if (pre_width) *pre_width = m->pre_widths[which];
+    std::vector<uint32_t> pre;
+    const std::vector<uint32_t>* src = kind == 0 ? &m->prog[which] : &m->tab[which];
+    if (kind == 2) {
+        const int c = m->order[which], h = m->height[c];
+        switch (c) {
+            case C_P2R: p2r_pre(sh, h, pre); break;
+            case C_ROWSUM: rowsum_pre(sh, h, pre); break;
+            case C_TS: ts_pre(sh, h, pre); break;
+            case C_QUERY: query_pre(sh, h, pre); break;
+            case C_OPENED: opened_pre(sh, h, pre); break;
+            case C_SAMPLES: frichip::samples_pre(sh.R, (size_t)sh.Q, h, pre, sh.TP); break;
+            case C_SCALARS: scalars_pre(sh, h, pre); break;
+            default: break;
+        }
+        for (uint32_t& v : pre) v = from_monty(v);
+        src = &pre;
+    }
+    if (out && cap_words >= src->size()) std::memcpy(out, src->data(), src->size() * 4);
+    return src->size();
+}
+
+}  // extern "C"
