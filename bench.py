@@ -91,6 +91,9 @@ def main():
                          "ZKHIP_LOGICAL_DEVICES=K, whose device ordinals 0..K-1 are logical devices on the physical ones (own pools, own workers, "
                          "traces checked to live where their shard is dealt); the line says so and is not a scaling result")
     ap.add_argument("--no-multichip", action="store_true", help="skip the multi-chip shard with LogUp pairs (SP1's shard structure, rows a7 mixed heights + a8) measured beside the headline")
+    ap.add_argument("--no-fri-graph", action="store_true",
+                    help="zkhip_set_fri_graph(0): the FRI commit phase as plain launches instead of one hipGraphLaunch per proof -- for runs under "
+                         "`rocprofv3 --kernel-trace`, which crashes on hipGraphLaunch from worker threads (tools/segv, profiles/r04_segv.md); same proof bytes")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--wait", choices=("auto", "poll", "block"), default="auto",
                     help="how the prover's host threads wait for their streams (zkhip_set_wait_mode): poll = hipStreamSynchronize, block = sleep "
@@ -150,6 +153,8 @@ def main():
     if wait_rc != 0 and wait_block:
         sys.stderr.write("bench.py: blocking waits could not be set (%d): polling\n" % wait_rc)
         wait_block = False
+    if args.no_fri_graph:
+        zk_lib.load().zkhip_set_fri_graph(0)
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: libzkhip has no CPU path")
     if args.share_gpu:
@@ -660,8 +665,28 @@ def main():
             rec = prove_fri_indices_batch(sps, log_n, width, spv, prm, prm, devices=[local_rank])
             t_rec = min(t_rec, time.perf_counter() - tb0)
         ok_rec = all(verify_fri_indices(p, fin, cap, log_n, prm.num_queries, prm.pow_bits, vk, prm) == (0, 0) for p, vk, fin, cap in rec)
-        recursion16 = {"workload": "the FRI check of 16 shard proofs (2^%d x %d, 100 queries x %d layers each) proven in-circuit: Poseidon2 chip (Merkle paths + transcript) + FRI-fold chip + SAMPLES chip + two tables per proof, one zkhip_prove_fri_indices_batch call, shard proofs in as bytes (host view included)" % (log_n, width, log_n),
-                       "ms": round(t_rec * 1e3, 2), "recursion_proofs_per_s": round(16 / t_rec, 1), "proof_bytes": int(rec[0][0].size), "all_verified": bool(ok_rec)}
+        # ... and THE JOIN: the same sixteen shard proofs verified WHOLE (transcript, AIR identity at zeta, every opening, reduced openings, FRI, proof
+        # of work) by ONE outer proof whose verifier takes the 16 x n_public public values and the shape's key -- no byte of an inner proof
+        from zktls_amd.device import verify_shard_recursive
+        set_lockstep(16, 6)
+        jkey = ctx.shard_verifier_setup(log_n, width, prm.num_queries, prm.pow_bits, len(spv[0]), prm, n_proofs=16)
+        ctx.prove_shard_verifier(jkey, sps, log_n, width, spv, prm, prm)
+        t_join, joined = 1e9, None
+        for _ in range(3):
+            tb0 = time.perf_counter()
+            joined = ctx.prove_shard_verifier(jkey, sps, log_n, width, spv, prm, prm)
+            t_join = min(t_join, time.perf_counter() - tb0)
+        tb0 = time.perf_counter()
+        ok_join = verify_shard_recursive(joined, log_n, width, prm.num_queries, prm.pow_bits, [v for pv_ in spv for v in pv_], jkey.root, prm, n_proofs=16) == (0, 0)
+        t_join_verify = time.perf_counter() - tb0
+        join16 = {"workload": "16 shard proofs (2^%d x %d, 100 queries) -> 1 proof: zkhip_prove_shard_verifier with n_proofs = 16 (eight chips; the Poseidon2 chip has %s rows), shard proofs in as bytes" % (log_n, width, "2^19" if log_n == 20 and width == 256 else "fewer"),
+                  "ms": round(t_join * 1e3, 2), "ms_per_inner_proof": round(t_join * 1e3 / 16, 3), "inner_bytes_total": int(sum(p_.size for p_ in sps)), "outer_bytes": int(joined.size),
+                  "compression": round(sum(p_.size for p_ in sps) / joined.size, 2), "host_verify_ms": round(t_join_verify * 1e3, 2), "verified": bool(ok_join),
+                  "verifier_inputs": "shape, 16 x %d public values, the shape's key (8 words); no byte of an inner proof" % len(spv[0])}
+        jkey.close()
+        recursion16 = {"join16": join16, "fri_only_workload": "the FRI check of 16 shard proofs (2^%d x %d, 100 queries x %d layers each) proven in-circuit: Poseidon2 chip (Merkle paths + transcript) + FRI-fold chip + SAMPLES chip + two tables per proof, one zkhip_prove_fri_indices_batch call, shard proofs in as bytes (host view included)" % (log_n, width, log_n),
+                       "fri_only_ms": round(t_rec * 1e3, 2), "fri_only_proof_bytes": int(rec[0][0].size), "fri_only_all_verified": bool(ok_rec),
+                       "ms": round(t_join * 1e3, 2), "recursion_proofs_per_s": round(16 / t_join, 1), "proof_bytes": int(joined.size), "all_verified": bool(ok_join)}
 
     # ---- SP1's real shard structure beside the headline: six chips of different heights in ONE proof (mixed-height commitments, row a7)
     # with in-table LogUp pairs (permutation traces + their commitment, row a8), proven with the same number of shards in flight
@@ -743,7 +768,7 @@ def main():
             "data": "synthetic",
             "streams_per_gpu": in_flight, "host_wait": "block" if wait_block else "poll", "host_cores_usable": cores_ok,
             "host_cores_busy_per_rank": round(host_cores_busy, 2),
-            "one_process_mode": bool(one_proc), "logical_devices_test_mode": int(args.logical_devices),
+            "fri_commit_phase_as_hip_graph": (not args.no_fri_graph), "one_process_mode": bool(one_proc), "logical_devices_test_mode": int(args.logical_devices),
             "rccl_world_size": (dist.get_world_size() if dist is not None else 1),
             "collective_backend": (dist.get_backend() if dist is not None else None), "rccl_selfcheck_calls": rccl_calls,
             "share_gpu_test_mode": bool(args.share_gpu),

@@ -613,6 +613,11 @@ void zkhip_lockstep_stats(uint64_t out[6]);
 /* the most bytes of a member's (fiber's) 2 MiB stack touched so far in this process, page granularity (guard pages at both ends of
  * every stack turn an overflow into a fault; this says how far from it the provers run).  0 before the first lock-step batch. */
 uint64_t zkhip_lockstep_stack_high_water(void);
+/* The FRI commit phase of a proof outside lock-step batches is a fixed sequence of ~250 small launches, captured once per shape into a HIP
+ * graph and replayed with one hipGraphLaunch per proof (csrc/prover.cpp).  on = 0 keeps the plain launches, process-wide (default on; same
+ * proof bytes).  The switch exists for runs under `rocprofv3 --kernel-trace`, whose interception crashes (SIGSEGV) on hipGraphLaunch from
+ * worker threads -- with no code of this library involved: tools/segv/repro_nolib g, profiles/r04_segv.md. */
+void zkhip_set_fri_graph(int on);
 
 /* A second real chip: the width-16 Poseidon2 permutation with Merkle-path chaining -- what a recursion machine (a STARK verifier proven
  * inside a STARK: the compress / shrink / wrap stages behind SP1ProofMode::Groth16, crates/guest-prover-sp1/src/sp1.rs:116; sp1-recursion's
@@ -773,16 +778,22 @@ int zkhip_prove_fri_indices_batch(const int* devices, int n_devices, zkhip_fri_j
  * proof's SHAPE alone.  Statement of an outer proof: "a shard proof of this shape exists that the verifier accepts for these public
  * values".  zkhip_verify_shard_recursive takes the shape, the inner proof's public values and the key -- no byte of the inner proof.
  * zkhip_shard_verifier_describe hands out the machine as data (position `which`, tallest chip first; kind 0 program, 1 interaction table,
- * 2 preprocessed trace as canonical words): tests/recursion_air.py writes the same independently, the words are compared. */
-int zkhip_shard_verifier_setup(zkhip_ctx* ctx, int log_n, uint32_t width, size_t n_queries, int inner_pow_bits, size_t n_public, const zkhip_params* outer,
+ * 2 preprocessed trace as canonical words): tests/recursion_air.py writes the same independently, the words are compared.
+ * THE JOIN: n_proofs > 1 makes ONE outer proof verify that many inner proofs of the shape (every chip holds proof 0's rows, then proof 1's, ...;
+ * tags, tree numbers and query numbers carry the proof's number; the SCALARS chip has one row per proof).  public_values = those of proof
+ * 0, then those of proof 1, ... (n_proofs x n_public words), which are the outer proof's public values.  Sixteen headline shard proofs
+ * (15 MB) become one proof of about a megabyte.  (A TREE of joins would need a verifier of THIS machine's proofs -- version 11, lookups and
+ * all -- in-circuit; that is not built: the join is flat, bounded by the 2^22-row limit of the Poseidon2 chip, i.e. 64 headline proofs.) */
+int zkhip_shard_verifier_setup(zkhip_ctx* ctx, int log_n, uint32_t width, size_t n_queries, int inner_pow_bits, size_t n_public, size_t n_proofs, const zkhip_params* outer,
                                zkhip_machine_key** key, uint32_t vk[8]);
-size_t zkhip_shard_verifier_proof_size(int log_n, uint32_t width, size_t n_queries, int inner_pow_bits, size_t n_public, const zkhip_params* outer);
-int zkhip_prove_shard_verifier(zkhip_ctx* ctx, const zkhip_machine_key* key, const uint8_t* shard_proof, size_t shard_proof_len, int log_n, uint32_t width,
-                               const uint32_t* public_values, size_t n_public, const zkhip_params* inner, const zkhip_params* outer, uint8_t* proof, size_t cap, size_t* len);
+size_t zkhip_shard_verifier_proof_size(int log_n, uint32_t width, size_t n_queries, int inner_pow_bits, size_t n_public, size_t n_proofs, const zkhip_params* outer);
+int zkhip_prove_shard_verifier(zkhip_ctx* ctx, const zkhip_machine_key* key, const uint8_t* const* shard_proofs, const size_t* shard_proof_lens, size_t n_proofs, int log_n,
+                               uint32_t width, const uint32_t* public_values, size_t n_public, const zkhip_params* inner, const zkhip_params* outer, uint8_t* proof, size_t cap,
+                               size_t* len);
 int zkhip_verify_shard_recursive(const uint8_t* proof, size_t len, int log_n, uint32_t width, size_t n_queries, int inner_pow_bits, const uint32_t* public_values,
-                                 size_t n_public, const uint32_t vk[8], const zkhip_params* outer, int* reason);
-size_t zkhip_shard_verifier_describe(int log_n, uint32_t width, size_t n_queries, int inner_pow_bits, size_t n_public, int which, int kind, uint32_t* out, size_t cap_words,
-                                     int* log_rows, uint32_t* main_width, uint32_t* pre_width);
+                                 size_t n_public, size_t n_proofs, const uint32_t vk[8], const zkhip_params* outer, int* reason);
+size_t zkhip_shard_verifier_describe(int log_n, uint32_t width, size_t n_queries, int inner_pow_bits, size_t n_public, size_t n_proofs, int which, int kind, uint32_t* out,
+                                     size_t cap_words, int* log_rows, uint32_t* main_width, uint32_t* pre_width);
 
 /* ---- Poseidon2 parameter tables from a file: the built-in sets are this repo's own
  * ("zktls-amd/p2-bb16-v1", "...-bb24-v1"; the SP1 / RISC Zero tables of reference Cargo.lock:4030, 6172, 5057 are not

@@ -148,18 +148,18 @@ extern "C" {
     pub fn zkhip_set_lockstep(max_batch: c_int, lanes: c_int);
     pub fn zkhip_lockstep_stats(out: *mut u64);
     pub fn zkhip_lockstep_stack_high_water() -> u64;
-    // the shard verifier as a machine: a whole shard proof checked in-circuit; the key is a function of the inner proof's shape
-    pub fn zkhip_shard_verifier_setup(ctx: *mut ZkhipCtx, log_n: c_int, width: u32, n_queries: usize, inner_pow_bits: c_int, n_public: usize, outer: *const ZkhipParams,
-                                      key: *mut *mut ZkhipMachineKey, vk: *mut u32) -> c_int;
-    pub fn zkhip_shard_verifier_proof_size(log_n: c_int, width: u32, n_queries: usize, inner_pow_bits: c_int, n_public: usize, outer: *const ZkhipParams) -> usize;
-    pub fn zkhip_prove_shard_verifier(ctx: *mut ZkhipCtx, key: *const ZkhipMachineKey, shard_proof: *const u8, shard_proof_len: usize, log_n: c_int, width: u32,
-                                      public_values: *const u32, n_public: usize, inner: *const ZkhipParams, outer: *const ZkhipParams, proof: *mut u8, cap: usize,
-                                      len: *mut usize) -> c_int;
+    pub fn zkhip_set_fri_graph(on: c_int);
+    // the shard verifier as a machine: whole shard proofs checked in-circuit (n_proofs of them by ONE outer proof); the key is a function of the shape
+    pub fn zkhip_shard_verifier_setup(ctx: *mut ZkhipCtx, log_n: c_int, width: u32, n_queries: usize, inner_pow_bits: c_int, n_public: usize, n_proofs: usize,
+                                      outer: *const ZkhipParams, key: *mut *mut ZkhipMachineKey, vk: *mut u32) -> c_int;
+    pub fn zkhip_shard_verifier_proof_size(log_n: c_int, width: u32, n_queries: usize, inner_pow_bits: c_int, n_public: usize, n_proofs: usize, outer: *const ZkhipParams) -> usize;
+    pub fn zkhip_prove_shard_verifier(ctx: *mut ZkhipCtx, key: *const ZkhipMachineKey, shard_proofs: *const *const u8, shard_proof_lens: *const usize, n_proofs: usize,
+                                      log_n: c_int, width: u32, public_values: *const u32, n_public: usize, inner: *const ZkhipParams, outer: *const ZkhipParams,
+                                      proof: *mut u8, cap: usize, len: *mut usize) -> c_int;
     pub fn zkhip_verify_shard_recursive(proof: *const u8, len: usize, log_n: c_int, width: u32, n_queries: usize, inner_pow_bits: c_int, public_values: *const u32,
-                                        n_public: usize, vk: *const u32, outer: *const ZkhipParams, reason: *mut c_int) -> c_int;
-    pub fn zkhip_shard_verifier_describe(log_n: c_int, width: u32, n_queries: usize, inner_pow_bits: c_int, n_public: usize, which: c_int, kind: c_int, out: *mut u32,
-                                         cap_words: usize, log_rows: *mut c_int, main_width: *mut u32, pre_width: *mut u32) -> usize;
-    pub fn zkhip_selftest_lockstep(members: c_int, rounds: c_int) -> c_int;
+                                        n_public: usize, n_proofs: usize, vk: *const u32, outer: *const ZkhipParams, reason: *mut c_int) -> c_int;
+    pub fn zkhip_shard_verifier_describe(log_n: c_int, width: u32, n_queries: usize, inner_pow_bits: c_int, n_public: usize, n_proofs: usize, which: c_int, kind: c_int,
+                                         out: *mut u32, cap_words: usize, log_rows: *mut c_int, main_width: *mut u32, pre_width: *mut u32) -> usize;
     // the Poseidon2 permutation chip: Merkle openings (of whole rows when row_width > 0) proven in-circuit
     pub fn zkhip_p2chip_air(program: *mut u32, cap_words: usize) -> usize;
     pub fn zkhip_merkle_paths_proof_size(n_paths: usize, depth: c_int, row_width: u32, prm: *const ZkhipParams) -> usize;

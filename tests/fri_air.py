@@ -23,7 +23,8 @@ BUS_S0, BUS_S1, BUS_I = 47, 48, 49             # the query-phase machine: the sa
 S_PRE, S_C, S_ROW, S_ACT, S_POW, S_KQ = 20, 0, 1, 2, 10, 11
 S_W, S_IDX, S_H1, S_H2, S_HH, S_BITS, S_MAIN = 0, 8, 16, 24, 32, 40, 288
 K2, IDX, L_WIRED = 32, 33, 34                  # the wired form's extra columns, its layer selectors start two columns later
-XS, L_REC = 34, 35                             # the recursion machine's form (tests/recursion_air.py): XS = X (1 - 2 BIT), the query's point / g on its first row
+XS, PT, LNX, L_REC = 34, 35, 36, 37            # the recursion machine's form (tests/recursion_air.py): XS = X (1 - 2 BIT), the query's point / g on its first row;
+#                                                PT = (number of the inner proof) x (its trees), constant along a chain; LNX = PT + LN names the layer's tree on the buses
 BUS_FIN = 60                                   # ... whose END rows send their folded value (the final value is an observed word of the transcript, no public value)
 QUERIES_PRE, ROOTS_PRE = 8, 12
 OPEN_PRE, OPEN_MAIN = 12, 4
@@ -105,6 +106,8 @@ def program(layers, wired=False, transcript=False, rec=None):
         add(O.SEL_ALL, [(1, [V(IDX)]), (P - 1, [V(K2)]), (P - 1, [V(BIT)])])
     if rec is not None:
         add(O.SEL_ALL, [(1, [V(XS)]), (P - 1, [V(X)]), (2, [V(X), V(BIT)])])
+        add(O.SEL_ALL, [(1, [V(LNX)]), (P - 1, [V(PT)]), (P - 1, [V(LN)])])
+        add(O.SEL_TRANSITION, gated([(1, [V(PT)]), (P - 1, [V(PT, True)])]))
         return O.air_program(width_of(R, rec=True), rec, cons)
     return O.air_program(width_of(R, wired), N_PUBLIC_T if transcript else n_public_of(R), cons)
 
@@ -125,7 +128,7 @@ def log_rows_of(layers, n_queries):
     return lr
 
 
-def trace(view, log_rows=None, wired=False, rec=False):
+def trace(view, log_rows=None, wired=False, rec=False, pt=0):
     """-> (trace [2^log_rows][width] canonical, final value): one row per (query, layer), padding rows zero with T = 1"""
     betas, queries = view["betas"], view["queries"]
     R = len(betas)
@@ -155,6 +158,7 @@ def trace(view, log_rows=None, wired=False, rec=False):
                 row[K2], row[IDX] = 2 * k, 2 * k + bit
             if rec:
                 row[XS] = (P - x) % P if bit else x
+                row[PT], row[LNX] = pt, pt + l
             own, idx = fold, k
         acc = root_const(R) if idx else 1
         for l in reversed(range(R)):

@@ -33,7 +33,7 @@ GEN, EXT_W = 31, 11
 SEND, RECV = O.SEND, O.RECEIVE
 # buses (F.BUS_E0 / E1 / R0 / R1 / Q / S0 / S1 / I keep their meaning from tests/fri_air.py)
 BUS_IN0, BUS_IN1, BUS_TC, BUS_BETA, BUS_SC, BUS_QI, BUS_AT, BUS_AQ = 61, 62, 63, 64, 65, 66, 67, 68
-BUS_K0, BUS_K1, BUS_K2, BUS_K3, BUS_KFA, BUS_KO0, BUS_KO1, BUS_KO2, BUS_OY, BUS_OA = 70, 71, 72, 73, 74, 75, 76, 77, 78, 79
+BUS_K0, BUS_KFA, BUS_KO0, BUS_OY, BUS_OA = 70, 77, 78, 83, 85               # K0 .. K0 + 6: the QUERY chip's seven constants; KO0 .. KO0 + 4: the OPENED chip's five; OY, OY + 1
 BUS_FIN = F.BUS_FIN
 
 
@@ -151,10 +151,12 @@ def lg(n, lo=5):
 
 # ---------------------------------------------------------------------------------------------------------------- the shape of an inner proof
 class Shape:
-    """everything the machine's structure depends on: (log_n, width, queries, pow_bits, n_public) of a version-1 shard proof"""
-    def __init__(self, log_n, width, n_queries, pow_bits, n_public):
-        assert width % 8 == 0 and width >= 8 and 2 <= log_n <= 22 and n_queries >= 1
-        self.n, self.W, self.Q, self.PB, self.NPUB = log_n, width, n_queries, pow_bits, n_public
+    """everything the machine's structure depends on: (log_n, width, queries, pow_bits, n_public) of a version-1 shard proof, and how many
+    such proofs ONE outer proof verifies (n_proofs: the join -- every chip holds the rows of proof 0, then those of proof 1, ...; tags, tree
+    numbers and query numbers carry the proof's number)"""
+    def __init__(self, log_n, width, n_queries, pow_bits, n_public, n_proofs=1):
+        assert width % 8 == 0 and width >= 8 and 2 <= log_n <= 22 and n_queries >= 1 and 1 <= n_proofs <= 64
+        self.n, self.W, self.Q, self.PB, self.NPUB, self.NP = log_n, width, n_queries, pow_bits, n_public, n_proofs
         self.R, self.H, self.G, self.WB = log_n, log_n + 1, width // 4, width // 8
         self.head = [log_n, width, 1, n_queries, pow_bits, n_public]           # the header words the transcript observes
         n0 = 6 + 8 + n_public
@@ -176,9 +178,14 @@ class Shape:
         self.p2_q0 = self.p2_tr0 + self.Q * (self.WB + self.H)                 # quotient openings: 1 sponge row + H path rows
         self.p2_rows = self.p2_q0 + self.Q * (1 + self.H)
         self.tag0 = self.NT                                                    # ROWSUM tags follow the transcript's
+        self.TAGSPAN = self.NT + self.Q * (self.WB + 1)                        # tags of one proof
+        self.TREES = self.R + 2                                                # trees of one proof: the FRI layers, the trace, the quotient
 
-    def row_tag(self, q, b):
-        return self.tag0 + q * (self.WB + 1) + b                              # b = WB: the quotient row
+    def ttag(self, p, T):
+        return p * self.TAGSPAN + T
+
+    def row_tag(self, p, q, b):
+        return p * self.TAGSPAN + self.tag0 + q * (self.WB + 1) + b            # b = WB: the quotient row
 
 
 def absorbed(sh, T):
@@ -219,7 +226,7 @@ def p2r_program(sh):
         cons.add(O.SEL_TRANSITION, pmul(pv(PP_K + j, True), padd(pv(IN + j, True), pneg(pv(OUT + j)))))
     cons.add(O.SEL_TRANSITION, pmul(pv(PP_CH, True), padd(pv(KP), pscale(pv(KP, True), P - 2), pneg(pv(BIT)))))
     cons.add(O.SEL_ALL, pmul(pv(PP_END), padd(pv(KP), pneg(pv(BIT)))))
-    return O.air_program(P2_PRE + P2_MAIN, sh.NPUB, cons.c)
+    return O.air_program(P2_PRE + P2_MAIN, sh.NP * sh.NPUB, cons.c)
 
 
 def p2r_table():
@@ -237,6 +244,12 @@ def p2r_table():
 def p2r_pre(sh, log_rows):
     """the structure of the chip: fixed by the shape"""
     t = np.zeros((1 << log_rows, P2_PRE), dtype=np.uint32)
+    for p in range(sh.NP):
+        _p2r_pre_one(sh, t[p * sh.p2_rows:(p + 1) * sh.p2_rows], p)
+    return t
+
+
+def _p2r_pre_one(sh, t, p):
     for T in range(sh.NT):
         r = t[T]
         k = absorbed(sh, T)
@@ -246,7 +259,7 @@ def p2r_pre(sh, log_rows):
             r[PP_SPG] = 1
             for j in range(k, 8):
                 r[PP_K + j] = 1
-        r[PP_TAG] = T
+        r[PP_TAG] = sh.ttag(p, T)
         if k:
             r[PP_RIN] = 1
         if T in (sh.TA, sh.TQ, sh.TF) or sh.TL0 <= T < sh.TP:
@@ -256,11 +269,11 @@ def p2r_pre(sh, log_rows):
     row = sh.p2_fri0
     for q in range(sh.Q):
         for l in range(sh.R):
-            t[row, PP_SS], t[row, PP_RPAIR], t[row, PP_TREE] = 1, 1, l
+            t[row, PP_SS], t[row, PP_RPAIR], t[row, PP_TREE] = 1, 1, p * sh.TREES + l
             row += 1
             depth = sh.H - (l + 1)
             for lvl in range(depth):
-                t[row, PP_CH], t[row, PP_TREE] = 1, l
+                t[row, PP_CH], t[row, PP_TREE] = 1, p * sh.TREES + l
                 if lvl == depth - 1:
                     t[row, PP_END] = t[row, PP_SROOT] = 1
                 row += 1
@@ -269,17 +282,16 @@ def p2r_pre(sh, log_rows):
         for q in range(sh.Q):
             for b in range(blocks):
                 t[row, PP_SS if b == 0 else PP_SPG] = 1
-                t[row, PP_RIN], t[row, PP_TAG] = 1, sh.row_tag(q, b if tree == sh.R else sh.WB)
+                t[row, PP_RIN], t[row, PP_TAG] = 1, sh.row_tag(p, q, b if tree == sh.R else sh.WB)
                 row += 1
             for lvl in range(sh.H):
-                t[row, PP_CH], t[row, PP_TREE] = 1, tree
+                t[row, PP_CH], t[row, PP_TREE] = 1, p * sh.TREES + tree
                 if lvl == 0:
-                    t[row, PP_QIDX], t[row, PP_QN] = 1, q
+                    t[row, PP_QIDX], t[row, PP_QN] = 1, p * sh.Q + q
                 if lvl == sh.H - 1:
                     t[row, PP_END] = t[row, PP_SROOT] = 1
                 row += 1
     assert row == sh.p2_rows
-    return t
 
 
 def _p2row(state, bit=0, kp=0):
@@ -287,8 +299,20 @@ def _p2row(state, bit=0, kp=0):
     return r[:M_KP] + [kp % P] + [0] * 7, out                                    # (the old chip's flag columns behind BIT are not this chip's)
 
 
-def p2r_main(sh, w, log_rows):
-    """w = the witness (see witness()) -> (main trace, sampled words [NS][8], challenges {T: out[7..4]})"""
+def p2r_main(sh, ws, log_rows):
+    """ws = the witnesses, one per inner proof (see witness()) -> (main trace, per proof: sampled words [NS][8], challenges {T: out[7..4]})"""
+    rows, samples, chals = [], [], []
+    for w in ws:
+        r, s, c = _p2r_main_one(sh, w)
+        rows += r
+        samples.append(s)
+        chals.append(c)
+    pad, _ = _p2row([0] * 16)
+    rows += [pad] * ((1 << log_rows) - len(rows))
+    return np.array(rows, dtype=np.uint64).astype(np.uint32), samples, chals
+
+
+def _p2r_main_one(sh, w):
     rows, chal, samples = [], {}, []
     state = [0] * 16
     for T in range(sh.NT):
@@ -330,16 +354,14 @@ def p2r_main(sh, w, log_rows):
                 digest = out[:8]
             assert digest == root, "an opening does not end in its root"
     assert len(rows) == sh.p2_rows
-    pad, _ = _p2row([0] * 16)
-    rows += [pad] * ((1 << log_rows) - len(rows))
-    return np.array(rows, dtype=np.uint64).astype(np.uint32), samples, chal
+    return rows, samples, chal
 
 
 # ---------------------------------------------------------------------------------------------------------------- TS
 def ts_cols(sh):
     c = Cols()
-    for name, w in (("T", 1), ("ACT", 1), ("NSEND", 1), ("CF", 8), ("CV", 8), ("IND0", 1), ("IP", len(sh.pub_rows)), ("NROOT", 1), ("NTR", 1), ("TREE", 1),
-                    ("HASCH", 1), ("NBETA", 1), ("NSC", 1), ("KIND", 1), ("NFIN", 1)):
+    for name, w in (("T", 1), ("ACT", 1), ("NSEND", 1), ("CF", 8), ("CV", 8), ("IND0", 1), ("IP", sh.NP * len(sh.pub_rows)), ("NROOT", 1), ("NTR", 1), ("TREE", 1),
+                    ("HASCH", 1), ("NBETA", 1), ("NSC", 1), ("KIND", 1), ("NFIN", 1), ("PT", 1)):
         c(name, w)
     pre = rup4(c.n)
     m = Cols(pre)
@@ -356,14 +378,16 @@ def ts_program(sh):
     W, TR = m["W"], m["TR"]
     for j in range(8):
         cons.add(O.SEL_ALL, pmul(pv(c["CF"] + j), padd(pv(W + j), pneg(pv(c["CV"] + j)))))
-    for i in range(sh.NPUB):
-        pos = 14 + i
-        cons.add(O.SEL_ALL, pmul(pv(c["IP"] + sh.pub_rows.index(pos // 8)), padd(pv(W + pos % 8), [(P - 1, [V(i, public=True)])])))
+    npr = len(sh.pub_rows)
+    for p in range(sh.NP):                                                      # the outer proof's public values: those of proof 0, then those of proof 1, ...
+        for i in range(sh.NPUB):
+            pos = 14 + i
+            cons.add(O.SEL_ALL, pmul(pv(c["IP"] + p * npr + sh.pub_rows.index(pos // 8)), padd(pv(W + pos % 8), [(P - 1, [V(p * sh.NPUB + i, public=True)])])))
     cons.add(O.SEL_ALL, pmul(pv(c["IND0"]), padd(pv(W + 6), pneg(pv(TR)))))
     cons.add(O.SEL_ALL, pmul(pv(c["IND0"]), padd(pv(W + 7), pneg(pv(TR + 1)))))
     for j in range(6):
         cons.add(O.SEL_TRANSITION, pmul(pv(c["IND0"]), padd(pv(W + j, True), pneg(pv(TR + 2 + j)))))
-    return O.air_program(pre + TS_MAIN, sh.NPUB, cons.c)
+    return O.air_program(pre + TS_MAIN, sh.NP * sh.NPUB, cons.c)
 
 
 def ts_table(sh):
@@ -376,49 +400,54 @@ def ts_table(sh):
         (SEND, c["NSC"], BUS_SC, [c["KIND"], CH, CH + 1, CH + 2, CH + 3]),
         (RECV, c["NROOT"], F.BUS_R0, [c["TREE"], W, W + 1, W + 2, W + 3]), (RECV, c["NROOT"], F.BUS_R1, [c["TREE"], W + 4, W + 5, W + 6, W + 7]),
         (RECV, c["NTR"], F.BUS_R0, [c["TREE"], TR, TR + 1, TR + 2, TR + 3]), (RECV, c["NTR"], F.BUS_R1, [c["TREE"], TR + 4, TR + 5, TR + 6, TR + 7]),
-        (RECV, c["NFIN"], BUS_FIN, [W, W + 1, W + 2, W + 3])])
+        (RECV, c["NFIN"], BUS_FIN, [c["PT"], W, W + 1, W + 2, W + 3])])
 
 
 def ts_pre(sh, log_rows):
     c, _, pre = ts_cols(sh)
     t = np.zeros((1 << log_rows, pre), dtype=np.uint32)
-    for T in range(sh.NTS):
-        r = t[T]
-        r[c["T"]], r[c["ACT"]], r[c["NSEND"]] = T, 1, 2 if sh.TO0 <= T <= sh.TF else 1
-        for j in range(8):
-            if 8 * T + j < 6:
-                r[c["CF"] + j], r[c["CV"] + j] = 1, sh.head[8 * T + j]
-        if T in sh.pub_rows:
-            r[c["IP"] + sh.pub_rows.index(T)] = 1
-        if T == 0:
-            r[c["IND0"]], r[c["NTR"]], r[c["TREE"]] = 1, sh.Q, sh.R
-        if T == sh.TQ:
-            r[c["NROOT"]], r[c["TREE"]] = sh.Q, sh.R + 1
-        if sh.TL0 <= T < sh.TP:
-            r[c["NROOT"]], r[c["TREE"]], r[c["NBETA"]] = sh.Q, T - sh.TL0, sh.Q
-        for kind, Tk in enumerate((sh.TA, sh.TQ, sh.TF)):
-            if T == Tk:
-                r[c["NSC"]], r[c["KIND"]] = 1, kind
-        if T in (sh.TA, sh.TQ, sh.TF) or sh.TL0 <= T < sh.TP:
-            r[c["HASCH"]] = 1
-        if T == sh.TP:
-            r[c["NFIN"]] = sh.Q
+    npr = len(sh.pub_rows)
+    for p in range(sh.NP):
+        for T in range(sh.NTS):
+            r = t[p * sh.NTS + T]
+            r[c["T"]], r[c["ACT"]], r[c["NSEND"]] = sh.ttag(p, T), 1, 2 if sh.TO0 <= T <= sh.TF else 1
+            for j in range(8):
+                if 8 * T + j < 6:
+                    r[c["CF"] + j], r[c["CV"] + j] = 1, sh.head[8 * T + j]
+            if T in sh.pub_rows:
+                r[c["IP"] + p * npr + sh.pub_rows.index(T)] = 1
+            if T == 0:
+                r[c["IND0"]], r[c["NTR"]], r[c["TREE"]] = 1, sh.Q, p * sh.TREES + sh.R
+            if T == sh.TQ:
+                r[c["NROOT"]], r[c["TREE"]] = sh.Q, p * sh.TREES + sh.R + 1
+            if sh.TL0 <= T < sh.TP:
+                r[c["NROOT"]], r[c["TREE"]], r[c["NBETA"]] = sh.Q, p * sh.TREES + T - sh.TL0, sh.Q
+            for kind, Tk in enumerate((sh.TA, sh.TQ, sh.TF)):
+                if T == Tk:
+                    r[c["NSC"]], r[c["KIND"]] = 1, 3 * p + kind
+            if T in (sh.TA, sh.TQ, sh.TF) or sh.TL0 <= T < sh.TP:
+                r[c["HASCH"]] = 1
+            if T == sh.TP:
+                r[c["NFIN"]], r[c["PT"]] = sh.Q, p * sh.TREES
     return t
 
 
-def ts_main(sh, w, chal, p2_main, log_rows):
+def ts_main(sh, ws, chals, p2_main, log_rows):
     t = np.zeros((1 << log_rows, TS_MAIN), dtype=np.uint32)
-    for T in range(sh.NTS):
-        t[T, 0:8] = p2_main[T, P2.IN:P2.IN + 8]                                 # the absorbed words, and whatever the kept ones are
-        if T in (sh.TA, sh.TQ, sh.TF) or sh.TL0 <= T < sh.TP:
-            t[T, 16:20] = chal[T]
-    t[0, 8:16] = w["trace_root"]
+    for p, (w, chal) in enumerate(zip(ws, chals)):
+        for T in range(sh.NTS):
+            r = t[p * sh.NTS + T]
+            r[0:8] = p2_main[p * sh.p2_rows + T, P2.IN:P2.IN + 8]               # the absorbed words, and whatever the kept ones are
+            if T in (sh.TA, sh.TQ, sh.TF) or sh.TL0 <= T < sh.TP:
+                r[16:20] = chal[T]
+        t[p * sh.NTS, 8:16] = w["trace_root"]
     return t
 
 
 # ---------------------------------------------------------------------------------------------------------------- ROWSUM
-RS_PRE = 8
-RP_TAG, RP_ACT, RP_NOTFIRST, RP_LAST0, RP_LAST1, RP_QN, RP_FIRST = 0, 1, 2, 3, 4, 5, 6
+RP_TAG, RP_ACT, RP_NOTFIRST, RP_LAST0, RP_LAST1, RP_QN, RP_FIRST, RP_PID = 0, 1, 2, 3, 4, 5, 6, 7
+RS_PRE = 12
+RP_NFC = 8                                                                       # the row is active and not the first of its proof: the constants stay
 RS_V, RS_ACCIN, RS_T, RS_FA, RS_MAIN = 0, 8, 12, 44, 48
 
 
@@ -426,7 +455,7 @@ def rowsum_program(sh):
     M0 = RS_PRE
     cons = Cons()
     fa = ev(M0 + RS_FA)
-    cons.ext(O.SEL_TRANSITION, esub(ev(M0 + RS_FA, True), fa))
+    cons.ext(O.SEL_TRANSITION, egate(pv(RP_NFC, True), esub(ev(M0 + RS_FA, True), fa)))
     prev = ev(M0 + RS_ACCIN)
     for s in range(7, -1, -1):
         cur = ev(M0 + RS_T + 4 * s)
@@ -434,7 +463,7 @@ def rowsum_program(sh):
         prev = cur
     cons.ext(O.SEL_TRANSITION, egate(pv(RP_NOTFIRST, True), esub(ev(M0 + RS_ACCIN, True), ev(M0 + RS_T))))
     cons.ext(O.SEL_ALL, egate(padd(pv(RP_ACT), pneg(pv(RP_NOTFIRST))), ev(M0 + RS_ACCIN)))
-    return O.air_program(RS_PRE + RS_MAIN, sh.NPUB, cons.c)
+    return O.air_program(RS_PRE + RS_MAIN, sh.NP * sh.NPUB, cons.c)
 
 
 def rowsum_table():
@@ -443,21 +472,22 @@ def rowsum_table():
     return O.interaction_table([
         (SEND, RP_ACT, BUS_IN0, [RP_TAG, v, v + 1, v + 2, v + 3]), (SEND, RP_ACT, BUS_IN1, [RP_TAG, v + 4, v + 5, v + 6, v + 7]),
         (SEND, RP_LAST0, BUS_AT, [RP_QN, t0, t0 + 1, t0 + 2, t0 + 3]), (SEND, RP_LAST1, BUS_AQ, [RP_QN, t0, t0 + 1, t0 + 2, t0 + 3]),
-        (RECV, RP_FIRST, BUS_KFA, [fa, fa + 1, fa + 2, fa + 3])])
+        (RECV, RP_FIRST, BUS_KFA, [RP_PID, fa, fa + 1, fa + 2, fa + 3])])
 
 
 def rowsum_rows(sh):
     """(q, block) in trace order: a query's trace blocks from the last to the first, then its quotient block"""
-    return [(q, b) for q in range(sh.Q) for b in list(range(sh.WB - 1, -1, -1)) + [sh.WB]]
+    return [(p, q, b) for p in range(sh.NP) for q in range(sh.Q) for b in list(range(sh.WB - 1, -1, -1)) + [sh.WB]]
 
 
 def rowsum_pre(sh, log_rows):
     t = np.zeros((1 << log_rows, RS_PRE), dtype=np.uint32)
-    for r, (q, b) in enumerate(rowsum_rows(sh)):
-        t[r, RP_TAG], t[r, RP_ACT], t[r, RP_QN] = sh.row_tag(q, b), 1, q
+    per = sh.Q * (sh.WB + 1)
+    for r, (p, q, b) in enumerate(rowsum_rows(sh)):
+        t[r, RP_TAG], t[r, RP_ACT], t[r, RP_QN], t[r, RP_PID] = sh.row_tag(p, q, b), 1, p * sh.Q + q, p
         t[r, RP_NOTFIRST] = 0 if b in (sh.WB - 1, sh.WB) else 1
         t[r, RP_LAST0], t[r, RP_LAST1] = (1 if b == 0 else 0), (1 if b == sh.WB else 0)
-    t[0, RP_FIRST] = 1
+        t[r, RP_FIRST], t[r, RP_NFC] = (1, 0) if r % per == 0 else (0, 1)
     return t
 
 
@@ -470,12 +500,14 @@ def _horner8(acc, vals, fa):
     return steps
 
 
-def rowsum_main(sh, w, fa, log_rows):
+def rowsum_main(sh, ws, fas, log_rows):
+    """-> (trace, at[(p, q)], aq[(p, q)]); padding rows keep the last proof's fa (no constraint reads it there)"""
     t = np.zeros((1 << log_rows, RS_MAIN), dtype=np.uint64)
-    t[:, RS_FA:RS_FA + 4] = fa
+    t[:, RS_FA:RS_FA + 4] = fas[-1]
     at, aq, acc = {}, {}, [0, 0, 0, 0]
-    for r, (q, b) in enumerate(rowsum_rows(sh)):
-        op = w["openings"][q]
+    for r, (p, q, b) in enumerate(rowsum_rows(sh)):
+        op, fa = ws[p]["openings"][q], fas[p]
+        t[r, RS_FA:RS_FA + 4] = fa
         vals = op["qrow"] if b == sh.WB else op["trow"][8 * b:8 * b + 8]
         if b in (sh.WB - 1, sh.WB):
             acc = [0, 0, 0, 0]
@@ -485,15 +517,15 @@ def rowsum_main(sh, w, fa, log_rows):
             t[r, RS_T + 4 * s:RS_T + 4 * s + 4] = steps[s]
         acc = steps[0]
         if b == 0:
-            at[q] = acc
+            at[(p, q)] = acc
         if b == sh.WB:
-            aq[q] = acc
+            aq[(p, q)] = acc
     return t.astype(np.uint32), at, aq
 
 
 # ---------------------------------------------------------------------------------------------------------------- QUERY
-Q_PRE = 4
-QP_QN, QP_ACT, QP_ACT2, QP_FIRST = 0, 1, 2, 3
+Q_PRE = 8
+QP_QN, QP_ACT, QP_ACT2, QP_FIRST, QP_PID, QP_NFC, QP_PT = 0, 1, 2, 3, 4, 5, 6
 
 
 def query_cols():
@@ -512,7 +544,7 @@ def query_program(sh):
     m = query_cols()
     cons = Cons()
     for name in QUERY_CONSTS:
-        cons.ext(O.SEL_TRANSITION, esub(ev(m[name], True), ev(m[name])))
+        cons.ext(O.SEL_TRANSITION, egate(pv(QP_NFC, True), esub(ev(m[name], True), ev(m[name]))))
     x = eb(pscale(pv(m["XQ"]), GEN))
     act = pv(QP_ACT)
     cons.ext(O.SEL_ALL, egate(act, esub(emul(esub(x, ev(m["ZETA"])), ev(m["I1"])), ec(1))))
@@ -523,7 +555,7 @@ def query_program(sh):
     cons.ext(O.SEL_ALL, esub(ev(m["P3"]), emul(esub(ev(m["AQ"]), ev(m["YQ"])), ev(m["I1"]))))
     cons.ext(O.SEL_ALL, esub(ev(m["P3O"]), emul(ev(m["OFFQ"]), ev(m["P3"]))))
     cons.ext(O.SEL_ALL, esub(ev(m["RO"]), eadd(ev(m["P1"]), ev(m["P2O"]), ev(m["P3O"]))))
-    return O.air_program(Q_PRE + Q_MAIN, sh.NPUB, cons.c)
+    return O.air_program(Q_PRE + Q_MAIN, sh.NP * sh.NPUB, cons.c)
 
 
 def _e4(c):
@@ -534,18 +566,17 @@ def query_table():
     m = query_cols()
     return O.interaction_table([
         (RECV, QP_ACT, F.BUS_I, [QP_QN, m["IDX"]]),
-        (RECV, QP_ACT, F.BUS_Q, [m["IDX"], m["XQ"]] + _e4(m["RO"])),
+        (RECV, QP_ACT, F.BUS_Q, [QP_PT, m["IDX"], m["XQ"]] + _e4(m["RO"])),
         (RECV, QP_ACT, BUS_AT, [QP_QN] + _e4(m["AT"])), (RECV, QP_ACT, BUS_AQ, [QP_QN] + _e4(m["AQ"])),
         (SEND, QP_ACT2, BUS_QI, [QP_QN, m["IDX"]]),
-        (RECV, QP_FIRST, BUS_K0, _e4(m["ZETA"]) + _e4(m["ZNX"])), (RECV, QP_FIRST, BUS_K1, _e4(m["YL"]) + _e4(m["YN"])),
-        (RECV, QP_FIRST, BUS_K2, _e4(m["YQ"]) + _e4(m["OFFN"])), (RECV, QP_FIRST, BUS_K3, _e4(m["OFFQ"]))])
+        ] + [(RECV, QP_FIRST, BUS_K0 + i, [QP_PID] + _e4(m[name])) for i, name in enumerate(QUERY_CONSTS)])
 
 
 def query_pre(sh, log_rows):
     t = np.zeros((1 << log_rows, Q_PRE), dtype=np.uint32)
-    for q in range(sh.Q):
-        t[q] = [q, 1, 2, 0]
-    t[0, QP_FIRST] = 1
+    for p in range(sh.NP):
+        for q in range(sh.Q):
+            t[p * sh.Q + q] = [p * sh.Q + q, 1, 2, 1 if q == 0 else 0, p, 0 if q == 0 else 1, p * sh.TREES, 0]
     return t
 
 
@@ -557,35 +588,39 @@ def e_add(a, b):
     return [(x + y) % P for x, y in zip(a, b)]
 
 
-def query_main(sh, w, sc, at, aq, log_rows):
+def query_main(sh, ws, scs, at, aq, log_rows):
     m = query_cols()
     t = np.zeros((1 << log_rows, Q_MAIN), dtype=np.uint64)
     for name in QUERY_CONSTS:
-        t[:, m[name] - Q_PRE:m[name] - Q_PRE + 4] = sc[name]
+        t[:, m[name] - Q_PRE:m[name] - Q_PRE + 4] = scs[-1][name]
     ros = []
     wM = two_adic_generator(sh.H)
-    for q in range(sh.Q):
+    for pq in range(sh.NP * sh.Q):
+        p, q = divmod(pq, sh.Q)
+        w, sc, key = ws[p], scs[p], (p, q)
+        for name in QUERY_CONSTS:
+            t[pq, m[name] - Q_PRE:m[name] - Q_PRE + 4] = sc[name]
         index = w["openings"][q]["index"]
         xq = pow(wM, pyref.bitrev(index, sh.H), P)
         x = [GEN * xq % P, 0, 0, 0]
         i1, i2 = pyref.ext_inv(e_sub(x, sc["ZETA"])), pyref.ext_inv(e_sub(x, sc["ZNX"]))
-        p1 = ext_mul(e_sub(at[q], sc["YL"]), i1)
-        p2 = ext_mul(e_sub(at[q], sc["YN"]), i2)
+        p1 = ext_mul(e_sub(at[key], sc["YL"]), i1)
+        p2 = ext_mul(e_sub(at[key], sc["YN"]), i2)
         p2o = ext_mul(sc["OFFN"], p2)
-        p3 = ext_mul(e_sub(aq[q], sc["YQ"]), i1)
+        p3 = ext_mul(e_sub(aq[key], sc["YQ"]), i1)
         p3o = ext_mul(sc["OFFQ"], p3)
         ro = e_add(e_add(p1, p2o), p3o)
         ros.append(ro)
-        r = t[q]
+        r = t[pq]
         r[m["IDX"] - Q_PRE], r[m["XQ"] - Q_PRE] = index, xq
-        for name, val in (("RO", ro), ("AT", at[q]), ("AQ", aq[q]), ("I1", i1), ("I2", i2), ("P1", p1), ("P2", p2), ("P2O", p2o), ("P3", p3), ("P3O", p3o)):
+        for name, val in (("RO", ro), ("AT", at[key]), ("AQ", aq[key]), ("I1", i1), ("I2", i2), ("P1", p1), ("P2", p2), ("P2O", p2o), ("P3", p3), ("P3O", p3o)):
             r[m[name] - Q_PRE:m[name] - Q_PRE + 4] = val
     return t.astype(np.uint32), ros                                            # (padding rows: everything but the constants zero -- every product has a zero factor)
 
 
 # ---------------------------------------------------------------------------------------------------------------- OPENED
 OP_PRE = 12
-OP_ACT, OP_FIRST, OP_LASTG, OP_NOTFIRST, OP_K1, OP_K2, OP_K3, OP_TL0, OP_TL1, OP_TN0, OP_TN1 = range(11)
+OP_ACT, OP_FIRST, OP_LASTG, OP_NOTFIRST, OP_K1, OP_K2, OP_K3, OP_TL0, OP_TL1, OP_TN0, OP_TN1, OP_PID = range(12)
 
 
 def opened_cols():
@@ -604,9 +639,9 @@ def opened_program(sh):
     m = opened_cols()
     cons = Cons()
     e = lambda name, nxt=False: ev(m[name], nxt)
-    for name in OPENED_CONSTS:
-        cons.ext(O.SEL_TRANSITION, esub(e(name, True), e(name)))
     first, nf = pv(OP_FIRST), pv(OP_NOTFIRST, True)
+    for name in OPENED_CONSTS:
+        cons.ext(O.SEL_TRANSITION, egate(nf, esub(e(name, True), e(name))))
     cons.ext(O.SEL_ALL, egate(first, esub(e("PW"), ec(1))))
     cons.ext(O.SEL_ALL, esub(e("PWN"), emul(e("PW"), e("FA4"))))
     cons.ext(O.SEL_TRANSITION, egate(nf, esub(e("PW", True), e("PWN"))))
@@ -629,7 +664,7 @@ def opened_program(sh):
     cons.ext(O.SEL_ALL, esub(e("U2"), eadd(emul(e("U1"), al), emul(e("SELT"), esub(esub(esub(e("DN"), e("AB")), e("C")), eb(pv(OP_K2)))))))
     cons.ext(O.SEL_ALL, esub(e("ACCO"), eadd(emul(e("U2"), al), emul(e("SELF"), esub(e("D"), eb(pv(OP_K3)))))))
     cons.ext(O.SEL_TRANSITION, egate(nf, esub(e("ACCIN", True), e("ACCO"))))
-    return O.air_program(OP_PRE + OP_MAIN, sh.NPUB, cons.c)
+    return O.air_program(OP_PRE + OP_MAIN, sh.NP * sh.NPUB, cons.c)
 
 
 def opened_table():
@@ -637,34 +672,41 @@ def opened_table():
     it = []
     for tag, lo, hi in ((OP_TL0, "A", "B"), (OP_TL1, "C", "D"), (OP_TN0, "AN", "BN"), (OP_TN1, "CN", "DN")):
         it += [(RECV, OP_ACT, BUS_IN0, [tag] + _e4(m[lo])), (RECV, OP_ACT, BUS_IN1, [tag] + _e4(m[hi]))]
-    it += [(SEND, OP_LASTG, BUS_OY, _e4(m["YLO"]) + _e4(m["YNO"])), (SEND, OP_LASTG, BUS_OA, _e4(m["ACCO"])),
-           (RECV, OP_FIRST, BUS_KO0, _e4(m["FA"]) + _e4(m["FA4"])), (RECV, OP_FIRST, BUS_KO1, _e4(m["ALPHA"]) + _e4(m["SELT"])),
-           (RECV, OP_FIRST, BUS_KO2, _e4(m["SELF"]))]
+    it += [(SEND, OP_LASTG, BUS_OY, [OP_PID] + _e4(m["YLO"])), (SEND, OP_LASTG, BUS_OY + 1, [OP_PID] + _e4(m["YNO"])), (SEND, OP_LASTG, BUS_OA, [OP_PID] + _e4(m["ACCO"]))]
+    it += [(RECV, OP_FIRST, BUS_KO0 + i, [OP_PID] + _e4(m[name])) for i, name in enumerate(OPENED_CONSTS)]
     return O.interaction_table(it)
 
 
 def opened_pre(sh, log_rows):
     t = np.zeros((1 << log_rows, OP_PRE), dtype=np.uint32)
-    for g in range(sh.G):
-        t[g, OP_ACT], t[g, OP_NOTFIRST] = 1, 1 if g else 0
-        t[g, OP_K1], t[g, OP_K2], t[g, OP_K3] = g + 1, 2 * g + 3, 5 * g + 7
-        t[g, OP_TL0], t[g, OP_TL1] = sh.TO0 + 2 * g, sh.TO0 + 2 * g + 1
-        t[g, OP_TN0], t[g, OP_TN1] = sh.TO0 + sh.W // 2 + 2 * g, sh.TO0 + sh.W // 2 + 2 * g + 1
-    t[0, OP_FIRST], t[sh.G - 1, OP_LASTG] = 1, 1
+    for p in range(sh.NP):
+        for g in range(sh.G):
+            r = t[p * sh.G + g]
+            r[OP_ACT], r[OP_NOTFIRST], r[OP_PID] = 1, 1 if g else 0, p
+            r[OP_K1], r[OP_K2], r[OP_K3] = g + 1, 2 * g + 3, 5 * g + 7
+            r[OP_TL0], r[OP_TL1] = sh.ttag(p, sh.TO0 + 2 * g), sh.ttag(p, sh.TO0 + 2 * g + 1)
+            r[OP_TN0], r[OP_TN1] = sh.ttag(p, sh.TO0 + sh.W // 2 + 2 * g), sh.ttag(p, sh.TO0 + sh.W // 2 + 2 * g + 1)
+        t[p * sh.G, OP_FIRST], t[p * sh.G + sh.G - 1, OP_LASTG] = 1, 1
     return t
 
 
-def opened_main(sh, w, sc, log_rows):
+def opened_main(sh, ws, scs, log_rows):
+    """-> (trace, per proof (y_loc, y_nxt, acc)); padding rows carry the last proof's constants"""
     m = opened_cols()
     t = np.zeros((1 << log_rows, OP_MAIN), dtype=np.uint64)
     put = lambda r, name, val: r.__setitem__(slice(m[name] - OP_PRE, m[name] - OP_PRE + 4), val)
-    fa, fa4, al, selt, self_ = sc["FA"], sc["FA4"], sc["ALPHA"], sc["SELT"], sc["SELF"]
-    pw, yl, yn, acc = [1, 0, 0, 0], [0] * 4, [0] * 4, [0] * 4
-    for g in range(1 << log_rows):
-        r = t[g]
+    results = []
+    for row in range(1 << log_rows):
+        p, g = divmod(row, sh.G)
+        active = p < sh.NP
+        w, sc = (ws[p], scs[p]) if active else (None, scs[-1])
+        fa, fa4, al, selt, self_ = sc["FA"], sc["FA4"], sc["ALPHA"], sc["SELT"], sc["SELF"]
+        if g == 0:
+            pw, yl, yn, acc = [1, 0, 0, 0], [0] * 4, [0] * 4, [0] * 4
+        r = t[row]
         for name, val in zip(OPENED_CONSTS, (fa, fa4, al, selt, self_)):
             put(r, name, val)
-        if g < sh.G:
+        if active:
             a, b, c, d = w["loc"][4 * g:4 * g + 4]
             an, bn, cn, dn = w["nxt"][4 * g:4 * g + 4]
         else:
@@ -687,20 +729,20 @@ def opened_main(sh, w, sc, log_rows):
         put(r, "YLO", yl), put(r, "YNO", yn)
         a2, ab = ext_mul(a, a), ext_mul(a, b)
         put(r, "A2", a2), put(r, "AB", ab), put(r, "ACCIN", acc)
-        k1, k2, k3 = (g + 1, 2 * g + 3, 5 * g + 7) if g < sh.G else (0, 0, 0)
+        k1, k2, k3 = (g + 1, 2 * g + 3, 5 * g + 7) if active else (0, 0, 0)
         u1 = e_add(ext_mul(acc, al), e_sub(e_sub(c, ext_mul(a2, b)), [k1, 0, 0, 0]))
         u2 = e_add(ext_mul(u1, al), ext_mul(selt, e_sub(e_sub(e_sub(dn, ab), c), [k2, 0, 0, 0])))
         acc = e_add(ext_mul(u2, al), ext_mul(self_, e_sub(d, [k3, 0, 0, 0])))
         put(r, "U1", u1), put(r, "U2", u2), put(r, "ACCO", acc)
         pw = pwn
-        if g == sh.G - 1:
-            result = (yl, yn, acc)
-    return t.astype(np.uint32), result
+        if active and g == sh.G - 1:
+            results.append((yl, yn, acc))
+    return t.astype(np.uint32), results
 
 
 # ---------------------------------------------------------------------------------------------------------------- SCALARS
-SC_PRE = 8
-SP_FIRST, SP_KA, SP_KZ, SP_KF, SP_TQZ = 0, 1, 2, 3, 4
+SC_PRE = 12
+SP_FIRST, SP_KA, SP_KZ, SP_KF, SP_TQZ, SP_PID = 0, 1, 2, 3, 4, 8                 # FIRST: the row is a proof's row (rows behind the proofs repeat row 0: every constraint holds there too)
 
 
 def scalars_cols(sh):
@@ -784,7 +826,7 @@ def scalars_program(sh):
     z0, z1 = eadd(escale(znn, a0), ec(b0)), eadd(escale(znn, a1), ec(b1))
     cons.ext(O.SEL_ALL, esub(e("QUO"), eadd(emul(z0, e("QK0")), emul(z1, e("QK1")))))
     cons.ext(O.SEL_ALL, esub(e("ACC"), emul(e("QUO"), esub(znn, ec(1)))))
-    return O.air_program(SC_PRE + rup4(m.n - SC_PRE), sh.NPUB, cons.c)
+    return O.air_program(SC_PRE + rup4(m.n - SC_PRE), sh.NP * sh.NPUB, cons.c)
 
 
 def scalars_table(sh):
@@ -792,21 +834,20 @@ def scalars_table(sh):
     it = [(RECV, SP_FIRST, BUS_SC, [SP_KA] + _e4(m["ALPHA"])), (RECV, SP_FIRST, BUS_SC, [SP_KZ] + _e4(m["ZETA"])), (RECV, SP_FIRST, BUS_SC, [SP_KF] + _e4(m["FA"]))]
     for i in range(4):
         it += [(RECV, SP_FIRST, BUS_IN0, [SP_TQZ + i] + _e4(m["QZ%d" % (2 * i)])), (RECV, SP_FIRST, BUS_IN1, [SP_TQZ + i] + _e4(m["QZ%d" % (2 * i + 1)]))]
-    it += [(RECV, SP_FIRST, BUS_OY, _e4(m["YL"]) + _e4(m["YN"])), (RECV, SP_FIRST, BUS_OA, _e4(m["ACC"])),
-           (SEND, SP_FIRST, BUS_K0, _e4(m["ZETA"]) + _e4(m["ZNX"])), (SEND, SP_FIRST, BUS_K1, _e4(m["YL"]) + _e4(m["YN"])),
-           (SEND, SP_FIRST, BUS_K2, _e4(m["HQ0"]) + _e4(m["OFFN"])), (SEND, SP_FIRST, BUS_K3, _e4(m["OFFQ"])),
-           (SEND, SP_FIRST, BUS_KFA, _e4(m["FA"])),
-           (SEND, SP_FIRST, BUS_KO0, _e4(m["FA"]) + _e4(m["FP2"])), (SEND, SP_FIRST, BUS_KO1, _e4(m["ALPHA"]) + _e4(m["SELT"])),
-           (SEND, SP_FIRST, BUS_KO2, _e4(m["SELF"]))]
+    it += [(RECV, SP_FIRST, BUS_OY, [SP_PID] + _e4(m["YL"])), (RECV, SP_FIRST, BUS_OY + 1, [SP_PID] + _e4(m["YN"])), (RECV, SP_FIRST, BUS_OA, [SP_PID] + _e4(m["ACC"]))]
+    it += [(SEND, SP_FIRST, BUS_K0 + i, [SP_PID] + _e4(m[name])) for i, name in enumerate(("ZETA", "ZNX", "YL", "YN", "HQ0", "OFFN", "OFFQ"))]
+    it += [(SEND, SP_FIRST, BUS_KFA, [SP_PID] + _e4(m["FA"]))]
+    it += [(SEND, SP_FIRST, BUS_KO0 + i, [SP_PID] + _e4(m[name])) for i, name in enumerate(("FA", "FP2", "ALPHA", "SELT", "SELF"))]
     return O.interaction_table(it)
 
 
 def scalars_pre(sh, log_rows):
     t = np.zeros((1 << log_rows, SC_PRE), dtype=np.uint32)
-    t[:, SP_KA], t[:, SP_KZ], t[:, SP_KF] = 0, 1, 2
-    for i in range(4):
-        t[:, SP_TQZ + i] = sh.TO0 + sh.W + i
-    t[0, SP_FIRST] = 1
+    for p in range(sh.NP):
+        t[p, SP_FIRST], t[p, SP_PID] = 1, p
+        t[p, SP_KA], t[p, SP_KZ], t[p, SP_KF] = 3 * p, 3 * p + 1, 3 * p + 2
+        for i in range(4):
+            t[p, SP_TQZ + i] = sh.ttag(p, sh.TO0 + sh.W + i)
     return t
 
 
@@ -857,31 +898,33 @@ def scalars_values(sh, w, chal):
     return m
 
 
-def scalars_main(sh, sc, log_rows):
+def scalars_main(sh, scs, log_rows):
     m = scalars_cols(sh)
     width = rup4(m.n - SC_PRE)
-    row = np.zeros(width, dtype=np.uint64)
-    for name, col in m.at.items():
-        row[col - SC_PRE:col - SC_PRE + 4] = sc[name]
-    return np.tile(row, (1 << log_rows, 1)).astype(np.uint32)
+    t = np.zeros((1 << log_rows, width), dtype=np.uint64)
+    for r in range(1 << log_rows):
+        sc = scs[r] if r < sh.NP else scs[0]
+        for name, col in m.at.items():
+            t[r, col - SC_PRE:col - SC_PRE + 4] = sc[name]
+    return t.astype(np.uint32)
 
 
 # ---------------------------------------------------------------------------------------------------------------- FOLD (tests/fri_air.py, rec form)
 def fold_table(layers):
-    t = [(SEND, F.ACTIVE, F.BUS_E0, [F.LN, F.K2, F.E0, F.E0 + 1, F.E0 + 2, F.E0 + 3]), (SEND, F.ACTIVE, F.BUS_E1, [F.LN, F.K2, F.E1, F.E1 + 1, F.E1 + 2, F.E1 + 3]),
-         (SEND, F.L_REC, F.BUS_Q, [F.IDX, F.XS, F.OWN, F.OWN + 1, F.OWN + 2, F.OWN + 3]),
-         (RECV, F.ACTIVE, BUS_BETA, [F.LN, F.BETA, F.BETA + 1, F.BETA + 2, F.BETA + 3]),
-         (SEND, F.L_REC + layers - 1, BUS_FIN, [F.FOLD, F.FOLD + 1, F.FOLD + 2, F.FOLD + 3])]
+    t = [(SEND, F.ACTIVE, F.BUS_E0, [F.LNX, F.K2, F.E0, F.E0 + 1, F.E0 + 2, F.E0 + 3]), (SEND, F.ACTIVE, F.BUS_E1, [F.LNX, F.K2, F.E1, F.E1 + 1, F.E1 + 2, F.E1 + 3]),
+         (SEND, F.L_REC, F.BUS_Q, [F.PT, F.IDX, F.XS, F.OWN, F.OWN + 1, F.OWN + 2, F.OWN + 3]),
+         (RECV, F.ACTIVE, BUS_BETA, [F.LNX, F.BETA, F.BETA + 1, F.BETA + 2, F.BETA + 3]),
+         (SEND, F.L_REC + layers - 1, BUS_FIN, [F.PT, F.FOLD, F.FOLD + 1, F.FOLD + 2, F.FOLD + 3])]
     return O.interaction_table(t)
 
 
 # ---------------------------------------------------------------------------------------------------------------- the witness and the machine
-def witness(proof, log_n, width, public_values, n_queries, pow_bits):
-    """everything the machine's main columns hold, taken from the inner proof by the Python verifier (which must accept it)"""
+def witness(proof, log_n, width, public_values, n_queries, pow_bits, sh=None):
+    """everything the machine's main columns hold for ONE inner proof, taken from it by the Python verifier (which must accept it)"""
     import pyverify
     view = {}
     pyverify.verify(proof, log_n, width, public_values, num_queries=n_queries, pow_bits=pow_bits, view=view)
-    sh = Shape(log_n, width, n_queries, pow_bits, len(public_values))
+    sh = sh or Shape(log_n, width, n_queries, pow_bits, len(public_values))
     w = {"trace_root": view["trace_root"], "quot_root": view["quot_root"], "layer_roots": view["roots"], "final": view["final"], "witness": view["witness"],
          "loc": view["loc"], "nxt": view["nxt"], "qz": view["qz"], "openings": view["openings"], "betas": view["betas"], "view": view}
     # the blocks the transcript absorbs, by sponge row
@@ -915,8 +958,9 @@ CHIPS = ("P2R", "ROWSUM", "FOLD", "TS", "QUERY", "OPENED", "SAMPLES", "SCALARS")
 
 
 def heights(sh):
-    return {"P2R": lg(sh.p2_rows), "ROWSUM": lg(sh.Q * (sh.WB + 1)), "FOLD": lg(sh.Q * sh.R), "TS": lg(sh.NTS), "QUERY": lg(sh.Q), "OPENED": lg(sh.G),
-            "SAMPLES": lg(sh.NS), "SCALARS": 5}
+    n = sh.NP
+    return {"P2R": lg(n * sh.p2_rows), "ROWSUM": lg(n * sh.Q * (sh.WB + 1)), "FOLD": lg(n * sh.Q * sh.R), "TS": lg(n * sh.NTS), "QUERY": lg(n * sh.Q), "OPENED": lg(n * sh.G),
+            "SAMPLES": lg(n * sh.NS), "SCALARS": lg(n)}
 
 
 def order(sh):
@@ -926,8 +970,9 @@ def order(sh):
 
 
 def programs(sh):
-    return {"P2R": p2r_program(sh), "ROWSUM": rowsum_program(sh), "FOLD": F.program(sh.R, wired=True, transcript=True, rec=sh.NPUB), "TS": ts_program(sh),
-            "QUERY": query_program(sh), "OPENED": opened_program(sh), "SAMPLES": F.samples_program(sh.R, sh.Q, sh.PB, sh.NPUB), "SCALARS": scalars_program(sh)}
+    npub = sh.NP * sh.NPUB
+    return {"P2R": p2r_program(sh), "ROWSUM": rowsum_program(sh), "FOLD": F.program(sh.R, wired=True, transcript=True, rec=npub), "TS": ts_program(sh),
+            "QUERY": query_program(sh), "OPENED": opened_program(sh), "SAMPLES": F.samples_program(sh.R, sh.Q, sh.PB, npub), "SCALARS": scalars_program(sh)}
 
 
 def tables(sh):
@@ -938,40 +983,71 @@ def tables(sh):
             "SAMPLES": s_tab, "SCALARS": scalars_table(sh)}
 
 
+def samples_stacked(sh, words_per_proof, log_rows):
+    """the SAMPLES chip for several proofs: proof p's rows behind proof p - 1's; its sponge rows are numbered from its own tags, its queries from p Q"""
+    pre = np.zeros((1 << log_rows, F.S_PRE), dtype=np.uint32)
+    main = np.zeros((1 << log_rows, F.S_MAIN), dtype=np.uint32)
+    drawn = []
+    for p, words in enumerate(words_per_proof):
+        a, b, d = F.samples_tables(sh.R, sh.Q, words, lg(sh.NS), base=sh.ttag(p, sh.TP))
+        for j in range(8):
+            a[:, F.S_KQ + j] += (p * sh.Q) * a[:, F.S_ACT + j]
+        pre[p * sh.NS:(p + 1) * sh.NS], main[p * sh.NS:(p + 1) * sh.NS] = a[:sh.NS], b[:sh.NS]
+        drawn.append(d)
+    return pre, main, drawn
+
+
 def preprocessed(sh):
     """the key material: every chip's preprocessed trace (None: the chip has none) -- a function of the shape"""
     h = heights(sh)
-    spre, _, _ = F.samples_tables(sh.R, sh.Q, [[0] * 8] * sh.NS, h["SAMPLES"], base=sh.TP)
+    spre, _, _ = samples_stacked(sh, [[[0] * 8] * sh.NS] * sh.NP, h["SAMPLES"])
     return {"P2R": p2r_pre(sh, h["P2R"]), "ROWSUM": rowsum_pre(sh, h["ROWSUM"]), "FOLD": None, "TS": ts_pre(sh, h["TS"]), "QUERY": query_pre(sh, h["QUERY"]),
             "OPENED": opened_pre(sh, h["OPENED"]), "SAMPLES": spre, "SCALARS": scalars_pre(sh, h["SCALARS"])}
 
 
-def main_traces(sh, w):
+def fold_stacked(sh, ws, log_rows):
+    t = np.zeros((1 << log_rows, F.width_of(sh.R, rec=True)), dtype=np.uint32)
+    t[:, F.T] = 1
+    per = sh.Q * sh.R
+    for p, w in enumerate(ws):
+        one, final = F.trace(w["view"], lg(per), wired=True, rec=True, pt=p * sh.TREES)
+        assert list(final) == list(w["final"])
+        t[p * per:(p + 1) * per] = one[:per]
+    return t
+
+
+def main_traces(sh, ws):
     h = heights(sh)
-    p2, samples, chal = p2r_main(sh, w, h["P2R"])
-    assert chal[sh.TA] == w["view"]["alpha"] and chal[sh.TQ] == w["view"]["zeta"] and chal[sh.TF] == w["view"]["fa"], "the sponge rows do not reproduce the verifier's challenges"
-    assert [chal[sh.TL0 + l] for l in range(sh.R)] == w["betas"]
-    sc = scalars_values(sh, w, chal)
-    opened, (yl, yn, acc) = opened_main(sh, w, sc, h["OPENED"])
-    sc["YL"], sc["YN"], sc["ACC"] = yl, yn, acc
-    assert acc == ext_mul(sc["QUO"], e_sub(sc["ZNN"], [1, 0, 0, 0])), "the AIR identity at zeta does not hold"
-    rs, at, aq = rowsum_main(sh, w, sc["FA"], h["ROWSUM"])
-    qm, ros = query_main(sh, w, sc, at, aq, h["QUERY"])
-    assert ros == [list(v) for _, v, _ in w["view"]["queries"]], "the reduced openings are not the verifier's"
-    fold, final = F.trace(w["view"], h["FOLD"], wired=True, rec=True)
-    assert list(final) == list(w["final"])
-    _, smain, drawn = F.samples_tables(sh.R, sh.Q, samples, h["SAMPLES"], base=sh.TP)
-    assert drawn == [op["index"] for op in w["openings"]], "the query indices are not the ones the transcript draws"
-    ts = ts_main(sh, w, chal, p2, h["TS"])
-    return {"P2R": p2, "ROWSUM": rs, "FOLD": fold, "TS": ts, "QUERY": qm, "OPENED": opened, "SAMPLES": smain, "SCALARS": scalars_main(sh, sc, h["SCALARS"])}
+    p2, samples, chals = p2r_main(sh, ws, h["P2R"])
+    scs = []
+    for w, chal in zip(ws, chals):
+        assert chal[sh.TA] == w["view"]["alpha"] and chal[sh.TQ] == w["view"]["zeta"] and chal[sh.TF] == w["view"]["fa"], "the sponge rows do not reproduce the verifier's challenges"
+        assert [chal[sh.TL0 + l] for l in range(sh.R)] == w["betas"]
+        scs.append(scalars_values(sh, w, chal))
+    opened, results = opened_main(sh, ws, scs, h["OPENED"])
+    for sc, (yl, yn, acc) in zip(scs, results):
+        sc["YL"], sc["YN"], sc["ACC"] = yl, yn, acc
+        assert acc == ext_mul(sc["QUO"], e_sub(sc["ZNN"], [1, 0, 0, 0])), "the AIR identity at zeta does not hold"
+    rs, at, aq = rowsum_main(sh, ws, [sc["FA"] for sc in scs], h["ROWSUM"])
+    qm, ros = query_main(sh, ws, scs, at, aq, h["QUERY"])
+    assert ros == [list(v) for w in ws for _, v, _ in w["view"]["queries"]], "the reduced openings are not the verifier's"
+    fold = fold_stacked(sh, ws, h["FOLD"])
+    _, smain, drawn = samples_stacked(sh, samples, h["SAMPLES"])
+    assert drawn == [[op["index"] for op in w["openings"]] for w in ws], "the query indices are not the ones the transcript draws"
+    ts = ts_main(sh, ws, chals, p2, h["TS"])
+    return {"P2R": p2, "ROWSUM": rs, "FOLD": fold, "TS": ts, "QUERY": qm, "OPENED": opened, "SAMPLES": smain, "SCALARS": scalars_main(sh, scs, h["SCALARS"])}
 
 
-def machine(proof, log_n, width, public_values, n_queries, pow_bits):
-    """-> (shape, main traces, preprocessed traces, programs, interaction tables, public values), chips tallest first"""
-    sh, w = witness(proof, log_n, width, public_values, n_queries, pow_bits)
+def machine(proofs, log_n, width, public_values, n_queries, pow_bits):
+    """proofs: ONE inner proof (bytes) with its public values, or a LIST of proofs with a list of public-value lists (the join: one outer proof for all)
+    -> (shape, main traces, preprocessed traces, programs, interaction tables, public values), chips tallest first"""
+    if isinstance(proofs, (bytes, bytearray)):
+        proofs, public_values = [proofs], [public_values]
+    sh = Shape(log_n, width, n_queries, pow_bits, len(public_values[0]), len(proofs))
+    ws = [witness(pr, log_n, width, pv, n_queries, pow_bits, sh)[1] for pr, pv in zip(proofs, public_values)]
     names = order(sh)
-    mt, pre, prog, tab = main_traces(sh, w), preprocessed(sh), programs(sh), tables(sh)
-    return sh, [mt[c] for c in names], [pre[c] for c in names], [prog[c] for c in names], [tab[c] for c in names], [int(v) % P for v in public_values]
+    mt, pre, prog, tab = main_traces(sh, ws), preprocessed(sh), programs(sh), tables(sh)
+    return sh, [mt[c] for c in names], [pre[c] for c in names], [prog[c] for c in names], [tab[c] for c in names], [int(v) % P for pv in public_values for v in pv]
 
 
 # ---------------------------------------------------------------------------------------------------------------- checks in plain integers

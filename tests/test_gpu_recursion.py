@@ -76,3 +76,60 @@ def test_headline_shard_proof_verified_in_circuit(ctx, oracle):
     assert verify_shard_recursive(outer, log_n, width, q, pb, pubs[:-1] + [0], key.root, prm)[0] != 0
     print("headline: inner %d bytes, outer %d bytes, P2R 2^%d rows" % (inner.size, outer.size, lns[0]))
     key.close()
+
+
+@pytest.mark.parametrize("nproofs", [2, 3])
+def test_the_join_bytes_equal_the_oracles(ctx, oracle, nproofs):
+    """ONE outer proof for several inner proofs of one shape: key and bytes against the oracle on the restatement's arrays"""
+    import recursion_air as R
+    O = oracle
+    log_n, width, q, pb = 6, 16, 5, 2
+    iprm, oprm, prm = Params(1, q, pb), O.default_params(1, 20, 8), Params(1, 20, 8)
+    pubs = [[3, 4, 50 + p] for p in range(nproofs)]
+    inner = [ctx.prove_shard(ctx.gen_trace(SEED, 20 + p, log_n, width), log_n, width, pubs[p], iprm) for p in range(nproofs)]
+    key = ctx.shard_verifier_setup(log_n, width, q, pb, 3, prm, n_proofs=nproofs)
+    sh, mains, pres, progs, tabs, pv = R.machine([x.tobytes() for x in inner], log_n, width, pubs, q, pb)
+    lns = [m.shape[0].bit_length() - 1 for m in mains]
+    assert key.root.tolist() == O.machine_setup(pres, lns, oprm).tolist()
+    outer = ctx.prove_shard_verifier(key, inner, log_n, width, pubs, iprm, prm)
+    assert outer.tobytes() == O.prove_machine_keyed(mains, pres, progs, tabs, pv, oprm).tobytes(), "joined proof bytes differ from the oracle's"
+    assert verify_shard_recursive(outer, log_n, width, q, pb, pv, key.root, prm, n_proofs=nproofs) == (0, 0)
+    assert verify_shard_recursive(outer, log_n, width, q, pb, pubs[1] + pubs[0] + [v for p in pubs[2:] for v in p], key.root, prm, n_proofs=nproofs)[0] != 0
+    # the proofs in another order are another statement: a new outer proof, accepted with the public values in THAT order
+    outer2 = ctx.prove_shard_verifier(key, inner[::-1], log_n, width, pubs[::-1], iprm, prm)
+    assert verify_shard_recursive(outer2, log_n, width, q, pb, [v for p in pubs[::-1] for v in p], key.root, prm, n_proofs=nproofs) == (0, 0)
+    # one bad inner proof spoils the call
+    bad = inner[0].copy()
+    bad[bad.size // 3] ^= 1
+    with pytest.raises(ZkHipError):
+        ctx.prove_shard_verifier(key, [bad] + inner[1:], log_n, width, pubs, iprm, prm)
+    key.close()
+
+
+def test_sixteen_headline_shard_proofs_become_one_proof(ctx, oracle):
+    """BASELINE configs[1] x 16: sixteen 2^20 x 256 shard proofs (15 MB) verified by ONE outer proof of about a megabyte; the oracle's verifier and
+    the host verifier accept it with the 16 x 9 public values, the shape's key and nothing else"""
+    O = oracle
+    log_n, width, q, pb, n = 20, 256, 100, 16, 16
+    iprm, prm, oprm = Params(1, q, pb), Params(1, 100, 16), O.default_params(1, 100, 16)
+    pubs = [[1, 2, 3, 4, 5, 6, 7, 8, 100 + p] for p in range(n)]
+    inner = []
+    for p in range(n):
+        tr = ctx.gen_trace(SEED, 200 + p, log_n, width)
+        inner.append(ctx.prove_shard(tr, log_n, width, pubs[p], iprm))
+        tr.free()
+    key = ctx.shard_verifier_setup(log_n, width, q, pb, 9, prm, n_proofs=n)
+    outer = ctx.prove_shard_verifier(key, inner, log_n, width, pubs, iprm, prm)
+    flat = [v for p in pubs for v in p]
+    assert verify_shard_recursive(outer, log_n, width, q, pb, flat, key.root, prm, n_proofs=n) == (0, 0)
+    assert outer.size * 8 < sum(x.size for x in inner), "the join does not compress"
+    progs, tabs, lns, widths, pws = [], [], [], [], []
+    for i in range(8):
+        p_, ln, mw, pw = shard_verifier_describe(log_n, width, q, pb, 9, i, 0, n)
+        t_, _, _, _ = shard_verifier_describe(log_n, width, q, pb, 9, i, 1, n)
+        progs.append(p_), tabs.append(t_), lns.append(ln), widths.append(mw), pws.append(pw)
+    assert O.verify_machine_keyed(outer, lns, widths, pws, key.root, progs, tabs, flat, oprm) == 0
+    flat[-1] += 1
+    assert verify_shard_recursive(outer, log_n, width, q, pb, flat, key.root, prm, n_proofs=n)[0] != 0
+    print("join: %d inner proofs, %d bytes -> %d bytes, P2R 2^%d rows" % (n, sum(x.size for x in inner), outer.size, lns[0]))
+    key.close()

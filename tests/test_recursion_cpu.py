@@ -58,17 +58,48 @@ def test_a_flipped_cell_breaks_a_constraint_or_a_bus(oracle):
 
 def test_product_machine_equals_the_restatement_word_for_word():
     from zktls_amd.device import shard_verifier_describe
-    for log_n, width, q, pb, npub in ((5, 8, 4, 3, 3), (6, 16, 5, 0, 0), (7, 24, 9, 4, 9), (5, 40, 3, 2, 11), (8, 64, 12, 5, 2)):
-        sh = R.Shape(log_n, width, q, pb, npub)
+    for log_n, width, q, pb, npub, nproofs in ((5, 8, 4, 3, 3, 1), (6, 16, 5, 0, 0, 1), (7, 24, 9, 4, 9, 1), (5, 40, 3, 2, 11, 1), (8, 64, 12, 5, 2, 1),
+                                               (5, 8, 4, 3, 3, 2), (5, 8, 4, 3, 3, 3), (6, 16, 5, 1, 9, 4)):
+        sh = R.Shape(log_n, width, q, pb, npub, nproofs)
         names, progs, tabs, pres, h = R.order(sh), R.programs(sh), R.tables(sh), R.preprocessed(sh), R.heights(sh)
         for i, nm in enumerate(names):
-            p, ln, mw, pw = shard_verifier_describe(log_n, width, q, pb, npub, i, 0)
-            t, _, _, _ = shard_verifier_describe(log_n, width, q, pb, npub, i, 1)
-            e, _, _, _ = shard_verifier_describe(log_n, width, q, pb, npub, i, 2)
-            assert ln == h[nm] and p.tolist() == [int(x) for x in progs[nm]], (nm, "program")
-            assert t.tolist() == [int(x) for x in tabs[nm]], (nm, "table")
+            p, ln, mw, pw = shard_verifier_describe(log_n, width, q, pb, npub, i, 0, nproofs)
+            t, _, _, _ = shard_verifier_describe(log_n, width, q, pb, npub, i, 1, nproofs)
+            e, _, _, _ = shard_verifier_describe(log_n, width, q, pb, npub, i, 2, nproofs)
+            assert ln == h[nm] and p.tolist() == [int(x) for x in progs[nm]], (nm, "program", nproofs)
+            assert t.tolist() == [int(x) for x in tabs[nm]], (nm, "table", nproofs)
             want = np.zeros(0, dtype=np.uint32) if pres[nm] is None else pres[nm].ravel()
-            assert e.tolist() == want.tolist() and pw == (0 if pres[nm] is None else pres[nm].shape[1]), (nm, "preprocessed")
+            assert e.tolist() == want.tolist() and pw == (0 if pres[nm] is None else pres[nm].shape[1]), (nm, "preprocessed", nproofs)
+
+
+def test_the_join_one_outer_proof_for_several_inner_proofs(oracle):
+    """n_proofs inner proofs of one shape, ONE outer proof: programs hold, buses balance, the oracle proves it, three verifiers accept the public
+    values of all proofs in order and refuse them swapped"""
+    import pyverify_chips
+    from zktls_amd._lib import Params
+    from zktls_amd.device import verify_shard_recursive
+    O = oracle
+    log_n, width, q, pb = 5, 8, 4, 3
+    oprm, prm = O.default_params(1, 20, 8), Params(1, 20, 8)
+    for nproofs in (2, 3):
+        pubs = [[1, 2, 10 + p] for p in range(nproofs)]
+        proofs = [inner_proof(O, log_n, width, q, pb, pubs[p], shard=p) for p in range(nproofs)]
+        sh, mains, pres, progs, tabs, pv = R.machine(proofs, log_n, width, pubs, q, pb)
+        for name, main, pre, prog in zip(R.order(sh), mains, pres, progs):
+            rows = main if pre is None else np.concatenate([pre, main], axis=1)
+            assert S.check_rows(prog, rows, pv) == [], name
+        assert R.bus_balance(mains, pres, tabs) == []
+        lns = [m.shape[0].bit_length() - 1 for m in mains]
+        widths, pws = [m.shape[1] for m in mains], [0 if p is None else p.shape[1] for p in pres]
+        vk = O.machine_setup(pres, lns, oprm)
+        op = O.prove_machine_keyed(mains, pres, progs, tabs, pv, oprm)
+        assert op.size < 60 * sum(len(p) for p in proofs)              # (small shapes: the outer proof is bigger than these tiny inner proofs; at the headline shape it is 1 / 11 of sixteen)
+        assert O.verify_machine_keyed(op, lns, widths, pws, vk, progs, tabs, pv, oprm) == 0
+        assert verify_shard_recursive(op, log_n, width, q, pb, pv, vk, prm, n_proofs=nproofs) == (0, 0)
+        assert pyverify_chips.verify(op.tobytes(), lns, widths, pv, log_blowup=1, num_queries=20, pow_bits=8, programs=progs, tables=tabs, pre_widths=pws, pre_root=[int(x) for x in vk]) is True
+        swapped = pubs[1] + pubs[0] + [v for p in pubs[2:] for v in p]
+        assert verify_shard_recursive(op, log_n, width, q, pb, swapped, vk, prm, n_proofs=nproofs)[0] != 0
+        assert verify_shard_recursive(op, log_n, width, q, pb, pv, vk, prm, n_proofs=nproofs + 1)[0] != 0
 
 
 def test_oracle_proves_the_machine_and_three_verifiers_take_no_byte_of_the_inner_proof(oracle):

@@ -2,6 +2,7 @@
 // `rocprofv3 --kernel-trace` (worker threads of the transcript batch; 0 of 80 runs without the profiler).
 //   repro_lib <mode> <calls>      mode a: lock-step off, 1 worker      b: lock-step off, 16 workers
 //                                      c: lock-step on, 1 lane          d: lock-step on, 6 lanes
+//                                      e: like b with zkhip_set_fri_graph(0): no hipGraphLaunch anywhere
 // Each call is one zkhip_prove_transcripts of 64 transcripts of 13 221 bytes (the bench's batch64).  Plain C++ over the C ABI.
 // Prints the calls completed; tools/segv/run.py starts it many times with and without the profiler and counts the exit statuses.
 #include <cstdio>
@@ -12,7 +13,7 @@
 #include "../../include/zkhip.h"
 
 int main(int argc, char** argv) {
-    if (argc < 3) { std::fprintf(stderr, "usage: %s a|b|c|d <calls>\n", argv[0]); return 1; }
+    if (argc < 3) { std::fprintf(stderr, "usage: %s a|b|c|d|e <calls>\n", argv[0]); return 1; }
     const char mode = argv[1][0];
     const int calls = std::atoi(argv[2]);
     if (zkhip_device_count() <= 0) { std::fprintf(stderr, "no device\n"); return 2; }
@@ -31,7 +32,7 @@ int main(int argc, char** argv) {
     }
     int in_flight = 4;
     if (mode == 'a') { zkhip_set_lockstep(0, 0); in_flight = 1; }
-    else if (mode == 'b') { zkhip_set_lockstep(0, 0); in_flight = 16; }
+    else if (mode == 'b' || mode == 'e') { zkhip_set_lockstep(0, 0); in_flight = 16; if (mode == 'e') zkhip_set_fri_graph(0); }
     else if (mode == 'c') zkhip_set_lockstep(16, 1);
     else zkhip_set_lockstep(16, 6);
     uint32_t vk[8];

@@ -47,7 +47,9 @@ constexpr uint32_t E0 = 0, E1 = 4, BIT = 8, K = 9, X = 10, XI = 11, S = 12, T = 
 constexpr uint32_t K2 = 32, IDX = 33, L_WIRED = 34;
 // the shard verifier's form (shard_verifier.inl): one more column, XS = X (1 - 2 BIT) -- on a query's first row the query's evaluation point
 // divided by the coset shift; no public final value (END rows send their folded value to the transcript table instead)
-constexpr uint32_t XS = 34, L_REC = 35, BUS_FIN = 60;
+// PT = (number of the inner proof) x (its trees), constant along a chain; LNX = PT + LN names the layer's tree on the buses (the join: several
+// inner proofs in one machine)
+constexpr uint32_t XS = 34, PT = 35, LNX = 36, L_REC = 37, BUS_FIN = 60;
 constexpr uint32_t BUS_E0 = 40, BUS_E1 = 41, BUS_R0 = 42, BUS_R1 = 43, BUS_Q = 44;
 constexpr uint32_t BUS_B = 45, BUS_BF = 46;                  // transcript machine: (layer, beta) from the Poseidon2 chip's transcript rows to the ROOTS table, and from there to the fold rows
 constexpr uint32_t BUS_S0 = 47, BUS_S1 = 48, BUS_I = 49;     // query-phase machine: a sponge row's sampled words (two halves) to the SAMPLES chip, (query, index) from there to QUERIES
@@ -162,7 +164,11 @@ std::vector<uint32_t> build_program(int RL, bool wired, bool transcript = false,
         b.add(ALL, Terms{{1u, {var(K2)}}, {P - 2, {var(K)}}});
         b.add(ALL, Terms{{1u, {var(IDX)}}, {P - 1, {var(K2)}}, {P - 1, {var(BIT)}}});
     }
-    if (rec) b.add(ALL, Terms{{1u, {var(XS)}}, {P - 1, {var(X)}}, {2u, {var(X), var(BIT)}}});
+    if (rec) {
+        b.add(ALL, Terms{{1u, {var(XS)}}, {P - 1, {var(X)}}, {2u, {var(X), var(BIT)}}});
+        b.add(ALL, Terms{{1u, {var(LNX)}}, {P - 1, {var(PT)}}, {P - 1, {var(LN)}}});
+        b.add(TRANSITION, gated(Terms{{1u, {var(PT)}}, {P - 1, {var(PT, true)}}}));
+    }
     std::vector<uint32_t> p{AIR_MAGIC, 1u, W, b.count, NP, (uint32_t)(6 + b.body.size())};
     p.insert(p.end(), b.body.begin(), b.body.end());
     return p;
@@ -369,15 +375,16 @@ struct TraceArgs {
     uint64_t rows;
     uint32_t* trace; uint64_t ld;                           // Montgomery
     uint32_t* finals;                                       // [n_queries][4] canonical: the value every chain ends in
+    uint32_t pt;                                            // rec form: the PT column's value (canonical)
+    uint64_t row_base, pad_from;                            // the chains' rows start at row_base; rows pad_from .. rows - 1 are padding (pad_from = rows: none)
 };
 // one thread per query walks its layers (the folded value of a layer is the next layer's own entry); threads past the queries fill
 // the padding rows: zeros with T = 1
 __device__ __forceinline__ void fri_trace_kernel_body(const TraceArgs& a) {
     const uint32_t q = blockIdx.x * blockDim.x + threadIdx.x;
     const uint32_t RL = a.layers, W = a.width, L = a.wired == 2u ? L_REC : a.wired ? L_WIRED : frichip::L;
-    const uint64_t used = (uint64_t)a.n_queries * RL;
     if (q >= a.n_queries) {
-        for (uint64_t r = used + (q - a.n_queries); r < a.rows; r += (uint64_t)gridDim.x * blockDim.x - a.n_queries) {
+        for (uint64_t r = a.pad_from + (q - a.n_queries); r < a.rows; r += (uint64_t)gridDim.x * blockDim.x - a.n_queries) {
             uint32_t* row = a.trace + r * a.ld;
             for (uint32_t c = 0; c < W; c++) row[c] = c == T ? MONTY_R1 : 0u;
         }
@@ -388,7 +395,7 @@ __device__ __forceinline__ void fri_trace_kernel_body(const TraceArgs& a) {
     for (int i = 0; i < 4; i++) own.c[i] = to_monty(a.values[4 * q + i]);
     uint32_t tcol[MAX_LAYERS];
     for (uint32_t l = 0; l < RL; l++) {
-        uint32_t* row = a.trace + ((uint64_t)q * RL + l) * a.ld;
+        uint32_t* row = a.trace + (a.row_base + (uint64_t)q * RL + l) * a.ld;
         const uint32_t bit = idx & 1u, k = idx >> 1;
         Ext sib, beta;
         for (int i = 0; i < 4; i++) { sib.c[i] = to_monty(a.siblings[4 * ((uint64_t)q * RL + l) + i]); beta.c[i] = to_monty(a.betas[4 * l + i]); }
@@ -412,7 +419,7 @@ __device__ __forceinline__ void fri_trace_kernel_body(const TraceArgs& a) {
         if (l + 1 < RL) { row[G] = MONTY_R1; row[GS] = row[S]; row[GT] = tcol[l]; }
         for (int i = 0; i < 4; i++) row[OWN + i] = own.c[i];
         if (a.wired) { row[K2] = to_monty(2u * k); row[IDX] = to_monty(2u * k + bit); }
-        if (a.wired == 2u) row[XS] = bit ? fsub(0u, x) : x;
+        if (a.wired == 2u) { row[XS] = bit ? fsub(0u, x) : x; row[PT] = to_monty(a.pt); row[LNX] = to_monty(a.pt + l); }
         own = fold;
         idx = k;
     }
@@ -420,7 +427,7 @@ __device__ __forceinline__ void fri_trace_kernel_body(const TraceArgs& a) {
     uint32_t bacc = idx ? two_adic_generator((int)RL + 1) : MONTY_R1;
     for (int l = (int)RL - 1; l >= 0; l--) {
         bacc = fmul(bacc, tcol[l]);
-        a.trace[((uint64_t)q * RL + (uint32_t)l) * a.ld + B] = bacc;
+        a.trace[(a.row_base + (uint64_t)q * RL + (uint32_t)l) * a.ld + B] = bacc;
     }
     for (int i = 0; i < 4; i++) a.finals[4 * q + i] = from_monty(own.c[i]);
 }
@@ -528,7 +535,8 @@ size_t zkhip_fri_chip_air(int layers, uint32_t* program, size_t cap_words) {
 
 }  // extern "C"
 static int fri_gen_trace(zkhip_ctx* ctx, int layers, size_t n_queries, const uint32_t* betas, const uint32_t* indices, const uint32_t* values,
-                         const uint32_t* siblings, int log_rows, uint32_t* d_trace, size_t ld, uint32_t* finals, bool wired, bool rec = false) {
+                         const uint32_t* siblings, int log_rows, uint32_t* d_trace, size_t ld, uint32_t* finals, bool wired, bool rec = false, uint32_t pt = 0,
+                         uint64_t row_base = 0, int64_t pad_from = -1) {
     CHECK_CTX(ctx);
     int need;
     ZK_TRY(frichip::shape_ok(layers, n_queries, &need));
@@ -553,7 +561,8 @@ static int fri_gen_trace(zkhip_ctx* ctx, int layers, size_t n_queries, const uin
     a.betas = d; a.indices = d + nb; a.values = d + nb + n_queries; a.siblings = d + nb + n_queries + nv;
     a.n_queries = (uint32_t)n_queries; a.layers = (uint32_t)layers; a.width = W; a.log_h = (uint32_t)layers + 1u; a.wired = rec ? 2u : wired ? 1u : 0u;
     a.rows = (uint64_t)1 << log_rows; a.trace = d_trace; a.ld = ld; a.finals = d + nb + n_queries + nv + ns;
-    const size_t pad = a.rows - n_queries * (size_t)layers;
+    a.pt = pt; a.row_base = row_base; a.pad_from = pad_from < 0 ? (uint64_t)n_queries * (uint64_t)layers : (uint64_t)pad_from;
+    const size_t pad = a.rows - a.pad_from;
     const size_t threads = n_queries + (pad < 4096 ? pad : 4096);            // the padding rows are shared among up to 4096 extra threads
     ZK_LAUNCH(frichip::fri_trace_kernel, frichip::fri_trace_kernel_batch, frichip::fri_trace_kernel_bargs, dim3((unsigned)((threads + 63) / 64)), dim3(64), 0, ctx->stream, a);
     ZK_HIP(hipGetLastError());

@@ -716,7 +716,7 @@ __device__ __forceinline__ void p2r_rows_kernel_body(const p2chip::P2RArgs& a) {
     const uint64_t r = p - a.n_chains;
     if (r < a.n_transcript) {
         for (int j = 0; j < 16; j++) in[j] = to_monty(a.chain_inputs[16 * r + j]);
-        p2chip_fill_row(a.trace + r * a.ld, in, 0u, 0u, 0u, 0u, 0u, 0u, out);
+        p2chip_fill_row(a.trace + (uint64_t)a.trows[r] * a.ld, in, 0u, 0u, 0u, 0u, 0u, 0u, out);
         return;
     }
     const uint64_t row = a.used_rows + (r - a.n_transcript);

@@ -56,13 +56,14 @@ struct LayerPathsArgs {
 // The shard verifier's chip (fri_chip.hip / shard_verifier.inl: P2R): the same 352 permutation columns (IN .. BIT), KP in column 352, nothing else
 // in the main trace (every flag is a PREPROCESSED column there).  Rows are filled by CHAINS: chain c starts at row desc[6 c], hashes
 // desc[6 c + 1] blocks of 8 words (data + desc[6 c + 2]) with the overwrite-mode sponge (KP = 2 index on the last of them), then walks
-// desc[6 c + 3] path levels with the leaf index desc[6 c + 4] and the siblings at data + desc[6 c + 5]; the first n_transcript rows are the
+// desc[6 c + 3] path levels with the leaf index desc[6 c + 4] and the siblings at data + desc[6 c + 5]; n_transcript rows (trows) are the
 // transcript's sponge rows, filled side by side from the input states the host walked.
 constexpr uint32_t R_KP = 352, R_WIDTH = 360;
 struct P2RArgs {
     const uint32_t* desc;            // [n_chains][6]
     const uint32_t* data;            // canonical words
     const uint32_t* chain_inputs;    // [n_transcript][16] canonical
+    const uint32_t* trows;           // [n_transcript] the row of every transcript entry (several inner proofs: each proof's sponge rows start its segment)
     uint32_t n_chains, n_transcript;
     uint64_t rows, used_rows;
     uint32_t* trace; uint64_t ld;    // [rows][ld >= R_WIDTH], Montgomery

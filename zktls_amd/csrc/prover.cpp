@@ -21,6 +21,7 @@
 #include "proof_common.h"
 #include "batch.h"
 
+namespace zk { std::atomic<bool> g_fri_graph{true}; }
 namespace zk {
 
 // The program digest is a sponge over every 16-bit half of the program (4 500 permutations for the 18 000-word SHA-256 chip: 6.5 ms
@@ -264,9 +265,10 @@ static int fri_commit_phase(zkhip_ctx* ctx, Challenger& ch, const Shape& sh, int
     // sizes and workspace addresses: it is captured once into a HIP graph and replayed with one launch per proof
     // (A/B builds: ZKHIP_FRI_GRAPH=0 keeps the plain launches); capture is thread-local, other contexts' threads are not affected.
 #ifdef ZKHIP_AB_HOOKS
-    static const bool use_graph = [] { const char* e = getenv("ZKHIP_FRI_GRAPH"); return !e || atoi(e) != 0; }();
+    static const bool env_graph = [] { const char* e = getenv("ZKHIP_FRI_GRAPH"); return !e || atoi(e) != 0; }();
+    const bool use_graph = env_graph && g_fri_graph.load();
 #else
-    constexpr bool use_graph = true;
+    const bool use_graph = g_fri_graph.load();       // zkhip_set_fri_graph: off for runs under rocprofv3, whose kernel tracing crashes on hipGraphLaunch (tools/segv)
 #endif
     if (d_chal && use_graph && !t_batcher) {                   // lock-step members launch one by one: their launches merge across the batch
         std::vector<uint64_t> key = {(uint64_t)H, (uint64_t)K, (uint64_t)RL, (uint64_t)sh.hw, (uint64_t)m, (uint64_t)(uintptr_t)layers,
@@ -1417,3 +1419,5 @@ int zkhip_last_prove_debug(zkhip_ctx* ctx, zkhip_prove_debug* out) {
 }
 
 }  // extern "C"
+
+extern "C" void zkhip_set_fri_graph(int on) { zk::g_fri_graph.store(on != 0); }

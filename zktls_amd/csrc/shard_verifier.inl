@@ -89,19 +89,23 @@ inline int lg(size_t n, int lo = 5) { int l = lo; while (((size_t)1 << l) < n) l
 
 // ---- buses (BUS_E0 / E1 / R0 / R1 / Q / S0 / S1 / I keep their meaning from the machines above)
 constexpr uint32_t BUS_IN0 = 61, BUS_IN1 = 62, BUS_TC = 63, BUS_BETA = 64, BUS_SC = 65, BUS_QI = 66, BUS_AT = 67, BUS_AQ = 68;
-constexpr uint32_t BUS_K0 = 70, BUS_K1 = 71, BUS_K2 = 72, BUS_K3 = 73, BUS_KFA = 74, BUS_KO0 = 75, BUS_KO1 = 76, BUS_KO2 = 77, BUS_OY = 78, BUS_OA = 79;
+// K0 .. K0 + 6: the QUERY chip's seven constants; KO0 .. KO0 + 4: the OPENED chip's five; OY, OY + 1: its two sums (every tuple keyed by the proof's number)
+constexpr uint32_t BUS_K0 = 70, BUS_KFA = 77, BUS_KO0 = 78, BUS_OY = 83, BUS_OA = 85;
 using frichip::BUS_FIN; using frichip::BUS_E0; using frichip::BUS_E1; using frichip::BUS_R0; using frichip::BUS_R1; using frichip::BUS_Q;
 using frichip::BUS_S0; using frichip::BUS_S1; using frichip::BUS_I;
 
 // ---- the shape of an inner proof: everything the machine's structure depends on
 struct Shape {
-    int n, W, Q, PB, NPUB, R, H, G, WB;
+    int n, W, Q, PB, NPUB, R, H, G, WB, NP;          // NP: inner proofs verified by ONE outer proof (the join); every chip holds proof 0's rows, then proof 1's, ...
+    int TAGSPAN, TREES;                               // tags / trees of one proof: tags, tree numbers and query numbers carry the proof's number
     uint32_t head[6];
     int f0, r0, TA, TQ, TO0, TF, TL0, TP, NS, NT, NTS;
     std::vector<int> pub_rows;
     size_t fri_rows, p2_fri0, p2_tr0, p2_q0, p2_rows;
     int tag0;
-    uint32_t row_tag(int q, int b) const { return (uint32_t)(tag0 + q * (WB + 1) + b); }
+    uint32_t ttag(int p, int T) const { return (uint32_t)(p * TAGSPAN + T); }
+    uint32_t row_tag(int p, int q, int b) const { return (uint32_t)(p * TAGSPAN + tag0 + q * (WB + 1) + b); }
+    uint32_t npub_total() const { return (uint32_t)(NP * NPUB); }
     int absorbed(int T) const {
         if (T < f0 || (TQ <= T && T < TP)) return 8;
         if (T == f0 && r0) return r0;
@@ -110,9 +114,11 @@ struct Shape {
     }
     bool has_challenge(int T) const { return T == TA || T == TQ || T == TF || (TL0 <= T && T < TP); }
 };
-int make_shape(int log_n, uint32_t width, size_t n_queries, int pow_bits, size_t n_public, Shape& s) {
-    if (log_n < frichip::MIN_LAYERS || log_n > 20 || width < 8 || width > 1024 || width % 8 || n_queries < 1 || n_queries > 1024 || pow_bits < 0 || pow_bits > 30 || n_public > 64)
-        return fail(ZKHIP_ERR_INVALID, "shard verifier: 2^2 .. 2^20 rows, a width of 8 .. 1024 in multiples of 8, 1 .. 1024 queries, 0 .. 30 proof-of-work bits, at most 64 public values");
+int make_shape(int log_n, uint32_t width, size_t n_queries, int pow_bits, size_t n_public, size_t n_proofs, Shape& s) {
+    if (log_n < frichip::MIN_LAYERS || log_n > 20 || width < 8 || width > 1024 || width % 8 || n_queries < 1 || n_queries > 1024 || pow_bits < 0 || pow_bits > 30 || n_public > 64 ||
+        n_proofs < 1 || n_proofs > 64)
+        return fail(ZKHIP_ERR_INVALID, "shard verifier: 2^2 .. 2^20 rows, a width of 8 .. 1024 in multiples of 8, 1 .. 1024 queries, 0 .. 30 proof-of-work bits, at most 64 public values, 1 .. 64 proofs");
+    s.NP = (int)n_proofs;
     s.n = log_n; s.W = (int)width; s.Q = (int)n_queries; s.PB = pow_bits; s.NPUB = (int)n_public;
     s.R = log_n; s.H = log_n + 1; s.G = s.W / 4; s.WB = s.W / 8;
     const uint32_t head[6] = {(uint32_t)log_n, width, 1u, (uint32_t)n_queries, (uint32_t)pow_bits, (uint32_t)n_public};
@@ -127,7 +133,8 @@ int make_shape(int log_n, uint32_t width, size_t n_queries, int pow_bits, size_t
     s.p2_fri0 = (size_t)s.NT; s.p2_tr0 = s.p2_fri0 + (size_t)s.Q * s.fri_rows; s.p2_q0 = s.p2_tr0 + (size_t)s.Q * (size_t)(s.WB + s.H);
     s.p2_rows = s.p2_q0 + (size_t)s.Q * (size_t)(1 + s.H);
     s.tag0 = s.NT;
-    if (lg(s.p2_rows) > MAX_LOG_ROWS) return fail(ZKHIP_ERR_INVALID, "shard verifier: the Poseidon2 chip would need more than 2^22 rows");
+    s.TAGSPAN = s.NT + s.Q * (s.WB + 1); s.TREES = s.R + 2;
+    if (lg((size_t)s.NP * s.p2_rows) > MAX_LOG_ROWS) return fail(ZKHIP_ERR_INVALID, "shard verifier: the Poseidon2 chip would need more than 2^22 rows");
     return ZKHIP_OK;
 }
 
@@ -149,7 +156,7 @@ std::vector<uint32_t> p2r_program(const Shape& sh) {
     for (uint32_t j = 0; j < 8; j++) c.add(TRANSITION, pmul(pv(PP_K + j, true), padd(pv(IN_ + j, true), pneg(pv(OUT + j)))));
     c.add(TRANSITION, pmul(pv(PP_CH, true), padd(padd(pv(KP_), pscale(pv(KP_, true), P - 2)), pneg(pv(BIT_)))));
     c.add(ALL, pmul(pv(PP_END), padd(pv(KP_), pneg(pv(BIT_)))));
-    return c.program(P2_PRE + P2_MAIN, (uint32_t)sh.NPUB);
+    return c.program(P2_PRE + P2_MAIN, sh.npub_total());
 }
 // interaction tables: {sign, multiplicity column, bus, n, columns...}
 struct Tab {
@@ -180,13 +187,14 @@ std::vector<uint32_t> p2r_table() {
 void monty_all(std::vector<uint32_t>& t) { for (uint32_t& v : t) v = to_monty(v); }
 void p2r_pre(const Shape& sh, int log_rows, std::vector<uint32_t>& t) {
     t.assign((size_t)P2_PRE << log_rows, 0u);
-    auto row = [&](size_t r) { return t.data() + (size_t)P2_PRE * r; };
+    for (int p = 0; p < sh.NP; p++) {
+    auto row = [&](size_t r) { return t.data() + (size_t)P2_PRE * ((size_t)p * sh.p2_rows + r); };
     for (int T = 0; T < sh.NT; T++) {
         uint32_t* r = row((size_t)T);
         const int k = sh.absorbed(T);
         if (T == 0) r[PP_SS] = 1;
         else { r[PP_SPG] = 1; for (int j = k; j < 8; j++) r[PP_K + j] = 1; }
-        r[PP_TAG] = (uint32_t)T;
+        r[PP_TAG] = sh.ttag(p, T);
         if (k) r[PP_RIN] = 1;
         if (sh.has_challenge(T)) r[PP_SCH] = 1;
         if (T >= sh.TP) r[PP_SSMP] = 1;
@@ -195,11 +203,11 @@ void p2r_pre(const Shape& sh, int log_rows, std::vector<uint32_t>& t) {
     for (int q = 0; q < sh.Q; q++)
         for (int l = 0; l < sh.R; l++) {
             uint32_t* r = row(at++);
-            r[PP_SS] = 1; r[PP_RPAIR] = 1; r[PP_TREE] = (uint32_t)l;
+            r[PP_SS] = 1; r[PP_RPAIR] = 1; r[PP_TREE] = (uint32_t)(p * sh.TREES + l);
             const int depth = sh.H - (l + 1);
             for (int lvl = 0; lvl < depth; lvl++) {
                 r = row(at++);
-                r[PP_CH] = 1; r[PP_TREE] = (uint32_t)l;
+                r[PP_CH] = 1; r[PP_TREE] = (uint32_t)(p * sh.TREES + l);
                 if (lvl == depth - 1) r[PP_END] = r[PP_SROOT] = 1;
             }
         }
@@ -209,28 +217,29 @@ void p2r_pre(const Shape& sh, int log_rows, std::vector<uint32_t>& t) {
             for (int b = 0; b < blocks; b++) {
                 uint32_t* r = row(at++);
                 r[b == 0 ? PP_SS : PP_SPG] = 1;
-                r[PP_RIN] = 1; r[PP_TAG] = sh.row_tag(q, which ? sh.WB : b);
+                r[PP_RIN] = 1; r[PP_TAG] = sh.row_tag(p, q, which ? sh.WB : b);
             }
             for (int lvl = 0; lvl < sh.H; lvl++) {
                 uint32_t* r = row(at++);
-                r[PP_CH] = 1; r[PP_TREE] = (uint32_t)tree;
-                if (lvl == 0) { r[PP_QIDX] = 1; r[PP_QN] = (uint32_t)q; }
+                r[PP_CH] = 1; r[PP_TREE] = (uint32_t)(p * sh.TREES + tree);
+                if (lvl == 0) { r[PP_QIDX] = 1; r[PP_QN] = (uint32_t)(p * sh.Q + q); }
                 if (lvl == sh.H - 1) r[PP_END] = r[PP_SROOT] = 1;
             }
         }
+    }
     }
     monty_all(t);
 }
 
 // ============================================================================================================ TS
-struct TsCols { uint32_t T, ACT, NSEND, CF, CV, IND0, IP, NROOT, NTR, TREE, HASCH, NBETA, NSC, KIND, NFIN, pre, W, TR, CH; };
+struct TsCols { uint32_t T, ACT, NSEND, CF, CV, IND0, IP, NROOT, NTR, TREE, HASCH, NBETA, NSC, KIND, NFIN, PT, pre, W, TR, CH; };
 constexpr uint32_t TS_MAIN = 20;
 TsCols ts_cols(const Shape& sh) {
     TsCols c{};
     uint32_t n = 0;
     auto take = [&](uint32_t w) { const uint32_t at = n; n += w; return at; };
-    c.T = take(1); c.ACT = take(1); c.NSEND = take(1); c.CF = take(8); c.CV = take(8); c.IND0 = take(1); c.IP = take((uint32_t)sh.pub_rows.size());
-    c.NROOT = take(1); c.NTR = take(1); c.TREE = take(1); c.HASCH = take(1); c.NBETA = take(1); c.NSC = take(1); c.KIND = take(1); c.NFIN = take(1);
+    c.T = take(1); c.ACT = take(1); c.NSEND = take(1); c.CF = take(8); c.CV = take(8); c.IND0 = take(1); c.IP = take((uint32_t)(sh.NP * (int)sh.pub_rows.size()));
+    c.NROOT = take(1); c.NTR = take(1); c.TREE = take(1); c.HASCH = take(1); c.NBETA = take(1); c.NSC = take(1); c.KIND = take(1); c.NFIN = take(1); c.PT = take(1);
     c.pre = rup4(n);
     c.W = c.pre; c.TR = c.pre + 8; c.CH = c.pre + 16;
     return c;
@@ -240,14 +249,16 @@ std::vector<uint32_t> ts_program(const Shape& sh) {
     const TsCols c = ts_cols(sh);
     Cons k;
     for (uint32_t j = 0; j < 8; j++) k.add(ALL, pmul(pv(c.CF + j), padd(pv(c.W + j), pneg(pv(c.CV + j)))));
-    for (int i = 0; i < sh.NPUB; i++) {
-        const int pos = 14 + i;
-        k.add(ALL, pmul(pv(c.IP + (uint32_t)pub_row_index(sh, pos / 8)), padd(pv(c.W + (uint32_t)(pos % 8)), pneg(ppub((uint32_t)i)))));
-    }
+    const int npr = (int)sh.pub_rows.size();
+    for (int p = 0; p < sh.NP; p++)              // the outer proof's public values: those of proof 0, then those of proof 1, ...
+        for (int i = 0; i < sh.NPUB; i++) {
+            const int pos = 14 + i;
+            k.add(ALL, pmul(pv(c.IP + (uint32_t)(p * npr + pub_row_index(sh, pos / 8))), padd(pv(c.W + (uint32_t)(pos % 8)), pneg(ppub((uint32_t)(p * sh.NPUB + i))))));
+        }
     k.add(ALL, pmul(pv(c.IND0), padd(pv(c.W + 6), pneg(pv(c.TR)))));
     k.add(ALL, pmul(pv(c.IND0), padd(pv(c.W + 7), pneg(pv(c.TR + 1)))));
     for (uint32_t j = 0; j < 6; j++) k.add(TRANSITION, pmul(pv(c.IND0), padd(pv(c.W + j, true), pneg(pv(c.TR + 2 + j)))));
-    return k.program(c.pre + TS_MAIN, (uint32_t)sh.NPUB);
+    return k.program(c.pre + TS_MAIN, sh.npub_total());
 }
 std::vector<uint32_t> ts_table(const Shape& sh) {
     const TsCols c = ts_cols(sh);
@@ -258,37 +269,40 @@ std::vector<uint32_t> ts_table(const Shape& sh) {
     t.add5(SEND, c.NSC, BUS_SC, c.KIND, c.CH);
     t.add5(RECV, c.NROOT, BUS_R0, c.TREE, c.W); t.add5(RECV, c.NROOT, BUS_R1, c.TREE, c.W + 4);
     t.add5(RECV, c.NTR, BUS_R0, c.TREE, c.TR); t.add5(RECV, c.NTR, BUS_R1, c.TREE, c.TR + 4);
-    t.add4(RECV, c.NFIN, BUS_FIN, c.W);
+    t.add5(RECV, c.NFIN, BUS_FIN, c.PT, c.W);
     return t.w;
 }
 void ts_pre(const Shape& sh, int log_rows, std::vector<uint32_t>& t) {
     const TsCols c = ts_cols(sh);
     t.assign((size_t)c.pre << log_rows, 0u);
+    const int npr = (int)sh.pub_rows.size();
+    for (int p = 0; p < sh.NP; p++)
     for (int T = 0; T < sh.NTS; T++) {
-        uint32_t* r = t.data() + (size_t)c.pre * (size_t)T;
-        r[c.T] = (uint32_t)T; r[c.ACT] = 1; r[c.NSEND] = (sh.TO0 <= T && T <= sh.TF) ? 2u : 1u;
+        uint32_t* r = t.data() + (size_t)c.pre * ((size_t)p * (size_t)sh.NTS + (size_t)T);
+        const uint32_t tree0 = (uint32_t)(p * sh.TREES);
+        r[c.T] = sh.ttag(p, T); r[c.ACT] = 1; r[c.NSEND] = (sh.TO0 <= T && T <= sh.TF) ? 2u : 1u;
         for (int j = 0; j < 8; j++) if (8 * T + j < 6) { r[c.CF + j] = 1; r[c.CV + j] = sh.head[8 * T + j]; }
         const int pi = pub_row_index(sh, T);
-        if (pi >= 0) r[c.IP + (uint32_t)pi] = 1;
-        if (T == 0) { r[c.IND0] = 1; r[c.NTR] = (uint32_t)sh.Q; r[c.TREE] = (uint32_t)sh.R; }
-        if (T == sh.TQ) { r[c.NROOT] = (uint32_t)sh.Q; r[c.TREE] = (uint32_t)sh.R + 1u; }
-        if (sh.TL0 <= T && T < sh.TP) { r[c.NROOT] = (uint32_t)sh.Q; r[c.TREE] = (uint32_t)(T - sh.TL0); r[c.NBETA] = (uint32_t)sh.Q; }
+        if (pi >= 0) r[c.IP + (uint32_t)(p * npr + pi)] = 1;
+        if (T == 0) { r[c.IND0] = 1; r[c.NTR] = (uint32_t)sh.Q; r[c.TREE] = tree0 + (uint32_t)sh.R; }
+        if (T == sh.TQ) { r[c.NROOT] = (uint32_t)sh.Q; r[c.TREE] = tree0 + (uint32_t)sh.R + 1u; }
+        if (sh.TL0 <= T && T < sh.TP) { r[c.NROOT] = (uint32_t)sh.Q; r[c.TREE] = tree0 + (uint32_t)(T - sh.TL0); r[c.NBETA] = (uint32_t)sh.Q; }
         const int kinds[3] = {sh.TA, sh.TQ, sh.TF};
-        for (int kd = 0; kd < 3; kd++) if (T == kinds[kd]) { r[c.NSC] = 1; r[c.KIND] = (uint32_t)kd; }
+        for (int kd = 0; kd < 3; kd++) if (T == kinds[kd]) { r[c.NSC] = 1; r[c.KIND] = (uint32_t)(3 * p + kd); }
         if (sh.has_challenge(T)) r[c.HASCH] = 1;
-        if (T == sh.TP) r[c.NFIN] = (uint32_t)sh.Q;
+        if (T == sh.TP) { r[c.NFIN] = (uint32_t)sh.Q; r[c.PT] = tree0; }
     }
     monty_all(t);
 }
 
 // ============================================================================================================ ROWSUM
-constexpr uint32_t RS_PRE = 8, RP_TAG = 0, RP_ACT = 1, RP_NOTFIRST = 2, RP_LAST0 = 3, RP_LAST1 = 4, RP_QN = 5, RP_FIRST = 6;
+constexpr uint32_t RS_PRE = 12, RP_TAG = 0, RP_ACT = 1, RP_NOTFIRST = 2, RP_LAST0 = 3, RP_LAST1 = 4, RP_QN = 5, RP_FIRST = 6, RP_PID = 7, RP_NFC = 8;
 constexpr uint32_t RS_V = 0, RS_ACCIN = 8, RS_T = 12, RS_FA = 44, RS_MAIN = 48;
 std::vector<uint32_t> rowsum_program(const Shape& sh) {
     const uint32_t M0 = RS_PRE;
     Cons c;
     const EE fa = ev(M0 + RS_FA);
-    c.ext(TRANSITION, esub(ev(M0 + RS_FA, true), fa));
+    c.ext(TRANSITION, egate(pv(RP_NFC, true), esub(ev(M0 + RS_FA, true), fa)));
     EE prev = ev(M0 + RS_ACCIN);
     for (int s = 7; s >= 0; s--) {
         const EE cur = ev(M0 + RS_T + 4u * (uint32_t)s);
@@ -297,40 +311,43 @@ std::vector<uint32_t> rowsum_program(const Shape& sh) {
     }
     c.ext(TRANSITION, egate(pv(RP_NOTFIRST, true), esub(ev(M0 + RS_ACCIN, true), ev(M0 + RS_T))));
     c.ext(ALL, egate(padd(pv(RP_ACT), pneg(pv(RP_NOTFIRST))), ev(M0 + RS_ACCIN)));
-    return c.program(RS_PRE + RS_MAIN, (uint32_t)sh.NPUB);
+    return c.program(RS_PRE + RS_MAIN, sh.npub_total());
 }
 std::vector<uint32_t> rowsum_table() {
     const uint32_t M0 = RS_PRE, v = M0 + RS_V, t0 = M0 + RS_T, fa = M0 + RS_FA;
     Tab t;
     t.add5(SEND, RP_ACT, BUS_IN0, RP_TAG, v); t.add5(SEND, RP_ACT, BUS_IN1, RP_TAG, v + 4);
     t.add5(SEND, RP_LAST0, BUS_AT, RP_QN, t0); t.add5(SEND, RP_LAST1, BUS_AQ, RP_QN, t0);
-    t.add4(RECV, RP_FIRST, BUS_KFA, fa);
+    t.add5(RECV, RP_FIRST, BUS_KFA, RP_PID, fa);
     return t.w;
 }
-// (q, block) in trace order: a query's trace blocks from the last to the first, then its quotient block (block number WB)
-inline void rowsum_row(const Shape& sh, size_t r, int* q, int* b) {
-    const size_t per = (size_t)sh.WB + 1;
+// (proof, q, block) in trace order: a query's trace blocks from the last to the first, then its quotient block (block number WB)
+inline void rowsum_row(const Shape& sh, size_t r, int* p, int* q, int* b) {
+    const size_t per = (size_t)sh.WB + 1, per_proof = (size_t)sh.Q * per;
+    *p = (int)(r / per_proof);
+    r %= per_proof;
     *q = (int)(r / per);
     const int i = (int)(r % per);
     *b = i < sh.WB ? sh.WB - 1 - i : sh.WB;
 }
 void rowsum_pre(const Shape& sh, int log_rows, std::vector<uint32_t>& t) {
     t.assign((size_t)RS_PRE << log_rows, 0u);
-    const size_t used = (size_t)sh.Q * (size_t)(sh.WB + 1);
+    const size_t per_proof = (size_t)sh.Q * (size_t)(sh.WB + 1), used = (size_t)sh.NP * per_proof;
     for (size_t r = 0; r < used; r++) {
-        int q, b;
-        rowsum_row(sh, r, &q, &b);
+        int p, q, b;
+        rowsum_row(sh, r, &p, &q, &b);
         uint32_t* row = t.data() + RS_PRE * r;
-        row[RP_TAG] = sh.row_tag(q, b); row[RP_ACT] = 1; row[RP_QN] = (uint32_t)q;
+        row[RP_TAG] = sh.row_tag(p, q, b); row[RP_ACT] = 1; row[RP_QN] = (uint32_t)(p * sh.Q + q); row[RP_PID] = (uint32_t)p;
         row[RP_NOTFIRST] = (b == sh.WB - 1 || b == sh.WB) ? 0u : 1u;
         row[RP_LAST0] = b == 0 ? 1u : 0u; row[RP_LAST1] = b == sh.WB ? 1u : 0u;
+        const bool first = r % per_proof == 0;
+        row[RP_FIRST] = first ? 1u : 0u; row[RP_NFC] = first ? 0u : 1u;
     }
-    t[RP_FIRST] = 1;
     monty_all(t);
 }
 
 // ============================================================================================================ QUERY
-constexpr uint32_t Q_PRE = 4, QP_QN = 0, QP_ACT = 1, QP_ACT2 = 2, QP_FIRST = 3;
+constexpr uint32_t Q_PRE = 8, QP_QN = 0, QP_ACT = 1, QP_ACT2 = 2, QP_FIRST = 3, QP_PID = 4, QP_NFC = 5, QP_PT = 6;
 struct QCols { uint32_t IDX, XQ, RO, AT, AQ, I1, I2, P1, P2, P2O, P3, P3O, ZETA, ZNX, YL, YN, YQ, OFFN, OFFQ, end; };
 constexpr QCols qcols() {
     QCols c{};
@@ -346,7 +363,7 @@ std::vector<uint32_t> query_program(const Shape& sh) {
     constexpr QCols m = qcols();
     Cons c;
     const uint32_t consts[7] = {m.ZETA, m.ZNX, m.YL, m.YN, m.YQ, m.OFFN, m.OFFQ};
-    for (uint32_t col : consts) c.ext(TRANSITION, esub(ev(col, true), ev(col)));
+    for (uint32_t col : consts) c.ext(TRANSITION, egate(pv(QP_NFC, true), esub(ev(col, true), ev(col))));
     const EE x = eb(pscale(pv(m.XQ), GEN));
     const Poly act = pv(QP_ACT);
     c.ext(ALL, egate(act, esub(emul(esub(x, ev(m.ZETA)), ev(m.I1)), ec(1))));
@@ -357,28 +374,32 @@ std::vector<uint32_t> query_program(const Shape& sh) {
     c.ext(ALL, esub(ev(m.P3), emul(esub(ev(m.AQ), ev(m.YQ)), ev(m.I1))));
     c.ext(ALL, esub(ev(m.P3O), emul(ev(m.OFFQ), ev(m.P3))));
     c.ext(ALL, esub(ev(m.RO), eadd(ev(m.P1), ev(m.P2O), ev(m.P3O))));
-    return c.program(Q_PRE + Q_MAIN, (uint32_t)sh.NPUB);
+    return c.program(Q_PRE + Q_MAIN, sh.npub_total());
 }
 std::vector<uint32_t> query_table() {
     constexpr QCols m = qcols();
     Tab t;
     t.add(RECV, QP_ACT, BUS_I, {QP_QN, m.IDX});
-    t.add(RECV, QP_ACT, BUS_Q, {m.IDX, m.XQ, m.RO, m.RO + 1, m.RO + 2, m.RO + 3});
+    t.add(RECV, QP_ACT, BUS_Q, {QP_PT, m.IDX, m.XQ, m.RO, m.RO + 1, m.RO + 2, m.RO + 3});
     t.add5(RECV, QP_ACT, BUS_AT, QP_QN, m.AT); t.add5(RECV, QP_ACT, BUS_AQ, QP_QN, m.AQ);
     t.add(SEND, QP_ACT2, BUS_QI, {QP_QN, m.IDX});
-    t.add8(RECV, QP_FIRST, BUS_K0, m.ZETA, m.ZNX); t.add8(RECV, QP_FIRST, BUS_K1, m.YL, m.YN); t.add8(RECV, QP_FIRST, BUS_K2, m.YQ, m.OFFN);
-    t.add4(RECV, QP_FIRST, BUS_K3, m.OFFQ);
+    const uint32_t consts[7] = {m.ZETA, m.ZNX, m.YL, m.YN, m.YQ, m.OFFN, m.OFFQ};
+    for (uint32_t i = 0; i < 7; i++) t.add5(RECV, QP_FIRST, BUS_K0 + i, QP_PID, consts[i]);
     return t.w;
 }
 void query_pre(const Shape& sh, int log_rows, std::vector<uint32_t>& t) {
     t.assign((size_t)Q_PRE << log_rows, 0u);
-    for (int q = 0; q < sh.Q; q++) { uint32_t* r = t.data() + Q_PRE * (size_t)q; r[QP_QN] = (uint32_t)q; r[QP_ACT] = 1; r[QP_ACT2] = 2; }
-    t[QP_FIRST] = 1;
+    for (int p = 0; p < sh.NP; p++)
+        for (int q = 0; q < sh.Q; q++) {
+            uint32_t* r = t.data() + Q_PRE * ((size_t)p * (size_t)sh.Q + (size_t)q);
+            r[QP_QN] = (uint32_t)(p * sh.Q + q); r[QP_ACT] = 1; r[QP_ACT2] = 2; r[QP_FIRST] = q == 0 ? 1u : 0u; r[QP_PID] = (uint32_t)p; r[QP_NFC] = q == 0 ? 0u : 1u;
+            r[QP_PT] = (uint32_t)(p * sh.TREES);
+        }
     monty_all(t);
 }
 
 // ============================================================================================================ OPENED
-constexpr uint32_t OP_PRE = 12, OP_ACT = 0, OP_FIRST = 1, OP_LASTG = 2, OP_NOTFIRST = 3, OP_K1 = 4, OP_K2 = 5, OP_K3 = 6, OP_TL0 = 7, OP_TL1 = 8, OP_TN0 = 9, OP_TN1 = 10;
+constexpr uint32_t OP_PRE = 12, OP_ACT = 0, OP_FIRST = 1, OP_LASTG = 2, OP_NOTFIRST = 3, OP_K1 = 4, OP_K2 = 5, OP_K3 = 6, OP_TL0 = 7, OP_TL1 = 8, OP_TN0 = 9, OP_TN1 = 10, OP_PID = 11;
 enum OpCol : uint32_t { O_A, O_B, O_C, O_D, O_AN, O_BN, O_CN, O_DN, O_FA, O_FA4, O_ALPHA, O_SELT, O_SELF, O_PW, O_PWN, O_H2, O_H1, O_IL, O_G2, O_G1, O_INX,
                         O_YLIN, O_YLO, O_YNIN, O_YNO, O_A2, O_AB, O_ACCIN, O_U1, O_U2, O_ACCO, O_COUNT };
 constexpr uint32_t oc(uint32_t name) { return OP_PRE + 4u * name; }
@@ -387,8 +408,8 @@ std::vector<uint32_t> opened_program(const Shape& sh) {
     Cons c;
     auto e = [&](uint32_t name, bool nxt = false) { return ev(oc(name), nxt); };
     const uint32_t consts[5] = {O_FA, O_FA4, O_ALPHA, O_SELT, O_SELF};
-    for (uint32_t nm : consts) c.ext(TRANSITION, esub(e(nm, true), e(nm)));
     const Poly first = pv(OP_FIRST), nf = pv(OP_NOTFIRST, true);
+    for (uint32_t nm : consts) c.ext(TRANSITION, egate(nf, esub(e(nm, true), e(nm))));
     c.ext(ALL, egate(first, esub(e(O_PW), ec(1))));
     c.ext(ALL, esub(e(O_PWN), emul(e(O_PW), e(O_FA4))));
     c.ext(TRANSITION, egate(nf, esub(e(O_PW, true), e(O_PWN))));
@@ -413,31 +434,34 @@ std::vector<uint32_t> opened_program(const Shape& sh) {
     c.ext(ALL, esub(e(O_U2), eadd(emul(e(O_U1), al), emul(e(O_SELT), esub(esub(esub(e(O_DN), e(O_AB)), e(O_C)), eb(pv(OP_K2)))))));
     c.ext(ALL, esub(e(O_ACCO), eadd(emul(e(O_U2), al), emul(e(O_SELF), esub(e(O_D), eb(pv(OP_K3)))))));
     c.ext(TRANSITION, egate(nf, esub(e(O_ACCIN, true), e(O_ACCO))));
-    return c.program(OP_PRE + OP_MAIN, (uint32_t)sh.NPUB);
+    return c.program(OP_PRE + OP_MAIN, sh.npub_total());
 }
 std::vector<uint32_t> opened_table() {
     Tab t;
     const uint32_t tags[4] = {OP_TL0, OP_TL1, OP_TN0, OP_TN1}, lo[4] = {O_A, O_C, O_AN, O_CN}, hi[4] = {O_B, O_D, O_BN, O_DN};
     for (int i = 0; i < 4; i++) { t.add5(RECV, OP_ACT, BUS_IN0, tags[i], oc(lo[i])); t.add5(RECV, OP_ACT, BUS_IN1, tags[i], oc(hi[i])); }
-    t.add8(SEND, OP_LASTG, BUS_OY, oc(O_YLO), oc(O_YNO)); t.add4(SEND, OP_LASTG, BUS_OA, oc(O_ACCO));
-    t.add8(RECV, OP_FIRST, BUS_KO0, oc(O_FA), oc(O_FA4)); t.add8(RECV, OP_FIRST, BUS_KO1, oc(O_ALPHA), oc(O_SELT)); t.add4(RECV, OP_FIRST, BUS_KO2, oc(O_SELF));
+    t.add5(SEND, OP_LASTG, BUS_OY, OP_PID, oc(O_YLO)); t.add5(SEND, OP_LASTG, BUS_OY + 1, OP_PID, oc(O_YNO)); t.add5(SEND, OP_LASTG, BUS_OA, OP_PID, oc(O_ACCO));
+    const uint32_t consts[5] = {O_FA, O_FA4, O_ALPHA, O_SELT, O_SELF};
+    for (uint32_t i = 0; i < 5; i++) t.add5(RECV, OP_FIRST, BUS_KO0 + i, OP_PID, oc(consts[i]));
     return t.w;
 }
 void opened_pre(const Shape& sh, int log_rows, std::vector<uint32_t>& t) {
     t.assign((size_t)OP_PRE << log_rows, 0u);
-    for (int g = 0; g < sh.G; g++) {
-        uint32_t* r = t.data() + OP_PRE * (size_t)g;
-        r[OP_ACT] = 1; r[OP_NOTFIRST] = g ? 1u : 0u;
-        r[OP_K1] = (uint32_t)g + 1u; r[OP_K2] = 2u * (uint32_t)g + 3u; r[OP_K3] = 5u * (uint32_t)g + 7u;
-        r[OP_TL0] = (uint32_t)(sh.TO0 + 2 * g); r[OP_TL1] = (uint32_t)(sh.TO0 + 2 * g + 1);
-        r[OP_TN0] = (uint32_t)(sh.TO0 + sh.W / 2 + 2 * g); r[OP_TN1] = (uint32_t)(sh.TO0 + sh.W / 2 + 2 * g + 1);
-    }
-    t[OP_FIRST] = 1; t[OP_PRE * (size_t)(sh.G - 1) + OP_LASTG] = 1;
+    for (int p = 0; p < sh.NP; p++)
+        for (int g = 0; g < sh.G; g++) {
+            uint32_t* r = t.data() + OP_PRE * ((size_t)p * (size_t)sh.G + (size_t)g);
+            r[OP_ACT] = 1; r[OP_NOTFIRST] = g ? 1u : 0u; r[OP_PID] = (uint32_t)p;
+            r[OP_K1] = (uint32_t)g + 1u; r[OP_K2] = 2u * (uint32_t)g + 3u; r[OP_K3] = 5u * (uint32_t)g + 7u;
+            r[OP_TL0] = sh.ttag(p, sh.TO0 + 2 * g); r[OP_TL1] = sh.ttag(p, sh.TO0 + 2 * g + 1);
+            r[OP_TN0] = sh.ttag(p, sh.TO0 + sh.W / 2 + 2 * g); r[OP_TN1] = sh.ttag(p, sh.TO0 + sh.W / 2 + 2 * g + 1);
+            if (g == 0) r[OP_FIRST] = 1;
+            if (g == sh.G - 1) r[OP_LASTG] = 1;
+        }
     monty_all(t);
 }
 
 // ============================================================================================================ SCALARS
-constexpr uint32_t SC_PRE = 8, SP_FIRST = 0, SP_KA = 1, SP_KZ = 2, SP_KF = 3, SP_TQZ = 4;
+constexpr uint32_t SC_PRE = 12, SP_FIRST = 0, SP_KA = 1, SP_KZ = 2, SP_KF = 3, SP_TQZ = 4, SP_PID = 8;
 struct ScCols {
     uint32_t ALPHA, ZETA, FA, ZP1, INVF, SELF, SELT, ZNX, FP1, PR1, OFFN, OFFQ, QZ0, HQ0, QK0, QK1, QUO, YL, YN, ACC, end;
     int mb, nbits; int bits[12];
@@ -512,27 +536,29 @@ std::vector<uint32_t> scalars_program(const Shape& sh) {
     const EE z0 = eadd(escale(znn, za[0]), ec(zb[0])), z1 = eadd(escale(znn, za[1]), ec(zb[1]));
     c.ext(ALL, esub(ev(m.QUO), eadd(emul(z0, ev(m.QK0)), emul(z1, ev(m.QK1)))));
     c.ext(ALL, esub(ev(m.ACC), emul(ev(m.QUO), esub(znn, ec(1)))));
-    return c.program(SC_PRE + rup4(m.end - SC_PRE), (uint32_t)sh.NPUB);
+    return c.program(SC_PRE + rup4(m.end - SC_PRE), sh.npub_total());
 }
 std::vector<uint32_t> scalars_table(const Shape& sh) {
     const ScCols m = sc_cols(sh);
     Tab t;
     t.add5(RECV, SP_FIRST, BUS_SC, SP_KA, m.ALPHA); t.add5(RECV, SP_FIRST, BUS_SC, SP_KZ, m.ZETA); t.add5(RECV, SP_FIRST, BUS_SC, SP_KF, m.FA);
     for (int i = 0; i < 4; i++) { t.add5(RECV, SP_FIRST, BUS_IN0, SP_TQZ + (uint32_t)i, m.qz(2 * i)); t.add5(RECV, SP_FIRST, BUS_IN1, SP_TQZ + (uint32_t)i, m.qz(2 * i + 1)); }
-    t.add8(RECV, SP_FIRST, BUS_OY, m.YL, m.YN); t.add4(RECV, SP_FIRST, BUS_OA, m.ACC);
-    t.add8(SEND, SP_FIRST, BUS_K0, m.ZETA, m.ZNX); t.add8(SEND, SP_FIRST, BUS_K1, m.YL, m.YN); t.add8(SEND, SP_FIRST, BUS_K2, m.hq(0), m.OFFN); t.add4(SEND, SP_FIRST, BUS_K3, m.OFFQ);
-    t.add4(SEND, SP_FIRST, BUS_KFA, m.FA);
-    t.add8(SEND, SP_FIRST, BUS_KO0, m.FA, m.fp(2)); t.add8(SEND, SP_FIRST, BUS_KO1, m.ALPHA, m.SELT); t.add4(SEND, SP_FIRST, BUS_KO2, m.SELF);
+    t.add5(RECV, SP_FIRST, BUS_OY, SP_PID, m.YL); t.add5(RECV, SP_FIRST, BUS_OY + 1, SP_PID, m.YN); t.add5(RECV, SP_FIRST, BUS_OA, SP_PID, m.ACC);
+    const uint32_t qk[7] = {m.ZETA, m.ZNX, m.YL, m.YN, m.hq(0), m.OFFN, m.OFFQ};
+    for (uint32_t i = 0; i < 7; i++) t.add5(SEND, SP_FIRST, BUS_K0 + i, SP_PID, qk[i]);
+    t.add5(SEND, SP_FIRST, BUS_KFA, SP_PID, m.FA);
+    const uint32_t ok[5] = {m.FA, m.fp(2), m.ALPHA, m.SELT, m.SELF};
+    for (uint32_t i = 0; i < 5; i++) t.add5(SEND, SP_FIRST, BUS_KO0 + i, SP_PID, ok[i]);
     return t.w;
 }
 void scalars_pre(const Shape& sh, int log_rows, std::vector<uint32_t>& t) {
     t.assign((size_t)SC_PRE << log_rows, 0u);
-    for (size_t r = 0; r < ((size_t)1 << log_rows); r++) {
-        uint32_t* row = t.data() + SC_PRE * r;
-        row[SP_KA] = 0; row[SP_KZ] = 1; row[SP_KF] = 2;
-        for (int i = 0; i < 4; i++) row[SP_TQZ + i] = (uint32_t)(sh.TO0 + sh.W + i);
+    for (int p = 0; p < sh.NP; p++) {
+        uint32_t* row = t.data() + SC_PRE * (size_t)p;
+        row[SP_FIRST] = 1; row[SP_PID] = (uint32_t)p;
+        row[SP_KA] = 3u * (uint32_t)p; row[SP_KZ] = 3u * (uint32_t)p + 1u; row[SP_KF] = 3u * (uint32_t)p + 2u;
+        for (int i = 0; i < 4; i++) row[SP_TQZ + i] = sh.ttag(p, sh.TO0 + sh.W + i);
     }
-    t[SP_FIRST] = 1;
     monty_all(t);
 }
 
@@ -551,24 +577,25 @@ std::vector<uint32_t> samples_table_words() { return frichip::samples_interactio
 std::vector<uint32_t> fold_table(const Shape& sh) {
     using namespace frichip;
     Tab t;
-    t.add(SEND, ACTIVE, BUS_E0, {LN, K2, E0, E0 + 1, E0 + 2, E0 + 3}); t.add(SEND, ACTIVE, BUS_E1, {LN, K2, E1, E1 + 1, E1 + 2, E1 + 3});
-    t.add(SEND, L_REC, BUS_Q, {IDX, XS, OWN, OWN + 1, OWN + 2, OWN + 3});
-    t.add5(RECV, ACTIVE, BUS_BETA, LN, BETA);
-    t.add4(SEND, L_REC + (uint32_t)sh.R - 1u, BUS_FIN, FOLD);
+    t.add(SEND, ACTIVE, BUS_E0, {LNX, K2, E0, E0 + 1, E0 + 2, E0 + 3}); t.add(SEND, ACTIVE, BUS_E1, {LNX, K2, E1, E1 + 1, E1 + 2, E1 + 3});
+    t.add(SEND, L_REC, BUS_Q, {frichip::PT, IDX, XS, OWN, OWN + 1, OWN + 2, OWN + 3});
+    t.add5(RECV, ACTIVE, BUS_BETA, LNX, BETA);
+    t.add5(SEND, L_REC + (uint32_t)sh.R - 1u, BUS_FIN, frichip::PT, FOLD);
     return t.w;
 }
 // the machine of a shape: programs, tables, heights.  Built once per (shape, Poseidon2 tables) and kept.
 std::shared_ptr<const Machine> machine_of(const Shape& sh) {
     static std::mutex mu;
     static std::map<std::vector<uint64_t>, std::shared_ptr<const Machine>> cache;
-    const std::vector<uint64_t> key{(uint64_t)sh.n, (uint64_t)sh.W, (uint64_t)sh.Q, (uint64_t)sh.PB, (uint64_t)sh.NPUB, g_p2_generation.load()};
+    const std::vector<uint64_t> key{(uint64_t)sh.n, (uint64_t)sh.W, (uint64_t)sh.Q, (uint64_t)sh.PB, (uint64_t)sh.NPUB, (uint64_t)sh.NP, g_p2_generation.load()};
     std::lock_guard<std::mutex> lk(mu);
     auto it = cache.find(key);
     if (it != cache.end()) return it->second;
     auto m = std::make_shared<Machine>();
     m->sh = sh;
-    const int h[N_CHIPS] = {lg(sh.p2_rows), lg((size_t)sh.Q * (size_t)(sh.WB + 1)), lg((size_t)sh.Q * (size_t)sh.R), lg((size_t)sh.NTS), lg((size_t)sh.Q), lg((size_t)sh.G),
-                            lg((size_t)sh.NS), 5};
+    const size_t np = (size_t)sh.NP;
+    const int h[N_CHIPS] = {lg(np * sh.p2_rows), lg(np * (size_t)sh.Q * (size_t)(sh.WB + 1)), lg(np * (size_t)sh.Q * (size_t)sh.R), lg(np * (size_t)sh.NTS), lg(np * (size_t)sh.Q),
+                            lg(np * (size_t)sh.G), lg(np * (size_t)sh.NS), lg(np)};
     for (int c = 0; c < N_CHIPS; c++) { m->height[c] = h[c]; m->order[c] = c; }
     std::stable_sort(m->order, m->order + N_CHIPS, [&](int a, int b) { return h[a] > h[b]; });
     const ScCols scc = sc_cols(sh);
@@ -580,11 +607,11 @@ std::shared_ptr<const Machine> machine_of(const Shape& sh) {
         switch (c) {
             case C_P2R: m->prog[i] = p2r_program(sh); m->tab[i] = p2r_table(); break;
             case C_ROWSUM: m->prog[i] = rowsum_program(sh); m->tab[i] = rowsum_table(); break;
-            case C_FOLD: m->prog[i] = *frichip::program(sh.R, true, true, sh.NPUB); m->tab[i] = fold_table(sh); break;
+            case C_FOLD: m->prog[i] = *frichip::program(sh.R, true, true, (int)sh.npub_total()); m->tab[i] = fold_table(sh); break;
             case C_TS: m->prog[i] = ts_program(sh); m->tab[i] = ts_table(sh); break;
             case C_QUERY: m->prog[i] = query_program(sh); m->tab[i] = query_table(); break;
             case C_OPENED: m->prog[i] = opened_program(sh); m->tab[i] = opened_table(); break;
-            case C_SAMPLES: m->prog[i] = *frichip::samples_program(sh.R, sh.PB, (uint32_t)sh.NPUB); m->tab[i] = samples_table_words(); break;
+            case C_SAMPLES: m->prog[i] = *frichip::samples_program(sh.R, sh.PB, sh.npub_total()); m->tab[i] = samples_table_words(); break;
             default: m->prog[i] = scalars_program(sh); m->tab[i] = scalars_table(sh); break;
         }
         m->log_ns[i] = h[c]; m->widths[i] = w_main[c]; m->pre_widths[i] = w_pre[c];
@@ -595,6 +622,19 @@ std::shared_ptr<const Machine> machine_of(const Shape& sh) {
     return m;
 }
 
+// the SAMPLES chip's fixed columns for several proofs: proof p's rows behind proof p - 1's; its sponge rows are numbered from ITS tags, its queries from p Q
+void samples_pre_all(const Shape& sh, int log_rows, std::vector<uint32_t>& t) {
+    t.assign((size_t)frichip::S_PRE << log_rows, 0u);
+    std::vector<uint32_t> one;
+    for (int p = 0; p < sh.NP; p++) {
+        frichip::samples_pre(sh.R, (size_t)sh.Q, lg((size_t)sh.NS), one, (int)sh.ttag(p, sh.TP));
+        for (int r = 0; r < sh.NS; r++) {
+            uint32_t* row = one.data() + (size_t)frichip::S_PRE * (size_t)r;
+            for (uint32_t j = 0; j < 8; j++) if (row[frichip::S_ACT + j]) row[frichip::S_KQ + j] = fadd(row[frichip::S_KQ + j], to_monty((uint32_t)(p * sh.Q)));
+        }
+        std::memcpy(t.data() + (size_t)frichip::S_PRE * (size_t)p * (size_t)sh.NS, one.data(), (size_t)frichip::S_PRE * (size_t)sh.NS * 4);
+    }
+}
 // ---- the witness: everything the main columns hold, read off the inner proof (which the host verifier has accepted)
 struct Witness {
     const uint32_t* w = nullptr;                // the proof's words (canonical)
@@ -610,29 +650,29 @@ inline void put_ext(uint32_t* row, uint32_t col, const Ext& e) { for (int i = 0;
 }  // namespace rec
 }  // namespace zk
 
-// ---- main traces + proof.  Host-side tables (TS, ROWSUM, QUERY, OPENED, SAMPLES, SCALARS: a few thousand rows together) are filled on the
-// host in Montgomery form and uploaded; the Poseidon2 chip's 2^15 rows and the fold chip's rows are filled on the device.
-static int shard_verifier_prove_impl(zkhip_ctx* ctx, const zkhip_machine_key* key, const uint8_t* inner, size_t inner_len, int log_n, uint32_t width,
-                                     const uint32_t* public_values, size_t n_public, const zkhip_params* inner_prm, const zkhip_params* outer,
-                                     uint8_t* proof, size_t cap, size_t* len) {
-    using namespace zk::rec;
-    CHECK_CTX(ctx);
-    if (!key || !inner || !inner_prm || !outer || !proof || !len || (n_public && !public_values)) return fail(ZKHIP_ERR_INVALID, "prove_shard_verifier: null argument");
-    if (inner_prm->log_blowup != 1 || inner_prm->logup_pairs != 0 || inner_prm->log_fold > 1 || inner_prm->log_final != 0 || (inner_prm->hash_width != 0 && inner_prm->hash_width != 16) ||
-        inner_prm->code_width != 0)
-        return fail(ZKHIP_ERR_INVALID, "prove_shard_verifier: version-1 shard proofs (SP1 shape: blowup 2, fold by 2, constant final value, no lookups)");
-    Shape sh;
-    ZK_TRY(make_shape(log_n, width, (size_t)inner_prm->num_queries, inner_prm->pow_bits, n_public, sh));
-    const auto mp = machine_of(sh);
-    const Machine& m = *mp;
+// ---- main traces + proof.  Host-side tables (TS, ROWSUM, QUERY, OPENED, SAMPLES, SCALARS: a few thousand rows per inner proof) are filled on
+// the host in Montgomery form and uploaded; the Poseidon2 chip's rows (2^15 per headline proof) and the fold chip's rows are filled on the device.
+namespace zk {
+namespace rec {
+namespace {
+// what ONE inner proof contributes: the host tables' rows of its segment, and its entries of the device work lists
+struct HostTables {
+    std::vector<uint32_t> sc, op, rs, q, ts, sm;            // SCALARS, OPENED, ROWSUM, QUERY, TS, SAMPLES main traces (all proofs)
+    std::vector<uint32_t> desc, data, chain_in, trows;      // P2R: chains, their data, the transcript rows' input states and row numbers
+    std::vector<const uint32_t*> want_roots;                // per chain: where it must end (canonical words; owned by the witnesses)
+};
+int fill_one(const Shape& sh, const Machine& m, int p, const uint8_t* inner, size_t inner_len, const uint32_t* public_values, const zkhip_params* inner_prm, Witness& wt,
+             std::vector<uint32_t>& words, HostTables& ht, Ext* fa_out) {
     const int R = sh.R, H = sh.H, Q = sh.Q, W = sh.W;
+    const int log_n = sh.n;
+    const uint32_t width = (uint32_t)W;
+    const size_t n_public = (size_t)sh.NPUB;
     // (a) one host pass: the verifier accepts the proof and hands out the FRI side; the rest is read off the words (docs/PROTOCOL.md section 6)
-    Witness wt;
     wt.betas.resize(4 * (size_t)R); wt.indices.resize((size_t)Q); wt.values.resize(4 * (size_t)Q); wt.siblings.resize(4 * (size_t)Q * (size_t)R); wt.lroots.resize(8 * (size_t)R);
     wt.paths.resize(zkhip_fri_view_path_words(R) * (size_t)Q);
     ZK_TRY(zkhip_fri_view_all(inner, inner_len, log_n, width, public_values, n_public, inner_prm, wt.betas.data(), wt.fin, wt.indices.data(), wt.values.data(),
                               wt.siblings.data(), wt.lroots.data(), wt.paths.data(), wt.tr));
-    std::vector<uint32_t> words(inner_len / 4);
+    words.resize(inner_len / 4);
     std::memcpy(words.data(), inner, words.size() * 4);
     wt.w = words.data();
     wt.o_troot = 8; wt.o_qroot = 16; wt.o_loc = 24; wt.o_nxt = wt.o_loc + 4 * (size_t)W; wt.o_qz = wt.o_nxt + 4 * (size_t)W; wt.o_lroots = wt.o_qz + 32;
@@ -644,8 +684,8 @@ static int shard_verifier_prove_impl(zkhip_ctx* ctx, const zkhip_machine_key* ke
     // (b) the transcript's sponge chain on the host (NT permutations): the input state of every row, the challenges, the sampled words
     std::vector<uint32_t> chain_in(16 * (size_t)sh.NT), samples(8 * (size_t)sh.NS);
     std::vector<Ext> chal((size_t)sh.NT);
-    std::vector<std::array<uint32_t, 8>> blocks((size_t)sh.NTS);      // observed words per absorbing row (canonical; absent ones zero)
     {
+        std::vector<std::array<uint32_t, 8>> blocks((size_t)sh.NTS);      // observed words per absorbing row (canonical; absent ones zero)
         std::vector<uint32_t> seq0(sh.head, sh.head + 6);
         seq0.insert(seq0.end(), pw + wt.o_troot, pw + wt.o_troot + 8);
         for (size_t i = 0; i < n_public; i++) seq0.push_back(public_values[i] % P);
@@ -669,11 +709,12 @@ static int shard_verifier_prove_impl(zkhip_ctx* ctx, const zkhip_machine_key* ke
             if (from_monty(chal[(size_t)(sh.TL0 + l)].c[j]) != wt.betas[4 * (size_t)l + j]) return fail(ZKHIP_ERR_INTERNAL, "prove_shard_verifier: the sponge rows do not reproduce the verifier's challenges");
     }
     const Ext alpha = chal[(size_t)sh.TA], zeta = chal[(size_t)sh.TQ], fa = chal[(size_t)sh.TF];
-    // (c) the scalars
+    *fa_out = fa;
+    // (c) the scalars: row p of SCALARS
     const ScCols scc = sc_cols(sh);
     const uint32_t sc_w = rup4(scc.end - SC_PRE);
-    std::vector<uint32_t> sc_row(sc_w, 0u);
-    auto scput = [&](uint32_t col, const Ext& e) { put_ext(sc_row.data(), col - SC_PRE, e); };
+    uint32_t* sc_row = ht.sc.data() + (size_t)sc_w * (size_t)p;
+    auto scput = [&](uint32_t col, const Ext& e) { put_ext(sc_row, col - SC_PRE, e); };
     Ext znn = zeta;
     scput(scc.ALPHA, alpha); scput(scc.ZETA, zeta); scput(scc.FA, fa);
     for (int i = 1; i <= sh.n; i++) { znn = ext_mul(znn, znn); scput(scc.zp(i), znn); }
@@ -702,17 +743,20 @@ static int shard_verifier_prove_impl(zkhip_ctx* ctx, const zkhip_machine_key* ke
     zps_consts(sh, za, zb);
     const Ext quo = ext_add(ext_mul(ext_add_base(ext_mul_base(znn, to_monty(za[0])), to_monty(zb[0])), qk[0]), ext_mul(ext_add_base(ext_mul_base(znn, to_monty(za[1])), to_monty(zb[1])), qk[1]));
     scput(scc.QUO, quo);
-    // (d) OPENED: the opened values, their fa-weighted sums, the AIR folded with alpha
-    const int h_op = m.height[C_OPENED];
-    std::vector<uint32_t> t_op((size_t)OP_MAIN << h_op, 0u);
+    // (d) OPENED: the opened values, their fa-weighted sums, the AIR folded with alpha.  The rows behind the last proof carry ITS constants.
+    const size_t op_rows = (size_t)1 << m.height[C_OPENED];
+    const size_t op_lo = (size_t)p * (size_t)sh.G, op_hi = p + 1 == sh.NP ? op_rows : op_lo + (size_t)sh.G;
     Ext yl = ext_zero(), yn = ext_zero(), acc = ext_zero(), pwr = ext_one(), res_yl = yl, res_yn = yn, res_acc = acc;
-    for (size_t g = 0; g < ((size_t)1 << h_op); g++) {
-        uint32_t* r = t_op.data() + (size_t)OP_MAIN * g;
+    for (size_t row = op_lo; row < op_hi; row++) {
+        const size_t g = row - op_lo;
+        const bool active = g < (size_t)sh.G;
+        if (!active && g % (size_t)sh.G == 0) { pwr = ext_one(); yl = yn = acc = ext_zero(); }      // (a padding "segment" starts like a proof's)
+        uint32_t* r = ht.op.data() + (size_t)OP_MAIN * row;
         auto put = [&](uint32_t name, const Ext& e) { put_ext(r, 4u * name, e); };
         put(O_FA, fa); put(O_FA4, fa4); put(O_ALPHA, alpha); put(O_SELT, selt); put(O_SELF, self_);
         Ext v[8];
         uint32_t k1 = 0, k2 = 0, k3 = 0;
-        if (g < (size_t)sh.G) {
+        if (active) {
             for (int i = 0; i < 4; i++) { v[i] = ext_canon(pw + wt.o_loc + 4 * (4 * g + (size_t)i)); v[4 + i] = ext_canon(pw + wt.o_nxt + 4 * (4 * g + (size_t)i)); }
             k1 = to_monty((uint32_t)g + 1u); k2 = to_monty(2u * (uint32_t)g + 3u); k3 = to_monty(5u * (uint32_t)g + 7u);
         } else {
@@ -744,22 +788,18 @@ static int shard_verifier_prove_impl(zkhip_ctx* ctx, const zkhip_machine_key* ke
     }
     scput(scc.YL, res_yl); scput(scc.YN, res_yn); scput(scc.ACC, res_acc);
     if (!ext_eq(res_acc, ext_mul(quo, ext_sub_base(znn, MONTY_R1)))) return fail(ZKHIP_ERR_INTERNAL, "prove_shard_verifier: the AIR identity at zeta does not hold");
-    const int h_sc = m.height[C_SCALARS];
-    std::vector<uint32_t> t_sc((size_t)sc_w << h_sc);
-    for (size_t r = 0; r < ((size_t)1 << h_sc); r++) std::memcpy(t_sc.data() + sc_w * r, sc_row.data(), sc_w * 4);
     // (e) ROWSUM
-    const int h_rs = m.height[C_ROWSUM];
-    std::vector<uint32_t> t_rs((size_t)RS_MAIN << h_rs, 0u);
     std::vector<Ext> at((size_t)Q), aq((size_t)Q);
     {
-        const size_t used = (size_t)Q * (size_t)(sh.WB + 1);
+        const size_t rs_rows = (size_t)1 << m.height[C_ROWSUM], per = (size_t)Q * (size_t)(sh.WB + 1);
+        const size_t lo = (size_t)p * per, hi = p + 1 == sh.NP ? rs_rows : lo + per;
         Ext a = ext_zero();
-        for (size_t r = 0; r < ((size_t)1 << h_rs); r++) {
-            uint32_t* row = t_rs.data() + (size_t)RS_MAIN * r;
+        for (size_t r = lo; r < hi; r++) {
+            uint32_t* row = ht.rs.data() + (size_t)RS_MAIN * r;
             put_ext(row, RS_FA, fa);
-            if (r >= used) continue;
-            int q, b;
-            rowsum_row(sh, r, &q, &b);
+            if (r >= lo + per) continue;
+            int pp, q, b;
+            rowsum_row(sh, r, &pp, &q, &b);
             const uint32_t* vals = b == sh.WB ? pw + wt.q_trow(q) + (size_t)W + 8 * (size_t)H : pw + wt.q_trow(q) + 8 * (size_t)b;
             if (b == sh.WB - 1 || b == sh.WB) a = ext_zero();
             put_ext(row, RS_ACCIN, a);
@@ -774,61 +814,55 @@ static int shard_verifier_prove_impl(zkhip_ctx* ctx, const zkhip_machine_key* ke
         }
     }
     // (f) QUERY
-    constexpr QCols qc = qcols();
-    const int h_q = m.height[C_QUERY];
-    std::vector<uint32_t> t_q((size_t)Q_MAIN << h_q, 0u);
-    for (size_t r = 0; r < ((size_t)1 << h_q); r++) {
-        uint32_t* row = t_q.data() + (size_t)Q_MAIN * r;
-        auto put = [&](uint32_t col, const Ext& e) { put_ext(row, col - Q_PRE, e); };
-        put(qc.ZETA, zeta); put(qc.ZNX, znx); put(qc.YL, res_yl); put(qc.YN, res_yn); put(qc.YQ, yq); put(qc.OFFN, offn); put(qc.OFFQ, offq);
-        if (r >= (size_t)Q) continue;
-        const uint32_t index = wt.indices[r];
-        const uint32_t xq = fpow(two_adic_generator(H), reverse_bits(index, H));
-        const Ext x = ext_from_base(fmul(MONTY_GEN, xq));
-        const Ext i1 = ext_inv(ext_sub(x, zeta)), i2 = ext_inv(ext_sub(x, znx));
-        const Ext p1 = ext_mul(ext_sub(at[r], res_yl), i1), p2 = ext_mul(ext_sub(at[r], res_yn), i2), p2o = ext_mul(offn, p2);
-        const Ext p3 = ext_mul(ext_sub(aq[r], yq), i1), p3o = ext_mul(offq, p3), ro = ext_add(ext_add(p1, p2o), p3o);
-        for (int i = 0; i < 4; i++) if (from_monty(ro.c[i]) != wt.values[4 * r + (size_t)i]) return fail(ZKHIP_ERR_INTERNAL, "prove_shard_verifier: a reduced opening is not the verifier's");
-        row[qc.IDX - Q_PRE] = to_monty(index); row[qc.XQ - Q_PRE] = xq;
-        put(qc.RO, ro); put(qc.AT, at[r]); put(qc.AQ, aq[r]); put(qc.I1, i1); put(qc.I2, i2); put(qc.P1, p1); put(qc.P2, p2); put(qc.P2O, p2o); put(qc.P3, p3); put(qc.P3O, p3o);
+    {
+        constexpr QCols qc = qcols();
+        const size_t q_rows = (size_t)1 << m.height[C_QUERY], lo = (size_t)p * (size_t)Q, hi = p + 1 == sh.NP ? q_rows : lo + (size_t)Q;
+        for (size_t rr = lo; rr < hi; rr++) {
+            uint32_t* row = ht.q.data() + (size_t)Q_MAIN * rr;
+            auto put = [&](uint32_t col, const Ext& e) { put_ext(row, col - Q_PRE, e); };
+            put(qc.ZETA, zeta); put(qc.ZNX, znx); put(qc.YL, res_yl); put(qc.YN, res_yn); put(qc.YQ, yq); put(qc.OFFN, offn); put(qc.OFFQ, offq);
+            const size_t r = rr - lo;
+            if (r >= (size_t)Q) continue;
+            const uint32_t index = wt.indices[r];
+            const uint32_t xq = fpow(two_adic_generator(H), reverse_bits(index, H));
+            const Ext x = ext_from_base(fmul(MONTY_GEN, xq));
+            const Ext i1 = ext_inv(ext_sub(x, zeta)), i2 = ext_inv(ext_sub(x, znx));
+            const Ext p1 = ext_mul(ext_sub(at[r], res_yl), i1), p2 = ext_mul(ext_sub(at[r], res_yn), i2), p2o = ext_mul(offn, p2);
+            const Ext p3 = ext_mul(ext_sub(aq[r], yq), i1), p3o = ext_mul(offq, p3), ro = ext_add(ext_add(p1, p2o), p3o);
+            for (int i = 0; i < 4; i++) if (from_monty(ro.c[i]) != wt.values[4 * r + (size_t)i]) return fail(ZKHIP_ERR_INTERNAL, "prove_shard_verifier: a reduced opening is not the verifier's");
+            row[qc.IDX - Q_PRE] = to_monty(index); row[qc.XQ - Q_PRE] = xq;
+            put(qc.RO, ro); put(qc.AT, at[r]); put(qc.AQ, aq[r]); put(qc.I1, i1); put(qc.I2, i2); put(qc.P1, p1); put(qc.P2, p2); put(qc.P2O, p2o); put(qc.P3, p3); put(qc.P3O, p3o);
+        }
     }
     // (g) TS
-    const TsCols tsc = ts_cols(sh);
-    const int h_ts = m.height[C_TS];
-    std::vector<uint32_t> t_ts((size_t)TS_MAIN << h_ts, 0u);
     for (int T = 0; T < sh.NTS; T++) {
-        uint32_t* row = t_ts.data() + (size_t)TS_MAIN * (size_t)T;
+        uint32_t* row = ht.ts.data() + (size_t)TS_MAIN * ((size_t)p * (size_t)sh.NTS + (size_t)T);
         for (int j = 0; j < 8; j++) row[j] = to_monty(chain_in[16 * (size_t)T + (size_t)j]);       // the absorbed words, and whatever the kept ones are
         if (sh.has_challenge(T)) put_ext(row, 16, chal[(size_t)T]);
+        if (T == 0) for (int j = 0; j < 8; j++) row[8 + j] = to_monty(pw[wt.o_troot + j]);
     }
-    for (int j = 0; j < 8; j++) t_ts[8 + (size_t)j] = to_monty(pw[wt.o_troot + j]);
-    // (h) SAMPLES
-    std::vector<uint32_t> t_sm, drawn;
-    frichip::samples_main(R, (size_t)Q, m.height[C_SAMPLES], samples.data(), t_sm, drawn);
-    if (sh.PB && (samples[0] & ((1u << sh.PB) - 1u))) return fail(ZKHIP_ERR_INTERNAL, "prove_shard_verifier: the witness does not satisfy the proof of work");
-    if (std::memcmp(drawn.data(), wt.indices.data(), 4 * (size_t)Q) != 0) return fail(ZKHIP_ERR_INTERNAL, "prove_shard_verifier: the query indices are not the ones the transcript draws");
-    // (i) device: P2R rows (chains) and the fold rows
-    void* dev[N_CHIPS] = {nullptr};
-    const int slots[N_CHIPS] = {S_REC_A, S_REC_C, S_REC_B, S_REC_D, S_REC_E, S_REC_F, S_REC_G, S_REC_H};
-    const uint32_t w_main[N_CHIPS] = {P2_MAIN, RS_MAIN, frichip::width_of(R, true, true), TS_MAIN, Q_MAIN, OP_MAIN, frichip::S_MAIN, sc_w};
-    for (int c = 0; c < N_CHIPS; c++) ZK_TRY(ctx_reserve(ctx, slots[c], ((size_t)w_main[c] << m.height[c]) * 4, &dev[c]));
+    // (h) SAMPLES: this proof's NS rows
     {
-        std::vector<uint32_t> finals(4 * (size_t)Q);
-        ZK_TRY(fri_gen_trace(ctx, R, (size_t)Q, wt.betas.data(), wt.indices.data(), wt.values.data(), wt.siblings.data(), m.height[C_FOLD], (uint32_t*)dev[C_FOLD],
-                             w_main[C_FOLD], finals.data(), true, true));
-        for (int q = 0; q < Q; q++) if (std::memcmp(finals.data() + 4 * (size_t)q, pw + wt.o_final, 16) != 0) return fail(ZKHIP_ERR_INTERNAL, "prove_shard_verifier: a chain does not end in the final value");
+        std::vector<uint32_t> t_sm, drawn;
+        frichip::samples_main(R, (size_t)Q, lg((size_t)sh.NS), samples.data(), t_sm, drawn);
+        if (sh.PB && (samples[0] & ((1u << sh.PB) - 1u))) return fail(ZKHIP_ERR_INTERNAL, "prove_shard_verifier: the witness does not satisfy the proof of work");
+        if (std::memcmp(drawn.data(), wt.indices.data(), 4 * (size_t)Q) != 0) return fail(ZKHIP_ERR_INTERNAL, "prove_shard_verifier: the query indices are not the ones the transcript draws");
+        std::memcpy(ht.sm.data() + (size_t)frichip::S_MAIN * (size_t)p * (size_t)sh.NS, t_sm.data(), (size_t)frichip::S_MAIN * (size_t)sh.NS * 4);
     }
+    // (i) this proof's entries of the P2R work lists: transcript rows, then Q R FRI paths (leaf block = the pair), Q trace openings, Q quotient openings
     {
-        // chains: Q R FRI paths (leaf block = the pair), Q trace openings, Q quotient openings; data = [pairs | fri siblings | proof words]
-        const size_t n_chains = (size_t)Q * (size_t)R + 2 * (size_t)Q, per_q_paths = zkhip_fri_view_path_words(R);
-        std::vector<uint32_t> desc(6 * n_chains), data;
-        data.reserve(8 * (size_t)Q * (size_t)R + wt.paths.size() + words.size());
-        data.resize(8 * (size_t)Q * (size_t)R);
-        const size_t off_paths = data.size();
-        data.insert(data.end(), wt.paths.begin(), wt.paths.end());
-        const size_t off_words = data.size();
-        data.insert(data.end(), words.begin(), words.end());
-        size_t row = sh.p2_fri0, ch = 0;
+        const size_t row0 = (size_t)p * sh.p2_rows;
+        for (int T = 0; T < sh.NT; T++) ht.trows.push_back((uint32_t)(row0 + (size_t)T));
+        ht.chain_in.insert(ht.chain_in.end(), chain_in.begin(), chain_in.end());
+        const size_t per_q_paths = zkhip_fri_view_path_words(R);
+        const size_t off_pairs = ht.data.size();
+        ht.data.resize(off_pairs + 8 * (size_t)Q * (size_t)R);
+        const size_t off_paths = ht.data.size();
+        ht.data.insert(ht.data.end(), wt.paths.begin(), wt.paths.end());
+        const size_t off_words = ht.data.size();
+        ht.data.insert(ht.data.end(), words.begin(), words.end());
+        if (ht.data.size() >= ((size_t)1 << 32)) return fail(ZKHIP_ERR_INVALID, "prove_shard_verifier: too much witness data for one call");
+        size_t row = row0 + sh.p2_fri0, ch = 0;
         for (int q = 0; q < Q; q++) {
             uint32_t idx = wt.indices[(size_t)q];
             Ext own = ext_canon(wt.values.data() + 4 * (size_t)q);
@@ -836,12 +870,13 @@ static int shard_verifier_prove_impl(zkhip_ctx* ctx, const zkhip_machine_key* ke
                 const uint32_t bit = idx & 1u, k = idx >> 1;
                 const Ext sib = ext_canon(wt.siblings.data() + 4 * ((size_t)q * (size_t)R + (size_t)l));
                 const Ext e0 = bit ? sib : own, e1 = bit ? own : sib;
-                uint32_t* pair = data.data() + 8 * ch;
+                uint32_t* pair = ht.data.data() + off_pairs + 8 * ch;
                 for (int i = 0; i < 4; i++) { pair[i] = from_monty(e0.c[i]); pair[4 + i] = from_monty(e1.c[i]); }
                 const int lh = H - (l + 1);
-                uint32_t* d = desc.data() + 6 * ch;
-                d[0] = (uint32_t)row; d[1] = 1; d[2] = (uint32_t)(8 * ch); d[3] = (uint32_t)lh; d[4] = k;
-                d[5] = (uint32_t)(off_paths + (size_t)q * per_q_paths + 8 * ((size_t)l * (size_t)R - (size_t)l * ((size_t)l - 1) / 2));
+                const uint32_t d[6] = {(uint32_t)row, 1u, (uint32_t)(off_pairs + 8 * ch), (uint32_t)lh, k,
+                                       (uint32_t)(off_paths + (size_t)q * per_q_paths + 8 * ((size_t)l * (size_t)R - (size_t)l * ((size_t)l - 1) / 2))};
+                ht.desc.insert(ht.desc.end(), d, d + 6);
+                ht.want_roots.push_back(wt.lroots.data() + 8 * (size_t)l);
                 row += 1 + (size_t)lh;
                 const uint32_t xi = finv(fpow(two_adic_generator(lh + 1), reverse_bits(k, lh)));
                 const Ext beta = ext_canon(wt.betas.data() + 4 * (size_t)l);
@@ -850,65 +885,114 @@ static int shard_verifier_prove_impl(zkhip_ctx* ctx, const zkhip_machine_key* ke
             }
         }
         for (int which = 0; which < 2; which++)
-            for (int q = 0; q < Q; q++, ch++) {
-                uint32_t* d = desc.data() + 6 * ch;
+            for (int q = 0; q < Q; q++) {
                 const size_t trow = wt.q_trow(q), tpath = trow + (size_t)W, qrow = tpath + 8 * (size_t)H, qpath = qrow + 8;
-                d[0] = (uint32_t)row; d[1] = which ? 1u : (uint32_t)sh.WB; d[2] = (uint32_t)(off_words + (which ? qrow : trow)); d[3] = (uint32_t)H; d[4] = wt.indices[(size_t)q];
-                d[5] = (uint32_t)(off_words + (which ? qpath : tpath));
+                const uint32_t d[6] = {(uint32_t)row, which ? 1u : (uint32_t)sh.WB, (uint32_t)(off_words + (which ? qrow : trow)), (uint32_t)H, wt.indices[(size_t)q],
+                                       (uint32_t)(off_words + (which ? qpath : tpath))};
+                ht.desc.insert(ht.desc.end(), d, d + 6);
+                ht.want_roots.push_back(pw + (which ? wt.o_qroot : wt.o_troot));
                 row += (which ? 1 : (size_t)sh.WB) + (size_t)H;
             }
-        if (row != sh.p2_rows || ch != n_chains) return fail(ZKHIP_ERR_INTERNAL, "prove_shard_verifier: row layout");
-        const size_t up_words = desc.size() + data.size() + chain_in.size(), down_words = 8 * n_chains;
+        if (row != row0 + sh.p2_rows) return fail(ZKHIP_ERR_INTERNAL, "prove_shard_verifier: row layout");
+    }
+    return ZKHIP_OK;
+}
+}  // namespace
+}  // namespace rec
+}  // namespace zk
+
+static int shard_verifier_prove_impl(zkhip_ctx* ctx, const zkhip_machine_key* key, const uint8_t* const* inner, const size_t* inner_len, size_t n_proofs, int log_n, uint32_t width,
+                                     const uint32_t* public_values, size_t n_public, const zkhip_params* inner_prm, const zkhip_params* outer,
+                                     uint8_t* proof, size_t cap, size_t* len) {
+    using namespace zk::rec;
+    CHECK_CTX(ctx);
+    if (!key || !inner || !inner_len || !inner_prm || !outer || !proof || !len || (n_public && !public_values)) return fail(ZKHIP_ERR_INVALID, "prove_shard_verifier: null argument");
+    if (inner_prm->log_blowup != 1 || inner_prm->logup_pairs != 0 || inner_prm->log_fold > 1 || inner_prm->log_final != 0 || (inner_prm->hash_width != 0 && inner_prm->hash_width != 16) ||
+        inner_prm->code_width != 0)
+        return fail(ZKHIP_ERR_INVALID, "prove_shard_verifier: version-1 shard proofs (SP1 shape: blowup 2, fold by 2, constant final value, no lookups)");
+    Shape sh;
+    ZK_TRY(make_shape(log_n, width, (size_t)inner_prm->num_queries, inner_prm->pow_bits, n_public, n_proofs, sh));
+    const auto mp = machine_of(sh);
+    const Machine& m = *mp;
+    const int R = sh.R, Q = sh.Q, NP = sh.NP;
+    const ScCols scc = sc_cols(sh);
+    const uint32_t sc_w = rup4(scc.end - SC_PRE);
+    const uint32_t w_main[N_CHIPS] = {P2_MAIN, RS_MAIN, frichip::width_of(R, true, true), TS_MAIN, Q_MAIN, OP_MAIN, frichip::S_MAIN, sc_w};
+    HostTables ht;
+    ht.sc.assign((size_t)sc_w << m.height[C_SCALARS], 0u); ht.op.assign((size_t)OP_MAIN << m.height[C_OPENED], 0u); ht.rs.assign((size_t)RS_MAIN << m.height[C_ROWSUM], 0u);
+    ht.q.assign((size_t)Q_MAIN << m.height[C_QUERY], 0u); ht.ts.assign((size_t)TS_MAIN << m.height[C_TS], 0u); ht.sm.assign((size_t)frichip::S_MAIN << m.height[C_SAMPLES], 0u);
+    std::vector<Witness> wts((size_t)NP);
+    std::vector<std::vector<uint32_t>> words((size_t)NP);
+    std::vector<Ext> fas((size_t)NP);
+    for (int p = 0; p < NP; p++) {
+        if (!inner[p]) return fail(ZKHIP_ERR_INVALID, "prove_shard_verifier: null proof");
+        ZK_TRY(fill_one(sh, m, p, inner[p], inner_len[p], public_values + (size_t)p * n_public, inner_prm, wts[(size_t)p], words[(size_t)p], ht, &fas[(size_t)p]));
+    }
+    for (size_t r = (size_t)NP; r < ((size_t)1 << m.height[C_SCALARS]); r++) std::memcpy(ht.sc.data() + sc_w * r, ht.sc.data(), sc_w * 4);     // rows behind the proofs repeat row 0
+    // device: the fold rows proof by proof (the last call fills the padding), then ONE launch for every Poseidon2 row
+    void* dev[N_CHIPS] = {nullptr};
+    const int slots[N_CHIPS] = {S_REC_A, S_REC_C, S_REC_B, S_REC_D, S_REC_E, S_REC_F, S_REC_G, S_REC_H};
+    for (int c = 0; c < N_CHIPS; c++) ZK_TRY(ctx_reserve(ctx, slots[c], ((size_t)w_main[c] << m.height[c]) * 4, &dev[c]));
+    for (int p = 0; p < NP; p++) {
+        const Witness& wt = wts[(size_t)p];
+        std::vector<uint32_t> finals(4 * (size_t)Q);
+        const uint64_t per = (uint64_t)Q * (uint64_t)R, rows = (uint64_t)1 << m.height[C_FOLD];
+        ZK_TRY(fri_gen_trace(ctx, R, (size_t)Q, wt.betas.data(), wt.indices.data(), wt.values.data(), wt.siblings.data(), m.height[C_FOLD], (uint32_t*)dev[C_FOLD],
+                             w_main[C_FOLD], finals.data(), true, true, (uint32_t)(p * sh.TREES), (uint64_t)p * per, (int64_t)(p + 1 == NP ? (uint64_t)NP * per : rows)));
+        for (int q = 0; q < Q; q++) if (std::memcmp(finals.data() + 4 * (size_t)q, wt.w + wt.o_final, 16) != 0) return fail(ZKHIP_ERR_INTERNAL, "prove_shard_verifier: a chain does not end in the final value");
+    }
+    {
+        const size_t n_chains = ht.desc.size() / 6;
+        const size_t up_words = ht.desc.size() + ht.data.size() + ht.chain_in.size() + ht.trows.size(), down_words = 8 * n_chains;
         void* stage;
         ZK_TRY(ctx_reserve(ctx, S_STAGE, (up_words + down_words) * 4, &stage));
         uint32_t* d = (uint32_t*)stage;
         {
             std::vector<uint32_t> up;
             up.reserve(up_words);
-            up.insert(up.end(), desc.begin(), desc.end()); up.insert(up.end(), data.begin(), data.end()); up.insert(up.end(), chain_in.begin(), chain_in.end());
+            up.insert(up.end(), ht.desc.begin(), ht.desc.end()); up.insert(up.end(), ht.data.begin(), ht.data.end()); up.insert(up.end(), ht.chain_in.begin(), ht.chain_in.end());
+            up.insert(up.end(), ht.trows.begin(), ht.trows.end());
             ZK_TRY(dev_h2d(ctx, d, up.data(), up_words * 4));
         }
         p2chip::P2RArgs a{};
-        a.desc = d; a.data = d + desc.size(); a.chain_inputs = d + desc.size() + data.size();
-        a.n_chains = (uint32_t)n_chains; a.n_transcript = (uint32_t)sh.NT; a.rows = (uint64_t)1 << m.height[C_P2R]; a.used_rows = sh.p2_rows;
+        a.desc = d; a.data = d + ht.desc.size(); a.chain_inputs = a.data + ht.data.size(); a.trows = a.chain_inputs + ht.chain_in.size();
+        a.n_chains = (uint32_t)n_chains; a.n_transcript = (uint32_t)ht.trows.size(); a.rows = (uint64_t)1 << m.height[C_P2R]; a.used_rows = (uint64_t)NP * sh.p2_rows;
         a.trace = (uint32_t*)dev[C_P2R]; a.ld = P2_MAIN; a.roots = d + up_words;
         ZK_HIP(launch_p2r_rows(a, ctx->stream));
         std::vector<uint32_t> down(down_words);
         ZK_TRY(dev_d2h(ctx, down.data(), a.roots, down_words * 4));
-        for (size_t c = 0; c < n_chains; c++) {
-            const uint32_t* want = c < (size_t)Q * (size_t)R ? wt.lroots.data() + 8 * (c % (size_t)R) : pw + (c < (size_t)Q * (size_t)R + (size_t)Q ? wt.o_troot : wt.o_qroot);
-            if (std::memcmp(down.data() + 8 * c, want, 32) != 0) return fail(ZKHIP_ERR_INTERNAL, "prove_shard_verifier: an opening does not end in its root");
-        }
+        for (size_t c = 0; c < n_chains; c++)
+            if (std::memcmp(down.data() + 8 * c, ht.want_roots[c], 32) != 0) return fail(ZKHIP_ERR_INTERNAL, "prove_shard_verifier: an opening does not end in its root");
     }
-    // (j) the host tables up, then the machine's proof
-    const std::vector<uint32_t>* host[N_CHIPS] = {nullptr, &t_rs, nullptr, &t_ts, &t_q, &t_op, &t_sm, &t_sc};
+    // the host tables up, then the machine's proof
+    const std::vector<uint32_t>* host[N_CHIPS] = {nullptr, &ht.rs, nullptr, &ht.ts, &ht.q, &ht.op, &ht.sm, &ht.sc};
     for (int c = 0; c < N_CHIPS; c++) if (host[c]) ZK_TRY(dev_h2d(ctx, dev[c], host[c]->data(), host[c]->size() * 4));
     zkhip_chip chips[N_CHIPS]{};
     for (int i = 0; i < N_CHIPS; i++) {
         const int c = m.order[i];
         chips[i].d_trace = (const uint32_t*)dev[c]; chips[i].ld = w_main[c]; chips[i].log_n = m.height[c]; chips[i].width = w_main[c]; chips[i].partner = -1;
     }
-    std::vector<uint32_t> pv(n_public);
-    for (size_t i = 0; i < n_public; i++) pv[i] = public_values[i] % P;
+    std::vector<uint32_t> pv((size_t)NP * n_public);
+    for (size_t i = 0; i < pv.size(); i++) pv[i] = public_values[i] % P;
     return zkhip_prove_machine_keyed(ctx, key, chips, m.progs, m.prog_words, m.tabs, m.tab_words, N_CHIPS, pv.data(), pv.size(), outer, proof, cap, len);
 }
 
 extern "C" {
 
 // the key of a SHAPE: the commitment to the eight chips' preprocessed columns -- no inner proof is involved
-int zkhip_shard_verifier_setup(zkhip_ctx* ctx, int log_n, uint32_t width, size_t n_queries, int inner_pow_bits, size_t n_public, const zkhip_params* outer,
+int zkhip_shard_verifier_setup(zkhip_ctx* ctx, int log_n, uint32_t width, size_t n_queries, int inner_pow_bits, size_t n_public, size_t n_proofs, const zkhip_params* outer,
                                zkhip_machine_key** key, uint32_t vk[8]) {
     using namespace zk::rec;
     CHECK_CTX(ctx);
     if (!outer || !key || !vk) return fail(ZKHIP_ERR_INVALID, "shard_verifier_setup: null argument");
     Shape sh;
-    ZK_TRY(make_shape(log_n, width, n_queries, inner_pow_bits, n_public, sh));
+    ZK_TRY(make_shape(log_n, width, n_queries, inner_pow_bits, n_public, n_proofs, sh));
     const auto mp = machine_of(sh);
     const Machine& m = *mp;
     std::vector<uint32_t> pre[N_CHIPS];
     p2r_pre(sh, m.height[C_P2R], pre[C_P2R]); rowsum_pre(sh, m.height[C_ROWSUM], pre[C_ROWSUM]); ts_pre(sh, m.height[C_TS], pre[C_TS]);
     query_pre(sh, m.height[C_QUERY], pre[C_QUERY]); opened_pre(sh, m.height[C_OPENED], pre[C_OPENED]); scalars_pre(sh, m.height[C_SCALARS], pre[C_SCALARS]);
-    frichip::samples_pre(sh.R, (size_t)sh.Q, m.height[C_SAMPLES], pre[C_SAMPLES], sh.TP);
+    samples_pre_all(sh, m.height[C_SAMPLES], pre[C_SAMPLES]);
     size_t total = 0;
     for (int c = 0; c < N_CHIPS; c++) total += pre[c].size();
     void* d;
@@ -926,41 +1010,43 @@ int zkhip_shard_verifier_setup(zkhip_ctx* ctx, int log_n, uint32_t width, size_t
     return zkhip_machine_setup(ctx, chips, N_CHIPS, outer, key, vk);
 }
 
-size_t zkhip_shard_verifier_proof_size(int log_n, uint32_t width, size_t n_queries, int inner_pow_bits, size_t n_public, const zkhip_params* outer) {
+size_t zkhip_shard_verifier_proof_size(int log_n, uint32_t width, size_t n_queries, int inner_pow_bits, size_t n_public, size_t n_proofs, const zkhip_params* outer) {
     using namespace zk::rec;
     Shape sh;
-    if (!outer || make_shape(log_n, width, n_queries, inner_pow_bits, n_public, sh) != ZKHIP_OK) return 0;
+    if (!outer || make_shape(log_n, width, n_queries, inner_pow_bits, n_public, n_proofs, sh) != ZKHIP_OK) return 0;
     const auto m = machine_of(sh);
-    return zkhip_machine_proof_size_keyed(m->log_ns, m->widths, m->pre_widths, m->progs, m->prog_words, m->tabs, m->tab_words, N_CHIPS, outer, n_public);
+    return zkhip_machine_proof_size_keyed(m->log_ns, m->widths, m->pre_widths, m->progs, m->prog_words, m->tabs, m->tab_words, N_CHIPS, outer, n_proofs * n_public);
 }
 
-int zkhip_prove_shard_verifier(zkhip_ctx* ctx, const zkhip_machine_key* key, const uint8_t* shard_proof, size_t shard_proof_len, int log_n, uint32_t width,
-                               const uint32_t* public_values, size_t n_public, const zkhip_params* inner, const zkhip_params* outer, uint8_t* proof, size_t cap, size_t* len) {
-    return shard_verifier_prove_impl(ctx, key, shard_proof, shard_proof_len, log_n, width, public_values, n_public, inner, outer, proof, cap, len);
+int zkhip_prove_shard_verifier(zkhip_ctx* ctx, const zkhip_machine_key* key, const uint8_t* const* shard_proofs, const size_t* shard_proof_lens, size_t n_proofs, int log_n,
+                               uint32_t width, const uint32_t* public_values, size_t n_public, const zkhip_params* inner, const zkhip_params* outer, uint8_t* proof, size_t cap,
+                               size_t* len) {
+    return shard_verifier_prove_impl(ctx, key, shard_proofs, shard_proof_lens, n_proofs, log_n, width, public_values, n_public, inner, outer, proof, cap, len);
 }
 
-// The verifier of the outer proof: the shape of the inner proof, ITS public values, the key of the shape.  No byte of the inner proof.
+// The verifier of the outer proof: the shape of the inner proofs, THEIR public values (proof 0's, then proof 1's, ...), the key of the shape.
+// No byte of an inner proof.
 int zkhip_verify_shard_recursive(const uint8_t* proof, size_t len, int log_n, uint32_t width, size_t n_queries, int inner_pow_bits, const uint32_t* public_values,
-                                 size_t n_public, const uint32_t vk[8], const zkhip_params* outer, int* reason) {
+                                 size_t n_public, size_t n_proofs, const uint32_t vk[8], const zkhip_params* outer, int* reason) {
     using namespace zk::rec;
     Shape sh;
-    if (!proof || !vk || !outer || (n_public && !public_values) || make_shape(log_n, width, n_queries, inner_pow_bits, n_public, sh) != ZKHIP_OK) {
+    if (!proof || !vk || !outer || (n_public && !public_values) || make_shape(log_n, width, n_queries, inner_pow_bits, n_public, n_proofs, sh) != ZKHIP_OK) {
         if (reason) *reason = 1;
         return fail(ZKHIP_ERR_VERIFY, "verify_shard_recursive: bad arguments");
     }
     const auto m = machine_of(sh);
-    std::vector<uint32_t> pv(n_public);
-    for (size_t i = 0; i < n_public; i++) pv[i] = public_values[i];
+    std::vector<uint32_t> pv(n_proofs * n_public);
+    for (size_t i = 0; i < pv.size(); i++) pv[i] = public_values[i];
     return zkhip_verify_machine_keyed(proof, len, m->log_ns, m->widths, m->pre_widths, vk, m->progs, m->prog_words, m->tabs, m->tab_words, N_CHIPS, pv.data(), pv.size(), outer, reason);
 }
 
 // the machine as data (tests compare with tests/recursion_air.py word for word): which = position (tallest chip first); kind 0 = the chip's
 // program, 1 = its interaction table, 2 = its preprocessed trace (canonical words, row-major); *log_rows, *main_width, *pre_width describe the chip
-size_t zkhip_shard_verifier_describe(int log_n, uint32_t width, size_t n_queries, int inner_pow_bits, size_t n_public, int which, int kind, uint32_t* out, size_t cap_words,
-                                     int* log_rows, uint32_t* main_width, uint32_t* pre_width) {
+size_t zkhip_shard_verifier_describe(int log_n, uint32_t width, size_t n_queries, int inner_pow_bits, size_t n_public, size_t n_proofs, int which, int kind, uint32_t* out,
+                                     size_t cap_words, int* log_rows, uint32_t* main_width, uint32_t* pre_width) {
     using namespace zk::rec;
     Shape sh;
-    if (which < 0 || which >= N_CHIPS || kind < 0 || kind > 2 || make_shape(log_n, width, n_queries, inner_pow_bits, n_public, sh) != ZKHIP_OK) return 0;
+    if (which < 0 || which >= N_CHIPS || kind < 0 || kind > 2 || make_shape(log_n, width, n_queries, inner_pow_bits, n_public, n_proofs, sh) != ZKHIP_OK) return 0;
     const auto m = machine_of(sh);
     if (log_rows) *log_rows = m->log_ns[which];
     if (main_width) *main_width = m->widths[which];
@@ -975,7 +1061,7 @@ size_t zkhip_shard_verifier_describe(int log_n, uint32_t width, size_t n_queries
             case C_TS: ts_pre(sh, h, pre); break;
             case C_QUERY: query_pre(sh, h, pre); break;
             case C_OPENED: opened_pre(sh, h, pre); break;
-            case C_SAMPLES: frichip::samples_pre(sh.R, (size_t)sh.Q, h, pre, sh.TP); break;
+            case C_SAMPLES: samples_pre_all(sh, h, pre); break;
             case C_SCALARS: scalars_pre(sh, h, pre); break;
             default: break;
         }

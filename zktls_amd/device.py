@@ -636,24 +636,31 @@ class Context:
                                                cap8.ctypes.data_as(u32p), int(witness), C.byref(params), buf.ctypes.data_as(u8p), size, C.byref(got)))
         return buf[: got.value]
 
-    def shard_verifier_setup(self, log_n, width, n_queries, inner_pow_bits, n_public, params=None):
-        """zkhip_shard_verifier_setup: the key of the shard-verifier machine for inner proofs of this SHAPE (no inner proof involved)"""
+    def shard_verifier_setup(self, log_n, width, n_queries, inner_pow_bits, n_public, params=None, n_proofs=1):
+        """zkhip_shard_verifier_setup: the key of the shard-verifier machine for n_proofs inner proofs of this SHAPE (no inner proof involved)"""
         params = params or Params(1, 100, 16)
         handle, root = C.c_void_p(), np.zeros(8, dtype=np.uint32)
-        check(self.lib.zkhip_shard_verifier_setup(self.handle, log_n, width, n_queries, inner_pow_bits, n_public, C.byref(params), C.byref(handle), root.ctypes.data_as(u32p)))
+        check(self.lib.zkhip_shard_verifier_setup(self.handle, log_n, width, n_queries, inner_pow_bits, n_public, n_proofs, C.byref(params), C.byref(handle), root.ctypes.data_as(u32p)))
         return MachineKey(self, handle, root, None)
 
-    def prove_shard_verifier(self, key, shard_proof, log_n, width, public_values, inner=None, outer=None):
-        """zkhip_prove_shard_verifier: the WHOLE verification of a shard proof (transcript, AIR identity, openings, FRI) proven in-circuit"""
+    def prove_shard_verifier(self, key, shard_proofs, log_n, width, public_values, inner=None, outer=None):
+        """zkhip_prove_shard_verifier: the WHOLE verification of a shard proof (transcript, AIR identity, openings, FRI) proven in-circuit.
+        shard_proofs: one proof (bytes / uint8 array) with its public values, or a LIST of proofs with a list of public-value lists (the join)"""
         inner, outer = inner or Params(1, 100, 16), outer or Params(1, 100, 16)
-        sp = np.ascontiguousarray(shard_proof, dtype=np.uint8)
-        pv = np.ascontiguousarray(np.array(public_values, dtype=np.uint32))
-        size = self.lib.zkhip_shard_verifier_proof_size(log_n, width, inner.num_queries, inner.pow_bits, pv.size, C.byref(outer))
+        if not isinstance(shard_proofs, (list, tuple)):
+            shard_proofs, public_values = [shard_proofs], [public_values]
+        sps = [np.ascontiguousarray(sp, dtype=np.uint8) for sp in shard_proofs]
+        n = len(sps)
+        pv = np.ascontiguousarray(np.array([list(v) for v in public_values], dtype=np.uint32).reshape(n, -1))
+        n_public = pv.shape[1]
+        size = self.lib.zkhip_shard_verifier_proof_size(log_n, width, inner.num_queries, inner.pow_bits, n_public, n, C.byref(outer))
         if size == 0:
             check(-1)
         buf = np.empty(size, dtype=np.uint8)
         got = C.c_size_t(0)
-        check(self.lib.zkhip_prove_shard_verifier(self.handle, key.handle, sp.ctypes.data_as(u8p), sp.size, log_n, width, pv.ctypes.data_as(u32p), pv.size, C.byref(inner),
+        ptrs = (u8p * n)(*[sp.ctypes.data_as(u8p) for sp in sps])
+        lens = (C.c_size_t * n)(*[sp.size for sp in sps])
+        check(self.lib.zkhip_prove_shard_verifier(self.handle, key.handle, ptrs, lens, n, log_n, width, pv.ctypes.data_as(u32p), n_public, C.byref(inner),
                                                   C.byref(outer), buf.ctypes.data_as(u8p), size, C.byref(got)))
         return buf[: got.value]
 
@@ -1125,24 +1132,25 @@ def fri_indices_programs(layers, inner_pow_bits):
     return out
 
 
-def verify_shard_recursive(proof, log_n, width, n_queries, inner_pow_bits, public_values, vk, params=None):
-    """zkhip_verify_shard_recursive (host): the inner proof's shape and public values and the shape's key -- no byte of the inner proof"""
+def verify_shard_recursive(proof, log_n, width, n_queries, inner_pow_bits, public_values, vk, params=None, n_proofs=1):
+    """zkhip_verify_shard_recursive (host): the inner proofs' shape and public values (a flat list: proof 0's, then proof 1's, ...) and the shape's key --
+    no byte of an inner proof"""
     params = params or Params(1, 100, 16)
     lib = _lib.load()
     pr = np.ascontiguousarray(proof, dtype=np.uint8)
-    pv = np.ascontiguousarray(np.array(public_values, dtype=np.uint32))
+    pv = np.ascontiguousarray(np.array(public_values, dtype=np.uint32).ravel())
     k = np.ascontiguousarray(np.array(vk, dtype=np.uint32))
     reason = C.c_int(0)
-    rc = lib.zkhip_verify_shard_recursive(pr.ctypes.data_as(u8p), pr.size, log_n, width, n_queries, inner_pow_bits, pv.ctypes.data_as(u32p), pv.size, k.ctypes.data_as(u32p),
-                                          C.byref(params), C.byref(reason))
+    rc = lib.zkhip_verify_shard_recursive(pr.ctypes.data_as(u8p), pr.size, log_n, width, n_queries, inner_pow_bits, pv.ctypes.data_as(u32p), pv.size // max(n_proofs, 1), n_proofs,
+                                          k.ctypes.data_as(u32p), C.byref(params), C.byref(reason))
     return rc, reason.value
 
 
-def shard_verifier_describe(log_n, width, n_queries, inner_pow_bits, n_public, which, kind):
+def shard_verifier_describe(log_n, width, n_queries, inner_pow_bits, n_public, which, kind, n_proofs=1):
     """zkhip_shard_verifier_describe -> (words, log_rows, main width, preprocessed width); kind 0 program, 1 interaction table, 2 preprocessed trace"""
     lib = _lib.load()
     ln, mw, pw = C.c_int(0), C.c_uint32(0), C.c_uint32(0)
-    shape = (log_n, width, n_queries, inner_pow_bits, n_public)
+    shape = (log_n, width, n_queries, inner_pow_bits, n_public, n_proofs)
     n = lib.zkhip_shard_verifier_describe(*shape, which, kind, None, 0, C.byref(ln), C.byref(mw), C.byref(pw))
     out = np.zeros(max(n, 1), dtype=np.uint32)
     lib.zkhip_shard_verifier_describe(*shape, which, kind, out.ctypes.data_as(u32p), n, C.byref(ln), C.byref(mw), C.byref(pw))
