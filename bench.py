@@ -92,8 +92,8 @@ def main():
                          "traces checked to live where their shard is dealt); the line says so and is not a scaling result")
     ap.add_argument("--no-multichip", action="store_true", help="skip the multi-chip shard with LogUp pairs (SP1's shard structure, rows a7 mixed heights + a8) measured beside the headline")
     ap.add_argument("--no-fri-graph", action="store_true",
-                    help="zkhip_set_fri_graph(0): the FRI commit phase as plain launches instead of one hipGraphLaunch per proof -- for runs under "
-                         "`rocprofv3 --kernel-trace`, which crashes on hipGraphLaunch from worker threads (tools/segv, profiles/r04_segv.md); same proof bytes")
+                    help="zkhip_set_fri_graph(0): the FRI commit phase as plain launches instead of one hipGraphLaunch per proof (a debugging switch; "
+                         "same proof bytes; profiles/r04_segv.md)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--wait", choices=("auto", "poll", "block"), default="auto",
                     help="how the prover's host threads wait for their streams (zkhip_set_wait_mode): poll = hipStreamSynchronize, block = sleep "

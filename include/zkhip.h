@@ -615,8 +615,10 @@ void zkhip_lockstep_stats(uint64_t out[6]);
 uint64_t zkhip_lockstep_stack_high_water(void);
 /* The FRI commit phase of a proof outside lock-step batches is a fixed sequence of ~250 small launches, captured once per shape into a HIP
  * graph and replayed with one hipGraphLaunch per proof (csrc/prover.cpp).  on = 0 keeps the plain launches, process-wide (default on; same
- * proof bytes).  The switch exists for runs under `rocprofv3 --kernel-trace`, whose interception crashes (SIGSEGV) on hipGraphLaunch from
- * worker threads -- with no code of this library involved: tools/segv/repro_nolib g, profiles/r04_segv.md. */
+ * proof bytes): a debugging switch that takes graphs out of the picture.  (It was added while chasing the SIGSEGV of runs under `rocprofv3
+ * --kernel-trace`: graph launches crash there every time with no code of this library involved, tools/segv/repro_nolib g -- but plain
+ * launches and copies from many threads crash inside the same interception too, so the switch does NOT make profiled runs safe;
+ * profiles/r04_segv.md.) */
 void zkhip_set_fri_graph(int on);
 
 /* A second real chip: the width-16 Poseidon2 permutation with Merkle-path chaining -- what a recursion machine (a STARK verifier proven

@@ -1,0 +1,30 @@
+#!/usr/bin/env python3
+"""where the join's time goes (A/B build: ZKHIP_REC_TIMING prints the phases of zkhip_prove_shard_verifier to stderr)"""
+import os
+import sys
+import time
+os.environ["ZKHIP_REC_TIMING"] = "1"
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tools"))
+import _ab  # noqa: E402,F401
+from zktls_amd._lib import Params  # noqa: E402
+from zktls_amd.device import Context, verify_shard  # noqa: E402
+
+ctx = Context(0)
+log_n, width, q, pb = 20, 256, 100, 16
+iprm, prm = Params(1, q, pb), Params(1, 100, 16)
+n = int(sys.argv[1]) if len(sys.argv) > 1 else 16
+tr = ctx.gen_trace(1, 0, log_n, width)
+pv = [[1, 2, 3, 4, 5, 6, 7, 8, s] for s in range(n)]
+inner = [ctx.prove_shard(tr, log_n, width, pv[s], iprm) for s in range(n)]
+t0 = time.perf_counter()
+verify_shard(inner[0], log_n, width, pv[0], iprm)
+print("host verify of one inner proof %.2f ms" % ((time.perf_counter() - t0) * 1e3))
+key = ctx.shard_verifier_setup(log_n, width, q, pb, 9, prm, n_proofs=n)
+for rep in range(3):
+    t0 = time.perf_counter()
+    outer = ctx.prove_shard_verifier(key, inner, log_n, width, pv, iprm, prm)
+    print("join %d: %.1f ms" % (n, (time.perf_counter() - t0) * 1e3), flush=True)
+key.close()
+ctx.close()

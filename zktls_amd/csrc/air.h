@@ -174,6 +174,22 @@ inline std::shared_ptr<const AirTermPlan> air_term_plan(const AirView& a) {
     cache.push_back(Entry{h, a.words, std::vector<uint32_t>(a.w, a.w + a.words), plan});
     return plan;
 }
+// public values a program READS: 1 + the largest index among its public-value factors (0: none).  A machine's chips all declare the
+// machine's public values, most read none -- the term kernels stage only what is read.
+inline uint32_t air_public_used(const AirView& a) {
+    uint32_t used = 0;
+    size_t p = 6;
+    for (uint32_t k = 0; k < a.K; k++) {
+        const uint32_t nt = a.w[p + 1];
+        p += 2;
+        for (uint32_t t = 0; t < nt; t++) {
+            const uint32_t d = a.w[p + 1];
+            p += 2;
+            for (uint32_t j = 0; j < d; j++, p++) if ((a.w[p] >> 30) == 2u && (a.w[p] & 0xFFFFu) + 1u > used) used = (a.w[p] & 0xFFFFu) + 1u;
+        }
+    }
+    return used;
+}
 inline size_t air_term_count(const AirView& a) { const size_t nm = air_term_plan(a)->monomials.size(); return nm + (nm & 1); }
 inline void air_term_records(const AirView& a, const Ext& alpha, std::vector<uint32_t>& recs, const Ext& scale = ext_one()) {
     std::vector<Ext> wts(a.K);

@@ -24,6 +24,8 @@
 #include <algorithm>
 #include <array>
 #include <atomic>
+#include <chrono>
+#include <cstdio>
 #include <condition_variable>
 #include <cstring>
 #include <map>
@@ -376,6 +378,8 @@ struct TraceArgs {
     uint32_t* trace; uint64_t ld;                           // Montgomery
     uint32_t* finals;                                       // [n_queries][4] canonical: the value every chain ends in
     uint32_t pt;                                            // rec form: the PT column's value (canonical)
+    uint32_t per_proof, pt_stride;                          // several inner proofs in one launch (per_proof > 0): query q belongs to proof q / per_proof -- its betas are
+                                                            // betas + 4 layers proof, its PT is pt + pt_stride proof
     uint64_t row_base, pad_from;                            // the chains' rows start at row_base; rows pad_from .. rows - 1 are padding (pad_from = rows: none)
 };
 // one thread per query walks its layers (the folded value of a layer is the next layer's own entry); threads past the queries fill
@@ -391,6 +395,8 @@ __device__ __forceinline__ void fri_trace_kernel_body(const TraceArgs& a) {
         return;
     }
     uint32_t idx = a.indices[q];
+    const uint32_t proof = a.per_proof ? q / a.per_proof : 0u, pt = a.pt + a.pt_stride * proof;
+    const uint32_t* betas = a.betas + 4u * RL * proof;
     Ext own;
     for (int i = 0; i < 4; i++) own.c[i] = to_monty(a.values[4 * q + i]);
     uint32_t tcol[MAX_LAYERS];
@@ -398,7 +404,7 @@ __device__ __forceinline__ void fri_trace_kernel_body(const TraceArgs& a) {
         uint32_t* row = a.trace + (a.row_base + (uint64_t)q * RL + l) * a.ld;
         const uint32_t bit = idx & 1u, k = idx >> 1;
         Ext sib, beta;
-        for (int i = 0; i < 4; i++) { sib.c[i] = to_monty(a.siblings[4 * ((uint64_t)q * RL + l) + i]); beta.c[i] = to_monty(a.betas[4 * l + i]); }
+        for (int i = 0; i < 4; i++) { sib.c[i] = to_monty(a.siblings[4 * ((uint64_t)q * RL + l) + i]); beta.c[i] = to_monty(betas[4 * l + i]); }
         const Ext e0 = bit ? sib : own, e1 = bit ? own : sib;
         const int lh = (int)a.log_h - (int)(l + 1);                       // the layer's vector has 2^(lh + 1) entries
         const uint32_t x = fpow(two_adic_generator(lh + 1), reverse_bits(k, lh));
@@ -419,7 +425,7 @@ __device__ __forceinline__ void fri_trace_kernel_body(const TraceArgs& a) {
         if (l + 1 < RL) { row[G] = MONTY_R1; row[GS] = row[S]; row[GT] = tcol[l]; }
         for (int i = 0; i < 4; i++) row[OWN + i] = own.c[i];
         if (a.wired) { row[K2] = to_monty(2u * k); row[IDX] = to_monty(2u * k + bit); }
-        if (a.wired == 2u) { row[XS] = bit ? fsub(0u, x) : x; row[PT] = to_monty(a.pt); row[LNX] = to_monty(a.pt + l); }
+        if (a.wired == 2u) { row[XS] = bit ? fsub(0u, x) : x; row[PT] = to_monty(pt); row[LNX] = to_monty(pt + l); }
         own = fold;
         idx = k;
     }
@@ -536,14 +542,17 @@ size_t zkhip_fri_chip_air(int layers, uint32_t* program, size_t cap_words) {
 }  // extern "C"
 static int fri_gen_trace(zkhip_ctx* ctx, int layers, size_t n_queries, const uint32_t* betas, const uint32_t* indices, const uint32_t* values,
                          const uint32_t* siblings, int log_rows, uint32_t* d_trace, size_t ld, uint32_t* finals, bool wired, bool rec = false, uint32_t pt = 0,
-                         uint64_t row_base = 0, int64_t pad_from = -1) {
+                         uint64_t row_base = 0, int64_t pad_from = -1, size_t n_proofs = 1, uint32_t pt_stride = 0) {
+    // n_proofs > 1 (the shard verifier's join): n_queries counts ALL proofs' queries (n_queries / n_proofs each), betas holds every proof's challenges
     CHECK_CTX(ctx);
     int need;
-    ZK_TRY(frichip::shape_ok(layers, n_queries, &need));
+    if (n_proofs < 1 || n_queries % n_proofs) return fail(ZKHIP_ERR_INVALID, "fri_chip_gen_trace: bad arguments");
+    ZK_TRY(frichip::shape_ok(layers, n_queries / n_proofs, &need));
+    if (n_proofs > 1) { need = 5; while (((size_t)1 << need) < n_queries * (size_t)layers) need++; }
     const uint32_t W = frichip::width_of(layers, wired, rec);
     if (!betas || !indices || !values || !siblings || !d_trace || !finals || ld < W || log_rows < need || log_rows > MAX_LOG_ROWS)
         return fail(ZKHIP_ERR_INVALID, "fri_chip_gen_trace: bad arguments");
-    const size_t nb = 4 * (size_t)layers, nv = 4 * n_queries, ns = nv * (size_t)layers;
+    const size_t nb = 4 * (size_t)layers * n_proofs, nv = 4 * n_queries, ns = nv * (size_t)layers;
     if (!frichip::canonical(betas, nb) || !frichip::canonical(values, nv) || !frichip::canonical(siblings, ns)) return fail(ZKHIP_ERR_INVALID, "fri_chip_gen_trace: values must be canonical");
     for (size_t q = 0; q < n_queries; q++) if (indices[q] >> (layers + 1)) return fail(ZKHIP_ERR_INVALID, "fri_chip_gen_trace: a query index has more than layers + 1 bits");
     void* stage;
@@ -561,6 +570,7 @@ static int fri_gen_trace(zkhip_ctx* ctx, int layers, size_t n_queries, const uin
     a.betas = d; a.indices = d + nb; a.values = d + nb + n_queries; a.siblings = d + nb + n_queries + nv;
     a.n_queries = (uint32_t)n_queries; a.layers = (uint32_t)layers; a.width = W; a.log_h = (uint32_t)layers + 1u; a.wired = rec ? 2u : wired ? 1u : 0u;
     a.rows = (uint64_t)1 << log_rows; a.trace = d_trace; a.ld = ld; a.finals = d + nb + n_queries + nv + ns;
+    a.per_proof = n_proofs > 1 ? (uint32_t)(n_queries / n_proofs) : 0u; a.pt_stride = pt_stride;
     a.pt = pt; a.row_base = row_base; a.pad_from = pad_from < 0 ? (uint64_t)n_queries * (uint64_t)layers : (uint64_t)pad_from;
     const size_t pad = a.rows - a.pad_from;
     const size_t threads = n_queries + (pad < 4096 ? pad : 4096);            // the padding rows are shared among up to 4096 extra threads

@@ -139,10 +139,13 @@ static int run_quotient_air(zkhip_ctx* ctx, const AirView& air, const uint32_t* 
     uint32_t cls[6] = {0, 0, 0, 0, 0, 0};
     // (not inside a lock-step batch: the batched twin takes its arguments from memory, its record loads then are per-lane loads of one
     // address instead of scalar loads, and that form is slower than the 8-point kernel)
+    // (the public values a program READS count, not the ones it declares: the chips of a machine declare the machine's, most read none --
+    // the shard verifier's join declares 16 x 9 and only its transcript table reads them)
+    const uint32_t pub_used = air_public_used(air);
     const bool wide = !t_batcher && ld % 4 == 0 && (reinterpret_cast<uintptr_t>(lde) & 15u) == 0 &&
-                      air_wide_form(width, (uint32_t)air_term_count(air), log_n, air.n_public);
+                      air_wide_form(width, (uint32_t)air_term_count(air), log_n, pub_used);
     if (wide) air_term_records_wide(air, alpha, recs, cls, scale);
-    else if (air.n_public <= 64) air_term_records(air, alpha, recs, scale);
+    else if (pub_used <= 64) air_term_records(air, alpha, recs, scale);
     // one staging buffer: body | weights (16-byte aligned) | public values | term records (16-byte aligned)
     const size_t body_w = (body.size() + 3) & ~(size_t)3, pub_w = (pub.size() + 3) & ~(size_t)3;
     std::vector<uint32_t> stage(body_w + weights.size() + pub_w + recs.size(), 0u);
@@ -164,7 +167,7 @@ static int run_quotient_air(zkhip_ctx* ctx, const AirView& air, const uint32_t* 
     q.weights = (const uint32_t*)d_stage + body_w; q.pub = (const uint32_t*)d_stage + body_w + weights.size();
     q.out = out_chunks; q.lde_out = lde_out; q.lde_ld = lde_ld;
     q.recs = recs.empty() ? nullptr : (const uint32_t*)d_stage + body_w + weights.size() + pub_w;
-    q.n_terms = (uint32_t)(recs.size() / 8); q.n_public = air.n_public;
+    q.n_terms = (uint32_t)(recs.size() / 8); q.n_public = recs.empty() ? air.n_public : pub_used;
     q.wide = wide ? 1u : 0u;
     for (int i = 0; i < 6; i++) q.cls[i] = cls[i];
     q.addend = addend;
@@ -268,7 +271,7 @@ static int fri_commit_phase(zkhip_ctx* ctx, Challenger& ch, const Shape& sh, int
     static const bool env_graph = [] { const char* e = getenv("ZKHIP_FRI_GRAPH"); return !e || atoi(e) != 0; }();
     const bool use_graph = env_graph && g_fri_graph.load();
 #else
-    const bool use_graph = g_fri_graph.load();       // zkhip_set_fri_graph: off for runs under rocprofv3, whose kernel tracing crashes on hipGraphLaunch (tools/segv)
+    const bool use_graph = g_fri_graph.load();       // zkhip_set_fri_graph (a debugging switch)
 #endif
     if (d_chal && use_graph && !t_batcher) {                   // lock-step members launch one by one: their launches merge across the batch
         std::vector<uint64_t> key = {(uint64_t)H, (uint64_t)K, (uint64_t)RL, (uint64_t)sh.hw, (uint64_t)m, (uint64_t)(uintptr_t)layers,

@@ -660,6 +660,7 @@ struct HostTables {
     std::vector<uint32_t> sc, op, rs, q, ts, sm;            // SCALARS, OPENED, ROWSUM, QUERY, TS, SAMPLES main traces (all proofs)
     std::vector<uint32_t> desc, data, chain_in, trows;      // P2R: chains, their data, the transcript rows' input states and row numbers
     std::vector<const uint32_t*> want_roots;                // per chain: where it must end (canonical words; owned by the witnesses)
+    // (desc / data / chain_in / trows / want_roots hold a fixed slice per proof)
 };
 int fill_one(const Shape& sh, const Machine& m, int p, const uint8_t* inner, size_t inner_len, const uint32_t* public_values, const zkhip_params* inner_prm, Witness& wt,
              std::vector<uint32_t>& words, HostTables& ht, Ext* fa_out) {
@@ -851,17 +852,18 @@ int fill_one(const Shape& sh, const Machine& m, int p, const uint8_t* inner, siz
     }
     // (i) this proof's entries of the P2R work lists: transcript rows, then Q R FRI paths (leaf block = the pair), Q trace openings, Q quotient openings
     {
+        // (every proof writes ITS slices of the shared lists: the proofs are filled side by side on a few host threads)
         const size_t row0 = (size_t)p * sh.p2_rows;
-        for (int T = 0; T < sh.NT; T++) ht.trows.push_back((uint32_t)(row0 + (size_t)T));
-        ht.chain_in.insert(ht.chain_in.end(), chain_in.begin(), chain_in.end());
+        for (int T = 0; T < sh.NT; T++) ht.trows[(size_t)p * (size_t)sh.NT + (size_t)T] = (uint32_t)(row0 + (size_t)T);
+        std::memcpy(ht.chain_in.data() + 16 * (size_t)p * (size_t)sh.NT, chain_in.data(), chain_in.size() * 4);
         const size_t per_q_paths = zkhip_fri_view_path_words(R);
-        const size_t off_pairs = ht.data.size();
-        ht.data.resize(off_pairs + 8 * (size_t)Q * (size_t)R);
-        const size_t off_paths = ht.data.size();
-        ht.data.insert(ht.data.end(), wt.paths.begin(), wt.paths.end());
-        const size_t off_words = ht.data.size();
-        ht.data.insert(ht.data.end(), words.begin(), words.end());
-        if (ht.data.size() >= ((size_t)1 << 32)) return fail(ZKHIP_ERR_INVALID, "prove_shard_verifier: too much witness data for one call");
+        const size_t seg = 8 * (size_t)Q * (size_t)R + wt.paths.size() + words.size();
+        const size_t off_pairs = (size_t)p * seg, off_paths = off_pairs + 8 * (size_t)Q * (size_t)R, off_words = off_paths + wt.paths.size();
+        std::memcpy(ht.data.data() + off_paths, wt.paths.data(), wt.paths.size() * 4);
+        std::memcpy(ht.data.data() + off_words, words.data(), words.size() * 4);
+        const size_t chains_per = (size_t)Q * (size_t)R + 2 * (size_t)Q;
+        uint32_t* desc = ht.desc.data() + 6 * (size_t)p * chains_per;
+        const uint32_t** want = ht.want_roots.data() + (size_t)p * chains_per;
         size_t row = row0 + sh.p2_fri0, ch = 0;
         for (int q = 0; q < Q; q++) {
             uint32_t idx = wt.indices[(size_t)q];
@@ -875,8 +877,8 @@ int fill_one(const Shape& sh, const Machine& m, int p, const uint8_t* inner, siz
                 const int lh = H - (l + 1);
                 const uint32_t d[6] = {(uint32_t)row, 1u, (uint32_t)(off_pairs + 8 * ch), (uint32_t)lh, k,
                                        (uint32_t)(off_paths + (size_t)q * per_q_paths + 8 * ((size_t)l * (size_t)R - (size_t)l * ((size_t)l - 1) / 2))};
-                ht.desc.insert(ht.desc.end(), d, d + 6);
-                ht.want_roots.push_back(wt.lroots.data() + 8 * (size_t)l);
+                std::memcpy(desc + 6 * ch, d, sizeof d);
+                want[ch] = wt.lroots.data() + 8 * (size_t)l;
                 row += 1 + (size_t)lh;
                 const uint32_t xi = finv(fpow(two_adic_generator(lh + 1), reverse_bits(k, lh)));
                 const Ext beta = ext_canon(wt.betas.data() + 4 * (size_t)l);
@@ -885,15 +887,15 @@ int fill_one(const Shape& sh, const Machine& m, int p, const uint8_t* inner, siz
             }
         }
         for (int which = 0; which < 2; which++)
-            for (int q = 0; q < Q; q++) {
+            for (int q = 0; q < Q; q++, ch++) {
                 const size_t trow = wt.q_trow(q), tpath = trow + (size_t)W, qrow = tpath + 8 * (size_t)H, qpath = qrow + 8;
                 const uint32_t d[6] = {(uint32_t)row, which ? 1u : (uint32_t)sh.WB, (uint32_t)(off_words + (which ? qrow : trow)), (uint32_t)H, wt.indices[(size_t)q],
                                        (uint32_t)(off_words + (which ? qpath : tpath))};
-                ht.desc.insert(ht.desc.end(), d, d + 6);
-                ht.want_roots.push_back(pw + (which ? wt.o_qroot : wt.o_troot));
+                std::memcpy(desc + 6 * ch, d, sizeof d);
+                want[ch] = pw + (which ? wt.o_qroot : wt.o_troot);
                 row += (which ? 1 : (size_t)sh.WB) + (size_t)H;
             }
-        if (row != row0 + sh.p2_rows) return fail(ZKHIP_ERR_INTERNAL, "prove_shard_verifier: row layout");
+        if (row != row0 + sh.p2_rows || ch != chains_per) return fail(ZKHIP_ERR_INTERNAL, "prove_shard_verifier: row layout");
     }
     return ZKHIP_OK;
 }
@@ -918,29 +920,71 @@ static int shard_verifier_prove_impl(zkhip_ctx* ctx, const zkhip_machine_key* ke
     const ScCols scc = sc_cols(sh);
     const uint32_t sc_w = rup4(scc.end - SC_PRE);
     const uint32_t w_main[N_CHIPS] = {P2_MAIN, RS_MAIN, frichip::width_of(R, true, true), TS_MAIN, Q_MAIN, OP_MAIN, frichip::S_MAIN, sc_w};
+#ifdef ZKHIP_AB_HOOKS
+    static const bool timing = getenv("ZKHIP_REC_TIMING") != nullptr;
+    auto t_last = std::chrono::steady_clock::now();
+    auto lap = [&](const char* what) {
+        if (!timing) return;
+        (void)hipStreamSynchronize(ctx->stream);
+        const auto now = std::chrono::steady_clock::now();
+        std::fprintf(stderr, "  [shard verifier] %-28s %8.2f ms\n", what, std::chrono::duration<double, std::milli>(now - t_last).count());
+        t_last = now;
+    };
+#else
+    auto lap = [](const char*) {};
+#endif
     HostTables ht;
     ht.sc.assign((size_t)sc_w << m.height[C_SCALARS], 0u); ht.op.assign((size_t)OP_MAIN << m.height[C_OPENED], 0u); ht.rs.assign((size_t)RS_MAIN << m.height[C_ROWSUM], 0u);
     ht.q.assign((size_t)Q_MAIN << m.height[C_QUERY], 0u); ht.ts.assign((size_t)TS_MAIN << m.height[C_TS], 0u); ht.sm.assign((size_t)frichip::S_MAIN << m.height[C_SAMPLES], 0u);
     std::vector<Witness> wts((size_t)NP);
     std::vector<std::vector<uint32_t>> words((size_t)NP);
     std::vector<Ext> fas((size_t)NP);
-    for (int p = 0; p < NP; p++) {
-        if (!inner[p]) return fail(ZKHIP_ERR_INVALID, "prove_shard_verifier: null proof");
-        ZK_TRY(fill_one(sh, m, p, inner[p], inner_len[p], public_values + (size_t)p * n_public, inner_prm, wts[(size_t)p], words[(size_t)p], ht, &fas[(size_t)p]));
+    {
+        // the shared lists have a fixed slice per proof (the shape fixes every size): the proofs are filled side by side
+        const size_t chains_per = (size_t)Q * (size_t)R + 2 * (size_t)Q, seg = 8 * (size_t)Q * (size_t)R + zkhip_fri_view_path_words(R) * (size_t)Q + inner_len[0] / 4;
+        for (int p = 0; p < NP; p++) {
+            if (!inner[p]) return fail(ZKHIP_ERR_INVALID, "prove_shard_verifier: null proof");
+            if (inner_len[p] != inner_len[0] || inner_len[p] % 4) return fail(ZKHIP_ERR_INVALID, "prove_shard_verifier: the proofs of one call have one shape, hence one length");
+        }
+        if ((size_t)NP * seg >= ((size_t)1 << 32)) return fail(ZKHIP_ERR_INVALID, "prove_shard_verifier: too much witness data for one call");
+        ht.desc.assign(6 * (size_t)NP * chains_per, 0u); ht.want_roots.assign((size_t)NP * chains_per, nullptr); ht.data.assign((size_t)NP * seg, 0u);
+        ht.chain_in.assign(16 * (size_t)NP * (size_t)sh.NT, 0u); ht.trows.assign((size_t)NP * (size_t)sh.NT, 0u);
+        std::vector<int> rcs((size_t)NP, ZKHIP_OK);
+        std::vector<std::string> msgs((size_t)NP);
+        auto one = [&](int p) {
+            rcs[(size_t)p] = fill_one(sh, m, p, inner[p], inner_len[p], public_values + (size_t)p * n_public, inner_prm, wts[(size_t)p], words[(size_t)p], ht, &fas[(size_t)p]);
+            if (rcs[(size_t)p] != ZKHIP_OK) msgs[(size_t)p] = zkhip_last_error();
+        };
+        if (NP == 1 || t_batcher) for (int p = 0; p < NP; p++) one(p);
+        else {
+            HostPool pool(NP < 8 ? NP : 8);
+            for (int p = 0; p < NP; p++) pool.submit([&one, p] { one(p); });
+            pool.wait();
+        }
+        for (int p = 0; p < NP; p++) if (rcs[(size_t)p] != ZKHIP_OK) { set_error("proof " + std::to_string(p) + ": " + msgs[(size_t)p]); return rcs[(size_t)p]; }
     }
+    lap("host: witnesses + tables");
     for (size_t r = (size_t)NP; r < ((size_t)1 << m.height[C_SCALARS]); r++) std::memcpy(ht.sc.data() + sc_w * r, ht.sc.data(), sc_w * 4);     // rows behind the proofs repeat row 0
     // device: the fold rows proof by proof (the last call fills the padding), then ONE launch for every Poseidon2 row
     void* dev[N_CHIPS] = {nullptr};
     const int slots[N_CHIPS] = {S_REC_A, S_REC_C, S_REC_B, S_REC_D, S_REC_E, S_REC_F, S_REC_G, S_REC_H};
     for (int c = 0; c < N_CHIPS; c++) ZK_TRY(ctx_reserve(ctx, slots[c], ((size_t)w_main[c] << m.height[c]) * 4, &dev[c]));
-    for (int p = 0; p < NP; p++) {
-        const Witness& wt = wts[(size_t)p];
-        std::vector<uint32_t> finals(4 * (size_t)Q);
-        const uint64_t per = (uint64_t)Q * (uint64_t)R, rows = (uint64_t)1 << m.height[C_FOLD];
-        ZK_TRY(fri_gen_trace(ctx, R, (size_t)Q, wt.betas.data(), wt.indices.data(), wt.values.data(), wt.siblings.data(), m.height[C_FOLD], (uint32_t*)dev[C_FOLD],
-                             w_main[C_FOLD], finals.data(), true, true, (uint32_t)(p * sh.TREES), (uint64_t)p * per, (int64_t)(p + 1 == NP ? (uint64_t)NP * per : rows)));
-        for (int q = 0; q < Q; q++) if (std::memcmp(finals.data() + 4 * (size_t)q, wt.w + wt.o_final, 16) != 0) return fail(ZKHIP_ERR_INTERNAL, "prove_shard_verifier: a chain does not end in the final value");
+    {   // the fold rows of every proof in ONE launch
+        const size_t nq = (size_t)NP * (size_t)Q;
+        std::vector<uint32_t> betas, indices, values, siblings, finals(4 * nq);
+        for (int p = 0; p < NP; p++) {
+            const Witness& wt = wts[(size_t)p];
+            betas.insert(betas.end(), wt.betas.begin(), wt.betas.end()); indices.insert(indices.end(), wt.indices.begin(), wt.indices.end());
+            values.insert(values.end(), wt.values.begin(), wt.values.end()); siblings.insert(siblings.end(), wt.siblings.begin(), wt.siblings.end());
+        }
+        ZK_TRY(fri_gen_trace(ctx, R, nq, betas.data(), indices.data(), values.data(), siblings.data(), m.height[C_FOLD], (uint32_t*)dev[C_FOLD], w_main[C_FOLD], finals.data(),
+                             true, true, 0u, 0, -1, (size_t)NP, (uint32_t)sh.TREES));
+        for (int p = 0; p < NP; p++)
+            for (int q = 0; q < Q; q++)
+                if (std::memcmp(finals.data() + 4 * ((size_t)p * (size_t)Q + (size_t)q), wts[(size_t)p].w + wts[(size_t)p].o_final, 16) != 0)
+                    return fail(ZKHIP_ERR_INTERNAL, "prove_shard_verifier: a chain does not end in the final value");
     }
+    lap("device: fold rows");
     {
         const size_t n_chains = ht.desc.size() / 6;
         const size_t up_words = ht.desc.size() + ht.data.size() + ht.chain_in.size() + ht.trows.size(), down_words = 8 * n_chains;
@@ -954,6 +998,7 @@ static int shard_verifier_prove_impl(zkhip_ctx* ctx, const zkhip_machine_key* ke
             up.insert(up.end(), ht.trows.begin(), ht.trows.end());
             ZK_TRY(dev_h2d(ctx, d, up.data(), up_words * 4));
         }
+        lap("upload: P2R work lists");
         p2chip::P2RArgs a{};
         a.desc = d; a.data = d + ht.desc.size(); a.chain_inputs = a.data + ht.data.size(); a.trows = a.chain_inputs + ht.chain_in.size();
         a.n_chains = (uint32_t)n_chains; a.n_transcript = (uint32_t)ht.trows.size(); a.rows = (uint64_t)1 << m.height[C_P2R]; a.used_rows = (uint64_t)NP * sh.p2_rows;
@@ -964,6 +1009,7 @@ static int shard_verifier_prove_impl(zkhip_ctx* ctx, const zkhip_machine_key* ke
         for (size_t c = 0; c < n_chains; c++)
             if (std::memcmp(down.data() + 8 * c, ht.want_roots[c], 32) != 0) return fail(ZKHIP_ERR_INTERNAL, "prove_shard_verifier: an opening does not end in its root");
     }
+    lap("device: P2R rows + roots back");
     // the host tables up, then the machine's proof
     const std::vector<uint32_t>* host[N_CHIPS] = {nullptr, &ht.rs, nullptr, &ht.ts, &ht.q, &ht.op, &ht.sm, &ht.sc};
     for (int c = 0; c < N_CHIPS; c++) if (host[c]) ZK_TRY(dev_h2d(ctx, dev[c], host[c]->data(), host[c]->size() * 4));
@@ -974,7 +1020,10 @@ static int shard_verifier_prove_impl(zkhip_ctx* ctx, const zkhip_machine_key* ke
     }
     std::vector<uint32_t> pv((size_t)NP * n_public);
     for (size_t i = 0; i < pv.size(); i++) pv[i] = public_values[i] % P;
-    return zkhip_prove_machine_keyed(ctx, key, chips, m.progs, m.prog_words, m.tabs, m.tab_words, N_CHIPS, pv.data(), pv.size(), outer, proof, cap, len);
+    lap("upload: host tables");
+    const int rc = zkhip_prove_machine_keyed(ctx, key, chips, m.progs, m.prog_words, m.tabs, m.tab_words, N_CHIPS, pv.data(), pv.size(), outer, proof, cap, len);
+    lap("the machine's proof");
+    return rc;
 }
 
 extern "C" {
