@@ -35,6 +35,9 @@
  *       SP1ProofMode::Groth16 (sp1.rs:116) spends its rows on besides Poseidon2.
  *       a second real chip -- the Poseidon2 permutation with Merkle-path / leaf-hash chaining, what the recursion stages behind
  *       SP1ProofMode::Groth16 (sp1.rs:116) spend their rows on (sp1-recursion's Poseidon2 chips, Cargo.lock:6172 ff.).
+ *   zkhip_shard_verifier_setup, zkhip_prove_shard_verifier, zkhip_verify_shard_recursive
+ *       the COMPRESS stage behind the same line (sp1.rs:116: core -> compress; prover.rs:90: lift -> join): whole shard proofs verified inside
+ *       ONE proof whose verifier needs the shape, the public values and the shape's key -- no byte of a shard proof.
  *   zkhip_proof_to_bincode / zkhip_chips_proof_to_bincode (+ _from_bincode)
  *       what `prover_output.bytes()` carries (sp1.rs:122-123): bincode-shaped forms of the proofs ([RECALLED] field order).
  *   zkhip_prove_segment

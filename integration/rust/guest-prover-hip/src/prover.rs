@@ -310,3 +310,39 @@ fn prove_one(ctx: &Context, d_trace: *const u32, log_n: i32, width: u32, column_
     check(unsafe { ffi::zkhip_verify_shard(proof.as_ptr(), proof.len(), log_n, width, pv.as_ptr(), pv.len(), prm, &mut reason) }, "zkhip_verify_shard")?;   // sp1.rs:120
     Ok(proof)
 }
+
+/// The compress stage (`client.prove(.., Groth16)`, sp1.rs:116: core -> COMPRESS; prover.rs:90: lift -> join): ONE proof that verifies all
+/// shard proofs of an execution in-circuit.  `public_values`: those of proof 0, then those of proof 1, ... (`n_public` each).  Returns the
+/// joined proof and the verifying key of the shape; `verify_compressed` then needs no byte of the shard proofs.  Limits (docs/RECURSION_NEXT.md):
+/// version-1 shard proofs of one shape, at most 64 per join, one level.
+pub fn compress_shards(ctx: &Context, proofs: &[Vec<u8>], log_n: i32, width: u32, public_values: &[u32], n_public: usize, inner: &ZkhipParams,
+                       outer: &ZkhipParams) -> Result<(Vec<u8>, [u32; 8])> {
+    anyhow::ensure!(!proofs.is_empty() && public_values.len() == proofs.len() * n_public, "compress_shards: one public-value list per proof");
+    let n = proofs.len();
+    let mut key: *mut ffi::ZkhipMachineKey = std::ptr::null_mut();
+    let mut vk = [0u32; 8];
+    check(unsafe { ffi::zkhip_shard_verifier_setup(ctx.raw(), log_n, width, inner.num_queries as usize, inner.pow_bits, n_public, n, outer, &mut key, vk.as_mut_ptr()) },
+          "zkhip_shard_verifier_setup")?;
+    let cap = unsafe { ffi::zkhip_shard_verifier_proof_size(log_n, width, inner.num_queries as usize, inner.pow_bits, n_public, n, outer) };
+    let ptrs: Vec<*const u8> = proofs.iter().map(|p| p.as_ptr()).collect();
+    let lens: Vec<usize> = proofs.iter().map(|p| p.len()).collect();
+    let mut out = vec![0u8; cap];
+    let mut len = 0usize;
+    let rc = unsafe {
+        ffi::zkhip_prove_shard_verifier(ctx.raw(), key, ptrs.as_ptr(), lens.as_ptr(), n, log_n, width, public_values.as_ptr(), n_public, inner, outer, out.as_mut_ptr(), cap, &mut len)
+    };
+    unsafe { ffi::zkhip_machine_key_destroy(key) };
+    check(rc, "zkhip_prove_shard_verifier")?;
+    out.truncate(len);
+    Ok((out, vk))
+}
+
+/// Host-only check of a joined proof: the shape, the shard proofs' public values and the key of the shape (sp1.rs:120 for the compressed proof).
+pub fn verify_compressed(proof: &[u8], log_n: i32, width: u32, public_values: &[u32], n_public: usize, n_proofs: usize, vk: &[u32; 8], inner: &ZkhipParams,
+                         outer: &ZkhipParams) -> Result<()> {
+    let mut reason = 0;
+    check(unsafe {
+        ffi::zkhip_verify_shard_recursive(proof.as_ptr(), proof.len(), log_n, width, inner.num_queries as usize, inner.pow_bits, public_values.as_ptr(), n_public, n_proofs,
+                                          vk.as_ptr(), outer, &mut reason)
+    }, "zkhip_verify_shard_recursive")
+}

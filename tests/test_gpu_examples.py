@@ -20,7 +20,7 @@ def run(*argv):
 
 def test_compress_shards_example():
     out = run("compress_shards", 6, 12, 16)
-    assert re.search(r"6 shards of 2\^12 x 16: shard proofs .* their FRI checks in-circuit .* host verification", out), out
+    assert re.search(r"6 shards of 2\^12 x 16: shard proofs .* ONE proof that verifies them all .* verified on the host .* from \(shape, 6 public values, key\) alone", out), out
 
 
 def test_prove_shard_example():

@@ -524,6 +524,14 @@ hipError_t launch_ntt_pass(const NttPassArgs& a_, bool inverse, hipStream_t s) {
     // with a run-time tile height it spills, so there it stays opt-in (cols_per_thread = 2).
     const bool pair_ok = a.ncols >= 32 && a.ncols % 2 == 0 && a.in_ld % 2 == 0 && a.out_ld % 2 == 0 &&
                          (reinterpret_cast<uintptr_t>(a.in) & 7) == 0 && (reinterpret_cast<uintptr_t>(a.out) & 7) == 0;
+#ifdef ZKHIP_AB_HOOKS
+    {   // A/B (tools/i1_wide_ab.py): the LDE's first pass with 64-column tiles -- 32 lanes x 8 B = 256-byte row chunks, 1024 lanes, one workgroup per CU
+        static const bool wide = getenv("ZKHIP_I1_WIDE") != nullptr;
+        if (wide && pair_ok && a.log_m == 10 && strided_in_block_out && a.ncols % 64 == 0 && inverse) return launch_ntt_k<5, true, 2, 5, 2>(a, s);
+        static const bool wide_f2 = getenv("ZKHIP_F2_WIDE") != nullptr;
+        if (wide_f2 && pair_ok && a.log_m == 10 && a.in_stride == 1 && a.out_stride == 1 && a.ncols % 64 == 0 && !inverse) return launch_ntt_k<5, false, 2, 5, 1>(a, s);
+    }
+#endif
     if (pair_ok && a.log_m == 10 && a.cols_per_thread != 1) {
         // non-temporal loads AND stores: the tile is read once and written once, its lines need not stay in L2 / MALL.
         // Pays on every pass except a strided one run in place (+6 %), which keeps the default policy; tools/ntt_policy_sweep.sh
