@@ -484,3 +484,51 @@ def test_a_consumer_checks_a_chained_commitment_blob_on_the_cpu(lib, oracle):
     assert verify_blob(lib, short, out, None, 6, 4)[0] == -1
     only_chain = struct.pack("<4sIII", b"ZKTB", 2, 2 | 8, 1) + struct.pack("<I", len(chain)) + chain
     assert verify_blob(lib, only_chain, out, None, 6, 4)[0] == -1
+
+
+def _compress_api(L):
+    u8pp, szp = C.POINTER(C.POINTER(C.c_uint8)), C.POINTER(C.c_size_t)
+    L.zktls_guest_prove_compressed.argtypes = [C.c_int, C.c_int, C.POINTER(Plan), C.c_char_p, C.c_size_t, C.c_char_p, C.c_size_t, u8pp, szp, u8pp, szp, C.c_char_p, C.c_size_t]
+    L.zktls_compress_key.argtypes = [C.c_int, C.POINTER(Plan), C.POINTER(C.c_uint32), C.c_char_p, C.c_size_t]
+    L.zktls_verify_compressed_blob.argtypes = [C.c_char_p, C.c_size_t, C.POINTER(Plan), C.c_char_p, C.c_size_t, C.c_char_p, C.c_size_t, C.POINTER(C.c_uint32), C.POINTER(C.c_int)]
+
+
+def test_compress_needs_a_plan_and_a_malformed_blob_is_refused(lib):
+    _compress_api(lib)
+    out, outn, pr, prn = C.POINTER(C.c_uint8)(), C.c_size_t(), C.POINTER(C.c_uint8)(), C.c_size_t()
+    err = C.create_string_buffer(512)
+    assert lib.zktls_guest_prove_compressed(0, 2, None, b"x", 1, b"y", 1, C.byref(out), C.byref(outn), C.byref(pr), C.byref(prn), err, 512) == -1
+    assert b"plan" in err.value
+    key = (C.c_uint32 * 8)()
+    plan = Plan(8, 8, 3, 10, 8)
+    assert lib.zktls_verify_compressed_blob(b"ZKTB" + bytes(40), 44, C.byref(plan), b"x", 1, b"y", 1, key, None) == -1
+
+
+@pytest.mark.gpu
+def test_compress_stage_behind_the_same_call(lib):
+    """core -> compress (sp1.rs:116): the blob carries ONE proof that verifies the shard proofs and the key of the shape; a consumer checks it on the
+    CPU from (plan, input, ELF, key) -- the shard proofs are not in the blob any more"""
+    _compress_api(lib)
+    plan = Plan(8, 8, 3, 10, 8)
+    cbor, elf = b"\xa1transcript", b"\x7fELFprog"
+    out, outn, pr, prn = C.POINTER(C.c_uint8)(), C.c_size_t(), C.POINTER(C.c_uint8)(), C.c_size_t()
+    err = C.create_string_buffer(512)
+    rc = lib.zktls_guest_prove_compressed(0, 2, C.byref(plan), cbor, len(cbor), elf, len(elf), C.byref(out), C.byref(outn), C.byref(pr), C.byref(prn), err, 512)
+    assert rc == 0, err.value
+    blob = C.string_at(pr, prn.value)
+    lib.zktls_free(out)
+    lib.zktls_free(pr)
+    assert lib.zktls_batch_flags(blob, len(blob)) == 1 | 16                  # SYNTHETIC | COMPRESSED
+    offs, lens = (C.c_size_t * 8)(), (C.c_size_t * 8)()
+    assert lib.zktls_unpack_batch(blob, len(blob), offs, lens, 8) == 2 and lens[1] == 36
+    key = (C.c_uint32 * 8)()
+    assert lib.zktls_compress_key(0, C.byref(plan), key, err, 512) == 0, err.value
+    assert bytes(key) == blob[offs[1]:offs[1] + 32]                          # the key of the SHAPE: the same whoever computes it
+    reason = C.c_int(0)
+    assert lib.zktls_verify_compressed_blob(blob, len(blob), C.byref(plan), cbor, len(cbor), elf, len(elf), key, C.byref(reason)) == 0
+    assert lib.zktls_verify_compressed_blob(blob, len(blob), C.byref(plan), cbor + b"!", len(cbor) + 1, elf, len(elf), key, C.byref(reason)) == -2     # another request
+    other = (C.c_uint32 * 8)(*[(v + 1) % 2013265921 for v in key])
+    assert lib.zktls_verify_compressed_blob(blob, len(blob), C.byref(plan), cbor, len(cbor), elf, len(elf), other, C.byref(reason)) == -1               # another key
+    plan4 = Plan(8, 8, 4, 10, 8)
+    assert lib.zktls_verify_compressed_blob(blob, len(blob), C.byref(plan4), cbor, len(cbor), elf, len(elf), key, C.byref(reason)) == -1              # another shard count
+    lib.zktls_release_cached()

@@ -389,9 +389,83 @@ ProveResult HipGuestProver::prove_inner(const GuestInput& input, const std::vect
         for (auto& t : pool) t.join();
     }
     if (failed.load()) throw std::runtime_error(first_error);
+    if (compress_) {
+        // core -> COMPRESS: the shard proofs verified in-circuit by ONE proof (the shard verifier machine, csrc/shard_verifier.inl); the blob then
+        // carries that proof and the key of the shape instead of the shard proofs
+        if (backend_ != Backend::Sp1) throw std::runtime_error("with_compress: the shard verifier takes SP1-shape shard proofs");
+        if (plan_.shards > 64) throw std::runtime_error("with_compress: at most 64 shards per join");
+        const zkhip_params outer{1, plan_.num_queries, plan_.pow_bits, 0, 0, 0, 0, 0};
+        CtxGuard g;
+        if (!g.take(devices_[0], words * 4)) {
+            g.device = devices_[0]; g.trace_bytes = words * 4;
+            if (zkhip_ctx_create(devices_[0], nullptr, &g.ctx) != ZKHIP_OK) fail_zkhip("zkhip_ctx_create");
+            if (zkhip_malloc(g.ctx, words * 4, &g.d_trace) != ZKHIP_OK) fail_zkhip("zkhip_malloc");
+        }
+        zkhip_machine_key* key = nullptr;
+        uint32_t vk[8];
+        if (zkhip_shard_verifier_setup(g.ctx, plan_.log_n, plan_.width, (size_t)plan_.num_queries, plan_.pow_bits, 9, plan_.shards, &outer, &key, vk) != ZKHIP_OK)
+            fail_zkhip("zkhip_shard_verifier_setup");
+        std::vector<const uint8_t*> ptrs(plan_.shards);
+        std::vector<size_t> lens(plan_.shards);
+        std::vector<uint32_t> pvs;
+        for (uint32_t sidx = 0; sidx < plan_.shards; sidx++) {
+            ptrs[sidx] = proofs[sidx].data(); lens[sidx] = proofs[sidx].size();
+            pvs.insert(pvs.end(), digest.begin(), digest.end());
+            pvs.push_back(sidx);
+        }
+        const size_t jcap = zkhip_shard_verifier_proof_size(plan_.log_n, plan_.width, (size_t)plan_.num_queries, plan_.pow_bits, 9, plan_.shards, &outer);
+        std::vector<uint8_t> joined(jcap);
+        size_t jlen = 0;
+        const int rc = zkhip_prove_shard_verifier(g.ctx, key, ptrs.data(), lens.data(), plan_.shards, plan_.log_n, plan_.width, pvs.data(), 9, &prm, &outer, joined.data(), jcap, &jlen);
+        (void)zkhip_ctx_sync(g.ctx);
+        zkhip_machine_key_destroy(key);
+        if (rc != ZKHIP_OK) fail_zkhip("zkhip_prove_shard_verifier");
+        joined.resize(jlen);
+        int reason = 0;
+        if (zkhip_verify_shard_recursive(joined.data(), jlen, plan_.log_n, plan_.width, (size_t)plan_.num_queries, plan_.pow_bits, pvs.data(), 9, plan_.shards, vk, &outer, &reason) != ZKHIP_OK)
+            fail_zkhip("zkhip_verify_shard_recursive");     // sp1.rs:120: the prover checks its own proof
+        g.healthy = true;
+        std::vector<uint8_t> tail(36);
+        std::memcpy(tail.data(), vk, 32);
+        const uint32_t cnt = plan_.shards;
+        std::memcpy(tail.data() + 32, &cnt, 4);
+        r.proof = pack_shard_proofs({joined, tail}, BATCH_FLAG_SYNTHETIC | BATCH_FLAG_COMPRESSED);
+        r.ok = true;
+        return r;
+    }
     r.proof = pack_shard_proofs(proofs, BATCH_FLAG_SYNTHETIC);
     r.ok = true;
     return r;
+}
+
+int verify_compressed_blob(const std::vector<uint8_t>& blob, const ShardPlan& plan, const std::vector<uint8_t>& cbor, const std::vector<uint8_t>& elf,
+                           const uint32_t key[8], int* reason) {
+    std::vector<std::vector<uint8_t>> entries;
+    uint32_t flags = 0;
+    if (!unpack_shard_proofs(blob, &entries, &flags) || entries.size() != 2 || !(flags & BATCH_FLAG_COMPRESSED) || entries[1].size() != 36) return -1;
+    uint32_t cnt = 0;
+    std::memcpy(&cnt, entries[1].data() + 32, 4);
+    if (cnt != plan.shards || cnt == 0 || cnt > 64 || std::memcmp(entries[1].data(), key, 32) != 0) return -1;        // (the key is the CALLER's: the blob's copy is informative)
+    const std::vector<uint32_t> digest = request_digest(cbor, elf);
+    std::vector<uint32_t> pvs;
+    for (uint32_t sidx = 0; sidx < cnt; sidx++) { pvs.insert(pvs.end(), digest.begin(), digest.end()); pvs.push_back(sidx); }
+    const zkhip_params outer{1, plan.num_queries, plan.pow_bits, 0, 0, 0, 0, 0};
+    int why = 0;
+    const int rc = zkhip_verify_shard_recursive(entries[0].data(), entries[0].size(), plan.log_n, plan.width, (size_t)plan.num_queries, plan.pow_bits, pvs.data(), 9, cnt, key, &outer, &why);
+    if (reason) *reason = why;
+    return rc == ZKHIP_OK ? 0 : -2;
+}
+
+bool compress_key(int device, const ShardPlan& plan, uint32_t key_out[8], std::string* error) {
+    zkhip_ctx* ctx = nullptr;
+    zkhip_machine_key* key = nullptr;
+    const zkhip_params outer{1, plan.num_queries, plan.pow_bits, 0, 0, 0, 0, 0};
+    bool ok = zkhip_ctx_create(device, nullptr, &ctx) == ZKHIP_OK &&
+              zkhip_shard_verifier_setup(ctx, plan.log_n, plan.width, (size_t)plan.num_queries, plan.pow_bits, 9, plan.shards, &outer, &key, key_out) == ZKHIP_OK;
+    if (!ok && error) *error = zkhip_last_error();
+    if (key) { (void)zkhip_ctx_sync(ctx); zkhip_machine_key_destroy(key); }
+    if (ctx) zkhip_ctx_destroy(ctx);
+    return ok;
 }
 
 void release_cached() {
@@ -416,8 +490,9 @@ struct zktls_shard_plan { int32_t log_n; uint32_t width; uint32_t shards; int32_
 // device; device < 0: every visible device, shards dealt round-robin.
 static int guest_prove(zktls::Backend backend, int device, int mode, const zktls_shard_plan* plan, const uint8_t* cbor, size_t cbor_len,
                        const uint8_t* elf, size_t elf_len, uint8_t** output, size_t* output_len, uint8_t** proof,
-                       size_t* proof_len, char* err, size_t err_cap) {
+                       size_t* proof_len, char* err, size_t err_cap, bool compress = false) {
     zktls::HipGuestProver p(device < 0 ? 0 : device, backend);
+    if (compress) p.with_compress();
     if (device < 0) {
         std::vector<int> all;
         for (int d = 0; d < zkhip_device_count(); d++) all.push_back(d);
@@ -450,6 +525,27 @@ static int guest_prove(zktls::Backend backend, int device, int mode, const zktls
     *proof = (uint8_t*)std::malloc(r.proof.size() ? r.proof.size() : 1);
     std::memcpy(*proof, r.proof.data(), r.proof.size());
     return 0;
+}
+// the same with the compress stage behind it (HipGuestProver::with_compress): the blob carries ONE proof that verifies the shards
+int zktls_guest_prove_compressed(int device, int mode, const zktls_shard_plan* plan, const uint8_t* cbor, size_t cbor_len, const uint8_t* elf, size_t elf_len,
+                                 uint8_t** output, size_t* output_len, uint8_t** proof, size_t* proof_len, char* err, size_t err_cap) {
+    if (!plan) { if (err && err_cap) { std::strncpy(err, "compress needs a shard plan", err_cap - 1); err[err_cap - 1] = 0; } return -1; }
+    return guest_prove(zktls::Backend::Sp1, device, mode, plan, cbor, cbor_len, elf, elf_len, output, output_len, proof, proof_len, err, err_cap, true);
+}
+// the key of the plan's shape (device work, once per shape), and the host-only check of a COMPRESSED blob against it: 0 / -1 / -2 (verify_compressed_blob)
+int zktls_compress_key(int device, const zktls_shard_plan* plan, uint32_t key[8], char* err, size_t err_cap) {
+    zktls::ShardPlan sp;
+    sp.log_n = plan->log_n; sp.width = plan->width; sp.shards = plan->shards; sp.num_queries = plan->num_queries; sp.pow_bits = plan->pow_bits;
+    std::string e;
+    if (zktls::compress_key(device, sp, key, &e)) return 0;
+    if (err && err_cap) { std::strncpy(err, e.c_str(), err_cap - 1); err[err_cap - 1] = 0; }
+    return -1;
+}
+int zktls_verify_compressed_blob(const uint8_t* blob, size_t len, const zktls_shard_plan* plan, const uint8_t* cbor, size_t cbor_len, const uint8_t* elf, size_t elf_len,
+                                 const uint32_t key[8], int* reason) {
+    zktls::ShardPlan sp;
+    sp.log_n = plan->log_n; sp.width = plan->width; sp.shards = plan->shards; sp.num_queries = plan->num_queries; sp.pow_bits = plan->pow_bits;
+    return zktls::verify_compressed_blob(std::vector<uint8_t>(blob, blob + len), sp, std::vector<uint8_t>(cbor, cbor + cbor_len), std::vector<uint8_t>(elf, elf + elf_len), key, reason);
 }
 int zktls_guest_prove(int device, int mode, const zktls_shard_plan* plan, const uint8_t* cbor, size_t cbor_len,
                       const uint8_t* elf, size_t elf_len, uint8_t** output, size_t* output_len, uint8_t** proof,

@@ -94,6 +94,11 @@ public:
     HipGuestProver& with_synthetic(const ShardPlan& p) { plan_ = p; synthetic_ = true; return *this; }
     // the input-commitment guest (see the header comment); num_queries / pow_bits of the proof come from `p`
     HipGuestProver& with_input_commitment(const ShardPlan& p = ShardPlan{}) { plan_ = p; commitment_ = true; return *this; }
+    // the COMPRESS stage behind the same call (sp1.rs:116: core -> compress; prover.rs:90: lift -> join): after the shards are proven, ONE
+    // proof verifies them all in-circuit (zkhip_prove_shard_verifier) and replaces them in the blob (flag COMPRESSED: entry 0 = the joined
+    // proof, entry 1 = 8 LE words of the shape's key + the shard count).  SP1 backend, synthetic shards, at most 64 of them, width a
+    // multiple of 8.  verify_compressed_blob checks such a blob on the host from (plan, input, ELF, key): the shard proofs are gone.
+    HipGuestProver& with_compress() { compress_ = true; return *this; }
     bool synthetic() const { return synthetic_; }
     ProverType mode() const { return mode_; }
     Backend backend() const { return backend_; }
@@ -111,6 +116,7 @@ private:
     ShardPlan plan_;
     bool synthetic_ = false;
     bool commitment_ = false;
+    bool compress_ = false;
     std::vector<uint8_t> vk_;              // non-empty after setup()
 };
 
@@ -132,6 +138,7 @@ std::vector<uint32_t> request_digest(const std::vector<uint8_t>& cbor, const std
 constexpr uint32_t BATCH_FLAG_SYNTHETIC = 1u;
 constexpr uint32_t BATCH_FLAG_INPUT_SHA256 = 2u;     // one proof of the SHA-256 chip over the request's input bytes
 constexpr uint32_t BATCH_FLAG_CHAINED = 8u;          // with INPUT_SHA256: an input beyond one chip proof (1 MiB): entry 0 = the chaining values ((n + 1) x 8 LE words), entries 1..n = the shard proofs of zkhip_prove_sha256_sharded (2^14 blocks per shard)
+constexpr uint32_t BATCH_FLAG_COMPRESSED = 16u;      // with SYNTHETIC: the shard proofs were joined into ONE proof (entry 0); entry 1 = the shape's key (8 LE words) + the shard count
 constexpr uint32_t BATCH_FLAG_KEYED = 4u;            // with INPUT_SHA256: the proof is the keyed SHA-256 MACHINE's (chip + range table), checked against a vk
 // a consumer's check of an input-commitment blob on the CPU: the blob's proof(s) against the claimed output (SHA-256 of the input).
 // The caller says what it EXPECTS, the blob's own flags only have to agree: a 64-byte `vk` (from setup) means "a KEYED proof under this
@@ -141,6 +148,13 @@ constexpr uint32_t BATCH_FLAG_KEYED = 4u;            // with INPUT_SHA256: the p
 // setup() saw, the proof itself does not bind it.  -> 0 or a negative value; *reason as the zkhip verifiers
 int verify_commitment_blob(const std::vector<uint8_t>& blob, const std::vector<uint8_t>& output, const std::vector<uint8_t>& vk,
                            int num_queries, int pow_bits, int* reason = nullptr, Backend backend = Backend::Sp1);
+// a COMPRESSED blob against the request it was made for: the public values of shard s are request_digest(cbor, elf) | s, the key must be the
+// caller's (compress_key: the key of the plan's shape, computed on the device once -- it depends on no proof).  0, or -1 (malformed / another
+// key) / -2 (the joined proof is rejected; *reason = the failing check)
+int verify_compressed_blob(const std::vector<uint8_t>& blob, const ShardPlan& plan, const std::vector<uint8_t>& cbor, const std::vector<uint8_t>& elf,
+                           const uint32_t key[8], int* reason = nullptr);
+// the key of the shard-verifier machine for `plan` (zkhip_shard_verifier_setup on `device`)
+bool compress_key(int device, const ShardPlan& plan, uint32_t key[8], std::string* error = nullptr);
 std::vector<uint8_t> pack_shard_proofs(const std::vector<std::vector<uint8_t>>& proofs, uint32_t flags);
 bool unpack_shard_proofs(const std::vector<uint8_t>& blob, std::vector<std::vector<uint8_t>>* proofs, uint32_t* flags = nullptr);
 
