@@ -4,6 +4,7 @@ import os
 import sys
 import time
 os.environ["ZKHIP_REC_TIMING"] = "1"
+os.environ["ZKHIP_CHIPS_TIMING"] = "1"          # the phases of the machine proof inside it
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tools"))

@@ -124,11 +124,21 @@ struct zkhip_ctx {
     zkhip_machine_key* sha_key = nullptr;
     int sha_key_blowup = 0;
     uint32_t sha_vk[8] = {0};
+    // grow-only PINNED host block (ctx_host_pinned): work lists that a prover fills on host threads and uploads in one DMA
+    void* host_pinned = nullptr;
+    size_t host_pinned_bytes = 0;
 };
 
 namespace zk {
 constexpr int MAX_LOG_ROWS = 22;     // tallest matrix the transforms / the shard prover take (2^20 in two passes; 2^21, 2^22 with a radix-2 / 4 combine pass)
 int ctx_reserve(zkhip_ctx* ctx, int slot, size_t bytes, void** out);
+int ctx_host_pinned(zkhip_ctx* ctx, size_t bytes, void** out);
+// verifier.cpp: a cap on the host threads one verifier call may start (0: none) for callers that are themselves one of many workers,
+// and the FRI view of a shard proof WITHOUT hashing its Merkle paths (the caller recomputes every opening and compares the roots)
+extern thread_local int t_query_threads_cap;
+int fri_view_all_unhashed(const uint8_t* proof, size_t len, int log_n, uint32_t width, const uint32_t* public_values, size_t n_public, const zkhip_params* prm,
+                          uint32_t* betas, uint32_t final_value[4], uint32_t* indices, uint32_t* values, uint32_t* siblings, uint32_t* roots, uint32_t* paths,
+                          uint32_t transcript[10]);      // the context's pinned host block, grown to `bytes`; contents undefined
 int get_plan(zkhip_ctx* ctx, int log_n, int kind, uint32_t shift_monty, const NttPlan** out);
 // internal op entry points shared by capi.cpp and prover.cpp (device pointers, ctx stream)
 int op_coset_lde(zkhip_ctx* ctx, const uint32_t* d_in, size_t in_ld, uint32_t* d_out, size_t out_ld,

@@ -746,16 +746,20 @@ hipError_t launch_post2d_table(uint32_t* out, uint32_t w, uint32_t shift, uint32
 template <int LOG_R, int VEC>
 __device__ __forceinline__ void ntt_combine_kernel_body(const CombineArgs& a) {
     constexpr int R = 1 << LOG_R;
+    typedef uint32_t u32x4_nt __attribute__((ext_vector_type(4)));
     const uint32_t cv = (a.ncols + VEC - 1) / VEC;                    // column vectors per row
-    const uint64_t idx = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    const uint64_t g = idx / cv;
-    const uint32_t c = (uint32_t)(idx % cv) * VEC;
-    if (g >= a.groups) return;
+    // blockIdx.x walks the groups in runs of blockDim.y rows, blockIdx.y / threadIdx.x the column vectors: no division per thread,
+    // and a wavefront stays inside one row whenever a row has 64 vectors or more
+    const uint32_t cx = blockIdx.y * blockDim.x + threadIdx.x;
+    const uint64_t g = (uint64_t)blockIdx.x * blockDim.y + threadIdx.y;
+    const uint32_t c = cx * VEC;
+    if (g >= a.groups || cx >= cv) return;
     uint32_t x[R][VEC];
 #pragma unroll
     for (int e = 0; e < R; e++) {
         const uint32_t* row = a.in + (g * a.in_group_mul + (uint64_t)e * a.in_elem_mul) * a.in_ld + c;
-        if (VEC == 4) { const uint4 v = *reinterpret_cast<const uint4*>(row); x[e][0] = v.x; x[e][1] = v.y; x[e][2] = v.z; x[e][VEC - 1] = v.w; }
+        // streamed once (a 2^21 x 256 matrix is 2 GiB): non-temporal both ways
+        if (VEC == 4) { const u32x4_nt v = __builtin_nontemporal_load(reinterpret_cast<const u32x4_nt*>(row)); x[e][0] = v.x; x[e][1] = v.y; x[e][2] = v.z; x[e][VEC - 1] = v.w; }
         else x[e][0] = row[0];
     }
     uint32_t tw[R];
@@ -789,7 +793,7 @@ __device__ __forceinline__ void ntt_combine_kernel_body(const CombineArgs& a) {
     for (int e = 0; e < R; e++) {
         const uint32_t slot = a.bitrev_out ? (LOG_R == 2 ? (uint32_t)(((e & 1) << 1) | (e >> 1)) : (uint32_t)e) : (uint32_t)e;
         uint32_t* row = a.out + (g * a.out_group_mul + (uint64_t)slot * a.out_elem_mul) * a.out_ld + c;
-        if (VEC == 4) *reinterpret_cast<uint4*>(row) = make_uint4(y[e][0], y[e][1], y[e][2], y[e][VEC - 1]);
+        if (VEC == 4) { const u32x4_nt v = {y[e][0], y[e][1], y[e][2], y[e][VEC - 1]}; __builtin_nontemporal_store(v, reinterpret_cast<u32x4_nt*>(row)); }
         else row[0] = y[e][0];
     }
 }
@@ -804,8 +808,13 @@ hipError_t launch_ntt_combine(const CombineArgs& a, hipStream_t s) {
     if (a.groups == 0 || a.ncols == 0) return hipSuccess;
     const bool vec = a.ncols % 4 == 0 && a.in_ld % 4 == 0 && a.out_ld % 4 == 0 && (reinterpret_cast<uintptr_t>(a.in) & 15) == 0 &&
                      (reinterpret_cast<uintptr_t>(a.out) & 15) == 0;
-    const uint64_t threads = a.groups * (vec ? a.ncols / 4 : a.ncols);
-    const dim3 grid((unsigned)((threads + 255) / 256)), block(256);
+    const uint32_t cv = vec ? a.ncols / 4 : a.ncols;
+    uint32_t bx = 1;
+    while (bx < 256u && bx < cv) bx <<= 1;                            // 256 threads = bx column vectors x (256 / bx) groups
+    const uint32_t by = 256u / bx;
+    const uint64_t gy = (a.groups + by - 1) / by;
+    if (gy > 0x7FFFFFFFull || (cv + bx - 1) / bx > 65535u) return hipErrorInvalidValue;
+    const dim3 grid((unsigned)gy, (cv + bx - 1) / bx), block(bx, by);
     if (a.log_r == 1) {
         if (vec) ZK_LAUNCH((ntt_combine_kernel<1, 4>), (ntt_combine_kernel_batch<1, 4>), ntt_combine_kernel_bargs, grid, block, 0, s, a);
         else ZK_LAUNCH((ntt_combine_kernel<1, 1>), (ntt_combine_kernel_batch<1, 1>), ntt_combine_kernel_bargs, grid, block, 0, s, a);

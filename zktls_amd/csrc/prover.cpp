@@ -985,6 +985,20 @@ static int prove_chips_impl(const ChipSet& cs, zkhip_ctx* ctx, const zkhip_chip*
     Challenger ch;
     chips_transcript_init(cs, ch, log_ns, widths, pairs, partners, n, prm, n_public);
     uint32_t root[8];
+#ifdef ZKHIP_AB_HOOKS
+    // A/B build only: ZKHIP_CHIPS_TIMING=1 prints the wall time of every phase (the stream is drained at each lap)
+    static const bool timing = getenv("ZKHIP_CHIPS_TIMING") != nullptr;
+    auto t_last = std::chrono::steady_clock::now();
+    auto lap = [&](const char* what) {
+        if (!timing) return;
+        (void)hipStreamSynchronize(ctx->stream);
+        const auto now = std::chrono::steady_clock::now();
+        std::fprintf(stderr, "    [chips prover] %-36s %8.2f ms\n", what, std::chrono::duration<double, std::milli>(now - t_last).count());
+        t_last = now;
+    };
+#else
+    auto lap = [](const char*) {};
+#endif
 
     // ---- 1. every chip's LDE, one mixed-height tree
     void *v_tlde, *v_ttree, *v_qlde, *v_qtree, *v_qchunk;
@@ -1005,7 +1019,9 @@ static int prove_chips_impl(const ChipSet& cs, zkhip_ctx* ctx, const zkhip_chip*
         tm[c] = MatDesc{tlde + tl_off[c] + pw, cw[c], widths[c]};
         qm[c] = MatDesc{qlde + ql_off[c], qw_of(cs, c), (uint32_t)qw_of(cs, c)};
     }
+    lap("1. trace LDEs");
     ZK_TRY(op_merkle_commit_mixed(ctx, tm, lh, n, ttree));
+    lap("1. trace tree");
     ZK_TRY(d2h(ctx, root, ttree + (2 * mmax - 2) * 8, 32));
     for (int i = 0; i < 8; i++) { ch.observe(root[i]); pf[pos++] = from_monty(root[i]); }
     for (size_t i = 0; i < n_public; i++) ch.observe_canonical(public_values[i]);
@@ -1039,7 +1055,9 @@ static int prove_chips_impl(const ChipSet& cs, zkhip_ctx* ctx, const zkhip_chip*
             ZK_TRY(op_coset_lde(ctx, (const uint32_t*)v_perm, wp[c], plde + pl_off[c], wp[c], log_ns[c], (uint32_t)wp[c], b, MONTY_GEN));
             pmats[np] = MatDesc{plde + pl_off[c], wp[c], (uint32_t)wp[c]}; plh[np] = lh[c]; np++;
         }
+        lap("1b. permutation traces + LDEs");
         ZK_TRY(op_merkle_commit_mixed(ctx, pmats, plh, np, ptree));
+        lap("1b. permutation tree");
         ZK_TRY(d2h(ctx, root, ptree + (2 * ((size_t)1 << Hp) - 2) * 8, 32));
         for (int i = 0; i < 8; i++) { ch.observe(root[i]); pf[pos++] = from_monty(root[i]); }
         if (cross)
@@ -1078,9 +1096,11 @@ static int prove_chips_impl(const ChipSet& cs, zkhip_ctx* ctx, const zkhip_chip*
                 ZK_TRY(op_coset_lde(ctx, qchunk + (size_t)k * nc * 4, 4, qlde + ql_off[c] + 4 * k, qw_of(cs, c), log_ns[c], 4, b, finv(fpow(w2n, (uint64_t)k))));
         }
     }
+    lap("2. quotients + chunk LDEs");
     ZK_TRY(op_merkle_commit_mixed(ctx, qm, lh, n, qtree));
     ZK_TRY(d2h(ctx, root, qtree + (2 * mmax - 2) * 8, 32));
     for (int i = 0; i < 8; i++) { ch.observe(root[i]); pf[pos++] = from_monty(root[i]); }
+    lap("2. quotient tree");
 
     // ---- 3. openings: one zeta, per-chip "next" point zeta * g_c
     const Ext zeta = ch.sample_ext();
@@ -1107,6 +1127,7 @@ static int prove_chips_impl(const ChipSet& cs, zkhip_ctx* ctx, const zkhip_chip*
     std::vector<uint32_t> opened(op_off[n]);
     ZK_TRY(d2h(ctx, opened.data(), d_open, opened.size() * 4));
     for (size_t i = 0; i < opened.size(); i++) { ch.observe(opened[i]); pf[pos++] = from_monty(opened[i]); }
+    lap("3. openings");
 
     // ---- 4. one reduced-opening vector per height (alpha powers run on across the chips of a height)
     const Ext fa = ch.sample_ext();
@@ -1189,6 +1210,7 @@ static int prove_chips_impl(const ChipSet& cs, zkhip_ctx* ctx, const zkhip_chip*
         }
     }
 
+    lap("4. reduced openings");
     // ---- 5. FRI commit phase; shorter vectors join at their height
     ZK_TRY(ensure_domain(ctx, log_ns[0], b));                   // fold twiddles of the largest domain
     ZK_TRY(fri_commit_phase(ctx, ch, sh, Hmax, L, layers, ltrees, layer_off, tree_off, (uint32_t*)v_at, mmax, inject, pf, pos));
@@ -1201,10 +1223,12 @@ static int prove_chips_impl(const ChipSet& cs, zkhip_ctx* ctx, const zkhip_chip*
         ch.observe_ext(last[0]);
     }
 
+    lap("5. FRI commit phase");
     // ---- 6. proof of work, 7. queries
     uint32_t witness = 0;
     ZK_TRY(grind_witness(ctx, ch, prm->pow_bits, &witness));
     pf[pos++] = witness;
+    lap("6. proof of work");
     {
         std::vector<GatherDesc> descs;
         size_t qpos = 0;
@@ -1244,6 +1268,7 @@ static int prove_chips_impl(const ChipSet& cs, zkhip_ctx* ctx, const zkhip_chip*
         ZK_TRY(d2h(ctx, pf + pos, v_out, qpos * 4));
         pos += qpos;
     }
+    lap("7. queries");
     *len = pos * 4;
     return ZKHIP_OK;
 }

@@ -656,9 +656,16 @@ namespace zk {
 namespace rec {
 namespace {
 // what ONE inner proof contributes: the host tables' rows of its segment, and its entries of the device work lists
+struct HostSpan {                                           // a slice of the context's pinned upload block
+    uint32_t* p = nullptr; size_t n = 0;
+    uint32_t* data() const { return p; }
+    size_t size() const { return n; }
+    uint32_t& operator[](size_t i) const { return p[i]; }
+};
 struct HostTables {
     std::vector<uint32_t> sc, op, rs, q, ts, sm;            // SCALARS, OPENED, ROWSUM, QUERY, TS, SAMPLES main traces (all proofs)
-    std::vector<uint32_t> desc, data, chain_in, trows;      // P2R: chains, their data, the transcript rows' input states and row numbers
+    HostSpan desc, data, chain_in, trows;                   // P2R: chains, their data, the transcript rows' input states and row numbers -- consecutive slices of ONE pinned block
+                                                            // (every word is written by fill_one: nothing is cleared)
     std::vector<const uint32_t*> want_roots;                // per chain: where it must end (canonical words; owned by the witnesses)
     // (desc / data / chain_in / trows / want_roots hold a fixed slice per proof)
 };
@@ -671,8 +678,9 @@ int fill_one(const Shape& sh, const Machine& m, int p, const uint8_t* inner, siz
     // (a) one host pass: the verifier accepts the proof and hands out the FRI side; the rest is read off the words (docs/PROTOCOL.md section 6)
     wt.betas.resize(4 * (size_t)R); wt.indices.resize((size_t)Q); wt.values.resize(4 * (size_t)Q); wt.siblings.resize(4 * (size_t)Q * (size_t)R); wt.lroots.resize(8 * (size_t)R);
     wt.paths.resize(zkhip_fri_view_path_words(R) * (size_t)Q);
-    ZK_TRY(zkhip_fri_view_all(inner, inner_len, log_n, width, public_values, n_public, inner_prm, wt.betas.data(), wt.fin, wt.indices.data(), wt.values.data(),
-                              wt.siblings.data(), wt.lroots.data(), wt.paths.data(), wt.tr));
+    // (the Merkle paths are not hashed here: the P2R rows kernel hashes every one of them for the trace, and the roots it arrives at are compared below)
+    ZK_TRY(fri_view_all_unhashed(inner, inner_len, log_n, width, public_values, n_public, inner_prm, wt.betas.data(), wt.fin, wt.indices.data(), wt.values.data(),
+                                 wt.siblings.data(), wt.lroots.data(), wt.paths.data(), wt.tr));
     words.resize(inner_len / 4);
     std::memcpy(words.data(), inner, words.size() * 4);
     wt.w = words.data();
@@ -947,17 +955,25 @@ static int shard_verifier_prove_impl(zkhip_ctx* ctx, const zkhip_machine_key* ke
             if (inner_len[p] != inner_len[0] || inner_len[p] % 4) return fail(ZKHIP_ERR_INVALID, "prove_shard_verifier: the proofs of one call have one shape, hence one length");
         }
         if ((size_t)NP * seg >= ((size_t)1 << 32)) return fail(ZKHIP_ERR_INVALID, "prove_shard_verifier: too much witness data for one call");
-        ht.desc.assign(6 * (size_t)NP * chains_per, 0u); ht.want_roots.assign((size_t)NP * chains_per, nullptr); ht.data.assign((size_t)NP * seg, 0u);
-        ht.chain_in.assign(16 * (size_t)NP * (size_t)sh.NT, 0u); ht.trows.assign((size_t)NP * (size_t)sh.NT, 0u);
+        ht.want_roots.assign((size_t)NP * chains_per, nullptr);
+        {   // the four P2R work lists are filled IN PLACE in the context's pinned block and go up as one DMA
+            const size_t n_desc = 6 * (size_t)NP * chains_per, n_data = (size_t)NP * seg, n_cin = 16 * (size_t)NP * (size_t)sh.NT, n_trows = (size_t)NP * (size_t)sh.NT;
+            void* up;
+            ZK_TRY(ctx_host_pinned(ctx, (n_desc + n_data + n_cin + n_trows) * 4, &up));
+            ht.desc = HostSpan{(uint32_t*)up, n_desc}; ht.data = HostSpan{ht.desc.p + n_desc, n_data};
+            ht.chain_in = HostSpan{ht.data.p + n_data, n_cin}; ht.trows = HostSpan{ht.chain_in.p + n_cin, n_trows};
+        }
         std::vector<int> rcs((size_t)NP, ZKHIP_OK);
         std::vector<std::string> msgs((size_t)NP);
         auto one = [&](int p) {
+            t_query_threads_cap = NP >= 16 ? 1 : 16 / NP;      // the proofs are filled side by side: a proof's host pass starts few threads of its own
             rcs[(size_t)p] = fill_one(sh, m, p, inner[p], inner_len[p], public_values + (size_t)p * n_public, inner_prm, wts[(size_t)p], words[(size_t)p], ht, &fas[(size_t)p]);
             if (rcs[(size_t)p] != ZKHIP_OK) msgs[(size_t)p] = zkhip_last_error();
+            t_query_threads_cap = 0;
         };
         if (NP == 1 || t_batcher) for (int p = 0; p < NP; p++) one(p);
         else {
-            HostPool pool(NP < 8 ? NP : 8);
+            HostPool pool(NP < 16 ? NP : 16);          // (a proof's pass is ~6 ms of hashing on one core; the boxes give a container 16)
             for (int p = 0; p < NP; p++) pool.submit([&one, p] { one(p); });
             pool.wait();
         }
@@ -991,13 +1007,7 @@ static int shard_verifier_prove_impl(zkhip_ctx* ctx, const zkhip_machine_key* ke
         void* stage;
         ZK_TRY(ctx_reserve(ctx, S_STAGE, (up_words + down_words) * 4, &stage));
         uint32_t* d = (uint32_t*)stage;
-        {
-            std::vector<uint32_t> up;
-            up.reserve(up_words);
-            up.insert(up.end(), ht.desc.begin(), ht.desc.end()); up.insert(up.end(), ht.data.begin(), ht.data.end()); up.insert(up.end(), ht.chain_in.begin(), ht.chain_in.end());
-            up.insert(up.end(), ht.trows.begin(), ht.trows.end());
-            ZK_TRY(dev_h2d(ctx, d, up.data(), up_words * 4));
-        }
+        ZK_TRY(dev_h2d(ctx, d, ht.desc.data(), up_words * 4));       // desc | data | chain_in | trows: one pinned block
         lap("upload: P2R work lists");
         p2chip::P2RArgs a{};
         a.desc = d; a.data = d + ht.desc.size(); a.chain_inputs = a.data + ht.data.size(); a.trows = a.chain_inputs + ht.chain_in.size();
@@ -1007,7 +1017,8 @@ static int shard_verifier_prove_impl(zkhip_ctx* ctx, const zkhip_machine_key* ke
         std::vector<uint32_t> down(down_words);
         ZK_TRY(dev_d2h(ctx, down.data(), a.roots, down_words * 4));
         for (size_t c = 0; c < n_chains; c++)
-            if (std::memcmp(down.data() + 8 * c, ht.want_roots[c], 32) != 0) return fail(ZKHIP_ERR_INTERNAL, "prove_shard_verifier: an opening does not end in its root");
+            if (std::memcmp(down.data() + 8 * c, ht.want_roots[c], 32) != 0)      // the Merkle check of the inner proofs (the host pass left it to this kernel)
+                return fail(ZKHIP_ERR_VERIFY, "prove_shard_verifier: proof " + std::to_string(c / (n_chains / (size_t)NP)) + " rejected: an opening does not end in its root");
     }
     lap("device: P2R rows + roots back");
     // the host tables up, then the machine's proof

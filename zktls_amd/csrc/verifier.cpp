@@ -145,6 +145,7 @@ static int run_queries(int n, const std::function<int(int)>& check, int min_per_
     unsigned hw = std::thread::hardware_concurrency();
     int threads = (int)(hw ? (hw < 8 ? hw : 8) : 1);
     if (threads > n / min_per_thread) threads = n / min_per_thread;
+    if (zk::t_query_threads_cap > 0 && threads > zk::t_query_threads_cap) threads = zk::t_query_threads_cap;      // a caller that is itself one of many workers
     if (threads <= 1) {
         for (int q = 0; q < n; q++) { const int r = check(q); if (r) return r; }
         return 0;
@@ -164,7 +165,12 @@ static int run_queries(int n, const std::function<int(int)>& check, int min_per_
 // challenges, the final value, and per query the index, the reduced opening it starts from and the sibling of every layer.
 // zkhip_fri_view_shard points this at its caller's buffers and runs the verifier; the FRI-fold chip (fri_chip.hip) proves
 // statements about exactly these values.  Canonical words.
-struct FriViewSink { uint32_t *betas, *final_value, *indices, *values, *siblings; int layers; uint32_t *roots, *paths; uint32_t* transcript; };      // roots / paths / transcript optional
+struct FriViewSink {
+    uint32_t *betas, *final_value, *indices, *values, *siblings; int layers; uint32_t *roots, *paths; uint32_t* transcript;      // roots / paths / transcript optional
+    // skip_paths: the Merkle paths are NOT hashed (every other check runs).  For a caller that recomputes every opening itself and
+    // compares the roots -- the shard verifier machine, whose device kernel hashes exactly these paths for its trace (shard_verifier.inl)
+    bool skip_paths = false;
+};
 
 static int verify_shard_impl(const uint8_t* proof, size_t len, int log_n, uint32_t width, const uint32_t* public_values,
                              size_t n_public, const zkhip_params* prm, int* reason, const AirView* air, FriViewSink* sink = nullptr) {
@@ -380,10 +386,13 @@ static int verify_shard_impl(const uint8_t* proof, size_t len, int log_n, uint32
             for (int j = 0; j < cnt; j++) { b.index[j] = idx[j]; b.row[j] = rows[j] + row_off; b.path[j] = paths[j]; }
             return b;
         };
-        if (CW) mark(verify_paths_x16(croot, H, batch(trow, 0, cpath, index), CW, sh.hw), 33);
-        mark(verify_paths_x16(troot, H, batch(trow, CW, tpath, index), width - CW, sh.hw), 30);
-        if (LQ) mark(verify_paths_x16(proot, H, batch(prow, 0, ppath, index), wp, sh.hw), 32);
-        mark(verify_paths_x16(qroot, H, batch(qrow, 0, qpath, index), QW, sh.hw), 31);
+        const bool hash_paths = !(sink && sink->skip_paths);
+        if (hash_paths) {
+            if (CW) mark(verify_paths_x16(croot, H, batch(trow, 0, cpath, index), CW, sh.hw), 33);
+            mark(verify_paths_x16(troot, H, batch(trow, CW, tpath, index), width - CW, sh.hw), 30);
+            if (LQ) mark(verify_paths_x16(proot, H, batch(prow, 0, ppath, index), wp, sh.hw), 32);
+            mark(verify_paths_x16(qroot, H, batch(qrow, 0, qpath, index), QW, sh.hw), 31);
+        }
         Ext folded[16];
         size_t idx[16];
         for (int j = 0; j < cnt; j++) {
@@ -430,7 +439,7 @@ static int verify_shard_impl(const uint8_t* proof, size_t len, int log_n, uint32
                 }
                 qpos[j] += 8 * (size_t)lh;
             }
-            mark(verify_paths_x16(&commits[8 * l], lh, batch(rows, 0, paths, rowidx), 4 * arity, sh.hw), 40 + (l < 50 ? l : 50));
+            if (hash_paths) mark(verify_paths_x16(&commits[8 * l], lh, batch(rows, 0, paths, rowidx), 4 * arity, sh.hw), 40 + (l < 50 ? l : 50));
             for (int j = 0; j < cnt; j++) { folded[j] = fold_row_k(rowidx[j], lh, K, betas[l], ev.data() + (size_t)j * arity); idx[j] = rowidx[j]; }
         }
         // the final polynomial at every query's point of the last domain <w_{2^(F+b)}> (Horner)
@@ -508,6 +517,25 @@ int zkhip_fri_view_transcript(const uint8_t* proof, size_t len, int log_n, uint3
     int why = 0;
     return verify_shard_impl(proof, len, log_n, width, public_values, n_public, prm, &why, nullptr, &sink);
 }
+
+// the same view WITHOUT hashing the Merkle paths (library-internal: the caller recomputes every opening and compares the roots)
+extern "C++" {
+namespace zk {
+thread_local int t_query_threads_cap = 0;
+int fri_view_all_unhashed(const uint8_t* proof, size_t len, int log_n, uint32_t width, const uint32_t* public_values, size_t n_public,
+                          const zkhip_params* prm, uint32_t* betas, uint32_t final_value[4], uint32_t* indices, uint32_t* values, uint32_t* siblings,
+                          uint32_t* roots, uint32_t* paths, uint32_t transcript[10]) {
+    Shape sh;
+    if (!prm || check_shape(log_n, width, prm) != ZKHIP_OK) return ZKHIP_ERR_INVALID;
+    shape_of(log_n, prm, sh);
+    if (sh.K != 1 || sh.F != 0 || sh.b != 1) return fail(ZKHIP_ERR_INVALID, "fri_view_all: fold-by-2, blowup-2 proofs with a constant final value only");
+    FriViewSink sink{betas, final_value, indices, values, siblings, sh.R, roots, paths, transcript};
+    sink.skip_paths = true;
+    int why = 0;
+    return verify_shard_impl(proof, len, log_n, width, public_values, n_public, prm, &why, nullptr, &sink);
+}
+}  // namespace zk
+}  // extern "C++"
 
 // everything the recursion machines read, from ONE pass over the proof: the view with roots and paths, and the challenger's side
 int zkhip_fri_view_all(const uint8_t* proof, size_t len, int log_n, uint32_t width, const uint32_t* public_values, size_t n_public,
