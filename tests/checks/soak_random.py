@@ -7,9 +7,10 @@ sys.path.insert(0, _ROOT); sys.path.insert(0, os.path.join(_ROOT, "tests"))
 import numpy as np
 import oracle_lib as O
 import airs
-from zktls_amd.device import Context, verify_shard, verify_chips, verify_shard_air, verify_chips_air, verify_machine, verify_machine_keyed
+from zktls_amd.device import Context, verify_shard, verify_chips, verify_shard_air, verify_chips_air, verify_machine, verify_machine_keyed, verify_shard_recursive
 import machines
 import poseidon2_air
+import recursion_air
 from zktls_amd._lib import Params
 O.set_threads(8)
 P = O.P
@@ -26,11 +27,32 @@ def with_quintic_identity(prog, col):
 budget = float(sys.argv[1]) if len(sys.argv) > 1 else 60.0
 rng = np.random.default_rng(int(time.time()))
 ctx = Context(0)
-t0 = time.time(); n_single = n_chips = n_air = n_machine = n_lookup = n_keyed = n_p2 = 0
+t0 = time.time(); n_single = n_chips = n_air = n_machine = n_lookup = n_keyed = n_p2 = n_rec = 0
 SEED = int(rng.integers(1, 2**40))
 while time.time() - t0 < budget:
     r_kind = rng.random()
-    if r_kind < 0.01:
+    if r_kind < 0.004:
+        # the shard verifier machine / the join: 1..3 shard proofs of a random small shape verified inside ONE outer proof; key and bytes against
+        # the oracle's keyed-machine prover on the Python restatement's arrays (tests/recursion_air.py); the verifier takes no inner proof
+        log_n, width, q, pb = int(rng.integers(5, 9)), 8 * int(rng.integers(1, 5)), int(rng.integers(1, 9)), int(rng.integers(0, 5))      # (the machine takes widths in multiples of 8)
+        npub, nproofs = int(rng.integers(0, 4)), int(rng.integers(1, 4))
+        pubs = [[int(x) for x in rng.integers(0, 2013265921, npub)] for _ in range(nproofs)]
+        oshape = (1, int(rng.integers(4, 12)), int(rng.integers(0, 6)))
+        iprm, prm, oprm = Params(1, q, pb), Params(*oshape), O.default_params(*oshape)
+        inner = []
+        for p_ in range(nproofs):
+            tr = ctx.gen_trace(SEED, 900 + p_, log_n, width)
+            inner.append(ctx.prove_shard(tr, log_n, width, pubs[p_], iprm)); tr.free()
+        key = ctx.shard_verifier_setup(log_n, width, q, pb, npub, prm, n_proofs=nproofs)
+        sh, mains, pres, progs, tabs, pv = recursion_air.machine([x.tobytes() for x in inner], log_n, width, pubs, q, pb)
+        lns = [m.shape[0].bit_length() - 1 for m in mains]
+        assert key.root.tolist() == O.machine_setup(pres, lns, oprm).tolist(), ("shard verifier key", log_n, width, q, pb, npub, nproofs, oshape)
+        outer = ctx.prove_shard_verifier(key, inner, log_n, width, pubs, iprm, prm)
+        assert outer.tobytes() == O.prove_machine_keyed(mains, pres, progs, tabs, pv, oprm).tobytes(), ("shard verifier", log_n, width, q, pb, npub, nproofs, oshape)
+        assert verify_shard_recursive(outer, log_n, width, q, pb, [v for p_ in pubs for v in p_], key.root, prm, n_proofs=nproofs) == (0, 0)
+        key.close()
+        n_rec += 1
+    elif r_kind < 0.01:
         # the Poseidon2 chip: random Merkle paths of a random tree; device trace against the Python restatement, proof bytes against the oracle
         depth, n_paths = int(rng.integers(1, 6)), int(rng.integers(1, 12))
         leaves, sibs, idx, root = poseidon2_air.tree_paths(depth, n_paths, seed=int(rng.integers(0, 2**31)))
@@ -171,5 +193,5 @@ while time.time() - t0 < budget:
         assert verify_chips(pf, [c[0] for c in chips], [c[1] for c in chips], [7], Params(*prm), prs, pas if cross else None) == (0, 0)
         for d in dev: d.free()
         n_chips += 1
-print("ok: %d single-matrix, %d multi-chip, %d constraint-program, %d chips-with-programs, %d lookup-machine, %d keyed-machine and %d Poseidon2-chip configurations in %.0f s"
-      % (n_single, n_chips, n_air, n_machine, n_lookup, n_keyed, n_p2, time.time() - t0))
+print("ok: %d single-matrix, %d multi-chip, %d constraint-program, %d chips-with-programs, %d lookup-machine, %d keyed-machine, %d Poseidon2-chip and %d shard-verifier (join) configurations in %.0f s"
+      % (n_single, n_chips, n_air, n_machine, n_lookup, n_keyed, n_p2, n_rec, time.time() - t0))

@@ -532,3 +532,31 @@ def test_compress_stage_behind_the_same_call(lib):
     plan4 = Plan(8, 8, 4, 10, 8)
     assert lib.zktls_verify_compressed_blob(blob, len(blob), C.byref(plan4), cbor, len(cbor), elf, len(elf), key, C.byref(reason)) == -1              # another shard count
     lib.zktls_release_cached()
+
+
+@pytest.mark.gpu
+def test_compress_stage_takes_more_than_64_shards_as_several_joins_of_one_shape(lib):
+    """70 shards: two joins of 35 under ONE key (the second repeats no shard here; 67 shards would repeat the last one three times)"""
+    _compress_api(lib)
+    for shards, joins in ((70, 2), (67, 2)):
+        plan = Plan(5, 8, shards, 4, 2)
+        cbor, elf = b"\xa1many", b"\x7fELFprog"
+        out, outn, pr, prn = C.POINTER(C.c_uint8)(), C.c_size_t(), C.POINTER(C.c_uint8)(), C.c_size_t()
+        err = C.create_string_buffer(512)
+        rc = lib.zktls_guest_prove_compressed(0, 2, C.byref(plan), cbor, len(cbor), elf, len(elf), C.byref(out), C.byref(outn), C.byref(pr), C.byref(prn), err, 512)
+        assert rc == 0, err.value
+        blob = C.string_at(pr, prn.value)
+        lib.zktls_free(out)
+        lib.zktls_free(pr)
+        offs, lens = (C.c_size_t * 8)(), (C.c_size_t * 8)()
+        assert lib.zktls_unpack_batch(blob, len(blob), offs, lens, 8) == joins + 1 and lens[joins] == 36 and lens[0] == lens[1]
+        key = (C.c_uint32 * 8)()
+        assert lib.zktls_compress_key(0, C.byref(plan), key, err, 512) == 0, err.value
+        reason = C.c_int(0)
+        assert lib.zktls_verify_compressed_blob(blob, len(blob), C.byref(plan), cbor, len(cbor), elf, len(elf), key, C.byref(reason)) == 0
+        swapped = bytearray(blob)                                               # the two joins exchanged: each is then checked against the other's shards
+        a, b = bytes(blob[offs[0]:offs[0] + lens[0]]), bytes(blob[offs[1]:offs[1] + lens[1]])
+        swapped[offs[0]:offs[0] + lens[0]] = b
+        swapped[offs[1]:offs[1] + lens[1]] = a
+        assert lib.zktls_verify_compressed_blob(bytes(swapped), len(blob), C.byref(plan), cbor, len(cbor), elf, len(elf), key, C.byref(reason)) == -2
+    lib.zktls_release_cached()

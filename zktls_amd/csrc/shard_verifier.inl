@@ -115,9 +115,9 @@ struct Shape {
     bool has_challenge(int T) const { return T == TA || T == TQ || T == TF || (TL0 <= T && T < TP); }
 };
 int make_shape(int log_n, uint32_t width, size_t n_queries, int pow_bits, size_t n_public, size_t n_proofs, Shape& s) {
-    if (log_n < frichip::MIN_LAYERS || log_n > 20 || width < 8 || width > 1024 || width % 8 || n_queries < 1 || n_queries > 1024 || pow_bits < 0 || pow_bits > 30 || n_public > 64 ||
+    if (log_n < frichip::MIN_LAYERS || log_n > MAX_LOG_ROWS || width < 8 || width > 1024 || width % 8 || n_queries < 1 || n_queries > 1024 || pow_bits < 0 || pow_bits > 30 || n_public > 64 ||
         n_proofs < 1 || n_proofs > 64)
-        return fail(ZKHIP_ERR_INVALID, "shard verifier: 2^2 .. 2^20 rows, a width of 8 .. 1024 in multiples of 8, 1 .. 1024 queries, 0 .. 30 proof-of-work bits, at most 64 public values, 1 .. 64 proofs");
+        return fail(ZKHIP_ERR_INVALID, "shard verifier: 2^2 .. 2^22 rows, a width of 8 .. 1024 in multiples of 8, 1 .. 1024 queries, 0 .. 30 proof-of-work bits, at most 64 public values, 1 .. 64 proofs");
     s.NP = (int)n_proofs;
     s.n = log_n; s.W = (int)width; s.Q = (int)n_queries; s.PB = pow_bits; s.NPUB = (int)n_public;
     s.R = log_n; s.H = log_n + 1; s.G = s.W / 4; s.WB = s.W / 8;

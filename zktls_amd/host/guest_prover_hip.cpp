@@ -393,7 +393,9 @@ ProveResult HipGuestProver::prove_inner(const GuestInput& input, const std::vect
         // core -> COMPRESS: the shard proofs verified in-circuit by ONE proof (the shard verifier machine, csrc/shard_verifier.inl); the blob then
         // carries that proof and the key of the shape instead of the shard proofs
         if (backend_ != Backend::Sp1) throw std::runtime_error("with_compress: the shard verifier takes SP1-shape shard proofs");
-        if (plan_.shards > 64) throw std::runtime_error("with_compress: at most 64 shards per join");
+        // more than 64 shards: several joins of ONE shape (compress_join_size: the last one repeats the execution's last shard proof, so that
+        // every join has the same key); the blob carries them in shard order
+        const uint32_t J = compress_join_size(plan_.shards), n_joins = (plan_.shards + J - 1) / J;
         const zkhip_params outer{1, plan_.num_queries, plan_.pow_bits, 0, 0, 0, 0, 0};
         CtxGuard g;
         if (!g.take(devices_[0], words * 4)) {
@@ -403,33 +405,41 @@ ProveResult HipGuestProver::prove_inner(const GuestInput& input, const std::vect
         }
         zkhip_machine_key* key = nullptr;
         uint32_t vk[8];
-        if (zkhip_shard_verifier_setup(g.ctx, plan_.log_n, plan_.width, (size_t)plan_.num_queries, plan_.pow_bits, 9, plan_.shards, &outer, &key, vk) != ZKHIP_OK)
+        if (zkhip_shard_verifier_setup(g.ctx, plan_.log_n, plan_.width, (size_t)plan_.num_queries, plan_.pow_bits, 9, J, &outer, &key, vk) != ZKHIP_OK)
             fail_zkhip("zkhip_shard_verifier_setup");
-        std::vector<const uint8_t*> ptrs(plan_.shards);
-        std::vector<size_t> lens(plan_.shards);
-        std::vector<uint32_t> pvs;
-        for (uint32_t sidx = 0; sidx < plan_.shards; sidx++) {
-            ptrs[sidx] = proofs[sidx].data(); lens[sidx] = proofs[sidx].size();
-            pvs.insert(pvs.end(), digest.begin(), digest.end());
-            pvs.push_back(sidx);
+        const size_t jcap = zkhip_shard_verifier_proof_size(plan_.log_n, plan_.width, (size_t)plan_.num_queries, plan_.pow_bits, 9, J, &outer);
+        std::vector<std::vector<uint8_t>> entries;
+        for (uint32_t c = 0; c < n_joins; c++) {
+            std::vector<const uint8_t*> ptrs(J);
+            std::vector<size_t> lens(J);
+            std::vector<uint32_t> pvs;
+            for (uint32_t k = 0; k < J; k++) {
+                const uint32_t sidx = c * J + k < plan_.shards ? c * J + k : plan_.shards - 1;
+                ptrs[k] = proofs[sidx].data(); lens[k] = proofs[sidx].size();
+                pvs.insert(pvs.end(), digest.begin(), digest.end());
+                pvs.push_back(sidx);
+            }
+            std::vector<uint8_t> joined(jcap);
+            size_t jlen = 0;
+            const int rc = zkhip_prove_shard_verifier(g.ctx, key, ptrs.data(), lens.data(), J, plan_.log_n, plan_.width, pvs.data(), 9, &prm, &outer, joined.data(), jcap, &jlen);
+            if (rc != ZKHIP_OK) { (void)zkhip_ctx_sync(g.ctx); zkhip_machine_key_destroy(key); fail_zkhip("zkhip_prove_shard_verifier"); }
+            joined.resize(jlen);
+            int reason = 0;
+            if (zkhip_verify_shard_recursive(joined.data(), jlen, plan_.log_n, plan_.width, (size_t)plan_.num_queries, plan_.pow_bits, pvs.data(), 9, J, vk, &outer, &reason) != ZKHIP_OK) {
+                (void)zkhip_ctx_sync(g.ctx); zkhip_machine_key_destroy(key);
+                fail_zkhip("zkhip_verify_shard_recursive");     // sp1.rs:120: the prover checks its own proof
+            }
+            entries.push_back(std::move(joined));
         }
-        const size_t jcap = zkhip_shard_verifier_proof_size(plan_.log_n, plan_.width, (size_t)plan_.num_queries, plan_.pow_bits, 9, plan_.shards, &outer);
-        std::vector<uint8_t> joined(jcap);
-        size_t jlen = 0;
-        const int rc = zkhip_prove_shard_verifier(g.ctx, key, ptrs.data(), lens.data(), plan_.shards, plan_.log_n, plan_.width, pvs.data(), 9, &prm, &outer, joined.data(), jcap, &jlen);
         (void)zkhip_ctx_sync(g.ctx);
         zkhip_machine_key_destroy(key);
-        if (rc != ZKHIP_OK) fail_zkhip("zkhip_prove_shard_verifier");
-        joined.resize(jlen);
-        int reason = 0;
-        if (zkhip_verify_shard_recursive(joined.data(), jlen, plan_.log_n, plan_.width, (size_t)plan_.num_queries, plan_.pow_bits, pvs.data(), 9, plan_.shards, vk, &outer, &reason) != ZKHIP_OK)
-            fail_zkhip("zkhip_verify_shard_recursive");     // sp1.rs:120: the prover checks its own proof
         g.healthy = true;
         std::vector<uint8_t> tail(36);
         std::memcpy(tail.data(), vk, 32);
         const uint32_t cnt = plan_.shards;
         std::memcpy(tail.data() + 32, &cnt, 4);
-        r.proof = pack_shard_proofs({joined, tail}, BATCH_FLAG_SYNTHETIC | BATCH_FLAG_COMPRESSED);
+        entries.push_back(tail);
+        r.proof = pack_shard_proofs(entries, BATCH_FLAG_SYNTHETIC | BATCH_FLAG_COMPRESSED);
         r.ok = true;
         return r;
     }
@@ -442,18 +452,27 @@ int verify_compressed_blob(const std::vector<uint8_t>& blob, const ShardPlan& pl
                            const uint32_t key[8], int* reason) {
     std::vector<std::vector<uint8_t>> entries;
     uint32_t flags = 0;
-    if (!unpack_shard_proofs(blob, &entries, &flags) || entries.size() != 2 || !(flags & BATCH_FLAG_COMPRESSED) || entries[1].size() != 36) return -1;
+    if (!unpack_shard_proofs(blob, &entries, &flags) || entries.size() < 2 || !(flags & BATCH_FLAG_COMPRESSED) || entries.back().size() != 36) return -1;
     uint32_t cnt = 0;
-    std::memcpy(&cnt, entries[1].data() + 32, 4);
-    if (cnt != plan.shards || cnt == 0 || cnt > 64 || std::memcmp(entries[1].data(), key, 32) != 0) return -1;        // (the key is the CALLER's: the blob's copy is informative)
+    std::memcpy(&cnt, entries.back().data() + 32, 4);
+    if (cnt != plan.shards || cnt == 0 || std::memcmp(entries.back().data(), key, 32) != 0) return -1;        // (the key is the CALLER's: the blob's copy is informative)
+    const uint32_t J = compress_join_size(cnt), n_joins = (cnt + J - 1) / J;
+    if (entries.size() != (size_t)n_joins + 1) return -1;
     const std::vector<uint32_t> digest = request_digest(cbor, elf);
-    std::vector<uint32_t> pvs;
-    for (uint32_t sidx = 0; sidx < cnt; sidx++) { pvs.insert(pvs.end(), digest.begin(), digest.end()); pvs.push_back(sidx); }
     const zkhip_params outer{1, plan.num_queries, plan.pow_bits, 0, 0, 0, 0, 0};
-    int why = 0;
-    const int rc = zkhip_verify_shard_recursive(entries[0].data(), entries[0].size(), plan.log_n, plan.width, (size_t)plan.num_queries, plan.pow_bits, pvs.data(), 9, cnt, key, &outer, &why);
-    if (reason) *reason = why;
-    return rc == ZKHIP_OK ? 0 : -2;
+    for (uint32_t c = 0; c < n_joins; c++) {
+        std::vector<uint32_t> pvs;
+        for (uint32_t k = 0; k < J; k++) {
+            const uint32_t sidx = c * J + k < cnt ? c * J + k : cnt - 1;      // the last join repeats the last shard (one shape, one key)
+            pvs.insert(pvs.end(), digest.begin(), digest.end());
+            pvs.push_back(sidx);
+        }
+        int why = 0;
+        const int rc = zkhip_verify_shard_recursive(entries[c].data(), entries[c].size(), plan.log_n, plan.width, (size_t)plan.num_queries, plan.pow_bits, pvs.data(), 9, J, key, &outer, &why);
+        if (reason) *reason = why;
+        if (rc != ZKHIP_OK) return -2;
+    }
+    return 0;
 }
 
 bool compress_key(int device, const ShardPlan& plan, uint32_t key_out[8], std::string* error) {
@@ -461,7 +480,7 @@ bool compress_key(int device, const ShardPlan& plan, uint32_t key_out[8], std::s
     zkhip_machine_key* key = nullptr;
     const zkhip_params outer{1, plan.num_queries, plan.pow_bits, 0, 0, 0, 0, 0};
     bool ok = zkhip_ctx_create(device, nullptr, &ctx) == ZKHIP_OK &&
-              zkhip_shard_verifier_setup(ctx, plan.log_n, plan.width, (size_t)plan.num_queries, plan.pow_bits, 9, plan.shards, &outer, &key, key_out) == ZKHIP_OK;
+              zkhip_shard_verifier_setup(ctx, plan.log_n, plan.width, (size_t)plan.num_queries, plan.pow_bits, 9, compress_join_size(plan.shards), &outer, &key, key_out) == ZKHIP_OK;
     if (!ok && error) *error = zkhip_last_error();
     if (key) { (void)zkhip_ctx_sync(ctx); zkhip_machine_key_destroy(key); }
     if (ctx) zkhip_ctx_destroy(ctx);
