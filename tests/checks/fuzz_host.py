@@ -125,8 +125,30 @@ L.zkhip_fri_view_path_words.restype = C.c_size_t
 g_out = [np.zeros(n_, dtype=np.uint32) for n_ in (4 * 8, 4, g_Q, 4 * g_Q, 4 * g_Q * 8, 8 * 8, L.zkhip_fri_view_path_words(8) * g_Q, 10)]
 q_fin, q_capv, q_vk = np.array(g_view["final"], dtype=np.uint32), np.array(g_cap, dtype=np.uint32), np.array(q_root, dtype=np.uint32)
 
+# the shard verifier machine: the oracle's outer proof for the golden shard proof, a join of two, and the host verifier that takes the shape,
+# the public values and the key (zkhip_verify_shard_recursive); its size / describe entries with hostile shapes
+import recursion_air as RA
+from zktls_amd.device import verify_shard_recursive
+r_sh, r_mains, r_pres, r_progs, r_tabs, r_pv = RA.machine(g_proof.tobytes(), _kat["log_n"], _kat["width"], _kat["public"], g_Q, _kat["shape"][2])
+r_lns = [m_.shape[0].bit_length() - 1 for m_ in r_mains]
+r_root = O.machine_setup(r_pres, r_lns, oprm)
+p_rec = O.prove_machine_keyed(r_mains, r_pres, r_progs, r_tabs, r_pv, oprm).tobytes()
+assert verify_shard_recursive(arr(p_rec), _kat["log_n"], _kat["width"], g_Q, _kat["shape"][2], _kat["public"], r_root, prm) == (0, 0)
+L.zkhip_shard_verifier_proof_size.restype = C.c_size_t
+L.zkhip_shard_verifier_describe.restype = C.c_size_t
+r_desc = np.zeros(1 << 16, dtype=np.uint32)
+
 t0, n = time.time(), 0
 while time.time() - t0 < budget:
+    verify_shard_recursive(arr(mutate(p_rec)), int(rng.choice([_kat["log_n"], _kat["log_n"], 2, 22, 23, -1])), int(rng.choice([_kat["width"], _kat["width"], 4, 1024, 2**31])),
+                           int(rng.choice([g_Q, g_Q, 1, 1024, 2**20])), int(rng.choice([_kat["shape"][2], 0, 30, 31])), _kat["public"] if rng.random() < 0.7 else [int(x) for x in rng.integers(0, 2**32, int(rng.integers(0, 70)))],
+                           r_root if rng.random() < 0.7 else rng.integers(0, 2**32, 8, dtype=np.uint64).astype(np.uint32), prm, n_proofs=int(rng.choice([1, 1, 2, 64, 65, 0])))
+    lr_, mw_, pw_ = C.c_int(0), C.c_uint32(0), C.c_uint32(0)
+    L.zkhip_shard_verifier_describe(int(rng.choice([6, 2, 22, 23, -5])), int(rng.choice([8, 16, 1024, 12, 2**31])), int(rng.choice([4, 1, 1024, 2**33])), int(rng.choice([3, 0, 30, 99])),
+                                    int(rng.choice([2, 0, 64, 65])), int(rng.choice([1, 2, 64, 65, 0])), int(rng.choice([0, 3, 7, 8, -1])), int(rng.choice([0, 1, 2, 3])),
+                                    r_desc.ctypes.data_as(u32p), int(rng.choice([r_desc.size, 0, 5])), C.byref(lr_), C.byref(mw_), C.byref(pw_))
+    L.zkhip_shard_verifier_proof_size(int(rng.choice([6, 20, 22, 23])), int(rng.choice([8, 256, 1024, 2**31])), int(rng.choice([4, 100, 1024, 2**33])), int(rng.choice([3, 16, 31])),
+                                      int(rng.choice([2, 9, 64, 65])), int(rng.choice([1, 16, 64, 65])), C.byref(prm))
     gm = arr(mutate(g_proof.tobytes()))
     L.zkhip_fri_view_all(gm.ctypes.data_as(u8p), gm.size, int(rng.choice([g_R, g_R, g_R + 1, 2])), int(rng.choice([_kat["width"], 4])), g_pv.ctypes.data_as(u32p), g_pv.size,
                          C.byref(g_prm), *[a.ctypes.data_as(u32p) for a in g_out])
@@ -166,4 +188,4 @@ while time.time() - t0 < budget:
     L.zkhip_chips_proof_from_bincode(cb.ctypes.data_as(u8p), cb.size, back2.ctypes.data_as(u8p), int(rng.choice([back2.size, 64, 0])), C.byref(got),
                                      pub2.ctypes.data_as(u32p), int(rng.choice([8, 0])), C.byref(got2))
     n += 1
-print("fuzz ok: %d rounds of 19 malformed calls in %.0f s (no crash; run under the sanitizer build for out-of-bounds reads)" % (n, time.time() - t0))
+print("fuzz ok: %d rounds of 22 malformed calls in %.0f s (no crash; run under the sanitizer build for out-of-bounds reads)" % (n, time.time() - t0))

@@ -18,6 +18,6 @@ import zktls_amd._lib as l
 l.LIB_PATH = os.path.join(os.getcwd(), 'zktls_amd', 'libzkhip_asan.so')
 import pytest
 sys.exit(pytest.main(['-x', '-q', '-m', 'not gpu', '-p', 'no:cacheprovider', 'tests/test_pyverify_cpu.py', 'tests/test_air_cpu.py', 'tests/test_serialize_cpu.py', 'tests/test_serialize_chips_cpu.py',
-                      'tests/test_groups_cpu.py', 'tests/test_chips_air_cpu.py', 'tests/test_machine_cpu.py', 'tests/test_keyed_machine_cpu.py', 'tests/test_sha256_chip_cpu.py', 'tests/test_abi_cpu.py', 'tests/test_fri_chip_cpu.py', 'tests/test_lockstep_cpu.py']))
+                      'tests/test_groups_cpu.py', 'tests/test_chips_air_cpu.py', 'tests/test_machine_cpu.py', 'tests/test_keyed_machine_cpu.py', 'tests/test_sha256_chip_cpu.py', 'tests/test_abi_cpu.py', 'tests/test_fri_chip_cpu.py', 'tests/test_lockstep_cpu.py', 'tests/test_recursion_cpu.py']))
 "
 ZKHIP_FUZZ_LIB=$PWD/zktls_amd/libzkhip_asan.so LD_PRELOAD=$RT python tests/checks/fuzz_host.py "${1:-30}"
