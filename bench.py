@@ -684,6 +684,21 @@ def main():
                   "compression": round(sum(p_.size for p_ in sps) / joined.size, 2), "host_verify_ms": round(t_join_verify * 1e3, 2), "verified": bool(ok_join),
                   "verifier_inputs": "shape, 16 x %d public values, the shape's key (8 words); no byte of an inner proof" % len(spv[0])}
         jkey.close()
+        # the same join with the OUTER proof in SP1's compress shape (blowup 4, 50 queries, 16 proof-of-work bits: ZKHIP_PARAMS_SP1_COMPRESS, [RECALLED]):
+        # half the queries over twice the domain -- a smaller proof for more transform and hashing work
+        from zktls_amd._lib import Params as _P
+        cprm = _P(2, 50, 16)
+        ckey = ctx.shard_verifier_setup(log_n, width, prm.num_queries, prm.pow_bits, len(spv[0]), cprm, n_proofs=16)
+        ctx.prove_shard_verifier(ckey, sps, log_n, width, spv, prm, cprm)
+        t_cj, cjoined = 1e9, None
+        for _ in range(2):
+            tb0 = time.perf_counter()
+            cjoined = ctx.prove_shard_verifier(ckey, sps, log_n, width, spv, prm, cprm)
+            t_cj = min(t_cj, time.perf_counter() - tb0)
+        ok_cj = verify_shard_recursive(cjoined, log_n, width, prm.num_queries, prm.pow_bits, [v for pv_ in spv for v in pv_], ckey.root, cprm, n_proofs=16) == (0, 0)
+        ckey.close()
+        join16["outer_in_sp1_compress_shape"] = {"outer_params": "log_blowup 2, 50 queries, 16 PoW bits", "ms": round(t_cj * 1e3, 2), "outer_bytes": int(cjoined.size),
+                                                 "compression": round(sum(p_.size for p_ in sps) / cjoined.size, 2), "verified": bool(ok_cj)}
         recursion16 = {"join16": join16, "fri_only_workload": "the FRI check of 16 shard proofs (2^%d x %d, 100 queries x %d layers each) proven in-circuit: Poseidon2 chip (Merkle paths + transcript) + FRI-fold chip + SAMPLES chip + two tables per proof, one zkhip_prove_fri_indices_batch call, shard proofs in as bytes (host view included)" % (log_n, width, log_n),
                        "fri_only_ms": round(t_rec * 1e3, 2), "fri_only_proof_bytes": int(rec[0][0].size), "fri_only_all_verified": bool(ok_rec),
                        "ms": round(t_join * 1e3, 2), "recursion_proofs_per_s": round(16 / t_join, 1), "proof_bytes": int(joined.size), "all_verified": bool(ok_join)}

@@ -78,13 +78,13 @@ def test_headline_shard_proof_verified_in_circuit(ctx, oracle):
     key.close()
 
 
-@pytest.mark.parametrize("nproofs", [2, 3])
-def test_the_join_bytes_equal_the_oracles(ctx, oracle, nproofs):
+@pytest.mark.parametrize("nproofs,oshape", [(2, (1, 20, 8)), (3, (1, 20, 8)), (2, (2, 10, 4))])      # (the last: the outer proof at blowup 4, SP1's compress shape in small)
+def test_the_join_bytes_equal_the_oracles(ctx, oracle, nproofs, oshape):
     """ONE outer proof for several inner proofs of one shape: key and bytes against the oracle on the restatement's arrays"""
     import recursion_air as R
     O = oracle
     log_n, width, q, pb = 6, 16, 5, 2
-    iprm, oprm, prm = Params(1, q, pb), O.default_params(1, 20, 8), Params(1, 20, 8)
+    iprm, oprm, prm = Params(1, q, pb), O.default_params(*oshape), Params(*oshape)
     pubs = [[3, 4, 50 + p] for p in range(nproofs)]
     inner = [ctx.prove_shard(ctx.gen_trace(SEED, 20 + p, log_n, width), log_n, width, pubs[p], iprm) for p in range(nproofs)]
     key = ctx.shard_verifier_setup(log_n, width, q, pb, 3, prm, n_proofs=nproofs)
