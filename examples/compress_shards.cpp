@@ -35,7 +35,9 @@ int main(int argc, char** argv) {
         std::fprintf(stderr, "no gfx950 device: libzkhip has no CPU fallback\n");
         return 2;
     }
-    if (shards < 1 || shards > 64) { std::fprintf(stderr, "1..64 shards (one join)\n"); return 1; }
+    const zkhip_params shape = {1, 100, 16, 0, 0, 0, 0, 0};
+    const size_t most = zkhip_shard_verifier_max_proofs(log_n, width, (size_t)shape.num_queries, shape.pow_bits, 1);
+    if (shards < 1 || (size_t)shards > most) { std::fprintf(stderr, "1..%zu shards of this shape fit one join\n", most); return 1; }
     const zkhip_params prm = {1, 100, 16, 0, 0, 0, 0, 0};            // SP1-core-like shape, for the shard proofs and for the proof about them
     const size_t n_public = 1;
     zkhip_ctx* ctx = nullptr;

@@ -788,10 +788,15 @@ int zkhip_prove_fri_indices_batch(const int* devices, int n_devices, zkhip_fri_j
  * tags, tree numbers and query numbers carry the proof's number; the SCALARS chip has one row per proof).  public_values = those of proof
  * 0, then those of proof 1, ... (n_proofs x n_public words), which are the outer proof's public values.  Sixteen headline shard proofs
  * (15 MB) become one proof of about a megabyte.  (A TREE of joins would need a verifier of THIS machine's proofs -- version 11, lookups and
- * all -- in-circuit; that is not built: the join is flat, bounded by the 2^22-row limit of the Poseidon2 chip, i.e. 64 headline proofs.) */
+ * all -- in-circuit; that is not built: the join is flat, bounded by the 2^21-row limit of the Poseidon2 chip -- 68 headline proofs,
+ * zkhip_shard_verifier_max_proofs -- and by 1024 proofs.) */
 int zkhip_shard_verifier_setup(zkhip_ctx* ctx, int log_n, uint32_t width, size_t n_queries, int inner_pow_bits, size_t n_public, size_t n_proofs, const zkhip_params* outer,
                                zkhip_machine_key** key, uint32_t vk[8]);
 size_t zkhip_shard_verifier_proof_size(int log_n, uint32_t width, size_t n_queries, int inner_pow_bits, size_t n_public, size_t n_proofs, const zkhip_params* outer);
+/* the largest n_proofs ONE join takes for this inner shape: every permutation of every proof is a row of the Poseidon2 chip, which holds 2^21
+ * (68 proofs of the headline shape), and the transcript table spends one preprocessed column per proof and sponge row that carries public
+ * values (497 proofs with 9 public values); never more than 1024.  0: bad shape.  Host only. */
+size_t zkhip_shard_verifier_max_proofs(int log_n, uint32_t width, size_t n_queries, int inner_pow_bits, size_t n_public);
 int zkhip_prove_shard_verifier(zkhip_ctx* ctx, const zkhip_machine_key* key, const uint8_t* const* shard_proofs, const size_t* shard_proof_lens, size_t n_proofs, int log_n,
                                uint32_t width, const uint32_t* public_values, size_t n_public, const zkhip_params* inner, const zkhip_params* outer, uint8_t* proof, size_t cap,
                                size_t* len);

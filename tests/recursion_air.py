@@ -155,7 +155,7 @@ class Shape:
     such proofs ONE outer proof verifies (n_proofs: the join -- every chip holds the rows of proof 0, then those of proof 1, ...; tags, tree
     numbers and query numbers carry the proof's number)"""
     def __init__(self, log_n, width, n_queries, pow_bits, n_public, n_proofs=1):
-        assert width % 8 == 0 and width >= 8 and 2 <= log_n <= 22 and n_queries >= 1 and 1 <= n_proofs <= 64
+        assert width % 8 == 0 and width >= 8 and 2 <= log_n <= 22 and n_queries >= 1 and 1 <= n_proofs <= 1024
         self.n, self.W, self.Q, self.PB, self.NPUB, self.NP = log_n, width, n_queries, pow_bits, n_public, n_proofs
         self.R, self.H, self.G, self.WB = log_n, log_n + 1, width // 4, width // 8
         self.head = [log_n, width, 1, n_queries, pow_bits, n_public]           # the header words the transcript observes

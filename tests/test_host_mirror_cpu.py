@@ -535,10 +535,13 @@ def test_compress_stage_behind_the_same_call(lib):
 
 
 @pytest.mark.gpu
-def test_compress_stage_takes_more_than_64_shards_as_several_joins_of_one_shape(lib):
-    """70 shards: two joins of 35 under ONE key (the second repeats no shard here; 67 shards would repeat the last one three times)"""
+def test_compress_stage_takes_more_shards_than_one_join_holds_as_several_joins_of_one_shape(lib):
+    """one join holds 497 proofs of this small shape with its 9 public values (zkhip_shard_verifier_max_proofs; 68 of the headline shape).  1100
+    shards: three joins of 367 under ONE key, the last repeats the last shard once; 1027 shards: three joins of 343, the last repeats it twice"""
     _compress_api(lib)
-    for shards, joins in ((70, 2), (67, 2)):
+    from zktls_amd.device import shard_verifier_max_proofs
+    assert shard_verifier_max_proofs(5, 8, 4, 2, 9) == 497 and shard_verifier_max_proofs(5, 8, 4, 2, 0) == 1024 and shard_verifier_max_proofs(20, 256, 100, 16, 9) == 68
+    for shards, joins in ((1100, 3), (1027, 3)):
         plan = Plan(5, 8, shards, 4, 2)
         cbor, elf = b"\xa1many", b"\x7fELFprog"
         out, outn, pr, prn = C.POINTER(C.c_uint8)(), C.c_size_t(), C.POINTER(C.c_uint8)(), C.c_size_t()

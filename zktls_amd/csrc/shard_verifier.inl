@@ -114,10 +114,12 @@ struct Shape {
     }
     bool has_challenge(int T) const { return T == TA || T == TQ || T == TF || (TL0 <= T && T < TP); }
 };
+constexpr size_t MAX_JOIN = 1024;       // proofs per join: as many as fit the Poseidon2 chip (68 at the headline shape), at most this
+constexpr int P2R_MAX_LOG_ROWS = 21;    // the chip's rows are 384 words apart with the key's columns: the transforms take 2^22-row matrices up to a pitch of 256 words only
 int make_shape(int log_n, uint32_t width, size_t n_queries, int pow_bits, size_t n_public, size_t n_proofs, Shape& s) {
     if (log_n < frichip::MIN_LAYERS || log_n > MAX_LOG_ROWS || width < 8 || width > 1024 || width % 8 || n_queries < 1 || n_queries > 1024 || pow_bits < 0 || pow_bits > 30 || n_public > 64 ||
-        n_proofs < 1 || n_proofs > 64)
-        return fail(ZKHIP_ERR_INVALID, "shard verifier: 2^2 .. 2^22 rows, a width of 8 .. 1024 in multiples of 8, 1 .. 1024 queries, 0 .. 30 proof-of-work bits, at most 64 public values, 1 .. 64 proofs");
+        n_proofs < 1 || n_proofs > MAX_JOIN)
+        return fail(ZKHIP_ERR_INVALID, "shard verifier: 2^2 .. 2^22 rows, a width of 8 .. 1024 in multiples of 8, 1 .. 1024 queries, 0 .. 30 proof-of-work bits, at most 64 public values, 1 .. 1024 proofs");
     s.NP = (int)n_proofs;
     s.n = log_n; s.W = (int)width; s.Q = (int)n_queries; s.PB = pow_bits; s.NPUB = (int)n_public;
     s.R = log_n; s.H = log_n + 1; s.G = s.W / 4; s.WB = s.W / 8;
@@ -134,7 +136,9 @@ int make_shape(int log_n, uint32_t width, size_t n_queries, int pow_bits, size_t
     s.p2_rows = s.p2_q0 + (size_t)s.Q * (size_t)(1 + s.H);
     s.tag0 = s.NT;
     s.TAGSPAN = s.NT + s.Q * (s.WB + 1); s.TREES = s.R + 2;
-    if (lg((size_t)s.NP * s.p2_rows) > MAX_LOG_ROWS) return fail(ZKHIP_ERR_INVALID, "shard verifier: the Poseidon2 chip would need more than 2^22 rows");
+    if (lg((size_t)s.NP * s.p2_rows) > P2R_MAX_LOG_ROWS) return fail(ZKHIP_ERR_INVALID, "shard verifier: the Poseidon2 chip would need more than 2^21 rows");
+    // the transcript table has one preprocessed indicator column per (proof, sponge row that carries public values): at most 1024 preprocessed columns
+    if (29 + (size_t)s.NP * s.pub_rows.size() > 1024) return fail(ZKHIP_ERR_INVALID, "shard verifier: too many proofs x public values for the transcript table's preprocessed columns");
     return ZKHIP_OK;
 }
 
@@ -1068,6 +1072,17 @@ int zkhip_shard_verifier_setup(zkhip_ctx* ctx, int log_n, uint32_t width, size_t
         at += pre[c].size();
     }
     return zkhip_machine_setup(ctx, chips, N_CHIPS, outer, key, vk);
+}
+
+// the largest n_proofs one join takes for this inner shape: the Poseidon2 chip holds every permutation of every proof in at most 2^21 rows
+size_t zkhip_shard_verifier_max_proofs(int log_n, uint32_t width, size_t n_queries, int inner_pow_bits, size_t n_public) {
+    using namespace zk::rec;
+    Shape sh;
+    if (make_shape(log_n, width, n_queries, inner_pow_bits, n_public, 1, sh) != ZKHIP_OK) return 0;
+    size_t fit = ((size_t)1 << P2R_MAX_LOG_ROWS) / sh.p2_rows;
+    if (fit > MAX_JOIN) fit = MAX_JOIN;
+    if (!sh.pub_rows.empty() && fit > (1024 - 29) / sh.pub_rows.size()) fit = (1024 - 29) / sh.pub_rows.size();      // (the transcript table's indicator columns)
+    return fit;
 }
 
 size_t zkhip_shard_verifier_proof_size(int log_n, uint32_t width, size_t n_queries, int inner_pow_bits, size_t n_public, size_t n_proofs, const zkhip_params* outer) {

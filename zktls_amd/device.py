@@ -1146,6 +1146,11 @@ def verify_shard_recursive(proof, log_n, width, n_queries, inner_pow_bits, publi
     return rc, reason.value
 
 
+def shard_verifier_max_proofs(log_n, width, n_queries, inner_pow_bits, n_public):
+    """zkhip_shard_verifier_max_proofs (host): how many shard proofs of this shape ONE join takes"""
+    return int(_lib.load().zkhip_shard_verifier_max_proofs(log_n, width, n_queries, inner_pow_bits, n_public))
+
+
 def shard_verifier_describe(log_n, width, n_queries, inner_pow_bits, n_public, which, kind, n_proofs=1):
     """zkhip_shard_verifier_describe -> (words, log_rows, main width, preprocessed width); kind 0 program, 1 interaction table, 2 preprocessed trace"""
     lib = _lib.load()

@@ -393,9 +393,9 @@ ProveResult HipGuestProver::prove_inner(const GuestInput& input, const std::vect
         // core -> COMPRESS: the shard proofs verified in-circuit by ONE proof (the shard verifier machine, csrc/shard_verifier.inl); the blob then
         // carries that proof and the key of the shape instead of the shard proofs
         if (backend_ != Backend::Sp1) throw std::runtime_error("with_compress: the shard verifier takes SP1-shape shard proofs");
-        // more than 64 shards: several joins of ONE shape (compress_join_size: the last one repeats the execution's last shard proof, so that
+        // more shards than one join holds: several joins of ONE shape (compress_join_size: the last one repeats the execution's last shard proof, so that
         // every join has the same key); the blob carries them in shard order
-        const uint32_t J = compress_join_size(plan_.shards), n_joins = (plan_.shards + J - 1) / J;
+        const uint32_t J = compress_join_size(plan_), n_joins = (plan_.shards + J - 1) / J;
         const zkhip_params outer{1, plan_.num_queries, plan_.pow_bits, 0, 0, 0, 0, 0};
         CtxGuard g;
         if (!g.take(devices_[0], words * 4)) {
@@ -448,6 +448,15 @@ ProveResult HipGuestProver::prove_inner(const GuestInput& input, const std::vect
     return r;
 }
 
+uint32_t compress_join_size(const ShardPlan& plan) {
+    const uint32_t shards = plan.shards ? plan.shards : 1u;
+    uint32_t most = (uint32_t)zkhip_shard_verifier_max_proofs(plan.log_n, plan.width, (size_t)plan.num_queries, plan.pow_bits, 9);
+    if (most == 0) most = 1;                           // (a shape the machine refuses: the join itself will say so)
+    if (shards <= most) return shards;
+    const uint32_t joins = (shards + most - 1u) / most;
+    return (shards + joins - 1u) / joins;
+}
+
 int verify_compressed_blob(const std::vector<uint8_t>& blob, const ShardPlan& plan, const std::vector<uint8_t>& cbor, const std::vector<uint8_t>& elf,
                            const uint32_t key[8], int* reason) {
     std::vector<std::vector<uint8_t>> entries;
@@ -456,7 +465,7 @@ int verify_compressed_blob(const std::vector<uint8_t>& blob, const ShardPlan& pl
     uint32_t cnt = 0;
     std::memcpy(&cnt, entries.back().data() + 32, 4);
     if (cnt != plan.shards || cnt == 0 || std::memcmp(entries.back().data(), key, 32) != 0) return -1;        // (the key is the CALLER's: the blob's copy is informative)
-    const uint32_t J = compress_join_size(cnt), n_joins = (cnt + J - 1) / J;
+    const uint32_t J = compress_join_size(plan), n_joins = (cnt + J - 1) / J;
     if (entries.size() != (size_t)n_joins + 1) return -1;
     const std::vector<uint32_t> digest = request_digest(cbor, elf);
     const zkhip_params outer{1, plan.num_queries, plan.pow_bits, 0, 0, 0, 0, 0};
@@ -480,7 +489,7 @@ bool compress_key(int device, const ShardPlan& plan, uint32_t key_out[8], std::s
     zkhip_machine_key* key = nullptr;
     const zkhip_params outer{1, plan.num_queries, plan.pow_bits, 0, 0, 0, 0, 0};
     bool ok = zkhip_ctx_create(device, nullptr, &ctx) == ZKHIP_OK &&
-              zkhip_shard_verifier_setup(ctx, plan.log_n, plan.width, (size_t)plan.num_queries, plan.pow_bits, 9, compress_join_size(plan.shards), &outer, &key, key_out) == ZKHIP_OK;
+              zkhip_shard_verifier_setup(ctx, plan.log_n, plan.width, (size_t)plan.num_queries, plan.pow_bits, 9, compress_join_size(plan), &outer, &key, key_out) == ZKHIP_OK;
     if (!ok && error) *error = zkhip_last_error();
     if (key) { (void)zkhip_ctx_sync(ctx); zkhip_machine_key_destroy(key); }
     if (ctx) zkhip_ctx_destroy(ctx);

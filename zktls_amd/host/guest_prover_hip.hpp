@@ -96,8 +96,8 @@ public:
     HipGuestProver& with_input_commitment(const ShardPlan& p = ShardPlan{}) { plan_ = p; commitment_ = true; return *this; }
     // the COMPRESS stage behind the same call (sp1.rs:116: core -> compress; prover.rs:90: lift -> join): after the shards are proven, ONE
     // proof verifies them all in-circuit (zkhip_prove_shard_verifier) and replaces them in the blob (flag COMPRESSED: entry 0 = the joined
-    // proof, entry 1 = 8 LE words of the shape's key + the shard count).  SP1 backend, synthetic shards, width a multiple of 8.  More than
-    // 64 shards take several joins of ONE shape (compress_join_size; entries 0 .. k-1, the key entry last).  verify_compressed_blob checks
+    // proof, entry 1 = 8 LE words of the shape's key + the shard count).  SP1 backend, synthetic shards, width a multiple of 8.  More shards
+    // than one join holds (68 of the headline shape) take several joins of ONE shape (compress_join_size; entries 0 .. k-1, the key entry last).  verify_compressed_blob checks
     // such a blob on the host from (plan, input, ELF, key): the shard proofs are gone.
     HipGuestProver& with_compress() { compress_ = true; return *this; }
     bool synthetic() const { return synthetic_; }
@@ -139,15 +139,11 @@ std::vector<uint32_t> request_digest(const std::vector<uint8_t>& cbor, const std
 constexpr uint32_t BATCH_FLAG_SYNTHETIC = 1u;
 constexpr uint32_t BATCH_FLAG_INPUT_SHA256 = 2u;     // one proof of the SHA-256 chip over the request's input bytes
 constexpr uint32_t BATCH_FLAG_CHAINED = 8u;          // with INPUT_SHA256: an input beyond one chip proof (1 MiB): entry 0 = the chaining values ((n + 1) x 8 LE words), entries 1..n = the shard proofs of zkhip_prove_sha256_sharded (2^14 blocks per shard)
-constexpr uint32_t BATCH_FLAG_COMPRESSED = 16u;      // with SYNTHETIC: the shard proofs were joined into ONE proof (entry 0; k proofs for more than 64 shards); last entry = the shape's key (8 LE words) + the shard count
-// shard proofs per join for an execution of `shards` shards: one join up to 64 (the Poseidon2 chip's row limit at the headline shape); beyond,
-// ceil(shards / 64) joins of equal size J = ceil(shards / joins) -- the last one repeats the execution's last shard proof to fill its J
-// places, so that every join has the same shape, hence the same key
-inline uint32_t compress_join_size(uint32_t shards) {
-    if (shards <= 64u) return shards ? shards : 1u;
-    const uint32_t joins = (shards + 63u) / 64u;
-    return (shards + joins - 1u) / joins;
-}
+constexpr uint32_t BATCH_FLAG_COMPRESSED = 16u;      // with SYNTHETIC: the shard proofs were joined into ONE proof (entry 0; k proofs when the shards do not fit one join); last entry = the shape's key (8 LE words) + the shard count
+// shard proofs per join for an execution of `shards` shards of `plan`'s shape: one join while they fit (zkhip_shard_verifier_max_proofs: the
+// Poseidon2 chip's 2^21 rows -- 68 proofs of the headline shape); beyond, ceil(shards / max) joins of equal size J = ceil(shards / joins) --
+// the last one repeats the execution's last shard proof to fill its J places, so that every join has the same shape, hence the same key
+uint32_t compress_join_size(const ShardPlan& plan);
 constexpr uint32_t BATCH_FLAG_KEYED = 4u;            // with INPUT_SHA256: the proof is the keyed SHA-256 MACHINE's (chip + range table), checked against a vk
 // a consumer's check of an input-commitment blob on the CPU: the blob's proof(s) against the claimed output (SHA-256 of the input).
 // The caller says what it EXPECTS, the blob's own flags only have to agree: a 64-byte `vk` (from setup) means "a KEYED proof under this
