@@ -46,8 +46,10 @@ def test_a_tampered_inner_proof_is_refused_by_the_prover(ctx):
     for at in (40, 200, inner.size // 2, inner.size - 8):
         bad = inner.copy()
         bad[at] ^= 1
-        with pytest.raises(ZkHipError):
+        with pytest.raises(ZkHipError) as e:
             ctx.prove_shard_verifier(key, bad, log_n, width, pubs, iprm, prm)
+        assert e.value.code == -6, (at, str(e.value))          # ZKHIP_ERR_VERIFY whoever notices: the host pass (transcript, AIR identity, folds) or -- for a
+        #                                                         digest inside a Merkle path, which only the device hashes -- the roots the P2R rows kernel arrives at
     with pytest.raises(ZkHipError):
         ctx.prove_shard_verifier(key, inner, log_n, width, [4, 6], iprm, prm)          # other public values than the proof's
     key.close()
