@@ -337,6 +337,31 @@ pub fn compress_shards(ctx: &Context, proofs: &[Vec<u8>], log_n: i32, width: u32
     Ok((out, vk))
 }
 
+/// The compress stage for an execution of ANY shard count (the C++ mirror's `HipGuestProver::with_compress`): while the shards fit one join
+/// (`zkhip_shard_verifier_max_proofs`: 68 proofs of the headline shape) that is one call of `compress_shards`; beyond, `ceil(n / max)` joins of
+/// equal size -- the last one repeats the last shard proof to fill its places, so that every join has the same shape and ONE key.  Returns the
+/// joined proofs in shard order, the key and the join size J (a verifier rebuilds the public-value lists from it the same way).
+pub fn compress_execution(ctx: &Context, proofs: &[Vec<u8>], log_n: i32, width: u32, public_values: &[u32], n_public: usize, inner: &ZkhipParams,
+                          outer: &ZkhipParams) -> Result<(Vec<Vec<u8>>, [u32; 8], usize)> {
+    anyhow::ensure!(!proofs.is_empty() && public_values.len() == proofs.len() * n_public, "compress_execution: one public-value list per proof");
+    let n = proofs.len();
+    let most = unsafe { ffi::zkhip_shard_verifier_max_proofs(log_n, width, inner.num_queries as usize, inner.pow_bits, n_public) };
+    anyhow::ensure!(most > 0, "compress_execution: the shard verifier does not take this shape");
+    let joins = (n + most - 1) / most;
+    let j = (n + joins - 1) / joins;
+    let (mut out, mut vk) = (Vec::with_capacity(joins), [0u32; 8]);
+    for c in 0..joins {
+        let idx: Vec<usize> = (0..j).map(|k| std::cmp::min(c * j + k, n - 1)).collect();
+        let chunk: Vec<Vec<u8>> = idx.iter().map(|&i| proofs[i].clone()).collect();
+        let pvs: Vec<u32> = idx.iter().flat_map(|&i| public_values[i * n_public..(i + 1) * n_public].iter().copied()).collect();
+        let (joined, key) = compress_shards(ctx, &chunk, log_n, width, &pvs, n_public, inner, outer)?;
+        anyhow::ensure!(c == 0 || key == vk, "compress_execution: joins of one shape must share a key");
+        vk = key;
+        out.push(joined);
+    }
+    Ok((out, vk, j))
+}
+
 /// Host-only check of a joined proof: the shape, the shard proofs' public values and the key of the shape (sp1.rs:120 for the compressed proof).
 pub fn verify_compressed(proof: &[u8], log_n: i32, width: u32, public_values: &[u32], n_public: usize, n_proofs: usize, vk: &[u32; 8], inner: &ZkhipParams,
                          outer: &ZkhipParams) -> Result<()> {
