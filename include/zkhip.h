@@ -775,7 +775,7 @@ int zkhip_prove_fri_indices_batch(const int* devices, int n_devices, zkhip_fri_j
 /* ---- THE SHARD VERIFIER AS A MACHINE: a whole shard proof checked in-circuit (csrc/shard_verifier.inl).
  * What the reference asks for behind `client.prove(&pk, &stdin, SP1ProofMode::Groth16)` (crates/guest-prover-sp1/src/sp1.rs:116: core ->
  * COMPRESS verifies the shard proofs; RISC Zero: lift -> join behind crates/guest-prover-r0/src/prover.rs:90).  Inner proofs: version 1 of
- * this library (zkhip_prove_shard with the SP1 shape -- blowup 2, fold by 2, constant final value, Poseidon2 width 16, no lookups), 2^2 ..
+ * this library (zkhip_prove_shard with the SP1 shape -- blowup 2, fold by 2, constant final value, Poseidon2 width 16, no lookups), 2^5 ..
  * 2^22 rows, a width that is a multiple of 8.  The machine has eight chips -- the Poseidon2 chip (transcript sponge rows, every Merkle path
  * of every query), ROWSUM (the opened rows and their batched sums), the fold chip, the transcript table, QUERY (reduced openings), OPENED
  * (opened values, the AIR's constraints at zeta), SAMPLES (proof of work, query indices), SCALARS (zeta^N, selectors, the quotient

@@ -11,7 +11,7 @@ pytestmark = pytest.mark.gpu
 SEED = 0x5A4B544C53
 
 
-@pytest.mark.parametrize("log_n,width,q,pb,pubs", [(5, 8, 4, 3, [1, 2, 3]), (6, 16, 5, 0, []), (9, 64, 12, 5, [7, 8, 9, 10, 11, 12, 13, 14, 15]), (21, 64, 6, 4, [9, 8])])      # (the last: a shard above 2^20 rows)
+@pytest.mark.parametrize("log_n,width,q,pb,pubs", [(5, 8, 4, 3, [1, 2, 3]), (6, 16, 5, 0, []), (9, 64, 12, 5, [7, 8, 9, 10, 11, 12, 13, 14, 15]), (21, 64, 6, 4, [9, 8]), (5, 8, 1, 0, []), (5, 1024, 2, 1, list(range(100, 164)))])      # (a shard above 2^20 rows; the smallest shape; the widest with the most public values)
 def test_key_and_proof_bytes_equal_the_oracles(ctx, oracle, log_n, width, q, pb, pubs):
     import recursion_air as R
     O = oracle

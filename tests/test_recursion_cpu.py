@@ -13,7 +13,7 @@ import recursion_air as R
 import sha256_air as S
 
 SEED = 0x5A4B544C53
-SHAPES = [(5, 8, 4, 3, [1, 2, 3]), (6, 16, 5, 0, []), (5, 40, 3, 2, list(range(20, 31)))]
+SHAPES = [(5, 8, 4, 3, [1, 2, 3]), (6, 16, 5, 0, []), (5, 40, 3, 2, list(range(20, 31))), (5, 8, 1, 0, [])]      # (the last: the smallest shape the machine takes)
 
 
 def inner_proof(O, log_n, width, q, pb, pubs, shard=0):
@@ -59,7 +59,7 @@ def test_a_flipped_cell_breaks_a_constraint_or_a_bus(oracle):
 def test_product_machine_equals_the_restatement_word_for_word():
     from zktls_amd.device import shard_verifier_describe
     for log_n, width, q, pb, npub, nproofs in ((5, 8, 4, 3, 3, 1), (6, 16, 5, 0, 0, 1), (7, 24, 9, 4, 9, 1), (5, 40, 3, 2, 11, 1), (8, 64, 12, 5, 2, 1),
-                                               (5, 8, 4, 3, 3, 2), (5, 8, 4, 3, 3, 3), (6, 16, 5, 1, 9, 4), (21, 8, 2, 1, 1, 1), (22, 8, 1, 0, 0, 2), (5, 8, 4, 3, 3, 65)):      # (the tallest shards the prover takes; a join of more than 64)
+                                               (5, 8, 4, 3, 3, 2), (5, 8, 4, 3, 3, 3), (6, 16, 5, 1, 9, 4), (21, 8, 2, 1, 1, 1), (22, 8, 1, 0, 0, 2), (5, 8, 4, 3, 3, 65), (5, 8, 1, 0, 0, 1), (5, 1024, 2, 1, 64, 1)):      # (the tallest shards the prover takes; a join of more than 64)
         sh = R.Shape(log_n, width, q, pb, npub, nproofs)
         names, progs, tabs, pres, h = R.order(sh), R.programs(sh), R.tables(sh), R.preprocessed(sh), R.heights(sh)
         for i, nm in enumerate(names):

@@ -117,9 +117,10 @@ struct Shape {
 constexpr size_t MAX_JOIN = 1024;       // proofs per join: as many as fit the Poseidon2 chip (68 at the headline shape), at most this
 constexpr int P2R_MAX_LOG_ROWS = 21;    // the chip's rows are 384 words apart with the key's columns: the transforms take 2^22-row matrices up to a pitch of 256 words only
 int make_shape(int log_n, uint32_t width, size_t n_queries, int pow_bits, size_t n_public, size_t n_proofs, Shape& s) {
-    if (log_n < frichip::MIN_LAYERS || log_n > MAX_LOG_ROWS || width < 8 || width > 1024 || width % 8 || n_queries < 1 || n_queries > 1024 || pow_bits < 0 || pow_bits > 30 || n_public > 64 ||
+    // (the inner proofs are zkhip_prove_shard's: its bounds on rows and proof-of-work bits -- proof_common.h, check_shape -- are this machine's)
+    if (log_n < 5 || log_n > MAX_LOG_ROWS || width < 8 || width > 1024 || width % 8 || n_queries < 1 || n_queries > 1024 || pow_bits < 0 || pow_bits > 28 || n_public > 64 ||
         n_proofs < 1 || n_proofs > MAX_JOIN)
-        return fail(ZKHIP_ERR_INVALID, "shard verifier: 2^2 .. 2^22 rows, a width of 8 .. 1024 in multiples of 8, 1 .. 1024 queries, 0 .. 30 proof-of-work bits, at most 64 public values, 1 .. 1024 proofs");
+        return fail(ZKHIP_ERR_INVALID, "shard verifier: 2^5 .. 2^22 rows, a width of 8 .. 1024 in multiples of 8, 1 .. 1024 queries, 0 .. 28 proof-of-work bits, at most 64 public values, 1 .. 1024 proofs");
     s.NP = (int)n_proofs;
     s.n = log_n; s.W = (int)width; s.Q = (int)n_queries; s.PB = pow_bits; s.NPUB = (int)n_public;
     s.R = log_n; s.H = log_n + 1; s.G = s.W / 4; s.WB = s.W / 8;
