@@ -90,6 +90,7 @@ def main():
                     help="TEST MODE with --one-process on a box with fewer GPUs than --gpus: load the A/B build (libzkhip_ab.so) with "
                          "ZKHIP_LOGICAL_DEVICES=K, whose device ordinals 0..K-1 are logical devices on the physical ones (own pools, own workers, "
                          "traces checked to live where their shard is dealt); the line says so and is not a scaling result")
+    ap.add_argument("--no-execution", action="store_true", help="skip the reference-sized execution (22 shards: core, then core + compress) through the host mirror of ZkProver::prove")
     ap.add_argument("--no-multichip", action="store_true", help="skip the multi-chip shard with LogUp pairs (SP1's shard structure, rows a7 mixed heights + a8) measured beside the headline")
     ap.add_argument("--no-fri-graph", action="store_true",
                     help="zkhip_set_fri_graph(0): the FRI commit phase as plain launches instead of one hipGraphLaunch per proof (a debugging switch; "
@@ -744,6 +745,58 @@ def main():
             b_[0].free()
         del mc_out
 
+    # ---- the plug point itself on the measuring path: ONE call of the host mirror of ZkProver::prove
+    # (zktls_amd/host, what crates/guest-prover-sp1/src/sp1.rs:102-133 would bind) for an execution of the size the reference benchmarks
+    # -- 22.1 M cycles = 22 shards of 2^20 rows (/root/reference/benchmark.md:9) -- first core only (every shard proven and checked,
+    # sp1.rs:116-120), then core + COMPRESS (the shard proofs joined into one proof, checked on the host without them)
+    execution = None
+    mirror_so = os.path.join(ROOT, "zktls_amd", "libzktls_guest_prover.so")
+    if (rank == 0 and world == 1 and not args.no_execution and chip_list is None and host_traces is None and args.shape == "sp1" and LQ == 0 and log_n <= 20 and width % 8 == 0
+            and not one_proc and os.path.exists(mirror_so)):
+        import ctypes as C_
+
+        class _Plan(C_.Structure):
+            _fields_ = [("log_n", C_.c_int32), ("width", C_.c_uint32), ("shards", C_.c_uint32), ("num_queries", C_.c_int32), ("pow_bits", C_.c_int32)]
+        ML = C_.CDLL(mirror_so)
+        u8pp_, szp_ = C_.POINTER(C_.POINTER(C_.c_uint8)), C_.POINTER(C_.c_size_t)
+        sig_ = [C_.c_int, C_.c_int, C_.POINTER(_Plan), C_.c_char_p, C_.c_size_t, C_.c_char_p, C_.c_size_t, u8pp_, szp_, u8pp_, szp_, C_.c_char_p, C_.c_size_t]
+        ML.zktls_guest_prove.argtypes = sig_
+        ML.zktls_guest_prove_compressed.argtypes = sig_
+        ML.zktls_compress_key.argtypes = [C_.c_int, C_.POINTER(_Plan), C_.POINTER(C_.c_uint32), C_.c_char_p, C_.c_size_t]
+        ML.zktls_verify_compressed_blob.argtypes = [C_.c_char_p, C_.c_size_t, C_.POINTER(_Plan), C_.c_char_p, C_.c_size_t, C_.c_char_p, C_.c_size_t, C_.POINTER(C_.c_uint32), C_.POINTER(C_.c_int)]
+        ML.zktls_free.argtypes = [C_.c_void_p]
+        eplan = _Plan(log_n, width, 22, prm.num_queries, prm.pow_bits)
+        ecbor, eelf = b"\xa1bench execution", b"\x7fELF bench guest"
+
+        def _run(fn):
+            out_, outn_, pr_, prn_ = C_.POINTER(C_.c_uint8)(), C_.c_size_t(), C_.POINTER(C_.c_uint8)(), C_.c_size_t()
+            err_ = C_.create_string_buffer(512)
+            t0_ = time.perf_counter()
+            rc_ = fn(local_rank, 2, C_.byref(eplan), ecbor, len(ecbor), eelf, len(eelf), C_.byref(out_), C_.byref(outn_), C_.byref(pr_), C_.byref(prn_), err_, 512)
+            dt_ = time.perf_counter() - t0_
+            if rc_ != 0:
+                raise RuntimeError("host mirror: %s" % err_.value.decode("utf-8", "replace"))
+            blob_ = C_.string_at(pr_, prn_.value)
+            ML.zktls_free(out_)
+            ML.zktls_free(pr_)
+            return dt_, blob_
+        _run(ML.zktls_guest_prove)                                   # warm the mirror's own contexts
+        t_core, b_core = min((_run(ML.zktls_guest_prove) for _ in range(2)), key=lambda x_: x_[0])
+        _run(ML.zktls_guest_prove_compressed)
+        t_cc, b_cc = min((_run(ML.zktls_guest_prove_compressed) for _ in range(2)), key=lambda x_: x_[0])
+        ekey = (C_.c_uint32 * 8)()
+        eerr = C_.create_string_buffer(512)
+        ok_key = ML.zktls_compress_key(local_rank, C_.byref(eplan), ekey, eerr, 512) == 0
+        t0_ = time.perf_counter()
+        ok_blob = ok_key and ML.zktls_verify_compressed_blob(b_cc, len(b_cc), C_.byref(eplan), ecbor, len(ecbor), eelf, len(eelf), ekey, None) == 0
+        t_ev = time.perf_counter() - t0_
+        ML.zktls_release_cached()
+        execution = {"workload": "ONE call of the host mirror of ZkProver::prove (libzktls_guest_prover.so) for 22 synthetic shards of 2^%d x %d -- the size of the reference's 22.1 M-cycle benchmark execution; every proof checked by the prover as sp1.rs:120 does" % (log_n, width),
+                     "core_ms": round(t_core * 1e3, 1), "core_ms_per_shard": round(t_core * 1e3 / 22, 2), "core_blob_bytes": len(b_core),
+                     "core_plus_compress_ms": round(t_cc * 1e3, 1), "compressed_blob_bytes": len(b_cc), "compressed_blob_verified_on_host": bool(ok_blob),
+                     "compressed_blob_host_verify_ms": round(t_ev * 1e3, 2),
+                     "note": "synthetic AIR in SP1's shard shape; no executor, no shrink / wrap / Groth16 (out of scope): not comparable with the reference's end-to-end seconds"}
+
     # ---- CPU baseline: the oracle on the host cores, bounded sample of the same workload
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
@@ -809,6 +862,7 @@ def main():
             "recursion_proofs_per_s": (recursion16["recursion_proofs_per_s"] if recursion16 else None),
             "recursion16": recursion16,
             "multichip": multichip,
+            "execution22": execution,
             "one_process": one_process,
             "one_process_value": (one_process["value"] if one_process else None),
             "cpu_baseline": cpu,

@@ -67,6 +67,9 @@ def test_the_rank_per_gpu_line_carries_the_one_process_entry_too():
     r = run_bench("--gpus", "1", "--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--no-batch64", "--no-recursion16", "--log-n", "18", "--width", "128")
     assert r["one_process"]["shards_proven"] == 2 and r["one_process"]["distinct_proofs"] == 2 and r["one_process"]["same_bytes_as_the_timed_step"] is True
     assert r["one_process_value"] > 0
+    # ... and the plug point itself: one call of the host mirror of ZkProver::prove for 22 shards, core and core + compress
+    e = r["execution22"]
+    assert e["compressed_blob_verified_on_host"] is True and e["compressed_blob_bytes"] * 4 < e["core_blob_bytes"] and e["core_plus_compress_ms"] > e["core_ms"] * 0.5
 
 
 def test_multi_device_entries_on_two_logical_devices():
