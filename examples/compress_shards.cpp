@@ -36,7 +36,7 @@ int main(int argc, char** argv) {
         return 2;
     }
     const zkhip_params shape = {1, 100, 16, 0, 0, 0, 0, 0};
-    const size_t most = zkhip_shard_verifier_max_proofs(log_n, width, (size_t)shape.num_queries, shape.pow_bits, 1);
+    const size_t most = zkhip_shard_verifier_max_proofs(log_n, width, (size_t)shape.num_queries, shape.pow_bits, 1, &shape);
     if (shards < 1 || (size_t)shards > most) { std::fprintf(stderr, "1..%zu shards of this shape fit one join\n", most); return 1; }
     const zkhip_params prm = {1, 100, 16, 0, 0, 0, 0, 0};            // SP1-core-like shape, for the shard proofs and for the proof about them
     const size_t n_public = 1;

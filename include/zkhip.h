@@ -185,7 +185,8 @@ int zkhip_gen_trace_logup_cross(zkhip_ctx* ctx, uint64_t seed, uint64_t shard, u
 /* ---- NTT / LDE over the columns of a row-major matrix, 2^log_n rows, 0 <= log_n <= 22 (fewer than 32 rows: by
  * definition, out of place).  Up to 2^20 rows a transform is two launches of the pass kernel; 2^21 and 2^22 rows (SP1 core
  * shards reach those heights: reference benchmark.md:9) add one streaming radix-2 / radix-4 pass and take a row pitch of at
- * most 512 / 256 words. ---- */
+ * most 512 / 256 words -- except zkhip_coset_lde at log_blowup 1, which runs its tile passes on dense 2^20-row classes and takes any
+ * pitch (up to 1023 columns). ---- */
 /* forward DFT: natural rows in; rows out natural (bitrev_out = 0) or bit-reversed (1);
  * inverse DFT (inverse = 1): natural in, natural out, scaled by 1/N. */
 int zkhip_dft(zkhip_ctx* ctx, const uint32_t* d_in, size_t in_ld, uint32_t* d_out, size_t out_ld,
@@ -445,7 +446,7 @@ int zkhip_verify_sha256(const uint8_t* proof, size_t len, const uint8_t digest[3
 /* ---- a shard made of several chips (AIR tables) of different heights, as an SP1 shard is (sp1-stark 4.1.4 ShardProof,
  * reference Cargo.lock:6172, behind crates/guest-prover-sp1/src/sp1.rs:116): one Merkle commitment per phase over all
  * chips (shorter matrices injected at their level), one opening point, one reduced-opening vector per height joining the
- * FRI vector when folding reaches it, one FRI proof.  Chips tallest first, log_n in [5, 22] (above 2^20 rows a chip's row pitch is limited as in zkhip_coset_lde: 512 words at 2^21, 256 at 2^22), at most 8 per height and 32
+ * FRI vector when folding reaches it, one FRI proof.  Chips tallest first, log_n in [5, 22] (above 2^20 rows and at a blowup other than 2 a chip's row pitch is limited as in zkhip_coset_lde: 512 words at 2^21, 256 at 2^22), at most 8 per height and 32
  * in all; zkhip_params: any log_blowup, the SP1 FRI shape (log_fold / log_final / hash_width / logup_pairs 0).
  * A chip may carry in-table LogUp pairs (logup_pairs > 0, trace from zkhip_gen_trace_logup): the permutation traces of
  * those chips are committed together in a third mixed-height tree (sp1-stark's permutation commitment).  Two chips of
@@ -788,15 +789,16 @@ int zkhip_prove_fri_indices_batch(const int* devices, int n_devices, zkhip_fri_j
  * tags, tree numbers and query numbers carry the proof's number; the SCALARS chip has one row per proof).  public_values = those of proof
  * 0, then those of proof 1, ... (n_proofs x n_public words), which are the outer proof's public values.  Sixteen headline shard proofs
  * (15 MB) become one proof of about a megabyte.  (A TREE of joins would need a verifier of THIS machine's proofs -- version 11, lookups and
- * all -- in-circuit; that is not built: the join is flat, bounded by the 2^21-row limit of the Poseidon2 chip -- 68 headline proofs,
+ * all -- in-circuit; that is not built: the join is flat, bounded by the 2^22-row limit of the Poseidon2 chip -- 136 headline proofs under an outer proof at blowup 2, 68 otherwise,
  * zkhip_shard_verifier_max_proofs -- and by 1024 proofs.) */
 int zkhip_shard_verifier_setup(zkhip_ctx* ctx, int log_n, uint32_t width, size_t n_queries, int inner_pow_bits, size_t n_public, size_t n_proofs, const zkhip_params* outer,
                                zkhip_machine_key** key, uint32_t vk[8]);
 size_t zkhip_shard_verifier_proof_size(int log_n, uint32_t width, size_t n_queries, int inner_pow_bits, size_t n_public, size_t n_proofs, const zkhip_params* outer);
-/* the largest n_proofs ONE join takes for this inner shape: every permutation of every proof is a row of the Poseidon2 chip, which holds 2^21
- * (68 proofs of the headline shape), and the transcript table spends one preprocessed column per proof and sponge row that carries public
- * values (497 proofs with 9 public values); never more than 1024.  0: bad shape.  Host only. */
-size_t zkhip_shard_verifier_max_proofs(int log_n, uint32_t width, size_t n_queries, int inner_pow_bits, size_t n_public);
+/* the largest n_proofs ONE join takes for this inner shape: every permutation of every proof is a row of the Poseidon2 chip, which holds 2^22
+ * rows under an outer proof at blowup 2 (136 proofs of the headline shape) and 2^21 under any other (68; `outer` NULL: blowup 2), and the
+ * transcript table spends one preprocessed column per proof and sponge row that carries public values (497 proofs with 9 public values);
+ * never more than 1024.  0: bad shape.  Host only. */
+size_t zkhip_shard_verifier_max_proofs(int log_n, uint32_t width, size_t n_queries, int inner_pow_bits, size_t n_public, const zkhip_params* outer);
 int zkhip_prove_shard_verifier(zkhip_ctx* ctx, const zkhip_machine_key* key, const uint8_t* const* shard_proofs, const size_t* shard_proof_lens, size_t n_proofs, int log_n,
                                uint32_t width, const uint32_t* public_values, size_t n_public, const zkhip_params* inner, const zkhip_params* outer, uint8_t* proof, size_t cap,
                                size_t* len);

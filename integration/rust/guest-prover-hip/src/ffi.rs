@@ -153,7 +153,7 @@ extern "C" {
     pub fn zkhip_shard_verifier_setup(ctx: *mut ZkhipCtx, log_n: c_int, width: u32, n_queries: usize, inner_pow_bits: c_int, n_public: usize, n_proofs: usize,
                                       outer: *const ZkhipParams, key: *mut *mut ZkhipMachineKey, vk: *mut u32) -> c_int;
     pub fn zkhip_shard_verifier_proof_size(log_n: c_int, width: u32, n_queries: usize, inner_pow_bits: c_int, n_public: usize, n_proofs: usize, outer: *const ZkhipParams) -> usize;
-    pub fn zkhip_shard_verifier_max_proofs(log_n: c_int, width: u32, n_queries: usize, inner_pow_bits: c_int, n_public: usize) -> usize;
+    pub fn zkhip_shard_verifier_max_proofs(log_n: c_int, width: u32, n_queries: usize, inner_pow_bits: c_int, n_public: usize, outer: *const ZkhipParams) -> usize;
     pub fn zkhip_prove_shard_verifier(ctx: *mut ZkhipCtx, key: *const ZkhipMachineKey, shard_proofs: *const *const u8, shard_proof_lens: *const usize, n_proofs: usize,
                                       log_n: c_int, width: u32, public_values: *const u32, n_public: usize, inner: *const ZkhipParams, outer: *const ZkhipParams,
                                       proof: *mut u8, cap: usize, len: *mut usize) -> c_int;

@@ -338,14 +338,14 @@ pub fn compress_shards(ctx: &Context, proofs: &[Vec<u8>], log_n: i32, width: u32
 }
 
 /// The compress stage for an execution of ANY shard count (the C++ mirror's `HipGuestProver::with_compress`): while the shards fit one join
-/// (`zkhip_shard_verifier_max_proofs`: 68 proofs of the headline shape) that is one call of `compress_shards`; beyond, `ceil(n / max)` joins of
+/// (`zkhip_shard_verifier_max_proofs`: 136 proofs of the headline shape under an outer proof at blowup 2) that is one call of `compress_shards`; beyond, `ceil(n / max)` joins of
 /// equal size -- the last one repeats the last shard proof to fill its places, so that every join has the same shape and ONE key.  Returns the
 /// joined proofs in shard order, the key and the join size J (a verifier rebuilds the public-value lists from it the same way).
 pub fn compress_execution(ctx: &Context, proofs: &[Vec<u8>], log_n: i32, width: u32, public_values: &[u32], n_public: usize, inner: &ZkhipParams,
                           outer: &ZkhipParams) -> Result<(Vec<Vec<u8>>, [u32; 8], usize)> {
     anyhow::ensure!(!proofs.is_empty() && public_values.len() == proofs.len() * n_public, "compress_execution: one public-value list per proof");
     let n = proofs.len();
-    let most = unsafe { ffi::zkhip_shard_verifier_max_proofs(log_n, width, inner.num_queries as usize, inner.pow_bits, n_public) };
+    let most = unsafe { ffi::zkhip_shard_verifier_max_proofs(log_n, width, inner.num_queries as usize, inner.pow_bits, n_public, outer) };
     anyhow::ensure!(most > 0, "compress_execution: the shard verifier does not take this shape");
     let joins = (n + most - 1) / most;
     let j = (n + joins - 1) / joins;

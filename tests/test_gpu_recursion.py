@@ -135,3 +135,28 @@ def test_sixteen_headline_shard_proofs_become_one_proof(ctx, oracle):
     assert verify_shard_recursive(outer, log_n, width, q, pb, flat, key.root, prm, n_proofs=n)[0] != 0
     print("join: %d inner proofs, %d bytes -> %d bytes, P2R 2^%d rows" % (n, sum(x.size for x in inner), outer.size, lns[0]))
     key.close()
+
+
+def test_the_largest_join_a_poseidon2_chip_of_2_pow_22_rows(ctx):
+    """136 headline shard proofs (the most ONE join takes: zkhip_shard_verifier_max_proofs) under an outer proof at blowup 2; another outer blowup
+    holds the Poseidon2 chip to 2^21 rows and refuses the shape at setup"""
+    from zktls_amd.device import shard_verifier_max_proofs
+    log_n, width, q, pb = 20, 256, 100, 16
+    iprm, prm = Params(1, q, pb), Params(1, 100, 16)
+    n = shard_verifier_max_proofs(log_n, width, q, pb, 9, prm)
+    assert n == 136 and shard_verifier_max_proofs(log_n, width, q, pb, 9, Params(2, 50, 16)) == 68
+    pubs = [[1, 2, 3, 4, 5, 6, 7, 8, p % 3] for p in range(n)]
+    tr = ctx.gen_trace(SEED, 300, log_n, width)
+    three = [ctx.prove_shard(tr, log_n, width, pubs[p], iprm) for p in range(3)]      # (three distinct proofs, repeated: the join does not care)
+    tr.free()
+    inner = [three[p % 3] for p in range(n)]
+    with pytest.raises(ZkHipError):
+        ctx.shard_verifier_setup(log_n, width, q, pb, 9, Params(2, 50, 16), n_proofs=n)
+    key = ctx.shard_verifier_setup(log_n, width, q, pb, 9, prm, n_proofs=n)
+    outer = ctx.prove_shard_verifier(key, inner, log_n, width, pubs, iprm, prm)
+    flat = [v for p in pubs for v in p]
+    assert verify_shard_recursive(outer, log_n, width, q, pb, flat, key.root, prm, n_proofs=n) == (0, 0)
+    flat[-1] ^= 1
+    assert verify_shard_recursive(outer, log_n, width, q, pb, flat, key.root, prm, n_proofs=n)[0] != 0
+    assert outer.size * 60 < sum(x.size for x in inner)
+    key.close()

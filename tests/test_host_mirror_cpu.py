@@ -536,11 +536,12 @@ def test_compress_stage_behind_the_same_call(lib):
 
 @pytest.mark.gpu
 def test_compress_stage_takes_more_shards_than_one_join_holds_as_several_joins_of_one_shape(lib):
-    """one join holds 497 proofs of this small shape with its 9 public values (zkhip_shard_verifier_max_proofs; 68 of the headline shape).  1100
+    """one join holds 497 proofs of this small shape with its 9 public values (zkhip_shard_verifier_max_proofs; 136 of the headline shape).  1100
     shards: three joins of 367 under ONE key, the last repeats the last shard once; 1027 shards: three joins of 343, the last repeats it twice"""
     _compress_api(lib)
     from zktls_amd.device import shard_verifier_max_proofs
-    assert shard_verifier_max_proofs(5, 8, 4, 2, 9) == 497 and shard_verifier_max_proofs(5, 8, 4, 2, 0) == 1024 and shard_verifier_max_proofs(20, 256, 100, 16, 9) == 68
+    from zktls_amd._lib import Params
+    assert shard_verifier_max_proofs(5, 8, 4, 2, 9) == 497 and shard_verifier_max_proofs(5, 8, 4, 2, 0) == 1024 and shard_verifier_max_proofs(20, 256, 100, 16, 9) == 136 and shard_verifier_max_proofs(20, 256, 100, 16, 9, Params(2, 50, 16)) == 68
     for shards, joins in ((1100, 3), (1027, 3)):
         plan = Plan(5, 8, shards, 4, 2)
         cbor, elf = b"\xa1many", b"\x7fELFprog"

@@ -223,7 +223,7 @@ def load():
     L.zkhip_shard_verifier_setup.argtypes = [C.c_void_p, C.c_int, C.c_uint32, C.c_size_t, C.c_int, C.c_size_t, C.c_size_t, C.POINTER(Params), C.POINTER(C.c_void_p), u32p]
     L.zkhip_shard_verifier_proof_size.argtypes = [C.c_int, C.c_uint32, C.c_size_t, C.c_int, C.c_size_t, C.c_size_t, C.POINTER(Params)]
     L.zkhip_shard_verifier_proof_size.restype = C.c_size_t
-    L.zkhip_shard_verifier_max_proofs.argtypes = [C.c_int, C.c_uint32, C.c_size_t, C.c_int, C.c_size_t]
+    L.zkhip_shard_verifier_max_proofs.argtypes = [C.c_int, C.c_uint32, C.c_size_t, C.c_int, C.c_size_t, C.POINTER(Params)]
     L.zkhip_shard_verifier_max_proofs.restype = C.c_size_t
     L.zkhip_prove_shard_verifier.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(u8p), C.POINTER(C.c_size_t), C.c_size_t, C.c_int, C.c_uint32, u32p, C.c_size_t, C.POINTER(Params),
                                              C.POINTER(Params), u8p, C.c_size_t, C.POINTER(C.c_size_t)]

@@ -115,7 +115,10 @@ struct Shape {
     bool has_challenge(int T) const { return T == TA || T == TQ || T == TF || (TL0 <= T && T < TP); }
 };
 constexpr size_t MAX_JOIN = 1024;       // proofs per join: as many as fit the Poseidon2 chip (68 at the headline shape), at most this
-constexpr int P2R_MAX_LOG_ROWS = 21;    // the chip's rows are 384 words apart with the key's columns: the transforms take 2^22-row matrices up to a pitch of 256 words only
+// the Poseidon2 chip's rows are 384 words apart with the key's columns.  An outer proof at blowup 2 extends 2^22-row matrices of any pitch (its
+// tile passes run on dense 2^20-row classes: context.cpp, coset_lde_big); other blowups write every 4th row of the LDE and take a pitch of 256 words
+constexpr int P2R_MAX_LOG_ROWS = 22;
+inline int p2r_max_log_rows(const zkhip_params* outer) { return !outer || outer->log_blowup == 1 ? 22 : 21; }
 int make_shape(int log_n, uint32_t width, size_t n_queries, int pow_bits, size_t n_public, size_t n_proofs, Shape& s) {
     // (the inner proofs are zkhip_prove_shard's: its bounds on rows and proof-of-work bits -- proof_common.h, check_shape -- are this machine's)
     if (log_n < 5 || log_n > MAX_LOG_ROWS || width < 8 || width > 1024 || width % 8 || n_queries < 1 || n_queries > 1024 || pow_bits < 0 || pow_bits > 28 || n_public > 64 ||
@@ -137,9 +140,15 @@ int make_shape(int log_n, uint32_t width, size_t n_queries, int pow_bits, size_t
     s.p2_rows = s.p2_q0 + (size_t)s.Q * (size_t)(1 + s.H);
     s.tag0 = s.NT;
     s.TAGSPAN = s.NT + s.Q * (s.WB + 1); s.TREES = s.R + 2;
-    if (lg((size_t)s.NP * s.p2_rows) > P2R_MAX_LOG_ROWS) return fail(ZKHIP_ERR_INVALID, "shard verifier: the Poseidon2 chip would need more than 2^21 rows");
+    if (lg((size_t)s.NP * s.p2_rows) > P2R_MAX_LOG_ROWS) return fail(ZKHIP_ERR_INVALID, "shard verifier: the Poseidon2 chip would need more than 2^22 rows");
     // the transcript table has one preprocessed indicator column per (proof, sponge row that carries public values): at most 1024 preprocessed columns
     if (29 + (size_t)s.NP * s.pub_rows.size() > 1024) return fail(ZKHIP_ERR_INVALID, "shard verifier: too many proofs x public values for the transcript table's preprocessed columns");
+    return ZKHIP_OK;
+}
+
+int check_outer(const Shape& s, const zkhip_params* outer) {
+    if (lg((size_t)s.NP * s.p2_rows) > p2r_max_log_rows(outer))
+        return fail(ZKHIP_ERR_INVALID, "shard verifier: a Poseidon2 chip of 2^22 rows takes an outer proof at blowup 2 (log_blowup 1) only");
     return ZKHIP_OK;
 }
 
@@ -927,6 +936,7 @@ static int shard_verifier_prove_impl(zkhip_ctx* ctx, const zkhip_machine_key* ke
         return fail(ZKHIP_ERR_INVALID, "prove_shard_verifier: version-1 shard proofs (SP1 shape: blowup 2, fold by 2, constant final value, no lookups)");
     Shape sh;
     ZK_TRY(make_shape(log_n, width, (size_t)inner_prm->num_queries, inner_prm->pow_bits, n_public, n_proofs, sh));
+    ZK_TRY(check_outer(sh, outer));
     const auto mp = machine_of(sh);
     const Machine& m = *mp;
     const int R = sh.R, Q = sh.Q, NP = sh.NP;
@@ -1052,6 +1062,7 @@ int zkhip_shard_verifier_setup(zkhip_ctx* ctx, int log_n, uint32_t width, size_t
     if (!outer || !key || !vk) return fail(ZKHIP_ERR_INVALID, "shard_verifier_setup: null argument");
     Shape sh;
     ZK_TRY(make_shape(log_n, width, n_queries, inner_pow_bits, n_public, n_proofs, sh));
+    ZK_TRY(check_outer(sh, outer));
     const auto mp = machine_of(sh);
     const Machine& m = *mp;
     std::vector<uint32_t> pre[N_CHIPS];
@@ -1075,12 +1086,13 @@ int zkhip_shard_verifier_setup(zkhip_ctx* ctx, int log_n, uint32_t width, size_t
     return zkhip_machine_setup(ctx, chips, N_CHIPS, outer, key, vk);
 }
 
-// the largest n_proofs one join takes for this inner shape: the Poseidon2 chip holds every permutation of every proof in at most 2^21 rows
-size_t zkhip_shard_verifier_max_proofs(int log_n, uint32_t width, size_t n_queries, int inner_pow_bits, size_t n_public) {
+// the largest n_proofs one join takes for this inner shape: the Poseidon2 chip holds every permutation of every proof in at most 2^22 rows
+// (2^21 when the outer proof's blowup is not 2)
+size_t zkhip_shard_verifier_max_proofs(int log_n, uint32_t width, size_t n_queries, int inner_pow_bits, size_t n_public, const zkhip_params* outer) {
     using namespace zk::rec;
     Shape sh;
     if (make_shape(log_n, width, n_queries, inner_pow_bits, n_public, 1, sh) != ZKHIP_OK) return 0;
-    size_t fit = ((size_t)1 << P2R_MAX_LOG_ROWS) / sh.p2_rows;
+    size_t fit = ((size_t)1 << p2r_max_log_rows(outer)) / sh.p2_rows;
     if (fit > MAX_JOIN) fit = MAX_JOIN;
     if (!sh.pub_rows.empty() && fit > (1024 - 29) / sh.pub_rows.size()) fit = (1024 - 29) / sh.pub_rows.size();      // (the transcript table's indicator columns)
     return fit;
@@ -1089,7 +1101,7 @@ size_t zkhip_shard_verifier_max_proofs(int log_n, uint32_t width, size_t n_queri
 size_t zkhip_shard_verifier_proof_size(int log_n, uint32_t width, size_t n_queries, int inner_pow_bits, size_t n_public, size_t n_proofs, const zkhip_params* outer) {
     using namespace zk::rec;
     Shape sh;
-    if (!outer || make_shape(log_n, width, n_queries, inner_pow_bits, n_public, n_proofs, sh) != ZKHIP_OK) return 0;
+    if (!outer || make_shape(log_n, width, n_queries, inner_pow_bits, n_public, n_proofs, sh) != ZKHIP_OK || check_outer(sh, outer) != ZKHIP_OK) return 0;
     const auto m = machine_of(sh);
     return zkhip_machine_proof_size_keyed(m->log_ns, m->widths, m->pre_widths, m->progs, m->prog_words, m->tabs, m->tab_words, N_CHIPS, outer, n_proofs * n_public);
 }

@@ -1146,9 +1146,9 @@ def verify_shard_recursive(proof, log_n, width, n_queries, inner_pow_bits, publi
     return rc, reason.value
 
 
-def shard_verifier_max_proofs(log_n, width, n_queries, inner_pow_bits, n_public):
-    """zkhip_shard_verifier_max_proofs (host): how many shard proofs of this shape ONE join takes"""
-    return int(_lib.load().zkhip_shard_verifier_max_proofs(log_n, width, n_queries, inner_pow_bits, n_public))
+def shard_verifier_max_proofs(log_n, width, n_queries, inner_pow_bits, n_public, outer=None):
+    """zkhip_shard_verifier_max_proofs (host): how many shard proofs of this shape ONE join takes (outer: the outer proof's params; None = blowup 2)"""
+    return int(_lib.load().zkhip_shard_verifier_max_proofs(log_n, width, n_queries, inner_pow_bits, n_public, C.byref(outer) if outer is not None else None))
 
 
 def shard_verifier_describe(log_n, width, n_queries, inner_pow_bits, n_public, which, kind, n_proofs=1):

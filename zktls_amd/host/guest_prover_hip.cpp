@@ -477,7 +477,8 @@ ProveResult HipGuestProver::prove_inner(const GuestInput& input, const std::vect
 
 uint32_t compress_join_size(const ShardPlan& plan) {
     const uint32_t shards = plan.shards ? plan.shards : 1u;
-    uint32_t most = (uint32_t)zkhip_shard_verifier_max_proofs(plan.log_n, plan.width, (size_t)plan.num_queries, plan.pow_bits, 9);
+    const zkhip_params outer{1, plan.num_queries, plan.pow_bits, 0, 0, 0, 0, 0};      // (the outer proof's shape: blowup 2, the plan's queries and proof-of-work bits)
+    uint32_t most = (uint32_t)zkhip_shard_verifier_max_proofs(plan.log_n, plan.width, (size_t)plan.num_queries, plan.pow_bits, 9, &outer);
     if (most == 0) most = 1;                           // (a shape the machine refuses: the join itself will say so)
     if (shards <= most) return shards;
     const uint32_t joins = (shards + most - 1u) / most;

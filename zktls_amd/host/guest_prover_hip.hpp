@@ -97,7 +97,7 @@ public:
     // the COMPRESS stage behind the same call (sp1.rs:116: core -> compress; prover.rs:90: lift -> join): after the shards are proven, ONE
     // proof verifies them all in-circuit (zkhip_prove_shard_verifier) and replaces them in the blob (flag COMPRESSED: entry 0 = the joined
     // proof, entry 1 = 8 LE words of the shape's key + the shard count).  SP1 backend, synthetic shards, width a multiple of 8.  More shards
-    // than one join holds (68 of the headline shape) take several joins of ONE shape (compress_join_size; entries 0 .. k-1, the key entry last).  verify_compressed_blob checks
+    // than one join holds (136 of the headline shape) take several joins of ONE shape (compress_join_size; entries 0 .. k-1, the key entry last).  verify_compressed_blob checks
     // such a blob on the host from (plan, input, ELF, key): the shard proofs are gone.
     HipGuestProver& with_compress() { compress_ = true; return *this; }
     bool synthetic() const { return synthetic_; }
@@ -141,7 +141,7 @@ constexpr uint32_t BATCH_FLAG_INPUT_SHA256 = 2u;     // one proof of the SHA-256
 constexpr uint32_t BATCH_FLAG_CHAINED = 8u;          // with INPUT_SHA256: an input beyond one chip proof (1 MiB): entry 0 = the chaining values ((n + 1) x 8 LE words), entries 1..n = the shard proofs of zkhip_prove_sha256_sharded (2^14 blocks per shard)
 constexpr uint32_t BATCH_FLAG_COMPRESSED = 16u;      // with SYNTHETIC: the shard proofs were joined into ONE proof (entry 0; k proofs when the shards do not fit one join); last entry = the shape's key (8 LE words) + the shard count
 // shard proofs per join for an execution of `shards` shards of `plan`'s shape: one join while they fit (zkhip_shard_verifier_max_proofs: the
-// Poseidon2 chip's 2^21 rows -- 68 proofs of the headline shape); beyond, ceil(shards / max) joins of equal size J = ceil(shards / joins) --
+// Poseidon2 chip's 2^22 rows -- 136 proofs of the headline shape); beyond, ceil(shards / max) joins of equal size J = ceil(shards / joins) --
 // the last one repeats the execution's last shard proof to fill its J places, so that every join has the same shape, hence the same key
 uint32_t compress_join_size(const ShardPlan& plan);
 constexpr uint32_t BATCH_FLAG_KEYED = 4u;            // with INPUT_SHA256: the proof is the keyed SHA-256 MACHINE's (chip + range table), checked against a vk
