@@ -59,6 +59,19 @@ def test_big_lde_into_interleaved_columns(ctx, oracle):
     d.free(); out.free()
 
 
+def test_big_lde_at_blowup_2_takes_any_pitch(ctx, oracle):
+    # at blowup 2 the tile passes run on dense 2^20-row classes: a 2^22-row matrix may sit in rows 300 words apart (the 256-word limit of the
+    # other blowups does not apply); eight columns into a pitch of 300, offset 40, everything else untouched
+    log_n = 22
+    m = oracle.fill_uniform(SEED + 11, log_n, 8)
+    d = ctx.from_numpy(m)
+    out = ctx.from_numpy(np.full((2 << log_n, 300), 9, dtype=np.uint32))
+    ctx.coset_lde(d, log_n, 8, 1, 31, out=out, out_ld=300, out_col=40)
+    got = out.download().reshape(-1, 300)
+    assert (got[:, 40:48] == oracle.coset_lde(m, 1, 31)).all() and (got[:, :40] == 9).all() and (got[:, 48:] == 9).all()
+    d.free(); out.free()
+
+
 @pytest.mark.parametrize("log_n,width", [(21, 512), (22, 256)])
 def test_big_fullwidth_round_trip(ctx, log_n, width):
     src = ctx.fill_uniform(SEED + 77, log_n, width)
