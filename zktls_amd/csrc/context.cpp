@@ -603,9 +603,15 @@ int op_merkle_commit_mixed(zkhip_ctx* ctx, const MatDesc* mats, const int* log_h
             return ZKHIP_OK;
         }
         uint32_t* next = level + 16 * cnt;
-        ZK_HIP(launch_compress_level(level, next, cnt, ctx->stream));
         LeafArgs inj;
         if (!gather(lvl, inj)) return fail(ZKHIP_ERR_INVALID, "merkle_commit_mixed: at most 8 matrices per height");
+        if (inj.nmats && compress_inject_ok(inj)) {           // parents, row digests and the injection in one launch
+            inj.digests = next;
+            ZK_HIP(launch_compress_inject(level, inj, ctx->stream));
+            level = next;
+            continue;
+        }
+        ZK_HIP(launch_compress_level(level, next, cnt, ctx->stream));
         if (inj.nmats) {
             void* tmp;
             ZK_TRY(ctx_reserve(ctx, S_TMP, cnt * 32, &tmp));

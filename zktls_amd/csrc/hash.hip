@@ -98,6 +98,86 @@ struct hash_rows_vec_kernel_bargs { const uint32_t* mat; uint64_t ld; uint32_t w
 __global__ void __launch_bounds__(256) hash_rows_vec_kernel_batch(const hash_rows_vec_kernel_bargs* __restrict__ zk_arr) { const hash_rows_vec_kernel_bargs& zk_b = zk_arr[blockIdx.z]; hash_rows_vec_kernel_body(zk_b.mat, zk_b.ld, zk_b.width, zk_b.height, zk_b.digests); }
 
 
+// Several matrices of one height whose widths and pitches are multiples of 4 words (16-byte aligned rows): the sponge absorbs the
+// CONCATENATED row, so with quads as the unit a rate block is two consecutive quads of the virtual row, wherever the matrix boundaries
+// fall.  A cursor (matrix, quad) walks the matrices -- wave-uniform, the descriptors come from the argument block through scalar loads --
+// and every absorbed block is two (or, for a last half block, one) 16-byte loads, as in the single-matrix kernel above; the generic
+// kernel's word-by-word load_virtual costs a quarter more per permutation (profiles/r05_multichip_*: SP1's shard shape puts two to three
+// matrices on the tallest height of every commitment).
+__device__ __forceinline__ void sponge_rows_vec(const LeafArgs& a, uint64_t row, uint32_t total_q, uint32_t s[16]) {
+    int m = 0;
+    uint32_t q = 0, nq = a.mats[0].width / 4;
+    const uint4* rp = reinterpret_cast<const uint4*>(a.mats[0].ptr + row * a.mats[0].ld);
+    for (uint32_t b = 0; b < total_q; b += 2) {
+        while (q == nq) { m++; q = 0; nq = a.mats[m].width / 4; rp = reinterpret_cast<const uint4*>(a.mats[m].ptr + row * a.mats[m].ld); }
+        const uint4 v0 = rp[q++];
+        s[0] = v0.x; s[1] = v0.y; s[2] = v0.z; s[3] = v0.w;
+        if (b + 1 < total_q) {                  // (a last half block keeps the other four rate words: overwrite mode)
+            while (q == nq) { m++; q = 0; nq = a.mats[m].width / 4; rp = reinterpret_cast<const uint4*>(a.mats[m].ptr + row * a.mats[m].ld); }
+            const uint4 v1 = rp[q++];
+            s[4] = v1.x; s[5] = v1.y; s[6] = v1.z; s[7] = v1.w;
+        }
+        p2_permute_dev(s);
+    }
+}
+__device__ __forceinline__ void hash_rows_mvec_kernel_body(const LeafArgs& a, uint32_t total_q) {
+    const uint64_t row = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (row >= a.height) return;
+    uint32_t s[16];
+#pragma unroll
+    for (int i = 0; i < 16; i++) s[i] = 0u;
+    sponge_rows_vec(a, row, total_q, s);
+    uint4* d = reinterpret_cast<uint4*>(a.digests + row * 8);
+    d[0] = make_uint4(s[0], s[1], s[2], s[3]);
+    d[1] = make_uint4(s[4], s[5], s[6], s[7]);
+}
+__global__ void __launch_bounds__(256) hash_rows_mvec_kernel(LeafArgs a, uint32_t total_q) { hash_rows_mvec_kernel_body(a, total_q); }
+struct hash_rows_mvec_kernel_bargs { LeafArgs a; uint32_t total_q; static hash_rows_mvec_kernel_bargs make(LeafArgs a, uint32_t total_q) { return hash_rows_mvec_kernel_bargs{a, total_q}; } };
+__global__ void __launch_bounds__(256) hash_rows_mvec_kernel_batch(const hash_rows_mvec_kernel_bargs* __restrict__ zk_arr) { const hash_rows_mvec_kernel_bargs& zk_b = zk_arr[blockIdx.z]; hash_rows_mvec_kernel_body(zk_b.a, zk_b.total_q); }
+
+// One level of a mixed-height tree at which matrices are injected, in ONE launch: parent = compress(children), then
+// node = compress(parent, sponge(the injected matrices' row)) -- what compress_level + hash_rows (into a scratch level) + inject did in
+// three launches with the row digests and the parents making a round trip through memory each.  a.digests = the parents' level.
+__device__ __forceinline__ void compress_inject_mvec_kernel_body(const uint32_t* __restrict__ children, const LeafArgs& a, uint32_t total_q) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= a.height) return;
+    const uint4* cp = reinterpret_cast<const uint4*>(children + 16 * i);
+    const uint4 c0 = cp[0], c1 = cp[1], c2 = cp[2], c3 = cp[3];
+    uint32_t s[16] = {c0.x, c0.y, c0.z, c0.w, c1.x, c1.y, c1.z, c1.w, c2.x, c2.y, c2.z, c2.w, c3.x, c3.y, c3.z, c3.w};
+    uint32_t t[16];
+#pragma unroll
+    for (int k = 0; k < 16; k++) t[k] = 0u;
+    p2_permute_dev(s);
+    sponge_rows_vec(a, i, total_q, t);
+#pragma unroll
+    for (int k = 0; k < 8; k++) s[8 + k] = t[k];
+    p2_permute_dev(s);
+    uint4* d = reinterpret_cast<uint4*>(a.digests + i * 8);
+    d[0] = make_uint4(s[0], s[1], s[2], s[3]);
+    d[1] = make_uint4(s[4], s[5], s[6], s[7]);
+}
+__global__ void __launch_bounds__(256) compress_inject_mvec_kernel(const uint32_t* __restrict__ children, LeafArgs a, uint32_t total_q) { compress_inject_mvec_kernel_body(children, a, total_q); }
+struct compress_inject_mvec_kernel_bargs { const uint32_t* children; LeafArgs a; uint32_t total_q; static compress_inject_mvec_kernel_bargs make(const uint32_t* children, LeafArgs a, uint32_t total_q) { return compress_inject_mvec_kernel_bargs{children, a, total_q}; } };
+__global__ void __launch_bounds__(256) compress_inject_mvec_kernel_batch(const compress_inject_mvec_kernel_bargs* __restrict__ zk_arr) { const compress_inject_mvec_kernel_bargs& zk_b = zk_arr[blockIdx.z]; compress_inject_mvec_kernel_body(zk_b.children, zk_b.a, zk_b.total_q); }
+
+// every matrix: width > 0, width and pitch multiples of 4 words, 16-byte aligned base
+static bool leaf_mats_vec(const LeafArgs& a) {
+    for (int m = 0; m < a.nmats; m++) {
+        const MatDesc& d = a.mats[m];
+        if (d.width == 0 || d.width % 4 || d.ld % 4 || (reinterpret_cast<uintptr_t>(d.ptr) & 15)) return false;
+    }
+    return a.nmats >= 1;
+}
+hipError_t launch_compress_inject(const uint32_t* children, const LeafArgs& a, hipStream_t s) {
+    if (a.height == 0) return hipSuccess;
+    if (a.nmats < 1 || a.nmats > MAX_LEAF_MATS || !leaf_mats_vec(a)) return hipErrorInvalidValue;
+    uint32_t total = 0;
+    for (int m = 0; m < a.nmats; m++) total += a.mats[m].width;
+    ZK_LAUNCH(compress_inject_mvec_kernel, compress_inject_mvec_kernel_batch, compress_inject_mvec_kernel_bargs, dim3((unsigned)((a.height + 255) / 256)), dim3(256), 0, s, children, a, total / 4);
+    return hipGetLastError();
+}
+bool compress_inject_ok(const LeafArgs& a) { return a.height > coop_max_nodes() && leaf_mats_vec(a); }
+
 hipError_t launch_hash_rows(const LeafArgs& a, hipStream_t s) {
     if (a.height == 0) return hipSuccess;
     if (a.nmats < 1 || a.nmats > MAX_LEAF_MATS) return hipErrorInvalidValue;
@@ -114,6 +194,8 @@ hipError_t launch_hash_rows(const LeafArgs& a, hipStream_t s) {
                (reinterpret_cast<uintptr_t>(m0.ptr) & 15) == 0;
     if (vec)
         ZK_LAUNCH(hash_rows_vec_kernel, hash_rows_vec_kernel_batch, hash_rows_vec_kernel_bargs, grid, block, 0, s, m0.ptr, m0.ld, m0.width, a.height, a.digests);
+    else if (leaf_mats_vec(a))
+        ZK_LAUNCH(hash_rows_mvec_kernel, hash_rows_mvec_kernel_batch, hash_rows_mvec_kernel_bargs, grid, block, 0, s, a, total / 4);
     else
         ZK_LAUNCH(hash_rows_generic_kernel, hash_rows_generic_kernel_batch, hash_rows_generic_kernel_bargs, grid, block, 0, s, a, total);
     return hipGetLastError();

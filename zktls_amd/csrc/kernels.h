@@ -144,6 +144,10 @@ hipError_t launch_compress_level(const uint32_t* children, uint32_t* parents, ui
                                  hipStream_t s);
 // nodes[i] = compress(nodes[i], extra[i])  (mixed-height commitments)
 hipError_t launch_inject(uint32_t* nodes, const uint32_t* extra, uint64_t count, hipStream_t s);
+// one level with an injection in one launch: a.digests[i] = compress(compress(children[2i], children[2i+1]), sponge(row i of a.mats)),
+// i < a.height; for levels above the latency-bound regime whose matrices allow 16-byte loads (compress_inject_ok)
+bool compress_inject_ok(const LeafArgs& a);
+hipError_t launch_compress_inject(const uint32_t* children, const LeafArgs& a, hipStream_t s);
 // all remaining levels of a small subtree in one launch: `tree` points at a level with
 // `count` (<= COOP_TOP_NODES, power of two) digests followed by room for the levels above it
 hipError_t launch_compress_top(uint32_t* tree, uint32_t count, hipStream_t s);
@@ -206,11 +210,14 @@ struct QuotientArgs {
     Ext gamma, beta;
     Ext cumsum;                 // last-row constraint S = cumsum (zero unless tables look each other up)
     const uint32_t* sel_last;
+    uint32_t* addend_out;       // logup_addend_kernel: [2N][4], the LogUp constraints of every point (weights folded in), storage order
+    const uint32_t* addend;     // quotient_kernel: the same table, added on lane 0 (NULL: no lookups)
     uint32_t* out;              // [2][N][4]: chunk k, natural row j
     uint32_t* lde_out;          // optional: the value of row p also goes to lde_out[p * lde_ld + 4 * chunk ...] -- on its own coset a chunk's
     uint64_t lde_ld;            // low-degree extension IS the quotient value, so that half of the chunk LDE needs no transform
 };
 hipError_t launch_quotient(const QuotientArgs& a, hipStream_t s);
+hipError_t launch_logup_addend(const QuotientArgs& a, hipStream_t s);      // needs pairs > 0, perm, addend_out
 
 // quotient values of a constraint PROGRAM (air.h): the interpreter form of launch_quotient for an AIR supplied as data.
 constexpr uint32_t AIR_SLOT_EXTRA = 4;      // per-point slots after the two rows: is_first, is_last, is_transition, 1 (then the public values)

@@ -121,6 +121,13 @@ static int run_quotient(zkhip_ctx* ctx, const uint32_t* lde, size_t ld, int log_
     q.gamma = lu.gamma; q.beta = lu.beta; q.cumsum = lu.cumsum; q.sel_last = ctx->dom_sel_last;
     q.out = out_chunks;
     q.lde_out = lde_out; q.lde_ld = lde_ld;
+    if (lu.pairs) {                      // the LogUp constraints first, one lane per point; the chain kernel adds them in
+        void* v_add;
+        ZK_TRY(ctx_reserve(ctx, S_ADDEND, ((size_t)2 << log_n) * 16, &v_add));
+        q.addend_out = (uint32_t*)v_add;
+        ZK_HIP(launch_logup_addend(q, ctx->stream));
+        q.addend = (const uint32_t*)v_add;
+    }
     ZK_HIP(launch_quotient(q, ctx->stream));
     return ZKHIP_OK;
 }

@@ -108,6 +108,55 @@ ZK_D uint32_t row_group_sum(uint32_t v, int L) {
     if (L > 8) v = dadd(v, dpp_mov<0x140>(v));       // row_mirror: halves 0<->1
     return v;
 }
+// LogUp constraints of the in-table lookup pairs, one LANE per point (weights continue after the G main entries: L_q, then T1, T2, T3):
+//   sum_q w_q (phi_q ds_q dr_q - (dr_q - ds_q)) + F1 (S - sum_q phi_q) + F2 (S' - S - sum_q phi'_q) + F3 (S - cumsum),
+//   F1 = w_Q sel_first, F2 = w_{Q+1} sel_trans, F3 = w_{Q+2} sel_last.
+// Until round 5 the chain kernel below evaluated these inline on the first `pairs` lanes of a row's lane group: with 1 .. 4 pairs on 8 or
+// 16 lanes a wavefront waited for five to eight serial extension products on a few lanes (a 2^21 x 96 LDE with 3 pairs took 0.82 ms
+// against 0.25 without -- profiles/r05_multichip_*).  Here every lane of a wavefront has a point of its own; the chain kernel adds the
+// result on lane 0.  The weights are wave-uniform (scalar loads).
+__device__ __forceinline__ void logup_addend_kernel_body(const QuotientArgs& a) {
+    const int H = a.log_n + 1;
+    const uint32_t m = 1u << H;
+    const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= m) return;
+    const uint32_t e = __brev(p) >> (32 - H);
+    const uint32_t pn = __brev((e + 2) & (m - 1)) >> (32 - H);
+    const uint32_t* row = a.lde + (uint64_t)p * a.ld;
+    const uint32_t* prow = a.perm + (uint64_t)p * a.perm_ld;
+    const uint32_t* pnrow = a.perm + (uint64_t)pn * a.perm_ld;
+    const uint32_t* wl = a.alpha_pow + 16 * (a.width / 4);          // [Q + 3] ext weights
+    const uint32_t sel_trans = dsub(a.xs[p], a.wn_inv);
+    Ext r = ext_zero(), sphi = ext_zero(), sphin = ext_zero();
+    for (uint32_t q = 0; q < a.pairs; q++) {
+        const uint4 vs = *reinterpret_cast<const uint4*>(row + 8 * q);
+        const uint4 vr = *reinterpret_cast<const uint4*>(row + 8 * q + 4);
+        const Ext ds = ext_add(ext_add_base(a.gamma, vs.x), ext_mul_base_dev(a.beta, vs.y));
+        const Ext dr = ext_add(ext_add_base(a.gamma, vr.x), ext_mul_base_dev(a.beta, vr.y));
+        const Ext phi = ld_ext(prow + 4 * q), phin = ld_ext(pnrow + 4 * q);
+        const Ext c = ext_sub(ext_mul_dev(ext_mul_dev(phi, ds), dr), ext_sub(dr, ds));
+        r = ext_add(r, ext_mul_dev(c, ld_ext(wl + 4 * q)));
+        sphi = ext_add(sphi, phi);
+        sphin = ext_add(sphin, phin);
+    }
+    const Ext S = ld_ext(prow + 4 * a.pairs), Sn = ld_ext(pnrow + 4 * a.pairs);
+    const Ext F1 = ext_mul_base_dev(ld_ext(wl + 4 * a.pairs), a.sel_first[p]);
+    const Ext F2 = ext_mul_base_dev(ld_ext(wl + 4 * (a.pairs + 1)), sel_trans);
+    const Ext F3 = ext_mul_base_dev(ld_ext(wl + 4 * (a.pairs + 2)), a.sel_last[p]);
+    r = ext_add(r, ext_mul_dev(F1, ext_sub(S, sphi)));
+    r = ext_add(r, ext_mul_dev(F2, ext_sub(ext_sub(Sn, S), sphin)));
+    r = ext_add(r, ext_mul_dev(F3, ext_sub(S, a.cumsum)));
+    st_ext(a.addend_out + 4 * (uint64_t)p, r);
+}
+__global__ void __launch_bounds__(256) logup_addend_kernel(QuotientArgs a) { logup_addend_kernel_body(a); }
+struct logup_addend_kernel_bargs { QuotientArgs a; static logup_addend_kernel_bargs make(QuotientArgs a) { return logup_addend_kernel_bargs{a}; } };
+__global__ void __launch_bounds__(256) logup_addend_kernel_batch(const logup_addend_kernel_bargs* __restrict__ zk_arr) { const logup_addend_kernel_bargs& zk_b = zk_arr[blockIdx.z]; logup_addend_kernel_body(zk_b.a); }
+
+hipError_t launch_logup_addend(const QuotientArgs& a, hipStream_t s) {
+    const uint64_t m = 2ull << a.log_n;
+    ZK_LAUNCH(logup_addend_kernel, logup_addend_kernel_batch, logup_addend_kernel_bargs, dim3((unsigned)((m + 255) / 256)), dim3(256), 0, s, a);
+    return hipGetLastError();
+}
 constexpr int QCHAIN = 16;
 template <int NG>
 #ifndef QWPE
@@ -180,35 +229,7 @@ __device__ __forceinline__ void quotient_kernel_body(const QuotientArgs& a) {
             }
         }
         Ext r = Ext{{dacc_finish(acc[0]), dacc_finish(acc[1]), dacc_finish(acc[2]), dacc_finish(acc[3])}};
-        if (a.pairs) {
-            // LogUp constraints (weights continue after the G main entries): L_q, then T1, T2, T3.
-            // The sums over q inside T1 / T2 are distributed: pair q adds -F1 phi_q - F2 phi'_q.
-            const uint32_t* row = a.lde + (uint64_t)p * a.ld;
-            const uint32_t* prow = a.perm + (uint64_t)p * a.perm_ld;
-            const uint32_t* pnrow = a.perm + (uint64_t)pn * a.perm_ld;
-            const uint32_t* wl = a.alpha_pow + 16 * G;                 // [Q + 3] ext weights
-            const Ext F1 = ext_mul_base_dev(ld_ext(wl + 4 * a.pairs), sel_first);
-            const Ext F2 = ext_mul_base_dev(ld_ext(wl + 4 * (a.pairs + 1)), sel_trans);
-            // F1 and F2 multiply the SUMS of the lane's phi_q / phi'_q (two extension products per lane instead of two per pair)
-            Ext sphi = ext_zero(), sphin = ext_zero();
-            for (uint32_t q = lane; q < a.pairs; q += L) {
-                const uint4 vs = *reinterpret_cast<const uint4*>(row + 8 * q);
-                const uint4 vr = *reinterpret_cast<const uint4*>(row + 8 * q + 4);
-                const Ext ds = ext_add(ext_add_base(a.gamma, vs.x), ext_mul_base_dev(a.beta, vs.y));
-                const Ext dr = ext_add(ext_add_base(a.gamma, vr.x), ext_mul_base_dev(a.beta, vr.y));
-                const Ext phi = ld_ext(prow + 4 * q), phin = ld_ext(pnrow + 4 * q);
-                const Ext c = ext_sub(ext_mul_dev(ext_mul_dev(phi, ds), dr), ext_sub(dr, ds));
-                r = ext_add(r, ext_mul_dev(c, ld_ext(wl + 4 * q)));
-                sphi = ext_add(sphi, phi);
-                sphin = ext_add(sphin, phin);
-            }
-            if ((uint32_t)lane < a.pairs) r = ext_sub(r, ext_add(ext_mul_dev(F1, sphi), ext_mul_dev(F2, sphin)));
-            if (lane == 0) {
-                const Ext S = ld_ext(prow + 4 * a.pairs), Sn = ld_ext(pnrow + 4 * a.pairs);
-                const Ext F3 = ext_mul_base_dev(ld_ext(wl + 4 * (a.pairs + 2)), a.sel_last[p]);
-                r = ext_add(r, ext_add(ext_mul_dev(F1, S), ext_add(ext_mul_dev(F2, ext_sub(Sn, S)), ext_mul_dev(F3, ext_sub(S, a.cumsum)))));
-            }
-        }
+        if (a.addend && lane == 0) r = ext_add(r, ld_ext(a.addend + 4 * (uint64_t)p));     // the LogUp constraints of this point (logup_addend_kernel)
 #pragma unroll
         for (int i = 0; i < 4; i++) r.c[i] = row_group_sum(r.c[i], L);
         if (lane == 0 && live) {
