@@ -525,6 +525,10 @@ int zkhip_verify_machine(const uint8_t* proof, size_t len, const int32_t* log_ns
 typedef struct zkhip_machine_key zkhip_machine_key;
 int zkhip_machine_setup(zkhip_ctx* ctx, const zkhip_chip* pre, int n_chips, const zkhip_params* prm, zkhip_machine_key** key, uint32_t root[8]);
 void zkhip_machine_key_destroy(zkhip_machine_key* key);
+/* zkhip_machine_setup's root[8] WITHOUT a device (host only, no context, no HIP call; csrc/host_key.cpp): h_traces[c] = the chip's preprocessed
+ * trace as HOST words, [2^log_ns[c]][pre_widths[c]] in Montgomery form (NULL with width 0: none), chips tallest first.  What a verifier that
+ * owns no GPU calls to derive the key it checks proofs against (the reference verifies on the CPU: sp1.rs:120). */
+int zkhip_machine_key_host(const uint32_t* const* h_traces, const int32_t* log_ns, const uint32_t* pre_widths, int n_chips, const zkhip_params* prm, uint32_t root[8]);
 size_t zkhip_machine_proof_size_keyed(const int32_t* log_ns, const uint32_t* widths, const uint32_t* pre_widths, const uint32_t* const* programs,
                                       const size_t* program_words, const uint32_t* const* tables, const size_t* table_words, int n_chips,
                                       const zkhip_params* prm, size_t n_public);
@@ -794,6 +798,11 @@ int zkhip_prove_fri_indices_batch(const int* devices, int n_devices, zkhip_fri_j
 int zkhip_shard_verifier_setup(zkhip_ctx* ctx, int log_n, uint32_t width, size_t n_queries, int inner_pow_bits, size_t n_public, size_t n_proofs, const zkhip_params* outer,
                                zkhip_machine_key** key, uint32_t vk[8]);
 size_t zkhip_shard_verifier_proof_size(int log_n, uint32_t width, size_t n_queries, int inner_pow_bits, size_t n_public, size_t n_proofs, const zkhip_params* outer);
+/* the same key WITHOUT a device: no context, no HIP call -- the preprocessed traces are low-degree-extended and committed on the host's cores
+ * (csrc/host_key.cpp), so that a party that owns no GPU derives the key of the shape it means and checks a compressed proof with
+ * zkhip_verify_shard_recursive alone, as the reference verifies on the CPU (crates/guest-prover-sp1/src/sp1.rs:120).  vk equals
+ * zkhip_shard_verifier_setup's at every shape (headline shape, 16 proofs joined: a 2^19 x 24 table, about a second on 16 cores). */
+int zkhip_shard_verifier_key_host(int log_n, uint32_t width, size_t n_queries, int inner_pow_bits, size_t n_public, size_t n_proofs, const zkhip_params* outer, uint32_t vk[8]);
 /* the largest n_proofs ONE join takes for this inner shape: every permutation of every proof is a row of the Poseidon2 chip, which holds 2^22
  * rows under an outer proof at blowup 2 (136 proofs of the headline shape) and 2^21 under any other (68; `outer` NULL: blowup 2), and the
  * transcript table spends one preprocessed column per proof and sponge row that carries public values (497 proofs with 9 public values);

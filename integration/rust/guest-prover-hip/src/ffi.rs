@@ -153,6 +153,10 @@ extern "C" {
     pub fn zkhip_shard_verifier_setup(ctx: *mut ZkhipCtx, log_n: c_int, width: u32, n_queries: usize, inner_pow_bits: c_int, n_public: usize, n_proofs: usize,
                                       outer: *const ZkhipParams, key: *mut *mut ZkhipMachineKey, vk: *mut u32) -> c_int;
     pub fn zkhip_shard_verifier_proof_size(log_n: c_int, width: u32, n_queries: usize, inner_pow_bits: c_int, n_public: usize, n_proofs: usize, outer: *const ZkhipParams) -> usize;
+    /// the key WITHOUT a device (host cores only): what a verifier that owns no GPU derives for the shape it means
+    pub fn zkhip_shard_verifier_key_host(log_n: c_int, width: u32, n_queries: usize, inner_pow_bits: c_int, n_public: usize, n_proofs: usize, outer: *const ZkhipParams,
+                                         vk: *mut u32) -> c_int;
+    pub fn zkhip_machine_key_host(h_traces: *const *const u32, log_ns: *const i32, pre_widths: *const u32, n_chips: c_int, prm: *const ZkhipParams, root: *mut u32) -> c_int;
     pub fn zkhip_shard_verifier_max_proofs(log_n: c_int, width: u32, n_queries: usize, inner_pow_bits: c_int, n_public: usize, outer: *const ZkhipParams) -> usize;
     pub fn zkhip_prove_shard_verifier(ctx: *mut ZkhipCtx, key: *const ZkhipMachineKey, shard_proofs: *const *const u8, shard_proof_lens: *const usize, n_proofs: usize,
                                       log_n: c_int, width: u32, public_values: *const u32, n_public: usize, inner: *const ZkhipParams, outer: *const ZkhipParams,

@@ -36,7 +36,7 @@ def test_zk_shift(ctx, oracle, count, log_size):
 @pytest.mark.parametrize("ext_field", [0, 1])
 def test_mix_poly_coeffs_and_batch_evaluate_any(ctx, oracle, ext_field):
     rng = np.random.default_rng(20 + ext_field)
-    for count, input_size, ncombo in ((6, 5, 3), (1 << 12, 40, 4), ((1 << 16) + 5, 9, 2), (777, 150, 11), (64, 1, 1)):      # (11 combos: beyond the register accumulators)
+    for count, input_size, ncombo in ((6, 5, 3), (1 << 12, 40, 4), ((1 << 16) + 5, 9, 2), (777, 150, 11), (64, 1, 1), (70, 4100, 3), (1 << 12, 333, 40)):      # (4100 inputs: beyond the plan kernel's LDS, the register form with per-term fallbacks; 40 combos in runs)
         inp = rng.integers(0, P, (input_size, count), dtype=np.uint32)
         combos = rng.integers(0, ncombo, input_size, dtype=np.uint32)
         start, mix = rng.integers(0, P, 4, dtype=np.uint32), rng.integers(0, P, 4, dtype=np.uint32)
@@ -44,7 +44,7 @@ def test_mix_poly_coeffs_and_batch_evaluate_any(ctx, oracle, ext_field):
         d_out = ctx.from_numpy(out0)
         ctx.mix_poly_coeffs(d_out, start, mix, ctx.from_numpy(inp), ctx.from_raw(combos), input_size, count, ext_field)
         assert (d_out.download() == oracle.hal_mix_poly_coeffs(out0, start, mix, inp, combos, input_size, count, ext_field)).all()
-    for npoly, log_size, nev in ((3, 0, 2), (3, 4, 5), (5, 11, 9), (2, 16, 3)):
+    for npoly, log_size, nev in ((3, 0, 2), (3, 4, 5), (5, 11, 9), (2, 16, 3), (2, 10, 2), (3, 15, 4), (2, 18, 3)):
         polys = rng.integers(0, P, (npoly, 1 << log_size), dtype=np.uint32)
         which = rng.integers(0, npoly, nev, dtype=np.uint32)
         xs = rng.integers(0, P, (nev, 4), dtype=np.uint32)

@@ -23,6 +23,8 @@ def test_key_and_proof_bytes_equal_the_oracles(ctx, oracle, log_n, width, q, pb,
     sh, mains, pres, progs, tabs, pv = R.machine(inner.tobytes(), log_n, width, pubs, q, pb)
     lns = [m.shape[0].bit_length() - 1 for m in mains]
     assert key.root.tolist() == O.machine_setup(pres, lns, oprm).tolist(), "the key differs from the oracle's commitment to the restatement's preprocessed traces"
+    from zktls_amd.device import shard_verifier_key_host
+    assert shard_verifier_key_host(log_n, width, q, pb, len(pubs), prm).tolist() == key.root.tolist(), "the key computed on the host's cores (no device) differs from the device's"
     outer = ctx.prove_shard_verifier(key, inner, log_n, width, pubs, iprm, prm)
     assert outer.tobytes() == O.prove_machine_keyed(mains, pres, progs, tabs, pv, oprm).tobytes(), "outer proof bytes differ from the oracle's"
     assert verify_shard_recursive(outer, log_n, width, q, pb, pubs, key.root, prm) == (0, 0)

@@ -491,6 +491,7 @@ def _compress_api(L):
     L.zktls_guest_prove_compressed.argtypes = [C.c_int, C.c_int, C.POINTER(Plan), C.c_char_p, C.c_size_t, C.c_char_p, C.c_size_t, u8pp, szp, u8pp, szp, C.c_char_p, C.c_size_t]
     L.zktls_compress_key.argtypes = [C.c_int, C.POINTER(Plan), C.POINTER(C.c_uint32), C.c_char_p, C.c_size_t]
     L.zktls_verify_compressed_blob.argtypes = [C.c_char_p, C.c_size_t, C.POINTER(Plan), C.c_char_p, C.c_size_t, C.c_char_p, C.c_size_t, C.POINTER(C.c_uint32), C.POINTER(C.c_int)]
+    L.zktls_compress_key_host.argtypes = [C.POINTER(Plan), C.POINTER(C.c_uint32), C.c_char_p, C.c_size_t]
 
 
 def test_compress_needs_a_plan_and_a_malformed_blob_is_refused(lib):
@@ -502,6 +503,33 @@ def test_compress_needs_a_plan_and_a_malformed_blob_is_refused(lib):
     key = (C.c_uint32 * 8)()
     plan = Plan(8, 8, 3, 10, 8)
     assert lib.zktls_verify_compressed_blob(b"ZKTB" + bytes(40), 44, C.byref(plan), b"x", 1, b"y", 1, key, None) == -1
+
+
+def test_a_verifier_without_a_gpu_checks_a_compressed_blob(lib):
+    """the consumer's side of `client.verify` (sp1.rs:120) with NO device: the blob was made on an MI355X (tests/golden/make_compressed_fixture.py), the key
+    of the plan's shape is derived here on the host's cores (zktls_compress_key_host -> zkhip_shard_verifier_key_host) and equals the one the prover
+    put into the blob; no HIP call is made (this suite runs where no GPU exists)"""
+    import os
+    _compress_api(lib)
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "proofs", "compressed_blob_8x8x3.bin")
+    blob = open(path, "rb").read()
+    plan = Plan(8, 8, 3, 10, 8)
+    cbor, elf = b"\xa1transcript", b"\x7fELFprog"
+    offs, lens = (C.c_size_t * 8)(), (C.c_size_t * 8)()
+    assert lib.zktls_batch_flags(blob, len(blob)) == 1 | 16 and lib.zktls_unpack_batch(blob, len(blob), offs, lens, 8) == 2 and lens[1] == 36
+    key, err = (C.c_uint32 * 8)(), C.create_string_buffer(512)
+    assert lib.zktls_compress_key_host(C.byref(plan), key, err, 512) == 0, err.value
+    assert bytes(key) == blob[offs[1]:offs[1] + 32]                          # the key of the SHAPE: host cores and the device agree
+    reason = C.c_int(0)
+    assert lib.zktls_verify_compressed_blob(blob, len(blob), C.byref(plan), cbor, len(cbor), elf, len(elf), key, C.byref(reason)) == 0
+    assert lib.zktls_verify_compressed_blob(blob, len(blob), C.byref(plan), cbor + b"!", len(cbor) + 1, elf, len(elf), key, C.byref(reason)) == -2
+    bad = bytearray(blob)
+    bad[offs[0] + lens[0] // 2] ^= 1
+    assert lib.zktls_verify_compressed_blob(bytes(bad), len(bad), C.byref(plan), cbor, len(cbor), elf, len(elf), key, C.byref(reason)) == -2
+    plan2 = Plan(8, 16, 3, 10, 8)                                             # another shape: another key, and the blob's is refused under it
+    key2 = (C.c_uint32 * 8)()
+    assert lib.zktls_compress_key_host(C.byref(plan2), key2, err, 512) == 0 and bytes(key2) != bytes(key)
+    assert lib.zktls_verify_compressed_blob(blob, len(blob), C.byref(plan2), cbor, len(cbor), elf, len(elf), key2, C.byref(reason)) == -1
 
 
 @pytest.mark.gpu
@@ -524,6 +552,8 @@ def test_compress_stage_behind_the_same_call(lib):
     key = (C.c_uint32 * 8)()
     assert lib.zktls_compress_key(0, C.byref(plan), key, err, 512) == 0, err.value
     assert bytes(key) == blob[offs[1]:offs[1] + 32]                          # the key of the SHAPE: the same whoever computes it
+    hkey = (C.c_uint32 * 8)()
+    assert lib.zktls_compress_key_host(C.byref(plan), hkey, err, 512) == 0 and bytes(hkey) == bytes(key)      # ... the host's cores included (no device)
     reason = C.c_int(0)
     assert lib.zktls_verify_compressed_blob(blob, len(blob), C.byref(plan), cbor, len(cbor), elf, len(elf), key, C.byref(reason)) == 0
     assert lib.zktls_verify_compressed_blob(blob, len(blob), C.byref(plan), cbor + b"!", len(cbor) + 1, elf, len(elf), key, C.byref(reason)) == -2     # another request

@@ -72,6 +72,22 @@ def test_product_machine_equals_the_restatement_word_for_word():
             assert e.tolist() == want.tolist() and pw == (0 if pres[nm] is None else pres[nm].shape[1]), (nm, "preprocessed", nproofs)
 
 
+def test_host_key_equals_the_oracles_key(oracle):
+    """zkhip_shard_verifier_key_host (csrc/host_key.cpp: coset LDE and mixed-height commitment on the host's cores, no device) against the
+    oracle's machine_setup over the RESTATEMENT's preprocessed traces, at both outer blowups; the generic entry on the same tables"""
+    from zktls_amd._lib import Params, to_monty
+    from zktls_amd.device import shard_verifier_key_host, machine_key_host
+    for log_n, width, q, pb, npub, nproofs in ((5, 8, 4, 3, 3, 1), (6, 16, 5, 0, 0, 1), (5, 8, 4, 3, 3, 2), (7, 24, 9, 4, 9, 3), (5, 40, 3, 2, 11, 1), (10, 64, 6, 2, 9, 4)):
+        sh = R.Shape(log_n, width, q, pb, npub, nproofs)
+        names, pres, h = R.order(sh), R.preprocessed(sh), R.heights(sh)
+        pl, lns = [pres[n] for n in names], [h[n] for n in names]
+        for blow, nq, pw in ((1, 20, 8), (2, 10, 4)):
+            want = [int(x) for x in oracle.machine_setup(pl, lns, oracle.default_params(blow, nq, pw))]
+            assert shard_verifier_key_host(log_n, width, q, pb, npub, Params(blow, nq, pw), nproofs).tolist() == want, (log_n, width, nproofs, blow)
+        mont = [None if t is None else to_monty(t) for t in pl]
+        assert machine_key_host(mont, lns, Params(1, 20, 8)).tolist() == [int(x) for x in oracle.machine_setup(pl, lns, oracle.default_params(1, 20, 8))]
+
+
 def test_the_join_one_outer_proof_for_several_inner_proofs(oracle):
     """n_proofs inner proofs of one shape, ONE outer proof: programs hold, buses balance, the oracle proves it, three verifiers accept the public
     values of all proofs in order and refuse them swapped"""

@@ -165,32 +165,134 @@ __global__ void __launch_bounds__(256) hal_mix_poly_coeffs_kernel(uint32_t* __re
     for (int c = 0; c < MIX_REGS; c++)
         if (touched & (1u << c)) { uint32_t* o = out + 4 * ((uint64_t)c * count + idx); st_ext(o, ext_add_d(ld_ext(o), acc[c])); }
 }
-// out[e] = polynomial which[e] at xs[e]: one workgroup of 1024 lanes per evaluation (the Horner chains are sequential: sixteen waves
-// per evaluation keep the SIMDs of a CU fed).  Lane t takes the coefficients i = t mod 1024 (a wave reads 256 consecutive bytes per
-// step): Horner in y = x^1024 over c[t], c[t + 1024], ..., from the top; the partial value is scaled by x^t and the partial values
-// are summed in LDS.
-constexpr uint32_t EVAL_T = 1024, EVAL_LOG_T = 10;
+// ---- the same operator with the terms GROUPED BY COMBO (round 5).  A plan kernel (one workgroup) ranks the inputs by (combo, index) and
+// writes, in that order, the input's row number, its mix power and its combo, plus for the first term of every combo where the combo's
+// run ends.  The streaming kernel then walks whole runs: ONE set of four 64-bit running sums per run (dacc2: two multiply-adds and one
+// conditional subtraction per pair of terms and component, no Montgomery reduction until the run ends), eight input words per lane in
+// flight, the powers and row numbers wave-uniform (scalar loads), one read-modify-write of the output per (combo, idx) -- for ANY number
+// of combos (the register form above spills to per-term read-modify-writes beyond eight).  The sum is exact field arithmetic, so the
+// order of the terms does not show in the result.
+constexpr uint32_t MIX_PLAN_MAX = 4096;                          // inputs the plan kernel ranks in LDS; longer lists keep the form above
+__global__ void __launch_bounds__(256) hal_mix_plan_kernel(const uint32_t* __restrict__ combos, const uint32_t* __restrict__ powers, uint32_t n,
+                                                           uint32_t* __restrict__ spow, uint32_t* __restrict__ srow, uint32_t* __restrict__ scombo, uint32_t* __restrict__ send) {
+    __shared__ uint32_t cb[MIX_PLAN_MAX], sc[MIX_PLAN_MAX];
+    for (uint32_t i = threadIdx.x; i < n; i += blockDim.x) cb[i] = combos[i];
+    __syncthreads();
+    for (uint32_t i = threadIdx.x; i < n; i += blockDim.x) {
+        const uint32_t c = cb[i];
+        uint32_t rank = 0;
+        for (uint32_t j = 0; j < n; j++) rank += (cb[j] < c || (cb[j] == c && j < i)) ? 1u : 0u;
+        srow[rank] = i; scombo[rank] = c; sc[rank] = c;
+        st_ext(spow + 4 * (uint64_t)rank, ld_ext(powers + 4 * (uint64_t)i));
+    }
+    __syncthreads();
+    for (uint32_t r = threadIdx.x; r < n; r += blockDim.x) {
+        uint32_t e = 0;
+        if (r == 0 || sc[r - 1] != sc[r]) { e = r + 1; while (e < n && sc[e] == sc[r]) e++; }
+        send[r] = e;                                           // end of the run that starts here (0: not a start)
+    }
+}
+__global__ void __launch_bounds__(256) hal_mix_sorted_kernel(uint32_t* __restrict__ out, const uint32_t* __restrict__ in, const uint32_t* __restrict__ spow,
+                                                             const uint32_t* __restrict__ srow, const uint32_t* __restrict__ scombo, const uint32_t* __restrict__ send,
+                                                             uint32_t n, uint64_t count) {
+    const uint64_t idx = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= count) return;
+    const uint32_t* col = in + idx;
+    uint32_t r = 0;
+    while (r < n) {
+        const uint32_t combo = __builtin_amdgcn_readfirstlane(scombo[r]), end = __builtin_amdgcn_readfirstlane(send[r]);
+        uint64_t s0 = 0, s1 = 0, s2 = 0, s3 = 0;
+        constexpr int AHEAD = 8;
+        for (; r + AHEAD <= end; r += AHEAD) {
+            uint32_t v[AHEAD];
+#pragma unroll
+            for (int u = 0; u < AHEAD; u++) v[u] = __builtin_nontemporal_load(col + (uint64_t)__builtin_amdgcn_readfirstlane(srow[r + u]) * count);
+#pragma unroll
+            for (int u = 0; u < AHEAD; u += 2) {
+                const uint4 pa = *reinterpret_cast<const uint4*>(spow + 4 * (uint64_t)(r + u)), pb = *reinterpret_cast<const uint4*>(spow + 4 * (uint64_t)(r + u + 1));
+                const uint32_t a0 = __builtin_amdgcn_readfirstlane(pa.x), a1 = __builtin_amdgcn_readfirstlane(pa.y), a2 = __builtin_amdgcn_readfirstlane(pa.z), a3 = __builtin_amdgcn_readfirstlane(pa.w);
+                const uint32_t b0 = __builtin_amdgcn_readfirstlane(pb.x), b1 = __builtin_amdgcn_readfirstlane(pb.y), b2 = __builtin_amdgcn_readfirstlane(pb.z), b3 = __builtin_amdgcn_readfirstlane(pb.w);
+                dacc2(s0, a0, v[u], b0, v[u + 1]); dacc2(s1, a1, v[u], b1, v[u + 1]);
+                dacc2(s2, a2, v[u], b2, v[u + 1]); dacc2(s3, a3, v[u], b3, v[u + 1]);
+            }
+        }
+        for (; r < end; r++) {
+            const uint32_t v = __builtin_nontemporal_load(col + (uint64_t)__builtin_amdgcn_readfirstlane(srow[r]) * count);
+            const uint4 pa = *reinterpret_cast<const uint4*>(spow + 4 * (uint64_t)r);
+            dacc2(s0, (uint32_t)__builtin_amdgcn_readfirstlane(pa.x), v, 0u, 0u); dacc2(s1, (uint32_t)__builtin_amdgcn_readfirstlane(pa.y), v, 0u, 0u);
+            dacc2(s2, (uint32_t)__builtin_amdgcn_readfirstlane(pa.z), v, 0u, 0u); dacc2(s3, (uint32_t)__builtin_amdgcn_readfirstlane(pa.w), v, 0u, 0u);
+        }
+        uint32_t* o = out + 4 * ((uint64_t)combo * count + idx);
+        st_ext(o, ext_add_d(ld_ext(o), Ext{{dacc_finish(s0), dacc_finish(s1), dacc_finish(s2), dacc_finish(s3)}}));
+    }
+}
+// out[e] = polynomial which[e] at xs[e].  One workgroup of 1024 lanes per evaluation; lane t takes the coefficients i = t mod 1024 (a wave
+// reads 256 consecutive bytes per step) and evaluates sum_k c[t + 1024 k] y^k with y = x^1024, which is WORKGROUP-UNIFORM: the powers
+// y^0 .. y^31 come from a small table (a tables kernel writes it per evaluation; scalar loads here), so a coefficient costs FOUR
+// multiply-adds into 64-bit running sums (base x extension, dacc2: no Montgomery reduction until a block of 32 coefficients ends) and
+// one extension product by y^32 per block -- 5 products per 4 bytes instead of the 19 of a Horner step in the extension field (round 4),
+// which made the operator arithmetic-bound at 0.22 of the HBM peak.  The partial value is scaled by x^t = x^(t mod 64) (x^64)^(t div 64)
+// (two more table rows) and the lanes are summed in LDS.
+constexpr uint32_t EVAL_T = 1024, EVAL_BLK = 32;
+constexpr uint32_t EVAL_TAB = 64 + 16 + EVAL_BLK + 1;             // per evaluation: x^l (l < 64), x^(64 w) (w < 16), y^j (j <= 32), extension elements
+template <uint32_t W>
+__global__ void __launch_bounds__(64) hal_eval_tables_kernel(const uint32_t* __restrict__ xs, uint32_t* __restrict__ tab) {
+    const uint32_t e = blockIdx.x, l = threadIdx.x;
+    Ext sq[16];                                                // x^(2^k)
+    sq[0] = ld_ext(xs + 4 * (uint64_t)e);
+#pragma unroll
+    for (int k = 1; k < 16; k++) sq[k] = ext_mul_t<W>(sq[k - 1], sq[k - 1]);
+    uint32_t* t = tab + 4 * (uint64_t)EVAL_TAB * e;
+    Ext a = ext_one(), b = ext_one(), c = ext_one();
+#pragma unroll
+    for (int k = 0; k < 6; k++) {
+        if ((l >> k) & 1u) { a = ext_mul_t<W>(a, sq[k]); c = ext_mul_t<W>(c, sq[10 + k]); }
+        if (k < 4 && ((l >> k) & 1u)) b = ext_mul_t<W>(b, sq[6 + k]);
+    }
+    st_ext(t + 4 * l, a);
+    if (l < 16) st_ext(t + 4 * (64 + l), b);
+    if (l < EVAL_BLK) st_ext(t + 4 * (80 + l), c);
+    if (l == 0) st_ext(t + 4 * (80 + EVAL_BLK), sq[15]);       // y^32 = x^32768
+}
 template <uint32_t W>
 __global__ void __launch_bounds__(EVAL_T) hal_batch_evaluate_any_kernel(const uint32_t* __restrict__ coeffs, int log_size, const uint32_t* __restrict__ which,
-                                                                        const uint32_t* __restrict__ xs, uint32_t* __restrict__ out) {
+                                                                        const uint32_t* __restrict__ tab, uint32_t* __restrict__ out) {
     __shared__ uint32_t part[EVAL_T][4];
     const uint64_t n = (uint64_t)1 << log_size;
     const uint32_t e = blockIdx.x, t = threadIdx.x;
-    const uint32_t* c = coeffs + (uint64_t)which[e] * n;
-    const Ext x = ld_ext(xs + 4 * (uint64_t)e);
+    const uint32_t* c = coeffs + (uint64_t)which[e] * n + t;
+    const uint32_t* tb = tab + 4 * (uint64_t)EVAL_TAB * e;
+    const uint32_t* yp = tb + 4 * 80;
+    const uint64_t m = n >= EVAL_T ? n / EVAL_T : 1;           // coefficients per lane (lanes t >= n of a short polynomial hold none)
+    const bool live = t < n;
     Ext acc = ext_zero();
-    if (t < n) {
-        Ext y = x;                                             // x^1024
-        for (uint32_t k = 0; k < EVAL_LOG_T; k++) y = ext_mul_t<W>(y, y);
-        const uint64_t top = t + ((n - 1 - t) / EVAL_T) * EVAL_T;    // the largest i = t mod 1024 below n
-        for (uint64_t i = top;; i -= EVAL_T) {
-            acc = ext_mul_t<W>(acc, y);
-            acc.c[0] = dadd(acc.c[0], __builtin_nontemporal_load(c + i));
-            if (i < EVAL_T) break;
+    const uint4 yt = *reinterpret_cast<const uint4*>(yp + 4 * EVAL_BLK);
+    const Ext y32{{(uint32_t)__builtin_amdgcn_readfirstlane(yt.x), (uint32_t)__builtin_amdgcn_readfirstlane(yt.y),
+                   (uint32_t)__builtin_amdgcn_readfirstlane(yt.z), (uint32_t)__builtin_amdgcn_readfirstlane(yt.w)}};
+    for (uint64_t b = (m + EVAL_BLK - 1) / EVAL_BLK; b-- > 0;) {
+        uint32_t v[EVAL_BLK];
+#pragma unroll
+        for (uint32_t j = 0; j < EVAL_BLK; j++) {
+            const uint64_t k = b * EVAL_BLK + j;
+            v[j] = (live && k < m) ? __builtin_nontemporal_load(c + k * EVAL_T) : 0u;
         }
-        Ext pw = ext_one(), b = x;                             // x^t by square and multiply
-        for (uint32_t k = t; k; k >>= 1) { if (k & 1) pw = ext_mul_t<W>(pw, b); b = ext_mul_t<W>(b, b); }
-        acc = ext_mul_t<W>(acc, pw);
+        acc = ext_mul_t<W>(acc, y32);
+        uint64_t s0 = 0, s1 = 0, s2 = 0, s3 = 0;
+#pragma unroll
+        for (uint32_t j = 0; j < EVAL_BLK; j += 2) {
+            const uint4 pa = *reinterpret_cast<const uint4*>(yp + 4 * j), pb = *reinterpret_cast<const uint4*>(yp + 4 * (j + 1));
+            const uint32_t a0 = __builtin_amdgcn_readfirstlane(pa.x), a1 = __builtin_amdgcn_readfirstlane(pa.y), a2 = __builtin_amdgcn_readfirstlane(pa.z), a3 = __builtin_amdgcn_readfirstlane(pa.w);
+            const uint32_t b0 = __builtin_amdgcn_readfirstlane(pb.x), b1 = __builtin_amdgcn_readfirstlane(pb.y), b2 = __builtin_amdgcn_readfirstlane(pb.z), b3 = __builtin_amdgcn_readfirstlane(pb.w);
+            dacc2(s0, a0, v[j], b0, v[j + 1]); dacc2(s1, a1, v[j], b1, v[j + 1]);
+            dacc2(s2, a2, v[j], b2, v[j + 1]); dacc2(s3, a3, v[j], b3, v[j + 1]);
+        }
+        acc = ext_add_d(acc, Ext{{dacc_finish(s0), dacc_finish(s1), dacc_finish(s2), dacc_finish(s3)}});
+    }
+    {   // x^t = x^(t mod 64) (x^64)^(t div 64)
+        const uint4 wv = *reinterpret_cast<const uint4*>(tb + 4 * (64 + (t >> 6)));
+        const Ext xw{{(uint32_t)__builtin_amdgcn_readfirstlane(wv.x), (uint32_t)__builtin_amdgcn_readfirstlane(wv.y),
+                      (uint32_t)__builtin_amdgcn_readfirstlane(wv.z), (uint32_t)__builtin_amdgcn_readfirstlane(wv.w)}};
+        acc = ext_mul_t<W>(ext_mul_t<W>(acc, ld_ext(tb + 4 * (t & 63u))), xw);
     }
     for (int k = 0; k < 4; k++) part[t][k] = acc.c[k];
     __syncthreads();
@@ -431,6 +533,16 @@ int zkhip_mix_poly_coeffs(zkhip_ctx* ctx, uint32_t* d_out, const uint32_t mix_st
     if (ext_field == ZKHIP_EXT_X4_PLUS_11) hipLaunchKernelGGL((hal_mix_powers_kernel<MONTY_W_R0>), dim3(1), dim3(64), 0, ctx->stream, powers, ms, mx, (uint64_t)input_size);
     else hipLaunchKernelGGL((hal_mix_powers_kernel<MONTY_W_SP1>), dim3(1), dim3(64), 0, ctx->stream, powers, ms, mx, (uint64_t)input_size);
     LAUNCHED();
+    if (input_size <= MIX_PLAN_MAX) {                            // terms grouped by combo: one set of running sums per run, any number of combos
+        void* v_plan;
+        ZK_TRY(ctx_reserve(ctx, S_COL_A, input_size * 28, &v_plan));
+        uint32_t *spow = (uint32_t*)v_plan, *srow = spow + 4 * input_size, *scombo = srow + input_size, *send = scombo + input_size;
+        hipLaunchKernelGGL(hal_mix_plan_kernel, dim3(1), dim3(256), 0, ctx->stream, d_combos, powers, (uint32_t)input_size, spow, srow, scombo, send);
+        LAUNCHED();
+        hipLaunchKernelGGL(hal_mix_sorted_kernel, dim3((unsigned)((count + 255) / 256)), dim3(256), 0, ctx->stream, d_out, d_in, spow, srow, scombo, send, (uint32_t)input_size, (uint64_t)count);
+        LAUNCHED();
+        return ZKHIP_OK;
+    }
     hipLaunchKernelGGL(hal_mix_poly_coeffs_kernel, dim3((unsigned)((count + 255) / 256)), dim3(256), 0, ctx->stream, d_out, powers, d_in, d_combos, (uint64_t)input_size, (uint64_t)count);
     LAUNCHED();
     return ZKHIP_OK;
@@ -441,8 +553,16 @@ int zkhip_batch_evaluate_any(zkhip_ctx* ctx, const uint32_t* d_coeffs, int log_s
     if (!d_coeffs || !d_which || !d_xs || !d_out || log_size < 0 || log_size > 30 || !ext_field_ok(ext_field) || (reinterpret_cast<uintptr_t>(d_xs) & 15))
         return fail(ZKHIP_ERR_INVALID, "batch_evaluate_any: bad arguments");
     if (!eval_count) return ZKHIP_OK;
-    if (ext_field == ZKHIP_EXT_X4_PLUS_11) hipLaunchKernelGGL((hal_batch_evaluate_any_kernel<MONTY_W_R0>), dim3((unsigned)eval_count), dim3(EVAL_T), 0, ctx->stream, d_coeffs, log_size, d_which, d_xs, d_out);
-    else hipLaunchKernelGGL((hal_batch_evaluate_any_kernel<MONTY_W_SP1>), dim3((unsigned)eval_count), dim3(EVAL_T), 0, ctx->stream, d_coeffs, log_size, d_which, d_xs, d_out);
+    void* v_tab;
+    ZK_TRY(ctx_reserve(ctx, S_COL_B, eval_count * EVAL_TAB * 16, &v_tab));
+    uint32_t* tab = (uint32_t*)v_tab;
+    if (ext_field == ZKHIP_EXT_X4_PLUS_11) {
+        hipLaunchKernelGGL((hal_eval_tables_kernel<MONTY_W_R0>), dim3((unsigned)eval_count), dim3(64), 0, ctx->stream, d_xs, tab);
+        hipLaunchKernelGGL((hal_batch_evaluate_any_kernel<MONTY_W_R0>), dim3((unsigned)eval_count), dim3(EVAL_T), 0, ctx->stream, d_coeffs, log_size, d_which, tab, d_out);
+    } else {
+        hipLaunchKernelGGL((hal_eval_tables_kernel<MONTY_W_SP1>), dim3((unsigned)eval_count), dim3(64), 0, ctx->stream, d_xs, tab);
+        hipLaunchKernelGGL((hal_batch_evaluate_any_kernel<MONTY_W_SP1>), dim3((unsigned)eval_count), dim3(EVAL_T), 0, ctx->stream, d_coeffs, log_size, d_which, tab, d_out);
+    }
     LAUNCHED();
     return ZKHIP_OK;
 }

@@ -1086,6 +1086,35 @@ int zkhip_shard_verifier_setup(zkhip_ctx* ctx, int log_n, uint32_t width, size_t
     return zkhip_machine_setup(ctx, chips, N_CHIPS, outer, key, vk);
 }
 
+// The same key WITHOUT a device (round 5; host_key.cpp): the preprocessed traces are host tables anyway -- their low-degree extensions and the
+// mixed-height Poseidon2 commitment are computed on the host's cores, so that a verifier that owns no GPU derives the key of the shape it
+// means by itself (the reference verifies on the CPU: sp1.rs:120).  Equal to zkhip_shard_verifier_setup's vk at every shape.
+int zkhip_shard_verifier_key_host(int log_n, uint32_t width, size_t n_queries, int inner_pow_bits, size_t n_public, size_t n_proofs, const zkhip_params* outer, uint32_t vk[8]) {
+    using namespace zk::rec;
+    try {
+        if (!outer || !vk) return fail(ZKHIP_ERR_INVALID, "shard_verifier_key_host: null argument");
+        Shape sh;
+        ZK_TRY(make_shape(log_n, width, n_queries, inner_pow_bits, n_public, n_proofs, sh));
+        ZK_TRY(check_outer(sh, outer));
+        const auto mp = machine_of(sh);
+        const Machine& m = *mp;
+        std::vector<uint32_t> pre[N_CHIPS];
+        p2r_pre(sh, m.height[C_P2R], pre[C_P2R]); rowsum_pre(sh, m.height[C_ROWSUM], pre[C_ROWSUM]); ts_pre(sh, m.height[C_TS], pre[C_TS]);
+        query_pre(sh, m.height[C_QUERY], pre[C_QUERY]); opened_pre(sh, m.height[C_OPENED], pre[C_OPENED]); scalars_pre(sh, m.height[C_SCALARS], pre[C_SCALARS]);
+        samples_pre_all(sh, m.height[C_SAMPLES], pre[C_SAMPLES]);
+        const uint32_t* traces[N_CHIPS]; int32_t lns[N_CHIPS]; uint32_t pws[N_CHIPS];
+        for (int i = 0; i < N_CHIPS; i++) {
+            const int c = m.order[i];
+            lns[i] = m.height[c]; pws[i] = m.pre_widths[i];
+            traces[i] = pre[c].empty() ? nullptr : pre[c].data();
+            if (pre[c].empty()) pws[i] = 0;
+        }
+        return zkhip_machine_key_host(traces, lns, pws, N_CHIPS, outer, vk);
+    } catch (const std::bad_alloc&) {
+        return fail(ZKHIP_ERR_NOMEM, "shard_verifier_key_host: out of host memory");
+    }
+}
+
 // the largest n_proofs one join takes for this inner shape: the Poseidon2 chip holds every permutation of every proof in at most 2^22 rows
 // (2^21 when the outer proof's blowup is not 2)
 size_t zkhip_shard_verifier_max_proofs(int log_n, uint32_t width, size_t n_queries, int inner_pow_bits, size_t n_public, const zkhip_params* outer) {

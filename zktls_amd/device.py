@@ -1146,6 +1146,26 @@ def verify_shard_recursive(proof, log_n, width, n_queries, inner_pow_bits, publi
     return rc, reason.value
 
 
+def shard_verifier_key_host(log_n, width, n_queries, inner_pow_bits, n_public, params=None, n_proofs=1):
+    """zkhip_shard_verifier_key_host: the key of the shape computed on the HOST (no context, no device) -> 8 canonical words"""
+    params = params or Params()
+    vk = np.zeros(8, dtype=np.uint32)
+    check(_lib.load().zkhip_shard_verifier_key_host(log_n, width, n_queries, inner_pow_bits, n_public, n_proofs, C.byref(params), vk.ctypes.data_as(u32p)))
+    return vk
+
+
+def machine_key_host(traces, log_ns, params=None):
+    """zkhip_machine_key_host: traces[c] = None or a [2^log_n][pre_width] array of MONTGOMERY words (host) -> the key's 8 canonical words"""
+    params = params or Params()
+    arrs = [None if t is None else np.ascontiguousarray(t, dtype=np.uint32) for t in traces]
+    ptrs = (u32p * len(arrs))(*[None if a is None else a.ctypes.data_as(u32p) for a in arrs])
+    lns = (C.c_int32 * len(arrs))(*[int(x) for x in log_ns])
+    pws = np.array([0 if a is None else a.shape[1] for a in arrs], dtype=np.uint32)
+    root = np.zeros(8, dtype=np.uint32)
+    check(_lib.load().zkhip_machine_key_host(ptrs, lns, pws.ctypes.data_as(u32p), len(arrs), C.byref(params), root.ctypes.data_as(u32p)))
+    return root
+
+
 def shard_verifier_max_proofs(log_n, width, n_queries, inner_pow_bits, n_public, outer=None):
     """zkhip_shard_verifier_max_proofs (host): how many shard proofs of this shape ONE join takes (outer: the outer proof's params; None = blowup 2)"""
     return int(_lib.load().zkhip_shard_verifier_max_proofs(log_n, width, n_queries, inner_pow_bits, n_public, C.byref(outer) if outer is not None else None))

@@ -524,6 +524,14 @@ bool compress_key(int device, const ShardPlan& plan, uint32_t key_out[8], std::s
     return ok;
 }
 
+// the same key on the host's cores: no context, no device (zkhip_shard_verifier_key_host) -- what a verifier without a GPU calls
+bool compress_key_host(const ShardPlan& plan, uint32_t key_out[8], std::string* error) {
+    const zkhip_params outer{1, plan.num_queries, plan.pow_bits, 0, 0, 0, 0, 0};
+    const bool ok = zkhip_shard_verifier_key_host(plan.log_n, plan.width, (size_t)plan.num_queries, plan.pow_bits, 9, compress_join_size(plan), &outer, key_out) == ZKHIP_OK;
+    if (!ok && error) *error = zkhip_last_error();
+    return ok;
+}
+
 void release_cached() {
     std::vector<Slot> all;
     { std::lock_guard<std::mutex> lk(g_slots_mu); all.swap(g_slots); }
@@ -597,6 +605,15 @@ int zktls_compress_key(int device, const zktls_shard_plan* plan, uint32_t key[8]
     sp.log_n = plan->log_n; sp.width = plan->width; sp.shards = plan->shards; sp.num_queries = plan->num_queries; sp.pow_bits = plan->pow_bits;
     std::string e;
     if (zktls::compress_key(device, sp, key, &e)) return 0;
+    if (err && err_cap) { std::strncpy(err, e.c_str(), err_cap - 1); err[err_cap - 1] = 0; }
+    return -1;
+}
+// ... and without a device: the verifier's side of `client.verify` (sp1.rs:120) for a compressed blob needs this and zktls_verify_compressed_blob only
+int zktls_compress_key_host(const zktls_shard_plan* plan, uint32_t key[8], char* err, size_t err_cap) {
+    zktls::ShardPlan sp;
+    sp.log_n = plan->log_n; sp.width = plan->width; sp.shards = plan->shards; sp.num_queries = plan->num_queries; sp.pow_bits = plan->pow_bits;
+    std::string e;
+    if (zktls::compress_key_host(sp, key, &e)) return 0;
     if (err && err_cap) { std::strncpy(err, e.c_str(), err_cap - 1); err[err_cap - 1] = 0; }
     return -1;
 }

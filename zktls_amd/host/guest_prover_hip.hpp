@@ -160,6 +160,8 @@ int verify_compressed_blob(const std::vector<uint8_t>& blob, const ShardPlan& pl
                            const uint32_t key[8], int* reason = nullptr);
 // the key of the shard-verifier machine for `plan` (zkhip_shard_verifier_setup on `device`)
 bool compress_key(int device, const ShardPlan& plan, uint32_t key[8], std::string* error = nullptr);
+// the same key computed on the host's cores (no device, no context): a verifier that owns no GPU checks a compressed blob with this and verify_compressed_blob
+bool compress_key_host(const ShardPlan& plan, uint32_t key[8], std::string* error = nullptr);
 std::vector<uint8_t> pack_shard_proofs(const std::vector<std::vector<uint8_t>>& proofs, uint32_t flags);
 bool unpack_shard_proofs(const std::vector<uint8_t>& blob, std::vector<std::vector<uint8_t>>* proofs, uint32_t* flags = nullptr);
 
