@@ -55,7 +55,7 @@ def main():
     start, mix = rng.integers(0, P, 4, dtype=np.uint32), rng.integers(0, P, 4, dtype=np.uint32)
     for ef in (0, 1):
         ms, _ = t.time(lambda: ctx.mix_poly_coeffs(mo, start, mix, polys, combos, cols, rows, ef), reps=10, warm=2)
-        row("mix_poly_coeffs (ext %d)" % ef, "hal_mix_powers_kernel + hal_mix_poly_coeffs_kernel", ms, 4.0 * rows * cols + 32.0 * ncombo * rows,
+        row("mix_poly_coeffs (ext %d)" % ef, "hal_mix_powers + hal_mix_plan + hal_mix_sorted_kernel", ms, 4.0 * rows * cols + 32.0 * ncombo * rows,
             "%d inputs of 2^%d into %d combos: read 4 B per input element + one read-modify-write per combo" % (cols, args.log_rows, ncombo))
     # batch_evaluate_any: every polynomial at two points
     nev = 2 * cols
@@ -64,7 +64,7 @@ def main():
     eo = ctx.alloc(4 * nev)
     for ef in (0, 1):
         ms, _ = t.time(lambda: ctx.batch_evaluate_any(polys, args.log_rows, which, xs, ef, out=eo), reps=5, warm=1)
-        row("batch_evaluate_any (ext %d)" % ef, "hal_batch_evaluate_any_kernel", ms, 4.0 * rows * nev, "%d evaluations of 2^%d-coefficient polynomials" % (nev, args.log_rows))
+        row("batch_evaluate_any (ext %d)" % ef, "hal_eval_tables + hal_batch_evaluate_any_kernel", ms, 4.0 * rows * nev, "%d evaluations of 2^%d-coefficient polynomials" % (nev, args.log_rows))
     # gather_sample: one row of a [size][stride] matrix
     ms, _ = t.time(lambda: ctx.gather_sample(polys, 5, rows, cols), reps=10, warm=2)
     row("gather_sample", "hal_gather_sample_kernel", ms, 8.0 * rows, "2^%d samples at stride %d words (a 4-byte gather: 64 B lines fetched for 4 B used)" % (args.log_rows, cols))

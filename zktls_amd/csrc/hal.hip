@@ -9,7 +9,7 @@
 // (RISC Zero's x^4 + 11).  All of these are HBM-bound streaming or gather kernels (no MFMA, nothing to tile).  The streaming ones
 // move 16 bytes per lane and instruction where alignment allows (add, zeroize, zk_shift, sum), mix_poly_coeffs keeps its
 // accumulators in registers and reads the (wave-uniform) mix powers from a small table, batch_evaluate_any reads its coefficients
-// coalesced (lane t takes coefficients t mod 256).  Measured per operator at RISC Zero's sizes: profiles/r04_hal_ops.md.
+// coalesced (lane t takes coefficients t mod 1024).  Measured per operator at RISC Zero's sizes: profiles/r05_hal_ops.md.
 #include "context.h"
 
 namespace zk {
