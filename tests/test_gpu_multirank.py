@@ -83,3 +83,24 @@ def test_multi_device_entries_on_two_logical_devices():
     r = json.loads([ln for ln in p.stdout.decode().splitlines() if ln.startswith("{")][-1])
     assert r["logical_devices"] == 2 and r["device_traces_dealt_where_they_live"] == 6 and r["misplaced_trace_refused"] is True
     assert r["null_device_list_same_bytes"] is True and r["lockstep_small_shards"] == 16 and r["host_traces"] == 5 and r["transcripts_over_the_device_list"] == 8
+
+
+def test_dry_run_of_the_eight_gpu_configuration_on_logical_devices():
+    """the 8-GPU configuration dry-run LOGICALLY on the one GPU -- a device list of eight (A/B build), four shards in flight per
+    device = 32 prover threads under the container's CPU quota, so `--wait auto` must pick blocking waits; every shard proven exactly once.  No
+    scaling number comes out of this; it removes first-contact failures from the day an 8-GPU node exists."""
+    r = run_bench("--gpus", "8", "--one-process", "--logical-devices", "8", "--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--no-batch64",
+                  "--no-recursion16", "--log-n", "18", "--width", "64", timeout=1500)
+    assert r["one_process_mode"] is True and r["n_gpus"] == 8 and r["logical_devices_test_mode"] == 8
+    assert r["shards_proven"] == 16 and r["distinct_shards_proven"] == 16
+    assert r["host_wait"] == "block" and r["host_cores_busy_per_rank"] is not None
+    assert r["verified"] is True and r["value"] > 0
+
+
+def test_dry_run_of_eight_ranks_sharing_the_one_gpu():
+    """the rank-per-GPU path at world size 8 (gloo collectives: RCCL refuses several ranks on one device): dealing, seed broadcast, max-over-ranks
+    timing and the digest gather with eight processes; blocking waits by default for N >= 4"""
+    r = run_bench("--gpus", "8", "--share-gpu", "--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--log-n", "18", "--width", "64", timeout=1500)
+    assert r["n_gpus"] == 8 and r["rccl_world_size"] == 8 and r["share_gpu_test_mode"] is True and r["collective_backend"] == "gloo"
+    assert r["shards_proven"] == 16 and r["distinct_shards_proven"] == 16 and r["shard_digests_gathered"] == 16
+    assert r["host_wait"] == "block" and r["verified"] is True and r["value"] > 0
