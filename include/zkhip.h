@@ -186,7 +186,7 @@ int zkhip_gen_trace_logup_cross(zkhip_ctx* ctx, uint64_t seed, uint64_t shard, u
  * definition, out of place).  Up to 2^20 rows a transform is two launches of the pass kernel; 2^21 and 2^22 rows (SP1 core
  * shards reach those heights: reference benchmark.md:9) add one streaming radix-2 / radix-4 pass and take a row pitch of at
  * most 512 / 256 words -- except zkhip_coset_lde at log_blowup 1, which runs its tile passes on dense 2^20-row classes and takes any
- * pitch (up to 1023 columns). ---- */
+ * pitch (up to 1024 columns). ---- */
 /* forward DFT: natural rows in; rows out natural (bitrev_out = 0) or bit-reversed (1);
  * inverse DFT (inverse = 1): natural in, natural out, scaled by 1/N. */
 int zkhip_dft(zkhip_ctx* ctx, const uint32_t* d_in, size_t in_ld, uint32_t* d_out, size_t out_ld,
@@ -270,7 +270,7 @@ int zkhip_eltwise_zeroize(zkhip_ctx* ctx, uint32_t* d_io, size_t n);
 /* Hal::eltwise_sum_extelem: out[i] = sum_j in[j * count + i] over extension elements (i < count, j < to_add) */
 int zkhip_eltwise_sum_ext(zkhip_ctx* ctx, uint32_t* d_out, const uint32_t* d_in, size_t count, size_t to_add);
 /* Hal::zk_shift: coefficient i of each of `count` polynomials of 2^log_size coefficients times shift^i (RISC Zero shifts
- * by 3); `shift` canonical */
+ * by 3); `shift` canonical.  Any 4-byte-aligned d_io (a slice inside a larger buffer: 16-byte alignment only selects the faster form), any count */
 int zkhip_zk_shift(zkhip_ctx* ctx, uint32_t* d_io, size_t count, int log_size, uint32_t shift);
 /* Hal::mix_poly_coeffs: d_out[combos[i] * count + idx] += mix_start * mix^i * d_in[i * count + idx], i < input_size, idx < count;
  * d_out holds extension elements ([n_combos][count]), d_in base elements ([input_size][count]), d_combos device u32 */
@@ -825,6 +825,9 @@ size_t zkhip_shard_verifier_describe(int log_n, uint32_t width, size_t n_queries
  * zkhip_release_cached_contexts first): a context uploads the set in effect to its device when it is created. ---- */
 /* (not thread-safe against any other call into the library, host-only entries included: load at start-up) */
 int zkhip_load_poseidon2_params(const char* path);
+/* a counter that moves whenever the table set in effect changes (each successful load, each reset): a caller that keeps values derived from
+ * the tables across calls -- a machine key, a verifying key -- stores it beside them and drops them when it differs */
+uint64_t zkhip_poseidon2_params_generation(void);
 int zkhip_reset_poseidon2_params(void);                 /* back to the built-in sets */
 const char* zkhip_poseidon2_params_name(int width);     /* name of the set in effect (thread-local copy) */
 

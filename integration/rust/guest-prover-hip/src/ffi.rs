@@ -153,6 +153,7 @@ extern "C" {
     pub fn zkhip_shard_verifier_setup(ctx: *mut ZkhipCtx, log_n: c_int, width: u32, n_queries: usize, inner_pow_bits: c_int, n_public: usize, n_proofs: usize,
                                       outer: *const ZkhipParams, key: *mut *mut ZkhipMachineKey, vk: *mut u32) -> c_int;
     pub fn zkhip_shard_verifier_proof_size(log_n: c_int, width: u32, n_queries: usize, inner_pow_bits: c_int, n_public: usize, n_proofs: usize, outer: *const ZkhipParams) -> usize;
+    pub fn zkhip_poseidon2_params_generation() -> u64;
     /// the key WITHOUT a device (host cores only): what a verifier that owns no GPU derives for the shape it means
     pub fn zkhip_shard_verifier_key_host(log_n: c_int, width: u32, n_queries: usize, inner_pow_bits: c_int, n_public: usize, n_proofs: usize, outer: *const ZkhipParams,
                                          vk: *mut u32) -> c_int;

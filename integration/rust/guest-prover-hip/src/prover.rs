@@ -314,7 +314,7 @@ fn prove_one(ctx: &Context, d_trace: *const u32, log_n: i32, width: u32, column_
 /// The compress stage (`client.prove(.., Groth16)`, sp1.rs:116: core -> COMPRESS; prover.rs:90: lift -> join): ONE proof that verifies all
 /// shard proofs of an execution in-circuit.  `public_values`: those of proof 0, then those of proof 1, ... (`n_public` each).  Returns the
 /// joined proof and the verifying key of the shape; `verify_compressed` then needs no byte of the shard proofs.  Limits (docs/RECURSION_NEXT.md):
-/// version-1 shard proofs of one shape, at most 64 per join, one level.
+/// version-1 shard proofs of one shape, at most `zkhip_shard_verifier_max_proofs` per join (136 of the headline shape under an outer proof at blowup 2), one level.
 pub fn compress_shards(ctx: &Context, proofs: &[Vec<u8>], log_n: i32, width: u32, public_values: &[u32], n_public: usize, inner: &ZkhipParams,
                        outer: &ZkhipParams) -> Result<(Vec<u8>, [u32; 8])> {
     anyhow::ensure!(!proofs.is_empty() && public_values.len() == proofs.len() * n_public, "compress_shards: one public-value list per proof");

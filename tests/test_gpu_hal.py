@@ -33,6 +33,22 @@ def test_zk_shift(ctx, oracle, count, log_size):
         assert (got == oracle.hal_zk_shift(polys, count, log_size, shift)).all()
 
 
+def test_zk_shift_of_a_slice_at_a_four_byte_offset(ctx, oracle):
+    """a Hal slice inside a larger buffer need not be 16-byte aligned: the 4-bytes-per-lane form serves it"""
+    import ctypes as C
+    from zktls_amd.device import DeviceBuffer
+    rng = np.random.default_rng(77)
+    count, log_size = 3, 9
+    polys = rng.integers(0, P, (count, 1 << log_size), dtype=np.uint32)
+    big = ctx.alloc(polys.size + 8)
+    for off in (1, 2, 3):
+        big.upload(np.concatenate([np.zeros(off, dtype=np.uint32), polys.ravel(), np.zeros(8 - off, dtype=np.uint32)]))
+        view = DeviceBuffer(ctx, polys.size, ptr=big.ptr + 4 * off, owner=big)
+        ctx.zk_shift(view, count, log_size, 3)
+        got = big.download()
+        assert (got[off:off + polys.size].reshape(count, -1) == oracle.hal_zk_shift(polys, count, log_size, 3)).all() and not got[:off].any() and not got[off + polys.size:].any()
+
+
 @pytest.mark.parametrize("ext_field", [0, 1])
 def test_mix_poly_coeffs_and_batch_evaluate_any(ctx, oracle, ext_field):
     rng = np.random.default_rng(20 + ext_field)

@@ -89,10 +89,11 @@ void LaunchBatcher::trampoline() {
     LaunchBatcher* self = t_batcher;
     const int b = self->current_;
     // nothing may unwind past this frame (there is no caller above it: uc_link is null): an exception that escapes a member --
-    // std::bad_alloc from a prover's vectors, std::system_error from a mutex -- fails THAT member and marks the batch, not the process
+    // std::bad_alloc from a prover's vectors, std::system_error from a mutex -- is caught by the member function the dealer hands in (jobs.cpp:
+    // that member's status, with its text); what still arrives here (a member function that does not catch) marks the whole batch, not the process
     try { (*self->fn_)(b); }
-    catch (const std::exception& e) { self->threw_ = true; self->sticky_ = hipErrorUnknown; set_error(std::string("lock-step member: ") + e.what()); }
-    catch (...) { self->threw_ = true; self->sticky_ = hipErrorUnknown; set_error("lock-step member: unknown exception"); }
+    catch (const std::exception& e) { self->sticky_ = hipErrorUnknown; set_error(std::string("lock-step member: ") + e.what()); }
+    catch (...) { self->sticky_ = hipErrorUnknown; set_error("lock-step member: unknown exception"); }
     self->fibers_[(size_t)b].state = DONE;
     swapcontext(&self->fibers_[(size_t)b].ctx, &self->lane_);  // never resumed
 }

@@ -415,7 +415,7 @@ static int coset_lde_big(zkhip_ctx* ctx, const uint32_t* in, size_t in_ld, uint3
     // blowup 2: every tile pass runs on a dense 2^20-row class (pitch = width; the radix-R passes address 64 bits), so the pitch of the
     // caller's matrices does not matter; other blowups write every R-th row of the LDE
     if (log_blowup == 1) {
-        if (4ull * (1023ull * 1024ull * width + 1024ull) >= (1ull << 32)) return fail(ZKHIP_ERR_INVALID, "coset_lde: at most 1023 columns");
+        if (4ull * (1023ull * 1024ull * width + 1024ull) >= (1ull << 32)) return fail(ZKHIP_ERR_INVALID, "coset_lde: at most 1024 columns");
     } else ZK_TRY(check_big_width(log_n, width, out_ld, "coset_lde"));
     const size_t n = (size_t)1 << log_n;
     const uint64_t R = 1ull << (log_n - BIG_INNER_LOG), Np = 1ull << BIG_INNER_LOG;

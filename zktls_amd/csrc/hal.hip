@@ -104,6 +104,16 @@ __global__ void hal_zk_shift_kernel(uint32_t* __restrict__ io, int log_size, uin
         s = dmul(s, step);
     }
 }
+// the same for a vector that is NOT 16-byte aligned (a Hal slice at a 4-byte offset inside a larger buffer): one coefficient per lane and
+// step, 4-byte accesses, the running power advanced by shift^(threads of the grid row)
+__global__ void hal_zk_shift_scalar_kernel(uint32_t* __restrict__ io, int log_size, uint32_t shift, uint32_t step) {
+    const uint64_t n = (uint64_t)1 << log_size;
+    uint32_t* v = io + (uint64_t)blockIdx.y * n;
+    const uint64_t tid = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x, nth = (uint64_t)gridDim.x * blockDim.x;
+    if (tid >= n) return;
+    uint32_t s = fpow(shift, tid);
+    for (uint64_t i = tid; i < n; i += nth) { v[i] = dmul(v[i], s); s = dmul(s, step); }
+}
 // mix_poly_coeffs: out[combos[i] * count + idx] += mix_start * mix^i * in[i * count + idx].
 // (1) the powers mix_start * mix^i are the same for every idx: one small launch writes them to a table (a wave's scan: lane l takes
 //     i = l, l + 64, ...; its start mix^l by square-and-multiply, its stride mix^64);
@@ -507,16 +517,22 @@ int zkhip_zk_shift(zkhip_ctx* ctx, uint32_t* d_io, size_t count, int log_size, u
     CHECK_CTX(ctx);
     if (!d_io || log_size < 0 || log_size > 30 || shift == 0 || shift >= P) return fail(ZKHIP_ERR_INVALID, "zk_shift: bad arguments (shift canonical, non-zero)");
     if (!count) return ZKHIP_OK;
-    if (count > 65535) return fail(ZKHIP_ERR_INVALID, "zk_shift: at most 65535 polynomials per call");
-    if (log_size >= 2 && (reinterpret_cast<uintptr_t>(d_io) & 15)) return fail(ZKHIP_ERR_INVALID, "zk_shift: the vector must be 16-byte aligned");
-    // a lane owns 4 coefficients per step; ~16 steps per lane amortise its fpow; whole polynomials per grid row
-    const uint64_t quads = log_size >= 2 ? ((uint64_t)1 << log_size) / 4 : 1;
-    uint64_t blocks = (quads + 256 * 16 - 1) / (256 * 16);
+    // a lane owns 4 coefficients per step; ~16 steps per lane amortise its fpow; whole polynomials per grid row (at most 65535 rows per
+    // launch: more polynomials take several launches)
+    const bool vec = log_size < 2 || (reinterpret_cast<uintptr_t>(d_io) & 15) == 0;
+    const uint64_t n = (uint64_t)1 << log_size;
+    const uint64_t quads = log_size >= 2 ? n / 4 : 1;
+    uint64_t blocks = vec ? (quads + 256 * 16 - 1) / (256 * 16) : (n + 256 * 16 - 1) / (256 * 16);
     if (blocks < 1) blocks = 1;
     if (blocks > 1024) blocks = 1024;
-    const uint32_t sm = to_monty(shift), s2 = fmul(sm, sm), s3 = fmul(s2, sm), step = fpow(sm, 4 * blocks * 256);
-    hipLaunchKernelGGL(hal_zk_shift_kernel, dim3((unsigned)blocks, (unsigned)count), dim3(256), 0, ctx->stream, d_io, log_size, sm, sm, s2, s3, step);
-    LAUNCHED();
+    const uint32_t sm = to_monty(shift), s2 = fmul(sm, sm), s3 = fmul(s2, sm), step = fpow(sm, (vec ? 4 : 1) * blocks * 256);
+    for (size_t done = 0; done < count; done += 65535) {
+        const size_t rows = count - done < 65535 ? count - done : 65535;
+        uint32_t* base = d_io + done * n;
+        if (vec) hipLaunchKernelGGL(hal_zk_shift_kernel, dim3((unsigned)blocks, (unsigned)rows), dim3(256), 0, ctx->stream, base, log_size, sm, sm, s2, s3, step);
+        else hipLaunchKernelGGL(hal_zk_shift_scalar_kernel, dim3((unsigned)blocks, (unsigned)rows), dim3(256), 0, ctx->stream, base, log_size, sm, step);
+        LAUNCHED();
+    }
     return ZKHIP_OK;
 }
 static int ext_field_ok(int ext) { return ext == ZKHIP_EXT_X4_MINUS_11 || ext == ZKHIP_EXT_X4_PLUS_11; }

@@ -202,6 +202,8 @@ int deal_jobs_lockstep(const int* devices, int n_devices, int n_jobs, const int*
     size_t pool_budget = (size_t)4 << 30;
     if (job_cells) {
         const size_t est = (size_t)job_cells * LOCKSTEP_BYTES_PER_CELL + ((size_t)16 << 20);
+        int caller_dev = -1;                                       // the caller's current device is the caller's: put it back after the queries
+        if (hipGetDevice(&caller_dev) != hipSuccess) { (void)hipGetLastError(); caller_dev = -1; }
         for (int d = 0; d < n_devices; d++) {
             size_t free_b = 0, total_b = 0;
             if (hipSetDevice(physical_device(devices[d])) != hipSuccess || hipMemGetInfo(&free_b, &total_b) != hipSuccess) { (void)hipGetLastError(); continue; }
@@ -212,6 +214,7 @@ int deal_jobs_lockstep(const int* devices, int n_devices, int n_jobs, const int*
             while ((size_t)lanes * (size_t)max_batch > cap && lanes > 1) lanes--;
             if (d == 0 || total_b / 4 < pool_budget) pool_budget = total_b / 4;
         }
+        if (caller_dev >= 0) (void)hipSetDevice(caller_dev);
     }
     std::mutex mu;
     int first_rc = ZKHIP_OK, first_job = n_jobs, ctx_rc = ZKHIP_OK;
@@ -283,10 +286,17 @@ int deal_jobs_lockstep(const int* devices, int n_devices, int n_jobs, const int*
                     LaunchBatcher lb(n, shared);
                     auto member = [&](int b) {
                         const int i = jobs[(size_t)(at + b)];
-                        const int rc = run(ctxs[(size_t)b], i);
+                        // a host-side exception inside ONE member (bad_alloc from a prover's vectors ...) is that member's status with its own
+                        // text -- out of memory takes the retry path below --, not a failed batch: the other members' proofs stay good
+                        int rc;
+                        std::string msg;
+                        try { rc = run(ctxs[(size_t)b], i); if (rc != ZKHIP_OK) msg = zkhip_last_error(); }
+                        catch (const std::bad_alloc&) { rc = ZKHIP_ERR_NOMEM; msg = "lock-step member: out of host memory"; }
+                        catch (const std::exception& e) { rc = ZKHIP_ERR_INTERNAL; msg = std::string("lock-step member: ") + e.what(); }
+                        catch (...) { rc = ZKHIP_ERR_INTERNAL; msg = "lock-step member: unknown exception"; }
                         ran[(size_t)i] = 1;
                         if (rc == ZKHIP_ERR_NOMEM) { retry.push_back(i); healthy[(size_t)b] = 0; }      // (fibers of ONE thread: no lock)
-                        else if (rc != ZKHIP_OK) { note(i, rc, zkhip_last_error()); healthy[(size_t)b] = 0; }
+                        else if (rc != ZKHIP_OK) { note(i, rc, msg); healthy[(size_t)b] = 0; }
                     };
                     if (lb.ok()) lb.run(member);                 // the members as fibers of this thread, their launches merged
                     else for (int b = 0; b < n; b++) member(b);  // (no pinned memory / stacks: one after the other, unmerged)

@@ -81,6 +81,8 @@ using namespace zk;
 
 extern "C" {
 
+// how often the table set changed in this process: holders of values derived from the tables (a parked machine key ...) compare it
+uint64_t zkhip_poseidon2_params_generation(void) { return zk::g_p2_generation.load(); }
 int zkhip_load_poseidon2_params(const char* path) {
     if (!path) return fail(ZKHIP_ERR_INVALID, "load_poseidon2_params: null path");
     std::lock_guard<std::mutex> lk(g_params_mu);

@@ -114,7 +114,7 @@ struct Shape {
     }
     bool has_challenge(int T) const { return T == TA || T == TQ || T == TF || (TL0 <= T && T < TP); }
 };
-constexpr size_t MAX_JOIN = 1024;       // proofs per join: as many as fit the Poseidon2 chip (68 at the headline shape), at most this
+constexpr size_t MAX_JOIN = 1024;       // proofs per join: as many as fit the Poseidon2 chip (zkhip_shard_verifier_max_proofs: 136 at the headline shape under an outer proof at blowup 2, 68 otherwise), at most this
 // the Poseidon2 chip's rows are 384 words apart with the key's columns.  An outer proof at blowup 2 extends 2^22-row matrices of any pitch (its
 // tile passes run on dense 2^20-row classes: context.cpp, coset_lde_big); other blowups write every 4th row of the LDE and take a pitch of 256 words
 constexpr int P2R_MAX_LOG_ROWS = 22;

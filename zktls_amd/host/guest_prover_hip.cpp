@@ -83,26 +83,50 @@ std::vector<Slot> g_slots;
 // the compress stage's key (the shard verifier machine's preprocessed traces on the device, zkhip_shard_verifier_setup: 30 - 110 ms at the
 // headline shape): a function of the shape, so a prover that serves many requests of one plan keeps it -- parked like the contexts
 // (a machine key belongs to the context that made it: the pair is parked together)
-struct JoinKey { int device; int32_t log_n; uint32_t width; int32_t queries, pow_bits; uint32_t join; zkhip_ctx* ctx; zkhip_machine_key* key; uint32_t vk[8]; };
+struct JoinKey { int device; int32_t log_n; uint32_t width; int32_t queries, pow_bits; uint32_t join; zkhip_ctx* ctx; zkhip_machine_key* key; uint32_t vk[8];
+                 uint64_t p2_generation; };          // the key commits with the Poseidon2 tables in effect when it was made (zkhip_load_poseidon2_params moves the counter)
 std::vector<JoinKey> g_join_keys;           // (under g_slots_mu)
 bool take_join_key(int device, const zktls::ShardPlan& plan, uint32_t join, JoinKey* out) {
-    std::lock_guard<std::mutex> lk(g_slots_mu);
-    for (size_t i = 0; i < g_join_keys.size(); i++) {
-        const JoinKey& k = g_join_keys[i];
-        if (k.device == device && k.log_n == plan.log_n && k.width == plan.width && k.queries == plan.num_queries && k.pow_bits == plan.pow_bits && k.join == join) {
-            *out = k;
-            g_join_keys.erase(g_join_keys.begin() + (long)i);
-            return true;
+    const uint64_t gen = zkhip_poseidon2_params_generation();
+    std::vector<JoinKey> stale;
+    bool found = false;
+    {
+        std::lock_guard<std::mutex> lk(g_slots_mu);
+        for (size_t i = 0; i < g_join_keys.size();) {
+            const JoinKey& k = g_join_keys[i];
+            if (k.p2_generation != gen) { stale.push_back(k); g_join_keys.erase(g_join_keys.begin() + (long)i); continue; }     // made under other tables: a verifier would derive another key
+            if (!found && k.device == device && k.log_n == plan.log_n && k.width == plan.width && k.queries == plan.num_queries && k.pow_bits == plan.pow_bits && k.join == join) {
+                *out = k;
+                g_join_keys.erase(g_join_keys.begin() + (long)i);
+                found = true;
+                continue;
+            }
+            i++;
         }
     }
-    return false;
+    for (auto& k : stale) { zkhip_machine_key_destroy(k.key); zkhip_ctx_destroy(k.ctx); }
+    return found;
 }
 void park_join_key(const JoinKey& k) {
-    std::lock_guard<std::mutex> lk(g_slots_mu);
-    if (g_join_keys.size() < 4) { g_join_keys.push_back(k); return; }
+    {
+        std::lock_guard<std::mutex> lk(g_slots_mu);
+        if (g_join_keys.size() < 4 && k.p2_generation == zkhip_poseidon2_params_generation()) { g_join_keys.push_back(k); return; }
+    }
     zkhip_machine_key_destroy(k.key);
     zkhip_ctx_destroy(k.ctx);
 }
+// the pair taken for one compress stage: parked again when the stage went through, destroyed on every other way out (an exception included)
+struct JoinGuard {
+    JoinKey jk;
+    bool done = false;
+    ~JoinGuard() {
+        if (!jk.ctx) return;
+        (void)zkhip_ctx_sync(jk.ctx);
+        if (done) { park_join_key(jk); return; }
+        if (jk.key) zkhip_machine_key_destroy(jk.key);
+        zkhip_ctx_destroy(jk.ctx);
+    }
+};
 struct CtxGuard {
     int device = 0;
     size_t trace_bytes = 0;
@@ -420,20 +444,17 @@ ProveResult HipGuestProver::prove_inner(const GuestInput& input, const std::vect
         // every join has the same key); the blob carries them in shard order
         const uint32_t J = compress_join_size(plan_), n_joins = (plan_.shards + J - 1) / J;
         const zkhip_params outer{1, plan_.num_queries, plan_.pow_bits, 0, 0, 0, 0, 0};
-        JoinKey jk{devices_[0], plan_.log_n, plan_.width, plan_.num_queries, plan_.pow_bits, J, nullptr, nullptr, {0}};
+        JoinGuard jg{JoinKey{devices_[0], plan_.log_n, plan_.width, plan_.num_queries, plan_.pow_bits, J, nullptr, nullptr, {0}, zkhip_poseidon2_params_generation()}};
+        JoinKey& jk = jg.jk;
         if (!take_join_key(devices_[0], plan_, J, &jk)) {
-            if (zkhip_ctx_create(devices_[0], nullptr, &jk.ctx) != ZKHIP_OK) fail_zkhip("zkhip_ctx_create");
-            if (zkhip_shard_verifier_setup(jk.ctx, plan_.log_n, plan_.width, (size_t)plan_.num_queries, plan_.pow_bits, 9, J, &outer, &jk.key, jk.vk) != ZKHIP_OK) {
-                const std::string why = zkhip_last_error();
-                zkhip_ctx_destroy(jk.ctx);
-                throw std::runtime_error("zkhip_shard_verifier_setup: " + why);
-            }
+            if (zkhip_ctx_create(devices_[0], nullptr, &jk.ctx) != ZKHIP_OK) { jk.ctx = nullptr; fail_zkhip("zkhip_ctx_create"); }
+            if (zkhip_shard_verifier_setup(jk.ctx, plan_.log_n, plan_.width, (size_t)plan_.num_queries, plan_.pow_bits, 9, J, &outer, &jk.key, jk.vk) != ZKHIP_OK)
+                throw std::runtime_error(std::string("zkhip_shard_verifier_setup: ") + zkhip_last_error());
         }
         zkhip_ctx* const jctx = jk.ctx;
         zkhip_machine_key* key = jk.key;
         uint32_t vk[8];
         std::memcpy(vk, jk.vk, sizeof vk);
-        auto drop_join = [&]() { (void)zkhip_ctx_sync(jctx); zkhip_machine_key_destroy(key); zkhip_ctx_destroy(jctx); };
         const size_t jcap = zkhip_shard_verifier_proof_size(plan_.log_n, plan_.width, (size_t)plan_.num_queries, plan_.pow_bits, 9, J, &outer);
         std::vector<std::vector<uint8_t>> entries;
         for (uint32_t c = 0; c < n_joins; c++) {
@@ -449,18 +470,15 @@ ProveResult HipGuestProver::prove_inner(const GuestInput& input, const std::vect
             std::vector<uint8_t> joined(jcap);
             size_t jlen = 0;
             const int rc = zkhip_prove_shard_verifier(jctx, key, ptrs.data(), lens.data(), J, plan_.log_n, plan_.width, pvs.data(), 9, &prm, &outer, joined.data(), jcap, &jlen);
-            if (rc != ZKHIP_OK) { const std::string why = zkhip_last_error(); drop_join(); throw std::runtime_error("zkhip_prove_shard_verifier: " + why); }
+            if (rc != ZKHIP_OK) throw std::runtime_error(std::string("zkhip_prove_shard_verifier: ") + zkhip_last_error());
             joined.resize(jlen);
             int reason = 0;
             if (zkhip_verify_shard_recursive(joined.data(), jlen, plan_.log_n, plan_.width, (size_t)plan_.num_queries, plan_.pow_bits, pvs.data(), 9, J, vk, &outer, &reason) != ZKHIP_OK) {
-                const std::string why = zkhip_last_error();
-                drop_join();
-                throw std::runtime_error("zkhip_verify_shard_recursive: " + why);     // sp1.rs:120: the prover checks its own proof
+                throw std::runtime_error(std::string("zkhip_verify_shard_recursive: ") + zkhip_last_error());     // sp1.rs:120: the prover checks its own proof
             }
             entries.push_back(std::move(joined));
         }
-        (void)zkhip_ctx_sync(jctx);
-        park_join_key(jk);                               // (only after every join went through: a failing call above destroys the pair)
+        jg.done = true;                                  // (only after every join went through: every other way out destroys the pair -- JoinGuard)
         std::vector<uint8_t> tail(36);
         std::memcpy(tail.data(), vk, 32);
         const uint32_t cnt = plan_.shards;
