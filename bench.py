@@ -489,7 +489,7 @@ def main():
 
         def i1_over_traces(which):
             """the LDE's first pass reads the shard's trace: its duration depends on where THAT trace lies relative to the context's
-            workspace (0.46 ... 0.52 ms over the pairs of one process, tools/i1_sources.py) -- timed over the traces of all timed shards,
+            workspace (0.46 ... 0.52 ms over the pairs of one process, tools/archive/i1_sources.py) -- timed over the traces of all timed shards,
             the same number of launches each, mean reported (and the spread beside it); nothing is selected"""
             per = max(10, reps // len(bufs))
             ms = [timed(lambda b=b: ctx.ntt_pass(b, None, log_n, width, which), per) for b in bufs]

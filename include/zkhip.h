@@ -27,6 +27,7 @@
  *       the reference's batch and large-transcript configurations (BASELINE.json configs[2], configs[3]) with a real statement per proof:
  *       many transcripts, or the shards of one long message, dealt over the GPUs of the node by one call.
  *   zkhip_p2chip_air, zkhip_prove_merkle_paths / zkhip_verify_merkle_paths
+ *   (DEPRECATED generations of the recursion step -- kept for their tests; new callers: zkhip_prove_shard_verifier, or zkhip_prove_fri_indices_batch as the cheap FRI-only mode)
  *   zkhip_fri_view_shard, zkhip_fri_chip_air, zkhip_fri_queries_key, zkhip_prove_fri_queries / zkhip_verify_fri_queries,
  *   zkhip_fri_view_shard_paths, zkhip_fri_layers_key, zkhip_prove_fri_layers / zkhip_verify_fri_layers,
  *   zkhip_fri_view_transcript, zkhip_fri_transcript_key, zkhip_prove_fri_transcript / zkhip_verify_fri_transcript,
@@ -80,6 +81,13 @@
  */
 #ifndef ZKHIP_H
 #define ZKHIP_H
+/* Entries superseded by a later one stay exported (their tests and the byte-equality against the oracle stay in the suites) but are marked:
+ * new callers take the entry named in the message.  Define ZKHIP_NO_DEPRECATION_WARNINGS to silence the attribute. */
+#if defined(ZKHIP_NO_DEPRECATION_WARNINGS) || !(defined(__GNUC__) || defined(__clang__))
+#define ZKHIP_DEPRECATED(msg)
+#else
+#define ZKHIP_DEPRECATED(msg) __attribute__((deprecated(msg)))
+#endif
 
 #include <stddef.h>
 #include <stdint.h>
@@ -675,6 +683,7 @@ int zkhip_fri_chip_gen_trace(zkhip_ctx* ctx, int layers, size_t n_queries, const
 int zkhip_fri_queries_key(zkhip_ctx* ctx, int layers, size_t n_queries, const uint32_t* betas, const uint32_t* indices, const uint32_t* values,
                           const uint32_t* siblings, const zkhip_params* prm, zkhip_machine_key** key, uint32_t vk[8], uint32_t final_value[4]);
 size_t zkhip_fri_queries_proof_size(int layers, size_t n_queries, const zkhip_params* prm);
+ZKHIP_DEPRECATED("the FRI-only machines are superseded: zkhip_prove_shard_verifier checks the whole shard proof in-circuit; zkhip_prove_fri_indices_batch is the cheap FRI-only mode")
 int zkhip_prove_fri_queries(zkhip_ctx* ctx, const zkhip_machine_key* key, int layers, size_t n_queries, const uint32_t* betas, const uint32_t* indices,
                             const uint32_t* values, const uint32_t* siblings, const zkhip_params* prm, uint8_t* proof, size_t cap, size_t* len);
 int zkhip_verify_fri_queries(const uint8_t* proof, size_t len, int layers, size_t n_queries, const uint32_t* betas, const uint32_t final_value[4],
@@ -713,6 +722,7 @@ int zkhip_fri_layers_gen_paths_trace(zkhip_ctx* ctx, int layers, size_t n_querie
 int zkhip_fri_layers_key(zkhip_ctx* ctx, int layers, size_t n_queries, const uint32_t* indices, const uint32_t* values, const uint32_t* roots,
                          const zkhip_params* prm, zkhip_machine_key** key, uint32_t vk[8]);
 size_t zkhip_fri_layers_proof_size(int layers, size_t n_queries, const zkhip_params* prm);
+ZKHIP_DEPRECATED("superseded: zkhip_prove_shard_verifier (whole verifier) or zkhip_prove_fri_indices_batch (FRI only)")
 int zkhip_prove_fri_layers(zkhip_ctx* ctx, const zkhip_machine_key* key, int layers, size_t n_queries, const uint32_t* betas, const uint32_t* indices,
                            const uint32_t* values, const uint32_t* siblings, const uint32_t* roots, const uint32_t* paths, const zkhip_params* prm,
                            uint8_t* proof, size_t cap, size_t* len);
@@ -734,6 +744,7 @@ size_t zkhip_p2chip_air_fri_transcript(int layers, uint32_t* program, size_t cap
 int zkhip_fri_transcript_key(zkhip_ctx* ctx, int layers, size_t n_queries, const uint32_t* indices, const uint32_t* values, const uint32_t* roots,
                              const zkhip_params* prm, zkhip_machine_key** key, uint32_t vk[8]);
 size_t zkhip_fri_transcript_proof_size(int layers, size_t n_queries, const zkhip_params* prm);
+ZKHIP_DEPRECATED("superseded: zkhip_prove_shard_verifier (whole verifier) or zkhip_prove_fri_indices_batch (FRI only)")
 int zkhip_prove_fri_transcript(zkhip_ctx* ctx, const zkhip_machine_key* key, int layers, size_t n_queries, const uint32_t* betas, const uint32_t* indices,
                                const uint32_t* values, const uint32_t* siblings, const uint32_t* roots, const uint32_t* paths, const uint32_t capacity[8],
                                const zkhip_params* prm, uint8_t* proof, size_t cap, size_t* len);

@@ -1,7 +1,7 @@
 """exploration (A/B library): the wide term kernel without its staging (ZKHIP_AIRQ_ABL=2) or without its terms (=4); run under
 rocprofv3 --kernel-trace --stats: python tools/airq_ablate.py"""
 import os, sys
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))      # (tools/archive/ -> the repository root)
 sys.path[:0] = [ROOT, os.path.join(ROOT, "tests"), os.path.join(ROOT, "tools")]
 import _ab  # noqa: F401
 from zktls_amd.device import Context, sha256_air, p2chip_air

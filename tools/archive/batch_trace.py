@@ -1,7 +1,7 @@
 """exploration: 64 keyed transcripts in one call under rocprofv3 --kernel-trace; prints how much the kernels of different proofs overlap"""
 import os
 import sys
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))      # (tools/archive/ -> the repository root)
 sys.path[:0] = [ROOT, os.path.join(ROOT, "tests")]
 from zktls_amd._lib import Params
 from zktls_amd.device import prove_transcripts

@@ -4,7 +4,7 @@ import os
 import sys
 
 os.environ.setdefault("ZKHIP_NTT_MAP", "255")
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))      # (tools/archive/ -> the repository root)
 sys.path[:0] = [ROOT, os.path.join(ROOT, "tools")]
 import _ab  # noqa: F401,E402
 from zktls_amd.device import Context  # noqa: E402

@@ -4,7 +4,7 @@ Run twice (with and without the variable): prints the pass times and a checksum 
 import hashlib
 import os
 import sys
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))      # (tools/archive/ -> the repository root)
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tools"))
 import _ab  # noqa: E402,F401

@@ -2,7 +2,7 @@
 stores dropped (reads only, buffer as source) and with the loads dropped (writes only, buffer as destination), then all pairs in full.
 Run with ZKHIP_NTT_DEBUG=0 in the environment (the library then re-reads the variable per launch)."""
 import ctypes as C, os, sys
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))      # (tools/archive/ -> the repository root)
 sys.path.insert(0, ROOT)
 sys.path.insert(0, __import__('os').path.dirname(__import__('os').path.abspath(__file__)))
 import _ab  # noqa: F401  (A/B build of the library: the env knobs below exist only there)

@@ -1,7 +1,7 @@
 """exploration: tile-order A/B of the strided pass on slow (same class) and fast buffer pairs, one process.
 Run with ZKHIP_NTT_MAP=1 ZKHIP_NTT_DEBUG=0 in the environment."""
 import ctypes as C, os, sys
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))      # (tools/archive/ -> the repository root)
 sys.path.insert(0, ROOT)
 sys.path.insert(0, __import__('os').path.dirname(__import__('os').path.abspath(__file__)))
 import _ab  # noqa: F401  (A/B build of the library: the env knobs below exist only there)

@@ -1,7 +1,7 @@
 """exploration: is the strided pass's bimodal duration (0.49 vs 0.53 ms between processes) a matter of WHERE the buffers lie?
 One process, several 1 GiB sources and destinations, every pair timed."""
 import ctypes as C, os, sys
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))      # (tools/archive/ -> the repository root)
 sys.path.insert(0, ROOT)
 from zktls_amd.device import Context
 hip = C.CDLL("libamdhip64.so")

@@ -1,7 +1,7 @@
 """exploration: cache-policy A/B of the NTT pass kernel inside ONE process (same buffers, same physical pages): needs the
 -DNTT_POLICY_SWEEP build (tools/ntt_policy_sweep.sh builds it); ZKHIP_NTT_POL is re-read at every launch."""
 import ctypes as C, os, sys
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))      # (tools/archive/ -> the repository root)
 sys.path.insert(0, ROOT)
 sys.path.insert(0, __import__('os').path.dirname(__import__('os').path.abspath(__file__)))
 import _ab  # noqa: F401  (A/B build of the library: the env knobs below exist only there)

@@ -1,7 +1,7 @@
 """exploration: strided-pass time against the address distance between source and destination (one process; the destination is
 carved out of one large allocation at several offsets)"""
 import ctypes as C, os, sys
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))      # (tools/archive/ -> the repository root)
 sys.path.insert(0, ROOT)
 from zktls_amd.device import Context, DeviceBuffer
 hip = C.CDLL("libamdhip64.so")

@@ -9,7 +9,7 @@ import os
 import shutil
 import sys
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))      # (tools/archive/ -> the repository root)
 src = os.path.join(ROOT, "gpurun_out", "prof3")
 dst = os.path.join(ROOT, "profiles")
 commit = sys.argv[1] if len(sys.argv) > 1 else ""

@@ -105,7 +105,7 @@ __device__ __forceinline__ void ntt_pass_kernel_body(const NttPassArgs& a) {
     {
         const uint32_t* ib = a.in + (uint64_t)tile * a.in_tile_mul * a.in_ld;
 #ifdef ZKHIP_AB_HOOKS
-        // timing-only knob of A/B builds (tools/ab_ntt2.sh): a zero-record descriptor drops the loads / stores
+        // timing-only knob of A/B builds (tools/archive/ab_ntt2.sh): a zero-record descriptor drops the loads / stores
         const auto rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint32_t*>(ib), 0, (a.debug_flags & 1u) ? 0u : 0xFFFFFFFFu, 0x00020000);
 #else
         const auto rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint32_t*>(ib), 0, 0xFFFFFFFFu, 0x00020000);
@@ -493,7 +493,7 @@ hipError_t launch_ntt_pass(const NttPassArgs& a_, bool inverse, hipStream_t s) {
     // by 4 bits (4), so that the ~64 tiles resident at any moment are spread over the whole 1 MiB row period instead of being 64
     // neighbouring rows.  With neighbours the reads and the writes of the chip sit in one narrow address window at a time, and when source
     // and destination happen to map that window onto the same channels the pass drops from 0.48 to 0.53 ms (two classes of buffers,
-    // slow iff both are in the same class: tools/ntt_buffer_quality.py); spread out, both cases run at 0.486-0.494 ms (tools/ntt_map_ab.py).
+    // slow iff both are in the same class: tools/archive/ntt_buffer_quality.py); spread out, both cases run at 0.486-0.494 ms (tools/archive/ntt_map_ab.py).
     const bool pow2_tiles = (a.num_tiles & (a.num_tiles - 1u)) == 0;
     if (a.map_mode >= 100u && a.map_mode < 116u) {           // A/B: 100 + r = rotation r for block-in / strided-out passes only, automatic otherwise
         const uint32_t r = a.map_mode - 100u;
@@ -501,7 +501,7 @@ hipError_t launch_ntt_pass(const NttPassArgs& a_, bool inverse, hipStream_t s) {
     }
     // A pass that reads strided but writes every tile as ONE block (the LDE's first pass in front of the fused launch) is the exception: its
     // writes are streams of their own, the rotation only scatters its reads -- 0.45 ms with plain XCD order on every (trace, workspace) pair
-    // against 0.46 ... 0.52 ms rotated (tools/i1_map_sweep.py); strided -> strided keeps the rotation (0.50 against 0.52), block -> strided is indifferent.
+    // against 0.46 ... 0.52 ms rotated (tools/archive/i1_map_sweep.py); strided -> strided keeps the rotation (0.50 against 0.52), block -> strided is indifferent.
     const bool strided_in_block_out = a.in_stride != 1 && a.out_stride == 1;
     if (a.map_mode == 255u) a.map_mode = (a.in_stride != 1 || a.out_stride != 1) && !strided_in_block_out && pow2_tiles && a.num_tiles >= 1024u ? 4u : 1u;     // smaller transforms lose 3-8 % with it
     if (a.map_mode == 1 && (a.num_tiles % 8u) != 0) a.map_mode = 0;
@@ -525,7 +525,7 @@ hipError_t launch_ntt_pass(const NttPassArgs& a_, bool inverse, hipStream_t s) {
     const bool pair_ok = a.ncols >= 32 && a.ncols % 2 == 0 && a.in_ld % 2 == 0 && a.out_ld % 2 == 0 &&
                          (reinterpret_cast<uintptr_t>(a.in) & 7) == 0 && (reinterpret_cast<uintptr_t>(a.out) & 7) == 0;
 #ifdef ZKHIP_AB_HOOKS
-    {   // A/B (tools/i1_wide_ab.py): the LDE's first pass with 64-column tiles -- 32 lanes x 8 B = 256-byte row chunks, 1024 lanes, one workgroup per CU
+    {   // A/B (tools/archive/i1_wide_ab.py): the LDE's first pass with 64-column tiles -- 32 lanes x 8 B = 256-byte row chunks, 1024 lanes, one workgroup per CU
         static const bool wide = getenv("ZKHIP_I1_WIDE") != nullptr;
         if (wide && pair_ok && a.log_m == 10 && strided_in_block_out && a.ncols % 64 == 0 && inverse) return launch_ntt_k<5, true, 2, 5, 2>(a, s);
         static const bool wide_f2 = getenv("ZKHIP_F2_WIDE") != nullptr;
@@ -534,7 +534,7 @@ hipError_t launch_ntt_pass(const NttPassArgs& a_, bool inverse, hipStream_t s) {
 #endif
     if (pair_ok && a.log_m == 10 && a.cols_per_thread != 1) {
         // non-temporal loads AND stores: the tile is read once and written once, its lines need not stay in L2 / MALL.
-        // Pays on every pass except a strided one run in place (+6 %), which keeps the default policy; tools/ntt_policy_sweep.sh
+        // Pays on every pass except a strided one run in place (+6 %), which keeps the default policy; tools/archive/ntt_policy_sweep.sh
         // walks the sc0 / sc1 / nt combinations (strided pass 0.537 -> 0.487 ms, block pass 0.457 -> 0.447 ms on the same box).
         const bool contiguous = a.in_stride == 1 && a.out_stride == 1;
         const bool in_place = a.in == a.out;
