@@ -2,7 +2,7 @@
 // (include/zkhip.h, zkhip_prove_sha256) and checked on the host -- plain C++ over the C ABI, no Python, no torch.
 //
 //   make -C examples && ./examples/prove_sha256 <file> [proof-out]
-//   ./examples/prove_sha256 --verify <proof> <hex digest>
+//   ./examples/prove_sha256 --verify <proof> <hex digest> <message length in bytes>
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
@@ -24,18 +24,19 @@ static bool read_file(const char* path, std::vector<uint8_t>& out) {
 
 int main(int argc, char** argv) {
     const zkhip_params prm = ZKHIP_PARAMS_SP1_CORE;                        // blowup 2, 100 queries, 16 PoW bits
-    if (argc == 4 && !std::strcmp(argv[1], "--verify")) {            // host only: no GPU needed to check a proof
+    if (argc == 5 && !std::strcmp(argv[1], "--verify")) {            // host only: no GPU needed to check a proof
         std::vector<uint8_t> proof;
         if (!read_file(argv[2], proof)) { std::fprintf(stderr, "cannot read %s\n", argv[2]); return 1; }
         uint8_t digest[32];
         if (std::strlen(argv[3]) != 64) { std::fprintf(stderr, "digest: 64 hex characters\n"); return 1; }
         for (int i = 0; i < 32; i++) { unsigned v; if (std::sscanf(argv[3] + 2 * i, "%2x", &v) != 1) return 1; digest[i] = (uint8_t)v; }
         int reason = 0;
-        const int rc = zkhip_verify_sha256(proof.data(), proof.size(), digest, &prm, &reason);
+        const uint64_t message_len = std::strtoull(argv[4], nullptr, 10);      // the statement: digest = SHA-256 of a message of THIS many bytes
+        const int rc = zkhip_verify_sha256(proof.data(), proof.size(), digest, message_len, &prm, &reason);
         std::printf("%s\n", rc == ZKHIP_OK ? "proof accepted" : zkhip_last_error());
         return rc == ZKHIP_OK ? 0 : 3;
     }
-    if (argc < 2) { std::fprintf(stderr, "usage: %s <file> [proof-out] | --verify <proof> <hex digest>\n", argv[0]); return 1; }
+    if (argc < 2) { std::fprintf(stderr, "usage: %s <file> [proof-out] | --verify <proof> <hex digest> <message length in bytes>\n", argv[0]); return 1; }
     std::vector<uint8_t> msg;
     if (!read_file(argv[1], msg)) { std::fprintf(stderr, "cannot read %s\n", argv[1]); return 1; }
     if (zkhip_device_count() <= 0) { std::fprintf(stderr, "no gfx950 device: libzkhip has no CPU fallback\n"); return 2; }
@@ -54,7 +55,7 @@ int main(int argc, char** argv) {
     }
     zkhip_sha256_digest(msg.data(), msg.size(), expect);
     int reason = 0;
-    if (std::memcmp(digest, expect, 32) != 0 || zkhip_verify_sha256(proof.data(), len, digest, &prm, &reason) != ZKHIP_OK) { std::fprintf(stderr, "self-check failed\n"); return 1; }
+    if (std::memcmp(digest, expect, 32) != 0 || zkhip_verify_sha256(proof.data(), len, digest, (uint64_t)msg.size(), &prm, &reason) != ZKHIP_OK) { std::fprintf(stderr, "self-check failed\n"); return 1; }
     std::printf("sha256 = ");
     for (int i = 0; i < 32; i++) std::printf("%02x", digest[i]);
     std::printf("  (proof verified)\n");

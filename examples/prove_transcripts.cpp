@@ -51,7 +51,7 @@ int main(int argc, char** argv) {
         zkhip_sha256_digest(msgs[i].data(), msgs[i].size(), expect);
         int reason = 0;
         if (std::memcmp(expect, jobs[i].digest, 32) != 0 ||
-            zkhip_verify_sha256_machine(jobs[i].proof, jobs[i].proof_len, jobs[i].digest, vk, &prm, &reason) != ZKHIP_OK) {
+            zkhip_verify_sha256_machine(jobs[i].proof, jobs[i].proof_len, jobs[i].digest, (uint64_t)jobs[i].message_len, vk, &prm, &reason) != ZKHIP_OK) {
             std::fprintf(stderr, "%s: check failed (%s)\n", argv[1 + i], zkhip_last_error());
             return 3;
         }

@@ -419,37 +419,41 @@ int zkhip_quotient_values_air(zkhip_ctx* ctx, const uint32_t* program, size_t pr
 
 /* ---- a real chip on the constraint-program path: SHA-256 compression (the hash of the TLS transcripts the reference's guest checks;
  * upstream SP1 proves it through the ShaExtend / ShaCompress chips of sp1-core-machine 4.1.4, reference Cargo.lock:5822, behind
- * crates/guest-prover-sp1/src/sp1.rs:116).  One row per round, 64 rows per 64-byte block, 608 columns, degree 3, 16 public values =
- * the digest as 16-bit limbs (low limb of word 0 first).
- * THE EXACT RELATION a proof attests: "I know k <= 2^(log_n - 6) 64-byte blocks whose compression chain, started from the standard
- * initial value (chained form: from the public chaining value c_s), ends in this digest (c_(s+1))"; blocks after the k-th are
- * inactive rows that pass the chaining value through, and ACT may drop after ANY block.  The FIPS 180-4 padding and length field are
- * applied by zkhip_prove_sha256 on the host and are NOT constrained: a verifier learns that a block sequence with this chain value
- * exists, not that its last block is a well-formed padding block -- which is what "SHA-256 of a message" would add.  For the use made
- * of it here (a commitment to the request's input bytes, which the party that checks the proof can hash itself) that is the
- * relation needed; a consumer that needs the padded form must check the last block outside the proof.  In the unkeyed program the
- * OUT limbs of the working variables d and h are not range-checked either: their integer value mod 2^32 is what the next round
- * consumes and the three-bit carries bound their growth; the keyed machine (zkhip_sha256_setup) looks every 16-bit limb up in a
- * range table.  Column layout and constraints: csrc/sha256_chip.hip. ---- */
-#define ZKHIP_SHA256_WIDTH 608
-#define ZKHIP_SHA256_PUBLIC 16
+ * crates/guest-prover-sp1/src/sp1.rs:116).  One row per round, 64 rows per 64-byte block, 612 columns, degree 3, 91 public values =
+ * the digest as 16-bit limbs (low limb of word 0 first), then 75 values the VERIFIER derives from the message's length
+ * (zkhip_sha256_padding_publics: the block count, where the 0x80 byte sits, which words must be zero, the length field).
+ * THE EXACT RELATION a proof attests (round 5): "I know a message of exactly L bytes whose SHA-256 digest is this" -- L public.  The
+ * FIPS 180-4 padding is constrained in-circuit: the number of active blocks is (L + 8) / 64 + 1 (a block counter that must reach zero
+ * exactly where ACT drops), the boundary word holds the message's last bytes, then 0x80, then zeros (checked bit by bit on the row where
+ * that word is the schedule's W_t), every word between it and the length field is zero, and W_14, W_15 of the last block are 8 L.  (Until
+ * round 4 the relation was "some block sequence's compression chain ends in this digest": ACT could drop after any block, padding and
+ * length were the host's.)  A chained shard (zkhip_sha256_air_chained: a slice of a longer message) takes the same constraints with the
+ * public values of ITS slice.  In the unkeyed program the OUT limbs of the working variables d and h are not range-checked: their integer
+ * value mod 2^32 is what the next round consumes and the three-bit carries bound their growth; the keyed machine (zkhip_sha256_setup) looks
+ * every 16-bit limb up in a range table.  Column layout and constraints: csrc/sha256_chip.hip. ---- */
+#define ZKHIP_SHA256_WIDTH 612
+#define ZKHIP_SHA256_PUBLIC 91           /* 16 digest limbs + ZKHIP_SHA256_PADDING_PUBLIC */
+#define ZKHIP_SHA256_PADDING_PUBLIC 75
+/* the 75 padding values of a trace that holds blocks [first_block, first_block + n_active) of the padded message of message_len bytes
+ * (a whole message: first_block 0, n_active (message_len + 8) / 64 + 1).  Host only; what a verifier computes instead of trusting. */
+void zkhip_sha256_padding_publics(uint64_t message_len, uint64_t first_block, uint64_t n_active, uint32_t out[75]);
 /* the constraint program (a zkhip_prove_shard_air program): returns its length in words; written when cap_words suffices */
 size_t zkhip_sha256_air(uint32_t* program, size_t cap_words);
 /* the digest itself, on the host (what a verifier compares the proof's public values with) */
 void zkhip_sha256_digest(const uint8_t* message, size_t len, uint8_t digest[32]);
 /* FIPS 180-4 padding: returns the padded length (a multiple of 64); written when cap suffices.  Host only. */
 size_t zkhip_sha256_pad(const uint8_t* message, size_t len, uint8_t* blocks, size_t cap);
-/* trace generation on the device: blocks = n_active padded 64-byte blocks (host memory), n_blocks = a power of two >= n_active;
- * d_trace [64 n_blocks][ld >= 608] Montgomery; digest_limbs (host) = the public values */
-int zkhip_sha256_gen_trace(zkhip_ctx* ctx, const uint8_t* blocks, size_t n_active, size_t n_blocks, uint32_t* d_trace, size_t ld,
-                           uint32_t digest_limbs[16]);
+/* trace generation on the device: blocks = the n_active = (message_len + 8) / 64 + 1 padded 64-byte blocks (host memory), n_blocks = a
+ * power of two >= n_active; d_trace [64 n_blocks][ld >= 612] Montgomery; publics (host) = the 91 public values */
+int zkhip_sha256_gen_trace(zkhip_ctx* ctx, const uint8_t* blocks, size_t n_active, size_t n_blocks, uint64_t message_len, uint32_t* d_trace, size_t ld,
+                           uint32_t publics[91]);
 /* message in, digest (32 bytes, as SHA-256 prints it) and proof out: pad, generate the trace on the device, zkhip_prove_shard_air.
  * zkhip_params: any shape zkhip_prove_shard_air takes (logup_pairs = code_width = 0). */
 size_t zkhip_sha256_proof_size(size_t message_len, const zkhip_params* prm);
 int zkhip_prove_sha256(zkhip_ctx* ctx, const uint8_t* message, size_t message_len, const zkhip_params* prm, uint8_t digest[32],
                        uint8_t* proof, size_t cap, size_t* len);
 /* host-side verifier: the block bound 2^(log_n - 6) is read from the proof header (and bound by the proof's transcript) */
-int zkhip_verify_sha256(const uint8_t* proof, size_t len, const uint8_t digest[32], const zkhip_params* prm, int* reason);
+int zkhip_verify_sha256(const uint8_t* proof, size_t len, const uint8_t digest[32], uint64_t message_len, const zkhip_params* prm, int* reason);
 
 /* ---- a shard made of several chips (AIR tables) of different heights, as an SP1 shard is (sp1-stark 4.1.4 ShardProof,
  * reference Cargo.lock:6172, behind crates/guest-prover-sp1/src/sp1.rs:116): one Merkle commitment per phase over all
@@ -566,27 +570,28 @@ int zkhip_verify_machine_keyed(const uint8_t* proof, size_t len, const int32_t* 
  * zkhip_sha256_shard_proof_size(k, prm)), proof_lens[s] out.  zkhip_verify_sha256_sharded checks the whole chain on the host (bad_shard /
  * reason name the first failing shard).  zkhip_sha256_gen_trace_chained = zkhip_sha256_gen_trace from a given chaining value. */
 size_t zkhip_sha256_air_chained(uint32_t* program, size_t cap_words);
-int zkhip_sha256_gen_trace_chained(zkhip_ctx* ctx, const uint32_t chain_in[8], const uint8_t* blocks, size_t n_active, size_t n_blocks, uint32_t* d_trace,
-                                   size_t ld, uint32_t digest_limbs[16]);
+int zkhip_sha256_gen_trace_chained(zkhip_ctx* ctx, const uint32_t chain_in[8], const uint8_t* blocks, size_t n_active, size_t n_blocks, uint64_t message_len,
+                                   uint64_t first_block, uint32_t* d_trace, size_t ld, uint32_t publics[91]);
 size_t zkhip_sha256_sharded_count(size_t message_len, int log_blocks_per_shard);
 size_t zkhip_sha256_shard_proof_size(int log_blocks, const zkhip_params* prm);
 int zkhip_prove_sha256_sharded(const int* devices, int n_devices, const uint8_t* message, size_t message_len, int log_blocks_per_shard, const zkhip_params* prm,
                                int in_flight_per_device, uint8_t digest[32], uint32_t* chain, uint8_t* proofs, size_t proof_stride, size_t* proof_lens);
 int zkhip_verify_sha256_sharded(const uint8_t* proofs, size_t proof_stride, const size_t* proof_lens, size_t n_shards, const uint32_t* chain,
-                                int log_blocks_per_shard, const uint8_t digest[32], const zkhip_params* prm, size_t* bad_shard, int* reason);
+                                int log_blocks_per_shard, const uint8_t digest[32], uint64_t message_len, const zkhip_params* prm, size_t* bad_shard, int* reason);
 
 /* The SHA-256 guest as a keyed machine: setup once, then one proof per message -- the reference's setup -> prove -> verify
- * (sp1.rs:113, :116, :120) on this repo's stand-in guest.  Two chips: the SHA-256 compression chip (zkhip_sha256_air, 608 columns) and a
+ * (sp1.rs:113, :116, :120) on this repo's stand-in guest.  Two chips: the SHA-256 compression chip (zkhip_sha256_air, 612 columns) and a
  * 2^16-row range table that receives the four 16-bit limbs per row the chip's own constraints do not range-check (the OUT limbs of d and
  * h); the table's values are a PREPROCESSED column committed by zkhip_sha256_setup (vk = that commitment, 8 canonical words; the key holds
  * the device data), its multiplicities are counted on the device per proof.  Messages up to 2^14 blocks (1 MiB).  A proof is a version-11
- * machine proof with public values = the digest's 16 limbs; zkhip_verify_sha256_machine reads the chip's height from the proof, rebuilds
+ * machine proof with public values = the digest's 16 limbs and the 75 padding values of the message's length (the statement: digest = SHA-256 of a
+ * message of message_len bytes); zkhip_verify_sha256_machine reads the chip's height from the proof, rebuilds
  * the machine and runs zkhip_verify_machine_keyed. */
 int zkhip_sha256_setup(zkhip_ctx* ctx, const zkhip_params* prm, zkhip_machine_key** key, uint32_t vk[8]);
 size_t zkhip_sha256_machine_proof_size(size_t message_len, const zkhip_params* prm);
 int zkhip_prove_sha256_machine(zkhip_ctx* ctx, const zkhip_machine_key* key, const uint8_t* message, size_t message_len, const zkhip_params* prm,
                                uint8_t digest[32], uint8_t* proof, size_t cap, size_t* len);
-int zkhip_verify_sha256_machine(const uint8_t* proof, size_t len, const uint8_t digest[32], const uint32_t vk[8], const zkhip_params* prm, int* reason);
+int zkhip_verify_sha256_machine(const uint8_t* proof, size_t len, const uint8_t digest[32], uint64_t message_len, const uint32_t vk[8], const zkhip_params* prm, int* reason);
 /* A batch of transcripts in one call -- the reference's batch configuration (BASELINE.json configs[2]: 64 independent transcripts), each proven
  * as the keyed SHA-256 machine: job i runs on devices[i mod n_devices] (NULL / 0: every visible device), `in_flight_per_device` at a time per
  * device, on pooled contexts that keep their proving key between calls (setup once per context).  Messages are host bytes; every job

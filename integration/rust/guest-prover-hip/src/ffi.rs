@@ -110,7 +110,7 @@ extern "C" {
         ctx: *mut ZkhipCtx, message: *const u8, message_len: usize, prm: *const ZkhipParams, digest: *mut u8,
         proof: *mut u8, cap: usize, len: *mut usize,
     ) -> c_int;
-    pub fn zkhip_verify_sha256(proof: *const u8, len: usize, digest: *const u8, prm: *const ZkhipParams, reason: *mut c_int) -> c_int;
+    pub fn zkhip_verify_sha256(proof: *const u8, len: usize, digest: *const u8, message_len: u64, prm: *const ZkhipParams, reason: *mut c_int) -> c_int;
     // setup -> prove -> verify (sp1.rs:113, :116, :120): preprocessed columns committed once, the key's root is the verifying key
     pub fn zkhip_machine_setup(ctx: *mut ZkhipCtx, pre: *const ZkhipChip, n_chips: c_int, prm: *const ZkhipParams, key: *mut *mut ZkhipMachineKey, root: *mut u32) -> c_int;
     pub fn zkhip_machine_key_destroy(key: *mut ZkhipMachineKey);
@@ -136,7 +136,7 @@ extern "C" {
         ctx: *mut ZkhipCtx, key: *const ZkhipMachineKey, message: *const u8, message_len: usize, prm: *const ZkhipParams, digest: *mut u8,
         proof: *mut u8, cap: usize, len: *mut usize,
     ) -> c_int;
-    pub fn zkhip_verify_sha256_machine(proof: *const u8, len: usize, digest: *const u8, vk: *const u32, prm: *const ZkhipParams, reason: *mut c_int) -> c_int;
+    pub fn zkhip_verify_sha256_machine(proof: *const u8, len: usize, digest: *const u8, message_len: u64, vk: *const u32, prm: *const ZkhipParams, reason: *mut c_int) -> c_int;
     // a batch of transcripts in one call (BASELINE configs[2]): job i on devices[i mod n], pooled contexts keep their proving key
     pub fn zkhip_prove_transcripts(
         devices: *const c_int, n_devices: c_int, jobs: *mut ZkhipTranscriptJob, n_jobs: c_int, prm: *const ZkhipParams,
@@ -182,7 +182,7 @@ extern "C" {
     ) -> c_int;
     pub fn zkhip_verify_sha256_sharded(
         proofs: *const u8, proof_stride: usize, proof_lens: *const usize, n_shards: usize, chain: *const u32, log_blocks_per_shard: c_int,
-        digest: *const u8, prm: *const ZkhipParams, bad_shard: *mut usize, reason: *mut c_int,
+        digest: *const u8, message_len: u64, prm: *const ZkhipParams, bad_shard: *mut usize, reason: *mut c_int,
     ) -> c_int;
     pub fn zkhip_verify_merkle_paths(proof: *const u8, len: usize, root: *const u32, n_paths: usize, prm: *const ZkhipParams, reason: *mut c_int) -> c_int;
     // the first piece of the compress stage (sp1.rs:116): the FRI check of many shard proofs proven in-circuit by one call; the outer

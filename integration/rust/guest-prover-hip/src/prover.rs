@@ -215,8 +215,9 @@ impl HipGuestProver {
             check(unsafe { ffi::zkhip_prove_sha256_machine(keyed.ctx.raw(), keyed.key, cbor.as_ptr(), cbor.len(), &prm, d.as_mut_ptr(), proof.as_mut_ptr(), cap, &mut len) }, "zkhip_prove_sha256_machine")?;
             proof.truncate(len);
             let mut reason = 0;
-            check(unsafe { ffi::zkhip_verify_sha256_machine(proof.as_ptr(), proof.len(), d.as_ptr(), vk.as_ptr() as *const u32, &prm, &mut reason) }, "zkhip_verify_sha256_machine")?;
+            check(unsafe { ffi::zkhip_verify_sha256_machine(proof.as_ptr(), proof.len(), d.as_ptr(), cbor.len() as u64, vk.as_ptr() as *const u32, &prm, &mut reason) }, "zkhip_verify_sha256_machine")?;
             proofs.push(proof);
+            proofs.push((cbor.len() as u64).to_le_bytes().to_vec());       // the statement's other half: the input's length (the padding is constrained in-circuit)
             (d.to_vec(), BATCH_FLAG_INPUT_SHA256 | BATCH_FLAG_KEYED)
         } else if self.commitment && cbor.len() > (1usize << 20) - 9 && matches!(self.backend, Backend::Sp1) {
             // a large transcript: SHA-256 as a CHAIN of shard proofs over the device list (as the C++ mirror): entry 0 of the blob
@@ -230,11 +231,12 @@ impl HipGuestProver {
             let devices = [self.device];
             check(unsafe { ffi::zkhip_prove_sha256_sharded(devices.as_ptr(), 1, cbor.as_ptr(), cbor.len(), k, &prm, 2, d.as_mut_ptr(), chain.as_mut_ptr(), buf.as_mut_ptr(), stride, lens.as_mut_ptr()) }, "zkhip_prove_sha256_sharded")?;
             let (mut bad, mut reason) = (0usize, 0);
-            check(unsafe { ffi::zkhip_verify_sha256_sharded(buf.as_ptr(), stride, lens.as_ptr(), n, chain.as_ptr(), k, d.as_ptr(), &prm, &mut bad, &mut reason) }, "zkhip_verify_sha256_sharded")?;   // sp1.rs:120
+            check(unsafe { ffi::zkhip_verify_sha256_sharded(buf.as_ptr(), stride, lens.as_ptr(), n, chain.as_ptr(), k, d.as_ptr(), cbor.len() as u64, &prm, &mut bad, &mut reason) }, "zkhip_verify_sha256_sharded")?;   // sp1.rs:120
             proofs.push(chain.iter().flat_map(|w| w.to_le_bytes()).collect());
             for s in 0..n {
                 proofs.push(buf[s * stride..s * stride + lens[s]].to_vec());
             }
+            proofs.push((cbor.len() as u64).to_le_bytes().to_vec());
             (d.to_vec(), BATCH_FLAG_INPUT_SHA256 | BATCH_FLAG_CHAINED)
         } else if self.commitment {
             // 64 rows per 64-byte block, block count (padding included) rounded up to a power of two
@@ -247,8 +249,9 @@ impl HipGuestProver {
             check(unsafe { ffi::zkhip_prove_sha256(ctx.raw(), cbor.as_ptr(), cbor.len(), &prm, d.as_mut_ptr(), proof.as_mut_ptr(), cap, &mut len) }, "zkhip_prove_sha256")?;
             proof.truncate(len);
             let mut reason = 0;
-            check(unsafe { ffi::zkhip_verify_sha256(proof.as_ptr(), proof.len(), d.as_ptr(), &prm, &mut reason) }, "zkhip_verify_sha256")?;   // sp1.rs:120
+            check(unsafe { ffi::zkhip_verify_sha256(proof.as_ptr(), proof.len(), d.as_ptr(), cbor.len() as u64, &prm, &mut reason) }, "zkhip_verify_sha256")?;   // sp1.rs:120
             proofs.push(proof);
+            proofs.push((cbor.len() as u64).to_le_bytes().to_vec());
             (d.to_vec(), BATCH_FLAG_INPUT_SHA256)
         } else if let Some(src) = self.source.as_mut() {
             let (output, shards) = src.shards(cbor, elf)?;

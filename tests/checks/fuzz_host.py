@@ -84,14 +84,14 @@ assert L.zkhip_proof_to_bincode(src.ctypes.data_as(u8p), src.size, 6, 8, C.byref
 
 # a chain of two SHA-256 shard proofs (chained chip) for zkhip_verify_sha256_sharded
 cblocks = S.pad(bytes(range(190)))
-ct0, cout0 = S.trace(cblocks[:128])
+ct0, cout0 = S.trace(cblocks[:128], message_len=190, first_block=0)
 civ1 = [cout0[2 * k] | (cout0[2 * k + 1] << 16) for k in range(8)]
-ct1, cout1 = S.trace(cblocks[128:], chain_in=civ1)
+ct1, cout1 = S.trace(cblocks[128:], chain_in=civ1, message_len=190, first_block=2)
 civ = []
 for x in S.IV:
     civ += [x & 0xffff, x >> 16]
 cprog = S.program(chained=True)
-cp0, cp1 = O.prove_shard_air(cprog, ct0, cout0 + civ, oprm), O.prove_shard_air(cprog, ct1, cout1 + cout0, oprm)
+cp0, cp1 = O.prove_shard_air(cprog, ct0, S.chained_publics(cout0, civ), oprm), O.prove_shard_air(cprog, ct1, S.chained_publics(cout1, cout0[:16]), oprm)
 cstride = max(cp0.size, cp1.size)
 cbuf = np.zeros(2 * cstride, dtype=np.uint8); cbuf[:cp0.size] = cp0; cbuf[cstride:cstride + cp1.size] = cp1
 cchain = np.array([S.IV, civ1, [cout1[2 * k] | (cout1[2 * k + 1] << 16) for k in range(8)]], dtype=np.uint32)
@@ -166,7 +166,7 @@ while time.time() - t0 < budget:
     verify_machine(arr(p_machine), mln, mws, mp, [words(mutate(mtab[0].tobytes())), mtab[1], mtab[2]], mpub, prm)
     verify_machine_keyed(arr(mutate(p_keyed)), kln, kws, kpw, kroot, kp, ktab, kpub, prm)
     verify_machine_keyed(arr(p_keyed), kln, kws, [int(x) for x in rng.choice([0, 4, 8, 1020, 1024, 2**31], len(kpw))], rng.integers(0, 2**32, 8, dtype=np.uint64).astype(np.uint32), kp, ktab, kpub, prm)
-    verify_sha256(arr(mutate(p_sha)) if rng.random() < 0.7 else arr(p_sha), bytes(rng.integers(0, 256, 32, dtype=np.uint8)), prm)
+    verify_sha256(arr(mutate(p_sha)) if rng.random() < 0.7 else arr(p_sha), bytes(rng.integers(0, 256, 32, dtype=np.uint8)), prm, int(rng.choice([3, 0, 55, 56, 2**20, 2**40, 2**64 - 1])))
     w = words(mutate(fib.tobytes()))
     L.zkhip_air_validate(w.ctypes.data_as(u32p), w.size, int(rng.choice([4, 8])), int(rng.choice([3, 0])))
     out8 = (C.c_uint32 * 8)()
@@ -181,7 +181,7 @@ while time.time() - t0 < budget:
     clens = (C.c_size_t * 2)(int(rng.choice([cp0.size, 0, 15, cstride, cstride + 1, 2**40])), cp1.size)
     bad_s, why = C.c_size_t(0), C.c_int(0)
     L.zkhip_verify_sha256_sharded(mb.ctypes.data_as(u8p), cstride, clens, int(rng.choice([2, 2, 1])), mc.ctypes.data_as(u32p), int(rng.choice([1, 1, 0, 14, 99])),
-                                  cdigest.ctypes.data_as(u8p), C.byref(prm), C.byref(bad_s), C.byref(why))
+                                  cdigest.ctypes.data_as(u8p), int(rng.choice([190, 190, 189, 0, 2**33, 2**64 - 1])), C.byref(prm), C.byref(bad_s), C.byref(why))
     cm = arr(mutate(p_keyed if rng.random() < 0.5 else p_machine))
     L.zkhip_chips_bincode_size(cm.ctypes.data_as(u8p), cm.size)
     cb = arr(mutate(cbc.tobytes()))

@@ -80,7 +80,7 @@ def main():
     msgs = [b"transcript %d " % i * 40 for i in range(4 * K)]
     vk, res = prove_transcripts(msgs, Params(1, 20, 8), devices=devs)
     assert all(d == hashlib.sha256(m).digest() for m, (d, _) in zip(msgs, res))
-    assert all(verify_sha256_machine(p, d, vk, Params(1, 20, 8)) == (0, 0) for d, p in res)
+    assert all(verify_sha256_machine(p, d, vk, Params(1, 20, 8), len(m)) == (0, 0) for m, (d, p) in zip(msgs, res))
     out["transcripts_over_the_device_list"] = len(msgs)
     for c in ctxs.values():
         c.close()

@@ -142,7 +142,7 @@ def sha256_machine(message):
     values[:, 0] = np.arange(1 << 16)
     main = values.copy()
     main[:, 1] = np.bincount(sha_t[:, sent].ravel(), minlength=1 << 16)
-    table_prog = O.air_program(8, 16, [(O.SEL_FIRST, [(1, [V(0)])])])
+    table_prog = O.air_program(8, S.N_PUBLIC, [(O.SEL_FIRST, [(1, [V(0)])])])
     table_tab = O.interaction_table([(O.RECEIVE, 5, 16, [0])])
     chips = [(sha_t, None, S.program(), sha_tab), (main, values, table_prog, table_tab)]
     if sha_t.shape[0] <= 1 << 16:

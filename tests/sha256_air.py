@@ -1,10 +1,10 @@
 """SHA-256 compression as a constraint program (test-side restatement; the product's generator is csrc/sha256_chip.cpp).
 
-One row per round, 64 rows per 64-byte block, blocks one after the other; 608 columns, every constraint of degree <= 3
-(log_quotient_degree 1).  What a proof says: "I know at most 2^k blocks whose SHA-256 chaining value, from the standard IV, is
-the 16 public 16-bit limbs" -- with FIPS 180-4 padding inside the blocks, that is the SHA-256 digest of a message.  The trace
-height is a power of two, the block count of a message is not: blocks after the message are INACTIVE (ACT = 0) and pass the
-chaining value through unchanged.
+One row per round, 64 rows per 64-byte block, blocks one after the other; 612 columns, every constraint of degree <= 3
+(log_quotient_degree 1).  What a proof says (round 5): "I know a message of exactly L bytes whose SHA-256 digest is the 16 public
+16-bit limbs" -- L public, the FIPS 180-4 padding constrained in-circuit through 75 more public values a verifier derives from L
+(padding_publics).  The trace height is a power of two, the block count of a message is not: blocks after the message are INACTIVE
+(ACT = 0) and pass the chaining value through unchanged; a block counter pins where ACT drops.
 
 Columns (bit i of a word = column base + i, least significant first; a limb pair = low 16 bits, high 16 bits):
   SEL  64   one-hot round selector s_t
@@ -16,7 +16,9 @@ Columns (bit i of a word = column base + i, least significant first; a limb pair
   X0 X13  32 bits each: W_t and W_{t+13};  XL  14 x 2 limbs: W_{t+j}, j = 1..12, 14, 15
   SG0 SG1  32 bits each: sigma0(W_t), sigma1(W_{t+13})
   CY   28 carry bits
-  ACT  1 while the block belongs to the message;  SKIP = s_63 (1 - ACT): round 63 of an inactive block;  2 unused columns
+  ACT  1 while the block belongs to the message;  SKIP = s_63 (1 - ACT): round 63 of an inactive block
+  CNT  active blocks left (this one included);  LASTB  the last active block;  L2  the block before it;  SB  the row whose W_t holds the 0x80 byte;
+  Z0 = s_0 LASTB;  Z2 = s_0 L2
 """
 import hashlib
 import struct
@@ -37,8 +39,13 @@ XL = 484
 SG0, SG1 = 512, 544
 CY = 576
 ACT, SKIP = 604, 605
-WIDTH = 608
-N_PUBLIC = 16
+CNT, LASTB, L2, SB, Z0, Z2 = 606, 607, 608, 609, 610, 611
+WIDTH = 612
+# public values: 16 digest limbs (chained: + 16 limbs of the initial chaining value), then the padding's 75:
+N_DIGEST = 16
+PP_K, PP_FIN, PP_Z13, PP_BWL, PP_BW2, PP_KIND, PP_ZWL, PP_ZW2, PP_LEN, N_PAD = 0, 1, 2, 3, 19, 35, 39, 55, 71, 75
+N_PUBLIC = N_DIGEST + N_PAD
+N_PUBLIC_CHAINED = 2 * N_DIGEST + N_PAD
 # carries: a (3 + 3), e (3 + 3), b c d f g h (1 + 1 each), schedule (2 + 2)
 CY_A, CY_E, CY_W6, CY_SCHED = CY, CY + 6, CY + 12, CY + 24
 
@@ -183,25 +190,109 @@ def program(chained=False):
         if l == 1:
             terms += [((P - (1 << k)) % P, [V(CY_SCHED + k)]) for k in range(2)]
         cons.append((O.SEL_TRANSITION, gated(terms)))
-    return O.air_program(WIDTH, 2 * N_PUBLIC if chained else N_PUBLIC, cons)
+    # ---- padding (FIPS 180-4 5.1.1), pinned through public values derived from the message length (padding_publics)
+    PB = 2 * N_DIGEST if chained else N_DIGEST
+    pv = lambda i: V(PB + i, public=True)
+    act, actn, cnt, lastb, l2, sb, z0, z2, s0 = V(ACT), V(ACT, True), V(CNT), V(LASTB), V(L2), V(SB), V(Z0), V(Z2), V(SEL)
+    # the block count: CNT starts at K, loses one where an active block ends, is zero on inactive rows, equals ACT on the last row
+    cons.append((O.SEL_FIRST, [(1, [cnt]), (P - 1, [pv(PP_K)])]))
+    cons.append((O.SEL_TRANSITION, [(1, [V(CNT, True)]), (P - 1, [cnt]), (1, [s63, act])]))
+    cons.append((O.SEL_ALL, [(1, [cnt]), (P - 1, [act, cnt])]))
+    cons.append((O.SEL_LAST, [(1, [cnt]), (P - 1, [act])]))
+    # LASTB, L2: bits, constant inside a block; ACT drops exactly behind the LASTB block; the block before it carries L2
+    for f in (LASTB, L2):
+        cons.append((O.SEL_ALL, [(1, [V(f), V(f)]), (P - 1, [V(f)])]))
+        cons.append((O.SEL_TRANSITION, [(1, [V(f, True)]), (P - 1, [V(f)]), (P - 1, [s63, V(f, True)]), (1, [s63, V(f)])]))
+    cons.append((O.SEL_TRANSITION, [(1, [s63, act]), (P - 1, [s63, actn]), (P - 1, [s63, lastb])]))
+    cons.append((O.SEL_LAST, [(1, [lastb]), (P - 1, [act])]))
+    cons.append((O.SEL_TRANSITION, [(1, [s63, V(LASTB, True)]), (P - 1, [s63, l2])]))
+    cons.append((O.SEL_LAST, [(1, [l2])]))
+    cons.append((O.SEL_ALL, [(1, [z0]), (P - 1, [s0, lastb])]))
+    cons.append((O.SEL_ALL, [(1, [z2]), (P - 1, [s0, l2])]))
+    # SB marks row t = j of the block with the 0x80 byte, j = the word's index: there X0 holds the word's bits
+    terms = [(1, [sb])]
+    for j in range(16):
+        terms += [(P - 1, [pv(PP_BWL + j), lastb, V(SEL + j)]), (P - 1, [pv(PP_BW2 + j), l2, V(SEL + j)])]
+    cons.append((O.SEL_ALL, terms))
+    for i in range(32):
+        terms = []
+        for c in range(4):
+            if i <= 31 - 8 * c:
+                terms.append((1, [pv(PP_KIND + c), sb, V(X0 + i)]))
+            if i == 31 - 8 * c:
+                terms.append((P - 1, [pv(PP_KIND + c), sb]))
+        cons.append((O.SEL_ALL, terms))
+    # zero words and the length field, at row s_0 of their block (all sixteen words of the block are in the window there)
+    for j in range(16):
+        kind, base = _x(j)
+        for l in range(2):
+            lj = _limb(kind, base, l)
+            terms = [(c, [pv(PP_ZWL + j), z0] + vs) for c, vs in lj] + [(c, [pv(PP_ZW2 + j), z2] + vs) for c, vs in lj]
+            if j <= 13:
+                terms += [(c, [pv(PP_Z13), z0] + vs) for c, vs in lj]
+            else:
+                terms += [(c, [pv(PP_FIN), z0] + vs) for c, vs in lj]
+                terms.append((P - 1, [pv(PP_FIN), z0, pv(PP_LEN + (0 if j == 15 else 2) + l)]))
+            cons.append((O.SEL_ALL, terms))
+    return O.air_program(WIDTH, N_PUBLIC_CHAINED if chained else N_PUBLIC, cons)
+
+
+def padding_publics(message_len, first_block=0, n_active=None):
+    """the 75 public values of the padding constraints for a trace that holds blocks [first_block, first_block + n_active) of the padded
+    message of message_len bytes (a whole message: all (L + 8) // 64 + 1 blocks) -> (values, (block, row) of the boundary word or None)"""
+    L = int(message_len)
+    k, q, r = (L + 8) // 64 + 1, L // 64, L % 64
+    if n_active is None:
+        n_active = k - first_block
+    out = [0] * N_PAD
+    has_last = first_block <= k - 1 < first_block + n_active
+    has_pad = first_block <= q < first_block + n_active
+    out[PP_K] = n_active
+    out[PP_FIN] = int(has_last)
+    out[PP_Z13] = int(has_last and q != k - 1)
+    place = None
+    if has_pad:
+        j, c = r // 4, r % 4
+        by_l2 = q != k - 1 and has_last
+        out[(PP_BW2 if by_l2 else PP_BWL) + j] = 1
+        out[PP_KIND + c] = 1
+        for w in range(j + 1, (13 if q == k - 1 else 15) + 1):
+            out[(PP_ZW2 if by_l2 else PP_ZWL) + w] = 1
+        place = (q - first_block, j)
+    if has_last:
+        bits = 8 * L
+        out[PP_LEN:PP_LEN + 4] = [bits & 0xffff, (bits >> 16) & 0xffff, (bits >> 32) & 0xffff, (bits >> 48) & 0xffff]
+    return out, place
 
 
 def _rotr(x, r):
     return ((x >> r) | (x << (32 - r))) & 0xffffffff
 
 
+class Padded(bytes):
+    """padded blocks that remember the length of the message they came from (a slice forgets it: pass message_len / first_block then)"""
+    message_len = None
+
+
 def pad(message):
     """FIPS 180-4 padding; the block count is then rounded up to a power of two is NOT done here: choose the message length"""
     m = bytes(message) + b"\x80"
     m += b"\x00" * ((56 - len(m)) % 64) + struct.pack(">Q", 8 * len(message))
+    m = Padded(m)
+    m.message_len = len(message)
     return m
 
 
-def trace(blocks, total_blocks=None, chain_in=None):
-    """blocks: bytes, a multiple of 64 long (the message's blocks); total_blocks: a power of two >= their number (default: the
-    next one), the rest are inactive all-zero blocks -> (trace [64 total_blocks][608] canonical, public values [16])"""
+def trace(blocks, total_blocks=None, chain_in=None, message_len=None, first_block=0):
+    """blocks: bytes, a multiple of 64 long: blocks [first_block, ...) of the padded message of message_len bytes (default: what pad()
+    remembered); total_blocks: a power of two >= their number (default: the next one), the rest are inactive all-zero blocks ->
+    (trace [64 total_blocks][612] canonical, public values: 16 limbs of the final chaining value, then the 75 padding values of this slice)"""
     assert len(blocks) % 64 == 0 and len(blocks) > 0
+    if message_len is None:
+        message_len = getattr(blocks, "message_len", None)
+    assert message_len is not None, "trace: the message length is part of the statement (pass message_len for a slice of padded blocks)"
     active = len(blocks) // 64
+    pad_pub, place = padding_publics(message_len, first_block, active)
     nb = total_blocks or 1 << (active - 1).bit_length()
     assert nb & (nb - 1) == 0 and nb >= active
     blocks = bytes(blocks) + bytes(64 * (nb - active))
@@ -228,6 +319,10 @@ def trace(blocks, total_blocks=None, chain_in=None):
             t[row, SEL + r] = 1
             act = blk < active
             t[row, ACT], t[row, SKIP] = int(act), int(r == 63 and not act)
+            t[row, CNT] = active - blk if act else 0
+            t[row, LASTB], t[row, L2] = int(blk == active - 1), int(blk == active - 2)
+            t[row, SB] = int(place == (blk, r))
+            t[row, Z0], t[row, Z2] = int(r == 0 and blk == active - 1), int(r == 0 and blk == active - 2)
             for base, x in ((A, a), (B, b), (C, c), (E, e), (F, f), (G, g)):
                 bits(row, base, x)
             limbs(row, D, d); limbs(row, HV, hh)
@@ -277,7 +372,12 @@ def trace(blocks, total_blocks=None, chain_in=None):
     pub = []
     for x in h:
         pub += [x & 0xffff, x >> 16]
-    return t, pub
+    return t, pub + pad_pub
+
+
+def chained_publics(out_pub, in_limbs):
+    """public values of the CHAINED program from trace()'s: final limbs, the initial chaining value's limbs, the slice's padding values"""
+    return list(out_pub[:N_DIGEST]) + list(in_limbs) + list(out_pub[N_DIGEST:])
 
 
 def digest_bytes(pub):
@@ -311,7 +411,7 @@ def check_rows(prog, t, pub):
 
 if __name__ == "__main__":
     prog = program()
-    for msg, total in ((b"abc", None), (bytes(range(150)), None), (b"abc", 2)):
+    for msg, total in ((b"abc", None), (bytes(range(150)), None), (b"abc", 2), (b"", None), (bytes(55), None), (bytes(56), None), (bytes(63), 4), (bytes(64), None), (bytes(119), None), (bytes(121), 8)):
         tr, pub = trace(pad(msg), total)
         assert digest_bytes(pub) == hashlib.sha256(msg).digest()
         print("rows", tr.shape[0], "program words", prog.size, "constraints", prog[3], "failing", check_rows(prog, tr, pub)[:5])

@@ -92,20 +92,20 @@ def test_sha256_chip_with_a_preprocessed_range_table(ctx, oracle):
     sha_tab = O.interaction_table([(O.SEND, None, 16, [c]) for c in sent])
     values = np.zeros((1 << 16, 4), dtype=np.uint32)
     values[:, 0] = np.arange(1 << 16)
-    d_counts = ctx.range_table(d_sha, 608, 1 << 10, sent, 16)                 # main columns (v, multiplicity, 0, 0)
+    d_counts = ctx.range_table(d_sha, 612, 1 << 10, sent, 16)                 # main columns (v, multiplicity, 0, 0)
     # combined row of the table: [v 0 0 0 | v m 0 0]; the program: a harmless first-row identity, the key fixes the values
-    table_prog = O.air_program(8, 16, [(O.SEL_FIRST, [(1, [V(0)])])])
+    table_prog = O.air_program(8, S.N_PUBLIC, [(O.SEL_FIRST, [(1, [V(0)])])])
     table_tab = O.interaction_table([(O.RECEIVE, 5, 16, [0])])
     progs, tables = [table_prog, sha256_air()], [table_tab, sha_tab]
     prm, oprm = Params(1, 12, 4), O.default_params(1, 12, 4)
     key = ctx.machine_setup([(ctx.from_numpy(values), 16, 4), (None, 10, 0)], prm)
-    proof = ctx.prove_machine_keyed(key, [(d_counts, 16, 4), (d_sha, 10, 608)], progs, tables, sha_pub, prm)
-    host = [d_counts.download().reshape(-1, 4), d_sha.download().reshape(-1, 608)]
+    proof = ctx.prove_machine_keyed(key, [(d_counts, 16, 4), (d_sha, 10, 612)], progs, tables, sha_pub, prm)
+    host = [d_counts.download().reshape(-1, 4), d_sha.download().reshape(-1, 612)]
     assert proof.tobytes() == O.prove_machine_keyed(host, [values, None], progs, tables, sha_pub, oprm).tobytes()
-    assert verify_machine_keyed(proof, [16, 10], [4, 608], [4, 0], key.root, progs, tables, sha_pub, prm) == (0, 0)
+    assert verify_machine_keyed(proof, [16, 10], [4, 612], [4, 0], key.root, progs, tables, sha_pub, prm) == (0, 0)
     wrong = list(sha_pub)
     wrong[0] ^= 1
-    assert verify_machine_keyed(proof, [16, 10], [4, 608], [4, 0], key.root, progs, tables, wrong, prm)[0] == -6
+    assert verify_machine_keyed(proof, [16, 10], [4, 612], [4, 0], key.root, progs, tables, wrong, prm)[0] == -6
 
 
 import hashlib
@@ -144,17 +144,18 @@ def test_sha256_machine_setup_prove_verify(ctx, oracle, n_bytes):
     lns, ws, pws = shape_of(tr, pre)
     assert key.root.tolist() == O.machine_setup(pre, lns, oprm).tolist()
     assert proof.tobytes() == O.prove_machine_keyed(tr, pre, pg, tb, pub, oprm).tobytes()
-    assert verify_sha256_machine(proof, digest, key.root, prm) == (0, 0)
+    assert verify_sha256_machine(proof, digest, key.root, prm, len(msg)) == (0, 0)
+    assert verify_sha256_machine(proof, digest, key.root, prm, len(msg) + 1)[0] == -6          # the digest is right, the stated length is not
     assert O.verify_machine_keyed(proof, lns, ws, pws, key.root, pg, tb, pub, oprm) == 0
     other = bytearray(digest)
     other[5] ^= 1
-    assert verify_sha256_machine(proof, bytes(other), key.root, prm)[0] == -6
+    assert verify_sha256_machine(proof, bytes(other), key.root, prm, len(msg))[0] == -6
     vk2 = key.root.copy()
     vk2[0] = (int(vk2[0]) + 1) % 2013265921
-    assert verify_sha256_machine(proof, digest, vk2, prm) == (-6, 3)
+    assert verify_sha256_machine(proof, digest, vk2, prm, len(msg)) == (-6, 3)
     # the same key proves the next message
     digest2, proof2 = ctx.prove_sha256_machine(key, msg + b"x", prm)
-    assert digest2 == hashlib.sha256(msg + b"x").digest() and verify_sha256_machine(proof2, digest2, key.root, prm) == (0, 0)
+    assert digest2 == hashlib.sha256(msg + b"x").digest() and verify_sha256_machine(proof2, digest2, key.root, prm, len(msg) + 1) == (0, 0)
 
 
 def test_sha256_machine_above_the_table_height(ctx):
@@ -166,8 +167,8 @@ def test_sha256_machine_above_the_table_height(ctx):
     digest, proof = ctx.prove_sha256_machine(key, msg, prm)
     assert digest == hashlib.sha256(msg).digest()
     w = np.frombuffer(proof.tobytes(), dtype=np.uint32)
-    assert list(w[8:18]) == [17, 608, 1, 4, 0, 16, 4, 1, 1, 4]
-    assert verify_sha256_machine(proof, digest, key.root, prm) == (0, 0)
+    assert list(w[8:18]) == [17, 612, 1, 4, 0, 16, 4, 1, 1, 4]
+    assert verify_sha256_machine(proof, digest, key.root, prm, len(msg)) == (0, 0)
 
 
 def test_a_batch_of_transcripts_in_one_call(ctx, oracle):
@@ -183,7 +184,7 @@ def test_a_batch_of_transcripts_in_one_call(ctx, oracle):
     assert len(res) == 64
     for m, (digest, proof) in zip(msgs, res):
         assert digest == hashlib.sha256(m).digest()
-        assert verify_sha256_machine(proof, digest, vk, prm) == (0, 0)
+        assert verify_sha256_machine(proof, digest, vk, prm, len(m)) == (0, 0)
     for i in (0, 31, 63):
         tr, pre, pg, tb, pub = M.sha256_machine(msgs[i])
         assert res[i][1].tobytes() == oracle.prove_machine_keyed(tr, pre, pg, tb, pub, oprm).tobytes()

@@ -48,7 +48,7 @@ def test_transcripts_in_lockstep_are_the_same_bytes(ctx, oracle, lockstep):
         vk2, res2 = prove_transcripts(msgs, prm, devices=[0], in_flight=4, verify=True)      # checked beside the lanes
         assert all(a[1].tobytes() == b[1].tobytes() for a, b in zip(ref, res2))
     for m, (d, p) in list(zip(msgs, res))[::7]:
-        assert verify_sha256_machine(p, d, vk, prm) == (0, 0)
+        assert verify_sha256_machine(p, d, vk, prm, len(m)) == (0, 0)
     tr, pre, pg, tb, pub = M.sha256_machine(msgs[14])
     assert res[14][1].tobytes() == oracle.prove_machine_keyed(tr, pre, pg, tb, pub, oprm).tobytes()
 

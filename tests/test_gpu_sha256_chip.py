@@ -36,21 +36,22 @@ def test_prove_sha256_bytes_equal_the_oracles(ctx, oracle, n, shape):
     log_n = t.shape[0].bit_length() - 1
     oproof = O.prove_shard_air(prog, t, pub, O.default_params(*shape))
     assert proof.tobytes() == oproof.tobytes()
-    assert verify_sha256(proof, digest, Params(*shape)) == (0, 0)
+    assert verify_sha256(proof, digest, Params(*shape), len(msg)) == (0, 0)
+    assert verify_sha256(proof, digest, Params(*shape), len(msg) + 1)[0] == -6        # the same digest under another stated length
     assert O.verify_shard_air(prog, proof, log_n, S.WIDTH, pub, O.default_params(*shape)) == 0
     if n <= 150:
         assert pyverify.verify(proof.tobytes(), log_n, S.WIDTH, pub, *shape, air=sha256_air()) is True
     wrong = bytearray(digest)
     wrong[31] ^= 0x80
-    assert verify_sha256(proof, bytes(wrong), Params(*shape))[0] == -6
+    assert verify_sha256(proof, bytes(wrong), Params(*shape), len(msg))[0] == -6
 
 
 def test_a_megabyte_transcript(ctx):
-    """1 MiB - 9 bytes: 2^14 blocks, 2^20 rows x 608 columns (2.4 GiB trace, 4.9 GiB LDE): digest against hashlib, proof verified"""
+    """1 MiB - 9 bytes: 2^14 blocks, 2^20 rows x 612 columns (2.4 GiB trace, 4.9 GiB LDE): digest against hashlib, proof verified"""
     msg = np.random.default_rng(7).integers(0, 256, (1 << 20) - 9, dtype=np.uint8).tobytes()
     digest, proof = ctx.prove_sha256(msg, Params(1, 100, 16))
     assert digest == hashlib.sha256(msg).digest()
-    assert verify_sha256(proof, digest, Params(1, 100, 16)) == (0, 0)
+    assert verify_sha256(proof, digest, Params(1, 100, 16), len(msg)) == (0, 0)
 
 
 def test_misuse_fails_loudly(ctx):
@@ -77,15 +78,15 @@ def test_sixty_four_transcripts_in_one_call(ctx):
         digests.append(hashlib.sha256(msg).digest())
         assert S.digest_bytes(pubs[-1]) == digests[-1]
     ctx.sync()
-    proofs = prove_shards_air_multi(sha256_air(), traces, 14, 608, pubs, prm, devices=[0], in_flight=4)
+    proofs = prove_shards_air_multi(sha256_air(), traces, 14, 612, pubs, prm, devices=[0], in_flight=4)
     assert len(proofs) == 64 and len({p.tobytes() for p in proofs}) == 64
     for i, p in enumerate(proofs):
-        assert verify_sha256(p, digests[i], prm) == (0, 0)
-    assert verify_sha256(proofs[3], digests[4], prm)[0] == -6
+        assert verify_sha256(p, digests[i], prm, len(base) + 4) == (0, 0)
+    assert verify_sha256(proofs[3], digests[4], prm, len(base) + 4)[0] == -6
 
 
 def test_a_64_kib_message_bytes_equal_the_oracles(ctx, oracle):
-    """2^10 blocks -> 2^16 rows x 608 columns: the program kernel, the LDE and the openings at a size where every kernel runs many
+    """2^10 blocks -> 2^16 rows x 612 columns: the program kernel, the LDE and the openings at a size where every kernel runs many
     workgroups; the oracle proves the same trace on all host cores"""
     import os
     O = oracle
@@ -103,7 +104,7 @@ def test_a_64_kib_message_bytes_equal_the_oracles(ctx, oracle):
 
 @pytest.mark.parametrize("kib", [256, 1024])
 def test_large_messages_bytes_equal_the_oracles(ctx, oracle, kib):
-    """2^18 and 2^20 rows x 608 (the chip at the headline height): the oracle proves the trace the DEVICE generated (its cells are checked against the restatement at the
+    """2^18 and 2^20 rows x 612 (the chip at the headline height): the oracle proves the trace the DEVICE generated (its cells are checked against the restatement at the
     smaller sizes above; the pure-Python generator would take minutes here)"""
     import os
     from zktls_amd.device import sha256_pad
@@ -137,14 +138,15 @@ def test_sharded_proofs_bytes_equal_the_oracles(ctx, oracle):
     blocks = S.pad(msg)
     prog = S.program(chained=True)
     for s, proof in enumerate(res.proofs):
-        t, out = S.trace(blocks[256 * s:256 * (s + 1)], chain_in=[int(v) for v in res.chain[s]])
+        t, out = S.trace(blocks[256 * s:256 * (s + 1)], chain_in=[int(v) for v in res.chain[s]], message_len=len(msg), first_block=4 * s)
         pin = []
         for x in res.chain[s]:
             pin += [int(x) & 0xffff, int(x) >> 16]
         assert [int(out[2 * k] | (out[2 * k + 1] << 16)) for k in range(8)] == [int(v) for v in res.chain[s + 1]]
-        assert proof.tobytes() == O.prove_shard_air(prog, t, out + pin, oprm).tobytes(), s
+        assert proof.tobytes() == O.prove_shard_air(prog, t, S.chained_publics(out, pin), oprm).tobytes(), s
     # another digest, a swapped pair of shards, a shard from another message
     assert verify_sha256_sharded(res, digest=hashlib.sha256(b"other").digest(), params=prm)[0] == -6
+    assert verify_sha256_sharded(res, params=prm, message_len=len(msg) - 1)[0] == -6 and verify_sha256_sharded(res, params=prm, message_len=len(msg) + 64)[0] == -6      # another stated length
     swapped = res.buf.copy()
     swapped[:res.stride], swapped[res.stride:2 * res.stride] = res.buf[res.stride:2 * res.stride], res.buf[:res.stride]
     assert verify_sha256_sharded(res, params=prm, proofs=swapped)[:2] == (-6, 0)
@@ -155,7 +157,7 @@ def test_sharded_proofs_bytes_equal_the_oracles(ctx, oracle):
 
 
 def test_a_three_megabyte_body_as_a_chain_of_shards(ctx):
-    """BASELINE configs[3] with a real statement: a 3 MiB body = 49 153 blocks -> three shards of 2^14 blocks (2^20 rows x 608 each) and a
+    """BASELINE configs[3] with a real statement: a 3 MiB body = 49 153 blocks -> three shards of 2^14 blocks (2^20 rows x 612 each) and a
     one-block shard; digest against hashlib, the chain accepted by the host verifier; a corrupted shard is named"""
     from zktls_amd.device import prove_sha256_sharded, verify_sha256_sharded
     msg = np.random.default_rng(9).integers(0, 256, 3 << 20, dtype=np.uint8).tobytes()

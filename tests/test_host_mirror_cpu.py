@@ -294,7 +294,7 @@ def test_commitment_guest_mock_mode_outputs_the_sha256_of_the_input(lib):
 @pytest.mark.gpu
 @pytest.mark.parametrize("backend", [0, 1])
 def test_commitment_guest_proves_the_reference_transcript(lib, backend):
-    """the recorded 13 217-byte transcript: 207 blocks -> 2^14 rows x 608 columns; the proof is a real statement about the
+    """the recorded 13 217-byte transcript: 207 blocks -> 2^14 rows x 612 columns; the proof is a real statement about the
     request (SHA-256 chip), checked by the library's verifier against hashlib's digest"""
     import hashlib
     from zktls_amd._lib import Params
@@ -305,12 +305,17 @@ def test_commitment_guest_proves_the_reference_transcript(lib, backend):
     assert out == hashlib.sha256(cbor).digest()
     assert lib.zktls_batch_flags(blob, len(blob)) == 2           # INPUT_SHA256, not SYNTHETIC
     offs, lens = (C.c_size_t * 2)(), (C.c_size_t * 2)()
-    assert lib.zktls_unpack_batch(blob, len(blob), offs, lens, 2) == 1
+    assert lib.zktls_unpack_batch(blob, len(blob), offs, lens, 2) == 2 and lens[1] == 8          # the proof, then the input's length
+    assert struct.unpack("<Q", blob[offs[1]:offs[1] + 8])[0] == len(cbor)
+    lib.zktls_commitment_blob_length.argtypes = [C.c_char_p, C.c_size_t, C.POINTER(C.c_uint64)]
+    stated = C.c_uint64(0)
+    assert lib.zktls_commitment_blob_length(blob, len(blob), C.byref(stated)) == 0 and stated.value == len(cbor)
     proof = np.frombuffer(blob[offs[0]:offs[0] + lens[0]], dtype=np.uint8)
     prm = Params(1, 20, 6) if backend == 0 else Params(2, 20, 6, 0, 4, 6, 24)      # 2^14 rows: 64 final coefficients
-    assert verify_sha256(proof, out, prm) == (0, 0)
+    assert verify_sha256(proof, out, prm, len(cbor)) == (0, 0)
+    assert verify_sha256(proof, out, prm, len(cbor) - 1)[0] == -6                   # the digest is right, the stated length is not
     other = hashlib.sha256(cbor + b"x").digest()
-    assert verify_sha256(proof, other, prm)[0] == -6
+    assert verify_sha256(proof, other, prm, len(cbor))[0] == -6
     # the consumer's check of the blob, told which backend's shape to expect (the SP1-shape check cannot accept a RISC-Zero-shape proof)
     lib.zktls_verify_commitment_blob_for.argtypes = [C.c_int, C.c_char_p, C.c_size_t, C.c_char_p, C.c_char_p, C.c_size_t, C.c_int, C.c_int, C.POINTER(C.c_int)]
     reason = C.c_int(0)
@@ -379,7 +384,8 @@ def test_a_consumer_checks_a_keyed_commitment_blob_on_the_cpu(lib, oracle):
     oprm = O.default_params(1, 8, 4)
     root = O.machine_setup(pre, lns, oprm)
     proof = O.prove_machine_keyed(tr, pre, pg, tb, pub, oprm).tobytes()
-    blob = struct.pack("<4sIII", b"ZKTB", 2, 2 | 4, 1) + struct.pack("<I", len(proof)) + proof
+    tail = struct.pack("<IQ", 8, len(msg))                                     # the last entry: the input's length (the statement's other half)
+    blob = struct.pack("<4sIII", b"ZKTB", 2, 2 | 4, 2) + struct.pack("<I", len(proof)) + proof + tail
     assert lib.zktls_batch_flags(blob, len(blob)) == 6
     vk = struct.pack("<8I", *[int(v) for v in root]) + program_digest_bytes(b"\x7fELFguest")
     out = hashlib.sha256(msg).digest()
@@ -389,7 +395,9 @@ def test_a_consumer_checks_a_keyed_commitment_blob_on_the_cpu(lib, oracle):
     other[1] ^= 1
     assert verify_blob(lib, blob, out, bytes(other), 8, 4) == (-6, 3)           # another key
     assert verify_blob(lib, blob, out, None, 8, 4) == (-1, 2)                   # a keyed blob needs its vk
-    unkeyed = struct.pack("<4sIII", b"ZKTB", 2, 2, 1) + struct.pack("<I", len(proof)) + proof
+    unkeyed = struct.pack("<4sIII", b"ZKTB", 2, 2, 2) + struct.pack("<I", len(proof)) + proof + tail
+    longer = struct.pack("<4sIII", b"ZKTB", 2, 2 | 4, 2) + struct.pack("<I", len(proof)) + proof + struct.pack("<IQ", 8, len(msg) + 1)
+    assert verify_blob(lib, longer, out, vk, 8, 4)[0] == -6                      # the same proof under another stated length
     assert verify_blob(lib, unkeyed, out, vk, 8, 4) == (-1, 2)                  # a vk was given: a blob that does not claim to be keyed is refused, not checked without the key
     assert verify_blob(lib, unkeyed, out, None, 8, 4)[0] != 0                   # ... and as a single-chip proof the machine's proof fails
 
@@ -412,7 +420,7 @@ def test_setup_prove_verify_on_the_reference_transcript(lib, oracle):
     oprm = O.default_params(1, 20, 6)
     assert vk[:32] == struct.pack("<8I", *[int(v) for v in O.machine_setup(pre, lns, oprm)]) and vk[32:] == program_digest_bytes(elf)
     offs, lens = (C.c_size_t * 2)(), (C.c_size_t * 2)()
-    assert lib.zktls_unpack_batch(blob, len(blob), offs, lens, 2) == 1
+    assert lib.zktls_unpack_batch(blob, len(blob), offs, lens, 2) == 2 and blob[offs[1]:offs[1] + lens[1]] == struct.pack("<Q", len(cbor))      # the proof, then the input's length
     assert blob[offs[0]:offs[0] + lens[0]] == O.prove_machine_keyed(tr, pre, pg, tb, pub, oprm).tobytes()
     rc, err, out2, blob2, vk2 = call_commitment_keyed(lib, 2, cbor + b"more", elf)
     assert rc == 0 and vk2 == vk and verify_blob(lib, blob2, out2, vk) == (0, 0) and out2 == hashlib.sha256(cbor + b"more").digest()
@@ -428,7 +436,7 @@ def test_a_large_transcript_is_proven_as_a_chain_of_shards(lib):
     assert rc == 0, err
     assert out == hashlib.sha256(cbor).digest() and lib.zktls_batch_flags(blob, len(blob)) == 2 | 8
     offs, lens = (C.c_size_t * 8)(), (C.c_size_t * 8)()
-    assert lib.zktls_unpack_batch(blob, len(blob), offs, lens, 8) == 4            # the chaining values + three shards
+    assert lib.zktls_unpack_batch(blob, len(blob), offs, lens, 8) == 5 and lens[4] == 8            # the chaining values + three shards + the input's length
     assert lens[0] == 4 * 32
     assert verify_blob(lib, blob, out, None) == (0, 0)
     assert verify_blob(lib, blob, hashlib.sha256(b"other").digest(), None)[0] != 0
@@ -449,18 +457,18 @@ def test_a_consumer_checks_a_chained_commitment_blob_on_the_cpu(lib, oracle):
     O = oracle
     msg = bytes(range(190))
     blocks = S.pad(msg)
-    t0, out0 = S.trace(blocks[:128])
+    t0, out0 = S.trace(blocks[:128], message_len=190, first_block=0)
     iv1 = [out0[2 * k] | (out0[2 * k + 1] << 16) for k in range(8)]
-    t1, out1 = S.trace(blocks[128:], chain_in=iv1)
+    t1, out1 = S.trace(blocks[128:], chain_in=iv1, message_len=190, first_block=2)
     ivl = []
     for x in S.IV:
         ivl += [x & 0xffff, x >> 16]
     prog = S.program(chained=True)
     oprm = O.default_params(1, 6, 4)
-    p0, p1 = O.prove_shard_air(prog, t0, out0 + ivl, oprm).tobytes(), O.prove_shard_air(prog, t1, out1 + out0, oprm).tobytes()
+    p0, p1 = O.prove_shard_air(prog, t0, S.chained_publics(out0, ivl), oprm).tobytes(), O.prove_shard_air(prog, t1, S.chained_publics(out1, out0[:16]), oprm).tobytes()
     chain = struct.pack("<24I", *(list(S.IV) + iv1 + [out1[2 * k] | (out1[2 * k + 1] << 16) for k in range(8)]))
-    blob = struct.pack("<4sIII", b"ZKTB", 2, 2 | 8, 3)
-    for e in (chain, p0, p1):
+    blob = struct.pack("<4sIII", b"ZKTB", 2, 2 | 8, 4)
+    for e in (chain, p0, p1, struct.pack("<Q", len(msg))):
         blob += struct.pack("<I", len(e)) + e
     out = hashlib.sha256(msg).digest()
     assert lib.zktls_batch_flags(blob, len(blob)) == 10
@@ -478,11 +486,12 @@ def test_a_consumer_checks_a_chained_commitment_blob_on_the_cpu(lib, oracle):
     prm = Params(1, 6, 4)
     bad, why = C.c_size_t(0), C.c_int(0)
     assert L.zkhip_verify_sha256_sharded(buf.ctypes.data_as(_lib.u8p), stride, lens, 2, ch.ctypes.data_as(_lib.u32p), 1, dg.ctypes.data_as(_lib.u8p),
-                                         C.byref(prm), C.byref(bad), C.byref(why)) == 0
+                                         len(msg), C.byref(prm), C.byref(bad), C.byref(why)) == 0
     # malformed framing: the chain entry of the wrong size, no shards
-    short = struct.pack("<4sIII", b"ZKTB", 2, 2 | 8, 2) + struct.pack("<I", len(chain) - 4) + chain[:-4] + struct.pack("<I", len(p0)) + p0
+    tail = struct.pack("<IQ", 8, len(msg))
+    short = struct.pack("<4sIII", b"ZKTB", 2, 2 | 8, 3) + struct.pack("<I", len(chain) - 4) + chain[:-4] + struct.pack("<I", len(p0)) + p0 + tail
     assert verify_blob(lib, short, out, None, 6, 4)[0] == -1
-    only_chain = struct.pack("<4sIII", b"ZKTB", 2, 2 | 8, 1) + struct.pack("<I", len(chain)) + chain
+    only_chain = struct.pack("<4sIII", b"ZKTB", 2, 2 | 8, 2) + struct.pack("<I", len(chain)) + chain + tail
     assert verify_blob(lib, only_chain, out, None, 6, 4)[0] == -1
 
 

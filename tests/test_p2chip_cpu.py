@@ -173,11 +173,12 @@ def test_the_python_verifier_accepts_the_chips_proofs(oracle):
     # chained SHA-256 chip: the second shard of a two-shard message
     blocks = S.pad(bytes(range(100)))
     assert len(blocks) == 128
-    t0, out0 = S.trace(blocks[:64])
+    t0, out0 = S.trace(blocks[:64], message_len=100, first_block=0)
     iv1 = [out0[2 * k] | (out0[2 * k + 1] << 16) for k in range(8)]
-    t1, out1 = S.trace(blocks[64:], chain_in=iv1)
+    t1, out1 = S.trace(blocks[64:], chain_in=iv1, message_len=100, first_block=1)
     prog = S.program(chained=True)
-    p1 = O.prove_shard_air(prog, t1, out1 + out0, oprm)
-    assert pyverify.verify(p1.tobytes(), 6, S.WIDTH, out1 + out0, *shape, air=prog) is True
+    pv1 = S.chained_publics(out1, out0[:16])
+    p1 = O.prove_shard_air(prog, t1, pv1, oprm)
+    assert pyverify.verify(p1.tobytes(), 6, S.WIDTH, pv1, *shape, air=prog) is True
     with pytest.raises(pyverify.Reject):
-        pyverify.verify(p1.tobytes(), 6, S.WIDTH, out1 + [(out0[0] + 1) % P] + out0[1:], *shape, air=prog)
+        pyverify.verify(p1.tobytes(), 6, S.WIDTH, pv1[:16] + [(pv1[16] + 1) % P] + pv1[17:], *shape, air=prog)

@@ -193,10 +193,10 @@ def test_prove_core_input_commitment_guest(server):
     output, blob = res[4:4 + on], res[4 + on:]
     assert output == hashlib.sha256(cbor).digest()
     magic, version, flags, count = struct.unpack_from("<4I", blob)
-    assert (magic, version, flags, count) == (0x42544B5A, 2, 2, 1)              # "ZKTB", flagged INPUT_SHA256
+    assert (magic, version, flags, count) == (0x42544B5A, 2, 2, 2)              # "ZKTB", flagged INPUT_SHA256: the proof, then the input's length
     ln = struct.unpack_from("<I", blob, 16)[0]
-    assert 20 + ln == len(blob)
-    assert verify_sha256(np.frombuffer(blob[20:], dtype=np.uint8), output, Params(1, 16, 5)) == (0, 0)
+    assert 20 + ln + 12 == len(blob) and struct.unpack_from("<IQ", blob, 20 + ln) == (8, len(cbor))
+    assert verify_sha256(np.frombuffer(blob[20:20 + ln], dtype=np.uint8), output, Params(1, 16, 5), len(cbor)) == (0, 0)
 
 
 def prove_payload_v2(shards, queries, pow_bits, cbor, elf, flags, backend=0, device=0):
@@ -228,7 +228,7 @@ def test_prove_core_keyed_commitment_guest(server):
     vn = struct.unpack_from("<I", res, 4 + on)[0]
     vk, blob = res[8 + on:8 + on + vn], res[8 + on + vn:]
     assert output == hashlib.sha256(cbor).digest() and vn == 64
-    assert struct.unpack_from("<4I", blob) == (0x42544B5A, 2, 6, 1)                # INPUT_SHA256 | KEYED
+    assert struct.unpack_from("<4I", blob) == (0x42544B5A, 2, 6, 2)                # INPUT_SHA256 | KEYED: the proof, then the input's length
     reason = C.c_int(0)
     assert L.zktls_verify_commitment_blob(blob, len(blob), output, vk, 64, 16, 5, C.byref(reason)) == 0
     assert L.zktls_verify_commitment_blob(blob, len(blob), hashlib.sha256(b"x").digest(), vk, 64, 16, 5, C.byref(reason)) != 0
@@ -236,4 +236,4 @@ def test_prove_core_keyed_commitment_guest(server):
     st, ct, body = call(server, "ProveCore", pb_bytes(prove_payload_v2(0, 16, 5, cbor, b"\x7fELFguest", 0)))
     res = pb_field1(body)
     on = struct.unpack_from("<I", res)[0]
-    assert st == 200 and struct.unpack_from("<I", res, 4 + on)[0] == 0 and struct.unpack_from("<4I", res, 8 + on) == (0x42544B5A, 2, 2, 1)
+    assert st == 200 and struct.unpack_from("<I", res, 4 + on)[0] == 0 and struct.unpack_from("<4I", res, 8 + on) == (0x42544B5A, 2, 2, 2)

@@ -14,23 +14,23 @@ ctx = Context(0)
 prm = Params(1, 100, 16)
 base = open(os.path.join(ROOT, "tests", "golden", "reference", "guest_input0.cbor"), "rb").read()
 inflight = int(sys.argv[1]) if len(sys.argv) > 1 else 4
-traces, pubs, digests = [], [], []
+traces, pubs, digests, lengths = [], [], [], []
 t0 = time.perf_counter()
 for i in range(64):
     msg = base + i.to_bytes(4, "little")
     d, limbs = ctx.sha256_gen_trace(sha256_pad(msg))
-    traces.append(d); pubs.append(limbs.tolist()); digests.append(hashlib.sha256(msg).digest())
+    traces.append(d); pubs.append(limbs.tolist()); digests.append(hashlib.sha256(msg).digest()); lengths.append(len(msg))
 ctx.sync()
 tg = time.perf_counter() - t0
 prog = sha256_air()
-prove_shards_air_multi(prog, traces[:8], 14, 608, pubs[:8], prm, devices=[0], in_flight=inflight)       # contexts, plans
+prove_shards_air_multi(prog, traces[:8], 14, 612, pubs[:8], prm, devices=[0], in_flight=inflight)       # contexts, plans
 for rep in range(3):
     t0 = time.perf_counter()
-    proofs = prove_shards_air_multi(prog, traces, 14, 608, pubs, prm, devices=[0], in_flight=inflight)
+    proofs = prove_shards_air_multi(prog, traces, 14, 612, pubs, prm, devices=[0], in_flight=inflight)
     dt = time.perf_counter() - t0
     print("64 transcripts of %d bytes: traces generated in %.1f ms, proven in %.1f ms = %.2f ms per transcript (%d in flight)" % (len(base) + 4, tg * 1e3, dt * 1e3, dt * 1e3 / 64, inflight))
 t0 = time.perf_counter()
-assert all(verify_sha256(p, digests[i], prm) == (0, 0) for i, p in enumerate(proofs))
+assert all(verify_sha256(p, digests[i], prm, lengths[i]) == (0, 0) for i, p in enumerate(proofs))
 print("all 64 verified on the host in %.1f ms" % ((time.perf_counter() - t0) * 1e3))
 
 # the same batch as KEYED MACHINES through one call of zkhip_prove_transcripts: padding, trace generation, the range table's multiplicities
@@ -49,5 +49,5 @@ for rep in range(2):
     dt = time.perf_counter() - t0
     print("... proven AND verified inside the call (each worker checks its proof on the host while the GPU runs the others): %.1f ms = %.2f ms per transcript" % (dt * 1e3, dt * 1e3 / 64))
 t0 = time.perf_counter()
-assert all(verify_sha256_machine(p, d, vk, prm) == (0, 0) and d == hashlib.sha256(m).digest() for m, (d, p) in zip(msgs, res))
+assert all(verify_sha256_machine(p, d, vk, prm, len(m)) == (0, 0) and d == hashlib.sha256(m).digest() for m, (d, p) in zip(msgs, res))
 print("all 64 verified against the vk on the host in %.1f ms" % ((time.perf_counter() - t0) * 1e3))

@@ -1,4 +1,4 @@
-"""latency of ONE keyed SHA-256 machine proof of the recorded 13 KB transcript (2^14 x 608 chip + 2^16-row table), one context, nothing else in
+"""latency of ONE keyed SHA-256 machine proof of the recorded 13 KB transcript (2^14 x 612 chip + 2^16-row table), one context, nothing else in
 flight: python tools/keyed_latency.py [reps=20]   (run under rocprofv3 --kernel-trace --stats for the launch count and the busy time)"""
 import os
 import sys
@@ -21,6 +21,6 @@ for _ in range(reps):
     digest, proof = ctx.prove_sha256_machine(key, msg, prm)
 dt = (time.perf_counter() - t0) / reps
 t0 = time.perf_counter()
-assert verify_sha256_machine(proof, digest, key.root, prm) == (0, 0)
+assert verify_sha256_machine(proof, digest, key.root, prm, len(msg)) == (0, 0)
 tv = time.perf_counter() - t0
 print("keyed SHA-256 machine, %d-byte transcript: %.2f ms per proof (one in flight), %d bytes; host verification %.2f ms" % (len(msg), dt * 1e3, proof.size, tv * 1e3))

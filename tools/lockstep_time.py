@@ -41,5 +41,5 @@ for batch, lanes in ((16, 4), (8, 8), (6, 11), (4, 16), (8, 4), (11, 6)):
         (s1[0] - s0[0]) // 3, (s1[1] - s0[1]) // 3, (s1[1] - s0[1]) / max(1, s1[0] - s0[0]), s1[2] - s0[2]))
     timed("... proven and verified inside the call", verify=True)
 t0 = time.perf_counter()
-assert all(verify_sha256_machine(p, d, vk, prm) == (0, 0) and d == hashlib.sha256(m).digest() for m, (d, p) in zip(msgs, res))
+assert all(verify_sha256_machine(p, d, vk, prm, len(m)) == (0, 0) and d == hashlib.sha256(m).digest() for m, (d, p) in zip(msgs, res))
 print("all %d verified against the vk on the host in %.1f ms" % (n, (time.perf_counter() - t0) * 1e3))

@@ -47,7 +47,7 @@ EXPORTS = [
     "zkhip_fri_indices_program", "zkhip_fri_indices_key", "zkhip_fri_indices_proof_size", "zkhip_prove_fri_indices", "zkhip_verify_fri_indices",
     "zkhip_prove_fri_indices_batch", "zkhip_fri_view_all",
     "zkhip_p2chip_air", "zkhip_p2chip_gen_merkle_trace", "zkhip_merkle_paths_proof_size", "zkhip_prove_merkle_paths", "zkhip_verify_merkle_paths",
-    "zkhip_sha256_air", "zkhip_sha256_digest", "zkhip_sha256_pad", "zkhip_sha256_gen_trace", "zkhip_sha256_proof_size", "zkhip_prove_sha256", "zkhip_verify_sha256",
+    "zkhip_sha256_air", "zkhip_sha256_digest", "zkhip_sha256_pad", "zkhip_sha256_padding_publics", "zkhip_sha256_gen_trace", "zkhip_sha256_proof_size", "zkhip_prove_sha256", "zkhip_verify_sha256",
 ]
 
 
@@ -207,7 +207,7 @@ def load():
     L.zkhip_sha256_machine_proof_size.restype = C.c_size_t
     L.zkhip_sha256_machine_proof_size.argtypes = [C.c_size_t, C.POINTER(Params)]
     L.zkhip_prove_sha256_machine.argtypes = [C.c_void_p, C.c_void_p, u8p, C.c_size_t, C.POINTER(Params), u8p, u8p, C.c_size_t, szp]
-    L.zkhip_verify_sha256_machine.argtypes = [u8p, C.c_size_t, u8p, u32p, C.POINTER(Params), C.POINTER(C.c_int)]
+    L.zkhip_verify_sha256_machine.argtypes = [u8p, C.c_size_t, u8p, C.c_uint64, u32p, C.POINTER(Params), C.POINTER(C.c_int)]
     L.zkhip_chips_bincode_size.restype = C.c_size_t
     L.zkhip_chips_bincode_size.argtypes = [u8p, C.c_size_t]
     L.zkhip_chips_proof_to_bincode.argtypes = [u8p, C.c_size_t, u32p, C.c_size_t, u8p, C.c_size_t, szp]
@@ -289,24 +289,26 @@ def load():
     L.zkhip_verify_merkle_paths.argtypes = [u8p, C.c_size_t, u32p, C.c_size_t, C.POINTER(Params), C.POINTER(C.c_int)]
     L.zkhip_sha256_air_chained.restype = C.c_size_t
     L.zkhip_sha256_air_chained.argtypes = [u32p, C.c_size_t]
-    L.zkhip_sha256_gen_trace_chained.argtypes = [C.c_void_p, u32p, u8p, C.c_size_t, C.c_size_t, C.c_void_p, C.c_size_t, u32p]
+    L.zkhip_sha256_gen_trace_chained.argtypes = [C.c_void_p, u32p, u8p, C.c_size_t, C.c_size_t, C.c_uint64, C.c_uint64, C.c_void_p, C.c_size_t, u32p]
     L.zkhip_sha256_sharded_count.restype = C.c_size_t
     L.zkhip_sha256_sharded_count.argtypes = [C.c_size_t, C.c_int]
     L.zkhip_sha256_shard_proof_size.restype = C.c_size_t
     L.zkhip_sha256_shard_proof_size.argtypes = [C.c_int, C.POINTER(Params)]
     L.zkhip_prove_sha256_sharded.argtypes = [C.POINTER(C.c_int), C.c_int, u8p, C.c_size_t, C.c_int, C.POINTER(Params), C.c_int, u8p, u32p, u8p, C.c_size_t, szp]
-    L.zkhip_verify_sha256_sharded.argtypes = [u8p, C.c_size_t, szp, C.c_size_t, u32p, C.c_int, u8p, C.POINTER(Params), szp, C.POINTER(C.c_int)]
+    L.zkhip_verify_sha256_sharded.argtypes = [u8p, C.c_size_t, szp, C.c_size_t, u32p, C.c_int, u8p, C.c_uint64, C.POINTER(Params), szp, C.POINTER(C.c_int)]
     L.zkhip_sha256_air.restype = C.c_size_t
     L.zkhip_sha256_air.argtypes = [u32p, C.c_size_t]
     L.zkhip_sha256_digest.restype = None
     L.zkhip_sha256_digest.argtypes = [u8p, C.c_size_t, u8p]
     L.zkhip_sha256_pad.restype = C.c_size_t
     L.zkhip_sha256_pad.argtypes = [u8p, C.c_size_t, u8p, C.c_size_t]
-    L.zkhip_sha256_gen_trace.argtypes = [C.c_void_p, u8p, C.c_size_t, C.c_size_t, C.c_void_p, C.c_size_t, u32p]
+    L.zkhip_sha256_gen_trace.argtypes = [C.c_void_p, u8p, C.c_size_t, C.c_size_t, C.c_uint64, C.c_void_p, C.c_size_t, u32p]
+    L.zkhip_sha256_padding_publics.argtypes = [C.c_uint64, C.c_uint64, C.c_uint64, u32p]
+    L.zkhip_sha256_padding_publics.restype = None
     L.zkhip_sha256_proof_size.restype = C.c_size_t
     L.zkhip_sha256_proof_size.argtypes = [C.c_size_t, C.POINTER(Params)]
     L.zkhip_prove_sha256.argtypes = [C.c_void_p, u8p, C.c_size_t, C.POINTER(Params), u8p, u8p, C.c_size_t, C.POINTER(C.c_size_t)]
-    L.zkhip_verify_sha256.argtypes = [u8p, C.c_size_t, u8p, C.POINTER(Params), C.POINTER(C.c_int)]
+    L.zkhip_verify_sha256.argtypes = [u8p, C.c_size_t, u8p, C.c_uint64, C.POINTER(Params), C.POINTER(C.c_int)]
     L.zkhip_load_poseidon2_params.argtypes = [C.c_char_p]
     L.zkhip_poseidon2_params_name.restype = C.c_char_p
     L.zkhip_poseidon2_params_name.argtypes = [C.c_int]

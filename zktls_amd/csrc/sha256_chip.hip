@@ -15,7 +15,24 @@
 //   S1 CH S0 MJ 32 bits each (Sigma1(e), Ch, Sigma0(a), Maj) | HC 8 limb pairs (chaining value of the block)
 //   OUT 8 limb pairs (variables after the round, + chaining value in round 63, mod 2^32) | X0 X13 32 bits (W_t, W_{t+13})
 //   XL 14 limb pairs (W_{t+j}, j = 1..12, 14, 15) | SG0 SG1 32 bits (sigma0(W_t), sigma1(W_{t+13})) | CY 28 carry bits
-//   ACT (block belongs to the message) | SKIP = s_63 (1 - ACT) | 2 unused
+//   ACT (block belongs to the message) | SKIP = s_63 (1 - ACT)
+//   CNT (active blocks left, this one included) | LASTB (the last active block) | L2 (the block before it) | SB (the row whose W_t is the
+//   word that holds the 0x80 byte) | Z0 = s_0 LASTB | Z2 = s_0 L2                                   -- the padding columns, round 5
+//
+// PADDING IN-CIRCUIT (round 5).  Until round 4 a proof said "a compression chain over SOME block sequence ends in this digest": ACT could
+// drop after any block, the 0x80 byte and the length field were the host's business.  Now the statement is "digest = SHA-256 of a message of
+// L bytes" with L PUBLIC: the verifier derives 75 more public values from L (sha::padding_publics: the block count K, where the 0x80 byte
+// sits -- block, word, byte --, which words must be zero, the length field) and the program pins
+//   * the block count: CNT = K on the first row, CNT' = CNT - s_63 ACT, (1 - ACT) CNT = 0, CNT = ACT on the last row -- ACT can neither drop
+//     early (CNT would not be 0 yet) nor late (CNT would pass 0);
+//   * LASTB / L2: block-constant flags; ACT - ACT' = LASTB where a block ends, LASTB = ACT on the last row, LASTB' = L2 where a block ends;
+//   * the boundary word: SB = sum_j (BWL_j LASTB + BW2_j L2) s_j selects the ROW t = j of the block with the 0x80 byte, where X0 holds the
+//     word's 32 bits: below the byte's position the bits are fixed (1 then zeros: KIND_c picks one of the four byte positions), above it
+//     they are the message's;
+//   * the words that must be zero and the 64-bit length field, at row s_0 of their block, where all sixteen words of the block are in the
+//     window (X0, X13 as bits, the others as limb pairs): Z0 / Z2 times a public mask times the limb.
+// Every term keeps to three factors (public values count: air.h), so the quotient degree stays 2 chunks.  A chained shard (a slice of a
+// longer message) gets the same constraints with the public values of ITS slice: no boundary, no length field in a slice that has neither.
 #include <algorithm>
 #include <atomic>
 #include <memory>
@@ -34,7 +51,10 @@ namespace sha {
 
 constexpr uint32_t SEL = 0, A = 64, B = 96, C = 128, E = 160, F = 192, G = 224, D = 256, HV = 258;
 constexpr uint32_t S1 = 260, CH = 292, S0 = 324, MJ = 356, HC = 388, OUT = 404, X0 = 420, X13 = 452, XL = 484;
-constexpr uint32_t SG0 = 512, SG1 = 544, CY = 576, ACT = 604, SKIP = 605, WIDTH = 608, N_PUBLIC = 16;
+constexpr uint32_t SG0 = 512, SG1 = 544, CY = 576, ACT = 604, SKIP = 605, CNT = 606, LASTB = 607, L2 = 608, SB = 609, Z0 = 610, Z2 = 611, WIDTH = 612;
+// public values: the digest's 16 limbs (chained: then the initial chaining value's 16), then the padding's:
+constexpr uint32_t N_DIGEST = 16, PP_K = 0, PP_FIN = 1, PP_Z13 = 2, PP_BWL = 3, PP_BW2 = 19, PP_KIND = 35, PP_ZWL = 39, PP_ZW2 = 55, PP_LEN = 71, N_PAD = 75;
+constexpr uint32_t N_PUBLIC = N_DIGEST + N_PAD, N_PUBLIC_CHAINED = 2 * N_DIGEST + N_PAD;
 constexpr uint32_t CY_A = CY, CY_E = CY + 6, CY_W6 = CY + 12, CY_SCHED = CY + 24;
 
 constexpr uint32_t IV[8] = {0x6a09e667u, 0xbb67ae85u, 0x3c6ef372u, 0xa54ff53au, 0x510e527fu, 0x9b05688cu, 0x1f83d9abu, 0x5be0cd19u};
@@ -64,6 +84,38 @@ __host__ __device__ inline uint32_t big_sigma0(uint32_t a) { return rotr(a, 2) ^
 __host__ __device__ inline uint32_t big_sigma1(uint32_t e) { return rotr(e, 6) ^ rotr(e, 11) ^ rotr(e, 25); }
 __host__ __device__ inline uint32_t small_sigma0(uint32_t w) { return rotr(w, 7) ^ rotr(w, 18) ^ (w >> 3); }
 __host__ __device__ inline uint32_t small_sigma1(uint32_t w) { return rotr(w, 17) ^ rotr(w, 19) ^ (w >> 10); }
+
+// ---- what the padding of a message of L bytes means for a trace that holds blocks [first, first + n_active) of the padded message ----
+// FIPS 180-4 5.1.1: the message, 0x80, zeros, the bit length as 64 bits big-endian; k = (L + 8) / 64 + 1 blocks; the 0x80 byte is byte
+// L mod 64 of block q = L / 64 (q = k - 1, or k - 2 when L mod 64 >= 56).  out[N_PAD]: the public values the program's padding constraints
+// read (layout PP_*), a function of (L, first, n_active) alone -- the verifier computes them, the proof does not carry them.
+struct PadPlace { uint32_t pad_block = 0xFFFFFFFFu, pad_row = 0; };       // trace-relative block with the 0x80 byte and the row (= word index) to flag
+inline PadPlace padding_publics(uint64_t L, uint64_t first, uint64_t n_active, uint32_t out[N_PAD]) {
+    for (uint32_t i = 0; i < N_PAD; i++) out[i] = 0u;
+    PadPlace pl;
+    const uint64_t k = (L + 8) / 64 + 1, q = L / 64, r = L % 64;
+    const bool has_last = n_active > 0 && k - 1 >= first && k - 1 < first + n_active;
+    const bool has_pad = n_active > 0 && q >= first && q < first + n_active;
+    out[PP_K] = (uint32_t)n_active;
+    out[PP_FIN] = has_last ? 1u : 0u;
+    out[PP_Z13] = (has_last && q != k - 1) ? 1u : 0u;           // the length block holds nothing else: words 0 .. 13 are zero
+    if (has_pad) {
+        const uint32_t j = (uint32_t)(r / 4), c = (uint32_t)(r % 4);
+        // the block with the 0x80 byte is this trace's LAST active block (flag LASTB), or the one before it (flag L2) when the length block follows it here
+        const bool by_l2 = q != k - 1 && has_last;
+        out[(by_l2 ? PP_BW2 : PP_BWL) + j] = 1u;
+        out[PP_KIND + c] = 1u;
+        const uint32_t upto = (q == k - 1) ? 13u : 15u;          // zeros run to the length field (same block) or to the block's end
+        for (uint32_t w = j + 1; w <= upto; w++) out[(by_l2 ? PP_ZW2 : PP_ZWL) + w] = 1u;
+        pl.pad_block = (uint32_t)(q - first); pl.pad_row = j;
+    }
+    if (has_last) {
+        const uint64_t bits = L * 8;
+        out[PP_LEN + 0] = (uint32_t)(bits & 0xffffu); out[PP_LEN + 1] = (uint32_t)((bits >> 16) & 0xffffu);       // W_15: low, high limb
+        out[PP_LEN + 2] = (uint32_t)((bits >> 32) & 0xffffu); out[PP_LEN + 3] = (uint32_t)((bits >> 48) & 0xffffu);  // W_14
+    }
+    return pl;
+}
 
 // ---- the constraint program ------------------------------------------------------------------------------------------
 struct Term { uint32_t coeff; std::vector<uint32_t> vars; };
@@ -227,7 +279,56 @@ static std::vector<uint32_t> build_program(bool chained) {
             if (l == 1) for (uint32_t k = 0; k < 2; k++) t.push_back(Term{P - (1u << k), {var(CY_SCHED + k)}});
             b.add(TRANSITION, gated(t));
         }
-        std::vector<uint32_t> p{AIR_MAGIC, 1u, WIDTH, b.count, chained ? 2 * N_PUBLIC : N_PUBLIC, (uint32_t)(6 + b.body.size())};
+        // ---- padding (round 5; the header comment states what each group pins).  PB: where the padding's public values start
+        {
+            const uint32_t PB = chained ? 2 * N_DIGEST : N_DIGEST;
+            const uint32_t act = var(ACT), actn = var(ACT, true), cnt = var(CNT), lastb = var(LASTB), l2 = var(L2), sb = var(SB), z0 = var(Z0), z2 = var(Z2), s0 = var(SEL);
+            // block count
+            b.add(FIRST, Terms{{1, {cnt}}, {P - 1, {pub(PB + PP_K)}}});
+            b.add(TRANSITION, Terms{{1, {var(CNT, true)}}, {P - 1, {cnt}}, {1, {s63, act}}});
+            b.add(ALL, Terms{{1, {cnt}}, {P - 1, {act, cnt}}});
+            b.add(LAST, Terms{{1, {cnt}}, {P - 1, {act}}});
+            // the flags: bits, constant inside a block, tied to where ACT drops
+            for (uint32_t f : {LASTB, L2}) {
+                b.add(ALL, Terms{{1, {var(f), var(f)}}, {P - 1, {var(f)}}});
+                b.add(TRANSITION, Terms{{1, {var(f, true)}}, {P - 1, {var(f)}}, {P - 1, {s63, var(f, true)}}, {1, {s63, var(f)}}});
+            }
+            b.add(TRANSITION, Terms{{1, {s63, act}}, {P - 1, {s63, actn}}, {P - 1, {s63, lastb}}});
+            b.add(LAST, Terms{{1, {lastb}}, {P - 1, {act}}});
+            b.add(TRANSITION, Terms{{1, {s63, var(LASTB, true)}}, {P - 1, {s63, l2}}});
+            b.add(LAST, Terms{{1, {l2}}});
+            b.add(ALL, Terms{{1, {z0}}, {P - 1, {s0, lastb}}});
+            b.add(ALL, Terms{{1, {z2}}, {P - 1, {s0, l2}}});
+            // the row of the boundary word
+            {
+                Terms t{{1, {sb}}};
+                for (uint32_t j = 0; j < 16; j++) { t.push_back(Term{P - 1, {pub(PB + PP_BWL + j), lastb, var(SEL + j)}}); t.push_back(Term{P - 1, {pub(PB + PP_BW2 + j), l2, var(SEL + j)}}); }
+                b.add(ALL, t);
+            }
+            // its bits: with c message bytes in front (KIND_c), bit 31 - 8c is the 1 of 0x80 and everything below it is zero
+            for (uint32_t i = 0; i < 32; i++) {
+                Terms t;
+                for (uint32_t c = 0; c < 4; c++) {
+                    if (i <= 31 - 8 * c) t.push_back(Term{1, {pub(PB + PP_KIND + c), sb, var(X0 + i)}});
+                    if (i == 31 - 8 * c) t.push_back(Term{P - 1, {pub(PB + PP_KIND + c), sb}});
+                }
+                b.add(ALL, t);
+            }
+            // words that must be zero, the length field: at row s_0 of the block, limb by limb
+            for (int j = 0; j < 16; j++)
+                for (int l = 0; l < 2; l++) {
+                    const Terms lj = limb(xw(j), l);
+                    Terms t = times(times(lj, z0, false), pub(PB + PP_ZWL + (uint32_t)j), false);
+                    append(t, times(times(lj, z2, false), pub(PB + PP_ZW2 + (uint32_t)j), false));
+                    if (j <= 13) append(t, times(times(lj, z0, false), pub(PB + PP_Z13), false));
+                    else {        // W_14, W_15: the bit length (W_15 low / high limb = LEN_0 / LEN_1, W_14 = LEN_2 / LEN_3) in the trace's last block when the message ends here
+                        append(t, times(times(lj, z0, false), pub(PB + PP_FIN), false));
+                        t.push_back(Term{P - 1, {pub(PB + PP_FIN), z0, pub(PB + PP_LEN + (j == 15 ? 0u : 2u) + (uint32_t)l)}});
+                    }
+                    b.add(ALL, t);
+                }
+        }
+        std::vector<uint32_t> p{AIR_MAGIC, 1u, WIDTH, b.count, chained ? N_PUBLIC_CHAINED : N_PUBLIC, (uint32_t)(6 + b.body.size())};
         p.insert(p.end(), b.body.begin(), b.body.end());
         return p;
     }
@@ -258,6 +359,7 @@ struct TraceArgs {
     uint32_t* out;
     uint64_t ld;
     uint32_t active;           // blocks [0, active) belong to the message
+    uint32_t pad_block, pad_row; // the block (0xFFFFFFFF: none in this trace) and the row = word index whose W_t holds the 0x80 byte (PadPlace)
     uint32_t k[64];
 };
 
@@ -334,8 +436,14 @@ __device__ __forceinline__ void sha256_trace_kernel_body(const TraceArgs& a) {
     }
     row[ACT] = act ? MONTY_R1 : 0u;
     row[SKIP] = skip ? MONTY_R1 : 0u;
-    row[SKIP + 1] = 0u;
-    row[SKIP + 2] = 0u;
+    // the padding columns: blocks left, the last active block and the one before it, the boundary word's row, the two s_0 products
+    const bool lastb = blk + 1 == a.active, l2 = blk + 2 == a.active;
+    row[CNT] = act ? mlimb(a.active - blk) : 0u;
+    row[LASTB] = lastb ? MONTY_R1 : 0u;
+    row[L2] = l2 ? MONTY_R1 : 0u;
+    row[SB] = (blk == a.pad_block && r == a.pad_row) ? MONTY_R1 : 0u;
+    row[Z0] = (r == 0 && lastb) ? MONTY_R1 : 0u;
+    row[Z2] = (r == 0 && l2) ? MONTY_R1 : 0u;
 }
 __global__ void __launch_bounds__(64) sha256_trace_kernel(TraceArgs a) { sha256_trace_kernel_body(a); }
 struct sha256_trace_kernel_bargs { TraceArgs a; static sha256_trace_kernel_bargs make(TraceArgs a) { return sha256_trace_kernel_bargs{a}; } };
@@ -436,17 +544,26 @@ void zkhip_sha256_digest(const uint8_t* message, size_t len, uint8_t digest[32])
     for (int i = 0; i < 8; i++) { digest[4 * i] = (uint8_t)(h[i] >> 24); digest[4 * i + 1] = (uint8_t)(h[i] >> 16); digest[4 * i + 2] = (uint8_t)(h[i] >> 8); digest[4 * i + 3] = (uint8_t)h[i]; }
 }
 
-int zkhip_sha256_gen_trace(zkhip_ctx* ctx, const uint8_t* blocks, size_t n_active, size_t n_blocks, uint32_t* d_trace, size_t ld,
-                           uint32_t digest_limbs[16]) {
-    return zkhip_sha256_gen_trace_chained(ctx, sha::IV, blocks, n_active, n_blocks, d_trace, ld, digest_limbs);
+void zkhip_sha256_padding_publics(uint64_t message_len, uint64_t first_block, uint64_t n_active, uint32_t out[75]) {
+    static_assert(sha::N_PAD == 75, "the header says 75");
+    (void)sha::padding_publics(message_len, first_block, n_active, out);
 }
-int zkhip_sha256_gen_trace_chained(zkhip_ctx* ctx, const uint32_t chain_in[8], const uint8_t* blocks, size_t n_active, size_t n_blocks, uint32_t* d_trace,
-                                   size_t ld, uint32_t digest_limbs[16]) {
+
+int zkhip_sha256_gen_trace(zkhip_ctx* ctx, const uint8_t* blocks, size_t n_active, size_t n_blocks, uint64_t message_len, uint32_t* d_trace, size_t ld,
+                           uint32_t publics[91]) {
+    if (n_active != (size_t)((message_len + 8) / 64 + 1)) return fail(ZKHIP_ERR_INVALID, "sha256_gen_trace: n_active must be the padded message's block count (message_len + 8) / 64 + 1");
+    return zkhip_sha256_gen_trace_chained(ctx, sha::IV, blocks, n_active, n_blocks, message_len, 0, d_trace, ld, publics);
+}
+// publics: [0, 16) the final chaining value's limbs, then the 75 padding values of this slice (the caller of the chained program puts the
+// initial value's 16 limbs between them)
+int zkhip_sha256_gen_trace_chained(zkhip_ctx* ctx, const uint32_t chain_in[8], const uint8_t* blocks, size_t n_active, size_t n_blocks, uint64_t message_len,
+                                   uint64_t first_block, uint32_t* d_trace, size_t ld, uint32_t publics[91]) {
     CHECK_CTX(ctx);
     if (!chain_in) return fail(ZKHIP_ERR_INVALID, "sha256_gen_trace: null chaining value");
     const int lb = log2_exact(n_blocks);
-    if (!blocks || !d_trace || !digest_limbs || n_active == 0 || n_active > n_blocks || lb < 0 || lb + 6 > MAX_LOG_ROWS || ld < sha::WIDTH)
-        return fail(ZKHIP_ERR_INVALID, "sha256_gen_trace: 1 <= n_active <= n_blocks = 2^k <= 2^16, ld >= 608");
+    if (!blocks || !d_trace || !publics || n_active == 0 || n_active > n_blocks || lb < 0 || lb + 6 > MAX_LOG_ROWS || ld < sha::WIDTH)
+        return fail(ZKHIP_ERR_INVALID, "sha256_gen_trace: 1 <= n_active <= n_blocks = 2^k <= 2^16, ld >= 612");
+    if (first_block + n_active > (message_len + 8) / 64 + 1) return fail(ZKHIP_ERR_INVALID, "sha256_gen_trace: the slice runs past the padded message");
     std::vector<uint32_t> host((size_t)n_blocks * 24, 0u);             // [n_blocks][16] words, then [n_blocks][8] chaining values
     uint32_t* words = host.data();
     uint32_t* chain = host.data() + n_blocks * 16;
@@ -460,7 +577,8 @@ int zkhip_sha256_gen_trace_chained(zkhip_ctx* ctx, const uint32_t chain_in[8], c
             sha::compress(h, b);
         }
     }
-    for (int i = 0; i < 8; i++) { digest_limbs[2 * i] = h[i] & 0xffffu; digest_limbs[2 * i + 1] = h[i] >> 16; }
+    for (int i = 0; i < 8; i++) { publics[2 * i] = h[i] & 0xffffu; publics[2 * i + 1] = h[i] >> 16; }
+    const sha::PadPlace pl = sha::padding_publics(message_len, first_block, n_active, publics + sha::N_DIGEST);
     void* stage;
     ZK_TRY(ctx_reserve(ctx, S_STAGE, host.size() * 4, &stage));
     ZK_TRY(dev_h2d(ctx, stage, host.data(), host.size() * 4));           // (returns when `host` may go out of scope)
@@ -470,6 +588,7 @@ int zkhip_sha256_gen_trace_chained(zkhip_ctx* ctx, const uint32_t chain_in[8], c
     a.out = d_trace;
     a.ld = ld;
     a.active = (uint32_t)n_active;
+    a.pad_block = pl.pad_block; a.pad_row = pl.pad_row;
     std::memcpy(a.k, sha::round_constants().k, sizeof(a.k));
     ZK_LAUNCH(sha::sha256_trace_kernel, sha::sha256_trace_kernel_batch, sha::sha256_trace_kernel_bargs, dim3((unsigned)n_blocks), dim3(64), 0, ctx->stream, a);
     ZK_HIP(hipGetLastError());
@@ -505,8 +624,8 @@ int zkhip_prove_sha256(zkhip_ctx* ctx, const uint8_t* message, size_t message_le
     zkhip_sha256_pad(message, message_len, blocks.data(), padded);
     void* trace;
     ZK_TRY(ctx_reserve(ctx, S_CHIP, ((size_t)sha::WIDTH << log_n) * 4, &trace));
-    uint32_t limbs[16];
-    ZK_TRY(zkhip_sha256_gen_trace(ctx, blocks.data(), na, nb, (uint32_t*)trace, sha::WIDTH, limbs));
+    uint32_t limbs[sha::N_PUBLIC];
+    ZK_TRY(zkhip_sha256_gen_trace(ctx, blocks.data(), na, nb, message_len, (uint32_t*)trace, sha::WIDTH, limbs));
     for (int i = 0; i < 8; i++) {
         const uint32_t w = limbs[2 * i] | (limbs[2 * i + 1] << 16);
         digest[4 * i] = (uint8_t)(w >> 24); digest[4 * i + 1] = (uint8_t)(w >> 16); digest[4 * i + 2] = (uint8_t)(w >> 8); digest[4 * i + 3] = (uint8_t)w;
@@ -515,17 +634,25 @@ int zkhip_prove_sha256(zkhip_ctx* ctx, const uint8_t* message, size_t message_le
     return zkhip_prove_shard_air(ctx, p.data(), p.size(), (const uint32_t*)trace, sha::WIDTH, log_n, sha::WIDTH, limbs, sha::N_PUBLIC, prm, proof, cap, len);
 }
 
-int zkhip_verify_sha256(const uint8_t* proof, size_t len, const uint8_t digest[32], const zkhip_params* prm, int* reason) {
+// the public values of "digest = SHA-256(a message of message_len bytes)": the digest's limbs, then the padding's
+static void sha_statement(const uint8_t digest[32], uint64_t message_len, uint32_t pv[sha::N_PUBLIC]) {
+    for (int i = 0; i < 8; i++) {
+        const uint32_t w = ((uint32_t)digest[4 * i] << 24) | ((uint32_t)digest[4 * i + 1] << 16) | ((uint32_t)digest[4 * i + 2] << 8) | digest[4 * i + 3];
+        pv[2 * i] = w & 0xffffu; pv[2 * i + 1] = w >> 16;
+    }
+    (void)sha::padding_publics(message_len, 0, (message_len + 8) / 64 + 1, pv + sha::N_DIGEST);
+}
+int zkhip_verify_sha256(const uint8_t* proof, size_t len, const uint8_t digest[32], uint64_t message_len, const zkhip_params* prm, int* reason) {
     if (!proof || !digest || !prm || len < 16) return fail(ZKHIP_ERR_INVALID, "verify_sha256: null argument");
     uint32_t head[4];
     std::memcpy(head, proof, 16);
-    const int log_n = (int)head[2];                                    // the block count 2^(log_n - 6) is read from the proof and bound by its transcript
-    if (log_n < 6 || log_n > MAX_LOG_ROWS) { if (reason) *reason = 1; return fail(ZKHIP_ERR_VERIFY, "verify_sha256: not a SHA-256 chip proof"); }
-    uint32_t limbs[16];
-    for (int i = 0; i < 8; i++) {
-        const uint32_t w = ((uint32_t)digest[4 * i] << 24) | ((uint32_t)digest[4 * i + 1] << 16) | ((uint32_t)digest[4 * i + 2] << 8) | digest[4 * i + 3];
-        limbs[2 * i] = w & 0xffffu; limbs[2 * i + 1] = w >> 16;
+    const int log_n = (int)head[2];                                    // the trace height is read from the proof and bound by its transcript; the block COUNT is the statement's
+    if (log_n < 6 || log_n > MAX_LOG_ROWS || (message_len + 8) / 64 + 1 > ((uint64_t)1 << (log_n - 6))) {
+        if (reason) *reason = 1;
+        return fail(ZKHIP_ERR_VERIFY, "verify_sha256: not a SHA-256 chip proof for a message of this length");
     }
+    uint32_t limbs[sha::N_PUBLIC];
+    sha_statement(digest, message_len, limbs);
     const std::vector<uint32_t>& p = sha::program();
     return zkhip_verify_shard_air(p.data(), p.size(), proof, len, log_n, sha::WIDTH, limbs, sha::N_PUBLIC, prm, reason);
 }
@@ -617,8 +744,8 @@ int zkhip_prove_sha256_machine(zkhip_ctx* ctx, const zkhip_machine_key* key, con
     void *trace, *counts;
     ZK_TRY(ctx_reserve(ctx, S_CHIP, ((size_t)sha::WIDTH << log_n) * 4, &trace));
     ZK_TRY(ctx_reserve(ctx, S_CHIP_B, ((size_t)1 << sha::RANGE_LOG) * 16, &counts));
-    uint32_t limbs[16];
-    ZK_TRY(zkhip_sha256_gen_trace(ctx, blocks.data(), na, nb, (uint32_t*)trace, sha::WIDTH, limbs));
+    uint32_t limbs[sha::N_PUBLIC];
+    ZK_TRY(zkhip_sha256_gen_trace(ctx, blocks.data(), na, nb, message_len, (uint32_t*)trace, sha::WIDTH, limbs));
     for (int i = 0; i < 8; i++) {
         const uint32_t w = limbs[2 * i] | (limbs[2 * i + 1] << 16);
         digest[4 * i] = (uint8_t)(w >> 24); digest[4 * i + 1] = (uint8_t)(w >> 16); digest[4 * i + 2] = (uint8_t)(w >> 8); digest[4 * i + 3] = (uint8_t)w;
@@ -634,7 +761,7 @@ int zkhip_prove_sha256_machine(zkhip_ctx* ctx, const zkhip_machine_key* key, con
     return zkhip_prove_machine_keyed_at(ctx, key, m.entries, chips, m.progs, m.prog_words, m.tabs, m.tab_words, 2, limbs, sha::N_PUBLIC, prm, proof, cap, len);
 }
 
-int zkhip_verify_sha256_machine(const uint8_t* proof, size_t len, const uint8_t digest[32], const uint32_t vk[8], const zkhip_params* prm, int* reason) {
+int zkhip_verify_sha256_machine(const uint8_t* proof, size_t len, const uint8_t digest[32], uint64_t message_len, const uint32_t vk[8], const zkhip_params* prm, int* reason) {
     if (!proof || !digest || !vk || !prm || len < 4 * 18) return fail(ZKHIP_ERR_INVALID, "verify_sha256_machine: null argument");
     uint32_t head[18];
     std::memcpy(head, proof, sizeof head);
@@ -642,15 +769,12 @@ int zkhip_verify_sha256_machine(const uint8_t* proof, size_t len, const uint8_t 
     // and bound by its transcript; everything else about the machine is fixed here
     const int sha_at = head[8 + 1] == sha::WIDTH ? 0 : 1;
     const int log_n = (int)head[8 + 5 * sha_at];
-    if (head[2] != 2u || log_n < 6 || log_n > 20 || (sha_at == 0) != (log_n > (int)sha::RANGE_LOG)) {
+    if (head[2] != 2u || log_n < 6 || log_n > 20 || (sha_at == 0) != (log_n > (int)sha::RANGE_LOG) || (message_len + 8) / 64 + 1 > ((uint64_t)1 << (log_n - 6))) {
         if (reason) *reason = 1;
-        return fail(ZKHIP_ERR_VERIFY, "verify_sha256_machine: not a proof of the SHA-256 machine");
+        return fail(ZKHIP_ERR_VERIFY, "verify_sha256_machine: not a proof of the SHA-256 machine for a message of this length");
     }
-    uint32_t limbs[16];
-    for (int i = 0; i < 8; i++) {
-        const uint32_t w = ((uint32_t)digest[4 * i] << 24) | ((uint32_t)digest[4 * i + 1] << 16) | ((uint32_t)digest[4 * i + 2] << 8) | digest[4 * i + 3];
-        limbs[2 * i] = w & 0xffffu; limbs[2 * i + 1] = w >> 16;
-    }
+    uint32_t limbs[sha::N_PUBLIC];
+    sha_statement(digest, message_len, limbs);
     const sha::MachineShape m = sha::machine_shape(log_n);
     return zkhip_verify_machine_keyed(proof, len, m.log_ns, m.widths, m.pre_widths, vk, m.progs, m.prog_words, m.tabs, m.tab_words, 2, limbs, sha::N_PUBLIC, prm, reason);
 }
@@ -704,11 +828,11 @@ int zkhip_prove_transcripts(const int* devices, int n_devices, zkhip_transcript_
                 zkhip_transcript_job* jp = &j;
                 std::string* msg = &check_msg[(size_t)i];
                 checkers->submit([jp, len, p, msg, key] {
-                    const int v = zkhip_verify_sha256_machine(jp->proof, len, jp->digest, key, &p, nullptr);
+                    const int v = zkhip_verify_sha256_machine(jp->proof, len, jp->digest, jp->message_len, key, &p, nullptr);
                     if (v != ZKHIP_OK) { jp->status = v; jp->proof_len = 0; *msg = zkhip_last_error(); }
                 });
             } else {
-                r = zkhip_verify_sha256_machine(j.proof, len, j.digest, ctx->sha_vk, prm, nullptr);
+                r = zkhip_verify_sha256_machine(j.proof, len, j.digest, j.message_len, ctx->sha_vk, prm, nullptr);
                 j.status = r;
                 j.proof_len = r == ZKHIP_OK ? len : 0;
             }
@@ -786,7 +910,7 @@ size_t zkhip_sha256_sharded_count(size_t message_len, int log_blocks_per_shard) 
 size_t zkhip_sha256_shard_proof_size(int log_blocks, const zkhip_params* prm) {
     const std::vector<uint32_t>& p = sha::program_chained();
     if (log_blocks < 0 || log_blocks > 14) return 0;
-    return zkhip_proof_size_air(p.data(), p.size(), 6 + log_blocks, sha::WIDTH, prm, 2 * sha::N_PUBLIC);
+    return zkhip_proof_size_air(p.data(), p.size(), 6 + log_blocks, sha::WIDTH, prm, sha::N_PUBLIC_CHAINED);
 }
 static void chain_limbs(const uint32_t in[8], const uint32_t out[8], uint32_t pv[32]) {      // public values of a shard: final limbs, then initial limbs
     for (int i = 0; i < 8; i++) { pv[2 * i] = out[i] & 0xffffu; pv[2 * i + 1] = out[i] >> 16; pv[16 + 2 * i] = in[i] & 0xffffu; pv[16 + 2 * i + 1] = in[i] >> 16; }
@@ -830,20 +954,27 @@ int zkhip_prove_sha256_sharded(const int* devices, int n_devices, const uint8_t*
         const int lb = (size_t)s + 1 == n_shards ? last_lb : log_blocks_per_shard;
         void* trace;
         ZK_TRY(ctx_reserve(ctx, S_CHIP, ((size_t)sha::WIDTH << (6 + lb)) * 4, &trace));
-        uint32_t out_limbs[16], pv[32];
-        ZK_TRY(zkhip_sha256_gen_trace_chained(ctx, chain + 8 * s, blocks.data() + 64 * first, active, (size_t)1 << lb, (uint32_t*)trace, sha::WIDTH, out_limbs));
+        uint32_t out_pub[sha::N_PUBLIC], pv[sha::N_PUBLIC_CHAINED];
+        ZK_TRY(zkhip_sha256_gen_trace_chained(ctx, chain + 8 * s, blocks.data() + 64 * first, active, (size_t)1 << lb, message_len, first, (uint32_t*)trace, sha::WIDTH, out_pub));
         chain_limbs(chain + 8 * s, chain + 8 * (s + 1), pv);
-        for (int i = 0; i < 16; i++) if (out_limbs[i] != pv[i]) return fail(ZKHIP_ERR_INTERNAL, "prove_sha256_sharded: a shard's trace does not end in the next chaining value");
-        return zkhip_prove_shard_air(ctx, prog.data(), prog.size(), (const uint32_t*)trace, sha::WIDTH, 6 + lb, sha::WIDTH, pv, 32, prm,
+        for (int i = 0; i < 16; i++) if (out_pub[i] != pv[i]) return fail(ZKHIP_ERR_INTERNAL, "prove_sha256_sharded: a shard's trace does not end in the next chaining value");
+        std::memcpy(pv + 2 * sha::N_DIGEST, out_pub + sha::N_DIGEST, sha::N_PAD * 4);            // this slice's padding values: the verifier derives the same from (length, shard)
+        return zkhip_prove_shard_air(ctx, prog.data(), prog.size(), (const uint32_t*)trace, sha::WIDTH, 6 + lb, sha::WIDTH, pv, sha::N_PUBLIC_CHAINED, prm,
                                      proofs + (size_t)s * proof_stride, proof_stride, &proof_lens[s]);
     }, ran);
 }
 // checks a chain of shard proofs: chain[0] = the standard IV, chain[n] = the digest, shard s proves chain[s] -> chain[s + 1]; every shard but
 // the last covers 2^log_blocks_per_shard blocks (the last proof's own header says how many rows it has).  *reason: the failing shard's check
 int zkhip_verify_sha256_sharded(const uint8_t* proofs, size_t proof_stride, const size_t* proof_lens, size_t n_shards, const uint32_t* chain,
-                                int log_blocks_per_shard, const uint8_t digest[32], const zkhip_params* prm, size_t* bad_shard, int* reason) {
+                                int log_blocks_per_shard, const uint8_t digest[32], uint64_t message_len, const zkhip_params* prm, size_t* bad_shard, int* reason) {
     if (!proofs || !proof_lens || !chain || !digest || !prm || n_shards < 1 || n_shards > 4096 || log_blocks_per_shard < 0 || log_blocks_per_shard > 14)
         return fail(ZKHIP_ERR_INVALID, "verify_sha256_sharded: bad arguments");
+    const uint64_t per_shard = (uint64_t)1 << log_blocks_per_shard, total_blocks = (message_len + 8) / 64 + 1;
+    if ((total_blocks + per_shard - 1) / per_shard != n_shards) {          // the statement's length fixes the number of shards
+        if (bad_shard) *bad_shard = 0;
+        if (reason) *reason = 1;
+        return fail(ZKHIP_ERR_VERIFY, "verify_sha256_sharded: a message of this length has another number of shards");
+    }
     if (bad_shard) *bad_shard = 0;
     if (reason) *reason = 0;
     auto reject = [&](size_t s, int why, const char* msg) { if (bad_shard) *bad_shard = s; if (reason) *reason = why; return fail(ZKHIP_ERR_VERIFY, msg); };
@@ -873,10 +1004,13 @@ int zkhip_verify_sha256_sharded(const uint8_t* proofs, size_t proof_stride, cons
                 bad(3, "verify_sha256_sharded: a shard has the wrong height");
                 continue;
             }
-            uint32_t pv[32];
+            uint32_t pv[sha::N_PUBLIC_CHAINED];
             chain_limbs(chain + 8 * s, chain + 8 * (s + 1), pv);
+            const uint64_t first = (uint64_t)s * per_shard, active = last ? total_blocks - first : per_shard;
+            if (active > ((uint64_t)1 << (log_n - 6))) { bad(3, "verify_sha256_sharded: a shard has the wrong height"); continue; }
+            (void)sha::padding_publics(message_len, first, active, pv + 2 * sha::N_DIGEST);
             int w = 0;
-            if (zkhip_verify_shard_air(prog.data(), prog.size(), pf, proof_lens[s], log_n, sha::WIDTH, pv, 32, prm, &w) != ZKHIP_OK) { rc[s] = ZKHIP_ERR_VERIFY; why[s] = w; msg[s] = zkhip_last_error(); }
+            if (zkhip_verify_shard_air(prog.data(), prog.size(), pf, proof_lens[s], log_n, sha::WIDTH, pv, sha::N_PUBLIC_CHAINED, prm, &w) != ZKHIP_OK) { rc[s] = ZKHIP_ERR_VERIFY; why[s] = w; msg[s] = zkhip_last_error(); }
         }
     };
     const size_t nt = n_shards < 4 ? n_shards : 4;

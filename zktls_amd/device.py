@@ -11,6 +11,9 @@ from . import _lib
 from ._lib import Params, ProveDebug, check, from_monty, to_monty, u32p, u8p
 
 
+SHA256_WIDTH, SHA256_PUBLIC, SHA256_PADDING_PUBLIC = 612, 91, 75      # include/zkhip.h: ZKHIP_SHA256_*
+
+
 class DeviceBuffer:
     """A device allocation of uint32 words owned by a Context (or wrapping a torch tensor)."""
 
@@ -342,14 +345,19 @@ class Context:
         return buf[: got.value]
 
     # ---- the SHA-256 compression chip (csrc/sha256_chip.hip)
-    def sha256_gen_trace(self, blocks, n_blocks=None, out=None):
-        """blocks: bytes, a multiple of 64 long (padding included) -> (device trace [64 n_blocks][608], digest limbs [16])"""
+    def sha256_gen_trace(self, blocks, n_blocks=None, out=None, message_len=None):
+        """blocks: the padded message, a multiple of 64 long (sha256_pad / sha256_air.pad remember the message's length; otherwise pass
+        message_len) -> (device trace [64 n_blocks][612], public values [91]: 16 digest limbs + the 75 padding values)"""
+        if message_len is None:
+            message_len = getattr(blocks, "message_len", None)
+        if message_len is None:
+            raise TypeError("sha256_gen_trace: the message length is part of the statement (pass message_len)")
         b = np.frombuffer(bytes(blocks), dtype=np.uint8)
         active = b.size // 64
         n_blocks = n_blocks or 1 << max(active - 1, 0).bit_length()
-        out = out or self.alloc(64 * n_blocks * 608)
-        limbs = np.zeros(16, dtype=np.uint32)
-        check(self.lib.zkhip_sha256_gen_trace(self.handle, b.ctypes.data_as(u8p), active, n_blocks, C.c_void_p(out.ptr), 608, limbs.ctypes.data_as(u32p)))
+        out = out or self.alloc(64 * n_blocks * SHA256_WIDTH)
+        limbs = np.zeros(SHA256_PUBLIC, dtype=np.uint32)
+        check(self.lib.zkhip_sha256_gen_trace(self.handle, b.ctypes.data_as(u8p), active, n_blocks, message_len, C.c_void_p(out.ptr), SHA256_WIDTH, limbs.ctypes.data_as(u32p)))
         return out, limbs
 
     def prove_sha256(self, message, params=None):
@@ -821,8 +829,8 @@ def sha256_air_chained():
 class ShardedSha256:
     """the result of prove_sha256_sharded: digest, chaining values [n + 1][8], the shard proofs"""
 
-    def __init__(self, digest, chain, proofs, stride, lens, log_blocks):
-        self.digest, self.chain, self.buf, self.stride, self.lens, self.log_blocks = digest, chain, proofs, stride, lens, log_blocks
+    def __init__(self, digest, chain, proofs, stride, lens, log_blocks, message_len):
+        self.digest, self.chain, self.buf, self.stride, self.lens, self.log_blocks, self.message_len = digest, chain, proofs, stride, lens, log_blocks, message_len
 
     @property
     def proofs(self):
@@ -845,11 +853,11 @@ def prove_sha256_sharded(message, log_blocks_per_shard, params=None, devices=Non
     devs = (C.c_int * len(devices))(*devices) if devices else None
     check(lib.zkhip_prove_sha256_sharded(devs, len(devices) if devices else 0, m.ctypes.data_as(u8p), len(message), log_blocks_per_shard, C.byref(params), in_flight,
                                          digest.ctypes.data_as(u8p), chain.ctypes.data_as(u32p), proofs.ctypes.data_as(u8p), stride, lens))
-    return ShardedSha256(digest.tobytes(), chain, proofs, stride, list(lens), log_blocks_per_shard)
+    return ShardedSha256(digest.tobytes(), chain, proofs, stride, list(lens), log_blocks_per_shard, len(message))
 
 
-def verify_sha256_sharded(result, digest=None, params=None, chain=None, proofs=None):
-    """-> (rc, failing shard, reason); digest / chain / proofs default to the result's own"""
+def verify_sha256_sharded(result, digest=None, params=None, chain=None, proofs=None, message_len=None):
+    """-> (rc, failing shard, reason); digest / chain / proofs / message length default to the result's own"""
     lib = _lib.load()
     params = params or Params(1, 100, 16)
     n = len(result.lens)
@@ -859,7 +867,7 @@ def verify_sha256_sharded(result, digest=None, params=None, chain=None, proofs=N
     dg = np.frombuffer(bytes(result.digest if digest is None else digest), dtype=np.uint8)
     bad, reason = C.c_size_t(0), C.c_int(0)
     rc = lib.zkhip_verify_sha256_sharded(buf.ctypes.data_as(u8p), result.stride, lens, n, ch.ctypes.data_as(u32p), result.log_blocks, dg.ctypes.data_as(u8p),
-                                         C.byref(params), C.byref(bad), C.byref(reason))
+                                         result.message_len if message_len is None else message_len, C.byref(params), C.byref(bad), C.byref(reason))
     return rc, bad.value, reason.value
 
 
@@ -872,22 +880,41 @@ def sha256_air():
     return out
 
 
+class PaddedMessage(bytes):
+    """padded blocks that remember the message's length (the statement's other half)"""
+    message_len = None
+
+
 def sha256_pad(message):
     lib = _lib.load()
     m = np.frombuffer(bytes(message), dtype=np.uint8) if len(message) else np.zeros(1, dtype=np.uint8)
     n = lib.zkhip_sha256_pad(m.ctypes.data_as(u8p), len(message), None, 0)
     out = np.empty(n, dtype=np.uint8)
     assert lib.zkhip_sha256_pad(m.ctypes.data_as(u8p), len(message), out.ctypes.data_as(u8p), n) == n
-    return out.tobytes()
+    res = PaddedMessage(out.tobytes())
+    res.message_len = len(message)
+    return res
 
 
-def verify_sha256(proof, digest, params=None):
+def sha256_padding_publics(message_len, first_block=0, n_active=None):
+    """zkhip_sha256_padding_publics: the 75 public values a verifier derives from the length (whole message: all its blocks)"""
+    if n_active is None:
+        n_active = (message_len + 8) // 64 + 1 - first_block
+    out = np.zeros(SHA256_PADDING_PUBLIC, dtype=np.uint32)
+    _lib.load().zkhip_sha256_padding_publics(message_len, first_block, n_active, out.ctypes.data_as(u32p))
+    return out
+
+
+def verify_sha256(proof, digest, params=None, message_len=None):
+    """the statement: digest = SHA-256 of a message of message_len bytes"""
+    if message_len is None:
+        raise TypeError("verify_sha256: the message length is part of the statement")
     params = params or Params(1, 100, 16)
     lib = _lib.load()
     pr = np.ascontiguousarray(proof, dtype=np.uint8)
     dg = np.frombuffer(bytes(digest), dtype=np.uint8)
     reason = C.c_int(0)
-    rc = lib.zkhip_verify_sha256(pr.ctypes.data_as(u8p), pr.size, dg.ctypes.data_as(u8p), C.byref(params), C.byref(reason))
+    rc = lib.zkhip_verify_sha256(pr.ctypes.data_as(u8p), pr.size, dg.ctypes.data_as(u8p), message_len, C.byref(params), C.byref(reason))
     return rc, reason.value
 
 
@@ -966,14 +993,16 @@ def verify_merkle_paths(proof, root, n_paths, params=None):
     return rc, reason.value
 
 
-def verify_sha256_machine(proof, digest, vk, params=None):
+def verify_sha256_machine(proof, digest, vk, params=None, message_len=None):
+    if message_len is None:
+        raise TypeError("verify_sha256_machine: the message length is part of the statement")
     params = params or Params(1, 100, 16)
     lib = _lib.load()
     pr = np.ascontiguousarray(proof, dtype=np.uint8)
     dg = np.frombuffer(bytes(digest), dtype=np.uint8)
     k = np.ascontiguousarray(np.array(vk, dtype=np.uint32))
     reason = C.c_int(0)
-    rc = lib.zkhip_verify_sha256_machine(pr.ctypes.data_as(u8p), pr.size, dg.ctypes.data_as(u8p), k.ctypes.data_as(u32p), C.byref(params), C.byref(reason))
+    rc = lib.zkhip_verify_sha256_machine(pr.ctypes.data_as(u8p), pr.size, dg.ctypes.data_as(u8p), message_len, k.ctypes.data_as(u32p), C.byref(params), C.byref(reason))
     return rc, reason.value
 
 

@@ -214,12 +214,33 @@ SetupResult HipGuestProver::setup(const std::vector<uint8_t>& guest_program) {
     return s;
 }
 
+static std::vector<uint8_t> length_entry(uint64_t n) {
+    std::vector<uint8_t> e(8);
+    for (int i = 0; i < 8; i++) e[(size_t)i] = (uint8_t)(n >> (8 * i));
+    return e;
+}
+bool commitment_blob_length(const std::vector<uint8_t>& blob, uint64_t* message_len) {
+    std::vector<std::vector<uint8_t>> proofs;
+    uint32_t flags = 0;
+    if (!unpack_shard_proofs(blob, &proofs, &flags) || proofs.size() < 2 || !(flags & BATCH_FLAG_INPUT_SHA256) || proofs.back().size() != 8) return false;
+    uint64_t n = 0;
+    for (int i = 0; i < 8; i++) n |= (uint64_t)proofs.back()[(size_t)i] << (8 * i);
+    if (message_len) *message_len = n;
+    return true;
+}
+
 int verify_commitment_blob(const std::vector<uint8_t>& blob, const std::vector<uint8_t>& output, const std::vector<uint8_t>& vk,
                            int num_queries, int pow_bits, int* reason, Backend backend) {
     std::vector<std::vector<uint8_t>> proofs;
     uint32_t flags = 0;
     if (reason) *reason = 0;
-    if (!unpack_shard_proofs(blob, &proofs, &flags) || proofs.empty() || !(flags & BATCH_FLAG_INPUT_SHA256) || output.size() != 32) return -1;
+    if (!unpack_shard_proofs(blob, &proofs, &flags) || proofs.size() < 2 || !(flags & BATCH_FLAG_INPUT_SHA256) || output.size() != 32 || proofs.back().size() != 8) return -1;
+    // the LAST entry is the statement's other half: the input's length in bytes (8 LE bytes).  The proofs say "output = SHA-256 of a message
+    // of exactly this length" (the padding is constrained in-circuit); a consumer that holds the input compares the length it knows
+    // (commitment_blob_length)
+    uint64_t message_len = 0;
+    for (int i = 0; i < 8; i++) message_len |= (uint64_t)proofs.back()[(size_t)i] << (8 * i);
+    proofs.pop_back();
     // what the caller expects decides the path; the blob's flags must agree
     const bool want_keyed = !vk.empty();
     if (want_keyed && (vk.size() != 64 || !(flags & BATCH_FLAG_KEYED) || (flags & BATCH_FLAG_CHAINED))) { if (reason) *reason = 2; return -1; }
@@ -246,11 +267,11 @@ int verify_commitment_blob(const std::vector<uint8_t>& blob, const std::vector<u
         std::vector<uint32_t> chain((n + 1) * 8);
         std::memcpy(chain.data(), proofs[0].data(), proofs[0].size());
         size_t bad = 0;
-        return zkhip_verify_sha256_sharded(buf.data(), stride, lens.data(), n, chain.data(), 14, output.data(), &prm, &bad, reason);
+        return zkhip_verify_sha256_sharded(buf.data(), stride, lens.data(), n, chain.data(), 14, output.data(), message_len, &prm, &bad, reason);
     }
     if (proofs.size() != 1) return -1;
-    if (want_keyed) return zkhip_verify_sha256_machine(proofs[0].data(), proofs[0].size(), output.data(), (const uint32_t*)vk.data(), &prm, reason);
-    return zkhip_verify_sha256(proofs[0].data(), proofs[0].size(), output.data(), &prm, reason);
+    if (want_keyed) return zkhip_verify_sha256_machine(proofs[0].data(), proofs[0].size(), output.data(), message_len, (const uint32_t*)vk.data(), &prm, reason);
+    return zkhip_verify_sha256(proofs[0].data(), proofs[0].size(), output.data(), message_len, &prm, reason);
 }
 
 ProveResult HipGuestProver::prove_inner(const GuestInput& input, const std::vector<uint8_t>& elf) {
@@ -298,10 +319,11 @@ ProveResult HipGuestProver::prove_inner(const GuestInput& input, const std::vect
                 fail_zkhip("zkhip_prove_sha256_sharded");
             size_t bad = 0;
             int reason = 0;
-            if (zkhip_verify_sha256_sharded(buf.data(), stride, lens.data(), n, chain.data(), k, digest32, &prm, &bad, &reason) != ZKHIP_OK) fail_zkhip("zkhip_verify_sha256_sharded");
+            if (zkhip_verify_sha256_sharded(buf.data(), stride, lens.data(), n, chain.data(), k, digest32, (uint64_t)input.cbor.size(), &prm, &bad, &reason) != ZKHIP_OK) fail_zkhip("zkhip_verify_sha256_sharded");
             std::vector<std::vector<uint8_t>> entries;
             entries.emplace_back((const uint8_t*)chain.data(), (const uint8_t*)chain.data() + chain.size() * 4);
             for (size_t s = 0; s < n; s++) entries.emplace_back(buf.begin() + (long)(s * stride), buf.begin() + (long)(s * stride + lens[s]));
+            entries.push_back(length_entry(input.cbor.size()));
             r.output.assign(digest32, digest32 + 32);
             r.proof = pack_shard_proofs(entries, BATCH_FLAG_INPUT_SHA256 | BATCH_FLAG_CHAINED);
             r.ok = true;
@@ -337,17 +359,17 @@ ProveResult HipGuestProver::prove_inner(const GuestInput& input, const std::vect
                 fail_zkhip("zkhip_prove_sha256_machine");
             g.healthy = true;
             proof.resize(len);
-            if (zkhip_verify_sha256_machine(proof.data(), proof.size(), digest32, (const uint32_t*)vk_.data(), &prm, &reason) != ZKHIP_OK)   // sp1.rs:120
+            if (zkhip_verify_sha256_machine(proof.data(), proof.size(), digest32, (uint64_t)input.cbor.size(), (const uint32_t*)vk_.data(), &prm, &reason) != ZKHIP_OK)   // sp1.rs:120
                 fail_zkhip("zkhip_verify_sha256_machine");
             r.vk = vk_;
         } else {
             if (zkhip_prove_sha256(g.ctx, input.cbor.data(), input.cbor.size(), &prm, digest32, proof.data(), cap, &len) != ZKHIP_OK) fail_zkhip("zkhip_prove_sha256");
             g.healthy = true;
             proof.resize(len);
-            if (zkhip_verify_sha256(proof.data(), proof.size(), digest32, &prm, &reason) != ZKHIP_OK) fail_zkhip("zkhip_verify_sha256");
+            if (zkhip_verify_sha256(proof.data(), proof.size(), digest32, (uint64_t)input.cbor.size(), &prm, &reason) != ZKHIP_OK) fail_zkhip("zkhip_verify_sha256");
         }
         r.output.assign(digest32, digest32 + 32);
-        r.proof = pack_shard_proofs({proof}, BATCH_FLAG_INPUT_SHA256 | (keyed ? BATCH_FLAG_KEYED : 0u));
+        r.proof = pack_shard_proofs({proof, length_entry(input.cbor.size())}, BATCH_FLAG_INPUT_SHA256 | (keyed ? BATCH_FLAG_KEYED : 0u));
         r.ok = true;
         return r;
     }
@@ -721,6 +743,11 @@ int zktls_verify_commitment_blob(const uint8_t* blob, size_t len, const uint8_t 
                                          vk ? std::vector<uint8_t>(vk, vk + vk_len) : std::vector<uint8_t>(), num_queries, pow_bits, reason);
 }
 // the same check for either backend's proof shape (0: SP1, 1: RISC Zero), as zktls_guest_prove_commitment takes it
+// the length (bytes) of the input a commitment blob speaks about -- the other half of its statement "output = SHA-256 of a message of this length";
+// a consumer that holds the input compares.  0 / -1 (not a commitment blob)
+int zktls_commitment_blob_length(const uint8_t* blob, size_t len, uint64_t* message_len) {
+    return zktls::commitment_blob_length(std::vector<uint8_t>(blob, blob + len), message_len) ? 0 : -1;
+}
 int zktls_verify_commitment_blob_for(int backend, const uint8_t* blob, size_t len, const uint8_t output[32], const uint8_t* vk, size_t vk_len,
                                      int num_queries, int pow_bits, int* reason) {
     if (!blob || !output || backend < 0 || backend > 1) return -1;

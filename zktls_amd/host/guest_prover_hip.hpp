@@ -137,7 +137,7 @@ std::vector<uint32_t> request_digest(const std::vector<uint8_t>& cbor, const std
 // batch proof container: "ZKTB", version 2, flags (bit 0: SYNTHETIC shards, attests nothing about a guest; bit 1: INPUT_SHA256), shard count,
 // then per shard (u32 length, bytes)
 constexpr uint32_t BATCH_FLAG_SYNTHETIC = 1u;
-constexpr uint32_t BATCH_FLAG_INPUT_SHA256 = 2u;     // one proof of the SHA-256 chip over the request's input bytes
+constexpr uint32_t BATCH_FLAG_INPUT_SHA256 = 2u;     // one proof of the SHA-256 chip over the request's input bytes; the LAST entry is the input's length (8 LE bytes): with the padding constrained in-circuit the statement is "output = SHA-256 of a message of this length"
 constexpr uint32_t BATCH_FLAG_CHAINED = 8u;          // with INPUT_SHA256: an input beyond one chip proof (1 MiB): entry 0 = the chaining values ((n + 1) x 8 LE words), entries 1..n = the shard proofs of zkhip_prove_sha256_sharded (2^14 blocks per shard)
 constexpr uint32_t BATCH_FLAG_COMPRESSED = 16u;      // with SYNTHETIC: the shard proofs were joined into ONE proof (entry 0; k proofs when the shards do not fit one join); last entry = the shape's key (8 LE words) + the shard count
 // shard proofs per join for an execution of `shards` shards of `plan`'s shape: one join while they fit (zkhip_shard_verifier_max_proofs: the
@@ -151,6 +151,8 @@ constexpr uint32_t BATCH_FLAG_KEYED = 4u;            // with INPUT_SHA256: the p
 // is refused.  `backend` picks the proof shape the prover used (Backend::Sp1: blowup 2, `num_queries`, `pow_bits`; Backend::Risc0: its
 // segment shape, fold 16).  Bytes 32..63 of a vk are the guest program's digest: the PROVER refuses a program that differs from the one
 // setup() saw, the proof itself does not bind it.  -> 0 or a negative value; *reason as the zkhip verifiers
+// the input length a commitment blob states (its last entry, 8 LE bytes): the proofs attest "output = SHA-256 of a message of exactly this length"
+bool commitment_blob_length(const std::vector<uint8_t>& blob, uint64_t* message_len);
 int verify_commitment_blob(const std::vector<uint8_t>& blob, const std::vector<uint8_t>& output, const std::vector<uint8_t>& vk,
                            int num_queries, int pow_bits, int* reason = nullptr, Backend backend = Backend::Sp1);
 // a COMPRESSED blob against the request it was made for: the public values of shard s are request_digest(cbor, elf) | s, the key must be the
