@@ -21,6 +21,8 @@ run_kt() {   # name, command...
 # 1. the multi-chip shard (SP1's real shard structure), one in flight: kernels + the phase table of zkhip_prove_chips (A/B build)
 run_kt multichip python3 tools/multichip_breakdown.py
 grep -v "^$" $P/multichip.log | tail -60 > $P/multichip_phases.txt
+# ... and the same four proofs WITHOUT the profiler (its interception of graph launches inflates the FRI commit phase: 5.2 against 2.2 ms)
+python3 tools/multichip_breakdown.py > $P/multichip_plain.log 2>&1; grep -E "chips prover|multichip shard" $P/multichip_plain.log | tail -24 > $P/multichip_phases_plain.txt
 # 2. the headline shard alone, one in flight: the clean per-proof table
 run_kt kt1 python3 bench.py --steps 10 --warmup 2 --no-cpu-baseline --streams 1 --no-batch64 --no-recursion16 --no-execution --no-multichip
 if [ "$WHAT" = all ]; then
