@@ -641,7 +641,7 @@ def main():
         t_lock_v, _ = best_of(2, verify=True)
         same = vk_p.tolist() == vk_l.tolist() and all(a[0] == b[0] and a[1].tobytes() == b[1].tobytes() for a, b in zip(res_p, res_l))
         ok64 = all(d == hashlib.sha256(m).digest() for m, (d, _) in zip(msgs, res_l)) and verify_sha256_machine(res_l[63][1], res_l[63][0], vk_l, tprm, len(msgs[63])) == (0, 0)
-        batch64 = {"workload": "64 transcripts of %d bytes, one zkhip_prove_transcripts call, keyed SHA-256 machine (chip 2^14 x 612 + range table 2^16), log_blowup 1, 100 queries, 16 PoW bits" % len(msgs[0]),
+        batch64 = {"workload": "64 transcripts of %d bytes, one zkhip_prove_transcripts call, keyed SHA-256 machine (chip 2^14 x 640 + range table 2^16), log_blowup 1, 100 queries, 16 PoW bits" % len(msgs[0]),
                    "ms": round(t_lock * 1e3, 2), "transcripts_per_s": round(64 / t_lock, 1), "mode": "lock-step: 6 lanes x up to 16 members, launches merged",
                    "ms_with_verify_inside": round(t_lock_v * 1e3, 2),
                    "merged_launches_per_call": (st1[0] - st0[0]) // 3, "member_launch_requests_per_call": (st1[1] - st0[1]) // 3,

@@ -419,7 +419,7 @@ int zkhip_quotient_values_air(zkhip_ctx* ctx, const uint32_t* program, size_t pr
 
 /* ---- a real chip on the constraint-program path: SHA-256 compression (the hash of the TLS transcripts the reference's guest checks;
  * upstream SP1 proves it through the ShaExtend / ShaCompress chips of sp1-core-machine 4.1.4, reference Cargo.lock:5822, behind
- * crates/guest-prover-sp1/src/sp1.rs:116).  One row per round, 64 rows per 64-byte block, 612 columns, degree 3, 91 public values =
+ * crates/guest-prover-sp1/src/sp1.rs:116).  One row per round, 64 rows per 64-byte block, 640 columns (612 in use, padded to whole 32-column tiles), degree 3, 91 public values =
  * the digest as 16-bit limbs (low limb of word 0 first), then 75 values the VERIFIER derives from the message's length
  * (zkhip_sha256_padding_publics: the block count, where the 0x80 byte sits, which words must be zero, the length field).
  * THE EXACT RELATION a proof attests (round 5): "I know a message of exactly L bytes whose SHA-256 digest is this" -- L public.  The
@@ -431,7 +431,7 @@ int zkhip_quotient_values_air(zkhip_ctx* ctx, const uint32_t* program, size_t pr
  * public values of ITS slice.  In the unkeyed program the OUT limbs of the working variables d and h are not range-checked: their integer
  * value mod 2^32 is what the next round consumes and the three-bit carries bound their growth; the keyed machine (zkhip_sha256_setup) looks
  * every 16-bit limb up in a range table.  Column layout and constraints: csrc/sha256_chip.hip. ---- */
-#define ZKHIP_SHA256_WIDTH 612
+#define ZKHIP_SHA256_WIDTH 640
 #define ZKHIP_SHA256_PUBLIC 91           /* 16 digest limbs + ZKHIP_SHA256_PADDING_PUBLIC */
 #define ZKHIP_SHA256_PADDING_PUBLIC 75
 /* the 75 padding values of a trace that holds blocks [first_block, first_block + n_active) of the padded message of message_len bytes
@@ -444,7 +444,7 @@ void zkhip_sha256_digest(const uint8_t* message, size_t len, uint8_t digest[32])
 /* FIPS 180-4 padding: returns the padded length (a multiple of 64); written when cap suffices.  Host only. */
 size_t zkhip_sha256_pad(const uint8_t* message, size_t len, uint8_t* blocks, size_t cap);
 /* trace generation on the device: blocks = the n_active = (message_len + 8) / 64 + 1 padded 64-byte blocks (host memory), n_blocks = a
- * power of two >= n_active; d_trace [64 n_blocks][ld >= 612] Montgomery; publics (host) = the 91 public values */
+ * power of two >= n_active; d_trace [64 n_blocks][ld >= 640] Montgomery; publics (host) = the 91 public values */
 int zkhip_sha256_gen_trace(zkhip_ctx* ctx, const uint8_t* blocks, size_t n_active, size_t n_blocks, uint64_t message_len, uint32_t* d_trace, size_t ld,
                            uint32_t publics[91]);
 /* message in, digest (32 bytes, as SHA-256 prints it) and proof out: pad, generate the trace on the device, zkhip_prove_shard_air.
@@ -580,7 +580,7 @@ int zkhip_verify_sha256_sharded(const uint8_t* proofs, size_t proof_stride, cons
                                 int log_blocks_per_shard, const uint8_t digest[32], uint64_t message_len, const zkhip_params* prm, size_t* bad_shard, int* reason);
 
 /* The SHA-256 guest as a keyed machine: setup once, then one proof per message -- the reference's setup -> prove -> verify
- * (sp1.rs:113, :116, :120) on this repo's stand-in guest.  Two chips: the SHA-256 compression chip (zkhip_sha256_air, 612 columns) and a
+ * (sp1.rs:113, :116, :120) on this repo's stand-in guest.  Two chips: the SHA-256 compression chip (zkhip_sha256_air, 640 columns) and a
  * 2^16-row range table that receives the four 16-bit limbs per row the chip's own constraints do not range-check (the OUT limbs of d and
  * h); the table's values are a PREPROCESSED column committed by zkhip_sha256_setup (vk = that commitment, 8 canonical words; the key holds
  * the device data), its multiplicities are counted on the device per proof.  Messages up to 2^14 blocks (1 MiB).  A proof is a version-11

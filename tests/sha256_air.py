@@ -1,6 +1,6 @@
 """SHA-256 compression as a constraint program (test-side restatement; the product's generator is csrc/sha256_chip.cpp).
 
-One row per round, 64 rows per 64-byte block, blocks one after the other; 612 columns, every constraint of degree <= 3
+One row per round, 64 rows per 64-byte block, blocks one after the other; 640 columns (612 in use), every constraint of degree <= 3
 (log_quotient_degree 1).  What a proof says (round 5): "I know a message of exactly L bytes whose SHA-256 digest is the 16 public
 16-bit limbs" -- L public, the FIPS 180-4 padding constrained in-circuit through 75 more public values a verifier derives from L
 (padding_publics).  The trace height is a power of two, the block count of a message is not: blocks after the message are INACTIVE
@@ -40,7 +40,7 @@ SG0, SG1 = 512, 544
 CY = 576
 ACT, SKIP = 604, 605
 CNT, LASTB, L2, SB, Z0, Z2 = 606, 607, 608, 609, 610, 611
-WIDTH = 612
+WIDTH = 640          # 612 columns in use: the product pads to whole 32-column tiles (the LDE's fast passes)
 # public values: 16 digest limbs (chained: + 16 limbs of the initial chaining value), then the padding's 75:
 N_DIGEST = 16
 PP_K, PP_FIN, PP_Z13, PP_BWL, PP_BW2, PP_KIND, PP_ZWL, PP_ZW2, PP_LEN, N_PAD = 0, 1, 2, 3, 19, 35, 39, 55, 71, 75
@@ -286,7 +286,7 @@ def pad(message):
 def trace(blocks, total_blocks=None, chain_in=None, message_len=None, first_block=0):
     """blocks: bytes, a multiple of 64 long: blocks [first_block, ...) of the padded message of message_len bytes (default: what pad()
     remembered); total_blocks: a power of two >= their number (default: the next one), the rest are inactive all-zero blocks ->
-    (trace [64 total_blocks][612] canonical, public values: 16 limbs of the final chaining value, then the 75 padding values of this slice)"""
+    (trace [64 total_blocks][640] canonical, public values: 16 limbs of the final chaining value, then the 75 padding values of this slice)"""
     assert len(blocks) % 64 == 0 and len(blocks) > 0
     if message_len is None:
         message_len = getattr(blocks, "message_len", None)

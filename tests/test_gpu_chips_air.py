@@ -36,7 +36,7 @@ def test_mixed_chip_set_bytes_equal_the_oracles(ctx, oracle, shape):
 
 
 def test_a_machine_with_the_sha256_chip(ctx, oracle):
-    """the SHA-256 chip (2^10 rows x 612) next to a counter table and a synthetic table: one proof, bytes equal the oracle's"""
+    """the SHA-256 chip (2^10 rows x 640) next to a counter table and a synthetic table: one proof, bytes equal the oracle's"""
     O = oracle
     msg = bytes(range(200)) * 4                                    # 800 bytes -> 13 blocks -> 16 blocks
     sha_t, sha_pub = S.trace(S.pad(msg))
@@ -48,14 +48,14 @@ def test_a_machine_with_the_sha256_chip(ctx, oracle):
     ct, _ = airs.counter_trace(8, 8, sha_pub[0], sha_pub[1])
     syn = O.gen_trace(SEED, 5, 6, 4)
     progs = [sha256_air(), cnt, None]
-    chips = [(d_sha, 10, 612), (ctx.from_numpy(ct), 8, 8), (ctx.from_numpy(syn), 6, 4)]
+    chips = [(d_sha, 10, 640), (ctx.from_numpy(ct), 8, 8), (ctx.from_numpy(syn), 6, 4)]
     proof = ctx.prove_chips_air(chips, progs, sha_pub, Params(1, 10, 4))
     oproof = O.prove_chips_air([sha_t, ct, syn], [S.program(), cnt, None], sha_pub, O.default_params(1, 10, 4))
     assert proof.tobytes() == oproof.tobytes()
-    assert verify_chips_air(proof, [10, 8, 6], [612, 8, 4], progs, sha_pub, Params(1, 10, 4)) == (0, 0)
+    assert verify_chips_air(proof, [10, 8, 6], [640, 8, 4], progs, sha_pub, Params(1, 10, 4)) == (0, 0)
     wrong = list(sha_pub)
     wrong[7] ^= 1
-    assert verify_chips_air(proof, [10, 8, 6], [612, 8, 4], progs, wrong, Params(1, 10, 4))[0] == -6
+    assert verify_chips_air(proof, [10, 8, 6], [640, 8, 4], progs, wrong, Params(1, 10, 4))[0] == -6
 
 
 def test_misuse_fails_loudly(ctx, oracle):

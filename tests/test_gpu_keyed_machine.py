@@ -92,20 +92,20 @@ def test_sha256_chip_with_a_preprocessed_range_table(ctx, oracle):
     sha_tab = O.interaction_table([(O.SEND, None, 16, [c]) for c in sent])
     values = np.zeros((1 << 16, 4), dtype=np.uint32)
     values[:, 0] = np.arange(1 << 16)
-    d_counts = ctx.range_table(d_sha, 612, 1 << 10, sent, 16)                 # main columns (v, multiplicity, 0, 0)
+    d_counts = ctx.range_table(d_sha, 640, 1 << 10, sent, 16)                 # main columns (v, multiplicity, 0, 0)
     # combined row of the table: [v 0 0 0 | v m 0 0]; the program: a harmless first-row identity, the key fixes the values
     table_prog = O.air_program(8, S.N_PUBLIC, [(O.SEL_FIRST, [(1, [V(0)])])])
     table_tab = O.interaction_table([(O.RECEIVE, 5, 16, [0])])
     progs, tables = [table_prog, sha256_air()], [table_tab, sha_tab]
     prm, oprm = Params(1, 12, 4), O.default_params(1, 12, 4)
     key = ctx.machine_setup([(ctx.from_numpy(values), 16, 4), (None, 10, 0)], prm)
-    proof = ctx.prove_machine_keyed(key, [(d_counts, 16, 4), (d_sha, 10, 612)], progs, tables, sha_pub, prm)
-    host = [d_counts.download().reshape(-1, 4), d_sha.download().reshape(-1, 612)]
+    proof = ctx.prove_machine_keyed(key, [(d_counts, 16, 4), (d_sha, 10, 640)], progs, tables, sha_pub, prm)
+    host = [d_counts.download().reshape(-1, 4), d_sha.download().reshape(-1, 640)]
     assert proof.tobytes() == O.prove_machine_keyed(host, [values, None], progs, tables, sha_pub, oprm).tobytes()
-    assert verify_machine_keyed(proof, [16, 10], [4, 612], [4, 0], key.root, progs, tables, sha_pub, prm) == (0, 0)
+    assert verify_machine_keyed(proof, [16, 10], [4, 640], [4, 0], key.root, progs, tables, sha_pub, prm) == (0, 0)
     wrong = list(sha_pub)
     wrong[0] ^= 1
-    assert verify_machine_keyed(proof, [16, 10], [4, 612], [4, 0], key.root, progs, tables, wrong, prm)[0] == -6
+    assert verify_machine_keyed(proof, [16, 10], [4, 640], [4, 0], key.root, progs, tables, wrong, prm)[0] == -6
 
 
 import hashlib
@@ -167,7 +167,7 @@ def test_sha256_machine_above_the_table_height(ctx):
     digest, proof = ctx.prove_sha256_machine(key, msg, prm)
     assert digest == hashlib.sha256(msg).digest()
     w = np.frombuffer(proof.tobytes(), dtype=np.uint32)
-    assert list(w[8:18]) == [17, 612, 1, 4, 0, 16, 4, 1, 1, 4]
+    assert list(w[8:18]) == [17, 640, 1, 4, 0, 16, 4, 1, 1, 4]
     assert verify_sha256_machine(proof, digest, key.root, prm, len(msg)) == (0, 0)
 
 

@@ -71,20 +71,20 @@ def test_sha256_chip_with_its_limbs_range_checked_by_a_table(ctx, oracle):
     table = np.zeros((1 << 16, 4), dtype=np.uint32)
     table[:, 0] = np.arange(1 << 16)
     table[:, 1] = np.bincount(sha_t[:, sent].ravel(), minlength=1 << 16)
-    d_table = ctx.range_table(d_sha, 612, 1 << 10, sent, 16)                 # the same table, counted on the device
+    d_table = ctx.range_table(d_sha, 640, 1 << 10, sent, 16)                 # the same table, counted on the device
     assert (d_table.download().reshape(-1, 4) == table).all()
     table_prog = O.air_program(4, S.N_PUBLIC, [(O.SEL_FIRST, [(1, [V(0)])]),
                                        (O.SEL_TRANSITION, [(1, [V(0, True)]), (O.P - 1, [V(0)]), (O.P - 1, [])])])
     table_tab = O.interaction_table([(O.RECEIVE, 1, 16, [0])])
     progs, tables = [table_prog, sha256_air()], [table_tab, sha_tab]
-    chips = [(d_table, 16, 4), (d_sha, 10, 612)]
+    chips = [(d_table, 16, 4), (d_sha, 10, 640)]
     proof = ctx.prove_machine(chips, progs, tables, sha_pub, Params(1, 12, 4))
     oproof = O.prove_machine([table, sha_t], [table_prog, S.program()], tables, sha_pub, O.default_params(1, 12, 4))
     assert proof.tobytes() == oproof.tobytes()
-    assert verify_machine(proof, [16, 10], [4, 612], progs, tables, sha_pub, Params(1, 12, 4)) == (0, 0)
+    assert verify_machine(proof, [16, 10], [4, 640], progs, tables, sha_pub, Params(1, 12, 4)) == (0, 0)
     wrong = list(sha_pub)
     wrong[0] ^= 1
-    assert verify_machine(proof, [16, 10], [4, 612], progs, tables, wrong, Params(1, 12, 4))[0] == -6
+    assert verify_machine(proof, [16, 10], [4, 640], progs, tables, wrong, Params(1, 12, 4))[0] == -6
 
 
 def test_range_table_refuses_values_it_does_not_hold(ctx):
@@ -130,7 +130,7 @@ def test_a_machine_of_thirty_tables(ctx, oracle):
 
 
 def test_sha256_machine_at_2_18_rows_bytes_equal_the_oracles(ctx, oracle):
-    """the SHA-256 chip (2^18 rows x 612) + its 2^16-row range table, both generated / counted on the device: bytes against the oracle
+    """the SHA-256 chip (2^18 rows x 640) + its 2^16-row range table, both generated / counted on the device: bytes against the oracle
     proving the downloaded tables on all host cores"""
     import hashlib
     import os
@@ -146,15 +146,15 @@ def test_sha256_machine_at_2_18_rows_bytes_equal_the_oracles(ctx, oracle):
         pub = limbs.tolist()
         assert S.digest_bytes(pub) == hashlib.sha256(msg).digest()
         sent = [S.OUT + 6, S.OUT + 7, S.OUT + 14, S.OUT + 15]
-        d_table = ctx.range_table(d_sha, 612, 1 << 18, sent, 16)
+        d_table = ctx.range_table(d_sha, 640, 1 << 18, sent, 16)
         sha_tab = O.interaction_table([(O.SEND, None, 16, [c]) for c in sent])
         table_prog = O.air_program(4, S.N_PUBLIC, [(O.SEL_FIRST, [(1, [V(0)])]), (O.SEL_TRANSITION, [(1, [V(0, True)]), (O.P - 1, [V(0)]), (O.P - 1, [])])])
         table_tab = O.interaction_table([(O.RECEIVE, 1, 16, [0])])
         progs, tables = [sha256_air(), table_prog], [sha_tab, table_tab]
-        proof = ctx.prove_machine([(d_sha, 18, 612), (d_table, 16, 4)], progs, tables, pub, Params(1, 16, 4))
-        host = [d_sha.download().reshape(-1, 612), d_table.download().reshape(-1, 4)]
+        proof = ctx.prove_machine([(d_sha, 18, 640), (d_table, 16, 4)], progs, tables, pub, Params(1, 16, 4))
+        host = [d_sha.download().reshape(-1, 640), d_table.download().reshape(-1, 4)]
         assert proof.tobytes() == O.prove_machine(host, progs, tables, pub, O.default_params(1, 16, 4)).tobytes()
-        assert verify_machine(proof, [18, 16], [612, 4], progs, tables, pub, Params(1, 16, 4)) == (0, 0)
+        assert verify_machine(proof, [18, 16], [640, 4], progs, tables, pub, Params(1, 16, 4)) == (0, 0)
     finally:
         O.set_threads(prev)
 

@@ -47,7 +47,7 @@ def test_prove_sha256_bytes_equal_the_oracles(ctx, oracle, n, shape):
 
 
 def test_a_megabyte_transcript(ctx):
-    """1 MiB - 9 bytes: 2^14 blocks, 2^20 rows x 612 columns (2.4 GiB trace, 4.9 GiB LDE): digest against hashlib, proof verified"""
+    """1 MiB - 9 bytes: 2^14 blocks, 2^20 rows x 640 columns (2.4 GiB trace, 4.9 GiB LDE): digest against hashlib, proof verified"""
     msg = np.random.default_rng(7).integers(0, 256, (1 << 20) - 9, dtype=np.uint8).tobytes()
     digest, proof = ctx.prove_sha256(msg, Params(1, 100, 16))
     assert digest == hashlib.sha256(msg).digest()
@@ -78,7 +78,7 @@ def test_sixty_four_transcripts_in_one_call(ctx):
         digests.append(hashlib.sha256(msg).digest())
         assert S.digest_bytes(pubs[-1]) == digests[-1]
     ctx.sync()
-    proofs = prove_shards_air_multi(sha256_air(), traces, 14, 612, pubs, prm, devices=[0], in_flight=4)
+    proofs = prove_shards_air_multi(sha256_air(), traces, 14, 640, pubs, prm, devices=[0], in_flight=4)
     assert len(proofs) == 64 and len({p.tobytes() for p in proofs}) == 64
     for i, p in enumerate(proofs):
         assert verify_sha256(p, digests[i], prm, len(base) + 4) == (0, 0)
@@ -86,7 +86,7 @@ def test_sixty_four_transcripts_in_one_call(ctx):
 
 
 def test_a_64_kib_message_bytes_equal_the_oracles(ctx, oracle):
-    """2^10 blocks -> 2^16 rows x 612 columns: the program kernel, the LDE and the openings at a size where every kernel runs many
+    """2^10 blocks -> 2^16 rows x 640 columns: the program kernel, the LDE and the openings at a size where every kernel runs many
     workgroups; the oracle proves the same trace on all host cores"""
     import os
     O = oracle
@@ -104,7 +104,7 @@ def test_a_64_kib_message_bytes_equal_the_oracles(ctx, oracle):
 
 @pytest.mark.parametrize("kib", [256, 1024])
 def test_large_messages_bytes_equal_the_oracles(ctx, oracle, kib):
-    """2^18 and 2^20 rows x 612 (the chip at the headline height): the oracle proves the trace the DEVICE generated (its cells are checked against the restatement at the
+    """2^18 and 2^20 rows x 640 (the chip at the headline height): the oracle proves the trace the DEVICE generated (its cells are checked against the restatement at the
     smaller sizes above; the pure-Python generator would take minutes here)"""
     import os
     from zktls_amd.device import sha256_pad
@@ -157,7 +157,7 @@ def test_sharded_proofs_bytes_equal_the_oracles(ctx, oracle):
 
 
 def test_a_three_megabyte_body_as_a_chain_of_shards(ctx):
-    """BASELINE configs[3] with a real statement: a 3 MiB body = 49 153 blocks -> three shards of 2^14 blocks (2^20 rows x 612 each) and a
+    """BASELINE configs[3] with a real statement: a 3 MiB body = 49 153 blocks -> three shards of 2^14 blocks (2^20 rows x 640 each) and a
     one-block shard; digest against hashlib, the chain accepted by the host verifier; a corrupted shard is named"""
     from zktls_amd.device import prove_sha256_sharded, verify_sha256_sharded
     msg = np.random.default_rng(9).integers(0, 256, 3 << 20, dtype=np.uint8).tobytes()

@@ -294,7 +294,7 @@ def test_commitment_guest_mock_mode_outputs_the_sha256_of_the_input(lib):
 @pytest.mark.gpu
 @pytest.mark.parametrize("backend", [0, 1])
 def test_commitment_guest_proves_the_reference_transcript(lib, backend):
-    """the recorded 13 217-byte transcript: 207 blocks -> 2^14 rows x 612 columns; the proof is a real statement about the
+    """the recorded 13 217-byte transcript: 207 blocks -> 2^14 rows x 640 columns; the proof is a real statement about the
     request (SHA-256 chip), checked by the library's verifier against hashlib's digest"""
     import hashlib
     from zktls_amd._lib import Params

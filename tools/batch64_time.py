@@ -23,10 +23,10 @@ for i in range(64):
 ctx.sync()
 tg = time.perf_counter() - t0
 prog = sha256_air()
-prove_shards_air_multi(prog, traces[:8], 14, 612, pubs[:8], prm, devices=[0], in_flight=inflight)       # contexts, plans
+prove_shards_air_multi(prog, traces[:8], 14, 640, pubs[:8], prm, devices=[0], in_flight=inflight)       # contexts, plans
 for rep in range(3):
     t0 = time.perf_counter()
-    proofs = prove_shards_air_multi(prog, traces, 14, 612, pubs, prm, devices=[0], in_flight=inflight)
+    proofs = prove_shards_air_multi(prog, traces, 14, 640, pubs, prm, devices=[0], in_flight=inflight)
     dt = time.perf_counter() - t0
     print("64 transcripts of %d bytes: traces generated in %.1f ms, proven in %.1f ms = %.2f ms per transcript (%d in flight)" % (len(base) + 4, tg * 1e3, dt * 1e3, dt * 1e3 / 64, inflight))
 t0 = time.perf_counter()

@@ -1,4 +1,4 @@
-"""latency of ONE keyed SHA-256 machine proof of the recorded 13 KB transcript (2^14 x 612 chip + 2^16-row table), one context, nothing else in
+"""latency of ONE keyed SHA-256 machine proof of the recorded 13 KB transcript (2^14 x 640 chip + 2^16-row table), one context, nothing else in
 flight: python tools/keyed_latency.py [reps=20]   (run under rocprofv3 --kernel-trace --stats for the launch count and the busy time)"""
 import os
 import sys

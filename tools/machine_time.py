@@ -26,9 +26,9 @@ for log_blocks in ([int(x) for x in sys.argv[1:]] or (4, 8, 12)):
     n = (64 << log_blocks) - 9
     msg = np.random.default_rng(log_blocks).integers(0, 256, n, dtype=np.uint8).tobytes()
     d_sha, limbs = ctx.sha256_gen_trace(sha256_pad(msg), 1 << log_blocks)
-    d_table = ctx.range_table(d_sha, 612, 64 << log_blocks, sent, 16)     # values + multiplicities counted on the device
-    lns, ws = [16, log_blocks + 6], [4, 612]
-    chips, progs, tables = [(d_table, 16, 4), (d_sha, log_blocks + 6, 612)], [table_prog, prog], [table_tab, sha_tab]
+    d_table = ctx.range_table(d_sha, 640, 64 << log_blocks, sent, 16)     # values + multiplicities counted on the device
+    lns, ws = [16, log_blocks + 6], [4, 640]
+    chips, progs, tables = [(d_table, 16, 4), (d_sha, log_blocks + 6, 640)], [table_prog, prog], [table_tab, sha_tab]
     if log_blocks + 6 > 16:
         chips, progs, tables, lns, ws = chips[::-1], progs[::-1], tables[::-1], lns[::-1], ws[::-1]
     pub = limbs.tolist()
@@ -41,5 +41,5 @@ for log_blocks in ([int(x) for x in sys.argv[1:]] or (4, 8, 12)):
     dt = (time.perf_counter() - t0) / reps
     assert verify_machine(proof, lns, ws, progs, tables, pub, prm) == (0, 0)
     assert S.digest_bytes(pub) == hashlib.sha256(msg).digest()
-    print("SHA-256 chip 2^%d x 612 + range table 2^16 x 4: %.1f ms per proof, %d bytes" % (log_blocks + 6, dt * 1e3, proof.size))
+    print("SHA-256 chip 2^%d x 640 + range table 2^16 x 4: %.1f ms per proof, %d bytes" % (log_blocks + 6, dt * 1e3, proof.size))
     d_sha.free(); d_table.free()

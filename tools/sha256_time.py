@@ -31,12 +31,12 @@ for log_blocks in ([int(x) for x in sys.argv[1:]] or (4, 8, 10, 12, 14)):
     ctx.sync()
     tg = time.perf_counter() - t1
     prog = sha256_air()
-    ctx.prove_shard_air(prog, buf, log_blocks + 6, 612, limbs.tolist(), prm)
+    ctx.prove_shard_air(prog, buf, log_blocks + 6, 640, limbs.tolist(), prm)
     t2 = time.perf_counter()
-    ctx.prove_shard_air(prog, buf, log_blocks + 6, 612, limbs.tolist(), prm)
+    ctx.prove_shard_air(prog, buf, log_blocks + 6, 640, limbs.tolist(), prm)
     tp = time.perf_counter() - t2
     print("   prove_shard_air on the resident trace alone: %.1f ms" % (tp * 1e3))
     buf.free()
     assert digest == hashlib.sha256(msg).digest() and verify_sha256(proof, digest, prm, len(msg)) == (0, 0)
-    print("2^%d blocks (%d bytes): rows 2^%d x 612, prove %.1f ms (trace gen alone %.1f ms), %.1f MB/s of message, %.2f G cells/s, proof %d bytes"
-          % (log_blocks, n, log_blocks + 6, dt * 1e3, tg * 1e3, n / dt / 1e6, (612 << (log_blocks + 6)) / dt / 1e9, proof.size))
+    print("2^%d blocks (%d bytes): rows 2^%d x 640, prove %.1f ms (trace gen alone %.1f ms), %.1f MB/s of message, %.2f G cells/s, proof %d bytes"
+          % (log_blocks, n, log_blocks + 6, dt * 1e3, tg * 1e3, n / dt / 1e6, (640 << (log_blocks + 6)) / dt / 1e9, proof.size))

@@ -20,8 +20,8 @@ for rep in range(3):
     t0 = time.perf_counter()
     res = prove_sha256_sharded(msg, 14, prm, devices=[0], in_flight=inflight)
     dt = time.perf_counter() - t0
-    print("%d MiB body: %d shards of 2^20 rows x 612 proven in %.1f ms = %.1f ms per MiB (%.2f G cells/s, %d in flight, host padding + chaining values included)"
-          % (mib, len(res.proofs), dt * 1e3, dt * 1e3 / mib, len(res.proofs) * (612 << 20) / dt / 1e9, inflight))
+    print("%d MiB body: %d shards of 2^20 rows x 640 proven in %.1f ms = %.1f ms per MiB (%.2f G cells/s, %d in flight, host padding + chaining values included)"
+          % (mib, len(res.proofs), dt * 1e3, dt * 1e3 / mib, len(res.proofs) * (640 << 20) / dt / 1e9, inflight))
 assert res.digest == hashlib.sha256(msg).digest()
 t0 = time.perf_counter()
 assert verify_sha256_sharded(res, params=prm) == (0, 0, 0)

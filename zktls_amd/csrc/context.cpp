@@ -492,6 +492,15 @@ int op_coset_lde(zkhip_ctx* ctx, const uint32_t* in, size_t in_ld, uint32_t* out
                                  two_adic_generator(log_n + log_blowup), shift, MONTY_R1, 1, ctx->stream));
         return ZKHIP_OK;
     }
+    // A width that is not a multiple of 32 columns: the tile passes take two columns per lane (and, at 2^20 rows, the fused middle launch) only
+    // for whole 32-column tiles -- a 612-column matrix went through the one-column-per-lane passes at 2.3 x the time of a 608-column one
+    // (14.5 against 6.2 ms per 2^20-row LDE; round 5: the SHA-256 chip's width).  Columns are independent: the whole tiles go first, the
+    // remainder follows as a narrow matrix of its own (the coefficient workspace is reused in stream order).
+    if (width > 32 && width % 32 != 0) {
+        const uint32_t w32 = width & ~31u;
+        ZK_TRY(op_coset_lde(ctx, in, in_ld, out, out_ld, log_n, w32, log_blowup, shift));
+        return op_coset_lde(ctx, in + w32, in_ld, out + w32, out_ld, log_n, width - w32, log_blowup, shift);
+    }
     const size_t n = (size_t)1 << log_n;
     const int B = 1 << log_blowup;
     int m1, m2;

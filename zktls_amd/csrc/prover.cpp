@@ -141,7 +141,7 @@ static int run_quotient_air(zkhip_ctx* ctx, const AirView& air, const uint32_t* 
     air_device_image(air, alpha, body, weights, scale);
     std::vector<uint32_t> pub(air.n_public ? air.n_public : 1, 0u);
     for (uint32_t i = 0; i < air.n_public; i++) pub[i] = to_monty(public_values[i]);
-    // the flattened form for the term-parallel kernel (up to 64 public values: they travel in every point's LDS slots)
+    // the flattened form for the term-parallel kernel (up to 256 public values: they travel in every point's LDS slots -- a quarter of a column group each; the SHA-256 chip reads 91 / 107 since its padding is constrained in-circuit)
     std::vector<uint32_t> recs;
     uint32_t cls[6] = {0, 0, 0, 0, 0, 0};
     // (not inside a lock-step batch: the batched twin takes its arguments from memory, its record loads then are per-lane loads of one
@@ -152,7 +152,7 @@ static int run_quotient_air(zkhip_ctx* ctx, const AirView& air, const uint32_t* 
     const bool wide = !t_batcher && ld % 4 == 0 && (reinterpret_cast<uintptr_t>(lde) & 15u) == 0 &&
                       air_wide_form(width, (uint32_t)air_term_count(air), log_n, pub_used);
     if (wide) air_term_records_wide(air, alpha, recs, cls, scale);
-    else if (pub_used <= 64) air_term_records(air, alpha, recs, scale);
+    else if (pub_used <= 256) air_term_records(air, alpha, recs, scale);
     // one staging buffer: body | weights (16-byte aligned) | public values | term records (16-byte aligned)
     const size_t body_w = (body.size() + 3) & ~(size_t)3, pub_w = (pub.size() + 3) & ~(size_t)3;
     std::vector<uint32_t> stage(body_w + weights.size() + pub_w + recs.size(), 0u);

@@ -5,7 +5,7 @@
 // it is a self-contained AIR for the same function, written out as a constraint program (air.h) plus its on-device trace
 // generator, proven and verified by zkhip_prove_shard_air / zkhip_verify_shard_air like any other program.
 //
-// One row per round, 64 rows per 64-byte block, blocks one after the other; 608 columns, every constraint of degree <= 3.
+// One row per round, 64 rows per 64-byte block, blocks one after the other; 640 columns (612 in use), every constraint of degree <= 3.
 // A proof says: "I know at most 2^k blocks whose SHA-256 chaining value, from the standard IV, is the 16 public 16-bit limbs"
 // -- with FIPS 180-4 padding inside the blocks, the SHA-256 digest of a message.  Blocks after the message are INACTIVE and
 // pass the chaining value through (the trace height is a power of two, a block count is not).
@@ -51,7 +51,9 @@ namespace sha {
 
 constexpr uint32_t SEL = 0, A = 64, B = 96, C = 128, E = 160, F = 192, G = 224, D = 256, HV = 258;
 constexpr uint32_t S1 = 260, CH = 292, S0 = 324, MJ = 356, HC = 388, OUT = 404, X0 = 420, X13 = 452, XL = 484;
-constexpr uint32_t SG0 = 512, SG1 = 544, CY = 576, ACT = 604, SKIP = 605, CNT = 606, LASTB = 607, L2 = 608, SB = 609, Z0 = 610, Z2 = 611, WIDTH = 612;
+constexpr uint32_t SG0 = 512, SG1 = 544, CY = 576, ACT = 604, SKIP = 605, CNT = 606, LASTB = 607, L2 = 608, SB = 609, Z0 = 610, Z2 = 611, USED = 612, WIDTH = 640;
+// (612 columns in use; 640 = 20 tiles of 32 columns: the LDE's two-columns-per-lane passes and its fused middle launch take whole tiles only --
+// a 612-wide matrix costs 9.7 ms per 2^20-row LDE against 6.3 at 640, and the leaf hash pays 80 permutations per row instead of 77)
 // public values: the digest's 16 limbs (chained: then the initial chaining value's 16), then the padding's:
 constexpr uint32_t N_DIGEST = 16, PP_K = 0, PP_FIN = 1, PP_Z13 = 2, PP_BWL = 3, PP_BW2 = 19, PP_KIND = 35, PP_ZWL = 39, PP_ZW2 = 55, PP_LEN = 71, N_PAD = 75;
 constexpr uint32_t N_PUBLIC = N_DIGEST + N_PAD, N_PUBLIC_CHAINED = 2 * N_DIGEST + N_PAD;
@@ -444,6 +446,7 @@ __device__ __forceinline__ void sha256_trace_kernel_body(const TraceArgs& a) {
     row[SB] = (blk == a.pad_block && r == a.pad_row) ? MONTY_R1 : 0u;
     row[Z0] = (r == 0 && lastb) ? MONTY_R1 : 0u;
     row[Z2] = (r == 0 && l2) ? MONTY_R1 : 0u;
+    for (uint32_t c = USED; c < WIDTH; c++) row[c] = 0u;              // the unused columns of the last tile
 }
 __global__ void __launch_bounds__(64) sha256_trace_kernel(TraceArgs a) { sha256_trace_kernel_body(a); }
 struct sha256_trace_kernel_bargs { TraceArgs a; static sha256_trace_kernel_bargs make(TraceArgs a) { return sha256_trace_kernel_bargs{a}; } };
@@ -562,7 +565,7 @@ int zkhip_sha256_gen_trace_chained(zkhip_ctx* ctx, const uint32_t chain_in[8], c
     if (!chain_in) return fail(ZKHIP_ERR_INVALID, "sha256_gen_trace: null chaining value");
     const int lb = log2_exact(n_blocks);
     if (!blocks || !d_trace || !publics || n_active == 0 || n_active > n_blocks || lb < 0 || lb + 6 > MAX_LOG_ROWS || ld < sha::WIDTH)
-        return fail(ZKHIP_ERR_INVALID, "sha256_gen_trace: 1 <= n_active <= n_blocks = 2^k <= 2^16, ld >= 612");
+        return fail(ZKHIP_ERR_INVALID, "sha256_gen_trace: 1 <= n_active <= n_blocks = 2^k <= 2^16, ld >= 640");
     if (first_block + n_active > (message_len + 8) / 64 + 1) return fail(ZKHIP_ERR_INVALID, "sha256_gen_trace: the slice runs past the padded message");
     std::vector<uint32_t> host((size_t)n_blocks * 24, 0u);             // [n_blocks][16] words, then [n_blocks][8] chaining values
     uint32_t* words = host.data();
@@ -702,7 +705,7 @@ static MachineShape machine_shape(int log_n) {
 }
 }  // namespace sha
 }  // namespace zk
-// lock-step batches of small transcripts (batch.h): the tallest chip that still counts as small (2^14 rows x 608 columns = 10 M cells, a
+// lock-step batches of small transcripts (batch.h): the tallest chip that still counts as small (2^14 rows x 640 columns = 10 M cells, a
 // 16 KB transcript -- the size measured as launch-bound; context.h LOCKSTEP_MAX_CELLS)
 constexpr int LOCKSTEP_MAX_LOG_N = 14;
 namespace zk { extern std::atomic<uint64_t> g_lockstep_stats[6]; }

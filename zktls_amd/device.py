@@ -11,7 +11,7 @@ from . import _lib
 from ._lib import Params, ProveDebug, check, from_monty, to_monty, u32p, u8p
 
 
-SHA256_WIDTH, SHA256_PUBLIC, SHA256_PADDING_PUBLIC = 612, 91, 75      # include/zkhip.h: ZKHIP_SHA256_*
+SHA256_WIDTH, SHA256_PUBLIC, SHA256_PADDING_PUBLIC = 640, 91, 75      # include/zkhip.h: ZKHIP_SHA256_*
 
 
 class DeviceBuffer:
@@ -347,7 +347,7 @@ class Context:
     # ---- the SHA-256 compression chip (csrc/sha256_chip.hip)
     def sha256_gen_trace(self, blocks, n_blocks=None, out=None, message_len=None):
         """blocks: the padded message, a multiple of 64 long (sha256_pad / sha256_air.pad remember the message's length; otherwise pass
-        message_len) -> (device trace [64 n_blocks][612], public values [91]: 16 digest limbs + the 75 padding values)"""
+        message_len) -> (device trace [64 n_blocks][640], public values [91]: 16 digest limbs + the 75 padding values)"""
         if message_len is None:
             message_len = getattr(blocks, "message_len", None)
         if message_len is None:
