@@ -831,6 +831,32 @@ int zkhip_verify_shard_recursive(const uint8_t* proof, size_t len, int log_n, ui
                                  size_t n_public, size_t n_proofs, const uint32_t vk[8], const zkhip_params* outer, int* reason);
 size_t zkhip_shard_verifier_describe(int log_n, uint32_t width, size_t n_queries, int inner_pow_bits, size_t n_public, size_t n_proofs, int which, int kind, uint32_t* out,
                                      size_t cap_words, int* log_rows, uint32_t* main_width, uint32_t* pre_width);
+/* ---- THE SAME MACHINE FOR INNER PROOFS OF A CONSTRAINT PROGRAM (round 5; version-7 proofs: zkhip_prove_shard_air, zkhip_prove_sha256, the chained
+ * shards of zkhip_prove_sha256_sharded, zkhip_prove_shards_air_multi) -- the proofs that carry a REAL statement become compressible: what
+ * `client.prove(.., SP1ProofMode::Groth16)` (crates/guest-prover-sp1/src/sp1.rs:116: core -> COMPRESS) does to the shard proofs of a real guest.
+ * Conditions on the inner proofs: SP1 shape (blowup 2, fold by 2, constant final value, Poseidon2 width 16, no lookups), a width that is a
+ * multiple of 8, a program of log_quotient_degree 1 whose terms have at most three factors (a selector counts), at most 128 public values.
+ * A NINTH chip, EVAL, holds one row per TERM of the program: coefficient and three factor keys preprocessed, the factor values -- opened
+ * values at zeta / zeta g from OPENED, public values from the transcript table, selectors from SCALARS -- received over one bus, the fold of
+ * the constraints with alpha as a running sum down the rows.  The transcript starts from 18 constant words (the six shape words, logup_pairs,
+ * fold, final, hash width, the program's digest).  THE KEY IS A FUNCTION OF THE SHAPE AND THE PROGRAM; the verifier of the outer proof takes
+ * the program, the shape, the inner proofs' public values and the key -- no byte of an inner proof.  Joins as above (n_proofs > 1). */
+int zkhip_shard_verifier_setup_air(zkhip_ctx* ctx, const uint32_t* program, size_t program_words, int log_n, uint32_t width, size_t n_queries, int inner_pow_bits, size_t n_public,
+                                   size_t n_proofs, const zkhip_params* outer, zkhip_machine_key** key, uint32_t vk[8]);
+int zkhip_shard_verifier_key_host_air(const uint32_t* program, size_t program_words, int log_n, uint32_t width, size_t n_queries, int inner_pow_bits, size_t n_public, size_t n_proofs,
+                                      const zkhip_params* outer, uint32_t vk[8]);
+size_t zkhip_shard_verifier_max_proofs_air(const uint32_t* program, size_t program_words, int log_n, uint32_t width, size_t n_queries, int inner_pow_bits, size_t n_public,
+                                           const zkhip_params* outer);
+size_t zkhip_shard_verifier_proof_size_air(const uint32_t* program, size_t program_words, int log_n, uint32_t width, size_t n_queries, int inner_pow_bits, size_t n_public,
+                                           size_t n_proofs, const zkhip_params* outer);
+int zkhip_prove_shard_verifier_air(zkhip_ctx* ctx, const zkhip_machine_key* key, const uint32_t* program, size_t program_words, const uint8_t* const* shard_proofs,
+                                   const size_t* shard_proof_lens, size_t n_proofs, int log_n, uint32_t width, const uint32_t* public_values, size_t n_public,
+                                   const zkhip_params* inner, const zkhip_params* outer, uint8_t* proof, size_t cap, size_t* len);
+int zkhip_verify_shard_recursive_air(const uint32_t* program, size_t program_words, const uint8_t* proof, size_t len, int log_n, uint32_t width, size_t n_queries, int inner_pow_bits,
+                                     const uint32_t* public_values, size_t n_public, size_t n_proofs, const uint32_t vk[8], const zkhip_params* outer, int* reason);
+size_t zkhip_shard_verifier_describe_air(const uint32_t* program, size_t program_words, int log_n, uint32_t width, size_t n_queries, int inner_pow_bits, size_t n_public,
+                                         size_t n_proofs, int which, int kind, uint32_t* out, size_t cap_words, int* log_rows, uint32_t* main_width, uint32_t* pre_width);
+
 
 /* ---- Poseidon2 parameter tables from a file: the built-in sets are this repo's own
  * ("zktls-amd/p2-bb16-v1", "...-bb24-v1"; the SP1 / RISC Zero tables of reference Cargo.lock:4030, 6172, 5057 are not

@@ -158,6 +158,24 @@ extern "C" {
     pub fn zkhip_shard_verifier_key_host(log_n: c_int, width: u32, n_queries: usize, inner_pow_bits: c_int, n_public: usize, n_proofs: usize, outer: *const ZkhipParams,
                                          vk: *mut u32) -> c_int;
     pub fn zkhip_machine_key_host(h_traces: *const *const u32, log_ns: *const i32, pre_widths: *const u32, n_chips: c_int, prm: *const ZkhipParams, root: *mut u32) -> c_int;
+    // the same machine for inner proofs of a constraint program (version 7: the SHA-256 chip's proofs ...): nine chips, the key = f(shape, program)
+    pub fn zkhip_shard_verifier_setup_air(ctx: *mut ZkhipCtx, program: *const u32, program_words: usize, log_n: c_int, width: u32, n_queries: usize, inner_pow_bits: c_int,
+                                          n_public: usize, n_proofs: usize, outer: *const ZkhipParams, key: *mut *mut ZkhipMachineKey, vk: *mut u32) -> c_int;
+    pub fn zkhip_shard_verifier_key_host_air(program: *const u32, program_words: usize, log_n: c_int, width: u32, n_queries: usize, inner_pow_bits: c_int, n_public: usize,
+                                             n_proofs: usize, outer: *const ZkhipParams, vk: *mut u32) -> c_int;
+    pub fn zkhip_shard_verifier_max_proofs_air(program: *const u32, program_words: usize, log_n: c_int, width: u32, n_queries: usize, inner_pow_bits: c_int, n_public: usize,
+                                               outer: *const ZkhipParams) -> usize;
+    pub fn zkhip_shard_verifier_proof_size_air(program: *const u32, program_words: usize, log_n: c_int, width: u32, n_queries: usize, inner_pow_bits: c_int, n_public: usize,
+                                               n_proofs: usize, outer: *const ZkhipParams) -> usize;
+    pub fn zkhip_prove_shard_verifier_air(ctx: *mut ZkhipCtx, key: *const ZkhipMachineKey, program: *const u32, program_words: usize, shard_proofs: *const *const u8,
+                                          shard_proof_lens: *const usize, n_proofs: usize, log_n: c_int, width: u32, public_values: *const u32, n_public: usize,
+                                          inner: *const ZkhipParams, outer: *const ZkhipParams, proof: *mut u8, cap: usize, len: *mut usize) -> c_int;
+    pub fn zkhip_verify_shard_recursive_air(program: *const u32, program_words: usize, proof: *const u8, len: usize, log_n: c_int, width: u32, n_queries: usize,
+                                            inner_pow_bits: c_int, public_values: *const u32, n_public: usize, n_proofs: usize, vk: *const u32, outer: *const ZkhipParams,
+                                            reason: *mut c_int) -> c_int;
+    pub fn zkhip_shard_verifier_describe_air(program: *const u32, program_words: usize, log_n: c_int, width: u32, n_queries: usize, inner_pow_bits: c_int, n_public: usize,
+                                             n_proofs: usize, which: c_int, kind: c_int, out: *mut u32, cap_words: usize, log_rows: *mut c_int, main_width: *mut u32,
+                                             pre_width: *mut u32) -> usize;
     pub fn zkhip_shard_verifier_max_proofs(log_n: c_int, width: u32, n_queries: usize, inner_pow_bits: c_int, n_public: usize, outer: *const ZkhipParams) -> usize;
     pub fn zkhip_prove_shard_verifier(ctx: *mut ZkhipCtx, key: *const ZkhipMachineKey, shard_proofs: *const *const u8, shard_proof_lens: *const usize, n_proofs: usize,
                                       log_n: c_int, width: u32, public_values: *const u32, n_public: usize, inner: *const ZkhipParams, outer: *const ZkhipParams,

@@ -86,7 +86,7 @@ enum Slot {
     S_ADDEND,          // machine mode: the folded lookup constraints of a chip on its quotient domain
     S_CHIP_B,          // second table of a built-in machine (the SHA-256 machine's range table: values at setup, multiplicities per proof)
     S_KEYTRACE,        // keyed machine: a chip's trace rows [preprocessed | main] for its permutation trace
-    S_REC_A, S_REC_B, S_REC_C, S_REC_D, S_REC_E, S_REC_F, S_REC_G, S_REC_H,   // recursion machines (fri_chip.hip, shard_verifier.inl): traces and tables of their chips, alive for the whole prove call
+    S_REC_A, S_REC_B, S_REC_C, S_REC_D, S_REC_E, S_REC_F, S_REC_G, S_REC_H, S_REC_I,   // recursion machines (fri_chip.hip, shard_verifier.inl): traces and tables of their chips, alive for the whole prove call
     S_COUNT
 };
 
@@ -138,7 +138,7 @@ int ctx_host_pinned(zkhip_ctx* ctx, size_t bytes, void** out);
 extern thread_local int t_query_threads_cap;
 int fri_view_all_unhashed(const uint8_t* proof, size_t len, int log_n, uint32_t width, const uint32_t* public_values, size_t n_public, const zkhip_params* prm,
                           uint32_t* betas, uint32_t final_value[4], uint32_t* indices, uint32_t* values, uint32_t* siblings, uint32_t* roots, uint32_t* paths,
-                          uint32_t transcript[10]);      // the context's pinned host block, grown to `bytes`; contents undefined
+                          uint32_t transcript[10], const uint32_t* program = nullptr, size_t program_words = 0);      // (program: a version-7 proof of that constraint program)  -- above: the context's pinned host block, grown to `bytes`; contents undefined
 int get_plan(zkhip_ctx* ctx, int log_n, int kind, uint32_t shift_monty, const NttPlan** out);
 // internal op entry points shared by capi.cpp and prover.cpp (device pointers, ctx stream)
 int op_coset_lde(zkhip_ctx* ctx, const uint32_t* d_in, size_t in_ld, uint32_t* d_out, size_t out_ld,

@@ -91,6 +91,8 @@ inline int lg(size_t n, int lo = 5) { int l = lo; while (((size_t)1 << l) < n) l
 constexpr uint32_t BUS_IN0 = 61, BUS_IN1 = 62, BUS_TC = 63, BUS_BETA = 64, BUS_SC = 65, BUS_QI = 66, BUS_AT = 67, BUS_AQ = 68;
 // K0 .. K0 + 6: the QUERY chip's seven constants; KO0 .. KO0 + 4: the OPENED chip's five; OY, OY + 1: its two sums (every tuple keyed by the proof's number)
 constexpr uint32_t BUS_K0 = 70, BUS_KFA = 77, BUS_KO0 = 78, BUS_OY = 83, BUS_OA = 85;
+// the program evaluator (air mode): VAL carries (key, value at zeta) to the EVAL chip's factor slots; EA hands it the proof's alpha
+constexpr uint32_t BUS_VAL = 86, BUS_EA = 87;
 using frichip::BUS_FIN; using frichip::BUS_E0; using frichip::BUS_E1; using frichip::BUS_R0; using frichip::BUS_R1; using frichip::BUS_Q;
 using frichip::BUS_S0; using frichip::BUS_S1; using frichip::BUS_I;
 
@@ -98,7 +100,21 @@ using frichip::BUS_S0; using frichip::BUS_S1; using frichip::BUS_I;
 struct Shape {
     int n, W, Q, PB, NPUB, R, H, G, WB, NP;          // NP: inner proofs verified by ONE outer proof (the join); every chip holds proof 0's rows, then proof 1's, ...
     int TAGSPAN, TREES;                               // tags / trees of one proof: tags, tree numbers and query numbers carry the proof's number
-    uint32_t head[6];
+    // AIR MODE (round 5): the inner proofs are version-7 proofs of a constraint PROGRAM (zkhip_prove_shard_air: the SHA-256 chip ...) instead of
+    // version-1 proofs of the synthetic AIR.  The transcript then starts from 18 constant words (6 shape words, logup_pairs / K / F / hash width,
+    // the program's 8-word digest: proof_common.h transcript_init), and the fold of the AIR at zeta is the EVAL chip's: one row per TERM.
+    bool air = false;
+    int HL = 6;                                       // header words the transcript starts from
+    struct ETerm { uint32_t coeff; uint32_t key[3]; uint32_t first; };      // factor keys inside one proof's key space (0 = the constant one)
+    std::vector<ETerm> terms;                         // the program flattened: constraint by constraint, a selector = one more factor
+    std::vector<uint32_t> mult;                       // per key: how many factor slots read it (the senders' preprocessed multiplicities)
+    uint32_t KSPAN = 0;                               // keys per proof: 1 + 2 W + NPUB + 3
+    std::vector<uint64_t> prog_id;                    // the program's digest (the machine cache's key)
+    uint32_t key_local(uint32_t c) const { return 1u + c; }
+    uint32_t key_next(uint32_t c) const { return 1u + (uint32_t)W + c; }
+    uint32_t key_pub(uint32_t i) const { return 1u + 2u * (uint32_t)W + i; }
+    uint32_t key_sel(uint32_t which) const { return 1u + 2u * (uint32_t)W + (uint32_t)NPUB + which; }     // 0 first row, 1 last row, 2 transition
+    uint32_t head[18];
     int f0, r0, TA, TQ, TO0, TF, TL0, TP, NS, NT, NTS;
     std::vector<int> pub_rows;
     size_t fri_rows, p2_fri0, p2_tr0, p2_q0, p2_rows;
@@ -119,22 +135,56 @@ constexpr size_t MAX_JOIN = 1024;       // proofs per join: as many as fit the P
 // tile passes run on dense 2^20-row classes: context.cpp, coset_lde_big); other blowups write every 4th row of the LDE and take a pitch of 256 words
 constexpr int P2R_MAX_LOG_ROWS = 22;
 inline int p2r_max_log_rows(const zkhip_params* outer) { return !outer || outer->log_blowup == 1 ? 22 : 21; }
-int make_shape(int log_n, uint32_t width, size_t n_queries, int pow_bits, size_t n_public, size_t n_proofs, Shape& s) {
+int make_shape(int log_n, uint32_t width, size_t n_queries, int pow_bits, size_t n_public, size_t n_proofs, Shape& s, const uint32_t* program = nullptr, size_t program_words = 0) {
     // (the inner proofs are zkhip_prove_shard's: its bounds on rows and proof-of-work bits -- proof_common.h, check_shape -- are this machine's)
-    if (log_n < 5 || log_n > MAX_LOG_ROWS || width < 8 || width > 1024 || width % 8 || n_queries < 1 || n_queries > 1024 || pow_bits < 0 || pow_bits > 28 || n_public > 64 ||
-        n_proofs < 1 || n_proofs > MAX_JOIN)
-        return fail(ZKHIP_ERR_INVALID, "shard verifier: 2^5 .. 2^22 rows, a width of 8 .. 1024 in multiples of 8, 1 .. 1024 queries, 0 .. 28 proof-of-work bits, at most 64 public values, 1 .. 1024 proofs");
+    if (log_n < 5 || log_n > MAX_LOG_ROWS || width < 8 || width > 1024 || width % 8 || n_queries < 1 || n_queries > 1024 || pow_bits < 0 || pow_bits > 28 ||
+        n_public > (program ? 128u : 64u) || n_proofs < 1 || n_proofs > MAX_JOIN)
+        return fail(ZKHIP_ERR_INVALID, "shard verifier: 2^5 .. 2^22 rows, a width of 8 .. 1024 in multiples of 8, 1 .. 1024 queries, 0 .. 28 proof-of-work bits, at most 64 public values (128 with a program), 1 .. 1024 proofs");
     s.NP = (int)n_proofs;
     s.n = log_n; s.W = (int)width; s.Q = (int)n_queries; s.PB = pow_bits; s.NPUB = (int)n_public;
     s.R = log_n; s.H = log_n + 1; s.G = s.W / 4; s.WB = s.W / 8;
     const uint32_t head[6] = {(uint32_t)log_n, width, 1u, (uint32_t)n_queries, (uint32_t)pow_bits, (uint32_t)n_public};
     std::memcpy(s.head, head, sizeof head);
-    const int n0 = 6 + 8 + s.NPUB;
+    s.air = program != nullptr; s.HL = 6;
+    s.terms.clear(); s.mult.clear(); s.prog_id.clear(); s.KSPAN = 0;
+    if (program) {
+        AirView av;
+        if (!air_validate(program, program_words, width, n_public, &av) || av.lqd != 1)
+            return fail(ZKHIP_ERR_INVALID, "shard verifier: the inner program must be a valid constraint program of this width and public-value count with log_quotient_degree 1");
+        // the header of a version-7 proof of the SP1 shape: + logup_pairs 0, fold by 2^1, constant final value, Poseidon2 width 16, the program's digest
+        s.HL = 18;
+        s.head[6] = 0u; s.head[7] = 1u; s.head[8] = 0u; s.head[9] = 16u;
+        uint32_t dg[8];
+        air_digest(av, dg);
+        for (int i = 0; i < 8; i++) { s.head[10 + i] = dg[i]; s.prog_id.push_back(dg[i]); }
+        s.KSPAN = 1u + 2u * width + (uint32_t)n_public + 3u;
+        s.mult.assign(s.KSPAN, 0u);
+        size_t p = 6;
+        for (uint32_t k = 0; k < program[3]; k++) {
+            const uint32_t sel = program[p++], nt = program[p++];
+            for (uint32_t t = 0; t < nt; t++) {
+                Shape::ETerm e{program[p], {0u, 0u, 0u}, t == 0 ? 1u : 0u};
+                const uint32_t d = program[p + 1];
+                p += 2;
+                uint32_t nf = 0;
+                if (d + (sel ? 1u : 0u) > 3) return fail(ZKHIP_ERR_INVALID, "shard verifier: a term of the inner program has more than three factors");
+                for (uint32_t j = 0; j < d; j++) {
+                    const uint32_t v = program[p++], kind = v >> 30, idx = v & 0xFFFFu;
+                    e.key[nf++] = kind == 0 ? s.key_local(idx) : (kind == 1 ? s.key_next(idx) : s.key_pub(idx));
+                }
+                if (sel) e.key[nf++] = s.key_sel(sel - 1u);        // program selectors: 1 first row, 2 last row, 3 transition
+                for (int j = 0; j < 3; j++) s.mult[e.key[j]]++;
+                s.terms.push_back(e);
+            }
+        }
+        if (s.terms.empty() || s.terms.size() > ((size_t)1 << 20)) return fail(ZKHIP_ERR_INVALID, "shard verifier: the inner program has no terms, or more than 2^20");
+    }
+    const int n0 = s.HL + 8 + s.NPUB;
     s.f0 = n0 / 8; s.r0 = n0 % 8;
     s.TA = s.r0 ? s.f0 : s.f0 - 1; s.TQ = s.TA + 1; s.TO0 = s.TQ + 1; s.TF = s.TO0 + s.W + 3; s.TL0 = s.TF + 1; s.TP = s.TL0 + s.R;
     s.NS = (int)frichip::sample_rows(n_queries); s.NT = s.TP + s.NS; s.NTS = s.TP + 1;
     s.pub_rows.clear();
-    for (int i = 0; i < s.NPUB; i++) { const int r = (14 + i) / 8; if (s.pub_rows.empty() || s.pub_rows.back() != r) s.pub_rows.push_back(r); }
+    for (int i = 0; i < s.NPUB; i++) { const int r = (s.HL + 8 + i) / 8; if (s.pub_rows.empty() || s.pub_rows.back() != r) s.pub_rows.push_back(r); }
     s.fri_rows = (size_t)s.R + (size_t)s.R * (size_t)(s.R + 1) / 2;
     s.p2_fri0 = (size_t)s.NT; s.p2_tr0 = s.p2_fri0 + (size_t)s.Q * s.fri_rows; s.p2_q0 = s.p2_tr0 + (size_t)s.Q * (size_t)(s.WB + s.H);
     s.p2_rows = s.p2_q0 + (size_t)s.Q * (size_t)(1 + s.H);
@@ -142,7 +192,7 @@ int make_shape(int log_n, uint32_t width, size_t n_queries, int pow_bits, size_t
     s.TAGSPAN = s.NT + s.Q * (s.WB + 1); s.TREES = s.R + 2;
     if (lg((size_t)s.NP * s.p2_rows) > P2R_MAX_LOG_ROWS) return fail(ZKHIP_ERR_INVALID, "shard verifier: the Poseidon2 chip would need more than 2^22 rows");
     // the transcript table has one preprocessed indicator column per (proof, sponge row that carries public values): at most 1024 preprocessed columns
-    if (29 + (size_t)s.NP * s.pub_rows.size() > 1024) return fail(ZKHIP_ERR_INVALID, "shard verifier: too many proofs x public values for the transcript table's preprocessed columns");
+    if ((s.air ? 46u : 29u) + (size_t)s.NP * s.pub_rows.size() > 1024) return fail(ZKHIP_ERR_INVALID, "shard verifier: too many proofs x public values for the transcript table's preprocessed columns");
     return ZKHIP_OK;
 }
 
@@ -246,7 +296,7 @@ void p2r_pre(const Shape& sh, int log_rows, std::vector<uint32_t>& t) {
 }
 
 // ============================================================================================================ TS
-struct TsCols { uint32_t T, ACT, NSEND, CF, CV, IND0, IP, NROOT, NTR, TREE, HASCH, NBETA, NSC, KIND, NFIN, PT, pre, W, TR, CH; };
+struct TsCols { uint32_t T, ACT, NSEND, CF, CV, IND0, IP, NROOT, NTR, TREE, HASCH, NBETA, NSC, KIND, NFIN, PT, PK, PM, Z, pre, W, TR, CH; };
 constexpr uint32_t TS_MAIN = 20;
 TsCols ts_cols(const Shape& sh) {
     TsCols c{};
@@ -254,6 +304,7 @@ TsCols ts_cols(const Shape& sh) {
     auto take = [&](uint32_t w) { const uint32_t at = n; n += w; return at; };
     c.T = take(1); c.ACT = take(1); c.NSEND = take(1); c.CF = take(8); c.CV = take(8); c.IND0 = take(1); c.IP = take((uint32_t)(sh.NP * (int)sh.pub_rows.size()));
     c.NROOT = take(1); c.NTR = take(1); c.TREE = take(1); c.HASCH = take(1); c.NBETA = take(1); c.NSC = take(1); c.KIND = take(1); c.NFIN = take(1); c.PT = take(1);
+    if (sh.air) { c.PK = take(8); c.PM = take(8); c.Z = take(1); }       // air mode: the public values go to the EVAL chip word by word (key, multiplicity per word; a zero column)
     c.pre = rup4(n);
     c.W = c.pre; c.TR = c.pre + 8; c.CH = c.pre + 16;
     return c;
@@ -266,12 +317,13 @@ std::vector<uint32_t> ts_program(const Shape& sh) {
     const int npr = (int)sh.pub_rows.size();
     for (int p = 0; p < sh.NP; p++)              // the outer proof's public values: those of proof 0, then those of proof 1, ...
         for (int i = 0; i < sh.NPUB; i++) {
-            const int pos = 14 + i;
+            const int pos = sh.HL + 8 + i;
             k.add(ALL, pmul(pv(c.IP + (uint32_t)(p * npr + pub_row_index(sh, pos / 8))), padd(pv(c.W + (uint32_t)(pos % 8)), pneg(ppub((uint32_t)(p * sh.NPUB + i))))));
         }
-    k.add(ALL, pmul(pv(c.IND0), padd(pv(c.W + 6), pneg(pv(c.TR)))));
-    k.add(ALL, pmul(pv(c.IND0), padd(pv(c.W + 7), pneg(pv(c.TR + 1)))));
-    for (uint32_t j = 0; j < 6; j++) k.add(TRANSITION, pmul(pv(c.IND0), padd(pv(c.W + j, true), pneg(pv(c.TR + 2 + j)))));
+    // the trace root sits behind the header: words HL .. HL + 7 of the transcript = the rest of row HL / 8 and the start of the next one
+    const uint32_t o = (uint32_t)(sh.HL % 8);
+    for (uint32_t j = 0; j < 8 - o; j++) k.add(ALL, pmul(pv(c.IND0), padd(pv(c.W + o + j), pneg(pv(c.TR + j)))));
+    for (uint32_t j = 0; j < o; j++) k.add(TRANSITION, pmul(pv(c.IND0), padd(pv(c.W + j, true), pneg(pv(c.TR + 8 - o + j)))));
     return k.program(c.pre + TS_MAIN, sh.npub_total());
 }
 std::vector<uint32_t> ts_table(const Shape& sh) {
@@ -284,6 +336,7 @@ std::vector<uint32_t> ts_table(const Shape& sh) {
     t.add5(RECV, c.NROOT, BUS_R0, c.TREE, c.W); t.add5(RECV, c.NROOT, BUS_R1, c.TREE, c.W + 4);
     t.add5(RECV, c.NTR, BUS_R0, c.TREE, c.TR); t.add5(RECV, c.NTR, BUS_R1, c.TREE, c.TR + 4);
     t.add5(RECV, c.NFIN, BUS_FIN, c.PT, c.W);
+    if (sh.air) for (uint32_t j = 0; j < 8; j++) t.add(SEND, c.PM + j, BUS_VAL, {c.PK + j, c.W + j, c.Z, c.Z, c.Z});
     return t.w;
 }
 void ts_pre(const Shape& sh, int log_rows, std::vector<uint32_t>& t) {
@@ -295,10 +348,15 @@ void ts_pre(const Shape& sh, int log_rows, std::vector<uint32_t>& t) {
         uint32_t* r = t.data() + (size_t)c.pre * ((size_t)p * (size_t)sh.NTS + (size_t)T);
         const uint32_t tree0 = (uint32_t)(p * sh.TREES);
         r[c.T] = sh.ttag(p, T); r[c.ACT] = 1; r[c.NSEND] = (sh.TO0 <= T && T <= sh.TF) ? 2u : 1u;
-        for (int j = 0; j < 8; j++) if (8 * T + j < 6) { r[c.CF + j] = 1; r[c.CV + j] = sh.head[8 * T + j]; }
+        for (int j = 0; j < 8; j++) if (8 * T + j < sh.HL) { r[c.CF + j] = 1; r[c.CV + j] = sh.head[8 * T + j]; }
         const int pi = pub_row_index(sh, T);
         if (pi >= 0) r[c.IP + (uint32_t)(p * npr + pi)] = 1;
-        if (T == 0) { r[c.IND0] = 1; r[c.NTR] = (uint32_t)sh.Q; r[c.TREE] = tree0 + (uint32_t)sh.R; }
+        if (sh.air)
+            for (int j = 0; j < 8; j++) {
+                const int i = 8 * T + j - (sh.HL + 8);
+                if (i >= 0 && i < sh.NPUB) { r[c.PK + j] = (uint32_t)p * sh.KSPAN + sh.key_pub((uint32_t)i); r[c.PM + j] = sh.mult[sh.key_pub((uint32_t)i)]; }
+            }
+        if (T == sh.HL / 8) { r[c.IND0] = 1; r[c.NTR] = (uint32_t)sh.Q; r[c.TREE] = tree0 + (uint32_t)sh.R; }
         if (T == sh.TQ) { r[c.NROOT] = (uint32_t)sh.Q; r[c.TREE] = tree0 + (uint32_t)sh.R + 1u; }
         if (sh.TL0 <= T && T < sh.TP) { r[c.NROOT] = (uint32_t)sh.Q; r[c.TREE] = tree0 + (uint32_t)(T - sh.TL0); r[c.NBETA] = (uint32_t)sh.Q; }
         const int kinds[3] = {sh.TA, sh.TQ, sh.TF};
@@ -418,9 +476,13 @@ enum OpCol : uint32_t { O_A, O_B, O_C, O_D, O_AN, O_BN, O_CN, O_DN, O_FA, O_FA4,
                         O_YLIN, O_YLO, O_YNIN, O_YNO, O_A2, O_AB, O_ACCIN, O_U1, O_U2, O_ACCO, O_COUNT };
 constexpr uint32_t oc(uint32_t name) { return OP_PRE + 4u * name; }
 constexpr uint32_t OP_MAIN = 4u * O_COUNT;
+// air mode: eight (key, multiplicity) pairs more -- the row's eight opened values go to the EVAL chip's factor slots
+constexpr uint32_t OP_PRE_AIR = 28, OP_KEY0 = 12, OP_MUL0 = 20;
+inline uint32_t op_pre(const Shape& sh) { return sh.air ? OP_PRE_AIR : OP_PRE; }
 std::vector<uint32_t> opened_program(const Shape& sh) {
     Cons c;
-    auto e = [&](uint32_t name, bool nxt = false) { return ev(oc(name), nxt); };
+    const uint32_t B0 = op_pre(sh);
+    auto e = [&](uint32_t name, bool nxt = false) { return ev(B0 + 4u * name, nxt); };
     const uint32_t consts[5] = {O_FA, O_FA4, O_ALPHA, O_SELT, O_SELF};
     const Poly first = pv(OP_FIRST), nf = pv(OP_NOTFIRST, true);
     for (uint32_t nm : consts) c.ext(TRANSITION, egate(nf, esub(e(nm, true), e(nm))));
@@ -440,6 +502,7 @@ std::vector<uint32_t> opened_program(const Shape& sh) {
         c.ext(ALL, esub(e(y[1]), eadd(e(y[0]), emul(e(O_PW), e(y[2])))));
         c.ext(TRANSITION, egate(nf, esub(e(y[0], true), e(y[1]))));
     }
+    if (sh.air) return c.program(B0 + OP_MAIN, sh.npub_total());       // (the AIR's fold is the EVAL chip's: the columns behind O_YNO stay zero)
     c.ext(ALL, esub(e(O_A2), emul(e(O_A), e(O_A))));
     c.ext(ALL, esub(e(O_AB), emul(e(O_A), e(O_B))));
     const EE al = e(O_ALPHA);
@@ -450,20 +513,31 @@ std::vector<uint32_t> opened_program(const Shape& sh) {
     c.ext(TRANSITION, egate(nf, esub(e(O_ACCIN, true), e(O_ACCO))));
     return c.program(OP_PRE + OP_MAIN, sh.npub_total());
 }
-std::vector<uint32_t> opened_table() {
+std::vector<uint32_t> opened_table(const Shape& sh) {
     Tab t;
+    const uint32_t B0 = op_pre(sh);
+    auto oc_ = [&](uint32_t name) { return B0 + 4u * name; };
     const uint32_t tags[4] = {OP_TL0, OP_TL1, OP_TN0, OP_TN1}, lo[4] = {O_A, O_C, O_AN, O_CN}, hi[4] = {O_B, O_D, O_BN, O_DN};
-    for (int i = 0; i < 4; i++) { t.add5(RECV, OP_ACT, BUS_IN0, tags[i], oc(lo[i])); t.add5(RECV, OP_ACT, BUS_IN1, tags[i], oc(hi[i])); }
-    t.add5(SEND, OP_LASTG, BUS_OY, OP_PID, oc(O_YLO)); t.add5(SEND, OP_LASTG, BUS_OY + 1, OP_PID, oc(O_YNO)); t.add5(SEND, OP_LASTG, BUS_OA, OP_PID, oc(O_ACCO));
+    for (int i = 0; i < 4; i++) { t.add5(RECV, OP_ACT, BUS_IN0, tags[i], oc_(lo[i])); t.add5(RECV, OP_ACT, BUS_IN1, tags[i], oc_(hi[i])); }
+    t.add5(SEND, OP_LASTG, BUS_OY, OP_PID, oc_(O_YLO)); t.add5(SEND, OP_LASTG, BUS_OY + 1, OP_PID, oc_(O_YNO));
+    if (!sh.air) t.add5(SEND, OP_LASTG, BUS_OA, OP_PID, oc_(O_ACCO));
     const uint32_t consts[5] = {O_FA, O_FA4, O_ALPHA, O_SELT, O_SELF};
-    for (uint32_t i = 0; i < 5; i++) t.add5(RECV, OP_FIRST, BUS_KO0 + i, OP_PID, oc(consts[i]));
+    for (uint32_t i = 0; i < 5; i++) t.add5(RECV, OP_FIRST, BUS_KO0 + i, OP_PID, oc_(consts[i]));
+    if (sh.air) for (uint32_t i = 0; i < 8; i++) t.add5(SEND, OP_MUL0 + i, BUS_VAL, OP_KEY0 + i, oc_(O_A + i));      // O_A .. O_D at zeta, O_AN .. O_DN at zeta g
     return t.w;
 }
 void opened_pre(const Shape& sh, int log_rows, std::vector<uint32_t>& t) {
-    t.assign((size_t)OP_PRE << log_rows, 0u);
+    const uint32_t PW = op_pre(sh);
+    t.assign((size_t)PW << log_rows, 0u);
     for (int p = 0; p < sh.NP; p++)
         for (int g = 0; g < sh.G; g++) {
-            uint32_t* r = t.data() + OP_PRE * ((size_t)p * (size_t)sh.G + (size_t)g);
+            uint32_t* r = t.data() + PW * ((size_t)p * (size_t)sh.G + (size_t)g);
+            if (sh.air)
+                for (uint32_t i = 0; i < 4; i++) {
+                    const uint32_t kl = sh.key_local(4u * (uint32_t)g + i), kn = sh.key_next(4u * (uint32_t)g + i);
+                    r[OP_KEY0 + i] = (uint32_t)p * sh.KSPAN + kl; r[OP_MUL0 + i] = sh.mult[kl];
+                    r[OP_KEY0 + 4 + i] = (uint32_t)p * sh.KSPAN + kn; r[OP_MUL0 + 4 + i] = sh.mult[kn];
+                }
             r[OP_ACT] = 1; r[OP_NOTFIRST] = g ? 1u : 0u; r[OP_PID] = (uint32_t)p;
             r[OP_K1] = (uint32_t)g + 1u; r[OP_K2] = 2u * (uint32_t)g + 3u; r[OP_K3] = 5u * (uint32_t)g + 7u;
             r[OP_TL0] = sh.ttag(p, sh.TO0 + 2 * g); r[OP_TL1] = sh.ttag(p, sh.TO0 + 2 * g + 1);
@@ -476,8 +550,11 @@ void opened_pre(const Shape& sh, int log_rows, std::vector<uint32_t>& t) {
 
 // ============================================================================================================ SCALARS
 constexpr uint32_t SC_PRE = 12, SP_FIRST = 0, SP_KA = 1, SP_KZ = 2, SP_KF = 3, SP_TQZ = 4, SP_PID = 8;
+// air mode: the three selectors and the constant one go to the EVAL chip (keys, multiplicities, a zero column)
+constexpr uint32_t SC_PRE_AIR = 20, SP_KSEL = 9, SP_KONE = 12, SP_MSEL = 13, SP_MONE = 16, SP_Z = 17;
+inline uint32_t sc_pre(const Shape& sh) { return sh.air ? SC_PRE_AIR : SC_PRE; }
 struct ScCols {
-    uint32_t ALPHA, ZETA, FA, ZP1, INVF, SELF, SELT, ZNX, FP1, PR1, OFFN, OFFQ, QZ0, HQ0, QK0, QK1, QUO, YL, YN, ACC, end;
+    uint32_t ALPHA, ZETA, FA, ZP1, INVF, SELF, SELT, ZNX, FP1, PR1, OFFN, OFFQ, QZ0, HQ0, QK0, QK1, QUO, YL, YN, ACC, INVT, SELL, end;
     int mb, nbits; int bits[12];
     uint32_t zp(int i) const { return ZP1 + 4u * (uint32_t)(i - 1); }       // ZP_i = zeta^(2^i), i = 1 .. n
     uint32_t fp(int i) const { return i == 0 ? FA : FP1 + 4u * (uint32_t)(i - 1); }
@@ -487,7 +564,7 @@ struct ScCols {
 };
 ScCols sc_cols(const Shape& sh) {
     ScCols c{};
-    uint32_t n = SC_PRE;
+    uint32_t n = sc_pre(sh);
     auto take = [&](uint32_t k = 1) { const uint32_t at = n; n += 4 * k; return at; };
     c.ALPHA = take(); c.ZETA = take(); c.FA = take();
     c.ZP1 = take((uint32_t)sh.n);
@@ -500,6 +577,7 @@ ScCols sc_cols(const Shape& sh) {
     c.OFFN = take(); c.OFFQ = take();
     c.QZ0 = take(8); c.HQ0 = take(7);
     c.QK0 = take(); c.QK1 = take(); c.QUO = take(); c.YL = take(); c.YN = take(); c.ACC = take();
+    if (sh.air) { c.INVT = take(); c.SELL = take(); }      // the last-row selector Z_H(zeta) / (zeta - w^-1): a program may use it
     c.end = n;
     return c;
 }
@@ -550,7 +628,11 @@ std::vector<uint32_t> scalars_program(const Shape& sh) {
     const EE z0 = eadd(escale(znn, za[0]), ec(zb[0])), z1 = eadd(escale(znn, za[1]), ec(zb[1]));
     c.ext(ALL, esub(ev(m.QUO), eadd(emul(z0, ev(m.QK0)), emul(z1, ev(m.QK1)))));
     c.ext(ALL, esub(ev(m.ACC), emul(ev(m.QUO), esub(znn, ec(1)))));
-    return c.program(SC_PRE + rup4(m.end - SC_PRE), sh.npub_total());
+    if (sh.air) {
+        c.ext(ALL, esub(emul(ev(m.SELT), ev(m.INVT)), ec(1)));
+        c.ext(ALL, esub(ev(m.SELL), emul(esub(znn, ec(1)), ev(m.INVT))));
+    }
+    return c.program(sc_pre(sh) + rup4(m.end - sc_pre(sh)), sh.npub_total());
 }
 std::vector<uint32_t> scalars_table(const Shape& sh) {
     const ScCols m = sc_cols(sh);
@@ -563,12 +645,23 @@ std::vector<uint32_t> scalars_table(const Shape& sh) {
     t.add5(SEND, SP_FIRST, BUS_KFA, SP_PID, m.FA);
     const uint32_t ok[5] = {m.FA, m.fp(2), m.ALPHA, m.SELT, m.SELF};
     for (uint32_t i = 0; i < 5; i++) t.add5(SEND, SP_FIRST, BUS_KO0 + i, SP_PID, ok[i]);
+    if (sh.air) {
+        const uint32_t sels[3] = {m.SELF, m.SELL, m.SELT};
+        for (uint32_t i = 0; i < 3; i++) t.add5(SEND, SP_MSEL + i, BUS_VAL, SP_KSEL + i, sels[i]);
+        t.add(SEND, SP_MONE, BUS_VAL, {SP_KONE, SP_FIRST, SP_Z, SP_Z, SP_Z});          // (key of one, (1, 0, 0, 0)): SP_FIRST is 1 on the proof's row
+        t.add5(SEND, SP_FIRST, BUS_EA, SP_PID, m.ALPHA);
+    }
     return t.w;
 }
 void scalars_pre(const Shape& sh, int log_rows, std::vector<uint32_t>& t) {
-    t.assign((size_t)SC_PRE << log_rows, 0u);
+    const uint32_t PW = sc_pre(sh);
+    t.assign((size_t)PW << log_rows, 0u);
     for (int p = 0; p < sh.NP; p++) {
-        uint32_t* row = t.data() + SC_PRE * (size_t)p;
+        uint32_t* row = t.data() + PW * (size_t)p;
+        if (sh.air) {
+            for (uint32_t i = 0; i < 3; i++) { row[SP_KSEL + i] = (uint32_t)p * sh.KSPAN + sh.key_sel(i); row[SP_MSEL + i] = sh.mult[sh.key_sel(i)]; }
+            row[SP_KONE] = (uint32_t)p * sh.KSPAN; row[SP_MONE] = sh.mult[0];
+        }
         row[SP_FIRST] = 1; row[SP_PID] = (uint32_t)p;
         row[SP_KA] = 3u * (uint32_t)p; row[SP_KZ] = 3u * (uint32_t)p + 1u; row[SP_KF] = 3u * (uint32_t)p + 2u;
         for (int i = 0; i < 4; i++) row[SP_TQZ + i] = sh.ttag(p, sh.TO0 + sh.W + i);
@@ -576,16 +669,60 @@ void scalars_pre(const Shape& sh, int log_rows, std::vector<uint32_t>& t) {
     monty_all(t);
 }
 
+// ============================================================================================================ EVAL (air mode)
+// One row per TERM of the inner program: coeff x F1 x F2 x F3 with the three factor VALUES received over BUS_VAL by their (preprocessed)
+// keys -- an opened value at zeta or zeta g from OPENED, a public value from TS, a selector or the constant one from SCALARS -- and the
+// fold of the constraints with alpha as a running sum: where a constraint's first term stands, ACC is multiplied by alpha first.
+// Everything that depends on the program is preprocessed: the key of a shape AND a program.
+constexpr uint32_t EV_PRE = 12, EP_COEF = 0, EP_K0 = 1, EP_FIRSTC = 4, EP_ACT = 5, EP_LAST = 6, EP_PID = 7, EP_NFC = 8, EP_PFIRST = 9;
+constexpr uint32_t EV_F0 = 0, EV_M = 12, EV_TV = 16, EV_ACCIN = 20, EV_ACCO = 24, EV_ALPHA = 28, EV_MAIN = 32;
+std::vector<uint32_t> eval_program(const Shape& sh) {
+    const uint32_t M0 = EV_PRE;
+    Cons c;
+    const EE f0 = ev(M0 + EV_F0), f1 = ev(M0 + EV_F0 + 4), f2 = ev(M0 + EV_F0 + 8), mm = ev(M0 + EV_M), tv = ev(M0 + EV_TV), ai = ev(M0 + EV_ACCIN), ao = ev(M0 + EV_ACCO), al = ev(M0 + EV_ALPHA);
+    c.ext(ALL, esub(mm, emul(f0, f1)));
+    c.ext(ALL, esub(tv, egate(pv(EP_COEF), emul(mm, f2))));
+    // ACCO = ACCIN (1 + FIRSTC (alpha - 1)) + TV
+    c.ext(ALL, esub(ao, eadd(ai, egate(pv(EP_FIRSTC), esub(emul(ai, al), ai)), tv)));
+    c.ext(TRANSITION, egate(pv(EP_NFC, true), esub(ev(M0 + EV_ACCIN, true), ao)));
+    c.ext(ALL, egate(pv(EP_PFIRST), ai));
+    c.ext(TRANSITION, egate(pv(EP_NFC, true), esub(ev(M0 + EV_ALPHA, true), al)));
+    return c.program(EV_PRE + EV_MAIN, sh.npub_total());
+}
+std::vector<uint32_t> eval_table() {
+    const uint32_t M0 = EV_PRE;
+    Tab t;
+    for (uint32_t j = 0; j < 3; j++) t.add5(RECV, EP_ACT, BUS_VAL, EP_K0 + j, M0 + EV_F0 + 4u * j);
+    t.add5(RECV, EP_PFIRST, BUS_EA, EP_PID, M0 + EV_ALPHA);
+    t.add5(SEND, EP_LAST, BUS_OA, EP_PID, M0 + EV_ACCO);
+    return t.w;
+}
+void eval_pre(const Shape& sh, int log_rows, std::vector<uint32_t>& t) {
+    t.assign((size_t)EV_PRE << log_rows, 0u);
+    const size_t nt = sh.terms.size();
+    for (int p = 0; p < sh.NP; p++)
+        for (size_t i = 0; i < nt; i++) {
+            uint32_t* r = t.data() + (size_t)EV_PRE * ((size_t)p * nt + i);
+            const Shape::ETerm& e = sh.terms[i];
+            r[EP_COEF] = e.coeff;
+            for (int j = 0; j < 3; j++) r[EP_K0 + j] = (uint32_t)p * sh.KSPAN + e.key[j];
+            r[EP_FIRSTC] = e.first; r[EP_ACT] = 1; r[EP_LAST] = i + 1 == nt ? 1u : 0u; r[EP_PID] = (uint32_t)p;
+            r[EP_NFC] = i ? 1u : 0u; r[EP_PFIRST] = i ? 0u : 1u;
+        }
+    monty_all(t);
+}
+
 // ============================================================================================================ the machine
-enum Chip : int { C_P2R, C_ROWSUM, C_FOLD, C_TS, C_QUERY, C_OPENED, C_SAMPLES, C_SCALARS, N_CHIPS };
+enum Chip : int { C_P2R, C_ROWSUM, C_FOLD, C_TS, C_QUERY, C_OPENED, C_SAMPLES, C_SCALARS, C_EVAL, N_CHIPS };      // (C_EVAL: air mode only)
 struct Machine {
     Shape sh;
+    int n = N_CHIPS - 1;                        // chips of this machine: eight, nine in air mode
     int order[N_CHIPS];                         // position -> chip, tallest first (equal heights in the order of the enum)
     int32_t log_ns[N_CHIPS]; uint32_t widths[N_CHIPS], pre_widths[N_CHIPS];
     std::vector<uint32_t> prog[N_CHIPS], tab[N_CHIPS];     // by position
     const uint32_t* progs[N_CHIPS]; size_t prog_words[N_CHIPS]; const uint32_t* tabs[N_CHIPS]; size_t tab_words[N_CHIPS];
     int height[N_CHIPS];                        // by chip
-    int pos_of(int chip) const { for (int i = 0; i < N_CHIPS; i++) if (order[i] == chip) return i; return -1; }
+    int pos_of(int chip) const { for (int i = 0; i < n; i++) if (order[i] == chip) return i; return -1; }
 };
 std::vector<uint32_t> samples_table_words() { return frichip::samples_interactions(); }
 std::vector<uint32_t> fold_table(const Shape& sh) {
@@ -601,22 +738,24 @@ std::vector<uint32_t> fold_table(const Shape& sh) {
 std::shared_ptr<const Machine> machine_of(const Shape& sh) {
     static std::mutex mu;
     static std::map<std::vector<uint64_t>, std::shared_ptr<const Machine>> cache;
-    const std::vector<uint64_t> key{(uint64_t)sh.n, (uint64_t)sh.W, (uint64_t)sh.Q, (uint64_t)sh.PB, (uint64_t)sh.NPUB, (uint64_t)sh.NP, g_p2_generation.load()};
+    std::vector<uint64_t> key{(uint64_t)sh.n, (uint64_t)sh.W, (uint64_t)sh.Q, (uint64_t)sh.PB, (uint64_t)sh.NPUB, (uint64_t)sh.NP, g_p2_generation.load()};
+    key.insert(key.end(), sh.prog_id.begin(), sh.prog_id.end());       // (air mode: the inner program's digest)
     std::lock_guard<std::mutex> lk(mu);
     auto it = cache.find(key);
     if (it != cache.end()) return it->second;
     auto m = std::make_shared<Machine>();
     m->sh = sh;
     const size_t np = (size_t)sh.NP;
+    m->n = sh.air ? N_CHIPS : N_CHIPS - 1;
     const int h[N_CHIPS] = {lg(np * sh.p2_rows), lg(np * (size_t)sh.Q * (size_t)(sh.WB + 1)), lg(np * (size_t)sh.Q * (size_t)sh.R), lg(np * (size_t)sh.NTS), lg(np * (size_t)sh.Q),
-                            lg(np * (size_t)sh.G), lg(np * (size_t)sh.NS), lg(np)};
+                            lg(np * (size_t)sh.G), lg(np * (size_t)sh.NS), lg(np), lg(np * (sh.air ? sh.terms.size() : (size_t)1))};
     for (int c = 0; c < N_CHIPS; c++) { m->height[c] = h[c]; m->order[c] = c; }
-    std::stable_sort(m->order, m->order + N_CHIPS, [&](int a, int b) { return h[a] > h[b]; });
+    std::stable_sort(m->order, m->order + m->n, [&](int a, int b) { return h[a] > h[b]; });
     const ScCols scc = sc_cols(sh);
     const TsCols tsc = ts_cols(sh);
-    const uint32_t w_main[N_CHIPS] = {P2_MAIN, RS_MAIN, frichip::width_of(sh.R, true, true), TS_MAIN, Q_MAIN, OP_MAIN, frichip::S_MAIN, rup4(scc.end - SC_PRE)};
-    const uint32_t w_pre[N_CHIPS] = {P2_PRE, RS_PRE, 0u, tsc.pre, Q_PRE, OP_PRE, frichip::S_PRE, SC_PRE};
-    for (int i = 0; i < N_CHIPS; i++) {
+    const uint32_t w_main[N_CHIPS] = {P2_MAIN, RS_MAIN, frichip::width_of(sh.R, true, true), TS_MAIN, Q_MAIN, OP_MAIN, frichip::S_MAIN, rup4(scc.end - sc_pre(sh)), EV_MAIN};
+    const uint32_t w_pre[N_CHIPS] = {P2_PRE, RS_PRE, 0u, tsc.pre, Q_PRE, op_pre(sh), frichip::S_PRE, sc_pre(sh), EV_PRE};
+    for (int i = 0; i < m->n; i++) {
         const int c = m->order[i];
         switch (c) {
             case C_P2R: m->prog[i] = p2r_program(sh); m->tab[i] = p2r_table(); break;
@@ -624,13 +763,14 @@ std::shared_ptr<const Machine> machine_of(const Shape& sh) {
             case C_FOLD: m->prog[i] = *frichip::program(sh.R, true, true, (int)sh.npub_total()); m->tab[i] = fold_table(sh); break;
             case C_TS: m->prog[i] = ts_program(sh); m->tab[i] = ts_table(sh); break;
             case C_QUERY: m->prog[i] = query_program(sh); m->tab[i] = query_table(); break;
-            case C_OPENED: m->prog[i] = opened_program(sh); m->tab[i] = opened_table(); break;
+            case C_OPENED: m->prog[i] = opened_program(sh); m->tab[i] = opened_table(sh); break;
+            case C_EVAL: m->prog[i] = eval_program(sh); m->tab[i] = eval_table(); break;
             case C_SAMPLES: m->prog[i] = *frichip::samples_program(sh.R, sh.PB, sh.npub_total()); m->tab[i] = samples_table_words(); break;
             default: m->prog[i] = scalars_program(sh); m->tab[i] = scalars_table(sh); break;
         }
         m->log_ns[i] = h[c]; m->widths[i] = w_main[c]; m->pre_widths[i] = w_pre[c];
     }
-    for (int i = 0; i < N_CHIPS; i++) { m->progs[i] = m->prog[i].data(); m->prog_words[i] = m->prog[i].size(); m->tabs[i] = m->tab[i].data(); m->tab_words[i] = m->tab[i].size(); }
+    for (int i = 0; i < m->n; i++) { m->progs[i] = m->prog[i].data(); m->prog_words[i] = m->prog[i].size(); m->tabs[i] = m->tab[i].data(); m->tab_words[i] = m->tab[i].size(); }
     if (cache.size() > 16) cache.clear();
     cache.emplace(key, m);
     return m;
@@ -648,6 +788,13 @@ void samples_pre_all(const Shape& sh, int log_rows, std::vector<uint32_t>& t) {
         }
         std::memcpy(t.data() + (size_t)frichip::S_PRE * (size_t)p * (size_t)sh.NS, one.data(), (size_t)frichip::S_PRE * (size_t)sh.NS * 4);
     }
+}
+// every chip's preprocessed trace, by chip
+void all_pre(const Shape& sh, const Machine& m, std::vector<uint32_t> pre[N_CHIPS]) {
+    p2r_pre(sh, m.height[C_P2R], pre[C_P2R]); rowsum_pre(sh, m.height[C_ROWSUM], pre[C_ROWSUM]); ts_pre(sh, m.height[C_TS], pre[C_TS]);
+    query_pre(sh, m.height[C_QUERY], pre[C_QUERY]); opened_pre(sh, m.height[C_OPENED], pre[C_OPENED]); scalars_pre(sh, m.height[C_SCALARS], pre[C_SCALARS]);
+    samples_pre_all(sh, m.height[C_SAMPLES], pre[C_SAMPLES]);
+    if (sh.air) eval_pre(sh, m.height[C_EVAL], pre[C_EVAL]);
 }
 // ---- the witness: everything the main columns hold, read off the inner proof (which the host verifier has accepted)
 struct Witness {
@@ -677,14 +824,14 @@ struct HostSpan {                                           // a slice of the co
     uint32_t& operator[](size_t i) const { return p[i]; }
 };
 struct HostTables {
-    std::vector<uint32_t> sc, op, rs, q, ts, sm;            // SCALARS, OPENED, ROWSUM, QUERY, TS, SAMPLES main traces (all proofs)
+    std::vector<uint32_t> sc, op, rs, q, ts, sm, evl;       // SCALARS, OPENED, ROWSUM, QUERY, TS, SAMPLES (and, air mode, EVAL) main traces (all proofs)
     HostSpan desc, data, chain_in, trows;                   // P2R: chains, their data, the transcript rows' input states and row numbers -- consecutive slices of ONE pinned block
                                                             // (every word is written by fill_one: nothing is cleared)
     std::vector<const uint32_t*> want_roots;                // per chain: where it must end (canonical words; owned by the witnesses)
     // (desc / data / chain_in / trows / want_roots hold a fixed slice per proof)
 };
 int fill_one(const Shape& sh, const Machine& m, int p, const uint8_t* inner, size_t inner_len, const uint32_t* public_values, const zkhip_params* inner_prm, Witness& wt,
-             std::vector<uint32_t>& words, HostTables& ht, Ext* fa_out) {
+             std::vector<uint32_t>& words, HostTables& ht, Ext* fa_out, const uint32_t* program, size_t program_words) {
     const int R = sh.R, H = sh.H, Q = sh.Q, W = sh.W;
     const int log_n = sh.n;
     const uint32_t width = (uint32_t)W;
@@ -694,11 +841,12 @@ int fill_one(const Shape& sh, const Machine& m, int p, const uint8_t* inner, siz
     wt.paths.resize(zkhip_fri_view_path_words(R) * (size_t)Q);
     // (the Merkle paths are not hashed here: the P2R rows kernel hashes every one of them for the trace, and the roots it arrives at are compared below)
     ZK_TRY(fri_view_all_unhashed(inner, inner_len, log_n, width, public_values, n_public, inner_prm, wt.betas.data(), wt.fin, wt.indices.data(), wt.values.data(),
-                                 wt.siblings.data(), wt.lroots.data(), wt.paths.data(), wt.tr));
+                                 wt.siblings.data(), wt.lroots.data(), wt.paths.data(), wt.tr, program, program_words));
     words.resize(inner_len / 4);
     std::memcpy(words.data(), inner, words.size() * 4);
     wt.w = words.data();
-    wt.o_troot = 8; wt.o_qroot = 16; wt.o_loc = 24; wt.o_nxt = wt.o_loc + 4 * (size_t)W; wt.o_qz = wt.o_nxt + 4 * (size_t)W; wt.o_lroots = wt.o_qz + 32;
+    wt.o_troot = sh.air ? 20 : 8;                       // a version-7 header: 12 shape words and the program's digest in front of the trace root
+    wt.o_qroot = wt.o_troot + 8; wt.o_loc = wt.o_qroot + 8; wt.o_nxt = wt.o_loc + 4 * (size_t)W; wt.o_qz = wt.o_nxt + 4 * (size_t)W; wt.o_lroots = wt.o_qz + 32;
     wt.o_final = wt.o_lroots + 8 * (size_t)R; wt.o_wit = wt.o_final + 4; wt.o_queries = wt.o_wit + 1;
     wt.per_query = (size_t)W + 8 * (size_t)H + 8 + 8 * (size_t)H;
     for (int l = 0; l < R; l++) wt.per_query += 4 + 8 * (size_t)(H - 1 - l);
@@ -709,7 +857,7 @@ int fill_one(const Shape& sh, const Machine& m, int p, const uint8_t* inner, siz
     std::vector<Ext> chal((size_t)sh.NT);
     {
         std::vector<std::array<uint32_t, 8>> blocks((size_t)sh.NTS);      // observed words per absorbing row (canonical; absent ones zero)
-        std::vector<uint32_t> seq0(sh.head, sh.head + 6);
+        std::vector<uint32_t> seq0(sh.head, sh.head + sh.HL);
         seq0.insert(seq0.end(), pw + wt.o_troot, pw + wt.o_troot + 8);
         for (size_t i = 0; i < n_public; i++) seq0.push_back(public_values[i] % P);
         for (auto& b : blocks) b.fill(0u);
@@ -735,15 +883,17 @@ int fill_one(const Shape& sh, const Machine& m, int p, const uint8_t* inner, siz
     *fa_out = fa;
     // (c) the scalars: row p of SCALARS
     const ScCols scc = sc_cols(sh);
-    const uint32_t sc_w = rup4(scc.end - SC_PRE);
+    const uint32_t scp = sc_pre(sh), sc_w = rup4(scc.end - scp);
     uint32_t* sc_row = ht.sc.data() + (size_t)sc_w * (size_t)p;
-    auto scput = [&](uint32_t col, const Ext& e) { put_ext(sc_row, col - SC_PRE, e); };
+    auto scput = [&](uint32_t col, const Ext& e) { put_ext(sc_row, col - scp, e); };
     Ext znn = zeta;
     scput(scc.ALPHA, alpha); scput(scc.ZETA, zeta); scput(scc.FA, fa);
     for (int i = 1; i <= sh.n; i++) { znn = ext_mul(znn, znn); scput(scc.zp(i), znn); }
     const uint32_t wn = two_adic_generator(sh.n), wni = finv(wn);
     const Ext invf = ext_inv(ext_sub_base(zeta, MONTY_R1)), self_ = ext_mul(ext_sub_base(znn, MONTY_R1), invf), selt = ext_sub_base(zeta, wni), znx = ext_mul_base(zeta, wn);
     scput(scc.INVF, invf); scput(scc.SELF, self_); scput(scc.SELT, selt); scput(scc.ZNX, znx);
+    const Ext invt = sh.air ? ext_inv(selt) : ext_zero(), sell = sh.air ? ext_mul(ext_sub_base(znn, MONTY_R1), invt) : ext_zero();
+    if (sh.air) { scput(scc.INVT, invt); scput(scc.SELL, sell); }
     std::vector<Ext> fp{fa};
     for (int i = 1; i <= scc.mb; i++) { fp.push_back(ext_mul(fp.back(), fp.back())); scput(scc.fp(i), fp.back()); }
     Ext offn = fp[(size_t)scc.bits[0]];
@@ -800,14 +950,42 @@ int fill_one(const Shape& sh, const Machine& m, int p, const uint8_t* inner, siz
         put(O_YLIN, yl); put(O_YNIN, yn);
         yl = ext_add(yl, ext_mul(pwr, il[0])); yn = ext_add(yn, ext_mul(pwr, il[1]));
         put(O_YLO, yl); put(O_YNO, yn);
-        const Ext a2 = ext_mul(v[0], v[0]), ab = ext_mul(v[0], v[1]);
-        put(O_A2, a2); put(O_AB, ab); put(O_ACCIN, acc);
-        const Ext u1 = ext_add(ext_mul(acc, alpha), ext_sub_base(ext_sub(v[2], ext_mul(a2, v[1])), k1));
-        const Ext u2 = ext_add(ext_mul(u1, alpha), ext_mul(selt, ext_sub_base(ext_sub(ext_sub(v[7], ab), v[2]), k2)));
-        acc = ext_add(ext_mul(u2, alpha), ext_mul(self_, ext_sub_base(v[3], k3)));
-        put(O_U1, u1); put(O_U2, u2); put(O_ACCO, acc);
+        if (!sh.air) {
+            const Ext a2 = ext_mul(v[0], v[0]), ab = ext_mul(v[0], v[1]);
+            put(O_A2, a2); put(O_AB, ab); put(O_ACCIN, acc);
+            const Ext u1 = ext_add(ext_mul(acc, alpha), ext_sub_base(ext_sub(v[2], ext_mul(a2, v[1])), k1));
+            const Ext u2 = ext_add(ext_mul(u1, alpha), ext_mul(selt, ext_sub_base(ext_sub(ext_sub(v[7], ab), v[2]), k2)));
+            acc = ext_add(ext_mul(u2, alpha), ext_mul(self_, ext_sub_base(v[3], k3)));
+            put(O_U1, u1); put(O_U2, u2); put(O_ACCO, acc);
+        }
         pwr = pwn;
         if (g + 1 == (size_t)sh.G) { res_yl = yl; res_yn = yn; res_acc = acc; }
+    }
+    if (sh.air) {
+        // EVAL: the program's terms at zeta, one row each; the fold with alpha runs down the rows.  The rows behind the last proof stay zero
+        // (no receive, coefficient 0: the running sum passes through them unread).
+        const size_t nt = sh.terms.size();
+        auto value_of = [&](uint32_t key) -> Ext {
+            if (key == 0) return ext_one();
+            const uint32_t W2 = 2u * (uint32_t)W;
+            if (key <= (uint32_t)W) return ext_canon(pw + wt.o_loc + 4 * (size_t)(key - 1u));
+            if (key <= W2) return ext_canon(pw + wt.o_nxt + 4 * (size_t)(key - 1u - (uint32_t)W));
+            if (key <= W2 + (uint32_t)sh.NPUB) return ext_from_base(to_monty(public_values[key - 1u - W2] % P));
+            const uint32_t which = key - 1u - W2 - (uint32_t)sh.NPUB;
+            return which == 0 ? self_ : (which == 1 ? sell : selt);
+        };
+        Ext run = ext_zero();
+        for (size_t i = 0; i < nt; i++) {
+            uint32_t* r = ht.evl.data() + (size_t)EV_MAIN * ((size_t)p * nt + i);
+            const Shape::ETerm& e = sh.terms[i];
+            const Ext f0 = value_of(e.key[0]), f1 = value_of(e.key[1]), f2 = value_of(e.key[2]);
+            const Ext mm = ext_mul(f0, f1), tv = ext_mul_base(ext_mul(mm, f2), to_monty(e.coeff));
+            put_ext(r, EV_F0, f0); put_ext(r, EV_F0 + 4, f1); put_ext(r, EV_F0 + 8, f2); put_ext(r, EV_M, mm); put_ext(r, EV_TV, tv);
+            put_ext(r, EV_ACCIN, run);
+            run = ext_add(e.first ? ext_mul(run, alpha) : run, tv);
+            put_ext(r, EV_ACCO, run); put_ext(r, EV_ALPHA, alpha);
+        }
+        res_acc = run;
     }
     scput(scc.YL, res_yl); scput(scc.YN, res_yn); scput(scc.ACC, res_acc);
     if (!ext_eq(res_acc, ext_mul(quo, ext_sub_base(znn, MONTY_R1)))) return fail(ZKHIP_ERR_INTERNAL, "prove_shard_verifier: the AIR identity at zeta does not hold");
@@ -862,7 +1040,7 @@ int fill_one(const Shape& sh, const Machine& m, int p, const uint8_t* inner, siz
         uint32_t* row = ht.ts.data() + (size_t)TS_MAIN * ((size_t)p * (size_t)sh.NTS + (size_t)T);
         for (int j = 0; j < 8; j++) row[j] = to_monty(chain_in[16 * (size_t)T + (size_t)j]);       // the absorbed words, and whatever the kept ones are
         if (sh.has_challenge(T)) put_ext(row, 16, chal[(size_t)T]);
-        if (T == 0) for (int j = 0; j < 8; j++) row[8 + j] = to_monty(pw[wt.o_troot + j]);
+        if (T == sh.HL / 8) for (int j = 0; j < 8; j++) row[8 + j] = to_monty(pw[wt.o_troot + j]);
     }
     // (h) SAMPLES: this proof's NS rows
     {
@@ -925,7 +1103,8 @@ int fill_one(const Shape& sh, const Machine& m, int p, const uint8_t* inner, siz
 }  // namespace rec
 }  // namespace zk
 
-static int shard_verifier_prove_impl(zkhip_ctx* ctx, const zkhip_machine_key* key, const uint8_t* const* inner, const size_t* inner_len, size_t n_proofs, int log_n, uint32_t width,
+static int shard_verifier_prove_impl(zkhip_ctx* ctx, const zkhip_machine_key* key, const uint32_t* program, size_t program_words, const uint8_t* const* inner, const size_t* inner_len,
+                                     size_t n_proofs, int log_n, uint32_t width,
                                      const uint32_t* public_values, size_t n_public, const zkhip_params* inner_prm, const zkhip_params* outer,
                                      uint8_t* proof, size_t cap, size_t* len) {
     using namespace zk::rec;
@@ -935,14 +1114,14 @@ static int shard_verifier_prove_impl(zkhip_ctx* ctx, const zkhip_machine_key* ke
         inner_prm->code_width != 0)
         return fail(ZKHIP_ERR_INVALID, "prove_shard_verifier: version-1 shard proofs (SP1 shape: blowup 2, fold by 2, constant final value, no lookups)");
     Shape sh;
-    ZK_TRY(make_shape(log_n, width, (size_t)inner_prm->num_queries, inner_prm->pow_bits, n_public, n_proofs, sh));
+    ZK_TRY(make_shape(log_n, width, (size_t)inner_prm->num_queries, inner_prm->pow_bits, n_public, n_proofs, sh, program, program_words));
     ZK_TRY(check_outer(sh, outer));
     const auto mp = machine_of(sh);
     const Machine& m = *mp;
     const int R = sh.R, Q = sh.Q, NP = sh.NP;
     const ScCols scc = sc_cols(sh);
-    const uint32_t sc_w = rup4(scc.end - SC_PRE);
-    const uint32_t w_main[N_CHIPS] = {P2_MAIN, RS_MAIN, frichip::width_of(R, true, true), TS_MAIN, Q_MAIN, OP_MAIN, frichip::S_MAIN, sc_w};
+    const uint32_t sc_w = rup4(scc.end - sc_pre(sh));
+    const uint32_t w_main[N_CHIPS] = {P2_MAIN, RS_MAIN, frichip::width_of(R, true, true), TS_MAIN, Q_MAIN, OP_MAIN, frichip::S_MAIN, sc_w, EV_MAIN};
 #ifdef ZKHIP_AB_HOOKS
     static const bool timing = getenv("ZKHIP_REC_TIMING") != nullptr;
     auto t_last = std::chrono::steady_clock::now();
@@ -959,6 +1138,7 @@ static int shard_verifier_prove_impl(zkhip_ctx* ctx, const zkhip_machine_key* ke
     HostTables ht;
     ht.sc.assign((size_t)sc_w << m.height[C_SCALARS], 0u); ht.op.assign((size_t)OP_MAIN << m.height[C_OPENED], 0u); ht.rs.assign((size_t)RS_MAIN << m.height[C_ROWSUM], 0u);
     ht.q.assign((size_t)Q_MAIN << m.height[C_QUERY], 0u); ht.ts.assign((size_t)TS_MAIN << m.height[C_TS], 0u); ht.sm.assign((size_t)frichip::S_MAIN << m.height[C_SAMPLES], 0u);
+    if (sh.air) ht.evl.assign((size_t)EV_MAIN << m.height[C_EVAL], 0u);
     std::vector<Witness> wts((size_t)NP);
     std::vector<std::vector<uint32_t>> words((size_t)NP);
     std::vector<Ext> fas((size_t)NP);
@@ -982,7 +1162,7 @@ static int shard_verifier_prove_impl(zkhip_ctx* ctx, const zkhip_machine_key* ke
         std::vector<std::string> msgs((size_t)NP);
         auto one = [&](int p) {
             t_query_threads_cap = NP >= 16 ? 1 : 16 / NP;      // the proofs are filled side by side: a proof's host pass starts few threads of its own
-            rcs[(size_t)p] = fill_one(sh, m, p, inner[p], inner_len[p], public_values + (size_t)p * n_public, inner_prm, wts[(size_t)p], words[(size_t)p], ht, &fas[(size_t)p]);
+            rcs[(size_t)p] = fill_one(sh, m, p, inner[p], inner_len[p], public_values + (size_t)p * n_public, inner_prm, wts[(size_t)p], words[(size_t)p], ht, &fas[(size_t)p], program, program_words);
             if (rcs[(size_t)p] != ZKHIP_OK) msgs[(size_t)p] = zkhip_last_error();
             t_query_threads_cap = 0;
         };
@@ -998,8 +1178,8 @@ static int shard_verifier_prove_impl(zkhip_ctx* ctx, const zkhip_machine_key* ke
     for (size_t r = (size_t)NP; r < ((size_t)1 << m.height[C_SCALARS]); r++) std::memcpy(ht.sc.data() + sc_w * r, ht.sc.data(), sc_w * 4);     // rows behind the proofs repeat row 0
     // device: the fold rows proof by proof (the last call fills the padding), then ONE launch for every Poseidon2 row
     void* dev[N_CHIPS] = {nullptr};
-    const int slots[N_CHIPS] = {S_REC_A, S_REC_C, S_REC_B, S_REC_D, S_REC_E, S_REC_F, S_REC_G, S_REC_H};
-    for (int c = 0; c < N_CHIPS; c++) ZK_TRY(ctx_reserve(ctx, slots[c], ((size_t)w_main[c] << m.height[c]) * 4, &dev[c]));
+    const int slots[N_CHIPS] = {S_REC_A, S_REC_C, S_REC_B, S_REC_D, S_REC_E, S_REC_F, S_REC_G, S_REC_H, S_REC_I};
+    for (int c = 0; c < m.n; c++) ZK_TRY(ctx_reserve(ctx, slots[c], ((size_t)w_main[c] << m.height[c]) * 4, &dev[c]));
     {   // the fold rows of every proof in ONE launch
         const size_t nq = (size_t)NP * (size_t)Q;
         std::vector<uint32_t> betas, indices, values, siblings, finals(4 * nq);
@@ -1037,45 +1217,42 @@ static int shard_verifier_prove_impl(zkhip_ctx* ctx, const zkhip_machine_key* ke
     }
     lap("device: P2R rows + roots back");
     // the host tables up, then the machine's proof
-    const std::vector<uint32_t>* host[N_CHIPS] = {nullptr, &ht.rs, nullptr, &ht.ts, &ht.q, &ht.op, &ht.sm, &ht.sc};
-    for (int c = 0; c < N_CHIPS; c++) if (host[c]) ZK_TRY(dev_h2d(ctx, dev[c], host[c]->data(), host[c]->size() * 4));
+    const std::vector<uint32_t>* host[N_CHIPS] = {nullptr, &ht.rs, nullptr, &ht.ts, &ht.q, &ht.op, &ht.sm, &ht.sc, &ht.evl};
+    for (int c = 0; c < m.n; c++) if (host[c]) ZK_TRY(dev_h2d(ctx, dev[c], host[c]->data(), host[c]->size() * 4));
     zkhip_chip chips[N_CHIPS]{};
-    for (int i = 0; i < N_CHIPS; i++) {
+    for (int i = 0; i < m.n; i++) {
         const int c = m.order[i];
         chips[i].d_trace = (const uint32_t*)dev[c]; chips[i].ld = w_main[c]; chips[i].log_n = m.height[c]; chips[i].width = w_main[c]; chips[i].partner = -1;
     }
     std::vector<uint32_t> pv((size_t)NP * n_public);
     for (size_t i = 0; i < pv.size(); i++) pv[i] = public_values[i] % P;
     lap("upload: host tables");
-    const int rc = zkhip_prove_machine_keyed(ctx, key, chips, m.progs, m.prog_words, m.tabs, m.tab_words, N_CHIPS, pv.data(), pv.size(), outer, proof, cap, len);
+    const int rc = zkhip_prove_machine_keyed(ctx, key, chips, m.progs, m.prog_words, m.tabs, m.tab_words, m.n, pv.data(), pv.size(), outer, proof, cap, len);
     lap("the machine's proof");
     return rc;
 }
 
-extern "C" {
-
-// the key of a SHAPE: the commitment to the eight chips' preprocessed columns -- no inner proof is involved
-int zkhip_shard_verifier_setup(zkhip_ctx* ctx, int log_n, uint32_t width, size_t n_queries, int inner_pow_bits, size_t n_public, size_t n_proofs, const zkhip_params* outer,
-                               zkhip_machine_key** key, uint32_t vk[8]) {
+// ---- the entries, with the inner AIR as the synthetic one (program == NULL: version-1 inner proofs) or as a constraint program (air mode:
+// version-7 inner proofs, zkhip_prove_shard_air's)
+static int sv_setup(zkhip_ctx* ctx, const uint32_t* program, size_t program_words, int log_n, uint32_t width, size_t n_queries, int inner_pow_bits, size_t n_public, size_t n_proofs,
+                    const zkhip_params* outer, zkhip_machine_key** key, uint32_t vk[8]) {
     using namespace zk::rec;
     CHECK_CTX(ctx);
     if (!outer || !key || !vk) return fail(ZKHIP_ERR_INVALID, "shard_verifier_setup: null argument");
     Shape sh;
-    ZK_TRY(make_shape(log_n, width, n_queries, inner_pow_bits, n_public, n_proofs, sh));
+    ZK_TRY(make_shape(log_n, width, n_queries, inner_pow_bits, n_public, n_proofs, sh, program, program_words));
     ZK_TRY(check_outer(sh, outer));
     const auto mp = machine_of(sh);
     const Machine& m = *mp;
     std::vector<uint32_t> pre[N_CHIPS];
-    p2r_pre(sh, m.height[C_P2R], pre[C_P2R]); rowsum_pre(sh, m.height[C_ROWSUM], pre[C_ROWSUM]); ts_pre(sh, m.height[C_TS], pre[C_TS]);
-    query_pre(sh, m.height[C_QUERY], pre[C_QUERY]); opened_pre(sh, m.height[C_OPENED], pre[C_OPENED]); scalars_pre(sh, m.height[C_SCALARS], pre[C_SCALARS]);
-    samples_pre_all(sh, m.height[C_SAMPLES], pre[C_SAMPLES]);
+    all_pre(sh, m, pre);
     size_t total = 0;
     for (int c = 0; c < N_CHIPS; c++) total += pre[c].size();
     void* d;
     ZK_TRY(ctx_reserve(ctx, S_REC_A, total * 4, &d));       // (staging: the key keeps its own copies)
     zkhip_chip chips[N_CHIPS]{};
     size_t at = 0;
-    for (int i = 0; i < N_CHIPS; i++) {
+    for (int i = 0; i < m.n; i++) {
         const int c = m.order[i];
         chips[i].log_n = m.height[c]; chips[i].width = m.pre_widths[i]; chips[i].ld = m.pre_widths[i]; chips[i].partner = -1;
         if (pre[c].empty()) continue;
@@ -1083,88 +1260,74 @@ int zkhip_shard_verifier_setup(zkhip_ctx* ctx, int log_n, uint32_t width, size_t
         chips[i].d_trace = (const uint32_t*)d + at;
         at += pre[c].size();
     }
-    return zkhip_machine_setup(ctx, chips, N_CHIPS, outer, key, vk);
+    return zkhip_machine_setup(ctx, chips, m.n, outer, key, vk);
 }
-
 // The same key WITHOUT a device (round 5; host_key.cpp): the preprocessed traces are host tables anyway -- their low-degree extensions and the
 // mixed-height Poseidon2 commitment are computed on the host's cores, so that a verifier that owns no GPU derives the key of the shape it
-// means by itself (the reference verifies on the CPU: sp1.rs:120).  Equal to zkhip_shard_verifier_setup's vk at every shape.
-int zkhip_shard_verifier_key_host(int log_n, uint32_t width, size_t n_queries, int inner_pow_bits, size_t n_public, size_t n_proofs, const zkhip_params* outer, uint32_t vk[8]) {
+// means by itself (the reference verifies on the CPU: sp1.rs:120).  Equal to the device's vk at every shape.
+static int sv_key_host(const uint32_t* program, size_t program_words, int log_n, uint32_t width, size_t n_queries, int inner_pow_bits, size_t n_public, size_t n_proofs,
+                       const zkhip_params* outer, uint32_t vk[8]) {
     using namespace zk::rec;
     try {
         if (!outer || !vk) return fail(ZKHIP_ERR_INVALID, "shard_verifier_key_host: null argument");
         Shape sh;
-        ZK_TRY(make_shape(log_n, width, n_queries, inner_pow_bits, n_public, n_proofs, sh));
+        ZK_TRY(make_shape(log_n, width, n_queries, inner_pow_bits, n_public, n_proofs, sh, program, program_words));
         ZK_TRY(check_outer(sh, outer));
         const auto mp = machine_of(sh);
         const Machine& m = *mp;
         std::vector<uint32_t> pre[N_CHIPS];
-        p2r_pre(sh, m.height[C_P2R], pre[C_P2R]); rowsum_pre(sh, m.height[C_ROWSUM], pre[C_ROWSUM]); ts_pre(sh, m.height[C_TS], pre[C_TS]);
-        query_pre(sh, m.height[C_QUERY], pre[C_QUERY]); opened_pre(sh, m.height[C_OPENED], pre[C_OPENED]); scalars_pre(sh, m.height[C_SCALARS], pre[C_SCALARS]);
-        samples_pre_all(sh, m.height[C_SAMPLES], pre[C_SAMPLES]);
+        all_pre(sh, m, pre);
         const uint32_t* traces[N_CHIPS]; int32_t lns[N_CHIPS]; uint32_t pws[N_CHIPS];
-        for (int i = 0; i < N_CHIPS; i++) {
+        for (int i = 0; i < m.n; i++) {
             const int c = m.order[i];
             lns[i] = m.height[c]; pws[i] = m.pre_widths[i];
             traces[i] = pre[c].empty() ? nullptr : pre[c].data();
             if (pre[c].empty()) pws[i] = 0;
         }
-        return zkhip_machine_key_host(traces, lns, pws, N_CHIPS, outer, vk);
+        return zkhip_machine_key_host(traces, lns, pws, m.n, outer, vk);
     } catch (const std::bad_alloc&) {
         return fail(ZKHIP_ERR_NOMEM, "shard_verifier_key_host: out of host memory");
     }
 }
-
-// the largest n_proofs one join takes for this inner shape: the Poseidon2 chip holds every permutation of every proof in at most 2^22 rows
-// (2^21 when the outer proof's blowup is not 2)
-size_t zkhip_shard_verifier_max_proofs(int log_n, uint32_t width, size_t n_queries, int inner_pow_bits, size_t n_public, const zkhip_params* outer) {
+static size_t sv_max_proofs(const uint32_t* program, size_t program_words, int log_n, uint32_t width, size_t n_queries, int inner_pow_bits, size_t n_public, const zkhip_params* outer) {
     using namespace zk::rec;
     Shape sh;
-    if (make_shape(log_n, width, n_queries, inner_pow_bits, n_public, 1, sh) != ZKHIP_OK) return 0;
+    if (make_shape(log_n, width, n_queries, inner_pow_bits, n_public, 1, sh, program, program_words) != ZKHIP_OK) return 0;
     size_t fit = ((size_t)1 << p2r_max_log_rows(outer)) / sh.p2_rows;
     if (fit > MAX_JOIN) fit = MAX_JOIN;
-    if (!sh.pub_rows.empty() && fit > (1024 - 29) / sh.pub_rows.size()) fit = (1024 - 29) / sh.pub_rows.size();      // (the transcript table's indicator columns)
+    const size_t fixed = sh.air ? 46 : 29;
+    if (!sh.pub_rows.empty() && fit > (1024 - fixed) / sh.pub_rows.size()) fit = (1024 - fixed) / sh.pub_rows.size();      // (the transcript table's indicator columns)
+    if (sh.air && fit > ((size_t)1 << MAX_LOG_ROWS) / sh.terms.size()) fit = ((size_t)1 << MAX_LOG_ROWS) / sh.terms.size();       // (the EVAL chip: one row per term and proof)
     return fit;
 }
-
-size_t zkhip_shard_verifier_proof_size(int log_n, uint32_t width, size_t n_queries, int inner_pow_bits, size_t n_public, size_t n_proofs, const zkhip_params* outer) {
+static size_t sv_proof_size(const uint32_t* program, size_t program_words, int log_n, uint32_t width, size_t n_queries, int inner_pow_bits, size_t n_public, size_t n_proofs,
+                            const zkhip_params* outer) {
     using namespace zk::rec;
     Shape sh;
-    if (!outer || make_shape(log_n, width, n_queries, inner_pow_bits, n_public, n_proofs, sh) != ZKHIP_OK || check_outer(sh, outer) != ZKHIP_OK) return 0;
+    if (!outer || make_shape(log_n, width, n_queries, inner_pow_bits, n_public, n_proofs, sh, program, program_words) != ZKHIP_OK || check_outer(sh, outer) != ZKHIP_OK) return 0;
     const auto m = machine_of(sh);
-    return zkhip_machine_proof_size_keyed(m->log_ns, m->widths, m->pre_widths, m->progs, m->prog_words, m->tabs, m->tab_words, N_CHIPS, outer, n_proofs * n_public);
+    return zkhip_machine_proof_size_keyed(m->log_ns, m->widths, m->pre_widths, m->progs, m->prog_words, m->tabs, m->tab_words, m->n, outer, n_proofs * n_public);
 }
-
-int zkhip_prove_shard_verifier(zkhip_ctx* ctx, const zkhip_machine_key* key, const uint8_t* const* shard_proofs, const size_t* shard_proof_lens, size_t n_proofs, int log_n,
-                               uint32_t width, const uint32_t* public_values, size_t n_public, const zkhip_params* inner, const zkhip_params* outer, uint8_t* proof, size_t cap,
-                               size_t* len) {
-    return shard_verifier_prove_impl(ctx, key, shard_proofs, shard_proof_lens, n_proofs, log_n, width, public_values, n_public, inner, outer, proof, cap, len);
-}
-
-// The verifier of the outer proof: the shape of the inner proofs, THEIR public values (proof 0's, then proof 1's, ...), the key of the shape.
-// No byte of an inner proof.
-int zkhip_verify_shard_recursive(const uint8_t* proof, size_t len, int log_n, uint32_t width, size_t n_queries, int inner_pow_bits, const uint32_t* public_values,
-                                 size_t n_public, size_t n_proofs, const uint32_t vk[8], const zkhip_params* outer, int* reason) {
+static int sv_verify(const uint32_t* program, size_t program_words, const uint8_t* proof, size_t len, int log_n, uint32_t width, size_t n_queries, int inner_pow_bits,
+                     const uint32_t* public_values, size_t n_public, size_t n_proofs, const uint32_t vk[8], const zkhip_params* outer, int* reason) {
     using namespace zk::rec;
     Shape sh;
-    if (!proof || !vk || !outer || (n_public && !public_values) || make_shape(log_n, width, n_queries, inner_pow_bits, n_public, n_proofs, sh) != ZKHIP_OK) {
+    if (!proof || !vk || !outer || (n_public && !public_values) || make_shape(log_n, width, n_queries, inner_pow_bits, n_public, n_proofs, sh, program, program_words) != ZKHIP_OK) {
         if (reason) *reason = 1;
         return fail(ZKHIP_ERR_VERIFY, "verify_shard_recursive: bad arguments");
     }
     const auto m = machine_of(sh);
     std::vector<uint32_t> pv(n_proofs * n_public);
     for (size_t i = 0; i < pv.size(); i++) pv[i] = public_values[i];
-    return zkhip_verify_machine_keyed(proof, len, m->log_ns, m->widths, m->pre_widths, vk, m->progs, m->prog_words, m->tabs, m->tab_words, N_CHIPS, pv.data(), pv.size(), outer, reason);
+    return zkhip_verify_machine_keyed(proof, len, m->log_ns, m->widths, m->pre_widths, vk, m->progs, m->prog_words, m->tabs, m->tab_words, m->n, pv.data(), pv.size(), outer, reason);
 }
-
-// the machine as data (tests compare with tests/recursion_air.py word for word): which = position (tallest chip first); kind 0 = the chip's
-// program, 1 = its interaction table, 2 = its preprocessed trace (canonical words, row-major); *log_rows, *main_width, *pre_width describe the chip
-size_t zkhip_shard_verifier_describe(int log_n, uint32_t width, size_t n_queries, int inner_pow_bits, size_t n_public, size_t n_proofs, int which, int kind, uint32_t* out,
-                                     size_t cap_words, int* log_rows, uint32_t* main_width, uint32_t* pre_width) {
+static size_t sv_describe(const uint32_t* program, size_t program_words, int log_n, uint32_t width, size_t n_queries, int inner_pow_bits, size_t n_public, size_t n_proofs, int which,
+                          int kind, uint32_t* out, size_t cap_words, int* log_rows, uint32_t* main_width, uint32_t* pre_width) {
     using namespace zk::rec;
     Shape sh;
-    if (which < 0 || which >= N_CHIPS || kind < 0 || kind > 2 || make_shape(log_n, width, n_queries, inner_pow_bits, n_public, n_proofs, sh) != ZKHIP_OK) return 0;
+    if (which < 0 || kind < 0 || kind > 2 || make_shape(log_n, width, n_queries, inner_pow_bits, n_public, n_proofs, sh, program, program_words) != ZKHIP_OK) return 0;
     const auto m = machine_of(sh);
+    if (which >= m->n) return 0;
     if (log_rows) *log_rows = m->log_ns[which];
     if (main_width) *main_width = m->widths[which];
     if (pre_width) *pre_width = m->pre_widths[which];
@@ -1180,6 +1343,7 @@ size_t zkhip_shard_verifier_describe(int log_n, uint32_t width, size_t n_queries
             case C_OPENED: opened_pre(sh, h, pre); break;
             case C_SAMPLES: samples_pre_all(sh, h, pre); break;
             case C_SCALARS: scalars_pre(sh, h, pre); break;
+            case C_EVAL: eval_pre(sh, h, pre); break;
             default: break;
         }
         for (uint32_t& v : pre) v = from_monty(v);
@@ -1187,6 +1351,79 @@ size_t zkhip_shard_verifier_describe(int log_n, uint32_t width, size_t n_queries
     }
     if (out && cap_words >= src->size()) std::memcpy(out, src->data(), src->size() * 4);
     return src->size();
+}
+
+extern "C" {
+
+// the key of a SHAPE: the commitment to the eight chips' preprocessed columns -- no inner proof is involved
+int zkhip_shard_verifier_setup(zkhip_ctx* ctx, int log_n, uint32_t width, size_t n_queries, int inner_pow_bits, size_t n_public, size_t n_proofs, const zkhip_params* outer,
+                               zkhip_machine_key** key, uint32_t vk[8]) {
+    return sv_setup(ctx, nullptr, 0, log_n, width, n_queries, inner_pow_bits, n_public, n_proofs, outer, key, vk);
+}
+int zkhip_shard_verifier_key_host(int log_n, uint32_t width, size_t n_queries, int inner_pow_bits, size_t n_public, size_t n_proofs, const zkhip_params* outer, uint32_t vk[8]) {
+    return sv_key_host(nullptr, 0, log_n, width, n_queries, inner_pow_bits, n_public, n_proofs, outer, vk);
+}
+// the largest n_proofs one join takes for this inner shape: the Poseidon2 chip holds every permutation of every proof in at most 2^22 rows
+// (2^21 when the outer proof's blowup is not 2)
+size_t zkhip_shard_verifier_max_proofs(int log_n, uint32_t width, size_t n_queries, int inner_pow_bits, size_t n_public, const zkhip_params* outer) {
+    return sv_max_proofs(nullptr, 0, log_n, width, n_queries, inner_pow_bits, n_public, outer);
+}
+size_t zkhip_shard_verifier_proof_size(int log_n, uint32_t width, size_t n_queries, int inner_pow_bits, size_t n_public, size_t n_proofs, const zkhip_params* outer) {
+    return sv_proof_size(nullptr, 0, log_n, width, n_queries, inner_pow_bits, n_public, n_proofs, outer);
+}
+int zkhip_prove_shard_verifier(zkhip_ctx* ctx, const zkhip_machine_key* key, const uint8_t* const* shard_proofs, const size_t* shard_proof_lens, size_t n_proofs, int log_n,
+                               uint32_t width, const uint32_t* public_values, size_t n_public, const zkhip_params* inner, const zkhip_params* outer, uint8_t* proof, size_t cap,
+                               size_t* len) {
+    return shard_verifier_prove_impl(ctx, key, nullptr, 0, shard_proofs, shard_proof_lens, n_proofs, log_n, width, public_values, n_public, inner, outer, proof, cap, len);
+}
+// The verifier of the outer proof: the shape of the inner proofs, THEIR public values (proof 0's, then proof 1's, ...), the key of the shape.
+// No byte of an inner proof.
+int zkhip_verify_shard_recursive(const uint8_t* proof, size_t len, int log_n, uint32_t width, size_t n_queries, int inner_pow_bits, const uint32_t* public_values,
+                                 size_t n_public, size_t n_proofs, const uint32_t vk[8], const zkhip_params* outer, int* reason) {
+    return sv_verify(nullptr, 0, proof, len, log_n, width, n_queries, inner_pow_bits, public_values, n_public, n_proofs, vk, outer, reason);
+}
+// the machine as data (tests compare with tests/recursion_air.py word for word): which = position (tallest chip first); kind 0 = the chip's
+// program, 1 = its interaction table, 2 = its preprocessed trace (canonical words, row-major); *log_rows, *main_width, *pre_width describe the chip
+size_t zkhip_shard_verifier_describe(int log_n, uint32_t width, size_t n_queries, int inner_pow_bits, size_t n_public, size_t n_proofs, int which, int kind, uint32_t* out,
+                                     size_t cap_words, int* log_rows, uint32_t* main_width, uint32_t* pre_width) {
+    return sv_describe(nullptr, 0, log_n, width, n_queries, inner_pow_bits, n_public, n_proofs, which, kind, out, cap_words, log_rows, main_width, pre_width);
+}
+
+// ---- the same entries for inner proofs of a constraint PROGRAM (version 7: zkhip_prove_shard_air, zkhip_prove_sha256, the chained SHA-256 shards;
+// SP1 shape, log_quotient_degree 1, a width that is a multiple of 8, terms of at most three factors): nine chips -- the EVAL chip evaluates the
+// program at zeta, one row per term.  The key is a function of the shape AND the program.
+int zkhip_shard_verifier_setup_air(zkhip_ctx* ctx, const uint32_t* program, size_t program_words, int log_n, uint32_t width, size_t n_queries, int inner_pow_bits, size_t n_public,
+                                   size_t n_proofs, const zkhip_params* outer, zkhip_machine_key** key, uint32_t vk[8]) {
+    if (!program) return fail(ZKHIP_ERR_INVALID, "shard_verifier_setup_air: null program");
+    return sv_setup(ctx, program, program_words, log_n, width, n_queries, inner_pow_bits, n_public, n_proofs, outer, key, vk);
+}
+int zkhip_shard_verifier_key_host_air(const uint32_t* program, size_t program_words, int log_n, uint32_t width, size_t n_queries, int inner_pow_bits, size_t n_public, size_t n_proofs,
+                                      const zkhip_params* outer, uint32_t vk[8]) {
+    if (!program) return fail(ZKHIP_ERR_INVALID, "shard_verifier_key_host_air: null program");
+    return sv_key_host(program, program_words, log_n, width, n_queries, inner_pow_bits, n_public, n_proofs, outer, vk);
+}
+size_t zkhip_shard_verifier_max_proofs_air(const uint32_t* program, size_t program_words, int log_n, uint32_t width, size_t n_queries, int inner_pow_bits, size_t n_public,
+                                           const zkhip_params* outer) {
+    return program ? sv_max_proofs(program, program_words, log_n, width, n_queries, inner_pow_bits, n_public, outer) : 0;
+}
+size_t zkhip_shard_verifier_proof_size_air(const uint32_t* program, size_t program_words, int log_n, uint32_t width, size_t n_queries, int inner_pow_bits, size_t n_public,
+                                           size_t n_proofs, const zkhip_params* outer) {
+    return program ? sv_proof_size(program, program_words, log_n, width, n_queries, inner_pow_bits, n_public, n_proofs, outer) : 0;
+}
+int zkhip_prove_shard_verifier_air(zkhip_ctx* ctx, const zkhip_machine_key* key, const uint32_t* program, size_t program_words, const uint8_t* const* shard_proofs,
+                                   const size_t* shard_proof_lens, size_t n_proofs, int log_n, uint32_t width, const uint32_t* public_values, size_t n_public,
+                                   const zkhip_params* inner, const zkhip_params* outer, uint8_t* proof, size_t cap, size_t* len) {
+    if (!program) return fail(ZKHIP_ERR_INVALID, "prove_shard_verifier_air: null program");
+    return shard_verifier_prove_impl(ctx, key, program, program_words, shard_proofs, shard_proof_lens, n_proofs, log_n, width, public_values, n_public, inner, outer, proof, cap, len);
+}
+int zkhip_verify_shard_recursive_air(const uint32_t* program, size_t program_words, const uint8_t* proof, size_t len, int log_n, uint32_t width, size_t n_queries, int inner_pow_bits,
+                                     const uint32_t* public_values, size_t n_public, size_t n_proofs, const uint32_t vk[8], const zkhip_params* outer, int* reason) {
+    if (!program) { if (reason) *reason = 1; return fail(ZKHIP_ERR_VERIFY, "verify_shard_recursive_air: null program"); }
+    return sv_verify(program, program_words, proof, len, log_n, width, n_queries, inner_pow_bits, public_values, n_public, n_proofs, vk, outer, reason);
+}
+size_t zkhip_shard_verifier_describe_air(const uint32_t* program, size_t program_words, int log_n, uint32_t width, size_t n_queries, int inner_pow_bits, size_t n_public,
+                                         size_t n_proofs, int which, int kind, uint32_t* out, size_t cap_words, int* log_rows, uint32_t* main_width, uint32_t* pre_width) {
+    return program ? sv_describe(program, program_words, log_n, width, n_queries, inner_pow_bits, n_public, n_proofs, which, kind, out, cap_words, log_rows, main_width, pre_width) : 0;
 }
 
 }  // extern "C"

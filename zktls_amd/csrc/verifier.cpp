@@ -524,7 +524,7 @@ namespace zk {
 thread_local int t_query_threads_cap = 0;
 int fri_view_all_unhashed(const uint8_t* proof, size_t len, int log_n, uint32_t width, const uint32_t* public_values, size_t n_public,
                           const zkhip_params* prm, uint32_t* betas, uint32_t final_value[4], uint32_t* indices, uint32_t* values, uint32_t* siblings,
-                          uint32_t* roots, uint32_t* paths, uint32_t transcript[10]) {
+                          uint32_t* roots, uint32_t* paths, uint32_t transcript[10], const uint32_t* program, size_t program_words) {
     Shape sh;
     if (!prm || check_shape(log_n, width, prm) != ZKHIP_OK) return ZKHIP_ERR_INVALID;
     shape_of(log_n, prm, sh);
@@ -532,7 +532,9 @@ int fri_view_all_unhashed(const uint8_t* proof, size_t len, int log_n, uint32_t 
     FriViewSink sink{betas, final_value, indices, values, siblings, sh.R, roots, paths, transcript};
     sink.skip_paths = true;
     int why = 0;
-    return verify_shard_impl(proof, len, log_n, width, public_values, n_public, prm, &why, nullptr, &sink);
+    AirView av;
+    if (program && !air_validate(program, program_words, width, n_public, &av)) return fail(ZKHIP_ERR_INVALID, "fri_view_all: malformed constraint program");
+    return verify_shard_impl(proof, len, log_n, width, public_values, n_public, prm, &why, program ? &av : nullptr, &sink);
 }
 }  // namespace zk
 }  // extern "C++"

@@ -644,14 +644,20 @@ class Context:
                                                cap8.ctypes.data_as(u32p), int(witness), C.byref(params), buf.ctypes.data_as(u8p), size, C.byref(got)))
         return buf[: got.value]
 
-    def shard_verifier_setup(self, log_n, width, n_queries, inner_pow_bits, n_public, params=None, n_proofs=1):
-        """zkhip_shard_verifier_setup: the key of the shard-verifier machine for n_proofs inner proofs of this SHAPE (no inner proof involved)"""
+    def shard_verifier_setup(self, log_n, width, n_queries, inner_pow_bits, n_public, params=None, n_proofs=1, program=None):
+        """zkhip_shard_verifier_setup: the key of the shard-verifier machine for n_proofs inner proofs of this SHAPE (no inner proof involved);
+        program: the inner proofs are version-7 proofs of that constraint program (zkhip_shard_verifier_setup_air)"""
         params = params or Params(1, 100, 16)
         handle, root = C.c_void_p(), np.zeros(8, dtype=np.uint32)
-        check(self.lib.zkhip_shard_verifier_setup(self.handle, log_n, width, n_queries, inner_pow_bits, n_public, n_proofs, C.byref(params), C.byref(handle), root.ctypes.data_as(u32p)))
+        if program is None:
+            check(self.lib.zkhip_shard_verifier_setup(self.handle, log_n, width, n_queries, inner_pow_bits, n_public, n_proofs, C.byref(params), C.byref(handle), root.ctypes.data_as(u32p)))
+        else:
+            pg = np.ascontiguousarray(program, dtype=np.uint32)
+            check(self.lib.zkhip_shard_verifier_setup_air(self.handle, pg.ctypes.data_as(u32p), pg.size, log_n, width, n_queries, inner_pow_bits, n_public, n_proofs, C.byref(params),
+                                                          C.byref(handle), root.ctypes.data_as(u32p)))
         return MachineKey(self, handle, root, None)
 
-    def prove_shard_verifier(self, key, shard_proofs, log_n, width, public_values, inner=None, outer=None):
+    def prove_shard_verifier(self, key, shard_proofs, log_n, width, public_values, inner=None, outer=None, program=None):
         """zkhip_prove_shard_verifier: the WHOLE verification of a shard proof (transcript, AIR identity, openings, FRI) proven in-circuit.
         shard_proofs: one proof (bytes / uint8 array) with its public values, or a LIST of proofs with a list of public-value lists (the join)"""
         inner, outer = inner or Params(1, 100, 16), outer or Params(1, 100, 16)
@@ -661,15 +667,23 @@ class Context:
         n = len(sps)
         pv = np.ascontiguousarray(np.array([list(v) for v in public_values], dtype=np.uint32).reshape(n, -1))
         n_public = pv.shape[1]
-        size = self.lib.zkhip_shard_verifier_proof_size(log_n, width, inner.num_queries, inner.pow_bits, n_public, n, C.byref(outer))
+        pg = None if program is None else np.ascontiguousarray(program, dtype=np.uint32)
+        if pg is None:
+            size = self.lib.zkhip_shard_verifier_proof_size(log_n, width, inner.num_queries, inner.pow_bits, n_public, n, C.byref(outer))
+        else:
+            size = self.lib.zkhip_shard_verifier_proof_size_air(pg.ctypes.data_as(u32p), pg.size, log_n, width, inner.num_queries, inner.pow_bits, n_public, n, C.byref(outer))
         if size == 0:
             check(-1)
         buf = np.empty(size, dtype=np.uint8)
         got = C.c_size_t(0)
         ptrs = (u8p * n)(*[sp.ctypes.data_as(u8p) for sp in sps])
         lens = (C.c_size_t * n)(*[sp.size for sp in sps])
-        check(self.lib.zkhip_prove_shard_verifier(self.handle, key.handle, ptrs, lens, n, log_n, width, pv.ctypes.data_as(u32p), n_public, C.byref(inner),
-                                                  C.byref(outer), buf.ctypes.data_as(u8p), size, C.byref(got)))
+        if pg is None:
+            check(self.lib.zkhip_prove_shard_verifier(self.handle, key.handle, ptrs, lens, n, log_n, width, pv.ctypes.data_as(u32p), n_public, C.byref(inner),
+                                                      C.byref(outer), buf.ctypes.data_as(u8p), size, C.byref(got)))
+        else:
+            check(self.lib.zkhip_prove_shard_verifier_air(self.handle, key.handle, pg.ctypes.data_as(u32p), pg.size, ptrs, lens, n, log_n, width, pv.ctypes.data_as(u32p), n_public,
+                                                          C.byref(inner), C.byref(outer), buf.ctypes.data_as(u8p), size, C.byref(got)))
         return buf[: got.value]
 
     def prove_machine_keyed(self, key, chips, programs, tables, public_values=(), params=None, key_entries=None):
@@ -1161,7 +1175,7 @@ def fri_indices_programs(layers, inner_pow_bits):
     return out
 
 
-def verify_shard_recursive(proof, log_n, width, n_queries, inner_pow_bits, public_values, vk, params=None, n_proofs=1):
+def verify_shard_recursive(proof, log_n, width, n_queries, inner_pow_bits, public_values, vk, params=None, n_proofs=1, program=None):
     """zkhip_verify_shard_recursive (host): the inner proofs' shape and public values (a flat list: proof 0's, then proof 1's, ...) and the shape's key --
     no byte of an inner proof"""
     params = params or Params(1, 100, 16)
@@ -1170,16 +1184,25 @@ def verify_shard_recursive(proof, log_n, width, n_queries, inner_pow_bits, publi
     pv = np.ascontiguousarray(np.array(public_values, dtype=np.uint32).ravel())
     k = np.ascontiguousarray(np.array(vk, dtype=np.uint32))
     reason = C.c_int(0)
-    rc = lib.zkhip_verify_shard_recursive(pr.ctypes.data_as(u8p), pr.size, log_n, width, n_queries, inner_pow_bits, pv.ctypes.data_as(u32p), pv.size // max(n_proofs, 1), n_proofs,
-                                          k.ctypes.data_as(u32p), C.byref(params), C.byref(reason))
+    if program is None:
+        rc = lib.zkhip_verify_shard_recursive(pr.ctypes.data_as(u8p), pr.size, log_n, width, n_queries, inner_pow_bits, pv.ctypes.data_as(u32p), pv.size // max(n_proofs, 1), n_proofs,
+                                              k.ctypes.data_as(u32p), C.byref(params), C.byref(reason))
+    else:
+        pg = np.ascontiguousarray(program, dtype=np.uint32)
+        rc = lib.zkhip_verify_shard_recursive_air(pg.ctypes.data_as(u32p), pg.size, pr.ctypes.data_as(u8p), pr.size, log_n, width, n_queries, inner_pow_bits, pv.ctypes.data_as(u32p),
+                                                  pv.size // max(n_proofs, 1), n_proofs, k.ctypes.data_as(u32p), C.byref(params), C.byref(reason))
     return rc, reason.value
 
 
-def shard_verifier_key_host(log_n, width, n_queries, inner_pow_bits, n_public, params=None, n_proofs=1):
-    """zkhip_shard_verifier_key_host: the key of the shape computed on the HOST (no context, no device) -> 8 canonical words"""
+def shard_verifier_key_host(log_n, width, n_queries, inner_pow_bits, n_public, params=None, n_proofs=1, program=None):
+    """zkhip_shard_verifier_key_host[_air]: the key of the shape (and program) computed on the HOST (no context, no device) -> 8 canonical words"""
     params = params or Params()
     vk = np.zeros(8, dtype=np.uint32)
-    check(_lib.load().zkhip_shard_verifier_key_host(log_n, width, n_queries, inner_pow_bits, n_public, n_proofs, C.byref(params), vk.ctypes.data_as(u32p)))
+    if program is None:
+        check(_lib.load().zkhip_shard_verifier_key_host(log_n, width, n_queries, inner_pow_bits, n_public, n_proofs, C.byref(params), vk.ctypes.data_as(u32p)))
+    else:
+        pg = np.ascontiguousarray(program, dtype=np.uint32)
+        check(_lib.load().zkhip_shard_verifier_key_host_air(pg.ctypes.data_as(u32p), pg.size, log_n, width, n_queries, inner_pow_bits, n_public, n_proofs, C.byref(params), vk.ctypes.data_as(u32p)))
     return vk
 
 
@@ -1200,14 +1223,19 @@ def shard_verifier_max_proofs(log_n, width, n_queries, inner_pow_bits, n_public,
     return int(_lib.load().zkhip_shard_verifier_max_proofs(log_n, width, n_queries, inner_pow_bits, n_public, C.byref(outer) if outer is not None else None))
 
 
-def shard_verifier_describe(log_n, width, n_queries, inner_pow_bits, n_public, which, kind, n_proofs=1):
-    """zkhip_shard_verifier_describe -> (words, log_rows, main width, preprocessed width); kind 0 program, 1 interaction table, 2 preprocessed trace"""
+def shard_verifier_describe(log_n, width, n_queries, inner_pow_bits, n_public, which, kind, n_proofs=1, program=None):
+    """zkhip_shard_verifier_describe[_air] -> (words, log_rows, main width, preprocessed width); kind 0 program, 1 interaction table, 2 preprocessed trace"""
     lib = _lib.load()
     ln, mw, pw = C.c_int(0), C.c_uint32(0), C.c_uint32(0)
     shape = (log_n, width, n_queries, inner_pow_bits, n_public, n_proofs)
-    n = lib.zkhip_shard_verifier_describe(*shape, which, kind, None, 0, C.byref(ln), C.byref(mw), C.byref(pw))
+    if program is None:
+        fn = lambda *a: lib.zkhip_shard_verifier_describe(*shape, *a)
+    else:
+        pg = np.ascontiguousarray(program, dtype=np.uint32)
+        fn = lambda *a: lib.zkhip_shard_verifier_describe_air(pg.ctypes.data_as(u32p), pg.size, *shape, *a)
+    n = fn(which, kind, None, 0, C.byref(ln), C.byref(mw), C.byref(pw))
     out = np.zeros(max(n, 1), dtype=np.uint32)
-    lib.zkhip_shard_verifier_describe(*shape, which, kind, out.ctypes.data_as(u32p), n, C.byref(ln), C.byref(mw), C.byref(pw))
+    fn(which, kind, out.ctypes.data_as(u32p), n, C.byref(ln), C.byref(mw), C.byref(pw))
     return out[:n], ln.value, mw.value, pw.value
 
 
