@@ -35,6 +35,7 @@ SEND, RECV = O.SEND, O.RECEIVE
 BUS_IN0, BUS_IN1, BUS_TC, BUS_BETA, BUS_SC, BUS_QI, BUS_AT, BUS_AQ = 61, 62, 63, 64, 65, 66, 67, 68
 BUS_K0, BUS_KFA, BUS_KO0, BUS_OY, BUS_OA = 70, 77, 78, 83, 85               # K0 .. K0 + 6: the QUERY chip's seven constants; KO0 .. KO0 + 4: the OPENED chip's five; OY, OY + 1
 BUS_FIN = F.BUS_FIN
+BUS_VAL, BUS_EA = 86, 87                                                        # air mode: (key, value at zeta) to the EVAL chip's factor slots; the proof's alpha
 
 
 # ---------------------------------------------------------------------------------------------------------------- polynomials over columns
@@ -154,12 +155,44 @@ class Shape:
     """everything the machine's structure depends on: (log_n, width, queries, pow_bits, n_public) of a version-1 shard proof, and how many
     such proofs ONE outer proof verifies (n_proofs: the join -- every chip holds the rows of proof 0, then those of proof 1, ...; tags, tree
     numbers and query numbers carry the proof's number)"""
-    def __init__(self, log_n, width, n_queries, pow_bits, n_public, n_proofs=1):
+    def __init__(self, log_n, width, n_queries, pow_bits, n_public, n_proofs=1, program=None):
         assert width % 8 == 0 and width >= 8 and 2 <= log_n <= 22 and n_queries >= 1 and 1 <= n_proofs <= 1024
         self.n, self.W, self.Q, self.PB, self.NPUB, self.NP = log_n, width, n_queries, pow_bits, n_public, n_proofs
         self.R, self.H, self.G, self.WB = log_n, log_n + 1, width // 4, width // 8
         self.head = [log_n, width, 1, n_queries, pow_bits, n_public]           # the header words the transcript observes
-        n0 = 6 + 8 + n_public
+        # AIR MODE (program given): the inner proofs are version-7 proofs of that constraint program.  Their transcript starts from 18 words
+        # (+ logup_pairs 0, fold 2^1, constant final value, Poseidon2 width 16, the program's 8-word digest), and the program is flattened
+        # into TERMS of exactly three factor keys (0 = the constant one; a constraint's selector is one more factor) for the EVAL chip
+        self.air = program is not None
+        self.HL = 6
+        if self.air:
+            prog = [int(x) for x in program]
+            assert prog[2] == width and prog[4] == n_public
+            self.head += [0, 1, 0, 16] + [int(x) for x in O.air_digest(np.array(prog, dtype=np.uint32))]
+            self.HL = 18
+            self.KSPAN = 1 + 2 * width + n_public + 3
+            self.mult = [0] * self.KSPAN
+            self.terms = []                                                     # (coefficient, [three keys], first term of its constraint)
+            at = 6
+            for _ in range(prog[3]):
+                sel, nt = prog[at], prog[at + 1]
+                at += 2
+                for t in range(nt):
+                    coeff, d = prog[at], prog[at + 1]
+                    at += 2
+                    keys = []
+                    for v in prog[at:at + d]:
+                        kind, idx = v >> 30, v & 0xffff
+                        keys.append(self.key_local(idx) if kind == 0 else (self.key_next(idx) if kind == 1 else self.key_pub(idx)))
+                    at += d
+                    if sel:
+                        keys.append(self.key_sel(sel - 1))                      # program selectors: 1 first row, 2 last row, 3 transition
+                    assert len(keys) <= 3
+                    keys += [0] * (3 - len(keys))
+                    for k in keys:
+                        self.mult[k] += 1
+                    self.terms.append((coeff, keys, 1 if t == 0 else 0))
+        n0 = self.HL + 8 + n_public
         self.f0, self.r0 = n0 // 8, n0 % 8
         self.TA = self.f0 if self.r0 else self.f0 - 1                          # the sponge row alpha is sampled behind
         self.TQ = self.TA + 1                                                  # absorbs the quotient root; zeta
@@ -170,7 +203,7 @@ class Shape:
         self.NS = F.sample_rows(n_queries)
         self.NT = self.TP + self.NS                                            # sponge rows of the transcript
         self.NTS = self.TP + 1                                                 # rows of the TS table (the absorbing ones)
-        self.pub_rows = sorted({(14 + i) // 8 for i in range(n_public)})       # TS rows that hold public values
+        self.pub_rows = sorted({(self.HL + 8 + i) // 8 for i in range(n_public)})       # TS rows that hold public values
         # P2R row layout
         self.fri_rows = self.R + self.R * (self.R + 1) // 2                    # per query: a leaf row + the path, every layer
         self.p2_fri0 = self.NT
@@ -183,6 +216,19 @@ class Shape:
 
     def ttag(self, p, T):
         return p * self.TAGSPAN + T
+
+    # keys of the values the EVAL chip's factor slots read, inside one proof's key space (proof p: + p KSPAN)
+    def key_local(self, c):
+        return 1 + c
+
+    def key_next(self, c):
+        return 1 + self.W + c
+
+    def key_pub(self, i):
+        return 1 + 2 * self.W + i
+
+    def key_sel(self, which):
+        return 1 + 2 * self.W + self.NPUB + which                              # 0 first row, 1 last row, 2 transition
 
     def row_tag(self, p, q, b):
         return p * self.TAGSPAN + self.tag0 + q * (self.WB + 1) + b            # b = WB: the quotient row
@@ -363,6 +409,8 @@ def ts_cols(sh):
     for name, w in (("T", 1), ("ACT", 1), ("NSEND", 1), ("CF", 8), ("CV", 8), ("IND0", 1), ("IP", sh.NP * len(sh.pub_rows)), ("NROOT", 1), ("NTR", 1), ("TREE", 1),
                     ("HASCH", 1), ("NBETA", 1), ("NSC", 1), ("KIND", 1), ("NFIN", 1), ("PT", 1)):
         c(name, w)
+    if sh.air:                                                                  # the public values go to the EVAL chip word by word: key and multiplicity per word, a zero column
+        c("PK", 8), c("PM", 8), c("Z", 1)
     pre = rup4(c.n)
     m = Cols(pre)
     m("W", 8), m("TR", 8), m("CH", 4)
@@ -381,26 +429,30 @@ def ts_program(sh):
     npr = len(sh.pub_rows)
     for p in range(sh.NP):                                                      # the outer proof's public values: those of proof 0, then those of proof 1, ...
         for i in range(sh.NPUB):
-            pos = 14 + i
+            pos = sh.HL + 8 + i
             cons.add(O.SEL_ALL, pmul(pv(c["IP"] + p * npr + sh.pub_rows.index(pos // 8)), padd(pv(W + pos % 8), [(P - 1, [V(p * sh.NPUB + i, public=True)])])))
-    cons.add(O.SEL_ALL, pmul(pv(c["IND0"]), padd(pv(W + 6), pneg(pv(TR)))))
-    cons.add(O.SEL_ALL, pmul(pv(c["IND0"]), padd(pv(W + 7), pneg(pv(TR + 1)))))
-    for j in range(6):
-        cons.add(O.SEL_TRANSITION, pmul(pv(c["IND0"]), padd(pv(W + j, True), pneg(pv(TR + 2 + j)))))
+    o = sh.HL % 8                                                               # the trace root: words HL .. HL + 7 of the transcript
+    for j in range(8 - o):
+        cons.add(O.SEL_ALL, pmul(pv(c["IND0"]), padd(pv(W + o + j), pneg(pv(TR + j)))))
+    for j in range(o):
+        cons.add(O.SEL_TRANSITION, pmul(pv(c["IND0"]), padd(pv(W + j, True), pneg(pv(TR + 8 - o + j)))))
     return O.air_program(pre + TS_MAIN, sh.NP * sh.NPUB, cons.c)
 
 
 def ts_table(sh):
     c, m, _ = ts_cols(sh)
     W, TR, CH = m["W"], m["TR"], m["CH"]
-    return O.interaction_table([
+    rows = [
         (SEND, c["NSEND"], BUS_IN0, [c["T"], W, W + 1, W + 2, W + 3]), (SEND, c["NSEND"], BUS_IN1, [c["T"], W + 4, W + 5, W + 6, W + 7]),
         (RECV, c["HASCH"], BUS_TC, [c["T"], CH, CH + 1, CH + 2, CH + 3]),
         (SEND, c["NBETA"], BUS_BETA, [c["TREE"], CH, CH + 1, CH + 2, CH + 3]),
         (SEND, c["NSC"], BUS_SC, [c["KIND"], CH, CH + 1, CH + 2, CH + 3]),
         (RECV, c["NROOT"], F.BUS_R0, [c["TREE"], W, W + 1, W + 2, W + 3]), (RECV, c["NROOT"], F.BUS_R1, [c["TREE"], W + 4, W + 5, W + 6, W + 7]),
         (RECV, c["NTR"], F.BUS_R0, [c["TREE"], TR, TR + 1, TR + 2, TR + 3]), (RECV, c["NTR"], F.BUS_R1, [c["TREE"], TR + 4, TR + 5, TR + 6, TR + 7]),
-        (RECV, c["NFIN"], BUS_FIN, [c["PT"], W, W + 1, W + 2, W + 3])])
+        (RECV, c["NFIN"], BUS_FIN, [c["PT"], W, W + 1, W + 2, W + 3])]
+    if sh.air:
+        rows += [(SEND, c["PM"] + j, BUS_VAL, [c["PK"] + j, W + j, c["Z"], c["Z"], c["Z"]]) for j in range(8)]
+    return O.interaction_table(rows)
 
 
 def ts_pre(sh, log_rows):
@@ -412,11 +464,16 @@ def ts_pre(sh, log_rows):
             r = t[p * sh.NTS + T]
             r[c["T"]], r[c["ACT"]], r[c["NSEND"]] = sh.ttag(p, T), 1, 2 if sh.TO0 <= T <= sh.TF else 1
             for j in range(8):
-                if 8 * T + j < 6:
+                if 8 * T + j < sh.HL:
                     r[c["CF"] + j], r[c["CV"] + j] = 1, sh.head[8 * T + j]
             if T in sh.pub_rows:
                 r[c["IP"] + p * npr + sh.pub_rows.index(T)] = 1
-            if T == 0:
+            if sh.air:
+                for j in range(8):
+                    i = 8 * T + j - (sh.HL + 8)
+                    if 0 <= i < sh.NPUB:
+                        r[c["PK"] + j], r[c["PM"] + j] = p * sh.KSPAN + sh.key_pub(i), sh.mult[sh.key_pub(i)]
+            if T == sh.HL // 8:
                 r[c["IND0"]], r[c["NTR"]], r[c["TREE"]] = 1, sh.Q, p * sh.TREES + sh.R
             if T == sh.TQ:
                 r[c["NROOT"]], r[c["TREE"]] = sh.Q, p * sh.TREES + sh.R + 1
@@ -440,7 +497,7 @@ def ts_main(sh, ws, chals, p2_main, log_rows):
             r[0:8] = p2_main[p * sh.p2_rows + T, P2.IN:P2.IN + 8]               # the absorbed words, and whatever the kept ones are
             if T in (sh.TA, sh.TQ, sh.TF) or sh.TL0 <= T < sh.TP:
                 r[16:20] = chal[T]
-        t[p * sh.NTS, 8:16] = w["trace_root"]
+        t[p * sh.NTS + sh.HL // 8, 8:16] = w["trace_root"]
     return t
 
 
@@ -623,8 +680,15 @@ OP_PRE = 12
 OP_ACT, OP_FIRST, OP_LASTG, OP_NOTFIRST, OP_K1, OP_K2, OP_K3, OP_TL0, OP_TL1, OP_TN0, OP_TN1, OP_PID = range(12)
 
 
-def opened_cols():
-    m = Cols(OP_PRE)
+OP_PRE_AIR, OP_KEY0, OP_MUL0 = 28, 12, 20                                       # air mode: (key, multiplicity) of the row's eight opened values on the EVAL chip's bus
+
+
+def op_pre(sh):
+    return OP_PRE_AIR if sh.air else OP_PRE
+
+
+def opened_cols(base=OP_PRE):
+    m = Cols(base)
     for name in ("A", "B", "C", "D", "AN", "BN", "CN", "DN", "FA", "FA4", "ALPHA", "SELT", "SELF", "PW", "PWN", "H2", "H1", "IL", "G2", "G1", "INX",
                  "YLIN", "YLO", "YNIN", "YNO", "A2", "AB", "ACCIN", "U1", "U2", "ACCO"):
         m(name)
@@ -636,7 +700,7 @@ OP_MAIN = opened_cols().n - OP_PRE
 
 
 def opened_program(sh):
-    m = opened_cols()
+    m = opened_cols(op_pre(sh))
     cons = Cons()
     e = lambda name, nxt=False: ev(m[name], nxt)
     first, nf = pv(OP_FIRST), pv(OP_NOTFIRST, True)
@@ -654,6 +718,8 @@ def opened_program(sh):
         cons.ext(O.SEL_ALL, egate(first, e(yin)))
         cons.ext(O.SEL_ALL, esub(e(yo), eadd(e(yin), emul(e("PW"), e(il)))))
         cons.ext(O.SEL_TRANSITION, egate(nf, esub(e(yin, True), e(yo))))
+    if sh.air:                                                                  # the AIR's fold is the EVAL chip's: the columns behind YNO stay zero
+        return O.air_program(op_pre(sh) + OP_MAIN, sh.NP * sh.NPUB, cons.c)
     # the synthetic AIR on the opened values (docs/PROTOCOL.md section 3): C1 = c - a^2 b - (g + 1), C2 = sel_transition (d' - a b - c - (2 g + 3)),
     # C3 = sel_first (d - (5 g + 7)), folded acc = acc alpha + C in this order, group after group
     cons.ext(O.SEL_ALL, esub(e("A2"), emul(e("A"), e("A"))))
@@ -667,21 +733,30 @@ def opened_program(sh):
     return O.air_program(OP_PRE + OP_MAIN, sh.NP * sh.NPUB, cons.c)
 
 
-def opened_table():
-    m = opened_cols()
+def opened_table(sh):
+    m = opened_cols(op_pre(sh))
     it = []
     for tag, lo, hi in ((OP_TL0, "A", "B"), (OP_TL1, "C", "D"), (OP_TN0, "AN", "BN"), (OP_TN1, "CN", "DN")):
         it += [(RECV, OP_ACT, BUS_IN0, [tag] + _e4(m[lo])), (RECV, OP_ACT, BUS_IN1, [tag] + _e4(m[hi]))]
-    it += [(SEND, OP_LASTG, BUS_OY, [OP_PID] + _e4(m["YLO"])), (SEND, OP_LASTG, BUS_OY + 1, [OP_PID] + _e4(m["YNO"])), (SEND, OP_LASTG, BUS_OA, [OP_PID] + _e4(m["ACCO"]))]
+    it += [(SEND, OP_LASTG, BUS_OY, [OP_PID] + _e4(m["YLO"])), (SEND, OP_LASTG, BUS_OY + 1, [OP_PID] + _e4(m["YNO"]))]
+    if not sh.air:
+        it += [(SEND, OP_LASTG, BUS_OA, [OP_PID] + _e4(m["ACCO"]))]
     it += [(RECV, OP_FIRST, BUS_KO0 + i, [OP_PID] + _e4(m[name])) for i, name in enumerate(OPENED_CONSTS)]
+    if sh.air:                                                                  # A .. D at zeta, AN .. DN at zeta g
+        it += [(SEND, OP_MUL0 + i, BUS_VAL, [OP_KEY0 + i] + _e4(m[name])) for i, name in enumerate(("A", "B", "C", "D", "AN", "BN", "CN", "DN"))]
     return O.interaction_table(it)
 
 
 def opened_pre(sh, log_rows):
-    t = np.zeros((1 << log_rows, OP_PRE), dtype=np.uint32)
+    t = np.zeros((1 << log_rows, op_pre(sh)), dtype=np.uint32)
     for p in range(sh.NP):
         for g in range(sh.G):
             r = t[p * sh.G + g]
+            if sh.air:
+                for i in range(4):
+                    kl, kn = sh.key_local(4 * g + i), sh.key_next(4 * g + i)
+                    r[OP_KEY0 + i], r[OP_MUL0 + i] = p * sh.KSPAN + kl, sh.mult[kl]
+                    r[OP_KEY0 + 4 + i], r[OP_MUL0 + 4 + i] = p * sh.KSPAN + kn, sh.mult[kn]
             r[OP_ACT], r[OP_NOTFIRST], r[OP_PID] = 1, 1 if g else 0, p
             r[OP_K1], r[OP_K2], r[OP_K3] = g + 1, 2 * g + 3, 5 * g + 7
             r[OP_TL0], r[OP_TL1] = sh.ttag(p, sh.TO0 + 2 * g), sh.ttag(p, sh.TO0 + 2 * g + 1)
@@ -727,13 +802,14 @@ def opened_main(sh, ws, scs, log_rows):
         put(r, "YLIN", yl), put(r, "YNIN", yn)
         yl, yn = e_add(yl, ext_mul(pw, outs[0])), e_add(yn, ext_mul(pw, outs[1]))
         put(r, "YLO", yl), put(r, "YNO", yn)
-        a2, ab = ext_mul(a, a), ext_mul(a, b)
-        put(r, "A2", a2), put(r, "AB", ab), put(r, "ACCIN", acc)
-        k1, k2, k3 = (g + 1, 2 * g + 3, 5 * g + 7) if active else (0, 0, 0)
-        u1 = e_add(ext_mul(acc, al), e_sub(e_sub(c, ext_mul(a2, b)), [k1, 0, 0, 0]))
-        u2 = e_add(ext_mul(u1, al), ext_mul(selt, e_sub(e_sub(e_sub(dn, ab), c), [k2, 0, 0, 0])))
-        acc = e_add(ext_mul(u2, al), ext_mul(self_, e_sub(d, [k3, 0, 0, 0])))
-        put(r, "U1", u1), put(r, "U2", u2), put(r, "ACCO", acc)
+        if not sh.air:
+            a2, ab = ext_mul(a, a), ext_mul(a, b)
+            put(r, "A2", a2), put(r, "AB", ab), put(r, "ACCIN", acc)
+            k1, k2, k3 = (g + 1, 2 * g + 3, 5 * g + 7) if active else (0, 0, 0)
+            u1 = e_add(ext_mul(acc, al), e_sub(e_sub(c, ext_mul(a2, b)), [k1, 0, 0, 0]))
+            u2 = e_add(ext_mul(u1, al), ext_mul(selt, e_sub(e_sub(e_sub(dn, ab), c), [k2, 0, 0, 0])))
+            acc = e_add(ext_mul(u2, al), ext_mul(self_, e_sub(d, [k3, 0, 0, 0])))
+            put(r, "U1", u1), put(r, "U2", u2), put(r, "ACCO", acc)
         pw = pwn
         if active and g == sh.G - 1:
             results.append((yl, yn, acc))
@@ -745,8 +821,15 @@ SC_PRE = 12
 SP_FIRST, SP_KA, SP_KZ, SP_KF, SP_TQZ, SP_PID = 0, 1, 2, 3, 4, 8                 # FIRST: the row is a proof's row (rows behind the proofs repeat row 0: every constraint holds there too)
 
 
+SC_PRE_AIR, SP_KSEL, SP_KONE, SP_MSEL, SP_MONE, SP_Z = 20, 9, 12, 13, 16, 17      # air mode: the selectors and the constant one go to the EVAL chip
+
+
+def sc_pre(sh):
+    return SC_PRE_AIR if sh.air else SC_PRE
+
+
 def scalars_cols(sh):
-    m = Cols(SC_PRE)
+    m = Cols(sc_pre(sh))
     for name in ("ALPHA", "ZETA", "FA"):
         m(name)
     for i in range(1, sh.n + 1):
@@ -766,6 +849,8 @@ def scalars_cols(sh):
         m("HQ%d" % j)
     for name in ("QK0", "QK1", "QUO", "YL", "YN", "ACC"):
         m(name)
+    if sh.air:                                                                  # the last-row selector Z_H(zeta) / (zeta - w^-1): a program may use it
+        m("INVT"), m("SELL")
     return m
 
 
@@ -826,7 +911,10 @@ def scalars_program(sh):
     z0, z1 = eadd(escale(znn, a0), ec(b0)), eadd(escale(znn, a1), ec(b1))
     cons.ext(O.SEL_ALL, esub(e("QUO"), eadd(emul(z0, e("QK0")), emul(z1, e("QK1")))))
     cons.ext(O.SEL_ALL, esub(e("ACC"), emul(e("QUO"), esub(znn, ec(1)))))
-    return O.air_program(SC_PRE + rup4(m.n - SC_PRE), sh.NP * sh.NPUB, cons.c)
+    if sh.air:
+        cons.ext(O.SEL_ALL, esub(emul(e("SELT"), e("INVT")), ec(1)))
+        cons.ext(O.SEL_ALL, esub(e("SELL"), emul(esub(znn, ec(1)), e("INVT"))))
+    return O.air_program(sc_pre(sh) + rup4(m.n - sc_pre(sh)), sh.NP * sh.NPUB, cons.c)
 
 
 def scalars_table(sh):
@@ -838,13 +926,20 @@ def scalars_table(sh):
     it += [(SEND, SP_FIRST, BUS_K0 + i, [SP_PID] + _e4(m[name])) for i, name in enumerate(("ZETA", "ZNX", "YL", "YN", "HQ0", "OFFN", "OFFQ"))]
     it += [(SEND, SP_FIRST, BUS_KFA, [SP_PID] + _e4(m["FA"]))]
     it += [(SEND, SP_FIRST, BUS_KO0 + i, [SP_PID] + _e4(m[name])) for i, name in enumerate(("FA", "FP2", "ALPHA", "SELT", "SELF"))]
+    if sh.air:
+        it += [(SEND, SP_MSEL + i, BUS_VAL, [SP_KSEL + i] + _e4(m[name])) for i, name in enumerate(("SELF", "SELL", "SELT"))]
+        it += [(SEND, SP_MONE, BUS_VAL, [SP_KONE, SP_FIRST, SP_Z, SP_Z, SP_Z]), (SEND, SP_FIRST, BUS_EA, [SP_PID] + _e4(m["ALPHA"]))]
     return O.interaction_table(it)
 
 
 def scalars_pre(sh, log_rows):
-    t = np.zeros((1 << log_rows, SC_PRE), dtype=np.uint32)
+    t = np.zeros((1 << log_rows, sc_pre(sh)), dtype=np.uint32)
     for p in range(sh.NP):
         t[p, SP_FIRST], t[p, SP_PID] = 1, p
+        if sh.air:
+            for i in range(3):
+                t[p, SP_KSEL + i], t[p, SP_MSEL + i] = p * sh.KSPAN + sh.key_sel(i), sh.mult[sh.key_sel(i)]
+            t[p, SP_KONE], t[p, SP_MONE] = p * sh.KSPAN, sh.mult[0]
         t[p, SP_KA], t[p, SP_KZ], t[p, SP_KF] = 3 * p, 3 * p + 1, 3 * p + 2
         for i in range(4):
             t[p, SP_TQZ + i] = sh.ttag(p, sh.TO0 + sh.W + i)
@@ -895,18 +990,93 @@ def scalars_values(sh, w, chal):
     m["QUO"] = e_add(ext_mul(z0, m["QK0"]), ext_mul(z1, m["QK1"]))
     m["FA4"], m["YQ"] = m["FP2"], m["HQ0"]
     m["ZNN"] = znn
+    if sh.air:
+        m["INVT"] = pyref.ext_inv(m["SELT"])
+        m["SELL"] = ext_mul(e_sub(znn, [1, 0, 0, 0]), m["INVT"])
     return m
 
 
 def scalars_main(sh, scs, log_rows):
     m = scalars_cols(sh)
-    width = rup4(m.n - SC_PRE)
+    base = sc_pre(sh)
+    width = rup4(m.n - base)
     t = np.zeros((1 << log_rows, width), dtype=np.uint64)
     for r in range(1 << log_rows):
         sc = scs[r] if r < sh.NP else scs[0]
         for name, col in m.at.items():
-            t[r, col - SC_PRE:col - SC_PRE + 4] = sc[name]
+            t[r, col - base:col - base + 4] = sc[name]
     return t.astype(np.uint32)
+
+
+# ---------------------------------------------------------------------------------------------------------------- EVAL (air mode)
+# One row per TERM of the inner program: coeff x F1 x F2 x F3, the three factor values received over BUS_VAL by their preprocessed keys (an opened
+# value at zeta / zeta g from OPENED, a public value from TS, a selector or the constant one from SCALARS); the fold of the constraints with alpha
+# runs down the rows: where a constraint's first term stands, ACC is multiplied by alpha first.
+EV_PRE = 12
+EP_COEF, EP_K0, EP_FIRSTC, EP_ACT, EP_LAST, EP_PID, EP_NFC, EP_PFIRST = 0, 1, 4, 5, 6, 7, 8, 9
+EV_F0, EV_M, EV_TV, EV_ACCIN, EV_ACCO, EV_ALPHA, EV_MAIN = 0, 12, 16, 20, 24, 28, 32
+
+
+def eval_program(sh):
+    M0 = EV_PRE
+    cons = Cons()
+    f0, f1, f2, mm, tv, ai, ao, al = (ev(M0 + c) for c in (EV_F0, EV_F0 + 4, EV_F0 + 8, EV_M, EV_TV, EV_ACCIN, EV_ACCO, EV_ALPHA))
+    cons.ext(O.SEL_ALL, esub(mm, emul(f0, f1)))
+    cons.ext(O.SEL_ALL, esub(tv, egate(pv(EP_COEF), emul(mm, f2))))
+    cons.ext(O.SEL_ALL, esub(ao, eadd(ai, egate(pv(EP_FIRSTC), esub(emul(ai, al), ai)), tv)))
+    cons.ext(O.SEL_TRANSITION, egate(pv(EP_NFC, True), esub(ev(M0 + EV_ACCIN, True), ao)))
+    cons.ext(O.SEL_ALL, egate(pv(EP_PFIRST), ai))
+    cons.ext(O.SEL_TRANSITION, egate(pv(EP_NFC, True), esub(ev(M0 + EV_ALPHA, True), al)))
+    return O.air_program(EV_PRE + EV_MAIN, sh.NP * sh.NPUB, cons.c)
+
+
+def eval_table():
+    M0 = EV_PRE
+    it = [(RECV, EP_ACT, BUS_VAL, [EP_K0 + j] + _e4(M0 + EV_F0 + 4 * j)) for j in range(3)]
+    it += [(RECV, EP_PFIRST, BUS_EA, [EP_PID] + _e4(M0 + EV_ALPHA)), (SEND, EP_LAST, BUS_OA, [EP_PID] + _e4(M0 + EV_ACCO))]
+    return O.interaction_table(it)
+
+
+def eval_pre(sh, log_rows):
+    t = np.zeros((1 << log_rows, EV_PRE), dtype=np.uint32)
+    nt = len(sh.terms)
+    for p in range(sh.NP):
+        for i, (coeff, keys, first) in enumerate(sh.terms):
+            r = t[p * nt + i]
+            r[EP_COEF], r[EP_FIRSTC], r[EP_ACT], r[EP_LAST], r[EP_PID] = coeff, first, 1, int(i + 1 == nt), p
+            r[EP_K0:EP_K0 + 3] = [p * sh.KSPAN + k for k in keys]
+            r[EP_NFC], r[EP_PFIRST] = int(i > 0), int(i == 0)
+    return t
+
+
+def eval_main(sh, ws, scs, public_values, log_rows):
+    """-> (trace, per proof the program folded with alpha at zeta)"""
+    t = np.zeros((1 << log_rows, EV_MAIN), dtype=np.uint64)
+    nt, W = len(sh.terms), sh.W
+    accs = []
+    for p, (w, sc, pubs) in enumerate(zip(ws, scs, public_values)):
+        def value(key):
+            if key == 0:
+                return [1, 0, 0, 0]
+            if key <= W:
+                return list(w["loc"][key - 1])
+            if key <= 2 * W:
+                return list(w["nxt"][key - 1 - W])
+            if key <= 2 * W + sh.NPUB:
+                return [int(pubs[key - 1 - 2 * W]) % P, 0, 0, 0]
+            return [sc["SELF"], sc["SELL"], sc["SELT"]][key - 1 - 2 * W - sh.NPUB]
+        run = [0] * 4
+        for i, (coeff, keys, first) in enumerate(sh.terms):
+            r = t[p * nt + i]
+            f0, f1, f2 = (value(k) for k in keys)
+            mm = ext_mul(f0, f1)
+            tv = [x * coeff % P for x in ext_mul(mm, f2)]
+            r[EV_F0:EV_F0 + 4], r[EV_F0 + 4:EV_F0 + 8], r[EV_F0 + 8:EV_F0 + 12], r[EV_M:EV_M + 4], r[EV_TV:EV_TV + 4] = f0, f1, f2, mm, tv
+            r[EV_ACCIN:EV_ACCIN + 4] = run
+            run = e_add(ext_mul(run, sc["ALPHA"]) if first else run, tv)
+            r[EV_ACCO:EV_ACCO + 4], r[EV_ALPHA:EV_ALPHA + 4] = run, sc["ALPHA"]
+        accs.append(run)
+    return t.astype(np.uint32), accs
 
 
 # ---------------------------------------------------------------------------------------------------------------- FOLD (tests/fri_air.py, rec form)
@@ -919,12 +1089,12 @@ def fold_table(layers):
 
 
 # ---------------------------------------------------------------------------------------------------------------- the witness and the machine
-def witness(proof, log_n, width, public_values, n_queries, pow_bits, sh=None):
+def witness(proof, log_n, width, public_values, n_queries, pow_bits, sh=None, program=None):
     """everything the machine's main columns hold for ONE inner proof, taken from it by the Python verifier (which must accept it)"""
     import pyverify
     view = {}
-    pyverify.verify(proof, log_n, width, public_values, num_queries=n_queries, pow_bits=pow_bits, view=view)
-    sh = sh or Shape(log_n, width, n_queries, pow_bits, len(public_values))
+    pyverify.verify(proof, log_n, width, public_values, num_queries=n_queries, pow_bits=pow_bits, view=view, air=program)
+    sh = sh or Shape(log_n, width, n_queries, pow_bits, len(public_values), program=program)
     w = {"trace_root": view["trace_root"], "quot_root": view["quot_root"], "layer_roots": view["roots"], "final": view["final"], "witness": view["witness"],
          "loc": view["loc"], "nxt": view["nxt"], "qz": view["qz"], "openings": view["openings"], "betas": view["betas"], "view": view}
     # the blocks the transcript absorbs, by sponge row
@@ -954,33 +1124,46 @@ def witness(proof, log_n, width, public_values, n_queries, pow_bits, sh=None):
     return sh, w
 
 
-CHIPS = ("P2R", "ROWSUM", "FOLD", "TS", "QUERY", "OPENED", "SAMPLES", "SCALARS")
+CHIPS = ("P2R", "ROWSUM", "FOLD", "TS", "QUERY", "OPENED", "SAMPLES", "SCALARS", "EVAL")       # (EVAL: air mode only)
+
+
+def chips(sh):
+    return CHIPS if sh.air else CHIPS[:-1]
 
 
 def heights(sh):
     n = sh.NP
-    return {"P2R": lg(n * sh.p2_rows), "ROWSUM": lg(n * sh.Q * (sh.WB + 1)), "FOLD": lg(n * sh.Q * sh.R), "TS": lg(n * sh.NTS), "QUERY": lg(n * sh.Q), "OPENED": lg(n * sh.G),
-            "SAMPLES": lg(n * sh.NS), "SCALARS": lg(n)}
+    h = {"P2R": lg(n * sh.p2_rows), "ROWSUM": lg(n * sh.Q * (sh.WB + 1)), "FOLD": lg(n * sh.Q * sh.R), "TS": lg(n * sh.NTS), "QUERY": lg(n * sh.Q), "OPENED": lg(n * sh.G),
+         "SAMPLES": lg(n * sh.NS), "SCALARS": lg(n)}
+    if sh.air:
+        h["EVAL"] = lg(n * len(sh.terms))
+    return h
 
 
 def order(sh):
     """tallest first; equal heights in the order of CHIPS"""
     h = heights(sh)
-    return sorted(CHIPS, key=lambda c: (-h[c], CHIPS.index(c)))
+    return sorted(chips(sh), key=lambda c: (-h[c], CHIPS.index(c)))
 
 
 def programs(sh):
     npub = sh.NP * sh.NPUB
-    return {"P2R": p2r_program(sh), "ROWSUM": rowsum_program(sh), "FOLD": F.program(sh.R, wired=True, transcript=True, rec=npub), "TS": ts_program(sh),
-            "QUERY": query_program(sh), "OPENED": opened_program(sh), "SAMPLES": F.samples_program(sh.R, sh.Q, sh.PB, npub), "SCALARS": scalars_program(sh)}
+    d = {"P2R": p2r_program(sh), "ROWSUM": rowsum_program(sh), "FOLD": F.program(sh.R, wired=True, transcript=True, rec=npub), "TS": ts_program(sh),
+         "QUERY": query_program(sh), "OPENED": opened_program(sh), "SAMPLES": F.samples_program(sh.R, sh.Q, sh.PB, npub), "SCALARS": scalars_program(sh)}
+    if sh.air:
+        d["EVAL"] = eval_program(sh)
+    return d
 
 
 def tables(sh):
     M0 = F.S_PRE
     s_tab = O.interaction_table([(RECV, F.S_ROW, F.BUS_S0, [F.S_C] + [M0 + F.S_W + j for j in range(4)]), (RECV, F.S_ROW, F.BUS_S1, [F.S_C] + [M0 + F.S_W + j for j in range(4, 8)])]
                                 + [(SEND, F.S_ACT + j, F.BUS_I, [F.S_KQ + j, M0 + F.S_IDX + j]) for j in range(8)])
-    return {"P2R": p2r_table(), "ROWSUM": rowsum_table(), "FOLD": fold_table(sh.R), "TS": ts_table(sh), "QUERY": query_table(), "OPENED": opened_table(),
-            "SAMPLES": s_tab, "SCALARS": scalars_table(sh)}
+    d = {"P2R": p2r_table(), "ROWSUM": rowsum_table(), "FOLD": fold_table(sh.R), "TS": ts_table(sh), "QUERY": query_table(), "OPENED": opened_table(sh),
+         "SAMPLES": s_tab, "SCALARS": scalars_table(sh)}
+    if sh.air:
+        d["EVAL"] = eval_table()
+    return d
 
 
 def samples_stacked(sh, words_per_proof, log_rows):
@@ -1001,8 +1184,11 @@ def preprocessed(sh):
     """the key material: every chip's preprocessed trace (None: the chip has none) -- a function of the shape"""
     h = heights(sh)
     spre, _, _ = samples_stacked(sh, [[[0] * 8] * sh.NS] * sh.NP, h["SAMPLES"])
-    return {"P2R": p2r_pre(sh, h["P2R"]), "ROWSUM": rowsum_pre(sh, h["ROWSUM"]), "FOLD": None, "TS": ts_pre(sh, h["TS"]), "QUERY": query_pre(sh, h["QUERY"]),
-            "OPENED": opened_pre(sh, h["OPENED"]), "SAMPLES": spre, "SCALARS": scalars_pre(sh, h["SCALARS"])}
+    d = {"P2R": p2r_pre(sh, h["P2R"]), "ROWSUM": rowsum_pre(sh, h["ROWSUM"]), "FOLD": None, "TS": ts_pre(sh, h["TS"]), "QUERY": query_pre(sh, h["QUERY"]),
+         "OPENED": opened_pre(sh, h["OPENED"]), "SAMPLES": spre, "SCALARS": scalars_pre(sh, h["SCALARS"])}
+    if sh.air:
+        d["EVAL"] = eval_pre(sh, h["EVAL"])
+    return d
 
 
 def fold_stacked(sh, ws, log_rows):
@@ -1016,7 +1202,7 @@ def fold_stacked(sh, ws, log_rows):
     return t
 
 
-def main_traces(sh, ws):
+def main_traces(sh, ws, public_values=None):
     h = heights(sh)
     p2, samples, chals = p2r_main(sh, ws, h["P2R"])
     scs = []
@@ -1025,6 +1211,10 @@ def main_traces(sh, ws):
         assert [chal[sh.TL0 + l] for l in range(sh.R)] == w["betas"]
         scs.append(scalars_values(sh, w, chal))
     opened, results = opened_main(sh, ws, scs, h["OPENED"])
+    evl = None
+    if sh.air:                                                                  # the fold of the AIR at zeta is the EVAL chip's
+        evl, accs = eval_main(sh, ws, scs, public_values, h["EVAL"])
+        results = [(yl, yn, acc) for (yl, yn, _), acc in zip(results, accs)]
     for sc, (yl, yn, acc) in zip(scs, results):
         sc["YL"], sc["YN"], sc["ACC"] = yl, yn, acc
         assert acc == ext_mul(sc["QUO"], e_sub(sc["ZNN"], [1, 0, 0, 0])), "the AIR identity at zeta does not hold"
@@ -1035,19 +1225,52 @@ def main_traces(sh, ws):
     _, smain, drawn = samples_stacked(sh, samples, h["SAMPLES"])
     assert drawn == [[op["index"] for op in w["openings"]] for w in ws], "the query indices are not the ones the transcript draws"
     ts = ts_main(sh, ws, chals, p2, h["TS"])
-    return {"P2R": p2, "ROWSUM": rs, "FOLD": fold, "TS": ts, "QUERY": qm, "OPENED": opened, "SAMPLES": smain, "SCALARS": scalars_main(sh, scs, h["SCALARS"])}
+    d = {"P2R": p2, "ROWSUM": rs, "FOLD": fold, "TS": ts, "QUERY": qm, "OPENED": opened, "SAMPLES": smain, "SCALARS": scalars_main(sh, scs, h["SCALARS"])}
+    if sh.air:
+        d["EVAL"] = evl
+    return d
 
 
-def machine(proofs, log_n, width, public_values, n_queries, pow_bits):
-    """proofs: ONE inner proof (bytes) with its public values, or a LIST of proofs with a list of public-value lists (the join: one outer proof for all)
+def machine(proofs, log_n, width, public_values, n_queries, pow_bits, program=None):
+    """proofs: ONE inner proof (bytes) with its public values, or a LIST of proofs with a list of public-value lists (the join: one outer proof for all);
+    program: the constraint program of version-7 inner proofs (air mode), None for version-1 proofs of the synthetic AIR
     -> (shape, main traces, preprocessed traces, programs, interaction tables, public values), chips tallest first"""
     if isinstance(proofs, (bytes, bytearray)):
         proofs, public_values = [proofs], [public_values]
-    sh = Shape(log_n, width, n_queries, pow_bits, len(public_values[0]), len(proofs))
-    ws = [witness(pr, log_n, width, pv, n_queries, pow_bits, sh)[1] for pr, pv in zip(proofs, public_values)]
+    sh = Shape(log_n, width, n_queries, pow_bits, len(public_values[0]), len(proofs), program=program)
+    ws = [witness(pr, log_n, width, pv, n_queries, pow_bits, sh, program)[1] for pr, pv in zip(proofs, public_values)]
     names = order(sh)
-    mt, pre, prog, tab = main_traces(sh, ws), preprocessed(sh), programs(sh), tables(sh)
+    mt, pre, prog, tab = main_traces(sh, ws, public_values), preprocessed(sh), programs(sh), tables(sh)
     return sh, [mt[c] for c in names], [pre[c] for c in names], [prog[c] for c in names], [tab[c] for c in names], [int(v) % P for pv in public_values for v in pv]
+
+
+# ---------------------------------------------------------------------------------------------------------------- a small inner program for the tests
+def counter_program(width=8):
+    """a small program that uses everything a program can: the three selectors, public values, a next-row variable, a degree-three term"""
+    v = O.air_var
+
+    def pub(i):
+        return O.air_var(i, public=True)
+    cons = [(O.SEL_FIRST, [(1, [v(0)]), (P - 1, [pub(0)])]),                                      # first row: c0 = pub0
+            (O.SEL_TRANSITION, [(1, [v(0, True)]), (P - 1, [v(0)]), (P - 1, [])]),              # c0' = c0 + 1
+            (O.SEL_LAST, [(1, [v(0)]), (P - 1, [pub(1)])]),                                       # last row: c0 = pub1
+            (O.SEL_ALL, [(1, [v(1)]), (P - 1, [v(0), v(0)])]),                                    # c1 = c0^2
+            (O.SEL_ALL, [(1, [v(2)]), (P - 3, [v(0), v(1), v(0)]), (P - 5, [pub(2)])]),         # c2 = 3 c0^2 c1 + 5 pub2
+            (O.SEL_TRANSITION, [(1, [v(3, True)]), (P - 1, [v(3), v(width - 1)])])]               # c3' = c3 c7
+    return O.air_program(width, 3, cons)
+
+
+def counter_trace(log_n, width, start, pub2, seed=3):
+    rng = np.random.default_rng(seed)
+    t = rng.integers(0, P, size=(1 << log_n, width), dtype=np.uint64)
+    for r in range(1 << log_n):
+        c0 = (start + r) % P
+        t[r, 0], t[r, 1] = c0, c0 * c0 % P
+        t[r, 2] = (3 * c0 * c0 % P * int(t[r, 1]) + 5 * pub2) % P
+        if r:
+            t[r, 3] = int(t[r - 1, 3]) * int(t[r - 1, width - 1]) % P
+    return t.astype(np.uint32), [start % P, (start + (1 << log_n) - 1) % P, pub2]
+
 
 
 # ---------------------------------------------------------------------------------------------------------------- checks in plain integers

@@ -162,3 +162,123 @@ def test_the_largest_join_a_poseidon2_chip_of_2_pow_22_rows(ctx):
     assert verify_shard_recursive(outer, log_n, width, q, pb, flat, key.root, prm, n_proofs=n)[0] != 0
     assert outer.size * 60 < sum(x.size for x in inner)
     key.close()
+
+
+# ---------------------------------------------------------------------------------------------------------------- air mode: version-7 inner proofs
+def _sha_statement(digest, message_len):
+    """the 91 public values of "digest = SHA-256 of a message of message_len bytes": what the verifier of a joined proof derives by itself"""
+    from zktls_amd.device import sha256_padding_publics
+    limbs = []
+    for i in range(8):
+        w = int.from_bytes(digest[4 * i:4 * i + 4], "big")
+        limbs += [w & 0xffff, w >> 16]
+    return limbs + sha256_padding_publics(message_len).tolist()
+
+
+@pytest.mark.parametrize("kind,log_n,width,q,pb,nproofs", [("synthetic", 5, 8, 4, 3, 1), ("counter", 6, 16, 3, 2, 2), ("counter", 5, 8, 2, 0, 3), ("synthetic", 9, 64, 6, 4, 1)])
+def test_air_mode_key_and_proof_bytes_equal_the_oracles(ctx, oracle, kind, log_n, width, q, pb, nproofs):
+    """inner proofs of a constraint PROGRAM (version 7: zkhip_prove_shard_air) verified in-circuit: the machine of (shape, program) with the EVAL
+    chip -- key and outer proof bytes against the oracle on the restatement's arrays; one proof and joins"""
+    import recursion_air as R
+    from zktls_amd.device import shard_verifier_key_host, verify_shard_air
+    O = oracle
+    iprm, oprm, prm = Params(1, q, pb), O.default_params(1, 20, 8), Params(1, 20, 8)
+    inner, pubs = [], []
+    for p in range(nproofs):
+        if kind == "synthetic":
+            pv_, prog = [4, 5, 6 + p], O.air_synthetic(width, 3)
+            tr = ctx.gen_trace(SEED, 30 + p, log_n, width)
+        else:
+            prog = R.counter_program(width)
+            t, pv_ = R.counter_trace(log_n, width, 500 + 9 * p, 70 + p, seed=p)
+            tr = ctx.alloc(t.size)
+            tr.upload(t)
+        inner.append(ctx.prove_shard_air(prog, tr, log_n, width, pv_, iprm))
+        assert verify_shard_air(prog, inner[-1], log_n, width, pv_, iprm)[0] == 0
+        pubs.append(pv_)
+    key = ctx.shard_verifier_setup(log_n, width, q, pb, 3, prm, n_proofs=nproofs, program=prog)
+    sh, mains, pres, progs, tabs, pv = R.machine([x.tobytes() for x in inner], log_n, width, pubs, q, pb, program=prog)
+    lns = [m.shape[0].bit_length() - 1 for m in mains]
+    assert key.root.tolist() == O.machine_setup(pres, lns, oprm).tolist(), "the key differs from the oracle's commitment to the restatement's preprocessed traces"
+    assert shard_verifier_key_host(log_n, width, q, pb, 3, prm, nproofs, program=prog).tolist() == key.root.tolist()
+    outer = ctx.prove_shard_verifier(key, inner, log_n, width, pubs, iprm, prm, program=prog)
+    assert outer.tobytes() == O.prove_machine_keyed(mains, pres, progs, tabs, pv, oprm).tobytes(), "outer proof bytes differ from the oracle's"
+    assert verify_shard_recursive(outer, log_n, width, q, pb, pv, key.root, prm, n_proofs=nproofs, program=prog) == (0, 0)
+    assert O.verify_machine_keyed(outer, lns, [m.shape[1] for m in mains], [0 if p is None else p.shape[1] for p in pres], key.root, progs, tabs, pv, oprm) == 0
+    other = list(pv)
+    other[-1] += 1
+    assert verify_shard_recursive(outer, log_n, width, q, pb, other, key.root, prm, n_proofs=nproofs, program=prog)[0] != 0
+    assert verify_shard_recursive(outer, log_n, width, q, pb, pv, key.root, prm, n_proofs=nproofs)[0] != 0              # the version-1 machine's verifier
+    # the prover refuses: a flipped byte of an inner proof, other public values than the proof's, the key of another program
+    bad = inner[0].copy()
+    bad[bad.size // 2] ^= 1
+    with pytest.raises(ZkHipError):
+        ctx.prove_shard_verifier(key, [bad] + inner[1:], log_n, width, pubs, iprm, prm, program=prog)
+    with pytest.raises(ZkHipError):
+        ctx.prove_shard_verifier(key, inner, log_n, width, [pubs[0][:2] + [pubs[0][2] + 1]] + pubs[1:], iprm, prm, program=prog)
+    if kind == "counter":
+        prog2 = prog.copy()
+        prog2[-4] = (int(prog2[-4]) + 1) % R.P
+        with pytest.raises(ZkHipError):
+            ctx.prove_shard_verifier(key, inner, log_n, width, pubs, iprm, prm, program=prog2)
+    key.close()
+
+
+def test_air_mode_a_sha256_proof_verified_in_circuit_bytes_equal_the_oracles(ctx, oracle):
+    """zkhip_prove_sha256's proof of "digest = SHA-256 of a message of 100 bytes" (2^6 x 640, the chip's 815 constraints) -> an outer proof that a
+    verifier checks from (the chip's program, digest, length, key).  Bytes against the oracle on the restatement's arrays."""
+    import hashlib
+    import recursion_air as R
+    from zktls_amd.device import sha256_air, verify_sha256
+    O = oracle
+    q, pb = 3, 2
+    iprm, oprm, prm = Params(1, q, pb), O.default_params(1, 20, 8), Params(1, 20, 8)
+    msg = bytes((5 * i + 1) & 0xff for i in range(100))
+    prog = sha256_air()
+    digest, inner = ctx.prove_sha256(msg, iprm)
+    assert digest == hashlib.sha256(msg).digest() and verify_sha256(inner, digest, iprm, len(msg)) == (0, 0)
+    pubs = _sha_statement(digest, len(msg))
+    log_n = 6
+    key = ctx.shard_verifier_setup(log_n, 640, q, pb, 91, prm, program=prog)
+    sh, mains, pres, progs, tabs, pv = R.machine(inner.tobytes(), log_n, 640, pubs, q, pb, program=prog)
+    lns = [m.shape[0].bit_length() - 1 for m in mains]
+    assert key.root.tolist() == O.machine_setup(pres, lns, oprm).tolist()
+    outer = ctx.prove_shard_verifier(key, inner, log_n, 640, pubs, iprm, prm, program=prog)
+    assert outer.tobytes() == O.prove_machine_keyed(mains, pres, progs, tabs, pv, oprm).tobytes(), "outer proof bytes differ from the oracle's"
+    assert verify_shard_recursive(outer, log_n, 640, q, pb, pubs, key.root, prm, program=prog) == (0, 0)
+    assert verify_shard_recursive(outer, log_n, 640, q, pb, _sha_statement(hashlib.sha256(msg + b"x").digest(), len(msg)), key.root, prm, program=prog)[0] != 0
+    assert verify_shard_recursive(outer, log_n, 640, q, pb, _sha_statement(digest, len(msg) + 1), key.root, prm, program=prog)[0] != 0
+    key.close()
+
+
+def test_air_mode_sixty_four_transcript_proofs_become_one_proof(ctx):
+    """BASELINE configs[2]'s unit of work in small: 64 TLS-transcript-sized messages (13 221 bytes: 2^14 x 640 rows each), each proven by
+    zkhip_prove_sha256 (20 queries), all 64 verified in-circuit by ONE outer proof.  Its verifier is handed the chip's program, the 64
+    (digest, length) pairs and the key (derived on the host: no device)."""
+    import hashlib
+    from zktls_amd.device import sha256_air, shard_verifier_key_host, shard_verifier_max_proofs
+    n, nbytes, q, pb = 64, 13221, 20, 8
+    iprm, prm = Params(1, q, pb), Params(1, 20, 8)
+    prog = sha256_air()
+    msgs = [bytes((7 * i + 3 * p + 1) & 0xff for i in range(nbytes)) for p in range(n)]
+    inner, pubs = [], []
+    for m in msgs:
+        d, pf = ctx.prove_sha256(m, iprm)
+        assert d == hashlib.sha256(m).digest()
+        inner.append(pf), pubs.append(_sha_statement(d, len(m)))
+    log_n = 14
+    assert shard_verifier_max_proofs(log_n, 640, q, pb, 91, prm, program=prog) >= n
+    key = ctx.shard_verifier_setup(log_n, 640, q, pb, 91, prm, n_proofs=n, program=prog)
+    assert shard_verifier_key_host(log_n, 640, q, pb, 91, prm, n, program=prog).tolist() == key.root.tolist()
+    outer = ctx.prove_shard_verifier(key, inner, log_n, 640, pubs, iprm, prm, program=prog)
+    flat = [v for p in pubs for v in p]
+    assert verify_shard_recursive(outer, log_n, 640, q, pb, flat, key.root, prm, n_proofs=n, program=prog) == (0, 0)
+    total = sum(x.size for x in inner)
+    assert outer.size * 4 < total, "the join does not compress"
+    bad = list(flat)
+    bad[91 * 17 + 2] ^= 1                                              # proof 17's digest
+    assert verify_shard_recursive(outer, log_n, 640, q, pb, bad, key.root, prm, n_proofs=n, program=prog)[0] != 0
+    bad = flat[:91 * 40] + _sha_statement(hashlib.sha256(msgs[40]).digest(), nbytes - 1) + flat[91 * 41:]      # proof 40: another length
+    assert verify_shard_recursive(outer, log_n, 640, q, pb, bad, key.root, prm, n_proofs=n, program=prog)[0] != 0
+    print("64 transcript proofs: %d bytes -> %d bytes" % (total, outer.size))
+    key.close()

@@ -149,3 +149,154 @@ def test_oracle_proves_the_machine_and_three_verifiers_take_no_byte_of_the_inner
     bad = op.copy()
     bad[len(bad) // 2] ^= 1
     assert verify_shard_recursive(bad, log_n, width, q, pb, pv, vk, prm)[0] != 0
+
+
+# ---------------------------------------------------------------------------------------------------------------- air mode (version-7 inner proofs)
+# The inner proofs are proofs of a constraint PROGRAM (zkhip_prove_shard_air, zkhip_prove_sha256 ...): the machine of (shape, program) has a ninth
+# chip, EVAL, one row per term of that program (csrc/shard_verifier.inl "AIR MODE").
+def air_inner(O, kind, log_n, width, q, pb, shard=0):
+    """-> (program, proof bytes, public values)"""
+    if kind == "synthetic":
+        pubs = [4, 5, 6 + shard]
+        prog = O.air_synthetic(width, len(pubs))
+        t = O.gen_trace(SEED, shard, log_n, width)
+    else:
+        prog = R.counter_program(width)
+        t, pubs = R.counter_trace(log_n, width, 1000 + 77 * shard, 9 + shard, seed=shard)
+    return prog, O.prove_shard_air(prog, t, pubs, O.default_params(1, q, pb)).tobytes(), pubs
+
+
+AIR_SHAPES = [("synthetic", 5, 8, 4, 3), ("counter", 5, 8, 3, 2), ("counter", 6, 16, 2, 0), ("synthetic", 5, 24, 1, 1)]
+
+
+@pytest.mark.parametrize("kind,log_n,width,q,pb", AIR_SHAPES)
+def test_air_mode_programs_hold_and_buses_balance(oracle, kind, log_n, width, q, pb):
+    prog, proof, pubs = air_inner(oracle, kind, log_n, width, q, pb)
+    sh, mains, pres, progs, tabs, pv = R.machine(proof, log_n, width, pubs, q, pb, program=prog)
+    assert "EVAL" in R.order(sh)
+    for name, main, pre, pr in zip(R.order(sh), mains, pres, progs):
+        rows = main if pre is None else np.concatenate([pre, main], axis=1)
+        assert rows.shape[1] == int(pr[2])
+        assert S.check_rows(pr, rows, pv) == [], name
+    assert R.bus_balance(mains, pres, tabs) == []
+
+
+def test_air_mode_a_flipped_cell_breaks_a_constraint_or_a_bus(oracle):
+    kind, log_n, width, q, pb = AIR_SHAPES[1]
+    prog, proof, pubs = air_inner(oracle, kind, log_n, width, q, pb)
+    sh, mains, pres, progs, tabs, pv = R.machine(proof, log_n, width, pubs, q, pb, program=prog)
+    names = R.order(sh)
+    rng = np.random.default_rng(11)
+    for name in ("EVAL", "OPENED", "SCALARS", "TS"):
+        i = names.index(name)
+        used = {"TS": sh.NTS, "OPENED": sh.G, "SCALARS": 1, "EVAL": len(sh.terms)}[name]
+        for _ in range(8):
+            r, c = int(rng.integers(0, used)), int(rng.integers(0, mains[i].shape[1]))
+            keep = int(mains[i][r, c])
+            mains[i][r, c] = (keep + 1) % R.P
+            rows = mains[i] if pres[i] is None else np.concatenate([pres[i], mains[i]], axis=1)
+            broken = bool(S.check_rows(progs[i], rows, pv)) or bool(R.bus_balance(mains, pres, tabs))
+            mains[i][r, c] = keep
+            oc = R.opened_cols(R.op_pre(sh))
+            unused = {"OPENED": c >= oc["YNO"] + 4 - R.op_pre(sh), "SCALARS": c >= R.scalars_cols(sh).n - R.sc_pre(sh),
+                      "TS": (c >= 8 and c < 16 and r != 0) or (c >= 16 and not (r in (sh.TA, sh.TQ, sh.TF) or sh.TL0 <= r < sh.TP))}.get(name, False)
+            assert broken or unused, (name, r, c)
+    # a term's coefficient, a factor's key, where a constraint starts: all KEY material -- another program is another key (below); a value
+    # that reaches a factor slot from nowhere has no sender
+    i = names.index("EVAL")
+    mains[i][0, R.EV_F0 + 8] = (int(mains[i][0, R.EV_F0 + 8]) + 1) % R.P
+    assert R.bus_balance(mains, pres, tabs)
+
+
+def test_air_mode_product_machine_equals_the_restatement_word_for_word():
+    from zktls_amd.device import shard_verifier_describe, sha256_air
+    import oracle_lib as O
+    cases = [(5, 8, 4, 3, 1, O.air_synthetic(8, 3)), (5, 8, 3, 2, 2, R.counter_program(8)), (6, 16, 2, 0, 3, R.counter_program(16)), (7, 64, 5, 1, 1, O.air_synthetic(64, 0)),
+             (10, 8, 2, 1, 65, R.counter_program(8)), (6, 640, 2, 1, 1, sha256_air()), (14, 640, 20, 8, 2, sha256_air())]
+    for log_n, width, q, pb, nproofs, prog in cases:
+        npub = int(prog[4])
+        sh = R.Shape(log_n, width, q, pb, npub, nproofs, program=prog)
+        names, progs, tabs, pres, h = R.order(sh), R.programs(sh), R.tables(sh), R.preprocessed(sh), R.heights(sh)
+        assert len(names) == 9
+        for i, nm in enumerate(names):
+            p, ln, mw, pw = shard_verifier_describe(log_n, width, q, pb, npub, i, 0, nproofs, program=prog)
+            t, _, _, _ = shard_verifier_describe(log_n, width, q, pb, npub, i, 1, nproofs, program=prog)
+            e, _, _, _ = shard_verifier_describe(log_n, width, q, pb, npub, i, 2, nproofs, program=prog)
+            assert ln == h[nm] and np.array_equal(p, np.asarray(progs[nm], dtype=np.uint32)), (nm, "program", width, nproofs)
+            assert np.array_equal(t, np.asarray(tabs[nm], dtype=np.uint32)), (nm, "table", width, nproofs)
+            want = np.zeros(0, dtype=np.uint32) if pres[nm] is None else pres[nm].ravel()
+            assert np.array_equal(e, want) and pw == (0 if pres[nm] is None else pres[nm].shape[1]), (nm, "preprocessed", width, nproofs)
+
+
+def test_air_mode_host_key_equals_the_oracles_key(oracle):
+    from zktls_amd._lib import Params
+    from zktls_amd.device import shard_verifier_key_host
+    for log_n, width, q, pb, nproofs, prog in ((5, 8, 4, 3, 1, oracle.air_synthetic(8, 3)), (5, 8, 3, 2, 2, R.counter_program(8)), (6, 16, 2, 0, 3, R.counter_program(16))):
+        npub = int(prog[4])
+        sh = R.Shape(log_n, width, q, pb, npub, nproofs, program=prog)
+        names, pres, h = R.order(sh), R.preprocessed(sh), R.heights(sh)
+        pl, lns = [pres[n] for n in names], [h[n] for n in names]
+        for blow, nq, pw in ((1, 20, 8), (2, 10, 4)):
+            want = [int(x) for x in oracle.machine_setup(pl, lns, oracle.default_params(blow, nq, pw))]
+            assert shard_verifier_key_host(log_n, width, q, pb, npub, Params(blow, nq, pw), nproofs, program=prog).tolist() == want, (log_n, width, nproofs, blow)
+    # the key is a function of the program: one coefficient changed is another key
+    prog = R.counter_program(8)
+    other = prog.copy()
+    other[-4] = (int(other[-4]) + 1) % R.P
+    a = shard_verifier_key_host(5, 8, 3, 2, 3, Params(1, 20, 8), 1, program=prog).tolist()
+    assert a != shard_verifier_key_host(5, 8, 3, 2, 3, Params(1, 20, 8), 1, program=other).tolist()
+    assert a != shard_verifier_key_host(5, 8, 3, 2, 3, Params(1, 20, 8), 1).tolist()
+
+
+def test_air_mode_the_oracle_proves_the_join_and_three_verifiers_accept(oracle):
+    """two version-7 proofs of one program -> ONE outer proof; checked from (program, public values of both, key): no byte of an inner proof.
+    Refused: other public values, the values swapped, another program's key, another key, the version-1 machine's entry"""
+    import pyverify_chips
+    from zktls_amd._lib import Params
+    from zktls_amd.device import verify_shard_recursive, shard_verifier_key_host
+    O = oracle
+    kind, log_n, width, q, pb = AIR_SHAPES[1]
+    oprm, prm = O.default_params(1, 20, 8), Params(1, 20, 8)
+    for nproofs in (1, 2):
+        made = [air_inner(O, kind, log_n, width, q, pb, shard=p) for p in range(nproofs)]
+        prog, proofs, pubs = made[0][0], [m[1] for m in made], [m[2] for m in made]
+        sh, mains, pres, progs, tabs, pv = R.machine(proofs, log_n, width, pubs, q, pb, program=prog)
+        lns = [m.shape[0].bit_length() - 1 for m in mains]
+        widths, pws = [m.shape[1] for m in mains], [0 if p is None else p.shape[1] for p in pres]
+        vk = O.machine_setup(pres, lns, oprm)
+        op = O.prove_machine_keyed(mains, pres, progs, tabs, pv, oprm)
+        assert O.verify_machine_keyed(op, lns, widths, pws, vk, progs, tabs, pv, oprm) == 0
+        assert verify_shard_recursive(op, log_n, width, q, pb, pv, vk, prm, n_proofs=nproofs, program=prog) == (0, 0)
+        assert pyverify_chips.verify(op.tobytes(), lns, widths, pv, log_blowup=1, num_queries=20, pow_bits=8, programs=progs, tables=tabs, pre_widths=pws, pre_root=[int(x) for x in vk]) is True
+        bad = list(pv)
+        bad[2] = (bad[2] + 1) % R.P
+        assert verify_shard_recursive(op, log_n, width, q, pb, bad, vk, prm, n_proofs=nproofs, program=prog)[0] != 0
+        if nproofs == 2:
+            assert verify_shard_recursive(op, log_n, width, q, pb, pubs[1] + pubs[0], vk, prm, n_proofs=2, program=prog)[0] != 0
+        other = prog.copy()
+        other[-4] = (int(other[-4]) + 1) % R.P
+        # (a coefficient lives in the KEY alone -- the EVAL chip's preprocessed columns: a verifier takes the key of the program it means, and
+        # can derive it without a device)
+        assert shard_verifier_key_host(log_n, width, q, pb, len(pubs[0]), prm, nproofs, program=prog).tolist() == [int(x) for x in vk]
+        vk_other = shard_verifier_key_host(log_n, width, q, pb, len(pubs[0]), prm, nproofs, program=other)
+        assert verify_shard_recursive(op, log_n, width, q, pb, pv, vk_other, prm, n_proofs=nproofs, program=other)[0] != 0
+        assert verify_shard_recursive(op, log_n, width, q, pb, pv, (vk + 1) % R.P, prm, n_proofs=nproofs, program=prog)[0] != 0
+        assert verify_shard_recursive(op, log_n, width, q, pb, pv, vk, prm, n_proofs=nproofs)[0] != 0
+
+
+def test_air_mode_a_sha256_proof_in_the_machine(oracle):
+    """the SHA-256 chip's program (815 constraints, 5 192 terms, 91 public values, all three selectors) as the inner statement: an oracle-made proof of
+    "digest = SHA-256 of a message of 100 bytes" -> the machine's rows hold, every bus balances"""
+    import hashlib
+    msg = bytes(range(100))
+    prog = S.program()
+    t, pub = S.trace(S.pad(msg))
+    assert S.digest_bytes(pub) == hashlib.sha256(msg).digest()
+    log_n, q, pb = t.shape[0].bit_length() - 1, 2, 1
+    proof = oracle.prove_shard_air(prog, t, pub, oracle.default_params(1, q, pb)).tobytes()
+    sh, mains, pres, progs, tabs, pv = R.machine(proof, log_n, S.WIDTH, pub, q, pb, program=prog)
+    assert len(sh.terms) == 5192 and R.heights(sh)["EVAL"] == 13
+    for name, main, pre, pr in zip(R.order(sh), mains, pres, progs):
+        rows = main if pre is None else np.concatenate([pre, main], axis=1)
+        assert S.check_rows(pr, rows, pv) == [], name
+    assert R.bus_balance(mains, pres, tabs) == []

@@ -1218,9 +1218,13 @@ def machine_key_host(traces, log_ns, params=None):
     return root
 
 
-def shard_verifier_max_proofs(log_n, width, n_queries, inner_pow_bits, n_public, outer=None):
-    """zkhip_shard_verifier_max_proofs (host): how many shard proofs of this shape ONE join takes (outer: the outer proof's params; None = blowup 2)"""
-    return int(_lib.load().zkhip_shard_verifier_max_proofs(log_n, width, n_queries, inner_pow_bits, n_public, C.byref(outer) if outer is not None else None))
+def shard_verifier_max_proofs(log_n, width, n_queries, inner_pow_bits, n_public, outer=None, program=None):
+    """zkhip_shard_verifier_max_proofs[_air] (host): how many shard proofs of this shape ONE join takes (outer: the outer proof's params; None = blowup 2)"""
+    o = C.byref(outer) if outer is not None else None
+    if program is None:
+        return int(_lib.load().zkhip_shard_verifier_max_proofs(log_n, width, n_queries, inner_pow_bits, n_public, o))
+    pg = np.ascontiguousarray(program, dtype=np.uint32)
+    return int(_lib.load().zkhip_shard_verifier_max_proofs_air(pg.ctypes.data_as(u32p), pg.size, log_n, width, n_queries, inner_pow_bits, n_public, o))
 
 
 def shard_verifier_describe(log_n, width, n_queries, inner_pow_bits, n_public, which, kind, n_proofs=1, program=None):
