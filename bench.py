@@ -648,7 +648,7 @@ def main():
                    "one_stream_per_worker_ms": round(t_plain * 1e3, 2), "one_stream_per_worker_in_flight": 16,
                    "same_bytes_both_ways": bool(same), "digests_and_last_proof_verified": bool(ok64),
                    "proof_bytes": int(res_l[0][1].size)}
-        # ... and the 64 statements as ONE proof: each message proven by zkhip_prove_sha256 (a version-7 proof of the chip's constraint program, the
+        # ... and the 64 statements as ONE proof: each message proven as zkhip_prove_sha256 does (zkhip_prove_transcripts_air: a version-7 proof of the chip's constraint program, the
         # same 100 queries / 16 PoW bits), the 64 proofs verified in-circuit by one zkhip_prove_shard_verifier_air call (nine chips: the EVAL
         # chip evaluates the SHA-256 program's 5 192 terms per proof).  The outer proof's verifier takes the program, 64 x (digest, length), the key.
         from zktls_amd.device import sha256_air, sha256_padding_publics, shard_verifier_max_proofs, verify_shard_recursive as _vsr
@@ -665,7 +665,7 @@ def main():
             ckey64 = ctx.shard_verifier_setup(s_log_n, 640, tprm.num_queries, tprm.pow_bits, 91, tprm, n_proofs=64, program=sprog)
             for _ in range(3):
                 tb0 = time.perf_counter()
-                made = [ctx.prove_sha256(m, tprm) for m in msgs]
+                made = prove_transcripts(msgs, tprm, devices=[local_rank], keyed=False)[1]
                 tb1 = time.perf_counter()
                 sinner, spubs = [pf for _, pf in made], [statement(d, len(m)) for (d, _), m in zip(made, msgs)]
                 tb2 = time.perf_counter()
@@ -676,7 +676,7 @@ def main():
             ok_c = _vsr(joined64, s_log_n, 640, tprm.num_queries, tprm.pow_bits, [v for pv_ in spubs for v in pv_], ckey64.root, tprm, n_proofs=64, program=sprog) == (0, 0)
             t_cv = time.perf_counter() - tb0
             ckey64.close()
-            batch64["compressed"] = {"workload": "the 64 transcripts -> ONE proof: 64 x zkhip_prove_sha256 (2^14 x 640, 100 queries, one after the other on one stream), then zkhip_prove_shard_verifier_air with n_proofs = 64",
+            batch64["compressed"] = {"workload": "the 64 transcripts -> ONE proof: zkhip_prove_transcripts_air (64 version-7 proofs of the chip alone, 2^14 x 640, 100 queries, lock-step lanes), then zkhip_prove_shard_verifier_air with n_proofs = 64",
                                      "inner_ms": round(t_inner * 1e3, 2), "compress_ms": round(t_cmp * 1e3, 2), "ms": round((t_inner + t_cmp) * 1e3, 2),
                                      "inner_bytes_total": int(sum(x.size for x in sinner)), "bytes": int(joined64.size), "compression": round(sum(x.size for x in sinner) / joined64.size, 2),
                                      "host_verify_ms": round(t_cv * 1e3, 2), "verified": bool(ok_c),

@@ -562,7 +562,7 @@ int zkhip_verify_machine_keyed(const uint8_t* proof, size_t len, const int32_t* 
 
 /* A message of ANY length as a CHAIN of shard proofs -- the reference's large-transcript configuration (BASELINE.json configs[3]: a
  * megabyte-scale response body, 1 -> 8 GPUs) with a real statement per shard.  The chained program (zkhip_sha256_air_chained) is the chip
- * with its initial chaining value PUBLIC as well: 32 public values = the final chaining value's 16 limbs, then the initial one's.  Shard s
+ * with its initial chaining value PUBLIC as well: 107 public values = the final chaining value's 16 limbs, the initial one's, then the slice's 75 padding values.  Shard s
  * covers blocks [s 2^k, (s + 1) 2^k) of the padded message and proves chain[s] -> chain[s + 1]; chain[0] is the standard initial value,
  * chain[n_shards] the digest.  The chaining values come from one pass of plain compression on the host, after which the shards are
  * independent: zkhip_prove_sha256_sharded deals them over the devices (shard s on devices[s mod n], in_flight_per_device at a time) like
@@ -578,6 +578,23 @@ int zkhip_prove_sha256_sharded(const int* devices, int n_devices, const uint8_t*
                                int in_flight_per_device, uint8_t digest[32], uint32_t* chain, uint8_t* proofs, size_t proof_stride, size_t* proof_lens);
 int zkhip_verify_sha256_sharded(const uint8_t* proofs, size_t proof_stride, const size_t* proof_lens, size_t n_shards, const uint32_t* chain,
                                 int log_blocks_per_shard, const uint8_t digest[32], uint64_t message_len, const zkhip_params* prm, size_t* bad_shard, int* reason);
+/* The chain as ONE proof -- the reference's core -> compress (sp1.rs:116) on a statement about real data: "digest = SHA-256 of a message
+ * of message_len bytes", whatever the length.  The shards (all at the full height 2^(6 + log_blocks_per_shard), the last one's unused
+ * blocks inactive) are dealt over `devices` as above and then verified in-circuit on ctx's device by the shard verifier machine in air
+ * mode (zkhip_prove_shard_verifier_air on the chained program).  The key is a function of (the number of shards, log_blocks_per_shard,
+ * inner's queries and proof-of-work bits, outer): zkhip_sha256_compress_setup on a device, zkhip_sha256_compress_key_host without one.
+ * The verifier takes the proof, the digest, the length, the chain (8 (n_shards + 1) words: chain[0] must be the standard initial value,
+ * chain[n_shards] the digest) and the key -- no shard proof.  At most as many shards as zkhip_shard_verifier_max_proofs_air allows
+ * (66 shards of 2^14 blocks = 66 MiB at 100 queries). */
+int zkhip_sha256_compress_setup(zkhip_ctx* ctx, size_t message_len, int log_blocks_per_shard, const zkhip_params* inner, const zkhip_params* outer,
+                                zkhip_machine_key** key, uint32_t vk[8]);
+int zkhip_sha256_compress_key_host(size_t message_len, int log_blocks_per_shard, const zkhip_params* inner, const zkhip_params* outer, uint32_t vk[8]);
+size_t zkhip_sha256_compressed_proof_size(size_t message_len, int log_blocks_per_shard, const zkhip_params* inner, const zkhip_params* outer);
+int zkhip_prove_sha256_compressed(zkhip_ctx* ctx, const zkhip_machine_key* key, const int* devices, int n_devices, const uint8_t* message, size_t message_len,
+                                  int log_blocks_per_shard, const zkhip_params* inner, const zkhip_params* outer, int in_flight_per_device, uint8_t digest[32],
+                                  uint32_t* chain, uint8_t* proof, size_t cap, size_t* len);
+int zkhip_verify_sha256_compressed(const uint8_t* proof, size_t len, const uint8_t digest[32], uint64_t message_len, const uint32_t* chain, int log_blocks_per_shard,
+                                   const uint32_t vk[8], const zkhip_params* inner, const zkhip_params* outer, int* reason);
 
 /* The SHA-256 guest as a keyed machine: setup once, then one proof per message -- the reference's setup -> prove -> verify
  * (sp1.rs:113, :116, :120) on this repo's stand-in guest.  Two chips: the SHA-256 compression chip (zkhip_sha256_air, 640 columns) and a
@@ -610,6 +627,11 @@ typedef struct zkhip_transcript_job {
 } zkhip_transcript_job;
 int zkhip_prove_transcripts(const int* devices, int n_devices, zkhip_transcript_job* jobs, int n_jobs, const zkhip_params* prm,
                             int in_flight_per_device, int verify, uint32_t vk[8]);
+/* The same batch with every job proven as zkhip_prove_sha256 makes it (the chip alone, a version-7 proof of zkhip_sha256_air's program; no
+ * key; proof_cap >= zkhip_sha256_proof_size; verify != 0 checks with zkhip_verify_sha256): the form zkhip_prove_shard_verifier_air
+ * compresses -- n proofs of one trace height become ONE proof (the reference's core -> compress on a batch of transcripts, sp1.rs:116). */
+int zkhip_prove_transcripts_air(const int* devices, int n_devices, zkhip_transcript_job* jobs, int n_jobs, const zkhip_params* prm,
+                                int in_flight_per_device, int verify);
 /* Small proofs are launch-bound: a proof of a 13 KB message is ~200 kernels, most of a few microseconds, and the GPU retires such kernels
  * at a fixed rate however many streams feed it.  The batch entries therefore prove small jobs OF ONE SHAPE in lock-step (csrc/batch.h):
  * up to `max_batch` provers run as fibers of one host thread on pooled contexts that share one stream, and their launches of the same

@@ -142,6 +142,11 @@ extern "C" {
         devices: *const c_int, n_devices: c_int, jobs: *mut ZkhipTranscriptJob, n_jobs: c_int, prm: *const ZkhipParams,
         in_flight_per_device: c_int, verify: c_int, vk: *mut u32,
     ) -> c_int;
+    // ... each job as zkhip_prove_sha256 makes it (version 7, no key): the form zkhip_prove_shard_verifier_air compresses into ONE proof
+    pub fn zkhip_prove_transcripts_air(
+        devices: *const c_int, n_devices: c_int, jobs: *mut ZkhipTranscriptJob, n_jobs: c_int, prm: *const ZkhipParams,
+        in_flight_per_device: c_int, verify: c_int,
+    ) -> c_int;
     // small jobs of a batch are proven in lock-step lanes (fibers of one thread per lane, merged kernel launches): members per batch
     // (0 / 1 = off; default 16) and lanes per device (default 6); same proof bytes either way
     pub fn zkhip_set_wait_mode(blocking: c_int, device: c_int) -> c_int;

@@ -53,6 +53,23 @@ def test_transcripts_in_lockstep_are_the_same_bytes(ctx, oracle, lockstep):
     assert res[14][1].tobytes() == oracle.prove_machine_keyed(tr, pre, pg, tb, pub, oprm).tobytes()
 
 
+def test_unkeyed_transcripts_in_lockstep_are_prove_sha256s_bytes(ctx, lockstep):
+    """zkhip_prove_transcripts_air: the batch with every job as the chip alone (version 7) -- the bytes zkhip_prove_sha256 makes on one
+    context, lock-step on and off, with and without the check inside"""
+    from zktls_amd.device import prove_transcripts, verify_sha256
+    base = open(os.path.join(HERE, "golden", "reference", "guest_input0.cbor"), "rb").read()
+    msgs = [base[: 3000 + 7 * i] for i in range(5)] + [base + bytes([i]) for i in range(9)] + [b"", b"abc", base[:100]]
+    prm = Params(1, 20, 8)
+    want = [ctx.prove_sha256(m, prm) for m in msgs]
+    for batch, lanes, check in ((0, 0, False), (16, 6, False), (4, 2, True)):
+        lockstep(batch, lanes)
+        vk, res = prove_transcripts(msgs, prm, devices=[0], in_flight=4, verify=check, keyed=False)
+        assert vk is None
+        for m, (d0, p0), (d, p) in zip(msgs, want, res):
+            assert d == d0 == hashlib.sha256(m).digest() and p.tobytes() == p0.tobytes()
+    assert verify_sha256(res[3][1], res[3][0], prm, len(msgs[3])) == (0, 0)
+
+
 def test_a_failing_member_does_not_hold_up_its_batch(ctx, lockstep):
     """one job of a lock-step batch has no room for its proof: it reports ZKHIP_ERR_BUFFER, the other members' proofs are made and are
     the usual bytes"""

@@ -225,7 +225,7 @@ def test_air_mode_key_and_proof_bytes_equal_the_oracles(ctx, oracle, kind, log_n
 
 
 def test_air_mode_a_sha256_proof_verified_in_circuit_bytes_equal_the_oracles(ctx, oracle):
-    """zkhip_prove_sha256's proof of "digest = SHA-256 of a message of 100 bytes" (2^6 x 640, the chip's 815 constraints) -> an outer proof that a
+    """zkhip_prove_sha256's proof of "digest = SHA-256 of a message of 100 bytes" (2^7 x 640, the chip's 815 constraints) -> an outer proof that a
     verifier checks from (the chip's program, digest, length, key).  Bytes against the oracle on the restatement's arrays."""
     import hashlib
     import recursion_air as R
@@ -238,7 +238,8 @@ def test_air_mode_a_sha256_proof_verified_in_circuit_bytes_equal_the_oracles(ctx
     digest, inner = ctx.prove_sha256(msg, iprm)
     assert digest == hashlib.sha256(msg).digest() and verify_sha256(inner, digest, iprm, len(msg)) == (0, 0)
     pubs = _sha_statement(digest, len(msg))
-    log_n = 6
+    log_n = int(np.frombuffer(inner[8:12].tobytes(), dtype=np.uint32)[0])
+    assert log_n == 7                                                      # two blocks
     key = ctx.shard_verifier_setup(log_n, 640, q, pb, 91, prm, program=prog)
     sh, mains, pres, progs, tabs, pv = R.machine(inner.tobytes(), log_n, 640, pubs, q, pb, program=prog)
     lns = [m.shape[0].bit_length() - 1 for m in mains]
@@ -261,9 +262,9 @@ def test_air_mode_sixty_four_transcript_proofs_become_one_proof(ctx):
     iprm, prm = Params(1, q, pb), Params(1, 20, 8)
     prog = sha256_air()
     msgs = [bytes((7 * i + 3 * p + 1) & 0xff for i in range(nbytes)) for p in range(n)]
+    from zktls_amd.device import prove_transcripts
     inner, pubs = [], []
-    for m in msgs:
-        d, pf = ctx.prove_sha256(m, iprm)
+    for m, (d, pf) in zip(msgs, prove_transcripts(msgs, iprm, devices=[0], keyed=False)[1]):          # (zkhip_prove_transcripts_air: the batch, lock-step lanes)
         assert d == hashlib.sha256(m).digest()
         inner.append(pf), pubs.append(_sha_statement(d, len(m)))
     log_n = 14

@@ -170,3 +170,62 @@ def test_a_three_megabyte_body_as_a_chain_of_shards(ctx):
     bad = res.buf.copy()
     bad[2 * res.stride + 5000] ^= 1
     assert verify_sha256_sharded(res, params=prm, proofs=bad)[:2] == (-6, 2)
+
+
+# ---- the chain as ONE proof (zkhip_prove_sha256_compressed: the shards verified in-circuit, shard verifier machine in air mode)
+def test_a_chain_of_shards_as_one_proof_bytes_equal_the_oracles(ctx, oracle):
+    """messages of 1 000 bytes (16 padded blocks: four full shards of 4 blocks) and of 600 bytes (10 blocks: the third shard has two
+    inactive blocks).  The ONE proof equals the oracle's generic keyed-machine proof of the restatement's arrays built from the shard
+    proofs; its verifier takes digest, length, chain and the key (derived on the host)"""
+    import recursion_air as R
+    from zktls_amd.device import sha256_compress_key_host, verify_sha256_compressed, verify_shard_air
+    O = oracle
+    iprm, prm, oprm = Params(1, 4, 2), Params(1, 20, 8), O.default_params(1, 20, 8)
+    for nbytes in (1000, 600):
+        msg = bytes((11 * i + 5) & 0xff for i in range(nbytes))
+        key = ctx.sha256_compress_setup(len(msg), 2, iprm, prm)
+        assert sha256_compress_key_host(len(msg), 2, iprm, prm).tolist() == key.root.tolist()
+        digest, chain, proof = ctx.prove_sha256_compressed(key, msg, 2, iprm, prm, devices=[0])
+        assert digest == hashlib.sha256(msg).digest()
+        assert verify_sha256_compressed(proof, digest, len(msg), chain, 2, key.root, iprm, prm) == (0, 0)
+        # the restatement: the shard proofs (all 2^8 rows) made by the oracle from the restatement's traces, the machine over them
+        blocks, prog = S.pad(msg), S.program(chained=True)
+        n_shards = chain.shape[0] - 1
+        assert n_shards == (len(blocks) // 64 + 3) // 4
+        inner, pubs = [], []
+        for s in range(n_shards):
+            t, out = S.trace(blocks[256 * s:256 * (s + 1)], 4, chain_in=[int(v) for v in chain[s]], message_len=len(msg), first_block=4 * s)
+            pin = []
+            for x in chain[s]:
+                pin += [int(x) & 0xffff, int(x) >> 16]
+            pubs.append(S.chained_publics(out, pin))
+            inner.append(O.prove_shard_air(prog, t, pubs[-1], O.default_params(1, 4, 2)).tobytes())
+        sh, mains, pres, progs, tabs, pv = R.machine(inner, 8, S.WIDTH, pubs, 4, 2, program=prog)
+        lns = [m.shape[0].bit_length() - 1 for m in mains]
+        assert key.root.tolist() == O.machine_setup(pres, lns, oprm).tolist()
+        assert proof.tobytes() == O.prove_machine_keyed(mains, pres, progs, tabs, pv, oprm).tobytes(), "the compressed chain differs from the oracle's proof"
+        # refused: another digest, another length, a chain that does not link up, a chain that starts elsewhere
+        assert verify_sha256_compressed(proof, hashlib.sha256(b"other").digest(), len(msg), chain, 2, key.root, iprm, prm)[0] == -6
+        assert verify_sha256_compressed(proof, digest, len(msg) - 1, chain, 2, key.root, iprm, prm)[0] == -6
+        bad = chain.copy()
+        bad[1, 3] ^= 1
+        assert verify_sha256_compressed(proof, digest, len(msg), bad, 2, key.root, iprm, prm)[0] == -6
+        bad = chain.copy()
+        bad[0, 0] ^= 1
+        assert verify_sha256_compressed(proof, digest, len(msg), bad, 2, key.root, iprm, prm)[0] == -6
+        key.close()
+
+
+def test_a_three_megabyte_body_as_one_proof(ctx):
+    """BASELINE configs[3] with a real statement, compressed: a 3 MiB body -> four shards of 2^20 rows x 640 (the last with one active block)
+    -> ONE proof; checked from (digest, length, chain, key derived on the host)"""
+    from zktls_amd.device import sha256_compress_key_host, verify_sha256_compressed
+    msg = np.random.default_rng(9).integers(0, 256, 3 << 20, dtype=np.uint8).tobytes()
+    iprm, prm = Params(1, 30, 8), Params(1, 30, 8)
+    key = ctx.sha256_compress_setup(len(msg), 14, iprm, prm)
+    digest, chain, proof = ctx.prove_sha256_compressed(key, msg, 14, iprm, prm, devices=[0])
+    assert digest == hashlib.sha256(msg).digest() and chain.shape[0] == 5
+    assert verify_sha256_compressed(proof, digest, len(msg), chain, 14, sha256_compress_key_host(len(msg), 14, iprm, prm), iprm, prm) == (0, 0)
+    assert verify_sha256_compressed(proof, digest, len(msg) + 1, chain, 14, key.root, iprm, prm)[0] == -6
+    print("3 MiB: one proof of %d bytes" % proof.size)
+    key.close()

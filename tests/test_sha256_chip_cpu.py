@@ -184,3 +184,41 @@ def test_a_chain_of_two_shards_proven_by_the_oracle(oracle):
     assert check(shifted, dg)[0] == -6                                           # the chain must start from the SHA-256 initial value
     assert L.zkhip_sha256_sharded_count(190, 1) == 2 and L.zkhip_sha256_sharded_count(190, 0) == 4 and L.zkhip_sha256_sharded_count(190, 2) == 1
     assert L.zkhip_sha256_sharded_count(190, 15) == 0
+
+
+def test_the_compressed_chain_verifier_accepts_the_oracles_proof(oracle):
+    """zkhip_verify_sha256_compressed / zkhip_sha256_compress_key_host with no device: a 400-byte message as two chained shards of 4 blocks
+    (the second with one inactive block), both proven by the oracle, verified in-circuit by the oracle's proof of the restatement's machine
+    (tests/recursion_air.py, air mode on the chained program) -- the library's host verifier takes it from (digest, length, chain, key)"""
+    import recursion_air as R
+    from zktls_amd.device import sha256_compress_key_host, verify_sha256_compressed
+    O = oracle
+    msg = bytes((13 * i + 1) & 0xff for i in range(400))
+    iprm, prm, oprm = Params(1, 2, 1), Params(1, 20, 8), O.default_params(1, 20, 8)
+    blocks, prog = S.pad(msg), S.program(chained=True)
+    assert len(blocks) == 7 * 64
+    chain, inner, pubs = [list(S.IV)], [], []
+    for s in range(2):
+        t, out = S.trace(blocks[256 * s:256 * (s + 1)], 4, chain_in=chain[s], message_len=len(msg), first_block=4 * s)
+        pin = []
+        for x in chain[s]:
+            pin += [x & 0xffff, x >> 16]
+        chain.append([int(out[2 * k] | (out[2 * k + 1] << 16)) for k in range(8)])
+        pubs.append(S.chained_publics(out, pin))
+        inner.append(O.prove_shard_air(prog, t, pubs[-1], O.default_params(1, 2, 1)).tobytes())
+    digest = b"".join(w.to_bytes(4, "big") for w in chain[2])
+    assert digest == hashlib.sha256(msg).digest()
+    sh, mains, pres, progs, tabs, pv = R.machine(inner, 8, S.WIDTH, pubs, 2, 1, program=prog)
+    lns = [m.shape[0].bit_length() - 1 for m in mains]
+    vk = sha256_compress_key_host(len(msg), 2, iprm, prm)
+    assert vk.tolist() == [int(x) for x in O.machine_setup(pres, lns, oprm)]
+    proof = O.prove_machine_keyed(mains, pres, progs, tabs, pv, oprm)
+    ch = np.array(chain, dtype=np.uint32)
+    assert verify_sha256_compressed(proof, digest, len(msg), ch, 2, vk, iprm, prm) == (0, 0)
+    assert verify_sha256_compressed(proof, hashlib.sha256(b"x").digest(), len(msg), ch, 2, vk, iprm, prm)[0] == -6
+    assert verify_sha256_compressed(proof, digest, len(msg) + 1, ch, 2, vk, iprm, prm)[0] == -6
+    bad = ch.copy()
+    bad[1, 0] ^= 1                                                          # a chain that does not link up: other public values than the proof's
+    assert verify_sha256_compressed(proof, digest, len(msg), bad, 2, vk, iprm, prm)[0] == -6
+    assert verify_sha256_compressed(proof, digest, len(msg), ch, 2, (vk + 1) % S.P, iprm, prm)[0] == -6
+    assert verify_sha256_compressed(proof, digest, len(msg) + 64 * 4, ch, 2, vk, iprm, prm)[0] != 0          # (another number of shards: another machine)

@@ -786,8 +786,11 @@ int zkhip_verify_sha256_machine(const uint8_t* proof, size_t len, const uint8_t 
 // proven on devices[i mod n_devices], `in_flight_per_device` at a time on each, every worker on a pooled context that keeps its own
 // proving key (setup runs once per context and proof shape; every context arrives at the same vk).  Per job: padding, trace generation
 // and the range table's multiplicities on the device, the keyed machine's proof into the job's host buffer, the digest.
-int zkhip_prove_transcripts(const int* devices, int n_devices, zkhip_transcript_job* jobs, int n_jobs, const zkhip_params* prm,
-                            int in_flight_per_device, int verify, uint32_t vk[8]) {
+// (keyed: the keyed SHA-256 machine, version 11; otherwise the chip alone as zkhip_prove_sha256 makes it, version 7 -- vk unused)
+static int prove_transcripts_impl(const int* devices, int n_devices, zkhip_transcript_job* jobs, int n_jobs, const zkhip_params* prm,
+                                  int in_flight_per_device, int verify, uint32_t vk[8], bool keyed) {
+    uint32_t vk_unused[8];
+    if (!keyed) vk = vk_unused;
     if (!jobs || n_jobs < 0 || !prm || !vk) return fail(ZKHIP_ERR_INVALID, "prove_transcripts: bad arguments");
     for (int i = 0; i < n_jobs; i++) { jobs[i].status = ZKHIP_ERR_INVALID; jobs[i].proof_len = 0; }
     std::vector<int> devs;
@@ -806,18 +809,21 @@ int zkhip_prove_transcripts(const int* devices, int n_devices, zkhip_transcript_
     auto run = [&](zkhip_ctx* ctx, int i) {
         zkhip_transcript_job& j = jobs[i];
         int r = ZKHIP_OK;
-        if (ctx->sha_key && ctx->sha_key_blowup != prm->log_blowup) { zkhip_machine_key_destroy(ctx->sha_key); ctx->sha_key = nullptr; }
-        if (!ctx->sha_key) {
-            r = zkhip_sha256_setup(ctx, prm, &ctx->sha_key, ctx->sha_vk);
-            ctx->sha_key_blowup = prm->log_blowup;
-        }
-        if (r == ZKHIP_OK) {
-            std::lock_guard<std::mutex> lk(mu);
-            if (!have_vk) { std::memcpy(vk, ctx->sha_vk, 32); have_vk = true; }
-            else if (std::memcmp(vk, ctx->sha_vk, 32) != 0) r = fail(ZKHIP_ERR_INTERNAL, "prove_transcripts: two contexts disagree about the verifying key");
+        if (keyed) {
+            if (ctx->sha_key && ctx->sha_key_blowup != prm->log_blowup) { zkhip_machine_key_destroy(ctx->sha_key); ctx->sha_key = nullptr; }
+            if (!ctx->sha_key) {
+                r = zkhip_sha256_setup(ctx, prm, &ctx->sha_key, ctx->sha_vk);
+                ctx->sha_key_blowup = prm->log_blowup;
+            }
+            if (r == ZKHIP_OK) {
+                std::lock_guard<std::mutex> lk(mu);
+                if (!have_vk) { std::memcpy(vk, ctx->sha_vk, 32); have_vk = true; }
+                else if (std::memcmp(vk, ctx->sha_vk, 32) != 0) r = fail(ZKHIP_ERR_INTERNAL, "prove_transcripts: two contexts disagree about the verifying key");
+            }
         }
         size_t len = 0;
-        if (r == ZKHIP_OK) r = zkhip_prove_sha256_machine(ctx, ctx->sha_key, j.message, j.message_len, prm, j.digest, j.proof, j.proof_cap, &len);
+        if (r == ZKHIP_OK) r = keyed ? zkhip_prove_sha256_machine(ctx, ctx->sha_key, j.message, j.message_len, prm, j.digest, j.proof, j.proof_cap, &len)
+                                     : zkhip_prove_sha256(ctx, j.message, j.message_len, prm, j.digest, j.proof, j.proof_cap, &len);
         batch_leave();                                           // (lock-step batch: the rest is host work)
         // the reference checks every proof right after proving it (sp1.rs:120): on a host thread, while the GPU runs the other proofs --
         // this worker's own thread, or (lock-step lanes, whose members share one thread) a small pool beside the lanes
@@ -830,12 +836,14 @@ int zkhip_prove_transcripts(const int* devices, int n_devices, zkhip_transcript_
                 const zkhip_params p = *prm;
                 zkhip_transcript_job* jp = &j;
                 std::string* msg = &check_msg[(size_t)i];
-                checkers->submit([jp, len, p, msg, key] {
-                    const int v = zkhip_verify_sha256_machine(jp->proof, len, jp->digest, jp->message_len, key, &p, nullptr);
+                checkers->submit([jp, len, p, msg, key, keyed] {
+                    const int v = keyed ? zkhip_verify_sha256_machine(jp->proof, len, jp->digest, jp->message_len, key, &p, nullptr)
+                                        : zkhip_verify_sha256(jp->proof, len, jp->digest, jp->message_len, &p, nullptr);
                     if (v != ZKHIP_OK) { jp->status = v; jp->proof_len = 0; *msg = zkhip_last_error(); }
                 });
             } else {
-                r = zkhip_verify_sha256_machine(j.proof, len, j.digest, j.message_len, ctx->sha_vk, prm, nullptr);
+                r = keyed ? zkhip_verify_sha256_machine(j.proof, len, j.digest, j.message_len, ctx->sha_vk, prm, nullptr)
+                          : zkhip_verify_sha256(j.proof, len, j.digest, j.message_len, prm, nullptr);
                 j.status = r;
                 j.proof_len = r == ZKHIP_OK ? len : 0;
             }
@@ -876,6 +884,14 @@ int zkhip_prove_transcripts(const int* devices, int n_devices, zkhip_transcript_
     }
     if (rc_small != ZKHIP_OK && (rc_big == ZKHIP_OK || small[0] < big[0])) { set_error(msg_small); return rc_small; }
     return rc_big;
+}
+int zkhip_prove_transcripts(const int* devices, int n_devices, zkhip_transcript_job* jobs, int n_jobs, const zkhip_params* prm,
+                            int in_flight_per_device, int verify, uint32_t vk[8]) {
+    return prove_transcripts_impl(devices, n_devices, jobs, n_jobs, prm, in_flight_per_device, verify, vk, true);
+}
+int zkhip_prove_transcripts_air(const int* devices, int n_devices, zkhip_transcript_job* jobs, int n_jobs, const zkhip_params* prm,
+                                int in_flight_per_device, int verify) {
+    return prove_transcripts_impl(devices, n_devices, jobs, n_jobs, prm, in_flight_per_device, verify, nullptr, false);
 }
 
 void zkhip_set_lockstep(int max_batch, int lanes) { lockstep_set(max_batch, lanes); }
@@ -918,8 +934,9 @@ size_t zkhip_sha256_shard_proof_size(int log_blocks, const zkhip_params* prm) {
 static void chain_limbs(const uint32_t in[8], const uint32_t out[8], uint32_t pv[32]) {      // public values of a shard: final limbs, then initial limbs
     for (int i = 0; i < 8; i++) { pv[2 * i] = out[i] & 0xffffu; pv[2 * i + 1] = out[i] >> 16; pv[16 + 2 * i] = in[i] & 0xffffu; pv[16 + 2 * i + 1] = in[i] >> 16; }
 }
-int zkhip_prove_sha256_sharded(const int* devices, int n_devices, const uint8_t* message, size_t message_len, int log_blocks_per_shard, const zkhip_params* prm,
-                               int in_flight_per_device, uint8_t digest[32], uint32_t* chain, uint8_t* proofs, size_t proof_stride, size_t* proof_lens) {
+// (uniform: the last shard at the full height too, its unused blocks inactive -- shards of ONE shape, which a join takes)
+static int prove_sharded(const int* devices, int n_devices, const uint8_t* message, size_t message_len, int log_blocks_per_shard, const zkhip_params* prm,
+                         int in_flight_per_device, uint8_t digest[32], uint32_t* chain, uint8_t* proofs, size_t proof_stride, size_t* proof_lens, bool uniform) {
     if ((message_len && !message) || !prm || !digest || !chain || !proofs || !proof_lens) return fail(ZKHIP_ERR_INVALID, "prove_sha256_sharded: null argument");
     size_t padded, n_shards;
     int last_lb;
@@ -954,7 +971,7 @@ int zkhip_prove_sha256_sharded(const int* devices, int n_devices, const uint8_t*
     return deal_jobs(devs.data(), (int)devs.size(), (int)n_shards, in_flight_per_device, [&](zkhip_ctx* ctx, int s) {
         while (ready.load(std::memory_order_acquire) < (size_t)s + 2) std::this_thread::yield();
         const size_t first = (size_t)s * per, active = (size_t)s + 1 == n_shards ? n_blocks - first : per;
-        const int lb = (size_t)s + 1 == n_shards ? last_lb : log_blocks_per_shard;
+        const int lb = (size_t)s + 1 == n_shards && !uniform ? last_lb : log_blocks_per_shard;
         void* trace;
         ZK_TRY(ctx_reserve(ctx, S_CHIP, ((size_t)sha::WIDTH << (6 + lb)) * 4, &trace));
         uint32_t out_pub[sha::N_PUBLIC], pv[sha::N_PUBLIC_CHAINED];
@@ -965,6 +982,10 @@ int zkhip_prove_sha256_sharded(const int* devices, int n_devices, const uint8_t*
         return zkhip_prove_shard_air(ctx, prog.data(), prog.size(), (const uint32_t*)trace, sha::WIDTH, 6 + lb, sha::WIDTH, pv, sha::N_PUBLIC_CHAINED, prm,
                                      proofs + (size_t)s * proof_stride, proof_stride, &proof_lens[s]);
     }, ran);
+}
+int zkhip_prove_sha256_sharded(const int* devices, int n_devices, const uint8_t* message, size_t message_len, int log_blocks_per_shard, const zkhip_params* prm,
+                               int in_flight_per_device, uint8_t digest[32], uint32_t* chain, uint8_t* proofs, size_t proof_stride, size_t* proof_lens) {
+    return prove_sharded(devices, n_devices, message, message_len, log_blocks_per_shard, prm, in_flight_per_device, digest, chain, proofs, proof_stride, proof_lens, false);
 }
 // checks a chain of shard proofs: chain[0] = the standard IV, chain[n] = the digest, shard s proves chain[s] -> chain[s + 1]; every shard but
 // the last covers 2^log_blocks_per_shard blocks (the last proof's own header says how many rows it has).  *reason: the failing shard's check
@@ -1028,6 +1049,85 @@ int zkhip_verify_sha256_sharded(const uint8_t* proofs, size_t proof_stride, cons
             return fail(ZKHIP_ERR_VERIFY, msg[s]);
         }
     return ZKHIP_OK;
+}
+
+// ---- the chain as ONE proof (core -> compress, sp1.rs:116, on a real statement): the shards -- all at the full height -- are verified in-circuit
+// by the shard verifier machine in air mode (fri_chip.hip / shard_verifier.inl: the chained program's terms on the EVAL chip).  The outer
+// proof's public values are the shards' (chaining values in and out, the slice's padding values): its verifier rebuilds them from the
+// digest, the length and the chain, and checks that the chain starts from the initial value, links up and ends in the digest.
+static int compressed_shape(size_t message_len, int log_blocks_per_shard, const zkhip_params* inner, const zkhip_params* outer, size_t* n_shards) {
+    if (!inner || !outer) return fail(ZKHIP_ERR_INVALID, "sha256_compressed: null argument");
+    size_t padded;
+    int last;
+    return sharded_shape(message_len, log_blocks_per_shard, &padded, n_shards, &last);
+}
+static void compressed_publics(uint64_t message_len, int log_blocks_per_shard, size_t n_shards, const uint32_t* chain, std::vector<uint32_t>& pv) {
+    const uint64_t per = (uint64_t)1 << log_blocks_per_shard, total = (message_len + 8) / 64 + 1;
+    pv.assign(n_shards * sha::N_PUBLIC_CHAINED, 0u);
+    for (size_t s = 0; s < n_shards; s++) {
+        uint32_t* p = pv.data() + s * sha::N_PUBLIC_CHAINED;
+        chain_limbs(chain + 8 * s, chain + 8 * (s + 1), p);
+        const uint64_t first = (uint64_t)s * per;
+        (void)sha::padding_publics(message_len, first, s + 1 == n_shards ? total - first : per, p + 2 * sha::N_DIGEST);
+    }
+}
+int zkhip_sha256_compress_setup(zkhip_ctx* ctx, size_t message_len, int log_blocks_per_shard, const zkhip_params* inner, const zkhip_params* outer,
+                                zkhip_machine_key** key, uint32_t vk[8]) {
+    size_t n;
+    ZK_TRY(compressed_shape(message_len, log_blocks_per_shard, inner, outer, &n));
+    const std::vector<uint32_t>& prog = sha::program_chained();
+    return zkhip_shard_verifier_setup_air(ctx, prog.data(), prog.size(), 6 + log_blocks_per_shard, sha::WIDTH, inner->num_queries, inner->pow_bits, sha::N_PUBLIC_CHAINED, n, outer, key, vk);
+}
+int zkhip_sha256_compress_key_host(size_t message_len, int log_blocks_per_shard, const zkhip_params* inner, const zkhip_params* outer, uint32_t vk[8]) {
+    size_t n;
+    ZK_TRY(compressed_shape(message_len, log_blocks_per_shard, inner, outer, &n));
+    const std::vector<uint32_t>& prog = sha::program_chained();
+    return zkhip_shard_verifier_key_host_air(prog.data(), prog.size(), 6 + log_blocks_per_shard, sha::WIDTH, inner->num_queries, inner->pow_bits, sha::N_PUBLIC_CHAINED, n, outer, vk);
+}
+size_t zkhip_sha256_compressed_proof_size(size_t message_len, int log_blocks_per_shard, const zkhip_params* inner, const zkhip_params* outer) {
+    size_t n;
+    if (compressed_shape(message_len, log_blocks_per_shard, inner, outer, &n) != ZKHIP_OK) return 0;
+    const std::vector<uint32_t>& prog = sha::program_chained();
+    return zkhip_shard_verifier_proof_size_air(prog.data(), prog.size(), 6 + log_blocks_per_shard, sha::WIDTH, inner->num_queries, inner->pow_bits, sha::N_PUBLIC_CHAINED, n, outer);
+}
+int zkhip_prove_sha256_compressed(zkhip_ctx* ctx, const zkhip_machine_key* key, const int* devices, int n_devices, const uint8_t* message, size_t message_len,
+                                  int log_blocks_per_shard, const zkhip_params* inner, const zkhip_params* outer, int in_flight_per_device, uint8_t digest[32],
+                                  uint32_t* chain, uint8_t* proof, size_t cap, size_t* len) {
+    CHECK_CTX(ctx);
+    if (!key || !chain || !digest || !proof || !len) return fail(ZKHIP_ERR_INVALID, "prove_sha256_compressed: null argument");
+    size_t n;
+    ZK_TRY(compressed_shape(message_len, log_blocks_per_shard, inner, outer, &n));
+    const size_t stride = zkhip_sha256_shard_proof_size(log_blocks_per_shard, inner);
+    if (stride == 0) return fail(ZKHIP_ERR_INVALID, "prove_sha256_compressed: bad inner proof shape");
+    std::vector<uint8_t> shards;
+    std::vector<size_t> lens(n, 0);
+    std::vector<const uint8_t*> ptrs(n);
+    try { shards.resize(n * stride); } catch (const std::bad_alloc&) { return fail(ZKHIP_ERR_NOMEM, "prove_sha256_compressed: no host memory for the shard proofs"); }
+    ZK_TRY(prove_sharded(devices, n_devices, message, message_len, log_blocks_per_shard, inner, in_flight_per_device, digest, chain, shards.data(), stride, lens.data(), true));
+    for (size_t s = 0; s < n; s++) ptrs[s] = shards.data() + s * stride;
+    std::vector<uint32_t> pv;
+    compressed_publics(message_len, log_blocks_per_shard, n, chain, pv);
+    const std::vector<uint32_t>& prog = sha::program_chained();
+    return zkhip_prove_shard_verifier_air(ctx, key, prog.data(), prog.size(), ptrs.data(), lens.data(), n, 6 + log_blocks_per_shard, sha::WIDTH, pv.data(), sha::N_PUBLIC_CHAINED,
+                                          inner, outer, proof, cap, len);
+}
+int zkhip_verify_sha256_compressed(const uint8_t* proof, size_t len, const uint8_t digest[32], uint64_t message_len, const uint32_t* chain, int log_blocks_per_shard,
+                                   const uint32_t vk[8], const zkhip_params* inner, const zkhip_params* outer, int* reason) {
+    if (!proof || !digest || !chain || !vk) return fail(ZKHIP_ERR_INVALID, "verify_sha256_compressed: null argument");
+    size_t n;
+    ZK_TRY(compressed_shape((size_t)message_len, log_blocks_per_shard, inner, outer, &n));
+    if (reason) *reason = 0;
+    auto reject = [&](const char* msg) { if (reason) *reason = 1; return fail(ZKHIP_ERR_VERIFY, msg); };
+    if (std::memcmp(chain, sha::IV, 32) != 0) return reject("verify_sha256_compressed: the chain does not start from the SHA-256 initial value");
+    for (int i = 0; i < 8; i++) {
+        const uint32_t w = ((uint32_t)digest[4 * i] << 24) | ((uint32_t)digest[4 * i + 1] << 16) | ((uint32_t)digest[4 * i + 2] << 8) | digest[4 * i + 3];
+        if (chain[8 * n + i] != w) return reject("verify_sha256_compressed: the chain does not end in the digest");
+    }
+    std::vector<uint32_t> pv;                                   // (shard s's final value IS shard s + 1's initial one: both are chain[s + 1])
+    compressed_publics(message_len, log_blocks_per_shard, n, chain, pv);
+    const std::vector<uint32_t>& prog = sha::program_chained();
+    return zkhip_verify_shard_recursive_air(prog.data(), prog.size(), proof, len, 6 + log_blocks_per_shard, sha::WIDTH, inner->num_queries, inner->pow_bits, pv.data(),
+                                            sha::N_PUBLIC_CHAINED, n, vk, outer, reason);
 }
 
 }  // extern "C"

@@ -414,6 +414,33 @@ class Context:
         check(self.lib.zkhip_sha256_setup(self.handle, C.byref(params), C.byref(handle), root.ctypes.data_as(u32p)))
         return MachineKey(self, handle, root, [4])
 
+    def sha256_compress_setup(self, message_len, log_blocks_per_shard, inner=None, outer=None):
+        """zkhip_sha256_compress_setup -> MachineKey (key.root = vk) for compressed chains of messages with this many shards"""
+        inner, outer = inner or Params(1, 100, 16), outer or Params(1, 100, 16)
+        handle = C.c_void_p()
+        vk = np.zeros(8, dtype=np.uint32)
+        check(self.lib.zkhip_sha256_compress_setup(self.handle, message_len, log_blocks_per_shard, C.byref(inner), C.byref(outer), C.byref(handle), vk.ctypes.data_as(u32p)))
+        return MachineKey(self, handle, vk, None)
+
+    def prove_sha256_compressed(self, key, message, log_blocks_per_shard, inner=None, outer=None, devices=None, in_flight=2):
+        """zkhip_prove_sha256_compressed: the message as a chain of shards (dealt over `devices`), the shards verified in-circuit on this
+        context's device -> (digest bytes, chain [(n_shards + 1) x 8], ONE proof)"""
+        inner, outer = inner or Params(1, 100, 16), outer or Params(1, 100, 16)
+        m = np.frombuffer(bytes(message), dtype=np.uint8) if len(message) else np.zeros(1, dtype=np.uint8)
+        n = self.lib.zkhip_sha256_sharded_count(len(message), log_blocks_per_shard)
+        size = self.lib.zkhip_sha256_compressed_proof_size(len(message), log_blocks_per_shard, C.byref(inner), C.byref(outer))
+        if n == 0 or size == 0:
+            raise _lib.ZkHipError(-1, "prove_sha256_compressed: bad shape")
+        chain = np.zeros((n + 1, 8), dtype=np.uint32)
+        digest = np.zeros(32, dtype=np.uint8)
+        buf = np.empty(size, dtype=np.uint8)
+        got = C.c_size_t(0)
+        devs = (C.c_int * len(devices))(*devices) if devices else None
+        check(self.lib.zkhip_prove_sha256_compressed(self.handle, key.handle, devs, len(devices) if devices else 0, m.ctypes.data_as(u8p), len(message), log_blocks_per_shard,
+                                                     C.byref(inner), C.byref(outer), in_flight, digest.ctypes.data_as(u8p), chain.ctypes.data_as(u32p),
+                                                     buf.ctypes.data_as(u8p), size, C.byref(got)))
+        return digest.tobytes(), chain, buf[: got.value]
+
     def prove_sha256_machine(self, key, message, params=None):
         """-> (digest bytes, proof bytes): the SHA-256 chip + its range table as a keyed machine (proof version 11)"""
         params = params or Params(1, 100, 16)
@@ -885,6 +912,27 @@ def verify_sha256_sharded(result, digest=None, params=None, chain=None, proofs=N
     return rc, bad.value, reason.value
 
 
+def sha256_compress_key_host(message_len, log_blocks_per_shard, inner=None, outer=None):
+    """zkhip_sha256_compress_key_host: the key of the compressed chain for a message of this length, without a device -> 8 words"""
+    inner, outer = inner or Params(1, 100, 16), outer or Params(1, 100, 16)
+    vk = np.zeros(8, dtype=np.uint32)
+    check(_lib.load().zkhip_sha256_compress_key_host(message_len, log_blocks_per_shard, C.byref(inner), C.byref(outer), vk.ctypes.data_as(u32p)))
+    return vk
+
+
+def verify_sha256_compressed(proof, digest, message_len, chain, log_blocks_per_shard, vk, inner=None, outer=None):
+    """zkhip_verify_sha256_compressed: "digest = SHA-256 of a message of message_len bytes" from ONE proof, the chain and the key -> (rc, reason)"""
+    inner, outer = inner or Params(1, 100, 16), outer or Params(1, 100, 16)
+    pr = np.ascontiguousarray(proof, dtype=np.uint8)
+    dg = np.frombuffer(bytes(digest), dtype=np.uint8)
+    ch = np.ascontiguousarray(chain, dtype=np.uint32)
+    k = np.ascontiguousarray(np.array(vk, dtype=np.uint32))
+    reason = C.c_int(0)
+    rc = _lib.load().zkhip_verify_sha256_compressed(pr.ctypes.data_as(u8p), pr.size, dg.ctypes.data_as(u8p), message_len, ch.ctypes.data_as(u32p), log_blocks_per_shard,
+                                                    k.ctypes.data_as(u32p), C.byref(inner), C.byref(outer), C.byref(reason))
+    return rc, reason.value
+
+
 def sha256_air():
     """the SHA-256 compression chip's constraint program (u32 words)"""
     lib = _lib.load()
@@ -932,9 +980,10 @@ def verify_sha256(proof, digest, params=None, message_len=None):
     return rc, reason.value
 
 
-def prove_transcripts(messages, params=None, devices=None, in_flight=4, verify=False):
+def prove_transcripts(messages, params=None, devices=None, in_flight=4, verify=False, keyed=True):
     """zkhip_prove_transcripts: every message proven as the keyed SHA-256 machine in one call, dealt over `devices` (None: all visible);
-    verify: each proof is checked against the key inside the call -> (vk, [(digest bytes, proof bytes), ...])"""
+    verify: each proof is checked against the key inside the call -> (vk, [(digest bytes, proof bytes), ...]).
+    keyed=False: zkhip_prove_transcripts_air -- the chip alone (version-7 proofs, what prove_sha256 makes); vk is None"""
     lib = _lib.load()
     params = params or Params(1, 100, 16)
     n = len(messages)
@@ -942,15 +991,18 @@ def prove_transcripts(messages, params=None, devices=None, in_flight=4, verify=F
     keep = []
     for i, m in enumerate(messages):
         msg = np.frombuffer(bytes(m), dtype=np.uint8) if len(m) else np.zeros(1, dtype=np.uint8)
-        size = lib.zkhip_sha256_machine_proof_size(len(m), C.byref(params))
+        size = lib.zkhip_sha256_machine_proof_size(len(m), C.byref(params)) if keyed else lib.zkhip_sha256_proof_size(len(m), C.byref(params))
         buf = np.empty(max(size, 1), dtype=np.uint8)
         keep.append((msg, buf))
         jobs[i].message = msg.ctypes.data_as(u8p); jobs[i].message_len = len(m)
         jobs[i].proof = buf.ctypes.data_as(u8p); jobs[i].proof_cap = size
     vk = np.zeros(8, dtype=np.uint32)
     devs = (C.c_int * len(devices))(*devices) if devices else None
-    check(lib.zkhip_prove_transcripts(devs, len(devices) if devices else 0, jobs, n, C.byref(params), in_flight, 1 if verify else 0, vk.ctypes.data_as(u32p)))
-    return vk, [(bytes(jobs[i].digest), keep[i][1][: jobs[i].proof_len]) for i in range(n)]
+    if keyed:
+        check(lib.zkhip_prove_transcripts(devs, len(devices) if devices else 0, jobs, n, C.byref(params), in_flight, 1 if verify else 0, vk.ctypes.data_as(u32p)))
+    else:
+        check(lib.zkhip_prove_transcripts_air(devs, len(devices) if devices else 0, jobs, n, C.byref(params), in_flight, 1 if verify else 0))
+    return (vk if keyed else None), [(bytes(jobs[i].digest), keep[i][1][: jobs[i].proof_len]) for i in range(n)]
 
 
 def prove_fri_indices_batch(shard_proofs, log_n, width, public_values, inner=None, outer=None, devices=None, in_flight=4, verify=False):
