@@ -125,7 +125,7 @@ inline uint32_t air_slots(const AirView& a) { return 2 * a.width + AIR_SLOT_EXTR
 // (kept by content) and a proof only adds up weighted coefficients.
 struct AirTermPlan {
     std::vector<std::array<uint32_t, 6>> monomials;    // n, then the n slot offsets in ascending order; sorted (by n first)
-    struct Src { uint32_t monomial, constraint, coeff_monty; };
+    struct Src { uint32_t monomial, constraint, coeff_monty; uint16_t n_pub, pub[5]; };      // (pub: the term's public-value factors -- constants of a proof, folded into its coefficient)
     std::vector<Src> terms;                            // every term of the program, in program order
 };
 inline std::shared_ptr<const AirTermPlan> air_term_plan(const AirView& a) {
@@ -150,9 +150,11 @@ inline std::shared_ptr<const AirTermPlan> air_term_plan(const AirView& a) {
             const uint32_t coeff = to_monty(a.w[p++]), d = a.w[p++];
             std::array<uint32_t, 6> key = {0, 0, 0, 0, 0, 0};
             uint32_t n = 0;
+            AirTermPlan::Src src{0, k, coeff, 0, {0, 0, 0, 0, 0}};
             for (uint32_t j = 0; j < d; j++) {
                 const uint32_t v = a.w[p++], kind = v >> 30, idx = v & 0xFFFFu;
-                key[1 + n++] = kind == 0 ? idx : (kind == 1 ? W + idx : 2 * W + AIR_SLOT_EXTRA + idx);
+                if (kind == 2) { src.pub[src.n_pub++] = (uint16_t)idx; continue; }      // a public value is no slot: it multiplies the coefficient (air_term_records)
+                key[1 + n++] = kind == 0 ? idx : W + idx;
             }
             if (sel) key[1 + n++] = 2 * W + (sel - 1);
             if (n == 0) key[1 + n++] = 2 * W + 3;
@@ -160,7 +162,8 @@ inline std::shared_ptr<const AirTermPlan> air_term_plan(const AirView& a) {
             key[0] = n;
             auto it = index.find(key);
             if (it == index.end()) { it = index.emplace(key, (uint32_t)keys.size()).first; keys.push_back(key); }
-            plan->terms.push_back(AirTermPlan::Src{it->second, k, coeff});
+            src.monomial = it->second;
+            plan->terms.push_back(src);
         }
     }
     // records in sorted key order (by n first: the lanes of a wavefront run the same number of products)
@@ -191,7 +194,14 @@ inline uint32_t air_public_used(const AirView& a) {
     return used;
 }
 inline size_t air_term_count(const AirView& a) { const size_t nm = air_term_plan(a)->monomials.size(); return nm + (nm & 1); }
-inline void air_term_records(const AirView& a, const Ext& alpha, std::vector<uint32_t>& recs, const Ext& scale = ext_one()) {
+// (pub_monty: the proof's public values, Montgomery form -- every record's coefficient carries its terms' public-value factors, so
+// that the kernels stage no public value at all: the shard verifier's transcript table reads 64 x 91 of them)
+inline uint32_t air_term_coeff(const AirTermPlan::Src& t, const uint32_t* pub_monty) {
+    uint32_t c = t.coeff_monty;
+    for (uint32_t j = 0; j < t.n_pub; j++) c = fmul(c, pub_monty[t.pub[j]]);
+    return c;
+}
+inline void air_term_records(const AirView& a, const Ext& alpha, const uint32_t* pub_monty, std::vector<uint32_t>& recs, const Ext& scale = ext_one()) {
     std::vector<Ext> wts(a.K);
     Ext w = scale;
     for (size_t k = a.K; k-- > 0;) { wts[k] = w; w = ext_mul(w, alpha); }
@@ -208,7 +218,7 @@ inline void air_term_records(const AirView& a, const Ext& alpha, std::vector<uin
     }
     for (const AirTermPlan::Src& t : plan->terms) {
         uint32_t* r = recs.data() + 8 * (size_t)t.monomial;
-        const Ext c = ext_mul_base(wts[t.constraint], t.coeff_monty);
+        const Ext c = ext_mul_base(wts[t.constraint], air_term_coeff(t, pub_monty));
         for (int i = 0; i < 4; i++) r[i] = fadd(r[i], c.c[i]);
     }
     if (nm & 1) {                                // the kernel takes terms in pairs: pad with 0 * (the constant 1)
@@ -221,7 +231,7 @@ inline void air_term_records(const AirView& a, const Ext& alpha, std::vector<uin
 // monomials, grouped by their number of factors -- cls[n - 1] .. cls[n] are the records of n factors, every class padded to an even
 // count (the kernel takes records in pairs) with a zero-weight record -- so that the kernel runs one branch-free loop per class.  A
 // factor travels as the LDS word of its column in the kernel's column-major tile (kernels.h, air_wide_word).
-inline void air_term_records_wide(const AirView& a, const Ext& alpha, std::vector<uint32_t>& recs, uint32_t cls[6], const Ext& scale = ext_one()) {
+inline void air_term_records_wide(const AirView& a, const Ext& alpha, const uint32_t* pub_monty, std::vector<uint32_t>& recs, uint32_t cls[6], const Ext& scale = ext_one()) {
     std::vector<Ext> wts(a.K);
     Ext w = scale;
     for (size_t k = a.K; k-- > 0;) { wts[k] = w; w = ext_mul(w, alpha); }
@@ -251,7 +261,7 @@ inline void air_term_records_wide(const AirView& a, const Ext& alpha, std::vecto
     while (cur <= 5) { pad_to_even(cur); cls[cur] = (uint32_t)(recs.size() / 8); cur++; }
     for (const AirTermPlan::Src& t : plan->terms) {
         uint32_t* r = recs.data() + 8 * (size_t)pos[t.monomial];
-        const Ext c = ext_mul_base(wts[t.constraint], t.coeff_monty);
+        const Ext c = ext_mul_base(wts[t.constraint], air_term_coeff(t, pub_monty));
         for (int i = 0; i < 4; i++) r[i] = fadd(r[i], c.c[i]);
     }
 }

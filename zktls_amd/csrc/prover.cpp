@@ -141,18 +141,18 @@ static int run_quotient_air(zkhip_ctx* ctx, const AirView& air, const uint32_t* 
     air_device_image(air, alpha, body, weights, scale);
     std::vector<uint32_t> pub(air.n_public ? air.n_public : 1, 0u);
     for (uint32_t i = 0; i < air.n_public; i++) pub[i] = to_monty(public_values[i]);
-    // the flattened form for the term-parallel kernel (up to 256 public values: they travel in every point's LDS slots -- a quarter of a column group each; the SHA-256 chip reads 91 / 107 since its padding is constrained in-circuit)
+    // the flattened form for the term-parallel kernels: one record per monomial of COLUMNS and selectors -- a term's public-value factors are
+    // constants of the proof and multiply its coefficient here (until round 5 they travelled in every point's LDS slots, which held a
+    // program to 256 of them: the shard verifier's transcript table reads every public value of a join -- 64 x 91 -- and its 1 472
+    // constraints ran on the row-per-lane interpreter, 15 ms of a 156 ms compression)
     std::vector<uint32_t> recs;
     uint32_t cls[6] = {0, 0, 0, 0, 0, 0};
     // (not inside a lock-step batch: the batched twin takes its arguments from memory, its record loads then are per-lane loads of one
     // address instead of scalar loads, and that form is slower than the 8-point kernel)
-    // (the public values a program READS count, not the ones it declares: the chips of a machine declare the machine's, most read none --
-    // the shard verifier's join declares 16 x 9 and only its transcript table reads them)
-    const uint32_t pub_used = air_public_used(air);
     const bool wide = !t_batcher && ld % 4 == 0 && (reinterpret_cast<uintptr_t>(lde) & 15u) == 0 &&
-                      air_wide_form(width, (uint32_t)air_term_count(air), log_n, pub_used);
-    if (wide) air_term_records_wide(air, alpha, recs, cls, scale);
-    else if (pub_used <= 256) air_term_records(air, alpha, recs, scale);
+                      air_wide_form(width, (uint32_t)air_term_count(air), log_n, 0);
+    if (wide) air_term_records_wide(air, alpha, pub.data(), recs, cls, scale);
+    else air_term_records(air, alpha, pub.data(), recs, scale);
     // one staging buffer: body | weights (16-byte aligned) | public values | term records (16-byte aligned)
     const size_t body_w = (body.size() + 3) & ~(size_t)3, pub_w = (pub.size() + 3) & ~(size_t)3;
     std::vector<uint32_t> stage(body_w + weights.size() + pub_w + recs.size(), 0u);
@@ -174,7 +174,7 @@ static int run_quotient_air(zkhip_ctx* ctx, const AirView& air, const uint32_t* 
     q.weights = (const uint32_t*)d_stage + body_w; q.pub = (const uint32_t*)d_stage + body_w + weights.size();
     q.out = out_chunks; q.lde_out = lde_out; q.lde_ld = lde_ld;
     q.recs = recs.empty() ? nullptr : (const uint32_t*)d_stage + body_w + weights.size() + pub_w;
-    q.n_terms = (uint32_t)(recs.size() / 8); q.n_public = recs.empty() ? air.n_public : pub_used;
+    q.n_terms = (uint32_t)(recs.size() / 8); q.n_public = recs.empty() ? air.n_public : 0u;
     q.wide = wide ? 1u : 0u;
     for (int i = 0; i < 6; i++) q.cls[i] = cls[i];
     q.addend = addend;

@@ -823,8 +823,21 @@ struct HostSpan {                                           // a slice of the co
     size_t size() const { return n; }
     uint32_t& operator[](size_t i) const { return p[i]; }
 };
+// a table of zero words whose pages the kernel hands out on first touch (calloc): the fill threads touch them side by side -- a serial
+// memset of the 170 MB a join of 64 SHA-256 proofs fills took 32 ms of its 185
+struct ZeroedWords {
+    uint32_t* p = nullptr; size_t n = 0;
+    ZeroedWords() = default;
+    ZeroedWords(const ZeroedWords&) = delete;
+    ZeroedWords& operator=(const ZeroedWords&) = delete;
+    ~ZeroedWords() { std::free(p); }
+    bool reset(size_t words) { std::free(p); p = (uint32_t*)std::calloc(words ? words : 1, 4); n = p ? words : 0; return p != nullptr; }
+    uint32_t* data() { return p; }
+    const uint32_t* data() const { return p; }
+    size_t size() const { return n; }
+};
 struct HostTables {
-    std::vector<uint32_t> sc, op, rs, q, ts, sm, evl;       // SCALARS, OPENED, ROWSUM, QUERY, TS, SAMPLES (and, air mode, EVAL) main traces (all proofs)
+    ZeroedWords sc, op, rs, q, ts, sm, evl;       // SCALARS, OPENED, ROWSUM, QUERY, TS, SAMPLES (and, air mode, EVAL) main traces (all proofs)
     HostSpan desc, data, chain_in, trows;                   // P2R: chains, their data, the transcript rows' input states and row numbers -- consecutive slices of ONE pinned block
                                                             // (every word is written by fill_one: nothing is cleared)
     std::vector<const uint32_t*> want_roots;                // per chain: where it must end (canonical words; owned by the witnesses)
@@ -1113,15 +1126,6 @@ static int shard_verifier_prove_impl(zkhip_ctx* ctx, const zkhip_machine_key* ke
     if (inner_prm->log_blowup != 1 || inner_prm->logup_pairs != 0 || inner_prm->log_fold > 1 || inner_prm->log_final != 0 || (inner_prm->hash_width != 0 && inner_prm->hash_width != 16) ||
         inner_prm->code_width != 0)
         return fail(ZKHIP_ERR_INVALID, "prove_shard_verifier: version-1 shard proofs (SP1 shape: blowup 2, fold by 2, constant final value, no lookups)");
-    Shape sh;
-    ZK_TRY(make_shape(log_n, width, (size_t)inner_prm->num_queries, inner_prm->pow_bits, n_public, n_proofs, sh, program, program_words));
-    ZK_TRY(check_outer(sh, outer));
-    const auto mp = machine_of(sh);
-    const Machine& m = *mp;
-    const int R = sh.R, Q = sh.Q, NP = sh.NP;
-    const ScCols scc = sc_cols(sh);
-    const uint32_t sc_w = rup4(scc.end - sc_pre(sh));
-    const uint32_t w_main[N_CHIPS] = {P2_MAIN, RS_MAIN, frichip::width_of(R, true, true), TS_MAIN, Q_MAIN, OP_MAIN, frichip::S_MAIN, sc_w, EV_MAIN};
 #ifdef ZKHIP_AB_HOOKS
     static const bool timing = getenv("ZKHIP_REC_TIMING") != nullptr;
     auto t_last = std::chrono::steady_clock::now();
@@ -1135,13 +1139,25 @@ static int shard_verifier_prove_impl(zkhip_ctx* ctx, const zkhip_machine_key* ke
 #else
     auto lap = [](const char*) {};
 #endif
+    Shape sh;
+    ZK_TRY(make_shape(log_n, width, (size_t)inner_prm->num_queries, inner_prm->pow_bits, n_public, n_proofs, sh, program, program_words));
+    ZK_TRY(check_outer(sh, outer));
+    const auto mp = machine_of(sh);
+    const Machine& m = *mp;
+    const int R = sh.R, Q = sh.Q, NP = sh.NP;
+    const ScCols scc = sc_cols(sh);
+    const uint32_t sc_w = rup4(scc.end - sc_pre(sh));
+    const uint32_t w_main[N_CHIPS] = {P2_MAIN, RS_MAIN, frichip::width_of(R, true, true), TS_MAIN, Q_MAIN, OP_MAIN, frichip::S_MAIN, sc_w, EV_MAIN};
+    lap("shape + machine");
     HostTables ht;
-    ht.sc.assign((size_t)sc_w << m.height[C_SCALARS], 0u); ht.op.assign((size_t)OP_MAIN << m.height[C_OPENED], 0u); ht.rs.assign((size_t)RS_MAIN << m.height[C_ROWSUM], 0u);
-    ht.q.assign((size_t)Q_MAIN << m.height[C_QUERY], 0u); ht.ts.assign((size_t)TS_MAIN << m.height[C_TS], 0u); ht.sm.assign((size_t)frichip::S_MAIN << m.height[C_SAMPLES], 0u);
-    if (sh.air) ht.evl.assign((size_t)EV_MAIN << m.height[C_EVAL], 0u);
+    if (!ht.sc.reset((size_t)sc_w << m.height[C_SCALARS]) || !ht.op.reset((size_t)OP_MAIN << m.height[C_OPENED]) || !ht.rs.reset((size_t)RS_MAIN << m.height[C_ROWSUM]) ||
+        !ht.q.reset((size_t)Q_MAIN << m.height[C_QUERY]) || !ht.ts.reset((size_t)TS_MAIN << m.height[C_TS]) || !ht.sm.reset((size_t)frichip::S_MAIN << m.height[C_SAMPLES]) ||
+        (sh.air && !ht.evl.reset((size_t)EV_MAIN << m.height[C_EVAL])))
+        return fail(ZKHIP_ERR_NOMEM, "prove_shard_verifier: no host memory for the machine's tables");
     std::vector<Witness> wts((size_t)NP);
     std::vector<std::vector<uint32_t>> words((size_t)NP);
     std::vector<Ext> fas((size_t)NP);
+    lap("host: tables zeroed");
     {
         // the shared lists have a fixed slice per proof (the shape fixes every size): the proofs are filled side by side
         const size_t chains_per = (size_t)Q * (size_t)R + 2 * (size_t)Q, seg = 8 * (size_t)Q * (size_t)R + zkhip_fri_view_path_words(R) * (size_t)Q + inner_len[0] / 4;
@@ -1217,7 +1233,7 @@ static int shard_verifier_prove_impl(zkhip_ctx* ctx, const zkhip_machine_key* ke
     }
     lap("device: P2R rows + roots back");
     // the host tables up, then the machine's proof
-    const std::vector<uint32_t>* host[N_CHIPS] = {nullptr, &ht.rs, nullptr, &ht.ts, &ht.q, &ht.op, &ht.sm, &ht.sc, &ht.evl};
+    const ZeroedWords* host[N_CHIPS] = {nullptr, &ht.rs, nullptr, &ht.ts, &ht.q, &ht.op, &ht.sm, &ht.sc, &ht.evl};
     for (int c = 0; c < m.n; c++) if (host[c]) ZK_TRY(dev_h2d(ctx, dev[c], host[c]->data(), host[c]->size() * 4));
     zkhip_chip chips[N_CHIPS]{};
     for (int i = 0; i < m.n; i++) {
