@@ -207,6 +207,22 @@ extern "C" {
         proofs: *const u8, proof_stride: usize, proof_lens: *const usize, n_shards: usize, chain: *const u32, log_blocks_per_shard: c_int,
         digest: *const u8, message_len: u64, prm: *const ZkhipParams, bad_shard: *mut usize, reason: *mut c_int,
     ) -> c_int;
+    // the chain as ONE proof (core -> compress on a statement about real data): the shards verified in-circuit (air mode of the shard verifier)
+    pub fn zkhip_sha256_compress_setup(
+        ctx: *mut ZkhipCtx, message_len: usize, log_blocks_per_shard: c_int, inner: *const ZkhipParams, outer: *const ZkhipParams,
+        key: *mut *mut ZkhipMachineKey, vk: *mut u32,
+    ) -> c_int;
+    pub fn zkhip_sha256_compress_key_host(message_len: usize, log_blocks_per_shard: c_int, inner: *const ZkhipParams, outer: *const ZkhipParams, vk: *mut u32) -> c_int;
+    pub fn zkhip_sha256_compressed_proof_size(message_len: usize, log_blocks_per_shard: c_int, inner: *const ZkhipParams, outer: *const ZkhipParams) -> usize;
+    pub fn zkhip_prove_sha256_compressed(
+        ctx: *mut ZkhipCtx, key: *const ZkhipMachineKey, devices: *const c_int, n_devices: c_int, message: *const u8, message_len: usize,
+        log_blocks_per_shard: c_int, inner: *const ZkhipParams, outer: *const ZkhipParams, in_flight_per_device: c_int, digest: *mut u8,
+        chain: *mut u32, proof: *mut u8, cap: usize, len: *mut usize,
+    ) -> c_int;
+    pub fn zkhip_verify_sha256_compressed(
+        proof: *const u8, len: usize, digest: *const u8, message_len: u64, chain: *const u32, log_blocks_per_shard: c_int, vk: *const u32,
+        inner: *const ZkhipParams, outer: *const ZkhipParams, reason: *mut c_int,
+    ) -> c_int;
     pub fn zkhip_verify_merkle_paths(proof: *const u8, len: usize, root: *const u32, n_paths: usize, prm: *const ZkhipParams, reason: *mut c_int) -> c_int;
     // the first piece of the compress stage (sp1.rs:116): the FRI check of many shard proofs proven in-circuit by one call; the outer
     // proofs are verified with (vk, final value, challenger capacity) beside them

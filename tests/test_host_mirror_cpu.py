@@ -445,6 +445,36 @@ def test_a_large_transcript_is_proven_as_a_chain_of_shards(lib):
     assert verify_blob(lib, bytes(tampered), out, None)[0] != 0
 
 
+@pytest.mark.gpu
+def test_a_large_transcript_leaves_as_one_proof_with_compress(lib):
+    """with_input_commitment().with_compress() on a 2.5 MiB input: the chain of three shard proofs is verified in-circuit and leaves as ONE
+    proof (blob flags INPUT_SHA256 | CHAINED | COMPRESSED: chaining values, the proof, the key, the length); the consumer's check derives
+    the key on the host and takes nothing else"""
+    import hashlib
+    cbor = np.random.default_rng(3).integers(0, 256, (5 << 19) + 77, dtype=np.uint8).tobytes()
+    L = lib
+    L.zktls_guest_prove_commitment_compressed.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, C.c_char_p, C.c_size_t, C.c_char_p, C.c_size_t,
+                                                          C.POINTER(C.POINTER(C.c_uint8)), C.POINTER(C.c_size_t), C.POINTER(C.POINTER(C.c_uint8)),
+                                                          C.POINTER(C.c_size_t), C.c_char_p, C.c_size_t]
+    out, outn, pr, prn = C.POINTER(C.c_uint8)(), C.c_size_t(), C.POINTER(C.c_uint8)(), C.c_size_t()
+    err = C.create_string_buffer(512)
+    rc = L.zktls_guest_prove_commitment_compressed(0, 2, 20, 6, cbor, len(cbor), b"\x7fELFguest", 9, C.byref(out), C.byref(outn), C.byref(pr), C.byref(prn), err, 512)
+    assert rc == 0, err.value
+    o, blob = bytes(bytearray(out[i] for i in range(outn.value))), bytes(np.ctypeslib.as_array(pr, shape=(prn.value,)))
+    L.zktls_free(out), L.zktls_free(pr)
+    assert o == hashlib.sha256(cbor).digest() and L.zktls_batch_flags(blob, len(blob)) == 2 | 8 | 16
+    offs, lens = (C.c_size_t * 8)(), (C.c_size_t * 8)()
+    assert L.zktls_unpack_batch(blob, len(blob), offs, lens, 8) == 4 and lens[0] == 4 * 32 and lens[2] == 32 and lens[3] == 8
+    assert lens[1] < 700_000                                                      # (three shard proofs of 20 queries are 1.2 MB)
+    assert verify_blob(lib, blob, o, None) == (0, 0)
+    assert verify_blob(lib, blob, hashlib.sha256(b"other").digest(), None)[0] != 0
+    for at in (offs[0] + 40, offs[1] + 5000, offs[2] + 3, offs[3]):              # a chaining value, the proof, the key, the length
+        tampered = bytearray(blob)
+        tampered[at] ^= 1
+        assert verify_blob(lib, bytes(tampered), o, None)[0] != 0, at
+    print("2.5 MiB input: blob of %d bytes" % len(blob))
+
+
 def test_a_consumer_checks_a_chained_commitment_blob_on_the_cpu(lib, oracle):
     """the CHAINED form of the commitment blob (inputs beyond one chip proof) checked without a GPU: entry 0 = the chaining values, then
     the shard proofs -- here two shards proven by the ORACLE from the Python restatement's traces.  The mirror shards at 2^14 blocks, so a

@@ -148,36 +148,55 @@ int make_shape(int log_n, uint32_t width, size_t n_queries, int pow_bits, size_t
     s.air = program != nullptr; s.HL = 6;
     s.terms.clear(); s.mult.clear(); s.prog_id.clear(); s.KSPAN = 0;
     if (program) {
-        AirView av;
-        if (!air_validate(program, program_words, width, n_public, &av) || av.lqd != 1)
-            return fail(ZKHIP_ERR_INVALID, "shard verifier: the inner program must be a valid constraint program of this width and public-value count with log_quotient_degree 1");
+        // (what follows depends on (program, width, public values) alone and costs 4 ms for the SHA-256 chip's program -- its digest is a
+        // sponge over 20 000 words --: the last few programs' results are kept)
+        struct AirPart { std::vector<uint32_t> prog; uint32_t width, npub, dg[8]; std::vector<Shape::ETerm> terms; std::vector<uint32_t> mult; };
+        static std::mutex mu;
+        static std::vector<std::shared_ptr<const AirPart>> kept;
+        std::shared_ptr<const AirPart> part;
+        {
+            std::lock_guard<std::mutex> lk(mu);
+            for (const auto& k : kept)
+                if (k->width == width && k->npub == (uint32_t)n_public && k->prog.size() == program_words && std::memcmp(k->prog.data(), program, program_words * 4) == 0) { part = k; break; }
+        }
+        s.KSPAN = 1u + 2u * width + (uint32_t)n_public + 3u;
+        if (!part) {
+            AirView av;
+            if (!air_validate(program, program_words, width, n_public, &av) || av.lqd != 1)
+                return fail(ZKHIP_ERR_INVALID, "shard verifier: the inner program must be a valid constraint program of this width and public-value count with log_quotient_degree 1");
+            auto np = std::make_shared<AirPart>();
+            np->prog.assign(program, program + program_words); np->width = width; np->npub = (uint32_t)n_public;
+            air_digest(av, np->dg);
+            np->mult.assign(s.KSPAN, 0u);
+            size_t p = 6;
+            for (uint32_t k = 0; k < program[3]; k++) {
+                const uint32_t sel = program[p++], nt = program[p++];
+                for (uint32_t t = 0; t < nt; t++) {
+                    Shape::ETerm e{program[p], {0u, 0u, 0u}, t == 0 ? 1u : 0u};
+                    const uint32_t d = program[p + 1];
+                    p += 2;
+                    uint32_t nf = 0;
+                    if (d + (sel ? 1u : 0u) > 3) return fail(ZKHIP_ERR_INVALID, "shard verifier: a term of the inner program has more than three factors");
+                    for (uint32_t j = 0; j < d; j++) {
+                        const uint32_t v = program[p++], kind = v >> 30, idx = v & 0xFFFFu;
+                        e.key[nf++] = kind == 0 ? s.key_local(idx) : (kind == 1 ? s.key_next(idx) : s.key_pub(idx));
+                    }
+                    if (sel) e.key[nf++] = s.key_sel(sel - 1u);        // program selectors: 1 first row, 2 last row, 3 transition
+                    for (int j = 0; j < 3; j++) np->mult[e.key[j]]++;
+                    np->terms.push_back(e);
+                }
+            }
+            if (np->terms.empty() || np->terms.size() > ((size_t)1 << 20)) return fail(ZKHIP_ERR_INVALID, "shard verifier: the inner program has no terms, or more than 2^20");
+            part = np;
+            std::lock_guard<std::mutex> lk(mu);
+            if (kept.size() >= 4) kept.erase(kept.begin());
+            kept.push_back(part);
+        }
         // the header of a version-7 proof of the SP1 shape: + logup_pairs 0, fold by 2^1, constant final value, Poseidon2 width 16, the program's digest
         s.HL = 18;
         s.head[6] = 0u; s.head[7] = 1u; s.head[8] = 0u; s.head[9] = 16u;
-        uint32_t dg[8];
-        air_digest(av, dg);
-        for (int i = 0; i < 8; i++) { s.head[10 + i] = dg[i]; s.prog_id.push_back(dg[i]); }
-        s.KSPAN = 1u + 2u * width + (uint32_t)n_public + 3u;
-        s.mult.assign(s.KSPAN, 0u);
-        size_t p = 6;
-        for (uint32_t k = 0; k < program[3]; k++) {
-            const uint32_t sel = program[p++], nt = program[p++];
-            for (uint32_t t = 0; t < nt; t++) {
-                Shape::ETerm e{program[p], {0u, 0u, 0u}, t == 0 ? 1u : 0u};
-                const uint32_t d = program[p + 1];
-                p += 2;
-                uint32_t nf = 0;
-                if (d + (sel ? 1u : 0u) > 3) return fail(ZKHIP_ERR_INVALID, "shard verifier: a term of the inner program has more than three factors");
-                for (uint32_t j = 0; j < d; j++) {
-                    const uint32_t v = program[p++], kind = v >> 30, idx = v & 0xFFFFu;
-                    e.key[nf++] = kind == 0 ? s.key_local(idx) : (kind == 1 ? s.key_next(idx) : s.key_pub(idx));
-                }
-                if (sel) e.key[nf++] = s.key_sel(sel - 1u);        // program selectors: 1 first row, 2 last row, 3 transition
-                for (int j = 0; j < 3; j++) s.mult[e.key[j]]++;
-                s.terms.push_back(e);
-            }
-        }
-        if (s.terms.empty() || s.terms.size() > ((size_t)1 << 20)) return fail(ZKHIP_ERR_INVALID, "shard verifier: the inner program has no terms, or more than 2^20");
+        for (int i = 0; i < 8; i++) { s.head[10 + i] = part->dg[i]; s.prog_id.push_back(part->dg[i]); }
+        s.terms = part->terms; s.mult = part->mult;
     }
     const int n0 = s.HL + 8 + s.NPUB;
     s.f0 = n0 / 8; s.r0 = n0 % 8;

@@ -256,6 +256,20 @@ int verify_commitment_blob(const std::vector<uint8_t>& blob, const std::vector<u
         const bool defaults = num_queries == 100 && pow_bits == 16;
         prm = zkhip_params{2, defaults ? 50 : num_queries, defaults ? 0 : pow_bits, 0, 4, lf, 24, 0};
     }
+    if ((flags & BATCH_FLAG_CHAINED) && (flags & BATCH_FLAG_COMPRESSED)) {
+        // entry 0: the chaining values, entry 1: the ONE proof (the shards verified in-circuit), entry 2: the key the prover used.  The key
+        // is a function of (shard count, shapes): derived HERE, on the host's cores -- the blob's copy only has to agree
+        if (proofs.size() != 3 || proofs[2].size() != 32 || proofs[0].size() < 64 || proofs[0].size() % 32) return -1;
+        const size_t n = proofs[0].size() / 32 - 1;
+        if (zkhip_sha256_sharded_count((size_t)message_len, 14) != n) { if (reason) *reason = 1; return -1; }
+        uint32_t key[8];
+        if (zkhip_sha256_compress_key_host((size_t)message_len, 14, &prm, &prm, key) != ZKHIP_OK) return -1;
+        if (std::memcmp(key, proofs[2].data(), 32) != 0) { if (reason) *reason = 2; return -1; }
+        std::vector<uint32_t> chain((n + 1) * 8);
+        std::memcpy(chain.data(), proofs[0].data(), proofs[0].size());
+        return zkhip_verify_sha256_compressed(proofs[1].data(), proofs[1].size(), output.data(), message_len, chain.data(), 14, key, &prm, &prm, reason);
+    }
+    if (flags & BATCH_FLAG_COMPRESSED) { if (reason) *reason = 2; return -1; }
     if (flags & BATCH_FLAG_CHAINED) {                    // entry 0: the chaining values; entries 1..n: the shard proofs
         const size_t n = proofs.size() - 1;
         if (n < 1 || proofs[0].size() != (n + 1) * 32) return -1;
@@ -311,6 +325,44 @@ ProveResult HipGuestProver::prove_inner(const GuestInput& input, const std::vect
             const int k = 14;
             const size_t n = zkhip_sha256_sharded_count(input.cbor.size(), k), stride = zkhip_sha256_shard_proof_size(k, &prm);
             if (n == 0 || stride == 0) throw std::runtime_error(std::string("input commitment: ") + zkhip_last_error());
+            if (compress_) {
+                // core -> compress (sp1.rs:116) on the chain: the shards (dealt over the devices) verified in-circuit on the first device -- ONE
+                // proof.  Blob: the chaining values, the proof, the key of (shard count, shapes), the length; checked like sp1.rs:120 with
+                // the key this context made (a consumer derives it on its host: verify_commitment_blob)
+                const size_t ccap = zkhip_sha256_compressed_proof_size(input.cbor.size(), k, &prm, &prm);
+                if (ccap == 0) throw std::runtime_error(std::string("input commitment, compressed: ") + zkhip_last_error());
+                CtxGuard g;
+                constexpr size_t PLACEHOLDER = 256;
+                if (!g.take(devices_[0], PLACEHOLDER)) {
+                    g.device = devices_[0]; g.trace_bytes = PLACEHOLDER;
+                    if (zkhip_ctx_create(devices_[0], nullptr, &g.ctx) != ZKHIP_OK) fail_zkhip("zkhip_ctx_create");
+                    if (zkhip_malloc(g.ctx, PLACEHOLDER, &g.d_trace) != ZKHIP_OK) fail_zkhip("zkhip_malloc");
+                }
+                struct KeyGuard { zkhip_machine_key* k = nullptr; ~KeyGuard() { if (k) zkhip_machine_key_destroy(k); } } ck;
+                uint32_t root[8];
+                if (zkhip_sha256_compress_setup(g.ctx, input.cbor.size(), k, &prm, &prm, &ck.k, root) != ZKHIP_OK) fail_zkhip("zkhip_sha256_compress_setup");
+                std::vector<uint32_t> chain((n + 1) * 8);
+                std::vector<uint8_t> proof(ccap);
+                uint8_t digest32[32];
+                size_t len = 0;
+                int reason = 0;
+                if (zkhip_prove_sha256_compressed(g.ctx, ck.k, devices_.data(), (int)devices_.size(), input.cbor.data(), input.cbor.size(), k, &prm, &prm, 2, digest32, chain.data(),
+                                                  proof.data(), ccap, &len) != ZKHIP_OK)
+                    fail_zkhip("zkhip_prove_sha256_compressed");
+                g.healthy = true;
+                proof.resize(len);
+                if (zkhip_verify_sha256_compressed(proof.data(), len, digest32, (uint64_t)input.cbor.size(), chain.data(), k, root, &prm, &prm, &reason) != ZKHIP_OK)
+                    fail_zkhip("zkhip_verify_sha256_compressed");
+                std::vector<std::vector<uint8_t>> entries;
+                entries.emplace_back((const uint8_t*)chain.data(), (const uint8_t*)chain.data() + chain.size() * 4);
+                entries.push_back(std::move(proof));
+                entries.emplace_back((const uint8_t*)root, (const uint8_t*)root + 32);
+                entries.push_back(length_entry(input.cbor.size()));
+                r.output.assign(digest32, digest32 + 32);
+                r.proof = pack_shard_proofs(entries, BATCH_FLAG_INPUT_SHA256 | BATCH_FLAG_CHAINED | BATCH_FLAG_COMPRESSED);
+                r.ok = true;
+                return r;
+            }
             std::vector<uint8_t> buf(n * stride);
             std::vector<size_t> lens(n);
             std::vector<uint32_t> chain((n + 1) * 8);
@@ -676,10 +728,11 @@ int zktls_guest_prove_r0(int device, int mode, const zktls_shard_plan* plan, con
 }
 // the input-commitment guest (HipGuestProver::with_input_commitment): output = SHA-256 of the CBOR input, proof = a batch blob
 // flagged INPUT_SHA256 holding one SHA-256 chip proof; backend 0 SP1 shape, 1 RISC Zero shape
-int zktls_guest_prove_commitment(int backend, int device, int mode, int num_queries, int pow_bits, const uint8_t* cbor, size_t cbor_len,
-                                 const uint8_t* elf, size_t elf_len, uint8_t** output, size_t* output_len, uint8_t** proof,
-                                 size_t* proof_len, char* err, size_t err_cap) {
+static int prove_commitment(bool compress, int backend, int device, int mode, int num_queries, int pow_bits, const uint8_t* cbor, size_t cbor_len,
+                            const uint8_t* elf, size_t elf_len, uint8_t** output, size_t* output_len, uint8_t** proof,
+                            size_t* proof_len, char* err, size_t err_cap) {
     zktls::HipGuestProver p(device < 0 ? 0 : device, backend ? zktls::Backend::Risc0 : zktls::Backend::Sp1);
+    if (compress) p.with_compress();
     switch (mode) {
         case 0: p.mock(); break;
         case 1: p.local(); break;
@@ -703,6 +756,18 @@ int zktls_guest_prove_commitment(int backend, int device, int mode, int num_quer
     *proof = (uint8_t*)std::malloc(r.proof.size() ? r.proof.size() : 1);
     std::memcpy(*proof, r.proof.data(), r.proof.size());
     return 0;
+}
+int zktls_guest_prove_commitment(int backend, int device, int mode, int num_queries, int pow_bits, const uint8_t* cbor, size_t cbor_len,
+                                 const uint8_t* elf, size_t elf_len, uint8_t** output, size_t* output_len, uint8_t** proof,
+                                 size_t* proof_len, char* err, size_t err_cap) {
+    return prove_commitment(false, backend, device, mode, num_queries, pow_bits, cbor, cbor_len, elf, elf_len, output, output_len, proof, proof_len, err, err_cap);
+}
+// ... with the COMPRESS stage (sp1.rs:116: core -> compress): an input beyond one chip proof leaves as ONE proof instead of a chain of shard
+// proofs (blob flags INPUT_SHA256 | CHAINED | COMPRESSED); smaller inputs are one proof already and come out as above
+int zktls_guest_prove_commitment_compressed(int device, int mode, int num_queries, int pow_bits, const uint8_t* cbor, size_t cbor_len,
+                                            const uint8_t* elf, size_t elf_len, uint8_t** output, size_t* output_len, uint8_t** proof,
+                                            size_t* proof_len, char* err, size_t err_cap) {
+    return prove_commitment(true, 0, device, mode, num_queries, pow_bits, cbor, cbor_len, elf, elf_len, output, output_len, proof, proof_len, err, err_cap);
 }
 // setup -> prove -> verify as the reference calls them (sp1.rs:113, :116, :120) on the input-commitment guest, SP1 backend: vk_out
 // receives the 64-byte verifying key, the blob is flagged INPUT_SHA256 | KEYED

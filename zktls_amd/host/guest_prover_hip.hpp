@@ -99,6 +99,8 @@ public:
     // proof, entry 1 = 8 LE words of the shape's key + the shard count).  SP1 backend, synthetic shards, width a multiple of 8.  More shards
     // than one join holds (136 of the headline shape) take several joins of ONE shape (compress_join_size; entries 0 .. k-1, the key entry last).  verify_compressed_blob checks
     // such a blob on the host from (plan, input, ELF, key): the shard proofs are gone.
+    // With with_input_commitment() and an input beyond one chip proof (1 MiB): the chain of SHA-256 shard proofs becomes ONE proof the same way
+    // (zkhip_prove_sha256_compressed; blob flags INPUT_SHA256 | CHAINED | COMPRESSED) -- verify_commitment_blob checks it from (output, blob) alone.
     HipGuestProver& with_compress() { compress_ = true; return *this; }
     bool synthetic() const { return synthetic_; }
     ProverType mode() const { return mode_; }
@@ -140,6 +142,8 @@ constexpr uint32_t BATCH_FLAG_SYNTHETIC = 1u;
 constexpr uint32_t BATCH_FLAG_INPUT_SHA256 = 2u;     // one proof of the SHA-256 chip over the request's input bytes; the LAST entry is the input's length (8 LE bytes): with the padding constrained in-circuit the statement is "output = SHA-256 of a message of this length"
 constexpr uint32_t BATCH_FLAG_CHAINED = 8u;          // with INPUT_SHA256: an input beyond one chip proof (1 MiB): entry 0 = the chaining values ((n + 1) x 8 LE words), entries 1..n = the shard proofs of zkhip_prove_sha256_sharded (2^14 blocks per shard)
 constexpr uint32_t BATCH_FLAG_COMPRESSED = 16u;      // with SYNTHETIC: the shard proofs were joined into ONE proof (entry 0; k proofs when the shards do not fit one join); last entry = the shape's key (8 LE words) + the shard count
+//                                                      with INPUT_SHA256 | CHAINED (with_input_commitment().with_compress(), inputs beyond 1 MiB): entry 0 = the chaining values, entry 1 = the ONE
+//                                                      proof that verifies the shard proofs in-circuit (zkhip_prove_sha256_compressed), entry 2 = its key (8 LE words; a verifier derives it itself), then the length
 // shard proofs per join for an execution of `shards` shards of `plan`'s shape: one join while they fit (zkhip_shard_verifier_max_proofs: the
 // Poseidon2 chip's 2^22 rows -- 136 proofs of the headline shape); beyond, ceil(shards / max) joins of equal size J = ceil(shards / joins) --
 // the last one repeats the execution's last shard proof to fill its J places, so that every join has the same shape, hence the same key
