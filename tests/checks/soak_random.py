@@ -27,7 +27,7 @@ def with_quintic_identity(prog, col):
 budget = float(sys.argv[1]) if len(sys.argv) > 1 else 60.0
 rng = np.random.default_rng(int(time.time()))
 ctx = Context(0)
-t0 = time.time(); n_single = n_chips = n_air = n_machine = n_lookup = n_keyed = n_p2 = n_rec = 0
+t0 = time.time(); n_single = n_chips = n_air = n_machine = n_lookup = n_keyed = n_p2 = n_rec = n_rec_air = 0
 SEED = int(rng.integers(1, 2**40))
 while time.time() - t0 < budget:
     r_kind = rng.random()
@@ -52,7 +52,31 @@ while time.time() - t0 < budget:
         assert verify_shard_recursive(outer, log_n, width, q, pb, [v for p_ in pubs for v in p_], key.root, prm, n_proofs=nproofs) == (0, 0)
         key.close()
         n_rec += 1
-    elif r_kind < 0.01:
+    elif r_kind < 0.008:
+        # the same machine in AIR MODE: 1..3 version-7 proofs of a pseudo-random constraint program (degree <= 3, all three selectors, public
+        # values, next-row variables) verified inside ONE outer proof; key and bytes against the oracle on the restatement's arrays
+        log_n, width, q, pb = int(rng.integers(5, 9)), 8 * int(rng.integers(1, 4)), int(rng.integers(1, 7)), int(rng.integers(0, 5))
+        nproofs = int(rng.integers(1, 4))
+        pseed = int(rng.integers(0, 2**31))
+        oshape = (1, int(rng.integers(4, 12)), int(rng.integers(0, 6)))
+        iprm, prm, oprm = Params(1, q, pb), Params(*oshape), O.default_params(*oshape)
+        prog, trace, pub = airs.random_program_and_trace(pseed, log_n, width, int(rng.choice([2, 3])))
+        if O.air_log_quotient_degree(prog) != 1: continue
+        # (one program, hence one key: the proofs differ in their public values -- the counter's start -- through other seeds of the SAME structure
+        # is not what random_program_and_trace offers, so the join repeats the statement with fresh proofs of it)
+        inner, pubs = [], []
+        for p_ in range(nproofs):
+            inner.append(ctx.prove_shard_air(prog, ctx.from_numpy(trace), log_n, width, pub, iprm)); pubs.append(list(pub))
+        key = ctx.shard_verifier_setup(log_n, width, q, pb, 3, prm, n_proofs=nproofs, program=prog)
+        sh, mains, pres, progs, tabs, pv = recursion_air.machine([x.tobytes() for x in inner], log_n, width, pubs, q, pb, program=prog)
+        lns = [m.shape[0].bit_length() - 1 for m in mains]
+        assert key.root.tolist() == O.machine_setup(pres, lns, oprm).tolist(), ("air-mode key", pseed, log_n, width, q, pb, nproofs, oshape)
+        outer = ctx.prove_shard_verifier(key, inner, log_n, width, pubs, iprm, prm, program=prog)
+        assert outer.tobytes() == O.prove_machine_keyed(mains, pres, progs, tabs, pv, oprm).tobytes(), ("air-mode join", pseed, log_n, width, q, pb, nproofs, oshape)
+        assert verify_shard_recursive(outer, log_n, width, q, pb, [v for p_ in pubs for v in p_], key.root, prm, n_proofs=nproofs, program=prog) == (0, 0)
+        key.close()
+        n_rec_air += 1
+    elif r_kind < 0.014:
         # the Poseidon2 chip: random Merkle paths of a random tree; device trace against the Python restatement, proof bytes against the oracle
         depth, n_paths = int(rng.integers(1, 6)), int(rng.integers(1, 12))
         leaves, sibs, idx, root = poseidon2_air.tree_paths(depth, n_paths, seed=int(rng.integers(0, 2**31)))
@@ -193,5 +217,5 @@ while time.time() - t0 < budget:
         assert verify_chips(pf, [c[0] for c in chips], [c[1] for c in chips], [7], Params(*prm), prs, pas if cross else None) == (0, 0)
         for d in dev: d.free()
         n_chips += 1
-print("ok: %d single-matrix, %d multi-chip, %d constraint-program, %d chips-with-programs, %d lookup-machine, %d keyed-machine, %d Poseidon2-chip and %d shard-verifier (join) configurations in %.0f s"
-      % (n_single, n_chips, n_air, n_machine, n_lookup, n_keyed, n_p2, n_rec, time.time() - t0))
+print("ok: %d single-matrix, %d multi-chip, %d constraint-program, %d chips-with-programs, %d lookup-machine, %d keyed-machine, %d Poseidon2-chip, %d shard-verifier (join) and %d air-mode shard-verifier configurations in %.0f s"
+      % (n_single, n_chips, n_air, n_machine, n_lookup, n_keyed, n_p2, n_rec, n_rec_air, time.time() - t0))

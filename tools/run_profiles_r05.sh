@@ -25,6 +25,9 @@ grep -v "^$" $P/multichip.log | tail -60 > $P/multichip_phases.txt
 python3 tools/multichip_breakdown.py > $P/multichip_plain.log 2>&1; grep -E "chips prover|multichip shard" $P/multichip_plain.log | tail -24 > $P/multichip_phases_plain.txt
 # 2. the headline shard alone, one in flight: the clean per-proof table
 run_kt kt1 python3 bench.py --steps 10 --warmup 2 --no-cpu-baseline --streams 1 --no-batch64 --no-recursion16 --no-execution --no-multichip
+# 2b. 64 transcript proofs -> ONE proof (air mode of the shard verifier machine): kernels, and the phases (A/B build, no profiler)
+run_kt compress64 python3 tools/compress64_trace.py
+python3 tools/join_breakdown.py --sha 64 > $P/compress64_phases.log 2>&1; tail -19 $P/compress64_phases.log > $P/compress64_phases.txt
 if [ "$WHAT" = all ]; then
 # 3. the contract command (four in flight)
 run_kt kt python3 bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-multichip --no-execution

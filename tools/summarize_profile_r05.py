@@ -15,7 +15,7 @@ dst = os.path.join(ROOT, "profiles")
 commit = sys.argv[1] if len(sys.argv) > 1 else ""
 attempts = open(os.path.join(src, "attempts.txt")).read().strip().split("\n") if os.path.exists(os.path.join(src, "attempts.txt")) else []
 
-for name, tag in (("multichip", "multichip"), ("kt1", "streams1"), ("kt", "contract")):
+for name, tag in (("multichip", "multichip"), ("kt1", "streams1"), ("kt", "contract"), ("compress64", "compress64")):
     stats = glob.glob(os.path.join(src, name, "**", "*_kernel_stats.csv"), recursive=True)
     if not stats:
         continue
@@ -31,11 +31,14 @@ for name, tag in (("multichip", "multichip"), ("kt1", "streams1"), ("kt", "contr
         for r in rows:
             f.write("| %s | %s | %.3f | %.2f | %s |\n" % ((r["Name"][:r["Name"].rfind("(")] if r["Name"].endswith(")") else r["Name"]), r["Calls"], float(r["TotalDurationNs"]) / 1e6,
                                                          float(r["AverageNs"]) / 1e3, r["Percentage"]))
+    times = [line for line in open(os.path.join(src, name + ".log")) if "transcripts:" in line]
+    if times:
+        open(os.path.join(dst, tag + "_times_under_rocprof.txt"), "w").write("".join(times))
     for line in open(os.path.join(src, name + ".log")):
         if line.startswith("{"):
             open(os.path.join(dst, tag + "_bench_under_rocprof.json"), "w").write(line)
 for a, b in (("stream_pmc.md", "r05_stream_pass_pmc.md"), ("bench_default.json", "r05_bench_default.json"), ("multichip_phases.txt", "r05_multichip_phases_under_rocprof.txt"),
-             ("multichip_phases_plain.txt", "r05_multichip_phases.txt")):
+             ("multichip_phases_plain.txt", "r05_multichip_phases.txt"), ("compress64_phases.txt", "r05_compress64_phases.txt")):
     if os.path.exists(os.path.join(src, a)):
         shutil.copy(os.path.join(src, a), os.path.join(dst, b))
 print("\n".join(attempts))
