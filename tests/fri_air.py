@@ -32,8 +32,15 @@ INV2 = (P + 1) // 2
 EXT_W = 11
 
 
-def width_of(layers, wired=False, rec=False):
-    return ((L_REC if rec else L_WIRED if wired else L) + layers + 3) & ~3
+def width_of(layers, wired=False, rec=False, inject=None):
+    w = ((L_REC if rec else L_WIRED if wired else L) + layers + 3) & ~3
+    return w + 8 if inject is not None else w          # (machine mode: INJ [4], INJF behind the recursion form's columns)
+
+
+def inj_cols(layers):
+    """machine mode (tests/recursion_machine.py): INJ = what joins the folded value at this row (the reduced opening of the height just reached), INJF = the row has one"""
+    w = width_of(layers, rec=True)
+    return w, w + 4
 
 
 def n_public_of(layers):
@@ -45,7 +52,7 @@ def root_const(l):
     return two_adic_generator(l + 1)
 
 
-def program(layers, wired=False, transcript=False, rec=None):
+def program(layers, wired=False, transcript=False, rec=None, inject=None):
     """transcript: the fold chip of the TRANSCRIPT machine -- the challenges are no public values any more (the rows receive
     (layer, beta) on a bus from the ROOTS table, which has them from the Poseidon2 chip's transcript rows); public values: the final
     value, then the challenger's capacity (8 words, read by the Poseidon2 chip)"""
@@ -96,8 +103,17 @@ def program(layers, wired=False, transcript=False, rec=None):
     add(O.SEL_TRANSITION, [(1, [V(G), V(B)]), (P - 1, [V(GT), V(B, True)])])
     add(O.SEL_ALL, [(1, [V(END), V(B)]), (P - 1, [V(END), V(T)]), (P - (root_const(R) - 1), [V(END), V(T), V(K)])])
     add(O.SEL_TRANSITION, [(1, [V(L), V(X)]), (P - 1, [V(L), V(B, True)])])
-    for j in range(4):
-        add(O.SEL_TRANSITION, gated([(1, [V(FOLD + j)]), (P - 1, [V(OWN + j, True)])]))
+    if inject is None:
+        for j in range(4):
+            add(O.SEL_TRANSITION, gated([(1, [V(FOLD + j)]), (P - 1, [V(OWN + j, True)])]))
+    else:                                              # inject: the layers (>= 1) at whose row the height just reached adds its reduced opening
+        assert rec is not None and all(1 <= l < R for l in inject)
+        INJ, INJF = inj_cols(R)
+        for j in range(4):
+            add(O.SEL_TRANSITION, gated([(1, [V(FOLD + j)]), (1, [V(INJ + j, True)]), (P - 1, [V(OWN + j, True)])]))
+        add(O.SEL_ALL, [(1, [V(INJF)])] + [(P - 1, [V(L + l)]) for l in inject])
+        for j in range(4):
+            add(O.SEL_ALL, [(1, [V(INJ + j)]), (P - 1, [V(INJF), V(INJ + j)])])
     if rec is None:
         for j in range(4):
             add(O.SEL_ALL, [(1, [V(END), V(FOLD + j)]), (P - 1, [V(END), V((0 if transcript else 4 * R) + j, public=True)])])
@@ -108,7 +124,7 @@ def program(layers, wired=False, transcript=False, rec=None):
         add(O.SEL_ALL, [(1, [V(XS)]), (P - 1, [V(X)]), (2, [V(X), V(BIT)])])
         add(O.SEL_ALL, [(1, [V(LNX)]), (P - 1, [V(PT)]), (P - 1, [V(LN)])])
         add(O.SEL_TRANSITION, gated([(1, [V(PT)]), (P - 1, [V(PT, True)])]))
-        return O.air_program(width_of(R, rec=True), rec, cons)
+        return O.air_program(width_of(R, rec=True, inject=inject), rec, cons)
     return O.air_program(width_of(R, wired), N_PUBLIC_T if transcript else n_public_of(R), cons)
 
 
@@ -128,12 +144,13 @@ def log_rows_of(layers, n_queries):
     return lr
 
 
-def trace(view, log_rows=None, wired=False, rec=False, pt=0):
-    """-> (trace [2^log_rows][width] canonical, final value): one row per (query, layer), padding rows zero with T = 1"""
+def trace(view, log_rows=None, wired=False, rec=False, pt=0, inject=None):
+    """-> (trace [2^log_rows][width] canonical, final value): one row per (query, layer), padding rows zero with T = 1.
+    inject: per query {layer: value that joins the folded value at that layer's row} (machine mode)"""
     betas, queries = view["betas"], view["queries"]
     R = len(betas)
     H = R + 1
-    W = width_of(R, wired, rec)
+    W = width_of(R, wired, rec, inject=inject)
     L = L_REC if rec else L_WIRED if wired else globals()["L"]
     lr = log_rows if log_rows is not None else log_rows_of(R, len(queries))
     t = np.zeros((1 << lr, W), dtype=np.uint64)
@@ -144,6 +161,10 @@ def trace(view, log_rows=None, wired=False, rec=False, pt=0):
         tcol = []
         for l in range(R):
             row = t[q * R + l]
+            if inject is not None and l in inject[q]:
+                INJ, INJF = inj_cols(R)
+                row[INJ:INJ + 4], row[INJF] = inject[q][l], 1
+                own = [(a + b) % P for a, b in zip(own, inject[q][l])]
             bit, k = idx & 1, idx >> 1
             e0, e1 = (sibs[l], own) if bit else (own, sibs[l])
             fold, x, xi = fold_pair(k, H - (l + 1), betas[l], e0, e1)

@@ -60,10 +60,12 @@ def mixed_root(rows_by_height, h_max, index, siblings):
 
 
 def verify(proof_bytes, log_ns, widths, public_values, log_blowup=1, num_queries=100, pow_bits=16, pairs=None, partners=None,
-           programs=None, tables=None, pre_widths=None, pre_root=None):
+           programs=None, tables=None, pre_widths=None, pre_root=None, view=None):
     """raises Reject(reason) or returns True.  pairs / partners: versions 5 / 6; programs: version 9; programs + tables (a list,
     entries may be None): version 10; with pre_widths (per chip, 0: none) and pre_root (the key's 8 words): version 11, where
-    programs and tables address the combined row [preprocessed | main]."""
+    programs and tables address the combined row [preprocessed | main].
+    view: a dict that receives everything a verifier INSIDE a proof needs (tests/recursion_machine.py): roots, challenges, opened values,
+    cumulative sums, and per query the opened rows with their paths and the FRI siblings with theirs."""
     if len(proof_bytes) % 4:
         raise Reject("length")
     w = list(struct.unpack("<%dI" % (len(proof_bytes) // 4), bytes(proof_bytes)))
@@ -352,10 +354,14 @@ def verify(proof_bytes, log_ns, widths, public_values, log_blowup=1, num_queries
                 r = e_add(r, ext_mul(offs[c][6], ext_mul(e_sub(ae, y_en), inv2)))
             roh[lh[c]] = e_add(roh.get(lh[c], ZERO), r)
         val, idx = roh.get(h_max, ZERO), index
+        qview = {"index": index, "erows": {c: list(v) for c, v in erows.items()}, "epath": [list(d) for d in epath] if keyed else [], "trows": [list(r) for r in trows],
+                 "tpath": [list(d) for d in tpath], "prows": {c: list(v) for c, v in prows.items()}, "ppath": [list(d) for d in ppath] if lk else [],
+                 "qrows": [list(r) for r in qrows], "qpath": [list(d) for d in qpath], "roh": {h: list(v) for h, v in roh.items()}, "sibs": [], "paths": []}
         for l in range(L):
             rows_log = h_max - 1 - l
             sib = take(4)
             path = [take(8) for _ in range(rows_log)]
+            qview["sibs"].append(list(sib)), qview["paths"].append([list(d) for d in path])
             pair = [None, None]
             pair[idx & 1], pair[(idx & 1) ^ 1] = val, sib
             cur = pyref.sponge_hash(pair[0] + pair[1])
@@ -371,6 +377,13 @@ def verify(proof_bytes, log_ns, widths, public_values, log_blowup=1, num_queries
             idx = row
         if val != final:
             raise Reject("final value")
+        if view is not None:
+            view.setdefault("queries", []).append(qview)
     if pos != len(w):
         raise Reject("trailing words")
+    if view is not None:
+        view.update({"head": head, "entries": entries, "digests": digests, "trace_root": list(trace_root), "perm_root": list(perm_root) if lk else None,
+                     "quot_root": list(quot_root), "cumsum": [list(c) for c in cumsum], "gamma": gamma, "beta": beta_l, "alpha": list(alpha), "zeta": list(zeta),
+                     "fa": list(fa), "opened": opened, "layer_roots": layer_roots, "betas": [list(b_) for b_ in betas], "final": list(final), "witness": witness,
+                     "wp": wp, "pws": pws, "lh": lh, "cols": cols, "inter": inter})
     return True
