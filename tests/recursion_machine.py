@@ -1124,7 +1124,7 @@ def scalars_main(sh, scs, log_rows):
 # (a preprocessed flag says which); the row's two values go out on the value bus, its PW to the ROWSUM rows that weight a segment with it.
 OS_PRE = 24
 (OS_ACT, OS_TAG, OS_PFIRST, OS_NFP, OS_PID, OS_ISN, OS_NISN, OS_RST, OS_NRST, OS_K0, OS_M0, OS_K1, OS_M1, OS_KPW, OS_MPW, OS_KYH, OS_MYH) = range(17)
-OS_W, OS_FA, OS_FA2, OS_PW, OS_M, OS_YZIN, OS_YNIN, OS_YZO, OS_YNO, OS_MAIN = 0, 8, 12, 16, 20, 24, 28, 32, 36, 40
+OS_W, OS_FA, OS_FA2, OS_PW, OS_M, OS_YZIN, OS_YNIN, OS_YZO, OS_YNO, OS_PWN, OS_MAIN = 0, 8, 12, 16, 20, 24, 28, 32, 36, 40, 44
 BUS_YH0, BUS_YH1 = 107, 108
 PWSPAN = 1 << 14                                                                # exponents of one (proof, height) on BUS_PW
 
@@ -1154,7 +1154,8 @@ def opened_program(sh):
     cons.ext(O.SEL_ALL, esub(fa2, emul(fa, fa)))
     cons.ext(O.SEL_ALL, esub(mm, eadd(v0, emul(fa, v1))))
     cons.ext(O.SEL_ALL, egate(pv(OS_RST), esub(pw, ec(1))))
-    cons.ext(O.SEL_TRANSITION, egate(pv(OS_NRST, True), esub(ev(M0 + OS_PW, True), emul(pw, fa2))))
+    cons.ext(O.SEL_ALL, esub(ev(M0 + OS_PWN), emul(pw, fa2)))                  # (a column of its own: a transition constraint under a flag has one degree left)
+    cons.ext(O.SEL_TRANSITION, egate(pv(OS_NRST, True), esub(ev(M0 + OS_PW, True), ev(M0 + OS_PWN))))
     cons.ext(O.SEL_ALL, esub(ev(M0 + OS_YZO), eadd(ev(M0 + OS_YZIN), egate(pv(OS_NISN), emul(pw, mm)))))
     cons.ext(O.SEL_ALL, esub(ev(M0 + OS_YNO), eadd(ev(M0 + OS_YNIN), egate(pv(OS_ISN), emul(pw, mm)))))
     cons.ext(O.SEL_TRANSITION, egate(pv(OS_NRST, True), esub(ev(M0 + OS_YZIN, True), ev(M0 + OS_YZO))))
@@ -1238,6 +1239,7 @@ def opened_main(sh, ws, log_rows):
             r[OS_YZO:OS_YZO + 4], r[OS_YNO:OS_YNO + 4] = yz, yn
             pwh[(h, e)] = pw
             pw = ext_mul(pw, fa2)
+            r[OS_PWN:OS_PWN + 4] = pw
             if last:
                 yh[h] = (yz, yn)
         ys.append(yh), pws.append(pwh)

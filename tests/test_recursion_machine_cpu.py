@@ -1,0 +1,103 @@
+"""MACHINE MODE of the shard verifier machine -- a verifier of version-11 keyed-machine proofs in-circuit (docs/RECURSION_NEXT.md),
+restated in tests/recursion_machine.py -- on the CPU:
+  * its programs hold row by row in plain integers on the witness of oracle-made keyed-machine proofs (one height, mixed heights either way,
+    random machines with tuples of 1 .. 8 values and odd interaction counts), every bus balances, a flipped cell breaks a constraint or a bus;
+  * THE TREE: two shard proofs -> two shard-verifier proofs (eight chips each, version 11) -> ONE proof that verifies both in-circuit; the
+    oracle's generic keyed-machine prover proves it and two verifiers (the oracle's, the pure-Python multi-chip verifier) accept it from
+    (the level-1 machine's description, the shard proofs' public values, the key) -- and refuse other public values."""
+import numpy as np
+import pytest
+
+import machines as M
+import recursion_air as R
+import recursion_machine as RM
+import sha256_air as S
+
+SEED = 0x5A4B544C53
+
+
+def inner(O, mains, pres, progs, tabs, pub, q=2, pb=1):
+    """-> (the machine's description, its key, one proof of it)"""
+    lns = [m.shape[0].bit_length() - 1 for m in mains]
+    prm = O.default_params(1, q, pb)
+    vk = [int(x) for x in O.machine_setup(pres, lns, prm)]
+    proof = O.prove_machine_keyed(mains, pres, progs, tabs, pub, prm).tobytes()
+    chips = [dict(ln=lns[c], W=mains[c].shape[1], Pw=0 if pres[c] is None else pres[c].shape[1], prog=progs[c], tab=tabs[c]) for c in range(len(mains))]
+    return chips, vk, proof
+
+
+def holds(sh, mains, pres, progs, tabs, pv):
+    for name, main, pre, prog in zip(RM.order(sh), mains, pres, progs):
+        rows = main if pre is None else np.concatenate([pre, main], axis=1)
+        assert rows.shape[1] == int(prog[2]), name
+        assert S.check_rows(prog, rows, pv) == [], name
+    assert R.bus_balance(mains, pres, tabs) == []
+
+
+@pytest.mark.parametrize("log_users,bits", [(6, 3), (7, 3), (5, 3)])          # one height; the chip without preprocessed columns taller; the table taller
+def test_rows_hold_and_buses_balance_on_a_two_chip_machine(oracle, log_users, bits):
+    mains, pres, progs, tabs, pub = M.byte_machine(log_users, bits)
+    chips, vk, proof = inner(oracle, mains, pres, progs, tabs, pub)
+    holds(*RM.machine(chips, vk, [proof], [pub], 2, 1))
+
+
+@pytest.mark.parametrize("seed", [1, 4, 6])                                     # three heights; four chips, three of one height; tuples of several values, odd interaction counts
+def test_rows_hold_and_buses_balance_on_random_machines(oracle, seed):
+    mains, pres, progs, tabs, pub = M.random_keyed_machine(seed)
+    chips, vk, proof = inner(oracle, mains, pres, progs, tabs, pub)
+    holds(*RM.machine(chips, vk, [proof], [pub], 2, 1))
+
+
+def test_a_join_of_two_machine_proofs_and_flipped_cells(oracle):
+    """two proofs of one machine in ONE outer machine; then a flipped cell in every chip this mode adds or changes"""
+    made = [M.byte_machine(7, 3, seed) for seed in (1, 2)]
+    chips, vk, p0 = inner(oracle, *made[0])
+    _, vk1, p1 = inner(oracle, *made[1])
+    assert vk == vk1                                                            # (one key: the table's contents)
+    sh, mains, pres, progs, tabs, pv = RM.machine(chips, vk, [p0, p1], [made[0][4], made[1][4]], 2, 1)
+    holds(sh, mains, pres, progs, tabs, pv)
+    names = RM.order(sh)
+    rng = np.random.default_rng(7)
+    used = {"P2R": sh.NP * sh.p2_rows, "ROWSUM": sh.NP * len(RM.rowsum_rows(sh)), "TS": sh.NP * sh.NTS, "QUERY": sh.NP * sh.Q * len(sh.hs), "OPENED": sh.NP * sh.NV // 2,
+            "SCALARS": sh.NP * sh.C, "EVAL": sh.NP * len(sh.terms), "LOGUP": sh.NP * len(sh.lrows), "FOLD": sh.NP * sh.Q * sh.R}
+    broken = tried = 0
+    for name in ("ROWSUM", "OPENED", "QUERY", "LOGUP", "SCALARS", "EVAL", "FOLD", "TS", "P2R"):
+        i = names.index(name)
+        for _ in range(6):
+            r, c = int(rng.integers(0, used[name])), int(rng.integers(0, mains[i].shape[1]))
+            keep = int(mains[i][r, c])
+            mains[i][r, c] = (keep + 1) % R.P
+            rows = mains[i] if pres[i] is None else np.concatenate([pres[i], mains[i]], axis=1)
+            bad = bool(S.check_rows(progs[i], rows, pv)) or bool(R.bus_balance(mains, pres, tabs))
+            mains[i][r, c] = keep
+            tried += 1
+            broken += bad
+    # (cells no constraint reads exist: padding columns, value slots whose receive flag is off, the boundary rows' unused sides)
+    assert broken >= tried * 2 // 3, (broken, tried)
+
+
+def test_the_tree_two_levels_proven_by_the_oracle(oracle):
+    import pyverify_chips
+    O = oracle
+    log_n, width, q, pb = 5, 8, 1, 0
+    prm1, prm2 = O.default_params(1, 1, 0), O.default_params(1, 2, 0)
+    level1 = []
+    for shard in range(2):
+        pubs = [7, shard]
+        proof0 = O.prove_shard(O.gen_trace(SEED, shard, log_n, width), pubs, O.default_params(1, q, pb)).tobytes()
+        sh1, mains, pres, progs, tabs, pv = R.machine(proof0, log_n, width, pubs, q, pb)
+        lns = [m.shape[0].bit_length() - 1 for m in mains]
+        vk1 = O.machine_setup(pres, lns, prm1)
+        level1.append((O.prove_machine_keyed(mains, pres, progs, tabs, pv, prm1).tobytes(), pv))
+    chips = [dict(ln=lns[c], W=mains[c].shape[1], Pw=0 if pres[c] is None else pres[c].shape[1], prog=progs[c], tab=tabs[c]) for c in range(len(mains))]
+    assert len(chips) == 8 and len({c["ln"] for c in chips}) == 2            # the shard verifier machine: eight chips of two heights, one of them without preprocessed columns
+    sh, m2, p2, g2, t2, pv2 = RM.machine(chips, [int(x) for x in vk1], [o for o, _ in level1], [p for _, p in level1], 1, 0)
+    holds(sh, m2, p2, g2, t2, pv2)
+    lns2, w2, pw2 = [m.shape[0].bit_length() - 1 for m in m2], [m.shape[1] for m in m2], [0 if p is None else p.shape[1] for p in p2]
+    vk2 = O.machine_setup(p2, lns2, prm2)
+    top = O.prove_machine_keyed(m2, p2, g2, t2, pv2, prm2)
+    assert pv2 == [7, 0, 7, 1]
+    assert O.verify_machine_keyed(top, lns2, w2, pw2, vk2, g2, t2, pv2, prm2) == 0
+    assert pyverify_chips.verify(top.tobytes(), lns2, w2, pv2, log_blowup=1, num_queries=2, pow_bits=0, programs=g2, tables=t2, pre_widths=pw2, pre_root=[int(x) for x in vk2]) is True
+    assert O.verify_machine_keyed(top, lns2, w2, pw2, vk2, g2, t2, [7, 1, 7, 0], prm2) != 0          # the shards swapped: another statement
+    # (the top's key is a function of the level-1 MACHINE -- its programs, tables, key -- and the number of proofs: RM.preprocessed takes the shape, no proof)
