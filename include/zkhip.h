@@ -876,6 +876,38 @@ int zkhip_prove_shard_verifier_air(zkhip_ctx* ctx, const zkhip_machine_key* key,
                                    const zkhip_params* inner, const zkhip_params* outer, uint8_t* proof, size_t cap, size_t* len);
 int zkhip_verify_shard_recursive_air(const uint32_t* program, size_t program_words, const uint8_t* proof, size_t len, int log_n, uint32_t width, size_t n_queries, int inner_pow_bits,
                                      const uint32_t* public_values, size_t n_public, size_t n_proofs, const uint32_t vk[8], const zkhip_params* outer, int* reason);
+
+/* ---- MACHINE MODE (round 5): the inner proofs are version-11 proofs of a KEYED MACHINE -- chips of mixed heights, each with its constraint
+ * program (log_quotient_degree 1) and its interaction table, preprocessed columns committed by the inner key -- described by
+ * zkhip_machine_desc.  The shard verifier machine's own outer proofs are such proofs (zkhip_shard_verifier_describe[_air] gives their
+ * description, zkhip_shard_verifier_setup[_air] their key): with these entries the JOIN'S OUTPUT IS JOINABLE -- a tree of joins
+ * (sp1.rs:116 core -> compress; prover.rs:90 lift -> join).  Ten chips (csrc/machine_verifier.inl; tests/recursion_machine.py restates
+ * them): the transcript with gamma / beta, the permutation root and the cumulative sums; per chip its program and its LogUp constraints
+ * at zeta with its own selectors and quotient; per query the four mixed-height commitments (the inner key's tree, main, permutation,
+ * quotient: concatenated leaves, injection of the shorter matrices' rows), one reduced opening per height, FRI with the heights joining
+ * on the way down; proof of work.  The key is a function of (the inner machine's description, n_proofs); the verifier takes the
+ * description, the inner proofs' public values and the key -- no byte of an inner proof.  Inner proofs: blowup 2 (log_blowup 1), fold by
+ * 2, constant final value; at most 16 chips, widths in multiples of 4, every chip with a program and a table, at most 64 proofs. */
+typedef struct zkhip_machine_desc {
+    int32_t n_chips;                      /* tallest first */
+    const int32_t* log_ns;
+    const uint32_t* widths;               /* main widths */
+    const uint32_t* pre_widths;           /* 0: the chip has no preprocessed columns */
+    const uint32_t* const* programs; const size_t* program_words;      /* over the combined row [preprocessed | main] */
+    const uint32_t* const* tables; const size_t* table_words;
+    uint32_t key_root[8];                 /* the inner machine's key (canonical words) */
+    int32_t num_queries, pow_bits;        /* how its proofs are made */
+    uint32_t n_public;
+} zkhip_machine_desc;
+int zkhip_machine_verifier_setup(zkhip_ctx* ctx, const zkhip_machine_desc* inner, size_t n_proofs, const zkhip_params* outer, zkhip_machine_key** key, uint32_t vk[8]);
+int zkhip_machine_verifier_key_host(const zkhip_machine_desc* inner, size_t n_proofs, const zkhip_params* outer, uint32_t vk[8]);
+size_t zkhip_machine_verifier_proof_size(const zkhip_machine_desc* inner, size_t n_proofs, const zkhip_params* outer);
+int zkhip_prove_machine_verifier(zkhip_ctx* ctx, const zkhip_machine_key* key, const zkhip_machine_desc* inner, const uint8_t* const* proofs, const size_t* proof_lens, size_t n_proofs,
+                                 const uint32_t* public_values, size_t n_public, const zkhip_params* outer, uint8_t* proof, size_t cap, size_t* len);
+int zkhip_verify_machine_recursive(const zkhip_machine_desc* inner, const uint8_t* proof, size_t len, const uint32_t* public_values, size_t n_public, size_t n_proofs, const uint32_t vk[8],
+                                   const zkhip_params* outer, int* reason);
+size_t zkhip_machine_verifier_describe(const zkhip_machine_desc* inner, size_t n_proofs, int which, int kind, uint32_t* out, size_t cap, int* log_rows, uint32_t* main_width,
+                                       uint32_t* pre_width);
 size_t zkhip_shard_verifier_describe_air(const uint32_t* program, size_t program_words, int log_n, uint32_t width, size_t n_queries, int inner_pow_bits, size_t n_public,
                                          size_t n_proofs, int which, int kind, uint32_t* out, size_t cap_words, int* log_rows, uint32_t* main_width, uint32_t* pre_width);
 

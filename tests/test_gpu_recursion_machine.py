@@ -1,0 +1,95 @@
+"""MACHINE MODE of the shard verifier machine on the GPU (csrc/machine_verifier.inl through the C ABI): version-11 keyed-machine proofs verified
+in-circuit -- key and outer proof bytes against the oracle's generic keyed-machine prover run on the Python restatement's arrays
+(tests/recursion_machine.py) -- and THE TREE: shard proofs -> joins (zkhip_prove_shard_verifier) -> ONE proof that verifies the joins
+(zkhip_prove_machine_verifier), checked from (the join machine's description, the shard proofs' public values, the key)."""
+import numpy as np
+import pytest
+
+import machines as M
+import recursion_air as R
+import recursion_machine as RM
+from zktls_amd._lib import Params, ZkHipError
+from zktls_amd.device import InnerMachine, machine_verifier_key_host, shard_verifier_describe, verify_machine_recursive, verify_shard_recursive
+
+pytestmark = pytest.mark.gpu
+SEED = 0x5A4B544C53
+
+
+def inner_of(O, mains, pres, progs, tabs, pub, q, pb):
+    lns = [m.shape[0].bit_length() - 1 for m in mains]
+    prm = O.default_params(1, q, pb)
+    vk = [int(x) for x in O.machine_setup(pres, lns, prm)]
+    chips = [dict(ln=lns[c], W=mains[c].shape[1], Pw=0 if pres[c] is None else pres[c].shape[1], prog=progs[c], tab=tabs[c]) for c in range(len(mains))]
+    return chips, vk, O.prove_machine_keyed(mains, pres, progs, tabs, pub, prm)
+
+
+@pytest.mark.parametrize("which", ["byte-6-3", "byte-7-3", "byte-5-3", "random-4", "random-6"])
+def test_key_and_proof_bytes_equal_the_oracles(ctx, oracle, which):
+    O = oracle
+    kind, *args = which.split("-")
+    q, pb = 3, 1
+    made = [M.byte_machine(int(args[0]), int(args[1]), seed) for seed in (1, 2)] if kind == "byte" else [M.random_keyed_machine(int(args[0]))]
+    chips, vk, p0 = inner_of(O, *made[0], q, pb)
+    proofs, pubs = [p0], [made[0][4]]
+    if len(made) > 1:                                                            # a join of two proofs of one machine
+        proofs.append(inner_of(O, *made[1], q, pb)[2]), pubs.append(made[1][4])
+    n = len(proofs)
+    prm, oprm = Params(1, 20, 8), O.default_params(1, 20, 8)
+    im = InnerMachine(chips, vk, q, pb, len(pubs[0]))
+    key = ctx.machine_verifier_setup(im, prm, n)
+    sh, mains, pres, progs, tabs, pv = RM.machine(chips, vk, [p.tobytes() for p in proofs], pubs, q, pb)
+    lns = [m.shape[0].bit_length() - 1 for m in mains]
+    assert key.root.tolist() == O.machine_setup(pres, lns, oprm).tolist(), "the key differs from the oracle's commitment to the restatement's preprocessed traces"
+    assert machine_verifier_key_host(im, prm, n).tolist() == key.root.tolist()
+    outer = ctx.prove_machine_verifier(key, im, proofs, pubs, prm)
+    assert outer.tobytes() == O.prove_machine_keyed(mains, pres, progs, tabs, pv, oprm).tobytes(), "outer proof bytes differ from the oracle's"
+    assert verify_machine_recursive(im, outer, pv, key.root, prm, n) == (0, 0)
+    other = list(pv)
+    other[-1] = (other[-1] + 1) % R.P
+    assert verify_machine_recursive(im, outer, other, key.root, prm, n)[0] != 0
+    assert verify_machine_recursive(im, outer, pv, (key.root + 1) % R.P, prm, n)[0] != 0
+    bad = proofs[0].copy()
+    bad[bad.size // 2] ^= 1
+    with pytest.raises(ZkHipError):
+        ctx.prove_machine_verifier(key, im, [bad] + proofs[1:], pubs, prm)
+    key.close()
+
+
+def join_machine(log_n, width, q, pb, npub, n_proofs, key_root, oq, opb):
+    """the shard verifier machine for n_proofs shard proofs of a shape, as the inner machine of machine mode: the library's own description of it"""
+    chips = []
+    for i in range(8):
+        p, ln, mw, pw = shard_verifier_describe(log_n, width, q, pb, npub, i, 0, n_proofs)
+        t, _, _, _ = shard_verifier_describe(log_n, width, q, pb, npub, i, 1, n_proofs)
+        chips.append(dict(ln=ln, W=mw, Pw=pw, prog=p, tab=t))
+    return chips, InnerMachine(chips, key_root, oq, opb, npub * n_proofs)
+
+
+def test_the_tree_four_shard_proofs_two_joins_one_proof(ctx, oracle):
+    """level 0: four shard proofs; level 1: two joins of two (zkhip_prove_shard_verifier: eight chips, version 11); level 2: ONE proof that verifies both
+    joins in-circuit.  Bytes against the oracle on the restatement's arrays; the verifier takes the join machine's description, the four
+    shards' public values and the key"""
+    O = oracle
+    log_n, width, q, pb = 6, 16, 3, 1
+    iprm, jprm, tprm, oprm = Params(1, q, pb), Params(1, 4, 2), Params(1, 20, 8), O.default_params(1, 20, 8)
+    pubs = [[5, 6, 30 + s] for s in range(4)]
+    shards = [ctx.prove_shard(ctx.gen_trace(SEED, 40 + s, log_n, width), log_n, width, pubs[s], iprm) for s in range(4)]
+    jkey = ctx.shard_verifier_setup(log_n, width, q, pb, 3, jprm, n_proofs=2)
+    joins = [ctx.prove_shard_verifier(jkey, shards[2 * j:2 * j + 2], log_n, width, pubs[2 * j:2 * j + 2], iprm, jprm) for j in range(2)]
+    jpubs = [pubs[0] + pubs[1], pubs[2] + pubs[3]]
+    for j in range(2):
+        assert verify_shard_recursive(joins[j], log_n, width, q, pb, jpubs[j], jkey.root, jprm, n_proofs=2) == (0, 0)
+    chips, im = join_machine(log_n, width, q, pb, 3, 2, jkey.root, 4, 2)
+    tkey = ctx.machine_verifier_setup(im, tprm, 2)
+    top = ctx.prove_machine_verifier(tkey, im, joins, jpubs, tprm)
+    flat = [v for p_ in jpubs for v in p_]
+    assert verify_machine_recursive(im, top, flat, tkey.root, tprm, 2) == (0, 0)
+    assert machine_verifier_key_host(im, tprm, 2).tolist() == tkey.root.tolist()
+    sh, mains, pres, progs, tabs, pv = RM.machine(chips, [int(x) for x in jkey.root], [j.tobytes() for j in joins], jpubs, 4, 2)
+    lns = [m.shape[0].bit_length() - 1 for m in mains]
+    assert tkey.root.tolist() == O.machine_setup(pres, lns, oprm).tolist()
+    assert top.tobytes() == O.prove_machine_keyed(mains, pres, progs, tabs, pv, oprm).tobytes(), "the tree's top differs from the oracle's proof"
+    swapped = pubs[2] + pubs[3] + pubs[0] + pubs[1]
+    assert verify_machine_recursive(im, top, swapped, tkey.root, tprm, 2)[0] != 0
+    print("tree: 4 shard proofs %d B -> 2 joins %d B -> top %d B" % (sum(s.size for s in shards), sum(j.size for j in joins), top.size))
+    jkey.close(), tkey.close()

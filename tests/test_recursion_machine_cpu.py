@@ -101,3 +101,64 @@ def test_the_tree_two_levels_proven_by_the_oracle(oracle):
     assert pyverify_chips.verify(top.tobytes(), lns2, w2, pv2, log_blowup=1, num_queries=2, pow_bits=0, programs=g2, tables=t2, pre_widths=pw2, pre_root=[int(x) for x in vk2]) is True
     assert O.verify_machine_keyed(top, lns2, w2, pw2, vk2, g2, t2, [7, 1, 7, 0], prm2) != 0          # the shards swapped: another statement
     # (the top's key is a function of the level-1 MACHINE -- its programs, tables, key -- and the number of proofs: RM.preprocessed takes the shape, no proof)
+
+
+# ---------------------------------------------------------------------------------------------------------------- the product's machine == the restatement
+def described(im, n_proofs=1):
+    from zktls_amd.device import machine_verifier_describe
+    out = []
+    for i in range(10):
+        p, ln, mw, pw = machine_verifier_describe(im, i, 0, n_proofs)
+        t, _, _, _ = machine_verifier_describe(im, i, 1, n_proofs)
+        e, _, _, _ = machine_verifier_describe(im, i, 2, n_proofs)
+        out.append((p, t, e, ln, mw, pw))
+    return out
+
+
+def same_machine(chips, vk, q, pb, npub, n_proofs):
+    from zktls_amd.device import InnerMachine
+    sh = RM.MShape(chips, vk, q, pb, npub, n_proofs)
+    RM.build_reads(sh)
+    names, progs, tabs, pres, h = RM.order(sh), RM.programs(sh), RM.tables(sh), RM.preprocessed(sh), RM.heights(sh)
+    got = described(InnerMachine(chips, vk, q, pb, npub), n_proofs)
+    for nm, (p, t, e, ln, mw, pw) in zip(names, got):
+        assert ln == h[nm] and np.array_equal(p, np.asarray(progs[nm], dtype=np.uint32)), (nm, "program")
+        assert np.array_equal(t, np.asarray(tabs[nm], dtype=np.uint32)), (nm, "table")
+        want = np.zeros(0, dtype=np.uint32) if pres[nm] is None else pres[nm].ravel()
+        assert np.array_equal(e, want) and pw == (0 if pres[nm] is None else pres[nm].shape[1]), (nm, "preprocessed")
+    return sh, names, pres, h
+
+
+def chips_of(mains, pres, progs, tabs):
+    lns = [m.shape[0].bit_length() - 1 for m in mains]
+    return [dict(ln=lns[c], W=mains[c].shape[1], Pw=0 if pres[c] is None else pres[c].shape[1], prog=progs[c], tab=tabs[c]) for c in range(len(mains))], lns
+
+
+def test_product_machine_equals_the_restatement_word_for_word(oracle):
+    """csrc/machine_verifier.inl against tests/recursion_machine.py: programs, interaction tables and preprocessed traces of all ten chips, for
+    two-chip machines (one height, mixed either way), random machines, the shard verifier's own eight-chip machine (THE TREE's level 2), joins;
+    and the key computed on the host against the oracle's commitment to the restatement's preprocessed traces"""
+    from zktls_amd._lib import Params
+    from zktls_amd.device import InnerMachine, machine_verifier_key_host
+    O = oracle
+    cases = []
+    for a, b in ((6, 3), (7, 3), (5, 3)):
+        mains, pres, progs, tabs, pub = M.byte_machine(a, b)
+        chips, lns = chips_of(mains, pres, progs, tabs)
+        cases.append((chips, [int(x) for x in O.machine_setup(pres, lns, O.default_params(1, 2, 1))], 2, 1, len(pub)))
+    for seed in (1, 4, 6):
+        mains, pres, progs, tabs, pub = M.random_keyed_machine(seed)
+        chips, lns = chips_of(mains, pres, progs, tabs)
+        cases.append((chips, [int(x) for x in O.machine_setup(pres, lns, O.default_params(1, 3, 0))], 3, 0, len(pub)))
+    sh1 = R.Shape(5, 8, 1, 0, 2)
+    names1, progs1, tabs1, pres1, h1 = R.order(sh1), R.programs(sh1), R.tables(sh1), R.preprocessed(sh1), R.heights(sh1)
+    chips1 = [dict(ln=h1[n], W=int(progs1[n][2]) - (0 if pres1[n] is None else pres1[n].shape[1]), Pw=0 if pres1[n] is None else pres1[n].shape[1], prog=progs1[n], tab=tabs1[n]) for n in names1]
+    vk1 = [int(x) for x in O.machine_setup([pres1[n] for n in names1], [h1[n] for n in names1], O.default_params(1, 2, 0))]
+    cases.append((chips1, vk1, 2, 0, 2))
+    for i, (chips, vk, q, pb, npub) in enumerate(cases):
+        for n_proofs in (1, 3) if i in (1, 6) else (1,):
+            sh, names, pres, h = same_machine(chips, vk, q, pb, npub, n_proofs)
+            if i in (0, 1, 4):
+                pl, lns = [pres[n] for n in names], [h[n] for n in names]
+                want = [int(x) for x in O.machine_setup(pl, lns, O.default_params(1, 20, 8))]
+                assert machine_verifier_key_host(InnerMachine(chips, vk, q, pb, npub), Params(1, 20, 8), n_proofs).tolist() == want

@@ -97,10 +97,13 @@ struct Builder {
 inline uint32_t root_const(int l) { return from_monty(two_adic_generator(l + 1)); }
 
 // rec_public >= 0: the shard verifier's form, a program with that many public values (none of them its own)
-std::vector<uint32_t> build_program(int RL, bool wired, bool transcript = false, int rec_public = -1) {
+// (inject: machine mode of the shard verifier -- machine_verifier.inl: the layers >= 1 at whose row the reduced opening of the height just reached
+// joins the folded value; two more column groups behind the recursion form's: INJ [4], INJF)
+std::vector<uint32_t> build_program(int RL, bool wired, bool transcript = false, int rec_public = -1, const std::vector<int>* inject = nullptr) {
     const bool rec = rec_public >= 0;
     const uint32_t L = rec ? L_REC : wired ? L_WIRED : frichip::L;       // first layer-selector column of this form
-    const uint32_t W = width_of(RL, wired, rec), NP = rec ? (uint32_t)rec_public : n_public_of(RL, transcript), END = L + (uint32_t)RL - 1u;
+    const uint32_t W = width_of(RL, wired, rec) + (inject ? 8u : 0u), NP = rec ? (uint32_t)rec_public : n_public_of(RL, transcript), END = L + (uint32_t)RL - 1u;
+    const uint32_t INJ = width_of(RL, wired, rec), INJF = INJ + 4;
     const uint32_t inv2 = (P + 1) / 2;
     Builder b;
     // G * t for the gate G = ACTIVE - END ("an active row that is not the last of its query").  A selector counts one degree, so a
@@ -159,8 +162,16 @@ std::vector<uint32_t> build_program(int RL, bool wired, bool transcript = false,
     b.add(TRANSITION, Terms{{1u, {var(G), var(B)}}, {P - 1, {var(GT), var(B, true)}}});                                    // B = B' T
     b.add(ALL, Terms{{1u, {var(END), var(B)}}, {P - 1, {var(END), var(T)}}, {neg((uint64_t)root_const(RL) + P - 1), {var(END), var(T), var(K)}}});
     b.add(TRANSITION, Terms{{1u, {var(L), var(X)}}, {P - 1, {var(L), var(B, true)}}});                             // first layer: X = product over the higher bits
+    if (!inject)
     for (uint32_t j = 0; j < 4; j++)        // the folded value is the next layer's own entry
         b.add(TRANSITION, gated(Terms{{1u, {var(FOLD + j)}}, {P - 1, {var(OWN + j, true)}}}));
+    else {                                  // ... plus what joins there
+        for (uint32_t j = 0; j < 4; j++) b.add(TRANSITION, gated(Terms{{1u, {var(FOLD + j)}}, {1u, {var(INJ + j, true)}}, {P - 1, {var(OWN + j, true)}}}));
+        Terms f{{1u, {var(INJF)}}};
+        for (int l : *inject) f.push_back(Term{P - 1, {var(L + (uint32_t)l)}});
+        b.add(ALL, f);
+        for (uint32_t j = 0; j < 4; j++) b.add(ALL, Terms{{1u, {var(INJ + j)}}, {P - 1, {var(INJF), var(INJ + j)}}});
+    }
     if (!rec) for (uint32_t j = 0; j < 4; j++) b.add(ALL, Terms{{1u, {var(END), var(FOLD + j)}}, {P - 1, {var(END), pub((transcript ? 0u : 4u * (uint32_t)RL) + j)}}});
     if (wired) {
         b.add(ALL, Terms{{1u, {var(K2)}}, {P - 2, {var(K)}}});
@@ -1131,3 +1142,4 @@ int zkhip_prove_fri_indices_batch(const int* devices, int n_devices, zkhip_fri_j
 }  // extern "C"
 
 #include "shard_verifier.inl"
+#include "machine_verifier.inl"

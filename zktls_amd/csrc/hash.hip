@@ -798,7 +798,9 @@ __device__ __forceinline__ void p2r_rows_kernel_body(const p2chip::P2RArgs& a) {
     const uint64_t r = p - a.n_chains;
     if (r < a.n_transcript) {
         for (int j = 0; j < 16; j++) in[j] = to_monty(a.chain_inputs[16 * r + j]);
-        p2chip_fill_row(a.trace + (uint64_t)a.trows[r] * a.ld, in, 0u, 0u, 0u, 0u, 0u, 0u, out);
+        uint32_t* t = a.trace + (uint64_t)a.trows[r] * a.ld;
+        p2chip_fill_row(t, in, a.row_bits ? a.row_bits[r] : 0u, 0u, 0u, 0u, 0u, 0u, out);
+        if (a.row_kps) t[R_KP] = to_monty(a.row_kps[r]);
         return;
     }
     const uint64_t row = a.used_rows + (r - a.n_transcript);

@@ -68,6 +68,8 @@ struct P2RArgs {
     uint64_t rows, used_rows;
     uint32_t* trace; uint64_t ld;    // [rows][ld >= R_WIDTH], Montgomery
     uint32_t* roots;                 // [n_chains][8] canonical: where every chain ends
+    const uint32_t* row_bits = nullptr;   // machine mode (machine_verifier.inl): EVERY used row arrives as a transcript-style row -- its input state, and here
+    const uint32_t* row_kps = nullptr;    // its direction bit and its KP column (canonical); null: 0 / untouched
 };
 
 // paths: path p = rows [p (row_width / 8 + depth), ...): row_width / 8 sponge rows over its opened row (none when row_width = 0: the

@@ -414,6 +414,30 @@ class Context:
         check(self.lib.zkhip_sha256_setup(self.handle, C.byref(params), C.byref(handle), root.ctypes.data_as(u32p)))
         return MachineKey(self, handle, root, [4])
 
+    def machine_verifier_setup(self, inner, params=None, n_proofs=1):
+        """zkhip_machine_verifier_setup: the key of the machine that verifies n_proofs proofs of the inner machine (InnerMachine) in-circuit"""
+        params = params or Params()
+        handle, root = C.c_void_p(), np.zeros(8, dtype=np.uint32)
+        check(self.lib.zkhip_machine_verifier_setup(self.handle, C.byref(inner.desc), n_proofs, C.byref(params), C.byref(handle), root.ctypes.data_as(u32p)))
+        return MachineKey(self, handle, root, None)
+
+    def prove_machine_verifier(self, key, inner, proofs, public_values, params=None):
+        """zkhip_prove_machine_verifier: proofs = a list of version-11 proofs of the inner machine, public_values one list per proof -> ONE proof"""
+        params = params or Params()
+        sps = [np.ascontiguousarray(sp, dtype=np.uint8) for sp in proofs]
+        n = len(sps)
+        pv = np.ascontiguousarray(np.array([list(v) for v in public_values], dtype=np.uint32).reshape(n, -1)) if inner.n_public else np.zeros((n, 1), dtype=np.uint32)
+        size = self.lib.zkhip_machine_verifier_proof_size(C.byref(inner.desc), n, C.byref(params))
+        if size == 0:
+            check(-1)
+        buf = np.empty(size, dtype=np.uint8)
+        got = C.c_size_t(0)
+        ptrs = (u8p * n)(*[sp.ctypes.data_as(u8p) for sp in sps])
+        lens = (C.c_size_t * n)(*[sp.size for sp in sps])
+        check(self.lib.zkhip_prove_machine_verifier(self.handle, key.handle, C.byref(inner.desc), ptrs, lens, n, pv.ctypes.data_as(u32p), inner.n_public, C.byref(params),
+                                                    buf.ctypes.data_as(u8p), size, C.byref(got)))
+        return buf[: got.value]
+
     def sha256_compress_setup(self, message_len, log_blocks_per_shard, inner=None, outer=None):
         """zkhip_sha256_compress_setup -> MachineKey (key.root = vk) for compressed chains of messages with this many shards"""
         inner, outer = inner or Params(1, 100, 16), outer or Params(1, 100, 16)
@@ -910,6 +934,52 @@ def verify_sha256_sharded(result, digest=None, params=None, chain=None, proofs=N
     rc = lib.zkhip_verify_sha256_sharded(buf.ctypes.data_as(u8p), result.stride, lens, n, ch.ctypes.data_as(u32p), result.log_blocks, dg.ctypes.data_as(u8p),
                                          result.message_len if message_len is None else message_len, C.byref(params), C.byref(bad), C.byref(reason))
     return rc, bad.value, reason.value
+
+
+class InnerMachine:
+    """zkhip_machine_desc built from Python: chips = [{ln, W, Pw, prog, tab}] tallest first, the machine's key, how its proofs are made"""
+    def __init__(self, chips, key_root, n_queries, pow_bits, n_public):
+        n = len(chips)
+        self.keep = [(np.ascontiguousarray(c["prog"], dtype=np.uint32), np.ascontiguousarray(c["tab"], dtype=np.uint32)) for c in chips]
+        self.log_ns = (C.c_int32 * n)(*[int(c["ln"]) for c in chips])
+        self.widths = (C.c_uint32 * n)(*[int(c["W"]) for c in chips])
+        self.pre_widths = (C.c_uint32 * n)(*[int(c["Pw"]) for c in chips])
+        self.progs = (C.POINTER(C.c_uint32) * n)(*[p.ctypes.data_as(u32p) for p, _ in self.keep])
+        self.prog_words = (C.c_size_t * n)(*[p.size for p, _ in self.keep])
+        self.tabs = (C.POINTER(C.c_uint32) * n)(*[t.ctypes.data_as(u32p) for _, t in self.keep])
+        self.tab_words = (C.c_size_t * n)(*[t.size for _, t in self.keep])
+        self.desc = _lib.MachineDesc(n, self.log_ns, self.widths, self.pre_widths, self.progs, self.prog_words, self.tabs, self.tab_words,
+                                     (C.c_uint32 * 8)(*[int(v) for v in key_root]), int(n_queries), int(pow_bits), int(n_public))
+        self.n_public = int(n_public)
+
+
+def machine_verifier_describe(inner, which, kind, n_proofs=1):
+    """zkhip_machine_verifier_describe -> (words, log_rows, main width, preprocessed width); kind 0 program, 1 interaction table, 2 preprocessed trace"""
+    lib = _lib.load()
+    ln, mw, pw = C.c_int(0), C.c_uint32(0), C.c_uint32(0)
+    n = lib.zkhip_machine_verifier_describe(C.byref(inner.desc), n_proofs, which, kind, None, 0, C.byref(ln), C.byref(mw), C.byref(pw))
+    out = np.zeros(max(n, 1), dtype=np.uint32)
+    lib.zkhip_machine_verifier_describe(C.byref(inner.desc), n_proofs, which, kind, out.ctypes.data_as(u32p), n, C.byref(ln), C.byref(mw), C.byref(pw))
+    return out[:n], ln.value, mw.value, pw.value
+
+
+def machine_verifier_key_host(inner, params=None, n_proofs=1):
+    params = params or Params()
+    vk = np.zeros(8, dtype=np.uint32)
+    check(_lib.load().zkhip_machine_verifier_key_host(C.byref(inner.desc), n_proofs, C.byref(params), vk.ctypes.data_as(u32p)))
+    return vk
+
+
+def verify_machine_recursive(inner, proof, public_values, vk, params=None, n_proofs=1):
+    """zkhip_verify_machine_recursive: the outer proof against (the inner machine's description, the inner proofs' public values, the key) -> (rc, reason)"""
+    params = params or Params()
+    pr = np.ascontiguousarray(proof, dtype=np.uint8)
+    pv = np.ascontiguousarray(np.array(list(public_values) or [0], dtype=np.uint32))
+    k = np.ascontiguousarray(np.array(vk, dtype=np.uint32))
+    reason = C.c_int(0)
+    rc = _lib.load().zkhip_verify_machine_recursive(C.byref(inner.desc), pr.ctypes.data_as(u8p), pr.size, pv.ctypes.data_as(u32p), inner.n_public, n_proofs, k.ctypes.data_as(u32p),
+                                                    C.byref(params), C.byref(reason))
+    return rc, reason.value
 
 
 def sha256_compress_key_host(message_len, log_blocks_per_shard, inner=None, outer=None):
