@@ -734,7 +734,42 @@ def main():
         ckey.close()
         join16["outer_in_sp1_compress_shape"] = {"outer_params": "log_blowup 2, 50 queries, 16 PoW bits", "ms": round(t_cj * 1e3, 2), "outer_bytes": int(cjoined.size),
                                                  "compression": round(sum(p_.size for p_ in sps) / cjoined.size, 2), "verified": bool(ok_cj)}
-        recursion16 = {"join16": join16, "fri_only_workload": "the FRI check of 16 shard proofs (2^%d x %d, 100 queries x %d layers each) proven in-circuit: Poseidon2 chip (Merkle paths + transcript) + FRI-fold chip + SAMPLES chip + two tables per proof, one zkhip_prove_fri_indices_batch call, shard proofs in as bytes (host view included)" % (log_n, width, log_n),
+        # ... and THE TREE (machine mode: csrc/machine_verifier.inl): 64 shard proofs -> four joins of 16 -> ONE proof that verifies the four joins
+        # in-circuit (zkhip_prove_machine_verifier: ten chips; the join machine's own description is the inner machine)
+        tree = None
+        if log_n == 20 and width == 256:
+            from zktls_amd.device import InnerMachine, machine_verifier_key_host, shard_verifier_describe, verify_machine_recursive
+            tkey1 = ctx.shard_verifier_setup(log_n, width, prm.num_queries, prm.pow_bits, len(spv[0]), prm, n_proofs=16)
+            tsps, tspv = list(sps), list(spv)
+            for i in range(16, 64):
+                tspv.append(public + [1000 + i])
+                tsps.append(ctx.prove_shard(bufs[i % nbuf], log_n, width, tspv[-1], prm))
+            chips_ = []
+            for i in range(8):
+                p_, ln_, mw_, pw_ = shard_verifier_describe(log_n, width, prm.num_queries, prm.pow_bits, len(spv[0]), i, 0, 16)
+                t_, _, _, _ = shard_verifier_describe(log_n, width, prm.num_queries, prm.pow_bits, len(spv[0]), i, 1, 16)
+                chips_.append(dict(ln=ln_, W=mw_, Pw=pw_, prog=p_, tab=t_))
+            im_ = InnerMachine(chips_, tkey1.root, prm.num_queries, prm.pow_bits, 16 * len(spv[0]))
+            tkey2 = ctx.machine_verifier_setup(im_, prm, 4)
+            t_joins, t_top, top, joins4 = 1e9, 1e9, None, None
+            jp = [[v for pv_ in tspv[16 * j:16 * j + 16] for v in pv_] for j in range(4)]
+            for _ in range(3):
+                tb0 = time.perf_counter()
+                joins4 = [ctx.prove_shard_verifier(tkey1, tsps[16 * j:16 * j + 16], log_n, width, tspv[16 * j:16 * j + 16], prm, prm) for j in range(4)]
+                tb1 = time.perf_counter()
+                top = ctx.prove_machine_verifier(tkey2, im_, joins4, jp, prm)
+                tb2 = time.perf_counter()
+                t_joins, t_top = min(t_joins, tb1 - tb0), min(t_top, tb2 - tb1)
+            tb0 = time.perf_counter()
+            ok_tree = verify_machine_recursive(im_, top, [v for p_ in jp for v in p_], machine_verifier_key_host(im_, prm, 4), prm, 4) == (0, 0)
+            t_tv = time.perf_counter() - tb0
+            tree = {"workload": "64 shard proofs (2^20 x 256, 100 queries) -> 4 joins of 16 (zkhip_prove_shard_verifier) -> ONE proof (zkhip_prove_machine_verifier: the four joins' version-11 proofs verified in-circuit, ten chips)",
+                    "joins_ms": round(t_joins * 1e3, 2), "top_ms": round(t_top * 1e3, 2), "ms": round((t_joins + t_top) * 1e3, 2), "inner_bytes_total": int(sum(x.size for x in tsps)),
+                    "join_bytes_total": int(sum(x.size for x in joins4)), "bytes": int(top.size), "compression": round(sum(x.size for x in tsps) / top.size, 2),
+                    "host_verify_ms_with_the_key_derived_on_the_host": round(t_tv * 1e3, 2), "verified": bool(ok_tree),
+                    "verifier_inputs": "the join machine's description (a function of the shard shape), 64 x %d public values, the key; no byte of a shard proof or of a join" % len(spv[0])}
+            tkey1.close(), tkey2.close()
+        recursion16 = {"join16": join16, "tree": tree, "tree_ms": tree["ms"] if tree else None, "tree_bytes": tree["bytes"] if tree else None, "fri_only_workload": "the FRI check of 16 shard proofs (2^%d x %d, 100 queries x %d layers each) proven in-circuit: Poseidon2 chip (Merkle paths + transcript) + FRI-fold chip + SAMPLES chip + two tables per proof, one zkhip_prove_fri_indices_batch call, shard proofs in as bytes (host view included)" % (log_n, width, log_n),
                        "fri_only_ms": round(t_rec * 1e3, 2), "fri_only_proof_bytes": int(rec[0][0].size), "fri_only_all_verified": bool(ok_rec),
                        "ms": round(t_join * 1e3, 2), "recursion_proofs_per_s": round(16 / t_join, 1), "proof_bytes": int(joined.size), "all_verified": bool(ok_join)}
 

@@ -93,3 +93,32 @@ def test_the_tree_four_shard_proofs_two_joins_one_proof(ctx, oracle):
     assert verify_machine_recursive(im, top, swapped, tkey.root, tprm, 2)[0] != 0
     print("tree: 4 shard proofs %d B -> 2 joins %d B -> top %d B" % (sum(s.size for s in shards), sum(j.size for j in joins), top.size))
     jkey.close(), tkey.close()
+
+
+def test_a_two_level_tree_over_sixty_four_headline_shard_proofs(ctx):
+    """VERDICT r4 item 1, done-criterion b: BASELINE configs[1] x 64 -- sixty-four 2^20 x 256 shard proofs (61 MB) -> four joins of sixteen (1.6 MB each)
+    -> ONE proof; its verifier takes the join machine's description (a function of the shard shape), the 64 x 9 public values and the key
+    (derived on the host)"""
+    log_n, width, q, pb, n_join, n_top = 20, 256, 100, 16, 16, 4
+    prm = Params(1, 100, 16)
+    pubs = [[1, 2, 3, 4, 5, 6, 7, 8, 500 + s] for s in range(n_join * n_top)]
+    shards = []
+    for s in range(n_join * n_top):
+        tr = ctx.gen_trace(SEED, 700 + s, log_n, width)
+        shards.append(ctx.prove_shard(tr, log_n, width, pubs[s], prm))
+        tr.free()
+    jkey = ctx.shard_verifier_setup(log_n, width, q, pb, 9, prm, n_proofs=n_join)
+    joins = [ctx.prove_shard_verifier(jkey, shards[n_join * j:n_join * (j + 1)], log_n, width, pubs[n_join * j:n_join * (j + 1)], prm, prm) for j in range(n_top)]
+    jpubs = [[v for p_ in pubs[n_join * j:n_join * (j + 1)] for v in p_] for j in range(n_top)]
+    chips, im = join_machine(log_n, width, q, pb, 9, n_join, jkey.root, 100, 16)
+    tkey = ctx.machine_verifier_setup(im, prm, n_top)
+    top = ctx.prove_machine_verifier(tkey, im, joins, jpubs, prm)
+    flat = [v for p_ in jpubs for v in p_]
+    assert verify_machine_recursive(im, top, flat, machine_verifier_key_host(im, prm, n_top), prm, n_top) == (0, 0)
+    bad = list(flat)
+    bad[9 * 37 + 8] += 1                                                        # shard 37's last public value
+    assert verify_machine_recursive(im, top, bad, tkey.root, prm, n_top)[0] != 0
+    total = sum(s.size for s in shards)
+    assert top.size * 20 < total
+    print("tree: 64 shard proofs %d B -> 4 joins %d B -> top %d B (1 / %.1f)" % (total, sum(j.size for j in joins), top.size, total / top.size))
+    jkey.close(), tkey.close()

@@ -97,8 +97,8 @@ struct Plan {
 int make_mshape(const zkhip_machine_desc* d, size_t n_proofs, MShape& s) {
     if (!d || d->n_chips < 1 || d->n_chips > MAX_INNER_CHIPS || !d->log_ns || !d->widths || !d->pre_widths || !d->programs || !d->program_words || !d->tables || !d->table_words)
         return fail(ZKHIP_ERR_INVALID, "machine verifier: null description, or more than 16 chips");
-    if (d->num_queries < 1 || d->num_queries > 1024 || d->pow_bits < 0 || d->pow_bits > 28 || d->n_public > 64 || n_proofs < 1 || n_proofs > 64)
-        return fail(ZKHIP_ERR_INVALID, "machine verifier: 1 .. 1024 queries, 0 .. 28 proof-of-work bits, at most 64 public values, 1 .. 64 proofs");
+    if (d->num_queries < 1 || d->num_queries > 1024 || d->pow_bits < 0 || d->pow_bits > 28 || d->n_public > 4096 || n_proofs < 1 || n_proofs > 64 || n_proofs * (size_t)d->n_public > 16384)
+        return fail(ZKHIP_ERR_INVALID, "machine verifier: 1 .. 1024 queries, 0 .. 28 proof-of-work bits, at most 4096 public values per proof and 16384 in all, 1 .. 64 proofs");
     const int C = d->n_chips;
     s.C = C; s.Q = d->num_queries; s.PB = d->pow_bits; s.NPUB = (int)d->n_public; s.NP = (int)n_proofs;
     std::memcpy(s.key_root, d->key_root, 32);
