@@ -158,6 +158,20 @@ extern "C" {
     pub fn zkhip_shard_verifier_setup(ctx: *mut ZkhipCtx, log_n: c_int, width: u32, n_queries: usize, inner_pow_bits: c_int, n_public: usize, n_proofs: usize,
                                       outer: *const ZkhipParams, key: *mut *mut ZkhipMachineKey, vk: *mut u32) -> c_int;
     pub fn zkhip_shard_verifier_proof_size(log_n: c_int, width: u32, n_queries: usize, inner_pow_bits: c_int, n_public: usize, n_proofs: usize, outer: *const ZkhipParams) -> usize;
+    /// MACHINE MODE: the join's own output (a version-11 keyed-machine proof) verified in-circuit -- a tree of joins.  `inner` describes
+    /// the inner machine (for the join machine: zkhip_shard_verifier_describe + the join key's root)
+    pub fn zkhip_machine_verifier_setup(ctx: *mut ZkhipCtx, inner: *const ZkhipMachineDesc, n_proofs: usize, outer: *const ZkhipParams,
+                                        key: *mut *mut ZkhipMachineKey, vk: *mut u32) -> c_int;
+    pub fn zkhip_machine_verifier_key_host(inner: *const ZkhipMachineDesc, n_proofs: usize, outer: *const ZkhipParams, vk: *mut u32) -> c_int;
+    pub fn zkhip_machine_verifier_proof_size(inner: *const ZkhipMachineDesc, n_proofs: usize, outer: *const ZkhipParams) -> usize;
+    pub fn zkhip_prove_machine_verifier(
+        ctx: *mut ZkhipCtx, key: *const ZkhipMachineKey, inner: *const ZkhipMachineDesc, proofs: *const *const u8, proof_lens: *const usize, n_proofs: usize,
+        public_values: *const u32, n_public: usize, outer: *const ZkhipParams, proof: *mut u8, cap: usize, len: *mut usize,
+    ) -> c_int;
+    pub fn zkhip_verify_machine_recursive(
+        inner: *const ZkhipMachineDesc, proof: *const u8, len: usize, public_values: *const u32, n_public: usize, n_proofs: usize, vk: *const u32,
+        outer: *const ZkhipParams, reason: *mut c_int,
+    ) -> c_int;
     pub fn zkhip_poseidon2_params_generation() -> u64;
     /// the key WITHOUT a device (host cores only): what a verifier that owns no GPU derives for the shape it means
     pub fn zkhip_shard_verifier_key_host(log_n: c_int, width: u32, n_queries: usize, inner_pow_bits: c_int, n_public: usize, n_proofs: usize, outer: *const ZkhipParams,
@@ -253,6 +267,22 @@ pub struct ZkhipFriJob {
     pub status: i32,
 }
 
+/// an inner keyed machine for the shard verifier's machine mode (zkhip_machine_desc)
+#[repr(C)]
+pub struct ZkhipMachineDesc {
+    pub n_chips: i32,
+    pub log_ns: *const i32,
+    pub widths: *const u32,
+    pub pre_widths: *const u32,
+    pub programs: *const *const u32,
+    pub program_words: *const usize,
+    pub tables: *const *const u32,
+    pub table_words: *const usize,
+    pub key_root: [u32; 8],
+    pub num_queries: i32,
+    pub pow_bits: i32,
+    pub n_public: u32,
+}
 /// one transcript of a batch (zkhip_transcript_job)
 #[repr(C)]
 pub struct ZkhipTranscriptJob {

@@ -919,9 +919,37 @@ void heights_of(const MShape& sh, int h[N_CHIPS]) {
 std::shared_ptr<const Machine> machine_of(const zkhip_machine_desc* d, size_t n_proofs, int* rc) {
     static std::mutex mu;
     static std::map<std::vector<uint64_t>, std::shared_ptr<const Machine>> cache;
+    struct Seen { uint64_t hash; size_t n_proofs; uint64_t gen; std::shared_ptr<const Machine> m; };
+    static std::vector<Seen> seen;                                          // by the description's CONTENT: a hit skips validation and the digests (25 ms for the join machine's programs)
     auto m = std::make_shared<Machine>();
     // the description's words are copied first: the shape keeps pointers into the copies
-    if (!d || d->n_chips < 1 || d->n_chips > MAX_INNER_CHIPS || !d->programs || !d->program_words || !d->tables || !d->table_words) { *rc = fail(ZKHIP_ERR_INVALID, "machine verifier: null description"); return nullptr; }
+    if (!d || d->n_chips < 1 || d->n_chips > MAX_INNER_CHIPS || !d->log_ns || !d->widths || !d->pre_widths || !d->programs || !d->program_words || !d->tables || !d->table_words) {
+        *rc = fail(ZKHIP_ERR_INVALID, "machine verifier: null description");
+        return nullptr;
+    }
+    uint64_t hsh = 1469598103934665603ull;
+    auto mix = [&](uint64_t v) { hsh = (hsh ^ v) * 1099511628211ull; };
+    mix((uint64_t)d->n_chips); mix((uint64_t)d->num_queries); mix((uint64_t)d->pow_bits); mix(d->n_public);
+    for (int i = 0; i < 8; i++) mix(d->key_root[i]);
+    for (int c = 0; c < d->n_chips; c++) {
+        if (!d->programs[c] || !d->tables[c] || d->program_words[c] > (1u << 24) || d->table_words[c] > (1u << 16)) { *rc = fail(ZKHIP_ERR_INVALID, "machine verifier: every chip needs a program and a table"); return nullptr; }
+        mix((uint64_t)d->log_ns[c]); mix(d->widths[c]); mix(d->pre_widths[c]); mix(d->program_words[c]); mix(d->table_words[c]);
+        for (size_t i = 0; i < d->program_words[c]; i++) mix(d->programs[c][i]);
+        for (size_t i = 0; i < d->table_words[c]; i++) mix(d->tables[c][i]);
+    }
+    {
+        std::lock_guard<std::mutex> lk(mu);
+        for (const Seen& sn : seen) {
+            if (sn.hash != hsh || sn.n_proofs != n_proofs || sn.gen != g_p2_generation.load() || sn.m->sh.C != d->n_chips) continue;
+            bool same = sn.m->sh.Q == d->num_queries && sn.m->sh.PB == d->pow_bits && sn.m->sh.NPUB == (int)d->n_public && std::memcmp(sn.m->sh.key_root, d->key_root, 32) == 0;
+            for (int c = 0; same && c < d->n_chips; c++)
+                same = sn.m->sh.ln[(size_t)c] == d->log_ns[c] && sn.m->sh.W[(size_t)c] == d->widths[c] && sn.m->sh.Pw[(size_t)c] == d->pre_widths[c] &&
+                       sn.m->programs_kept[(size_t)c].size() == d->program_words[c] && sn.m->tables_kept[(size_t)c].size() == d->table_words[c] &&
+                       std::memcmp(sn.m->programs_kept[(size_t)c].data(), d->programs[c], d->program_words[c] * 4) == 0 &&
+                       std::memcmp(sn.m->tables_kept[(size_t)c].data(), d->tables[c], d->table_words[c] * 4) == 0;
+            if (same) { *rc = ZKHIP_OK; return sn.m; }
+        }
+    }
     zkhip_machine_desc dd = *d;
     std::vector<const uint32_t*> pp((size_t)d->n_chips), tp((size_t)d->n_chips);
     for (int c = 0; c < d->n_chips; c++) {
@@ -938,7 +966,7 @@ std::shared_ptr<const Machine> machine_of(const zkhip_machine_desc* d, size_t n_
     {
         std::lock_guard<std::mutex> lk(mu);
         auto it = cache.find(key);
-        if (it != cache.end()) return it->second;
+        if (it != cache.end()) { if (seen.size() >= 8) seen.erase(seen.begin()); seen.push_back(Seen{hsh, n_proofs, g_p2_generation.load(), it->second}); return it->second; }
     }
     const MShape& sh = m->sh;
     int h[N_CHIPS];
@@ -971,6 +999,8 @@ std::shared_ptr<const Machine> machine_of(const zkhip_machine_desc* d, size_t n_
     std::lock_guard<std::mutex> lk(mu);
     if (cache.size() > 8) cache.clear();
     cache.emplace(key, m);
+    if (seen.size() >= 8) seen.erase(seen.begin());
+    seen.push_back(Seen{hsh, n_proofs, g_p2_generation.load(), m});
     return m;
 }
 void samples_pre_all(const MShape& sh, int log_rows, std::vector<uint32_t>& t) {
@@ -1287,8 +1317,10 @@ int fill_proof(const Machine& m, int p, const uint8_t* inner, size_t inner_len, 
     {
         using namespace frichip;
         const uint32_t FW = m.w_main[C_FOLD], INJ = width_of(R, true, true), INJF = INJ + 4;
-        size_t prow = sh.p2_fri0;
-        for (int q = 0; q < Q; q++) {
+        // (the queries are independent: a few threads per proof walk them -- one scalar permutation per Poseidon2 row is most of this function's time)
+        std::vector<int> qerr((size_t)Q, 0);
+        auto fri_q = [&](int q) -> int {
+            size_t prow = sh.p2_fri0 + (size_t)q * sh.fri_rows;
             uint32_t idx = wt.indices[(size_t)q];
             Ext own = wt.roh[(size_t)q * 32 + (size_t)H];
             uint32_t tcol[MAX_LAYERS];
@@ -1333,7 +1365,7 @@ int fill_proof(const Machine& m, int p, const uint8_t* inner, size_t inner_len, 
                     std::memcpy(st, in, sizeof st);
                     p2_permute(st);
                 }
-                for (int j = 0; j < 8; j++) if (from_monty(st[j]) != w[wt.o_lroots + 8 * (size_t)l + (size_t)j]) return bad("a FRI layer opening does not end in the layer's root");
+                for (int j = 0; j < 8; j++) if (from_monty(st[j]) != w[wt.o_lroots + 8 * (size_t)l + (size_t)j]) return 1;
                 own = fold; idx = k;
             }
             uint32_t bacc = idx ? two_adic_generator(R + 1) : MONTY_R1;
@@ -1341,16 +1373,18 @@ int fill_proof(const Machine& m, int p, const uint8_t* inner, size_t inner_len, 
                 bacc = fmul(bacc, tcol[l]);
                 ht.fold.data()[(size_t)FW * (((size_t)p * (size_t)Q + (size_t)q) * (size_t)R + (size_t)l) + frichip::B] = bacc;
             }
-            for (int j = 0; j < 4; j++) if (from_monty(own.c[j]) != w[wt.o_final + (size_t)j]) return bad("a fold chain does not end in the final value");
-        }
+            for (int j = 0; j < 4; j++) if (from_monty(own.c[j]) != w[wt.o_final + (size_t)j]) return 2;
+            return 0;
+        };
         // ---- the four commitments: the shorter heights' sponges, the tallest's, the path with the injections
+        auto tree_q = [&](int q) -> int {
         for (int tr = 0; tr < N_TREES; tr++) {
             if (!sh.has_tree[tr]) continue;
             const std::vector<int>& hs = sh.tree_hs[tr];
             const std::vector<int> so = sponge_order(sh, tr);
             const uint32_t* root = tr == T_E ? sh.key_root : w + (tr == T_T ? wt.o_troot : tr == T_P ? wt.o_proot : wt.o_qroot);
-            if (prow != sh.p2_tree0[tr]) return fail(ZKHIP_ERR_INTERNAL, "prove_machine_verifier: row layout");
-            for (int q = 0; q < Q; q++) {
+            size_t prow = sh.p2_tree0[tr] + (size_t)q * sh.tree_rows[tr];
+            {
                 const uint32_t index = wt.indices[(size_t)q] >> (H - hs[0]);
                 uint32_t dg[32][8], st[16];
                 for (int h : so) {
@@ -1385,10 +1419,25 @@ int fill_proof(const Machine& m, int p, const uint8_t* inner, size_t inner_len, 
                         for (int j = 0; j < 8; j++) cur[j] = in[j];
                     }
                 }
-                for (int j = 0; j < 8; j++) if (from_monty(cur[j]) != root[j]) return bad("an opening does not end in its root");
+                for (int j = 0; j < 8; j++) if (from_monty(cur[j]) != root[j]) return 3;
+                if (prow != sh.p2_tree0[tr] + (size_t)(q + 1) * sh.tree_rows[tr]) return 4;
             }
         }
-        if (prow != sh.p2_rows) return fail(ZKHIP_ERR_INTERNAL, "prove_machine_verifier: row layout");
+        return 0;
+        };
+        const int nth = sh.NP >= 16 ? 1 : 16 / sh.NP;
+        if (nth == 1 || Q < 4) for (int q = 0; q < Q; q++) { qerr[(size_t)q] = fri_q(q); if (!qerr[(size_t)q]) qerr[(size_t)q] = tree_q(q); }
+        else {
+            HostPool pool(nth);
+            for (int t = 0; t < nth; t++) pool.submit([&, t] { for (int q = t; q < Q; q += nth) { qerr[(size_t)q] = fri_q(q); if (!qerr[(size_t)q]) qerr[(size_t)q] = tree_q(q); } });
+            pool.wait();
+        }
+        for (int q = 0; q < Q; q++) {
+            if (qerr[(size_t)q] == 1) return bad("a FRI layer opening does not end in the layer's root");
+            if (qerr[(size_t)q] == 2) return bad("a fold chain does not end in the final value");
+            if (qerr[(size_t)q] == 3) return bad("an opening does not end in its root");
+            if (qerr[(size_t)q]) return fail(ZKHIP_ERR_INTERNAL, "prove_machine_verifier: row layout");
+        }
     }
     // ---- TS
     {
@@ -1500,6 +1549,19 @@ int m_prove_machine_verifier(zkhip_ctx* ctx, const zkhip_machine_key* key, const
     const MShape& sh = m.sh;
     if ((int)n_public != sh.NPUB) return fail(ZKHIP_ERR_INVALID, "prove_machine_verifier: n_public is not the machine's");
     const int NP = sh.NP;
+#ifdef ZKHIP_AB_HOOKS
+    static const bool timing = getenv("ZKHIP_REC_TIMING") != nullptr;
+    auto t_last = std::chrono::steady_clock::now();
+    auto lap = [&](const char* what) {
+        if (!timing) return;
+        (void)hipStreamSynchronize(ctx->stream);
+        const auto now = std::chrono::steady_clock::now();
+        std::fprintf(stderr, "  [machine verifier] %-34s %8.2f ms\n", what, std::chrono::duration<double, std::milli>(now - t_last).count());
+        t_last = now;
+    };
+#else
+    auto lap = [](const char*) {};
+#endif
     HostTabs ht;
     ZeroedWords* tabs[N_CHIPS] = {nullptr, &ht.rs, &ht.fold, &ht.ts, &ht.q, &ht.op, &ht.sm, &ht.sc, &ht.evl, &ht.lgu};
     for (int c = 0; c < N_CHIPS; c++) if (tabs[c] && !tabs[c]->reset((size_t)m.w_main[c] << m.height[c])) return fail(ZKHIP_ERR_NOMEM, "prove_machine_verifier: no host memory for the machine's tables");
@@ -1517,7 +1579,13 @@ int m_prove_machine_verifier(zkhip_ctx* ctx, const zkhip_machine_key* key, const
             int r = proofs[p] ? zkhip_verify_machine_keyed(proofs[p], proof_lens[p], lns.data(), sh.W.data(), sh.Pw.data(), sh.key_root, sh.prog.data(), sh.prog_words.data(), sh.tab.data(),
                                                            sh.tab_words.data(), (size_t)sh.C, public_values + (size_t)p * n_public, n_public, &iprm, &reason)
                               : fail(ZKHIP_ERR_INVALID, "prove_machine_verifier: null proof");
+#ifdef ZKHIP_AB_HOOKS
+            const auto tv = std::chrono::steady_clock::now();
+#endif
             if (r == ZKHIP_OK) r = fill_proof(m, p, proofs[p], proof_lens[p], public_values + (size_t)p * n_public, ht);
+#ifdef ZKHIP_AB_HOOKS
+            if (timing) std::fprintf(stderr, "    [machine verifier] proof %d: tables filled in %.2f ms\n", p, std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tv).count());
+#endif
             rcs[(size_t)p] = r;
             if (r != ZKHIP_OK) msgs[(size_t)p] = zkhip_last_error();
         };
@@ -1529,6 +1597,7 @@ int m_prove_machine_verifier(zkhip_ctx* ctx, const zkhip_machine_key* key, const
         }
         for (int p = 0; p < NP; p++) if (rcs[(size_t)p] != ZKHIP_OK) { set_error("proof " + std::to_string(p) + ": " + msgs[(size_t)p]); return rcs[(size_t)p]; }
     }
+    lap("host: verify + witnesses + tables");
     void* dev[N_CHIPS] = {nullptr};
     const int slots[N_CHIPS] = {S_REC_A, S_REC_C, S_REC_B, S_REC_D, S_REC_E, S_REC_F, S_REC_G, S_REC_H, S_REC_I, S_REC_J};
     for (int c = 0; c < N_CHIPS; c++) ZK_TRY(ctx_reserve(ctx, slots[c], ((size_t)m.w_main[c] << m.height[c]) * 4, &dev[c]));
@@ -1549,7 +1618,9 @@ int m_prove_machine_verifier(zkhip_ctx* ctx, const zkhip_machine_key* key, const
         a.row_bits = d + 16 * used; a.row_kps = d + 17 * used;
         ZK_HIP(launch_p2r_rows(a, ctx->stream));
     }
+    lap("device: Poseidon2 rows");
     for (int c = 0; c < N_CHIPS; c++) if (tabs[c]) ZK_TRY(dev_h2d(ctx, dev[c], tabs[c]->data(), tabs[c]->size() * 4));
+    lap("upload: host tables");
     zkhip_chip chips[N_CHIPS]{};
     for (int i = 0; i < N_CHIPS; i++) {
         const int c = m.order[i];
@@ -1557,7 +1628,9 @@ int m_prove_machine_verifier(zkhip_ctx* ctx, const zkhip_machine_key* key, const
     }
     std::vector<uint32_t> pv((size_t)NP * n_public);
     for (size_t i = 0; i < pv.size(); i++) pv[i] = public_values[i] % P;
-    return zkhip_prove_machine_keyed(ctx, key, chips, m.progs, m.prog_words, m.tabs, m.tab_words, N_CHIPS, pv.data(), pv.size(), outer, proof, cap, len);
+    const int prc = zkhip_prove_machine_keyed(ctx, key, chips, m.progs, m.prog_words, m.tabs, m.tab_words, N_CHIPS, pv.data(), pv.size(), outer, proof, cap, len);
+    lap("the machine's proof");
+    return prc;
 }
 
 int m_verify_machine_recursive(const zkhip_machine_desc* inner, const uint8_t* proof, size_t len, const uint32_t* public_values, size_t n_public, size_t n_proofs, const uint32_t vk[8],
