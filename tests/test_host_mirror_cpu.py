@@ -604,9 +604,46 @@ def test_compress_stage_behind_the_same_call(lib):
 
 
 @pytest.mark.gpu
+def test_compress_stage_joins_the_joins_a_tree(lib):
+    """joins of at most three shard proofs (zktls_set_compress_join_size): seven shards -> three joins (the last repeats the last shard twice) -> ONE
+    proof that verifies the three joins in-circuit (machine mode; blob flag TREE).  The consumer derives the join key AND the top's key on the host"""
+    _compress_api(lib)
+    lib.zktls_set_compress_join_size.argtypes = [C.c_uint32]
+    lib.zktls_set_compress_join_size(3)
+    try:
+        plan = Plan(8, 8, 7, 10, 8)
+        cbor, elf = b"\xa1tree", b"\x7fELFprog"
+        out, outn, pr, prn = C.POINTER(C.c_uint8)(), C.c_size_t(), C.POINTER(C.c_uint8)(), C.c_size_t()
+        err = C.create_string_buffer(512)
+        rc = lib.zktls_guest_prove_compressed(0, 2, C.byref(plan), cbor, len(cbor), elf, len(elf), C.byref(out), C.byref(outn), C.byref(pr), C.byref(prn), err, 512)
+        assert rc == 0, err.value
+        blob = C.string_at(pr, prn.value)
+        lib.zktls_free(out)
+        lib.zktls_free(pr)
+        assert lib.zktls_batch_flags(blob, len(blob)) == 1 | 16 | 32            # SYNTHETIC | COMPRESSED | TREE
+        offs, lens = (C.c_size_t * 8)(), (C.c_size_t * 8)()
+        assert lib.zktls_unpack_batch(blob, len(blob), offs, lens, 8) == 2 and lens[1] == 36
+        key = (C.c_uint32 * 8)()
+        assert lib.zktls_compress_key_host(C.byref(plan), key, err, 512) == 0 and bytes(key) == blob[offs[1]:offs[1] + 32]
+        reason = C.c_int(0)
+        assert lib.zktls_verify_compressed_blob(blob, len(blob), C.byref(plan), cbor, len(cbor), elf, len(elf), key, C.byref(reason)) == 0
+        assert lib.zktls_verify_compressed_blob(blob, len(blob), C.byref(plan), cbor + b"!", len(cbor) + 1, elf, len(elf), key, C.byref(reason)) == -2
+        bad = bytearray(blob)
+        bad[offs[0] + lens[0] // 2] ^= 1
+        assert lib.zktls_verify_compressed_blob(bytes(bad), len(blob), C.byref(plan), cbor, len(cbor), elf, len(elf), key, C.byref(reason)) == -2
+        lib.zktls_set_compress_join_size(0)                                     # a verifier that means joins of another size means another statement
+        assert lib.zktls_verify_compressed_blob(blob, len(blob), C.byref(plan), cbor, len(cbor), elf, len(elf), key, C.byref(reason)) != 0
+    finally:
+        lib.zktls_set_compress_join_size(0)
+        lib.zktls_release_cached()
+
+
+@pytest.mark.gpu
 def test_compress_stage_takes_more_shards_than_one_join_holds_as_several_joins_of_one_shape(lib):
     """one join holds 497 proofs of this small shape with its 9 public values (zkhip_shard_verifier_max_proofs; 136 of the headline shape).  1100
-    shards: three joins of 367 under ONE key, the last repeats the last shard once; 1027 shards: three joins of 343, the last repeats it twice"""
+    shards: three joins of 367 under ONE key, the last repeats the last shard once; 1027 shards: three joins of 343, the last repeats it twice.
+    (The joins stay side by side here: a top over joins of 367 x 9 public values each is more than machine mode's transcript table takes --
+    test_compress_stage_joins_the_joins_a_tree has the tree)"""
     _compress_api(lib)
     from zktls_amd.device import shard_verifier_max_proofs
     from zktls_amd._lib import Params

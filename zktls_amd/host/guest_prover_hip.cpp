@@ -162,6 +162,39 @@ struct CtxGuard {
 [[noreturn]] void fail_zkhip(const char* what) { throw std::runtime_error(std::string(what) + ": " + zkhip_last_error()); }
 }  // namespace
 
+// the join machine (zkhip_prove_shard_verifier over J shard proofs of the plan's shape) as the INNER machine of machine mode: its eight chips as the
+// library describes them, the join key's root, how join proofs are made
+namespace {
+struct JoinMachine {
+    std::vector<std::vector<uint32_t>> progs, tabs;
+    std::vector<const uint32_t*> pp, tp;
+    std::vector<size_t> pw_, tw_;
+    int32_t lns[8]; uint32_t widths[8], pres[8];
+    zkhip_machine_desc desc{};
+    bool build(const ShardPlan& plan, uint32_t J, const uint32_t join_key[8]) {
+        progs.resize(8); tabs.resize(8); pp.resize(8); tp.resize(8); pw_.resize(8); tw_.resize(8);
+        for (int i = 0; i < 8; i++) {
+            int ln = 0; uint32_t mw = 0, pw = 0;
+            for (int kind = 0; kind < 2; kind++) {
+                std::vector<uint32_t>& dst = kind ? tabs[(size_t)i] : progs[(size_t)i];
+                const size_t n = zkhip_shard_verifier_describe(plan.log_n, plan.width, (size_t)plan.num_queries, plan.pow_bits, 9, J, i, kind, nullptr, 0, &ln, &mw, &pw);
+                if (n == 0) return false;
+                dst.resize(n);
+                if (zkhip_shard_verifier_describe(plan.log_n, plan.width, (size_t)plan.num_queries, plan.pow_bits, 9, J, i, kind, dst.data(), n, &ln, &mw, &pw) != n) return false;
+            }
+            lns[i] = ln; widths[i] = mw; pres[i] = pw;
+            pp[(size_t)i] = progs[(size_t)i].data(); tp[(size_t)i] = tabs[(size_t)i].data(); pw_[(size_t)i] = progs[(size_t)i].size(); tw_[(size_t)i] = tabs[(size_t)i].size();
+        }
+        desc.n_chips = 8; desc.log_ns = lns; desc.widths = widths; desc.pre_widths = pres; desc.programs = pp.data(); desc.program_words = pw_.data();
+        desc.tables = tp.data(); desc.table_words = tw_.data();
+        std::memcpy(desc.key_root, join_key, 32);
+        desc.num_queries = plan.num_queries; desc.pow_bits = plan.pow_bits; desc.n_public = 9u * J;
+        return true;
+    }
+};
+std::atomic<uint32_t> g_join_size{0};
+}  // namespace
+
 ProveResult HipGuestProver::prove(const GuestInput& input, const std::vector<uint8_t>& guest_program) {
     if (backend_ == Backend::Risc0) set_env_r0(mode_);   // prover.rs:65
     else set_env(mode_);                              // sp1.rs:72
@@ -552,13 +585,47 @@ ProveResult HipGuestProver::prove_inner(const GuestInput& input, const std::vect
             }
             entries.push_back(std::move(joined));
         }
+        uint32_t flags_extra = 0;
+        JoinMachine jm;
+        // (a top the machine refuses -- thousands of public values per join: its transcript table runs out of columns -- leaves the joins side by side)
+        if (n_joins > 1 && jm.build(plan_, J, vk) && zkhip_machine_verifier_proof_size(&jm.desc, n_joins, &outer) != 0) {
+            // THE TREE: the joins themselves are verified in-circuit by ONE proof (machine mode: csrc/machine_verifier.inl) -- the blob carries that
+            // proof alone; its key is a function of (the join machine, the number of joins) and is derived by whoever checks the blob
+            struct KeyGuard { zkhip_machine_key* k = nullptr; zkhip_ctx* c = nullptr; ~KeyGuard() { if (k) { (void)zkhip_ctx_sync(c); zkhip_machine_key_destroy(k); } } } tk;
+            tk.c = jctx;
+            uint32_t tvk[8];
+            if (zkhip_machine_verifier_setup(jctx, &jm.desc, n_joins, &outer, &tk.k, tvk) != ZKHIP_OK) throw std::runtime_error(std::string("zkhip_machine_verifier_setup: ") + zkhip_last_error());
+            const size_t tcap = zkhip_machine_verifier_proof_size(&jm.desc, n_joins, &outer);
+            std::vector<uint8_t> top(tcap);
+            std::vector<const uint8_t*> ptrs(n_joins);
+            std::vector<size_t> lens(n_joins);
+            std::vector<uint32_t> pvs;
+            for (uint32_t c = 0; c < n_joins; c++) {
+                ptrs[c] = entries[c].data(); lens[c] = entries[c].size();
+                for (uint32_t k = 0; k < J; k++) {
+                    const uint32_t sidx = c * J + k < plan_.shards ? c * J + k : plan_.shards - 1;
+                    pvs.insert(pvs.end(), digest.begin(), digest.end());
+                    pvs.push_back(sidx);
+                }
+            }
+            size_t tlen = 0;
+            if (zkhip_prove_machine_verifier(jctx, tk.k, &jm.desc, ptrs.data(), lens.data(), n_joins, pvs.data(), 9u * J, &outer, top.data(), tcap, &tlen) != ZKHIP_OK)
+                throw std::runtime_error(std::string("zkhip_prove_machine_verifier: ") + zkhip_last_error());
+            top.resize(tlen);
+            int reason = 0;
+            if (zkhip_verify_machine_recursive(&jm.desc, top.data(), tlen, pvs.data(), 9u * J, n_joins, tvk, &outer, &reason) != ZKHIP_OK)
+                throw std::runtime_error(std::string("zkhip_verify_machine_recursive: ") + zkhip_last_error());
+            entries.clear();
+            entries.push_back(std::move(top));
+            flags_extra = BATCH_FLAG_TREE;
+        }
         jg.done = true;                                  // (only after every join went through: every other way out destroys the pair -- JoinGuard)
         std::vector<uint8_t> tail(36);
         std::memcpy(tail.data(), vk, 32);
         const uint32_t cnt = plan_.shards;
         std::memcpy(tail.data() + 32, &cnt, 4);
         entries.push_back(tail);
-        r.proof = pack_shard_proofs(entries, BATCH_FLAG_SYNTHETIC | BATCH_FLAG_COMPRESSED);
+        r.proof = pack_shard_proofs(entries, BATCH_FLAG_SYNTHETIC | BATCH_FLAG_COMPRESSED | flags_extra);
         r.ok = true;
         return r;
     }
@@ -567,11 +634,15 @@ ProveResult HipGuestProver::prove_inner(const GuestInput& input, const std::vect
     return r;
 }
 
+void set_compress_join_size(uint32_t shard_proofs_per_join) { g_join_size.store(shard_proofs_per_join); }
+
 uint32_t compress_join_size(const ShardPlan& plan) {
     const uint32_t shards = plan.shards ? plan.shards : 1u;
     const zkhip_params outer{1, plan.num_queries, plan.pow_bits, 0, 0, 0, 0, 0};      // (the outer proof's shape: blowup 2, the plan's queries and proof-of-work bits)
     uint32_t most = (uint32_t)zkhip_shard_verifier_max_proofs(plan.log_n, plan.width, (size_t)plan.num_queries, plan.pow_bits, 9, &outer);
     if (most == 0) most = 1;                           // (a shape the machine refuses: the join itself will say so)
+    const uint32_t cap = g_join_size.load();           // (set_compress_join_size: smaller joins -- bounded latency per join, more of them, a tree above)
+    if (cap && cap < most) most = cap;
     if (shards <= most) return shards;
     const uint32_t joins = (shards + most - 1u) / most;
     return (shards + joins - 1u) / joins;
@@ -586,9 +657,28 @@ int verify_compressed_blob(const std::vector<uint8_t>& blob, const ShardPlan& pl
     std::memcpy(&cnt, entries.back().data() + 32, 4);
     if (cnt != plan.shards || cnt == 0 || std::memcmp(entries.back().data(), key, 32) != 0) return -1;        // (the key is the CALLER's: the blob's copy is informative)
     const uint32_t J = compress_join_size(plan), n_joins = (cnt + J - 1) / J;
-    if (entries.size() != (size_t)n_joins + 1) return -1;
     const std::vector<uint32_t> digest = request_digest(cbor, elf);
     const zkhip_params outer{1, plan.num_queries, plan.pow_bits, 0, 0, 0, 0, 0};
+    if (flags & BATCH_FLAG_TREE) {
+        // ONE proof that verifies the joins: its key is derived here, on the host, from the join machine (a function of the plan) and the join key
+        if (n_joins < 2 || entries.size() != 2) return -1;
+        JoinMachine jm;
+        if (!jm.build(plan, J, key)) return -1;
+        uint32_t tvk[8];
+        if (zkhip_machine_verifier_key_host(&jm.desc, n_joins, &outer, tvk) != ZKHIP_OK) return -1;
+        std::vector<uint32_t> pvs;
+        for (uint32_t c = 0; c < n_joins; c++)
+            for (uint32_t k = 0; k < J; k++) {
+                const uint32_t sidx = c * J + k < cnt ? c * J + k : cnt - 1;
+                pvs.insert(pvs.end(), digest.begin(), digest.end());
+                pvs.push_back(sidx);
+            }
+        int why = 0;
+        const int rc = zkhip_verify_machine_recursive(&jm.desc, entries[0].data(), entries[0].size(), pvs.data(), 9u * J, n_joins, tvk, &outer, &why);
+        if (reason) *reason = why;
+        return rc == ZKHIP_OK ? 0 : -2;
+    }
+    if (entries.size() != (size_t)n_joins + 1) return -1;
     for (uint32_t c = 0; c < n_joins; c++) {
         std::vector<uint32_t> pvs;
         for (uint32_t k = 0; k < J; k++) {
@@ -640,6 +730,9 @@ extern "C" {
 
 // frees the contexts and trace buffers parked by finished workers
 void zktls_release_cached(void) { zktls::release_cached(); }
+// shard proofs per join of the compress stage (0: as many as one join holds -- 136 of the headline shape); with fewer, an execution takes several
+// joins and ONE more proof above them (the tree: blob flag TREE).  Process-wide; prover and verifier must agree (it is part of the plan)
+void zktls_set_compress_join_size(uint32_t shard_proofs_per_join) { zktls::set_compress_join_size(shard_proofs_per_join); }
 
 struct zktls_shard_plan { int32_t log_n; uint32_t width; uint32_t shards; int32_t num_queries; int32_t pow_bits; };
 

@@ -97,7 +97,7 @@ public:
     // the COMPRESS stage behind the same call (sp1.rs:116: core -> compress; prover.rs:90: lift -> join): after the shards are proven, ONE
     // proof verifies them all in-circuit (zkhip_prove_shard_verifier) and replaces them in the blob (flag COMPRESSED: entry 0 = the joined
     // proof, entry 1 = 8 LE words of the shape's key + the shard count).  SP1 backend, synthetic shards, width a multiple of 8.  More shards
-    // than one join holds (136 of the headline shape) take several joins of ONE shape (compress_join_size; entries 0 .. k-1, the key entry last).  verify_compressed_blob checks
+    // than one join holds (136 of the headline shape) take several joins of ONE shape (compress_join_size) and ONE more proof above them (the tree; blob flag TREE).  verify_compressed_blob checks
     // such a blob on the host from (plan, input, ELF, key): the shard proofs are gone.
     // With with_input_commitment() and an input beyond one chip proof (1 MiB): the chain of SHA-256 shard proofs becomes ONE proof the same way
     // (zkhip_prove_sha256_compressed; blob flags INPUT_SHA256 | CHAINED | COMPRESSED) -- verify_commitment_blob checks it from (output, blob) alone.
@@ -148,6 +148,10 @@ constexpr uint32_t BATCH_FLAG_COMPRESSED = 16u;      // with SYNTHETIC: the shar
 // Poseidon2 chip's 2^22 rows -- 136 proofs of the headline shape); beyond, ceil(shards / max) joins of equal size J = ceil(shards / joins) --
 // the last one repeats the execution's last shard proof to fill its J places, so that every join has the same shape, hence the same key
 uint32_t compress_join_size(const ShardPlan& plan);
+// ... or fewer per join (0: the most): an execution then takes several joins, and ONE more proof verifies the joins (machine mode of the shard
+// verifier machine, csrc/machine_verifier.inl): the blob carries that proof alone and the flag TREE
+void set_compress_join_size(uint32_t shard_proofs_per_join);
+constexpr uint32_t BATCH_FLAG_TREE = 32u;            // with COMPRESSED: several joins were needed and were joined again: entry 0 = the ONE proof above them
 constexpr uint32_t BATCH_FLAG_KEYED = 4u;            // with INPUT_SHA256: the proof is the keyed SHA-256 MACHINE's (chip + range table), checked against a vk
 // a consumer's check of an input-commitment blob on the CPU: the blob's proof(s) against the claimed output (SHA-256 of the input).
 // The caller says what it EXPECTS, the blob's own flags only have to agree: a 64-byte `vk` (from setup) means "a KEYED proof under this
