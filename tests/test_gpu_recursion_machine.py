@@ -122,3 +122,46 @@ def test_a_two_level_tree_over_sixty_four_headline_shard_proofs(ctx):
     assert top.size * 20 < total
     print("tree: 64 shard proofs %d B -> 4 joins %d B -> top %d B (1 / %.1f)" % (total, sum(j.size for j in joins), top.size, total / top.size))
     jkey.close(), tkey.close()
+
+
+def sha256_machine_desc(log_n_sha, key_root, q, pb):
+    """the keyed SHA-256 machine of zkhip_prove_transcripts (the compression chip + the preprocessed 2^16-row range table) as an inner machine:
+    programs and tables as tests/machines.py's sha256_machine builds them (equal to the library's: tests/test_gpu_keyed_machine.py)"""
+    import oracle_lib as O
+    import sha256_air as S
+    sent = [S.OUT + 6, S.OUT + 7, S.OUT + 14, S.OUT + 15]
+    sha = dict(ln=log_n_sha, W=S.WIDTH, Pw=0, prog=S.program(), tab=O.interaction_table([(O.SEND, None, 16, [c]) for c in sent]))
+    table = dict(ln=16, W=4, Pw=4, prog=O.air_program(8, S.N_PUBLIC, [(O.SEL_FIRST, [(1, [O.air_var(0)])])]), tab=O.interaction_table([(O.RECEIVE, 5, 16, [0])]))
+    chips = [sha, table] if log_n_sha > 16 else [table, sha]
+    return chips, InnerMachine(chips, key_root, q, pb, S.N_PUBLIC)
+
+
+def test_sixty_four_keyed_transcript_proofs_become_one_proof(ctx):
+    """VERDICT r4 item 1, done-criterion a, to the letter: 64 transcript proofs of zkhip_prove_transcripts (the KEYED SHA-256 machine: version 11, two chips
+    of heights 2^16 and 2^14, a preprocessed table, a bus) -> ONE proof, verified with (the machine's description, 64 x (digest, length), the key)"""
+    import hashlib
+    from zktls_amd.device import prove_transcripts, sha256_padding_publics
+    n, nbytes = 64, 13221
+    prm = Params(1, 100, 16)
+    msgs = [bytes((5 * i + 11 * p + 3) & 0xff for i in range(nbytes)) for p in range(n)]
+    vk, res = prove_transcripts(msgs, prm, devices=[0])
+    pubs = []
+    for m, (d, _) in zip(msgs, res):
+        assert d == hashlib.sha256(m).digest()
+        limbs = []
+        for i in range(8):
+            w = int.from_bytes(d[4 * i:4 * i + 4], "big")
+            limbs += [w & 0xffff, w >> 16]
+        pubs.append(limbs + sha256_padding_publics(len(m)).tolist())
+    chips, im = sha256_machine_desc(14, vk, 100, 16)
+    tkey = ctx.machine_verifier_setup(im, prm, n)
+    top = ctx.prove_machine_verifier(tkey, im, [p for _, p in res], pubs, prm)
+    flat = [v for p_ in pubs for v in p_]
+    assert verify_machine_recursive(im, top, flat, tkey.root, prm, n) == (0, 0)
+    bad = list(flat)
+    bad[91 * 23 + 5] ^= 1                                                       # transcript 23's digest
+    assert verify_machine_recursive(im, top, bad, tkey.root, prm, n)[0] != 0
+    total = sum(p.size for _, p in res)
+    assert top.size * 10 < total
+    print("64 keyed transcript proofs: %d B -> %d B (1 / %.1f)" % (total, top.size, total / top.size))
+    tkey.close()

@@ -38,7 +38,7 @@ for name, tag in (("multichip", "multichip"), ("kt1", "streams1"), ("kt", "contr
         if line.startswith("{"):
             open(os.path.join(dst, tag + "_bench_under_rocprof.json"), "w").write(line)
 for a, b in (("stream_pmc.md", "r05_stream_pass_pmc.md"), ("bench_default.json", "r05_bench_default.json"), ("multichip_phases.txt", "r05_multichip_phases_under_rocprof.txt"),
-             ("multichip_phases_plain.txt", "r05_multichip_phases.txt"), ("compress64_phases.txt", "r05_compress64_phases.txt")):
+             ("multichip_phases_plain.txt", "r05_multichip_phases.txt"), ("compress64_phases.txt", "r05_compress64_phases.txt"), ("tree_phases.txt", "r05_tree_phases.txt")):
     if os.path.exists(os.path.join(src, a)):
         shutil.copy(os.path.join(src, a), os.path.join(dst, b))
 print("\n".join(attempts))
