@@ -682,6 +682,22 @@ def main():
                                      "host_verify_ms": round(t_cv * 1e3, 2), "verified": bool(ok_c),
                                      "verifier_inputs": "the chip's program, 64 x (digest, message length), the key of (shape, program) -- derivable on the host; no byte of an inner proof"}
             batch64["compressed_ms"], batch64["compressed_bytes"] = batch64["compressed"]["ms"], batch64["compressed"]["bytes"]
+            # ... and the KEYED proofs of the batch above themselves (version 11: two chips, a preprocessed table, a bus) as ONE proof: machine mode
+            from zktls_amd.device import sha256_inner_machine, verify_machine_recursive as _vmr
+            kim = sha256_inner_machine(len(msgs[0]), vk_l, tprm)
+            kkey = ctx.machine_verifier_setup(kim, tprm, 64)
+            kproofs = [pf for _, pf in res_l]
+            kpubs = [statement(d, len(m)) for (d, _), m in zip(res_l, msgs)]
+            t_k, ktop = 1e9, None
+            for _ in range(3):
+                tb0 = time.perf_counter()
+                ktop = ctx.prove_machine_verifier(kkey, kim, kproofs, kpubs, tprm)
+                t_k = min(t_k, time.perf_counter() - tb0)
+            ok_k = _vmr(kim, ktop, [v for pv_ in kpubs for v in pv_], kkey.root, tprm, 64) == (0, 0)
+            kkey.close()
+            batch64["compressed_keyed"] = {"workload": "the 64 KEYED proofs of the zkhip_prove_transcripts call above -> ONE proof: zkhip_prove_machine_verifier (machine mode: lookups, two heights, the preprocessed table's openings against the machine's key, in-circuit)",
+                                           "compress_ms": round(t_k * 1e3, 2), "ms": round((t_lock + t_k) * 1e3, 2), "inner_bytes_total": int(sum(x.size for x in kproofs)),
+                                           "bytes": int(ktop.size), "compression": round(sum(x.size for x in kproofs) / ktop.size, 2), "verified": bool(ok_k)}
 
     # ---- the compress-like step (sp1.rs:116: core -> compress verifies the shard proofs): the FRI check of sixteen shard proofs of the headline
     # shape proven in-circuit (Merkle paths, folds, challenges, proof of work, query indices) by ONE call of zkhip_prove_fri_indices_batch

@@ -609,6 +609,9 @@ size_t zkhip_sha256_machine_proof_size(size_t message_len, const zkhip_params* p
 int zkhip_prove_sha256_machine(zkhip_ctx* ctx, const zkhip_machine_key* key, const uint8_t* message, size_t message_len, const zkhip_params* prm,
                                uint8_t digest[32], uint8_t* proof, size_t cap, size_t* len);
 int zkhip_verify_sha256_machine(const uint8_t* proof, size_t len, const uint8_t digest[32], uint64_t message_len, const uint32_t vk[8], const zkhip_params* prm, int* reason);
+/* the keyed machine of a message of this length as data -- chip `which` (0, 1: tallest first), kind 0 its program, 1 its interaction table: what a
+ * zkhip_machine_desc takes, so that proofs of zkhip_prove_transcripts go to zkhip_prove_machine_verifier (64 transcript proofs -> ONE proof). */
+size_t zkhip_sha256_machine_describe(size_t message_len, int which, int kind, uint32_t* out, size_t cap, int* log_n, uint32_t* width, uint32_t* pre_width);
 /* A batch of transcripts in one call -- the reference's batch configuration (BASELINE.json configs[2]: 64 independent transcripts), each proven
  * as the keyed SHA-256 machine: job i runs on devices[i mod n_devices] (NULL / 0: every visible device), `in_flight_per_device` at a time per
  * device, on pooled contexts that keep their proving key between calls (setup once per context).  Messages are host bytes; every job

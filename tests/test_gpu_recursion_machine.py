@@ -153,7 +153,9 @@ def test_sixty_four_keyed_transcript_proofs_become_one_proof(ctx):
             w = int.from_bytes(d[4 * i:4 * i + 4], "big")
             limbs += [w & 0xffff, w >> 16]
         pubs.append(limbs + sha256_padding_publics(len(m)).tolist())
-    chips, im = sha256_machine_desc(14, vk, 100, 16)
+    from zktls_amd.device import sha256_inner_machine
+    im = sha256_inner_machine(nbytes, vk, prm)                                  # (zkhip_sha256_machine_describe: the library's own description; sha256_machine_desc above is the test-side one)
+    assert [k[0].tolist() for k in im.keep] == [np.asarray(c["prog"]).tolist() for c in sha256_machine_desc(14, vk, 100, 16)[0]]
     tkey = ctx.machine_verifier_setup(im, prm, n)
     top = ctx.prove_machine_verifier(tkey, im, [p for _, p in res], pubs, prm)
     flat = [v for p_ in pubs for v in p_]

@@ -764,6 +764,22 @@ int zkhip_prove_sha256_machine(zkhip_ctx* ctx, const zkhip_machine_key* key, con
     return zkhip_prove_machine_keyed_at(ctx, key, m.entries, chips, m.progs, m.prog_words, m.tabs, m.tab_words, 2, limbs, sha::N_PUBLIC, prm, proof, cap, len);
 }
 
+// the keyed machine of a message of this length as data: chip `which` (0, 1: tallest first), kind 0 its program, 1 its interaction table -- what a
+// zkhip_machine_desc needs to hand the machine's proofs to zkhip_prove_machine_verifier (64 transcript proofs -> one)
+size_t zkhip_sha256_machine_describe(size_t message_len, int which, int kind, uint32_t* out, size_t cap, int* log_n, uint32_t* width, uint32_t* pre_width) {
+    size_t padded, na, nb;
+    int ln;
+    if (sha_shape(message_len, &padded, &na, &nb, &ln) != ZKHIP_OK || ln > 20 || which < 0 || which > 1 || kind < 0 || kind > 1) return 0;
+    const sha::MachineShape m = sha::machine_shape(ln);
+    if (log_n) *log_n = m.log_ns[which];
+    if (width) *width = m.widths[which];
+    if (pre_width) *pre_width = m.pre_widths[which];
+    const uint32_t* src = kind ? m.tabs[which] : m.progs[which];
+    const size_t n = kind ? m.tab_words[which] : m.prog_words[which];
+    if (out && cap >= n) std::memcpy(out, src, n * 4);
+    return n;
+}
+
 int zkhip_verify_sha256_machine(const uint8_t* proof, size_t len, const uint8_t digest[32], uint64_t message_len, const uint32_t vk[8], const zkhip_params* prm, int* reason) {
     if (!proof || !digest || !vk || !prm || len < 4 * 18) return fail(ZKHIP_ERR_INVALID, "verify_sha256_machine: null argument");
     uint32_t head[18];

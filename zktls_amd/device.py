@@ -953,6 +953,23 @@ class InnerMachine:
         self.n_public = int(n_public)
 
 
+def sha256_inner_machine(message_len, key_root, params=None):
+    """the keyed SHA-256 machine of messages of this length (zkhip_prove_transcripts' proofs) as an InnerMachine for machine mode"""
+    params = params or Params(1, 100, 16)
+    lib = _lib.load()
+    chips = []
+    for which in range(2):
+        ln, w, pw = C.c_int(0), C.c_uint32(0), C.c_uint32(0)
+        parts = []
+        for kind in range(2):
+            n = lib.zkhip_sha256_machine_describe(message_len, which, kind, None, 0, C.byref(ln), C.byref(w), C.byref(pw))
+            out = np.zeros(max(n, 1), dtype=np.uint32)
+            assert n and lib.zkhip_sha256_machine_describe(message_len, which, kind, out.ctypes.data_as(u32p), n, C.byref(ln), C.byref(w), C.byref(pw)) == n
+            parts.append(out[:n])
+        chips.append(dict(ln=ln.value, W=w.value, Pw=pw.value, prog=parts[0], tab=parts[1]))
+    return InnerMachine(chips, key_root, params.num_queries, params.pow_bits, SHA256_PUBLIC)
+
+
 def machine_verifier_describe(inner, which, kind, n_proofs=1):
     """zkhip_machine_verifier_describe -> (words, log_rows, main width, preprocessed width); kind 0 program, 1 interaction table, 2 preprocessed trace"""
     lib = _lib.load()
