@@ -37,6 +37,7 @@
 #include "context.h"
 #include "batch.h"
 #include "p2chip.h"
+#include "p2_x16.h"
 
 namespace zk {
 namespace frichip {

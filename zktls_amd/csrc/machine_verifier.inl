@@ -1319,6 +1319,9 @@ int fill_proof(const Machine& m, int p, const uint8_t* inner, size_t inner_len, 
         const uint32_t FW = m.w_main[C_FOLD], INJ = width_of(R, true, true), INJF = INJ + 4;
         // (the queries are independent: a few threads per proof walk them -- one scalar permutation per Poseidon2 row is most of this function's time)
         std::vector<int> qerr((size_t)Q, 0);
+        const bool x16 = p2x16_available();                 // sixteen queries walked in lockstep, one per AVX-512 lane (p2_x16.h); else one scalar permutation per row
+        std::vector<uint32_t> pair_words(x16 ? 8 * (size_t)Q * (size_t)R : 0), pair_k(x16 ? (size_t)Q * (size_t)R : 0);
+        std::vector<size_t> pair_path(x16 ? (size_t)Q * (size_t)R : 0);
         auto fri_q = [&](int q) -> int {
             size_t prow = sh.p2_fri0 + (size_t)q * sh.fri_rows;
             uint32_t idx = wt.indices[(size_t)q];
@@ -1349,6 +1352,13 @@ int fill_proof(const Machine& m, int p, const uint8_t* inner, size_t inner_len, 
                 put_ext(row, OWN, own);
                 row[K2] = to_monty(2u * k); row[IDX] = to_monty(2u * k + bit);
                 row[XS] = bit ? fsub(0u, x) : x; row[frichip::PT] = to_monty((uint32_t)p * sh.NTREES); row[LNX] = to_monty((uint32_t)p * sh.NTREES + (uint32_t)l);
+                if (x16) {                                   // (hashed below, sixteen queries at a time)
+                    uint32_t* pw8 = pair_words.data() + 8 * ((size_t)q * (size_t)R + (size_t)l);
+                    for (int j = 0; j < 4; j++) { pw8[j] = e0.c[j]; pw8[4 + j] = e1.c[j]; }
+                    pair_k[(size_t)q * (size_t)R + (size_t)l] = k; pair_path[(size_t)q * (size_t)R + (size_t)l] = (size_t)(path - w);
+                    own = fold; idx = k;
+                    continue;
+                }
                 // the layer's leaf (the pair) and its path: Poseidon2 rows
                 uint32_t st[16];
                 for (int j = 0; j < 4; j++) { st[j] = e0.c[j]; st[4 + j] = e1.c[j]; }
@@ -1425,8 +1435,98 @@ int fill_proof(const Machine& m, int p, const uint8_t* inner, size_t inner_len, 
         }
         return 0;
         };
+        // the same rows, sixteen queries in lockstep (the queries of a proof have one structure): st[element][lane]
+        auto walk16 = [&](int q0, int cnt) -> int {
+            uint32_t st[16][16], cur[8][16];
+            uint32_t bits[16], kps[16];
+            auto emit = [&](size_t base0, size_t stride, size_t r) {
+                for (int j = 0; j < cnt; j++) {
+                    const size_t row = base0 + (size_t)(q0 + j) * stride + r;
+                    for (int e = 0; e < 16; e++) tin[16 * row + (size_t)e] = from_monty(st[e][j]);
+                    tbit[row] = bits[j]; tkp[row] = kps[j];
+                }
+                p2x16_permute(st);
+            };
+            for (int l = 0; l < R; l++) {
+                size_t r = (size_t)l + (size_t)l * (size_t)(2 * (H - 1) - (l - 1)) / 2;          // rows of the layers before: l leaves + sum_{i < l} (H - 1 - i) path rows
+                for (int j = 0; j < 16; j++) {
+                    const size_t at = ((size_t)(q0 + (j < cnt ? j : 0)) * (size_t)R + (size_t)l);
+                    for (int e = 0; e < 8; e++) st[e][j] = pair_words[8 * at + (size_t)e];
+                    for (int e = 8; e < 16; e++) st[e][j] = 0u;
+                    bits[j] = 0; kps[j] = 2u * pair_k[at];
+                }
+                emit(sh.p2_fri0, sh.fri_rows, r++);
+                for (int lvl = 0; lvl < H - 1 - l; lvl++) {
+                    for (int e = 0; e < 8; e++) for (int j = 0; j < 16; j++) cur[e][j] = st[e][j];
+                    for (int j = 0; j < 16; j++) {
+                        const size_t at = ((size_t)(q0 + (j < cnt ? j : 0)) * (size_t)R + (size_t)l);
+                        const uint32_t k = pair_k[at], b = (k >> lvl) & 1u;
+                        const uint32_t* path = w + pair_path[at];
+                        for (int e = 0; e < 8; e++) { const uint32_t sv = to_monty(path[8 * (size_t)lvl + (size_t)e]); st[b ? 8 + e : e][j] = cur[e][j]; st[b ? e : 8 + e][j] = sv; }
+                        bits[j] = b; kps[j] = k >> lvl;
+                    }
+                    emit(sh.p2_fri0, sh.fri_rows, r++);
+                }
+                for (int j = 0; j < cnt; j++) for (int e = 0; e < 8; e++) if (from_monty(st[e][j]) != w[wt.o_lroots + 8 * (size_t)l + (size_t)e]) return 1;
+            }
+            for (int tr = 0; tr < N_TREES; tr++) {
+                if (!sh.has_tree[tr]) continue;
+                const std::vector<int>& hs = sh.tree_hs[tr];
+                const std::vector<int> so = sponge_order(sh, tr);
+                const uint32_t* root = tr == T_E ? sh.key_root : w + (tr == T_T ? wt.o_troot : tr == T_P ? wt.o_proot : wt.o_qroot);
+                uint32_t index[16];
+                for (int j = 0; j < 16; j++) index[j] = wt.indices[(size_t)(q0 + (j < cnt ? j : 0))] >> (H - hs[0]);
+                static thread_local uint32_t dg[32][8][16];
+                size_t r = 0;
+                for (int h : so) {
+                    const uint32_t words = sh.leaf[tr][h].words, nb = (words + 7) / 8;
+                    for (int e = 0; e < 16; e++) for (int j = 0; j < 16; j++) st[e][j] = 0u;
+                    for (uint32_t b = 0; b < nb; b++) {
+                        const uint32_t k = words - 8 * b < 8 ? words - 8 * b : 8u;
+                        for (int j = 0; j < 16; j++) {
+                            const int q = q0 + (j < cnt ? j : 0);
+                            for (uint32_t e = 0; e < k; e++) st[e][j] = to_monty(leaf_word(q, tr, h, 8 * b + e));
+                            bits[j] = 0; kps[j] = (b == nb - 1 && h == hs[0]) ? 2u * index[j] : 0u;
+                        }
+                        emit(sh.p2_tree0[tr], sh.tree_rows[tr], r++);
+                    }
+                    for (int e = 0; e < 8; e++) for (int j = 0; j < 16; j++) dg[h][e][j] = st[e][j];
+                }
+                for (int e = 0; e < 8; e++) for (int j = 0; j < 16; j++) cur[e][j] = dg[hs[0]][e][j];
+                for (int lvl = 0; lvl < hs[0]; lvl++) {
+                    for (int j = 0; j < 16; j++) {
+                        const uint32_t* path = w + qp[(size_t)(q0 + (j < cnt ? j : 0))].path[tr];
+                        const uint32_t b = (index[j] >> lvl) & 1u;
+                        for (int e = 0; e < 8; e++) { const uint32_t sv = to_monty(path[8 * (size_t)lvl + (size_t)e]); st[b ? 8 + e : e][j] = cur[e][j]; st[b ? e : 8 + e][j] = sv; }
+                        bits[j] = b; kps[j] = index[j] >> lvl;
+                    }
+                    emit(sh.p2_tree0[tr], sh.tree_rows[tr], r++);
+                    for (int e = 0; e < 8; e++) for (int j = 0; j < 16; j++) cur[e][j] = st[e][j];
+                    const int h = hs[0] - lvl - 1;
+                    if (h != hs[0] && sh.has_h(tr, h)) {
+                        for (int e = 0; e < 8; e++) for (int j = 0; j < 16; j++) { st[e][j] = cur[e][j]; st[8 + e][j] = dg[h][e][j]; }
+                        for (int j = 0; j < 16; j++) { bits[j] = 0; kps[j] = index[j] >> (lvl + 1); }
+                        emit(sh.p2_tree0[tr], sh.tree_rows[tr], r++);
+                        for (int e = 0; e < 8; e++) for (int j = 0; j < 16; j++) cur[e][j] = st[e][j];
+                    }
+                }
+                if (r != sh.tree_rows[tr]) return 4;
+                for (int j = 0; j < cnt; j++) for (int e = 0; e < 8; e++) if (from_monty(cur[e][j]) != root[e]) return 3;
+            }
+            return 0;
+        };
         const int nth = sh.NP >= 16 ? 1 : 16 / sh.NP;
-        if (nth == 1 || Q < 4) for (int q = 0; q < Q; q++) { qerr[(size_t)q] = fri_q(q); if (!qerr[(size_t)q]) qerr[(size_t)q] = tree_q(q); }
+        if (x16) {
+            for (int q = 0; q < Q; q++) qerr[(size_t)q] = fri_q(q);          // (the fold rows and the pairs: field arithmetic only)
+            const int ng = (Q + 15) / 16;
+            auto group = [&](int g) { const int q0 = 16 * g, cnt = Q - q0 < 16 ? Q - q0 : 16; const int e = walk16(q0, cnt); if (e) for (int j = 0; j < cnt; j++) if (!qerr[(size_t)(q0 + j)]) qerr[(size_t)(q0 + j)] = e; };
+            if (nth == 1 || ng < 2) for (int g = 0; g < ng; g++) group(g);
+            else {
+                HostPool pool(nth < ng ? nth : ng);
+                for (int g = 0; g < ng; g++) pool.submit([&group, g] { group(g); });
+                pool.wait();
+            }
+        } else if (nth == 1 || Q < 4) for (int q = 0; q < Q; q++) { qerr[(size_t)q] = fri_q(q); if (!qerr[(size_t)q]) qerr[(size_t)q] = tree_q(q); }
         else {
             HostPool pool(nth);
             for (int t = 0; t < nth; t++) pool.submit([&, t] { for (int q = t; q < Q; q += nth) { qerr[(size_t)q] = fri_q(q); if (!qerr[(size_t)q]) qerr[(size_t)q] = tree_q(q); } });
