@@ -39,6 +39,13 @@
  *   zkhip_shard_verifier_setup, zkhip_prove_shard_verifier, zkhip_verify_shard_recursive
  *       the COMPRESS stage behind the same line (sp1.rs:116: core -> compress; prover.rs:90: lift -> join): whole shard proofs verified inside
  *       ONE proof whose verifier needs the shape, the public values and the shape's key -- no byte of a shard proof.
+ *   zkhip_shard_verifier_setup_air, zkhip_prove_shard_verifier_air, zkhip_verify_shard_recursive_air, zkhip_prove_transcripts_air,
+ *   zkhip_prove_sha256_compressed / zkhip_verify_sha256_compressed
+ *       the same stage for proofs that carry a real statement: inner proofs of any constraint program of degree <= 3 (the SHA-256 chip's:
+ *       64 transcript proofs -> one; the shards of one long message -> one).
+ *   zkhip_machine_verifier_setup / _key_host, zkhip_prove_machine_verifier, zkhip_verify_machine_recursive, zkhip_sha256_machine_describe
+ *       the same stage over KEYED-MACHINE proofs (lookups, chips of mixed heights, preprocessed openings in-circuit): the join of joins --
+ *       sp1-recursion's compress tree (Cargo.lock:6172 ff.; RISC Zero's join of joins, prover.rs:90) -- and the keyed transcript proofs.
  *   zkhip_proof_to_bincode / zkhip_chips_proof_to_bincode (+ _from_bincode)
  *       what `prover_output.bytes()` carries (sp1.rs:122-123): bincode-shaped forms of the proofs ([RECALLED] field order).
  *   zkhip_prove_segment

@@ -27,7 +27,7 @@ def with_quintic_identity(prog, col):
 budget = float(sys.argv[1]) if len(sys.argv) > 1 else 60.0
 rng = np.random.default_rng(int(time.time()))
 ctx = Context(0)
-t0 = time.time(); n_single = n_chips = n_air = n_machine = n_lookup = n_keyed = n_p2 = n_rec = n_rec_air = 0
+t0 = time.time(); n_single = n_chips = n_air = n_machine = n_lookup = n_keyed = n_p2 = n_rec = n_rec_air = n_rec_machine = 0
 SEED = int(rng.integers(1, 2**40))
 while time.time() - t0 < budget:
     r_kind = rng.random()
@@ -76,7 +76,32 @@ while time.time() - t0 < budget:
         assert verify_shard_recursive(outer, log_n, width, q, pb, [v for p_ in pubs for v in p_], key.root, prm, n_proofs=nproofs, program=prog) == (0, 0)
         key.close()
         n_rec_air += 1
-    elif r_kind < 0.014:
+    elif r_kind < 0.011:
+        # MACHINE MODE: a proof of a pseudo-random keyed machine (2 .. 5 tables of random heights, tuples of 1 .. 8 values, preprocessed columns) verified
+        # in-circuit; key and bytes against the oracle on the restatement's arrays (tests/recursion_machine.py)
+        import recursion_machine as RMM
+        from zktls_amd.device import InnerMachine, verify_machine_recursive
+        mseed = int(rng.integers(0, 2**31))
+        mains_, pres_, progs_, tabs_, pub_ = machines.random_keyed_machine(mseed)
+        if any(p_ is None for p_ in progs_) or any(t_ is None for t_ in tabs_): continue
+        q_, pb_ = int(rng.integers(1, 5)), int(rng.integers(0, 3))
+        lns_ = [m_.shape[0].bit_length() - 1 for m_ in mains_]
+        iprm_ = O.default_params(1, q_, pb_)
+        ivk = [int(x) for x in O.machine_setup(pres_, lns_, iprm_)]
+        iproof = O.prove_machine_keyed(mains_, pres_, progs_, tabs_, pub_, iprm_)
+        chips_ = [dict(ln=lns_[c], W=mains_[c].shape[1], Pw=0 if pres_[c] is None else pres_[c].shape[1], prog=progs_[c], tab=tabs_[c]) for c in range(len(mains_))]
+        oshape = (1, int(rng.integers(4, 12)), int(rng.integers(0, 6)))
+        im_ = InnerMachine(chips_, ivk, q_, pb_, len(pub_))
+        key = ctx.machine_verifier_setup(im_, Params(*oshape), 1)
+        sh_, m2, p2, g2, t2, pv2 = RMM.machine(chips_, ivk, [iproof.tobytes()], [pub_], q_, pb_)
+        lns2 = [m_.shape[0].bit_length() - 1 for m_ in m2]
+        assert key.root.tolist() == O.machine_setup(p2, lns2, O.default_params(*oshape)).tolist(), ("machine-mode key", mseed, q_, pb_, oshape)
+        outer = ctx.prove_machine_verifier(key, im_, [iproof], [pub_], Params(*oshape))
+        assert outer.tobytes() == O.prove_machine_keyed(m2, p2, g2, t2, pv2, O.default_params(*oshape)).tobytes(), ("machine mode", mseed, q_, pb_, oshape)
+        assert verify_machine_recursive(im_, outer, pv2, key.root, Params(*oshape), 1) == (0, 0)
+        key.close()
+        n_rec_machine += 1
+    elif r_kind < 0.017:
         # the Poseidon2 chip: random Merkle paths of a random tree; device trace against the Python restatement, proof bytes against the oracle
         depth, n_paths = int(rng.integers(1, 6)), int(rng.integers(1, 12))
         leaves, sibs, idx, root = poseidon2_air.tree_paths(depth, n_paths, seed=int(rng.integers(0, 2**31)))
@@ -217,5 +242,5 @@ while time.time() - t0 < budget:
         assert verify_chips(pf, [c[0] for c in chips], [c[1] for c in chips], [7], Params(*prm), prs, pas if cross else None) == (0, 0)
         for d in dev: d.free()
         n_chips += 1
-print("ok: %d single-matrix, %d multi-chip, %d constraint-program, %d chips-with-programs, %d lookup-machine, %d keyed-machine, %d Poseidon2-chip, %d shard-verifier (join) and %d air-mode shard-verifier configurations in %.0f s"
-      % (n_single, n_chips, n_air, n_machine, n_lookup, n_keyed, n_p2, n_rec, n_rec_air, time.time() - t0))
+print("ok: %d single-matrix, %d multi-chip, %d constraint-program, %d chips-with-programs, %d lookup-machine, %d keyed-machine, %d Poseidon2-chip, %d shard-verifier (join), %d air-mode and %d machine-mode shard-verifier configurations in %.0f s"
+      % (n_single, n_chips, n_air, n_machine, n_lookup, n_keyed, n_p2, n_rec, n_rec_air, n_rec_machine, time.time() - t0))

@@ -174,3 +174,45 @@ def test_sixty_four_keyed_transcript_proofs_become_one_proof(ctx):
     assert top.size * 10 < total
     print("64 keyed transcript proofs: %d B -> %d B (1 / %.1f)" % (total, top.size, total / top.size))
     tkey.close()
+
+
+def described_machine(im, n_proofs, key_root, oq, opb, npub_total):
+    """the machine-mode machine over n_proofs proofs of `im` as an inner machine itself: the library's description of its ten chips"""
+    from zktls_amd.device import machine_verifier_describe
+    chips = []
+    for i in range(10):
+        p, ln, mw, pw = machine_verifier_describe(im, i, 0, n_proofs)
+        t, _, _, _ = machine_verifier_describe(im, i, 1, n_proofs)
+        chips.append(dict(ln=ln, W=mw, Pw=pw, prog=p, tab=t))
+    return chips, InnerMachine(chips, key_root, oq, opb, npub_total)
+
+
+def test_the_machine_verifies_its_own_proofs_three_levels(ctx, oracle):
+    """the recursion closes: a machine-mode proof is a version-11 proof of a ten-chip keyed machine, which machine mode takes like any other.
+    shard proofs -> joins (level 1) -> tops over the joins (level 2) -> ONE proof over the tops (level 3); its bytes against the oracle on the
+    restatement's arrays, its verifier handed the level-2 machine's description, the shards' public values and the key"""
+    O = oracle
+    log_n, width, q, pb = 5, 8, 2, 0
+    iprm, p1, p2, p3, o3 = Params(1, q, pb), Params(1, 2, 0), Params(1, 2, 1), Params(1, 20, 8), O.default_params(1, 20, 8)
+    pubs = [[9, 40 + s] for s in range(2)]
+    shards = [ctx.prove_shard(ctx.gen_trace(SEED, 90 + s, log_n, width), log_n, width, pubs[s], iprm) for s in range(2)]
+    jkey = ctx.shard_verifier_setup(log_n, width, q, pb, 2, p1, n_proofs=1)
+    joins = [ctx.prove_shard_verifier(jkey, shards[s], log_n, width, pubs[s], iprm, p1) for s in range(2)]
+    chips1, im1 = join_machine(log_n, width, q, pb, 2, 1, jkey.root, 2, 0)
+    k2 = ctx.machine_verifier_setup(im1, p2, 1)
+    tops = [ctx.prove_machine_verifier(k2, im1, [joins[s]], [pubs[s]], p2) for s in range(2)]
+    for s in range(2):
+        assert verify_machine_recursive(im1, tops[s], pubs[s], k2.root, p2, 1) == (0, 0)
+    chips2, im2 = described_machine(im1, 1, k2.root, 2, 1, 2)
+    k3 = ctx.machine_verifier_setup(im2, p3, 2)
+    top3 = ctx.prove_machine_verifier(k3, im2, tops, pubs, p3)
+    flat = pubs[0] + pubs[1]
+    assert verify_machine_recursive(im2, top3, flat, k3.root, p3, 2) == (0, 0)
+    assert verify_machine_recursive(im2, top3, pubs[1] + pubs[0], k3.root, p3, 2)[0] != 0
+    assert machine_verifier_key_host(im2, p3, 2).tolist() == k3.root.tolist()
+    sh, mains, pres, progs, tabs, pv = RM.machine(chips2, [int(x) for x in k2.root], [t.tobytes() for t in tops], pubs, 2, 1)
+    lns = [m.shape[0].bit_length() - 1 for m in mains]
+    assert k3.root.tolist() == O.machine_setup(pres, lns, o3).tolist()
+    assert top3.tobytes() == O.prove_machine_keyed(mains, pres, progs, tabs, pv, o3).tobytes(), "the level-3 proof differs from the oracle's"
+    print("three levels: shard proofs %d B -> joins %d B -> tops %d B -> one proof %d B" % (sum(x.size for x in shards), sum(x.size for x in joins), sum(x.size for x in tops), top3.size))
+    jkey.close(), k2.close(), k3.close()

@@ -29,6 +29,7 @@ run_kt kt1 python3 bench.py --steps 10 --warmup 2 --no-cpu-baseline --streams 1 
 run_kt compress64 python3 tools/compress64_trace.py
 python3 tools/join_breakdown.py --sha 64 > $P/compress64_phases.log 2>&1; tail -19 $P/compress64_phases.log > $P/compress64_phases.txt
 # 2c. the tree: 64 headline shard proofs -> 4 joins of 16 -> one proof (machine mode): the phases of its top (A/B build, no profiler)
+run_kt tree python3 tools/tree_breakdown.py 4
 python3 tools/tree_breakdown.py 4 > $P/tree_phases.log 2>&1; grep -E "machine verifier|top over|chips prover" $P/tree_phases.log | tail -20 > $P/tree_phases.txt
 if [ "$WHAT" = all ]; then
 # 3. the contract command (four in flight)

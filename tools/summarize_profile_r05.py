@@ -15,7 +15,7 @@ dst = os.path.join(ROOT, "profiles")
 commit = sys.argv[1] if len(sys.argv) > 1 else ""
 attempts = open(os.path.join(src, "attempts.txt")).read().strip().split("\n") if os.path.exists(os.path.join(src, "attempts.txt")) else []
 
-for name, tag in (("multichip", "multichip"), ("kt1", "streams1"), ("kt", "contract"), ("compress64", "compress64")):
+for name, tag in (("multichip", "multichip"), ("kt1", "streams1"), ("kt", "contract"), ("compress64", "compress64"), ("tree", "tree")):
     stats = glob.glob(os.path.join(src, name, "**", "*_kernel_stats.csv"), recursive=True)
     if not stats:
         continue
