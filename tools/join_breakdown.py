@@ -38,6 +38,30 @@ if "--sha" in sys.argv:
     key.close()
     ctx.close()
     sys.exit(0)
+if "--keyed" in sys.argv:
+    # machine mode: n KEYED transcript proofs (zkhip_prove_transcripts) -> one proof
+    from zktls_amd.device import prove_transcripts, sha256_inner_machine, sha256_padding_publics
+    sys.argv.remove("--keyed")
+    n = int(sys.argv[1]) if len(sys.argv) > 1 else 64
+    prm = Params(1, 100, 16)
+    msgs = [bytes((7 * i + 3 * p + 1) & 0xff for i in range(13221)) for p in range(n)]
+    vk, made = prove_transcripts(msgs, prm, devices=[0])
+    pv = []
+    for (d, _), m in zip(made, msgs):
+        limbs = []
+        for i in range(8):
+            w = int.from_bytes(d[4 * i:4 * i + 4], "big")
+            limbs += [w & 0xffff, w >> 16]
+        pv.append(limbs + sha256_padding_publics(len(m)).tolist())
+    im = sha256_inner_machine(len(msgs[0]), vk, prm)
+    key = ctx.machine_verifier_setup(im, prm, n)
+    for rep in range(3):
+        t0 = time.perf_counter()
+        outer = ctx.prove_machine_verifier(key, im, [p for _, p in made], pv, prm)
+        print("compress %d keyed transcript proofs: %.1f ms, %d bytes" % (n, (time.perf_counter() - t0) * 1e3, outer.size), flush=True)
+    key.close()
+    ctx.close()
+    sys.exit(0)
 log_n, width, q, pb = 20, 256, 100, 16
 iprm, prm = Params(1, q, pb), Params(1, 100, 16)
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 16

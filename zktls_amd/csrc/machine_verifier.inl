@@ -1041,7 +1041,7 @@ struct Wit {
 };
 struct HostTabs {
     ZeroedWords rs, fold, ts, q, op, sm, sc, evl, lgu;
-    std::vector<uint32_t> p2_in, p2_bit, p2_kp;     // the Poseidon2 rows: input state [16] canonical, direction bit, KP (canonical), per used row
+    std::unique_ptr<uint32_t[]> p2_in, p2_bit, p2_kp;     // the Poseidon2 rows: input state [16] canonical, direction bit, KP (canonical), per used row (every one written: not cleared)
 };
 inline Ext ext_at(const uint32_t* p) { return Ext{{to_monty(p[0]), to_monty(p[1]), to_monty(p[2]), to_monty(p[3])}}; }
 inline Ext recombine4(const Ext* four) {            // sum_k X^k four[k]
@@ -1067,11 +1067,16 @@ int fill_proof(const Machine& m, int p, const uint8_t* inner, size_t inner_len, 
     for (int l = 0; l < R; l++) perq += 4 + 8 * (size_t)(H - 1 - l);
     wt.per_query = perq;
     if (inner_len != (wt.o_queries + (size_t)Q * perq) * 4) return bad("its length is not that of a proof of this machine");
+    if (w[0] != 0x41544B5Au || w[7] != 16u) return bad("not a proof");                 // ("ZKTA": proof_common.h PROOF_MAGIC)
     for (int i = 0; i < sh.HL; i++) if (w[(i < 6 ? 1 : 2) + i] != sh.head[(size_t)i]) return bad("another machine's header");
+    // (what follows is a complete verifier of the proof -- every check of zkhip_verify_machine_keyed has its mismatch below --, and a proof that
+    // passed here wrongly would still fail the outer machine's constraints: no second pass through the host verifier)
+    for (size_t i = (size_t)sh.HL + 2; i < inner_len / 4; i++) if (w[i] >= P) return bad("a non-canonical word");
+    for (int i = 0; i < sh.NPUB; i++) if (pubs[i] >= P) return bad("a non-canonical public value");
     // ---- the transcript: every sponge row's input state, the challenges
-    uint32_t* tin = ht.p2_in.data() + 16 * (size_t)p * sh.p2_rows;
-    uint32_t* tbit = ht.p2_bit.data() + (size_t)p * sh.p2_rows;
-    uint32_t* tkp = ht.p2_kp.data() + (size_t)p * sh.p2_rows;
+    uint32_t* tin = ht.p2_in.get() + 16 * (size_t)p * sh.p2_rows;
+    uint32_t* tbit = ht.p2_bit.get() + (size_t)p * sh.p2_rows;
+    uint32_t* tkp = ht.p2_kp.get() + (size_t)p * sh.p2_rows;
     auto src_val = [&](const Src& s) -> uint32_t {
         switch (s.kind) {
             case S_CONST: return s.a; case S_TROOT: return w[wt.o_troot + s.a]; case S_PUB: return pubs[s.a] % P; case S_PROOT: return w[wt.o_proot + s.a];
@@ -1667,18 +1672,13 @@ int m_prove_machine_verifier(zkhip_ctx* ctx, const zkhip_machine_key* key, const
     for (int c = 0; c < N_CHIPS; c++) if (tabs[c] && !tabs[c]->reset((size_t)m.w_main[c] << m.height[c])) return fail(ZKHIP_ERR_NOMEM, "prove_machine_verifier: no host memory for the machine's tables");
     for (size_t r = 0; r < ((size_t)1 << m.height[C_FOLD]); r++) ht.fold.data()[(size_t)m.w_main[C_FOLD] * r + frichip::T] = MONTY_R1;      // (the fold chip's padding rows: T = 1)
     const size_t used = (size_t)NP * sh.p2_rows;
-    try { ht.p2_in.assign(16 * used, 0u); ht.p2_bit.assign(used, 0u); ht.p2_kp.assign(used, 0u); } catch (const std::bad_alloc&) { return fail(ZKHIP_ERR_NOMEM, "prove_machine_verifier: no host memory"); }
-    // the inner proofs are checked by the host verifier first (it names what is wrong with a bad one); then side by side
+    try { ht.p2_in.reset(new uint32_t[16 * used]); ht.p2_bit.reset(new uint32_t[used]); ht.p2_kp.reset(new uint32_t[used]); } catch (const std::bad_alloc&) { return fail(ZKHIP_ERR_NOMEM, "prove_machine_verifier: no host memory"); }
+    // the inner proofs side by side: each one's tables, which is its verification
     {
-        zkhip_params iprm{1, sh.Q, sh.PB, 0, 0, 0, 0, 0};
-        std::vector<int32_t> lns(sh.ln.begin(), sh.ln.end());
         std::vector<int> rcs((size_t)NP, ZKHIP_OK);
         std::vector<std::string> msgs((size_t)NP);
         auto one = [&](int p) {
-            int reason = 0;
-            int r = proofs[p] ? zkhip_verify_machine_keyed(proofs[p], proof_lens[p], lns.data(), sh.W.data(), sh.Pw.data(), sh.key_root, sh.prog.data(), sh.prog_words.data(), sh.tab.data(),
-                                                           sh.tab_words.data(), (size_t)sh.C, public_values + (size_t)p * n_public, n_public, &iprm, &reason)
-                              : fail(ZKHIP_ERR_INVALID, "prove_machine_verifier: null proof");
+            int r = proofs[p] ? ZKHIP_OK : fail(ZKHIP_ERR_INVALID, "prove_machine_verifier: null proof");
 #ifdef ZKHIP_AB_HOOKS
             const auto tv = std::chrono::steady_clock::now();
 #endif
@@ -1708,9 +1708,9 @@ int m_prove_machine_verifier(zkhip_ctx* ctx, const zkhip_machine_key* key, const
         uint32_t* d = (uint32_t*)stage;
         std::vector<uint32_t> trows(used);
         for (size_t r = 0; r < used; r++) trows[r] = (uint32_t)r;
-        ZK_TRY(dev_h2d(ctx, d, ht.p2_in.data(), 16 * used * 4));
-        ZK_TRY(dev_h2d(ctx, d + 16 * used, ht.p2_bit.data(), used * 4));
-        ZK_TRY(dev_h2d(ctx, d + 17 * used, ht.p2_kp.data(), used * 4));
+        ZK_TRY(dev_h2d(ctx, d, ht.p2_in.get(), 16 * used * 4));
+        ZK_TRY(dev_h2d(ctx, d + 16 * used, ht.p2_bit.get(), used * 4));
+        ZK_TRY(dev_h2d(ctx, d + 17 * used, ht.p2_kp.get(), used * 4));
         ZK_TRY(dev_h2d(ctx, d + 18 * used, trows.data(), used * 4));
         p2chip::P2RArgs a{};
         a.desc = nullptr; a.data = nullptr; a.chain_inputs = d; a.trows = d + 18 * used; a.n_chains = 0; a.n_transcript = (uint32_t)used;
