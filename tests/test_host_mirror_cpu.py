@@ -571,6 +571,37 @@ def test_a_verifier_without_a_gpu_checks_a_compressed_blob(lib):
     assert lib.zktls_verify_compressed_blob(blob, len(blob), C.byref(plan2), cbor, len(cbor), elf, len(elf), key2, C.byref(reason)) == -1
 
 
+def test_a_verifier_without_a_gpu_checks_a_tree_blob(lib):
+    """a TREE blob made on an MI355X (tests/golden/make_compressed_fixture.py: five shards, joins of at most two -> three joins -> ONE proof above them) checked
+    with NO device: the join key AND the top's key are derived here on the host's cores (zktls_compress_key_host; zkhip_machine_verifier_key_host inside
+    zktls_verify_compressed_blob), the top is checked by zkhip_verify_machine_recursive.  No shard proof and no join proof is in the blob"""
+    import os
+    _compress_api(lib)
+    lib.zktls_set_compress_join_size.argtypes = [C.c_uint32]
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "proofs", "compressed_tree_blob_5x8x5.bin")
+    blob = open(path, "rb").read()
+    plan = Plan(5, 8, 5, 2, 0)
+    cbor, elf = b"\xa1transcript", b"\x7fELFprog"
+    lib.zktls_set_compress_join_size(2)
+    try:
+        offs, lens = (C.c_size_t * 8)(), (C.c_size_t * 8)()
+        assert lib.zktls_batch_flags(blob, len(blob)) == 1 | 16 | 32 and lib.zktls_unpack_batch(blob, len(blob), offs, lens, 8) == 2 and lens[1] == 36
+        key = (C.c_uint32 * 8)()
+        err = C.create_string_buffer(512)
+        assert lib.zktls_compress_key_host(C.byref(plan), key, err, 512) == 0, err.value
+        assert bytes(key) == blob[offs[1]:offs[1] + 32]
+        reason = C.c_int(0)
+        assert lib.zktls_verify_compressed_blob(blob, len(blob), C.byref(plan), cbor, len(cbor), elf, len(elf), key, C.byref(reason)) == 0
+        assert lib.zktls_verify_compressed_blob(blob, len(blob), C.byref(plan), cbor + b"!", len(cbor) + 1, elf, len(elf), key, C.byref(reason)) == -2
+        bad = bytearray(blob)
+        bad[offs[0] + 4000] ^= 1
+        assert lib.zktls_verify_compressed_blob(bytes(bad), len(blob), C.byref(plan), cbor, len(cbor), elf, len(elf), key, C.byref(reason)) == -2
+        plan6 = Plan(5, 8, 6, 2, 0)
+        assert lib.zktls_verify_compressed_blob(blob, len(blob), C.byref(plan6), cbor, len(cbor), elf, len(elf), key, C.byref(reason)) == -1
+    finally:
+        lib.zktls_set_compress_join_size(0)
+
+
 @pytest.mark.gpu
 def test_compress_stage_behind_the_same_call(lib):
     """core -> compress (sp1.rs:116): the blob carries ONE proof that verifies the shard proofs and the key of the shape; a consumer checks it on the
