@@ -918,6 +918,11 @@ int zkhip_verify_machine_recursive(const zkhip_machine_desc* inner, const uint8_
                                    const zkhip_params* outer, int* reason);
 size_t zkhip_machine_verifier_describe(const zkhip_machine_desc* inner, size_t n_proofs, int which, int kind, uint32_t* out, size_t cap, int* log_rows, uint32_t* main_width,
                                        uint32_t* pre_width);
+/* the MAIN trace of the chip at position `which` as zkhip_prove_machine_verifier fills it on the host (canonical words, [2^log_rows][main width]; the
+ * Poseidon2 chip: (input state [16], direction bit, KP) per used row -- its columns are the device's): no device, no context.  Filling the tables of an
+ * inner proof is its verification: 0 (zkhip_last_error) for a proof the machine would not take.  For tests and for looking. */
+size_t zkhip_machine_verifier_host_tables(const zkhip_machine_desc* inner, const uint8_t* const* proofs, const size_t* proof_lens, size_t n_proofs, const uint32_t* public_values,
+                                          size_t n_public, int which, uint32_t* out, size_t cap);
 size_t zkhip_shard_verifier_describe_air(const uint32_t* program, size_t program_words, int log_n, uint32_t width, size_t n_queries, int inner_pow_bits, size_t n_public,
                                          size_t n_proofs, int which, int kind, uint32_t* out, size_t cap_words, int* log_rows, uint32_t* main_width, uint32_t* pre_width);
 

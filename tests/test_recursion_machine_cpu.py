@@ -162,3 +162,42 @@ def test_product_machine_equals_the_restatement_word_for_word(oracle):
                 pl, lns = [pres[n] for n in names], [h[n] for n in names]
                 want = [int(x) for x in O.machine_setup(pl, lns, O.default_params(1, 20, 8))]
                 assert machine_verifier_key_host(InnerMachine(chips, vk, q, pb, npub), Params(1, 20, 8), n_proofs).tolist() == want
+
+
+def test_the_products_host_tables_equal_the_restatements_main_traces(oracle):
+    """zkhip_prove_machine_verifier fills every main trace but the Poseidon2 chip's columns on the HOST (csrc/machine_verifier.inl, fill_proof: which IS the
+    verification of the inner proof): those tables, word for word, against the restatement's main traces -- a join of two proofs of a mixed-height machine,
+    a random machine, the shard verifier's own machine (the tree's upper level); the Poseidon2 rows as (input state, bit, index); a tampered proof refused"""
+    import poseidon2_air as P2
+    from zktls_amd.device import InnerMachine, machine_verifier_host_tables
+    O = oracle
+    cases = []
+    made = [M.byte_machine(7, 3, seed) for seed in (1, 2)]
+    chips, vk, p0 = inner(O, *made[0])
+    cases.append((chips, vk, [p0, inner(O, *made[1])[2]], [made[0][4], made[1][4]], 2, 1))
+    mains, pres, progs, tabs, pub = M.random_keyed_machine(6)
+    chips, vk, pr = inner(O, mains, pres, progs, tabs, pub, 3, 0)
+    cases.append((chips, vk, [pr], [pub], 3, 0))
+    proof0 = O.prove_shard(O.gen_trace(SEED, 3, 5, 8), [7, 3], O.default_params(1, 1, 0)).tobytes()
+    sh1, m1, p1, g1, t1, pv1 = R.machine(proof0, 5, 8, [7, 3], 1, 0)
+    lns1 = [m.shape[0].bit_length() - 1 for m in m1]
+    vk1 = [int(x) for x in O.machine_setup(p1, lns1, O.default_params(1, 2, 0))]
+    chips1 = [dict(ln=lns1[c], W=m1[c].shape[1], Pw=0 if p1[c] is None else p1[c].shape[1], prog=g1[c], tab=t1[c]) for c in range(8)]
+    cases.append((chips1, vk1, [O.prove_machine_keyed(m1, p1, g1, t1, pv1, O.default_params(1, 2, 0)).tobytes()], [pv1], 2, 0))
+    for chips, vk, proofs, pubs, q, pb in cases:
+        sh, mains, pres, progs, tabs, pv = RM.machine(chips, vk, proofs, pubs, q, pb)
+        im = InnerMachine(chips, vk, q, pb, len(pubs[0]))
+        blobs = [np.frombuffer(p, dtype=np.uint8) for p in proofs]
+        for i, name in enumerate(RM.order(sh)):
+            got = machine_verifier_host_tables(im, blobs, pubs, i)
+            assert got is not None, name
+            if name == "P2R":
+                used = sh.NP * sh.p2_rows
+                got = got.reshape(used, 18)
+                want = mains[i][:used]
+                assert np.array_equal(got[:, :16], want[:, P2.IN:P2.IN + 16]) and np.array_equal(got[:, 16], want[:, P2.BIT]) and np.array_equal(got[:, 17], want[:, RM.M_KP]), name
+            else:
+                assert np.array_equal(got, mains[i].ravel()), name
+        bad = blobs[0].copy()
+        bad[bad.size // 2] ^= 1
+        assert machine_verifier_host_tables(im, [bad] + blobs[1:], pubs, 0) is None

@@ -1733,6 +1733,35 @@ int m_prove_machine_verifier(zkhip_ctx* ctx, const zkhip_machine_key* key, const
     return prc;
 }
 
+// the machine's MAIN traces as the prover fills them on the host, for tests without a device: chip at position `which` (tallest first), canonical words,
+// [2^log_rows][main width]; for the Poseidon2 chip the rows are (input state [16], direction bit, KP) x used rows -- its 360 columns are the device's.
+// Returns the word count (0: refused -- zkhip_last_error says why, a bad inner proof included); out may be null
+size_t m_machine_verifier_host_tables(const zkhip_machine_desc* inner, const uint8_t* const* proofs, const size_t* proof_lens, size_t n_proofs, const uint32_t* public_values,
+                                      size_t n_public, int which, uint32_t* out, size_t cap) {
+    int rc = ZKHIP_OK;
+    const auto mp = machine_of(inner, n_proofs, &rc);
+    if (!mp || !proofs || !proof_lens || which < 0 || which >= N_CHIPS || (int)n_public != mp->sh.NPUB || (n_public && !public_values)) { if (mp) (void)fail(ZKHIP_ERR_INVALID, "machine_verifier_host_tables: bad arguments"); return 0; }
+    const Machine& m = *mp;
+    const MShape& sh = m.sh;
+    HostTabs ht;
+    ZeroedWords* tabs[N_CHIPS] = {nullptr, &ht.rs, &ht.fold, &ht.ts, &ht.q, &ht.op, &ht.sm, &ht.sc, &ht.evl, &ht.lgu};
+    for (int c = 0; c < N_CHIPS; c++) if (tabs[c] && !tabs[c]->reset((size_t)m.w_main[c] << m.height[c])) { (void)fail(ZKHIP_ERR_NOMEM, "machine_verifier_host_tables: no host memory"); return 0; }
+    for (size_t r = 0; r < ((size_t)1 << m.height[C_FOLD]); r++) ht.fold.data()[(size_t)m.w_main[C_FOLD] * r + frichip::T] = MONTY_R1;
+    const size_t used = (size_t)sh.NP * sh.p2_rows;
+    try { ht.p2_in.reset(new uint32_t[16 * used]); ht.p2_bit.reset(new uint32_t[used]); ht.p2_kp.reset(new uint32_t[used]); } catch (const std::bad_alloc&) { (void)fail(ZKHIP_ERR_NOMEM, "machine_verifier_host_tables: no host memory"); return 0; }
+    for (int p = 0; p < sh.NP; p++) if (!proofs[p] || fill_proof(m, p, proofs[p], proof_lens[p], public_values + (size_t)p * n_public, ht) != ZKHIP_OK) return 0;
+    const int c = m.order[which];
+    if (c == C_P2R) {
+        const size_t n = 18 * used;
+        if (out && cap >= n)
+            for (size_t r = 0; r < used; r++) { std::memcpy(out + 18 * r, ht.p2_in.get() + 16 * r, 64); out[18 * r + 16] = ht.p2_bit.get()[r]; out[18 * r + 17] = ht.p2_kp.get()[r]; }
+        return n;
+    }
+    const size_t n = tabs[c]->size();
+    if (out && cap >= n) for (size_t i = 0; i < n; i++) out[i] = from_monty(tabs[c]->data()[i]);
+    return n;
+}
+
 int m_verify_machine_recursive(const zkhip_machine_desc* inner, const uint8_t* proof, size_t len, const uint32_t* public_values, size_t n_public, size_t n_proofs, const uint32_t vk[8],
                                    const zkhip_params* outer, int* reason) {
     if (!proof || !vk || !outer || (n_public && !public_values)) { if (reason) *reason = 1; return fail(ZKHIP_ERR_VERIFY, "verify_machine_recursive: null argument"); }
@@ -1761,6 +1790,10 @@ size_t zkhip_machine_verifier_describe(const zkhip_machine_desc* inner, size_t n
 int zkhip_prove_machine_verifier(zkhip_ctx* ctx, const zkhip_machine_key* key, const zkhip_machine_desc* inner, const uint8_t* const* proofs, const size_t* proof_lens, size_t n_proofs,
                                  const uint32_t* public_values, size_t n_public, const zkhip_params* outer, uint8_t* proof, size_t cap, size_t* len) {
     return zk::mrec::m_prove_machine_verifier(ctx, key, inner, proofs, proof_lens, n_proofs, public_values, n_public, outer, proof, cap, len);
+}
+size_t zkhip_machine_verifier_host_tables(const zkhip_machine_desc* inner, const uint8_t* const* proofs, const size_t* proof_lens, size_t n_proofs, const uint32_t* public_values,
+                                          size_t n_public, int which, uint32_t* out, size_t cap) {
+    return zk::mrec::m_machine_verifier_host_tables(inner, proofs, proof_lens, n_proofs, public_values, n_public, which, out, cap);
 }
 int zkhip_verify_machine_recursive(const zkhip_machine_desc* inner, const uint8_t* proof, size_t len, const uint32_t* public_values, size_t n_public, size_t n_proofs, const uint32_t vk[8],
                                    const zkhip_params* outer, int* reason) {

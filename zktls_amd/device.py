@@ -980,6 +980,22 @@ def machine_verifier_describe(inner, which, kind, n_proofs=1):
     return out[:n], ln.value, mw.value, pw.value
 
 
+def machine_verifier_host_tables(inner, proofs, public_values, which):
+    """zkhip_machine_verifier_host_tables: the main trace of the chip at position `which` as the prover fills it on the host (canonical words, flat); None: refused"""
+    lib = _lib.load()
+    sps = [np.ascontiguousarray(sp, dtype=np.uint8) for sp in proofs]
+    n = len(sps)
+    pv = np.ascontiguousarray(np.array([list(v) for v in public_values], dtype=np.uint32).reshape(n, -1)) if inner.n_public else np.zeros((n, 1), dtype=np.uint32)
+    ptrs = (u8p * n)(*[sp.ctypes.data_as(u8p) for sp in sps])
+    lens = (C.c_size_t * n)(*[sp.size for sp in sps])
+    words = lib.zkhip_machine_verifier_host_tables(C.byref(inner.desc), ptrs, lens, n, pv.ctypes.data_as(u32p), inner.n_public, which, None, 0)
+    if words == 0:
+        return None
+    out = np.zeros(words, dtype=np.uint32)
+    assert lib.zkhip_machine_verifier_host_tables(C.byref(inner.desc), ptrs, lens, n, pv.ctypes.data_as(u32p), inner.n_public, which, out.ctypes.data_as(u32p), words) == words
+    return out
+
+
 def machine_verifier_key_host(inner, params=None, n_proofs=1):
     params = params or Params()
     vk = np.zeros(8, dtype=np.uint32)
