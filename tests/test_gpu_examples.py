@@ -23,6 +23,11 @@ def test_compress_shards_example():
     assert re.search(r"6 shards of 2\^12 x 16: shard proofs .* ONE proof that verifies them all .* verified on the host .* from \(shape, 6 public values, key\) alone", out), out
 
 
+def test_compress_tree_example():
+    out = run("compress_tree", 6, 3, 10, 16)
+    assert re.search(r"6 shards of 2\^10 x 16: .* 2 joins of 3: .* ONE proof over the joins .* verified on the host .* keys derived on the host", out), out
+
+
 def test_prove_shard_example():
     out = run("prove_shard", 12, 16, 3, "batch")
     assert "mean" in out and "proof bytes" in out, out
