@@ -201,3 +201,32 @@ def test_the_products_host_tables_equal_the_restatements_main_traces(oracle):
         bad = blobs[0].copy()
         bad[bad.size // 2] ^= 1
         assert machine_verifier_host_tables(im, [bad] + blobs[1:], pubs, 0) is None
+
+
+def test_descriptions_the_machine_does_not_take_are_refused():
+    """zkhip_machine_verifier_key_host on malformed or unsupported inner machines: an error, never a crash"""
+    from zktls_amd._lib import Params, ZkHipError
+    from zktls_amd.device import InnerMachine, machine_verifier_key_host
+    import oracle_lib as O
+    mains, pres, progs, tabs, pub = M.byte_machine(6, 3)
+    chips, lns = chips_of(mains, pres, progs, tabs)
+    vk = [1] * 8
+
+    def refused(ch, q=2, pb=1, npub=1, n_proofs=1):
+        with pytest.raises(ZkHipError):
+            machine_verifier_key_host(InnerMachine(ch, vk, q, pb, npub), Params(1, 20, 8), n_proofs)
+    assert machine_verifier_key_host(InnerMachine(chips, vk, 2, 1, 1), Params(1, 20, 8)).size == 8
+    refused(chips[::-1] if chips[0]["ln"] != chips[1]["ln"] else [dict(chips[0], ln=5), dict(chips[1], ln=6)])          # not tallest first
+    refused([dict(chips[0], W=chips[0]["W"] + 2)] + chips[1:])                                                            # a width that is no multiple of 4 (and not the program's)
+    refused(chips, q=0)
+    refused(chips, pb=29)
+    refused(chips, npub=2)                                                                                               # another number of public values than the programs declare
+    refused(chips, n_proofs=65)
+    refused(chips * 9)                                                                                                   # more than 16 chips
+    quintic = O.air_program(int(chips[0]["prog"][2]), 1, [(O.SEL_ALL, [(1, [O.air_var(0)] * 5)])])                       # log_quotient_degree 2
+    refused([dict(chips[0], prog=quintic)] + chips[1:])
+    nopre = [dict(c, Pw=0, prog=O.air_program(c["W"], 1, [(O.SEL_FIRST, [(1, [O.air_var(0)])])]), tab=O.interaction_table([(O.SEND, None, 5, [0])])) for c in chips]
+    refused(nopre)                                                                                                       # no preprocessed columns at all: not a KEYED machine
+    garbage = np.arange(40, dtype=np.uint32)
+    refused([dict(chips[0], prog=garbage)] + chips[1:])
+    refused([dict(chips[0], tab=garbage)] + chips[1:])
