@@ -317,7 +317,7 @@ fn prove_one(ctx: &Context, d_trace: *const u32, log_n: i32, width: u32, column_
 /// The compress stage (`client.prove(.., Groth16)`, sp1.rs:116: core -> COMPRESS; prover.rs:90: lift -> join): ONE proof that verifies all
 /// shard proofs of an execution in-circuit.  `public_values`: those of proof 0, then those of proof 1, ... (`n_public` each).  Returns the
 /// joined proof and the verifying key of the shape; `verify_compressed` then needs no byte of the shard proofs.  Limits (docs/RECURSION_NEXT.md):
-/// version-1 shard proofs of one shape, at most `zkhip_shard_verifier_max_proofs` per join (136 of the headline shape under an outer proof at blowup 2), one level.
+/// version-1 shard proofs of one shape, at most `zkhip_shard_verifier_max_proofs` per join (136 of the headline shape under an outer proof at blowup 2); `compress_tree` joins the joins.
 pub fn compress_shards(ctx: &Context, proofs: &[Vec<u8>], log_n: i32, width: u32, public_values: &[u32], n_public: usize, inner: &ZkhipParams,
                        outer: &ZkhipParams) -> Result<(Vec<u8>, [u32; 8])> {
     anyhow::ensure!(!proofs.is_empty() && public_values.len() == proofs.len() * n_public, "compress_shards: one public-value list per proof");
@@ -363,6 +363,71 @@ pub fn compress_execution(ctx: &Context, proofs: &[Vec<u8>], log_n: i32, width: 
         out.push(joined);
     }
     Ok((out, vk, j))
+}
+
+/// The join machine over `join` shard proofs of a shape, as the inner machine of machine mode (zkhip_machine_desc): the library's own
+/// description of its eight chips + the join key's root.  The vectors own the words the raw description points into.
+pub struct JoinMachine {
+    progs: Vec<Vec<u32>>, tabs: Vec<Vec<u32>>, pp: Vec<*const u32>, tp: Vec<*const u32>, pw: Vec<usize>, tw: Vec<usize>,
+    lns: [i32; 8], widths: [u32; 8], pres: [u32; 8],
+    pub desc: ffi::ZkhipMachineDesc,
+}
+impl JoinMachine {
+    pub fn new(log_n: i32, width: u32, n_public: usize, join: usize, join_key: &[u32; 8], outer_of_the_joins: &ZkhipParams, inner: &ZkhipParams) -> Result<Box<Self>> {
+        let mut m = Box::new(JoinMachine { progs: vec![], tabs: vec![], pp: vec![], tp: vec![], pw: vec![], tw: vec![], lns: [0; 8], widths: [0; 8], pres: [0; 8],
+                                           desc: unsafe { std::mem::zeroed() } });
+        for i in 0..8 {
+            let (mut ln, mut mw, mut pw) = (0i32, 0u32, 0u32);
+            for kind in 0..2 {
+                let n = unsafe { ffi::zkhip_shard_verifier_describe(log_n, width, inner.num_queries as usize, inner.pow_bits, n_public, join, i, kind, std::ptr::null_mut(), 0, &mut ln, &mut mw, &mut pw) };
+                anyhow::ensure!(n > 0, "zkhip_shard_verifier_describe");
+                let mut v = vec![0u32; n];
+                unsafe { ffi::zkhip_shard_verifier_describe(log_n, width, inner.num_queries as usize, inner.pow_bits, n_public, join, i, kind, v.as_mut_ptr(), n, &mut ln, &mut mw, &mut pw) };
+                if kind == 0 { m.progs.push(v) } else { m.tabs.push(v) }
+            }
+            m.lns[i as usize] = ln; m.widths[i as usize] = mw; m.pres[i as usize] = pw;
+        }
+        m.pp = m.progs.iter().map(|v| v.as_ptr()).collect(); m.tp = m.tabs.iter().map(|v| v.as_ptr()).collect();
+        m.pw = m.progs.iter().map(|v| v.len()).collect(); m.tw = m.tabs.iter().map(|v| v.len()).collect();
+        m.desc = ffi::ZkhipMachineDesc { n_chips: 8, log_ns: m.lns.as_ptr(), widths: m.widths.as_ptr(), pre_widths: m.pres.as_ptr(), programs: m.pp.as_ptr(), program_words: m.pw.as_ptr(),
+                                         tables: m.tp.as_ptr(), table_words: m.tw.as_ptr(), key_root: *join_key, num_queries: outer_of_the_joins.num_queries,
+                                         pow_bits: outer_of_the_joins.pow_bits, n_public: (n_public * join) as u32 };
+        Ok(m)
+    }
+}
+
+/// THE TREE (sp1-recursion joins the joins; prover.rs:90 lift -> join): `joins` are the proofs of `compress_execution` (join size `j`, key `join_vk`);
+/// ONE proof verifies them all in-circuit (machine mode of the shard verifier machine).  Returns that proof and its key (a verifier derives the
+/// same key with `zkhip_machine_verifier_key_host`).  `public_values`: the shard proofs' in join order (`j * n_public` per join).
+pub fn compress_tree(ctx: &Context, joins: &[Vec<u8>], log_n: i32, width: u32, public_values: &[u32], n_public: usize, j: usize, join_vk: &[u32; 8], inner: &ZkhipParams,
+                     outer: &ZkhipParams) -> Result<(Vec<u8>, [u32; 8])> {
+    anyhow::ensure!(joins.len() >= 2 && public_values.len() == joins.len() * j * n_public, "compress_tree: j * n_public public values per join");
+    let jm = JoinMachine::new(log_n, width, n_public, j, join_vk, outer, inner)?;
+    let n = joins.len();
+    let mut key: *mut ffi::ZkhipMachineKey = std::ptr::null_mut();
+    let mut vk = [0u32; 8];
+    check(unsafe { ffi::zkhip_machine_verifier_setup(ctx.raw(), &jm.desc, n, outer, &mut key, vk.as_mut_ptr()) }, "zkhip_machine_verifier_setup")?;
+    let cap = unsafe { ffi::zkhip_machine_verifier_proof_size(&jm.desc, n, outer) };
+    let ptrs: Vec<*const u8> = joins.iter().map(|p| p.as_ptr()).collect();
+    let lens: Vec<usize> = joins.iter().map(|p| p.len()).collect();
+    let mut out = vec![0u8; cap];
+    let mut len = 0usize;
+    let rc = unsafe { ffi::zkhip_prove_machine_verifier(ctx.raw(), key, &jm.desc, ptrs.as_ptr(), lens.as_ptr(), n, public_values.as_ptr(), j * n_public, outer, out.as_mut_ptr(), cap, &mut len) };
+    unsafe { ffi::zkhip_machine_key_destroy(key) };
+    check(rc, "zkhip_prove_machine_verifier")?;
+    out.truncate(len);
+    Ok((out, vk))
+}
+
+/// Host-only check of a tree's top: the join machine's description (a function of the shard shape and the join key), the shard proofs' public values, the key.
+pub fn verify_tree(top: &[u8], log_n: i32, width: u32, public_values: &[u32], n_public: usize, j: usize, n_joins: usize, join_vk: &[u32; 8], inner: &ZkhipParams,
+                   outer: &ZkhipParams) -> Result<()> {
+    let jm = JoinMachine::new(log_n, width, n_public, j, join_vk, outer, inner)?;
+    let mut vk = [0u32; 8];
+    check(unsafe { ffi::zkhip_machine_verifier_key_host(&jm.desc, n_joins, outer, vk.as_mut_ptr()) }, "zkhip_machine_verifier_key_host")?;
+    let mut reason = 0;
+    check(unsafe { ffi::zkhip_verify_machine_recursive(&jm.desc, top.as_ptr(), top.len(), public_values.as_ptr(), j * n_public, n_joins, vk.as_ptr(), outer, &mut reason) },
+          "zkhip_verify_machine_recursive")
 }
 
 /// Host-only check of a joined proof: the shape, the shard proofs' public values and the key of the shape (sp1.rs:120 for the compressed proof).
