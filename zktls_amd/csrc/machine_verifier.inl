@@ -916,7 +916,7 @@ void heights_of(const MShape& sh, int h[N_CHIPS]) {
     h[C_QUERY] = lg(np * (size_t)sh.Q * sh.hs.size()); h[C_OPENED] = lg(np * (size_t)(sh.NV / 2)); h[C_SAMPLES] = lg(np * (size_t)sh.NS); h[C_SCALARS] = lg(np * (size_t)sh.C);
     h[C_EVAL] = lg(np * sh.terms.size()); h[C_LOGUP] = lg(np * sh.lrows.size());
 }
-std::shared_ptr<const Machine> machine_of(const zkhip_machine_desc* d, size_t n_proofs, int* rc) {
+std::shared_ptr<const Machine> machine_of_impl(const zkhip_machine_desc* d, size_t n_proofs, int* rc) {
     static std::mutex mu;
     static std::map<std::vector<uint64_t>, std::shared_ptr<const Machine>> cache;
     struct Seen { uint64_t hash; size_t n_proofs; uint64_t gen; std::shared_ptr<const Machine> m; };
@@ -1002,6 +1002,13 @@ std::shared_ptr<const Machine> machine_of(const zkhip_machine_desc* d, size_t n_
     if (seen.size() >= 8) seen.erase(seen.begin());
     seen.push_back(Seen{hsh, n_proofs, g_p2_generation.load(), m});
     return m;
+}
+// (nothing may unwind across the C ABI: the entries below start here)
+std::shared_ptr<const Machine> machine_of(const zkhip_machine_desc* d, size_t n_proofs, int* rc) {
+    try { return machine_of_impl(d, n_proofs, rc); }
+    catch (const std::bad_alloc&) { *rc = fail(ZKHIP_ERR_NOMEM, "machine verifier: out of host memory"); }
+    catch (const std::exception& e) { *rc = fail(ZKHIP_ERR_INTERNAL, std::string("machine verifier: ") + e.what()); }
+    return nullptr;
 }
 void samples_pre_all(const MShape& sh, int log_rows, std::vector<uint32_t>& t) {
     t.assign((size_t)frichip::S_PRE << log_rows, 0u);
@@ -1524,7 +1531,12 @@ int fill_proof(const Machine& m, int p, const uint8_t* inner, size_t inner_len, 
         if (x16) {
             for (int q = 0; q < Q; q++) qerr[(size_t)q] = fri_q(q);          // (the fold rows and the pairs: field arithmetic only)
             const int ng = (Q + 15) / 16;
-            auto group = [&](int g) { const int q0 = 16 * g, cnt = Q - q0 < 16 ? Q - q0 : 16; const int e = walk16(q0, cnt); if (e) for (int j = 0; j < cnt; j++) if (!qerr[(size_t)(q0 + j)]) qerr[(size_t)(q0 + j)] = e; };
+            auto group = [&](int g) {
+                const int q0 = 16 * g, cnt = Q - q0 < 16 ? Q - q0 : 16;
+                int e;
+                try { e = walk16(q0, cnt); } catch (...) { e = 4; }
+                if (e) for (int j = 0; j < cnt; j++) if (!qerr[(size_t)(q0 + j)]) qerr[(size_t)(q0 + j)] = e;
+            };
             if (nth == 1 || ng < 2) for (int g = 0; g < ng; g++) group(g);
             else {
                 HostPool pool(nth < ng ? nth : ng);
@@ -1678,6 +1690,7 @@ int m_prove_machine_verifier(zkhip_ctx* ctx, const zkhip_machine_key* key, const
         std::vector<int> rcs((size_t)NP, ZKHIP_OK);
         std::vector<std::string> msgs((size_t)NP);
         auto one = [&](int p) {
+          try {                                                            // (a pool thread: nothing may unwind out of it)
             int r = proofs[p] ? ZKHIP_OK : fail(ZKHIP_ERR_INVALID, "prove_machine_verifier: null proof");
 #ifdef ZKHIP_AB_HOOKS
             const auto tv = std::chrono::steady_clock::now();
@@ -1688,6 +1701,8 @@ int m_prove_machine_verifier(zkhip_ctx* ctx, const zkhip_machine_key* key, const
 #endif
             rcs[(size_t)p] = r;
             if (r != ZKHIP_OK) msgs[(size_t)p] = zkhip_last_error();
+          } catch (const std::bad_alloc&) { rcs[(size_t)p] = ZKHIP_ERR_NOMEM; msgs[(size_t)p] = "prove_machine_verifier: out of host memory"; }
+            catch (const std::exception& e) { rcs[(size_t)p] = ZKHIP_ERR_INTERNAL; msgs[(size_t)p] = std::string("prove_machine_verifier: ") + e.what(); }
         };
         if (NP == 1) one(0);
         else {
@@ -1749,7 +1764,9 @@ size_t m_machine_verifier_host_tables(const zkhip_machine_desc* inner, const uin
     for (size_t r = 0; r < ((size_t)1 << m.height[C_FOLD]); r++) ht.fold.data()[(size_t)m.w_main[C_FOLD] * r + frichip::T] = MONTY_R1;
     const size_t used = (size_t)sh.NP * sh.p2_rows;
     try { ht.p2_in.reset(new uint32_t[16 * used]); ht.p2_bit.reset(new uint32_t[used]); ht.p2_kp.reset(new uint32_t[used]); } catch (const std::bad_alloc&) { (void)fail(ZKHIP_ERR_NOMEM, "machine_verifier_host_tables: no host memory"); return 0; }
-    for (int p = 0; p < sh.NP; p++) if (!proofs[p] || fill_proof(m, p, proofs[p], proof_lens[p], public_values + (size_t)p * n_public, ht) != ZKHIP_OK) return 0;
+    try {
+        for (int p = 0; p < sh.NP; p++) if (!proofs[p] || fill_proof(m, p, proofs[p], proof_lens[p], public_values + (size_t)p * n_public, ht) != ZKHIP_OK) return 0;
+    } catch (const std::exception& e) { (void)fail(ZKHIP_ERR_NOMEM, std::string("machine_verifier_host_tables: ") + e.what()); return 0; }
     const int c = m.order[which];
     if (c == C_P2R) {
         const size_t n = 18 * used;
@@ -1777,26 +1794,31 @@ int m_verify_machine_recursive(const zkhip_machine_desc* inner, const uint8_t* p
 }  // namespace mrec
 }  // namespace zk
 
+// (nothing unwinds across the C ABI)
+#define ZK_MREC_GUARD(expr, on_error)                                                                                        \
+    try { return expr; }                                                                                                     \
+    catch (const std::bad_alloc&) { (void)fail(ZKHIP_ERR_NOMEM, "machine verifier: out of host memory"); return on_error; }  \
+    catch (const std::exception& e) { (void)fail(ZKHIP_ERR_INTERNAL, std::string("machine verifier: ") + e.what()); return on_error; }
 extern "C" {
 int zkhip_machine_verifier_setup(zkhip_ctx* ctx, const zkhip_machine_desc* inner, size_t n_proofs, const zkhip_params* outer, zkhip_machine_key** key, uint32_t vk[8]) {
-    return zk::mrec::m_machine_verifier_setup(ctx, inner, n_proofs, outer, key, vk);
+    ZK_MREC_GUARD(zk::mrec::m_machine_verifier_setup(ctx, inner, n_proofs, outer, key, vk), ZKHIP_ERR_NOMEM)
 }
-int zkhip_machine_verifier_key_host(const zkhip_machine_desc* inner, size_t n_proofs, const zkhip_params* outer, uint32_t vk[8]) { return zk::mrec::m_machine_verifier_key_host(inner, n_proofs, outer, vk); }
-size_t zkhip_machine_verifier_proof_size(const zkhip_machine_desc* inner, size_t n_proofs, const zkhip_params* outer) { return zk::mrec::m_machine_verifier_proof_size(inner, n_proofs, outer); }
+int zkhip_machine_verifier_key_host(const zkhip_machine_desc* inner, size_t n_proofs, const zkhip_params* outer, uint32_t vk[8]) { ZK_MREC_GUARD(zk::mrec::m_machine_verifier_key_host(inner, n_proofs, outer, vk), ZKHIP_ERR_NOMEM) }
+size_t zkhip_machine_verifier_proof_size(const zkhip_machine_desc* inner, size_t n_proofs, const zkhip_params* outer) { ZK_MREC_GUARD(zk::mrec::m_machine_verifier_proof_size(inner, n_proofs, outer), 0) }
 size_t zkhip_machine_verifier_describe(const zkhip_machine_desc* inner, size_t n_proofs, int which, int kind, uint32_t* out, size_t cap, int* log_rows, uint32_t* main_width,
                                        uint32_t* pre_width) {
-    return zk::mrec::m_machine_verifier_describe(inner, n_proofs, which, kind, out, cap, log_rows, main_width, pre_width);
+    ZK_MREC_GUARD(zk::mrec::m_machine_verifier_describe(inner, n_proofs, which, kind, out, cap, log_rows, main_width, pre_width), 0)
 }
 int zkhip_prove_machine_verifier(zkhip_ctx* ctx, const zkhip_machine_key* key, const zkhip_machine_desc* inner, const uint8_t* const* proofs, const size_t* proof_lens, size_t n_proofs,
                                  const uint32_t* public_values, size_t n_public, const zkhip_params* outer, uint8_t* proof, size_t cap, size_t* len) {
-    return zk::mrec::m_prove_machine_verifier(ctx, key, inner, proofs, proof_lens, n_proofs, public_values, n_public, outer, proof, cap, len);
+    ZK_MREC_GUARD(zk::mrec::m_prove_machine_verifier(ctx, key, inner, proofs, proof_lens, n_proofs, public_values, n_public, outer, proof, cap, len), ZKHIP_ERR_NOMEM)
 }
 size_t zkhip_machine_verifier_host_tables(const zkhip_machine_desc* inner, const uint8_t* const* proofs, const size_t* proof_lens, size_t n_proofs, const uint32_t* public_values,
                                           size_t n_public, int which, uint32_t* out, size_t cap) {
-    return zk::mrec::m_machine_verifier_host_tables(inner, proofs, proof_lens, n_proofs, public_values, n_public, which, out, cap);
+    ZK_MREC_GUARD(zk::mrec::m_machine_verifier_host_tables(inner, proofs, proof_lens, n_proofs, public_values, n_public, which, out, cap), 0)
 }
 int zkhip_verify_machine_recursive(const zkhip_machine_desc* inner, const uint8_t* proof, size_t len, const uint32_t* public_values, size_t n_public, size_t n_proofs, const uint32_t vk[8],
                                    const zkhip_params* outer, int* reason) {
-    return zk::mrec::m_verify_machine_recursive(inner, proof, len, public_values, n_public, n_proofs, vk, outer, reason);
+    ZK_MREC_GUARD(zk::mrec::m_verify_machine_recursive(inner, proof, len, public_values, n_public, n_proofs, vk, outer, reason), ZKHIP_ERR_NOMEM)
 }
 }  // extern "C"
