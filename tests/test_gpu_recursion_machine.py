@@ -216,3 +216,43 @@ def test_the_machine_verifies_its_own_proofs_three_levels(ctx, oracle):
     assert top3.tobytes() == O.prove_machine_keyed(mains, pres, progs, tabs, pv, o3).tobytes(), "the level-3 proof differs from the oracle's"
     print("three levels: shard proofs %d B -> joins %d B -> tops %d B -> one proof %d B" % (sum(x.size for x in shards), sum(x.size for x in joins), sum(x.size for x in tops), top3.size))
     jkey.close(), k2.close(), k3.close()
+
+
+def test_a_tree_over_statements_about_real_data(ctx):
+    """four SHA-256 proofs ("digest = SHA-256 of a message of L bytes") -> two air-mode joins of two (nine chips: the EVAL chip over the SHA-256 program)
+    -> ONE proof over the joins (machine mode takes the nine-chip machine like any other); its verifier is handed the join machine's
+    description, the four (digest, length) statements and the key"""
+    import hashlib
+    from zktls_amd.device import sha256_air, sha256_padding_publics
+    q, pb = 4, 2
+    iprm, jprm, tprm = Params(1, q, pb), Params(1, 3, 1), Params(1, 20, 8)
+    prog = sha256_air()
+    msgs = [bytes((3 * i + 17 * p + 1) & 0xff for i in range(100)) for p in range(4)]
+    inner, pubs = [], []
+    for m in msgs:
+        d, pf = ctx.prove_sha256(m, iprm)
+        assert d == hashlib.sha256(m).digest()
+        limbs = []
+        for i in range(8):
+            w = int.from_bytes(d[4 * i:4 * i + 4], "big")
+            limbs += [w & 0xffff, w >> 16]
+        inner.append(pf), pubs.append(limbs + sha256_padding_publics(len(m)).tolist())
+    jkey = ctx.shard_verifier_setup(7, 640, q, pb, 91, jprm, n_proofs=2, program=prog)
+    joins = [ctx.prove_shard_verifier(jkey, inner[2 * j:2 * j + 2], 7, 640, pubs[2 * j:2 * j + 2], iprm, jprm, program=prog) for j in range(2)]
+    chips = []
+    for i in range(9):
+        p_, ln, mw, pw = shard_verifier_describe(7, 640, q, pb, 91, i, 0, 2, program=prog)
+        t_, _, _, _ = shard_verifier_describe(7, 640, q, pb, 91, i, 1, 2, program=prog)
+        chips.append(dict(ln=ln, W=mw, Pw=pw, prog=p_, tab=t_))
+    im = InnerMachine(chips, jkey.root, 3, 1, 2 * 91)
+    tkey = ctx.machine_verifier_setup(im, tprm, 2)
+    jpubs = [pubs[0] + pubs[1], pubs[2] + pubs[3]]
+    top = ctx.prove_machine_verifier(tkey, im, joins, jpubs, tprm)
+    flat = [v for p_ in jpubs for v in p_]
+    assert verify_machine_recursive(im, top, flat, machine_verifier_key_host(im, tprm, 2), tprm, 2) == (0, 0)
+    bad = list(flat)
+    bad[91 * 3 + 1] ^= 1                                                        # the fourth message's digest
+    assert verify_machine_recursive(im, top, bad, tkey.root, tprm, 2)[0] != 0
+    bad = flat[:91 * 2] + pubs[2][:16] + sha256_padding_publics(99).tolist() + flat[91 * 3:]      # the third message: another length
+    assert verify_machine_recursive(im, top, bad, tkey.root, tprm, 2)[0] != 0
+    jkey.close(), tkey.close()
