@@ -946,6 +946,7 @@ def main():
             "batch64": batch64,
             "recursion_proofs_per_s": (recursion16["recursion_proofs_per_s"] if recursion16 else None),
             "recursion16": recursion16,
+            "recursion": ({"tree_ms": recursion16["tree_ms"], "tree_bytes": recursion16["tree_bytes"], "join16_ms": recursion16["join16"]["ms"], "join16_bytes": recursion16["join16"]["outer_bytes"]} if recursion16 else None),
             "multichip": multichip,
             "execution22": execution,
             "one_process": one_process,
