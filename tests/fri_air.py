@@ -38,7 +38,8 @@ def width_of(layers, wired=False, rec=False, inject=None):
 
 
 def inj_cols(layers):
-    """machine mode (tests/recursion_machine.py): INJ = what joins the folded value at this row (the reduced opening of the height just reached), INJF = the row has one"""
+    """machine mode (tests/recursion_machine.py): INJ = what joins the folded value at this row (the reduced opening of the height just reached), INJF = the row has one;
+    IDX0 (at INJF + 1) = the query's index, constant along its chain: what joins is named by the query it joins"""
     w = width_of(layers, rec=True)
     return w, w + 4
 
@@ -114,6 +115,9 @@ def program(layers, wired=False, transcript=False, rec=None, inject=None):
         add(O.SEL_ALL, [(1, [V(INJF)])] + [(P - 1, [V(L + l)]) for l in inject])
         for j in range(4):
             add(O.SEL_ALL, [(1, [V(INJ + j)]), (P - 1, [V(INJF), V(INJ + j)])])
+        IDX0 = INJF + 1
+        add(O.SEL_ALL, [(1, [V(L), V(IDX0)]), (P - 1, [V(L), V(IDX)])])                 # the chain's first row: the query's index
+        add(O.SEL_TRANSITION, gated([(1, [V(IDX0)]), (P - 1, [V(IDX0, True)])]))
     if rec is None:
         for j in range(4):
             add(O.SEL_ALL, [(1, [V(END), V(FOLD + j)]), (P - 1, [V(END), V((0 if transcript else 4 * R) + j, public=True)])])
@@ -161,6 +165,8 @@ def trace(view, log_rows=None, wired=False, rec=False, pt=0, inject=None):
         tcol = []
         for l in range(R):
             row = t[q * R + l]
+            if inject is not None:
+                row[inj_cols(R)[1] + 1] = index
             if inject is not None and l in inject[q]:
                 INJ, INJF = inj_cols(R)
                 row[INJ:INJ + 4], row[INJF] = inject[q][l], 1

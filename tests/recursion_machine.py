@@ -1389,12 +1389,12 @@ def rowsum_main(sh, ws, pws, log_rows):
 # (Az - Yz) / (x_h - zeta) + (An - Yn) / (x_h - zeta g_h).  The fold chain sends (layer's name, index at that layer, XS, what it takes in
 # there): its first row the value it starts from, a later row what joins its folded value -- both must be this row's reduced opening.
 Q_PRE = 12
-QP_ACT, QP_KEY, QP_KAH, QP_KYH, QP_KZH, QP_TOP, QP_QNS, QP_QN, QP_NQI = range(9)
+QP_ACT, QP_KEY, QP_KAH, QP_KYH, QP_KZH, QP_TOP, QP_QNS, QP_QN, QP_NQI, QP_LOW, QP_NQ = range(11)      # LOW: a height below the tallest; NQ: the row continues its query
 
 
 def query_cols():
     m = Cols(Q_PRE)
-    m("IDX", 1), m("XQ", 1)
+    m("IDX", 1), m("XQ", 1), m("IDX0", 1), m("PAD", 1)
     for name in ("RO", "AZ", "AN", "YZ", "YN", "ZETA", "ZNX", "I1", "I2", "P1", "P2"):
         m(name)
     return m
@@ -1413,6 +1413,9 @@ def query_program(sh):
     cons.ext(O.SEL_ALL, esub(ev(m["P1"]), emul(esub(ev(m["AZ"]), ev(m["YZ"])), ev(m["I1"]))))
     cons.ext(O.SEL_ALL, esub(ev(m["P2"]), emul(esub(ev(m["AN"]), ev(m["YN"])), ev(m["I2"]))))
     cons.ext(O.SEL_ALL, esub(ev(m["RO"]), eadd(ev(m["P1"]), ev(m["P2"]))))
+    # the rows of a query carry its index: what the fold chain hands a LOWER height is named by the query (two heights of two queries cannot be exchanged)
+    cons.add(O.SEL_ALL, pmul(pv(QP_TOP), padd(pv(m["IDX0"]), pneg(pv(m["IDX"])))))
+    cons.add(O.SEL_TRANSITION, pmul(pv(QP_NQ, True), padd(pv(m["IDX0"], True), pneg(pv(m["IDX0"])))))
     return O.air_program(Q_PRE + Q_MAIN, sh.NP * sh.NPUB, cons.c)
 
 
@@ -1420,7 +1423,8 @@ def query_table():
     m = query_cols()
     return O.interaction_table([
         (RECV, QP_TOP, F.BUS_I, [QP_QNS, m["IDX"]]),
-        (RECV, QP_ACT, F.BUS_Q, [QP_KEY, m["IDX"], m["XQ"]] + _e4(m["RO"])),
+        (RECV, QP_TOP, F.BUS_Q, [QP_KEY, m["IDX"], m["XQ"]] + _e4(m["RO"])),
+        (RECV, QP_LOW, F.BUS_Q, [QP_KEY, m["IDX0"], m["IDX"], m["XQ"]] + _e4(m["RO"])),
         (RECV, QP_ACT, BUS_AH0, [QP_KAH] + _e4(m["AZ"])), (RECV, QP_ACT, BUS_AH1, [QP_KAH] + _e4(m["AN"])),
         (RECV, QP_ACT, BUS_YH0, [QP_KYH] + _e4(m["YZ"])), (RECV, QP_ACT, BUS_YH1, [QP_KYH] + _e4(m["YN"])),
         (RECV, QP_ACT, BUS_ZH0, [QP_KZH] + _e4(m["ZETA"])), (RECV, QP_ACT, BUS_ZH1, [QP_KZH] + _e4(m["ZNX"])),
@@ -1436,7 +1440,7 @@ def query_pre(sh, log_rows):
     for i, (p, q, h) in enumerate(query_rows(sh)):
         r = t[i]
         r[QP_ACT], r[QP_KEY], r[QP_KAH], r[QP_KYH], r[QP_KZH] = 1, p * sh.NTREES + (sh.H - h), ah_key(sh, p, q, h), p * 32 + h, p * 32 + h
-        r[QP_TOP], r[QP_QNS] = int(h == sh.H), p * sh.Q + q
+        r[QP_TOP], r[QP_QNS], r[QP_LOW], r[QP_NQ] = int(h == sh.H), p * sh.Q + q, int(h != sh.H), int(h != sh.H)
         r[QP_QN], r[QP_NQI] = (p * sh.Q + q) * 32 + h, sum(1 for tr in sh.trees if sh.tree_hs[tr][0] == h)
     return t
 
@@ -1458,7 +1462,7 @@ def query_main(sh, ws, scs, ahs, yhs, log_rows):
         p1, p2 = ext_mul(e_sub(az, yz), i1), ext_mul(e_sub(an, yn), i2)
         ro = e_add(p1, p2)
         assert ro == list(qv["roh"][h]), "a height's reduced opening is not the verifier's"
-        r[m["IDX"] - Q_PRE], r[m["XQ"] - Q_PRE] = ic, xq
+        r[m["IDX"] - Q_PRE], r[m["XQ"] - Q_PRE], r[m["IDX0"] - Q_PRE] = ic, xq, qv["index"]
         for name, val in (("RO", ro), ("AZ", az), ("AN", an), ("YZ", yz), ("YN", yn), ("ZETA", zeta), ("ZNX", znx), ("I1", i1), ("I2", i2), ("P1", p1), ("P2", p2)):
             r[m[name] - Q_PRE:m[name] - Q_PRE + 4] = val
     return t.astype(np.uint32)
@@ -1473,7 +1477,7 @@ def inject_layers(sh):
 def fold_table(sh):
     INJ, INJF = F.inj_cols(sh.R)
     t = [(SEND, F.ACTIVE, F.BUS_E0, [F.LNX, F.K2] + _e4(F.E0)), (SEND, F.ACTIVE, F.BUS_E1, [F.LNX, F.K2] + _e4(F.E1)),
-         (SEND, F.L_REC, F.BUS_Q, [F.PT, F.IDX, F.XS] + _e4(F.OWN)), (SEND, INJF, F.BUS_Q, [F.LNX, F.IDX, F.XS] + _e4(INJ)),
+         (SEND, F.L_REC, F.BUS_Q, [F.PT, F.IDX, F.XS] + _e4(F.OWN)), (SEND, INJF, F.BUS_Q, [F.LNX, INJF + 1, F.IDX, F.XS] + _e4(INJ)),
          (RECV, F.ACTIVE, BUS_BETA, [F.LNX] + _e4(F.BETA)), (SEND, F.L_REC + sh.R - 1, BUS_FIN, [F.PT] + _e4(F.FOLD))]
     return O.interaction_table(t)
 

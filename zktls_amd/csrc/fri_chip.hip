@@ -172,6 +172,9 @@ std::vector<uint32_t> build_program(int RL, bool wired, bool transcript = false,
         for (int l : *inject) f.push_back(Term{P - 1, {var(L + (uint32_t)l)}});
         b.add(ALL, f);
         for (uint32_t j = 0; j < 4; j++) b.add(ALL, Terms{{1u, {var(INJ + j)}}, {P - 1, {var(INJF), var(INJ + j)}}});
+        const uint32_t IDX0 = INJF + 1;     // the query's index, constant along its chain: what joins is named by the query it joins
+        b.add(ALL, Terms{{1u, {var(L), var(IDX0)}}, {P - 1, {var(L), var(IDX)}}});
+        b.add(TRANSITION, gated(Terms{{1u, {var(IDX0)}}, {P - 1, {var(IDX0, true)}}}));
     }
     if (!rec) for (uint32_t j = 0; j < 4; j++) b.add(ALL, Terms{{1u, {var(END), var(FOLD + j)}}, {P - 1, {var(END), pub((transcript ? 0u : 4u * (uint32_t)RL) + j)}}});
     if (wired) {

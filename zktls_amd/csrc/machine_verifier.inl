@@ -845,8 +845,8 @@ void rowsum_pre(const MShape& sh, int log_rows, std::vector<uint32_t>& t) {
 }
 
 // ============================================================================================================ QUERY
-constexpr uint32_t Q_PRE = 12, QP_ACT = 0, QP_KEY = 1, QP_KAH = 2, QP_KYH = 3, QP_KZH = 4, QP_TOP = 5, QP_QNS = 6, QP_QN = 7, QP_NQI = 8;
-constexpr uint32_t QM_IDX = Q_PRE, QM_XQ = Q_PRE + 1, QM_RO = Q_PRE + 2, QM_AZ = QM_RO + 4, QM_AN = QM_AZ + 4, QM_YZ = QM_AN + 4, QM_YN = QM_YZ + 4, QM_ZETA = QM_YN + 4, QM_ZNX = QM_ZETA + 4,
+constexpr uint32_t Q_PRE = 12, QP_ACT = 0, QP_KEY = 1, QP_KAH = 2, QP_KYH = 3, QP_KZH = 4, QP_TOP = 5, QP_QNS = 6, QP_QN = 7, QP_NQI = 8, QP_LOW = 9, QP_NQ = 10;
+constexpr uint32_t QM_IDX = Q_PRE, QM_XQ = Q_PRE + 1, QM_IDX0 = Q_PRE + 2, QM_RO = Q_PRE + 4, QM_AZ = QM_RO + 4, QM_AN = QM_AZ + 4, QM_YZ = QM_AN + 4, QM_YN = QM_YZ + 4, QM_ZETA = QM_YN + 4, QM_ZNX = QM_ZETA + 4,
                    QM_I1 = QM_ZNX + 4, QM_I2 = QM_I1 + 4, QM_P1 = QM_I2 + 4, QM_P2 = QM_P1 + 4, QM_END = QM_P2 + 4;
 constexpr uint32_t Q_MAIN = ((QM_END - Q_PRE) + 3u) & ~3u;
 std::vector<uint32_t> query_program(const MShape& sh) {
@@ -857,12 +857,16 @@ std::vector<uint32_t> query_program(const MShape& sh) {
     c.ext(ALL, esub(ev(QM_P1), emul(esub(ev(QM_AZ), ev(QM_YZ)), ev(QM_I1))));
     c.ext(ALL, esub(ev(QM_P2), emul(esub(ev(QM_AN), ev(QM_YN)), ev(QM_I2))));
     c.ext(ALL, esub(ev(QM_RO), eadd(ev(QM_P1), ev(QM_P2))));
+    // the rows of a query carry its index: what the fold chain hands a LOWER height is named by the query (two heights of two queries cannot be exchanged)
+    c.add(ALL, pmul(pv(QP_TOP), padd(pv(QM_IDX0), pneg(pv(QM_IDX)))));
+    c.add(TRANSITION, pmul(pv(QP_NQ, true), padd(pv(QM_IDX0, true), pneg(pv(QM_IDX0)))));
     return c.program(Q_PRE + Q_MAIN, sh.npub_total());
 }
 std::vector<uint32_t> query_table() {
     Tab t;
     t.add(RECV, QP_TOP, BUS_I, {QP_QNS, QM_IDX});
-    t.add(RECV, QP_ACT, BUS_Q, {QP_KEY, QM_IDX, QM_XQ, QM_RO, QM_RO + 1, QM_RO + 2, QM_RO + 3});
+    t.add(RECV, QP_TOP, BUS_Q, {QP_KEY, QM_IDX, QM_XQ, QM_RO, QM_RO + 1, QM_RO + 2, QM_RO + 3});
+    t.add(RECV, QP_LOW, BUS_Q, {QP_KEY, QM_IDX0, QM_IDX, QM_XQ, QM_RO, QM_RO + 1, QM_RO + 2, QM_RO + 3});
     t.add5(RECV, QP_ACT, BUS_AH0, QP_KAH, QM_AZ); t.add5(RECV, QP_ACT, BUS_AH1, QP_KAH, QM_AN);
     t.add5(RECV, QP_ACT, BUS_YH0, QP_KYH, QM_YZ); t.add5(RECV, QP_ACT, BUS_YH1, QP_KYH, QM_YN);
     t.add5(RECV, QP_ACT, BUS_ZH0, QP_KZH, QM_ZETA); t.add5(RECV, QP_ACT, BUS_ZH1, QP_KZH, QM_ZNX);
@@ -877,7 +881,7 @@ void query_pre(const MShape& sh, int log_rows, std::vector<uint32_t>& t) {
             for (int h : sh.hs) {
                 uint32_t* r = t.data() + (size_t)Q_PRE * i++;
                 r[QP_ACT] = 1; r[QP_KEY] = (uint32_t)p * sh.NTREES + (uint32_t)(sh.H - h); r[QP_KAH] = sh.ah_key(p, q, h); r[QP_KYH] = (uint32_t)(p * 32 + h); r[QP_KZH] = (uint32_t)(p * 32 + h);
-                r[QP_TOP] = h == sh.H; r[QP_QNS] = (uint32_t)(p * sh.Q + q); r[QP_QN] = (uint32_t)((p * sh.Q + q) * 32 + h);
+                r[QP_TOP] = h == sh.H; r[QP_LOW] = h != sh.H; r[QP_NQ] = h != sh.H; r[QP_QNS] = (uint32_t)(p * sh.Q + q); r[QP_QN] = (uint32_t)((p * sh.Q + q) * 32 + h);
                 uint32_t nqi = 0;
                 for (int tr = 0; tr < N_TREES; tr++) if (sh.has_tree[tr] && sh.tree_hs[tr][0] == h) nqi++;
                 r[QP_NQI] = nqi;
@@ -892,7 +896,7 @@ std::vector<uint32_t> fold_table(const MShape& sh) {
     const uint32_t INJ = width_of(sh.R, true, true), INJF = INJ + 4;
     Tab t;
     t.add(SEND, ACTIVE, BUS_E0, {LNX, K2, E0, E0 + 1, E0 + 2, E0 + 3}); t.add(SEND, ACTIVE, BUS_E1, {LNX, K2, E1, E1 + 1, E1 + 2, E1 + 3});
-    t.add(SEND, L_REC, BUS_Q, {frichip::PT, IDX, XS, OWN, OWN + 1, OWN + 2, OWN + 3}); t.add(SEND, INJF, BUS_Q, {LNX, IDX, XS, INJ, INJ + 1, INJ + 2, INJ + 3});
+    t.add(SEND, L_REC, BUS_Q, {frichip::PT, IDX, XS, OWN, OWN + 1, OWN + 2, OWN + 3}); t.add(SEND, INJF, BUS_Q, {LNX, INJF + 1, IDX, XS, INJ, INJ + 1, INJ + 2, INJ + 3});
     t.add5(RECV, ACTIVE, BUS_BETA, LNX, BETA);
     t.add5(SEND, L_REC + (uint32_t)sh.R - 1u, BUS_FIN, frichip::PT, FOLD);
     return t.w;
@@ -1320,7 +1324,7 @@ int fill_proof(const Machine& m, int p, const uint8_t* inner, size_t inner_len, 
                 const Ext i1 = ext_inv(ext_sub(x, zeta)), i2 = ext_inv(ext_sub(x, znx));
                 const Ext p1 = ext_mul(ext_sub(az, yz), i1), p2 = ext_mul(ext_sub(an, yn), i2), ro = ext_add(p1, p2);
                 wt.roh[(size_t)q * 32 + (size_t)h] = ro;
-                r[QM_IDX - Q_PRE] = to_monty(ic); r[QM_XQ - Q_PRE] = xq;
+                r[QM_IDX - Q_PRE] = to_monty(ic); r[QM_XQ - Q_PRE] = xq; r[QM_IDX0 - Q_PRE] = to_monty(wt.indices[(size_t)q]);
                 auto put = [&](uint32_t col, const Ext& e) { put_ext(r, col - Q_PRE, e); };
                 put(QM_RO, ro); put(QM_AZ, az); put(QM_AN, an); put(QM_YZ, yz); put(QM_YN, yn); put(QM_ZETA, zeta); put(QM_ZNX, znx); put(QM_I1, i1); put(QM_I2, i2); put(QM_P1, p1); put(QM_P2, p2);
             }
@@ -1342,6 +1346,7 @@ int fill_proof(const Machine& m, int p, const uint8_t* inner, size_t inner_len, 
             size_t fat = qp[(size_t)q].fri;
             for (int l = 0; l < R; l++) {
                 uint32_t* row = ht.fold.data() + (size_t)FW * (((size_t)p * (size_t)Q + (size_t)q) * (size_t)R + (size_t)l);
+                row[INJF + 1] = to_monty(wt.indices[(size_t)q]);
                 const int hh = H - l;
                 if (l > 0 && hh != H) {
                     bool inj = false;
