@@ -784,6 +784,18 @@ def main():
                     "join_bytes_total": int(sum(x.size for x in joins4)), "bytes": int(top.size), "compression": round(sum(x.size for x in tsps) / top.size, 2),
                     "host_verify_ms_with_the_key_derived_on_the_host": round(t_tv * 1e3, 2), "verified": bool(ok_tree),
                     "verifier_inputs": "the join machine's description (a function of the shard shape), 64 x %d public values, the key; no byte of a shard proof or of a join" % len(spv[0])}
+            # the same top with ITS proof in SP1's compress shape (blowup 4, 50 queries): what leaves the tree is half the size
+            from zktls_amd._lib import Params as _P2
+            cprm2 = _P2(2, 50, 16)
+            tkey3 = ctx.machine_verifier_setup(im_, cprm2, 4)
+            ctx.prove_machine_verifier(tkey3, im_, joins4, jp, cprm2)
+            tb0 = time.perf_counter()
+            ctop = ctx.prove_machine_verifier(tkey3, im_, joins4, jp, cprm2)
+            t_ctop = time.perf_counter() - tb0
+            ok_ctop = verify_machine_recursive(im_, ctop, [v for p_ in jp for v in p_], tkey3.root, cprm2, 4) == (0, 0)
+            tree["top_in_sp1_compress_shape"] = {"outer_params": "log_blowup 2, 50 queries, 16 PoW bits", "top_ms": round(t_ctop * 1e3, 2), "bytes": int(ctop.size),
+                                                 "compression": round(sum(x.size for x in tsps) / ctop.size, 2), "verified": bool(ok_ctop)}
+            tkey3.close()
             tkey1.close(), tkey2.close()
         recursion16 = {"join16": join16, "tree": tree, "tree_ms": tree["ms"] if tree else None, "tree_bytes": tree["bytes"] if tree else None, "fri_only_workload": "the FRI check of 16 shard proofs (2^%d x %d, 100 queries x %d layers each) proven in-circuit: Poseidon2 chip (Merkle paths + transcript) + FRI-fold chip + SAMPLES chip + two tables per proof, one zkhip_prove_fri_indices_batch call, shard proofs in as bytes (host view included)" % (log_n, width, log_n),
                        "fri_only_ms": round(t_rec * 1e3, 2), "fri_only_proof_bytes": int(rec[0][0].size), "fri_only_all_verified": bool(ok_rec),

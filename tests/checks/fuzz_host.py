@@ -138,8 +138,28 @@ L.zkhip_shard_verifier_proof_size.restype = C.c_size_t
 L.zkhip_shard_verifier_describe.restype = C.c_size_t
 r_desc = np.zeros(1 << 16, dtype=np.uint32)
 
+# machine mode: the byte machine's keyed proof as the inner proof -- the host side of zkhip_prove_machine_verifier (its tables ARE the inner proof's
+# verification: zkhip_machine_verifier_host_tables) with malformed proofs, and descriptions with hostile numbers
+from zktls_amd.device import InnerMachine, machine_verifier_host_tables
+m_chips = [dict(ln=kln[c_], W=kws[c_], Pw=kpw[c_], prog=kp[c_], tab=ktab[c_]) for c_ in range(len(kt))]
+m_im = InnerMachine(m_chips, [int(x) for x in kroot], 4, 3, len(kpub))
+assert machine_verifier_host_tables(m_im, [arr(p_keyed)], [kpub], 1) is not None
+L.zkhip_machine_verifier_proof_size.restype = C.c_size_t
+
 t0, n = time.time(), 0
 while time.time() - t0 < budget:
+    machine_verifier_host_tables(m_im, [arr(mutate(p_keyed))], [kpub if rng.random() < 0.7 else [int(rng.integers(0, 2**32))]], int(rng.choice([0, 1, 5, 9])))
+    h_chips = [dict(c_) for c_ in m_chips]
+    hc = h_chips[int(rng.integers(0, len(h_chips)))]
+    which_ = int(rng.integers(0, 5))
+    if which_ == 0: hc["ln"] = int(rng.choice([4, 5, 21, 22, 31, -1]))
+    elif which_ == 1: hc["W"] = int(rng.choice([0, 2, 4, 1024, 1028, 2**31]))
+    elif which_ == 2: hc["Pw"] = int(rng.choice([0, 2, 4, 1020, 1024, 2**31]))
+    elif which_ == 3: hc["prog"] = words(mutate(np.asarray(hc["prog"], dtype=np.uint32).tobytes()))
+    else: hc["tab"] = words(mutate(np.asarray(hc["tab"], dtype=np.uint32).tobytes()))
+    h_im = InnerMachine(h_chips, [int(x) for x in rng.integers(0, 2**32, 8, dtype=np.uint64)], int(rng.choice([4, 0, 1024, 1025, -1])), int(rng.choice([3, 28, 29, -1])), int(rng.choice([len(kpub), 0, 4096, 4097])))
+    L.zkhip_machine_verifier_proof_size(C.byref(h_im.desc), int(rng.choice([1, 2, 64, 65, 0])), C.byref(prm))
+    machine_verifier_host_tables(h_im, [arr(p_keyed)], [[1] * h_im.n_public if h_im.n_public <= 8 else kpub], 0) if h_im.n_public in (len(kpub),) else None
     verify_shard_recursive(arr(mutate(p_rec)), int(rng.choice([_kat["log_n"], _kat["log_n"], 2, 22, 23, -1])), int(rng.choice([_kat["width"], _kat["width"], 4, 1024, 2**31])),
                            int(rng.choice([g_Q, g_Q, 1, 1024, 2**20])), int(rng.choice([_kat["shape"][2], 0, 30, 31])), _kat["public"] if rng.random() < 0.7 else [int(x) for x in rng.integers(0, 2**32, int(rng.integers(0, 70)))],
                            r_root if rng.random() < 0.7 else rng.integers(0, 2**32, 8, dtype=np.uint64).astype(np.uint32), prm, n_proofs=int(rng.choice([1, 1, 2, 64, 65, 0])))
@@ -188,4 +208,4 @@ while time.time() - t0 < budget:
     L.zkhip_chips_proof_from_bincode(cb.ctypes.data_as(u8p), cb.size, back2.ctypes.data_as(u8p), int(rng.choice([back2.size, 64, 0])), C.byref(got),
                                      pub2.ctypes.data_as(u32p), int(rng.choice([8, 0])), C.byref(got2))
     n += 1
-print("fuzz ok: %d rounds of 22 malformed calls in %.0f s (no crash; run under the sanitizer build for out-of-bounds reads)" % (n, time.time() - t0))
+print("fuzz ok: %d rounds of 25 malformed calls in %.0f s (no crash; run under the sanitizer build for out-of-bounds reads)" % (n, time.time() - t0))

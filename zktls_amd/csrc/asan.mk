@@ -4,7 +4,9 @@ include Makefile
 SAN = -fsanitize=address
 ASAN_OUT ?= ../libzkhip_asan.so
 HOST_SRCS = $(filter %.cpp,$(SRCS))
-ASAN_OBJS = $(patsubst %,build/asan/%.o,$(HOST_SRCS)) $(patsubst %,build/%.o,$(filter %.hip,$(SRCS)))
+# .hip files with host-side verifiers and witness builders: device code as shipped, host code sanitized (-Xarch_host)
+HOSTY_HIP = fri_chip.hip sha256_chip.hip hal.hip
+ASAN_OBJS = $(patsubst %,build/asan/%.o,$(HOST_SRCS) $(HOSTY_HIP)) $(patsubst %,build/%.o,$(filter-out $(HOSTY_HIP),$(filter %.hip,$(SRCS))))
 asan: $(ASAN_OUT)
 $(ASAN_OUT): $(ASAN_OBJS)
 	$(HIPCC) --offload-arch=$(ARCH) -shared -fPIC $(SAN) -o $@ $(ASAN_OBJS)
@@ -14,4 +16,7 @@ build/asan/p2_x16.cpp.o: p2_x16.cpp $(HDRS)
 build/asan/%.cpp.o: %.cpp $(HDRS)
 	@mkdir -p build/asan
 	$(HIPCC) -O1 -g -std=c++17 -fPIC --offload-arch=$(ARCH) -Wall -Wno-unused-function -Wno-option-ignored $(SAN) -fno-omit-frame-pointer -x hip -c $< -o $@
+build/asan/%.hip.o: %.hip $(HDRS)
+	@mkdir -p build/asan
+	$(HIPCC) -O1 -g -std=c++17 -fPIC --offload-arch=$(ARCH) -Wall -Wno-unused-function -Wno-option-ignored -Xarch_host $(SAN) -fno-omit-frame-pointer -c $< -o $@
 .PHONY: asan

@@ -1031,6 +1031,9 @@ def verify_sha256_compressed(proof, digest, message_len, chain, log_blocks_per_s
     ch = np.ascontiguousarray(chain, dtype=np.uint32)
     k = np.ascontiguousarray(np.array(vk, dtype=np.uint32))
     reason = C.c_int(0)
+    # the C entry reads 8 (n_shards + 1) chain words, n_shards following from the length: another number of shards is another statement
+    if ch.size != 8 * (_lib.load().zkhip_sha256_sharded_count(message_len, log_blocks_per_shard) + 1):
+        return -6, 1                                               # ZKHIP_ERR_VERIFY
     rc = _lib.load().zkhip_verify_sha256_compressed(pr.ctypes.data_as(u8p), pr.size, dg.ctypes.data_as(u8p), message_len, ch.ctypes.data_as(u32p), log_blocks_per_shard,
                                                     k.ctypes.data_as(u32p), C.byref(inner), C.byref(outer), C.byref(reason))
     return rc, reason.value
