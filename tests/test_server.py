@@ -74,6 +74,11 @@ def prove_payload(log_n, width, shards, queries, pow_bits, cbor, elf, backend=0,
             + struct.pack("<I", len(cbor)) + cbor + struct.pack("<I", len(elf)) + elf)
 
 
+def compress_payload(log_n, width, shards, queries, pow_bits, cbor, elf, blob, device=0, per_join=0):
+    return (b"ZKMC" + struct.pack("<IiIIiiiI", 1, log_n, width, shards, queries, pow_bits, device, per_join)
+            + struct.pack("<I", len(cbor)) + cbor + struct.pack("<I", len(elf)) + elf + struct.pack("<I", len(blob)) + blob)
+
+
 def test_routing_framing_and_twirp_errors(server):
     from zktls_amd import _lib
     port = server
@@ -93,8 +98,13 @@ def test_routing_framing_and_twirp_errors(server):
                                (dict(method="Ready", body=b"", verb="GET"), 404, "bad_route"),
                                (dict(method="Ready", body=b"{}", ctype="application/json"), 404, "bad_route"),
                                (dict(method="Ready", body=b"", path="/other/Ready"), 404, "bad_route"),
-                               (dict(method="Compress", body=pb_bytes(b"x")), 501, "unimplemented"),
+                               (dict(method="Shrink", body=pb_bytes(b"x")), 501, "unimplemented"),
                                (dict(method="Wrap", body=pb_bytes(b"x")), 501, "unimplemented"),
+                               (dict(method="Compress", body=pb_bytes(b"x")), 400, "invalid_argument"),
+                               (dict(method="Compress", body=pb_bytes(compress_payload(6, 8, 2, 10, 4, b"in", b"elf", b"blob")[:-1])), 400, "invalid_argument"),
+                               (dict(method="Compress", body=pb_bytes(compress_payload(6, 8, 0, 10, 4, b"in", b"elf", b"blob"))), 400, "invalid_argument"),
+                               (dict(method="Compress", body=pb_bytes(compress_payload(6, 8, 2, 10, 4, b"in", b"elf", b"blob", per_join=5000))), 400, "invalid_argument"),
+                               (dict(method="Compress", body=pb_bytes(compress_payload(40, 8, 2, 10, 4, b"in", b"elf", b"blob"))), 400, "invalid_argument"),
                                (dict(method="Setup", body=b"\x0a\x05ab"), 400, "malformed"),
                                (dict(method="Setup", body=pb_bytes(b"")), 400, "invalid_argument"),
                                (dict(method="ProveCore", body=pb_bytes(b"not a payload")), 400, "invalid_argument"),
@@ -105,6 +115,11 @@ def test_routing_framing_and_twirp_errors(server):
     if _lib.device_count() == 0:
         st, ct, body = call(port, "ProveCore", pb_bytes(prove_payload(6, 8, 2, 10, 4, b"input", b"elf")))
         assert st == 503 and json.loads(body)["code"] == "unavailable" and "no CPU fallback" in json.loads(body)["msg"]
+        st, ct, body = call(port, "Compress", pb_bytes(compress_payload(6, 8, 2, 10, 4, b"input", b"elf", b"blob")))
+        assert st == 503 and json.loads(body)["code"] == "unavailable" and "no CPU fallback" in json.loads(body)["msg"]
+    else:
+        st, ct, body = call(port, "Compress", pb_bytes(compress_payload(6, 8, 2, 10, 4, b"input", b"elf", b"not a batch blob")))
+        assert st == 400 and json.loads(body)["code"] == "invalid_argument" and "batch blob" in json.loads(body)["msg"]
 
 
 def test_plan_from_the_wire_is_bounded_before_anything_is_sized_by_it(server):
@@ -199,15 +214,17 @@ def test_prove_core_input_commitment_guest(server):
     assert verify_sha256(np.frombuffer(blob[20:20 + ln], dtype=np.uint8), output, Params(1, 16, 5), len(cbor)) == (0, 0)
 
 
-def prove_payload_v2(shards, queries, pow_bits, cbor, elf, flags, backend=0, device=0):
-    return (b"ZKMG" + struct.pack("<IiIIiiIiI", 2, 0, 0, shards, queries, pow_bits, backend, device, flags)
+def prove_payload_v2(shards, queries, pow_bits, cbor, elf, flags, backend=0, device=0, log_n=0, width=0):
+    return (b"ZKMG" + struct.pack("<IiIIiiIiI", 2, log_n, width, shards, queries, pow_bits, backend, device, flags)
             + struct.pack("<I", len(cbor)) + cbor + struct.pack("<I", len(elf)) + elf)
 
 
 def test_prove_core_v2_argument_checks(server):
     for payload in (prove_payload_v2(1, 10, 4, b"in", b"elf", 1),            # KEYED with shards > 0
                     prove_payload_v2(0, 10, 4, b"in", b"elf", 1, backend=1),   # KEYED in the RISC Zero shape
-                    prove_payload_v2(0, 10, 4, b"in", b"elf", 2)):             # unknown flag
+                    prove_payload_v2(0, 10, 4, b"in", b"elf", 3),              # KEYED and COMPRESS together
+                    prove_payload_v2(2, 10, 4, b"in", b"elf", 2, backend=1, log_n=8, width=8),   # COMPRESS in the RISC Zero shape
+                    prove_payload_v2(0, 10, 4, b"in", b"elf", 4)):             # unknown flag
         st, ct, body = call(server, "ProveCore", pb_bytes(payload))
         assert st == 400 and json.loads(body)["code"] == "invalid_argument"
 
@@ -237,3 +254,53 @@ def test_prove_core_keyed_commitment_guest(server):
     res = pb_field1(body)
     on = struct.unpack_from("<I", res)[0]
     assert st == 200 and struct.unpack_from("<I", res, 4 + on)[0] == 0 and struct.unpack_from("<4I", res, 8 + on) == (0x42544B5A, 2, 2, 2)
+
+
+@pytest.mark.gpu
+def test_compress_is_a_step_of_its_own_and_a_flag_of_prove_core(server):
+    """sp1-cuda's prove_core -> compress pair (behind sp1.rs:116): ProveCore returns the shard proofs, Compress takes that blob and returns ONE proof
+    that verifies them in-circuit -- the same bytes ProveCore returns with the COMPRESS flag; with two shard proofs per join the five shards take three
+    joins and ONE proof above them (the tree).  A verifier with no device checks either blob from (plan, input, ELF, key derived on the host)."""
+    import ctypes as C
+    L = C.CDLL(os.path.join(ROOT, "zktls_amd", "libzktls_guest_prover.so"))
+
+    class Plan(C.Structure):
+        _fields_ = [("log_n", C.c_int32), ("width", C.c_uint32), ("shards", C.c_uint32), ("num_queries", C.c_int32), ("pow_bits", C.c_int32)]
+    L.zktls_verify_compressed_blob.argtypes = [C.c_char_p, C.c_size_t, C.POINTER(Plan), C.c_char_p, C.c_size_t, C.c_char_p, C.c_size_t, C.POINTER(C.c_uint32), C.POINTER(C.c_int)]
+    L.zktls_compress_key_host.argtypes = [C.POINTER(Plan), C.POINTER(C.c_uint32), C.c_char_p, C.c_size_t]
+    L.zktls_set_compress_join_size.argtypes = [C.c_uint32]
+    L.zktls_batch_flags.argtypes = [C.c_char_p, C.c_size_t]
+    cbor, elf = b"\xa1transcript" * 9, b"\x7fELFguest"
+    shape = (8, 8, 5, 4, 2)
+    st, ct, body = call(server, "ProveCore", pb_bytes(prove_payload(*shape, cbor, elf)))
+    assert st == 200, body
+    res = pb_field1(body)
+    on = struct.unpack_from("<I", res)[0]
+    core = res[4 + on:]
+    plan, key, err, reason = Plan(*shape), (C.c_uint32 * 8)(), C.create_string_buffer(512), C.c_int(0)
+    for per_join, flags in ((0, 1 | 16), (2, 1 | 16 | 32)):
+        st, ct, body = call(server, "Compress", pb_bytes(compress_payload(*shape, cbor, elf, core, per_join=per_join)))
+        assert st == 200, body
+        blob = pb_field1(body)
+        assert L.zktls_batch_flags(blob, len(blob)) == flags and len(blob) < len(core)
+        L.zktls_set_compress_join_size(per_join)
+        try:
+            assert L.zktls_compress_key_host(C.byref(plan), key, err, 512) == 0, err.value
+            assert L.zktls_verify_compressed_blob(blob, len(blob), C.byref(plan), cbor, len(cbor), elf, len(elf), key, C.byref(reason)) == 0
+            assert L.zktls_verify_compressed_blob(blob, len(blob), C.byref(plan), cbor + b"!", len(cbor) + 1, elf, len(elf), key, C.byref(reason)) == -2
+        finally:
+            L.zktls_set_compress_join_size(0)
+        if per_join == 0:
+            st, ct, body = call(server, "ProveCore", pb_bytes(prove_payload_v2(shape[2], shape[3], shape[4], cbor, elf, 2, log_n=shape[0], width=shape[1])))
+            assert st == 200, body
+            res2 = pb_field1(body)
+            on2 = struct.unpack_from("<I", res2)[0]
+            assert struct.unpack_from("<I", res2, 4 + on2)[0] == 0 and res2[8 + on2:] == blob          # (version 2: an empty vk, then the blob)
+    # another request's shard proofs do not compress under this one: the machine's tables are the verification
+    st, ct, body = call(server, "Compress", pb_bytes(compress_payload(*shape, cbor + b"!", elf, core)))
+    assert st == 400 and json.loads(body)["code"] == "invalid_argument", body
+    # ... nor does a blob with a shard missing
+    st, ct, body = call(server, "Compress", pb_bytes(compress_payload(8, 8, 4, 4, 2, cbor, elf, core)))
+    assert st == 400 and json.loads(body)["code"] == "invalid_argument"
+    st, _, _ = call(server, "Ready", b"")
+    assert st == 200

@@ -195,6 +195,92 @@ struct JoinMachine {
 std::atomic<uint32_t> g_join_size{0};
 }  // namespace
 
+// core -> COMPRESS (sp1.rs:116; sp1-cuda's prove_core -> compress): `proofs` = the plan's shard proofs, public values request digest | shard index
+static std::vector<uint8_t> compress_shard_proofs(int device, const ShardPlan& plan, const zkhip_params& prm, const std::vector<uint32_t>& digest,
+                                                  const std::vector<std::vector<uint8_t>>& proofs) {
+    // core -> COMPRESS: the shard proofs verified in-circuit by ONE proof (the shard verifier machine, csrc/shard_verifier.inl); the blob then
+    // carries that proof and the key of the shape instead of the shard proofs
+    // more shards than one join holds: several joins of ONE shape (compress_join_size: the last one repeats the execution's last shard proof, so that
+    // every join has the same key); the blob carries them in shard order
+    const uint32_t J = compress_join_size(plan), n_joins = (plan.shards + J - 1) / J;
+    const zkhip_params outer{1, plan.num_queries, plan.pow_bits, 0, 0, 0, 0, 0};
+    JoinGuard jg{JoinKey{device, plan.log_n, plan.width, plan.num_queries, plan.pow_bits, J, nullptr, nullptr, {0}, zkhip_poseidon2_params_generation()}};
+    JoinKey& jk = jg.jk;
+    if (!take_join_key(device, plan, J, &jk)) {
+        if (zkhip_ctx_create(device, nullptr, &jk.ctx) != ZKHIP_OK) { jk.ctx = nullptr; fail_zkhip("zkhip_ctx_create"); }
+        if (zkhip_shard_verifier_setup(jk.ctx, plan.log_n, plan.width, (size_t)plan.num_queries, plan.pow_bits, 9, J, &outer, &jk.key, jk.vk) != ZKHIP_OK)
+            throw std::runtime_error(std::string("zkhip_shard_verifier_setup: ") + zkhip_last_error());
+    }
+    zkhip_ctx* const jctx = jk.ctx;
+    zkhip_machine_key* key = jk.key;
+    uint32_t vk[8];
+    std::memcpy(vk, jk.vk, sizeof vk);
+    const size_t jcap = zkhip_shard_verifier_proof_size(plan.log_n, plan.width, (size_t)plan.num_queries, plan.pow_bits, 9, J, &outer);
+    std::vector<std::vector<uint8_t>> entries;
+    for (uint32_t c = 0; c < n_joins; c++) {
+        std::vector<const uint8_t*> ptrs(J);
+        std::vector<size_t> lens(J);
+        std::vector<uint32_t> pvs;
+        for (uint32_t k = 0; k < J; k++) {
+            const uint32_t sidx = c * J + k < plan.shards ? c * J + k : plan.shards - 1;
+            ptrs[k] = proofs[sidx].data(); lens[k] = proofs[sidx].size();
+            pvs.insert(pvs.end(), digest.begin(), digest.end());
+            pvs.push_back(sidx);
+        }
+        std::vector<uint8_t> joined(jcap);
+        size_t jlen = 0;
+        const int rc = zkhip_prove_shard_verifier(jctx, key, ptrs.data(), lens.data(), J, plan.log_n, plan.width, pvs.data(), 9, &prm, &outer, joined.data(), jcap, &jlen);
+        if (rc != ZKHIP_OK) throw std::runtime_error(std::string("zkhip_prove_shard_verifier: ") + zkhip_last_error());
+        joined.resize(jlen);
+        int reason = 0;
+        if (zkhip_verify_shard_recursive(joined.data(), jlen, plan.log_n, plan.width, (size_t)plan.num_queries, plan.pow_bits, pvs.data(), 9, J, vk, &outer, &reason) != ZKHIP_OK) {
+            throw std::runtime_error(std::string("zkhip_verify_shard_recursive: ") + zkhip_last_error());     // sp1.rs:120: the prover checks its own proof
+        }
+        entries.push_back(std::move(joined));
+    }
+    uint32_t flags_extra = 0;
+    JoinMachine jm;
+    // (a top the machine refuses -- thousands of public values per join: its transcript table runs out of columns -- leaves the joins side by side)
+    if (n_joins > 1 && jm.build(plan, J, vk) && zkhip_machine_verifier_proof_size(&jm.desc, n_joins, &outer) != 0) {
+        // THE TREE: the joins themselves are verified in-circuit by ONE proof (machine mode: csrc/machine_verifier.inl) -- the blob carries that
+        // proof alone; its key is a function of (the join machine, the number of joins) and is derived by whoever checks the blob
+        struct KeyGuard { zkhip_machine_key* k = nullptr; zkhip_ctx* c = nullptr; ~KeyGuard() { if (k) { (void)zkhip_ctx_sync(c); zkhip_machine_key_destroy(k); } } } tk;
+        tk.c = jctx;
+        uint32_t tvk[8];
+        if (zkhip_machine_verifier_setup(jctx, &jm.desc, n_joins, &outer, &tk.k, tvk) != ZKHIP_OK) throw std::runtime_error(std::string("zkhip_machine_verifier_setup: ") + zkhip_last_error());
+        const size_t tcap = zkhip_machine_verifier_proof_size(&jm.desc, n_joins, &outer);
+        std::vector<uint8_t> top(tcap);
+        std::vector<const uint8_t*> ptrs(n_joins);
+        std::vector<size_t> lens(n_joins);
+        std::vector<uint32_t> pvs;
+        for (uint32_t c = 0; c < n_joins; c++) {
+            ptrs[c] = entries[c].data(); lens[c] = entries[c].size();
+            for (uint32_t k = 0; k < J; k++) {
+                const uint32_t sidx = c * J + k < plan.shards ? c * J + k : plan.shards - 1;
+                pvs.insert(pvs.end(), digest.begin(), digest.end());
+                pvs.push_back(sidx);
+            }
+        }
+        size_t tlen = 0;
+        if (zkhip_prove_machine_verifier(jctx, tk.k, &jm.desc, ptrs.data(), lens.data(), n_joins, pvs.data(), 9u * J, &outer, top.data(), tcap, &tlen) != ZKHIP_OK)
+            throw std::runtime_error(std::string("zkhip_prove_machine_verifier: ") + zkhip_last_error());
+        top.resize(tlen);
+        int reason = 0;
+        if (zkhip_verify_machine_recursive(&jm.desc, top.data(), tlen, pvs.data(), 9u * J, n_joins, tvk, &outer, &reason) != ZKHIP_OK)
+            throw std::runtime_error(std::string("zkhip_verify_machine_recursive: ") + zkhip_last_error());
+        entries.clear();
+        entries.push_back(std::move(top));
+        flags_extra = BATCH_FLAG_TREE;
+    }
+    jg.done = true;                                  // (only after every join went through: every other way out destroys the pair -- JoinGuard)
+    std::vector<uint8_t> tail(36);
+    std::memcpy(tail.data(), vk, 32);
+    const uint32_t cnt = plan.shards;
+    std::memcpy(tail.data() + 32, &cnt, 4);
+    entries.push_back(tail);
+    return pack_shard_proofs(entries, BATCH_FLAG_SYNTHETIC | BATCH_FLAG_COMPRESSED | flags_extra);
+}
+
 ProveResult HipGuestProver::prove(const GuestInput& input, const std::vector<uint8_t>& guest_program) {
     if (backend_ == Backend::Risc0) set_env_r0(mode_);   // prover.rs:65
     else set_env(mode_);                              // sp1.rs:72
@@ -544,88 +630,8 @@ ProveResult HipGuestProver::prove_inner(const GuestInput& input, const std::vect
     }
     if (failed.load()) throw std::runtime_error(first_error);
     if (compress_) {
-        // core -> COMPRESS: the shard proofs verified in-circuit by ONE proof (the shard verifier machine, csrc/shard_verifier.inl); the blob then
-        // carries that proof and the key of the shape instead of the shard proofs
         if (backend_ != Backend::Sp1) throw std::runtime_error("with_compress: the shard verifier takes SP1-shape shard proofs");
-        // more shards than one join holds: several joins of ONE shape (compress_join_size: the last one repeats the execution's last shard proof, so that
-        // every join has the same key); the blob carries them in shard order
-        const uint32_t J = compress_join_size(plan_), n_joins = (plan_.shards + J - 1) / J;
-        const zkhip_params outer{1, plan_.num_queries, plan_.pow_bits, 0, 0, 0, 0, 0};
-        JoinGuard jg{JoinKey{devices_[0], plan_.log_n, plan_.width, plan_.num_queries, plan_.pow_bits, J, nullptr, nullptr, {0}, zkhip_poseidon2_params_generation()}};
-        JoinKey& jk = jg.jk;
-        if (!take_join_key(devices_[0], plan_, J, &jk)) {
-            if (zkhip_ctx_create(devices_[0], nullptr, &jk.ctx) != ZKHIP_OK) { jk.ctx = nullptr; fail_zkhip("zkhip_ctx_create"); }
-            if (zkhip_shard_verifier_setup(jk.ctx, plan_.log_n, plan_.width, (size_t)plan_.num_queries, plan_.pow_bits, 9, J, &outer, &jk.key, jk.vk) != ZKHIP_OK)
-                throw std::runtime_error(std::string("zkhip_shard_verifier_setup: ") + zkhip_last_error());
-        }
-        zkhip_ctx* const jctx = jk.ctx;
-        zkhip_machine_key* key = jk.key;
-        uint32_t vk[8];
-        std::memcpy(vk, jk.vk, sizeof vk);
-        const size_t jcap = zkhip_shard_verifier_proof_size(plan_.log_n, plan_.width, (size_t)plan_.num_queries, plan_.pow_bits, 9, J, &outer);
-        std::vector<std::vector<uint8_t>> entries;
-        for (uint32_t c = 0; c < n_joins; c++) {
-            std::vector<const uint8_t*> ptrs(J);
-            std::vector<size_t> lens(J);
-            std::vector<uint32_t> pvs;
-            for (uint32_t k = 0; k < J; k++) {
-                const uint32_t sidx = c * J + k < plan_.shards ? c * J + k : plan_.shards - 1;
-                ptrs[k] = proofs[sidx].data(); lens[k] = proofs[sidx].size();
-                pvs.insert(pvs.end(), digest.begin(), digest.end());
-                pvs.push_back(sidx);
-            }
-            std::vector<uint8_t> joined(jcap);
-            size_t jlen = 0;
-            const int rc = zkhip_prove_shard_verifier(jctx, key, ptrs.data(), lens.data(), J, plan_.log_n, plan_.width, pvs.data(), 9, &prm, &outer, joined.data(), jcap, &jlen);
-            if (rc != ZKHIP_OK) throw std::runtime_error(std::string("zkhip_prove_shard_verifier: ") + zkhip_last_error());
-            joined.resize(jlen);
-            int reason = 0;
-            if (zkhip_verify_shard_recursive(joined.data(), jlen, plan_.log_n, plan_.width, (size_t)plan_.num_queries, plan_.pow_bits, pvs.data(), 9, J, vk, &outer, &reason) != ZKHIP_OK) {
-                throw std::runtime_error(std::string("zkhip_verify_shard_recursive: ") + zkhip_last_error());     // sp1.rs:120: the prover checks its own proof
-            }
-            entries.push_back(std::move(joined));
-        }
-        uint32_t flags_extra = 0;
-        JoinMachine jm;
-        // (a top the machine refuses -- thousands of public values per join: its transcript table runs out of columns -- leaves the joins side by side)
-        if (n_joins > 1 && jm.build(plan_, J, vk) && zkhip_machine_verifier_proof_size(&jm.desc, n_joins, &outer) != 0) {
-            // THE TREE: the joins themselves are verified in-circuit by ONE proof (machine mode: csrc/machine_verifier.inl) -- the blob carries that
-            // proof alone; its key is a function of (the join machine, the number of joins) and is derived by whoever checks the blob
-            struct KeyGuard { zkhip_machine_key* k = nullptr; zkhip_ctx* c = nullptr; ~KeyGuard() { if (k) { (void)zkhip_ctx_sync(c); zkhip_machine_key_destroy(k); } } } tk;
-            tk.c = jctx;
-            uint32_t tvk[8];
-            if (zkhip_machine_verifier_setup(jctx, &jm.desc, n_joins, &outer, &tk.k, tvk) != ZKHIP_OK) throw std::runtime_error(std::string("zkhip_machine_verifier_setup: ") + zkhip_last_error());
-            const size_t tcap = zkhip_machine_verifier_proof_size(&jm.desc, n_joins, &outer);
-            std::vector<uint8_t> top(tcap);
-            std::vector<const uint8_t*> ptrs(n_joins);
-            std::vector<size_t> lens(n_joins);
-            std::vector<uint32_t> pvs;
-            for (uint32_t c = 0; c < n_joins; c++) {
-                ptrs[c] = entries[c].data(); lens[c] = entries[c].size();
-                for (uint32_t k = 0; k < J; k++) {
-                    const uint32_t sidx = c * J + k < plan_.shards ? c * J + k : plan_.shards - 1;
-                    pvs.insert(pvs.end(), digest.begin(), digest.end());
-                    pvs.push_back(sidx);
-                }
-            }
-            size_t tlen = 0;
-            if (zkhip_prove_machine_verifier(jctx, tk.k, &jm.desc, ptrs.data(), lens.data(), n_joins, pvs.data(), 9u * J, &outer, top.data(), tcap, &tlen) != ZKHIP_OK)
-                throw std::runtime_error(std::string("zkhip_prove_machine_verifier: ") + zkhip_last_error());
-            top.resize(tlen);
-            int reason = 0;
-            if (zkhip_verify_machine_recursive(&jm.desc, top.data(), tlen, pvs.data(), 9u * J, n_joins, tvk, &outer, &reason) != ZKHIP_OK)
-                throw std::runtime_error(std::string("zkhip_verify_machine_recursive: ") + zkhip_last_error());
-            entries.clear();
-            entries.push_back(std::move(top));
-            flags_extra = BATCH_FLAG_TREE;
-        }
-        jg.done = true;                                  // (only after every join went through: every other way out destroys the pair -- JoinGuard)
-        std::vector<uint8_t> tail(36);
-        std::memcpy(tail.data(), vk, 32);
-        const uint32_t cnt = plan_.shards;
-        std::memcpy(tail.data() + 32, &cnt, 4);
-        entries.push_back(tail);
-        r.proof = pack_shard_proofs(entries, BATCH_FLAG_SYNTHETIC | BATCH_FLAG_COMPRESSED | flags_extra);
+        r.proof = compress_shard_proofs(devices_[0], plan_, prm, digest, proofs);
         r.ok = true;
         return r;
     }
@@ -714,6 +720,33 @@ bool compress_key_host(const ShardPlan& plan, uint32_t key_out[8], std::string* 
     return ok;
 }
 
+// core -> compress as a step of its own (sp1-cuda's prove_core / compress pair behind sp1.rs:116): the SYNTHETIC batch blob prove() returned for
+// (plan, input, ELF) -> the COMPRESSED blob with_compress() would have returned.  Every shard proof is verified on the way: the machine's tables
+// ARE the verification, a proof that does not verify has no witness.
+ProveResult compress_blob(int device, const ShardPlan& plan, const std::vector<uint8_t>& cbor, const std::vector<uint8_t>& elf, const std::vector<uint8_t>& blob) {
+    ProveResult r;
+    try {
+        std::vector<std::vector<uint8_t>> proofs;
+        uint32_t flags = 0;
+        if (!unpack_shard_proofs(blob, &proofs, &flags)) throw std::runtime_error("compress: not a batch blob");
+        if (flags != BATCH_FLAG_SYNTHETIC) throw std::runtime_error("compress: the blob must hold SP1-shape shard proofs of a synthetic plan (flags = SYNTHETIC)");
+        if (plan.shards == 0 || proofs.size() != plan.shards) throw std::runtime_error("compress: the blob does not hold the plan's number of shard proofs");
+        const zkhip_params prm{1, plan.num_queries, plan.pow_bits, 0, 0, 0, 0, 0};
+        const std::vector<uint32_t> digest = request_digest(cbor, elf);
+        r.output.resize(32);
+        std::memcpy(r.output.data(), digest.data(), 32);
+        r.proof = compress_shard_proofs(device, plan, prm, digest, proofs);
+        r.ok = true;
+    } catch (const std::exception& e) {
+        r = ProveResult{};
+        r.error = e.what();
+    } catch (...) {
+        r = ProveResult{};
+        r.error = "unknown failure in compress_blob";
+    }
+    return r;
+}
+
 void release_cached() {
     std::vector<Slot> all;
     { std::lock_guard<std::mutex> lk(g_slots_mu); all.swap(g_slots); }
@@ -773,6 +806,20 @@ static int guest_prove(zktls::Backend backend, int device, int mode, const zktls
     *output_len = r.output.size();
     *output = (uint8_t*)std::malloc(r.output.size() ? r.output.size() : 1);
     std::memcpy(*output, r.output.data(), r.output.size());
+    *proof_len = r.proof.size();
+    *proof = (uint8_t*)std::malloc(r.proof.size() ? r.proof.size() : 1);
+    std::memcpy(*proof, r.proof.data(), r.proof.size());
+    return 0;
+}
+// compress as its own step: the batch blob of zktls_guest_prove (mode 2, the same plan / input / ELF) -> the compressed blob (malloc'd, zktls_free)
+int zktls_compress_blob(int device, const zktls_shard_plan* plan, const uint8_t* cbor, size_t cbor_len, const uint8_t* elf, size_t elf_len,
+                        const uint8_t* blob, size_t blob_len, uint8_t** proof, size_t* proof_len, char* err, size_t err_cap) {
+    if (!plan || !blob || !proof || !proof_len) { if (err && err_cap) { std::strncpy(err, "compress: null argument", err_cap - 1); err[err_cap - 1] = 0; } return -1; }
+    zktls::ShardPlan sp;
+    sp.log_n = plan->log_n; sp.width = plan->width; sp.shards = plan->shards; sp.num_queries = plan->num_queries; sp.pow_bits = plan->pow_bits;
+    const zktls::ProveResult r = zktls::compress_blob(device < 0 ? 0 : device, sp, std::vector<uint8_t>(cbor, cbor + cbor_len), std::vector<uint8_t>(elf, elf + elf_len),
+                                                      std::vector<uint8_t>(blob, blob + blob_len));
+    if (!r.ok) { if (err && err_cap) { std::strncpy(err, r.error.c_str(), err_cap - 1); err[err_cap - 1] = 0; } return -1; }
     *proof_len = r.proof.size();
     *proof = (uint8_t*)std::malloc(r.proof.size() ? r.proof.size() : 1);
     std::memcpy(*proof, r.proof.data(), r.proof.size());

@@ -168,6 +168,9 @@ int verify_commitment_blob(const std::vector<uint8_t>& blob, const std::vector<u
 // key) / -2 (the joined proof is rejected; *reason = the failing check)
 int verify_compressed_blob(const std::vector<uint8_t>& blob, const ShardPlan& plan, const std::vector<uint8_t>& cbor, const std::vector<uint8_t>& elf,
                            const uint32_t key[8], int* reason = nullptr);
+// core -> compress as a step of its own (sp1-cuda's prove_core / compress pair behind sp1.rs:116): the SYNTHETIC batch blob prove() returned for
+// (plan, input, ELF) -> the COMPRESSED (| TREE) blob with_compress() would have returned; verify_compressed_blob checks it the same way
+ProveResult compress_blob(int device, const ShardPlan& plan, const std::vector<uint8_t>& cbor, const std::vector<uint8_t>& elf, const std::vector<uint8_t>& blob);
 // the key of the shard-verifier machine for `plan` (zkhip_shard_verifier_setup on `device`)
 bool compress_key(int device, const ShardPlan& plan, uint32_t key[8], std::string* error = nullptr);
 // the same key computed on the host's cores (no device, no context): a verifier that owns no GPU checks a compressed blob with this and verify_compressed_blob

@@ -22,7 +22,14 @@
 //                  version 2 = version 1 + u32 flags after `device` (bit 0 KEYED: shards must be 0; the mirror's setup() runs first -- the
 //                         reference's setup -> prove -> verify, sp1.rs:113-120 -- and the commitment guest is proven as the keyed SHA-256
 //                         machine)       -> result = u32 output length | output | u32 vk length | vk (64 bytes, or 0) | batch blob
-//       Compress / Shrink / Wrap                             -> Twirp error `unimplemented` (recursion is out of scope)
+//                         bit 1 COMPRESS (version 2): core -> compress behind the one call (HipGuestProver::with_compress, sp1.rs:116): the blob
+//                         carries ONE proof that verifies the shard proofs in-circuit -- flags COMPRESSED (| TREE when the joins were joined again)
+//       Compress   data = "ZKMC" u32 version(1) | i32 log_n | u32 width | u32 shards | i32 num_queries | i32 pow_bits | i32 device (-1: the first) |
+//                         u32 shard proofs per join (0: as many as one join holds; fewer: several joins and ONE proof above them, the tree) |
+//                         u32 cbor_len | cbor | u32 elf_len | elf | u32 blob_len | the batch blob ProveCore returned for that plan, input and ELF
+//                                                            -> result = the compressed batch blob (zktls::compress_blob): sp1-cuda's compress step
+//                                                               as its own call; zktls_verify_compressed_blob checks it from (plan, input, ELF, key)
+//       Shrink / Wrap                                        -> Twirp error `unimplemented` (the BN254 wrap + Groth16 stages are out of scope)
 //     Swapping in upstream's payload structs is the remaining work once they can be read; the transport does not change.
 // One request at a time per connection, connections served one after the other (proofs serialise on the GPU anyway); 127.0.0.1 only
 // unless --bind is given.  No TLS, no auth: it is meant to sit next to the client like the container it replaces.
@@ -173,8 +180,9 @@ struct Cursor {
 };
 
 void handle(int fd) {
-    // a request carries one CBOR input and one ELF (tens of KB to a few MB): 64 MiB is generous
-    const Request rq = read_request(fd, (size_t)64 << 20);
+    // a request carries one CBOR input and one ELF (tens of KB to a few MB) and, for Compress, a batch of shard proofs (64 of the headline
+    // shape are 61 MB): 256 MiB is generous, and the body buffer grows only with bytes that arrive
+    const Request rq = read_request(fd, (size_t)256 << 20);
     if (!rq.ok) { twirp_error(fd, "malformed", "could not read an HTTP request"); return; }
     const std::string prefix = "/twirp/api.ProverService/";
     if (rq.method != "POST") { twirp_error(fd, "bad_route", "unsupported method " + rq.method + " (only POST is allowed)"); return; }
@@ -187,8 +195,8 @@ void handle(int fd) {
         else respond(fd, 200, "OK", "application/protobuf", nullptr, 0);        // proto3: false is the empty message
         return;
     }
-    if (method == "Compress" || method == "Shrink" || method == "Wrap") { twirp_error(fd, "unimplemented", method + ": recursion / wrapping is not part of the shard-prove hot path"); return; }
-    if (method != "Setup" && method != "ProveCore") { twirp_error(fd, "bad_route", "no handler for path " + rq.path); return; }
+    if (method == "Shrink" || method == "Wrap") { twirp_error(fd, "unimplemented", method + ": the BN254 wrap and Groth16 stages are not part of the shard-prove hot path"); return; }
+    if (method != "Setup" && method != "ProveCore" && method != "Compress") { twirp_error(fd, "bad_route", "no handler for path " + rq.path); return; }
     std::vector<uint8_t> data;
     if (!pb_get_bytes1(rq.body, &data)) { twirp_error(fd, "malformed", "the request is not a protobuf message with a bytes field 1"); return; }
     if (method == "Setup") {
@@ -201,7 +209,43 @@ void handle(int fd) {
         respond(fd, 200, "OK", "application/protobuf", msg.data(), msg.size());
         return;
     }
+    // the plan comes from an unauthenticated peer: bound every field before anything is sized by it (advice r2: shards = 2^32 - 1
+    // value-initialised ~100 GB of proof slots).  Ranges are the library's own (include/zkhip.h) with a batch cap on top.
+    auto bad_plan = [](const zktls::ShardPlan& plan, int device) -> std::string {
+        const int ndev = zkhip_device_count();
+        if (plan.shards > 4096u) return "shards must be in [0, 4096]";
+        if (plan.shards != 0 && (plan.log_n < 5 || plan.log_n > 22)) return "log_n must be in [5, 22]";
+        if (plan.shards != 0 && (plan.width < 4u || plan.width > 1024u)) return "width must be in [4, 1024]";
+        if (plan.num_queries < 1 || plan.num_queries > 256) return "num_queries must be in [1, 256]";
+        if (plan.pow_bits < 0 || plan.pow_bits > 24) return "pow_bits must be in [0, 24]";
+        if (device < -1 || device >= (ndev > 0 ? ndev : 1)) return "device must be -1 (every GPU) or a visible device ordinal";
+        if (plan.shards != 0 && ((uint64_t)plan.shards << plan.log_n) * plan.width > ((uint64_t)1 << 36)) return "the batch exceeds 2^36 trace cells";
+        return "";
+    };
+    auto unavailable = [](const std::string& e) { return e.find("no CPU fallback") != std::string::npos || e.find("NO_DEVICE") != std::string::npos || e.find("no device") != std::string::npos; };
     Cursor c{data};
+    if (method == "Compress") {
+        const uint32_t magic = c.u32(), version = c.u32();
+        if (magic != 0x434D4B5Au || version != 1u) { twirp_error(fd, "invalid_argument", "Compress: payload must start with \"ZKMC\", version 1 (see moongate_hip.cpp)"); return; }
+        zktls::ShardPlan plan;
+        plan.log_n = (int)c.u32(); plan.width = c.u32(); plan.shards = c.u32(); plan.num_queries = (int)c.u32(); plan.pow_bits = (int)c.u32();
+        const int device = (int)c.u32();
+        const uint32_t per_join = c.u32();
+        const std::vector<uint8_t> cbor = c.blob(), elf = c.blob(), blob = c.blob();
+        if (!c.ok || c.p != data.size()) { twirp_error(fd, "invalid_argument", "Compress: truncated or oversized payload"); return; }
+        std::string bad = bad_plan(plan, device);
+        if (bad.empty() && plan.shards == 0) bad = "shards must be at least 1";
+        if (bad.empty() && per_join > 4096u) bad = "shard proofs per join must be in [0, 4096]";
+        if (!bad.empty()) { twirp_error(fd, "invalid_argument", "Compress: " + bad); return; }
+        if (zkhip_device_count() <= 0) { twirp_error(fd, "unavailable", "Compress: no device (there is no CPU fallback)"); return; }
+        zktls::set_compress_join_size(per_join);                                           // (process-wide, one request at a time: part of the plan)
+        const zktls::ProveResult r = zktls::compress_blob(device < 0 ? 0 : device, plan, cbor, elf, blob);
+        zktls::set_compress_join_size(0);
+        if (!r.ok) { twirp_error(fd, unavailable(r.error) ? "unavailable" : "invalid_argument", r.error); return; }
+        const std::vector<uint8_t> msg = pb_bytes1(r.proof);
+        respond(fd, 200, "OK", "application/protobuf", msg.data(), msg.size());
+        return;
+    }
     const uint32_t magic = c.u32(), version = c.u32();
     if (magic != 0x474D4B5Au || (version != 1u && version != 2u)) { twirp_error(fd, "invalid_argument", "ProveCore: payload must start with \"ZKMG\", version 1 or 2 (see moongate_hip.cpp)"); return; }
     zktls::ShardPlan plan;
@@ -212,26 +256,19 @@ void handle(int fd) {
     zktls::GuestInput in;
     in.cbor = c.blob();
     const std::vector<uint8_t> elf = c.blob();
-    if (!c.ok || c.p != data.size() || backend > 1 || flags > 1) { twirp_error(fd, "invalid_argument", "ProveCore: truncated or oversized payload"); return; }
-    // the plan comes from an unauthenticated peer: bound every field before anything is sized by it (advice r2: shards = 2^32 - 1
-    // value-initialised ~100 GB of proof slots).  Ranges are the library's own (include/zkhip.h) with a batch cap on top.
+    if (!c.ok || c.p != data.size() || backend > 1 || flags > 3) { twirp_error(fd, "invalid_argument", "ProveCore: truncated or oversized payload"); return; }
     {
-        const int ndev = zkhip_device_count();
-        std::string bad;
-        if (plan.shards > 4096u) bad = "shards must be in [0, 4096]";
-        else if (plan.shards != 0 && (plan.log_n < 5 || plan.log_n > 22)) bad = "log_n must be in [5, 22]";
-        else if (plan.shards != 0 && (plan.width < 4u || plan.width > 1024u)) bad = "width must be in [4, 1024]";
-        else if (plan.num_queries < 1 || plan.num_queries > 256) bad = "num_queries must be in [1, 256]";
-        else if (plan.pow_bits < 0 || plan.pow_bits > 24) bad = "pow_bits must be in [0, 24]";
-        else if (device < -1 || device >= (ndev > 0 ? ndev : 1)) bad = "device must be -1 (every GPU) or a visible device ordinal";
-        else if (plan.shards != 0 && ((uint64_t)plan.shards << plan.log_n) * plan.width > ((uint64_t)1 << 36)) bad = "the batch exceeds 2^36 trace cells";
+        const std::string bad = bad_plan(plan, device);
         if (!bad.empty()) { twirp_error(fd, "invalid_argument", "ProveCore: " + bad); return; }
     }
     if ((flags & 1u) && (plan.shards != 0 || backend != 0)) { twirp_error(fd, "invalid_argument", "ProveCore: KEYED asks for the input-commitment guest (shards = 0) in the SP1 shape"); return; }
     zktls::HipGuestProver prover(device < 0 ? 0 : device, backend ? zktls::Backend::Risc0 : zktls::Backend::Sp1);
     if (device < 0) { std::vector<int> all; for (int d = 0; d < zkhip_device_count(); d++) all.push_back(d); if (!all.empty()) prover.with_devices(all); }
+    if ((flags & 2u) && backend != 0) { twirp_error(fd, "invalid_argument", "ProveCore: COMPRESS takes SP1-shape shard proofs"); return; }
+    if ((flags & 3u) == 3u) { twirp_error(fd, "invalid_argument", "ProveCore: KEYED and COMPRESS do not combine"); return; }
     if (plan.shards == 0) prover.hip().with_input_commitment(plan);
     else prover.hip().with_synthetic(plan);
+    if (flags & 2u) prover.with_compress();
     if (flags & 1u) {
         const zktls::SetupResult s = prover.setup(elf);                                // sp1.rs:113
         if (!s.ok) {
