@@ -754,7 +754,7 @@ def main():
         # in-circuit (zkhip_prove_machine_verifier: ten chips; the join machine's own description is the inner machine)
         tree = None
         if log_n == 20 and width == 256:
-            from zktls_amd.device import InnerMachine, machine_verifier_key_host, shard_verifier_describe, verify_machine_recursive
+            from zktls_amd.device import InnerMachine, machine_verifier_key_host, prove_shard_verifier_batch, shard_verifier_describe, verify_machine_recursive
             tkey1 = ctx.shard_verifier_setup(log_n, width, prm.num_queries, prm.pow_bits, len(spv[0]), prm, n_proofs=16)
             tsps, tspv = list(sps), list(spv)
             for i in range(16, 64):
@@ -771,7 +771,7 @@ def main():
             jp = [[v for pv_ in tspv[16 * j:16 * j + 16] for v in pv_] for j in range(4)]
             for _ in range(3):
                 tb0 = time.perf_counter()
-                joins4 = [ctx.prove_shard_verifier(tkey1, tsps[16 * j:16 * j + 16], log_n, width, tspv[16 * j:16 * j + 16], prm, prm) for j in range(4)]
+                joins4, jvk = prove_shard_verifier_batch(tsps, 16, log_n, width, tspv, prm, prm, devices=[local_rank], in_flight=4)
                 tb1 = time.perf_counter()
                 top = ctx.prove_machine_verifier(tkey2, im_, joins4, jp, prm)
                 tb2 = time.perf_counter()
@@ -779,7 +779,8 @@ def main():
             tb0 = time.perf_counter()
             ok_tree = verify_machine_recursive(im_, top, [v for p_ in jp for v in p_], machine_verifier_key_host(im_, prm, 4), prm, 4) == (0, 0)
             t_tv = time.perf_counter() - tb0
-            tree = {"workload": "64 shard proofs (2^20 x 256, 100 queries) -> 4 joins of 16 (zkhip_prove_shard_verifier) -> ONE proof (zkhip_prove_machine_verifier: the four joins' version-11 proofs verified in-circuit, ten chips)",
+            assert jvk.tolist() == tkey1.root.tolist()
+            tree = {"workload": "64 shard proofs (2^20 x 256, 100 queries) -> 4 joins of 16 (zkhip_prove_shard_verifier_batch: the four in flight on pooled contexts, as the shards below them are) -> ONE proof (zkhip_prove_machine_verifier: the four joins' version-11 proofs verified in-circuit, ten chips)",
                     "joins_ms": round(t_joins * 1e3, 2), "top_ms": round(t_top * 1e3, 2), "ms": round((t_joins + t_top) * 1e3, 2), "inner_bytes_total": int(sum(x.size for x in tsps)),
                     "join_bytes_total": int(sum(x.size for x in joins4)), "bytes": int(top.size), "compression": round(sum(x.size for x in tsps) / top.size, 2),
                     "host_verify_ms_with_the_key_derived_on_the_host": round(t_tv * 1e3, 2), "verified": bool(ok_tree),

@@ -859,6 +859,20 @@ size_t zkhip_shard_verifier_max_proofs(int log_n, uint32_t width, size_t n_queri
 int zkhip_prove_shard_verifier(zkhip_ctx* ctx, const zkhip_machine_key* key, const uint8_t* const* shard_proofs, const size_t* shard_proof_lens, size_t n_proofs, int log_n,
                                uint32_t width, const uint32_t* public_values, size_t n_public, const zkhip_params* inner, const zkhip_params* outer, uint8_t* proof, size_t cap,
                                size_t* len);
+/* The compress stage over several joins and several GPUs (sp1.rs:116: the recursion tree's first level; prover.rs:90: lift -> join): n_proofs /
+ * proofs_per_join joins of ONE shape, hence one key.  Join j verifies the shard proofs [j J, (j + 1) J) with their public values and is proven on
+ * devices[j mod n_devices] (devices NULL / n_devices 0: every visible device), in_flight_per_device at a time on each (0: four) -- the joins are
+ * independent units like the shards below them (no exchange step), and one join's host stretches overlap another's kernels (four joins of 16
+ * headline shard proofs on one MI355X: 129 ms one after the other, 96 with two in flight, 76 with four).  Workers run on
+ * pooled contexts (zkhip_release_cached_contexts) that keep the shape's proving key: setup once per context and shape, every context arrives
+ * at the same vk (returned).  Join j's proof: joined + j joined_stride (stride >= zkhip_shard_verifier_proof_size), joined_lens[j] bytes.
+ * verify != 0: every join is checked by zkhip_verify_shard_recursive on its worker's thread (sp1.rs:120).  n_proofs must be a multiple of
+ * proofs_per_join (a caller with a remainder repeats its last shard proof, as zktls::compress_join_size describes).  Returns the status of the
+ * lowest failing join; the proofs are the bytes zkhip_prove_shard_verifier makes. */
+int zkhip_prove_shard_verifier_batch(const int* devices, int n_devices, const uint8_t* const* shard_proofs, const size_t* shard_proof_lens, size_t n_proofs,
+                                     size_t proofs_per_join, int log_n, uint32_t width, const uint32_t* public_values, size_t n_public, const zkhip_params* inner,
+                                     const zkhip_params* outer, int in_flight_per_device, int verify, uint8_t* joined, size_t joined_stride, size_t* joined_lens,
+                                     uint32_t vk[8]);
 int zkhip_verify_shard_recursive(const uint8_t* proof, size_t len, int log_n, uint32_t width, size_t n_queries, int inner_pow_bits, const uint32_t* public_values,
                                  size_t n_public, size_t n_proofs, const uint32_t vk[8], const zkhip_params* outer, int* reason);
 size_t zkhip_shard_verifier_describe(int log_n, uint32_t width, size_t n_queries, int inner_pow_bits, size_t n_public, size_t n_proofs, int which, int kind, uint32_t* out,

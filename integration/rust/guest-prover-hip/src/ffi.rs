@@ -199,6 +199,10 @@ extern "C" {
     pub fn zkhip_prove_shard_verifier(ctx: *mut ZkhipCtx, key: *const ZkhipMachineKey, shard_proofs: *const *const u8, shard_proof_lens: *const usize, n_proofs: usize,
                                       log_n: c_int, width: u32, public_values: *const u32, n_public: usize, inner: *const ZkhipParams, outer: *const ZkhipParams,
                                       proof: *mut u8, cap: usize, len: *mut usize) -> c_int;
+    pub fn zkhip_prove_shard_verifier_batch(devices: *const c_int, n_devices: c_int, shard_proofs: *const *const u8, shard_proof_lens: *const usize, n_proofs: usize,
+                                            proofs_per_join: usize, log_n: c_int, width: u32, public_values: *const u32, n_public: usize, inner: *const ZkhipParams,
+                                            outer: *const ZkhipParams, in_flight_per_device: c_int, verify: c_int, joined: *mut u8, joined_stride: usize,
+                                            joined_lens: *mut usize, vk: *mut u32) -> c_int;
     pub fn zkhip_verify_shard_recursive(proof: *const u8, len: usize, log_n: c_int, width: u32, n_queries: usize, inner_pow_bits: c_int, public_values: *const u32,
                                         n_public: usize, n_proofs: usize, vk: *const u32, outer: *const ZkhipParams, reason: *mut c_int) -> c_int;
     pub fn zkhip_shard_verifier_describe(log_n: c_int, width: u32, n_queries: usize, inner_pow_bits: c_int, n_public: usize, n_proofs: usize, which: c_int, kind: c_int,

@@ -396,6 +396,26 @@ impl JoinMachine {
     }
 }
 
+/// The tree's first level in ONE call: `proofs.len() / j` joins of one shape, dealt over `devices` (empty: every visible one), `in_flight` at a time on
+/// each, every join checked on its worker's thread (`zkhip_prove_shard_verifier_batch`).  Returns the joins and the key of the shape.
+pub fn join_batch(devices: &[i32], proofs: &[Vec<u8>], j: usize, log_n: i32, width: u32, public_values: &[u32], n_public: usize, inner: &ZkhipParams, outer: &ZkhipParams,
+                  in_flight: i32) -> Result<(Vec<Vec<u8>>, [u32; 8])> {
+    anyhow::ensure!(j >= 1 && !proofs.is_empty() && proofs.len() % j == 0 && public_values.len() == proofs.len() * n_public, "join_batch: a multiple of j shard proofs, n_public values each");
+    let n_joins = proofs.len() / j;
+    let cap = unsafe { ffi::zkhip_shard_verifier_proof_size(log_n, width, inner.num_queries as usize, inner.pow_bits, n_public, j, outer) };
+    anyhow::ensure!(cap != 0, "join_batch: bad shape");
+    let ptrs: Vec<*const u8> = proofs.iter().map(|p| p.as_ptr()).collect();
+    let lens: Vec<usize> = proofs.iter().map(|p| p.len()).collect();
+    let mut out = vec![0u8; n_joins * cap];
+    let mut out_lens = vec![0usize; n_joins];
+    let mut vk = [0u32; 8];
+    check(unsafe {
+        ffi::zkhip_prove_shard_verifier_batch(if devices.is_empty() { std::ptr::null() } else { devices.as_ptr() }, devices.len() as i32, ptrs.as_ptr(), lens.as_ptr(), proofs.len(), j,
+                                              log_n, width, public_values.as_ptr(), n_public, inner, outer, in_flight, 1, out.as_mut_ptr(), cap, out_lens.as_mut_ptr(), vk.as_mut_ptr())
+    }, "zkhip_prove_shard_verifier_batch")?;
+    Ok(((0..n_joins).map(|c| out[c * cap..c * cap + out_lens[c]].to_vec()).collect(), vk))
+}
+
 /// THE TREE (sp1-recursion joins the joins; prover.rs:90 lift -> join): `joins` are the proofs of `compress_execution` (join size `j`, key `join_vk`);
 /// ONE proof verifies them all in-circuit (machine mode of the shard verifier machine).  Returns that proof and its key (a verifier derives the
 /// same key with `zkhip_machine_verifier_key_host`).  `public_values`: the shard proofs' in join order (`j * n_public` per join).

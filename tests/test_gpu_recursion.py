@@ -283,3 +283,36 @@ def test_air_mode_sixty_four_transcript_proofs_become_one_proof(ctx):
     assert verify_shard_recursive(outer, log_n, 640, q, pb, bad, key.root, prm, n_proofs=n, program=prog)[0] != 0
     print("64 transcript proofs: %d bytes -> %d bytes" % (total, outer.size))
     key.close()
+
+
+@pytest.mark.parametrize("in_flight", [1, 3])
+def test_a_batch_of_joins_of_one_shape_is_the_joins_one_by_one(ctx, in_flight):
+    """zkhip_prove_shard_verifier_batch: six shard proofs, two per join -> three joins dealt over pooled contexts (each makes the shape's key once
+    and keeps it): the bytes and the key are those of zkhip_shard_verifier_setup / zkhip_prove_shard_verifier; a join with a tampered shard proof
+    fails the call with the verifier's code; a second shape on the same pooled contexts gets its own key"""
+    from zktls_amd.device import prove_shard_verifier_batch
+    log_n, width, q, pb = 6, 16, 5, 2
+    iprm, prm = Params(1, q, pb), Params(1, 20, 8)
+    pubs = [[3, 4, 100 + s] for s in range(6)]
+    inner = [ctx.prove_shard(ctx.gen_trace(SEED, 20 + s, log_n, width), log_n, width, pubs[s], iprm) for s in range(6)]
+    key = ctx.shard_verifier_setup(log_n, width, q, pb, 3, prm, n_proofs=2)
+    one_by_one = [ctx.prove_shard_verifier(key, inner[2 * j:2 * j + 2], log_n, width, pubs[2 * j:2 * j + 2], iprm, prm) for j in range(3)]
+    for rep in range(2):                                                        # (the second call finds the keys with the pooled contexts)
+        joins, vk = prove_shard_verifier_batch(inner, 2, log_n, width, pubs, iprm, prm, devices=[0], in_flight=in_flight, verify=True)
+        assert vk.tolist() == key.root.tolist()
+        assert [j.tobytes() for j in joins] == [j.tobytes() for j in one_by_one]
+    for j in range(3):
+        assert verify_shard_recursive(joins[j], log_n, width, q, pb, [v for p in pubs[2 * j:2 * j + 2] for v in p], vk, prm, n_proofs=2) == (0, 0)
+    bad = [p.copy() for p in inner]
+    bad[3][bad[3].size // 2] ^= 1
+    with pytest.raises(ZkHipError) as e:
+        prove_shard_verifier_batch(bad, 2, log_n, width, pubs, iprm, prm, devices=[0], in_flight=in_flight)
+    assert e.value.code == -6
+    with pytest.raises(ZkHipError):
+        prove_shard_verifier_batch(inner[:5], 2, log_n, width, pubs[:5], iprm, prm, devices=[0])          # five proofs do not make joins of two
+    # another shape (three per join, the outer proof at blowup 4) on the same contexts: another key
+    joins3, vk3 = prove_shard_verifier_batch(inner, 3, log_n, width, pubs, iprm, Params(2, 10, 4), devices=[0], in_flight=in_flight, verify=True)
+    key3 = ctx.shard_verifier_setup(log_n, width, q, pb, 3, Params(2, 10, 4), n_proofs=3)
+    assert vk3.tolist() == key3.root.tolist() and vk3.tolist() != vk.tolist() and len(joins3) == 2
+    assert joins3[1].tobytes() == ctx.prove_shard_verifier(key3, inner[3:], log_n, width, pubs[3:], iprm, Params(2, 10, 4)).tobytes()
+    key.close(), key3.close()

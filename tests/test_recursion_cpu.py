@@ -300,3 +300,36 @@ def test_air_mode_a_sha256_proof_in_the_machine(oracle):
         rows = main if pre is None else np.concatenate([pre, main], axis=1)
         assert S.check_rows(pr, rows, pv) == [], name
     assert R.bus_balance(mains, pres, tabs) == []
+
+
+def test_the_batch_of_joins_checks_its_arguments_before_it_touches_a_device():
+    """zkhip_prove_shard_verifier_batch with no device: a count that is no multiple of the join size, a stride below the size query's answer and a
+    null pointer are ZKHIP_ERR_INVALID; a well-formed call is ZKHIP_ERR_NO_DEVICE (there is no CPU fallback)"""
+    import ctypes as C
+    from zktls_amd import _lib
+    from zktls_amd._lib import Params
+    L = _lib.load()
+    u8p = C.POINTER(C.c_uint8)
+    inner, outer = Params(1, 5, 2), Params(1, 20, 8)
+    a = np.zeros(64, dtype=np.uint8)
+    ptrs = (u8p * 4)(*[a.ctypes.data_as(u8p)] * 4)
+    lens = (C.c_size_t * 4)(*[64] * 4)
+    pv = np.arange(8, dtype=np.uint32)
+    cap = L.zkhip_shard_verifier_proof_size(6, 16, 5, 2, 2, 2, C.byref(outer))
+    assert cap > 0
+    out = np.zeros(2 * cap, dtype=np.uint8)
+    jl = (C.c_size_t * 2)()
+    vk = np.zeros(8, dtype=np.uint32)
+    u32p = C.POINTER(C.c_uint32)
+
+    def call(n=4, j=2, stride=cap, proofs=ptrs, width=16):
+        return L.zkhip_prove_shard_verifier_batch(None, 0, proofs, lens, n, j, 6, width, pv.ctypes.data_as(u32p), 2, C.byref(inner), C.byref(outer), 2, 1,
+                                                  out.ctypes.data_as(u8p), stride, jl, vk.ctypes.data_as(u32p))
+    assert call(n=3) == -1 and b"multiple" in L.zkhip_last_error()
+    assert call(j=0) == -1
+    assert call(n=0) == -1
+    assert call(stride=cap - 1) == -1 and b"stride" in L.zkhip_last_error()
+    assert call(proofs=None) == -1
+    assert call(width=12) == -1                                            # (the machine takes widths in multiples of 8: the size query refuses)
+    if _lib.device_count() == 0:
+        assert call() == -2

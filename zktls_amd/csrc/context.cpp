@@ -747,6 +747,7 @@ void zkhip_ctx_destroy(zkhip_ctx* ctx) {
     (void)hipSetDevice(ctx->device);
     if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
     if (ctx->sha_key) zkhip_machine_key_destroy(ctx->sha_key);
+    if (ctx->rec_key) zkhip_machine_key_destroy(ctx->rec_key);
     if (ctx->fri_graph_exec) (void)hipGraphExecDestroy(ctx->fri_graph_exec);
     for (NttPlan& p : ctx->plans) { if (p.pre) (void)hipFree(p.pre); if (p.post) (void)hipFree(p.post); if (p.pre_f) (void)hipFree(p.pre_f); if (p.post_f) (void)hipFree(p.post_f); }
     if (ctx->w1024f_fwd) (void)hipFree(ctx->w1024f_fwd);

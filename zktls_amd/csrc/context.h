@@ -124,6 +124,10 @@ struct zkhip_ctx {
     zkhip_machine_key* sha_key = nullptr;
     int sha_key_blowup = 0;
     uint32_t sha_vk[8] = {0};
+    // the shard verifier machine's proving key made on this context by zkhip_prove_shard_verifier_batch, with what it is a function of
+    zkhip_machine_key* rec_key = nullptr;
+    std::vector<uint64_t> rec_key_sig;
+    uint32_t rec_vk[8] = {0};
     // grow-only PINNED host block (ctx_host_pinned): work lists that a prover fills on host threads and uploads in one DMA
     void* host_pinned = nullptr;
     size_t host_pinned_bytes = 0;

@@ -1411,6 +1411,61 @@ int zkhip_prove_shard_verifier(zkhip_ctx* ctx, const zkhip_machine_key* key, con
                                size_t* len) {
     return shard_verifier_prove_impl(ctx, key, nullptr, 0, shard_proofs, shard_proof_lens, n_proofs, log_n, width, public_values, n_public, inner, outer, proof, cap, len);
 }
+// The compress stage over several joins: n_proofs / proofs_per_join joins of ONE shape (hence one key); join j verifies the shard proofs
+// [j J, (j + 1) J) and is proven on devices[j mod n_devices], `in_flight_per_device` at a time on each -- the joins are independent units like the
+// shards below them (no exchange step), and one join's host stretches (witness tables, transcript round trips) overlap another's
+// kernels.  Every worker runs on a pooled context that keeps the shape's proving key (setup once per context and shape; every context arrives at
+// the same vk).  Join j's proof goes to joined + j joined_stride (stride >= zkhip_shard_verifier_proof_size).  verify != 0: each join is checked by
+// the host verifier on its worker's thread (sp1.rs:120), beside the other workers' kernels.
+int zkhip_prove_shard_verifier_batch(const int* devices, int n_devices, const uint8_t* const* shard_proofs, const size_t* shard_proof_lens, size_t n_proofs,
+                                     size_t proofs_per_join, int log_n, uint32_t width, const uint32_t* public_values, size_t n_public, const zkhip_params* inner,
+                                     const zkhip_params* outer, int in_flight_per_device, int verify, uint8_t* joined, size_t joined_stride, size_t* joined_lens,
+                                     uint32_t vk[8]) {
+    if (!shard_proofs || !shard_proof_lens || !inner || !outer || !joined || !joined_lens || !vk || (n_public && !public_values))
+        return fail(ZKHIP_ERR_INVALID, "prove_shard_verifier_batch: null argument");
+    if (proofs_per_join == 0 || n_proofs == 0 || n_proofs % proofs_per_join != 0)
+        return fail(ZKHIP_ERR_INVALID, "prove_shard_verifier_batch: the number of shard proofs must be a positive multiple of proofs_per_join");
+    const size_t J = proofs_per_join, n_joins = n_proofs / J;
+    if (n_joins > (size_t)1 << 20) return fail(ZKHIP_ERR_INVALID, "prove_shard_verifier_batch: too many joins");
+    const size_t cap = zkhip_shard_verifier_proof_size(log_n, width, (size_t)inner->num_queries, inner->pow_bits, n_public, J, outer);
+    if (cap == 0) return ZKHIP_ERR_INVALID;                       // (the message is the size query's)
+    if (joined_stride < cap) return fail(ZKHIP_ERR_INVALID, "prove_shard_verifier_batch: joined_stride is below zkhip_shard_verifier_proof_size");
+    for (size_t j = 0; j < n_joins; j++) joined_lens[j] = 0;
+    std::vector<int> devs;
+    ZK_TRY(resolve_devices(devices, n_devices, "prove_shard_verifier_batch", devs));
+    const std::vector<uint64_t> sig = {(uint64_t)(uint32_t)log_n, width, (uint64_t)(uint32_t)inner->num_queries, (uint64_t)(uint32_t)inner->pow_bits, n_public, J,
+                                       (uint64_t)(uint32_t)outer->log_blowup, (uint64_t)(uint32_t)outer->num_queries, (uint64_t)(uint32_t)outer->pow_bits,
+                                       (uint64_t)(uint32_t)outer->log_fold, (uint64_t)(uint32_t)outer->log_final, (uint64_t)(uint32_t)outer->hash_width,
+                                       zkhip_poseidon2_params_generation()};
+    std::mutex mu;
+    bool have_vk = false;
+    std::memset(vk, 0, 32);
+    std::vector<char> ran;
+    auto run = [&](zkhip_ctx* ctx, int j) {
+        int r = ZKHIP_OK;
+        if (ctx->rec_key && ctx->rec_key_sig != sig) { (void)zkhip_ctx_sync(ctx); zkhip_machine_key_destroy(ctx->rec_key); ctx->rec_key = nullptr; }
+        if (!ctx->rec_key) {
+            r = zkhip_shard_verifier_setup(ctx, log_n, width, (size_t)inner->num_queries, inner->pow_bits, n_public, J, outer, &ctx->rec_key, ctx->rec_vk);
+            if (r == ZKHIP_OK) ctx->rec_key_sig = sig;
+            else ctx->rec_key = nullptr;
+        }
+        if (r == ZKHIP_OK) {
+            std::lock_guard<std::mutex> lk(mu);
+            if (!have_vk) { std::memcpy(vk, ctx->rec_vk, 32); have_vk = true; }
+            else if (std::memcmp(vk, ctx->rec_vk, 32) != 0) r = fail(ZKHIP_ERR_INTERNAL, "prove_shard_verifier_batch: two contexts disagree about the key of the shape");
+        }
+        size_t len = 0;
+        uint8_t* const out = joined + (size_t)j * joined_stride;
+        const uint32_t* const pv = n_public ? public_values + (size_t)j * J * n_public : nullptr;
+        if (r == ZKHIP_OK) r = zkhip_prove_shard_verifier(ctx, ctx->rec_key, shard_proofs + (size_t)j * J, shard_proof_lens + (size_t)j * J, J, log_n, width, pv, n_public,
+                                                          inner, outer, out, joined_stride, &len);
+        if (r == ZKHIP_OK && verify)
+            r = zkhip_verify_shard_recursive(out, len, log_n, width, (size_t)inner->num_queries, inner->pow_bits, pv, n_public, J, ctx->rec_vk, outer, nullptr);
+        joined_lens[(size_t)j] = r == ZKHIP_OK ? len : 0;
+        return r;
+    };
+    return deal_jobs(devs.data(), (int)devs.size(), (int)n_joins, in_flight_per_device, run, ran);          // (0: four)
+}
 // The verifier of the outer proof: the shape of the inner proofs, THEIR public values (proof 0's, then proof 1's, ...), the key of the shape.
 // No byte of an inner proof.
 int zkhip_verify_shard_recursive(const uint8_t* proof, size_t len, int log_n, uint32_t width, size_t n_queries, int inner_pow_bits, const uint32_t* public_values,

@@ -1133,6 +1133,30 @@ def prove_fri_indices_batch(shard_proofs, log_n, width, public_values, inner=Non
     return [(keep[i][2][: jobs[i].proof_len], list(jobs[i].vk), list(jobs[i].final_value), list(jobs[i].capacity)) for i in range(n)]
 
 
+def prove_shard_verifier_batch(shard_proofs, proofs_per_join, log_n, width, public_values, inner=None, outer=None, devices=None, in_flight=4, verify=False):
+    """zkhip_prove_shard_verifier_batch: len(shard_proofs) / proofs_per_join joins of one shape, dealt over `devices`, `in_flight` at a time on each
+    -> ([join proof bytes, ...], vk [8]); public_values: one list per shard proof"""
+    lib = _lib.load()
+    inner, outer = inner or Params(1, 100, 16), outer or Params(1, 100, 16)
+    sps = [np.ascontiguousarray(sp, dtype=np.uint8) for sp in shard_proofs]
+    n = len(sps)
+    pv = np.ascontiguousarray(np.array([list(v) for v in public_values], dtype=np.uint32).reshape(max(n, 1), -1))
+    n_public = pv.shape[1]
+    size = lib.zkhip_shard_verifier_proof_size(log_n, width, inner.num_queries, inner.pow_bits, n_public, proofs_per_join, C.byref(outer))
+    if size == 0:
+        check(-1)
+    n_joins = n // proofs_per_join if proofs_per_join else 0
+    buf = np.empty((max(n_joins, 1), size), dtype=np.uint8)
+    lens = (C.c_size_t * max(n_joins, 1))()
+    ptrs = (u8p * max(n, 1))(*[sp.ctypes.data_as(u8p) for sp in sps])
+    plens = (C.c_size_t * max(n, 1))(*[sp.size for sp in sps])
+    vk = np.zeros(8, dtype=np.uint32)
+    devs = (C.c_int * len(devices))(*devices) if devices else None
+    check(lib.zkhip_prove_shard_verifier_batch(devs, len(devices) if devices else 0, ptrs, plens, n, proofs_per_join, log_n, width, pv.ctypes.data_as(u32p), n_public,
+                                               C.byref(inner), C.byref(outer), in_flight, 1 if verify else 0, buf.ctypes.data_as(u8p), size, lens, vk.ctypes.data_as(u32p)))
+    return [buf[j, : lens[j]] for j in range(n_joins)], vk
+
+
 def set_lockstep(max_batch, lanes=0):
     """zkhip_set_lockstep: members per lock-step batch of small transcripts (0 / 1 = off), batches in flight per device (0 = keep)"""
     _lib.load().zkhip_set_lockstep(int(max_batch), int(lanes))

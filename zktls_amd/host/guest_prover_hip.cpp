@@ -196,8 +196,10 @@ std::atomic<uint32_t> g_join_size{0};
 }  // namespace
 
 // core -> COMPRESS (sp1.rs:116; sp1-cuda's prove_core -> compress): `proofs` = the plan's shard proofs, public values request digest | shard index
-static std::vector<uint8_t> compress_shard_proofs(int device, const ShardPlan& plan, const zkhip_params& prm, const std::vector<uint32_t>& digest,
+static std::vector<uint8_t> compress_shard_proofs(const std::vector<int>& devices, const ShardPlan& plan, const zkhip_params& prm, const std::vector<uint32_t>& digest,
                                                   const std::vector<std::vector<uint8_t>>& proofs) {
+    if (devices.empty()) throw std::runtime_error("device list is empty");
+    const int device = devices[0];
     // core -> COMPRESS: the shard proofs verified in-circuit by ONE proof (the shard verifier machine, csrc/shard_verifier.inl); the blob then
     // carries that proof and the key of the shape instead of the shard proofs
     // more shards than one join holds: several joins of ONE shape (compress_join_size: the last one repeats the execution's last shard proof, so that
@@ -217,7 +219,29 @@ static std::vector<uint8_t> compress_shard_proofs(int device, const ShardPlan& p
     std::memcpy(vk, jk.vk, sizeof vk);
     const size_t jcap = zkhip_shard_verifier_proof_size(plan.log_n, plan.width, (size_t)plan.num_queries, plan.pow_bits, 9, J, &outer);
     std::vector<std::vector<uint8_t>> entries;
-    for (uint32_t c = 0; c < n_joins; c++) {
+    if (n_joins > 1) {
+        // several joins of one shape: ONE call deals them over the prover's devices, four in flight on each (zkhip_prove_shard_verifier_batch: pooled contexts
+        // that keep the shape's key); every join is checked on its worker's thread (sp1.rs:120: the prover checks its own proof)
+        std::vector<const uint8_t*> ptrs((size_t)n_joins * J);
+        std::vector<size_t> lens((size_t)n_joins * J), jlens(n_joins);
+        std::vector<uint32_t> pvs;
+        for (uint32_t c = 0; c < n_joins; c++)
+            for (uint32_t k = 0; k < J; k++) {
+                const uint32_t sidx = c * J + k < plan.shards ? c * J + k : plan.shards - 1;
+                ptrs[(size_t)c * J + k] = proofs[sidx].data(); lens[(size_t)c * J + k] = proofs[sidx].size();
+                pvs.insert(pvs.end(), digest.begin(), digest.end());
+                pvs.push_back(sidx);
+            }
+        std::vector<uint8_t> joined((size_t)n_joins * jcap);
+        uint32_t bvk[8];
+        if (zkhip_prove_shard_verifier_batch(devices.data(), (int)devices.size(), ptrs.data(), lens.data(), (size_t)n_joins * J, J, plan.log_n, plan.width, pvs.data(), 9, &prm, &outer,
+                                             0, 1, joined.data(), jcap, jlens.data(), bvk) != ZKHIP_OK)
+            throw std::runtime_error(std::string("zkhip_prove_shard_verifier_batch: ") + zkhip_last_error());
+        if (std::memcmp(bvk, vk, 32) != 0) throw std::runtime_error("compress: the batch's key differs from the shape's");
+        for (uint32_t c = 0; c < n_joins; c++) entries.emplace_back(joined.begin() + (long)((size_t)c * jcap), joined.begin() + (long)((size_t)c * jcap + jlens[c]));
+    }
+    if (n_joins == 1) {
+        const uint32_t c = 0;
         std::vector<const uint8_t*> ptrs(J);
         std::vector<size_t> lens(J);
         std::vector<uint32_t> pvs;
@@ -631,7 +655,7 @@ ProveResult HipGuestProver::prove_inner(const GuestInput& input, const std::vect
     if (failed.load()) throw std::runtime_error(first_error);
     if (compress_) {
         if (backend_ != Backend::Sp1) throw std::runtime_error("with_compress: the shard verifier takes SP1-shape shard proofs");
-        r.proof = compress_shard_proofs(devices_[0], plan_, prm, digest, proofs);
+        r.proof = compress_shard_proofs(devices_, plan_, prm, digest, proofs);
         r.ok = true;
         return r;
     }
@@ -735,7 +759,7 @@ ProveResult compress_blob(int device, const ShardPlan& plan, const std::vector<u
         const std::vector<uint32_t> digest = request_digest(cbor, elf);
         r.output.resize(32);
         std::memcpy(r.output.data(), digest.data(), 32);
-        r.proof = compress_shard_proofs(device, plan, prm, digest, proofs);
+        r.proof = compress_shard_proofs(std::vector<int>{device}, plan, prm, digest, proofs);
         r.ok = true;
     } catch (const std::exception& e) {
         r = ProveResult{};
