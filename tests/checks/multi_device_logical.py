@@ -82,6 +82,21 @@ def main():
     assert all(d == hashlib.sha256(m).digest() for m, (d, _) in zip(msgs, res))
     assert all(verify_sha256_machine(p, d, vk, Params(1, 20, 8), len(m)) == (0, 0) for m, (d, p) in zip(msgs, res))
     out["transcripts_over_the_device_list"] = len(msgs)
+    # (7) the compress stage over the device list: joins of one shape, join j on device j mod K (every device makes the shape's key; one vk),
+    # the bytes those of one context proving them one by one
+    from zktls_amd.device import prove_shard_verifier_batch, verify_shard_recursive
+    jl, jw, iq = 6, 16, Params(1, 5, 2)
+    jpv = [[3, 4, 100 + s] for s in range(2 * (2 * K + 1))]
+    c0 = ctxs[devs[0]]
+    inner = [c0.prove_shard(c0.gen_trace(SEED, 500 + s, jl, jw), jl, jw, jpv[s], iq) for s in range(len(jpv))]
+    joins, jvk = prove_shard_verifier_batch(inner, 2, jl, jw, jpv, iq, Params(1, 20, 8), devices=devs, in_flight=2, verify=True)
+    jkey = c0.shard_verifier_setup(jl, jw, 5, 2, 3, Params(1, 20, 8), n_proofs=2)
+    assert jvk.tolist() == jkey.root.tolist() and len(joins) == 2 * K + 1
+    for j in range(len(joins)):
+        assert joins[j].tobytes() == c0.prove_shard_verifier(jkey, inner[2 * j:2 * j + 2], jl, jw, jpv[2 * j:2 * j + 2], iq, Params(1, 20, 8)).tobytes()
+        assert verify_shard_recursive(joins[j], jl, jw, 5, 2, [v for q in jpv[2 * j:2 * j + 2] for v in q], jvk, Params(1, 20, 8), n_proofs=2) == (0, 0)
+    jkey.close()
+    out["joins_over_the_device_list"] = len(joins)
     for c in ctxs.values():
         c.close()
     _lib.load().zkhip_release_cached_contexts()

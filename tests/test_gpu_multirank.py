@@ -74,7 +74,7 @@ def test_the_rank_per_gpu_line_carries_the_one_process_entry_too():
 
 def test_multi_device_entries_on_two_logical_devices():
     """tests/checks/multi_device_logical.py: device traces dealt where they live (and refused where they do not), the NULL device list, the
-    lock-step dealer, host traces and a transcript batch -- all over a device list of two, bytes against the oracle"""
+    lock-step dealer, host traces, a transcript batch and a batch of joins (the compress stage) -- all over a device list of two, bytes against the oracle"""
     env = dict(os.environ)
     env["ZKHIP_LOGICAL_DEVICES"] = "2"
     p = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "checks", "multi_device_logical.py")], env=env, cwd=ROOT, timeout=900,
@@ -82,7 +82,7 @@ def test_multi_device_entries_on_two_logical_devices():
     assert p.returncode == 0, p.stderr.decode()[-3000:]
     r = json.loads([ln for ln in p.stdout.decode().splitlines() if ln.startswith("{")][-1])
     assert r["logical_devices"] == 2 and r["device_traces_dealt_where_they_live"] == 6 and r["misplaced_trace_refused"] is True
-    assert r["null_device_list_same_bytes"] is True and r["lockstep_small_shards"] == 16 and r["host_traces"] == 5 and r["transcripts_over_the_device_list"] == 8
+    assert r["null_device_list_same_bytes"] is True and r["lockstep_small_shards"] == 16 and r["host_traces"] == 5 and r["transcripts_over_the_device_list"] == 8 and r["joins_over_the_device_list"] == 5
 
 
 def test_dry_run_of_the_eight_gpu_configuration_on_logical_devices():
