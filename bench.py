@@ -24,6 +24,7 @@ buffer placement), `valu_roofline` for the Poseidon2 leaf kernel
 timed on the host cores, bounded sample, N = 1 only).
 """
 import argparse
+import gc
 import json
 import os
 import sys
@@ -360,6 +361,12 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    # The interpreter's cyclic collector stays out of every timed region of this script (as timeit keeps it out): a full collection over
+    # torch's heap holds the GIL for tens of milliseconds, and a prover thread that finishes a shard meanwhile cannot pick up the next one --
+    # measured on one box, same library: 14.0 - 14.3 ms per step when no collection fell into the ten steps, 15 - 18 ms when one did (which
+    # of the two a run got depended on the allocation count at start-up: bytecode cache or not, one more ctypes binding or not).
+    gc.collect()
+    gc.disable()
     barrier()
     t0 = time.perf_counter()
     cpu0 = time.process_time()                          # CPU time of all threads of this rank
@@ -940,7 +947,7 @@ def main():
             "share_gpu_test_mode": bool(args.share_gpu),
             "shards_proven": K * world, "distinct_shards_proven": len(digests), "shard_digests_gathered": len(digests),
             "shard_assignment": "round-robin (zkhip_shard_device: shard s on device s mod N, inside zkhip_prove_shards_multi)" if one_proc else "round-robin (zktls_amd.shards.shard_indices)",
-            "timing_note": "ms_per_step is amortised throughput with %d shards in flight per GPU, not latency" % in_flight,
+            "timing_note": "ms_per_step is amortised throughput with %d shards in flight per GPU, not latency; the Python harness's cyclic garbage collector is off from the first timed region on (gc.disable, as timeit does)" % in_flight,
             "single_shard_latency_ms": (round(latency_ms, 3) if latency_ms is not None else None),
             "inputs": "host memory, H2D copy inside every step" if host_traces is not None else "resident in HBM",
             "config": {"workload": ("multi-chip shard (SP1's shard structure): chips %s, one commitment per phase, %d trace cells, log_blowup 1, 100 queries, 16 PoW bits, full prove_chips" % (args.chips, cells))
