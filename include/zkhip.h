@@ -930,6 +930,20 @@ int zkhip_prove_machine_verifier(zkhip_ctx* ctx, const zkhip_machine_key* key, c
                                  const uint32_t* public_values, size_t n_public, const zkhip_params* outer, uint8_t* proof, size_t cap, size_t* len);
 int zkhip_verify_machine_recursive(const zkhip_machine_desc* inner, const uint8_t* proof, size_t len, const uint32_t* public_values, size_t n_public, size_t n_proofs, const uint32_t vk[8],
                                    const zkhip_params* outer, int* reason);
+/* THE TREE in one call (sp1.rs:116: core -> compress, the recursion tree; prover.rs:90: lift -> join): the shard proofs of an execution -> n_proofs /
+ * proofs_per_join joins (as zkhip_prove_shard_verifier_batch makes them: join j on devices[j mod n_devices], in_flight_per_device at a time, pooled
+ * contexts that keep the shape's key) -> ONE proof over the joins, proven on ctx under top_key = zkhip_machine_verifier_setup(ctx, join_machine,
+ * n_joins, top_outer, ...).  join_machine describes the join machine (zkhip_shard_verifier_describe's eight chips, the join key as key_root,
+ * join_outer's queries and proof-of-work bits, proofs_per_join x n_public public values).  A join's tables for the top -- which are its verification --
+ * are filled on its worker's thread the moment the join exists, beside the joins still being proven: after the last join only the uploads and the
+ * machine's proof remain.  The joins stay with the caller (joined + j joined_stride, joined_lens[j]; stride >= zkhip_shard_verifier_proof_size and a
+ * multiple of 4), join_vk receives their key (it must equal join_machine->key_root).  The proof is the bytes zkhip_prove_machine_verifier makes from
+ * the same joins; zkhip_verify_machine_recursive checks it from (join_machine, the shard proofs' public values, the top's key). */
+int zkhip_prove_shard_tree(zkhip_ctx* ctx, const zkhip_machine_key* top_key, const zkhip_machine_desc* join_machine, const int* devices, int n_devices,
+                           const uint8_t* const* shard_proofs, const size_t* shard_proof_lens, size_t n_proofs, size_t proofs_per_join, int log_n, uint32_t width,
+                           const uint32_t* public_values, size_t n_public, const zkhip_params* inner, const zkhip_params* join_outer, const zkhip_params* top_outer,
+                           int in_flight_per_device, uint8_t* joined, size_t joined_stride, size_t* joined_lens, uint32_t join_vk[8], uint8_t* proof, size_t cap, size_t* len);
+
 size_t zkhip_machine_verifier_describe(const zkhip_machine_desc* inner, size_t n_proofs, int which, int kind, uint32_t* out, size_t cap, int* log_rows, uint32_t* main_width,
                                        uint32_t* pre_width);
 /* the MAIN trace of the chip at position `which` as zkhip_prove_machine_verifier fills it on the host (canonical words, [2^log_rows][main width]; the

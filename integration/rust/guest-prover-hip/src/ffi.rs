@@ -168,6 +168,11 @@ extern "C" {
         ctx: *mut ZkhipCtx, key: *const ZkhipMachineKey, inner: *const ZkhipMachineDesc, proofs: *const *const u8, proof_lens: *const usize, n_proofs: usize,
         public_values: *const u32, n_public: usize, outer: *const ZkhipParams, proof: *mut u8, cap: usize, len: *mut usize,
     ) -> c_int;
+    pub fn zkhip_prove_shard_tree(ctx: *mut ZkhipCtx, top_key: *const ZkhipMachineKey, join_machine: *const ZkhipMachineDesc, devices: *const c_int, n_devices: c_int,
+                                  shard_proofs: *const *const u8, shard_proof_lens: *const usize, n_proofs: usize, proofs_per_join: usize, log_n: c_int, width: u32,
+                                  public_values: *const u32, n_public: usize, inner: *const ZkhipParams, join_outer: *const ZkhipParams, top_outer: *const ZkhipParams,
+                                  in_flight_per_device: c_int, joined: *mut u8, joined_stride: usize, joined_lens: *mut usize, join_vk: *mut u32, proof: *mut u8, cap: usize,
+                                  len: *mut usize) -> c_int;
     pub fn zkhip_verify_machine_recursive(
         inner: *const ZkhipMachineDesc, proof: *const u8, len: usize, public_values: *const u32, n_public: usize, n_proofs: usize, vk: *const u32,
         outer: *const ZkhipParams, reason: *mut c_int,

@@ -146,6 +146,8 @@ m_im = InnerMachine(m_chips, [int(x) for x in kroot], 4, 3, len(kpub))
 assert machine_verifier_host_tables(m_im, [arr(p_keyed)], [kpub], 1) is not None
 L.zkhip_machine_verifier_proof_size.restype = C.c_size_t
 
+gm0 = arr(g_proof.tobytes())
+b_pv, b_out, b_jl, b_vk = np.zeros(64 * 4097, dtype=np.uint32), np.zeros(32 << 20, dtype=np.uint8), (C.c_size_t * 64)(), np.zeros(8, dtype=np.uint32)
 t0, n = time.time(), 0
 while time.time() - t0 < budget:
     machine_verifier_host_tables(m_im, [arr(mutate(p_keyed))], [kpub if rng.random() < 0.7 else [int(rng.integers(0, 2**32))]], int(rng.choice([0, 1, 5, 9])))
@@ -169,6 +171,13 @@ while time.time() - t0 < budget:
                                     r_desc.ctypes.data_as(u32p), int(rng.choice([r_desc.size, 0, 5])), C.byref(lr_), C.byref(mw_), C.byref(pw_))
     L.zkhip_shard_verifier_proof_size(int(rng.choice([6, 20, 22, 23])), int(rng.choice([8, 256, 1024, 2**31])), int(rng.choice([4, 100, 1024, 2**33])), int(rng.choice([3, 16, 31])),
                                       int(rng.choice([2, 9, 64, 65])), int(rng.choice([1, 16, 64, 65])), C.byref(prm))
+    # the batch of joins: whatever the numbers, it answers from its argument checks / the size query (no device here: ZKHIP_ERR_NO_DEVICE at the latest)
+    b_n, b_j = int(rng.choice([4, 3, 0, 64])), int(rng.choice([2, 0, 3, 2**40]))
+    b_ptrs = (u8p * 64)(*[gm0.ctypes.data_as(u8p)] * 64)
+    b_lens = (C.c_size_t * 64)(*[gm0.size] * 64)
+    L.zkhip_prove_shard_verifier_batch(None, int(rng.choice([0, 0, -1, 3])), b_ptrs, b_lens, b_n, b_j, int(rng.choice([_kat["log_n"], 2, 23])), int(rng.choice([_kat["width"], 12, 2**31])),
+                                              b_pv.ctypes.data_as(u32p), int(rng.choice([2, 0, 4097])), C.byref(prm), C.byref(prm), int(rng.choice([0, 2, -5, 2**20])), 1,
+                                              b_out.ctypes.data_as(u8p), int(rng.choice([b_out.size // 32, 0, 5])), b_jl, b_vk.ctypes.data_as(u32p))
     gm = arr(mutate(g_proof.tobytes()))
     L.zkhip_fri_view_all(gm.ctypes.data_as(u8p), gm.size, int(rng.choice([g_R, g_R, g_R + 1, 2])), int(rng.choice([_kat["width"], 4])), g_pv.ctypes.data_as(u32p), g_pv.size,
                          C.byref(g_prm), *[a.ctypes.data_as(u32p) for a in g_out])

@@ -256,3 +256,38 @@ def test_a_tree_over_statements_about_real_data(ctx):
     bad = flat[:91 * 2] + pubs[2][:16] + sha256_padding_publics(99).tolist() + flat[91 * 3:]      # the third message: another length
     assert verify_machine_recursive(im, top, bad, tkey.root, tprm, 2)[0] != 0
     jkey.close(), tkey.close()
+
+
+@pytest.mark.parametrize("in_flight", [1, 3])
+def test_the_tree_in_one_call_is_the_joins_and_the_top_made_one_by_one(ctx, in_flight):
+    """zkhip_prove_shard_tree: six shard proofs -> three joins of two (in flight on pooled contexts; each one's tables for the top filled on its worker's
+    thread the moment it exists) -> ONE proof; the joins and the top are the bytes of zkhip_prove_shard_verifier / zkhip_prove_machine_verifier called one
+    by one; a tampered shard proof, a join machine with another key and a count that is no multiple of the join size are refused"""
+    from zktls_amd.device import prove_shard_tree
+    log_n, width, q, pb = 6, 16, 3, 1
+    iprm, jprm, tprm = Params(1, q, pb), Params(1, 4, 2), Params(1, 20, 8)
+    pubs = [[5, 6, 30 + s] for s in range(6)]
+    shards = [ctx.prove_shard(ctx.gen_trace(SEED, 140 + s, log_n, width), log_n, width, pubs[s], iprm) for s in range(6)]
+    jkey = ctx.shard_verifier_setup(log_n, width, q, pb, 3, jprm, n_proofs=2)
+    joins = [ctx.prove_shard_verifier(jkey, shards[2 * j:2 * j + 2], log_n, width, pubs[2 * j:2 * j + 2], iprm, jprm) for j in range(3)]
+    jpubs = [pubs[2 * j] + pubs[2 * j + 1] for j in range(3)]
+    chips, im = join_machine(log_n, width, q, pb, 3, 2, jkey.root, 4, 2)
+    tkey = ctx.machine_verifier_setup(im, tprm, 3)
+    top = ctx.prove_machine_verifier(tkey, im, joins, jpubs, tprm)
+    for rep in range(2):
+        top1, joins1, jvk = prove_shard_tree(ctx, tkey, im, shards, 2, log_n, width, pubs, iprm, jprm, tprm, devices=[0], in_flight=in_flight)
+        assert jvk.tolist() == jkey.root.tolist()
+        assert [j.tobytes() for j in joins1] == [j.tobytes() for j in joins]
+        assert top1.tobytes() == top.tobytes()
+    assert verify_machine_recursive(im, top1, [v for p in jpubs for v in p], tkey.root, tprm, 3) == (0, 0)
+    bad = [p.copy() for p in shards]
+    bad[4][bad[4].size // 2] ^= 1
+    with pytest.raises(ZkHipError) as e:
+        prove_shard_tree(ctx, tkey, im, bad, 2, log_n, width, pubs, iprm, jprm, tprm, devices=[0], in_flight=in_flight)
+    assert e.value.code == -6
+    with pytest.raises(ZkHipError):
+        prove_shard_tree(ctx, tkey, im, shards[:5], 2, log_n, width, pubs[:5], iprm, jprm, tprm, devices=[0])
+    _, other = join_machine(log_n, width, q, pb, 3, 2, [(int(x) + 1) % 2013265921 for x in jkey.root], 4, 2)
+    with pytest.raises(ZkHipError):
+        prove_shard_tree(ctx, tkey, other, shards, 2, log_n, width, pubs, iprm, jprm, tprm, devices=[0])          # (a join machine with another key: its tables reject the joins)
+    jkey.close(), tkey.close()

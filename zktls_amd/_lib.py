@@ -35,7 +35,7 @@ EXPORTS = [
     "zkhip_chips_proof_size_air", "zkhip_prove_chips_air", "zkhip_verify_chips_air",
     "zkhip_prove_shards_air_multi", "zkhip_selftest_host_simd", "zkhip_host_simd", "zkhip_machine_proof_size", "zkhip_prove_machine", "zkhip_verify_machine", "zkhip_range_table",
     "zkhip_machine_setup", "zkhip_machine_key_destroy", "zkhip_machine_proof_size_keyed", "zkhip_prove_machine_keyed", "zkhip_verify_machine_keyed", "zkhip_prove_machine_keyed_at",
-    "zkhip_sha256_setup", "zkhip_sha256_machine_proof_size", "zkhip_prove_sha256_machine", "zkhip_verify_sha256_machine", "zkhip_prove_transcripts", "zkhip_prove_transcripts_air", "zkhip_sha256_machine_describe", "zkhip_machine_verifier_setup", "zkhip_machine_verifier_key_host", "zkhip_machine_verifier_proof_size", "zkhip_prove_machine_verifier", "zkhip_verify_machine_recursive", "zkhip_machine_verifier_describe", "zkhip_machine_verifier_host_tables", "zkhip_sha256_compress_setup", "zkhip_sha256_compress_key_host", "zkhip_sha256_compressed_proof_size", "zkhip_prove_sha256_compressed", "zkhip_verify_sha256_compressed", "zkhip_set_wait_mode", "zkhip_set_lockstep", "zkhip_lockstep_stats", "zkhip_lockstep_stack_high_water", "zkhip_set_fri_graph", "zkhip_shard_verifier_setup", "zkhip_shard_verifier_proof_size", "zkhip_shard_verifier_max_proofs", "zkhip_prove_shard_verifier", "zkhip_prove_shard_verifier_batch", "zkhip_verify_shard_recursive", "zkhip_shard_verifier_describe", "zkhip_shard_verifier_key_host", "zkhip_machine_key_host", "zkhip_shard_verifier_setup_air", "zkhip_shard_verifier_key_host_air", "zkhip_shard_verifier_max_proofs_air", "zkhip_shard_verifier_proof_size_air", "zkhip_prove_shard_verifier_air", "zkhip_verify_shard_recursive_air", "zkhip_shard_verifier_describe_air", "zkhip_poseidon2_params_generation", "zkhip_selftest_lockstep",
+    "zkhip_sha256_setup", "zkhip_sha256_machine_proof_size", "zkhip_prove_sha256_machine", "zkhip_verify_sha256_machine", "zkhip_prove_transcripts", "zkhip_prove_transcripts_air", "zkhip_sha256_machine_describe", "zkhip_machine_verifier_setup", "zkhip_machine_verifier_key_host", "zkhip_machine_verifier_proof_size", "zkhip_prove_machine_verifier", "zkhip_prove_shard_tree", "zkhip_verify_machine_recursive", "zkhip_machine_verifier_describe", "zkhip_machine_verifier_host_tables", "zkhip_sha256_compress_setup", "zkhip_sha256_compress_key_host", "zkhip_sha256_compressed_proof_size", "zkhip_prove_sha256_compressed", "zkhip_verify_sha256_compressed", "zkhip_set_wait_mode", "zkhip_set_lockstep", "zkhip_lockstep_stats", "zkhip_lockstep_stack_high_water", "zkhip_set_fri_graph", "zkhip_shard_verifier_setup", "zkhip_shard_verifier_proof_size", "zkhip_shard_verifier_max_proofs", "zkhip_prove_shard_verifier", "zkhip_prove_shard_verifier_batch", "zkhip_verify_shard_recursive", "zkhip_shard_verifier_describe", "zkhip_shard_verifier_key_host", "zkhip_machine_key_host", "zkhip_shard_verifier_setup_air", "zkhip_shard_verifier_key_host_air", "zkhip_shard_verifier_max_proofs_air", "zkhip_shard_verifier_proof_size_air", "zkhip_prove_shard_verifier_air", "zkhip_verify_shard_recursive_air", "zkhip_shard_verifier_describe_air", "zkhip_poseidon2_params_generation", "zkhip_selftest_lockstep",
     "zkhip_sha256_air_chained", "zkhip_sha256_gen_trace_chained", "zkhip_sha256_sharded_count", "zkhip_sha256_shard_proof_size", "zkhip_prove_sha256_sharded",
     "zkhip_verify_sha256_sharded",
     "zkhip_fri_view_shard", "zkhip_fri_chip_width", "zkhip_fri_chip_air", "zkhip_fri_chip_gen_trace", "zkhip_fri_queries_key", "zkhip_fri_queries_proof_size",
@@ -268,6 +268,8 @@ def load():
     L.zkhip_sha256_machine_describe.restype = C.c_size_t
     L.zkhip_machine_verifier_setup.argtypes = [C.c_void_p, MD, C.c_size_t, PP, C.POINTER(C.c_void_p), u32p]
     L.zkhip_machine_verifier_key_host.argtypes = [MD, C.c_size_t, PP, u32p]
+    L.zkhip_prove_shard_tree.argtypes = [C.c_void_p, C.c_void_p, MD, C.POINTER(C.c_int), C.c_int, C.POINTER(u8p), C.POINTER(C.c_size_t), C.c_size_t, C.c_size_t, C.c_int, C.c_uint32, u32p,
+                                         C.c_size_t, PP, PP, PP, C.c_int, u8p, C.c_size_t, C.POINTER(C.c_size_t), u32p, u8p, C.c_size_t, C.POINTER(C.c_size_t)]
     L.zkhip_machine_verifier_proof_size.argtypes = [MD, C.c_size_t, PP]
     L.zkhip_machine_verifier_proof_size.restype = C.c_size_t
     L.zkhip_prove_machine_verifier.argtypes = [C.c_void_p, C.c_void_p, MD, C.POINTER(u8p), C.POINTER(C.c_size_t), C.c_size_t, u32p, C.c_size_t, PP, u8p, C.c_size_t, C.POINTER(C.c_size_t)]

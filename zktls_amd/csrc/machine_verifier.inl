@@ -1660,64 +1660,46 @@ size_t m_machine_verifier_describe(const zkhip_machine_desc* inner, size_t n_pro
     return src->size();
 }
 
-int m_prove_machine_verifier(zkhip_ctx* ctx, const zkhip_machine_key* key, const zkhip_machine_desc* inner, const uint8_t* const* proofs, const size_t* proof_lens, size_t n_proofs,
-                                 const uint32_t* public_values, size_t n_public, const zkhip_params* outer, uint8_t* proof, size_t cap, size_t* len) {
-    CHECK_CTX(ctx);
-    if (!key || !inner || !proofs || !proof_lens || !outer || !proof || !len || (n_public && !public_values)) return fail(ZKHIP_ERR_INVALID, "prove_machine_verifier: null argument");
+// The top in three steps, so that a caller that makes the inner proofs itself (zkhip_prove_shard_tree: the joins of a tree) fills a proof's tables the
+// moment it exists, beside the others still being proven: begin (the machine, zeroed tables), fill (one inner proof -- its tables ARE its verification;
+// distinct proofs may be filled from distinct threads), finish (uploads, the Poseidon2 columns, the machine's proof).
+struct TopSession {
+    std::shared_ptr<const Machine> mp;
+    HostTabs ht;
+    size_t used = 0;
+};
+int top_begin(const zkhip_machine_desc* inner, size_t n_proofs, size_t n_public, TopSession& s) {
     int rc = ZKHIP_OK;
-    const auto mp = machine_of(inner, n_proofs, &rc);
-    if (!mp) return rc;
-    const Machine& m = *mp;
+    s.mp = machine_of(inner, n_proofs, &rc);
+    if (!s.mp) return rc;
+    const Machine& m = *s.mp;
     const MShape& sh = m.sh;
     if ((int)n_public != sh.NPUB) return fail(ZKHIP_ERR_INVALID, "prove_machine_verifier: n_public is not the machine's");
-    const int NP = sh.NP;
-#ifdef ZKHIP_AB_HOOKS
-    static const bool timing = getenv("ZKHIP_REC_TIMING") != nullptr;
-    auto t_last = std::chrono::steady_clock::now();
-    auto lap = [&](const char* what) {
-        if (!timing) return;
-        (void)hipStreamSynchronize(ctx->stream);
-        const auto now = std::chrono::steady_clock::now();
-        std::fprintf(stderr, "  [machine verifier] %-34s %8.2f ms\n", what, std::chrono::duration<double, std::milli>(now - t_last).count());
-        t_last = now;
-    };
-#else
-    auto lap = [](const char*) {};
-#endif
-    HostTabs ht;
+    HostTabs& ht = s.ht;
     ZeroedWords* tabs[N_CHIPS] = {nullptr, &ht.rs, &ht.fold, &ht.ts, &ht.q, &ht.op, &ht.sm, &ht.sc, &ht.evl, &ht.lgu};
     for (int c = 0; c < N_CHIPS; c++) if (tabs[c] && !tabs[c]->reset((size_t)m.w_main[c] << m.height[c])) return fail(ZKHIP_ERR_NOMEM, "prove_machine_verifier: no host memory for the machine's tables");
     for (size_t r = 0; r < ((size_t)1 << m.height[C_FOLD]); r++) ht.fold.data()[(size_t)m.w_main[C_FOLD] * r + frichip::T] = MONTY_R1;      // (the fold chip's padding rows: T = 1)
-    const size_t used = (size_t)NP * sh.p2_rows;
-    try { ht.p2_in.reset(new uint32_t[16 * used]); ht.p2_bit.reset(new uint32_t[used]); ht.p2_kp.reset(new uint32_t[used]); } catch (const std::bad_alloc&) { return fail(ZKHIP_ERR_NOMEM, "prove_machine_verifier: no host memory"); }
-    // the inner proofs side by side: each one's tables, which is its verification
-    {
-        std::vector<int> rcs((size_t)NP, ZKHIP_OK);
-        std::vector<std::string> msgs((size_t)NP);
-        auto one = [&](int p) {
-          try {                                                            // (a pool thread: nothing may unwind out of it)
-            int r = proofs[p] ? ZKHIP_OK : fail(ZKHIP_ERR_INVALID, "prove_machine_verifier: null proof");
-#ifdef ZKHIP_AB_HOOKS
-            const auto tv = std::chrono::steady_clock::now();
-#endif
-            if (r == ZKHIP_OK) r = fill_proof(m, p, proofs[p], proof_lens[p], public_values + (size_t)p * n_public, ht);
-#ifdef ZKHIP_AB_HOOKS
-            if (timing) std::fprintf(stderr, "    [machine verifier] proof %d: tables filled in %.2f ms\n", p, std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tv).count());
-#endif
-            rcs[(size_t)p] = r;
-            if (r != ZKHIP_OK) msgs[(size_t)p] = zkhip_last_error();
-          } catch (const std::bad_alloc&) { rcs[(size_t)p] = ZKHIP_ERR_NOMEM; msgs[(size_t)p] = "prove_machine_verifier: out of host memory"; }
-            catch (const std::exception& e) { rcs[(size_t)p] = ZKHIP_ERR_INTERNAL; msgs[(size_t)p] = std::string("prove_machine_verifier: ") + e.what(); }
-        };
-        if (NP == 1) one(0);
-        else {
-            HostPool pool(NP < 16 ? NP : 16);
-            for (int p = 0; p < NP; p++) pool.submit([&one, p] { one(p); });
-            pool.wait();
-        }
-        for (int p = 0; p < NP; p++) if (rcs[(size_t)p] != ZKHIP_OK) { set_error("proof " + std::to_string(p) + ": " + msgs[(size_t)p]); return rcs[(size_t)p]; }
-    }
-    lap("host: verify + witnesses + tables");
+    s.used = (size_t)sh.NP * sh.p2_rows;
+    try { ht.p2_in.reset(new uint32_t[16 * s.used]); ht.p2_bit.reset(new uint32_t[s.used]); ht.p2_kp.reset(new uint32_t[s.used]); } catch (const std::bad_alloc&) { return fail(ZKHIP_ERR_NOMEM, "prove_machine_verifier: no host memory"); }
+    return ZKHIP_OK;
+}
+// (any thread, a pool's included: nothing unwinds out of it; the message stays in this thread's zkhip_last_error)
+int top_fill(TopSession& s, int p, const uint8_t* proof, size_t proof_len, const uint32_t* pubs) {
+    try {
+        if (!proof) return fail(ZKHIP_ERR_INVALID, "prove_machine_verifier: null proof");
+        return fill_proof(*s.mp, p, proof, proof_len, pubs, s.ht);
+    } catch (const std::bad_alloc&) { return fail(ZKHIP_ERR_NOMEM, "prove_machine_verifier: out of host memory"); }
+      catch (const std::exception& e) { return fail(ZKHIP_ERR_INTERNAL, std::string("prove_machine_verifier: ") + e.what()); }
+}
+template <class Lap>
+int top_finish(zkhip_ctx* ctx, const zkhip_machine_key* key, TopSession& s, const uint32_t* public_values, size_t n_public, const zkhip_params* outer, uint8_t* proof, size_t cap,
+               size_t* len, Lap&& lap) {
+    const Machine& m = *s.mp;
+    const MShape& sh = m.sh;
+    const int NP = sh.NP;
+    HostTabs& ht = s.ht;
+    const size_t used = s.used;
+    ZeroedWords* tabs[N_CHIPS] = {nullptr, &ht.rs, &ht.fold, &ht.ts, &ht.q, &ht.op, &ht.sm, &ht.sc, &ht.evl, &ht.lgu};
     void* dev[N_CHIPS] = {nullptr};
     const int slots[N_CHIPS] = {S_REC_A, S_REC_C, S_REC_B, S_REC_D, S_REC_E, S_REC_F, S_REC_G, S_REC_H, S_REC_I, S_REC_J};
     for (int c = 0; c < N_CHIPS; c++) ZK_TRY(ctx_reserve(ctx, slots[c], ((size_t)m.w_main[c] << m.height[c]) * 4, &dev[c]));
@@ -1751,6 +1733,77 @@ int m_prove_machine_verifier(zkhip_ctx* ctx, const zkhip_machine_key* key, const
     const int prc = zkhip_prove_machine_keyed(ctx, key, chips, m.progs, m.prog_words, m.tabs, m.tab_words, N_CHIPS, pv.data(), pv.size(), outer, proof, cap, len);
     lap("the machine's proof");
     return prc;
+}
+
+int m_prove_machine_verifier(zkhip_ctx* ctx, const zkhip_machine_key* key, const zkhip_machine_desc* inner, const uint8_t* const* proofs, const size_t* proof_lens, size_t n_proofs,
+                                 const uint32_t* public_values, size_t n_public, const zkhip_params* outer, uint8_t* proof, size_t cap, size_t* len) {
+    CHECK_CTX(ctx);
+    if (!key || !inner || !proofs || !proof_lens || !outer || !proof || !len || (n_public && !public_values)) return fail(ZKHIP_ERR_INVALID, "prove_machine_verifier: null argument");
+#ifdef ZKHIP_AB_HOOKS
+    static const bool timing = getenv("ZKHIP_REC_TIMING") != nullptr;
+    auto t_last = std::chrono::steady_clock::now();
+    auto lap = [&](const char* what) {
+        if (!timing) return;
+        (void)hipStreamSynchronize(ctx->stream);
+        const auto now = std::chrono::steady_clock::now();
+        std::fprintf(stderr, "  [machine verifier] %-34s %8.2f ms\n", what, std::chrono::duration<double, std::milli>(now - t_last).count());
+        t_last = now;
+    };
+#else
+    auto lap = [](const char*) {};
+#endif
+    TopSession s;
+    ZK_TRY(top_begin(inner, n_proofs, n_public, s));
+    const int NP = s.mp->sh.NP;
+    // the inner proofs side by side: each one's tables, which is its verification
+    {
+        std::vector<int> rcs((size_t)NP, ZKHIP_OK);
+        std::vector<std::string> msgs((size_t)NP);
+        auto one = [&](int p) {
+#ifdef ZKHIP_AB_HOOKS
+            const auto tv = std::chrono::steady_clock::now();
+#endif
+            const int r = top_fill(s, p, proofs[p], proof_lens[p], public_values + (size_t)p * n_public);
+#ifdef ZKHIP_AB_HOOKS
+            if (timing) std::fprintf(stderr, "    [machine verifier] proof %d: tables filled in %.2f ms\n", p, std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tv).count());
+#endif
+            rcs[(size_t)p] = r;
+            if (r != ZKHIP_OK) msgs[(size_t)p] = zkhip_last_error();
+        };
+        if (NP == 1) one(0);
+        else {
+            HostPool pool(NP < 16 ? NP : 16);
+            for (int p = 0; p < NP; p++) pool.submit([&one, p] { one(p); });
+            pool.wait();
+        }
+        for (int p = 0; p < NP; p++) if (rcs[(size_t)p] != ZKHIP_OK) { set_error("proof " + std::to_string(p) + ": " + msgs[(size_t)p]); return rcs[(size_t)p]; }
+    }
+    lap("host: verify + witnesses + tables");
+    return top_finish(ctx, key, s, public_values, n_public, outer, proof, cap, len, lap);
+}
+
+// THE TREE in one call: the shard proofs of an execution -> joins of proofs_per_join (zkhip_prove_shard_verifier_batch's way: dealt over the devices,
+// several in flight) -> ONE proof over the joins, on ctx.  A join's tables for the top are filled on its worker's thread the moment the join exists,
+// beside the joins still being proven, so that after the last join only the uploads and the machine's proof remain.
+int m_prove_shard_tree(zkhip_ctx* ctx, const zkhip_machine_key* top_key, const zkhip_machine_desc* join_machine, const int* devices, int n_devices,
+                       const uint8_t* const* shard_proofs, const size_t* shard_proof_lens, size_t n_proofs, size_t proofs_per_join, int log_n, uint32_t width,
+                       const uint32_t* public_values, size_t n_public, const zkhip_params* inner, const zkhip_params* join_outer, const zkhip_params* top_outer,
+                       int in_flight_per_device, uint8_t* joined, size_t joined_stride, size_t* joined_lens, uint32_t join_vk[8], uint8_t* proof, size_t cap, size_t* len) {
+    CHECK_CTX(ctx);
+    if (!top_key || !join_machine || !top_outer || !proof || !len || !join_vk) return fail(ZKHIP_ERR_INVALID, "prove_shard_tree: null argument");
+    if (proofs_per_join == 0 || n_proofs == 0 || n_proofs % proofs_per_join != 0) return fail(ZKHIP_ERR_INVALID, "prove_shard_tree: the number of shard proofs must be a positive multiple of proofs_per_join");
+    if (joined_stride % 4 != 0) return fail(ZKHIP_ERR_INVALID, "prove_shard_tree: joined_stride must be a multiple of 4");
+    const size_t J = proofs_per_join, n_joins = n_proofs / J, jpub = J * n_public;
+    if (join_machine->n_public != jpub) return fail(ZKHIP_ERR_INVALID, "prove_shard_tree: the join machine's public values are not proofs_per_join x n_public");
+    TopSession s;
+    ZK_TRY(top_begin(join_machine, n_joins, jpub, s));
+    const std::function<int(size_t, const uint8_t*, size_t)> on_join = [&](size_t j, const uint8_t* jp, size_t jl) {
+        return top_fill(s, (int)j, jp, jl, public_values + j * jpub);
+    };
+    ZK_TRY(sv_prove_batch(devices, n_devices, shard_proofs, shard_proof_lens, n_proofs, J, log_n, width, public_values, n_public, inner, join_outer, in_flight_per_device, 0,
+                          joined, joined_stride, joined_lens, join_vk, &on_join));
+    if (std::memcmp(join_vk, join_machine->key_root, 32) != 0) return fail(ZKHIP_ERR_INVALID, "prove_shard_tree: the join machine's key is not the key of this shape");
+    return top_finish(ctx, top_key, s, public_values, jpub, top_outer, proof, cap, len, [](const char*) {});
 }
 
 // the machine's MAIN traces as the prover fills them on the host, for tests without a device: chip at position `which` (tallest first), canonical words,
@@ -1817,6 +1870,13 @@ size_t zkhip_machine_verifier_describe(const zkhip_machine_desc* inner, size_t n
 int zkhip_prove_machine_verifier(zkhip_ctx* ctx, const zkhip_machine_key* key, const zkhip_machine_desc* inner, const uint8_t* const* proofs, const size_t* proof_lens, size_t n_proofs,
                                  const uint32_t* public_values, size_t n_public, const zkhip_params* outer, uint8_t* proof, size_t cap, size_t* len) {
     ZK_MREC_GUARD(zk::mrec::m_prove_machine_verifier(ctx, key, inner, proofs, proof_lens, n_proofs, public_values, n_public, outer, proof, cap, len), ZKHIP_ERR_NOMEM)
+}
+int zkhip_prove_shard_tree(zkhip_ctx* ctx, const zkhip_machine_key* top_key, const zkhip_machine_desc* join_machine, const int* devices, int n_devices,
+                           const uint8_t* const* shard_proofs, const size_t* shard_proof_lens, size_t n_proofs, size_t proofs_per_join, int log_n, uint32_t width,
+                           const uint32_t* public_values, size_t n_public, const zkhip_params* inner, const zkhip_params* join_outer, const zkhip_params* top_outer,
+                           int in_flight_per_device, uint8_t* joined, size_t joined_stride, size_t* joined_lens, uint32_t join_vk[8], uint8_t* proof, size_t cap, size_t* len) {
+    ZK_MREC_GUARD(zk::mrec::m_prove_shard_tree(ctx, top_key, join_machine, devices, n_devices, shard_proofs, shard_proof_lens, n_proofs, proofs_per_join, log_n, width, public_values,
+                                               n_public, inner, join_outer, top_outer, in_flight_per_device, joined, joined_stride, joined_lens, join_vk, proof, cap, len), ZKHIP_ERR_NOMEM)
 }
 size_t zkhip_machine_verifier_host_tables(const zkhip_machine_desc* inner, const uint8_t* const* proofs, const size_t* proof_lens, size_t n_proofs, const uint32_t* public_values,
                                           size_t n_public, int which, uint32_t* out, size_t cap) {

@@ -1417,10 +1417,12 @@ int zkhip_prove_shard_verifier(zkhip_ctx* ctx, const zkhip_machine_key* key, con
 // kernels.  Every worker runs on a pooled context that keeps the shape's proving key (setup once per context and shape; every context arrives at
 // the same vk).  Join j's proof goes to joined + j joined_stride (stride >= zkhip_shard_verifier_proof_size).  verify != 0: each join is checked by
 // the host verifier on its worker's thread (sp1.rs:120), beside the other workers' kernels.
-int zkhip_prove_shard_verifier_batch(const int* devices, int n_devices, const uint8_t* const* shard_proofs, const size_t* shard_proof_lens, size_t n_proofs,
-                                     size_t proofs_per_join, int log_n, uint32_t width, const uint32_t* public_values, size_t n_public, const zkhip_params* inner,
-                                     const zkhip_params* outer, int in_flight_per_device, int verify, uint8_t* joined, size_t joined_stride, size_t* joined_lens,
-                                     uint32_t vk[8]) {
+// (on_join, when given, runs on the worker's thread right after join j exists -- zkhip_prove_shard_tree fills the top's tables for it there; its
+// failure is the join's)
+extern "C++" int sv_prove_batch(const int* devices, int n_devices, const uint8_t* const* shard_proofs, const size_t* shard_proof_lens, size_t n_proofs,
+                                size_t proofs_per_join, int log_n, uint32_t width, const uint32_t* public_values, size_t n_public, const zkhip_params* inner,
+                                const zkhip_params* outer, int in_flight_per_device, int verify, uint8_t* joined, size_t joined_stride, size_t* joined_lens,
+                                uint32_t vk[8], const std::function<int(size_t, const uint8_t*, size_t)>* on_join) {
     if (!shard_proofs || !shard_proof_lens || !inner || !outer || !joined || !joined_lens || !vk || (n_public && !public_values))
         return fail(ZKHIP_ERR_INVALID, "prove_shard_verifier_batch: null argument");
     if (proofs_per_join == 0 || n_proofs == 0 || n_proofs % proofs_per_join != 0)
@@ -1461,10 +1463,18 @@ int zkhip_prove_shard_verifier_batch(const int* devices, int n_devices, const ui
                                                           inner, outer, out, joined_stride, &len);
         if (r == ZKHIP_OK && verify)
             r = zkhip_verify_shard_recursive(out, len, log_n, width, (size_t)inner->num_queries, inner->pow_bits, pv, n_public, J, ctx->rec_vk, outer, nullptr);
+        if (r == ZKHIP_OK && on_join) r = (*on_join)((size_t)j, out, len);
         joined_lens[(size_t)j] = r == ZKHIP_OK ? len : 0;
         return r;
     };
     return deal_jobs(devs.data(), (int)devs.size(), (int)n_joins, in_flight_per_device, run, ran);          // (0: four)
+}
+int zkhip_prove_shard_verifier_batch(const int* devices, int n_devices, const uint8_t* const* shard_proofs, const size_t* shard_proof_lens, size_t n_proofs,
+                                     size_t proofs_per_join, int log_n, uint32_t width, const uint32_t* public_values, size_t n_public, const zkhip_params* inner,
+                                     const zkhip_params* outer, int in_flight_per_device, int verify, uint8_t* joined, size_t joined_stride, size_t* joined_lens,
+                                     uint32_t vk[8]) {
+    return sv_prove_batch(devices, n_devices, shard_proofs, shard_proof_lens, n_proofs, proofs_per_join, log_n, width, public_values, n_public, inner, outer,
+                          in_flight_per_device, verify, joined, joined_stride, joined_lens, vk, nullptr);
 }
 // The verifier of the outer proof: the shape of the inner proofs, THEIR public values (proof 0's, then proof 1's, ...), the key of the shape.
 // No byte of an inner proof.

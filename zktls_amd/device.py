@@ -1157,6 +1157,34 @@ def prove_shard_verifier_batch(shard_proofs, proofs_per_join, log_n, width, publ
     return [buf[j, : lens[j]] for j in range(n_joins)], vk
 
 
+def prove_shard_tree(ctx, top_key, join_machine, shard_proofs, proofs_per_join, log_n, width, public_values, inner=None, join_outer=None, top_outer=None, devices=None, in_flight=4):
+    """zkhip_prove_shard_tree: shard proofs -> joins of proofs_per_join (in flight, dealt over `devices`) -> ONE proof over the joins on `ctx`
+    -> (top proof bytes, [join proof bytes, ...], join vk [8]); join_machine: the InnerMachine of the join machine; public_values: one list per shard proof"""
+    lib = _lib.load()
+    inner, join_outer, top_outer = inner or Params(1, 100, 16), join_outer or Params(1, 100, 16), top_outer or Params(1, 100, 16)
+    sps = [np.ascontiguousarray(sp, dtype=np.uint8) for sp in shard_proofs]
+    n = len(sps)
+    pv = np.ascontiguousarray(np.array([list(v) for v in public_values], dtype=np.uint32).reshape(max(n, 1), -1))
+    n_public = pv.shape[1]
+    jsize = lib.zkhip_shard_verifier_proof_size(log_n, width, inner.num_queries, inner.pow_bits, n_public, proofs_per_join, C.byref(join_outer))
+    n_joins = n // proofs_per_join if proofs_per_join else 0
+    tsize = lib.zkhip_machine_verifier_proof_size(C.byref(join_machine.desc), max(n_joins, 1), C.byref(top_outer))
+    if jsize == 0 or tsize == 0:
+        check(-1)
+    jbuf = np.empty((max(n_joins, 1), jsize), dtype=np.uint8)
+    jlens = (C.c_size_t * max(n_joins, 1))()
+    ptrs = (u8p * max(n, 1))(*[sp.ctypes.data_as(u8p) for sp in sps])
+    plens = (C.c_size_t * max(n, 1))(*[sp.size for sp in sps])
+    jvk = np.zeros(8, dtype=np.uint32)
+    top = np.empty(tsize, dtype=np.uint8)
+    got = C.c_size_t(0)
+    devs = (C.c_int * len(devices))(*devices) if devices else None
+    check(lib.zkhip_prove_shard_tree(ctx.handle, top_key.handle, C.byref(join_machine.desc), devs, len(devices) if devices else 0, ptrs, plens, n, proofs_per_join, log_n, width,
+                                     pv.ctypes.data_as(u32p), n_public, C.byref(inner), C.byref(join_outer), C.byref(top_outer), in_flight, jbuf.ctypes.data_as(u8p), jsize, jlens,
+                                     jvk.ctypes.data_as(u32p), top.ctypes.data_as(u8p), tsize, C.byref(got)))
+    return top[: got.value], [jbuf[j, : jlens[j]] for j in range(n_joins)], jvk
+
+
 def set_lockstep(max_batch, lanes=0):
     """zkhip_set_lockstep: members per lock-step batch of small transcripts (0 / 1 = off), batches in flight per device (0 = keep)"""
     _lib.load().zkhip_set_lockstep(int(max_batch), int(lanes))
