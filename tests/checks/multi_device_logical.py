@@ -95,6 +95,22 @@ def main():
     for j in range(len(joins)):
         assert joins[j].tobytes() == c0.prove_shard_verifier(jkey, inner[2 * j:2 * j + 2], jl, jw, jpv[2 * j:2 * j + 2], iq, Params(1, 20, 8)).tobytes()
         assert verify_shard_recursive(joins[j], jl, jw, 5, 2, [v for q in jpv[2 * j:2 * j + 2] for v in q], jvk, Params(1, 20, 8), n_proofs=2) == (0, 0)
+    # (8) the tree in one call: the same joins dealt over the device list, each one's tables for the top filled on its worker's thread, the top on device 0
+    from zktls_amd.device import InnerMachine, prove_shard_tree, shard_verifier_describe, verify_machine_recursive
+    chips = []
+    for i in range(8):
+        p_, ln_, mw_, pw_ = shard_verifier_describe(jl, jw, 5, 2, 3, i, 0, 2)
+        t_, _, _, _ = shard_verifier_describe(jl, jw, 5, 2, 3, i, 1, 2)
+        chips.append(dict(ln=ln_, W=mw_, Pw=pw_, prog=p_, tab=t_))
+    im = InnerMachine(chips, jkey.root, 20, 8, 6)
+    tkey = c0.machine_verifier_setup(im, Params(1, 20, 8), len(joins))
+    jflat = [jpv[2 * j] + jpv[2 * j + 1] for j in range(len(joins))]
+    top = c0.prove_machine_verifier(tkey, im, joins, jflat, Params(1, 20, 8))
+    top1, joins1, jvk1 = prove_shard_tree(c0, tkey, im, inner, 2, jl, jw, jpv, iq, Params(1, 20, 8), Params(1, 20, 8), devices=devs, in_flight=2)
+    assert top1.tobytes() == top.tobytes() and jvk1.tolist() == jvk.tolist() and [x.tobytes() for x in joins1] == [x.tobytes() for x in joins]
+    assert verify_machine_recursive(im, top1, [v for q in jflat for v in q], tkey.root, Params(1, 20, 8), len(joins)) == (0, 0)
+    tkey.close()
+    out["tree_in_one_call_over_the_device_list"] = True
     jkey.close()
     out["joins_over_the_device_list"] = len(joins)
     for c in ctxs.values():

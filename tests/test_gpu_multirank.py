@@ -82,7 +82,7 @@ def test_multi_device_entries_on_two_logical_devices():
     assert p.returncode == 0, p.stderr.decode()[-3000:]
     r = json.loads([ln for ln in p.stdout.decode().splitlines() if ln.startswith("{")][-1])
     assert r["logical_devices"] == 2 and r["device_traces_dealt_where_they_live"] == 6 and r["misplaced_trace_refused"] is True
-    assert r["null_device_list_same_bytes"] is True and r["lockstep_small_shards"] == 16 and r["host_traces"] == 5 and r["transcripts_over_the_device_list"] == 8 and r["joins_over_the_device_list"] == 5
+    assert r["null_device_list_same_bytes"] is True and r["lockstep_small_shards"] == 16 and r["host_traces"] == 5 and r["transcripts_over_the_device_list"] == 8 and r["joins_over_the_device_list"] == 5 and r["tree_in_one_call_over_the_device_list"] is True
 
 
 def test_dry_run_of_the_eight_gpu_configuration_on_logical_devices():
