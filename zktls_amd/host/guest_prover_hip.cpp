@@ -210,8 +210,13 @@ static std::vector<uint8_t> compress_shard_proofs(const std::vector<int>& device
     JoinKey& jk = jg.jk;
     if (!take_join_key(device, plan, J, &jk)) {
         if (zkhip_ctx_create(device, nullptr, &jk.ctx) != ZKHIP_OK) { jk.ctx = nullptr; fail_zkhip("zkhip_ctx_create"); }
-        if (zkhip_shard_verifier_setup(jk.ctx, plan.log_n, plan.width, (size_t)plan.num_queries, plan.pow_bits, 9, J, &outer, &jk.key, jk.vk) != ZKHIP_OK)
-            throw std::runtime_error(std::string("zkhip_shard_verifier_setup: ") + zkhip_last_error());
+    }
+    // (one join: this context proves it and keeps the shape's key, parked with it; several: the batch entry's pooled contexts make the joins and keep
+    // their own keys -- this context then proves the top only, and its key slot stays empty until a one-join request of the same shape comes by)
+    if (n_joins == 1 && !jk.key &&
+        zkhip_shard_verifier_setup(jk.ctx, plan.log_n, plan.width, (size_t)plan.num_queries, plan.pow_bits, 9, J, &outer, &jk.key, jk.vk) != ZKHIP_OK) {
+        jk.key = nullptr;
+        throw std::runtime_error(std::string("zkhip_shard_verifier_setup: ") + zkhip_last_error());
     }
     zkhip_ctx* const jctx = jk.ctx;
     zkhip_machine_key* key = jk.key;
@@ -237,7 +242,9 @@ static std::vector<uint8_t> compress_shard_proofs(const std::vector<int>& device
         if (zkhip_prove_shard_verifier_batch(devices.data(), (int)devices.size(), ptrs.data(), lens.data(), (size_t)n_joins * J, J, plan.log_n, plan.width, pvs.data(), 9, &prm, &outer,
                                              0, 1, joined.data(), jcap, jlens.data(), bvk) != ZKHIP_OK)
             throw std::runtime_error(std::string("zkhip_prove_shard_verifier_batch: ") + zkhip_last_error());
-        if (std::memcmp(bvk, vk, 32) != 0) throw std::runtime_error("compress: the batch's key differs from the shape's");
+        if (jk.key && std::memcmp(bvk, vk, 32) != 0) throw std::runtime_error("compress: the batch's key differs from the shape's");
+        std::memcpy(vk, bvk, 32);
+        std::memcpy(jk.vk, bvk, 32);
         for (uint32_t c = 0; c < n_joins; c++) entries.emplace_back(joined.begin() + (long)((size_t)c * jcap), joined.begin() + (long)((size_t)c * jcap + jlens[c]));
     }
     if (n_joins == 1) {
