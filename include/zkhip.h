@@ -46,6 +46,9 @@
  *   zkhip_machine_verifier_setup / _key_host, zkhip_prove_machine_verifier, zkhip_verify_machine_recursive, zkhip_sha256_machine_describe
  *       the same stage over KEYED-MACHINE proofs (lookups, chips of mixed heights, preprocessed openings in-circuit): the join of joins --
  *       sp1-recursion's compress tree (Cargo.lock:6172 ff.; RISC Zero's join of joins, prover.rs:90) -- and the keyed transcript proofs.
+ *   zkhip_prove_shard_verifier_batch, zkhip_prove_shard_tree
+ *       that tree's first level as ONE call (the joins of one shape dealt over the GPUs, several in flight), and the whole tree as one call
+ *       (shard proofs in, ONE proof out: the reference's compress, sp1.rs:116).
  *   zkhip_proof_to_bincode / zkhip_chips_proof_to_bincode (+ _from_bincode)
  *       what `prover_output.bytes()` carries (sp1.rs:122-123): bincode-shaped forms of the proofs ([RECALLED] field order).
  *   zkhip_prove_segment
