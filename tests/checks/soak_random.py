@@ -101,6 +101,31 @@ while time.time() - t0 < budget:
         assert verify_machine_recursive(im_, outer, pv2, key.root, Params(*oshape), 1) == (0, 0)
         key.close()
         n_rec_machine += 1
+    elif r_kind < 0.013:
+        # THE TREE in one call (zkhip_prove_shard_tree: joins in flight on pooled contexts, each one's tables for the top filled on its worker's thread): a random
+        # small shape, 2 .. 3 joins of 1 .. 3 shard proofs; the joins and the top against the step-by-step entries (whose bytes the kinds above hold to the oracle's)
+        from zktls_amd.device import InnerMachine, prove_shard_tree, shard_verifier_describe, verify_machine_recursive
+        log_n, width, q, pb = int(rng.integers(5, 8)), 8 * int(rng.integers(1, 4)), int(rng.integers(1, 6)), int(rng.integers(0, 4))
+        npub, J, nj = int(rng.integers(1, 4)), int(rng.integers(1, 4)), int(rng.integers(2, 4))
+        pubs = [[int(x) for x in rng.integers(0, 2013265921, npub)] for _ in range(J * nj)]
+        jsh, tsh = (1, int(rng.integers(2, 6)), int(rng.integers(0, 3))), (1, int(rng.integers(4, 12)), int(rng.integers(0, 6)))
+        inner = [ctx.prove_shard(ctx.gen_trace(SEED, int(rng.integers(0, 2**31)), log_n, width), log_n, width, pubs[i], Params(1, q, pb)) for i in range(J * nj)]
+        jkey = ctx.shard_verifier_setup(log_n, width, q, pb, npub, Params(*jsh), n_proofs=J)
+        joins = [ctx.prove_shard_verifier(jkey, inner[J * j:J * (j + 1)], log_n, width, pubs[J * j:J * (j + 1)], Params(1, q, pb), Params(*jsh)) for j in range(nj)]
+        chips_ = []
+        for i in range(8):
+            p_, ln_, mw_, pw_ = shard_verifier_describe(log_n, width, q, pb, npub, i, 0, J)
+            t_, _, _, _ = shard_verifier_describe(log_n, width, q, pb, npub, i, 1, J)
+            chips_.append(dict(ln=ln_, W=mw_, Pw=pw_, prog=p_, tab=t_))
+        im_ = InnerMachine(chips_, jkey.root, jsh[1], jsh[2], J * npub)
+        tkey = ctx.machine_verifier_setup(im_, Params(*tsh), nj)
+        jflat = [[v for p_ in pubs[J * j:J * (j + 1)] for v in p_] for j in range(nj)]
+        top = ctx.prove_machine_verifier(tkey, im_, joins, jflat, Params(*tsh))
+        top1, joins1, jvk1 = prove_shard_tree(ctx, tkey, im_, inner, J, log_n, width, pubs, Params(1, q, pb), Params(*jsh), Params(*tsh), devices=[0], in_flight=int(rng.integers(1, 4)))
+        assert top1.tobytes() == top.tobytes() and [x.tobytes() for x in joins1] == [x.tobytes() for x in joins] and jvk1.tolist() == jkey.root.tolist(), ("tree in one call", log_n, width, q, pb, npub, J, nj, jsh, tsh)
+        assert verify_machine_recursive(im_, top1, [v for f_ in jflat for v in f_], tkey.root, Params(*tsh), nj) == (0, 0)
+        jkey.close(), tkey.close()
+        n_rec_machine += 1
     elif r_kind < 0.017:
         # the Poseidon2 chip: random Merkle paths of a random tree; device trace against the Python restatement, proof bytes against the oracle
         depth, n_paths = int(rng.integers(1, 6)), int(rng.integers(1, 12))
