@@ -31,6 +31,8 @@ python3 tools/join_breakdown.py --sha 64 > $P/compress64_phases.log 2>&1; tail -
 # 2c. the tree: 64 headline shard proofs -> 4 joins of 16 -> one proof (machine mode): the phases of its top (A/B build, no profiler)
 run_kt tree python3 tools/tree_breakdown.py 4
 python3 tools/tree_breakdown.py 4 > $P/tree_phases.log 2>&1; grep -E "machine verifier|top over|chips prover" $P/tree_phases.log | tail -20 > $P/tree_phases.txt
+# 2d. the tree's first level with 1 / 2 / 4 joins in flight (Python threads, then zkhip_prove_shard_verifier_batch): profiles/r05_join_overlap.txt
+python3 tools/join_overlap_probe.py 4 16 > $P/join_overlap.txt 2>&1
 if [ "$WHAT" = all ]; then
 # 3. the contract command (four in flight)
 run_kt kt python3 bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-multichip --no-execution
