@@ -811,9 +811,29 @@ __device__ __forceinline__ void p2r_rows_kernel_body(const p2chip::P2RArgs& a) {
 __global__ void __launch_bounds__(64) p2r_rows_kernel(p2chip::P2RArgs a) { p2r_rows_kernel_body(a); }
 struct p2r_rows_kernel_bargs { p2chip::P2RArgs a; static p2r_rows_kernel_bargs make(p2chip::P2RArgs a) { return p2r_rows_kernel_bargs{a}; } };
 __global__ void __launch_bounds__(64) p2r_rows_kernel_batch(const p2r_rows_kernel_bargs* __restrict__ zk_arr) { const p2r_rows_kernel_bargs& zk_b = zk_arr[blockIdx.z]; p2r_rows_kernel_body(zk_b.a); }
+// The rows after the used ones are all the permutation of the zero state: ONE lane fills the first of them, and this kernel replicates it over the
+// rest -- consecutive rows are one contiguous block, so every store instruction writes 1 KB of consecutive bytes (a lane that fills its own row
+// stores 16 bytes at a stride of 1 440: 640 GB/s, docs/RECURSION_NEXT.md)
+__device__ __forceinline__ void p2r_pad_rows_kernel_body(uint32_t* trace, uint32_t ld, uint64_t src_row, uint64_t n_rows) {
+    const uint64_t per_row = ld / 4, i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_rows * per_row) return;
+    const uint4 v = ((const uint4*)(trace + src_row * ld))[i % per_row];
+    ((uint4*)(trace + (src_row + 1) * ld))[i] = v;
+}
+__global__ void __launch_bounds__(256) p2r_pad_rows_kernel(uint32_t* trace, uint32_t ld, uint64_t src_row, uint64_t n_rows) { p2r_pad_rows_kernel_body(trace, ld, src_row, n_rows); }
+struct p2r_pad_rows_kernel_bargs { uint32_t* trace; uint32_t ld; uint64_t src_row, n_rows; static p2r_pad_rows_kernel_bargs make(uint32_t* trace, uint32_t ld, uint64_t src_row, uint64_t n_rows) { return p2r_pad_rows_kernel_bargs{trace, ld, src_row, n_rows}; } };
+__global__ void __launch_bounds__(256) p2r_pad_rows_kernel_batch(const p2r_pad_rows_kernel_bargs* __restrict__ zk_arr) { const p2r_pad_rows_kernel_bargs& zk_b = zk_arr[blockIdx.z]; p2r_pad_rows_kernel_body(zk_b.trace, zk_b.ld, zk_b.src_row, zk_b.n_rows); }
 hipError_t launch_p2r_rows(const p2chip::P2RArgs& a, hipStream_t s) {
-    const uint64_t lanes = (uint64_t)a.n_chains + a.n_transcript + (a.rows - a.used_rows);
-    ZK_LAUNCH(p2r_rows_kernel, p2r_rows_kernel_batch, p2r_rows_kernel_bargs, dim3((unsigned)((lanes + 63) / 64)), dim3(64), 0, s, a);
+    p2chip::P2RArgs b = a;
+    const uint64_t pad = a.rows - a.used_rows;
+    const bool replicate = pad > 1 && a.ld % 4 == 0 && ((uintptr_t)a.trace & 15) == 0;
+    if (replicate) b.rows = a.used_rows + 1;                    // (the kernel fills the first padding row only)
+    const uint64_t lanes = (uint64_t)b.n_chains + b.n_transcript + (b.rows - b.used_rows);
+    ZK_LAUNCH(p2r_rows_kernel, p2r_rows_kernel_batch, p2r_rows_kernel_bargs, dim3((unsigned)((lanes + 63) / 64)), dim3(64), 0, s, b);
+    if (replicate) {
+        const uint64_t vecs = (pad - 1) * (a.ld / 4);
+        ZK_LAUNCH(p2r_pad_rows_kernel, p2r_pad_rows_kernel_batch, p2r_pad_rows_kernel_bargs, dim3((unsigned)((vecs + 255) / 256)), dim3(256), 0, s, a.trace, (uint32_t)a.ld, (uint64_t)a.used_rows, pad - 1);
+    }
     return hipGetLastError();
 }
 
