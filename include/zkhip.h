@@ -383,7 +383,9 @@ int zkhip_prove_shards_air_multi(const int* devices, int n_devices, zkhip_shard_
 /* the device ordinal shard `shard_index` of a batch is proven on (devices == NULL: ordinal shard_index mod n_devices); -1 on bad arguments */
 int zkhip_shard_device(int shard_index, const int* devices, int n_devices);
 /* the internal contexts of zkhip_prove_shards stay cached between calls (creating and freeing multi-GiB workspaces costs more than
- * a proof); this frees them */
+ * a proof); this frees them -- and with them the HOST tables the recursion provers keep between calls (zkhip_prove_shard_verifier[_air / _batch],
+ * zkhip_prove_machine_verifier, zkhip_prove_shard_tree: hundreds of megabytes of zeroed words per call, zeroed again on a thread of their own when
+ * a call is done and handed to the next call of the same shape; at most 6 GiB are kept) */
 void zkhip_release_cached_contexts(void);
 /* Segment proof from RISC Zero's data layout (risc0-zkp Hal, reference Cargo.lock:5057; call site
  * crates/guest-prover-r0/src/prover.rs:90): d_cols holds `width` contiguous columns of 2^log_n words

@@ -181,6 +181,8 @@ constexpr size_t LOCKSTEP_BYTES_PER_CELL = 48;               // workspace estima
 int deal_jobs_lockstep(const int* devices, int n_devices, int n_jobs, const int* shape, int max_batch, int lanes,
                        const std::function<int(zkhip_ctx*, int)>& run, std::vector<char>& ran, uint64_t job_cells = 0);
 int resolve_devices(const int* devices, int n_devices, const char* what, std::vector<int>& devs);
+// fri_chip.hip (shard_verifier.inl): the recursion provers' pooled host tables, emptied by zkhip_release_cached_contexts
+void rec_release_host_tables();
 int physical_device(int device);     // the HIP ordinal behind a device-list entry (identity in the shipped library)
 #ifdef ZKHIP_AB_HOOKS
 int logical_devices();               // ZKHIP_LOGICAL_DEVICES (0: off)

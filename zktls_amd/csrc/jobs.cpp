@@ -71,6 +71,7 @@ void zkhip_release_cached_contexts(void) {
     std::vector<std::pair<int, zkhip_ctx*>> all;
     { std::lock_guard<std::mutex> lk(g_pool_mu); all.swap(g_pool); }
     for (auto& e : all) zkhip_ctx_destroy(e.second);
+    zk::rec_release_host_tables();
 }
 // Job i of a batch goes to devices[i mod n_devices] (shard-parallel, no exchange step); every device runs up to
 // `in_flight` workers (a pooled context + HIP stream + host thread each) that take that device's jobs in index order and call

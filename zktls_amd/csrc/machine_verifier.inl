@@ -1052,7 +1052,11 @@ struct Wit {
 };
 struct HostTabs {
     ZeroedWords rs, fold, ts, q, op, sm, sc, evl, lgu;
-    std::unique_ptr<uint32_t[]> p2_in, p2_bit, p2_kp;     // the Poseidon2 rows: input state [16] canonical, direction bit, KP (canonical), per used row (every one written: not cleared)
+    ZeroedWords p2_in, p2_bit, p2_kp;     // the Poseidon2 rows: input state [16] canonical, direction bit, KP (canonical), per used row (every one written)
+    void release_later() {                                   // (a finished call: zeroed again and kept for the next one, off the caller's path -- rec::recycle_later)
+        rec::recycle_later({rs.release(), fold.release(), ts.release(), q.release(), op.release(), sm.release(), sc.release(), evl.release(), lgu.release(),
+                            p2_in.release(), p2_bit.release(), p2_kp.release()});
+    }
 };
 inline Ext ext_at(const uint32_t* p) { return Ext{{to_monty(p[0]), to_monty(p[1]), to_monty(p[2]), to_monty(p[3])}}; }
 inline Ext recombine4(const Ext* four) {            // sum_k X^k four[k]
@@ -1085,9 +1089,9 @@ int fill_proof(const Machine& m, int p, const uint8_t* inner, size_t inner_len, 
     for (size_t i = (size_t)sh.HL + 2; i < inner_len / 4; i++) if (w[i] >= P) return bad("a non-canonical word");
     for (int i = 0; i < sh.NPUB; i++) if (pubs[i] >= P) return bad("a non-canonical public value");
     // ---- the transcript: every sponge row's input state, the challenges
-    uint32_t* tin = ht.p2_in.get() + 16 * (size_t)p * sh.p2_rows;
-    uint32_t* tbit = ht.p2_bit.get() + (size_t)p * sh.p2_rows;
-    uint32_t* tkp = ht.p2_kp.get() + (size_t)p * sh.p2_rows;
+    uint32_t* tin = ht.p2_in.data() + 16 * (size_t)p * sh.p2_rows;
+    uint32_t* tbit = ht.p2_bit.data() + (size_t)p * sh.p2_rows;
+    uint32_t* tkp = ht.p2_kp.data() + (size_t)p * sh.p2_rows;
     auto src_val = [&](const Src& s) -> uint32_t {
         switch (s.kind) {
             case S_CONST: return s.a; case S_TROOT: return w[wt.o_troot + s.a]; case S_PUB: return pubs[s.a] % P; case S_PROOT: return w[wt.o_proot + s.a];
@@ -1680,7 +1684,7 @@ int top_begin(const zkhip_machine_desc* inner, size_t n_proofs, size_t n_public,
     for (int c = 0; c < N_CHIPS; c++) if (tabs[c] && !tabs[c]->reset((size_t)m.w_main[c] << m.height[c])) return fail(ZKHIP_ERR_NOMEM, "prove_machine_verifier: no host memory for the machine's tables");
     for (size_t r = 0; r < ((size_t)1 << m.height[C_FOLD]); r++) ht.fold.data()[(size_t)m.w_main[C_FOLD] * r + frichip::T] = MONTY_R1;      // (the fold chip's padding rows: T = 1)
     s.used = (size_t)sh.NP * sh.p2_rows;
-    try { ht.p2_in.reset(new uint32_t[16 * s.used]); ht.p2_bit.reset(new uint32_t[s.used]); ht.p2_kp.reset(new uint32_t[s.used]); } catch (const std::bad_alloc&) { return fail(ZKHIP_ERR_NOMEM, "prove_machine_verifier: no host memory"); }
+    if (!ht.p2_in.reset(16 * s.used) || !ht.p2_bit.reset(s.used) || !ht.p2_kp.reset(s.used)) return fail(ZKHIP_ERR_NOMEM, "prove_machine_verifier: no host memory");
     return ZKHIP_OK;
 }
 // (any thread, a pool's included: nothing unwinds out of it; the message stays in this thread's zkhip_last_error)
@@ -1710,9 +1714,9 @@ int top_finish(zkhip_ctx* ctx, const zkhip_machine_key* key, TopSession& s, cons
         uint32_t* d = (uint32_t*)stage;
         std::vector<uint32_t> trows(used);
         for (size_t r = 0; r < used; r++) trows[r] = (uint32_t)r;
-        ZK_TRY(dev_h2d(ctx, d, ht.p2_in.get(), 16 * used * 4));
-        ZK_TRY(dev_h2d(ctx, d + 16 * used, ht.p2_bit.get(), used * 4));
-        ZK_TRY(dev_h2d(ctx, d + 17 * used, ht.p2_kp.get(), used * 4));
+        ZK_TRY(dev_h2d(ctx, d, ht.p2_in.data(), 16 * used * 4));
+        ZK_TRY(dev_h2d(ctx, d + 16 * used, ht.p2_bit.data(), used * 4));
+        ZK_TRY(dev_h2d(ctx, d + 17 * used, ht.p2_kp.data(), used * 4));
         ZK_TRY(dev_h2d(ctx, d + 18 * used, trows.data(), used * 4));
         p2chip::P2RArgs a{};
         a.desc = nullptr; a.data = nullptr; a.chain_inputs = d; a.trows = d + 18 * used; a.n_chains = 0; a.n_transcript = (uint32_t)used;
@@ -1779,7 +1783,9 @@ int m_prove_machine_verifier(zkhip_ctx* ctx, const zkhip_machine_key* key, const
         for (int p = 0; p < NP; p++) if (rcs[(size_t)p] != ZKHIP_OK) { set_error("proof " + std::to_string(p) + ": " + msgs[(size_t)p]); return rcs[(size_t)p]; }
     }
     lap("host: verify + witnesses + tables");
-    return top_finish(ctx, key, s, public_values, n_public, outer, proof, cap, len, lap);
+    const int prc = top_finish(ctx, key, s, public_values, n_public, outer, proof, cap, len, lap);
+    s.ht.release_later();
+    return prc;
 }
 
 // THE TREE in one call: the shard proofs of an execution -> joins of proofs_per_join (zkhip_prove_shard_verifier_batch's way: dealt over the devices,
@@ -1803,7 +1809,9 @@ int m_prove_shard_tree(zkhip_ctx* ctx, const zkhip_machine_key* top_key, const z
     ZK_TRY(sv_prove_batch(devices, n_devices, shard_proofs, shard_proof_lens, n_proofs, J, log_n, width, public_values, n_public, inner, join_outer, in_flight_per_device, 0,
                           joined, joined_stride, joined_lens, join_vk, &on_join));
     if (std::memcmp(join_vk, join_machine->key_root, 32) != 0) return fail(ZKHIP_ERR_INVALID, "prove_shard_tree: the join machine's key is not the key of this shape");
-    return top_finish(ctx, top_key, s, public_values, jpub, top_outer, proof, cap, len, [](const char*) {});
+    const int prc = top_finish(ctx, top_key, s, public_values, jpub, top_outer, proof, cap, len, [](const char*) {});
+    s.ht.release_later();
+    return prc;
 }
 
 // the machine's MAIN traces as the prover fills them on the host, for tests without a device: chip at position `which` (tallest first), canonical words,
@@ -1821,7 +1829,7 @@ size_t m_machine_verifier_host_tables(const zkhip_machine_desc* inner, const uin
     for (int c = 0; c < N_CHIPS; c++) if (tabs[c] && !tabs[c]->reset((size_t)m.w_main[c] << m.height[c])) { (void)fail(ZKHIP_ERR_NOMEM, "machine_verifier_host_tables: no host memory"); return 0; }
     for (size_t r = 0; r < ((size_t)1 << m.height[C_FOLD]); r++) ht.fold.data()[(size_t)m.w_main[C_FOLD] * r + frichip::T] = MONTY_R1;
     const size_t used = (size_t)sh.NP * sh.p2_rows;
-    try { ht.p2_in.reset(new uint32_t[16 * used]); ht.p2_bit.reset(new uint32_t[used]); ht.p2_kp.reset(new uint32_t[used]); } catch (const std::bad_alloc&) { (void)fail(ZKHIP_ERR_NOMEM, "machine_verifier_host_tables: no host memory"); return 0; }
+    if (!ht.p2_in.reset(16 * used) || !ht.p2_bit.reset(used) || !ht.p2_kp.reset(used)) { (void)fail(ZKHIP_ERR_NOMEM, "machine_verifier_host_tables: no host memory"); return 0; }
     try {
         for (int p = 0; p < sh.NP; p++) if (!proofs[p] || fill_proof(m, p, proofs[p], proof_lens[p], public_values + (size_t)p * n_public, ht) != ZKHIP_OK) return 0;
     } catch (const std::exception& e) { (void)fail(ZKHIP_ERR_NOMEM, std::string("machine_verifier_host_tables: ") + e.what()); return 0; }
@@ -1829,7 +1837,7 @@ size_t m_machine_verifier_host_tables(const zkhip_machine_desc* inner, const uin
     if (c == C_P2R) {
         const size_t n = 18 * used;
         if (out && cap >= n)
-            for (size_t r = 0; r < used; r++) { std::memcpy(out + 18 * r, ht.p2_in.get() + 16 * r, 64); out[18 * r + 16] = ht.p2_bit.get()[r]; out[18 * r + 17] = ht.p2_kp.get()[r]; }
+            for (size_t r = 0; r < used; r++) { std::memcpy(out + 18 * r, ht.p2_in.data() + 16 * r, 64); out[18 * r + 16] = ht.p2_bit.data()[r]; out[18 * r + 17] = ht.p2_kp.data()[r]; }
         return n;
     }
     const size_t n = tabs[c]->size();

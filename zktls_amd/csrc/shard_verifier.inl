@@ -844,17 +844,65 @@ struct HostSpan {                                           // a slice of the co
 };
 // a table of zero words whose pages the kernel hands out on first touch (calloc): the fill threads touch them side by side -- a serial
 // memset of the 170 MB a join of 64 SHA-256 proofs fills took 32 ms of its 185
+// The machines' host tables are hundreds of megabytes of zeroed words per call, most of them written once.  Fresh from calloc they cost a page fault per
+// 4 KB while they are filled and a munmap when they go (55 of the 216 ms the 64 keyed transcript proofs took were spent AFTER the proof was done).  So the
+// tables of a finished call are zeroed again on a thread of their own, off the caller's path, and kept for the next call that asks for the same size
+// (WordPool: at most POOL_CAP bytes; zkhip_release_cached_contexts empties it); a call that finds nothing takes fresh calloc pages as before.
+struct WordPool {
+    static constexpr size_t POOL_CAP = (size_t)6 << 30;
+    std::mutex mu;
+    std::vector<std::pair<uint32_t*, size_t>> idle;          // (zeroed block, words)
+    size_t bytes = 0;
+    uint32_t* take(size_t words) {
+        std::lock_guard<std::mutex> lk(mu);
+        for (size_t i = idle.size(); i-- > 0;)
+            if (idle[i].second == words) { uint32_t* q = idle[i].first; idle.erase(idle.begin() + (long)i); bytes -= words * 4; return q; }
+        return nullptr;
+    }
+    void give(uint32_t* q, size_t words) {
+        {
+            std::lock_guard<std::mutex> lk(mu);
+            if (bytes + words * 4 <= POOL_CAP) { idle.emplace_back(q, words); bytes += words * 4; return; }
+        }
+        std::free(q);
+    }
+    void clear() {
+        std::vector<std::pair<uint32_t*, size_t>> all;
+        { std::lock_guard<std::mutex> lk(mu); all.swap(idle); bytes = 0; }
+        for (auto& e : all) std::free(e.first);
+    }
+};
+inline WordPool& word_pool() { static WordPool* pool = new WordPool(); return *pool; }       // (never destroyed: a recycling thread may outlive main)
 struct ZeroedWords {
     uint32_t* p = nullptr; size_t n = 0;
     ZeroedWords() = default;
     ZeroedWords(const ZeroedWords&) = delete;
     ZeroedWords& operator=(const ZeroedWords&) = delete;
     ~ZeroedWords() { std::free(p); }
-    bool reset(size_t words) { std::free(p); p = (uint32_t*)std::calloc(words ? words : 1, 4); n = p ? words : 0; return p != nullptr; }
+    bool reset(size_t words) {
+        std::free(p);
+        const size_t w = words ? words : 1;
+        p = w >= ((size_t)1 << 18) ? word_pool().take(w) : nullptr;          // (blocks of a megabyte and more are worth keeping)
+        if (!p) p = (uint32_t*)std::calloc(w, 4);
+        n = p ? words : 0;
+        return p != nullptr;
+    }
     uint32_t* data() { return p; }
     const uint32_t* data() const { return p; }
     size_t size() const { return n; }
+    std::pair<uint32_t*, size_t> release() { const std::pair<uint32_t*, size_t> r{p, n ? n : 1}; p = nullptr; n = 0; return r; }
 };
+// the tables of a finished call: zeroed and pooled (the large ones) or freed (the small ones) on a thread of their own
+inline void recycle_later(std::vector<std::pair<uint32_t*, size_t>> blocks) {
+    auto job = [blocks] {
+        for (const auto& b : blocks) {
+            if (!b.first) continue;
+            if (b.second >= ((size_t)1 << 18)) { std::memset(b.first, 0, b.second * 4); word_pool().give(b.first, b.second); }
+            else std::free(b.first);
+        }
+    };
+    try { std::thread(job).detach(); } catch (...) { for (const auto& b : blocks) std::free(b.first); }
+}
 struct HostTables {
     ZeroedWords sc, op, rs, q, ts, sm, evl;       // SCALARS, OPENED, ROWSUM, QUERY, TS, SAMPLES (and, air mode, EVAL) main traces (all proofs)
     HostSpan desc, data, chain_in, trows;                   // P2R: chains, their data, the transcript rows' input states and row numbers -- consecutive slices of ONE pinned block
@@ -1133,6 +1181,8 @@ int fill_one(const Shape& sh, const Machine& m, int p, const uint8_t* inner, siz
 }
 }  // namespace
 }  // namespace rec
+// (zkhip_release_cached_contexts, jobs.cpp: the pooled host tables go with the pooled contexts)
+void rec_release_host_tables() { rec::word_pool().clear(); }
 }  // namespace zk
 
 static int shard_verifier_prove_impl(zkhip_ctx* ctx, const zkhip_machine_key* key, const uint32_t* program, size_t program_words, const uint8_t* const* inner, const size_t* inner_len,
@@ -1264,6 +1314,7 @@ static int shard_verifier_prove_impl(zkhip_ctx* ctx, const zkhip_machine_key* ke
     lap("upload: host tables");
     const int rc = zkhip_prove_machine_keyed(ctx, key, chips, m.progs, m.prog_words, m.tabs, m.tab_words, m.n, pv.data(), pv.size(), outer, proof, cap, len);
     lap("the machine's proof");
+    recycle_later({ht.sc.release(), ht.op.release(), ht.rs.release(), ht.q.release(), ht.ts.release(), ht.sm.release(), ht.evl.release()});
     return rc;
 }
 
