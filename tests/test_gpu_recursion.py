@@ -316,3 +316,27 @@ def test_a_batch_of_joins_of_one_shape_is_the_joins_one_by_one(ctx, in_flight):
     assert vk3.tolist() == key3.root.tolist() and vk3.tolist() != vk.tolist() and len(joins3) == 2
     assert joins3[1].tobytes() == ctx.prove_shard_verifier(key3, inner[3:], log_n, width, pubs[3:], iprm, Params(2, 10, 4)).tobytes()
     key.close(), key3.close()
+
+
+def test_host_tables_kept_between_calls_start_from_zero(ctx):
+    """the recursion provers keep their large host tables between calls (zeroed again on a thread of their own, csrc/shard_verifier.inl WordPool): a join
+    made with tables that served ANOTHER set of shard proofs is the join made with fresh pages, byte for byte"""
+    import time
+    from zktls_amd import _lib
+    log_n, width, q, pb, n = 12, 128, 100, 8, 16
+    iprm, prm = Params(1, q, pb), Params(1, 20, 8)
+    sets = []
+    for k in range(2):
+        pubs = [[k, 7, s] for s in range(n)]
+        sets.append((pubs, [ctx.prove_shard(ctx.gen_trace(SEED, 700 + 100 * k + s, log_n, width), log_n, width, pubs[s], iprm) for s in range(n)]))
+    key = ctx.shard_verifier_setup(log_n, width, q, pb, 3, prm, n_proofs=n)
+    _lib.load().zkhip_release_cached_contexts()                              # (empties the pool: the first call below takes fresh pages)
+    fresh = ctx.prove_shard_verifier(key, sets[0][1], log_n, width, sets[0][0], iprm, prm)
+    time.sleep(0.5)                                                           # (the recycling thread zeroes and parks the tables)
+    other = ctx.prove_shard_verifier(key, sets[1][1], log_n, width, sets[1][0], iprm, prm)
+    time.sleep(0.5)
+    again = ctx.prove_shard_verifier(key, sets[0][1], log_n, width, sets[0][0], iprm, prm)
+    assert again.tobytes() == fresh.tobytes() and other.tobytes() != fresh.tobytes()
+    for proof, (pubs, _) in ((again, sets[0]), (other, sets[1])):
+        assert verify_shard_recursive(proof, log_n, width, q, pb, [v for p in pubs for v in p], key.root, prm, n_proofs=n) == (0, 0)
+    key.close()
