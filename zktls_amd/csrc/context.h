@@ -170,6 +170,7 @@ int dev_d2h(zkhip_ctx* ctx, void* dst, const void* src, size_t bytes);
 int dev_h2d(zkhip_ctx* ctx, void* dst, const void* src, size_t bytes);
 int dev_memset(zkhip_ctx* ctx, void* dst, int byte, size_t bytes);
 int lockstep_batch();
+uint64_t lockstep_max_cells();
 int lockstep_lanes();
 void lockstep_set(int max_batch, int lanes);
 // trace cells of a proof that still counts as small.  Measured as launch-bound (lock-step pays): the 13 KB transcript machine (2^14 x 608 +

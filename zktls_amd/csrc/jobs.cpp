@@ -134,6 +134,13 @@ int deal_jobs(const int* devices, int n_devices, int n_jobs, int in_flight, cons
 // lock-step batches (batch.h): members per batch (0 / 1: off) and batches in flight per device; process-wide
 static std::atomic<int> g_lockstep_batch{16}, g_lockstep_lanes{6};
 int lockstep_batch() { return g_lockstep_batch.load(); }
+// the largest member (trace cells) that still goes through the lock-step lanes
+uint64_t lockstep_max_cells() {
+#ifdef ZKHIP_AB_HOOKS
+    if (const char* e = getenv("ZKHIP_LOCKSTEP_MAX_CELLS")) return strtoull(e, nullptr, 0);
+#endif
+    return LOCKSTEP_MAX_CELLS;
+}
 int lockstep_lanes() { return g_lockstep_lanes.load(); }
 void lockstep_set(int max_batch, int lanes) {
     g_lockstep_batch.store(max_batch < 0 ? 0 : (max_batch > LaunchBatcher::MAX_MEMBERS ? LaunchBatcher::MAX_MEMBERS : max_batch));
@@ -414,7 +421,7 @@ static int prove_shards_on(const int* devices, int n_devices, zkhip_shard_job* j
     uint64_t max_cells = 0;
     for (int i = 0; i < n_jobs && small; i++) {
         const zkhip_shard_job& j = jobs[i];
-        if (j.log_n < 1 || j.log_n > 24 || j.width == 0 || ((uint64_t)j.width << j.log_n) > LOCKSTEP_MAX_CELLS) { small = false; break; }
+        if (j.log_n < 1 || j.log_n > 24 || j.width == 0 || ((uint64_t)j.width << j.log_n) > lockstep_max_cells()) { small = false; break; }
         shape[(size_t)i] = (int)(((uint32_t)j.log_n << 24) ^ j.width);
         const uint64_t cells = ((uint64_t)j.width << j.log_n) << (prm->log_blowup > 1 ? prm->log_blowup - 1 : 0);
         if (cells > max_cells) max_cells = cells;
