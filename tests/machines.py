@@ -148,3 +148,47 @@ def sha256_machine(message):
     if sha_t.shape[0] <= 1 << 16:
         chips.reverse()
     return [c[0] for c in chips], [c[1] for c in chips], [c[2] for c in chips], [c[3] for c in chips], list(pub)
+
+
+BUS_SP1 = 300
+
+
+def sp1_shaped_spec(spec):
+    """spec: [(log_n, width, pairs, partner)] tallest first; partner = index of the chip of EQUAL height whose sender groups this chip's receiver
+    groups hold (-1: the pairs are in-table).  -> per chip the interaction list: pair q sends the (a, b) of column group 2q and receives at group
+    2q + 1 -- on a bus of the chip's own for an in-table pair, and for a cross pair the sender's bus (chip c sends on BUS_SP1 + 16 c + q, its
+    partner receives there), so that the two tables' cumulative sums cancel instead of vanishing one by one (SP1's cross-table lookups)."""
+    inter = []
+    for c, (ln, w, pairs, partner) in enumerate(spec):
+        assert w % 4 == 0 and 8 * pairs <= w and pairs <= 16
+        it = []
+        for q in range(pairs):
+            it.append((O.SEND, None, BUS_SP1 + 16 * c + q, [8 * q, 8 * q + 1]))
+            src = c if partner < 0 else partner
+            it.append((O.RECEIVE, None, BUS_SP1 + 16 * src + q, [8 * q + 4, 8 * q + 5]))
+        if partner >= 0:
+            assert spec[partner][0] == ln and spec[partner][3] == c and spec[partner][2] == pairs, "cross pairs come in two tables of one height that look each other up"
+        inter.append(it)
+    return inter
+
+
+def sp1_shaped_machine(spec, seed=1, shard=0, pre=(), n_public=3, key_shard=9999):
+    """SP1's shard structure as a KEYED machine (proof version 11): chips of mixed heights, each under the synthetic AIR (as a constraint program)
+    on traces of orc_gen_trace_logup / _cross, in-table LogUp pairs and a cross-table bus between two chips of one height, and preprocessed
+    leading columns on the chips listed in `pre` ((chip, columns), ...).  The chip streams are seed + 100 shard + chip; the preprocessed
+    columns come from the stream of shard `key_shard`, so every shard is proven against ONE key (zktls_amd.device.Sp1ShapedShard does the same
+    on the device).  -> (main traces, preprocessed traces or None, programs, tables, public values)"""
+    inter = sp1_shaped_spec(spec)
+    pw = dict(pre)
+
+    def gen(c, sh):
+        ln, w, pairs, partner = spec[c]
+        if partner < 0:
+            return O.gen_trace_logup(seed, 100 * sh + c, ln, w, pairs)
+        return O.gen_trace_logup_cross(seed, 100 * sh + c, 100 * sh + partner, ln, w, spec[partner][1], pairs)
+    traces = [gen(c, shard) for c in range(len(spec))]
+    progs = [O.air_synthetic(w, n_public) for _, w, _, _ in spec]
+    tabs = [O.interaction_table(it) if it else None for it in inter]
+    pres = [np.ascontiguousarray(gen(c, key_shard)[:, :pw[c]]) if pw.get(c) else None for c in range(len(spec))]
+    mains = [np.ascontiguousarray(t[:, pw.get(c, 0):]) for c, t in enumerate(traces)]
+    return mains, pres, progs, tabs, [(11 * (i + 1)) % P for i in range(n_public - 1)] + [shard]

@@ -291,3 +291,85 @@ def test_the_tree_in_one_call_is_the_joins_and_the_top_made_one_by_one(ctx, in_f
     with pytest.raises(ZkHipError):
         prove_shard_tree(ctx, tkey, other, shards, 2, log_n, width, pubs, iprm, jprm, tprm, devices=[0])          # (a join machine with another key: its tables reject the joins)
     jkey.close(), tkey.close()
+
+
+# ---------------------------------------------------------------------------------------------------------------- SP1's shard structure, core -> compress
+SP1_SMALL = [(8, 24, 3, 1), (8, 32, 3, 0), (7, 16, 2, -1), (6, 32, 2, -1), (5, 8, 1, -1)]
+
+
+def sp1_shards(ctx, shape, seed, shards, prm):
+    """-> (key, inner machine, [proof], [public values]) for the listed shards of one SP1-shaped machine, proven on the device"""
+    key, keep = shape.setup(ctx, seed, prm)
+    proofs, pubs = [], []
+    for s in shards:
+        traces = shape.gen_traces(ctx, seed, s)
+        pv = [(11 * (i + 1)) % R.P for i in range(shape.n_public - 1)] + [s]
+        proofs.append(ctx.prove_machine_keyed(key, shape.main_chips(traces), shape.programs, shape.tables, pv, prm))
+        pubs.append(pv)
+        for t in traces:
+            t.free()
+    return key, keep, shape.inner_machine(key.root, prm), proofs, pubs
+
+
+def test_the_sp1_shaped_shard_core_to_compress_bytes_equal_the_oracles(ctx, oracle):
+    """VERDICT r5 item 3 at a small shape: three shards of SP1's structure (five chips of four heights, in-table LogUp pairs, a cross-table bus, preprocessed
+    columns) proven on the device as version-11 proofs of ONE keyed machine -- key and bytes == the oracle's on tests/machines.py's traces --, joined in machine
+    mode: the join's key and bytes == the oracle's on the restatement's arrays; accepted from (description, public values, key); the shards swapped: refused"""
+    from zktls_amd.device import Sp1ShapedShard
+    O = oracle
+    q, pb, seed = 3, 1, 5
+    iprm, oiprm = Params(1, q, pb), O.default_params(1, q, pb)
+    shape = Sp1ShapedShard(SP1_SMALL, ((3, 8),), 3)
+    key, keep, im, proofs, pubs = sp1_shards(ctx, shape, seed, [0, 1, 2], iprm)
+    for s in range(3):
+        mains, pres, progs, tabs, pub = M.sp1_shaped_machine(SP1_SMALL, seed=seed, shard=s, pre=((3, 8),))
+        assert pub == pubs[s]
+        lns = [m.shape[0].bit_length() - 1 for m in mains]
+        assert key.root.tolist() == O.machine_setup(pres, lns, oiprm).tolist(), "the shard machine's key differs from the oracle's"
+        assert proofs[s].tobytes() == O.prove_machine_keyed(mains, pres, progs, tabs, pub, oiprm).tobytes(), "shard %d: proof bytes differ from the oracle's" % s
+    prm, oprm = Params(1, 20, 8), O.default_params(1, 20, 8)
+    tkey = ctx.machine_verifier_setup(im, prm, 3)
+    top = ctx.prove_machine_verifier(tkey, im, proofs, pubs, prm)
+    chips = [dict(ln=ln, W=w, Pw=pw, prog=g, tab=t) for ln, w, pw, g, t in zip(shape.log_ns, shape.widths, shape.pre_widths, shape.programs, shape.tables)]
+    sh, mains, pres, progs, tabs, pv = RM.machine(chips, [int(x) for x in key.root], [p.tobytes() for p in proofs], pubs, q, pb)
+    lns = [m.shape[0].bit_length() - 1 for m in mains]
+    assert tkey.root.tolist() == O.machine_setup(pres, lns, oprm).tolist(), "the join's key differs from the oracle's commitment to the restatement's preprocessed traces"
+    assert machine_verifier_key_host(im, prm, 3).tolist() == tkey.root.tolist()
+    assert top.tobytes() == O.prove_machine_keyed(mains, pres, progs, tabs, pv, oprm).tobytes(), "the join's bytes differ from the oracle's"
+    flat = pubs[0] + pubs[1] + pubs[2]
+    assert pv == flat and verify_machine_recursive(im, top, flat, tkey.root, prm, 3) == (0, 0)
+    assert verify_machine_recursive(im, top, pubs[1] + pubs[0] + pubs[2], tkey.root, prm, 3)[0] != 0
+    with pytest.raises(ZkHipError):                                             # the shard PROOFS swapped under the stated order
+        ctx.prove_machine_verifier(tkey, im, [proofs[1], proofs[0], proofs[2]], pubs, prm)
+    key.close(), tkey.close()
+
+
+def test_sp1_shaped_shards_at_the_bench_size_join_and_top(ctx, oracle):
+    """the bench's six-chip shard (2^20 x 96, 2^20 x 32 looking each other up, 2^19 x 64, 2^18 x 128, 2^16 x 256 with 32 preprocessed columns, 2^14 x 40;
+    LogUp pairs 3, 3, 2, 4, 8, 1) as a keyed machine: four shard proofs accepted by the oracle's verifier and the host's, joined two by two in machine
+    mode, the two joins topped -- the top checked from (the join machine's description, the four shards' public values, the key derived on the host)"""
+    from zktls_amd.device import Sp1ShapedShard, verify_machine_keyed
+    O = oracle
+    prm, oprm = Params(1, 100, 16), O.default_params(1, 100, 16)
+    shape = Sp1ShapedShard()
+    key, keep, im, proofs, pubs = sp1_shards(ctx, shape, SEED, [0, 1, 2, 3], prm)
+    widths = shape.widths
+    for s in (0, 3):
+        assert O.verify_machine_keyed(proofs[s], shape.log_ns, widths, shape.pre_widths, key.root, shape.programs, shape.tables, pubs[s], oprm) == 0, "the oracle refuses shard %d" % s
+    for s in range(4):
+        assert verify_machine_keyed(proofs[s], shape.log_ns, widths, shape.pre_widths, key.root, shape.programs, shape.tables, pubs[s], prm) == (0, 0)
+    assert verify_machine_keyed(proofs[1], shape.log_ns, widths, shape.pre_widths, key.root, shape.programs, shape.tables, pubs[2], prm)[0] != 0
+    jkey = ctx.machine_verifier_setup(im, prm, 2)
+    joins = [ctx.prove_machine_verifier(jkey, im, proofs[2 * j:2 * j + 2], pubs[2 * j:2 * j + 2], prm) for j in range(2)]
+    jpubs = [pubs[0] + pubs[1], pubs[2] + pubs[3]]
+    for j in range(2):
+        assert verify_machine_recursive(im, joins[j], jpubs[j], jkey.root, prm, 2) == (0, 0)
+    assert verify_machine_recursive(im, joins[0], jpubs[1], jkey.root, prm, 2)[0] != 0
+    chips2, im2 = described_machine(im, 2, jkey.root, 100, 16, 2 * shape.n_public)
+    tkey = ctx.machine_verifier_setup(im2, prm, 2)
+    top = ctx.prove_machine_verifier(tkey, im2, joins, jpubs, prm)
+    flat = jpubs[0] + jpubs[1]
+    assert verify_machine_recursive(im2, top, flat, machine_verifier_key_host(im2, prm, 2), prm, 2) == (0, 0)
+    assert verify_machine_recursive(im2, top, jpubs[1] + jpubs[0], tkey.root, prm, 2)[0] != 0
+    print("SP1-shaped shards: 4 x %d B -> 2 joins %d B -> top %d B" % (proofs[0].size, sum(j.size for j in joins), top.size))
+    key.close(), jkey.close(), tkey.close()

@@ -230,3 +230,51 @@ def test_descriptions_the_machine_does_not_take_are_refused():
     garbage = np.arange(40, dtype=np.uint32)
     refused([dict(chips[0], prog=garbage)] + chips[1:])
     refused([dict(chips[0], tab=garbage)] + chips[1:])
+
+
+# ---------------------------------------------------------------------------------------------------------------- SP1's shard structure, core -> compress
+SP1_SMALL = [(8, 24, 3, 1), (8, 32, 3, 0), (7, 16, 2, -1), (6, 32, 2, -1), (5, 8, 1, -1)]
+
+
+def test_the_sp1_shaped_shard_is_joinable(oracle):
+    """VERDICT r5 item 3 on the CPU: shards of SP1's structure -- chips of mixed heights, in-table LogUp pairs, a cross-table bus between two chips of one
+    height, preprocessed columns -- as version-11 proofs of ONE keyed machine; the machine-mode machine over two of them holds row by row, its buses
+    balance, the oracle proves it and accepts it from (the machine's description, the shards' public values, the key), and refuses the shards swapped"""
+    O = oracle
+    q, pb = 2, 1
+    made = [M.sp1_shaped_machine(SP1_SMALL, seed=5, shard=s, pre=((3, 8),)) for s in (0, 1)]
+    for mains, pres, progs, tabs, pub in made:                                  # the shards themselves: rows hold, buses balance (the cross pair only across its two tables)
+        assert R.bus_balance(mains, pres, tabs) == []
+        for m, p, g in zip(mains, pres, progs):
+            assert S.check_rows(g, m if p is None else np.concatenate([p, m], axis=1), pub) == []
+    lone = [made[0][0][0]], [None], [made[0][2][0]], [made[0][3][0]]
+    assert R.bus_balance(lone[0], lone[1], lone[3]) != [], "a table of a cross pair balances on its own"
+    chips, vk, p0 = inner(O, *made[0], q=q, pb=pb)
+    _, vk1, p1 = inner(O, *made[1], q=q, pb=pb)
+    assert vk == vk1                                                            # ONE key for every shard: the preprocessed columns are the program's, not the shard's
+    pubs = [made[0][4], made[1][4]]
+    sh, mains, pres, progs, tabs, pv = RM.machine(chips, vk, [p0, p1], pubs, q, pb)
+    holds(sh, mains, pres, progs, tabs, pv)
+    lns, ws, pws = [m.shape[0].bit_length() - 1 for m in mains], [m.shape[1] for m in mains], [0 if p is None else p.shape[1] for p in pres]
+    prm = O.default_params(1, 3, 1)
+    key = O.machine_setup(pres, lns, prm)
+    top = O.prove_machine_keyed(mains, pres, progs, tabs, pv, prm)
+    assert pv == pubs[0] + pubs[1]
+    assert O.verify_machine_keyed(top, lns, ws, pws, key, progs, tabs, pv, prm) == 0
+    assert O.verify_machine_keyed(top, lns, ws, pws, key, progs, tabs, pubs[1] + pubs[0], prm) != 0
+    other = M.sp1_shaped_machine(SP1_SMALL, seed=5, shard=1, pre=((3, 8),), key_shard=77)
+    _, vk2, p2 = inner(O, *other, q=q, pb=pb)
+    assert vk2 != vk
+    with pytest.raises(Exception):                                              # a shard proof of another key's machine: the restatement's own verification refuses it
+        RM.machine(chips, vk, [p0, p2], pubs, q, pb)
+
+
+def test_the_sp1_shaped_machine_of_the_library_is_the_tests(oracle):
+    """zktls_amd.device.Sp1ShapedShard (what bench.py and the GPU tests prove) describes the machine tests/machines.py builds: programs, tables, widths"""
+    from zktls_amd.device import Sp1ShapedShard
+    s = Sp1ShapedShard(SP1_SMALL, ((3, 8),), 3)
+    mains, pres, progs, tabs, pub = M.sp1_shaped_machine(SP1_SMALL, seed=5, shard=0, pre=((3, 8),))
+    assert all(np.array_equal(a, b) for a, b in zip(s.programs, progs)) and all(np.array_equal(a, b) for a, b in zip(s.tables, tabs))
+    assert s.widths == [m.shape[1] for m in mains] and s.pre_widths == [0 if p is None else p.shape[1] for p in pres]
+    full = Sp1ShapedShard()
+    assert full.cells == sum(w << ln for ln, w in [(20, 96), (20, 32), (19, 64), (18, 128), (16, 256), (14, 40)])      # bench.py's multichip shard

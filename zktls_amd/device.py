@@ -61,6 +61,14 @@ class DeviceBuffer:
             pass
 
 
+class DeviceView:
+    """words of a DeviceBuffer from an offset on (a column slice of a row-major matrix is a view with the matrix's row pitch)"""
+
+    def __init__(self, buf, words):
+        self.base = buf
+        self.ptr = buf.ptr + 4 * int(words)
+
+
 class Context:
     def __init__(self, device=0, stream=None):
         self.lib = _lib.load()
@@ -589,7 +597,7 @@ class Context:
         (.root: the 8 canonical words a verifier needs; .pre_widths)"""
         params = params or Params(1, 100, 16, 0)
         n = len(pre_chips)
-        arr = (_lib.Chip * n)(*[_lib.Chip(b.ptr if b is not None else None, w, ln, w, 0, -1) for b, ln, w in pre_chips])
+        arr = (_lib.Chip * n)(*[_lib.Chip(c[0].ptr if c[0] is not None else None, c[3] if len(c) > 3 else c[2], c[1], c[2], 0, -1) for c in pre_chips])      # (buffer, log_n, width[, row pitch])
         handle = C.c_void_p()
         root = np.zeros(8, dtype=np.uint32)
         check(self.lib.zkhip_machine_setup(self.handle, arr, n, C.byref(params), C.byref(handle), root.ctypes.data_as(u32p)))
@@ -743,7 +751,7 @@ class Context:
         key holds tables only (zkhip_prove_machine_keyed_at); its preprocessed widths then come from the entries"""
         params = params or Params(1, 100, 16, 0)
         n = len(chips)
-        arr = (_lib.Chip * n)(*[_lib.Chip(b.ptr, w, ln, w, 0, -1) for b, ln, w in chips])
+        arr = (_lib.Chip * n)(*[_lib.Chip(c[0].ptr, c[3] if len(c) > 3 else c[2], c[1], c[2], 0, -1) for c in chips])      # (buffer, log_n, width[, row pitch])
         log_ns = (C.c_int32 * n)(*[c[1] for c in chips])
         widths = (C.c_uint32 * n)(*[c[2] for c in chips])
         if key_entries is not None:
@@ -1183,6 +1191,76 @@ def prove_shard_tree(ctx, top_key, join_machine, shard_proofs, proofs_per_join, 
                                      pv.ctypes.data_as(u32p), n_public, C.byref(inner), C.byref(join_outer), C.byref(top_outer), in_flight, jbuf.ctypes.data_as(u8p), jsize, jlens,
                                      jvk.ctypes.data_as(u32p), top.ctypes.data_as(u8p), tsize, C.byref(got)))
     return top[: got.value], [jbuf[j, : jlens[j]] for j in range(n_joins)], jvk
+
+
+LKUP_MAGIC, LKUP_SEND, LKUP_RECEIVE = 0x50554B4C, 0, 1
+
+
+def interaction_table(interactions):
+    """[(LKUP_SEND | LKUP_RECEIVE, multiplicity column or None for the constant 1, bus, [value columns]), ...] -> the flat u32 table of include/zkhip.h"""
+    body = []
+    for sign, mult, bus, cols in interactions:
+        body += [sign, 0xFFFFFFFF if mult is None else mult, bus % _lib.P, len(cols)] + list(cols)
+    return np.array([LKUP_MAGIC, len(interactions), 3 + len(body)] + body, dtype=np.uint32)
+
+
+SP1_SHAPED_SPEC = ((20, 96, 3, 1), (20, 32, 3, 0), (19, 64, 2, -1), (18, 128, 4, -1), (16, 256, 8, -1), (14, 40, 1, -1))
+SP1_SHAPED_PRE = ((4, 32),)
+BUS_SP1 = 300
+
+
+class Sp1ShapedShard:
+    """SP1's shard structure as a KEYED machine (proof version 11; sp1-core-machine's shards, reference Cargo.lock:5822): chips of mixed heights
+    (spec: (log_n, width, LogUp pairs, partner) tallest first), each under the synthetic AIR as a constraint program, pair q of a chip sends the
+    (a, b) of column group 2q and receives at group 2q + 1 -- in-table (partner -1), or ACROSS two tables of one height that look each other up
+    (chip c sends on bus BUS_SP1 + 16 c + q, its partner receives there: the two cumulative sums cancel) --, and preprocessed leading columns
+    on the chips of `pre` ((chip, columns), ...: what setup commits once, sp1.rs:113).  Traces are generated on the device
+    (zkhip_gen_trace_logup / _cross, stream seed + 100 shard + chip)."""
+
+    def __init__(self, spec=SP1_SHAPED_SPEC, pre=SP1_SHAPED_PRE, n_public=9):
+        self.spec, self.pre, self.n_public = [tuple(c) for c in spec], dict(pre), int(n_public)
+        self.programs = [air_synthetic(w, n_public) for _, w, _, _ in self.spec]
+        self.tables = []
+        for c, (ln, w, pairs, partner) in enumerate(self.spec):
+            it = []
+            for q in range(pairs):
+                it.append((LKUP_SEND, None, BUS_SP1 + 16 * c + q, [8 * q, 8 * q + 1]))
+                it.append((LKUP_RECEIVE, None, BUS_SP1 + 16 * (c if partner < 0 else partner) + q, [8 * q + 4, 8 * q + 5]))
+            self.tables.append(interaction_table(it) if it else None)
+        self.log_ns = [c[0] for c in self.spec]
+        self.pre_widths = [self.pre.get(c, 0) for c in range(len(self.spec))]
+        self.widths = [w - pw for (_, w, _, _), pw in zip(self.spec, self.pre_widths)]                  # main widths
+        self.cells = sum(w << ln for ln, w, _, _ in self.spec)
+
+    def gen_traces(self, ctx, seed, shard):
+        """-> the full traces [pre | main] of one shard as DeviceBuffers"""
+        out = []
+        for c, (ln, w, pairs, partner) in enumerate(self.spec):
+            if partner < 0:
+                out.append(ctx.gen_trace_logup(seed, 100 * shard + c, ln, w, pairs))
+            else:
+                out.append(ctx.gen_trace_logup_cross(seed, 100 * shard + c, 100 * shard + partner, ln, w, self.spec[partner][1], pairs))
+        return out
+
+    def main_chips(self, traces):
+        """the chips argument of Context.prove_machine_keyed: the main columns as views of the full traces"""
+        return [(DeviceView(t, pw), ln, w, w + pw) for t, ln, w, pw in zip(traces, self.log_ns, self.widths, self.pre_widths)]
+
+    KEY_SHARD = 9999
+
+    def setup(self, ctx, seed, params=None):
+        """the key (zkhip_machine_setup) over the preprocessed columns: the leading columns of the chips of `pre`, generated from a stream of their
+        own (shard KEY_SHARD) so that every shard of the execution is proven against ONE key, as a program's shards are.  -> (key, the traces it views)"""
+        keep = []
+        for c, (ln, w, pairs, partner) in enumerate(self.spec):
+            keep.append(ctx.gen_trace_logup(seed, 100 * self.KEY_SHARD + c, ln, w, pairs) if self.pre_widths[c] else None)
+            assert not (self.pre_widths[c] and (partner >= 0 or self.pre_widths[c] % 8)), "preprocessed columns: whole in-table pairs"
+        return ctx.machine_setup([(t, ln, pw, (w + pw) if pw else 0) for t, ln, w, pw in zip(keep, self.log_ns, self.widths, self.pre_widths)], params), keep
+
+    def inner_machine(self, key_root, params=None):
+        params = params or Params(1, 100, 16, 0)
+        chips = [dict(ln=ln, W=w, Pw=pw, prog=g, tab=t) for ln, w, pw, g, t in zip(self.log_ns, self.widths, self.pre_widths, self.programs, self.tables)]
+        return InnerMachine(chips, key_root, params.num_queries, params.pow_bits, self.n_public)
 
 
 def set_lockstep(max_batch, lanes=0):
