@@ -29,12 +29,46 @@ static void hash_concat_row(const uint32_t* const* mats, const size_t* widths,
     free(buf);
 }
 
+/* rows r0 .. r0 + 7 of the selected matrices, concatenated, hashed eight at a time (poseidon2_x8.c); a single selected matrix is read in place */
+static void hash_concat_rows8(const uint32_t* const* mats, const size_t* widths, const int* sel, int nsel, size_t r0, uint32_t* const out[8]) {
+    size_t total = 0;
+    for (int k = 0; k < nsel; k++) total += widths[sel[k]];
+    const uint32_t* in[8];
+    uint32_t* buf = NULL;
+    if (nsel == 1) {
+        for (int l = 0; l < 8; l++) in[l] = mats[sel[0]] + (r0 + (size_t)l) * widths[sel[0]];
+    } else {
+        buf = (uint32_t*)malloc((total ? total : 1) * 8 * sizeof(uint32_t));
+        for (int l = 0; l < 8; l++) {
+            size_t pos = 0;
+            for (int k = 0; k < nsel; k++) {
+                int m = sel[k];
+                memcpy(buf + (size_t)l * total + pos, mats[m] + (r0 + (size_t)l) * widths[m], widths[m] * sizeof(uint32_t));
+                pos += widths[m];
+            }
+            in[l] = buf + (size_t)l * total;
+        }
+    }
+    orc_sponge_hash_x8(in, total, out);
+    free(buf);
+}
+static void hash_rows_range(const uint32_t* const* mats, const size_t* widths, const int* sel, int nsel, size_t n, uint32_t* digests) {
+    const size_t n8 = orc_simd_enabled() ? n / 8 : 0;
+#pragma omp parallel for schedule(static)
+    for (size_t b = 0; b < n8; b++) {
+        uint32_t* out[8];
+        for (int l = 0; l < 8; l++) out[l] = digests + 8 * (8 * b + (size_t)l);
+        hash_concat_rows8(mats, widths, sel, nsel, 8 * b, out);
+    }
+#pragma omp parallel for schedule(static)
+    for (size_t r = 8 * n8; r < n; r++) hash_concat_row(mats, widths, sel, nsel, r, digests + 8 * r);
+}
+
 void orc_hash_rows(const uint32_t* const* mats, const size_t* widths, int nmats,
                    size_t height, uint32_t* digests) {
     int sel[64];
     for (int i = 0; i < nmats; i++) sel[i] = i;
-#pragma omp parallel for schedule(static)
-    for (size_t r = 0; r < height; r++) hash_concat_row(mats, widths, sel, nmats, r, digests + 8 * r);
+    hash_rows_range(mats, widths, sel, nmats, height, digests);
 }
 
 void orc_merkle_tree_mixed(const uint32_t* const* mats, const size_t* widths,
@@ -44,16 +78,31 @@ void orc_merkle_tree_mixed(const uint32_t* const* mats, const size_t* widths,
     int sel[64], nsel = 0;
     for (int i = 0; i < nmats; i++) if (log_heights[i] == log_h) sel[nsel++] = i;
     size_t n = (size_t)1 << log_h;
-#pragma omp parallel for schedule(static)
-    for (size_t r = 0; r < n; r++) hash_concat_row(mats, widths, sel, nsel, r, tree + 8 * r);
+    hash_rows_range(mats, widths, sel, nsel, n, tree);
     uint32_t* prev = tree;
     for (int lvl = log_h - 1; lvl >= 0; lvl--) {
         size_t cnt = (size_t)1 << lvl;
         uint32_t* cur = prev + 16 * cnt;   /* prev has 2*cnt digests */
         nsel = 0;
         for (int i = 0; i < nmats; i++) if (log_heights[i] == lvl) sel[nsel++] = i;
+        const size_t c8 = orc_simd_enabled() ? cnt / 8 : 0;
 #pragma omp parallel for schedule(static)
-        for (size_t i = 0; i < cnt; i++) {
+        for (size_t b = 0; b < c8; b++) {
+            const uint32_t *l8[8], *r8[8];
+            uint32_t* o8[8];
+            for (int l = 0; l < 8; l++) { const size_t i = 8 * b + (size_t)l; l8[l] = prev + 16 * i; r8[l] = prev + 16 * i + 8; o8[l] = cur + 8 * i; }
+            orc_compress_x8(l8, r8, o8);
+            if (nsel) {
+                uint32_t rh[8][8];
+                uint32_t* rp[8];
+                const uint32_t* rc[8];
+                for (int l = 0; l < 8; l++) { rp[l] = rh[l]; rc[l] = rh[l]; l8[l] = o8[l]; }
+                hash_concat_rows8(mats, widths, sel, nsel, 8 * b, rp);
+                orc_compress_x8(l8, rc, o8);
+            }
+        }
+#pragma omp parallel for schedule(static)
+        for (size_t i = 8 * c8; i < cnt; i++) {
             orc_compress(prev + 16 * i, prev + 16 * i + 8, cur + 8 * i);
             if (nsel) {
                 uint32_t rh[8];

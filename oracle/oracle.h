@@ -51,6 +51,10 @@ void orc_poseidon2_permute(uint32_t state[16]);
 void orc_sponge_hash(const uint32_t* in, size_t n, uint32_t out[8]);
 /* TruncatedPermutation<2,8,16>: permute(left || right)[0..8]. */
 void orc_compress(const uint32_t left[8], const uint32_t right[8], uint32_t out[8]);
+/* the same eight at a time (poseidon2_x8.c: AVX-512 lanes behind a start-up self-check against the scalar functions; scalar otherwise) */
+int orc_simd_enabled(void);
+void orc_sponge_hash_x8(const uint32_t* const in[8], size_t n, uint32_t* const out[8]);
+void orc_compress_x8(const uint32_t* const left[8], const uint32_t* const right[8], uint32_t* const out[8]);
 
 /* ---- width 24 (RISC Zero's Poseidon2 shape) ---- */
 void orc_poseidon2_24_permute(uint32_t state[24]);

@@ -37,18 +37,18 @@ def big_oracle(oracle):
     oracle.set_threads(prev)
 
 
-def test_config1_fullsize_proof_bytes_equal_the_oracles(ctx, big_oracle):
-    O = big_oracle
-    pv = [1, 2, 3]
-    trace = ctx.gen_trace(SEED, 7, LOG_N, WIDTH)
+def test_config1_fullsize_proof_bytes_equal_the_oracles(ctx, oracle_shard_proof):
+    """(the shard is shard 31 of configs[2]'s batch below: ONE oracle proof of it serves both tests -- conftest.oracle_shard_proof)"""
+    pv = [9, 8, 7, 31]
+    trace = ctx.gen_trace(SEED, 1031, LOG_N, WIDTH)
     proof = ctx.prove_shard(trace, LOG_N, WIDTH, pv, Params(1, 100, 16))
     trace.free()
-    oproof = O.prove_shard(O.gen_trace(SEED, 7, LOG_N, WIDTH), pv, O.default_params(1, 100, 16))
-    assert proof.size == oproof.size == 953076
-    assert proof.tobytes() == oproof.tobytes(), "2^20 x 256 proof bytes differ from the oracle's"
+    oproof = oracle_shard_proof(SEED, 1031, LOG_N, WIDTH, pv)
+    assert proof.size == len(oproof) == 953076
+    assert proof.tobytes() == oproof, "2^20 x 256 proof bytes differ from the oracle's"
 
 
-def test_config2_batch_of_64_shards_in_one_call(ctx, big_oracle):
+def test_config2_batch_of_64_shards_in_one_call(ctx, big_oracle, oracle_shard_proof):
     O = big_oracle
     n_shards = 64
     prm, oprm = Params(1, 100, 16), O.default_params(1, 100, 16)
@@ -61,9 +61,8 @@ def test_config2_batch_of_64_shards_in_one_call(ctx, big_oracle):
     for s, p in enumerate(proofs):
         assert O.verify_shard(p, LOG_N, WIDTH, pvs[s], oprm) == 0, "oracle verifier rejects shard %d" % s
     assert O.verify_shard(proofs[5], LOG_N, WIDTH, pvs[6], oprm) != 0                       # bound to its own public values
-    for s in (0, 31, 63):
-        op = O.prove_shard(O.gen_trace(SEED, 1000 + s, LOG_N, WIDTH), pvs[s], oprm)
-        assert proofs[s].tobytes() == op.tobytes(), "shard %d differs from the oracle's proof" % s
+    for s in (31, 63):                                                                      # (31: the oracle proof config1 made; 63: one of its own)
+        assert proofs[s].tobytes() == oracle_shard_proof(SEED, 1000 + s, LOG_N, WIDTH, pvs[s]), "shard %d differs from the oracle's proof" % s
     # the device-list entry: same shards, same bytes (one visible device here: every shard lands on it; with more devices the
     # traces would have to live where zkhip_shard_device puts the shard, see test_multi_device_* below)
     sub = list(range(0, n_shards, 8))
@@ -158,21 +157,21 @@ def test_config3_one_request_of_four_2_20_row_shards_through_the_host_mirror(big
 SEG_WIDTH = 128          # blowup 4: a 2^20 x 128 segment has the 2^22 x 128 LDE (2 GiB) of the headline shard
 
 
-def test_config4_segment_proof_bytes_equal_the_oracles(ctx, big_oracle):
+def test_config4_segment_proof_bytes_equal_the_oracles(ctx, oracle_shard_proof):
     """one 2^20-cycle segment in RISC Zero's shape (blowup 4, fold by 16, 256 final coefficients, 50 queries, Poseidon2 width 24):
-    proof bytes == the CPU oracle's.  The LDE of this shape takes the fused middle launch twice (four cosets)."""
+    proof bytes == the CPU oracle's.  The LDE of this shape takes the fused middle launch twice (four cosets).
+    (The segment is segment 2 of the four-segment call below: one oracle proof serves both tests.)"""
     from zktls_amd._lib import segment_params
-    O = big_oracle
-    pv = [4, 5, 6]
-    trace = ctx.gen_trace(SEED, 11, LOG_N, SEG_WIDTH)
+    pv = [3, 1, 4, 2]
+    trace = ctx.gen_trace(SEED, 2002, LOG_N, SEG_WIDTH)
     proof = ctx.prove_shard(trace, LOG_N, SEG_WIDTH, pv, segment_params())
     trace.free()
-    oproof = O.prove_shard(O.gen_trace(SEED, 11, LOG_N, SEG_WIDTH), pv, O.segment_params())
-    assert proof.size == oproof.size
-    assert proof.tobytes() == oproof.tobytes(), "2^20 x 128 segment proof bytes differ from the oracle's"
+    oproof = oracle_shard_proof(SEED, 2002, LOG_N, SEG_WIDTH, pv, "r0")
+    assert proof.size == len(oproof)
+    assert proof.tobytes() == oproof, "2^20 x 128 segment proof bytes differ from the oracle's"
 
 
-def test_config4_four_segments_in_one_call(ctx, big_oracle):
+def test_config4_four_segments_in_one_call(ctx, big_oracle, oracle_shard_proof):
     """a multi-segment proof at 2^20 cycles per segment: four segments through ONE zkhip_prove_shards call with the segment
     parameters, every proof accepted by the oracle's verifier, one byte-equal to the oracle's proof"""
     from zktls_amd._lib import segment_params
@@ -188,8 +187,7 @@ def test_config4_four_segments_in_one_call(ctx, big_oracle):
         assert verify_shard(p, LOG_N, SEG_WIDTH, pvs[s], prm) == (0, 0)
         assert O.verify_shard(p, LOG_N, SEG_WIDTH, pvs[s], oprm) == 0, "oracle verifier rejects segment %d" % s
     assert O.verify_shard(proofs[1], LOG_N, SEG_WIDTH, pvs[2], oprm) != 0
-    op = O.prove_shard(O.gen_trace(SEED, 2002, LOG_N, SEG_WIDTH), pvs[2], oprm)
-    assert proofs[2].tobytes() == op.tobytes()
+    assert proofs[2].tobytes() == oracle_shard_proof(SEED, 2002, LOG_N, SEG_WIDTH, pvs[2], "r0")
     for t in traces:
         t.free()
     _lib.load().zkhip_release_cached_contexts()

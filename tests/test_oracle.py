@@ -556,3 +556,33 @@ def test_golden_chip_lookup_proofs(oracle, name):
     cross = any(p >= 0 for p in pas)
     pf = oracle.prove_chips(traces, g["public"], oracle.default_params(*g["params"]), prs, pas if cross else None)
     assert pf.size == g["bytes"] and hashlib.sha256(pf.tobytes()).hexdigest() == g["sha256"]
+
+
+def test_the_oracles_eight_lane_poseidon2_equals_its_scalar_form_on_whole_proofs():
+    """oracle/poseidon2_x8.c (AVX-512 lanes behind a start-up self-check) against ORC_NO_SIMD=1 in a fresh process: the same mixed-height tree and the same
+    proof bytes -- the vector path is a restatement of the scalar one, not a second oracle.  (Skipped where the CPU has no AVX-512: both runs are scalar.)"""
+    import hashlib
+    import os
+    import subprocess
+    import sys
+    code = r'''
+import hashlib, sys
+sys.path.insert(0, "tests")
+import numpy as np
+import oracle_lib as O
+O.set_threads(4)
+rng = np.random.default_rng(1)
+m, m2 = rng.integers(0, O.P, (1 << 9, 37)).astype(np.uint32), rng.integers(0, O.P, (1 << 7, 5)).astype(np.uint32)
+t = np.asarray(O.merkle_tree_mixed([m, m2]))
+p = O.prove_shard(O.gen_trace(5, 1, 10, 24), [1, 2], O.default_params(1, 20, 4))
+print(int(O.lib().orc_simd_enabled()), hashlib.sha256(t.tobytes()).hexdigest(), hashlib.sha256(p.tobytes()).hexdigest())
+'''
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    outs = []
+    for no_simd in ("0", "1"):
+        env = dict(os.environ, ORC_NO_SIMD=no_simd)
+        outs.append(subprocess.run([sys.executable, "-c", code], cwd=root, env=env, capture_output=True, text=True, check=True).stdout.split())
+    assert outs[1][0] == "0"
+    if outs[0][0] != "1":
+        pytest.skip("no AVX-512 on this CPU: the oracle is scalar either way")
+    assert outs[0][1:] == outs[1][1:]

@@ -473,6 +473,62 @@ static int coset_lde_big(zkhip_ctx* ctx, const uint32_t* in, size_t in_ld, uint3
     return ZKHIP_OK;
 }
 
+// ---- 2^11 .. 2^15 rows: the whole LDE as ONE launch (ntt_small.hip), 4 + 4 * 2^b bytes per trace cell.  The tables are per context, built
+// on first use on the context's stream: the twiddle bases of a height (N / 32 words each way) and, per (height, coset shift), shift^j / N.
+constexpr int SMALL_LDE_MIN_LOG = 11, SMALL_LDE_MAX_LOG = 15;
+static int get_small_plan(zkhip_ctx* ctx, int log_n, const SmallPlan** out) {
+    for (const SmallPlan& p : ctx->small_plans) if (p.log_n == log_n) { *out = &p; return ZKHIP_OK; }
+    SmallPlan p;
+    p.log_n = log_n;
+    const size_t m = (size_t)1 << (log_n - 5);
+    const uint32_t w = two_adic_generator(log_n);
+    ZK_HIP(hipMalloc((void**)&p.tw_inv, m * 4));
+    if (hipMalloc((void**)&p.tw_fwd, m * 4) != hipSuccess) { (void)hipFree(p.tw_inv); return fail(ZKHIP_ERR_HIP, "hipMalloc (small LDE tables)"); }
+    hipError_t e = launch_pow_table(p.tw_inv, m, finv(w), MONTY_R1, ctx->stream);
+    if (e == hipSuccess) e = launch_pow_table(p.tw_fwd, m, w, MONTY_R1, ctx->stream);
+    if (e != hipSuccess) { (void)hipFree(p.tw_inv); (void)hipFree(p.tw_fwd); return hip_fail(e, "small LDE tables"); }
+    ctx->small_plans.push_back(p);
+    *out = &ctx->small_plans.back();
+    return ZKHIP_OK;
+}
+static int get_small_pre(zkhip_ctx* ctx, int log_n, uint32_t shift, const uint32_t** out) {
+    for (const SmallPre& p : ctx->small_pres) if (p.log_n == log_n && p.shift == shift) { *out = p.pre; return ZKHIP_OK; }
+    SmallPre p;
+    p.log_n = log_n; p.shift = shift;
+    const size_t n = (size_t)1 << log_n;
+    ZK_HIP(hipMalloc((void**)&p.pre, n * 4));
+    const hipError_t e = launch_pow_table(p.pre, n, shift, finv(to_monty((uint32_t)n)), ctx->stream);
+    if (e != hipSuccess) { (void)hipFree(p.pre); return hip_fail(e, "small LDE coset powers"); }
+    ctx->small_pres.push_back(p);
+    *out = p.pre;
+    return ZKHIP_OK;
+}
+// ZKHIP_OK with *done = true when the launch was enqueued; *done = false: a shape it does not take (the caller goes on to the pass kernels)
+static int lde_small(zkhip_ctx* ctx, const uint32_t* in, size_t in_ld, uint32_t* out, size_t out_ld, int log_n, uint32_t width, int log_blowup,
+                     uint32_t shift, bool* done) {
+    *done = false;
+    if (log_n < SMALL_LDE_MIN_LOG || log_n > SMALL_LDE_MAX_LOG || !ctx->lde_fusion) return ZKHIP_OK;
+#ifdef ZKHIP_AB_HOOKS
+    if (const char* e = getenv("ZKHIP_LDE_SMALL")) { const int mx = atoi(e); if (mx == 0 || log_n > mx) return ZKHIP_OK; }     // 0: off; else the largest log_n it takes
+#endif
+    const size_t n = (size_t)1 << log_n;
+    const int B = 1 << log_blowup;
+    LdeSmallArgs a{};
+    a.in = in; a.in_ld = in_ld; a.out_ld = out_ld; a.ncols = width; a.cosets = (uint32_t)B;
+    if (!lde_small_supported(a, log_n)) return ZKHIP_OK;
+    const SmallPlan* sp;
+    ZK_TRY(get_small_plan(ctx, log_n, &sp));
+    a.tw_inv = sp->tw_inv; a.tw_fwd = sp->tw_fwd;
+    const uint32_t wnb = two_adic_generator(log_n + log_blowup);
+    for (int t = 0; t < B; t++) {
+        ZK_TRY(get_small_pre(ctx, log_n, fmul(shift, fpow(wnb, (uint64_t)t)), &a.pre[t]));
+        a.out[t] = out + (size_t)reverse_bits((uint32_t)t, log_blowup) * n * out_ld;
+    }
+    ZK_HIP(launch_lde_small(a, log_n, ctx->stream));
+    *done = true;
+    return ZKHIP_OK;
+}
+
 int op_coset_lde(zkhip_ctx* ctx, const uint32_t* in, size_t in_ld, uint32_t* out, size_t out_ld,
                  int log_n, uint32_t width, int log_blowup, uint32_t shift) {
     if (log_n < 0 || log_n > MAX_LOG_ROWS) return fail(ZKHIP_ERR_INVALID, "coset_lde: log_n must be in [0, 22]");
@@ -491,6 +547,11 @@ int op_coset_lde(zkhip_ctx* ctx, const uint32_t* in, size_t in_ld, uint32_t* out
         ZK_HIP(launch_small_eval((const uint32_t*)coef_s, width, out, out_ld, log_n, log_n + log_blowup, width,
                                  two_adic_generator(log_n + log_blowup), shift, MONTY_R1, 1, ctx->stream));
         return ZKHIP_OK;
+    }
+    {   // 2^11 .. 2^15 rows: one launch, any width
+        bool done = false;
+        ZK_TRY(lde_small(ctx, in, in_ld, out, out_ld, log_n, width, log_blowup, shift, &done));
+        if (done) return ZKHIP_OK;
     }
     // A width that is not a multiple of 32 columns: the tile passes take two columns per lane (and, at 2^20 rows, the fused middle launch) only
     // for whole 32-column tiles -- a 612-column matrix went through the one-column-per-lane passes at 2.3 x the time of a 608-column one
@@ -753,6 +814,8 @@ void zkhip_ctx_destroy(zkhip_ctx* ctx) {
     if (ctx->w1024f_fwd) (void)hipFree(ctx->w1024f_fwd);
     if (ctx->w1024f_inv) (void)hipFree(ctx->w1024f_inv);
     for (BigPlan& p : ctx->big_plans) if (p.tw) (void)hipFree(p.tw);
+    for (SmallPlan& p : ctx->small_plans) { if (p.tw_inv) (void)hipFree(p.tw_inv); if (p.tw_fwd) (void)hipFree(p.tw_fwd); }
+    for (SmallPre& p : ctx->small_pres) if (p.pre) (void)hipFree(p.pre);
     for (ColPlan& p : ctx->col_plans) { if (p.pre) (void)hipFree(p.pre); if (p.post2d) (void)hipFree(p.post2d); }
     for (DeviceBuffer& b : ctx->scratch) if (b.ptr) (void)hipFree(b.ptr);
     if (ctx->host_pinned) (void)hipHostFree(ctx->host_pinned);

@@ -41,6 +41,18 @@ struct NttPlan {
     uint32_t* post_f = nullptr;
 };
 
+// tables of the one-launch LDE of 2^11 .. 2^15 rows (ntt_small.hip): the inter-phase twiddle bases per height, the coset powers per (height, shift)
+struct SmallPlan {
+    int log_n = 0;
+    uint32_t* tw_inv = nullptr;   // device, w_N^(-i), i < N / 32
+    uint32_t* tw_fwd = nullptr;   // device, w_N^(+i)
+};
+struct SmallPre {
+    int log_n = 0;
+    uint32_t shift = 0;           // Montgomery
+    uint32_t* pre = nullptr;      // device, shift^j / N, j < N
+};
+
 // radix-R combine twiddles of a 2^21 / 2^22-row transform (ntt.hip, ntt_combine_kernel)
 struct BigPlan {
     int log_n = 0;
@@ -103,6 +115,8 @@ struct zkhip_ctx {
     uint32_t* w1024f_inv = nullptr;
     std::deque<zk::NttPlan> plans;   // deque: references stay valid on push_back
     std::deque<zk::BigPlan> big_plans;
+    std::deque<zk::SmallPlan> small_plans;
+    std::deque<zk::SmallPre> small_pres;
     std::deque<zk::ColPlan> col_plans;
     zk::DeviceBuffer scratch[zk::S_COUNT];   // grow-only workspaces, indexed by zk::Slot
     zkhip_prove_debug debug{};

@@ -70,6 +70,22 @@ hipError_t launch_lde_fused(const LdeFusedArgs& a, hipStream_t s);
 hipError_t launch_fused_table(uint32_t* out, const uint32_t* in, uint32_t blocks, int mode, hipStream_t s);
 bool lde_fused_supported(const LdeFusedArgs& a);      // shape / alignment / 32-bit tile span
 
+// ---- a whole coset LDE of 2^11 .. 2^15 rows in ONE launch (ntt_small.hip): column in registers, 4 + 4 * cosets bytes per trace cell
+struct LdeSmallArgs {
+    const uint32_t* in;
+    uint64_t in_ld, out_ld;
+    uint32_t ncols;
+    uint32_t cosets;                 // 1 .. 16
+    uint32_t groups;                 // column groups of 32 / P columns (filled in by the launcher)
+    uint32_t reserved;
+    const uint32_t* tw_inv;          // w_N^(-i), i < N / 32
+    const uint32_t* tw_fwd;          // w_N^(+i), i < N / 32
+    uint32_t* out[16];               // per coset: first row of its block of the LDE
+    const uint32_t* pre[16];         // per coset: shift_t^j / N, j < N
+};
+bool lde_small_supported(const LdeSmallArgs& a, int log_n);
+hipError_t launch_lde_small(const LdeSmallArgs& a, int log_n, hipStream_t s);
+
 // ---- native passes over CONTIGUOUS VECTORS (RISC Zero's Hal layout: `count` polynomials of 2^20 coefficients, column-major).
 // A polynomial is viewed as a 1024 x 1024 matrix A[r][c] = v[1024 r + c]; a pass transforms the 1024-point columns of 32
 // adjacent c at a time (the tile shape of ntt_pass_kernel<4, *, 2, 5>), and where the four-step transpose requires it the tile
