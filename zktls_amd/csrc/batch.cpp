@@ -61,7 +61,12 @@ LaunchBatcher::LaunchBatcher(int members, hipStream_t stream) : members_(members
     }
     if (ring_ || !stream_) return;                           // (no stream: the scheduler alone, see zkhip_selftest_lockstep)
     void* p = nullptr;
-    if (hipHostMalloc(&p, RING_BYTES, hipHostMallocPortable | hipHostMallocMapped) != hipSuccess) { (void)hipGetLastError(); return; }
+    unsigned flags = hipHostMallocPortable | hipHostMallocMapped;
+#ifdef ZKHIP_AB_HOOKS
+    static const int ring_nc = getenv("ZKHIP_RING_NC") ? atoi(getenv("ZKHIP_RING_NC")) : 0;
+    if (ring_nc) flags |= hipHostMallocNonCoherent;
+#endif
+    if (hipHostMalloc(&p, RING_BYTES, flags) != hipSuccess) { (void)hipGetLastError(); return; }
     ring_ = (uint8_t*)p;
 }
 

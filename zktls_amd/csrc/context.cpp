@@ -475,7 +475,8 @@ static int coset_lde_big(zkhip_ctx* ctx, const uint32_t* in, size_t in_ld, uint3
 
 // ---- 2^11 .. 2^15 rows: the whole LDE as ONE launch (ntt_small.hip), 4 + 4 * 2^b bytes per trace cell.  The tables are per context, built
 // on first use on the context's stream: the twiddle bases of a height (N / 32 words each way) and, per (height, coset shift), shift^j / N.
-constexpr int SMALL_LDE_MIN_LOG = 11, SMALL_LDE_MAX_LOG = 15;
+constexpr int SMALL_LDE_MIN_LOG = 11, SMALL_LDE_MAX_LOG = 15, SMALL_LDE_DEFAULT_MAX_LOG = 13;
+constexpr uint32_t SMALL_LDE_MIN_WIDTH = 128;
 static int get_small_plan(zkhip_ctx* ctx, int log_n, const SmallPlan** out) {
     for (const SmallPlan& p : ctx->small_plans) if (p.log_n == log_n) { *out = &p; return ZKHIP_OK; }
     SmallPlan p;
@@ -508,9 +509,15 @@ static int lde_small(zkhip_ctx* ctx, const uint32_t* in, size_t in_ld, uint32_t*
                      uint32_t shift, bool* done) {
     *done = false;
     if (log_n < SMALL_LDE_MIN_LOG || log_n > SMALL_LDE_MAX_LOG || !ctx->lde_fusion) return ZKHIP_OK;
+    // where it pays (tools/small_lde_time.py, profiles/r06_small_lde.md): wide matrices of up to 2^13 rows -- 16 .. 64-byte row chunks per workgroup;
+    // at 2^14 / 2^15 rows (8 / 4 bytes per row and workgroup, one workgroup per CU with its load and store phases exposed) and for narrow
+    // matrices (one or two workgroups: latency of the whole column against six short launches) the pass kernels are faster
+    int max_log = SMALL_LDE_DEFAULT_MAX_LOG;
+    uint32_t min_width = SMALL_LDE_MIN_WIDTH;
 #ifdef ZKHIP_AB_HOOKS
-    if (const char* e = getenv("ZKHIP_LDE_SMALL")) { const int mx = atoi(e); if (mx == 0 || log_n > mx) return ZKHIP_OK; }     // 0: off; else the largest log_n it takes
+    if (const char* e = getenv("ZKHIP_LDE_SMALL")) { max_log = atoi(e); min_width = 1; }     // 0: off; else the largest log_n it takes, any width
 #endif
+    if (log_n > max_log || width < min_width) return ZKHIP_OK;
     const size_t n = (size_t)1 << log_n;
     const int B = 1 << log_blowup;
     LdeSmallArgs a{};

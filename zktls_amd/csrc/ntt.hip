@@ -563,6 +563,27 @@ hipError_t launch_ntt_pass(const NttPassArgs& a_, bool inverse, hipStream_t s) {
         }
         return inverse ? launch_ntt_k<4, true, 2, 5>(a, s) : launch_ntt_k<4, false, 2, 5>(a, s);
     }
+    // 64 .. 512-row tiles (the two passes of a 2^11 .. 2^18-row transform): the same two-columns-per-lane form with the tile height fixed at
+    // compile time (round 6).  These heights used to fall to the one-column-per-lane kernel with a run-time height -- 64-byte row chunks, offsets in
+    // VGPRs --, at 0.8 - 0.9 TB/s per pass on the 2^14 x 640 traces of BASELINE configs[2] (profiles/r05_compress64_kernel_stats.md).
+#ifdef ZKHIP_AB_HOOKS
+    static const bool tile_fix_off = getenv("ZKHIP_TILE_FIX") != nullptr && atoi(getenv("ZKHIP_TILE_FIX")) == 0;
+#else
+    constexpr bool tile_fix_off = false;
+#endif
+    if (!tile_fix_off && pair_ok && a.cols_per_thread != 1 && a.log_m >= 6 && a.log_m <= 9) {
+        const bool contiguous = a.in_stride == 1 && a.out_stride == 1;
+        const bool in_place = a.in == a.out;
+        const int pol = contiguous ? 1 : (!in_place ? 2 : 0);
+#define ZK_TILE_CASE(LM, BF)                                                                                                                         \
+        if (a.log_m == LM) {                                                                                                                         \
+            if (pol == 1) return inverse ? launch_ntt_k<4, true, 2, BF, 1>(a, s) : launch_ntt_k<4, false, 2, BF, 1>(a, s);                          \
+            if (pol == 2) return inverse ? launch_ntt_k<4, true, 2, BF, 2>(a, s) : launch_ntt_k<4, false, 2, BF, 2>(a, s);                          \
+            return inverse ? launch_ntt_k<4, true, 2, BF>(a, s) : launch_ntt_k<4, false, 2, BF>(a, s);                                              \
+        }
+        ZK_TILE_CASE(6, 1) ZK_TILE_CASE(7, 2) ZK_TILE_CASE(8, 3) ZK_TILE_CASE(9, 4)
+#undef ZK_TILE_CASE
+    }
     if (pair_ok && a.cols_per_thread == 2) return inverse ? launch_ntt_k<4, true, 2>(a, s) : launch_ntt_k<4, false, 2>(a, s);
     // narrow matrices use narrower tiles so that lanes are not wasted on masked columns
     if (a.ncols <= 4) return inverse ? launch_ntt_k<2, true, 1>(a, s) : launch_ntt_k<2, false, 1>(a, s);
