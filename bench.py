@@ -859,6 +859,71 @@ def main():
         for b_ in mc_bufs:
             b_[0].free()
         del mc_out
+        # ---- the same shard structure through core -> compress (sp1.rs:116: core, then compress, in one client.prove): the six chips
+        # as ONE keyed machine (proof version 11: constraint programs, the LogUp pairs as interaction tables -- two of them ACROSS the two 2^20-row
+        # tables --, 32 preprocessed columns committed once by setup), mc_k shards proven with S in flight, then joined into ONE proof in machine mode
+        # (zkhip_prove_machine_verifier: lookups, mixed heights, the preprocessed openings against the machine's key, in-circuit)
+        try:
+            from zktls_amd.device import Sp1ShapedShard, machine_verifier_key_host, verify_machine_recursive
+            shape_ = Sp1ShapedShard()
+            mc_keys = [shape_.setup(c_, SEED, prm) for c_ in ctxs]                  # a key belongs to the context it was made with
+            mc_k = 2 * S
+            mc_pubs = [public + [9000 + i_] for i_ in range(mc_k)]
+            mc_tr = [shape_.gen_traces(ctx, SEED, 9000 + i_) for i_ in range(mc_k)]
+            ctx.sync()
+            mc_proofs = [None] * mc_k
+
+            def mk_worker(w_, lo_, hi_):
+                for i_ in range(lo_ + w_, hi_, S):
+                    mc_proofs[i_] = ctxs[w_].prove_machine_keyed(mc_keys[w_][0], shape_.main_chips(mc_tr[i_]), shape_.programs, shape_.tables, mc_pubs[i_], prm)
+
+            def mk_round(lo_, hi_):
+                ts_ = [threading.Thread(target=mk_worker, args=(w_, lo_, hi_)) for w_ in range(S)]
+                for t_ in ts_:
+                    t_.start()
+                for t_ in ts_:
+                    t_.join()
+            mk_round(0, S)                                                        # warm every context at these shapes
+            tk0 = time.perf_counter()
+            mk_round(0, mc_k)
+            for c_ in ctxs:
+                c_.sync()
+            mk_dt = (time.perf_counter() - tk0) / mc_k
+            for tr_ in mc_tr:
+                for b_ in tr_:
+                    b_.free()
+            im_ = shape_.inner_machine(mc_keys[0][0].root, prm)
+            jk_ = ctx.machine_verifier_setup(im_, prm, mc_k)
+            ctx.prove_machine_verifier(jk_, im_, mc_proofs, mc_pubs, prm)            # warm: workspaces, host tables
+            tj0 = time.perf_counter()
+            mc_top = ctx.prove_machine_verifier(jk_, im_, mc_proofs, mc_pubs, prm)
+            mj_dt = time.perf_counter() - tj0
+            flat_ = [v_ for p_ in mc_pubs for v_ in p_]
+            th0 = time.perf_counter()
+            mc_ok = verify_machine_recursive(im_, mc_top, flat_, jk_.root, prm, mc_k) == (0, 0)
+            mh_dt = time.perf_counter() - th0
+            swapped_ = mc_pubs[1] + mc_pubs[0] + [v_ for p_ in mc_pubs[2:] for v_ in p_]
+            mc_ok = mc_ok and verify_machine_recursive(im_, mc_top, swapped_, jk_.root, prm, mc_k)[0] != 0
+            inner_total = sum(int(p_.size) for p_ in mc_proofs)
+            multichip["compressed"] = {
+                "workload": "the same six chips as ONE keyed machine (version 11: constraint programs, pairs %s as interaction tables -- chips 0 and 1 look each other up ACROSS tables --, 32 preprocessed columns on the 2^16-row chip), %d shards proven with %d in flight (zkhip_prove_machine_keyed), then ONE zkhip_prove_machine_verifier call over them (machine mode: n_proofs = %d)" % (
+                    [c_[2] for c_ in shape_.spec], mc_k, S, mc_k),
+                "keyed_ms_per_shard": round(mk_dt * 1e3, 3), "keyed_trace_cells_per_s": round(shape_.cells / mk_dt, 1), "keyed_proof_bytes": int(mc_proofs[0].size),
+                "compress_ms": round(mj_dt * 1e3, 2), "inner_bytes_total": inner_total, "bytes": int(mc_top.size), "compression": round(inner_total / mc_top.size, 2),
+                "host_verify_ms": round(mh_dt * 1e3, 2), "verified_and_a_swap_refused": bool(mc_ok),
+                "verifier_inputs": "the machine's description (programs, tables, heights, key root), %d x %d public values, the join's key; no byte of a shard proof" % (mc_k, shape_.n_public),
+                "bound": "machine mode takes inner machines of at most 16 chips and a Poseidon2 chip of at most 2^22 rows per join"}
+            multichip["compressed_ms"] = multichip["compressed"]["compress_ms"]
+            multichip["compressed_bytes"] = multichip["compressed"]["bytes"]
+            jk_.close()
+            for k_, keep_ in mc_keys:
+                k_.close()
+                for b_ in keep_:
+                    if b_ is not None:
+                        b_.free()
+            del mc_proofs, mc_top
+        except Exception as e_:                                               # the line says so instead of dropping the section silently
+            multichip["compressed"] = {"error": repr(e_)}
 
     # ---- the plug point itself on the measuring path: ONE call of the host mirror of ZkProver::prove
     # (zktls_amd/host, what crates/guest-prover-sp1/src/sp1.rs:102-133 would bind) for an execution of the size the reference benchmarks
