@@ -1274,6 +1274,69 @@ def counter_trace(log_n, width, start, pub2, seed=3):
 
 
 # ---------------------------------------------------------------------------------------------------------------- checks in plain integers
+def bus_events(mains, pres, tabs):
+    """every active interaction of every row: -> {bus: [(sign, chip, interaction index, row, multiplicity, tuple, preprocessed?-per-position)]}"""
+    out = {}
+    for ci, (main, pre, tab) in enumerate(zip(mains, pres, tabs)):
+        if tab is None:
+            continue
+        pw = 0 if pre is None else pre.shape[1]
+        rows = (main if pre is None else np.concatenate([pre, main], axis=1)).astype(np.int64)
+        t = [int(x) for x in tab]
+        p = 3
+        for k in range(t[1]):
+            sign, mult, bus, nv = t[p:p + 4]
+            cols = t[p + 4:p + 4 + nv]
+            p += 4 + nv
+            mus = np.ones(rows.shape[0], dtype=np.int64) if mult == 0xFFFFFFFF else rows[:, mult]
+            for r in np.nonzero(mus)[0]:
+                out.setdefault(bus, []).append((sign, ci, k, int(r), int(mus[r]), tuple(int(rows[r, c]) for c in cols), tuple(c < pw for c in cols)))
+    return out
+
+
+def bus_ambiguity(mains, pres, tabs, extra_identity=None, function_tables=()):
+    """A bus is a MULTISET: two sends whose tuples agree on everything that NAMES their receiver are exchangeable without any cell looking wrong
+    (the class of 8ca4614: the fold chain's tuple for a lower height lacked the query's index, so two queries could take each other's reduced openings;
+    a flipped-cell test cannot see it).  The audit, over an honest trace:
+      * the positions of a bus's tuple that NAME the receiver: those that are PREPROCESSED columns on the receiving side in every receive interaction of
+        the bus (the key fixes them per row), or preprocessed on the sending side in every send interaction; plus `extra_identity[bus]` -- main columns
+        that a constraint pins to the receiver's identity (declared with their reason where the machine is defined);
+      * two active RECEIVES on different rows whose tuples agree on the naming positions but differ elsewhere are a finding: a sender cannot tell
+        the two receivers apart, so what it hands one of them can be handed to the other.  (Receivers that agree on the WHOLE tuple are one
+        receiver with a multiplicity; buses in `function_tables` are lookups into a relation -- the receiver's whole tuple is fixed by its own
+        constraints, e.g. a Poseidon2 row's (input, output) -- where any row may serve any sender by design.)
+    -> [(bus, naming positions, (chip, row, tuple), (chip, row, tuple))], empty when every receiver is named"""
+    extra_identity = extra_identity or {}
+    findings = []
+    for bus, ev in sorted(bus_events(mains, pres, tabs).items()):
+        if bus in function_tables:
+            continue
+        recv, send = [e for e in ev if e[0] == RECV], [e for e in ev if e[0] == SEND]
+        if not recv:
+            continue
+        width = len(recv[0][5])
+        if any(len(e[5]) != width for e in ev):                # (interactions of different lengths on one bus never meet: audit them by length)
+            groups = {}
+            for e in ev:
+                groups.setdefault(len(e[5]), []).append(e)
+        else:
+            groups = {width: ev}
+        for width, evs in sorted(groups.items()):
+            recv, send = [e for e in evs if e[0] == RECV], [e for e in evs if e[0] == SEND]
+            if not recv:
+                continue
+            named = [k for k in range(width) if all(e[6][k] for e in recv) or (send and all(e[6][k] for e in send))]
+            named = sorted(set(named) | set(extra_identity.get((bus, width), extra_identity.get(bus, []))))
+            seen = {}
+            for e in recv:
+                key = tuple(e[5][k] for k in named)
+                if key in seen and seen[key][5] != e[5] and (seen[key][1], seen[key][3]) != (e[1], e[3]):
+                    findings.append((bus, tuple(named), (seen[key][1], seen[key][3], seen[key][5]), (e[1], e[3], e[5])))
+                    break                                      # one finding per bus and length is enough to fail
+                seen.setdefault(key, e)
+    return findings
+
+
 def bus_balance(mains, pres, tabs):
     """every tuple sent on a bus is received with the same total multiplicity -> the list of (bus, tuple) that do not balance"""
     tot = {}

@@ -278,3 +278,124 @@ def test_the_sp1_shaped_machine_of_the_library_is_the_tests(oracle):
     assert s.widths == [m.shape[1] for m in mains] and s.pre_widths == [0 if p is None else p.shape[1] for p in pres]
     full = Sp1ShapedShard()
     assert full.cells == sum(w << ln for ln, w in [(20, 96), (20, 32), (19, 64), (18, 128), (16, 256), (14, 40)])      # bench.py's multichip shard
+
+
+# ---------------------------------------------------------------------------------------------------------------- buses are multisets: every receiver must be NAMED
+#   What the audit (R.bus_ambiguity) is told about the machines, with the reason:
+#   * BUS_E0 / BUS_E1 are lookups into a RELATION: a Poseidon2 leaf row proves "the pair (e0, e1) sits at index k of layer l's tree" by itself (its path rows
+#     end in the layer's root, which TS ties to the transcript), so any such row may serve any fold row that claims that (tree, index, pair);
+#   * on BUS_Q the position after the key names the query: in the TOP form (7 values) it is IDX, which the row also receives from SAMPLES under the
+#     PREPROCESSED query number (BUS_I); in the LOWER-height form (8 values) it is IDX0, constant along the query's rows and equal to that IDX (two constraints
+#     of the QUERY program, one of the FOLD program) -- the column 8ca4614 added.
+import fri_air as F
+FUNCTION_TABLES = (F.BUS_E0, F.BUS_E1)
+NAMED = {(F.BUS_Q, 7): [1], (F.BUS_Q, 8): [1]}
+
+
+def _table_entries(tab):
+    t, p, out = [int(x) for x in tab], 3, []
+    for _ in range(int(tab[1])):
+        sign, mult, bus, nv = t[p:p + 4]
+        out.append((sign, None if mult == 0xFFFFFFFF else mult, bus, t[p + 4:p + 4 + nv]))
+        p += 4 + nv
+    return out
+
+
+def _mixed_height_join(O):
+    """a machine-mode machine over 2 proofs x 3 queries of an inner machine with four heights (the SP1-shaped one): -> (sh, names, mains, pres, progs, tabs, pv)"""
+    q, pb = 3, 1
+    made = [M.sp1_shaped_machine(SP1_SMALL, seed=5, shard=s, pre=((3, 8),)) for s in (0, 1)]
+    chips, vk, p0 = inner(O, *made[0], q=q, pb=pb)
+    _, _, p1 = inner(O, *made[1], q=q, pb=pb)
+    sh, mains, pres, progs, tabs, pv = RM.machine(chips, vk, [p0, p1], [made[0][4], made[1][4]], q, pb)
+    return sh, RM.order(sh), mains, pres, progs, tabs, pv
+
+
+def test_every_receiver_of_every_bus_is_named_in_all_three_machines(oracle):
+    """the audit over honest traces of >= 2 proofs x >= 2 queries: the ten-chip machine (machine mode, mixed heights), the eight-chip one (version-1 shard proofs)
+    and the nine-chip one (air mode) -- no two receivers of a bus agree on everything that names them and differ in what they take"""
+    O = oracle
+    sh, names, mains, pres, progs, tabs, pv = _mixed_height_join(O)
+    assert len(sh.hs) >= 3 and sh.NP == 2 and sh.Q == 3
+    assert R.bus_ambiguity(mains, pres, tabs, NAMED, FUNCTION_TABLES) == []
+    found = {f[0] for f in R.bus_ambiguity(mains, pres, tabs)}                  # told nothing, it reports exactly the buses documented above
+    assert found == {F.BUS_E0, F.BUS_E1, F.BUS_Q}
+    log_n, width, q, pb = 6, 16, 3, 1
+    pubs = [[5, 6, 30 + s] for s in range(2)]
+    proofs = [O.prove_shard(O.gen_trace(SEED, 40 + s, log_n, width), pubs[s], O.default_params(1, q, pb)).tobytes() for s in range(2)]
+    _, m8, p8, _, t8, _ = R.machine(proofs, log_n, width, pubs, q, pb)
+    assert len(m8) == 8 and R.bus_ambiguity(m8, p8, t8, NAMED, FUNCTION_TABLES) == []
+    prog = O.air_synthetic(width, 3)
+    proofs7 = [O.prove_shard_air(prog, O.gen_trace(SEED, 40 + s, log_n, width), pubs[s], O.default_params(1, q, pb)).tobytes() for s in range(2)]
+    _, m9, p9, _, t9, _ = R.machine(proofs7, log_n, width, pubs, q, pb, program=prog)
+    assert len(m9) == 9 and R.bus_ambiguity(m9, p9, t9, NAMED, FUNCTION_TABLES) == []
+
+
+def test_two_queries_cannot_exchange_their_lower_heights(oracle):
+    """the regression 8ca4614 lacked.  Before it the fold chain handed a lower height's reduced opening over as (layer, index there, point, value) -- nothing
+    in the tuple named the QUERY.  (a) the audit refuses that tuple: with IDX0 dropped from both sides of the lower-height form, two queries' receivers of one
+    (proof, height) agree on the key and nothing else names them; (b) the exchange itself: the QUERY rows of two queries at one lower height take each
+    other's (index, point) -- every constraint of the QUERY program but the IDX0 ones is recomputed and holds -- and the two fold chains take each other's
+    reduced openings: BUS_Q balances under the old tuple and does NOT under the new one."""
+    O = oracle
+    sh, names, mains, pres, progs, tabs, pv = _mixed_height_join(O)
+    qi, fi = names.index("QUERY"), names.index("FOLD")
+    m = RM.query_cols()
+
+    def old_table(tab):
+        ent = []
+        for sign, mult, bus, cols in _table_entries(tab):
+            if bus == F.BUS_Q and len(cols) == 8:
+                cols = cols[:1] + cols[2:]                                       # (key, IDX0, IDX, X, value) -> (key, IDX, X, value)
+            ent.append((sign, mult, bus, cols))
+        return O.interaction_table(ent)
+    old_tabs = [old_table(t) if i in (qi, fi) else t for i, t in enumerate(tabs)]
+    assert R.bus_balance(mains, pres, old_tabs) == []                           # (honest traces balance either way)
+    # (a) IDX may be declared a name only where something pins it: the TOP rows (BUS_I).  The old lower-height receive shares its 7-value form with them, and its
+    # IDX is pinned by nothing -- so nothing may be declared for it, and the audit finds the receivers of one (proof, height) indistinguishable
+    assert F.BUS_Q in {f[0] for f in R.bus_ambiguity(mains, pres, old_tabs, {}, FUNCTION_TABLES)}
+    # (b) the exchange
+    ev = [e for e in R.bus_events(mains, pres, tabs)[F.BUS_Q] if len(e[5]) == 8]
+    recv = {e[5]: e for e in ev if e[0] == R.RECV}
+    sends = [e for e in ev if e[0] == R.SEND]
+    pair = None
+    for a in sends:
+        for b in sends:
+            if a[5][0] == b[5][0] and a[5][1] != b[5][1]:                        # one (proof, height), two queries
+                pair = (a, b)
+                break
+        if pair:
+            break
+    assert pair, "the machine has no two queries at one lower height"
+    (sa, sb), (ra, rb) = pair, (recv[pair[0][5]], recv[pair[1][5]])
+    mq, mf = mains[qi].copy().astype(np.int64), mains[fi].copy().astype(np.int64)
+    pw_q = pres[qi].shape[1]
+
+    def col(name):
+        return m[name] - pw_q
+    rows_q = {"a": ra[3], "b": rb[3]}
+    keep = {k: (int(mq[r, col("IDX")]), int(mq[r, col("XQ")])) for k, r in rows_q.items()}
+    new_ro = {}
+    for k, other in (("a", "b"), ("b", "a")):
+        r = rows_q[k]
+        idx, xq = keep[other]
+        mq[r, col("IDX")], mq[r, col("XQ")] = idx, xq
+        ext = lambda name: [int(v) for v in mq[r, col(name):col(name) + 4]]  # noqa: E731
+        x = [RM.GEN * xq % R.P, 0, 0, 0]
+        i1, i2 = RM.pyref.ext_inv(RM.e_sub(x, ext("ZETA"))), RM.pyref.ext_inv(RM.e_sub(x, ext("ZNX")))
+        p1, p2 = RM.ext_mul(RM.e_sub(ext("AZ"), ext("YZ")), i1), RM.ext_mul(RM.e_sub(ext("AN"), ext("YN")), i2)
+        ro = RM.e_add(p1, p2)
+        for name, val in (("I1", i1), ("I2", i2), ("P1", p1), ("P2", p2), ("RO", ro)):
+            mq[r, col(name):col(name) + 4] = val
+        new_ro[k] = ro
+    INJ, INJF = F.inj_cols(sh.R)
+    mf[sa[3], INJ:INJ + 4], mf[sb[3], INJ:INJ + 4] = new_ro["b"], new_ro["a"]     # chain A takes what row B now holds under A's (index, point), and the other way round
+    ex_mains = [mq.astype(np.uint32) if i == qi else (mf.astype(np.uint32) if i == fi else x) for i, x in enumerate(mains)]
+    # the QUERY rows still satisfy their program -- IDX0 was not touched, so even the constraints 8ca4614 added hold
+    rows = np.concatenate([pres[qi], ex_mains[qi]], axis=1)
+    assert S.check_rows(progs[qi], rows, pv) == []
+
+    def busq_unbalanced(tb):
+        return [k for k in R.bus_balance(ex_mains, pres, tb) if k[0] == F.BUS_Q]
+    assert busq_unbalanced(old_tabs) == [], "under the old tuple the exchange is invisible to the bus"
+    assert busq_unbalanced(tabs) != [], "under the tuple with IDX0 the bus refuses the exchange"
