@@ -373,3 +373,39 @@ def test_sp1_shaped_shards_at_the_bench_size_join_and_top(ctx, oracle):
     assert verify_machine_recursive(im2, top, jpubs[1] + jpubs[0], tkey.root, prm, 2)[0] != 0
     print("SP1-shaped shards: 4 x %d B -> 2 joins %d B -> top %d B" % (proofs[0].size, sum(j.size for j in joins), top.size))
     key.close(), jkey.close(), tkey.close()
+
+
+def test_device_witnesses_and_the_hosts_walk_give_one_proof():
+    """round 6: the per-query tables of machine mode (ROWSUM, QUERY, FOLD, the queries' Poseidon2 rows) are filled by device kernels from the inner proofs'
+    words; ZKHIP_REC_HOST=1 keeps the host's walk (fill_proof).  Same machine, same inner proofs -> the same outer proof bytes, in fresh processes."""
+    import hashlib
+    import os
+    import subprocess
+    import sys
+    code = r'''
+import hashlib, sys
+sys.path[:0] = [".", "tests"]
+import machines as M, oracle_lib as O
+from zktls_amd._lib import Params
+from zktls_amd.device import Context, InnerMachine
+ctx = Context(0)
+made = [M.byte_machine(7, 3, seed) for seed in (1, 2)]
+q, pb = 3, 1
+proofs, pubs, chips, vk = [], [], None, None
+for mains, pres, progs, tabs, pub in made:
+    lns = [m.shape[0].bit_length() - 1 for m in mains]
+    prm = O.default_params(1, q, pb)
+    vk = [int(x) for x in O.machine_setup(pres, lns, prm)]
+    chips = [dict(ln=lns[c], W=mains[c].shape[1], Pw=0 if pres[c] is None else pres[c].shape[1], prog=progs[c], tab=tabs[c]) for c in range(len(mains))]
+    proofs.append(O.prove_machine_keyed(mains, pres, progs, tabs, pub, prm)); pubs.append(pub)
+im = InnerMachine(chips, vk, q, pb, len(pubs[0]))
+prm = Params(1, 20, 8)
+key = ctx.machine_verifier_setup(im, prm, 2)
+print(hashlib.sha256(ctx.prove_machine_verifier(key, im, proofs, pubs, prm).tobytes()).hexdigest())
+'''
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    outs = []
+    for host in ("0", "1"):
+        env = dict(os.environ, ZKHIP_REC_HOST=host)
+        outs.append(subprocess.run([sys.executable, "-c", code], cwd=root, env=env, capture_output=True, text=True, check=True).stdout.split()[-1])
+    assert outs[0] == outs[1]

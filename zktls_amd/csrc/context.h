@@ -99,6 +99,7 @@ enum Slot {
     S_CHIP_B,          // second table of a built-in machine (the SHA-256 machine's range table: values at setup, multiplicities per proof)
     S_KEYTRACE,        // keyed machine: a chip's trace rows [preprocessed | main] for its permutation trace
     S_REC_A, S_REC_B, S_REC_C, S_REC_D, S_REC_E, S_REC_F, S_REC_G, S_REC_H, S_REC_I, S_REC_J,   // recursion machines (fri_chip.hip, shard_verifier.inl): traces and tables of their chips, alive for the whole prove call
+    S_WIT_A, S_WIT_B, S_WIT_C,   // recursion machines, device witnesses (machine_verifier.inl): the inner proofs' words; plan + per-proof values + scratch; every Poseidon2 row's (state, bit, KP)
     S_COUNT
 };
 

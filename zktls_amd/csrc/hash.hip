@@ -797,8 +797,9 @@ __device__ __forceinline__ void p2r_rows_kernel_body(const p2chip::P2RArgs& a) {
     }
     const uint64_t r = p - a.n_chains;
     if (r < a.n_transcript) {
-        for (int j = 0; j < 16; j++) in[j] = to_monty(a.chain_inputs[16 * r + j]);
-        uint32_t* t = a.trace + (uint64_t)a.trows[r] * a.ld;
+        if (a.seg_rows && (r % a.seg_rows) < a.skip_first) return;            // (a proof's transcript rows: filled by another launch, from the host's walk)
+        for (int j = 0; j < 16; j++) in[j] = a.inputs_monty ? a.chain_inputs[16 * r + j] : to_monty(a.chain_inputs[16 * r + j]);
+        uint32_t* t = a.trace + (uint64_t)(a.trows ? a.trows[r] : r) * a.ld;
         p2chip_fill_row(t, in, a.row_bits ? a.row_bits[r] : 0u, 0u, 0u, 0u, 0u, 0u, out);
         if (a.row_kps) t[R_KP] = to_monty(a.row_kps[r]);
         return;
@@ -811,6 +812,89 @@ __device__ __forceinline__ void p2r_rows_kernel_body(const p2chip::P2RArgs& a) {
 __global__ void __launch_bounds__(64) p2r_rows_kernel(p2chip::P2RArgs a) { p2r_rows_kernel_body(a); }
 struct p2r_rows_kernel_bargs { p2chip::P2RArgs a; static p2r_rows_kernel_bargs make(p2chip::P2RArgs a) { return p2r_rows_kernel_bargs{a}; } };
 __global__ void __launch_bounds__(64) p2r_rows_kernel_batch(const p2r_rows_kernel_bargs* __restrict__ zk_arr) { const p2r_rows_kernel_bargs& zk_b = zk_arr[blockIdx.z]; p2r_rows_kernel_body(zk_b.a); }
+// machine mode's chains (p2chip.h, MrecChainArgs): what machine_verifier.inl's fill_proof walks on the host (tree_q / fri_q), one lane per chain
+__global__ void __launch_bounds__(64) mrec_chains_kernel(p2chip::MrecChainArgs a) {
+    using namespace p2chip;
+    const uint64_t gid = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t per_q = a.n_trees + a.R;
+    if (gid >= (uint64_t)a.NP * a.Q * per_q) return;
+    const uint32_t c = (uint32_t)(gid % per_q), q = (uint32_t)((gid / per_q) % a.Q), p = (uint32_t)(gid / ((uint64_t)per_q * a.Q));
+    const uint32_t* w = a.proofs + (uint64_t)p * a.proof_words;
+    const uint32_t qidx = a.vals[(uint64_t)p * a.vals_stride + q];
+    const uint32_t* qw = w + a.o_queries + (uint64_t)q * a.per_query;
+    uint32_t in[16], out[16];
+    // a row = its input state, direction bit and KP column (the row kernel fills the 360 columns from them, one lane per row); out = the permutation
+    auto emit = [&](uint64_t row, uint32_t bit, uint32_t kp) {
+        uint32_t* d = a.row_in + 16 * row;
+        for (int j = 0; j < 16; j++) { d[j] = in[j]; out[j] = in[j]; }
+        a.row_bit[row] = bit; a.row_kp[row] = kp;
+        p2_permute_dev(out);
+    };
+    if (c >= a.n_trees) {                                          // ---- a FRI layer: the pair's leaf, then its path
+        const uint32_t l = c - a.n_trees;
+        const uint64_t at = ((uint64_t)p * a.Q + q) * a.R + l;
+        const uint32_t k = a.pair_k[at];
+        uint64_t fat = a.fri_off;
+        for (uint32_t i = 0; i < l; i++) fat += 4 + 8 * (uint64_t)(a.H - 1 - i);
+        const uint32_t* path = qw + fat + 4;
+        const uint64_t r0 = (uint64_t)l + (uint64_t)l * (uint64_t)(2 * (a.H - 1) - (l - 1)) / 2;      // rows of the layers before: l leaves + sum_{i < l} (H - 1 - i) path rows
+        uint64_t row = (uint64_t)p * a.p2_rows + a.p2_fri0 + (uint64_t)q * a.fri_rows + r0;
+        for (int j = 0; j < 8; j++) { in[j] = a.pairs[8 * at + (uint64_t)j]; in[8 + j] = 0u; }
+        emit(row++, 0u, 2u * k);
+        const uint32_t depth = a.H - 1 - l;
+        for (uint32_t lvl = 0; lvl < depth; lvl++) {
+            const uint32_t b = (k >> lvl) & 1u;
+            for (int j = 0; j < 8; j++) { in[b ? 8 + j : j] = out[j]; in[b ? j : 8 + j] = to_monty(path[8 * lvl + j]); }
+            emit(row++, b, k >> lvl);
+        }
+        bool ok = true;
+        for (int j = 0; j < 8; j++) ok = ok && from_monty(out[j]) == w[a.o_lroots + 8 * l + (uint32_t)j];
+        if (!ok) atomicCAS(a.err + p, 0u, 1u);
+        return;
+    }
+    // ---- a commitment: sponges (shorter heights first, the tallest last), then the path with the injections
+    const MrecTreePlan& tp = a.trees[c];
+    const uint32_t index = qidx >> tp.shift;
+    uint64_t row = (uint64_t)p * a.p2_rows + tp.row0 + (uint64_t)q * tp.rows_per_query;
+    uint32_t dg[16][8];
+    for (uint32_t sidx = 0; sidx < tp.n_sponges; sidx++) {
+        const uint32_t words = tp.sp_words[sidx], nb = (words + 7) / 8;
+        const int32_t* so = a.src + tp.sp_src[sidx];
+        for (int j = 0; j < 16; j++) in[j] = 0u;
+        for (uint32_t b = 0; b < nb; b++) {
+            const uint32_t kk = words - 8 * b < 8 ? words - 8 * b : 8u;
+            for (uint32_t j = 0; j < kk; j++) { const int32_t o = so[8 * b + j]; in[j] = o < 0 ? 0u : to_monty(qw[o]); }
+            emit(row++, 0u, (b == nb - 1 && sidx + 1 == tp.n_sponges) ? 2u * index : 0u);
+            for (int j = 0; j < 16; j++) in[j] = out[j];                                                // the sponge's state goes on (overwrite mode)
+        }
+        for (int j = 0; j < 8; j++) dg[sidx][j] = in[j];
+    }
+    uint32_t cur[8];
+    for (int j = 0; j < 8; j++) cur[j] = dg[tp.n_sponges - 1][j];
+    const uint32_t* path = qw + tp.path_off;
+    for (uint32_t lvl = 0; lvl < tp.depth; lvl++) {
+        const uint32_t b = (index >> lvl) & 1u;
+        for (int j = 0; j < 8; j++) { in[b ? 8 + j : j] = cur[j]; in[b ? j : 8 + j] = to_monty(path[8 * lvl + j]); }
+        emit(row++, b, index >> lvl);
+        for (int j = 0; j < 8; j++) cur[j] = out[j];
+        const int32_t js = tp.inj[lvl];
+        if (js >= 0) {
+            for (int j = 0; j < 8; j++) { in[j] = cur[j]; in[8 + j] = dg[js][j]; }
+            emit(row++, 0u, index >> (lvl + 1));
+            for (int j = 0; j < 8; j++) cur[j] = out[j];
+        }
+    }
+    bool ok = true;
+    for (int j = 0; j < 8; j++) ok = ok && from_monty(cur[j]) == (tp.root_off < 0 ? a.key_root[j] : w[tp.root_off + j]);
+    if (!ok) atomicCAS(a.err + p, 0u, 3u);
+}
+hipError_t launch_mrec_chains(const p2chip::MrecChainArgs& a, hipStream_t s) {
+    const uint64_t n = (uint64_t)a.NP * a.Q * (a.n_trees + a.R);
+    if (n == 0) return hipSuccess;
+    hipLaunchKernelGGL(mrec_chains_kernel, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, s, a);
+    return hipGetLastError();
+}
+
 // The rows after the used ones are all the permutation of the zero state: ONE lane fills the first of them, and this kernel replicates it over the
 // rest -- consecutive rows are one contiguous block, so every store instruction writes 1 KB of consecutive bytes (a lane that fills its own row
 // stores 16 bytes at a stride of 1 440: 640 GB/s, docs/RECURSION_NEXT.md)

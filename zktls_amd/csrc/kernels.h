@@ -180,9 +180,10 @@ struct P2Tables;
 hipError_t hash_upload_p2_tables(const P2Tables& t, hipStream_t s);
 hipError_t stark_upload_p2_tables(const P2Tables& t, hipStream_t s);
 // trace of the Poseidon2 permutation chip for a set of Merkle paths (p2chip.h)
-namespace p2chip { struct MerkleTraceArgs; struct LayerPathsArgs; struct P2RArgs; }
+namespace p2chip { struct MerkleTraceArgs; struct LayerPathsArgs; struct P2RArgs; struct MrecChainArgs; }
 hipError_t launch_p2chip_merkle(const p2chip::MerkleTraceArgs& a, hipStream_t s);
 hipError_t launch_p2chip_layer_paths(const p2chip::LayerPathsArgs& a, hipStream_t s);     // the FRI-layers variant: paths of different depths
+hipError_t launch_mrec_chains(const p2chip::MrecChainArgs& a, hipStream_t s);                // machine mode: the queries' Poseidon2 chains walked on the device
 hipError_t launch_p2r_rows(const p2chip::P2RArgs& a, hipStream_t s);                        // the shard verifier's chip: chains of sponge + path rows, transcript rows
 // raw permutation on `count` states of 16 words (KAT / microbenchmark)
 hipError_t launch_permute_states(uint32_t* states, uint64_t count, hipStream_t s);

@@ -1066,13 +1066,111 @@ inline Ext recombine4(const Ext* four) {            // sum_k X^k four[k]
 }
 struct ScVals { Ext zn, invf, invt, self, sell, selt, znx, q0, q1, quo, acc, cum, totin, toto; Ext qz[8]; };
 
-int fill_proof(const Machine& m, int p, const uint8_t* inner, size_t inner_len, const uint32_t* pubs, HostTabs& ht) {
+// ---- the per-query part of a proof's tables ON THE DEVICE (round 6).  The plan is a function of the machine's shape alone: the ROWSUM
+// rows of one query (where each of a row's eight words sits in the proof relative to the query's first word, which power a segment's sum is weighted with,
+// where Horner restarts), the commitments' chains (p2chip.h MrecTreePlan) and the layers at which a height joins the fold chain.  What is left on the
+// host per proof is its transcript (a serial sponge chain) and the tables that follow a proof's opened values once (SCALARS, EVAL, LOGUP, OPENED, TS,
+// SAMPLES); it hands the device the challenges and sums the per-query rows read (DevVals).
+struct WRow { int32_t src[8]; int32_t kz[2], kn[2]; uint32_t flags; };                 // flags: 1 = Horner restarts at word 7 (r7), 2 = at word 3 (r3)
+struct WitPlan {
+    std::vector<WRow> rows;                 // the rows of ONE query, in table order
+    std::vector<uint32_t> g0;               // rows [g0[hi], g0[hi + 1]) belong to height sh.hs[hi]
+    std::vector<std::pair<int, uint32_t>> pw_keys;      // (height, exponent) of every power the rows read: DevVals::pw in this order
+    std::vector<p2chip::MrecTreePlan> trees;
+    std::vector<int32_t> src;               // the commitments' leaf word offsets
+    int32_t inj_hi[32];                     // layer -> index in sh.hs of the height that joins there, -1: none
+    uint32_t fri_off = 0;                   // a query's first FRI word relative to its first word
+    int32_t c0[32];                         // per height index: the first chip of that height (whose zeta g the QUERY row takes)
+};
+struct DevVals { std::vector<uint32_t> v; };    // [indices Q][betas 4 R][fa 4][zeta 4][per height: znx 4, yz 4, yn 4][pw 4 each], Montgomery except the indices
+inline size_t dv_words(const MShape& sh, const WitPlan& pl) { return (size_t)sh.Q + 4 * (size_t)sh.R + 8 + 12 * sh.hs.size() + 4 * pl.pw_keys.size(); }
+WitPlan build_wit_plan(const MShape& sh) {
+    WitPlan pl;
+    const int H = sh.H, R = sh.R;
+    // where a query's pieces sit relative to its first word (fill_proof's QPos with q_at = 0)
+    size_t row_off[N_TREES][MAX_INNER_CHIPS] = {}, path_off[N_TREES] = {}, at = 0;
+    for (int t = 0; t < N_TREES; t++) {
+        if (!sh.has_tree[t]) continue;
+        for (int c : sh.tree_chips[t]) { row_off[t][c] = at; at += (*sh.tree_w[t])[(size_t)c]; }
+        path_off[t] = at; at += 8 * (size_t)sh.tree_hs[t][0];
+    }
+    pl.fri_off = (uint32_t)at;
+    auto leaf_off = [&](int t, int h, uint32_t i) -> int32_t {
+        for (const LeafSeg& sg : sh.leaf[t][h].segs) if (i >= sg.at && i < sg.at + sg.width) return (int32_t)(row_off[t][sg.chip] + (i - sg.at));
+        return -1;
+    };
+    auto pw_index = [&](int h, uint32_t e) -> int32_t {
+        for (size_t i = 0; i < pl.pw_keys.size(); i++) if (pl.pw_keys[i].first == h && pl.pw_keys[i].second == e) return (int32_t)i;
+        pl.pw_keys.emplace_back(h, e);
+        return (int32_t)pl.pw_keys.size() - 1;
+    };
+    const int kz[N_TREES] = {K_EL, K_TL, K_PL, K_Q}, kn[N_TREES] = {K_EN, K_TN, K_PN, -1};
+    const std::vector<RsRow> all = rowsum_rows(sh);
+    const size_t nq = all.size() / (size_t)sh.Q;
+    pl.g0.assign(sh.hs.size() + 1, 0u);
+    for (size_t i = 0; i < nq; i++) {                       // query 0's rows: every query has the same
+        const RsRow& rr = all[i];
+        WRow wr{};
+        for (uint32_t j = 0; j < 8; j++) wr.src[j] = j < rr.k ? leaf_off(rr.tr, rr.h, 8 * rr.b + j) : -1;
+        for (int sidx = 0; sidx < 2; sidx++) {
+            wr.kz[sidx] = wr.kn[sidx] = -1;
+            if (rr.start[sidx] < 0) continue;
+            wr.kz[sidx] = pw_index(rr.h, sh.seg_e[rr.start[sidx]][kz[rr.tr]]);
+            if (kn[rr.tr] >= 0) wr.kn[sidx] = pw_index(rr.h, sh.seg_e[rr.start[sidx]][kn[rr.tr]]);
+        }
+        wr.flags = (rr.r7 ? 1u : 0u) | (rr.r3 ? 2u : 0u);
+        pl.rows.push_back(wr);
+        size_t hi = 0;
+        while (sh.hs[hi] != rr.h) hi++;
+        pl.g0[hi + 1] = (uint32_t)(i + 1);
+    }
+    for (size_t hi = 1; hi <= sh.hs.size(); hi++) if (pl.g0[hi] < pl.g0[hi - 1]) pl.g0[hi] = pl.g0[hi - 1];     // (a height without rows: an empty range)
+    for (size_t hi = 0; hi < sh.hs.size(); hi++) { int c = 0; while (sh.lh[c] != sh.hs[hi]) c++; pl.c0[hi] = c; }
+    for (int l = 0; l < 32; l++) pl.inj_hi[l] = -1;
+    for (int l = 1; l < R; l++) for (size_t hi = 0; hi < sh.hs.size(); hi++) if (sh.hs[hi] == H - l && sh.hs[hi] != H) pl.inj_hi[l] = (int32_t)hi;
+    for (int tr = 0; tr < N_TREES; tr++) {
+        if (!sh.has_tree[tr]) continue;
+        const std::vector<int>& hs = sh.tree_hs[tr];
+        const std::vector<int> so = sponge_order(sh, tr);
+        p2chip::MrecTreePlan tp{};
+        tp.row0 = (uint32_t)sh.p2_tree0[tr]; tp.rows_per_query = (uint32_t)sh.tree_rows[tr];
+        tp.n_sponges = (uint32_t)so.size(); tp.depth = (uint32_t)hs[0]; tp.shift = (uint32_t)(H - hs[0]); tp.path_off = (uint32_t)path_off[tr];
+        tp.root_off = -1;
+        for (size_t sidx = 0; sidx < so.size(); sidx++) {
+            const uint32_t words = sh.leaf[tr][so[sidx]].words;
+            tp.sp_words[sidx] = words; tp.sp_src[sidx] = (uint32_t)pl.src.size();
+            for (uint32_t i = 0; i < ((words + 7) / 8) * 8; i++) pl.src.push_back(i < words ? leaf_off(tr, so[sidx], i) : -1);
+        }
+        for (int lvl = 0; lvl < 32; lvl++) tp.inj[lvl] = -1;
+        for (int lvl = 0; lvl < hs[0]; lvl++) {
+            const int h = hs[0] - lvl - 1;
+            if (h != hs[0] && sh.has_h(tr, h)) for (size_t sidx = 0; sidx < so.size(); sidx++) if (so[sidx] == h) tp.inj[lvl] = (int32_t)sidx;
+        }
+        pl.trees.push_back(tp);
+    }
+    return pl;
+}
+
+int fill_proof(const Machine& m, int p, const uint8_t* inner, size_t inner_len, const uint32_t* pubs, HostTabs& ht, const WitPlan* dplan = nullptr, DevVals* dvals = nullptr) {
     const MShape& sh = m.sh;
+    const bool on_device = dplan != nullptr;               // the per-query tables (ROWSUM, QUERY, FOLD, the queries' Poseidon2 rows) are the device's: see top_finish
     const int C = sh.C, Q = sh.Q, R = sh.R, H = sh.H;
     auto bad = [&](const char* what) { return fail(ZKHIP_ERR_VERIFY, std::string("prove_machine_verifier: proof ") + std::to_string(p) + " rejected: " + what); };
     Wit wt;
     wt.w = (const uint32_t*)inner; wt.pubs = pubs;
     const uint32_t* w = wt.w;
+#ifdef ZKHIP_AB_HOOKS
+    static const bool sec_timing = getenv("ZKHIP_REC_SECTIONS") != nullptr;
+    auto sec_t = std::chrono::steady_clock::now();
+    auto sec = [&](const char* what) {
+        if (!sec_timing) return;
+        const auto now = std::chrono::steady_clock::now();
+        std::fprintf(stderr, "      [fill_proof %d] %-28s %8.1f us\n", p, what, std::chrono::duration<double, std::micro>(now - sec_t).count());
+        sec_t = now;
+    };
+#else
+    auto sec = [](const char*) {};
+#endif
     // ---- positions
     size_t pos = (size_t)sh.HL + 2;
     wt.o_troot = pos; pos += 8; wt.o_proot = pos; pos += 8; wt.o_cum = pos; pos += 4 * (size_t)C; wt.o_qroot = pos; pos += 8; wt.o_stream = pos; pos += 4 * (size_t)sh.NV;
@@ -1089,9 +1187,10 @@ int fill_proof(const Machine& m, int p, const uint8_t* inner, size_t inner_len, 
     for (size_t i = (size_t)sh.HL + 2; i < inner_len / 4; i++) if (w[i] >= P) return bad("a non-canonical word");
     for (int i = 0; i < sh.NPUB; i++) if (pubs[i] >= P) return bad("a non-canonical public value");
     // ---- the transcript: every sponge row's input state, the challenges
-    uint32_t* tin = ht.p2_in.data() + 16 * (size_t)p * sh.p2_rows;
-    uint32_t* tbit = ht.p2_bit.data() + (size_t)p * sh.p2_rows;
-    uint32_t* tkp = ht.p2_kp.data() + (size_t)p * sh.p2_rows;
+    const size_t p2_stride = on_device ? (size_t)sh.NT : sh.p2_rows;      // (device mode: only the transcript's rows are walked here)
+    uint32_t* tin = ht.p2_in.data() + 16 * (size_t)p * p2_stride;
+    uint32_t* tbit = ht.p2_bit.data() + (size_t)p * p2_stride;
+    uint32_t* tkp = ht.p2_kp.data() + (size_t)p * p2_stride;
     auto src_val = [&](const Src& s) -> uint32_t {
         switch (s.kind) {
             case S_CONST: return s.a; case S_TROOT: return w[wt.o_troot + s.a]; case S_PUB: return pubs[s.a] % P; case S_PROOT: return w[wt.o_proot + s.a];
@@ -1113,6 +1212,7 @@ int fill_proof(const Machine& m, int p, const uint8_t* inner, size_t inner_len, 
             if (T >= sh.TP) for (int j = 0; j < 8; j++) wt.samples[8 * (size_t)(T - sh.TP) + (size_t)j] = from_monty(st[7 - j]);
         }
     }
+    sec("checks + transcript");
     wt.gamma = chal[(size_t)sh.TG]; wt.beta = chal2[(size_t)sh.TG]; wt.alpha = chal[(size_t)sh.TA]; wt.zeta = chal[(size_t)sh.TQ]; wt.fa = chal[(size_t)sh.TF];
     for (int l = 0; l < R; l++) wt.betas.push_back(chal[(size_t)(sh.TL0 + l)]);
     // proof of work and the query indices (SAMPLES main)
@@ -1124,6 +1224,7 @@ int fill_proof(const Machine& m, int p, const uint8_t* inner, size_t inner_len, 
         wt.indices = drawn;
         if ((int)wt.indices.size() != Q) return fail(ZKHIP_ERR_INTERNAL, "prove_machine_verifier: query indices");
     }
+    sec("samples");
     auto stream_ext = [&](uint32_t posv) { return ext_at(w + wt.o_stream + 4 * (size_t)posv); };
     // ---- SCALARS values per chip
     std::vector<ScVals> sc((size_t)C);
@@ -1169,6 +1270,7 @@ int fill_proof(const Machine& m, int p, const uint8_t* inner, size_t inner_len, 
         const uint32_t c = (key - 1 - sh.NV - (uint32_t)sh.NPUB) / 3, which = (key - 1 - sh.NV - (uint32_t)sh.NPUB) % 3;
         return which == 0 ? sc[c].self : (which == 1 ? sc[c].sell : sc[c].selt);
     };
+    sec("scalars");
     // ---- EVAL
     std::vector<Ext> acc_eval((size_t)C);
     {
@@ -1186,6 +1288,7 @@ int fill_proof(const Machine& m, int p, const uint8_t* inner, size_t inner_len, 
             acc_eval[(size_t)e.chip] = run;
         }
     }
+    sec("eval");
     // ---- LOGUP
     {
         const LgCols lc = lg_cols();
@@ -1235,6 +1338,7 @@ int fill_proof(const Machine& m, int p, const uint8_t* inner, size_t inner_len, 
             if (i == sh.lrow1[(size_t)c] && !ext_eq(acco, sc[(size_t)c].acc)) return bad("a chip's constraints do not match its quotient at zeta");
         }
     }
+    sec("logup");
     // ---- OPENED (the stream): the sums per height, the powers the row sums are weighted with
     std::map<std::pair<int, uint32_t>, Ext> pwh;
     Ext yz_h[32], yn_h[32];
@@ -1260,6 +1364,20 @@ int fill_proof(const Machine& m, int p, const uint8_t* inner, size_t inner_len, 
             if (s.last) { yz_h[s.h] = yz; yn_h[s.h] = yn; }
         }
     }
+    sec("opened");
+    if (on_device) {
+        // ---- what the device's per-query kernels read of this proof
+        std::vector<uint32_t>& v = dvals->v;
+        v.assign(dv_words(sh, *dplan), 0u);
+        size_t at = 0;
+        for (int q = 0; q < Q; q++) v[at++] = wt.indices[(size_t)q];
+        auto pute = [&](const Ext& e) { for (int j = 0; j < 4; j++) v[at++] = e.c[j]; };
+        for (int l = 0; l < R; l++) pute(wt.betas[(size_t)l]);
+        pute(wt.fa); pute(wt.zeta);
+        for (size_t hi = 0; hi < sh.hs.size(); hi++) { pute(sc[(size_t)dplan->c0[hi]].znx); pute(yz_h[sh.hs[hi]]); pute(yn_h[sh.hs[hi]]); }
+        for (const auto& k : dplan->pw_keys) pute(pwh[{k.first, k.second}]);
+    }
+    if (!on_device) {
     // ---- per query: where its rows and paths are
     struct QPos { size_t row[N_TREES][MAX_INNER_CHIPS]; size_t path[N_TREES]; size_t fri; };
     std::vector<QPos> qp((size_t)Q);
@@ -1313,6 +1431,7 @@ int fill_proof(const Machine& m, int p, const uint8_t* inner, size_t inner_len, 
             az_qh[(size_t)rr.q * 32 + (size_t)rr.h] = az; an_qh[(size_t)rr.q * 32 + (size_t)rr.h] = an;
         }
     }
+    sec("rowsum");
     // ---- QUERY
     {
         size_t i = (size_t)p * (size_t)Q * sh.hs.size();
@@ -1333,6 +1452,7 @@ int fill_proof(const Machine& m, int p, const uint8_t* inner, size_t inner_len, 
                 put(QM_RO, ro); put(QM_AZ, az); put(QM_AN, an); put(QM_YZ, yz); put(QM_YN, yn); put(QM_ZETA, zeta); put(QM_ZNX, znx); put(QM_I1, i1); put(QM_I2, i2); put(QM_P1, p1); put(QM_P2, p2);
             }
     }
+    sec("query");
     // ---- FOLD rows (host: the recursion form with what joins on the way down) and the Poseidon2 rows of the FRI layers
     {
         using namespace frichip;
@@ -1565,6 +1685,8 @@ int fill_proof(const Machine& m, int p, const uint8_t* inner, size_t inner_len, 
             if (qerr[(size_t)q]) return fail(ZKHIP_ERR_INTERNAL, "prove_machine_verifier: row layout");
         }
     }
+    sec("fold rows + Poseidon2 chains");
+    }   // (!on_device)
     // ---- TS
     {
         for (int T = 0; T < sh.NTS; T++) {
@@ -1575,6 +1697,7 @@ int fill_proof(const Machine& m, int p, const uint8_t* inner, size_t inner_len, 
             if (T == sh.HL / 8) for (int j = 0; j < 8; j++) row[8 + j] = to_monty(w[wt.o_troot + (size_t)j]);
         }
     }
+    sec("ts");
     return ZKHIP_OK;
 }
 }  // namespace
@@ -1584,6 +1707,142 @@ int fill_proof(const Machine& m, int p, const uint8_t* inner, size_t inner_len, 
 // ---- the entries (their bodies live in the namespace: its names hide shard_verifier.inl's of the same spelling)
 namespace zk {
 namespace mrec {
+
+// ---- the per-query tables on the device (WitPlan above): what fill_proof's ROWSUM / QUERY / FOLD sections compute on the host, word for word
+struct WitArgs {
+    const uint32_t* proofs; uint64_t proof_words;       // [NP][proof_words] canonical
+    const uint32_t* vals; uint64_t vals_stride;         // DevVals per proof
+    uint32_t v_betas, v_fa, v_zeta, v_h, v_pw;
+    const WRow* rows; const uint32_t* g0; const int32_t* hs; const int32_t* inj_hi;
+    uint32_t nh, nq, NP, Q, R, H, NTREES;
+    uint32_t o_queries, per_query, o_final, fri_off;
+    uint32_t* rs; uint32_t* qt; uint32_t* fold; uint32_t fw, inj_col;
+    uint32_t* roh;                                       // [NP][Q][nh][4]
+    uint32_t* pairs; uint32_t* pair_k;                   // [NP Q R][8], [NP Q R]
+    uint32_t* err;
+};
+__device__ __forceinline__ Ext w_ld4(const uint32_t* p) { return Ext{{p[0], p[1], p[2], p[3]}}; }
+__device__ __forceinline__ Ext w_ext_at(const uint32_t* p) { return Ext{{to_monty(p[0]), to_monty(p[1]), to_monty(p[2]), to_monty(p[3])}}; }
+__device__ __forceinline__ void w_put(uint32_t* r, uint32_t col, const Ext& e) { r[col] = e.c[0]; r[col + 1] = e.c[1]; r[col + 2] = e.c[2]; r[col + 3] = e.c[3]; }
+// one lane per (proof, query, height): the height's ROWSUM rows (Horner from the back over the row words the sponge rows hash), then its QUERY row
+__global__ void __launch_bounds__(64) mrec_rowsum_query_kernel(WitArgs a) {
+    const uint64_t gid = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (gid >= (uint64_t)a.NP * a.Q * a.nh) return;
+    const uint32_t hi = (uint32_t)(gid % a.nh), q = (uint32_t)((gid / a.nh) % a.Q), p = (uint32_t)(gid / ((uint64_t)a.nh * a.Q));
+    const uint32_t* w = a.proofs + (uint64_t)p * a.proof_words;
+    const uint32_t* qw = w + a.o_queries + (uint64_t)q * a.per_query;
+    const uint32_t* v = a.vals + (uint64_t)p * a.vals_stride;
+    const Ext fa = w_ld4(v + a.v_fa), zeta = w_ld4(v + a.v_zeta);
+    Ext acc = ext_zero(), az = ext_zero(), an = ext_zero();
+    for (uint32_t i = a.g0[hi]; i < a.g0[hi + 1]; i++) {
+        const WRow& rr = a.rows[i];
+        uint32_t* r = a.rs + (uint64_t)RS_MAIN * (((uint64_t)p * a.Q + q) * a.nq + i);
+        uint32_t vals[8];
+        for (int j = 0; j < 8; j++) { const int32_t o = rr.src[j]; vals[j] = o < 0 ? 0u : to_monty(qw[o]); r[RS_V + j] = vals[j]; }
+        w_put(r, RS_FA, fa); w_put(r, RS_ACCIN, acc); w_put(r, RS_AZIN, az); w_put(r, RS_ANIN, an);
+        Ext t0 = ext_zero(), t4 = ext_zero(), prev = acc;
+        for (int sidx = 7; sidx >= 0; sidx--) {
+            const bool restart = (sidx == 7 && (rr.flags & 1u)) || (sidx == 3 && (rr.flags & 2u));
+            const Ext carried = restart ? ext_zero() : ext_mul(prev, fa);
+            prev = ext_add_base(carried, vals[sidx]);
+            w_put(r, RS_T + 4u * (uint32_t)sidx, prev);
+            if (sidx == 4) t4 = prev;
+            if (sidx == 0) t0 = prev;
+        }
+        acc = t0;
+        const uint32_t kzc[2] = {RS_KZ0, RS_KZ4}, knc[2] = {RS_KN0, RS_KN4};
+        for (int sidx = 0; sidx < 2; sidx++) {
+            if (rr.kz[sidx] < 0) continue;
+            const Ext st = sidx ? t4 : t0;
+            const Ext kzv = w_ld4(v + a.v_pw + 4u * (uint32_t)rr.kz[sidx]);
+            w_put(r, kzc[sidx], kzv);
+            az = ext_add(az, ext_mul(kzv, st));
+            if (rr.kn[sidx] >= 0) { const Ext knv = w_ld4(v + a.v_pw + 4u * (uint32_t)rr.kn[sidx]); w_put(r, knc[sidx], knv); an = ext_add(an, ext_mul(knv, st)); }
+        }
+        w_put(r, RS_AZO, az); w_put(r, RS_ANO, an);
+    }
+    // ---- the QUERY row of (query, height)
+    const int h = a.hs[hi];
+    const uint32_t idx0 = v[q], ic = idx0 >> (a.H - (uint32_t)h);
+    const uint32_t xq = fpow(two_adic_generator(h), reverse_bits(ic, h));
+    const Ext x = ext_from_base(fmul(MONTY_GEN, xq));
+    const Ext znx = w_ld4(v + a.v_h + 12u * hi), yz = w_ld4(v + a.v_h + 12u * hi + 4), yn = w_ld4(v + a.v_h + 12u * hi + 8);
+    const Ext i1 = ext_inv(ext_sub(x, zeta)), i2 = ext_inv(ext_sub(x, znx));
+    const Ext p1 = ext_mul(ext_sub(az, yz), i1), p2 = ext_mul(ext_sub(an, yn), i2), ro = ext_add(p1, p2);
+    uint32_t* r = a.qt + (uint64_t)Q_MAIN * (((uint64_t)p * a.Q + q) * a.nh + hi);
+    r[QM_IDX - Q_PRE] = to_monty(ic); r[QM_XQ - Q_PRE] = xq; r[QM_IDX0 - Q_PRE] = to_monty(idx0);
+    w_put(r, QM_RO - Q_PRE, ro); w_put(r, QM_AZ - Q_PRE, az); w_put(r, QM_AN - Q_PRE, an); w_put(r, QM_YZ - Q_PRE, yz); w_put(r, QM_YN - Q_PRE, yn);
+    w_put(r, QM_ZETA - Q_PRE, zeta); w_put(r, QM_ZNX - Q_PRE, znx); w_put(r, QM_I1 - Q_PRE, i1); w_put(r, QM_I2 - Q_PRE, i2); w_put(r, QM_P1 - Q_PRE, p1); w_put(r, QM_P2 - Q_PRE, p2);
+    w_put(a.roh, 4u * (uint32_t)((((uint64_t)p * a.Q + q) * a.nh + hi)), ro);
+}
+// the host's running value is ONE variable over all rows of a proof: the first row of a (query, height) group carries, in ACCIN, the last row of the
+// group before it (a column no constraint reads there: Horner restarts) -- copied here so that the tables are the host's word for word
+__global__ void __launch_bounds__(64) mrec_rowsum_accin_kernel(WitArgs a) {
+    const uint64_t gid = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (gid >= (uint64_t)a.NP * a.Q * a.nh) return;
+    const uint32_t hi = (uint32_t)(gid % a.nh), q = (uint32_t)((gid / a.nh) % a.Q), p = (uint32_t)(gid / ((uint64_t)a.nh * a.Q));
+    if (a.g0[hi] == a.g0[hi + 1]) return;
+    const uint64_t local = (uint64_t)q * a.nq + a.g0[hi];
+    if (local == 0) return;
+    uint32_t* r = a.rs + (uint64_t)RS_MAIN * ((uint64_t)p * a.Q * a.nq + local);
+    const uint32_t* before = r - RS_MAIN;
+    for (int j = 0; j < 4; j++) r[RS_ACCIN + j] = before[RS_T + j];
+}
+// one lane per (proof, query): the fold chain's rows, the layers' pairs for the Poseidon2 chains, the final value
+__global__ void __launch_bounds__(64) mrec_fold_kernel(WitArgs a) {
+    using namespace frichip;
+    const uint64_t gid = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (gid >= (uint64_t)a.NP * a.Q) return;
+    const uint32_t q = (uint32_t)(gid % a.Q), p = (uint32_t)(gid / a.Q);
+    const uint32_t* w = a.proofs + (uint64_t)p * a.proof_words;
+    const uint32_t* qw = w + a.o_queries + (uint64_t)q * a.per_query;
+    const uint32_t* v = a.vals + (uint64_t)p * a.vals_stride;
+    const uint32_t idx0 = v[q], INJ = a.inj_col, INJF = INJ + 4;
+    uint32_t idx = idx0;
+    const uint32_t* rohq = a.roh + 4u * (uint32_t)(((uint64_t)p * a.Q + q) * a.nh);
+    Ext own = w_ld4(rohq);                                     // the tallest height's reduced opening (sh.hs[0] = H)
+    uint32_t tcol[MAX_LAYERS];
+    uint64_t fat = a.fri_off;
+    const int H = (int)a.H, R = (int)a.R;
+    for (int l = 0; l < R; l++) {
+        const uint64_t at = ((uint64_t)p * a.Q + q) * (uint64_t)R + (uint64_t)l;
+        uint32_t* row = a.fold + (uint64_t)a.fw * at;
+        row[INJF + 1] = to_monty(idx0);
+        if (l > 0 && a.inj_hi[l] >= 0) { const Ext jv = w_ld4(rohq + 4 * a.inj_hi[l]); w_put(row, INJ, jv); row[INJF] = MONTY_R1; own = ext_add(own, jv); }
+        const uint32_t bit = idx & 1u, k = idx >> 1;
+        const Ext sib = w_ext_at(qw + fat), beta = w_ld4(v + a.v_betas + 4u * (uint32_t)l);
+        fat += 4 + 8 * (uint64_t)(H - 1 - l);
+        const Ext e0 = bit ? sib : own, e1 = bit ? own : sib;
+        const int lhh = H - (l + 1);
+        const uint32_t x = fpow(two_adic_generator(lhh + 1), reverse_bits(k, lhh)), xi = finv(x);
+        const Ext even = ext_mul_base(ext_add(e0, e1), MONTY_INV2), odd = ext_mul_base(ext_sub(e0, e1), fmul(MONTY_INV2, xi)), fold = ext_add(even, ext_mul(beta, odd));
+        w_put(row, E0, e0); w_put(row, E1, e1); w_put(row, BETA, beta); w_put(row, FOLD, fold);
+        row[BIT] = bit ? MONTY_R1 : 0u; row[K] = to_monty(k); row[X] = x; row[XI] = xi; row[S] = fmul(x, x);
+        tcol[l] = bit ? two_adic_generator(l + 1) : MONTY_R1;
+        row[frichip::T] = tcol[l]; row[ACTIVE] = MONTY_R1; row[LN] = to_monty((uint32_t)l); row[L_REC + (uint32_t)l] = MONTY_R1;
+        if (l + 1 < R) { row[G] = MONTY_R1; row[GS] = row[S]; row[GT] = tcol[l]; }
+        w_put(row, OWN, own);
+        row[K2] = to_monty(2u * k); row[IDX] = to_monty(2u * k + bit);
+        row[XS] = bit ? fsub(0u, x) : x; row[frichip::PT] = to_monty(p * a.NTREES); row[LNX] = to_monty(p * a.NTREES + (uint32_t)l);
+        uint32_t* pw8 = a.pairs + 8 * at;
+        for (int j = 0; j < 4; j++) { pw8[j] = e0.c[j]; pw8[4 + j] = e1.c[j]; }
+        a.pair_k[at] = k;
+        own = fold; idx = k;
+    }
+    uint32_t bacc = idx ? two_adic_generator(R + 1) : MONTY_R1;
+    for (int l = R - 1; l >= 0; l--) {
+        bacc = fmul(bacc, tcol[l]);
+        a.fold[(uint64_t)a.fw * (((uint64_t)p * a.Q + q) * (uint64_t)R + (uint64_t)l) + frichip::B] = bacc;
+    }
+    bool ok = true;
+    for (int j = 0; j < 4; j++) ok = ok && from_monty(own.c[j]) == w[a.o_final + (uint32_t)j];
+    if (!ok) atomicCAS(a.err + p, 0u, 2u);
+}
+// the fold chip's padding rows: T = 1 (what the host table starts from)
+__global__ void __launch_bounds__(256) mrec_fold_pad_kernel(uint32_t* fold, uint32_t fw, uint64_t row0, uint64_t rows) {
+    const uint64_t r = row0 + (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r < rows) fold[(uint64_t)fw * r + frichip::T] = MONTY_R1;
+}
 
 int m_machine_verifier_setup(zkhip_ctx* ctx, const zkhip_machine_desc* inner, size_t n_proofs, const zkhip_params* outer, zkhip_machine_key** key, uint32_t vk[8]) {
     CHECK_CTX(ctx);
@@ -1671,7 +1930,17 @@ struct TopSession {
     std::shared_ptr<const Machine> mp;
     HostTabs ht;
     size_t used = 0;
+    // round 6: the per-query tables are the device's (WitPlan); the host keeps a proof's transcript and the tables that follow its opened values once
+    bool device = true;
+    WitPlan plan;
+    std::vector<DevVals> vals;
+    std::vector<const uint8_t*> ptrs;
+    size_t proof_len = 0;
 };
+inline bool rec_host_forced() {
+    static const bool forced = getenv("ZKHIP_REC_HOST") != nullptr && atoi(getenv("ZKHIP_REC_HOST")) != 0;     // (a switch for A/B runs and for a device that misbehaves: the host's walk)
+    return forced;
+}
 int top_begin(const zkhip_machine_desc* inner, size_t n_proofs, size_t n_public, TopSession& s) {
     int rc = ZKHIP_OK;
     s.mp = machine_of(inner, n_proofs, &rc);
@@ -1680,17 +1949,28 @@ int top_begin(const zkhip_machine_desc* inner, size_t n_proofs, size_t n_public,
     const MShape& sh = m.sh;
     if ((int)n_public != sh.NPUB) return fail(ZKHIP_ERR_INVALID, "prove_machine_verifier: n_public is not the machine's");
     HostTabs& ht = s.ht;
+    s.device = !rec_host_forced();
+    if (s.device) { s.plan = build_wit_plan(sh); s.vals.assign((size_t)sh.NP, DevVals{}); s.ptrs.assign((size_t)sh.NP, nullptr); }
     ZeroedWords* tabs[N_CHIPS] = {nullptr, &ht.rs, &ht.fold, &ht.ts, &ht.q, &ht.op, &ht.sm, &ht.sc, &ht.evl, &ht.lgu};
-    for (int c = 0; c < N_CHIPS; c++) if (tabs[c] && !tabs[c]->reset((size_t)m.w_main[c] << m.height[c])) return fail(ZKHIP_ERR_NOMEM, "prove_machine_verifier: no host memory for the machine's tables");
-    for (size_t r = 0; r < ((size_t)1 << m.height[C_FOLD]); r++) ht.fold.data()[(size_t)m.w_main[C_FOLD] * r + frichip::T] = MONTY_R1;      // (the fold chip's padding rows: T = 1)
+    for (int c = 0; c < N_CHIPS; c++) {
+        if (!tabs[c] || (s.device && (c == C_ROWSUM || c == C_FOLD || c == C_QUERY))) continue;       // (device mode: those three never exist on the host)
+        if (!tabs[c]->reset((size_t)m.w_main[c] << m.height[c])) return fail(ZKHIP_ERR_NOMEM, "prove_machine_verifier: no host memory for the machine's tables");
+    }
+    if (!s.device) for (size_t r = 0; r < ((size_t)1 << m.height[C_FOLD]); r++) ht.fold.data()[(size_t)m.w_main[C_FOLD] * r + frichip::T] = MONTY_R1;      // (the fold chip's padding rows: T = 1)
     s.used = (size_t)sh.NP * sh.p2_rows;
-    if (!ht.p2_in.reset(16 * s.used) || !ht.p2_bit.reset(s.used) || !ht.p2_kp.reset(s.used)) return fail(ZKHIP_ERR_NOMEM, "prove_machine_verifier: no host memory");
+    const size_t walked = s.device ? (size_t)sh.NP * (size_t)sh.NT : s.used;                          // Poseidon2 rows whose input states the host walks
+    if (!ht.p2_in.reset(16 * walked) || !ht.p2_bit.reset(walked) || !ht.p2_kp.reset(walked)) return fail(ZKHIP_ERR_NOMEM, "prove_machine_verifier: no host memory");
     return ZKHIP_OK;
 }
 // (any thread, a pool's included: nothing unwinds out of it; the message stays in this thread's zkhip_last_error)
 int top_fill(TopSession& s, int p, const uint8_t* proof, size_t proof_len, const uint32_t* pubs) {
     try {
         if (!proof) return fail(ZKHIP_ERR_INVALID, "prove_machine_verifier: null proof");
+        if (s.device) {
+            if (s.proof_len == 0) s.proof_len = proof_len;                 // (every proof of one machine has one length: fill_proof checks it)
+            s.ptrs[(size_t)p] = proof;
+            return fill_proof(*s.mp, p, proof, proof_len, pubs, s.ht, &s.plan, &s.vals[(size_t)p]);
+        }
         return fill_proof(*s.mp, p, proof, proof_len, pubs, s.ht);
     } catch (const std::bad_alloc&) { return fail(ZKHIP_ERR_NOMEM, "prove_machine_verifier: out of host memory"); }
       catch (const std::exception& e) { return fail(ZKHIP_ERR_INTERNAL, std::string("prove_machine_verifier: ") + e.what()); }
@@ -1707,7 +1987,127 @@ int top_finish(zkhip_ctx* ctx, const zkhip_machine_key* key, TopSession& s, cons
     void* dev[N_CHIPS] = {nullptr};
     const int slots[N_CHIPS] = {S_REC_A, S_REC_C, S_REC_B, S_REC_D, S_REC_E, S_REC_F, S_REC_G, S_REC_H, S_REC_I, S_REC_J};
     for (int c = 0; c < N_CHIPS; c++) ZK_TRY(ctx_reserve(ctx, slots[c], ((size_t)m.w_main[c] << m.height[c]) * 4, &dev[c]));
-    {   // the Poseidon2 rows: input states, bits, indices up; one launch fills the 360 columns of every row
+    if (s.device) {
+        // ---- the per-query tables on the device: the inner proofs' words up once, then four launches (ROWSUM + QUERY rows, the fold chains, the
+        // Poseidon2 chains) fill ROWSUM, QUERY, FOLD and the queries' rows of the Poseidon2 chip in place
+        const WitPlan& pl = s.plan;
+        const size_t NPs = (size_t)NP, Q = (size_t)sh.Q, R = (size_t)sh.R, nh = sh.hs.size(), nq = pl.rows.size();
+        const size_t pwords = s.proof_len / 4, vstride = dv_words(sh, pl);
+        // positions in a proof (fill_proof's)
+        size_t pos = (size_t)sh.HL + 2;
+        const size_t o_troot = pos; pos += 8; const size_t o_proot = pos; pos += 8; pos += 4 * (size_t)sh.C; const size_t o_qroot = pos; pos += 8; pos += 4 * (size_t)sh.NV;
+        const size_t o_lroots = pos; pos += 8 * R; const size_t o_final = pos; pos += 4; pos += 1; const size_t o_queries = pos;
+        size_t perq = 0;
+        for (int t = 0; t < N_TREES; t++) if (sh.has_tree[t]) { for (int c : sh.tree_chips[t]) perq += (*sh.tree_w[t])[(size_t)c]; perq += 8 * (size_t)sh.tree_hs[t][0]; }
+        for (int l = 0; l < sh.R; l++) perq += 4 + 8 * (size_t)(sh.H - 1 - l);
+        if (pwords > 0xFFFFFFFFull || o_queries + Q * perq != pwords) return fail(ZKHIP_ERR_INTERNAL, "prove_machine_verifier: proof layout");
+        std::vector<p2chip::MrecTreePlan> trees = pl.trees;
+        {
+            size_t i = 0;
+            for (int tr = 0; tr < N_TREES; tr++) { if (!sh.has_tree[tr]) continue; trees[i++].root_off = tr == T_E ? -1 : (int32_t)(tr == T_T ? o_troot : tr == T_P ? o_proot : o_qroot); }
+        }
+        // one block of small things: [vals NP][rows][g0][hs][inj_hi][trees][src], then scratch [roh][pairs][pair_k][err]
+        auto rup = [](size_t b) { return (b + 255) & ~(size_t)255; };
+        const size_t b_vals = rup(NPs * vstride * 4), b_rows = rup(nq * sizeof(WRow)), b_g0 = rup((nh + 1) * 4), b_hs = rup(nh * 4), b_inj = rup(32 * 4),
+                     b_trees = rup(trees.size() * sizeof(p2chip::MrecTreePlan)), b_src = rup(pl.src.size() * 4 + 4);
+        const size_t up_bytes = b_vals + b_rows + b_g0 + b_hs + b_inj + b_trees + b_src;
+        const size_t b_roh = rup(NPs * Q * nh * 16), b_pairs = rup(NPs * Q * R * 32), b_pk = rup(NPs * Q * R * 4), b_err = rup(NPs * 4);
+        void *dprf, *dblk, *hpin;
+        ZK_TRY(ctx_reserve(ctx, S_WIT_A, NPs * s.proof_len, &dprf));
+        ZK_TRY(ctx_reserve(ctx, S_WIT_B, up_bytes + b_roh + b_pairs + b_pk + b_err, &dblk));
+        ZK_TRY(ctx_host_pinned(ctx, NPs * s.proof_len + up_bytes, &hpin));
+        uint8_t* hp = (uint8_t*)hpin;
+        {   // the proofs into the pinned block side by side (a few threads: 60 MB for 64 transcript proofs), the small block behind them
+            const int nthr = NP < 8 ? NP : 8;
+            if (nthr <= 1) for (int p = 0; p < NP; p++) std::memcpy(hp + (size_t)p * s.proof_len, s.ptrs[(size_t)p], s.proof_len);
+            else {
+                HostPool pool(nthr);
+                for (int p = 0; p < NP; p++) pool.submit([&, p] { std::memcpy(hp + (size_t)p * s.proof_len, s.ptrs[(size_t)p], s.proof_len); });
+                pool.wait();
+            }
+            uint8_t* u = hp + NPs * s.proof_len;
+            std::memset(u, 0, up_bytes);
+            for (int p = 0; p < NP; p++) std::memcpy(u + (size_t)p * vstride * 4, s.vals[(size_t)p].v.data(), vstride * 4);
+            size_t at = b_vals;
+            std::memcpy(u + at, pl.rows.data(), nq * sizeof(WRow)); at += b_rows;
+            std::memcpy(u + at, pl.g0.data(), (nh + 1) * 4); at += b_g0;
+            for (size_t i = 0; i < nh; i++) ((int32_t*)(u + at))[i] = sh.hs[i];
+            at += b_hs;
+            std::memcpy(u + at, pl.inj_hi, 32 * 4); at += b_inj;
+            std::memcpy(u + at, trees.data(), trees.size() * sizeof(p2chip::MrecTreePlan)); at += b_trees;
+            if (!pl.src.empty()) std::memcpy(u + at, pl.src.data(), pl.src.size() * 4);
+        }
+        uint8_t* db = (uint8_t*)dblk;
+        ZK_HIP(hipMemcpyAsync(dprf, hp, NPs * s.proof_len, hipMemcpyHostToDevice, ctx->stream));
+        ZK_HIP(hipMemcpyAsync(db, hp + NPs * s.proof_len, up_bytes, hipMemcpyHostToDevice, ctx->stream));
+        ZK_HIP(hipMemsetAsync(db + up_bytes, 0, b_roh + b_pairs + b_pk + b_err, ctx->stream));
+        ZK_HIP(hipMemsetAsync(dev[C_ROWSUM], 0, ((size_t)m.w_main[C_ROWSUM] << m.height[C_ROWSUM]) * 4, ctx->stream));
+        ZK_HIP(hipMemsetAsync(dev[C_QUERY], 0, ((size_t)m.w_main[C_QUERY] << m.height[C_QUERY]) * 4, ctx->stream));
+        ZK_HIP(hipMemsetAsync(dev[C_FOLD], 0, ((size_t)m.w_main[C_FOLD] << m.height[C_FOLD]) * 4, ctx->stream));
+        WitArgs a{};
+        a.proofs = (const uint32_t*)dprf; a.proof_words = pwords; a.vals = (const uint32_t*)db; a.vals_stride = vstride;
+        a.v_betas = (uint32_t)Q; a.v_fa = a.v_betas + 4u * (uint32_t)R; a.v_zeta = a.v_fa + 4; a.v_h = a.v_zeta + 4; a.v_pw = a.v_h + 12u * (uint32_t)nh;
+        size_t at = b_vals;
+        a.rows = (const WRow*)(db + at); at += b_rows; a.g0 = (const uint32_t*)(db + at); at += b_g0; a.hs = (const int32_t*)(db + at); at += b_hs;
+        a.inj_hi = (const int32_t*)(db + at); at += b_inj;
+        const p2chip::MrecTreePlan* d_trees = (const p2chip::MrecTreePlan*)(db + at); at += b_trees;
+        const int32_t* d_src = (const int32_t*)(db + at);
+        a.nh = (uint32_t)nh; a.nq = (uint32_t)nq; a.NP = (uint32_t)NP; a.Q = (uint32_t)Q; a.R = (uint32_t)R; a.H = (uint32_t)sh.H; a.NTREES = sh.NTREES;
+        a.o_queries = (uint32_t)o_queries; a.per_query = (uint32_t)perq; a.o_final = (uint32_t)o_final; a.fri_off = pl.fri_off;
+        a.rs = (uint32_t*)dev[C_ROWSUM]; a.qt = (uint32_t*)dev[C_QUERY]; a.fold = (uint32_t*)dev[C_FOLD]; a.fw = m.w_main[C_FOLD]; a.inj_col = frichip::width_of(sh.R, true, true);
+        a.roh = (uint32_t*)(db + up_bytes); a.pairs = (uint32_t*)(db + up_bytes + b_roh); a.pair_k = (uint32_t*)(db + up_bytes + b_roh + b_pairs);
+        a.err = (uint32_t*)(db + up_bytes + b_roh + b_pairs + b_pk);
+        const unsigned gq = (unsigned)((NPs * Q * nh + 63) / 64), gf = (unsigned)((NPs * Q + 63) / 64);
+        hipLaunchKernelGGL(mrec_rowsum_query_kernel, dim3(gq), dim3(64), 0, ctx->stream, a);
+        hipLaunchKernelGGL(mrec_rowsum_accin_kernel, dim3(gq), dim3(64), 0, ctx->stream, a);
+        hipLaunchKernelGGL(mrec_fold_kernel, dim3(gf), dim3(64), 0, ctx->stream, a);
+        {
+            const uint64_t frows = (uint64_t)1 << m.height[C_FOLD], fused = NPs * Q * R;
+            if (frows > fused) hipLaunchKernelGGL(mrec_fold_pad_kernel, dim3((unsigned)((frows - fused + 255) / 256)), dim3(256), 0, ctx->stream, a.fold, a.fw, fused, frows);
+        }
+        ZK_HIP(hipGetLastError());
+        p2chip::MrecChainArgs ca{};
+        ca.proofs = a.proofs; ca.proof_words = pwords; ca.vals = a.vals; ca.vals_stride = vstride; ca.trees = d_trees; ca.n_trees = (uint32_t)trees.size(); ca.src = d_src;
+        ca.NP = a.NP; ca.Q = a.Q; ca.R = a.R; ca.H = a.H; ca.o_queries = a.o_queries; ca.per_query = a.per_query; ca.o_lroots = (uint32_t)o_lroots; ca.fri_off = pl.fri_off;
+        ca.p2_rows = (uint32_t)sh.p2_rows; ca.p2_fri0 = (uint32_t)sh.p2_fri0; ca.fri_rows = (uint32_t)sh.fri_rows;
+        ca.pairs = a.pairs; ca.pair_k = a.pair_k;
+        for (int j = 0; j < 8; j++) ca.key_root[j] = sh.key_root[j];
+        void* rowbuf;                                                     // every used row's (input state, bit, KP)
+        ZK_TRY(ctx_reserve(ctx, S_WIT_C, used * 18 * 4, &rowbuf));
+        ca.row_in = (uint32_t*)rowbuf; ca.row_bit = ca.row_in + 16 * used; ca.row_kp = ca.row_in + 17 * used; ca.err = a.err;
+        ZK_HIP(launch_mrec_chains(ca, ctx->stream));
+        {   // the queries' rows: 360 columns each from (state, bit, KP), one lane per row; the transcripts' rows are skipped here
+            p2chip::P2RArgs qa{};
+            qa.chain_inputs = ca.row_in; qa.trows = nullptr; qa.n_chains = 0; qa.n_transcript = (uint32_t)used;
+            qa.rows = (uint64_t)1 << m.height[C_P2R]; qa.used_rows = qa.rows;      // (no padding rows from this launch)
+            qa.trace = (uint32_t*)dev[C_P2R]; qa.ld = P2_MAIN; qa.roots = nullptr; qa.row_bits = ca.row_bit; qa.row_kps = ca.row_kp;
+            qa.inputs_monty = 1; qa.seg_rows = (uint32_t)sh.p2_rows; qa.skip_first = (uint32_t)sh.NT;
+            ZK_HIP(launch_p2r_rows(qa, ctx->stream));
+        }
+        // the transcripts' rows (walked on the host: a serial sponge chain per proof) and the padding rows
+        const size_t nt = NPs * (size_t)sh.NT;
+        void* stage;
+        ZK_TRY(ctx_reserve(ctx, S_STAGE, (16 * nt + 3 * nt) * 4, &stage));
+        uint32_t* d = (uint32_t*)stage;
+        std::vector<uint32_t> trows(nt);
+        for (size_t p = 0; p < NPs; p++) for (size_t T = 0; T < (size_t)sh.NT; T++) trows[p * (size_t)sh.NT + T] = (uint32_t)(p * sh.p2_rows + T);
+        ZK_TRY(dev_h2d(ctx, d, ht.p2_in.data(), 16 * nt * 4));
+        ZK_TRY(dev_h2d(ctx, d + 16 * nt, ht.p2_bit.data(), nt * 4));
+        ZK_TRY(dev_h2d(ctx, d + 17 * nt, ht.p2_kp.data(), nt * 4));
+        ZK_TRY(dev_h2d(ctx, d + 18 * nt, trows.data(), nt * 4));
+        p2chip::P2RArgs pa{};
+        pa.desc = nullptr; pa.data = nullptr; pa.chain_inputs = d; pa.trows = d + 18 * nt; pa.n_chains = 0; pa.n_transcript = (uint32_t)nt;
+        pa.rows = (uint64_t)1 << m.height[C_P2R]; pa.used_rows = used; pa.trace = (uint32_t*)dev[C_P2R]; pa.ld = P2_MAIN; pa.roots = nullptr;
+        pa.row_bits = d + 16 * nt; pa.row_kps = d + 17 * nt;
+        ZK_HIP(launch_p2r_rows(pa, ctx->stream));
+        std::vector<uint32_t> errs(NPs, 0u);
+        ZK_TRY(dev_d2h(ctx, errs.data(), a.err, NPs * 4));
+        for (size_t p = 0; p < NPs; p++) {
+            if (!errs[p]) continue;
+            const char* what = errs[p] == 1 ? "a FRI layer opening does not end in the layer's root" : errs[p] == 2 ? "a fold chain does not end in the final value" : "an opening does not end in its root";
+            return fail(ZKHIP_ERR_VERIFY, "prove_machine_verifier: proof " + std::to_string(p) + " rejected: " + what);
+        }
+    } else {   // the Poseidon2 rows: input states, bits, indices up; one launch fills the 360 columns of every row
         const size_t words = 16 * used + 3 * used;
         void* stage;
         ZK_TRY(ctx_reserve(ctx, S_STAGE, words * 4, &stage));
@@ -1725,7 +2125,7 @@ int top_finish(zkhip_ctx* ctx, const zkhip_machine_key* key, TopSession& s, cons
         ZK_HIP(launch_p2r_rows(a, ctx->stream));
     }
     lap("device: Poseidon2 rows");
-    for (int c = 0; c < N_CHIPS; c++) if (tabs[c]) ZK_TRY(dev_h2d(ctx, dev[c], tabs[c]->data(), tabs[c]->size() * 4));
+    for (int c = 0; c < N_CHIPS; c++) if (tabs[c] && tabs[c]->size()) ZK_TRY(dev_h2d(ctx, dev[c], tabs[c]->data(), tabs[c]->size() * 4));
     lap("upload: host tables");
     zkhip_chip chips[N_CHIPS]{};
     for (int i = 0; i < N_CHIPS; i++) {

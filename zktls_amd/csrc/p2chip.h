@@ -70,6 +70,38 @@ struct P2RArgs {
     uint32_t* roots;                 // [n_chains][8] canonical: where every chain ends
     const uint32_t* row_bits = nullptr;   // machine mode (machine_verifier.inl): EVERY used row arrives as a transcript-style row -- its input state, and here
     const uint32_t* row_kps = nullptr;    // its direction bit and its KP column (canonical); null: 0 / untouched
+    // round 6 (machine mode, the queries' rows walked by mrec_chains_kernel): the input states arrive in Montgomery form, entry r is row r (trows null),
+    // and the first skip_first rows of every segment of seg_rows rows are left alone (a proof's transcript rows)
+    uint32_t inputs_monty = 0, seg_rows = 0, skip_first = 0;
+};
+
+// ---- machine mode (machine_verifier.inl), round 6: the Poseidon2 chains of the inner proofs' queries walked ON THE DEVICE -- one lane per
+// (proof, query, commitment) and per (proof, query, FRI layer).  A commitment's chain: the sponges over the concatenated rows of every height
+// (shorter heights first, the tallest last; the words are gathered from the proof by the plan's offsets), then the path with the
+// injections (compress(node, digest of the height reached)); a layer's chain: the pair's leaf row, then its path.  A lane writes every row's
+// input state, direction bit and KP column where the host's walk put them (machine_verifier.inl fill_proof) -- the chains are serial, so it runs the
+// fast permutation only; the rows' 360 columns are filled by p2r_rows_kernel, one lane per row --; a chain that does not end in its root marks its
+// proof in err (1: a FRI layer, 3: a commitment).
+struct MrecTreePlan {
+    uint32_t row0, rows_per_query;     // P2 rows: proof segment + row0 + query * rows_per_query
+    uint32_t n_sponges, depth, shift;  // heights hashed; path levels; index = query index >> shift
+    uint32_t path_off;                 // the path's first word relative to the query's first word
+    int32_t root_off;                  // word offset of the root in the proof; -1: the inner key's root
+    uint32_t sp_words[16], sp_src[16]; // per sponge: words, where its offsets start in src
+    int32_t inj[32];                   // level -> the sponge whose digest joins behind that level's compression, -1: none
+};
+struct MrecChainArgs {
+    const uint32_t* proofs; uint64_t proof_words;     // [NP][proof_words] canonical
+    const uint32_t* vals; uint64_t vals_stride;       // per proof: the query indices at words [0, Q)
+    const MrecTreePlan* trees; uint32_t n_trees;
+    const int32_t* src;                                // leaf word offsets relative to the query's first word
+    uint32_t NP, Q, R, H;
+    uint32_t o_queries, per_query, o_lroots, fri_off;
+    uint32_t p2_rows, p2_fri0, fri_rows;
+    const uint32_t* pairs; const uint32_t* pair_k;     // [NP Q R][8] Montgomery, [NP Q R]: a layer's pair and its index
+    uint32_t key_root[8];                              // canonical
+    uint32_t* row_in; uint32_t* row_bit; uint32_t* row_kp;   // [used rows][16] Montgomery, [used rows], [used rows]: what every row starts from (p2r_rows_kernel fills the columns)
+    uint32_t* err;                                     // [NP]
 };
 
 // paths: path p = rows [p (row_width / 8 + depth), ...): row_width / 8 sponge rows over its opened row (none when row_width = 0: the
