@@ -594,6 +594,24 @@ static int fri_gen_trace(zkhip_ctx* ctx, int layers, size_t n_queries, const uin
     ZK_HIP(hipGetLastError());
     return dev_d2h(ctx, finals, a.finals, nv * 4);
 }
+// the same launch with every input ALREADY on the device (round 6: the shard verifier's reduced openings and siblings are produced there): the rec form,
+// n_proofs proofs of n_queries / n_proofs queries each; d_finals [n_queries][4] stays on the device
+static int fri_gen_trace_dev(zkhip_ctx* ctx, int layers, size_t n_queries, const uint32_t* d_betas, const uint32_t* d_indices, const uint32_t* d_values, const uint32_t* d_siblings,
+                             int log_rows, uint32_t* d_trace, size_t ld, uint32_t* d_finals, size_t n_proofs, uint32_t pt_stride) {
+    const uint32_t W = frichip::width_of(layers, true, true);
+    if (n_proofs < 1 || n_queries % n_proofs || ld < W || log_rows > MAX_LOG_ROWS || ((size_t)1 << log_rows) < n_queries * (size_t)layers) return fail(ZKHIP_ERR_INVALID, "fri_chip_gen_trace: bad arguments");
+    frichip::TraceArgs a{};
+    a.betas = d_betas; a.indices = d_indices; a.values = d_values; a.siblings = d_siblings;
+    a.n_queries = (uint32_t)n_queries; a.layers = (uint32_t)layers; a.width = W; a.log_h = (uint32_t)layers + 1u; a.wired = 2u;
+    a.rows = (uint64_t)1 << log_rows; a.trace = d_trace; a.ld = ld; a.finals = d_finals;
+    a.per_proof = n_proofs > 1 ? (uint32_t)(n_queries / n_proofs) : 0u; a.pt_stride = pt_stride;
+    a.pt = 0u; a.row_base = 0; a.pad_from = (uint64_t)n_queries * (uint64_t)layers;
+    const size_t pad = a.rows - a.pad_from;
+    const size_t threads = n_queries + (pad < 4096 ? pad : 4096);
+    ZK_LAUNCH(frichip::fri_trace_kernel, frichip::fri_trace_kernel_batch, frichip::fri_trace_kernel_bargs, dim3((unsigned)((threads + 63) / 64)), dim3(64), 0, ctx->stream, a);
+    ZK_HIP(hipGetLastError());
+    return ZKHIP_OK;
+}
 extern "C" {
 int zkhip_fri_chip_gen_trace(zkhip_ctx* ctx, int layers, size_t n_queries, const uint32_t* betas, const uint32_t* indices, const uint32_t* values,
                              const uint32_t* siblings, int log_rows, uint32_t* d_trace, size_t ld, uint32_t* finals) {

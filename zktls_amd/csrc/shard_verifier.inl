@@ -910,18 +910,34 @@ struct HostTables {
     std::vector<const uint32_t*> want_roots;                // per chain: where it must end (canonical words; owned by the witnesses)
     // (desc / data / chain_in / trows / want_roots hold a fixed slice per proof)
 };
+// round 6 (device mode): what the device's per-query kernels read of ONE proof -- [indices Q][betas 4 R canonical][fa][zeta][znx][yl][yn][yq][offn][offq] (extension
+// elements in Montgomery form)
+inline size_t sv_vals_words(const Shape& sh) { return (size_t)sh.Q + 4 * (size_t)sh.R + 32; }
 int fill_one(const Shape& sh, const Machine& m, int p, const uint8_t* inner, size_t inner_len, const uint32_t* public_values, const zkhip_params* inner_prm, Witness& wt,
-             std::vector<uint32_t>& words, HostTables& ht, Ext* fa_out, const uint32_t* program, size_t program_words) {
+             std::vector<uint32_t>& words, HostTables& ht, Ext* fa_out, const uint32_t* program, size_t program_words, uint32_t* dev_vals = nullptr) {
     const int R = sh.R, H = sh.H, Q = sh.Q, W = sh.W;
     const int log_n = sh.n;
     const uint32_t width = (uint32_t)W;
     const size_t n_public = (size_t)sh.NPUB;
-    // (a) one host pass: the verifier accepts the proof and hands out the FRI side; the rest is read off the words (docs/PROTOCOL.md section 6)
-    wt.betas.resize(4 * (size_t)R); wt.indices.resize((size_t)Q); wt.values.resize(4 * (size_t)Q); wt.siblings.resize(4 * (size_t)Q * (size_t)R); wt.lroots.resize(8 * (size_t)R);
-    wt.paths.resize(zkhip_fri_view_path_words(R) * (size_t)Q);
-    // (the Merkle paths are not hashed here: the P2R rows kernel hashes every one of them for the trace, and the roots it arrives at are compared below)
-    ZK_TRY(fri_view_all_unhashed(inner, inner_len, log_n, width, public_values, n_public, inner_prm, wt.betas.data(), wt.fin, wt.indices.data(), wt.values.data(),
-                                 wt.siblings.data(), wt.lroots.data(), wt.paths.data(), wt.tr, program, program_words));
+    const bool on_device = dev_vals != nullptr;        // ROWSUM, QUERY, the fold chains and the layers' pairs are the device's (shard_verifier_prove_impl)
+    wt.lroots.resize(8 * (size_t)R);
+    if (!on_device) {
+        // (a) one host pass: the verifier accepts the proof and hands out the FRI side; the rest is read off the words (docs/PROTOCOL.md section 6)
+        wt.betas.resize(4 * (size_t)R); wt.indices.resize((size_t)Q); wt.values.resize(4 * (size_t)Q); wt.siblings.resize(4 * (size_t)Q * (size_t)R);
+        wt.paths.resize(zkhip_fri_view_path_words(R) * (size_t)Q);
+        // (the Merkle paths are not hashed here: the P2R rows kernel hashes every one of them for the trace, and the roots it arrives at are compared below)
+        ZK_TRY(fri_view_all_unhashed(inner, inner_len, log_n, width, public_values, n_public, inner_prm, wt.betas.data(), wt.fin, wt.indices.data(), wt.values.data(),
+                                     wt.siblings.data(), wt.lroots.data(), wt.paths.data(), wt.tr, program, program_words));
+    } else {
+        // device mode has no separate verifier pass: filling the tables IS the verification (as in machine mode).  What that pass checked of the words
+        // themselves: the header names this shape, every word is a canonical residue
+        const uint32_t* pf = (const uint32_t*)inner;
+        auto bad = [&](const char* what) { return fail(ZKHIP_ERR_VERIFY, std::string("prove_shard_verifier: proof ") + std::to_string(p) + " rejected: " + what); };
+        if (inner_len < 32 || pf[0] != 0x41544B5Au || pf[1] != (sh.air ? 7u : 1u)) return bad("not a shard proof of this kind");
+        for (int i = 0; i < sh.HL; i++) if (pf[2 + i] != sh.head[i]) return bad("another shape's header");
+        for (size_t i = (size_t)sh.HL + 2; i < inner_len / 4; i++) if (pf[i] >= P) return bad("a non-canonical word");
+        for (size_t i = 0; i < n_public; i++) if (public_values[i] >= P) return bad("a non-canonical public value");
+    }
     words.resize(inner_len / 4);
     std::memcpy(words.data(), inner, words.size() * 4);
     wt.w = words.data();
@@ -956,6 +972,11 @@ int fill_one(const Shape& sh, const Machine& m, int p, const uint8_t* inner, siz
             chal[(size_t)T] = Ext{{st[7], st[6], st[5], st[4]}};
             if (T >= sh.TP) for (int j = 0; j < 8; j++) samples[8 * (size_t)(T - sh.TP) + j] = from_monty(st[7 - j]);
         }
+        if (on_device) {
+            wt.betas.resize(4 * (size_t)R);
+            for (int l = 0; l < R; l++) for (int j = 0; j < 4; j++) wt.betas[4 * (size_t)l + j] = from_monty(chal[(size_t)(sh.TL0 + l)].c[j]);
+            std::memcpy(wt.lroots.data(), pw + wt.o_lroots, 32 * (size_t)R);
+        } else
         for (int l = 0; l < R; l++) for (int j = 0; j < 4; j++)
             if (from_monty(chal[(size_t)(sh.TL0 + l)].c[j]) != wt.betas[4 * (size_t)l + j]) return fail(ZKHIP_ERR_INTERNAL, "prove_shard_verifier: the sponge rows do not reproduce the verifier's challenges");
     }
@@ -1068,10 +1089,12 @@ int fill_one(const Shape& sh, const Machine& m, int p, const uint8_t* inner, siz
         res_acc = run;
     }
     scput(scc.YL, res_yl); scput(scc.YN, res_yn); scput(scc.ACC, res_acc);
-    if (!ext_eq(res_acc, ext_mul(quo, ext_sub_base(znn, MONTY_R1)))) return fail(ZKHIP_ERR_INTERNAL, "prove_shard_verifier: the AIR identity at zeta does not hold");
+    if (!ext_eq(res_acc, ext_mul(quo, ext_sub_base(znn, MONTY_R1))))
+        return fail(on_device ? ZKHIP_ERR_VERIFY : ZKHIP_ERR_INTERNAL, on_device ? "prove_shard_verifier: proof " + std::to_string(p) + " rejected: the constraints do not match the quotient at zeta"
+                                                                       : std::string("prove_shard_verifier: the AIR identity at zeta does not hold"));
     // (e) ROWSUM
     std::vector<Ext> at((size_t)Q), aq((size_t)Q);
-    {
+    if (!on_device) {
         const size_t rs_rows = (size_t)1 << m.height[C_ROWSUM], per = (size_t)Q * (size_t)(sh.WB + 1);
         const size_t lo = (size_t)p * per, hi = p + 1 == sh.NP ? rs_rows : lo + per;
         Ext a = ext_zero();
@@ -1095,7 +1118,7 @@ int fill_one(const Shape& sh, const Machine& m, int p, const uint8_t* inner, siz
         }
     }
     // (f) QUERY
-    {
+    if (!on_device) {
         constexpr QCols qc = qcols();
         const size_t q_rows = (size_t)1 << m.height[C_QUERY], lo = (size_t)p * (size_t)Q, hi = p + 1 == sh.NP ? q_rows : lo + (size_t)Q;
         for (size_t rr = lo; rr < hi; rr++) {
@@ -1126,9 +1149,56 @@ int fill_one(const Shape& sh, const Machine& m, int p, const uint8_t* inner, siz
     {
         std::vector<uint32_t> t_sm, drawn;
         frichip::samples_main(R, (size_t)Q, lg((size_t)sh.NS), samples.data(), t_sm, drawn);
-        if (sh.PB && (samples[0] & ((1u << sh.PB) - 1u))) return fail(ZKHIP_ERR_INTERNAL, "prove_shard_verifier: the witness does not satisfy the proof of work");
-        if (std::memcmp(drawn.data(), wt.indices.data(), 4 * (size_t)Q) != 0) return fail(ZKHIP_ERR_INTERNAL, "prove_shard_verifier: the query indices are not the ones the transcript draws");
+        if (sh.PB && (samples[0] & ((1u << sh.PB) - 1u)))
+            return fail(on_device ? ZKHIP_ERR_VERIFY : ZKHIP_ERR_INTERNAL, on_device ? "prove_shard_verifier: proof " + std::to_string(p) + " rejected: proof of work" : std::string("prove_shard_verifier: the witness does not satisfy the proof of work"));
+        if (on_device) { if (drawn.size() != (size_t)Q) return fail(ZKHIP_ERR_INTERNAL, "prove_shard_verifier: query indices"); wt.indices = drawn; }
+        else if (std::memcmp(drawn.data(), wt.indices.data(), 4 * (size_t)Q) != 0) return fail(ZKHIP_ERR_INTERNAL, "prove_shard_verifier: the query indices are not the ones the transcript draws");
         std::memcpy(ht.sm.data() + (size_t)frichip::S_MAIN * (size_t)p * (size_t)sh.NS, t_sm.data(), (size_t)frichip::S_MAIN * (size_t)sh.NS * 4);
+    }
+    if (on_device) {
+        // what the device reads of this proof, and its entries of the P2R work lists with the pairs left to the device (the words go up with the lists; a layer's
+        // path is read where it sits in them)
+        uint32_t* v = dev_vals;
+        size_t at_v = 0;
+        for (int q = 0; q < Q; q++) v[at_v++] = wt.indices[(size_t)q];
+        for (size_t i = 0; i < 4 * (size_t)R; i++) v[at_v++] = wt.betas[i];
+        const Ext exts[8] = {fa, zeta, znx, res_yl, res_yn, yq, offn, offq};
+        for (const Ext& e : exts) for (int j = 0; j < 4; j++) v[at_v++] = e.c[j];
+        const size_t row0 = (size_t)p * sh.p2_rows;
+        for (int T = 0; T < sh.NT; T++) ht.trows[(size_t)p * (size_t)sh.NT + (size_t)T] = (uint32_t)(row0 + (size_t)T);
+        std::memcpy(ht.chain_in.data() + 16 * (size_t)p * (size_t)sh.NT, chain_in.data(), chain_in.size() * 4);
+        const size_t seg = 8 * (size_t)Q * (size_t)R + words.size();
+        const size_t off_pairs = (size_t)p * seg, off_words = off_pairs + 8 * (size_t)Q * (size_t)R;
+        std::memcpy(ht.data.data() + off_words, words.data(), words.size() * 4);
+        const size_t chains_per = (size_t)Q * (size_t)R + 2 * (size_t)Q;
+        uint32_t* desc = ht.desc.data() + 6 * (size_t)p * chains_per;
+        const uint32_t** want = ht.want_roots.data() + (size_t)p * chains_per;
+        size_t row = row0 + sh.p2_fri0, ch = 0;
+        for (int q = 0; q < Q; q++) {
+            uint32_t idx = wt.indices[(size_t)q];
+            size_t fat = wt.q_trow(q) + (size_t)W + 8 * (size_t)H + 8 + 8 * (size_t)H;       // the query's first FRI word
+            for (int l = 0; l < R; l++, ch++) {
+                const uint32_t k = idx >> 1;
+                const int lh = H - (l + 1);
+                const uint32_t d[6] = {(uint32_t)row, 1u, (uint32_t)(off_pairs + 8 * ch), (uint32_t)lh, k, (uint32_t)(off_words + fat + 4)};
+                std::memcpy(desc + 6 * ch, d, sizeof d);
+                want[ch] = wt.lroots.data() + 8 * (size_t)l;
+                row += 1 + (size_t)lh;
+                fat += 4 + 8 * (size_t)lh;
+                idx = k;
+            }
+        }
+        for (int which = 0; which < 2; which++)
+            for (int q = 0; q < Q; q++, ch++) {
+                const size_t trow = wt.q_trow(q), tpath = trow + (size_t)W, qrow = tpath + 8 * (size_t)H, qpath = qrow + 8;
+                const uint32_t d[6] = {(uint32_t)row, which ? 1u : (uint32_t)sh.WB, (uint32_t)(off_words + (which ? qrow : trow)), (uint32_t)H, wt.indices[(size_t)q],
+                                       (uint32_t)(off_words + (which ? qpath : tpath))};
+                std::memcpy(desc + 6 * ch, d, sizeof d);
+                want[ch] = pw + (which ? wt.o_qroot : wt.o_troot);
+                row += (which ? 1 : (size_t)sh.WB) + (size_t)H;
+            }
+        if (row != row0 + sh.p2_rows || ch != chains_per) return fail(ZKHIP_ERR_INTERNAL, "prove_shard_verifier: row layout");
+        return ZKHIP_OK;
     }
     // (i) this proof's entries of the P2R work lists: transcript rows, then Q R FRI paths (leaf block = the pair), Q trace openings, Q quotient openings
     {
@@ -1181,6 +1251,107 @@ int fill_one(const Shape& sh, const Machine& m, int p, const uint8_t* inner, siz
 }
 }  // namespace
 }  // namespace rec
+// ---- round 6: the per-query part of the shard verifier's tables ON THE DEVICE (what fill_one's sections (e), (f) and the pair arithmetic of (i) compute on the
+// host): one lane per (proof, query) fills the query's ROWSUM rows and its QUERY row from the proof's words, and hands the fold kernel its inputs -- the
+// reduced opening, the layers' siblings --; a second kernel walks the fold chain once more for the layers' pairs (the leaf blocks of the FRI paths' chains).
+namespace rec {
+struct SvWitArgs {
+    uint32_t* data; uint64_t seg; uint32_t words_off;       // proof p's words: data + p seg + words_off; its pairs: data + p seg + 8 (q R + l)
+    const uint32_t* vals; uint32_t vstride;                 // sv_vals_words per proof
+    uint32_t NP, Q, R, H, W, WB;
+    uint32_t o_queries, per_query;
+    uint32_t* rs; uint64_t rs_rows; uint32_t* qt; uint64_t q_rows;
+    uint32_t *f_betas, *f_indices, *f_values, *f_siblings;  // the fold kernel's inputs, canonical
+};
+__device__ __forceinline__ Ext sv_ld4(const uint32_t* p) { return Ext{{p[0], p[1], p[2], p[3]}}; }
+__device__ __forceinline__ void sv_put(uint32_t* r, uint32_t col, const Ext& e) { r[col] = e.c[0]; r[col + 1] = e.c[1]; r[col + 2] = e.c[2]; r[col + 3] = e.c[3]; }
+__global__ void __launch_bounds__(64) sv_rowsum_query_kernel(SvWitArgs a) {
+    constexpr QCols qc = qcols();
+    const uint64_t gid = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x, nq = (uint64_t)a.NP * a.Q;
+    const uint32_t ve = a.Q + 4u * a.R;                    // where a proof's extension values start: fa zeta znx yl yn yq offn offq
+    if (gid >= nq) {
+        // the rows behind the last proof carry ITS constants (ROWSUM: fa; QUERY: the seven constants)
+        const uint32_t* v = a.vals + (uint64_t)(a.NP - 1) * a.vstride + ve;
+        const Ext fa = sv_ld4(v);
+        const uint64_t k = gid - nq, stride = (uint64_t)gridDim.x * blockDim.x - nq;
+        for (uint64_t r = nq * (a.WB + 1) + k; r < a.rs_rows; r += stride) sv_put(a.rs + (uint64_t)RS_MAIN * r, RS_FA, fa);
+        for (uint64_t r = nq + k; r < a.q_rows; r += stride) {
+            uint32_t* row = a.qt + (uint64_t)Q_MAIN * r;
+            sv_put(row, qc.ZETA - Q_PRE, sv_ld4(v + 4)); sv_put(row, qc.ZNX - Q_PRE, sv_ld4(v + 8)); sv_put(row, qc.YL - Q_PRE, sv_ld4(v + 12)); sv_put(row, qc.YN - Q_PRE, sv_ld4(v + 16));
+            sv_put(row, qc.YQ - Q_PRE, sv_ld4(v + 20)); sv_put(row, qc.OFFN - Q_PRE, sv_ld4(v + 24)); sv_put(row, qc.OFFQ - Q_PRE, sv_ld4(v + 28));
+        }
+        return;
+    }
+    const uint32_t q = (uint32_t)(gid % a.Q), p = (uint32_t)(gid / a.Q);
+    const uint32_t* vv = a.vals + (uint64_t)p * a.vstride;
+    const uint32_t* v = vv + ve;
+    const Ext fa = sv_ld4(v), zeta = sv_ld4(v + 4), znx = sv_ld4(v + 8), yl = sv_ld4(v + 12), yn = sv_ld4(v + 16), yq = sv_ld4(v + 20), offn = sv_ld4(v + 24), offq = sv_ld4(v + 28);
+    const uint32_t* pw = a.data + (uint64_t)p * a.seg + a.words_off;
+    const uint32_t* qw = pw + a.o_queries + (uint64_t)q * a.per_query;
+    // ---- ROWSUM: the trace row's blocks from the last to the first, then the quotient row
+    Ext acc = ext_zero(), at = ext_zero(), aq = ext_zero();
+    for (uint32_t i = 0; i <= a.WB; i++) {
+        const uint32_t b = i < a.WB ? a.WB - 1 - i : a.WB;
+        const uint32_t* vals = b == a.WB ? qw + a.W + 8 * a.H : qw + 8 * b;
+        uint32_t* row = a.rs + (uint64_t)RS_MAIN * (gid * (a.WB + 1) + i);
+        sv_put(row, RS_FA, fa);
+        if (b == a.WB - 1 || b == a.WB) acc = ext_zero();
+        sv_put(row, RS_ACCIN, acc);
+        for (int sidx = 7; sidx >= 0; sidx--) {
+            const uint32_t x = to_monty(vals[sidx]);
+            row[RS_V + sidx] = x;
+            acc = ext_add_base(ext_mul(acc, fa), x);
+            sv_put(row, RS_T + 4u * (uint32_t)sidx, acc);
+        }
+        if (b == 0) at = acc;
+        if (b == a.WB) aq = acc;
+    }
+    // ---- QUERY
+    const uint32_t index = vv[q];
+    const uint32_t xq = fpow(two_adic_generator((int)a.H), reverse_bits(index, (int)a.H));
+    const Ext x = ext_from_base(fmul(MONTY_GEN, xq));
+    const Ext i1 = ext_inv(ext_sub(x, zeta)), i2 = ext_inv(ext_sub(x, znx));
+    const Ext p1 = ext_mul(ext_sub(at, yl), i1), p2 = ext_mul(ext_sub(at, yn), i2), p2o = ext_mul(offn, p2);
+    const Ext p3 = ext_mul(ext_sub(aq, yq), i1), p3o = ext_mul(offq, p3), ro = ext_add(ext_add(p1, p2o), p3o);
+    uint32_t* row = a.qt + (uint64_t)Q_MAIN * gid;
+    sv_put(row, qc.ZETA - Q_PRE, zeta); sv_put(row, qc.ZNX - Q_PRE, znx); sv_put(row, qc.YL - Q_PRE, yl); sv_put(row, qc.YN - Q_PRE, yn);
+    sv_put(row, qc.YQ - Q_PRE, yq); sv_put(row, qc.OFFN - Q_PRE, offn); sv_put(row, qc.OFFQ - Q_PRE, offq);
+    row[qc.IDX - Q_PRE] = to_monty(index); row[qc.XQ - Q_PRE] = xq;
+    sv_put(row, qc.RO - Q_PRE, ro); sv_put(row, qc.AT - Q_PRE, at); sv_put(row, qc.AQ - Q_PRE, aq); sv_put(row, qc.I1 - Q_PRE, i1); sv_put(row, qc.I2 - Q_PRE, i2);
+    sv_put(row, qc.P1 - Q_PRE, p1); sv_put(row, qc.P2 - Q_PRE, p2); sv_put(row, qc.P2O - Q_PRE, p2o); sv_put(row, qc.P3 - Q_PRE, p3); sv_put(row, qc.P3O - Q_PRE, p3o);
+    // ---- the fold kernel's inputs
+    a.f_indices[gid] = index;
+    for (int j = 0; j < 4; j++) a.f_values[4 * gid + (uint64_t)j] = from_monty(ro.c[j]);
+    uint64_t fat = (uint64_t)a.W + 8 * (uint64_t)a.H + 8 + 8 * (uint64_t)a.H;
+    for (uint32_t l = 0; l < a.R; l++) {
+        for (int j = 0; j < 4; j++) a.f_siblings[4 * (gid * a.R + l) + (uint64_t)j] = qw[fat + (uint64_t)j];
+        fat += 4 + 8 * (uint64_t)(a.H - 1 - l);
+    }
+    if (q == 0) for (uint32_t i = 0; i < 4 * a.R; i++) a.f_betas[(uint64_t)p * 4 * a.R + i] = vv[a.Q + i];
+}
+// the layers' pairs (canonical) into the chains' leaf blocks: the fold chain of (proof, query) once more
+__global__ void __launch_bounds__(64) sv_pairs_kernel(SvWitArgs a) {
+    const uint64_t gid = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (gid >= (uint64_t)a.NP * a.Q) return;
+    const uint32_t q = (uint32_t)(gid % a.Q), p = (uint32_t)(gid / a.Q);
+    uint32_t idx = a.f_indices[gid];
+    Ext own = Ext{{to_monty(a.f_values[4 * gid]), to_monty(a.f_values[4 * gid + 1]), to_monty(a.f_values[4 * gid + 2]), to_monty(a.f_values[4 * gid + 3])}};
+    uint32_t* pairs = a.data + (uint64_t)p * a.seg + 8 * ((uint64_t)q * a.R);
+    for (uint32_t l = 0; l < a.R; l++) {
+        const uint32_t bit = idx & 1u, k = idx >> 1;
+        const uint32_t* sp = a.f_siblings + 4 * (gid * a.R + l);
+        const uint32_t* bp = a.f_betas + (uint64_t)p * 4 * a.R + 4 * l;
+        const Ext sib = Ext{{to_monty(sp[0]), to_monty(sp[1]), to_monty(sp[2]), to_monty(sp[3])}}, beta = Ext{{to_monty(bp[0]), to_monty(bp[1]), to_monty(bp[2]), to_monty(bp[3])}};
+        const Ext e0 = bit ? sib : own, e1 = bit ? own : sib;
+        uint32_t* pair = pairs + 8 * l;
+        for (int i = 0; i < 4; i++) { pair[i] = from_monty(e0.c[i]); pair[4 + i] = from_monty(e1.c[i]); }
+        const int lh = (int)a.H - (int)(l + 1);
+        const uint32_t xi = finv(fpow(two_adic_generator(lh + 1), reverse_bits(k, lh)));
+        own = ext_add(ext_mul_base(ext_add(e0, e1), MONTY_INV2), ext_mul(beta, ext_mul_base(ext_sub(e0, e1), fmul(MONTY_INV2, xi))));
+        idx = k;
+    }
+}
+}  // namespace rec
 // (zkhip_release_cached_contexts, jobs.cpp: the pooled host tables go with the pooled contexts)
 void rec_release_host_tables() { rec::word_pool().clear(); }
 }  // namespace zk
@@ -1218,9 +1389,13 @@ static int shard_verifier_prove_impl(zkhip_ctx* ctx, const zkhip_machine_key* ke
     const uint32_t sc_w = rup4(scc.end - sc_pre(sh));
     const uint32_t w_main[N_CHIPS] = {P2_MAIN, RS_MAIN, frichip::width_of(R, true, true), TS_MAIN, Q_MAIN, OP_MAIN, frichip::S_MAIN, sc_w, EV_MAIN};
     lap("shape + machine");
+    // round 6: ROWSUM, QUERY, the fold chains and the layers' pairs are the device's (sv_rowsum_query_kernel, sv_pairs_kernel); ZKHIP_REC_HOST=1 (and a call
+    // from inside a lock-step batch, whose launches are merged) keeps the host's walk
+    static const bool host_forced = getenv("ZKHIP_REC_HOST") != nullptr && atoi(getenv("ZKHIP_REC_HOST")) != 0;
+    const bool on_device = !host_forced && !t_batcher;
     HostTables ht;
-    if (!ht.sc.reset((size_t)sc_w << m.height[C_SCALARS]) || !ht.op.reset((size_t)OP_MAIN << m.height[C_OPENED]) || !ht.rs.reset((size_t)RS_MAIN << m.height[C_ROWSUM]) ||
-        !ht.q.reset((size_t)Q_MAIN << m.height[C_QUERY]) || !ht.ts.reset((size_t)TS_MAIN << m.height[C_TS]) || !ht.sm.reset((size_t)frichip::S_MAIN << m.height[C_SAMPLES]) ||
+    if (!ht.sc.reset((size_t)sc_w << m.height[C_SCALARS]) || !ht.op.reset((size_t)OP_MAIN << m.height[C_OPENED]) || (!on_device && !ht.rs.reset((size_t)RS_MAIN << m.height[C_ROWSUM])) ||
+        (!on_device && !ht.q.reset((size_t)Q_MAIN << m.height[C_QUERY])) || !ht.ts.reset((size_t)TS_MAIN << m.height[C_TS]) || !ht.sm.reset((size_t)frichip::S_MAIN << m.height[C_SAMPLES]) ||
         (sh.air && !ht.evl.reset((size_t)EV_MAIN << m.height[C_EVAL])))
         return fail(ZKHIP_ERR_NOMEM, "prove_shard_verifier: no host memory for the machine's tables");
     std::vector<Witness> wts((size_t)NP);
@@ -1229,7 +1404,7 @@ static int shard_verifier_prove_impl(zkhip_ctx* ctx, const zkhip_machine_key* ke
     lap("host: tables zeroed");
     {
         // the shared lists have a fixed slice per proof (the shape fixes every size): the proofs are filled side by side
-        const size_t chains_per = (size_t)Q * (size_t)R + 2 * (size_t)Q, seg = 8 * (size_t)Q * (size_t)R + zkhip_fri_view_path_words(R) * (size_t)Q + inner_len[0] / 4;
+        const size_t chains_per = (size_t)Q * (size_t)R + 2 * (size_t)Q, seg = 8 * (size_t)Q * (size_t)R + (on_device ? 0 : zkhip_fri_view_path_words(R) * (size_t)Q) + inner_len[0] / 4;
         for (int p = 0; p < NP; p++) {
             if (!inner[p]) return fail(ZKHIP_ERR_INVALID, "prove_shard_verifier: null proof");
             if (inner_len[p] != inner_len[0] || inner_len[p] % 4) return fail(ZKHIP_ERR_INVALID, "prove_shard_verifier: the proofs of one call have one shape, hence one length");
@@ -1239,15 +1414,17 @@ static int shard_verifier_prove_impl(zkhip_ctx* ctx, const zkhip_machine_key* ke
         {   // the four P2R work lists are filled IN PLACE in the context's pinned block and go up as one DMA
             const size_t n_desc = 6 * (size_t)NP * chains_per, n_data = (size_t)NP * seg, n_cin = 16 * (size_t)NP * (size_t)sh.NT, n_trows = (size_t)NP * (size_t)sh.NT;
             void* up;
-            ZK_TRY(ctx_host_pinned(ctx, (n_desc + n_data + n_cin + n_trows) * 4, &up));
+            ZK_TRY(ctx_host_pinned(ctx, (n_desc + n_data + n_cin + n_trows + (on_device ? (size_t)NP * sv_vals_words(sh) : 0)) * 4, &up));
             ht.desc = HostSpan{(uint32_t*)up, n_desc}; ht.data = HostSpan{ht.desc.p + n_desc, n_data};
             ht.chain_in = HostSpan{ht.data.p + n_data, n_cin}; ht.trows = HostSpan{ht.chain_in.p + n_cin, n_trows};
         }
+        uint32_t* const vals_host = on_device ? ht.trows.p + ht.trows.size() : nullptr;      // (device mode: the per-proof values behind the lists, same DMA)
         std::vector<int> rcs((size_t)NP, ZKHIP_OK);
         std::vector<std::string> msgs((size_t)NP);
         auto one = [&](int p) {
             t_query_threads_cap = NP >= 16 ? 1 : 16 / NP;      // the proofs are filled side by side: a proof's host pass starts few threads of its own
-            rcs[(size_t)p] = fill_one(sh, m, p, inner[p], inner_len[p], public_values + (size_t)p * n_public, inner_prm, wts[(size_t)p], words[(size_t)p], ht, &fas[(size_t)p], program, program_words);
+            rcs[(size_t)p] = fill_one(sh, m, p, inner[p], inner_len[p], public_values + (size_t)p * n_public, inner_prm, wts[(size_t)p], words[(size_t)p], ht, &fas[(size_t)p], program, program_words,
+                                      on_device ? vals_host + (size_t)p * sv_vals_words(sh) : nullptr);
             if (rcs[(size_t)p] != ZKHIP_OK) msgs[(size_t)p] = zkhip_last_error();
             t_query_threads_cap = 0;
         };
@@ -1265,6 +1442,50 @@ static int shard_verifier_prove_impl(zkhip_ctx* ctx, const zkhip_machine_key* ke
     void* dev[N_CHIPS] = {nullptr};
     const int slots[N_CHIPS] = {S_REC_A, S_REC_C, S_REC_B, S_REC_D, S_REC_E, S_REC_F, S_REC_G, S_REC_H, S_REC_I};
     for (int c = 0; c < m.n; c++) ZK_TRY(ctx_reserve(ctx, slots[c], ((size_t)w_main[c] << m.height[c]) * 4, &dev[c]));
+    if (on_device) {
+        // ---- lists, words and values up in ONE DMA; the per-query rows, the fold rows, the pairs and every Poseidon2 row on the device
+        const size_t nq = (size_t)NP * (size_t)Q, vw = sv_vals_words(sh), n_chains = ht.desc.size() / 6;
+        const size_t up_words = ht.desc.size() + ht.data.size() + ht.chain_in.size() + ht.trows.size() + (size_t)NP * vw, down_words = 8 * n_chains;
+        void *stage, *scratch;
+        ZK_TRY(ctx_reserve(ctx, S_STAGE, (up_words + down_words) * 4, &stage));
+        const size_t n_fb = 4 * (size_t)R * (size_t)NP, n_fi = nq, n_fv = 4 * nq, n_fs = 4 * nq * (size_t)R;
+        ZK_TRY(ctx_reserve(ctx, S_WIT_B, (n_fb + n_fi + n_fv + n_fs + n_fv) * 4, &scratch));
+        uint32_t* d = (uint32_t*)stage;
+        ZK_HIP(hipMemcpyAsync(d, ht.desc.data(), up_words * 4, hipMemcpyHostToDevice, ctx->stream));       // desc | data | chain_in | trows | vals: one pinned block
+        ZK_HIP(hipMemsetAsync(dev[C_ROWSUM], 0, ((size_t)RS_MAIN << m.height[C_ROWSUM]) * 4, ctx->stream));
+        ZK_HIP(hipMemsetAsync(dev[C_QUERY], 0, ((size_t)Q_MAIN << m.height[C_QUERY]) * 4, ctx->stream));
+        SvWitArgs a{};
+        a.data = d + ht.desc.size(); a.seg = ht.data.size() / (size_t)NP; a.words_off = (uint32_t)(8 * (size_t)Q * (size_t)R);
+        a.vals = d + ht.desc.size() + ht.data.size() + ht.chain_in.size() + ht.trows.size(); a.vstride = (uint32_t)vw;
+        a.NP = (uint32_t)NP; a.Q = (uint32_t)Q; a.R = (uint32_t)R; a.H = (uint32_t)sh.H; a.W = (uint32_t)sh.W; a.WB = (uint32_t)sh.WB;
+        a.o_queries = (uint32_t)wts[0].o_queries; a.per_query = (uint32_t)wts[0].per_query;
+        a.rs = (uint32_t*)dev[C_ROWSUM]; a.rs_rows = (uint64_t)1 << m.height[C_ROWSUM]; a.qt = (uint32_t*)dev[C_QUERY]; a.q_rows = (uint64_t)1 << m.height[C_QUERY];
+        uint32_t* sc = (uint32_t*)scratch;
+        a.f_betas = sc; a.f_indices = sc + n_fb; a.f_values = a.f_indices + n_fi; a.f_siblings = a.f_values + n_fv;
+        uint32_t* d_finals = a.f_siblings + n_fs;
+        hipLaunchKernelGGL(sv_rowsum_query_kernel, dim3((unsigned)((nq + 4096 + 63) / 64)), dim3(64), 0, ctx->stream, a);
+        ZK_HIP(hipGetLastError());
+        ZK_TRY(fri_gen_trace_dev(ctx, R, nq, a.f_betas, a.f_indices, a.f_values, a.f_siblings, m.height[C_FOLD], (uint32_t*)dev[C_FOLD], w_main[C_FOLD], d_finals, (size_t)NP, (uint32_t)sh.TREES));
+        hipLaunchKernelGGL(sv_pairs_kernel, dim3((unsigned)((nq + 63) / 64)), dim3(64), 0, ctx->stream, a);
+        ZK_HIP(hipGetLastError());
+        lap("device: ROWSUM, QUERY, fold rows, pairs");
+        p2chip::P2RArgs pa{};
+        pa.desc = d; pa.data = a.data; pa.chain_inputs = pa.data + ht.data.size(); pa.trows = pa.chain_inputs + ht.chain_in.size();
+        pa.n_chains = (uint32_t)n_chains; pa.n_transcript = (uint32_t)ht.trows.size(); pa.rows = (uint64_t)1 << m.height[C_P2R]; pa.used_rows = (uint64_t)NP * sh.p2_rows;
+        pa.trace = (uint32_t*)dev[C_P2R]; pa.ld = P2_MAIN; pa.roots = d + up_words;
+        ZK_HIP(launch_p2r_rows(pa, ctx->stream));
+        std::vector<uint32_t> down(down_words), finals(n_fv);
+        ZK_TRY(dev_d2h(ctx, finals.data(), d_finals, n_fv * 4));
+        ZK_TRY(dev_d2h(ctx, down.data(), pa.roots, down_words * 4));
+        for (int p = 0; p < NP; p++)
+            for (int q = 0; q < Q; q++)
+                if (std::memcmp(finals.data() + 4 * ((size_t)p * (size_t)Q + (size_t)q), wts[(size_t)p].w + wts[(size_t)p].o_final, 16) != 0)
+                    return fail(ZKHIP_ERR_VERIFY, "prove_shard_verifier: proof " + std::to_string(p) + " rejected: a fold chain does not end in the final value");
+        for (size_t c = 0; c < n_chains; c++)
+            if (std::memcmp(down.data() + 8 * c, ht.want_roots[c], 32) != 0)
+                return fail(ZKHIP_ERR_VERIFY, "prove_shard_verifier: proof " + std::to_string(c / (n_chains / (size_t)NP)) + " rejected: an opening does not end in its root");
+        lap("device: P2R rows + roots back");
+    } else {
     {   // the fold rows of every proof in ONE launch
         const size_t nq = (size_t)NP * (size_t)Q;
         std::vector<uint32_t> betas, indices, values, siblings, finals(4 * nq);
@@ -1301,9 +1522,10 @@ static int shard_verifier_prove_impl(zkhip_ctx* ctx, const zkhip_machine_key* ke
                 return fail(ZKHIP_ERR_VERIFY, "prove_shard_verifier: proof " + std::to_string(c / (n_chains / (size_t)NP)) + " rejected: an opening does not end in its root");
     }
     lap("device: P2R rows + roots back");
+    }   // (host mode)
     // the host tables up, then the machine's proof
     const ZeroedWords* host[N_CHIPS] = {nullptr, &ht.rs, nullptr, &ht.ts, &ht.q, &ht.op, &ht.sm, &ht.sc, &ht.evl};
-    for (int c = 0; c < m.n; c++) if (host[c]) ZK_TRY(dev_h2d(ctx, dev[c], host[c]->data(), host[c]->size() * 4));
+    for (int c = 0; c < m.n; c++) if (host[c] && host[c]->size()) ZK_TRY(dev_h2d(ctx, dev[c], host[c]->data(), host[c]->size() * 4));
     zkhip_chip chips[N_CHIPS]{};
     for (int i = 0; i < m.n; i++) {
         const int c = m.order[i];
