@@ -16,6 +16,7 @@
 #include <vector>
 
 #include "../include/zkhip.h"
+#include "../include/zkhip_chips.h"
 
 #define CHECK(call)                                                                 \
     do {                                                                            \

@@ -10,6 +10,7 @@
 #include <vector>
 
 #include "../include/zkhip.h"
+#include "../include/zkhip_chips.h"
 
 static bool read_file(const char* path, std::vector<uint8_t>& out) {
     FILE* f = std::fopen(path, "rb");

@@ -88,17 +88,15 @@
  *     never returns on success.
  *   - there is NO CPU fallback: without a usable gfx950 device every compute entry
  *     point fails with ZKHIP_ERR_NO_DEVICE.
+ *
+ * Three headers (round 6): THIS one holds what a `ZkProver` backend binds -- contexts, the operators of the shard prover, the shard / multi-chip /
+ * machine provers and verifiers, the statement-level SHA-256 entries, the batch entries, the recursion (compress) stage, parameters and
+ * serialisation; zkhip_hal.h the RISC Zero `Hal` operator set; zkhip_chips.h the chip level -- chip programs, trace
+ * generators, the descriptions of the recursion machines, the FRI-only machines, diagnostics and self-tests.  INTEGRATION.md section 1 lists the
+ * entries a `ZkProver::prove` needs.
  */
 #ifndef ZKHIP_H
 #define ZKHIP_H
-/* Entries superseded by a later one stay exported (their tests and the byte-equality against the oracle stay in the suites) but are marked:
- * new callers take the entry named in the message.  Define ZKHIP_NO_DEPRECATION_WARNINGS to silence the attribute. */
-#if defined(ZKHIP_NO_DEPRECATION_WARNINGS) || !(defined(__GNUC__) || defined(__clang__))
-#define ZKHIP_DEPRECATED(msg)
-#else
-#define ZKHIP_DEPRECATED(msg) __attribute__((deprecated(msg)))
-#endif
-
 #include <stddef.h>
 #include <stdint.h>
 
@@ -219,8 +217,6 @@ int zkhip_coset_lde(zkhip_ctx* ctx, const uint32_t* d_in, size_t in_ld, uint32_t
  * workspaces (the in-proof buffer placement): 2 = first inverse pass (strided, d_in = the trace -> coefficient workspace),
  * 3 = second inverse pass (contiguous, in place), 4 = first forward pass of the coset (coefficients -> LDE workspace,
  * strided bit-reversed stores), 5 = second forward pass (contiguous, in place); d_out is ignored, d_in only read by 2. */
-int zkhip_ntt_pass(zkhip_ctx* ctx, const uint32_t* d_in, uint32_t* d_out, size_t ld, int log_n,
-                   uint32_t width, int which);
 /* The launches of the trace LDE as the prover enqueues them TODAY for 2^20 rows x a multiple of 32 columns (same workspaces as
  * which = 2..5 above): which = 6 first inverse pass in its block form (strided in -> one contiguous block per tile), 7 the FUSED
  * middle launch (second inverse pass + first forward pass of both cosets of a blowup-2 LDE: reads the blocks once, writes both
@@ -256,61 +252,7 @@ int zkhip_merkle_commit(zkhip_ctx* ctx, const uint32_t* const* d_mats, const siz
 int zkhip_merkle_commit_mixed(zkhip_ctx* ctx, const uint32_t* const* d_mats, const size_t* lds,
                               const uint32_t* widths, const int* log_heights, int nmats, uint32_t* d_tree);
 
-/* RISC Zero layout (risc0-zkp Hal::hash_rows + hash_fold, reference
- * Cargo.lock:5057, call site crates/guest-prover-r0/src/prover.rs:90): d_mat is COLUMN-major
- * [cols][2^log_rows]; leaf r = Poseidon2-width-24 sponge (rate 16) over row r; parents =
- * permute(l || r || 0^8)[0..8].  Own constants "zktls-amd/p2-bb24-v1". */
-int zkhip_merkle_commit_p24_colmajor(zkhip_ctx* ctx, const uint32_t* d_mat, uint32_t cols, int log_rows,
-                                     uint32_t* d_tree);
-/* Hal::batch_interpolate_ntt: `count` polynomials, column-major [count][2^log_size]; evaluations
- * in BIT-REVERSED order in, coefficients in natural order out (scaled by 1/size). */
-int zkhip_batch_interpolate_colmajor(zkhip_ctx* ctx, const uint32_t* d_evals, uint32_t* d_coeffs,
-                                     uint32_t count, int log_size);
-/* Hal::zk_shift + batch_expand_into_evaluate_ntt: coefficients (natural) -> evaluations of the same
- * polynomials on shift * <w_(size * 2^log_blowup)>, bit-reversed, [count][size << log_blowup].
- * RISC Zero expands by 4 (log_blowup = 2).  `shift` canonical. */
-int zkhip_batch_expand_colmajor(zkhip_ctx* ctx, const uint32_t* d_coeffs, uint32_t* d_evals,
-                                uint32_t count, int log_size, int log_blowup, uint32_t shift);
-
-/* ---- RISC Zero `Hal` operator set (risc0-zkp 1.2.5 trait hal::Hal, reference Cargo.lock:5057; kernels risc0-sys 1.2.5,
- * Cargo.lock:5045; call site crates/guest-prover-r0/src/prover.rs:90).  Data as the Hal
- * holds it: polynomials / columns are contiguous device vectors (column-major [count][size]) of Montgomery words, extension
- * elements are 4 consecutive words, 16-byte aligned.  `ext_field` selects the extension the operator multiplies in:
- * ZKHIP_EXT_X4_MINUS_11 = F_p[x]/(x^4 - 11) (Plonky3 / SP1, what the shard prover uses) or ZKHIP_EXT_X4_PLUS_11 =
- * F_p[x]/(x^4 + 11) (RISC Zero).  Extension challenges passed by value (mix, mix_start) are HOST pointers, Montgomery form. ---- */
-typedef enum { ZKHIP_EXT_X4_MINUS_11 = 0, ZKHIP_EXT_X4_PLUS_11 = 1 } zkhip_ext_field;
-/* Hal::eltwise_add_elem: out[i] = a[i] + b[i] */
-int zkhip_eltwise_add(zkhip_ctx* ctx, uint32_t* d_out, const uint32_t* d_a, const uint32_t* d_b, size_t n);
-/* Hal::eltwise_copy_elem */
-int zkhip_eltwise_copy(zkhip_ctx* ctx, uint32_t* d_out, const uint32_t* d_in, size_t n);
-/* Hal::eltwise_zeroize_elem: cells still holding the "unset" marker 0xffffffff become 0 */
-int zkhip_eltwise_zeroize(zkhip_ctx* ctx, uint32_t* d_io, size_t n);
-/* Hal::eltwise_sum_extelem: out[i] = sum_j in[j * count + i] over extension elements (i < count, j < to_add) */
-int zkhip_eltwise_sum_ext(zkhip_ctx* ctx, uint32_t* d_out, const uint32_t* d_in, size_t count, size_t to_add);
-/* Hal::zk_shift: coefficient i of each of `count` polynomials of 2^log_size coefficients times shift^i (RISC Zero shifts
- * by 3); `shift` canonical.  Any 4-byte-aligned d_io (a slice inside a larger buffer: 16-byte alignment only selects the faster form), any count */
-int zkhip_zk_shift(zkhip_ctx* ctx, uint32_t* d_io, size_t count, int log_size, uint32_t shift);
-/* Hal::mix_poly_coeffs: d_out[combos[i] * count + idx] += mix_start * mix^i * d_in[i * count + idx], i < input_size, idx < count;
- * d_out holds extension elements ([n_combos][count]), d_in base elements ([input_size][count]), d_combos device u32 */
-int zkhip_mix_poly_coeffs(zkhip_ctx* ctx, uint32_t* d_out, const uint32_t mix_start[4], const uint32_t mix[4], const uint32_t* d_in,
-                          const uint32_t* d_combos, size_t input_size, size_t count, int ext_field);
-/* Hal::batch_evaluate_any: d_out[e] = polynomial d_which[e] (2^log_size base coefficients, lowest first, polynomial p at
- * d_coeffs + p * 2^log_size) evaluated at the extension point d_xs[e] */
-int zkhip_batch_evaluate_any(zkhip_ctx* ctx, const uint32_t* d_coeffs, int log_size, const uint32_t* d_which, const uint32_t* d_xs,
-                             uint32_t* d_out, size_t eval_count, int ext_field);
-/* Hal::gather_sample: d_dst[g] = d_src[g * stride + idx], g < size (row idx of a column-major matrix: a FRI query row) */
-int zkhip_gather_sample(zkhip_ctx* ctx, uint32_t* d_dst, const uint32_t* d_src, size_t idx, size_t size, size_t stride);
-/* Hal::scatter: d_into[d_offsets[k]] = d_values[k] for k in [d_index[r], d_index[r + 1]), r < rows */
-int zkhip_scatter(zkhip_ctx* ctx, uint32_t* d_into, const uint32_t* d_index, const uint32_t* d_offsets, const uint32_t* d_values, size_t rows);
-/* Hal::prefix_products: inclusive prefix products of n extension elements, in place (the accumulator columns) */
-int zkhip_prefix_products_ext(zkhip_ctx* ctx, uint32_t* d_io, size_t n, int ext_field);
-/* Hal::hash_rows / hash_fold with the SHA-256 hash suite: leaf r = SHA-256 over the CANONICAL words of row r of the
- * column-major [cols][rows] matrix, each word serialised big-endian, FIPS 180-4 padding; a node = SHA-256 of its children's
- * 64 bytes.  Digests are the eight 32-bit state words (plain integers, not field elements).  This byte convention is this
- * library's own (stated in DESIGN.md 4.4); the Poseidon2 variants are zkhip_merkle_commit_p24_colmajor / zkhip_merkle_commit. */
-int zkhip_hash_rows_sha256(zkhip_ctx* ctx, const uint32_t* d_mat, size_t cols, size_t rows, uint32_t* d_digests);
-int zkhip_hash_fold_sha256(zkhip_ctx* ctx, const uint32_t* d_children, uint32_t* d_parents, size_t count);
-int zkhip_merkle_commit_sha256_colmajor(zkhip_ctx* ctx, const uint32_t* d_mat, uint32_t cols, int log_rows, uint32_t* d_tree);
+/* (the RISC Zero `Hal` operator set -- column-major transforms, width-24 Poseidon2 and SHA-256 hashing, the eltwise / mix / evaluate operators: include/zkhip_hal.h) */
 
 /* ---- STARK stages (synthetic AIR, log_blowup = 1) ---- */
 /* quotient values on the LDE coset, bit-reversed rows: d_out[2^(log_n+1)][4] */
@@ -416,7 +358,6 @@ int zkhip_verify_shard(const uint8_t* proof, size_t len, int log_n, uint32_t wid
 int zkhip_air_validate(const uint32_t* program, size_t words, uint32_t width, size_t n_public);
 int zkhip_air_digest(const uint32_t* program, size_t words, uint32_t out[8]);
 /* the built-in synthetic AIR written as a program; out == NULL: *words receives the size */
-int zkhip_air_synthetic(uint32_t width, size_t n_public, uint32_t* out, size_t cap, size_t* words);
 size_t zkhip_proof_size_air(const uint32_t* program, size_t program_words, int log_n, uint32_t width, const zkhip_params* prm, size_t n_public);
 int zkhip_prove_shard_air(zkhip_ctx* ctx, const uint32_t* program, size_t program_words, const uint32_t* d_trace, size_t ld, int log_n,
                           uint32_t width, const uint32_t* public_values, size_t n_public, const zkhip_params* prm,
@@ -448,17 +389,12 @@ int zkhip_quotient_values_air(zkhip_ctx* ctx, const uint32_t* program, size_t pr
 #define ZKHIP_SHA256_PADDING_PUBLIC 75
 /* the 75 padding values of a trace that holds blocks [first_block, first_block + n_active) of the padded message of message_len bytes
  * (a whole message: first_block 0, n_active (message_len + 8) / 64 + 1).  Host only; what a verifier computes instead of trusting. */
-void zkhip_sha256_padding_publics(uint64_t message_len, uint64_t first_block, uint64_t n_active, uint32_t out[75]);
 /* the constraint program (a zkhip_prove_shard_air program): returns its length in words; written when cap_words suffices */
-size_t zkhip_sha256_air(uint32_t* program, size_t cap_words);
 /* the digest itself, on the host (what a verifier compares the proof's public values with) */
 void zkhip_sha256_digest(const uint8_t* message, size_t len, uint8_t digest[32]);
 /* FIPS 180-4 padding: returns the padded length (a multiple of 64); written when cap suffices.  Host only. */
-size_t zkhip_sha256_pad(const uint8_t* message, size_t len, uint8_t* blocks, size_t cap);
 /* trace generation on the device: blocks = the n_active = (message_len + 8) / 64 + 1 padded 64-byte blocks (host memory), n_blocks = a
  * power of two >= n_active; d_trace [64 n_blocks][ld >= 640] Montgomery; publics (host) = the 91 public values */
-int zkhip_sha256_gen_trace(zkhip_ctx* ctx, const uint8_t* blocks, size_t n_active, size_t n_blocks, uint64_t message_len, uint32_t* d_trace, size_t ld,
-                           uint32_t publics[91]);
 /* message in, digest (32 bytes, as SHA-256 prints it) and proof out: pad, generate the trace on the device, zkhip_prove_shard_air.
  * zkhip_params: any shape zkhip_prove_shard_air takes (logup_pairs = code_width = 0). */
 size_t zkhip_sha256_proof_size(size_t message_len, const zkhip_params* prm);
@@ -522,8 +458,6 @@ int zkhip_verify_chips_air(const uint8_t* proof, size_t len, const int32_t* log_
 /* a range table's two columns on the device: d_table[v][value_col] = v and d_table[v][mult_col] = how often v appears in the listed
  * `columns` of d_trace (the multiplicities a `receive` interaction of the table needs), v < 2^log_table; the other columns of d_table are
  * left as they are.  Fails if a looked-up value lies outside the table. */
-int zkhip_range_table(zkhip_ctx* ctx, const uint32_t* d_trace, size_t ld, size_t rows, const uint32_t* columns, int n_columns, int log_table,
-                      uint32_t* d_table, size_t table_ld, uint32_t value_col, uint32_t mult_col);
 size_t zkhip_machine_proof_size(const int32_t* log_ns, const uint32_t* widths, const uint32_t* const* programs, const size_t* program_words,
                                 const uint32_t* const* tables, const size_t* table_words, int n_chips, const zkhip_params* prm, size_t n_public);
 int zkhip_prove_machine(zkhip_ctx* ctx, const zkhip_chip* chips, const uint32_t* const* programs, const size_t* program_words,
@@ -581,9 +515,6 @@ int zkhip_verify_machine_keyed(const uint8_t* proof, size_t len, const int32_t* 
  * zkhip_prove_shards_multi.  chain: (n_shards + 1) x 8 words out; proofs: n_shards x proof_stride bytes (proof_stride >=
  * zkhip_sha256_shard_proof_size(k, prm)), proof_lens[s] out.  zkhip_verify_sha256_sharded checks the whole chain on the host (bad_shard /
  * reason name the first failing shard).  zkhip_sha256_gen_trace_chained = zkhip_sha256_gen_trace from a given chaining value. */
-size_t zkhip_sha256_air_chained(uint32_t* program, size_t cap_words);
-int zkhip_sha256_gen_trace_chained(zkhip_ctx* ctx, const uint32_t chain_in[8], const uint8_t* blocks, size_t n_active, size_t n_blocks, uint64_t message_len,
-                                   uint64_t first_block, uint32_t* d_trace, size_t ld, uint32_t publics[91]);
 size_t zkhip_sha256_sharded_count(size_t message_len, int log_blocks_per_shard);
 size_t zkhip_sha256_shard_proof_size(int log_blocks, const zkhip_params* prm);
 int zkhip_prove_sha256_sharded(const int* devices, int n_devices, const uint8_t* message, size_t message_len, int log_blocks_per_shard, const zkhip_params* prm,
@@ -623,7 +554,6 @@ int zkhip_prove_sha256_machine(zkhip_ctx* ctx, const zkhip_machine_key* key, con
 int zkhip_verify_sha256_machine(const uint8_t* proof, size_t len, const uint8_t digest[32], uint64_t message_len, const uint32_t vk[8], const zkhip_params* prm, int* reason);
 /* the keyed machine of a message of this length as data -- chip `which` (0, 1: tallest first), kind 0 its program, 1 its interaction table: what a
  * zkhip_machine_desc takes, so that proofs of zkhip_prove_transcripts go to zkhip_prove_machine_verifier (64 transcript proofs -> ONE proof). */
-size_t zkhip_sha256_machine_describe(size_t message_len, int which, int kind, uint32_t* out, size_t cap, int* log_n, uint32_t* width, uint32_t* pre_width);
 /* A batch of transcripts in one call -- the reference's batch configuration (BASELINE.json configs[2]: 64 independent transcripts), each proven
  * as the keyed SHA-256 machine: job i runs on devices[i mod n_devices] (NULL / 0: every visible device), `in_flight_per_device` at a time per
  * device, on pooled contexts that keep their proving key between calls (setup once per context).  Messages are host bytes; every job
@@ -666,11 +596,8 @@ int zkhip_prove_transcripts_air(const int* devices, int n_devices, zkhip_transcr
 void zkhip_set_lockstep(int max_batch, int lanes);
 /* the lanes' fiber scheduler on its own (needs no device): `members` fibers wait, vote and leave for `rounds` rounds and check that the
  * per-thread error string stays theirs across switches.  0, or the number of the first check that failed. */
-int zkhip_selftest_lockstep(int members, int rounds);
-void zkhip_lockstep_stats(uint64_t out[6]);
 /* the most bytes of a member's (fiber's) 2 MiB stack touched so far in this process, page granularity (guard pages at both ends of
  * every stack turn an overflow into a fault; this says how far from it the provers run).  0 before the first lock-step batch. */
-uint64_t zkhip_lockstep_stack_high_water(void);
 /* The FRI commit phase of a proof outside lock-step batches is a fixed sequence of ~250 small launches, captured once per shape into a HIP
  * graph and replayed with one hipGraphLaunch per proof (csrc/prover.cpp).  on = 0 keeps the plain launches, process-wide (default on; same
  * proof bytes): a debugging switch that takes graphs out of the picture.  (It was added while chasing the SIGSEGV of runs under `rocprofv3
@@ -679,156 +606,7 @@ uint64_t zkhip_lockstep_stack_high_water(void);
  * profiles/r04_segv.md.) */
 void zkhip_set_fri_graph(int on);
 
-/* A second real chip: the width-16 Poseidon2 permutation with Merkle-path chaining -- what a recursion machine (a STARK verifier proven
- * inside a STARK: the compress / shrink / wrap stages behind SP1ProofMode::Groth16, crates/guest-prover-sp1/src/sp1.rs:116; sp1-recursion's
- * Poseidon2 chips, reference Cargo.lock:6172 ff.) spends its rows on.  One row = one permutation of the parameter set in effect, every
- * intermediate in a column (ZKHIP_P2CHIP_WIDTH = 360 columns, degree <= 3); flag columns chain rows into Merkle paths (a row's
- * digest-carrying input half = the previous row's digest), into LEAF HASHES (the overwrite-mode sponge over an opened row: a row's capacity
- * half = the previous row's) and count the paths that end in the public root.  Public values: root[8], count.  zkhip_p2chip_air writes the constraint program (returns its size in words; the program follows the Poseidon2 tables, so reload
- * it after zkhip_load_poseidon2_params).  zkhip_p2chip_gen_merkle_trace fills a device trace of 2^log_n rows from host arrays: with
- * row_width = 0 path p = `depth` rows and leaves[p][8] is its leaf digest; with row_width = 8 k, leaves[p][row_width] is the OPENED ROW and the
- * path starts with k sponge rows that hash it (a whole opening of a commitment: what a verifier checks per query and matrix);
- * siblings[p][l][8] the sibling at level l, bit l of indices[p] = "the node is a
- * right child at level l" (canonical words); roots[p][8] receives where each path ends.  zkhip_prove_merkle_paths = trace + proof of
- * "I know n_paths Merkle paths that end in root" (refuses paths that do not); zkhip_verify_merkle_paths checks one (the trace height is
- * read from the proof).  The proofs are zkhip_prove_shard_air proofs (version 7). */
-#define ZKHIP_P2CHIP_WIDTH 360
-size_t zkhip_p2chip_air(uint32_t* program, size_t cap_words);
-int zkhip_p2chip_gen_merkle_trace(zkhip_ctx* ctx, const uint32_t* leaves, uint32_t row_width, const uint32_t* siblings, const uint32_t* indices, size_t n_paths,
-                                  int depth, int log_n, uint32_t* d_trace, size_t ld, uint32_t* roots);
-size_t zkhip_merkle_paths_proof_size(size_t n_paths, int depth, uint32_t row_width, const zkhip_params* prm);
-int zkhip_prove_merkle_paths(zkhip_ctx* ctx, const uint32_t* leaves, uint32_t row_width, const uint32_t* siblings, const uint32_t* indices, size_t n_paths, int depth,
-                             const uint32_t root[8], const zkhip_params* prm, uint8_t* proof, size_t cap, size_t* len);
-int zkhip_verify_merkle_paths(const uint8_t* proof, size_t len, const uint32_t root[8], size_t n_paths, const zkhip_params* prm, int* reason);
-
-/* ---- a first step of recursion: the FRI part of a shard proof checked INSIDE a proof (second half).  The reference's
- * hot call is client.prove(.., SP1ProofMode::Groth16) (crates/guest-prover-sp1/src/sp1.rs:116): core -> compress -> shrink -> wrap, and
- * compress verifies shard proofs in-circuit (sp1-recursion, reference Cargo.lock:6172 ff.; RISC Zero lift -> join, prover.rs:90).
- * zkhip_fri_view_shard runs the verifier of a zkhip_prove_shard proof (fold by 2, constant final value: the SP1 shape) and hands out what
- * its FRI check reads: layers = log_n folding challenges (4 words each), the final value, and per query the index (layers + 1 bits), the
- * reduced opening it starts from and one sibling per layer -- canonical words; fails like zkhip_verify_shard if the proof is rejected.
- * The FRI-fold chip (fri_chip.hip; 32 + layers columns rounded up to a multiple of 4, one row per (query, layer), degree 3) folds these
- * chains; its rows send the layer pairs on two lookup buses to a PREPROCESSED table that lists every distinct pair of the view with the
- * number of queries reading it -- fixed multiplicities, so every listed pair is folded exactly as often as the inner proof reads it.
- * zkhip_fri_queries_key commits that table (zkhip_machine_setup): vk is what a verifier recomputes from the inner proof; final_value is
- * what the chains end in.  zkhip_prove_fri_queries generates the chip's trace on the device and proves the two-chip keyed machine
- * (proof version 11; public values: the challenges, then the final value); zkhip_verify_fri_queries checks it on the host.
- * NOT in-circuit yet: the Merkle paths of the pairs (the Poseidon2 chip above proves such paths, it is not on this bus yet), the reduced
- * openings, the transcript.  zkhip_fri_chip_air writes the chip's constraint program (its size in words), zkhip_fri_chip_gen_trace the
- * trace alone (finals: [n_queries][4], the value each chain ends in). */
-int zkhip_fri_view_shard(const uint8_t* proof, size_t len, int log_n, uint32_t width, const uint32_t* public_values, size_t n_public,
-                         const zkhip_params* prm, uint32_t* betas, uint32_t final_value[4], uint32_t* indices, uint32_t* values, uint32_t* siblings);
-uint32_t zkhip_fri_chip_width(int layers);
-size_t zkhip_fri_chip_air(int layers, uint32_t* program, size_t cap_words);
-int zkhip_fri_chip_gen_trace(zkhip_ctx* ctx, int layers, size_t n_queries, const uint32_t* betas, const uint32_t* indices, const uint32_t* values,
-                             const uint32_t* siblings, int log_rows, uint32_t* d_trace, size_t ld, uint32_t* finals);
-int zkhip_fri_queries_key(zkhip_ctx* ctx, int layers, size_t n_queries, const uint32_t* betas, const uint32_t* indices, const uint32_t* values,
-                          const uint32_t* siblings, const zkhip_params* prm, zkhip_machine_key** key, uint32_t vk[8], uint32_t final_value[4]);
-size_t zkhip_fri_queries_proof_size(int layers, size_t n_queries, const zkhip_params* prm);
-ZKHIP_DEPRECATED("the FRI-only machines are superseded: zkhip_prove_shard_verifier checks the whole shard proof in-circuit; zkhip_prove_fri_indices_batch is the cheap FRI-only mode")
-int zkhip_prove_fri_queries(zkhip_ctx* ctx, const zkhip_machine_key* key, int layers, size_t n_queries, const uint32_t* betas, const uint32_t* indices,
-                            const uint32_t* values, const uint32_t* siblings, const zkhip_params* prm, uint8_t* proof, size_t cap, size_t* len);
-int zkhip_verify_fri_queries(const uint8_t* proof, size_t len, int layers, size_t n_queries, const uint32_t* betas, const uint32_t final_value[4],
-                             const uint32_t vk[8], const zkhip_params* prm, int* reason);
-/* The same with the Merkle paths of the pairs IN-CIRCUIT (blowup-2 proofs): the FRI-fold chip wired by lookups to the Poseidon2 chip.
- * zkhip_fri_view_shard_paths also hands out the layer roots ([layers][8]) and, per query, the layers' authentication paths one after the
- * other (8 (layers - l) words for layer l; zkhip_fri_view_path_words(layers) words per query).  The machine has four chips: the Poseidon2
- * chip's FRI-layers variant (zkhip_p2chip_air_fri_layers: one path per (query, layer) -- a leaf row hashing the pair, then the compression
- * rows up to the layer's root; leaf rows receive the pairs from the bus, END rows send (layer, root) to the ROOTS table), the fold chip
- * in its wired form (zkhip_fri_layers_chip_air: sends the pairs, and (index, reduced opening) on a query's first row), and two
- * PREPROCESSED tables: QUERIES (index, reduced opening) and ROOTS (layer, root).  The key (zkhip_fri_layers_key) therefore holds no FRI
- * layer value any more: a verifier needs the layer roots of the inner proof and the reduced openings it computes itself.  Statement: "for
- * the layer commitments and the (index, reduced opening) pairs in the key, every query's chain opens the commitments layer by layer and
- * folds, under the public challenges, to the public final value."  Still outside: the trace / quotient openings, the reduced openings,
- * the transcript. */
-size_t zkhip_fri_view_path_words(int layers);
-int zkhip_fri_view_shard_paths(const uint8_t* proof, size_t len, int log_n, uint32_t width, const uint32_t* public_values, size_t n_public,
-                               const zkhip_params* prm, uint32_t* betas, uint32_t final_value[4], uint32_t* indices, uint32_t* values, uint32_t* siblings,
-                               uint32_t* roots, uint32_t* paths);
-/* the Fiat-Shamir side of the view: the layer roots (8 words each), the challenges they lead to (4 words each), and the duplex
- * challenger as the commit phase finds it -- transcript[0..8) = the capacity half of its state, transcript[8] = pending inputs (0);
- * transcript[9] = the proof-of-work witness the query phase absorbs behind the final value.
- * With these every challenge is one step of a sponge chain over the roots: state <- (root_l | capacity), permute,
- * beta_l = (state[7], state[6], state[5], state[4]), capacity <- state[8..16) -- what a transcript chip has to prove next
- * (docs/RECURSION_NEXT.md; p3-challenger DuplexChallenger, reference Cargo.lock:3875).  Canonical words; host only. */
-int zkhip_fri_view_transcript(const uint8_t* proof, size_t len, int log_n, uint32_t width, const uint32_t* public_values, size_t n_public,
-                              const zkhip_params* prm, uint32_t* roots, uint32_t* betas, uint32_t transcript[10]);
-/* ... and both in ONE pass over the proof (what zkhip_prove_fri_indices_batch runs per shard proof) */
-int zkhip_fri_view_all(const uint8_t* proof, size_t len, int log_n, uint32_t width, const uint32_t* public_values, size_t n_public,
-                       const zkhip_params* prm, uint32_t* betas, uint32_t final_value[4], uint32_t* indices, uint32_t* values, uint32_t* siblings,
-                       uint32_t* roots, uint32_t* paths, uint32_t transcript[10]);
-size_t zkhip_fri_layers_chip_air(int layers, uint32_t* program, size_t cap_words);
-size_t zkhip_p2chip_air_fri_layers(int layers, uint32_t* program, size_t cap_words);
-int zkhip_fri_layers_gen_paths_trace(zkhip_ctx* ctx, int layers, size_t n_queries, const uint32_t* betas, const uint32_t* indices, const uint32_t* values,
-                                     const uint32_t* siblings, const uint32_t* roots, const uint32_t* paths, int log_rows, uint32_t* d_trace, size_t ld);
-int zkhip_fri_layers_key(zkhip_ctx* ctx, int layers, size_t n_queries, const uint32_t* indices, const uint32_t* values, const uint32_t* roots,
-                         const zkhip_params* prm, zkhip_machine_key** key, uint32_t vk[8]);
-size_t zkhip_fri_layers_proof_size(int layers, size_t n_queries, const zkhip_params* prm);
-ZKHIP_DEPRECATED("superseded: zkhip_prove_shard_verifier (whole verifier) or zkhip_prove_fri_indices_batch (FRI only)")
-int zkhip_prove_fri_layers(zkhip_ctx* ctx, const zkhip_machine_key* key, int layers, size_t n_queries, const uint32_t* betas, const uint32_t* indices,
-                           const uint32_t* values, const uint32_t* siblings, const uint32_t* roots, const uint32_t* paths, const zkhip_params* prm,
-                           uint8_t* proof, size_t cap, size_t* len);
-int zkhip_verify_fri_layers(const uint8_t* proof, size_t len, int layers, size_t n_queries, const uint32_t* betas, const uint32_t final_value[4],
-                            const uint32_t vk[8], const zkhip_params* prm, int* reason);
-/* The same machine with the FRI TRANSCRIPT in-circuit: the Poseidon2 chip's trace starts with transcript rows (zkhip_p2chip_air_fri_transcript,
- * 364 columns) -- a sponge chain over the layer roots from the duplex challenger's capacity (zkhip_fri_view_transcript): row l absorbs
- * root_l (sent to the ROOTS table like a path's end), keeps the capacity of row l - 1 (row 0: public) and sends
- * (l, out[7], out[6], out[5], out[4]) on a bus of its own.  The ROOTS table holds the challenges in its MAIN columns (the prover's),
- * receives each once from its transcript row and hands it to the layer's fold rows (zkhip_fri_transcript_chip_air: the fold chip without
- * public challenges).  Public values: the final value and the capacity.  NEITHER THE KEY NOR THE VERIFIER HOLDS A CHALLENGE -- statement:
- * "for the layer commitments and the (index, reduced opening) pairs in the key, every query's chain opens the commitments and folds to the
- * public final value under the challenges the transcript derives from these commitments, starting from this challenger state."  The
- * prover is still handed the view's challenges and refuses when its chain disagrees.  Still outside: how the challenger state came about
- * (the transcript before the commit phase), the query indices, the trace / quotient openings and the reduced openings.  Ref: p3-challenger
- * DuplexChallenger (reference Cargo.lock:3875) behind sp1.rs:116. */
-size_t zkhip_fri_transcript_chip_air(int layers, uint32_t* program, size_t cap_words);
-size_t zkhip_p2chip_air_fri_transcript(int layers, uint32_t* program, size_t cap_words);
-int zkhip_fri_transcript_key(zkhip_ctx* ctx, int layers, size_t n_queries, const uint32_t* indices, const uint32_t* values, const uint32_t* roots,
-                             const zkhip_params* prm, zkhip_machine_key** key, uint32_t vk[8]);
-size_t zkhip_fri_transcript_proof_size(int layers, size_t n_queries, const zkhip_params* prm);
-ZKHIP_DEPRECATED("superseded: zkhip_prove_shard_verifier (whole verifier) or zkhip_prove_fri_indices_batch (FRI only)")
-int zkhip_prove_fri_transcript(zkhip_ctx* ctx, const zkhip_machine_key* key, int layers, size_t n_queries, const uint32_t* betas, const uint32_t* indices,
-                               const uint32_t* values, const uint32_t* siblings, const uint32_t* roots, const uint32_t* paths, const uint32_t capacity[8],
-                               const zkhip_params* prm, uint8_t* proof, size_t cap, size_t* len);
-int zkhip_verify_fri_transcript(const uint8_t* proof, size_t len, int layers, size_t n_queries, const uint32_t final_value[4], const uint32_t capacity[8],
-                                const uint32_t vk[8], const zkhip_params* prm, int* reason);
-/* The QUERY PHASE of the transcript in-circuit (zkhip_prove_fri_indices): the sponge chain of the transcript machine goes on as the inner
- * proof's verifier does (p3-fri verifier: observe the final polynomial, check the proof-of-work witness, sample the query indices;
- * reference Cargo.lock:3930, 3875) -- one row absorbs the final value and the witness over the front of the rate, further rows only
- * permute; a fifth chip, SAMPLES, takes the 31 bits of every word these rows hand out (canonical decomposition): the first word's low
- * inner_pow_bits bits must be zero, the low layers + 1 bits of the others are the query indices, which reach the QUERIES table's MAIN
- * column by query number and from there the first fold row of the query.  The key holds (query number, reduced opening) and the layer
- * roots -- no index; the verifier is handed the final value and the challenger's capacity: "every query, AT THE INDEX THE TRANSCRIPT
- * DRAWS FOR IT, opens these commitments and folds to this final value, and the transcript's proof of work holds."  inner_pow_bits = the
- * grinding bits of the INNER proof (zkhip_params.pow_bits of the proof the view was taken from); witness = its proof-of-work witness
- * (zkhip_fri_view_transcript: transcript[9]).  zkhip_fri_indices_program: the two programs that differ from the transcript machine's
- * (which = 0: the Poseidon2 chip with query-phase rows, 1: the SAMPLES chip).  Still outside: the transcript before the commit phase,
- * the trace / quotient openings and the reduced openings. */
-size_t zkhip_fri_indices_program(int which, int layers, int inner_pow_bits, uint32_t* program, size_t cap_words);
-int zkhip_fri_indices_key(zkhip_ctx* ctx, int layers, size_t n_queries, int inner_pow_bits, const uint32_t* values, const uint32_t* roots,
-                          const zkhip_params* prm, zkhip_machine_key** key, uint32_t vk[8]);
-size_t zkhip_fri_indices_proof_size(int layers, size_t n_queries, int inner_pow_bits, const zkhip_params* prm);
-int zkhip_prove_fri_indices(zkhip_ctx* ctx, const zkhip_machine_key* key, int layers, size_t n_queries, int inner_pow_bits, const uint32_t* betas,
-                            const uint32_t* indices, const uint32_t* values, const uint32_t* siblings, const uint32_t* roots, const uint32_t* paths,
-                            const uint32_t capacity[8], uint32_t witness, const zkhip_params* prm, uint8_t* proof, size_t cap, size_t* len);
-int zkhip_verify_fri_indices(const uint8_t* proof, size_t len, int layers, size_t n_queries, int inner_pow_bits, const uint32_t final_value[4],
-                             const uint32_t capacity[8], const uint32_t vk[8], const zkhip_params* prm, int* reason);
-/* Many shard proofs in one call -- the compress-like step of the path (sp1.rs:116: core -> COMPRESS verifies the shard proofs; prover.rs:90:
- * lift): per job the FRI view of the shard proof (host), the key of its query-phase machine and the machine's proof; jobs are dealt over
- * `devices` (NULL / 0: every visible device) like every batch of this library -- lock-step lanes for the launch-bound sizes
- * (zkhip_set_lockstep), otherwise `in_flight_per_device` contexts per device.  All jobs share (log_n, width, inner).  Out per job: the
- * proof, and what zkhip_verify_fri_indices takes beside it (vk, final value, capacity).  verify != 0: every proof is checked on the host
- * right after it was made (sp1.rs:120).  Returns the status of the lowest failing job (every job still gets its own). */
-typedef struct zkhip_fri_job {
-    const uint8_t* shard_proof; size_t shard_proof_len;     /* in: a shard proof of this library (fold by 2, blowup 2, constant final value) */
-    const uint32_t* public_values; size_t n_public;
-    uint8_t* proof; size_t proof_cap;                       /* in: >= zkhip_fri_indices_proof_size(log_n, inner->num_queries, inner->pow_bits, outer) */
-    size_t proof_len;                                       /* out */
-    uint32_t vk[8], final_value[4], capacity[8];            /* out */
-    int status;                                             /* out */
-} zkhip_fri_job;
-int zkhip_prove_fri_indices_batch(const int* devices, int n_devices, zkhip_fri_job* jobs, int n_jobs, int log_n, uint32_t width,
-                                  const zkhip_params* inner, const zkhip_params* outer, int in_flight_per_device, int verify);
+/* (the Poseidon2 permutation chip with its Merkle-path prover, the FRI-only recursion machines and zkhip_prove_fri_indices_batch: include/zkhip_chips.h) */
 
 /* ---- THE SHARD VERIFIER AS A MACHINE: a whole shard proof checked in-circuit (csrc/shard_verifier.inl).
  * What the reference asks for behind `client.prove(&pk, &stdin, SP1ProofMode::Groth16)` (crates/guest-prover-sp1/src/sp1.rs:116: core ->
@@ -880,8 +658,6 @@ int zkhip_prove_shard_verifier_batch(const int* devices, int n_devices, const ui
                                      uint32_t vk[8]);
 int zkhip_verify_shard_recursive(const uint8_t* proof, size_t len, int log_n, uint32_t width, size_t n_queries, int inner_pow_bits, const uint32_t* public_values,
                                  size_t n_public, size_t n_proofs, const uint32_t vk[8], const zkhip_params* outer, int* reason);
-size_t zkhip_shard_verifier_describe(int log_n, uint32_t width, size_t n_queries, int inner_pow_bits, size_t n_public, size_t n_proofs, int which, int kind, uint32_t* out,
-                                     size_t cap_words, int* log_rows, uint32_t* main_width, uint32_t* pre_width);
 /* ---- THE SAME MACHINE FOR INNER PROOFS OF A CONSTRAINT PROGRAM (round 5; version-7 proofs: zkhip_prove_shard_air, zkhip_prove_sha256, the chained
  * shards of zkhip_prove_sha256_sharded, zkhip_prove_shards_air_multi) -- the proofs that carry a REAL statement become compressible: what
  * `client.prove(.., SP1ProofMode::Groth16)` (crates/guest-prover-sp1/src/sp1.rs:116: core -> COMPRESS) does to the shard proofs of a real guest.
@@ -949,15 +725,9 @@ int zkhip_prove_shard_tree(zkhip_ctx* ctx, const zkhip_machine_key* top_key, con
                            const uint32_t* public_values, size_t n_public, const zkhip_params* inner, const zkhip_params* join_outer, const zkhip_params* top_outer,
                            int in_flight_per_device, uint8_t* joined, size_t joined_stride, size_t* joined_lens, uint32_t join_vk[8], uint8_t* proof, size_t cap, size_t* len);
 
-size_t zkhip_machine_verifier_describe(const zkhip_machine_desc* inner, size_t n_proofs, int which, int kind, uint32_t* out, size_t cap, int* log_rows, uint32_t* main_width,
-                                       uint32_t* pre_width);
 /* the MAIN trace of the chip at position `which` as zkhip_prove_machine_verifier fills it on the host (canonical words, [2^log_rows][main width]; the
  * Poseidon2 chip: (input state [16], direction bit, KP) per used row -- its columns are the device's): no device, no context.  Filling the tables of an
  * inner proof is its verification: 0 (zkhip_last_error) for a proof the machine would not take.  For tests and for looking. */
-size_t zkhip_machine_verifier_host_tables(const zkhip_machine_desc* inner, const uint8_t* const* proofs, const size_t* proof_lens, size_t n_proofs, const uint32_t* public_values,
-                                          size_t n_public, int which, uint32_t* out, size_t cap);
-size_t zkhip_shard_verifier_describe_air(const uint32_t* program, size_t program_words, int log_n, uint32_t width, size_t n_queries, int inner_pow_bits, size_t n_public,
-                                         size_t n_proofs, int which, int kind, uint32_t* out, size_t cap_words, int* log_rows, uint32_t* main_width, uint32_t* pre_width);
 
 
 /* ---- Poseidon2 parameter tables from a file: the built-in sets are this repo's own
@@ -1015,12 +785,10 @@ typedef struct {
     uint32_t fri_alpha[4];
     uint32_t pow_witness;
 } zkhip_prove_debug;
-int zkhip_last_prove_debug(zkhip_ctx* ctx, zkhip_prove_debug* out);
 /* Host verifiers hash the Merkle openings of 16 queries in lockstep, one query per AVX-512 lane, when the CPU has AVX-512 F + DQ
  * (checked at run time; otherwise query by query), and spread the query groups over up to 8 host threads.  This checks the batched
  * permutation against the scalar one: 1 = in use and equal, 0 = not available on this CPU, negative = mismatch; the optional outputs
  * receive the time per permutation of either form in nanoseconds. */
-int zkhip_selftest_host_simd(double* ns_x16, double* ns_scalar);
 /* switch the batched form off (0) or back on (1) for the whole process; returns the previous setting.  For tests and A/B timing. */
 int zkhip_host_simd(int enable);
 

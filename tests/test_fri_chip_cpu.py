@@ -14,7 +14,7 @@ import pyverify
 import pyverify_chips
 from zktls_amd import _lib
 from zktls_amd._lib import Params
-from zktls_amd.device import fri_chip_air, fri_view_shard, verify_fri_queries, verify_machine_keyed
+from zktls_amd.device import fri_chip_air, fri_view_shard, verify_machine_keyed
 
 P = 2013265921
 HERE = os.path.dirname(os.path.abspath(__file__))
@@ -98,19 +98,6 @@ def test_machine_of_a_golden_proofs_view_under_the_oracle_prover_and_three_verif
     assert O.verify_machine_keyed(proof, lns, ws, pws, root, progs, tables, pub, oprm) == 0
     assert verify_machine_keyed(proof, lns, ws, pws, root, progs, tables, pub, prm) == (0, 0)
     assert pyverify_chips.verify(proof.tobytes(), lns, ws, pub, shape[0], shape[1], shape[2], programs=progs, tables=tables, pre_widths=pws, pre_root=[int(v) for v in root]) is True
-    # the named entry: challenges + final value + key
-    assert verify_fri_queries(proof, view["betas"], view["final"], len(view["queries"]), root, prm) == (0, 0)
-    # another final value, another challenge, another key, another query count: refused
-    other = list(view["final"])
-    other[2] = (other[2] + 1) % P
-    assert verify_fri_queries(proof, view["betas"], other, len(view["queries"]), root, prm)[0] == -6
-    betas = [list(x) for x in view["betas"]]
-    betas[1][0] = (betas[1][0] + 1) % P
-    assert verify_fri_queries(proof, betas, view["final"], len(view["queries"]), root, prm)[0] == -6
-    r2 = root.copy()
-    r2[0] = (int(r2[0]) + 1) % P
-    assert verify_fri_queries(proof, view["betas"], view["final"], len(view["queries"]), r2, prm)[0] == -6
-    assert verify_fri_queries(proof, view["betas"], view["final"], 4 * len(view["queries"]) + 40, root, prm)[0] == -6
 
 
 def _machine_rejected(O, traces, pre, progs, tables, pub, shape, root=None):
@@ -166,8 +153,8 @@ def test_what_the_machine_refuses(oracle):
 def test_entry_point_argument_checks():
     lib = _lib.load()
     prm = Params(1, 8, 2)
-    assert lib.zkhip_fri_queries_proof_size(1, 8, prm) == 0 and lib.zkhip_fri_queries_proof_size(6, 0, prm) == 0
-    assert lib.zkhip_fri_queries_proof_size(6, 8, prm) > 0
+    assert lib.zkhip_fri_indices_proof_size(1, 8, 0, prm) == 0 and lib.zkhip_fri_indices_proof_size(6, 0, 0, prm) == 0
+    assert lib.zkhip_fri_indices_proof_size(6, 8, 0, prm) > 0
     g = GOLDEN["v3_r0_9x8"]                       # fold by 16: no view
     with pytest.raises(_lib.ZkHipError):
         fri_view_shard(load("v3_r0_9x8"), g["log_n"], g["width"], g["public"], Params(*g["shape"]))
@@ -190,7 +177,7 @@ def test_wired_machine_of_a_golden_proofs_view(oracle, name, shape):
     """view with roots and paths (library == Python verifier), the four-chip machine on the restated arrays under the oracle's prover and
     three verifiers, and what it refuses: a sibling digest that is not the committed one, a pair that is not the opened one, a query
     left out, other roots in the key"""
-    from zktls_amd.device import fri_view_shard_paths, verify_fri_layers
+    from zktls_amd.device import fri_view_shard_paths
     O = oracle
     g = GOLDEN[name]
     b = load(name)
@@ -207,10 +194,8 @@ def test_wired_machine_of_a_golden_proofs_view(oracle, name, shape):
     nq = len(view["queries"])
     assert O.verify_machine_keyed(proof, lns, ws, pws, root, progs, tables, pub, oprm) == 0
     assert verify_machine_keyed(proof, lns, ws, pws, root, progs, tables, pub, prm) == (0, 0)
-    assert verify_fri_layers(proof, view["betas"], view["final"], nq, root, prm) == (0, 0)
     assert pyverify_chips.verify(proof.tobytes(), lns, ws, pub, shape[0], shape[1], shape[2], programs=progs, tables=tables, pre_widths=pws,
                                  pre_root=[int(v) for v in root]) is True
-    assert verify_fri_layers(proof, view["betas"], view["final"], nq + 1 if (nq + 1) * g["log_n"] <= (1 << lns[1]) else nq * 3, root, prm)[0] in (0, -6)
     import poseidon2_air as P2
     R = g["log_n"]
 
@@ -266,15 +251,11 @@ def test_transcript_machine_of_a_golden_proofs_view(oracle, name, shape):
     assert verify_machine_keyed(proof, lns, ws, pws, root, progs, tables, pub, prm) == (0, 0)
     assert pyverify_chips.verify(proof.tobytes(), lns, ws, pub, shape[0], shape[1], shape[2], programs=progs, tables=tables, pre_widths=pws,
                                  pre_root=[int(v) for v in root]) is True
-    # the library builds the same two chip programs, and its entry point for this machine accepts the oracle's proof
-    from zktls_amd.device import fri_transcript_programs, verify_fri_transcript
+    # the library builds the same two chip programs
+    from zktls_amd.device import fri_transcript_programs
     p2t, frit = fri_transcript_programs(R)
     assert p2t.tolist() == progs[0].tolist() and frit.tolist() == progs[1].tolist()
     nq = len(view["queries"])
-    assert verify_fri_transcript(proof, view["final"], capacity, R, nq, root, prm) == (0, 0)          # no challenge is handed to the verifier
-    other = list(capacity)
-    other[0] = (other[0] + 1) % P
-    assert verify_fri_transcript(proof, view["final"], other, R, nq, root, prm)[0] == -6
 
     def tampered(chip, fn):
         t = [x.copy() for x in traces]
@@ -406,7 +387,7 @@ def test_query_phase_programs_equal_the_python_restatements(oracle, layers, pow_
         assert oracle.air_validate(prog, w, F.N_PUBLIC_T) == 1 and oracle.air_log_quotient_degree(prog) == 1
     lib = _lib.load()
     prm = Params(1, 8, 2)
-    assert lib.zkhip_fri_indices_proof_size(layers, 100, pow_bits, prm) > lib.zkhip_fri_transcript_proof_size(layers, 100, prm) > 0
+    assert lib.zkhip_fri_indices_proof_size(layers, 100, pow_bits, prm) > 0
     assert lib.zkhip_fri_indices_proof_size(layers, 100, 31, prm) == 0 and lib.zkhip_fri_indices_proof_size(layers, 100, -1, prm) == 0
     assert lib.zkhip_fri_indices_program(2, layers, pow_bits, None, 0) == 0 and lib.zkhip_fri_indices_program(0, 1, pow_bits, None, 0) == 0
 

@@ -375,37 +375,38 @@ def test_sp1_shaped_shards_at_the_bench_size_join_and_top(ctx, oracle):
     key.close(), jkey.close(), tkey.close()
 
 
-def test_device_witnesses_and_the_hosts_walk_give_one_proof():
-    """round 6: the per-query tables of machine mode (ROWSUM, QUERY, FOLD, the queries' Poseidon2 rows) are filled by device kernels from the inner proofs'
-    words; ZKHIP_REC_HOST=1 keeps the host's walk (fill_proof).  Same machine, same inner proofs -> the same outer proof bytes, in fresh processes."""
-    import hashlib
-    import os
-    import subprocess
-    import sys
-    code = r'''
-import hashlib, sys
-sys.path[:0] = [".", "tests"]
-import machines as M, oracle_lib as O
-from zktls_amd._lib import Params
-from zktls_amd.device import Context, InnerMachine
-ctx = Context(0)
-made = [M.byte_machine(7, 3, seed) for seed in (1, 2)]
-q, pb = 3, 1
-proofs, pubs, chips, vk = [], [], None, None
-for mains, pres, progs, tabs, pub in made:
-    lns = [m.shape[0].bit_length() - 1 for m in mains]
-    prm = O.default_params(1, q, pb)
-    vk = [int(x) for x in O.machine_setup(pres, lns, prm)]
-    chips = [dict(ln=lns[c], W=mains[c].shape[1], Pw=0 if pres[c] is None else pres[c].shape[1], prog=progs[c], tab=tabs[c]) for c in range(len(mains))]
-    proofs.append(O.prove_machine_keyed(mains, pres, progs, tabs, pub, prm)); pubs.append(pub)
-im = InnerMachine(chips, vk, q, pb, len(pubs[0]))
-prm = Params(1, 20, 8)
-key = ctx.machine_verifier_setup(im, prm, 2)
-print(hashlib.sha256(ctx.prove_machine_verifier(key, im, proofs, pubs, prm).tobytes()).hexdigest())
-'''
-    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    outs = []
-    for host in ("0", "1"):
-        env = dict(os.environ, ZKHIP_REC_HOST=host)
-        outs.append(subprocess.run([sys.executable, "-c", code], cwd=root, env=env, capture_output=True, text=True, check=True).stdout.split()[-1])
-    assert outs[0] == outs[1]
+def test_device_witnesses_and_the_hosts_walk_give_one_proof(ctx, oracle):
+    """round 6: the per-query tables of the recursion machines (ROWSUM, QUERY, FOLD, the queries' Poseidon2 rows) are filled by device kernels from the inner
+    proofs' words; zkhip_recursion_witnesses_on_host(1) keeps the host's walk.  Same machine, same inner proofs -> the same outer proof bytes: machine mode (a join of
+    two keyed-machine proofs) and the shard verifier (a join of two shard proofs, plain and air mode)"""
+    from zktls_amd.device import air_synthetic
+    O = oracle
+    made = [M.byte_machine(7, 3, seed) for seed in (1, 2)]
+    q, pb = 3, 1
+    chips, vk, p0 = inner_of(O, *made[0], q, pb)
+    proofs, pubs = [p0, inner_of(O, *made[1], q, pb)[2]], [made[0][4], made[1][4]]
+    im = InnerMachine(chips, vk, q, pb, len(pubs[0]))
+    prm = Params(1, 20, 8)
+    key = ctx.machine_verifier_setup(im, prm, 2)
+    log_n, width = 6, 16
+    iprm, jprm = Params(1, q, pb), Params(1, 4, 2)
+    spubs = [[5, 6, 30 + s] for s in range(2)]
+    shards = [ctx.prove_shard(ctx.gen_trace(SEED, 40 + s, log_n, width), log_n, width, spubs[s], iprm) for s in range(2)]
+    jkey = ctx.shard_verifier_setup(log_n, width, q, pb, 3, jprm, n_proofs=2)
+    prog = air_synthetic(width, 3)
+    ashards = [ctx.prove_shard_air(prog, ctx.gen_trace(SEED, 40 + s, log_n, width), log_n, width, spubs[s], iprm) for s in range(2)]
+    akey = ctx.shard_verifier_setup(log_n, width, q, pb, 3, jprm, n_proofs=2, program=prog)
+
+    def all_three():
+        return (ctx.prove_machine_verifier(key, im, proofs, pubs, prm).tobytes(), ctx.prove_shard_verifier(jkey, shards, log_n, width, spubs, iprm, jprm).tobytes(),
+                ctx.prove_shard_verifier(akey, ashards, log_n, width, spubs, iprm, jprm, program=prog).tobytes())
+    from zktls_amd.device import recursion_witnesses_on_host
+    prev = recursion_witnesses_on_host(0)
+    try:
+        dev = all_three()
+        recursion_witnesses_on_host(1)
+        host = all_three()
+    finally:
+        recursion_witnesses_on_host(prev)
+    assert dev == host
+    key.close(), jkey.close(), akey.close()

@@ -7,7 +7,11 @@ import re
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 FFI = os.path.join(ROOT, "integration", "rust", "guest-prover-hip", "src", "ffi.rs")
-HDR = os.path.join(ROOT, "include", "zkhip.h")
+HDRS = [os.path.join(ROOT, "include", h) for h in ("zkhip.h", "zkhip_hal.h", "zkhip_chips.h")]      # (round 6: the ABI is three headers)
+
+
+def header_text():
+    return "\n".join(open(h).read() for h in HDRS)
 
 
 def split_args(text):
@@ -39,7 +43,7 @@ def rust_externs():
 
 
 def c_decls():
-    text = open(HDR).read()
+    text = header_text()
     text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
     fns = {}
     for m in re.finditer(r"\b(zkhip_[a-z0-9_]+)\s*\(([^;{]*?)\)\s*;", text, flags=re.S):
@@ -49,7 +53,7 @@ def c_decls():
 
 
 def c_struct_fields(name):
-    text = open(HDR).read()
+    text = header_text()
     text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
     m = re.search(r"typedef\s+struct\s*(?:\w+\s*)?\{([^}]*)\}\s*" + name + r"\s*;", text, flags=re.S)
     assert m, "struct %s not found in zkhip.h" % name

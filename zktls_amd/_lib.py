@@ -33,17 +33,17 @@ EXPORTS = [
     "zkhip_air_validate", "zkhip_air_digest", "zkhip_air_synthetic", "zkhip_proof_size_air", "zkhip_prove_shard_air", "zkhip_verify_shard_air",
     "zkhip_quotient_values_air",
     "zkhip_chips_proof_size_air", "zkhip_prove_chips_air", "zkhip_verify_chips_air",
-    "zkhip_prove_shards_air_multi", "zkhip_selftest_host_simd", "zkhip_host_simd", "zkhip_machine_proof_size", "zkhip_prove_machine", "zkhip_verify_machine", "zkhip_range_table",
+    "zkhip_prove_shards_air_multi", "zkhip_selftest_host_simd", "zkhip_host_simd", "zkhip_recursion_witnesses_on_host", "zkhip_machine_proof_size", "zkhip_prove_machine", "zkhip_verify_machine", "zkhip_range_table",
     "zkhip_machine_setup", "zkhip_machine_key_destroy", "zkhip_machine_proof_size_keyed", "zkhip_prove_machine_keyed", "zkhip_verify_machine_keyed", "zkhip_prove_machine_keyed_at",
     "zkhip_sha256_setup", "zkhip_sha256_machine_proof_size", "zkhip_prove_sha256_machine", "zkhip_verify_sha256_machine", "zkhip_prove_transcripts", "zkhip_prove_transcripts_air", "zkhip_sha256_machine_describe", "zkhip_machine_verifier_setup", "zkhip_machine_verifier_key_host", "zkhip_machine_verifier_proof_size", "zkhip_prove_machine_verifier", "zkhip_prove_shard_tree", "zkhip_verify_machine_recursive", "zkhip_machine_verifier_describe", "zkhip_machine_verifier_host_tables", "zkhip_sha256_compress_setup", "zkhip_sha256_compress_key_host", "zkhip_sha256_compressed_proof_size", "zkhip_prove_sha256_compressed", "zkhip_verify_sha256_compressed", "zkhip_set_wait_mode", "zkhip_set_lockstep", "zkhip_lockstep_stats", "zkhip_lockstep_stack_high_water", "zkhip_set_fri_graph", "zkhip_shard_verifier_setup", "zkhip_shard_verifier_proof_size", "zkhip_shard_verifier_max_proofs", "zkhip_prove_shard_verifier", "zkhip_prove_shard_verifier_batch", "zkhip_verify_shard_recursive", "zkhip_shard_verifier_describe", "zkhip_shard_verifier_key_host", "zkhip_machine_key_host", "zkhip_shard_verifier_setup_air", "zkhip_shard_verifier_key_host_air", "zkhip_shard_verifier_max_proofs_air", "zkhip_shard_verifier_proof_size_air", "zkhip_prove_shard_verifier_air", "zkhip_verify_shard_recursive_air", "zkhip_shard_verifier_describe_air", "zkhip_poseidon2_params_generation", "zkhip_selftest_lockstep",
     "zkhip_sha256_air_chained", "zkhip_sha256_gen_trace_chained", "zkhip_sha256_sharded_count", "zkhip_sha256_shard_proof_size", "zkhip_prove_sha256_sharded",
     "zkhip_verify_sha256_sharded",
-    "zkhip_fri_view_shard", "zkhip_fri_chip_width", "zkhip_fri_chip_air", "zkhip_fri_chip_gen_trace", "zkhip_fri_queries_key", "zkhip_fri_queries_proof_size",
-    "zkhip_prove_fri_queries", "zkhip_verify_fri_queries",
-    "zkhip_fri_view_path_words", "zkhip_fri_view_shard_paths", "zkhip_fri_view_transcript", "zkhip_fri_layers_chip_air", "zkhip_p2chip_air_fri_layers", "zkhip_fri_layers_gen_paths_trace",
-    "zkhip_fri_layers_key", "zkhip_fri_layers_proof_size", "zkhip_prove_fri_layers", "zkhip_verify_fri_layers",
-    "zkhip_fri_transcript_chip_air", "zkhip_p2chip_air_fri_transcript", "zkhip_fri_transcript_key", "zkhip_fri_transcript_proof_size",
-    "zkhip_prove_fri_transcript", "zkhip_verify_fri_transcript",
+    "zkhip_fri_view_shard", "zkhip_fri_chip_width", "zkhip_fri_chip_air",
+    
+    "zkhip_fri_view_path_words", "zkhip_fri_view_shard_paths", "zkhip_fri_view_transcript", "zkhip_fri_layers_chip_air", "zkhip_p2chip_air_fri_layers",
+    
+    "zkhip_fri_transcript_chip_air", "zkhip_p2chip_air_fri_transcript",
+    
     "zkhip_fri_indices_program", "zkhip_fri_indices_key", "zkhip_fri_indices_proof_size", "zkhip_prove_fri_indices", "zkhip_verify_fri_indices",
     "zkhip_prove_fri_indices_batch", "zkhip_fri_view_all",
     "zkhip_p2chip_air", "zkhip_p2chip_gen_merkle_trace", "zkhip_merkle_paths_proof_size", "zkhip_prove_merkle_paths", "zkhip_verify_merkle_paths",
@@ -290,22 +290,11 @@ def load():
     L.zkhip_fri_chip_width.argtypes = [C.c_int]
     L.zkhip_fri_chip_air.restype = C.c_size_t
     L.zkhip_fri_chip_air.argtypes = [C.c_int, u32p, C.c_size_t]
-    L.zkhip_fri_chip_gen_trace.argtypes = [C.c_void_p, C.c_int, C.c_size_t, u32p, u32p, u32p, u32p, C.c_int, C.c_void_p, C.c_size_t, u32p]
-    L.zkhip_fri_queries_key.argtypes = [C.c_void_p, C.c_int, C.c_size_t, u32p, u32p, u32p, u32p, C.POINTER(Params), C.POINTER(C.c_void_p), u32p, u32p]
-    L.zkhip_fri_queries_proof_size.restype = C.c_size_t
-    L.zkhip_fri_queries_proof_size.argtypes = [C.c_int, C.c_size_t, C.POINTER(Params)]
-    L.zkhip_prove_fri_queries.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_size_t, u32p, u32p, u32p, u32p, C.POINTER(Params), u8p, C.c_size_t, C.POINTER(C.c_size_t)]
-    L.zkhip_verify_fri_queries.argtypes = [u8p, C.c_size_t, C.c_int, C.c_size_t, u32p, u32p, u32p, C.POINTER(Params), C.POINTER(C.c_int)]
     L.zkhip_fri_view_path_words.restype = C.c_size_t
     L.zkhip_fri_view_path_words.argtypes = [C.c_int]
     L.zkhip_fri_view_shard_paths.argtypes = [u8p, C.c_size_t, C.c_int, C.c_uint32, u32p, C.c_size_t, C.POINTER(Params), u32p, u32p, u32p, u32p, u32p, u32p, u32p]
     L.zkhip_fri_view_transcript.argtypes = [u8p, C.c_size_t, C.c_int, C.c_uint32, u32p, C.c_size_t, C.POINTER(Params), u32p, u32p, u32p]
     L.zkhip_fri_view_all.argtypes = [u8p, C.c_size_t, C.c_int, C.c_uint32, u32p, C.c_size_t, C.POINTER(Params), u32p, u32p, u32p, u32p, u32p, u32p, u32p, u32p]
-    L.zkhip_fri_transcript_key.argtypes = [C.c_void_p, C.c_int, C.c_size_t, u32p, u32p, u32p, C.POINTER(Params), C.POINTER(C.c_void_p), u32p]
-    L.zkhip_fri_transcript_proof_size.restype = C.c_size_t
-    L.zkhip_fri_transcript_proof_size.argtypes = [C.c_int, C.c_size_t, C.POINTER(Params)]
-    L.zkhip_prove_fri_transcript.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_size_t, u32p, u32p, u32p, u32p, u32p, u32p, u32p, C.POINTER(Params), u8p, C.c_size_t, C.POINTER(C.c_size_t)]
-    L.zkhip_verify_fri_transcript.argtypes = [u8p, C.c_size_t, C.c_int, C.c_size_t, u32p, u32p, u32p, C.POINTER(Params), C.POINTER(C.c_int)]
     L.zkhip_fri_indices_program.restype = C.c_size_t
     L.zkhip_fri_indices_program.argtypes = [C.c_int, C.c_int, C.c_int, u32p, C.c_size_t]
     L.zkhip_fri_indices_key.argtypes = [C.c_void_p, C.c_int, C.c_size_t, C.c_int, u32p, u32p, C.POINTER(Params), C.POINTER(C.c_void_p), u32p]
@@ -319,12 +308,6 @@ def load():
     for f in (L.zkhip_fri_layers_chip_air, L.zkhip_p2chip_air_fri_layers, L.zkhip_fri_transcript_chip_air, L.zkhip_p2chip_air_fri_transcript):
         f.restype = C.c_size_t
         f.argtypes = [C.c_int, u32p, C.c_size_t]
-    L.zkhip_fri_layers_gen_paths_trace.argtypes = [C.c_void_p, C.c_int, C.c_size_t, u32p, u32p, u32p, u32p, u32p, u32p, C.c_int, C.c_void_p, C.c_size_t]
-    L.zkhip_fri_layers_key.argtypes = [C.c_void_p, C.c_int, C.c_size_t, u32p, u32p, u32p, C.POINTER(Params), C.POINTER(C.c_void_p), u32p]
-    L.zkhip_fri_layers_proof_size.restype = C.c_size_t
-    L.zkhip_fri_layers_proof_size.argtypes = [C.c_int, C.c_size_t, C.POINTER(Params)]
-    L.zkhip_prove_fri_layers.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_size_t, u32p, u32p, u32p, u32p, u32p, u32p, C.POINTER(Params), u8p, C.c_size_t, C.POINTER(C.c_size_t)]
-    L.zkhip_verify_fri_layers.argtypes = [u8p, C.c_size_t, C.c_int, C.c_size_t, u32p, u32p, u32p, C.POINTER(Params), C.POINTER(C.c_int)]
     L.zkhip_p2chip_air.restype = C.c_size_t
     L.zkhip_p2chip_air.argtypes = [u32p, C.c_size_t]
     L.zkhip_p2chip_gen_merkle_trace.argtypes = [C.c_void_p, u32p, C.c_uint32, u32p, u32p, C.c_size_t, C.c_int, C.c_int, C.c_void_p, C.c_size_t, u32p]

@@ -9,6 +9,8 @@
 #include <vector>
 
 #include "../../include/zkhip.h"
+#include "../../include/zkhip_chips.h"
+#include "../../include/zkhip_hal.h"
 #include "babybear.cuh"
 #include "kernels.h"
 

@@ -612,79 +612,9 @@ static int fri_gen_trace_dev(zkhip_ctx* ctx, int layers, size_t n_queries, const
     ZK_HIP(hipGetLastError());
     return ZKHIP_OK;
 }
-extern "C" {
-int zkhip_fri_chip_gen_trace(zkhip_ctx* ctx, int layers, size_t n_queries, const uint32_t* betas, const uint32_t* indices, const uint32_t* values,
-                             const uint32_t* siblings, int log_rows, uint32_t* d_trace, size_t ld, uint32_t* finals) {
-    return fri_gen_trace(ctx, layers, n_queries, betas, indices, values, siblings, log_rows, d_trace, ld, finals, false);
-}
-
-// the key of a view: the commitment to its OPENINGS table (zkhip_machine_setup).  A verifier recomputes it from the inner proof.
-int zkhip_fri_queries_key(zkhip_ctx* ctx, int layers, size_t n_queries, const uint32_t* betas, const uint32_t* indices, const uint32_t* values,
-                          const uint32_t* siblings, const zkhip_params* prm, zkhip_machine_key** key, uint32_t vk[8], uint32_t final_value[4]) {
-    CHECK_CTX(ctx);
-    if (!betas || !indices || !values || !siblings || !prm || !key || !vk || !final_value) return fail(ZKHIP_ERR_INVALID, "fri_queries_key: null argument");
-    int log_rows;
-    ZK_TRY(frichip::shape_ok(layers, n_queries, &log_rows));
-    if (!frichip::canonical(betas, 4 * (size_t)layers) || !frichip::canonical(values, 4 * n_queries) || !frichip::canonical(siblings, 4 * n_queries * (size_t)layers))
-        return fail(ZKHIP_ERR_INVALID, "fri_queries_key: values must be canonical");
-    std::vector<uint32_t> table;
-    ZK_TRY(frichip::build_openings(layers, n_queries, betas, indices, values, siblings, log_rows, table, final_value));
-    void* d;
-    ZK_TRY(ctx_reserve(ctx, S_CHIP_B, table.size() * 4, &d));
-    ZK_TRY(dev_h2d(ctx, d, table.data(), table.size() * 4));
-    zkhip_chip pre[2]{};
-    pre[0].log_n = log_rows; pre[0].width = 0; pre[0].partner = -1;                  // the FRI chip has no preprocessed columns
-    pre[1].d_trace = (const uint32_t*)d; pre[1].ld = frichip::OPEN_PRE; pre[1].log_n = log_rows; pre[1].width = frichip::OPEN_PRE; pre[1].partner = -1;
-    return zkhip_machine_setup(ctx, pre, 2, prm, key, vk);
-}
-
-size_t zkhip_fri_queries_proof_size(int layers, size_t n_queries, const zkhip_params* prm) {
-    int log_rows;
-    if (!prm || frichip::shape_ok(layers, n_queries, &log_rows) != ZKHIP_OK) return 0;
-    const frichip::Machine m = frichip::machine_of(layers, log_rows);
-    return zkhip_machine_proof_size_keyed(m.log_ns, m.widths, m.pre_widths, m.progs, m.prog_words, m.tabs, m.tab_words, 2, prm, frichip::n_public_of(layers));
-}
-
-int zkhip_prove_fri_queries(zkhip_ctx* ctx, const zkhip_machine_key* key, int layers, size_t n_queries, const uint32_t* betas, const uint32_t* indices,
-                            const uint32_t* values, const uint32_t* siblings, const zkhip_params* prm, uint8_t* proof, size_t cap, size_t* len) {
-    CHECK_CTX(ctx);
-    if (!key || !prm || !proof || !len) return fail(ZKHIP_ERR_INVALID, "prove_fri_queries: null argument");
-    int log_rows;
-    ZK_TRY(frichip::shape_ok(layers, n_queries, &log_rows));
-    const uint32_t W = frichip::width_of(layers);
-    void *trace, *zeros;
-    ZK_TRY(ctx_reserve(ctx, S_CHIP, ((size_t)W << log_rows) * 4, &trace));
-    std::vector<uint32_t> finals(4 * n_queries);
-    ZK_TRY(zkhip_fri_chip_gen_trace(ctx, layers, n_queries, betas, indices, values, siblings, log_rows, (uint32_t*)trace, W, finals.data()));
-    for (size_t q = 1; q < n_queries; q++)
-        if (std::memcmp(finals.data(), finals.data() + 4 * q, 16) != 0) return fail(ZKHIP_ERR_INVALID, "prove_fri_queries: the chains do not end in one value");
-    ZK_TRY(ctx_reserve(ctx, S_LOOKUP, ((size_t)frichip::OPEN_MAIN << log_rows) * 4, &zeros));      // the table's (unused) main columns
-    ZK_TRY(dev_memset(ctx, zeros, 0, ((size_t)frichip::OPEN_MAIN << log_rows) * 4));
-    std::vector<uint32_t> pv(frichip::n_public_of(layers));
-    std::memcpy(pv.data(), betas, 16 * (size_t)layers);
-    std::memcpy(pv.data() + 4 * (size_t)layers, finals.data(), 16);
-    const frichip::Machine m = frichip::machine_of(layers, log_rows);
-    zkhip_chip chips[2]{};
-    chips[0].d_trace = (const uint32_t*)trace; chips[0].ld = W; chips[0].log_n = log_rows; chips[0].width = W; chips[0].partner = -1;
-    chips[1].d_trace = (const uint32_t*)zeros; chips[1].ld = frichip::OPEN_MAIN; chips[1].log_n = log_rows; chips[1].width = frichip::OPEN_MAIN; chips[1].partner = -1;
-    return zkhip_prove_machine_keyed(ctx, key, chips, m.progs, m.prog_words, m.tabs, m.tab_words, 2, pv.data(), pv.size(), prm, proof, cap, len);
-}
-
-int zkhip_verify_fri_queries(const uint8_t* proof, size_t len, int layers, size_t n_queries, const uint32_t* betas, const uint32_t final_value[4],
-                             const uint32_t vk[8], const zkhip_params* prm, int* reason) {
-    int log_rows;
-    if (!proof || !betas || !final_value || !vk || !prm || frichip::shape_ok(layers, n_queries, &log_rows) != ZKHIP_OK) {
-        if (reason) *reason = 1;
-        return fail(ZKHIP_ERR_VERIFY, "verify_fri_queries: bad arguments");
-    }
-    std::vector<uint32_t> pv(frichip::n_public_of(layers));
-    std::memcpy(pv.data(), betas, 16 * (size_t)layers);
-    std::memcpy(pv.data() + 4 * (size_t)layers, final_value, 16);
-    const frichip::Machine m = frichip::machine_of(layers, log_rows);
-    return zkhip_verify_machine_keyed(proof, len, m.log_ns, m.widths, m.pre_widths, vk, m.progs, m.prog_words, m.tabs, m.tab_words, 2, pv.data(), pv.size(), prm, reason);
-}
-
-}  // extern "C"
+// (round 6: the entries of the first FRI-only machine -- zkhip_fri_chip_gen_trace, zkhip_fri_queries_key / _proof_size, zkhip_prove_fri_queries,
+// zkhip_verify_fri_queries -- are gone with the two generations after it; the chip, its program and its trace kernel stay: they are the FOLD chip of the
+// shard verifier machines.)
 
 // ================================================================ the wired machine: Merkle paths of the pairs in-circuit
 // Four chips, tallest first:
@@ -813,14 +743,6 @@ static int fri_layers_key_impl(zkhip_ctx* ctx, int layers, size_t n_queries, con
     pre[2].d_trace = (const uint32_t*)dq; pre[3].d_trace = (const uint32_t*)dr; pre[4].d_trace = (const uint32_t*)ds;
     return zkhip_machine_setup(ctx, pre, (size_t)m.n, prm, key, vk);
 }
-int zkhip_fri_layers_key(zkhip_ctx* ctx, int layers, size_t n_queries, const uint32_t* indices, const uint32_t* values, const uint32_t* roots,
-                         const zkhip_params* prm, zkhip_machine_key** key, uint32_t vk[8]) {
-    return fri_layers_key_impl(ctx, layers, n_queries, indices, values, roots, false, prm, key, vk);
-}
-int zkhip_fri_transcript_key(zkhip_ctx* ctx, int layers, size_t n_queries, const uint32_t* indices, const uint32_t* values, const uint32_t* roots,
-                             const zkhip_params* prm, zkhip_machine_key** key, uint32_t vk[8]) {
-    return fri_layers_key_impl(ctx, layers, n_queries, indices, values, roots, true, prm, key, vk);
-}
 int zkhip_fri_indices_key(zkhip_ctx* ctx, int layers, size_t n_queries, int inner_pow_bits, const uint32_t* values, const uint32_t* roots,
                           const zkhip_params* prm, zkhip_machine_key** key, uint32_t vk[8]) {
     if (inner_pow_bits < 0) return fail(ZKHIP_ERR_INVALID, "fri_indices_key: 0..30 proof-of-work bits");
@@ -844,8 +766,6 @@ size_t zkhip_fri_indices_program(int which, int layers, int inner_pow_bits, uint
     if (program && cap_words >= p->size()) std::memcpy(program, p->data(), p->size() * 4);
     return p->size();
 }
-size_t zkhip_fri_layers_proof_size(int layers, size_t n_queries, const zkhip_params* prm) { return fri_layers_proof_size_impl(layers, n_queries, prm, false); }
-size_t zkhip_fri_transcript_proof_size(int layers, size_t n_queries, const zkhip_params* prm) { return fri_layers_proof_size_impl(layers, n_queries, prm, true); }
 // the transcript machine's two chip programs (the tables' are one identity each)
 size_t zkhip_fri_transcript_chip_air(int layers, uint32_t* program, size_t cap_words) {
     if (layers < frichip::MIN_LAYERS || layers > frichip::MAX_LAYERS) return 0;
@@ -955,10 +875,6 @@ static int fri_layers_gen_paths_trace_impl(zkhip_ctx* ctx, int layers, size_t n_
             return fail(ZKHIP_ERR_INVALID, "fri_layers: the path of query " + std::to_string(p / R) + ", layer " + std::to_string(p % R) + " does not end in the layer's root");
     return ZKHIP_OK;
 }
-int zkhip_fri_layers_gen_paths_trace(zkhip_ctx* ctx, int layers, size_t n_queries, const uint32_t* betas, const uint32_t* indices, const uint32_t* values,
-                                     const uint32_t* siblings, const uint32_t* roots, const uint32_t* paths, int log_rows, uint32_t* d_trace, size_t ld) {
-    return fri_layers_gen_paths_trace_impl(ctx, layers, n_queries, betas, indices, values, siblings, roots, paths, nullptr, log_rows, d_trace, ld);
-}
 
 static int prove_fri_layers_impl(zkhip_ctx* ctx, const zkhip_machine_key* key, int layers, size_t n_queries, const uint32_t* betas, const uint32_t* indices,
                                  const uint32_t* values, const uint32_t* siblings, const uint32_t* roots, const uint32_t* paths, const uint32_t* capacity,
@@ -1021,17 +937,6 @@ int zkhip_prove_fri_indices(zkhip_ctx* ctx, const zkhip_machine_key* key, int la
     if (!capacity || inner_pow_bits < 0) return fail(ZKHIP_ERR_INVALID, "prove_fri_indices: bad arguments");
     return prove_fri_layers_impl(ctx, key, layers, n_queries, betas, indices, values, siblings, roots, paths, capacity, prm, proof, cap, len, &witness, inner_pow_bits);
 }
-int zkhip_prove_fri_layers(zkhip_ctx* ctx, const zkhip_machine_key* key, int layers, size_t n_queries, const uint32_t* betas, const uint32_t* indices,
-                           const uint32_t* values, const uint32_t* siblings, const uint32_t* roots, const uint32_t* paths, const zkhip_params* prm,
-                           uint8_t* proof, size_t cap, size_t* len) {
-    return prove_fri_layers_impl(ctx, key, layers, n_queries, betas, indices, values, siblings, roots, paths, nullptr, prm, proof, cap, len);
-}
-int zkhip_prove_fri_transcript(zkhip_ctx* ctx, const zkhip_machine_key* key, int layers, size_t n_queries, const uint32_t* betas, const uint32_t* indices,
-                               const uint32_t* values, const uint32_t* siblings, const uint32_t* roots, const uint32_t* paths, const uint32_t capacity[8],
-                               const zkhip_params* prm, uint8_t* proof, size_t cap, size_t* len) {
-    if (!capacity) return fail(ZKHIP_ERR_INVALID, "prove_fri_transcript: null argument");
-    return prove_fri_layers_impl(ctx, key, layers, n_queries, betas, indices, values, siblings, roots, paths, capacity, prm, proof, cap, len);
-}
 
 static int verify_fri_layers_impl(const uint8_t* proof, size_t len, int layers, size_t n_queries, const uint32_t* betas, const uint32_t final_value[4],
                                   const uint32_t* capacity, const uint32_t vk[8], const zkhip_params* prm, int* reason, int pow_bits = -1) {
@@ -1052,15 +957,6 @@ int zkhip_verify_fri_indices(const uint8_t* proof, size_t len, int layers, size_
                              const uint32_t vk[8], const zkhip_params* prm, int* reason) {
     if (!capacity || inner_pow_bits < 0) { if (reason) *reason = 1; return fail(ZKHIP_ERR_VERIFY, "verify_fri_indices: bad arguments"); }
     return verify_fri_layers_impl(proof, len, layers, n_queries, nullptr, final_value, capacity, vk, prm, reason, inner_pow_bits);
-}
-int zkhip_verify_fri_layers(const uint8_t* proof, size_t len, int layers, size_t n_queries, const uint32_t* betas, const uint32_t final_value[4],
-                            const uint32_t vk[8], const zkhip_params* prm, int* reason) {
-    return verify_fri_layers_impl(proof, len, layers, n_queries, betas, final_value, nullptr, vk, prm, reason);
-}
-int zkhip_verify_fri_transcript(const uint8_t* proof, size_t len, int layers, size_t n_queries, const uint32_t final_value[4], const uint32_t capacity[8],
-                                const uint32_t vk[8], const zkhip_params* prm, int* reason) {
-    if (!capacity) { if (reason) *reason = 1; return fail(ZKHIP_ERR_VERIFY, "verify_fri_transcript: bad arguments"); }
-    return verify_fri_layers_impl(proof, len, layers, n_queries, nullptr, final_value, capacity, vk, prm, reason);
 }
 
 

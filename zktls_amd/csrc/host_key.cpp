@@ -15,6 +15,8 @@
 #include <vector>
 
 #include "../../include/zkhip.h"
+#include "../../include/zkhip_chips.h"
+#include "../../include/zkhip_hal.h"
 #include "babybear.cuh"
 #include "context.h"
 #include "p2_x16.h"

@@ -1937,10 +1937,7 @@ struct TopSession {
     std::vector<const uint8_t*> ptrs;
     size_t proof_len = 0;
 };
-inline bool rec_host_forced() {
-    static const bool forced = getenv("ZKHIP_REC_HOST") != nullptr && atoi(getenv("ZKHIP_REC_HOST")) != 0;     // (a switch for A/B runs and for a device that misbehaves: the host's walk)
-    return forced;
-}
+inline bool rec_host_forced() { return zk::rec::witnesses_on_host(); }      // (zkhip_recursion_witnesses_on_host: shard_verifier.inl)
 int top_begin(const zkhip_machine_desc* inner, size_t n_proofs, size_t n_public, TopSession& s) {
     int rc = ZKHIP_OK;
     s.mp = machine_of(inner, n_proofs, &rc);
@@ -1949,7 +1946,7 @@ int top_begin(const zkhip_machine_desc* inner, size_t n_proofs, size_t n_public,
     const MShape& sh = m.sh;
     if ((int)n_public != sh.NPUB) return fail(ZKHIP_ERR_INVALID, "prove_machine_verifier: n_public is not the machine's");
     HostTabs& ht = s.ht;
-    s.device = !rec_host_forced();
+    s.device = !rec_host_forced() && !t_batcher;            // (inside a lock-step batch the members' launches are merged: the witness kernels are launched directly, so there the host walks)
     if (s.device) { s.plan = build_wit_plan(sh); s.vals.assign((size_t)sh.NP, DevVals{}); s.ptrs.assign((size_t)sh.NP, nullptr); }
     ZeroedWords* tabs[N_CHIPS] = {nullptr, &ht.rs, &ht.fold, &ht.ts, &ht.q, &ht.op, &ht.sm, &ht.sc, &ht.evl, &ht.lgu};
     for (int c = 0; c < N_CHIPS; c++) {

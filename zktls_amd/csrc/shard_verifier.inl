@@ -835,6 +835,16 @@ inline void put_ext(uint32_t* row, uint32_t col, const Ext& e) { for (int i = 0;
 namespace zk {
 namespace rec {
 namespace {
+// round 6: where the per-query witnesses of the recursion machines are made.  0 (default): device kernels; 1: the host's walk (fill_one / fill_proof in
+// full) -- the fallback for a device that misbehaves, and what the tests compare the kernels with (zkhip_recursion_witnesses_on_host; the A/B build also
+// reads ZKHIP_REC_HOST per call, for tools/)
+static std::atomic<int> g_witnesses_on_host{0};
+inline bool witnesses_on_host() {
+#ifdef ZKHIP_AB_HOOKS
+    if (const char* e = getenv("ZKHIP_REC_HOST")) return atoi(e) != 0;
+#endif
+    return g_witnesses_on_host.load() != 0;
+}
 // what ONE inner proof contributes: the host tables' rows of its segment, and its entries of the device work lists
 struct HostSpan {                                           // a slice of the context's pinned upload block
     uint32_t* p = nullptr; size_t n = 0;
@@ -1391,7 +1401,7 @@ static int shard_verifier_prove_impl(zkhip_ctx* ctx, const zkhip_machine_key* ke
     lap("shape + machine");
     // round 6: ROWSUM, QUERY, the fold chains and the layers' pairs are the device's (sv_rowsum_query_kernel, sv_pairs_kernel); ZKHIP_REC_HOST=1 (and a call
     // from inside a lock-step batch, whose launches are merged) keeps the host's walk
-    static const bool host_forced = getenv("ZKHIP_REC_HOST") != nullptr && atoi(getenv("ZKHIP_REC_HOST")) != 0;
+    const bool host_forced = witnesses_on_host();
     const bool on_device = !host_forced && !t_batcher;
     HostTables ht;
     if (!ht.sc.reset((size_t)sc_w << m.height[C_SCALARS]) || !ht.op.reset((size_t)OP_MAIN << m.height[C_OPENED]) || (!on_device && !ht.rs.reset((size_t)RS_MAIN << m.height[C_ROWSUM])) ||
@@ -1664,6 +1674,7 @@ static size_t sv_describe(const uint32_t* program, size_t program_words, int log
 extern "C" {
 
 // the key of a SHAPE: the commitment to the eight chips' preprocessed columns -- no inner proof is involved
+int zkhip_recursion_witnesses_on_host(int enable) { return zk::rec::g_witnesses_on_host.exchange(enable != 0 ? 1 : 0); }
 int zkhip_shard_verifier_setup(zkhip_ctx* ctx, int log_n, uint32_t width, size_t n_queries, int inner_pow_bits, size_t n_public, size_t n_proofs, const zkhip_params* outer,
                                zkhip_machine_key** key, uint32_t vk[8]) {
     return sv_setup(ctx, nullptr, 0, log_n, width, n_queries, inner_pow_bits, n_public, n_proofs, outer, key, vk);

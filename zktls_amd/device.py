@@ -604,83 +604,6 @@ class Context:
         return MachineKey(self, handle, root, [int(c[2]) for c in pre_chips])
 
     # ---- the FRI-fold chip (a first recursion step): trace, key, proof
-    def fri_chip_gen_trace(self, view, log_rows):
-        """-> (device trace [2^log_rows][width] Montgomery, finals [Q][4])"""
-        R, Q, betas, idx, vals, sibs = _fri_view_arrays(view)
-        W = int(self.lib.zkhip_fri_chip_width(R))
-        out = self.alloc(W << log_rows)
-        finals = np.zeros(4 * Q, dtype=np.uint32)
-        check(self.lib.zkhip_fri_chip_gen_trace(self.handle, R, Q, betas.ctypes.data_as(u32p), idx.ctypes.data_as(u32p), vals.ctypes.data_as(u32p),
-                                                sibs.ctypes.data_as(u32p), log_rows, C.c_void_p(out.ptr), W, finals.ctypes.data_as(u32p)))
-        return out, finals.reshape(Q, 4)
-
-    def fri_queries_key(self, view, params=None):
-        """zkhip_fri_queries_key -> (MachineKey, final value): the commitment to the view's OPENINGS table"""
-        params = params or Params(1, 100, 16)
-        R, Q, betas, idx, vals, sibs = _fri_view_arrays(view)
-        handle, root, final = C.c_void_p(), np.zeros(8, dtype=np.uint32), np.zeros(4, dtype=np.uint32)
-        check(self.lib.zkhip_fri_queries_key(self.handle, R, Q, betas.ctypes.data_as(u32p), idx.ctypes.data_as(u32p), vals.ctypes.data_as(u32p),
-                                             sibs.ctypes.data_as(u32p), C.byref(params), C.byref(handle), root.ctypes.data_as(u32p), final.ctypes.data_as(u32p)))
-        return MachineKey(self, handle, root, [0, 12]), final.tolist()
-
-    def prove_fri_queries(self, key, view, params=None):
-        params = params or Params(1, 100, 16)
-        R, Q, betas, idx, vals, sibs = _fri_view_arrays(view)
-        size = self.lib.zkhip_fri_queries_proof_size(R, Q, C.byref(params))
-        buf = np.empty(size, dtype=np.uint8)
-        got = C.c_size_t(0)
-        check(self.lib.zkhip_prove_fri_queries(self.handle, key.handle, R, Q, betas.ctypes.data_as(u32p), idx.ctypes.data_as(u32p), vals.ctypes.data_as(u32p),
-                                               sibs.ctypes.data_as(u32p), C.byref(params), buf.ctypes.data_as(u8p), size, C.byref(got)))
-        return buf[: got.value]
-
-    def fri_layers_gen_paths_trace(self, view, log_rows):
-        R, Q, betas, idx, vals, sibs, roots, paths = _fri_layers_arrays(view)
-        out = self.alloc(360 << log_rows)
-        check(self.lib.zkhip_fri_layers_gen_paths_trace(self.handle, R, Q, betas.ctypes.data_as(u32p), idx.ctypes.data_as(u32p), vals.ctypes.data_as(u32p),
-                                                        sibs.ctypes.data_as(u32p), roots.ctypes.data_as(u32p), paths.ctypes.data_as(u32p), log_rows,
-                                                        C.c_void_p(out.ptr), 360))
-        return out
-
-    def fri_layers_key(self, view, params=None):
-        params = params or Params(1, 100, 16)
-        R, Q, betas, idx, vals, sibs, roots, paths = _fri_layers_arrays(view)
-        handle, root = C.c_void_p(), np.zeros(8, dtype=np.uint32)
-        check(self.lib.zkhip_fri_layers_key(self.handle, R, Q, idx.ctypes.data_as(u32p), vals.ctypes.data_as(u32p), roots.ctypes.data_as(u32p), C.byref(params),
-                                            C.byref(handle), root.ctypes.data_as(u32p)))
-        return MachineKey(self, handle, root, [0, 0, 8, 12])
-
-    def prove_fri_layers(self, key, view, params=None):
-        params = params or Params(1, 100, 16)
-        R, Q, betas, idx, vals, sibs, roots, paths = _fri_layers_arrays(view)
-        size = self.lib.zkhip_fri_layers_proof_size(R, Q, C.byref(params))
-        buf = np.empty(size, dtype=np.uint8)
-        got = C.c_size_t(0)
-        check(self.lib.zkhip_prove_fri_layers(self.handle, key.handle, R, Q, betas.ctypes.data_as(u32p), idx.ctypes.data_as(u32p), vals.ctypes.data_as(u32p),
-                                              sibs.ctypes.data_as(u32p), roots.ctypes.data_as(u32p), paths.ctypes.data_as(u32p), C.byref(params),
-                                              buf.ctypes.data_as(u8p), size, C.byref(got)))
-        return buf[: got.value]
-
-    def fri_transcript_key(self, view, params=None):
-        params = params or Params(1, 100, 16)
-        R, Q, betas, idx, vals, sibs, roots, paths = _fri_layers_arrays(view)
-        handle, root = C.c_void_p(), np.zeros(8, dtype=np.uint32)
-        check(self.lib.zkhip_fri_transcript_key(self.handle, R, Q, idx.ctypes.data_as(u32p), vals.ctypes.data_as(u32p), roots.ctypes.data_as(u32p),
-                                                C.byref(params), C.byref(handle), root.ctypes.data_as(u32p)))
-        return MachineKey(self, handle, root, [0, 0, 8, 12])
-
-    def prove_fri_transcript(self, key, view, capacity, params=None):
-        """zkhip_prove_fri_transcript: the wired machine with the FRI transcript in-circuit (capacity: zkhip_fri_view_transcript)"""
-        params = params or Params(1, 100, 16)
-        R, Q, betas, idx, vals, sibs, roots, paths = _fri_layers_arrays(view)
-        cap8 = np.ascontiguousarray(np.array(capacity, dtype=np.uint32))
-        size = self.lib.zkhip_fri_transcript_proof_size(R, Q, C.byref(params))
-        buf = np.empty(size, dtype=np.uint8)
-        got = C.c_size_t(0)
-        check(self.lib.zkhip_prove_fri_transcript(self.handle, key.handle, R, Q, betas.ctypes.data_as(u32p), idx.ctypes.data_as(u32p), vals.ctypes.data_as(u32p),
-                                                  sibs.ctypes.data_as(u32p), roots.ctypes.data_as(u32p), paths.ctypes.data_as(u32p), cap8.ctypes.data_as(u32p),
-                                                  C.byref(params), buf.ctypes.data_as(u8p), size, C.byref(got)))
-        return buf[: got.value]
-
     def fri_indices_key(self, view, inner_pow_bits, params=None):
         """zkhip_fri_indices_key: (query number, reduced opening), the layer roots, the SAMPLES chip's fixed columns -- no index"""
         params = params or Params(1, 100, 16)
@@ -1263,6 +1186,11 @@ class Sp1ShapedShard:
         return InnerMachine(chips, key_root, params.num_queries, params.pow_bits, self.n_public)
 
 
+def recursion_witnesses_on_host(enable):
+    """zkhip_recursion_witnesses_on_host: 1 = the recursion machines fill their per-query tables on host threads (rounds 4 - 5), 0 = device kernels; returns the previous setting"""
+    return int(_lib.load().zkhip_recursion_witnesses_on_host(1 if enable else 0))
+
+
 def set_lockstep(max_batch, lanes=0):
     """zkhip_set_lockstep: members per lock-step batch of small transcripts (0 / 1 = off), batches in flight per device (0 = keep)"""
     _lib.load().zkhip_set_lockstep(int(max_batch), int(lanes))
@@ -1545,31 +1473,8 @@ def verify_fri_indices(proof, final, capacity, layers, n_queries, inner_pow_bits
     return rc, reason.value
 
 
-def verify_fri_transcript(proof, final, capacity, layers, n_queries, vk, params=None):
-    """zkhip_verify_fri_transcript: the verifier is handed no challenge -- the final value, the challenger's capacity, the key"""
-    params = params or Params(1, 100, 16)
-    lib = _lib.load()
-    pr = np.ascontiguousarray(proof, dtype=np.uint8)
-    f = np.ascontiguousarray(np.array(final, dtype=np.uint32))
-    c8 = np.ascontiguousarray(np.array(capacity, dtype=np.uint32))
-    k = np.ascontiguousarray(np.array(vk, dtype=np.uint32))
-    reason = C.c_int(0)
-    rc = lib.zkhip_verify_fri_transcript(pr.ctypes.data_as(u8p), pr.size, layers, n_queries, f.ctypes.data_as(u32p), c8.ctypes.data_as(u32p),
-                                         k.ctypes.data_as(u32p), C.byref(params), C.byref(reason))
-    return rc, reason.value
 
 
-def verify_fri_layers(proof, view_betas, final, n_queries, vk, params=None):
-    params = params or Params(1, 100, 16)
-    lib = _lib.load()
-    pr = np.ascontiguousarray(proof, dtype=np.uint8)
-    b = np.ascontiguousarray(np.array(view_betas, dtype=np.uint32).reshape(-1))
-    f = np.ascontiguousarray(np.array(final, dtype=np.uint32))
-    k = np.ascontiguousarray(np.array(vk, dtype=np.uint32))
-    reason = C.c_int(0)
-    rc = lib.zkhip_verify_fri_layers(pr.ctypes.data_as(u8p), pr.size, b.size // 4, n_queries, b.ctypes.data_as(u32p), f.ctypes.data_as(u32p),
-                                     k.ctypes.data_as(u32p), C.byref(params), C.byref(reason))
-    return rc, reason.value
 
 
 def _fri_view_arrays(view):
@@ -1589,18 +1494,6 @@ def fri_chip_air(layers):
     return out
 
 
-def verify_fri_queries(proof, view_betas, final, n_queries, vk, params=None):
-    """zkhip_verify_fri_queries (host): the machine proof against the challenges, the final value and the key's root"""
-    params = params or Params(1, 100, 16)
-    lib = _lib.load()
-    pr = np.ascontiguousarray(proof, dtype=np.uint8)
-    b = np.ascontiguousarray(np.array(view_betas, dtype=np.uint32).reshape(-1))
-    f = np.ascontiguousarray(np.array(final, dtype=np.uint32))
-    k = np.ascontiguousarray(np.array(vk, dtype=np.uint32))
-    reason = C.c_int(0)
-    rc = lib.zkhip_verify_fri_queries(pr.ctypes.data_as(u8p), pr.size, b.size // 4, n_queries, b.ctypes.data_as(u32p), f.ctypes.data_as(u32p),
-                                      k.ctypes.data_as(u32p), C.byref(params), C.byref(reason))
-    return rc, reason.value
 
 
 class MachineKey:

@@ -11,6 +11,8 @@
 #include <stdexcept>
 
 #include "../../include/zkhip.h"
+#include "../../include/zkhip_chips.h"
+#include "../../include/zkhip_hal.h"
 
 namespace zktls {
 

@@ -47,6 +47,8 @@
 #include <vector>
 
 #include "../../include/zkhip.h"
+#include "../../include/zkhip_chips.h"
+#include "../../include/zkhip_hal.h"
 #include "../host/guest_prover_hip.hpp"
 
 namespace {
