@@ -1,5 +1,6 @@
 #include "oracle.h"
 #include "zkhip.h"
+#include "zkhip_chips.h"
 #include <stdio.h>
 #include <stdlib.h>
 int main(void) {

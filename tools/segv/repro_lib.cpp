@@ -11,6 +11,7 @@
 #include <vector>
 
 #include "../../include/zkhip.h"
+#include "../../include/zkhip_chips.h"
 
 int main(int argc, char** argv) {
     if (argc < 3) { std::fprintf(stderr, "usage: %s a|b|c|d|e <calls>\n", argv[0]); return 1; }

@@ -5,6 +5,7 @@
 #include <cstdlib>
 #include <vector>
 #include "../../include/zkhip.h"
+#include "../../include/zkhip_chips.h"
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { std::printf("%s -> %s\n", #x, hipGetErrorString(e_)); std::exit(1); } } while (0)
 static float time_pass(zkhip_ctx* ctx, const uint32_t* src, uint32_t* dst, int which) {
     hipStream_t st = (hipStream_t)zkhip_ctx_stream(ctx);
