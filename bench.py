@@ -1010,7 +1010,7 @@ def main():
             except Exception:
                 dt = dt_simd
         cpu = {"value": round((width << cl) / dt, 1), "unit": "trace-cells/s", "cores": used, "kind": "port",
-               "sample": "one 2^%d x %d shard proof (same AIR, %s), %.1f s, scalar C oracle + OpenMP on %d threads (%d host CPUs visible, CPU quota of the container %s cores)" % (
+               "sample": "one 2^%d x %d shard proof (same AIR, %s), %.1f s, C oracle with its scalar Poseidon2 (ORC_NO_SIMD=1, a child process) + OpenMP on %d threads (%d host CPUs visible, CPU quota of the container %s cores)" % (
                    cl, width, "log_blowup 1, 100 queries, 16 PoW bits" if args.shape == "sp1" else "RISC-Zero-like shape", dt, used, cores,
                    ("%g" % cores_ok) if cores_ok else "none")}
         if simd_on:
