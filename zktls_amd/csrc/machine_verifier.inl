@@ -1066,6 +1066,54 @@ inline Ext recombine4(const Ext* four) {            // sum_k X^k four[k]
 }
 struct ScVals { Ext zn, invf, invt, self, sell, selt, znx, q0, q1, quo, acc, cum, totin, toto; Ext qz[8]; };
 
+// ---- the transcripts of SEVERAL proofs side by side (round 6): a transcript is one serial sponge chain (NT permutations), so the vector unit is used ACROSS
+// the proofs -- sixteen chains per AVX-512 permutation (p2_x16.h), the way the host verifiers walk sixteen queries.  What a chain leaves behind per proof:
+struct Transcript { std::vector<Ext> chal, chal2; std::vector<uint32_t> samples; bool done = false; };
+struct ProofPos { size_t o_troot, o_proot, o_cum, o_qroot, o_stream, o_lroots, o_final, o_wit, o_queries, per_query, words; };
+inline ProofPos proof_pos(const MShape& sh) {
+    ProofPos q{};
+    size_t pos = (size_t)sh.HL + 2;
+    q.o_troot = pos; pos += 8; q.o_proot = pos; pos += 8; q.o_cum = pos; pos += 4 * (size_t)sh.C; q.o_qroot = pos; pos += 8; q.o_stream = pos; pos += 4 * (size_t)sh.NV;
+    q.o_lroots = pos; pos += 8 * (size_t)sh.R; q.o_final = pos; pos += 4; q.o_wit = pos; pos += 1; q.o_queries = pos;
+    size_t perq = 0;
+    for (int t = 0; t < N_TREES; t++) if (sh.has_tree[t]) { for (int c : sh.tree_chips[t]) perq += (*sh.tree_w[t])[(size_t)c]; perq += 8 * (size_t)sh.tree_hs[t][0]; }
+    for (int l = 0; l < sh.R; l++) perq += 4 + 8 * (size_t)(sh.H - 1 - l);
+    q.per_query = perq; q.words = q.o_queries + (size_t)sh.Q * perq;
+    return q;
+}
+// n <= 16 proofs (words ws[i], public values pubss[i], proof numbers ps[i]); writes every transcript row's input state / bit / KP where fill_proof would
+// (stride p2_stride rows per proof) and the challenges into out[i].  Only called when p2x16_available(); every ws[i] has the machine's length.
+void walk_transcripts_x16(const MShape& sh, int n, const uint32_t* const* ws, const uint32_t* const* pubss, const int* ps, size_t p2_stride, HostTabs& ht, Transcript* const* out) {
+    const ProofPos pp = proof_pos(sh);
+    auto src_val = [&](const Src& s, const uint32_t* w, const uint32_t* pubs) -> uint32_t {
+        switch (s.kind) {
+            case S_CONST: return s.a; case S_TROOT: return w[pp.o_troot + s.a]; case S_PUB: return pubs[s.a] % P; case S_PROOT: return w[pp.o_proot + s.a];
+            case S_CUM: return w[pp.o_cum + 4 * s.a + s.b]; case S_QROOT: return w[pp.o_qroot + s.a]; case S_OP: return w[pp.o_stream + s.a];
+            case S_LROOT: return w[pp.o_lroots + 8 * s.a + s.b]; case S_FIN: return w[pp.o_final + s.a]; default: return w[pp.o_wit];
+        }
+    };
+    for (int i = 0; i < n; i++) { out[i]->chal.assign((size_t)sh.NT, ext_zero()); out[i]->chal2.assign((size_t)sh.NT, ext_zero()); out[i]->samples.assign(8 * (size_t)sh.NS, 0u); }
+    uint32_t st[16][16];
+    for (int e = 0; e < 16; e++) for (int j = 0; j < 16; j++) st[e][j] = 0u;
+    for (int T = 0; T < sh.NT; T++) {
+        if (T <= sh.TP) {
+            const std::vector<Src>& pl = sh.plan[(size_t)T];
+            for (size_t e = 0; e < pl.size(); e++) for (int i = 0; i < 16; i++) st[e][i] = to_monty(src_val(pl[e], ws[i < n ? i : 0], pubss[i < n ? i : 0]));
+        }
+        for (int i = 0; i < n; i++) {
+            uint32_t* tin = ht.p2_in.data() + 16 * ((size_t)ps[i] * p2_stride + (size_t)T);
+            for (int e = 0; e < 16; e++) tin[e] = from_monty(st[e][i]);
+            ht.p2_bit.data()[(size_t)ps[i] * p2_stride + (size_t)T] = 0; ht.p2_kp.data()[(size_t)ps[i] * p2_stride + (size_t)T] = 0;
+        }
+        p2x16_permute(st);
+        for (int i = 0; i < n; i++) {
+            out[i]->chal[(size_t)T] = Ext{{st[7][i], st[6][i], st[5][i], st[4][i]}}; out[i]->chal2[(size_t)T] = Ext{{st[3][i], st[2][i], st[1][i], st[0][i]}};
+            if (T >= sh.TP) for (int j = 0; j < 8; j++) out[i]->samples[8 * (size_t)(T - sh.TP) + (size_t)j] = from_monty(st[7 - j][i]);
+        }
+    }
+    for (int i = 0; i < n; i++) out[i]->done = true;
+}
+
 // ---- the per-query part of a proof's tables ON THE DEVICE (round 6).  The plan is a function of the machine's shape alone: the ROWSUM
 // rows of one query (where each of a row's eight words sits in the proof relative to the query's first word, which power a segment's sum is weighted with,
 // where Horner restarts), the commitments' chains (p2chip.h MrecTreePlan) and the layers at which a height joins the fold chain.  What is left on the
@@ -1151,7 +1199,8 @@ WitPlan build_wit_plan(const MShape& sh) {
     return pl;
 }
 
-int fill_proof(const Machine& m, int p, const uint8_t* inner, size_t inner_len, const uint32_t* pubs, HostTabs& ht, const WitPlan* dplan = nullptr, DevVals* dvals = nullptr) {
+int fill_proof(const Machine& m, int p, const uint8_t* inner, size_t inner_len, const uint32_t* pubs, HostTabs& ht, const WitPlan* dplan = nullptr, DevVals* dvals = nullptr,
+               const Transcript* pre = nullptr) {
     const MShape& sh = m.sh;
     const bool on_device = dplan != nullptr;               // the per-query tables (ROWSUM, QUERY, FOLD, the queries' Poseidon2 rows) are the device's: see top_finish
     const int C = sh.C, Q = sh.Q, R = sh.R, H = sh.H;
@@ -1200,7 +1249,8 @@ int fill_proof(const Machine& m, int p, const uint8_t* inner, size_t inner_len, 
     };
     std::vector<Ext> chal((size_t)sh.NT), chal2((size_t)sh.NT);
     wt.samples.assign(8 * (size_t)sh.NS, 0u);
-    {
+    if (pre && pre->done) { chal = pre->chal; chal2 = pre->chal2; wt.samples = pre->samples; }       // (walked beside other proofs' transcripts: walk_transcripts_x16)
+    else {
         uint32_t st[16];
         for (int j = 0; j < 16; j++) st[j] = 0u;
         for (int T = 0; T < sh.NT; T++) {
@@ -1936,6 +1986,7 @@ struct TopSession {
     std::vector<DevVals> vals;
     std::vector<const uint8_t*> ptrs;
     size_t proof_len = 0;
+    std::vector<Transcript> transcripts;          // filled by top_transcripts (all proofs at hand: sixteen chains per permutation); empty / not done: fill_proof walks its own
 };
 inline bool rec_host_forced() { return zk::rec::witnesses_on_host(); }      // (zkhip_recursion_witnesses_on_host: shard_verifier.inl)
 int top_begin(const zkhip_machine_desc* inner, size_t n_proofs, size_t n_public, TopSession& s) {
@@ -1966,11 +2017,36 @@ int top_fill(TopSession& s, int p, const uint8_t* proof, size_t proof_len, const
         if (s.device) {
             if (s.proof_len == 0) s.proof_len = proof_len;                 // (every proof of one machine has one length: fill_proof checks it)
             s.ptrs[(size_t)p] = proof;
-            return fill_proof(*s.mp, p, proof, proof_len, pubs, s.ht, &s.plan, &s.vals[(size_t)p]);
+            return fill_proof(*s.mp, p, proof, proof_len, pubs, s.ht, &s.plan, &s.vals[(size_t)p], s.transcripts.empty() ? nullptr : &s.transcripts[(size_t)p]);
         }
-        return fill_proof(*s.mp, p, proof, proof_len, pubs, s.ht);
+        return fill_proof(*s.mp, p, proof, proof_len, pubs, s.ht, nullptr, nullptr, s.transcripts.empty() ? nullptr : &s.transcripts[(size_t)p]);
     } catch (const std::bad_alloc&) { return fail(ZKHIP_ERR_NOMEM, "prove_machine_verifier: out of host memory"); }
       catch (const std::exception& e) { return fail(ZKHIP_ERR_INTERNAL, std::string("prove_machine_verifier: ") + e.what()); }
+}
+// every proof at hand before the fills start: their transcripts in groups of sixteen, one AVX-512 permutation per row of the group (a few threads when there are
+// several groups).  Proofs of another length are left to fill_proof, which refuses them.
+void top_transcripts(TopSession& s, const uint8_t* const* proofs, const size_t* proof_lens, const uint32_t* public_values, size_t n_public) {
+    const MShape& sh = s.mp->sh;
+    if (sh.NP < 8 || !p2x16_available()) return;               // (fewer proofs than half the lanes: a thread per proof walks its own chain sooner -- 2.2 against 2.8 ms for the tree's four joins)
+    const ProofPos pp = proof_pos(sh);
+    s.transcripts.assign((size_t)sh.NP, Transcript{});
+    std::vector<int> good;
+    for (int p = 0; p < sh.NP; p++) if (proofs[p] && proof_lens[p] == pp.words * 4) good.push_back(p);
+    const size_t stride = s.device ? (size_t)sh.NT : sh.p2_rows;
+    const int ng = ((int)good.size() + 15) / 16;
+    auto group = [&](int g) {
+        const uint32_t* ws[16]; const uint32_t* pubss[16]; int ps[16]; Transcript* out[16];
+        int n = 0;
+        for (int i = 16 * g; i < (int)good.size() && n < 16; i++, n++) {
+            const int p = good[(size_t)i];
+            ws[n] = (const uint32_t*)proofs[p]; pubss[n] = public_values + (size_t)p * n_public; ps[n] = p; out[n] = &s.transcripts[(size_t)p];
+        }
+        try { if (n) walk_transcripts_x16(sh, n, ws, pubss, ps, stride, s.ht, out); } catch (...) { for (int i = 0; i < n; i++) out[i]->done = false; }
+    };
+    if (ng <= 1) { if (ng) group(0); return; }
+    HostPool pool(ng < 8 ? ng : 8);
+    for (int g = 0; g < ng; g++) pool.submit([&group, g] { group(g); });
+    pool.wait();
 }
 template <class Lap>
 int top_finish(zkhip_ctx* ctx, const zkhip_machine_key* key, TopSession& s, const uint32_t* public_values, size_t n_public, const zkhip_params* outer, uint8_t* proof, size_t cap,
@@ -2156,6 +2232,8 @@ int m_prove_machine_verifier(zkhip_ctx* ctx, const zkhip_machine_key* key, const
     TopSession s;
     ZK_TRY(top_begin(inner, n_proofs, n_public, s));
     const int NP = s.mp->sh.NP;
+    top_transcripts(s, proofs, proof_lens, public_values, n_public);
+    lap("host: transcripts (sixteen per permutation)");
     // the inner proofs side by side: each one's tables, which is its verification
     {
         std::vector<int> rcs((size_t)NP, ZKHIP_OK);

@@ -920,11 +920,50 @@ struct HostTables {
     std::vector<const uint32_t*> want_roots;                // per chain: where it must end (canonical words; owned by the witnesses)
     // (desc / data / chain_in / trows / want_roots hold a fixed slice per proof)
 };
+// round 6: the transcripts of up to sixteen proofs side by side, one AVX-512 permutation per sponge row of the group (p2_x16.h) -- a transcript is a serial chain, so
+// the vector unit is used ACROSS the proofs.  What a chain leaves behind per proof:
+struct SvTranscript { std::vector<uint32_t> chain_in, samples; std::vector<Ext> chal; bool done = false; };
+inline void sv_blocks(const Shape& sh, const uint32_t* pw, const uint32_t* public_values, std::vector<std::array<uint32_t, 8>>& blocks) {
+    // observed words per absorbing row (canonical; absent ones zero): fill_one's section (b)
+    const int W = sh.W, R = sh.R;
+    const size_t n_public = (size_t)sh.NPUB;
+    const size_t o_troot = sh.air ? 20 : 8, o_qroot = o_troot + 8, o_loc = o_qroot + 8, o_qz = o_loc + 8 * (size_t)W, o_lroots = o_qz + 32, o_final = o_lroots + 8 * (size_t)R, o_wit = o_final + 4;
+    blocks.assign((size_t)sh.NTS, std::array<uint32_t, 8>{});
+    std::vector<uint32_t> seq0(sh.head, sh.head + sh.HL);
+    seq0.insert(seq0.end(), pw + o_troot, pw + o_troot + 8);
+    for (size_t i = 0; i < n_public; i++) seq0.push_back(public_values[i] % P);
+    for (int T = 0; T < sh.f0 + (sh.r0 ? 1 : 0); T++) for (int j = 0; j < 8 && 8 * (size_t)T + j < seq0.size(); j++) blocks[(size_t)T][j] = seq0[8 * (size_t)T + j];
+    for (int j = 0; j < 8; j++) blocks[(size_t)sh.TQ][j] = pw[o_qroot + j];
+    for (int i = 0; i < W + 4; i++) for (int j = 0; j < 8; j++) blocks[(size_t)(sh.TO0 + i)][j] = pw[o_loc + 8 * (size_t)i + j];
+    for (int l = 0; l < R; l++) for (int j = 0; j < 8; j++) blocks[(size_t)(sh.TL0 + l)][j] = pw[o_lroots + 8 * (size_t)l + j];
+    for (int j = 0; j < 4; j++) blocks[(size_t)sh.TP][j] = pw[o_final + j];
+    blocks[(size_t)sh.TP][4] = pw[o_wit];
+}
+void sv_walk_transcripts_x16(const Shape& sh, int n, const uint32_t* const* pws, const uint32_t* const* pubss, SvTranscript* const* out) {
+    std::vector<std::array<uint32_t, 8>> blocks[16];
+    for (int i = 0; i < n; i++) {
+        sv_blocks(sh, pws[i], pubss[i], blocks[i]);
+        out[i]->chain_in.assign(16 * (size_t)sh.NT, 0u); out[i]->samples.assign(8 * (size_t)sh.NS, 0u); out[i]->chal.assign((size_t)sh.NT, ext_zero());
+    }
+    uint32_t st[16][16];
+    for (int e = 0; e < 16; e++) for (int j = 0; j < 16; j++) st[e][j] = 0u;
+    for (int T = 0; T < sh.NT; T++) {
+        const int k = sh.absorbed(T);
+        for (int e = 0; e < k; e++) for (int i = 0; i < 16; i++) st[e][i] = to_monty(blocks[i < n ? i : 0][(size_t)T][(size_t)e]);
+        for (int i = 0; i < n; i++) for (int e = 0; e < 16; e++) out[i]->chain_in[16 * (size_t)T + (size_t)e] = from_monty(st[e][i]);
+        p2x16_permute(st);
+        for (int i = 0; i < n; i++) {
+            out[i]->chal[(size_t)T] = Ext{{st[7][i], st[6][i], st[5][i], st[4][i]}};
+            if (T >= sh.TP) for (int j = 0; j < 8; j++) out[i]->samples[8 * (size_t)(T - sh.TP) + (size_t)j] = from_monty(st[7 - j][i]);
+        }
+    }
+    for (int i = 0; i < n; i++) out[i]->done = true;
+}
 // round 6 (device mode): what the device's per-query kernels read of ONE proof -- [indices Q][betas 4 R canonical][fa][zeta][znx][yl][yn][yq][offn][offq] (extension
 // elements in Montgomery form)
 inline size_t sv_vals_words(const Shape& sh) { return (size_t)sh.Q + 4 * (size_t)sh.R + 32; }
 int fill_one(const Shape& sh, const Machine& m, int p, const uint8_t* inner, size_t inner_len, const uint32_t* public_values, const zkhip_params* inner_prm, Witness& wt,
-             std::vector<uint32_t>& words, HostTables& ht, Ext* fa_out, const uint32_t* program, size_t program_words, uint32_t* dev_vals = nullptr) {
+             std::vector<uint32_t>& words, HostTables& ht, Ext* fa_out, const uint32_t* program, size_t program_words, uint32_t* dev_vals = nullptr, const SvTranscript* pre = nullptr) {
     const int R = sh.R, H = sh.H, Q = sh.Q, W = sh.W;
     const int log_n = sh.n;
     const uint32_t width = (uint32_t)W;
@@ -961,7 +1000,16 @@ int fill_one(const Shape& sh, const Machine& m, int p, const uint8_t* inner, siz
     // (b) the transcript's sponge chain on the host (NT permutations): the input state of every row, the challenges, the sampled words
     std::vector<uint32_t> chain_in(16 * (size_t)sh.NT), samples(8 * (size_t)sh.NS);
     std::vector<Ext> chal((size_t)sh.NT);
-    {
+    if (pre && pre->done) {                                                // (walked beside other proofs' transcripts: sv_walk_transcripts_x16)
+        chain_in = pre->chain_in; samples = pre->samples; chal = pre->chal;
+        if (on_device) {
+            wt.betas.resize(4 * (size_t)R);
+            for (int l = 0; l < R; l++) for (int j = 0; j < 4; j++) wt.betas[4 * (size_t)l + j] = from_monty(chal[(size_t)(sh.TL0 + l)].c[j]);
+            std::memcpy(wt.lroots.data(), pw + wt.o_lroots, 32 * (size_t)R);
+        } else
+        for (int l = 0; l < R; l++) for (int j = 0; j < 4; j++)
+            if (from_monty(chal[(size_t)(sh.TL0 + l)].c[j]) != wt.betas[4 * (size_t)l + j]) return fail(ZKHIP_ERR_INTERNAL, "prove_shard_verifier: the sponge rows do not reproduce the verifier's challenges");
+    } else {
         std::vector<std::array<uint32_t, 8>> blocks((size_t)sh.NTS);      // observed words per absorbing row (canonical; absent ones zero)
         std::vector<uint32_t> seq0(sh.head, sh.head + sh.HL);
         seq0.insert(seq0.end(), pw + wt.o_troot, pw + wt.o_troot + 8);
@@ -1429,12 +1477,31 @@ static int shard_verifier_prove_impl(zkhip_ctx* ctx, const zkhip_machine_key* ke
             ht.chain_in = HostSpan{ht.data.p + n_data, n_cin}; ht.trows = HostSpan{ht.chain_in.p + n_cin, n_trows};
         }
         uint32_t* const vals_host = on_device ? ht.trows.p + ht.trows.size() : nullptr;      // (device mode: the per-proof values behind the lists, same DMA)
+        std::vector<SvTranscript> pres;
+        if (NP >= 8 && p2x16_available() && !t_batcher) {           // (fewer proofs than half the lanes: a thread per proof walks its own chain sooner)
+            // every proof's transcript before the fills: sixteen chains per permutation, a few threads when there are several groups
+            pres.assign((size_t)NP, SvTranscript{});
+            const int ng = (NP + 15) / 16;
+            auto group = [&](int g) {
+                const uint32_t* pws[16]; const uint32_t* pubss[16]; SvTranscript* outp[16];
+                int n = 0;
+                for (int p = 16 * g; p < NP && n < 16; p++, n++) { pws[n] = (const uint32_t*)inner[p]; pubss[n] = public_values + (size_t)p * n_public; outp[n] = &pres[(size_t)p]; }
+                try { sv_walk_transcripts_x16(sh, n, pws, pubss, outp); } catch (...) { for (int i = 0; i < n; i++) outp[i]->done = false; }
+            };
+            // (lengths were checked above: every proof has the shape's length, and make_shape / the first fill check that it IS the shape's)
+            const size_t want_words = (size_t)(sh.air ? 20 : 8) + 8 + 8 + 8 * (size_t)sh.W + 32 + 8 * (size_t)R + 4 + 1;
+            if (inner_len[0] / 4 > want_words) {
+                if (ng == 1) group(0);
+                else { HostPool tp(ng < 8 ? ng : 8); for (int g = 0; g < ng; g++) tp.submit([&group, g] { group(g); }); tp.wait(); }
+            } else pres.clear();
+        }
+        lap("host: transcripts (sixteen per permutation)");
         std::vector<int> rcs((size_t)NP, ZKHIP_OK);
         std::vector<std::string> msgs((size_t)NP);
         auto one = [&](int p) {
             t_query_threads_cap = NP >= 16 ? 1 : 16 / NP;      // the proofs are filled side by side: a proof's host pass starts few threads of its own
             rcs[(size_t)p] = fill_one(sh, m, p, inner[p], inner_len[p], public_values + (size_t)p * n_public, inner_prm, wts[(size_t)p], words[(size_t)p], ht, &fas[(size_t)p], program, program_words,
-                                      on_device ? vals_host + (size_t)p * sv_vals_words(sh) : nullptr);
+                                      on_device ? vals_host + (size_t)p * sv_vals_words(sh) : nullptr, pres.empty() ? nullptr : &pres[(size_t)p]);
             if (rcs[(size_t)p] != ZKHIP_OK) msgs[(size_t)p] = zkhip_last_error();
             t_query_threads_cap = 0;
         };
