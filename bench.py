@@ -976,6 +976,55 @@ def main():
                      "core_plus_compress_ms": round(t_cc * 1e3, 1), "compressed_blob_bytes": len(b_cc), "compressed_blob_verified_on_host": bool(ok_blob),
                      "compressed_blob_host_verify_ms": round(t_ev * 1e3, 2),
                      "note": "synthetic AIR in SP1's shard shape; no executor, no shrink / wrap / Groth16 (out of scope): not comparable with the reference's end-to-end seconds"}
+        # ... and the same execution in SP1's shard STRUCTURE: 22 shards of the six-chip keyed machine of the `multichip` section through the same plug
+        # point -- setup (the preprocessed columns committed once), every shard ONE version-11 proof checked against the key (sp1.rs:113-120), then the compress stage in
+        # machine mode behind the same call; the compressed blob checked on the host from (plan, input, ELF, vk) alone
+        try:
+            from zktls_amd.device import SP1_SHAPED_SPEC, SP1_SHAPED_PRE
+
+            class _MPlan(C_.Structure):
+                _fields_ = [("n_chips", C_.c_int32), ("log_ns", C_.POINTER(C_.c_int32)), ("widths", C_.POINTER(C_.c_uint32)), ("pairs", C_.POINTER(C_.c_uint32)),
+                            ("partners", C_.POINTER(C_.c_int32)), ("pre_widths", C_.POINTER(C_.c_uint32)), ("shards", C_.c_uint32), ("num_queries", C_.c_int32),
+                            ("pow_bits", C_.c_int32), ("in_flight", C_.c_uint32)]
+            nch_, prew_ = len(SP1_SHAPED_SPEC), dict(SP1_SHAPED_PRE)
+            keep_ = ((C_.c_int32 * nch_)(*[c_[0] for c_ in SP1_SHAPED_SPEC]), (C_.c_uint32 * nch_)(*[c_[1] for c_ in SP1_SHAPED_SPEC]), (C_.c_uint32 * nch_)(*[c_[2] for c_ in SP1_SHAPED_SPEC]),
+                     (C_.c_int32 * nch_)(*[c_[3] for c_ in SP1_SHAPED_SPEC]), (C_.c_uint32 * nch_)(*[prew_.get(i_, 0) for i_ in range(nch_)]))
+            mplan_ = _MPlan(nch_, keep_[0], keep_[1], keep_[2], keep_[3], keep_[4], 22, prm.num_queries, prm.pow_bits, 0)
+            ML.zktls_guest_prove_machine.argtypes = [C_.c_int, C_.c_int, C_.POINTER(_MPlan), C_.c_int, C_.c_int, C_.c_char_p, C_.c_size_t, C_.c_char_p, C_.c_size_t, u8pp_, szp_, u8pp_, szp_,
+                                                     C_.c_char_p, C_.c_char_p, C_.c_size_t]
+            ML.zktls_verify_machine_blob.argtypes = [C_.c_char_p, C_.c_size_t, C_.POINTER(_MPlan), C_.c_char_p, C_.c_size_t, C_.c_char_p, C_.c_size_t, C_.c_char_p, C_.POINTER(C_.c_int)]
+
+            def _mrun(compress_):
+                out_, outn_, pr_, prn_ = C_.POINTER(C_.c_uint8)(), C_.c_size_t(), C_.POINTER(C_.c_uint8)(), C_.c_size_t()
+                err_, vk_ = C_.create_string_buffer(512), C_.create_string_buffer(64)
+                t0_ = time.perf_counter()
+                rc_ = ML.zktls_guest_prove_machine(local_rank, 2, C_.byref(mplan_), compress_, 1, ecbor, len(ecbor), eelf, len(eelf), C_.byref(out_), C_.byref(outn_), C_.byref(pr_),
+                                                   C_.byref(prn_), vk_, err_, 512)
+                dt_ = time.perf_counter() - t0_
+                if rc_ != 0:
+                    raise RuntimeError("host mirror, machine shards: %s" % err_.value.decode("utf-8", "replace"))
+                blob_ = C_.string_at(pr_, prn_.value)
+                ML.zktls_free(out_)
+                ML.zktls_free(pr_)
+                return dt_, blob_, vk_.raw
+            _mrun(0)
+            tm_core, bm_core, mvk_ = min((_mrun(0) for _ in range(2)), key=lambda x_: x_[0])
+            _mrun(1)
+            tm_cc, bm_cc, mvk2_ = min((_mrun(1) for _ in range(2)), key=lambda x_: x_[0])
+            t0_ = time.perf_counter()
+            okm_ = mvk_ == mvk2_ and ML.zktls_verify_machine_blob(bm_cc, len(bm_cc), C_.byref(mplan_), ecbor, len(ecbor), eelf, len(eelf), mvk_, None) == 0
+            tm_ev = time.perf_counter() - t0_
+            okm_ = okm_ and ML.zktls_verify_machine_blob(bm_cc, len(bm_cc), C_.byref(mplan_), ecbor + b"!", len(ecbor) + 1, eelf, len(eelf), mvk_, None) == -2
+            mcells_ = sum(c_[1] << c_[0] for c_ in SP1_SHAPED_SPEC)
+            execution["multichip"] = {
+                "workload": "the same ONE call for 22 shards in SP1's shard structure: six chips %s (LogUp pairs in-table and ACROSS the two 2^20-row tables, 32 preprocessed columns), setup + every shard one keyed-machine proof (version 11) checked against the key, then the compress stage in machine mode (22 shard proofs -> ONE proof)" % (
+                    ",".join("%dx%d" % (c_[0], c_[1]) for c_ in SP1_SHAPED_SPEC)),
+                "core_ms": round(tm_core * 1e3, 1), "core_ms_per_shard": round(tm_core * 1e3 / 22, 2), "core_trace_cells_per_s": round(22 * mcells_ / tm_core, 1), "core_blob_bytes": len(bm_core),
+                "core_plus_compress_ms": round(tm_cc * 1e3, 1), "compressed_blob_bytes": len(bm_cc), "compressed_blob_verified_on_host_and_another_request_refused": bool(okm_),
+                "compressed_blob_host_verify_ms": round(tm_ev * 1e3, 2)}
+            ML.zktls_release_cached()
+        except Exception as e_:
+            execution["multichip"] = {"error": repr(e_)}
 
     # ---- CPU baseline: the oracle on the host cores, bounded sample of the same workload
     cpu = None

@@ -172,20 +172,22 @@ def sp1_shaped_spec(spec):
     return inter
 
 
-def sp1_shaped_machine(spec, seed=1, shard=0, pre=(), n_public=3, key_shard=9999):
+def sp1_shaped_machine(spec, seed=1, shard=0, pre=(), n_public=3, key_shard=9999, key_seed=None):
     """SP1's shard structure as a KEYED machine (proof version 11): chips of mixed heights, each under the synthetic AIR (as a constraint program)
     on traces of orc_gen_trace_logup / _cross, in-table LogUp pairs and a cross-table bus between two chips of one height, and preprocessed
     leading columns on the chips listed in `pre` ((chip, columns), ...).  The chip streams are seed + 100 shard + chip; the preprocessed
     columns come from the stream of shard `key_shard`, so every shard is proven against ONE key (zktls_amd.device.Sp1ShapedShard does the same
-    on the device).  -> (main traces, preprocessed traces or None, programs, tables, public values)"""
+    on the device).  key_seed: the preprocessed columns' stream when it is not the shards' (the host mirror derives it from the guest program alone: setup(elf),
+    sp1.rs:113).  -> (main traces, preprocessed traces or None, programs, tables, public values)"""
     inter = sp1_shaped_spec(spec)
     pw = dict(pre)
 
     def gen(c, sh):
         ln, w, pairs, partner = spec[c]
+        sd = key_seed if (sh == key_shard and key_seed is not None) else seed
         if partner < 0:
-            return O.gen_trace_logup(seed, 100 * sh + c, ln, w, pairs)
-        return O.gen_trace_logup_cross(seed, 100 * sh + c, 100 * sh + partner, ln, w, spec[partner][1], pairs)
+            return O.gen_trace_logup(sd, 100 * sh + c, ln, w, pairs)
+        return O.gen_trace_logup_cross(sd, 100 * sh + c, 100 * sh + partner, ln, w, spec[partner][1], pairs)
     traces = [gen(c, shard) for c in range(len(spec))]
     progs = [O.air_synthetic(w, n_public) for _, w, _, _ in spec]
     tabs = [O.interaction_table(it) if it else None for it in inter]

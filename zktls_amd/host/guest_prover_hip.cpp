@@ -314,6 +314,284 @@ static std::vector<uint8_t> compress_shard_proofs(const std::vector<int>& device
     return pack_shard_proofs(entries, BATCH_FLAG_SYNTHETIC | BATCH_FLAG_COMPRESSED | flags_extra);
 }
 
+// ---- synthetic shards in SP1's shard STRUCTURE (MachinePlan): the keyed machine, its shard proofs, the machine-mode compress stage ----
+namespace {
+constexpr uint32_t LKUP_MAGIC = 0x50554B4Cu, LKUP_SEND = 0u, LKUP_RECEIVE = 1u, LKUP_ONE = 0xFFFFFFFFu;
+constexpr uint32_t BUS_SP1 = 300u;             // pair q of chip c travels on bus BUS_SP1 + 16 c + q (zktls_amd.device.Sp1ShapedShard: the same machine from Python)
+constexpr uint64_t KEY_SHARD = 9999u;          // the preprocessed columns come from a stream of their own
+constexpr uint32_t MACHINE_PUBLICS = 9u;       // request digest | shard index
+
+// a machine as zkhip_machine_desc wants it, with the storage behind the pointers
+struct MachineHolder {
+    std::vector<std::vector<uint32_t>> progs, tabs;
+    std::vector<const uint32_t*> pp, tp;
+    std::vector<size_t> pw_, tw_;
+    std::vector<int32_t> lns;
+    std::vector<uint32_t> widths, pres;          // main widths, preprocessed widths
+    zkhip_machine_desc desc{};
+    void finish(const uint32_t key_root[8], int q, int pb, uint32_t n_public) {
+        const size_t n = progs.size();
+        pp.resize(n); tp.resize(n); pw_.resize(n); tw_.resize(n);
+        for (size_t i = 0; i < n; i++) {
+            pp[i] = progs[i].data(); pw_[i] = progs[i].size();
+            tp[i] = tabs[i].empty() ? nullptr : tabs[i].data(); tw_[i] = tabs[i].size();
+        }
+        desc.n_chips = (int32_t)n; desc.log_ns = lns.data(); desc.widths = widths.data(); desc.pre_widths = pres.data();
+        desc.programs = pp.data(); desc.program_words = pw_.data(); desc.tables = tp.data(); desc.table_words = tw_.data();
+        if (key_root) std::memcpy(desc.key_root, key_root, 32);
+        desc.num_queries = q; desc.pow_bits = pb; desc.n_public = n_public;
+    }
+    // the shard machine of a plan: every chip under the synthetic AIR as a constraint program over [preprocessed | main], its pairs as an interaction table
+    void build_plan(const MachinePlan& plan, const uint32_t key_root[8]) {
+        const size_t n = plan.chips.size();
+        if (n == 0 || n > 16) throw std::runtime_error("machine plan: 1 to 16 chips");
+        progs.assign(n, {}); tabs.assign(n, {}); lns.resize(n); widths.resize(n); pres.resize(n);
+        for (size_t c = 0; c < n; c++) {
+            const ChipPlan& ch = plan.chips[c];
+            if (c && ch.log_n > plan.chips[c - 1].log_n) throw std::runtime_error("machine plan: chips tallest first");
+            if (ch.width == 0 || ch.width % 4 || 8u * ch.pairs > ch.width) throw std::runtime_error("machine plan: a chip's width is a multiple of 4 and holds 8 columns per LogUp pair");
+            if (ch.pre_width && (ch.pre_width % 8 || ch.pre_width >= ch.width || ch.partner >= 0)) throw std::runtime_error("machine plan: preprocessed columns are whole in-table pairs (a multiple of 8, fewer than the width)");
+            if (ch.partner >= 0) {
+                if ((size_t)ch.partner >= n || (size_t)ch.partner == c) throw std::runtime_error("machine plan: partner out of range");
+                const ChipPlan& o = plan.chips[(size_t)ch.partner];
+                if (o.partner != (int)c || o.log_n != ch.log_n || o.pairs != ch.pairs) throw std::runtime_error("machine plan: partners are mutual, of one height and one pair count");
+            }
+            size_t words = 0;
+            if (zkhip_air_synthetic(ch.width, MACHINE_PUBLICS, nullptr, 0, &words) != ZKHIP_OK || words == 0) fail_zkhip("zkhip_air_synthetic");
+            progs[c].resize(words);
+            if (zkhip_air_synthetic(ch.width, MACHINE_PUBLICS, progs[c].data(), words, &words) != ZKHIP_OK) fail_zkhip("zkhip_air_synthetic");
+            if (ch.pairs) {
+                std::vector<uint32_t>& t = tabs[c];
+                t = {LKUP_MAGIC, 2u * ch.pairs, 0u};
+                for (uint32_t q = 0; q < ch.pairs; q++) {
+                    const uint32_t to = ch.partner < 0 ? (uint32_t)c : (uint32_t)ch.partner;
+                    const uint32_t send[] = {LKUP_SEND, LKUP_ONE, BUS_SP1 + 16u * (uint32_t)c + q, 2u, 8u * q, 8u * q + 1u};
+                    const uint32_t recv[] = {LKUP_RECEIVE, LKUP_ONE, BUS_SP1 + 16u * to + q, 2u, 8u * q + 4u, 8u * q + 5u};
+                    t.insert(t.end(), send, send + 6);
+                    t.insert(t.end(), recv, recv + 6);
+                }
+                t[2] = (uint32_t)t.size();
+            }
+            lns[c] = ch.log_n; widths[c] = ch.width - ch.pre_width; pres[c] = ch.pre_width;
+        }
+        finish(key_root, plan.num_queries, plan.pow_bits, MACHINE_PUBLICS);
+    }
+    // the machine-mode machine over n_proofs proofs of `inner` as an inner machine itself (the library describes its chips): what a tree's top verifies
+    void build_described(const zkhip_machine_desc& inner, size_t n_proofs, const uint32_t key_root[8], int q, int pb, uint32_t n_public) {
+        progs.clear(); tabs.clear(); lns.clear(); widths.clear(); pres.clear();
+        for (int i = 0; i < 16; i++) {
+            int ln = 0; uint32_t mw = 0, pw = 0;
+            const size_t np = zkhip_machine_verifier_describe(&inner, n_proofs, i, 0, nullptr, 0, &ln, &mw, &pw);
+            if (np == 0) break;
+            std::vector<uint32_t> prog(np);
+            if (zkhip_machine_verifier_describe(&inner, n_proofs, i, 0, prog.data(), np, &ln, &mw, &pw) != np) fail_zkhip("zkhip_machine_verifier_describe");
+            const size_t nt = zkhip_machine_verifier_describe(&inner, n_proofs, i, 1, nullptr, 0, &ln, &mw, &pw);
+            std::vector<uint32_t> tab(nt);
+            if (nt && zkhip_machine_verifier_describe(&inner, n_proofs, i, 1, tab.data(), nt, &ln, &mw, &pw) != nt) fail_zkhip("zkhip_machine_verifier_describe");
+            progs.push_back(std::move(prog)); tabs.push_back(std::move(tab)); lns.push_back(ln); widths.push_back(mw); pres.push_back(pw);
+        }
+        if (progs.empty()) fail_zkhip("zkhip_machine_verifier_describe");
+        finish(key_root, q, pb, n_public);
+    }
+};
+
+uint64_t stream_seed(const std::vector<uint32_t>& digest) {
+    uint64_t seed = 0;
+    for (int i = 0; i < 4; i++) seed = (seed << 16) ^ digest[(size_t)i];
+    return seed;
+}
+size_t plan_trace_bytes(const MachinePlan& plan, std::vector<size_t>* offsets) {
+    size_t at = 0;
+    for (const ChipPlan& ch : plan.chips) {
+        if (offsets) offsets->push_back(at);
+        at += ((((size_t)ch.width << ch.log_n) * 4u + 255u) / 256u) * 256u;
+    }
+    return at + 64u;                           // (+ 64: never the size of a single-matrix plan's buffer, whose parked slots these must not be taken for)
+}
+// setup (sp1.rs:113) on one context: the preprocessed columns of the plan's chips from the PROGRAM's stream, committed once
+void machine_setup_on(zkhip_ctx* ctx, const MachinePlan& plan, const std::vector<uint8_t>& elf, const zkhip_params& prm, zkhip_machine_key** key, uint32_t root[8]) {
+    const uint64_t key_seed = stream_seed(request_digest({}, elf));
+    const size_t n = plan.chips.size();
+    std::vector<zkhip_chip> pre(n);
+    struct Bufs { zkhip_ctx* c; std::vector<void*> p; ~Bufs() { (void)zkhip_ctx_sync(c); for (void* q : p) zkhip_free(c, q); } } bufs{ctx, {}};
+    for (size_t c = 0; c < n; c++) {
+        const ChipPlan& ch = plan.chips[c];
+        pre[c] = zkhip_chip{nullptr, 0, ch.log_n, 0, 0, -1};
+        if (!ch.pre_width) continue;
+        void* d = nullptr;
+        if (zkhip_malloc(ctx, ((size_t)ch.width << ch.log_n) * 4u, &d) != ZKHIP_OK) fail_zkhip("zkhip_malloc");
+        bufs.p.push_back(d);
+        if (zkhip_gen_trace_logup(ctx, key_seed, 100u * KEY_SHARD + c, ch.log_n, ch.width, (int)ch.pairs, (uint32_t*)d, ch.width) != ZKHIP_OK) fail_zkhip("zkhip_gen_trace_logup");
+        pre[c] = zkhip_chip{(const uint32_t*)d, ch.width, ch.log_n, ch.pre_width, 0, -1};
+    }
+    if (zkhip_machine_setup(ctx, pre.data(), (int)n, &prm, key, root) != ZKHIP_OK) { *key = nullptr; fail_zkhip("zkhip_machine_setup"); }
+}
+std::vector<uint32_t> machine_publics(const std::vector<uint32_t>& digest, uint32_t J, uint32_t n_joins, uint32_t shards) {
+    std::vector<uint32_t> pvs;
+    for (uint32_t c = 0; c < n_joins; c++)
+        for (uint32_t k = 0; k < J; k++) {
+            const uint32_t sidx = c * J + k < shards ? c * J + k : shards - 1;       // the last join repeats the last shard (one shape, one key)
+            pvs.insert(pvs.end(), digest.begin(), digest.end());
+            pvs.push_back(sidx);
+        }
+    return pvs;
+}
+}  // namespace
+
+MachinePlan MachinePlan::sp1_shaped(uint32_t shards) {
+    MachinePlan p;
+    p.chips = {ChipPlan{20, 96, 3, 1, 0}, ChipPlan{20, 32, 3, 0, 0}, ChipPlan{19, 64, 2, -1, 0}, ChipPlan{18, 128, 4, -1, 0}, ChipPlan{16, 256, 8, -1, 32}, ChipPlan{14, 40, 1, -1, 0}};
+    p.shards = shards;
+    return p;
+}
+
+uint32_t machine_join_size(const MachinePlan& plan) {
+    const uint32_t shards = plan.shards ? plan.shards : 1u;
+    MachineHolder m;
+    const uint32_t zero[8] = {0};
+    m.build_plan(plan, zero);
+    const zkhip_params outer{1, plan.num_queries, plan.pow_bits, 0, 0, 0, 0, 0};
+    uint32_t most = 1;                                  // (a machine the join refuses at one proof: the join itself will say so)
+    for (uint32_t n = 64; n >= 1; n--)                  // machine mode: at most 64 proofs, and a Poseidon2 chip of at most 2^22 rows
+        if (zkhip_machine_verifier_proof_size(&m.desc, n, &outer) != 0) { most = n; break; }
+    const uint32_t cap = g_join_size.load();
+    if (cap && cap < most) most = cap;
+    if (shards <= most) return shards;
+    const uint32_t joins = (shards + most - 1u) / most;
+    return (shards + joins - 1u) / joins;
+}
+
+// core -> COMPRESS for machine shards: the shard proofs verified in-circuit in machine mode; several joins are joined again
+static std::vector<uint8_t> compress_machine_proofs(int device, const MachinePlan& plan, const uint32_t key_root[8], const std::vector<uint32_t>& digest,
+                                                    const std::vector<std::vector<uint8_t>>& proofs) {
+    const uint32_t J = machine_join_size(plan), n_joins = (plan.shards + J - 1) / J;
+    const zkhip_params outer{1, plan.num_queries, plan.pow_bits, 0, 0, 0, 0, 0};
+    MachineHolder m;
+    m.build_plan(plan, key_root);
+    const size_t jcap = zkhip_machine_verifier_proof_size(&m.desc, J, &outer);
+    if (jcap == 0) throw std::runtime_error(std::string("zkhip_machine_verifier_proof_size: ") + zkhip_last_error());
+    struct Guard {
+        zkhip_ctx* ctx = nullptr; zkhip_machine_key* jkey = nullptr; zkhip_machine_key* tkey = nullptr;
+        ~Guard() {
+            if (!ctx) return;
+            (void)zkhip_ctx_sync(ctx);
+            if (jkey) zkhip_machine_key_destroy(jkey);
+            if (tkey) zkhip_machine_key_destroy(tkey);
+            zkhip_ctx_destroy(ctx);
+        }
+    } g;
+    if (zkhip_ctx_create(device, nullptr, &g.ctx) != ZKHIP_OK) { g.ctx = nullptr; fail_zkhip("zkhip_ctx_create"); }
+    uint32_t jvk[8];
+    if (zkhip_machine_verifier_setup(g.ctx, &m.desc, J, &outer, &g.jkey, jvk) != ZKHIP_OK) { g.jkey = nullptr; fail_zkhip("zkhip_machine_verifier_setup"); }
+    const std::vector<uint32_t> pvs = machine_publics(digest, J, n_joins, plan.shards);
+    std::vector<std::vector<uint8_t>> entries;
+    for (uint32_t c = 0; c < n_joins; c++) {
+        std::vector<const uint8_t*> ptrs(J);
+        std::vector<size_t> lens(J);
+        for (uint32_t k = 0; k < J; k++) {
+            const uint32_t sidx = c * J + k < plan.shards ? c * J + k : plan.shards - 1;
+            ptrs[k] = proofs[sidx].data(); lens[k] = proofs[sidx].size();
+        }
+        std::vector<uint8_t> joined(jcap);
+        size_t jlen = 0;
+        const uint32_t* pv = pvs.data() + (size_t)c * J * MACHINE_PUBLICS;
+        if (zkhip_prove_machine_verifier(g.ctx, g.jkey, &m.desc, ptrs.data(), lens.data(), J, pv, MACHINE_PUBLICS, &outer, joined.data(), jcap, &jlen) != ZKHIP_OK)
+            fail_zkhip("zkhip_prove_machine_verifier");
+        joined.resize(jlen);
+        int reason = 0;
+        if (zkhip_verify_machine_recursive(&m.desc, joined.data(), jlen, pv, MACHINE_PUBLICS, J, jvk, &outer, &reason) != ZKHIP_OK)      // sp1.rs:120: the prover checks its own proof
+            fail_zkhip("zkhip_verify_machine_recursive");
+        entries.push_back(std::move(joined));
+    }
+    uint32_t flags_extra = 0;
+    if (n_joins > 1) {
+        MachineHolder jm;
+        jm.build_described(m.desc, J, jvk, plan.num_queries, plan.pow_bits, MACHINE_PUBLICS * J);
+        const size_t tcap = zkhip_machine_verifier_proof_size(&jm.desc, n_joins, &outer);
+        if (tcap != 0) {                                  // (a top the machine refuses leaves the joins side by side)
+            uint32_t tvk[8];
+            if (zkhip_machine_verifier_setup(g.ctx, &jm.desc, n_joins, &outer, &g.tkey, tvk) != ZKHIP_OK) { g.tkey = nullptr; fail_zkhip("zkhip_machine_verifier_setup"); }
+            std::vector<const uint8_t*> ptrs(n_joins);
+            std::vector<size_t> lens(n_joins);
+            for (uint32_t c = 0; c < n_joins; c++) { ptrs[c] = entries[c].data(); lens[c] = entries[c].size(); }
+            std::vector<uint8_t> top(tcap);
+            size_t tlen = 0;
+            if (zkhip_prove_machine_verifier(g.ctx, g.tkey, &jm.desc, ptrs.data(), lens.data(), n_joins, pvs.data(), MACHINE_PUBLICS * J, &outer, top.data(), tcap, &tlen) != ZKHIP_OK)
+                fail_zkhip("zkhip_prove_machine_verifier (top)");
+            top.resize(tlen);
+            int reason = 0;
+            if (zkhip_verify_machine_recursive(&jm.desc, top.data(), tlen, pvs.data(), MACHINE_PUBLICS * J, n_joins, tvk, &outer, &reason) != ZKHIP_OK)
+                fail_zkhip("zkhip_verify_machine_recursive (top)");
+            entries.clear();
+            entries.push_back(std::move(top));
+            flags_extra = BATCH_FLAG_TREE;
+        }
+    }
+    std::vector<uint8_t> tail(36);
+    std::memcpy(tail.data(), jvk, 32);
+    const uint32_t cnt = plan.shards;
+    std::memcpy(tail.data() + 32, &cnt, 4);
+    entries.push_back(tail);
+    return pack_shard_proofs(entries, BATCH_FLAG_SYNTHETIC | BATCH_FLAG_MACHINE | BATCH_FLAG_COMPRESSED | flags_extra);
+}
+
+int verify_machine_blob(const std::vector<uint8_t>& blob, const MachinePlan& plan, const std::vector<uint8_t>& cbor, const std::vector<uint8_t>& elf,
+                        const std::vector<uint8_t>& vk, int* reason) {
+    try {
+        std::vector<std::vector<uint8_t>> entries;
+        uint32_t flags = 0;
+        if (vk.size() != 64 || plan.shards == 0 || !unpack_shard_proofs(blob, &entries, &flags) || !(flags & BATCH_FLAG_MACHINE) || !(flags & BATCH_FLAG_SYNTHETIC)) return -1;
+        const std::vector<uint32_t> pd = request_digest({}, elf);
+        if (std::memcmp(vk.data() + 32, pd.data(), 32) != 0) return -1;                      // a key made for another program
+        uint32_t root[8];
+        std::memcpy(root, vk.data(), 32);
+        const std::vector<uint32_t> digest = request_digest(cbor, elf);
+        MachineHolder m;
+        m.build_plan(plan, root);
+        const zkhip_params prm{1, plan.num_queries, plan.pow_bits, 0, 0, 0, 0, 0};
+        int why = 0;
+        if (!(flags & BATCH_FLAG_COMPRESSED)) {
+            if (entries.size() != plan.shards) return -1;
+            for (uint32_t s = 0; s < plan.shards; s++) {
+                std::vector<uint32_t> pv(digest);
+                pv.push_back(s);
+                const int rc = zkhip_verify_machine_keyed(entries[s].data(), entries[s].size(), m.lns.data(), m.widths.data(), m.pres.data(), root, m.pp.data(), m.pw_.data(), m.tp.data(),
+                                                          m.tw_.data(), m.desc.n_chips, pv.data(), pv.size(), &prm, &why);
+                if (reason) *reason = why;
+                if (rc != ZKHIP_OK) return -2;
+            }
+            return 0;
+        }
+        if (entries.size() < 2 || entries.back().size() != 36) return -1;
+        uint32_t cnt = 0;
+        std::memcpy(&cnt, entries.back().data() + 32, 4);
+        if (cnt != plan.shards) return -1;
+        const uint32_t J = machine_join_size(plan), n_joins = (cnt + J - 1) / J;
+        uint32_t jvk[8];
+        if (zkhip_machine_verifier_key_host(&m.desc, J, &prm, jvk) != ZKHIP_OK) return -1;  // the join's key is DERIVED: the blob's copy is informative
+        const std::vector<uint32_t> pvs = machine_publics(digest, J, n_joins, cnt);
+        if (flags & BATCH_FLAG_TREE) {
+            if (n_joins < 2 || entries.size() != 2) return -1;
+            MachineHolder jm;
+            jm.build_described(m.desc, J, jvk, plan.num_queries, plan.pow_bits, MACHINE_PUBLICS * J);
+            uint32_t tvk[8];
+            if (zkhip_machine_verifier_key_host(&jm.desc, n_joins, &prm, tvk) != ZKHIP_OK) return -1;
+            const int rc = zkhip_verify_machine_recursive(&jm.desc, entries[0].data(), entries[0].size(), pvs.data(), MACHINE_PUBLICS * J, n_joins, tvk, &prm, &why);
+            if (reason) *reason = why;
+            return rc == ZKHIP_OK ? 0 : -2;
+        }
+        if (entries.size() != (size_t)n_joins + 1) return -1;
+        for (uint32_t c = 0; c < n_joins; c++) {
+            const int rc = zkhip_verify_machine_recursive(&m.desc, entries[c].data(), entries[c].size(), pvs.data() + (size_t)c * J * MACHINE_PUBLICS, MACHINE_PUBLICS, J, jvk, &prm, &why);
+            if (reason) *reason = why;
+            if (rc != ZKHIP_OK) return -2;
+        }
+        return 0;
+    } catch (...) {
+        return -1;
+    }
+}
+
 ProveResult HipGuestProver::prove(const GuestInput& input, const std::vector<uint8_t>& guest_program) {
     if (backend_ == Backend::Risc0) set_env_r0(mode_);   // prover.rs:65
     else set_env(mode_);                              // sp1.rs:72
@@ -336,12 +614,31 @@ SetupResult HipGuestProver::setup(const std::vector<uint8_t>& guest_program) {
     SetupResult s;
     try {
         if (guest_program.empty()) throw std::runtime_error("guest program is empty");
-        if (!commitment_) throw std::runtime_error("setup: only the input-commitment guest has preprocessed tables (with_input_commitment())");
+        if (!commitment_ && !machine_) throw std::runtime_error("setup: only the input-commitment guest and machine shards have preprocessed tables (with_input_commitment(), with_synthetic_machine())");
         if (backend_ != Backend::Sp1) throw std::runtime_error("setup: the keyed machine uses the SP1 proof shape");
         if (mode_ == ProverType::Network) throw std::runtime_error("network proving is not provided by the HIP backend");
         std::vector<uint8_t> vk(64, 0);
         const std::vector<uint32_t> pd = request_digest({}, guest_program);
         std::memcpy(vk.data() + 32, pd.data(), 32);
+        if (machine_) {
+            // the machine's preprocessed columns, a function of (plan, program), committed on the first device: the key every shard proof opens against
+            if (mode_ != ProverType::Mock) {
+                if (devices_.empty()) throw std::runtime_error("device list is empty");
+                const zkhip_params prm{1, mplan_.num_queries, mplan_.pow_bits, 0, 0, 0, 0, 0};
+                MachineHolder shape;
+                const uint32_t zero[8] = {0};
+                shape.build_plan(mplan_, zero);                            // (refuses a malformed plan before any device work)
+                struct G { zkhip_ctx* c = nullptr; zkhip_machine_key* k = nullptr; ~G() { if (k) { (void)zkhip_ctx_sync(c); zkhip_machine_key_destroy(k); } if (c) zkhip_ctx_destroy(c); } } g;
+                if (zkhip_ctx_create(devices_[0], nullptr, &g.c) != ZKHIP_OK) { g.c = nullptr; fail_zkhip("zkhip_ctx_create"); }
+                uint32_t root[8];
+                machine_setup_on(g.c, mplan_, guest_program, prm, &g.k, root);
+                std::memcpy(vk.data(), root, 32);
+            }
+            vk_ = vk;
+            s.vk = vk;
+            s.ok = true;
+            return s;
+        }
         if (mode_ != ProverType::Mock) {
             if (devices_.empty()) throw std::runtime_error("device list is empty");
             const zkhip_params prm{1, plan_.num_queries, plan_.pow_bits, 0, 0, 0, 0, 0};
@@ -574,6 +871,119 @@ ProveResult HipGuestProver::prove_inner(const GuestInput& input, const std::vect
         }
         r.output.assign(digest32, digest32 + 32);
         r.proof = pack_shard_proofs({proof, length_entry(input.cbor.size())}, BATCH_FLAG_INPUT_SHA256 | (keyed ? BATCH_FLAG_KEYED : 0u));
+        r.ok = true;
+        return r;
+    }
+    if (machine_) {
+        // synthetic shards in SP1's shard structure: every shard ONE keyed-machine proof (version 11) against ONE key, checked like sp1.rs:120
+        if (backend_ != Backend::Sp1) throw std::runtime_error("machine shards use the SP1 proof shape");
+        if (mplan_.shards == 0) throw std::runtime_error("shard plan is empty");
+        if (devices_.empty()) throw std::runtime_error("device list is empty");
+        const zkhip_params prm{1, mplan_.num_queries, mplan_.pow_bits, 0, 0, 0, 0, 0};
+        if (!vk_.empty()) {
+            const std::vector<uint32_t> pd = request_digest({}, elf);
+            if (std::memcmp(vk_.data() + 32, pd.data(), 32) != 0) throw std::runtime_error("prove: the guest program is not the one setup() was called with");
+        }
+        MachineHolder shape;
+        const uint32_t zero[8] = {0};
+        shape.build_plan(mplan_, zero);
+        const int nc = shape.desc.n_chips;
+        const size_t cap = zkhip_machine_proof_size_keyed(shape.lns.data(), shape.widths.data(), shape.pres.data(), shape.pp.data(), shape.pw_.data(), shape.tp.data(), shape.tw_.data(), nc, &prm,
+                                                          MACHINE_PUBLICS);
+        if (cap == 0) throw std::runtime_error(std::string("bad machine plan: ") + zkhip_last_error());
+        const uint64_t seed = stream_seed(digest);
+        uint32_t in_flight = mplan_.in_flight;
+        if (in_flight == 0) {
+            const char* e = std::getenv("ZKTLS_HIP_IN_FLIGHT");
+            in_flight = e && std::atoi(e) > 0 ? (uint32_t)std::atoi(e) : 4u;
+        }
+        if (in_flight > mplan_.shards) in_flight = mplan_.shards;
+        std::vector<size_t> offsets;
+        const size_t bytes = plan_trace_bytes(mplan_, &offsets);
+        std::vector<std::vector<uint8_t>> proofs(mplan_.shards);
+        const int n_dev = (int)devices_.size();
+        std::vector<std::atomic<uint32_t>> next(n_dev);
+        for (auto& a : next) a.store(0);
+        std::atomic<bool> failed{false};
+        std::mutex err_mu;
+        std::string first_error;
+        uint32_t root[8] = {0};
+        bool have_root = false;
+        if (!vk_.empty()) { std::memcpy(root, vk_.data(), 32); have_root = true; }
+        auto worker = [&](int slot) {
+            try {
+                const int device = devices_[slot];
+                CtxGuard g;
+                if (!g.take(device, bytes)) {
+                    g.device = device; g.trace_bytes = bytes;
+                    if (zkhip_ctx_create(device, nullptr, &g.ctx) != ZKHIP_OK) fail_zkhip("zkhip_ctx_create");
+                    if (zkhip_malloc(g.ctx, bytes, &g.d_trace) != ZKHIP_OK) fail_zkhip("zkhip_malloc");
+                }
+                // pk: a key belongs to the context it was made with; every context arrives at ONE root (setup()'s, when it was called)
+                struct KeyGuard { zkhip_ctx* c; zkhip_machine_key* k = nullptr; ~KeyGuard() { if (k) { (void)zkhip_ctx_sync(c); zkhip_machine_key_destroy(k); } } } kg{g.ctx};
+                uint32_t mine[8];
+                machine_setup_on(g.ctx, mplan_, elf, prm, &kg.k, mine);
+                {
+                    std::lock_guard<std::mutex> lk(err_mu);
+                    if (!have_root) { std::memcpy(root, mine, 32); have_root = true; }
+                    else if (std::memcmp(root, mine, 32) != 0) throw std::runtime_error("prove: this context's key does not match the verifying key");
+                }
+                std::vector<zkhip_chip> chips((size_t)nc);
+                for (;;) {
+                    const uint64_t s = (uint64_t)slot + (uint64_t)next[slot].fetch_add(1) * (uint64_t)n_dev;
+                    if (s >= mplan_.shards || failed.load()) break;
+                    if (zkhip_shard_device((int)s, devices_.data(), n_dev) != device) throw std::runtime_error("shard dealt to the wrong device");
+                    for (int c = 0; c < nc; c++) {
+                        const ChipPlan& ch = mplan_.chips[(size_t)c];
+                        uint32_t* d = (uint32_t*)((uint8_t*)g.d_trace + offsets[(size_t)c]);
+                        const int rc = ch.partner < 0
+                            ? zkhip_gen_trace_logup(g.ctx, seed, 100u * s + (uint64_t)c, ch.log_n, ch.width, (int)ch.pairs, d, ch.width)
+                            : zkhip_gen_trace_logup_cross(g.ctx, seed, 100u * s + (uint64_t)c, 100u * s + (uint64_t)ch.partner, ch.log_n, ch.width, mplan_.chips[(size_t)ch.partner].width,
+                                                          (int)ch.pairs, d, ch.width);
+                        if (rc != ZKHIP_OK) fail_zkhip("zkhip_gen_trace_logup");
+                        chips[(size_t)c] = zkhip_chip{d + ch.pre_width, ch.width, ch.log_n, ch.width - ch.pre_width, 0, -1};      // the main columns: a view of [preprocessed | main]
+                    }
+                    std::vector<uint32_t> pv(digest);
+                    pv.push_back((uint32_t)s);
+                    std::vector<uint8_t> proof(cap);
+                    size_t len = 0;
+                    if (zkhip_prove_machine_keyed(g.ctx, kg.k, chips.data(), shape.pp.data(), shape.pw_.data(), shape.tp.data(), shape.tw_.data(), nc, pv.data(), pv.size(), &prm, proof.data(), cap,
+                                                  &len) != ZKHIP_OK)
+                        fail_zkhip("zkhip_prove_machine_keyed");
+                    proof.resize(len);
+                    int reason = 0;
+                    if (zkhip_verify_machine_keyed(proof.data(), len, shape.lns.data(), shape.widths.data(), shape.pres.data(), mine, shape.pp.data(), shape.pw_.data(), shape.tp.data(),
+                                                   shape.tw_.data(), nc, pv.data(), pv.size(), &prm, &reason) != ZKHIP_OK)
+                        fail_zkhip("zkhip_verify_machine_keyed");          // sp1.rs:120: the prover checks its own proof
+                    proofs[s] = std::move(proof);
+                }
+                g.healthy = true;
+            } catch (const std::exception& e) {
+                failed.store(true);
+                std::lock_guard<std::mutex> lk(err_mu);
+                if (first_error.empty()) first_error = e.what();
+            } catch (...) {
+                failed.store(true);
+                std::lock_guard<std::mutex> lk(err_mu);
+                if (first_error.empty()) first_error = "unknown failure in a shard worker";
+            }
+        };
+        if (in_flight <= 1 && n_dev == 1) {
+            worker(0);
+        } else {
+            std::vector<std::thread> pool;
+            for (int slot = 0; slot < n_dev; slot++) {
+                const uint32_t mine = (mplan_.shards - (uint32_t)slot + (uint32_t)n_dev - 1) / (uint32_t)n_dev;
+                for (uint32_t t = 0; t < (mine < in_flight ? mine : in_flight); t++) pool.emplace_back(worker, slot);
+            }
+            for (auto& t : pool) t.join();
+        }
+        if (failed.load()) throw std::runtime_error(first_error);
+        r.vk.assign(64, 0);
+        std::memcpy(r.vk.data(), root, 32);
+        const std::vector<uint32_t> pd = request_digest({}, elf);
+        std::memcpy(r.vk.data() + 32, pd.data(), 32);
+        r.proof = compress_ ? compress_machine_proofs(devices_[0], mplan_, root, digest, proofs) : pack_shard_proofs(proofs, BATCH_FLAG_SYNTHETIC | BATCH_FLAG_MACHINE);
         r.ok = true;
         return r;
     }
@@ -992,6 +1402,80 @@ int zktls_verify_commitment_blob_for(int backend, const uint8_t* blob, size_t le
     return zktls::verify_commitment_blob(std::vector<uint8_t>(blob, blob + len), std::vector<uint8_t>(output, output + 32),
                                          vk ? std::vector<uint8_t>(vk, vk + vk_len) : std::vector<uint8_t>(), num_queries, pow_bits, reason,
                                          backend == 1 ? zktls::Backend::Risc0 : zktls::Backend::Sp1);
+}
+// ---- machine shards (MachinePlan): SP1's shard structure through the same plug point ----
+struct zktls_machine_plan {
+    int32_t n_chips; const int32_t* log_ns; const uint32_t* widths; const uint32_t* pairs; const int32_t* partners; const uint32_t* pre_widths;      // per chip, tallest first
+    uint32_t shards; int32_t num_queries; int32_t pow_bits; uint32_t in_flight;
+};
+static bool machine_plan_of(const zktls_machine_plan* plan, zktls::MachinePlan* out) {
+    if (!plan || plan->n_chips <= 0 || plan->n_chips > 16 || !plan->log_ns || !plan->widths) return false;
+    for (int c = 0; c < plan->n_chips; c++)
+        out->chips.push_back(zktls::ChipPlan{plan->log_ns[c], plan->widths[c], plan->pairs ? plan->pairs[c] : 0u, plan->partners ? plan->partners[c] : -1, plan->pre_widths ? plan->pre_widths[c] : 0u});
+    out->shards = plan->shards; out->num_queries = plan->num_queries; out->pow_bits = plan->pow_bits; out->in_flight = plan->in_flight;
+    return true;
+}
+static void put_err(char* err, size_t err_cap, const std::string& what) {
+    if (err && err_cap) { std::strncpy(err, what.c_str(), err_cap - 1); err[err_cap - 1] = 0; }
+}
+// `let (pk, vk) = client.setup(elf)` (sp1.rs:113) for a machine plan: vk[64] = the key's root (8 LE words) + the program's digest
+int zktls_machine_setup(int device, int mode, const zktls_machine_plan* plan, const uint8_t* elf, size_t elf_len, uint8_t vk[64], char* err, size_t err_cap) {
+    zktls::MachinePlan mp;
+    if (!machine_plan_of(plan, &mp) || !vk) { put_err(err, err_cap, "machine setup: bad plan"); return -1; }
+    zktls::HipGuestProver p(device < 0 ? 0 : device);
+    switch (mode) { case 0: p.mock(); break; case 1: p.local(); break; case 2: p.hip(); break; default: p.network(); break; }
+    p.with_synthetic_machine(mp);
+    const zktls::SetupResult s = p.setup(std::vector<uint8_t>(elf, elf + elf_len));
+    if (!s.ok) { put_err(err, err_cap, s.error); return -1; }
+    std::memcpy(vk, s.vk.data(), 64);
+    return 0;
+}
+// ONE call of ZkProver::prove for an execution of machine shards; setup_first != 0: setup(elf) before it, as prove<P> does (sp1.rs:113-116); compress != 0: the
+// compress stage behind it.  vk_out[64] receives the verifying key the proofs were checked against.  `device` < 0: every visible device.
+int zktls_guest_prove_machine(int device, int mode, const zktls_machine_plan* plan, int compress, int setup_first, const uint8_t* cbor, size_t cbor_len, const uint8_t* elf, size_t elf_len,
+                              uint8_t** output, size_t* output_len, uint8_t** proof, size_t* proof_len, uint8_t vk_out[64], char* err, size_t err_cap) {
+    zktls::MachinePlan mp;
+    if (!machine_plan_of(plan, &mp) || !output || !output_len || !proof || !proof_len) { put_err(err, err_cap, "machine prove: bad plan or null argument"); return -1; }
+    zktls::HipGuestProver p(device < 0 ? 0 : device);
+    if (device < 0) {
+        std::vector<int> all;
+        for (int d = 0; d < zkhip_device_count(); d++) all.push_back(d);
+        if (!all.empty()) p.with_devices(all);
+    }
+    switch (mode) { case 0: p.mock(); break; case 1: p.local(); break; case 2: p.hip(); break; default: p.network(); break; }
+    p.with_synthetic_machine(mp);
+    if (compress) p.with_compress();
+    const std::vector<uint8_t> program(elf, elf + elf_len);
+    if (setup_first) {
+        const zktls::SetupResult s = p.setup(program);
+        if (!s.ok) { put_err(err, err_cap, s.error); return -1; }
+    }
+    zktls::GuestInput in;
+    in.cbor.assign(cbor, cbor + cbor_len);
+    const zktls::ProveResult r = p.prove(in, program);
+    if (!r.ok) { put_err(err, err_cap, r.error); return -1; }
+    *output_len = r.output.size();
+    *output = (uint8_t*)std::malloc(r.output.size() ? r.output.size() : 1);
+    std::memcpy(*output, r.output.data(), r.output.size());
+    *proof_len = r.proof.size();
+    *proof = (uint8_t*)std::malloc(r.proof.size() ? r.proof.size() : 1);
+    std::memcpy(*proof, r.proof.data(), r.proof.size());
+    if (vk_out) { std::memset(vk_out, 0, 64); if (r.vk.size() == 64) std::memcpy(vk_out, r.vk.data(), 64); }
+    return 0;
+}
+// the host-only check of a machine blob (plain, COMPRESSED or COMPRESSED | TREE) against (plan, input, ELF, vk): 0 / -1 / -2 (verify_machine_blob)
+int zktls_verify_machine_blob(const uint8_t* blob, size_t len, const zktls_machine_plan* plan, const uint8_t* cbor, size_t cbor_len, const uint8_t* elf, size_t elf_len, const uint8_t vk[64],
+                              int* reason) {
+    zktls::MachinePlan mp;
+    if (!machine_plan_of(plan, &mp) || !blob || !vk) return -1;
+    return zktls::verify_machine_blob(std::vector<uint8_t>(blob, blob + len), mp, std::vector<uint8_t>(cbor, cbor + cbor_len), std::vector<uint8_t>(elf, elf + elf_len),
+                                      std::vector<uint8_t>(vk, vk + 64), reason);
+}
+// shard proofs per machine-mode join for the plan (0: a plan the library refuses)
+uint32_t zktls_machine_join_size(const zktls_machine_plan* plan) {
+    zktls::MachinePlan mp;
+    if (!machine_plan_of(plan, &mp)) return 0;
+    try { return zktls::machine_join_size(mp); } catch (...) { return 0; }
 }
 void zktls_free(void* p) { std::free(p); }
 const char* zktls_current_risc0_prover_env(void) { const char* e = getenv("RISC0_PROVER"); return e ? e : ""; }

@@ -81,6 +81,29 @@ struct ShardPlan {
     uint32_t in_flight = 0;    // shards proven at the same time (own context + host thread each); 0: $ZKTLS_HIP_IN_FLIGHT or 4
 };
 
+// One chip of a synthetic MACHINE shard (SP1's real shard structure, sp1-core-machine, reference Cargo.lock:5822): 2^log_n rows x width columns
+// [preprocessed | main] under the synthetic AIR, `pairs` LogUp pairs as an interaction table -- in-table (partner -1) or ACROSS two tables of one
+// height that look each other up (partner = the other chip's index, mutual) --, `pre_width` leading columns committed once by setup (a multiple of 8)
+struct ChipPlan {
+    int log_n = 20;
+    uint32_t width = 32;
+    uint32_t pairs = 1;
+    int partner = -1;
+    uint32_t pre_width = 0;
+};
+// An execution of `shards` such shards, each ONE version-11 proof of the keyed machine (zkhip_prove_machine_keyed) against ONE key: the
+// preprocessed columns depend on the guest program alone (sp1.rs:113: setup(guest_program)), the main columns on (input, program, shard).
+struct MachinePlan {
+    std::vector<ChipPlan> chips;   // tallest first, at most 16
+    uint32_t shards = 1;
+    int num_queries = 100;
+    int pow_bits = 16;
+    uint32_t in_flight = 0;        // as ShardPlan::in_flight
+    // the six chips bench.py's `multichip` section proves: 2^20 x 96 and 2^20 x 32 looking each other up, 2^19 x 64, 2^18 x 128, 2^16 x 256 with 32
+    // preprocessed columns, 2^14 x 40; LogUp pairs 3, 3, 2, 4, 8, 1 (zktls_amd.device.SP1_SHAPED_SPEC)
+    static MachinePlan sp1_shaped(uint32_t shards = 1);
+};
+
 class HipGuestProver : public ZkProver {
 public:
     explicit HipGuestProver(int device = 0, Backend backend = Backend::Sp1) : devices_{device}, backend_(backend) {}
@@ -92,6 +115,12 @@ public:
     HipGuestProver& network() { mode_ = ProverType::Network; return *this; }
     // explicit opt-in to the synthetic shard plan (no zkVM executor wired): see the header comment
     HipGuestProver& with_synthetic(const ShardPlan& p) { plan_ = p; synthetic_ = true; return *this; }
+    // ... or to synthetic shards in SP1's shard STRUCTURE: several chips of mixed heights, lookups inside and across tables, preprocessed columns --
+    // every shard one keyed-machine proof, checked against the key like sp1.rs:120 (blob flags SYNTHETIC | MACHINE; the result's vk = the key's
+    // root + the program's digest, what setup() returns).  with_compress(): the shard proofs are verified in-circuit in machine mode
+    // (zkhip_prove_machine_verifier: lookups, mixed heights, the preprocessed openings against the key) -- ONE proof while the shards fit one join
+    // (64, or a Poseidon2 chip of 2^22 rows), else equal joins and ONE proof above them (flag TREE).  verify_machine_blob checks either blob on the host.
+    HipGuestProver& with_synthetic_machine(const MachinePlan& p) { mplan_ = p; machine_ = true; synthetic_ = true; return *this; }
     // the input-commitment guest (see the header comment); num_queries / pow_bits of the proof come from `p`
     HipGuestProver& with_input_commitment(const ShardPlan& p = ShardPlan{}) { plan_ = p; commitment_ = true; return *this; }
     // the COMPRESS stage behind the same call (sp1.rs:116: core -> compress; prover.rs:90: lift -> join): after the shards are proven, ONE
@@ -117,6 +146,8 @@ private:
     std::vector<int> devices_;
     Backend backend_ = Backend::Sp1;
     ShardPlan plan_;
+    MachinePlan mplan_;
+    bool machine_ = false;
     bool synthetic_ = false;
     bool commitment_ = false;
     bool compress_ = false;
@@ -152,6 +183,7 @@ uint32_t compress_join_size(const ShardPlan& plan);
 // verifier machine, csrc/machine_verifier.inl): the blob carries that proof alone and the flag TREE
 void set_compress_join_size(uint32_t shard_proofs_per_join);
 constexpr uint32_t BATCH_FLAG_TREE = 32u;            // with COMPRESSED: several joins were needed and were joined again: entry 0 = the ONE proof above them
+constexpr uint32_t BATCH_FLAG_MACHINE = 64u;         // with SYNTHETIC: every shard is a keyed-MACHINE proof (MachinePlan); with COMPRESSED the joins are machine-mode proofs and the last entry = the join's key (8 LE words) + the shard count
 constexpr uint32_t BATCH_FLAG_KEYED = 4u;            // with INPUT_SHA256: the proof is the keyed SHA-256 MACHINE's (chip + range table), checked against a vk
 // a consumer's check of an input-commitment blob on the CPU: the blob's proof(s) against the claimed output (SHA-256 of the input).
 // The caller says what it EXPECTS, the blob's own flags only have to agree: a 64-byte `vk` (from setup) means "a KEYED proof under this
@@ -175,6 +207,14 @@ ProveResult compress_blob(int device, const ShardPlan& plan, const std::vector<u
 bool compress_key(int device, const ShardPlan& plan, uint32_t key[8], std::string* error = nullptr);
 // the same key computed on the host's cores (no device, no context): a verifier that owns no GPU checks a compressed blob with this and verify_compressed_blob
 bool compress_key_host(const ShardPlan& plan, uint32_t key[8], std::string* error = nullptr);
+// A MACHINE blob against the request it was made for, on the host: vk = the 64 bytes setup() / prove() returned (the machine key's root + the program's
+// digest, which must be request_digest("", elf)).  Plain: every shard proof under (the plan's machine, digest | s, the key).  COMPRESSED: the join's key
+// -- and with TREE the top's -- is DERIVED here from (the plan, the key's root, the shard count): no byte of a shard proof is needed.
+// 0, or -1 (malformed / another plan / another program) / -2 (a proof is rejected; *reason = the failing check)
+int verify_machine_blob(const std::vector<uint8_t>& blob, const MachinePlan& plan, const std::vector<uint8_t>& cbor, const std::vector<uint8_t>& elf,
+                        const std::vector<uint8_t>& vk, int* reason = nullptr);
+// shard proofs per machine-mode join for `plan` (the most one join takes, bounded by set_compress_join_size; equal joins beyond)
+uint32_t machine_join_size(const MachinePlan& plan);
 std::vector<uint8_t> pack_shard_proofs(const std::vector<std::vector<uint8_t>>& proofs, uint32_t flags);
 bool unpack_shard_proofs(const std::vector<uint8_t>& blob, std::vector<std::vector<uint8_t>>* proofs, uint32_t* flags = nullptr);
 
