@@ -1014,6 +1014,9 @@ def main():
             t0_ = time.perf_counter()
             okm_ = mvk_ == mvk2_ and ML.zktls_verify_machine_blob(bm_cc, len(bm_cc), C_.byref(mplan_), ecbor, len(ecbor), eelf, len(eelf), mvk_, None) == 0
             tm_ev = time.perf_counter() - t0_
+            t0_ = time.perf_counter()
+            okm_ = okm_ and ML.zktls_verify_machine_blob(bm_cc, len(bm_cc), C_.byref(mplan_), ecbor, len(ecbor), eelf, len(eelf), mvk_, None) == 0
+            tm_ev2 = time.perf_counter() - t0_
             okm_ = okm_ and ML.zktls_verify_machine_blob(bm_cc, len(bm_cc), C_.byref(mplan_), ecbor + b"!", len(ecbor) + 1, eelf, len(eelf), mvk_, None) == -2
             mcells_ = sum(c_[1] << c_[0] for c_ in SP1_SHAPED_SPEC)
             execution["multichip"] = {
@@ -1021,7 +1024,8 @@ def main():
                     ",".join("%dx%d" % (c_[0], c_[1]) for c_ in SP1_SHAPED_SPEC)),
                 "core_ms": round(tm_core * 1e3, 1), "core_ms_per_shard": round(tm_core * 1e3 / 22, 2), "core_trace_cells_per_s": round(22 * mcells_ / tm_core, 1), "core_blob_bytes": len(bm_core),
                 "core_plus_compress_ms": round(tm_cc * 1e3, 1), "compressed_blob_bytes": len(bm_cc), "compressed_blob_verified_on_host_and_another_request_refused": bool(okm_),
-                "compressed_blob_host_verify_ms": round(tm_ev * 1e3, 2)}
+                "compressed_blob_host_verify_ms_with_the_join_key_derived": round(tm_ev * 1e3, 2), "compressed_blob_host_verify_ms": round(tm_ev2 * 1e3, 2),
+                "note": "the join's key is a function of (plan, vk): the verifier derives it on its host cores once per plan (the first figure) and keeps it (the second)"}
             ML.zktls_release_cached()
         except Exception as e_:
             execution["multichip"] = {"error": repr(e_)}

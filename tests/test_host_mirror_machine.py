@@ -213,10 +213,10 @@ def test_machine_shards_through_the_plug_point_bytes_equal_the_oracles(lib, orac
 
 
 @pytest.mark.gpu
-def test_machine_shards_core_to_compress_behind_the_same_call(lib, oracle):
+def test_machine_shards_core_to_compress_behind_the_same_call(lib, ctx):
     """core -> compress (sp1.rs:116) for machine shards: ONE machine-mode proof replaces the shard proofs in the blob -- its bytes == zkhip_prove_machine_verifier's on the
     shard proofs of the plain call --; with joins of at most two, five shards -> three joins -> ONE proof above them (flag TREE).  Both checked on the host from (plan, input, ELF, vk)"""
-    from zktls_amd.device import Context, Sp1ShapedShard, InnerMachine
+    from zktls_amd.device import Sp1ShapedShard
     from zktls_amd._lib import Params
     q, pb = 3, 1
     plan = mplan(SP1_SMALL, PRE, 3, q, pb)
@@ -233,11 +233,12 @@ def test_machine_shards_core_to_compress_behind_the_same_call(lib, oracle):
     im = shape.inner_machine(np.frombuffer(vk[:32], dtype=np.uint32), prm)
     dg = digest_words(lib, CBOR, ELF)
     shard_proofs = [np.frombuffer(e, dtype=np.uint8) for e in entries(lib, plain)[0]]
-    with Context(0) as ctx:
-        jkey = ctx.machine_verifier_setup(im, prm, 3)
-        assert jkey.root.tobytes() == ent[1][:32]
-        assert ctx.prove_machine_verifier(jkey, im, shard_proofs, [dg + [s] for s in range(3)], prm).tobytes() == ent[0]
-        jkey.close()
+    jkey = ctx.machine_verifier_setup(im, prm, 3)
+    assert jkey.root.tobytes() == ent[1][:32]
+    assert ctx.prove_machine_verifier(jkey, im, shard_proofs, [dg + [s] for s in range(3)], prm).tobytes() == ent[0]
+    jkey.close()
+    rc, err, _, again, _ = prove(lib, 2, plan, compress=1)                        # the second request of a plan finds the join's key parked with its context: the same bytes
+    assert rc == 0 and again == blob
     assert check(lib, blob, plan, vk) == 0
     assert check(lib, blob, plan, vk, cbor=CBOR + b"!") == -2
     assert check(lib, plain, plan, vk) == 0

@@ -3,6 +3,7 @@
 #include "guest_prover_hip.hpp"
 
 #include <cstdlib>
+#include <array>
 #include <atomic>
 #include <algorithm>
 #include <cstring>
@@ -438,6 +439,66 @@ std::vector<uint32_t> machine_publics(const std::vector<uint32_t>& digest, uint3
 }
 }  // namespace
 
+namespace {
+// A recursion machine's key is a function of (the inner machine's description, the number of proofs, the outer shape, the Poseidon2 tables): deriving it on the host
+// commits the machine's preprocessed traces (hundreds of milliseconds at the bench's shapes), so a verifier that checks many blobs of one plan derives it ONCE --
+// the cache is keyed by the description's exact bytes, nothing of a blob enters it
+std::mutex g_derived_mu;
+std::vector<std::pair<std::string, std::array<uint32_t, 8>>> g_derived;
+std::string desc_bytes(const zkhip_machine_desc& d, size_t n_proofs, const zkhip_params& outer) {
+    std::string b;
+    auto put = [&](const void* p, size_t n) { b.append((const char*)p, n); };
+    const uint64_t gen = zkhip_poseidon2_params_generation(), np = n_proofs;
+    put(&gen, 8); put(&np, 8); put(&outer, sizeof outer);
+    put(&d.n_chips, 4); put(d.key_root, 32); put(&d.num_queries, 4); put(&d.pow_bits, 4); put(&d.n_public, 4);
+    for (int c = 0; c < d.n_chips; c++) {
+        put(&d.log_ns[c], 4); put(&d.widths[c], 4); put(&d.pre_widths[c], 4);
+        const uint64_t pw = d.program_words[c], tw = d.tables[c] ? d.table_words[c] : 0;
+        put(&pw, 8); put(d.programs[c], pw * 4);
+        put(&tw, 8); if (tw) put(d.tables[c], tw * 4);
+    }
+    return b;
+}
+bool machine_verifier_key_host_cached(const zkhip_machine_desc& d, size_t n_proofs, const zkhip_params& outer, uint32_t key[8]) {
+    const std::string id = desc_bytes(d, n_proofs, outer);
+    {
+        std::lock_guard<std::mutex> lk(g_derived_mu);
+        for (auto& e : g_derived)
+            if (e.first == id) { std::memcpy(key, e.second.data(), 32); return true; }
+    }
+    if (zkhip_machine_verifier_key_host(&d, n_proofs, &outer, key) != ZKHIP_OK) return false;
+    std::array<uint32_t, 8> k;
+    std::memcpy(k.data(), key, 32);
+    std::lock_guard<std::mutex> lk(g_derived_mu);
+    if (g_derived.size() >= 8) g_derived.erase(g_derived.begin());
+    g_derived.emplace_back(id, k);
+    return true;
+}
+
+// the machine-mode join's proving key (the join machine's preprocessed traces on the device) with the context that made it: a function of (plan, the shard machine's
+// key, J), parked between requests like the single-matrix path's JoinKey
+struct MachineJoinKey { int device; std::string id; zkhip_ctx* ctx; zkhip_machine_key* key; uint32_t vk[8]; };
+std::vector<MachineJoinKey> g_machine_join_keys;       // (under g_slots_mu)
+bool take_machine_join_key(int device, const std::string& id, MachineJoinKey* out) {
+    std::lock_guard<std::mutex> lk(g_slots_mu);
+    for (size_t i = 0; i < g_machine_join_keys.size(); i++)
+        if (g_machine_join_keys[i].device == device && g_machine_join_keys[i].id == id) {
+            *out = g_machine_join_keys[i];
+            g_machine_join_keys.erase(g_machine_join_keys.begin() + (long)i);
+            return true;
+        }
+    return false;
+}
+void park_machine_join_key(const MachineJoinKey& k) {
+    {
+        std::lock_guard<std::mutex> lk(g_slots_mu);
+        if (g_machine_join_keys.size() < 2) { g_machine_join_keys.push_back(k); return; }
+    }
+    zkhip_machine_key_destroy(k.key);
+    zkhip_ctx_destroy(k.ctx);
+}
+}  // namespace
+
 MachinePlan MachinePlan::sp1_shaped(uint32_t shards) {
     MachinePlan p;
     p.chips = {ChipPlan{20, 96, 3, 1, 0}, ChipPlan{20, 32, 3, 0, 0}, ChipPlan{19, 64, 2, -1, 0}, ChipPlan{18, 128, 4, -1, 0}, ChipPlan{16, 256, 8, -1, 32}, ChipPlan{14, 40, 1, -1, 0}};
@@ -472,17 +533,33 @@ static std::vector<uint8_t> compress_machine_proofs(int device, const MachinePla
     if (jcap == 0) throw std::runtime_error(std::string("zkhip_machine_verifier_proof_size: ") + zkhip_last_error());
     struct Guard {
         zkhip_ctx* ctx = nullptr; zkhip_machine_key* jkey = nullptr; zkhip_machine_key* tkey = nullptr;
+        int device = 0; std::string id; uint32_t vk[8] = {0}; bool done = false;
         ~Guard() {
             if (!ctx) return;
             (void)zkhip_ctx_sync(ctx);
-            if (jkey) zkhip_machine_key_destroy(jkey);
             if (tkey) zkhip_machine_key_destroy(tkey);
+            if (done && jkey) {                           // the stage went through: the pair is parked for the next request of this plan
+                MachineJoinKey k{device, id, ctx, jkey, {0}};
+                std::memcpy(k.vk, vk, 32);
+                park_machine_join_key(k);
+                return;
+            }
+            if (jkey) zkhip_machine_key_destroy(jkey);
             zkhip_ctx_destroy(ctx);
         }
     } g;
-    if (zkhip_ctx_create(device, nullptr, &g.ctx) != ZKHIP_OK) { g.ctx = nullptr; fail_zkhip("zkhip_ctx_create"); }
+    g.device = device;
+    g.id = desc_bytes(m.desc, J, outer);
     uint32_t jvk[8];
-    if (zkhip_machine_verifier_setup(g.ctx, &m.desc, J, &outer, &g.jkey, jvk) != ZKHIP_OK) { g.jkey = nullptr; fail_zkhip("zkhip_machine_verifier_setup"); }
+    MachineJoinKey parked{};
+    if (take_machine_join_key(device, g.id, &parked)) {
+        g.ctx = parked.ctx; g.jkey = parked.key;
+        std::memcpy(jvk, parked.vk, 32);
+    } else {
+        if (zkhip_ctx_create(device, nullptr, &g.ctx) != ZKHIP_OK) { g.ctx = nullptr; fail_zkhip("zkhip_ctx_create"); }
+        if (zkhip_machine_verifier_setup(g.ctx, &m.desc, J, &outer, &g.jkey, jvk) != ZKHIP_OK) { g.jkey = nullptr; fail_zkhip("zkhip_machine_verifier_setup"); }
+    }
+    std::memcpy(g.vk, jvk, 32);
     const std::vector<uint32_t> pvs = machine_publics(digest, J, n_joins, plan.shards);
     std::vector<std::vector<uint8_t>> entries;
     for (uint32_t c = 0; c < n_joins; c++) {
@@ -527,6 +604,7 @@ static std::vector<uint8_t> compress_machine_proofs(int device, const MachinePla
             flags_extra = BATCH_FLAG_TREE;
         }
     }
+    g.done = true;
     std::vector<uint8_t> tail(36);
     std::memcpy(tail.data(), jvk, 32);
     const uint32_t cnt = plan.shards;
@@ -568,14 +646,14 @@ int verify_machine_blob(const std::vector<uint8_t>& blob, const MachinePlan& pla
         if (cnt != plan.shards) return -1;
         const uint32_t J = machine_join_size(plan), n_joins = (cnt + J - 1) / J;
         uint32_t jvk[8];
-        if (zkhip_machine_verifier_key_host(&m.desc, J, &prm, jvk) != ZKHIP_OK) return -1;  // the join's key is DERIVED: the blob's copy is informative
+        if (!machine_verifier_key_host_cached(m.desc, J, prm, jvk)) return -1;               // the join's key is DERIVED (once per plan and key): the blob's copy is informative
         const std::vector<uint32_t> pvs = machine_publics(digest, J, n_joins, cnt);
         if (flags & BATCH_FLAG_TREE) {
             if (n_joins < 2 || entries.size() != 2) return -1;
             MachineHolder jm;
             jm.build_described(m.desc, J, jvk, plan.num_queries, plan.pow_bits, MACHINE_PUBLICS * J);
             uint32_t tvk[8];
-            if (zkhip_machine_verifier_key_host(&jm.desc, n_joins, &prm, tvk) != ZKHIP_OK) return -1;
+            if (!machine_verifier_key_host_cached(jm.desc, n_joins, prm, tvk)) return -1;
             const int rc = zkhip_verify_machine_recursive(&jm.desc, entries[0].data(), entries[0].size(), pvs.data(), MACHINE_PUBLICS * J, n_joins, tvk, &prm, &why);
             if (reason) *reason = why;
             return rc == ZKHIP_OK ? 0 : -2;
@@ -1114,7 +1192,7 @@ int verify_compressed_blob(const std::vector<uint8_t>& blob, const ShardPlan& pl
         JoinMachine jm;
         if (!jm.build(plan, J, key)) return -1;
         uint32_t tvk[8];
-        if (zkhip_machine_verifier_key_host(&jm.desc, n_joins, &outer, tvk) != ZKHIP_OK) return -1;
+        if (!machine_verifier_key_host_cached(jm.desc, n_joins, outer, tvk)) return -1;      // (derived once per plan and join key: hundreds of milliseconds at the bench's shape)
         std::vector<uint32_t> pvs;
         for (uint32_t c = 0; c < n_joins; c++)
             for (uint32_t k = 0; k < J; k++) {
@@ -1196,6 +1274,10 @@ void release_cached() {
     std::vector<JoinKey> keys;
     { std::lock_guard<std::mutex> lk(g_slots_mu); keys.swap(g_join_keys); }
     for (auto& k : keys) { zkhip_machine_key_destroy(k.key); zkhip_ctx_destroy(k.ctx); }
+    std::vector<MachineJoinKey> mkeys;
+    { std::lock_guard<std::mutex> lk(g_slots_mu); mkeys.swap(g_machine_join_keys); }
+    for (auto& k : mkeys) { zkhip_machine_key_destroy(k.key); zkhip_ctx_destroy(k.ctx); }
+    { std::lock_guard<std::mutex> lk(g_derived_mu); g_derived.clear(); }
     for (auto& e : all) { if (e.key) zkhip_machine_key_destroy(e.key); zkhip_free(e.ctx, e.d_trace); zkhip_ctx_destroy(e.ctx); }
 }
 
