@@ -696,14 +696,16 @@ def main():
             kproofs = [pf for _, pf in res_l]
             kpubs = [statement(d, len(m)) for (d, _), m in zip(res_l, msgs)]
             t_k, ktop = 1e9, None
+            kcpu0, kwall0 = time.process_time(), time.perf_counter()
             for _ in range(3):
                 tb0 = time.perf_counter()
                 ktop = ctx.prove_machine_verifier(kkey, kim, kproofs, kpubs, tprm)
                 t_k = min(t_k, time.perf_counter() - tb0)
+            k_cores = (time.process_time() - kcpu0) / (time.perf_counter() - kwall0)
             ok_k = _vmr(kim, ktop, [v for pv_ in kpubs for v in pv_], kkey.root, tprm, 64) == (0, 0)
             kkey.close()
             batch64["compressed_keyed"] = {"workload": "the 64 KEYED proofs of the zkhip_prove_transcripts call above -> ONE proof: zkhip_prove_machine_verifier (machine mode: lookups, two heights, the preprocessed table's openings against the machine's key, in-circuit)",
-                                           "compress_ms": round(t_k * 1e3, 2), "ms": round((t_lock + t_k) * 1e3, 2), "inner_bytes_total": int(sum(x.size for x in kproofs)),
+                                           "compress_ms": round(t_k * 1e3, 2), "host_cores_busy": round(k_cores, 2), "ms": round((t_lock + t_k) * 1e3, 2), "inner_bytes_total": int(sum(x.size for x in kproofs)),
                                            "bytes": int(ktop.size), "compression": round(sum(x.size for x in kproofs) / ktop.size, 2), "verified": bool(ok_k)}
 
     # ---- the compress-like step (sp1.rs:116: core -> compress verifies the shard proofs): the FRI check of sixteen shard proofs of the headline
@@ -787,10 +789,12 @@ def main():
             # exists, beside the joins still being proven -- after the last join only the uploads and the machine's proof remain.  Same bytes.
             from zktls_amd.device import prove_shard_tree
             t_one = 1e9
+            tcpu0, twall0 = time.process_time(), time.perf_counter()
             for _ in range(3):
                 tb0 = time.perf_counter()
                 top1, joins1, jvk1 = prove_shard_tree(ctx, tkey2, im_, tsps, 16, log_n, width, tspv, prm, prm, prm, devices=[local_rank], in_flight=4)
                 t_one = min(t_one, time.perf_counter() - tb0)
+            tree_cores = (time.process_time() - tcpu0) / (time.perf_counter() - twall0)      # CPU time of ALL threads of the process per second of the calls
             assert top1.tobytes() == top.tobytes() and all(a_.tobytes() == b_.tobytes() for a_, b_ in zip(joins1, joins4))
             tb0 = time.perf_counter()
             ok_tree = verify_machine_recursive(im_, top, [v for p_ in jp for v in p_], machine_verifier_key_host(im_, prm, 4), prm, 4) == (0, 0)
@@ -798,6 +802,7 @@ def main():
             assert jvk.tolist() == tkey1.root.tolist()
             tree = {"workload": "64 shard proofs (2^20 x 256, 100 queries) -> 4 joins of 16 (zkhip_prove_shard_verifier_batch: the four in flight on pooled contexts, as the shards below them are) -> ONE proof (zkhip_prove_machine_verifier: the four joins' version-11 proofs verified in-circuit, ten chips)",
                     "ms": round(t_one * 1e3, 2), "entry": "zkhip_prove_shard_tree (one call: the four joins in flight, each one's tables for the top filled the moment it exists, then the machine's proof)",
+                    "host_cores_busy": round(tree_cores, 2), "host_wait": "block" if wait_block else "poll",
                     "two_calls_ms": round((t_joins + t_top) * 1e3, 2), "joins_ms": round(t_joins * 1e3, 2), "top_ms": round(t_top * 1e3, 2), "inner_bytes_total": int(sum(x.size for x in tsps)),
                     "join_bytes_total": int(sum(x.size for x in joins4)), "bytes": int(top.size), "compression": round(sum(x.size for x in tsps) / top.size, 2),
                     "host_verify_ms_with_the_key_derived_on_the_host": round(t_tv * 1e3, 2), "verified": bool(ok_tree),
