@@ -969,6 +969,18 @@ int fill_one(const Shape& sh, const Machine& m, int p, const uint8_t* inner, siz
     const uint32_t width = (uint32_t)W;
     const size_t n_public = (size_t)sh.NPUB;
     const bool on_device = dev_vals != nullptr;        // ROWSUM, QUERY, the fold chains and the layers' pairs are the device's (shard_verifier_prove_impl)
+#ifdef ZKHIP_AB_HOOKS
+    static const bool sec_timing = getenv("ZKHIP_REC_SECTIONS") != nullptr;
+    auto sec_t = std::chrono::steady_clock::now();
+    auto sec = [&](const char* what) {
+        if (!sec_timing) return;
+        const auto now = std::chrono::steady_clock::now();
+        std::fprintf(stderr, "      [fill_one %d] %-28s %8.1f us\n", p, what, std::chrono::duration<double, std::micro>(now - sec_t).count());
+        sec_t = now;
+    };
+#else
+    auto sec = [](const char*) {};
+#endif
     wt.lroots.resize(8 * (size_t)R);
     if (!on_device) {
         // (a) one host pass: the verifier accepts the proof and hands out the FRI side; the rest is read off the words (docs/PROTOCOL.md section 6)
@@ -997,6 +1009,7 @@ int fill_one(const Shape& sh, const Machine& m, int p, const uint8_t* inner, siz
     for (int l = 0; l < R; l++) wt.per_query += 4 + 8 * (size_t)(H - 1 - l);
     if (words.size() != wt.o_queries + (size_t)Q * wt.per_query) return fail(ZKHIP_ERR_INTERNAL, "prove_shard_verifier: unexpected proof length");
     const uint32_t* pw = wt.w;
+    sec("checks + words");
     // (b) the transcript's sponge chain on the host (NT permutations): the input state of every row, the challenges, the sampled words
     std::vector<uint32_t> chain_in(16 * (size_t)sh.NT), samples(8 * (size_t)sh.NS);
     std::vector<Ext> chal((size_t)sh.NT);
@@ -1040,6 +1053,7 @@ int fill_one(const Shape& sh, const Machine& m, int p, const uint8_t* inner, siz
     }
     const Ext alpha = chal[(size_t)sh.TA], zeta = chal[(size_t)sh.TQ], fa = chal[(size_t)sh.TF];
     *fa_out = fa;
+    sec("transcript");
     // (c) the scalars: row p of SCALARS
     const ScCols scc = sc_cols(sh);
     const uint32_t scp = sc_pre(sh), sc_w = rup4(scc.end - scp);
@@ -1075,6 +1089,7 @@ int fill_one(const Shape& sh, const Machine& m, int p, const uint8_t* inner, siz
     zps_consts(sh, za, zb);
     const Ext quo = ext_add(ext_mul(ext_add_base(ext_mul_base(znn, to_monty(za[0])), to_monty(zb[0])), qk[0]), ext_mul(ext_add_base(ext_mul_base(znn, to_monty(za[1])), to_monty(zb[1])), qk[1]));
     scput(scc.QUO, quo);
+    sec("scalars");
     // (d) OPENED: the opened values, their fa-weighted sums, the AIR folded with alpha.  The rows behind the last proof carry ITS constants.
     const size_t op_rows = (size_t)1 << m.height[C_OPENED];
     const size_t op_lo = (size_t)p * (size_t)sh.G, op_hi = p + 1 == sh.NP ? op_rows : op_lo + (size_t)sh.G;
@@ -1150,6 +1165,7 @@ int fill_one(const Shape& sh, const Machine& m, int p, const uint8_t* inner, siz
     if (!ext_eq(res_acc, ext_mul(quo, ext_sub_base(znn, MONTY_R1))))
         return fail(on_device ? ZKHIP_ERR_VERIFY : ZKHIP_ERR_INTERNAL, on_device ? "prove_shard_verifier: proof " + std::to_string(p) + " rejected: the constraints do not match the quotient at zeta"
                                                                        : std::string("prove_shard_verifier: the AIR identity at zeta does not hold"));
+    sec("opened + eval");
     // (e) ROWSUM
     std::vector<Ext> at((size_t)Q), aq((size_t)Q);
     if (!on_device) {
@@ -1196,6 +1212,7 @@ int fill_one(const Shape& sh, const Machine& m, int p, const uint8_t* inner, siz
             put(qc.RO, ro); put(qc.AT, at[r]); put(qc.AQ, aq[r]); put(qc.I1, i1); put(qc.I2, i2); put(qc.P1, p1); put(qc.P2, p2); put(qc.P2O, p2o); put(qc.P3, p3); put(qc.P3O, p3o);
         }
     }
+    sec("rowsum + query");
     // (g) TS
     for (int T = 0; T < sh.NTS; T++) {
         uint32_t* row = ht.ts.data() + (size_t)TS_MAIN * ((size_t)p * (size_t)sh.NTS + (size_t)T);
@@ -1203,6 +1220,7 @@ int fill_one(const Shape& sh, const Machine& m, int p, const uint8_t* inner, siz
         if (sh.has_challenge(T)) put_ext(row, 16, chal[(size_t)T]);
         if (T == sh.HL / 8) for (int j = 0; j < 8; j++) row[8 + j] = to_monty(pw[wt.o_troot + j]);
     }
+    sec("ts");
     // (h) SAMPLES: this proof's NS rows
     {
         std::vector<uint32_t> t_sm, drawn;
@@ -1258,6 +1276,7 @@ int fill_one(const Shape& sh, const Machine& m, int p, const uint8_t* inner, siz
         if (row != row0 + sh.p2_rows || ch != chains_per) return fail(ZKHIP_ERR_INTERNAL, "prove_shard_verifier: row layout");
         return ZKHIP_OK;
     }
+    sec("samples");
     // (i) this proof's entries of the P2R work lists: transcript rows, then Q R FRI paths (leaf block = the pair), Q trace openings, Q quotient openings
     {
         // (every proof writes ITS slices of the shared lists: the proofs are filled side by side on a few host threads)
@@ -1305,6 +1324,7 @@ int fill_one(const Shape& sh, const Machine& m, int p, const uint8_t* inner, siz
             }
         if (row != row0 + sh.p2_rows || ch != chains_per) return fail(ZKHIP_ERR_INTERNAL, "prove_shard_verifier: row layout");
     }
+    sec("work lists");
     return ZKHIP_OK;
 }
 }  // namespace
