@@ -64,6 +64,12 @@ extern "C" {
     pub fn zkhip_memcpy_h2d(ctx: *mut ZkhipCtx, d_dst: *mut c_void, h_src: *const c_void, bytes: usize) -> c_int;
     pub fn zkhip_to_monty(ctx: *mut ZkhipCtx, d_in: *const u32, d_out: *mut u32, n: usize) -> c_int;
     pub fn zkhip_gen_trace(ctx: *mut ZkhipCtx, seed: u64, shard: u64, log_n: c_int, width: u32, d_out: *mut u32, ld: usize) -> c_int;
+    pub fn zkhip_gen_trace_logup(ctx: *mut ZkhipCtx, seed: u64, shard: u64, log_n: c_int, width: u32, pairs: c_int, d_out: *mut u32, ld: usize) -> c_int;
+    pub fn zkhip_gen_trace_logup_cross(ctx: *mut ZkhipCtx, seed: u64, shard: u64, partner_shard: u64, log_n: c_int, width: u32, partner_width: u32, pairs: c_int,
+                                       d_out: *mut u32, ld: usize) -> c_int;
+    pub fn zkhip_air_synthetic(width: u32, n_public: usize, out: *mut u32, cap: usize, words: *mut usize) -> c_int;
+    pub fn zkhip_machine_proof_size_keyed(log_ns: *const i32, widths: *const u32, pre_widths: *const u32, programs: *const *const u32, program_words: *const usize,
+                                          tables: *const *const u32, table_words: *const usize, n_chips: c_int, prm: *const ZkhipParams, n_public: usize) -> usize;
     pub fn zkhip_proof_size(log_n: c_int, width: u32, prm: *const ZkhipParams, n_public: usize) -> usize;
     pub fn zkhip_prove_shard(
         ctx: *mut ZkhipCtx, d_trace: *const u32, ld: usize, log_n: c_int, width: u32,

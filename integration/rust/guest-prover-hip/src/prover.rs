@@ -459,3 +459,157 @@ pub fn verify_compressed(proof: &[u8], log_n: i32, width: u32, public_values: &[
                                           vk.as_ptr(), outer, &mut reason)
     }, "zkhip_verify_shard_recursive")
 }
+
+
+// ---- shards in SP1's shard STRUCTURE (the C++ mirror's MachinePlan, zktls_amd/host/guest_prover_hip.hpp): chips of mixed heights, LogUp pairs inside and
+// across tables, preprocessed columns committed by setup -- every shard ONE keyed-machine proof (version 11), the compress stage in machine mode ----
+
+/// One chip of a machine shard: `2^log_n x width` columns `[preprocessed | main]` under the synthetic AIR, `pairs` LogUp pairs as an interaction table
+/// (in-table when `partner < 0`, else exchanged with the chip `partner` of the same height), `pre_width` leading columns committed once by `machine_setup`.
+#[derive(Clone, Copy, Debug)]
+pub struct ChipPlan { pub log_n: i32, pub width: u32, pub pairs: u32, pub partner: i32, pub pre_width: u32 }
+
+/// The keyed machine of a plan: programs, interaction tables, heights and widths as the library's entries take them.
+pub struct MachineShape {
+    pub chips: Vec<ChipPlan>,
+    progs: Vec<Vec<u32>>, tabs: Vec<Vec<u32>>, pp: Vec<*const u32>, tp: Vec<*const u32>, pw: Vec<usize>, tw: Vec<usize>,
+    lns: Vec<i32>, widths: Vec<u32>, pres: Vec<u32>,
+}
+const LKUP_MAGIC: u32 = 0x5055_4B4C;
+const BUS_SP1: u32 = 300;
+const KEY_SHARD: u64 = 9999;
+const MACHINE_PUBLICS: usize = 9;             // request digest | shard index
+
+impl MachineShape {
+    /// bench.py's `multichip` shard: 2^20 x 96 and 2^20 x 32 looking each other up, 2^19 x 64, 2^18 x 128, 2^16 x 256 (32 preprocessed columns), 2^14 x 40
+    pub fn sp1_shaped() -> Result<Box<Self>> {
+        Self::new(vec![ChipPlan { log_n: 20, width: 96, pairs: 3, partner: 1, pre_width: 0 }, ChipPlan { log_n: 20, width: 32, pairs: 3, partner: 0, pre_width: 0 },
+                       ChipPlan { log_n: 19, width: 64, pairs: 2, partner: -1, pre_width: 0 }, ChipPlan { log_n: 18, width: 128, pairs: 4, partner: -1, pre_width: 0 },
+                       ChipPlan { log_n: 16, width: 256, pairs: 8, partner: -1, pre_width: 32 }, ChipPlan { log_n: 14, width: 40, pairs: 1, partner: -1, pre_width: 0 }])
+    }
+    pub fn new(chips: Vec<ChipPlan>) -> Result<Box<Self>> {
+        anyhow::ensure!(!chips.is_empty() && chips.len() <= 16 && chips.iter().any(|c| c.pre_width != 0), "machine plan: 1 to 16 chips, one of them with preprocessed columns");
+        let mut m = Box::new(MachineShape { chips, progs: vec![], tabs: vec![], pp: vec![], tp: vec![], pw: vec![], tw: vec![], lns: vec![], widths: vec![], pres: vec![] });
+        for (c, ch) in m.chips.clone().iter().enumerate() {
+            anyhow::ensure!(c == 0 || ch.log_n <= m.chips[c - 1].log_n, "machine plan: chips tallest first");
+            anyhow::ensure!(ch.width % 4 == 0 && 8 * ch.pairs <= ch.width, "machine plan: widths in multiples of 4, 8 columns per LogUp pair");
+            anyhow::ensure!(ch.pre_width == 0 || (ch.pre_width % 8 == 0 && ch.pre_width < ch.width && ch.partner < 0), "machine plan: preprocessed columns are whole in-table pairs");
+            if ch.partner >= 0 {
+                let o = m.chips.get(ch.partner as usize).ok_or_else(|| anyhow!("machine plan: partner out of range"))?;
+                anyhow::ensure!(o.partner == c as i32 && o.log_n == ch.log_n && o.pairs == ch.pairs, "machine plan: partners are mutual, of one height and one pair count");
+            }
+            let mut words = 0usize;
+            check(unsafe { ffi::zkhip_air_synthetic(ch.width, MACHINE_PUBLICS, std::ptr::null_mut(), 0, &mut words) }, "zkhip_air_synthetic")?;
+            let mut prog = vec![0u32; words];
+            check(unsafe { ffi::zkhip_air_synthetic(ch.width, MACHINE_PUBLICS, prog.as_mut_ptr(), words, &mut words) }, "zkhip_air_synthetic")?;
+            let mut tab = vec![LKUP_MAGIC, 2 * ch.pairs, 0];
+            for q in 0..ch.pairs {
+                let to = if ch.partner < 0 { c as u32 } else { ch.partner as u32 };
+                tab.extend_from_slice(&[0, u32::MAX, BUS_SP1 + 16 * c as u32 + q, 2, 8 * q, 8 * q + 1]);            // send (a, b) of group 2q
+                tab.extend_from_slice(&[1, u32::MAX, BUS_SP1 + 16 * to + q, 2, 8 * q + 4, 8 * q + 5]);               // receive at group 2q + 1
+            }
+            tab[2] = tab.len() as u32;
+            m.progs.push(prog);
+            m.tabs.push(if ch.pairs > 0 { tab } else { vec![] });
+            m.lns.push(ch.log_n); m.widths.push(ch.width - ch.pre_width); m.pres.push(ch.pre_width);
+        }
+        m.pp = m.progs.iter().map(|v| v.as_ptr()).collect();
+        m.tp = m.tabs.iter().map(|v| if v.is_empty() { std::ptr::null() } else { v.as_ptr() }).collect();
+        m.pw = m.progs.iter().map(|v| v.len()).collect(); m.tw = m.tabs.iter().map(|v| v.len()).collect();
+        Ok(m)
+    }
+    /// the machine as the INNER machine of machine mode (zkhip_machine_desc): `key_root` from `machine_setup`
+    pub fn desc(&self, key_root: &[u32; 8], prm: &ZkhipParams) -> ffi::ZkhipMachineDesc {
+        ffi::ZkhipMachineDesc { n_chips: self.chips.len() as i32, log_ns: self.lns.as_ptr(), widths: self.widths.as_ptr(), pre_widths: self.pres.as_ptr(), programs: self.pp.as_ptr(),
+                                program_words: self.pw.as_ptr(), tables: self.tp.as_ptr(), table_words: self.tw.as_ptr(), key_root: *key_root, num_queries: prm.num_queries,
+                                pow_bits: prm.pow_bits, n_public: MACHINE_PUBLICS as u32 }
+    }
+}
+
+fn stream_seed(digest: &[u32; 8]) -> u64 { digest[..4].iter().fold(0u64, |h, w| (h << 16) ^ (*w as u64)) }
+
+/// `client.setup(elf)` (sp1.rs:113) for a machine plan: the preprocessed columns -- a function of the PROGRAM -- committed on `ctx`.  The key belongs to `ctx`.
+pub fn machine_setup(ctx: &Context, shape: &MachineShape, elf: &[u8], prm: &ZkhipParams) -> Result<(*mut ffi::ZkhipMachineKey, [u32; 8])> {
+    let mut pd = [0u32; 8];
+    check(unsafe { ffi::zkhip_request_digest(std::ptr::null(), 0, elf.as_ptr(), elf.len(), pd.as_mut_ptr()) }, "zkhip_request_digest")?;
+    let seed = stream_seed(&pd);
+    let mut bufs = Vec::new();
+    let mut pre = Vec::new();
+    for (c, ch) in shape.chips.iter().enumerate() {
+        if ch.pre_width == 0 {
+            pre.push(ffi::ZkhipChip { d_trace: std::ptr::null(), ld: 0, log_n: ch.log_n, width: 0, logup_pairs: 0, partner: -1 });
+            continue;
+        }
+        let buf = ctx.alloc((ch.width as usize) << ch.log_n)?;
+        check(unsafe { ffi::zkhip_gen_trace_logup(ctx.raw(), seed, 100 * KEY_SHARD + c as u64, ch.log_n, ch.width, ch.pairs as i32, buf.ptr, ch.width as usize) }, "zkhip_gen_trace_logup")?;
+        pre.push(ffi::ZkhipChip { d_trace: buf.ptr, ld: ch.width as usize, log_n: ch.log_n, width: ch.pre_width, logup_pairs: 0, partner: -1 });
+        bufs.push(buf);
+    }
+    let (mut key, mut root) = (std::ptr::null_mut(), [0u32; 8]);
+    check(unsafe { ffi::zkhip_machine_setup(ctx.raw(), pre.as_ptr(), pre.len() as i32, prm, &mut key, root.as_mut_ptr()) }, "zkhip_machine_setup")?;
+    Ok((key, root))                              // (the key keeps its own device copies: `bufs` may go)
+}
+
+/// Shard `s` of the request `digest` as ONE keyed-machine proof, checked against the key like sp1.rs:120.  Traces: the C++ mirror's streams (seed from the request
+/// digest, stream 100 s + chip), so both hosts make the same bytes.
+pub fn prove_machine_shard(ctx: &Context, shape: &MachineShape, key: *const ffi::ZkhipMachineKey, root: &[u32; 8], digest: &[u32; 8], s: u32, prm: &ZkhipParams) -> Result<Vec<u8>> {
+    let seed = stream_seed(digest);
+    let mut bufs = Vec::new();
+    let mut chips = Vec::new();
+    for (c, ch) in shape.chips.iter().enumerate() {
+        let buf = ctx.alloc((ch.width as usize) << ch.log_n)?;
+        let stream = 100 * s as u64 + c as u64;
+        let rc = if ch.partner < 0 {
+            unsafe { ffi::zkhip_gen_trace_logup(ctx.raw(), seed, stream, ch.log_n, ch.width, ch.pairs as i32, buf.ptr, ch.width as usize) }
+        } else {
+            let o = &shape.chips[ch.partner as usize];
+            unsafe { ffi::zkhip_gen_trace_logup_cross(ctx.raw(), seed, stream, 100 * s as u64 + ch.partner as u64, ch.log_n, ch.width, o.width, ch.pairs as i32, buf.ptr, ch.width as usize) }
+        };
+        check(rc, "zkhip_gen_trace_logup")?;
+        chips.push(ffi::ZkhipChip { d_trace: unsafe { buf.ptr.add(ch.pre_width as usize) }, ld: ch.width as usize, log_n: ch.log_n, width: ch.width - ch.pre_width, logup_pairs: 0, partner: -1 });
+        bufs.push(buf);
+    }
+    let mut pv = digest.to_vec();
+    pv.push(s);
+    let n = shape.chips.len() as i32;
+    let cap = unsafe { ffi::zkhip_machine_proof_size_keyed(shape.lns.as_ptr(), shape.widths.as_ptr(), shape.pres.as_ptr(), shape.pp.as_ptr(), shape.pw.as_ptr(), shape.tp.as_ptr(), shape.tw.as_ptr(), n, prm, pv.len()) };
+    anyhow::ensure!(cap > 0, "bad machine plan");
+    let (mut proof, mut len) = (vec![0u8; cap], 0usize);
+    check(unsafe { ffi::zkhip_prove_machine_keyed(ctx.raw(), key, chips.as_ptr(), shape.pp.as_ptr(), shape.pw.as_ptr(), shape.tp.as_ptr(), shape.tw.as_ptr(), n, pv.as_ptr(), pv.len(), prm,
+                                                  proof.as_mut_ptr(), cap, &mut len) }, "zkhip_prove_machine_keyed")?;
+    proof.truncate(len);
+    let mut reason = 0;
+    check(unsafe { ffi::zkhip_verify_machine_keyed(proof.as_ptr(), proof.len(), shape.lns.as_ptr(), shape.widths.as_ptr(), shape.pres.as_ptr(), root.as_ptr(), shape.pp.as_ptr(), shape.pw.as_ptr(),
+                                                   shape.tp.as_ptr(), shape.tw.as_ptr(), n, pv.as_ptr(), pv.len(), prm, &mut reason) }, "zkhip_verify_machine_keyed")?;   // sp1.rs:120
+    Ok(proof)
+}
+
+/// core -> compress for machine shards (sp1.rs:116): ONE machine-mode proof over `proofs` (at most 64, or a Poseidon2 chip of 2^22 rows).  `public_values`: 9 per proof.
+/// Returns the proof and its key; `verify_machine_compressed` derives the same key on the host.
+pub fn compress_machine_shards(ctx: &Context, shape: &MachineShape, root: &[u32; 8], proofs: &[Vec<u8>], public_values: &[u32], prm: &ZkhipParams) -> Result<(Vec<u8>, [u32; 8])> {
+    anyhow::ensure!(!proofs.is_empty() && public_values.len() == proofs.len() * MACHINE_PUBLICS, "compress_machine_shards: 9 public values per proof");
+    let desc = shape.desc(root, prm);
+    let n = proofs.len();
+    let cap = unsafe { ffi::zkhip_machine_verifier_proof_size(&desc, n, prm) };
+    anyhow::ensure!(cap > 0, "compress_machine_shards: more proofs than one join takes");
+    let (mut key, mut vk) = (std::ptr::null_mut(), [0u32; 8]);
+    check(unsafe { ffi::zkhip_machine_verifier_setup(ctx.raw(), &desc, n, prm, &mut key, vk.as_mut_ptr()) }, "zkhip_machine_verifier_setup")?;
+    let ptrs: Vec<*const u8> = proofs.iter().map(|p| p.as_ptr()).collect();
+    let lens: Vec<usize> = proofs.iter().map(|p| p.len()).collect();
+    let (mut out, mut len) = (vec![0u8; cap], 0usize);
+    let rc = unsafe { ffi::zkhip_prove_machine_verifier(ctx.raw(), key, &desc, ptrs.as_ptr(), lens.as_ptr(), n, public_values.as_ptr(), MACHINE_PUBLICS, prm, out.as_mut_ptr(), cap, &mut len) };
+    unsafe { ffi::zkhip_machine_key_destroy(key) };
+    check(rc, "zkhip_prove_machine_verifier")?;
+    out.truncate(len);
+    Ok((out, vk))
+}
+
+/// Host-only check of `compress_machine_shards`' proof from (the plan, the machine key's root, the shards' public values): the join's key is derived here.
+pub fn verify_machine_compressed(shape: &MachineShape, root: &[u32; 8], proof: &[u8], public_values: &[u32], n_proofs: usize, prm: &ZkhipParams) -> Result<()> {
+    let desc = shape.desc(root, prm);
+    let mut vk = [0u32; 8];
+    check(unsafe { ffi::zkhip_machine_verifier_key_host(&desc, n_proofs, prm, vk.as_mut_ptr()) }, "zkhip_machine_verifier_key_host")?;
+    let mut reason = 0;
+    check(unsafe { ffi::zkhip_verify_machine_recursive(&desc, proof.as_ptr(), proof.len(), public_values.as_ptr(), MACHINE_PUBLICS, n_proofs, vk.as_ptr(), prm, &mut reason) },
+          "zkhip_verify_machine_recursive")
+}

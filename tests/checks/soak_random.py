@@ -126,6 +126,53 @@ while time.time() - t0 < budget:
         assert verify_machine_recursive(im_, top1, [v for f_ in jflat for v in f_], tkey.root, Params(*tsh), nj) == (0, 0)
         jkey.close(), tkey.close()
         n_rec_machine += 1
+    elif r_kind < 0.015:
+        # THE PLUG POINT for shards in SP1's shard structure (zktls_amd/host MachinePlan): a random small machine (2 .. 5 chips, LogUp pairs in-table and across
+        # two tables of one height, preprocessed columns) x 1 .. 4 shards through setup -> prove -> verify; plain: every shard proof and the key against the oracle
+        # on tests/machines.py's traces; compressed (joins of at most 1 .. 3): the blob checked on the host from (plan, input, ELF, vk), another request refused
+        import ctypes as C_
+        import test_host_mirror_machine as TM
+        if "mirror" not in globals():
+            mirror = TM.lib.__wrapped__()
+        hs = sorted((int(x) for x in rng.integers(5, 10, int(rng.integers(2, 6)))), reverse=True)
+        spec = []
+        for ln in hs:
+            w = 8 * int(rng.integers(1, 5))
+            spec.append([ln, w, int(rng.integers(1, w // 8 + 1)), -1])
+        for i in range(len(spec) - 1):
+            if spec[i][0] == spec[i + 1][0] and spec[i][3] < 0 and rng.random() < 0.7:
+                pr_ = min(spec[i][2], spec[i + 1][2])
+                spec[i][2] = spec[i + 1][2] = pr_
+                spec[i][3], spec[i + 1][3] = i + 1, i
+                break
+        cand = [c for c, ch in enumerate(spec) if ch[3] < 0 and ch[1] >= 16]
+        if not cand: continue                                # (a keyed machine has preprocessed columns somewhere)
+        must = int(rng.choice(cand))
+        pre = tuple((c, 8) for c in cand if c == must or rng.random() < 0.3)
+        spec = [tuple(c) for c in spec]
+        shards, q, pb = int(rng.integers(1, 5)), int(rng.integers(1, 5)), int(rng.integers(0, 3))
+        cbor, elf = bytes(rng.integers(0, 256, int(rng.integers(1, 40)), dtype=np.uint8)), b"\x7fELF" + bytes(rng.integers(0, 256, 8, dtype=np.uint8))
+        compress = rng.random() < 0.5
+        plan = TM.mplan(spec, pre, shards, q, pb, in_flight=int(rng.integers(0, 3)))
+        if compress: mirror.zktls_set_compress_join_size(int(rng.integers(1, 4)))
+        try:
+            rc, err, out, blob, vk = TM.prove(mirror, 2, plan, cbor=cbor, elf=elf, compress=1 if compress else 0, setup_first=int(rng.integers(0, 2)))
+            assert rc == 0, ("mirror machine", spec, pre, shards, q, pb, err)
+            dg = TM.digest_words(mirror, cbor, elf)
+            if not compress:
+                ent = TM.entries(mirror, blob)[0]
+                assert len(ent) == shards
+                seed_, kseed_ = TM.stream_seed(dg), TM.stream_seed(TM.digest_words(mirror, b"", elf))
+                oprm_ = O.default_params(1, q, pb)
+                for s_ in range(shards):
+                    mains_, pres_, progs_, tabs_, _ = machines.sp1_shaped_machine(spec, seed=seed_, shard=s_, pre=pre, n_public=9, key_seed=kseed_)
+                    assert vk[:32] == O.machine_setup(pres_, [c[0] for c in spec], oprm_).tobytes(), ("mirror machine key", spec, pre)
+                    assert ent[s_] == O.prove_machine_keyed(mains_, pres_, progs_, tabs_, dg + [s_], oprm_).tobytes(), ("mirror machine shard", spec, pre, shards, q, pb, s_)
+            assert TM.check(mirror, blob, plan, vk, cbor=cbor, elf=elf) == 0, ("mirror machine verify", spec, pre, shards, q, pb, compress)
+            assert TM.check(mirror, blob, plan, vk, cbor=cbor + b"!", elf=elf) == -2
+        finally:
+            mirror.zktls_set_compress_join_size(0)
+        n_mirror = globals().get("n_mirror", 0) + 1
     elif r_kind < 0.017:
         # the Poseidon2 chip: random Merkle paths of a random tree; device trace against the Python restatement, proof bytes against the oracle
         depth, n_paths = int(rng.integers(1, 6)), int(rng.integers(1, 12))
@@ -267,5 +314,5 @@ while time.time() - t0 < budget:
         assert verify_chips(pf, [c[0] for c in chips], [c[1] for c in chips], [7], Params(*prm), prs, pas if cross else None) == (0, 0)
         for d in dev: d.free()
         n_chips += 1
-print("ok: %d single-matrix, %d multi-chip, %d constraint-program, %d chips-with-programs, %d lookup-machine, %d keyed-machine, %d Poseidon2-chip, %d shard-verifier (join), %d air-mode and %d machine-mode shard-verifier configurations in %.0f s"
-      % (n_single, n_chips, n_air, n_machine, n_lookup, n_keyed, n_p2, n_rec, n_rec_air, n_rec_machine, time.time() - t0))
+print("ok: %d single-matrix, %d multi-chip, %d constraint-program, %d chips-with-programs, %d lookup-machine, %d keyed-machine, %d Poseidon2-chip, %d shard-verifier (join), %d air-mode and %d machine-mode shard-verifier, %d host-mirror machine-plan configurations in %.0f s"
+      % (n_single, n_chips, n_air, n_machine, n_lookup, n_keyed, n_p2, n_rec, n_rec_air, n_rec_machine, globals().get("n_mirror", 0), time.time() - t0))

@@ -101,7 +101,8 @@ def test_mock_mode_and_the_argument_checks_of_a_machine_plan(lib):
     assert prove(lib, 3, plan)[1].find("network") >= 0
     # malformed plans are refused before any device work, as values (nothing unwinds across the boundary: sp1.rs:80-100)
     for spec, pre, what in (([(7, 16, 2, -1), (8, 24, 3, -1)], (), "tallest first"), ([(8, 24, 3, 1), (8, 32, 2, 0)], (), "mutual"), ([(8, 24, 3, 0)], (), "partner"),
-                            ([(8, 24, 4, -1)], (), "8 columns per LogUp pair"), ([(8, 24, 1, -1)], ((0, 12),), "whole in-table pairs"), ([(8, 24, 3, 1), (8, 32, 3, 0)], ((0, 8),), "whole in-table pairs")):
+                            ([(8, 24, 4, -1)], (), "8 columns per LogUp pair"), ([(8, 24, 1, -1)], ((0, 12),), "whole in-table pairs"), ([(8, 24, 3, 1), (8, 32, 3, 0)], ((0, 8),), "whole in-table pairs"),
+                            ([(8, 24, 3, -1), (7, 16, 1, -1)], (), "KEYED machine")):
         rc, err, _, _, _ = prove(lib, 2, mplan(spec, pre, 2, 3, 1), setup_first=0)
         assert rc == -1 and what in err, (spec, err)
     assert prove(lib, 2, mplan(SP1_SMALL, PRE, 0, 3, 1), setup_first=0)[1].find("empty") >= 0

@@ -375,6 +375,9 @@ struct MachineHolder {
             }
             lns[c] = ch.log_n; widths[c] = ch.width - ch.pre_width; pres[c] = ch.pre_width;
         }
+        bool keyed = false;
+        for (const ChipPlan& ch : plan.chips) keyed = keyed || ch.pre_width != 0;
+        if (!keyed) throw std::runtime_error("machine plan: at least one chip carries preprocessed columns (the shards are proofs of a KEYED machine: what setup commits)");
         finish(key_root, plan.num_queries, plan.pow_bits, MACHINE_PUBLICS);
     }
     // the machine-mode machine over n_proofs proofs of `inner` as an inner machine itself (the library describes its chips): what a tree's top verifies
