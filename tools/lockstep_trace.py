@@ -1,7 +1,9 @@
 """one lock-step batch under the profiler: usage python tools/lockstep_trace.py [batch=64] [lanes=1] [n=64]"""
 import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-sys.path[:0] = [ROOT, os.path.join(ROOT, "tests")]
+sys.path[:0] = [ROOT, os.path.join(ROOT, "tests"), os.path.join(ROOT, "tools")]
+if os.environ.get("ZKHIP_AB_LIB"):        # the A/B build (tools/_ab.py): ZKHIP_HOST_MERGE=0 keeps the members' host work serial
+    import _ab  # noqa: F401
 from zktls_amd._lib import Params
 from zktls_amd.device import lockstep_stats, prove_transcripts, set_lockstep
 batch = int(sys.argv[1]) if len(sys.argv) > 1 else 64

@@ -184,11 +184,30 @@ void LaunchBatcher::resolve() {
         sync_ns += ns_since(t0);
         return;
     }
+    for (int b = 0; b < members_; b++) if (fibers_[(size_t)b].state == AT_HOST) idx[n++] = b;
+    if (n > 0) {
+        // the members' host work of one kind, side by side (groups of equal (fn, n); a member that came alone is served alone)
+        bool taken[MAX_MEMBERS] = {};
+        for (int i = 0; i < n; i++) {
+            if (taken[i]) continue;
+            const HostOp& a = fibers_[(size_t)idx[i]].host;
+            void* objs[MAX_MEMBERS]; const uint32_t* words[MAX_MEMBERS];
+            int cnt = 0;
+            for (int j = i; j < n; j++) {
+                const HostOp& r = fibers_[(size_t)idx[j]].host;
+                if (!taken[j] && r.fn == a.fn && r.n == a.n) { taken[j] = true; objs[cnt] = r.obj; words[cnt] = r.words; cnt++; }
+            }
+            a.fn(objs, words, a.n, cnt);
+            host_merges++;
+        }
+        for (int k = 0; k < n; k++) fibers_[(size_t)idx[k]].state = RUNNABLE;
+        return;
+    }
     bool verdict = true;
     for (int b = 0; b < members_; b++) if (fibers_[(size_t)b].state == AT_VOTE) { idx[n++] = b; verdict = verdict && fibers_[(size_t)b].vote; }
     vote_result_ = verdict;
     for (int k = 0; k < n; k++) fibers_[(size_t)idx[k]].state = RUNNABLE;
-    if (n == 0) {                                               // cannot happen: a live fiber is runnable or parked in one of the three states
+    if (n == 0) {                                               // cannot happen: a live fiber is runnable or parked in one of the four states
         sticky_ = hipErrorUnknown;
         for (auto& f : fibers_) if (f.state != DONE) f.state = RUNNABLE;
     }
@@ -236,6 +255,17 @@ bool LaunchBatcher::all(bool mine) {
     fibers_[(size_t)current_].vote = mine;
     park(AT_VOTE);
     return vote_result_;
+}
+
+void LaunchBatcher::host_merge(HostMergeFn fn, void* obj, const uint32_t* words, size_t n) {
+    if (current_ < 0) { fn(&obj, &words, n, 1); return; }
+#ifdef ZKHIP_AB_HOOKS
+    static const bool serial = getenv("ZKHIP_HOST_MERGE") && atoi(getenv("ZKHIP_HOST_MERGE")) == 0;      // A/B: every member on its own, as before round 6
+    if (serial) { fn(&obj, &words, n, 1); return; }
+#endif
+    HostOp& h = fibers_[(size_t)current_].host;
+    h.fn = fn; h.obj = obj; h.words = words; h.n = n;
+    park(AT_HOST);
 }
 
 hipError_t LaunchBatcher::sync_all() {

@@ -666,7 +666,8 @@ static int prove_shard_impl(zkhip_ctx* ctx, const uint32_t* d_trace, size_t ld, 
     ZK_TRY(run_open(ctx, qlde, QW, log_n, (uint32_t)QW, zpts, 1, xw, d_open + 8 * (size_t)width + 8 * wp));
     std::vector<uint32_t> opened((2 * (size_t)width + 2 * wp + QW) * 4);
     ZK_TRY(d2h(ctx, opened.data(), d_open, opened.size() * 4));
-    for (size_t i = 0; i < opened.size(); i++) { ch.observe(opened[i]); pf[pos++] = from_monty(opened[i]); }
+    observe_words(ch, opened.data(), opened.size());          // (inside a lock-step batch: the members' sponges side by side, proof_common.h)
+    for (size_t i = 0; i < opened.size(); i++) pf[pos++] = from_monty(opened[i]);
     const Ext* op_loc = (const Ext*)opened.data();
     const Ext* op_nxt = op_loc + width;
     const Ext* op_pl = op_nxt + width;
@@ -1133,7 +1134,8 @@ static int prove_chips_impl(const ChipSet& cs, zkhip_ctx* ctx, const zkhip_chip*
     }
     std::vector<uint32_t> opened(op_off[n]);
     ZK_TRY(d2h(ctx, opened.data(), d_open, opened.size() * 4));
-    for (size_t i = 0; i < opened.size(); i++) { ch.observe(opened[i]); pf[pos++] = from_monty(opened[i]); }
+    observe_words(ch, opened.data(), opened.size());          // (inside a lock-step batch: the members' sponges side by side, proof_common.h)
+    for (size_t i = 0; i < opened.size(); i++) pf[pos++] = from_monty(opened[i]);
     lap("3. openings");
 
     // ---- 4. one reduced-opening vector per height (alpha powers run on across the chips of a height)
@@ -1456,3 +1458,34 @@ int zkhip_last_prove_debug(zkhip_ctx* ctx, zkhip_prove_debug* out) {
 }  // extern "C"
 
 extern "C" void zkhip_set_fri_graph(int on) { zk::g_fri_graph.store(on != 0); }
+
+// ---- self-check of the merged transcript absorption (zkhip_selftest_lockstep; no device): `members` fibers, each with a transcript of its own history, send word
+// vectors of several lengths through observe_words at the same points of their programs -- a fifth of them with another length (its own group), one round with
+// unequal buffer fills (the one-after-the-other path) --; every state, buffer and squeezed word against the scalar Challenger's.  10 + the failing member's check.
+namespace zk {
+int lockstep_selftest_observe(int members) {
+    if (members < 1 || members > LaunchBatcher::MAX_MEMBERS) return 1;
+    LaunchBatcher lb(members, nullptr);
+    if (!lb.ok_scheduler()) return 2;
+    std::vector<int> bad((size_t)members, 0);
+    auto word = [](uint64_t b, uint64_t r, uint64_t i) { uint64_t x = (b + 1) * 0x9E3779B97F4A7C15ull ^ (r + 7) * 0xC2B2AE3D27D4EB4Full ^ (i + 3) * 0x165667B19E3779F9ull; x ^= x >> 29; x *= 0xBF58476D1CE4E5B9ull; x ^= x >> 32; return (uint32_t)(x % P); };
+    const size_t lens[5] = {64, 71, 200, 1000, 5501};
+    lb.run([&](int b) {
+        Challenger got, want;
+        for (int r = 0; r < 5; r++) {
+            const int pre = r == 3 ? b % 3 : r;                       // round 3: the members' buffers are filled unequally
+            for (int i = 0; i < pre; i++) { const uint32_t w = word((uint64_t)b, 100 + (uint64_t)r, (uint64_t)i); got.observe(w); want.observe(w); }
+            const size_t n = lens[r] + (b % 5 == 4 ? 8 : 0);
+            std::vector<uint32_t> ws(n);
+            for (size_t i = 0; i < n; i++) ws[i] = word((uint64_t)b, (uint64_t)r, i);
+            observe_words(got, ws.data(), n);
+            for (size_t i = 0; i < n; i++) want.observe(ws[i]);
+            if (std::memcmp(got.state, want.state, sizeof got.state) != 0 || got.n_in != want.n_in || got.n_out != want.n_out || std::memcmp(got.in, want.in, 4 * (size_t)got.n_in) != 0 ||
+                std::memcmp(got.out, want.out, 4 * (size_t)got.n_out) != 0) bad[(size_t)b] = 10 + r;
+            if (got.sample() != want.sample()) bad[(size_t)b] = 20 + r;
+        }
+    });
+    for (int b = 0; b < members; b++) if (bad[(size_t)b]) return bad[(size_t)b];
+    return 0;
+}
+}  // namespace zk

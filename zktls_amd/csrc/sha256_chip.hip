@@ -45,6 +45,7 @@
 #include "air.h"
 #include "context.h"
 #include "batch.h"
+namespace zk { int lockstep_selftest_observe(int members); }      // prover.cpp: the members' transcripts absorbing side by side (LaunchBatcher::host_merge) against one after the other
 
 namespace zk {
 namespace sha {
@@ -911,7 +912,10 @@ int zkhip_prove_transcripts_air(const int* devices, int n_devices, zkhip_transcr
 }
 
 void zkhip_set_lockstep(int max_batch, int lanes) { lockstep_set(max_batch, lanes); }
-int zkhip_selftest_lockstep(int members, int rounds) { return lockstep_selftest(members, rounds); }
+int zkhip_selftest_lockstep(int members, int rounds) {
+    const int rc = lockstep_selftest(members, rounds);
+    return rc ? rc : lockstep_selftest_observe(members);
+}
 void zkhip_lockstep_stats(uint64_t out[6]) {
     for (int i = 0; i < 6; i++) out[i] = g_lockstep_stats[i].load();
 }
