@@ -797,15 +797,20 @@ def main():
             tree_cores = (time.process_time() - tcpu0) / (time.perf_counter() - twall0)      # CPU time of ALL threads of the process per second of the calls
             assert top1.tobytes() == top.tobytes() and all(a_.tobytes() == b_.tobytes() for a_, b_ in zip(joins1, joins4))
             tb0 = time.perf_counter()
-            ok_tree = verify_machine_recursive(im_, top, [v for p_ in jp for v in p_], machine_verifier_key_host(im_, prm, 4), prm, 4) == (0, 0)
-            t_tv = time.perf_counter() - tb0
+            hkey_ = machine_verifier_key_host(im_, prm, 4)            # the top's key on the host's cores: a function of the shape, derived ONCE by a verifier and kept
+            t_hk = time.perf_counter() - tb0
+            tb0 = time.perf_counter()
+            ok_tree = verify_machine_recursive(im_, top, [v for p_ in jp for v in p_], hkey_, prm, 4) == (0, 0)
+            t_tv1 = time.perf_counter() - tb0
+            t_tv = t_hk + t_tv1
             assert jvk.tolist() == tkey1.root.tolist()
             tree = {"workload": "64 shard proofs (2^20 x 256, 100 queries) -> 4 joins of 16 (zkhip_prove_shard_verifier_batch: the four in flight on pooled contexts, as the shards below them are) -> ONE proof (zkhip_prove_machine_verifier: the four joins' version-11 proofs verified in-circuit, ten chips)",
                     "ms": round(t_one * 1e3, 2), "entry": "zkhip_prove_shard_tree (one call: the four joins in flight, each one's tables for the top filled the moment it exists, then the machine's proof)",
                     "host_cores_busy": round(tree_cores, 2), "host_wait": "block" if wait_block else "poll",
                     "two_calls_ms": round((t_joins + t_top) * 1e3, 2), "joins_ms": round(t_joins * 1e3, 2), "top_ms": round(t_top * 1e3, 2), "inner_bytes_total": int(sum(x.size for x in tsps)),
                     "join_bytes_total": int(sum(x.size for x in joins4)), "bytes": int(top.size), "compression": round(sum(x.size for x in tsps) / top.size, 2),
-                    "host_verify_ms_with_the_key_derived_on_the_host": round(t_tv * 1e3, 2), "verified": bool(ok_tree),
+                    "host_verify_ms_with_the_key_derived_on_the_host": round(t_tv * 1e3, 2), "host_verify_ms": round(t_tv1 * 1e3, 2), "host_key_derivation_ms_once_per_shape": round(t_hk * 1e3, 2),
+                    "verified": bool(ok_tree),
                     "verifier_inputs": "the join machine's description (a function of the shard shape), 64 x %d public values, the key; no byte of a shard proof or of a join" % len(spv[0])}
             # the same top with ITS proof in SP1's compress shape (blowup 4, 50 queries): what leaves the tree is half the size
             from zktls_amd._lib import Params as _P2
