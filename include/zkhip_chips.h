@@ -167,6 +167,7 @@ int zkhip_ntt_pass(zkhip_ctx* ctx, const uint32_t* d_in, uint32_t* d_out, size_t
 int zkhip_last_prove_debug(zkhip_ctx* ctx, zkhip_prove_debug* out);
 int zkhip_selftest_lockstep(int members, int rounds);
 int zkhip_selftest_host_simd(double* ns_x16, double* ns_scalar);
+double zkhip_host_permutation_ns(int form);
 void zkhip_lockstep_stats(uint64_t out[6]);
 uint64_t zkhip_lockstep_stack_high_water(void);
 /* Where the recursion machines (zkhip_prove_shard_verifier[_air], zkhip_prove_machine_verifier, zkhip_prove_shard_tree) make their per-query witness tables -- ROWSUM,

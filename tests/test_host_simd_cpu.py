@@ -24,6 +24,27 @@ def test_batched_permutation_equals_the_scalar_one():
         assert 0 < a.value < b.value * 2                 # not slower than twice the scalar form (it is ~4 x faster)
 
 
+def test_the_one_register_permutation_is_what_a_transcript_calls():
+    """round 6: a transcript is ONE serial sponge chain, so the vector unit is used inside the permutation -- the state in one AVX-512 register (p2_x16.cpp
+    p2h_permute behind p2_permute on the host).  zkhip_selftest_host_simd compares it with the scalar form on every state it tries (a mismatch is its -7 return);
+    here: it is in use when the CPU has AVX-512, not slower than the scalar form, and switched off together with the batched form"""
+    L = _lib.load()
+    rc = L.zkhip_selftest_host_simd(None, None)
+    assert rc in (0, 1)
+    best = lambda form: min(L.zkhip_host_permutation_ns(form) for _ in range(5))      # (the least of five: other processes share this host)
+    scalar, fast = best(0), best(1)
+    assert scalar > 0 and fast > 0
+    if rc == 1:
+        assert fast < scalar * 1.1, (fast, scalar)
+        prev = L.zkhip_host_simd(0)
+        try:
+            off = best(1)
+        finally:
+            L.zkhip_host_simd(prev)
+        assert off > fast * 1.1, (off, fast)              # with the vector forms off the transcripts are back on the scalar permutation
+    print("host Poseidon2, one state: scalar %.0f ns, one-register %.0f ns" % (scalar, fast))
+
+
 def verdicts(fn):
     L = _lib.load()
     out = []

@@ -33,7 +33,7 @@ EXPORTS = [
     "zkhip_air_validate", "zkhip_air_digest", "zkhip_air_synthetic", "zkhip_proof_size_air", "zkhip_prove_shard_air", "zkhip_verify_shard_air",
     "zkhip_quotient_values_air",
     "zkhip_chips_proof_size_air", "zkhip_prove_chips_air", "zkhip_verify_chips_air",
-    "zkhip_prove_shards_air_multi", "zkhip_selftest_host_simd", "zkhip_host_simd", "zkhip_recursion_witnesses_on_host", "zkhip_machine_proof_size", "zkhip_prove_machine", "zkhip_verify_machine", "zkhip_range_table",
+    "zkhip_prove_shards_air_multi", "zkhip_selftest_host_simd", "zkhip_host_permutation_ns", "zkhip_host_simd", "zkhip_recursion_witnesses_on_host", "zkhip_machine_proof_size", "zkhip_prove_machine", "zkhip_verify_machine", "zkhip_range_table",
     "zkhip_machine_setup", "zkhip_machine_key_destroy", "zkhip_machine_proof_size_keyed", "zkhip_prove_machine_keyed", "zkhip_verify_machine_keyed", "zkhip_prove_machine_keyed_at",
     "zkhip_sha256_setup", "zkhip_sha256_machine_proof_size", "zkhip_prove_sha256_machine", "zkhip_verify_sha256_machine", "zkhip_prove_transcripts", "zkhip_prove_transcripts_air", "zkhip_sha256_machine_describe", "zkhip_machine_verifier_setup", "zkhip_machine_verifier_key_host", "zkhip_machine_verifier_proof_size", "zkhip_prove_machine_verifier", "zkhip_prove_shard_tree", "zkhip_verify_machine_recursive", "zkhip_machine_verifier_describe", "zkhip_machine_verifier_host_tables", "zkhip_sha256_compress_setup", "zkhip_sha256_compress_key_host", "zkhip_sha256_compressed_proof_size", "zkhip_prove_sha256_compressed", "zkhip_verify_sha256_compressed", "zkhip_set_wait_mode", "zkhip_set_lockstep", "zkhip_lockstep_stats", "zkhip_lockstep_stack_high_water", "zkhip_set_fri_graph", "zkhip_shard_verifier_setup", "zkhip_shard_verifier_proof_size", "zkhip_shard_verifier_max_proofs", "zkhip_prove_shard_verifier", "zkhip_prove_shard_verifier_batch", "zkhip_verify_shard_recursive", "zkhip_shard_verifier_describe", "zkhip_shard_verifier_key_host", "zkhip_machine_key_host", "zkhip_shard_verifier_setup_air", "zkhip_shard_verifier_key_host_air", "zkhip_shard_verifier_max_proofs_air", "zkhip_shard_verifier_proof_size_air", "zkhip_prove_shard_verifier_air", "zkhip_verify_shard_recursive_air", "zkhip_shard_verifier_describe_air", "zkhip_poseidon2_params_generation", "zkhip_selftest_lockstep",
     "zkhip_sha256_air_chained", "zkhip_sha256_gen_trace_chained", "zkhip_sha256_sharded_count", "zkhip_sha256_shard_proof_size", "zkhip_prove_sha256_sharded",
@@ -191,6 +191,8 @@ def load():
                                          C.POINTER(Params), C.POINTER(C.c_int)]
     L.zkhip_prove_shards_air_multi.argtypes = [C.POINTER(C.c_int), C.c_int, C.POINTER(ShardJob), C.c_int, u32p, C.c_size_t, C.POINTER(Params), C.c_int]
     L.zkhip_selftest_host_simd.argtypes = [C.POINTER(C.c_double), C.POINTER(C.c_double)]
+    L.zkhip_host_permutation_ns.argtypes = [C.c_int]
+    L.zkhip_host_permutation_ns.restype = C.c_double
     L.zkhip_range_table.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_size_t, C.POINTER(C.c_uint32), C.c_int, C.c_int, C.c_void_p, C.c_size_t,
                                     C.c_uint32, C.c_uint32]
     L.zkhip_machine_proof_size.restype = C.c_size_t

@@ -90,6 +90,73 @@ void p2x16_permute(uint32_t st[16][16]) {
     for (int i = 0; i < 16; i++) _mm512_storeu_si512((void*)st[i], s[i]);
 }
 
+// ---- ONE permutation, the state in one register (element i in 32-bit lane i): what a transcript -- a single serial sponge chain -- can use of the vector
+// unit.  External rounds: sixteen S-boxes per vmul; M4 = circ(2, 3, 1, 1) on every 128-bit block as y = (x + r1 + r2 + r3) + x + 2 r1 with r_k the block rotated
+// by k lanes, then the sum over the four blocks.  Internal rounds: lane 0 lives in a scalar register (its S-box is the dependency chain: four scalar products),
+// lanes 1 .. 15 take their diagonal product and the sum of the others beside it.  Canonical Montgomery residues in and out; modular additions are exact, so the
+// order they are taken in does not change a bit of the result.
+namespace {
+#define ZK_ROT1(v) _mm512_shuffle_epi32(v, (_MM_PERM_ENUM)0x39)
+#define ZK_ROT2(v) _mm512_shuffle_epi32(v, (_MM_PERM_ENUM)0x4E)
+#define ZK_ROT3(v) _mm512_shuffle_epi32(v, (_MM_PERM_ENUM)0x93)
+#define ZK_BLK1(v) _mm512_shuffle_i32x4(v, v, 0x39)
+#define ZK_BLK2(v) _mm512_shuffle_i32x4(v, v, 0x4E)
+#define ZK_BLK3(v) _mm512_shuffle_i32x4(v, v, 0x93)
+inline V external_linear_h(V s) {
+    const V r1 = ZK_ROT1(s), r2 = ZK_ROT2(s), r3 = ZK_ROT3(s);
+    const V sum = vadd(vadd(s, r1), vadd(r2, r3));
+    const V y = vadd(vadd(sum, s), vdbl(r1));
+    const V t = vadd(vadd(y, ZK_BLK1(y)), vadd(ZK_BLK2(y), ZK_BLK3(y)));
+    return vadd(y, t);
+}
+inline uint32_t lane0(V v) { return (uint32_t)_mm_cvtsi128_si32(_mm512_castsi512_si128(v)); }
+void permute_h(uint32_t st[16]) {
+    V s = _mm512_loadu_si512((const void*)st);
+    const V diag = _mm512_loadu_si512((const void*)P2K.diag);
+    s = external_linear_h(s);
+    for (int r = 0; r < 4; r++) s = external_linear_h(sbox(vadd(s, _mm512_loadu_si512((const void*)P2K.ext_rc[r]))));
+    uint32_t s0 = lane0(s);
+    s = _mm512_maskz_mov_epi32(0xFFFE, s);                       // lanes 1 .. 15; lane 0 stays zero in here
+    for (int r = 0; r < 13; r++) {
+        V t = vadd(s, ZK_ROT2(s));                               // the others' sum, in every lane
+        t = vadd(t, ZK_ROT1(t));
+        t = vadd(t, ZK_BLK2(t));
+        t = vadd(t, ZK_BLK1(t));
+        const V prod = vmul(s, diag);
+        const uint32_t x0 = p2_sbox(fadd(s0, P2K.int_rc[r]));
+        const uint32_t sum = fadd(x0, lane0(t));
+        s0 = fadd(fmul(x0, P2K.diag[0]), sum);
+        s = _mm512_maskz_mov_epi32(0xFFFE, vadd(prod, splat(sum)));
+    }
+    s = _mm512_mask_set1_epi32(s, 1, (int)s0);
+    for (int r = 4; r < 8; r++) s = external_linear_h(sbox(vadd(s, _mm512_loadu_si512((const void*)P2K.ext_rc[r]))));
+    _mm512_storeu_si512((void*)st, s);
+}
+// checked once per table set against the scalar form on states that include the extremes; a mismatch keeps the scalar form for good
+bool permute_h_checked() {
+    uint64_t z = 0xD1B54A32D192ED03ull;
+    for (int round = 0; round < 6; round++) {
+        uint32_t a[16], b[16];
+        for (int e = 0; e < 16; e++) {
+            z = z * 6364136223846793005ull + 1442695040888963407ull;
+            a[e] = b[e] = round == 0 ? ((e & 1) ? P - 1 : 0u) : (uint32_t)((z >> 33) % P);
+        }
+        permute_h(a);
+        p2_permute_scalar(b);
+        for (int e = 0; e < 16; e++) if (a[e] != b[e]) return false;
+    }
+    return true;
+}
+}  // namespace
+
+bool p2h_permute(uint32_t st[16]) {
+    if (!p2x16_available()) return false;
+    static const bool ok = permute_h_checked();                 // (with the tables in effect at the first call; another set is another instance of the same arithmetic)
+    if (!ok) return false;
+    permute_h(st);
+    return true;
+}
+
 void p2x16_to_monty(uint32_t v[16]) {
     const V x = _mm512_loadu_si512((const void*)v);
     _mm512_storeu_si512((void*)v, vmul(x, splat(MONTY_R2)));      // canonical -> Montgomery: multiply by R^2

@@ -979,6 +979,18 @@ int zkhip_verify_machine_keyed(const uint8_t* proof, size_t len, const int32_t* 
 // 0 = this CPU lacks it (the verifiers then hash query by query), negative = mismatch.  *ns_x16 / *ns_scalar (optional): time per
 // permutation of either form.
 int zkhip_host_simd(int enable) { return p2x16_enable(enable != 0) ? 1 : 0; }
+// nanoseconds per Poseidon2 permutation of ONE state on this host: form 0 = the scalar permutation, 1 = what the transcripts and host Merkle checks call (the state
+// in one AVX-512 register when the CPU has it: p2_x16.cpp p2h_permute, else the scalar form again).  A measurement for docs and tools; no device.
+double zkhip_host_permutation_ns(int form) {
+    uint32_t s1[16];
+    for (int e = 0; e < 16; e++) s1[e] = (uint32_t)(e + 1);
+    const int reps = 20000;
+    for (int k = 0; k < 200; k++) { if (form) p2_permute(s1); else p2_permute_scalar(s1); }
+    const auto t0 = std::chrono::steady_clock::now();
+    for (int k = 0; k < reps; k++) { if (form) p2_permute(s1); else p2_permute_scalar(s1); }
+    const double ns = std::chrono::duration<double, std::nano>(std::chrono::steady_clock::now() - t0).count() / reps;
+    return ns + (s1[0] == 0xFFFFFFFFu ? 1.0 : 0.0);
+}
 int zkhip_selftest_host_simd(double* ns_x16, double* ns_scalar) {
     if (ns_x16) *ns_x16 = 0;
     if (ns_scalar) *ns_scalar = 0;
@@ -996,8 +1008,11 @@ int zkhip_selftest_host_simd(double* ns_x16, double* ns_scalar) {
         for (int j = 0; j < 16; j++) {
             uint32_t s1[16];
             for (int e = 0; e < 16; e++) s1[e] = ref[e][j];
-            p2_permute(s1);
+            uint32_t s2[16];
+            for (int e = 0; e < 16; e++) s2[e] = s1[e];
+            p2_permute_scalar(s1);
             for (int e = 0; e < 16; e++) if (s1[e] != st[e][j]) return fail(ZKHIP_ERR_INTERNAL, "host SIMD permutation differs from the scalar one");
+            if (p2h_permute(s2)) for (int e = 0; e < 16; e++) if (s1[e] != s2[e]) return fail(ZKHIP_ERR_INTERNAL, "the one-register host permutation differs from the scalar one");
         }
     }
     const int reps = 2000;
@@ -1007,8 +1022,9 @@ int zkhip_selftest_host_simd(double* ns_x16, double* ns_scalar) {
     uint32_t s1[16];
     for (int e = 0; e < 16; e++) s1[e] = st[e][0];
     t0 = std::chrono::steady_clock::now();
-    for (int k = 0; k < reps; k++) p2_permute(s1);
+    for (int k = 0; k < reps; k++) p2_permute_scalar(s1);
     const double b = std::chrono::duration<double, std::nano>(std::chrono::steady_clock::now() - t0).count() / reps;
+
     if (ns_x16) *ns_x16 = a;
     if (ns_scalar) *ns_scalar = b + (s1[0] == 0xFFFFFFFFu ? 1 : 0);
     return 1;
