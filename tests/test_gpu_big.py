@@ -62,13 +62,22 @@ def test_big_lde_into_interleaved_columns(ctx, oracle):
 def test_big_lde_at_blowup_2_takes_any_pitch(ctx, oracle):
     # at blowup 2 the tile passes run on dense 2^20-row classes: a 2^22-row matrix may sit in rows 300 words apart (the 256-word limit of the
     # other blowups does not apply); eight columns into a pitch of 300, offset 40, everything else untouched
-    log_n = 22
+    # (checked on three windows of 2^17 rows -- the first, one across the middle, the last -- against the oracle's rows; the surrounding columns against what
+    # they held before: the 10 GB of the whole buffer never cross the PCIe link or numpy)
+    from zktls_amd._lib import from_monty
+    log_n, pitch, win = 22, 300, 1 << 17
     m = oracle.fill_uniform(SEED + 11, log_n, 8)
+    want = oracle.coset_lde(m, 1, 31)
     d = ctx.from_numpy(m)
-    out = ctx.from_numpy(np.full((2 << log_n, 300), 9, dtype=np.uint32))
-    ctx.coset_lde(d, log_n, 8, 1, 31, out=out, out_ld=300, out_col=40)
-    got = out.download().reshape(-1, 300)
-    assert (got[:, 40:48] == oracle.coset_lde(m, 1, 31)).all() and (got[:, :40] == 9).all() and (got[:, 48:] == 9).all()
+    out = ctx.fill_uniform(SEED + 12, log_n, 2 * pitch)            # 2^23 rows of 300 words
+    rows = 2 << log_n
+    starts = (0, rows // 2 - win // 2, rows - win)
+    before = [out.download_monty(win * pitch, r0 * pitch).reshape(win, pitch) for r0 in starts]
+    ctx.coset_lde(d, log_n, 8, 1, 31, out=out, out_ld=pitch, out_col=40)
+    for r0, was in zip(starts, before):
+        got = out.download_monty(win * pitch, r0 * pitch).reshape(win, pitch)
+        assert (from_monty(np.ascontiguousarray(got[:, 40:48])) == want[r0:r0 + win]).all(), r0
+        assert (got[:, :40] == was[:, :40]).all() and (got[:, 48:] == was[:, 48:]).all(), r0
     d.free(); out.free()
 
 
