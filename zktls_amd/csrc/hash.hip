@@ -771,10 +771,132 @@ struct p2chip_layer_paths_kernel_bargs { p2chip::LayerPathsArgs a; static p2chip
 __global__ void __launch_bounds__(64) p2chip_layer_paths_kernel_batch(const p2chip_layer_paths_kernel_bargs* __restrict__ zk_arr) { const p2chip_layer_paths_kernel_bargs& zk_b = zk_arr[blockIdx.z]; p2chip_layer_paths_kernel_body(zk_b.a); }
 
 // the shard verifier's chip (p2chip.h, P2RArgs): one lane per chain, one per transcript row, the rest share the padding rows
+// ---- the same rows written COOPERATIVELY (round 6).  A lane that fills its own 360-word row stores 4 bytes at a time 1 440 bytes away from its neighbours' stores:
+// 2^21 rows took 8 ms for 3 GB.  Here the wave's 64 lanes produce a group of 16 columns each (IN, S0, a round's cubes, a round's state ...: the row's natural
+// units), park them in LDS (pitch 17: conflict-free both ways) and write them out as 16-byte stores, sixteen rows x 64 bytes per instruction.  One wave per
+// workgroup; every lane takes part in every store (a lane without a row passes ~0 as its offset), so the callers loop wave-uniformly.
+__device__ __forceinline__ void p2r_coop_put16(uint32_t* stage, const uint64_t* rowoff, uint32_t* trace, uint32_t col, const uint32_t v[16], bool vec, int n = 16) {
+    const int l = (int)threadIdx.x;
+#pragma unroll
+    for (int j = 0; j < 16; j++) stage[l * 17 + j] = v[j];
+    __syncthreads();
+    if (vec) {
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const int r = 16 * k + (l >> 2), q = l & 3;
+            const uint64_t off = rowoff[r];
+            const uint32_t* sp = stage + r * 17 + 4 * q;
+            if (off != ~0ull && 4 * q < n) *reinterpret_cast<uint4*>(trace + off + col + 4 * q) = make_uint4(sp[0], sp[1], sp[2], sp[3]);
+        }
+    } else {
+#pragma unroll
+        for (int k = 0; k < 16; k++) {
+            const int r = 4 * k + (l >> 4), j = l & 15;
+            const uint64_t off = rowoff[r];
+            if (off != ~0ull && j < n) trace[off + col + j] = stage[r * 17 + j];
+        }
+    }
+    __syncthreads();
+}
+// one row per lane, the shard-verifier machines' flags (bit; KP in column R_KP as a Montgomery word; every other flag zero): what p2chip_fill_row(t, in, bit, 0 ...)
+// followed by t[R_KP] = kp writes, word for word
+__device__ void p2chip_fill_row_coop(uint32_t* stage, uint64_t* rowoff, uint32_t* trace, uint64_t my_off, bool vec, const uint32_t in[16], uint32_t bit, uint32_t kp_monty,
+                                     uint32_t out16[16]) {
+    using namespace p2chip;
+    static_assert(R_WIDTH == 360 && SP == 327 && D == 343 && BIT == 351 && R_KP == 352 && s0p(0) == 288 && oute(7) == 272, "the cooperative writer knows the row's layout");
+    __syncthreads();                                             // (the previous row's stores read rowoff)
+    rowoff[threadIdx.x] = my_off;
+    uint32_t s[16], x3[16], tail[72];
+    for (int i = 0; i < 16; i++) s[i] = in[i];
+    p2r_coop_put16(stage, rowoff, trace, IN, s, vec);
+    p2_external_linear(s);
+    p2r_coop_put16(stage, rowoff, trace, S0, s, vec);
+    auto external_round = [&](int r) {
+        for (int i = 0; i < 16; i++) {
+            const uint32_t y = fadd(s[i], P2K.ext_rc[r][i]);
+            x3[i] = fmul(fmul(y, y), y);
+            s[i] = fmul(fmul(x3[i], x3[i]), y);
+        }
+        p2r_coop_put16(stage, rowoff, trace, x3e((uint32_t)r), x3, vec);
+        p2_external_linear(s);
+        p2r_coop_put16(stage, rowoff, trace, oute((uint32_t)r), s, vec);
+    };
+#pragma unroll 1
+    for (int r = 0; r < 4; r++) external_round(r);
+#pragma unroll
+    for (int r = 0; r < 13; r++) {
+        tail[3 * r] = s[0];
+        const uint32_t y = fadd(s[0], P2K.int_rc[r]);
+        const uint32_t c3 = fmul(fmul(y, y), y);
+        tail[3 * r + 1] = c3;
+        s[0] = fmul(fmul(c3, c3), y);
+        tail[3 * r + 2] = s[0];
+        p2_internal_linear(s);
+    }
+    for (int i = 0; i < 16; i++) tail[39 + i] = s[i];            // SP = 327 = 288 + 39
+#pragma unroll 1
+    for (int r = 4; r < 8; r++) external_round(r);
+    for (int j = 0; j < 8; j++) tail[55 + j] = bit ? in[8 + j] : in[j];      // D = 343
+    tail[63] = bit ? MONTY_R1 : 0u;                              // BIT = 351
+    tail[64] = kp_monty;                                         // R_KP = 352
+    for (int j = 65; j < 72; j++) tail[j] = 0u;
+    p2r_coop_put16(stage, rowoff, trace, 288, tail, vec);
+    p2r_coop_put16(stage, rowoff, trace, 304, tail + 16, vec);
+    p2r_coop_put16(stage, rowoff, trace, 320, tail + 32, vec);
+    p2r_coop_put16(stage, rowoff, trace, 336, tail + 48, vec);
+    p2r_coop_put16(stage, rowoff, trace, 352, tail + 64, vec, 8);
+    for (int j = 0; j < 16; j++) out16[j] = s[j];
+}
+
 __device__ __forceinline__ void p2r_rows_kernel_body(const p2chip::P2RArgs& a) {
     using namespace p2chip;
     const uint64_t p = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     uint32_t in[16], out[16];
+    if (a.ld == R_WIDTH) {
+        // every lane has `total` rows to fill (a chain: its leaf blocks, then its levels; a transcript or padding row: one; nothing: zero) and the wave walks them together
+        __shared__ uint32_t stage[64 * 17];
+        __shared__ uint64_t rowoff[64];
+        const bool vec = ((uintptr_t)a.trace & 15) == 0;
+        uint32_t kind = 0, total = 0, blocks = 0, index = 0;
+        uint64_t row0 = 0, r = 0;
+        const uint32_t *vals = nullptr, *sib = nullptr;
+        if (p < a.n_chains) {
+            const uint32_t* d = a.desc + 6 * p;
+            kind = 1; row0 = d[0]; blocks = d[1]; index = d[4]; total = blocks + d[3];
+            vals = a.data + d[2]; sib = a.data + d[5];
+        } else {
+            r = p - a.n_chains;
+            if (r < a.n_transcript) {
+                if (!(a.seg_rows && (r % a.seg_rows) < a.skip_first)) { kind = 2; total = 1; row0 = a.trows ? a.trows[r] : r; }
+            } else if (a.used_rows + (r - a.n_transcript) < a.rows) { kind = 3; total = 1; row0 = a.used_rows + (r - a.n_transcript); }
+        }
+        for (int j = 0; j < 16; j++) out[j] = 0u;
+        for (uint32_t step = 0; __any(step < total); step++) {
+            const bool valid = step < total;
+            uint32_t bit = 0u, kp = 0u;
+            for (int j = 0; j < 16; j++) in[j] = 0u;
+            if (valid && kind == 1) {
+                if (step < blocks) {
+                    for (int j = 0; j < 8; j++) { in[j] = to_monty(vals[8 * step + j]); in[8 + j] = out[8 + j]; }
+                    kp = step + 1 == blocks ? to_monty(2u * index) : 0u;
+                } else {
+                    const uint32_t lvl = step - blocks;
+                    bit = (index >> lvl) & 1u;
+                    for (int j = 0; j < 8; j++) { in[bit ? 8 + j : j] = out[j]; in[bit ? j : 8 + j] = to_monty(sib[8 * lvl + j]); }
+                    kp = to_monty(index >> lvl);
+                }
+            } else if (valid && kind == 2) {
+                for (int j = 0; j < 16; j++) in[j] = a.inputs_monty ? a.chain_inputs[16 * r + j] : to_monty(a.chain_inputs[16 * r + j]);
+                bit = a.row_bits ? a.row_bits[r] : 0u;
+                kp = a.row_kps ? to_monty(a.row_kps[r]) : 0u;
+            }
+            uint32_t o2[16];
+            p2chip_fill_row_coop(stage, rowoff, a.trace, valid ? (row0 + step) * a.ld : ~0ull, vec, in, bit, kp, o2);
+            if (valid) for (int j = 0; j < 16; j++) out[j] = o2[j];        // (a lane whose rows are done keeps its last state: the chain's root)
+        }
+        if (kind == 1) for (int j = 0; j < 8; j++) a.roots[8 * p + j] = from_monty(out[j]);
+        return;
+    }
     if (p < a.n_chains) {
         const uint32_t* d = a.desc + 6 * p;
         uint32_t* t = a.trace + (uint64_t)d[0] * a.ld;
