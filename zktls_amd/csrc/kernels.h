@@ -337,7 +337,13 @@ constexpr int LOOKUP_REC_WORDS = 12;
 struct LookupArgs {
     const uint32_t* table; uint32_t ni, cols;      // device records; cols = ceil(ni / 2)
     Ext gamma, bpow[9];                            // beta^0 .. beta^8
+    // round 6: the columns the interactions read are few (26 of the Poseidon2 chip's 384, in 4 of its 24 sixteen-column chunks) and a lane that reads them from
+    // ITS row makes 64 scattered requests per load.  cmap (device, LOOKUP_MAX_COLS bytes; nullptr: rows are read where they lie): column -> its place in a staged
+    // row of n_used words, 0xFF = not read; chunk_mask: bit c = chunk c (columns 16 c .. 16 c + 15) holds a column that is read.  The kernels then load those
+    // chunks of a workgroup's 256 rows with 16-byte loads, 64 bytes of a row per four lanes, into an LDS tile of pitch n_used | 1.
+    const uint8_t* cmap; uint32_t n_used, chunk_mask;
 };
+constexpr uint32_t LOOKUP_MAX_COLS = 512, LOOKUP_STAGE_MAX_USED = 56;   // (256 rows x 57 words = 57 KiB of LDS)
 struct MachinePermArgs {
     LookupArgs lk;
     const uint32_t* trace; uint64_t ld; uint64_t rows;

@@ -402,14 +402,31 @@ static int lookup_args(zkhip_ctx* ctx, const LookupView& lv, const Ext& gamma, c
                        const uint32_t** d_weights) {
     std::vector<uint32_t> recs;
     lookup_device_records(lv, recs);
-    const size_t rec_w = (recs.size() + 3) & ~(size_t)3;
-    std::vector<uint32_t> stage(rec_w + weights.size(), 0u);
+    const size_t rec_w = (recs.size() + 3) & ~(size_t)3, map_w = LOOKUP_MAX_COLS / 4;
+    std::vector<uint32_t> stage(rec_w + weights.size() + map_w, 0u);
     memcpy(stage.data(), recs.data(), recs.size() * 4);
     if (!weights.empty()) memcpy(stage.data() + rec_w, weights.data(), weights.size() * 4);
+    // the columns the interactions read, in the order they are first met: the kernels stage exactly these (kernels.h LookupArgs)
+    uint8_t* cmap = (uint8_t*)(stage.data() + rec_w + weights.size());
+    memset(cmap, 0xFF, LOOKUP_MAX_COLS);
+    uint32_t n_used = 0, chunk_mask = 0;
+    bool stageable = true;
+    auto touch = [&](uint32_t col) {
+        if (col >= LOOKUP_MAX_COLS) { stageable = false; return; }
+        if (cmap[col] == 0xFF) { if (n_used >= LOOKUP_STAGE_MAX_USED) { stageable = false; return; } cmap[col] = (uint8_t)n_used++; }
+        chunk_mask |= 1u << (col >> 4);
+    };
+    for (uint32_t i = 0; i < lv.ni && stageable; i++) {
+        const uint32_t* rec = recs.data() + (size_t)i * LOOKUP_REC_WORDS;
+        if (rec[1] != 0xFFFFFFFFu) touch(rec[1]);
+        for (uint32_t v = 0; v < rec[3]; v++) touch(rec[4 + v]);
+    }
     void* d_stage;
     ZK_TRY(ctx_reserve(ctx, S_LOOKUP, stage.size() * 4, &d_stage));
     ZK_TRY(h2d(ctx, d_stage, stage.data(), stage.size() * 4));
     lk->table = (const uint32_t*)d_stage; lk->ni = lv.ni; lk->cols = lv.cols; lk->gamma = gamma;
+    lk->cmap = stageable && n_used ? (const uint8_t*)((const uint32_t*)d_stage + rec_w + weights.size()) : nullptr;
+    lk->n_used = n_used; lk->chunk_mask = chunk_mask;
     lk->bpow[0] = ext_one();
     for (int t = 1; t < 9; t++) lk->bpow[t] = ext_mul(lk->bpow[t - 1], beta);
     if (d_weights) *d_weights = (const uint32_t*)d_stage + rec_w;

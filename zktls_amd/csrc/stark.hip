@@ -1302,31 +1302,74 @@ hipError_t launch_perm_trace(const PermArgs& a, uint32_t* block_scratch, hipStre
 }
 
 // ---- lookups as data (kernels.h, LookupArgs): the same three launches with the interactions read from a table
-ZK_D Ext lookup_fingerprint(const LookupArgs& lk, const uint32_t* rec, const uint32_t* row) {
+// (cm != nullptr: `row` is the lane's STAGED row in LDS and cm[column] the word's place in it -- lookup_stage_rows below)
+ZK_D Ext lookup_fingerprint(const LookupArgs& lk, const uint32_t* rec, const uint32_t* row, const uint8_t* cm = nullptr) {
     Ext d = ext_add_base(lk.gamma, rec[2]);
-    for (uint32_t v = 0; v < rec[3]; v++) d = ext_add(d, ext_mul_base_dev(lk.bpow[v + 1], row[rec[4 + v]]));
+    for (uint32_t v = 0; v < rec[3]; v++) d = ext_add(d, ext_mul_base_dev(lk.bpow[v + 1], row[cm ? cm[rec[4 + v]] : rec[4 + v]]));
     return d;
 }
-ZK_D uint32_t lookup_mult(const uint32_t* rec, const uint32_t* row) {       // signed multiplicity, base field
-    const uint32_t m = rec[1] == 0xFFFFFFFFu ? MONTY_R1 : row[rec[1]];
+ZK_D uint32_t lookup_mult(const uint32_t* rec, const uint32_t* row, const uint8_t* cm = nullptr) {       // signed multiplicity, base field
+    const uint32_t m = rec[1] == 0xFFFFFFFFu ? MONTY_R1 : row[cm ? cm[rec[1]] : rec[1]];
     return rec[0] ? (m ? P - m : 0u) : m;
+}
+// The rows [row0, row0 + 256) of a row-major matrix, the columns the interactions read, into an LDS tile (kernels.h LookupArgs: cmap, chunk_mask): a workgroup of 256
+// lanes loads every touched 16-column chunk with 16-byte loads -- four lanes per row and chunk, 64 rows per instruction -- instead of every lane gathering its own
+// row's words one scattered request at a time.  dyn: LOOKUP_MAX_COLS bytes of map, then 256 x pitch words; returns the calling lane's staged row.
+ZK_D const uint32_t* lookup_stage_rows(const LookupArgs& lk, const uint32_t* mat, uint64_t ld, uint64_t row0, uint64_t rows, uint32_t* dyn, const uint8_t** cm_out) {
+    uint8_t* cm = reinterpret_cast<uint8_t*>(dyn);
+    uint32_t* tile = dyn + LOOKUP_MAX_COLS / 4;
+    const uint32_t pitch = lk.n_used | 1u, tid = threadIdx.x;
+    for (uint32_t i = tid; i < LOOKUP_MAX_COLS / 4; i += blockDim.x) dyn[i] = reinterpret_cast<const uint32_t*>(lk.cmap)[i];
+    __syncthreads();
+    const uint32_t q = tid & 3u;
+    for (uint32_t m = lk.chunk_mask; m; m &= m - 1u) {
+        const uint32_t col = 16u * (uint32_t)(__ffs((int)m) - 1) + 4u * q;
+        const uint8_t k0 = cm[col], k1 = cm[col + 1], k2 = cm[col + 2], k3 = cm[col + 3];
+        if ((k0 & k1 & k2 & k3) == 0xFF) continue;                           // (none of this lane's four words is read; the other lanes of the row go on)
+        for (uint32_t r = tid >> 2; r < 256u; r += blockDim.x >> 2) {
+            if (row0 + r >= rows) break;
+            const uint32_t* src = mat + (row0 + r) * ld + col;
+            uint32_t* dst = tile + r * pitch;
+            if (col + 3 < ld) {
+                const uint4 v = *reinterpret_cast<const uint4*>(src);
+                if (k0 != 0xFF) dst[k0] = v.x;
+                if (k1 != 0xFF) dst[k1] = v.y;
+                if (k2 != 0xFF) dst[k2] = v.z;
+                if (k3 != 0xFF) dst[k3] = v.w;
+            } else {
+                if (k0 != 0xFF && col < ld) dst[k0] = src[0];
+                if (k1 != 0xFF && col + 1 < ld) dst[k1] = src[1];
+                if (k2 != 0xFF && col + 2 < ld) dst[k2] = src[2];
+            }
+        }
+    }
+    __syncthreads();
+    *cm_out = cm;
+    return tile + tid * pitch;
+}
+ZK_D bool lookup_stageable(const LookupArgs& lk, const uint32_t* mat, uint64_t ld) { return lk.cmap != nullptr && (ld & 3u) == 0 && ((uintptr_t)mat & 15u) == 0; }
+static size_t lookup_stage_bytes(const LookupArgs& lk, const uint32_t* mat, uint64_t ld) {
+    return lk.cmap != nullptr && (ld & 3u) == 0 && ((uintptr_t)mat & 15u) == 0 ? LOOKUP_MAX_COLS + 256 * (size_t)(lk.n_used | 1u) * 4 : 0;
 }
 __device__ __forceinline__ void perm_rows_machine_kernel_body(const MachinePermArgs& a, uint32_t* __restrict__ block_tot) {
     __shared__ uint32_t sh[PERM_BLOCK * 4];
     const uint64_t i = (uint64_t)blockIdx.x * PERM_BLOCK + threadIdx.x;
     Ext sum = ext_zero();
+    extern __shared__ uint32_t lookup_dyn[];
+    const uint8_t* cm = nullptr;
+    const uint32_t* row = a.trace + i * a.ld;
+    if (lookup_stageable(a.lk, a.trace, a.ld)) row = lookup_stage_rows(a.lk, a.trace, a.ld, (uint64_t)blockIdx.x * PERM_BLOCK, a.rows, lookup_dyn, &cm);
     if (i < a.rows) {
-        const uint32_t* row = a.trace + i * a.ld;
         uint32_t* prow = a.out + i * a.out_ld;
         for (uint32_t j = 0; j < a.lk.cols; j++) {
             const uint32_t* ra = a.lk.table + (size_t)(2 * j) * LOOKUP_REC_WORDS;
-            const Ext da = lookup_fingerprint(a.lk, ra, row);
-            const uint32_t ma = lookup_mult(ra, row);
+            const Ext da = lookup_fingerprint(a.lk, ra, row, cm);
+            const uint32_t ma = lookup_mult(ra, row, cm);
             Ext phi;
             if (2 * j + 1 < a.lk.ni) {
                 const uint32_t* rb = ra + LOOKUP_REC_WORDS;
-                const Ext db = lookup_fingerprint(a.lk, rb, row);
-                const uint32_t mb = lookup_mult(rb, row);
+                const Ext db = lookup_fingerprint(a.lk, rb, row, cm);
+                const uint32_t mb = lookup_mult(rb, row, cm);
                 // m_a / d_a + m_b / d_b = (m_a d_b + m_b d_a) / (d_a d_b): one inversion per column; 1/0 = 0 takes the direct formula
                 const Ext d = ext_mul_dev(da, db);
                 phi = ext_eq(d, ext_zero()) ? ext_add(ext_mul_base_dev(ext_inv_dev(da), ma), ext_mul_base_dev(ext_inv_dev(db), mb))
@@ -1355,7 +1398,8 @@ __global__ void __launch_bounds__(PERM_BLOCK) perm_rows_machine_kernel_batch(con
 
 hipError_t launch_perm_trace_machine(const MachinePermArgs& a, uint32_t* block_scratch, hipStream_t s) {
     const uint32_t nblocks = (uint32_t)((a.rows + PERM_BLOCK - 1) / PERM_BLOCK);
-    ZK_LAUNCH(perm_rows_machine_kernel, perm_rows_machine_kernel_batch, perm_rows_machine_kernel_bargs, dim3(nblocks), dim3(PERM_BLOCK), 0, s, a, block_scratch);
+    static_assert(PERM_BLOCK == 256, "lookup_stage_rows stages 256 rows per workgroup");
+    ZK_LAUNCH(perm_rows_machine_kernel, perm_rows_machine_kernel_batch, perm_rows_machine_kernel_bargs, dim3(nblocks), dim3(PERM_BLOCK), lookup_stage_bytes(a.lk, a.trace, a.ld), s, a, block_scratch);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return e;
     ZK_LAUNCH(perm_scan_blocks_kernel, perm_scan_blocks_kernel_batch, perm_scan_blocks_kernel_bargs, dim3(1), dim3(1024), 0, s, block_scratch, nblocks);
@@ -1370,23 +1414,26 @@ __device__ __forceinline__ void lookup_addend_kernel_body(const MachineQuotArgs&
     const int H = a.log_n + a.log_qd;
     const uint32_t m = 1u << H;
     const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
+    extern __shared__ uint32_t lookup_dyn[];
+    const uint8_t* cm = nullptr;
+    const uint32_t* row = a.lde + (uint64_t)p * a.ld;
+    if (lookup_stageable(a.lk, a.lde, a.ld)) row = lookup_stage_rows(a.lk, a.lde, a.ld, (uint64_t)blockIdx.x * 256u, m, lookup_dyn, &cm);
     if (p >= m) return;
     const uint32_t e = __brev(p) >> (32 - H);
     const uint32_t pn = __brev((e + (1u << a.log_qd)) & (m - 1)) >> (32 - H);
-    const uint32_t* row = a.lde + (uint64_t)p * a.ld;
     const uint32_t* prow = a.perm + (uint64_t)p * a.perm_ld;
     const uint32_t* pnrow = a.perm + (uint64_t)pn * a.perm_ld;
     Ext r = ext_zero(), sphi = ext_zero(), sphin = ext_zero();
     for (uint32_t j = 0; j < a.lk.cols; j++) {
         const uint32_t* ra = a.lk.table + (size_t)(2 * j) * LOOKUP_REC_WORDS;
-        const Ext da = lookup_fingerprint(a.lk, ra, row);
-        const uint32_t ma = lookup_mult(ra, row);
+        const Ext da = lookup_fingerprint(a.lk, ra, row, cm);
+        const uint32_t ma = lookup_mult(ra, row, cm);
         const Ext phi = ld_ext(prow + 4 * j);
         Ext c;
         if (2 * j + 1 < a.lk.ni) {
             const uint32_t* rb = ra + LOOKUP_REC_WORDS;
-            const Ext db = lookup_fingerprint(a.lk, rb, row);
-            const uint32_t mb = lookup_mult(rb, row);
+            const Ext db = lookup_fingerprint(a.lk, rb, row, cm);
+            const uint32_t mb = lookup_mult(rb, row, cm);
             c = ext_sub(ext_mul_dev(ext_mul_dev(phi, da), db), ext_add(ext_mul_base_dev(db, ma), ext_mul_base_dev(da, mb)));
         } else c = ext_sub_base(ext_mul_dev(phi, da), ma);
         r = ext_add(r, ext_mul_dev(c, ld_ext(a.weights + 4 * j)));
@@ -1409,7 +1456,7 @@ __global__ void __launch_bounds__(256) lookup_addend_kernel_batch(const lookup_a
 
 hipError_t launch_lookup_addend(const MachineQuotArgs& a, hipStream_t s) {
     const uint64_t m = 1ull << (a.log_n + a.log_qd);
-    ZK_LAUNCH(lookup_addend_kernel, lookup_addend_kernel_batch, lookup_addend_kernel_bargs, dim3((unsigned)((m + 255) / 256)), dim3(256), 0, s, a);
+    ZK_LAUNCH(lookup_addend_kernel, lookup_addend_kernel_batch, lookup_addend_kernel_bargs, dim3((unsigned)((m + 255) / 256)), dim3(256), lookup_stage_bytes(a.lk, a.lde, a.ld), s, a);
     return hipGetLastError();
 }
 
