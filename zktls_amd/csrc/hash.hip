@@ -1029,7 +1029,92 @@ __device__ __forceinline__ void p2r_pad_rows_kernel_body(uint32_t* trace, uint32
 __global__ void __launch_bounds__(256) p2r_pad_rows_kernel(uint32_t* trace, uint32_t ld, uint64_t src_row, uint64_t n_rows) { p2r_pad_rows_kernel_body(trace, ld, src_row, n_rows); }
 struct p2r_pad_rows_kernel_bargs { uint32_t* trace; uint32_t ld; uint64_t src_row, n_rows; static p2r_pad_rows_kernel_bargs make(uint32_t* trace, uint32_t ld, uint64_t src_row, uint64_t n_rows) { return p2r_pad_rows_kernel_bargs{trace, ld, src_row, n_rows}; } };
 __global__ void __launch_bounds__(256) p2r_pad_rows_kernel_batch(const p2r_pad_rows_kernel_bargs* __restrict__ zk_arr) { const p2r_pad_rows_kernel_bargs& zk_b = zk_arr[blockIdx.z]; p2r_pad_rows_kernel_body(zk_b.trace, zk_b.ld, zk_b.src_row, zk_b.n_rows); }
+// ---- the chains (a commitment opening: leaf sponge blocks, then the path's levels) with SIXTEEN lanes per chain (round 6).  A chain is ~100 dependent
+// permutations; with one lane per chain a wave waits for its longest chain at ~8 us per row.  Here state word i lives in lane i of a DPP row (the latency form of the
+// tree kernels above, in canonical arithmetic because the row's columns ARE the intermediates): a row costs ~1 000 instructions instead of 4 700 in sequence, and a
+// round's sixteen cubes / state words go out as one 64-byte store.
+ZK_D uint32_t coopc_external_linear(uint32_t x) {
+    const uint32_t r1 = dpp<0x39>(x), r2 = dpp<0x4E>(x), r3 = dpp<0x93>(x);
+    const uint32_t sum = fadd(fadd(x, r1), fadd(r2, r3));
+    const uint32_t y = fadd(fadd(sum, x), fadd(r1, r1));
+    uint32_t t = fadd(y, dpp<0x124>(y));
+    t = fadd(t, dpp<0x128>(t));
+    return fadd(y, t);
+}
+// one row of the shard-verifier machines' Poseidon2 chip from lane l's word of the input state; returns lane l's word of the output state
+ZK_D uint32_t p2chip_fill_row16(uint32_t* t, uint32_t in, int l, uint32_t bit, uint32_t kp_monty) {
+    using namespace p2chip;
+    uint32_t x = in;
+    t[IN + l] = x;
+    x = coopc_external_linear(x);
+    t[S0 + l] = x;
+    auto external_round = [&](int r) {
+        const uint32_t y = fadd(x, P2K.ext_rc[r][l]);
+        const uint32_t c3 = fmul(fmul(y, y), y);
+        t[x3e((uint32_t)r) + l] = c3;
+        x = coopc_external_linear(fmul(fmul(c3, c3), y));
+        t[oute((uint32_t)r) + l] = x;
+    };
+#pragma unroll 1
+    for (int r = 0; r < 4; r++) external_round(r);
+#pragma unroll 1
+    for (int r = 0; r < 13; r++) {
+        const uint32_t y = fadd(x, P2K.int_rc[r]);
+        const uint32_t c3 = fmul(fmul(y, y), y), sb = fmul(fmul(c3, c3), y);
+        if (l == 0) { t[s0p((uint32_t)r)] = x; t[x3p((uint32_t)r)] = c3; t[sbp((uint32_t)r)] = sb; }
+        x = l == 0 ? sb : x;
+        uint32_t u = fadd(x, dpp<0x128>(x));
+        u = fadd(u, dpp<0x124>(u));
+        u = fadd(u, dpp<0x122>(u));
+        u = fadd(u, dpp<0x121>(u));                               // every lane holds the sum
+        x = fadd(fmul(x, P2K.diag[l]), u);
+    }
+    t[SP + l] = x;
+#pragma unroll 1
+    for (int r = 4; r < 8; r++) external_round(r);
+    const uint32_t in_sw = dpp<0x128>(in);                        // lane l: word (l + 8) mod 16
+    if (l < 8) t[D + l] = bit ? in_sw : in;
+    if (l < 9) t[BIT + l] = l == 0 ? (bit ? MONTY_R1 : 0u) : (l == 1 ? kp_monty : 0u);      // BIT, R_KP, then the unused flags
+    return x;
+}
+__device__ __forceinline__ void p2r_chains16_kernel_body(const p2chip::P2RArgs& a) {
+    using namespace p2chip;
+    static_assert(R_KP == BIT + 1 && R_WIDTH == BIT + 9, "the sixteen-lane writer knows the flags' places");
+    const uint64_t g = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 4;
+    const int l = (int)(threadIdx.x & 15u);
+    if (g >= a.n_chains) return;                                  // (whole DPP rows leave together)
+    const uint32_t* d = a.desc + 6 * g;
+    uint32_t* t = a.trace + (uint64_t)d[0] * a.ld;
+    const uint32_t blocks = d[1], depth = d[3], index = d[4];
+    const uint32_t *vals = a.data + d[2], *sib = a.data + d[5];
+    uint32_t out = 0u;
+    for (uint32_t k = 0; k < blocks; k++, t += a.ld) {
+        const uint32_t in = l < 8 ? to_monty(vals[8 * k + (uint32_t)l]) : out;
+        out = p2chip_fill_row16(t, in, l, 0u, k + 1 == blocks ? to_monty(2u * index) : 0u);
+    }
+    for (uint32_t lvl = 0; lvl < depth; lvl++, t += a.ld) {
+        const uint32_t bit = (index >> lvl) & 1u;
+        const uint32_t osw = dpp<0x128>(out), sv = to_monty(sib[8 * lvl + (uint32_t)(l & 7)]);
+        const uint32_t in = bit ? (l < 8 ? sv : osw) : (l < 8 ? out : sv);
+        out = p2chip_fill_row16(t, in, l, bit, to_monty(index >> lvl));
+    }
+    if (l < 8) a.roots[8 * g + (uint64_t)l] = from_monty(out);
+}
+__global__ void __launch_bounds__(256) p2r_chains16_kernel(p2chip::P2RArgs a) { p2r_chains16_kernel_body(a); }
+struct p2r_chains16_kernel_bargs { p2chip::P2RArgs a; static p2r_chains16_kernel_bargs make(p2chip::P2RArgs a) { return p2r_chains16_kernel_bargs{a}; } };
+__global__ void __launch_bounds__(256) p2r_chains16_kernel_batch(const p2r_chains16_kernel_bargs* __restrict__ zk_arr) { const p2r_chains16_kernel_bargs& zk_b = zk_arr[blockIdx.z]; p2r_chains16_kernel_body(zk_b.a); }
+
 hipError_t launch_p2r_rows(const p2chip::P2RArgs& a, hipStream_t s) {
+    if (a.n_chains && a.ld == p2chip::R_WIDTH) {
+        // the chains sixteen lanes each; everything else (transcript rows, padding) through the row kernel below, which then sees no chain
+        ZK_LAUNCH(p2r_chains16_kernel, p2r_chains16_kernel_batch, p2r_chains16_kernel_bargs, dim3((unsigned)(((uint64_t)a.n_chains * 16 + 255) / 256)), dim3(256), 0, s, a);
+        const hipError_t e = hipGetLastError();
+        if (e != hipSuccess) return e;
+        p2chip::P2RArgs rest = a;
+        rest.n_chains = 0;
+        if (rest.n_transcript == 0 && rest.rows == rest.used_rows) return hipSuccess;
+        return launch_p2r_rows(rest, s);
+    }
     p2chip::P2RArgs b = a;
     const uint64_t pad = a.rows - a.used_rows;
     const bool replicate = pad > 1 && a.ld % 4 == 0 && ((uintptr_t)a.trace & 15) == 0;
