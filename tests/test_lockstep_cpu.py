@@ -30,7 +30,7 @@ def test_every_kernel_launch_of_the_prover_goes_through_the_batcher():
                 direct[f] = sorted(set(names))
     direct.pop("hal.hip", None)                                   # the RISC Zero operator surface: not on the lock-step path
     direct.pop("ntt_fused.hip", None)                             # 2^20-row shapes only
-    assert direct == {"hash.hip": ["mrec_chains_kernel"],        # round 6: the recursion machines' witness kernels (with the ones in the .inl files) -- never launched inside a batch:
+    assert direct == {"hash.hip": ["mrec_chains16_kernel", "mrec_chains_kernel"],        # round 6: the recursion machines' witness kernels (with the ones in the .inl files) -- never launched inside a batch:
                                                                   # shard_verifier_prove_impl / top_begin take the host's walk when t_batcher is set
                       "ntt.hip": ["combine_table_kernel", "ntt_colpass_kernel", "ntt_pass1024x2_kernel", "post2d_table_kernel",
                                   "post_table_kernel", "pow_table_kernel"]}      # plan tables, the column-major pass, an A/B kernel

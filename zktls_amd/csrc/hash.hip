@@ -1010,9 +1010,11 @@ __global__ void __launch_bounds__(64) mrec_chains_kernel(p2chip::MrecChainArgs a
     for (int j = 0; j < 8; j++) ok = ok && from_monty(cur[j]) == (tp.root_off < 0 ? a.key_root[j] : w[tp.root_off + j]);
     if (!ok) atomicCAS(a.err + p, 0u, 3u);
 }
+static hipError_t launch_mrec_chains16(const p2chip::MrecChainArgs& a, uint64_t n, hipStream_t s);
 hipError_t launch_mrec_chains(const p2chip::MrecChainArgs& a, hipStream_t s) {
     const uint64_t n = (uint64_t)a.NP * a.Q * (a.n_trees + a.R);
     if (n == 0) return hipSuccess;
+    if (a.trace && a.ld == p2chip::R_WIDTH) return launch_mrec_chains16(a, n, s);
     hipLaunchKernelGGL(mrec_chains_kernel, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, s, a);
     return hipGetLastError();
 }
@@ -1103,6 +1105,82 @@ __device__ __forceinline__ void p2r_chains16_kernel_body(const p2chip::P2RArgs& 
 __global__ void __launch_bounds__(256) p2r_chains16_kernel(p2chip::P2RArgs a) { p2r_chains16_kernel_body(a); }
 struct p2r_chains16_kernel_bargs { p2chip::P2RArgs a; static p2r_chains16_kernel_bargs make(p2chip::P2RArgs a) { return p2r_chains16_kernel_bargs{a}; } };
 __global__ void __launch_bounds__(256) p2r_chains16_kernel_batch(const p2r_chains16_kernel_bargs* __restrict__ zk_arr) { const p2r_chains16_kernel_bargs& zk_b = zk_arr[blockIdx.z]; p2r_chains16_kernel_body(zk_b.a); }
+
+// machine mode's chains the same way (mrec_chains_kernel above is the one-lane-per-chain form that hands rows to the row kernel): sixteen lanes per chain, every row
+// written where it is computed.  A commitment's sponge digests wait in LDS for their injection levels.
+__global__ void __launch_bounds__(256) mrec_chains16_kernel(p2chip::MrecChainArgs a) {
+    using namespace p2chip;
+    __shared__ uint32_t dgs[16][16][8];
+    const uint64_t gid = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 4;
+    const int l = (int)(threadIdx.x & 15u), grp = (int)(threadIdx.x >> 4);
+    const uint32_t per_q = a.n_trees + a.R;
+    if (gid >= (uint64_t)a.NP * a.Q * per_q) return;              // (whole DPP rows leave together)
+    const uint32_t c = (uint32_t)(gid % per_q), q = (uint32_t)((gid / per_q) % a.Q), p = (uint32_t)(gid / ((uint64_t)per_q * a.Q));
+    const uint32_t* w = a.proofs + (uint64_t)p * a.proof_words;
+    const uint32_t qidx = a.vals[(uint64_t)p * a.vals_stride + q];
+    const uint32_t* qw = w + a.o_queries + (uint64_t)q * a.per_query;
+    uint32_t out = 0u;
+    auto emit = [&](uint64_t row, uint32_t in, uint32_t bit, uint32_t kp) { out = p2chip_fill_row16(a.trace + row * a.ld, in, l, bit, to_monty(kp)); };
+    // true when some lane of this chain's sixteen says `bad` (the other chains of the wave may be elsewhere in the code: their bits are not looked at)
+    auto any16 = [&](bool bad) { const unsigned long long m = __ballot(bad); return ((m >> (16u * ((threadIdx.x & 63u) >> 4))) & 0xFFFFull) != 0; };
+    if (c >= a.n_trees) {                                          // ---- a FRI layer: the pair's leaf, then its path
+        const uint32_t lay = c - a.n_trees;
+        const uint64_t at = ((uint64_t)p * a.Q + q) * a.R + lay;
+        const uint32_t k = a.pair_k[at];
+        uint64_t fat = a.fri_off;
+        for (uint32_t i = 0; i < lay; i++) fat += 4 + 8 * (uint64_t)(a.H - 1 - i);
+        const uint32_t* path = qw + fat + 4;
+        const uint64_t r0 = (uint64_t)lay + (uint64_t)lay * (uint64_t)(2 * (a.H - 1) - (lay - 1)) / 2;
+        uint64_t row = (uint64_t)p * a.p2_rows + a.p2_fri0 + (uint64_t)q * a.fri_rows + r0;
+        emit(row++, l < 8 ? a.pairs[8 * at + (uint64_t)l] : 0u, 0u, 2u * k);
+        const uint32_t depth = a.H - 1 - lay;
+        for (uint32_t lvl = 0; lvl < depth; lvl++) {
+            const uint32_t b = (k >> lvl) & 1u;
+            const uint32_t osw = dpp<0x128>(out), sv = to_monty(path[8 * lvl + (uint32_t)(l & 7)]);
+            emit(row++, b ? (l < 8 ? sv : osw) : (l < 8 ? out : sv), b, k >> lvl);
+        }
+        const bool bad = l < 8 && from_monty(out) != w[a.o_lroots + 8 * lay + (uint32_t)l];
+        if (any16(bad) && l == 0) atomicCAS(a.err + p, 0u, 1u);
+        return;
+    }
+    // ---- a commitment: sponges (shorter heights first, the tallest last), then the path with the injections
+    const MrecTreePlan& tp = a.trees[c];
+    const uint32_t index = qidx >> tp.shift;
+    uint64_t row = (uint64_t)p * a.p2_rows + tp.row0 + (uint64_t)q * tp.rows_per_query;
+    for (uint32_t sidx = 0; sidx < tp.n_sponges; sidx++) {
+        const uint32_t words = tp.sp_words[sidx], nb = (words + 7) / 8;
+        const int32_t* so = a.src + tp.sp_src[sidx];
+        uint32_t state = 0u;                                       // (overwrite mode: a block replaces the first words of the state, the rest goes on)
+        for (uint32_t b = 0; b < nb; b++) {
+            const uint32_t kk = words - 8 * b < 8 ? words - 8 * b : 8u;
+            uint32_t in = state;
+            if ((uint32_t)l < kk) { const int32_t o = so[8 * b + (uint32_t)l]; in = o < 0 ? 0u : to_monty(qw[o]); }
+            emit(row++, in, 0u, (b == nb - 1 && sidx + 1 == tp.n_sponges) ? 2u * index : 0u);
+            state = out;
+        }
+        if (l < 8) dgs[grp][sidx][l] = out;
+    }
+    __threadfence_block();
+    uint32_t cur = out;                                            // lanes 0 .. 7: the node on the way up
+    const uint32_t* path = qw + tp.path_off;
+    for (uint32_t lvl = 0; lvl < tp.depth; lvl++) {
+        const uint32_t b = (index >> lvl) & 1u;
+        const uint32_t csw = dpp<0x128>(cur), sv = to_monty(path[8 * lvl + (uint32_t)(l & 7)]);
+        emit(row++, b ? (l < 8 ? sv : csw) : (l < 8 ? cur : sv), b, index >> lvl);
+        cur = out;
+        const int32_t js = tp.inj[lvl];
+        if (js >= 0) {
+            emit(row++, l < 8 ? cur : dgs[grp][js][l - 8], 0u, index >> (lvl + 1));
+            cur = out;
+        }
+    }
+    const bool bad = l < 8 && from_monty(cur) != (tp.root_off < 0 ? a.key_root[l] : w[tp.root_off + l]);
+    if (any16(bad) && l == 0) atomicCAS(a.err + p, 0u, 3u);
+}
+static hipError_t launch_mrec_chains16(const p2chip::MrecChainArgs& a, uint64_t n, hipStream_t s) {
+    hipLaunchKernelGGL(mrec_chains16_kernel, dim3((unsigned)((n * 16 + 255) / 256)), dim3(256), 0, s, a);
+    return hipGetLastError();
+}
 
 hipError_t launch_p2r_rows(const p2chip::P2RArgs& a, hipStream_t s) {
     if (a.n_chains && a.ld == p2chip::R_WIDTH) {

@@ -2148,8 +2148,9 @@ int top_finish(zkhip_ctx* ctx, const zkhip_machine_key* key, TopSession& s, cons
         void* rowbuf;                                                     // every used row's (input state, bit, KP)
         ZK_TRY(ctx_reserve(ctx, S_WIT_C, used * 18 * 4, &rowbuf));
         ca.row_in = (uint32_t*)rowbuf; ca.row_bit = ca.row_in + 16 * used; ca.row_kp = ca.row_in + 17 * used; ca.err = a.err;
+        ca.trace = (uint32_t*)dev[C_P2R]; ca.ld = P2_MAIN;              // sixteen lanes per chain write the queries' rows themselves (hash.hip mrec_chains16_kernel)
         ZK_HIP(launch_mrec_chains(ca, ctx->stream));
-        {   // the queries' rows: 360 columns each from (state, bit, KP), one lane per row; the transcripts' rows are skipped here
+        if (!(ca.trace && ca.ld == p2chip::R_WIDTH)) {   // the one-lane form: 360 columns each from (state, bit, KP), one lane per row; the transcripts' rows are skipped here
             p2chip::P2RArgs qa{};
             qa.chain_inputs = ca.row_in; qa.trows = nullptr; qa.n_chains = 0; qa.n_transcript = (uint32_t)used;
             qa.rows = (uint64_t)1 << m.height[C_P2R]; qa.used_rows = qa.rows;      // (no padding rows from this launch)

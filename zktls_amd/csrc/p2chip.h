@@ -102,6 +102,7 @@ struct MrecChainArgs {
     uint32_t key_root[8];                              // canonical
     uint32_t* row_in; uint32_t* row_bit; uint32_t* row_kp;   // [used rows][16] Montgomery, [used rows], [used rows]: what every row starts from (p2r_rows_kernel fills the columns)
     uint32_t* err;                                     // [NP]
+    uint32_t* trace; uint64_t ld;                      // non-null: sixteen lanes per chain fill the Poseidon2 chip's rows themselves (mrec_chains16_kernel); row_in / row_bit / row_kp are then unused
 };
 
 // paths: path p = rows [p (row_width / 8 + depth), ...): row_width / 8 sponge rows over its opened row (none when row_width = 0: the
