@@ -348,7 +348,11 @@ struct MachinePermArgs {
     LookupArgs lk;
     const uint32_t* trace; uint64_t ld; uint64_t rows;
     uint32_t* out; uint64_t out_ld;                // [rows][4 (cols + 1)]
+    // a keyed machine's rows are [preprocessed | main]: with pre != nullptr columns [0, pre_w) come from the key's trace (pitch pre_ld) and column c >= pre_w is column
+    // c - pre_w of `trace` -- the staged form reads both where they lie instead of a copy of the two side by side (pre_w a multiple of 4; staged launches only)
+    const uint32_t* pre; uint64_t pre_ld; uint32_t pre_w;
 };
+bool lookup_perm_two_sources_ok(const MachinePermArgs& a);     // stark.hip: the launch can take (pre, trace) as they lie
 hipError_t launch_perm_trace_machine(const MachinePermArgs& a, uint32_t* block_scratch, hipStream_t s);
 // the lookup constraints of one chip on its quotient domain (the first 2N rows of the bit-reversed LDEs), folded with their
 // weights: addend[p] (extension) = sum_j w_j (phi_j d_a d_b - (m_a d_b + m_b d_a)) + w_F1 is_first (S - sum phi)

@@ -432,11 +432,18 @@ static int lookup_args(zkhip_ctx* ctx, const LookupView& lv, const Ext& gamma, c
     if (d_weights) *d_weights = (const uint32_t*)d_stage + rec_w;
     return ZKHIP_OK;
 }
+// (pre != nullptr: the rows are [pre | trace]; *took_two = whether the kernel could read the two where they lie -- else the caller copies them side by side and calls again)
 static int run_lookup_perm(zkhip_ctx* ctx, const uint32_t* d_trace, size_t ld, int log_n, const LookupView& lv, const Ext& gamma, const Ext& beta,
-                           uint32_t* d_out) {
+                           uint32_t* d_out, const uint32_t* d_pre = nullptr, size_t pre_ld = 0, uint32_t pre_w = 0, bool* took_two = nullptr) {
     MachinePermArgs a{};
     ZK_TRY(lookup_args(ctx, lv, gamma, beta, {}, &a.lk, nullptr));
     a.trace = d_trace; a.ld = ld; a.rows = (uint64_t)1 << log_n; a.out = d_out; a.out_ld = 4 * ((uint64_t)lv.cols + 1);
+    if (d_pre) {
+        a.pre = d_pre; a.pre_ld = pre_ld; a.pre_w = pre_w;
+        const bool ok = lookup_perm_two_sources_ok(a);
+        if (took_two) *took_two = ok;
+        if (!ok) return ZKHIP_OK;
+    }
     void* scratch;
     ZK_TRY(ctx_reserve(ctx, S_GATHER_OUT, ((a.rows + 255) / 256) * 16, &scratch));
     ZK_HIP(launch_perm_trace_machine(a, (uint32_t*)scratch, ctx->stream));
@@ -1067,12 +1074,17 @@ static int prove_chips_impl(const ChipSet& cs, zkhip_ctx* ctx, const zkhip_chip*
             if (!wp[c]) continue;
             if (cs.machine && pre_w(cs, c)) {           // the interactions address [preprocessed | main] rows of the trace domain
                 const size_t nc = (size_t)1 << log_ns[c], pw = pre_w(cs, c);
-                void* v_ct;
-                ZK_TRY(ctx_reserve(ctx, S_KEYTRACE, nc * cw[c] * 4, &v_ct));
-                uint32_t* ct = (uint32_t*)v_ct;
-                ZK_HIP(launch_copy2d(ct, cw[c], cs.key->d_trace[c], pw, (uint32_t)pw, nc, st));
-                ZK_HIP(launch_copy2d(ct + pw, cw[c], chips[c].d_trace, chips[c].ld, widths[c], nc, st));
-                ZK_TRY(run_lookup_perm(ctx, ct, cw[c], log_ns[c], *lookup_of(cs, c), gamma, beta_l, (uint32_t*)v_perm));
+                // the kernel stages the few columns it reads from the key's trace and the main trace where they lie (round 6); when it cannot, the two are put side by side first
+                bool two = false;
+                ZK_TRY(run_lookup_perm(ctx, chips[c].d_trace, chips[c].ld, log_ns[c], *lookup_of(cs, c), gamma, beta_l, (uint32_t*)v_perm, cs.key->d_trace[c], pw, (uint32_t)pw, &two));
+                if (!two) {
+                    void* v_ct;
+                    ZK_TRY(ctx_reserve(ctx, S_KEYTRACE, nc * cw[c] * 4, &v_ct));
+                    uint32_t* ct = (uint32_t*)v_ct;
+                    ZK_HIP(launch_copy2d(ct, cw[c], cs.key->d_trace[c], pw, (uint32_t)pw, nc, st));
+                    ZK_HIP(launch_copy2d(ct + pw, cw[c], chips[c].d_trace, chips[c].ld, widths[c], nc, st));
+                    ZK_TRY(run_lookup_perm(ctx, ct, cw[c], log_ns[c], *lookup_of(cs, c), gamma, beta_l, (uint32_t*)v_perm));
+                }
             } else if (cs.machine) ZK_TRY(run_lookup_perm(ctx, chips[c].d_trace, chips[c].ld, log_ns[c], *lookup_of(cs, c), gamma, beta_l, (uint32_t*)v_perm));
             else ZK_TRY(run_perm_trace(ctx, chips[c].d_trace, chips[c].ld, log_ns[c], (uint32_t)pairs[c], gamma, beta_l, (uint32_t*)v_perm));
             if (cross)          // the running sum's last value: row N - 1, column S

@@ -1315,7 +1315,8 @@ ZK_D uint32_t lookup_mult(const uint32_t* rec, const uint32_t* row, const uint8_
 // The rows [row0, row0 + 256) of a row-major matrix, the columns the interactions read, into an LDS tile (kernels.h LookupArgs: cmap, chunk_mask): a workgroup of 256
 // lanes loads every touched 16-column chunk with 16-byte loads -- four lanes per row and chunk, 64 rows per instruction -- instead of every lane gathering its own
 // row's words one scattered request at a time.  dyn: LOOKUP_MAX_COLS bytes of map, then 256 x pitch words; returns the calling lane's staged row.
-ZK_D const uint32_t* lookup_stage_rows(const LookupArgs& lk, const uint32_t* mat, uint64_t ld, uint64_t row0, uint64_t rows, uint32_t* dyn, const uint8_t** cm_out) {
+ZK_D const uint32_t* lookup_stage_rows(const LookupArgs& lk, const uint32_t* mat, uint64_t ld, uint64_t row0, uint64_t rows, uint32_t* dyn, const uint8_t** cm_out,
+                                       const uint32_t* pre = nullptr, uint64_t pre_ld = 0, uint32_t pre_w = 0) {
     uint8_t* cm = reinterpret_cast<uint8_t*>(dyn);
     uint32_t* tile = dyn + LOOKUP_MAX_COLS / 4;
     const uint32_t pitch = lk.n_used | 1u, tid = threadIdx.x;
@@ -1328,18 +1329,21 @@ ZK_D const uint32_t* lookup_stage_rows(const LookupArgs& lk, const uint32_t* mat
         if ((k0 & k1 & k2 & k3) == 0xFF) continue;                           // (none of this lane's four words is read; the other lanes of the row go on)
         for (uint32_t r = tid >> 2; r < 256u; r += blockDim.x >> 2) {
             if (row0 + r >= rows) break;
-            const uint32_t* src = mat + (row0 + r) * ld + col;
+            // (two sources: a quad of columns lies on one side of pre_w, a multiple of 4)
+            const bool from_pre = pre != nullptr && col < pre_w;
+            const uint32_t* src = from_pre ? pre + (row0 + r) * pre_ld + col : mat + (row0 + r) * ld + (col - (pre ? pre_w : 0u));
             uint32_t* dst = tile + r * pitch;
-            if (col + 3 < ld) {
+            if (from_pre || col - (pre ? pre_w : 0u) + 3 < ld) {
                 const uint4 v = *reinterpret_cast<const uint4*>(src);
                 if (k0 != 0xFF) dst[k0] = v.x;
                 if (k1 != 0xFF) dst[k1] = v.y;
                 if (k2 != 0xFF) dst[k2] = v.z;
                 if (k3 != 0xFF) dst[k3] = v.w;
             } else {
-                if (k0 != 0xFF && col < ld) dst[k0] = src[0];
-                if (k1 != 0xFF && col + 1 < ld) dst[k1] = src[1];
-                if (k2 != 0xFF && col + 2 < ld) dst[k2] = src[2];
+                const uint32_t mc = col - (pre ? pre_w : 0u);
+                if (k0 != 0xFF && mc < ld) dst[k0] = src[0];
+                if (k1 != 0xFF && mc + 1 < ld) dst[k1] = src[1];
+                if (k2 != 0xFF && mc + 2 < ld) dst[k2] = src[2];
             }
         }
     }
@@ -1358,7 +1362,7 @@ __device__ __forceinline__ void perm_rows_machine_kernel_body(const MachinePermA
     extern __shared__ uint32_t lookup_dyn[];
     const uint8_t* cm = nullptr;
     const uint32_t* row = a.trace + i * a.ld;
-    if (lookup_stageable(a.lk, a.trace, a.ld)) row = lookup_stage_rows(a.lk, a.trace, a.ld, (uint64_t)blockIdx.x * PERM_BLOCK, a.rows, lookup_dyn, &cm);
+    if (lookup_stageable(a.lk, a.trace, a.ld)) row = lookup_stage_rows(a.lk, a.trace, a.ld, (uint64_t)blockIdx.x * PERM_BLOCK, a.rows, lookup_dyn, &cm, a.pre, a.pre_ld, a.pre_w);
     if (i < a.rows) {
         uint32_t* prow = a.out + i * a.out_ld;
         for (uint32_t j = 0; j < a.lk.cols; j++) {
@@ -1396,7 +1400,11 @@ __global__ void __launch_bounds__(PERM_BLOCK) perm_rows_machine_kernel(MachinePe
 struct perm_rows_machine_kernel_bargs { MachinePermArgs a; uint32_t* block_tot; static perm_rows_machine_kernel_bargs make(MachinePermArgs a, uint32_t* block_tot) { return perm_rows_machine_kernel_bargs{a, block_tot}; } };
 __global__ void __launch_bounds__(PERM_BLOCK) perm_rows_machine_kernel_batch(const perm_rows_machine_kernel_bargs* __restrict__ zk_arr) { const perm_rows_machine_kernel_bargs& zk_b = zk_arr[blockIdx.z]; perm_rows_machine_kernel_body(zk_b.a, zk_b.block_tot); }
 
+bool lookup_perm_two_sources_ok(const MachinePermArgs& a) {
+    return lookup_stage_bytes(a.lk, a.trace, a.ld) != 0 && a.pre != nullptr && (a.pre_w & 3u) == 0 && (a.pre_ld & 3u) == 0 && ((uintptr_t)a.pre & 15u) == 0;
+}
 hipError_t launch_perm_trace_machine(const MachinePermArgs& a, uint32_t* block_scratch, hipStream_t s) {
+    if (a.pre && !lookup_perm_two_sources_ok(a)) return hipErrorInvalidValue;         // (the caller puts the two side by side first when they cannot be read as they lie)
     const uint32_t nblocks = (uint32_t)((a.rows + PERM_BLOCK - 1) / PERM_BLOCK);
     static_assert(PERM_BLOCK == 256, "lookup_stage_rows stages 256 rows per workgroup");
     ZK_LAUNCH(perm_rows_machine_kernel, perm_rows_machine_kernel_batch, perm_rows_machine_kernel_bargs, dim3(nblocks), dim3(PERM_BLOCK), lookup_stage_bytes(a.lk, a.trace, a.ld), s, a, block_scratch);
