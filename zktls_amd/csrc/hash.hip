@@ -1044,20 +1044,28 @@ ZK_D uint32_t coopc_external_linear(uint32_t x) {
     return fadd(y, t);
 }
 // one row of the shard-verifier machines' Poseidon2 chip from lane l's word of the input state; returns lane l's word of the output state
-ZK_D uint32_t p2chip_fill_row16(uint32_t* t, uint32_t in, int l, uint32_t bit, uint32_t kp_monty) {
+struct Coop16Consts { uint32_t rc[8]; uint32_t diag; };          // lane l's round constants and diagonal entry: loaded once per chain, not once per row
+ZK_D Coop16Consts coop16_load_consts(int l) {
+    Coop16Consts k;
+#pragma unroll
+    for (int r = 0; r < 8; r++) k.rc[r] = P2K.ext_rc[r][l];
+    k.diag = P2K.diag[l];
+    return k;
+}
+ZK_D uint32_t p2chip_fill_row16(uint32_t* t, uint32_t in, int l, uint32_t bit, uint32_t kp_monty, const Coop16Consts& kc) {
     using namespace p2chip;
     uint32_t x = in;
     t[IN + l] = x;
     x = coopc_external_linear(x);
     t[S0 + l] = x;
     auto external_round = [&](int r) {
-        const uint32_t y = fadd(x, P2K.ext_rc[r][l]);
+        const uint32_t y = fadd(x, kc.rc[r]);
         const uint32_t c3 = fmul(fmul(y, y), y);
         t[x3e((uint32_t)r) + l] = c3;
         x = coopc_external_linear(fmul(fmul(c3, c3), y));
         t[oute((uint32_t)r) + l] = x;
     };
-#pragma unroll 1
+#pragma unroll
     for (int r = 0; r < 4; r++) external_round(r);
 #pragma unroll 1
     for (int r = 0; r < 13; r++) {
@@ -1069,10 +1077,10 @@ ZK_D uint32_t p2chip_fill_row16(uint32_t* t, uint32_t in, int l, uint32_t bit, u
         u = fadd(u, dpp<0x124>(u));
         u = fadd(u, dpp<0x122>(u));
         u = fadd(u, dpp<0x121>(u));                               // every lane holds the sum
-        x = fadd(fmul(x, P2K.diag[l]), u);
+        x = fadd(fmul(x, kc.diag), u);
     }
     t[SP + l] = x;
-#pragma unroll 1
+#pragma unroll
     for (int r = 4; r < 8; r++) external_round(r);
     const uint32_t in_sw = dpp<0x128>(in);                        // lane l: word (l + 8) mod 16
     if (l < 8) t[D + l] = bit ? in_sw : in;
@@ -1089,16 +1097,17 @@ __device__ __forceinline__ void p2r_chains16_kernel_body(const p2chip::P2RArgs& 
     uint32_t* t = a.trace + (uint64_t)d[0] * a.ld;
     const uint32_t blocks = d[1], depth = d[3], index = d[4];
     const uint32_t *vals = a.data + d[2], *sib = a.data + d[5];
+    const Coop16Consts kc = coop16_load_consts(l);
     uint32_t out = 0u;
     for (uint32_t k = 0; k < blocks; k++, t += a.ld) {
         const uint32_t in = l < 8 ? to_monty(vals[8 * k + (uint32_t)l]) : out;
-        out = p2chip_fill_row16(t, in, l, 0u, k + 1 == blocks ? to_monty(2u * index) : 0u);
+        out = p2chip_fill_row16(t, in, l, 0u, k + 1 == blocks ? to_monty(2u * index) : 0u, kc);
     }
     for (uint32_t lvl = 0; lvl < depth; lvl++, t += a.ld) {
         const uint32_t bit = (index >> lvl) & 1u;
         const uint32_t osw = dpp<0x128>(out), sv = to_monty(sib[8 * lvl + (uint32_t)(l & 7)]);
         const uint32_t in = bit ? (l < 8 ? sv : osw) : (l < 8 ? out : sv);
-        out = p2chip_fill_row16(t, in, l, bit, to_monty(index >> lvl));
+        out = p2chip_fill_row16(t, in, l, bit, to_monty(index >> lvl), kc);
     }
     if (l < 8) a.roots[8 * g + (uint64_t)l] = from_monty(out);
 }
@@ -1120,7 +1129,8 @@ __global__ void __launch_bounds__(256) mrec_chains16_kernel(p2chip::MrecChainArg
     const uint32_t qidx = a.vals[(uint64_t)p * a.vals_stride + q];
     const uint32_t* qw = w + a.o_queries + (uint64_t)q * a.per_query;
     uint32_t out = 0u;
-    auto emit = [&](uint64_t row, uint32_t in, uint32_t bit, uint32_t kp) { out = p2chip_fill_row16(a.trace + row * a.ld, in, l, bit, to_monty(kp)); };
+    const Coop16Consts kc = coop16_load_consts(l);
+    auto emit = [&](uint64_t row, uint32_t in, uint32_t bit, uint32_t kp) { out = p2chip_fill_row16(a.trace + row * a.ld, in, l, bit, to_monty(kp), kc); };
     // true when some lane of this chain's sixteen says `bad` (the other chains of the wave may be elsewhere in the code: their bits are not looked at)
     auto any16 = [&](bool bad) { const unsigned long long m = __ballot(bad); return ((m >> (16u * ((threadIdx.x & 63u) >> 4))) & 0xFFFFull) != 0; };
     if (c >= a.n_trees) {                                          // ---- a FRI layer: the pair's leaf, then its path
